@@ -1,0 +1,115 @@
+/*
+ * oracle/orc_sort.c — CPU oracle (test infrastructure; see orc.h): coordinate order.
+ * Restates sam.CoordinateLess + modFlag (sam/sam-types.go:408-473) and the observable result of
+ * By.ParallelStableSort (sam/sam-types.go:599-641): a permutation consistent with CoordinateLess in
+ * which records that compare equal under all keys keep their input order.
+ */
+#include "orc.h"
+#include <stdlib.h>
+#include <string.h>
+
+/* sam/sam-types.go:408-421 */
+uint16_t orc_mod_flag(uint16_t flag) {
+  if ((flag & ORC_MULTIPLE) == 0) {
+    flag &= (uint16_t)~ORC_NEXT_UNMAPPED;
+    flag &= (uint16_t)~ORC_NEXT_REVERSED;
+  }
+  if (flag & ORC_UNMAPPED) flag &= (uint16_t)~ORC_REVERSED;
+  if (flag & ORC_NEXT_UNMAPPED) flag &= (uint16_t)~ORC_NEXT_REVERSED;
+  return flag;
+}
+
+/* Go string comparison: bytewise, shorter prefix is smaller */
+static int qname_cmp(const orc_batch *b, uint64_t i, uint64_t j) {
+  uint64_t li = b->qname_off[i + 1] - b->qname_off[i], lj = b->qname_off[j + 1] - b->qname_off[j];
+  uint64_t m = li < lj ? li : lj;
+  int c = memcmp(b->qname + b->qname_off[i], b->qname + b->qname_off[j], m);
+  if (c) return c;
+  return li < lj ? -1 : (li > lj ? 1 : 0);
+}
+
+/* sam/sam-types.go:425-473 */
+int orc_coordinate_less(const orc_batch *b, uint64_t i, uint64_t j) {
+  int32_t refid1 = b->refid[i], refid2 = b->refid[j];
+  if (refid1 < refid2) return refid1 >= 0;
+  if (refid2 < refid1) return refid2 < 0;
+  if (b->pos[i] < b->pos[j]) return 1;
+  if (b->pos[i] > b->pos[j]) return 0;
+  int rev1 = (b->flag[i] & ORC_REVERSED) != 0, rev2 = (b->flag[j] & ORC_REVERSED) != 0;
+  if (rev1 != rev2) return !rev1;
+  uint64_t l1 = b->qname_off[i + 1] - b->qname_off[i], l2 = b->qname_off[j + 1] - b->qname_off[j];
+  if (l1 != 0 && l2 != 0) {
+    int c = qname_cmp(b, i, j);
+    if (c < 0) return 1;
+    if (c > 0) return 0;
+  }
+  uint16_t flag1 = orc_mod_flag(b->flag[i]), flag2 = orc_mod_flag(b->flag[j]);
+  if (flag1 < flag2) return 1;
+  if (flag1 > flag2) return 0;
+  if (b->mapq[i] < b->mapq[j]) return 1;
+  if (b->mapq[i] > b->mapq[j]) return 0;
+  if ((b->flag[i] & ORC_MULTIPLE) && (b->flag[j] & ORC_MULTIPLE)) {
+    int32_t n1 = b->next_refid[i], n2 = b->next_refid[j];
+    if (n1 < n2) return 1; /* no special treatment of negative values (reference comment) */
+    if (n1 > n2) return 0;
+    if (b->pnext[i] < b->pnext[j]) return 1;
+    if (b->pnext[i] > b->pnext[j]) return 0;
+  }
+  return b->tlen[i] < b->tlen[j];
+}
+
+/* top-down stable merge sort on the index permutation */
+static void msort(const orc_batch *b, uint32_t *a, uint32_t *tmp, uint64_t lo, uint64_t hi) {
+  if (hi - lo < 2) return;
+  if (hi - lo <= 8) { /* stable insertion sort */
+    for (uint64_t i = lo + 1; i < hi; i++) {
+      uint32_t v = a[i];
+      uint64_t k = i;
+      while (k > lo && orc_coordinate_less(b, v, a[k - 1])) { a[k] = a[k - 1]; k--; }
+      a[k] = v;
+    }
+    return;
+  }
+  uint64_t mid = lo + (hi - lo) / 2;
+  msort(b, a, tmp, lo, mid);
+  msort(b, a, tmp, mid, hi);
+  if (!orc_coordinate_less(b, a[mid], a[mid - 1])) return; /* already ordered */
+  uint64_t i = lo, j = mid, k = lo;
+  while (i < mid && j < hi) {
+    if (orc_coordinate_less(b, a[j], a[i])) tmp[k++] = a[j++]; /* take right only if strictly less: stable */
+    else tmp[k++] = a[i++];
+  }
+  while (i < mid) tmp[k++] = a[i++];
+  while (j < hi) tmp[k++] = a[j++];
+  memcpy(a + lo, tmp + lo, (hi - lo) * sizeof(uint32_t));
+}
+
+int orc_sort_coordinate(const orc_batch *b, uint32_t *perm_out) {
+  uint64_t n = b->n;
+  if (n > 0xFFFFFFFFull) return -1;
+  for (uint64_t i = 0; i < n; i++) perm_out[i] = (uint32_t)i;
+  if (n < 2) return 0;
+  uint32_t *tmp = (uint32_t *)malloc(n * sizeof(uint32_t));
+  if (!tmp) return -2;
+  msort(b, perm_out, tmp, 0, n);
+  free(tmp);
+  return 0;
+}
+
+/* sam/split-merge.go:178-213 computeContigGroups (group numbering only; "unmapped" is group 0) */
+int orc_contig_groups(const int32_t *ref_len, int n_ref, int contig_group_size, int32_t *group_of_ref) {
+  if (contig_group_size <= 0) {
+    for (int i = 0; i < n_ref; i++)
+      if (ref_len[i] > contig_group_size) contig_group_size = ref_len[i];
+    if (contig_group_size <= 0) return -1;
+  }
+  int idx = 1;
+  int64_t cur = 0;
+  for (int i = 0; i < n_ref; i++) {
+    int64_t ln = ref_len[i];
+    if (cur > 0 && cur + ln > contig_group_size) { idx++; cur = 0; }
+    group_of_ref[i] = idx;
+    cur += ln;
+  }
+  return n_ref ? idx : 0;
+}

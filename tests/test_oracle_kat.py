@@ -1,0 +1,219 @@
+"""Known-answer tests that pin the CPU oracle.
+
+(a) the reference's own interval tests (intervals/intervals_test.go:53-213) restated verbatim;
+(b) hand-derived vectors of SURVEY.md §8(c), re-derived here from the cited reference lines.
+The oracle is otherwise PARITY UNPINNED (the reference has no tests for sort/markdup/BQSR).
+"""
+import numpy as np
+import pytest
+
+import oracle as orc
+from elprep_amd.batch import parse_cigar, batch_from_records, Header, NIL16
+
+
+def iv(x):
+    return np.asarray(x, dtype=np.int32).reshape(-1, 2)
+
+
+# ---------- (a) intervals/intervals_test.go ----------
+@pytest.mark.parametrize("inp,exp", [
+    ([], []),                                                               # :54
+    ([[2, 3], [3, 4]], [[2, 4]]),                                           # :57
+    ([[2, 3], [4, 5]], [[2, 3], [4, 5]]),                                   # :60
+    ([[2, 4], [3, 5], [4, 6]], [[2, 6]]),                                   # :63
+    ([[2, 4], [3, 5], [4, 6], [7, 9]], [[2, 6], [7, 9]]),                   # :66
+    ([[2, 3], [3, 4], [5, 6], [6, 7]], [[2, 4], [5, 7]]),                   # :69
+    ([[2, 3], [2, 5], [2, 4], [2, 3], [2, 6], [2, 7]], [[2, 7]]),           # :72
+])
+def test_flatten_reference_vectors(inp, exp):
+    assert orc.flatten(iv(inp)).tolist() == iv(exp).tolist()
+
+
+def test_flatten_large_random():  # :75-84 with makeLargeIntervalsSlice :38-50
+    rng = np.random.default_rng(7)
+    start = rng.integers(0, 1 << 20, 0x30000)
+    raw = np.stack([start, start + rng.integers(0, 64, start.size)], axis=1)
+    out = orc.flatten(orc.sort_by_start(raw))
+    assert (out[:, 0] <= out[:, 1]).all()
+    assert (out[1:, 0] > out[:-1, 1]).all()
+
+
+@pytest.mark.parametrize("ivs,s,e,exp", [
+    ([], 2, 3, False), ([[1, 3], [7, 8]], 4, 6, False),
+    ([[2, 4], [6, 8]], 1, 3, True), ([[2, 4], [6, 8]], 2, 3, True), ([[2, 4], [6, 8]], 2, 5, True),
+    ([[2, 4], [6, 8]], 2, 6, True), ([[2, 4], [6, 8]], 3, 7, True), ([[2, 4], [6, 8]], 5, 7, True),
+    ([[2, 4], [6, 8]], 6, 8, True), ([[2, 4], [6, 8]], 6, 9, True), ([[2, 4], [6, 8]], 5, 9, True),
+    ([[2, 4], [6, 8]], 1, 10, True),
+])
+def test_overlap_reference_vectors(ivs, s, e, exp):  # :137-174
+    assert orc.overlap(iv(ivs), s, e) == exp
+
+
+@pytest.mark.parametrize("ivs,s,e,exp", [
+    ([], 2, 3, []), ([[1, 3], [7, 8]], 4, 6, []),
+    ([[2, 4], [6, 8]], 1, 3, [[2, 4]]), ([[2, 4], [6, 8]], 2, 3, [[2, 4]]), ([[2, 4], [6, 8]], 2, 5, [[2, 4]]),
+    ([[2, 4], [6, 8]], 2, 6, [[2, 4], [6, 8]]), ([[2, 4], [6, 8]], 3, 7, [[2, 4], [6, 8]]),
+    ([[2, 4], [6, 8]], 5, 7, [[6, 8]]), ([[2, 4], [6, 8]], 6, 8, [[6, 8]]), ([[2, 4], [6, 8]], 6, 9, [[6, 8]]),
+    ([[2, 4], [6, 8]], 5, 9, [[6, 8]]), ([[2, 4], [6, 8]], 1, 10, [[2, 4], [6, 8]]),
+])
+def test_intersect_reference_vectors(ivs, s, e, exp):  # :176-213
+    assert orc.intersect(iv(ivs), s, e).tolist() == iv(exp).tolist()
+
+
+# ---------- (b) hand-derived KATs ----------
+@pytest.mark.parametrize("pos,flag,cigar,exp", [
+    (100, 0, "5S95M", 95), (100, 0, "3H2S95M", 95), (100, 16, "90M10S", 199), (100, 16, "5S95M", 194),
+    (100, 16, "50M2D50M", 201), (100, 16, "10S80M5I5M10S", 194), (100, 16, "95M5S3H", 202), (100, 16, "150S", 249),
+    (100, 0, "150S", -50), (100, 0, "*", 100), (100, 16, "*", 100),
+])
+def test_unclipped_position(pos, flag, cigar, exp):  # filters/mark-duplicates.go:79-110
+    assert orc.unclipped_position(pos, flag, parse_cigar(cigar)) == exp
+
+
+def test_phred_score():  # filters/mark-duplicates.go:36-68
+    assert orc.phred_score(np.array([14, 15, 40], dtype=np.uint8)) == 55
+    assert orc.phred_score(np.array([], dtype=np.uint8)) == 0
+    assert orc.phred_score(np.array([93, 93], dtype=np.uint8)) == 186
+    with pytest.raises(ValueError):
+        orc.phred_score(np.array([94], dtype=np.uint8))
+
+
+def test_mod_flag():  # sam/sam-types.go:408-421
+    assert orc.mod_flag(0x30) == 0x10
+    assert orc.mod_flag(0x1 | 0x8 | 0x20) == 0x1 | 0x8
+    assert orc.mod_flag(0x4 | 0x10) == 0x4
+    assert orc.mod_flag(99) == 99
+
+
+@pytest.mark.parametrize("flag,l,i,exp", [
+    (0x40, 150, 0, 1), (0x40, 150, 149, 150), (0x40 | 0x10, 150, 0, 150), (0x80, 150, 0, -1),
+    (0x80 | 0x10, 150, 0, -150), (0x80 | 0x10, 150, 149, -1),
+])
+def test_cycle(flag, l, i, exp):  # filters/bqsr.go:376-387
+    assert orc.cycle(flag, l, i) == exp
+
+
+@pytest.mark.parametrize("seq,exp", [
+    (b"ACGT", [-1, 66, 146, 226]), (b"NACGT", [-1, -1, 66, 146, 226]), (b"ANCGT", [-1, -1, -1, 146, 226]),
+    (b"ACNGT", [-1, 66, -1, -1, 226]), (b"NNACG", [-1, -1, -1, 66, 146]), (b"A", [-1]), (b"", []), (b"TT", [-1, 242]),
+])
+def test_context_with(seq, exp):  # filters/bqsr.go:87-131
+    assert orc.context_with(seq).tolist() == exp
+
+
+@pytest.mark.parametrize("cigar,ss,ref,left,right", [
+    ("10M", 100, 105, (5, True), (5, True)), ("10M", 100, 100, (0, True), (0, True)), ("10M", 100, 109, (9, True), (9, True)),
+    ("10M", 100, 110, (-1, False), (-1, False)), ("10M", 100, 99, (-1, False), (-1, False)),
+    ("5M2D5M", 100, 104, (4, True), (4, True)), ("5M2D5M", 100, 105, (4, True), (5, True)),
+    ("5M2D5M", 100, 106, (4, True), (5, True)), ("5M2D5M", 100, 107, (5, True), (5, True)),
+    ("5M3I5M", 100, 104, (4, True), (4, True)), ("5M3I5M", 100, 105, (8, True), (8, True)),
+    ("3I7M", 100, 100, (3, True), (0, True)), ("3S7M", 97, 100, (3, True), (3, True)),
+])
+def test_read_coordinate_for_reference_coordinate(cigar, ss, ref, left, right):  # filters/utils.go:267-349
+    c = parse_cigar(cigar)
+    assert orc.read_coordinate_for_reference_coordinate(c, ss, ref, False) == left
+    assert orc.read_coordinate_for_reference_coordinate(c, ss, ref, True) == right
+
+
+def test_tile_info():  # filters/mark-optical-duplicates.go:50-71
+    assert orc.tile_info(b"SIM:1:FC1:3:1101:12345:6789") == (1101, 12345, 6789)
+    assert orc.tile_info(b"FC:3:1101:12345:6789") == (1101, 12345, 6789)
+    assert orc.tile_info(b"read1") == (-1, -1, -1)
+    assert orc.tile_info(b"a:b:c:d:e:f") == (-1, -1, -1)
+
+
+def test_contig_groups():  # sam/split-merge.go:178-213
+    n, g = orc.contig_groups(np.array([100, 40, 50, 30, 100], dtype=np.int32))
+    # target = 100: [100] | [40,50] | [30] would overflow with 100 -> [30] | [100]
+    assert g.tolist() == [1, 2, 2, 3, 4] and n == 4
+    n, g = orc.contig_groups(np.array([10, 10, 10], dtype=np.int32), 20)
+    assert g.tolist() == [1, 1, 2] and n == 2
+
+
+def _rec(qname, flag, refid, pos, cigar="10M", mapq=60, qual=None, next_refid=-1, pnext=0, tlen=0, rgid=0, seq=None):
+    n = sum(int(c) >> 4 for c in parse_cigar(cigar) if (int(c) & 0xF) in (0, 1, 4, 7, 8)) if cigar != "*" else 10
+    return dict(qname=qname, flag=flag, refid=refid, pos=pos, cigar=cigar, mapq=mapq, next_refid=next_refid, pnext=pnext,
+                tlen=tlen, rgid=rgid, seq=seq or "A" * n, qual=qual if qual is not None else [30] * n)
+
+
+def test_coordinate_order_rules():  # sam/sam-types.go:425-473
+    recs = [
+        _rec("u", 4, -1, 0, "*"),          # 0 unmapped: last
+        _rec("b", 16, 0, 100),             # 1 reverse at 100
+        _rec("a", 0, 0, 100),              # 2 forward at 100 -> before reverse
+        _rec("c", 0, 1, 5),                # 3 refid 1
+        _rec("a", 0, 0, 99),               # 4
+        _rec("a", 0, 0, 100, mapq=10),     # 5 same as 2 but lower MAPQ -> before 2
+        _rec("Z", 0, 0, 100),              # 6 'Z' < 'a' bytewise
+        _rec("a", 0, 0, 100, tlen=-5),     # 7 same as 2 but smaller TLEN -> before 2 (after 5: mapq 10 < 60)
+    ]
+    b = batch_from_records(recs)
+    perm = orc.sort_coordinate(b).tolist()
+    assert perm == [4, 6, 5, 7, 2, 1, 3, 0]
+
+
+def test_sort_is_stable_for_identical_records():
+    recs = [_rec("x", 0, 0, 10) for _ in range(5)] + [_rec("w", 0, 0, 10)]
+    perm = orc.sort_coordinate(batch_from_records(recs)).tolist()
+    assert perm == [5, 0, 1, 2, 3, 4]
+
+
+def _hdr(n_ref=2, libs=(0,), ref_len=1000):
+    rg_lib = np.asarray(libs, dtype=np.uint16)
+    return Header(ref_len=np.full(n_ref, ref_len, dtype=np.int32), rg_lib=rg_lib, rg_cov=np.arange(len(libs), dtype=np.uint16))
+
+
+def test_markdup_fragments():  # filters/mark-duplicates.go:210-254
+    h = _hdr()
+    q = lambda v: [v] * 10
+    recs = [
+        _rec("f1", 0, 0, 100, qual=q(30)),   # score 300
+        _rec("f2", 0, 0, 100, qual=q(35)),   # score 350  -> best
+        _rec("f3", 0, 0, 100, qual=q(20)),   # score 200
+        _rec("f4", 16, 0, 100, qual=q(20)),  # other strand: own group (upos = 109), alone
+        _rec("f5", 0, 0, 102, "2S8M", qual=q(35)),  # upos 100, score 350, QNAME 'f5' > 'f2' -> duplicate
+        _rec("f0", 0, 0, 100, qual=q(35)),   # ties on score, QNAME 'f0' < 'f2' -> new best, f2 becomes duplicate
+    ]
+    flags = orc.mark_duplicates(batch_from_records(recs), h)
+    assert [(int(f) & 0x400) != 0 for f in flags] == [True, True, True, False, True, False]
+
+
+def test_markdup_pair_knocks_out_fragments_and_pairs():  # :222-253, :329-396
+    h = _hdr()
+    q = lambda v: [v] * 10
+    recs = [
+        _rec("frag", 0, 0, 100, qual=q(40)),                                            # true fragment at (0,100,+)
+        _rec("p1", 99, 0, 100, qual=q(20), next_refid=0, pnext=300, tlen=210),           # pair read, same fragment key
+        _rec("p1", 147, 0, 300, qual=q(20), next_refid=0, pnext=100, tlen=-210),
+        _rec("p2", 99, 0, 100, qual=q(30), next_refid=0, pnext=300, tlen=210),           # better pair, same ends
+        _rec("p2", 147, 0, 300, qual=q(30), next_refid=0, pnext=100, tlen=-210),
+        _rec("mu", 73, 0, 100, qual=q(40), next_refid=0, pnext=100),                     # mate unmapped => true fragment
+        _rec("mu", 133, 0, 100, "*", mapq=0, qual=q(40), next_refid=0, pnext=100),       # unmapped mate: not a candidate
+    ]
+    flags = orc.mark_duplicates(batch_from_records(recs), h)
+    dup = [(int(f) & 0x400) != 0 for f in flags]
+    assert dup == [True, True, True, False, False, True, False]
+
+
+def test_markdup_library_separates_groups():
+    h = _hdr(libs=(0, 1, NIL16))
+    q = [30] * 10
+    recs = [_rec("a", 0, 0, 100, qual=q, rgid=0), _rec("b", 0, 0, 100, qual=q, rgid=1), _rec("c", 0, 0, 100, qual=q, rgid=2),
+            _rec("d", 0, 0, 100, qual=q, rgid=NIL16), _rec("e", 0, 0, 100, qual=q, rgid=0)]
+    flags = orc.mark_duplicates(batch_from_records(recs), h)
+    # rg2 (no LB) and the read without RG share the nil library; a/e share lib 0 (a < e wins on QNAME)
+    assert [(int(f) & 0x400) != 0 for f in flags] == [False, False, False, True, True]
+
+
+def test_float_helpers():
+    assert orc.go_log10(1000.0) == pytest.approx(3.0, abs=1e-15)
+    assert orc.go_log10(0.001) == pytest.approx(-3.0, abs=1e-15)
+    assert orc.go_pow10(-3.0) == pytest.approx(1e-3, rel=1e-15)
+    assert orc.go_pow10(2.0) == 100.0
+    # bqsr.go:623-642: 1002 observations, 2 mismatches (smoothed), prior 30 -> posterior mode stays near Q27..30
+    assert 25 <= orc.bayesian_estimate(1002, 2, 30.0) <= 30
+    # a large clean sample at reported Q30 keeps Q30
+    assert orc.bayesian_estimate(10_000_002, 10_001, 30.0) == 30
+    # library size estimate (mark-optical-duplicates.go:541-569): no duplicates -> 0
+    assert orc.estimate_library_size(1000, 1000) == 0
+    assert orc.estimate_library_size(1000, 900) > 900
