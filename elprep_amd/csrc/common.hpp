@@ -1,0 +1,224 @@
+// common.hpp — context, device vectors, launch/profiling helpers shared by the HIP translation units of
+// libelprep_hip.so (gfx950 only; wave64).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/elprep_hip.h"
+
+namespace elp {
+
+constexpr int WAVE = 64;
+
+// SAM FLAG bits (sam/sam-types.go:484-520)
+enum : uint16_t {
+  F_MULTIPLE = 0x1, F_PROPER = 0x2, F_UNMAPPED = 0x4, F_NEXT_UNMAPPED = 0x8, F_REVERSED = 0x10, F_NEXT_REVERSED = 0x20,
+  F_FIRST = 0x40, F_LAST = 0x80, F_SECONDARY = 0x100, F_QCFAILED = 0x200, F_DUPLICATE = 0x400, F_SUPPLEMENTARY = 0x800
+};
+
+// BAM CIGAR op codes: index into "MIDNSHP=X"
+enum : uint32_t { OP_M = 0, OP_I = 1, OP_D = 2, OP_N = 3, OP_S = 4, OP_H = 5, OP_P = 6, OP_EQ = 7, OP_X = 8 };
+
+__host__ __device__ inline bool op_consumes_read(uint32_t op) { return op == OP_M || op == OP_I || op == OP_S || op == OP_EQ || op == OP_X; }
+__host__ __device__ inline bool op_consumes_ref(uint32_t op) { return op == OP_M || op == OP_D || op == OP_N || op == OP_EQ || op == OP_X; }
+
+template <class T>
+struct DVec {
+  T *p = nullptr;
+  size_t cap = 0;  // elements
+  DVec() = default;
+  DVec(const DVec &) = delete;
+  DVec &operator=(const DVec &) = delete;
+  ~DVec() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  size_t bytes() const { return cap * sizeof(T); }
+};
+
+struct ProfPending {
+  int name_id;
+  hipEvent_t a, b;
+};
+
+}  // namespace elp
+
+struct elp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  std::mutex stage_mu;
+
+  // header
+  bool have_header = false;
+  int32_t n_ref = 0, n_rg = 0, n_lib = 0, n_cov = 0;
+  std::vector<int32_t> h_ref_len;
+  std::vector<uint16_t> h_rg_lib, h_rg_cov;
+  elp::DVec<int32_t> ref_len;
+  elp::DVec<uint16_t> rg_lib, rg_cov;
+
+  // staged columns
+  uint64_t n = 0, qname_bytes = 0, cigar_ops = 0, seq_bytes = 0, qual_bytes = 0;
+  elp::DVec<int32_t> refid, pos, next_refid, pnext, tlen;
+  elp::DVec<uint16_t> flag, rgid;
+  elp::DVec<uint8_t> mapq, has_sr;
+  elp::DVec<uint32_t> l_seq;
+  elp::DVec<uint64_t> qname_off, cigar_off, seq_off, qual_off;  // n+1
+  elp::DVec<uint8_t> qname, seq4, qual;
+  elp::DVec<uint32_t> cigar;
+  elp::DVec<uint64_t> stage_tmp;  // offsets of the batch being staged
+  uint32_t max_qname_len = 0, max_l_seq = 0;
+
+  // derived state
+  bool adapted = false, sorted = false, marked = false;
+  elp::DVec<int32_t> upos, score;
+  elp::DVec<uint64_t> key;      // coordinate sort keys, staging order
+  elp::DVec<uint32_t> perm;     // sorted position -> staging index
+  elp::DVec<uint32_t> err_flag; // device-side error word(s)
+
+  // mark-duplicates results kept for the metrics pass
+  elp::DVec<uint32_t> mate;        // per record: staging index of its mate if the two form a pair (classifyPair), else 0xFFFFFFFF
+  elp::DVec<uint32_t> pair_slot;   // per record that owns a pair (the later-arriving mate): slot in the pair table
+  elp::DVec<uint32_t> pair_winner; // per pair-table slot: owner record of the best pair
+  uint64_t pair_table_size = 0;
+
+  // BQSR inputs
+  std::vector<uint8_t *> h_ref_seq;  // device pointers per refid
+  std::vector<int64_t> h_ref_seq_len;
+  std::vector<int32_t *> h_sites;    // device pointers per refid, [n][2]
+  std::vector<int64_t> h_n_sites;
+  elp::DVec<uint8_t *> d_ref_seq;
+  elp::DVec<int64_t> d_ref_seq_len;
+  elp::DVec<int32_t *> d_sites;
+  elp::DVec<int64_t> d_n_sites;
+  bool bqsr_ptrs_dirty = true;
+
+  // generic scratch pool (grown on demand, reused between calls)
+  elp::DVec<uint8_t> scratch[8];
+
+  // profiling
+  bool profiling = false;
+  std::vector<std::string> prof_names;
+  std::map<std::string, int> prof_index;
+  std::vector<uint64_t> prof_launches;
+  std::vector<double> prof_ms;
+  std::vector<elp::ProfPending> prof_pending;
+};
+
+namespace elp {
+
+int set_error(elp_ctx *c, int code, const char *fmt, ...);
+int prof_begin(elp_ctx *c, const char *name);  // returns pending index or -1
+void prof_end(elp_ctx *c, int pending);
+int prof_flush(elp_ctx *c);
+
+#define ELP_HIP(ctx, call)                                                                             \
+  do {                                                                                                 \
+    hipError_t e__ = (call);                                                                           \
+    if (e__ != hipSuccess)                                                                             \
+      return elp::set_error((ctx), e__ == hipErrorOutOfMemory ? ELP_ERR_NOMEM : ELP_ERR_HIP, "%s failed: %s (%s:%d)", #call, \
+                            hipGetErrorString(e__), __FILE__, __LINE__);                               \
+  } while (0)
+
+#define ELP_TRY(expr)            \
+  do {                           \
+    int rc__ = (expr);           \
+    if (rc__ != 0) return rc__;  \
+  } while (0)
+
+// grow-only allocation; keep = copy old contents (device to device)
+template <class T>
+int ensure(elp_ctx *c, DVec<T> &v, size_t n, bool keep = false, size_t keep_elems = 0) {
+  if (n <= v.cap) return 0;
+  size_t ncap = keep ? (n + n / 2 + 16) : n;
+  T *np = nullptr;
+  ELP_HIP(c, hipMalloc((void **)&np, ncap * sizeof(T)));
+  if (keep && v.p && keep_elems) {
+    hipError_t e = hipMemcpyAsync(np, v.p, keep_elems * sizeof(T), hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+      (void)hipFree(np);
+      return set_error(c, ELP_ERR_HIP, "device copy failed while growing a column: %s", hipGetErrorString(e));
+    }
+  }
+  if (v.p) {
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(v.p);
+  }
+  v.p = np;
+  v.cap = ncap;
+  return 0;
+}
+
+// typed view into the scratch pool
+template <class T>
+int scratch(elp_ctx *c, int slot, size_t n, T **out) {
+  ELP_TRY(ensure(c, c->scratch[slot], n * sizeof(T) + 256));
+  *out = reinterpret_cast<T *>(c->scratch[slot].p);
+  return 0;
+}
+
+// launch with optional event bracketing
+#define ELP_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                              \
+  do {                                                                                      \
+    int pp__ = (ctx)->profiling ? elp::prof_begin((ctx), (name)) : -1;                      \
+    hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__);             \
+    if (pp__ >= 0) elp::prof_end((ctx), pp__);                                              \
+    ELP_HIP((ctx), hipGetLastError());                                                      \
+  } while (0)
+
+inline unsigned blocks_for(uint64_t n, unsigned per_block) { return (unsigned)((n + per_block - 1) / per_block); }
+
+// ---- shared device-side helpers ----
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; x ^= x >> 31;
+  return x;
+}
+
+// bytewise QNAME comparison with Go string semantics (shorter prefix is smaller)
+__device__ inline int qname_cmp(const uint8_t *__restrict__ q, const uint64_t *__restrict__ off, uint32_t a, uint32_t b) {
+  uint64_t oa = off[a], ob = off[b];
+  uint32_t la = (uint32_t)(off[a + 1] - oa), lb = (uint32_t)(off[b + 1] - ob);
+  uint32_t m = la < lb ? la : lb;
+  for (uint32_t i = 0; i < m; i++) {
+    int d = (int)q[oa + i] - (int)q[ob + i];
+    if (d) return d;
+  }
+  return la < lb ? -1 : (la > lb ? 1 : 0);
+}
+__device__ inline bool qname_eq(const uint8_t *__restrict__ q, const uint64_t *__restrict__ off, uint32_t a, uint32_t b) {
+  uint64_t oa = off[a], ob = off[b];
+  uint32_t la = (uint32_t)(off[a + 1] - oa), lb = (uint32_t)(off[b + 1] - ob);
+  if (la != lb) return false;
+  for (uint32_t i = 0; i < la; i++)
+    if (q[oa + i] != q[ob + i]) return false;
+  return true;
+}
+
+// sam/sam-types.go:408-421
+__host__ __device__ inline uint16_t mod_flag(uint16_t flag) {
+  if ((flag & F_MULTIPLE) == 0) flag &= (uint16_t) ~(F_NEXT_UNMAPPED | F_NEXT_REVERSED);
+  if (flag & F_UNMAPPED) flag &= (uint16_t)~F_REVERSED;
+  if (flag & F_NEXT_UNMAPPED) flag &= (uint16_t)~F_NEXT_REVERSED;
+  return flag;
+}
+
+// ---- cross-TU entry points ----
+int radix_sort_pairs(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *keys_tmp, uint32_t *vals_tmp, uint64_t n,
+                     uint64_t **keys_out, uint32_t **vals_out);
+int exclusive_scan_u32(elp_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n, uint32_t *total_host /* may be null */);
+int ensure_adapted(elp_ctx *c);
+int fetch_err(elp_ctx *c, uint32_t *words /* 4 */);
+
+}  // namespace elp

@@ -1,0 +1,291 @@
+// ctx.hip — context life cycle, staging of record batches into the HBM column store, result fetch, profiling.
+// Replaces the collection side of record batching: Sam.AddNodes / Slice(&alns) (sam/filter-pipeline.go:108-124).
+#include "common.hpp"
+
+namespace elp {
+
+int set_error(elp_ctx *c, int code, const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf;
+  return code;
+}
+
+int prof_begin(elp_ctx *c, const char *name) {
+  auto it = c->prof_index.find(name);
+  int id;
+  if (it == c->prof_index.end()) {
+    id = (int)c->prof_names.size();
+    c->prof_names.push_back(name);
+    c->prof_index[name] = id;
+    c->prof_launches.push_back(0);
+    c->prof_ms.push_back(0.0);
+  } else {
+    id = it->second;
+  }
+  ProfPending p;
+  p.name_id = id;
+  if (hipEventCreate(&p.a) != hipSuccess) return -1;
+  if (hipEventCreate(&p.b) != hipSuccess) { (void)hipEventDestroy(p.a); return -1; }
+  (void)hipEventRecord(p.a, c->stream);
+  c->prof_pending.push_back(p);
+  return (int)c->prof_pending.size() - 1;
+}
+void prof_end(elp_ctx *c, int pending) { (void)hipEventRecord(c->prof_pending[pending].b, c->stream); }
+int prof_flush(elp_ctx *c) {
+  if (c->prof_pending.empty()) return 0;
+  ELP_HIP(c, hipStreamSynchronize(c->stream));
+  for (auto &p : c->prof_pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      c->prof_ms[p.name_id] += ms;
+      c->prof_launches[p.name_id] += 1;
+    }
+    (void)hipEventDestroy(p.a);
+    (void)hipEventDestroy(p.b);
+  }
+  c->prof_pending.clear();
+  return 0;
+}
+
+__global__ void k_rebase_offsets(const uint64_t *__restrict__ src, uint64_t *__restrict__ dst, uint64_t n_plus_1, uint64_t base,
+                                 uint64_t src0) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_plus_1) dst[i] = src[i] - src0 + base;
+}
+
+int fetch_err(elp_ctx *c, uint32_t *words) {
+  ELP_HIP(c, hipMemcpyAsync(words, c->err_flag.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  ELP_HIP(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+}  // namespace elp
+
+using namespace elp;
+
+extern "C" {
+
+int elp_create(int device_ordinal, elp_ctx **out) {
+  if (!out) return ELP_ERR_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ELP_ERR_HIP;  // no CPU fallback by design
+  if (device_ordinal < 0 || device_ordinal >= ndev) return ELP_ERR_ARG;
+  if (hipSetDevice(device_ordinal) != hipSuccess) return ELP_ERR_HIP;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess) return ELP_ERR_HIP;
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return ELP_ERR_UNSUPPORTED;  // kernels are built for gfx950 only
+  elp_ctx *c = new elp_ctx();
+  c->device = device_ordinal;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ELP_ERR_HIP; }
+  if (ensure(c, c->err_flag, 4) != 0 || hipMemsetAsync(c->err_flag.p, 0, 16, c->stream) != hipSuccess) { delete c; return ELP_ERR_HIP; }
+  *out = c;
+  return ELP_OK;
+}
+
+void elp_destroy(elp_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (auto &p : c->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+  for (auto p : c->h_ref_seq) if (p) (void)hipFree(p);
+  for (auto p : c->h_sites) if (p) (void)hipFree(p);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char *elp_last_error(const elp_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int elp_sync(elp_ctx *c) {
+  if (!c) return ELP_ERR_ARG;
+  ELP_HIP(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+void *elp_stream(elp_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int elp_set_header(elp_ctx *c, const elp_header *h) {
+  if (!c || !h || h->n_ref < 0 || h->n_rg < 0) return set_error(c, ELP_ERR_ARG, "elp_set_header: bad arguments");
+  ELP_HIP(c, hipSetDevice(c->device));
+  c->n_ref = h->n_ref; c->n_rg = h->n_rg; c->n_lib = h->n_lib; c->n_cov = h->n_cov;
+  c->h_ref_len.assign(h->ref_len, h->ref_len + h->n_ref);
+  c->h_rg_lib.assign(h->rg_lib, h->rg_lib + h->n_rg);
+  c->h_rg_cov.assign(h->rg_cov, h->rg_cov + h->n_rg);
+  for (int i = 0; i < h->n_rg; i++) {
+    if (c->h_rg_lib[i] != ELP_NIL16 && c->h_rg_lib[i] >= h->n_lib) return set_error(c, ELP_ERR_ARG, "rg_lib[%d] out of range", i);
+    if (c->h_rg_cov[i] >= h->n_cov) return set_error(c, ELP_ERR_ARG, "rg_cov[%d] out of range", i);
+  }
+  ELP_TRY(ensure(c, c->ref_len, (size_t)h->n_ref + 1));
+  ELP_TRY(ensure(c, c->rg_lib, (size_t)h->n_rg + 1));
+  ELP_TRY(ensure(c, c->rg_cov, (size_t)h->n_rg + 1));
+  if (h->n_ref) ELP_HIP(c, hipMemcpyAsync(c->ref_len.p, h->ref_len, h->n_ref * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  if (h->n_rg) {
+    ELP_HIP(c, hipMemcpyAsync(c->rg_lib.p, h->rg_lib, h->n_rg * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+    ELP_HIP(c, hipMemcpyAsync(c->rg_cov.p, h->rg_cov, h->n_rg * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+  }
+  ELP_HIP(c, hipStreamSynchronize(c->stream));
+  c->h_ref_seq.resize(h->n_ref, nullptr);
+  c->h_ref_seq_len.resize(h->n_ref, 0);
+  c->h_sites.resize(h->n_ref, nullptr);
+  c->h_n_sites.resize(h->n_ref, 0);
+  c->bqsr_ptrs_dirty = true;
+  c->have_header = true;
+  return 0;
+}
+
+static int reserve_locked(elp_ctx *c, uint64_t n, uint64_t qb, uint64_t co, uint64_t sb, uint64_t lb) {
+  bool keep = c->n > 0;
+  ELP_TRY(ensure(c, c->refid, n, keep, c->n));
+  ELP_TRY(ensure(c, c->pos, n, keep, c->n));
+  ELP_TRY(ensure(c, c->next_refid, n, keep, c->n));
+  ELP_TRY(ensure(c, c->pnext, n, keep, c->n));
+  ELP_TRY(ensure(c, c->tlen, n, keep, c->n));
+  ELP_TRY(ensure(c, c->flag, n, keep, c->n));
+  ELP_TRY(ensure(c, c->rgid, n, keep, c->n));
+  ELP_TRY(ensure(c, c->mapq, n, keep, c->n));
+  ELP_TRY(ensure(c, c->has_sr, n, keep, c->n));
+  ELP_TRY(ensure(c, c->l_seq, n, keep, c->n));
+  ELP_TRY(ensure(c, c->qname_off, n + 1, keep, c->n + 1));
+  ELP_TRY(ensure(c, c->cigar_off, n + 1, keep, c->n + 1));
+  ELP_TRY(ensure(c, c->seq_off, n + 1, keep, c->n + 1));
+  ELP_TRY(ensure(c, c->qual_off, n + 1, keep, c->n + 1));
+  ELP_TRY(ensure(c, c->qname, qb + 16, keep, c->qname_bytes));
+  ELP_TRY(ensure(c, c->cigar, co + 4, keep, c->cigar_ops));
+  ELP_TRY(ensure(c, c->seq4, sb + 16, keep, c->seq_bytes));
+  ELP_TRY(ensure(c, c->qual, lb + 16, keep, c->qual_bytes));
+  return 0;
+}
+
+int elp_reserve(elp_ctx *c, uint64_t n, uint64_t qb, uint64_t co, uint64_t sb, uint64_t lb) {
+  if (!c) return ELP_ERR_ARG;
+  std::lock_guard<std::mutex> g(c->stage_mu);
+  ELP_HIP(c, hipSetDevice(c->device));
+  return reserve_locked(c, n, qb, co, sb, lb);
+}
+
+int elp_reset(elp_ctx *c) {
+  if (!c) return ELP_ERR_ARG;
+  std::lock_guard<std::mutex> g(c->stage_mu);
+  c->n = c->qname_bytes = c->cigar_ops = c->seq_bytes = c->qual_bytes = 0;
+  c->max_qname_len = c->max_l_seq = 0;
+  c->adapted = c->sorted = c->marked = false;
+  return 0;
+}
+
+uint64_t elp_num_records(const elp_ctx *c) { return c ? c->n : 0; }
+
+int elp_stage(elp_ctx *c, const elp_batch *b) {
+  if (!c || !b) return ELP_ERR_ARG;
+  std::lock_guard<std::mutex> g(c->stage_mu);
+  ELP_HIP(c, hipSetDevice(c->device));
+  if (!c->have_header) return set_error(c, ELP_ERR_ARG, "elp_stage: call elp_set_header first");
+  uint64_t n = b->n;
+  if (n == 0) return 0;
+  if (c->n + n > 0xFFFFFFF0ull) return set_error(c, ELP_ERR_UNSUPPORTED, "more than 2^32-16 records per context");
+  uint64_t q0 = b->qname_off[0], c0 = b->cigar_off[0], s0 = b->seq_off[0], l0 = b->qual_off[0];
+  uint64_t qb = b->qname_off[n] - q0, co = b->cigar_off[n] - c0, sb = b->seq_off[n] - s0, lb = b->qual_off[n] - l0;
+  ELP_TRY(reserve_locked(c, c->n + n, c->qname_bytes + qb, c->cigar_ops + co, c->seq_bytes + sb, c->qual_bytes + lb));
+  // host-side scan for limits the kernels rely on
+  for (uint64_t i = 0; i < n; i++) {
+    uint64_t ql = b->qname_off[i + 1] - b->qname_off[i];
+    if (ql > c->max_qname_len) c->max_qname_len = (uint32_t)ql;
+    if (b->l_seq[i] > c->max_l_seq) c->max_l_seq = b->l_seq[i];
+    if (b->rgid[i] != ELP_NIL16 && b->rgid[i] >= c->n_rg) return set_error(c, ELP_ERR_ARG, "record %llu: rgid %u not in header", (unsigned long long)i, b->rgid[i]);
+    if (b->refid[i] >= c->n_ref) return set_error(c, ELP_ERR_ARG, "record %llu: refid %d not in header", (unsigned long long)i, b->refid[i]);
+  }
+  hipStream_t st = c->stream;
+  uint64_t at = c->n;
+#define H2D(dst, src, cnt, T) ELP_HIP(c, hipMemcpyAsync((dst), (src), (cnt) * sizeof(T), hipMemcpyHostToDevice, st))
+  H2D(c->refid.p + at, b->refid, n, int32_t);
+  H2D(c->pos.p + at, b->pos, n, int32_t);
+  H2D(c->next_refid.p + at, b->next_refid, n, int32_t);
+  H2D(c->pnext.p + at, b->pnext, n, int32_t);
+  H2D(c->tlen.p + at, b->tlen, n, int32_t);
+  H2D(c->flag.p + at, b->flag, n, uint16_t);
+  H2D(c->rgid.p + at, b->rgid, n, uint16_t);
+  H2D(c->mapq.p + at, b->mapq, n, uint8_t);
+  H2D(c->l_seq.p + at, b->l_seq, n, uint32_t);
+  if (b->has_sr) H2D(c->has_sr.p + at, b->has_sr, n, uint8_t);
+  else ELP_HIP(c, hipMemsetAsync(c->has_sr.p + at, 0, n, st));
+  if (qb) H2D(c->qname.p + c->qname_bytes, b->qname + q0, qb, uint8_t);
+  if (co) H2D(c->cigar.p + c->cigar_ops, b->cigar + c0, co, uint32_t);
+  if (sb) H2D(c->seq4.p + c->seq_bytes, b->seq4 + s0, sb, uint8_t);
+  if (lb) H2D(c->qual.p + c->qual_bytes, b->qual + l0, lb, uint8_t);
+  // offsets: copy raw, rebase on device
+  ELP_TRY(ensure(c, c->stage_tmp, n + 1));
+  unsigned blk = 256, grd = blocks_for(n + 1, blk);
+  struct { const uint64_t *src; uint64_t *dst; uint64_t base; } offs[4] = {
+      {b->qname_off, c->qname_off.p + at, c->qname_bytes}, {b->cigar_off, c->cigar_off.p + at, c->cigar_ops},
+      {b->seq_off, c->seq_off.p + at, c->seq_bytes}, {b->qual_off, c->qual_off.p + at, c->qual_bytes}};
+  for (auto &o : offs) {
+    H2D(c->stage_tmp.p, o.src, n + 1, uint64_t);
+    hipLaunchKernelGGL(k_rebase_offsets, dim3(grd), dim3(blk), 0, st, (const uint64_t *)c->stage_tmp.p, o.dst, n + 1, o.base, o.src[0]);
+    ELP_HIP(c, hipGetLastError());
+  }
+#undef H2D
+  ELP_HIP(c, hipStreamSynchronize(st));  // host buffers may be reused on return
+  c->n += n; c->qname_bytes += qb; c->cigar_ops += co; c->seq_bytes += sb; c->qual_bytes += lb;
+  c->adapted = c->sorted = c->marked = false;
+  return 0;
+}
+
+static int d2h(elp_ctx *c, void *dst, const void *src, size_t bytes) {
+  if (!bytes) return 0;
+  ELP_HIP(c, hipSetDevice(c->device));
+  ELP_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  ELP_HIP(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int elp_get_permutation(elp_ctx *c, uint32_t *out) {
+  if (!c || !out) return ELP_ERR_ARG;
+  if (!c->sorted) return set_error(c, ELP_ERR_ARG, "elp_get_permutation: call elp_sort_coordinate first");
+  return d2h(c, out, c->perm.p, c->n * sizeof(uint32_t));
+}
+int elp_get_flags(elp_ctx *c, uint16_t *out) {
+  if (!c || !out) return ELP_ERR_ARG;
+  return d2h(c, out, c->flag.p, c->n * sizeof(uint16_t));
+}
+int elp_get_adapted(elp_ctx *c, int32_t *upos, int32_t *score) {
+  if (!c) return ELP_ERR_ARG;
+  ELP_TRY(ensure_adapted(c));
+  if (upos) ELP_TRY(d2h(c, upos, c->upos.p, c->n * sizeof(int32_t)));
+  if (score) ELP_TRY(d2h(c, score, c->score.p, c->n * sizeof(int32_t)));
+  return 0;
+}
+int elp_get_qual(elp_ctx *c, uint8_t *out) {
+  if (!c || !out) return ELP_ERR_ARG;
+  return d2h(c, out, c->qual.p, c->qual_bytes);
+}
+
+int elp_profile_enable(elp_ctx *c, int on) {
+  if (!c) return ELP_ERR_ARG;
+  if (!on) ELP_TRY(prof_flush(c));
+  c->profiling = on != 0;
+  return 0;
+}
+int elp_profile_reset(elp_ctx *c) {
+  if (!c) return ELP_ERR_ARG;
+  ELP_TRY(prof_flush(c));
+  for (auto &v : c->prof_launches) v = 0;
+  for (auto &v : c->prof_ms) v = 0.0;
+  return 0;
+}
+int elp_profile_count(elp_ctx *c) {
+  if (!c) return ELP_ERR_ARG;
+  if (prof_flush(c) != 0) return ELP_ERR_HIP;
+  return (int)c->prof_names.size();
+}
+int elp_profile_get(elp_ctx *c, int index, const char **name, uint64_t *launches, double *total_ms) {
+  if (!c || index < 0 || index >= (int)c->prof_names.size()) return ELP_ERR_ARG;
+  if (name) *name = c->prof_names[index].c_str();
+  if (launches) *launches = c->prof_launches[index];
+  if (total_ms) *total_ms = c->prof_ms[index];
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,304 @@
+// markdup.hip — duplicate marking on the HBM column store.
+//
+// Reference: filters/mark-duplicates.go (classifyFragment :210-254, classifyPair :329-396, MarkDuplicates :398-445).
+// The reference runs three pargo sync.Maps with CAS tournaments whose outcome depends on goroutine interleaving only
+// for exact (score, QNAME) ties; this implementation computes the outcome of the single-threaded execution (records
+// arrive in staging order), which is a deterministic function of the data:
+//
+//   fragments  key {lib, refid, unclipped 5' pos, strand}: if the group holds a read of a true pair, every true fragment
+//              of the group is a duplicate; otherwise all but the best (score desc, QNAME asc, later arrival) are.
+//   mates      key {lib, QNAME}: reads pair up in arrival order (DeleteOrStore toggling, :336-340).
+//   pairs      key {lib, refid1, refid2, pos1, pos2, strand1, strand2} with ends ordered as in :347-353: all but the best
+//              pair (score sum desc, QNAME asc, later completion) have both reads flagged.
+//
+// Grouping uses open-addressing tables in HBM whose entries are record indices (keys are compared by dereferencing the
+// representative's columns, so there are no fingerprint collisions); group payloads are indexed by the representative.
+// All cross-workgroup words are touched with agent-scope atomics; stale plain reads cannot occur because table entries
+// only ever change EMPTY -> value and tournaments are re-checked through the CAS return value.
+#include "common.hpp"
+
+namespace elp {
+
+constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+
+struct MdCols {
+  uint64_t n;
+  const int32_t *refid;
+  const uint16_t *flag_in;  // flags as staged (before this call)
+  const uint16_t *rgid;
+  const uint16_t *rg_lib;
+  const int32_t *upos, *score;
+  const uint64_t *qname_off;
+  const uint8_t *qname;
+};
+
+__device__ __forceinline__ bool is_candidate(uint16_t f) { return (f & (F_UNMAPPED | F_SECONDARY | F_SUPPLEMENTARY)) == 0; }
+__device__ __forceinline__ bool is_true_pair(uint16_t f) { return (f & (F_MULTIPLE | F_NEXT_UNMAPPED)) == F_MULTIPLE; }  // :182-184
+__device__ __forceinline__ uint16_t lib_of(const MdCols &m, uint32_t i) {
+  const uint16_t rg = m.rgid[i];
+  return rg == ELP_NIL16 ? (uint16_t)ELP_NIL16 : m.rg_lib[rg];  // addLIBID :142-150
+}
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long ld_agent64(const unsigned long long *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------- fragments
+__device__ __forceinline__ bool frag_key_eq(const MdCols &m, uint32_t a, uint32_t b) {
+  return m.refid[a] == m.refid[b] && m.upos[a] == m.upos[b] && ((m.flag_in[a] ^ m.flag_in[b]) & F_REVERSED) == 0 && lib_of(m, a) == lib_of(m, b);
+}
+__device__ __forceinline__ uint64_t frag_hash(const MdCols &m, uint32_t i) {
+  uint64_t h = ((uint64_t)(uint32_t)m.refid[i] << 32) | (uint32_t)m.upos[i];
+  h = mix64(h) ^ (((uint64_t)lib_of(m, i) << 1) | ((m.flag_in[i] & F_REVERSED) ? 1 : 0));
+  return mix64(h);
+}
+
+// generic find-or-insert; returns the representative record of i's group
+template <class Eq>
+__device__ __forceinline__ uint32_t find_or_insert(uint32_t *table, uint64_t mask, uint64_t h, uint32_t i, Eq eq) {
+  uint64_t s = h & mask;
+  for (;;) {
+    uint32_t cur = ld_agent(&table[s]);
+    if (cur == EMPTY) {
+      cur = atomicCAS(&table[s], EMPTY, i);
+      if (cur == EMPTY) return i;
+    }
+    if (cur == i || eq(cur, i)) return cur;
+    s = (s + 1) & mask;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_frag_insert(MdCols m, uint32_t *table, uint64_t mask, uint32_t *__restrict__ frep,
+                                                     unsigned long long *fbest) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.n) return;
+  const uint16_t f = m.flag_in[i];
+  if (!is_candidate(f)) { frep[i] = EMPTY; return; }
+  const uint32_t rep = find_or_insert(table, mask, frag_hash(m, (uint32_t)i), (uint32_t)i, [&](uint32_t a, uint32_t b) { return frag_key_eq(m, a, b); });
+  frep[i] = rep;
+  const unsigned long long v = is_true_pair(f) ? (1ull << 63) : (unsigned long long)(uint32_t)m.score[i];
+  atomicMax(&fbest[rep], v);
+}
+
+// (QNAME asc, later arrival wins) tournament among contenders
+__device__ __forceinline__ void tournament(const MdCols &m, uint32_t *winner, uint32_t me) {
+  uint32_t w = ld_agent(winner);
+  for (;;) {
+    if (w == EMPTY) {
+      const uint32_t old = atomicCAS(winner, EMPTY, me);
+      if (old == EMPTY) return;
+      w = old;
+      continue;
+    }
+    const int cq = qname_cmp(m.qname, m.qname_off, me, w);
+    const bool better = cq < 0 || (cq == 0 && me > w);  // :232-238: on equal QNAME the later arrival replaces the holder
+    if (!better) return;
+    const uint32_t old = atomicCAS(winner, w, me);
+    if (old == w) return;
+    w = old;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_frag_tie(MdCols m, const uint32_t *__restrict__ frep, const unsigned long long *__restrict__ fbest,
+                                                  uint32_t *fwinner) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.n) return;
+  const uint32_t rep = frep[i];
+  if (rep == EMPTY || is_true_pair(m.flag_in[i])) return;
+  const unsigned long long b = fbest[rep];
+  if ((b >> 63) || (unsigned long long)(uint32_t)m.score[i] != b) return;
+  tournament(m, &fwinner[rep], (uint32_t)i);
+}
+
+__global__ __launch_bounds__(256) void k_frag_flag(MdCols m, const uint32_t *__restrict__ frep, const unsigned long long *__restrict__ fbest,
+                                                   const uint32_t *__restrict__ fwinner, uint16_t *__restrict__ flag_out) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.n) return;
+  const uint32_t rep = frep[i];
+  if (rep == EMPTY || is_true_pair(m.flag_in[i])) return;
+  const unsigned long long b = fbest[rep];
+  const bool dup = (b >> 63) || (unsigned long long)(uint32_t)m.score[i] < b || fwinner[rep] != (uint32_t)i;
+  if (dup) flag_out[i] = (uint16_t)(m.flag_in[i] | F_DUPLICATE);
+}
+
+// ---------------- mates
+__device__ __forceinline__ uint64_t qname_hash(const MdCols &m, uint32_t i) {
+  const uint64_t o = m.qname_off[i];
+  const uint32_t l = (uint32_t)(m.qname_off[i + 1] - o);
+  uint64_t h = 0x9e3779b97f4a7c15ull ^ l;
+  uint32_t k = 0;
+  for (; k + 8 <= l; k += 8) {
+    uint64_t w = 0;
+#pragma unroll
+    for (int b = 0; b < 8; b++) w |= (uint64_t)m.qname[o + k + b] << (8 * b);
+    h = mix64(h ^ w);
+  }
+  uint64_t w = 0;
+  for (uint32_t b = 0; k + b < l; b++) w |= (uint64_t)m.qname[o + k + b] << (8 * b);
+  return mix64(h ^ w ^ ((uint64_t)lib_of(m, i) << 48));
+}
+
+__global__ __launch_bounds__(256) void k_mate_insert(MdCols m, uint32_t *table, uint64_t mask, uint32_t *__restrict__ mrep, uint32_t *cnt,
+                                                     uint32_t *lo, uint32_t *hi) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.n) return;
+  const uint16_t f = m.flag_in[i];
+  if (!is_candidate(f) || !is_true_pair(f)) { mrep[i] = EMPTY; return; }
+  const uint32_t rep = find_or_insert(table, mask, qname_hash(m, (uint32_t)i), (uint32_t)i,
+                                      [&](uint32_t a, uint32_t b) { return lib_of(m, a) == lib_of(m, b) && qname_eq(m.qname, m.qname_off, a, b); });
+  mrep[i] = rep;
+  atomicAdd(&cnt[rep], 1u);
+  atomicMin(&lo[rep], (uint32_t)i);
+  atomicMax(&hi[rep], (uint32_t)i);
+}
+
+__global__ __launch_bounds__(256) void k_mate_resolve(MdCols m, const uint32_t *__restrict__ mrep, const uint32_t *__restrict__ cnt,
+                                                      const uint32_t *__restrict__ lo, const uint32_t *__restrict__ hi,
+                                                      uint32_t *__restrict__ mate, uint32_t *err) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.n) return;
+  const uint32_t rep = mrep[i];
+  uint32_t mt = EMPTY;
+  if (rep != EMPTY) {
+    const uint32_t c = cnt[rep];
+    if (c == 2) mt = ((uint32_t)i == lo[rep]) ? hi[rep] : lo[rep];
+    else if (c > 2) atomicOr(&err[1], 1u);  // more than two primary mapped records share {library, QNAME}
+  }
+  mate[i] = mt;
+}
+
+// ---------------- pairs
+struct PairEnds { uint32_t a1, a2; };
+// order the two ends (:347-353); `second` arrived later than `first`
+__device__ __forceinline__ PairEnds order_pair(const MdCols &m, uint32_t second, uint32_t first) {
+  uint32_t a1 = second, a2 = first;
+  const int32_t r1 = m.refid[a1], r2 = m.refid[a2];
+  const int32_t p1 = m.upos[a1], p2 = m.upos[a2];
+  const bool v1 = m.flag_in[a1] & F_REVERSED, v2 = m.flag_in[a2] & F_REVERSED;
+  if (r1 > r2 || (r1 == r2 && (p1 > p2 || (p1 == p2 && v1 && !v2)))) { uint32_t t = a1; a1 = a2; a2 = t; }
+  return PairEnds{a1, a2};
+}
+__device__ __forceinline__ bool pair_key_eq(const MdCols &m, const uint32_t *__restrict__ mate, uint32_t oa, uint32_t ob) {
+  const PairEnds a = order_pair(m, oa, mate[oa]), b = order_pair(m, ob, mate[ob]);
+  return m.refid[a.a1] == m.refid[b.a1] && m.refid[a.a2] == m.refid[b.a2] && m.upos[a.a1] == m.upos[b.a1] && m.upos[a.a2] == m.upos[b.a2] &&
+         ((m.flag_in[a.a1] ^ m.flag_in[b.a1]) & F_REVERSED) == 0 && ((m.flag_in[a.a2] ^ m.flag_in[b.a2]) & F_REVERSED) == 0 &&
+         lib_of(m, a.a1) == lib_of(m, b.a1);
+}
+
+__global__ __launch_bounds__(256) void k_pair_insert(MdCols m, const uint32_t *__restrict__ mate, uint32_t *table, uint64_t mask,
+                                                     uint32_t *__restrict__ prep, unsigned long long *pbest) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.n) return;
+  const uint32_t mt = mate[i];
+  if (mt == EMPTY || mt > (uint32_t)i) { prep[i] = EMPTY; return; }  // the later-arriving mate owns the pair (:336-340)
+  const PairEnds e = order_pair(m, (uint32_t)i, mt);
+  uint64_t h = mix64(((uint64_t)(uint32_t)m.refid[e.a1] << 32) | (uint32_t)m.refid[e.a2]);
+  h = mix64(h ^ (((uint64_t)(uint32_t)m.upos[e.a1] << 32) | (uint32_t)m.upos[e.a2]));
+  h = mix64(h ^ (((uint64_t)lib_of(m, e.a1) << 2) | ((m.flag_in[e.a1] & F_REVERSED) ? 2 : 0) | ((m.flag_in[e.a2] & F_REVERSED) ? 1 : 0)));
+  const uint32_t rep = find_or_insert(table, mask, h, (uint32_t)i, [&](uint32_t a, uint32_t b) { return pair_key_eq(m, mate, a, b); });
+  prep[i] = rep;
+  const int32_t sc = m.score[i] + m.score[mt];  // :342
+  atomicMax(&pbest[rep], (unsigned long long)(uint32_t)sc);
+}
+
+__global__ __launch_bounds__(256) void k_pair_tie(MdCols m, const uint32_t *__restrict__ mate, const uint32_t *__restrict__ prep,
+                                                  const unsigned long long *__restrict__ pbest, uint32_t *pwinner) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.n) return;
+  const uint32_t rep = prep[i];
+  if (rep == EMPTY) return;
+  const int32_t sc = m.score[i] + m.score[mate[i]];
+  if ((unsigned long long)(uint32_t)sc != pbest[rep]) return;
+  tournament(m, &pwinner[rep], (uint32_t)i);  // both mates share the QNAME, so the owner's QNAME stands for aln1.QNAME (:383)
+}
+
+__global__ __launch_bounds__(256) void k_pair_flag(MdCols m, const uint32_t *__restrict__ mate, const uint32_t *__restrict__ prep,
+                                                   const uint32_t *__restrict__ pwinner, uint16_t *__restrict__ flag_out) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.n) return;
+  const uint32_t rep = prep[i];
+  if (rep == EMPTY) return;
+  if (pwinner[rep] != (uint32_t)i) {
+    const uint32_t mt = mate[i];
+    flag_out[i] = (uint16_t)(flag_out[i] | F_DUPLICATE);
+    flag_out[mt] = (uint16_t)(flag_out[mt] | F_DUPLICATE);
+  }
+}
+
+static uint64_t table_size_for(uint64_t n) {
+  uint64_t t = 1024;
+  while (t < 2 * n + 16) t <<= 1;
+  return t;
+}
+
+static int markdup_impl(elp_ctx *c) {
+  const uint64_t n = c->n;
+  ELP_TRY(ensure_adapted(c));
+  ELP_TRY(ensure(c, c->mate, n + 1));
+  ELP_TRY(ensure(c, c->pair_slot, n + 1));
+  ELP_TRY(ensure(c, c->pair_winner, n + 1));
+  if (n == 0) { c->marked = true; return 0; }
+  const unsigned grid = blocks_for(n, 256);
+  hipStream_t st = c->stream;
+  // flag_in snapshot: tournaments must see the flags as staged (isTruePair/IsReversed never change, but keep it explicit)
+  uint16_t *flag_in;
+  ELP_TRY(scratch(c, 4, n + 8, &flag_in));
+  ELP_HIP(c, hipMemcpyAsync(flag_in, c->flag.p, n * sizeof(uint16_t), hipMemcpyDeviceToDevice, st));
+  MdCols m{n, c->refid.p, flag_in, c->rgid.p, c->rg_lib.p, c->upos.p, c->score.p, c->qname_off.p, c->qname.p};
+  const uint64_t T = table_size_for(n);
+  uint32_t *table;
+  ELP_TRY(scratch(c, 0, T, &table));
+  uint32_t *rep;
+  ELP_TRY(scratch(c, 1, n + 8, &rep));
+  unsigned long long *best;
+  ELP_TRY(scratch(c, 2, 2 * n + 8, &best));  // also holds cnt/lo/hi (3n u32) in the mate phase
+  uint32_t *winner;
+  ELP_TRY(scratch(c, 3, n + 8, &winner));
+
+  // ---- fragments
+  ELP_HIP(c, hipMemsetAsync(table, 0xFF, T * sizeof(uint32_t), st));
+  ELP_HIP(c, hipMemsetAsync(best, 0, n * sizeof(unsigned long long), st));
+  ELP_HIP(c, hipMemsetAsync(winner, 0xFF, n * sizeof(uint32_t), st));
+  ELP_LAUNCH(c, "md_frag_insert", k_frag_insert, dim3(grid), dim3(256), 0, m, table, T - 1, rep, best);
+  ELP_LAUNCH(c, "md_frag_tie", k_frag_tie, dim3(grid), dim3(256), 0, m, (const uint32_t *)rep, (const unsigned long long *)best, winner);
+  ELP_LAUNCH(c, "md_frag_flag", k_frag_flag, dim3(grid), dim3(256), 0, m, (const uint32_t *)rep, (const unsigned long long *)best,
+             (const uint32_t *)winner, c->flag.p);
+
+  // ---- mates
+  uint32_t *cnt = reinterpret_cast<uint32_t *>(best), *lo = cnt + n, *hi = cnt + 2 * n;
+  ELP_HIP(c, hipMemsetAsync(table, 0xFF, T * sizeof(uint32_t), st));
+  ELP_HIP(c, hipMemsetAsync(cnt, 0, n * sizeof(uint32_t), st));
+  ELP_HIP(c, hipMemsetAsync(lo, 0xFF, n * sizeof(uint32_t), st));
+  ELP_HIP(c, hipMemsetAsync(hi, 0, n * sizeof(uint32_t), st));
+  ELP_LAUNCH(c, "md_mate_insert", k_mate_insert, dim3(grid), dim3(256), 0, m, table, T - 1, rep, cnt, lo, hi);
+  ELP_LAUNCH(c, "md_mate_resolve", k_mate_resolve, dim3(grid), dim3(256), 0, m, (const uint32_t *)rep, (const uint32_t *)cnt, (const uint32_t *)lo,
+             (const uint32_t *)hi, c->mate.p, c->err_flag.p);
+
+  // ---- pairs
+  ELP_HIP(c, hipMemsetAsync(table, 0xFF, T * sizeof(uint32_t), st));
+  ELP_HIP(c, hipMemsetAsync(best, 0, n * sizeof(unsigned long long), st));
+  ELP_HIP(c, hipMemsetAsync(c->pair_winner.p, 0xFF, n * sizeof(uint32_t), st));
+  ELP_LAUNCH(c, "md_pair_insert", k_pair_insert, dim3(grid), dim3(256), 0, m, (const uint32_t *)c->mate.p, table, T - 1, c->pair_slot.p, best);
+  ELP_LAUNCH(c, "md_pair_tie", k_pair_tie, dim3(grid), dim3(256), 0, m, (const uint32_t *)c->mate.p, (const uint32_t *)c->pair_slot.p,
+             (const unsigned long long *)best, c->pair_winner.p);
+  ELP_LAUNCH(c, "md_pair_flag", k_pair_flag, dim3(grid), dim3(256), 0, m, (const uint32_t *)c->mate.p, (const uint32_t *)c->pair_slot.p,
+             (const uint32_t *)c->pair_winner.p, c->flag.p);
+  uint32_t e[4];
+  ELP_TRY(fetch_err(c, e));
+  if (e[1]) {
+    ELP_HIP(c, hipMemsetAsync(c->err_flag.p + 1, 0, 4, st));
+    return set_error(c, ELP_ERR_UNSUPPORTED, "more than two primary mapped records share one {library, QNAME}: mate pairing by arrival order is not implemented");
+  }
+  c->marked = true;
+  return 0;
+}
+
+}  // namespace elp
+
+extern "C" int elp_mark_duplicates(elp_ctx *c, int also_opticals) {
+  (void)also_opticals;  // LIBID is derived from rgid on demand for every read
+  if (!c) return ELP_ERR_ARG;
+  ELP_HIP(c, hipSetDevice(c->device));
+  c->marked = false;
+  return elp::markdup_impl(c);
+}

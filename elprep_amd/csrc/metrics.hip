@@ -1,0 +1,245 @@
+// metrics.hip — DuplicationMetrics counters and optical-duplicate counting.
+//
+// Reference: filters.MarkOpticalDuplicates (filters/mark-optical-duplicates.go:469-525), markOpticalDuplicatesPair (:182-224),
+// countOpticalDuplicates (:275-325), countOpticalDuplicatesFromSlice (:327-368), countOpticalDuplicatesWithGraph (:232-273),
+// computeTileInfo (:50-71), isOpticalDuplicateShort (filters/unpedantic.go:32-34), graph.cluster (filters/graph.go:72-85).
+//
+// For every pair group the "origin" is the best pair; each losing (duplicate) pair contributes its First-flag read.  Origin and
+// duplicates are split by the strand of the listed read; the optical count of a list is  n - #connected components  under the
+// relation {same RG, same tile != -1, |dx| <= d, |dy| <= d}, which is what both the n <= 3 special cases and the union-find of
+// the reference compute.  Lists longer than 300000 (the reference's cap, :289-299) are rejected as unsupported.
+#include "common.hpp"
+
+namespace elp {
+
+constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+
+struct MxCols {
+  uint64_t n;
+  const int32_t *refid;
+  const uint16_t *flag;   // flags after elp_mark_duplicates
+  const uint16_t *rgid;
+  const uint16_t *rg_lib;
+  const int32_t *upos;
+  const uint64_t *qname_off;
+  const uint8_t *qname;
+  const uint32_t *mate, *prep, *pwinner;
+  int32_t n_lib;
+};
+
+__device__ __forceinline__ uint32_t lib_row(const MxCols &m, uint32_t i) {
+  const uint16_t rg = m.rgid[i];
+  const uint16_t lb = rg == ELP_NIL16 ? (uint16_t)ELP_NIL16 : m.rg_lib[rg];
+  return lb == ELP_NIL16 ? (uint32_t)m.n_lib : (uint32_t)lb;  // "Unknown Library" row (:435-447)
+}
+__device__ __forceinline__ bool true_pair(uint16_t f) { return (f & (F_MULTIPLE | F_NEXT_UNMAPPED)) == F_MULTIPLE; }
+
+// ends ordered as in filters/mark-duplicates.go:347-353 (`second` arrived after `first`)
+__device__ __forceinline__ void order_ends(const MxCols &m, uint32_t second, uint32_t first, uint32_t &a1, uint32_t &a2) {
+  a1 = second; a2 = first;
+  const int32_t r1 = m.refid[a1], r2 = m.refid[a2];
+  const int32_t p1 = m.upos[a1], p2 = m.upos[a2];
+  const bool v1 = m.flag[a1] & F_REVERSED, v2 = m.flag[a2] & F_REVERSED;
+  if (r1 > r2 || (r1 == r2 && (p1 > p2 || (p1 == p2 && v1 && !v2)))) { uint32_t t = a1; a1 = a2; a2 = t; }
+}
+__device__ __forceinline__ uint32_t listed_read(const MxCols &m, uint32_t owner) {  // :216-221 / :278-283
+  uint32_t a1, a2;
+  order_ends(m, owner, m.mate[owner], a1, a2);
+  return (m.flag[a1] & F_FIRST) ? a1 : a2;
+}
+
+// :473-502 — one pass over all records (order does not matter for sums)
+__global__ __launch_bounds__(256) void k_dup_counters(MxCols m, unsigned long long *__restrict__ ctr) {
+  extern __shared__ unsigned int lds_ctr[];  // [(n_lib+1)*7]
+  const int ncell = (m.n_lib + 1) * ELP_NCTR;
+  for (int k = threadIdx.x; k < ncell; k += blockDim.x) lds_ctr[k] = 0;
+  __syncthreads();
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m.n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint16_t f = m.flag[i];
+    unsigned int *row = lds_ctr + lib_row(m, (uint32_t)i) * ELP_NCTR;
+    if (f & F_UNMAPPED) { atomicAdd(&row[3], 1u); continue; }
+    if (f & (F_SECONDARY | F_SUPPLEMENTARY)) { atomicAdd(&row[2], 1u); continue; }
+    const bool tp = true_pair(f);
+    atomicAdd(&row[tp ? 1 : 0], 1u);
+    if (f & F_DUPLICATE) {
+      if (!tp) atomicAdd(&row[4], 1u);
+      else {
+        const uint32_t mt = m.mate[i];
+        // counted once per pair, when the second of two duplicate-flagged mates is met (:186-192)
+        if (mt != EMPTY && mt < (uint32_t)i && (m.flag[mt] & F_DUPLICATE)) atomicAdd(&row[5], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < ncell; k += blockDim.x)
+    if (lds_ctr[k]) atomicAdd(&ctr[k], (unsigned long long)lds_ctr[k]);
+}
+
+// losing pairs per group
+__global__ __launch_bounds__(256) void k_opt_count(MxCols m, uint32_t *gsize) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.n) return;
+  const uint32_t rep = m.prep[i];
+  if (rep == EMPTY || m.pwinner[rep] == (uint32_t)i) return;
+  atomicAdd(&gsize[rep], 1u);
+}
+__global__ __launch_bounds__(256) void k_opt_plus_origin(uint64_t n, uint32_t *gsize) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && gsize[i] > 0) gsize[i] += 1;
+}
+
+struct Tile { long long t, x, y; };
+
+// computeTileInfo :50-71; *bad is set where internal.ParseInt would panic
+__device__ inline Tile tile_info(const uint8_t *__restrict__ q, uint32_t len, bool *bad) {
+  uint32_t st[8], en[8];
+  int ncol = 0;
+  uint32_t s = 0;
+  for (uint32_t i = 0; i <= len; i++) {
+    if (i == len || q[i] == ':') {
+      if (ncol < 8) { st[ncol] = s; en[ncol] = i; }
+      ncol++;
+      s = i + 1;
+    }
+  }
+  int a;
+  if (ncol == 7) a = 4;
+  else if (ncol == 5) a = 2;
+  else return Tile{-1, -1, -1};
+  long long v[3];
+  for (int k = 0; k < 3; k++) {
+    uint32_t b = st[a + k], e = en[a + k];
+    bool neg = false;
+    if (b < e && (q[b] == '+' || q[b] == '-')) { neg = q[b] == '-'; b++; }
+    if (b >= e) { *bad = true; return Tile{-1, -1, -1}; }
+    long long x = 0;
+    for (uint32_t i = b; i < e; i++) {
+      const uint32_t d = (uint32_t)q[i] - '0';
+      if (d > 9 || (e - b) > 18) { *bad = true; return Tile{-1, -1, -1}; }
+      x = x * 10 + d;
+    }
+    v[k] = neg ? -x : x;
+  }
+  return Tile{v[0], v[1], v[2]};
+}
+
+struct Member { long long t, x, y; uint32_t rg_rev; };  // rg_rev = rgid << 1 | reversed
+
+__device__ inline Member make_member(const MxCols &m, uint32_t read, uint32_t *err) {
+  bool bad = false;
+  const uint64_t o = m.qname_off[read];
+  Tile tl = tile_info(m.qname + o, (uint32_t)(m.qname_off[read + 1] - o), &bad);
+  if (bad) atomicOr(&err[2], 1u);
+  return Member{tl.t, tl.x, tl.y, ((uint32_t)m.rgid[read] << 1) | ((m.flag[read] & F_REVERSED) ? 1u : 0u)};
+}
+
+__global__ __launch_bounds__(256) void k_opt_fill(MxCols m, const uint32_t *__restrict__ goff, uint32_t *gfill, Member *__restrict__ members,
+                                                  uint32_t *err) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.n) return;
+  const uint32_t rep = m.prep[i];
+  if (rep == EMPTY) return;
+  const bool is_origin = m.pwinner[rep] == (uint32_t)i;
+  if (is_origin && goff[rep + 1] == goff[rep]) return;  // group without duplicates: count is 0
+  const uint32_t slot = goff[rep] + (is_origin ? 0u : 1u + atomicAdd(&gfill[rep], 1u));
+  members[slot] = make_member(m, listed_read(m, (uint32_t)i), err);
+}
+
+__device__ inline uint32_t uf_find(uint32_t *p, uint32_t x) {
+  uint32_t r = x;
+  while (p[r] != r) r = p[r];
+  while (p[x] != r) { uint32_t nx = p[x]; p[x] = r; x = nx; }
+  return r;
+}
+
+// one thread per group with duplicates
+__global__ __launch_bounds__(128) void k_opt_eval(MxCols m, const uint32_t *__restrict__ goff, const Member *__restrict__ members,
+                                                  uint32_t *__restrict__ parent, long long dist, unsigned long long *__restrict__ ctr,
+                                                  uint32_t *err) {
+  uint64_t rep = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (rep >= m.n) return;
+  const uint32_t b = goff[rep], e = goff[rep + 1];
+  const uint32_t cnt = e - b;
+  if (cnt < 2) return;
+  if (cnt > 300000u) { atomicOr(&err[2], 2u); return; }
+  const Member *g = members + b;
+  uint32_t *p = parent + b;
+  for (uint32_t k = 0; k < cnt; k++) p[k] = k;
+  uint32_t comps = cnt;
+  for (uint32_t a = 0; a < cnt; a++) {
+    const Member ma = g[a];
+    if (ma.t == -1) continue;
+    for (uint32_t c2 = a + 1; c2 < cnt; c2++) {
+      const Member mb = g[c2];
+      if (mb.rg_rev != ma.rg_rev || mb.t != ma.t) continue;  // same RG, same strand list, same tile
+      long long dx = ma.x - mb.x, dy = ma.y - mb.y;
+      if (dx < 0) dx = -dx;
+      if (dy < 0) dy = -dy;
+      if (dx <= dist && dy <= dist) {
+        const uint32_t ra = uf_find(p, a), rb = uf_find(p, c2);
+        if (ra != rb) { p[rb] = ra; comps--; }
+      }
+    }
+  }
+  const uint32_t optical = cnt - comps;  // sum over both strand lists of (n - components): lists never connect (rg_rev differs)
+  if (optical) {
+    const uint32_t owner = m.pwinner[rep];
+    uint32_t a1, a2;
+    order_ends(m, owner, m.mate[owner], a1, a2);
+    atomicAdd(&ctr[lib_row(m, a1) * ELP_NCTR + 6], (unsigned long long)optical);  // origin.aln1.LIBID() :381
+  }
+}
+
+static int metrics_impl(elp_ctx *c, int dist, int64_t *counters_host) {
+  const uint64_t n = c->n;
+  const int ncell = (c->n_lib + 1) * ELP_NCTR;
+  if (!c->marked) return set_error(c, ELP_ERR_ARG, "elp_dup_metrics: call elp_mark_duplicates first");
+  unsigned long long *ctr;
+  ELP_TRY(scratch(c, 0, (size_t)ncell + 8, &ctr));
+  hipStream_t st = c->stream;
+  ELP_HIP(c, hipMemsetAsync(ctr, 0, ncell * sizeof(unsigned long long), st));
+  if (n) {
+    MxCols m{n, c->refid.p, c->flag.p, c->rgid.p, c->rg_lib.p, c->upos.p, c->qname_off.p, c->qname.p, c->mate.p, c->pair_slot.p, c->pair_winner.p, c->n_lib};
+    const unsigned grid = blocks_for(n, 256);
+    ELP_LAUNCH(c, "mx_counters", k_dup_counters, dim3(std::min(grid, 2048u)), dim3(256), ncell * sizeof(unsigned int), m, ctr);
+    uint32_t *gs;
+    ELP_TRY(scratch(c, 1, 3 * n + 16, &gs));
+    uint32_t *gsize = gs, *goff = gs + n + 1, *gfill = gs + 2 * n + 2;
+    ELP_HIP(c, hipMemsetAsync(gsize, 0, (n + 1) * sizeof(uint32_t), st));
+    ELP_HIP(c, hipMemsetAsync(gfill, 0, n * sizeof(uint32_t), st));
+    ELP_LAUNCH(c, "mx_opt_count", k_opt_count, dim3(grid), dim3(256), 0, m, gsize);
+    ELP_LAUNCH(c, "mx_opt_plus_origin", k_opt_plus_origin, dim3(grid), dim3(256), 0, n, gsize);
+    uint32_t total = 0;
+    ELP_TRY(exclusive_scan_u32(c, gsize, goff, n + 1, &total));  // goff[n] = total
+    if (total) {
+      Member *members;
+      uint32_t *parent;
+      ELP_TRY(scratch(c, 2, (size_t)total + 4, &members));
+      ELP_TRY(scratch(c, 3, (size_t)total + 4, &parent));
+      ELP_LAUNCH(c, "mx_opt_fill", k_opt_fill, dim3(grid), dim3(256), 0, m, (const uint32_t *)goff, gfill, members, c->err_flag.p);
+      ELP_LAUNCH(c, "mx_opt_eval", k_opt_eval, dim3(blocks_for(n, 128)), dim3(128), 0, m, (const uint32_t *)goff, (const Member *)members, parent,
+                 (long long)dist, ctr, c->err_flag.p);
+    }
+  }
+  std::vector<unsigned long long> h(ncell);
+  ELP_HIP(c, hipMemcpyAsync(h.data(), ctr, ncell * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  uint32_t e[4];
+  ELP_TRY(fetch_err(c, e));
+  if (e[2]) {
+    ELP_HIP(c, hipMemsetAsync(c->err_flag.p + 2, 0, 4, st));
+    if (e[2] & 1u) return set_error(c, ELP_ERR_DATA, "QNAME tile/x/y field is not an integer (reference: internal.ParseInt panics, filters/mark-optical-duplicates.go:55-61)");
+    return set_error(c, ELP_ERR_UNSUPPORTED, "a duplicate set exceeds 300000 pairs (the reference truncates such lists, filters/mark-optical-duplicates.go:289-299)");
+  }
+  for (int l = 0; l <= c->n_lib; l++)
+    for (int k = 0; k < ELP_NCTR; k++) counters_host[l * ELP_NCTR + k] = (int64_t)h[l * ELP_NCTR + k];
+  for (int l = 0; l <= c->n_lib; l++) counters_host[l * ELP_NCTR + 1] /= 2;  // ReadPairsExamined counts reads, then halves (:504-506)
+  return 0;
+}
+
+}  // namespace elp
+
+extern "C" int elp_dup_metrics(elp_ctx *c, int optical_pixel_distance, int64_t *counters) {
+  if (!c || !counters) return ELP_ERR_ARG;
+  ELP_HIP(c, hipSetDevice(c->device));
+  return elp::metrics_impl(c, optical_pixel_distance, counters);
+}

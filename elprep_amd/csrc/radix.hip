@@ -1,0 +1,311 @@
+// radix.hip — device-wide exclusive scan and stable LSD radix sort of (key64, val32) pairs for gfx950.
+//
+// This is the mechanism behind the coordinate sort (By.ParallelStableSort, sam/sam-types.go:639-641; pargo
+// sort.StableSort in the reference) and the tie-break / grouping passes.  8-bit digits; digit positions whose
+// histogram has a single non-empty bin are skipped (the 64-bit coordinate key of a human genome has ~5 live bytes).
+//
+// Per live pass:  k_radix_tile_hist (LDS histogram per 4096-key tile)  ->  exclusive scan of the [256][tiles] count
+// matrix  ->  k_radix_scatter (wave64 ballot multisplit: stable local ranks, then direct scatter).
+// HBM traffic per key per pass: 8 (hist) + 12 (read) + 12 (write) = 32 B.
+#include "common.hpp"
+
+namespace elp {
+
+// ------------------------------------------------------------------ block scan helpers
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+// exclusive scan across a 256-thread block; returns exclusive prefix of `v`, total in *total (all threads)
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *total, uint32_t *lds /* >= 5 words */) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t inc = wave_incl_scan(v);
+  if (lane == 63) lds[w] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    uint32_t s = lds[i];
+    if (i < w) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = 256 * SCAN_ITEMS;
+
+__global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t *__restrict__ in, uint32_t *__restrict__ sums, uint64_t n) {
+  __shared__ uint32_t lds[8];
+  uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++)
+    if (base + i < n) s += in[base + i];
+  uint32_t tot;
+  (void)block_excl_scan_256(s, &tot, lds);
+  if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_scan_down(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                   const uint32_t *__restrict__ block_base, uint64_t n) {
+  __shared__ uint32_t lds[8];
+  uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+  uint32_t v[SCAN_ITEMS];
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) {
+    v[i] = (base + i < n) ? in[base + i] : 0u;
+    s += v[i];
+  }
+  uint32_t tot;
+  uint32_t ex = block_excl_scan_256(s, &tot, lds) + (block_base ? block_base[blockIdx.x] : 0u);
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) {
+    if (base + i < n) out[base + i] = ex;
+    ex += v[i];
+  }
+}
+
+// single-block scan for small inputs (n <= SCAN_TILE); also writes the total to out[n]
+__global__ __launch_bounds__(256) void k_scan_small(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t n) {
+  __shared__ uint32_t lds[8];
+  uint32_t base = threadIdx.x * SCAN_ITEMS;
+  uint32_t v[SCAN_ITEMS];
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) {
+    v[i] = (base + i < n) ? in[base + i] : 0u;
+    s += v[i];
+  }
+  uint32_t tot;
+  uint32_t ex = block_excl_scan_256(s, &tot, lds);
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) {
+    if (base + i < n) out[base + i] = ex;
+    ex += v[i];
+  }
+  if (threadIdx.x == 0) out[n] = tot;
+}
+
+static int scan_levels(elp_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n, uint32_t *total_dev) {
+  if (n == 0) {
+    if (total_dev) ELP_HIP(c, hipMemsetAsync(total_dev, 0, 4, c->stream));
+    return 0;
+  }
+  // sizes of each level
+  std::vector<uint64_t> cnt;  // cnt[0] = n, cnt[k+1] = blocks of level k
+  cnt.push_back(n);
+  while (true) {
+    uint64_t nb = (cnt.back() + SCAN_TILE - 1) / SCAN_TILE;
+    cnt.push_back(nb);
+    if (nb <= 1) break;
+  }
+  size_t need = 0;
+  for (size_t k = 1; k < cnt.size(); k++) need += cnt[k] + 4;
+  uint32_t *pool;
+  ELP_TRY(scratch(c, 7, need + 16, &pool));
+  std::vector<uint32_t *> sums(cnt.size(), nullptr);
+  size_t off = 0;
+  for (size_t k = 1; k < cnt.size(); k++) { sums[k] = pool + off; off += cnt[k] + 4; }
+  // up-sweep
+  const uint32_t *src = in;
+  for (size_t k = 0; k + 1 < cnt.size(); k++) {
+    ELP_LAUNCH(c, "scan_reduce", k_scan_reduce, dim3((unsigned)cnt[k + 1]), dim3(256), 0, src, sums[k + 1], cnt[k]);
+    src = sums[k + 1];
+  }
+  // top level has exactly one element = grand total
+  size_t top = cnt.size() - 1;
+  if (total_dev) ELP_HIP(c, hipMemcpyAsync(total_dev, sums[top], 4, hipMemcpyDeviceToDevice, c->stream));
+  ELP_HIP(c, hipMemsetAsync(sums[top], 0, 4, c->stream));
+  // down-sweep: level k's sums become exclusive prefixes using level k+1
+  for (size_t k = top - 1; k >= 1; k--) {
+    ELP_LAUNCH(c, "scan_down", k_scan_down, dim3((unsigned)cnt[k + 1]), dim3(256), 0, (const uint32_t *)sums[k], sums[k],
+               (const uint32_t *)sums[k + 1], cnt[k]);
+  }
+  ELP_LAUNCH(c, "scan_down", k_scan_down, dim3((unsigned)cnt[1]), dim3(256), 0, in, out, (const uint32_t *)sums[1], n);
+  return 0;
+}
+
+int exclusive_scan_u32(elp_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n, uint32_t *total_host) {
+  uint32_t *tot_dev = nullptr;
+  if (total_host) tot_dev = c->err_flag.p + 3;  // word 3 of the error block doubles as the scan-total mailbox
+  ELP_TRY(scan_levels(c, in, out, n, tot_dev));
+  if (total_host) {
+    ELP_HIP(c, hipMemcpyAsync(total_host, tot_dev, 4, hipMemcpyDeviceToHost, c->stream));
+    ELP_HIP(c, hipStreamSynchronize(c->stream));
+    ELP_HIP(c, hipMemsetAsync(tot_dev, 0, 4, c->stream));
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------ radix sort
+constexpr int RS_THREADS = 256;
+constexpr int RS_ITEMS = 16;
+constexpr int RS_TILE = RS_THREADS * RS_ITEMS;  // 4096 keys per workgroup
+constexpr int RS_WAVES = RS_THREADS / 64;
+
+// one sweep: histograms of all 8 digit positions (decides which passes are live)
+__global__ __launch_bounds__(256) void k_radix_hist_all(const uint64_t *__restrict__ keys, uint64_t n, unsigned long long *__restrict__ ghist /* [8][256] */) {
+  __shared__ uint32_t h[8][256];
+  for (int i = threadIdx.x; i < 8 * 256; i += 256) (&h[0][0])[i] = 0;
+  __syncthreads();
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+    uint64_t k = keys[i];
+    const unsigned long long act = __ballot(1);
+    const int first = __ffsll((long long)act) - 1;
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+      // constant digit positions (most of the high bytes) would be a 64-way same-address LDS conflict: aggregate per wave
+      uint32_t dg = (uint32_t)(k >> (8 * d)) & 0xFF;
+      uint32_t d0 = __shfl(dg, first, 64);
+      if (__all(dg == d0)) {
+        if ((int)(threadIdx.x & 63) == first) atomicAdd(&h[d][d0], (uint32_t)__popcll(act));
+      } else {
+        atomicAdd(&h[d][dg], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 8 * 256; i += 256) {
+    uint32_t v = (&h[0][0])[i];
+    if (v) atomicAdd(&ghist[i], (unsigned long long)v);
+  }
+}
+
+// per-tile digit histogram, written digit-major: counts[d * ntiles + tile]
+__global__ __launch_bounds__(RS_THREADS) void k_radix_tile_hist(const uint64_t *__restrict__ keys, uint64_t n, int shift,
+                                                                uint32_t *__restrict__ counts, uint32_t ntiles) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  uint64_t base = (uint64_t)blockIdx.x * RS_TILE;
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; r++) {
+    uint64_t i = base + (uint64_t)r * RS_THREADS + threadIdx.x;
+    bool valid = i < n;
+    uint32_t dg = valid ? (uint32_t)(keys[i] >> shift) & 0xFF : 0u;
+    const unsigned long long act = __ballot(valid);
+    if (act == 0) continue;
+    const int first = __ffsll((long long)act) - 1;
+    uint32_t d0 = __shfl(dg, first, 64);
+    if (__all(!valid || dg == d0)) {
+      if ((int)(threadIdx.x & 63) == first) atomicAdd(&h[d0], (uint32_t)__popcll(act));
+    } else if (valid) {
+      atomicAdd(&h[dg], 1u);
+    }
+  }
+  __syncthreads();
+  counts[(uint64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+
+// stable scatter.  Element order inside a tile: wave-major, then round, then lane (== index order, because each wave
+// owns a contiguous 1024-key sub-tile and reads it 64 keys per round).
+__global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                              uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint64_t n,
+                                                              int shift, const uint32_t *__restrict__ offsets /* scanned counts */,
+                                                              uint32_t ntiles) {
+  __shared__ uint32_t cnt[RS_WAVES][256];
+  __shared__ uint32_t gbase[256];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < RS_WAVES * 256; i += RS_THREADS) (&cnt[0][0])[i] = 0;
+  gbase[threadIdx.x] = offsets[(uint64_t)threadIdx.x * ntiles + blockIdx.x];
+  __syncthreads();
+  const uint64_t wbase = (uint64_t)blockIdx.x * RS_TILE + (uint64_t)w * (64 * RS_ITEMS);
+  uint64_t k[RS_ITEMS];
+  uint32_t rank[RS_ITEMS];
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; r++) {
+    uint64_t i = wbase + (uint64_t)r * 64 + lane;
+    bool valid = i < n;
+    k[r] = valid ? keys[i] : ~0ull;
+    uint32_t d = (uint32_t)(k[r] >> shift) & 0xFF;
+    // peers = lanes of this wave holding the same digit this round (invalid lanes form their own class via bit 8)
+    unsigned long long peers = __ballot(valid) ;
+    peers = valid ? peers : ~peers;
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      unsigned long long m = __ballot((d >> b) & 1);
+      peers &= ((d >> b) & 1) ? m : ~m;
+    }
+    uint32_t before = (uint32_t)__popcll(peers & lt_mask);
+    int leader = __ffsll((long long)peers) - 1;
+    uint32_t old = 0;
+    if (valid && lane == leader) {
+      old = cnt[w][d];
+      cnt[w][d] = old + (uint32_t)__popcll(peers);
+    }
+    old = __shfl(old, leader, 64);
+    rank[r] = old + before;
+  }
+  __syncthreads();
+  // exclusive prefix over waves for each digit; thread t owns digit t
+  {
+    uint32_t run = gbase[threadIdx.x];
+#pragma unroll
+    for (int i = 0; i < RS_WAVES; i++) {
+      uint32_t t = cnt[i][threadIdx.x];
+      cnt[i][threadIdx.x] = run;
+      run += t;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; r++) {
+    uint64_t i = wbase + (uint64_t)r * 64 + lane;
+    if (i < n) {
+      uint32_t d = (uint32_t)(k[r] >> shift) & 0xFF;
+      uint32_t dst = cnt[w][d] + rank[r];
+      keys_out[dst] = k[r];
+      vals_out[dst] = vals[i];
+    }
+  }
+}
+
+int radix_sort_pairs(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *keys_tmp, uint32_t *vals_tmp, uint64_t n, uint64_t **keys_out,
+                     uint32_t **vals_out) {
+  *keys_out = keys;
+  *vals_out = vals;
+  if (n < 2) return 0;
+  if (n >= 0xFFFFFFFFull) return set_error(c, ELP_ERR_UNSUPPORTED, "radix sort: more than 2^32-1 elements");
+  unsigned long long *ghist;
+  ELP_TRY(scratch(c, 6, 8 * 256, &ghist));
+  ELP_HIP(c, hipMemsetAsync(ghist, 0, 8 * 256 * sizeof(unsigned long long), c->stream));
+  unsigned hb = (unsigned)std::min<uint64_t>((n + 255) / 256, 2048);
+  ELP_LAUNCH(c, "radix_hist_all", k_radix_hist_all, dim3(hb), dim3(256), 0, (const uint64_t *)keys, n, ghist);
+  unsigned long long hh[8 * 256];
+  ELP_HIP(c, hipMemcpyAsync(hh, ghist, sizeof hh, hipMemcpyDeviceToHost, c->stream));
+  ELP_HIP(c, hipStreamSynchronize(c->stream));
+  uint32_t ntiles = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
+  uint32_t *counts;
+  ELP_TRY(scratch(c, 5, (size_t)256 * ntiles + 8, &counts));
+  uint64_t *ksrc = keys, *kdst = keys_tmp;
+  uint32_t *vsrc = vals, *vdst = vals_tmp;
+  for (int d = 0; d < 8; d++) {
+    bool live = true;
+    for (int b = 0; b < 256; b++)
+      if (hh[d * 256 + b] == n) { live = false; break; }
+    if (!live) continue;
+    int shift = 8 * d;
+    ELP_LAUNCH(c, "radix_tile_hist", k_radix_tile_hist, dim3(ntiles), dim3(RS_THREADS), 0, (const uint64_t *)ksrc, n, shift, counts, ntiles);
+    ELP_TRY(exclusive_scan_u32(c, counts, counts, (uint64_t)256 * ntiles, nullptr));
+    ELP_LAUNCH(c, "radix_scatter", k_radix_scatter, dim3(ntiles), dim3(RS_THREADS), 0, (const uint64_t *)ksrc, (const uint32_t *)vsrc, kdst,
+               vdst, n, shift, (const uint32_t *)counts, ntiles);
+    std::swap(ksrc, kdst);
+    std::swap(vsrc, vdst);
+  }
+  *keys_out = ksrc;
+  *vals_out = vsrc;
+  return 0;
+}
+
+}  // namespace elp

@@ -1,0 +1,303 @@
+// sort.hip — adapt (unclipped position, Phred-sum score, coordinate key) and the coordinate sort.
+//
+// Reference: sam.CoordinateLess + modFlag (sam/sam-types.go:408-473), By.ParallelStableSort (:639-641),
+// computeUnclippedPosition / computePhredScore (filters/mark-duplicates.go:57-110).
+//
+// Sort = (1) 64-bit primary key {refid (unmapped last), POS, strand} sorted by the LSD radix sort of radix.hip,
+//        (2) tie resolution inside runs of equal primary key with the comparator tail
+//            {QNAME bytes, modFlag, MAPQ, [NextREFID, PNEXT if paired], TLEN}, ties keep staging order:
+//            runs <= TIE_SMALL records: every record computes its rank in the run directly (all-pairs);
+//            larger runs (the unmapped block, pile-ups): LSD radix over the zero-padded comparator byte string,
+//            8 bytes per round, then one stable round on the run id.
+#include "common.hpp"
+
+namespace elp {
+
+constexpr int TIE_SMALL = 48;
+
+// ------------------------------------------------------------------ adapt
+__global__ __launch_bounds__(256) void k_adapt(uint64_t n, const int32_t *__restrict__ pos, const int32_t *__restrict__ refid,
+                                               const uint16_t *__restrict__ flag, const uint64_t *__restrict__ cigar_off,
+                                               const uint32_t *__restrict__ cigar, const uint64_t *__restrict__ qual_off,
+                                               const uint8_t *__restrict__ qual, int32_t *__restrict__ upos, int32_t *__restrict__ score,
+                                               uint64_t *__restrict__ key, uint32_t *__restrict__ err) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint16_t f = flag[i];
+  const int32_t p = pos[i];
+  const int32_t r = refid[i];
+  // CoordinateLess primary key: REFID ascending with negative last (:429-432), POS (:433-436), forward before reverse (:437-438)
+  const uint64_t ru = r < 0 ? 0x7FFFFFFFull : (uint64_t)(uint32_t)r;
+  key[i] = (ru << 33) | ((uint64_t)(uint32_t)p << 1) | ((f & F_REVERSED) ? 1ull : 0ull);
+  int32_t up = 0, sc = 0;
+  if ((f & (F_UNMAPPED | F_SECONDARY | F_SUPPLEMENTARY)) == 0) {  // mark-duplicates.go:427,436
+    const uint64_t c0 = cigar_off[i], c1 = cigar_off[i + 1];
+    up = p;
+    if (c1 > c0) {
+      if (f & F_REVERSED) {  // :90-100
+        int32_t clipped = 1;
+        up--;
+        for (uint64_t k = c1; k-- > c0;) {
+          const uint32_t c = cigar[k];
+          const uint32_t op = c & 0xF;
+          const int32_t isclip = (op == OP_S || op == OP_H) ? 1 : 0;
+          const int32_t isref = op_consumes_ref(op) ? 1 : 0;
+          clipped *= isclip;
+          up += (isref | clipped) * (int32_t)(c >> 4);
+        }
+      } else {  // :101-108
+        for (uint64_t k = c0; k < c1; k++) {
+          const uint32_t c = cigar[k];
+          const uint32_t op = c & 0xF;
+          if (!(op == OP_S || op == OP_H)) break;
+          up -= (int32_t)(c >> 4);
+        }
+      }
+    }
+    // computePhredScore :57-68: sum of qualities >= 15; any quality > 93 is an error
+    const uint64_t q0 = qual_off[i], q1 = qual_off[i + 1];
+    bool bad = false;
+    for (uint64_t k = q0; k < q1; k++) {
+      const uint32_t q = qual[k];
+      bad |= q > 93;
+      sc += (q >= 15 && q <= 93) ? (int32_t)q : 0;
+    }
+    if (bad) atomicOr(&err[0], 1u);
+  }
+  upos[i] = up;
+  score[i] = sc;
+}
+
+int ensure_adapted(elp_ctx *c) {
+  if (c->adapted) return 0;
+  ELP_HIP(c, hipSetDevice(c->device));
+  uint64_t n = c->n;
+  ELP_TRY(ensure(c, c->upos, n + 1));
+  ELP_TRY(ensure(c, c->score, n + 1));
+  ELP_TRY(ensure(c, c->key, n + 1));
+  if (n) {
+    ELP_LAUNCH(c, "adapt", k_adapt, dim3(blocks_for(n, 256)), dim3(256), 0, n, (const int32_t *)c->pos.p, (const int32_t *)c->refid.p,
+               (const uint16_t *)c->flag.p, (const uint64_t *)c->cigar_off.p, (const uint32_t *)c->cigar.p, (const uint64_t *)c->qual_off.p,
+               (const uint8_t *)c->qual.p, c->upos.p, c->score.p, c->key.p, c->err_flag.p);
+    uint32_t e[4];
+    ELP_TRY(fetch_err(c, e));
+    if (e[0] & 1u) {
+      ELP_HIP(c, hipMemsetAsync(c->err_flag.p, 0, 4, c->stream));
+      return set_error(c, ELP_ERR_DATA, "Invalid QUAL character (phred > 93) in a duplicate-marking candidate (reference: log.Panic, filters/mark-duplicates.go:64-66)");
+    }
+  }
+  c->adapted = true;
+  return 0;
+}
+
+// ------------------------------------------------------------------ tie-break
+struct TieCols {
+  const uint64_t *qname_off;
+  const uint8_t *qname;
+  const uint16_t *flag;
+  const uint8_t *mapq;
+  const int32_t *next_refid, *pnext, *tlen;
+};
+
+// comparator tail of CoordinateLess (:439-472) for two records with equal (refid, pos, strand)
+__device__ inline bool tie_less(const TieCols &t, uint32_t a, uint32_t b) {
+  const uint32_t la = (uint32_t)(t.qname_off[a + 1] - t.qname_off[a]), lb = (uint32_t)(t.qname_off[b + 1] - t.qname_off[b]);
+  if (la != 0 && lb != 0) {
+    int c = qname_cmp(t.qname, t.qname_off, a, b);
+    if (c < 0) return true;
+    if (c > 0) return false;
+  }
+  const uint16_t fa = mod_flag(t.flag[a]), fb = mod_flag(t.flag[b]);
+  if (fa < fb) return true;
+  if (fa > fb) return false;
+  const uint8_t ma = t.mapq[a], mb = t.mapq[b];
+  if (ma < mb) return true;
+  if (ma > mb) return false;
+  if ((t.flag[a] & F_MULTIPLE) && (t.flag[b] & F_MULTIPLE)) {
+    const int32_t na = t.next_refid[a], nb = t.next_refid[b];
+    if (na < nb) return true;
+    if (na > nb) return false;
+    const int32_t pa = t.pnext[a], pb = t.pnext[b];
+    if (pa < pb) return true;
+    if (pa > pb) return false;
+  }
+  return t.tlen[a] < t.tlen[b];
+}
+
+__global__ __launch_bounds__(256) void k_iota(uint32_t *v, uint64_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = (uint32_t)i;
+}
+
+// Resolve runs of <= TIE_SMALL equal keys; flag members of longer runs.
+__global__ __launch_bounds__(256) void k_tie_small(uint64_t n, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ perm_in,
+                                                   uint32_t *__restrict__ perm_out, uint32_t *__restrict__ large_flag, TieCols t) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t k = keys[i];
+  const uint32_t me = perm_in[i];
+  uint64_t s = i, e = i + 1;  // run [s, e)
+  bool large = false;
+  while (s > 0 && keys[s - 1] == k) {
+    s--;
+    if (i - s >= (uint64_t)TIE_SMALL) { large = true; break; }
+  }
+  if (!large) {
+    while (e < n && keys[e] == k) {
+      e++;
+      if (e - s > (uint64_t)TIE_SMALL) { large = true; break; }
+    }
+  }
+  if (large) {
+    large_flag[i] = 1;
+    perm_out[i] = me;
+    return;
+  }
+  large_flag[i] = 0;
+  if (e - s == 1) { perm_out[i] = me; return; }
+  uint32_t rank = 0;
+  for (uint64_t j = s; j < e; j++) {
+    if (j == i) continue;
+    const uint32_t other = perm_in[j];
+    // other precedes me iff other < me, or neither is less and other came first (radix sort is stable: j < i <=> earlier staging index)
+    if (tie_less(t, other, me)) rank++;
+    else if (j < i && !tie_less(t, me, other)) rank++;
+  }
+  perm_out[s + rank] = me;
+}
+
+__global__ __launch_bounds__(256) void k_large_fill(uint64_t n, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ perm,
+                                                    const uint32_t *__restrict__ large_flag, const uint32_t *__restrict__ idx,
+                                                    uint32_t *__restrict__ u_pos, uint32_t *__restrict__ u_read, uint32_t *__restrict__ u_head) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !large_flag[i]) return;
+  const uint32_t j = idx[i];
+  u_pos[j] = (uint32_t)i;
+  u_read[j] = perm[i];
+  u_head[j] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+
+// comparator byte string of record r: QNAME zero-padded to maxq, then modFlag(2, BE), MAPQ(1), NextREFID^msb(4, BE), PNEXT^msb(4, BE)
+// (both zero when unpaired; paired-ness is part of modFlag so it is constant within equal prefixes), TLEN^msb(4, BE).
+__device__ inline uint32_t material_byte(const TieCols &t, uint32_t r, uint32_t j, uint32_t maxq) {
+  if (j < maxq) {
+    const uint64_t o = t.qname_off[r];
+    const uint32_t l = (uint32_t)(t.qname_off[r + 1] - o);
+    return j < l ? t.qname[o + j] : 0u;
+  }
+  const uint32_t f = j - maxq;
+  const uint16_t fl = t.flag[r];
+  if (f < 2) { const uint16_t m = mod_flag(fl); return f == 0 ? (m >> 8) : (m & 0xFF); }
+  if (f == 2) return t.mapq[r];
+  if (f < 11) {
+    if (!(fl & F_MULTIPLE)) return 0u;
+    const uint32_t v = (f < 7 ? (uint32_t)t.next_refid[r] : (uint32_t)t.pnext[r]) ^ 0x80000000u;
+    const uint32_t b = (f < 7) ? (f - 3) : (f - 7);
+    return (v >> (8 * (3 - b))) & 0xFF;
+  }
+  if (f < 15) {
+    const uint32_t v = (uint32_t)t.tlen[r] ^ 0x80000000u;
+    return (v >> (8 * (3 - (f - 11)))) & 0xFF;
+  }
+  return 0u;
+}
+
+__global__ __launch_bounds__(256) void k_material_keys(uint32_t nu, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ u_read,
+                                                       uint32_t chunk, uint32_t maxq, uint64_t *__restrict__ keys, TieCols t) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nu) return;
+  const uint32_t r = u_read[vals[j]];
+  uint64_t k = 0;
+#pragma unroll
+  for (uint32_t b = 0; b < 8; b++) k = (k << 8) | material_byte(t, r, chunk * 8 + b, maxq);
+  keys[j] = k;
+}
+
+__global__ __launch_bounds__(256) void k_seg_keys(uint32_t nu, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ u_seg_incl,
+                                                  uint64_t *__restrict__ keys) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < nu) keys[j] = (uint64_t)u_seg_incl[vals[j]];
+}
+
+// inclusive "segment rank": exclusive scan of head flags + own flag
+__global__ __launch_bounds__(256) void k_add_own(uint32_t nu, const uint32_t *__restrict__ head, uint32_t *__restrict__ excl) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < nu) excl[j] += head[j];
+}
+
+__global__ __launch_bounds__(256) void k_large_scatter(uint32_t nu, const uint32_t *__restrict__ vals_sorted, const uint32_t *__restrict__ u_pos,
+                                                       const uint32_t *__restrict__ u_read, uint32_t *__restrict__ perm_out) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < nu) perm_out[u_pos[j]] = u_read[vals_sorted[j]];
+}
+
+static int sort_impl(elp_ctx *c) {
+  const uint64_t n = c->n;
+  ELP_TRY(ensure_adapted(c));
+  ELP_TRY(ensure(c, c->perm, n + 1));
+  if (n == 0) { c->sorted = true; return 0; }
+  uint64_t *kbuf;
+  uint32_t *vbuf, *flags;
+  ELP_TRY(scratch(c, 0, 2 * n + 8, &kbuf));
+  ELP_TRY(scratch(c, 1, 2 * n + 8, &vbuf));
+  ELP_TRY(scratch(c, 2, 2 * n + 8, &flags));
+  uint64_t *k0 = kbuf, *k1 = kbuf + n;
+  uint32_t *v0 = vbuf, *v1 = vbuf + n;
+  ELP_HIP(c, hipMemcpyAsync(k0, c->key.p, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
+  ELP_LAUNCH(c, "iota", k_iota, dim3(blocks_for(n, 256)), dim3(256), 0, v0, n);
+  uint64_t *ks;
+  uint32_t *vs;
+  ELP_TRY(radix_sort_pairs(c, k0, v0, k1, v1, n, &ks, &vs));
+  TieCols t{c->qname_off.p, c->qname.p, c->flag.p, c->mapq.p, c->next_refid.p, c->pnext.p, c->tlen.p};
+  uint32_t *large_flag = flags, *large_idx = flags + n;
+  ELP_LAUNCH(c, "tie_small", k_tie_small, dim3(blocks_for(n, 256)), dim3(256), 0, n, (const uint64_t *)ks, (const uint32_t *)vs, c->perm.p,
+             large_flag, t);
+  uint32_t nu = 0;
+  ELP_TRY(exclusive_scan_u32(c, large_flag, large_idx, n, &nu));
+  if (nu > 0) {
+    // compacted large-run members
+    uint32_t *u;
+    ELP_TRY(scratch(c, 3, (size_t)6 * nu + 64, &u));
+    uint32_t *u_pos = u, *u_read = u + nu, *u_head = u + 2 * (size_t)nu, *u_seg = u + 3 * (size_t)nu, *uv0 = u + 4 * (size_t)nu, *uv1 = u + 5 * (size_t)nu;
+    uint64_t *uk;
+    ELP_TRY(scratch(c, 4, (size_t)2 * nu + 16, &uk));
+    uint64_t *uk0 = uk, *uk1 = uk + nu;
+    ELP_LAUNCH(c, "large_fill", k_large_fill, dim3(blocks_for(n, 256)), dim3(256), 0, n, (const uint64_t *)ks, (const uint32_t *)vs,
+               (const uint32_t *)large_flag, (const uint32_t *)large_idx, u_pos, u_read, u_head);
+    ELP_TRY(exclusive_scan_u32(c, u_head, u_seg, nu, nullptr));
+    ELP_LAUNCH(c, "add_own", k_add_own, dim3(blocks_for(nu, 256)), dim3(256), 0, nu, (const uint32_t *)u_head, u_seg);
+    ELP_LAUNCH(c, "iota", k_iota, dim3(blocks_for(nu, 256)), dim3(256), 0, uv0, (uint64_t)nu);
+    const uint32_t maxq = c->max_qname_len;
+    const uint32_t m_bytes = maxq + 15;
+    const uint32_t chunks = (m_bytes + 7) / 8;
+    uint32_t *vcur = uv0, *vtmp = uv1;
+    for (int ch = (int)chunks - 1; ch >= 0; ch--) {
+      ELP_LAUNCH(c, "material_keys", k_material_keys, dim3(blocks_for(nu, 256)), dim3(256), 0, nu, (const uint32_t *)vcur, (const uint32_t *)u_read,
+                 (uint32_t)ch, maxq, uk0, t);
+      uint64_t *ko;
+      uint32_t *vo;
+      ELP_TRY(radix_sort_pairs(c, uk0, vcur, uk1, vtmp, nu, &ko, &vo));
+      if (vo != vcur) { vtmp = vcur; vcur = vo; }
+    }
+    ELP_LAUNCH(c, "seg_keys", k_seg_keys, dim3(blocks_for(nu, 256)), dim3(256), 0, nu, (const uint32_t *)vcur, (const uint32_t *)u_seg, uk0);
+    {
+      uint64_t *ko;
+      uint32_t *vo;
+      ELP_TRY(radix_sort_pairs(c, uk0, vcur, uk1, vtmp, nu, &ko, &vo));
+      if (vo != vcur) { vtmp = vcur; vcur = vo; }
+    }
+    ELP_LAUNCH(c, "large_scatter", k_large_scatter, dim3(blocks_for(nu, 256)), dim3(256), 0, nu, (const uint32_t *)vcur, (const uint32_t *)u_pos,
+               (const uint32_t *)u_read, c->perm.p);
+  }
+  c->sorted = true;
+  return 0;
+}
+
+}  // namespace elp
+
+extern "C" int elp_sort_coordinate(elp_ctx *c) {
+  if (!c) return ELP_ERR_ARG;
+  ELP_HIP(c, hipSetDevice(c->device));
+  c->sorted = false;
+  return elp::sort_impl(c);
+}

@@ -1,0 +1,244 @@
+"""Python face of the two C ABIs (harness for tests and bench.py; the product is the shared objects).
+
+`Engine` wraps one elp_ctx (one GPU).  Method names follow the reference operators they stand in for:
+
+    Engine.sort_coordinate   ~ sam.By(sam.CoordinateLess).ParallelStableSort        (sam/sam-types.go:639)
+    Engine.mark_duplicates   ~ filters.MarkDuplicates(alsoOpticals)                 (filters/mark-duplicates.go:406)
+    Engine.dup_metrics       ~ filters.MarkOpticalDuplicates(reads, pairs, dist)    (filters/mark-optical-duplicates.go:469)
+    Engine.recalibrate       ~ (*BaseRecalibrator).Recalibrate(reads, maxCycle)     (filters/bqsr.go:467)
+    BqsrTables.finalize      ~ (*BaseRecalibratorTables).FinalizeBQSRTables()       (filters/bqsr.go:677)
+    Engine.apply_bqsr        ~ (*BaseRecalibratorTables).ApplyBQSR(...)             (filters/bqsr.go:936)
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from .batch import Batch, Header
+
+NCTR, NQUAL, NCTX = 7, 94, 16
+
+
+class ElpError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[elp {code}] {msg}")
+        self.code = code
+
+
+def _vp(a: Optional[np.ndarray]):
+    return C.c_void_p(a.ctypes.data) if a is not None and a.size else C.c_void_p(0)
+
+
+class Engine:
+    """One GPU context holding the staged column store."""
+
+    def __init__(self, header: Header, device: int = 0):
+        self.L = _lib.hip()
+        h = C.c_void_p()
+        rc = self.L.elp_create(device, C.byref(h))
+        if rc != 0 or not h.value:
+            raise ElpError(rc, "elp_create failed: no usable gfx950 device (there is no CPU fallback)")
+        self.h = h
+        self.header = header
+        hs = header.as_struct()
+        self._check(self.L.elp_set_header(self.h, C.byref(hs)))
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.elp_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise ElpError(rc, (self.L.elp_last_error(self.h) or b"").decode())
+
+    # ---- staging
+    @property
+    def n(self) -> int:
+        return int(self.L.elp_num_records(self.h))
+
+    def reserve(self, n, qname_bytes, cigar_ops, seq_bytes, qual_bytes):
+        self._check(self.L.elp_reserve(self.h, n, qname_bytes, cigar_ops, seq_bytes, qual_bytes))
+
+    def stage(self, b: Batch):
+        s = b.as_struct()
+        self._check(self.L.elp_stage(self.h, C.byref(s)))
+        self._qual_bytes = getattr(self, "_qual_bytes", 0) + int(b.qual_off[-1] - b.qual_off[0])
+
+    def reset(self):
+        self._check(self.L.elp_reset(self.h))
+        self._qual_bytes = 0
+
+    def sync(self):
+        self._check(self.L.elp_sync(self.h))
+
+    # ---- operators
+    def sort_coordinate(self, fetch: bool = True) -> Optional[np.ndarray]:
+        self._check(self.L.elp_sort_coordinate(self.h))
+        return self.permutation() if fetch else None
+
+    def permutation(self) -> np.ndarray:
+        perm = np.empty(self.n, dtype=np.uint32)
+        self._check(self.L.elp_get_permutation(self.h, _vp(perm)))
+        return perm
+
+    def mark_duplicates(self, also_opticals: bool = False, fetch: bool = True) -> Optional[np.ndarray]:
+        self._check(self.L.elp_mark_duplicates(self.h, 1 if also_opticals else 0))
+        return self.flags() if fetch else None
+
+    def flags(self) -> np.ndarray:
+        f = np.empty(self.n, dtype=np.uint16)
+        self._check(self.L.elp_get_flags(self.h, _vp(f)))
+        return f
+
+    def adapted(self) -> Tuple[np.ndarray, np.ndarray]:
+        up = np.empty(self.n, dtype=np.int32)
+        sc = np.empty(self.n, dtype=np.int32)
+        self._check(self.L.elp_get_adapted(self.h, _vp(up), _vp(sc)))
+        return up, sc
+
+    def dup_metrics(self, pixel_dist: int = 100) -> np.ndarray:
+        ctr = np.zeros((self.header.n_lib + 1, NCTR), dtype=np.int64)
+        self._check(self.L.elp_dup_metrics(self.h, pixel_dist, _vp(ctr)))
+        return ctr
+
+    def set_reference(self, refid: int, bases: np.ndarray):
+        b = np.ascontiguousarray(bases, dtype=np.uint8)
+        self._check(self.L.elp_bqsr_set_reference(self.h, refid, _vp(b), b.size))
+
+    def set_known_sites(self, refid: int, intervals: np.ndarray):
+        iv = np.ascontiguousarray(np.asarray(intervals, dtype=np.int32).reshape(-1, 2))
+        self._check(self.L.elp_bqsr_set_known_sites(self.h, refid, _vp(iv), iv.shape[0]))
+
+    def recalibrate(self, max_cycle: int = 500):
+        ncyc = 2 * max_cycle + 1
+        nc = self.header.n_cov
+        qt = np.zeros((nc, NQUAL, 2), dtype=np.int64)
+        ct = np.zeros((nc, NQUAL, ncyc, 2), dtype=np.int64)
+        xt = np.zeros((nc, NQUAL, NCTX, 2), dtype=np.int64)
+        self._check(self.L.elp_bqsr_gather(self.h, max_cycle, _vp(qt), _vp(ct), _vp(xt)))
+        return qt, ct, xt
+
+    def apply_bqsr(self, lut: np.ndarray, cov_present: np.ndarray, max_cycle: int = 500, fetch: bool = True) -> Optional[np.ndarray]:
+        lut = np.ascontiguousarray(lut, dtype=np.uint8)
+        cp = np.ascontiguousarray(cov_present, dtype=np.uint8)
+        assert lut.size == self.header.n_cov * NQUAL * (2 * max_cycle + 1) * 17
+        self._check(self.L.elp_bqsr_apply(self.h, max_cycle, _vp(lut), _vp(cp)))
+        return self.qual() if fetch else None
+
+    def qual(self) -> np.ndarray:
+        q = np.empty(getattr(self, "_qual_bytes", 0), dtype=np.uint8)
+        self._check(self.L.elp_get_qual(self.h, _vp(q)))
+        return q
+
+    # ---- measurement
+    def profile_enable(self, on: bool = True):
+        self._check(self.L.elp_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._check(self.L.elp_profile_reset(self.h))
+
+    def profile(self) -> Dict[str, Tuple[int, float]]:
+        """-> {kernel name: (launches, total ms)} measured with HIP events on the ctx stream"""
+        out = {}
+        n = self.L.elp_profile_count(self.h)
+        if n < 0:
+            self._check(n)
+        for i in range(n):
+            name, cnt, ms = C.c_char_p(), C.c_uint64(), C.c_double()
+            self._check(self.L.elp_profile_get(self.h, i, C.byref(name), C.byref(cnt), C.byref(ms)))
+            out[name.value.decode()] = (int(cnt.value), float(ms.value))
+        return out
+
+
+class BqsrTables:
+    """BaseRecalibratorTables on the host (float64): merge, finalize, LUT, report."""
+
+    def __init__(self, qt: np.ndarray, ct: np.ndarray, xt: np.ndarray, max_cycle: int = 500):
+        self.H = _lib.host()
+        self.n_cov = int(qt.shape[0])
+        self.max_cycle = max_cycle
+        q, c, x = (np.ascontiguousarray(t, dtype=np.int64) for t in (qt, ct, xt))
+        self.t = C.c_void_p(self.H.elp_bqsr_tables_new(self.n_cov, max_cycle, _vp(q), _vp(c), _vp(x)))
+        if not self.t.value:
+            raise RuntimeError("elp_bqsr_tables_new failed")
+
+    def __del__(self):
+        try:
+            if self.t.value:
+                self.H.elp_bqsr_tables_free(self.t)
+        except Exception:
+            pass
+
+    def merge(self, qt, ct, xt):
+        q, c, x = (np.ascontiguousarray(t, dtype=np.int64) for t in (qt, ct, xt))
+        assert self.H.elp_bqsr_tables_merge(self.t, _vp(q), _vp(c), _vp(x)) == 0
+
+    def finalize(self):
+        assert self.H.elp_bqsr_tables_finalize(self.t) == 0
+        return self
+
+    def empirical(self):
+        ncyc = 2 * self.max_cycle + 1
+        q = np.zeros((self.n_cov, NQUAL), np.uint8)
+        c = np.zeros((self.n_cov, NQUAL, ncyc), np.uint8)
+        x = np.zeros((self.n_cov, NQUAL, NCTX), np.uint8)
+        assert self.H.elp_bqsr_tables_empirical(self.t, _vp(q), _vp(c), _vp(x)) == 0
+        return q, c, x
+
+    def combined(self):
+        rep = np.zeros(self.n_cov, np.float64)
+        emp = np.zeros(self.n_cov, np.uint8)
+        obs = np.zeros(self.n_cov, np.int64)
+        mism = np.zeros(self.n_cov, np.int64)
+        present = np.zeros(self.n_cov, np.uint8)
+        assert self.H.elp_bqsr_tables_combined(self.t, _vp(rep), _vp(emp), _vp(obs), _vp(mism), _vp(present)) == 0
+        return rep, emp, obs, mism, present
+
+    def quantize(self, levels: int):
+        counts = np.zeros(94, np.int64)
+        scores = np.zeros(94, np.uint8)
+        assert self.H.elp_bqsr_tables_quantize(self.t, levels, _vp(counts), _vp(scores)) == 0
+        return counts, scores
+
+    def build_lut(self, quantize_levels: int = 0, sqq: Sequence[int] = ()):
+        ncyc = 2 * self.max_cycle + 1
+        lut = np.zeros((self.n_cov, NQUAL, ncyc, 17), np.uint8)
+        present = np.zeros(self.n_cov, np.uint8)
+        s = np.asarray(list(sqq), dtype=np.uint8)
+        assert self.H.elp_bqsr_tables_build_lut(self.t, quantize_levels, _vp(s), s.size, _vp(lut), _vp(present)) == 0
+        return lut, present
+
+    def report(self, cov_names: Sequence[str], prefix: str = "GATK") -> str:
+        arr = (C.c_char_p * len(cov_names))(*[n.encode() for n in cov_names])
+        p = self.H.elp_bqsr_tables_report(self.t, C.cast(arr, C.c_void_p), prefix.encode())
+        s = C.string_at(p).decode()
+        self.H.elp_host_free(C.c_void_p(p))
+        return s
+
+
+def dup_derived(ctr_row: np.ndarray) -> Tuple[float, int]:
+    H = _lib.host()
+    row = np.ascontiguousarray(ctr_row, dtype=np.int64)
+    pct, ls = C.c_double(), C.c_int64()
+    assert H.elp_dup_derived(_vp(row), C.byref(pct), C.byref(ls)) == 0
+    return pct.value, ls.value
+
+
+def dup_metrics_report(counters: np.ndarray, lib_names: Sequence[str], command_line: str = "") -> str:
+    H = _lib.host()
+    ctr = np.ascontiguousarray(counters, dtype=np.int64)
+    arr = (C.c_char_p * max(len(lib_names), 1))(*[n.encode() for n in lib_names])
+    p = H.elp_dup_metrics_report(_vp(ctr), len(lib_names), C.cast(arr, C.c_void_p), command_line.encode())
+    s = C.string_at(p).decode()
+    H.elp_host_free(C.c_void_p(p))
+    return s

@@ -1,0 +1,526 @@
+// bqsr_tables.cpp — host-side (float64) BQSR table finalisation, LUT tabulation and report text.
+//
+// C++ mirror of the Go host code that stays on the CPU in the drop-in design:
+//   FinalizeBQSRTables / calculateEmpiricalQuality / calculateBayesianEstimateOfEmpiricalQuality (filters/bqsr.go:553-694),
+//   initializeCombinedBQSRTable (:655-674), quantisation (:746-899), estimateHierarchicalBayesianQuality (:901-919),
+//   the quality mapping of ApplyBQSR (:959-999), PrintBQSRTables (filters/print-bqsr.go:49-298).
+//
+// Go's math.Log10 and math.Pow are restated structurally (log2(x)*Ln2/Ln10; frexp/ldexp exponentiation) on top of libm;
+// math.Lgamma is lgamma_r (same Sun algorithm).  Where the reference iterates a Go map (initializeCombinedBQSRTable) the
+// (rg, qual) entries are visited in ascending qual.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/elprep_host.h"
+
+namespace {
+
+constexpr int NQ = 94, NX = 16;
+
+inline double go_log2(double x) {
+  int e;
+  double frac = std::frexp(x, &e);
+  if (frac == 0.5) return double(e - 1);
+  return std::log(frac) * 1.44269504088896340735992468100189213742664595415298593413 + double(e);
+}
+inline double go_log10(double x) { return go_log2(x) * 0.30102999566398119521373889472449302676818988146210854131; }
+
+double go_pow(double x, double y) {  // finite x > 0
+  if (y == 0 || x == 1) return 1;
+  if (y == 1) return x;
+  if (y == 0.5) return std::sqrt(x);
+  if (y == -0.5) return 1 / std::sqrt(x);
+  double yi;
+  double yf = std::modf(std::fabs(y), &yi);
+  double a1 = 1.0;
+  int ae = 0;
+  if (yf != 0) {
+    if (yf > 0.5) { yf--; yi++; }
+    a1 = std::exp(yf * std::log(x));
+  }
+  int xe;
+  double x1 = std::frexp(x, &xe);
+  for (long long i = (long long)yi; i != 0; i >>= 1) {
+    if (xe < -(1 << 12) || (1 << 12) < xe) { ae += xe; break; }
+    if (i & 1) { a1 *= x1; ae += xe; }
+    x1 *= x1;
+    xe <<= 1;
+    if (x1 < .5) { x1 += x1; xe--; }
+  }
+  if (y < 0) { a1 = 1 / a1; ae = -ae; }
+  return std::ldexp(a1, ae);
+}
+
+inline double q_to_err(double phred) { return go_pow(10, phred / -10); }
+inline double q_to_prob(double phred) { return 1 - go_pow(10, phred / -10); }
+
+const double kPrior[21] = {-0.045757490560675115, -0.9143464543671788, -3.5201133457866898, -7.863058164819208, -13.943180911464733,
+                           -21.760481585723266,   -31.314960187594806, -42.606616717079355, -55.63545117417691, -70.40146355888747,
+                           -86.90465387121104,    -105.14502211114761, -125.1225682786972,  -146.83729237385978, -170.2891943966354,
+                           -195.47827434702398,   -222.4045322250256,  -251.06796803064023, -281.46858176386786, -313.60637342472336,
+                           -1.7976931348623157e308};
+
+inline double log10_gamma(long long n) {
+  int sg;
+  return lgamma_r(double(n), &sg) * 0.43429448190325182765112891891660508229439700580366656611445378316586464920887077;
+}
+
+// calculateBayesianEstimateOfEmpiricalQuality, bqsr.go:623-642
+uint8_t bayes(long long obs, long long mism, double prior) {
+  const long long kMax = 2147483647LL - 1;
+  if (obs > kMax) {
+    mism = (long long)std::round(double(mism) * (double(kMax) / double(obs)));
+    obs = kMax;
+  }
+  double best = -DBL_MAX;
+  uint8_t arg = 0;
+  for (int i = 0; i <= 60; i++) {
+    const double fi = double(i);
+    int d = int(fi - prior);
+    if (d < 0) d = -d;
+    if (d > 20) d = 20;
+    double like;
+    if (obs == 0) {
+      like = 0.0;
+    } else {
+      const double log10p = fi / -10.0;
+      if (log10p == 0.0) {
+        like = -DBL_MAX;
+      } else {
+        const double log10minp = go_log10(1.0 - go_pow(10, log10p));
+        const double c = log10_gamma(obs + 1) - log10_gamma(mism + 1) - log10_gamma(obs - mism + 1);
+        like = c + log10p * double(mism) + log10minp * double(obs - mism);
+      }
+    }
+    const double post = kPrior[d] + like;
+    if (best < post) { best = post; arg = uint8_t(i); }
+  }
+  return arg;
+}
+inline uint8_t empirical(long long obs, long long mism, double prior) {  // bqsr.go:644-649
+  const uint8_t q = bayes(obs + 2, mism + 1, prior);
+  return q < 93 ? q : 93;
+}
+
+struct Interval { int next; double rate; long long nobs, leaf, nerr; };
+inline double err_rate(long long nobs, long long nerr) { return nobs == 0 ? 0.0 : double(nerr + 1) / double(nobs + 1); }
+
+}  // namespace
+
+struct elp_bqsr_tables {
+  int n_cov, max_cycle, ncyc;
+  std::vector<long long> q, c, x;           // {obs, mism} pairs
+  std::vector<uint8_t> qe, ce, xe;          // EmpiricalQuality, 255 = absent
+  std::vector<double> rep;                  // combined reportedQuality per cov
+  std::vector<uint8_t> cemp, present;
+  std::vector<long long> cobs, cmism;
+  bool finalized = false;
+
+  size_t qi(int cov, int qual) const { return size_t(cov) * NQ + qual; }
+};
+
+extern "C" {
+
+elp_bqsr_tables *elp_bqsr_tables_new(int n_cov, int max_cycle, const int64_t *qt, const int64_t *ct, const int64_t *xt) {
+  if (n_cov < 0 || max_cycle < 1) return nullptr;
+  auto *t = new elp_bqsr_tables();
+  t->n_cov = n_cov; t->max_cycle = max_cycle; t->ncyc = 2 * max_cycle + 1;
+  const size_t nq = size_t(n_cov) * NQ;
+  t->q.assign(nq * 2, 0); t->c.assign(nq * t->ncyc * 2, 0); t->x.assign(nq * NX * 2, 0);
+  if (qt) for (size_t i = 0; i < t->q.size(); i++) t->q[i] = qt[i];
+  if (ct) for (size_t i = 0; i < t->c.size(); i++) t->c[i] = ct[i];
+  if (xt) for (size_t i = 0; i < t->x.size(); i++) t->x[i] = xt[i];
+  return t;
+}
+void elp_bqsr_tables_free(elp_bqsr_tables *t) { delete t; }
+
+int elp_bqsr_tables_merge(elp_bqsr_tables *t, const int64_t *qt, const int64_t *ct, const int64_t *xt) {
+  if (!t || !qt || !ct || !xt) return -1;
+  for (size_t i = 0; i < t->q.size(); i++) t->q[i] += qt[i];
+  for (size_t i = 0; i < t->c.size(); i++) t->c[i] += ct[i];
+  for (size_t i = 0; i < t->x.size(); i++) t->x[i] += xt[i];
+  t->finalized = false;
+  return 0;
+}
+
+int elp_bqsr_tables_finalize(elp_bqsr_tables *t) {
+  if (!t) return -1;
+  const size_t nq = size_t(t->n_cov) * NQ;
+  t->qe.assign(nq, 255); t->ce.assign(nq * t->ncyc, 255); t->xe.assign(nq * NX, 255);
+  for (size_t i = 0; i < nq; i++)
+    if (t->q[2 * i] > 0) t->qe[i] = empirical(t->q[2 * i], t->q[2 * i + 1], double(i % NQ));
+  for (size_t i = 0; i < nq * t->ncyc; i++)
+    if (t->c[2 * i] > 0) t->ce[i] = empirical(t->c[2 * i], t->c[2 * i + 1], double((i / t->ncyc) % NQ));
+  for (size_t i = 0; i < nq * NX; i++)
+    if (t->x[2 * i] > 0) t->xe[i] = empirical(t->x[2 * i], t->x[2 * i + 1], double((i / NX) % NQ));
+  t->rep.assign(t->n_cov, 0.0); t->cemp.assign(t->n_cov, 0); t->present.assign(t->n_cov, 0);
+  t->cobs.assign(t->n_cov, 0); t->cmism.assign(t->n_cov, 0);
+  for (int cv = 0; cv < t->n_cov; cv++) {
+    for (int ql = 0; ql < NQ; ql++) {
+      const long long obs = t->q[2 * t->qi(cv, ql)], mism = t->q[2 * t->qi(cv, ql) + 1];
+      if (obs <= 0) continue;
+      if (t->present[cv]) {
+        const double sum = double(t->cobs[cv]) * q_to_err(t->rep[cv]) + double(obs) * q_to_err(double(ql));
+        t->cobs[cv] += obs; t->cmism[cv] += mism;
+        t->rep[cv] = -10 * go_log10(sum / double(t->cobs[cv]));
+      } else {
+        t->present[cv] = 1; t->rep[cv] = double(ql); t->cobs[cv] = obs; t->cmism[cv] = mism;
+      }
+    }
+    if (t->present[cv]) t->cemp[cv] = empirical(t->cobs[cv], t->cmism[cv], t->rep[cv]);
+  }
+  t->finalized = true;
+  return 0;
+}
+
+int elp_bqsr_tables_empirical(const elp_bqsr_tables *t, uint8_t *qe, uint8_t *ce, uint8_t *xe) {
+  if (!t || !t->finalized) return -1;
+  std::memcpy(qe, t->qe.data(), t->qe.size()); std::memcpy(ce, t->ce.data(), t->ce.size()); std::memcpy(xe, t->xe.data(), t->xe.size());
+  return 0;
+}
+int elp_bqsr_tables_combined(const elp_bqsr_tables *t, double *rep, uint8_t *emp, int64_t *obs, int64_t *mism, uint8_t *present) {
+  if (!t || !t->finalized) return -1;
+  for (int c = 0; c < t->n_cov; c++) { rep[c] = t->rep[c]; emp[c] = t->cemp[c]; obs[c] = t->cobs[c]; mism[c] = t->cmism[c]; present[c] = t->present[c]; }
+  return 0;
+}
+
+int elp_bqsr_tables_quantize(const elp_bqsr_tables *t, int levels, int64_t *counts, uint8_t *scores) {
+  if (!t || !t->finalized) return -1;
+  for (int i = 0; i < 94; i++) { counts[i] = 0; scores[i] = 0; }
+  if (levels == 0) { for (int i = 0; i < 94; i++) scores[i] = uint8_t(i); return 0; }
+  for (size_t i = 0; i < t->qe.size(); i++)
+    if (t->q[2 * i] > 0) counts[t->qe[i]] += t->q[2 * i];
+  Interval iv[94];
+  for (int i = 0; i < 94; i++) {
+    const double er = q_to_err(double(i));
+    iv[i] = Interval{i + 1 == 94 ? -1 : i + 1, er, counts[i], counts[i], (long long)(double(counts[i]) * er)};
+  }
+  auto leaf_penalty = [&](int k, double global) { return k <= 6 ? 0.0 : std::fabs(go_log10(iv[k].rate) - go_log10(global)) * double(iv[k].leaf); };
+  auto merge_penalty = [&](int i, int j) {
+    const double rate = err_rate(iv[i].nobs + iv[j].nobs, iv[i].nerr + iv[j].nerr);
+    if (rate == 0) return 0.0;
+    double si = 0, sj = 0;
+    for (int k = i; k < j; k++) si += leaf_penalty(k, rate);
+    const int kend = iv[j].next >= 0 ? iv[j].next : 94;
+    for (int k = j; k < kend; k++) sj += leaf_penalty(k, rate);
+    return si + sj;
+  };
+  int n = 94;
+  while (n > levels) {
+    int i = 0, j = iv[0].next;
+    if (j < 0) break;
+    int min_i = 0;
+    double pen = merge_penalty(i, j);
+    for (;;) {
+      i = j; j = iv[i].next;
+      if (j < 0) break;
+      const double p = merge_penalty(i, j);
+      if (p < pen) { min_i = i; pen = p; }
+    }
+    Interval &a = iv[min_i], &b = iv[a.next];
+    const long long nobs = a.nobs + b.nobs, nerr = a.nerr + b.nerr;
+    a.next = b.next; a.nobs = nobs; a.nerr = nerr;
+    n--;
+  }
+  for (int i = 0; i >= 0;) {
+    const bool leaf = iv[i].next < 0 ? (i == 93) : (iv[i].next == i + 1);
+    uint8_t qs;
+    if (leaf) qs = uint8_t(i);
+    else {
+      const double prob = err_rate(iv[i].nobs, iv[i].nerr);
+      int qv = 93;
+      if (prob != 0.0) { qv = int(std::round(-10 * go_log10(prob))); if (qv > 93) qv = 93; if (qv < 1) qv = 1; }
+      qs = uint8_t(qv);
+    }
+    const int kend = iv[i].next >= 0 ? iv[i].next : 94;
+    for (int k = i; k < kend; k++) scores[k] = qs;
+    i = iv[i].next;
+  }
+  return 0;
+}
+
+static void static_quantized(const uint8_t *quals_in, int n, uint8_t *out) {  // bqsr.go:710-744
+  std::vector<uint8_t> quals(quals_in, quals_in + n);
+  std::memset(out, 0, 254);
+  for (int i = 0; i < 6; i++) out[i] = uint8_t(i);
+  if (n == 1) { for (int i = 6; i < 254; i++) out[i] = quals[0]; return; }
+  std::sort(quals.begin(), quals.end());
+  uint8_t prev_q = 6;
+  double prev_p = q_to_prob(double(prev_q));
+  for (uint8_t next_q : quals) {
+    for (uint8_t i = prev_q; i < next_q; i++) {  // the reference advances prevProb/prevQual inside this loop (:727-737)
+      const double next_p = q_to_prob(double(next_q)), ip = q_to_prob(double(i));
+      out[i] = (ip - prev_p > next_p - ip) ? next_q : prev_q;
+      prev_p = next_p;
+      prev_q = next_q;
+    }
+  }
+  for (int i = prev_q; i < 254; i++) out[i] = prev_q;
+}
+
+// The reference memoises applyKey{rg, qual, cycle, context} -> uint8 (bqsr.go:970-999).  estimateHierarchicalBayesianQuality
+// (:901-919) factorises: deltaGlobal depends on rg; deltaReported and the conditional prior on (rg, qual); the cycle term on
+// (rg, qual, cycle); the context term on (rg, qual, context).  Tabulating the three factors and combining them with the very
+// same float64 operations in the same order (conditionalPrior + (cycleTerm + contextTerm)) reproduces every memo value.
+int elp_bqsr_tables_build_lut(const elp_bqsr_tables *t, int quantize_levels, const uint8_t *sqq, int n_sqq, uint8_t *lut, uint8_t *cov_present) {
+  if (!t || !t->finalized || !lut || !cov_present) return -1;
+  int64_t counts[94];
+  uint8_t quantized[94], stat[254];
+  elp_bqsr_tables_quantize(t, quantize_levels, counts, quantized);
+  if (n_sqq > 0) static_quantized(sqq, n_sqq, stat);
+  const int ncyc = t->ncyc;
+  std::vector<double> dcyc(ncyc), dctx(17);
+  for (int cv = 0; cv < t->n_cov; cv++) {
+    cov_present[cv] = t->present[cv];
+    uint8_t *lc = lut + size_t(cv) * NQ * ncyc * 17;
+    if (!t->present[cv]) { std::memset(lc, 0, size_t(NQ) * ncyc * 17); continue; }
+    const double epsilon = t->rep[cv];  // globalQualityScorePrior = -1 (:959-964)
+    const double d_global = double(empirical(t->cobs[cv], t->cmism[cv], epsilon)) - epsilon;
+    for (int ql = 0; ql < NQ; ql++) {
+      const size_t qi = t->qi(cv, ql);
+      double d_reported = 0;
+      if (t->q[2 * qi] > 0) d_reported = double(empirical(t->q[2 * qi], t->q[2 * qi + 1], d_global + epsilon)) - d_global - epsilon;
+      const double cond = d_reported + d_global + epsilon;
+      for (int cy = 0; cy < ncyc; cy++) {
+        const size_t ci = qi * ncyc + cy;
+        dcyc[cy] = t->c[2 * ci] > 0 ? double(empirical(t->c[2 * ci], t->c[2 * ci + 1], cond)) - cond : 0.0;
+      }
+      for (int cx = 0; cx < 16; cx++) {
+        const size_t xi = qi * NX + cx;
+        dctx[cx] = t->x[2 * xi] > 0 ? double(empirical(t->x[2 * xi], t->x[2 * xi + 1], cond)) - cond : 0.0;
+      }
+      uint8_t *lq = lc + size_t(ql) * ncyc * 17;
+      for (int cy = 0; cy < ncyc; cy++) {
+        const bool has_c = t->c[2 * (qi * ncyc + cy)] > 0;
+        for (int cx = 0; cx < 17; cx++) {
+          const bool has_x = cx < 16 && t->x[2 * (qi * NX + cx)] > 0;
+          double d_cov = 0;
+          if (has_c) d_cov = dcyc[cy];
+          if (has_x) d_cov += dctx[cx];
+          const double est = cond + d_cov;
+          int r = int(std::round(est));
+          if (r > 93) r = 93;
+          if (r < 1) r = 1;
+          uint8_t o = quantized[r];
+          if (n_sqq > 0) o = stat[o];
+          lq[size_t(cy) * 17 + cx] = o;
+        }
+      }
+    }
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------- report text (filters/print-bqsr.go)
+namespace {
+struct Sb {
+  std::string s;
+  void f(const char *fmt, ...) __attribute__((format(printf, 2, 3))) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    int w = vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (w >= (int)sizeof buf) {
+      std::vector<char> big(w + 1);
+      va_start(ap, fmt);
+      vsnprintf(big.data(), big.size(), fmt, ap);
+      va_end(ap);
+      s.append(big.data(), w);
+    } else {
+      s.append(buf, w);
+    }
+  }
+};
+inline int ilen(long long v) { char b[32]; return snprintf(b, sizeof b, "%lld", v); }
+struct Row2 { std::string rg; int qual; bool cycle; std::string text; long long obs, mism; int emp; };
+}  // namespace
+
+char *elp_bqsr_tables_report(const elp_bqsr_tables *t, const char *const *names, const char *prefix) {
+  if (!t || !t->finalized) return nullptr;
+  Sb o;
+  o.f("#:%sReport.v1.1:5\n", prefix);
+  o.f("#:%sTable:2:17:%%s:%%s:;\n", prefix);
+  o.f("#:%sTable:Arguments:Recalibration argument collection values used in this run\n", prefix);
+  static const char *kArgs[][2] = {{"Argument", "Value"}, {"binary_tag_name", "null"},
+      {"covariate", "ReadGroupCovariate,QualityScoreCovariate,ContextCovariate,CycleCovariate"}, {"default_platform", "null"},
+      {"deletions_default_quality", "45"}, {"force_platform", "null"}, {"indels_context_size", "3"}, {"insertions_default_quality", "45"},
+      {"low_quality_tail", "2"}, {"maximum_cycle_value", "500"}, {"mismatches_context_size", "2"}, {"mismatches_default_quality", "-1"},
+      {"no_standard_covs", "false"}, {"quantizing_levels", "16"}, {"recalibration_report", "null"}, {"run_without_dbsnp", "false"},
+      {"solid_nocall_strategy", "THROW_EXCEPTION"}, {"solid_recal_mode", "SET_Q_ZERO"}};
+  for (auto &a : kArgs) o.f("%-26s  %-72s\n", a[0], a[1]);  // fixed-width literal lines of print-bqsr.go:275-292
+  o.f("\n");
+  {  // printQuantizationTable :49-76
+    int64_t counts[94]; uint8_t scores[94];
+    elp_bqsr_tables_quantize(t, 16, counts, scores);
+    o.f("#:%sTable:3:%d:%%d:%%d:%%d:;\n", prefix, 94);
+    o.f("#:%sTable:Quantized:Quality quantization map\n", prefix);
+    int w1 = 12, w2 = 5, w3 = 14;
+    for (int i = 0; i < 94; i++) { w1 = std::max(w1, ilen(i)); w2 = std::max(w2, ilen(counts[i])); w3 = std::max(w3, ilen(scores[i])); }
+    o.f("%-*s  %-*s  %-*s\n", w1, "QualityScore", w2, "Count", w3, "QuantizedScore");
+    for (int i = 0; i < 94; i++) o.f("%*d  %*lld  %*d\n", w1, i, w2, (long long)counts[i], w3, scores[i]);
+    o.f("\n");
+  }
+  std::vector<int> order;
+  for (int c = 0; c < t->n_cov; c++) order.push_back(c);
+  std::sort(order.begin(), order.end(), [&](int a, int b) { return std::strcmp(names[a], names[b]) < 0; });
+  {  // printCombinedBQSRTable :78-124
+    int n = 0;
+    for (int c = 0; c < t->n_cov; c++) n += t->present[c];
+    o.f("#:%sTable:6:%d:%%s:%%s:%%.4f:%%.4f:%%d:%%.2f:;\n", prefix, n);
+    o.f("#:%sTable:RecalTable0:\n", prefix);
+    int wrg = 9, wev = 9, wemp = 16, west = 18, wobs = 12, werr = 6;
+    char b[64];
+    for (int c = 0; c < t->n_cov; c++) {
+      if (!t->present[c]) continue;
+      wrg = std::max(wrg, (int)std::strlen(names[c])); wemp = std::max(wemp, ilen(t->cemp[c]) + 5);
+      west = std::max(west, snprintf(b, sizeof b, "%.4f", t->rep[c])); wobs = std::max(wobs, ilen(t->cobs[c])); werr = std::max(werr, ilen(t->cmism[c]) + 3);
+    }
+    o.f("%-*s  %-*s  %-*s  %-*s  %-*s  %-*s\n", wrg, "ReadGroup", wev, "EventType", wemp, "EmpiricalQuality", west, "EstimatedQReported", wobs,
+        "Observations", werr, "Errors");
+    for (int c : order) {
+      if (!t->present[c]) continue;
+      o.f("%-*s  %-*s  %*d.0000  %*.4f  %*lld  %*lld.00\n", wrg, names[c], wev, "M", wemp - 5, t->cemp[c], west, t->rep[c], wobs, t->cobs[c], werr - 3,
+          t->cmism[c]);
+    }
+    o.f("\n");
+  }
+  {  // printBQSRTable :126-178
+    int n = 0;
+    for (size_t i = 0; i < t->qe.size(); i++) n += t->q[2 * i] > 0;
+    o.f("#:%sTable:6:%d:%%s:%%d:%%s:%%.4f:%%d:%%.2f:;\n", prefix, n);
+    o.f("#:%sTable:RecalTable1:\n", prefix);
+    int wrg = 9, wq = 12, wev = 9, wemp = 16, wobs = 12, werr = 6;
+    for (int c = 0; c < t->n_cov; c++)
+      for (int q = 0; q < NQ; q++) {
+        const size_t i = t->qi(c, q);
+        if (t->q[2 * i] <= 0) continue;
+        wrg = std::max(wrg, (int)std::strlen(names[c])); wq = std::max(wq, ilen(q)); wemp = std::max(wemp, ilen(t->qe[i]) + 5);
+        wobs = std::max(wobs, ilen(t->q[2 * i])); werr = std::max(werr, ilen(t->q[2 * i + 1]) + 3);
+      }
+    o.f("%-*s  %-*s  %-*s  %-*s  %-*s  %-*s\n", wrg, "ReadGroup", wq, "QualityScore", wev, "EventType", wemp, "EmpiricalQuality", wobs, "Observations",
+        werr, "Errors");
+    for (int c : order)
+      for (int q = 0; q < NQ; q++) {
+        const size_t i = t->qi(c, q);
+        if (t->q[2 * i] <= 0) continue;
+        o.f("%-*s  %*d  %-*s  %*d.0000  %*lld  %*lld.00\n", wrg, names[c], wq, q, wev, "M", wemp - 5, t->qe[i], wobs, t->q[2 * i], werr - 3, t->q[2 * i + 1]);
+      }
+    o.f("\n");
+  }
+  {  // printOtherCovariateTable :186-266
+    std::vector<Row2> rows;
+    static const char kB[] = "ACGT";
+    for (int c = 0; c < t->n_cov; c++)
+      for (int q = 0; q < NQ; q++) {
+        const size_t qi = t->qi(c, q);
+        for (int cy = 0; cy < t->ncyc; cy++) {
+          const size_t i = qi * t->ncyc + cy;
+          if (t->c[2 * i] > 0) rows.push_back(Row2{names[c], q, true, std::to_string(cy - t->max_cycle), t->c[2 * i], t->c[2 * i + 1], t->ce[i]});
+        }
+        for (int cx = 0; cx < NX; cx++) {
+          const size_t i = qi * NX + cx;
+          if (t->x[2 * i] > 0) rows.push_back(Row2{names[c], q, false, std::string{kB[cx & 3], kB[(cx >> 2) & 3]}, t->x[2 * i], t->x[2 * i + 1], t->xe[i]});
+        }
+      }
+    int wrg = 9, wq = 12, wcv = 14, wcn = 13, wev = 9, wemp = 16, wobs = 12, werr = 6;
+    for (auto &r : rows) {
+      wrg = std::max(wrg, (int)r.rg.size()); wq = std::max(wq, ilen(r.qual)); wcv = std::max(wcv, (int)r.text.size());
+      wemp = std::max(wemp, ilen(r.emp) + 5); wobs = std::max(wobs, ilen(r.obs)); werr = std::max(werr, ilen(r.mism) + 3);
+    }
+    o.f("#:%sTable:8:%zu:%%s:%%d:%%s:%%s:%%s:%%.4f:%%d:%%.2f:;\n", prefix, rows.size());
+    o.f("#:%sTable:RecalTable2:\n", prefix);
+    o.f("%-*s  %-*s  %-*s  %-*s  %-*s  %-*s  %-*s  %-*s\n", wrg, "ReadGroup", wq, "QualityScore", wcv, "CovariateValue", wcn, "CovariateName", wev,
+        "EventType", wemp, "EmpiricalQuality", wobs, "Observations", werr, "Errors");
+    std::sort(rows.begin(), rows.end(), [](const Row2 &a, const Row2 &b) {  // (ReadGroup, Qual, covariate AS TEXT) :229-243
+      if (a.rg != b.rg) return a.rg < b.rg;
+      if (a.qual != b.qual) return a.qual < b.qual;
+      return a.text < b.text;
+    });
+    for (auto &r : rows)
+      o.f("%-*s  %*d  %-*s  %-*s  %-*s  %*d.0000  %*lld  %*lld.00\n", wrg, r.rg.c_str(), wq, r.qual, wcv, r.text.c_str(), wcn, r.cycle ? "Cycle" : "Context",
+          wev, "M", wemp - 5, r.emp, wobs, r.obs, werr - 3, r.mism);
+    o.f("\n");
+  }
+  char *out = (char *)std::malloc(o.s.size() + 1);
+  std::memcpy(out, o.s.c_str(), o.s.size() + 1);
+  return out;
+}
+
+void elp_host_free(void *p) { std::free(p); }
+
+// ---------------------------------------------------------------- duplication metrics (filters/mark-optical-duplicates.go:527-699)
+static double f_lib(double x, double c, double n) { return c / x - 1 + std::exp(-n / x); }
+static long long estimate_library_size(long long n_pairs, long long n_unique) {
+  const double n = double(n_pairs), c = double(n_unique);
+  if (n_pairs > 0 && n_pairs - n_unique > 0) {
+    double m = 1.0, M = 100.0;
+    double fd = f_lib(M * c, c, n);
+    while (fd >= 0.0) { M *= 10.0; fd = f_lib(M * c, c, n); }
+    for (int i = 0; i < 40; i++) {
+      const double r = (m + M) / 2.0, u = f_lib(r * c, c, n);
+      if (u == 0.0) break;
+      if (u > 0.0) m = r;
+      if (u < 0.0) M = r;
+    }
+    return (long long)(c * ((m + M) / 2.0));
+  }
+  return 0;
+}
+
+int elp_dup_derived(const int64_t *k, double *pct, int64_t *lib_size) {
+  if (!k) return -1;
+  // order: UnpairedReadsExamined, ReadPairsExamined, SecondaryOrSupplementary, UnmappedReads, UnpairedReadDuplicates, ReadPairDuplicates, ReadPairOpticalDuplicates
+  if (lib_size) *lib_size = k[1] > 0 ? estimate_library_size(k[1] - k[6], k[1] - k[5]) : 0;
+  if (pct) *pct = double(k[4] + k[5] * 2) / double(k[0] + k[1] * 2);
+  return 0;
+}
+
+static std::string format_float(double v) {  // formatFloat :590-605
+  char b[64];
+  snprintf(b, sizeof b, "%.6f", v);
+  std::string s(b);
+  size_t dot = s.find('.');
+  if (dot == std::string::npos) return s;
+  size_t j = s.size() - 1;
+  while (j > dot && s[j] == '0') j--;
+  if (j == dot) return s;  // all zeros after the point: Go returns the untrimmed string
+  return s.substr(0, j + 1);
+}
+
+char *elp_dup_metrics_report(const int64_t *ctr, int n_lib, const char *const *lib_names, const char *command_line) {
+  Sb o;
+  o.f("## htsjdk.samtools.metrics.StringHeader\n");
+  o.f("# %s\n", command_line ? command_line : "");
+  o.f("## htsjdk.samtools.metrics.StringHeader\n");
+  o.f("# Started on: (timestamp omitted)\n\n");
+  o.f("## METRICS CLASS\tpicard.sam.DuplicationMetrics\n");
+  o.f("LIBRARY\tUNPAIRED_READS_EXAMINED\tREAD_PAIRS_EXAMINED\tSECONDARY_OR_SUPPLEMENTARY_RDS\tUNMAPPED_READS\tUNPAIRED_READ_DUPLICATES\tREAD_PAIR_DUPLICATES\t"
+      "READ_PAIR_OPTICAL_DUPLICATES\tPERCENT_DUPLICATION\tESTIMATED_LIBRARY_SIZE\n");
+  for (int l = 0; l <= n_lib; l++) {  // the reference iterates a Go map (:621): row order is not part of the contract
+    const int64_t *k = ctr + size_t(l) * 7;
+    const char *name = l < n_lib ? lib_names[l] : "Unknown Library";
+    double pct; int64_t ls;
+    elp_dup_derived(k, &pct, &ls);
+    std::string ps = std::isnan(pct) ? "NaN" : format_float(pct);
+    if (k[1] > 0)
+      o.f("%s\t%lld\t%lld\t%lld\t%lld\t%lld\t%lld\t%lld\t%s\t%lld\n", name, (long long)k[0], (long long)k[1], (long long)k[2], (long long)k[3], (long long)k[4],
+          (long long)k[5], (long long)k[6], ps.c_str(), (long long)ls);
+    else
+      o.f("%s\t%lld\t%lld\t%lld\t%lld\t%lld\t%lld\t%lld\t%s\n", name, (long long)k[0], (long long)k[1], (long long)k[2], (long long)k[3], (long long)k[4],
+          (long long)k[5], (long long)k[6], ps.c_str());
+  }
+  o.f("\n\n");
+  char *out = (char *)std::malloc(o.s.size() + 1);
+  std::memcpy(out, o.s.c_str(), o.s.size() + 1);
+  return out;
+}
+
+}  // extern "C"

@@ -1,0 +1,157 @@
+/*
+ * elprep_hip.h — C ABI of libelprep_hip.so: the MI355X (gfx950) implementation of elPrep's
+ * coordinate-sort -> mark-duplicates -> optical-duplicate metrics -> BQSR gather -> BQSR apply hot path.
+ *
+ * This is the drop-in boundary a host program (elPrep's Go code through cgo; the C++
+ * host layer in elprep_amd/host; the Python test/bench harness through ctypes) binds to.  Plain C types
+ * only.  Every entry point cites the reference interface it replaces (paths relative to
+ * ExaScience/elprep v5.1.3).
+ *
+ * Conventions
+ *  - Every function returns 0 on success and a negative elp_status on error; elp_last_error(ctx) holds a
+ *    message.  The reference reports all errors by log.Panic (internal/misc.go:31-43); a Go adapter turns a
+ *    non-zero status into log.Panic(elp_last_error(ctx)).
+ *  - One elp_ctx per GPU.  A ctx owns one HIP stream, the staged column store in HBM and all scratch.
+ *    Calls on one ctx must not overlap in time, except elp_stage, which may be called from many host
+ *    threads (it serialises internally; it mirrors the reference's LimitedPar batch nodes,
+ *    sam/filter-pipeline.go:290-292).
+ *  - Records are identified by their staging index (order of arrival = input order), 0-based.
+ *  - There is NO CPU fallback: if no gfx950 device is usable, elp_create fails.
+ */
+#ifndef ELPREP_HIP_H
+#define ELPREP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ELP_NIL16 0xFFFFu /* "no value" for 16-bit dictionary ids (Go nil interface{} LIBID / missing RG tag) */
+
+typedef enum elp_status {
+  ELP_OK = 0,
+  ELP_ERR_ARG = -1,       /* invalid argument / call order */
+  ELP_ERR_HIP = -2,       /* HIP runtime error */
+  ELP_ERR_NOMEM = -3,     /* out of device memory */
+  ELP_ERR_DATA = -4,      /* input the reference would panic on (invalid QUAL, cycle > max_cycle, read without RG in ApplyBQSR ...) */
+  ELP_ERR_UNSUPPORTED = -5 /* valid for the reference but outside this implementation's stated limits */
+} elp_status;
+
+typedef struct elp_ctx elp_ctx;
+
+/* ---------------------------------------------------------------------------------------------------
+ * Record batches: the SoA restaging of sam.Alignment (sam/sam-types.go:289-331) produced where the
+ * reference batches records (InputFile.RunPipeline, sam/filter-pipeline.go:282-296; BytesToAlignment :92).
+ * Fixed fields are exactly BAM's (sam/bam-files.go:299-312) after AddREFID (filters/simple-filters.go:208-231).
+ * --------------------------------------------------------------------------------------------------- */
+typedef struct elp_batch {
+  uint64_t n;                 /* records in this batch */
+  const int32_t *refid;       /* REFID temp: index of RNAME in @SQ, -1 for '*' / unknown */
+  const int32_t *pos;         /* POS, 1-based */
+  const int32_t *next_refid;  /* NextREFID temp ('=' already resolved) */
+  const int32_t *pnext;       /* PNEXT, 1-based */
+  const int32_t *tlen;        /* TLEN */
+  const uint16_t *flag;       /* FLAG */
+  const uint8_t *mapq;        /* MAPQ */
+  const uint16_t *rgid;       /* dense id of the RG:Z tag string (index into elp_header.rg_*), ELP_NIL16 = no RG tag */
+  const uint8_t *has_sr;      /* 1 = record carries the sr:i tag written by `elprep split` (sam/split-merge.go:291); may be NULL */
+  const uint32_t *l_seq;      /* SEQ length in bases */
+  const uint64_t *qname_off;  /* n+1 byte offsets into qname */
+  const uint8_t *qname;       /* QNAME bytes, no terminator */
+  const uint64_t *cigar_off;  /* n+1 offsets (in ops) into cigar */
+  const uint32_t *cigar;      /* BAM-encoded ops: len<<4 | op, op indexes "MIDNSHP=X" (sam/bam-files.go:289) */
+  const uint64_t *seq_off;    /* n+1 byte offsets into seq4 */
+  const uint8_t *seq4;        /* BAM 4-bit bases, high nibble first, "=ACMGRSVTWYHKDBN" (utils/nibbles, sam/sam-types.go:228) */
+  const uint64_t *qual_off;   /* n+1 byte offsets into qual */
+  const uint8_t *qual;        /* raw phred, no +33 (sam/sam-files.go:400-402) */
+} elp_batch;
+
+/* Header facts read by the filters: @SQ LN (alignmentAgreesWithHeader, filters/utils.go:130-139) and the @RG
+ * dictionaries (lbTable, filters/mark-duplicates.go:413-423; readGroupCovariate, filters/bqsr.go:35-51). */
+typedef struct elp_header {
+  int32_t n_ref;
+  const int32_t *ref_len;   /* @SQ LN per refid */
+  int32_t n_rg;
+  const uint16_t *rg_lib;   /* per rgid: dense id of the LB string, ELP_NIL16 if the RG has no LB / is not in the header */
+  const uint16_t *rg_cov;   /* per rgid: dense id of the BQSR read-group covariate string (PU if present, else ID) */
+  int32_t n_lib;
+  int32_t n_cov;
+} elp_header;
+
+/* ---- context ---- */
+int elp_create(int device_ordinal, elp_ctx **out);
+void elp_destroy(elp_ctx *ctx);
+const char *elp_last_error(const elp_ctx *ctx);
+int elp_sync(elp_ctx *ctx);                 /* wait for the ctx stream */
+void *elp_stream(elp_ctx *ctx);             /* the hipStream_t all kernels of this ctx are launched on */
+
+/* ---- staging (replaces Sam.AddNodes' Slice(&alns) collection, sam/filter-pipeline.go:108-124) ---- */
+int elp_set_header(elp_ctx *ctx, const elp_header *hdr);
+int elp_reserve(elp_ctx *ctx, uint64_t n_records, uint64_t qname_bytes, uint64_t cigar_ops, uint64_t seq_bytes, uint64_t qual_bytes);
+int elp_stage(elp_ctx *ctx, const elp_batch *batch); /* appends; host buffers may be reused when the call returns */
+int elp_reset(elp_ctx *ctx);                         /* drops all staged records and results */
+uint64_t elp_num_records(const elp_ctx *ctx);
+
+/* ---- coordinate sort: By(CoordinateLess).ParallelStableSort (sam/sam-types.go:425-473, 639-641) ----
+ * Builds the permutation on device: perm[k] = staging index of the record at sorted position k; records equal
+ * under all nine keys of CoordinateLess keep staging order.  Payload permutation is the caller's (host) work. */
+int elp_sort_coordinate(elp_ctx *ctx);
+int elp_get_permutation(elp_ctx *ctx, uint32_t *perm_out /* n */);
+
+/* ---- mark duplicates: filters.MarkDuplicates (filters/mark-duplicates.go:398-445) ----
+ * Sets FLAG |= 0x400 on the staged flag column exactly as the reference's fragment/pair tournaments do
+ * (deterministic total order: score, then QNAME, then later arrival — the single-threaded execution of the
+ * reference).  also_opticals is accepted for signature parity (it only changes which reads carry a LIBID temp). */
+int elp_mark_duplicates(elp_ctx *ctx, int also_opticals);
+int elp_get_flags(elp_ctx *ctx, uint16_t *flag_out /* n, staging order */);
+/* adapted values of filters/mark-duplicates.go:79-110 (unclipped 5' position) and :57-68 (Phred-sum score);
+ * 0 for records that are not duplicate-marking candidates.  Either pointer may be NULL. */
+int elp_get_adapted(elp_ctx *ctx, int32_t *upos_out, int32_t *score_out);
+
+/* ---- DuplicationMetrics counters: filters.MarkOpticalDuplicates (filters/mark-optical-duplicates.go:469-525) ----
+ * counters: [(n_lib + 1)][7] int64 in the order UnpairedReadsExamined, ReadPairsExamined, SecondaryOrSupplementaryReads,
+ * UnmappedReads, UnpairedReadDuplicates, ReadPairDuplicates, ReadPairOpticalDuplicates; row n_lib = "Unknown Library".
+ * Requires elp_mark_duplicates.  Derived float metrics (PERCENT_DUPLICATION, ESTIMATED_LIBRARY_SIZE, :527-569) and the
+ * Picard text (:608-699) stay on the host. */
+#define ELP_NCTR 7
+int elp_dup_metrics(elp_ctx *ctx, int optical_pixel_distance, int64_t *counters);
+
+/* ---- BQSR inputs: NewBaseRecalibrator(knownSites, referenceFasta) (filters/bqsr.go:424-443) ----
+ * bases = raw .elfasta bytes of one contig (fasta.MappedFasta.Seq, fasta/fasta-files.go:355);
+ * start_end = known-site intervals [n][2], 1-based inclusive, ALREADY sorted by start and flattened
+ * (intervals.ParallelSortByStart + ParallelFlatten, intervals/intervals.go:77-132) — the host keeps doing that. */
+int elp_bqsr_set_reference(elp_ctx *ctx, int32_t refid, const uint8_t *bases, int64_t len);
+int elp_bqsr_set_known_sites(elp_ctx *ctx, int32_t refid, const int32_t *start_end, int64_t n);
+
+/* ---- BQSR gather: BaseRecalibrator.Recalibrate (filters/bqsr.go:467-551) ----
+ * Walks the records in any order (integer sums) and fills dense {observations, mismatches} int64 tables:
+ *   qual_tbl  [n_cov][94][2]
+ *   cycle_tbl [n_cov][94][2*max_cycle+1][2]     cycle c at index c + max_cycle
+ *   ctx_tbl   [n_cov][94][16][2]                context key k (filters/bqsr.go:64-76) at index (k >> 4) & 15
+ * A Go map entry of the reference exists iff observations > 0.  Uses the staged flag column (duplicates excluded,
+ * recalibrateAln filters/bqsr.go:225-244), so call after elp_mark_duplicates. */
+#define ELP_NQUAL 94
+#define ELP_NCTX 16
+int elp_bqsr_gather(elp_ctx *ctx, int max_cycle, int64_t *qual_tbl, int64_t *cycle_tbl, int64_t *ctx_tbl);
+
+/* ---- BQSR apply: BaseRecalibratorTables.ApplyBQSR (filters/bqsr.go:936-1005) ----
+ * lut: [n_cov][94][2*max_cycle+1][17] bytes = the reference's memo map applyKey{rg, qual, cycle, context} -> uint8,
+ * densely tabulated by the host from the finalized tables (context index 16 = key -1); cov_present[c] = 0 means the read
+ * group is absent from the tables (read left untouched, :953-955).  Rewrites the staged qual column in place. */
+int elp_bqsr_apply(elp_ctx *ctx, int max_cycle, const uint8_t *lut, const uint8_t *cov_present);
+int elp_get_qual(elp_ctx *ctx, uint8_t *qual_out /* qual_bytes, staging order and offsets */);
+
+/* ---- measurement ----
+ * With profiling on, every kernel launch is bracketed by hipEvents on the ctx stream; elp_profile_get returns, per
+ * kernel name, the launch count and the summed duration in milliseconds. */
+int elp_profile_enable(elp_ctx *ctx, int on);
+int elp_profile_reset(elp_ctx *ctx);
+int elp_profile_count(elp_ctx *ctx);
+int elp_profile_get(elp_ctx *ctx, int index, const char **name, uint64_t *launches, double *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ELPREP_HIP_H */

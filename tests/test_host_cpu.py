@@ -1,0 +1,126 @@
+"""CPU tests (-m "not gpu"): the C-ABI libraries load and export every declared symbol; the host float code
+(libelprep_host.so) agrees with the oracle; the synthetic generator is deterministic.  No GPU compute calls."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle as orc
+from elprep_amd import _lib
+from elprep_amd.engine import BqsrTables, dup_derived, dup_metrics_report
+from tests.common import dataset
+from tools import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    return sorted(set(re.findall(r"\b(elp_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_hip_library_exports_every_declared_symbol():
+    L = C.CDLL(_lib.HIP_SO)  # must exist: build() makes it; no fallback
+    names = _declared("elprep_hip.h")
+    assert set(names) == set(_lib.HIP_SYMBOLS)
+    for n in names:
+        assert hasattr(L, n), n
+
+
+def test_host_library_exports_every_declared_symbol():
+    L = C.CDLL(_lib.HOST_SO)
+    names = _declared("elprep_host.h")
+    assert set(names) == set(_lib.HOST_SYMBOLS)
+    for n in names:
+        assert hasattr(L, n), n
+
+
+def test_create_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    rc = _lib.hip().elp_create(0, C.byref(h))
+    assert rc != 0 and not h.value
+
+
+def test_synth_is_deterministic_and_shardable():
+    cfg = synth.config("tiny")
+    a = synth.generate(cfg, 0, 600)
+    b1, b2 = synth.generate(cfg, 0, 250), synth.generate(cfg, 250, 600)
+    from elprep_amd.batch import Batch
+    c = Batch.concat([b1, b2])
+    for name in ("refid", "pos", "flag", "mapq", "rgid", "qname", "cigar", "seq4", "qual", "qname_off", "qual_off", "tlen"):
+        assert np.array_equal(getattr(a, name), getattr(c, name)), name
+    # shape of the data: mates adjacent, duplicates and unmapped pairs present
+    assert a.n >= 1200 and (a.flag & 0x4).any() and (a.flag & 0x800).any()
+
+
+@pytest.fixture(scope="module")
+def tables():
+    cfg, b, h, refs, sites = dataset("tiny", 3000)
+    flags = orc.mark_duplicates(b, h)
+    qt, ct, xt = orc.bqsr_gather(b, h, orc.BqsrRef(refs, sites), flags, 500)
+    return h, qt, ct, xt
+
+
+def test_host_finalize_matches_oracle(tables):
+    h, qt, ct, xt = tables
+    fo = orc.BqsrFinal(qt, ct, xt, 500)
+    ft = BqsrTables(qt, ct, xt, 500).finalize()
+    for a, b in zip(fo.empirical(), ft.empirical()):
+        assert np.array_equal(a, b)
+    ro, eo, oo, mo, po = fo.combined()
+    rt, et, ot, mt, pt = ft.combined()
+    assert np.array_equal(ro, rt) and np.array_equal(eo, et) and np.array_equal(oo, ot) and np.array_equal(mo, mt) and np.array_equal(po, pt)
+    for lv in (0, 4, 16):
+        co, so = fo.quantize(lv)
+        ct_, st = ft.quantize(lv)
+        assert np.array_equal(co, ct_) and np.array_equal(so, st)
+
+
+@pytest.mark.parametrize("levels,sqq", [(0, ()), (8, ()), (0, (10, 20, 30)), (0, (25,))])
+def test_host_lut_matches_oracle_memo(tables, levels, sqq):
+    """The factorised LUT must reproduce estimateHierarchicalBayesianQuality for every key the apply pass can hit."""
+    h, qt, ct, xt = tables
+    fo = orc.BqsrFinal(qt, ct, xt, 500)
+    ft = BqsrTables(qt, ct, xt, 500).finalize()
+    lut, present = ft.build_lut(levels, sqq)
+    _, quantized = fo.quantize(levels)
+    stat = orc.static_quantized_scores(sqq) if sqq else None
+    rng = np.random.default_rng(1)
+    quals = [q for q in range(94) if qt[:, q, 0].sum() > 0] + [6, 40, 93]
+    checked = 0
+    for cov in range(h.n_cov):
+        assert present[cov] == 1
+        for q in quals:
+            for cyc in list(rng.integers(-150, 151, 12)) + [-500, 500, 1, -1]:
+                if cyc == 0:
+                    continue
+                for cx in list(rng.integers(0, 16, 4)) + [-1]:
+                    key = -1 if cx < 0 else (2 | ((cx & 3) << 4) | ((cx >> 2) << 6))
+                    want = fo.recal_qual(cov, q, int(cyc), key, quantized, stat)
+                    got = lut[cov, q, int(cyc) + 500, 16 if cx < 0 else ((key >> 4) & 15)]
+                    assert got == want, (cov, q, cyc, cx)
+                    checked += 1
+    assert checked > 2000
+
+
+def test_host_report_matches_oracle_text(tables):
+    h, qt, ct, xt = tables
+    fo = orc.BqsrFinal(qt, ct, xt, 500)
+    ft = BqsrTables(qt, ct, xt, 500).finalize()
+    assert ft.report(h.cov_names) == fo.report(h.cov_names)
+    assert ft.report(h.cov_names, "ELP").startswith("#:ELPReport.v1.1:5\n")
+
+
+def test_dup_derived_and_report():
+    row = np.array([10, 1000, 5, 7, 2, 100, 20], dtype=np.int64)
+    pct, ls = dup_derived(row)
+    assert pct == pytest.approx((2 + 200) / (10 + 2000))
+    assert ls == orc.estimate_library_size(1000 - 20, 1000 - 100)
+    txt = dup_metrics_report(np.stack([row, np.zeros(7, np.int64)]), ["libA"], "elprep filter in out")
+    assert "libA\t10\t1000\t5\t7\t2\t100\t20\t0.100498\t" in txt
+    assert "Unknown Library\t0\t0\t0\t0\t0\t0\t0\tNaN\n" in txt
