@@ -242,12 +242,12 @@ static int d2h(elp_ctx *c, void *dst, const void *src, size_t bytes) {
 }
 
 int elp_get_permutation(elp_ctx *c, uint32_t *out) {
-  if (!c || !out) return ELP_ERR_ARG;
+  if (!c || (!out && c->n)) return ELP_ERR_ARG;
   if (!c->sorted) return set_error(c, ELP_ERR_ARG, "elp_get_permutation: call elp_sort_coordinate first");
   return d2h(c, out, c->perm.p, c->n * sizeof(uint32_t));
 }
 int elp_get_flags(elp_ctx *c, uint16_t *out) {
-  if (!c || !out) return ELP_ERR_ARG;
+  if (!c || (!out && c->n)) return ELP_ERR_ARG;
   return d2h(c, out, c->flag.p, c->n * sizeof(uint16_t));
 }
 int elp_get_adapted(elp_ctx *c, int32_t *upos, int32_t *score) {
@@ -258,7 +258,7 @@ int elp_get_adapted(elp_ctx *c, int32_t *upos, int32_t *score) {
   return 0;
 }
 int elp_get_qual(elp_ctx *c, uint8_t *out) {
-  if (!c || !out) return ELP_ERR_ARG;
+  if (!c || (!out && c->qual_bytes)) return ELP_ERR_ARG;
   return d2h(c, out, c->qual.p, c->qual_bytes);
 }
 
