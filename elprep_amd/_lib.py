@@ -22,7 +22,7 @@ HIP_SYMBOLS = [
     "elp_create", "elp_destroy", "elp_last_error", "elp_sync", "elp_stream", "elp_set_header", "elp_reserve", "elp_stage", "elp_reset",
     "elp_num_records", "elp_sort_coordinate", "elp_get_permutation", "elp_mark_duplicates", "elp_get_flags", "elp_get_adapted",
     "elp_dup_metrics", "elp_bqsr_set_reference", "elp_bqsr_set_known_sites", "elp_bqsr_gather", "elp_bqsr_apply", "elp_get_qual",
-    "elp_profile_enable", "elp_profile_reset", "elp_profile_count", "elp_profile_get",
+    "elp_snapshot", "elp_rollback", "elp_profile_enable", "elp_profile_reset", "elp_profile_count", "elp_profile_get",
 ]
 HOST_SYMBOLS = [
     "elp_bqsr_tables_new", "elp_bqsr_tables_free", "elp_bqsr_tables_merge", "elp_bqsr_tables_finalize", "elp_bqsr_tables_empirical",
@@ -56,7 +56,7 @@ def hip() -> C.CDLL:
         L.elp_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         L.elp_destroy.argtypes = [C.c_void_p]
         L.elp_destroy.restype = None
-        for name in ("elp_sync", "elp_reset", "elp_sort_coordinate", "elp_profile_reset", "elp_profile_count"):
+        for name in ("elp_sync", "elp_reset", "elp_sort_coordinate", "elp_profile_reset", "elp_profile_count", "elp_snapshot", "elp_rollback"):
             getattr(L, name).argtypes = [C.c_void_p]
         L.elp_set_header.argtypes = [C.c_void_p, C.c_void_p]
         L.elp_stage.argtypes = [C.c_void_p, C.c_void_p]

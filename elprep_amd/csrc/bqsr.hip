@@ -1,359 +1,25 @@
 // bqsr.hip — base quality score recalibration on the HBM column store: covariate-table gather and LUT apply.
 //
-// Reference: BaseRecalibrator.Recalibrate (filters/bqsr.go:467-551) with recalibrateAln (:225-244), computeSnpEvents
-// (:254-285), computeStrandedClippedSeq (:312-362), contextWith (:87-131), cycle covariates (:364-387), calculateSkipSlice
-// (:389-414); the clipping helpers hardClipAdaptorSequence / hardClipSoftClippedBases / hardClip / hardClipCigar /
-// cleanHardClippedCigar / getReadCoordinateForReferenceCoordinate (filters/utils.go:148-534); intervals.Intersect
-// (intervals/intervals.go:166-173); BaseRecalibratorTables.ApplyBQSR (filters/bqsr.go:936-1005).
+// Reference: BaseRecalibrator.Recalibrate (filters/bqsr.go:467-551), BaseRecalibratorTables.ApplyBQSR (:936-1005); device
+// helpers (clipping, covariates) and their citations are in bqsr_dev.hpp.
 //
-// Float finalisation (FinalizeBQSRTables, the hierarchical Bayesian estimate) is host work; the device consumes its result
-// as a dense byte LUT.
-//
-// Per-base covariates are local functions of the read:
-//   cycle(k)   = cycleFactor + k * increment                                   (bqsr.go:376-387)
-//   context(k) = 2-mer key of (previous, current) base in sequencing direction, -1 at the first sequenced base, next to a
-//                non-ACGT base, or inside the low-quality tails (quality <= 2 from either end)   (bqsr.go:87-146, 312-362)
-#include "common.hpp"
+// Gather = three kernels
+//   bqsr_prologue  one thread per record: eligibility (recalibrateAln), adaptor + soft-clip hard clipping on a working copy,
+//                  known-site skip mask (calculateSkipSlice) written into a 1-bit-per-base column, low-quality-tail bounds;
+//                  leaves a 20-byte descriptor per record and the rewritten CIGAR in scratch.
+//   bqsr_count     flat stream over QUAL/SEQ (flat.hpp): one lane per 16 bases; SNP event against the reference, cycle and
+//                  context covariates, then ONE packed LDS atomic per base into a workgroup-private cycle table
+//                  (observations in the low, mismatches in the high 16 bits) and one into the private context table.
+//                  Private tables are flushed into per-workgroup partial tables in HBM (plain stores, no atomics).
+//   bqsr_reduce    sums the partial tables into the dense int64 tables of the C ABI; the QualityScores table is the sum of the
+//                  Cycles table over cycles (every counted base updates both with the same (read group, quality)).
+// Apply = a small per-record prologue (low-quality bounds) + a flat per-base LUT kernel that rewrites QUAL in place.
+#include "bqsr_dev.hpp"
+#include "flat.hpp"
 
 namespace elp {
 
-constexpr int MAX_BQSR_READ = 1024;  // bases; longer reads exceed any sane --max-cycle and make the reference panic anyway
-
-// ------------------------------------------------------------------ CIGAR helpers (BAM-encoded ops)
-__device__ __forceinline__ uint32_t c_op(uint32_t c) { return c & 0xF; }
-__device__ __forceinline__ int32_t c_len(uint32_t c) { return (int32_t)(c >> 4); }
-__device__ __forceinline__ uint32_t c_make(uint32_t op, int32_t len) { return ((uint32_t)len << 4) | op; }
-
-struct RAln {  // working copy of one alignment (`*aln = *alignment`, bqsr.go:479)
-  int32_t pos, pnext, tlen, refid, next_refid;
-  uint16_t flag;
-  const uint32_t *cig;  // current CIGAR
-  int ncig;
-  int off, len;         // surviving bases [off, off+len) in original read coordinates
-  uint32_t *buf[2];     // ping-pong scratch for rewritten CIGARs
-  int cur;              // index of the buffer holding `cig`, -1 = original
-};
-
-__device__ inline int32_t read_len_of(const uint32_t *c, int n) {
-  int32_t l = 0;
-  for (int i = 0; i < n; i++) l += op_consumes_read(c_op(c[i])) ? c_len(c[i]) : 0;
-  return l;
-}
-__device__ inline int32_t ref_len_of(const uint32_t *c, int n) {
-  int32_t l = 0;
-  for (int i = 0; i < n; i++) l += op_consumes_ref(c_op(c[i])) ? c_len(c[i]) : 0;
-  return l;
-}
-__device__ inline int32_t aln_end(const RAln &a) { return a.pos + ref_len_of(a.cig, a.ncig) - 1; }  // sam/sam-types.go:769-775
-__device__ inline bool strict_unmapped(const RAln &a) { return (a.flag & F_UNMAPPED) || a.refid < 0 || a.pos == 0; }      // utils.go:141-143
-__device__ inline bool strict_next_unmapped(const RAln &a) { return (a.flag & F_NEXT_UNMAPPED) || a.next_refid < 0 || a.pnext == 0; }
-
-// utils.go:224-248
-__device__ inline int soft_start(const RAln &a) {
-  int32_t s = a.pos;
-  for (int i = 0; i < a.ncig; i++) {
-    const uint32_t op = c_op(a.cig[i]);
-    if (op == OP_S) s -= c_len(a.cig[i]);
-    else if (op != OP_H) break;
-  }
-  return s;
-}
-__device__ inline int soft_end(const RAln &a) {
-  const int32_t end = aln_end(a);
-  int32_t se = end;
-  for (int i = a.ncig - 1; i >= 0; i--) {
-    const uint32_t op = c_op(a.cig[i]);
-    if (op == OP_S) se += c_len(a.cig[i]);
-    else if (op != OP_H) return se;
-  }
-  return end;
-}
-
-// utils.go:267-326; returns read coordinate or -1, *falls = fallsInsideOrJustBeforeDeletionOrSkippedRegion
-__device__ inline int compute_read_coord(const uint32_t *c, int n, int softstart, int ref_index, bool *falls) {
-  const int goal = ref_index - softstart;
-  *falls = false;
-  if (goal < 0) return -1;
-  int read_bases = 0, ref_bases = 0;
-  bool falls_inside = false, ends_before = false, fob = false;
-  int index = 0;
-  while (ref_bases != goal && index < n) {
-    const uint32_t el = c[index++];
-    const uint32_t op = c_op(el);
-    const int el_len = c_len(el);
-    int shift = 0;
-    if (op_consumes_ref(op) || op == OP_S) {
-      shift = (ref_bases + el_len < goal) ? el_len : goal - ref_bases;
-      ref_bases += shift;
-    }
-    const int cr = op_consumes_read(op) ? 1 : 0;
-    if (ref_bases != goal) {
-      read_bases += cr * el_len;
-    } else {
-      if (shift >= el_len && index == n) return -1;
-      uint32_t next_op = 0xF;
-      if (shift < el_len) {
-        falls_inside = op == OP_D || op == OP_N;
-      } else {
-        uint32_t nx = c[index++];
-        if (c_op(nx) == OP_I) {
-          read_bases += c_len(nx);
-          if (index == n) return -1;
-          nx = c[index++];
-        }
-        next_op = c_op(nx);
-        ends_before = next_op == OP_D || next_op == OP_N;
-      }
-      fob = ends_before || falls_inside;
-      if (!fob) read_bases += cr * shift;
-      else if (ends_before) read_bases += cr * (shift - 1);
-      else if (falls_inside) read_bases--;
-    }
-  }
-  if (ref_bases != goal) return -1;
-  *falls = fob;
-  return read_bases;
-}
-
-// utils.go:335-349 (+ readStartsWithInsertion bqsr.go:287-299)
-__device__ inline int get_read_coord(const uint32_t *c, int n, int softstart, int ref_index, bool right_tail, bool *ok) {
-  bool falls;
-  int rb = compute_read_coord(c, n, softstart, ref_index, &falls);
-  if (rb == -1) { *ok = false; return -1; }
-  if (right_tail && falls) rb++;
-  if (!right_tail && rb == 0) {
-    for (int i = 0; i < n; i++) {
-      const uint32_t op = c_op(c[i]);
-      if (op == OP_I) {
-        const int32_t m = read_len_of(c, n) - 1;
-        rb = c_len(c[i]) < m ? c_len(c[i]) : m;
-        break;
-      }
-      if (op == OP_H || op == OP_S) continue;
-      break;
-    }
-  }
-  *ok = true;
-  return rb;
-}
-
-// utils.go:351-372
-__device__ inline int32_t hard_soft_offset(const uint32_t *c, int n) {
-  int32_t size = 0;
-  int i = 0;
-  for (; i < n && c_op(c[i]) == OP_H; i++) size += c_len(c[i]);
-  for (; i < n && c_op(c[i]) == OP_S; i++) size += c_len(c[i]);
-  return size;
-}
-// utils.go:378-386
-__device__ inline int clip_shift(uint32_t el, int cigar_length) {
-  const uint32_t op = c_op(el);
-  if (op == OP_I) return -cigar_length;
-  if (op == OP_D || op == OP_N) return c_len(el);
-  return 0;
-}
-
-// utils.go:488-517, in place
-__device__ inline int clean_hard_clipped(uint32_t *c, int n) {
-  int total = 0, index = 0;
-  for (; index < n; index++) {
-    const uint32_t op = c_op(c[index]);
-    if (op == OP_H || op == OP_D || op == OP_N) total += c_len(c[index]);
-    else break;
-  }
-  if (index > 0) {
-    c[0] = c_make(OP_H, total);
-    for (int k = index; k < n; k++) c[1 + k - index] = c[k];
-    n = 1 + (n - index);
-  }
-  total = 0;
-  index = n - 1;
-  for (; index >= 0; index--) {
-    const uint32_t op = c_op(c[index]);
-    if (op == OP_H || op == OP_D || op == OP_N) total += c_len(c[index]);
-    else break;
-  }
-  if (index < n - 1) {
-    n = index + 1;
-    c[n++] = c_make(OP_H, total);
-  }
-  return n;
-}
-
-// utils.go:406-486; writes the new CIGAR to `out` (capacity ncig + 4) and returns its length
-__device__ inline int hard_clip_cigar(const RAln &a, int start, int stop, uint32_t *out) {
-  const uint32_t *cv = a.cig;
-  const int n = a.ncig;
-  int index = 0, total_hard = stop - start + 1, shift_acc = 0, no = 0;
-  if (start == 0) {
-    int ci = 0;
-    for (int k = 0; k < n; k++) {  // Go: for cigarOpIndex, cigarOp = range cigarVec
-      ci = k;
-      if (c_op(cv[k]) != OP_H) break;
-      total_hard += c_len(cv[k]);
-    }
-    for (; index <= stop && ci < n; ci++) {
-      const uint32_t el = cv[ci];
-      const int el_len = c_len(el);
-      const int shift = op_consumes_read(c_op(el)) ? el_len : 0;
-      if (index + shift == stop + 1) {
-        shift_acc += clip_shift(el, el_len);
-        out[no++] = c_make(OP_H, total_hard + shift_acc);
-      } else if (index + shift > stop + 1) {
-        const int after = el_len - (stop - index + 1);
-        shift_acc += clip_shift(el, stop - index + 1);
-        out[no++] = c_make(OP_H, total_hard + shift_acc);
-        out[no++] = c_make(c_op(el), after);
-      }
-      index += shift;
-      shift_acc += clip_shift(el, shift);
-    }
-    for (; ci < n; ci++) out[no++] = cv[ci];
-  } else {
-    int ci = 0;
-    for (; index < start && ci < n; ci++) {
-      const uint32_t el = cv[ci];
-      const int el_len = c_len(el);
-      const int shift = op_consumes_read(c_op(el)) ? el_len : 0;
-      if (index + shift < start) {
-        out[no++] = el;
-      } else {
-        const int after = start - index;
-        shift_acc += clip_shift(el, el_len - (start - index));
-        if (c_op(el) == OP_H) total_hard += after;
-        else out[no++] = c_make(c_op(el), after);
-      }
-      index += shift;
-    }
-    for (; ci < n; ci++) {
-      const uint32_t el = cv[ci];
-      shift_acc += clip_shift(el, c_len(el));
-      if (c_op(el) == OP_H) total_hard += c_len(el);
-    }
-    out[no++] = c_make(OP_H, total_hard + shift_acc);
-  }
-  return clean_hard_clipped(out, no);
-}
-
-// utils.go:388-404
-__device__ inline void hard_clip(RAln &a, int start, int stop) {
-  const int nb = a.cur == 0 ? 1 : 0;
-  uint32_t *out = a.buf[nb];
-  const int no = hard_clip_cigar(a, start, stop, out);
-  const int new_len = a.len - (stop - start + 1);
-  const int copy_start = start == 0 ? stop + 1 : 0;
-  const int32_t old_off = hard_soft_offset(a.cig, a.ncig);
-  a.cig = out; a.ncig = no; a.cur = nb;
-  a.off += copy_start;
-  a.len = new_len;
-  if (start == 0 && !strict_unmapped(a)) a.pos += hard_soft_offset(a.cig, a.ncig) - old_off;
-}
-
-// utils.go:149-180, 214-222; returns false where the reference panics
-__device__ inline bool hard_clip_adaptor(RAln &a) {
-  const bool rev = a.flag & F_REVERSED;
-  if (!(a.tlen != 0 && (a.flag & F_MULTIPLE) && !strict_unmapped(a) && !strict_next_unmapped(a) && rev != (bool)(a.flag & F_NEXT_REVERSED)))
-    return true;
-  int end_v;
-  bool well;
-  if (rev) { const int32_t e = aln_end(a); well = e > a.pnext; end_v = e; }
-  else { well = a.pos <= a.pnext + a.tlen; end_v = -1; }
-  if (!well) return true;
-  const int boundary = rev ? (int)a.pnext - 1 : (int)a.pos + (a.tlen < 0 ? -(int)a.tlen : (int)a.tlen);
-  if (boundary < (int)a.pos) return true;  // isInsideRead
-  if (end_v < 0) end_v = aln_end(a);
-  if (boundary > end_v) return true;
-  bool ok;
-  if (rev) {
-    const int stop = get_read_coord(a.cig, a.ncig, soft_start(a), boundary, false, &ok);
-    if (!ok) return false;
-    hard_clip(a, 0, stop);
-  } else {
-    const int start = get_read_coord(a.cig, a.ncig, soft_start(a), boundary, true, &ok);
-    if (!ok) return false;
-    hard_clip(a, start, a.len - 1);
-  }
-  return true;
-}
-
-// utils.go:519-548
-__device__ inline void hard_clip_soft_clipped(RAln &a) {
-  int read_index = 0, cut_left = -1, cut_right = -1;
-  bool right_tail = false;
-  for (int i = 0; i < a.ncig; i++) {
-    const uint32_t op = c_op(a.cig[i]);
-    const int ln = c_len(a.cig[i]);
-    if (op == OP_S) {
-      if (right_tail) cut_right = read_index;
-      else cut_left = read_index + ln - 1;
-    } else if (op != OP_H) {
-      right_tail = true;
-    }
-    read_index += op_consumes_read(op) ? ln : 0;
-  }
-  if (cut_right >= 0) hard_clip(a, cut_right, a.len - 1);
-  if (cut_left >= 0) hard_clip(a, 0, cut_left);
-}
-
-// ------------------------------------------------------------------ bases
-__device__ __forceinline__ uint32_t nibble_at(const uint8_t *__restrict__ s4, int k) {
-  const uint32_t b = s4[k >> 1];
-  return (k & 1) ? (b & 0xF) : (b >> 4);
-}
-// simpleBaseToBaseIndex on Sequence.Base(): A0 C1 G2 T3, everything else -1 (bqsr.go:55-62; '=' is not '*')
-__device__ __forceinline__ int base_index_of_nibble(uint32_t nb) { return nb == 1 ? 0 : nb == 2 ? 1 : nb == 4 ? 2 : nb == 8 ? 3 : -1; }
-// baseToIntMap on a raw reference byte (bqsr.go:247-252)
-__device__ __forceinline__ int base_code_of_ref(uint8_t c) {
-  switch (c) {
-    case 'a': case 'A': case '*': return 1;
-    case 'c': case 'C': return 2;
-    case 'g': case 'G': return 3;
-    case 't': case 'T': return 4;
-    default: return 0;
-  }
-}
-// baseToIntMap on Sequence.Base(): "=ACMGRSVTWYHKDBN" -> A1 C2 G3 T4 else 0
-__device__ __forceinline__ int base_code_of_nibble(uint32_t nb) { return nb == 1 ? 1 : nb == 2 ? 2 : nb == 4 ? 3 : nb == 8 ? 4 : 0; }
-
-struct ReadView {
-  const uint8_t *seq4;  // original packed bases of the record
-  const uint8_t *qual;  // original quals of the record
-  int off, len;         // current window
-  bool reversed;
-  int left, right;      // low-quality-tail mask bounds inside the window (left > right: whole read masked)
-};
-
-// computeStrandedClippedSeq mask bounds, bqsr.go:316-332
-__device__ inline void low_quality_bounds(ReadView &v) {
-  int left = v.len;
-  for (int i = 0; i < v.len; i++) if (v.qual[v.off + i] > 2) { left = i; break; }
-  int right = left - 1;
-  for (int i = v.len - 1; i >= left; i--) if (v.qual[v.off + i] > 2) { right = i; break; }
-  v.left = left; v.right = right;
-}
-__device__ __forceinline__ int masked_index(const ReadView &v, int k) {  // base index or -1 (masked / non-ACGT / outside)
-  if (k < v.left || k > v.right) return -1;
-  return base_index_of_nibble(nibble_at(v.seq4, v.off + k));
-}
-// context covariate of base k, bqsr.go:87-146
-__device__ __forceinline__ int context_key(const ReadView &v, int k) {
-  if (!v.reversed) {
-    if (k < 1) return -1;
-    const int p = masked_index(v, k - 1), q = masked_index(v, k);
-    if (p < 0 || q < 0) return -1;
-    return 2 | (p << 4) | (q << 6);
-  }
-  if (k > v.len - 2) return -1;
-  const int p = masked_index(v, k + 1), q = masked_index(v, k);
-  if (p < 0 || q < 0) return -1;
-  return 2 | ((3 - p) << 4) | ((3 - q) << 6);  // complement: A<->T, C<->G
-}
-__device__ __forceinline__ void cycle_params(uint16_t flag, int len, int *factor, int *incr) {  // bqsr.go:376-383
-  const int reversed = (flag & F_REVERSED) >> 4, last = (flag & F_LAST) >> 7;
-  const int rof = 1 - 2 * last;
-  *factor = rof + reversed * (len - 1) * rof;
-  *incr = (1 - 2 * reversed) * rof;
-}
+constexpr int MAX_DESC_READ = 65535;  // u16 fields of the record descriptor
 
 struct BqCols {
   uint64_t n;
@@ -399,13 +65,27 @@ __device__ inline bool recalibrate_aln(const BqCols &m, uint64_t i) {
   return refl >= 0 && (int32_t)ls == rl;
 }
 
-// Recalibrate per-read body, bqsr.go:478-539.  One thread per record; tables updated with 64-bit atomics.
-__global__ __launch_bounds__(256) void k_bqsr_gather(BqCols m, int max_cycle, uint32_t *__restrict__ cig_scratch, unsigned long long *qual_tbl,
-                                                     unsigned long long *cycle_tbl, unsigned long long *ctx_tbl, uint32_t *err) {
+// per-record descriptor produced by the prologue
+struct BqDesc {
+  int32_t pos;     // POS of the clipped working copy
+  uint32_t cig;    // index of its CIGAR: into the scratch CIGAR pool (fl & 8) or into the staged cigar column
+  uint16_t ncig;
+  uint16_t a;      // first surviving base (original read coordinates)
+  uint16_t len;    // surviving bases; 0 = record contributes nothing
+  uint16_t left;   // low-quality-tail bounds inside the surviving window (left > right: everything masked)
+  uint16_t right;
+  uint8_t cov;     // read-group covariate id
+  uint8_t fl;      // 1 eligible, 2 reversed, 4 last segment, 8 CIGAR in scratch
+};
+
+__global__ __launch_bounds__(256) void k_bqsr_prologue(BqCols m, uint32_t *__restrict__ cig_scratch, BqDesc *__restrict__ desc,
+                                                       uint32_t *skipbits, uint32_t *err) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m.n) return;
-  if (!recalibrate_aln(m, i)) return;
-  if (m.l_seq[i] > (uint32_t)MAX_BQSR_READ) { atomicOr(&err[0], 2u); return; }
+  BqDesc d;
+  d.pos = 0; d.cig = 0; d.ncig = 0; d.a = 0; d.len = 0; d.left = 0; d.right = 0; d.cov = 0; d.fl = 0;
+  if (!recalibrate_aln(m, i)) { desc[i] = d; return; }
+  if (m.l_seq[i] > (uint32_t)MAX_DESC_READ) { atomicOr(&err[0], 2u); desc[i] = d; return; }
   RAln a;
   a.pos = m.pos[i]; a.pnext = m.pnext[i]; a.tlen = m.tlen[i]; a.refid = m.refid[i]; a.next_refid = m.next_refid[i];
   a.flag = m.flag[i];
@@ -415,125 +95,389 @@ __global__ __launch_bounds__(256) void k_bqsr_gather(BqCols m, int max_cycle, ui
   uint32_t *sc = cig_scratch + 2 * (m.cigar_off[i] + 4 * i);
   a.buf[0] = sc; a.buf[1] = sc + (a.ncig + 4);
   a.cur = -1;
-  if (!hard_clip_adaptor(a)) { atomicOr(&err[0], 4u); return; }
-  if (a.len == 0) return;
+  if (!hard_clip_adaptor(a)) { atomicOr(&err[0], 4u); desc[i] = d; return; }
+  if (a.len == 0) { desc[i] = d; return; }
   hard_clip_soft_clipped(a);
-  if (a.len == 0) return;
+  if (a.len == 0) { desc[i] = d; return; }
 
-  const uint8_t *seq4 = m.seq4 + m.seq_off[i];
-  const uint8_t *qual = m.qual + m.qual_off[i];
-  uint32_t skip[MAX_BQSR_READ / 32], snp[MAX_BQSR_READ / 32];
-  const int nw = (a.len + 31) >> 5;
-  for (int w = 0; w < nw; w++) { skip[w] = 0; snp[w] = 0; }
-
-  // calculateSkipSlice :389-414
+  // calculateSkipSlice, bqsr.go:389-414: bits live at (qual_off[i] + original base index)
   {
     const int ss = soft_start(a), se = soft_end(a);
     const int32_t *sv = m.sites[a.refid];
     const int64_t ns = m.n_sites[a.refid];
     int64_t lo = 0, hi = ns;
     while (lo < hi) { const int64_t md = lo + (hi - lo) / 2; if (!(sv[2 * md + 1] >= ss)) lo = md + 1; else hi = md; }
-    int64_t first = lo;
+    const int64_t first = lo;
     lo = 0; hi = ns;
     while (lo < hi) { const int64_t md = lo + (hi - lo) / 2; if (!(sv[2 * md] > se)) lo = md + 1; else hi = md; }
     const int64_t last = lo;
+    const uint64_t bit0 = m.qual_off[i] + (uint64_t)a.off;
     for (int64_t s = first; s < last; s++) {
       bool ok;
       int fs = get_read_coord(a.cig, a.ncig, ss, sv[2 * s], false, &ok);
       if (!ok || fs < 0) fs = 0;
       int fe = get_read_coord(a.cig, a.ncig, ss, sv[2 * s + 1], false, &ok);
       if (!ok || fe > a.len - 1) fe = a.len - 1;
-      for (int k = fs; k <= fe; k++) skip[k >> 5] |= 1u << (k & 31);
-    }
-  }
-  // computeSnpEvents :254-285 (reference bytes past the contig end: the Go code panics; read as 'N' here)
-  {
-    const uint8_t *ref = m.ref_seq[a.refid];
-    const int64_t rlen = m.ref_seq_len[a.refid];
-    int ri = 0;
-    int64_t j = (int64_t)a.pos - 1;
-    for (int c = 0; c < a.ncig; c++) {
-      const uint32_t op = c_op(a.cig[c]);
-      const int ln = c_len(a.cig[c]);
-      if (op == OP_M || op == OP_EQ || op == OP_X) {
-        for (int k = 0; k < ln; k++, ri++, j++) {
-          if (ri >= a.len) continue;
-          const int rb = (j >= 0 && j < rlen) ? base_code_of_ref(ref[j]) : 0;
-          if (base_code_of_nibble(nibble_at(seq4, a.off + ri)) != rb) snp[ri >> 5] |= 1u << (ri & 31);
-        }
-      } else if (op == OP_D || op == OP_N) {
-        j += ln;
-      } else if (op == OP_I || op == OP_S) {
-        ri += ln;
+      for (int k = fs; k <= fe;) {  // set bits word by word
+        const uint64_t b = bit0 + (uint64_t)k;
+        const int in_word = (int)(b & 31);
+        int cnt = 32 - in_word;
+        if (cnt > fe - k + 1) cnt = fe - k + 1;
+        const uint32_t mask = (cnt == 32 ? 0xFFFFFFFFu : ((1u << cnt) - 1u)) << in_word;
+        atomicOr(&skipbits[b >> 5], mask);
+        k += cnt;
       }
     }
   }
-  const uint32_t cov = m.rg_cov[m.rgid[i]];
-  int cf, ci;
-  cycle_params(a.flag, a.len, &cf, &ci);
-  ReadView v{seq4, qual, a.off, a.len, (bool)(a.flag & F_REVERSED), 0, -1};
+  ReadView v{m.seq4 + m.seq_off[i], m.qual + m.qual_off[i], a.off, a.len, (bool)(a.flag & F_REVERSED), 0, -1};
   low_quality_bounds(v);
-  const int ncyc = 2 * max_cycle + 1;
-  for (int k = 0; k < a.len; k++) {
-    if (skip[k >> 5] & (1u << (k & 31))) continue;
-    if (base_index_of_nibble(nibble_at(seq4, a.off + k)) < 0) continue;
-    const uint32_t q = qual[a.off + k];
-    if (q < 6) continue;
-    if (q >= ELP_NQUAL) { atomicOr(&err[0], 8u); return; }
-    const unsigned long long e = (snp[k >> 5] >> (k & 31)) & 1u;
-    const size_t qi = (size_t)cov * ELP_NQUAL + q;
-    atomicAdd(&qual_tbl[2 * qi], 1ull);
-    if (e) atomicAdd(&qual_tbl[2 * qi + 1], 1ull);
-    const int cyc = cf + k * ci;
-    if (cyc > max_cycle || cyc < -max_cycle) { atomicOr(&err[0], 16u); return; }  // checkCycleCovariate :364-369
-    const size_t cyi = qi * ncyc + (size_t)(cyc + max_cycle);
-    atomicAdd(&cycle_tbl[2 * cyi], 1ull);
-    if (e) atomicAdd(&cycle_tbl[2 * cyi + 1], 1ull);
-    const int cx = context_key(v, k);
-    if (cx >= 0) {
-      const size_t xi = qi * ELP_NCTX + (size_t)((cx >> 4) & 15);
-      atomicAdd(&ctx_tbl[2 * xi], 1ull);
-      if (e) atomicAdd(&ctx_tbl[2 * xi + 1], 1ull);
+  d.pos = a.pos;
+  if (a.cur < 0) { d.cig = (uint32_t)m.cigar_off[i]; }
+  else { d.cig = (uint32_t)(a.buf[a.cur] - cig_scratch); d.fl |= 8; }
+  d.ncig = (uint16_t)a.ncig;
+  d.a = (uint16_t)a.off; d.len = (uint16_t)a.len;
+  d.left = (uint16_t)v.left; d.right = (uint16_t)(v.right < 0 ? 0xFFFF : v.right);
+  d.cov = (uint8_t)m.rg_cov[m.rgid[i]];
+  d.fl |= 1 | ((a.flag & F_REVERSED) ? 2 : 0) | ((a.flag & F_LAST) ? 4 : 0);
+  desc[i] = d;
+}
+
+struct QMap { uint8_t slot[96]; };  // quality value -> table slot of this pass, 255 = not in this pass
+
+struct CountArgs {
+  uint64_t n, qual_bytes;
+  const uint64_t *qual_off, *seq_off;
+  const uint8_t *qual, *seq4;
+  const int32_t *refid;
+  const BqDesc *desc;
+  const uint32_t *cigar, *cig_scratch;
+  const uint16_t *skip16;   // the skip-bit column viewed as 16-bit words (one per 16-byte QUAL chunk)
+  uint8_t *const *ref_seq;
+  const int64_t *ref_seq_len;
+  int n_cov, n_q, lmax, cs, s16, max_cycle;  // cs = 16 * s16 padded cycle row, s16 = ceil((2*lmax+1)/16)
+  uint32_t *partial;        // [grid][cyc cells * 2 + ctx cells * 2] u32
+  uint32_t *err;
+  const uint32_t *tile_first;
+};
+
+// 128-bit window over the packed bases of one record: nibble(k) for k in [kb, kb+32)
+struct SeqWin {
+  uint64_t v0, v1;
+  int kb;
+  __device__ __forceinline__ uint32_t nib(int k) const {
+    const int t = k - kb;           // 0..31
+    const int byte = t >> 1;
+    const uint64_t w = byte < 8 ? v0 : v1;
+    const uint32_t b = (uint32_t)(w >> (8 * (byte & 7))) & 0xFF;
+    return (t & 1) ? (b & 0xF) : (b >> 4);
+  }
+};
+__device__ __forceinline__ SeqWin load_seq_window(const uint8_t *__restrict__ seq, int k_first) {
+  SeqWin w;
+  w.kb = (k_first > 0 ? k_first : 0) & ~1;
+  const uint8_t *p = seq + (w.kb >> 1);
+  __builtin_memcpy(&w.v0, p, 8);
+  __builtin_memcpy(&w.v1, p + 8, 8);
+  return w;
+}
+
+__global__ __launch_bounds__(FL_THREADS) void k_bqsr_count(CountArgs A, QMap qm) {
+  __shared__ FlatLds L;
+  __shared__ BqDesc s_desc[FL_RMAX];
+  __shared__ uint64_t s_seq[FL_RMAX];
+  __shared__ int32_t s_ref[FL_RMAX];
+  extern __shared__ __attribute__((aligned(16))) uint32_t tbl[];  // cyc[n_cov*n_q*cs] | ctx_obs[n_cov*n_q*16] | ctx_mism[n_cov*n_q*16]
+  const int ncq = A.n_cov * A.n_q;
+  const int n_cyc = ncq * A.cs, n_ctx = ncq * 16;
+  uint32_t *t_cyc = tbl, *t_cobs = tbl + n_cyc, *t_cmis = t_cobs + n_ctx;
+  const int n_all = n_cyc + 2 * n_ctx;
+  for (int k = threadIdx.x; k < n_all; k += FL_THREADS) tbl[k] = 0;
+  uint32_t *part = A.partial + (size_t)blockIdx.x * (size_t)(2 * n_cyc + 2 * n_ctx);
+  __syncthreads();
+  uint32_t reads_since_flush = 0;
+  uint32_t my_err = 0;
+  auto flush = [&]() {
+    __syncthreads();
+    for (int k = threadIdx.x; k < n_cyc; k += FL_THREADS) {
+      const uint32_t v = t_cyc[k];
+      if (v) { part[2 * k] += v & 0xFFFF; part[2 * k + 1] += v >> 16; t_cyc[k] = 0; }
+    }
+    for (int k = threadIdx.x; k < n_ctx; k += FL_THREADS) {
+      const uint32_t o = t_cobs[k], e = t_cmis[k];
+      if (o) { part[2 * n_cyc + 2 * k] += o; t_cobs[k] = 0; }
+      if (e) { part[2 * n_cyc + 2 * k + 1] += e; t_cmis[k] = 0; }
+    }
+    __syncthreads();
+  };
+  const uint64_t ntiles = (A.qual_bytes + FL_TILE - 1) / FL_TILE;
+  for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const uint64_t tb = t * FL_TILE, te = (tb + FL_TILE < A.qual_bytes) ? tb + FL_TILE : A.qual_bytes;
+    reads_since_flush += flat_tile(A.qual_off, A.n, A.qual, tb, te, A.tile_first[t], A.tile_first[t + 1], L,
+              [&](uint32_t g0, uint32_t ng) __attribute__((always_inline)) {  // stage the group's descriptors in LDS (coalesced)
+                for (uint32_t k = threadIdx.x; k < ng; k += FL_THREADS) {
+                  s_desc[k] = A.desc[g0 + k];
+                  s_seq[k] = A.seq_off[g0 + k];
+                  s_ref[k] = A.refid[g0 + k];
+                }
+              },
+              [&](uint32_t rl, int k0, int k1, Chunk &ch, int o, uint64_t p) __attribute__((always_inline)) {
+                const BqDesc d = s_desc[rl];
+                if (!(d.fl & 1)) return;
+                int c0 = k0 - (int)d.a, c1 = k1 - (int)d.a;  // clipped coordinates
+                if (c0 < 0) c0 = 0;
+                if (c1 > (int)d.len) c1 = (int)d.len;
+                if (c0 >= c1) return;
+                const uint8_t *seq = A.seq4 + s_seq[rl];
+                const SeqWin sw = load_seq_window(seq, (int)d.a + c0 - 1);
+                const uint32_t skipw = A.skip16[p >> 4];
+                const int rf = s_ref[rl];
+                const uint8_t *ref = A.ref_seq[rf];
+                const int64_t rlen = A.ref_seq_len[rf];
+                const uint32_t *cg = ((d.fl & 8) ? A.cig_scratch : A.cigar) + d.cig;
+                const bool rev = d.fl & 2;
+                const int rof = (d.fl & 4) ? -1 : 1;
+                const int cf = rof + (rev ? ((int)d.len - 1) * rof : 0), ci = (rev ? -1 : 1) * rof;  // bqsr.go:376-383
+                const int left = d.left, right = d.right == 0xFFFF ? -1 : (int)d.right;
+                // walk the CIGAR to clipped base c0 (computeSnpEvents, bqsr.go:254-285)
+                int opi = 0, rem = 0;
+                bool ism = false;
+                int64_t j = (int64_t)d.pos - 1;
+                {
+                  int ri = 0;
+                  for (; opi < (int)d.ncig; opi++) {
+                    const uint32_t el = cg[opi];
+                    const uint32_t op = c_op(el);
+                    const int ln = c_len(el);
+                    if (op == OP_M || op == OP_EQ || op == OP_X) {
+                      if (c0 < ri + ln) { ism = true; rem = ri + ln - c0; j += c0 - ri; break; }
+                      ri += ln; j += ln;
+                    } else if (op == OP_D || op == OP_N) {
+                      j += ln;
+                    } else if (op == OP_I || op == OP_S) {
+                      if (c0 < ri + ln) { ism = false; rem = ri + ln - c0; break; }
+                      ri += ln;
+                    }
+                  }
+                }
+                const int row0 = (int)d.cov * A.n_q;
+                for (int c = c0; c < c1; c++) {
+                  // advance to the op that holds base c
+                  while (rem == 0 && opi < (int)d.ncig) {
+                    opi++;
+                    if (opi >= (int)d.ncig) break;
+                    const uint32_t el = cg[opi];
+                    const uint32_t op = c_op(el);
+                    if (op == OP_M || op == OP_EQ || op == OP_X) { ism = true; rem = c_len(el); }
+                    else if (op == OP_I || op == OP_S) { ism = false; rem = c_len(el); }
+                    else if (op == OP_D || op == OP_N) { j += c_len(el); }
+                  }
+                  const bool in_cigar = rem > 0;
+                  const int64_t jj = j;
+                  if (in_cigar) { rem--; if (ism) j++; }
+                  const int kk = (int)d.a + c;                 // original base index
+                  const int bi = o + (kk - k0);                // byte inside the lane's chunk
+                  if ((skipw >> bi) & 1u) continue;
+                  const uint32_t nb = sw.nib(kk);
+                  const int bidx = base_index_of_nibble(nb);
+                  if (bidx < 0) continue;
+                  const uint32_t q = ch.get(bi);
+                  if (q < 6) continue;
+                  if (q >= ELP_NQUAL) { my_err |= 8u; continue; }
+                  const uint32_t slot = qm.slot[q];
+                  if (slot == 255) continue;
+                  uint32_t e = 0;
+                  if (in_cigar && ism) {
+                    const int rb = (jj >= 0 && jj < rlen) ? base_code_of_ref(ref[jj]) : 0;
+                    e = (bidx + 1) != rb;
+                  }
+                  const int cyc = cf + c * ci;
+                  if (cyc > A.max_cycle || cyc < -A.max_cycle) { my_err |= 16u; continue; }  // checkCycleCovariate :364-369
+                  const int cidx = cyc + A.lmax;
+                  const int row = row0 + (int)slot;
+                  atomicAdd(&t_cyc[row * A.cs + (cidx & 15) * A.s16 + (cidx >> 4)], 1u | (e << 16));
+                  // context covariate (bqsr.go:87-146) of clipped base c
+                  int cx = -1;
+                  if (c >= left && c <= right) {
+                    const int cn = rev ? c + 1 : c - 1;
+                    if (cn >= left && cn <= right && cn >= 0 && cn < (int)d.len) {
+                      const int pn = base_index_of_nibble(sw.nib((int)d.a + cn));
+                      if (pn >= 0) cx = rev ? (((3 - pn)) | ((3 - bidx) << 2)) : (pn | (bidx << 2));
+                    }
+                  }
+                  if (cx >= 0) {
+                    atomicAdd(&t_cobs[row * 16 + cx], 1u);
+                    if (e) atomicAdd(&t_cmis[row * 16 + cx], 1u);
+                  }
+                }
+              },
+              [&](uint64_t, int, int, Chunk &) __attribute__((always_inline)) {}, [&](uint32_t, uint32_t) __attribute__((always_inline)) {});
+    if (reads_since_flush > 50000u) { flush(); reads_since_flush = 0; }
+  }
+  flush();
+  if (__any(my_err != 0)) {
+    for (int d = 32; d >= 1; d >>= 1) my_err |= __shfl_xor(my_err, d, 64);
+    if ((threadIdx.x & 63) == 0) atomicOr(&A.err[0], my_err);
+  }
+}
+
+// sums the per-workgroup partials into the dense tables; one thread per logical (cov, slot, cycle) / (cov, slot, ctx) cell
+__global__ __launch_bounds__(256) void k_bqsr_reduce(const uint32_t *__restrict__ partial, int nblk, int n_cov, int n_q, int lmax, int cs, int s16,
+                                                     int max_cycle, QMap slot_to_q, unsigned long long *cycle_tbl, unsigned long long *ctx_tbl) {
+  const int ncq = n_cov * n_q;
+  const int ncyc_l = 2 * lmax + 1;
+  const int n_cyc = ncq * cs, n_ctx = ncq * 16;
+  const size_t stride = (size_t)(2 * n_cyc + 2 * n_ctx);
+  const int total = ncq * ncyc_l + ncq * 16;
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= total) return;
+  const int ncyc_g = 2 * max_cycle + 1;
+  if (id < ncq * ncyc_l) {
+    const int row = id / ncyc_l, cidx = id % ncyc_l;
+    const size_t k = (size_t)row * cs + (size_t)(cidx & 15) * s16 + (cidx >> 4);
+    unsigned long long o = 0, e = 0;
+    for (int b = 0; b < nblk; b++) { o += partial[b * stride + 2 * k]; e += partial[b * stride + 2 * k + 1]; }
+    if (o | e) {
+      const int cov = row / n_q, q = slot_to_q.slot[row % n_q];
+      const int cyc = cidx - lmax;
+      const size_t g = (((size_t)cov * ELP_NQUAL + q) * ncyc_g + (size_t)(cyc + max_cycle)) * 2;
+      cycle_tbl[g] += o; cycle_tbl[g + 1] += e;
+    }
+  } else {
+    const int x = id - ncq * ncyc_l;
+    const int row = x / 16, cx = x % 16;
+    unsigned long long o = 0, e = 0;
+    for (int b = 0; b < nblk; b++) { o += partial[b * stride + 2 * n_cyc + 2 * x]; e += partial[b * stride + 2 * n_cyc + 2 * x + 1]; }
+    if (o | e) {
+      const int cov = row / n_q, q = slot_to_q.slot[row % n_q];
+      // cx = prev | cur << 2 is exactly (key >> 4) & 15 of keyFromContext (bqsr.go:64-76)
+      const size_t g = (((size_t)cov * ELP_NQUAL + q) * ELP_NCTX + (size_t)cx) * 2;
+      ctx_tbl[g] += o; ctx_tbl[g + 1] += e;
     }
   }
 }
 
-// ApplyBQSR per-read body, bqsr.go:947-1003
-__global__ __launch_bounds__(256) void k_bqsr_apply(uint64_t n, const uint16_t *__restrict__ flag, const uint16_t *__restrict__ rgid,
-                                                    const uint16_t *__restrict__ rg_cov, const uint32_t *__restrict__ l_seq,
-                                                    const uint64_t *__restrict__ seq_off, const uint8_t *__restrict__ seq4,
-                                                    const uint64_t *__restrict__ qual_off, uint8_t *__restrict__ qual, int max_cycle,
-                                                    const uint8_t *__restrict__ lut, const uint8_t *__restrict__ cov_present, uint32_t *err) {
+// QualityScores[cov][q] = sum over cycles of Cycles[cov][q][*]
+__global__ __launch_bounds__(256) void k_bqsr_qual_from_cycle(int n_rows, int ncyc_g, const unsigned long long *__restrict__ cycle_tbl,
+                                                              unsigned long long *__restrict__ qual_tbl) {
+  const int row = blockIdx.x;  // one workgroup per (cov, q)
+  if (row >= n_rows) return;
+  __shared__ unsigned long long so[256], se[256];
+  unsigned long long o = 0, e = 0;
+  for (int c = threadIdx.x; c < ncyc_g; c += 256) { o += cycle_tbl[((size_t)row * ncyc_g + c) * 2]; e += cycle_tbl[((size_t)row * ncyc_g + c) * 2 + 1]; }
+  so[threadIdx.x] = o; se[threadIdx.x] = e;
+  __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {
+    if ((int)threadIdx.x < d) { so[threadIdx.x] += so[threadIdx.x + d]; se[threadIdx.x] += se[threadIdx.x + d]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { qual_tbl[2 * row] = so[0]; qual_tbl[2 * row + 1] = se[0]; }
+}
+
+// ------------------------------------------------------------------ apply
+struct ApDesc { uint16_t left, right; uint8_t cov; uint8_t fl; };  // fl: 1 recalibrate, 2 reversed, 4 last
+
+__global__ __launch_bounds__(256) void k_apply_prologue(uint64_t n, const uint16_t *__restrict__ flag, const uint16_t *__restrict__ rgid,
+                                                        const uint16_t *__restrict__ rg_cov, const uint32_t *__restrict__ l_seq,
+                                                        const uint64_t *__restrict__ qual_off, const uint8_t *__restrict__ qual,
+                                                        const uint8_t *__restrict__ cov_present, ApDesc *__restrict__ desc, uint32_t *err) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  ApDesc d{0, 0, 0, 0};
   const uint16_t rg = rgid[i];
-  if (rg == ELP_NIL16) { atomicOr(&err[0], 32u); return; }  // readGroupCovariate panics, bqsr.go:38
+  if (rg == ELP_NIL16) { atomicOr(&err[0], 32u); desc[i] = d; return; }  // readGroupCovariate panics, bqsr.go:38
   const uint32_t cov = rg_cov[rg];
-  if (!cov_present[cov]) return;  // :953-955
+  if (!cov_present[cov]) { desc[i] = d; return; }  // :953-955
   const int len = (int)l_seq[i];
-  if ((uint64_t)len != qual_off[i + 1] - qual_off[i]) { atomicOr(&err[0], 64u); return; }
-  uint8_t *q = qual + qual_off[i];
+  if ((uint64_t)len != qual_off[i + 1] - qual_off[i]) { atomicOr(&err[0], 64u); desc[i] = d; return; }
+  if (len > MAX_DESC_READ) { atomicOr(&err[0], 2u); desc[i] = d; return; }
   const uint16_t f = flag[i];
-  ReadView v{seq4 + seq_off[i], q, 0, len, (bool)(f & F_REVERSED), 0, -1};
+  ReadView v{nullptr, qual + qual_off[i], 0, len, (bool)(f & F_REVERSED), 0, -1};
   low_quality_bounds(v);
-  int cf, ci;
-  cycle_params(f, len, &cf, &ci);
-  const int ncyc = 2 * max_cycle + 1;
-  for (int k = 0; k < len; k++) {
-    const uint32_t qq = q[k];
-    if (qq < 6) continue;
-    if (qq >= ELP_NQUAL) { atomicOr(&err[0], 8u); return; }
-    const int cyc = cf + k * ci;
-    if (cyc > max_cycle || cyc < -max_cycle) { atomicOr(&err[0], 16u); return; }
-    const int cx = context_key(v, k);
-    const size_t li = (((size_t)cov * ELP_NQUAL + qq) * ncyc + (size_t)(cyc + max_cycle)) * 17 + (size_t)(cx < 0 ? 16 : ((cx >> 4) & 15));
-    q[k] = lut[li];
+  d.left = (uint16_t)v.left; d.right = (uint16_t)(v.right < 0 ? 0xFFFF : v.right);
+  d.cov = (uint8_t)cov;
+  d.fl = 1 | ((f & F_REVERSED) ? 2 : 0) | ((f & F_LAST) ? 4 : 0);
+  desc[i] = d;
+}
+
+struct ApplyArgs {
+  uint64_t n, qual_bytes;
+  const uint64_t *qual_off, *seq_off;
+  uint8_t *qual;
+  const uint8_t *seq4;
+  const uint32_t *l_seq;
+  const ApDesc *desc;
+  const uint32_t *tile_first;
+  const uint8_t *lut;  // [n_cov][94][2*max_cycle+1][17]
+  int max_cycle;
+  uint32_t *err;
+};
+
+__global__ __launch_bounds__(FL_THREADS) void k_bqsr_apply_flat(ApplyArgs A) {
+  __shared__ FlatLds L;
+  __shared__ ApDesc s_desc[FL_RMAX];
+  __shared__ uint64_t s_seq[FL_RMAX];
+  __shared__ uint32_t s_len[FL_RMAX];
+  uint32_t my_err = 0;
+  const int ncyc = 2 * A.max_cycle + 1;
+  const uint64_t ntiles = (A.qual_bytes + FL_TILE - 1) / FL_TILE;
+  for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const uint64_t tb = t * FL_TILE, te = (tb + FL_TILE < A.qual_bytes) ? tb + FL_TILE : A.qual_bytes;
+    flat_tile(A.qual_off, A.n, A.qual, tb, te, A.tile_first[t], A.tile_first[t + 1], L,
+              [&](uint32_t g0, uint32_t ng) __attribute__((always_inline)) {
+                for (uint32_t k = threadIdx.x; k < ng; k += FL_THREADS) {
+                  s_desc[k] = A.desc[g0 + k];
+                  s_seq[k] = A.seq_off[g0 + k];
+                  s_len[k] = A.l_seq[g0 + k];
+                }
+              },
+              [&](uint32_t rl, int k0, int k1, Chunk &ch, int o, uint64_t) __attribute__((always_inline)) {
+                const ApDesc d = s_desc[rl];
+                if (!(d.fl & 1)) return;
+                const int len = (int)s_len[rl];
+                const SeqWin sw = load_seq_window(A.seq4 + s_seq[rl], k0 - 1);
+                const bool rev = d.fl & 2;
+                const int rof = (d.fl & 4) ? -1 : 1;
+                const int cf = rof + (rev ? (len - 1) * rof : 0), ci = (rev ? -1 : 1) * rof;
+                const int left = d.left, right = d.right == 0xFFFF ? -1 : (int)d.right;
+                const uint8_t *lc = A.lut + (size_t)d.cov * ELP_NQUAL * ncyc * 17;
+                for (int k = k0; k < k1; k++) {
+                  const int bi = o + (k - k0);
+                  const uint32_t q = ch.get(bi);
+                  if (q < 6) continue;
+                  if (q >= ELP_NQUAL) { my_err |= 8u; continue; }
+                  const int cyc = cf + k * ci;
+                  if (cyc > A.max_cycle || cyc < -A.max_cycle) { my_err |= 16u; continue; }
+                  int cx = 16;
+                  if (k >= left && k <= right) {
+                    const int kn = rev ? k + 1 : k - 1;
+                    if (kn >= left && kn <= right && kn >= 0 && kn < len) {
+                      const int pn = base_index_of_nibble(sw.nib(kn)), cu = base_index_of_nibble(sw.nib(k));
+                      if (pn >= 0 && cu >= 0) cx = rev ? ((3 - pn) | ((3 - cu) << 2)) : (pn | (cu << 2));
+                    }
+                  }
+                  ch.set(bi, lc[((size_t)q * ncyc + (size_t)(cyc + A.max_cycle)) * 17 + cx]);
+                }
+              },
+              [&](uint64_t p, int lo, int hi, Chunk &ch) __attribute__((always_inline)) {
+                if (lo == 0 && hi == FL_CHUNK) {
+                  uint4 v;
+                  v.x = (uint32_t)ch.w0; v.y = (uint32_t)(ch.w0 >> 32); v.z = (uint32_t)ch.w1; v.w = (uint32_t)(ch.w1 >> 32);
+                  *reinterpret_cast<uint4 *>(A.qual + p) = v;
+                } else {
+                  for (int b = lo; b < hi; b++) A.qual[p + b] = (uint8_t)ch.get(b);  // partial chunk: another lane may own the rest
+                }
+              },
+              [&](uint32_t, uint32_t) __attribute__((always_inline)) {});
+  }
+  if (__any(my_err != 0)) {
+    for (int d = 32; d >= 1; d >>= 1) my_err |= __shfl_xor(my_err, d, 64);
+    if ((threadIdx.x & 63) == 0) atomicOr(&A.err[0], my_err);
   }
 }
 
 static int bqsr_error(elp_ctx *c, uint32_t e) {
   ELP_HIP(c, hipMemsetAsync(c->err_flag.p, 0, 4, c->stream));
-  if (e & 2u) return set_error(c, ELP_ERR_UNSUPPORTED, "BQSR: read longer than %d bases", MAX_BQSR_READ);
+  if (e & 2u) return set_error(c, ELP_ERR_UNSUPPORTED, "BQSR: read longer than %d bases", MAX_DESC_READ);
   if (e & 4u) return set_error(c, ELP_ERR_DATA, "reference coordinate matches a non-existing base in read (reference: log.Panicf, filters/utils.go:253,262)");
   if (e & 8u) return set_error(c, ELP_ERR_DATA, "BQSR: base quality above 93");
   if (e & 16u) return set_error(c, ELP_ERR_DATA, "cycle value exceeds maximum cycle value (reference: log.Panic, filters/bqsr.go:364-369)");
@@ -557,6 +501,81 @@ static int sync_bqsr_ptrs(elp_ctx *c) {
     ELP_HIP(c, hipStreamSynchronize(c->stream));
   }
   c->bqsr_ptrs_dirty = false;
+  return 0;
+}
+
+static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cycle_tbl, int64_t *ctx_tbl) {
+  for (int r = 0; r < c->n_ref; r++)
+    if (!c->h_ref_seq[r]) return set_error(c, ELP_ERR_ARG, "elp_bqsr_gather: no reference sequence set for refid %d", r);
+  for (int r = 0; r < c->n_ref; r++)
+    if (!c->h_sites[r]) ELP_TRY(elp_bqsr_set_known_sites(c, r, nullptr, 0));
+  ELP_TRY(sync_bqsr_ptrs(c));
+  ELP_TRY(ensure_adapted(c));  // provides the set of quality values present (qual_present)
+  if (c->n_cov > 255) return set_error(c, ELP_ERR_UNSUPPORTED, "more than 255 read-group covariates");
+  if (c->cigar_ops + 4 * c->n >= 0x7FFFFFFFull) return set_error(c, ELP_ERR_UNSUPPORTED, "CIGAR pool exceeds 2^31 operations per context");
+  const int ncyc_g = 2 * max_cycle + 1;
+  const size_t nq = (size_t)c->n_cov * ELP_NQUAL * 2, nc = nq * ncyc_g, nx = nq * ELP_NCTX;
+  unsigned long long *tb;
+  ELP_TRY(scratch(c, 0, nq + nc + nx + 8, &tb));
+  hipStream_t st = c->stream;
+  ELP_HIP(c, hipMemsetAsync(tb, 0, (nq + nc + nx) * sizeof(unsigned long long), st));
+  const uint64_t n = c->n;
+  if (n && c->qual_bytes) {
+    uint32_t *cs_pool;
+    ELP_TRY(scratch(c, 1, 2 * (c->cigar_ops + 4 * n) + 64, &cs_pool));
+    BqDesc *desc;
+    ELP_TRY(scratch(c, 2, n + 4, &desc));
+    uint32_t *skipbits;
+    const size_t skip_words = (size_t)((c->qual_bytes + 31) / 32 + 8);
+    ELP_TRY(scratch(c, 3, skip_words, &skipbits));
+    ELP_HIP(c, hipMemsetAsync(skipbits, 0, skip_words * 4, st));
+    BqCols m{n, c->refid.p, c->pos.p, c->next_refid.p, c->pnext.p, c->tlen.p, c->flag.p, c->rgid.p, c->mapq.p, c->has_sr.p, c->l_seq.p,
+             c->cigar_off.p, c->seq_off.p, c->qual_off.p, c->cigar.p, c->seq4.p, c->qual.p, c->ref_len.p, c->rg_cov.p, c->n_ref,
+             c->d_ref_seq.p, c->d_ref_seq_len.p, c->d_sites.p, c->d_n_sites.p};
+    ELP_LAUNCH(c, "bqsr_prologue", k_bqsr_prologue, dim3(blocks_for(n, 256)), dim3(256), 0, m, cs_pool, desc, skipbits, c->err_flag.p);
+    // quality values present (>= 6, <= 93) -> passes of at most `qcap` slots so the private tables fit in LDS
+    std::vector<int> quals;
+    for (int q = 6; q < ELP_NQUAL; q++)
+      if ((q < 64 ? (c->qual_present[0] >> q) : (c->qual_present[1] >> (q - 64))) & 1ull) quals.push_back(q);
+    const int lmax = (int)std::max<uint32_t>(c->max_l_seq, 1);
+    const int s16 = (2 * lmax + 1 + 15) / 16, cs = 16 * s16;
+    // dynamic LDS for the private tables: 160 KiB per CU / 3 workgroups, minus the kernel's static LDS (offsets + descriptors)
+    const size_t static_lds = sizeof(FlatLds) + (size_t)FL_RMAX * (sizeof(BqDesc) + 8 + 4);
+    const size_t lds_budget = 53 * 1024 - static_lds - 256;
+    const size_t per_slot = (size_t)c->n_cov * ((size_t)cs + 32) * 4;
+    int qcap = (int)(lds_budget / std::max<size_t>(per_slot, 1));
+    if (qcap < 1) return set_error(c, ELP_ERR_UNSUPPORTED, "BQSR private tables do not fit in LDS (n_cov=%d, max read length=%d)", c->n_cov, lmax);
+    const uint64_t ntiles = (c->qual_bytes + FL_TILE - 1) / FL_TILE;
+    const int grid = (int)std::min<uint64_t>(ntiles, 768);  // 3 workgroups per CU
+    for (size_t q0 = 0; q0 < quals.size(); q0 += (size_t)qcap) {
+      const int nqs = (int)std::min<size_t>((size_t)qcap, quals.size() - q0);
+      QMap qm, s2q;
+      memset(qm.slot, 255, sizeof qm.slot);
+      memset(s2q.slot, 0, sizeof s2q.slot);
+      for (int s = 0; s < nqs; s++) { qm.slot[quals[q0 + s]] = (uint8_t)s; s2q.slot[s] = (uint8_t)quals[q0 + s]; }
+      const int ncq = c->n_cov * nqs;
+      const size_t cells = (size_t)ncq * cs + 2 * (size_t)ncq * 16;
+      const size_t part_words = (size_t)grid * (2 * (size_t)ncq * cs + 2 * (size_t)ncq * 16);
+      uint32_t *partial;
+      ELP_TRY(scratch(c, 4, part_words + 16, &partial));
+      ELP_HIP(c, hipMemsetAsync(partial, 0, part_words * 4, st));
+      CountArgs A{n, c->qual_bytes, c->qual_off.p, c->seq_off.p, c->qual.p, c->seq4.p, c->refid.p, desc, c->cigar.p, cs_pool,
+                  reinterpret_cast<const uint16_t *>(skipbits), c->d_ref_seq.p, c->d_ref_seq_len.p, c->n_cov, nqs, lmax, cs, s16, max_cycle,
+                  partial, c->err_flag.p, c->tile_first.p};
+      ELP_LAUNCH(c, "bqsr_count", k_bqsr_count, dim3(grid), dim3(FL_THREADS), cells * 4, A, qm);
+      const int total = ncq * (2 * lmax + 1) + ncq * 16;
+      ELP_LAUNCH(c, "bqsr_reduce", k_bqsr_reduce, dim3(blocks_for(total, 256)), dim3(256), 0, (const uint32_t *)partial, grid, c->n_cov, nqs, lmax, cs,
+                 s16, max_cycle, s2q, tb + nq, tb + nq + nc);
+    }
+    ELP_LAUNCH(c, "bqsr_qual_from_cycle", k_bqsr_qual_from_cycle, dim3(c->n_cov * ELP_NQUAL), dim3(256), 0, c->n_cov * ELP_NQUAL, ncyc_g,
+               (const unsigned long long *)(tb + nq), tb);
+  }
+  ELP_HIP(c, hipMemcpyAsync(qual_tbl, tb, nq * 8, hipMemcpyDeviceToHost, st));
+  ELP_HIP(c, hipMemcpyAsync(cycle_tbl, tb + nq, nc * 8, hipMemcpyDeviceToHost, st));
+  ELP_HIP(c, hipMemcpyAsync(ctx_tbl, tb + nq + nc, nx * 8, hipMemcpyDeviceToHost, st));
+  uint32_t e[4];
+  ELP_TRY(fetch_err(c, e));
+  if (e[0]) return bqsr_error(c, e[0]);
   return 0;
 }
 
@@ -599,37 +618,13 @@ int elp_bqsr_set_known_sites(elp_ctx *c, int32_t refid, const int32_t *start_end
 int elp_bqsr_gather(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cycle_tbl, int64_t *ctx_tbl) {
   if (!c || !qual_tbl || !cycle_tbl || !ctx_tbl || max_cycle < 1) return set_error(c, ELP_ERR_ARG, "elp_bqsr_gather: bad arguments");
   ELP_HIP(c, hipSetDevice(c->device));
-  for (int r = 0; r < c->n_ref; r++)
-    if (!c->h_ref_seq[r]) return set_error(c, ELP_ERR_ARG, "elp_bqsr_gather: no reference sequence set for refid %d", r);
-  for (int r = 0; r < c->n_ref; r++)
-    if (!c->h_sites[r]) ELP_TRY(elp_bqsr_set_known_sites(c, r, nullptr, 0));
-  ELP_TRY(sync_bqsr_ptrs(c));
-  const int ncyc = 2 * max_cycle + 1;
-  const size_t nq = (size_t)c->n_cov * ELP_NQUAL * 2, nc = nq * ncyc, nx = nq * ELP_NCTX;
-  unsigned long long *tb;
-  ELP_TRY(scratch(c, 0, nq + nc + nx + 8, &tb));
-  ELP_HIP(c, hipMemsetAsync(tb, 0, (nq + nc + nx) * sizeof(unsigned long long), c->stream));
-  const uint64_t n = c->n;
-  if (n) {
-    uint32_t *cs;
-    ELP_TRY(scratch(c, 1, 2 * (c->cigar_ops + 4 * n) + 64, &cs));
-    BqCols m{n, c->refid.p, c->pos.p, c->next_refid.p, c->pnext.p, c->tlen.p, c->flag.p, c->rgid.p, c->mapq.p, c->has_sr.p, c->l_seq.p,
-             c->cigar_off.p, c->seq_off.p, c->qual_off.p, c->cigar.p, c->seq4.p, c->qual.p, c->ref_len.p, c->rg_cov.p, c->n_ref,
-             c->d_ref_seq.p, c->d_ref_seq_len.p, c->d_sites.p, c->d_n_sites.p};
-    ELP_LAUNCH(c, "bqsr_gather", k_bqsr_gather, dim3(blocks_for(n, 256)), dim3(256), 0, m, max_cycle, cs, tb, tb + nq, tb + nq + nc, c->err_flag.p);
-  }
-  ELP_HIP(c, hipMemcpyAsync(qual_tbl, tb, nq * 8, hipMemcpyDeviceToHost, c->stream));
-  ELP_HIP(c, hipMemcpyAsync(cycle_tbl, tb + nq, nc * 8, hipMemcpyDeviceToHost, c->stream));
-  ELP_HIP(c, hipMemcpyAsync(ctx_tbl, tb + nq + nc, nx * 8, hipMemcpyDeviceToHost, c->stream));
-  uint32_t e[4];
-  ELP_TRY(fetch_err(c, e));
-  if (e[0]) return bqsr_error(c, e[0]);
-  return 0;
+  return gather_impl(c, max_cycle, qual_tbl, cycle_tbl, ctx_tbl);
 }
 
 int elp_bqsr_apply(elp_ctx *c, int max_cycle, const uint8_t *lut, const uint8_t *cov_present) {
   if (!c || !lut || !cov_present || max_cycle < 1) return set_error(c, ELP_ERR_ARG, "elp_bqsr_apply: bad arguments");
   ELP_HIP(c, hipSetDevice(c->device));
+  if (c->n_cov > 255) return set_error(c, ELP_ERR_UNSUPPORTED, "more than 255 read-group covariates");
   const size_t ncyc = 2 * (size_t)max_cycle + 1;
   const size_t lut_bytes = (size_t)c->n_cov * ELP_NQUAL * ncyc * 17;
   uint8_t *dl;
@@ -638,9 +633,18 @@ int elp_bqsr_apply(elp_ctx *c, int max_cycle, const uint8_t *lut, const uint8_t 
   ELP_HIP(c, hipMemcpyAsync(dl + lut_bytes, cov_present, (size_t)c->n_cov, hipMemcpyHostToDevice, c->stream));
   const uint64_t n = c->n;
   if (n) {
-    ELP_LAUNCH(c, "bqsr_apply", k_bqsr_apply, dim3(blocks_for(n, 256)), dim3(256), 0, n, (const uint16_t *)c->flag.p, (const uint16_t *)c->rgid.p,
-               (const uint16_t *)c->rg_cov.p, (const uint32_t *)c->l_seq.p, (const uint64_t *)c->seq_off.p, (const uint8_t *)c->seq4.p,
-               (const uint64_t *)c->qual_off.p, c->qual.p, max_cycle, (const uint8_t *)dl, (const uint8_t *)(dl + lut_bytes), c->err_flag.p);
+    ApDesc *desc;
+    ELP_TRY(scratch(c, 2, n + 4, &desc));
+    ELP_LAUNCH(c, "bqsr_apply_prologue", k_apply_prologue, dim3(blocks_for(n, 256)), dim3(256), 0, n, (const uint16_t *)c->flag.p,
+               (const uint16_t *)c->rgid.p, (const uint16_t *)c->rg_cov.p, (const uint32_t *)c->l_seq.p, (const uint64_t *)c->qual_off.p,
+               (const uint8_t *)c->qual.p, (const uint8_t *)(dl + lut_bytes), desc, c->err_flag.p);
+    if (c->qual_bytes) {
+      const uint64_t ntiles = (c->qual_bytes + FL_TILE - 1) / FL_TILE;
+      const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * 8);
+      ELP_TRY(ensure_flat_index(c));
+      ApplyArgs A{n, c->qual_bytes, c->qual_off.p, c->seq_off.p, c->qual.p, c->seq4.p, c->l_seq.p, desc, c->tile_first.p, dl, max_cycle, c->err_flag.p};
+      ELP_LAUNCH(c, "bqsr_apply", k_bqsr_apply_flat, dim3(grid), dim3(FL_THREADS), 0, A);
+    }
   }
   uint32_t e[4];
   ELP_TRY(fetch_err(c, e));

@@ -82,10 +82,13 @@ struct elp_ctx {
 
   // derived state
   bool adapted = false, sorted = false, marked = false;
+  unsigned long long qual_present[2] = {0, 0};  // bit q set iff quality value q occurs in the staged QUAL column (valid when adapted)
   elp::DVec<int32_t> upos, score;
   elp::DVec<uint64_t> key;      // coordinate sort keys, staging order
   elp::DVec<uint32_t> perm;     // sorted position -> staging index
   elp::DVec<uint32_t> err_flag; // device-side error word(s)
+  elp::DVec<uint32_t> tile_first;  // flat.hpp tile index over the QUAL column
+  uint64_t flat_index_n = 0, flat_index_bytes = 0;
 
   // mark-duplicates results kept for the metrics pass
   elp::DVec<uint32_t> mate;        // per record: staging index of its mate if the two form a pair (classifyPair), else 0xFFFFFFFF
@@ -103,6 +106,12 @@ struct elp_ctx {
   elp::DVec<int32_t *> d_sites;
   elp::DVec<int64_t> d_n_sites;
   bool bqsr_ptrs_dirty = true;
+
+  // snapshot of the mutable columns
+  elp::DVec<uint16_t> snap_flag;
+  elp::DVec<uint8_t> snap_qual;
+  uint64_t snap_n = 0, snap_qual_bytes = 0;
+  bool have_snapshot = false;
 
   // generic scratch pool (grown on demand, reused between calls)
   elp::DVec<uint8_t> scratch[8];

@@ -173,6 +173,8 @@ int elp_reset(elp_ctx *c) {
   c->n = c->qname_bytes = c->cigar_ops = c->seq_bytes = c->qual_bytes = 0;
   c->max_qname_len = c->max_l_seq = 0;
   c->adapted = c->sorted = c->marked = false;
+  c->have_snapshot = false;
+  c->flat_index_n = 0;
   return 0;
 }
 
@@ -230,6 +232,8 @@ int elp_stage(elp_ctx *c, const elp_batch *b) {
   ELP_HIP(c, hipStreamSynchronize(st));  // host buffers may be reused on return
   c->n += n; c->qname_bytes += qb; c->cigar_ops += co; c->seq_bytes += sb; c->qual_bytes += lb;
   c->adapted = c->sorted = c->marked = false;
+  c->have_snapshot = false;
+  c->flat_index_n = 0;
   return 0;
 }
 
@@ -260,6 +264,29 @@ int elp_get_adapted(elp_ctx *c, int32_t *upos, int32_t *score) {
 int elp_get_qual(elp_ctx *c, uint8_t *out) {
   if (!c || (!out && c->qual_bytes)) return ELP_ERR_ARG;
   return d2h(c, out, c->qual.p, c->qual_bytes);
+}
+
+int elp_snapshot(elp_ctx *c) {
+  if (!c) return ELP_ERR_ARG;
+  ELP_HIP(c, hipSetDevice(c->device));
+  ELP_TRY(ensure(c, c->snap_flag, c->n + 1));
+  ELP_TRY(ensure(c, c->snap_qual, c->qual_bytes + 16));
+  if (c->n) ELP_HIP(c, hipMemcpyAsync(c->snap_flag.p, c->flag.p, c->n * sizeof(uint16_t), hipMemcpyDeviceToDevice, c->stream));
+  if (c->qual_bytes) ELP_HIP(c, hipMemcpyAsync(c->snap_qual.p, c->qual.p, c->qual_bytes, hipMemcpyDeviceToDevice, c->stream));
+  c->snap_n = c->n;
+  c->snap_qual_bytes = c->qual_bytes;
+  c->have_snapshot = true;
+  return 0;
+}
+int elp_rollback(elp_ctx *c) {
+  if (!c) return ELP_ERR_ARG;
+  if (!c->have_snapshot || c->snap_n != c->n || c->snap_qual_bytes != c->qual_bytes)
+    return set_error(c, ELP_ERR_ARG, "elp_rollback: no snapshot of the current record set");
+  ELP_HIP(c, hipSetDevice(c->device));
+  if (c->n) ELP_HIP(c, hipMemcpyAsync(c->flag.p, c->snap_flag.p, c->n * sizeof(uint16_t), hipMemcpyDeviceToDevice, c->stream));
+  if (c->qual_bytes) ELP_HIP(c, hipMemcpyAsync(c->qual.p, c->snap_qual.p, c->qual_bytes, hipMemcpyDeviceToDevice, c->stream));
+  c->adapted = c->sorted = c->marked = false;
+  return 0;
 }
 
 int elp_profile_enable(elp_ctx *c, int on) {

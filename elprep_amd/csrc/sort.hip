@@ -10,17 +10,18 @@
 //            larger runs (the unmapped block, pile-ups): LSD radix over the zero-padded comparator byte string,
 //            8 bytes per round, then one stable round on the run id.
 #include "common.hpp"
+#include "flat.hpp"
 
 namespace elp {
 
 constexpr int TIE_SMALL = 48;
 
 // ------------------------------------------------------------------ adapt
-__global__ __launch_bounds__(256) void k_adapt(uint64_t n, const int32_t *__restrict__ pos, const int32_t *__restrict__ refid,
-                                               const uint16_t *__restrict__ flag, const uint64_t *__restrict__ cigar_off,
-                                               const uint32_t *__restrict__ cigar, const uint64_t *__restrict__ qual_off,
-                                               const uint8_t *__restrict__ qual, int32_t *__restrict__ upos, int32_t *__restrict__ score,
-                                               uint64_t *__restrict__ key, uint32_t *__restrict__ err) {
+// fixed-field part: unclipped 5' position (computeUnclippedPosition :79-110) and the CoordinateLess primary key
+__global__ __launch_bounds__(256) void k_adapt_fixed(uint64_t n, const int32_t *__restrict__ pos, const int32_t *__restrict__ refid,
+                                                     const uint16_t *__restrict__ flag, const uint64_t *__restrict__ cigar_off,
+                                                     const uint32_t *__restrict__ cigar, int32_t *__restrict__ upos, int32_t *__restrict__ score,
+                                                     uint64_t *__restrict__ key) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint16_t f = flag[i];
@@ -29,7 +30,7 @@ __global__ __launch_bounds__(256) void k_adapt(uint64_t n, const int32_t *__rest
   // CoordinateLess primary key: REFID ascending with negative last (:429-432), POS (:433-436), forward before reverse (:437-438)
   const uint64_t ru = r < 0 ? 0x7FFFFFFFull : (uint64_t)(uint32_t)r;
   key[i] = (ru << 33) | ((uint64_t)(uint32_t)p << 1) | ((f & F_REVERSED) ? 1ull : 0ull);
-  int32_t up = 0, sc = 0;
+  int32_t up = 0;
   if ((f & (F_UNMAPPED | F_SECONDARY | F_SUPPLEMENTARY)) == 0) {  // mark-duplicates.go:427,436
     const uint64_t c0 = cigar_off[i], c1 = cigar_off[i + 1];
     up = p;
@@ -54,31 +55,113 @@ __global__ __launch_bounds__(256) void k_adapt(uint64_t n, const int32_t *__rest
         }
       }
     }
-    // computePhredScore :57-68: sum of qualities >= 15; any quality > 93 is an error
-    const uint64_t q0 = qual_off[i], q1 = qual_off[i + 1];
-    bool bad = false;
-    for (uint64_t k = q0; k < q1; k++) {
-      const uint32_t q = qual[k];
-      bad |= q > 93;
-      sc += (q >= 15 && q <= 93) ? (int32_t)q : 0;
-    }
-    if (bad) atomicOr(&err[0], 1u);
   }
   upos[i] = up;
-  score[i] = sc;
+  score[i] = 0;
+}
+
+// computePhredScore :57-68 as a flat stream over the QUAL column: sum of qualities >= 15 per duplicate-marking candidate;
+// any quality > 93 in a candidate is an error.  Also ORs the set of quality values present into qmask[2] (bit q).
+__global__ __launch_bounds__(FL_THREADS) void k_score_flat(uint64_t n, const uint64_t *__restrict__ qual_off, const uint8_t *__restrict__ qual,
+                                                           uint64_t qual_bytes, const uint32_t *__restrict__ tile_first,
+                                                           const uint16_t *__restrict__ flag, int32_t *score, unsigned long long *qmask,
+                                                           uint32_t *err) {
+  __shared__ FlatLds L;
+  __shared__ int32_t acc[FL_RMAX];   // per-read partial sums of this group (LDS atomics; one global atomic per read and tile)
+  __shared__ uint8_t cand[FL_RMAX];  // duplicate-marking candidate?
+  unsigned long long m0 = 0, m1 = 0;
+  bool bad = false;
+  const uint64_t ntiles = (qual_bytes + FL_TILE - 1) / FL_TILE;
+  for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const uint64_t tb = t * FL_TILE, te = (tb + FL_TILE < qual_bytes) ? tb + FL_TILE : qual_bytes;
+    flat_tile(qual_off, n, qual, tb, te, tile_first[t], tile_first[t + 1], L,
+              [&](uint32_t g0, uint32_t ng) __attribute__((always_inline)) {
+                for (uint32_t k = threadIdx.x; k < ng; k += FL_THREADS) {
+                  acc[k] = 0;
+                  cand[k] = (flag[g0 + k] & (F_UNMAPPED | F_SECONDARY | F_SUPPLEMENTARY)) == 0;
+                }
+              },
+              [&](uint32_t rl, int k0, int k1, Chunk &ch, int o, uint64_t) __attribute__((always_inline)) {
+                const bool cd = cand[rl];
+                int32_t s = 0;
+                for (int k = k0; k < k1; k++) {
+                  const uint32_t q = ch.get(o + k - k0);
+                  // branch-free on purpose: "if (q < 64) m0 |= .. else m1 |= .." is turned into a dynamically indexed private
+                  // array by the compiler, i.e. a scratch-memory read-modify-write per base
+                  const unsigned long long bit = 1ull << ((q < 128 ? q : 127u) & 63u);
+                  m0 |= (q < 64) ? bit : 0ull;
+                  m1 |= (q < 64) ? 0ull : bit;
+                  if (q > 93) bad |= cd;
+                  else if (q >= 15) s += (int32_t)q;
+                }
+                if (cd && s) atomicAdd(&acc[rl], s);
+              },
+              [&](uint64_t, int, int, Chunk &) __attribute__((always_inline)) {},
+              [&](uint32_t g0, uint32_t ng) __attribute__((always_inline)) {
+                for (uint32_t k = threadIdx.x; k < ng; k += FL_THREADS)
+                  if (acc[k]) atomicAdd(&score[g0 + k], acc[k]);  // a read can span two tiles / groups
+              });
+  }
+  // wave-reduce the presence masks
+  for (int d = 32; d >= 1; d >>= 1) {
+    m0 |= __shfl_xor(m0, d, 64);
+    m1 |= __shfl_xor(m1, d, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (m0) atomicOr(&qmask[0], m0);
+    if (m1) atomicOr(&qmask[1], m1);
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&err[0], 1u);
+}
+
+// tile_first[t] = last read r (0 <= r <= n) with qual_off[r] <= t * FL_TILE, for t in [0, ntiles]
+__global__ __launch_bounds__(256) void k_flat_index(const uint64_t *__restrict__ qual_off, uint64_t n_reads, uint64_t ntiles,
+                                                    uint32_t *__restrict__ tile_first) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t > ntiles) return;
+  const uint64_t x = t * FL_TILE;
+  uint64_t lo = 0, hi = n_reads + 1;  // invariant: qual_off[lo] <= x (qual_off[0] == 0)
+  while (hi - lo > 1) {
+    const uint64_t mid = lo + (hi - lo) / 2;
+    if (qual_off[mid] <= x) lo = mid; else hi = mid;
+  }
+  tile_first[t] = (uint32_t)lo;
+}
+
+int ensure_flat_index(elp_ctx *c) {
+  if (c->flat_index_n == c->n && c->flat_index_bytes == c->qual_bytes && c->n) return 0;
+  const uint64_t ntiles = (c->qual_bytes + FL_TILE - 1) / FL_TILE;
+  ELP_TRY(ensure(c, c->tile_first, ntiles + 2));
+  if (c->n)
+    ELP_LAUNCH(c, "flat_index", k_flat_index, dim3(blocks_for(ntiles + 1, 256)), dim3(256), 0, (const uint64_t *)c->qual_off.p, c->n, ntiles,
+               c->tile_first.p);
+  c->flat_index_n = c->n;
+  c->flat_index_bytes = c->qual_bytes;
+  return 0;
 }
 
 int ensure_adapted(elp_ctx *c) {
   if (c->adapted) return 0;
   ELP_HIP(c, hipSetDevice(c->device));
   uint64_t n = c->n;
+  ELP_TRY(ensure_flat_index(c));
   ELP_TRY(ensure(c, c->upos, n + 1));
   ELP_TRY(ensure(c, c->score, n + 1));
   ELP_TRY(ensure(c, c->key, n + 1));
+  c->qual_present[0] = c->qual_present[1] = 0;
   if (n) {
-    ELP_LAUNCH(c, "adapt", k_adapt, dim3(blocks_for(n, 256)), dim3(256), 0, n, (const int32_t *)c->pos.p, (const int32_t *)c->refid.p,
-               (const uint16_t *)c->flag.p, (const uint64_t *)c->cigar_off.p, (const uint32_t *)c->cigar.p, (const uint64_t *)c->qual_off.p,
-               (const uint8_t *)c->qual.p, c->upos.p, c->score.p, c->key.p, c->err_flag.p);
+    ELP_LAUNCH(c, "adapt_fixed", k_adapt_fixed, dim3(blocks_for(n, 256)), dim3(256), 0, n, (const int32_t *)c->pos.p, (const int32_t *)c->refid.p,
+               (const uint16_t *)c->flag.p, (const uint64_t *)c->cigar_off.p, (const uint32_t *)c->cigar.p, c->upos.p, c->score.p, c->key.p);
+    unsigned long long *qm;
+    ELP_TRY(scratch(c, 6, 4, &qm));
+    ELP_HIP(c, hipMemsetAsync(qm, 0, 16, c->stream));
+    if (c->qual_bytes) {
+      const uint64_t ntiles = (c->qual_bytes + FL_TILE - 1) / FL_TILE;
+      const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * 8);
+      ELP_LAUNCH(c, "adapt_score", k_score_flat, dim3(grid), dim3(FL_THREADS), 0, n, (const uint64_t *)c->qual_off.p, (const uint8_t *)c->qual.p,
+                 c->qual_bytes, (const uint32_t *)c->tile_first.p, (const uint16_t *)c->flag.p, c->score.p, qm, c->err_flag.p);
+    }
+    ELP_HIP(c, hipMemcpyAsync(c->qual_present, qm, 16, hipMemcpyDeviceToHost, c->stream));
     uint32_t e[4];
     ELP_TRY(fetch_err(c, e));
     if (e[0] & 1u) {

@@ -78,6 +78,12 @@ class Engine:
         self._check(self.L.elp_reset(self.h))
         self._qual_bytes = 0
 
+    def snapshot(self):
+        self._check(self.L.elp_snapshot(self.h))
+
+    def rollback(self):
+        self._check(self.L.elp_rollback(self.h))
+
     def sync(self):
         self._check(self.L.elp_sync(self.h))
 

@@ -143,6 +143,13 @@ int elp_bqsr_gather(elp_ctx *ctx, int max_cycle, int64_t *qual_tbl, int64_t *cyc
 int elp_bqsr_apply(elp_ctx *ctx, int max_cycle, const uint8_t *lut, const uint8_t *cov_present);
 int elp_get_qual(elp_ctx *ctx, uint8_t *qual_out /* qual_bytes, staging order and offsets */);
 
+/* ---- snapshot of the two columns the path mutates (FLAG by elp_mark_duplicates, QUAL by elp_bqsr_apply) ----
+ * elp_snapshot copies them aside in HBM; elp_rollback restores them and invalidates derived state (sort keys, scores,
+ * duplicate tables).  Lets a host re-run the path on identical input (bench.py's timed steps; `--bqsr-tables-only`
+ * style what-if runs) without re-staging over PCIe. */
+int elp_snapshot(elp_ctx *ctx);
+int elp_rollback(elp_ctx *ctx);
+
 /* ---- measurement ----
  * With profiling on, every kernel launch is bracketed by hipEvents on the ctx stream; elp_profile_get returns, per
  * kernel name, the launch count and the summed duration in milliseconds. */
