@@ -84,18 +84,34 @@ def main():
     # ---- generate the shard and stage it (untimed; PCIe-inclusive staging rate reported separately)
     eng = Engine(hdr, local_rank if world > 1 else 0)
     t0 = time.time()
-    chunk = 2_000_000
+    chunk = 1_000_000
     n_total = 0
     stage_s = 0.0
     qual_bytes = 0
-    for lo in range(p_lo, p_hi, chunk):
-        b = synth.generate(cfg, lo, min(lo + chunk, p_hi))
-        ts = time.time()
-        eng.stage(b)
-        stage_s += time.time() - ts
-        n_total += b.n
-        qual_bytes += int(b.qual_off[-1])
-        del b
+    # the generator is deterministic per pair index, so chunks are produced by a small thread pool (ctypes releases the
+    # GIL) and staged strictly in order
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+    workers = max(1, min(12, (os.cpu_count() or 2) // max(world, 1)))
+    ranges = [(lo, min(lo + chunk, p_hi)) for lo in range(p_lo, p_hi, chunk)]
+    with ThreadPoolExecutor(workers) as pool:
+        q = deque()
+        it = iter(ranges)
+        for _ in range(workers + 1):
+            r = next(it, None)
+            if r is not None:
+                q.append(pool.submit(synth.generate, cfg, r[0], r[1]))
+        while q:
+            b = q.popleft().result()
+            r = next(it, None)
+            if r is not None:
+                q.append(pool.submit(synth.generate, cfg, r[0], r[1]))
+            ts = time.time()
+            eng.stage(b)
+            stage_s += time.time() - ts
+            n_total += b.n
+            qual_bytes += int(b.qual_off[-1])
+            del b
     gen_s = time.time() - t0 - stage_s
     for r in range(hdr.n_ref):
         eng.set_reference(r, synth.reference(cfg, r))
