@@ -3,17 +3,20 @@
 // Reference: BaseRecalibrator.Recalibrate (filters/bqsr.go:467-551), BaseRecalibratorTables.ApplyBQSR (:936-1005); device
 // helpers (clipping, covariates) and their citations are in bqsr_dev.hpp.
 //
-// Gather = three kernels
+// Gather = two kernels
 //   bqsr_prologue  one thread per record: eligibility (recalibrateAln), adaptor + soft-clip hard clipping on a working copy,
-//                  known-site skip mask (calculateSkipSlice) written into a 1-bit-per-base column, low-quality-tail bounds;
-//                  leaves a 20-byte descriptor per record and the rewritten CIGAR in scratch.
-//   bqsr_count     flat stream over QUAL/SEQ (flat.hpp): one lane per 16 bases; SNP event against the reference, cycle and
-//                  context covariates, then ONE packed LDS atomic per base into a workgroup-private cycle table
-//                  (observations in the low, mismatches in the high 16 bits) and one into the private context table.
-//                  Private tables are flushed into per-workgroup partial tables in HBM (plain stores, no atomics).
-//   bqsr_reduce    sums the partial tables into the dense int64 tables of the C ABI; the QualityScores table is the sum of the
-//                  Cycles table over cycles (every counted base updates both with the same (read group, quality)).
-// Apply = a small per-record prologue (low-quality bounds) + a flat per-base LUT kernel that rewrites QUAL in place.
+//                  known-site skip mask (calculateSkipSlice) written into a 1-bit-per-base column, low-quality-tail bounds, and
+//                  the clipped CIGAR folded into <= 3 (clipped base -> reference index) pieces; leaves a 32-byte descriptor.
+//   bqsr_count     flat stream over QUAL/SEQ (flat.hpp): one lane per 16 bases.  Per chunk, SWAR in nibble space gives the
+//                  eligible-base flags, the SNP flags (one XOR of 16 read nibbles with 16 nibbles of the 4-bit packed
+//                  reference), the cycle parameters and the 16 context keys; then per counted base ONE packed 32-bit LDS
+//                  atomic into the workgroup-private cycle table and ONE 64-bit LDS atomic into the private context table.
+//                  Private tables are added into the dense int64 tables in HBM with global atomics when a workgroup is done
+//                  (and every 50000 reads).  QualityScores is the sum of the Cycles table over cycles.
+// Apply = a small per-record prologue (low-quality bounds) + a flat per-base LUT kernel that rewrites QUAL in place (16
+// independent byte gathers from the L2-resident LUT per lane and chunk).
+#include <utility>
+
 #include "bqsr_dev.hpp"
 #include "flat.hpp"
 
@@ -65,25 +68,75 @@ __device__ inline bool recalibrate_aln(const BqCols &m, uint64_t i) {
   return refl >= 0 && (int32_t)ls == rl;
 }
 
-// per-record descriptor produced by the prologue
-struct BqDesc {
-  int32_t pos;     // POS of the clipped working copy
-  uint32_t cig;    // index of its CIGAR: into the scratch CIGAR pool (fl & 8) or into the staged cigar column
-  uint16_t ncig;
+// per-record descriptor produced by the prologue (32 bytes, staged into LDS by k_bqsr_count)
+//
+// The clipped working copy of an eligible record is the base window [a, a+len) of the original read, and the mapping of its
+// bases to the reference (computeSnpEvents, bqsr.go:254-285) is piecewise: clipped base c in piece k = [B_k, B_k+1) (B_0 = 0,
+// B_1 = b1, B_2 = b2, B_3 = infinity) lies at 0-based reference index D_k + c, or has no reference base (insertion) if
+// D_k == BQ_NOREF.  A clipped CIGAR of the form M, M I M, M D M, I M ... needs at most three pieces; records that need more
+// are flagged BQ_COMPLEX and walk their CIGAR in the kernel (D0 = CIGAR index, b1 = op count, D2 = POS - 1).
+constexpr int32_t BQ_NOREF = INT32_MIN;
+enum : uint8_t { BQ_ELIGIBLE = 1, BQ_REVERSED = 2, BQ_LAST = 4, BQ_CIG_SCRATCH = 8, BQ_COMPLEX = 16 };
+struct __attribute__((aligned(16))) BqDesc {
+  int32_t D0, D1, D2;
+  int32_t refid;
+  uint16_t b1, b2;
   uint16_t a;      // first surviving base (original read coordinates)
   uint16_t len;    // surviving bases; 0 = record contributes nothing
   uint16_t left;   // low-quality-tail bounds inside the surviving window (left > right: everything masked)
-  uint16_t right;
+  uint16_t right;  // 0xFFFF = -1
   uint8_t cov;     // read-group covariate id
-  uint8_t fl;      // 1 eligible, 2 reversed, 4 last segment, 8 CIGAR in scratch
+  uint8_t fl;
+  uint16_t pad;
 };
+static_assert(sizeof(BqDesc) == 32, "BqDesc is staged as two 16-byte words");
+
+// pieces of the clipped CIGAR; false if it needs more than three
+__device__ inline bool build_pieces(const uint32_t *cig, int ncig, int32_t pos, BqDesc &d) {
+  int64_t val[3];
+  bool noref[3];
+  int start[3];
+  int np = 0;
+  int c = 0;
+  int64_t delta = (int64_t)pos - 1;  // reference index minus clipped read index for the current match run
+  for (int i = 0; i < ncig; i++) {
+    const uint32_t op = c_op(cig[i]);
+    const int ln = c_len(cig[i]);
+    if (op == OP_M || op == OP_EQ || op == OP_X) {
+      if (ln > 0 && (np == 0 || noref[np - 1] || val[np - 1] != delta)) {
+        if (np == 3) return false;
+        val[np] = delta; noref[np] = false; start[np] = c; np++;
+      }
+      c += ln;
+    } else if (op == OP_I || op == OP_S) {
+      if (ln > 0 && (np == 0 || !noref[np - 1])) {
+        if (np == 3) return false;
+        val[np] = 0; noref[np] = true; start[np] = c; np++;
+      }
+      c += ln;
+      delta -= ln;
+    } else if (op == OP_D || op == OP_N) {
+      delta += ln;
+    }
+  }
+  int32_t D[3] = {BQ_NOREF, BQ_NOREF, BQ_NOREF};
+  for (int k = 0; k < np; k++) {
+    if (noref[k]) continue;
+    if (val[k] <= (int64_t)INT32_MIN + 70000 || val[k] >= (int64_t)INT32_MAX - 70000) return false;
+    D[k] = (int32_t)val[k];
+  }
+  d.D0 = D[0]; d.D1 = D[1]; d.D2 = D[2];
+  d.b1 = np > 1 ? (uint16_t)start[1] : (uint16_t)0xFFFF;
+  d.b2 = np > 2 ? (uint16_t)start[2] : (uint16_t)0xFFFF;
+  return true;
+}
 
 __global__ __launch_bounds__(256) void k_bqsr_prologue(BqCols m, uint32_t *__restrict__ cig_scratch, BqDesc *__restrict__ desc,
                                                        uint32_t *skipbits, uint32_t *err) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m.n) return;
   BqDesc d;
-  d.pos = 0; d.cig = 0; d.ncig = 0; d.a = 0; d.len = 0; d.left = 0; d.right = 0; d.cov = 0; d.fl = 0;
+  d.D0 = d.D1 = d.D2 = BQ_NOREF; d.refid = 0; d.b1 = d.b2 = 0xFFFF; d.a = 0; d.len = 0; d.left = 0; d.right = 0; d.cov = 0; d.fl = 0; d.pad = 0;
   if (!recalibrate_aln(m, i)) { desc[i] = d; return; }
   if (m.l_seq[i] > (uint32_t)MAX_DESC_READ) { atomicOr(&err[0], 2u); desc[i] = d; return; }
   RAln a;
@@ -131,228 +184,376 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue(BqCols m, uint32_t *__res
   }
   ReadView v{m.seq4 + m.seq_off[i], m.qual + m.qual_off[i], a.off, a.len, (bool)(a.flag & F_REVERSED), 0, -1};
   low_quality_bounds(v);
-  d.pos = a.pos;
-  if (a.cur < 0) { d.cig = (uint32_t)m.cigar_off[i]; }
-  else { d.cig = (uint32_t)(a.buf[a.cur] - cig_scratch); d.fl |= 8; }
-  d.ncig = (uint16_t)a.ncig;
+  d.refid = a.refid;
   d.a = (uint16_t)a.off; d.len = (uint16_t)a.len;
   d.left = (uint16_t)v.left; d.right = (uint16_t)(v.right < 0 ? 0xFFFF : v.right);
   d.cov = (uint8_t)m.rg_cov[m.rgid[i]];
-  d.fl |= 1 | ((a.flag & F_REVERSED) ? 2 : 0) | ((a.flag & F_LAST) ? 4 : 0);
+  d.fl = BQ_ELIGIBLE | ((a.flag & F_REVERSED) ? BQ_REVERSED : 0) | ((a.flag & F_LAST) ? BQ_LAST : 0);
+  if (!build_pieces(a.cig, a.ncig, a.pos, d)) {
+    d.fl |= BQ_COMPLEX;
+    if (a.cur < 0) { d.D0 = (int32_t)m.cigar_off[i]; }
+    else { d.D0 = (int32_t)(a.buf[a.cur] - cig_scratch); d.fl |= BQ_CIG_SCRATCH; }
+    d.b1 = (uint16_t)a.ncig;
+    d.D2 = a.pos - 1;
+    if (a.ncig > 0xFFFF) atomicOr(&err[0], 2u);
+  }
   desc[i] = d;
 }
 
-struct QMap { uint8_t slot[96]; };  // quality value -> table slot of this pass, 255 = not in this pass
+// reference contigs are kept as 4-bit BAM base codes, first base in the LOW nibble: A 1, C 2, G 4, T 8, anything else 0
+// (baseToIntMap, bqsr.go:247-252: a/A/'*' -> A ...; a read base is only ever compared when it is A, C, G or T, so "other"
+// needs no finer code).  Comparing 16 read bases with 16 reference bases is then one 64-bit XOR.
+__global__ __launch_bounds__(256) void k_pack_reference(const uint8_t *__restrict__ ascii, int64_t len, uint8_t *__restrict__ packed, int64_t packed_bytes) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= packed_bytes) return;
+  uint32_t out = 0;
+  for (int h = 0; h < 2; h++) {
+    const int64_t j = 2 * i + h;
+    uint32_t code = 0;
+    if (j < len) {
+      switch (ascii[j]) {
+        case 'a': case 'A': case '*': code = 1; break;
+        case 'c': case 'C': code = 2; break;
+        case 'g': case 'G': code = 4; break;
+        case 't': case 'T': code = 8; break;
+        default: code = 0;
+      }
+    }
+    out |= code << (4 * h);
+  }
+  packed[i] = (uint8_t)out;
+}
+constexpr int64_t REF_PAD = 32;  // zero bytes after the packed bases of a contig
+
+// nibble b = reference base jb + b of the contig (0 outside [0, rlen))
+__device__ __forceinline__ uint64_t ref_nibbles(const uint8_t *__restrict__ rp, int64_t rlen, int64_t jb) {
+  if (jb >= rlen || jb <= -16) return 0ull;
+  const int64_t jw = jb < 0 ? 0 : (jb & ~(int64_t)1);
+  uint64_t v0, v1;
+  __builtin_memcpy(&v0, rp + (jw >> 1), 8);
+  __builtin_memcpy(&v1, rp + (jw >> 1) + 8, 8);
+  return nib_ext(v0, v1, (int)(jb - jw));
+}
+
+// reference nibbles of a chunk for a record whose clipped CIGAR has more than three pieces: walks the CIGAR.
+// Bits [blo, bhi) of the chunk are clipped bases cbase + b.  Insertions copy the read's own nibble (=> no mismatch).
+__device__ __noinline__ uint64_t ref_nibbles_complex(const uint32_t *__restrict__ cg, int ncig, int64_t j0, int cbase, int blo, int bhi,
+                                                     const uint8_t *__restrict__ rp, int64_t rlen, uint64_t S) {
+  uint64_t R = 0;
+  int ri = 0;
+  int64_t j = j0;
+  for (int i = 0; i < ncig; i++) {
+    const uint32_t op = c_op(cg[i]);
+    const int ln = c_len(cg[i]);
+    if (op == OP_M || op == OP_EQ || op == OP_X || op == OP_I || op == OP_S) {
+      int lo = ri - cbase, hi = ri + ln - cbase;
+      lo = lo > blo ? lo : blo;
+      hi = hi < bhi ? hi : bhi;
+      if (lo < hi) {
+        const uint64_t m = nib_fill(nib_range(lo, hi));
+        if (op == OP_I || op == OP_S) R |= S & m;
+        else R |= ref_nibbles(rp, rlen, j - ri + cbase) & m;
+      }
+      ri += ln;
+      if (op != OP_I && op != OP_S) j += ln;
+      if (ri - cbase >= bhi) break;
+    } else if (op == OP_D || op == OP_N) {
+      j += ln;
+    }
+  }
+  return R;
+}
+
+// quality value -> LDS table row offset of this pass; the special values:
+constexpr uint16_t QROW_SKIP = 0xFFFF;     // quality < 6 (minInterestingQual, bqsr.go:698) or handled by another pass
+constexpr uint16_t QROW_BAD = 0xFFFE;      // quality > 93
+constexpr uint16_t QROW_MISSING = 0xFFFD;  // a quality the host did not know about (sampling hint incomplete): reported, host retries
+struct QMap { uint8_t slot[96]; };         // 6..93 -> slot of this pass, 255 = other pass, 254 = unknown to the host
 
 struct CountArgs {
   uint64_t n, qual_bytes;
   const uint64_t *qual_off, *seq_off;
   const uint8_t *qual, *seq4;
-  const int32_t *refid;
   const BqDesc *desc;
   const uint32_t *cigar, *cig_scratch;
   const uint16_t *skip16;   // the skip-bit column viewed as 16-bit words (one per 16-byte QUAL chunk)
-  uint8_t *const *ref_seq;
+  uint8_t *const *ref_seq;  // packed (k_pack_reference)
   const int64_t *ref_seq_len;
-  int n_cov, n_q, lmax, cs, s16, max_cycle;  // cs = 16 * s16 padded cycle row, s16 = ceil((2*lmax+1)/16)
-  uint32_t *partial;        // [grid][cyc cells * 2 + ctx cells * 2] u32
+  int n_cov, n_q, lmax, cs, rs, max_cycle;  // cs = cycle cells per row, rs = cs + 32 = row stride (u32 words)
+  unsigned long long *cycle_tbl, *ctx_tbl;  // dense int64 tables of the C ABI (device copies)
+  unsigned long long *missing;              // [2] qualities met without a table slot
   uint32_t *err;
   const uint32_t *tile_first;
 };
 
-// 128-bit window over the packed bases of one record: nibble(k) for k in [kb, kb+32)
-struct SeqWin {
-  uint64_t v0, v1;
-  int kb;
-  __device__ __forceinline__ uint32_t nib(int k) const {
-    const int t = k - kb;           // 0..31
-    const int byte = t >> 1;
-    const uint64_t w = byte < 8 ? v0 : v1;
-    const uint32_t b = (uint32_t)(w >> (8 * (byte & 7))) & 0xFF;
-    return (t & 1) ? (b & 0xF) : (b >> 4);
-  }
-};
-__device__ __forceinline__ SeqWin load_seq_window(const uint8_t *__restrict__ seq, int k_first) {
-  SeqWin w;
-  w.kb = (k_first > 0 ? k_first : 0) & ~1;
-  const uint8_t *p = seq + (w.kb >> 1);
-  __builtin_memcpy(&w.v0, p, 8);
-  __builtin_memcpy(&w.v1, p + 8, 8);
-  return w;
-}
+// LDS table of one workgroup: n_cov * n_q rows of
+//   [ cs cycle cells: observations in the low, mismatches in the high 16 bits | 16 context cells: u64, observations low, mismatches high 32 ]
+// cycle cell of cycle index x = cycle + lmax is (17 x) >> 4 = x + x / 16: lanes of a wave work on bases 16 apart, the skew puts
+// them on different banks.  16-bit cycle counters are safe because a read touches a cycle cell at most once and the table is
+// flushed (atomic adds into the dense int64 tables in HBM) at least every 50000 reads.
+template <bool CHECK_CYCLE>
+struct CountBody {
+  static constexpr int MAX_SEG = 2;
+  // kernel arguments (scalar copies: a reference to the argument struct would keep this object in scratch memory)
+  const uint64_t *__restrict__ seq_off;
+  const uint8_t *__restrict__ qual;
+  const uint8_t *__restrict__ seq4;
+  const uint4 *__restrict__ desc;
+  const uint32_t *__restrict__ cigar;
+  const uint32_t *__restrict__ cig_scratch;
+  const uint16_t *__restrict__ skip16;
+  uint8_t *const *__restrict__ ref_seq;
+  const int64_t *__restrict__ ref_seq_len;
+  unsigned long long *cycle_tbl, *ctx_tbl, *missing;
+  int n_cov, n_q, lmax, cs, rs, max_cycle;
+  // LDS
+  uint4 *s_desc;
+  uint32_t *s_seq;
+  const uint16_t *qrow;
+  const uint8_t *slot_q;
+  uint32_t *tbl;
+  uint32_t trash_idx;      // index (in u32 words, even) of this lane's 8-byte trash cell behind the tables
+  // per chunk
+  uint64_t seq_base;
+  Chunk ch;
+  uint32_t skipw;
+  uint64_t F, X, CV, CX;   // nibble space: count-eligible flags, mismatch flags, context-valid flags, context keys
+  int nseg, split;
+  int PA, PB, stA, stB;    // 16 * (cov row offset) + 17 * cycle index of bit 0, and its step per bit
+  uint32_t cxA, cxB;       // cov row offset + cs
+  int cyA, cyB, ciA, ciB;  // cycle of bit 0 / increment (only used when CHECK_CYCLE)
+  uint32_t err;
+  uint32_t reads_since_flush;
 
-__global__ __launch_bounds__(FL_THREADS) void k_bqsr_count(CountArgs A, QMap qm) {
-  __shared__ FlatLds L;
-  __shared__ BqDesc s_desc[FL_RMAX];
-  __shared__ uint64_t s_seq[FL_RMAX];
-  __shared__ int32_t s_ref[FL_RMAX];
-  extern __shared__ __attribute__((aligned(16))) uint32_t tbl[];  // cyc[n_cov*n_q*cs] | ctx_obs[n_cov*n_q*16] | ctx_mism[n_cov*n_q*16]
-  const int ncq = A.n_cov * A.n_q;
-  const int n_cyc = ncq * A.cs, n_ctx = ncq * 16;
-  uint32_t *t_cyc = tbl, *t_cobs = tbl + n_cyc, *t_cmis = t_cobs + n_ctx;
-  const int n_all = n_cyc + 2 * n_ctx;
-  for (int k = threadIdx.x; k < n_all; k += FL_THREADS) tbl[k] = 0;
-  uint32_t *part = A.partial + (size_t)blockIdx.x * (size_t)(2 * n_cyc + 2 * n_ctx);
-  __syncthreads();
-  uint32_t reads_since_flush = 0;
-  uint32_t my_err = 0;
-  auto flush = [&]() {
-    __syncthreads();
-    for (int k = threadIdx.x; k < n_cyc; k += FL_THREADS) {
-      const uint32_t v = t_cyc[k];
-      if (v) { part[2 * k] += v & 0xFFFF; part[2 * k + 1] += v >> 16; t_cyc[k] = 0; }
+  __device__ __forceinline__ void stage(uint32_t g0, uint32_t ng) {
+    const uint4 *src = desc + 2 * (size_t)g0;
+    for (uint32_t k = threadIdx.x; k < 2 * ng; k += FL_THREADS) s_desc[k] = src[k];
+    seq_base = seq_off[g0];
+    for (uint32_t k = threadIdx.x; k < ng; k += FL_THREADS) s_seq[k] = (uint32_t)(seq_off[g0 + k] - seq_base);
+  }
+  __device__ __forceinline__ void chunk_begin(uint64_t p) {
+    ch.load(qual + p);
+    skipw = skip16[p >> 4];
+  }
+  __device__ __forceinline__ void round_begin() { F = X = CV = CX = 0; nseg = 0; split = 16; }
+
+  __device__ __forceinline__ int segment(uint32_t rl, int k0, int nb, int o) {
+    const uint4 dy = s_desc[2 * rl + 1];
+    const uint32_t fl = (dy.w >> 8) & 0xFFu;
+    if (!(fl & BQ_ELIGIBLE)) return 0;
+    const int a = (int)(dy.y & 0xFFFFu), len = (int)(dy.y >> 16);
+    const int kb = k0 - o;      // original base index of chunk bit 0
+    const int cbase = kb - a;   // clipped base index of chunk bit 0
+    int blo = -cbase, bhi = len - cbase;
+    blo = blo > o ? blo : o;
+    bhi = bhi < o + nb ? bhi : o + nb;
+    if (blo >= bhi) return 0;
+    const uint4 dx = s_desc[2 * rl];
+    const int32_t D0 = (int32_t)dx.x, D1 = (int32_t)dx.y, D2 = (int32_t)dx.z, refid = (int32_t)dx.w;
+    const int b1 = (int)(dy.x & 0xFFFFu), b2 = (int)(dy.x >> 16);
+    const int left = (int)(dy.z & 0xFFFFu), right = (dy.z >> 16) == 0xFFFFu ? -1 : (int)(dy.z >> 16);
+    const uint32_t cov = dy.w & 0xFFu;
+    const bool rev = fl & BQ_REVERSED;
+    uint64_t S, N;
+    seq_nibbles(seq4 + seq_base + s_seq[rl], kb, rev ? 1 : -1, S, N);
+    const uint64_t inw = nib_range(blo, bhi);
+    uint64_t ohS, cS, ohN, cN;
+    nib_classify(S, ohS, cS);
+    nib_classify(N, ohN, cN);
+    F |= inw & ohS;
+    // context covariate (bqsr.go:87-146): base and its predecessor in sequencing direction inside [left, right]
+    {
+      const int cl = left + (rev ? 0 : 1), cr = right - (rev ? 1 : 0);
+      const uint64_t valid = ohS & ohN & inw & nib_range_clamped(cl - cbase, cr - cbase + 1);
+      uint64_t k = cN | (cS << 2);
+      k ^= rev ? NIBF : 0ull;
+      CX |= k & nib_fill(valid);
+      CV |= valid;
     }
-    for (int k = threadIdx.x; k < n_ctx; k += FL_THREADS) {
-      const uint32_t o = t_cobs[k], e = t_cmis[k];
-      if (o) { part[2 * n_cyc + 2 * k] += o; t_cobs[k] = 0; }
-      if (e) { part[2 * n_cyc + 2 * k + 1] += e; t_cmis[k] = 0; }
+    // SNP events (computeSnpEvents, bqsr.go:254-285): read nibble vs reference nibble
+    {
+      const uint8_t *__restrict__ rp = ref_seq[refid];
+      const int64_t rlen = ref_seq_len[refid];
+      uint64_t R = 0;
+      if (!(fl & BQ_COMPLEX)) {
+        const int B1 = b1 - cbase, B2 = b2 - cbase;  // piece boundaries in chunk bits (0xFFFF - cbase >= 16 when unused)
+        {
+          const int hi = bhi < B1 ? bhi : B1;
+          if (blo < hi) {
+            const uint64_t m = nib_fill(nib_range(blo, hi));
+            R |= (D0 == BQ_NOREF ? S : ref_nibbles(rp, rlen, (int64_t)D0 + cbase)) & m;
+          }
+        }
+        if (B1 < bhi) {
+          const int lo = blo > B1 ? blo : B1, hi = bhi < B2 ? bhi : B2;
+          if (lo < hi) {
+            const uint64_t m = nib_fill(nib_range(lo, hi));
+            R |= (D1 == BQ_NOREF ? S : ref_nibbles(rp, rlen, (int64_t)D1 + cbase)) & m;
+          }
+          if (B2 < bhi) {
+            const int lo2 = blo > B2 ? blo : B2;
+            if (lo2 < bhi) {
+              const uint64_t m = nib_fill(nib_range(lo2, bhi));
+              R |= (D2 == BQ_NOREF ? S : ref_nibbles(rp, rlen, (int64_t)D2 + cbase)) & m;
+            }
+          }
+        }
+      } else {
+        const uint32_t *cg = ((fl & BQ_CIG_SCRATCH) ? cig_scratch : cigar) + (uint32_t)D0;
+        R = ref_nibbles_complex(cg, b1, (int64_t)D2, cbase, blo, bhi, rp, rlen, S);
+      }
+      X |= nib_nonzero(S ^ R) & inw;
+    }
+    // cycle covariate (bqsr.go:376-387) of chunk bit b: cf + (cbase + b) * ci
+    const int rof = (fl & BQ_LAST) ? -1 : 1;
+    const int cf = rof + (rev ? (len - 1) * rof : 0), ci = rev ? -rof : rof;
+    const int cyc0 = cf + cbase * ci;
+    const uint32_t rowc = cov * (uint32_t)n_q * (uint32_t)rs;
+    const int P = (int)(rowc << 4) + 17 * (cyc0 + lmax), st = 17 * ci;
+    if (nseg == 0) { PA = P; stA = st; cxA = rowc + (uint32_t)cs; cyA = cyc0; ciA = ci; }
+    else { PB = P; stB = st; cxB = rowc + (uint32_t)cs; cyB = cyc0; ciB = ci; split = blo; }
+    nseg++;
+    return 1;
+  }
+
+  // One base, branch-free: a base that is not counted adds 0 to the lane's own trash cell behind the tables, so the sixteen
+  // bases of a chunk are straight-line code the compiler can interleave (no exec-mask juggling, no serialised LDS waits).
+  template <int I>
+  __device__ __forceinline__ void base(uint32_t fw, uint32_t xw, uint32_t vw, uint32_t cw, uint32_t ro, uint32_t trash, uint32_t &rare) {
+    constexpr int sh = 4 * (I & 7);
+    const bool fb = (fw >> sh) & 1u;
+    bool act = fb && ro < QROW_MISSING;
+    rare |= (fb && ro >= QROW_MISSING && ro != QROW_SKIP) ? (1u << I) : 0u;
+    const bool sb = I >= split;
+    if (CHECK_CYCLE) {  // checkCycleCovariate, bqsr.go:364-369
+      const int cyc = (sb ? cyB : cyA) + I * (sb ? ciB : ciA);
+      const bool out = act && (cyc > max_cycle || cyc < -max_cycle);
+      err |= out ? 16u : 0u;
+      act = act && !out;
+    }
+    const int t = (sb ? PB : PA) + I * (sb ? stB : stA);
+    const uint32_t e = (xw >> sh) & 1u;
+    const uint32_t i1 = act ? ro + (uint32_t)(t >> 4) : trash;
+    atomicAdd(&tbl[i1], act ? (1u | (e << 16)) : 0u);
+    const bool act2 = act && ((vw >> sh) & 1u);
+    const uint32_t cx = (cw >> sh) & 15u;
+    const uint32_t i2 = act2 ? ro + (sb ? cxB : cxA) + 2u * cx : trash;
+    atomicAdd(reinterpret_cast<unsigned long long *>(&tbl[i2]), act2 ? (1ull | ((unsigned long long)e << 32)) : 0ull);
+  }
+  template <int I>
+  __device__ __forceinline__ void rare_base(uint32_t rare) {  // quality > 93, or a quality without a table slot
+    if (rare & (1u << I)) {
+      const uint32_t q = ch.get<I>();
+      if (q >= (uint32_t)ELP_NQUAL) err |= 8u;
+      else { err |= 128u; atomicOr(&missing[q >> 6], 1ull << (q & 63u)); }
+    }
+  }
+  template <int... Is>
+  __device__ __forceinline__ void rare_bases(std::integer_sequence<int, Is...>, uint32_t rare) { (rare_base<Is>(rare), ...); }
+
+  __device__ __forceinline__ void round_end() {
+    const uint64_t f = F & ~nib_spread16(skipw);
+    if (f == 0) return;
+    const uint32_t f0 = (uint32_t)f, x0 = (uint32_t)X, v0 = (uint32_t)CV, c0 = (uint32_t)CX;
+    const uint32_t f1 = (uint32_t)(f >> 32), x1 = (uint32_t)(X >> 32), v1 = (uint32_t)(CV >> 32), c1 = (uint32_t)(CX >> 32);
+    const uint32_t trash = trash_idx;
+    uint32_t rare = 0;
+    const uint32_t r0 = qrow[ch.get<0>()], r1 = qrow[ch.get<1>()], r2 = qrow[ch.get<2>()], r3 = qrow[ch.get<3>()];
+    const uint32_t r4 = qrow[ch.get<4>()], r5 = qrow[ch.get<5>()], r6 = qrow[ch.get<6>()], r7 = qrow[ch.get<7>()];
+    const uint32_t r8 = qrow[ch.get<8>()], r9 = qrow[ch.get<9>()], r10 = qrow[ch.get<10>()], r11 = qrow[ch.get<11>()];
+    const uint32_t r12 = qrow[ch.get<12>()], r13 = qrow[ch.get<13>()], r14 = qrow[ch.get<14>()], r15 = qrow[ch.get<15>()];
+    base<0>(f0, x0, v0, c0, r0, trash, rare); base<1>(f0, x0, v0, c0, r1, trash, rare);
+    base<2>(f0, x0, v0, c0, r2, trash, rare); base<3>(f0, x0, v0, c0, r3, trash, rare);
+    base<4>(f0, x0, v0, c0, r4, trash, rare); base<5>(f0, x0, v0, c0, r5, trash, rare);
+    base<6>(f0, x0, v0, c0, r6, trash, rare); base<7>(f0, x0, v0, c0, r7, trash, rare);
+    base<8>(f1, x1, v1, c1, r8, trash, rare); base<9>(f1, x1, v1, c1, r9, trash, rare);
+    base<10>(f1, x1, v1, c1, r10, trash, rare); base<11>(f1, x1, v1, c1, r11, trash, rare);
+    base<12>(f1, x1, v1, c1, r12, trash, rare); base<13>(f1, x1, v1, c1, r13, trash, rare);
+    base<14>(f1, x1, v1, c1, r14, trash, rare); base<15>(f1, x1, v1, c1, r15, trash, rare);
+    if (rare) rare_bases(std::make_integer_sequence<int, 16>{}, rare);
+  }
+  __device__ __forceinline__ void chunk_end(uint64_t, int, int) {}
+  __device__ __forceinline__ void group_end(uint32_t, uint32_t) {}
+
+  // adds the private table into the dense int64 tables (cycle: [cov][94][2*max_cycle+1][2], context: [cov][94][16][2]) and clears it
+  __device__ __forceinline__ void flush() {
+    __syncthreads();
+    const int rows = n_cov * n_q;
+    const int ncyc_l = 2 * lmax + 1, ncyc_g = 2 * max_cycle + 1;
+    for (int k = threadIdx.x; k < rows * ncyc_l; k += FL_THREADS) {
+      const int row = k / ncyc_l, x = k % ncyc_l;
+      uint32_t *cell = &tbl[row * rs + ((17 * x) >> 4)];
+      const uint32_t v = *cell;
+      if (v) {
+        *cell = 0;
+        const int cyc = x - lmax;
+        if (cyc >= -max_cycle && cyc <= max_cycle) {
+          const int cov = row / n_q, q = slot_q[row % n_q];
+          unsigned long long *g = cycle_tbl + (((size_t)cov * ELP_NQUAL + q) * ncyc_g + (size_t)(cyc + max_cycle)) * 2;
+          atomicAdd(g, (unsigned long long)(v & 0xFFFFu));
+          if (v >> 16) atomicAdd(g + 1, (unsigned long long)(v >> 16));
+        }
+      }
+    }
+    for (int k = threadIdx.x; k < rows * 16; k += FL_THREADS) {
+      const int row = k >> 4, cx = k & 15;
+      unsigned long long *cell = reinterpret_cast<unsigned long long *>(&tbl[row * rs + cs + 2 * cx]);
+      const unsigned long long v = *cell;
+      if (v) {
+        *cell = 0;
+        const int cov = row / n_q, q = slot_q[row % n_q];
+        // cx = prev | cur << 2 is exactly (key >> 4) & 15 of keyFromContext (bqsr.go:64-76)
+        unsigned long long *g = ctx_tbl + (((size_t)cov * ELP_NQUAL + q) * ELP_NCTX + (size_t)cx) * 2;
+        atomicAdd(g, v & 0xFFFFFFFFull);
+        if (v >> 32) atomicAdd(g + 1, v >> 32);
+      }
     }
     __syncthreads();
-  };
-  const uint64_t ntiles = (A.qual_bytes + FL_TILE - 1) / FL_TILE;
-  for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const uint64_t tb = t * FL_TILE, te = (tb + FL_TILE < A.qual_bytes) ? tb + FL_TILE : A.qual_bytes;
-    reads_since_flush += flat_tile(A.qual_off, A.n, A.qual, tb, te, A.tile_first[t], A.tile_first[t + 1], L,
-              [&](uint32_t g0, uint32_t ng) __attribute__((always_inline)) {  // stage the group's descriptors in LDS (coalesced)
-                for (uint32_t k = threadIdx.x; k < ng; k += FL_THREADS) {
-                  s_desc[k] = A.desc[g0 + k];
-                  s_seq[k] = A.seq_off[g0 + k];
-                  s_ref[k] = A.refid[g0 + k];
-                }
-              },
-              [&](uint32_t rl, int k0, int k1, Chunk &ch, int o, uint64_t p) __attribute__((always_inline)) {
-                const BqDesc d = s_desc[rl];
-                if (!(d.fl & 1)) return;
-                int c0 = k0 - (int)d.a, c1 = k1 - (int)d.a;  // clipped coordinates
-                if (c0 < 0) c0 = 0;
-                if (c1 > (int)d.len) c1 = (int)d.len;
-                if (c0 >= c1) return;
-                const uint8_t *seq = A.seq4 + s_seq[rl];
-                const SeqWin sw = load_seq_window(seq, (int)d.a + c0 - 1);
-                const uint32_t skipw = A.skip16[p >> 4];
-                const int rf = s_ref[rl];
-                const uint8_t *ref = A.ref_seq[rf];
-                const int64_t rlen = A.ref_seq_len[rf];
-                const uint32_t *cg = ((d.fl & 8) ? A.cig_scratch : A.cigar) + d.cig;
-                const bool rev = d.fl & 2;
-                const int rof = (d.fl & 4) ? -1 : 1;
-                const int cf = rof + (rev ? ((int)d.len - 1) * rof : 0), ci = (rev ? -1 : 1) * rof;  // bqsr.go:376-383
-                const int left = d.left, right = d.right == 0xFFFF ? -1 : (int)d.right;
-                // walk the CIGAR to clipped base c0 (computeSnpEvents, bqsr.go:254-285)
-                int opi = 0, rem = 0;
-                bool ism = false;
-                int64_t j = (int64_t)d.pos - 1;
-                {
-                  int ri = 0;
-                  for (; opi < (int)d.ncig; opi++) {
-                    const uint32_t el = cg[opi];
-                    const uint32_t op = c_op(el);
-                    const int ln = c_len(el);
-                    if (op == OP_M || op == OP_EQ || op == OP_X) {
-                      if (c0 < ri + ln) { ism = true; rem = ri + ln - c0; j += c0 - ri; break; }
-                      ri += ln; j += ln;
-                    } else if (op == OP_D || op == OP_N) {
-                      j += ln;
-                    } else if (op == OP_I || op == OP_S) {
-                      if (c0 < ri + ln) { ism = false; rem = ri + ln - c0; break; }
-                      ri += ln;
-                    }
-                  }
-                }
-                const int row0 = (int)d.cov * A.n_q;
-                for (int c = c0; c < c1; c++) {
-                  // advance to the op that holds base c
-                  while (rem == 0 && opi < (int)d.ncig) {
-                    opi++;
-                    if (opi >= (int)d.ncig) break;
-                    const uint32_t el = cg[opi];
-                    const uint32_t op = c_op(el);
-                    if (op == OP_M || op == OP_EQ || op == OP_X) { ism = true; rem = c_len(el); }
-                    else if (op == OP_I || op == OP_S) { ism = false; rem = c_len(el); }
-                    else if (op == OP_D || op == OP_N) { j += c_len(el); }
-                  }
-                  const bool in_cigar = rem > 0;
-                  const int64_t jj = j;
-                  if (in_cigar) { rem--; if (ism) j++; }
-                  const int kk = (int)d.a + c;                 // original base index
-                  const int bi = o + (kk - k0);                // byte inside the lane's chunk
-                  if ((skipw >> bi) & 1u) continue;
-                  const uint32_t nb = sw.nib(kk);
-                  const int bidx = base_index_of_nibble(nb);
-                  if (bidx < 0) continue;
-                  const uint32_t q = ch.get(bi);
-                  if (q < 6) continue;
-                  if (q >= ELP_NQUAL) { my_err |= 8u; continue; }
-                  const uint32_t slot = qm.slot[q];
-                  if (slot == 255) continue;
-                  uint32_t e = 0;
-                  if (in_cigar && ism) {
-                    const int rb = (jj >= 0 && jj < rlen) ? base_code_of_ref(ref[jj]) : 0;
-                    e = (bidx + 1) != rb;
-                  }
-                  const int cyc = cf + c * ci;
-                  if (cyc > A.max_cycle || cyc < -A.max_cycle) { my_err |= 16u; continue; }  // checkCycleCovariate :364-369
-                  const int cidx = cyc + A.lmax;
-                  const int row = row0 + (int)slot;
-                  atomicAdd(&t_cyc[row * A.cs + (cidx & 15) * A.s16 + (cidx >> 4)], 1u | (e << 16));
-                  // context covariate (bqsr.go:87-146) of clipped base c
-                  int cx = -1;
-                  if (c >= left && c <= right) {
-                    const int cn = rev ? c + 1 : c - 1;
-                    if (cn >= left && cn <= right && cn >= 0 && cn < (int)d.len) {
-                      const int pn = base_index_of_nibble(sw.nib((int)d.a + cn));
-                      if (pn >= 0) cx = rev ? (((3 - pn)) | ((3 - bidx) << 2)) : (pn | (bidx << 2));
-                    }
-                  }
-                  if (cx >= 0) {
-                    atomicAdd(&t_cobs[row * 16 + cx], 1u);
-                    if (e) atomicAdd(&t_cmis[row * 16 + cx], 1u);
-                  }
-                }
-              },
-              [&](uint64_t, int, int, Chunk &) __attribute__((always_inline)) {}, [&](uint32_t, uint32_t) __attribute__((always_inline)) {});
+  }
+  __device__ __forceinline__ void tile_end(uint32_t nreads) {
+    reads_since_flush += nreads;
     if (reads_since_flush > 50000u) { flush(); reads_since_flush = 0; }
   }
-  flush();
+};
+
+template <bool CHECK_CYCLE>
+__global__ __launch_bounds__(FL_THREADS, 4) void k_bqsr_count(CountArgs A, QMap qm) {
+  __shared__ FlatLds L;
+  __shared__ uint4 s_desc[2 * FL_RMAX];
+  __shared__ uint32_t s_seq[FL_RMAX];
+  __shared__ uint16_t qrow[256];
+  __shared__ uint8_t slot_q[96];
+  extern __shared__ __attribute__((aligned(16))) uint32_t tbl[];
+  const int n_all = A.n_cov * A.n_q * A.rs;
+  for (int k = threadIdx.x; k < n_all; k += FL_THREADS) tbl[k] = 0;
+  for (int q = threadIdx.x; q < 256; q += FL_THREADS) {
+    uint16_t v;
+    if (q < 6) v = QROW_SKIP;
+    else if (q >= ELP_NQUAL) v = QROW_BAD;
+    else {
+      const uint8_t s = qm.slot[q];
+      v = s == 255 ? QROW_SKIP : (s == 254 ? QROW_MISSING : (uint16_t)(s * A.rs));
+      if (s < 254) slot_q[s] = (uint8_t)q;
+    }
+    qrow[q] = v;
+  }
+  __syncthreads();
+  CountBody<CHECK_CYCLE> B;
+  B.seq_off = A.seq_off; B.qual = A.qual; B.seq4 = A.seq4; B.desc = reinterpret_cast<const uint4 *>(A.desc);
+  B.cigar = A.cigar; B.cig_scratch = A.cig_scratch; B.skip16 = A.skip16; B.ref_seq = A.ref_seq; B.ref_seq_len = A.ref_seq_len;
+  B.cycle_tbl = A.cycle_tbl; B.ctx_tbl = A.ctx_tbl; B.missing = A.missing;
+  B.n_cov = A.n_cov; B.n_q = A.n_q; B.lmax = A.lmax; B.cs = A.cs; B.rs = A.rs; B.max_cycle = A.max_cycle;
+  B.s_desc = s_desc; B.s_seq = s_seq; B.qrow = qrow; B.slot_q = slot_q; B.tbl = tbl;
+  B.trash_idx = (uint32_t)((n_all + 1) & ~1) + 2u * threadIdx.x;
+  B.err = 0;
+  B.reads_since_flush = 0;
+  B.cyA = B.cyB = B.ciA = B.ciB = 0; B.PA = B.PB = B.stA = B.stB = 0; B.cxA = B.cxB = 0;
+  flat_run(A.qual_off, A.n, A.qual_bytes, A.tile_first, L, B);
+  B.flush();
+  uint32_t my_err = B.err;
   if (__any(my_err != 0)) {
     for (int d = 32; d >= 1; d >>= 1) my_err |= __shfl_xor(my_err, d, 64);
     if ((threadIdx.x & 63) == 0) atomicOr(&A.err[0], my_err);
-  }
-}
-
-// sums the per-workgroup partials into the dense tables; one thread per logical (cov, slot, cycle) / (cov, slot, ctx) cell
-__global__ __launch_bounds__(256) void k_bqsr_reduce(const uint32_t *__restrict__ partial, int nblk, int n_cov, int n_q, int lmax, int cs, int s16,
-                                                     int max_cycle, QMap slot_to_q, unsigned long long *cycle_tbl, unsigned long long *ctx_tbl) {
-  const int ncq = n_cov * n_q;
-  const int ncyc_l = 2 * lmax + 1;
-  const int n_cyc = ncq * cs, n_ctx = ncq * 16;
-  const size_t stride = (size_t)(2 * n_cyc + 2 * n_ctx);
-  const int total = ncq * ncyc_l + ncq * 16;
-  const int id = blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= total) return;
-  const int ncyc_g = 2 * max_cycle + 1;
-  if (id < ncq * ncyc_l) {
-    const int row = id / ncyc_l, cidx = id % ncyc_l;
-    const size_t k = (size_t)row * cs + (size_t)(cidx & 15) * s16 + (cidx >> 4);
-    unsigned long long o = 0, e = 0;
-    for (int b = 0; b < nblk; b++) { o += partial[b * stride + 2 * k]; e += partial[b * stride + 2 * k + 1]; }
-    if (o | e) {
-      const int cov = row / n_q, q = slot_to_q.slot[row % n_q];
-      const int cyc = cidx - lmax;
-      const size_t g = (((size_t)cov * ELP_NQUAL + q) * ncyc_g + (size_t)(cyc + max_cycle)) * 2;
-      cycle_tbl[g] += o; cycle_tbl[g + 1] += e;
-    }
-  } else {
-    const int x = id - ncq * ncyc_l;
-    const int row = x / 16, cx = x % 16;
-    unsigned long long o = 0, e = 0;
-    for (int b = 0; b < nblk; b++) { o += partial[b * stride + 2 * n_cyc + 2 * x]; e += partial[b * stride + 2 * n_cyc + 2 * x + 1]; }
-    if (o | e) {
-      const int cov = row / n_q, q = slot_to_q.slot[row % n_q];
-      // cx = prev | cur << 2 is exactly (key >> 4) & 15 of keyFromContext (bqsr.go:64-76)
-      const size_t g = (((size_t)cov * ELP_NQUAL + q) * ELP_NCTX + (size_t)cx) * 2;
-      ctx_tbl[g] += o; ctx_tbl[g + 1] += e;
-    }
   }
 }
 
@@ -374,7 +575,8 @@ __global__ __launch_bounds__(256) void k_bqsr_qual_from_cycle(int n_rows, int nc
 }
 
 // ------------------------------------------------------------------ apply
-struct ApDesc { uint16_t left, right; uint8_t cov; uint8_t fl; };  // fl: 1 recalibrate, 2 reversed, 4 last
+struct ApDesc { uint16_t left, right, len; uint8_t cov; uint8_t fl; };  // fl: BQ_ELIGIBLE recalibrate, BQ_REVERSED, BQ_LAST
+static_assert(sizeof(ApDesc) == 8, "ApDesc is staged as one 8-byte word");
 
 __global__ __launch_bounds__(256) void k_apply_prologue(uint64_t n, const uint16_t *__restrict__ flag, const uint16_t *__restrict__ rgid,
                                                         const uint16_t *__restrict__ rg_cov, const uint32_t *__restrict__ l_seq,
@@ -382,7 +584,7 @@ __global__ __launch_bounds__(256) void k_apply_prologue(uint64_t n, const uint16
                                                         const uint8_t *__restrict__ cov_present, ApDesc *__restrict__ desc, uint32_t *err) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  ApDesc d{0, 0, 0, 0};
+  ApDesc d{0, 0, 0, 0, 0};
   const uint16_t rg = rgid[i];
   if (rg == ELP_NIL16) { atomicOr(&err[0], 32u); desc[i] = d; return; }  // readGroupCovariate panics, bqsr.go:38
   const uint32_t cov = rg_cov[rg];
@@ -394,8 +596,9 @@ __global__ __launch_bounds__(256) void k_apply_prologue(uint64_t n, const uint16
   ReadView v{nullptr, qual + qual_off[i], 0, len, (bool)(f & F_REVERSED), 0, -1};
   low_quality_bounds(v);
   d.left = (uint16_t)v.left; d.right = (uint16_t)(v.right < 0 ? 0xFFFF : v.right);
+  d.len = (uint16_t)len;
   d.cov = (uint8_t)cov;
-  d.fl = 1 | ((f & F_REVERSED) ? 2 : 0) | ((f & F_LAST) ? 4 : 0);
+  d.fl = BQ_ELIGIBLE | ((f & F_REVERSED) ? BQ_REVERSED : 0) | ((f & F_LAST) ? BQ_LAST : 0);
   desc[i] = d;
 }
 
@@ -404,7 +607,6 @@ struct ApplyArgs {
   const uint64_t *qual_off, *seq_off;
   uint8_t *qual;
   const uint8_t *seq4;
-  const uint32_t *l_seq;
   const ApDesc *desc;
   const uint32_t *tile_first;
   const uint8_t *lut;  // [n_cov][94][2*max_cycle+1][17]
@@ -412,63 +614,127 @@ struct ApplyArgs {
   uint32_t *err;
 };
 
-__global__ __launch_bounds__(FL_THREADS) void k_bqsr_apply_flat(ApplyArgs A) {
-  __shared__ FlatLds L;
-  __shared__ ApDesc s_desc[FL_RMAX];
-  __shared__ uint64_t s_seq[FL_RMAX];
-  __shared__ uint32_t s_len[FL_RMAX];
-  uint32_t my_err = 0;
-  const int ncyc = 2 * A.max_cycle + 1;
-  const uint64_t ntiles = (A.qual_bytes + FL_TILE - 1) / FL_TILE;
-  for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const uint64_t tb = t * FL_TILE, te = (tb + FL_TILE < A.qual_bytes) ? tb + FL_TILE : A.qual_bytes;
-    flat_tile(A.qual_off, A.n, A.qual, tb, te, A.tile_first[t], A.tile_first[t + 1], L,
-              [&](uint32_t g0, uint32_t ng) __attribute__((always_inline)) {
-                for (uint32_t k = threadIdx.x; k < ng; k += FL_THREADS) {
-                  s_desc[k] = A.desc[g0 + k];
-                  s_seq[k] = A.seq_off[g0 + k];
-                  s_len[k] = A.l_seq[g0 + k];
-                }
-              },
-              [&](uint32_t rl, int k0, int k1, Chunk &ch, int o, uint64_t) __attribute__((always_inline)) {
-                const ApDesc d = s_desc[rl];
-                if (!(d.fl & 1)) return;
-                const int len = (int)s_len[rl];
-                const SeqWin sw = load_seq_window(A.seq4 + s_seq[rl], k0 - 1);
-                const bool rev = d.fl & 2;
-                const int rof = (d.fl & 4) ? -1 : 1;
-                const int cf = rof + (rev ? (len - 1) * rof : 0), ci = (rev ? -1 : 1) * rof;
-                const int left = d.left, right = d.right == 0xFFFF ? -1 : (int)d.right;
-                const uint8_t *lc = A.lut + (size_t)d.cov * ELP_NQUAL * ncyc * 17;
-                for (int k = k0; k < k1; k++) {
-                  const int bi = o + (k - k0);
-                  const uint32_t q = ch.get(bi);
-                  if (q < 6) continue;
-                  if (q >= ELP_NQUAL) { my_err |= 8u; continue; }
-                  const int cyc = cf + k * ci;
-                  if (cyc > A.max_cycle || cyc < -A.max_cycle) { my_err |= 16u; continue; }
-                  int cx = 16;
-                  if (k >= left && k <= right) {
-                    const int kn = rev ? k + 1 : k - 1;
-                    if (kn >= left && kn <= right && kn >= 0 && kn < len) {
-                      const int pn = base_index_of_nibble(sw.nib(kn)), cu = base_index_of_nibble(sw.nib(k));
-                      if (pn >= 0 && cu >= 0) cx = rev ? ((3 - pn) | ((3 - cu) << 2)) : (pn | (cu << 2));
-                    }
-                  }
-                  ch.set(bi, lc[((size_t)q * ncyc + (size_t)(cyc + A.max_cycle)) * 17 + cx]);
-                }
-              },
-              [&](uint64_t p, int lo, int hi, Chunk &ch) __attribute__((always_inline)) {
-                if (lo == 0 && hi == FL_CHUNK) {
-                  uint4 v;
-                  v.x = (uint32_t)ch.w0; v.y = (uint32_t)(ch.w0 >> 32); v.z = (uint32_t)ch.w1; v.w = (uint32_t)(ch.w1 >> 32);
-                  *reinterpret_cast<uint4 *>(A.qual + p) = v;
-                } else {
-                  for (int b = lo; b < hi; b++) A.qual[p + b] = (uint8_t)ch.get(b);  // partial chunk: another lane may own the rest
-                }
-              },
-              [&](uint32_t, uint32_t) __attribute__((always_inline)) {});
+// ApplyBQSR (bqsr.go:936-1005): every base with quality >= 6 of a record with a known read group is replaced by the LUT value
+// of (read group, quality, cycle, context); cycle and context are taken on the full, unclipped read.
+template <bool CHECK_CYCLE>
+struct ApplyBody {
+  static constexpr int MAX_SEG = 2;
+  const uint64_t *__restrict__ seq_off;
+  uint8_t *__restrict__ qual;
+  const uint8_t *__restrict__ seq4;
+  const uint64_t *__restrict__ desc;
+  const uint8_t *__restrict__ lut;
+  int max_cycle;
+  uint64_t *s_desc;
+  uint32_t *s_seq;
+  uint64_t seq_base;
+  Chunk ch;
+  uint32_t inr;           // bits of the chunk that belong to records being recalibrated
+  uint64_t CV, CX;
+  int nseg, split;
+  uint32_t QA, QB;        // LUT offset of (cov, quality 0, cycle of bit 0, context 0)
+  int stA, stB;
+  int cyA, cyB, ciA, ciB;
+  uint32_t err;
+
+  __device__ __forceinline__ void stage(uint32_t g0, uint32_t ng) {
+    for (uint32_t k = threadIdx.x; k < ng; k += FL_THREADS) s_desc[k] = desc[g0 + k];
+    seq_base = seq_off[g0];
+    for (uint32_t k = threadIdx.x; k < ng; k += FL_THREADS) s_seq[k] = (uint32_t)(seq_off[g0 + k] - seq_base);
   }
+  __device__ __forceinline__ void chunk_begin(uint64_t p) { ch.load(qual + p); }
+  __device__ __forceinline__ void round_begin() { inr = 0; CV = CX = 0; nseg = 0; split = 16; }
+  __device__ __forceinline__ int segment(uint32_t rl, int k0, int nb, int o) {
+    const uint64_t dw = s_desc[rl];
+    const uint32_t fl = (uint32_t)(dw >> 56);
+    if (!(fl & BQ_ELIGIBLE)) return 0;
+    const int left = (int)(dw & 0xFFFFu), right = ((dw >> 16) & 0xFFFFu) == 0xFFFFu ? -1 : (int)((dw >> 16) & 0xFFFFu);
+    const int len = (int)((dw >> 32) & 0xFFFFu);
+    const uint32_t cov = (uint32_t)(dw >> 48) & 0xFFu;
+    const int kb = k0 - o;
+    const bool rev = fl & BQ_REVERSED;
+    uint64_t S, N;
+    seq_nibbles(seq4 + seq_base + s_seq[rl], kb, rev ? 1 : -1, S, N);
+    const uint64_t inw = nib_range(o, o + nb);
+    inr |= ((1u << nb) - 1u) << o;
+    {
+      uint64_t ohS, cS, ohN, cN;
+      nib_classify(S, ohS, cS);
+      nib_classify(N, ohN, cN);
+      const int cl = left + (rev ? 0 : 1), cr = right - (rev ? 1 : 0);
+      const uint64_t valid = ohS & ohN & inw & nib_range_clamped(cl - kb, cr - kb + 1);
+      uint64_t k = cN | (cS << 2);
+      k ^= rev ? NIBF : 0ull;
+      CX |= k & nib_fill(valid);
+      CV |= valid;
+    }
+    const int rof = (fl & BQ_LAST) ? -1 : 1;
+    const int cf = rof + (rev ? (len - 1) * rof : 0), ci = rev ? -rof : rof;
+    const int cyc0 = cf + kb * ci;
+    const int ncyc = 2 * max_cycle + 1;
+    const uint32_t Q = (uint32_t)((int)cov * ELP_NQUAL * ncyc * 17 + (cyc0 + max_cycle) * 17);
+    if (nseg == 0) { QA = Q; stA = 17 * ci; cyA = cyc0; ciA = ci; }
+    else { QB = Q; stB = 17 * ci; cyB = cyc0; ciB = ci; split = o; }
+    nseg++;
+    return 1;
+  }
+  template <int I>
+  __device__ __forceinline__ uint32_t base(uint32_t vw, uint32_t cw, uint32_t qstride) {
+    constexpr int sh = 4 * (I & 7);
+    const uint32_t q = ch.get<I>();
+    bool act = ((inr >> I) & 1u) && q >= 6u;
+    if (act && q >= (uint32_t)ELP_NQUAL) { err |= 8u; act = false; }
+    const bool sb = I >= split;
+    if (CHECK_CYCLE) {
+      const int cyc = (sb ? cyB : cyA) + I * (sb ? ciB : ciA);
+      if (act && (cyc > max_cycle || cyc < -max_cycle)) { err |= 16u; act = false; }
+    }
+    const uint32_t cx = ((cw >> sh) & 15u) | ((((~vw) >> sh) & 1u) << 4);  // 16 = no context
+    const uint32_t idx = (sb ? QB : QA) + (uint32_t)(I * (sb ? stB : stA)) + q * qstride + cx;
+    const uint32_t v = lut[act ? idx : 0u];
+    return act ? v : q;
+  }
+  __device__ __forceinline__ void round_end() {
+    if (inr == 0) return;
+    const uint32_t qstride = (uint32_t)(2 * max_cycle + 1) * 17u;
+    const uint32_t v0 = (uint32_t)CV, v1 = (uint32_t)(CV >> 32), c0 = (uint32_t)CX, c1 = (uint32_t)(CX >> 32);
+    const uint32_t b0 = base<0>(v0, c0, qstride), b1 = base<1>(v0, c0, qstride), b2 = base<2>(v0, c0, qstride), b3 = base<3>(v0, c0, qstride);
+    const uint32_t b4 = base<4>(v0, c0, qstride), b5 = base<5>(v0, c0, qstride), b6 = base<6>(v0, c0, qstride), b7 = base<7>(v0, c0, qstride);
+    const uint32_t b8 = base<8>(v1, c1, qstride), b9 = base<9>(v1, c1, qstride), b10 = base<10>(v1, c1, qstride), b11 = base<11>(v1, c1, qstride);
+    const uint32_t b12 = base<12>(v1, c1, qstride), b13 = base<13>(v1, c1, qstride), b14 = base<14>(v1, c1, qstride), b15 = base<15>(v1, c1, qstride);
+    ch.w0 = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+    ch.w1 = b4 | (b5 << 8) | (b6 << 16) | (b7 << 24);
+    ch.w2 = b8 | (b9 << 8) | (b10 << 16) | (b11 << 24);
+    ch.w3 = b12 | (b13 << 8) | (b14 << 16) | (b15 << 24);
+  }
+  template <int I>
+  __device__ __forceinline__ void store_byte(uint64_t p, int lo, int hi) {
+    if (lo <= I && I < hi) qual[p + I] = (uint8_t)ch.get<I>();
+  }
+  template <int... Is>
+  __device__ __forceinline__ void store_bytes(std::integer_sequence<int, Is...>, uint64_t p, int lo, int hi) {
+    (store_byte<Is>(p, lo, hi), ...);
+  }
+  __device__ __forceinline__ void chunk_end(uint64_t p, int lo, int hi) {
+    if (lo == 0 && hi == FL_CHUNK) ch.store(qual + p);
+    else store_bytes(std::make_integer_sequence<int, 16>{}, p, lo, hi);  // partial chunk: another lane may own the rest
+  }
+  __device__ __forceinline__ void group_end(uint32_t, uint32_t) {}
+  __device__ __forceinline__ void tile_end(uint32_t) {}
+};
+
+template <bool CHECK_CYCLE>
+__global__ __launch_bounds__(FL_THREADS, 4) void k_bqsr_apply_flat(ApplyArgs A) {
+  __shared__ FlatLds L;
+  __shared__ uint64_t s_desc[FL_RMAX];
+  __shared__ uint32_t s_seq[FL_RMAX];
+  ApplyBody<CHECK_CYCLE> B;
+  B.seq_off = A.seq_off; B.qual = A.qual; B.seq4 = A.seq4; B.desc = reinterpret_cast<const uint64_t *>(A.desc); B.lut = A.lut;
+  B.max_cycle = A.max_cycle; B.s_desc = s_desc; B.s_seq = s_seq;
+  B.err = 0;
+  B.QA = B.QB = 0; B.stA = B.stB = 0; B.cyA = B.cyB = B.ciA = B.ciB = 0;
+  flat_run(A.qual_off, A.n, A.qual_bytes, A.tile_first, L, B);
+  uint32_t my_err = B.err;
   if (__any(my_err != 0)) {
     for (int d = 32; d >= 1; d >>= 1) my_err |= __shfl_xor(my_err, d, 64);
     if ((threadIdx.x & 63) == 0) atomicOr(&A.err[0], my_err);
@@ -510,7 +776,8 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
   for (int r = 0; r < c->n_ref; r++)
     if (!c->h_sites[r]) ELP_TRY(elp_bqsr_set_known_sites(c, r, nullptr, 0));
   ELP_TRY(sync_bqsr_ptrs(c));
-  ELP_TRY(ensure_adapted(c));  // provides the set of quality values present (qual_present)
+  ELP_TRY(ensure_flat_index(c));
+  ELP_TRY(ensure_qual_present(c));  // sizing hint: the set of quality values seen in a sample of the column
   if (c->n_cov > 255) return set_error(c, ELP_ERR_UNSUPPORTED, "more than 255 read-group covariates");
   if (c->cigar_ops + 4 * c->n >= 0x7FFFFFFFull) return set_error(c, ELP_ERR_UNSUPPORTED, "CIGAR pool exceeds 2^31 operations per context");
   const int ncyc_g = 2 * max_cycle + 1;
@@ -528,44 +795,69 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
     uint32_t *skipbits;
     const size_t skip_words = (size_t)((c->qual_bytes + 31) / 32 + 8);
     ELP_TRY(scratch(c, 3, skip_words, &skipbits));
+    unsigned long long *missing;
+    ELP_TRY(scratch(c, 6, 4, &missing));
     ELP_HIP(c, hipMemsetAsync(skipbits, 0, skip_words * 4, st));
     BqCols m{n, c->refid.p, c->pos.p, c->next_refid.p, c->pnext.p, c->tlen.p, c->flag.p, c->rgid.p, c->mapq.p, c->has_sr.p, c->l_seq.p,
              c->cigar_off.p, c->seq_off.p, c->qual_off.p, c->cigar.p, c->seq4.p, c->qual.p, c->ref_len.p, c->rg_cov.p, c->n_ref,
              c->d_ref_seq.p, c->d_ref_seq_len.p, c->d_sites.p, c->d_n_sites.p};
     ELP_LAUNCH(c, "bqsr_prologue", k_bqsr_prologue, dim3(blocks_for(n, 256)), dim3(256), 0, m, cs_pool, desc, skipbits, c->err_flag.p);
-    // quality values present (>= 6, <= 93) -> passes of at most `qcap` slots so the private tables fit in LDS
-    std::vector<int> quals;
-    for (int q = 6; q < ELP_NQUAL; q++)
-      if ((q < 64 ? (c->qual_present[0] >> q) : (c->qual_present[1] >> (q - 64))) & 1ull) quals.push_back(q);
     const int lmax = (int)std::max<uint32_t>(c->max_l_seq, 1);
-    const int s16 = (2 * lmax + 1 + 15) / 16, cs = 16 * s16;
-    // dynamic LDS for the private tables: 160 KiB per CU / 3 workgroups, minus the kernel's static LDS (offsets + descriptors)
-    const size_t static_lds = sizeof(FlatLds) + (size_t)FL_RMAX * (sizeof(BqDesc) + 8 + 4);
-    const size_t lds_budget = 53 * 1024 - static_lds - 256;
-    const size_t per_slot = (size_t)c->n_cov * ((size_t)cs + 32) * 4;
-    int qcap = (int)(lds_budget / std::max<size_t>(per_slot, 1));
-    if (qcap < 1) return set_error(c, ELP_ERR_UNSUPPORTED, "BQSR private tables do not fit in LDS (n_cov=%d, max read length=%d)", c->n_cov, lmax);
+    if (lmax > MAX_DESC_READ) return set_error(c, ELP_ERR_UNSUPPORTED, "BQSR: read longer than %d bases", MAX_DESC_READ);
+    const bool check_cycle = lmax > max_cycle;
+    const int cs = ((((17 * 2 * lmax) >> 4) + 1) + 1) & ~1, rs = cs + 32;
+    const size_t per_slot = (size_t)c->n_cov * (size_t)rs * 4;
+    const size_t static_lds = sizeof(FlatLds) + (size_t)FL_RMAX * (sizeof(BqDesc) + 4) + 512 + 96 + 64 + 8 + (size_t)FL_THREADS * 8;
+    const size_t lds_cu = 160 * 1024;
     const uint64_t ntiles = (c->qual_bytes + FL_TILE - 1) / FL_TILE;
-    const int grid = (int)std::min<uint64_t>(ntiles, 768);  // 3 workgroups per CU
-    for (size_t q0 = 0; q0 < quals.size(); q0 += (size_t)qcap) {
-      const int nqs = (int)std::min<size_t>((size_t)qcap, quals.size() - q0);
-      QMap qm, s2q;
-      memset(qm.slot, 255, sizeof qm.slot);
-      memset(s2q.slot, 0, sizeof s2q.slot);
-      for (int s = 0; s < nqs; s++) { qm.slot[quals[q0 + s]] = (uint8_t)s; s2q.slot[s] = (uint8_t)quals[q0 + s]; }
-      const int ncq = c->n_cov * nqs;
-      const size_t cells = (size_t)ncq * cs + 2 * (size_t)ncq * 16;
-      const size_t part_words = (size_t)grid * (2 * (size_t)ncq * cs + 2 * (size_t)ncq * 16);
-      uint32_t *partial;
-      ELP_TRY(scratch(c, 4, part_words + 16, &partial));
-      ELP_HIP(c, hipMemsetAsync(partial, 0, part_words * 4, st));
-      CountArgs A{n, c->qual_bytes, c->qual_off.p, c->seq_off.p, c->qual.p, c->seq4.p, c->refid.p, desc, c->cigar.p, cs_pool,
-                  reinterpret_cast<const uint16_t *>(skipbits), c->d_ref_seq.p, c->d_ref_seq_len.p, c->n_cov, nqs, lmax, cs, s16, max_cycle,
-                  partial, c->err_flag.p, c->tile_first.p};
-      ELP_LAUNCH(c, "bqsr_count", k_bqsr_count, dim3(grid), dim3(FL_THREADS), cells * 4, A, qm);
-      const int total = ncq * (2 * lmax + 1) + ncq * 16;
-      ELP_LAUNCH(c, "bqsr_reduce", k_bqsr_reduce, dim3(blocks_for(total, 256)), dim3(256), 0, (const uint32_t *)partial, grid, c->n_cov, nqs, lmax, cs,
-                 s16, max_cycle, s2q, tb + nq, tb + nq + nc);
+    for (int attempt = 0;; attempt++) {
+      // quality values to give table slots (>= 6, <= 93)
+      std::vector<int> quals;
+      for (int q = 6; q < ELP_NQUAL; q++)
+        if ((q < 64 ? (c->qual_present[0] >> q) : (c->qual_present[1] >> (q - 64))) & 1ull) quals.push_back(q);
+      if (quals.empty()) quals.push_back(6);
+      // as many workgroups per CU (512 threads each) as still hold all slots in one pass; else one per CU and several passes
+      int wg_per_cu = 1, qcap = 0;
+      for (int w = 3; w >= 1; w--) {
+        const size_t budget = lds_cu / (size_t)w;
+        if (budget <= static_lds + 256) continue;
+        const int cap = (int)std::min<size_t>((budget - static_lds - 256) / per_slot, 65000 / (size_t)rs);
+        if (cap >= (int)quals.size() || w == 1) { wg_per_cu = w; qcap = cap; break; }
+      }
+      if (qcap < 1) return set_error(c, ELP_ERR_UNSUPPORTED, "BQSR private tables do not fit in LDS (n_cov=%d, max read length=%d)", c->n_cov, lmax);
+      const int grid = (int)std::min<uint64_t>(ntiles, (uint64_t)wg_per_cu * (uint64_t)c->n_cu);
+      ELP_HIP(c, hipMemsetAsync(missing, 0, 16, st));
+      for (size_t q0 = 0; q0 < quals.size(); q0 += (size_t)qcap) {
+        const int nqs = (int)std::min<size_t>((size_t)qcap, quals.size() - q0);
+        QMap qm;
+        memset(qm.slot, 254, sizeof qm.slot);
+        for (int q : quals) qm.slot[q] = 255;
+        for (int s = 0; s < nqs; s++) qm.slot[quals[q0 + s]] = (uint8_t)s;
+        const size_t dyn = (size_t)c->n_cov * nqs * rs * 4 + 8 + (size_t)FL_THREADS * 8;  // tables + one trash cell per lane
+        CountArgs A{n, c->qual_bytes, c->qual_off.p, c->seq_off.p, c->qual.p, c->seq4.p, desc, c->cigar.p, cs_pool,
+                    reinterpret_cast<const uint16_t *>(skipbits), c->d_ref_seq.p, c->d_ref_seq_len.p, c->n_cov, nqs, lmax, cs, rs, max_cycle,
+                    tb + nq, tb + nq + nc, missing, c->err_flag.p, c->tile_first.p};
+        if (check_cycle) {
+          ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bqsr_count<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+          ELP_LAUNCH(c, "bqsr_count", k_bqsr_count<true>, dim3(grid), dim3(FL_THREADS), dyn, A, qm);
+        } else {
+          ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bqsr_count<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+          ELP_LAUNCH(c, "bqsr_count", k_bqsr_count<false>, dim3(grid), dim3(FL_THREADS), dyn, A, qm);
+        }
+      }
+      uint32_t e[4];
+      ELP_TRY(fetch_err(c, e));
+      if ((e[0] & ~128u) != 0) return bqsr_error(c, e[0] & ~128u);
+      if (!(e[0] & 128u)) break;
+      // a counted base had a quality the sampled hint did not contain: add it and redo the count
+      unsigned long long miss[2];
+      ELP_HIP(c, hipMemcpyAsync(miss, missing, 16, hipMemcpyDeviceToHost, st));
+      ELP_HIP(c, hipStreamSynchronize(st));
+      ELP_HIP(c, hipMemsetAsync(c->err_flag.p, 0, 4, st));
+      c->qual_present[0] |= miss[0];
+      c->qual_present[1] |= miss[1];
+      if (attempt >= 3) return set_error(c, ELP_ERR_HIP, "BQSR: quality-slot retry did not converge");
+      ELP_HIP(c, hipMemsetAsync(tb, 0, (nq + nc + nx) * sizeof(unsigned long long), st));
     }
     ELP_LAUNCH(c, "bqsr_qual_from_cycle", k_bqsr_qual_from_cycle, dim3(c->n_cov * ELP_NQUAL), dim3(256), 0, c->n_cov * ELP_NQUAL, ncyc_g,
                (const unsigned long long *)(tb + nq), tb);
@@ -589,9 +881,18 @@ int elp_bqsr_set_reference(elp_ctx *c, int32_t refid, const uint8_t *bases, int6
   if (!c || !c->have_header || refid < 0 || refid >= c->n_ref || len < 0 || (len && !bases)) return set_error(c, ELP_ERR_ARG, "elp_bqsr_set_reference: bad arguments");
   ELP_HIP(c, hipSetDevice(c->device));
   if (c->h_ref_seq[refid]) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->h_ref_seq[refid]); c->h_ref_seq[refid] = nullptr; }
+  // the contig is kept as 4-bit base codes (k_pack_reference); the ASCII bytes only pass through scratch
+  const int64_t packed = (len + 1) / 2;
   uint8_t *d = nullptr;
-  ELP_HIP(c, hipMalloc((void **)&d, (size_t)len + 16));
-  if (len) ELP_HIP(c, hipMemcpyAsync(d, bases, (size_t)len, hipMemcpyHostToDevice, c->stream));
+  ELP_HIP(c, hipMalloc((void **)&d, (size_t)(packed + REF_PAD)));
+  ELP_HIP(c, hipMemsetAsync(d, 0, (size_t)(packed + REF_PAD), c->stream));
+  if (len) {
+    uint8_t *tmp;
+    ELP_TRY(scratch(c, 7, (size_t)len + 16, &tmp));
+    ELP_HIP(c, hipMemcpyAsync(tmp, bases, (size_t)len, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_pack_reference, dim3(blocks_for((uint64_t)packed, 256)), dim3(256), 0, c->stream, (const uint8_t *)tmp, len, d, packed);
+    ELP_HIP(c, hipGetLastError());
+  }
   ELP_HIP(c, hipStreamSynchronize(c->stream));
   c->h_ref_seq[refid] = d;
   c->h_ref_seq_len[refid] = len;
@@ -640,16 +941,18 @@ int elp_bqsr_apply(elp_ctx *c, int max_cycle, const uint8_t *lut, const uint8_t 
                (const uint8_t *)c->qual.p, (const uint8_t *)(dl + lut_bytes), desc, c->err_flag.p);
     if (c->qual_bytes) {
       const uint64_t ntiles = (c->qual_bytes + FL_TILE - 1) / FL_TILE;
-      const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * 8);
+      const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, (uint64_t)c->n_cu * 8);
       ELP_TRY(ensure_flat_index(c));
-      ApplyArgs A{n, c->qual_bytes, c->qual_off.p, c->seq_off.p, c->qual.p, c->seq4.p, c->l_seq.p, desc, c->tile_first.p, dl, max_cycle, c->err_flag.p};
-      ELP_LAUNCH(c, "bqsr_apply", k_bqsr_apply_flat, dim3(grid), dim3(FL_THREADS), 0, A);
+      ApplyArgs A{n, c->qual_bytes, c->qual_off.p, c->seq_off.p, c->qual.p, c->seq4.p, desc, c->tile_first.p, dl, max_cycle, c->err_flag.p};
+      if ((int64_t)c->max_l_seq > (int64_t)max_cycle) ELP_LAUNCH(c, "bqsr_apply", k_bqsr_apply_flat<true>, dim3(grid), dim3(FL_THREADS), 0, A);
+      else ELP_LAUNCH(c, "bqsr_apply", k_bqsr_apply_flat<false>, dim3(grid), dim3(FL_THREADS), 0, A);
     }
   }
   uint32_t e[4];
   ELP_TRY(fetch_err(c, e));
   if (e[0]) return bqsr_error(c, e[0]);
   c->adapted = false;  // scores depend on QUAL
+  c->have_qual_present = false;
   return 0;
 }
 

@@ -56,6 +56,7 @@ struct ProfPending {
 
 struct elp_ctx {
   int device = 0;
+  int n_cu = 256;  // compute units of the device (grid sizing)
   hipStream_t stream = nullptr;
   std::string err;
   std::mutex stage_mu;
@@ -82,7 +83,8 @@ struct elp_ctx {
 
   // derived state
   bool adapted = false, sorted = false, marked = false;
-  unsigned long long qual_present[2] = {0, 0};  // bit q set iff quality value q occurs in the staged QUAL column (valid when adapted)
+  bool have_qual_present = false;
+  unsigned long long qual_present[2] = {0, 0};  // bit q set if quality value q was seen in a sample of the QUAL column (sizing hint for the BQSR tables)
   elp::DVec<int32_t> upos, score;
   elp::DVec<uint64_t> key;      // coordinate sort keys, staging order
   elp::DVec<uint32_t> perm;     // sorted position -> staging index
@@ -228,6 +230,7 @@ int radix_sort_pairs(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *keys_
                      uint64_t **keys_out, uint32_t **vals_out);
 int exclusive_scan_u32(elp_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n, uint32_t *total_host /* may be null */);
 int ensure_adapted(elp_ctx *c);
+int ensure_qual_present(elp_ctx *c);
 int fetch_err(elp_ctx *c, uint32_t *words /* 4 */);
 
 }  // namespace elp

@@ -81,6 +81,7 @@ int elp_create(int device_ordinal, elp_ctx **out) {
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return ELP_ERR_UNSUPPORTED;  // kernels are built for gfx950 only
   elp_ctx *c = new elp_ctx();
   c->device = device_ordinal;
+  c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ELP_ERR_HIP; }
   if (ensure(c, c->err_flag, 4) != 0 || hipMemsetAsync(c->err_flag.p, 0, 16, c->stream) != hipSuccess) { delete c; return ELP_ERR_HIP; }
   *out = c;
@@ -155,8 +156,8 @@ static int reserve_locked(elp_ctx *c, uint64_t n, uint64_t qb, uint64_t co, uint
   ELP_TRY(ensure(c, c->qual_off, n + 1, keep, c->n + 1));
   ELP_TRY(ensure(c, c->qname, qb + 16, keep, c->qname_bytes));
   ELP_TRY(ensure(c, c->cigar, co + 4, keep, c->cigar_ops));
-  ELP_TRY(ensure(c, c->seq4, sb + 16, keep, c->seq_bytes));
-  ELP_TRY(ensure(c, c->qual, lb + 16, keep, c->qual_bytes));
+  ELP_TRY(ensure(c, c->seq4, sb + 32, keep, c->seq_bytes));
+  ELP_TRY(ensure(c, c->qual, lb + 32, keep, c->qual_bytes));
   return 0;
 }
 
@@ -173,6 +174,7 @@ int elp_reset(elp_ctx *c) {
   c->n = c->qname_bytes = c->cigar_ops = c->seq_bytes = c->qual_bytes = 0;
   c->max_qname_len = c->max_l_seq = 0;
   c->adapted = c->sorted = c->marked = false;
+  c->have_qual_present = false;
   c->have_snapshot = false;
   c->flat_index_n = 0;
   return 0;
@@ -196,6 +198,8 @@ int elp_stage(elp_ctx *c, const elp_batch *b) {
     uint64_t ql = b->qname_off[i + 1] - b->qname_off[i];
     if (ql > c->max_qname_len) c->max_qname_len = (uint32_t)ql;
     if (b->l_seq[i] > c->max_l_seq) c->max_l_seq = b->l_seq[i];
+    if (b->qual_off[i + 1] - b->qual_off[i] > 0x3FFFFFFFull || b->l_seq[i] > 0x3FFFFFFFu)
+      return set_error(c, ELP_ERR_UNSUPPORTED, "record %llu: more than 2^30-1 bases", (unsigned long long)i);
     if (b->rgid[i] != ELP_NIL16 && b->rgid[i] >= c->n_rg) return set_error(c, ELP_ERR_ARG, "record %llu: rgid %u not in header", (unsigned long long)i, b->rgid[i]);
     if (b->refid[i] >= c->n_ref) return set_error(c, ELP_ERR_ARG, "record %llu: refid %d not in header", (unsigned long long)i, b->refid[i]);
   }
@@ -232,6 +236,7 @@ int elp_stage(elp_ctx *c, const elp_batch *b) {
   ELP_HIP(c, hipStreamSynchronize(st));  // host buffers may be reused on return
   c->n += n; c->qname_bytes += qb; c->cigar_ops += co; c->seq_bytes += sb; c->qual_bytes += lb;
   c->adapted = c->sorted = c->marked = false;
+  c->have_qual_present = false;
   c->have_snapshot = false;
   c->flat_index_n = 0;
   return 0;
@@ -286,6 +291,7 @@ int elp_rollback(elp_ctx *c) {
   if (c->n) ELP_HIP(c, hipMemcpyAsync(c->flag.p, c->snap_flag.p, c->n * sizeof(uint16_t), hipMemcpyDeviceToDevice, c->stream));
   if (c->qual_bytes) ELP_HIP(c, hipMemcpyAsync(c->qual.p, c->snap_qual.p, c->qual_bytes, hipMemcpyDeviceToDevice, c->stream));
   c->adapted = c->sorted = c->marked = false;
+  c->have_qual_present = false;
   return 0;
 }
 

@@ -9,6 +9,8 @@
 //            runs <= TIE_SMALL records: every record computes its rank in the run directly (all-pairs);
 //            larger runs (the unmapped block, pile-ups): LSD radix over the zero-padded comparator byte string,
 //            8 bytes per round, then one stable round on the run id.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "flat.hpp"
 
@@ -60,58 +62,112 @@ __global__ __launch_bounds__(256) void k_adapt_fixed(uint64_t n, const int32_t *
   score[i] = 0;
 }
 
+// byte mask (0xFF per byte) for bytes [lo, hi) of a 32-bit word, lo/hi relative to the word and unclamped
+__device__ __forceinline__ uint32_t byte_range32(int lo, int hi) {
+  lo = lo < 0 ? 0 : lo;
+  hi = hi > 4 ? 4 : hi;
+  return lo < hi ? ((0xFFFFFFFFu << (8 * lo)) & (0xFFFFFFFFu >> (32 - 8 * hi))) : 0u;
+}
+
 // computePhredScore :57-68 as a flat stream over the QUAL column: sum of qualities >= 15 per duplicate-marking candidate;
-// any quality > 93 in a candidate is an error.  Also ORs the set of quality values present into qmask[2] (bit q).
+// any quality > 93 in a candidate is an error.  SWAR over the lane's 16 bytes, v_sad_u8 for the byte sums.
+struct ScoreBody {
+  static constexpr int MAX_SEG = 1 << 20;  // segments never use parameter slots
+  const uint16_t *__restrict__ flag;
+  const uint8_t *__restrict__ qual;
+  int32_t *score;
+  int32_t *acc;    // LDS [FL_RMAX]: per-read partial sums of this group (LDS atomics; one global atomic per read and group)
+  uint8_t *cand;   // LDS [FL_RMAX]: duplicate-marking candidate?
+  uint32_t xa, xb, xc, xd;  // the chunk's bytes with values < 15 zeroed
+  uint32_t ba, bb, bc, bd;  // bit 7 of a byte set: quality >= 94
+  uint32_t bad;
+
+  __device__ __forceinline__ void stage(uint32_t g0, uint32_t ng) {
+    for (uint32_t k = threadIdx.x; k < ng; k += FL_THREADS) {
+      acc[k] = 0;
+      cand[k] = (flag[g0 + k] & (F_UNMAPPED | F_SECONDARY | F_SUPPLEMENTARY)) == 0;
+    }
+  }
+  static __device__ __forceinline__ void prep(uint32_t x, uint32_t &x15, uint32_t &bw) {
+    const uint32_t ge15 = (((x | 0x80808080u) - 0x0F0F0F0Fu) & 0x80808080u) >> 7;  // bit 0 of the byte: low 7 bits >= 15
+    x15 = x & (ge15 * 0xFFu);
+    bw = (((x | 0x80808080u) - 0x5E5E5E5Eu) | x) & 0x80808080u;                  // byte >= 94
+  }
+  __device__ __forceinline__ void chunk_begin(uint64_t p) {
+    Chunk ch;
+    ch.load(qual + p);
+    prep(ch.w0, xa, ba);
+    prep(ch.w1, xb, bb);
+    prep(ch.w2, xc, bc);
+    prep(ch.w3, xd, bd);
+  }
+  __device__ __forceinline__ void round_begin() {}
+  __device__ __forceinline__ int segment(uint32_t rl, int, int nb, int o) {
+    if (!cand[rl]) return 0;
+    const uint32_t m0 = byte_range32(o, o + nb), m1 = byte_range32(o - 4, o + nb - 4), m2 = byte_range32(o - 8, o + nb - 8),
+                   m3 = byte_range32(o - 12, o + nb - 12);
+    uint32_t s = __builtin_amdgcn_sad_u8(xa & m0, 0u, 0u);
+    s = __builtin_amdgcn_sad_u8(xb & m1, 0u, s);
+    s = __builtin_amdgcn_sad_u8(xc & m2, 0u, s);
+    s = __builtin_amdgcn_sad_u8(xd & m3, 0u, s);
+    bad |= (ba & m0) | (bb & m1) | (bc & m2) | (bd & m3);
+    if (s) atomicAdd(&acc[rl], (int32_t)s);
+    return 0;
+  }
+  __device__ __forceinline__ void round_end() {}
+  __device__ __forceinline__ void chunk_end(uint64_t, int, int) {}
+  __device__ __forceinline__ void group_end(uint32_t g0, uint32_t ng) {
+    for (uint32_t k = threadIdx.x; k < ng; k += FL_THREADS)
+      if (acc[k]) atomicAdd(&score[g0 + k], acc[k]);  // a read can span two tiles / groups
+  }
+  __device__ __forceinline__ void tile_end(uint32_t) {}
+};
+
 __global__ __launch_bounds__(FL_THREADS) void k_score_flat(uint64_t n, const uint64_t *__restrict__ qual_off, const uint8_t *__restrict__ qual,
                                                            uint64_t qual_bytes, const uint32_t *__restrict__ tile_first,
-                                                           const uint16_t *__restrict__ flag, int32_t *score, unsigned long long *qmask,
-                                                           uint32_t *err) {
+                                                           const uint16_t *__restrict__ flag, int32_t *score, uint32_t *err) {
   __shared__ FlatLds L;
-  __shared__ int32_t acc[FL_RMAX];   // per-read partial sums of this group (LDS atomics; one global atomic per read and tile)
-  __shared__ uint8_t cand[FL_RMAX];  // duplicate-marking candidate?
-  unsigned long long m0 = 0, m1 = 0;
-  bool bad = false;
+  __shared__ int32_t acc[FL_RMAX];
+  __shared__ uint8_t cand[FL_RMAX];
+  ScoreBody B{flag, qual, score, acc, cand, 0, 0, 0, 0, 0, 0, 0, 0, 0u};
+  flat_run(qual_off, n, qual_bytes, tile_first, L, B);
+  if (__any(B.bad != 0) && (threadIdx.x & 63) == 0) atomicOr(&err[0], 1u);
+}
+
+// Set of quality values present, from a sample of the tiles (every `stride`-th).  It is a sizing hint for the BQSR gather's
+// LDS tables, not a correctness input: k_bqsr_count reports any counted quality it has no table slot for and the host retries.
+__global__ __launch_bounds__(256) void k_qual_present_sample(const uint8_t *__restrict__ qual, uint64_t qual_bytes, uint64_t stride,
+                                                             unsigned long long *qmask) {
   const uint64_t ntiles = (qual_bytes + FL_TILE - 1) / FL_TILE;
-  for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+  uint32_t m[3] = {0, 0, 0};  // bits 0..95
+  for (uint64_t t = (uint64_t)blockIdx.x * stride; t < ntiles; t += (uint64_t)gridDim.x * stride) {
     const uint64_t tb = t * FL_TILE, te = (tb + FL_TILE < qual_bytes) ? tb + FL_TILE : qual_bytes;
-    flat_tile(qual_off, n, qual, tb, te, tile_first[t], tile_first[t + 1], L,
-              [&](uint32_t g0, uint32_t ng) __attribute__((always_inline)) {
-                for (uint32_t k = threadIdx.x; k < ng; k += FL_THREADS) {
-                  acc[k] = 0;
-                  cand[k] = (flag[g0 + k] & (F_UNMAPPED | F_SECONDARY | F_SUPPLEMENTARY)) == 0;
-                }
-              },
-              [&](uint32_t rl, int k0, int k1, Chunk &ch, int o, uint64_t) __attribute__((always_inline)) {
-                const bool cd = cand[rl];
-                int32_t s = 0;
-                for (int k = k0; k < k1; k++) {
-                  const uint32_t q = ch.get(o + k - k0);
-                  // branch-free on purpose: "if (q < 64) m0 |= .. else m1 |= .." is turned into a dynamically indexed private
-                  // array by the compiler, i.e. a scratch-memory read-modify-write per base
-                  const unsigned long long bit = 1ull << ((q < 128 ? q : 127u) & 63u);
-                  m0 |= (q < 64) ? bit : 0ull;
-                  m1 |= (q < 64) ? 0ull : bit;
-                  if (q > 93) bad |= cd;
-                  else if (q >= 15) s += (int32_t)q;
-                }
-                if (cd && s) atomicAdd(&acc[rl], s);
-              },
-              [&](uint64_t, int, int, Chunk &) __attribute__((always_inline)) {},
-              [&](uint32_t g0, uint32_t ng) __attribute__((always_inline)) {
-                for (uint32_t k = threadIdx.x; k < ng; k += FL_THREADS)
-                  if (acc[k]) atomicAdd(&score[g0 + k], acc[k]);  // a read can span two tiles / groups
-              });
+    for (uint64_t p = tb + (uint64_t)threadIdx.x * 16; p < te; p += 256 * 16) {
+      Chunk ch;
+      ch.load(qual + p);
+      const int nv = (int)((te - p) < 16 ? (te - p) : 16);
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const uint32_t wv = (i >> 2) == 0 ? ch.w0 : ((i >> 2) == 1 ? ch.w1 : ((i >> 2) == 2 ? ch.w2 : ch.w3));
+        const uint32_t q = (wv >> (8 * (i & 3))) & 0xFFu;
+        const uint32_t bit = (i < nv) ? (1u << (q & 31u)) : 0u;
+        const uint32_t wsel = q >> 5;
+        m[0] |= wsel == 0 ? bit : 0u;
+        m[1] |= wsel == 1 ? bit : 0u;
+        m[2] |= wsel == 2 ? bit : 0u;
+      }
+    }
   }
-  // wave-reduce the presence masks
   for (int d = 32; d >= 1; d >>= 1) {
-    m0 |= __shfl_xor(m0, d, 64);
-    m1 |= __shfl_xor(m1, d, 64);
+    m[0] |= __shfl_xor(m[0], d, 64);
+    m[1] |= __shfl_xor(m[1], d, 64);
+    m[2] |= __shfl_xor(m[2], d, 64);
   }
   if ((threadIdx.x & 63) == 0) {
-    if (m0) atomicOr(&qmask[0], m0);
-    if (m1) atomicOr(&qmask[1], m1);
+    const unsigned long long lo = (unsigned long long)m[0] | ((unsigned long long)m[1] << 32);
+    if (lo) atomicOr(&qmask[0], lo);
+    if (m[2]) atomicOr(&qmask[1], (unsigned long long)m[2]);
   }
-  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&err[0], 1u);
 }
 
 // tile_first[t] = last read r (0 <= r <= n) with qual_off[r] <= t * FL_TILE, for t in [0, ntiles]
@@ -148,20 +204,15 @@ int ensure_adapted(elp_ctx *c) {
   ELP_TRY(ensure(c, c->upos, n + 1));
   ELP_TRY(ensure(c, c->score, n + 1));
   ELP_TRY(ensure(c, c->key, n + 1));
-  c->qual_present[0] = c->qual_present[1] = 0;
   if (n) {
     ELP_LAUNCH(c, "adapt_fixed", k_adapt_fixed, dim3(blocks_for(n, 256)), dim3(256), 0, n, (const int32_t *)c->pos.p, (const int32_t *)c->refid.p,
                (const uint16_t *)c->flag.p, (const uint64_t *)c->cigar_off.p, (const uint32_t *)c->cigar.p, c->upos.p, c->score.p, c->key.p);
-    unsigned long long *qm;
-    ELP_TRY(scratch(c, 6, 4, &qm));
-    ELP_HIP(c, hipMemsetAsync(qm, 0, 16, c->stream));
     if (c->qual_bytes) {
       const uint64_t ntiles = (c->qual_bytes + FL_TILE - 1) / FL_TILE;
-      const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * 8);
+      const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * 4);
       ELP_LAUNCH(c, "adapt_score", k_score_flat, dim3(grid), dim3(FL_THREADS), 0, n, (const uint64_t *)c->qual_off.p, (const uint8_t *)c->qual.p,
-                 c->qual_bytes, (const uint32_t *)c->tile_first.p, (const uint16_t *)c->flag.p, c->score.p, qm, c->err_flag.p);
+                 c->qual_bytes, (const uint32_t *)c->tile_first.p, (const uint16_t *)c->flag.p, c->score.p, c->err_flag.p);
     }
-    ELP_HIP(c, hipMemcpyAsync(c->qual_present, qm, 16, hipMemcpyDeviceToHost, c->stream));
     uint32_t e[4];
     ELP_TRY(fetch_err(c, e));
     if (e[0] & 1u) {
@@ -170,6 +221,26 @@ int ensure_adapted(elp_ctx *c) {
     }
   }
   c->adapted = true;
+  return 0;
+}
+
+// c->qual_present = quality values seen in a sample of the QUAL column (a sizing hint, see k_qual_present_sample)
+int ensure_qual_present(elp_ctx *c) {
+  if (c->have_qual_present) return 0;
+  c->qual_present[0] = c->qual_present[1] = 0;
+  // test hook: with ELP_DEBUG_NO_QUAL_HINT set the hint stays empty, which forces the gather's report-and-retry path
+  if (c->qual_bytes && !getenv("ELP_DEBUG_NO_QUAL_HINT")) {
+    unsigned long long *qm;
+    ELP_TRY(scratch(c, 6, 4, &qm));
+    ELP_HIP(c, hipMemsetAsync(qm, 0, 16, c->stream));
+    const uint64_t ntiles = (c->qual_bytes + FL_TILE - 1) / FL_TILE;
+    const uint64_t stride = std::min<uint64_t>(16, std::max<uint64_t>(1, ntiles / 2048));
+    const unsigned grid = (unsigned)std::min<uint64_t>((ntiles + stride - 1) / stride, 2048);
+    ELP_LAUNCH(c, "qual_present_sample", k_qual_present_sample, dim3(grid), dim3(256), 0, (const uint8_t *)c->qual.p, c->qual_bytes, stride, qm);
+    ELP_HIP(c, hipMemcpyAsync(c->qual_present, qm, 16, hipMemcpyDeviceToHost, c->stream));
+    ELP_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  c->have_qual_present = true;
   return 0;
 }
 
