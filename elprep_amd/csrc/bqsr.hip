@@ -440,16 +440,18 @@ struct CountBody {
     const uint32_t i2 = act2 ? ro + (sb ? cxB : cxA) + 2u * cx : trash;
     atomicAdd(reinterpret_cast<unsigned long long *>(&tbl[i2]), act2 ? (1ull | ((unsigned long long)e << 32)) : 0ull);
   }
-  template <int I>
-  __device__ __forceinline__ void rare_base(uint32_t rare) {  // quality > 93, or a quality without a table slot
-    if (rare & (1u << I)) {
-      const uint32_t q = ch.get<I>();
+  // bases with a quality > 93 or a quality without a table slot (rare: a rolled loop, kept out of the way of the hot code)
+  __device__ __forceinline__ void rare_bases(uint32_t rare) {
+    const uint64_t lo = (uint64_t)ch.w0 | ((uint64_t)ch.w1 << 32), hi = (uint64_t)ch.w2 | ((uint64_t)ch.w3 << 32);
+#pragma unroll 1
+    while (rare) {
+      const int i = __builtin_ctz(rare);
+      rare &= rare - 1;
+      const uint32_t q = (uint32_t)(((i & 8) ? hi : lo) >> (8 * (i & 7))) & 0xFFu;
       if (q >= (uint32_t)ELP_NQUAL) err |= 8u;
       else { err |= 128u; atomicOr(&missing[q >> 6], 1ull << (q & 63u)); }
     }
   }
-  template <int... Is>
-  __device__ __forceinline__ void rare_bases(std::integer_sequence<int, Is...>, uint32_t rare) { (rare_base<Is>(rare), ...); }
 
   __device__ __forceinline__ void round_end() {
     const uint64_t f = F & ~nib_spread16(skipw);
@@ -458,19 +460,29 @@ struct CountBody {
     const uint32_t f1 = (uint32_t)(f >> 32), x1 = (uint32_t)(X >> 32), v1 = (uint32_t)(CV >> 32), c1 = (uint32_t)(CX >> 32);
     const uint32_t trash = trash_idx;
     uint32_t rare = 0;
-    const uint32_t r0 = qrow[ch.get<0>()], r1 = qrow[ch.get<1>()], r2 = qrow[ch.get<2>()], r3 = qrow[ch.get<3>()];
-    const uint32_t r4 = qrow[ch.get<4>()], r5 = qrow[ch.get<5>()], r6 = qrow[ch.get<6>()], r7 = qrow[ch.get<7>()];
-    const uint32_t r8 = qrow[ch.get<8>()], r9 = qrow[ch.get<9>()], r10 = qrow[ch.get<10>()], r11 = qrow[ch.get<11>()];
-    const uint32_t r12 = qrow[ch.get<12>()], r13 = qrow[ch.get<13>()], r14 = qrow[ch.get<14>()], r15 = qrow[ch.get<15>()];
-    base<0>(f0, x0, v0, c0, r0, trash, rare); base<1>(f0, x0, v0, c0, r1, trash, rare);
-    base<2>(f0, x0, v0, c0, r2, trash, rare); base<3>(f0, x0, v0, c0, r3, trash, rare);
-    base<4>(f0, x0, v0, c0, r4, trash, rare); base<5>(f0, x0, v0, c0, r5, trash, rare);
-    base<6>(f0, x0, v0, c0, r6, trash, rare); base<7>(f0, x0, v0, c0, r7, trash, rare);
-    base<8>(f1, x1, v1, c1, r8, trash, rare); base<9>(f1, x1, v1, c1, r9, trash, rare);
-    base<10>(f1, x1, v1, c1, r10, trash, rare); base<11>(f1, x1, v1, c1, r11, trash, rare);
-    base<12>(f1, x1, v1, c1, r12, trash, rare); base<13>(f1, x1, v1, c1, r13, trash, rare);
-    base<14>(f1, x1, v1, c1, r14, trash, rare); base<15>(f1, x1, v1, c1, r15, trash, rare);
-    if (rare) rare_bases(std::make_integer_sequence<int, 16>{}, rare);
+    // groups of four bases between scheduling barriers: enough independent work to cover the LDS latency without letting the
+    // scheduler hoist all sixteen address computations at once (register pressure => occupancy)
+    {
+      const uint32_t r0 = qrow[ch.get<0>()], r1 = qrow[ch.get<1>()], r2 = qrow[ch.get<2>()], r3 = qrow[ch.get<3>()];
+      const uint32_t r4 = qrow[ch.get<4>()], r5 = qrow[ch.get<5>()], r6 = qrow[ch.get<6>()], r7 = qrow[ch.get<7>()];
+      base<0>(f0, x0, v0, c0, r0, trash, rare); base<1>(f0, x0, v0, c0, r1, trash, rare);
+      base<2>(f0, x0, v0, c0, r2, trash, rare); base<3>(f0, x0, v0, c0, r3, trash, rare);
+      __builtin_amdgcn_sched_barrier(0);
+      base<4>(f0, x0, v0, c0, r4, trash, rare); base<5>(f0, x0, v0, c0, r5, trash, rare);
+      base<6>(f0, x0, v0, c0, r6, trash, rare); base<7>(f0, x0, v0, c0, r7, trash, rare);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    {
+      const uint32_t r8 = qrow[ch.get<8>()], r9 = qrow[ch.get<9>()], r10 = qrow[ch.get<10>()], r11 = qrow[ch.get<11>()];
+      const uint32_t r12 = qrow[ch.get<12>()], r13 = qrow[ch.get<13>()], r14 = qrow[ch.get<14>()], r15 = qrow[ch.get<15>()];
+      base<8>(f1, x1, v1, c1, r8, trash, rare); base<9>(f1, x1, v1, c1, r9, trash, rare);
+      base<10>(f1, x1, v1, c1, r10, trash, rare); base<11>(f1, x1, v1, c1, r11, trash, rare);
+      __builtin_amdgcn_sched_barrier(0);
+      base<12>(f1, x1, v1, c1, r12, trash, rare); base<13>(f1, x1, v1, c1, r13, trash, rare);
+      base<14>(f1, x1, v1, c1, r14, trash, rare); base<15>(f1, x1, v1, c1, r15, trash, rare);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (rare) rare_bases(rare);
   }
   __device__ __forceinline__ void chunk_end(uint64_t, int, int) {}
   __device__ __forceinline__ void group_end(uint32_t, uint32_t) {}

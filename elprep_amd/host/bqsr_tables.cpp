@@ -72,13 +72,27 @@ inline double log10_gamma(long long n) {
   return lgamma_r(double(n), &sg) * 0.43429448190325182765112891891660508229439700580366656611445378316586464920887077;
 }
 
-// calculateBayesianEstimateOfEmpiricalQuality, bqsr.go:623-642
+// log10(1 - 10^(-Q/10)) for Q = 1..60: the only transcendental work of the likelihood that depends on the bin alone
+struct Log10MinP {
+  double v[61];
+  Log10MinP() {
+    v[0] = 0.0;
+    for (int i = 1; i <= 60; i++) v[i] = go_log10(1.0 - go_pow(10, double(i) / -10.0));
+  }
+};
+const Log10MinP kLog10MinP;
+
+// calculateBayesianEstimateOfEmpiricalQuality, bqsr.go:623-642.  The binomial coefficient term (three Lgamma calls) does not
+// depend on the bin and log10(1-p) only on the bin: both are hoisted, every floating-point operation and its order is the
+// reference's (log10QualEmpiricalLikelihood :598-613), so the argmax is unchanged.
 uint8_t bayes(long long obs, long long mism, double prior) {
   const long long kMax = 2147483647LL - 1;
   if (obs > kMax) {
     mism = (long long)std::round(double(mism) * (double(kMax) / double(obs)));
     obs = kMax;
   }
+  const double c = obs == 0 ? 0.0 : log10_gamma(obs + 1) - log10_gamma(mism + 1) - log10_gamma(obs - mism + 1);
+  const double dm = double(mism), dn = double(obs - mism);
   double best = -DBL_MAX;
   uint8_t arg = 0;
   for (int i = 0; i <= 60; i++) {
@@ -91,13 +105,8 @@ uint8_t bayes(long long obs, long long mism, double prior) {
       like = 0.0;
     } else {
       const double log10p = fi / -10.0;
-      if (log10p == 0.0) {
-        like = -DBL_MAX;
-      } else {
-        const double log10minp = go_log10(1.0 - go_pow(10, log10p));
-        const double c = log10_gamma(obs + 1) - log10_gamma(mism + 1) - log10_gamma(obs - mism + 1);
-        like = c + log10p * double(mism) + log10minp * double(obs - mism);
-      }
+      if (log10p == 0.0) like = -DBL_MAX;
+      else like = c + log10p * dm + kLog10MinP.v[i] * dn;
     }
     const double post = kPrior[d] + like;
     if (best < post) { best = post; arg = uint8_t(i); }
@@ -297,20 +306,27 @@ int elp_bqsr_tables_build_lut(const elp_bqsr_tables *t, int quantize_levels, con
         dctx[cx] = t->x[2 * xi] > 0 ? double(empirical(t->x[2 * xi], t->x[2 * xi + 1], cond)) - cond : 0.0;
       }
       uint8_t *lq = lc + size_t(ql) * ncyc * 17;
+      auto entry = [&](bool has_c, int cy, int cx) {
+        const bool has_x = cx < 16 && t->x[2 * (qi * NX + cx)] > 0;
+        double d_cov = 0;
+        if (has_c) d_cov = dcyc[cy];
+        if (has_x) d_cov += dctx[cx];
+        const double est = cond + d_cov;
+        int r = int(std::round(est));
+        if (r > 93) r = 93;
+        if (r < 1) r = 1;
+        uint8_t o = quantized[r];
+        if (n_sqq > 0) o = stat[o];
+        return o;
+      };
+      uint8_t no_cycle[17];  // the 17 values of a cycle without table entry (the same for every such cycle)
+      for (int cx = 0; cx < 17; cx++) no_cycle[cx] = entry(false, 0, cx);
       for (int cy = 0; cy < ncyc; cy++) {
-        const bool has_c = t->c[2 * (qi * ncyc + cy)] > 0;
-        for (int cx = 0; cx < 17; cx++) {
-          const bool has_x = cx < 16 && t->x[2 * (qi * NX + cx)] > 0;
-          double d_cov = 0;
-          if (has_c) d_cov = dcyc[cy];
-          if (has_x) d_cov += dctx[cx];
-          const double est = cond + d_cov;
-          int r = int(std::round(est));
-          if (r > 93) r = 93;
-          if (r < 1) r = 1;
-          uint8_t o = quantized[r];
-          if (n_sqq > 0) o = stat[o];
-          lq[size_t(cy) * 17 + cx] = o;
+        uint8_t *le = lq + size_t(cy) * 17;
+        if (t->c[2 * (qi * ncyc + cy)] > 0) {
+          for (int cx = 0; cx < 17; cx++) le[cx] = entry(true, cy, cx);
+        } else {
+          std::memcpy(le, no_cycle, 17);
         }
       }
     }
