@@ -327,9 +327,9 @@ struct CountBody {
 
   __device__ __forceinline__ void stage(uint32_t g0, uint32_t ng) {
     const uint4 *src = desc + 2 * (size_t)g0;
-    for (uint32_t k = threadIdx.x; k < 2 * ng; k += FL_THREADS) s_desc[k] = src[k];
+    for (uint32_t k = threadIdx.x; k < 2 * ng; k += blockDim.x) s_desc[k] = src[k];
     seq_base = seq_off[g0];
-    for (uint32_t k = threadIdx.x; k < ng; k += FL_THREADS) s_seq[k] = (uint32_t)(seq_off[g0 + k] - seq_base);
+    for (uint32_t k = threadIdx.x; k < ng; k += blockDim.x) s_seq[k] = (uint32_t)(seq_off[g0 + k] - seq_base);
   }
   __device__ __forceinline__ void chunk_begin(uint64_t p) {
     ch.load(qual + p);
@@ -492,7 +492,7 @@ struct CountBody {
     __syncthreads();
     const int rows = n_cov * n_q;
     const int ncyc_l = 2 * lmax + 1, ncyc_g = 2 * max_cycle + 1;
-    for (int k = threadIdx.x; k < rows * ncyc_l; k += FL_THREADS) {
+    for (int k = threadIdx.x; k < rows * ncyc_l; k += blockDim.x) {
       const int row = k / ncyc_l, x = k % ncyc_l;
       uint32_t *cell = &tbl[row * rs + ((17 * x) >> 4)];
       const uint32_t v = *cell;
@@ -507,7 +507,7 @@ struct CountBody {
         }
       }
     }
-    for (int k = threadIdx.x; k < rows * 16; k += FL_THREADS) {
+    for (int k = threadIdx.x; k < rows * 16; k += blockDim.x) {
       const int row = k >> 4, cx = k & 15;
       unsigned long long *cell = reinterpret_cast<unsigned long long *>(&tbl[row * rs + cs + 2 * cx]);
       const unsigned long long v = *cell;
@@ -537,8 +537,8 @@ __global__ __launch_bounds__(FL_THREADS, 4) void k_bqsr_count(CountArgs A, QMap 
   __shared__ uint8_t slot_q[96];
   extern __shared__ __attribute__((aligned(16))) uint32_t tbl[];
   const int n_all = A.n_cov * A.n_q * A.rs;
-  for (int k = threadIdx.x; k < n_all; k += FL_THREADS) tbl[k] = 0;
-  for (int q = threadIdx.x; q < 256; q += FL_THREADS) {
+  for (int k = threadIdx.x; k < n_all; k += blockDim.x) tbl[k] = 0;
+  for (int q = threadIdx.x; q < 256; q += blockDim.x) {
     uint16_t v;
     if (q < 6) v = QROW_SKIP;
     else if (q >= ELP_NQUAL) v = QROW_BAD;
@@ -624,11 +624,15 @@ struct ApplyArgs {
   const uint8_t *lut;  // [n_cov][94][2*max_cycle+1][17]
   int max_cycle;
   uint32_t *err;
+  // LDS-resident compact LUT (k_bqsr_apply_flat<.., true>): [n_cov][n_slot][2*lmax+1][17], slot = qslot[quality] (255 = not resident)
+  const uint8_t *clut;
+  int n_cov, n_slot, lmax;
 };
+struct QSlots { uint8_t slot[96]; };
 
 // ApplyBQSR (bqsr.go:936-1005): every base with quality >= 6 of a record with a known read group is replaced by the LUT value
 // of (read group, quality, cycle, context); cycle and context are taken on the full, unclipped read.
-template <bool CHECK_CYCLE>
+template <bool CHECK_CYCLE, bool LDSLUT>
 struct ApplyBody {
   static constexpr int MAX_SEG = 2;
   const uint64_t *__restrict__ seq_off;
@@ -639,20 +643,24 @@ struct ApplyBody {
   int max_cycle;
   uint64_t *s_desc;
   uint32_t *s_seq;
+  const uint8_t *qs;      // LDS: quality -> resident slot (LDSLUT)
+  const uint8_t *llut;    // LDS: compact LUT (LDSLUT)
+  int lmax, n_slot;
   uint64_t seq_base;
   Chunk ch;
   uint32_t inr;           // bits of the chunk that belong to records being recalibrated
   uint64_t CV, CX;
   int nseg, split;
-  uint32_t QA, QB;        // LUT offset of (cov, quality 0, cycle of bit 0, context 0)
+  uint32_t QA, QB;        // dense LUT offset of (cov, quality 0, cycle of bit 0, context 0)
+  uint32_t LA, LB;        // compact LUT offset of (cov, slot 0, cycle of bit 0, context 0)
   int stA, stB;
   int cyA, cyB, ciA, ciB;
   uint32_t err;
 
   __device__ __forceinline__ void stage(uint32_t g0, uint32_t ng) {
-    for (uint32_t k = threadIdx.x; k < ng; k += FL_THREADS) s_desc[k] = desc[g0 + k];
+    for (uint32_t k = threadIdx.x; k < ng; k += blockDim.x) s_desc[k] = desc[g0 + k];
     seq_base = seq_off[g0];
-    for (uint32_t k = threadIdx.x; k < ng; k += FL_THREADS) s_seq[k] = (uint32_t)(seq_off[g0 + k] - seq_base);
+    for (uint32_t k = threadIdx.x; k < ng; k += blockDim.x) s_seq[k] = (uint32_t)(seq_off[g0 + k] - seq_base);
   }
   __device__ __forceinline__ void chunk_begin(uint64_t p) { ch.load(qual + p); }
   __device__ __forceinline__ void round_begin() { inr = 0; CV = CX = 0; nseg = 0; split = 16; }
@@ -685,11 +693,13 @@ struct ApplyBody {
     const int cyc0 = cf + kb * ci;
     const int ncyc = 2 * max_cycle + 1;
     const uint32_t Q = (uint32_t)((int)cov * ELP_NQUAL * ncyc * 17 + (cyc0 + max_cycle) * 17);
-    if (nseg == 0) { QA = Q; stA = 17 * ci; cyA = cyc0; ciA = ci; }
-    else { QB = Q; stB = 17 * ci; cyB = cyc0; ciB = ci; split = o; }
+    const uint32_t Lq = (uint32_t)(((int)cov * n_slot * (2 * lmax + 1) + (cyc0 + lmax)) * 17);
+    if (nseg == 0) { QA = Q; LA = Lq; stA = 17 * ci; cyA = cyc0; ciA = ci; }
+    else { QB = Q; LB = Lq; stB = 17 * ci; cyB = cyc0; ciB = ci; split = o; }
     nseg++;
     return 1;
   }
+  // dense LUT in HBM/L2: one byte gather per base
   template <int I>
   __device__ __forceinline__ uint32_t base(uint32_t vw, uint32_t cw, uint32_t qstride) {
     constexpr int sh = 4 * (I & 7);
@@ -706,18 +716,77 @@ struct ApplyBody {
     const uint32_t v = lut[act ? idx : 0u];
     return act ? v : q;
   }
+  // compact LUT in LDS: one LDS byte read per base; a quality without a resident slot is left for the fix-up loop
+  template <int I>
+  __device__ __forceinline__ uint32_t base_lds(uint32_t vw, uint32_t cw, uint32_t sstride, uint32_t slot, uint32_t &todo) {
+    constexpr int sh = 4 * (I & 7);
+    const uint32_t q = ch.get<I>();
+    bool act = ((inr >> I) & 1u) && q >= 6u;
+    err |= (act && q >= (uint32_t)ELP_NQUAL) ? 8u : 0u;
+    act = act && q < (uint32_t)ELP_NQUAL;
+    const bool sb = I >= split;
+    if (CHECK_CYCLE) {
+      const int cyc = (sb ? cyB : cyA) + I * (sb ? ciB : ciA);
+      const bool out = act && (cyc > max_cycle || cyc < -max_cycle);
+      err |= out ? 16u : 0u;
+      act = act && !out;
+    }
+    todo |= (act && slot == 255u) ? (1u << I) : 0u;
+    act = act && slot != 255u;
+    const uint32_t cx = ((cw >> sh) & 15u) | ((((~vw) >> sh) & 1u) << 4);
+    const uint32_t idx = (sb ? LB : LA) + (uint32_t)(I * (sb ? stB : stA)) + slot * sstride + cx;
+    const uint32_t v = llut[act ? idx : 0u];
+    return act ? v : q;
+  }
+  // bases whose quality has no resident slot: dense LUT, rolled loop (rare)
+  __device__ __forceinline__ void fixup(uint32_t todo) {
+    uint64_t lo = (uint64_t)ch.w0 | ((uint64_t)ch.w1 << 32), hi = (uint64_t)ch.w2 | ((uint64_t)ch.w3 << 32);
+    const uint32_t qstride = (uint32_t)(2 * max_cycle + 1) * 17u;
+#pragma unroll 1
+    while (todo) {
+      const int i = __builtin_ctz(todo);
+      todo &= todo - 1;
+      const int bs = 8 * (i & 7);
+      const uint32_t q = (uint32_t)(((i & 8) ? hi : lo) >> bs) & 0xFFu;
+      const bool sb = i >= split;
+      const uint32_t cx = ((uint32_t)(CX >> (4 * i)) & 15u) | ((((uint32_t)(~CV >> (4 * i))) & 1u) << 4);
+      const uint32_t idx = (sb ? QB : QA) + (uint32_t)(i * (sb ? stB : stA)) + q * qstride + cx;
+      const uint64_t v = (uint64_t)lut[idx];
+      const uint64_t m = ~(0xFFull << bs);
+      lo = (i & 8) ? lo : ((lo & m) | (v << bs));
+      hi = (i & 8) ? ((hi & m) | (v << bs)) : hi;
+    }
+    ch.w0 = (uint32_t)lo; ch.w1 = (uint32_t)(lo >> 32); ch.w2 = (uint32_t)hi; ch.w3 = (uint32_t)(hi >> 32);
+  }
   __device__ __forceinline__ void round_end() {
     if (inr == 0) return;
-    const uint32_t qstride = (uint32_t)(2 * max_cycle + 1) * 17u;
     const uint32_t v0 = (uint32_t)CV, v1 = (uint32_t)(CV >> 32), c0 = (uint32_t)CX, c1 = (uint32_t)(CX >> 32);
-    const uint32_t b0 = base<0>(v0, c0, qstride), b1 = base<1>(v0, c0, qstride), b2 = base<2>(v0, c0, qstride), b3 = base<3>(v0, c0, qstride);
-    const uint32_t b4 = base<4>(v0, c0, qstride), b5 = base<5>(v0, c0, qstride), b6 = base<6>(v0, c0, qstride), b7 = base<7>(v0, c0, qstride);
-    const uint32_t b8 = base<8>(v1, c1, qstride), b9 = base<9>(v1, c1, qstride), b10 = base<10>(v1, c1, qstride), b11 = base<11>(v1, c1, qstride);
-    const uint32_t b12 = base<12>(v1, c1, qstride), b13 = base<13>(v1, c1, qstride), b14 = base<14>(v1, c1, qstride), b15 = base<15>(v1, c1, qstride);
+    uint32_t b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, b10, b11, b12, b13, b14, b15;
+    uint32_t todo = 0;
+    if (LDSLUT) {
+      const uint32_t ss = (uint32_t)(2 * lmax + 1) * 17u;
+      const uint32_t s0 = qs[ch.get<0>()], s1 = qs[ch.get<1>()], s2 = qs[ch.get<2>()], s3 = qs[ch.get<3>()];
+      const uint32_t s4 = qs[ch.get<4>()], s5 = qs[ch.get<5>()], s6 = qs[ch.get<6>()], s7 = qs[ch.get<7>()];
+      const uint32_t s8 = qs[ch.get<8>()], s9 = qs[ch.get<9>()], s10 = qs[ch.get<10>()], s11 = qs[ch.get<11>()];
+      const uint32_t s12 = qs[ch.get<12>()], s13 = qs[ch.get<13>()], s14 = qs[ch.get<14>()], s15 = qs[ch.get<15>()];
+      b0 = base_lds<0>(v0, c0, ss, s0, todo); b1 = base_lds<1>(v0, c0, ss, s1, todo); b2 = base_lds<2>(v0, c0, ss, s2, todo);
+      b3 = base_lds<3>(v0, c0, ss, s3, todo); b4 = base_lds<4>(v0, c0, ss, s4, todo); b5 = base_lds<5>(v0, c0, ss, s5, todo);
+      b6 = base_lds<6>(v0, c0, ss, s6, todo); b7 = base_lds<7>(v0, c0, ss, s7, todo); b8 = base_lds<8>(v1, c1, ss, s8, todo);
+      b9 = base_lds<9>(v1, c1, ss, s9, todo); b10 = base_lds<10>(v1, c1, ss, s10, todo); b11 = base_lds<11>(v1, c1, ss, s11, todo);
+      b12 = base_lds<12>(v1, c1, ss, s12, todo); b13 = base_lds<13>(v1, c1, ss, s13, todo); b14 = base_lds<14>(v1, c1, ss, s14, todo);
+      b15 = base_lds<15>(v1, c1, ss, s15, todo);
+    } else {
+      const uint32_t qstride = (uint32_t)(2 * max_cycle + 1) * 17u;
+      b0 = base<0>(v0, c0, qstride); b1 = base<1>(v0, c0, qstride); b2 = base<2>(v0, c0, qstride); b3 = base<3>(v0, c0, qstride);
+      b4 = base<4>(v0, c0, qstride); b5 = base<5>(v0, c0, qstride); b6 = base<6>(v0, c0, qstride); b7 = base<7>(v0, c0, qstride);
+      b8 = base<8>(v1, c1, qstride); b9 = base<9>(v1, c1, qstride); b10 = base<10>(v1, c1, qstride); b11 = base<11>(v1, c1, qstride);
+      b12 = base<12>(v1, c1, qstride); b13 = base<13>(v1, c1, qstride); b14 = base<14>(v1, c1, qstride); b15 = base<15>(v1, c1, qstride);
+    }
     ch.w0 = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
     ch.w1 = b4 | (b5 << 8) | (b6 << 16) | (b7 << 24);
     ch.w2 = b8 | (b9 << 8) | (b10 << 16) | (b11 << 24);
     ch.w3 = b12 | (b13 << 8) | (b14 << 16) | (b15 << 24);
+    if (LDSLUT && todo) fixup(todo);
   }
   template <int I>
   __device__ __forceinline__ void store_byte(uint64_t p, int lo, int hi) {
@@ -735,22 +804,45 @@ struct ApplyBody {
   __device__ __forceinline__ void tile_end(uint32_t) {}
 };
 
-template <bool CHECK_CYCLE>
-__global__ __launch_bounds__(FL_THREADS, 4) void k_bqsr_apply_flat(ApplyArgs A) {
+template <bool CHECK_CYCLE, bool LDSLUT>
+__global__ __launch_bounds__(LDSLUT ? 1024 : FL_THREADS, LDSLUT ? 4 : 4) void k_bqsr_apply_flat(ApplyArgs A, QSlots slots) {
   __shared__ FlatLds L;
   __shared__ uint64_t s_desc[FL_RMAX];
   __shared__ uint32_t s_seq[FL_RMAX];
-  ApplyBody<CHECK_CYCLE> B;
+  __shared__ uint8_t qs[256];
+  extern __shared__ __attribute__((aligned(16))) uint8_t llut[];
+  if (LDSLUT) {
+    for (int q = threadIdx.x; q < 256; q += blockDim.x) qs[q] = (q >= 6 && q < ELP_NQUAL) ? slots.slot[q] : (uint8_t)255;
+    const int nbytes = A.n_cov * A.n_slot * (2 * A.lmax + 1) * 17;
+    const uint4 *src = reinterpret_cast<const uint4 *>(A.clut);  // padded to 16 bytes by the builder
+    uint4 *dst = reinterpret_cast<uint4 *>(llut);
+    for (int k = threadIdx.x; k < (nbytes + 15) / 16; k += blockDim.x) dst[k] = src[k];
+    __syncthreads();
+  }
+  ApplyBody<CHECK_CYCLE, LDSLUT> B;
   B.seq_off = A.seq_off; B.qual = A.qual; B.seq4 = A.seq4; B.desc = reinterpret_cast<const uint64_t *>(A.desc); B.lut = A.lut;
   B.max_cycle = A.max_cycle; B.s_desc = s_desc; B.s_seq = s_seq;
+  B.qs = qs; B.llut = llut; B.lmax = A.lmax; B.n_slot = A.n_slot;
   B.err = 0;
-  B.QA = B.QB = 0; B.stA = B.stB = 0; B.cyA = B.cyB = B.ciA = B.ciB = 0;
+  B.QA = B.QB = B.LA = B.LB = 0; B.stA = B.stB = 0; B.cyA = B.cyB = B.ciA = B.ciB = 0;
   flat_run(A.qual_off, A.n, A.qual_bytes, A.tile_first, L, B);
   uint32_t my_err = B.err;
   if (__any(my_err != 0)) {
     for (int d = 32; d >= 1; d >>= 1) my_err |= __shfl_xor(my_err, d, 64);
     if ((threadIdx.x & 63) == 0) atomicOr(&A.err[0], my_err);
   }
+}
+
+// dense LUT -> compact LUT of the resident quality slots and the cycles a read of at most lmax bases can have
+__global__ __launch_bounds__(256) void k_compact_lut(const uint8_t *__restrict__ lut, uint8_t *__restrict__ clut, int n_cov, int n_slot, int lmax,
+                                                     int max_cycle, QSlots slot_q) {
+  const int ncl = 2 * lmax + 1, ncyc = 2 * max_cycle + 1;
+  const int total = n_cov * n_slot * ncl * 17;
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= total) return;
+  const int cx = id % 17, x = (id / 17) % ncl, slot = (id / (17 * ncl)) % n_slot, cov = id / (17 * ncl * n_slot);
+  const int q = slot_q.slot[slot], cyc = x - lmax;
+  clut[id] = lut[(((size_t)cov * ELP_NQUAL + q) * ncyc + (size_t)(cyc + max_cycle)) * 17 + cx];
 }
 
 static int bqsr_error(elp_ctx *c, uint32_t e) {
@@ -955,9 +1047,37 @@ int elp_bqsr_apply(elp_ctx *c, int max_cycle, const uint8_t *lut, const uint8_t 
       const uint64_t ntiles = (c->qual_bytes + FL_TILE - 1) / FL_TILE;
       const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, (uint64_t)c->n_cu * 8);
       ELP_TRY(ensure_flat_index(c));
-      ApplyArgs A{n, c->qual_bytes, c->qual_off.p, c->seq_off.p, c->qual.p, c->seq4.p, desc, c->tile_first.p, dl, max_cycle, c->err_flag.p};
-      if ((int64_t)c->max_l_seq > (int64_t)max_cycle) ELP_LAUNCH(c, "bqsr_apply", k_bqsr_apply_flat<true>, dim3(grid), dim3(FL_THREADS), 0, A);
-      else ELP_LAUNCH(c, "bqsr_apply", k_bqsr_apply_flat<false>, dim3(grid), dim3(FL_THREADS), 0, A);
+      // LDS-resident compact LUT when [n_cov][resident qualities][2*lmax+1][17] fits beside the kernel's static LDS
+      ELP_TRY(ensure_qual_present(c));
+      std::vector<int> quals;
+      for (int q = 6; q < ELP_NQUAL; q++)
+        if ((q < 64 ? (c->qual_present[0] >> q) : (c->qual_present[1] >> (q - 64))) & 1ull) quals.push_back(q);
+      const int lmax = (int)std::max<uint32_t>(c->max_l_seq, 1);
+      const bool chk = (int64_t)c->max_l_seq > (int64_t)max_cycle;
+      const size_t per_slot = (size_t)c->n_cov * (size_t)(2 * lmax + 1) * 17;
+      const size_t lds_budget = 160 * 1024 - (sizeof(FlatLds) + (size_t)FL_RMAX * 12 + 256 + 512);
+      const size_t cbytes = per_slot * quals.size();
+      ApplyArgs A{n, c->qual_bytes, c->qual_off.p, c->seq_off.p, c->qual.p, c->seq4.p, desc, c->tile_first.p, dl, max_cycle, c->err_flag.p,
+                  nullptr, c->n_cov, (int)quals.size(), lmax};
+      QSlots qs, sq;
+      memset(qs.slot, 255, sizeof qs.slot);
+      memset(sq.slot, 0, sizeof sq.slot);
+      for (size_t k = 0; k < quals.size(); k++) { qs.slot[quals[k]] = (uint8_t)k; sq.slot[k] = (uint8_t)quals[k]; }
+      if (!chk && !quals.empty() && quals.size() < 255 && cbytes + 16 <= lds_budget && lmax <= max_cycle) {
+        uint8_t *clut;
+        ELP_TRY(scratch(c, 4, cbytes + 64, &clut));
+        ELP_LAUNCH(c, "bqsr_apply_lut", k_compact_lut, dim3(blocks_for(cbytes, 256)), dim3(256), 0, (const uint8_t *)dl, clut, c->n_cov, (int)quals.size(),
+                   lmax, max_cycle, sq);
+        A.clut = clut;
+        const size_t dyn = (cbytes + 15) & ~(size_t)15;
+        ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bqsr_apply_flat<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        const unsigned g1 = (unsigned)std::min<uint64_t>(ntiles, (uint64_t)c->n_cu);
+        ELP_LAUNCH(c, "bqsr_apply", (k_bqsr_apply_flat<false, true>), dim3(g1), dim3(1024), dyn, A, qs);
+      } else if (chk) {
+        ELP_LAUNCH(c, "bqsr_apply", (k_bqsr_apply_flat<true, false>), dim3(grid), dim3(FL_THREADS), 0, A, qs);
+      } else {
+        ELP_LAUNCH(c, "bqsr_apply", (k_bqsr_apply_flat<false, false>), dim3(grid), dim3(FL_THREADS), 0, A, qs);
+      }
     }
   }
   uint32_t e[4];

@@ -15,10 +15,9 @@
 
 namespace elp {
 
-constexpr int FL_THREADS = 512;
+constexpr int FL_THREADS = 512;                                               // default workgroup size (kernels use blockDim.x)
 constexpr int FL_CHUNK = 16;
-constexpr int FL_CPL = 4;                                                    // chunks per lane and tile
-constexpr uint64_t FL_TILE = (uint64_t)FL_THREADS * FL_CHUNK * FL_CPL;       // 32 KiB of QUAL bytes per tile
+constexpr uint64_t FL_TILE = 32768;                                          // QUAL bytes per tile (2048 chunks)
 constexpr int FL_RMAX = 384;                                                 // reads held in LDS at a time (150-base reads: ~220 per tile)
 constexpr uint32_t FL_MAX_READ = 0x3FFFFFFFu;                                // per-read QUAL length limit of the tile-relative int32 offsets
 
@@ -138,7 +137,7 @@ __device__ __forceinline__ void flat_run(const uint64_t *__restrict__ qual_off, 
     for (uint32_t g0 = r_first; g0 <= r_last; g0 += FL_RMAX) {
       const uint32_t g1 = (g0 + FL_RMAX <= r_last + 1) ? g0 + FL_RMAX : r_last + 1;  // reads [g0, g1)
       const uint32_t ng = g1 - g0;
-      for (uint32_t k = threadIdx.x; k <= ng; k += FL_THREADS) {
+      for (uint32_t k = threadIdx.x; k <= ng; k += blockDim.x) {
         int64_t d = (int64_t)qual_off[g0 + k] - (int64_t)tb;
         const int64_t dmin = -(int64_t)FL_MAX_READ, dmax = (int64_t)FL_MAX_READ + (int64_t)FL_TILE;
         d = d < dmin ? dmin : (d > dmax ? dmax : d);
@@ -152,8 +151,8 @@ __device__ __forceinline__ void flat_run(const uint64_t *__restrict__ qual_off, 
       if (rb < re) {
         const float inv_avg = (float)ng / ((float)on - (float)o0);
 #pragma unroll 1
-        for (int j = 0; j < FL_CPL; j++) {
-          const int32_t pr = (j * FL_THREADS + (int)threadIdx.x) * FL_CHUNK;  // chunk start relative to the tile
+        for (int ck = (int)threadIdx.x; ck < (int)(FL_TILE / FL_CHUNK); ck += (int)blockDim.x) {
+          const int32_t pr = ck * FL_CHUNK;  // chunk start relative to the tile
           const int32_t lo = pr > rb ? pr : rb, hi = (pr + FL_CHUNK) < re ? (pr + FL_CHUNK) : re;
           if (lo >= hi) continue;
           const uint64_t p = tb + (uint64_t)pr;

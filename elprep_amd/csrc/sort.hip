@@ -83,7 +83,7 @@ struct ScoreBody {
   uint32_t bad;
 
   __device__ __forceinline__ void stage(uint32_t g0, uint32_t ng) {
-    for (uint32_t k = threadIdx.x; k < ng; k += FL_THREADS) {
+    for (uint32_t k = threadIdx.x; k < ng; k += blockDim.x) {
       acc[k] = 0;
       cand[k] = (flag[g0 + k] & (F_UNMAPPED | F_SECONDARY | F_SUPPLEMENTARY)) == 0;
     }
@@ -117,7 +117,7 @@ struct ScoreBody {
   __device__ __forceinline__ void round_end() {}
   __device__ __forceinline__ void chunk_end(uint64_t, int, int) {}
   __device__ __forceinline__ void group_end(uint32_t g0, uint32_t ng) {
-    for (uint32_t k = threadIdx.x; k < ng; k += FL_THREADS)
+    for (uint32_t k = threadIdx.x; k < ng; k += blockDim.x)
       if (acc[k]) atomicAdd(&score[g0 + k], acc[k]);  // a read can span two tiles / groups
   }
   __device__ __forceinline__ void tile_end(uint32_t) {}
@@ -239,6 +239,12 @@ int ensure_qual_present(elp_ctx *c) {
     ELP_LAUNCH(c, "qual_present_sample", k_qual_present_sample, dim3(grid), dim3(256), 0, (const uint8_t *)c->qual.p, c->qual_bytes, stride, qm);
     ELP_HIP(c, hipMemcpyAsync(c->qual_present, qm, 16, hipMemcpyDeviceToHost, c->stream));
     ELP_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  // test hook: ELP_DEBUG_QUAL_HINT_DROP=<q> removes one quality from the hint (exercises the kernels' no-slot paths)
+  if (const char *d = getenv("ELP_DEBUG_QUAL_HINT_DROP")) {
+    const int q = atoi(d);
+    if (q >= 0 && q < 64) c->qual_present[0] &= ~(1ull << q);
+    else if (q < 128) c->qual_present[1] &= ~(1ull << (q - 64));
   }
   c->have_qual_present = true;
   return 0;

@@ -206,6 +206,13 @@ def test_quality_hint_retry(monkeypatch):
     _check_gather_apply(b, h, refs, sites)
 
 
+def test_quality_hint_incomplete(monkeypatch):
+    """One quality missing from the hint: the gather retries, the LDS-LUT apply kernel takes its dense-LUT fix-up path."""
+    b, h, refs, sites = _random_case(6, 3000, quals=[2, 6, 13, 27, 38])
+    monkeypatch.setenv("ELP_DEBUG_QUAL_HINT_DROP", "27")
+    _check_gather_apply(b, h, refs, sites)
+
+
 def test_cycle_exceeds_max_cycle_is_an_error():
     """checkCycleCovariate (filters/bqsr.go:364-369): a counted base with |cycle| > max_cycle panics in the reference."""
     b, h, refs, sites = _random_case(7, 400, quals=[30, 35], len_mix=((100, 170, 1.0),))
