@@ -276,7 +276,7 @@ struct CountArgs {
   const uint8_t *qual, *seq4;
   const BqDesc *desc;
   const uint32_t *cigar, *cig_scratch;
-  const uint16_t *skip16;   // the skip-bit column viewed as 16-bit words (one per 16-byte QUAL chunk)
+  const uint8_t *skipbits;  // the skip-bit column: bit (QUAL offset of the base)
   uint8_t *const *ref_seq;  // packed (k_pack_reference)
   const int64_t *ref_seq_len;
   int n_cov, n_q, lmax, cs, rs, max_cycle;  // cs = cycle cells per row, rs = cs + 32 = row stride (u32 words)
@@ -293,7 +293,6 @@ struct CountArgs {
 // flushed (atomic adds into the dense int64 tables in HBM) at least every 50000 reads.
 template <bool CHECK_CYCLE>
 struct CountBody {
-  static constexpr int MAX_SEG = 2;
   // kernel arguments (scalar copies: a reference to the argument struct would keep this object in scratch memory)
   const uint64_t *__restrict__ seq_off;
   const uint8_t *__restrict__ qual;
@@ -301,7 +300,7 @@ struct CountBody {
   const uint4 *__restrict__ desc;
   const uint32_t *__restrict__ cigar;
   const uint32_t *__restrict__ cig_scratch;
-  const uint16_t *__restrict__ skip16;
+  const uint8_t *__restrict__ skipbits;
   uint8_t *const *__restrict__ ref_seq;
   const int64_t *__restrict__ ref_seq_len;
   unsigned long long *cycle_tbl, *ctx_tbl, *missing;
@@ -313,15 +312,7 @@ struct CountBody {
   const uint8_t *slot_q;
   uint32_t *tbl;
   uint32_t trash_idx;      // index (in u32 words, even) of this lane's 8-byte trash cell behind the tables
-  // per chunk
   uint64_t seq_base;
-  Chunk ch;
-  uint32_t skipw;
-  uint64_t F, X, CV, CX;   // nibble space: count-eligible flags, mismatch flags, context-valid flags, context keys
-  int nseg, split;
-  int PA, PB, stA, stB;    // 16 * (cov row offset) + 17 * cycle index of bit 0, and its step per bit
-  uint32_t cxA, cxB;       // cov row offset + cs
-  int cyA, cyB, ciA, ciB;  // cycle of bit 0 / increment (only used when CHECK_CYCLE)
   uint32_t err;
   uint32_t reads_since_flush;
 
@@ -331,52 +322,86 @@ struct CountBody {
     seq_base = seq_off[g0];
     for (uint32_t k = threadIdx.x; k < ng; k += blockDim.x) s_seq[k] = (uint32_t)(seq_off[g0 + k] - seq_base);
   }
-  __device__ __forceinline__ void chunk_begin(uint64_t p) {
-    ch.load(qual + p);
-    skipw = skip16[p >> 4];
-  }
-  __device__ __forceinline__ void round_begin() { F = X = CV = CX = 0; nseg = 0; split = 16; }
 
-  __device__ __forceinline__ int segment(uint32_t rl, int k0, int nb, int o) {
+  // One base, branch-free: a base that is not counted adds 0 to the lane's own trash cell behind the tables, so the sixteen
+  // bases of a block are straight-line code the compiler can interleave (no exec-mask juggling, no serialised LDS waits).
+  template <int I>
+  __device__ __forceinline__ void base(uint32_t fw, uint32_t xw, uint32_t vw, uint32_t cw, uint32_t ro, int P, int st, uint32_t cxb, int cyc0,
+                                       int ci, uint32_t trash, uint32_t &rare) {
+    constexpr int sh = 4 * (I & 7);
+    const bool fb = (fw >> sh) & 1u;
+    bool act = fb && ro < QROW_MISSING;
+    rare |= (fb && ro >= QROW_MISSING && ro != QROW_SKIP) ? (1u << I) : 0u;
+    if (CHECK_CYCLE) {  // checkCycleCovariate, bqsr.go:364-369
+      const int cyc = cyc0 + I * ci;
+      const bool out = act && (cyc > max_cycle || cyc < -max_cycle);
+      err |= out ? 16u : 0u;
+      act = act && !out;
+    }
+    const int t = P + I * st;
+    const uint32_t e = (xw >> sh) & 1u;
+    const uint32_t i1 = act ? ro + (uint32_t)(t >> 4) : trash;
+    atomicAdd(&tbl[i1], act ? (1u | (e << 16)) : 0u);
+    const bool act2 = act && ((vw >> sh) & 1u);
+    const uint32_t cx = (cw >> sh) & 15u;
+    const uint32_t i2 = act2 ? ro + cxb + 2u * cx : trash;
+    atomicAdd(reinterpret_cast<unsigned long long *>(&tbl[i2]), act2 ? (1ull | ((unsigned long long)e << 32)) : 0ull);
+  }
+  // bases with a quality > 93 or a quality without a table slot (rare: a rolled loop, kept out of the way of the hot code)
+  __device__ __forceinline__ void rare_bases(const Chunk &ch, uint32_t rare) {
+    const uint64_t lo = (uint64_t)ch.w0 | ((uint64_t)ch.w1 << 32), hi = (uint64_t)ch.w2 | ((uint64_t)ch.w3 << 32);
+#pragma unroll 1
+    while (rare) {
+      const int i = __builtin_ctz(rare);
+      rare &= rare - 1;
+      const uint32_t q = (uint32_t)(((i & 8) ? hi : lo) >> (8 * (i & 7))) & 0xFFu;
+      if (q >= (uint32_t)ELP_NQUAL) err |= 8u;
+      else { err |= 128u; atomicOr(&missing[q >> 6], 1ull << (q & 63u)); }
+    }
+  }
+
+  __device__ __forceinline__ void block(uint32_t rl, int k0, int nb, uint64_t qpos) {
     const uint4 dy = s_desc[2 * rl + 1];
     const uint32_t fl = (dy.w >> 8) & 0xFFu;
-    if (!(fl & BQ_ELIGIBLE)) return 0;
+    if (!(fl & BQ_ELIGIBLE)) return;
     const int a = (int)(dy.y & 0xFFFFu), len = (int)(dy.y >> 16);
-    const int kb = k0 - o;      // original base index of chunk bit 0
-    const int cbase = kb - a;   // clipped base index of chunk bit 0
+    const int cbase = k0 - a;   // clipped base index of block bit 0
     int blo = -cbase, bhi = len - cbase;
-    blo = blo > o ? blo : o;
-    bhi = bhi < o + nb ? bhi : o + nb;
-    if (blo >= bhi) return 0;
+    blo = blo > 0 ? blo : 0;
+    bhi = bhi < nb ? bhi : nb;
+    if (blo >= bhi) return;
     const uint4 dx = s_desc[2 * rl];
     const int32_t D0 = (int32_t)dx.x, D1 = (int32_t)dx.y, D2 = (int32_t)dx.z, refid = (int32_t)dx.w;
     const int b1 = (int)(dy.x & 0xFFFFu), b2 = (int)(dy.x >> 16);
     const int left = (int)(dy.z & 0xFFFFu), right = (dy.z >> 16) == 0xFFFFu ? -1 : (int)(dy.z >> 16);
     const uint32_t cov = dy.w & 0xFFu;
     const bool rev = fl & BQ_REVERSED;
+    Chunk ch;
+    ch.load(qual + qpos);
+    // known-site skip bits of the block's bases: bit (qpos + b) of the skip column
+    uint32_t skipw;
+    __builtin_memcpy(&skipw, skipbits + (qpos >> 3), 4);
+    skipw >>= (uint32_t)(qpos & 7);
     uint64_t S, N;
-    seq_nibbles(seq4 + seq_base + s_seq[rl], kb, rev ? 1 : -1, S, N);
+    seq_nibbles(seq4 + seq_base + s_seq[rl], k0, rev, S, N);
     const uint64_t inw = nib_range(blo, bhi);
     uint64_t ohS, cS, ohN, cN;
     nib_classify(S, ohS, cS);
     nib_classify(N, ohN, cN);
-    F |= inw & ohS;
+    const uint64_t F = inw & ohS & ~nib_spread16(skipw);
+    if (F == 0) return;
     // context covariate (bqsr.go:87-146): base and its predecessor in sequencing direction inside [left, right]
-    {
-      const int cl = left + (rev ? 0 : 1), cr = right - (rev ? 1 : 0);
-      const uint64_t valid = ohS & ohN & inw & nib_range_clamped(cl - cbase, cr - cbase + 1);
-      uint64_t k = cN | (cS << 2);
-      k ^= rev ? NIBF : 0ull;
-      CX |= k & nib_fill(valid);
-      CV |= valid;
-    }
+    const int cl = left + (rev ? 0 : 1), cr = right - (rev ? 1 : 0);
+    const uint64_t CV = ohS & ohN & inw & nib_range_clamped(cl - cbase, cr - cbase + 1);
+    const uint64_t CX = (cN | (cS << 2)) ^ (rev ? NIBF : 0ull);  // only read where CV is set
     // SNP events (computeSnpEvents, bqsr.go:254-285): read nibble vs reference nibble
+    uint64_t X;
     {
       const uint8_t *__restrict__ rp = ref_seq[refid];
       const int64_t rlen = ref_seq_len[refid];
       uint64_t R = 0;
       if (!(fl & BQ_COMPLEX)) {
-        const int B1 = b1 - cbase, B2 = b2 - cbase;  // piece boundaries in chunk bits (0xFFFF - cbase >= 16 when unused)
+        const int B1 = b1 - cbase, B2 = b2 - cbase;  // piece boundaries in block bits (0xFFFF - cbase >= 16 when unused)
         {
           const int hi = bhi < B1 ? bhi : B1;
           if (blo < hi) {
@@ -402,89 +427,42 @@ struct CountBody {
         const uint32_t *cg = ((fl & BQ_CIG_SCRATCH) ? cig_scratch : cigar) + (uint32_t)D0;
         R = ref_nibbles_complex(cg, b1, (int64_t)D2, cbase, blo, bhi, rp, rlen, S);
       }
-      X |= nib_nonzero(S ^ R) & inw;
+      X = nib_nonzero(S ^ R);  // only read where F is set
     }
-    // cycle covariate (bqsr.go:376-387) of chunk bit b: cf + (cbase + b) * ci
+    // cycle covariate (bqsr.go:376-387) of block bit b: cf + (cbase + b) * ci
     const int rof = (fl & BQ_LAST) ? -1 : 1;
     const int cf = rof + (rev ? (len - 1) * rof : 0), ci = rev ? -rof : rof;
     const int cyc0 = cf + cbase * ci;
     const uint32_t rowc = cov * (uint32_t)n_q * (uint32_t)rs;
     const int P = (int)(rowc << 4) + 17 * (cyc0 + lmax), st = 17 * ci;
-    if (nseg == 0) { PA = P; stA = st; cxA = rowc + (uint32_t)cs; cyA = cyc0; ciA = ci; }
-    else { PB = P; stB = st; cxB = rowc + (uint32_t)cs; cyB = cyc0; ciB = ci; split = blo; }
-    nseg++;
-    return 1;
-  }
+    const uint32_t cxb = rowc + (uint32_t)cs;
 
-  // One base, branch-free: a base that is not counted adds 0 to the lane's own trash cell behind the tables, so the sixteen
-  // bases of a chunk are straight-line code the compiler can interleave (no exec-mask juggling, no serialised LDS waits).
-  template <int I>
-  __device__ __forceinline__ void base(uint32_t fw, uint32_t xw, uint32_t vw, uint32_t cw, uint32_t ro, uint32_t trash, uint32_t &rare) {
-    constexpr int sh = 4 * (I & 7);
-    const bool fb = (fw >> sh) & 1u;
-    bool act = fb && ro < QROW_MISSING;
-    rare |= (fb && ro >= QROW_MISSING && ro != QROW_SKIP) ? (1u << I) : 0u;
-    const bool sb = I >= split;
-    if (CHECK_CYCLE) {  // checkCycleCovariate, bqsr.go:364-369
-      const int cyc = (sb ? cyB : cyA) + I * (sb ? ciB : ciA);
-      const bool out = act && (cyc > max_cycle || cyc < -max_cycle);
-      err |= out ? 16u : 0u;
-      act = act && !out;
-    }
-    const int t = (sb ? PB : PA) + I * (sb ? stB : stA);
-    const uint32_t e = (xw >> sh) & 1u;
-    const uint32_t i1 = act ? ro + (uint32_t)(t >> 4) : trash;
-    atomicAdd(&tbl[i1], act ? (1u | (e << 16)) : 0u);
-    const bool act2 = act && ((vw >> sh) & 1u);
-    const uint32_t cx = (cw >> sh) & 15u;
-    const uint32_t i2 = act2 ? ro + (sb ? cxB : cxA) + 2u * cx : trash;
-    atomicAdd(reinterpret_cast<unsigned long long *>(&tbl[i2]), act2 ? (1ull | ((unsigned long long)e << 32)) : 0ull);
-  }
-  // bases with a quality > 93 or a quality without a table slot (rare: a rolled loop, kept out of the way of the hot code)
-  __device__ __forceinline__ void rare_bases(uint32_t rare) {
-    const uint64_t lo = (uint64_t)ch.w0 | ((uint64_t)ch.w1 << 32), hi = (uint64_t)ch.w2 | ((uint64_t)ch.w3 << 32);
-#pragma unroll 1
-    while (rare) {
-      const int i = __builtin_ctz(rare);
-      rare &= rare - 1;
-      const uint32_t q = (uint32_t)(((i & 8) ? hi : lo) >> (8 * (i & 7))) & 0xFFu;
-      if (q >= (uint32_t)ELP_NQUAL) err |= 8u;
-      else { err |= 128u; atomicOr(&missing[q >> 6], 1ull << (q & 63u)); }
-    }
-  }
-
-  __device__ __forceinline__ void round_end() {
-    const uint64_t f = F & ~nib_spread16(skipw);
-    if (f == 0) return;
-    const uint32_t f0 = (uint32_t)f, x0 = (uint32_t)X, v0 = (uint32_t)CV, c0 = (uint32_t)CX;
-    const uint32_t f1 = (uint32_t)(f >> 32), x1 = (uint32_t)(X >> 32), v1 = (uint32_t)(CV >> 32), c1 = (uint32_t)(CX >> 32);
+    const uint32_t f0 = (uint32_t)F, x0 = (uint32_t)X, v0 = (uint32_t)CV, c0 = (uint32_t)CX;
+    const uint32_t f1 = (uint32_t)(F >> 32), x1 = (uint32_t)(X >> 32), v1 = (uint32_t)(CV >> 32), c1 = (uint32_t)(CX >> 32);
     const uint32_t trash = trash_idx;
     uint32_t rare = 0;
-    // groups of four bases between scheduling barriers: enough independent work to cover the LDS latency without letting the
+    // groups of eight bases between scheduling barriers: enough independent work to cover the LDS latency without letting the
     // scheduler hoist all sixteen address computations at once (register pressure => occupancy)
     {
       const uint32_t r0 = qrow[ch.get<0>()], r1 = qrow[ch.get<1>()], r2 = qrow[ch.get<2>()], r3 = qrow[ch.get<3>()];
       const uint32_t r4 = qrow[ch.get<4>()], r5 = qrow[ch.get<5>()], r6 = qrow[ch.get<6>()], r7 = qrow[ch.get<7>()];
-      base<0>(f0, x0, v0, c0, r0, trash, rare); base<1>(f0, x0, v0, c0, r1, trash, rare);
-      base<2>(f0, x0, v0, c0, r2, trash, rare); base<3>(f0, x0, v0, c0, r3, trash, rare);
-      __builtin_amdgcn_sched_barrier(0);
-      base<4>(f0, x0, v0, c0, r4, trash, rare); base<5>(f0, x0, v0, c0, r5, trash, rare);
-      base<6>(f0, x0, v0, c0, r6, trash, rare); base<7>(f0, x0, v0, c0, r7, trash, rare);
+      base<0>(f0, x0, v0, c0, r0, P, st, cxb, cyc0, ci, trash, rare); base<1>(f0, x0, v0, c0, r1, P, st, cxb, cyc0, ci, trash, rare);
+      base<2>(f0, x0, v0, c0, r2, P, st, cxb, cyc0, ci, trash, rare); base<3>(f0, x0, v0, c0, r3, P, st, cxb, cyc0, ci, trash, rare);
+      base<4>(f0, x0, v0, c0, r4, P, st, cxb, cyc0, ci, trash, rare); base<5>(f0, x0, v0, c0, r5, P, st, cxb, cyc0, ci, trash, rare);
+      base<6>(f0, x0, v0, c0, r6, P, st, cxb, cyc0, ci, trash, rare); base<7>(f0, x0, v0, c0, r7, P, st, cxb, cyc0, ci, trash, rare);
       __builtin_amdgcn_sched_barrier(0);
     }
     {
       const uint32_t r8 = qrow[ch.get<8>()], r9 = qrow[ch.get<9>()], r10 = qrow[ch.get<10>()], r11 = qrow[ch.get<11>()];
       const uint32_t r12 = qrow[ch.get<12>()], r13 = qrow[ch.get<13>()], r14 = qrow[ch.get<14>()], r15 = qrow[ch.get<15>()];
-      base<8>(f1, x1, v1, c1, r8, trash, rare); base<9>(f1, x1, v1, c1, r9, trash, rare);
-      base<10>(f1, x1, v1, c1, r10, trash, rare); base<11>(f1, x1, v1, c1, r11, trash, rare);
-      __builtin_amdgcn_sched_barrier(0);
-      base<12>(f1, x1, v1, c1, r12, trash, rare); base<13>(f1, x1, v1, c1, r13, trash, rare);
-      base<14>(f1, x1, v1, c1, r14, trash, rare); base<15>(f1, x1, v1, c1, r15, trash, rare);
+      base<8>(f1, x1, v1, c1, r8, P, st, cxb, cyc0, ci, trash, rare); base<9>(f1, x1, v1, c1, r9, P, st, cxb, cyc0, ci, trash, rare);
+      base<10>(f1, x1, v1, c1, r10, P, st, cxb, cyc0, ci, trash, rare); base<11>(f1, x1, v1, c1, r11, P, st, cxb, cyc0, ci, trash, rare);
+      base<12>(f1, x1, v1, c1, r12, P, st, cxb, cyc0, ci, trash, rare); base<13>(f1, x1, v1, c1, r13, P, st, cxb, cyc0, ci, trash, rare);
+      base<14>(f1, x1, v1, c1, r14, P, st, cxb, cyc0, ci, trash, rare); base<15>(f1, x1, v1, c1, r15, P, st, cxb, cyc0, ci, trash, rare);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (rare) rare_bases(rare);
+    if (rare) rare_bases(ch, rare);
   }
-  __device__ __forceinline__ void chunk_end(uint64_t, int, int) {}
   __device__ __forceinline__ void group_end(uint32_t, uint32_t) {}
 
   // adds the private table into the dense int64 tables (cycle: [cov][94][2*max_cycle+1][2], context: [cov][94][16][2]) and clears it
@@ -552,14 +530,13 @@ __global__ __launch_bounds__(FL_THREADS, 4) void k_bqsr_count(CountArgs A, QMap 
   __syncthreads();
   CountBody<CHECK_CYCLE> B;
   B.seq_off = A.seq_off; B.qual = A.qual; B.seq4 = A.seq4; B.desc = reinterpret_cast<const uint4 *>(A.desc);
-  B.cigar = A.cigar; B.cig_scratch = A.cig_scratch; B.skip16 = A.skip16; B.ref_seq = A.ref_seq; B.ref_seq_len = A.ref_seq_len;
+  B.cigar = A.cigar; B.cig_scratch = A.cig_scratch; B.skipbits = A.skipbits; B.ref_seq = A.ref_seq; B.ref_seq_len = A.ref_seq_len;
   B.cycle_tbl = A.cycle_tbl; B.ctx_tbl = A.ctx_tbl; B.missing = A.missing;
   B.n_cov = A.n_cov; B.n_q = A.n_q; B.lmax = A.lmax; B.cs = A.cs; B.rs = A.rs; B.max_cycle = A.max_cycle;
   B.s_desc = s_desc; B.s_seq = s_seq; B.qrow = qrow; B.slot_q = slot_q; B.tbl = tbl;
   B.trash_idx = (uint32_t)((n_all + 1) & ~1) + 2u * threadIdx.x;
   B.err = 0;
   B.reads_since_flush = 0;
-  B.cyA = B.cyB = B.ciA = B.ciB = 0; B.PA = B.PB = B.stA = B.stB = 0; B.cxA = B.cxB = 0;
   flat_run(A.qual_off, A.n, A.qual_bytes, A.tile_first, L, B);
   B.flush();
   uint32_t my_err = B.err;
@@ -634,7 +611,6 @@ struct QSlots { uint8_t slot[96]; };
 // of (read group, quality, cycle, context); cycle and context are taken on the full, unclipped read.
 template <bool CHECK_CYCLE, bool LDSLUT>
 struct ApplyBody {
-  static constexpr int MAX_SEG = 2;
   const uint64_t *__restrict__ seq_off;
   uint8_t *__restrict__ qual;
   const uint8_t *__restrict__ seq4;
@@ -647,14 +623,6 @@ struct ApplyBody {
   const uint8_t *llut;    // LDS: compact LUT (LDSLUT)
   int lmax, n_slot;
   uint64_t seq_base;
-  Chunk ch;
-  uint32_t inr;           // bits of the chunk that belong to records being recalibrated
-  uint64_t CV, CX;
-  int nseg, split;
-  uint32_t QA, QB;        // dense LUT offset of (cov, quality 0, cycle of bit 0, context 0)
-  uint32_t LA, LB;        // compact LUT offset of (cov, slot 0, cycle of bit 0, context 0)
-  int stA, stB;
-  int cyA, cyB, ciA, ciB;
   uint32_t err;
 
   __device__ __forceinline__ void stage(uint32_t g0, uint32_t ng) {
@@ -662,71 +630,36 @@ struct ApplyBody {
     seq_base = seq_off[g0];
     for (uint32_t k = threadIdx.x; k < ng; k += blockDim.x) s_seq[k] = (uint32_t)(seq_off[g0 + k] - seq_base);
   }
-  __device__ __forceinline__ void chunk_begin(uint64_t p) { ch.load(qual + p); }
-  __device__ __forceinline__ void round_begin() { inr = 0; CV = CX = 0; nseg = 0; split = 16; }
-  __device__ __forceinline__ int segment(uint32_t rl, int k0, int nb, int o) {
-    const uint64_t dw = s_desc[rl];
-    const uint32_t fl = (uint32_t)(dw >> 56);
-    if (!(fl & BQ_ELIGIBLE)) return 0;
-    const int left = (int)(dw & 0xFFFFu), right = ((dw >> 16) & 0xFFFFu) == 0xFFFFu ? -1 : (int)((dw >> 16) & 0xFFFFu);
-    const int len = (int)((dw >> 32) & 0xFFFFu);
-    const uint32_t cov = (uint32_t)(dw >> 48) & 0xFFu;
-    const int kb = k0 - o;
-    const bool rev = fl & BQ_REVERSED;
-    uint64_t S, N;
-    seq_nibbles(seq4 + seq_base + s_seq[rl], kb, rev ? 1 : -1, S, N);
-    const uint64_t inw = nib_range(o, o + nb);
-    inr |= ((1u << nb) - 1u) << o;
-    {
-      uint64_t ohS, cS, ohN, cN;
-      nib_classify(S, ohS, cS);
-      nib_classify(N, ohN, cN);
-      const int cl = left + (rev ? 0 : 1), cr = right - (rev ? 1 : 0);
-      const uint64_t valid = ohS & ohN & inw & nib_range_clamped(cl - kb, cr - kb + 1);
-      uint64_t k = cN | (cS << 2);
-      k ^= rev ? NIBF : 0ull;
-      CX |= k & nib_fill(valid);
-      CV |= valid;
-    }
-    const int rof = (fl & BQ_LAST) ? -1 : 1;
-    const int cf = rof + (rev ? (len - 1) * rof : 0), ci = rev ? -rof : rof;
-    const int cyc0 = cf + kb * ci;
-    const int ncyc = 2 * max_cycle + 1;
-    const uint32_t Q = (uint32_t)((int)cov * ELP_NQUAL * ncyc * 17 + (cyc0 + max_cycle) * 17);
-    const uint32_t Lq = (uint32_t)(((int)cov * n_slot * (2 * lmax + 1) + (cyc0 + lmax)) * 17);
-    if (nseg == 0) { QA = Q; LA = Lq; stA = 17 * ci; cyA = cyc0; ciA = ci; }
-    else { QB = Q; LB = Lq; stB = 17 * ci; cyB = cyc0; ciB = ci; split = o; }
-    nseg++;
-    return 1;
-  }
   // dense LUT in HBM/L2: one byte gather per base
   template <int I>
-  __device__ __forceinline__ uint32_t base(uint32_t vw, uint32_t cw, uint32_t qstride) {
+  __device__ __forceinline__ uint32_t base(const Chunk &ch, int nb, uint32_t vw, uint32_t cw, uint32_t Q, int st, int cyc0, int ci, uint32_t qstride) {
     constexpr int sh = 4 * (I & 7);
     const uint32_t q = ch.get<I>();
-    bool act = ((inr >> I) & 1u) && q >= 6u;
-    if (act && q >= (uint32_t)ELP_NQUAL) { err |= 8u; act = false; }
-    const bool sb = I >= split;
+    bool act = I < nb && q >= 6u;
+    err |= (act && q >= (uint32_t)ELP_NQUAL) ? 8u : 0u;
+    act = act && q < (uint32_t)ELP_NQUAL;
     if (CHECK_CYCLE) {
-      const int cyc = (sb ? cyB : cyA) + I * (sb ? ciB : ciA);
-      if (act && (cyc > max_cycle || cyc < -max_cycle)) { err |= 16u; act = false; }
+      const int cyc = cyc0 + I * ci;
+      const bool out = act && (cyc > max_cycle || cyc < -max_cycle);
+      err |= out ? 16u : 0u;
+      act = act && !out;
     }
     const uint32_t cx = ((cw >> sh) & 15u) | ((((~vw) >> sh) & 1u) << 4);  // 16 = no context
-    const uint32_t idx = (sb ? QB : QA) + (uint32_t)(I * (sb ? stB : stA)) + q * qstride + cx;
+    const uint32_t idx = Q + (uint32_t)(I * st) + q * qstride + cx;
     const uint32_t v = lut[act ? idx : 0u];
     return act ? v : q;
   }
   // compact LUT in LDS: one LDS byte read per base; a quality without a resident slot is left for the fix-up loop
   template <int I>
-  __device__ __forceinline__ uint32_t base_lds(uint32_t vw, uint32_t cw, uint32_t sstride, uint32_t slot, uint32_t &todo) {
+  __device__ __forceinline__ uint32_t base_lds(const Chunk &ch, int nb, uint32_t vw, uint32_t cw, uint32_t Lq, int st, int cyc0, int ci,
+                                               uint32_t sstride, uint32_t slot, uint32_t &todo) {
     constexpr int sh = 4 * (I & 7);
     const uint32_t q = ch.get<I>();
-    bool act = ((inr >> I) & 1u) && q >= 6u;
+    bool act = I < nb && q >= 6u;
     err |= (act && q >= (uint32_t)ELP_NQUAL) ? 8u : 0u;
     act = act && q < (uint32_t)ELP_NQUAL;
-    const bool sb = I >= split;
     if (CHECK_CYCLE) {
-      const int cyc = (sb ? cyB : cyA) + I * (sb ? ciB : ciA);
+      const int cyc = cyc0 + I * ci;
       const bool out = act && (cyc > max_cycle || cyc < -max_cycle);
       err |= out ? 16u : 0u;
       act = act && !out;
@@ -734,12 +667,12 @@ struct ApplyBody {
     todo |= (act && slot == 255u) ? (1u << I) : 0u;
     act = act && slot != 255u;
     const uint32_t cx = ((cw >> sh) & 15u) | ((((~vw) >> sh) & 1u) << 4);
-    const uint32_t idx = (sb ? LB : LA) + (uint32_t)(I * (sb ? stB : stA)) + slot * sstride + cx;
+    const uint32_t idx = Lq + (uint32_t)(I * st) + slot * sstride + cx;
     const uint32_t v = llut[act ? idx : 0u];
     return act ? v : q;
   }
   // bases whose quality has no resident slot: dense LUT, rolled loop (rare)
-  __device__ __forceinline__ void fixup(uint32_t todo) {
+  __device__ __forceinline__ void fixup(Chunk &ch, uint32_t todo, uint64_t CV, uint64_t CX, uint32_t Q, int st) {
     uint64_t lo = (uint64_t)ch.w0 | ((uint64_t)ch.w1 << 32), hi = (uint64_t)ch.w2 | ((uint64_t)ch.w3 << 32);
     const uint32_t qstride = (uint32_t)(2 * max_cycle + 1) * 17u;
 #pragma unroll 1
@@ -748,9 +681,8 @@ struct ApplyBody {
       todo &= todo - 1;
       const int bs = 8 * (i & 7);
       const uint32_t q = (uint32_t)(((i & 8) ? hi : lo) >> bs) & 0xFFu;
-      const bool sb = i >= split;
       const uint32_t cx = ((uint32_t)(CX >> (4 * i)) & 15u) | ((((uint32_t)(~CV >> (4 * i))) & 1u) << 4);
-      const uint32_t idx = (sb ? QB : QA) + (uint32_t)(i * (sb ? stB : stA)) + q * qstride + cx;
+      const uint32_t idx = Q + (uint32_t)(i * st) + q * qstride + cx;
       const uint64_t v = (uint64_t)lut[idx];
       const uint64_t m = ~(0xFFull << bs);
       lo = (i & 8) ? lo : ((lo & m) | (v << bs));
@@ -758,47 +690,67 @@ struct ApplyBody {
     }
     ch.w0 = (uint32_t)lo; ch.w1 = (uint32_t)(lo >> 32); ch.w2 = (uint32_t)hi; ch.w3 = (uint32_t)(hi >> 32);
   }
-  __device__ __forceinline__ void round_end() {
-    if (inr == 0) return;
+
+  __device__ __forceinline__ void block(uint32_t rl, int k0, int nb, uint64_t qpos) {
+    const uint64_t dw = s_desc[rl];
+    const uint32_t fl = (uint32_t)(dw >> 56);
+    if (!(fl & BQ_ELIGIBLE)) return;
+    const int left = (int)(dw & 0xFFFFu), right = ((dw >> 16) & 0xFFFFu) == 0xFFFFu ? -1 : (int)((dw >> 16) & 0xFFFFu);
+    const int len = (int)((dw >> 32) & 0xFFFFu);
+    const uint32_t cov = (uint32_t)(dw >> 48) & 0xFFu;
+    const bool rev = fl & BQ_REVERSED;
+    Chunk ch;
+    ch.load(qual + qpos);
+    uint64_t S, N;
+    seq_nibbles(seq4 + seq_base + s_seq[rl], k0, rev, S, N);
+    uint64_t ohS, cS, ohN, cN;
+    nib_classify(S, ohS, cS);
+    nib_classify(N, ohN, cN);
+    const int cl = left + (rev ? 0 : 1), cr = right - (rev ? 1 : 0);
+    int rhi = cr - k0 + 1;
+    rhi = rhi < nb ? rhi : nb;
+    const uint64_t CV = ohS & ohN & nib_range_clamped(cl - k0, rhi);
+    const uint64_t CX = ((cN | (cS << 2)) ^ (rev ? NIBF : 0ull)) & nib_fill(CV);
+    const int rof = (fl & BQ_LAST) ? -1 : 1;
+    const int cf = rof + (rev ? (len - 1) * rof : 0), ci = rev ? -rof : rof;
+    const int cyc0 = cf + k0 * ci, st = 17 * ci;
+    const int ncyc = 2 * max_cycle + 1;
+    const uint32_t Q = (uint32_t)((int)cov * ELP_NQUAL * ncyc * 17 + (cyc0 + max_cycle) * 17);
     const uint32_t v0 = (uint32_t)CV, v1 = (uint32_t)(CV >> 32), c0 = (uint32_t)CX, c1 = (uint32_t)(CX >> 32);
     uint32_t b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, b10, b11, b12, b13, b14, b15;
     uint32_t todo = 0;
     if (LDSLUT) {
+      const uint32_t Lq = (uint32_t)(((int)cov * n_slot * (2 * lmax + 1) + (cyc0 + lmax)) * 17);
       const uint32_t ss = (uint32_t)(2 * lmax + 1) * 17u;
       const uint32_t s0 = qs[ch.get<0>()], s1 = qs[ch.get<1>()], s2 = qs[ch.get<2>()], s3 = qs[ch.get<3>()];
       const uint32_t s4 = qs[ch.get<4>()], s5 = qs[ch.get<5>()], s6 = qs[ch.get<6>()], s7 = qs[ch.get<7>()];
       const uint32_t s8 = qs[ch.get<8>()], s9 = qs[ch.get<9>()], s10 = qs[ch.get<10>()], s11 = qs[ch.get<11>()];
       const uint32_t s12 = qs[ch.get<12>()], s13 = qs[ch.get<13>()], s14 = qs[ch.get<14>()], s15 = qs[ch.get<15>()];
-      b0 = base_lds<0>(v0, c0, ss, s0, todo); b1 = base_lds<1>(v0, c0, ss, s1, todo); b2 = base_lds<2>(v0, c0, ss, s2, todo);
-      b3 = base_lds<3>(v0, c0, ss, s3, todo); b4 = base_lds<4>(v0, c0, ss, s4, todo); b5 = base_lds<5>(v0, c0, ss, s5, todo);
-      b6 = base_lds<6>(v0, c0, ss, s6, todo); b7 = base_lds<7>(v0, c0, ss, s7, todo); b8 = base_lds<8>(v1, c1, ss, s8, todo);
-      b9 = base_lds<9>(v1, c1, ss, s9, todo); b10 = base_lds<10>(v1, c1, ss, s10, todo); b11 = base_lds<11>(v1, c1, ss, s11, todo);
-      b12 = base_lds<12>(v1, c1, ss, s12, todo); b13 = base_lds<13>(v1, c1, ss, s13, todo); b14 = base_lds<14>(v1, c1, ss, s14, todo);
-      b15 = base_lds<15>(v1, c1, ss, s15, todo);
+      b0 = base_lds<0>(ch, nb, v0, c0, Lq, st, cyc0, ci, ss, s0, todo); b1 = base_lds<1>(ch, nb, v0, c0, Lq, st, cyc0, ci, ss, s1, todo);
+      b2 = base_lds<2>(ch, nb, v0, c0, Lq, st, cyc0, ci, ss, s2, todo); b3 = base_lds<3>(ch, nb, v0, c0, Lq, st, cyc0, ci, ss, s3, todo);
+      b4 = base_lds<4>(ch, nb, v0, c0, Lq, st, cyc0, ci, ss, s4, todo); b5 = base_lds<5>(ch, nb, v0, c0, Lq, st, cyc0, ci, ss, s5, todo);
+      b6 = base_lds<6>(ch, nb, v0, c0, Lq, st, cyc0, ci, ss, s6, todo); b7 = base_lds<7>(ch, nb, v0, c0, Lq, st, cyc0, ci, ss, s7, todo);
+      b8 = base_lds<8>(ch, nb, v1, c1, Lq, st, cyc0, ci, ss, s8, todo); b9 = base_lds<9>(ch, nb, v1, c1, Lq, st, cyc0, ci, ss, s9, todo);
+      b10 = base_lds<10>(ch, nb, v1, c1, Lq, st, cyc0, ci, ss, s10, todo); b11 = base_lds<11>(ch, nb, v1, c1, Lq, st, cyc0, ci, ss, s11, todo);
+      b12 = base_lds<12>(ch, nb, v1, c1, Lq, st, cyc0, ci, ss, s12, todo); b13 = base_lds<13>(ch, nb, v1, c1, Lq, st, cyc0, ci, ss, s13, todo);
+      b14 = base_lds<14>(ch, nb, v1, c1, Lq, st, cyc0, ci, ss, s14, todo); b15 = base_lds<15>(ch, nb, v1, c1, Lq, st, cyc0, ci, ss, s15, todo);
     } else {
-      const uint32_t qstride = (uint32_t)(2 * max_cycle + 1) * 17u;
-      b0 = base<0>(v0, c0, qstride); b1 = base<1>(v0, c0, qstride); b2 = base<2>(v0, c0, qstride); b3 = base<3>(v0, c0, qstride);
-      b4 = base<4>(v0, c0, qstride); b5 = base<5>(v0, c0, qstride); b6 = base<6>(v0, c0, qstride); b7 = base<7>(v0, c0, qstride);
-      b8 = base<8>(v1, c1, qstride); b9 = base<9>(v1, c1, qstride); b10 = base<10>(v1, c1, qstride); b11 = base<11>(v1, c1, qstride);
-      b12 = base<12>(v1, c1, qstride); b13 = base<13>(v1, c1, qstride); b14 = base<14>(v1, c1, qstride); b15 = base<15>(v1, c1, qstride);
+      const uint32_t qstride = (uint32_t)ncyc * 17u;
+      b0 = base<0>(ch, nb, v0, c0, Q, st, cyc0, ci, qstride); b1 = base<1>(ch, nb, v0, c0, Q, st, cyc0, ci, qstride);
+      b2 = base<2>(ch, nb, v0, c0, Q, st, cyc0, ci, qstride); b3 = base<3>(ch, nb, v0, c0, Q, st, cyc0, ci, qstride);
+      b4 = base<4>(ch, nb, v0, c0, Q, st, cyc0, ci, qstride); b5 = base<5>(ch, nb, v0, c0, Q, st, cyc0, ci, qstride);
+      b6 = base<6>(ch, nb, v0, c0, Q, st, cyc0, ci, qstride); b7 = base<7>(ch, nb, v0, c0, Q, st, cyc0, ci, qstride);
+      b8 = base<8>(ch, nb, v1, c1, Q, st, cyc0, ci, qstride); b9 = base<9>(ch, nb, v1, c1, Q, st, cyc0, ci, qstride);
+      b10 = base<10>(ch, nb, v1, c1, Q, st, cyc0, ci, qstride); b11 = base<11>(ch, nb, v1, c1, Q, st, cyc0, ci, qstride);
+      b12 = base<12>(ch, nb, v1, c1, Q, st, cyc0, ci, qstride); b13 = base<13>(ch, nb, v1, c1, Q, st, cyc0, ci, qstride);
+      b14 = base<14>(ch, nb, v1, c1, Q, st, cyc0, ci, qstride); b15 = base<15>(ch, nb, v1, c1, Q, st, cyc0, ci, qstride);
     }
     ch.w0 = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
     ch.w1 = b4 | (b5 << 8) | (b6 << 16) | (b7 << 24);
     ch.w2 = b8 | (b9 << 8) | (b10 << 16) | (b11 << 24);
     ch.w3 = b12 | (b13 << 8) | (b14 << 16) | (b15 << 24);
-    if (LDSLUT && todo) fixup(todo);
-  }
-  template <int I>
-  __device__ __forceinline__ void store_byte(uint64_t p, int lo, int hi) {
-    if (lo <= I && I < hi) qual[p + I] = (uint8_t)ch.get<I>();
-  }
-  template <int... Is>
-  __device__ __forceinline__ void store_bytes(std::integer_sequence<int, Is...>, uint64_t p, int lo, int hi) {
-    (store_byte<Is>(p, lo, hi), ...);
-  }
-  __device__ __forceinline__ void chunk_end(uint64_t p, int lo, int hi) {
-    if (lo == 0 && hi == FL_CHUNK) ch.store(qual + p);
-    else store_bytes(std::make_integer_sequence<int, 16>{}, p, lo, hi);  // partial chunk: another lane may own the rest
+    if (LDSLUT && todo) fixup(ch, todo, CV, CX, Q, st);
+    ch.store(qual + qpos, nb);
   }
   __device__ __forceinline__ void group_end(uint32_t, uint32_t) {}
   __device__ __forceinline__ void tile_end(uint32_t) {}
@@ -824,7 +776,6 @@ __global__ __launch_bounds__(LDSLUT ? 1024 : FL_THREADS, LDSLUT ? 4 : 4) void k_
   B.max_cycle = A.max_cycle; B.s_desc = s_desc; B.s_seq = s_seq;
   B.qs = qs; B.llut = llut; B.lmax = A.lmax; B.n_slot = A.n_slot;
   B.err = 0;
-  B.QA = B.QB = B.LA = B.LB = 0; B.stA = B.stB = 0; B.cyA = B.cyB = B.ciA = B.ciB = 0;
   flat_run(A.qual_off, A.n, A.qual_bytes, A.tile_first, L, B);
   uint32_t my_err = B.err;
   if (__any(my_err != 0)) {
@@ -939,7 +890,7 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
         for (int s = 0; s < nqs; s++) qm.slot[quals[q0 + s]] = (uint8_t)s;
         const size_t dyn = (size_t)c->n_cov * nqs * rs * 4 + 8 + (size_t)FL_THREADS * 8;  // tables + one trash cell per lane
         CountArgs A{n, c->qual_bytes, c->qual_off.p, c->seq_off.p, c->qual.p, c->seq4.p, desc, c->cigar.p, cs_pool,
-                    reinterpret_cast<const uint16_t *>(skipbits), c->d_ref_seq.p, c->d_ref_seq_len.p, c->n_cov, nqs, lmax, cs, rs, max_cycle,
+                    reinterpret_cast<const uint8_t *>(skipbits), c->d_ref_seq.p, c->d_ref_seq_len.p, c->n_cov, nqs, lmax, cs, rs, max_cycle,
                     tb + nq, tb + nq + nc, missing, c->err_flag.p, c->tile_first.p};
         if (check_cycle) {
           ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bqsr_count<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));

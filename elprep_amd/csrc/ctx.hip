@@ -198,8 +198,8 @@ int elp_stage(elp_ctx *c, const elp_batch *b) {
     uint64_t ql = b->qname_off[i + 1] - b->qname_off[i];
     if (ql > c->max_qname_len) c->max_qname_len = (uint32_t)ql;
     if (b->l_seq[i] > c->max_l_seq) c->max_l_seq = b->l_seq[i];
-    if (b->qual_off[i + 1] - b->qual_off[i] > 0x3FFFFFFFull || b->l_seq[i] > 0x3FFFFFFFu)
-      return set_error(c, ELP_ERR_UNSUPPORTED, "record %llu: more than 2^30-1 bases", (unsigned long long)i);
+    if (b->qual_off[i + 1] - b->qual_off[i] > 0x3FFFFFull || b->l_seq[i] > 0x3FFFFFu)  // FL_MAX_READ (flat.hpp)
+      return set_error(c, ELP_ERR_UNSUPPORTED, "record %llu: more than 4194303 bases", (unsigned long long)i);
     if (b->rgid[i] != ELP_NIL16 && b->rgid[i] >= c->n_rg) return set_error(c, ELP_ERR_ARG, "record %llu: rgid %u not in header", (unsigned long long)i, b->rgid[i]);
     if (b->refid[i] >= c->n_ref) return set_error(c, ELP_ERR_ARG, "record %llu: refid %d not in header", (unsigned long long)i, b->refid[i]);
   }

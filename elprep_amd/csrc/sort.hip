@@ -62,24 +62,17 @@ __global__ __launch_bounds__(256) void k_adapt_fixed(uint64_t n, const int32_t *
   score[i] = 0;
 }
 
-// byte mask (0xFF per byte) for bytes [lo, hi) of a 32-bit word, lo/hi relative to the word and unclamped
-__device__ __forceinline__ uint32_t byte_range32(int lo, int hi) {
-  lo = lo < 0 ? 0 : lo;
-  hi = hi > 4 ? 4 : hi;
-  return lo < hi ? ((0xFFFFFFFFu << (8 * lo)) & (0xFFFFFFFFu >> (32 - 8 * hi))) : 0u;
-}
+// byte mask (0xFF per byte) for the first n bytes (n unclamped) of a 32-bit word
+__device__ __forceinline__ uint32_t first_bytes32(int n) { return n <= 0 ? 0u : (n >= 4 ? 0xFFFFFFFFu : (0xFFFFFFFFu >> (32 - 8 * n))); }
 
 // computePhredScore :57-68 as a flat stream over the QUAL column: sum of qualities >= 15 per duplicate-marking candidate;
 // any quality > 93 in a candidate is an error.  SWAR over the lane's 16 bytes, v_sad_u8 for the byte sums.
 struct ScoreBody {
-  static constexpr int MAX_SEG = 1 << 20;  // segments never use parameter slots
   const uint16_t *__restrict__ flag;
   const uint8_t *__restrict__ qual;
   int32_t *score;
-  int32_t *acc;    // LDS [FL_RMAX]: per-read partial sums of this group (LDS atomics; one global atomic per read and group)
+  int32_t *acc;    // LDS [FL_RMAX]: per-read partial sums of this group (LDS atomics; one global store per read)
   uint8_t *cand;   // LDS [FL_RMAX]: duplicate-marking candidate?
-  uint32_t xa, xb, xc, xd;  // the chunk's bytes with values < 15 zeroed
-  uint32_t ba, bb, bc, bd;  // bit 7 of a byte set: quality >= 94
   uint32_t bad;
 
   __device__ __forceinline__ void stage(uint32_t g0, uint32_t ng) {
@@ -88,37 +81,25 @@ struct ScoreBody {
       cand[k] = (flag[g0 + k] & (F_UNMAPPED | F_SECONDARY | F_SUPPLEMENTARY)) == 0;
     }
   }
-  static __device__ __forceinline__ void prep(uint32_t x, uint32_t &x15, uint32_t &bw) {
+  static __device__ __forceinline__ uint32_t part(uint32_t x, uint32_t m, uint32_t s, uint32_t &badw) {
     const uint32_t ge15 = (((x | 0x80808080u) - 0x0F0F0F0Fu) & 0x80808080u) >> 7;  // bit 0 of the byte: low 7 bits >= 15
-    x15 = x & (ge15 * 0xFFu);
-    bw = (((x | 0x80808080u) - 0x5E5E5E5Eu) | x) & 0x80808080u;                  // byte >= 94
+    badw |= ((((x | 0x80808080u) - 0x5E5E5E5Eu) | x) & 0x80808080u) & m;          // byte >= 94
+    return __builtin_amdgcn_sad_u8(x & (ge15 * 0xFFu) & m, 0u, s);
   }
-  __device__ __forceinline__ void chunk_begin(uint64_t p) {
+  __device__ __forceinline__ void block(uint32_t rl, int, int nb, uint64_t qpos) {
+    if (!cand[rl]) return;
     Chunk ch;
-    ch.load(qual + p);
-    prep(ch.w0, xa, ba);
-    prep(ch.w1, xb, bb);
-    prep(ch.w2, xc, bc);
-    prep(ch.w3, xd, bd);
-  }
-  __device__ __forceinline__ void round_begin() {}
-  __device__ __forceinline__ int segment(uint32_t rl, int, int nb, int o) {
-    if (!cand[rl]) return 0;
-    const uint32_t m0 = byte_range32(o, o + nb), m1 = byte_range32(o - 4, o + nb - 4), m2 = byte_range32(o - 8, o + nb - 8),
-                   m3 = byte_range32(o - 12, o + nb - 12);
-    uint32_t s = __builtin_amdgcn_sad_u8(xa & m0, 0u, 0u);
-    s = __builtin_amdgcn_sad_u8(xb & m1, 0u, s);
-    s = __builtin_amdgcn_sad_u8(xc & m2, 0u, s);
-    s = __builtin_amdgcn_sad_u8(xd & m3, 0u, s);
-    bad |= (ba & m0) | (bb & m1) | (bc & m2) | (bd & m3);
+    ch.load(qual + qpos);
+    uint32_t s = 0, b = 0;
+    s = part(ch.w0, first_bytes32(nb), s, b);
+    s = part(ch.w1, first_bytes32(nb - 4), s, b);
+    s = part(ch.w2, first_bytes32(nb - 8), s, b);
+    s = part(ch.w3, first_bytes32(nb - 12), s, b);
+    bad |= b;
     if (s) atomicAdd(&acc[rl], (int32_t)s);
-    return 0;
   }
-  __device__ __forceinline__ void round_end() {}
-  __device__ __forceinline__ void chunk_end(uint64_t, int, int) {}
   __device__ __forceinline__ void group_end(uint32_t g0, uint32_t ng) {
-    for (uint32_t k = threadIdx.x; k < ng; k += blockDim.x)
-      if (acc[k]) atomicAdd(&score[g0 + k], acc[k]);  // a read can span two tiles / groups
+    for (uint32_t k = threadIdx.x; k < ng; k += blockDim.x) score[g0 + k] = acc[k];  // a read belongs to exactly one group
   }
   __device__ __forceinline__ void tile_end(uint32_t) {}
 };
@@ -129,7 +110,7 @@ __global__ __launch_bounds__(FL_THREADS) void k_score_flat(uint64_t n, const uin
   __shared__ FlatLds L;
   __shared__ int32_t acc[FL_RMAX];
   __shared__ uint8_t cand[FL_RMAX];
-  ScoreBody B{flag, qual, score, acc, cand, 0, 0, 0, 0, 0, 0, 0, 0, 0u};
+  ScoreBody B{flag, qual, score, acc, cand, 0u};
   flat_run(qual_off, n, qual_bytes, tile_first, L, B);
   if (__any(B.bad != 0) && (threadIdx.x & 63) == 0) atomicOr(&err[0], 1u);
 }
@@ -170,16 +151,17 @@ __global__ __launch_bounds__(256) void k_qual_present_sample(const uint8_t *__re
   }
 }
 
-// tile_first[t] = last read r (0 <= r <= n) with qual_off[r] <= t * FL_TILE, for t in [0, ntiles]
+// tile_first[t] = first read r (0 <= r <= n) with qual_off[r] >= t * FL_TILE, for t in [0, ntiles); tile_first[ntiles] = n
 __global__ __launch_bounds__(256) void k_flat_index(const uint64_t *__restrict__ qual_off, uint64_t n_reads, uint64_t ntiles,
                                                     uint32_t *__restrict__ tile_first) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t > ntiles) return;
+  if (t == ntiles) { tile_first[t] = (uint32_t)n_reads; return; }
   const uint64_t x = t * FL_TILE;
-  uint64_t lo = 0, hi = n_reads + 1;  // invariant: qual_off[lo] <= x (qual_off[0] == 0)
-  while (hi - lo > 1) {
+  uint64_t lo = 0, hi = n_reads;  // answer in [lo, hi]: qual_off[n_reads] = qual_bytes > x
+  while (lo < hi) {
     const uint64_t mid = lo + (hi - lo) / 2;
-    if (qual_off[mid] <= x) lo = mid; else hi = mid;
+    if (qual_off[mid] >= x) hi = mid; else lo = mid + 1;
   }
   tile_first[t] = (uint32_t)lo;
 }
