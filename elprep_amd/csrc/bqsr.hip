@@ -224,15 +224,29 @@ __global__ __launch_bounds__(256) void k_pack_reference(const uint8_t *__restric
   packed[i] = (uint8_t)out;
 }
 constexpr int64_t REF_PAD = 32;  // zero bytes after the packed bases of a contig
+constexpr int REF_LDS = 256;      // contigs whose packed-base pointer and length are kept in LDS by k_bqsr_count
 
-// nibble b = reference base jb + b of the contig (0 outside [0, rlen))
-__device__ __forceinline__ uint64_t ref_nibbles(const uint8_t *__restrict__ rp, int64_t rlen, int64_t jb) {
-  if (jb >= rlen || jb <= -16) return 0ull;
-  const int64_t jw = jb < 0 ? 0 : (jb & ~(int64_t)1);
-  uint64_t v0, v1;
+// Reference window of a block: ref_load ISSUES the load of the 32 packed bases around reference index jb (clamped into the
+// contig; its packed bases are followed by REF_PAD zero bytes) and returns the nibble shift for ref_unpack, REF_NONE if
+// nothing of [jb, jb+16) lies inside the contig.  ref_unpack: nibble b = reference base jb + b (0 outside [0, rlen)).
+constexpr int REF_NONE = 99;
+__device__ __forceinline__ int ref_load(const uint8_t *__restrict__ rp, int64_t rlen, int64_t jb, uint64_t &v0, uint64_t &v1) {
+  const bool valid = jb < rlen && jb > -16;
+  int64_t jw = jb < 0 ? 0 : jb;
+  jw = jw > rlen ? rlen : jw;
+  jw &= ~(int64_t)1;
   __builtin_memcpy(&v0, rp + (jw >> 1), 8);
   __builtin_memcpy(&v1, rp + (jw >> 1) + 8, 8);
-  return nib_ext(v0, v1, (int)(jb - jw));
+  return valid ? (int)(jb - jw) : REF_NONE;  // -15 .. 1
+}
+__device__ __forceinline__ uint64_t ref_unpack(uint64_t v0, uint64_t v1, int sn) {
+  const uint64_t r = nib_ext(v0, v1, sn == REF_NONE ? 0 : sn);
+  return sn == REF_NONE ? 0ull : r;
+}
+__device__ __forceinline__ uint64_t ref_nibbles(const uint8_t *__restrict__ rp, int64_t rlen, int64_t jb) {
+  uint64_t v0, v1;
+  const int sn = ref_load(rp, rlen, jb, v0, v1);
+  return ref_unpack(v0, v1, sn);
 }
 
 // reference nibbles of a chunk for a record whose clipped CIGAR has more than three pieces: walks the CIGAR.
@@ -266,8 +280,8 @@ __device__ __noinline__ uint64_t ref_nibbles_complex(const uint32_t *__restrict_
 
 // quality value -> LDS table row offset of this pass; the special values:
 constexpr uint16_t QROW_SKIP = 0xFFFF;     // quality < 6 (minInterestingQual, bqsr.go:698) or handled by another pass
-constexpr uint16_t QROW_BAD = 0xFFFE;      // quality > 93
-constexpr uint16_t QROW_MISSING = 0xFFFD;  // a quality the host did not know about (sampling hint incomplete): reported, host retries
+// qualities > 93 count into row n_q ("bad"), qualities 6..93 the host did not give a slot (sampling hint incomplete) into row
+// n_q + 1 ("missing") of their covariate; the flush turns a non-zero cell of those rows into an error bit and the host reacts
 struct QMap { uint8_t slot[96]; };         // 6..93 -> slot of this pass, 255 = other pass, 254 = unknown to the host
 
 struct CountArgs {
@@ -279,9 +293,8 @@ struct CountArgs {
   const uint8_t *skipbits;  // the skip-bit column: bit (QUAL offset of the base)
   uint8_t *const *ref_seq;  // packed (k_pack_reference)
   const int64_t *ref_seq_len;
-  int n_cov, n_q, lmax, cs, rs, max_cycle;  // cs = cycle cells per row, rs = cs + 32 = row stride (u32 words)
+  int n_ref, n_cov, n_q, lmax, cs, rs, max_cycle;  // cs = cycle cells per row, rs = cs + 32 = row stride (u32 words)
   unsigned long long *cycle_tbl, *ctx_tbl;  // dense int64 tables of the C ABI (device copies)
-  unsigned long long *missing;              // [2] qualities met without a table slot
   uint32_t *err;
   const uint32_t *tile_first;
 };
@@ -291,7 +304,7 @@ struct CountArgs {
 // cycle cell of cycle index x = cycle + lmax is (17 x) >> 4 = x + x / 16: lanes of a wave work on bases 16 apart, the skew puts
 // them on different banks.  16-bit cycle counters are safe because a read touches a cycle cell at most once and the table is
 // flushed (atomic adds into the dense int64 tables in HBM) at least every 50000 reads.
-template <bool CHECK_CYCLE>
+template <bool CHECK_CYCLE, bool REFLDS>
 struct CountBody {
   // kernel arguments (scalar copies: a reference to the argument struct would keep this object in scratch memory)
   const uint64_t *__restrict__ seq_off;
@@ -303,9 +316,11 @@ struct CountBody {
   const uint8_t *__restrict__ skipbits;
   uint8_t *const *__restrict__ ref_seq;
   const int64_t *__restrict__ ref_seq_len;
-  unsigned long long *cycle_tbl, *ctx_tbl, *missing;
+  unsigned long long *cycle_tbl, *ctx_tbl;
   int n_cov, n_q, lmax, cs, rs, max_cycle;
   // LDS
+  const uint64_t *s_refp;  // [REF_LDS] packed-contig pointers and lengths (REFLDS: n_ref <= REF_LDS; else they are read from HBM)
+  const int64_t *s_refl;
   uint4 *s_desc;
   uint32_t *s_seq;
   const uint16_t *qrow;
@@ -323,71 +338,90 @@ struct CountBody {
     for (uint32_t k = threadIdx.x; k < ng; k += blockDim.x) s_seq[k] = (uint32_t)(seq_off[g0 + k] - seq_base);
   }
 
-  // One base, branch-free: a base that is not counted adds 0 to the lane's own trash cell behind the tables, so the sixteen
+  // One base, branch-free: a base that is not counted adds to the lane's own trash cell behind the tables, so the sixteen
   // bases of a block are straight-line code the compiler can interleave (no exec-mask juggling, no serialised LDS waits).
+  // Qualities > 93 and qualities without a table slot count into two extra rows behind the real ones (checked at flush time).
   template <int I>
   __device__ __forceinline__ void base(uint32_t fw, uint32_t xw, uint32_t vw, uint32_t cw, uint32_t ro, int P, int st, uint32_t cxb, int cyc0,
-                                       int ci, uint32_t trash, uint32_t &rare) {
+                                       int ci, uint32_t trash) {
     constexpr int sh = 4 * (I & 7);
-    const bool fb = (fw >> sh) & 1u;
-    bool act = fb && ro < QROW_MISSING;
-    rare |= (fb && ro >= QROW_MISSING && ro != QROW_SKIP) ? (1u << I) : 0u;
+    bool act = ((fw >> sh) & 1u) && ro != QROW_SKIP;
     if (CHECK_CYCLE) {  // checkCycleCovariate, bqsr.go:364-369
       const int cyc = cyc0 + I * ci;
-      const bool out = act && (cyc > max_cycle || cyc < -max_cycle);
+      const bool out = act && ro < 0x8000u && (cyc > max_cycle || cyc < -max_cycle);
       err |= out ? 16u : 0u;
       act = act && !out;
     }
     const int t = P + I * st;
     const uint32_t e = (xw >> sh) & 1u;
     const uint32_t i1 = act ? ro + (uint32_t)(t >> 4) : trash;
-    atomicAdd(&tbl[i1], act ? (1u | (e << 16)) : 0u);
+    atomicAdd(&tbl[i1], 1u | (e << 16));
     const bool act2 = act && ((vw >> sh) & 1u);
     const uint32_t cx = (cw >> sh) & 15u;
     const uint32_t i2 = act2 ? ro + cxb + 2u * cx : trash;
-    atomicAdd(reinterpret_cast<unsigned long long *>(&tbl[i2]), act2 ? (1ull | ((unsigned long long)e << 32)) : 0ull);
-  }
-  // bases with a quality > 93 or a quality without a table slot (rare: a rolled loop, kept out of the way of the hot code)
-  __device__ __forceinline__ void rare_bases(const Chunk &ch, uint32_t rare) {
-    const uint64_t lo = (uint64_t)ch.w0 | ((uint64_t)ch.w1 << 32), hi = (uint64_t)ch.w2 | ((uint64_t)ch.w3 << 32);
-#pragma unroll 1
-    while (rare) {
-      const int i = __builtin_ctz(rare);
-      rare &= rare - 1;
-      const uint32_t q = (uint32_t)(((i & 8) ? hi : lo) >> (8 * (i & 7))) & 0xFFu;
-      if (q >= (uint32_t)ELP_NQUAL) err |= 8u;
-      else { err |= 128u; atomicOr(&missing[q >> 6], 1ull << (q & 63u)); }
-    }
+    atomicAdd(reinterpret_cast<unsigned long long *>(&tbl[i2]), 1ull | ((unsigned long long)e << 32));
   }
 
-  __device__ __forceinline__ void block(uint32_t rl, int k0, int nb, uint64_t qpos) {
+  struct Pre {
+    Chunk ch;            // QUAL bytes
+    uint32_t skipw;      // 32 skip bits starting at bit (qpos & ~7)
+    uint64_t v0, v1;     // SEQ window
+    uint64_t r0, r1;     // reference window of the first piece
+    int rsn;
+    uint32_t rl, qlow;
+    int k0, nb;
+  };
+  __device__ __forceinline__ void ref_of(int32_t refid, const uint8_t *__restrict__ &rp, int64_t &rlen) const {
+    if (REFLDS) { rp = (const uint8_t *)(const __attribute__((address_space(1))) uint8_t *)s_refp[refid]; rlen = s_refl[refid]; }
+    else { rp = ref_seq[refid]; rlen = ref_seq_len[refid]; }
+  }
+  // every global load of the block is issued here: QUAL, skip bits, SEQ window, reference window
+  __device__ __forceinline__ bool prefetch(uint32_t rl, int k0, int nb, uint64_t qpos, Pre &p) {
     const uint4 dy = s_desc[2 * rl + 1];
     const uint32_t fl = (dy.w >> 8) & 0xFFu;
-    if (!(fl & BQ_ELIGIBLE)) return;
+    if (!(fl & BQ_ELIGIBLE)) return false;
     const int a = (int)(dy.y & 0xFFFFu), len = (int)(dy.y >> 16);
     const int cbase = k0 - a;   // clipped base index of block bit 0
+    if ((cbase < 0 ? -cbase : 0) >= (len - cbase < nb ? len - cbase : nb)) return false;  // no clipped base in the block
+    const uint4 dx = s_desc[2 * rl];
+    p.rl = rl; p.k0 = k0; p.nb = nb; p.qlow = (uint32_t)(qpos & 7);
+    p.ch.load(qual + qpos);
+    __builtin_memcpy(&p.skipw, skipbits + (qpos >> 3), 4);
+    seq_load(seq4 + seq_base + s_seq[rl], k0, p.v0, p.v1);
+    const uint8_t *__restrict__ rp;
+    int64_t rlen;
+    ref_of((int32_t)dx.w, rp, rlen);
+    const int32_t D0 = (int32_t)dx.x;
+    p.rsn = ref_load(rp, rlen, ((fl & BQ_COMPLEX) || D0 == BQ_NOREF) ? (int64_t)0 : (int64_t)D0 + cbase, p.r0, p.r1);
+    return true;
+  }
+
+  __device__ __forceinline__ void process(Pre &p) {
+    const uint32_t rl = p.rl;
+    const int k0 = p.k0, nb = p.nb;
+    const uint4 dy = s_desc[2 * rl + 1];
+    const uint4 dx = s_desc[2 * rl];
+    const uint32_t fl = (dy.w >> 8) & 0xFFu;
+    const int a = (int)(dy.y & 0xFFFFu), len = (int)(dy.y >> 16);
+    const int cbase = k0 - a;
     int blo = -cbase, bhi = len - cbase;
     blo = blo > 0 ? blo : 0;
     bhi = bhi < nb ? bhi : nb;
-    if (blo >= bhi) return;
-    const uint4 dx = s_desc[2 * rl];
     const int32_t D0 = (int32_t)dx.x, D1 = (int32_t)dx.y, D2 = (int32_t)dx.z, refid = (int32_t)dx.w;
     const int b1 = (int)(dy.x & 0xFFFFu), b2 = (int)(dy.x >> 16);
     const int left = (int)(dy.z & 0xFFFFu), right = (dy.z >> 16) == 0xFFFFu ? -1 : (int)(dy.z >> 16);
     const uint32_t cov = dy.w & 0xFFu;
     const bool rev = fl & BQ_REVERSED;
-    Chunk ch;
-    ch.load(qual + qpos);
-    // known-site skip bits of the block's bases: bit (qpos + b) of the skip column
-    uint32_t skipw;
-    __builtin_memcpy(&skipw, skipbits + (qpos >> 3), 4);
-    skipw >>= (uint32_t)(qpos & 7);
+    const bool complex_read = fl & BQ_COMPLEX;
+    const Chunk ch = p.ch;
+    const uint32_t skipw = p.skipw >> p.qlow;  // known-site skip bits of the block's bases: bit (qpos + b) of the skip column
     uint64_t S, N;
-    seq_nibbles(seq4 + seq_base + s_seq[rl], k0, rev, S, N);
+    seq_unpack(p.v0, p.v1, k0, rev, S, N);
+    const uint64_t R0 = ref_unpack(p.r0, p.r1, p.rsn);
     const uint64_t inw = nib_range(blo, bhi);
     uint64_t ohS, cS, ohN, cN;
     nib_classify(S, ohS, cS);
-    nib_classify(N, ohN, cN);
+    nib_classify_neighbour(N, rev, ohS, cS, ohN, cN);
     const uint64_t F = inw & ohS & ~nib_spread16(skipw);
     if (F == 0) return;
     // context covariate (bqsr.go:87-146): base and its predecessor in sequencing direction inside [left, right]
@@ -397,19 +431,20 @@ struct CountBody {
     // SNP events (computeSnpEvents, bqsr.go:254-285): read nibble vs reference nibble
     uint64_t X;
     {
-      const uint8_t *__restrict__ rp = ref_seq[refid];
-      const int64_t rlen = ref_seq_len[refid];
       uint64_t R = 0;
-      if (!(fl & BQ_COMPLEX)) {
+      if (!complex_read) {
         const int B1 = b1 - cbase, B2 = b2 - cbase;  // piece boundaries in block bits (0xFFFF - cbase >= 16 when unused)
         {
           const int hi = bhi < B1 ? bhi : B1;
           if (blo < hi) {
             const uint64_t m = nib_fill(nib_range(blo, hi));
-            R |= (D0 == BQ_NOREF ? S : ref_nibbles(rp, rlen, (int64_t)D0 + cbase)) & m;
+            R |= (D0 == BQ_NOREF ? S : R0) & m;
           }
         }
         if (B1 < bhi) {
+          const uint8_t *__restrict__ rp;
+          int64_t rlen;
+          ref_of(refid, rp, rlen);
           const int lo = blo > B1 ? blo : B1, hi = bhi < B2 ? bhi : B2;
           if (lo < hi) {
             const uint64_t m = nib_fill(nib_range(lo, hi));
@@ -424,6 +459,9 @@ struct CountBody {
           }
         }
       } else {
+        const uint8_t *__restrict__ rp;
+        int64_t rlen;
+        ref_of(refid, rp, rlen);
         const uint32_t *cg = ((fl & BQ_CIG_SCRATCH) ? cig_scratch : cigar) + (uint32_t)D0;
         R = ref_nibbles_complex(cg, b1, (int64_t)D2, cbase, blo, bhi, rp, rlen, S);
       }
@@ -433,42 +471,41 @@ struct CountBody {
     const int rof = (fl & BQ_LAST) ? -1 : 1;
     const int cf = rof + (rev ? (len - 1) * rof : 0), ci = rev ? -rof : rof;
     const int cyc0 = cf + cbase * ci;
-    const uint32_t rowc = cov * (uint32_t)n_q * (uint32_t)rs;
+    const uint32_t rowc = cov * (uint32_t)(n_q + 2) * (uint32_t)rs;
     const int P = (int)(rowc << 4) + 17 * (cyc0 + lmax), st = 17 * ci;
     const uint32_t cxb = rowc + (uint32_t)cs;
 
     const uint32_t f0 = (uint32_t)F, x0 = (uint32_t)X, v0 = (uint32_t)CV, c0 = (uint32_t)CX;
     const uint32_t f1 = (uint32_t)(F >> 32), x1 = (uint32_t)(X >> 32), v1 = (uint32_t)(CV >> 32), c1 = (uint32_t)(CX >> 32);
     const uint32_t trash = trash_idx;
-    uint32_t rare = 0;
     // groups of eight bases between scheduling barriers: enough independent work to cover the LDS latency without letting the
     // scheduler hoist all sixteen address computations at once (register pressure => occupancy)
     {
       const uint32_t r0 = qrow[ch.get<0>()], r1 = qrow[ch.get<1>()], r2 = qrow[ch.get<2>()], r3 = qrow[ch.get<3>()];
       const uint32_t r4 = qrow[ch.get<4>()], r5 = qrow[ch.get<5>()], r6 = qrow[ch.get<6>()], r7 = qrow[ch.get<7>()];
-      base<0>(f0, x0, v0, c0, r0, P, st, cxb, cyc0, ci, trash, rare); base<1>(f0, x0, v0, c0, r1, P, st, cxb, cyc0, ci, trash, rare);
-      base<2>(f0, x0, v0, c0, r2, P, st, cxb, cyc0, ci, trash, rare); base<3>(f0, x0, v0, c0, r3, P, st, cxb, cyc0, ci, trash, rare);
-      base<4>(f0, x0, v0, c0, r4, P, st, cxb, cyc0, ci, trash, rare); base<5>(f0, x0, v0, c0, r5, P, st, cxb, cyc0, ci, trash, rare);
-      base<6>(f0, x0, v0, c0, r6, P, st, cxb, cyc0, ci, trash, rare); base<7>(f0, x0, v0, c0, r7, P, st, cxb, cyc0, ci, trash, rare);
+      base<0>(f0, x0, v0, c0, r0, P, st, cxb, cyc0, ci, trash); base<1>(f0, x0, v0, c0, r1, P, st, cxb, cyc0, ci, trash);
+      base<2>(f0, x0, v0, c0, r2, P, st, cxb, cyc0, ci, trash); base<3>(f0, x0, v0, c0, r3, P, st, cxb, cyc0, ci, trash);
+      base<4>(f0, x0, v0, c0, r4, P, st, cxb, cyc0, ci, trash); base<5>(f0, x0, v0, c0, r5, P, st, cxb, cyc0, ci, trash);
+      base<6>(f0, x0, v0, c0, r6, P, st, cxb, cyc0, ci, trash); base<7>(f0, x0, v0, c0, r7, P, st, cxb, cyc0, ci, trash);
       __builtin_amdgcn_sched_barrier(0);
     }
     {
       const uint32_t r8 = qrow[ch.get<8>()], r9 = qrow[ch.get<9>()], r10 = qrow[ch.get<10>()], r11 = qrow[ch.get<11>()];
       const uint32_t r12 = qrow[ch.get<12>()], r13 = qrow[ch.get<13>()], r14 = qrow[ch.get<14>()], r15 = qrow[ch.get<15>()];
-      base<8>(f1, x1, v1, c1, r8, P, st, cxb, cyc0, ci, trash, rare); base<9>(f1, x1, v1, c1, r9, P, st, cxb, cyc0, ci, trash, rare);
-      base<10>(f1, x1, v1, c1, r10, P, st, cxb, cyc0, ci, trash, rare); base<11>(f1, x1, v1, c1, r11, P, st, cxb, cyc0, ci, trash, rare);
-      base<12>(f1, x1, v1, c1, r12, P, st, cxb, cyc0, ci, trash, rare); base<13>(f1, x1, v1, c1, r13, P, st, cxb, cyc0, ci, trash, rare);
-      base<14>(f1, x1, v1, c1, r14, P, st, cxb, cyc0, ci, trash, rare); base<15>(f1, x1, v1, c1, r15, P, st, cxb, cyc0, ci, trash, rare);
+      base<8>(f1, x1, v1, c1, r8, P, st, cxb, cyc0, ci, trash); base<9>(f1, x1, v1, c1, r9, P, st, cxb, cyc0, ci, trash);
+      base<10>(f1, x1, v1, c1, r10, P, st, cxb, cyc0, ci, trash); base<11>(f1, x1, v1, c1, r11, P, st, cxb, cyc0, ci, trash);
+      base<12>(f1, x1, v1, c1, r12, P, st, cxb, cyc0, ci, trash); base<13>(f1, x1, v1, c1, r13, P, st, cxb, cyc0, ci, trash);
+      base<14>(f1, x1, v1, c1, r14, P, st, cxb, cyc0, ci, trash); base<15>(f1, x1, v1, c1, r15, P, st, cxb, cyc0, ci, trash);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (rare) rare_bases(ch, rare);
   }
   __device__ __forceinline__ void group_end(uint32_t, uint32_t) {}
 
-  // adds the private table into the dense int64 tables (cycle: [cov][94][2*max_cycle+1][2], context: [cov][94][16][2]) and clears it
+  // adds the private table into the dense int64 tables (cycle: [cov][94][2*max_cycle+1][2], context: [cov][94][16][2]) and clears it;
+  // the two extra rows per covariate (bad / missing qualities) become error bits
   __device__ __forceinline__ void flush() {
     __syncthreads();
-    const int rows = n_cov * n_q;
+    const int rpc = n_q + 2, rows = n_cov * rpc;
     const int ncyc_l = 2 * lmax + 1, ncyc_g = 2 * max_cycle + 1;
     for (int k = threadIdx.x; k < rows * ncyc_l; k += blockDim.x) {
       const int row = k / ncyc_l, x = k % ncyc_l;
@@ -476,9 +513,12 @@ struct CountBody {
       const uint32_t v = *cell;
       if (v) {
         *cell = 0;
+        const int cov = row / rpc, slot = row % rpc;
         const int cyc = x - lmax;
-        if (cyc >= -max_cycle && cyc <= max_cycle) {
-          const int cov = row / n_q, q = slot_q[row % n_q];
+        if (slot >= n_q) {
+          err |= slot == n_q ? 8u : 128u;
+        } else if (cyc >= -max_cycle && cyc <= max_cycle) {
+          const int q = slot_q[slot];
           unsigned long long *g = cycle_tbl + (((size_t)cov * ELP_NQUAL + q) * ncyc_g + (size_t)(cyc + max_cycle)) * 2;
           atomicAdd(g, (unsigned long long)(v & 0xFFFFu));
           if (v >> 16) atomicAdd(g + 1, (unsigned long long)(v >> 16));
@@ -491,11 +531,14 @@ struct CountBody {
       const unsigned long long v = *cell;
       if (v) {
         *cell = 0;
-        const int cov = row / n_q, q = slot_q[row % n_q];
-        // cx = prev | cur << 2 is exactly (key >> 4) & 15 of keyFromContext (bqsr.go:64-76)
-        unsigned long long *g = ctx_tbl + (((size_t)cov * ELP_NQUAL + q) * ELP_NCTX + (size_t)cx) * 2;
-        atomicAdd(g, v & 0xFFFFFFFFull);
-        if (v >> 32) atomicAdd(g + 1, v >> 32);
+        const int cov = row / rpc, slot = row % rpc;
+        if (slot < n_q) {
+          const int q = slot_q[slot];
+          // cx = prev | cur << 2 is exactly (key >> 4) & 15 of keyFromContext (bqsr.go:64-76)
+          unsigned long long *g = ctx_tbl + (((size_t)cov * ELP_NQUAL + q) * ELP_NCTX + (size_t)cx) * 2;
+          atomicAdd(g, v & 0xFFFFFFFFull);
+          if (v >> 32) atomicAdd(g + 1, v >> 32);
+        }
       }
     }
     __syncthreads();
@@ -506,34 +549,39 @@ struct CountBody {
   }
 };
 
-template <bool CHECK_CYCLE>
+template <bool CHECK_CYCLE, bool REFLDS>
 __global__ __launch_bounds__(FL_THREADS, 4) void k_bqsr_count(CountArgs A, QMap qm) {
   __shared__ FlatLds L;
   __shared__ uint4 s_desc[2 * FL_RMAX];
   __shared__ uint32_t s_seq[FL_RMAX];
   __shared__ uint16_t qrow[256];
   __shared__ uint8_t slot_q[96];
+  __shared__ uint64_t s_refp[REF_LDS];
+  __shared__ int64_t s_refl[REF_LDS];
   extern __shared__ __attribute__((aligned(16))) uint32_t tbl[];
-  const int n_all = A.n_cov * A.n_q * A.rs;
+  const int n_all = A.n_cov * (A.n_q + 2) * A.rs;
+  if (REFLDS)
+    for (int r = threadIdx.x; r < A.n_ref; r += blockDim.x) { s_refp[r] = reinterpret_cast<uint64_t>(A.ref_seq[r]); s_refl[r] = A.ref_seq_len[r]; }
   for (int k = threadIdx.x; k < n_all; k += blockDim.x) tbl[k] = 0;
   for (int q = threadIdx.x; q < 256; q += blockDim.x) {
     uint16_t v;
     if (q < 6) v = QROW_SKIP;
-    else if (q >= ELP_NQUAL) v = QROW_BAD;
+    else if (q >= ELP_NQUAL) v = (uint16_t)(A.n_q * A.rs);  // "bad" row
     else {
       const uint8_t s = qm.slot[q];
-      v = s == 255 ? QROW_SKIP : (s == 254 ? QROW_MISSING : (uint16_t)(s * A.rs));
+      v = s == 255 ? QROW_SKIP : (s == 254 ? (uint16_t)((A.n_q + 1) * A.rs) : (uint16_t)(s * A.rs));
       if (s < 254) slot_q[s] = (uint8_t)q;
     }
     qrow[q] = v;
   }
   __syncthreads();
-  CountBody<CHECK_CYCLE> B;
+  CountBody<CHECK_CYCLE, REFLDS> B;
   B.seq_off = A.seq_off; B.qual = A.qual; B.seq4 = A.seq4; B.desc = reinterpret_cast<const uint4 *>(A.desc);
   B.cigar = A.cigar; B.cig_scratch = A.cig_scratch; B.skipbits = A.skipbits; B.ref_seq = A.ref_seq; B.ref_seq_len = A.ref_seq_len;
-  B.cycle_tbl = A.cycle_tbl; B.ctx_tbl = A.ctx_tbl; B.missing = A.missing;
+  B.cycle_tbl = A.cycle_tbl; B.ctx_tbl = A.ctx_tbl;
   B.n_cov = A.n_cov; B.n_q = A.n_q; B.lmax = A.lmax; B.cs = A.cs; B.rs = A.rs; B.max_cycle = A.max_cycle;
   B.s_desc = s_desc; B.s_seq = s_seq; B.qrow = qrow; B.slot_q = slot_q; B.tbl = tbl;
+  B.s_refp = s_refp; B.s_refl = s_refl;
   B.trash_idx = (uint32_t)((n_all + 1) & ~1) + 2u * threadIdx.x;
   B.err = 0;
   B.reads_since_flush = 0;
@@ -691,21 +739,37 @@ struct ApplyBody {
     ch.w0 = (uint32_t)lo; ch.w1 = (uint32_t)(lo >> 32); ch.w2 = (uint32_t)hi; ch.w3 = (uint32_t)(hi >> 32);
   }
 
-  __device__ __forceinline__ void block(uint32_t rl, int k0, int nb, uint64_t qpos) {
+  struct Pre {
+    Chunk ch;
+    uint64_t v0, v1;  // SEQ window
+    uint64_t qpos;
+    uint32_t rl;
+    int k0, nb;
+  };
+  __device__ __forceinline__ bool prefetch(uint32_t rl, int k0, int nb, uint64_t qpos, Pre &p) {
+    const uint32_t fl = (uint32_t)(s_desc[rl] >> 56);
+    if (!(fl & BQ_ELIGIBLE)) return false;
+    p.rl = rl; p.k0 = k0; p.nb = nb; p.qpos = qpos;
+    p.ch.load(qual + qpos);
+    seq_load(seq4 + seq_base + s_seq[rl], k0, p.v0, p.v1);
+    return true;
+  }
+  __device__ __forceinline__ void process(Pre &p) {
+    const uint32_t rl = p.rl;
+    const int k0 = p.k0, nb = p.nb;
+    const uint64_t qpos = p.qpos;
     const uint64_t dw = s_desc[rl];
     const uint32_t fl = (uint32_t)(dw >> 56);
-    if (!(fl & BQ_ELIGIBLE)) return;
     const int left = (int)(dw & 0xFFFFu), right = ((dw >> 16) & 0xFFFFu) == 0xFFFFu ? -1 : (int)((dw >> 16) & 0xFFFFu);
     const int len = (int)((dw >> 32) & 0xFFFFu);
     const uint32_t cov = (uint32_t)(dw >> 48) & 0xFFu;
     const bool rev = fl & BQ_REVERSED;
-    Chunk ch;
-    ch.load(qual + qpos);
+    Chunk ch = p.ch;
     uint64_t S, N;
-    seq_nibbles(seq4 + seq_base + s_seq[rl], k0, rev, S, N);
+    seq_unpack(p.v0, p.v1, k0, rev, S, N);
     uint64_t ohS, cS, ohN, cN;
     nib_classify(S, ohS, cS);
-    nib_classify(N, ohN, cN);
+    nib_classify_neighbour(N, rev, ohS, cS, ohN, cN);
     const int cl = left + (rev ? 0 : 1), cr = right - (rev ? 1 : 0);
     int rhi = cr - k0 + 1;
     rhi = rhi < nb ? rhi : nb;
@@ -850,8 +914,6 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
     uint32_t *skipbits;
     const size_t skip_words = (size_t)((c->qual_bytes + 31) / 32 + 8);
     ELP_TRY(scratch(c, 3, skip_words, &skipbits));
-    unsigned long long *missing;
-    ELP_TRY(scratch(c, 6, 4, &missing));
     ELP_HIP(c, hipMemsetAsync(skipbits, 0, skip_words * 4, st));
     BqCols m{n, c->refid.p, c->pos.p, c->next_refid.p, c->pnext.p, c->tlen.p, c->flag.p, c->rgid.p, c->mapq.p, c->has_sr.p, c->l_seq.p,
              c->cigar_off.p, c->seq_off.p, c->qual_off.p, c->cigar.p, c->seq4.p, c->qual.p, c->ref_len.p, c->rg_cov.p, c->n_ref,
@@ -862,7 +924,7 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
     const bool check_cycle = lmax > max_cycle;
     const int cs = ((((17 * 2 * lmax) >> 4) + 1) + 1) & ~1, rs = cs + 32;
     const size_t per_slot = (size_t)c->n_cov * (size_t)rs * 4;
-    const size_t static_lds = sizeof(FlatLds) + (size_t)FL_RMAX * (sizeof(BqDesc) + 4) + 512 + 96 + 64 + 8 + (size_t)FL_THREADS * 8;
+    const size_t static_lds = sizeof(FlatLds) + (size_t)FL_RMAX * (sizeof(BqDesc) + 4) + 512 + 96 + 64 + 8 + (size_t)FL_THREADS * 8 + (size_t)REF_LDS * 16;
     const size_t lds_cu = 160 * 1024;
     const uint64_t ntiles = (c->qual_bytes + FL_TILE - 1) / FL_TILE;
     for (int attempt = 0;; attempt++) {
@@ -876,42 +938,42 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
       for (int w = 3; w >= 1; w--) {
         const size_t budget = lds_cu / (size_t)w;
         if (budget <= static_lds + 256) continue;
-        const int cap = (int)std::min<size_t>((budget - static_lds - 256) / per_slot, 65000 / (size_t)rs);
+        const int cap = (int)std::min<size_t>((budget - static_lds - 256) / per_slot, 65000 / (size_t)rs) - 2;  // two extra rows per covariate
         if (cap >= (int)quals.size() || w == 1) { wg_per_cu = w; qcap = cap; break; }
       }
       if (qcap < 1) return set_error(c, ELP_ERR_UNSUPPORTED, "BQSR private tables do not fit in LDS (n_cov=%d, max read length=%d)", c->n_cov, lmax);
       const int grid = (int)std::min<uint64_t>(ntiles, (uint64_t)wg_per_cu * (uint64_t)c->n_cu);
-      ELP_HIP(c, hipMemsetAsync(missing, 0, 16, st));
       for (size_t q0 = 0; q0 < quals.size(); q0 += (size_t)qcap) {
         const int nqs = (int)std::min<size_t>((size_t)qcap, quals.size() - q0);
         QMap qm;
         memset(qm.slot, 254, sizeof qm.slot);
         for (int q : quals) qm.slot[q] = 255;
         for (int s = 0; s < nqs; s++) qm.slot[quals[q0 + s]] = (uint8_t)s;
-        const size_t dyn = (size_t)c->n_cov * nqs * rs * 4 + 8 + (size_t)FL_THREADS * 8;  // tables + one trash cell per lane
+        const size_t dyn = (size_t)c->n_cov * (nqs + 2) * rs * 4 + 8 + (size_t)FL_THREADS * 8;  // tables + one trash cell per lane
         CountArgs A{n, c->qual_bytes, c->qual_off.p, c->seq_off.p, c->qual.p, c->seq4.p, desc, c->cigar.p, cs_pool,
-                    reinterpret_cast<const uint8_t *>(skipbits), c->d_ref_seq.p, c->d_ref_seq_len.p, c->n_cov, nqs, lmax, cs, rs, max_cycle,
-                    tb + nq, tb + nq + nc, missing, c->err_flag.p, c->tile_first.p};
-        if (check_cycle) {
-          ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bqsr_count<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-          ELP_LAUNCH(c, "bqsr_count", k_bqsr_count<true>, dim3(grid), dim3(FL_THREADS), dyn, A, qm);
-        } else {
-          ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bqsr_count<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-          ELP_LAUNCH(c, "bqsr_count", k_bqsr_count<false>, dim3(grid), dim3(FL_THREADS), dyn, A, qm);
-        }
+                    reinterpret_cast<const uint8_t *>(skipbits), c->d_ref_seq.p, c->d_ref_seq_len.p, c->n_ref, c->n_cov, nqs, lmax, cs, rs, max_cycle,
+                    tb + nq, tb + nq + nc, c->err_flag.p, c->tile_first.p};
+        const bool ref_lds = c->n_ref <= REF_LDS;
+#define ELP_COUNT_LAUNCH(CC, RL)                                                                                                              \
+  do {                                                                                                                                        \
+    ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bqsr_count<CC, RL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)); \
+    ELP_LAUNCH(c, "bqsr_count", (k_bqsr_count<CC, RL>), dim3(grid), dim3(FL_THREADS), dyn, A, qm);                                            \
+  } while (0)
+        if (check_cycle && ref_lds) ELP_COUNT_LAUNCH(true, true);
+        else if (check_cycle) ELP_COUNT_LAUNCH(true, false);
+        else if (ref_lds) ELP_COUNT_LAUNCH(false, true);
+        else ELP_COUNT_LAUNCH(false, false);
+#undef ELP_COUNT_LAUNCH
       }
       uint32_t e[4];
       ELP_TRY(fetch_err(c, e));
       if ((e[0] & ~128u) != 0) return bqsr_error(c, e[0] & ~128u);
       if (!(e[0] & 128u)) break;
-      // a counted base had a quality the sampled hint did not contain: add it and redo the count
-      unsigned long long miss[2];
-      ELP_HIP(c, hipMemcpyAsync(miss, missing, 16, hipMemcpyDeviceToHost, st));
-      ELP_HIP(c, hipStreamSynchronize(st));
+      // a counted base had a quality the sampled hint did not contain: take the exact set (full scan) and redo the count
       ELP_HIP(c, hipMemsetAsync(c->err_flag.p, 0, 4, st));
-      c->qual_present[0] |= miss[0];
-      c->qual_present[1] |= miss[1];
-      if (attempt >= 3) return set_error(c, ELP_ERR_HIP, "BQSR: quality-slot retry did not converge");
+      c->have_qual_present = false;
+      ELP_TRY(ensure_qual_present(c, true));
+      if (attempt >= 2) return set_error(c, ELP_ERR_HIP, "BQSR: quality-slot retry did not converge");
       ELP_HIP(c, hipMemsetAsync(tb, 0, (nq + nc + nx) * sizeof(unsigned long long), st));
     }
     ELP_LAUNCH(c, "bqsr_qual_from_cycle", k_bqsr_qual_from_cycle, dim3(c->n_cov * ELP_NQUAL), dim3(256), 0, c->n_cov * ELP_NQUAL, ncyc_g,

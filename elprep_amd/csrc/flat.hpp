@@ -20,8 +20,8 @@ namespace elp {
 constexpr int FL_THREADS = 512;                  // default workgroup size (kernels use blockDim.x)
 constexpr int FL_CHUNK = 16;                     // bases per block
 constexpr uint64_t FL_TILE = 32768;              // QUAL bytes per tile
-constexpr int FL_RMAX = 384;                     // reads held in LDS at a time (150-base reads: ~220 per tile)
-constexpr uint32_t FL_MAX_READ = 0x3FFFFFu;      // per-read QUAL length limit (group-relative 32-bit offsets: 384 reads must stay < 2^31)
+constexpr int FL_RMAX = 256;                     // reads held in LDS at a time (150-base reads: ~220 per tile)
+constexpr uint32_t FL_MAX_READ = 0x3FFFFFu;      // per-read QUAL length limit (group-relative 32-bit offsets: FL_RMAX reads must stay < 2^31)
 
 struct FlatLds {
   uint32_t off[FL_RMAX + 4];  // QUAL offsets of the group's reads minus the first one's (n+1 used; sized to keep LDS 16-byte aligned)
@@ -42,7 +42,7 @@ __device__ __forceinline__ uint64_t nib_range_clamped(int lo, int hi) {
   return lo < hi ? nib_range(lo, hi) : 0ull;
 }
 // flag bits (bit 4b) -> full nibbles (0xF)
-__device__ __forceinline__ uint64_t nib_fill(uint64_t flags) { return flags * 15ull; }
+__device__ __forceinline__ uint64_t nib_fill(uint64_t flags) { return (flags << 4) - flags; }
 // bit i of a 16-bit word -> bit 4i
 __device__ __forceinline__ uint64_t nib_spread16(uint32_t x16) {
   uint64_t x = x16 & 0xFFFFu;
@@ -71,15 +71,26 @@ __device__ __forceinline__ void nib_classify(uint64_t x, uint64_t &onehot, uint6
   code = (b | d) | ((c | d) << 1);
 }
 
+// classification of the neighbour word N from the classification of S: N is S moved by one base (towards higher nibbles for a
+// forward read, lower for a reverse read) except for its one nibble that lies outside S, which is classified on its own
+__device__ __forceinline__ void nib_classify_neighbour(uint64_t N, bool reversed, uint64_t ohS, uint64_t cS, uint64_t &ohN, uint64_t &cN) {
+  const uint32_t n = reversed ? (uint32_t)(N >> 60) : ((uint32_t)N & 15u);
+  const uint64_t oh1 = (n != 0u && (n & (n - 1u)) == 0u) ? 1ull : 0ull;
+  const uint64_t c1 = (uint64_t)((((n >> 1) | (n >> 3)) & 1u) | ((((n >> 2) | (n >> 3)) & 1u) << 1));
+  ohN = reversed ? ((ohS >> 4) | (oh1 << 60)) : ((ohS << 4) | oh1);
+  cN = reversed ? ((cS >> 4) | (c1 << 60)) : ((cS << 4) | c1);
+}
+
 // Bases k0 .. k0+15 of a record (S) and their neighbours in sequencing direction (N: k0-1 .. k0+14 forward, k0+1 .. k0+16
 // reverse) as nibbles; k0 is a multiple of 16.  Bases before the record's first read 0, bases past its end are garbage
 // (callers mask).  `sp` = the record's packed bases (BAM order: first base of a byte in the HIGH nibble).
-__device__ __forceinline__ void seq_nibbles(const uint8_t *__restrict__ sp, int k0, bool reversed, uint64_t &S, uint64_t &N) {
-  // window of 32 bases starting at base k0 - 2 (k0 > 0) or 0
+// seq_load issues the load of the 32-base window that starts at base k0 - 2 (k0 > 0) or 0; seq_unpack uses it.
+__device__ __forceinline__ void seq_load(const uint8_t *__restrict__ sp, int k0, uint64_t &v0, uint64_t &v1) {
   const int lead = k0 ? 2 : 0;
-  uint64_t v0, v1;
   __builtin_memcpy(&v0, sp + ((k0 - lead) >> 1), 8);
   __builtin_memcpy(&v1, sp + ((k0 - lead) >> 1) + 8, 8);
+}
+__device__ __forceinline__ void seq_unpack(uint64_t v0, uint64_t v1, int k0, bool reversed, uint64_t &S, uint64_t &N) {
   v0 = nib_swap(v0);
   v1 = nib_swap(v1);
   // S = window >> lead nibbles; N forward = window >> (lead - 1) (zero nibble shifted in at k0 = 0), N reverse = window >> (lead + 1)
@@ -124,11 +135,17 @@ struct Chunk {
 };
 
 // Drives one workgroup over its tiles.  Body provides:
+//   struct Pre                                                the registers a block's global loads land in (+ what identifies it)
 //   void stage(uint32_t g0, uint32_t ng)                      all threads: put per-read data of reads [g0, g0+ng) into LDS
-//   void block(uint32_t rl, int k0, int nb, uint64_t qpos)    per lane: bases [k0, k0+nb) of read g0+rl (k0 a multiple of 16,
-//                                                             1 <= nb <= 16), whose first QUAL byte is at column offset qpos
+//   bool prefetch(uint32_t rl, int k0, int nb, uint64_t qpos, Pre &)
+//                                                             per lane: ISSUE the global loads of bases [k0, k0+nb) of read g0+rl
+//                                                             (k0 a multiple of 16, 1 <= nb <= 16; first QUAL byte at column offset
+//                                                             qpos) without using their results; false = nothing to do for the block
+//   void process(Pre &)                                       per lane: the block's work
 //   void group_end(uint32_t g0, uint32_t ng)                  all threads, after a barrier
 //   void tile_end(uint32_t nreads)                            all threads (uniform), may contain barriers
+// The lane's next block is prefetched before the current one is processed, so the HBM latency of block i+1 hides behind the ALU
+// and LDS work of block i (the loads stay in flight across the loop's back edge).
 // tile_first[t] = first read whose QUAL offset is >= t * FL_TILE (tile_first[ntiles] = n_reads).
 template <class Body>
 __device__ __forceinline__ void flat_run(const uint64_t *__restrict__ qual_off, uint64_t n_reads, uint64_t qual_bytes,
@@ -143,21 +160,32 @@ __device__ __forceinline__ void flat_run(const uint64_t *__restrict__ qual_off, 
       B.stage(g0, ng);
       __syncthreads();
       const uint32_t nslots = (L.off[ng] + 15u * ng) >> 4;  // slot of read k: (off[k] + 15 k) >> 4
-      if (nslots) {
-        const float inv_avg = (float)ng / (float)nslots;
+      const float inv_avg = nslots ? (float)ng / (float)nslots : 0.f;
+      // locate slot s and issue its loads
+      auto fetch = [&](uint32_t s, typename Body::Pre &pre) __attribute__((always_inline)) -> bool {
+        // read owning slot s: guess from the mean, then walk (exact for uniform read lengths)
+        int k = (int)((float)s * inv_avg);
+        k = k >= (int)ng ? (int)ng - 1 : k;
+        while (((L.off[k] + 15u * (uint32_t)k) >> 4) > s) k--;
+        while (((L.off[k + 1] + 15u * (uint32_t)(k + 1)) >> 4) <= s) k++;
+        const uint32_t o = L.off[k], len = L.off[k + 1] - o;
+        const uint32_t k0 = (s - ((o + 15u * (uint32_t)k) >> 4)) << 4;
+        if (k0 >= len) return false;  // the (at most one) empty slot behind a read
+        const uint32_t nb = len - k0 < 16u ? len - k0 : 16u;
+        return B.prefetch((uint32_t)k, (int)k0, (int)nb, base + o + k0, pre);
+      };
+      uint32_t s = threadIdx.x;
+      typename Body::Pre cur;
+      bool have = s < nslots ? fetch(s, cur) : false;
 #pragma unroll 1
-        for (uint32_t s = threadIdx.x; s < nslots; s += blockDim.x) {
-          // read owning slot s: guess from the mean, then walk (exact for uniform read lengths)
-          int k = (int)((float)s * inv_avg);
-          k = k >= (int)ng ? (int)ng - 1 : k;
-          while (((L.off[k] + 15u * (uint32_t)k) >> 4) > s) k--;
-          while (((L.off[k + 1] + 15u * (uint32_t)(k + 1)) >> 4) <= s) k++;
-          const uint32_t o = L.off[k], len = L.off[k + 1] - o;
-          const uint32_t k0 = (s - ((o + 15u * (uint32_t)k) >> 4)) << 4;
-          if (k0 >= len) continue;  // the (at most one) empty slot behind a read
-          const uint32_t nb = len - k0 < 16u ? len - k0 : 16u;
-          B.block((uint32_t)k, (int)k0, (int)nb, base + o + k0);
-        }
+      while (s < nslots) {
+        const uint32_t sn = s + blockDim.x;
+        typename Body::Pre nxt;
+        const bool have_n = sn < nslots ? fetch(sn, nxt) : false;
+        if (have) B.process(cur);
+        cur = nxt;
+        have = have_n;
+        s = sn;
       }
       __syncthreads();
       B.group_end(g0, ng);

@@ -86,17 +86,21 @@ struct ScoreBody {
     badw |= ((((x | 0x80808080u) - 0x5E5E5E5Eu) | x) & 0x80808080u) & m;          // byte >= 94
     return __builtin_amdgcn_sad_u8(x & (ge15 * 0xFFu) & m, 0u, s);
   }
-  __device__ __forceinline__ void block(uint32_t rl, int, int nb, uint64_t qpos) {
-    if (!cand[rl]) return;
-    Chunk ch;
-    ch.load(qual + qpos);
+  struct Pre { Chunk ch; uint32_t rl; int nb; };
+  __device__ __forceinline__ bool prefetch(uint32_t rl, int, int nb, uint64_t qpos, Pre &p) {
+    if (!cand[rl]) return false;
+    p.rl = rl; p.nb = nb;
+    p.ch.load(qual + qpos);
+    return true;
+  }
+  __device__ __forceinline__ void process(Pre &p) {
     uint32_t s = 0, b = 0;
-    s = part(ch.w0, first_bytes32(nb), s, b);
-    s = part(ch.w1, first_bytes32(nb - 4), s, b);
-    s = part(ch.w2, first_bytes32(nb - 8), s, b);
-    s = part(ch.w3, first_bytes32(nb - 12), s, b);
+    s = part(p.ch.w0, first_bytes32(p.nb), s, b);
+    s = part(p.ch.w1, first_bytes32(p.nb - 4), s, b);
+    s = part(p.ch.w2, first_bytes32(p.nb - 8), s, b);
+    s = part(p.ch.w3, first_bytes32(p.nb - 12), s, b);
     bad |= b;
-    if (s) atomicAdd(&acc[rl], (int32_t)s);
+    if (s) atomicAdd(&acc[p.rl], (int32_t)s);
   }
   __device__ __forceinline__ void group_end(uint32_t g0, uint32_t ng) {
     for (uint32_t k = threadIdx.x; k < ng; k += blockDim.x) score[g0 + k] = acc[k];  // a read belongs to exactly one group
@@ -207,23 +211,23 @@ int ensure_adapted(elp_ctx *c) {
 }
 
 // c->qual_present = quality values seen in a sample of the QUAL column (a sizing hint, see k_qual_present_sample)
-int ensure_qual_present(elp_ctx *c) {
+int ensure_qual_present(elp_ctx *c, bool exact) {
   if (c->have_qual_present) return 0;
   c->qual_present[0] = c->qual_present[1] = 0;
   // test hook: with ELP_DEBUG_NO_QUAL_HINT set the hint stays empty, which forces the gather's report-and-retry path
-  if (c->qual_bytes && !getenv("ELP_DEBUG_NO_QUAL_HINT")) {
+  if (c->qual_bytes && (exact || !getenv("ELP_DEBUG_NO_QUAL_HINT"))) {
     unsigned long long *qm;
     ELP_TRY(scratch(c, 6, 4, &qm));
     ELP_HIP(c, hipMemsetAsync(qm, 0, 16, c->stream));
     const uint64_t ntiles = (c->qual_bytes + FL_TILE - 1) / FL_TILE;
-    const uint64_t stride = std::min<uint64_t>(16, std::max<uint64_t>(1, ntiles / 2048));
+    const uint64_t stride = exact ? 1 : std::min<uint64_t>(16, std::max<uint64_t>(1, ntiles / 2048));
     const unsigned grid = (unsigned)std::min<uint64_t>((ntiles + stride - 1) / stride, 2048);
     ELP_LAUNCH(c, "qual_present_sample", k_qual_present_sample, dim3(grid), dim3(256), 0, (const uint8_t *)c->qual.p, c->qual_bytes, stride, qm);
     ELP_HIP(c, hipMemcpyAsync(c->qual_present, qm, 16, hipMemcpyDeviceToHost, c->stream));
     ELP_HIP(c, hipStreamSynchronize(c->stream));
   }
   // test hook: ELP_DEBUG_QUAL_HINT_DROP=<q> removes one quality from the hint (exercises the kernels' no-slot paths)
-  if (const char *d = getenv("ELP_DEBUG_QUAL_HINT_DROP")) {
+  if (const char *d = exact ? nullptr : getenv("ELP_DEBUG_QUAL_HINT_DROP")) {
     const int q = atoi(d);
     if (q >= 0 && q < 64) c->qual_present[0] &= ~(1ull << q);
     else if (q < 128) c->qual_present[1] &= ~(1ull << (q - 64));

@@ -169,10 +169,14 @@ def _check_gather_apply(b, h, refs, sites, max_cycle=500, chunks=3):
     assert np.array_equal(qt, oq), "quality tables differ"
     tb = BqsrTables(qt, ct, xt, max_cycle).finalize()
     lut, present = tb.build_lut(0)
-    got = e.apply_bqsr(lut, present, max_cycle)
     want = orc.BqsrFinal(oq, oc, ox, max_cycle).apply(b, h, 0)
+    got = e.apply_bqsr(lut, present, max_cycle)
     assert np.array_equal(got, want)
     e.close()
+    e2 = _stage(b, h, 1)  # a fresh context: its quality hint has not been completed by a gather retry
+    got2 = e2.apply_bqsr(lut, present, max_cycle)
+    assert np.array_equal(got2, want)
+    e2.close()
     return qt
 
 

@@ -19,7 +19,7 @@ for db in sys.argv[2:]:
     idd = cols.index("dispatch_id") if "dispatch_id" in cols else None
     seen = set()
     for r in rows:
-        k = r[ik].split("(")[0]
+        k = r[ik].split("(")[0].replace(", ", ";").replace(",", ";")
         acc[k][r[ic]] += float(r[iv])
         if r[ic] not in names:
             names.append(r[ic])
