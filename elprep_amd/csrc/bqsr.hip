@@ -41,6 +41,7 @@ struct BqCols {
   const int64_t *ref_seq_len;
   int32_t *const *sites;
   const int64_t *n_sites;
+  uint32_t *const *site_idx;  // per contig and 64-bp bucket: first site whose end is >= 64 * bucket (k_site_index)
 };
 
 // recalibrateAln, bqsr.go:225-244 (+ utils.go:121-139)
@@ -158,12 +159,18 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue(BqCols m, uint32_t *__res
     const int ss = soft_start(a), se = soft_end(a);
     const int32_t *sv = m.sites[a.refid];
     const int64_t ns = m.n_sites[a.refid];
-    int64_t lo = 0, hi = ns;
-    while (lo < hi) { const int64_t md = lo + (hi - lo) / 2; if (!(sv[2 * md + 1] >= ss)) lo = md + 1; else hi = md; }
-    const int64_t first = lo;
-    lo = 0; hi = ns;
-    while (lo < hi) { const int64_t md = lo + (hi - lo) / 2; if (!(sv[2 * md] > se)) lo = md + 1; else hi = md; }
-    const int64_t last = lo;
+    // intervals.Intersect (intervals/intervals.go:166-173): sites with End >= softStart and Start <= softEnd.  The bucket index
+    // replaces the two binary searches (28 dependent loads) by one look-up and a short walk.
+    int64_t first = ns, last = ns;
+    if (ns > 0) {
+      const int64_t nbuck = ((int64_t)m.ref_len[a.refid] >> 6) + 1;
+      int64_t bk = (int64_t)(ss < 0 ? 0 : ss) >> 6;
+      bk = bk >= nbuck ? nbuck - 1 : bk;
+      first = m.site_idx[a.refid][bk];
+      while (first < ns && sv[2 * first + 1] < ss) first++;
+      last = first;
+      while (last < ns && sv[2 * last] <= se) last++;
+    }
     const uint64_t bit0 = m.qual_off[i] + (uint64_t)a.off;
     for (int64_t s = first; s < last; s++) {
       bool ok;
@@ -276,6 +283,16 @@ __device__ __noinline__ uint64_t ref_nibbles_complex(const uint32_t *__restrict_
     }
   }
   return R;
+}
+
+// idx[b] = first site whose End is >= 64 b (sites are sorted and flattened, so Ends increase with the index)
+__global__ __launch_bounds__(256) void k_site_index(const int32_t *__restrict__ sv, int64_t ns, int64_t nbuck, uint32_t *__restrict__ idx) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbuck) return;
+  const int64_t x = b << 6;
+  int64_t lo = 0, hi = ns;
+  while (lo < hi) { const int64_t md = lo + (hi - lo) / 2; if (sv[2 * md + 1] < x) lo = md + 1; else hi = md; }
+  idx[b] = (uint32_t)lo;
 }
 
 // quality value -> LDS table row offset of this pass; the special values:
@@ -878,11 +895,13 @@ static int sync_bqsr_ptrs(elp_ctx *c) {
   ELP_TRY(ensure(c, c->d_ref_seq_len, nr + 1));
   ELP_TRY(ensure(c, c->d_sites, nr + 1));
   ELP_TRY(ensure(c, c->d_n_sites, nr + 1));
+  ELP_TRY(ensure(c, c->d_site_idx, nr + 1));
   if (nr) {
     ELP_HIP(c, hipMemcpyAsync(c->d_ref_seq.p, c->h_ref_seq.data(), nr * sizeof(uint8_t *), hipMemcpyHostToDevice, c->stream));
     ELP_HIP(c, hipMemcpyAsync(c->d_ref_seq_len.p, c->h_ref_seq_len.data(), nr * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
     ELP_HIP(c, hipMemcpyAsync(c->d_sites.p, c->h_sites.data(), nr * sizeof(int32_t *), hipMemcpyHostToDevice, c->stream));
     ELP_HIP(c, hipMemcpyAsync(c->d_n_sites.p, c->h_n_sites.data(), nr * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    ELP_HIP(c, hipMemcpyAsync(c->d_site_idx.p, c->h_site_idx.data(), nr * sizeof(uint32_t *), hipMemcpyHostToDevice, c->stream));
     ELP_HIP(c, hipStreamSynchronize(c->stream));
   }
   c->bqsr_ptrs_dirty = false;
@@ -917,7 +936,7 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
     ELP_HIP(c, hipMemsetAsync(skipbits, 0, skip_words * 4, st));
     BqCols m{n, c->refid.p, c->pos.p, c->next_refid.p, c->pnext.p, c->tlen.p, c->flag.p, c->rgid.p, c->mapq.p, c->has_sr.p, c->l_seq.p,
              c->cigar_off.p, c->seq_off.p, c->qual_off.p, c->cigar.p, c->seq4.p, c->qual.p, c->ref_len.p, c->rg_cov.p, c->n_ref,
-             c->d_ref_seq.p, c->d_ref_seq_len.p, c->d_sites.p, c->d_n_sites.p};
+             c->d_ref_seq.p, c->d_ref_seq_len.p, c->d_sites.p, c->d_n_sites.p, c->d_site_idx.p};
     ELP_LAUNCH(c, "bqsr_prologue", k_bqsr_prologue, dim3(blocks_for(n, 256)), dim3(256), 0, m, cs_pool, desc, skipbits, c->err_flag.p);
     const int lmax = (int)std::max<uint32_t>(c->max_l_seq, 1);
     if (lmax > MAX_DESC_READ) return set_error(c, ELP_ERR_UNSUPPORTED, "BQSR: read longer than %d bases", MAX_DESC_READ);
@@ -1023,10 +1042,17 @@ int elp_bqsr_set_known_sites(elp_ctx *c, int32_t refid, const int32_t *start_end
     if (!(start_end[2 * k] > start_end[2 * k - 1])) return set_error(c, ELP_ERR_ARG, "known sites of refid %d are not sorted and flattened at index %lld", refid, (long long)k);
   ELP_HIP(c, hipSetDevice(c->device));
   if (c->h_sites[refid]) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->h_sites[refid]); c->h_sites[refid] = nullptr; }
+  if (c->h_site_idx[refid]) { (void)hipFree(c->h_site_idx[refid]); c->h_site_idx[refid] = nullptr; }
   int32_t *d = nullptr;
   ELP_HIP(c, hipMalloc((void **)&d, (size_t)(2 * n + 4) * sizeof(int32_t)));
   if (n) ELP_HIP(c, hipMemcpyAsync(d, start_end, (size_t)(2 * n) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  const int64_t nbuck = ((int64_t)c->h_ref_len[refid] >> 6) + 1;
+  uint32_t *ix = nullptr;
+  ELP_HIP(c, hipMalloc((void **)&ix, (size_t)(nbuck + 4) * sizeof(uint32_t)));
+  hipLaunchKernelGGL(k_site_index, dim3(blocks_for((uint64_t)nbuck, 256)), dim3(256), 0, c->stream, (const int32_t *)d, n, nbuck, ix);
+  ELP_HIP(c, hipGetLastError());
   ELP_HIP(c, hipStreamSynchronize(c->stream));
+  c->h_site_idx[refid] = ix;
   c->h_sites[refid] = d;
   c->h_n_sites[refid] = n;
   c->bqsr_ptrs_dirty = true;

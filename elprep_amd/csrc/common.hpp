@@ -103,9 +103,11 @@ struct elp_ctx {
   std::vector<int64_t> h_ref_seq_len;
   std::vector<int32_t *> h_sites;    // device pointers per refid, [n][2]
   std::vector<int64_t> h_n_sites;
+  std::vector<uint32_t *> h_site_idx;  // device pointers per refid: per 64-bp bucket b the first site whose end is >= 64 b
   elp::DVec<uint8_t *> d_ref_seq;
   elp::DVec<int64_t> d_ref_seq_len;
   elp::DVec<int32_t *> d_sites;
+  elp::DVec<uint32_t *> d_site_idx;
   elp::DVec<int64_t> d_n_sites;
   bool bqsr_ptrs_dirty = true;
 

@@ -95,6 +95,7 @@ void elp_destroy(elp_ctx *c) {
   for (auto &p : c->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto p : c->h_ref_seq) if (p) (void)hipFree(p);
   for (auto p : c->h_sites) if (p) (void)hipFree(p);
+  for (auto p : c->h_site_idx) if (p) (void)hipFree(p);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -132,6 +133,7 @@ int elp_set_header(elp_ctx *c, const elp_header *h) {
   c->h_ref_seq.resize(h->n_ref, nullptr);
   c->h_ref_seq_len.resize(h->n_ref, 0);
   c->h_sites.resize(h->n_ref, nullptr);
+  c->h_site_idx.resize(h->n_ref, nullptr);
   c->h_n_sites.resize(h->n_ref, 0);
   c->bqsr_ptrs_dirty = true;
   c->have_header = true;

@@ -208,29 +208,36 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_tile_hist(const uint64_t *
 }
 
 // stable scatter.  Element order inside a tile: wave-major, then round, then lane (== index order, because each wave
-// owns a contiguous 1024-key sub-tile and reads it 64 keys per round).
+// owns a contiguous 1024-key sub-tile and reads it 64 keys per round).  Keys (then values) are first reordered by digit inside
+// the tile through LDS, so that the global stores of a workgroup are runs of consecutive addresses per digit (on average 16
+// keys = 128 bytes with 4096-key tiles and 256 bins) instead of 64 scattered 8-byte stores per wave instruction.
 __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
                                                               uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint64_t n,
                                                               int shift, const uint32_t *__restrict__ offsets /* scanned counts */,
                                                               uint32_t ntiles) {
   __shared__ uint32_t cnt[RS_WAVES][256];
-  __shared__ uint32_t gbase[256];
+  __shared__ uint32_t gbase[256];   // global position of the tile's first key with digit d, minus its position inside the sorted tile
+  __shared__ uint32_t scan_lds[8];
+  __shared__ uint64_t sbuf[RS_TILE];  // the tile in digit order: keys first, then (as uint32) the values
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < RS_WAVES * 256; i += RS_THREADS) (&cnt[0][0])[i] = 0;
-  gbase[threadIdx.x] = offsets[(uint64_t)threadIdx.x * ntiles + blockIdx.x];
   __syncthreads();
-  const uint64_t wbase = (uint64_t)blockIdx.x * RS_TILE + (uint64_t)w * (64 * RS_ITEMS);
+  const uint64_t tbase = (uint64_t)blockIdx.x * RS_TILE;
+  const uint64_t wbase = tbase + (uint64_t)w * (64 * RS_ITEMS);
+  const uint32_t tile_n = (uint32_t)((n - tbase) < (uint64_t)RS_TILE ? (n - tbase) : (uint64_t)RS_TILE);
   uint64_t k[RS_ITEMS];
-  uint32_t rank[RS_ITEMS];
+  uint32_t v[RS_ITEMS];
+  uint32_t pos[RS_ITEMS];
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
   for (int r = 0; r < RS_ITEMS; r++) {
     uint64_t i = wbase + (uint64_t)r * 64 + lane;
     bool valid = i < n;
     k[r] = valid ? keys[i] : ~0ull;
+    v[r] = valid ? vals[i] : 0u;
     uint32_t d = (uint32_t)(k[r] >> shift) & 0xFF;
-    // peers = lanes of this wave holding the same digit this round (invalid lanes form their own class via bit 8)
-    unsigned long long peers = __ballot(valid) ;
+    // peers = lanes of this wave holding the same digit this round (invalid lanes form their own class)
+    unsigned long long peers = __ballot(valid);
     peers = valid ? peers : ~peers;
 #pragma unroll
     for (int b = 0; b < 8; b++) {
@@ -245,29 +252,60 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint64_t *__
       cnt[w][d] = old + (uint32_t)__popcll(peers);
     }
     old = __shfl(old, leader, 64);
-    rank[r] = old + before;
+    pos[r] = old + before;  // rank among the wave's keys with this digit
   }
   __syncthreads();
-  // exclusive prefix over waves for each digit; thread t owns digit t
+  // thread t owns digit t: position of the digit inside the sorted tile (exclusive scan over digits), then per-wave starts
   {
-    uint32_t run = gbase[threadIdx.x];
+    uint32_t tot = 0;
+#pragma unroll
+    for (int i = 0; i < RS_WAVES; i++) tot += cnt[i][threadIdx.x];
+    uint32_t all;
+    const uint32_t tstart = block_excl_scan_256(tot, &all, scan_lds);
+    uint32_t run = tstart;
 #pragma unroll
     for (int i = 0; i < RS_WAVES; i++) {
       uint32_t t = cnt[i][threadIdx.x];
       cnt[i][threadIdx.x] = run;
       run += t;
     }
+    gbase[threadIdx.x] = offsets[(uint64_t)threadIdx.x * ntiles + blockIdx.x] - tstart;
   }
   __syncthreads();
+  // keys into digit order
 #pragma unroll
   for (int r = 0; r < RS_ITEMS; r++) {
     uint64_t i = wbase + (uint64_t)r * 64 + lane;
     if (i < n) {
       uint32_t d = (uint32_t)(k[r] >> shift) & 0xFF;
-      uint32_t dst = cnt[w][d] + rank[r];
-      keys_out[dst] = k[r];
-      vals_out[dst] = vals[i];
+      pos[r] += cnt[w][d];
+      sbuf[pos[r]] = k[r];
     }
+  }
+  __syncthreads();
+  uint32_t dst[RS_ITEMS];
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; r++) {
+    const uint32_t j = (uint32_t)r * RS_THREADS + threadIdx.x;
+    if (j < tile_n) {
+      const uint64_t key = sbuf[j];
+      dst[r] = gbase[(uint32_t)(key >> shift) & 0xFF] + j;
+      keys_out[dst[r]] = key;
+    }
+  }
+  __syncthreads();
+  // values through the same buffer
+  uint32_t *sval = reinterpret_cast<uint32_t *>(sbuf);
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; r++) {
+    uint64_t i = wbase + (uint64_t)r * 64 + lane;
+    if (i < n) sval[pos[r]] = v[r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; r++) {
+    const uint32_t j = (uint32_t)r * RS_THREADS + threadIdx.x;
+    if (j < tile_n) vals_out[dst[r]] = sval[j];
   }
 }
 
