@@ -132,10 +132,130 @@ __device__ inline bool build_pieces(const uint32_t *cig, int ncig, int32_t pos, 
   return true;
 }
 
-__global__ __launch_bounds__(256) void k_bqsr_prologue(BqCols m, uint32_t *__restrict__ cig_scratch, BqDesc *__restrict__ desc,
-                                                       uint32_t *skipbits, uint32_t *err) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m.n) return;
+// marks bases [fs, fe] of the record whose first QUAL byte is at bit0 in the skip column
+__device__ __forceinline__ void set_skip_bits(uint32_t *skipbits, uint64_t bit0, int fs, int fe) {
+  for (int k = fs; k <= fe;) {  // word by word
+    const uint64_t b = bit0 + (uint64_t)k;
+    const int in_word = (int)(b & 31);
+    int cnt = 32 - in_word;
+    if (cnt > fe - k + 1) cnt = fe - k + 1;
+    const uint32_t mask = (cnt == 32 ? 0xFFFFFFFFu : ((1u << cnt) - 1u)) << in_word;
+    atomicOr(&skipbits[b >> 5], mask);
+    k += cnt;
+  }
+}
+
+// Fast prologue, one thread per record.  Decides eligibility (recalibrateAln) for every record and finishes the records whose
+// CIGAR is a single M/=/X operation and that need no adaptor clipping (≈ 5 of 6 reads): for those the clipped copy is the read
+// itself, getReadCoordinateForReferenceCoordinate(ref) is ref - POS inside the read and fails outside (utils.go:267-349 with one
+// match operation), and there is one reference piece.  Everything else is appended to `queue` for the general kernel, so that
+// kernel's long divergent code runs with all lanes busy.  All column loads are issued before the first test (one latency, not 15).
+constexpr int PF_TILES = 16;
+__global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__restrict__ desc, uint32_t *skipbits, uint32_t *__restrict__ queue,
+                                                            uint32_t *queue_n, uint32_t *err) {
+  // a workgroup handles PF_TILES * 256 consecutive records and collects the deferred ones in LDS: one global atomic per
+  // workgroup (a global atomic per wave on the single queue counter serialises at ~12 ns each: 9 ms for 50 M reads)
+  __shared__ uint32_t lq[PF_TILES * 256];
+  __shared__ uint32_t lcount, gbase;
+  if (threadIdx.x == 0) lcount = 0;
+  __syncthreads();
+#pragma unroll 1
+  for (int tile = 0; tile < PF_TILES; tile++) {
+  const uint64_t i = ((uint64_t)blockIdx.x * PF_TILES + (uint64_t)tile) * 256 + threadIdx.x;
+  bool defer = false;
+  if (i < m.n) {
+    const uint8_t has_sr = m.has_sr[i], mq = m.mapq[i];
+    const uint16_t f = m.flag[i], rg = m.rgid[i];
+    const int32_t r = m.refid[i], p = m.pos[i], pnext = m.pnext[i], tlen = m.tlen[i], nrefid = m.next_refid[i];
+    const uint32_t ls = m.l_seq[i];
+    const uint64_t q0 = m.qual_off[i], q1 = m.qual_off[i + 1], c0 = m.cigar_off[i], c1 = m.cigar_off[i + 1];
+    BqDesc d;
+    d.D0 = d.D1 = d.D2 = BQ_NOREF; d.refid = 0; d.b1 = d.b2 = 0xFFFF; d.a = 0; d.len = 0; d.left = 0; d.right = 0; d.cov = 0; d.fl = 0; d.pad = 0;
+    // recalibrateAln, bqsr.go:225-244 (+ utils.go:121-139), the part that needs no dependent load
+    bool ok = !has_sr && mq > 0 && mq < 255 && !(f & (F_SECONDARY | F_DUPLICATE | F_QCFAILED)) && !(f & F_UNMAPPED) && r >= 0 && p > 0 && ls != 0 &&
+              (uint64_t)ls == q1 - q0 && rg != ELP_NIL16 && r < m.n_ref;
+    if (ok) {
+      const uint32_t op0 = c1 > c0 ? m.cigar[c0] : 0u;
+      const int32_t rl = m.ref_len[r];
+      ok = p <= rl;
+      const bool single_match = c1 - c0 == 1 && (c_op(op0) == OP_M || c_op(op0) == OP_EQ || c_op(op0) == OP_X);
+      if (ok && !(single_match && ls <= (uint32_t)MAX_DESC_READ)) { defer = true; ok = false; }  // the general kernel redoes the tests
+      if (ok) ok = (uint32_t)c_len(op0) == ls;  // SEQ length == CIGAR read length (utils.go:121-128)
+      if (ok) {
+        const int len = (int)ls;
+        const int32_t end = p + len - 1;  // aln.End() (sam/sam-types.go:769-775)
+        // hardClipAdaptorSequence (utils.go:149-180, 214-222) would clip?
+        const bool rev = f & F_REVERSED;
+        bool clip = false;
+        if (tlen != 0 && (f & F_MULTIPLE) && !((f & F_NEXT_UNMAPPED) || nrefid < 0 || pnext == 0) && rev != (bool)(f & F_NEXT_REVERSED)) {
+          const bool well = rev ? end > pnext : p <= pnext + tlen;
+          if (well) {
+            const int boundary = rev ? (int)pnext - 1 : (int)p + (tlen < 0 ? -(int)tlen : (int)tlen);
+            clip = boundary >= (int)p && boundary <= (int)end;
+          }
+        }
+        if (clip) {
+          defer = true;
+        } else {
+          // calculateSkipSlice (bqsr.go:389-414): softStart = POS, softEnd = End
+          const int32_t *sv = m.sites[r];
+          const int64_t ns = m.n_sites[r];
+          if (ns > 0) {
+            const int64_t nbuck = ((int64_t)rl >> 6) + 1;
+            int64_t bk = (int64_t)p >> 6;
+            bk = bk >= nbuck ? nbuck - 1 : bk;
+            int64_t s = m.site_idx[r][bk];
+            while (s < ns && sv[2 * s + 1] < p) s++;
+            for (; s < ns && sv[2 * s] <= end; s++) {
+              const int a0 = sv[2 * s] - p, a1 = sv[2 * s + 1] - p;
+              const int fs = (a0 < 0 || a0 >= len) ? 0 : a0;          // !ok || < 0 -> 0
+              const int fe = (a1 < 0 || a1 >= len) ? len - 1 : a1;    // !ok || > len-1 -> len-1 (a1 < 0 cannot happen: End >= POS)
+              set_skip_bits(skipbits, q0, fs, fe);
+            }
+          }
+          // computeStrandedClippedSeq mask bounds (bqsr.go:316-332)
+          const uint8_t *ql = m.qual + q0;
+          int left = len;
+          for (int k = 0; k < len; k++) if (ql[k] > 2) { left = k; break; }
+          int right = left - 1;
+          for (int k = len - 1; k >= left; k--) if (ql[k] > 2) { right = k; break; }
+          d.D0 = p - 1;
+          d.refid = r;
+          d.len = (uint16_t)len;
+          d.left = (uint16_t)left; d.right = (uint16_t)(right < 0 ? 0xFFFF : right);
+          d.cov = (uint8_t)m.rg_cov[rg];
+          d.fl = BQ_ELIGIBLE | (rev ? BQ_REVERSED : 0) | ((f & F_LAST) ? BQ_LAST : 0);
+        }
+      }
+    }
+    if (!defer) desc[i] = d;
+  }
+  // append deferred records to the workgroup's list: one LDS atomic per wave
+  const unsigned long long mask = __ballot(defer);
+  if (mask) {
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&lcount, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    if (defer) lq[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)i;
+  }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) gbase = lcount ? atomicAdd(queue_n, lcount) : 0u;
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < lcount; k += 256) queue[gbase + k] = lq[k];
+  (void)err;
+}
+
+// General prologue: one thread per record of `queue` (the records k_bqsr_prologue_fast left: anything but a plain "<len>M" CIGAR
+// without adaptor read-through); literal transliteration of the reference's clipping code.
+__global__ __launch_bounds__(256) void k_bqsr_prologue(BqCols m, const uint32_t *__restrict__ queue, const uint32_t *__restrict__ queue_n,
+                                                       uint32_t *__restrict__ cig_scratch, BqDesc *__restrict__ desc, uint32_t *skipbits,
+                                                       uint32_t *err) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (uint64_t)*queue_n) return;
+  const uint64_t i = queue[t];
   BqDesc d;
   d.D0 = d.D1 = d.D2 = BQ_NOREF; d.refid = 0; d.b1 = d.b2 = 0xFFFF; d.a = 0; d.len = 0; d.left = 0; d.right = 0; d.cov = 0; d.fl = 0; d.pad = 0;
   if (!recalibrate_aln(m, i)) { desc[i] = d; return; }
@@ -178,15 +298,7 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue(BqCols m, uint32_t *__res
       if (!ok || fs < 0) fs = 0;
       int fe = get_read_coord(a.cig, a.ncig, ss, sv[2 * s + 1], false, &ok);
       if (!ok || fe > a.len - 1) fe = a.len - 1;
-      for (int k = fs; k <= fe;) {  // set bits word by word
-        const uint64_t b = bit0 + (uint64_t)k;
-        const int in_word = (int)(b & 31);
-        int cnt = 32 - in_word;
-        if (cnt > fe - k + 1) cnt = fe - k + 1;
-        const uint32_t mask = (cnt == 32 ? 0xFFFFFFFFu : ((1u << cnt) - 1u)) << in_word;
-        atomicOr(&skipbits[b >> 5], mask);
-        k += cnt;
-      }
+      set_skip_bits(skipbits, bit0, fs, fe);
     }
   }
   ReadView v{m.seq4 + m.seq_off[i], m.qual + m.qual_off[i], a.off, a.len, (bool)(a.flag & F_REVERSED), 0, -1};
@@ -639,15 +751,16 @@ __global__ __launch_bounds__(256) void k_apply_prologue(uint64_t n, const uint16
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   ApDesc d{0, 0, 0, 0, 0};
-  const uint16_t rg = rgid[i];
+  // all column loads first (one memory latency instead of one per test)
+  const uint16_t rg = rgid[i], f = flag[i];
+  const int len = (int)l_seq[i];
+  const uint64_t q0 = qual_off[i], q1 = qual_off[i + 1];
   if (rg == ELP_NIL16) { atomicOr(&err[0], 32u); desc[i] = d; return; }  // readGroupCovariate panics, bqsr.go:38
   const uint32_t cov = rg_cov[rg];
   if (!cov_present[cov]) { desc[i] = d; return; }  // :953-955
-  const int len = (int)l_seq[i];
-  if ((uint64_t)len != qual_off[i + 1] - qual_off[i]) { atomicOr(&err[0], 64u); desc[i] = d; return; }
+  if ((uint64_t)len != q1 - q0) { atomicOr(&err[0], 64u); desc[i] = d; return; }
   if (len > MAX_DESC_READ) { atomicOr(&err[0], 2u); desc[i] = d; return; }
-  const uint16_t f = flag[i];
-  ReadView v{nullptr, qual + qual_off[i], 0, len, (bool)(f & F_REVERSED), 0, -1};
+  ReadView v{nullptr, qual + q0, 0, len, (bool)(f & F_REVERSED), 0, -1};
   low_quality_bounds(v);
   d.left = (uint16_t)v.left; d.right = (uint16_t)(v.right < 0 ? 0xFFFF : v.right);
   d.len = (uint16_t)len;
@@ -937,7 +1050,16 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
     BqCols m{n, c->refid.p, c->pos.p, c->next_refid.p, c->pnext.p, c->tlen.p, c->flag.p, c->rgid.p, c->mapq.p, c->has_sr.p, c->l_seq.p,
              c->cigar_off.p, c->seq_off.p, c->qual_off.p, c->cigar.p, c->seq4.p, c->qual.p, c->ref_len.p, c->rg_cov.p, c->n_ref,
              c->d_ref_seq.p, c->d_ref_seq_len.p, c->d_sites.p, c->d_n_sites.p, c->d_site_idx.p};
-    ELP_LAUNCH(c, "bqsr_prologue", k_bqsr_prologue, dim3(blocks_for(n, 256)), dim3(256), 0, m, cs_pool, desc, skipbits, c->err_flag.p);
+    uint32_t *queue;
+    ELP_TRY(scratch(c, 5, n + 16, &queue));  // [0] = count, [4..] = records left to the general kernel
+    ELP_HIP(c, hipMemsetAsync(queue, 0, 16, st));
+    ELP_LAUNCH(c, "bqsr_prologue_fast", k_bqsr_prologue_fast, dim3(blocks_for(n, 256 * PF_TILES)), dim3(256), 0, m, desc, skipbits, queue + 4, queue, c->err_flag.p);
+    uint32_t n_queued = 0;
+    ELP_HIP(c, hipMemcpyAsync(&n_queued, queue, 4, hipMemcpyDeviceToHost, st));
+    ELP_HIP(c, hipStreamSynchronize(st));
+    if (n_queued)
+      ELP_LAUNCH(c, "bqsr_prologue", k_bqsr_prologue, dim3(blocks_for(n_queued, 256)), dim3(256), 0, m, (const uint32_t *)(queue + 4), (const uint32_t *)queue,
+                 cs_pool, desc, skipbits, c->err_flag.p);
     const int lmax = (int)std::max<uint32_t>(c->max_l_seq, 1);
     if (lmax > MAX_DESC_READ) return set_error(c, ELP_ERR_UNSUPPORTED, "BQSR: read longer than %d bases", MAX_DESC_READ);
     const bool check_cycle = lmax > max_cycle;
