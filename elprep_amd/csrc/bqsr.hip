@@ -42,6 +42,7 @@ struct BqCols {
   int32_t *const *sites;
   const int64_t *n_sites;
   uint32_t *const *site_idx;  // per contig and 64-bp bucket: first site whose end is >= 64 * bucket (k_site_index)
+  const uint64_t *qbounds;    // per record: low-quality-tail bounds of the full read (adapt_score)
 };
 
 // recalibrateAln, bqsr.go:225-244 (+ utils.go:121-139)
@@ -169,6 +170,7 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
     const int32_t r = m.refid[i], p = m.pos[i], pnext = m.pnext[i], tlen = m.tlen[i], nrefid = m.next_refid[i];
     const uint32_t ls = m.l_seq[i];
     const uint64_t q0 = m.qual_off[i], q1 = m.qual_off[i + 1], c0 = m.cigar_off[i], c1 = m.cigar_off[i + 1];
+    const uint64_t qb = m.qbounds[i];
     BqDesc d;
     d.D0 = d.D1 = d.D2 = BQ_NOREF; d.refid = 0; d.b1 = d.b2 = 0xFFFF; d.a = 0; d.len = 0; d.left = 0; d.right = 0; d.cov = 0; d.fl = 0; d.pad = 0;
     // recalibrateAln, bqsr.go:225-244 (+ utils.go:121-139), the part that needs no dependent load
@@ -213,12 +215,9 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
               set_skip_bits(skipbits, q0, fs, fe);
             }
           }
-          // computeStrandedClippedSeq mask bounds (bqsr.go:316-332)
-          const uint8_t *ql = m.qual + q0;
-          int left = len;
-          for (int k = 0; k < len; k++) if (ql[k] > 2) { left = k; break; }
-          int right = left - 1;
-          for (int k = len - 1; k >= left; k--) if (ql[k] > 2) { right = k; break; }
+          // computeStrandedClippedSeq mask bounds (bqsr.go:316-332), precomputed on the full read by adapt_score
+          const uint32_t hi1 = (uint32_t)qb;
+          const int left = hi1 ? (int)(qb >> 32) : len, right = hi1 ? (int)hi1 - 1 : len - 1;
           d.D0 = p - 1;
           d.refid = r;
           d.len = (uint16_t)len;
@@ -746,7 +745,7 @@ static_assert(sizeof(ApDesc) == 8, "ApDesc is staged as one 8-byte word");
 
 __global__ __launch_bounds__(256) void k_apply_prologue(uint64_t n, const uint16_t *__restrict__ flag, const uint16_t *__restrict__ rgid,
                                                         const uint16_t *__restrict__ rg_cov, const uint32_t *__restrict__ l_seq,
-                                                        const uint64_t *__restrict__ qual_off, const uint8_t *__restrict__ qual,
+                                                        const uint64_t *__restrict__ qual_off, const uint64_t *__restrict__ qbounds,
                                                         const uint8_t *__restrict__ cov_present, ApDesc *__restrict__ desc, uint32_t *err) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -754,15 +753,16 @@ __global__ __launch_bounds__(256) void k_apply_prologue(uint64_t n, const uint16
   // all column loads first (one memory latency instead of one per test)
   const uint16_t rg = rgid[i], f = flag[i];
   const int len = (int)l_seq[i];
-  const uint64_t q0 = qual_off[i], q1 = qual_off[i + 1];
+  const uint64_t q0 = qual_off[i], q1 = qual_off[i + 1], qb = qbounds[i];
   if (rg == ELP_NIL16) { atomicOr(&err[0], 32u); desc[i] = d; return; }  // readGroupCovariate panics, bqsr.go:38
   const uint32_t cov = rg_cov[rg];
   if (!cov_present[cov]) { desc[i] = d; return; }  // :953-955
   if ((uint64_t)len != q1 - q0) { atomicOr(&err[0], 64u); desc[i] = d; return; }
   if (len > MAX_DESC_READ) { atomicOr(&err[0], 2u); desc[i] = d; return; }
-  ReadView v{nullptr, qual + q0, 0, len, (bool)(f & F_REVERSED), 0, -1};
-  low_quality_bounds(v);
-  d.left = (uint16_t)v.left; d.right = (uint16_t)(v.right < 0 ? 0xFFFF : v.right);
+  // computeStrandedClippedSeq mask bounds (bqsr.go:316-332) on the full read, precomputed by adapt_score
+  const uint32_t hi1 = (uint32_t)qb;
+  const int left = hi1 ? (int)(qb >> 32) : len, right = hi1 ? (int)hi1 - 1 : len - 1;
+  d.left = (uint16_t)left; d.right = (uint16_t)(right < 0 ? 0xFFFF : right);
   d.len = (uint16_t)len;
   d.cov = (uint8_t)cov;
   d.fl = BQ_ELIGIBLE | ((f & F_REVERSED) ? BQ_REVERSED : 0) | ((f & F_LAST) ? BQ_LAST : 0);
@@ -1027,6 +1027,7 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
   for (int r = 0; r < c->n_ref; r++)
     if (!c->h_sites[r]) ELP_TRY(elp_bqsr_set_known_sites(c, r, nullptr, 0));
   ELP_TRY(sync_bqsr_ptrs(c));
+  ELP_TRY(ensure_adapted(c, false));  // low-quality-tail bounds per read (adapt_score)
   ELP_TRY(ensure_flat_index(c));
   ELP_TRY(ensure_qual_present(c));  // sizing hint: the set of quality values seen in a sample of the column
   if (c->n_cov > 255) return set_error(c, ELP_ERR_UNSUPPORTED, "more than 255 read-group covariates");
@@ -1049,7 +1050,7 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
     ELP_HIP(c, hipMemsetAsync(skipbits, 0, skip_words * 4, st));
     BqCols m{n, c->refid.p, c->pos.p, c->next_refid.p, c->pnext.p, c->tlen.p, c->flag.p, c->rgid.p, c->mapq.p, c->has_sr.p, c->l_seq.p,
              c->cigar_off.p, c->seq_off.p, c->qual_off.p, c->cigar.p, c->seq4.p, c->qual.p, c->ref_len.p, c->rg_cov.p, c->n_ref,
-             c->d_ref_seq.p, c->d_ref_seq_len.p, c->d_sites.p, c->d_n_sites.p, c->d_site_idx.p};
+             c->d_ref_seq.p, c->d_ref_seq_len.p, c->d_sites.p, c->d_n_sites.p, c->d_site_idx.p, c->qbounds.p};
     uint32_t *queue;
     ELP_TRY(scratch(c, 5, n + 16, &queue));  // [0] = count, [4..] = records left to the general kernel
     ELP_HIP(c, hipMemsetAsync(queue, 0, 16, st));
@@ -1193,6 +1194,7 @@ int elp_bqsr_apply(elp_ctx *c, int max_cycle, const uint8_t *lut, const uint8_t 
   if (c->n_cov > 255) return set_error(c, ELP_ERR_UNSUPPORTED, "more than 255 read-group covariates");
   const size_t ncyc = 2 * (size_t)max_cycle + 1;
   const size_t lut_bytes = (size_t)c->n_cov * ELP_NQUAL * ncyc * 17;
+  ELP_TRY(ensure_adapted(c, false));  // low-quality-tail bounds per read (adapt_score)
   uint8_t *dl;
   ELP_TRY(scratch(c, 0, lut_bytes + (size_t)c->n_cov + 64, &dl));
   ELP_HIP(c, hipMemcpyAsync(dl, lut, lut_bytes, hipMemcpyHostToDevice, c->stream));
@@ -1203,7 +1205,7 @@ int elp_bqsr_apply(elp_ctx *c, int max_cycle, const uint8_t *lut, const uint8_t 
     ELP_TRY(scratch(c, 2, n + 4, &desc));
     ELP_LAUNCH(c, "bqsr_apply_prologue", k_apply_prologue, dim3(blocks_for(n, 256)), dim3(256), 0, n, (const uint16_t *)c->flag.p,
                (const uint16_t *)c->rgid.p, (const uint16_t *)c->rg_cov.p, (const uint32_t *)c->l_seq.p, (const uint64_t *)c->qual_off.p,
-               (const uint8_t *)c->qual.p, (const uint8_t *)(dl + lut_bytes), desc, c->err_flag.p);
+               (const uint64_t *)c->qbounds.p, (const uint8_t *)(dl + lut_bytes), desc, c->err_flag.p);
     if (c->qual_bytes) {
       const uint64_t ntiles = (c->qual_bytes + FL_TILE - 1) / FL_TILE;
       const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, (uint64_t)c->n_cu * 8);

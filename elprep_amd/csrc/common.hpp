@@ -83,9 +83,12 @@ struct elp_ctx {
 
   // derived state
   bool adapted = false, sorted = false, marked = false;
+  bool adapt_bad_qual = false;  // adapt_score met a quality > 93 in a duplicate-marking candidate
   bool have_qual_present = false;
   unsigned long long qual_present[2] = {0, 0};  // bit q set if quality value q was seen in a sample of the QUAL column (sizing hint for the BQSR tables)
   elp::DVec<int32_t> upos, score;
+  elp::DVec<uint64_t> qbounds;  // per record: 1 + index of the last quality > 2 (low 32 bits; 0 = none) and index of the first one (high): the
+                                // low-quality-tail bounds of computeStrandedClippedSeq (bqsr.go:316-332) on the full read; valid when adapted
   elp::DVec<uint64_t> key;      // coordinate sort keys, staging order
   elp::DVec<uint32_t> perm;     // sorted position -> staging index
   elp::DVec<uint32_t> err_flag; // device-side error word(s)
@@ -246,7 +249,7 @@ __host__ __device__ inline uint16_t mod_flag(uint16_t flag) {
 int radix_sort_pairs(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *keys_tmp, uint32_t *vals_tmp, uint64_t n,
                      uint64_t **keys_out, uint32_t **vals_out);
 int exclusive_scan_u32(elp_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n, uint32_t *total_host /* may be null */);
-int ensure_adapted(elp_ctx *c);
+int ensure_adapted(elp_ctx *c, bool check_quals = true);
 int ensure_qual_present(elp_ctx *c, bool exact = false);  // exact: scan the whole column instead of a sample
 int fetch_err(elp_ctx *c, uint32_t *words /* 4 */);
 

@@ -71,13 +71,18 @@ struct ScoreBody {
   const uint16_t *__restrict__ flag;
   const uint8_t *__restrict__ qual;
   int32_t *score;
+  uint64_t *qbounds;
   int32_t *acc;    // LDS [FL_RMAX]: per-read partial sums of this group (LDS atomics; one global store per read)
+  uint32_t *lo;    // LDS [FL_RMAX]: index of the first quality > 2 of the read (0xFFFFFFFF: none yet)
+  uint32_t *hi;    // LDS [FL_RMAX]: 1 + index of the last quality > 2 (0: none yet)
   uint8_t *cand;   // LDS [FL_RMAX]: duplicate-marking candidate?
   uint32_t bad;
 
   __device__ __forceinline__ void stage(uint32_t g0, uint32_t ng) {
     for (uint32_t k = threadIdx.x; k < ng; k += blockDim.x) {
       acc[k] = 0;
+      lo[k] = 0xFFFFFFFFu;
+      hi[k] = 0u;
       cand[k] = (flag[g0 + k] & (F_UNMAPPED | F_SECONDARY | F_SUPPLEMENTARY)) == 0;
     }
   }
@@ -86,35 +91,52 @@ struct ScoreBody {
     badw |= ((((x | 0x80808080u) - 0x5E5E5E5Eu) | x) & 0x80808080u) & m;          // byte >= 94
     return __builtin_amdgcn_sad_u8(x & (ge15 * 0xFFu) & m, 0u, s);
   }
-  struct Pre { Chunk ch; uint32_t rl; int nb; };
-  __device__ __forceinline__ bool prefetch(uint32_t rl, int, int nb, uint64_t qpos, Pre &p) {
-    if (!cand[rl]) return false;
-    p.rl = rl; p.nb = nb;
+  static __device__ __forceinline__ uint32_t gt2(uint32_t x, uint32_t m) {  // bit 7 of every byte > 2 (inside mask m)
+    return ((((x | 0x80808080u) - 0x03030303u) | x) & 0x80808080u) & m;
+  }
+  struct Pre { Chunk ch; uint32_t rl; int nb; int k0; };
+  __device__ __forceinline__ bool prefetch(uint32_t rl, int k0, int nb, uint64_t qpos, Pre &p) {
+    p.rl = rl; p.nb = nb; p.k0 = k0;
     p.ch.load(qual + qpos);
     return true;
   }
   __device__ __forceinline__ void process(Pre &p) {
+    const uint32_t m0 = first_bytes32(p.nb), m1 = first_bytes32(p.nb - 4), m2 = first_bytes32(p.nb - 8), m3 = first_bytes32(p.nb - 12);
+    // low-quality-tail bounds: first / last quality > 2 of the read
+    const uint64_t glo = (uint64_t)gt2(p.ch.w0, m0) | ((uint64_t)gt2(p.ch.w1, m1) << 32);
+    const uint64_t ghi = (uint64_t)gt2(p.ch.w2, m2) | ((uint64_t)gt2(p.ch.w3, m3) << 32);
+    if (glo | ghi) {
+      const int first = glo ? (__builtin_ctzll(glo) >> 3) : 8 + (__builtin_ctzll(ghi) >> 3);
+      const int last = ghi ? 8 + ((63 - __builtin_clzll(ghi)) >> 3) : ((63 - __builtin_clzll(glo)) >> 3);
+      atomicMin(&lo[p.rl], (uint32_t)(p.k0 + first));
+      atomicMax(&hi[p.rl], (uint32_t)(p.k0 + last + 1));
+    }
+    if (!cand[p.rl]) return;
     uint32_t s = 0, b = 0;
-    s = part(p.ch.w0, first_bytes32(p.nb), s, b);
-    s = part(p.ch.w1, first_bytes32(p.nb - 4), s, b);
-    s = part(p.ch.w2, first_bytes32(p.nb - 8), s, b);
-    s = part(p.ch.w3, first_bytes32(p.nb - 12), s, b);
+    s = part(p.ch.w0, m0, s, b);
+    s = part(p.ch.w1, m1, s, b);
+    s = part(p.ch.w2, m2, s, b);
+    s = part(p.ch.w3, m3, s, b);
     bad |= b;
     if (s) atomicAdd(&acc[p.rl], (int32_t)s);
   }
   __device__ __forceinline__ void group_end(uint32_t g0, uint32_t ng) {
-    for (uint32_t k = threadIdx.x; k < ng; k += blockDim.x) score[g0 + k] = acc[k];  // a read belongs to exactly one group
+    for (uint32_t k = threadIdx.x; k < ng; k += blockDim.x) {  // a read belongs to exactly one group
+      score[g0 + k] = acc[k];
+      qbounds[g0 + k] = (uint64_t)hi[k] | ((uint64_t)lo[k] << 32);  // all-zero = no quality > 2
+    }
   }
   __device__ __forceinline__ void tile_end(uint32_t) {}
 };
 
 __global__ __launch_bounds__(FL_THREADS) void k_score_flat(uint64_t n, const uint64_t *__restrict__ qual_off, const uint8_t *__restrict__ qual,
                                                            uint64_t qual_bytes, const uint32_t *__restrict__ tile_first,
-                                                           const uint16_t *__restrict__ flag, int32_t *score, uint32_t *err) {
+                                                           const uint16_t *__restrict__ flag, int32_t *score, uint64_t *qbounds, uint32_t *err) {
   __shared__ FlatLds L;
   __shared__ int32_t acc[FL_RMAX];
+  __shared__ uint32_t lo[FL_RMAX], hi[FL_RMAX];
   __shared__ uint8_t cand[FL_RMAX];
-  ScoreBody B{flag, qual, score, acc, cand, 0u};
+  ScoreBody B{flag, qual, score, qbounds, acc, lo, hi, cand, 0u};
   flat_run(qual_off, n, qual_bytes, tile_first, L, B);
   if (__any(B.bad != 0) && (threadIdx.x & 63) == 0) atomicOr(&err[0], 1u);
 }
@@ -182,32 +204,41 @@ int ensure_flat_index(elp_ctx *c) {
   return 0;
 }
 
-int ensure_adapted(elp_ctx *c) {
-  if (c->adapted) return 0;
+static int adapt_quality_error(elp_ctx *c) {
+  return set_error(c, ELP_ERR_DATA, "Invalid QUAL character (phred > 93) in a duplicate-marking candidate (reference: log.Panic, filters/mark-duplicates.go:64-66)");
+}
+
+// check_quals: report a quality > 93 in a duplicate-marking candidate (computePhredScore panics); the BQSR entry points, which
+// only need the per-read low-quality-tail bounds, pass false and leave that error to a later elp_mark_duplicates
+int ensure_adapted(elp_ctx *c, bool check_quals) {
+  if (c->adapted) return (check_quals && c->adapt_bad_qual) ? adapt_quality_error(c) : 0;
   ELP_HIP(c, hipSetDevice(c->device));
   uint64_t n = c->n;
   ELP_TRY(ensure_flat_index(c));
   ELP_TRY(ensure(c, c->upos, n + 1));
   ELP_TRY(ensure(c, c->score, n + 1));
   ELP_TRY(ensure(c, c->key, n + 1));
+  ELP_TRY(ensure(c, c->qbounds, n + 1));
+  c->adapt_bad_qual = false;
   if (n) {
+    if (!c->qual_bytes) ELP_HIP(c, hipMemsetAsync(c->qbounds.p, 0, n * sizeof(uint64_t), c->stream));  // no QUAL bytes at all: no tile, no kernel
     ELP_LAUNCH(c, "adapt_fixed", k_adapt_fixed, dim3(blocks_for(n, 256)), dim3(256), 0, n, (const int32_t *)c->pos.p, (const int32_t *)c->refid.p,
                (const uint16_t *)c->flag.p, (const uint64_t *)c->cigar_off.p, (const uint32_t *)c->cigar.p, c->upos.p, c->score.p, c->key.p);
     if (c->qual_bytes) {
       const uint64_t ntiles = (c->qual_bytes + FL_TILE - 1) / FL_TILE;
       const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * 4);
       ELP_LAUNCH(c, "adapt_score", k_score_flat, dim3(grid), dim3(FL_THREADS), 0, n, (const uint64_t *)c->qual_off.p, (const uint8_t *)c->qual.p,
-                 c->qual_bytes, (const uint32_t *)c->tile_first.p, (const uint16_t *)c->flag.p, c->score.p, c->err_flag.p);
+                 c->qual_bytes, (const uint32_t *)c->tile_first.p, (const uint16_t *)c->flag.p, c->score.p, c->qbounds.p, c->err_flag.p);
     }
     uint32_t e[4];
     ELP_TRY(fetch_err(c, e));
     if (e[0] & 1u) {
       ELP_HIP(c, hipMemsetAsync(c->err_flag.p, 0, 4, c->stream));
-      return set_error(c, ELP_ERR_DATA, "Invalid QUAL character (phred > 93) in a duplicate-marking candidate (reference: log.Panic, filters/mark-duplicates.go:64-66)");
+      c->adapt_bad_qual = true;
     }
   }
   c->adapted = true;
-  return 0;
+  return (check_quals && c->adapt_bad_qual) ? adapt_quality_error(c) : 0;
 }
 
 // c->qual_present = quality values seen in a sample of the QUAL column (a sizing hint, see k_qual_present_sample)
@@ -379,7 +410,7 @@ __global__ __launch_bounds__(256) void k_large_scatter(uint32_t nu, const uint32
 
 static int sort_impl(elp_ctx *c) {
   const uint64_t n = c->n;
-  ELP_TRY(ensure_adapted(c));
+  ELP_TRY(ensure_adapted(c, false));
   ELP_TRY(ensure(c, c->perm, n + 1));
   if (n == 0) { c->sorted = true; return 0; }
   uint64_t *kbuf;
