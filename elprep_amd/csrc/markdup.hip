@@ -130,33 +130,20 @@ __device__ __forceinline__ uint64_t qname_hash(const MdCols &m, uint32_t i) {
   return mix64(h ^ ((uint64_t)lib_of(m, i) << 48));
 }
 
-__global__ __launch_bounds__(256) void k_mate_insert(MdCols m, uint32_t *table, uint64_t mask, uint32_t *__restrict__ mrep, uint32_t *cnt,
-                                                     uint32_t *lo, uint32_t *hi) {
+// Mates pair up through the table alone: the first record of a {library, QNAME} key becomes the slot's representative, the
+// second one finds it and claims it with one CAS on mate[representative]; a third record fails that CAS (more than two primary
+// mapped records per key: unsupported).  mate[] must be EMPTY-initialised.
+__global__ __launch_bounds__(256) void k_mate_insert(MdCols m, uint32_t *table, uint64_t mask, uint32_t *mate, uint32_t *err) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m.n) return;
   const uint16_t f = m.flag_in[i];
-  if (!is_candidate(f) || !is_true_pair(f)) { mrep[i] = EMPTY; return; }
+  if (!is_candidate(f) || !is_true_pair(f)) return;
   const uint32_t rep = find_or_insert(table, mask, qname_hash(m, (uint32_t)i), (uint32_t)i,
                                       [&](uint32_t a, uint32_t b) { return lib_of(m, a) == lib_of(m, b) && qname_eq(m.qname, m.qname_off, a, b); });
-  mrep[i] = rep;
-  atomicAdd(&cnt[rep], 1u);
-  atomicMin(&lo[rep], (uint32_t)i);
-  atomicMax(&hi[rep], (uint32_t)i);
-}
-
-__global__ __launch_bounds__(256) void k_mate_resolve(MdCols m, const uint32_t *__restrict__ mrep, const uint32_t *__restrict__ cnt,
-                                                      const uint32_t *__restrict__ lo, const uint32_t *__restrict__ hi,
-                                                      uint32_t *__restrict__ mate, uint32_t *err) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m.n) return;
-  const uint32_t rep = mrep[i];
-  uint32_t mt = EMPTY;
-  if (rep != EMPTY) {
-    const uint32_t c = cnt[rep];
-    if (c == 2) mt = ((uint32_t)i == lo[rep]) ? hi[rep] : lo[rep];
-    else if (c > 2) atomicOr(&err[1], 1u);  // more than two primary mapped records share {library, QNAME}
-  }
-  mate[i] = mt;
+  if (rep == (uint32_t)i) return;  // first of its key: the mate (if any) will write both entries
+  const uint32_t old = atomicCAS(&mate[rep], EMPTY, (uint32_t)i);
+  if (old == EMPTY) mate[i] = rep;
+  else atomicOr(&err[1], 1u);  // more than two primary mapped records share {library, QNAME}
 }
 
 // ---------------- pairs
@@ -243,7 +230,7 @@ static int markdup_impl(elp_ctx *c) {
   uint32_t *rep;
   ELP_TRY(scratch(c, 1, n + 8, &rep));
   unsigned long long *best;
-  ELP_TRY(scratch(c, 2, 2 * n + 8, &best));  // also holds cnt/lo/hi (3n u32) in the mate phase
+  ELP_TRY(scratch(c, 2, n + 8, &best));
   uint32_t *winner;
   ELP_TRY(scratch(c, 3, n + 8, &winner));
 
@@ -257,14 +244,9 @@ static int markdup_impl(elp_ctx *c) {
              (const uint32_t *)winner, c->flag.p);
 
   // ---- mates
-  uint32_t *cnt = reinterpret_cast<uint32_t *>(best), *lo = cnt + n, *hi = cnt + 2 * n;
   ELP_HIP(c, hipMemsetAsync(table, 0xFF, T * sizeof(uint32_t), st));
-  ELP_HIP(c, hipMemsetAsync(cnt, 0, n * sizeof(uint32_t), st));
-  ELP_HIP(c, hipMemsetAsync(lo, 0xFF, n * sizeof(uint32_t), st));
-  ELP_HIP(c, hipMemsetAsync(hi, 0, n * sizeof(uint32_t), st));
-  ELP_LAUNCH(c, "md_mate_insert", k_mate_insert, dim3(grid), dim3(256), 0, m, table, T - 1, rep, cnt, lo, hi);
-  ELP_LAUNCH(c, "md_mate_resolve", k_mate_resolve, dim3(grid), dim3(256), 0, m, (const uint32_t *)rep, (const uint32_t *)cnt, (const uint32_t *)lo,
-             (const uint32_t *)hi, c->mate.p, c->err_flag.p);
+  ELP_HIP(c, hipMemsetAsync(c->mate.p, 0xFF, n * sizeof(uint32_t), st));
+  ELP_LAUNCH(c, "md_mate_insert", k_mate_insert, dim3(grid), dim3(256), 0, m, table, T - 1, c->mate.p, c->err_flag.p);
 
   // ---- pairs
   ELP_HIP(c, hipMemsetAsync(table, 0xFF, T * sizeof(uint32_t), st));

@@ -90,37 +90,47 @@ __global__ __launch_bounds__(256) void k_opt_plus_origin(uint64_t n, uint32_t *g
 
 struct Tile { long long t, x, y; };
 
-// computeTileInfo :50-71; *bad is set where internal.ParseInt would panic
+// computeTileInfo :50-71; *bad is set where internal.ParseInt would panic.  One pass over the name, eight bytes per load: the
+// integer value (and parse status) of fields 2..6 is kept in scalars, the field count decides at the end which three are used
+// (7 fields -> 4,5,6; 5 fields -> 2,3,4).
 __device__ inline Tile tile_info(const uint8_t *__restrict__ q, uint32_t len, bool *bad) {
-  uint32_t st[8], en[8];
-  int ncol = 0;
-  uint32_t s = 0;
-  for (uint32_t i = 0; i <= len; i++) {
-    if (i == len || q[i] == ':') {
-      if (ncol < 8) { st[ncol] = s; en[ncol] = i; }
-      ncol++;
-      s = i + 1;
+  long long v2 = 0, v3 = 0, v4 = 0, v5 = 0, v6 = 0;
+  uint32_t badmask = 0;       // bit k: field k does not parse
+  int col = 0;
+  long long x = 0;
+  uint32_t ndig = 0;          // digits seen in the current field
+  bool neg = false, fbad = false, first = true;
+  uint64_t w = 0;
+  for (uint32_t i = 0;; i++) {
+    const bool end = i == len;
+    if (!end && (i & 7u) == 0) w = load8(q + i);
+    const uint32_t ch = end ? (uint32_t)':' : (uint32_t)(w >> (8 * (i & 7u))) & 0xFFu;
+    if (ch == ':') {
+      const bool fb = fbad || ndig == 0 || ndig > 18;
+      const long long val = neg ? -x : x;
+      if (col == 2) v2 = val; else if (col == 3) v3 = val; else if (col == 4) v4 = val; else if (col == 5) v5 = val; else if (col == 6) v6 = val;
+      if (col >= 2 && col <= 6 && fb) badmask |= 1u << col;
+      col++;
+      x = 0; ndig = 0; neg = false; fbad = false; first = true;
+    } else {
+      if (first && (ch == '+' || ch == '-')) {
+        neg = ch == '-';
+      } else {
+        const uint32_t d = ch - (uint32_t)'0';
+        if (d > 9) fbad = true;
+        else if (ndig < 19) x = x * 10 + (long long)d;
+        ndig++;
+      }
+      first = false;
     }
+    if (end) break;
   }
   int a;
-  if (ncol == 7) a = 4;
-  else if (ncol == 5) a = 2;
+  if (col == 7) a = 4;
+  else if (col == 5) a = 2;
   else return Tile{-1, -1, -1};
-  long long v[3];
-  for (int k = 0; k < 3; k++) {
-    uint32_t b = st[a + k], e = en[a + k];
-    bool neg = false;
-    if (b < e && (q[b] == '+' || q[b] == '-')) { neg = q[b] == '-'; b++; }
-    if (b >= e) { *bad = true; return Tile{-1, -1, -1}; }
-    long long x = 0;
-    for (uint32_t i = b; i < e; i++) {
-      const uint32_t d = (uint32_t)q[i] - '0';
-      if (d > 9 || (e - b) > 18) { *bad = true; return Tile{-1, -1, -1}; }
-      x = x * 10 + d;
-    }
-    v[k] = neg ? -x : x;
-  }
-  return Tile{v[0], v[1], v[2]};
+  if (badmask & (7u << a)) { *bad = true; return Tile{-1, -1, -1}; }
+  return a == 4 ? Tile{v4, v5, v6} : Tile{v2, v3, v4};
 }
 
 struct Member { long long t, x, y; uint32_t rg_rev; };  // rg_rev = rgid << 1 | reversed
