@@ -318,35 +318,36 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue(BqCols m, const uint32_t 
   desc[i] = d;
 }
 
-// reference contigs are kept as 4-bit BAM base codes, first base in the LOW nibble: A 1, C 2, G 4, T 8, anything else 0
-// (baseToIntMap, bqsr.go:247-252: a/A/'*' -> A ...; a read base is only ever compared when it is A, C, G or T, so "other"
-// needs no finer code).  Comparing 16 read bases with 16 reference bases is then one 64-bit XOR.
+// reference contigs are kept as 4-bit code nibbles like the restaged SEQ column (ctx.hip k_recode_seq), first base in the LOW
+// nibble: A 0, C 1, G 2, T 3, anything else 8 (baseToIntMap, bqsr.go:247-252: a/A/'*' -> A ...; a read base is only ever compared
+// when it is A, C, G or T, so "other" needs no finer code).  Comparing 16 read bases with 16 reference bases is one 64-bit XOR.
 __global__ __launch_bounds__(256) void k_pack_reference(const uint8_t *__restrict__ ascii, int64_t len, uint8_t *__restrict__ packed, int64_t packed_bytes) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= packed_bytes) return;
   uint32_t out = 0;
   for (int h = 0; h < 2; h++) {
     const int64_t j = 2 * i + h;
-    uint32_t code = 0;
+    uint32_t code = 8;  // past the contig: "other"
     if (j < len) {
       switch (ascii[j]) {
-        case 'a': case 'A': case '*': code = 1; break;
-        case 'c': case 'C': code = 2; break;
-        case 'g': case 'G': code = 4; break;
-        case 't': case 'T': code = 8; break;
-        default: code = 0;
+        case 'a': case 'A': case '*': code = 0; break;
+        case 'c': case 'C': code = 1; break;
+        case 'g': case 'G': code = 2; break;
+        case 't': case 'T': code = 3; break;
+        default: code = 8;
       }
     }
     out |= code << (4 * h);
   }
   packed[i] = (uint8_t)out;
 }
-constexpr int64_t REF_PAD = 32;  // zero bytes after the packed bases of a contig
+constexpr int64_t REF_PAD = 32;  // bytes of "other" (0x88) after the packed bases of a contig
+constexpr uint64_t REF_OTHER = 0x8888888888888888ull;
 constexpr int REF_LDS = 256;      // contigs whose packed-base pointer and length are kept in LDS by k_bqsr_count
 
 // Reference window of a block: ref_load ISSUES the load of the 32 packed bases around reference index jb (clamped into the
-// contig; its packed bases are followed by REF_PAD zero bytes) and returns the nibble shift for ref_unpack, REF_NONE if
-// nothing of [jb, jb+16) lies inside the contig.  ref_unpack: nibble b = reference base jb + b (0 outside [0, rlen)).
+// contig; its packed bases are followed by REF_PAD bytes of "other") and returns the nibble shift for ref_unpack, REF_NONE if
+// nothing of [jb, jb+16) lies inside the contig.  ref_unpack: nibble b = reference base jb + b ("other" outside [0, rlen)).
 constexpr int REF_NONE = 99;
 __device__ __forceinline__ int ref_load(const uint8_t *__restrict__ rp, int64_t rlen, int64_t jb, uint64_t &v0, uint64_t &v1) {
   const bool valid = jb < rlen && jb > -16;
@@ -358,8 +359,10 @@ __device__ __forceinline__ int ref_load(const uint8_t *__restrict__ rp, int64_t 
   return valid ? (int)(jb - jw) : REF_NONE;  // -15 .. 1
 }
 __device__ __forceinline__ uint64_t ref_unpack(uint64_t v0, uint64_t v1, int sn) {
-  const uint64_t r = nib_ext(v0, v1, sn == REF_NONE ? 0 : sn);
-  return sn == REF_NONE ? 0ull : r;
+  const int s = sn == REF_NONE ? 0 : sn;
+  uint64_t r = nib_ext(v0, v1, s);
+  if (s < 0) r |= REF_OTHER & ~(NIBF << (4 * -s));  // positions before the contig's first base: "other" (-s <= 15)
+  return sn == REF_NONE ? REF_OTHER : r;
 }
 __device__ __forceinline__ uint64_t ref_nibbles(const uint8_t *__restrict__ rp, int64_t rlen, int64_t jb) {
   uint64_t v0, v1;
@@ -549,7 +552,7 @@ struct CountBody {
     const uint64_t inw = nib_range(blo, bhi);
     uint64_t ohS, cS, ohN, cN;
     nib_classify(S, ohS, cS);
-    nib_classify_neighbour(N, rev, ohS, cS, ohN, cN);
+    nib_classify(N, ohN, cN);
     const uint64_t F = inw & ohS & ~nib_spread16(skipw);
     if (F == 0) return;
     // context covariate (bqsr.go:87-146): base and its predecessor in sequencing direction inside [left, right]
@@ -899,7 +902,7 @@ struct ApplyBody {
     seq_unpack(p.v0, p.v1, k0, rev, S, N);
     uint64_t ohS, cS, ohN, cN;
     nib_classify(S, ohS, cS);
-    nib_classify_neighbour(N, rev, ohS, cS, ohN, cN);
+    nib_classify(N, ohN, cN);
     const int cl = left + (rev ? 0 : 1), cr = right - (rev ? 1 : 0);
     int rhi = cr - k0 + 1;
     rhi = rhi < nb ? rhi : nb;
@@ -1144,7 +1147,7 @@ int elp_bqsr_set_reference(elp_ctx *c, int32_t refid, const uint8_t *bases, int6
   const int64_t packed = (len + 1) / 2;
   uint8_t *d = nullptr;
   ELP_HIP(c, hipMalloc((void **)&d, (size_t)(packed + REF_PAD)));
-  ELP_HIP(c, hipMemsetAsync(d, 0, (size_t)(packed + REF_PAD), c->stream));
+  ELP_HIP(c, hipMemsetAsync(d, 0x88, (size_t)(packed + REF_PAD), c->stream));
   if (len) {
     uint8_t *tmp;
     ELP_TRY(scratch(c, 7, (size_t)len + 16, &tmp));

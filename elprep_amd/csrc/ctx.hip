@@ -57,6 +57,31 @@ __global__ void k_rebase_offsets(const uint64_t *__restrict__ src, uint64_t *__r
   if (i < n_plus_1) dst[i] = src[i] - src0 + base;
 }
 
+// SEQ is restaged from BAM's 4-bit IUPAC codes (first base of a byte in the HIGH nibble) into "code nibbles", first base in the
+// LOW nibble: A 0, C 1, G 2, T 3, anything else 8.  The per-base kernels then get the 2-bit base code and the "is A/C/G/T" test
+// of 16 bases with two 64-bit ALU operations instead of a nibble swap plus a 17-operation SWAR classification per block, and the
+// reference contigs (k_pack_reference) use the same code, so read-vs-reference comparison stays one XOR.
+__device__ __forceinline__ uint32_t recode_byte(uint32_t b) {
+  constexpr uint64_t TAB = 0x8888888388828108ull;  // nibble n of TAB = code of BAM base n: 1 -> 0, 2 -> 1, 4 -> 2, 8 -> 3, else 8
+  return (uint32_t)((TAB >> (4 * (b >> 4))) & 15u) | ((uint32_t)((TAB >> (4 * (b & 15u))) & 15u) << 4);
+}
+__global__ __launch_bounds__(256) void k_recode_seq(uint8_t *__restrict__ seq, uint64_t nbytes) {
+  const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+  if (i >= nbytes) return;
+  if (i + 16 <= nbytes) {
+    uint32_t w[4];
+    __builtin_memcpy(w, seq + i, 16);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t x = w[k];
+      w[k] = recode_byte(x & 0xFFu) | (recode_byte((x >> 8) & 0xFFu) << 8) | (recode_byte((x >> 16) & 0xFFu) << 16) | (recode_byte(x >> 24) << 24);
+    }
+    __builtin_memcpy(seq + i, w, 16);
+  } else {
+    for (uint64_t k = i; k < nbytes; k++) seq[k] = (uint8_t)recode_byte(seq[k]);
+  }
+}
+
 int fetch_err(elp_ctx *c, uint32_t *words) {
   ELP_HIP(c, hipMemcpyAsync(words, c->err_flag.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   ELP_HIP(c, hipStreamSynchronize(c->stream));
@@ -221,7 +246,11 @@ int elp_stage(elp_ctx *c, const elp_batch *b) {
   else ELP_HIP(c, hipMemsetAsync(c->has_sr.p + at, 0, n, st));
   if (qb) H2D(c->qname.p + c->qname_bytes, b->qname + q0, qb, uint8_t);
   if (co) H2D(c->cigar.p + c->cigar_ops, b->cigar + c0, co, uint32_t);
-  if (sb) H2D(c->seq4.p + c->seq_bytes, b->seq4 + s0, sb, uint8_t);
+  if (sb) {
+    H2D(c->seq4.p + c->seq_bytes, b->seq4 + s0, sb, uint8_t);
+    hipLaunchKernelGGL(k_recode_seq, dim3(blocks_for((sb + 15) / 16, 256)), dim3(256), 0, st, c->seq4.p + c->seq_bytes, sb);
+    ELP_HIP(c, hipGetLastError());
+  }
   if (lb) H2D(c->qual.p + c->qual_bytes, b->qual + l0, lb, uint8_t);
   // offsets: copy raw, rebase on device
   ELP_TRY(ensure(c, c->stage_tmp, n + 1));

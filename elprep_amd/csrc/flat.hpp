@@ -64,26 +64,16 @@ __device__ __forceinline__ uint64_t nib_ext(uint64_t v0, uint64_t v1, int sn) {
 }
 // flag where the nibble is non-zero
 __device__ __forceinline__ uint64_t nib_nonzero(uint64_t x) { return (x | (x >> 1) | (x >> 2) | (x >> 3)) & NIB1; }
-// BAM base nibbles: onehot = flag where the nibble is A(1) C(2) G(4) T(8); code = 2-bit A0 C1 G2 T3 (valid where onehot)
-__device__ __forceinline__ void nib_classify(uint64_t x, uint64_t &onehot, uint64_t &code) {
-  const uint64_t a = x & NIB1, b = (x >> 1) & NIB1, c = (x >> 2) & NIB1, d = (x >> 3) & NIB1;
-  onehot = (a ^ b ^ c ^ d) & ~((a & b) | (c & d));
-  code = (b | d) | ((c | d) << 1);
-}
-
-// classification of the neighbour word N from the classification of S: N is S moved by one base (towards higher nibbles for a
-// forward read, lower for a reverse read) except for its one nibble that lies outside S, which is classified on its own
-__device__ __forceinline__ void nib_classify_neighbour(uint64_t N, bool reversed, uint64_t ohS, uint64_t cS, uint64_t &ohN, uint64_t &cN) {
-  const uint32_t n = reversed ? (uint32_t)(N >> 60) : ((uint32_t)N & 15u);
-  const uint64_t oh1 = (n != 0u && (n & (n - 1u)) == 0u) ? 1ull : 0ull;
-  const uint64_t c1 = (uint64_t)((((n >> 1) | (n >> 3)) & 1u) | ((((n >> 2) | (n >> 3)) & 1u) << 1));
-  ohN = reversed ? ((ohS >> 4) | (oh1 << 60)) : ((ohS << 4) | oh1);
-  cN = reversed ? ((cS >> 4) | (c1 << 60)) : ((cS << 4) | c1);
+// code nibbles (A 0, C 1, G 2, T 3, anything else has bit 3 set; ctx.hip k_recode_seq): acgt = flag where the base is A/C/G/T,
+// code = its 2-bit code
+__device__ __forceinline__ void nib_classify(uint64_t x, uint64_t &acgt, uint64_t &code) {
+  acgt = ~(x >> 3) & NIB1;
+  code = x & 0x3333333333333333ull;
 }
 
 // Bases k0 .. k0+15 of a record (S) and their neighbours in sequencing direction (N: k0-1 .. k0+14 forward, k0+1 .. k0+16
 // reverse) as nibbles; k0 is a multiple of 16.  Bases before the record's first read 0, bases past its end are garbage
-// (callers mask).  `sp` = the record's packed bases (BAM order: first base of a byte in the HIGH nibble).
+// (callers mask).  `sp` = the record's packed bases as code nibbles, first base of a byte in the LOW nibble (k_recode_seq).
 // seq_load issues the load of the 32-base window that starts at base k0 - 2 (k0 > 0) or 0; seq_unpack uses it.
 __device__ __forceinline__ void seq_load(const uint8_t *__restrict__ sp, int k0, uint64_t &v0, uint64_t &v1) {
   const int lead = k0 ? 2 : 0;
@@ -91,8 +81,6 @@ __device__ __forceinline__ void seq_load(const uint8_t *__restrict__ sp, int k0,
   __builtin_memcpy(&v1, sp + ((k0 - lead) >> 1) + 8, 8);
 }
 __device__ __forceinline__ void seq_unpack(uint64_t v0, uint64_t v1, int k0, bool reversed, uint64_t &S, uint64_t &N) {
-  v0 = nib_swap(v0);
-  v1 = nib_swap(v1);
   // S = window >> lead nibbles; N forward = window >> (lead - 1) (zero nibble shifted in at k0 = 0), N reverse = window >> (lead + 1)
   const uint64_t s_hi = (v0 >> 8) | (v1 << 56), p_hi = (v0 >> 4) | (v1 << 60), n_hi = (v0 >> 12) | (v1 << 52);  // lead = 2
   const uint64_t p_lo = v0 << 4, n_lo = (v0 >> 4) | (v1 << 60);                                                 // lead = 0
