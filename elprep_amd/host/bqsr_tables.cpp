@@ -321,12 +321,18 @@ int elp_bqsr_tables_build_lut(const elp_bqsr_tables *t, int quantize_levels, con
       };
       uint8_t no_cycle[17];  // the 17 values of a cycle without table entry (the same for every such cycle)
       for (int cx = 0; cx < 17; cx++) no_cycle[cx] = entry(false, 0, cx);
+      // the whole (cov, quality) row = that pattern repeated (filled by doubling), then the cycles that do have an entry
+      const size_t row_bytes = size_t(ncyc) * 17;
+      std::memcpy(lq, no_cycle, 17);
+      for (size_t have = 17; have < row_bytes;) {
+        const size_t n = std::min(have, row_bytes - have);
+        std::memcpy(lq + have, lq, n);
+        have += n;
+      }
       for (int cy = 0; cy < ncyc; cy++) {
-        uint8_t *le = lq + size_t(cy) * 17;
         if (t->c[2 * (qi * ncyc + cy)] > 0) {
+          uint8_t *le = lq + size_t(cy) * 17;
           for (int cx = 0; cx < 17; cx++) le[cx] = entry(true, cy, cx);
-        } else {
-          std::memcpy(le, no_cycle, 17);
         }
       }
     }
