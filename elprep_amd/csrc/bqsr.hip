@@ -790,6 +790,8 @@ struct QSlots { uint8_t slot[96]; };
 
 // ApplyBQSR (bqsr.go:936-1005): every base with quality >= 6 of a record with a known read group is replaced by the LUT value
 // of (read group, quality, cycle, context); cycle and context are taken on the full, unclipped read.
+constexpr uint32_t QOFF_KEEP = 0x7FFFFFFFu, QOFF_BAD = 0x80000000u, QOFF_TODO = 0x80000001u;
+
 template <bool CHECK_CYCLE, bool LDSLUT>
 struct ApplyBody {
   const uint64_t *__restrict__ seq_off;
@@ -800,7 +802,7 @@ struct ApplyBody {
   int max_cycle;
   uint64_t *s_desc;
   uint32_t *s_seq;
-  const uint8_t *qs;      // LDS: quality -> resident slot (LDSLUT)
+  const uint32_t *qoff;   // LDS: quality -> row offset in the compact LUT or a QOFF_* code (LDSLUT)
   const uint8_t *llut;    // LDS: compact LUT (LDSLUT)
   int lmax, n_slot;
   uint64_t seq_base;
@@ -830,38 +832,43 @@ struct ApplyBody {
     const uint32_t v = lut[act ? idx : 0u];
     return act ? v : q;
   }
-  // compact LUT in LDS: one LDS byte read per base; a quality without a resident slot is left for the fix-up loop
+  // compact LUT in LDS: one LDS byte read per base.  `off` = qoff[quality]: byte offset of the quality's row block inside a
+  // covariate's part of the compact LUT, or QOFF_KEEP (quality < 6: unchanged), QOFF_BAD (> 93), QOFF_TODO (no resident slot);
+  // the two rare cases are found by OR-ing the sixteen offsets (high bit) and handled by a rolled loop afterwards.
   template <int I>
-  __device__ __forceinline__ uint32_t base_lds(const Chunk &ch, int nb, uint32_t vw, uint32_t cw, uint32_t Lq, int st, int cyc0, int ci,
-                                               uint32_t sstride, uint32_t slot, uint32_t &todo) {
+  __device__ __forceinline__ uint32_t base_lds(const Chunk &ch, int nb, uint32_t vw, uint32_t cw, const uint8_t *bp, int st, int cyc0, int ci,
+                                               uint32_t off) {
     constexpr int sh = 4 * (I & 7);
     const uint32_t q = ch.get<I>();
-    bool act = I < nb && q >= 6u;
-    err |= (act && q >= (uint32_t)ELP_NQUAL) ? 8u : 0u;
-    act = act && q < (uint32_t)ELP_NQUAL;
+    bool act = I < nb && off < QOFF_KEEP;
     if (CHECK_CYCLE) {
       const int cyc = cyc0 + I * ci;
       const bool out = act && (cyc > max_cycle || cyc < -max_cycle);
       err |= out ? 16u : 0u;
       act = act && !out;
     }
-    todo |= (act && slot == 255u) ? (1u << I) : 0u;
-    act = act && slot != 255u;
-    const uint32_t cx = ((cw >> sh) & 15u) | ((((~vw) >> sh) & 1u) << 4);
-    const uint32_t idx = Lq + (uint32_t)(I * st) + slot * sstride + cx;
-    const uint32_t v = llut[act ? idx : 0u];
+    const uint32_t cx = ((cw >> sh) & 15u) | ((((~vw) >> sh) & 1u) << 4);  // 16 = no context
+    const uint8_t *ap = act ? bp + (I * st + (int)(off + cx)) : llut;
+    const uint32_t v = *ap;
     return act ? v : q;
   }
-  // bases whose quality has no resident slot: dense LUT, rolled loop (rare)
-  __device__ __forceinline__ void fixup(Chunk &ch, uint32_t todo, uint64_t CV, uint64_t CX, uint32_t Q, int st) {
+  // rare bases of a block (found by the high bit of the OR of the sixteen offsets; slots past nb may have raised it falsely):
+  // quality > 93 -> error; quality without a resident slot -> dense LUT.  Rolled loop over the original bytes.
+  __device__ __forceinline__ void fixup(Chunk &ch, const Chunk &orig, int nb, uint64_t CV, uint64_t CX, uint32_t Q, int st, int cyc0, int ci) {
     uint64_t lo = (uint64_t)ch.w0 | ((uint64_t)ch.w1 << 32), hi = (uint64_t)ch.w2 | ((uint64_t)ch.w3 << 32);
+    const uint64_t olo = (uint64_t)orig.w0 | ((uint64_t)orig.w1 << 32), ohi = (uint64_t)orig.w2 | ((uint64_t)orig.w3 << 32);
     const uint32_t qstride = (uint32_t)(2 * max_cycle + 1) * 17u;
 #pragma unroll 1
-    while (todo) {
-      const int i = __builtin_ctz(todo);
-      todo &= todo - 1;
+    for (int i = 0; i < nb; i++) {
       const int bs = 8 * (i & 7);
-      const uint32_t q = (uint32_t)(((i & 8) ? hi : lo) >> bs) & 0xFFu;
+      const uint32_t q = (uint32_t)(((i & 8) ? ohi : olo) >> bs) & 0xFFu;
+      const uint32_t off = qoff[q];
+      if (off < QOFF_BAD) continue;  // resident or unchanged: done by the straight-line code
+      if (off == QOFF_BAD) { err |= 8u; continue; }
+      if (CHECK_CYCLE) {
+        const int cyc = cyc0 + i * ci;
+        if (cyc > max_cycle || cyc < -max_cycle) { err |= 16u; continue; }
+      }
       const uint32_t cx = ((uint32_t)(CX >> (4 * i)) & 15u) | ((((uint32_t)(~CV >> (4 * i))) & 1u) << 4);
       const uint32_t idx = Q + (uint32_t)(i * st) + q * qstride + cx;
       const uint64_t v = (uint64_t)lut[idx];
@@ -915,22 +922,23 @@ struct ApplyBody {
     const uint32_t Q = (uint32_t)((int)cov * ELP_NQUAL * ncyc * 17 + (cyc0 + max_cycle) * 17);
     const uint32_t v0 = (uint32_t)CV, v1 = (uint32_t)(CV >> 32), c0 = (uint32_t)CX, c1 = (uint32_t)(CX >> 32);
     uint32_t b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, b10, b11, b12, b13, b14, b15;
-    uint32_t todo = 0;
+    const Chunk orig = ch;
+    uint32_t any = 0;
     if (LDSLUT) {
-      const uint32_t Lq = (uint32_t)(((int)cov * n_slot * (2 * lmax + 1) + (cyc0 + lmax)) * 17);
-      const uint32_t ss = (uint32_t)(2 * lmax + 1) * 17u;
-      const uint32_t s0 = qs[ch.get<0>()], s1 = qs[ch.get<1>()], s2 = qs[ch.get<2>()], s3 = qs[ch.get<3>()];
-      const uint32_t s4 = qs[ch.get<4>()], s5 = qs[ch.get<5>()], s6 = qs[ch.get<6>()], s7 = qs[ch.get<7>()];
-      const uint32_t s8 = qs[ch.get<8>()], s9 = qs[ch.get<9>()], s10 = qs[ch.get<10>()], s11 = qs[ch.get<11>()];
-      const uint32_t s12 = qs[ch.get<12>()], s13 = qs[ch.get<13>()], s14 = qs[ch.get<14>()], s15 = qs[ch.get<15>()];
-      b0 = base_lds<0>(ch, nb, v0, c0, Lq, st, cyc0, ci, ss, s0, todo); b1 = base_lds<1>(ch, nb, v0, c0, Lq, st, cyc0, ci, ss, s1, todo);
-      b2 = base_lds<2>(ch, nb, v0, c0, Lq, st, cyc0, ci, ss, s2, todo); b3 = base_lds<3>(ch, nb, v0, c0, Lq, st, cyc0, ci, ss, s3, todo);
-      b4 = base_lds<4>(ch, nb, v0, c0, Lq, st, cyc0, ci, ss, s4, todo); b5 = base_lds<5>(ch, nb, v0, c0, Lq, st, cyc0, ci, ss, s5, todo);
-      b6 = base_lds<6>(ch, nb, v0, c0, Lq, st, cyc0, ci, ss, s6, todo); b7 = base_lds<7>(ch, nb, v0, c0, Lq, st, cyc0, ci, ss, s7, todo);
-      b8 = base_lds<8>(ch, nb, v1, c1, Lq, st, cyc0, ci, ss, s8, todo); b9 = base_lds<9>(ch, nb, v1, c1, Lq, st, cyc0, ci, ss, s9, todo);
-      b10 = base_lds<10>(ch, nb, v1, c1, Lq, st, cyc0, ci, ss, s10, todo); b11 = base_lds<11>(ch, nb, v1, c1, Lq, st, cyc0, ci, ss, s11, todo);
-      b12 = base_lds<12>(ch, nb, v1, c1, Lq, st, cyc0, ci, ss, s12, todo); b13 = base_lds<13>(ch, nb, v1, c1, Lq, st, cyc0, ci, ss, s13, todo);
-      b14 = base_lds<14>(ch, nb, v1, c1, Lq, st, cyc0, ci, ss, s14, todo); b15 = base_lds<15>(ch, nb, v1, c1, Lq, st, cyc0, ci, ss, s15, todo);
+      const uint8_t *bp = llut + ((int)cov * n_slot * (2 * lmax + 1) + (cyc0 + lmax)) * 17;
+      const uint32_t o0 = qoff[ch.get<0>()], o1 = qoff[ch.get<1>()], o2 = qoff[ch.get<2>()], o3 = qoff[ch.get<3>()];
+      const uint32_t o4 = qoff[ch.get<4>()], o5 = qoff[ch.get<5>()], o6 = qoff[ch.get<6>()], o7 = qoff[ch.get<7>()];
+      const uint32_t o8 = qoff[ch.get<8>()], o9 = qoff[ch.get<9>()], o10 = qoff[ch.get<10>()], o11 = qoff[ch.get<11>()];
+      const uint32_t o12 = qoff[ch.get<12>()], o13 = qoff[ch.get<13>()], o14 = qoff[ch.get<14>()], o15 = qoff[ch.get<15>()];
+      any = (o0 | o1 | o2 | o3) | (o4 | o5 | o6 | o7) | (o8 | o9 | o10 | o11) | (o12 | o13 | o14 | o15);
+      b0 = base_lds<0>(ch, nb, v0, c0, bp, st, cyc0, ci, o0); b1 = base_lds<1>(ch, nb, v0, c0, bp, st, cyc0, ci, o1);
+      b2 = base_lds<2>(ch, nb, v0, c0, bp, st, cyc0, ci, o2); b3 = base_lds<3>(ch, nb, v0, c0, bp, st, cyc0, ci, o3);
+      b4 = base_lds<4>(ch, nb, v0, c0, bp, st, cyc0, ci, o4); b5 = base_lds<5>(ch, nb, v0, c0, bp, st, cyc0, ci, o5);
+      b6 = base_lds<6>(ch, nb, v0, c0, bp, st, cyc0, ci, o6); b7 = base_lds<7>(ch, nb, v0, c0, bp, st, cyc0, ci, o7);
+      b8 = base_lds<8>(ch, nb, v1, c1, bp, st, cyc0, ci, o8); b9 = base_lds<9>(ch, nb, v1, c1, bp, st, cyc0, ci, o9);
+      b10 = base_lds<10>(ch, nb, v1, c1, bp, st, cyc0, ci, o10); b11 = base_lds<11>(ch, nb, v1, c1, bp, st, cyc0, ci, o11);
+      b12 = base_lds<12>(ch, nb, v1, c1, bp, st, cyc0, ci, o12); b13 = base_lds<13>(ch, nb, v1, c1, bp, st, cyc0, ci, o13);
+      b14 = base_lds<14>(ch, nb, v1, c1, bp, st, cyc0, ci, o14); b15 = base_lds<15>(ch, nb, v1, c1, bp, st, cyc0, ci, o15);
     } else {
       const uint32_t qstride = (uint32_t)ncyc * 17u;
       b0 = base<0>(ch, nb, v0, c0, Q, st, cyc0, ci, qstride); b1 = base<1>(ch, nb, v0, c0, Q, st, cyc0, ci, qstride);
@@ -946,7 +954,7 @@ struct ApplyBody {
     ch.w1 = b4 | (b5 << 8) | (b6 << 16) | (b7 << 24);
     ch.w2 = b8 | (b9 << 8) | (b10 << 16) | (b11 << 24);
     ch.w3 = b12 | (b13 << 8) | (b14 << 16) | (b15 << 24);
-    if (LDSLUT && todo) fixup(ch, todo, CV, CX, Q, st);
+    if (LDSLUT && (any & 0x80000000u)) fixup(ch, orig, nb, CV, CX, Q, st, cyc0, ci);
     ch.store(qual + qpos, nb);
   }
   __device__ __forceinline__ void group_end(uint32_t, uint32_t) {}
@@ -958,10 +966,11 @@ __global__ __launch_bounds__(LDSLUT ? 1024 : FL_THREADS, LDSLUT ? 4 : 4) void k_
   __shared__ FlatLds L;
   __shared__ uint64_t s_desc[FL_RMAX];
   __shared__ uint32_t s_seq[FL_RMAX];
-  __shared__ uint8_t qs[256];
+  __shared__ uint32_t qoff[256];
   extern __shared__ __attribute__((aligned(16))) uint8_t llut[];
   if (LDSLUT) {
-    for (int q = threadIdx.x; q < 256; q += blockDim.x) qs[q] = (q >= 6 && q < ELP_NQUAL) ? slots.slot[q] : (uint8_t)255;
+    for (int q = threadIdx.x; q < 256; q += blockDim.x)
+      qoff[q] = q < 6 ? QOFF_KEEP : (q >= ELP_NQUAL ? QOFF_BAD : (slots.slot[q] == 255 ? QOFF_TODO : (uint32_t)slots.slot[q] * (uint32_t)((2 * A.lmax + 1) * 17)));
     const int nbytes = A.n_cov * A.n_slot * (2 * A.lmax + 1) * 17;
     const uint4 *src = reinterpret_cast<const uint4 *>(A.clut);  // padded to 16 bytes by the builder
     uint4 *dst = reinterpret_cast<uint4 *>(llut);
@@ -971,7 +980,7 @@ __global__ __launch_bounds__(LDSLUT ? 1024 : FL_THREADS, LDSLUT ? 4 : 4) void k_
   ApplyBody<CHECK_CYCLE, LDSLUT> B;
   B.seq_off = A.seq_off; B.qual = A.qual; B.seq4 = A.seq4; B.desc = reinterpret_cast<const uint64_t *>(A.desc); B.lut = A.lut;
   B.max_cycle = A.max_cycle; B.s_desc = s_desc; B.s_seq = s_seq;
-  B.qs = qs; B.llut = llut; B.lmax = A.lmax; B.n_slot = A.n_slot;
+  B.qoff = qoff; B.llut = llut; B.lmax = A.lmax; B.n_slot = A.n_slot;
   B.err = 0;
   flat_run(A.qual_off, A.n, A.qual_bytes, A.tile_first, L, B);
   uint32_t my_err = B.err;
@@ -1221,7 +1230,7 @@ int elp_bqsr_apply(elp_ctx *c, int max_cycle, const uint8_t *lut, const uint8_t 
       const int lmax = (int)std::max<uint32_t>(c->max_l_seq, 1);
       const bool chk = (int64_t)c->max_l_seq > (int64_t)max_cycle;
       const size_t per_slot = (size_t)c->n_cov * (size_t)(2 * lmax + 1) * 17;
-      const size_t lds_budget = 160 * 1024 - (sizeof(FlatLds) + (size_t)FL_RMAX * 12 + 256 + 512);
+      const size_t lds_budget = 160 * 1024 - (sizeof(FlatLds) + (size_t)FL_RMAX * 12 + 1024 + 512);
       const size_t cbytes = per_slot * quals.size();
       ApplyArgs A{n, c->qual_bytes, c->qual_off.p, c->seq_off.p, c->qual.p, c->seq4.p, desc, c->tile_first.p, dl, max_cycle, c->err_flag.p,
                   nullptr, c->n_cov, (int)quals.size(), lmax};
