@@ -250,6 +250,15 @@ def main():
         # achieved = algorithmic bytes of the stage the dominant kernel belongs to, per launch of that kernel
         achieved = (dom_bytes / max(launches_per_step, 1)) / (dom_launch_ms * 1e-3) / 1e9 if dom_launch_ms > 0 else 0.0
         kernel_total_ms = sum(stage_ms.values())
+        # HBM traffic of the dominant kernel from the committed PMC passes (bytes per read measured at the profile's size, scaled to
+        # this run's reads; per launch like `achieved`); null if the kernel was not profiled
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if dom in tj["bytes_per_read"]:
+                traffic = round(tj["bytes_per_read"][dom] * n_total / max(launches_per_step, 1))
+        except Exception:
+            traffic = None
         out = {
             "metric": "Mreads/s through sort+markdup+BQSR, 150bp PE",
             "value": round(value, 3),
@@ -266,7 +275,7 @@ def main():
             "config": {"workload": f"C3-style ({mode}): {n_total} reads on rank 0, {args.reads} requested per GPU, 150bp PE, genome {args.genome} (24 contigs hg38/12), sort+markdup+optical metrics+BQSR gather+finalize+apply",
                        "reads_per_gpu": n_total, "max_cycle": MAX_CYCLE, "parallelism": ("filter: one context" if world == 1 else f"sfm: contig groups over {world} GPUs, spread split on one rank, one all-reduce per step")},
             "roofline": {"bound": "hbm", "kernel": dom, "stage": dom_stage, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "path_frac": round((BYTES_FULL_PATH * n_total / (kernel_total_ms * 1e-3) / 1e9) / HBM_PEAK_GBS, 5) if kernel_total_ms else None},
             "stage_ms_per_step": {k: round(v, 3) for k, v in sorted(stage_ms.items())},
             "kernel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:12]},
