@@ -80,6 +80,7 @@ struct elp_ctx {
   elp::DVec<uint32_t> cigar;
   elp::DVec<uint64_t> stage_tmp;  // offsets of the batch being staged
   uint32_t max_qname_len = 0, max_l_seq = 0;
+  uint32_t max_pos = 0;  // largest staged POS (as uint32): width of the POS field of the coordinate-sort key
 
   // derived state
   bool adapted = false, sorted = false, marked = false;

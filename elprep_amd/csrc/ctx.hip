@@ -200,6 +200,7 @@ int elp_reset(elp_ctx *c) {
   std::lock_guard<std::mutex> g(c->stage_mu);
   c->n = c->qname_bytes = c->cigar_ops = c->seq_bytes = c->qual_bytes = 0;
   c->max_qname_len = c->max_l_seq = 0;
+  c->max_pos = 0;
   c->adapted = c->sorted = c->marked = false;
   c->have_qual_present = false;
   c->have_snapshot = false;
@@ -225,6 +226,7 @@ int elp_stage(elp_ctx *c, const elp_batch *b) {
     uint64_t ql = b->qname_off[i + 1] - b->qname_off[i];
     if (ql > c->max_qname_len) c->max_qname_len = (uint32_t)ql;
     if (b->l_seq[i] > c->max_l_seq) c->max_l_seq = b->l_seq[i];
+    if ((uint32_t)b->pos[i] > c->max_pos) c->max_pos = (uint32_t)b->pos[i];
     if (b->qual_off[i + 1] - b->qual_off[i] > 0x3FFFFFull || b->l_seq[i] > 0x3FFFFFu)  // FL_MAX_READ (flat.hpp)
       return set_error(c, ELP_ERR_UNSUPPORTED, "record %llu: more than 4194303 bases", (unsigned long long)i);
     if (b->rgid[i] != ELP_NIL16 && b->rgid[i] >= c->n_rg) return set_error(c, ELP_ERR_ARG, "record %llu: rgid %u not in header", (unsigned long long)i, b->rgid[i]);

@@ -23,15 +23,17 @@ constexpr int TIE_SMALL = 48;
 __global__ __launch_bounds__(256) void k_adapt_fixed(uint64_t n, const int32_t *__restrict__ pos, const int32_t *__restrict__ refid,
                                                      const uint16_t *__restrict__ flag, const uint64_t *__restrict__ cigar_off,
                                                      const uint32_t *__restrict__ cigar, int32_t *__restrict__ upos, int32_t *__restrict__ score,
-                                                     uint64_t *__restrict__ key) {
+                                                     uint64_t *__restrict__ key, uint32_t n_ref, int pos_bits) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint16_t f = flag[i];
   const int32_t p = pos[i];
   const int32_t r = refid[i];
   // CoordinateLess primary key: REFID ascending with negative last (:429-432), POS (:433-436), forward before reverse (:437-438)
-  const uint64_t ru = r < 0 ? 0x7FFFFFFFull : (uint64_t)(uint32_t)r;
-  key[i] = (ru << 33) | ((uint64_t)(uint32_t)p << 1) | ((f & F_REVERSED) ? 1ull : 0ull);
+  // The key is packed into as few bits as the data needs (unmapped = one code above the last contig; POS in pos_bits bits, the
+  // width of the largest staged POS), so that the LSD radix sort has as few live digit positions as possible.
+  const uint64_t ru = r < 0 ? (uint64_t)n_ref : (uint64_t)(uint32_t)r;
+  key[i] = (ru << (pos_bits + 1)) | ((uint64_t)(uint32_t)p << 1) | ((f & F_REVERSED) ? 1ull : 0ull);
   int32_t up = 0;
   if ((f & (F_UNMAPPED | F_SECONDARY | F_SUPPLEMENTARY)) == 0) {  // mark-duplicates.go:427,436
     const uint64_t c0 = cigar_off[i], c1 = cigar_off[i + 1];
@@ -220,10 +222,13 @@ int ensure_adapted(elp_ctx *c, bool check_quals) {
   ELP_TRY(ensure(c, c->key, n + 1));
   ELP_TRY(ensure(c, c->qbounds, n + 1));
   c->adapt_bad_qual = false;
+  int pos_bits = 1;
+  while (pos_bits < 32 && (c->max_pos >> pos_bits) != 0) pos_bits++;
   if (n) {
     if (!c->qual_bytes) ELP_HIP(c, hipMemsetAsync(c->qbounds.p, 0, n * sizeof(uint64_t), c->stream));  // no QUAL bytes at all: no tile, no kernel
     ELP_LAUNCH(c, "adapt_fixed", k_adapt_fixed, dim3(blocks_for(n, 256)), dim3(256), 0, n, (const int32_t *)c->pos.p, (const int32_t *)c->refid.p,
-               (const uint16_t *)c->flag.p, (const uint64_t *)c->cigar_off.p, (const uint32_t *)c->cigar.p, c->upos.p, c->score.p, c->key.p);
+               (const uint16_t *)c->flag.p, (const uint64_t *)c->cigar_off.p, (const uint32_t *)c->cigar.p, c->upos.p, c->score.p, c->key.p,
+               (uint32_t)c->n_ref, pos_bits);
     if (c->qual_bytes) {
       const uint64_t ntiles = (c->qual_bytes + FL_TILE - 1) / FL_TILE;
       const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * 4);
