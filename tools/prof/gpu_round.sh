@@ -9,6 +9,7 @@ tail -3 $OUT/pytest.log
 timeout 900 python bench.py --reads $BR > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
 cat $OUT/bench.json; tail -3 $OUT/bench.err
 if [ "$PR" != "0" ]; then
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o trace -- python $GRAFT_REPO_ROOT/tools/prof/run_path.py $PR 1 > $OUT/prof.log 2>&1; echo "prof rc=$?")
+  # the kernel trace is taken over the bench command itself (same reads, steps and warm-up), without the CPU baseline leg
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --reads $PR --no-cpu-baseline > $OUT/prof.log 2>&1; echo "prof rc=$?")
   find $OUT/prof -name "*kernel_stats*" | head; find $OUT/prof -name "*kernel_trace*" -size +20M -delete
 fi
