@@ -203,6 +203,14 @@ def test_long_reads_tile_spanning():
     _check_gather_apply(b, h, refs, sites, chunks=2)
 
 
+def test_many_contigs():
+    """More than 256 contigs: the count kernel reads contig pointers from HBM instead of its LDS table (hg38 with alts has 3366)."""
+    b, h, refs, sites = _random_case(41, 4000, quals=[2, 9, 22, 35], ref_len=tuple([700 + 13 * (k % 7) for k in range(300)]),
+                                     len_mix=((1, 20, 0.2), (21, 60, 0.3), (100, 170, 0.5)))
+    assert h.n_ref == 300
+    _check_gather_apply(b, h, refs, sites, chunks=2)
+
+
 def test_quality_hint_retry(monkeypatch):
     """With an empty sampling hint the count kernel must report the qualities it met and the host must retry: same tables."""
     b, h, refs, sites = _random_case(5, 3000, quals=[2, 6, 13, 27, 38, 64, 93])
