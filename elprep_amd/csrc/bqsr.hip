@@ -359,10 +359,13 @@ __device__ __forceinline__ int ref_load(const uint8_t *__restrict__ rp, int64_t 
   return valid ? (int)(jb - jw) : REF_NONE;  // -15 .. 1
 }
 __device__ __forceinline__ uint64_t ref_unpack(uint64_t v0, uint64_t v1, int sn) {
-  const int s = sn == REF_NONE ? 0 : sn;
-  uint64_t r = nib_ext(v0, v1, s);
-  if (s < 0) r |= REF_OTHER & ~(NIBF << (4 * -s));  // positions before the contig's first base: "other" (-s <= 15)
-  return sn == REF_NONE ? REF_OTHER : r;
+  if (sn == 0 || sn == 1) {  // the common case (reference index >= 0): two 32-bit funnel shifts
+    const uint32_t w0 = (uint32_t)v0, w1 = (uint32_t)(v0 >> 32), w2 = (uint32_t)v1, sh = 4u * (uint32_t)sn;
+    return (uint64_t)__builtin_amdgcn_alignbit(w1, w0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(w2, w1, sh) << 32);
+  }
+  if (sn == REF_NONE) return REF_OTHER;
+  // window starts at the contig's first base but the block starts before it (sn < 0): positions before the contig are "other"
+  return nib_ext(v0, v1, sn) | (REF_OTHER & ~(NIBF << (4 * -sn)));
 }
 __device__ __forceinline__ uint64_t ref_nibbles(const uint8_t *__restrict__ rp, int64_t rlen, int64_t jb) {
   uint64_t v0, v1;
@@ -596,7 +599,7 @@ struct CountBody {
         const uint32_t *cg = ((fl & BQ_CIG_SCRATCH) ? cig_scratch : cigar) + (uint32_t)D0;
         R = ref_nibbles_complex(cg, b1, (int64_t)D2, cbase, blo, bhi, rp, rlen, S);
       }
-      X = nib_nonzero(S ^ R);  // only read where F is set
+      X = nib_code_differs(S ^ R);  // only read where F is set
     }
     // cycle covariate (bqsr.go:376-387) of block bit b: cf + (cbase + b) * ci
     const int rof = (fl & BQ_LAST) ? -1 : 1;

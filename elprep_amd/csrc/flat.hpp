@@ -64,6 +64,8 @@ __device__ __forceinline__ uint64_t nib_ext(uint64_t v0, uint64_t v1, int sn) {
 }
 // flag where the nibble is non-zero
 __device__ __forceinline__ uint64_t nib_nonzero(uint64_t x) { return (x | (x >> 1) | (x >> 2) | (x >> 3)) & NIB1; }
+// same for XORs of code nibbles (values 0..3 and 8: bit 2 is never set)
+__device__ __forceinline__ uint64_t nib_code_differs(uint64_t x) { return (x | (x >> 1) | (x >> 3)) & NIB1; }
 // code nibbles (A 0, C 1, G 2, T 3, anything else has bit 3 set; ctx.hip k_recode_seq): acgt = flag where the base is A/C/G/T,
 // code = its 2-bit code
 __device__ __forceinline__ void nib_classify(uint64_t x, uint64_t &acgt, uint64_t &code) {
@@ -81,11 +83,17 @@ __device__ __forceinline__ void seq_load(const uint8_t *__restrict__ sp, int k0,
   __builtin_memcpy(&v1, sp + ((k0 - lead) >> 1) + 8, 8);
 }
 __device__ __forceinline__ void seq_unpack(uint64_t v0, uint64_t v1, int k0, bool reversed, uint64_t &S, uint64_t &N) {
-  // S = window >> lead nibbles; N forward = window >> (lead - 1) (zero nibble shifted in at k0 = 0), N reverse = window >> (lead + 1)
-  const uint64_t s_hi = (v0 >> 8) | (v1 << 56), p_hi = (v0 >> 4) | (v1 << 60), n_hi = (v0 >> 12) | (v1 << 52);  // lead = 2
-  const uint64_t p_lo = v0 << 4, n_lo = (v0 >> 4) | (v1 << 60);                                                 // lead = 0
-  S = k0 ? s_hi : v0;
-  N = reversed ? (k0 ? n_hi : n_lo) : (k0 ? p_hi : p_lo);
+  // 32-bit funnel shifts (v_alignbit_b32: ({hi, lo} >> sh) & 0xFFFFFFFF, sh in 0..31) over the window words with one zero word
+  // in front: S = window >> 4 lead bits; N forward = window >> 4 (lead - 1) (a zero nibble comes in at k0 = 0), N reverse =
+  // window >> 4 (lead + 1);  lead = 2 nibbles for k0 > 0, else 0
+  const uint32_t w0 = (uint32_t)v0, w1 = (uint32_t)(v0 >> 32), w2 = (uint32_t)v1;
+  const uint32_t ss = k0 ? 8u : 0u;
+  S = (uint64_t)__builtin_amdgcn_alignbit(w1, w0, ss) | ((uint64_t)__builtin_amdgcn_alignbit(w2, w1, ss) << 32);
+  // N: total right shift t = 32 + 4 (lead +- 1) over the words {0, w0, w1, w2}: t = 28 (k0 = 0, forward) uses {w0:0, w1:w0}
+  const bool lowcase = !k0 && !reversed;
+  const uint32_t ns = lowcase ? 28u : (k0 ? (reversed ? 12u : 4u) : 4u);  // k0 = 0 & reversed: >> 4
+  const uint32_t a0 = lowcase ? 0u : w0, a1 = lowcase ? w0 : w1, a2 = lowcase ? w1 : w2;
+  N = (uint64_t)__builtin_amdgcn_alignbit(a1, a0, ns) | ((uint64_t)__builtin_amdgcn_alignbit(a2, a1, ns) << 32);
 }
 
 // The lane's 16 loaded bytes (four scalar members on purpose: an array member keeps the enclosing body object in scratch memory)
