@@ -455,6 +455,8 @@ struct CountBody {
   // LDS
   const uint64_t *s_refp;  // [REF_LDS] packed-contig pointers and lengths (REFLDS: n_ref <= REF_LDS; else they are read from HBM)
   const int64_t *s_refl;
+  uint64_t *s_rp;          // [FL_RMAX] per read of the group: its contig's packed bases and length (resolved once per read at
+  int32_t *s_rl;           //           stage time, so that a block's loads depend on ONE LDS round trip after the read is known)
   uint4 *s_desc;
   uint32_t *s_seq;
   const uint16_t *qrow;
@@ -465,11 +467,27 @@ struct CountBody {
   uint32_t err;
   uint32_t reads_since_flush;
 
+  __device__ __forceinline__ void ref_of(int32_t refid, const uint8_t *__restrict__ &rp, int64_t &rlen) const {
+    if (REFLDS) { rp = (const uint8_t *)(const __attribute__((address_space(1))) uint8_t *)s_refp[refid]; rlen = s_refl[refid]; }
+    else { rp = ref_seq[refid]; rlen = ref_seq_len[refid]; }
+  }
   __device__ __forceinline__ void stage(uint32_t g0, uint32_t ng) {
     const uint4 *src = desc + 2 * (size_t)g0;
     for (uint32_t k = threadIdx.x; k < 2 * ng; k += blockDim.x) s_desc[k] = src[k];
     seq_base = seq_off[g0];
-    for (uint32_t k = threadIdx.x; k < ng; k += blockDim.x) s_seq[k] = (uint32_t)(seq_off[g0 + k] - seq_base);
+    for (uint32_t k = threadIdx.x; k < ng; k += blockDim.x) {
+      s_seq[k] = (uint32_t)(seq_off[g0 + k] - seq_base);
+      const uint4 dx = src[2 * k], dy = src[2 * k + 1];
+      const uint8_t *rp = nullptr;
+      int64_t rlen = 0;
+      if ((dy.w >> 8) & BQ_ELIGIBLE) ref_of((int32_t)dx.w, rp, rlen);
+      s_rp[k] = reinterpret_cast<uint64_t>(rp);
+      s_rl[k] = (int32_t)rlen;
+    }
+  }
+  __device__ __forceinline__ void ref_of_read(uint32_t rl, const uint8_t *__restrict__ &rp, int64_t &rlen) const {
+    rp = (const uint8_t *)(const __attribute__((address_space(1))) uint8_t *)s_rp[rl];
+    rlen = s_rl[rl];
   }
 
   // One base, branch-free: a base that is not counted adds to the lane's own trash cell behind the tables, so the sixteen
@@ -482,7 +500,7 @@ struct CountBody {
     bool act = ((fw >> sh) & 1u) && ro != QROW_SKIP;
     if (CHECK_CYCLE) {  // checkCycleCovariate, bqsr.go:364-369
       const int cyc = cyc0 + I * ci;
-      const bool out = act && ro < 0x8000u && (cyc > max_cycle || cyc < -max_cycle);
+      const bool out = act && ro < (uint32_t)(n_q * rs) && (cyc > max_cycle || cyc < -max_cycle);
       err |= out ? 16u : 0u;
       act = act && !out;
     }
@@ -505,10 +523,6 @@ struct CountBody {
     uint32_t rl, qlow;
     int k0, nb;
   };
-  __device__ __forceinline__ void ref_of(int32_t refid, const uint8_t *__restrict__ &rp, int64_t &rlen) const {
-    if (REFLDS) { rp = (const uint8_t *)(const __attribute__((address_space(1))) uint8_t *)s_refp[refid]; rlen = s_refl[refid]; }
-    else { rp = ref_seq[refid]; rlen = ref_seq_len[refid]; }
-  }
   // every global load of the block is issued here: QUAL, skip bits, SEQ window, reference window
   __device__ __forceinline__ bool prefetch(uint32_t rl, int k0, int nb, uint64_t qpos, Pre &p) {
     const uint4 dy = s_desc[2 * rl + 1];
@@ -524,7 +538,7 @@ struct CountBody {
     seq_load(seq4 + seq_base + s_seq[rl], k0, p.v0, p.v1);
     const uint8_t *__restrict__ rp;
     int64_t rlen;
-    ref_of((int32_t)dx.w, rp, rlen);
+    ref_of_read(rl, rp, rlen);
     const int32_t D0 = (int32_t)dx.x;
     p.rsn = ref_load(rp, rlen, ((fl & BQ_COMPLEX) || D0 == BQ_NOREF) ? (int64_t)0 : (int64_t)D0 + cbase, p.r0, p.r1);
     return true;
@@ -541,7 +555,7 @@ struct CountBody {
     int blo = -cbase, bhi = len - cbase;
     blo = blo > 0 ? blo : 0;
     bhi = bhi < nb ? bhi : nb;
-    const int32_t D0 = (int32_t)dx.x, D1 = (int32_t)dx.y, D2 = (int32_t)dx.z, refid = (int32_t)dx.w;
+    const int32_t D0 = (int32_t)dx.x, D1 = (int32_t)dx.y, D2 = (int32_t)dx.z;
     const int b1 = (int)(dy.x & 0xFFFFu), b2 = (int)(dy.x >> 16);
     const int left = (int)(dy.z & 0xFFFFu), right = (dy.z >> 16) == 0xFFFFu ? -1 : (int)(dy.z >> 16);
     const uint32_t cov = dy.w & 0xFFu;
@@ -578,7 +592,7 @@ struct CountBody {
         if (B1 < bhi) {
           const uint8_t *__restrict__ rp;
           int64_t rlen;
-          ref_of(refid, rp, rlen);
+          ref_of_read(rl, rp, rlen);
           const int lo = blo > B1 ? blo : B1, hi = bhi < B2 ? bhi : B2;
           if (lo < hi) {
             const uint64_t m = nib_fill(nib_range(lo, hi));
@@ -595,7 +609,7 @@ struct CountBody {
       } else {
         const uint8_t *__restrict__ rp;
         int64_t rlen;
-        ref_of(refid, rp, rlen);
+        ref_of_read(rl, rp, rlen);
         const uint32_t *cg = ((fl & BQ_CIG_SCRATCH) ? cig_scratch : cigar) + (uint32_t)D0;
         R = ref_nibbles_complex(cg, b1, (int64_t)D2, cbase, blo, bhi, rp, rlen, S);
       }
@@ -692,6 +706,8 @@ __global__ __launch_bounds__(FL_THREADS, 4) void k_bqsr_count(CountArgs A, QMap 
   __shared__ uint8_t slot_q[96];
   __shared__ uint64_t s_refp[REF_LDS];
   __shared__ int64_t s_refl[REF_LDS];
+  __shared__ uint64_t s_rp[FL_RMAX];
+  __shared__ int32_t s_rl[FL_RMAX];
   extern __shared__ __attribute__((aligned(16))) uint32_t tbl[];
   const int n_all = A.n_cov * (A.n_q + 2) * A.rs;
   if (REFLDS)
@@ -715,7 +731,7 @@ __global__ __launch_bounds__(FL_THREADS, 4) void k_bqsr_count(CountArgs A, QMap 
   B.cycle_tbl = A.cycle_tbl; B.ctx_tbl = A.ctx_tbl;
   B.n_cov = A.n_cov; B.n_q = A.n_q; B.lmax = A.lmax; B.cs = A.cs; B.rs = A.rs; B.max_cycle = A.max_cycle;
   B.s_desc = s_desc; B.s_seq = s_seq; B.qrow = qrow; B.slot_q = slot_q; B.tbl = tbl;
-  B.s_refp = s_refp; B.s_refl = s_refl;
+  B.s_refp = s_refp; B.s_refl = s_refl; B.s_rp = s_rp; B.s_rl = s_rl;
   B.trash_idx = (uint32_t)((n_all + 1) & ~1) + 2u * threadIdx.x;
   B.err = 0;
   B.reads_since_flush = 0;
@@ -1081,7 +1097,7 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
     const bool check_cycle = lmax > max_cycle;
     const int cs = ((((17 * 2 * lmax) >> 4) + 1) + 1) & ~1, rs = cs + 32;
     const size_t per_slot = (size_t)c->n_cov * (size_t)rs * 4;
-    const size_t static_lds = sizeof(FlatLds) + (size_t)FL_RMAX * (sizeof(BqDesc) + 4) + 512 + 96 + 64 + 8 + (size_t)FL_THREADS * 8 + (size_t)REF_LDS * 16;
+    const size_t static_lds = sizeof(FlatLds) + (size_t)FL_RMAX * (sizeof(BqDesc) + 4) + 512 + 96 + 64 + 8 + (size_t)FL_THREADS * 8 + (size_t)REF_LDS * 16 + (size_t)FL_RMAX * 12;
     const size_t lds_cu = 160 * 1024;
     const uint64_t ntiles = (c->qual_bytes + FL_TILE - 1) / FL_TILE;
     for (int attempt = 0;; attempt++) {

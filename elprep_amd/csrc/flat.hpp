@@ -159,12 +159,33 @@ __device__ __forceinline__ void flat_run(const uint64_t *__restrict__ qual_off, 
       const float inv_avg = nslots ? (float)ng / (float)nslots : 0.f;
       // locate slot s and issue its loads
       auto fetch = [&](uint32_t s, typename Body::Pre &pre) __attribute__((always_inline)) -> bool {
-        // read owning slot s: guess from the mean, then walk (exact for uniform read lengths)
+        // read owning slot s: guess g from the mean; the four offsets around g are read at once (one LDS latency) and decide
+        // among g-1, g, g+1 — always enough for uniform read lengths; otherwise walk
         int k = (int)((float)s * inv_avg);
-        k = k >= (int)ng ? (int)ng - 1 : k;
-        while (((L.off[k] + 15u * (uint32_t)k) >> 4) > s) k--;
-        while (((L.off[k + 1] + 15u * (uint32_t)(k + 1)) >> 4) <= s) k++;
-        const uint32_t o = L.off[k], len = L.off[k + 1] - o;
+        k = k >= (int)ng - 1 ? (int)ng - 2 : k;
+        k = k < 1 ? 1 : k;
+        bool found = false;
+        uint32_t o = 0, nxt = 0;
+        if (ng >= 3) {
+          const uint32_t a0 = L.off[k - 1], a1 = L.off[k], a2 = L.off[k + 1], a3 = L.off[k + 2];
+          const uint32_t v0 = (a0 + 15u * (uint32_t)(k - 1)) >> 4, v1 = (a1 + 15u * (uint32_t)k) >> 4, v2 = (a2 + 15u * (uint32_t)(k + 1)) >> 4,
+                         v3 = (a3 + 15u * (uint32_t)(k + 2)) >> 4;
+          if (s >= v0 && s < v3) {
+            found = true;
+            const bool hi = s >= v2, mid = s >= v1;
+            o = hi ? a2 : (mid ? a1 : a0);
+            nxt = hi ? a3 : (mid ? a2 : a1);
+            k = hi ? k + 1 : (mid ? k : k - 1);
+          }
+        }
+        if (!found) {
+          k = k >= (int)ng ? (int)ng - 1 : k;
+          while (((L.off[k] + 15u * (uint32_t)k) >> 4) > s) k--;
+          while (((L.off[k + 1] + 15u * (uint32_t)(k + 1)) >> 4) <= s) k++;
+          o = L.off[k];
+          nxt = L.off[k + 1];
+        }
+        const uint32_t len = nxt - o;
         const uint32_t k0 = (s - ((o + 15u * (uint32_t)k) >> 4)) << 4;
         if (k0 >= len) return false;  // the (at most one) empty slot behind a read
         const uint32_t nb = len - k0 < 16u ? len - k0 : 16u;
