@@ -159,12 +159,19 @@ def main():
         owner = sfm.assign_splits(weights, world)
         mine = [g for g in range(1, G + 1) if owner[g] == rank]
         mylen = sum(glen[g - 1] for g in mine)
+        # per-GPU work is fixed (weak scaling): every rank ends up with about `--reads` records.  The owners of the spread and of the
+        # unmapped split receive records from everybody (fractions measured on a small sample), so they generate fewer of their own.
+        sample = synth.generate(cfg, 0, 20000)
+        sg, ssp = sfm.split_records(sample, gof)
+        f_spread, f_unmapped = float(ssp.mean()), float((sg == 0).mean())
+        extra = (f_spread * world if owner[G + 1] == rank else 0.0) + (f_unmapped * world if owner[0] == rank else 0.0) - f_unmapped
+        my_pairs = max(int(pairs_per_rank * (1.0 - extra)), pairs_per_rank // 4)
         jobs = []
-        for g in mine:  # per-GPU work is fixed (weak scaling): this rank's pairs are spread over its groups by length
+        for g in mine:  # this rank's pairs are spread over its groups by length
             c = synth.config(args.genome)
             c.seed = cfg.seed + 7919 * g
             c.home_lo, c.home_hi = ranges[g - 1]
-            npairs = int(pairs_per_rank * glen[g - 1] / mylen)
+            npairs = int(my_pairs * glen[g - 1] / max(mylen, 1.0))
             jobs += [(c, lo, min(lo + chunk, npairs)) for lo in range(0, npairs, chunk)]
         rounds = torch.tensor([len(jobs)], dtype=torch.int64, device=cdev)
         dist.all_reduce(rounds, op=dist.ReduceOp.MAX)  # every rank takes part in every routing round
