@@ -196,6 +196,27 @@ def route(b: Batch, group_of_ref: np.ndarray, n_groups: int, owner: np.ndarray, 
     return RankSplits(Batch.concat(lp) if lp else empty_batch(), Batch.concat(sp) if sp else empty_batch())
 
 
+# ------------------------------------------------------------------------------------------------ output order
+def merge_order(group_refid: np.ndarray, group_pos: np.ndarray, spread_refid: np.ndarray, spread_pos: np.ndarray) -> np.ndarray:
+    """MergeSortedFilesSplitPerChromosome (sam/split-merge.go:410-576): the group splits, coordinate-sorted and concatenated in
+    group order (= @SQ order, so the concatenation is sorted by (refid, POS)), are streamed out and every read of the
+    coordinate-sorted spread split is inserted in front of the first group read that is strictly greater by (refid, POS) — i.e.
+    behind all group reads of the same position; spread reads left over follow, then the unmapped split (not part of this
+    function).  Returns for every output slot a code: i >= 0 = the i-th group read, -(j + 1) = the j-th spread read."""
+    ng, ns = int(group_refid.shape[0]), int(spread_refid.shape[0])
+    kg = (group_refid.astype(np.int64) << 32) | group_pos.astype(np.int64)
+    ks = (spread_refid.astype(np.int64) << 32) | spread_pos.astype(np.int64)
+    # spread read j goes behind every group read with key <= its key: number of group reads in front of it
+    before = np.searchsorted(kg, ks, side="right")
+    out = np.empty(ng + ns, dtype=np.int64)
+    slot_s = before + np.arange(ns, dtype=np.int64)          # spread reads keep their own order
+    is_spread = np.zeros(ng + ns, dtype=bool)
+    is_spread[slot_s] = True
+    out[slot_s] = -(np.arange(ns, dtype=np.int64) + 1)
+    out[~is_spread] = np.arange(ng, dtype=np.int64)
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ per-rank driver
 class SfmRank:
     """The splits of one rank on one GPU: context 0 = its group splits, context 1 = the spread split (if owned)."""

@@ -102,3 +102,43 @@ def test_two_ranks_route_and_allreduce_over_gloo(tmp_path):
     assert total.sum() > 0
     for r in range(world):
         assert np.array_equal(res[r]["reduced"], total)
+
+
+def _merge_reference(group, spread):
+    """literal transliteration of the merge loop of sam/split-merge.go:519-549 on (refid, pos) pairs (refid >= 0 everywhere)"""
+    def less(a, b):  # coordinateLess :417-434
+        if a[0] < b[0]:
+            return a[0] >= 0
+        if b[0] < a[0]:
+            return b[0] < 0
+        return a[1] < b[1]
+    out, sp, j = [], list(spread), 0
+    # the reference processes blocks per contig; inserting inside a block or across blocks is the same scan
+    alns = [("g", i) + tuple(k) for i, k in enumerate(group)]
+    i = 0
+    cur = sp[j] if j < len(sp) else None
+    res = []
+    for tag, gi, r, p in alns:
+        while cur is not None and less(cur, (r, p)):
+            res.append(-(j + 1))
+            j += 1
+            cur = sp[j] if j < len(sp) else None
+        res.append(gi)
+    while cur is not None:
+        res.append(-(j + 1))
+        j += 1
+        cur = sp[j] if j < len(sp) else None
+    return np.asarray(res, dtype=np.int64)
+
+
+def test_merge_order_matches_the_reference_loop():
+    rng = np.random.default_rng(3)
+    for trial in range(50):
+        ng, ns = int(rng.integers(0, 60)), int(rng.integers(0, 25))
+        g = np.stack([rng.integers(0, 4, ng), rng.integers(1, 12, ng)], axis=1)
+        sp = np.stack([rng.integers(0, 4, ns), rng.integers(1, 12, ns)], axis=1)
+        g = g[np.lexsort((g[:, 1], g[:, 0]))] if ng else g
+        sp = sp[np.lexsort((sp[:, 1], sp[:, 0]))] if ns else sp
+        got = sfm.merge_order(g[:, 0], g[:, 1], sp[:, 0], sp[:, 1])
+        want = _merge_reference([tuple(x) for x in g], [tuple(x) for x in sp])
+        assert np.array_equal(got, want), trial
