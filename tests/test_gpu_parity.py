@@ -171,3 +171,60 @@ def test_full_size_properties():
     assert np.array_equal(qt[..., 0], ct[..., 0].sum(axis=2)) and np.array_equal(qt[..., 1], ct[..., 1].sum(axis=2))
     assert (xt[..., 0].sum(axis=2) <= qt[..., 0]).all()
     e.close()
+
+
+def test_c3_scale_properties():
+    """Size-independent properties on the bench workload itself (genome c3, 24 contigs) at 12 M reads — far beyond what the oracle
+    finishes in seconds: permutation validity and sortedness of sampled neighbours under CoordinateLess, idempotence of duplicate
+    marking, duplicate-count plausibility, table identities (every counted base is in the quality table and in exactly one cycle
+    cell), apply touches only qualities >= 6 and is a function of the input (two contexts give the same bytes)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from tools import synth
+    cfg = synth.config("c3")
+    h = cfg.header()
+    with ThreadPoolExecutor(8) as pool:
+        parts = list(pool.map(lambda lo: synth.generate(cfg, lo, lo + 500_000), range(0, 6_000_000, 500_000)))
+    engines = [Engine(h), Engine(h)]
+    for e in engines:
+        for p in parts:
+            e.stage(p)
+    e = engines[0]
+    n = e.n
+    assert n > 12_000_000
+    perm = e.sort_coordinate()
+    seen = np.zeros(n, dtype=bool)
+    seen[perm] = True
+    assert seen.all()
+    b = Batch.concat(parts)
+    rng = np.random.default_rng(1)
+    for k in rng.integers(0, n - 1, 3000):
+        assert not orc.coordinate_less(b, int(perm[k + 1]), int(perm[k]))
+    f1 = e.mark_duplicates(True)
+    f2 = e.mark_duplicates(True)
+    assert np.array_equal(f1, f2)
+    dup_frac = ((f1 & 0x400) != 0).mean()
+    assert 0.05 < dup_frac < 0.2  # the generator makes 10 % of the pairs copies of an earlier pair
+    assert (((f1 ^ b.flag) & ~np.uint16(0x400)) == 0).all()  # only the duplicate bit ever changes
+    ctr = e.dup_metrics(100)
+    assert ctr[:, 6].sum() > 0 and ctr[:, 5].sum() >= ctr[:, 6].sum()
+    refs_sites = [(r, synth.reference(cfg, r), orc.flatten(orc.sort_by_start(synth.known_sites_raw(cfg, r)))) for r in range(h.n_ref)]
+    for eng in engines:
+        for r, ref, st in refs_sites:
+            eng.set_reference(r, ref)
+            eng.set_known_sites(r, st)
+    qt, ct, xt = e.recalibrate(500)
+    assert qt[..., 0].sum() > 1_000_000_000
+    assert np.array_equal(qt[..., 0], ct[..., 0].sum(axis=2)) and np.array_equal(qt[..., 1], ct[..., 1].sum(axis=2))
+    assert (xt[..., 0].sum(axis=2) <= qt[..., 0]).all() and (qt[..., 1] <= qt[..., 0]).all()
+    assert qt[:, :6].sum() == 0 and ct[:, :, 500].sum() == 0  # no quality < 6, no cycle 0
+    tb = BqsrTables(qt, ct, xt, 500).finalize()
+    lut, present = tb.build_lut(0)
+    q1 = e.apply_bqsr(lut, present, 500)
+    engines[1].mark_duplicates(True)  # flags do not influence apply; same staged input
+    q2 = engines[1].apply_bqsr(lut, present, 500)
+    assert np.array_equal(q1, q2)
+    low = b.qual < 6
+    assert np.array_equal(q1[low], b.qual[low])
+    assert (q1[~low] >= 1).all() and (q1 != b.qual).mean() > 0.3
+    for eng in engines:
+        eng.close()
