@@ -143,16 +143,26 @@ __device__ inline Member make_member(const MxCols &m, uint32_t read, uint32_t *e
   return Member{tl.t, tl.x, tl.y, ((uint32_t)m.rgid[read] << 1) | ((m.flag[read] & F_REVERSED) ? 1u : 0u)};
 }
 
-__global__ __launch_bounds__(256) void k_opt_fill(MxCols m, const uint32_t *__restrict__ goff, uint32_t *gfill, Member *__restrict__ members,
-                                                  uint32_t *err) {
+// Members of the duplicate sets are laid out group by group (goff); this pass (one thread per record, most exit at once) only
+// decides the slot of each member and notes which read is listed there; the origin's slot also gets {set size, group id}.
+__global__ __launch_bounds__(256) void k_opt_slots(MxCols m, const uint32_t *__restrict__ goff, uint32_t *gfill, uint32_t *__restrict__ mread,
+                                                   uint2 *__restrict__ ginfo) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m.n) return;
   const uint32_t rep = m.prep[i];
   if (rep == EMPTY) return;
   const bool is_origin = m.pwinner[rep] == (uint32_t)i;
-  if (is_origin && goff[rep + 1] == goff[rep]) return;  // group without duplicates: count is 0
-  const uint32_t slot = goff[rep] + (is_origin ? 0u : 1u + atomicAdd(&gfill[rep], 1u));
-  members[slot] = make_member(m, listed_read(m, (uint32_t)i), err);
+  const uint32_t g0 = goff[rep], g1 = goff[rep + 1];
+  if (is_origin && g1 == g0) return;  // group without duplicates: count is 0
+  const uint32_t slot = g0 + (is_origin ? 0u : 1u + atomicAdd(&gfill[rep], 1u));
+  mread[slot] = listed_read(m, (uint32_t)i);
+  if (is_origin) ginfo[slot] = make_uint2(g1 - g0, rep);
+}
+// dense pass over the member slots: tile / x / y from the QNAME (every lane busy, unlike a pass over all records)
+__global__ __launch_bounds__(256) void k_opt_fill(MxCols m, uint32_t total, const uint32_t *__restrict__ mread, Member *__restrict__ members, uint32_t *err) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= total) return;
+  members[s] = make_member(m, mread[s], err);
 }
 
 __device__ inline uint32_t uf_find(uint32_t *p, uint32_t x) {
@@ -161,43 +171,65 @@ __device__ inline uint32_t uf_find(uint32_t *p, uint32_t x) {
   while (p[x] != r) { uint32_t nx = p[x]; p[x] = r; x = nx; }
   return r;
 }
+__device__ __forceinline__ bool optical_close(const Member &a, const Member &b, long long dist) {  // isOpticalDuplicate + same RG / strand list / tile
+  if (a.t == -1 || b.rg_rev != a.rg_rev || b.t != a.t) return false;
+  long long dx = a.x - b.x, dy = a.y - b.y;
+  if (dx < 0) dx = -dx;
+  if (dy < 0) dy = -dy;
+  return dx <= dist && dy <= dist;
+}
 
-// one thread per group with duplicates
-__global__ __launch_bounds__(128) void k_opt_eval(MxCols m, const uint32_t *__restrict__ goff, const Member *__restrict__ members,
+// one thread per member slot; the origin's slot evaluates its set: optical count = n - #components under the closeness relation
+// (sets of two and three members, the bulk, are evaluated in registers; larger ones with a union-find in `parent`)
+__global__ __launch_bounds__(128) void k_opt_eval(MxCols m, uint32_t total, const uint2 *__restrict__ ginfo, const Member *__restrict__ members,
                                                   uint32_t *__restrict__ parent, long long dist, unsigned long long *__restrict__ ctr,
                                                   uint32_t *err) {
-  uint64_t rep = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (rep >= m.n) return;
-  const uint32_t b = goff[rep], e = goff[rep + 1];
-  const uint32_t cnt = e - b;
-  if (cnt < 2) return;
-  if (cnt > 300000u) { atomicOr(&err[2], 2u); return; }
+  // per-library optical counts are collected in LDS first: the global counters are a handful of addresses, and a global atomic
+  // on one address serialises at ~12 ns
+  extern __shared__ unsigned int lds_opt[];  // [n_lib + 1]
+  for (int k = threadIdx.x; k <= m.n_lib; k += blockDim.x) lds_opt[k] = 0;
+  __syncthreads();
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint2 gi = b < total ? ginfo[b] : make_uint2(0u, 0u);
+  const uint32_t cnt = gi.x;
+  uint32_t optical = 0;
+  if (cnt > 300000u) {
+    atomicOr(&err[2], 2u);
+  } else if (cnt >= 2) {
   const Member *g = members + b;
-  uint32_t *p = parent + b;
-  for (uint32_t k = 0; k < cnt; k++) p[k] = k;
-  uint32_t comps = cnt;
-  for (uint32_t a = 0; a < cnt; a++) {
-    const Member ma = g[a];
-    if (ma.t == -1) continue;
-    for (uint32_t c2 = a + 1; c2 < cnt; c2++) {
-      const Member mb = g[c2];
-      if (mb.rg_rev != ma.rg_rev || mb.t != ma.t) continue;  // same RG, same strand list, same tile
-      long long dx = ma.x - mb.x, dy = ma.y - mb.y;
-      if (dx < 0) dx = -dx;
-      if (dy < 0) dy = -dy;
-      if (dx <= dist && dy <= dist) {
-        const uint32_t ra = uf_find(p, a), rb = uf_find(p, c2);
-        if (ra != rb) { p[rb] = ra; comps--; }
+  if (cnt == 2) {
+    optical = optical_close(g[0], g[1], dist) ? 1u : 0u;
+  } else if (cnt == 3) {
+    const Member m0 = g[0], m1 = g[1], m2 = g[2];
+    const uint32_t e01 = optical_close(m0, m1, dist), e02 = optical_close(m0, m2, dist), e12 = optical_close(m1, m2, dist);
+    const uint32_t edges = e01 + e02 + e12;
+    optical = edges >= 2 ? 2u : edges;  // components = 3 - min(edges, 2)
+  } else {
+    uint32_t *p = parent + b;
+    for (uint32_t k = 0; k < cnt; k++) p[k] = k;
+    uint32_t comps = cnt;
+    for (uint32_t a = 0; a < cnt; a++) {
+      const Member ma = g[a];
+      if (ma.t == -1) continue;
+      for (uint32_t c2 = a + 1; c2 < cnt; c2++) {
+        if (optical_close(ma, g[c2], dist)) {
+          const uint32_t ra = uf_find(p, a), rb = uf_find(p, c2);
+          if (ra != rb) { p[rb] = ra; comps--; }
+        }
       }
     }
+    optical = cnt - comps;  // sum over both strand lists of (n - components): lists never connect (rg_rev differs)
   }
-  const uint32_t optical = cnt - comps;  // sum over both strand lists of (n - components): lists never connect (rg_rev differs)
+  }
   if (optical) {
-    const uint32_t owner = m.pwinner[rep];
+    const uint32_t owner = m.pwinner[gi.y];
     uint32_t a1, a2;
     order_ends(m, owner, m.mate[owner], a1, a2);
-    atomicAdd(&ctr[lib_row(m, a1) * ELP_NCTR + 6], (unsigned long long)optical);  // origin.aln1.LIBID() :381
+    atomicAdd(&lds_opt[lib_row(m, a1)], optical);  // origin.aln1.LIBID() :381
   }
+  __syncthreads();
+  for (int k = threadIdx.x; k <= m.n_lib; k += blockDim.x)
+    if (lds_opt[k]) atomicAdd(&ctr[k * ELP_NCTR + 6], (unsigned long long)lds_opt[k]);
 }
 
 static int metrics_impl(elp_ctx *c, int dist, int64_t *counters_host) {
@@ -223,11 +255,16 @@ static int metrics_impl(elp_ctx *c, int dist, int64_t *counters_host) {
     ELP_TRY(exclusive_scan_u32(c, gsize, goff, n + 1, &total));  // goff[n] = total
     if (total) {
       Member *members;
-      uint32_t *parent;
+      uint32_t *parent, *mread;
+      uint2 *ginfo;
       ELP_TRY(scratch(c, 2, (size_t)total + 4, &members));
       ELP_TRY(scratch(c, 3, (size_t)total + 4, &parent));
-      ELP_LAUNCH(c, "mx_opt_fill", k_opt_fill, dim3(grid), dim3(256), 0, m, (const uint32_t *)goff, gfill, members, c->err_flag.p);
-      ELP_LAUNCH(c, "mx_opt_eval", k_opt_eval, dim3(blocks_for(n, 128)), dim3(128), 0, m, (const uint32_t *)goff, (const Member *)members, parent,
+      ELP_TRY(scratch(c, 4, (size_t)total + 4, &mread));
+      ELP_TRY(scratch(c, 5, (size_t)total + 4, &ginfo));
+      ELP_HIP(c, hipMemsetAsync(ginfo, 0, (size_t)total * sizeof(uint2), st));
+      ELP_LAUNCH(c, "mx_opt_slots", k_opt_slots, dim3(grid), dim3(256), 0, m, (const uint32_t *)goff, gfill, mread, ginfo);
+      ELP_LAUNCH(c, "mx_opt_fill", k_opt_fill, dim3(blocks_for(total, 256)), dim3(256), 0, m, total, (const uint32_t *)mread, members, c->err_flag.p);
+      ELP_LAUNCH(c, "mx_opt_eval", k_opt_eval, dim3(blocks_for(total, 128)), dim3(128), (c->n_lib + 1) * sizeof(unsigned int), m, total, (const uint2 *)ginfo, (const Member *)members, parent,
                  (long long)dist, ctr, c->err_flag.p);
     }
   }
