@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/elprep_host.h"
@@ -118,6 +119,19 @@ inline uint8_t empirical(long long obs, long long mism, double prior) {  // bqsr
   return q < 93 ? q : 93;
 }
 
+// rows are independent: a handful of threads (the results do not depend on the split)
+template <class F>
+void parallel_rows(size_t n, F f) {
+  unsigned hw = std::thread::hardware_concurrency();
+  size_t nt = hw ? std::min<size_t>(hw, 8) : 1;
+  if (nt > n) nt = n ? n : 1;
+  if (nt <= 1) { for (size_t i = 0; i < n; i++) f(i); return; }
+  std::vector<std::thread> th;
+  for (size_t k = 0; k < nt; k++)
+    th.emplace_back([=]() { for (size_t i = k; i < n; i += nt) f(i); });
+  for (auto &x : th) x.join();
+}
+
 struct Interval { int next; double rate; long long nobs, leaf, nerr; };
 inline double err_rate(long long nobs, long long nerr) { return nobs == 0 ? 0.0 : double(nerr + 1) / double(nobs + 1); }
 
@@ -165,8 +179,10 @@ int elp_bqsr_tables_finalize(elp_bqsr_tables *t) {
   t->qe.assign(nq, 255); t->ce.assign(nq * t->ncyc, 255); t->xe.assign(nq * NX, 255);
   for (size_t i = 0; i < nq; i++)
     if (t->q[2 * i] > 0) t->qe[i] = empirical(t->q[2 * i], t->q[2 * i + 1], double(i % NQ));
-  for (size_t i = 0; i < nq * t->ncyc; i++)
-    if (t->c[2 * i] > 0) t->ce[i] = empirical(t->c[2 * i], t->c[2 * i + 1], double((i / t->ncyc) % NQ));
+  parallel_rows(nq, [&](size_t row) {  // one (covariate, quality) row of cycle entries per task
+    for (size_t i = row * t->ncyc; i < (row + 1) * t->ncyc; i++)
+      if (t->c[2 * i] > 0) t->ce[i] = empirical(t->c[2 * i], t->c[2 * i + 1], double(row % NQ));
+  });
   for (size_t i = 0; i < nq * NX; i++)
     if (t->x[2 * i] > 0) t->xe[i] = empirical(t->x[2 * i], t->x[2 * i + 1], double((i / NX) % NQ));
   t->rep.assign(t->n_cov, 0.0); t->cemp.assign(t->n_cov, 0); t->present.assign(t->n_cov, 0);
@@ -285,14 +301,20 @@ int elp_bqsr_tables_build_lut(const elp_bqsr_tables *t, int quantize_levels, con
   elp_bqsr_tables_quantize(t, quantize_levels, counts, quantized);
   if (n_sqq > 0) static_quantized(sqq, n_sqq, stat);
   const int ncyc = t->ncyc;
-  std::vector<double> dcyc(ncyc), dctx(17);
+  std::vector<double> eps(t->n_cov, 0.0), dglob(t->n_cov, 0.0);
   for (int cv = 0; cv < t->n_cov; cv++) {
     cov_present[cv] = t->present[cv];
-    uint8_t *lc = lut + size_t(cv) * NQ * ncyc * 17;
-    if (!t->present[cv]) { std::memset(lc, 0, size_t(NQ) * ncyc * 17); continue; }
-    const double epsilon = t->rep[cv];  // globalQualityScorePrior = -1 (:959-964)
-    const double d_global = double(empirical(t->cobs[cv], t->cmism[cv], epsilon)) - epsilon;
-    for (int ql = 0; ql < NQ; ql++) {
+    if (!t->present[cv]) { std::memset(lut + size_t(cv) * NQ * ncyc * 17, 0, size_t(NQ) * ncyc * 17); continue; }
+    eps[cv] = t->rep[cv];  // globalQualityScorePrior = -1 (:959-964)
+    dglob[cv] = double(empirical(t->cobs[cv], t->cmism[cv], eps[cv])) - eps[cv];
+  }
+  {
+    parallel_rows(size_t(t->n_cov) * NQ, [&](size_t row) {  // one (covariate, quality) row of the LUT per task
+      const int cv = int(row / NQ), ql = int(row % NQ);
+      if (!t->present[cv]) return;
+      uint8_t *lc = lut + size_t(cv) * NQ * ncyc * 17;
+      const double epsilon = eps[cv], d_global = dglob[cv];
+      std::vector<double> dcyc(ncyc), dctx(17);
       const size_t qi = t->qi(cv, ql);
       double d_reported = 0;
       if (t->q[2 * qi] > 0) d_reported = double(empirical(t->q[2 * qi], t->q[2 * qi + 1], d_global + epsilon)) - d_global - epsilon;
@@ -335,7 +357,7 @@ int elp_bqsr_tables_build_lut(const elp_bqsr_tables *t, int quantize_levels, con
           for (int cx = 0; cx < 17; cx++) le[cx] = entry(true, cy, cx);
         }
       }
-    }
+    });
   }
   return 0;
 }
