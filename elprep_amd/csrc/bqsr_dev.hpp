@@ -9,7 +9,7 @@
 // Float finalisation (FinalizeBQSRTables, the hierarchical Bayesian estimate) is host work; the device consumes its result
 // as a dense byte LUT.
 //
-// Per-base covariates are local functions of the read:
+// Per-base covariates are local functions of the read (evaluated block-wise in bqsr.hip / flat.hpp):
 //   cycle(k)   = cycleFactor + k * increment                                   (bqsr.go:376-387)
 //   context(k) = 2-mer key of (previous, current) base in sequencing direction, -1 at the first sequenced base, next to a
 //                non-ACGT base, or inside the low-quality tails (quality <= 2 from either end)   (bqsr.go:87-146, 312-362)
@@ -296,64 +296,23 @@ __device__ inline void hard_clip_soft_clipped(RAln &a) {
   if (cut_left >= 0) hard_clip(a, 0, cut_left);
 }
 
-// ------------------------------------------------------------------ bases
-__device__ __forceinline__ uint32_t nibble_at(const uint8_t *__restrict__ s4, int k) {
-  const uint32_t b = s4[k >> 1];
-  return (k & 1) ? (b & 0xF) : (b >> 4);
-}
-// simpleBaseToBaseIndex on Sequence.Base(): A0 C1 G2 T3, everything else -1 (bqsr.go:55-62; '=' is not '*')
-__device__ __forceinline__ int base_index_of_nibble(uint32_t nb) { return nb == 1 ? 0 : nb == 2 ? 1 : nb == 4 ? 2 : nb == 8 ? 3 : -1; }
-// baseToIntMap on a raw reference byte (bqsr.go:247-252)
-__device__ __forceinline__ int base_code_of_ref(uint8_t c) {
-  switch (c) {
-    case 'a': case 'A': case '*': return 1;
-    case 'c': case 'C': return 2;
-    case 'g': case 'G': return 3;
-    case 't': case 'T': return 4;
-    default: return 0;
-  }
-}
-// baseToIntMap on Sequence.Base(): "=ACMGRSVTWYHKDBN" -> A1 C2 G3 T4 else 0
-__device__ __forceinline__ int base_code_of_nibble(uint32_t nb) { return nb == 1 ? 1 : nb == 2 ? 2 : nb == 4 ? 3 : nb == 8 ? 4 : 0; }
-
+// ------------------------------------------------------------------ low-quality tails
 struct ReadView {
-  const uint8_t *seq4;  // original packed bases of the record
+  const uint8_t *seq4;  // unused by the bounds (kept for symmetry with the record's columns)
   const uint8_t *qual;  // original quals of the record
   int off, len;         // current window
   bool reversed;
   int left, right;      // low-quality-tail mask bounds inside the window (left > right: whole read masked)
 };
 
-// computeStrandedClippedSeq mask bounds, bqsr.go:316-332
+// computeStrandedClippedSeq mask bounds, bqsr.go:316-332 (the general prologue needs them inside the clipped window; for
+// unclipped reads they come from adapt_score)
 __device__ inline void low_quality_bounds(ReadView &v) {
   int left = v.len;
   for (int i = 0; i < v.len; i++) if (v.qual[v.off + i] > 2) { left = i; break; }
   int right = left - 1;
   for (int i = v.len - 1; i >= left; i--) if (v.qual[v.off + i] > 2) { right = i; break; }
   v.left = left; v.right = right;
-}
-__device__ __forceinline__ int masked_index(const ReadView &v, int k) {  // base index or -1 (masked / non-ACGT / outside)
-  if (k < v.left || k > v.right) return -1;
-  return base_index_of_nibble(nibble_at(v.seq4, v.off + k));
-}
-// context covariate of base k, bqsr.go:87-146
-__device__ __forceinline__ int context_key(const ReadView &v, int k) {
-  if (!v.reversed) {
-    if (k < 1) return -1;
-    const int p = masked_index(v, k - 1), q = masked_index(v, k);
-    if (p < 0 || q < 0) return -1;
-    return 2 | (p << 4) | (q << 6);
-  }
-  if (k > v.len - 2) return -1;
-  const int p = masked_index(v, k + 1), q = masked_index(v, k);
-  if (p < 0 || q < 0) return -1;
-  return 2 | ((3 - p) << 4) | ((3 - q) << 6);  // complement: A<->T, C<->G
-}
-__device__ __forceinline__ void cycle_params(uint16_t flag, int len, int *factor, int *incr) {  // bqsr.go:376-383
-  const int reversed = (flag & F_REVERSED) >> 4, last = (flag & F_LAST) >> 7;
-  const int rof = 1 - 2 * last;
-  *factor = rof + reversed * (len - 1) * rof;
-  *incr = (1 - 2 * reversed) * rof;
 }
 
 }  // namespace elp

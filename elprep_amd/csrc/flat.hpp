@@ -52,8 +52,6 @@ __device__ __forceinline__ uint64_t nib_spread16(uint32_t x16) {
   x = (x | (x << 3)) & NIB1;
   return x;
 }
-// swap the two nibbles of every byte (BAM packs the first base of a byte into the HIGH nibble)
-__device__ __forceinline__ uint64_t nib_swap(uint64_t v) { return ((v & 0x0F0F0F0F0F0F0F0Full) << 4) | ((v >> 4) & 0x0F0F0F0F0F0F0F0Full); }
 // nibble b of the result = nibble (b + sn) of the 128-bit value v1:v0, zero where b + sn < 0;  sn in [-16, 15]
 __device__ __forceinline__ uint64_t nib_ext(uint64_t v0, uint64_t v1, int sn) {
   const int shr = 4 * (sn < 0 ? 0 : sn);          // 0..60
@@ -62,9 +60,7 @@ __device__ __forceinline__ uint64_t nib_ext(uint64_t v0, uint64_t v1, int sn) {
   const uint64_t neg = shl >= 64 ? 0ull : (v0 << (shl & 63));
   return sn < 0 ? neg : pos;
 }
-// flag where the nibble is non-zero
-__device__ __forceinline__ uint64_t nib_nonzero(uint64_t x) { return (x | (x >> 1) | (x >> 2) | (x >> 3)) & NIB1; }
-// same for XORs of code nibbles (values 0..3 and 8: bit 2 is never set)
+// flag where the XOR of two code nibbles (values 0..3 and 8: bit 2 is never set) is non-zero
 __device__ __forceinline__ uint64_t nib_code_differs(uint64_t x) { return (x | (x >> 1) | (x >> 3)) & NIB1; }
 // code nibbles (A 0, C 1, G 2, T 3, anything else has bit 3 set; ctx.hip k_recode_seq): acgt = flag where the base is A/C/G/T,
 // code = its 2-bit code
