@@ -413,7 +413,6 @@ __global__ __launch_bounds__(256) void k_site_index(const int32_t *__restrict__ 
 }
 
 // quality value -> LDS table row offset of this pass; the special values:
-constexpr uint16_t QROW_SKIP = 0xFFFF;     // quality < 6 (minInterestingQual, bqsr.go:698) or handled by another pass
 // qualities > 93 count into row n_q ("bad"), qualities 6..93 the host did not give a slot (sampling hint incomplete) into row
 // n_q + 1 ("missing") of their covariate; the flush turns a non-zero cell of those rows into an error bit and the host reacts
 struct QMap { uint8_t slot[96]; };         // 6..93 -> slot of this pass, 255 = other pass, 254 = unknown to the host
@@ -427,7 +426,7 @@ struct CountArgs {
   const uint8_t *skipbits;  // the skip-bit column: bit (QUAL offset of the base)
   uint8_t *const *ref_seq;  // packed (k_pack_reference)
   const int64_t *ref_seq_len;
-  int n_ref, n_cov, n_q, lmax, cs, rs, max_cycle;  // cs = cycle cells per row, rs = cs + 32 = row stride (u32 words)
+  int n_ref, n_cov, n_q, lmax, rs, max_cycle;  // rs = row stride of the private table (u32 words)
   unsigned long long *cycle_tbl, *ctx_tbl;  // dense int64 tables of the C ABI (device copies)
   uint32_t *err;
   const uint32_t *tile_first;
@@ -438,8 +437,43 @@ struct CountArgs {
 // cycle cell of cycle index x = cycle + lmax is (17 x) >> 4 = x + x / 16: lanes of a wave work on bases 16 apart, the skew puts
 // them on different banks.  16-bit cycle counters are safe because a read touches a cycle cell at most once and the table is
 // flushed (atomic adds into the dense int64 tables in HBM) at least every 50000 reads.
+// private table of one workgroup: per covariate n_q + CT_XROWS rows of rs words - [0, CT_CYC) sixteen context cells of 32 | 32
+// bits (observations | mismatches), then the cycle cells of 16 | 16 bits at word CT_CYC + ((17 * (cycle + lmax)) >> 4) (the 17/16
+// stretch keeps the blocks of one read, sixteen cycles apart, out of each other's LDS banks); CT_PAD words behind the last row
+// take the zero-adds of bases outside the read
+constexpr int CT_CYC = 32, CT_XROWS = 3, CT_PAD = 64;
+
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
+__device__ __forceinline__ uint32_t lds_address(const void *p) {
+  return (uint32_t)reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) void *)p);
+}
+__device__ __forceinline__ void lds_add_u32(uint32_t at, uint32_t v) {
+  __hip_atomic_fetch_add(reinterpret_cast<lds_u32_t *>((uintptr_t)at), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_add_u64(uint32_t at, uint32_t lo, uint32_t hi) {
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  const u32x2 v = {lo, hi};
+  __hip_atomic_fetch_add(reinterpret_cast<lds_u64_t *>((uintptr_t)at), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// the instruction, not whatever instcombine makes of the shift-and-mask around it
+template <int OFF, int W>
+__device__ __forceinline__ uint32_t bfe_u32(uint32_t x) {
+  uint32_t r;
+  asm("v_bfe_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "n"(OFF), "n"(W));
+  return r;
+}
+template <int SH>
+__device__ __forceinline__ uint32_t lshl_add_u32(uint32_t a, uint32_t b) {  // (a << SH) + b
+  uint32_t r;
+  asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(SH), "v"(b));
+  return r;
+}
+
 template <bool CHECK_CYCLE, bool REFLDS>
 struct CountBody {
+  static constexpr int NT = FL_THREADS;
   // kernel arguments (scalar copies: a reference to the argument struct would keep this object in scratch memory)
   const uint64_t *__restrict__ seq_off;
   const uint8_t *__restrict__ qual;
@@ -451,7 +485,7 @@ struct CountBody {
   uint8_t *const *__restrict__ ref_seq;
   const int64_t *__restrict__ ref_seq_len;
   unsigned long long *cycle_tbl, *ctx_tbl;
-  int n_cov, n_q, lmax, cs, rs, max_cycle;
+  int n_cov, n_q, lmax, rs, max_cycle;
   // LDS
   const uint64_t *s_refp;  // [REF_LDS] packed-contig pointers and lengths (REFLDS: n_ref <= REF_LDS; else they are read from HBM)
   const int64_t *s_refl;
@@ -459,13 +493,15 @@ struct CountBody {
   int32_t *s_rl;           //           stage time, so that a block's loads depend on ONE LDS round trip after the read is known)
   uint4 *s_desc;
   uint32_t *s_seq;
-  const uint16_t *qrow;
+  const uint32_t *qrow;    // [256] quality -> LDS byte address of its row in covariate 0
   const uint8_t *slot_q;
   uint32_t *tbl;
-  uint32_t trash_idx;      // index (in u32 words, even) of this lane's 8-byte trash cell behind the tables
+  uint32_t real_end;       // LDS byte address behind the last real row of covariate 0
+  uint32_t rpc_bytes;      // bytes of one covariate's rows
   uint64_t seq_base;
   uint32_t err;
   uint32_t reads_since_flush;
+  uint64_t bases_since_flush;
 
   __device__ __forceinline__ void ref_of(int32_t refid, const uint8_t *__restrict__ &rp, int64_t &rlen) const {
     if (REFLDS) { rp = (const uint8_t *)(const __attribute__((address_space(1))) uint8_t *)s_refp[refid]; rlen = s_refl[refid]; }
@@ -473,9 +509,9 @@ struct CountBody {
   }
   __device__ __forceinline__ void stage(uint32_t g0, uint32_t ng) {
     const uint4 *src = desc + 2 * (size_t)g0;
-    for (uint32_t k = threadIdx.x; k < 2 * ng; k += blockDim.x) s_desc[k] = src[k];
+    for (uint32_t k = threadIdx.x; k < 2 * ng; k += NT) s_desc[k] = src[k];
     seq_base = seq_off[g0];
-    for (uint32_t k = threadIdx.x; k < ng; k += blockDim.x) {
+    for (uint32_t k = threadIdx.x; k < ng; k += NT) {
       s_seq[k] = (uint32_t)(seq_off[g0 + k] - seq_base);
       const uint4 dx = src[2 * k], dy = src[2 * k + 1];
       const uint8_t *rp = nullptr;
@@ -490,28 +526,25 @@ struct CountBody {
     rlen = s_rl[rl];
   }
 
-  // One base, branch-free: a base that is not counted adds to the lane's own trash cell behind the tables, so the sixteen
-  // bases of a block are straight-line code the compiler can interleave (no exec-mask juggling, no serialised LDS waits).
-  // Qualities > 93 and qualities without a table slot count into two extra rows behind the real ones (checked at flush time).
+  // One base, branch-free and without a select: a base that is not counted adds ZERO to whatever cell its quality and cycle
+  // point at (a cell of the table, of the row pad behind it, or of the static arrays in front of it - harmless everywhere), so
+  // the sixteen bases of a block are straight-line code of ~11 VALU instructions each.  Qualities that are not counted at all
+  // (< 6, or not in this pass) have a row of their own that the flush throws away; qualities > 93 and qualities without a table
+  // slot count into two more rows behind the real ones (they become error bits at flush time).
+  // z: (counted | mismatch << 16) of four bases, 4 bits apart; fv / ev: counted-with-context / its mismatch, 4 bits apart
   template <int I>
-  __device__ __forceinline__ void base(uint32_t fw, uint32_t xw, uint32_t vw, uint32_t cw, uint32_t ro, int P, int st, uint32_t cxb, int cyc0,
-                                       int ci, uint32_t trash) {
-    constexpr int sh = 4 * (I & 7);
-    bool act = ((fw >> sh) & 1u) && ro != QROW_SKIP;
+  __device__ __forceinline__ void base(uint32_t z, uint32_t fv, uint32_t ev, uint32_t cw, uint32_t ro, int t, uint32_t rowb, int cyc) {
+    constexpr int sh = 4 * (I & 7), zs = 4 * (I & 3);
+    uint32_t v1 = (z >> zs) & 0x10001u;
+    uint32_t lo = bfe_u32<sh, 1>(fv), hi = bfe_u32<sh, 1>(ev);
     if (CHECK_CYCLE) {  // checkCycleCovariate, bqsr.go:364-369
-      const int cyc = cyc0 + I * ci;
-      const bool out = act && ro < (uint32_t)(n_q * rs) && (cyc > max_cycle || cyc < -max_cycle);
+      const bool out = v1 != 0 && ro < real_end && (cyc > max_cycle || cyc < -max_cycle);
       err |= out ? 16u : 0u;
-      act = act && !out;
+      v1 = out ? 0u : v1; lo = out ? 0u : lo; hi = out ? 0u : hi;
     }
-    const int t = P + I * st;
-    const uint32_t e = (xw >> sh) & 1u;
-    const uint32_t i1 = act ? ro + (uint32_t)(t >> 4) : trash;
-    atomicAdd(&tbl[i1], 1u | (e << 16));
-    const bool act2 = act && ((vw >> sh) & 1u);
-    const uint32_t cx = (cw >> sh) & 15u;
-    const uint32_t i2 = act2 ? ro + cxb + 2u * cx : trash;
-    atomicAdd(reinterpret_cast<unsigned long long *>(&tbl[i2]), 1ull | ((unsigned long long)e << 32));
+    const uint32_t row = ro + rowb;
+    lds_add_u32(lshl_add_u32<2>((uint32_t)(t >> 4), row), v1);
+    lds_add_u64(lshl_add_u32<3>(bfe_u32<sh, 4>(cw), row), lo, hi);
   }
 
   struct Pre {
@@ -619,33 +652,33 @@ struct CountBody {
     const int rof = (fl & BQ_LAST) ? -1 : 1;
     const int cf = rof + (rev ? (len - 1) * rof : 0), ci = rev ? -rof : rof;
     const int cyc0 = cf + cbase * ci;
-    const uint32_t rowc = cov * (uint32_t)(n_q + 2) * (uint32_t)rs;
-    const int P = (int)(rowc << 4) + 17 * (cyc0 + lmax), st = 17 * ci;
-    const uint32_t cxb = rowc + (uint32_t)cs;
+    const uint32_t rowb = cov * rpc_bytes;                               // the covariate's rows
+    const int P = (CT_CYC << 4) + 17 * (cyc0 + lmax), st = 17 * ci;     // cycle cell (in words from the row start): (P + b * st) >> 4
 
-    const uint32_t f0 = (uint32_t)F, x0 = (uint32_t)X, v0 = (uint32_t)CV, c0 = (uint32_t)CX;
-    const uint32_t f1 = (uint32_t)(F >> 32), x1 = (uint32_t)(X >> 32), v1 = (uint32_t)(CV >> 32), c1 = (uint32_t)(CX >> 32);
-    const uint32_t trash = trash_idx;
+    const uint64_t E = X & F, FV = F & CV, EV = E & CV;
+    const uint32_t f0 = (uint32_t)F, e0 = (uint32_t)E, f1 = (uint32_t)(F >> 32), e1 = (uint32_t)(E >> 32);
+    const uint32_t za = (f0 & 0x1111u) | (e0 << 16), zb = (f0 >> 16) | (e0 & 0x11110000u);
+    const uint32_t zc = (f1 & 0x1111u) | (e1 << 16), zd = (f1 >> 16) | (e1 & 0x11110000u);
+    const uint32_t fv0 = (uint32_t)FV, ev0 = (uint32_t)EV, fv1 = (uint32_t)(FV >> 32), ev1 = (uint32_t)(EV >> 32);
+    const uint32_t c0 = (uint32_t)CX, c1 = (uint32_t)(CX >> 32);
     // groups of eight bases between scheduling barriers: enough independent work to cover the LDS latency without letting the
     // scheduler hoist all sixteen address computations at once (register pressure => occupancy)
+#define ELP_B(I, Z, FVW, EVW, CW, R) base<I>(Z, FVW, EVW, CW, R, P + (I) * st, rowb, cyc0 + (I) * ci)
     {
       const uint32_t r0 = qrow[ch.get<0>()], r1 = qrow[ch.get<1>()], r2 = qrow[ch.get<2>()], r3 = qrow[ch.get<3>()];
       const uint32_t r4 = qrow[ch.get<4>()], r5 = qrow[ch.get<5>()], r6 = qrow[ch.get<6>()], r7 = qrow[ch.get<7>()];
-      base<0>(f0, x0, v0, c0, r0, P, st, cxb, cyc0, ci, trash); base<1>(f0, x0, v0, c0, r1, P, st, cxb, cyc0, ci, trash);
-      base<2>(f0, x0, v0, c0, r2, P, st, cxb, cyc0, ci, trash); base<3>(f0, x0, v0, c0, r3, P, st, cxb, cyc0, ci, trash);
-      base<4>(f0, x0, v0, c0, r4, P, st, cxb, cyc0, ci, trash); base<5>(f0, x0, v0, c0, r5, P, st, cxb, cyc0, ci, trash);
-      base<6>(f0, x0, v0, c0, r6, P, st, cxb, cyc0, ci, trash); base<7>(f0, x0, v0, c0, r7, P, st, cxb, cyc0, ci, trash);
+      ELP_B(0, za, fv0, ev0, c0, r0); ELP_B(1, za, fv0, ev0, c0, r1); ELP_B(2, za, fv0, ev0, c0, r2); ELP_B(3, za, fv0, ev0, c0, r3);
+      ELP_B(4, zb, fv0, ev0, c0, r4); ELP_B(5, zb, fv0, ev0, c0, r5); ELP_B(6, zb, fv0, ev0, c0, r6); ELP_B(7, zb, fv0, ev0, c0, r7);
       __builtin_amdgcn_sched_barrier(0);
     }
     {
       const uint32_t r8 = qrow[ch.get<8>()], r9 = qrow[ch.get<9>()], r10 = qrow[ch.get<10>()], r11 = qrow[ch.get<11>()];
       const uint32_t r12 = qrow[ch.get<12>()], r13 = qrow[ch.get<13>()], r14 = qrow[ch.get<14>()], r15 = qrow[ch.get<15>()];
-      base<8>(f1, x1, v1, c1, r8, P, st, cxb, cyc0, ci, trash); base<9>(f1, x1, v1, c1, r9, P, st, cxb, cyc0, ci, trash);
-      base<10>(f1, x1, v1, c1, r10, P, st, cxb, cyc0, ci, trash); base<11>(f1, x1, v1, c1, r11, P, st, cxb, cyc0, ci, trash);
-      base<12>(f1, x1, v1, c1, r12, P, st, cxb, cyc0, ci, trash); base<13>(f1, x1, v1, c1, r13, P, st, cxb, cyc0, ci, trash);
-      base<14>(f1, x1, v1, c1, r14, P, st, cxb, cyc0, ci, trash); base<15>(f1, x1, v1, c1, r15, P, st, cxb, cyc0, ci, trash);
+      ELP_B(8, zc, fv1, ev1, c1, r8); ELP_B(9, zc, fv1, ev1, c1, r9); ELP_B(10, zc, fv1, ev1, c1, r10); ELP_B(11, zc, fv1, ev1, c1, r11);
+      ELP_B(12, zd, fv1, ev1, c1, r12); ELP_B(13, zd, fv1, ev1, c1, r13); ELP_B(14, zd, fv1, ev1, c1, r14); ELP_B(15, zd, fv1, ev1, c1, r15);
       __builtin_amdgcn_sched_barrier(0);
     }
+#undef ELP_B
   }
   __device__ __forceinline__ void group_end(uint32_t, uint32_t) {}
 
@@ -653,18 +686,18 @@ struct CountBody {
   // the two extra rows per covariate (bad / missing qualities) become error bits
   __device__ __forceinline__ void flush() {
     __syncthreads();
-    const int rpc = n_q + 2, rows = n_cov * rpc;
+    const int rpc = n_q + CT_XROWS, rows = n_cov * rpc;
     const int ncyc_l = 2 * lmax + 1, ncyc_g = 2 * max_cycle + 1;
-    for (int k = threadIdx.x; k < rows * ncyc_l; k += blockDim.x) {
+    for (int k = threadIdx.x; k < rows * ncyc_l; k += NT) {
       const int row = k / ncyc_l, x = k % ncyc_l;
-      uint32_t *cell = &tbl[row * rs + ((17 * x) >> 4)];
+      uint32_t *cell = &tbl[row * rs + CT_CYC + ((17 * x) >> 4)];
       const uint32_t v = *cell;
       if (v) {
         *cell = 0;
         const int cov = row / rpc, slot = row % rpc;
         const int cyc = x - lmax;
         if (slot >= n_q) {
-          err |= slot == n_q ? 8u : 128u;
+          err |= slot == n_q ? 8u : (slot == n_q + 1 ? 128u : 0u);
         } else if (cyc >= -max_cycle && cyc <= max_cycle) {
           const int q = slot_q[slot];
           unsigned long long *g = cycle_tbl + (((size_t)cov * ELP_NQUAL + q) * ncyc_g + (size_t)(cyc + max_cycle)) * 2;
@@ -673,9 +706,9 @@ struct CountBody {
         }
       }
     }
-    for (int k = threadIdx.x; k < rows * 16; k += blockDim.x) {
+    for (int k = threadIdx.x; k < rows * 16; k += NT) {
       const int row = k >> 4, cx = k & 15;
-      unsigned long long *cell = reinterpret_cast<unsigned long long *>(&tbl[row * rs + cs + 2 * cx]);
+      unsigned long long *cell = reinterpret_cast<unsigned long long *>(&tbl[row * rs + 2 * cx]);
       const unsigned long long v = *cell;
       if (v) {
         *cell = 0;
@@ -691,9 +724,12 @@ struct CountBody {
     }
     __syncthreads();
   }
-  __device__ __forceinline__ void tile_end(uint32_t nreads) {
+  // a cycle cell (16 | 16 bits) takes at most one count per read, a context cell (32 | 32 bits) at most one per base; a tile
+  // starts at most FL_TILE reads and holds at most FL_TILE + FL_MAX_READ bases
+  __device__ __forceinline__ void tile_end(uint32_t nreads, uint64_t nbases) {
     reads_since_flush += nreads;
-    if (reads_since_flush > 50000u) { flush(); reads_since_flush = 0; }
+    bases_since_flush += nbases;
+    if (reads_since_flush > 30000u || bases_since_flush > (1ull << 31)) { flush(); reads_since_flush = 0; bases_since_flush = 0; }
   }
 };
 
@@ -702,39 +738,42 @@ __global__ __launch_bounds__(FL_THREADS, 4) void k_bqsr_count(CountArgs A, QMap 
   __shared__ FlatLds L;
   __shared__ uint4 s_desc[2 * FL_RMAX];
   __shared__ uint32_t s_seq[FL_RMAX];
-  __shared__ uint16_t qrow[256];
+  __shared__ uint32_t qrow[256];
   __shared__ uint8_t slot_q[96];
   __shared__ uint64_t s_refp[REF_LDS];
   __shared__ int64_t s_refl[REF_LDS];
   __shared__ uint64_t s_rp[FL_RMAX];
   __shared__ int32_t s_rl[FL_RMAX];
   extern __shared__ __attribute__((aligned(16))) uint32_t tbl[];
-  const int n_all = A.n_cov * (A.n_q + 2) * A.rs;
+  const int n_all = A.n_cov * (A.n_q + CT_XROWS) * A.rs + CT_PAD;
+  const uint32_t tbl_at = lds_address(tbl);
   if (REFLDS)
-    for (int r = threadIdx.x; r < A.n_ref; r += blockDim.x) { s_refp[r] = reinterpret_cast<uint64_t>(A.ref_seq[r]); s_refl[r] = A.ref_seq_len[r]; }
-  for (int k = threadIdx.x; k < n_all; k += blockDim.x) tbl[k] = 0;
-  for (int q = threadIdx.x; q < 256; q += blockDim.x) {
-    uint16_t v;
-    if (q < 6) v = QROW_SKIP;
-    else if (q >= ELP_NQUAL) v = (uint16_t)(A.n_q * A.rs);  // "bad" row
+    for (int r = threadIdx.x; r < A.n_ref; r += FL_THREADS) { s_refp[r] = reinterpret_cast<uint64_t>(A.ref_seq[r]); s_refl[r] = A.ref_seq_len[r]; }
+  for (int k = threadIdx.x; k < n_all; k += FL_THREADS) tbl[k] = 0;
+  for (int q = threadIdx.x; q < 256; q += FL_THREADS) {
+    int row;
+    if (q < 6) row = A.n_q + 2;                // not counted (bqsr.go:301-305)
+    else if (q >= ELP_NQUAL) row = A.n_q;      // bad quality
     else {
       const uint8_t s = qm.slot[q];
-      v = s == 255 ? QROW_SKIP : (s == 254 ? (uint16_t)((A.n_q + 1) * A.rs) : (uint16_t)(s * A.rs));
+      row = s == 255 ? A.n_q + 2 : (s == 254 ? A.n_q + 1 : (int)s);  // counted in another pass / not in the table
       if (s < 254) slot_q[s] = (uint8_t)q;
     }
-    qrow[q] = v;
+    qrow[q] = tbl_at + (uint32_t)(row * A.rs) * 4u;
   }
   __syncthreads();
   CountBody<CHECK_CYCLE, REFLDS> B;
   B.seq_off = A.seq_off; B.qual = A.qual; B.seq4 = A.seq4; B.desc = reinterpret_cast<const uint4 *>(A.desc);
   B.cigar = A.cigar; B.cig_scratch = A.cig_scratch; B.skipbits = A.skipbits; B.ref_seq = A.ref_seq; B.ref_seq_len = A.ref_seq_len;
   B.cycle_tbl = A.cycle_tbl; B.ctx_tbl = A.ctx_tbl;
-  B.n_cov = A.n_cov; B.n_q = A.n_q; B.lmax = A.lmax; B.cs = A.cs; B.rs = A.rs; B.max_cycle = A.max_cycle;
+  B.n_cov = A.n_cov; B.n_q = A.n_q; B.lmax = A.lmax; B.rs = A.rs; B.max_cycle = A.max_cycle;
   B.s_desc = s_desc; B.s_seq = s_seq; B.qrow = qrow; B.slot_q = slot_q; B.tbl = tbl;
   B.s_refp = s_refp; B.s_refl = s_refl; B.s_rp = s_rp; B.s_rl = s_rl;
-  B.trash_idx = (uint32_t)((n_all + 1) & ~1) + 2u * threadIdx.x;
+  B.real_end = tbl_at + (uint32_t)(A.n_q * A.rs) * 4u;
+  B.rpc_bytes = (uint32_t)((A.n_q + CT_XROWS) * A.rs) * 4u;
   B.err = 0;
   B.reads_since_flush = 0;
+  B.bases_since_flush = 0;
   flat_run(A.qual_off, A.n, A.qual_bytes, A.tile_first, L, B);
   B.flush();
   uint32_t my_err = B.err;
@@ -813,6 +852,7 @@ constexpr uint32_t QOFF_KEEP = 0x7FFFFFFFu, QOFF_BAD = 0x80000000u, QOFF_TODO = 
 
 template <bool CHECK_CYCLE, bool LDSLUT>
 struct ApplyBody {
+  static constexpr int NT = LDSLUT ? 1024 : FL_THREADS;
   const uint64_t *__restrict__ seq_off;
   uint8_t *__restrict__ qual;
   const uint8_t *__restrict__ seq4;
@@ -828,9 +868,9 @@ struct ApplyBody {
   uint32_t err;
 
   __device__ __forceinline__ void stage(uint32_t g0, uint32_t ng) {
-    for (uint32_t k = threadIdx.x; k < ng; k += blockDim.x) s_desc[k] = desc[g0 + k];
+    for (uint32_t k = threadIdx.x; k < ng; k += NT) s_desc[k] = desc[g0 + k];
     seq_base = seq_off[g0];
-    for (uint32_t k = threadIdx.x; k < ng; k += blockDim.x) s_seq[k] = (uint32_t)(seq_off[g0 + k] - seq_base);
+    for (uint32_t k = threadIdx.x; k < ng; k += NT) s_seq[k] = (uint32_t)(seq_off[g0 + k] - seq_base);
   }
   // dense LUT in HBM/L2: one byte gather per base
   template <int I>
@@ -977,7 +1017,7 @@ struct ApplyBody {
     ch.store(qual + qpos, nb);
   }
   __device__ __forceinline__ void group_end(uint32_t, uint32_t) {}
-  __device__ __forceinline__ void tile_end(uint32_t) {}
+  __device__ __forceinline__ void tile_end(uint32_t, uint64_t) {}
 };
 
 template <bool CHECK_CYCLE, bool LDSLUT>
@@ -988,12 +1028,13 @@ __global__ __launch_bounds__(LDSLUT ? 1024 : FL_THREADS, LDSLUT ? 4 : 4) void k_
   __shared__ uint32_t qoff[256];
   extern __shared__ __attribute__((aligned(16))) uint8_t llut[];
   if (LDSLUT) {
-    for (int q = threadIdx.x; q < 256; q += blockDim.x)
+    constexpr int NT = ApplyBody<CHECK_CYCLE, LDSLUT>::NT;
+    for (int q = threadIdx.x; q < 256; q += NT)
       qoff[q] = q < 6 ? QOFF_KEEP : (q >= ELP_NQUAL ? QOFF_BAD : (slots.slot[q] == 255 ? QOFF_TODO : (uint32_t)slots.slot[q] * (uint32_t)((2 * A.lmax + 1) * 17)));
     const int nbytes = A.n_cov * A.n_slot * (2 * A.lmax + 1) * 17;
     const uint4 *src = reinterpret_cast<const uint4 *>(A.clut);  // padded to 16 bytes by the builder
     uint4 *dst = reinterpret_cast<uint4 *>(llut);
-    for (int k = threadIdx.x; k < (nbytes + 15) / 16; k += blockDim.x) dst[k] = src[k];
+    for (int k = threadIdx.x; k < (nbytes + 15) / 16; k += NT) dst[k] = src[k];
     __syncthreads();
   }
   ApplyBody<CHECK_CYCLE, LDSLUT> B;
@@ -1095,9 +1136,9 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
     const int lmax = (int)std::max<uint32_t>(c->max_l_seq, 1);
     if (lmax > MAX_DESC_READ) return set_error(c, ELP_ERR_UNSUPPORTED, "BQSR: read longer than %d bases", MAX_DESC_READ);
     const bool check_cycle = lmax > max_cycle;
-    const int cs = ((((17 * 2 * lmax) >> 4) + 1) + 1) & ~1, rs = cs + 32;
+    const int rs = (CT_CYC + ((17 * 2 * lmax) >> 4) + 1 + 1) & ~1;  // words per row
     const size_t per_slot = (size_t)c->n_cov * (size_t)rs * 4;
-    const size_t static_lds = sizeof(FlatLds) + (size_t)FL_RMAX * (sizeof(BqDesc) + 4) + 512 + 96 + 64 + 8 + (size_t)FL_THREADS * 8 + (size_t)REF_LDS * 16 + (size_t)FL_RMAX * 12;
+    const size_t static_lds = sizeof(FlatLds) + (size_t)FL_RMAX * (sizeof(BqDesc) + 4) + 1024 + 96 + 64 + 8 + (size_t)CT_PAD * 4 + (size_t)REF_LDS * 16 + (size_t)FL_RMAX * 12;
     const size_t lds_cu = 160 * 1024;
     const uint64_t ntiles = (c->qual_bytes + FL_TILE - 1) / FL_TILE;
     for (int attempt = 0;; attempt++) {
@@ -1111,7 +1152,7 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
       for (int w = 3; w >= 1; w--) {
         const size_t budget = lds_cu / (size_t)w;
         if (budget <= static_lds + 256) continue;
-        const int cap = (int)std::min<size_t>((budget - static_lds - 256) / per_slot, 65000 / (size_t)rs) - 2;  // two extra rows per covariate
+        const int cap = (int)((budget - static_lds - 256) / per_slot) - CT_XROWS;  // minus the extra rows per covariate
         if (cap >= (int)quals.size() || w == 1) { wg_per_cu = w; qcap = cap; break; }
       }
       if (qcap < 1) return set_error(c, ELP_ERR_UNSUPPORTED, "BQSR private tables do not fit in LDS (n_cov=%d, max read length=%d)", c->n_cov, lmax);
@@ -1122,9 +1163,9 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
         memset(qm.slot, 254, sizeof qm.slot);
         for (int q : quals) qm.slot[q] = 255;
         for (int s = 0; s < nqs; s++) qm.slot[quals[q0 + s]] = (uint8_t)s;
-        const size_t dyn = (size_t)c->n_cov * (nqs + 2) * rs * 4 + 8 + (size_t)FL_THREADS * 8;  // tables + one trash cell per lane
+        const size_t dyn = ((size_t)c->n_cov * (nqs + CT_XROWS) * rs + CT_PAD) * 4;
         CountArgs A{n, c->qual_bytes, c->qual_off.p, c->seq_off.p, c->qual.p, c->seq4.p, desc, c->cigar.p, cs_pool,
-                    reinterpret_cast<const uint8_t *>(skipbits), c->d_ref_seq.p, c->d_ref_seq_len.p, c->n_ref, c->n_cov, nqs, lmax, cs, rs, max_cycle,
+                    reinterpret_cast<const uint8_t *>(skipbits), c->d_ref_seq.p, c->d_ref_seq_len.p, c->n_ref, c->n_cov, nqs, lmax, rs, max_cycle,
                     tb + nq, tb + nq + nc, c->err_flag.p, c->tile_first.p};
         const bool ref_lds = c->n_ref <= REF_LDS;
 #define ELP_COUNT_LAUNCH(CC, RL)                                                                                                              \

@@ -17,7 +17,9 @@
 
 namespace elp {
 
-constexpr int FL_THREADS = 512;                  // default workgroup size (kernels use blockDim.x)
+constexpr int FL_THREADS = 512;                  // default workgroup size; every body states its own as Body::NT (a compile-time constant:
+                                                 // blockDim.x is a load from the dispatch packet, and a load inside the block loop drains
+                                                 // vmcnt, i.e. waits for the prefetched loads of the next block)
 constexpr int FL_CHUNK = 16;                     // bases per block
 constexpr uint64_t FL_TILE = 32768;              // QUAL bytes per tile
 constexpr int FL_RMAX = 256;                     // reads held in LDS at a time (150-base reads: ~220 per tile)
@@ -127,6 +129,7 @@ struct Chunk {
 };
 
 // Drives one workgroup over its tiles.  Body provides:
+//   static constexpr int NT                                   workgroup size the kernel is launched with
 //   struct Pre                                                the registers a block's global loads land in (+ what identifies it)
 //   void stage(uint32_t g0, uint32_t ng)                      all threads: put per-read data of reads [g0, g0+ng) into LDS
 //   bool prefetch(uint32_t rl, int k0, int nb, uint64_t qpos, Pre &)
@@ -135,7 +138,7 @@ struct Chunk {
 //                                                             qpos) without using their results; false = nothing to do for the block
 //   void process(Pre &)                                       per lane: the block's work
 //   void group_end(uint32_t g0, uint32_t ng)                  all threads, after a barrier
-//   void tile_end(uint32_t nreads)                            all threads (uniform), may contain barriers
+//   void tile_end(uint32_t nreads, uint64_t nbases)           all threads (uniform), may contain barriers
 // The lane's next block is prefetched before the current one is processed, so the HBM latency of block i+1 hides behind the ALU
 // and LDS work of block i (the loads stay in flight across the loop's back edge).
 // tile_first[t] = first read whose QUAL offset is >= t * FL_TILE (tile_first[ntiles] = n_reads).
@@ -148,7 +151,7 @@ __device__ __forceinline__ void flat_run(const uint64_t *__restrict__ qual_off, 
     for (uint32_t g0 = r_first; g0 < r_end; g0 += FL_RMAX) {
       const uint32_t ng = (r_end - g0 < (uint32_t)FL_RMAX) ? r_end - g0 : (uint32_t)FL_RMAX;  // reads [g0, g0 + ng)
       const uint64_t base = qual_off[g0];
-      for (uint32_t k = threadIdx.x; k <= ng; k += blockDim.x) L.off[k] = (uint32_t)(qual_off[g0 + k] - base);
+      for (uint32_t k = threadIdx.x; k <= ng; k += Body::NT) L.off[k] = (uint32_t)(qual_off[g0 + k] - base);
       B.stage(g0, ng);
       __syncthreads();
       const uint32_t nslots = (L.off[ng] + 15u * ng) >> 4;  // slot of read k: (off[k] + 15 k) >> 4
@@ -192,7 +195,7 @@ __device__ __forceinline__ void flat_run(const uint64_t *__restrict__ qual_off, 
       bool have = s < nslots ? fetch(s, cur) : false;
 #pragma unroll 1
       while (s < nslots) {
-        const uint32_t sn = s + blockDim.x;
+        const uint32_t sn = s + Body::NT;
         typename Body::Pre nxt;
         const bool have_n = sn < nslots ? fetch(sn, nxt) : false;
         if (have) B.process(cur);
@@ -204,7 +207,7 @@ __device__ __forceinline__ void flat_run(const uint64_t *__restrict__ qual_off, 
       B.group_end(g0, ng);
       __syncthreads();
     }
-    B.tile_end(r_end - r_first);
+    B.tile_end(r_end - r_first, qual_off[r_end] - qual_off[r_first]);
   }
 }
 

@@ -70,6 +70,7 @@ __device__ __forceinline__ uint32_t first_bytes32(int n) { return n <= 0 ? 0u : 
 // computePhredScore :57-68 as a flat stream over the QUAL column: sum of qualities >= 15 per duplicate-marking candidate;
 // any quality > 93 in a candidate is an error.  SWAR over the lane's 16 bytes, v_sad_u8 for the byte sums.
 struct ScoreBody {
+  static constexpr int NT = FL_THREADS;
   const uint16_t *__restrict__ flag;
   const uint8_t *__restrict__ qual;
   int32_t *score;
@@ -81,7 +82,7 @@ struct ScoreBody {
   uint32_t bad;
 
   __device__ __forceinline__ void stage(uint32_t g0, uint32_t ng) {
-    for (uint32_t k = threadIdx.x; k < ng; k += blockDim.x) {
+    for (uint32_t k = threadIdx.x; k < ng; k += NT) {
       acc[k] = 0;
       lo[k] = 0xFFFFFFFFu;
       hi[k] = 0u;
@@ -123,12 +124,12 @@ struct ScoreBody {
     if (s) atomicAdd(&acc[p.rl], (int32_t)s);
   }
   __device__ __forceinline__ void group_end(uint32_t g0, uint32_t ng) {
-    for (uint32_t k = threadIdx.x; k < ng; k += blockDim.x) {  // a read belongs to exactly one group
+    for (uint32_t k = threadIdx.x; k < ng; k += NT) {  // a read belongs to exactly one group
       score[g0 + k] = acc[k];
       qbounds[g0 + k] = (uint64_t)hi[k] | ((uint64_t)lo[k] << 32);  // all-zero = no quality > 2
     }
   }
-  __device__ __forceinline__ void tile_end(uint32_t) {}
+  __device__ __forceinline__ void tile_end(uint32_t, uint64_t) {}
 };
 
 __global__ __launch_bounds__(FL_THREADS) void k_score_flat(uint64_t n, const uint64_t *__restrict__ qual_off, const uint8_t *__restrict__ qual,
