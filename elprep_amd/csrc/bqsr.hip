@@ -473,7 +473,9 @@ __device__ __forceinline__ uint32_t lshl_add_u32(uint32_t a, uint32_t b) {  // (
 
 template <bool CHECK_CYCLE, bool REFLDS>
 struct CountBody {
-  static constexpr int NT = FL_THREADS;
+  // groups of 256 reads: the per-read LDS (44 B) competes with the private tables for the 80 KB that let two workgroups share a CU
+  // (with four read groups and six qualities the tables take 50 KB); 256 KiB steps save the per-step restart of the pipeline
+  static constexpr int NT = FL_THREADS, TILES = 8, RMAX = 256;
   // kernel arguments (scalar copies: a reference to the argument struct would keep this object in scratch memory)
   const uint64_t *__restrict__ seq_off;
   const uint8_t *__restrict__ qual;
@@ -489,7 +491,7 @@ struct CountBody {
   // LDS
   const uint64_t *s_refp;  // [REF_LDS] packed-contig pointers and lengths (REFLDS: n_ref <= REF_LDS; else they are read from HBM)
   const int64_t *s_refl;
-  uint64_t *s_rp;          // [FL_RMAX] per read of the group: its contig's packed bases and length (resolved once per read at
+  uint64_t *s_rp;          // [RMAX] per read of the group: its contig's packed bases and length (resolved once per read at
   int32_t *s_rl;           //           stage time, so that a block's loads depend on ONE LDS round trip after the read is known)
   uint4 *s_desc;
   uint32_t *s_seq;
@@ -680,6 +682,7 @@ struct CountBody {
     }
 #undef ELP_B
   }
+  __device__ __forceinline__ void retire() {}
   __device__ __forceinline__ void group_end(uint32_t, uint32_t) {}
 
   // adds the private table into the dense int64 tables (cycle: [cov][94][2*max_cycle+1][2], context: [cov][94][16][2]) and clears it;
@@ -735,15 +738,16 @@ struct CountBody {
 
 template <bool CHECK_CYCLE, bool REFLDS>
 __global__ __launch_bounds__(FL_THREADS, 4) void k_bqsr_count(CountArgs A, QMap qm) {
-  __shared__ FlatLds L;
-  __shared__ uint4 s_desc[2 * FL_RMAX];
-  __shared__ uint32_t s_seq[FL_RMAX];
+  constexpr int RMAX = CountBody<CHECK_CYCLE, REFLDS>::RMAX;
+  __shared__ FlatLds<RMAX> L;
+  __shared__ uint4 s_desc[2 * RMAX];
+  __shared__ uint32_t s_seq[RMAX];
   __shared__ uint32_t qrow[256];
   __shared__ uint8_t slot_q[96];
   __shared__ uint64_t s_refp[REF_LDS];
   __shared__ int64_t s_refl[REF_LDS];
-  __shared__ uint64_t s_rp[FL_RMAX];
-  __shared__ int32_t s_rl[FL_RMAX];
+  __shared__ uint64_t s_rp[RMAX];
+  __shared__ int32_t s_rl[RMAX];
   extern __shared__ __attribute__((aligned(16))) uint32_t tbl[];
   const int n_all = A.n_cov * (A.n_q + CT_XROWS) * A.rs + CT_PAD;
   const uint32_t tbl_at = lds_address(tbl);
@@ -848,11 +852,11 @@ struct QSlots { uint8_t slot[96]; };
 
 // ApplyBQSR (bqsr.go:936-1005): every base with quality >= 6 of a record with a known read group is replaced by the LUT value
 // of (read group, quality, cycle, context); cycle and context are taken on the full, unclipped read.
-constexpr uint32_t QOFF_KEEP = 0x7FFFFFFFu, QOFF_BAD = 0x80000000u, QOFF_TODO = 0x80000001u;
 
 template <bool CHECK_CYCLE, bool LDSLUT>
 struct ApplyBody {
-  static constexpr int NT = LDSLUT ? 1024 : FL_THREADS;
+  // 128 KiB steps in groups of up to 1024 reads (12 B of LDS per read): ~9 blocks per lane between two pipeline restarts
+  static constexpr int NT = LDSLUT ? 1024 : FL_THREADS, TILES = 4, RMAX = 1024;
   const uint64_t *__restrict__ seq_off;
   uint8_t *__restrict__ qual;
   const uint8_t *__restrict__ seq4;
@@ -861,11 +865,14 @@ struct ApplyBody {
   int max_cycle;
   uint64_t *s_desc;
   uint32_t *s_seq;
-  const uint32_t *qoff;   // LDS: quality -> row offset in the compact LUT or a QOFF_* code (LDSLUT)
-  const uint8_t *llut;    // LDS: compact LUT (LDSLUT)
+  const uint32_t *qoff;   // LDS: quality -> row block offset in a covariate's part of the compact LUT (LDSLUT)
+  uint32_t llut_at;       // LDS byte address of the compact LUT (LDSLUT)
   int lmax, n_slot;
   uint64_t seq_base;
   uint32_t err;
+  Chunk out;              // the block processed last: stored by retire()
+  uint64_t out_at;
+  int out_nb;
 
   __device__ __forceinline__ void stage(uint32_t g0, uint32_t ng) {
     for (uint32_t k = threadIdx.x; k < ng; k += NT) s_desc[k] = desc[g0 + k];
@@ -891,46 +898,46 @@ struct ApplyBody {
     const uint32_t v = lut[act ? idx : 0u];
     return act ? v : q;
   }
-  // compact LUT in LDS: one LDS byte read per base.  `off` = qoff[quality]: byte offset of the quality's row block inside a
-  // covariate's part of the compact LUT, or QOFF_KEEP (quality < 6: unchanged), QOFF_BAD (> 93), QOFF_TODO (no resident slot);
-  // the two rare cases are found by OR-ing the sixteen offsets (high bit) and handled by a rolled loop afterwards.
+  // compact LUT in LDS: one LDS byte read per base and no select.  `off` = qoff[quality]: byte offset of the quality's row block
+  // inside a covariate's part of the compact LUT; qualities without a row block (> 93, or not resident) point at one more block
+  // behind the real ones that holds 0x80 everywhere, so the (rare) bases that need another look are found by bit 7 of the four
+  // result words.  cxw: context index (0..15, 16 = none) of four bases, one byte each.  Bases past the read's end are looked up
+  // too (their bytes are never stored), qualities < 6 are put back by a byte-mask select over the result words.
   template <int I>
-  __device__ __forceinline__ uint32_t base_lds(const Chunk &ch, int nb, uint32_t vw, uint32_t cw, const uint8_t *bp, int st, int cyc0, int ci,
-                                               uint32_t off) {
-    constexpr int sh = 4 * (I & 7);
-    const uint32_t q = ch.get<I>();
-    bool act = I < nb && off < QOFF_KEEP;
-    if (CHECK_CYCLE) {
-      const int cyc = cyc0 + I * ci;
-      const bool out = act && (cyc > max_cycle || cyc < -max_cycle);
-      err |= out ? 16u : 0u;
-      act = act && !out;
-    }
-    const uint32_t cx = ((cw >> sh) & 15u) | ((((~vw) >> sh) & 1u) << 4);  // 16 = no context
-    const uint8_t *ap = act ? bp + (I * st + (int)(off + cx)) : llut;
-    const uint32_t v = *ap;
-    return act ? v : q;
+  __device__ __forceinline__ uint32_t base_lds(uint32_t cxw, uint32_t bp, int st, uint32_t off) {
+    constexpr int bs = 8 * ((I & 7) >> 1);
+    const uint32_t at = bp + (uint32_t)(I * st) + off + ((cxw >> bs) & 0xFFu);
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>((uintptr_t)at);
   }
-  // rare bases of a block (found by the high bit of the OR of the sixteen offsets; slots past nb may have raised it falsely):
-  // quality > 93 -> error; quality without a resident slot -> dense LUT.  Rolled loop over the original bytes.
+  // word of result bytes where the original quality is >= 6, original bytes elsewhere (ApplyBQSR leaves qualities < 6 alone)
+  __device__ __forceinline__ static uint32_t keep_low(uint32_t orig, uint32_t res) {
+    const uint32_t t = ((orig | 0x80808080u) - 0x06060606u) & 0x80808080u;  // bit 7 of a byte: (quality & 127) >= 6
+    const uint32_t m = (t - (t >> 7)) | t;
+    return (res & m) | (orig & ~m);
+  }
+  // bases of a block whose lookup hit the 0x80 block (bases past nb may have raised the flag falsely): quality > 93 -> error;
+  // quality without a resident slot -> dense LUT.  Rolled loop over the original bytes.
   __device__ __forceinline__ void fixup(Chunk &ch, const Chunk &orig, int nb, uint64_t CV, uint64_t CX, uint32_t Q, int st, int cyc0, int ci) {
     uint64_t lo = (uint64_t)ch.w0 | ((uint64_t)ch.w1 << 32), hi = (uint64_t)ch.w2 | ((uint64_t)ch.w3 << 32);
     const uint64_t olo = (uint64_t)orig.w0 | ((uint64_t)orig.w1 << 32), ohi = (uint64_t)orig.w2 | ((uint64_t)orig.w3 << 32);
     const uint32_t qstride = (uint32_t)(2 * max_cycle + 1) * 17u;
+    const uint32_t off_x = (uint32_t)(n_slot * (2 * lmax + 1) * 17);
 #pragma unroll 1
     for (int i = 0; i < nb; i++) {
       const int bs = 8 * (i & 7);
       const uint32_t q = (uint32_t)(((i & 8) ? ohi : olo) >> bs) & 0xFFu;
-      const uint32_t off = qoff[q];
-      if (off < QOFF_BAD) continue;  // resident or unchanged: done by the straight-line code
-      if (off == QOFF_BAD) { err |= 8u; continue; }
-      if (CHECK_CYCLE) {
-        const int cyc = cyc0 + i * ci;
-        if (cyc > max_cycle || cyc < -max_cycle) { err |= 16u; continue; }
+      if (q < 6u) continue;                                      // put back by keep_low
+      uint64_t v = q;
+      if (q >= (uint32_t)ELP_NQUAL) err |= 8u;
+      else if (qoff[q] != off_x) continue;                       // resident: done by the straight-line code
+      else {
+        if (CHECK_CYCLE) {
+          const int cyc = cyc0 + i * ci;
+          if (cyc > max_cycle || cyc < -max_cycle) { err |= 16u; continue; }
+        }
+        const uint32_t cx = ((uint32_t)(CX >> (4 * i)) & 15u) | ((((uint32_t)(~CV >> (4 * i))) & 1u) << 4);
+        v = (uint64_t)lut[Q + (uint32_t)(i * st) + q * qstride + cx];
       }
-      const uint32_t cx = ((uint32_t)(CX >> (4 * i)) & 15u) | ((((uint32_t)(~CV >> (4 * i))) & 1u) << 4);
-      const uint32_t idx = Q + (uint32_t)(i * st) + q * qstride + cx;
-      const uint64_t v = (uint64_t)lut[idx];
       const uint64_t m = ~(0xFFull << bs);
       lo = (i & 8) ? lo : ((lo & m) | (v << bs));
       hi = (i & 8) ? ((hi & m) | (v << bs)) : hi;
@@ -982,22 +989,21 @@ struct ApplyBody {
     const uint32_t v0 = (uint32_t)CV, v1 = (uint32_t)(CV >> 32), c0 = (uint32_t)CX, c1 = (uint32_t)(CX >> 32);
     uint32_t b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, b10, b11, b12, b13, b14, b15;
     const Chunk orig = ch;
-    uint32_t any = 0;
     if (LDSLUT) {
-      const uint8_t *bp = llut + ((int)cov * n_slot * (2 * lmax + 1) + (cyc0 + lmax)) * 17;
+      const uint32_t bp = llut_at + (uint32_t)(((int)cov * (n_slot + 1) * (2 * lmax + 1) + (cyc0 + lmax)) * 17);
+      // context index per base, one byte each: even bases in ce, odd bases in co
+      constexpr uint64_t EVN = 0x0F0F0F0F0F0F0F0Full;
+      const uint64_t NV = ~CV & NIB1;
+      const uint64_t ce = (CX & EVN) | ((NV & (NIB1 & EVN)) << 4), co = ((CX >> 4) & EVN) | (NV & (NIB1 & ~EVN));
+      const uint32_t e0 = (uint32_t)ce, e1 = (uint32_t)(ce >> 32), d0 = (uint32_t)co, d1 = (uint32_t)(co >> 32);
       const uint32_t o0 = qoff[ch.get<0>()], o1 = qoff[ch.get<1>()], o2 = qoff[ch.get<2>()], o3 = qoff[ch.get<3>()];
       const uint32_t o4 = qoff[ch.get<4>()], o5 = qoff[ch.get<5>()], o6 = qoff[ch.get<6>()], o7 = qoff[ch.get<7>()];
       const uint32_t o8 = qoff[ch.get<8>()], o9 = qoff[ch.get<9>()], o10 = qoff[ch.get<10>()], o11 = qoff[ch.get<11>()];
       const uint32_t o12 = qoff[ch.get<12>()], o13 = qoff[ch.get<13>()], o14 = qoff[ch.get<14>()], o15 = qoff[ch.get<15>()];
-      any = (o0 | o1 | o2 | o3) | (o4 | o5 | o6 | o7) | (o8 | o9 | o10 | o11) | (o12 | o13 | o14 | o15);
-      b0 = base_lds<0>(ch, nb, v0, c0, bp, st, cyc0, ci, o0); b1 = base_lds<1>(ch, nb, v0, c0, bp, st, cyc0, ci, o1);
-      b2 = base_lds<2>(ch, nb, v0, c0, bp, st, cyc0, ci, o2); b3 = base_lds<3>(ch, nb, v0, c0, bp, st, cyc0, ci, o3);
-      b4 = base_lds<4>(ch, nb, v0, c0, bp, st, cyc0, ci, o4); b5 = base_lds<5>(ch, nb, v0, c0, bp, st, cyc0, ci, o5);
-      b6 = base_lds<6>(ch, nb, v0, c0, bp, st, cyc0, ci, o6); b7 = base_lds<7>(ch, nb, v0, c0, bp, st, cyc0, ci, o7);
-      b8 = base_lds<8>(ch, nb, v1, c1, bp, st, cyc0, ci, o8); b9 = base_lds<9>(ch, nb, v1, c1, bp, st, cyc0, ci, o9);
-      b10 = base_lds<10>(ch, nb, v1, c1, bp, st, cyc0, ci, o10); b11 = base_lds<11>(ch, nb, v1, c1, bp, st, cyc0, ci, o11);
-      b12 = base_lds<12>(ch, nb, v1, c1, bp, st, cyc0, ci, o12); b13 = base_lds<13>(ch, nb, v1, c1, bp, st, cyc0, ci, o13);
-      b14 = base_lds<14>(ch, nb, v1, c1, bp, st, cyc0, ci, o14); b15 = base_lds<15>(ch, nb, v1, c1, bp, st, cyc0, ci, o15);
+      b0 = base_lds<0>(e0, bp, st, o0); b1 = base_lds<1>(d0, bp, st, o1); b2 = base_lds<2>(e0, bp, st, o2); b3 = base_lds<3>(d0, bp, st, o3);
+      b4 = base_lds<4>(e0, bp, st, o4); b5 = base_lds<5>(d0, bp, st, o5); b6 = base_lds<6>(e0, bp, st, o6); b7 = base_lds<7>(d0, bp, st, o7);
+      b8 = base_lds<8>(e1, bp, st, o8); b9 = base_lds<9>(d1, bp, st, o9); b10 = base_lds<10>(e1, bp, st, o10); b11 = base_lds<11>(d1, bp, st, o11);
+      b12 = base_lds<12>(e1, bp, st, o12); b13 = base_lds<13>(d1, bp, st, o13); b14 = base_lds<14>(e1, bp, st, o14); b15 = base_lds<15>(d1, bp, st, o15);
     } else {
       const uint32_t qstride = (uint32_t)ncyc * 17u;
       b0 = base<0>(ch, nb, v0, c0, Q, st, cyc0, ci, qstride); b1 = base<1>(ch, nb, v0, c0, Q, st, cyc0, ci, qstride);
@@ -1013,25 +1019,34 @@ struct ApplyBody {
     ch.w1 = b4 | (b5 << 8) | (b6 << 16) | (b7 << 24);
     ch.w2 = b8 | (b9 << 8) | (b10 << 16) | (b11 << 24);
     ch.w3 = b12 | (b13 << 8) | (b14 << 16) | (b15 << 24);
-    if (LDSLUT && (any & 0x80000000u)) fixup(ch, orig, nb, CV, CX, Q, st, cyc0, ci);
-    ch.store(qual + qpos, nb);
+    if (LDSLUT) {
+      const uint32_t any = (ch.w0 | ch.w1) | (ch.w2 | ch.w3);
+      ch.w0 = keep_low(orig.w0, ch.w0); ch.w1 = keep_low(orig.w1, ch.w1); ch.w2 = keep_low(orig.w2, ch.w2); ch.w3 = keep_low(orig.w3, ch.w3);
+      if (any & 0x80808080u) fixup(ch, orig, nb, CV, CX, Q, st, cyc0, ci);
+    }
+    out = ch; out_at = qpos; out_nb = nb;
+  }
+  __device__ __forceinline__ void retire() {
+    if (out_nb) out.store(qual + out_at, out_nb);
+    out_nb = 0;
   }
   __device__ __forceinline__ void group_end(uint32_t, uint32_t) {}
   __device__ __forceinline__ void tile_end(uint32_t, uint64_t) {}
 };
 
 template <bool CHECK_CYCLE, bool LDSLUT>
-__global__ __launch_bounds__(LDSLUT ? 1024 : FL_THREADS, LDSLUT ? 4 : 4) void k_bqsr_apply_flat(ApplyArgs A, QSlots slots) {
-  __shared__ FlatLds L;
-  __shared__ uint64_t s_desc[FL_RMAX];
-  __shared__ uint32_t s_seq[FL_RMAX];
+__global__ __launch_bounds__(LDSLUT ? 1024 : FL_THREADS, 4) void k_bqsr_apply_flat(ApplyArgs A, QSlots slots) {
+  constexpr int RMAX = ApplyBody<CHECK_CYCLE, LDSLUT>::RMAX;
+  __shared__ FlatLds<RMAX> L;
+  __shared__ uint64_t s_desc[RMAX];
+  __shared__ uint32_t s_seq[RMAX];
   __shared__ uint32_t qoff[256];
   extern __shared__ __attribute__((aligned(16))) uint8_t llut[];
   if (LDSLUT) {
     constexpr int NT = ApplyBody<CHECK_CYCLE, LDSLUT>::NT;
     for (int q = threadIdx.x; q < 256; q += NT)
-      qoff[q] = q < 6 ? QOFF_KEEP : (q >= ELP_NQUAL ? QOFF_BAD : (slots.slot[q] == 255 ? QOFF_TODO : (uint32_t)slots.slot[q] * (uint32_t)((2 * A.lmax + 1) * 17)));
-    const int nbytes = A.n_cov * A.n_slot * (2 * A.lmax + 1) * 17;
+      qoff[q] = (uint32_t)((q < 6 ? 0 : (q >= ELP_NQUAL || slots.slot[q] == 255 ? A.n_slot : (int)slots.slot[q])) * ((2 * A.lmax + 1) * 17));
+    const int nbytes = A.n_cov * (A.n_slot + 1) * (2 * A.lmax + 1) * 17;
     const uint4 *src = reinterpret_cast<const uint4 *>(A.clut);  // padded to 16 bytes by the builder
     uint4 *dst = reinterpret_cast<uint4 *>(llut);
     for (int k = threadIdx.x; k < (nbytes + 15) / 16; k += NT) dst[k] = src[k];
@@ -1040,8 +1055,9 @@ __global__ __launch_bounds__(LDSLUT ? 1024 : FL_THREADS, LDSLUT ? 4 : 4) void k_
   ApplyBody<CHECK_CYCLE, LDSLUT> B;
   B.seq_off = A.seq_off; B.qual = A.qual; B.seq4 = A.seq4; B.desc = reinterpret_cast<const uint64_t *>(A.desc); B.lut = A.lut;
   B.max_cycle = A.max_cycle; B.s_desc = s_desc; B.s_seq = s_seq;
-  B.qoff = qoff; B.llut = llut; B.lmax = A.lmax; B.n_slot = A.n_slot;
+  B.qoff = qoff; B.llut_at = lds_address(llut); B.lmax = A.lmax; B.n_slot = A.n_slot;
   B.err = 0;
+  B.out_nb = 0; B.out_at = 0; B.out.w0 = B.out.w1 = B.out.w2 = B.out.w3 = 0;
   flat_run(A.qual_off, A.n, A.qual_bytes, A.tile_first, L, B);
   uint32_t my_err = B.err;
   if (__any(my_err != 0)) {
@@ -1050,14 +1066,16 @@ __global__ __launch_bounds__(LDSLUT ? 1024 : FL_THREADS, LDSLUT ? 4 : 4) void k_
   }
 }
 
-// dense LUT -> compact LUT of the resident quality slots and the cycles a read of at most lmax bases can have
+// dense LUT -> compact LUT [n_cov][n_slot + 1][2 * lmax + 1][17] of the resident quality slots and the cycles a read of at most
+// lmax bases can have
 __global__ __launch_bounds__(256) void k_compact_lut(const uint8_t *__restrict__ lut, uint8_t *__restrict__ clut, int n_cov, int n_slot, int lmax,
                                                      int max_cycle, QSlots slot_q) {
   const int ncl = 2 * lmax + 1, ncyc = 2 * max_cycle + 1;
-  const int total = n_cov * n_slot * ncl * 17;
+  const int total = n_cov * (n_slot + 1) * ncl * 17;
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= total) return;
-  const int cx = id % 17, x = (id / 17) % ncl, slot = (id / (17 * ncl)) % n_slot, cov = id / (17 * ncl * n_slot);
+  const int cx = id % 17, x = (id / 17) % ncl, slot = (id / (17 * ncl)) % (n_slot + 1), cov = id / (17 * ncl * (n_slot + 1));
+  if (slot == n_slot) { clut[id] = 0x80; return; }  // the block the qualities without a slot point at
   const int q = slot_q.slot[slot], cyc = x - lmax;
   clut[id] = lut[(((size_t)cov * ELP_NQUAL + q) * ncyc + (size_t)(cyc + max_cycle)) * 17 + cx];
 }
@@ -1138,9 +1156,10 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
     const bool check_cycle = lmax > max_cycle;
     const int rs = (CT_CYC + ((17 * 2 * lmax) >> 4) + 1 + 1) & ~1;  // words per row
     const size_t per_slot = (size_t)c->n_cov * (size_t)rs * 4;
-    const size_t static_lds = sizeof(FlatLds) + (size_t)FL_RMAX * (sizeof(BqDesc) + 4) + 1024 + 96 + 64 + 8 + (size_t)CT_PAD * 4 + (size_t)REF_LDS * 16 + (size_t)FL_RMAX * 12;
+    typedef CountBody<false, true> CB;
+    const size_t static_lds = sizeof(FlatLds<CB::RMAX>) + (size_t)CB::RMAX * (sizeof(BqDesc) + 4) + 1024 + 96 + 64 + 8 + (size_t)CT_PAD * 4 + (size_t)REF_LDS * 16 + (size_t)CB::RMAX * 12;
     const size_t lds_cu = 160 * 1024;
-    const uint64_t ntiles = (c->qual_bytes + FL_TILE - 1) / FL_TILE;
+    const uint64_t nsteps = flat_steps<CB>(c->qual_bytes);
     for (int attempt = 0;; attempt++) {
       // quality values to give table slots (>= 6, <= 93)
       std::vector<int> quals;
@@ -1156,7 +1175,7 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
         if (cap >= (int)quals.size() || w == 1) { wg_per_cu = w; qcap = cap; break; }
       }
       if (qcap < 1) return set_error(c, ELP_ERR_UNSUPPORTED, "BQSR private tables do not fit in LDS (n_cov=%d, max read length=%d)", c->n_cov, lmax);
-      const int grid = (int)std::min<uint64_t>(ntiles, (uint64_t)wg_per_cu * (uint64_t)c->n_cu);
+      const int grid = (int)std::min<uint64_t>(nsteps, (uint64_t)wg_per_cu * (uint64_t)c->n_cu);
       for (size_t q0 = 0; q0 < quals.size(); q0 += (size_t)qcap) {
         const int nqs = (int)std::min<size_t>((size_t)qcap, quals.size() - q0);
         QMap qm;
@@ -1279,8 +1298,9 @@ int elp_bqsr_apply(elp_ctx *c, int max_cycle, const uint8_t *lut, const uint8_t 
                (const uint16_t *)c->rgid.p, (const uint16_t *)c->rg_cov.p, (const uint32_t *)c->l_seq.p, (const uint64_t *)c->qual_off.p,
                (const uint64_t *)c->qbounds.p, (const uint8_t *)(dl + lut_bytes), desc, c->err_flag.p);
     if (c->qual_bytes) {
-      const uint64_t ntiles = (c->qual_bytes + FL_TILE - 1) / FL_TILE;
-      const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, (uint64_t)c->n_cu * 8);
+      typedef ApplyBody<false, true> AB;
+      const uint64_t nsteps = flat_steps<AB>(c->qual_bytes);
+      const unsigned grid = (unsigned)std::min<uint64_t>(nsteps, (uint64_t)c->n_cu * 8);
       ELP_TRY(ensure_flat_index(c));
       // LDS-resident compact LUT when [n_cov][resident qualities][2*lmax+1][17] fits beside the kernel's static LDS
       ELP_TRY(ensure_qual_present(c));
@@ -1290,8 +1310,8 @@ int elp_bqsr_apply(elp_ctx *c, int max_cycle, const uint8_t *lut, const uint8_t 
       const int lmax = (int)std::max<uint32_t>(c->max_l_seq, 1);
       const bool chk = (int64_t)c->max_l_seq > (int64_t)max_cycle;
       const size_t per_slot = (size_t)c->n_cov * (size_t)(2 * lmax + 1) * 17;
-      const size_t lds_budget = 160 * 1024 - (sizeof(FlatLds) + (size_t)FL_RMAX * 12 + 1024 + 512);
-      const size_t cbytes = per_slot * quals.size();
+      const size_t lds_budget = 160 * 1024 - (sizeof(FlatLds<AB::RMAX>) + (size_t)AB::RMAX * 12 + 1024 + 512);
+      const size_t cbytes = per_slot * (quals.size() + 1);  // + the 0x80 block
       ApplyArgs A{n, c->qual_bytes, c->qual_off.p, c->seq_off.p, c->qual.p, c->seq4.p, desc, c->tile_first.p, dl, max_cycle, c->err_flag.p,
                   nullptr, c->n_cov, (int)quals.size(), lmax};
       QSlots qs, sq;
@@ -1306,7 +1326,7 @@ int elp_bqsr_apply(elp_ctx *c, int max_cycle, const uint8_t *lut, const uint8_t 
         A.clut = clut;
         const size_t dyn = (cbytes + 15) & ~(size_t)15;
         ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bqsr_apply_flat<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-        const unsigned g1 = (unsigned)std::min<uint64_t>(ntiles, (uint64_t)c->n_cu);
+        const unsigned g1 = (unsigned)std::min<uint64_t>(nsteps, (uint64_t)c->n_cu);
         ELP_LAUNCH(c, "bqsr_apply", (k_bqsr_apply_flat<false, true>), dim3(g1), dim3(1024), dyn, A, qs);
       } else if (chk) {
         ELP_LAUNCH(c, "bqsr_apply", (k_bqsr_apply_flat<true, false>), dim3(grid), dim3(FL_THREADS), 0, A, qs);

@@ -21,12 +21,12 @@ constexpr int FL_THREADS = 512;                  // default workgroup size; ever
                                                  // blockDim.x is a load from the dispatch packet, and a load inside the block loop drains
                                                  // vmcnt, i.e. waits for the prefetched loads of the next block)
 constexpr int FL_CHUNK = 16;                     // bases per block
-constexpr uint64_t FL_TILE = 32768;              // QUAL bytes per tile
-constexpr int FL_RMAX = 256;                     // reads held in LDS at a time (150-base reads: ~220 per tile)
-constexpr uint32_t FL_MAX_READ = 0x3FFFFFu;      // per-read QUAL length limit (group-relative 32-bit offsets: FL_RMAX reads must stay < 2^31)
+constexpr uint64_t FL_TILE = 32768;              // QUAL bytes per index tile (tile_first); a workgroup step covers Body::TILES of them
+constexpr uint32_t FL_MAX_READ = 0x3FFFFFu;      // per-read QUAL length limit (group-relative offsets < step bytes + FL_MAX_READ stay 32-bit)
 
+template <int RMAX>
 struct FlatLds {
-  uint32_t off[FL_RMAX + 4];  // QUAL offsets of the group's reads minus the first one's (n+1 used; sized to keep LDS 16-byte aligned)
+  uint32_t off[RMAX + 4];  // QUAL offsets of the group's reads minus the first one's (n+1 used; sized to keep LDS 16-byte aligned)
 };
 
 int ensure_flat_index(elp_ctx *c);  // builds c->tile_first for the staged QUAL column (sort.hip)
@@ -130,26 +130,35 @@ struct Chunk {
 
 // Drives one workgroup over its tiles.  Body provides:
 //   static constexpr int NT                                   workgroup size the kernel is launched with
+//   static constexpr int TILES, RMAX                          index tiles per workgroup step; reads held in LDS at a time (a step's
+//                                                             reads are handled in groups of at most RMAX)
 //   struct Pre                                                the registers a block's global loads land in (+ what identifies it)
 //   void stage(uint32_t g0, uint32_t ng)                      all threads: put per-read data of reads [g0, g0+ng) into LDS
 //   bool prefetch(uint32_t rl, int k0, int nb, uint64_t qpos, Pre &)
 //                                                             per lane: ISSUE the global loads of bases [k0, k0+nb) of read g0+rl
 //                                                             (k0 a multiple of 16, 1 <= nb <= 16; first QUAL byte at column offset
 //                                                             qpos) without using their results; false = nothing to do for the block
-//   void process(Pre &)                                       per lane: the block's work
+//   void process(Pre &)                                       per lane: the block's work, except its global stores
+//   void retire()                                             per lane: issue the global stores of the block processed last.  Called
+//                                                             in front of the next prefetch: a store issued behind the prefetch loads
+//                                                             would sit in the same in-order counter (vmcnt) and be waited for, with
+//                                                             its full latency, as soon as the loaded registers are needed
 //   void group_end(uint32_t g0, uint32_t ng)                  all threads, after a barrier
 //   void tile_end(uint32_t nreads, uint64_t nbases)           all threads (uniform), may contain barriers
 // The lane's next block is prefetched before the current one is processed, so the HBM latency of block i+1 hides behind the ALU
 // and LDS work of block i (the loads stay in flight across the loop's back edge).
 // tile_first[t] = first read whose QUAL offset is >= t * FL_TILE (tile_first[ntiles] = n_reads).
+// flat_steps(): number of workgroup steps of a body over a column = the most workgroups worth launching.
 template <class Body>
 __device__ __forceinline__ void flat_run(const uint64_t *__restrict__ qual_off, uint64_t n_reads, uint64_t qual_bytes,
-                                         const uint32_t *__restrict__ tile_first, FlatLds &L, Body &B) {
-  const uint64_t ntiles = (qual_bytes + FL_TILE - 1) / FL_TILE;
-  for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const uint32_t r_first = tile_first[t], r_end = tile_first[t + 1];
-    for (uint32_t g0 = r_first; g0 < r_end; g0 += FL_RMAX) {
-      const uint32_t ng = (r_end - g0 < (uint32_t)FL_RMAX) ? r_end - g0 : (uint32_t)FL_RMAX;  // reads [g0, g0 + ng)
+                                         const uint32_t *__restrict__ tile_first, FlatLds<Body::RMAX> &L, Body &B) {
+  constexpr uint32_t RMAX = Body::RMAX;
+  const uint64_t ntiles = (qual_bytes + FL_TILE - 1) / FL_TILE, nsteps = (ntiles + Body::TILES - 1) / Body::TILES;
+  for (uint64_t t = blockIdx.x; t < nsteps; t += gridDim.x) {
+    const uint64_t t1 = (t + 1) * Body::TILES < ntiles ? (t + 1) * Body::TILES : ntiles;
+    const uint32_t r_first = tile_first[t * Body::TILES], r_end = tile_first[t1];
+    for (uint32_t g0 = r_first; g0 < r_end; g0 += RMAX) {
+      const uint32_t ng = (r_end - g0 < RMAX) ? r_end - g0 : RMAX;  // reads [g0, g0 + ng)
       const uint64_t base = qual_off[g0];
       for (uint32_t k = threadIdx.x; k <= ng; k += Body::NT) L.off[k] = (uint32_t)(qual_off[g0 + k] - base);
       B.stage(g0, ng);
@@ -195,6 +204,7 @@ __device__ __forceinline__ void flat_run(const uint64_t *__restrict__ qual_off, 
       bool have = s < nslots ? fetch(s, cur) : false;
 #pragma unroll 1
       while (s < nslots) {
+        B.retire();
         const uint32_t sn = s + Body::NT;
         typename Body::Pre nxt;
         const bool have_n = sn < nslots ? fetch(sn, nxt) : false;
@@ -203,12 +213,19 @@ __device__ __forceinline__ void flat_run(const uint64_t *__restrict__ qual_off, 
         have = have_n;
         s = sn;
       }
+      B.retire();
       __syncthreads();
       B.group_end(g0, ng);
       __syncthreads();
     }
     B.tile_end(r_end - r_first, qual_off[r_end] - qual_off[r_first]);
   }
+}
+
+template <class Body>
+inline uint64_t flat_steps(uint64_t qual_bytes) {
+  const uint64_t ntiles = (qual_bytes + FL_TILE - 1) / FL_TILE;
+  return (ntiles + Body::TILES - 1) / Body::TILES;
 }
 
 }  // namespace elp

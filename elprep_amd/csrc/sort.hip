@@ -70,15 +70,15 @@ __device__ __forceinline__ uint32_t first_bytes32(int n) { return n <= 0 ? 0u : 
 // computePhredScore :57-68 as a flat stream over the QUAL column: sum of qualities >= 15 per duplicate-marking candidate;
 // any quality > 93 in a candidate is an error.  SWAR over the lane's 16 bytes, v_sad_u8 for the byte sums.
 struct ScoreBody {
-  static constexpr int NT = FL_THREADS;
+  static constexpr int NT = FL_THREADS, TILES = 4, RMAX = 1024;
   const uint16_t *__restrict__ flag;
   const uint8_t *__restrict__ qual;
   int32_t *score;
   uint64_t *qbounds;
-  int32_t *acc;    // LDS [FL_RMAX]: per-read partial sums of this group (LDS atomics; one global store per read)
-  uint32_t *lo;    // LDS [FL_RMAX]: index of the first quality > 2 of the read (0xFFFFFFFF: none yet)
-  uint32_t *hi;    // LDS [FL_RMAX]: 1 + index of the last quality > 2 (0: none yet)
-  uint8_t *cand;   // LDS [FL_RMAX]: duplicate-marking candidate?
+  int32_t *acc;    // LDS [RMAX]: per-read partial sums of this group (LDS atomics; one global store per read)
+  uint32_t *lo;    // LDS [RMAX]: index of the first quality > 2 of the read (0xFFFFFFFF: none yet)
+  uint32_t *hi;    // LDS [RMAX]: 1 + index of the last quality > 2 (0: none yet)
+  uint8_t *cand;   // LDS [RMAX]: duplicate-marking candidate?
   uint32_t bad;
 
   __device__ __forceinline__ void stage(uint32_t g0, uint32_t ng) {
@@ -129,16 +129,17 @@ struct ScoreBody {
       qbounds[g0 + k] = (uint64_t)hi[k] | ((uint64_t)lo[k] << 32);  // all-zero = no quality > 2
     }
   }
+  __device__ __forceinline__ void retire() {}
   __device__ __forceinline__ void tile_end(uint32_t, uint64_t) {}
 };
 
 __global__ __launch_bounds__(FL_THREADS) void k_score_flat(uint64_t n, const uint64_t *__restrict__ qual_off, const uint8_t *__restrict__ qual,
                                                            uint64_t qual_bytes, const uint32_t *__restrict__ tile_first,
                                                            const uint16_t *__restrict__ flag, int32_t *score, uint64_t *qbounds, uint32_t *err) {
-  __shared__ FlatLds L;
-  __shared__ int32_t acc[FL_RMAX];
-  __shared__ uint32_t lo[FL_RMAX], hi[FL_RMAX];
-  __shared__ uint8_t cand[FL_RMAX];
+  __shared__ FlatLds<ScoreBody::RMAX> L;
+  __shared__ int32_t acc[ScoreBody::RMAX];
+  __shared__ uint32_t lo[ScoreBody::RMAX], hi[ScoreBody::RMAX];
+  __shared__ uint8_t cand[ScoreBody::RMAX];
   ScoreBody B{flag, qual, score, qbounds, acc, lo, hi, cand, 0u};
   flat_run(qual_off, n, qual_bytes, tile_first, L, B);
   if (__any(B.bad != 0) && (threadIdx.x & 63) == 0) atomicOr(&err[0], 1u);
@@ -231,8 +232,7 @@ int ensure_adapted(elp_ctx *c, bool check_quals) {
                (const uint16_t *)c->flag.p, (const uint64_t *)c->cigar_off.p, (const uint32_t *)c->cigar.p, c->upos.p, c->score.p, c->key.p,
                (uint32_t)c->n_ref, pos_bits);
     if (c->qual_bytes) {
-      const uint64_t ntiles = (c->qual_bytes + FL_TILE - 1) / FL_TILE;
-      const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * 4);
+      const unsigned grid = (unsigned)std::min<uint64_t>(flat_steps<ScoreBody>(c->qual_bytes), (uint64_t)c->n_cu * 4);
       ELP_LAUNCH(c, "adapt_score", k_score_flat, dim3(grid), dim3(FL_THREADS), 0, n, (const uint64_t *)c->qual_off.p, (const uint8_t *)c->qual.p,
                  c->qual_bytes, (const uint32_t *)c->tile_first.p, (const uint16_t *)c->flag.p, c->score.p, c->qbounds.p, c->err_flag.p);
     }
