@@ -1088,6 +1088,7 @@ static int bqsr_error(elp_ctx *c, uint32_t e) {
   if (e & 16u) return set_error(c, ELP_ERR_DATA, "cycle value exceeds maximum cycle value (reference: log.Panic, filters/bqsr.go:364-369)");
   if (e & 32u) return set_error(c, ELP_ERR_DATA, "BQSR requires input with read groups (reference: log.Panic, filters/bqsr.go:38)");
   if (e & 64u) return set_error(c, ELP_ERR_DATA, "ApplyBQSR: len(QUAL) != len(SEQ) (reference: index out of range panic)");
+  if (e & 256u) return set_error(c, ELP_ERR_HIP, "radix sort: tile look-back timed out");
   return set_error(c, ELP_ERR_DATA, "BQSR: device error word %u", e);
 }
 

@@ -94,6 +94,9 @@ struct elp_ctx {
   elp::DVec<uint32_t> perm;     // sorted position -> staging index
   elp::DVec<uint32_t> err_flag; // device-side error word(s)
   elp::DVec<uint32_t> tile_first;  // flat.hpp tile index over the QUAL column
+  elp::DVec<unsigned long long> radix_state;  // radix.hip: per (tile, digit) look-back words, tagged with the pass epoch
+  elp::DVec<uint32_t> radix_ticket;           // radix.hip: tile ticket counters
+  uint32_t radix_epoch = 0;
   uint64_t flat_index_n = 0, flat_index_bytes = 0;
 
   // mark-duplicates results kept for the metrics pass

@@ -4,9 +4,11 @@
 // sort.StableSort in the reference) and the tie-break / grouping passes.  8-bit digits; digit positions whose
 // histogram has a single non-empty bin are skipped (the 64-bit coordinate key of a human genome has ~5 live bytes).
 //
-// Per live pass:  k_radix_tile_hist (LDS histogram per 4096-key tile)  ->  exclusive scan of the [256][tiles] count
-// matrix  ->  k_radix_scatter (wave64 ballot multisplit: stable local ranks, then direct scatter).
-// HBM traffic per key per pass: 8 (hist) + 12 (read) + 12 (write) = 32 B.
+// Per live pass ONE kernel, k_radix_scatter: wave64 ballot multisplit of a 4096-key tile (stable local ranks), the tile's
+// global bin offsets by decoupled look-back over the tiles in front of it (tiles take tickets, so a tile only ever waits
+// for tiles that are already running), digit-ordered staging in LDS, scatter.  The global digit histograms of all eight
+// digit positions come from one sweep up front (k_radix_hist_all), which also decides the live passes.
+// HBM traffic per key per pass: 12 (read) + 12 (write) = 24 B, + 8 B once for the histogram sweep.
 #include "common.hpp"
 
 namespace elp {
@@ -181,48 +183,31 @@ __global__ __launch_bounds__(256) void k_radix_hist_all(const uint64_t *__restri
   }
 }
 
-// per-tile digit histogram, written digit-major: counts[d * ntiles + tile]
-__global__ __launch_bounds__(RS_THREADS) void k_radix_tile_hist(const uint64_t *__restrict__ keys, uint64_t n, int shift,
-                                                                uint32_t *__restrict__ counts, uint32_t ntiles) {
-  __shared__ uint32_t h[256];
-  h[threadIdx.x] = 0;
-  __syncthreads();
-  uint64_t base = (uint64_t)blockIdx.x * RS_TILE;
-#pragma unroll
-  for (int r = 0; r < RS_ITEMS; r++) {
-    uint64_t i = base + (uint64_t)r * RS_THREADS + threadIdx.x;
-    bool valid = i < n;
-    uint32_t dg = valid ? (uint32_t)(keys[i] >> shift) & 0xFF : 0u;
-    const unsigned long long act = __ballot(valid);
-    if (act == 0) continue;
-    const int first = __ffsll((long long)act) - 1;
-    uint32_t d0 = __shfl(dg, first, 64);
-    if (__all(!valid || dg == d0)) {
-      if ((int)(threadIdx.x & 63) == first) atomicAdd(&h[d0], (uint32_t)__popcll(act));
-    } else if (valid) {
-      atomicAdd(&h[dg], 1u);
-    }
-  }
-  __syncthreads();
-  counts[(uint64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
-}
-
 // stable scatter.  Element order inside a tile: wave-major, then round, then lane (== index order, because each wave
 // owns a contiguous 1024-key sub-tile and reads it 64 keys per round).  Keys (then values) are first reordered by digit inside
 // the tile through LDS, so that the global stores of a workgroup are runs of consecutive addresses per digit (on average 16
 // keys = 128 bytes with 4096-key tiles and 256 bins) instead of 64 scattered 8-byte stores per wave instruction.
+//
+// Look-back word of (tile, digit): [63:34] pass epoch, [33:32] 1 = the tile's own count, 2 = inclusive count over tiles 0..tile,
+// [31:0] the count.  Words of earlier passes carry an older epoch and read as "not there yet", so the array is never cleared.
+constexpr unsigned long long RS_AGG = 1ull << 32, RS_INCL = 2ull << 32;
+
 __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
                                                               uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint64_t n,
-                                                              int shift, const uint32_t *__restrict__ offsets /* scanned counts */,
-                                                              uint32_t ntiles) {
+                                                              int shift, const unsigned long long *__restrict__ ghist /* [256] of this digit */,
+                                                              unsigned long long *state, uint32_t epoch, uint32_t *ticket,
+                                                              uint32_t *err) {
   __shared__ uint32_t cnt[RS_WAVES][256];
   __shared__ uint32_t gbase[256];   // global position of the tile's first key with digit d, minus its position inside the sorted tile
   __shared__ uint32_t scan_lds[8];
   __shared__ uint64_t sbuf[RS_TILE];  // the tile in digit order: keys first, then (as uint32) the values
+  __shared__ uint32_t my_tile;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (threadIdx.x == 0) my_tile = atomicAdd(ticket, 1u);  // tiles are numbered in the order they start (the host zeroes the counter)
   for (int i = threadIdx.x; i < RS_WAVES * 256; i += RS_THREADS) (&cnt[0][0])[i] = 0;
   __syncthreads();
-  const uint64_t tbase = (uint64_t)blockIdx.x * RS_TILE;
+  const uint32_t tile = my_tile;
+  const uint64_t tbase = (uint64_t)tile * RS_TILE;
   const uint64_t wbase = tbase + (uint64_t)w * (64 * RS_ITEMS);
   const uint32_t tile_n = (uint32_t)((n - tbase) < (uint64_t)RS_TILE ? (n - tbase) : (uint64_t)RS_TILE);
   uint64_t k[RS_ITEMS];
@@ -269,7 +254,29 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint64_t *__
       cnt[i][threadIdx.x] = run;
       run += t;
     }
-    gbase[threadIdx.x] = offsets[(uint64_t)threadIdx.x * ntiles + blockIdx.x] - tstart;
+    // first output position of digit t: keys with a smaller digit (global histogram) + keys with digit t in the tiles in front
+    uint32_t dall;
+    const uint32_t dbase = block_excl_scan_256((uint32_t)ghist[threadIdx.x], &dall, scan_lds);
+    const unsigned long long tag = (unsigned long long)epoch << 34;
+    unsigned long long *mine = state + (size_t)tile * 256 + threadIdx.x;
+    uint32_t prefix = 0;
+    if (tile == 0) {
+      __hip_atomic_store(mine, tag | RS_INCL | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      __hip_atomic_store(mine, tag | RS_AGG | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (const unsigned long long *p = mine - 256;; p -= 256) {
+        unsigned long long v;
+        uint32_t spins = 0;
+        while (((v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 34) != epoch) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins == (1u << 24)) { atomicOr(err, 256u); v = RS_INCL; break; }  // seconds: something is broken, do not hang the device
+        }
+        prefix += (uint32_t)v;
+        if (v & RS_INCL) break;
+      }
+      __hip_atomic_store(mine, tag | RS_INCL | (prefix + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    gbase[threadIdx.x] = dbase + prefix - tstart;
   }
   __syncthreads();
   // keys into digit order
@@ -322,10 +329,18 @@ int radix_sort_pairs(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *keys_
   ELP_LAUNCH(c, "radix_hist_all", k_radix_hist_all, dim3(hb), dim3(256), 0, (const uint64_t *)keys, n, ghist);
   unsigned long long hh[8 * 256];
   ELP_HIP(c, hipMemcpyAsync(hh, ghist, sizeof hh, hipMemcpyDeviceToHost, c->stream));
+  uint32_t dev_err = 0;
+  ELP_HIP(c, hipMemcpyAsync(&dev_err, c->err_flag.p, 4, hipMemcpyDeviceToHost, c->stream));
   ELP_HIP(c, hipStreamSynchronize(c->stream));
-  uint32_t ntiles = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
-  uint32_t *counts;
-  ELP_TRY(scratch(c, 5, (size_t)256 * ntiles + 8, &counts));
+  if (dev_err & 256u) return set_error(c, ELP_ERR_HIP, "radix sort: tile look-back timed out");
+  const uint32_t ntiles = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
+  if ((size_t)ntiles * 256 > c->radix_state.cap) {
+    ELP_TRY(ensure(c, c->radix_state, (size_t)ntiles * 256));
+    ELP_HIP(c, hipMemsetAsync(c->radix_state.p, 0, c->radix_state.cap * sizeof(unsigned long long), c->stream));
+    c->radix_epoch = 0;
+  }
+  ELP_TRY(ensure(c, c->radix_ticket, 8));  // one ticket counter per digit position
+  ELP_HIP(c, hipMemsetAsync(c->radix_ticket.p, 0, 8 * sizeof(uint32_t), c->stream));
   uint64_t *ksrc = keys, *kdst = keys_tmp;
   uint32_t *vsrc = vals, *vdst = vals_tmp;
   for (int d = 0; d < 8; d++) {
@@ -333,11 +348,13 @@ int radix_sort_pairs(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *keys_
     for (int b = 0; b < 256; b++)
       if (hh[d * 256 + b] == n) { live = false; break; }
     if (!live) continue;
-    int shift = 8 * d;
-    ELP_LAUNCH(c, "radix_tile_hist", k_radix_tile_hist, dim3(ntiles), dim3(RS_THREADS), 0, (const uint64_t *)ksrc, n, shift, counts, ntiles);
-    ELP_TRY(exclusive_scan_u32(c, counts, counts, (uint64_t)256 * ntiles, nullptr));
+    if (++c->radix_epoch >= (1u << 30)) {  // the tag wrapped: forget every word
+      ELP_HIP(c, hipMemsetAsync(c->radix_state.p, 0, c->radix_state.cap * sizeof(unsigned long long), c->stream));
+      c->radix_epoch = 1;
+    }
     ELP_LAUNCH(c, "radix_scatter", k_radix_scatter, dim3(ntiles), dim3(RS_THREADS), 0, (const uint64_t *)ksrc, (const uint32_t *)vsrc, kdst,
-               vdst, n, shift, (const uint32_t *)counts, ntiles);
+               vdst, n, 8 * d, (const unsigned long long *)(ghist + d * 256), c->radix_state.p, c->radix_epoch, c->radix_ticket.p + d,
+               c->err_flag.p);
     std::swap(ksrc, kdst);
     std::swap(vsrc, vdst);
   }
