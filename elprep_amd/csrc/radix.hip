@@ -264,15 +264,28 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint64_t *__
       __hip_atomic_store(mine, tag | RS_INCL | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       __hip_atomic_store(mine, tag | RS_AGG | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      for (const unsigned long long *p = mine - 256;; p -= 256) {
-        unsigned long long v;
-        uint32_t spins = 0;
-        while (((v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 34) != epoch) {
-          __builtin_amdgcn_s_sleep(1);
-          if (++spins == (1u << 24)) { atomicOr(err, 256u); v = RS_INCL; break; }  // seconds: something is broken, do not hang the device
+      // walk back over the tiles in front, eight words per round trip (device-scope loads cross the XCDs: ~1 us each)
+      constexpr int LB = 8;
+      uint32_t back = 1, spins = 0;  // next tile to look at: tile - back
+      bool done = false;
+      while (!done) {
+        unsigned long long v[LB];
+#pragma unroll
+        for (int i = 0; i < LB; i++) {
+          const uint32_t b = back + (uint32_t)i;
+          v[i] = b <= tile ? __hip_atomic_load(mine - (size_t)b * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (tag | RS_INCL);
         }
-        prefix += (uint32_t)v;
-        if (v & RS_INCL) break;
+#pragma unroll
+        for (int i = 0; i < LB; i++) {
+          if (done || (v[i] >> 34) != epoch) break;  // not published yet: poll again from here
+          prefix += (uint32_t)v[i];
+          back++;
+          done = (v[i] & RS_INCL) != 0;
+        }
+        if (!done) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins == (1u << 22)) { atomicOr(err, 256u); break; }  // seconds: something is broken, do not hang the device
+        }
       }
       __hip_atomic_store(mine, tag | RS_INCL | (prefix + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
