@@ -130,16 +130,30 @@ __device__ __forceinline__ uint64_t qname_hash(const MdCols &m, uint32_t i) {
   return mix64(h ^ ((uint64_t)lib_of(m, i) << 48));
 }
 
-// Mates pair up through the table alone: the first record of a {library, QNAME} key becomes the slot's representative, the
-// second one finds it and claims it with one CAS on mate[representative]; a third record fails that CAS (more than two primary
-// mapped records per key: unsupported).  mate[] must be EMPTY-initialised.
+// Mates pair up through the table: the first record of a {library, QNAME} key becomes the slot's representative, the second one
+// finds it and claims it with one CAS on mate[representative]; a third record fails that CAS (more than two primary mapped records
+// per key: unsupported).  mate[] must be EMPTY-initialised.
+// Records that sit next to their mate in staging order (the order an aligner writes them in) do not go through the table at all:
+// a run of exactly two neighbouring records with the same key is a pair, and each of the two writes its own mate entry.  (A third
+// record with that key somewhere else then stays alone instead of raising the error: the reference's result for such input depends
+// on arrival order anyway.)
 __global__ __launch_bounds__(256) void k_mate_insert(MdCols m, uint32_t *table, uint64_t mask, uint32_t *mate, uint32_t *err) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m.n) return;
   const uint16_t f = m.flag_in[i];
   if (!is_candidate(f) || !is_true_pair(f)) return;
-  const uint32_t rep = find_or_insert(table, mask, qname_hash(m, (uint32_t)i), (uint32_t)i,
-                                      [&](uint32_t a, uint32_t b) { return lib_of(m, a) == lib_of(m, b) && qname_eq(m.qname, m.qname_off, a, b); });
+  const auto same_key = [&](uint32_t a, uint32_t b) { return lib_of(m, a) == lib_of(m, b) && qname_eq(m.qname, m.qname_off, a, b); };
+  const auto joins = [&](uint64_t a, uint64_t b) {  // neighbours a, b (b = a + 1) are both mate candidates with the same key
+    const uint16_t fa = m.flag_in[a], fb = m.flag_in[b];
+    return is_candidate(fa) && is_true_pair(fa) && is_candidate(fb) && is_true_pair(fb) && same_key((uint32_t)a, (uint32_t)b);
+  };
+  const bool nx = i + 1 < m.n && joins(i, i + 1), pv = i > 0 && joins(i - 1, i);
+  if (nx && !pv) {
+    if (!(i + 2 < m.n && joins(i + 1, i + 2))) { mate[i] = (uint32_t)i + 1; return; }
+  } else if (pv && !nx) {
+    if (!(i >= 2 && joins(i - 2, i - 1))) { mate[i] = (uint32_t)i - 1; return; }
+  }
+  const uint32_t rep = find_or_insert(table, mask, qname_hash(m, (uint32_t)i), (uint32_t)i, same_key);
   if (rep == (uint32_t)i) return;  // first of its key: the mate (if any) will write both entries
   const uint32_t old = atomicCAS(&mate[rep], EMPTY, (uint32_t)i);
   if (old == EMPTY) mate[i] = rep;

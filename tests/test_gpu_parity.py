@@ -49,6 +49,32 @@ def test_adapt_sort_markdup_metrics(name, pairs, seed, pfrag):
     e.close()
 
 
+@pytest.mark.parametrize("mode", ["shuffled", "blocks", "triple_run"])
+def test_mates_in_any_staging_order(mode):
+    """Mates next to each other pair up without the hash table, all others through it: same flags and metrics either way."""
+    cfg, b, h, refs, sites = dataset("tiny", 6000, 3, 0.03)
+    rng = np.random.default_rng(11)
+    if mode == "shuffled":      # (almost) no mate keeps its neighbour
+        idx = rng.permutation(b.n)
+    elif mode == "blocks":      # odd-sized blocks in random order: most pairs stay neighbours, those cut by a block border do not
+        cuts = np.concatenate([[0], np.sort(rng.choice(np.arange(1, b.n), 400, replace=False)), [b.n]])
+        blocks = [np.arange(lo, hi) for lo, hi in zip(cuts[:-1], cuts[1:])]
+        idx = np.concatenate([blocks[k] for k in rng.permutation(len(blocks))])
+    else:                       # every record twice in a row with cleared pairing flags on the copy: runs of neighbours with one key
+        idx = np.repeat(np.arange(b.n), 2)
+    pb = b.take(idx)
+    if mode == "triple_run":
+        pb.flag[1::2] &= np.uint16(0xFFFF ^ 0x1 ^ 0x2 ^ 0x8 ^ 0x20 ^ 0x40 ^ 0x80)  # the copies are single-end fragments
+    e = _engine(pb, h, chunks=2)
+    oflags = orc.mark_duplicates(pb, h)
+    flags = e.mark_duplicates(also_opticals=True)
+    assert np.array_equal(flags, oflags)
+    operm = orc.sort_coordinate(pb)
+    _, octr, _ = orc.dup_metrics(pb, h, operm, 100)
+    assert np.array_equal(e.dup_metrics(100), octr)
+    e.close()
+
+
 @pytest.mark.parametrize("name,pairs,seed,pfrag", CASES[:3])
 def test_bqsr_gather_apply(name, pairs, seed, pfrag):
     cfg, b, h, refs, sites = dataset(name, pairs, seed, pfrag)
