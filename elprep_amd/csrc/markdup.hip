@@ -138,20 +138,28 @@ __device__ __forceinline__ uint64_t qname_hash(const MdCols &m, uint32_t i) {
 // record with that key somewhere else then stays alone instead of raising the error: the reference's result for such input depends
 // on arrival order anyway.)
 __global__ __launch_bounds__(256) void k_mate_insert(MdCols m, uint32_t *table, uint64_t mask, uint32_t *mate, uint32_t *err) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t base = (uint64_t)blockIdx.x * 256, i = base + threadIdx.x;
+  const auto same_key = [&](uint32_t a, uint32_t b) { return lib_of(m, a) == lib_of(m, b) && qname_eq(m.qname, m.qname_off, a, b); };
+  const auto joins = [&](uint64_t a) -> bool {  // neighbours a, a + 1 are both mate candidates with the same key
+    if (a + 1 >= m.n) return false;
+    const uint16_t fa = m.flag_in[a], fb = m.flag_in[a + 1];
+    return is_candidate(fa) && is_true_pair(fa) && is_candidate(fb) && is_true_pair(fb) && same_key((uint32_t)a, (uint32_t)a + 1);
+  };
+  // s_join[t] = joins(base - 2 + t) for t in [0, 259): every neighbour test of the block is made once
+  __shared__ uint8_t s_join[264];
+  s_join[threadIdx.x + 2] = joins(i);
+  if (threadIdx.x < 2) s_join[threadIdx.x] = base + threadIdx.x >= 2 ? joins(base - 2 + threadIdx.x) : false;
+  if (threadIdx.x == 2) s_join[258] = joins(base + 256);
+  __syncthreads();
   if (i >= m.n) return;
   const uint16_t f = m.flag_in[i];
   if (!is_candidate(f) || !is_true_pair(f)) return;
-  const auto same_key = [&](uint32_t a, uint32_t b) { return lib_of(m, a) == lib_of(m, b) && qname_eq(m.qname, m.qname_off, a, b); };
-  const auto joins = [&](uint64_t a, uint64_t b) {  // neighbours a, b (b = a + 1) are both mate candidates with the same key
-    const uint16_t fa = m.flag_in[a], fb = m.flag_in[b];
-    return is_candidate(fa) && is_true_pair(fa) && is_candidate(fb) && is_true_pair(fb) && same_key((uint32_t)a, (uint32_t)b);
-  };
-  const bool nx = i + 1 < m.n && joins(i, i + 1), pv = i > 0 && joins(i - 1, i);
+  const uint8_t *j = s_join + threadIdx.x + 2;  // j[0] = joins(i)
+  const bool nx = j[0], pv = j[-1];
   if (nx && !pv) {
-    if (!(i + 2 < m.n && joins(i + 1, i + 2))) { mate[i] = (uint32_t)i + 1; return; }
+    if (!j[1]) { mate[i] = (uint32_t)i + 1; return; }
   } else if (pv && !nx) {
-    if (!(i >= 2 && joins(i - 2, i - 1))) { mate[i] = (uint32_t)i - 1; return; }
+    if (!j[-2]) { mate[i] = (uint32_t)i - 1; return; }
   }
   const uint32_t rep = find_or_insert(table, mask, qname_hash(m, (uint32_t)i), (uint32_t)i, same_key);
   if (rep == (uint32_t)i) return;  // first of its key: the mate (if any) will write both entries
