@@ -140,11 +140,13 @@ def main():
             eng.sort_coordinate(fetch=False)
             eng.mark_duplicates(True, fetch=False)
             eng.dup_metrics(100)
-            qt, ct, xt = eng.recalibrate(MAX_CYCLE)
+            qt, ct, xt = eng.recalibrate(MAX_CYCLE, reuse=True)
             tb = BqsrTables(qt, ct, xt, MAX_CYCLE).finalize()
-            lut, present = tb.build_lut(0)
+            lut, present = tb.build_lut(0, out=lut_buf[0])
+            lut_buf[0] = (lut, present)
             eng.apply_bqsr(lut, present, MAX_CYCLE, fetch=False)
             eng.sync()
+        lut_buf = [None]  # the host side keeps its arrays from step to step, as a long-running caller would
         mode = "filter"
     else:
         # ---- `elprep sfm`: contig groups -> ranks; every rank produces the reads of the groups it owns, the few records that

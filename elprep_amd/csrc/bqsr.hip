@@ -1213,12 +1213,22 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
     ELP_LAUNCH(c, "bqsr_qual_from_cycle", k_bqsr_qual_from_cycle, dim3(c->n_cov * ELP_NQUAL), dim3(256), 0, c->n_cov * ELP_NQUAL, ncyc_g,
                (const unsigned long long *)(tb + nq), tb);
   }
-  ELP_HIP(c, hipMemcpyAsync(qual_tbl, tb, nq * 8, hipMemcpyDeviceToHost, st));
-  ELP_HIP(c, hipMemcpyAsync(cycle_tbl, tb + nq, nc * 8, hipMemcpyDeviceToHost, st));
-  ELP_HIP(c, hipMemcpyAsync(ctx_tbl, tb + nq + nc, nx * 8, hipMemcpyDeviceToHost, st));
+  // the three tables lie behind each other on the device: one copy into pinned memory, then into the caller's arrays
+  const size_t bytes = (nq + nc + nx) * 8;
+  if (bytes > c->h_pinned_cap) {
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    c->h_pinned = nullptr; c->h_pinned_cap = 0;
+    ELP_HIP(c, hipHostMalloc(&c->h_pinned, bytes, hipHostMallocDefault));
+    c->h_pinned_cap = bytes;
+  }
+  ELP_HIP(c, hipMemcpyAsync(c->h_pinned, tb, bytes, hipMemcpyDeviceToHost, st));
   uint32_t e[4];
   ELP_TRY(fetch_err(c, e));
   if (e[0]) return bqsr_error(c, e[0]);
+  const int64_t *hp = static_cast<const int64_t *>(c->h_pinned);
+  memcpy(qual_tbl, hp, nq * 8);
+  memcpy(cycle_tbl, hp + nq, nc * 8);
+  memcpy(ctx_tbl, hp + nq + nc, nx * 8);
   return 0;
 }
 

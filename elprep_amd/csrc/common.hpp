@@ -94,6 +94,8 @@ struct elp_ctx {
   elp::DVec<uint32_t> perm;     // sorted position -> staging index
   elp::DVec<uint32_t> err_flag; // device-side error word(s)
   elp::DVec<uint32_t> tile_first;  // flat.hpp tile index over the QUAL column
+  void *h_pinned = nullptr;        // pinned host staging (BQSR tables come back in one copy)
+  size_t h_pinned_cap = 0;
   elp::DVec<unsigned long long> radix_state;  // radix.hip: per (tile, digit) look-back words, tagged with the pass epoch
   elp::DVec<uint32_t> radix_ticket;           // radix.hip: tile ticket counters
   uint32_t radix_epoch = 0;

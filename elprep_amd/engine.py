@@ -125,12 +125,18 @@ class Engine:
         iv = np.ascontiguousarray(np.asarray(intervals, dtype=np.int32).reshape(-1, 2))
         self._check(self.L.elp_bqsr_set_known_sites(self.h, refid, _vp(iv), iv.shape[0]))
 
-    def recalibrate(self, max_cycle: int = 500):
+    def recalibrate(self, max_cycle: int = 500, reuse: bool = False):
+        """BaseRecalibrator tables.  reuse=True hands out the engine's own arrays (overwritten by the next call): a caller that
+        merges or finalizes right away saves the page faults of 6 MB of fresh memory per call."""
         ncyc = 2 * max_cycle + 1
         nc = self.header.n_cov
-        qt = np.zeros((nc, NQUAL, 2), dtype=np.int64)
-        ct = np.zeros((nc, NQUAL, ncyc, 2), dtype=np.int64)
-        xt = np.zeros((nc, NQUAL, NCTX, 2), dtype=np.int64)
+        bufs = getattr(self, "_tables", None) if reuse else None
+        if bufs is None or bufs[0] != (nc, max_cycle):
+            bufs = ((nc, max_cycle), np.zeros((nc, NQUAL, 2), dtype=np.int64), np.zeros((nc, NQUAL, ncyc, 2), dtype=np.int64),
+                    np.zeros((nc, NQUAL, NCTX, 2), dtype=np.int64))
+            if reuse:
+                self._tables = bufs
+        _, qt, ct, xt = bufs
         self._check(self.L.elp_bqsr_gather(self.h, max_cycle, _vp(qt), _vp(ct), _vp(xt)))
         return qt, ct, xt
 
@@ -216,10 +222,15 @@ class BqsrTables:
         assert self.H.elp_bqsr_tables_quantize(self.t, levels, _vp(counts), _vp(scores)) == 0
         return counts, scores
 
-    def build_lut(self, quantize_levels: int = 0, sqq: Sequence[int] = ()):
+    def build_lut(self, quantize_levels: int = 0, sqq: Sequence[int] = (), out=None):
+        """out: a (lut, present) pair of an earlier call to fill again (rows of covariates that are not present keep their bytes)."""
         ncyc = 2 * self.max_cycle + 1
-        lut = np.zeros((self.n_cov, NQUAL, ncyc, 17), np.uint8)
-        present = np.zeros(self.n_cov, np.uint8)
+        if out is not None and out[0].shape == (self.n_cov, NQUAL, ncyc, 17):
+            lut, present = out
+            present[:] = 0
+        else:
+            lut = np.zeros((self.n_cov, NQUAL, ncyc, 17), np.uint8)
+            present = np.zeros(self.n_cov, np.uint8)
         s = np.asarray(list(sqq), dtype=np.uint8)
         assert self.H.elp_bqsr_tables_build_lut(self.t, quantize_levels, _vp(s), s.size, _vp(lut), _vp(present)) == 0
         return lut, present

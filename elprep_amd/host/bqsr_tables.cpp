@@ -16,6 +16,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -119,18 +123,62 @@ inline uint8_t empirical(long long obs, long long mism, double prior) {  // bqsr
   return q < 93 ? q : 93;
 }
 
-// rows are independent: a handful of threads (the results do not depend on the split)
+// rows are independent (the results do not depend on the split): a small pool of workers that lives as long as the library,
+// so that a call costs two condition-variable round trips instead of thread creations; rows are handed out one at a time
+class RowPool {
+ public:
+  static RowPool &get() { static RowPool p; return p; }
+  void run(size_t n, const std::function<void(size_t)> &f) {
+    if (workers_.empty() || n < 2) { for (size_t i = 0; i < n; i++) f(i); return; }
+    std::lock_guard<std::mutex> call(call_mu_);  // one parallel region at a time
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      f_ = &f; n_ = n; next_.store(0); running_ = workers_.size(); gen_++;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> lk(mu_);
+    done_.wait(lk, [&] { return running_ == 0; });
+    f_ = nullptr;
+  }
+
+ private:
+  RowPool() {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned nt = hw > 1 ? std::min(hw, 16u) - 1 : 0;  // the caller works too
+    for (unsigned k = 0; k < nt; k++) workers_.emplace_back([this] { loop(); });
+  }
+  ~RowPool() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+    cv_.notify_all();
+    for (auto &t : workers_) t.join();
+  }
+  void work() { for (size_t i; (i = next_.fetch_add(1)) < n_;) (*f_)(i); }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+        if (stop_) return;
+        seen = gen_;
+      }
+      work();
+      std::lock_guard<std::mutex> lk(mu_);
+      if (--running_ == 0) done_.notify_one();
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex mu_, call_mu_;
+  std::condition_variable cv_, done_;
+  const std::function<void(size_t)> *f_ = nullptr;
+  size_t n_ = 0, running_ = 0;
+  std::atomic<size_t> next_{0};
+  uint64_t gen_ = 0;
+  bool stop_ = false;
+};
 template <class F>
-void parallel_rows(size_t n, F f) {
-  unsigned hw = std::thread::hardware_concurrency();
-  size_t nt = hw ? std::min<size_t>(hw, 8) : 1;
-  if (nt > n) nt = n ? n : 1;
-  if (nt <= 1) { for (size_t i = 0; i < n; i++) f(i); return; }
-  std::vector<std::thread> th;
-  for (size_t k = 0; k < nt; k++)
-    th.emplace_back([=]() { for (size_t i = k; i < n; i += nt) f(i); });
-  for (auto &x : th) x.join();
-}
+void parallel_rows(size_t n, F f) { RowPool::get().run(n, std::function<void(size_t)>(f)); }
 
 struct Interval { int next; double rate; long long nobs, leaf, nerr; };
 inline double err_rate(long long nobs, long long nerr) { return nobs == 0 ? 0.0 : double(nerr + 1) / double(nobs + 1); }
@@ -156,10 +204,12 @@ elp_bqsr_tables *elp_bqsr_tables_new(int n_cov, int max_cycle, const int64_t *qt
   auto *t = new elp_bqsr_tables();
   t->n_cov = n_cov; t->max_cycle = max_cycle; t->ncyc = 2 * max_cycle + 1;
   const size_t nq = size_t(n_cov) * NQ;
-  t->q.assign(nq * 2, 0); t->c.assign(nq * t->ncyc * 2, 0); t->x.assign(nq * NX * 2, 0);
-  if (qt) for (size_t i = 0; i < t->q.size(); i++) t->q[i] = qt[i];
-  if (ct) for (size_t i = 0; i < t->c.size(); i++) t->c[i] = ct[i];
-  if (xt) for (size_t i = 0; i < t->x.size(); i++) t->x[i] = xt[i];
+  static_assert(sizeof(long long) == sizeof(int64_t), "tables are kept as long long");
+  const auto fill = [](std::vector<long long> &v, const int64_t *src, size_t n) {
+    if (src) v.assign(reinterpret_cast<const long long *>(src), reinterpret_cast<const long long *>(src) + n);
+    else v.assign(n, 0);
+  };
+  fill(t->q, qt, nq * 2); fill(t->c, ct, nq * t->ncyc * 2); fill(t->x, xt, nq * NX * 2);
   return t;
 }
 void elp_bqsr_tables_free(elp_bqsr_tables *t) { delete t; }

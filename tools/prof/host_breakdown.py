@@ -24,7 +24,7 @@ for it in range(3):
     e.sort_coordinate(fetch=False); lap()
     e.mark_duplicates(True, fetch=False); lap()
     e.dup_metrics(100); lap()
-    qt, ct, xt = e.recalibrate(500); lap()
+    qt, ct, xt = e.recalibrate(500, reuse=True); lap()
     tb = BqsrTables(qt, ct, xt, 500); lap()
     tb.finalize(); lap()
     lut, present = tb.build_lut(0); lap()
