@@ -44,13 +44,18 @@ __device__ __forceinline__ unsigned long long ld_agent64(const unsigned long lon
 }
 
 // ---------------- fragments
-__device__ __forceinline__ bool frag_key_eq(const MdCols &m, uint32_t a, uint32_t b) {
-  return m.refid[a] == m.refid[b] && m.upos[a] == m.upos[b] && ((m.flag_in[a] ^ m.flag_in[b]) & F_REVERSED) == 0 && lib_of(m, a) == lib_of(m, b);
+// The fragment key of a record in one 16-byte word: {REFID, unclipped 5' position, LIBID << 1 | reversed, 0}.  A probe that lands on
+// an occupied slot compares against ONE random 16-byte load instead of four column gathers (the tables are at the random-access
+// limit of the memory system, so accesses are what counts).
+__global__ __launch_bounds__(256) void k_md_keys(MdCols m, uint4 *__restrict__ fkey) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.n) return;
+  fkey[i] = make_uint4((uint32_t)m.refid[i], (uint32_t)m.upos[i], ((uint32_t)lib_of(m, (uint32_t)i) << 1) | ((m.flag_in[i] & F_REVERSED) ? 1u : 0u), 0u);
 }
-__device__ __forceinline__ uint64_t frag_hash(const MdCols &m, uint32_t i) {
-  uint64_t h = ((uint64_t)(uint32_t)m.refid[i] << 32) | (uint32_t)m.upos[i];
-  h = mix64(h) ^ (((uint64_t)lib_of(m, i) << 1) | ((m.flag_in[i] & F_REVERSED) ? 1 : 0));
-  return mix64(h);
+__device__ __forceinline__ bool key_eq(const uint4 &a, const uint4 &b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+__device__ __forceinline__ uint64_t frag_hash(const uint4 &k) {
+  const uint64_t h = ((uint64_t)k.x << 32) | k.y;
+  return mix64(mix64(h) ^ (uint64_t)k.z);
 }
 
 // generic find-or-insert; returns the representative record of i's group
@@ -68,13 +73,14 @@ __device__ __forceinline__ uint32_t find_or_insert(uint32_t *table, uint64_t mas
   }
 }
 
-__global__ __launch_bounds__(256) void k_frag_insert(MdCols m, uint32_t *table, uint64_t mask, uint32_t *__restrict__ frep,
-                                                     unsigned long long *fbest) {
+__global__ __launch_bounds__(256) void k_frag_insert(MdCols m, const uint4 *__restrict__ fkey, uint32_t *table, uint64_t mask,
+                                                     uint32_t *__restrict__ frep, unsigned long long *fbest) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m.n) return;
   const uint16_t f = m.flag_in[i];
   if (!is_candidate(f)) { frep[i] = EMPTY; return; }
-  const uint32_t rep = find_or_insert(table, mask, frag_hash(m, (uint32_t)i), (uint32_t)i, [&](uint32_t a, uint32_t b) { return frag_key_eq(m, a, b); });
+  const uint4 mine = fkey[i];
+  const uint32_t rep = find_or_insert(table, mask, frag_hash(mine), (uint32_t)i, [&](uint32_t a, uint32_t) { return key_eq(fkey[a], mine); });
   frep[i] = rep;
   const unsigned long long v = is_true_pair(f) ? (1ull << 63) : (unsigned long long)(uint32_t)m.score[i];
   atomicMax(&fbest[rep], v);
@@ -169,34 +175,31 @@ __global__ __launch_bounds__(256) void k_mate_insert(MdCols m, uint32_t *table, 
 }
 
 // ---------------- pairs
-struct PairEnds { uint32_t a1, a2; };
-// order the two ends (:347-353); `second` arrived later than `first`
-__device__ __forceinline__ PairEnds order_pair(const MdCols &m, uint32_t second, uint32_t first) {
-  uint32_t a1 = second, a2 = first;
-  const int32_t r1 = m.refid[a1], r2 = m.refid[a2];
-  const int32_t p1 = m.upos[a1], p2 = m.upos[a2];
-  const bool v1 = m.flag_in[a1] & F_REVERSED, v2 = m.flag_in[a2] & F_REVERSED;
-  if (r1 > r2 || (r1 == r2 && (p1 > p2 || (p1 == p2 && v1 && !v2)))) { uint32_t t = a1; a1 = a2; a2 = t; }
-  return PairEnds{a1, a2};
+struct PairKey { uint4 k1, k2; };  // fragment keys of the two ends, ordered (:347-353)
+// `second` arrived later than `first`
+__device__ __forceinline__ PairKey pair_key(const uint4 &second, const uint4 &first) {
+  const int32_t r1 = (int32_t)second.x, r2 = (int32_t)first.x, p1 = (int32_t)second.y, p2 = (int32_t)first.y;
+  const bool v1 = second.z & 1u, v2 = first.z & 1u;
+  const bool swap = r1 > r2 || (r1 == r2 && (p1 > p2 || (p1 == p2 && v1 && !v2)));
+  return swap ? PairKey{first, second} : PairKey{second, first};
 }
-__device__ __forceinline__ bool pair_key_eq(const MdCols &m, const uint32_t *__restrict__ mate, uint32_t oa, uint32_t ob) {
-  const PairEnds a = order_pair(m, oa, mate[oa]), b = order_pair(m, ob, mate[ob]);
-  return m.refid[a.a1] == m.refid[b.a1] && m.refid[a.a2] == m.refid[b.a2] && m.upos[a.a1] == m.upos[b.a1] && m.upos[a.a2] == m.upos[b.a2] &&
-         ((m.flag_in[a.a1] ^ m.flag_in[b.a1]) & F_REVERSED) == 0 && ((m.flag_in[a.a2] ^ m.flag_in[b.a2]) & F_REVERSED) == 0 &&
-         lib_of(m, a.a1) == lib_of(m, b.a1);
+// same two ends (positions, orientations) in the same library (the library of the first end stands for the pair, :355)
+__device__ __forceinline__ bool pair_key_eq(const PairKey &a, const PairKey &b) {
+  return a.k1.x == b.k1.x && a.k2.x == b.k2.x && a.k1.y == b.k1.y && a.k2.y == b.k2.y && a.k1.z == b.k1.z && ((a.k2.z ^ b.k2.z) & 1u) == 0;
 }
 
-__global__ __launch_bounds__(256) void k_pair_insert(MdCols m, const uint32_t *__restrict__ mate, uint32_t *table, uint64_t mask,
-                                                     uint32_t *__restrict__ prep, unsigned long long *pbest) {
+__global__ __launch_bounds__(256) void k_pair_insert(MdCols m, const uint4 *__restrict__ fkey, const uint32_t *__restrict__ mate, uint32_t *table,
+                                                     uint64_t mask, uint32_t *__restrict__ prep, unsigned long long *pbest) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m.n) return;
   const uint32_t mt = mate[i];
   if (mt == EMPTY || mt > (uint32_t)i) { prep[i] = EMPTY; return; }  // the later-arriving mate owns the pair (:336-340)
-  const PairEnds e = order_pair(m, (uint32_t)i, mt);
-  uint64_t h = mix64(((uint64_t)(uint32_t)m.refid[e.a1] << 32) | (uint32_t)m.refid[e.a2]);
-  h = mix64(h ^ (((uint64_t)(uint32_t)m.upos[e.a1] << 32) | (uint32_t)m.upos[e.a2]));
-  h = mix64(h ^ (((uint64_t)lib_of(m, e.a1) << 2) | ((m.flag_in[e.a1] & F_REVERSED) ? 2 : 0) | ((m.flag_in[e.a2] & F_REVERSED) ? 1 : 0)));
-  const uint32_t rep = find_or_insert(table, mask, h, (uint32_t)i, [&](uint32_t a, uint32_t b) { return pair_key_eq(m, mate, a, b); });
+  const PairKey mine = pair_key(fkey[i], fkey[mt]);
+  uint64_t h = mix64(((uint64_t)mine.k1.x << 32) | mine.k2.x);
+  h = mix64(h ^ (((uint64_t)mine.k1.y << 32) | mine.k2.y));
+  h = mix64(h ^ (((uint64_t)mine.k1.z << 1) | (mine.k2.z & 1u)));
+  const uint32_t rep = find_or_insert(table, mask, h, (uint32_t)i,
+                                      [&](uint32_t a, uint32_t) { return pair_key_eq(pair_key(fkey[a], fkey[mate[a]]), mine); });
   prep[i] = rep;
   const int32_t sc = m.score[i] + m.score[mt];  // :342
   atomicMax(&pbest[rep], (unsigned long long)(uint32_t)sc);
@@ -256,11 +259,15 @@ static int markdup_impl(elp_ctx *c) {
   uint32_t *winner;
   ELP_TRY(scratch(c, 3, n + 8, &winner));
 
+  uint4 *fkey;
+  ELP_TRY(scratch(c, 5, n + 8, &fkey));
+  ELP_LAUNCH(c, "md_keys", k_md_keys, dim3(grid), dim3(256), 0, m, fkey);
+
   // ---- fragments
   ELP_HIP(c, hipMemsetAsync(table, 0xFF, T * sizeof(uint32_t), st));
   ELP_HIP(c, hipMemsetAsync(best, 0, n * sizeof(unsigned long long), st));
   ELP_HIP(c, hipMemsetAsync(winner, 0xFF, n * sizeof(uint32_t), st));
-  ELP_LAUNCH(c, "md_frag_insert", k_frag_insert, dim3(grid), dim3(256), 0, m, table, T - 1, rep, best);
+  ELP_LAUNCH(c, "md_frag_insert", k_frag_insert, dim3(grid), dim3(256), 0, m, (const uint4 *)fkey, table, T - 1, rep, best);
   ELP_LAUNCH(c, "md_frag_tie", k_frag_tie, dim3(grid), dim3(256), 0, m, (const uint32_t *)rep, (const unsigned long long *)best, winner);
   ELP_LAUNCH(c, "md_frag_flag", k_frag_flag, dim3(grid), dim3(256), 0, m, (const uint32_t *)rep, (const unsigned long long *)best,
              (const uint32_t *)winner, c->flag.p);
@@ -274,7 +281,8 @@ static int markdup_impl(elp_ctx *c) {
   ELP_HIP(c, hipMemsetAsync(table, 0xFF, T * sizeof(uint32_t), st));
   ELP_HIP(c, hipMemsetAsync(best, 0, n * sizeof(unsigned long long), st));
   ELP_HIP(c, hipMemsetAsync(c->pair_winner.p, 0xFF, n * sizeof(uint32_t), st));
-  ELP_LAUNCH(c, "md_pair_insert", k_pair_insert, dim3(grid), dim3(256), 0, m, (const uint32_t *)c->mate.p, table, T - 1, c->pair_slot.p, best);
+  ELP_LAUNCH(c, "md_pair_insert", k_pair_insert, dim3(grid), dim3(256), 0, m, (const uint4 *)fkey, (const uint32_t *)c->mate.p, table,
+             T - 1, c->pair_slot.p, best);
   ELP_LAUNCH(c, "md_pair_tie", k_pair_tie, dim3(grid), dim3(256), 0, m, (const uint32_t *)c->mate.p, (const uint32_t *)c->pair_slot.p,
              (const unsigned long long *)best, c->pair_winner.p);
   ELP_LAUNCH(c, "md_pair_flag", k_pair_flag, dim3(grid), dim3(256), 0, m, (const uint32_t *)c->mate.p, (const uint32_t *)c->pair_slot.p,
