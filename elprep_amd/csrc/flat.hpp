@@ -106,24 +106,33 @@ struct Chunk {
   __device__ __forceinline__ uint32_t word() const { return I == 0 ? w0 : (I == 1 ? w1 : (I == 2 ? w2 : w3)); }
   template <int I>
   __device__ __forceinline__ uint32_t get() const { return (word<(I >> 2)>() >> (8 * (I & 3))) & 0xFFu; }
-  // stores bytes [0, nb) at p (any alignment) and nothing else: the bytes behind a read's last block belong to another lane
-  template <int W>
-  __device__ __forceinline__ void store_word(uint8_t *__restrict__ p, int nb) const {
-    const uint32_t w = word<W>();
-    if (nb >= 4 * W + 4) {
-      __builtin_memcpy(p + 4 * W, &w, 4);
-    } else {
-      if (nb > 4 * W) p[4 * W] = (uint8_t)w;
-      if (nb > 4 * W + 1) p[4 * W + 1] = (uint8_t)(w >> 8);
-      if (nb > 4 * W + 2) p[4 * W + 2] = (uint8_t)(w >> 16);
-    }
-  }
+  // stores bytes [0, nb) at p (any alignment) and nothing else: the bytes behind a read's last block belong to another lane.
+  // A partial block goes out as its binary pieces - 8, 4, 2, 1 bytes where the bit of nb is set, each taken from what the previous
+  // pieces left - i.e. four predicated stores instead of a tree of per-word cases (nearly every wave holds the last block of
+  // some read, so this path runs all the time).
   __device__ __forceinline__ void store(uint8_t *__restrict__ p, int nb) const {
     if (nb == FL_CHUNK) {
       const uint4 v = make_uint4(w0, w1, w2, w3);
       __builtin_memcpy(p, &v, 16);
     } else {
-      store_word<0>(p, nb); store_word<1>(p, nb); store_word<2>(p, nb); store_word<3>(p, nb);
+      // every piece and address is computed before the first store goes out: a register that an outstanding store still reads
+      // can only be overwritten after a wait for that store
+      const bool b8 = nb & 8, b4 = nb & 4, b2 = nb & 2, b1 = nb & 1;
+      // (the words pass through registers the optimiser cannot look into: a select between two MEMBERS becomes a load from a
+      // selected address, and the object that holds this chunk would move to scratch memory)
+      uint32_t a0 = w0, a1 = w1, a2 = w2, a3 = w3;
+      asm("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+      const uint2 d8 = make_uint2(a0, a1);
+      const uint32_t d4 = b8 ? a2 : a0, x1 = b8 ? a3 : a1;     // the eight bytes behind the 8-byte piece
+      const uint32_t y = b4 ? x1 : d4;                         // the four bytes behind the 4-byte piece
+      const uint16_t d2 = (uint16_t)y;
+      const uint8_t d1 = (uint8_t)(b2 ? y >> 16 : y);
+      uint8_t *q4 = p + (nb & 8), *q2 = p + (nb & 12), *q1 = p + (nb & 14);
+      __builtin_amdgcn_sched_barrier(0);
+      if (b8) __builtin_memcpy(p, &d8, 8);
+      if (b4) __builtin_memcpy(q4, &d4, 4);
+      if (b2) __builtin_memcpy(q2, &d2, 2);
+      if (b1) *q1 = d1;
     }
   }
 };
