@@ -181,20 +181,16 @@ __device__ __forceinline__ void flat_run(const uint64_t *__restrict__ qual_off, 
         int k = (int)((float)s * inv_avg);
         k = k >= (int)ng - 1 ? (int)ng - 2 : k;
         k = k < 1 ? 1 : k;
-        bool found = false;
-        uint32_t o = 0, nxt = 0;
-        if (ng >= 3) {
-          const uint32_t a0 = L.off[k - 1], a1 = L.off[k], a2 = L.off[k + 1], a3 = L.off[k + 2];
-          const uint32_t v0 = (a0 + 15u * (uint32_t)(k - 1)) >> 4, v1 = (a1 + 15u * (uint32_t)k) >> 4, v2 = (a2 + 15u * (uint32_t)(k + 1)) >> 4,
-                         v3 = (a3 + 15u * (uint32_t)(k + 2)) >> 4;
-          if (s >= v0 && s < v3) {
-            found = true;
-            const bool hi = s >= v2, mid = s >= v1;
-            o = hi ? a2 : (mid ? a1 : a0);
-            nxt = hi ? a3 : (mid ? a2 : a1);
-            k = hi ? k + 1 : (mid ? k : k - 1);
-          }
-        }
+        // straight-line on purpose (bitwise &, selects): with && the compiler nests branches and reads the offsets in two
+        // dependent LDS round trips.  For ng < 3 the four words are read all the same (the array is longer) and not used.
+        const uint32_t a0 = L.off[k - 1], a1 = L.off[k], a2 = L.off[k + 1], a3 = L.off[k + 2];
+        const uint32_t v0 = (a0 + 15u * (uint32_t)(k - 1)) >> 4, v1 = (a1 + 15u * (uint32_t)k) >> 4, v2 = (a2 + 15u * (uint32_t)(k + 1)) >> 4,
+                       v3 = (a3 + 15u * (uint32_t)(k + 2)) >> 4;
+        const bool found = (ng >= 3u) & (s >= v0) & (s < v3);
+        const bool hi = s >= v2, mid = s >= v1;
+        uint32_t o = hi ? a2 : (mid ? a1 : a0);
+        uint32_t nxt = hi ? a3 : (mid ? a2 : a1);
+        k = found ? (hi ? k + 1 : (mid ? k : k - 1)) : k;
         if (!found) {
           k = k >= (int)ng ? (int)ng - 1 : k;
           while (((L.off[k] + 15u * (uint32_t)k) >> 4) > s) k--;
