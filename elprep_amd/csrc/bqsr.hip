@@ -559,7 +559,7 @@ struct CountBody {
     int k0, nb;
   };
   // every global load of the block is issued here: QUAL, skip bits, SEQ window, reference window
-  __device__ __forceinline__ bool prefetch(uint32_t rl, int k0, int nb, uint64_t qpos, Pre &p) {
+  __device__ __forceinline__ bool prefetch(uint32_t rl, int k0, int nb, uint64_t qpos, uint32_t, Pre &p) {
     const uint4 dy = s_desc[2 * rl + 1];
     const uint32_t fl = (dy.w >> 8) & 0xFFu;
     if (!(fl & BQ_ELIGIBLE)) return false;
@@ -682,6 +682,7 @@ struct CountBody {
     }
 #undef ELP_B
   }
+  __device__ __forceinline__ void slots(uint32_t) {}
   __device__ __forceinline__ void retire() {}
   __device__ __forceinline__ void group_end(uint32_t, uint32_t) {}
 
@@ -952,7 +953,7 @@ struct ApplyBody {
     uint32_t rl;
     int k0, nb;
   };
-  __device__ __forceinline__ bool prefetch(uint32_t rl, int k0, int nb, uint64_t qpos, Pre &p) {
+  __device__ __forceinline__ bool prefetch(uint32_t rl, int k0, int nb, uint64_t qpos, uint32_t, Pre &p) {
     const uint32_t fl = (uint32_t)(s_desc[rl] >> 56);
     if (!(fl & BQ_ELIGIBLE)) return false;
     p.rl = rl; p.k0 = k0; p.nb = nb; p.qpos = qpos;
@@ -1026,6 +1027,7 @@ struct ApplyBody {
     }
     out = ch; out_at = qpos; out_nb = nb;
   }
+  __device__ __forceinline__ void slots(uint32_t) {}
   __device__ __forceinline__ void retire() {
     if (out_nb) out.store(qual + out_at, out_nb);
     out_nb = 0;

@@ -143,10 +143,12 @@ struct Chunk {
 //                                                             reads are handled in groups of at most RMAX)
 //   struct Pre                                                the registers a block's global loads land in (+ what identifies it)
 //   void stage(uint32_t g0, uint32_t ng)                      all threads: put per-read data of reads [g0, g0+ng) into LDS
-//   bool prefetch(uint32_t rl, int k0, int nb, uint64_t qpos, Pre &)
+//   void slots(uint32_t nslots)                               all threads (uniform), behind the barrier: the group has nslots slots
+//   bool prefetch(uint32_t rl, int k0, int nb, uint64_t qpos, uint32_t slot, Pre &)
 //                                                             per lane: ISSUE the global loads of bases [k0, k0+nb) of read g0+rl
 //                                                             (k0 a multiple of 16, 1 <= nb <= 16; first QUAL byte at column offset
-//                                                             qpos) without using their results; false = nothing to do for the block
+//                                                             qpos; the block is slot `slot` of the group) without using their results;
+//                                                             false = nothing to do for the block
 //   void process(Pre &)                                       per lane: the block's work, except its global stores
 //   void retire()                                             per lane: issue the global stores of the block processed last.  Called
 //                                                             in front of the next prefetch: a store issued behind the prefetch loads
@@ -169,15 +171,35 @@ __device__ __forceinline__ void flat_run(const uint64_t *__restrict__ qual_off, 
     for (uint32_t g0 = r_first; g0 < r_end; g0 += RMAX) {
       const uint32_t ng = (r_end - g0 < RMAX) ? r_end - g0 : RMAX;  // reads [g0, g0 + ng)
       const uint64_t base = qual_off[g0];
-      for (uint32_t k = threadIdx.x; k <= ng; k += Body::NT) L.off[k] = (uint32_t)(qual_off[g0 + k] - base);
+      const uint32_t len0 = (uint32_t)(qual_off[g0 + 1] - base);
+      int same = 1;  // every read of the group has len0 bases (what a sequencer writes): slots are found by arithmetic alone
+      for (uint32_t k = threadIdx.x; k <= ng; k += Body::NT) {
+        const uint32_t o = (uint32_t)(qual_off[g0 + k] - base);
+        L.off[k] = o;
+        same &= o == k * len0;
+      }
       B.stage(g0, ng);
-      __syncthreads();
+      const bool uniform = __syncthreads_and(same) != 0 && len0 != 0;
       const uint32_t nslots = (L.off[ng] + 15u * ng) >> 4;  // slot of read k: (off[k] + 15 k) >> 4
-      const float inv_avg = nslots ? (float)ng / (float)nslots : 0.f;
+      B.slots(nslots);
+      const float inv_avg = nslots ? (float)ng / (float)nslots : 0.f, inv_step = 1.0f / (float)(len0 + 15u);
       // locate slot s and issue its loads
       auto fetch = [&](uint32_t s, typename Body::Pre &pre) __attribute__((always_inline)) -> bool {
+        if (uniform) {
+          // read k starts at slot ((len0 + 15) k) >> 4, so slot s belongs to read floor((16 s + 15) / (len0 + 15)); the float
+          // quotient (16 s + 15 < 2^24) is off by at most one
+          const uint32_t step = len0 + 15u;  // < 2^24, like every read index: 24-bit multiplies
+          int k = (int)((float)(16u * s + 15u) * inv_step);
+          k = k >= (int)ng ? (int)ng - 1 : k;
+          k = (__umul24(step, (uint32_t)k) >> 4) > s ? k - 1 : k;
+          k = ((k + 1 < (int)ng) & ((__umul24(step, (uint32_t)(k + 1)) >> 4) <= s)) ? k + 1 : k;
+          const uint32_t k0 = (s - (__umul24(step, (uint32_t)k) >> 4)) << 4;
+          if (k0 >= len0) return false;  // the (at most one) empty slot behind a read
+          const uint32_t nb = len0 - k0 < 16u ? len0 - k0 : 16u;
+          return B.prefetch((uint32_t)k, (int)k0, (int)nb, base + __umul24(len0, (uint32_t)k) + k0, s, pre);
+        }
         // read owning slot s: guess g from the mean; the four offsets around g are read at once (one LDS latency) and decide
-        // among g-1, g, g+1 — always enough for uniform read lengths; otherwise walk
+        // among g-1, g, g+1; otherwise walk
         int k = (int)((float)s * inv_avg);
         k = k >= (int)ng - 1 ? (int)ng - 2 : k;
         k = k < 1 ? 1 : k;
@@ -202,7 +224,7 @@ __device__ __forceinline__ void flat_run(const uint64_t *__restrict__ qual_off, 
         const uint32_t k0 = (s - ((o + 15u * (uint32_t)k) >> 4)) << 4;
         if (k0 >= len) return false;  // the (at most one) empty slot behind a read
         const uint32_t nb = len - k0 < 16u ? len - k0 : 16u;
-        return B.prefetch((uint32_t)k, (int)k0, (int)nb, base + o + k0, pre);
+        return B.prefetch((uint32_t)k, (int)k0, (int)nb, base + o + k0, s, pre);
       };
       uint32_t s = threadIdx.x;
       typename Body::Pre cur;

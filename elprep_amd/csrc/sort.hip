@@ -98,7 +98,7 @@ struct ScoreBody {
     return ((((x | 0x80808080u) - 0x03030303u) | x) & 0x80808080u) & m;
   }
   struct Pre { Chunk ch; uint32_t rl; int nb; int k0; };
-  __device__ __forceinline__ bool prefetch(uint32_t rl, int k0, int nb, uint64_t qpos, Pre &p) {
+  __device__ __forceinline__ bool prefetch(uint32_t rl, int k0, int nb, uint64_t qpos, uint32_t, Pre &p) {
     p.rl = rl; p.nb = nb; p.k0 = k0;
     p.ch.load(qual + qpos);
     return true;
@@ -129,6 +129,7 @@ struct ScoreBody {
       qbounds[g0 + k] = (uint64_t)hi[k] | ((uint64_t)lo[k] << 32);  // all-zero = no quality > 2
     }
   }
+  __device__ __forceinline__ void slots(uint32_t) {}
   __device__ __forceinline__ void retire() {}
   __device__ __forceinline__ void tile_end(uint32_t, uint64_t) {}
 };

@@ -145,6 +145,26 @@ def test_markdup_exact_ties_and_fragments():
     e.close()
 
 
+def test_scores_of_very_long_reads():
+    """Reads far longer than a step of the score kernel (its per-block LDS words do not cover the group: the atomics path), mixed with
+    short ones; scores are compared with the oracle, the low-quality bounds through a second adapt after nothing changed."""
+    rng = np.random.default_rng(5)
+    recs = []
+    for k in range(40):
+        L = int(rng.choice([90_000, 130_000, 7, 150, 31]))
+        q = rng.choice([2, 2, 14, 15, 30, 40, 93], size=L).tolist()
+        recs.append(dict(qname="L%d" % k, flag=0, refid=0, pos=100 + k, cigar="%dM" % L, mapq=60, seq="A" * L, qual=q, rgid=0))
+    b = batch_from_records(recs)
+    h = Header(ref_len=np.array([400000], np.int32), rg_lib=np.array([0], np.uint16), rg_cov=np.array([0], np.uint16))
+    e = Engine(h)
+    e.stage(b)
+    _, oupos, oscore = orc.mark_duplicates(b, h, with_adapted=True)
+    up, sc = e.adapted()
+    assert np.array_equal(up, oupos) and np.array_equal(sc, oscore)
+    assert np.array_equal(e.mark_duplicates(), orc.mark_duplicates(b, h))
+    e.close()
+
+
 def test_empty_and_single_record():
     h = Header(ref_len=np.array([1000], np.int32), rg_lib=np.array([0], np.uint16), rg_cov=np.array([0], np.uint16))
     e = Engine(h)
