@@ -241,12 +241,17 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint64_t *__
   }
   __syncthreads();
   // thread t owns digit t: position of the digit inside the sorted tile (exclusive scan over digits), then per-wave starts
+  uint32_t tot = 0, tstart;
+  const unsigned long long tag = (unsigned long long)epoch << 34;
+  unsigned long long *mine = state + (size_t)tile * 256 + threadIdx.x;
   {
-    uint32_t tot = 0;
 #pragma unroll
     for (int i = 0; i < RS_WAVES; i++) tot += cnt[i][threadIdx.x];
+    // the tile's own count goes out as early as possible, the look-back comes as late as possible (behind the LDS reorder of the
+    // keys): the tiles in front get that time to publish
+    __hip_atomic_store(mine, tag | (tile == 0 ? RS_INCL : RS_AGG) | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t all;
-    const uint32_t tstart = block_excl_scan_256(tot, &all, scan_lds);
+    tstart = block_excl_scan_256(tot, &all, scan_lds);
     uint32_t run = tstart;
 #pragma unroll
     for (int i = 0; i < RS_WAVES; i++) {
@@ -254,16 +259,24 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint64_t *__
       cnt[i][threadIdx.x] = run;
       run += t;
     }
+  }
+  __syncthreads();
+  // keys into digit order
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; r++) {
+    uint64_t i = wbase + (uint64_t)r * 64 + lane;
+    if (i < n) {
+      uint32_t d = (uint32_t)(k[r] >> shift) & 0xFF;
+      pos[r] += cnt[w][d];
+      sbuf[pos[r]] = k[r];
+    }
+  }
+  {
     // first output position of digit t: keys with a smaller digit (global histogram) + keys with digit t in the tiles in front
     uint32_t dall;
     const uint32_t dbase = block_excl_scan_256((uint32_t)ghist[threadIdx.x], &dall, scan_lds);
-    const unsigned long long tag = (unsigned long long)epoch << 34;
-    unsigned long long *mine = state + (size_t)tile * 256 + threadIdx.x;
     uint32_t prefix = 0;
-    if (tile == 0) {
-      __hip_atomic_store(mine, tag | RS_INCL | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      __hip_atomic_store(mine, tag | RS_AGG | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tile != 0) {
       // walk back over the tiles in front, eight words per round trip (device-scope loads cross the XCDs: ~1 us each)
       constexpr int LB = 8;
       uint32_t back = 1, spins = 0;  // next tile to look at: tile - back
@@ -290,17 +303,6 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint64_t *__
       __hip_atomic_store(mine, tag | RS_INCL | (prefix + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     gbase[threadIdx.x] = dbase + prefix - tstart;
-  }
-  __syncthreads();
-  // keys into digit order
-#pragma unroll
-  for (int r = 0; r < RS_ITEMS; r++) {
-    uint64_t i = wbase + (uint64_t)r * 64 + lane;
-    if (i < n) {
-      uint32_t d = (uint32_t)(k[r] >> shift) & 0xFF;
-      pos[r] += cnt[w][d];
-      sbuf[pos[r]] = k[r];
-    }
   }
   __syncthreads();
   uint32_t dst[RS_ITEMS];
