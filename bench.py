@@ -49,8 +49,8 @@ def kernel_stage(name: str) -> str:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=int(os.environ.get("ELP_BENCH_READS", 50_000_000)), help="reads per GPU (approximate: pairs = reads/2)")
     ap.add_argument("--genome", default="c3", help="synthetic genome preset (tools/synth): c3 = hg38/12, 24 contigs")
     ap.add_argument("--cpu-reads", type=int, default=2_000_000, help="sample size for the CPU baseline leg (0 = skip)")
@@ -203,9 +203,11 @@ def main():
         def step():
             qt, ct, xt, ctr = rk.gather(MAX_CYCLE, 100)
             tb = BqsrTables(qt, ct, xt, MAX_CYCLE).finalize()
-            lut, present = tb.build_lut(0)
+            lut, present = tb.build_lut(0, out=lut_buf[0])
+            lut_buf[0] = (lut, present)
             rk.apply(lut, present, MAX_CYCLE)
             rk.sync()
+        lut_buf = [None]
         mode = "sfm"
     gen_s = time.time() - t0 - stage_s
 
