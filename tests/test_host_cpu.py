@@ -124,3 +124,35 @@ def test_dup_derived_and_report():
     txt = dup_metrics_report(np.stack([row, np.zeros(7, np.int64)]), ["libA"], "elprep filter in out")
     assert "libA\t10\t1000\t5\t7\t2\t100\t20\t0.100498\t" in txt
     assert "Unknown Library\t0\t0\t0\t0\t0\t0\t0\tNaN\n" in txt
+
+
+def test_host_pool_is_reentrant_and_arrays_can_be_reused(tables):
+    """finalize / build_lut run their rows on a shared worker pool: calls from several host threads at once give the results of
+    sequential calls, and filling a LUT pair of an earlier call again gives the same bytes as a fresh one."""
+    import threading
+    h, qt, ct, xt = tables
+    ref = BqsrTables(qt, ct, xt, 500).finalize()
+    lut0, present0 = ref.build_lut(0)
+    emp0 = ref.empirical()
+    results = [None] * 6
+
+    def work(k):
+        t = BqsrTables(qt * (1 if k % 2 == 0 else 2), ct * (1 if k % 2 == 0 else 2), xt * (1 if k % 2 == 0 else 2), 500).finalize()
+        results[k] = (t.empirical(), t.build_lut(0))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(6)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    twice = BqsrTables(qt * 2, ct * 2, xt * 2, 500).finalize()
+    lut2, present2 = twice.build_lut(0)
+    for k in range(6):
+        emp, (lut, present) = results[k]
+        want_emp, want_lut, want_p = (emp0, lut0, present0) if k % 2 == 0 else (twice.empirical(), lut2, present2)
+        assert all(np.array_equal(a, b) for a, b in zip(emp, want_emp))
+        assert np.array_equal(lut, want_lut) and np.array_equal(present, want_p)
+    # refill: first the doubled tables, then the original ones into the same arrays
+    pair = twice.build_lut(0)
+    again = ref.build_lut(0, out=pair)
+    assert again[0] is pair[0] and np.array_equal(again[0], lut0) and np.array_equal(again[1], present0)
