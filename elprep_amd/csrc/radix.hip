@@ -77,27 +77,6 @@ __global__ __launch_bounds__(256) void k_scan_down(const uint32_t *__restrict__ 
   }
 }
 
-// single-block scan for small inputs (n <= SCAN_TILE); also writes the total to out[n]
-__global__ __launch_bounds__(256) void k_scan_small(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t n) {
-  __shared__ uint32_t lds[8];
-  uint32_t base = threadIdx.x * SCAN_ITEMS;
-  uint32_t v[SCAN_ITEMS];
-  uint32_t s = 0;
-#pragma unroll
-  for (int i = 0; i < SCAN_ITEMS; i++) {
-    v[i] = (base + i < n) ? in[base + i] : 0u;
-    s += v[i];
-  }
-  uint32_t tot;
-  uint32_t ex = block_excl_scan_256(s, &tot, lds);
-#pragma unroll
-  for (int i = 0; i < SCAN_ITEMS; i++) {
-    if (base + i < n) out[base + i] = ex;
-    ex += v[i];
-  }
-  if (threadIdx.x == 0) out[n] = tot;
-}
-
 static int scan_levels(elp_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n, uint32_t *total_dev) {
   if (n == 0) {
     if (total_dev) ELP_HIP(c, hipMemsetAsync(total_dev, 0, 4, c->stream));
