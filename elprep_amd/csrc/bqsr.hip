@@ -432,15 +432,11 @@ struct CountArgs {
   const uint32_t *tile_first;
 };
 
-// LDS table of one workgroup: n_cov * n_q rows of
-//   [ cs cycle cells: observations in the low, mismatches in the high 16 bits | 16 context cells: u64, observations low, mismatches high 32 ]
-// cycle cell of cycle index x = cycle + lmax is (17 x) >> 4 = x + x / 16: lanes of a wave work on bases 16 apart, the skew puts
-// them on different banks.  16-bit cycle counters are safe because a read touches a cycle cell at most once and the table is
-// flushed (atomic adds into the dense int64 tables in HBM) at least every 50000 reads.
 // private table of one workgroup: per covariate n_q + CT_XROWS rows of rs words - [0, CT_CYC) sixteen context cells of 32 | 32
 // bits (observations | mismatches), then the cycle cells of 16 | 16 bits at word CT_CYC + ((17 * (cycle + lmax)) >> 4) (the 17/16
 // stretch keeps the blocks of one read, sixteen cycles apart, out of each other's LDS banks); CT_PAD words behind the last row
-// take the zero-adds of bases outside the read
+// take the zero-adds of bases outside the read.  16-bit cycle counters are safe because a read touches a cycle cell at most once and
+// the table is flushed (atomic adds into the dense int64 tables in HBM) before 2^16 reads have passed (CountBody::tile_end).
 constexpr int CT_CYC = 32, CT_XROWS = 3, CT_PAD = 64;
 
 typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
@@ -687,7 +683,7 @@ struct CountBody {
   __device__ __forceinline__ void group_end(uint32_t, uint32_t) {}
 
   // adds the private table into the dense int64 tables (cycle: [cov][94][2*max_cycle+1][2], context: [cov][94][16][2]) and clears it;
-  // the two extra rows per covariate (bad / missing qualities) become error bits
+  // the extra rows per covariate: bad and missing qualities become error bits, the row of the qualities that are not counted is dropped
   __device__ __forceinline__ void flush() {
     __syncthreads();
     const int rpc = n_q + CT_XROWS, rows = n_cov * rpc;
