@@ -98,6 +98,7 @@ struct elp_ctx {
   size_t h_pinned_cap = 0;
   elp::DVec<unsigned long long> radix_state;  // radix.hip: per (tile, digit) look-back words, tagged with the pass epoch
   elp::DVec<uint32_t> radix_ticket;           // radix.hip: tile ticket counters
+  elp::DVec<uint32_t> tie_live;               // sort.hip: bit j = byte j of the comparator string differs among the members of large runs
   uint32_t radix_epoch = 0;
   uint64_t flat_index_n = 0, flat_index_bytes = 0;
 
@@ -254,6 +255,9 @@ __host__ __device__ inline uint16_t mod_flag(uint16_t flag) {
 // ---- cross-TU entry points ----
 int radix_sort_pairs(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *keys_tmp, uint32_t *vals_tmp, uint64_t n,
                      uint64_t **keys_out, uint32_t **vals_out);
+// the same over the low `ndigits` bytes of the keys only, every pass run (no histogram read-back, no host synchronisation)
+int radix_sort_pairs_low(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *keys_tmp, uint32_t *vals_tmp, uint64_t n, int ndigits,
+                         uint64_t **keys_out, uint32_t **vals_out);
 int exclusive_scan_u32(elp_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n, uint32_t *total_host /* may be null */);
 int ensure_adapted(elp_ctx *c, bool check_quals = true);
 int ensure_qual_present(elp_ctx *c, bool exact = false);  // exact: scan the whole column instead of a sample

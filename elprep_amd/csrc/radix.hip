@@ -310,6 +310,53 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint64_t *__
   }
 }
 
+// state words, ticket counters and the epoch of one more pass over `ntiles` tiles
+static int radix_pass_setup(elp_ctx *c, uint32_t ntiles) {
+  if ((size_t)ntiles * 256 > c->radix_state.cap) {
+    ELP_TRY(ensure(c, c->radix_state, (size_t)ntiles * 256));
+    ELP_HIP(c, hipMemsetAsync(c->radix_state.p, 0, c->radix_state.cap * sizeof(unsigned long long), c->stream));
+    c->radix_epoch = 0;
+  }
+  ELP_TRY(ensure(c, c->radix_ticket, 8));  // one ticket counter per digit position
+  ELP_HIP(c, hipMemsetAsync(c->radix_ticket.p, 0, 8 * sizeof(uint32_t), c->stream));
+  return 0;
+}
+static int radix_next_epoch(elp_ctx *c) {
+  if (++c->radix_epoch >= (1u << 30)) {  // the tag wrapped: forget every word
+    ELP_HIP(c, hipMemsetAsync(c->radix_state.p, 0, c->radix_state.cap * sizeof(unsigned long long), c->stream));
+    c->radix_epoch = 1;
+  }
+  return 0;
+}
+
+int radix_sort_pairs_low(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *keys_tmp, uint32_t *vals_tmp, uint64_t n, int ndigits,
+                         uint64_t **keys_out, uint32_t **vals_out) {
+  *keys_out = keys;
+  *vals_out = vals;
+  if (n < 2 || ndigits <= 0) return 0;
+  if (n >= 0xFFFFFFFFull || ndigits > 8) return set_error(c, ELP_ERR_UNSUPPORTED, "radix sort: bad size");
+  unsigned long long *ghist;
+  ELP_TRY(scratch(c, 6, 8 * 256, &ghist));
+  ELP_HIP(c, hipMemsetAsync(ghist, 0, 8 * 256 * sizeof(unsigned long long), c->stream));
+  const unsigned hb = (unsigned)std::min<uint64_t>((n + 255) / 256, 2048);
+  ELP_LAUNCH(c, "radix_hist_all", k_radix_hist_all, dim3(hb), dim3(256), 0, (const uint64_t *)keys, n, ghist);
+  const uint32_t ntiles = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
+  ELP_TRY(radix_pass_setup(c, ntiles));
+  uint64_t *ksrc = keys, *kdst = keys_tmp;
+  uint32_t *vsrc = vals, *vdst = vals_tmp;
+  for (int d = 0; d < ndigits; d++) {
+    ELP_TRY(radix_next_epoch(c));
+    ELP_LAUNCH(c, "radix_scatter", k_radix_scatter, dim3(ntiles), dim3(RS_THREADS), 0, (const uint64_t *)ksrc, (const uint32_t *)vsrc, kdst,
+               vdst, n, 8 * d, (const unsigned long long *)(ghist + d * 256), c->radix_state.p, c->radix_epoch, c->radix_ticket.p + d,
+               c->err_flag.p);
+    std::swap(ksrc, kdst);
+    std::swap(vsrc, vdst);
+  }
+  *keys_out = ksrc;
+  *vals_out = vsrc;
+  return 0;
+}
+
 int radix_sort_pairs(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *keys_tmp, uint32_t *vals_tmp, uint64_t n, uint64_t **keys_out,
                      uint32_t **vals_out) {
   *keys_out = keys;
@@ -328,13 +375,7 @@ int radix_sort_pairs(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *keys_
   ELP_HIP(c, hipStreamSynchronize(c->stream));
   if (dev_err & 256u) return set_error(c, ELP_ERR_HIP, "radix sort: tile look-back timed out");
   const uint32_t ntiles = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
-  if ((size_t)ntiles * 256 > c->radix_state.cap) {
-    ELP_TRY(ensure(c, c->radix_state, (size_t)ntiles * 256));
-    ELP_HIP(c, hipMemsetAsync(c->radix_state.p, 0, c->radix_state.cap * sizeof(unsigned long long), c->stream));
-    c->radix_epoch = 0;
-  }
-  ELP_TRY(ensure(c, c->radix_ticket, 8));  // one ticket counter per digit position
-  ELP_HIP(c, hipMemsetAsync(c->radix_ticket.p, 0, 8 * sizeof(uint32_t), c->stream));
+  ELP_TRY(radix_pass_setup(c, ntiles));
   uint64_t *ksrc = keys, *kdst = keys_tmp;
   uint32_t *vsrc = vals, *vdst = vals_tmp;
   for (int d = 0; d < 8; d++) {
@@ -342,10 +383,7 @@ int radix_sort_pairs(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *keys_
     for (int b = 0; b < 256; b++)
       if (hh[d * 256 + b] == n) { live = false; break; }
     if (!live) continue;
-    if (++c->radix_epoch >= (1u << 30)) {  // the tag wrapped: forget every word
-      ELP_HIP(c, hipMemsetAsync(c->radix_state.p, 0, c->radix_state.cap * sizeof(unsigned long long), c->stream));
-      c->radix_epoch = 1;
-    }
+    ELP_TRY(radix_next_epoch(c));
     ELP_LAUNCH(c, "radix_scatter", k_radix_scatter, dim3(ntiles), dim3(RS_THREADS), 0, (const uint64_t *)ksrc, (const uint32_t *)vsrc, kdst,
                vdst, n, 8 * d, (const unsigned long long *)(ghist + d * 256), c->radix_state.p, c->radix_epoch, c->radix_ticket.p + d,
                c->err_flag.p);

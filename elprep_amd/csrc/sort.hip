@@ -7,7 +7,7 @@
 //        (2) tie resolution inside runs of equal primary key with the comparator tail
 //            {QNAME bytes, modFlag, MAPQ, [NextREFID, PNEXT if paired], TLEN}, ties keep staging order:
 //            runs <= TIE_SMALL records: every record computes its rank in the run directly (all-pairs);
-//            larger runs (the unmapped block, pile-ups): LSD radix over the zero-padded comparator byte string,
+//            larger runs (the unmapped block, pile-ups): LSD radix over the live bytes of the zero-padded comparator string,
 //            8 bytes per round, then one stable round on the run id.
 #include <cstdlib>
 
@@ -386,14 +386,46 @@ __device__ inline uint32_t material_byte(const TieCols &t, uint32_t r, uint32_t 
   return 0u;
 }
 
-__global__ __launch_bounds__(256) void k_material_keys(uint32_t nu, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ u_read,
-                                                       uint32_t chunk, uint32_t maxq, uint64_t *__restrict__ keys, TieCols t) {
+// bit j of live[]: byte j of the comparator string is not the same for all members of large runs (compared with member 0's).
+// QNAME bytes are compared eight at a time (zero-padded behind the name's end, as material_byte pads them).
+__global__ __launch_bounds__(256) void k_material_live(uint32_t nu, const uint32_t *__restrict__ u_read, uint32_t maxq, uint32_t nbytes,
+                                                       uint32_t *live, TieCols t) {
+  __shared__ uint32_t acc[16];
+  if (threadIdx.x < 16) acc[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m < nu) {
+    const uint32_t r = u_read[m], r0 = u_read[0];
+    const uint64_t oa = t.qname_off[r], ob = t.qname_off[r0];
+    const uint32_t la = (uint32_t)(t.qname_off[r + 1] - oa), lb = (uint32_t)(t.qname_off[r0 + 1] - ob);
+    for (uint32_t k = 0; k < maxq; k += 8) {
+      const uint64_t a = k < la ? low_bytes(load8(t.qname + oa + k), la - k) : 0ull;
+      const uint64_t b = k < lb ? low_bytes(load8(t.qname + ob + k), lb - k) : 0ull;
+      uint64_t x = a ^ b;
+      if (x) {
+        x |= x >> 4; x |= x >> 2; x |= x >> 1;  // bit 0 of every byte: the byte is not zero
+        x &= 0x0101010101010101ull;
+        const uint32_t bits = (uint32_t)((x * 0x0102040810204080ull) >> 56);  // bit i: byte i differs
+        for (uint32_t i = 0; i < 8 && k + i < maxq; i++)
+          if ((bits >> i) & 1u) atomicOr(&acc[(k + i) >> 5], 1u << ((k + i) & 31));
+      }
+    }
+    for (uint32_t j = maxq; j < nbytes; j++)
+      if (material_byte(t, r, j, maxq) != material_byte(t, r0, j, maxq)) atomicOr(&acc[j >> 5], 1u << (j & 31));
+  }
+  __syncthreads();
+  if (threadIdx.x < 16 && acc[threadIdx.x]) atomicOr(&live[threadIdx.x], acc[threadIdx.x]);
+}
+
+// key of a member = the bytes of its comparator string at the (up to eight) positions pos[0] < pos[1] < ..., most significant first
+struct TieSel { uint16_t pos[8]; uint32_t n; };
+__global__ __launch_bounds__(256) void k_material_keys_sel(uint32_t nu, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ u_read,
+                                                           TieSel sel, uint32_t maxq, uint64_t *__restrict__ keys, TieCols t) {
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nu) return;
   const uint32_t r = u_read[vals[j]];
   uint64_t k = 0;
-#pragma unroll
-  for (uint32_t b = 0; b < 8; b++) k = (k << 8) | material_byte(t, r, chunk * 8 + b, maxq);
+  for (uint32_t b = 0; b < sel.n; b++) k = (k << 8) | material_byte(t, r, sel.pos[b], maxq);
   keys[j] = k;
 }
 
@@ -452,16 +484,32 @@ static int sort_impl(elp_ctx *c) {
     ELP_LAUNCH(c, "add_own", k_add_own, dim3(blocks_for(nu, 256)), dim3(256), 0, nu, (const uint32_t *)u_head, u_seg);
     ELP_LAUNCH(c, "iota", k_iota, dim3(blocks_for(nu, 256)), dim3(256), 0, uv0, (uint64_t)nu);
     const uint32_t maxq = c->max_qname_len;
-    const uint32_t m_bytes = maxq + 15;
-    const uint32_t chunks = (m_bytes + 7) / 8;
+    const uint32_t m_bytes = maxq + 15;  // <= 270 positions
+    // which positions of the comparator string differ at all among the members: one kernel, one read-back; the LSD rounds then
+    // take eight live positions each and run every pass (no histogram read-back per round, no rounds over constant bytes)
+    ELP_TRY(ensure(c, c->tie_live, 16));
+    ELP_HIP(c, hipMemsetAsync(c->tie_live.p, 0, 16 * sizeof(uint32_t), c->stream));
+    ELP_LAUNCH(c, "material_live", k_material_live, dim3(blocks_for(nu, 256)), dim3(256), 0, nu, (const uint32_t *)u_read, maxq, m_bytes,
+               c->tie_live.p, t);
+    uint32_t live[16];
+    ELP_HIP(c, hipMemcpyAsync(live, c->tie_live.p, sizeof live, hipMemcpyDeviceToHost, c->stream));
+    ELP_HIP(c, hipStreamSynchronize(c->stream));
+    std::vector<uint16_t> lp;
+    for (uint32_t j = 0; j < m_bytes; j++)
+      if ((live[j >> 5] >> (j & 31)) & 1u) lp.push_back((uint16_t)j);
     uint32_t *vcur = uv0, *vtmp = uv1;
-    for (int ch = (int)chunks - 1; ch >= 0; ch--) {
-      ELP_LAUNCH(c, "material_keys", k_material_keys, dim3(blocks_for(nu, 256)), dim3(256), 0, nu, (const uint32_t *)vcur, (const uint32_t *)u_read,
-                 (uint32_t)ch, maxq, uk0, t);
+    for (size_t hi = lp.size(); hi > 0;) {  // least significant positions first
+      const size_t lo = hi >= 8 ? hi - 8 : 0;
+      TieSel sel;
+      sel.n = (uint32_t)(hi - lo);
+      for (size_t b = 0; b < 8; b++) sel.pos[b] = b < sel.n ? lp[lo + b] : 0;
+      ELP_LAUNCH(c, "material_keys", k_material_keys_sel, dim3(blocks_for(nu, 256)), dim3(256), 0, nu, (const uint32_t *)vcur,
+                 (const uint32_t *)u_read, sel, maxq, uk0, t);
       uint64_t *ko;
       uint32_t *vo;
-      ELP_TRY(radix_sort_pairs(c, uk0, vcur, uk1, vtmp, nu, &ko, &vo));
+      ELP_TRY(radix_sort_pairs_low(c, uk0, vcur, uk1, vtmp, nu, (int)sel.n, &ko, &vo));
       if (vo != vcur) { vtmp = vcur; vcur = vo; }
+      hi = lo;
     }
     ELP_LAUNCH(c, "seg_keys", k_seg_keys, dim3(blocks_for(nu, 256)), dim3(256), 0, nu, (const uint32_t *)vcur, (const uint32_t *)u_seg, uk0);
     {
