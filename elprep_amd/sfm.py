@@ -217,6 +217,27 @@ def merge_order(group_refid: np.ndarray, group_pos: np.ndarray, spread_refid: np
     return out
 
 
+def sorted_output(b: Batch, perm: np.ndarray, flags: np.ndarray, qual: np.ndarray) -> Batch:
+    """The records of a split as the output phase writes them: coordinate order (the device's permutation), duplicate flags and
+    recalibrated qualities in place of the staged ones.  Payload permutation is host work (it sits next to the BAM encoder)."""
+    out = Batch(**{f: getattr(b, f) for f in ("refid", "pos", "next_refid", "pnext", "tlen", "mapq", "rgid", "has_sr", "l_seq", "qname_off", "qname",
+                                                  "cigar_off", "cigar", "seq_off", "seq4", "qual_off")},
+                flag=np.asarray(flags, dtype=b.flag.dtype), qual=np.asarray(qual, dtype=b.qual.dtype))
+    return out.take(perm)
+
+
+def merge_splits(groups: List[Batch], spread: Batch, unmapped: Batch) -> Batch:
+    """MergeSortedFilesSplitPerChromosome on payloads (sam/split-merge.go:410-576): `groups` are the coordinate-sorted group
+    splits in group order, `spread` the coordinate-sorted spread split, `unmapped` the unmapped split; the result is the one
+    coordinate-sorted output the reference's merge phase writes (group reads with the spread reads inserted by merge_order,
+    then the unmapped split)."""
+    cat = Batch.concat(groups) if groups else spread.take(np.zeros(0, dtype=np.int64))
+    code = merge_order(cat.refid, cat.pos, spread.refid, spread.pos)
+    both = Batch.concat([cat, spread])
+    idx = np.where(code >= 0, code, cat.n + (-code - 1))
+    return Batch.concat([both.take(idx), unmapped])
+
+
 # ------------------------------------------------------------------------------------------------ per-rank driver
 class SfmRank:
     """The splits of one rank on one GPU: context 0 = its group splits, context 1 = the spread split (if owned)."""

@@ -142,3 +142,39 @@ def test_merge_order_matches_the_reference_loop():
         got = sfm.merge_order(g[:, 0], g[:, 1], sp[:, 0], sp[:, 1])
         want = _merge_reference([tuple(x) for x in g], [tuple(x) for x in sp])
         assert np.array_equal(got, want), trial
+
+
+def test_merge_splits_gives_one_sorted_output_with_every_payload():
+    """Payload side of the merge phase: every split sorted on its own (oracle permutation), then merge_splits; the result holds
+    every record once, mapped part in CoordinateLess order with spread reads behind the group reads of their position, unmapped
+    split last - and is the same record sequence as the reference loop's codes select."""
+    import oracle as orc
+    from tests.common import dataset
+    cfg, b, h, refs, sites = dataset("tiny", 3000, 4, 0.02)
+    gof, G = sfm.contig_groups(cfg.ref_len, int(max(cfg.ref_len)))
+    g, spread = sfm.split_records(b, gof)
+    ids = np.arange(b.n)
+    parts, part_ids = [], []
+    for sel in [np.nonzero((g == k) & ~spread)[0] for k in range(1, G + 1)] + [np.nonzero(spread)[0], np.nonzero((g == 0) & ~spread)[0]]:
+        sb = b.take(sel)
+        perm = orc.sort_coordinate(sb)
+        parts.append(sfm.sorted_output(sb, perm, sb.flag, sb.qual))
+        part_ids.append(ids[sel][perm])
+    out = sfm.merge_splits(parts[:G], parts[G], parts[G + 1])
+    assert out.n == b.n
+    # which original record sits in every output slot, by the reference loop
+    gcat = np.concatenate(part_ids[:G]) if G else np.zeros(0, np.int64)
+    gk = [(int(b.refid[i]), int(b.pos[i])) for i in gcat]
+    sk = [(int(b.refid[i]), int(b.pos[i])) for i in part_ids[G]]
+    code = _merge_reference(gk, sk)
+    want = np.concatenate([np.where(code >= 0, gcat[np.clip(code, 0, None)] if len(gcat) else 0, part_ids[G][np.clip(-code - 1, 0, None)] if len(part_ids[G]) else 0),
+                           part_ids[G + 1]])
+    assert sorted(want.tolist()) == list(range(b.n))
+    for i in (0, 1, out.n // 2, out.n - 1):
+        assert out.qname_of(i) == b.qname_of(int(want[i])) and out.seq_of(i) == b.seq_of(int(want[i]))
+    assert np.array_equal(out.refid, b.refid[want]) and np.array_equal(out.pos, b.pos[want]) and np.array_equal(out.flag, b.flag[want])
+    assert np.array_equal(np.diff(out.qual_off.astype(np.int64)), np.diff(b.qual_off.astype(np.int64))[want])
+    # mapped part sorted by (refid, pos)
+    m = out.refid >= 0
+    key = (out.refid[m].astype(np.int64) << 32) | out.pos[m].astype(np.int64)
+    assert (np.diff(key) >= 0).all()
