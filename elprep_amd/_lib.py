@@ -21,13 +21,13 @@ _host: Optional[C.CDLL] = None
 HIP_SYMBOLS = [
     "elp_create", "elp_destroy", "elp_last_error", "elp_sync", "elp_stream", "elp_set_header", "elp_reserve", "elp_stage", "elp_reset",
     "elp_num_records", "elp_sort_coordinate", "elp_get_permutation", "elp_mark_duplicates", "elp_get_flags", "elp_get_adapted",
-    "elp_dup_metrics", "elp_bqsr_set_reference", "elp_bqsr_set_known_sites", "elp_bqsr_gather", "elp_bqsr_apply", "elp_get_qual",
+    "elp_dup_metrics", "elp_dup_metrics_hist", "elp_bqsr_set_reference", "elp_bqsr_set_known_sites", "elp_bqsr_gather", "elp_bqsr_apply", "elp_get_qual",
     "elp_snapshot", "elp_rollback", "elp_profile_enable", "elp_profile_reset", "elp_profile_count", "elp_profile_get",
 ]
 HOST_SYMBOLS = [
     "elp_bqsr_tables_new", "elp_bqsr_tables_free", "elp_bqsr_tables_merge", "elp_bqsr_tables_finalize", "elp_bqsr_tables_empirical",
     "elp_bqsr_tables_combined", "elp_bqsr_tables_quantize", "elp_bqsr_tables_build_lut", "elp_bqsr_tables_report", "elp_host_free",
-    "elp_dup_derived", "elp_dup_metrics_report",
+    "elp_dup_derived", "elp_dup_metrics_report", "elp_dup_metrics_report_hist",
 ]
 
 
@@ -66,6 +66,7 @@ def hip() -> C.CDLL:
         L.elp_get_flags.argtypes = [C.c_void_p, C.c_void_p]
         L.elp_get_adapted.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.elp_dup_metrics.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.elp_dup_metrics_hist.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.elp_bqsr_set_reference.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
         L.elp_bqsr_set_known_sites.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
         L.elp_bqsr_gather.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -100,5 +101,7 @@ def host() -> C.CDLL:
         L.elp_dup_derived.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.elp_dup_metrics_report.restype = C.c_void_p
         L.elp_dup_metrics_report.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_char_p]
+        L.elp_dup_metrics_report_hist.restype = C.c_void_p
+        L.elp_dup_metrics_report_hist.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_char_p]
         _host = L
     return _host

@@ -181,13 +181,19 @@ __device__ __forceinline__ bool optical_close(const Member &a, const Member &b, 
 
 // one thread per member slot; the origin's slot evaluates its set: optical count = n - #components under the closeness relation
 // (sets of two and three members, the bulk, are evaluated in registers; larger ones with a union-find in `parent`)
+// hist (may be null): the three set-size histograms per library, [(n_lib + 1)][3][hist_len] (incrementDuplicatesCountsHistograms
+// :150-174: sets of n listed reads, of them `optical` optical duplicates - bin n of the first, bin n - optical (if > 0) of the
+// second, bin optical + 1 (if optical > 0) of the third; indices beyond the last bin count into the last bin); the first lds_bins
+// bins of every histogram are collected in LDS like the optical counts
 __global__ __launch_bounds__(128) void k_opt_eval(MxCols m, uint32_t total, const uint2 *__restrict__ ginfo, const Member *__restrict__ members,
                                                   uint32_t *__restrict__ parent, long long dist, unsigned long long *__restrict__ ctr,
-                                                  uint32_t *err) {
+                                                  uint32_t *err, unsigned long long *__restrict__ hist, int hist_len, int lds_bins) {
   // per-library optical counts are collected in LDS first: the global counters are a handful of addresses, and a global atomic
   // on one address serialises at ~12 ns
-  extern __shared__ unsigned int lds_opt[];  // [n_lib + 1]
-  for (int k = threadIdx.x; k <= m.n_lib; k += blockDim.x) lds_opt[k] = 0;
+  extern __shared__ unsigned int lds_opt[];  // [n_lib + 1], then [(n_lib + 1)][3][lds_bins]
+  unsigned int *lds_h = lds_opt + (m.n_lib + 1);
+  const int n_h = hist ? (m.n_lib + 1) * 3 * lds_bins : 0;
+  for (int k = threadIdx.x; k <= m.n_lib + n_h; k += blockDim.x) lds_opt[k] = 0;
   __syncthreads();
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   const uint2 gi = b < total ? ginfo[b] : make_uint2(0u, 0u);
@@ -221,25 +227,60 @@ __global__ __launch_bounds__(128) void k_opt_eval(MxCols m, uint32_t total, cons
     optical = cnt - comps;  // sum over both strand lists of (n - components): lists never connect (rg_rev differs)
   }
   }
-  if (optical) {
+  if (optical || (hist && cnt >= 2 && cnt <= 300000u)) {
     const uint32_t owner = m.pwinner[gi.y];
     uint32_t a1, a2;
     order_ends(m, owner, m.mate[owner], a1, a2);
-    atomicAdd(&lds_opt[lib_row(m, a1)], optical);  // origin.aln1.LIBID() :381
+    const uint32_t lib = lib_row(m, a1);  // origin.aln1.LIBID() :381
+    if (optical) atomicAdd(&lds_opt[lib], optical);
+    if (hist && cnt >= 2 && cnt <= 300000u) {
+      const int idx[3] = {(int)cnt, (int)(cnt - optical), optical ? (int)optical + 1 : 0};  // cnt - optical >= 1: a set has a component
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        if (idx[k] <= 0) continue;
+        const int bin = idx[k] < hist_len ? idx[k] : hist_len - 1;
+        if (bin < lds_bins) atomicAdd(&lds_h[((int)lib * 3 + k) * lds_bins + bin], 1u);
+        else atomicAdd(&hist[((size_t)lib * 3 + k) * hist_len + bin], 1ull);
+      }
+    }
   }
   __syncthreads();
   for (int k = threadIdx.x; k <= m.n_lib; k += blockDim.x)
     if (lds_opt[k]) atomicAdd(&ctr[k * ELP_NCTR + 6], (unsigned long long)lds_opt[k]);
+  for (int k = threadIdx.x; k < n_h; k += blockDim.x)
+    if (lds_h[k]) atomicAdd(&hist[(size_t)(k / lds_bins) * hist_len + (k % lds_bins)], (unsigned long long)lds_h[k]);
 }
 
-static int metrics_impl(elp_ctx *c, int dist, int64_t *counters_host) {
+// number of pair groups (= origins, the pairs that stayed best of their group) per library
+__global__ __launch_bounds__(256) void k_origin_count(MxCols m, unsigned long long *__restrict__ origins) {
+  extern __shared__ unsigned int lds_org[];  // [n_lib + 1]
+  for (int k = threadIdx.x; k <= m.n_lib; k += blockDim.x) lds_org[k] = 0;
+  __syncthreads();
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m.n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t rep = m.prep[i];
+    if (rep == EMPTY || m.pwinner[rep] != (uint32_t)i) continue;
+    uint32_t a1, a2;
+    order_ends(m, (uint32_t)i, m.mate[i], a1, a2);
+    atomicAdd(&lds_org[lib_row(m, a1)], 1u);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k <= m.n_lib; k += blockDim.x)
+    if (lds_org[k]) atomicAdd(&origins[k], (unsigned long long)lds_org[k]);
+}
+
+static int metrics_impl(elp_ctx *c, int dist, int64_t *counters_host, int64_t *hist_host, int hist_len) {
   const uint64_t n = c->n;
   const int ncell = (c->n_lib + 1) * ELP_NCTR;
   if (!c->marked) return set_error(c, ELP_ERR_ARG, "elp_dup_metrics: call elp_mark_duplicates first");
+  // device block: the counters, then (if asked for) the origins per library and the three histograms per library
+  const size_t nhist = hist_host ? (size_t)(c->n_lib + 1) * 3 * (size_t)hist_len : 0, norg = hist_host ? (size_t)(c->n_lib + 1) : 0;
   unsigned long long *ctr;
-  ELP_TRY(scratch(c, 0, (size_t)ncell + 8, &ctr));
+  ELP_TRY(scratch(c, 0, (size_t)ncell + norg + nhist + 8, &ctr));
+  unsigned long long *origins = ctr + ncell, *hist = hist_host ? origins + norg : nullptr;
   hipStream_t st = c->stream;
-  ELP_HIP(c, hipMemsetAsync(ctr, 0, ncell * sizeof(unsigned long long), st));
+  ELP_HIP(c, hipMemsetAsync(ctr, 0, ((size_t)ncell + norg + nhist) * sizeof(unsigned long long), st));
+  int lds_bins = hist_host ? std::min(hist_len, 32) : 0;
+  if ((size_t)(c->n_lib + 1) * (1 + 3 * (size_t)lds_bins) * sizeof(unsigned int) > 32768) lds_bins = 0;
   if (n) {
     MxCols m{n, c->refid.p, c->flag.p, c->rgid.p, c->rg_lib.p, c->upos.p, c->qname_off.p, c->qname.p, c->mate.p, c->pair_slot.p, c->pair_winner.p, c->n_lib};
     const unsigned grid = blocks_for(n, 256);
@@ -264,12 +305,15 @@ static int metrics_impl(elp_ctx *c, int dist, int64_t *counters_host) {
       ELP_HIP(c, hipMemsetAsync(ginfo, 0, (size_t)total * sizeof(uint2), st));
       ELP_LAUNCH(c, "mx_opt_slots", k_opt_slots, dim3(grid), dim3(256), 0, m, (const uint32_t *)goff, gfill, mread, ginfo);
       ELP_LAUNCH(c, "mx_opt_fill", k_opt_fill, dim3(blocks_for(total, 256)), dim3(256), 0, m, total, (const uint32_t *)mread, members, c->err_flag.p);
-      ELP_LAUNCH(c, "mx_opt_eval", k_opt_eval, dim3(blocks_for(total, 128)), dim3(128), (c->n_lib + 1) * sizeof(unsigned int), m, total, (const uint2 *)ginfo, (const Member *)members, parent,
-                 (long long)dist, ctr, c->err_flag.p);
+      ELP_LAUNCH(c, "mx_opt_eval", k_opt_eval, dim3(blocks_for(total, 128)), dim3(128),
+                 (size_t)(c->n_lib + 1) * (1 + (hist ? 3 * (size_t)lds_bins : 0)) * sizeof(unsigned int), m, total, (const uint2 *)ginfo,
+                 (const Member *)members, parent, (long long)dist, ctr, c->err_flag.p, hist, hist_len, lds_bins);
     }
+    if (hist)
+      ELP_LAUNCH(c, "mx_origin_count", k_origin_count, dim3(std::min(grid, 2048u)), dim3(256), (c->n_lib + 1) * sizeof(unsigned int), m, origins);
   }
-  std::vector<unsigned long long> h(ncell);
-  ELP_HIP(c, hipMemcpyAsync(h.data(), ctr, ncell * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  std::vector<unsigned long long> h((size_t)ncell + norg + nhist);
+  ELP_HIP(c, hipMemcpyAsync(h.data(), ctr, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   uint32_t e[4];
   ELP_TRY(fetch_err(c, e));
   if (e[2]) {
@@ -280,6 +324,20 @@ static int metrics_impl(elp_ctx *c, int dist, int64_t *counters_host) {
   for (int l = 0; l <= c->n_lib; l++)
     for (int k = 0; k < ELP_NCTR; k++) counters_host[l * ELP_NCTR + k] = (int64_t)h[l * ELP_NCTR + k];
   for (int l = 0; l <= c->n_lib; l++) counters_host[l * ELP_NCTR + 1] /= 2;  // ReadPairsExamined counts reads, then halves (:504-506)
+  if (hist_host) {
+    // the device counted the sets that have duplicates; an origin without duplicates is a set of one read, none of them optical
+    const unsigned long long *ho = h.data() + ncell, *hh = ho + norg;
+    for (int l = 0; l <= c->n_lib; l++) {
+      int64_t *out = hist_host + (size_t)l * 3 * hist_len;
+      unsigned long long with_dups = 0;
+      for (size_t k = 0; k < (size_t)3 * hist_len; k++) out[k] = (int64_t)hh[(size_t)l * 3 * hist_len + k];
+      for (int b = 0; b < hist_len; b++) with_dups += hh[(size_t)l * 3 * hist_len + b];
+      const int64_t alone = (int64_t)(ho[l] - with_dups);
+      const int one = 1 < hist_len ? 1 : hist_len - 1;
+      out[one] += alone;             // duplicatesCountHistogram[1]
+      out[hist_len + one] += alone;  // nonOpticalDuplicatesCountHistogram[1]
+    }
+  }
   return 0;
 }
 
@@ -288,5 +346,11 @@ static int metrics_impl(elp_ctx *c, int dist, int64_t *counters_host) {
 extern "C" int elp_dup_metrics(elp_ctx *c, int optical_pixel_distance, int64_t *counters) {
   if (!c || !counters) return ELP_ERR_ARG;
   ELP_HIP(c, hipSetDevice(c->device));
-  return elp::metrics_impl(c, optical_pixel_distance, counters);
+  return elp::metrics_impl(c, optical_pixel_distance, counters, nullptr, 0);
+}
+
+extern "C" int elp_dup_metrics_hist(elp_ctx *c, int optical_pixel_distance, int64_t *counters, int64_t *hist, int hist_len) {
+  if (!c || !counters || !hist || hist_len < 2) return elp::set_error(c, ELP_ERR_ARG, "elp_dup_metrics_hist: bad arguments (hist_len >= 2)");
+  ELP_HIP(c, hipSetDevice(c->device));
+  return elp::metrics_impl(c, optical_pixel_distance, counters, hist, hist_len);
 }

@@ -112,8 +112,14 @@ class Engine:
         self._check(self.L.elp_get_adapted(self.h, _vp(up), _vp(sc)))
         return up, sc
 
-    def dup_metrics(self, pixel_dist: int = 100) -> np.ndarray:
+    def dup_metrics(self, pixel_dist: int = 100, hist_len: int = 0):
+        """DuplicationMetrics counters [n_lib + 1][7]; with hist_len >= 2 also the three set-size histograms
+        [n_lib + 1][3][hist_len] (duplicates / non-optical / optical, the last bin takes everything beyond it)."""
         ctr = np.zeros((self.header.n_lib + 1, NCTR), dtype=np.int64)
+        if hist_len:
+            hist = np.zeros((self.header.n_lib + 1, 3, hist_len), dtype=np.int64)
+            self._check(self.L.elp_dup_metrics_hist(self.h, pixel_dist, _vp(ctr), _vp(hist), hist_len))
+            return ctr, hist
         self._check(self.L.elp_dup_metrics(self.h, pixel_dist, _vp(ctr)))
         return ctr
 
@@ -251,11 +257,16 @@ def dup_derived(ctr_row: np.ndarray) -> Tuple[float, int]:
     return pct.value, ls.value
 
 
-def dup_metrics_report(counters: np.ndarray, lib_names: Sequence[str], command_line: str = "") -> str:
+def dup_metrics_report(counters: np.ndarray, lib_names: Sequence[str], command_line: str = "", hist: Optional[np.ndarray] = None) -> str:
+    """PrintDuplicatesMetrics; with `hist` (Engine.dup_metrics(..., hist_len)) also the "## HISTOGRAM" block."""
     H = _lib.host()
     ctr = np.ascontiguousarray(counters, dtype=np.int64)
     arr = (C.c_char_p * max(len(lib_names), 1))(*[n.encode() for n in lib_names])
-    p = H.elp_dup_metrics_report(_vp(ctr), len(lib_names), C.cast(arr, C.c_void_p), command_line.encode())
+    if hist is not None:
+        hh = np.ascontiguousarray(hist, dtype=np.int64)
+        p = H.elp_dup_metrics_report_hist(_vp(ctr), _vp(hh), int(hh.shape[2]), len(lib_names), C.cast(arr, C.c_void_p), command_line.encode())
+    else:
+        p = H.elp_dup_metrics_report(_vp(ctr), len(lib_names), C.cast(arr, C.c_void_p), command_line.encode())
     s = C.string_at(p).decode()
     H.elp_host_free(C.c_void_p(p))
     return s

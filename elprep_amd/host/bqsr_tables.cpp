@@ -589,7 +589,8 @@ static std::string format_float(double v) {  // formatFloat :590-605
   return s.substr(0, j + 1);
 }
 
-char *elp_dup_metrics_report(const int64_t *ctr, int n_lib, const char *const *lib_names, const char *command_line) {
+char *elp_dup_metrics_report_hist(const int64_t *ctr, const int64_t *hist, int hist_len, int n_lib, const char *const *lib_names,
+                                  const char *command_line) {
   Sb o;
   o.f("## htsjdk.samtools.metrics.StringHeader\n");
   o.f("# %s\n", command_line ? command_line : "");
@@ -611,10 +612,37 @@ char *elp_dup_metrics_report(const int64_t *ctr, int n_lib, const char *const *l
       o.f("%s\t%lld\t%lld\t%lld\t%lld\t%lld\t%lld\t%lld\t%s\n", name, (long long)k[0], (long long)k[1], (long long)k[2], (long long)k[3], (long long)k[4],
           (long long)k[5], (long long)k[6], ps.c_str());
   }
-  o.f("\n\n");
+  o.f("\n");
+  // the histogram block is only written if exactly one library has pairs (:628-646)
+  int one = -1, many = 0;
+  for (int l = 0; l <= n_lib; l++)
+    if (ctr[size_t(l) * 7 + 1] > 0) { many += one >= 0; one = l; }
+  if (!hist || one < 0 || many) {
+    o.f("\n");
+  } else {
+    const int64_t *k = ctr + size_t(one) * 7;
+    const int64_t *h0 = hist + size_t(one) * 3 * hist_len, *h1 = h0 + hist_len, *h2 = h1 + hist_len;  // all / non-optical / optical sets
+    const auto at = [&](const int64_t *h, int b) { return b < hist_len ? (long long)h[b] : 0ll; };
+    double pct; int64_t ls;
+    elp_dup_derived(k, &pct, &ls);
+    const int64_t n_pairs = k[1], n_unique = k[1] - k[5];
+    o.f("## HISTOGRAM\tjava.lang.Double\n");
+    o.f("BIN\tCoverageMult\tall_sets\toptical_sets\tnon_optical_sets\n");
+    for (int x = 1; x <= 100; x++) {  // histogramRoi / estimateRoi :576-588
+      const double roi = double(ls) * (1.0 - std::exp(-double(int64_t(x) * n_pairs) / double(ls))) / double(n_unique);
+      o.f("%d.0\t%s\t%lld\t%lld\t%lld\n", x, format_float(roi).c_str(), at(h0, x), at(h2, x), at(h1, x));
+    }
+    for (int b = 101; b < hist_len; b++)  // set sizes beyond 100 that occur (the reference sorts its map keys, :659-697)
+      if (h0[b] || h1[b] || h2[b]) o.f("%d.0\t0\t%lld\t%lld\t%lld\n", b, (long long)h0[b], (long long)h2[b], (long long)h1[b]);
+    o.f("\n");
+  }
   char *out = (char *)std::malloc(o.s.size() + 1);
   std::memcpy(out, o.s.c_str(), o.s.size() + 1);
   return out;
+}
+
+char *elp_dup_metrics_report(const int64_t *ctr, int n_lib, const char *const *lib_names, const char *command_line) {
+  return elp_dup_metrics_report_hist(ctr, nullptr, 0, n_lib, lib_names, command_line);
 }
 
 }  // extern "C"

@@ -117,6 +117,12 @@ int elp_get_adapted(elp_ctx *ctx, int32_t *upos_out, int32_t *score_out);
  * Picard text (:608-699) stay on the host. */
 #define ELP_NCTR 7
 int elp_dup_metrics(elp_ctx *ctx, int optical_pixel_distance, int64_t *counters);
+/* The same plus the three set-size histograms the reference keeps per library (duplicatesCountHistogram,
+ * nonOpticalDuplicatesCountHistogram, opticalDuplicatesCountHistogram, filters/mark-optical-duplicates.go:104-174, 310-324):
+ * hist = [(n_lib + 1)][3][hist_len] int64; a set of n listed reads with k optical duplicates counts into bin n of the first,
+ * bin n - k (if > 0) of the second and bin k + 1 (if k > 0) of the third histogram; indices >= hist_len count into the last bin
+ * (the reference's maps are unbounded); hist_len >= 2. */
+int elp_dup_metrics_hist(elp_ctx *ctx, int optical_pixel_distance, int64_t *counters, int64_t *hist, int hist_len);
 
 /* ---- BQSR inputs: NewBaseRecalibrator(knownSites, referenceFasta) (filters/bqsr.go:424-443) ----
  * bases = raw .elfasta bytes of one contig (fasta.MappedFasta.Seq, fasta/fasta-files.go:355);

@@ -42,9 +42,15 @@ void elp_host_free(void *p);
 /* calculateDerivedDuplicateMetrics (filters/mark-optical-duplicates.go:527-569) for one library row of elp_dup_metrics */
 int elp_dup_derived(const int64_t *ctr7, double *percent_duplication, int64_t *estimated_library_size);
 /* PrintDuplicatesMetrics (filters/mark-optical-duplicates.go:608-699) without the timestamp line's clock value and without set-size
- * histograms (not carried over the C ABI; the reference loses them in sfm mode too, :702-731).  lib_names has n_lib entries;
+ * histograms (elp_dup_metrics_report_hist adds them; the reference loses them in sfm mode, :702-731).  lib_names has n_lib entries;
  * row n_lib is "Unknown Library".  Returns a malloc'd string. */
 char *elp_dup_metrics_report(const int64_t *counters, int n_lib, const char *const *lib_names, const char *command_line);
+/* The same with the "## HISTOGRAM" block (:628-697): written when exactly one library has pairs - the return-on-investment column
+ * (histogramRoi :580-588) and, per set size 1..100 and every larger size that occurs, the number of duplicate sets / sets with optical
+ * duplicates / sets with non-optical duplicates from elp_dup_metrics_hist's histograms [(n_lib + 1)][3][hist_len] (sizes >= hist_len - 1
+ * are merged into the last bin there: pass a hist_len above the largest set to get the reference's rows). */
+char *elp_dup_metrics_report_hist(const int64_t *counters, const int64_t *hist, int hist_len, int n_lib, const char *const *lib_names,
+                                  const char *command_line);
 
 #ifdef __cplusplus
 }

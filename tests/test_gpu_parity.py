@@ -46,6 +46,12 @@ def test_adapt_sort_markdup_metrics(name, pairs, seed, pfrag):
     assert np.array_equal(ctr, octr)
     if pairs >= 4000:
         assert ctr[:, 6].sum() > 0  # optical duplicates present
+    # the three set-size histograms per library, with a short last bin (3) and a long one
+    for hl in (3, 24):
+        _, octr2, ohist = orc.dup_metrics(b, h, operm, 100, hist_len=hl)
+        ctr2, hist = e.dup_metrics(100, hist_len=hl)
+        assert np.array_equal(ctr2, octr2) and np.array_equal(hist, ohist)
+        assert hist[:, 0, 1].sum() > 0 and hist[:, 0, 2:].sum() > 0
     e.close()
 
 

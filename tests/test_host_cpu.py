@@ -126,6 +126,37 @@ def test_dup_derived_and_report():
     assert "Unknown Library\t0\t0\t0\t0\t0\t0\t0\tNaN\n" in txt
 
 
+def test_dup_report_histogram_block():
+    """'## HISTOGRAM' (filters/mark-optical-duplicates.go:628-697): only with exactly one library that has pairs; ROI column from
+    estimateRoi, counts from the three set-size histograms, sizes beyond 100 as extra rows."""
+    import math
+    row = np.array([10, 1000, 5, 7, 2, 100, 20], dtype=np.int64)
+    ctr = np.stack([row, np.zeros(7, np.int64)])
+    hist = np.zeros((2, 3, 140), np.int64)
+    hist[0, 0, 1], hist[0, 0, 2], hist[0, 0, 3], hist[0, 0, 120] = 800, 90, 9, 1   # all sets
+    hist[0, 1, 1], hist[0, 1, 2], hist[0, 1, 119] = 815, 84, 1                     # non-optical
+    hist[0, 2, 2], hist[0, 2, 3] = 18, 2                                            # optical
+    txt = dup_metrics_report(ctr, ["libA"], "cmd", hist=hist)
+    lines = txt.split("\n")
+    k = lines.index("## HISTOGRAM\tjava.lang.Double")
+    assert lines[k + 1] == "BIN\tCoverageMult\tall_sets\toptical_sets\tnon_optical_sets"
+    _, ls = dup_derived(row)
+
+    def fmt(f):
+        s = "%.6f" % f
+        t = s.rstrip("0")
+        return s if t.endswith(".") else t
+
+    for x in (1, 2, 3, 50, 100):
+        roi = float(ls) * (1.0 - math.exp(-float(x * 1000) / float(ls))) / float(1000 - 100)
+        assert lines[k + 1 + x] == "%d.0\t%s\t%d\t%d\t%d" % (x, fmt(roi), hist[0, 0, x], hist[0, 2, x], hist[0, 1, x]), x
+    assert lines[k + 102] == "119.0\t0\t0\t0\t1" and lines[k + 103] == "120.0\t0\t1\t0\t0" and lines[k + 104] == ""
+    # two libraries with pairs: no histogram block; without histograms: the old text
+    two = np.stack([row, row, np.zeros(7, np.int64)])
+    assert "## HISTOGRAM" not in dup_metrics_report(two, ["a", "b"], "cmd", hist=np.zeros((3, 3, 8), np.int64))
+    assert dup_metrics_report(ctr, ["libA"], "cmd") == txt[:txt.index("## HISTOGRAM")] + "\n"
+
+
 def test_host_pool_is_reentrant_and_arrays_can_be_reused(tables):
     """finalize / build_lut run their rows on a shared worker pool: calls from several host threads at once give the results of
     sequential calls, and filling a LUT pair of an earlier call again gives the same bytes as a fresh one."""
