@@ -217,3 +217,25 @@ def test_float_helpers():
     # library size estimate (mark-optical-duplicates.go:541-569): no duplicates -> 0
     assert orc.estimate_library_size(1000, 1000) == 0
     assert orc.estimate_library_size(1000, 900) > 900
+
+
+def test_duplicate_set_size_histograms():  # filters/mark-optical-duplicates.go:150-174, 275-325, 469-525 (hand-derived)
+    """One set of four pairs at the same ends: the origin (best score) and two of its duplicates lie within 100 px of each other on one
+    tile (a cluster of three listed reads = 2 optical duplicates, :244-273), the third duplicate is on another tile -> bins all[4],
+    non_optical[4 - 2], optical[2 + 1]; one pair without duplicates -> all[1], non_optical[1]."""
+    h = _hdr()
+    q = lambda v: [v] * 10
+    recs = []
+    for name, score in (("M:1:F:1:1101:1000:2000", 40), ("M:1:F:1:1101:1050:2050", 20), ("M:1:F:1:1101:1080:2010", 20), ("M:1:F:1:2205:1000:2000", 20)):
+        recs.append(_rec(name, 99, 0, 100, qual=q(score), next_refid=0, pnext=300, tlen=210))
+        recs.append(_rec(name, 147, 0, 300, qual=q(score), next_refid=0, pnext=100, tlen=-210))
+    recs.append(_rec("M:1:F:1:1101:5:5", 99, 0, 500, qual=q(30), next_refid=0, pnext=700, tlen=210))
+    recs.append(_rec("M:1:F:1:1101:5:5", 147, 0, 700, qual=q(30), next_refid=0, pnext=500, tlen=-210))
+    b = batch_from_records(recs)
+    perm = orc.sort_coordinate(b)
+    flags, ctr, hist = orc.dup_metrics(b, h, perm, 100, hist_len=8)
+    assert ctr[0, 1] == 5 and ctr[0, 5] == 3 and ctr[0, 6] == 2   # pairs examined, pair duplicates, optical duplicates
+    want = np.zeros((3, 8), np.int64)
+    want[0, 4] = 1; want[1, 2] = 1; want[2, 3] = 1
+    want[0, 1] = 1; want[1, 1] = 1
+    assert np.array_equal(hist[0], want), hist[0]
