@@ -239,3 +239,22 @@ def test_duplicate_set_size_histograms():  # filters/mark-optical-duplicates.go:
     want[0, 4] = 1; want[1, 2] = 1; want[2, 3] = 1
     want[0, 1] = 1; want[1, 1] = 1
     assert np.array_equal(hist[0], want), hist[0]
+
+
+@pytest.mark.parametrize("rec,exp", [
+    # forward read reading through into the adaptor: boundary = POS + |TLEN| = 130 lies inside [100, 149] -> right tail from read
+    # coordinate 30 on is clipped (filters/utils.go:149-180, 214-222, 253-262): bases [0, 30), 30M20H, POS unchanged
+    (dict(flag=0x1 | 0x20 | 0x40, pos=100, cigar="50M", pnext=110, tlen=30), (0, 30, 100, [(30, "M"), (20, "H")])),
+    # reverse read, mate forward at 120: boundary = PNEXT - 1 = 119 -> left tail up to read coordinate 19 is clipped: bases
+    # [20, 50), 20H30M, POS moves by the 20 clipped bases (calculateAlnStartShift)
+    (dict(flag=0x1 | 0x10 | 0x80, pos=100, cigar="50M", pnext=120, tlen=-30), (20, 50, 120, [(20, "H"), (30, "M")])),
+    # soft clips become hard clips (hardClipSoftClippedBases); POS is the first aligned base already
+    (dict(flag=0, pos=100, cigar="5S40M5S", pnext=0, tlen=0), (5, 45, 100, [(5, "H"), (40, "M"), (5, "H")])),
+    # insert longer than the read: the boundary (350) lies behind the read's end (149): nothing to clip
+    (dict(flag=0x1 | 0x20 | 0x40, pos=100, cigar="50M", pnext=300, tlen=250), (0, 50, 100, [(50, "M")])),
+])
+def test_clipping_for_bqsr(rec, exp):  # hand-derived from filters/utils.go:149-262, 374-470
+    r = dict(qname="q", refid=0, mapq=60, next_refid=0, seq="A" * 50, qual=[30] * 50, rgid=0)
+    r.update(rec)
+    a, e, npos, cg = orc.clip_for_bqsr(batch_from_records([r]), 0)
+    assert (a, e, npos, [(int(c) >> 4, "MIDNSHP=X"[int(c) & 15]) for c in cg]) == exp
