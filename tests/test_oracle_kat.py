@@ -258,3 +258,60 @@ def test_clipping_for_bqsr(rec, exp):  # hand-derived from filters/utils.go:149-
     r.update(rec)
     a, e, npos, cg = orc.clip_for_bqsr(batch_from_records([r]), 0)
     assert (a, e, npos, [(int(c) >> 4, "MIDNSHP=X"[int(c) & 15]) for c in cg]) == exp
+
+
+def test_bqsr_tables_of_one_read_from_first_principles():  # filters/bqsr.go:254-285 (SNP events), 376-387 (cycle), 87-146 (context)
+    """A 12-base forward single-end read, all qualities 30, one mismatch against the reference at read index 5, no known sites:
+    every base is observed once in its (quality, cycle) cell, cycle = index + 1; bases 1..11 once in the context cell of
+    (previous base, base) with index prev | cur << 2 (A0 C1 G2 T3); the mismatch counts in all three tables."""
+    from elprep_amd.batch import Header
+    seq = "ACGTACGTACGT"
+    ref = list("N" * 10 + seq + "N" * 8)
+    ref[10 + 5] = "A"  # the read has C there
+    refb = np.frombuffer("".join(ref).encode(), dtype=np.uint8)
+    b = batch_from_records([dict(qname="q", flag=0, refid=0, pos=11, cigar="12M", mapq=60, seq=seq, qual=[30] * 12, rgid=0)])
+    h = Header(ref_len=np.array([len(ref)], np.int32), rg_lib=np.array([0], np.uint16), rg_cov=np.array([0], np.uint16))
+    qt, ct, xt = orc.bqsr_gather(b, h, orc.BqsrRef([refb], [np.zeros((0, 2), np.int32)]), None, 500)
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    wq = np.zeros_like(qt); wc = np.zeros_like(ct); wx = np.zeros_like(xt)
+    for i in range(12):
+        e = 1 if i == 5 else 0
+        wq[0, 30] += (1, e)
+        wc[0, 30, 500 + (i + 1)] += (1, e)
+        if i >= 1:
+            wx[0, 30, code[seq[i - 1]] | (code[seq[i]] << 2)] += (1, e)
+    assert np.array_equal(qt, wq) and np.array_equal(ct, wc) and np.array_equal(xt, wx)
+    # the same read as the reverse-strand second of a pair: cycles are negative and run from the read's end (-(12 - i)), the
+    # context is taken on the reverse complement (previous base = the complement of base i + 1)
+    b2 = batch_from_records([dict(qname="q", flag=0x1 | 0x10 | 0x80, refid=0, pos=11, cigar="12M", mapq=60, next_refid=0, pnext=400, tlen=0,
+                                  seq=seq, qual=[30] * 12, rgid=0)])
+    qt, ct, xt = orc.bqsr_gather(b2, h, orc.BqsrRef([refb], [np.zeros((0, 2), np.int32)]), None, 500)
+    comp = {"A": 3, "C": 2, "G": 1, "T": 0}
+    wc[:] = 0; wx[:] = 0
+    for i in range(12):
+        e = 1 if i == 5 else 0
+        wc[0, 30, 500 - (12 - i)] += (1, e)
+        if i <= 10:
+            wx[0, 30, comp[seq[i + 1]] | (comp[seq[i]] << 2)] += (1, e)
+    assert np.array_equal(qt, wq) and np.array_equal(ct, wc) and np.array_equal(xt, wx)
+
+
+def test_bqsr_known_site_skips_only_its_own_bases():  # filters/bqsr.go:389-414 (calculateSkipSlice), :301-305
+    """A known site over reference positions 14..15 (read indices 3, 4 of a read at POS 11): exactly those two bases drop out of all
+    three tables; base 5 keeps its context (the base in front of it is still its predecessor)."""
+    from elprep_amd.batch import Header
+    seq = "ACGTACGTACGT"
+    refb = np.frombuffer(("N" * 10 + seq + "N" * 8).encode(), dtype=np.uint8)
+    b = batch_from_records([dict(qname="q", flag=0, refid=0, pos=11, cigar="12M", mapq=60, seq=seq, qual=[30] * 12, rgid=0)])
+    h = Header(ref_len=np.array([len(refb)], np.int32), rg_lib=np.array([0], np.uint16), rg_cov=np.array([0], np.uint16))
+    qt, ct, xt = orc.bqsr_gather(b, h, orc.BqsrRef([refb], [np.array([[14, 15]], np.int32)]), None, 500)
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    wq = np.zeros_like(qt); wc = np.zeros_like(ct); wx = np.zeros_like(xt)
+    for i in range(12):
+        if i in (3, 4):
+            continue
+        wq[0, 30, 0] += 1
+        wc[0, 30, 500 + (i + 1), 0] += 1
+        if i >= 1:
+            wx[0, 30, code[seq[i - 1]] | (code[seq[i]] << 2), 0] += 1
+    assert np.array_equal(qt, wq) and np.array_equal(ct, wc) and np.array_equal(xt, wx)
