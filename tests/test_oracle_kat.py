@@ -315,3 +315,49 @@ def test_bqsr_known_site_skips_only_its_own_bases():  # filters/bqsr.go:389-414 
         if i >= 1:
             wx[0, 30, code[seq[i - 1]] | (code[seq[i]] << 2), 0] += 1
     assert np.array_equal(qt, wq) and np.array_equal(ct, wc) and np.array_equal(xt, wx)
+
+
+def test_bqsr_low_quality_tails_mask_the_context():  # filters/bqsr.go:310-345 (computeStrandedClippedSeq), :301-305 (quality < 6)
+    """Qualities <= 2 at both ends: those bases read as N for the context covariate and are not counted themselves (quality < 6);
+    the first base behind the left tail is counted for quality and cycle but has no context (its predecessor is N)."""
+    from elprep_amd.batch import Header
+    seq = "ACGTACGTACGT"
+    refb = np.frombuffer(("N" * 10 + seq + "N" * 8).encode(), dtype=np.uint8)
+    qual = [2, 2] + [30] * 9 + [2]
+    b = batch_from_records([dict(qname="q", flag=0, refid=0, pos=11, cigar="12M", mapq=60, seq=seq, qual=qual, rgid=0)])
+    h = Header(ref_len=np.array([len(refb)], np.int32), rg_lib=np.array([0], np.uint16), rg_cov=np.array([0], np.uint16))
+    qt, ct, xt = orc.bqsr_gather(b, h, orc.BqsrRef([refb], [np.zeros((0, 2), np.int32)]), None, 500)
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    wq = np.zeros_like(qt); wc = np.zeros_like(ct); wx = np.zeros_like(xt)
+    for i in range(2, 11):
+        wq[0, 30, 0] += 1
+        wc[0, 30, 500 + (i + 1), 0] += 1
+        if i >= 3:
+            wx[0, 30, code[seq[i - 1]] | (code[seq[i]] << 2), 0] += 1
+    assert np.array_equal(qt, wq) and np.array_equal(ct, wc) and np.array_equal(xt, wx)
+
+
+def test_bqsr_insertion_and_deletion_in_snp_events():  # filters/bqsr.go:254-285
+    """5M2I5M against a reference without the two inserted bases, then 5M3D7M against a reference with three extra bases: inserted
+    bases are observed and never mismatch, a deletion only advances the reference; one planted mismatch behind each indel lands at
+    its read index (cycle = index + 1)."""
+    from elprep_amd.batch import Header
+    seq = "ACGTACGTACGT"
+    h1 = lambda n: Header(ref_len=np.array([n], np.int32), rg_lib=np.array([0], np.uint16), rg_cov=np.array([0], np.uint16))
+    no_sites = [np.zeros((0, 2), np.int32)]
+    # insertion: read indices 5, 6 are inserted; read index 8 is aligned to reference offset 6
+    ref = list("N" * 10 + seq[:5] + seq[7:] + "N" * 8)
+    ref[10 + 6] = "G"  # read has A at index 8
+    refb = np.frombuffer("".join(ref).encode(), dtype=np.uint8)
+    b = batch_from_records([dict(qname="q", flag=0, refid=0, pos=11, cigar="5M2I5M", mapq=60, seq=seq, qual=[30] * 12, rgid=0)])
+    qt, ct, xt = orc.bqsr_gather(b, h1(len(refb)), orc.BqsrRef([refb], no_sites), None, 500)
+    assert qt[0, 30].tolist() == [12, 1]
+    assert ct[0, 30, 501:513, 0].tolist() == [1] * 12 and np.nonzero(ct[0, 30, :, 1])[0].tolist() == [500 + 9]
+    # deletion: read index 5.. continues three reference bases later; read index 6 is aligned to reference offset 9
+    ref = list("N" * 10 + seq[:5] + "TTT" + seq[5:] + "N" * 8)
+    ref[10 + 9] = "A"  # read has G at index 6
+    refb = np.frombuffer("".join(ref).encode(), dtype=np.uint8)
+    b = batch_from_records([dict(qname="q", flag=0, refid=0, pos=11, cigar="5M3D7M", mapq=60, seq=seq, qual=[30] * 12, rgid=0)])
+    qt, ct, xt = orc.bqsr_gather(b, h1(len(refb)), orc.BqsrRef([refb], no_sites), None, 500)
+    assert qt[0, 30].tolist() == [12, 1]
+    assert ct[0, 30, 501:513, 0].tolist() == [1] * 12 and np.nonzero(ct[0, 30, :, 1])[0].tolist() == [500 + 7]
