@@ -361,3 +361,41 @@ def test_bqsr_insertion_and_deletion_in_snp_events():  # filters/bqsr.go:254-285
     qt, ct, xt = orc.bqsr_gather(b, h1(len(refb)), orc.BqsrRef([refb], no_sites), None, 500)
     assert qt[0, 30].tolist() == [12, 1]
     assert ct[0, 30, 501:513, 0].tolist() == [1] * 12 and np.nonzero(ct[0, 30, :, 1])[0].tolist() == [500 + 7]
+
+
+def test_bayesian_estimate_against_a_second_restatement():  # filters/bqsr.go:560-642
+    """calculateBayesianEstimateOfEmpiricalQuality written a second time from the source, in Python: Gaussian prior table
+    log10(0.9) - 2 d^2 log10(e) for d = 0..19 (what the reference's literal table holds), -MaxFloat64 from d = 20 on; binomial
+    log-likelihood with Lgamma; first maximum over the 61 candidate qualities wins.  Cases where the two best posteriors are closer
+    than 1e-9 are skipped (libm vs Python last-bit differences could flip them)."""
+    import math
+    import sys
+    log10e = math.log10(math.e)
+    prior = [math.log10(0.9) - 2.0 * d * d * log10e for d in range(20)] + [-sys.float_info.max]
+
+    def post(i, n, k, pq):
+        p1 = prior[min(abs(int(float(i) - pq)), 20)]
+        if n == 0:
+            return p1
+        lp = float(i) / -10.0
+        if lp == 0.0:
+            return p1 + -sys.float_info.max
+        coeff = (math.lgamma(n + 1) - math.lgamma(k + 1) - math.lgamma(n - k + 1)) * log10e
+        return p1 + coeff + lp * k + math.log10(1.0 - 10.0 ** lp) * (n - k)
+
+    rng = np.random.default_rng(9)
+    checked = 0
+    for _ in range(400):
+        n = int(rng.choice([0, 1, 2, 10, 100, 5000, 10 ** 6, 3 * 10 ** 8]))
+        k = int(rng.integers(0, min(n, 10 ** 5) + 1)) if n else 0
+        pq = float(rng.choice([0.0, 2.0, 17.0, 30.0, 37.5, 45.0, 60.0, 93.0]))
+        ps = [post(i, n, k, pq) for i in range(61)]
+        best = max(range(61), key=lambda i: (ps[i], -i))
+        top = sorted(ps, reverse=True)
+        if top[0] - top[1] < 1e-9 * max(1.0, abs(top[0])):
+            continue
+        assert orc.bayesian_estimate(n, k, pq) == best, (n, k, pq)
+        checked += 1
+    assert checked > 300
+    # the literal value the table starts with and ends with before the sentinel
+    assert abs(prior[5] - -21.760481585723266) < 1e-9 and abs(prior[19] - -313.60637342472336) < 1e-7
