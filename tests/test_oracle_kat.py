@@ -399,3 +399,39 @@ def test_bayesian_estimate_against_a_second_restatement():  # filters/bqsr.go:56
     assert checked > 300
     # the literal value the table starts with and ends with before the sentinel
     assert abs(prior[5] - -21.760481585723266) < 1e-9 and abs(prior[19] - -313.60637342472336) < 1e-7
+
+
+def test_estimate_library_size_against_a_second_restatement():  # filters/mark-optical-duplicates.go:532-569
+    """The bisection of estimateLibrarySize written a second time in Python, and one value that can be checked by hand: with
+    n = 1000 pairs and c = 900 unique ones the root x of c/x - 1 + exp(-n/x) lies near 4 600 molecules."""
+    import math
+
+    def f(x, c, n):
+        return c / x - 1 + math.exp(-n / x)
+
+    def est(n_pairs, n_unique):
+        n, c = float(n_pairs), float(n_unique)
+        if not (n_pairs > 0 and n_pairs - n_unique > 0):
+            return 0
+        m, M = 1.0, 100.0
+        while f(M * c, c, n) >= 0.0:
+            M *= 10.0
+        for _ in range(40):
+            r = (m + M) / 2.0
+            u = f(r * c, c, n)
+            if u == 0.0:
+                break
+            if u > 0.0:
+                m = r
+            if u < 0.0:
+                M = r
+        return int(c * ((m + M) / 2.0))
+
+    rng = np.random.default_rng(4)
+    for _ in range(200):
+        n = int(rng.integers(1, 10 ** 7))
+        c = int(rng.integers(max(1, n // 50), n + 1))
+        assert orc.estimate_library_size(n, c) == est(n, c), (n, c)
+    x = orc.estimate_library_size(1000, 900)
+    assert abs(f(float(x), 900.0, 1000.0)) < 1e-4 and 4000 < x < 5200  # x is truncated to an integer
+    assert orc.estimate_library_size(1000, 1000) == 0 and orc.estimate_library_size(0, 0) == 0
