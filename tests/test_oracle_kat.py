@@ -435,3 +435,44 @@ def test_estimate_library_size_against_a_second_restatement():  # filters/mark-o
     x = orc.estimate_library_size(1000, 900)
     assert abs(f(float(x), 900.0, 1000.0)) < 1e-4 and 4000 < x < 5200  # x is truncated to an integer
     assert orc.estimate_library_size(1000, 1000) == 0 and orc.estimate_library_size(0, 0) == 0
+
+
+def test_hierarchical_estimate_against_a_second_restatement():  # filters/bqsr.go:899-919, 970-999
+    """estimateHierarchicalBayesianQuality + the final rounding / bounding, written a second time in Python on top of the Bayesian
+    estimate (checked above), for tables with ONE reported quality per read group (then the combined read-group entry is that entry
+    and no map-iteration order enters): cycle and context entries present or absent."""
+    rng = np.random.default_rng(12)
+
+    def emp(obs, mism, prior):  # calculateEmpiricalQuality :644-649
+        return min(orc.bayesian_estimate(int(obs) + 2, int(mism) + 1, float(prior)), 93)
+
+    checked = 0
+    for trial in range(40):
+        q = int(rng.choice([8, 20, 30, 37]))
+        qt = np.zeros((1, 94, 2), np.int64); ct = np.zeros((1, 94, 1001, 2), np.int64); xt = np.zeros((1, 94, 16, 2), np.int64)
+        cycles = rng.choice(np.arange(-150, 151), size=6, replace=False)
+        cycles = cycles[cycles != 0]
+        for cy in cycles:
+            o = int(rng.integers(1, 20000)); ct[0, q, 500 + cy] = (o, int(rng.integers(0, o // 20 + 1)))
+        for cx in rng.choice(16, size=5, replace=False):
+            o = int(rng.integers(1, 50000)); xt[0, q, cx] = (o, int(rng.integers(0, o // 20 + 1)))
+        qt[0, q] = ct[0, q].sum(axis=0)
+        fo = orc.BqsrFinal(qt, ct, xt, 500)
+        _, quantized = fo.quantize(0)
+        eps = float(q)
+        d_g = emp(qt[0, q, 0], qt[0, q, 1], eps) - eps
+        d_q = emp(qt[0, q, 0], qt[0, q, 1], d_g + eps) - d_g - eps
+        cond = d_q + d_g + eps
+        for cy in list(cycles[:3]) + [151 if 151 not in cycles else 152]:
+            for cx in (int(np.nonzero(xt[0, q, :, 0])[0][0]), int(np.nonzero(xt[0, q, :, 0] == 0)[0][0]), -1):
+                d_c = 0.0
+                if ct[0, q, 500 + cy, 0] > 0:
+                    d_c = emp(ct[0, q, 500 + cy, 0], ct[0, q, 500 + cy, 1], cond) - cond
+                if cx >= 0 and xt[0, q, cx, 0] > 0:
+                    d_c += emp(xt[0, q, cx, 0], xt[0, q, cx, 1], cond) - cond
+                est = cond + d_c
+                want = int(quantized[max(1, min(int(np.floor(est + 0.5)) if est >= 0 else -int(np.floor(-est + 0.5)), 93))])
+                key = -1 if cx < 0 else (2 | ((cx & 3) << 4) | ((cx >> 2) << 6))
+                assert fo.recal_qual(0, q, int(cy), key, quantized, None) == want, (trial, q, cy, cx)
+                checked += 1
+    assert checked > 300
