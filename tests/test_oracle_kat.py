@@ -476,3 +476,60 @@ def test_hierarchical_estimate_against_a_second_restatement():  # filters/bqsr.g
                 assert fo.recal_qual(0, q, int(cy), key, quantized, None) == want, (trial, q, cy, cx)
                 checked += 1
     assert checked > 300
+
+
+def test_coordinate_sort_against_a_second_restatement():  # sam/sam-types.go:408-473, :639-641 (stable sort)
+    """CoordinateLess written a second time in Python and fed to Python's stable sort, on random records full of ties (few positions,
+    few names, paired and unpaired, unmapped, both strands)."""
+    import functools
+    rng = np.random.default_rng(21)
+
+    def mod_flag(f):
+        if f & 0x1 == 0:
+            f &= ~0x8 & ~0x20
+        if f & 0x4:
+            f &= ~0x10
+        if f & 0x8:
+            f &= ~0x20
+        return f
+
+    def less(a, b):
+        r1, r2 = a["refid"], b["refid"]
+        if r1 < r2:
+            return r1 >= 0
+        if r2 < r1:
+            return r2 < 0
+        if a["pos"] != b["pos"]:
+            return a["pos"] < b["pos"]
+        rv1, rv2 = bool(a["flag"] & 0x10), bool(b["flag"] & 0x10)
+        if rv1 != rv2:
+            return not rv1
+        if a["qname"] != b["qname"]:
+            return a["qname"].encode() < b["qname"].encode()
+        f1, f2 = mod_flag(a["flag"]), mod_flag(b["flag"])
+        if f1 != f2:
+            return f1 < f2
+        if a["mapq"] != b["mapq"]:
+            return a["mapq"] < b["mapq"]
+        if (a["flag"] & 0x1) and (b["flag"] & 0x1):
+            if a["next_refid"] != b["next_refid"]:
+                return a["next_refid"] < b["next_refid"]
+            if a["pnext"] != b["pnext"]:
+                return a["pnext"] < b["pnext"]
+        return a["tlen"] < b["tlen"]
+
+    for trial in range(6):
+        recs = []
+        for k in range(400):
+            unm = rng.random() < 0.15
+            paired = rng.random() < 0.6
+            flag = (0x1 if paired else 0) | (0x10 if rng.random() < 0.5 else 0) | (0x4 if unm else 0)
+            if paired:
+                flag |= (0x40 if rng.random() < 0.5 else 0x80) | (0x20 if rng.random() < 0.3 else 0) | (0x8 if rng.random() < 0.1 else 0)
+            recs.append(dict(qname="n%d" % rng.integers(0, 12) + "x" * int(rng.integers(0, 2)), flag=flag,
+                             refid=-1 if unm and rng.random() < 0.7 else int(rng.integers(0, 3)), pos=0 if unm else int(rng.integers(1, 6)),
+                             cigar="*" if unm else "10M", mapq=int(rng.integers(0, 3)), next_refid=int(rng.integers(-1, 3)),
+                             pnext=int(rng.integers(0, 4)), tlen=int(rng.integers(-2, 3)), seq="A" * 10, qual=[30] * 10, rgid=0))
+        want = sorted(range(len(recs)), key=functools.cmp_to_key(lambda i, j: -1 if less(recs[i], recs[j]) else (1 if less(recs[j], recs[i]) else 0)))
+        got = orc.sort_coordinate(batch_from_records(recs))
+        assert got.tolist() == want, trial
