@@ -533,3 +533,68 @@ def test_coordinate_sort_against_a_second_restatement():  # sam/sam-types.go:408
         want = sorted(range(len(recs)), key=functools.cmp_to_key(lambda i, j: -1 if less(recs[i], recs[j]) else (1 if less(recs[j], recs[i]) else 0)))
         got = orc.sort_coordinate(batch_from_records(recs))
         assert got.tolist() == want, trial
+
+
+def test_mark_duplicates_against_a_second_restatement():  # filters/mark-duplicates.go:177-445, one goroutine (arrival = index order)
+    """classifyFragment / classifyPair written a second time as plain sequential Python over dicts, on synthetic batches with many
+    duplicates, on the same batches shuffled, and on a pile-up with exact (score, QNAME) ties."""
+    from tests.common import dataset
+    from elprep_amd.batch import Header, NIL16
+
+    def restate(b, h):
+        _, upos, score = orc.mark_duplicates(b, h, with_adapted=True)
+        flag = b.flag.astype(np.int64).copy()
+        names = [b.qname_of(i) for i in range(b.n)]
+        lib = [None if b.rgid[i] == NIL16 or h.rg_lib[b.rgid[i]] == NIL16 else int(h.rg_lib[b.rgid[i]]) for i in range(b.n)]
+        true_pair = lambda i: (int(b.flag[i]) & (0x1 | 0x8)) == 0x1
+        rev = lambda i: bool(int(b.flag[i]) & 0x10)
+        frags, waiting, pairs = {}, {}, {}
+        for i in range(b.n):
+            if int(b.flag[i]) & (0x4 | 0x100 | 0x800):
+                continue
+            k = (lib[i], int(b.refid[i]), int(upos[i]), rev(i))
+            if k not in frags:
+                frags[k] = i
+            else:
+                best = frags[k]
+                if not true_pair(i):
+                    if true_pair(best) or score[best] > score[i] or (score[best] == score[i] and names[i] > names[best]):
+                        flag[i] |= 0x400
+                    else:
+                        frags[k] = i; flag[best] |= 0x400
+                elif not true_pair(best):
+                    frags[k] = i; flag[best] |= 0x400
+            if not true_pair(i):
+                continue
+            wk = (lib[i], names[i])
+            if wk not in waiting:
+                waiting[wk] = i
+                continue
+            a1, a2 = i, waiting.pop(wk)
+            sc = int(score[a1]) + int(score[a2])
+            if (b.refid[a1] > b.refid[a2] or (b.refid[a1] == b.refid[a2] and (upos[a1] > upos[a2] or (upos[a1] == upos[a2] and rev(a1) and not rev(a2))))):
+                a1, a2 = a2, a1
+            pk = (lib[a1], int(b.refid[a1]), int(b.refid[a2]), (int(upos[a1]) << 32) + int(upos[a2]), rev(a1), rev(a2))
+            if pk not in pairs:
+                pairs[pk] = (sc, a1, a2)
+                continue
+            bs, b1, b2 = pairs[pk]
+            if bs > sc or (bs == sc and names[a1] > names[b1]):
+                flag[a1] |= 0x400; flag[a2] |= 0x400
+            else:
+                pairs[pk] = (sc, a1, a2); flag[b1] |= 0x400; flag[b2] |= 0x400
+        return flag.astype(np.uint16)
+
+    rng = np.random.default_rng(2)
+    for seed in (0, 1):
+        cfg, b, h, refs, sites = dataset("tiny", 2500, seed, 0.05)
+        for bb in (b, b.take(rng.permutation(b.n))):
+            got = orc.mark_duplicates(bb, h)
+            assert np.array_equal(got, restate(bb, h)) and ((got & 0x400) != 0).sum() > 100
+    q = [30] * 10
+    recs = [dict(qname=n, flag=0, refid=0, pos=100, cigar="10M", mapq=60, seq="A" * 10, qual=q, rgid=0) for n in ("b", "a", "b", "a", "c")]
+    recs += [dict(qname=n, flag=f, refid=0, pos=p, cigar="10M", mapq=60, next_refid=0, pnext=pn, tlen=t, seq="A" * 10, qual=q, rgid=0)
+             for n in ("p2", "p1", "p2b") for f, p, pn, t in ((99, 200, 300, 110), (147, 300, 200, -110))]
+    bb = batch_from_records(recs)
+    hh = Header(ref_len=np.array([1000], np.int32), rg_lib=np.array([0], np.uint16), rg_cov=np.array([0], np.uint16))
+    assert np.array_equal(orc.mark_duplicates(bb, hh), restate(bb, hh))
