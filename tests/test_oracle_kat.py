@@ -535,56 +535,60 @@ def test_coordinate_sort_against_a_second_restatement():  # sam/sam-types.go:408
         assert got.tolist() == want, trial
 
 
+def _restate_markdup(b, h):
+    """filters/mark-duplicates.go:177-445 as plain sequential Python over dicts (one goroutine: arrival = index order).
+    -> (flags, pair table {key: (score, aln1, aln2)}, unclipped positions, names, library per record)"""
+    from elprep_amd.batch import NIL16
+    _, upos, score = orc.mark_duplicates(b, h, with_adapted=True)
+    flag = b.flag.astype(np.int64).copy()
+    names = [b.qname_of(i) for i in range(b.n)]
+    lib = [None if b.rgid[i] == NIL16 or h.rg_lib[b.rgid[i]] == NIL16 else int(h.rg_lib[b.rgid[i]]) for i in range(b.n)]
+    true_pair = lambda i: (int(b.flag[i]) & (0x1 | 0x8)) == 0x1
+    rev = lambda i: bool(int(b.flag[i]) & 0x10)
+    frags, waiting, pairs = {}, {}, {}
+    for i in range(b.n):
+        if int(b.flag[i]) & (0x4 | 0x100 | 0x800):
+            continue
+        k = (lib[i], int(b.refid[i]), int(upos[i]), rev(i))
+        if k not in frags:
+            frags[k] = i
+        else:
+            best = frags[k]
+            if not true_pair(i):
+                if true_pair(best) or score[best] > score[i] or (score[best] == score[i] and names[i] > names[best]):
+                    flag[i] |= 0x400
+                else:
+                    frags[k] = i; flag[best] |= 0x400
+            elif not true_pair(best):
+                frags[k] = i; flag[best] |= 0x400
+        if not true_pair(i):
+            continue
+        wk = (lib[i], names[i])
+        if wk not in waiting:
+            waiting[wk] = i
+            continue
+        a1, a2 = i, waiting.pop(wk)
+        sc = int(score[a1]) + int(score[a2])
+        if (b.refid[a1] > b.refid[a2] or (b.refid[a1] == b.refid[a2] and (upos[a1] > upos[a2] or (upos[a1] == upos[a2] and rev(a1) and not rev(a2))))):
+            a1, a2 = a2, a1
+        pk = (lib[a1], int(b.refid[a1]), int(b.refid[a2]), (int(upos[a1]) << 32) + int(upos[a2]), rev(a1), rev(a2))
+        if pk not in pairs:
+            pairs[pk] = (sc, a1, a2)
+            continue
+        bs, b1, b2 = pairs[pk]
+        if bs > sc or (bs == sc and names[a1] > names[b1]):
+            flag[a1] |= 0x400; flag[a2] |= 0x400
+        else:
+            pairs[pk] = (sc, a1, a2); flag[b1] |= 0x400; flag[b2] |= 0x400
+    return flag.astype(np.uint16), pairs, upos, names, lib
+
+
 def test_mark_duplicates_against_a_second_restatement():  # filters/mark-duplicates.go:177-445, one goroutine (arrival = index order)
     """classifyFragment / classifyPair written a second time as plain sequential Python over dicts, on synthetic batches with many
     duplicates, on the same batches shuffled, and on a pile-up with exact (score, QNAME) ties."""
     from tests.common import dataset
-    from elprep_amd.batch import Header, NIL16
-
-    def restate(b, h):
-        _, upos, score = orc.mark_duplicates(b, h, with_adapted=True)
-        flag = b.flag.astype(np.int64).copy()
-        names = [b.qname_of(i) for i in range(b.n)]
-        lib = [None if b.rgid[i] == NIL16 or h.rg_lib[b.rgid[i]] == NIL16 else int(h.rg_lib[b.rgid[i]]) for i in range(b.n)]
-        true_pair = lambda i: (int(b.flag[i]) & (0x1 | 0x8)) == 0x1
-        rev = lambda i: bool(int(b.flag[i]) & 0x10)
-        frags, waiting, pairs = {}, {}, {}
-        for i in range(b.n):
-            if int(b.flag[i]) & (0x4 | 0x100 | 0x800):
-                continue
-            k = (lib[i], int(b.refid[i]), int(upos[i]), rev(i))
-            if k not in frags:
-                frags[k] = i
-            else:
-                best = frags[k]
-                if not true_pair(i):
-                    if true_pair(best) or score[best] > score[i] or (score[best] == score[i] and names[i] > names[best]):
-                        flag[i] |= 0x400
-                    else:
-                        frags[k] = i; flag[best] |= 0x400
-                elif not true_pair(best):
-                    frags[k] = i; flag[best] |= 0x400
-            if not true_pair(i):
-                continue
-            wk = (lib[i], names[i])
-            if wk not in waiting:
-                waiting[wk] = i
-                continue
-            a1, a2 = i, waiting.pop(wk)
-            sc = int(score[a1]) + int(score[a2])
-            if (b.refid[a1] > b.refid[a2] or (b.refid[a1] == b.refid[a2] and (upos[a1] > upos[a2] or (upos[a1] == upos[a2] and rev(a1) and not rev(a2))))):
-                a1, a2 = a2, a1
-            pk = (lib[a1], int(b.refid[a1]), int(b.refid[a2]), (int(upos[a1]) << 32) + int(upos[a2]), rev(a1), rev(a2))
-            if pk not in pairs:
-                pairs[pk] = (sc, a1, a2)
-                continue
-            bs, b1, b2 = pairs[pk]
-            if bs > sc or (bs == sc and names[a1] > names[b1]):
-                flag[a1] |= 0x400; flag[a2] |= 0x400
-            else:
-                pairs[pk] = (sc, a1, a2); flag[b1] |= 0x400; flag[b2] |= 0x400
-        return flag.astype(np.uint16)
-
+    from elprep_amd.batch import Header
+    restate = lambda bb, hh: _restate_markdup(bb, hh)[0]
     rng = np.random.default_rng(2)
     for seed in (0, 1):
         cfg, b, h, refs, sites = dataset("tiny", 2500, seed, 0.05)
@@ -598,3 +602,85 @@ def test_mark_duplicates_against_a_second_restatement():  # filters/mark-duplica
     bb = batch_from_records(recs)
     hh = Header(ref_len=np.array([1000], np.int32), rg_lib=np.array([0], np.uint16), rg_cov=np.array([0], np.uint16))
     assert np.array_equal(orc.mark_duplicates(bb, hh), restate(bb, hh))
+
+
+def test_duplication_metrics_against_a_second_restatement():  # filters/mark-optical-duplicates.go:176-525
+    """MarkOpticalDuplicates written a second time in Python on top of the mark-duplicates restatement: the seven counters per
+    library, optical duplicates per duplicate set (pairwise rules for two and three listed reads, connected components per
+    (read group, tile) from four on) and the three set-size histograms."""
+    from tests.common import dataset
+    cfg, b, h, refs, sites = dataset("tiny", 6000, 1, 0.05)
+    flags, pairs, upos, names, lib = _restate_markdup(b, h)
+    perm = orc.sort_coordinate(b)
+    dist = 100
+    nl = h.n_lib
+    ctr = np.zeros((nl + 1, 7), np.int64)
+    true_pair = lambda i: (int(b.flag[i]) & (0x1 | 0x8)) == 0x1
+    rev = lambda i: bool(int(b.flag[i]) & 0x10)
+    row = lambda i: nl if lib[i] is None else lib[i]
+    waiting, lists = {}, {k: [] for k in pairs}
+    for i in (int(x) for x in perm):
+        f = int(flags[i])
+        if f & 0x4:
+            ctr[row(i), 3] += 1; continue
+        if f & (0x100 | 0x800):
+            ctr[row(i), 2] += 1; continue
+        if true_pair(i):
+            ctr[row(i), 1] += 1
+        else:
+            ctr[row(i), 0] += 1
+        if not f & 0x400:
+            continue
+        if not true_pair(i):
+            ctr[row(i), 4] += 1; continue
+        wk = (lib[i], names[i])
+        if wk not in waiting:
+            waiting[wk] = i; continue
+        a1, a2 = i, waiting.pop(wk)
+        ctr[row(i), 5] += 1
+        if (b.refid[a1] > b.refid[a2] or (b.refid[a1] == b.refid[a2] and (upos[a1] > upos[a2] or (upos[a1] == upos[a2] and rev(a1) and not rev(a2))))):
+            a1, a2 = a2, a1
+        pk = (lib[a1], int(b.refid[a1]), int(b.refid[a2]), (int(upos[a1]) << 32) + int(upos[a2]), rev(a1), rev(a2))
+        if pairs[pk][1] != a1:
+            lists[pk].append(a1 if int(b.flag[a1]) & 0x40 else a2)
+    ctr[:, 1] //= 2
+
+    def close(x, y):
+        tx, ty = orc.tile_info(names[x]), orc.tile_info(names[y])
+        return b.rgid[x] == b.rgid[y] and tx[0] != -1 and ty[0] != -1 and tx[0] == ty[0] and abs(tx[1] - ty[1]) <= dist and abs(tx[2] - ty[2]) <= dist
+
+    def optical(members):
+        n = len(members)
+        if n < 2:
+            return 0
+        if n < 4:
+            return min(sum(close(members[x], members[y]) for x in range(n) for y in range(x + 1, n)), n - 1)
+        parent = list(range(n))
+        def find(x):
+            while parent[x] != x:
+                x = parent[x]
+            return x
+        for x in range(n):
+            for y in range(x + 1, n):
+                if close(members[x], members[y]):
+                    parent[find(y)] = find(x)
+        return n - len({find(x) for x in range(n)})
+
+    hl = 16
+    hist = np.zeros((nl + 1, 3, hl), np.int64)
+    for pk, (sc, a1, a2) in pairs.items():
+        origin = a1 if int(b.flag[a1]) & 0x40 else a2
+        members = [origin] + lists[pk]
+        fw, rv = [m for m in members if not rev(m)], [m for m in members if rev(m)]
+        opt = optical(fw) + optical(rv)
+        r = nl if lib[a1] is None else lib[a1]
+        ctr[r, 6] += opt
+        n = len(members)
+        hist[r, 0, min(n, hl - 1)] += 1
+        if n - opt > 0:
+            hist[r, 1, min(n - opt, hl - 1)] += 1
+        if opt > 0:
+            hist[r, 2, min(opt + 1, hl - 1)] += 1
+    oflags, octr, ohist = orc.dup_metrics(b, h, perm, dist, hist_len=hl)
+    assert np.array_equal(oflags, flags) and octr[:, 6].sum() > 0
+    assert np.array_equal(octr, ctr) and np.array_equal(ohist, hist)
