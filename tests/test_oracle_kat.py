@@ -684,3 +684,74 @@ def test_duplication_metrics_against_a_second_restatement():  # filters/mark-opt
     oflags, octr, ohist = orc.dup_metrics(b, h, perm, dist, hist_len=hl)
     assert np.array_equal(oflags, flags) and octr[:, 6].sum() > 0
     assert np.array_equal(octr, ctr) and np.array_equal(ohist, hist)
+
+
+def test_bqsr_gather_against_a_second_restatement_on_plain_reads():  # filters/bqsr.go:225-551 for reads that need no clipping
+    """Recalibrate written a second time in Python for unpaired reads with a single match operation (no adaptor, no soft clips):
+    eligibility of a base (no known site, A/C/G/T, quality >= 6), mismatch against the reference, cycle, the two-base context on
+    the stranded read with low-quality tails and N masked - on random reads of two read groups, both strands, with N bases, qualities
+    below 6 and below 3, and random known sites."""
+    from elprep_amd.batch import Header
+    rng = np.random.default_rng(33)
+    L_ref = 3000
+    ref = rng.choice(list("ACGT"), size=L_ref)
+    ref[rng.random(L_ref) < 0.01] = "N"
+    refb = np.frombuffer("".join(ref).encode(), dtype=np.uint8)
+    sites = np.sort(rng.choice(np.arange(1, L_ref - 5), size=60, replace=False))
+    iv = orc.flatten(orc.sort_by_start(np.stack([sites, sites + rng.integers(0, 4, size=60)], axis=1)))
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    recs = []
+    for k in range(400):
+        L = int(rng.integers(1, 60))
+        pos = int(rng.integers(1, L_ref - L))
+        seq = [ref[pos - 1 + i] if rng.random() > 0.05 and ref[pos - 1 + i] != "N" else "ACGT"[rng.integers(0, 4)] for i in range(L)]
+        for i in range(L):
+            if rng.random() < 0.02:
+                seq[i] = "N"
+        qual = rng.choice([2, 5, 11, 25, 37], size=L, p=[0.05, 0.05, 0.3, 0.3, 0.3])
+        if rng.random() < 0.3:
+            qual[: rng.integers(0, min(4, L) + 1)] = 2
+        if rng.random() < 0.3 and L > 1:
+            qual[L - int(rng.integers(1, min(4, L) + 1)):] = 2
+        recs.append(dict(qname="r%d" % k, flag=16 if rng.random() < 0.5 else 0, refid=0, pos=pos, cigar="%dM" % L, mapq=int(rng.choice([0, 30, 60])),
+                         seq="".join(seq), qual=qual.tolist(), rgid=int(rng.integers(0, 2))))
+    b = batch_from_records(recs)
+    h = Header(ref_len=np.array([L_ref], np.int32), rg_lib=np.array([0, 0], np.uint16), rg_cov=np.array([0, 1], np.uint16))
+    wq = np.zeros((2, 94, 2), np.int64); wc = np.zeros((2, 94, 1001, 2), np.int64); wx = np.zeros((2, 94, 16, 2), np.int64)
+    for r in recs:
+        if not (0 < r["mapq"] < 255):
+            continue
+        seq, qual, L, pos, revd, cov = r["seq"], r["qual"], len(r["seq"]), r["pos"], bool(r["flag"] & 16), r["rgid"]
+        skip = [False] * L
+        for s, e in iv:
+            if e >= pos and s <= pos + L - 1:  # intersects [softStart, softEnd]
+                lo = s - pos if 0 <= s - pos < L else 0
+                hi = e - pos if 0 <= e - pos <= L - 1 else L - 1
+                for i in range(lo, hi + 1):
+                    skip[i] = True
+        good = [i for i in range(L) if qual[i] > 2]
+        if good:
+            left, right = good[0], good[-1]
+            strand = [seq[i] if left <= i <= right else "N" for i in range(L)]
+        else:
+            strand = None
+        for i in range(L):
+            if skip[i] or seq[i] not in code or qual[i] < 6:
+                continue
+            e = 1 if seq[i] != ref[pos - 1 + i] else 0  # baseToIntMap: N in the reference is its own class
+            q = qual[i]
+            cyc = (L - i) if revd else (i + 1)
+            wq[cov, q] += (1, e); wc[cov, q, 500 + cyc] += (1, e)
+            if strand is None:
+                continue
+            if not revd:
+                prev, cur = (strand[i - 1] if i >= 1 else None), strand[i]
+            else:  # the stranded read is the reverse complement: the base sequenced before base i is base i + 1
+                prev, cur = (comp.get(strand[i + 1], "N") if i + 1 < L else None), comp.get(strand[i], "N")
+            if prev in code and cur in code:
+                wx[cov, q, code[prev] | (code[cur] << 2)] += (1, e)
+    qt, ct, xt = orc.bqsr_gather(b, h, orc.BqsrRef([refb], [iv]), None, 500)
+    assert qt.sum() > 3000 and np.array_equal(qt, wq)
+    assert np.array_equal(ct, wc)
+    assert np.array_equal(xt, wx)
