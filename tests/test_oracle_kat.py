@@ -755,3 +755,53 @@ def test_bqsr_gather_against_a_second_restatement_on_plain_reads():  # filters/b
     assert qt.sum() > 3000 and np.array_equal(qt, wq)
     assert np.array_equal(ct, wc)
     assert np.array_equal(xt, wx)
+
+
+def test_bqsr_apply_covariates_against_a_second_restatement():  # filters/bqsr.go:936-1005
+    """ApplyBQSR's per-base keys written a second time: every base with quality >= 6 of a read with a known read group is replaced
+    by the memo value of (read group, quality, cycle, context) - cycle and context taken on the whole read (no clipping in this
+    pass), context with low-quality tails and N masked, on either strand, second-of-pair cycles negative."""
+    from elprep_amd.batch import Header
+    from tests.common import dataset
+    cfg, b, h, refs, sites = dataset("tiny", 1500, 5, 0.03)
+    flags = orc.mark_duplicates(b, h)
+    qt, ct, xt = orc.bqsr_gather(b, h, orc.BqsrRef(refs, sites), flags, 500)
+    fo = orc.BqsrFinal(qt, ct, xt, 500)
+    got = fo.apply(b, h, 0)
+    _, quantized = fo.quantize(0)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    want = b.qual.copy()
+    changed = 0
+    for i in range(b.n):
+        from elprep_amd.batch import NIL16
+        if b.rgid[i] == NIL16:
+            continue
+        cov = int(h.rg_cov[b.rgid[i]])
+        if qt[cov, :, 0].sum() == 0:
+            continue
+        o = int(b.qual_off[i]); L = int(b.qual_off[i + 1]) - o
+        if L == 0:
+            continue
+        qual = b.qual[o:o + L]; seq = b.seq_of(i)
+        f = int(b.flag[i]); revd = bool(f & 0x10); last = bool(f & 0x80)
+        good = np.nonzero(qual > 2)[0]
+        strand = [seq[k] if len(good) and good[0] <= k <= good[-1] else "N" for k in range(L)] if len(good) else None
+        for k in range(L):
+            q = int(qual[k])
+            if q < 6:
+                continue
+            cyc = (L - k) if revd else (k + 1)
+            if last:
+                cyc = -cyc
+            key = -1
+            if strand is not None:
+                if not revd:
+                    prev, cur = (strand[k - 1] if k >= 1 else None), strand[k]
+                else:
+                    prev, cur = (comp.get(strand[k + 1], "N") if k + 1 < L else None), comp.get(strand[k], "N")
+                if prev in code and cur in code:
+                    key = 2 | (code[prev] << 4) | (code[cur] << 6)
+            want[o + k] = fo.recal_qual(cov, q, cyc, key, quantized, None)
+            changed += want[o + k] != q
+    assert changed > 1000 and np.array_equal(got, want)
