@@ -805,3 +805,243 @@ def test_bqsr_apply_covariates_against_a_second_restatement():  # filters/bqsr.g
             want[o + k] = fo.recal_qual(cov, q, cyc, key, quantized, None)
             changed += want[o + k] != q
     assert changed > 1000 and np.array_equal(got, want)
+
+
+def test_clipping_chain_against_a_second_restatement():  # filters/utils.go:149-262 (adaptor), 267-349 (read coordinate), 374-512 (hard clip)
+    """hardClipAdaptorSequence + hardClipSoftClippedBases written a second time in Python (computeReadCoordinateForReferenceCoordinate,
+    getReadCoordinateForReferenceCoordinate, hardClipCigar, cleanHardClippedCigar, hardClip with the POS shift), on random CIGARs
+    with clips, insertions and deletions and random mate geometry: base window, new POS and new CIGAR must be the oracle's; where the
+    reference would panic the oracle must say so."""
+    rng = np.random.default_rng(77)
+    READ = set("MIS=X"); REF = set("MDN=X")
+
+    def read_coord(cig, soft_start, ref_index):  # :267-321
+        goal = ref_index - soft_start
+        if goal < 0:
+            return -1, False
+        read_bases = ref_bases = 0
+        falls = before = False
+        index = 0
+        fall_or = False
+        while ref_bases != goal and index < len(cig):
+            op, ln = cig[index]; index += 1
+            shift = 0
+            if op in REF or op == "S":
+                shift = ln if ref_bases + ln < goal else goal - ref_bases
+                ref_bases += shift
+            if ref_bases != goal:
+                read_bases += ln if op in READ else 0
+            else:
+                if shift >= ln and index == len(cig):
+                    return -1, False
+                nxt = None
+                if shift < ln:
+                    falls = op in "DN"
+                else:
+                    nxt = cig[index]; index += 1
+                    if nxt[0] == "I":
+                        read_bases += nxt[1]
+                        if index == len(cig):
+                            return -1, False
+                        nxt = cig[index]; index += 1
+                    before = nxt[0] in "DN"
+                fall_or = before or falls
+                if not fall_or:
+                    read_bases += shift if op in READ else 0
+                elif before:
+                    read_bases += (shift - 1) if op in READ else 0
+                elif falls:
+                    read_bases -= 1
+        if ref_bases != goal:
+            return -1, False
+        return read_bases, fall_or
+
+    def get_read_coord(cig, soft_start, ref_index, right):  # :330-349
+        rb, fall_or = read_coord(cig, soft_start, ref_index)
+        if rb == -1:
+            return -1, False
+        if right and fall_or:
+            rb += 1
+        if not right and rb == 0:
+            for op, ln in cig:
+                if op == "I":
+                    rb = min(ln, sum(l for o, l in cig if o in READ) - 1)
+                    break
+                if op in "HS":
+                    continue
+                break
+        return rb, True
+
+    def shift_of(op, ln, n):  # calculateHardClippingAlignmentShift
+        return -n if op == "I" else (ln if op in "DN" else 0)
+
+    def clean(cig):  # :472-512
+        total = idx = 0
+        while idx < len(cig) and cig[idx][0] in "HDN":
+            total += cig[idx][1]; idx += 1
+        if idx > 0:
+            cig = [("H", total)] + cig[idx:]
+        total = 0
+        idx = len(cig) - 1
+        while idx >= 0 and cig[idx][0] in "HDN":
+            total += cig[idx][1]; idx -= 1
+        if idx < len(cig) - 1:
+            cig = cig[:idx + 1] + [("H", total)]
+        return cig
+
+    def hard_clip_cigar(cig, start, stop):  # :407-470
+        index = 0
+        total = stop - start + 1
+        ashift = 0
+        new = []
+        if start == 0:
+            k = 0
+            while k < len(cig) and cig[k][0] == "H":
+                total += cig[k][1]; k += 1
+            while index <= stop and k < len(cig):
+                op, ln = cig[k]
+                shift = ln if op in READ else 0
+                if index + shift == stop + 1:
+                    ashift += shift_of(op, ln, ln)
+                    new.append(("H", total + ashift))
+                elif index + shift > stop + 1:
+                    ashift += shift_of(op, ln, stop - index + 1)
+                    new += [("H", total + ashift), (op, ln - (stop - index + 1))]
+                index += shift
+                ashift += shift_of(op, ln, shift)
+                k += 1
+            new += cig[k:]
+        else:
+            k = 0
+            while index < start and k < len(cig):
+                op, ln = cig[k]
+                shift = ln if op in READ else 0
+                if index + shift < start:
+                    new.append((op, ln))
+                else:
+                    ashift += shift_of(op, ln, ln - (start - index))
+                    if op == "H":
+                        total += start - index
+                    else:
+                        new.append((op, start - index))
+                index += shift
+                k += 1
+            while k < len(cig):
+                op, ln = cig[k]
+                ashift += shift_of(op, ln, ln)
+                if op == "H":
+                    total += ln
+                k += 1
+            new.append(("H", total + ashift))
+        return clean(new)
+
+    def hs_offset(cig):
+        size = i = 0
+        while i < len(cig) and cig[i][0] == "H":
+            size += cig[i][1]; i += 1
+        while i < len(cig) and cig[i][0] == "S":
+            size += cig[i][1]; i += 1
+        return size
+
+    class Panic(Exception):
+        pass
+
+    def clip(rec):
+        cig = [(op, ln) for ln, op in rec["ops"]]
+        st = dict(a=0, n=rec["L"], pos=rec["pos"], cig=cig)
+        def soft_start():  # :224-234
+            start = st["pos"]
+            for op, ln in st["cig"]:
+                if op == "S":
+                    start -= ln
+                elif op != "H":
+                    break
+            return start
+
+        end = lambda: st["pos"] + sum(l for o, l in st["cig"] if o in REF) - 1
+
+        def hard_clip(start, stop):
+            new = hard_clip_cigar(st["cig"], start, stop)
+            new_len = st["n"] - (stop - start + 1)
+            copy_start = stop + 1 if start == 0 else 0
+            old = st["cig"]
+            st["a"] += copy_start; st["n"] = new_len; st["cig"] = new
+            if start == 0:
+                st["pos"] += hs_offset(new) - hs_offset(old)
+
+        f = rec["flag"]; revd = bool(f & 0x10)
+        if rec["tlen"] != 0 and f & 0x1 and not (f & 0x8 or rec["next_refid"] < 0 or rec["pnext"] == 0) and revd != bool(f & 0x20):
+            aln_end = end()
+            well = aln_end > rec["pnext"] if revd else st["pos"] <= rec["pnext"] + rec["tlen"]
+            if well:
+                boundary = rec["pnext"] - 1 if revd else st["pos"] + abs(rec["tlen"])
+                if st["pos"] <= boundary <= aln_end:
+                    if revd:
+                        stop, ok = get_read_coord(st["cig"], soft_start(), boundary, False)
+                        if not ok:
+                            raise Panic()
+                        hard_clip(0, stop)
+                    else:
+                        start, ok = get_read_coord(st["cig"], soft_start(), boundary, True)
+                        if not ok:
+                            raise Panic()
+                        hard_clip(start, st["n"] - 1)
+        if st["n"] == 0:
+            return st
+        read_index = 0; cut_left = cut_right = -1; right_tail = False
+        for op, ln in st["cig"]:
+            if op == "S":
+                if right_tail:
+                    cut_right = read_index
+                else:
+                    cut_left = read_index + ln - 1
+            elif op != "H":
+                right_tail = True
+            read_index += ln if op in READ else 0
+        if cut_right >= 0:
+            hard_clip(cut_right, st["n"] - 1)
+        if cut_left >= 0:
+            hard_clip(0, cut_left)
+        return st
+
+    checked = panics = 0
+    for trial in range(1500):
+        ops = []
+        if rng.random() < 0.15:
+            ops.append((int(rng.integers(1, 4)), "H"))
+        if rng.random() < 0.35:
+            ops.append((int(rng.integers(1, 6)), "S"))
+        ops.append((int(rng.integers(2, 12)), "M"))
+        for _ in range(int(rng.integers(0, 3))):
+            ops.append((int(rng.integers(1, 4)), "ID"[rng.integers(0, 2)]))
+            ops.append((int(rng.integers(1, 10)), "M"))
+        if rng.random() < 0.35:
+            ops.append((int(rng.integers(1, 6)), "S"))
+        if rng.random() < 0.15:
+            ops.append((int(rng.integers(1, 4)), "H"))
+        L = sum(l for l, o in ops if o in READ)
+        span = sum(l for l, o in ops if o in REF)
+        pos = int(rng.integers(50, 100))
+        revd = rng.random() < 0.5
+        paired = rng.random() < 0.8
+        flag = (0x1 | (0x40 if rng.random() < 0.5 else 0x80) | (0x20 if not revd else 0) if paired else 0) | (0x10 if revd else 0)
+        pnext = int(rng.integers(pos - 10, pos + span + 10))
+        tlen = int(rng.integers(-40, 41))
+        rec = dict(ops=ops, L=L, pos=pos, flag=flag, pnext=pnext, tlen=tlen, next_refid=0)
+        b = batch_from_records([dict(qname="q", flag=flag, refid=0, pos=pos, cigar="".join("%d%s" % x for x in ops), mapq=60, next_refid=0, pnext=pnext,
+                                     tlen=tlen, seq="A" * L, qual=[30] * L, rgid=0)])
+        try:
+            st = clip(rec)
+        except Panic:
+            with pytest.raises(RuntimeError):
+                orc.clip_for_bqsr(b, 0)
+            panics += 1
+            continue
+        a, e, npos, cg = orc.clip_for_bqsr(b, 0)
+        got = (a, e, npos, [("MIDNSHP=X"[int(c) & 15], int(c) >> 4) for c in cg])
+        if st["n"] == 0:
+            assert e - a == 0, (trial, ops)
+        else:
+            assert got == (st["a"], st["a"] + st["n"], st["pos"], st["cig"]), (trial, ops, flag, pnext, tlen, got, st)
+        checked += 1
+    assert checked > 1200
