@@ -807,203 +807,208 @@ def test_bqsr_apply_covariates_against_a_second_restatement():  # filters/bqsr.g
     assert changed > 1000 and np.array_equal(got, want)
 
 
+# ---- the clipping chain of filters/utils.go written a second time (used by two tests below)
+_READ = set("MIS=X"); _REF = set("MDN=X")
+
+def _c_read_coord(cig, soft_start, ref_index):  # :267-321
+    goal = ref_index - soft_start
+    if goal < 0:
+        return -1, False
+    read_bases = ref_bases = 0
+    falls = before = False
+    index = 0
+    fall_or = False
+    while ref_bases != goal and index < len(cig):
+        op, ln = cig[index]; index += 1
+        shift = 0
+        if op in _REF or op == "S":
+            shift = ln if ref_bases + ln < goal else goal - ref_bases
+            ref_bases += shift
+        if ref_bases != goal:
+            read_bases += ln if op in _READ else 0
+        else:
+            if shift >= ln and index == len(cig):
+                return -1, False
+            nxt = None
+            if shift < ln:
+                falls = op in "DN"
+            else:
+                nxt = cig[index]; index += 1
+                if nxt[0] == "I":
+                    read_bases += nxt[1]
+                    if index == len(cig):
+                        return -1, False
+                    nxt = cig[index]; index += 1
+                before = nxt[0] in "DN"
+            fall_or = before or falls
+            if not fall_or:
+                read_bases += shift if op in _READ else 0
+            elif before:
+                read_bases += (shift - 1) if op in _READ else 0
+            elif falls:
+                read_bases -= 1
+    if ref_bases != goal:
+        return -1, False
+    return read_bases, fall_or
+
+def _c_get_read_coord(cig, soft_start, ref_index, right):  # :330-349
+    rb, fall_or = _c_read_coord(cig, soft_start, ref_index)
+    if rb == -1:
+        return -1, False
+    if right and fall_or:
+        rb += 1
+    if not right and rb == 0:
+        for op, ln in cig:
+            if op == "I":
+                rb = min(ln, sum(l for o, l in cig if o in _READ) - 1)
+                break
+            if op in "HS":
+                continue
+            break
+    return rb, True
+
+def _c_shift_of(op, ln, n):  # calculateHardClippingAlignmentShift
+    return -n if op == "I" else (ln if op in "DN" else 0)
+
+def _c_clean(cig):  # :472-512
+    total = idx = 0
+    while idx < len(cig) and cig[idx][0] in "HDN":
+        total += cig[idx][1]; idx += 1
+    if idx > 0:
+        cig = [("H", total)] + cig[idx:]
+    total = 0
+    idx = len(cig) - 1
+    while idx >= 0 and cig[idx][0] in "HDN":
+        total += cig[idx][1]; idx -= 1
+    if idx < len(cig) - 1:
+        cig = cig[:idx + 1] + [("H", total)]
+    return cig
+
+def _c_hard_clip_cigar(cig, start, stop):  # :407-470
+    index = 0
+    total = stop - start + 1
+    ashift = 0
+    new = []
+    if start == 0:
+        k = 0
+        while k < len(cig) and cig[k][0] == "H":
+            total += cig[k][1]; k += 1
+        while index <= stop and k < len(cig):
+            op, ln = cig[k]
+            shift = ln if op in _READ else 0
+            if index + shift == stop + 1:
+                ashift += _c_shift_of(op, ln, ln)
+                new.append(("H", total + ashift))
+            elif index + shift > stop + 1:
+                ashift += _c_shift_of(op, ln, stop - index + 1)
+                new += [("H", total + ashift), (op, ln - (stop - index + 1))]
+            index += shift
+            ashift += _c_shift_of(op, ln, shift)
+            k += 1
+        new += cig[k:]
+    else:
+        k = 0
+        while index < start and k < len(cig):
+            op, ln = cig[k]
+            shift = ln if op in _READ else 0
+            if index + shift < start:
+                new.append((op, ln))
+            else:
+                ashift += _c_shift_of(op, ln, ln - (start - index))
+                if op == "H":
+                    total += start - index
+                else:
+                    new.append((op, start - index))
+            index += shift
+            k += 1
+        while k < len(cig):
+            op, ln = cig[k]
+            ashift += _c_shift_of(op, ln, ln)
+            if op == "H":
+                total += ln
+            k += 1
+        new.append(("H", total + ashift))
+    return _c_clean(new)
+
+def _c_hs_offset(cig):
+    size = i = 0
+    while i < len(cig) and cig[i][0] == "H":
+        size += cig[i][1]; i += 1
+    while i < len(cig) and cig[i][0] == "S":
+        size += cig[i][1]; i += 1
+    return size
+
+class _ClipPanic(Exception):
+    pass
+
+def _c_clip(rec):
+    cig = [(op, ln) for ln, op in rec["ops"]]
+    st = dict(a=0, n=rec["L"], pos=rec["pos"], cig=cig)
+    def soft_start():  # :224-234
+        start = st["pos"]
+        for op, ln in st["cig"]:
+            if op == "S":
+                start -= ln
+            elif op != "H":
+                break
+        return start
+
+    end = lambda: st["pos"] + sum(l for o, l in st["cig"] if o in _REF) - 1
+
+    def hard_clip(start, stop):
+        new = _c_hard_clip_cigar(st["cig"], start, stop)
+        new_len = st["n"] - (stop - start + 1)
+        copy_start = stop + 1 if start == 0 else 0
+        old = st["cig"]
+        st["a"] += copy_start; st["n"] = new_len; st["cig"] = new
+        if start == 0:
+            st["pos"] += _c_hs_offset(new) - _c_hs_offset(old)
+
+    f = rec["flag"]; revd = bool(f & 0x10)
+    if rec["tlen"] != 0 and f & 0x1 and not (f & 0x8 or rec["next_refid"] < 0 or rec["pnext"] == 0) and revd != bool(f & 0x20):
+        aln_end = end()
+        well = aln_end > rec["pnext"] if revd else st["pos"] <= rec["pnext"] + rec["tlen"]
+        if well:
+            boundary = rec["pnext"] - 1 if revd else st["pos"] + abs(rec["tlen"])
+            if st["pos"] <= boundary <= aln_end:
+                if revd:
+                    stop, ok = _c_get_read_coord(st["cig"], soft_start(), boundary, False)
+                    if not ok:
+                        raise _ClipPanic()
+                    hard_clip(0, stop)
+                else:
+                    start, ok = _c_get_read_coord(st["cig"], soft_start(), boundary, True)
+                    if not ok:
+                        raise _ClipPanic()
+                    hard_clip(start, st["n"] - 1)
+    if st["n"] == 0:
+        return st
+    read_index = 0; cut_left = cut_right = -1; right_tail = False
+    for op, ln in st["cig"]:
+        if op == "S":
+            if right_tail:
+                cut_right = read_index
+            else:
+                cut_left = read_index + ln - 1
+        elif op != "H":
+            right_tail = True
+        read_index += ln if op in _READ else 0
+    if cut_right >= 0:
+        hard_clip(cut_right, st["n"] - 1)
+    if cut_left >= 0:
+        hard_clip(0, cut_left)
+    return st
+
+
+
 def test_clipping_chain_against_a_second_restatement():  # filters/utils.go:149-262 (adaptor), 267-349 (read coordinate), 374-512 (hard clip)
     """hardClipAdaptorSequence + hardClipSoftClippedBases written a second time in Python (computeReadCoordinateForReferenceCoordinate,
     getReadCoordinateForReferenceCoordinate, hardClipCigar, cleanHardClippedCigar, hardClip with the POS shift), on random CIGARs
     with clips, insertions and deletions and random mate geometry: base window, new POS and new CIGAR must be the oracle's; where the
     reference would panic the oracle must say so."""
     rng = np.random.default_rng(77)
-    READ = set("MIS=X"); REF = set("MDN=X")
-
-    def read_coord(cig, soft_start, ref_index):  # :267-321
-        goal = ref_index - soft_start
-        if goal < 0:
-            return -1, False
-        read_bases = ref_bases = 0
-        falls = before = False
-        index = 0
-        fall_or = False
-        while ref_bases != goal and index < len(cig):
-            op, ln = cig[index]; index += 1
-            shift = 0
-            if op in REF or op == "S":
-                shift = ln if ref_bases + ln < goal else goal - ref_bases
-                ref_bases += shift
-            if ref_bases != goal:
-                read_bases += ln if op in READ else 0
-            else:
-                if shift >= ln and index == len(cig):
-                    return -1, False
-                nxt = None
-                if shift < ln:
-                    falls = op in "DN"
-                else:
-                    nxt = cig[index]; index += 1
-                    if nxt[0] == "I":
-                        read_bases += nxt[1]
-                        if index == len(cig):
-                            return -1, False
-                        nxt = cig[index]; index += 1
-                    before = nxt[0] in "DN"
-                fall_or = before or falls
-                if not fall_or:
-                    read_bases += shift if op in READ else 0
-                elif before:
-                    read_bases += (shift - 1) if op in READ else 0
-                elif falls:
-                    read_bases -= 1
-        if ref_bases != goal:
-            return -1, False
-        return read_bases, fall_or
-
-    def get_read_coord(cig, soft_start, ref_index, right):  # :330-349
-        rb, fall_or = read_coord(cig, soft_start, ref_index)
-        if rb == -1:
-            return -1, False
-        if right and fall_or:
-            rb += 1
-        if not right and rb == 0:
-            for op, ln in cig:
-                if op == "I":
-                    rb = min(ln, sum(l for o, l in cig if o in READ) - 1)
-                    break
-                if op in "HS":
-                    continue
-                break
-        return rb, True
-
-    def shift_of(op, ln, n):  # calculateHardClippingAlignmentShift
-        return -n if op == "I" else (ln if op in "DN" else 0)
-
-    def clean(cig):  # :472-512
-        total = idx = 0
-        while idx < len(cig) and cig[idx][0] in "HDN":
-            total += cig[idx][1]; idx += 1
-        if idx > 0:
-            cig = [("H", total)] + cig[idx:]
-        total = 0
-        idx = len(cig) - 1
-        while idx >= 0 and cig[idx][0] in "HDN":
-            total += cig[idx][1]; idx -= 1
-        if idx < len(cig) - 1:
-            cig = cig[:idx + 1] + [("H", total)]
-        return cig
-
-    def hard_clip_cigar(cig, start, stop):  # :407-470
-        index = 0
-        total = stop - start + 1
-        ashift = 0
-        new = []
-        if start == 0:
-            k = 0
-            while k < len(cig) and cig[k][0] == "H":
-                total += cig[k][1]; k += 1
-            while index <= stop and k < len(cig):
-                op, ln = cig[k]
-                shift = ln if op in READ else 0
-                if index + shift == stop + 1:
-                    ashift += shift_of(op, ln, ln)
-                    new.append(("H", total + ashift))
-                elif index + shift > stop + 1:
-                    ashift += shift_of(op, ln, stop - index + 1)
-                    new += [("H", total + ashift), (op, ln - (stop - index + 1))]
-                index += shift
-                ashift += shift_of(op, ln, shift)
-                k += 1
-            new += cig[k:]
-        else:
-            k = 0
-            while index < start and k < len(cig):
-                op, ln = cig[k]
-                shift = ln if op in READ else 0
-                if index + shift < start:
-                    new.append((op, ln))
-                else:
-                    ashift += shift_of(op, ln, ln - (start - index))
-                    if op == "H":
-                        total += start - index
-                    else:
-                        new.append((op, start - index))
-                index += shift
-                k += 1
-            while k < len(cig):
-                op, ln = cig[k]
-                ashift += shift_of(op, ln, ln)
-                if op == "H":
-                    total += ln
-                k += 1
-            new.append(("H", total + ashift))
-        return clean(new)
-
-    def hs_offset(cig):
-        size = i = 0
-        while i < len(cig) and cig[i][0] == "H":
-            size += cig[i][1]; i += 1
-        while i < len(cig) and cig[i][0] == "S":
-            size += cig[i][1]; i += 1
-        return size
-
-    class Panic(Exception):
-        pass
-
-    def clip(rec):
-        cig = [(op, ln) for ln, op in rec["ops"]]
-        st = dict(a=0, n=rec["L"], pos=rec["pos"], cig=cig)
-        def soft_start():  # :224-234
-            start = st["pos"]
-            for op, ln in st["cig"]:
-                if op == "S":
-                    start -= ln
-                elif op != "H":
-                    break
-            return start
-
-        end = lambda: st["pos"] + sum(l for o, l in st["cig"] if o in REF) - 1
-
-        def hard_clip(start, stop):
-            new = hard_clip_cigar(st["cig"], start, stop)
-            new_len = st["n"] - (stop - start + 1)
-            copy_start = stop + 1 if start == 0 else 0
-            old = st["cig"]
-            st["a"] += copy_start; st["n"] = new_len; st["cig"] = new
-            if start == 0:
-                st["pos"] += hs_offset(new) - hs_offset(old)
-
-        f = rec["flag"]; revd = bool(f & 0x10)
-        if rec["tlen"] != 0 and f & 0x1 and not (f & 0x8 or rec["next_refid"] < 0 or rec["pnext"] == 0) and revd != bool(f & 0x20):
-            aln_end = end()
-            well = aln_end > rec["pnext"] if revd else st["pos"] <= rec["pnext"] + rec["tlen"]
-            if well:
-                boundary = rec["pnext"] - 1 if revd else st["pos"] + abs(rec["tlen"])
-                if st["pos"] <= boundary <= aln_end:
-                    if revd:
-                        stop, ok = get_read_coord(st["cig"], soft_start(), boundary, False)
-                        if not ok:
-                            raise Panic()
-                        hard_clip(0, stop)
-                    else:
-                        start, ok = get_read_coord(st["cig"], soft_start(), boundary, True)
-                        if not ok:
-                            raise Panic()
-                        hard_clip(start, st["n"] - 1)
-        if st["n"] == 0:
-            return st
-        read_index = 0; cut_left = cut_right = -1; right_tail = False
-        for op, ln in st["cig"]:
-            if op == "S":
-                if right_tail:
-                    cut_right = read_index
-                else:
-                    cut_left = read_index + ln - 1
-            elif op != "H":
-                right_tail = True
-            read_index += ln if op in READ else 0
-        if cut_right >= 0:
-            hard_clip(cut_right, st["n"] - 1)
-        if cut_left >= 0:
-            hard_clip(0, cut_left)
-        return st
-
+    Panic = _ClipPanic
+    clip = _c_clip
     checked = panics = 0
     for trial in range(1500):
         ops = []
@@ -1019,8 +1024,8 @@ def test_clipping_chain_against_a_second_restatement():  # filters/utils.go:149-
             ops.append((int(rng.integers(1, 6)), "S"))
         if rng.random() < 0.15:
             ops.append((int(rng.integers(1, 4)), "H"))
-        L = sum(l for l, o in ops if o in READ)
-        span = sum(l for l, o in ops if o in REF)
+        L = sum(l for l, o in ops if o in _READ)
+        span = sum(l for l, o in ops if o in _REF)
         pos = int(rng.integers(50, 100))
         revd = rng.random() < 0.5
         paired = rng.random() < 0.8
@@ -1045,3 +1050,83 @@ def test_clipping_chain_against_a_second_restatement():  # filters/utils.go:149-
             assert got == (st["a"], st["a"] + st["n"], st["pos"], st["cig"]), (trial, ops, flag, pnext, tlen, got, st)
         checked += 1
     assert checked > 1200
+
+
+def test_bqsr_gather_against_a_full_second_restatement():  # filters/bqsr.go:225-551 + the clipping chain above
+    """Recalibrate as a whole, written a second time in Python: recalibrateAln, adaptor and soft-clip hard clipping, the skip slice
+    from the known sites (read coordinates by the 'left' rule on the clipped CIGAR), SNP events over the clipped CIGAR, cycle and
+    context on the clipped read - on a synthetic batch with indels, clips, adaptor read-through, supplementary records, duplicates."""
+    from tests.common import dataset
+    from elprep_amd.batch import NIL16
+    cfg, b, h, refs, sites = dataset("tiny", 2500, 7, 0.03)
+    flags = orc.mark_duplicates(b, h)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    b2i = {ord("a"): 1, ord("A"): 1, ord("*"): 1, ord("c"): 2, ord("C"): 2, ord("g"): 3, ord("G"): 3, ord("t"): 4, ord("T"): 4}
+    wq = np.zeros((h.n_cov, 94, 2), np.int64); wc = np.zeros((h.n_cov, 94, 1001, 2), np.int64); wx = np.zeros((h.n_cov, 94, 16, 2), np.int64)
+    used = clipped_reads = 0
+    for i in range(b.n):
+        f = int(flags[i]); mq = int(b.mapq[i]); r = int(b.refid[i]); pos = int(b.pos[i])
+        ops = [(int(c) >> 4, "MIDNSHP=X"[int(c) & 15]) for c in b.cigar[int(b.cigar_off[i]):int(b.cigar_off[i + 1])]]
+        o = int(b.qual_off[i]); L = int(b.qual_off[i + 1]) - o
+        if b.has_sr[i] or not (0 < mq < 255) or f & (0x100 | 0x400 | 0x200) or f & 0x4 or r < 0 or pos <= 0 or L == 0 or L != int(b.l_seq[i]):
+            continue
+        if b.rgid[i] == NIL16 or pos > int(h.ref_len[r]) or any(op == "N" for _, op in ops) or sum(l for l, op in ops if op in _READ) != L:
+            continue
+        rec = dict(ops=ops, L=L, pos=pos, flag=f, pnext=int(b.pnext[i]), tlen=int(b.tlen[i]), next_refid=int(b.next_refid[i]))
+        st = _c_clip(rec)
+        n, a, cig, cpos = st["n"], st["a"], st["cig"], st["pos"]
+        if n == 0:
+            continue
+        clipped_reads += n != L
+        seq = b.seq_of(i)[a:a + n]; qual = b.qual[o + a:o + a + n]
+        revd, last = bool(f & 0x10), bool(f & 0x80)
+        # soft start / soft end of the clipped record (no soft clips are left, hard clips do not count)
+        ss, se = cpos, cpos + sum(l for op, l in cig if op in _REF) - 1
+        skip = [False] * n
+        for s, e in orc.intersect(sites[r], ss, se):
+            fs, ok = _c_get_read_coord(cig, ss, int(s), False)
+            if not ok or fs < 0:
+                fs = 0
+            fe, ok = _c_get_read_coord(cig, ss, int(e), False)
+            if not ok or fe > n - 1:
+                fe = n - 1
+            for k in range(fs, fe + 1):
+                skip[k] = True
+        snp = [0] * n
+        ri, rj = 0, cpos - 1
+        for op, ln in cig:
+            if op in "M=X":
+                for _ in range(ln):
+                    if b2i.get(ord(seq[ri]), 0) != b2i.get(int(refs[r][rj]), 0):
+                        snp[ri] = 1
+                    ri += 1; rj += 1
+            elif op in "DN":
+                rj += ln
+            elif op in "IS":
+                ri += ln
+        good = np.nonzero(qual > 2)[0]
+        strand = [seq[k] if len(good) and good[0] <= k <= good[-1] else "N" for k in range(n)] if len(good) else None
+        rof = -1 if last else 1
+        cf = rof + (n - 1) * rof * (1 if revd else 0); inc = (-1 if revd else 1) * rof
+        cov = int(h.rg_cov[b.rgid[i]])
+        used += 1
+        for k in range(n):
+            q = int(qual[k])
+            if skip[k] or seq[k] not in code or q < 6:
+                continue
+            e = snp[k]
+            wq[cov, q] += (1, e); wc[cov, q, 500 + cf + k * inc] += (1, e)
+            if strand is None:
+                continue
+            if not revd:
+                prev, cur = (strand[k - 1] if k >= 1 else None), strand[k]
+            else:
+                prev, cur = (comp.get(strand[k + 1], "N") if k + 1 < n else None), comp.get(strand[k], "N")
+            if prev in code and cur in code:
+                wx[cov, q, code[prev] | (code[cur] << 2)] += (1, e)
+    qt, ct, xt = orc.bqsr_gather(b, h, orc.BqsrRef(refs, sites), flags, 500)
+    assert used > 3000 and clipped_reads > 100 and wq[..., 1].sum() > 1000
+    assert np.array_equal(qt, wq)
+    assert np.array_equal(ct, wc)
+    assert np.array_equal(xt, wx)
