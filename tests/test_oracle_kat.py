@@ -1130,3 +1130,78 @@ def test_bqsr_gather_against_a_full_second_restatement():  # filters/bqsr.go:225
     assert np.array_equal(qt, wq)
     assert np.array_equal(ct, wc)
     assert np.array_equal(xt, wx)
+
+
+def test_quantization_against_a_second_restatement():  # filters/bqsr.go:743-897
+    """initializeQuantizedQualityScores written a second time in Python: the observation count per empirical quality, the
+    minimal-penalty merging of neighbouring intervals down to `levels`, the score of every interval."""
+    import math
+    from tests.common import dataset
+    cfg, b, h, refs, sites = dataset("tiny", 3000, 2, 0.02)
+    flags = orc.mark_duplicates(b, h)
+    qt, ct, xt = orc.bqsr_gather(b, h, orc.BqsrRef(refs, sites), flags, 500)
+    fo = orc.BqsrFinal(qt, ct, xt, 500)
+    qe, _, _ = fo.empirical()
+    qmap = [0] * 94
+    for cov in range(qt.shape[0]):
+        for q in range(94):
+            if qt[cov, q, 0] > 0:
+                qmap[int(qe[cov, q])] += int(qt[cov, q, 0])
+
+    def quantize(levels):
+        if levels == 0:
+            return [0] * 94, list(range(94))
+        iv = []
+        for i, nobs in enumerate(qmap):
+            er = math.pow(10, i / -10)
+            iv.append(dict(next=i + 1 if i + 1 < 94 else -1, er=er, nobs=nobs, leaf=nobs, nerr=int(float(nobs) * er)))
+        rate = lambda nobs, nerr: 0.0 if nobs == 0 else float(nerr + 1) / float(nobs + 1)
+
+        def leaf_penalty(k, g):
+            return 0.0 if k <= 6 else abs(math.log10(iv[k]["er"]) - math.log10(g)) * float(iv[k]["leaf"])
+
+        def merge_penalty(i, j):
+            g = rate(iv[i]["nobs"] + iv[j]["nobs"], iv[i]["nerr"] + iv[j]["nerr"])
+            if g == 0:
+                return 0.0
+            kend = iv[j]["next"] if iv[j]["next"] >= 0 else 94
+            return sum(leaf_penalty(k, g) for k in range(i, j)) + sum(leaf_penalty(k, g) for k in range(j, kend))
+
+        n = 94
+        while n > levels:
+            i, j = 0, iv[0]["next"]
+            if j < 0:
+                break
+            min_i, best = i, merge_penalty(i, j)
+            while True:
+                i = j; j = iv[i]["next"]
+                if j < 0:
+                    break
+                p = merge_penalty(i, j)
+                if p < best:
+                    min_i, best = i, p
+            a, c = iv[min_i], iv[iv[min_i]["next"]]
+            a["next"], a["nobs"], a["nerr"] = c["next"], a["nobs"] + c["nobs"], a["nerr"] + c["nerr"]
+            n -= 1
+        scores = [0] * 94
+        i = 0
+        while i >= 0:
+            x = iv[i]
+            leaf = (i == 93) if x["next"] < 0 else (x["next"] == i + 1)
+            if leaf:
+                sc = i
+            else:
+                p = rate(x["nobs"], x["nerr"])
+                sc = 93 if p == 0.0 else max(min(int(math.floor(-10 * math.log10(p) + 0.5)), 93), 1)
+            for k in range(i, x["next"] if x["next"] >= 0 else 94):
+                scores[k] = sc
+            i = x["next"]
+        return qmap, scores
+
+    for levels in (0, 2, 4, 8, 16, 64):
+        counts, quantized = fo.quantize(levels)
+        wc, ws = quantize(levels)
+        assert quantized.tolist() == ws, levels
+        if levels:
+            assert counts.tolist() == wc
+    assert len(set(fo.quantize(4)[1].tolist())) <= 4 + 7  # four levels above the qualities the penalty ignores
