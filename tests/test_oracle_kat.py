@@ -1205,3 +1205,35 @@ def test_quantization_against_a_second_restatement():  # filters/bqsr.go:743-897
         if levels:
             assert counts.tolist() == wc
     assert len(set(fo.quantize(4)[1].tolist())) <= 4 + 7  # four levels above the qualities the penalty ignores
+
+
+def test_static_quantized_scores_against_a_second_restatement():  # filters/bqsr.go:710-742
+    """initializeStaticQuantizedScores (--sqq) written a second time, including its quirk: prevProb / prevQual are updated INSIDE the
+    loop over i, so from the second i of a gap on every quality maps to the upper bin."""
+    import math
+    prob = lambda q: 1 - math.pow(10, float(q) / -10)
+
+    def static(quals):
+        s = [0] * 254
+        for i in range(6):
+            s[i] = i
+        if len(quals) == 1:
+            for i in range(6, 254):
+                s[i] = quals[0]
+            return s
+        quals = sorted(quals)
+        prev_q = 6
+        prev_p = prob(prev_q)
+        for nq in quals:
+            i = prev_q
+            while i < nq:  # the Go loop bound nextQual is fixed, its start prevQual was read once
+                nxt = prob(nq); ip = prob(i)
+                s[i] = nq if ip - prev_p > nxt - ip else prev_q
+                prev_p = nxt; prev_q = nq
+                i += 1
+        for i in range(prev_q, 254):
+            s[i] = prev_q
+        return s
+
+    for quals in ([20], [10, 20, 30], [10, 20, 30, 40], [7, 8, 50], [25], [6, 93], [15, 16]):
+        assert orc.static_quantized_scores(quals).tolist() == static(list(quals)), quals
