@@ -20,7 +20,7 @@ _host: Optional[C.CDLL] = None
 
 HIP_SYMBOLS = [
     "elp_create", "elp_destroy", "elp_last_error", "elp_sync", "elp_stream", "elp_set_header", "elp_reserve", "elp_stage", "elp_reset",
-    "elp_num_records", "elp_sort_coordinate", "elp_get_permutation", "elp_mark_duplicates", "elp_get_flags", "elp_get_adapted",
+    "elp_num_records", "elp_num_sorted", "elp_sort_coordinate", "elp_get_permutation", "elp_mark_duplicates", "elp_get_flags", "elp_get_adapted",
     "elp_dup_metrics", "elp_dup_metrics_hist", "elp_bqsr_set_reference", "elp_bqsr_set_known_sites", "elp_bqsr_gather", "elp_bqsr_apply", "elp_get_qual",
     "elp_snapshot", "elp_rollback", "elp_profile_enable", "elp_profile_reset", "elp_profile_count", "elp_profile_get",
 ]
@@ -51,6 +51,8 @@ def hip() -> C.CDLL:
         L.elp_last_error.argtypes = [C.c_void_p]
         L.elp_num_records.restype = C.c_uint64
         L.elp_num_records.argtypes = [C.c_void_p]
+        L.elp_num_sorted.restype = C.c_uint64
+        L.elp_num_sorted.argtypes = [C.c_void_p]
         L.elp_stream.restype = C.c_void_p
         L.elp_stream.argtypes = [C.c_void_p]
         L.elp_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]

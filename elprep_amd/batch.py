@@ -37,6 +37,7 @@ class CBatch(C.Structure):
         ("cigar_off", C.c_void_p), ("cigar", C.c_void_p),
         ("seq_off", C.c_void_p), ("seq4", C.c_void_p),
         ("qual_off", C.c_void_p), ("qual", C.c_void_p),
+        ("split", C.c_void_p),
     ]
 
 
@@ -55,7 +56,9 @@ _COLS = [
     ("flag", np.uint16), ("mapq", np.uint8), ("rgid", np.uint16), ("has_sr", np.uint8), ("l_seq", np.uint32),
     ("qname_off", np.uint64), ("qname", np.uint8), ("cigar_off", np.uint64), ("cigar", np.uint32),
     ("seq_off", np.uint64), ("seq4", np.uint8), ("qual_off", np.uint64), ("qual", np.uint8),
+    ("split", np.uint16),
 ]
+_FIXED = ("refid", "pos", "next_refid", "pnext", "tlen", "flag", "mapq", "rgid", "has_sr", "l_seq", "split")
 
 
 def _ptr(a: np.ndarray) -> int:
@@ -84,13 +87,16 @@ class Batch:
     seq4: np.ndarray
     qual_off: np.ndarray
     qual: np.ndarray
+    split: Optional[np.ndarray] = None  # id of the `elprep split` file a record belongs to (default: all 0 = one filter run)
 
     def __post_init__(self):
+        if self.split is None:
+            self.split = np.zeros(np.asarray(self.refid).shape[0], dtype=np.uint16)
         for name, dt in _COLS:
             a = np.ascontiguousarray(getattr(self, name), dtype=dt)
             setattr(self, name, a)
         n = self.n
-        for name in ("pos", "next_refid", "pnext", "tlen", "flag", "mapq", "rgid", "has_sr", "l_seq"):
+        for name in _FIXED[1:]:
             if getattr(self, name).shape[0] != n:
                 raise ValueError(f"column {name} has {getattr(self, name).shape[0]} rows, expected {n}")
         for name in ("qname_off", "cigar_off", "seq_off", "qual_off"):
@@ -130,7 +136,7 @@ class Batch:
     def take(self, idx) -> "Batch":
         """Gather records `idx` (any order) into a new batch (payload permutation: host work in the reference design)."""
         idx = np.asarray(idx, dtype=np.int64)
-        cols = {name: getattr(self, name)[idx] for name in ("refid", "pos", "next_refid", "pnext", "tlen", "flag", "mapq", "rgid", "has_sr", "l_seq")}
+        cols = {name: getattr(self, name)[idx] for name in _FIXED}
         for off, dat in (("qname_off", "qname"), ("cigar_off", "cigar"), ("seq_off", "seq4"), ("qual_off", "qual")):
             o = getattr(self, off).astype(np.int64)
             lens = (o[1:] - o[:-1])[idx]
@@ -151,7 +157,7 @@ class Batch:
     @staticmethod
     def concat(parts: List["Batch"]) -> "Batch":
         cols = {}
-        for name in ("refid", "pos", "next_refid", "pnext", "tlen", "flag", "mapq", "rgid", "has_sr", "l_seq", "qname", "cigar", "seq4", "qual"):
+        for name in _FIXED + ("qname", "cigar", "seq4", "qual"):
             cols[name] = np.concatenate([getattr(p, name) for p in parts])
         for off in ("qname_off", "cigar_off", "seq_off", "qual_off"):
             acc = [np.zeros(1, dtype=np.uint64)]
@@ -265,6 +271,7 @@ def batch_from_records(records) -> Batch:
     Small-case helper for tests and the host harness."""
     n = len(records)
     cols = {k: np.zeros(n, dtype=dt) for k, dt in _COLS[:10]}
+    cols["split"] = np.zeros(n, dtype=np.uint16)
     qn, cg, sq, ql = [], [], [], []
     qo, co, so, lo = [0], [0], [0], [0]
     for i, r in enumerate(records):
@@ -278,6 +285,7 @@ def batch_from_records(records) -> Batch:
         rg = r.get("rgid", NIL16)
         cols["rgid"][i] = NIL16 if rg is None else rg
         cols["has_sr"][i] = 1 if r.get("has_sr") else 0
+        cols["split"][i] = r.get("split", 0)
         name = r.get("qname", b"")
         name = name.encode() if isinstance(name, str) else name
         qn.append(np.frombuffer(name, dtype=np.uint8))

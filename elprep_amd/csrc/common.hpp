@@ -71,8 +71,9 @@ struct elp_ctx {
 
   // staged columns
   uint64_t n = 0, qname_bytes = 0, cigar_ops = 0, seq_bytes = 0, qual_bytes = 0;
+  uint64_t n_sr = 0;  // staged records that carry the sr tag (dropped by RemoveOptionalReads: behind everything else in the permutation)
   elp::DVec<int32_t> refid, pos, next_refid, pnext, tlen;
-  elp::DVec<uint16_t> flag, rgid;
+  elp::DVec<uint16_t> flag, rgid, split;
   elp::DVec<uint8_t> mapq, has_sr;
   elp::DVec<uint32_t> l_seq;
   elp::DVec<uint64_t> qname_off, cigar_off, seq_off, qual_off;  // n+1
@@ -80,6 +81,7 @@ struct elp_ctx {
   elp::DVec<uint32_t> cigar;
   elp::DVec<uint64_t> stage_tmp;  // offsets of the batch being staged
   uint32_t max_qname_len = 0, max_l_seq = 0;
+  uint32_t max_split = 0;  // largest staged split id
   uint32_t max_pos = 0;  // largest staged POS (as uint32): width of the POS field of the coordinate-sort key
 
   // derived state
@@ -99,6 +101,8 @@ struct elp_ctx {
   elp::DVec<unsigned long long> radix_state;  // radix.hip: per (tile, digit) look-back words, tagged with the pass epoch
   elp::DVec<uint32_t> radix_ticket;           // radix.hip: tile ticket counters
   elp::DVec<uint32_t> tie_live;               // sort.hip: bit j = byte j of the comparator string differs among the members of large runs
+  static constexpr uint32_t MAX_QNAME = 1000; // staged QNAME length limit; the comparator string (QNAME + 15 bytes) fits TIE_LIVE_WORDS * 32 bits
+  static constexpr uint32_t TIE_LIVE_WORDS = 32;
   uint32_t radix_epoch = 0;
   uint64_t flat_index_n = 0, flat_index_bytes = 0;
 

@@ -175,6 +175,7 @@ static int reserve_locked(elp_ctx *c, uint64_t n, uint64_t qb, uint64_t co, uint
   ELP_TRY(ensure(c, c->tlen, n, keep, c->n));
   ELP_TRY(ensure(c, c->flag, n, keep, c->n));
   ELP_TRY(ensure(c, c->rgid, n, keep, c->n));
+  ELP_TRY(ensure(c, c->split, n, keep, c->n));
   ELP_TRY(ensure(c, c->mapq, n, keep, c->n));
   ELP_TRY(ensure(c, c->has_sr, n, keep, c->n));
   ELP_TRY(ensure(c, c->l_seq, n, keep, c->n));
@@ -200,6 +201,8 @@ int elp_reset(elp_ctx *c) {
   if (!c) return ELP_ERR_ARG;
   std::lock_guard<std::mutex> g(c->stage_mu);
   c->n = c->qname_bytes = c->cigar_ops = c->seq_bytes = c->qual_bytes = 0;
+  c->n_sr = 0;
+  c->max_split = 0;
   c->max_qname_len = c->max_l_seq = 0;
   c->max_pos = 0;
   c->adapted = c->sorted = c->marked = false;
@@ -210,6 +213,7 @@ int elp_reset(elp_ctx *c) {
 }
 
 uint64_t elp_num_records(const elp_ctx *c) { return c ? c->n : 0; }
+uint64_t elp_num_sorted(const elp_ctx *c) { return c ? c->n - c->n_sr : 0; }
 
 int elp_stage(elp_ctx *c, const elp_batch *b) {
   if (!c || !b) return ELP_ERR_ARG;
@@ -223,11 +227,17 @@ int elp_stage(elp_ctx *c, const elp_batch *b) {
   uint64_t qb = b->qname_off[n] - q0, co = b->cigar_off[n] - c0, sb = b->seq_off[n] - s0, lb = b->qual_off[n] - l0;
   ELP_TRY(reserve_locked(c, c->n + n, c->qname_bytes + qb, c->cigar_ops + co, c->seq_bytes + sb, c->qual_bytes + lb));
   // host-side scan for limits the kernels rely on
+  uint64_t n_sr = 0;
+  uint32_t max_split = c->max_split;
+  uint32_t max_qname_len = c->max_qname_len, max_l_seq = c->max_l_seq, max_pos = c->max_pos;  // committed when the batch is
   for (uint64_t i = 0; i < n; i++) {
     uint64_t ql = b->qname_off[i + 1] - b->qname_off[i];
-    if (ql > c->max_qname_len) c->max_qname_len = (uint32_t)ql;
-    if (b->l_seq[i] > c->max_l_seq) c->max_l_seq = b->l_seq[i];
-    if ((uint32_t)b->pos[i] > c->max_pos) c->max_pos = (uint32_t)b->pos[i];
+    if (ql > elp_ctx::MAX_QNAME) return set_error(c, ELP_ERR_UNSUPPORTED, "record %llu: QNAME of %llu bytes (limit %u)", (unsigned long long)i, (unsigned long long)ql, elp_ctx::MAX_QNAME);
+    if (b->has_sr && b->has_sr[i]) n_sr++;
+    if (b->split && b->split[i] > max_split) max_split = b->split[i];
+    if (ql > max_qname_len) max_qname_len = (uint32_t)ql;
+    if (b->l_seq[i] > max_l_seq) max_l_seq = b->l_seq[i];
+    if ((uint32_t)b->pos[i] > max_pos) max_pos = (uint32_t)b->pos[i];
     if (b->qual_off[i + 1] - b->qual_off[i] > 0x3FFFFFull || b->l_seq[i] > 0x3FFFFFu)  // FL_MAX_READ (flat.hpp)
       return set_error(c, ELP_ERR_UNSUPPORTED, "record %llu: more than 4194303 bases", (unsigned long long)i);
     if (b->rgid[i] != ELP_NIL16 && b->rgid[i] >= c->n_rg) return set_error(c, ELP_ERR_ARG, "record %llu: rgid %u not in header", (unsigned long long)i, b->rgid[i]);
@@ -243,6 +253,8 @@ int elp_stage(elp_ctx *c, const elp_batch *b) {
   H2D(c->tlen.p + at, b->tlen, n, int32_t);
   H2D(c->flag.p + at, b->flag, n, uint16_t);
   H2D(c->rgid.p + at, b->rgid, n, uint16_t);
+  if (b->split) H2D(c->split.p + at, b->split, n, uint16_t);
+  else ELP_HIP(c, hipMemsetAsync(c->split.p + at, 0, n * sizeof(uint16_t), st));
   H2D(c->mapq.p + at, b->mapq, n, uint8_t);
   H2D(c->l_seq.p + at, b->l_seq, n, uint32_t);
   if (b->has_sr) H2D(c->has_sr.p + at, b->has_sr, n, uint8_t);
@@ -269,6 +281,9 @@ int elp_stage(elp_ctx *c, const elp_batch *b) {
 #undef H2D
   ELP_HIP(c, hipStreamSynchronize(st));  // host buffers may be reused on return
   c->n += n; c->qname_bytes += qb; c->cigar_ops += co; c->seq_bytes += sb; c->qual_bytes += lb;
+  c->n_sr += n_sr;
+  c->max_split = max_split;
+  c->max_qname_len = max_qname_len; c->max_l_seq = max_l_seq; c->max_pos = max_pos;
   c->adapted = c->sorted = c->marked = false;
   c->have_qual_present = false;
   c->have_snapshot = false;

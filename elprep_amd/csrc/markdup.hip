@@ -7,7 +7,8 @@
 //
 //   fragments  key {lib, refid, unclipped 5' pos, strand}: if the group holds a read of a true pair, every true fragment
 //              of the group is a duplicate; otherwise all but the best (score desc, QNAME asc, later arrival) are.
-//   mates      key {lib, QNAME}: reads pair up in arrival order (DeleteOrStore toggling, :336-340).
+//   mates      key {lib, QNAME}: reads pair up in arrival order (DeleteOrStore toggling, :336-340): of the records r0 < r1 < r2 ...
+//              (staging order) that share a key, (r0, r1), (r2, r3), ... are pairs, an odd last one stays alone.
 //   pairs      key {lib, refid1, refid2, pos1, pos2, strand1, strand2} with ends ordered as in :347-353: all but the best
 //              pair (score sum desc, QNAME asc, later completion) have both reads flagged.
 //
@@ -27,6 +28,7 @@ struct MdCols {
   const uint16_t *flag_in;  // flags as staged (before this call)
   const uint16_t *rgid;
   const uint16_t *rg_lib;
+  const uint16_t *split;    // elp_batch.split: records of different splits never share a key
   const int32_t *upos, *score;
   const uint64_t *qname_off;
   const uint8_t *qname;
@@ -44,18 +46,18 @@ __device__ __forceinline__ unsigned long long ld_agent64(const unsigned long lon
 }
 
 // ---------------- fragments
-// The fragment key of a record in one 16-byte word: {REFID, unclipped 5' position, LIBID << 1 | reversed, 0}.  A probe that lands on
+// The fragment key of a record in one 16-byte word: {REFID, unclipped 5' position, LIBID << 1 | reversed, split id}.  A probe that lands on
 // an occupied slot compares against ONE random 16-byte load instead of four column gathers (the tables are at the random-access
 // limit of the memory system, so accesses are what counts).
 __global__ __launch_bounds__(256) void k_md_keys(MdCols m, uint4 *__restrict__ fkey) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m.n) return;
-  fkey[i] = make_uint4((uint32_t)m.refid[i], (uint32_t)m.upos[i], ((uint32_t)lib_of(m, (uint32_t)i) << 1) | ((m.flag_in[i] & F_REVERSED) ? 1u : 0u), 0u);
+  fkey[i] = make_uint4((uint32_t)m.refid[i], (uint32_t)m.upos[i], ((uint32_t)lib_of(m, (uint32_t)i) << 1) | ((m.flag_in[i] & F_REVERSED) ? 1u : 0u), (uint32_t)m.split[i]);
 }
-__device__ __forceinline__ bool key_eq(const uint4 &a, const uint4 &b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+__device__ __forceinline__ bool key_eq(const uint4 &a, const uint4 &b) { return a.x == b.x && a.y == b.y && a.z == b.z && a.w == b.w; }
 __device__ __forceinline__ uint64_t frag_hash(const uint4 &k) {
   const uint64_t h = ((uint64_t)k.x << 32) | k.y;
-  return mix64(mix64(h) ^ (uint64_t)k.z);
+  return mix64(mix64(h) ^ (((uint64_t)k.w << 32) | (uint64_t)k.z));
 }
 
 // generic find-or-insert; returns the representative record of i's group
@@ -133,23 +135,32 @@ __device__ __forceinline__ uint64_t qname_hash(const MdCols &m, uint32_t i) {
   const uint32_t l = (uint32_t)(m.qname_off[i + 1] - o);
   uint64_t h = 0x9e3779b97f4a7c15ull ^ l;
   for (uint32_t k = 0; k < l; k += 8) h = mix64(h ^ low_bytes(load8(m.qname + o + k), l - k));
-  return mix64(h ^ ((uint64_t)lib_of(m, i) << 48));
+  return mix64(h ^ ((uint64_t)lib_of(m, i) << 48) ^ ((uint64_t)m.split[i] << 24));
 }
+__device__ __forceinline__ bool mate_key_eq(const MdCols &m, uint32_t a, uint32_t b) {
+  return lib_of(m, a) == lib_of(m, b) && m.split[a] == m.split[b] && qname_eq(m.qname, m.qname_off, a, b);
+}
+__device__ __forceinline__ bool is_mate_candidate(uint16_t f) { return is_candidate(f) && is_true_pair(f); }
 
-// Mates pair up through the table: the first record of a {library, QNAME} key becomes the slot's representative, the second one
-// finds it and claims it with one CAS on mate[representative]; a third record fails that CAS (more than two primary mapped records
-// per key: unsupported).  mate[] must be EMPTY-initialised.
-// Records that sit next to their mate in staging order (the order an aligner writes them in) do not go through the table at all:
-// a run of exactly two neighbouring records with the same key is a pair, and each of the two writes its own mate entry.  (A third
-// record with that key somewhere else then stays alone instead of raising the error: the reference's result for such input depends
-// on arrival order anyway.)
-__global__ __launch_bounds__(256) void k_mate_insert(MdCols m, uint32_t *table, uint64_t mask, uint32_t *mate, uint32_t *err) {
+// Mate matching reproduces DeleteOrStore toggling in staging order (:336-340).  Three paths:
+//  (1) neighbours: a run of exactly two neighbouring candidates with the same {split, library, QNAME} (the order an aligner writes
+//      mates in) is a pair WITHOUT touching the hash table - provided no other record shares the key.  Records that are not part of
+//      such a run announce their key in a Bloom filter first (k_mate_scan); a neighbour pair whose key hits the filter takes path (2).
+//  (2) table: the first record of a key to arrive at its slot becomes the slot's representative, the second claims it with one CAS on
+//      mate[representative]; both are the only records of the key, so they are a pair whatever their order.
+//  (3) a third record of a key fails that CAS and marks the key's group BIG; the host then lists the members of the big groups,
+//      sorts them by (representative, staging index) and pairs them up 0-1, 2-3, ... within every group (k_big_collect, k_big_pair).
+// k_mate_scan: code[i] = 0 not a mate candidate, 1 table path, 2 leader / 3 follower of a neighbour pair; hash32 of the leader = the
+// high half of its key hash (the bits the table index does not use).
+enum : uint8_t { MC_NONE = 0, MC_TABLE = 1, MC_LEAD = 2, MC_FOLLOW = 3 };
+constexpr uint32_t MATE_BIG = 0xFFFFFFFEu;
+
+__global__ __launch_bounds__(256) void k_mate_scan(MdCols m, uint8_t *__restrict__ code, uint32_t *__restrict__ hash32, uint32_t *bloom,
+                                                   uint32_t bloom_mask) {
   const uint64_t base = (uint64_t)blockIdx.x * 256, i = base + threadIdx.x;
-  const auto same_key = [&](uint32_t a, uint32_t b) { return lib_of(m, a) == lib_of(m, b) && qname_eq(m.qname, m.qname_off, a, b); };
   const auto joins = [&](uint64_t a) -> bool {  // neighbours a, a + 1 are both mate candidates with the same key
     if (a + 1 >= m.n) return false;
-    const uint16_t fa = m.flag_in[a], fb = m.flag_in[a + 1];
-    return is_candidate(fa) && is_true_pair(fa) && is_candidate(fb) && is_true_pair(fb) && same_key((uint32_t)a, (uint32_t)a + 1);
+    return is_mate_candidate(m.flag_in[a]) && is_mate_candidate(m.flag_in[a + 1]) && mate_key_eq(m, (uint32_t)a, (uint32_t)a + 1);
   };
   // s_join[t] = joins(base - 2 + t) for t in [0, 259): every neighbour test of the block is made once
   __shared__ uint8_t s_join[264];
@@ -158,20 +169,74 @@ __global__ __launch_bounds__(256) void k_mate_insert(MdCols m, uint32_t *table, 
   if (threadIdx.x == 2) s_join[258] = joins(base + 256);
   __syncthreads();
   if (i >= m.n) return;
-  const uint16_t f = m.flag_in[i];
-  if (!is_candidate(f) || !is_true_pair(f)) return;
-  const uint8_t *j = s_join + threadIdx.x + 2;  // j[0] = joins(i)
-  const bool nx = j[0], pv = j[-1];
-  if (nx && !pv) {
-    if (!j[1]) { mate[i] = (uint32_t)i + 1; return; }
-  } else if (pv && !nx) {
-    if (!j[-2]) { mate[i] = (uint32_t)i - 1; return; }
+  uint8_t cd = MC_NONE;
+  if (is_mate_candidate(m.flag_in[i])) {
+    const uint8_t *j = s_join + threadIdx.x + 2;  // j[0] = joins(i)
+    const bool nx = j[0], pv = j[-1];
+    cd = MC_TABLE;
+    if (nx && !pv && !j[1]) cd = MC_LEAD;
+    else if (pv && !nx && !j[-2]) cd = MC_FOLLOW;
+    if (cd != MC_FOLLOW) {
+      const uint32_t hi = (uint32_t)(qname_hash(m, (uint32_t)i) >> 32);
+      if (cd == MC_LEAD) hash32[i] = hi;
+      else atomicOr(&bloom[(hi >> 5) & bloom_mask], 1u << (hi & 31u));
+    }
   }
-  const uint32_t rep = find_or_insert(table, mask, qname_hash(m, (uint32_t)i), (uint32_t)i, same_key);
-  if (rep == (uint32_t)i) return;  // first of its key: the mate (if any) will write both entries
+  code[i] = cd;
+}
+
+// mate[] and rep[] must be EMPTY-initialised.  rep[i] = representative of i's key for records that went through the table and are
+// not the representative themselves; rep[representative] = MATE_BIG iff its key has more than two records.
+__global__ __launch_bounds__(256) void k_mate_insert(MdCols m, const uint8_t *__restrict__ code, const uint32_t *__restrict__ hash32,
+                                                     const uint32_t *__restrict__ bloom, uint32_t bloom_mask, uint32_t *table, uint64_t mask,
+                                                     uint32_t *mate, uint32_t *rep_of, uint32_t *err) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= m.n) return;
+  const uint8_t cd = code[i];
+  if (cd == MC_NONE) return;
+  if (cd != MC_TABLE) {
+    const uint32_t hi = hash32[cd == MC_LEAD ? i : i - 1];
+    if (!((bloom[(hi >> 5) & bloom_mask] >> (hi & 31u)) & 1u)) {  // nobody else announced this key: the two neighbours are the pair
+      mate[i] = cd == MC_LEAD ? (uint32_t)i + 1 : (uint32_t)i - 1;
+      return;
+    }
+  }
+  const uint32_t rep = find_or_insert(table, mask, qname_hash(m, (uint32_t)i), (uint32_t)i, [&](uint32_t a, uint32_t b) { return mate_key_eq(m, a, b); });
+  if (rep == (uint32_t)i) return;  // first of its key at the slot
+  rep_of[i] = rep;
   const uint32_t old = atomicCAS(&mate[rep], EMPTY, (uint32_t)i);
-  if (old == EMPTY) mate[i] = rep;
-  else atomicOr(&err[1], 1u);  // more than two primary mapped records share {library, QNAME}
+  if (old == EMPTY) { mate[i] = rep; return; }
+  rep_of[rep] = MATE_BIG;  // more than two records share {split, library, QNAME}
+  atomicOr(&err[1], 1u);
+}
+
+// members of big groups -> list of (representative << 32 | record); their mate entries are reset
+__global__ __launch_bounds__(256) void k_big_collect(uint64_t n, const uint32_t *__restrict__ rep_of, uint32_t *mate, uint64_t *__restrict__ keys,
+                                                     uint32_t *__restrict__ vals, uint32_t *count) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t r = rep_of[i];
+  if (r == EMPTY) return;
+  uint32_t rep;
+  if (r == MATE_BIG) rep = (uint32_t)i;
+  else if (rep_of[r] == MATE_BIG) rep = r;
+  else return;
+  const uint32_t at = atomicAdd(count, 1u);
+  keys[at] = ((uint64_t)rep << 32) | (uint64_t)i;
+  vals[at] = (uint32_t)i;
+  mate[i] = EMPTY;
+}
+// list sorted by (representative, record): the head of every group pairs its members up in arrival order
+__global__ __launch_bounds__(256) void k_big_pair(uint32_t cnt, const uint64_t *__restrict__ keys, uint32_t *mate) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= cnt) return;
+  const uint32_t rep = (uint32_t)(keys[j] >> 32);
+  if (j > 0 && (uint32_t)(keys[j - 1] >> 32) == rep) return;
+  for (uint32_t k = j; k + 1 < cnt && (uint32_t)(keys[k + 1] >> 32) == rep; k += 2) {
+    const uint32_t a = (uint32_t)keys[k], b = (uint32_t)keys[k + 1];
+    mate[a] = b;
+    mate[b] = a;
+  }
 }
 
 // ---------------- pairs
@@ -185,7 +250,8 @@ __device__ __forceinline__ PairKey pair_key(const uint4 &second, const uint4 &fi
 }
 // same two ends (positions, orientations) in the same library (the library of the first end stands for the pair, :355)
 __device__ __forceinline__ bool pair_key_eq(const PairKey &a, const PairKey &b) {
-  return a.k1.x == b.k1.x && a.k2.x == b.k2.x && a.k1.y == b.k1.y && a.k2.y == b.k2.y && a.k1.z == b.k1.z && ((a.k2.z ^ b.k2.z) & 1u) == 0;
+  return a.k1.x == b.k1.x && a.k2.x == b.k2.x && a.k1.y == b.k1.y && a.k2.y == b.k2.y && a.k1.z == b.k1.z && ((a.k2.z ^ b.k2.z) & 1u) == 0 &&
+         a.k1.w == b.k1.w;  // mates share their split id
 }
 
 __global__ __launch_bounds__(256) void k_pair_insert(MdCols m, const uint4 *__restrict__ fkey, const uint32_t *__restrict__ mate, uint32_t *table,
@@ -197,7 +263,7 @@ __global__ __launch_bounds__(256) void k_pair_insert(MdCols m, const uint4 *__re
   const PairKey mine = pair_key(fkey[i], fkey[mt]);
   uint64_t h = mix64(((uint64_t)mine.k1.x << 32) | mine.k2.x);
   h = mix64(h ^ (((uint64_t)mine.k1.y << 32) | mine.k2.y));
-  h = mix64(h ^ (((uint64_t)mine.k1.z << 1) | (mine.k2.z & 1u)));
+  h = mix64(h ^ (((uint64_t)mine.k1.z << 1) | (mine.k2.z & 1u)) ^ ((uint64_t)mine.k1.w << 40));
   const uint32_t rep = find_or_insert(table, mask, h, (uint32_t)i,
                                       [&](uint32_t a, uint32_t) { return pair_key_eq(pair_key(fkey[a], fkey[mate[a]]), mine); });
   prep[i] = rep;
@@ -248,7 +314,7 @@ static int markdup_impl(elp_ctx *c) {
   uint16_t *flag_in;
   ELP_TRY(scratch(c, 4, n + 8, &flag_in));
   ELP_HIP(c, hipMemcpyAsync(flag_in, c->flag.p, n * sizeof(uint16_t), hipMemcpyDeviceToDevice, st));
-  MdCols m{n, c->refid.p, flag_in, c->rgid.p, c->rg_lib.p, c->upos.p, c->score.p, c->qname_off.p, c->qname.p};
+  MdCols m{n, c->refid.p, flag_in, c->rgid.p, c->rg_lib.p, c->split.p, c->upos.p, c->score.p, c->qname_off.p, c->qname.p};
   const uint64_t T = table_size_for(n);
   uint32_t *table;
   ELP_TRY(scratch(c, 0, T, &table));
@@ -273,9 +339,46 @@ static int markdup_impl(elp_ctx *c) {
              (const uint32_t *)winner, c->flag.p);
 
   // ---- mates
-  ELP_HIP(c, hipMemsetAsync(table, 0xFF, T * sizeof(uint32_t), st));
-  ELP_HIP(c, hipMemsetAsync(c->mate.p, 0xFF, n * sizeof(uint32_t), st));
-  ELP_LAUNCH(c, "md_mate_insert", k_mate_insert, dim3(grid), dim3(256), 0, m, table, T - 1, c->mate.p, c->err_flag.p);
+  {
+    uint64_t bw = 1024;  // Bloom filter words: ~2 bits per record, at most 4 MiB (what one XCD's L2 holds)
+    while (bw < n / 16 && bw < (1u << 20)) bw <<= 1;
+    uint32_t *bloom, *hash32;
+    uint8_t *code;
+    ELP_TRY(scratch(c, 6, bw + n + 16 + (n + 16) / 4, &bloom));
+    hash32 = bloom + bw;
+    code = reinterpret_cast<uint8_t *>(hash32 + n + 8);
+    uint32_t *rep_of = c->pair_slot.p;  // free until k_pair_insert fills it
+    ELP_HIP(c, hipMemsetAsync(bloom, 0, bw * sizeof(uint32_t), st));
+    ELP_HIP(c, hipMemsetAsync(table, 0xFF, T * sizeof(uint32_t), st));
+    ELP_HIP(c, hipMemsetAsync(c->mate.p, 0xFF, n * sizeof(uint32_t), st));
+    ELP_HIP(c, hipMemsetAsync(rep_of, 0xFF, n * sizeof(uint32_t), st));
+    ELP_LAUNCH(c, "md_mate_scan", k_mate_scan, dim3(grid), dim3(256), 0, m, code, hash32, bloom, (uint32_t)(bw - 1));
+    ELP_LAUNCH(c, "md_mate_insert", k_mate_insert, dim3(grid), dim3(256), 0, m, (const uint8_t *)code, (const uint32_t *)hash32,
+               (const uint32_t *)bloom, (uint32_t)(bw - 1), table, T - 1, c->mate.p, rep_of, c->err_flag.p);
+    uint32_t e[4];
+    ELP_TRY(fetch_err(c, e));
+    if (e[1]) {
+      // keys with more than two records: pair their members up in arrival order
+      ELP_HIP(c, hipMemsetAsync(c->err_flag.p + 1, 0, 4, st));
+      uint64_t *bk;
+      uint32_t *bv, *cnt_dev = c->err_flag.p + 3;  // the scan-total mailbox doubles as the list counter
+      ELP_TRY(scratch(c, 2, 2 * n + 8, &bk));  // `best` is free between the fragment and the pair phase
+      ELP_TRY(scratch(c, 3, 2 * n + 8, &bv));  // so is `winner`
+      ELP_HIP(c, hipMemsetAsync(cnt_dev, 0, 4, st));
+      ELP_LAUNCH(c, "md_big_collect", k_big_collect, dim3(grid), dim3(256), 0, n, (const uint32_t *)rep_of, c->mate.p, bk, bv, cnt_dev);
+      uint32_t cnt = 0;
+      ELP_HIP(c, hipMemcpyAsync(&cnt, cnt_dev, 4, hipMemcpyDeviceToHost, st));
+      ELP_HIP(c, hipStreamSynchronize(st));
+      ELP_HIP(c, hipMemsetAsync(cnt_dev, 0, 4, st));
+      uint64_t *ks;
+      uint32_t *vs;
+      ELP_TRY(radix_sort_pairs(c, bk, bv, bk + n, bv + n, cnt, &ks, &vs));
+      ELP_LAUNCH(c, "md_big_pair", k_big_pair, dim3(blocks_for(cnt, 256)), dim3(256), 0, cnt, (const uint64_t *)ks, c->mate.p);
+      // the scratch the pair phase uses was re-pointed above: take the (possibly grown) arrays again
+      ELP_TRY(scratch(c, 2, n + 8, &best));
+      ELP_TRY(scratch(c, 3, n + 8, &winner));
+    }
+  }
 
   // ---- pairs
   ELP_HIP(c, hipMemsetAsync(table, 0xFF, T * sizeof(uint32_t), st));
@@ -287,12 +390,6 @@ static int markdup_impl(elp_ctx *c) {
              (const unsigned long long *)best, c->pair_winner.p);
   ELP_LAUNCH(c, "md_pair_flag", k_pair_flag, dim3(grid), dim3(256), 0, m, (const uint32_t *)c->mate.p, (const uint32_t *)c->pair_slot.p,
              (const uint32_t *)c->pair_winner.p, c->flag.p);
-  uint32_t e[4];
-  ELP_TRY(fetch_err(c, e));
-  if (e[1]) {
-    ELP_HIP(c, hipMemsetAsync(c->err_flag.p + 1, 0, 4, st));
-    return set_error(c, ELP_ERR_UNSUPPORTED, "more than two primary mapped records share one {library, QNAME}: mate pairing by arrival order is not implemented");
-  }
   c->marked = true;
   return 0;
 }

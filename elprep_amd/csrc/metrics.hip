@@ -7,7 +7,12 @@
 // For every pair group the "origin" is the best pair; each losing (duplicate) pair contributes its First-flag read.  Origin and
 // duplicates are split by the strand of the listed read; the optical count of a list is  n - #connected components  under the
 // relation {same RG, same tile != -1, |dx| <= d, |dy| <= d}, which is what both the n <= 3 special cases and the union-find of
-// the reference compute.  Lists longer than 300000 (the reference's cap, :289-299) are rejected as unsupported.
+// the reference compute.  The reference caps each strand list at 300001 entries and counts 0 optical duplicates for a list longer
+// than 300000 (:289-299, :328-330); the same is done here.  Records with the sr tag never reach MarkOpticalDuplicates
+// (RemoveOptionalReads, cmd/filter.go:803): they are not counted, and a duplicate pair with a tagged read is never listed.
+// Sets of up to OPT_SMALL listed reads are evaluated by one thread each; larger ones cooperatively: their members are sorted by a hash
+// of (set, RG, strand, tile), every member compares itself with the members behind it in its bucket (the all-pairs test of
+// fillGraphFromAGroup, :232-243, per (RG, tile) bucket) and joins them in a lock-free union-find; optical = members - components.
 #include "common.hpp"
 
 namespace elp {
@@ -25,7 +30,12 @@ struct MxCols {
   const uint8_t *qname;
   const uint32_t *mate, *prep, *pwinner;
   int32_t n_lib;
+  const uint8_t *has_sr;
+  const uint16_t *split;
+  int32_t n_split;  // 1 + largest staged split id
 };
+constexpr uint32_t OPT_SMALL = 32;        // sets up to this size: one thread, all pairs
+constexpr uint32_t OPT_LIST_CAP = 300000; // :289-299
 
 __device__ __forceinline__ uint32_t lib_row(const MxCols &m, uint32_t i) {
   const uint16_t rg = m.rgid[i];
@@ -49,30 +59,36 @@ __device__ __forceinline__ uint32_t listed_read(const MxCols &m, uint32_t owner)
 }
 
 // :473-502 — one pass over all records (order does not matter for sums)
-__global__ __launch_bounds__(256) void k_dup_counters(MxCols m, unsigned long long *__restrict__ ctr) {
-  extern __shared__ unsigned int lds_ctr[];  // [(n_lib+1)*7]
-  const int ncell = (m.n_lib + 1) * ELP_NCTR;
+// ReadPairsExamined counts reads and is halved at the end of a filter run (:504-506), i.e. once per split file: the reads of
+// true pairs are counted per (split, library) in pair_reads[n_split][n_lib + 1] and halved by the host, split by split.
+__global__ __launch_bounds__(256) void k_dup_counters(MxCols m, unsigned long long *__restrict__ ctr, unsigned long long *__restrict__ pair_reads) {
+  extern __shared__ unsigned int lds_ctr[];  // [(n_lib+1)*7], then [n_split][n_lib+1]
+  const int nrow = (m.n_lib + 1) * ELP_NCTR, ncell = nrow + m.n_split * (m.n_lib + 1);
   for (int k = threadIdx.x; k < ncell; k += blockDim.x) lds_ctr[k] = 0;
   __syncthreads();
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m.n; i += (uint64_t)gridDim.x * blockDim.x) {
+    if (m.has_sr[i]) continue;  // dropped by RemoveOptionalReads before the metrics pass
     const uint16_t f = m.flag[i];
     unsigned int *row = lds_ctr + lib_row(m, (uint32_t)i) * ELP_NCTR;
     if (f & F_UNMAPPED) { atomicAdd(&row[3], 1u); continue; }
     if (f & (F_SECONDARY | F_SUPPLEMENTARY)) { atomicAdd(&row[2], 1u); continue; }
     const bool tp = true_pair(f);
-    atomicAdd(&row[tp ? 1 : 0], 1u);
+    if (tp) atomicAdd(&lds_ctr[nrow + (int)m.split[i] * (m.n_lib + 1) + (int)lib_row(m, (uint32_t)i)], 1u);
+    else atomicAdd(&row[0], 1u);
     if (f & F_DUPLICATE) {
       if (!tp) atomicAdd(&row[4], 1u);
       else {
         const uint32_t mt = m.mate[i];
         // counted once per pair, when the second of two duplicate-flagged mates is met (:186-192)
-        if (mt != EMPTY && mt < (uint32_t)i && (m.flag[mt] & F_DUPLICATE)) atomicAdd(&row[5], 1u);
+        if (mt != EMPTY && mt < (uint32_t)i && (m.flag[mt] & F_DUPLICATE) && !m.has_sr[mt]) atomicAdd(&row[5], 1u);
       }
     }
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < ncell; k += blockDim.x)
+  for (int k = threadIdx.x; k < nrow; k += blockDim.x)
     if (lds_ctr[k]) atomicAdd(&ctr[k], (unsigned long long)lds_ctr[k]);
+  for (int k = threadIdx.x + nrow; k < ncell; k += blockDim.x)
+    if (lds_ctr[k]) atomicAdd(&pair_reads[k - nrow], (unsigned long long)lds_ctr[k]);
 }
 
 // losing pairs per group
@@ -81,6 +97,7 @@ __global__ __launch_bounds__(256) void k_opt_count(MxCols m, uint32_t *gsize) {
   if (i >= m.n) return;
   const uint32_t rep = m.prep[i];
   if (rep == EMPTY || m.pwinner[rep] == (uint32_t)i) return;
+  if (m.has_sr[i] || m.has_sr[m.mate[i]]) return;  // the pass over the reads never completes this pair (:186-190)
   atomicAdd(&gsize[rep], 1u);
 }
 __global__ __launch_bounds__(256) void k_opt_plus_origin(uint64_t n, uint32_t *gsize) {
@@ -146,16 +163,18 @@ __device__ inline Member make_member(const MxCols &m, uint32_t read, uint32_t *e
 // Members of the duplicate sets are laid out group by group (goff); this pass (one thread per record, most exit at once) only
 // decides the slot of each member and notes which read is listed there; the origin's slot also gets {set size, group id}.
 __global__ __launch_bounds__(256) void k_opt_slots(MxCols m, const uint32_t *__restrict__ goff, uint32_t *gfill, uint32_t *__restrict__ mread,
-                                                   uint2 *__restrict__ ginfo) {
+                                                   uint2 *__restrict__ ginfo, uint32_t *__restrict__ mset) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m.n) return;
   const uint32_t rep = m.prep[i];
   if (rep == EMPTY) return;
   const bool is_origin = m.pwinner[rep] == (uint32_t)i;
+  if (!is_origin && (m.has_sr[i] || m.has_sr[m.mate[i]])) return;
   const uint32_t g0 = goff[rep], g1 = goff[rep + 1];
   if (is_origin && g1 == g0) return;  // group without duplicates: count is 0
   const uint32_t slot = g0 + (is_origin ? 0u : 1u + atomicAdd(&gfill[rep], 1u));
   mread[slot] = listed_read(m, (uint32_t)i);
+  mset[slot] = g0;  // the set a member belongs to = the slot of its origin
   if (is_origin) ginfo[slot] = make_uint2(g1 - g0, rep);
 }
 // dense pass over the member slots: tile / x / y from the QNAME (every lane busy, unlike a pass over all records)
@@ -187,7 +206,8 @@ __device__ __forceinline__ bool optical_close(const Member &a, const Member &b, 
 // bins of every histogram are collected in LDS like the optical counts
 __global__ __launch_bounds__(128) void k_opt_eval(MxCols m, uint32_t total, const uint2 *__restrict__ ginfo, const Member *__restrict__ members,
                                                   uint32_t *__restrict__ parent, long long dist, unsigned long long *__restrict__ ctr,
-                                                  uint32_t *err, unsigned long long *__restrict__ hist, int hist_len, int lds_bins) {
+                                                  uint32_t *err, unsigned long long *__restrict__ hist, int hist_len, int lds_bins,
+                                                  uint32_t *__restrict__ linfo, uint32_t *__restrict__ lcount, uint32_t *n_large) {
   // per-library optical counts are collected in LDS first: the global counters are a handful of addresses, and a global atomic
   // on one address serialises at ~12 ns
   extern __shared__ unsigned int lds_opt[];  // [n_lib + 1], then [(n_lib + 1)][3][lds_bins]
@@ -199,8 +219,18 @@ __global__ __launch_bounds__(128) void k_opt_eval(MxCols m, uint32_t total, cons
   const uint2 gi = b < total ? ginfo[b] : make_uint2(0u, 0u);
   const uint32_t cnt = gi.x;
   uint32_t optical = 0;
-  if (cnt > 300000u) {
-    atomicOr(&err[2], 2u);
+  bool large = false;
+  if (cnt > OPT_SMALL) {
+    // left to the cooperative kernels: note which strand lists are over the reference's cap (they count 0 and are cut to 300001
+    // entries in the set-size histograms) and the capped size of the set
+    const Member *g = members + b;
+    uint32_t nr = 0;
+    for (uint32_t k = 0; k < cnt; k++) nr += g[k].rg_rev & 1u;
+    const uint32_t nf = cnt - nr;
+    linfo[b] = 1u | (nf > OPT_LIST_CAP ? 2u : 0u) | (nr > OPT_LIST_CAP ? 4u : 0u);
+    lcount[b] = (nf > OPT_LIST_CAP ? OPT_LIST_CAP + 1 : nf) + (nr > OPT_LIST_CAP ? OPT_LIST_CAP + 1 : nr);
+    atomicAdd(n_large, cnt);
+    large = true;
   } else if (cnt >= 2) {
   const Member *g = members + b;
   if (cnt == 2) {
@@ -227,13 +257,13 @@ __global__ __launch_bounds__(128) void k_opt_eval(MxCols m, uint32_t total, cons
     optical = cnt - comps;  // sum over both strand lists of (n - components): lists never connect (rg_rev differs)
   }
   }
-  if (optical || (hist && cnt >= 2 && cnt <= 300000u)) {
+  if (!large && (optical || (hist && cnt >= 2))) {
     const uint32_t owner = m.pwinner[gi.y];
     uint32_t a1, a2;
     order_ends(m, owner, m.mate[owner], a1, a2);
     const uint32_t lib = lib_row(m, a1);  // origin.aln1.LIBID() :381
     if (optical) atomicAdd(&lds_opt[lib], optical);
-    if (hist && cnt >= 2 && cnt <= 300000u) {
+    if (hist && cnt >= 2) {
       const int idx[3] = {(int)cnt, (int)(cnt - optical), optical ? (int)optical + 1 : 0};  // cnt - optical >= 1: a set has a component
 #pragma unroll
       for (int k = 0; k < 3; k++) {
@@ -249,6 +279,88 @@ __global__ __launch_bounds__(128) void k_opt_eval(MxCols m, uint32_t total, cons
     if (lds_opt[k]) atomicAdd(&ctr[k * ELP_NCTR + 6], (unsigned long long)lds_opt[k]);
   for (int k = threadIdx.x; k < n_h; k += blockDim.x)
     if (lds_h[k]) atomicAdd(&hist[(size_t)(k / lds_bins) * hist_len + (k % lds_bins)], (unsigned long long)lds_h[k]);
+}
+
+// ---- large sets (more than OPT_SMALL listed reads)
+// members that can have an optical partner at all (tile parsed, strand list not over the cap) -> (bucket hash, member slot)
+__global__ __launch_bounds__(256) void k_large_list(uint32_t total, const uint32_t *__restrict__ mset, const uint32_t *__restrict__ linfo,
+                                                    const Member *__restrict__ members, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                    uint32_t *count) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= total) return;
+  const uint32_t b = mset[s], li = linfo[b];
+  if (!(li & 1u)) return;
+  const Member mem = members[s];
+  if (mem.t == -1 || (li & ((mem.rg_rev & 1u) ? 4u : 2u))) return;
+  const uint32_t at = atomicAdd(count, 1u);
+  keys[at] = mix64(mix64(((uint64_t)b << 32) | mem.rg_rev) ^ (uint64_t)mem.t);
+  vals[at] = s;
+}
+__device__ __forceinline__ uint32_t puf_find(uint32_t *parent, uint32_t x) {
+  for (;;) {
+    const uint32_t p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (p == x) return x;
+    x = p;
+  }
+}
+// roots only ever get a smaller parent, so there are no cycles and every chain ends
+__device__ inline void puf_union(uint32_t *parent, uint32_t a, uint32_t b) {
+  for (;;) {
+    a = puf_find(parent, a);
+    b = puf_find(parent, b);
+    if (a == b) return;
+    const uint32_t hi = a > b ? a : b, lo = a > b ? b : a;
+    if (atomicCAS(&parent[hi], hi, lo) == hi) return;
+  }
+}
+// sorted by bucket hash: member j looks at the members behind it with the same hash (same bucket, or a colliding one: the exact
+// test is repeated) and joins the ones that are optical duplicates of it
+__global__ __launch_bounds__(256) void k_large_union(uint32_t cnt, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                     const uint32_t *__restrict__ mset, const Member *__restrict__ members, long long dist,
+                                                     uint32_t *parent) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= cnt) return;
+  const uint64_t kj = keys[j];
+  const uint32_t sj = vals[j], bj = mset[sj];
+  const Member mj = members[sj];
+  for (uint32_t k = j + 1; k < cnt && keys[k] == kj; k++) {
+    const uint32_t sk = vals[k];
+    if (mset[sk] == bj && optical_close(mj, members[sk], dist)) puf_union(parent, j, k);
+  }
+}
+// per set: members listed (low word) and roots among them (high word)
+__global__ __launch_bounds__(256) void k_large_roots(uint32_t cnt, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ mset,
+                                                     const uint32_t *__restrict__ parent, unsigned long long *setcnt) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= cnt) return;
+  atomicAdd(&setcnt[mset[vals[j]]], 1ull | (parent[j] == j ? (1ull << 32) : 0ull));
+}
+// one thread per member slot; origins of large sets account for their set
+__global__ __launch_bounds__(256) void k_large_final(MxCols m, uint32_t total, const uint2 *__restrict__ ginfo, const uint32_t *__restrict__ linfo,
+                                                     const uint32_t *__restrict__ lcount, const unsigned long long *__restrict__ setcnt,
+                                                     unsigned long long *__restrict__ ctr, unsigned long long *__restrict__ hist, int hist_len) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= total || !(linfo[b] & 1u) || ginfo[b].x == 0) return;
+  const unsigned long long sc = setcnt[b];
+  const uint32_t optical = (uint32_t)sc - (uint32_t)(sc >> 32);
+  const uint32_t owner = m.pwinner[ginfo[b].y];
+  uint32_t a1, a2;
+  order_ends(m, owner, m.mate[owner], a1, a2);
+  const uint32_t lib = lib_row(m, a1);
+  if (optical) atomicAdd(&ctr[lib * ELP_NCTR + 6], (unsigned long long)optical);
+  if (hist) {
+    const uint32_t cnt = lcount[b];
+    const int idx[3] = {(int)cnt, (int)(cnt - optical), optical ? (int)optical + 1 : 0};
+    for (int k = 0; k < 3; k++) {
+      if (idx[k] <= 0) continue;
+      const int bin = idx[k] < hist_len ? idx[k] : hist_len - 1;
+      atomicAdd(&hist[((size_t)lib * 3 + k) * hist_len + bin], 1ull);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_iota32(uint32_t *v, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = i;
 }
 
 // number of pair groups (= origins, the pairs that stayed best of their group) per library
@@ -274,17 +386,22 @@ static int metrics_impl(elp_ctx *c, int dist, int64_t *counters_host, int64_t *h
   if (!c->marked) return set_error(c, ELP_ERR_ARG, "elp_dup_metrics: call elp_mark_duplicates first");
   // device block: the counters, then (if asked for) the origins per library and the three histograms per library
   const size_t nhist = hist_host ? (size_t)(c->n_lib + 1) * 3 * (size_t)hist_len : 0, norg = hist_host ? (size_t)(c->n_lib + 1) : 0;
+  const int n_split = (int)c->max_split + 1;
+  const size_t npr = (size_t)n_split * (size_t)(c->n_lib + 1);
+  if (((size_t)ncell + npr) * sizeof(unsigned int) > 60000)
+    return set_error(c, ELP_ERR_UNSUPPORTED, "elp_dup_metrics: %d split ids x %d libraries in one context", n_split, c->n_lib + 1);
   unsigned long long *ctr;
-  ELP_TRY(scratch(c, 0, (size_t)ncell + norg + nhist + 8, &ctr));
-  unsigned long long *origins = ctr + ncell, *hist = hist_host ? origins + norg : nullptr;
+  ELP_TRY(scratch(c, 0, (size_t)ncell + norg + nhist + npr + 8, &ctr));
+  unsigned long long *origins = ctr + ncell, *hist = hist_host ? origins + norg : nullptr, *pair_reads = ctr + ncell + norg + nhist;
   hipStream_t st = c->stream;
-  ELP_HIP(c, hipMemsetAsync(ctr, 0, ((size_t)ncell + norg + nhist) * sizeof(unsigned long long), st));
+  ELP_HIP(c, hipMemsetAsync(ctr, 0, ((size_t)ncell + norg + nhist + npr) * sizeof(unsigned long long), st));
   int lds_bins = hist_host ? std::min(hist_len, 32) : 0;
   if ((size_t)(c->n_lib + 1) * (1 + 3 * (size_t)lds_bins) * sizeof(unsigned int) > 32768) lds_bins = 0;
   if (n) {
-    MxCols m{n, c->refid.p, c->flag.p, c->rgid.p, c->rg_lib.p, c->upos.p, c->qname_off.p, c->qname.p, c->mate.p, c->pair_slot.p, c->pair_winner.p, c->n_lib};
+    MxCols m{n, c->refid.p, c->flag.p, c->rgid.p, c->rg_lib.p, c->upos.p, c->qname_off.p, c->qname.p, c->mate.p, c->pair_slot.p, c->pair_winner.p, c->n_lib,
+             c->has_sr.p, c->split.p, n_split};
     const unsigned grid = blocks_for(n, 256);
-    ELP_LAUNCH(c, "mx_counters", k_dup_counters, dim3(std::min(grid, 2048u)), dim3(256), ncell * sizeof(unsigned int), m, ctr);
+    ELP_LAUNCH(c, "mx_counters", k_dup_counters, dim3(std::min(grid, 2048u)), dim3(256), ((size_t)ncell + npr) * sizeof(unsigned int), m, ctr, pair_reads);
     uint32_t *gs;
     ELP_TRY(scratch(c, 1, 3 * n + 16, &gs));
     uint32_t *gsize = gs, *goff = gs + n + 1, *gfill = gs + 2 * n + 2;
@@ -296,34 +413,68 @@ static int metrics_impl(elp_ctx *c, int dist, int64_t *counters_host, int64_t *h
     ELP_TRY(exclusive_scan_u32(c, gsize, goff, n + 1, &total));  // goff[n] = total
     if (total) {
       Member *members;
-      uint32_t *parent, *mread;
+      uint32_t *wk, *mread;
       uint2 *ginfo;
+      const size_t tp = ((size_t)total + 7) & ~(size_t)7;
       ELP_TRY(scratch(c, 2, (size_t)total + 4, &members));
-      ELP_TRY(scratch(c, 3, (size_t)total + 4, &parent));
+      ELP_TRY(scratch(c, 3, 12 * tp + 16, &wk));  // parent | mset | linfo | lcount | setcnt (u64) | vals x 2 | keys (u64) x 2
       ELP_TRY(scratch(c, 4, (size_t)total + 4, &mread));
       ELP_TRY(scratch(c, 5, (size_t)total + 4, &ginfo));
+      uint32_t *parent = wk, *mset = wk + tp, *linfo = wk + 2 * tp, *lcount = wk + 3 * tp, *lvals = wk + 6 * tp;
+      unsigned long long *setcnt = reinterpret_cast<unsigned long long *>(wk + 4 * tp);
+      uint64_t *lkeys = reinterpret_cast<uint64_t *>(wk + 8 * tp);
+      uint32_t *mailbox = c->err_flag.p + 3;  // the scan-total word: members of large sets, then the length of their candidate list
       ELP_HIP(c, hipMemsetAsync(ginfo, 0, (size_t)total * sizeof(uint2), st));
-      ELP_LAUNCH(c, "mx_opt_slots", k_opt_slots, dim3(grid), dim3(256), 0, m, (const uint32_t *)goff, gfill, mread, ginfo);
+      ELP_HIP(c, hipMemsetAsync(linfo, 0, 4 * tp * sizeof(uint32_t), st));  // linfo, lcount, setcnt
+      ELP_LAUNCH(c, "mx_opt_slots", k_opt_slots, dim3(grid), dim3(256), 0, m, (const uint32_t *)goff, gfill, mread, ginfo, mset);
       ELP_LAUNCH(c, "mx_opt_fill", k_opt_fill, dim3(blocks_for(total, 256)), dim3(256), 0, m, total, (const uint32_t *)mread, members, c->err_flag.p);
       ELP_LAUNCH(c, "mx_opt_eval", k_opt_eval, dim3(blocks_for(total, 128)), dim3(128),
                  (size_t)(c->n_lib + 1) * (1 + (hist ? 3 * (size_t)lds_bins : 0)) * sizeof(unsigned int), m, total, (const uint2 *)ginfo,
-                 (const Member *)members, parent, (long long)dist, ctr, c->err_flag.p, hist, hist_len, lds_bins);
+                 (const Member *)members, parent, (long long)dist, ctr, c->err_flag.p, hist, hist_len, lds_bins, linfo, lcount, mailbox);
+      uint32_t n_large = 0;
+      ELP_HIP(c, hipMemcpyAsync(&n_large, mailbox, 4, hipMemcpyDeviceToHost, st));
+      ELP_HIP(c, hipStreamSynchronize(st));
+      ELP_HIP(c, hipMemsetAsync(mailbox, 0, 4, st));
+      if (n_large) {
+        ELP_LAUNCH(c, "mx_large_list", k_large_list, dim3(blocks_for(total, 256)), dim3(256), 0, total, (const uint32_t *)mset, (const uint32_t *)linfo,
+                   (const Member *)members, lkeys, lvals, mailbox);
+        uint32_t cl = 0;
+        ELP_HIP(c, hipMemcpyAsync(&cl, mailbox, 4, hipMemcpyDeviceToHost, st));
+        ELP_HIP(c, hipStreamSynchronize(st));
+        ELP_HIP(c, hipMemsetAsync(mailbox, 0, 4, st));
+        if (cl) {
+          uint64_t *ks;
+          uint32_t *vs;
+          ELP_TRY(radix_sort_pairs(c, lkeys, lvals, lkeys + tp, lvals + tp, cl, &ks, &vs));
+          ELP_LAUNCH(c, "mx_large_iota", k_iota32, dim3(blocks_for(cl, 256)), dim3(256), 0, parent, cl);
+          ELP_LAUNCH(c, "mx_large_union", k_large_union, dim3(blocks_for(cl, 256)), dim3(256), 0, cl, (const uint64_t *)ks, (const uint32_t *)vs,
+                     (const uint32_t *)mset, (const Member *)members, (long long)dist, parent);
+          ELP_LAUNCH(c, "mx_large_roots", k_large_roots, dim3(blocks_for(cl, 256)), dim3(256), 0, cl, (const uint32_t *)vs, (const uint32_t *)mset,
+                     (const uint32_t *)parent, setcnt);
+        }
+        ELP_LAUNCH(c, "mx_large_final", k_large_final, dim3(blocks_for(total, 256)), dim3(256), 0, m, total, (const uint2 *)ginfo, (const uint32_t *)linfo,
+                   (const uint32_t *)lcount, (const unsigned long long *)setcnt, ctr, hist, hist_len);
+      }
     }
     if (hist)
       ELP_LAUNCH(c, "mx_origin_count", k_origin_count, dim3(std::min(grid, 2048u)), dim3(256), (c->n_lib + 1) * sizeof(unsigned int), m, origins);
   }
-  std::vector<unsigned long long> h((size_t)ncell + norg + nhist);
+  std::vector<unsigned long long> h((size_t)ncell + norg + nhist + npr);
   ELP_HIP(c, hipMemcpyAsync(h.data(), ctr, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   uint32_t e[4];
   ELP_TRY(fetch_err(c, e));
   if (e[2]) {
     ELP_HIP(c, hipMemsetAsync(c->err_flag.p + 2, 0, 4, st));
-    if (e[2] & 1u) return set_error(c, ELP_ERR_DATA, "QNAME tile/x/y field is not an integer (reference: internal.ParseInt panics, filters/mark-optical-duplicates.go:55-61)");
-    return set_error(c, ELP_ERR_UNSUPPORTED, "a duplicate set exceeds 300000 pairs (the reference truncates such lists, filters/mark-optical-duplicates.go:289-299)");
+    return set_error(c, ELP_ERR_DATA, "QNAME tile/x/y field is not an integer (reference: internal.ParseInt panics, filters/mark-optical-duplicates.go:55-61)");
   }
   for (int l = 0; l <= c->n_lib; l++)
     for (int k = 0; k < ELP_NCTR; k++) counters_host[l * ELP_NCTR + k] = (int64_t)h[l * ELP_NCTR + k];
-  for (int l = 0; l <= c->n_lib; l++) counters_host[l * ELP_NCTR + 1] /= 2;  // ReadPairsExamined counts reads, then halves (:504-506)
+  // ReadPairsExamined counts reads, then halves (:504-506) - per filter run, i.e. per split file
+  for (int l = 0; l <= c->n_lib; l++) {
+    int64_t pairs = 0;
+    for (int sp = 0; sp < n_split; sp++) pairs += (int64_t)(h[(size_t)ncell + norg + nhist + (size_t)sp * (c->n_lib + 1) + l] / 2);
+    counters_host[l * ELP_NCTR + 1] = pairs;
+  }
   if (hist_host) {
     // the device counted the sets that have duplicates; an origin without duplicates is a set of one read, none of them optical
     const unsigned long long *ho = h.data() + ncell, *hh = ho + norg;

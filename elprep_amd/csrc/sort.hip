@@ -23,7 +23,8 @@ constexpr int TIE_SMALL = 48;
 __global__ __launch_bounds__(256) void k_adapt_fixed(uint64_t n, const int32_t *__restrict__ pos, const int32_t *__restrict__ refid,
                                                      const uint16_t *__restrict__ flag, const uint64_t *__restrict__ cigar_off,
                                                      const uint32_t *__restrict__ cigar, int32_t *__restrict__ upos, int32_t *__restrict__ score,
-                                                     uint64_t *__restrict__ key, uint32_t n_ref, int pos_bits) {
+                                                     uint64_t *__restrict__ key, uint32_t n_ref, int pos_bits,
+                                                     const uint8_t *__restrict__ has_sr) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint16_t f = flag[i];
@@ -32,7 +33,9 @@ __global__ __launch_bounds__(256) void k_adapt_fixed(uint64_t n, const int32_t *
   // CoordinateLess primary key: REFID ascending with negative last (:429-432), POS (:433-436), forward before reverse (:437-438)
   // The key is packed into as few bits as the data needs (unmapped = one code above the last contig; POS in pos_bits bits, the
   // width of the largest staged POS), so that the LSD radix sort has as few live digit positions as possible.
-  const uint64_t ru = r < 0 ? (uint64_t)n_ref : (uint64_t)(uint32_t)r;
+  // Records with the sr tag are dropped behind the mark-duplicates filter (RemoveOptionalReads, cmd/filter.go:803) and never reach
+  // the sort: they get one more code above "unmapped", i.e. the tail of the permutation (elp_num_sorted()).
+  const uint64_t ru = has_sr[i] ? (uint64_t)n_ref + 1 : (r < 0 ? (uint64_t)n_ref : (uint64_t)(uint32_t)r);
   key[i] = (ru << (pos_bits + 1)) | ((uint64_t)(uint32_t)p << 1) | ((f & F_REVERSED) ? 1ull : 0ull);
   int32_t up = 0;
   if ((f & (F_UNMAPPED | F_SECONDARY | F_SUPPLEMENTARY)) == 0) {  // mark-duplicates.go:427,436
@@ -231,7 +234,7 @@ int ensure_adapted(elp_ctx *c, bool check_quals) {
     if (!c->qual_bytes) ELP_HIP(c, hipMemsetAsync(c->qbounds.p, 0, n * sizeof(uint64_t), c->stream));  // no QUAL bytes at all: no tile, no kernel
     ELP_LAUNCH(c, "adapt_fixed", k_adapt_fixed, dim3(blocks_for(n, 256)), dim3(256), 0, n, (const int32_t *)c->pos.p, (const int32_t *)c->refid.p,
                (const uint16_t *)c->flag.p, (const uint64_t *)c->cigar_off.p, (const uint32_t *)c->cigar.p, c->upos.p, c->score.p, c->key.p,
-               (uint32_t)c->n_ref, pos_bits);
+               (uint32_t)c->n_ref, pos_bits, (const uint8_t *)c->has_sr.p);
     if (c->qual_bytes) {
       const unsigned grid = (unsigned)std::min<uint64_t>(flat_steps<ScoreBody>(c->qual_bytes), (uint64_t)c->n_cu * 4);
       ELP_LAUNCH(c, "adapt_score", k_score_flat, dim3(grid), dim3(FL_THREADS), 0, n, (const uint64_t *)c->qual_off.p, (const uint8_t *)c->qual.p,
@@ -390,8 +393,8 @@ __device__ inline uint32_t material_byte(const TieCols &t, uint32_t r, uint32_t 
 // QNAME bytes are compared eight at a time (zero-padded behind the name's end, as material_byte pads them).
 __global__ __launch_bounds__(256) void k_material_live(uint32_t nu, const uint32_t *__restrict__ u_read, uint32_t maxq, uint32_t nbytes,
                                                        uint32_t *live, TieCols t) {
-  __shared__ uint32_t acc[16];
-  if (threadIdx.x < 16) acc[threadIdx.x] = 0;
+  __shared__ uint32_t acc[elp_ctx::TIE_LIVE_WORDS];
+  if (threadIdx.x < elp_ctx::TIE_LIVE_WORDS) acc[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m < nu) {
@@ -414,7 +417,7 @@ __global__ __launch_bounds__(256) void k_material_live(uint32_t nu, const uint32
       if (material_byte(t, r, j, maxq) != material_byte(t, r0, j, maxq)) atomicOr(&acc[j >> 5], 1u << (j & 31));
   }
   __syncthreads();
-  if (threadIdx.x < 16 && acc[threadIdx.x]) atomicOr(&live[threadIdx.x], acc[threadIdx.x]);
+  if (threadIdx.x < elp_ctx::TIE_LIVE_WORDS && acc[threadIdx.x]) atomicOr(&live[threadIdx.x], acc[threadIdx.x]);
 }
 
 // key of a member = the bytes of its comparator string at the (up to eight) positions pos[0] < pos[1] < ..., most significant first
@@ -484,14 +487,15 @@ static int sort_impl(elp_ctx *c) {
     ELP_LAUNCH(c, "add_own", k_add_own, dim3(blocks_for(nu, 256)), dim3(256), 0, nu, (const uint32_t *)u_head, u_seg);
     ELP_LAUNCH(c, "iota", k_iota, dim3(blocks_for(nu, 256)), dim3(256), 0, uv0, (uint64_t)nu);
     const uint32_t maxq = c->max_qname_len;
-    const uint32_t m_bytes = maxq + 15;  // <= 270 positions
+    const uint32_t m_bytes = maxq + 15;  // <= MAX_QNAME + 15 <= 32 * TIE_LIVE_WORDS positions (elp_stage enforces the QNAME limit)
     // which positions of the comparator string differ at all among the members: one kernel, one read-back; the LSD rounds then
     // take eight live positions each and run every pass (no histogram read-back per round, no rounds over constant bytes)
-    ELP_TRY(ensure(c, c->tie_live, 16));
-    ELP_HIP(c, hipMemsetAsync(c->tie_live.p, 0, 16 * sizeof(uint32_t), c->stream));
+    static_assert(elp_ctx::MAX_QNAME + 15 <= 32 * elp_ctx::TIE_LIVE_WORDS, "live-position bitmap too small");
+    ELP_TRY(ensure(c, c->tie_live, elp_ctx::TIE_LIVE_WORDS));
+    ELP_HIP(c, hipMemsetAsync(c->tie_live.p, 0, elp_ctx::TIE_LIVE_WORDS * sizeof(uint32_t), c->stream));
     ELP_LAUNCH(c, "material_live", k_material_live, dim3(blocks_for(nu, 256)), dim3(256), 0, nu, (const uint32_t *)u_read, maxq, m_bytes,
                c->tie_live.p, t);
-    uint32_t live[16];
+    uint32_t live[elp_ctx::TIE_LIVE_WORDS];
     ELP_HIP(c, hipMemcpyAsync(live, c->tie_live.p, sizeof live, hipMemcpyDeviceToHost, c->stream));
     ELP_HIP(c, hipStreamSynchronize(c->stream));
     std::vector<uint16_t> lp;
@@ -520,6 +524,13 @@ static int sort_impl(elp_ctx *c) {
     }
     ELP_LAUNCH(c, "large_scatter", k_large_scatter, dim3(blocks_for(nu, 256)), dim3(256), 0, nu, (const uint32_t *)vcur, (const uint32_t *)u_pos,
                (const uint32_t *)u_read, c->perm.p);
+  }
+  // a look-back that timed out (radix.hip) leaves a wrong permutation: report it here, behind the last pass, and clear the bit
+  uint32_t e[4];
+  ELP_TRY(fetch_err(c, e));
+  if (e[0] & 256u) {
+    ELP_HIP(c, hipMemsetAsync(c->err_flag.p, 0, 4, c->stream));
+    return set_error(c, ELP_ERR_HIP, "radix sort: tile look-back timed out");
   }
   c->sorted = true;
   return 0;

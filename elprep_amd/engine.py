@@ -66,6 +66,11 @@ class Engine:
     def n(self) -> int:
         return int(self.L.elp_num_records(self.h))
 
+    @property
+    def n_sorted(self) -> int:
+        """records that survive RemoveOptionalReads (no sr tag): the first n_sorted entries of the permutation are the output"""
+        return int(self.L.elp_num_sorted(self.h))
+
     def reserve(self, n, qname_bytes, cigar_ops, seq_bytes, qual_bytes):
         self._check(self.L.elp_reserve(self.h, n, qname_bytes, cigar_ops, seq_bytes, qual_bytes))
 

@@ -10,8 +10,10 @@ Host-side mirror (Python, as the rest of the harness; the reference's is Go) of
 Splits are numbered 0 = "unmapped" (RNAME '*'), 1..G = contig groups in @SQ order, G+1 = "spread" (reads whose mate maps
 to another group; they are ALSO kept, tagged sr:i:1, in their own group split, where they only knock out fragments and are
 ignored by BQSR).  A split is processed by exactly one rank, as the reference processes a split file by one `filter`
-process; group splits owned by the same rank share one GPU context (their duplicate-marking keys cannot collide: every
-key carries a refid), the spread split always gets its own context (it repeats the QNAMEs of the tagged copies).
+process; group splits owned by the same rank share one GPU context: every record carries the id of its split file
+(elp_batch.split), which is part of every duplicate-marking key, so fragments, mates and pairs of different splits never meet
+(two tagged copies of a spread pair whose groups land on one rank would otherwise pair up there).  The spread split always
+gets its own context: it is coordinate-sorted by itself and merged into the groups' output afterwards.
 
 The only data-path collectives are (1) the routing of the few records (spread mates, supplementary alignments, unmapped
 pairs: ~3 %) that a rank produced for a split it does not own — point-to-point sends of packed batches — and (2) ONE
@@ -111,10 +113,14 @@ def empty_batch() -> Batch:
     return Batch(**cols)
 
 
-def with_sr(b: Batch, sr: np.ndarray) -> Batch:
-    """copy of b whose has_sr column is OR-ed with `sr` (aln.TAGS.Set(sr, 1), sam/split-merge.go:291)"""
+def with_sr(b: Batch, sr: np.ndarray, split: Optional[np.ndarray] = None) -> Batch:
+    """copy of b whose has_sr column is OR-ed with `sr` (aln.TAGS.Set(sr, 1), sam/split-merge.go:291); `split` (optional) becomes the
+    split-id column: the split file of every record, which keeps the duplicate-marking keys of the splits that share a GPU context
+    apart (the reference runs one `filter` process per split file)"""
     cols = {name: getattr(b, name) for name, _ in _COLS}
     cols["has_sr"] = (b.has_sr | sr.astype(np.uint8)).astype(np.uint8)
+    if split is not None:
+        cols["split"] = split.astype(np.uint16)
     return Batch(**cols)
 
 
@@ -177,7 +183,7 @@ class RankSplits:
 def route(b: Batch, group_of_ref: np.ndarray, n_groups: int, owner: np.ndarray, comm: Comm) -> RankSplits:
     """Send every record this rank holds to the owner of its split(s) and collect what this rank owns."""
     g, spread = split_records(b, group_of_ref)
-    tagged = with_sr(b, spread)
+    tagged = with_sr(b, spread, g)
     spread_owner = int(owner[n_groups + 1])
     dest = owner[g]
     out_local, out_spread = [], []
@@ -221,7 +227,7 @@ def sorted_output(b: Batch, perm: np.ndarray, flags: np.ndarray, qual: np.ndarra
     """The records of a split as the output phase writes them: coordinate order (the device's permutation), duplicate flags and
     recalibrated qualities in place of the staged ones.  Payload permutation is host work (it sits next to the BAM encoder)."""
     out = Batch(**{f: getattr(b, f) for f in ("refid", "pos", "next_refid", "pnext", "tlen", "mapq", "rgid", "has_sr", "l_seq", "qname_off", "qname",
-                                                  "cigar_off", "cigar", "seq_off", "seq4", "qual_off")},
+                                                  "cigar_off", "cigar", "seq_off", "seq4", "qual_off", "split")},
                 flag=np.asarray(flags, dtype=b.flag.dtype), qual=np.asarray(qual, dtype=b.qual.dtype))
     return out.take(perm)
 

@@ -16,6 +16,11 @@
  *    threads (it serialises internally; it mirrors the reference's LimitedPar batch nodes,
  *    sam/filter-pipeline.go:290-292).
  *  - Records are identified by their staging index (order of arrival = input order), 0-based.
+ *  - Records that carry the sr:i tag (has_sr; the copies `elprep split` leaves in a contig-group file, sam/split-merge.go:286-293)
+ *    take part in duplicate marking and are then dropped by filters.RemoveOptionalReads (filters/simple-filters.go:146-152, appended
+ *    behind the mark-duplicates filter, cmd/filter.go:773,803): they never reach Sam.Alignments.  Here they stay staged, but the sort
+ *    puts them behind every other record (elp_num_sorted() records are output), and the duplication metrics and BQSR ignore them.
+ *  - Limits (ELP_ERR_UNSUPPORTED): 2^32-16 records per context, 4194303 bases per read, QNAMEs of at most 1000 bytes.
  *  - There is NO CPU fallback: if no gfx950 device is usable, elp_create fails.
  */
 #ifndef ELPREP_HIP_H
@@ -66,6 +71,10 @@ typedef struct elp_batch {
   const uint8_t *seq4;        /* BAM 4-bit bases, high nibble first, "=ACMGRSVTWYHKDBN" (utils/nibbles, sam/sam-types.go:228) */
   const uint64_t *qual_off;   /* n+1 byte offsets into qual */
   const uint8_t *qual;        /* raw phred, no +33 (sam/sam-files.go:400-402) */
+  const uint16_t *split;      /* optional (NULL = all 0): id of the `elprep split` file the record belongs to.  Records with different
+                                 split ids are duplicate-marked as if by separate `elprep filter` runs (their fragment / mate / pair
+                                 keys never match), so that one context can hold several contig-group splits of an `sfm` run
+                                 (cmd/sfm.go:129-805 runs one filter process per split file) */
 } elp_batch;
 
 /* Header facts read by the filters: @SQ LN (alignmentAgreesWithHeader, filters/utils.go:130-139) and the @RG
@@ -99,6 +108,9 @@ uint64_t elp_num_records(const elp_ctx *ctx);
  * under all nine keys of CoordinateLess keep staging order.  Payload permutation is the caller's (host) work. */
 int elp_sort_coordinate(elp_ctx *ctx);
 int elp_get_permutation(elp_ctx *ctx, uint32_t *perm_out /* n */);
+/* number of records that survive RemoveOptionalReads = staged records without the sr tag: the first elp_num_sorted() entries of
+ * the permutation are the output of the run, the tagged copies follow behind them */
+uint64_t elp_num_sorted(const elp_ctx *ctx);
 
 /* ---- mark duplicates: filters.MarkDuplicates (filters/mark-duplicates.go:398-445) ----
  * Sets FLAG |= 0x400 on the staged flag column exactly as the reference's fragment/pair tournaments do

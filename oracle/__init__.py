@@ -55,6 +55,7 @@ def lib() -> C.CDLL:
         L.orc_estimate_library_size.restype = C.c_int64
         L.orc_estimate_library_size.argtypes = [C.c_int64, C.c_int64]
         L.orc_flatten.restype = C.c_size_t
+        L.orc_num_sorted.restype = C.c_uint64
         L.orc_bqsr_recal_qual.restype = C.c_uint8
     return _LIB
 
@@ -78,6 +79,12 @@ def sort_coordinate(b: Batch) -> np.ndarray:
     s = b.as_struct()
     _check(lib().orc_sort_coordinate(C.byref(s), _p(perm)), "sort_coordinate")
     return perm
+
+
+def num_sorted(b: Batch) -> int:
+    """records without the sr tag: perm[:num_sorted] of sort_coordinate is the sorted output (RemoveOptionalReads drops the rest)"""
+    s = b.as_struct()
+    return int(lib().orc_num_sorted(C.byref(s)))
 
 
 def coordinate_less(b: Batch, i: int, j: int) -> bool:

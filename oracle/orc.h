@@ -50,6 +50,7 @@ typedef struct orc_batch {
   const uint64_t *cigar_off; const uint32_t *cigar;  /* n+1 offsets (in ops), BAM encoding len<<4|op, op index into "MIDNSHP=X" */
   const uint64_t *seq_off;   const uint8_t *seq4;    /* n+1 byte offsets, BAM nibbles high nibble first, "=ACMGRSVTWYHKDBN" */
   const uint64_t *qual_off;  const uint8_t *qual;    /* n+1 byte offsets, raw phred (no +33) */
+  const uint16_t *split;     /* layout parity with elp_batch only: the oracle is run once per split file, as the reference is */
 } orc_batch;
 
 /* Header facts the path needs (sam.Header @SQ / @RG) */
@@ -64,6 +65,7 @@ typedef struct orc_header {
 uint16_t orc_mod_flag(uint16_t flag);
 /* perm_out[k] = index of the record at sorted position k; equal records keep input order */
 int orc_sort_coordinate(const orc_batch *b, uint32_t *perm_out);
+uint64_t orc_num_sorted(const orc_batch *b); /* records without the sr tag (RemoveOptionalReads): the sorted prefix of perm_out */
 int orc_coordinate_less(const orc_batch *b, uint64_t i, uint64_t j);
 
 /* ---- mark duplicates (filters/mark-duplicates.go) ---- */

@@ -412,9 +412,12 @@ int orc_dup_metrics(const orc_batch *b, const orc_header *h, const uint32_t *per
   if (hist) memset(hist, 0, (size_t)nl * 3 * hist_len * sizeof(int64_t));
   qmap pf;
   if (qmap_init(&pf, n)) { md_free(&s); return -2; }
-  /* MarkOpticalDuplicates :469-502, sequential left-to-right over the sorted records */
+  /* MarkOpticalDuplicates :469-502, sequential left-to-right over reads.Alignments = the sorted records.  Records with the sr
+   * tag are not among them: RemoveOptionalReads (filters/simple-filters.go:146-152) follows the mark-duplicates filter in
+   * filters1 (cmd/filter.go:773,803), so they took part in the tournaments above and were then dropped. */
   for (uint64_t kk = 0; kk < n; kk++) {
     uint64_t aln = perm ? perm[kk] : kk;
+    if (b->has_sr && b->has_sr[aln]) continue;
     uint16_t f = flag_out[aln];
     int lib = s.lib_of[aln] == ORC_NIL16 ? h->n_lib : s.lib_of[aln];
     int64_t *ctr = counters + (size_t)lib * ORC_NCTR;

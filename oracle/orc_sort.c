@@ -84,14 +84,29 @@ static void msort(const orc_batch *b, uint32_t *a, uint32_t *tmp, uint64_t lo, u
   memcpy(a + lo, tmp + lo, (hi - lo) * sizeof(uint32_t));
 }
 
+/* records that survive RemoveOptionalReads (filters/simple-filters.go:146-152): the filter sits behind MarkDuplicates in
+ * filters1 (cmd/filter.go:773,803), so a record with the sr tag is dropped before Slice(&alns) (sam/filter-pipeline.go:108-124)
+ * collects it: it is never sorted, never seen by MarkOpticalDuplicates, Recalibrate or ApplyBQSR. */
+uint64_t orc_num_sorted(const orc_batch *b) {
+  uint64_t k = 0;
+  for (uint64_t i = 0; i < b->n; i++)
+    if (!(b->has_sr && b->has_sr[i])) k++;
+  return k;
+}
+
+/* perm_out[0 .. orc_num_sorted) = the surviving records in coordinate order; the dropped (sr-tagged) ones follow in input order */
 int orc_sort_coordinate(const orc_batch *b, uint32_t *perm_out) {
-  uint64_t n = b->n;
+  uint64_t n = b->n, k = 0;
   if (n > 0xFFFFFFFFull) return -1;
-  for (uint64_t i = 0; i < n; i++) perm_out[i] = (uint32_t)i;
-  if (n < 2) return 0;
-  uint32_t *tmp = (uint32_t *)malloc(n * sizeof(uint32_t));
+  for (uint64_t i = 0; i < n; i++)
+    if (!(b->has_sr && b->has_sr[i])) perm_out[k++] = (uint32_t)i;
+  uint64_t n_out = k;
+  for (uint64_t i = 0; i < n; i++)
+    if (b->has_sr && b->has_sr[i]) perm_out[k++] = (uint32_t)i;
+  if (n_out < 2) return 0;
+  uint32_t *tmp = (uint32_t *)malloc(n_out * sizeof(uint32_t));
   if (!tmp) return -2;
-  msort(b, perm_out, tmp, 0, n);
+  msort(b, perm_out, tmp, 0, n_out);
   free(tmp);
   return 0;
 }

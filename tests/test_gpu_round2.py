@@ -1,0 +1,195 @@
+"""GPU parity tests (-m gpu) added in round 2: sr-tagged copies, DeleteOrStore toggling for more than two primary records per
+QNAME, the optical-duplicate list cap and large duplicate sets, the bench workload itself against the oracle."""
+import numpy as np
+import pytest
+
+import oracle as orc
+from elprep_amd.batch import Batch, Header, batch_from_records
+from elprep_amd.engine import BqsrTables, Engine, ElpError
+from tests import kat_cases
+from tests.common import dataset
+
+pytestmark = pytest.mark.gpu
+
+
+def test_sr_tagged_copies_hand_derived():
+    """tests/kat_cases.sr_case through the C ABI: `filter` on everything, then `sfm` with the two group splits in ONE context
+    (split ids 1 and 2) and the spread split in another; counters are the hand-derived ones, flags those of the oracle run split by
+    split (the tagged copies of a spread pair must not pair up in the shared context)."""
+    whole, splits, expected, dups = kat_cases.sr_case()
+    h = kat_cases.header2()
+    e = Engine(h)
+    e.stage(whole)
+    assert np.array_equal(e.sort_coordinate(), orc.sort_coordinate(whole))
+    flags = e.mark_duplicates(True)
+    assert kat_cases.flagged_names(whole, flags) == dups["filter"]
+    assert e.dup_metrics(100)[0].tolist() == expected
+    e.close()
+    a, b = splits["A"], splits["B"]
+    a.split[:] = 1
+    b.split[:] = 2
+    both = Batch.concat([a, b])
+    eg, es = Engine(h), Engine(h)
+    eg.stage(both)
+    es.stage(splits["spread"])
+    perm = eg.sort_coordinate()
+    n_out = eg.n_sorted
+    assert n_out == both.n - 4 and not both.has_sr[perm[:n_out]].any() and both.has_sr[perm[n_out:]].all()
+    # group A's output, then group B's (refid order): what the two filter runs write, concatenated
+    want = np.concatenate([orc.sort_coordinate(a)[:orc.num_sorted(a)], a.n + orc.sort_coordinate(b)[:orc.num_sorted(b)]])
+    assert np.array_equal(perm[:n_out], want)
+    fg = eg.mark_duplicates(True)
+    assert np.array_equal(fg, np.concatenate([orc.mark_duplicates(a, h), orc.mark_duplicates(b, h)]))
+    fs = es.mark_duplicates(True)
+    assert kat_cases.flagged_names(splits["spread"], fs) == dups["spread"]
+    cg, cs = eg.dup_metrics(100), es.dup_metrics(100)
+    assert cg[0].tolist() == [1, 2, 0, 1, 1, 0, 0] and cs[0].tolist() == [0, 2, 0, 0, 0, 1, 0]
+    assert (cg + cs)[0].tolist() == expected
+    eg.close()
+    es.close()
+
+
+def test_delete_or_store_toggling_hand_derived():
+    h = kat_cases.header2()
+    for k, (b, want) in enumerate(kat_cases.toggling_cases()):
+        e = Engine(h)
+        e.stage(b)
+        flags = e.mark_duplicates(True)
+        assert np.nonzero(flags & 0x400)[0].tolist() == want, k
+        assert np.array_equal(flags, orc.mark_duplicates(b, h)), k
+        e.close()
+
+
+@pytest.mark.parametrize("where", ["adjacent", "anywhere"])
+def test_third_primary_record_per_qname_against_oracle(where):
+    """A synthetic batch in which 300 pairs get a third primary mapped record with the same QNAME (a copy of one mate, moved), next
+    to the pair or anywhere in staging order, in front of it or behind it: flags and counters equal the oracle's sequential run."""
+    cfg, b, h, refs, sites = dataset("tiny", 5000, 5, 0.02)
+    rng = np.random.default_rng(3)
+    cand = np.nonzero(((b.flag & 0x904) == 0) & ((b.flag & 0x9) == 0x1))[0]
+    picks = rng.choice(cand, 300, replace=False)
+    order = list(range(b.n))
+    extra_src = []
+    for k, i in enumerate(picks):
+        extra_src.append(int(i))
+        new_id = b.n + k
+        if where == "adjacent":
+            at = order.index(int(i)) + int(rng.integers(0, 2))
+        else:
+            at = int(rng.integers(0, len(order) + 1))
+        order.insert(at, new_id)
+    ext = b.take(np.asarray(extra_src))
+    ext.pos[:] = np.maximum(1, ext.pos + rng.integers(-40, 40, ext.n)).astype(np.int32)  # some land on the old key, most elsewhere
+    pb = Batch.concat([b, ext]).take(np.asarray(order))
+    e = Engine(h)
+    e.stage(pb)
+    oflags = orc.mark_duplicates(pb, h)
+    flags = e.mark_duplicates(True)
+    assert np.array_equal(flags, oflags)
+    operm = orc.sort_coordinate(pb)
+    assert np.array_equal(e.sort_coordinate(), operm)
+    _, octr, ohist = orc.dup_metrics(pb, h, operm, 100, hist_len=16)
+    ctr, hist = e.dup_metrics(100, hist_len=16)
+    assert np.array_equal(ctr, octr) and np.array_equal(hist, ohist)
+    e.close()
+
+
+def _pileup(n_fwd_first, n_rev_first, rng):
+    """one duplicate set: pairs on one pair key (0:1000 forward, 0:1200 reverse); in n_fwd_first of them the forward read is the
+    first of the pair (so it is the read that is listed), in n_rev_first the reverse read; QNAMEs carry tile/x/y with optical
+    clusters (few tiles, small coordinate range)."""
+    n = n_fwd_first + n_rev_first
+    first_fwd = np.zeros(n, dtype=bool)
+    first_fwd[:n_fwd_first] = True
+    rng.shuffle(first_fwd)
+    tile = rng.integers(1101, 1109, n)
+    x, y = rng.integers(1000, 3000, n), rng.integers(1000, 3000, n)
+    names = [b"P%d:1:FC:1:%d:%d:%d" % (k, tile[k], x[k], y[k]) for k in range(n)]
+    lens = np.fromiter((len(s) for s in names), dtype=np.int64, count=n)
+    qname = np.frombuffer(b"".join(s + s for s in names), dtype=np.uint8)
+    N = 2 * n
+    qoff = np.zeros(N + 1, np.uint64)
+    np.cumsum(np.repeat(lens, 2), out=qoff[1:])
+    L = 8
+    flag = np.empty(N, np.uint16)
+    flag[0::2] = np.where(first_fwd, 99, 163)   # forward mate: first (99) or last (163) of the pair
+    flag[1::2] = np.where(first_fwd, 147, 83)   # reverse mate
+    pos = np.empty(N, np.int32); pos[0::2] = 1000; pos[1::2] = 1200
+    pnext = np.empty(N, np.int32); pnext[0::2] = 1200; pnext[1::2] = 1000
+    tlen = np.empty(N, np.int32); tlen[0::2] = 200 + L; tlen[1::2] = -(200 + L)
+    qual = np.full(N * L, 30, np.uint8)
+    qual[:2 * L] = 40  # pair 0 is the best pair: the origin
+    off = np.arange(N + 1, dtype=np.uint64)
+    return Batch(refid=np.zeros(N, np.int32), pos=pos, next_refid=np.zeros(N, np.int32), pnext=pnext, tlen=tlen, flag=flag,
+                 mapq=np.full(N, 60, np.uint8), rgid=np.asarray(rng.integers(0, 2, n).repeat(2), np.uint16), has_sr=np.zeros(N, np.uint8),
+                 l_seq=np.full(N, L, np.uint32), qname_off=qoff, qname=qname, cigar_off=off, cigar=np.full(N, (L << 4) | 0, np.uint32),
+                 seq_off=off * np.uint64(L // 2), seq4=np.full(N * L // 2, 0x12, np.uint8), qual_off=off * np.uint64(L), qual=qual)
+
+
+@pytest.mark.parametrize("n_fwd,n_rev", [(3000, 2500), (300_040, 700)])
+def test_large_duplicate_sets_and_the_list_cap(n_fwd, n_rev):
+    """Duplicate sets far beyond what one thread evaluates: 5500 listed reads (both strand lists counted by the cooperative
+    union-find), and a forward list of more than 300000 reads, which the reference cuts to 300001 entries and counts as 0 optical
+    duplicates (filters/mark-optical-duplicates.go:289-299, 328-330) while the reverse list is counted as usual."""
+    rng = np.random.default_rng(n_fwd)
+    b = _pileup(n_fwd, n_rev, rng)
+    h = Header(ref_len=np.array([5000], np.int32), rg_lib=np.array([0, 0], np.uint16), rg_cov=np.array([0, 1], np.uint16))
+    e = Engine(h)
+    e.stage(b)
+    flags = e.mark_duplicates(True)
+    oflags, octr, ohist = orc.dup_metrics(b, h, None, 100, hist_len=8)
+    assert np.array_equal(flags, oflags)
+    assert int(((flags & 0x400) != 0).sum()) == b.n - 2
+    ctr, hist = e.dup_metrics(100, hist_len=8)
+    assert np.array_equal(ctr, octr) and np.array_equal(hist, ohist)
+    assert ctr[0, 5] == b.n // 2 - 1 and ctr[0, 6] > 100
+    assert np.array_equal(e.dup_metrics(100), octr)
+    e.close()
+
+
+def test_qname_length_limit():
+    h = kat_cases.header2()
+    e = Engine(h)
+    rec = dict(qname="q" * 1001, flag=0, refid=0, pos=5, cigar="2M", mapq=60, seq="AC", qual=[30, 30], rgid=0)
+    with pytest.raises(ElpError, match="QNAME"):
+        e.stage(batch_from_records([rec]))
+    # a pile-up of long names (1000 bytes, differing in the last bytes) goes through the live-byte tie-break
+    recs = [dict(rec, qname="q" * 990 + "%010d" % ((k * 7919) % 100)) for k in range(100)]
+    b = batch_from_records(recs)
+    e.stage(b)
+    assert np.array_equal(e.sort_coordinate(), orc.sort_coordinate(b))
+    e.close()
+
+
+def test_bench_workload_against_the_oracle():
+    """The bench configuration itself (genome c3: 24 contigs, hg38 / 12; the generator's read mix) at 2 M reads, every output of
+    the path compared with the oracle: adapted values, permutation, flags, counters, the three BQSR tables, every QUAL byte."""
+    from bench import flatten_sites
+    from tools import synth
+    cfg = synth.config("c3")
+    h = cfg.header()
+    b = synth.generate(cfg, 0, 1_000_000)
+    refs = [synth.reference(cfg, r) for r in range(h.n_ref)]
+    sites = [flatten_sites(synth.known_sites_raw(cfg, r)) for r in range(h.n_ref)]
+    for r in (0, 7, 23):
+        assert np.array_equal(sites[r], orc.flatten(orc.sort_by_start(synth.known_sites_raw(cfg, r))))
+    e = Engine(h)
+    cuts = np.linspace(0, b.n, 4).astype(int)
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        e.stage(b.take(np.arange(lo, hi)))
+    operm = orc.sort_coordinate(b)
+    assert np.array_equal(e.sort_coordinate(), operm)
+    oflags, octr, _ = orc.dup_metrics(b, h, operm, 100)
+    assert np.array_equal(e.mark_duplicates(True), oflags)
+    assert np.array_equal(e.dup_metrics(100), octr)
+    for r in range(h.n_ref):
+        e.set_reference(r, refs[r])
+        e.set_known_sites(r, sites[r])
+    qt, ct, xt = e.recalibrate(500)
+    oq, oc, ox = orc.bqsr_gather(b, h, orc.BqsrRef(refs, sites), oflags, 500)
+    assert np.array_equal(qt, oq) and np.array_equal(ct, oc) and np.array_equal(xt, ox)
+    tb = BqsrTables(qt, ct, xt, 500).finalize()
+    lut, present = tb.build_lut(0)
+    got = e.apply_bqsr(lut, present, 500)
+    assert np.array_equal(got, orc.BqsrFinal(oq, oc, ox, 500).apply(b, h, 0))
+    e.close()

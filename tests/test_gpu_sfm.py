@@ -14,8 +14,9 @@ from tools import synth
 pytestmark = pytest.mark.gpu
 
 
-def test_sfm_two_ranks_on_one_gpu():
-    world = 2
+@pytest.mark.parametrize("world", [2, 1])
+def test_sfm_ranks_on_one_gpu(world):
+    """world = 1: both contig groups, the unmapped split (one context, three split ids) and the spread split on one rank"""
     inputs, owner, gof, G, cfg = [], None, None, None, None
     for r in range(world):
         cfg, gof, G, owner, b = sfm_worker.make_rank_input(r, world, pairs_per_rank=4000)
@@ -28,7 +29,7 @@ def test_sfm_two_ranks_on_one_gpu():
     spread = []
     for b in inputs:
         g, sp = sfm.split_records(b, gof)
-        tagged = sfm.with_sr(b, sp)
+        tagged = sfm.with_sr(b, sp, g)
         for r in range(world):
             idx = np.nonzero(owner[g] == r)[0]
             if idx.size:
@@ -63,24 +64,34 @@ def test_sfm_two_ranks_on_one_gpu():
         at += n
     qt, ct, xt, ctr = tabs
 
-    # ---- oracle: split by split
+    # ---- oracle: split file by split file (one `filter` run each, as cmd/sfm.go runs them)
     oq = oc = ox = octr = None
-    oflags = {}
+    oflags, operms = {}, {}
     for key, p in parts.items():
         if p.n == 0:
             continue
-        perm = orc.sort_coordinate(p)
-        fl, c7, _ = orc.dup_metrics(p, h, perm, 100)
-        q, c, x = orc.bqsr_gather(p, h, orc.BqsrRef(refs, sites), fl, 500)
-        oflags[key] = fl
-        oq = q if oq is None else oq + q
-        oc = c if oc is None else oc + c
-        ox = x if ox is None else ox + x
-        octr = c7 if octr is None else octr + c7
+        oflags[key] = np.zeros(p.n, np.uint16)
+        out_order = []
+        for sid in np.unique(p.split):
+            sel = np.nonzero(p.split == sid)[0]
+            sub = p.take(sel)
+            perm = orc.sort_coordinate(sub)
+            fl, c7, _ = orc.dup_metrics(sub, h, perm, 100)
+            q, c, x = orc.bqsr_gather(sub, h, orc.BqsrRef(refs, sites), fl, 500)
+            oflags[key][sel] = fl
+            out_order.append((int(sid), sel[perm[:orc.num_sorted(sub)]]))
+            oq = q if oq is None else oq + q
+            oc = c if oc is None else oc + c
+            ox = x if ox is None else ox + x
+            octr = c7 if octr is None else octr + c7
+        # the context's output: its contig groups in @SQ order, then the unmapped split (id 0)
+        operms[key] = np.concatenate([o for sid, o in sorted(out_order, key=lambda t: (t[0] == 0, t[0]))])
     assert np.array_equal(qt, oq) and np.array_equal(ct, oc) and np.array_equal(xt, ox)
     assert np.array_equal(ctr, octr)
     for (r, w), fl in oflags.items():
-        assert np.array_equal(ranks[r].engines[w].flags(), fl), (r, w)
+        eng = ranks[r].engines[w]
+        assert np.array_equal(eng.flags(), fl), (r, w)
+        assert np.array_equal(eng.permutation()[:eng.n_sorted], operms[(r, w)]), (r, w)
     # the tagged copies never reach the tables: the same reads without the copies give the same BQSR tables
     tb = BqsrTables(qt, ct, xt, 500).finalize()
     lut, present = tb.build_lut(0)
