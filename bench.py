@@ -137,8 +137,10 @@ def main():
             eng.sync()
 
         def step():
-            eng.sort_coordinate(fetch=False)
+            # the reference's order of events (cmd/filter.go:142-211): MarkDuplicates is a filter of the phase-1 pipeline, the sort is
+            # that pipeline's Finalize (sam/filter-pipeline.go:116), then the metrics pass, Recalibrate, finalize, ApplyBQSR
             eng.mark_duplicates(True, fetch=False)
+            eng.sort_coordinate(fetch=False)
             eng.dup_metrics(100)
             qt, ct, xt = eng.recalibrate(MAX_CYCLE, reuse=True)
             tb = BqsrTables(qt, ct, xt, MAX_CYCLE).finalize()
@@ -328,7 +330,7 @@ def cpu_baseline(cfg, hdr, n_reads):
     refs = [synth.reference(cfg, r) for r in range(hdr.n_ref)]
     sites = [flatten_sites(synth.known_sites_raw(cfg, r)) for r in range(hdr.n_ref)]
     t0 = time.perf_counter()
-    perm = orc.sort_coordinate(b)
+    perm = orc.sort_coordinate(b, orc.mark_duplicates(b, hdr))
     flags, ctr, _ = orc.dup_metrics(b, hdr, perm, 100)
     qt, ct, xt = orc.bqsr_gather(b, hdr, orc.BqsrRef(refs, sites), flags, MAX_CYCLE)
     fin = orc.BqsrFinal(qt, ct, xt, MAX_CYCLE)

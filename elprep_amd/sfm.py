@@ -283,8 +283,8 @@ class SfmRank:
         """sort + mark duplicates + duplication metrics + BQSR tables of every split of this rank, then THE all-reduce."""
         tot = None
         for e in self.engines:
-            e.sort_coordinate(fetch=False)
             e.mark_duplicates(True, fetch=False)
+            e.sort_coordinate(fetch=False)  # the sort is the Finalize step behind the filters (sam/filter-pipeline.go:116)
             ctr = e.dup_metrics(pixel_dist)
             qt, ct, xt = e.recalibrate(max_cycle)
             flat = np.concatenate([qt.ravel(), ct.ravel(), xt.ravel(), ctr.ravel()])

@@ -105,7 +105,10 @@ uint64_t elp_num_records(const elp_ctx *ctx);
 
 /* ---- coordinate sort: By(CoordinateLess).ParallelStableSort (sam/sam-types.go:425-473, 639-641) ----
  * Builds the permutation on device: perm[k] = staging index of the record at sorted position k; records equal
- * under all nine keys of CoordinateLess keep staging order.  Payload permutation is the caller's (host) work. */
+ * under all nine keys of CoordinateLess keep staging order.  Payload permutation is the caller's (host) work.
+ * The comparator's modFlag(FLAG) tie-break reads the FLAG column as it is at the time of the call.  In `elprep filter` the sort is
+ * the Finalize step of the phase-1 pipeline (sam/filter-pipeline.go:116): it runs BEHIND the filters, so with --mark-duplicates it
+ * sees the duplicate bits.  A drop-in host therefore calls elp_mark_duplicates first, then elp_sort_coordinate. */
 int elp_sort_coordinate(elp_ctx *ctx);
 int elp_get_permutation(elp_ctx *ctx, uint32_t *perm_out /* n */);
 /* number of records that survive RemoveOptionalReads = staged records without the sr tag: the first elp_num_sorted() entries of

@@ -74,8 +74,15 @@ def mod_flag(flag: int) -> int:
     return int(lib().orc_mod_flag(flag))
 
 
-def sort_coordinate(b: Batch) -> np.ndarray:
+def sort_coordinate(b: Batch, flags: Optional[np.ndarray] = None) -> np.ndarray:
+    """flags: the FLAG column the sort sees.  In `elprep filter` the sort is the Finalize step of the phase-1 pipeline
+    (sam/filter-pipeline.go:116), i.e. it runs behind the filters: with --mark-duplicates the comparator's modFlag(FLAG) tie-break
+    (sam/sam-types.go:447-452) sees the duplicate bits.  Pass the flags after MarkDuplicates to get that order."""
     perm = np.empty(b.n, dtype=np.uint32)
+    if flags is not None:
+        cols = {name: getattr(b, name) for name in b.__dataclass_fields__}
+        cols["flag"] = np.ascontiguousarray(flags, dtype=np.uint16)
+        b = Batch(**cols)
     s = b.as_struct()
     _check(lib().orc_sort_coordinate(C.byref(s), _p(perm)), "sort_coordinate")
     return perm

@@ -74,6 +74,21 @@ def toggling_cases():
     ]
 
 
+def sort_sees_duplicate_bits_case():
+    """The coordinate sort is the Finalize step of the pipeline the MarkDuplicates filter runs in (sam/filter-pipeline.go:116;
+    filters first, cmd/filter.go:773), so CoordinateLess's modFlag(FLAG) tie-break (sam/sam-types.go:447-452) sees the duplicate bits.
+    Pair "n" of read group 1 (library 1) loses against pair "m" there and is flagged; pair "n" of read group 0 (library 0, same
+    QNAME, same ends) is alone in its library.  Staged Y = (n, rg1) before X = (n, rg0): on (refid, POS, strand, QNAME) they tie;
+    FLAG 99 < 99 | 0x400, so X sorts in front of Y although it was staged behind it.
+    -> (batch, header, staging indices in sorted order, duplicate-flagged staging indices)"""
+    h = Header(ref_len=np.array([1000, 1000], np.int32), rg_lib=np.array([0, 1], np.uint16), rg_cov=np.array([0, 1], np.uint16))
+    y = [_rec("n", 99, 0, 100, 0, 300, 210, qual=Q20, rgid=1), _rec("n", 147, 0, 300, 0, 100, -210, qual=Q20, rgid=1)]
+    x = [_rec("n", 99, 0, 100, 0, 300, 210, qual=Q20, rgid=0), _rec("n", 147, 0, 300, 0, 100, -210, qual=Q20, rgid=0)]
+    m = [_rec("m", 99, 0, 100, 0, 300, 210, qual=Q40, rgid=1), _rec("m", 147, 0, 300, 0, 100, -210, qual=Q40, rgid=1)]
+    # staging: y0 y1 x0 x1 m0 m1; sorted: POS 100: m0 ("m" < "n"), x0 (99), y0 (99 | 0x400); POS 300: m1, x1, y1
+    return batch_from_records(y + x + m), h, [4, 2, 0, 5, 3, 1], [0, 1]
+
+
 def flagged_names(b, flags):
     """QNAMEs of the records whose duplicate bit is set"""
     return {b.qname_of(i).decode() for i in range(b.n) if int(flags[i]) & 0x400}

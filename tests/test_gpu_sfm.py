@@ -75,7 +75,7 @@ def test_sfm_ranks_on_one_gpu(world):
         for sid in np.unique(p.split):
             sel = np.nonzero(p.split == sid)[0]
             sub = p.take(sel)
-            perm = orc.sort_coordinate(sub)
+            perm = orc.sort_coordinate(sub, orc.mark_duplicates(sub, h))
             fl, c7, _ = orc.dup_metrics(sub, h, perm, 100)
             q, c, x = orc.bqsr_gather(sub, h, orc.BqsrRef(refs, sites), fl, 500)
             oflags[key][sel] = fl

@@ -48,3 +48,11 @@ def test_sort_keeps_only_records_without_sr():
     # flags 73 < 133), no tagged copy among them
     assert [sb.qname_of(i).decode() for i in perm[:n_out]] == ["p1", "p1", "f1", "f1"]
     assert [int(sb.flag[i]) for i in perm[:n_out]] == [99, 147, 73, 133]
+
+
+def test_sort_runs_behind_mark_duplicates():
+    b, h, order, dup = kat_cases.sort_sees_duplicate_bits_case()
+    flags = orc.mark_duplicates(b, h)
+    assert np.nonzero(flags & 0x400)[0].tolist() == dup
+    assert orc.sort_coordinate(b, flags).tolist() == order
+    assert orc.sort_coordinate(b).tolist() == [4, 0, 2, 5, 1, 3]  # without the duplicate bits the tie keeps staging order
