@@ -22,6 +22,8 @@ HIP_SYMBOLS = [
     "elp_create", "elp_destroy", "elp_last_error", "elp_sync", "elp_stream", "elp_set_header", "elp_reserve", "elp_stage", "elp_reset",
     "elp_num_records", "elp_num_sorted", "elp_sort_coordinate", "elp_get_permutation", "elp_mark_duplicates", "elp_get_flags", "elp_get_adapted",
     "elp_dup_metrics", "elp_dup_metrics_hist", "elp_bqsr_set_reference", "elp_bqsr_set_known_sites", "elp_bqsr_gather", "elp_bqsr_apply", "elp_get_qual",
+    "elp_bqsr_gather_device", "elp_bqsr_tables_fetch", "elp_group_unique_id", "elp_group_init", "elp_group_rank", "elp_group_size",
+    "elp_bqsr_tables_add", "elp_bqsr_tables_allreduce", "elp_allreduce_i64",
     "elp_snapshot", "elp_rollback", "elp_profile_enable", "elp_profile_reset", "elp_profile_count", "elp_profile_get",
 ]
 HOST_SYMBOLS = [
@@ -74,6 +76,15 @@ def hip() -> C.CDLL:
         L.elp_bqsr_gather.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.elp_bqsr_apply.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.elp_get_qual.argtypes = [C.c_void_p, C.c_void_p]
+        L.elp_bqsr_gather_device.argtypes = [C.c_void_p, C.c_int]
+        L.elp_bqsr_tables_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.elp_group_unique_id.argtypes = [C.c_void_p]
+        L.elp_group_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.elp_group_rank.argtypes = [C.c_void_p]
+        L.elp_group_size.argtypes = [C.c_void_p]
+        L.elp_bqsr_tables_add.argtypes = [C.c_void_p, C.c_void_p]
+        L.elp_bqsr_tables_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.elp_allreduce_i64.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.elp_profile_enable.argtypes = [C.c_void_p, C.c_int]
         L.elp_profile_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
         _hip = L

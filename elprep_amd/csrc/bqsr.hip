@@ -841,19 +841,31 @@ struct ApplyArgs {
   const uint8_t *lut;  // [n_cov][94][2*max_cycle+1][17]
   int max_cycle;
   uint32_t *err;
-  // LDS-resident compact LUT (k_bqsr_apply_flat<.., true>): [n_cov][n_slot][2*lmax+1][17], slot = qslot[quality] (255 = not resident)
-  const uint8_t *clut;
-  int n_cov, n_slot, lmax;
+  // LDS-resident two-level LUT (MODE 1 / 2): t1 [n_cov][n_qi + 1][2*lmax+1] ids of distinct 17-byte LUT rows (qi = quality - qlo;
+  // row n_qi = "not resident"), t2 [n_dict + 1][17] the rows themselves (row n_dict = 0x80 everywhere)
+  const uint16_t *t1;
+  const uint8_t *t2;
+  int n_cov, n_qi, qlo, lmax, n_dict;
 };
-struct QSlots { uint8_t slot[96]; };
 
 // ApplyBQSR (bqsr.go:936-1005): every base with quality >= 6 of a record with a known read group is replaced by the LUT value
 // of (read group, quality, cycle, context); cycle and context are taken on the full, unclipped read.
-
-template <bool CHECK_CYCLE, bool LDSLUT>
+//
+// MODE 0: one byte gather per base from the dense LUT in HBM / L2.
+// MODE 1, 2: two-level LUT in LDS.  The dense LUT is a table of 17-byte rows (one per (read group, quality, cycle); 16 contexts +
+// "no context"), and few of them are distinct: estimateHierarchicalBayesianQuality (bqsr.go:901-919) adds the cycle entry's and
+// the context entry's integer empirical qualities to a prior that depends on (read group, quality) only, so a row is determined by
+// (read group, quality, empirical quality of the cycle entry).  Level 1 maps (read group, quality in [qlo, qhi], cycle) to a row id
+// (MODE 1: one byte, at most 255 rows, level 2 rows 32 bytes apart; MODE 2: the row's byte offset in 16 bits), level 2 holds the
+// distinct rows.  A few tens of KB instead of the 143 KB of the rows spelled out, so three workgroups share a CU (one before), and
+// ~40 distinct qualities x 4 read groups still fit (the spelled-out table did not: HBM gathers).  Qualities below qlo read row qlo
+// (they are < 6 and put back by a byte mask), qualities above qhi read the "not resident" row: bit 7 of the result sends them to
+// the rolled fix-up loop (dense LUT, or the error for qualities > 93).
+template <bool CHECK_CYCLE, int MODE>
 struct ApplyBody {
-  // 128 KiB steps in groups of up to 1024 reads (12 B of LDS per read): ~9 blocks per lane between two pipeline restarts
-  static constexpr int NT = LDSLUT ? 1024 : FL_THREADS, TILES = 4, RMAX = 1024;
+  // 128 KiB steps in groups of up to 512 reads (12 B of LDS per read)
+  static constexpr int NT = FL_THREADS, TILES = 4, RMAX = 512;
+  static constexpr int ES = MODE == 1 ? 1 : 2;  // bytes per level-1 entry
   const uint64_t *__restrict__ seq_off;
   uint8_t *__restrict__ qual;
   const uint8_t *__restrict__ seq4;
@@ -862,9 +874,10 @@ struct ApplyBody {
   int max_cycle;
   uint64_t *s_desc;
   uint32_t *s_seq;
-  const uint32_t *qoff;   // LDS: quality -> row block offset in a covariate's part of the compact LUT (LDSLUT)
-  uint32_t llut_at;       // LDS byte address of the compact LUT (LDSLUT)
-  int lmax, n_slot;
+  uint32_t t1_at, t2_at;  // LDS byte addresses of the two levels (MODE != 0); t1_at already has qlo's rows subtracted
+  int lmax, rows_w;       // rows_w = (n_qi + 1) * (2 * lmax + 1): level-1 entries per read group
+  uint32_t w_es;          // (2 * lmax + 1) * ES
+  uint32_t qlo, qhi1;     // resident quality range [qlo, qhi1 - 1]; qhi1 reads the "not resident" row
   uint64_t seq_base;
   uint32_t err;
   Chunk out;              // the block processed last: stored by retire()
@@ -895,16 +908,22 @@ struct ApplyBody {
     const uint32_t v = lut[act ? idx : 0u];
     return act ? v : q;
   }
-  // compact LUT in LDS: one LDS byte read per base and no select.  `off` = qoff[quality]: byte offset of the quality's row block
-  // inside a covariate's part of the compact LUT; qualities without a row block (> 93, or not resident) point at one more block
-  // behind the real ones that holds 0x80 everywhere, so the (rare) bases that need another look are found by bit 7 of the four
-  // result words.  cxw: context index (0..15, 16 = none) of four bases, one byte each.  Bases past the read's end are looked up
-  // too (their bytes are never stored), qualities < 6 are put back by a byte-mask select over the result words.
+  // two-level LUT in LDS: two dependent LDS reads per base, no select.  bpi = level-1 address of (read group, quality 0 + qlo
+  // folded in, cycle of base I); cxw: context index (0..15, 16 = none) of four bases, one byte each.  Bases past the read's end
+  // are looked up too (their bytes are never stored), qualities < 6 are put back by a byte-mask select over the result words.
   template <int I>
-  __device__ __forceinline__ uint32_t base_lds(uint32_t cxw, uint32_t bp, int st, uint32_t off) {
+  __device__ __forceinline__ uint32_t base_lds(const Chunk &ch, uint32_t cxw, uint32_t bp, int ci_es) {
     constexpr int bs = 8 * ((I & 7) >> 1);
-    const uint32_t at = bp + (uint32_t)(I * st) + off + ((cxw >> bs) & 0xFFu);
-    return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>((uintptr_t)at);
+    uint32_t qc;
+    const uint32_t q = ch.get<I>();
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(qc) : "v"(q), "v"(qlo), "v"(qhi1));
+    const uint32_t a1 = __umul24(qc, w_es) + (bp + (uint32_t)(I * ci_es));
+    uint32_t id;
+    if (MODE == 1) id = *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>((uintptr_t)a1);
+    else id = *reinterpret_cast<const __attribute__((address_space(3))) uint16_t *>((uintptr_t)a1);
+    const uint32_t cx = t2_at + ((cxw >> bs) & 0xFFu);
+    const uint32_t a2 = MODE == 1 ? lshl_add_u32<5>(id, cx) : id + cx;
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>((uintptr_t)a2);
   }
   // word of result bytes where the original quality is >= 6, original bytes elsewhere (ApplyBQSR leaves qualities < 6 alone)
   __device__ __forceinline__ static uint32_t keep_low(uint32_t orig, uint32_t res) {
@@ -912,13 +931,12 @@ struct ApplyBody {
     const uint32_t m = (t - (t >> 7)) | t;
     return (res & m) | (orig & ~m);
   }
-  // bases of a block whose lookup hit the 0x80 block (bases past nb may have raised the flag falsely): quality > 93 -> error;
-  // quality without a resident slot -> dense LUT.  Rolled loop over the original bytes.
+  // bases of a block whose lookup hit the 0x80 row (bases past nb may have raised the flag falsely): quality > 93 -> error;
+  // quality above the resident range -> dense LUT.  Rolled loop over the original bytes.
   __device__ __forceinline__ void fixup(Chunk &ch, const Chunk &orig, int nb, uint64_t CV, uint64_t CX, uint32_t Q, int st, int cyc0, int ci) {
     uint64_t lo = (uint64_t)ch.w0 | ((uint64_t)ch.w1 << 32), hi = (uint64_t)ch.w2 | ((uint64_t)ch.w3 << 32);
     const uint64_t olo = (uint64_t)orig.w0 | ((uint64_t)orig.w1 << 32), ohi = (uint64_t)orig.w2 | ((uint64_t)orig.w3 << 32);
     const uint32_t qstride = (uint32_t)(2 * max_cycle + 1) * 17u;
-    const uint32_t off_x = (uint32_t)(n_slot * (2 * lmax + 1) * 17);
 #pragma unroll 1
     for (int i = 0; i < nb; i++) {
       const int bs = 8 * (i & 7);
@@ -926,7 +944,7 @@ struct ApplyBody {
       if (q < 6u) continue;                                      // put back by keep_low
       uint64_t v = q;
       if (q >= (uint32_t)ELP_NQUAL) err |= 8u;
-      else if (qoff[q] != off_x) continue;                       // resident: done by the straight-line code
+      else if (q < qhi1) continue;                               // resident: done by the straight-line code
       else {
         if (CHECK_CYCLE) {
           const int cyc = cyc0 + i * ci;
@@ -986,21 +1004,18 @@ struct ApplyBody {
     const uint32_t v0 = (uint32_t)CV, v1 = (uint32_t)(CV >> 32), c0 = (uint32_t)CX, c1 = (uint32_t)(CX >> 32);
     uint32_t b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, b10, b11, b12, b13, b14, b15;
     const Chunk orig = ch;
-    if (LDSLUT) {
-      const uint32_t bp = llut_at + (uint32_t)(((int)cov * (n_slot + 1) * (2 * lmax + 1) + (cyc0 + lmax)) * 17);
+    if (MODE) {
+      const uint32_t bp = t1_at + (uint32_t)((int)cov * rows_w + (cyc0 + lmax)) * (uint32_t)ES;
+      const int ci_es = ci * ES;
       // context index per base, one byte each: even bases in ce, odd bases in co
       constexpr uint64_t EVN = 0x0F0F0F0F0F0F0F0Full;
       const uint64_t NV = ~CV & NIB1;
       const uint64_t ce = (CX & EVN) | ((NV & (NIB1 & EVN)) << 4), co = ((CX >> 4) & EVN) | (NV & (NIB1 & ~EVN));
       const uint32_t e0 = (uint32_t)ce, e1 = (uint32_t)(ce >> 32), d0 = (uint32_t)co, d1 = (uint32_t)(co >> 32);
-      const uint32_t o0 = qoff[ch.get<0>()], o1 = qoff[ch.get<1>()], o2 = qoff[ch.get<2>()], o3 = qoff[ch.get<3>()];
-      const uint32_t o4 = qoff[ch.get<4>()], o5 = qoff[ch.get<5>()], o6 = qoff[ch.get<6>()], o7 = qoff[ch.get<7>()];
-      const uint32_t o8 = qoff[ch.get<8>()], o9 = qoff[ch.get<9>()], o10 = qoff[ch.get<10>()], o11 = qoff[ch.get<11>()];
-      const uint32_t o12 = qoff[ch.get<12>()], o13 = qoff[ch.get<13>()], o14 = qoff[ch.get<14>()], o15 = qoff[ch.get<15>()];
-      b0 = base_lds<0>(e0, bp, st, o0); b1 = base_lds<1>(d0, bp, st, o1); b2 = base_lds<2>(e0, bp, st, o2); b3 = base_lds<3>(d0, bp, st, o3);
-      b4 = base_lds<4>(e0, bp, st, o4); b5 = base_lds<5>(d0, bp, st, o5); b6 = base_lds<6>(e0, bp, st, o6); b7 = base_lds<7>(d0, bp, st, o7);
-      b8 = base_lds<8>(e1, bp, st, o8); b9 = base_lds<9>(d1, bp, st, o9); b10 = base_lds<10>(e1, bp, st, o10); b11 = base_lds<11>(d1, bp, st, o11);
-      b12 = base_lds<12>(e1, bp, st, o12); b13 = base_lds<13>(d1, bp, st, o13); b14 = base_lds<14>(e1, bp, st, o14); b15 = base_lds<15>(d1, bp, st, o15);
+      b0 = base_lds<0>(ch, e0, bp, ci_es); b1 = base_lds<1>(ch, d0, bp, ci_es); b2 = base_lds<2>(ch, e0, bp, ci_es); b3 = base_lds<3>(ch, d0, bp, ci_es);
+      b4 = base_lds<4>(ch, e0, bp, ci_es); b5 = base_lds<5>(ch, d0, bp, ci_es); b6 = base_lds<6>(ch, e0, bp, ci_es); b7 = base_lds<7>(ch, d0, bp, ci_es);
+      b8 = base_lds<8>(ch, e1, bp, ci_es); b9 = base_lds<9>(ch, d1, bp, ci_es); b10 = base_lds<10>(ch, e1, bp, ci_es); b11 = base_lds<11>(ch, d1, bp, ci_es);
+      b12 = base_lds<12>(ch, e1, bp, ci_es); b13 = base_lds<13>(ch, d1, bp, ci_es); b14 = base_lds<14>(ch, e1, bp, ci_es); b15 = base_lds<15>(ch, d1, bp, ci_es);
     } else {
       const uint32_t qstride = (uint32_t)ncyc * 17u;
       b0 = base<0>(ch, nb, v0, c0, Q, st, cyc0, ci, qstride); b1 = base<1>(ch, nb, v0, c0, Q, st, cyc0, ci, qstride);
@@ -1016,7 +1031,7 @@ struct ApplyBody {
     ch.w1 = b4 | (b5 << 8) | (b6 << 16) | (b7 << 24);
     ch.w2 = b8 | (b9 << 8) | (b10 << 16) | (b11 << 24);
     ch.w3 = b12 | (b13 << 8) | (b14 << 16) | (b15 << 24);
-    if (LDSLUT) {
+    if (MODE) {
       const uint32_t any = (ch.w0 | ch.w1) | (ch.w2 | ch.w3);
       ch.w0 = keep_low(orig.w0, ch.w0); ch.w1 = keep_low(orig.w1, ch.w1); ch.w2 = keep_low(orig.w2, ch.w2); ch.w3 = keep_low(orig.w3, ch.w3);
       if (any & 0x80808080u) fixup(ch, orig, nb, CV, CX, Q, st, cyc0, ci);
@@ -1032,28 +1047,38 @@ struct ApplyBody {
   __device__ __forceinline__ void tile_end(uint32_t, uint64_t) {}
 };
 
-template <bool CHECK_CYCLE, bool LDSLUT>
-__global__ __launch_bounds__(LDSLUT ? 1024 : FL_THREADS, 4) void k_bqsr_apply_flat(ApplyArgs A, QSlots slots) {
-  constexpr int RMAX = ApplyBody<CHECK_CYCLE, LDSLUT>::RMAX;
+template <bool CHECK_CYCLE, int MODE>
+__global__ __launch_bounds__(FL_THREADS, MODE ? 6 : 4) void k_bqsr_apply_flat(ApplyArgs A) {
+  typedef ApplyBody<CHECK_CYCLE, MODE> AB;
+  constexpr int RMAX = AB::RMAX;
   __shared__ FlatLds<RMAX> L;
   __shared__ uint64_t s_desc[RMAX];
   __shared__ uint32_t s_seq[RMAX];
-  __shared__ uint32_t qoff[256];
   extern __shared__ __attribute__((aligned(16))) uint8_t llut[];
-  if (LDSLUT) {
-    constexpr int NT = ApplyBody<CHECK_CYCLE, LDSLUT>::NT;
-    for (int q = threadIdx.x; q < 256; q += NT)
-      qoff[q] = (uint32_t)((q < 6 ? 0 : (q >= ELP_NQUAL || slots.slot[q] == 255 ? A.n_slot : (int)slots.slot[q])) * ((2 * A.lmax + 1) * 17));
-    const int nbytes = A.n_cov * (A.n_slot + 1) * (2 * A.lmax + 1) * 17;
-    const uint4 *src = reinterpret_cast<const uint4 *>(A.clut);  // padded to 16 bytes by the builder
-    uint4 *dst = reinterpret_cast<uint4 *>(llut);
-    for (int k = threadIdx.x; k < (nbytes + 15) / 16; k += NT) dst[k] = src[k];
+  const int w = 2 * A.lmax + 1, n1 = A.n_cov * (A.n_qi + 1) * w;
+  const int t1_bytes = (n1 * AB::ES + 15) & ~15;
+  if (MODE) {
+    // level 1: ids -> one byte (MODE 1) or the row's byte offset (MODE 2)
+    for (int k = threadIdx.x; k < n1; k += AB::NT) {
+      const uint32_t id = A.t1[k];
+      if (MODE == 1) llut[k] = (uint8_t)id;
+      else reinterpret_cast<uint16_t *>(llut)[k] = (uint16_t)(id * 17u);
+    }
+    // level 2: rows 32 (MODE 1) or 17 (MODE 2) bytes apart
+    const int n2 = (A.n_dict + 1) * 17;
+    for (int k = threadIdx.x; k < n2; k += AB::NT) {
+      const int row = k / 17, cx = k - 17 * row;
+      llut[t1_bytes + (MODE == 1 ? 32 * row + cx : k)] = A.t2[k];
+    }
     __syncthreads();
   }
-  ApplyBody<CHECK_CYCLE, LDSLUT> B;
+  AB B;
   B.seq_off = A.seq_off; B.qual = A.qual; B.seq4 = A.seq4; B.desc = reinterpret_cast<const uint64_t *>(A.desc); B.lut = A.lut;
   B.max_cycle = A.max_cycle; B.s_desc = s_desc; B.s_seq = s_seq;
-  B.qoff = qoff; B.llut_at = lds_address(llut); B.lmax = A.lmax; B.n_slot = A.n_slot;
+  B.lmax = A.lmax; B.rows_w = (A.n_qi + 1) * w; B.w_es = (uint32_t)(w * AB::ES);
+  B.qlo = (uint32_t)A.qlo; B.qhi1 = (uint32_t)(A.qlo + A.n_qi);
+  B.t1_at = lds_address(llut) - (uint32_t)A.qlo * B.w_es;
+  B.t2_at = lds_address(llut) + (uint32_t)t1_bytes;
   B.err = 0;
   B.out_nb = 0; B.out_at = 0; B.out.w0 = B.out.w1 = B.out.w2 = B.out.w3 = 0;
   flat_run(A.qual_off, A.n, A.qual_bytes, A.tile_first, L, B);
@@ -1064,18 +1089,64 @@ __global__ __launch_bounds__(LDSLUT ? 1024 : FL_THREADS, 4) void k_bqsr_apply_fl
   }
 }
 
-// dense LUT -> compact LUT [n_cov][n_slot + 1][2 * lmax + 1][17] of the resident quality slots and the cycles a read of at most
-// lmax bases can have
-__global__ __launch_bounds__(256) void k_compact_lut(const uint8_t *__restrict__ lut, uint8_t *__restrict__ clut, int n_cov, int n_slot, int lmax,
-                                                     int max_cycle, QSlots slot_q) {
-  const int ncl = 2 * lmax + 1, ncyc = 2 * max_cycle + 1;
-  const int total = n_cov * (n_slot + 1) * ncl * 17;
-  const int id = blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= total) return;
-  const int cx = id % 17, x = (id / 17) % ncl, slot = (id / (17 * ncl)) % (n_slot + 1), cov = id / (17 * ncl * (n_slot + 1));
-  if (slot == n_slot) { clut[id] = 0x80; return; }  // the block the qualities without a slot point at
-  const int q = slot_q.slot[slot], cyc = x - lmax;
-  clut[id] = lut[(((size_t)cov * ELP_NQUAL + q) * ncyc + (size_t)(cyc + max_cycle)) * 17 + cx];
+// ---- distinct rows of the dense LUT over (read group, quality in [qlo, qlo + n_qi), cycle in [-lmax, lmax]) ----
+struct LutRows { const uint8_t *lut; int n_cov, qlo, n_qi, lmax, max_cycle; };
+__device__ __forceinline__ const uint8_t *lut_row(const LutRows &R, int r) {  // r = (cov * n_qi + qi) * w + x
+  const int w = 2 * R.lmax + 1, ncyc = 2 * R.max_cycle + 1;
+  const int x = r % w, qi = (r / w) % R.n_qi, cov = r / (w * R.n_qi);
+  return R.lut + (((size_t)cov * ELP_NQUAL + (size_t)(R.qlo + qi)) * ncyc + (size_t)(x - R.lmax + R.max_cycle)) * 17;
+}
+__device__ __forceinline__ bool row_eq(const uint8_t *a, const uint8_t *b) {
+  bool eq = true;
+#pragma unroll
+  for (int k = 0; k < 17; k++) eq &= a[k] == b[k];
+  return eq;
+}
+// every row finds or becomes the representative of its content in an open-addressing table of row indices
+__global__ __launch_bounds__(256) void k_lut_rows_insert(LutRows R, int n_rows, uint32_t *slots, uint32_t mask, uint32_t *__restrict__ row_slot) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rows) return;
+  const uint8_t *mine = lut_row(R, r);
+  uint64_t h = 0x9e3779b97f4a7c15ull;
+#pragma unroll
+  for (int k = 0; k < 17; k++) h = (h ^ mine[k]) * 0x100000001b3ull;
+  uint32_t s = (uint32_t)mix64(h) & mask;
+  for (;;) {
+    uint32_t cur = __hip_atomic_load(&slots[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == 0xFFFFFFFFu) {
+      cur = atomicCAS(&slots[s], 0xFFFFFFFFu, (uint32_t)r);
+      if (cur == 0xFFFFFFFFu) break;
+    }
+    if (row_eq(lut_row(R, (int)cur), mine)) break;
+    s = (s + 1) & mask;
+  }
+  row_slot[r] = s;
+}
+// occupied slots get dense ids; the representative's row becomes row `id` of level 2
+__global__ __launch_bounds__(256) void k_lut_rows_number(LutRows R, const uint32_t *__restrict__ slots, uint32_t n_slots, uint32_t *__restrict__ slot_id,
+                                                         uint32_t *counter, uint8_t *__restrict__ t2, uint32_t t2_cap) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_slots) return;
+  const uint32_t rep = slots[s];
+  if (rep == 0xFFFFFFFFu) return;
+  const uint32_t id = atomicAdd(counter, 1u);
+  slot_id[s] = id;
+  if (id < t2_cap) {
+    const uint8_t *src = lut_row(R, (int)rep);
+    for (int k = 0; k < 17; k++) t2[(size_t)id * 17 + k] = src[k];
+  }
+}
+// level 1 [cov][n_qi + 1][w]: ids; the extra row per read group and (below) the extra level-2 row stand for "not resident"
+__global__ __launch_bounds__(256) void k_lut_rows_index(LutRows R, const uint32_t *__restrict__ row_slot, const uint32_t *__restrict__ slot_id,
+                                                        const uint32_t *__restrict__ counter, uint16_t *__restrict__ t1, uint8_t *__restrict__ t2,
+                                                        uint32_t t2_cap) {
+  const int w = 2 * R.lmax + 1, n1 = R.n_cov * (R.n_qi + 1) * w;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n_dict = *counter;
+  if (k < 17 && n_dict < t2_cap) t2[(size_t)n_dict * 17 + k] = 0x80;
+  if (k >= n1) return;
+  const int x = k % w, qi = (k / w) % (R.n_qi + 1), cov = k / (w * (R.n_qi + 1));
+  t1[k] = qi == R.n_qi ? (uint16_t)n_dict : (uint16_t)slot_id[row_slot[(cov * R.n_qi + qi) * w + x]];
 }
 
 static int bqsr_error(elp_ctx *c, uint32_t e) {
@@ -1110,6 +1181,7 @@ static int sync_bqsr_ptrs(elp_ctx *c) {
   return 0;
 }
 
+// builds the three tables in c->dev_tables; qual_tbl != nullptr: also copies them to the host
 static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cycle_tbl, int64_t *ctx_tbl) {
   for (int r = 0; r < c->n_ref; r++)
     if (!c->h_ref_seq[r]) return set_error(c, ELP_ERR_ARG, "elp_bqsr_gather: no reference sequence set for refid %d", r);
@@ -1123,8 +1195,9 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
   if (c->cigar_ops + 4 * c->n >= 0x7FFFFFFFull) return set_error(c, ELP_ERR_UNSUPPORTED, "CIGAR pool exceeds 2^31 operations per context");
   const int ncyc_g = 2 * max_cycle + 1;
   const size_t nq = (size_t)c->n_cov * ELP_NQUAL * 2, nc = nq * ncyc_g, nx = nq * ELP_NCTX;
-  unsigned long long *tb;
-  ELP_TRY(scratch(c, 0, nq + nc + nx + 8, &tb));
+  c->tables_n = 0;
+  ELP_TRY(ensure(c, c->dev_tables, nq + nc + nx + elp_ctx::TABLES_TAIL));
+  unsigned long long *tb = c->dev_tables.p;
   hipStream_t st = c->stream;
   ELP_HIP(c, hipMemsetAsync(tb, 0, (nq + nc + nx) * sizeof(unsigned long long), st));
   const uint64_t n = c->n;
@@ -1211,6 +1284,14 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
     ELP_LAUNCH(c, "bqsr_qual_from_cycle", k_bqsr_qual_from_cycle, dim3(c->n_cov * ELP_NQUAL), dim3(256), 0, c->n_cov * ELP_NQUAL, ncyc_g,
                (const unsigned long long *)(tb + nq), tb);
   }
+  c->tables_n = nq + nc + nx;
+  c->tables_max_cycle = max_cycle;
+  if (!qual_tbl) {  // tables stay in HBM
+    uint32_t e[4];
+    ELP_TRY(fetch_err(c, e));
+    if (e[0]) return bqsr_error(c, e[0]);
+    return 0;
+  }
   // the three tables lie behind each other on the device: one copy into pinned memory, then into the caller's arrays
   const size_t bytes = (nq + nc + nx) * 8;
   if (bytes > c->h_pinned_cap) {
@@ -1288,6 +1369,33 @@ int elp_bqsr_gather(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cycle
   return gather_impl(c, max_cycle, qual_tbl, cycle_tbl, ctx_tbl);
 }
 
+int elp_bqsr_gather_device(elp_ctx *c, int max_cycle) {
+  if (!c || max_cycle < 1) return set_error(c, ELP_ERR_ARG, "elp_bqsr_gather_device: bad arguments");
+  ELP_HIP(c, hipSetDevice(c->device));
+  return gather_impl(c, max_cycle, nullptr, nullptr, nullptr);
+}
+
+int elp_bqsr_tables_fetch(elp_ctx *c, int64_t *qual_tbl, int64_t *cycle_tbl, int64_t *ctx_tbl) {
+  if (!c || !qual_tbl || !cycle_tbl || !ctx_tbl) return ELP_ERR_ARG;
+  if (!c->tables_n) return set_error(c, ELP_ERR_ARG, "elp_bqsr_tables_fetch: no device tables (elp_bqsr_gather_device)");
+  ELP_HIP(c, hipSetDevice(c->device));
+  const size_t nq = (size_t)c->n_cov * ELP_NQUAL * 2, nc = nq * (size_t)(2 * c->tables_max_cycle + 1), nx = nq * ELP_NCTX;
+  const size_t bytes = (nq + nc + nx) * 8;
+  if (bytes > c->h_pinned_cap) {
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    c->h_pinned = nullptr; c->h_pinned_cap = 0;
+    ELP_HIP(c, hipHostMalloc(&c->h_pinned, bytes, hipHostMallocDefault));
+    c->h_pinned_cap = bytes;
+  }
+  ELP_HIP(c, hipMemcpyAsync(c->h_pinned, c->dev_tables.p, bytes, hipMemcpyDeviceToHost, c->stream));
+  ELP_HIP(c, hipStreamSynchronize(c->stream));
+  const int64_t *hp = static_cast<const int64_t *>(c->h_pinned);
+  memcpy(qual_tbl, hp, nq * 8);
+  memcpy(cycle_tbl, hp + nq, nc * 8);
+  memcpy(ctx_tbl, hp + nq + nc, nx * 8);
+  return 0;
+}
+
 int elp_bqsr_apply(elp_ctx *c, int max_cycle, const uint8_t *lut, const uint8_t *cov_present) {
   if (!c || !lut || !cov_present || max_cycle < 1) return set_error(c, ELP_ERR_ARG, "elp_bqsr_apply: bad arguments");
   ELP_HIP(c, hipSetDevice(c->device));
@@ -1307,40 +1415,67 @@ int elp_bqsr_apply(elp_ctx *c, int max_cycle, const uint8_t *lut, const uint8_t 
                (const uint16_t *)c->rgid.p, (const uint16_t *)c->rg_cov.p, (const uint32_t *)c->l_seq.p, (const uint64_t *)c->qual_off.p,
                (const uint64_t *)c->qbounds.p, (const uint8_t *)(dl + lut_bytes), desc, c->err_flag.p);
     if (c->qual_bytes) {
-      typedef ApplyBody<false, true> AB;
+      typedef ApplyBody<false, 1> AB;
       const uint64_t nsteps = flat_steps<AB>(c->qual_bytes);
-      const unsigned grid = (unsigned)std::min<uint64_t>(nsteps, (uint64_t)c->n_cu * 8);
       ELP_TRY(ensure_flat_index(c));
-      // LDS-resident compact LUT when [n_cov][resident qualities][2*lmax+1][17] fits beside the kernel's static LDS
-      ELP_TRY(ensure_qual_present(c));
-      std::vector<int> quals;
+      ELP_TRY(ensure_qual_present(c));  // the resident quality range comes from a sample of the column (a hint: qualities outside it take the fix-up path)
+      int qlo = 0, qhi = -1;
       for (int q = 6; q < ELP_NQUAL; q++)
-        if ((q < 64 ? (c->qual_present[0] >> q) : (c->qual_present[1] >> (q - 64))) & 1ull) quals.push_back(q);
+        if ((q < 64 ? (c->qual_present[0] >> q) : (c->qual_present[1] >> (q - 64))) & 1ull) { if (qhi < 0) qlo = q; qhi = q; }
       const int lmax = (int)std::max<uint32_t>(c->max_l_seq, 1);
       const bool chk = (int64_t)c->max_l_seq > (int64_t)max_cycle;
-      const size_t per_slot = (size_t)c->n_cov * (size_t)(2 * lmax + 1) * 17;
-      const size_t lds_budget = 160 * 1024 - (sizeof(FlatLds<AB::RMAX>) + (size_t)AB::RMAX * 12 + 1024 + 512);
-      const size_t cbytes = per_slot * (quals.size() + 1);  // + the 0x80 block
       ApplyArgs A{n, c->qual_bytes, c->qual_off.p, c->seq_off.p, c->qual.p, c->seq4.p, desc, c->tile_first.p, dl, max_cycle, c->err_flag.p,
-                  nullptr, c->n_cov, (int)quals.size(), lmax};
-      QSlots qs, sq;
-      memset(qs.slot, 255, sizeof qs.slot);
-      memset(sq.slot, 0, sizeof sq.slot);
-      for (size_t k = 0; k < quals.size(); k++) { qs.slot[quals[k]] = (uint8_t)k; sq.slot[k] = (uint8_t)quals[k]; }
-      if (!chk && !quals.empty() && quals.size() < 255 && cbytes + 16 <= lds_budget && lmax <= max_cycle) {
-        uint8_t *clut;
-        ELP_TRY(scratch(c, 4, cbytes + 64, &clut));
-        ELP_LAUNCH(c, "bqsr_apply_lut", k_compact_lut, dim3(blocks_for(cbytes, 256)), dim3(256), 0, (const uint8_t *)dl, clut, c->n_cov, (int)quals.size(),
-                   lmax, max_cycle, sq);
-        A.clut = clut;
-        const size_t dyn = (cbytes + 15) & ~(size_t)15;
-        ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bqsr_apply_flat<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-        const unsigned g1 = (unsigned)std::min<uint64_t>(nsteps, (uint64_t)c->n_cu);
-        ELP_LAUNCH(c, "bqsr_apply", (k_bqsr_apply_flat<false, true>), dim3(g1), dim3(1024), dyn, A, qs);
-      } else if (chk) {
-        ELP_LAUNCH(c, "bqsr_apply", (k_bqsr_apply_flat<true, false>), dim3(grid), dim3(FL_THREADS), 0, A, qs);
+                  nullptr, nullptr, c->n_cov, 0, 0, lmax, 0};
+      int mode = 0;
+      size_t dyn = 0;
+      const int n_qi = qhi - qlo + 1, w = 2 * lmax + 1;
+      const size_t static_lds = sizeof(FlatLds<AB::RMAX>) + (size_t)AB::RMAX * 12 + 512;
+      const size_t n_rows = (size_t)c->n_cov * (size_t)std::max(n_qi, 0) * (size_t)w, n1 = (size_t)c->n_cov * (size_t)(n_qi + 1) * (size_t)w;
+      if (!chk && qhi >= 0 && lmax <= max_cycle && n1 + static_lds <= 160 * 1024 && n_rows < (1u << 22)) {
+        // distinct rows of the resident part of the LUT (three small kernels, one read-back of their number)
+        uint32_t n_slots = 1024;
+        while (n_slots < 2 * n_rows) n_slots <<= 1;
+        const uint32_t t2_cap = 3855;  // 16-bit byte offsets
+        uint32_t *wk;
+        ELP_TRY(scratch(c, 4, (size_t)2 * n_slots + n_rows + n1 + (size_t)(t2_cap + 1) * 5 + 64, &wk));
+        uint32_t *slots = wk, *slot_id = wk + n_slots, *row_slot = wk + 2 * (size_t)n_slots, *counter = c->err_flag.p + 3;
+        uint16_t *t1 = reinterpret_cast<uint16_t *>(row_slot + n_rows);
+        uint8_t *t2 = reinterpret_cast<uint8_t *>(t1 + ((n1 + 1) & ~(size_t)1));
+        ELP_HIP(c, hipMemsetAsync(slots, 0xFF, (size_t)n_slots * 4, c->stream));
+        ELP_HIP(c, hipMemsetAsync(counter, 0, 4, c->stream));
+        LutRows R{dl, c->n_cov, qlo, n_qi, lmax, max_cycle};
+        ELP_LAUNCH(c, "bqsr_apply_lut", k_lut_rows_insert, dim3(blocks_for(n_rows, 256)), dim3(256), 0, R, (int)n_rows, slots, n_slots - 1, row_slot);
+        ELP_LAUNCH(c, "bqsr_apply_lut", k_lut_rows_number, dim3(blocks_for(n_slots, 256)), dim3(256), 0, R, (const uint32_t *)slots, n_slots, slot_id, counter, t2, t2_cap);
+        ELP_LAUNCH(c, "bqsr_apply_lut", k_lut_rows_index, dim3(blocks_for(std::max<size_t>(n1, 17), 256)), dim3(256), 0, R, (const uint32_t *)row_slot,
+                   (const uint32_t *)slot_id, (const uint32_t *)counter, t1, t2, t2_cap);
+        uint32_t n_dict = 0;
+        ELP_HIP(c, hipMemcpyAsync(&n_dict, counter, 4, hipMemcpyDeviceToHost, c->stream));
+        ELP_HIP(c, hipStreamSynchronize(c->stream));
+        ELP_HIP(c, hipMemsetAsync(counter, 0, 4, c->stream));
+        if (n_dict < t2_cap) {
+          const int m = n_dict + 1 <= 256 ? 1 : 2;
+          const size_t bytes = ((n1 * (size_t)m + 15) & ~(size_t)15) + (size_t)(n_dict + 1) * (m == 1 ? 32 : 17) + 16;
+          if (bytes + static_lds <= 160 * 1024) {
+            mode = m;
+            dyn = bytes;
+            A.t1 = t1; A.t2 = t2; A.n_qi = n_qi; A.qlo = qlo; A.n_dict = (int)n_dict;
+          }
+        }
+      }
+      if (mode) {
+        const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / (dyn + static_lds)));
+        const unsigned g1 = (unsigned)std::min<uint64_t>(nsteps, (uint64_t)c->n_cu * per_cu);
+        if (mode == 1) {
+          ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bqsr_apply_flat<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+          ELP_LAUNCH(c, "bqsr_apply", (k_bqsr_apply_flat<false, 1>), dim3(g1), dim3(FL_THREADS), dyn, A);
+        } else {
+          ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bqsr_apply_flat<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+          ELP_LAUNCH(c, "bqsr_apply", (k_bqsr_apply_flat<false, 2>), dim3(g1), dim3(FL_THREADS), dyn, A);
+        }
       } else {
-        ELP_LAUNCH(c, "bqsr_apply", (k_bqsr_apply_flat<false, false>), dim3(grid), dim3(FL_THREADS), 0, A, qs);
+        const unsigned grid = (unsigned)std::min<uint64_t>(nsteps, (uint64_t)c->n_cu * 8);
+        if (chk) ELP_LAUNCH(c, "bqsr_apply", (k_bqsr_apply_flat<true, 0>), dim3(grid), dim3(FL_THREADS), 0, A);
+        else ELP_LAUNCH(c, "bqsr_apply", (k_bqsr_apply_flat<false, 0>), dim3(grid), dim3(FL_THREADS), 0, A);
       }
     }
   }

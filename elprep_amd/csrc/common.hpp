@@ -125,6 +125,16 @@ struct elp_ctx {
   elp::DVec<int64_t> d_n_sites;
   bool bqsr_ptrs_dirty = true;
 
+  // BQSR count tables in HBM (elp_bqsr_gather_device): [n_cov][94][2] | [n_cov][94][2 max_cycle + 1][2] | [n_cov][94][16][2], then
+  // TABLES_TAIL spare values (the duplication counters ride behind the tables through the all-reduce, group.hip)
+  static constexpr size_t TABLES_TAIL = 4096;
+  elp::DVec<unsigned long long> dev_tables;
+  size_t tables_n = 0;
+  int tables_max_cycle = 0;
+  // device group (group.hip)
+  void *comm = nullptr;  // ncclComm_t
+  int group_rank = 0, group_world = 1;
+
   // snapshot of the mutable columns
   elp::DVec<uint16_t> snap_flag;
   elp::DVec<uint8_t> snap_qual;
@@ -266,5 +276,6 @@ int exclusive_scan_u32(elp_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n
 int ensure_adapted(elp_ctx *c, bool check_quals = true);
 int ensure_qual_present(elp_ctx *c, bool exact = false);  // exact: scan the whole column instead of a sample
 int fetch_err(elp_ctx *c, uint32_t *words /* 4 */);
+void group_release(elp_ctx *c);
 
 }  // namespace elp

@@ -122,6 +122,7 @@ void elp_destroy(elp_ctx *c) {
   for (auto p : c->h_sites) if (p) (void)hipFree(p);
   for (auto p : c->h_site_idx) if (p) (void)hipFree(p);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+  group_release(c);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }

@@ -151,6 +151,49 @@ class Engine:
         self._check(self.L.elp_bqsr_gather(self.h, max_cycle, _vp(qt), _vp(ct), _vp(xt)))
         return qt, ct, xt
 
+    # ---- device-resident tables and the device group (include/elprep_hip.h: the `sfm` merge phase's sums)
+    def recalibrate_device(self, max_cycle: int = 500):
+        """Recalibrate, tables stay in HBM (for tables_add / tables_allreduce); tables_fetch copies them out."""
+        self._max_cycle = max_cycle
+        self._check(self.L.elp_bqsr_gather_device(self.h, max_cycle))
+
+    def tables_add(self, other: "Engine"):
+        """device tables of this context += those of `other` (another split of the same rank, same GPU)"""
+        self._check(self.L.elp_bqsr_tables_add(self.h, other.h))
+
+    def tables_allreduce(self, counters: Optional[np.ndarray] = None) -> Optional[np.ndarray]:
+        """ONE RCCL all-reduce (sum, int64) of the device tables over the context's group, in place in HBM; `counters` (int64,
+        e.g. the duplication counters) ride behind them and come back summed.  A group of one: no-op."""
+        if counters is None:
+            self._check(self.L.elp_bqsr_tables_allreduce(self.h, C.c_void_p(0), 0))
+            return None
+        c = np.ascontiguousarray(counters, dtype=np.int64).copy()
+        self._check(self.L.elp_bqsr_tables_allreduce(self.h, _vp(c), c.size))
+        return c.reshape(np.shape(counters))
+
+    def tables_fetch(self, reuse: bool = False):
+        max_cycle = self._max_cycle
+        ncyc = 2 * max_cycle + 1
+        nc = self.header.n_cov
+        bufs = getattr(self, "_tables", None) if reuse else None
+        if bufs is None or bufs[0] != (nc, max_cycle):
+            bufs = ((nc, max_cycle), np.zeros((nc, NQUAL, 2), dtype=np.int64), np.zeros((nc, NQUAL, ncyc, 2), dtype=np.int64),
+                    np.zeros((nc, NQUAL, NCTX, 2), dtype=np.int64))
+            if reuse:
+                self._tables = bufs
+        _, qt, ct, xt = bufs
+        self._check(self.L.elp_bqsr_tables_fetch(self.h, _vp(qt), _vp(ct), _vp(xt)))
+        return qt, ct, xt
+
+    def group_init(self, rank: int, world: int, uid: Optional[bytes]):
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid) if uid is not None else None
+        self._check(self.L.elp_group_init(self.h, rank, world, buf))
+
+    def allreduce_i64(self, a: np.ndarray) -> np.ndarray:
+        out = np.ascontiguousarray(a, dtype=np.int64).copy()
+        self._check(self.L.elp_allreduce_i64(self.h, _vp(out), out.size))
+        return out.reshape(a.shape)
+
     def apply_bqsr(self, lut: np.ndarray, cov_present: np.ndarray, max_cycle: int = 500, fetch: bool = True) -> Optional[np.ndarray]:
         lut = np.ascontiguousarray(lut, dtype=np.uint8)
         cp = np.ascontiguousarray(cov_present, dtype=np.uint8)
@@ -181,6 +224,15 @@ class Engine:
             self._check(self.L.elp_profile_get(self.h, i, C.byref(name), C.byref(cnt), C.byref(ms)))
             out[name.value.decode()] = (int(cnt.value), float(ms.value))
         return out
+
+
+def group_unique_id() -> bytes:
+    """ncclUniqueId made by rank 0; the host passes the 128 bytes to the other ranks (any channel)."""
+    buf = (C.c_uint8 * 128)()
+    rc = _lib.hip().elp_group_unique_id(buf)
+    if rc != 0:
+        raise ElpError(rc, "elp_group_unique_id failed (RCCL not loadable?)")
+    return bytes(buf)
 
 
 class BqsrTables:

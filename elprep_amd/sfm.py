@@ -246,13 +246,27 @@ def merge_splits(groups: List[Batch], spread: Batch, unmapped: Batch) -> Batch:
 
 # ------------------------------------------------------------------------------------------------ per-rank driver
 class SfmRank:
-    """The splits of one rank on one GPU: context 0 = its group splits, context 1 = the spread split (if owned)."""
+    """The splits of one rank on one GPU: context 0 = its group splits, context 1 = the spread split (if owned).
 
-    def __init__(self, header: Header, device_ordinal: int, comm: Comm):
-        from .engine import Engine
+    collective = "cabi": the tables stay in HBM, the two contexts are summed on the device and ONE ncclAllReduce over the device
+    group of the C ABI (elp_group_init / elp_bqsr_tables_allreduce: RCCL over xGMI, no host hop) merges tables + duplication
+    counters of all ranks; the group id is made by rank 0 and handed round with one torch.distributed broadcast (a Go host would
+    use a file next to its split files).  collective = "torch": the tables go through the host and torch.distributed - what the CPU
+    tests (gloo) and ranks that share one GPU use.  Default: "cabi" when every rank has its own GPU (nccl backend)."""
+
+    def __init__(self, header: Header, device_ordinal: int, comm: Comm, collective: Optional[str] = None):
+        import os
+        from .engine import Engine, group_unique_id
         self.header, self.comm = header, comm
         self.engines = [Engine(header, device_ordinal), Engine(header, device_ordinal)]
         self.n = [0, 0]
+        if collective is None:
+            collective = os.environ.get("ELP_SFM_COLLECTIVE", "cabi" if (comm.world > 1 and comm.device.type == "cuda") else "torch")
+        self.collective = collective if comm.world > 1 else "none"
+        if self.collective == "cabi":
+            box = [group_unique_id() if comm.rank == 0 else None]
+            comm.dist.broadcast_object_list(box, src=0)
+            self.engines[0].group_init(comm.rank, comm.world, box[0])
 
     def stage(self, which: int, b: Batch):
         if b.n:
@@ -280,23 +294,36 @@ class SfmRank:
             e.sync()
 
     def gather(self, max_cycle: int, pixel_dist: int = 100):
-        """sort + mark duplicates + duplication metrics + BQSR tables of every split of this rank, then THE all-reduce."""
-        tot = None
+        """mark duplicates + sort + duplication metrics + BQSR tables of every split of this rank, then THE all-reduce."""
+        if self.collective == "torch":
+            tot = None
+            for e in self.engines:
+                e.mark_duplicates(True, fetch=False)
+                e.sort_coordinate(fetch=False)  # the sort is the Finalize step behind the filters (sam/filter-pipeline.go:116)
+                ctr = e.dup_metrics(pixel_dist)
+                qt, ct, xt = e.recalibrate(max_cycle)
+                flat = np.concatenate([qt.ravel(), ct.ravel(), xt.ravel(), ctr.ravel()])
+                tot = flat if tot is None else tot + flat
+                shapes = (qt.shape, ct.shape, xt.shape, ctr.shape)
+            tot = self.comm.allreduce_i64(tot)
+            out, at = [], 0
+            for shp in shapes:
+                n = int(np.prod(shp))
+                out.append(tot[at:at + n].reshape(shp))
+                at += n
+            return tuple(out)  # (qual table, cycle table, context table, duplication counters): identical on every rank
+        ctr = None
         for e in self.engines:
             e.mark_duplicates(True, fetch=False)
-            e.sort_coordinate(fetch=False)  # the sort is the Finalize step behind the filters (sam/filter-pipeline.go:116)
-            ctr = e.dup_metrics(pixel_dist)
-            qt, ct, xt = e.recalibrate(max_cycle)
-            flat = np.concatenate([qt.ravel(), ct.ravel(), xt.ravel(), ctr.ravel()])
-            tot = flat if tot is None else tot + flat
-            shapes = (qt.shape, ct.shape, xt.shape, ctr.shape)
-        tot = self.comm.allreduce_i64(tot)
-        out, at = [], 0
-        for shp in shapes:
-            n = int(np.prod(shp))
-            out.append(tot[at:at + n].reshape(shp))
-            at += n
-        return tuple(out)  # (qual table, cycle table, context table, duplication counters): identical on every rank
+            e.sort_coordinate(fetch=False)
+            c7 = e.dup_metrics(pixel_dist)
+            ctr = c7 if ctr is None else ctr + c7
+            e.recalibrate_device(max_cycle)  # tables stay in HBM
+        e0 = self.engines[0]
+        e0.tables_add(self.engines[1])       # this rank's splits, summed on the device
+        ctr = e0.tables_allreduce(ctr)       # RCCL, in place on the tables in HBM; the counters ride along
+        qt, ct, xt = e0.tables_fetch(reuse=True)
+        return qt, ct, xt, ctr
 
     def apply(self, lut: np.ndarray, present: np.ndarray, max_cycle: int):
         for e in self.engines:

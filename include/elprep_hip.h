@@ -157,6 +157,30 @@ int elp_bqsr_set_known_sites(elp_ctx *ctx, int32_t refid, const int32_t *start_e
 #define ELP_NCTX 16
 int elp_bqsr_gather(elp_ctx *ctx, int max_cycle, int64_t *qual_tbl, int64_t *cycle_tbl, int64_t *ctx_tbl);
 
+/* The same, but the tables stay in HBM (ctx-owned) for the device group's all-reduce below; elp_bqsr_tables_fetch copies them out. */
+int elp_bqsr_gather_device(elp_ctx *ctx, int max_cycle);
+int elp_bqsr_tables_fetch(elp_ctx *ctx, int64_t *qual_tbl, int64_t *cycle_tbl, int64_t *ctx_tbl);
+
+/* ---- device group and its one collective: the table / metrics combination of `elprep sfm`'s merge phase ----
+ * LoadAndCombineBQSRTables (filters/print-bqsr.go:310-329) and LoadAndCombineDuplicateMetrics
+ * (filters/mark-optical-duplicates.go:711-731) sum what the per-split `filter --bqsr-tables-only` runs produced.  One process per
+ * GPU; rank 0 makes the group id (RCCL's ncclUniqueId) and the host hands it to the other ranks by whatever channel it has (the Go
+ * host: a file next to the split files, or its parent `sfm` process); every rank then joins with its context.  A group of one needs
+ * no id and makes every collective a no-op.
+ *   elp_bqsr_tables_add        dst += src on the device: the contexts (splits) of ONE rank are summed before the collective
+ *   elp_bqsr_tables_allreduce  ONE ncclAllReduce(ncclInt64, ncclSum) over xGMI, in place on the tables in HBM; `counters`
+ *                              (n_counters <= 4096 int64 in host memory, e.g. the duplication counters) ride behind the tables
+ *                              through the same call and come back summed
+ *   elp_allreduce_i64          the same collective for a plain host buffer */
+#define ELP_GROUP_ID_BYTES 128
+int elp_group_unique_id(uint8_t *id_out /* ELP_GROUP_ID_BYTES */);
+int elp_group_init(elp_ctx *ctx, int rank, int world, const uint8_t *id /* ELP_GROUP_ID_BYTES; may be NULL if world == 1 */);
+int elp_group_rank(const elp_ctx *ctx);
+int elp_group_size(const elp_ctx *ctx);
+int elp_bqsr_tables_add(elp_ctx *dst, elp_ctx *src);
+int elp_bqsr_tables_allreduce(elp_ctx *ctx, int64_t *counters, size_t n_counters);
+int elp_allreduce_i64(elp_ctx *ctx, int64_t *buf, size_t n);
+
 /* ---- BQSR apply: BaseRecalibratorTables.ApplyBQSR (filters/bqsr.go:936-1005) ----
  * lut: [n_cov][94][2*max_cycle+1][17] bytes = the reference's memo map applyKey{rg, qual, cycle, context} -> uint8,
  * densely tabulated by the host from the finalized tables (context index 16 = key -1); cov_present[c] = 0 means the read

@@ -207,3 +207,64 @@ def test_bench_workload_against_the_oracle():
     got = e.apply_bqsr(lut, present, 500)
     assert np.array_equal(got, orc.BqsrFinal(oq, oc, ox, 500).apply(b, h, 0))
     e.close()
+
+
+def test_device_tables_add_allreduce_fetch():
+    """The device-resident side of the C ABI's collective: tables of two contexts of one rank summed in HBM, the all-reduce of a
+    group of one (a no-op that still returns the counters), fetch - equal to the host-side sum of the per-context tables."""
+    cfg, b, h, refs, sites = dataset("tiny", 4000, 1, 0.05)
+    half = b.n // 2 & ~1
+    parts = [b.take(np.arange(0, half)), b.take(np.arange(half, b.n))]
+    engines, host = [], None
+    for p in parts:
+        e = Engine(h)
+        e.stage(p)
+        e.mark_duplicates(True)
+        for r in range(h.n_ref):
+            e.set_reference(r, refs[r])
+            e.set_known_sites(r, sites[r])
+        t = e.recalibrate(500)
+        host = [x.copy() for x in t] if host is None else [a + x for a, x in zip(host, t)]
+        e.recalibrate_device(500)
+        engines.append(e)
+    e0 = engines[0]
+    e0.group_init(0, 1, None)
+    e0.tables_add(engines[1])
+    ctr = np.arange(21, dtype=np.int64).reshape(3, 7)
+    assert np.array_equal(e0.tables_allreduce(ctr), ctr)
+    assert np.array_equal(e0.allreduce_i64(ctr), ctr)
+    got = e0.tables_fetch()
+    for a, x in zip(got, host):
+        assert np.array_equal(a, x)
+    assert got[0][..., 0].sum() > 0
+    for e in engines:
+        e.close()
+
+
+def test_group_of_two_processes():
+    """Two processes, one GPU each, the group id handed over in a file (as a Go host would): ncclAllReduce through the C ABI.
+    Skipped without two GPUs."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import os, subprocess, sys, tempfile
+    d = tempfile.mkdtemp()
+    code = r"""
+import os, sys, time, numpy as np
+sys.path.insert(0, %r)
+from elprep_amd.engine import Engine, group_unique_id
+from tests import kat_cases
+rank, d = int(sys.argv[1]), sys.argv[2]
+e = Engine(kat_cases.header2(), rank)
+idf = os.path.join(d, "id")
+if rank == 0:
+    open(idf + ".tmp", "wb").write(group_unique_id()); os.rename(idf + ".tmp", idf)
+while not os.path.exists(idf): time.sleep(0.05)
+e.group_init(rank, 2, open(idf, "rb").read())
+out = e.allreduce_i64(np.arange(1000, dtype=np.int64) * (rank + 1))
+assert np.array_equal(out, np.arange(1000, dtype=np.int64) * 3)
+print("ok", rank)
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), d], stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
