@@ -20,10 +20,12 @@ _host: Optional[C.CDLL] = None
 
 HIP_SYMBOLS = [
     "elp_create", "elp_destroy", "elp_last_error", "elp_sync", "elp_stream", "elp_set_header", "elp_reserve", "elp_stage", "elp_reset",
-    "elp_num_records", "elp_num_sorted", "elp_sort_coordinate", "elp_get_permutation", "elp_mark_duplicates", "elp_get_flags", "elp_get_adapted",
+    "elp_num_records", "elp_num_qual_bytes", "elp_num_sorted", "elp_sort_coordinate", "elp_get_permutation", "elp_mark_duplicates", "elp_get_flags", "elp_get_adapted",
     "elp_dup_metrics", "elp_dup_metrics_hist", "elp_bqsr_set_reference", "elp_bqsr_set_known_sites", "elp_bqsr_gather", "elp_bqsr_apply", "elp_get_qual",
     "elp_bqsr_gather_device", "elp_bqsr_tables_fetch", "elp_group_unique_id", "elp_group_init", "elp_group_rank", "elp_group_size",
     "elp_bqsr_tables_add", "elp_bqsr_tables_allreduce", "elp_allreduce_i64",
+    "elp_filter_records", "elp_split_classify", "elp_merge_spread",
+    "elp_set_read_group_ids", "elp_pinned_alloc", "elp_pinned_free", "elp_stage_bam", "elp_emit_sorted_bam",
     "elp_snapshot", "elp_rollback", "elp_profile_enable", "elp_profile_reset", "elp_profile_count", "elp_profile_get",
 ]
 HOST_SYMBOLS = [
@@ -53,6 +55,8 @@ def hip() -> C.CDLL:
         L.elp_last_error.argtypes = [C.c_void_p]
         L.elp_num_records.restype = C.c_uint64
         L.elp_num_records.argtypes = [C.c_void_p]
+        L.elp_num_qual_bytes.restype = C.c_uint64
+        L.elp_num_qual_bytes.argtypes = [C.c_void_p]
         L.elp_num_sorted.restype = C.c_uint64
         L.elp_num_sorted.argtypes = [C.c_void_p]
         L.elp_stream.restype = C.c_void_p
@@ -76,6 +80,16 @@ def hip() -> C.CDLL:
         L.elp_bqsr_gather.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.elp_bqsr_apply.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.elp_get_qual.argtypes = [C.c_void_p, C.c_void_p]
+        L.elp_set_read_group_ids.argtypes = [C.c_void_p, C.c_void_p]
+        L.elp_pinned_alloc.restype = C.c_void_p
+        L.elp_pinned_alloc.argtypes = [C.c_size_t]
+        L.elp_pinned_free.restype = None
+        L.elp_pinned_free.argtypes = [C.c_void_p]
+        L.elp_stage_bam.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint16]
+        L.elp_emit_sorted_bam.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.elp_filter_records.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.elp_split_classify.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.elp_merge_spread.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.elp_bqsr_gather_device.argtypes = [C.c_void_p, C.c_int]
         L.elp_bqsr_tables_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.elp_group_unique_id.argtypes = [C.c_void_p]

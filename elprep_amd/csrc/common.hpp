@@ -71,7 +71,9 @@ struct elp_ctx {
 
   // staged columns
   uint64_t n = 0, qname_bytes = 0, cigar_ops = 0, seq_bytes = 0, qual_bytes = 0;
-  uint64_t n_sr = 0;  // staged records that carry the sr tag (dropped by RemoveOptionalReads: behind everything else in the permutation)
+  uint64_t n_sr = 0;  // staged records that carry the sr tag (dropped by RemoveOptionalReads) or were rejected by elp_filter_records:
+                      // behind everything else in the permutation
+  uint64_t n_filtered = 0;  // of those, rejected by elp_filter_records (state 2 in the has_sr column: no duplicate marking either)
   elp::DVec<int32_t> refid, pos, next_refid, pnext, tlen;
   elp::DVec<uint16_t> flag, rgid, split;
   elp::DVec<uint8_t> mapq, has_sr;
@@ -134,6 +136,17 @@ struct elp_ctx {
   // device group (group.hip)
   void *comm = nullptr;  // ncclComm_t
   int group_rank = 0, group_world = 1;
+
+  // records staged from BAM bytes (bam.hip): the inflated records stay in HBM, elp_emit_sorted_bam reads bases and tags from them
+  elp::DVec<uint8_t> raw;
+  elp::DVec<uint64_t> raw_off;  // per staged record: offset of its block_size field in raw (n + 1)
+  uint64_t raw_n = 0, raw_bytes = 0;
+  elp::DVec<uint8_t> rg_ids;    // header read-group ids, concatenated (RG:Z -> rgid)
+  elp::DVec<uint32_t> rg_ids_off;
+  bool have_rg_ids = false;
+  hipStream_t copy_stream = nullptr;
+  void *bounce[2] = {nullptr, nullptr};  // pinned double buffer for pageable sources
+  hipEvent_t bounce_ev[2] = {nullptr, nullptr};
 
   // snapshot of the mutable columns
   elp::DVec<uint16_t> snap_flag;
@@ -277,5 +290,7 @@ int ensure_adapted(elp_ctx *c, bool check_quals = true);
 int ensure_qual_present(elp_ctx *c, bool exact = false);  // exact: scan the whole column instead of a sample
 int fetch_err(elp_ctx *c, uint32_t *words /* 4 */);
 void group_release(elp_ctx *c);
+int stage_reserve(elp_ctx *c, uint64_t n, uint64_t qb, uint64_t co, uint64_t sb, uint64_t lb);  // grows the staged columns (ctx.hip)
+int stage_recode_seq(elp_ctx *c, uint64_t from, uint64_t bytes);                               // BAM nibbles -> code nibbles on seq4[from, from + bytes)
 
 }  // namespace elp

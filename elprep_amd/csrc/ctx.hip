@@ -82,6 +82,12 @@ __global__ __launch_bounds__(256) void k_recode_seq(uint8_t *__restrict__ seq, u
   }
 }
 
+int stage_recode_seq(elp_ctx *c, uint64_t from, uint64_t bytes) {
+  hipLaunchKernelGGL(k_recode_seq, dim3(blocks_for((bytes + 15) / 16, 256)), dim3(256), 0, c->stream, c->seq4.p + from, bytes);
+  ELP_HIP(c, hipGetLastError());
+  return 0;
+}
+
 int fetch_err(elp_ctx *c, uint32_t *words) {
   ELP_HIP(c, hipMemcpyAsync(words, c->err_flag.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   ELP_HIP(c, hipStreamSynchronize(c->stream));
@@ -122,6 +128,11 @@ void elp_destroy(elp_ctx *c) {
   for (auto p : c->h_sites) if (p) (void)hipFree(p);
   for (auto p : c->h_site_idx) if (p) (void)hipFree(p);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+  for (int k = 0; k < 2; k++) {
+    if (c->bounce[k]) (void)hipHostFree(c->bounce[k]);
+    if (c->bounce_ev[k]) (void)hipEventDestroy(c->bounce_ev[k]);
+  }
+  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   group_release(c);
   (void)hipStreamDestroy(c->stream);
   delete c;
@@ -167,7 +178,9 @@ int elp_set_header(elp_ctx *c, const elp_header *h) {
   return 0;
 }
 
-static int reserve_locked(elp_ctx *c, uint64_t n, uint64_t qb, uint64_t co, uint64_t sb, uint64_t lb) {
+}  // extern "C"
+namespace elp {
+int stage_reserve(elp_ctx *c, uint64_t n, uint64_t qb, uint64_t co, uint64_t sb, uint64_t lb) {
   bool keep = c->n > 0;
   ELP_TRY(ensure(c, c->refid, n, keep, c->n));
   ELP_TRY(ensure(c, c->pos, n, keep, c->n));
@@ -190,12 +203,14 @@ static int reserve_locked(elp_ctx *c, uint64_t n, uint64_t qb, uint64_t co, uint
   ELP_TRY(ensure(c, c->qual, lb + 32, keep, c->qual_bytes));
   return 0;
 }
+}  // namespace elp
+extern "C" {
 
 int elp_reserve(elp_ctx *c, uint64_t n, uint64_t qb, uint64_t co, uint64_t sb, uint64_t lb) {
   if (!c) return ELP_ERR_ARG;
   std::lock_guard<std::mutex> g(c->stage_mu);
   ELP_HIP(c, hipSetDevice(c->device));
-  return reserve_locked(c, n, qb, co, sb, lb);
+  return stage_reserve(c, n, qb, co, sb, lb);
 }
 
 int elp_reset(elp_ctx *c) {
@@ -203,6 +218,8 @@ int elp_reset(elp_ctx *c) {
   std::lock_guard<std::mutex> g(c->stage_mu);
   c->n = c->qname_bytes = c->cigar_ops = c->seq_bytes = c->qual_bytes = 0;
   c->n_sr = 0;
+  c->n_filtered = 0;
+  c->raw_n = c->raw_bytes = 0;
   c->max_split = 0;
   c->max_qname_len = c->max_l_seq = 0;
   c->max_pos = 0;
@@ -215,6 +232,7 @@ int elp_reset(elp_ctx *c) {
 
 uint64_t elp_num_records(const elp_ctx *c) { return c ? c->n : 0; }
 uint64_t elp_num_sorted(const elp_ctx *c) { return c ? c->n - c->n_sr : 0; }
+uint64_t elp_num_qual_bytes(const elp_ctx *c) { return c ? c->qual_bytes : 0; }
 
 int elp_stage(elp_ctx *c, const elp_batch *b) {
   if (!c || !b) return ELP_ERR_ARG;
@@ -226,7 +244,7 @@ int elp_stage(elp_ctx *c, const elp_batch *b) {
   if (c->n + n > 0xFFFFFFF0ull) return set_error(c, ELP_ERR_UNSUPPORTED, "more than 2^32-16 records per context");
   uint64_t q0 = b->qname_off[0], c0 = b->cigar_off[0], s0 = b->seq_off[0], l0 = b->qual_off[0];
   uint64_t qb = b->qname_off[n] - q0, co = b->cigar_off[n] - c0, sb = b->seq_off[n] - s0, lb = b->qual_off[n] - l0;
-  ELP_TRY(reserve_locked(c, c->n + n, c->qname_bytes + qb, c->cigar_ops + co, c->seq_bytes + sb, c->qual_bytes + lb));
+  ELP_TRY(stage_reserve(c, c->n + n, c->qname_bytes + qb, c->cigar_ops + co, c->seq_bytes + sb, c->qual_bytes + lb));
   // host-side scan for limits the kernels rely on
   uint64_t n_sr = 0;
   uint32_t max_split = c->max_split;

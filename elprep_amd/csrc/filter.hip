@@ -1,0 +1,238 @@
+// filter.hip — the per-record predicates next to the hot path, evaluated on the column store, and the `elprep split` / `merge`
+// bookkeeping done in HBM.
+//
+// (1) Fused predicates.  Reference: filters/simple-filters.go — RemoveUnmappedReads :73-75, RemoveUnmappedReadsStrict :79-83,
+//     RemoveNonExactMappingReads :90-99, RemoveDuplicateReads :136-138, RemoveNonOverlappingReads :310-328 (+ intervals.Overlap,
+//     intervals/intervals.go:146-160), RemoveMappingQualityLessThan :332-347.  In `elprep filter` they stand in FRONT of AddREFID
+//     and MarkDuplicates in filters1 (cmd/filter.go:696-803): a read they reject never reaches duplicate marking, the sort, the
+//     metrics or BQSR.  Here one kernel evaluates the selected predicates for every staged record and marks the rejected ones in the
+//     record-state column (2 = filtered; 1 = sr-tagged copy, which still takes part in duplicate marking): every later stage skips
+//     them, the sort puts them behind the output (elp_num_sorted).
+// (2) `elprep split`: SplitFilePerChromosome's routing rule (sam/split-merge.go:280-293) per record — split of RNAME and the
+//     "spread" test — and the per-split record counts, so that a host can partition a staged file across GPUs without touching the
+//     payload on the CPU.
+// (3) `elprep merge`: MergeSortedFilesSplitPerChromosome (sam/split-merge.go:410-576) as a rank computation: where every record of
+//     the coordinate-sorted spread split goes among the concatenated, coordinate-sorted group splits (behind all group reads of
+//     its position).
+#include "common.hpp"
+
+namespace elp {
+
+struct FilterCols {
+  uint64_t n;
+  const int32_t *refid, *pos;
+  const uint16_t *flag;
+  const uint8_t *mapq;
+  const uint64_t *cigar_off;
+  const uint32_t *cigar;
+  uint8_t *state;  // has_sr column: 0 live, 1 sr-tagged, 2 filtered
+  int32_t n_ref;
+  int32_t *const *regions;   // per refid: [n][2] Start, End of intervals.FromBed, sorted by Start and flattened
+  const int64_t *n_regions;
+};
+
+// intervals.Overlap, intervals/intervals.go:146-160 (binary search, same comparisons)
+__device__ inline bool overlap(const int32_t *iv, int64_t n, int32_t start, int32_t end) {
+  int64_t left = 0, right = n - 1;
+  while (left <= right) {
+    const int64_t mid = (left + right) / 2;
+    const int32_t is = iv[2 * mid], ie = iv[2 * mid + 1];
+    if (is > end - 1) right = mid - 1;
+    else if (ie <= start - 1) left = mid + 1;
+    else return true;
+  }
+  return false;
+}
+
+__global__ __launch_bounds__(256) void k_filter_records(FilterCols m, elp_predicates p, unsigned long long *n_dropped) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool drop = false;
+  if (i < m.n && m.state[i] != 2) {
+    const uint16_t f = m.flag[i];
+    const int32_t r = m.refid[i], ps = m.pos[i];
+    if (p.remove_unmapped && (f & F_UNMAPPED)) drop = true;
+    if (p.remove_unmapped_strict && ((f & F_UNMAPPED) || ps == 0 || r < 0)) drop = true;
+    if (p.min_mapq > 0 && (p.min_mapq > 255 || (int)m.mapq[i] < p.min_mapq)) drop = true;
+    if (p.remove_duplicates && (f & F_DUPLICATE)) drop = true;
+    if (!drop && (p.remove_non_exact || p.use_regions)) {
+      int32_t ref_len = 0, read_len = 0;
+      bool exact = true;
+      for (uint64_t k = m.cigar_off[i]; k < m.cigar_off[i + 1]; k++) {
+        const uint32_t c = m.cigar[k], op = c & 0xF;
+        const int32_t ln = (int32_t)(c >> 4);
+        if (op != OP_M && op != OP_S) exact = false;  // nonExactMappingOperator: I D N H P X =
+        if (op_consumes_ref(op)) ref_len += ln;
+        if (op_consumes_read(op)) read_len += ln;
+      }
+      if (p.remove_non_exact && !exact) drop = true;
+      if (!drop && p.use_regions) {
+        int32_t a_end = ps;  // :318-324
+        if (!(f & F_UNMAPPED) && read_len > 0) a_end = ps + ref_len - 1;
+        drop = !(r >= 0 && r < m.n_ref && overlap(m.regions[r], m.n_regions[r], ps, a_end));
+      }
+    }
+    if (drop) {
+      drop = m.state[i] == 0;  // a tagged copy that is rejected was already counted among the records that leave the output
+      m.state[i] = 2;
+    }
+  }
+  const unsigned long long b = __ballot(drop);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_dropped, (unsigned long long)__popcll(b));
+}
+
+// ---- split: routing rule of SplitFilePerChromosome
+__global__ __launch_bounds__(256) void k_split_classify(uint64_t n, const int32_t *__restrict__ refid, const int32_t *__restrict__ next_refid,
+                                                        const int32_t *__restrict__ group_of_ref, int32_t n_ref, int32_t n_groups,
+                                                        uint16_t *__restrict__ split_out, uint8_t *__restrict__ spread_out,
+                                                        unsigned long long *__restrict__ counts /* [n_groups + 2]: unmapped, groups, spread */) {
+  extern __shared__ unsigned int lds_cnt[];
+  for (int k = threadIdx.x; k < n_groups + 2; k += blockDim.x) lds_cnt[k] = 0;
+  __syncthreads();
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const int32_t r = refid[i], nr = next_refid[i];
+    const int32_t g = (r >= 0 && r < n_ref) ? group_of_ref[r] : 0;       // contigToGroup["*"] = "unmapped" (:254)
+    const int32_t gn = (nr >= 0 && nr < n_ref) ? group_of_ref[nr] : 0;
+    // :286: RNEXT != "=" (BAM: next_refid != refid, sam/bam-files.go:344-346), RNAME != "*", and the mate's group differs
+    const bool spread = nr != r && r >= 0 && gn != g;
+    split_out[i] = (uint16_t)g;
+    spread_out[i] = spread ? 1 : 0;
+    atomicAdd(&lds_cnt[g], 1u);
+    if (spread) atomicAdd(&lds_cnt[n_groups + 1], 1u);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < n_groups + 2; k += blockDim.x)
+    if (lds_cnt[k]) atomicAdd(&counts[k], (unsigned long long)lds_cnt[k]);
+}
+
+// ---- merge: spread read j (key ks[j]) goes behind every group read with key <= ks[j]
+__global__ __launch_bounds__(256) void k_merge_rank(uint64_t ng, const uint64_t *__restrict__ kg, uint64_t ns, const uint64_t *__restrict__ ks,
+                                                    uint64_t *__restrict__ slot_of_spread) {
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ns) return;
+  const uint64_t key = ks[j];
+  uint64_t lo = 0, hi = ng;  // first group read with key > ks[j]
+  while (lo < hi) {
+    const uint64_t mid = lo + (hi - lo) / 2;
+    if (kg[mid] <= key) lo = mid + 1; else hi = mid;
+  }
+  slot_of_spread[j] = lo + j;  // spread reads keep their own order
+}
+__global__ __launch_bounds__(256) void k_perm_keys(uint64_t n_out, const uint32_t *__restrict__ perm, const int32_t *__restrict__ refid,
+                                                   const int32_t *__restrict__ pos, uint64_t *__restrict__ keys) {
+  const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_out) return;
+  const uint32_t i = perm[k];
+  keys[k] = ((uint64_t)(uint32_t)refid[i] << 32) | (uint64_t)(uint32_t)pos[i];  // (refid, POS) as the merge loop compares them (:417-434)
+}
+
+}  // namespace elp
+
+using namespace elp;
+
+extern "C" {
+
+int elp_filter_records(elp_ctx *c, const elp_predicates *p, uint64_t *n_dropped_out) {
+  if (!c || !p) return ELP_ERR_ARG;
+  ELP_HIP(c, hipSetDevice(c->device));
+  if (p->use_regions && (!p->regions || !p->n_regions)) return set_error(c, ELP_ERR_ARG, "elp_filter_records: use_regions without regions");
+  const uint64_t n = c->n;
+  unsigned long long dropped = 0;
+  if (n) {
+    // target regions -> device (per refid pointer table)
+    std::vector<int32_t *> h_ptr((size_t)c->n_ref, nullptr);
+    std::vector<int64_t> h_cnt((size_t)c->n_ref, 0);
+    int32_t **d_ptr = nullptr;
+    int64_t *d_cnt = nullptr;
+    int32_t *pool = nullptr;
+    if (p->use_regions) {
+      size_t total = 0;
+      for (int r = 0; r < c->n_ref; r++) total += (size_t)p->n_regions[r];
+      uint8_t *blk;
+      ELP_TRY(scratch(c, 5, total * 8 + (size_t)c->n_ref * 16 + 64, &blk));
+      pool = reinterpret_cast<int32_t *>(blk);
+      d_ptr = reinterpret_cast<int32_t **>(blk + ((total * 8 + 15) & ~(size_t)15));
+      d_cnt = reinterpret_cast<int64_t *>(d_ptr + c->n_ref);
+      size_t at = 0;
+      for (int r = 0; r < c->n_ref; r++) {
+        const size_t k = (size_t)p->n_regions[r];
+        if (k) ELP_HIP(c, hipMemcpyAsync(pool + 2 * at, p->regions[r], k * 8, hipMemcpyHostToDevice, c->stream));
+        h_ptr[r] = pool + 2 * at;
+        h_cnt[r] = (int64_t)k;
+        at += k;
+      }
+      if (c->n_ref) {
+        ELP_HIP(c, hipMemcpyAsync(d_ptr, h_ptr.data(), (size_t)c->n_ref * sizeof(int32_t *), hipMemcpyHostToDevice, c->stream));
+        ELP_HIP(c, hipMemcpyAsync(d_cnt, h_cnt.data(), (size_t)c->n_ref * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+      }
+    }
+    unsigned long long *cnt;
+    ELP_TRY(scratch(c, 6, 4, &cnt));
+    ELP_HIP(c, hipMemsetAsync(cnt, 0, 8, c->stream));
+    FilterCols m{n, c->refid.p, c->pos.p, c->flag.p, c->mapq.p, c->cigar_off.p, c->cigar.p, c->has_sr.p, c->n_ref, d_ptr, d_cnt};
+    ELP_LAUNCH(c, "filter_records", k_filter_records, dim3(blocks_for(n, 256)), dim3(256), 0, m, *p, cnt);
+    ELP_HIP(c, hipMemcpyAsync(&dropped, cnt, 8, hipMemcpyDeviceToHost, c->stream));
+    ELP_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  c->n_sr += dropped;  // they leave the output like the tagged copies do
+  c->n_filtered += dropped;
+  c->adapted = c->sorted = c->marked = false;
+  if (n_dropped_out) *n_dropped_out = dropped;
+  return 0;
+}
+
+int elp_split_classify(elp_ctx *c, const int32_t *group_of_ref, int32_t n_groups, uint16_t *split_out, uint8_t *spread_out, uint64_t *counts_out) {
+  if (!c || !group_of_ref || n_groups < 0 || n_groups > 8000) return set_error(c, ELP_ERR_ARG, "elp_split_classify: bad arguments");
+  ELP_HIP(c, hipSetDevice(c->device));
+  const uint64_t n = c->n;
+  const size_t nc = (size_t)n_groups + 2;
+  uint8_t *blk;
+  ELP_TRY(scratch(c, 5, (size_t)c->n_ref * 4 + nc * 8 + n * 3 + 64, &blk));
+  int32_t *d_gof = reinterpret_cast<int32_t *>(blk);
+  unsigned long long *d_cnt = reinterpret_cast<unsigned long long *>(blk + (((size_t)c->n_ref * 4 + 15) & ~(size_t)15));
+  uint16_t *d_split = reinterpret_cast<uint16_t *>(d_cnt + nc);
+  uint8_t *d_spread = reinterpret_cast<uint8_t *>(d_split + n + 8);
+  if (c->n_ref) ELP_HIP(c, hipMemcpyAsync(d_gof, group_of_ref, (size_t)c->n_ref * 4, hipMemcpyHostToDevice, c->stream));
+  ELP_HIP(c, hipMemsetAsync(d_cnt, 0, nc * 8, c->stream));
+  if (n) {
+    const unsigned grid = std::min(blocks_for(n, 256), 2048u);
+    ELP_LAUNCH(c, "split_classify", k_split_classify, dim3(grid), dim3(256), nc * sizeof(unsigned int), n, (const int32_t *)c->refid.p,
+               (const int32_t *)c->next_refid.p, (const int32_t *)d_gof, c->n_ref, n_groups, d_split, d_spread, d_cnt);
+    if (split_out) ELP_HIP(c, hipMemcpyAsync(split_out, d_split, n * 2, hipMemcpyDeviceToHost, c->stream));
+    if (spread_out) ELP_HIP(c, hipMemcpyAsync(spread_out, d_spread, n, hipMemcpyDeviceToHost, c->stream));
+  }
+  std::vector<unsigned long long> h(nc);
+  ELP_HIP(c, hipMemcpyAsync(h.data(), d_cnt, nc * 8, hipMemcpyDeviceToHost, c->stream));
+  ELP_HIP(c, hipStreamSynchronize(c->stream));
+  if (counts_out)
+    for (size_t k = 0; k < nc; k++) counts_out[k] = h[k];
+  return 0;
+}
+
+int elp_merge_spread(elp_ctx *groups, elp_ctx *spread, uint64_t *slot_of_spread_out) {
+  if (!groups || !spread || groups == spread) return ELP_ERR_ARG;
+  if (!groups->sorted || !spread->sorted) return set_error(groups, ELP_ERR_ARG, "elp_merge_spread: both contexts must be coordinate-sorted");
+  if (groups->device != spread->device) return set_error(groups, ELP_ERR_ARG, "elp_merge_spread: contexts on different devices");
+  ELP_HIP(groups, hipSetDevice(groups->device));
+  // the mapped part of the groups' output (the unmapped split is appended behind the merge, :560-576)
+  const uint64_t ns = spread->n - spread->n_sr;
+  uint64_t *kg, *ks, *slots;
+  ELP_TRY(scratch(groups, 5, (groups->n + 8) + 2 * (ns + 8), &kg));
+  ks = kg + groups->n + 8;
+  slots = ks + ns + 8;
+  const uint64_t ng_all = groups->n - groups->n_sr;
+  ELP_HIP(groups, hipStreamSynchronize(spread->stream));
+  if (ng_all)
+    ELP_LAUNCH(groups, "merge_keys", k_perm_keys, dim3(blocks_for(ng_all, 256)), dim3(256), 0, ng_all, (const uint32_t *)groups->perm.p,
+               (const int32_t *)groups->refid.p, (const int32_t *)groups->pos.p, kg);
+  if (ns) {
+    ELP_LAUNCH(groups, "merge_keys", k_perm_keys, dim3(blocks_for(ns, 256)), dim3(256), 0, ns, (const uint32_t *)spread->perm.p,
+               (const int32_t *)spread->refid.p, (const int32_t *)spread->pos.p, ks);
+    // unmapped reads (refid -1 -> 0xFFFFFFFF........) sort behind every contig: the search covers them without a special case
+    ELP_LAUNCH(groups, "merge_rank", k_merge_rank, dim3(blocks_for(ns, 256)), dim3(256), 0, ng_all, (const uint64_t *)kg, ns, (const uint64_t *)ks, slots);
+    ELP_HIP(groups, hipMemcpyAsync(slot_of_spread_out, slots, ns * 8, hipMemcpyDeviceToHost, groups->stream));
+  }
+  ELP_HIP(groups, hipStreamSynchronize(groups->stream));
+  return 0;
+}
+
+}  // extern "C"

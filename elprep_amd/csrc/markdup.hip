@@ -49,6 +49,14 @@ __device__ __forceinline__ unsigned long long ld_agent64(const unsigned long lon
 // The fragment key of a record in one 16-byte word: {REFID, unclipped 5' position, LIBID << 1 | reversed, split id}.  A probe that lands on
 // an occupied slot compares against ONE random 16-byte load instead of four column gathers (the tables are at the random-access
 // limit of the memory system, so accesses are what counts).
+// the FLAG column the tournaments read: the flags as staged, with records the fused predicates rejected (state 2, filter.hip) made
+// non-candidates - in the reference they never reach the MarkDuplicates filter (cmd/filter.go:696-773)
+__global__ __launch_bounds__(256) void k_md_flag_in(uint64_t n, const uint16_t *__restrict__ flag, const uint8_t *__restrict__ state,
+                                                    uint16_t *__restrict__ flag_in) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag_in[i] = state[i] == 2 ? (uint16_t)(flag[i] | F_SECONDARY) : flag[i];
+}
+
 __global__ __launch_bounds__(256) void k_md_keys(MdCols m, uint4 *__restrict__ fkey) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m.n) return;
@@ -313,7 +321,10 @@ static int markdup_impl(elp_ctx *c) {
   // flag_in snapshot: tournaments must see the flags as staged (isTruePair/IsReversed never change, but keep it explicit)
   uint16_t *flag_in;
   ELP_TRY(scratch(c, 4, n + 8, &flag_in));
-  ELP_HIP(c, hipMemcpyAsync(flag_in, c->flag.p, n * sizeof(uint16_t), hipMemcpyDeviceToDevice, st));
+  if (c->n_filtered)
+    ELP_LAUNCH(c, "md_flag_in", k_md_flag_in, dim3(grid), dim3(256), 0, n, (const uint16_t *)c->flag.p, (const uint8_t *)c->has_sr.p, flag_in);
+  else
+    ELP_HIP(c, hipMemcpyAsync(flag_in, c->flag.p, n * sizeof(uint16_t), hipMemcpyDeviceToDevice, st));
   MdCols m{n, c->refid.p, flag_in, c->rgid.p, c->rg_lib.p, c->split.p, c->upos.p, c->score.p, c->qname_off.p, c->qname.p};
   const uint64_t T = table_size_for(n);
   uint32_t *table;

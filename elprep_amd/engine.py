@@ -77,11 +77,9 @@ class Engine:
     def stage(self, b: Batch):
         s = b.as_struct()
         self._check(self.L.elp_stage(self.h, C.byref(s)))
-        self._qual_bytes = getattr(self, "_qual_bytes", 0) + int(b.qual_off[-1] - b.qual_off[0])
 
     def reset(self):
         self._check(self.L.elp_reset(self.h))
-        self._qual_bytes = 0
 
     def snapshot(self):
         self._check(self.L.elp_snapshot(self.h))
@@ -91,6 +89,58 @@ class Engine:
 
     def sync(self):
         self._check(self.L.elp_sync(self.h))
+
+    # ---- BAM in / BAM out (include/elprep_hip.h: sam/bam-files.go on the device)
+    def set_read_group_ids(self, ids: Sequence[str]):
+        arr = (C.c_char_p * max(len(ids), 1))(*[s.encode() for s in ids])
+        self._check(self.L.elp_set_read_group_ids(self.h, C.cast(arr, C.c_void_p)))
+
+    def stage_bam(self, data: np.ndarray, split_id: int = 0):
+        """data: uint8 array of whole inflated BAM alignment records (page-locked memory is read in place by the DMA engine)"""
+        d = np.ascontiguousarray(data, dtype=np.uint8)
+        self._check(self.L.elp_stage_bam(self.h, _vp(d), d.size, split_id))
+
+    def emit_sorted_bam(self, out: Optional[np.ndarray] = None) -> np.ndarray:
+        n = C.c_uint64()
+        if out is None:
+            self._check(self.L.elp_emit_sorted_bam(self.h, C.c_void_p(0), 0, C.byref(n)))
+            out = np.empty(int(n.value), dtype=np.uint8)
+        self._check(self.L.elp_emit_sorted_bam(self.h, _vp(out), out.size, C.byref(n)))
+        return out[:int(n.value)]
+
+    # ---- fused predicates, split / merge bookkeeping (include/elprep_hip.h)
+    def filter_records(self, remove_unmapped=False, remove_unmapped_strict=False, min_mapq=0, remove_non_exact=False, remove_duplicates=False,
+                       regions=None) -> int:
+        """filters/simple-filters.go predicates in one pass; regions: per refid an int32 [k][2] array (sorted, flattened) or None.
+        -> number of records rejected by this call"""
+        class P(C.Structure):
+            _fields_ = [(k, C.c_int) for k in ("remove_unmapped", "remove_unmapped_strict", "min_mapq", "remove_non_exact", "remove_duplicates", "use_regions")] + \
+                       [("regions", C.c_void_p), ("n_regions", C.c_void_p)]
+        p = P(int(remove_unmapped), int(remove_unmapped_strict), int(min_mapq), int(remove_non_exact), int(remove_duplicates), 0, None, None)
+        keep = []
+        if regions is not None:
+            arrs = [np.ascontiguousarray(np.asarray(r, dtype=np.int32).reshape(-1, 2)) for r in regions]
+            ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data if a.size else 0 for a in arrs])
+            cnts = np.asarray([a.shape[0] for a in arrs], dtype=np.int64)
+            keep = [arrs, ptrs, cnts]
+            p.use_regions, p.regions, p.n_regions = 1, C.cast(ptrs, C.c_void_p), cnts.ctypes.data
+        n = C.c_uint64()
+        self._check(self.L.elp_filter_records(self.h, C.byref(p), C.byref(n)))
+        del keep
+        return int(n.value)
+
+    def split_classify(self, group_of_ref: np.ndarray, n_groups: int):
+        g = np.ascontiguousarray(group_of_ref, dtype=np.int32)
+        split = np.empty(self.n, dtype=np.uint16)
+        spread = np.empty(self.n, dtype=np.uint8)
+        counts = np.zeros(n_groups + 2, dtype=np.uint64)
+        self._check(self.L.elp_split_classify(self.h, _vp(g), n_groups, _vp(split), _vp(spread), _vp(counts)))
+        return split, spread, counts
+
+    def merge_spread(self, spread: "Engine") -> np.ndarray:
+        slots = np.empty(spread.n_sorted, dtype=np.uint64)
+        self._check(self.L.elp_merge_spread(self.h, spread.h, _vp(slots)))
+        return slots
 
     # ---- operators
     def sort_coordinate(self, fetch: bool = True) -> Optional[np.ndarray]:
@@ -202,7 +252,7 @@ class Engine:
         return self.qual() if fetch else None
 
     def qual(self) -> np.ndarray:
-        q = np.empty(getattr(self, "_qual_bytes", 0), dtype=np.uint8)
+        q = np.empty(int(self.L.elp_num_qual_bytes(self.h)), dtype=np.uint8)
         self._check(self.L.elp_get_qual(self.h, _vp(q)))
         return q
 

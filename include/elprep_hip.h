@@ -102,6 +102,51 @@ int elp_reserve(elp_ctx *ctx, uint64_t n_records, uint64_t qname_bytes, uint64_t
 int elp_stage(elp_ctx *ctx, const elp_batch *batch); /* appends; host buffers may be reused when the call returns */
 int elp_reset(elp_ctx *ctx);                         /* drops all staged records and results */
 uint64_t elp_num_records(const elp_ctx *ctx);
+uint64_t elp_num_qual_bytes(const elp_ctx *ctx);     /* size of the staged QUAL column (elp_get_qual) */
+
+/* ---- staging straight from BAM, and BAM out: the data formats either side of the path (sam/bam-files.go) ----
+ * elp_set_read_group_ids: the @RG ID strings in the order of elp_header.rg_* (RG:Z tags are looked up in them).
+ * elp_stage_bam: `bytes` = inflated BGZF payload holding whole alignment records (block_size, fixed fields, read name, CIGAR, bases,
+ *   qualities, optional fields; SAMv1 4.2) as bamReader hands them to parseBamAlignment (:299-400).  The records cross PCIe as
+ *   they are and are cut into the columns on the device; all of them get `split_id`.  Appends like elp_stage and may be mixed with
+ *   it only in separate contexts.  Fast path: `bytes` in page-locked memory (elp_pinned_alloc) - the DMA engine reads it in place;
+ *   pageable memory goes through a pinned double buffer.  Returns when `bytes` may be reused.
+ * elp_emit_sorted_bam: formatBamAlignment (:635-737) of the elp_num_sorted() records of the sort's output, in that order, into
+ *   `out` (host memory, `cap` bytes; NULL = just compute *n_bytes_out): FLAG and QUAL as the path left them, bin() recomputed
+ *   (:443-468), optional fields re-encoded as formatBamTag does (:481-632).  BGZF deflate stays with the host. */
+int elp_set_read_group_ids(elp_ctx *ctx, const char *const *ids);
+void *elp_pinned_alloc(size_t bytes);
+void elp_pinned_free(void *p);
+int elp_stage_bam(elp_ctx *ctx, const uint8_t *bytes, uint64_t n_bytes, uint16_t split_id);
+int elp_emit_sorted_bam(elp_ctx *ctx, uint8_t *out, uint64_t cap, uint64_t *n_bytes_out);
+
+/* ---- fused per-record predicates: filters/simple-filters.go ----
+ * The filters that stand in front of MarkDuplicates in filters1 (cmd/filter.go:696-803), evaluated in one pass over the staged
+ * records: a rejected record takes part in nothing that follows (duplicate marking, sort output, metrics, BQSR tables) - it is
+ * behind the elp_num_sorted() records of the permutation.  Call before the other operators; may be called again (predicates add up).
+ *   remove_unmapped          RemoveUnmappedReads          :73-75    FLAG & 0x4
+ *   remove_unmapped_strict   RemoveUnmappedReadsStrict    :79-83    ... or POS == 0 or RNAME == "*"
+ *   min_mapq                 RemoveMappingQualityLessThan :332-347  keep MAPQ >= min_mapq (0 = off, > 255 rejects everything)
+ *   remove_non_exact         RemoveNonExactMappingReads   :90-99    CIGAR may hold M and S only
+ *   remove_duplicates        RemoveDuplicateReads         :136-138  FLAG & 0x400 as the column is now
+ *   use_regions              RemoveNonOverlappingReads    :310-328  regions[refid] = [n_regions[refid]][2] {Start, End} as
+ *                            intervals.FromBed makes them, sorted by Start and flattened; intervals.Overlap's comparisons */
+typedef struct elp_predicates {
+  int remove_unmapped, remove_unmapped_strict, min_mapq, remove_non_exact, remove_duplicates, use_regions;
+  const int32_t *const *regions;
+  const int64_t *n_regions;
+} elp_predicates;
+int elp_filter_records(elp_ctx *ctx, const elp_predicates *p, uint64_t *n_rejected_out /* may be NULL */);
+
+/* ---- `elprep split` / `merge` without touching payloads on the CPU: sam/split-merge.go ----
+ * elp_split_classify: SplitFilePerChromosome's routing rule (:280-293) for every staged record: split_out[i] = 0 for RNAME "*",
+ *   else group_of_ref[refid] (1..n_groups, computeContigGroups :178-213 on the host); spread_out[i] = 1 if the read also goes to the
+ *   spread file (mate in another group); counts_out[n_groups + 2] = records per split (unmapped, groups, spread).
+ * elp_merge_spread: MergeSortedFilesSplitPerChromosome (:410-576) as ranks: both contexts coordinate-sorted; slot_of_spread_out[j] =
+ *   output slot of the j-th record of `spread`'s sorted output among `groups`' sorted output (behind every group read of its
+ *   (refid, POS) and in front of the first greater one; group reads fill the remaining slots in order). */
+int elp_split_classify(elp_ctx *ctx, const int32_t *group_of_ref, int32_t n_groups, uint16_t *split_out, uint8_t *spread_out, uint64_t *counts_out);
+int elp_merge_spread(elp_ctx *groups, elp_ctx *spread, uint64_t *slot_of_spread_out);
 
 /* ---- coordinate sort: By(CoordinateLess).ParallelStableSort (sam/sam-types.go:425-473, 639-641) ----
  * Builds the permutation on device: perm[k] = staging index of the record at sorted position k; records equal

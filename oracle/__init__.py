@@ -28,7 +28,7 @@ CTR_NAMES = ["UnpairedReadsExamined", "ReadPairsExamined", "SecondaryOrSupplemen
 
 def build(force: bool = False) -> str:
     path = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("orc_sort.c", "orc_markdup.c", "orc_bqsr.c", "orc.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("orc_sort.c", "orc_markdup.c", "orc_bqsr.c", "orc_bam.c", "orc.h")]
     if force or not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in srcs if os.path.exists(s)):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return path
@@ -56,6 +56,7 @@ def lib() -> C.CDLL:
         L.orc_estimate_library_size.argtypes = [C.c_int64, C.c_int64]
         L.orc_flatten.restype = C.c_size_t
         L.orc_num_sorted.restype = C.c_uint64
+        L.orc_bam_encode.restype = C.c_size_t
         L.orc_bqsr_recal_qual.restype = C.c_uint8
     return _LIB
 
@@ -326,3 +327,22 @@ def contig_groups(ref_len: np.ndarray, contig_group_size: int = 0):
     out = np.zeros(rl.size, dtype=np.int32)
     n = lib().orc_contig_groups(_p(rl), C.c_int(rl.size), C.c_int(contig_group_size), _p(out))
     return int(n), out
+
+
+# ---------------- BAM records ----------------
+def bam_encode(b: Batch, rg_ids: Sequence[str], order: Optional[np.ndarray] = None, flags: Optional[np.ndarray] = None,
+               qual: Optional[np.ndarray] = None, normalize_tags: bool = False, out: Optional[np.ndarray] = None) -> np.ndarray:
+    """formatBamAlignment over the records `order` (default: all, input order); see orc_bam.c for the optional fields.
+    out: a uint8 array to write into (e.g. over pinned memory); default: a fresh array."""
+    arr = (C.c_char_p * max(len(rg_ids), 1))(*[s.encode() for s in rg_ids])
+    o = None if order is None else np.ascontiguousarray(order, dtype=np.uint32)
+    f = None if flags is None else np.ascontiguousarray(flags, dtype=np.uint16)
+    q = None if qual is None else np.ascontiguousarray(qual, dtype=np.uint8)
+    s = b.as_struct()
+    args = (C.byref(s), arr, _p(o), C.c_uint64(0 if o is None else o.size), _p(f), _p(q), C.c_int(1 if normalize_tags else 0))
+    n = lib().orc_bam_encode(*args, C.c_void_p(0))
+    if out is None:
+        out = np.empty(n, dtype=np.uint8)
+    assert out.size >= n
+    lib().orc_bam_encode(*args, C.c_void_p(out.ctypes.data))
+    return out[:n]

@@ -147,6 +147,12 @@ double orc_go_log10(double x);
 double orc_go_pow10(double y);  /* math.Pow(10, y) */
 uint8_t orc_bayesian_estimate(int64_t observations, int64_t mismatches, double prior);
 
+/* BAM alignment records (sam/bam-files.go:443-468, 481-737): the records order[0 .. n_order) of b (NULL: all, in input order) behind
+ * each other, FLAG / QUAL optionally replaced; the optional fields are a deterministic function of the record (orc_bam.c), written
+ * in arbitrary integer types (normalize_tags = 0: a BAM as other tools write it) or as elPrep re-encodes them (1).  out NULL: size only. */
+size_t orc_bam_encode(const orc_batch *b, const char *const *rg_ids, const uint32_t *order, uint64_t n_order, const uint16_t *flags,
+                      const uint8_t *qual, int normalize_tags, uint8_t *out);
+
 /* sfm contig groups (sam/split-merge.go:178-213): group_of_ref[n_ref] gets 1-based group index; returns #groups (excl. unmapped) */
 int orc_contig_groups(const int32_t *ref_len, int n_ref, int contig_group_size, int32_t *group_of_ref);
 

@@ -1,0 +1,89 @@
+"""CPU oracle (TEST INFRASTRUCTURE - see oracle/orc.h), numpy part: restatements of the per-record filters and of the split / merge
+bookkeeping that sit next to the hot path.  Only tests may import this.
+
+  keep_mask        filters/simple-filters.go: RemoveUnmappedReads :73-75, RemoveUnmappedReadsStrict :79-83,
+                   RemoveNonExactMappingReads :90-99, RemoveDuplicateReads :136-138, RemoveNonOverlappingReads :310-328,
+                   RemoveMappingQualityLessThan :332-347; intervals.Overlap intervals/intervals.go:146-160
+  split_records    SplitFilePerChromosome's routing rule, sam/split-merge.go:280-293
+  merge_slots      MergeSortedFilesSplitPerChromosome's insertion loop, sam/split-merge.go:410-576, one record at a time
+"""
+import numpy as np
+
+CONSUMES_READ = {0, 1, 4, 7, 8}   # M I S = X   (sam.CigarOperatorConsumesReadBases)
+CONSUMES_REF = {0, 2, 3, 7, 8}    # M D N = X
+
+
+def overlap(ivals, start, end):
+    """intervals.Overlap: same binary search, same comparisons"""
+    left, right = 0, len(ivals) - 1
+    while left <= right:
+        mid = (left + right) // 2
+        s, e = int(ivals[mid][0]), int(ivals[mid][1])
+        if s > end - 1:
+            right = mid - 1
+        elif e <= start - 1:
+            left = mid + 1
+        else:
+            return True
+    return False
+
+
+def keep_mask(b, remove_unmapped=False, remove_unmapped_strict=False, min_mapq=0, remove_non_exact=False, remove_duplicates=False,
+              regions=None, flags=None):
+    """-> bool[n]: the record passes every selected filter (record by record, as the AlignmentFilter closures do)"""
+    flag = b.flag if flags is None else flags
+    keep = np.ones(b.n, dtype=bool)
+    for i in range(b.n):
+        f, pos, r = int(flag[i]), int(b.pos[i]), int(b.refid[i])
+        ops = b.cigar[int(b.cigar_off[i]):int(b.cigar_off[i + 1])]
+        ok = True
+        if remove_unmapped and (f & 0x4):
+            ok = False
+        if remove_unmapped_strict and ((f & 0x4) or pos == 0 or r < 0):
+            ok = False
+        if min_mapq > 0 and (min_mapq > 255 or int(b.mapq[i]) < min_mapq):
+            ok = False
+        if remove_non_exact and any((int(c) & 0xF) not in (0, 4) for c in ops):   # anything but M and S
+            ok = False
+        if remove_duplicates and (f & 0x400):
+            ok = False
+        if ok and regions is not None:
+            aln_start = aln_end = pos
+            if not (f & 0x4):
+                read_len = sum(int(c) >> 4 for c in ops if (int(c) & 0xF) in CONSUMES_READ)
+                if read_len > 0:
+                    aln_end = pos + sum(int(c) >> 4 for c in ops if (int(c) & 0xF) in CONSUMES_REF) - 1
+            ok = r >= 0 and overlap(regions[r], aln_start, aln_end)   # ivals["*"] is nil: Overlap(nil, ...) = false
+        keep[i] = ok
+    return keep
+
+
+def split_records(b, group_of_ref):
+    """-> (split of RNAME per record: 0 = "unmapped", 1..G; spread flag per record), one record at a time"""
+    split = np.zeros(b.n, dtype=np.uint16)
+    spread = np.zeros(b.n, dtype=np.uint8)
+    for i in range(b.n):
+        r, nr = int(b.refid[i]), int(b.next_refid[i])
+        g = int(group_of_ref[r]) if r >= 0 else 0
+        gn = int(group_of_ref[nr]) if nr >= 0 else 0
+        split[i] = g
+        # RNEXT != "=" && RNAME != "*" && contigToGroup[RNEXT] != group; BAM input: RNEXT is "=" iff next_refid == refid
+        spread[i] = 1 if (nr != r and r >= 0 and gn != g) else 0
+    return split, spread
+
+
+def merge_slots(group_keys, spread_keys):
+    """The merge loop: group reads stream out; before a group read that is strictly greater than the pending spread read the spread
+    read goes out first.  Keys = (refid, pos) tuples, both lists coordinate-sorted.  -> output slot of every spread read."""
+    out, j, slot = [], 0, 0
+    for gk in group_keys:
+        while j < len(spread_keys) and spread_keys[j] < gk:
+            out.append(slot)
+            slot += 1
+            j += 1
+        slot += 1
+    while j < len(spread_keys):
+        out.append(slot)
+        slot += 1
+        j += 1
+    return np.asarray(out, dtype=np.uint64)

@@ -268,3 +268,161 @@ print("ok", rank)
     procs = [subprocess.Popen([sys.executable, "-c", code, str(r), d], stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+def _regions_for(cfg, rng):
+    out = []
+    for ln in cfg.ref_len:
+        k = int(rng.integers(0, 40))
+        s = np.sort(rng.integers(0, max(ln - 2000, 1), k))
+        iv = np.stack([s, s + rng.integers(1, 1500, k)], axis=1).astype(np.int32)
+        out.append(orc.flatten(orc.sort_by_start(iv)) if k else iv.reshape(0, 2))
+    return out
+
+
+@pytest.mark.parametrize("sel", [dict(remove_unmapped=True), dict(remove_unmapped_strict=True, min_mapq=20), dict(remove_non_exact=True),
+                                 dict(use_regions=True), dict(remove_unmapped=True, min_mapq=1, remove_non_exact=True, use_regions=True)])
+def test_fused_predicates_in_front_of_the_path(sel):
+    """elp_filter_records against the restated filters (oracle/simple_filters.py), then the whole path on the survivors: a
+    rejected record must behave as if it had never been staged (the reference applies these filters before MarkDuplicates)."""
+    from oracle import simple_filters as sf
+    cfg, b, h, refs, sites = dataset("tiny", 3000, 6, 0.05)
+    rng = np.random.default_rng(9)
+    sel = dict(sel)
+    regions = _regions_for(cfg, rng) if sel.pop("use_regions", False) else None
+    keep = sf.keep_mask(b, regions=regions, **sel)
+    assert 0 < keep.sum() < b.n
+    e = Engine(h)
+    e.stage(b)
+    assert e.filter_records(regions=regions, **sel) == int((~keep).sum())
+    assert e.n_sorted == int(keep.sum())
+    kept = np.nonzero(keep)[0]
+    kb = b.take(kept)
+    oflags = orc.mark_duplicates(kb, h)
+    flags = e.mark_duplicates(True)
+    assert np.array_equal(flags[kept], oflags) and np.array_equal(flags[~keep], b.flag[~keep])
+    operm = orc.sort_coordinate(kb, oflags)
+    assert np.array_equal(e.sort_coordinate()[:e.n_sorted], kept[operm])
+    _, octr, _ = orc.dup_metrics(kb, h, operm, 100)
+    assert np.array_equal(e.dup_metrics(100), octr)
+    for r in range(h.n_ref):
+        e.set_reference(r, refs[r])
+        e.set_known_sites(r, sites[r])
+    oq, oc, ox = orc.bqsr_gather(kb, h, orc.BqsrRef(refs, sites), oflags, 500)
+    qt, ct, xt = e.recalibrate(500)
+    assert np.array_equal(qt, oq) and np.array_equal(ct, oc) and np.array_equal(xt, ox)
+    # RemoveDuplicateReads works on the flags as they are now (filters2, at output time)
+    n_dup = e.filter_records(remove_duplicates=True)
+    assert n_dup == int(((oflags & 0x400) != 0).sum())
+    e.close()
+
+
+def test_split_classify_and_merge_on_device():
+    """`elprep split` routing and `elprep merge` order without the payload: device results against the record-by-record
+    restatements (oracle/simple_filters.py) of sam/split-merge.go:280-293 and :410-576."""
+    from elprep_amd import sfm
+    from oracle import simple_filters as sf
+    cfg, b, h, refs, sites = dataset("tiny", 4000, 7, 0.03)
+    n_groups, gof = orc.contig_groups(cfg.ref_len, 80000)
+    e = Engine(h)
+    e.stage(b)
+    split, spread, counts = e.split_classify(gof, n_groups)
+    osplit, ospread = sf.split_records(b, gof)
+    assert np.array_equal(split, osplit) and np.array_equal(spread, ospread) and spread.sum() > 20
+    assert counts.tolist() == [int((osplit == g).sum()) for g in range(n_groups + 1)] + [int(ospread.sum())]
+    e.close()
+    # merge: the group splits (with the tagged copies, which drop out) in one context, the spread split in another
+    tagged = sfm.with_sr(b, ospread.astype(bool), osplit)
+    eg, es = Engine(h), Engine(h)
+    eg.stage(tagged)
+    sp = b.take(np.nonzero(ospread)[0])
+    es.stage(sp)
+    pg, ps = eg.sort_coordinate()[:eg.n_sorted], es.sort_coordinate()[:es.n_sorted]
+    slots = eg.merge_spread(es)
+    gk = [(int(tagged.refid[i]) & 0xFFFFFFFF, int(tagged.pos[i])) for i in pg]
+    sk = [(int(sp.refid[i]) & 0xFFFFFFFF, int(sp.pos[i])) for i in ps]
+    assert np.array_equal(slots, sf.merge_slots(gk, sk))
+    # and it is what the host-side order model (sfm.merge_order, tested against the reference loop on CPU) gives for the mapped part
+    mapped = [k for k in gk if k[0] != 0xFFFFFFFF]
+    code = sfm.merge_order(np.asarray([k[0] for k in mapped], np.int64), np.asarray([k[1] for k in mapped], np.int64),
+                           np.asarray([k[0] for k in sk], np.int64), np.asarray([k[1] for k in sk], np.int64))
+    assert np.array_equal(np.nonzero(code < 0)[0], slots.astype(np.int64))
+    eg.close()
+    es.close()
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_stage_from_bam_and_emit_sorted_bam(pinned):
+    """BAM records in, BAM records out (sam/bam-files.go:299-400, 635-737 on the device).  The staged columns must be what elp_stage
+    makes of the same batch (every output of the path equal), and the emitted stream byte-equal to the oracle's formatBamAlignment
+    of the sorted, duplicate-marked, recalibrated records with the optional fields re-encoded as elPrep does."""
+    import ctypes
+    from elprep_amd import _lib
+    from elprep_amd import sfm
+    cfg, b, h, refs, sites = dataset("tiny", 3000, 8, 0.04)
+    # a few sr-tagged copies, as in a contig-group split file
+    b = sfm.with_sr(b, (np.arange(b.n) % 37 == 5) & ((b.flag & 0x904) == 0) & ((b.flag & 0x9) == 1))
+    raw = orc.bam_encode(b, h.rg_ids)
+    L = _lib.hip()
+    if pinned:
+        ptr = L.elp_pinned_alloc(raw.size)
+        buf = np.frombuffer((ctypes.c_uint8 * raw.size).from_address(ptr), dtype=np.uint8)
+        buf[:] = raw
+    else:
+        buf = raw
+    e, e2 = Engine(h), Engine(h)
+    e.set_read_group_ids(h.rg_ids)
+    # split the byte stream at a record boundary in the middle
+    off, p = [], 0
+    while p < raw.size:
+        off.append(p)
+        p += 4 + int(raw[p:p + 4].view(np.uint32)[0])
+    mid = off[len(off) // 2]
+    e.stage_bam(buf[:mid])
+    e.stage_bam(buf[mid:])
+    e2.stage(b)
+    assert e.n == b.n and e.n_sorted == e2.n_sorted == orc.num_sorted(b)
+    up, sc = e.adapted()
+    up2, sc2 = e2.adapted()
+    assert np.array_equal(up, up2) and np.array_equal(sc, sc2)
+    oflags = orc.mark_duplicates(b, h)
+    assert np.array_equal(e.mark_duplicates(True), oflags)
+    operm = orc.sort_coordinate(b, oflags)
+    perm = e.sort_coordinate()
+    assert np.array_equal(perm[:e.n_sorted], operm[:e.n_sorted])
+    _, octr, _ = orc.dup_metrics(b, h, operm, 100)
+    assert np.array_equal(e.dup_metrics(100), octr)
+    for r in range(h.n_ref):
+        e.set_reference(r, refs[r])
+        e.set_known_sites(r, sites[r])
+    qt, ct, xt = e.recalibrate(500)
+    oq, oc, ox = orc.bqsr_gather(b, h, orc.BqsrRef(refs, sites), oflags, 500)
+    assert np.array_equal(qt, oq) and np.array_equal(ct, oc) and np.array_equal(xt, ox)
+    lut, present = BqsrTables(qt, ct, xt, 500).finalize().build_lut(0)
+    qual = e.apply_bqsr(lut, present, 500)
+    oqual = orc.BqsrFinal(oq, oc, ox, 500).apply(b, h, 0)
+    assert np.array_equal(qual, oqual)
+    got = e.emit_sorted_bam()
+    want = orc.bam_encode(b, h.rg_ids, order=operm[:orc.num_sorted(b)], flags=oflags, qual=oqual, normalize_tags=True)
+    assert got.size == want.size and np.array_equal(got, want)
+    assert not np.array_equal(orc.bam_encode(b, h.rg_ids, order=operm[:orc.num_sorted(b)], flags=oflags, qual=oqual), want)  # the re-encoding matters
+    e.close()
+    e2.close()
+    if pinned:
+        del buf
+        L.elp_pinned_free(ptr)
+
+
+def test_stage_bam_rejects_malformed_input():
+    cfg, b, h, refs, sites = dataset("tiny", 50, 8, 0.0)
+    raw = orc.bam_encode(b, h.rg_ids)
+    e = Engine(h)
+    e.set_read_group_ids(h.rg_ids)
+    with pytest.raises(ElpError, match="block_size|truncated"):
+        e.stage_bam(raw[:-3])
+    e2 = Engine(h)
+    e2.set_read_group_ids(["nope"] * len(h.rg_ids))
+    with pytest.raises(ElpError, match="read group"):
+        e2.stage_bam(raw)
+    e.close()
+    e2.close()
