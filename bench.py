@@ -141,13 +141,21 @@ def main():
             # that pipeline's Finalize (sam/filter-pipeline.go:116), then the metrics pass, Recalibrate, finalize, ApplyBQSR
             eng.mark_duplicates(True, fetch=False)
             eng.sort_coordinate(fetch=False)
-            eng.dup_metrics(100)
             qt, ct, xt = eng.recalibrate(MAX_CYCLE, reuse=True)
+            # the float64 finalisation + LUT (host) and the duplication-metrics pass (device) do not depend on each other: the
+            # host thread finalises while the GPU counts (the reference runs them one after the other, cmd/filter.go:162-196)
+            fin = host_pool.submit(finalize_lut, qt, ct, xt)
+            eng.dup_metrics(100)
+            lut, present = fin.result()
+            eng.apply_bqsr(lut, present, MAX_CYCLE, fetch=False)
+            eng.sync()
+
+        def finalize_lut(qt, ct, xt):
             tb = BqsrTables(qt, ct, xt, MAX_CYCLE).finalize()
             lut, present = tb.build_lut(0, out=lut_buf[0])
             lut_buf[0] = (lut, present)
-            eng.apply_bqsr(lut, present, MAX_CYCLE, fetch=False)
-            eng.sync()
+            return lut, present
+        host_pool = ThreadPoolExecutor(1)
         lut_buf = [None]  # the host side keeps its arrays from step to step, as a long-running caller would
         mode = "filter"
     else:

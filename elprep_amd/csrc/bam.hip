@@ -486,12 +486,13 @@ int elp_emit_sorted_bam(elp_ctx *c, uint8_t *out, uint64_t cap, uint64_t *n_byte
     ELP_HIP(c, hipStreamSynchronize(st));
     if (he & 16u) return set_error(c, ELP_ERR_UNSUPPORTED, "elp_emit_sorted_bam: H-typed optional field");
     if (he) return set_error(c, ELP_ERR_DATA, "elp_emit_sorted_bam: malformed optional fields");
+    if (!out) { total += chunk_bytes; continue; }  // size query
     if (total + chunk_bytes > cap) return set_error(c, ELP_ERR_ARG, "elp_emit_sorted_bam: output buffer too small (%llu bytes needed so far)", (unsigned long long)(total + chunk_bytes));
     uint8_t *d_out;
     ELP_TRY(scratch(c, 5, (size_t)chunk_bytes + 64, &d_out));
     const unsigned grid = std::min<unsigned>(blocks_for((uint64_t)cnt * 64, 256), (unsigned)c->n_cu * 32);
     ELP_LAUNCH(c, "emit_bam", k_bam_out_emit, dim3(grid), dim3(256), 0, m, k0, cnt, (const uint32_t *)offs, d_out);
-    if (out) ELP_HIP(c, hipMemcpyAsync(out + total, d_out, chunk_bytes, hipMemcpyDeviceToHost, st));
+    ELP_HIP(c, hipMemcpyAsync(out + total, d_out, chunk_bytes, hipMemcpyDeviceToHost, st));
     ELP_HIP(c, hipStreamSynchronize(st));
     total += chunk_bytes;
   }
