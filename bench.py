@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=int(os.environ.get("ELP_BENCH_READS", 50_000_000)), help="reads per GPU (approximate: pairs = reads/2)")
     ap.add_argument("--genome", default="c3", help="synthetic genome preset (tools/synth): c3 = hg38/12, 24 contigs")
-    ap.add_argument("--cpu-reads", type=int, default=2_000_000, help="sample size for the CPU baseline leg (0 = skip)")
+    ap.add_argument("--cpu-reads", type=int, default=16_000_000, help="sample size for the CPU baseline leg (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -330,23 +330,33 @@ def flatten_sites(raw: np.ndarray) -> np.ndarray:
 
 
 def cpu_baseline(cfg, hdr, n_reads):
-    """The CPU oracle (plain-C restatement of the reference's algorithms, single thread) timed on a bounded sample of the
-    same workload on this box's host cores.  kind = "port": it is NOT the elPrep binary (no Go toolchain)."""
+    """The CPU oracle (plain-C restatement of the reference's algorithms) on ALL host cores - parallel merge sort with the
+    CoordinateLess comparator, sharded duplicate-marking maps, thread-private BQSR tables summed at the end, as the reference's
+    pargo-based CPU path is organised - timed on a bounded sample of the same workload.  kind = "port": it is NOT the elPrep binary
+    (no Go toolchain and no elprep on the box: profiles/r2a_reference_toolchain_probe.txt)."""
     import oracle as orc
     from tools import synth
-    b = synth.generate(cfg, 0, n_reads // 2)
+    from concurrent.futures import ThreadPoolExecutor
+    from elprep_amd.batch import Batch
+    cores = os.cpu_count() or 1
+    chunk = 500_000
+    with ThreadPoolExecutor(min(cores, 16)) as pool:
+        parts = list(pool.map(lambda lo: synth.generate(cfg, lo, min(lo + chunk, n_reads // 2)), range(0, n_reads // 2, chunk)))
+    b = Batch.concat(parts) if len(parts) > 1 else parts[0]
+    del parts
     refs = [synth.reference(cfg, r) for r in range(hdr.n_ref)]
     sites = [flatten_sites(synth.known_sites_raw(cfg, r)) for r in range(hdr.n_ref)]
     t0 = time.perf_counter()
-    perm = orc.sort_coordinate(b, orc.mark_duplicates(b, hdr))
-    flags, ctr, _ = orc.dup_metrics(b, hdr, perm, 100)
-    qt, ct, xt = orc.bqsr_gather(b, hdr, orc.BqsrRef(refs, sites), flags, MAX_CYCLE)
+    flags, _ = orc.dup_metrics_mt(b, hdr, None, 100, cores)          # MarkDuplicates while the records stream in
+    perm = orc.sort_coordinate_mt(b, flags, cores)                    # the sort: Finalize of that pipeline
+    flags, ctr = orc.dup_metrics_mt(b, hdr, perm, 100, cores)         # MarkOpticalDuplicates over the sorted reads (marking repeated: part of the port's cost)
+    qt, ct, xt = orc.bqsr_gather_mt(b, hdr, orc.BqsrRef(refs, sites), flags, MAX_CYCLE, cores)
     fin = orc.BqsrFinal(qt, ct, xt, MAX_CYCLE)
-    fin.apply(b, hdr, 0)
+    orc.bqsr_apply_mt(fin, b, hdr, 0, (), cores)
     dt = time.perf_counter() - t0
-    return {"value": round(b.n / dt / 1e6, 4), "unit": "Mreads/s", "cores": 1, "kind": "port",
-            "sample": f"{b.n} reads of the same synthetic workload, full path (sort+markdup+optical metrics+BQSR gather+finalize+apply), "
-                      f"single-threaded C restatement of the reference algorithms (oracle/), {dt:.1f} s; host has {os.cpu_count()} cores"}
+    return {"value": round(b.n / dt / 1e6, 4), "unit": "Mreads/s", "cores": cores, "kind": "port",
+            "sample": f"{b.n} reads of the same synthetic workload, full path (mark duplicates + sort + optical metrics + BQSR gather + finalize + apply), "
+                      f"multithreaded C restatement of the reference algorithms (oracle/, OpenMP, {cores} threads), {dt:.1f} s wall = {dt * cores:.0f} core-seconds"}
 
 
 if __name__ == "__main__":

@@ -236,7 +236,7 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
   return x;
 }
 
-// QNAME access goes through unaligned 8-byte loads (the column is padded by 16 bytes, so reading up to 7 bytes past a name is safe)
+// QNAME access goes through unaligned 8-byte loads (the column is padded by 64 bytes, so reading up to 31 bytes past a name is safe)
 __device__ __forceinline__ uint64_t load8(const uint8_t *__restrict__ p) {
   uint64_t w;
   __builtin_memcpy(&w, p, 8);
@@ -260,15 +260,23 @@ __device__ inline int qname_cmp(const uint8_t *__restrict__ q, const uint64_t *_
   }
   return la < lb ? -1 : (la > lb ? 1 : 0);
 }
+// 32 bytes per round trip: all eight loads of a round are issued before the first compare (names of up to 32 bytes - the usual
+// case - cost one memory latency, not one per 8 bytes).  The column is padded by 64 bytes, so reading past a name's end is safe.
 __device__ inline bool qname_eq(const uint8_t *__restrict__ q, const uint64_t *__restrict__ off, uint32_t a, uint32_t b) {
   const uint64_t oa = off[a], ob = off[b];
   const uint32_t la = (uint32_t)(off[a + 1] - oa), lb = (uint32_t)(off[b + 1] - ob);
   if (la != lb) return false;
-  for (uint32_t i = 0; i < la; i += 8) {
-    const uint32_t nb = la - i;
-    if (low_bytes(load8(q + oa + i), nb) != low_bytes(load8(q + ob + i), nb)) return false;
+  uint64_t diff = 0;
+  for (uint32_t i = 0; i < la && diff == 0; i += 32) {
+    const uint64_t a0 = load8(q + oa + i), a1 = load8(q + oa + i + 8), a2 = load8(q + oa + i + 16), a3 = load8(q + oa + i + 24);
+    const uint64_t b0 = load8(q + ob + i), b1 = load8(q + ob + i + 8), b2 = load8(q + ob + i + 16), b3 = load8(q + ob + i + 24);
+    const uint32_t nb = la - i;  // bytes left (>= 1)
+    diff |= low_bytes(a0 ^ b0, nb);
+    diff |= nb > 8 ? low_bytes(a1 ^ b1, nb - 8) : 0ull;
+    diff |= nb > 16 ? low_bytes(a2 ^ b2, nb - 16) : 0ull;
+    diff |= nb > 24 ? low_bytes(a3 ^ b3, nb - 24) : 0ull;
   }
-  return true;
+  return diff == 0;
 }
 
 // sam/sam-types.go:408-421

@@ -197,7 +197,7 @@ int stage_reserve(elp_ctx *c, uint64_t n, uint64_t qb, uint64_t co, uint64_t sb,
   ELP_TRY(ensure(c, c->cigar_off, n + 1, keep, c->n + 1));
   ELP_TRY(ensure(c, c->seq_off, n + 1, keep, c->n + 1));
   ELP_TRY(ensure(c, c->qual_off, n + 1, keep, c->n + 1));
-  ELP_TRY(ensure(c, c->qname, qb + 16, keep, c->qname_bytes));
+  ELP_TRY(ensure(c, c->qname, qb + 64, keep, c->qname_bytes));
   ELP_TRY(ensure(c, c->cigar, co + 4, keep, c->cigar_ops));
   ELP_TRY(ensure(c, c->seq4, sb + 32, keep, c->seq_bytes));
   ELP_TRY(ensure(c, c->qual, lb + 32, keep, c->qual_bytes));

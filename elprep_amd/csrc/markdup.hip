@@ -142,7 +142,7 @@ __device__ __forceinline__ uint64_t qname_hash(const MdCols &m, uint32_t i) {
   const uint64_t o = m.qname_off[i];
   const uint32_t l = (uint32_t)(m.qname_off[i + 1] - o);
   uint64_t h = 0x9e3779b97f4a7c15ull ^ l;
-  for (uint32_t k = 0; k < l; k += 8) h = mix64(h ^ low_bytes(load8(m.qname + o + k), l - k));
+  for (uint32_t k = 0; k < l; k += 8) h = (h ^ low_bytes(load8(m.qname + o + k), l - k)) * 0xff51afd7ed558ccdull + (h >> 29);
   return mix64(h ^ ((uint64_t)lib_of(m, i) << 48) ^ ((uint64_t)m.split[i] << 24));
 }
 __device__ __forceinline__ bool mate_key_eq(const MdCols &m, uint32_t a, uint32_t b) {

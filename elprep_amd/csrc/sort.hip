@@ -420,6 +420,41 @@ __global__ __launch_bounds__(256) void k_material_live(uint32_t nu, const uint32
   if (threadIdx.x < elp_ctx::TIE_LIVE_WORDS && acc[threadIdx.x]) atomicOr(&live[threadIdx.x], acc[threadIdx.x]);
 }
 
+// which byte values occur at every live position (bitmap of 256 bits per position, collected in LDS)
+constexpr int TIE_MAX_PACKED = 96;  // live positions up to which the packed keys below are used
+struct TiePosList { uint16_t pos[TIE_MAX_PACKED]; uint32_t n; };
+__global__ __launch_bounds__(256) void k_material_values(uint32_t nu, const uint32_t *__restrict__ u_read, TiePosList lp, uint32_t maxq,
+                                                         uint32_t *vals /* [n][8] */, TieCols t) {
+  __shared__ uint32_t acc[TIE_MAX_PACKED * 8];
+  for (uint32_t k = threadIdx.x; k < lp.n * 8; k += blockDim.x) acc[k] = 0;
+  __syncthreads();
+  for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < nu; m += gridDim.x * blockDim.x) {
+    const uint32_t r = u_read[m];
+    for (uint32_t k = 0; k < lp.n; k++) {
+      const uint32_t v = material_byte(t, r, lp.pos[k], maxq);
+      const uint32_t bit = 1u << (v & 31u);
+      uint32_t *w = &acc[k * 8 + (v >> 5)];
+      if (!(*w & bit)) atomicOr(w, bit);
+    }
+  }
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < lp.n * 8; k += blockDim.x)
+    if (acc[k]) atomicOr(&vals[k], acc[k]);
+}
+// key of a member = the RANKS of its bytes (among the values that occur at the position: same order, fewer bits) at up to 64
+// positions, most significant first: pos[j] is shifted to bit `shift[j]`; rank = lut[slot[j] * 256 + byte]
+struct TiePacked { uint16_t pos[64]; uint8_t shift[64]; uint8_t slot[64]; uint32_t n; };
+__global__ __launch_bounds__(256) void k_material_keys_packed(uint32_t nu, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ u_read,
+                                                              TiePacked sel, const uint8_t *__restrict__ lut, uint32_t maxq, uint64_t *__restrict__ keys,
+                                                              TieCols t) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nu) return;
+  const uint32_t r = u_read[vals[j]];
+  uint64_t k = 0;
+  for (uint32_t b = 0; b < sel.n; b++) k |= (uint64_t)lut[(uint32_t)sel.slot[b] * 256u + material_byte(t, r, sel.pos[b], maxq)] << sel.shift[b];
+  keys[j] = k;
+}
+
 // key of a member = the bytes of its comparator string at the (up to eight) positions pos[0] < pos[1] < ..., most significant first
 struct TieSel { uint16_t pos[8]; uint32_t n; };
 __global__ __launch_bounds__(256) void k_material_keys_sel(uint32_t nu, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ u_read,
@@ -502,7 +537,55 @@ static int sort_impl(elp_ctx *c) {
     for (uint32_t j = 0; j < m_bytes; j++)
       if ((live[j >> 5] >> (j & 31)) & 1u) lp.push_back((uint16_t)j);
     uint32_t *vcur = uv0, *vtmp = uv1;
-    for (size_t hi = lp.size(); hi > 0;) {  // least significant positions first
+    bool packed_done = false;
+    if (!lp.empty() && lp.size() <= (size_t)TIE_MAX_PACKED) {
+      // Few distinct byte values per live position (read names: digits and ':'): sort on their ranks instead of the bytes, as
+      // many positions per 64-bit key as fit - typically two LSD rounds of ~10 passes instead of five rounds of eight.
+      TiePosList pl;
+      pl.n = (uint32_t)lp.size();
+      for (size_t k = 0; k < lp.size(); k++) pl.pos[k] = lp[k];
+      uint32_t *d_vals;
+      ELP_TRY(scratch(c, 5, (size_t)TIE_MAX_PACKED * 8 + (size_t)TIE_MAX_PACKED * 64 + 64, &d_vals));
+      uint8_t *d_lut = reinterpret_cast<uint8_t *>(d_vals + TIE_MAX_PACKED * 8);
+      ELP_HIP(c, hipMemsetAsync(d_vals, 0, (size_t)pl.n * 8 * 4, c->stream));
+      ELP_LAUNCH(c, "material_values", k_material_values, dim3(std::min(blocks_for(nu, 256), 1024u)), dim3(256), 0, nu, (const uint32_t *)u_read, pl, maxq, d_vals, t);
+      std::vector<uint32_t> hv((size_t)pl.n * 8);
+      ELP_HIP(c, hipMemcpyAsync(hv.data(), d_vals, hv.size() * 4, hipMemcpyDeviceToHost, c->stream));
+      ELP_HIP(c, hipStreamSynchronize(c->stream));
+      std::vector<uint8_t> lut((size_t)pl.n * 256, 0);
+      std::vector<int> bits(pl.n);
+      for (uint32_t k = 0; k < pl.n; k++) {
+        int rank = 0;
+        for (int v = 0; v < 256; v++)
+          if ((hv[(size_t)k * 8 + (v >> 5)] >> (v & 31)) & 1u) lut[(size_t)k * 256 + v] = (uint8_t)rank++;
+        int b = 1;
+        while ((1 << b) < rank) b++;
+        bits[k] = b;
+      }
+      ELP_HIP(c, hipMemcpyAsync(d_lut, lut.data(), lut.size(), hipMemcpyHostToDevice, c->stream));
+      // rounds from the least significant position upwards, each filling at most 64 bits / 64 positions
+      for (int hi = (int)pl.n; hi > 0;) {
+        TiePacked sel;
+        memset(&sel, 0, sizeof sel);
+        int total = 0, lo = hi;
+        while (lo > 0 && total + bits[lo - 1] <= 64 && hi - lo < 64) { lo--; total += bits[lo]; }
+        int sh = total;
+        for (int k = lo; k < hi; k++) {
+          sh -= bits[k];
+          sel.pos[sel.n] = pl.pos[k]; sel.shift[sel.n] = (uint8_t)sh; sel.slot[sel.n] = (uint8_t)k;
+          sel.n++;
+        }
+        ELP_LAUNCH(c, "material_keys", k_material_keys_packed, dim3(blocks_for(nu, 256)), dim3(256), 0, nu, (const uint32_t *)vcur, (const uint32_t *)u_read,
+                   sel, (const uint8_t *)d_lut, maxq, uk0, t);
+        uint64_t *ko;
+        uint32_t *vo;
+        ELP_TRY(radix_sort_pairs_low(c, uk0, vcur, uk1, vtmp, nu, (total + 7) / 8, &ko, &vo));
+        if (vo != vcur) { vtmp = vcur; vcur = vo; }
+        hi = lo;
+      }
+      packed_done = true;
+    }
+    for (size_t hi = packed_done ? 0 : lp.size(); hi > 0;) {  // least significant positions first
       const size_t lo = hi >= 8 ? hi - 8 : 0;
       TieSel sel;
       sel.n = (uint32_t)(hi - lo);

@@ -346,3 +346,45 @@ def bam_encode(b: Batch, rg_ids: Sequence[str], order: Optional[np.ndarray] = No
     assert out.size >= n
     lib().orc_bam_encode(*args, C.c_void_p(out.ctypes.data))
     return out[:n]
+
+
+# ---------------- all host cores (bench.py's CPU baseline; same results as the sequential functions) ----------------
+def sort_coordinate_mt(b: Batch, flags: Optional[np.ndarray] = None, n_threads: int = 0) -> np.ndarray:
+    perm = np.empty(b.n, dtype=np.uint32)
+    if flags is not None:
+        cols = {name: getattr(b, name) for name in b.__dataclass_fields__}
+        cols["flag"] = np.ascontiguousarray(flags, dtype=np.uint16)
+        b = Batch(**cols)
+    s = b.as_struct()
+    _check(lib().orc_sort_coordinate_mt(C.byref(s), _p(perm), C.c_int(n_threads)), "sort_coordinate_mt")
+    return perm
+
+
+def dup_metrics_mt(b: Batch, h: Header, perm: Optional[np.ndarray], pixel_dist: int = 100, n_threads: int = 0):
+    flags = np.empty(b.n, dtype=np.uint16)
+    ctr = np.zeros((h.n_lib + 1, NCTR), dtype=np.int64)
+    pp = None if perm is None else np.ascontiguousarray(perm, dtype=np.uint32)
+    s, hs = b.as_struct(), h.as_struct()
+    _check(lib().orc_dup_metrics_mt(C.byref(s), C.byref(hs), _p(pp), C.c_int(pixel_dist), _p(flags), _p(ctr), C.c_int(n_threads)), "dup_metrics_mt")
+    return flags, ctr
+
+
+def bqsr_gather_mt(b: Batch, h: Header, ref: BqsrRef, flags: Optional[np.ndarray] = None, max_cycle: int = 500, n_threads: int = 0):
+    ncyc = 2 * max_cycle + 1
+    qt = np.zeros((h.n_cov, NQUAL, 2), dtype=np.int64)
+    ct = np.zeros((h.n_cov, NQUAL, ncyc, 2), dtype=np.int64)
+    xt = np.zeros((h.n_cov, NQUAL, NCTX, 2), dtype=np.int64)
+    f = None if flags is None else np.ascontiguousarray(flags, dtype=np.uint16)
+    s, hs = b.as_struct(), h.as_struct()
+    _check(lib().orc_bqsr_gather_mt(C.byref(s), C.byref(hs), C.byref(ref.struct), _p(f), C.c_int(max_cycle), _p(qt), _p(ct), _p(xt), C.c_int(n_threads)),
+           "bqsr_gather_mt")
+    return qt, ct, xt
+
+
+def bqsr_apply_mt(fin: "BqsrFinal", b: Batch, h: Header, quantize_levels: int = 0, sqq: Sequence[int] = (), n_threads: int = 0) -> np.ndarray:
+    out = np.empty_like(b.qual)
+    sq = np.asarray(list(sqq), dtype=np.uint8)
+    s, hs = b.as_struct(), h.as_struct()
+    _check(lib().orc_bqsr_apply_mt(C.byref(s), C.byref(hs), fin.h, C.c_int(quantize_levels), _p(sq), C.c_int(sq.size), C.c_int(fin.max_cycle), _p(out),
+                                   C.c_int(n_threads)), "bqsr_apply_mt")
+    return out

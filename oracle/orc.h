@@ -153,6 +153,16 @@ uint8_t orc_bayesian_estimate(int64_t observations, int64_t mismatches, double p
 size_t orc_bam_encode(const orc_batch *b, const char *const *rg_ids, const uint32_t *order, uint64_t n_order, const uint16_t *flags,
                       const uint8_t *qual, int normalize_tags, uint8_t *out);
 
+/* the same operators on n_threads host cores (<= 0: all): bench.py's CPU baseline ("port" of the reference's parallel CPU path:
+ * parallel merge sort, sharded maps, thread-private tables).  Same results as the sequential functions above. */
+int orc_sort_coordinate_mt(const orc_batch *b, uint32_t *perm_out, int n_threads);
+int orc_dup_metrics_mt(const orc_batch *b, const orc_header *h, const uint32_t *perm, int pixel_dist, uint16_t *flag_out, int64_t *counters,
+                       int n_threads);
+int orc_bqsr_gather_mt(const orc_batch *b, const orc_header *h, const orc_bqsr_ref *r, const uint16_t *flags, int max_cycle,
+                       int64_t *qual_tbl, int64_t *cycle_tbl, int64_t *ctx_tbl, int n_threads);
+int orc_bqsr_apply_mt(const orc_batch *b, const orc_header *h, const orc_bqsr_final *f, int quantize_levels, const uint8_t *sqq, int n_sqq,
+                      int max_cycle, uint8_t *qual_out, int n_threads);
+
 /* sfm contig groups (sam/split-merge.go:178-213): group_of_ref[n_ref] gets 1-based group index; returns #groups (excl. unmapped) */
 int orc_contig_groups(const int32_t *ref_len, int n_ref, int contig_group_size, int32_t *group_of_ref);
 

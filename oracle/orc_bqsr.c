@@ -608,23 +608,68 @@ static void snp_events(const waln *a, const uint8_t *ref, int64_t ref_len, int *
   }
 }
 
-/* Recalibrate :467-551 */
+/* Recalibrate :467-551 over the records [lo, hi) (the body of the RangeReduce worker :471-540); tables are added to */
+static int gather_range(const orc_batch *b, const orc_header *h, const orc_bqsr_ref *r, const uint16_t *flags, int max_cycle,
+                        uint64_t lo, uint64_t hi, uint32_t maxl, int64_t *qual_tbl, int64_t *cycle_tbl, int64_t *ctx_tbl);
+
 int orc_bqsr_gather(const orc_batch *b, const orc_header *h, const orc_bqsr_ref *r, const uint16_t *flags, int max_cycle,
                     int64_t *qual_tbl, int64_t *cycle_tbl, int64_t *ctx_tbl) {
   int ncyc = 2 * max_cycle + 1;
   memset(qual_tbl, 0, (size_t)h->n_cov * ORC_NQUAL * 2 * sizeof(int64_t));
   memset(cycle_tbl, 0, (size_t)h->n_cov * ORC_NQUAL * ncyc * 2 * sizeof(int64_t));
   memset(ctx_tbl, 0, (size_t)h->n_cov * ORC_NQUAL * ORC_NCTX * 2 * sizeof(int64_t));
-  waln a; memset(&a, 0, sizeof a);
-  cvec sc; memset(&sc, 0, sizeof sc);
   uint32_t maxl = 1;
   for (uint64_t i = 0; i < b->n; i++) if (b->l_seq[i] > maxl) maxl = b->l_seq[i];
+  return gather_range(b, h, r, flags, max_cycle, 0, b->n, maxl, qual_tbl, cycle_tbl, ctx_tbl);
+}
+
+/* the same with thread-private tables over sub-ranges, summed at the end: parallel.RangeReduce + bqsrTable.merge (:210-223, 471) */
+#include <omp.h>
+int orc_bqsr_gather_mt(const orc_batch *b, const orc_header *h, const orc_bqsr_ref *r, const uint16_t *flags, int max_cycle,
+                       int64_t *qual_tbl, int64_t *cycle_tbl, int64_t *ctx_tbl, int n_threads) {
+  int ncyc = 2 * max_cycle + 1;
+  size_t nq = (size_t)h->n_cov * ORC_NQUAL * 2, nc = nq * ncyc, nx = nq * ORC_NCTX;
+  memset(qual_tbl, 0, nq * sizeof(int64_t));
+  memset(cycle_tbl, 0, nc * sizeof(int64_t));
+  memset(ctx_tbl, 0, nx * sizeof(int64_t));
+  if (n_threads < 1) n_threads = omp_get_max_threads();
+  uint32_t maxl = 1;
+  for (uint64_t i = 0; i < b->n; i++) if (b->l_seq[i] > maxl) maxl = b->l_seq[i];
+  int rc_all = 0;
+#pragma omp parallel num_threads(n_threads)
+  {
+    int64_t *t = (int64_t *)calloc(nq + nc + nx, sizeof(int64_t));
+    int rc = t ? 0 : -2;
+#pragma omp for schedule(dynamic, 1)
+    for (uint64_t c = 0; c < (b->n + 16383) / 16384; c++) {
+      uint64_t lo = c * 16384, hi = lo + 16384 < b->n ? lo + 16384 : b->n;
+      if (rc == 0) rc = gather_range(b, h, r, flags, max_cycle, lo, hi, maxl, t, t + nq, t + nq + nc);
+    }
+#pragma omp critical
+    {
+      if (rc) rc_all = rc;
+      if (t) {
+        for (size_t k = 0; k < nq; k++) qual_tbl[k] += t[k];
+        for (size_t k = 0; k < nc; k++) cycle_tbl[k] += t[nq + k];
+        for (size_t k = 0; k < nx; k++) ctx_tbl[k] += t[nq + nc + k];
+      }
+    }
+    free(t);
+  }
+  return rc_all;
+}
+
+static int gather_range(const orc_batch *b, const orc_header *h, const orc_bqsr_ref *r, const uint16_t *flags, int max_cycle,
+                        uint64_t lo, uint64_t hi, uint32_t maxl, int64_t *qual_tbl, int64_t *cycle_tbl, int64_t *ctx_tbl) {
+  int ncyc = 2 * max_cycle + 1;
+  waln a; memset(&a, 0, sizeof a);
+  cvec sc; memset(&sc, 0, sizeof sc);
   int *snps = (int *)malloc(maxl * sizeof(int));
   uint8_t *sbuf = (uint8_t *)malloc(maxl + 1);
   int32_t *ctx = (int32_t *)malloc((maxl + 2) * sizeof(int32_t));
   uint8_t *skip = (uint8_t *)malloc(maxl + 1);
   int rc = 0;
-  for (uint64_t i = 0; i < b->n && rc == 0; i++) {
+  for (uint64_t i = lo; i < hi && rc == 0; i++) {
     if (!orc_recalibrate_aln(b, h, flags, i)) continue;
     load_aln(b, i, flags, &a);
     if (hard_clip_adaptor_sequence(&a, &sc) < 0) { rc = -5; break; }
@@ -970,8 +1015,18 @@ uint8_t orc_bqsr_recal_qual(const orc_bqsr_final *fc, int cov, int qual, int cyc
 }
 
 /* ApplyBQSR :936-1005 */
+static int apply_range(const orc_batch *b, const orc_header *h, const orc_bqsr_final *f, const uint8_t *quantized, const uint8_t *static_q,
+                       int max_cycle, int16_t *memo, uint32_t maxl, uint64_t lo, uint64_t hi, uint8_t *qual_out);
+
 int orc_bqsr_apply(const orc_batch *b, const orc_header *h, const orc_bqsr_final *f, int quantize_levels, const uint8_t *sqq,
                    int n_sqq, int max_cycle, uint8_t *qual_out) {
+  return orc_bqsr_apply_mt(b, h, f, quantize_levels, sqq, n_sqq, max_cycle, qual_out, 1);
+}
+
+/* n_threads > 1: the reads are split among threads as the reference's batch pipeline does (sam/filter-pipeline.go:269-278); the
+ * memo (one per worker in the reference, :944-946) is shared here: every entry has one possible value */
+int orc_bqsr_apply_mt(const orc_batch *b, const orc_header *h, const orc_bqsr_final *f, int quantize_levels, const uint8_t *sqq,
+                      int n_sqq, int max_cycle, uint8_t *qual_out, int n_threads) {
   uint8_t static_q[254];
   int64_t counts[94];
   uint8_t quantized[94];
@@ -983,12 +1038,35 @@ int orc_bqsr_apply(const orc_batch *b, const orc_header *h, const orc_bqsr_final
   for (size_t i = 0; i < memo_n; i++) memo[i] = -1;
   uint32_t maxl = 1;
   for (uint64_t i = 0; i < b->n; i++) if (b->l_seq[i] > maxl) maxl = b->l_seq[i];
+  if (n_threads < 1) n_threads = omp_get_max_threads();
+  int rc_all = 0;
+  if (n_threads == 1) {
+    memcpy(qual_out, b->qual, b->qual_off[b->n]);
+    rc_all = apply_range(b, h, f, quantized, n_sqq > 0 ? static_q : NULL, max_cycle, memo, maxl, 0, b->n, qual_out);
+  } else {
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
+    for (uint64_t c = 0; c < (b->n + 16383) / 16384; c++) {
+      uint64_t lo = c * 16384, hi = lo + 16384 < b->n ? lo + 16384 : b->n;
+      memcpy(qual_out + b->qual_off[lo], b->qual + b->qual_off[lo], b->qual_off[hi] - b->qual_off[lo]);
+      int rc = apply_range(b, h, f, quantized, n_sqq > 0 ? static_q : NULL, max_cycle, memo, maxl, lo, hi, qual_out);
+      if (rc) {
+#pragma omp atomic write
+        rc_all = rc;
+      }
+    }
+  }
+  free(memo);
+  return rc_all;
+}
+
+static int apply_range(const orc_batch *b, const orc_header *h, const orc_bqsr_final *f, const uint8_t *quantized, const uint8_t *static_q,
+                       int max_cycle, int16_t *memo, uint32_t maxl, uint64_t lo, uint64_t hi, uint8_t *qual_out) {
+  int ncyc = 2 * max_cycle + 1;
   uint8_t *sbuf = (uint8_t *)malloc(maxl + 1);
   int32_t *ctx = (int32_t *)malloc((maxl + 2) * sizeof(int32_t));
   waln a; memset(&a, 0, sizeof a);
   int rc = 0;
-  memcpy(qual_out, b->qual, b->qual_off[b->n]);
-  for (uint64_t i = 0; i < b->n; i++) {
+  for (uint64_t i = lo; i < hi; i++) {
     uint16_t rg = b->rgid[i];
     if (rg == ORC_NIL16) { rc = -10; break; } /* readGroupCovariate panics :38 */
     int cov = (int32_t)rg < h->n_rg ? h->rg_cov[rg] : -1;
@@ -1008,12 +1086,13 @@ int orc_bqsr_apply(const orc_batch *b, const orc_header *h, const orc_bqsr_final
       if (cyc > max_cycle || cyc < -max_cycle) { rc = -9; break; }
       int32_t cx = ctx[k]; /* nk == len here: some qual >= 6 > lowQualityTail */
       size_t mi = (((size_t)cov * ORC_NQUAL + q) * ncyc + (size_t)(cyc + max_cycle)) * 17 + (size_t)(cx < 0 ? 16 : ((cx >> 4) & 15));
-      if (memo[mi] < 0) memo[mi] = orc_bqsr_recal_qual(f, cov, q, cyc, cx, quantized, n_sqq > 0 ? static_q : NULL);
-      qo[k] = (uint8_t)memo[mi];
+      int16_t v = memo[mi];
+      if (v < 0) { v = orc_bqsr_recal_qual(f, cov, q, cyc, cx, quantized, static_q); memo[mi] = v; }
+      qo[k] = (uint8_t)v;
     }
     if (rc) break;
   }
-  free(memo); free(sbuf); free(ctx); free(a.cigar);
+  free(sbuf); free(ctx); free(a.cigar);
   return rc;
 }
 

@@ -216,13 +216,18 @@ static void order_pair(const md_state *s, uint64_t *aln1, uint64_t *aln2, pair_k
   k->rev2 = (s->flag[*aln2] & ORC_REVERSED) != 0;
 }
 
+/* :342-396: the pair (aln1 = the mate that arrived later, aln2) enters the pair tournament */
+static void classify_pair_of(md_state *s, uint64_t aln1, uint64_t aln2);
+
 /* :329-396 */
 static void classify_pair(md_state *s, uint64_t aln) {
   if (!is_true_pair(s->flag[aln])) return;
-  uint64_t aln1 = aln, aln2;
   int64_t e = qmap_delete_or_store(&s->pair_frags, s->b, s->lib_of[aln], s->lib_of, aln);
   if (e < 0) return;
-  aln2 = (uint64_t)e;
+  classify_pair_of(s, aln, (uint64_t)e);
+}
+
+static void classify_pair_of(md_state *s, uint64_t aln1, uint64_t aln2) {
   int32_t score = s->score[aln1] + s->score[aln2];
   pair_key k;
   order_pair(s, &aln1, &aln2, &k);
@@ -492,6 +497,266 @@ int orc_dup_metrics(const orc_batch *b, const orc_header *h, const uint32_t *per
   free(fw); free(rv);
   md_free(&s);
   return 0;
+}
+
+/* ---------- the same on all host cores (bench.py's CPU baseline) ----------
+ * The reference runs the three tournaments on sharded maps (sync.NewMap(16 * GOMAXPROCS), mark-duplicates.go:407-410): a key lives
+ * in exactly one shard.  Here every shard is owned by one thread at a time and sees its records in input order, so the result is
+ * the sequential execution's (orc_dup_metrics), whatever the thread count:
+ *   records -> fragment-key shards -> classifyFragment;  records -> {library, QNAME} shards -> DeleteOrStore toggling;
+ *   completed pairs (in order of completion) -> pair-key shards -> pair tournament;  the metrics pass likewise. */
+#include <omp.h>
+
+typedef struct { uint64_t *idx; uint64_t *start; int n_shards; } shard_lists;
+
+/* stable counting sort of the items [0, n) with shard_of[i] >= 0 into per-shard lists (ascending item order inside a shard) */
+static int build_shards(uint64_t n, const int32_t *shard_of, int n_shards, int n_threads, shard_lists *out) {
+  out->n_shards = n_shards;
+  out->start = (uint64_t *)calloc((size_t)n_shards + 1, sizeof(uint64_t));
+  uint64_t *cnt = (uint64_t *)calloc((size_t)n_threads * n_shards, sizeof(uint64_t));
+  if (!out->start || !cnt) return -2;
+#pragma omp parallel num_threads(n_threads)
+  {
+    int t = omp_get_thread_num();
+    uint64_t lo = n * (uint64_t)t / (uint64_t)n_threads, hi = n * (uint64_t)(t + 1) / (uint64_t)n_threads;
+    uint64_t *c = cnt + (size_t)t * n_shards;
+    for (uint64_t i = lo; i < hi; i++)
+      if (shard_of[i] >= 0) c[shard_of[i]]++;
+  }
+  uint64_t total = 0;
+  for (int sh = 0; sh < n_shards; sh++) {
+    out->start[sh] = total;
+    for (int t = 0; t < n_threads; t++) { uint64_t c = cnt[(size_t)t * n_shards + sh]; cnt[(size_t)t * n_shards + sh] = total; total += c; }
+  }
+  out->start[n_shards] = total;
+  out->idx = (uint64_t *)malloc((total + 1) * sizeof(uint64_t));
+  if (!out->idx) return -2;
+#pragma omp parallel num_threads(n_threads)
+  {
+    int t = omp_get_thread_num();
+    uint64_t lo = n * (uint64_t)t / (uint64_t)n_threads, hi = n * (uint64_t)(t + 1) / (uint64_t)n_threads;
+    uint64_t *c = cnt + (size_t)t * n_shards;
+    for (uint64_t i = lo; i < hi; i++)
+      if (shard_of[i] >= 0) out->idx[c[shard_of[i]]++] = i;
+  }
+  free(cnt);
+  return 0;
+}
+static void free_shards(shard_lists *l) { free(l->idx); free(l->start); }
+
+static uint64_t frag_key_hash(const md_state *s, uint64_t i) {
+  frag_key k;
+  memset(&k, 0, sizeof k);
+  k.lb = s->lib_of[i]; k.refid = s->b->refid[i]; k.pos = s->upos[i]; k.reversed = (s->flag[i] & ORC_REVERSED) != 0;
+  return hash_bytes((const uint8_t *)&k, sizeof k);
+}
+static uint64_t qname_key_hash(const md_state *s, uint64_t i) {
+  return mix64(hash_bytes(s->b->qname + s->b->qname_off[i], s->b->qname_off[i + 1] - s->b->qname_off[i]) ^ s->lib_of[i]);
+}
+
+int orc_dup_metrics_mt(const orc_batch *b, const orc_header *h, const uint32_t *perm, int pixel_dist, uint16_t *flag_out, int64_t *counters,
+                       int n_threads) {
+  uint64_t n = b->n;
+  if (n_threads < 1) n_threads = omp_get_max_threads();
+  int n_shards = 16 * n_threads;
+  int nl = h->n_lib + 1;
+  md_state g; /* shared columns */
+  memset(&g, 0, sizeof g);
+  g.b = b; g.flag = flag_out;
+  g.lib_of = (uint16_t *)malloc((n + 1) * sizeof(uint16_t));
+  g.upos = (int32_t *)calloc(n + 1, sizeof(int32_t));
+  g.score = (int32_t *)calloc(n + 1, sizeof(int32_t));
+  int32_t *sh_f = (int32_t *)malloc((n + 1) * sizeof(int32_t)), *sh_q = (int32_t *)malloc((n + 1) * sizeof(int32_t)), *sh_p = (int32_t *)malloc((n + 1) * sizeof(int32_t));
+  int64_t *pair_of = (int64_t *)malloc((n + 1) * sizeof(int64_t));
+  if (!g.lib_of || !g.upos || !g.score || !sh_f || !sh_q || !sh_p || !pair_of) return -2;
+  int bad = 0;
+  /* adapt + shard ids (MarkDuplicates closure :425-440) */
+#pragma omp parallel for schedule(static) num_threads(n_threads) reduction(|:bad)
+  for (uint64_t i = 0; i < n; i++) {
+    flag_out[i] = b->flag[i];
+    uint16_t rg = b->rgid[i];
+    g.lib_of[i] = (rg != ORC_NIL16 && (int32_t)rg < h->n_rg) ? h->rg_lib[rg] : ORC_NIL16;
+    sh_f[i] = sh_q[i] = -1;
+    pair_of[i] = -1;
+    if ((flag_out[i] & (ORC_UNMAPPED | ORC_SECONDARY | ORC_SUPPLEMENTARY)) != 0) continue;
+    int invalid;
+    g.upos[i] = orc_unclipped_position(b->pos[i], flag_out[i], b->cigar + b->cigar_off[i], (uint32_t)(b->cigar_off[i + 1] - b->cigar_off[i]));
+    g.score[i] = orc_phred_score(b->qual + b->qual_off[i], (uint32_t)(b->qual_off[i + 1] - b->qual_off[i]), &invalid);
+    bad |= invalid;
+    sh_f[i] = (int32_t)(frag_key_hash(&g, i) % (uint64_t)n_shards);
+    if (is_true_pair(flag_out[i])) sh_q[i] = (int32_t)(qname_key_hash(&g, i) % (uint64_t)n_shards);
+  }
+  if (bad) return -3;
+  shard_lists lf, lq, lp;
+  if (build_shards(n, sh_f, n_shards, n_threads, &lf) || build_shards(n, sh_q, n_shards, n_threads, &lq)) return -2;
+  /* fragments, and mate matching */
+  int rc_all = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
+  for (int sh = 0; sh < n_shards; sh++) {
+    md_state s = g;
+    uint64_t cnt = lf.start[sh + 1] - lf.start[sh];
+    if (fmap_init(&s.fragments, sizeof(frag_key), cnt)) { rc_all = -2; continue; }
+    for (uint64_t k = lf.start[sh]; k < lf.start[sh + 1]; k++) classify_fragment(&s, lf.idx[k]);
+    fmap_free(&s.fragments);
+    cnt = lq.start[sh + 1] - lq.start[sh];
+    if (qmap_init(&s.pair_frags, cnt)) { rc_all = -2; continue; }
+    for (uint64_t k = lq.start[sh]; k < lq.start[sh + 1]; k++) {
+      uint64_t aln = lq.idx[k];
+      int64_t e = qmap_delete_or_store(&s.pair_frags, b, g.lib_of[aln], g.lib_of, aln);
+      if (e >= 0) pair_of[aln] = e;
+    }
+    qmap_free(&s.pair_frags);
+  }
+  if (rc_all) return rc_all;
+  /* pairs -> pair-key shards, in order of completion */
+#pragma omp parallel for schedule(static) num_threads(n_threads)
+  for (uint64_t i = 0; i < n; i++) {
+    sh_p[i] = -1;
+    if (pair_of[i] < 0) continue;
+    uint64_t a1 = i, a2 = (uint64_t)pair_of[i];
+    pair_key k;
+    order_pair(&g, &a1, &a2, &k);
+    sh_p[i] = (int32_t)(hash_bytes((const uint8_t *)&k, sizeof k) % (uint64_t)n_shards);
+  }
+  if (build_shards(n, sh_p, n_shards, n_threads, &lp)) return -2;
+  md_state *ps = (md_state *)calloc((size_t)n_shards, sizeof(md_state));
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
+  for (int sh = 0; sh < n_shards; sh++) {
+    md_state *s = &ps[sh];
+    *s = g;
+    uint64_t cnt = lp.start[sh + 1] - lp.start[sh];
+    s->prec = (pair_rec *)malloc((cnt + 1) * sizeof(pair_rec));
+    s->cons = (aln_cons *)malloc((cnt + 1) * sizeof(aln_cons));
+    s->n_prec = s->n_cons = 0;
+    if (!s->prec || !s->cons || fmap_init(&s->pairs, sizeof(pair_key), cnt)) { rc_all = -2; continue; }
+    for (uint64_t k = lp.start[sh]; k < lp.start[sh + 1]; k++) classify_pair_of(s, lp.idx[k], (uint64_t)pair_of[lp.idx[k]]);
+  }
+  if (rc_all) return rc_all;
+  /* MarkOpticalDuplicates :469-502: counters over the sorted reads (thread-private, summed: RangeReduce) */
+  memset(counters, 0, (size_t)nl * ORC_NCTR * sizeof(int64_t));
+#pragma omp parallel num_threads(n_threads)
+  {
+    int64_t *c = (int64_t *)calloc((size_t)nl * ORC_NCTR, sizeof(int64_t));
+#pragma omp for schedule(static)
+    for (uint64_t kk = 0; kk < n; kk++) {
+      uint64_t aln = perm ? perm[kk] : kk;
+      if (b->has_sr && b->has_sr[aln]) continue;
+      uint16_t f = flag_out[aln];
+      int lib = g.lib_of[aln] == ORC_NIL16 ? h->n_lib : g.lib_of[aln];
+      int64_t *ctr = c + (size_t)lib * ORC_NCTR;
+      if (f & ORC_UNMAPPED) { ctr[3]++; continue; }
+      if (f & (ORC_SECONDARY | ORC_SUPPLEMENTARY)) { ctr[2]++; continue; }
+      if (is_true_fragment(f)) ctr[0]++;
+      if (is_true_pair(f)) ctr[1]++;
+      if ((f & ORC_DUPLICATE) && is_true_fragment(f)) ctr[4]++;
+    }
+#pragma omp critical
+    for (int k = 0; k < nl * ORC_NCTR; k++) counters[k] += c[k];
+    free(c);
+  }
+  /* duplicate pairs: toggling per {library, QNAME} shard over the SORTED reads (:182-190), then each completed pair is attached to
+   * its origin in its pair-key shard (:191-222) */
+  int32_t *sh_d = (int32_t *)malloc((n + 1) * sizeof(int32_t));
+  int64_t *done_with = (int64_t *)malloc((n + 1) * sizeof(int64_t)); /* per sorted slot: the stored mate it completed a pair with */
+#pragma omp parallel for schedule(static) num_threads(n_threads)
+  for (uint64_t kk = 0; kk < n; kk++) {
+    uint64_t aln = perm ? perm[kk] : kk;
+    uint16_t f = flag_out[aln];
+    done_with[kk] = -1;
+    sh_d[kk] = -1;
+    if (b->has_sr && b->has_sr[aln]) continue;
+    if ((f & (ORC_UNMAPPED | ORC_SECONDARY | ORC_SUPPLEMENTARY)) || !(f & ORC_DUPLICATE) || !is_true_pair(f)) continue;
+    sh_d[kk] = (int32_t)(qname_key_hash(&g, aln) % (uint64_t)n_shards);
+  }
+  shard_lists ld;
+  if (build_shards(n, sh_d, n_shards, n_threads, &ld)) return -2;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
+  for (int sh = 0; sh < n_shards; sh++) {
+    qmap pf;
+    if (qmap_init(&pf, ld.start[sh + 1] - ld.start[sh])) { rc_all = -2; continue; }
+    for (uint64_t k = ld.start[sh]; k < ld.start[sh + 1]; k++) {
+      uint64_t kk = ld.idx[k], aln = perm ? perm[kk] : kk;
+      int64_t e = qmap_delete_or_store(&pf, b, g.lib_of[aln], g.lib_of, aln);
+      if (e >= 0) done_with[kk] = e;
+    }
+    qmap_free(&pf);
+  }
+  /* completed duplicate pairs -> their pair-key shard (sorted order kept) */
+#pragma omp parallel for schedule(static) num_threads(n_threads)
+  for (uint64_t kk = 0; kk < n; kk++) {
+    sh_d[kk] = -1;
+    if (done_with[kk] < 0) continue;
+    uint64_t a1 = perm ? perm[kk] : kk, a2 = (uint64_t)done_with[kk];
+    pair_key k;
+    order_pair(&g, &a1, &a2, &k);
+    sh_d[kk] = (int32_t)(hash_bytes((const uint8_t *)&k, sizeof k) % (uint64_t)n_shards);
+  }
+  free_shards(&ld);
+  if (build_shards(n, sh_d, n_shards, n_threads, &ld)) return -2;
+  int64_t *pairdup = (int64_t *)calloc((size_t)n_shards * nl, sizeof(int64_t)), *opt = (int64_t *)calloc((size_t)n_shards * nl, sizeof(int64_t));
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
+  for (int sh = 0; sh < n_shards; sh++) {
+    md_state *s = &ps[sh];
+    uint64_t cnt = ld.start[sh + 1] - ld.start[sh];
+    free(s->cons);
+    s->cons = (aln_cons *)malloc((cnt + 1) * sizeof(aln_cons));
+    s->n_cons = 0;
+    for (uint64_t k = ld.start[sh]; k < ld.start[sh + 1]; k++) {
+      uint64_t kk = ld.idx[k], aln1 = perm ? perm[kk] : kk, aln2 = (uint64_t)done_with[kk];
+      int lib = g.lib_of[aln1] == ORC_NIL16 ? h->n_lib : g.lib_of[aln1];
+      pairdup[(size_t)sh * nl + lib]++; /* ctr.ReadPairDuplicates++ (:192), on the read that completes the pair */
+      pair_key key;
+      order_pair(&g, &aln1, &aln2, &key);
+      int found;
+      int64_t *slot = fmap_get(&s->pairs, &key, 0, 0, &found);
+      if (!found) { rc_all = -4; continue; }
+      pair_rec *best = &s->prec[*slot];
+      if ((uint64_t)best->aln1 != aln1) {
+        aln_cons *c = &s->cons[s->n_cons];
+        c->aln = (int64_t)((flag_out[aln1] & ORC_FIRST) ? aln1 : aln2);
+        c->next = best->opt_head;
+        best->opt_head = (int64_t)s->n_cons++;
+      }
+    }
+    /* countOpticalDuplicatesPairs :370-431 over this shard's origins */
+    tinfo *fw = NULL, *rv = NULL;
+    size_t cap_f = 0, cap_r = 0;
+    for (uint64_t p = 0; p < s->n_prec; p++) {
+      pair_rec *origin = &s->prec[p];
+      size_t nf = 0, nr = 0;
+      uint64_t oa = (flag_out[origin->aln1] & ORC_FIRST) ? (uint64_t)origin->aln1 : (uint64_t)origin->aln2;
+      for (int pass = 0; pass < 2; pass++) {
+        size_t cf = 0, cr = 0;
+        if (flag_out[oa] & ORC_REVERSED) { if (pass) get_tinfo(b, oa, &rv[cr]); cr++; }
+        else { if (pass) get_tinfo(b, oa, &fw[cf]); cf++; }
+        for (int64_t e = origin->opt_head; e >= 0; e = s->cons[e].next) {
+          uint64_t a = (uint64_t)s->cons[e].aln;
+          if (flag_out[a] & ORC_REVERSED) { if (cr <= 300000) { if (pass) get_tinfo(b, a, &rv[cr]); cr++; } }
+          else { if (cf <= 300000) { if (pass) get_tinfo(b, a, &fw[cf]); cf++; } }
+        }
+        if (!pass) {
+          nf = cf; nr = cr;
+          if (nf > cap_f) { cap_f = nf * 2; fw = (tinfo *)realloc(fw, cap_f * sizeof(tinfo)); }
+          if (nr > cap_r) { cap_r = nr * 2; rv = (tinfo *)realloc(rv, cap_r * sizeof(tinfo)); }
+        }
+      }
+      int lib = g.lib_of[origin->aln1] == ORC_NIL16 ? h->n_lib : g.lib_of[origin->aln1];
+      opt[(size_t)sh * nl + lib] += count_from_slice(fw, (int)nf, pixel_dist) + count_from_slice(rv, (int)nr, pixel_dist);
+    }
+    free(fw); free(rv);
+  }
+  for (int sh = 0; sh < n_shards; sh++) {
+    for (int l = 0; l < nl; l++) {
+      counters[(size_t)l * ORC_NCTR + 5] += pairdup[(size_t)sh * nl + l];
+      counters[(size_t)l * ORC_NCTR + 6] += opt[(size_t)sh * nl + l];
+    }
+    fmap_free(&ps[sh].pairs); free(ps[sh].prec); free(ps[sh].cons);
+  }
+  for (int l = 0; l < nl; l++) counters[(size_t)l * ORC_NCTR + 1] /= 2; /* :504-506 */
+  free(pairdup); free(opt); free(ps); free(sh_f); free(sh_q); free(sh_p); free(sh_d); free(pair_of); free(done_with);
+  free_shards(&lf); free_shards(&lq); free_shards(&lp); free_shards(&ld);
+  free(g.lib_of); free(g.upos); free(g.score);
+  return rc_all;
 }
 
 /* :537-569 */

@@ -111,6 +111,65 @@ int orc_sort_coordinate(const orc_batch *b, uint32_t *perm_out) {
   return 0;
 }
 
+/* ---- the same with all host cores (bench.py's CPU baseline): chunks sorted independently, then merged pairwise; every merge is
+ * split among the threads along the merge path (the output slot k is produced from (i, j), i + j = k, found by binary search), which
+ * is what a parallel merge sort (pargo sort.StableSort, sam/sam-types.go:639-641) does.  Same permutation as orc_sort_coordinate. */
+#include <omp.h>
+static void merge_seg(const orc_batch *b, const uint32_t *x, uint64_t nx, const uint32_t *y, uint64_t ny, uint32_t *out, uint64_t k0, uint64_t k1) {
+  /* co-rank: i = number of elements of x among the first k0 outputs of the stable merge (x before y on ties) */
+  uint64_t lo = k0 > ny ? k0 - ny : 0, hi = k0 < nx ? k0 : nx;
+  while (lo < hi) {
+    uint64_t i = lo + (hi - lo) / 2, j = k0 - i;
+    /* too few from x if y[j-1] is strictly less than x[i] is false ... : x[i] must come before y[j-1] iff !(y[j-1] < x[i]) */
+    if (j > 0 && i < nx && !orc_coordinate_less(b, y[j - 1], x[i])) lo = i + 1;
+    else hi = i;
+  }
+  uint64_t i = lo, j = k0 - lo;
+  for (uint64_t k = k0; k < k1; k++) {
+    if (i < nx && (j >= ny || !orc_coordinate_less(b, y[j], x[i]))) out[k] = x[i++];
+    else out[k] = y[j++];
+  }
+}
+int orc_sort_coordinate_mt(const orc_batch *b, uint32_t *perm_out, int n_threads) {
+  uint64_t n = b->n, k = 0;
+  if (n > 0xFFFFFFFFull) return -1;
+  if (n_threads < 1) n_threads = omp_get_max_threads();
+  for (uint64_t i = 0; i < n; i++)
+    if (!(b->has_sr && b->has_sr[i])) perm_out[k++] = (uint32_t)i;
+  uint64_t n_out = k;
+  for (uint64_t i = 0; i < n; i++)
+    if (b->has_sr && b->has_sr[i]) perm_out[k++] = (uint32_t)i;
+  if (n_out < 2) return 0;
+  uint32_t *tmp = (uint32_t *)malloc(n_out * sizeof(uint32_t));
+  if (!tmp) return -2;
+  uint64_t chunks = 1;
+  while (chunks < (uint64_t)n_threads * 4 && n_out / (chunks * 2) >= 4096) chunks *= 2;
+  uint64_t clen = (n_out + chunks - 1) / chunks;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
+  for (uint64_t c = 0; c < chunks; c++) {
+    uint64_t lo = c * clen, hi = lo + clen < n_out ? lo + clen : n_out;
+    if (lo < hi) msort(b, perm_out, tmp, lo, hi);
+  }
+  uint32_t *src = perm_out, *dst = tmp;
+  for (uint64_t w = clen; w < n_out; w *= 2) {
+    uint64_t pairs = (n_out + 2 * w - 1) / (2 * w);
+    uint64_t seg = 1 << 16;  /* output slots per task */
+#pragma omp parallel for schedule(dynamic, 4) num_threads(n_threads)
+    for (uint64_t t = 0; t < pairs * ((2 * w + seg - 1) / seg); t++) {
+      uint64_t per = (2 * w + seg - 1) / seg, p = t / per, s0 = (t % per) * seg;
+      uint64_t lo = p * 2 * w, mid = lo + w < n_out ? lo + w : n_out, hi = lo + 2 * w < n_out ? lo + 2 * w : n_out;
+      uint64_t len = hi - lo;
+      if (s0 >= len) continue;
+      uint64_t s1 = s0 + seg < len ? s0 + seg : len;
+      merge_seg(b, src + lo, mid - lo, src + mid, hi - mid, dst + lo, s0, s1);
+    }
+    uint32_t *t2 = src; src = dst; dst = t2;
+  }
+  if (src != perm_out) memcpy(perm_out, src, n_out * sizeof(uint32_t));
+  free(tmp);
+  return 0;
+}
+
 /* sam/split-merge.go:178-213 computeContigGroups (group numbering only; "unmapped" is group 0) */
 int orc_contig_groups(const int32_t *ref_len, int n_ref, int contig_group_size, int32_t *group_of_ref) {
   if (contig_group_size <= 0) {
