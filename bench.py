@@ -1,15 +1,20 @@
 #!/usr/bin/env python3
-"""bench.py — Mreads/s through coordinate sort + mark duplicates (+ optical metrics) + BQSR gather + finalize + apply.
+"""bench.py — Mreads/s through mark duplicates + coordinate sort (+ optical metrics) + BQSR gather + finalize + apply.
 
 Contract (see the task description): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches it under
 torch.distributed.run, one rank per GPU.  A "step" is one pass of the whole hot path over the rank's resident shard of
 synthetic 150 bp paired-end reads (inputs are in HBM before the timed region starts; staging over PCIe is reported
 separately and is never `value`).  Rank 0 prints ONE JSON line.
 
-Multi-GPU (weak scaling): every rank holds its own shard (`--reads` per GPU, contig-partition style, no data-path
-collective); the only exchange is one RCCL all-reduce of the BQSR count tables + duplicate metrics (the sfm
-"sum the per-split tables" step, cmd/sfm.go:769-805 / filters/print-bqsr.go:310-329), after which every rank finalizes
-and applies locally.
+N = 1 is `elprep filter` (one context): BASELINE.json's config C3 (50 M reads, sort + markdup + BQSR), the largest single-GPU
+configuration.  The same line carries, as `extra`, the other single-GPU facts asked for: config C2 (mark duplicates + sort only) on
+the same staged reads, the path on a read set with ~40 distinct quality values (the 7-value binned qualities of the main workload
+are the easy case for the BQSR kernels), and the PCIe-inclusive staging rate through elp_stage_bam.
+
+N > 1 is `elprep sfm`: contig groups -> ranks; the only exchange per step is ONE all-reduce (RCCL through the C ABI's device
+group) of the BQSR count tables + duplication counters.  `--scaling weak` (default; per-GPU reads fixed) or `--scaling strong
+--total-reads R` (a fixed read set partitioned by the real computeContigGroups of the genome: per-rank counts and the imbalance
+are in the line).
 """
 from __future__ import annotations
 
@@ -28,12 +33,13 @@ if ROOT not in sys.path:
 # algorithmic HBM bytes per read, SURVEY.md §8(d) / BASELINE.md §3
 BYTES_PER_READ = {"adapt": 185, "sort": 152, "markdup": 138, "bqsr_gather": 424, "bqsr_apply": 385}
 BYTES_FULL_PATH = 1284
+BYTES_C2 = 475
 HBM_PEAK_GBS = 8000.0
 MAX_CYCLE = 500
 
 
 def kernel_stage(name: str) -> str:
-    if name.startswith("adapt"):
+    if name.startswith("adapt") or name.startswith("flat_index") or name.startswith("qual_present"):
         return "adapt"
     if name.startswith("md_"):
         return "markdup"
@@ -46,6 +52,55 @@ def kernel_stage(name: str) -> str:
     return "sort"  # radix_*, scan_*, tie_*, iota, material_*, seg_*, large_*, add_own
 
 
+def timed(step, restore, steps, warmup, prof_eng, barrier):
+    """W untimed + K timed steps, bracketed by barrier + device sync; restore (two D2D copies) is bookkeeping, not the path"""
+    for _ in range(warmup):
+        restore()
+        step()
+    prof_eng.profile_enable(True)
+    prof_eng.profile_reset()
+    restore_s = 0.0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr = time.perf_counter()
+        restore()
+        restore_s += time.perf_counter() - tr
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0 - restore_s
+    prof = prof_eng.profile()
+    prof_eng.profile_enable(False)
+    return elapsed, prof
+
+
+def summarize(prof, steps, n_reads, full_bytes):
+    """per-stage kernel ms per step, the dominant kernel and its roofline figures"""
+    stage_ms = {}
+    for name, (cnt, ms) in prof.items():
+        st = kernel_stage(name)
+        stage_ms[st] = stage_ms.get(st, 0.0) + ms / steps
+    dom = max(prof.items(), key=lambda kv: kv[1][1])[0]
+    dom_stage = kernel_stage(dom)
+    launches_per_step = max(prof[dom][0] / steps, 1)
+    dom_launch_ms = prof[dom][1] / max(prof[dom][0], 1)
+    # achieved = algorithmic bytes of the stage the dominant kernel belongs to (SURVEY.md 8d x the reads one launch processes), per launch
+    achieved = (BYTES_PER_READ.get(dom_stage, 0) * n_reads / launches_per_step) / (dom_launch_ms * 1e-3) / 1e9 if dom_launch_ms > 0 else 0.0
+    kernel_total_ms = sum(stage_ms.values())
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if dom in tj["bytes_per_read"]:
+            traffic = round(tj["bytes_per_read"][dom] * n_reads / launches_per_step)
+    except Exception:
+        traffic = None
+    roof = {"bound": "hbm", "kernel": dom, "stage": dom_stage, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+            "path_frac": round((full_bytes * n_reads / (kernel_total_ms * 1e-3) / 1e9) / HBM_PEAK_GBS, 5) if kernel_total_ms else None}
+    kern = {k: round(v[1] / steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:14]}
+    return {k: round(v, 3) for k, v in sorted(stage_ms.items())}, kern, roof
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -53,8 +108,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=int(os.environ.get("ELP_BENCH_READS", 50_000_000)), help="reads per GPU (approximate: pairs = reads/2)")
     ap.add_argument("--genome", default="c3", help="synthetic genome preset (tools/synth): c3 = hg38/12, 24 contigs")
+    ap.add_argument("--quals", choices=["binned", "full"], default="binned", help="quality alphabet of the main workload: 7 binned values or ~40 values")
+    ap.add_argument("--stages", choices=["full", "c2"], default="full", help="full = BASELINE config C3 (sort+markdup+BQSR); c2 = mark duplicates + sort only")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="N > 1: per-GPU reads fixed, or --total-reads partitioned by contig groups")
+    ap.add_argument("--total-reads", type=int, default=0, help="strong scaling: reads of the whole job (default: --reads)")
     ap.add_argument("--cpu-reads", type=int, default=16_000_000, help="sample size for the CPU baseline leg (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="N = 1: skip the C2 / full-quality / PCIe-inclusive side measurements")
+    ap.add_argument("--extra-reads", type=int, default=16_000_000, help="reads of the full-quality side measurement")
     args = ap.parse_args()
 
     import torch
@@ -86,14 +147,16 @@ def main():
     from tools import synth
 
     cfg = synth.config(args.genome)
+    cfg.qual_mode = 1 if args.quals == "full" else 0
     hdr = cfg.header()
     pairs_per_rank = args.reads // 2
-    refs_sites = lambda: ((r, synth.reference(cfg, r), flatten_sites(synth.known_sites_raw(cfg, r))) for r in range(hdr.n_ref))
+    refs_sites = [(r, synth.reference(cfg, r), flatten_sites(synth.known_sites_raw(cfg, r))) for r in range(hdr.n_ref)]
 
     from collections import deque
     from concurrent.futures import ThreadPoolExecutor
     workers = max(1, min(12, (os.cpu_count() or 2) // max(world, 1)))
     chunk = 1_000_000
+    host_pool = ThreadPoolExecutor(1)
 
     def generated(jobs):
         """yield the batches of `jobs` = [(config, pair_lo, pair_hi), ...] in order; the generator is deterministic per pair index,
@@ -112,33 +175,22 @@ def main():
                     q.append(pool.submit(synth.generate, *j))
                 yield b
 
-    t0 = time.time()
-    stage_s = 0.0
-    dev_id = local_rank if world > 1 else 0
-    if world == 1:
-        # ---- `elprep filter`: one context holds everything (untimed staging; PCIe-inclusive rate reported separately)
-        eng = Engine(hdr, dev_id)
-        n_total = 0
-        for b in generated([(cfg, lo, min(lo + chunk, pairs_per_rank)) for lo in range(0, pairs_per_rank, chunk)]):
-            ts = time.time()
-            eng.stage(b)
-            stage_s += time.time() - ts
-            n_total += b.n
-            del b
-        for r, ref, sites in refs_sites():
-            eng.set_reference(r, ref)
-            eng.set_known_sites(r, sites)
-        eng.sync()
-        eng.snapshot()  # FLAG and QUAL are the only columns the path mutates; every step starts from the same staged input
-        prof_eng = eng
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
 
-        def restore():
-            eng.rollback()
-            eng.sync()
+    def make_filter_steps(eng, lut_buf):
+        """the step functions of one `elprep filter` context.  Order of events as in the reference (cmd/filter.go:142-211): MarkDuplicates
+        is a filter of the phase-1 pipeline, the sort is that pipeline's Finalize (sam/filter-pipeline.go:116), then the metrics pass,
+        Recalibrate, finalize, ApplyBQSR."""
+        def finalize_lut(qt, ct, xt):
+            tb = BqsrTables(qt, ct, xt, MAX_CYCLE).finalize()
+            lut, present = tb.build_lut(0, out=lut_buf[0])
+            lut_buf[0] = (lut, present)
+            return lut, present
 
-        def step():
-            # the reference's order of events (cmd/filter.go:142-211): MarkDuplicates is a filter of the phase-1 pipeline, the sort is
-            # that pipeline's Finalize (sam/filter-pipeline.go:116), then the metrics pass, Recalibrate, finalize, ApplyBQSR
+        def step_full():
             eng.mark_duplicates(True, fetch=False)
             eng.sort_coordinate(fetch=False)
             qt, ct, xt = eng.recalibrate(MAX_CYCLE, reuse=True)
@@ -150,41 +202,73 @@ def main():
             eng.apply_bqsr(lut, present, MAX_CYCLE, fetch=False)
             eng.sync()
 
-        def finalize_lut(qt, ct, xt):
-            tb = BqsrTables(qt, ct, xt, MAX_CYCLE).finalize()
-            lut, present = tb.build_lut(0, out=lut_buf[0])
-            lut_buf[0] = (lut, present)
-            return lut, present
-        host_pool = ThreadPoolExecutor(1)
-        lut_buf = [None]  # the host side keeps its arrays from step to step, as a long-running caller would
+        def step_c2():
+            eng.mark_duplicates(True, fetch=False)
+            eng.sort_coordinate(fetch=False)
+            eng.sync()
+
+        def restore():
+            eng.rollback()
+            eng.sync()
+        return step_full, step_c2, restore
+
+    t0 = time.time()
+    stage_s = 0.0
+    dev_id = local_rank if world > 1 else 0
+    per_rank_reads = None
+    if world == 1:
+        # ---- `elprep filter`: one context holds everything (untimed staging; PCIe-inclusive rate reported separately)
+        eng = Engine(hdr, dev_id)
+        n_total = 0
+        for b in generated([(cfg, lo, min(lo + chunk, pairs_per_rank)) for lo in range(0, pairs_per_rank, chunk)]):
+            ts = time.time()
+            eng.stage(b)
+            stage_s += time.time() - ts
+            n_total += b.n
+            del b
+        for r, ref, sites in refs_sites:
+            eng.set_reference(r, ref)
+            eng.set_known_sites(r, sites)
+        eng.sync()
+        eng.snapshot()  # FLAG and QUAL are the only columns the path mutates; every step starts from the same staged input
+        prof_eng = eng
+        step_full, step_c2, restore = make_filter_steps(eng, [None])
+        step = step_full if args.stages == "full" else step_c2
         mode = "filter"
     else:
         # ---- `elprep sfm`: contig groups -> ranks; every rank produces the reads of the groups it owns, the few records that
         # belong to another rank's split (spread mates, supplementary alignments, unmapped pairs) are routed point to point;
-        # per step ONE all-reduce (RCCL over xGMI) of the BQSR count tables + duplication counters
+        # per step ONE all-reduce (RCCL over xGMI, through the C ABI's device group) of the BQSR count tables + duplication counters
         from elprep_amd import sfm
         comm = sfm.Comm(cdev)
-        gof, G = sfm.contig_groups(cfg.ref_len)
+        gof, G = sfm.contig_groups(cfg.ref_len)  # computeContigGroups on the genome's @SQ lengths (hg38 proportions)
         ranges = sfm.group_ranges(gof, G)
         glen = [float(sum(cfg.ref_len[lo:hi])) for lo, hi in ranges]
         weights = [0.012 * sum(glen)] + glen + [0.03 * sum(glen)]
         owner = sfm.assign_splits(weights, world)
         mine = [g for g in range(1, G + 1) if owner[g] == rank]
         mylen = sum(glen[g - 1] for g in mine)
-        # per-GPU work is fixed (weak scaling): every rank ends up with about `--reads` records.  The owners of the spread and of the
-        # unmapped split receive records from everybody (fractions measured on a small sample), so they generate fewer of their own.
-        sample = synth.generate(cfg, 0, 20000)
-        sg, ssp = sfm.split_records(sample, gof)
-        f_spread, f_unmapped = float(ssp.mean()), float((sg == 0).mean())
-        extra = (f_spread * world if owner[G + 1] == rank else 0.0) + (f_unmapped * world if owner[0] == rank else 0.0) - f_unmapped
-        my_pairs = max(int(pairs_per_rank * (1.0 - extra)), pairs_per_rank // 4)
         jobs = []
-        for g in mine:  # this rank's pairs are spread over its groups by length
+        if args.scaling == "weak":
+            # per-GPU work is fixed: every rank ends up with about `--reads` records.  The owners of the spread and of the unmapped
+            # split receive records from everybody (fractions measured on a small sample), so they generate fewer of their own.
+            sample = synth.generate(cfg, 0, 20000)
+            sg, ssp = sfm.split_records(sample, gof)
+            f_spread, f_unmapped = float(ssp.mean()), float((sg == 0).mean())
+            extra = (f_spread * world if owner[G + 1] == rank else 0.0) + (f_unmapped * world if owner[0] == rank else 0.0) - f_unmapped
+            my_pairs = max(int(pairs_per_rank * (1.0 - extra)), pairs_per_rank // 4)
+            pairs_of_group = {g: int(my_pairs * glen[g - 1] / max(mylen, 1.0)) for g in mine}
+        else:
+            # total work is fixed: the read set of the whole job is spread over the genome, a group gets its share by length, a rank
+            # the groups computeContigGroups + the balanced assignment give it - the imbalance of the real `sfm` split shows
+            total_pairs = (args.total_reads or args.reads) // 2
+            pairs_of_group = {g: int(total_pairs * glen[g - 1] / sum(glen)) for g in mine}
+        for g in mine:
             c = synth.config(args.genome)
+            c.qual_mode = cfg.qual_mode
             c.seed = cfg.seed + 7919 * g
             c.home_lo, c.home_hi = ranges[g - 1]
-            npairs = int(my_pairs * glen[g - 1] / max(mylen, 1.0))
-            jobs += [(c, lo, min(lo + chunk, npairs)) for lo in range(0, npairs, chunk)]
+            jobs += [(c, lo, min(lo + chunk, pairs_of_group[g])) for lo in range(0, pairs_of_group[g], chunk)]
         rounds = torch.tensor([len(jobs)], dtype=torch.int64, device=cdev)
         dist.all_reduce(rounds, op=dist.ReduceOp.MAX)  # every rank takes part in every routing round
         rk = sfm.SfmRank(hdr, dev_id, comm)
@@ -199,12 +283,13 @@ def main():
             stage_s += time.time() - ts
             n_total += int((got.local.has_sr == 0).sum()) + got.spread.n  # the tagged copies are not reads of their own
             del b, got
-        for r, ref, sites in refs_sites():
+        for r, ref, sites in refs_sites:
             rk.set_reference(r, ref)
             rk.set_known_sites(r, sites)
         rk.sync()
         rk.snapshot()
         prof_eng = rk.engines[0]
+        lut_buf = [None]
 
         def restore():
             rk.rollback()
@@ -217,69 +302,30 @@ def main():
             lut_buf[0] = (lut, present)
             rk.apply(lut, present, MAX_CYCLE)
             rk.sync()
-        lut_buf = [None]
         mode = "sfm"
+        counts = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(world)]
+        dist.all_gather(counts, torch.tensor([n_total], dtype=torch.int64, device=cdev))
+        per_rank_reads = [int(c.item()) for c in counts]
     gen_s = time.time() - t0 - stage_s
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        restore()
-        step()
-    prof_eng.profile_enable(True)
-    prof_eng.profile_reset()
-    restore_s = 0.0
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tr = time.perf_counter()
-        restore()
-        restore_s += time.perf_counter() - tr
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0 - restore_s  # state restore (two D2D copies) is bookkeeping, not part of the path
-    prof = prof_eng.profile()
-    prof_eng.profile_enable(False)
+    elapsed, prof = timed(step, restore, args.steps, args.warmup, prof_eng, barrier)
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        nt = torch.tensor([n_total], dtype=torch.int64, device=cdev)
-        dist.all_reduce(nt, op=dist.ReduceOp.SUM)
-        n_global = int(nt.item())
+        n_global = sum(per_rank_reads)
     else:
         n_global = n_total
 
+    out = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = n_global / (elapsed / args.steps) / 1e6
-        # per-stage kernel time (HIP events on the ctx stream) -> dominant kernel roofline
-        stage_ms = {}
-        for name, (cnt, ms) in prof.items():
-            st = kernel_stage(name)
-            stage_ms[st] = stage_ms.get(st, 0.0) + ms / args.steps
-        kern_ms = {name: ms / max(cnt, 1) for name, (cnt, ms) in prof.items()}
-        dom = max(prof.items(), key=lambda kv: kv[1][1])[0]
-        dom_stage = kernel_stage(dom)
-        dom_launch_ms = kern_ms[dom]
-        dom_bytes = BYTES_PER_READ.get(dom_stage, 0) * n_total
-        launches_per_step = prof[dom][0] / args.steps
-        # achieved = algorithmic bytes of the stage the dominant kernel belongs to, per launch of that kernel
-        achieved = (dom_bytes / max(launches_per_step, 1)) / (dom_launch_ms * 1e-3) / 1e9 if dom_launch_ms > 0 else 0.0
-        kernel_total_ms = sum(stage_ms.values())
-        # HBM traffic of the dominant kernel from the committed PMC passes (bytes per read measured at the profile's size, scaled to
-        # this run's reads; per launch like `achieved`); null if the kernel was not profiled
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            if dom in tj["bytes_per_read"]:
-                traffic = round(tj["bytes_per_read"][dom] * n_total / max(launches_per_step, 1))
-        except Exception:
-            traffic = None
+        full_bytes = BYTES_FULL_PATH if args.stages == "full" else BYTES_C2
+        stage_ms, kern_ms, roof = summarize(prof, args.steps, n_total, full_bytes)
+        what = ("mark duplicates + coordinate sort + optical metrics + BQSR gather + finalize + apply (BASELINE config C3)" if args.stages == "full"
+                else "mark duplicates + coordinate sort (BASELINE config C2)")
         out = {
             "metric": "Mreads/s through sort+markdup+BQSR, 150bp PE",
             "value": round(value, 3),
@@ -289,19 +335,71 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None,
             "dtype": "u8/int32/int64 (integer path; float64 finalize on host)",
             "data": "synthetic",
-            "config": {"workload": f"C3-style ({mode}): {n_total} reads on rank 0, {args.reads} requested per GPU, 150bp PE, genome {args.genome} (24 contigs hg38/12), sort+markdup+optical metrics+BQSR gather+finalize+apply",
-                       "reads_per_gpu": n_total, "max_cycle": MAX_CYCLE, "parallelism": ("filter: one context" if world == 1 else f"sfm: contig groups over {world} GPUs, spread split on one rank, one all-reduce per step")},
-            "roofline": {"bound": "hbm", "kernel": dom, "stage": dom_stage, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "path_frac": round((BYTES_FULL_PATH * n_total / (kernel_total_ms * 1e-3) / 1e9) / HBM_PEAK_GBS, 5) if kernel_total_ms else None},
-            "stage_ms_per_step": {k: round(v, 3) for k, v in sorted(stage_ms.items())},
-            "kernel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:12]},
-            "staging": {"gen_s": round(gen_s, 2), "h2d_stage_s": round(stage_s, 2)},
+            "config": {"workload": f"{'C3' if args.stages == 'full' else 'C2'}-style ({mode}): {n_total} reads on rank 0, {args.reads} requested per GPU, 150bp PE, genome {args.genome} "
+                                   f"(24 contigs hg38/12), {args.quals} qualities, {what}",
+                       "reads_per_gpu": n_total, "max_cycle": MAX_CYCLE,
+                       "parallelism": ("filter: one context" if world == 1 else f"sfm: contig groups over {world} GPUs, spread split on one rank, one all-reduce per step "
+                                                                              f"({rk.collective} collective)")},
+            "roofline": roof,
+            "stage_ms_per_step": stage_ms,
+            "kernel_ms_per_step": kern_ms,
+            "staging": {"gen_s": round(gen_s, 2), "h2d_stage_s": round(stage_s, 2),
+                        "elp_stage_Mreads_per_s": round(n_total / max(stage_s, 1e-9) / 1e6, 2)},
         }
+        if world > 1:
+            out["ranks_seen"] = dist.get_world_size()
+            out["per_rank_reads"] = per_rank_reads
+            out["imbalance_max_over_mean"] = round(max(per_rank_reads) / (sum(per_rank_reads) / len(per_rank_reads)), 4)
+
+    # ---- N = 1 side measurements: config C2 on the same reads, the ~40-quality read set, the PCIe-inclusive staging rate
+    if world == 1 and rank == 0 and not args.no_extra:
+        extra = {}
+        try:
+            if args.stages == "full":
+                el, pr = timed(step_c2, restore, 3, 1, eng, barrier)
+                st, km, rf = summarize(pr, 3, n_total, BYTES_C2)
+                extra["c2_sort_markdup"] = {"workload": f"BASELINE config C2: mark duplicates + coordinate sort of the same {n_total} staged reads",
+                                            "value": round(n_total / (el / 3) / 1e6, 3), "unit": "Mreads/s", "ms_per_step": round(el / 3 * 1e3, 3),
+                                            "stage_ms_per_step": st, "roofline": rf}
+        except Exception as e:  # a side measurement must not cost the main line
+            extra["c2_sort_markdup"] = {"error": repr(e)}
+        eng.close()
+        eng = None
+        try:
+            extra["pcie_inclusive"] = pcie_inclusive(cfg, hdr, min(args.extra_reads, 8_000_000), out["ms_per_step"], n_total)
+        except Exception as e:
+            extra["pcie_inclusive"] = {"error": repr(e)}
+        try:
+            if args.quals == "binned" and args.extra_reads > 0:
+                cq = synth.config(args.genome)
+                cq.qual_mode = 1
+                e2 = Engine(hdr, dev_id)
+                n2 = 0
+                for b in generated([(cq, lo, min(lo + chunk, args.extra_reads // 2)) for lo in range(0, args.extra_reads // 2, chunk)]):
+                    e2.stage(b)
+                    n2 += b.n
+                    del b
+                for r, ref, sites in refs_sites:
+                    e2.set_reference(r, ref)
+                    e2.set_known_sites(r, sites)
+                e2.sync()
+                e2.snapshot()
+                sf2, _, rs2 = make_filter_steps(e2, [None])
+                el, pr = timed(sf2, rs2, 3, 1, e2, barrier)
+                st, km, rf = summarize(pr, 3, n2, BYTES_FULL_PATH)
+                extra["full_quals"] = {"workload": f"{n2} reads, same generator with ~40 distinct quality values (3..41 and 2), full path",
+                                       "value": round(n2 / (el / 3) / 1e6, 3), "unit": "Mreads/s", "ms_per_step": round(el / 3 * 1e3, 3),
+                                       "stage_ms_per_step": st, "kernel_ms_per_step": km, "roofline": rf}
+                e2.close()
+        except Exception as e:
+            extra["full_quals"] = {"error": repr(e)}
+        out["extra"] = extra
+
+    if rank == 0:
         if not args.no_cpu_baseline and args.cpu_reads > 0:
             out["cpu_baseline"] = cpu_baseline(cfg, hdr, args.cpu_reads)
         print(json.dumps(out))
@@ -309,8 +407,53 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         rk.close()
-    else:
+    elif eng is not None:
         eng.close()
+
+
+def pcie_inclusive(cfg, hdr, n_reads, ms_per_step, n_main):
+    """Staging straight from inflated BAM records in page-locked memory (elp_stage_bam: one DMA of the raw bytes, the columns are cut
+    on the device) and the way back (elp_emit_sorted_bam: gather in sorted order + D2H), timed: what a host that inflates BGZF blocks
+    into pinned buffers gets.  The BAM bytes are made by the oracle's encoder (test infrastructure standing in for the BAM reader)."""
+    import ctypes
+    import oracle as orc
+    from elprep_amd import _lib
+    from elprep_amd.engine import Engine
+    from tools import synth
+    b = synth.generate(cfg, 0, n_reads // 2)
+    L = _lib.hip()
+    arr = (ctypes.c_char_p * len(hdr.rg_ids))(*[s.encode() for s in hdr.rg_ids])
+    st = b.as_struct()
+    size = orc.lib().orc_bam_encode(ctypes.byref(st), arr, None, ctypes.c_uint64(0), None, None, ctypes.c_int(0), None)
+    ptr = L.elp_pinned_alloc(size)
+    buf = np.frombuffer((ctypes.c_uint8 * size).from_address(ptr), dtype=np.uint8)
+    orc.bam_encode(b, hdr.rg_ids, out=buf)
+    e = Engine(hdr, 0)
+    e.set_read_group_ids(hdr.rg_ids)
+    e.stage_bam(buf[:0])  # empty call: creates the copy stream outside the timed region
+    e.reserve(b.n, int(b.qname_off[-1]), int(b.cigar_off[-1]), int(b.seq_off[-1]), int(b.qual_off[-1]))
+    t0 = time.perf_counter()
+    e.stage_bam(buf)
+    e.sync()
+    t_in = time.perf_counter() - t0
+    e.mark_duplicates(True, fetch=False)
+    e.sort_coordinate(fetch=False)
+    out_ptr = L.elp_pinned_alloc(size + 64)
+    out = np.frombuffer((ctypes.c_uint8 * (size + 64)).from_address(out_ptr), dtype=np.uint8)
+    t0 = time.perf_counter()
+    got = e.emit_sorted_bam(out)
+    t_out = time.perf_counter() - t0
+    n = b.n
+    res = {"workload": f"{n} reads as {size} bytes of inflated BAM records in page-locked host memory",
+           "stage_bam_Mreads_per_s": round(n / t_in / 1e6, 2), "stage_bam_GB_per_s": round(size / t_in / 1e9, 2),
+           "emit_sorted_bam_Mreads_per_s": round(n / t_out / 1e6, 2), "emit_sorted_bam_GB_per_s": round(got.size / t_out / 1e9, 2),
+           # one pass of the path with both transfers, at the main run's step time per read
+           "end_to_end_Mreads_per_s": round(n / (t_in + t_out + ms_per_step * 1e-3 * n / max(n_main, 1)) / 1e6, 2)}
+    e.close()
+    del buf, out
+    L.elp_pinned_free(ptr)
+    L.elp_pinned_free(out_ptr)
+    return res
 
 
 def flatten_sites(raw: np.ndarray) -> np.ndarray:

@@ -29,6 +29,8 @@ typedef struct synth_cfg {
   double p_spread;         /* 0.02 mates on different contigs */
   double p_frag;           /* 0.0  unpaired single-end records (flag 0/16) — extra coverage for fragment logic */
   int32_t n_lanes;         /* 4 read groups, one per lane; lanes 1..n/2 -> lib 0, rest -> lib 1 */
+  int32_t qual_mode;       /* 0 = binned qualities (2, 12, 23, 25, 27, 32, 37: NovaSeq-style), 1 = full range (~40 distinct values 2..41, as an
+                              unbinned HiSeq run reports them) */
   int32_t home_lo, home_hi; /* the fragment's contig is drawn from [home_lo, home_hi) (both 0 = all contigs); the mate of a spread pair
                               is drawn from the whole genome.  Used to generate the reads of one contig group directly (sfm-style shards). */
 } synth_cfg;
@@ -274,6 +276,12 @@ static void emit_record(emit *e, uint64_t p, int rec, const layout *L, const cha
       else if (u < pd * 0.7) qq = 23;
       else if (u < pd) qq = 27;
       else qq = mean == 37 ? 37 : (mean == 30 ? 32 : 25);
+      if (c->qual_mode == 1 && qq != 2) { /* spread every bin over +-4 around its centre */
+        uint64_t hd = sm64(hq ^ (0x9E3779B97F4A7C15ull * (uint64_t)(i + 1)));
+        qq += (int)(hd % 9) - 4;
+        if (qq > 41) qq = 41;
+        if (qq < 3) qq = 3;
+      }
       q[i] = (uint8_t)qq;
     }
     if (u01(sm64(hm)) < 0.1) { /* low-quality tail at the 3' end of the sequencing direction */
