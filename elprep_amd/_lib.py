@@ -85,7 +85,7 @@ def hip() -> C.CDLL:
         L.elp_pinned_alloc.argtypes = [C.c_size_t]
         L.elp_pinned_free.restype = None
         L.elp_pinned_free.argtypes = [C.c_void_p]
-        L.elp_stage_bam.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint16]
+        L.elp_stage_bam.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint16]
         L.elp_emit_sorted_bam.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.elp_filter_records.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.elp_split_classify.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -467,11 +467,12 @@ __device__ __forceinline__ uint32_t lshl_add_u32(uint32_t a, uint32_t b) {  // (
   return r;
 }
 
-template <bool CHECK_CYCLE, bool REFLDS>
+template <bool CHECK_CYCLE, bool REFLDS, int NTV = FL_THREADS>
 struct CountBody {
   // groups of 256 reads: the per-read LDS (44 B) competes with the private tables for the 80 KB that let two workgroups share a CU
-  // (with four read groups and six qualities the tables take 50 KB); 256 KiB steps save the per-step restart of the pipeline
-  static constexpr int NT = FL_THREADS, TILES = 8, RMAX = 256;
+  // (with four read groups and six qualities the tables take 50 KB); 256 KiB steps save the per-step restart of the pipeline.
+  // NTV = 1024: one workgroup per CU shares one big table (many qualities x read groups): same waves per SIMD as two of 512
+  static constexpr int NT = NTV, TILES = 8, RMAX = NTV == 1024 ? 512 : 256;
   // kernel arguments (scalar copies: a reference to the argument struct would keep this object in scratch memory)
   const uint64_t *__restrict__ seq_off;
   const uint8_t *__restrict__ qual;
@@ -733,9 +734,9 @@ struct CountBody {
   }
 };
 
-template <bool CHECK_CYCLE, bool REFLDS>
-__global__ __launch_bounds__(FL_THREADS, 4) void k_bqsr_count(CountArgs A, QMap qm) {
-  constexpr int RMAX = CountBody<CHECK_CYCLE, REFLDS>::RMAX;
+template <bool CHECK_CYCLE, bool REFLDS, int NTV>
+__global__ __launch_bounds__(NTV, 4) void k_bqsr_count(CountArgs A, QMap qm) {
+  constexpr int RMAX = CountBody<CHECK_CYCLE, REFLDS, NTV>::RMAX;
   __shared__ FlatLds<RMAX> L;
   __shared__ uint4 s_desc[2 * RMAX];
   __shared__ uint32_t s_seq[RMAX];
@@ -749,9 +750,9 @@ __global__ __launch_bounds__(FL_THREADS, 4) void k_bqsr_count(CountArgs A, QMap 
   const int n_all = A.n_cov * (A.n_q + CT_XROWS) * A.rs + CT_PAD;
   const uint32_t tbl_at = lds_address(tbl);
   if (REFLDS)
-    for (int r = threadIdx.x; r < A.n_ref; r += FL_THREADS) { s_refp[r] = reinterpret_cast<uint64_t>(A.ref_seq[r]); s_refl[r] = A.ref_seq_len[r]; }
-  for (int k = threadIdx.x; k < n_all; k += FL_THREADS) tbl[k] = 0;
-  for (int q = threadIdx.x; q < 256; q += FL_THREADS) {
+    for (int r = threadIdx.x; r < A.n_ref; r += NTV) { s_refp[r] = reinterpret_cast<uint64_t>(A.ref_seq[r]); s_refl[r] = A.ref_seq_len[r]; }
+  for (int k = threadIdx.x; k < n_all; k += NTV) tbl[k] = 0;
+  for (int q = threadIdx.x; q < 256; q += NTV) {
     int row;
     if (q < 6) row = A.n_q + 2;                // not counted (bqsr.go:301-305)
     else if (q >= ELP_NQUAL) row = A.n_q;      // bad quality
@@ -763,7 +764,7 @@ __global__ __launch_bounds__(FL_THREADS, 4) void k_bqsr_count(CountArgs A, QMap 
     qrow[q] = tbl_at + (uint32_t)(row * A.rs) * 4u;
   }
   __syncthreads();
-  CountBody<CHECK_CYCLE, REFLDS> B;
+  CountBody<CHECK_CYCLE, REFLDS, NTV> B;
   B.seq_off = A.seq_off; B.qual = A.qual; B.seq4 = A.seq4; B.desc = reinterpret_cast<const uint4 *>(A.desc);
   B.cigar = A.cigar; B.cig_scratch = A.cig_scratch; B.skipbits = A.skipbits; B.ref_seq = A.ref_seq; B.ref_seq_len = A.ref_seq_len;
   B.cycle_tbl = A.cycle_tbl; B.ctx_tbl = A.ctx_tbl;
@@ -1229,7 +1230,9 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
     const int rs = (CT_CYC + ((17 * 2 * lmax) >> 4) + 1 + 1) & ~1;  // words per row
     const size_t per_slot = (size_t)c->n_cov * (size_t)rs * 4;
     typedef CountBody<false, true> CB;
+    typedef CountBody<false, true, 1024> CB1;
     const size_t static_lds = sizeof(FlatLds<CB::RMAX>) + (size_t)CB::RMAX * (sizeof(BqDesc) + 4) + 1024 + 96 + 64 + 8 + (size_t)CT_PAD * 4 + (size_t)REF_LDS * 16 + (size_t)CB::RMAX * 12;
+    const size_t static_lds1 = sizeof(FlatLds<CB1::RMAX>) + (size_t)CB1::RMAX * (sizeof(BqDesc) + 4) + 1024 + 96 + 64 + 8 + (size_t)CT_PAD * 4 + (size_t)REF_LDS * 16 + (size_t)CB1::RMAX * 12;
     const size_t lds_cu = 160 * 1024;
     const uint64_t nsteps = flat_steps<CB>(c->qual_bytes);
     for (int attempt = 0;; attempt++) {
@@ -1239,12 +1242,14 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
         if ((q < 64 ? (c->qual_present[0] >> q) : (c->qual_present[1] >> (q - 64))) & 1ull) quals.push_back(q);
       if (quals.empty()) quals.push_back(6);
       // as many workgroups per CU (512 threads each) as still hold all slots in one pass; else one per CU and several passes
+      // if not even two workgroups fit: ONE workgroup of 1024 threads per CU around one table (as many waves per SIMD as two of 512)
       int wg_per_cu = 1, qcap = 0;
+      bool big = false;
       for (int w = 3; w >= 1; w--) {
-        const size_t budget = lds_cu / (size_t)w;
-        if (budget <= static_lds + 256) continue;
-        const int cap = (int)((budget - static_lds - 256) / per_slot) - CT_XROWS;  // minus the extra rows per covariate
-        if (cap >= (int)quals.size() || w == 1) { wg_per_cu = w; qcap = cap; break; }
+        const size_t budget = lds_cu / (size_t)w, st_lds = w == 1 ? static_lds1 : static_lds;
+        if (budget <= st_lds + 256) continue;
+        const int cap = (int)((budget - st_lds - 256) / per_slot) - CT_XROWS;  // minus the extra rows per covariate
+        if (cap >= (int)quals.size() || w == 1) { wg_per_cu = w; qcap = cap; big = w == 1; break; }
       }
       if (qcap < 1) return set_error(c, ELP_ERR_UNSUPPORTED, "BQSR private tables do not fit in LDS (n_cov=%d, max read length=%d)", c->n_cov, lmax);
       const int grid = (int)std::min<uint64_t>(nsteps, (uint64_t)wg_per_cu * (uint64_t)c->n_cu);
@@ -1261,8 +1266,13 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
         const bool ref_lds = c->n_ref <= REF_LDS;
 #define ELP_COUNT_LAUNCH(CC, RL)                                                                                                              \
   do {                                                                                                                                        \
-    ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bqsr_count<CC, RL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)); \
-    ELP_LAUNCH(c, "bqsr_count", (k_bqsr_count<CC, RL>), dim3(grid), dim3(FL_THREADS), dyn, A, qm);                                            \
+    if (big) {                                                                                                                                \
+      ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bqsr_count<CC, RL, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)); \
+      ELP_LAUNCH(c, "bqsr_count", (k_bqsr_count<CC, RL, 1024>), dim3(grid), dim3(1024), dyn, A, qm);                                          \
+    } else {                                                                                                                                  \
+      ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bqsr_count<CC, RL, FL_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)); \
+      ELP_LAUNCH(c, "bqsr_count", (k_bqsr_count<CC, RL, FL_THREADS>), dim3(grid), dim3(FL_THREADS), dyn, A, qm);                              \
+    }                                                                                                                                         \
   } while (0)
         if (check_cycle && ref_lds) ELP_COUNT_LAUNCH(true, true);
         else if (check_cycle) ELP_COUNT_LAUNCH(true, false);

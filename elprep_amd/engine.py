@@ -95,10 +95,15 @@ class Engine:
         arr = (C.c_char_p * max(len(ids), 1))(*[s.encode() for s in ids])
         self._check(self.L.elp_set_read_group_ids(self.h, C.cast(arr, C.c_void_p)))
 
-    def stage_bam(self, data: np.ndarray, split_id: int = 0):
-        """data: uint8 array of whole inflated BAM alignment records (page-locked memory is read in place by the DMA engine)"""
+    def stage_bam(self, data: np.ndarray, split_id: int = 0, rec_off: Optional[np.ndarray] = None):
+        """data: uint8 array of whole inflated BAM alignment records (page-locked memory is read in place by the DMA engine);
+        rec_off: uint64 offsets of the records' block_size fields + the total (optional: else the block_size chain is walked)"""
         d = np.ascontiguousarray(data, dtype=np.uint8)
-        self._check(self.L.elp_stage_bam(self.h, _vp(d), d.size, split_id))
+        if rec_off is None:
+            self._check(self.L.elp_stage_bam(self.h, _vp(d), d.size, C.c_void_p(0), 0, split_id))
+        else:
+            ro = np.ascontiguousarray(rec_off, dtype=np.uint64)
+            self._check(self.L.elp_stage_bam(self.h, _vp(d), d.size, _vp(ro), ro.size - 1, split_id))
 
     def emit_sorted_bam(self, out: Optional[np.ndarray] = None) -> np.ndarray:
         n = C.c_uint64()

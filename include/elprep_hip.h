@@ -109,7 +109,9 @@ uint64_t elp_num_qual_bytes(const elp_ctx *ctx);     /* size of the staged QUAL 
  * elp_stage_bam: `bytes` = inflated BGZF payload holding whole alignment records (block_size, fixed fields, read name, CIGAR, bases,
  *   qualities, optional fields; SAMv1 4.2) as bamReader hands them to parseBamAlignment (:299-400).  The records cross PCIe as
  *   they are and are cut into the columns on the device; all of them get `split_id`.  Appends like elp_stage and may be mixed with
- *   it only in separate contexts.  Fast path: `bytes` in page-locked memory (elp_pinned_alloc) - the DMA engine reads it in place;
+ *   it only in separate contexts.  rec_off (optional): byte offset of every record's block_size field, rec_off[n_records] = n_bytes -
+ *   a BAM reader knows them; without them the call walks the block_size chain on the host (one dependent load per record).
+ *   Fast path: `bytes` in page-locked memory (elp_pinned_alloc) - the DMA engine reads it in place;
  *   pageable memory goes through a pinned double buffer.  Returns when `bytes` may be reused.
  * elp_emit_sorted_bam: formatBamAlignment (:635-737) of the elp_num_sorted() records of the sort's output, in that order, into
  *   `out` (host memory, `cap` bytes; NULL = just compute *n_bytes_out): FLAG and QUAL as the path left them, bin() recomputed
@@ -117,7 +119,8 @@ uint64_t elp_num_qual_bytes(const elp_ctx *ctx);     /* size of the staged QUAL 
 int elp_set_read_group_ids(elp_ctx *ctx, const char *const *ids);
 void *elp_pinned_alloc(size_t bytes);
 void elp_pinned_free(void *p);
-int elp_stage_bam(elp_ctx *ctx, const uint8_t *bytes, uint64_t n_bytes, uint16_t split_id);
+int elp_stage_bam(elp_ctx *ctx, const uint8_t *bytes, uint64_t n_bytes, const uint64_t *rec_off /* n_records + 1, may be NULL */,
+                  uint64_t n_records, uint16_t split_id);
 int elp_emit_sorted_bam(elp_ctx *ctx, uint8_t *out, uint64_t cap, uint64_t *n_bytes_out);
 
 /* ---- fused per-record predicates: filters/simple-filters.go ----

@@ -388,3 +388,12 @@ def bqsr_apply_mt(fin: "BqsrFinal", b: Batch, h: Header, quantize_levels: int = 
     _check(lib().orc_bqsr_apply_mt(C.byref(s), C.byref(hs), fin.h, C.c_int(quantize_levels), _p(sq), C.c_int(sq.size), C.c_int(fin.max_cycle), _p(out),
                                    C.c_int(n_threads)), "bqsr_apply_mt")
     return out
+
+
+def bam_offsets(b: Batch, rg_ids: Sequence[str], normalize_tags: bool = False) -> np.ndarray:
+    """byte offsets (n + 1) of the records of bam_encode(b, rg_ids) - what a BAM reader knows about the stream it hands over"""
+    arr = (C.c_char_p * max(len(rg_ids), 1))(*[s.encode() for s in rg_ids])
+    off = np.empty(b.n + 1, dtype=np.uint64)
+    s = b.as_struct()
+    lib().orc_bam_offsets(C.byref(s), arr, C.c_void_p(0), C.c_uint64(0), C.c_int(1 if normalize_tags else 0), _p(off))
+    return off

@@ -163,6 +163,8 @@ int orc_bqsr_gather_mt(const orc_batch *b, const orc_header *h, const orc_bqsr_r
 int orc_bqsr_apply_mt(const orc_batch *b, const orc_header *h, const orc_bqsr_final *f, int quantize_levels, const uint8_t *sqq, int n_sqq,
                       int max_cycle, uint8_t *qual_out, int n_threads);
 
+void orc_bam_offsets(const orc_batch *b, const char *const *rg_ids, const uint32_t *order, uint64_t n_order, int normalize_tags, uint64_t *off_out);
+
 /* sfm contig groups (sam/split-merge.go:178-213): group_of_ref[n_ref] gets 1-based group index; returns #groups (excl. unmapped) */
 int orc_contig_groups(const int32_t *ref_len, int n_ref, int contig_group_size, int32_t *group_of_ref);
 

@@ -133,3 +133,16 @@ size_t orc_bam_encode(const orc_batch *b, const char *const *rg_ids, const uint3
   }
   return at;
 }
+
+/* byte offset of every record of the stream orc_bam_encode writes (n_order + 1 values) */
+void orc_bam_offsets(const orc_batch *b, const char *const *rg_ids, const uint32_t *order, uint64_t n_order, int normalize_tags, uint64_t *off_out) {
+  size_t at = 0;
+  if (!order) n_order = b->n;
+  for (uint64_t k = 0; k < n_order; k++) {
+    uint64_t i = order ? order[k] : k;
+    off_out[k] = at;
+    at += 4 + 32 + (size_t)(b->qname_off[i + 1] - b->qname_off[i]) + 1 + 4 * (size_t)(b->cigar_off[i + 1] - b->cigar_off[i]) + ((b->l_seq[i] + 1) >> 1) + b->l_seq[i] +
+          put_tags(NULL, b, i, rg_ids, normalize_tags);
+  }
+  off_out[n_order] = at;
+}

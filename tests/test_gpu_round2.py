@@ -378,8 +378,10 @@ def test_stage_from_bam_and_emit_sorted_bam(pinned):
         off.append(p)
         p += 4 + int(raw[p:p + 4].view(np.uint32)[0])
     mid = off[len(off) // 2]
-    e.stage_bam(buf[:mid])
-    e.stage_bam(buf[mid:])
+    e.stage_bam(buf[:mid])  # record starts by walking the block_size chain
+    ro = np.asarray(off[len(off) // 2:] + [raw.size], dtype=np.uint64) - np.uint64(mid)
+    assert np.array_equal(ro, orc.bam_offsets(b, h.rg_ids)[len(off) // 2:] - np.uint64(mid))
+    e.stage_bam(buf[mid:], rec_off=ro)  # record starts handed over
     e2.stage(b)
     assert e.n == b.n and e.n_sorted == e2.n_sorted == orc.num_sorted(b)
     up, sc = e.adapted()
