@@ -1,5 +1,7 @@
 """How the all-cores CPU baseline (oracle *_mt) scales on this box: threads -> Mreads/s per stage.  usage: cpu_scaling.py [reads]"""
-import os, sys, time
+import faulthandler, functools, os, sys, time
+faulthandler.enable()
+print = functools.partial(print, flush=True)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import oracle as orc, bench
 from tools import synth
@@ -11,7 +13,9 @@ for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys
     except Exception as e:
         print(f, "-")
 cfg = synth.config("c3"); h = cfg.header()
-b = synth.generate(cfg, 0, n // 2)
+from elprep_amd.batch import Batch
+b = Batch.concat([synth.generate(cfg, lo, min(lo + 500_000, n // 2)) for lo in range(0, n // 2, 500_000)])
+print("generated", b.n)
 refs = [synth.reference(cfg, r) for r in range(h.n_ref)]
 sites = [bench.flatten_sites(synth.known_sites_raw(cfg, r)) for r in range(h.n_ref)]
 ref = orc.BqsrRef(refs, sites)

@@ -19,8 +19,8 @@ for r in range(h.n_ref):
 e.snapshot()
 for s in range(steps):
     e.rollback()
-    e.sort_coordinate(fetch=False)
     e.mark_duplicates(True, fetch=False)
+    e.sort_coordinate(fetch=False)
     e.dup_metrics(100)
     qt, ct, xt = e.recalibrate(500)
     lut, present = BqsrTables(qt, ct, xt, 500).finalize().build_lut(0)
