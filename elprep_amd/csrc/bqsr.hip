@@ -467,7 +467,10 @@ __device__ __forceinline__ uint32_t lshl_add_u32(uint32_t a, uint32_t b) {  // (
   return r;
 }
 
-template <bool CHECK_CYCLE, bool REFLDS, int NTV = FL_THREADS>
+// MG ("mismatches global"): the cycle cells hold observations only, 16 bits each, two per word, and the (rare) mismatches of the
+// cycle table go straight to the dense table in HBM with one global atomic each - the private table shrinks from 4 to 2 bytes per
+// (quality, cycle), so that ~40 qualities x 4 read groups x 150-base reads fit ONE workgroup's LDS in ONE pass.
+template <bool CHECK_CYCLE, bool REFLDS, int NTV = FL_THREADS, bool MG = false>
 struct CountBody {
   // groups of 256 reads: the per-read LDS (44 B) competes with the private tables for the 80 KB that let two workgroups share a CU
   // (with four read groups and six qualities the tables take 50 KB); 256 KiB steps save the per-step restart of the pipeline.
@@ -542,8 +545,22 @@ struct CountBody {
       v1 = out ? 0u : v1; lo = out ? 0u : lo; hi = out ? 0u : hi;
     }
     const uint32_t row = ro + rowb;
-    lds_add_u32(lshl_add_u32<2>((uint32_t)(t >> 4), row), v1);
+    if (MG) lds_add_u32(lshl_add_u32<2>((uint32_t)(t >> 5), row), (v1 & 1u) << (t & 16));  // cell (t >> 4): word cell / 2, half cell & 1
+    else lds_add_u32(lshl_add_u32<2>((uint32_t)(t >> 4), row), v1);
     lds_add_u64(lshl_add_u32<3>(bfe_u32<sh, 4>(cw), row), lo, hi);
+  }
+  // MG: the mismatches of the block's counted bases -> cycle table in HBM.  E: flag nibbles (bit 4b = base b counted and mismatching)
+  __device__ __forceinline__ void mismatches_global(uint64_t E, const Chunk &ch, uint32_t cov, int cyc0, int ci) {
+    const uint64_t qlo = (uint64_t)ch.w0 | ((uint64_t)ch.w1 << 32), qhi = (uint64_t)ch.w2 | ((uint64_t)ch.w3 << 32);
+    const int ncyc_g = 2 * max_cycle + 1;
+    while (E) {
+      const int b = __builtin_ctzll(E) >> 2;
+      E &= E - 1;
+      const uint32_t q = (uint32_t)(((b & 8) ? qhi : qlo) >> (8 * (b & 7))) & 0xFFu;
+      const int cyc = cyc0 + b * ci;
+      if (qrow[q] < real_end && cyc >= -max_cycle && cyc <= max_cycle)  // a real row of this pass (not "not counted" / bad / missing)
+        atomicAdd(cycle_tbl + (((size_t)cov * ELP_NQUAL + q) * ncyc_g + (size_t)(cyc + max_cycle)) * 2 + 1, 1ull);
+    }
   }
 
   struct Pre {
@@ -652,7 +669,8 @@ struct CountBody {
     const int cf = rof + (rev ? (len - 1) * rof : 0), ci = rev ? -rof : rof;
     const int cyc0 = cf + cbase * ci;
     const uint32_t rowb = cov * rpc_bytes;                               // the covariate's rows
-    const int P = (CT_CYC << 4) + 17 * (cyc0 + lmax), st = 17 * ci;     // cycle cell (in words from the row start): (P + b * st) >> 4
+    // cycle cell (in words from the row start): (P + b * st) >> 4;  MG: two cells per word, word (P + b * st) >> 5 (CT_CYC doubled in P)
+    const int P = (CT_CYC << (MG ? 5 : 4)) + 17 * (cyc0 + lmax), st = 17 * ci;
 
     const uint64_t E = X & F, FV = F & CV, EV = E & CV;
     const uint32_t f0 = (uint32_t)F, e0 = (uint32_t)E, f1 = (uint32_t)(F >> 32), e1 = (uint32_t)(E >> 32);
@@ -678,6 +696,7 @@ struct CountBody {
       __builtin_amdgcn_sched_barrier(0);
     }
 #undef ELP_B
+    if (MG && E) mismatches_global(E, ch, cov, cyc0, ci);
   }
   __device__ __forceinline__ void slots(uint32_t) {}
   __device__ __forceinline__ void retire() {}
@@ -689,6 +708,31 @@ struct CountBody {
     __syncthreads();
     const int rpc = n_q + CT_XROWS, rows = n_cov * rpc;
     const int ncyc_l = 2 * lmax + 1, ncyc_g = 2 * max_cycle + 1;
+    if (MG) {
+      // words of two observation cells: cell c = 2 w + half holds cycle index x with (17 x) >> 4 == c, i.e. x = c - c / 17
+      const int nw = (((17 * (ncyc_l - 1)) >> 4) >> 1) + 1;
+      for (int k = threadIdx.x; k < rows * nw; k += NT) {
+        const int row = k / nw, w = k % nw;
+        uint32_t *cell = &tbl[row * rs + CT_CYC + w];
+        const uint32_t v = *cell;
+        if (v) {
+          *cell = 0;
+          const int cov = row / rpc, slot = row % rpc;
+          if (slot >= n_q) {
+            err |= slot == n_q ? 8u : (slot == n_q + 1 ? 128u : 0u);
+          } else {
+            const int q = slot_q[slot];
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+              const uint32_t obs = (v >> (16 * half)) & 0xFFFFu;
+              const int c = 2 * w + half, cyc = c - c / 17 - lmax;
+              if (obs && cyc >= -max_cycle && cyc <= max_cycle)
+                atomicAdd(cycle_tbl + (((size_t)cov * ELP_NQUAL + q) * ncyc_g + (size_t)(cyc + max_cycle)) * 2, (unsigned long long)obs);
+            }
+          }
+        }
+      }
+    } else
     for (int k = threadIdx.x; k < rows * ncyc_l; k += NT) {
       const int row = k / ncyc_l, x = k % ncyc_l;
       uint32_t *cell = &tbl[row * rs + CT_CYC + ((17 * x) >> 4)];
@@ -734,9 +778,9 @@ struct CountBody {
   }
 };
 
-template <bool CHECK_CYCLE, bool REFLDS, int NTV>
+template <bool CHECK_CYCLE, bool REFLDS, int NTV, bool MG = false>
 __global__ __launch_bounds__(NTV, 4) void k_bqsr_count(CountArgs A, QMap qm) {
-  constexpr int RMAX = CountBody<CHECK_CYCLE, REFLDS, NTV>::RMAX;
+  constexpr int RMAX = CountBody<CHECK_CYCLE, REFLDS, NTV, MG>::RMAX;
   __shared__ FlatLds<RMAX> L;
   __shared__ uint4 s_desc[2 * RMAX];
   __shared__ uint32_t s_seq[RMAX];
@@ -764,7 +808,7 @@ __global__ __launch_bounds__(NTV, 4) void k_bqsr_count(CountArgs A, QMap qm) {
     qrow[q] = tbl_at + (uint32_t)(row * A.rs) * 4u;
   }
   __syncthreads();
-  CountBody<CHECK_CYCLE, REFLDS, NTV> B;
+  CountBody<CHECK_CYCLE, REFLDS, NTV, MG> B;
   B.seq_off = A.seq_off; B.qual = A.qual; B.seq4 = A.seq4; B.desc = reinterpret_cast<const uint4 *>(A.desc);
   B.cigar = A.cigar; B.cig_scratch = A.cig_scratch; B.skipbits = A.skipbits; B.ref_seq = A.ref_seq; B.ref_seq_len = A.ref_seq_len;
   B.cycle_tbl = A.cycle_tbl; B.ctx_tbl = A.ctx_tbl;
@@ -1252,6 +1296,14 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
         if (cap >= (int)quals.size() || w == 1) { wg_per_cu = w; qcap = cap; big = w == 1; break; }
       }
       if (qcap < 1) return set_error(c, ELP_ERR_UNSUPPORTED, "BQSR private tables do not fit in LDS (n_cov=%d, max read length=%d)", c->n_cov, lmax);
+      // one workgroup per CU and still several passes: observation-only cycle cells (half the bytes; mismatches by global atomics)
+      bool mg = false;
+      int rs_use = rs;
+      if (big && qcap < (int)quals.size()) {
+        const int rs_mg = (CT_CYC + (((17 * 2 * lmax) >> 4) >> 1) + 1 + 1) & ~1;
+        const int cap_mg = (int)((lds_cu - static_lds1 - 256) / ((size_t)c->n_cov * (size_t)rs_mg * 4)) - CT_XROWS;
+        if (cap_mg > qcap) { mg = true; rs_use = rs_mg; qcap = cap_mg; }
+      }
       const int grid = (int)std::min<uint64_t>(nsteps, (uint64_t)wg_per_cu * (uint64_t)c->n_cu);
       for (size_t q0 = 0; q0 < quals.size(); q0 += (size_t)qcap) {
         const int nqs = (int)std::min<size_t>((size_t)qcap, quals.size() - q0);
@@ -1259,14 +1311,17 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
         memset(qm.slot, 254, sizeof qm.slot);
         for (int q : quals) qm.slot[q] = 255;
         for (int s = 0; s < nqs; s++) qm.slot[quals[q0 + s]] = (uint8_t)s;
-        const size_t dyn = ((size_t)c->n_cov * (nqs + CT_XROWS) * rs + CT_PAD) * 4;
+        const size_t dyn = ((size_t)c->n_cov * (nqs + CT_XROWS) * rs_use + CT_PAD) * 4;
         CountArgs A{n, c->qual_bytes, c->qual_off.p, c->seq_off.p, c->qual.p, c->seq4.p, desc, c->cigar.p, cs_pool,
-                    reinterpret_cast<const uint8_t *>(skipbits), c->d_ref_seq.p, c->d_ref_seq_len.p, c->n_ref, c->n_cov, nqs, lmax, rs, max_cycle,
+                    reinterpret_cast<const uint8_t *>(skipbits), c->d_ref_seq.p, c->d_ref_seq_len.p, c->n_ref, c->n_cov, nqs, lmax, rs_use, max_cycle,
                     tb + nq, tb + nq + nc, c->err_flag.p, c->tile_first.p};
         const bool ref_lds = c->n_ref <= REF_LDS;
 #define ELP_COUNT_LAUNCH(CC, RL)                                                                                                              \
   do {                                                                                                                                        \
-    if (big) {                                                                                                                                \
+    if (big && mg) {                                                                                                                          \
+      ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bqsr_count<CC, RL, 1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)); \
+      ELP_LAUNCH(c, "bqsr_count", (k_bqsr_count<CC, RL, 1024, true>), dim3(grid), dim3(1024), dyn, A, qm);                                    \
+    } else if (big) {                                                                                                                         \
       ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bqsr_count<CC, RL, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)); \
       ELP_LAUNCH(c, "bqsr_count", (k_bqsr_count<CC, RL, 1024>), dim3(grid), dim3(1024), dyn, A, qm);                                          \
     } else {                                                                                                                                  \

@@ -428,3 +428,30 @@ def test_stage_bam_rejects_malformed_input():
         e2.stage_bam(raw)
     e.close()
     e2.close()
+
+
+def test_full_quality_range_tables_and_apply():
+    """~40 distinct quality values x 4 read groups: the BQSR count takes its one-workgroup-per-CU form (observation-only cycle
+    cells, mismatches by global atomics), the apply its two-level LUT with 16-bit row offsets; tables and qualities vs the oracle."""
+    from tools import synth
+    cfg = synth.config("tiny", 9)
+    cfg.qual_mode = 1
+    b = synth.generate(cfg, 0, 20000)
+    h = cfg.header()
+    assert np.unique(b.qual).size >= 36
+    refs = [synth.reference(cfg, r) for r in range(h.n_ref)]
+    sites = [orc.flatten(orc.sort_by_start(synth.known_sites_raw(cfg, r))) for r in range(h.n_ref)]
+    e = Engine(h)
+    e.stage(b)
+    flags = e.mark_duplicates(True)
+    for r in range(h.n_ref):
+        e.set_reference(r, refs[r])
+        e.set_known_sites(r, sites[r])
+    qt, ct, xt = e.recalibrate(500)
+    oq, oc, ox = orc.bqsr_gather(b, h, orc.BqsrRef(refs, sites), flags, 500)
+    assert np.array_equal(qt, oq) and np.array_equal(ct, oc) and np.array_equal(xt, ox)
+    assert ct[..., 1].sum() > 1000
+    lut, present = BqsrTables(qt, ct, xt, 500).finalize().build_lut(0)
+    got = e.apply_bqsr(lut, present, 500)
+    assert np.array_equal(got, orc.BqsrFinal(oq, oc, ox, 500).apply(b, h, 0))
+    e.close()
