@@ -112,7 +112,7 @@ def main():
     ap.add_argument("--stages", choices=["full", "c2"], default="full", help="full = BASELINE config C3 (sort+markdup+BQSR); c2 = mark duplicates + sort only")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="N > 1: per-GPU reads fixed, or --total-reads partitioned by contig groups")
     ap.add_argument("--total-reads", type=int, default=0, help="strong scaling: reads of the whole job (default: --reads)")
-    ap.add_argument("--cpu-reads", type=int, default=16_000_000, help="sample size for the CPU baseline leg (0 = skip)")
+    ap.add_argument("--cpu-reads", type=int, default=8_000_000, help="sample size for the CPU baseline leg (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="N = 1: skip the C2 / full-quality / PCIe-inclusive side measurements")
     ap.add_argument("--extra-reads", type=int, default=16_000_000, help="reads of the full-quality side measurement")
@@ -480,6 +480,19 @@ def flatten_sites(raw: np.ndarray) -> np.ndarray:
     return np.stack([starts, ends], axis=1).astype(np.int32)
 
 
+def effective_cores() -> int:
+    """host cores this process may actually use: the scheduler affinity, capped by the cgroup CPU quota (the GPU box shows 256
+    logical CPUs but grants a container 16 CPUs' worth of time: cpu.max = 1600000 100000)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(cfg, hdr, n_reads):
     """The CPU oracle (plain-C restatement of the reference's algorithms) on ALL host cores - parallel merge sort with the
     CoordinateLess comparator, sharded duplicate-marking maps, thread-private BQSR tables summed at the end, as the reference's
@@ -489,7 +502,7 @@ def cpu_baseline(cfg, hdr, n_reads):
     from tools import synth
     from concurrent.futures import ThreadPoolExecutor
     from elprep_amd.batch import Batch
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     chunk = 500_000
     with ThreadPoolExecutor(min(cores, 16)) as pool:
         parts = list(pool.map(lambda lo: synth.generate(cfg, lo, min(lo + chunk, n_reads // 2)), range(0, n_reads // 2, chunk)))
@@ -507,7 +520,8 @@ def cpu_baseline(cfg, hdr, n_reads):
     dt = time.perf_counter() - t0
     return {"value": round(b.n / dt / 1e6, 4), "unit": "Mreads/s", "cores": cores, "kind": "port",
             "sample": f"{b.n} reads of the same synthetic workload, full path (mark duplicates + sort + optical metrics + BQSR gather + finalize + apply), "
-                      f"multithreaded C restatement of the reference algorithms (oracle/, OpenMP, {cores} threads), {dt:.1f} s wall = {dt * cores:.0f} core-seconds"}
+                      f"multithreaded C restatement of the reference algorithms (oracle/, OpenMP, {cores} threads = the CPUs the container is granted: "
+                      f"{os.cpu_count()} logical CPUs visible, cgroup quota {cores}), {dt:.1f} s wall = {dt * cores:.0f} core-seconds"}
 
 
 if __name__ == "__main__":

@@ -68,11 +68,13 @@ __device__ __forceinline__ uint64_t frag_hash(const uint4 &k) {
   return mix64(mix64(h) ^ (((uint64_t)k.w << 32) | (uint64_t)k.z));
 }
 
-// generic find-or-insert; returns the representative record of i's group
+// generic find-or-insert; returns the representative record of i's group (EMPTY: no free slot within `limit` probes - only
+// possible for a table that was sized by an estimate)
 template <class Eq>
-__device__ __forceinline__ uint32_t find_or_insert(uint32_t *table, uint64_t mask, uint64_t h, uint32_t i, Eq eq) {
+__device__ __forceinline__ uint32_t find_or_insert(uint32_t *table, uint64_t mask, uint64_t h, uint32_t i, Eq eq, uint64_t limit = ~0ull) {
   uint64_t s = h & mask;
-  for (;;) {
+  for (uint64_t probes = 0;; probes++) {
+    if (probes > limit) return EMPTY;
     uint32_t cur = ld_agent(&table[s]);
     if (cur == EMPTY) {
       cur = atomicCAS(&table[s], EMPTY, i);
@@ -163,34 +165,75 @@ __device__ __forceinline__ bool is_mate_candidate(uint16_t f) { return is_candid
 enum : uint8_t { MC_NONE = 0, MC_TABLE = 1, MC_LEAD = 2, MC_FOLLOW = 3 };
 constexpr uint32_t MATE_BIG = 0xFFFFFFFEu;
 
-__global__ __launch_bounds__(256) void k_mate_scan(MdCols m, uint8_t *__restrict__ code, uint32_t *__restrict__ hash32, uint32_t *bloom,
-                                                   uint32_t bloom_mask) {
-  const uint64_t base = (uint64_t)blockIdx.x * 256, i = base + threadIdx.x;
-  const auto joins = [&](uint64_t a) -> bool {  // neighbours a, a + 1 are both mate candidates with the same key
-    if (a + 1 >= m.n) return false;
-    return is_mate_candidate(m.flag_in[a]) && is_mate_candidate(m.flag_in[a + 1]) && mate_key_eq(m, (uint32_t)a, (uint32_t)a + 1);
-  };
-  // s_join[t] = joins(base - 2 + t) for t in [0, 259): every neighbour test of the block is made once
+// The kernel is bound by memory latency (a wave waits for ~40 dependent loads otherwise), so every load of a record and its
+// neighbour is issued up front in two rounds - fixed columns and QNAME offsets, then library ids and the first 32 bytes of both
+// names - and the tests follow without further loads (names longer than 32 bytes finish in a loop).  Threads 256..258 of the
+// 320-thread workgroup make the three neighbour tests across the block's borders the same way.
+constexpr int MS_THREADS = 320;
+__global__ __launch_bounds__(MS_THREADS) void k_mate_scan(MdCols m, uint8_t *__restrict__ code, uint32_t *__restrict__ hash32, uint32_t *bloom,
+                                                          uint32_t bloom_mask, uint32_t *n_table /* records that announce their key (sizes the table) */) {
+  const uint64_t base = (uint64_t)blockIdx.x * 256;
+  const uint32_t t = threadIdx.x;
+  // a = the record this thread tests against its right neighbour; s_join[a - (base - 2)]
+  const int64_t a_s = t < 256 ? (int64_t)(base + t) : (t == 256 ? (int64_t)base - 2 : (t == 257 ? (int64_t)base - 1 : (t == 258 ? (int64_t)base + 256 : -1)));
+  const bool valid = a_s >= 0 && (uint64_t)a_s + 1 < m.n;          // both a and a + 1 exist
+  const bool own = a_s >= 0 && (uint64_t)a_s < m.n;                 // a exists
+  const uint64_t a = own ? (uint64_t)a_s : 0, b = valid ? a + 1 : a;
+  // round 1
+  const uint16_t fa = m.flag_in[a], fb = m.flag_in[b], ra = m.rgid[a], rb = m.rgid[b], sa = m.split[a], sb = m.split[b];
+  const uint64_t oa = m.qname_off[a], ob = m.qname_off[b], oe = m.qname_off[b + 1];
+  const uint32_t la = (uint32_t)((valid ? ob : oe) - oa), lb = (uint32_t)(oe - ob);
+  // round 2
+  const uint16_t lia = ra == ELP_NIL16 ? (uint16_t)ELP_NIL16 : m.rg_lib[ra], lib_b = rb == ELP_NIL16 ? (uint16_t)ELP_NIL16 : m.rg_lib[rb];
+  const uint8_t *pa = m.qname + oa, *pb = m.qname + ob;
+  const uint64_t a0 = load8(pa), a1 = load8(pa + 8), a2 = load8(pa + 16), a3 = load8(pa + 24);
+  const uint64_t b0 = load8(pb), b1 = load8(pb + 8), b2 = load8(pb + 16), b3 = load8(pb + 24);
+  // first 32 bytes of a's name, zero behind its end (the hash takes them as they are)
+  const uint64_t w0 = la > 0 ? low_bytes(a0, la) : 0ull, w1 = la > 8 ? low_bytes(a1, la - 8) : 0ull, w2 = la > 16 ? low_bytes(a2, la - 16) : 0ull,
+                 w3 = la > 24 ? low_bytes(a3, la - 24) : 0ull;
+  bool join = valid && is_mate_candidate(fa) && is_mate_candidate(fb) && lia == lib_b && sa == sb && la == lb;
+  if (join) {
+    uint64_t diff = w0 ^ (lb > 0 ? low_bytes(b0, lb) : 0ull);
+    diff |= w1 ^ (lb > 8 ? low_bytes(b1, lb - 8) : 0ull);
+    diff |= w2 ^ (lb > 16 ? low_bytes(b2, lb - 16) : 0ull);
+    diff |= w3 ^ (lb > 24 ? low_bytes(b3, lb - 24) : 0ull);
+    join = diff == 0;
+    for (uint32_t k = 32; join && k < la; k += 8) join = low_bytes(load8(pa + k), la - k) == low_bytes(load8(pb + k), la - k);
+  }
+  // s_join[u] = joins(base - 2 + u) for u in [0, 259): every neighbour test of the block is made once
   __shared__ uint8_t s_join[264];
-  s_join[threadIdx.x + 2] = joins(i);
-  if (threadIdx.x < 2) s_join[threadIdx.x] = base + threadIdx.x >= 2 ? joins(base - 2 + threadIdx.x) : false;
-  if (threadIdx.x == 2) s_join[258] = joins(base + 256);
+  if (a_s >= 0 || t >= 256) {
+    const int64_t u = a_s - ((int64_t)base - 2);
+    if (t < 259) s_join[t < 256 ? t + 2 : (t == 256 ? 0 : (t == 257 ? 1 : 258))] = join;
+    (void)u;
+  }
   __syncthreads();
-  if (i >= m.n) return;
   uint8_t cd = MC_NONE;
-  if (is_mate_candidate(m.flag_in[i])) {
-    const uint8_t *j = s_join + threadIdx.x + 2;  // j[0] = joins(i)
+  const uint64_t i = base + t;
+  if (t < 256 && i < m.n && is_mate_candidate(fa)) {
+    const uint8_t *j = s_join + t + 2;  // j[0] = joins(i)
     const bool nx = j[0], pv = j[-1];
     cd = MC_TABLE;
     if (nx && !pv && !j[1]) cd = MC_LEAD;
     else if (pv && !nx && !j[-2]) cd = MC_FOLLOW;
     if (cd != MC_FOLLOW) {
-      const uint32_t hi = (uint32_t)(qname_hash(m, (uint32_t)i) >> 32);
+      // qname_hash(m, i) from the words at hand
+      uint64_t h = 0x9e3779b97f4a7c15ull ^ la;
+      const uint64_t K = 0xff51afd7ed558ccdull;
+      if (la > 0) h = (h ^ w0) * K + (h >> 29);
+      if (la > 8) h = (h ^ w1) * K + (h >> 29);
+      if (la > 16) h = (h ^ w2) * K + (h >> 29);
+      if (la > 24) h = (h ^ w3) * K + (h >> 29);
+      for (uint32_t k = 32; k < la; k += 8) h = (h ^ low_bytes(load8(pa + k), la - k)) * K + (h >> 29);
+      h = mix64(h ^ ((uint64_t)lia << 48) ^ ((uint64_t)sa << 24));
+      const uint32_t hi = (uint32_t)(h >> 32);
       if (cd == MC_LEAD) hash32[i] = hi;
       else atomicOr(&bloom[(hi >> 5) & bloom_mask], 1u << (hi & 31u));
     }
   }
-  code[i] = cd;
+  if (t < 256 && i < m.n) code[i] = cd;
+  const unsigned long long tb = __ballot(cd == MC_TABLE);
+  if ((t & 63) == 0 && tb) atomicAdd(n_table, (uint32_t)__popcll(tb));
 }
 
 // mate[] and rep[] must be EMPTY-initialised.  rep[i] = representative of i's key for records that went through the table and are
@@ -209,7 +252,8 @@ __global__ __launch_bounds__(256) void k_mate_insert(MdCols m, const uint8_t *__
       return;
     }
   }
-  const uint32_t rep = find_or_insert(table, mask, qname_hash(m, (uint32_t)i), (uint32_t)i, [&](uint32_t a, uint32_t b) { return mate_key_eq(m, a, b); });
+  const uint32_t rep = find_or_insert(table, mask, qname_hash(m, (uint32_t)i), (uint32_t)i, [&](uint32_t a, uint32_t b) { return mate_key_eq(m, a, b); }, mask);
+  if (rep == EMPTY) { atomicOr(&err[1], 2u); return; }  // the estimated table is full: the host repeats the pass with the full-size one
   if (rep == (uint32_t)i) return;  // first of its key at the slot
   rep_of[i] = rep;
   const uint32_t old = atomicCAS(&mate[rep], EMPTY, (uint32_t)i);
@@ -359,15 +403,33 @@ static int markdup_impl(elp_ctx *c) {
     hash32 = bloom + bw;
     code = reinterpret_cast<uint8_t *>(hash32 + n + 8);
     uint32_t *rep_of = c->pair_slot.p;  // free until k_pair_insert fills it
+    uint32_t *n_table_dev = c->err_flag.p + 3;  // the scan-total mailbox
     ELP_HIP(c, hipMemsetAsync(bloom, 0, bw * sizeof(uint32_t), st));
-    ELP_HIP(c, hipMemsetAsync(table, 0xFF, T * sizeof(uint32_t), st));
+    ELP_HIP(c, hipMemsetAsync(n_table_dev, 0, 4, st));
     ELP_HIP(c, hipMemsetAsync(c->mate.p, 0xFF, n * sizeof(uint32_t), st));
     ELP_HIP(c, hipMemsetAsync(rep_of, 0xFF, n * sizeof(uint32_t), st));
-    ELP_LAUNCH(c, "md_mate_scan", k_mate_scan, dim3(grid), dim3(256), 0, m, code, hash32, bloom, (uint32_t)(bw - 1));
-    ELP_LAUNCH(c, "md_mate_insert", k_mate_insert, dim3(grid), dim3(256), 0, m, (const uint8_t *)code, (const uint32_t *)hash32,
-               (const uint32_t *)bloom, (uint32_t)(bw - 1), table, T - 1, c->mate.p, rep_of, c->err_flag.p);
+    ELP_LAUNCH(c, "md_mate_scan", k_mate_scan, dim3(grid), dim3(MS_THREADS), 0, m, code, hash32, bloom, (uint32_t)(bw - 1), n_table_dev);
+    // the table only has to hold the records that are not exactly-two-neighbours (few in aligner order) plus the neighbour pairs a
+    // Bloom-filter hit sends there (at most as many again, in practice a fraction): size it by their number, not by n
+    uint32_t n_tab = 0;
+    ELP_HIP(c, hipMemcpyAsync(&n_tab, n_table_dev, 4, hipMemcpyDeviceToHost, st));
+    ELP_HIP(c, hipStreamSynchronize(st));
+    ELP_HIP(c, hipMemsetAsync(n_table_dev, 0, 4, st));
+    uint64_t Tm = std::min<uint64_t>(T, table_size_for(std::min<uint64_t>(n, 4ull * n_tab + 1024)));
     uint32_t e[4];
-    ELP_TRY(fetch_err(c, e));
+    for (;;) {
+      ELP_HIP(c, hipMemsetAsync(table, 0xFF, Tm * sizeof(uint32_t), st));
+      ELP_LAUNCH(c, "md_mate_insert", k_mate_insert, dim3(grid), dim3(256), 0, m, (const uint8_t *)code, (const uint32_t *)hash32,
+                 (const uint32_t *)bloom, (uint32_t)(bw - 1), table, Tm - 1, c->mate.p, rep_of, c->err_flag.p);
+      ELP_TRY(fetch_err(c, e));
+      if (!(e[1] & 2u)) break;
+      if (Tm == T) return set_error(c, ELP_ERR_HIP, "mark duplicates: mate table overflow");
+      // more Bloom-filter hits than estimated: once more with the full-size table
+      Tm = T;
+      ELP_HIP(c, hipMemsetAsync(c->err_flag.p + 1, 0, 4, st));
+      ELP_HIP(c, hipMemsetAsync(c->mate.p, 0xFF, n * sizeof(uint32_t), st));
+      ELP_HIP(c, hipMemsetAsync(rep_of, 0xFF, n * sizeof(uint32_t), st));
+    }
     if (e[1]) {
       // keys with more than two records: pair their members up in arrival order
       ELP_HIP(c, hipMemsetAsync(c->err_flag.p + 1, 0, 4, st));
@@ -391,12 +453,13 @@ static int markdup_impl(elp_ctx *c) {
     }
   }
 
-  // ---- pairs
-  ELP_HIP(c, hipMemsetAsync(table, 0xFF, T * sizeof(uint32_t), st));
+  // ---- pairs (at most n / 2 of them)
+  const uint64_t Tp = table_size_for(n / 2 + 8);
+  ELP_HIP(c, hipMemsetAsync(table, 0xFF, Tp * sizeof(uint32_t), st));
   ELP_HIP(c, hipMemsetAsync(best, 0, n * sizeof(unsigned long long), st));
   ELP_HIP(c, hipMemsetAsync(c->pair_winner.p, 0xFF, n * sizeof(uint32_t), st));
   ELP_LAUNCH(c, "md_pair_insert", k_pair_insert, dim3(grid), dim3(256), 0, m, (const uint4 *)fkey, (const uint32_t *)c->mate.p, table,
-             T - 1, c->pair_slot.p, best);
+             Tp - 1, c->pair_slot.p, best);
   ELP_LAUNCH(c, "md_pair_tie", k_pair_tie, dim3(grid), dim3(256), 0, m, (const uint32_t *)c->mate.p, (const uint32_t *)c->pair_slot.p,
              (const unsigned long long *)best, c->pair_winner.p);
   ELP_LAUNCH(c, "md_pair_flag", k_pair_flag, dim3(grid), dim3(256), 0, m, (const uint32_t *)c->mate.p, (const uint32_t *)c->pair_slot.p,

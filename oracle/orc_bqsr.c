@@ -1087,7 +1087,12 @@ static int apply_range(const orc_batch *b, const orc_header *h, const orc_bqsr_f
       int32_t cx = ctx[k]; /* nk == len here: some qual >= 6 > lowQualityTail */
       size_t mi = (((size_t)cov * ORC_NQUAL + q) * ncyc + (size_t)(cyc + max_cycle)) * 17 + (size_t)(cx < 0 ? 16 : ((cx >> 4) & 15));
       int16_t v = memo[mi];
-      if (v < 0) { v = orc_bqsr_recal_qual(f, cov, q, cyc, cx, quantized, static_q); memo[mi] = v; }
+      if (v < 0) {
+        /* the finalized-table object fills its own lazily allocated caches: one thread at a time (misses are rare) */
+#pragma omp critical(orc_recal_qual)
+        v = orc_bqsr_recal_qual(f, cov, q, cyc, cx, quantized, static_q);
+        memo[mi] = v;
+      }
       qo[k] = (uint8_t)v;
     }
     if (rc) break;

@@ -19,7 +19,7 @@ print("generated", b.n)
 refs = [synth.reference(cfg, r) for r in range(h.n_ref)]
 sites = [bench.flatten_sites(synth.known_sites_raw(cfg, r)) for r in range(h.n_ref)]
 ref = orc.BqsrRef(refs, sites)
-for c in (8, 32, 64, 128, 256):
+for c in (4, 8, 16, 32, 64):
     if c > (os.cpu_count() or 1):
         break
     t = [time.perf_counter()]
