@@ -30,6 +30,26 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+
+def effective_cores() -> int:
+    """host cores this process may actually use: the scheduler affinity, capped by the cgroup CPU quota (the GPU box shows 256
+    logical CPUs but grants a container 16 CPUs' worth of time: cpu.max = 1600000 100000)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+# The synthetic generator and the CPU baseline are OpenMP code: without these two settings every parallel region starts one thread
+# per VISIBLE CPU (256 on the GPU box, of which the container may use 16) and the idle ones spin - which starves the host thread
+# that finalises the BQSR tables inside the timed steps (measured: 15 ms of host time per step instead of 2).
+os.environ.setdefault("OMP_NUM_THREADS", str(effective_cores()))
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 # algorithmic HBM bytes per read, SURVEY.md §8(d) / BASELINE.md §3
 BYTES_PER_READ = {"adapt": 185, "sort": 152, "markdup": 138, "bqsr_gather": 424, "bqsr_apply": 385}
 BYTES_FULL_PATH = 1284
@@ -154,7 +174,7 @@ def main():
 
     from collections import deque
     from concurrent.futures import ThreadPoolExecutor
-    workers = max(1, min(12, (os.cpu_count() or 2) // max(world, 1)))
+    workers = max(1, min(12, effective_cores() // max(world, 1)))
     chunk = 1_000_000
     host_pool = ThreadPoolExecutor(1)
 
@@ -478,19 +498,6 @@ def flatten_sites(raw: np.ndarray) -> np.ndarray:
     ends = np.zeros(starts.size, dtype=np.int64)
     np.maximum.at(ends, grp, e)
     return np.stack([starts, ends], axis=1).astype(np.int32)
-
-
-def effective_cores() -> int:
-    """host cores this process may actually use: the scheduler affinity, capped by the cgroup CPU quota (the GPU box shows 256
-    logical CPUs but grants a container 16 CPUs' worth of time: cpu.max = 1600000 100000)"""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except Exception:
-        pass
-    return n
 
 
 def cpu_baseline(cfg, hdr, n_reads):
