@@ -151,6 +151,7 @@ __device__ __forceinline__ void set_skip_bits(uint32_t *skipbits, uint64_t bit0,
 // itself, getReadCoordinateForReferenceCoordinate(ref) is ref - POS inside the read and fails outside (utils.go:267-349 with one
 // match operation), and there is one reference piece.  Everything else is appended to `queue` for the general kernel, so that
 // kernel's long divergent code runs with all lanes busy.  All column loads are issued before the first test (one latency, not 15).
+constexpr int REF_LDS = 256;      // contigs whose per-contig facts (pointers, lengths) are kept in LDS by the BQSR kernels
 constexpr int PF_TILES = 16;
 __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__restrict__ desc, uint32_t *skipbits, uint32_t *__restrict__ queue,
                                                             uint32_t *queue_n, uint32_t *err) {
@@ -158,6 +159,15 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
   // workgroup (a global atomic per wave on the single queue counter serialises at ~12 ns each: 9 ms for 50 M reads)
   __shared__ uint32_t lq[PF_TILES * 256];
   __shared__ uint32_t lcount, gbase;
+  // per-contig facts in LDS (contig length, known-site array, its length, its bucket index): the walk over the known sites then
+  // depends on ONE global round trip (the bucket entry) instead of three (pointer tables first); the kernel is latency-bound
+  __shared__ int32_t s_ref_len[REF_LDS];
+  __shared__ const int32_t *s_sites[REF_LDS];
+  __shared__ int64_t s_nsites[REF_LDS];
+  __shared__ const uint32_t *s_sidx[REF_LDS];
+  const bool ref_lds = m.n_ref <= REF_LDS;
+  if (ref_lds)
+    for (int r = threadIdx.x; r < m.n_ref; r += 256) { s_ref_len[r] = m.ref_len[r]; s_sites[r] = m.sites[r]; s_nsites[r] = m.n_sites[r]; s_sidx[r] = m.site_idx[r]; }
   if (threadIdx.x == 0) lcount = 0;
   __syncthreads();
 #pragma unroll 1
@@ -178,7 +188,7 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
               (uint64_t)ls == q1 - q0 && rg != ELP_NIL16 && r < m.n_ref;
     if (ok) {
       const uint32_t op0 = c1 > c0 ? m.cigar[c0] : 0u;
-      const int32_t rl = m.ref_len[r];
+      const int32_t rl = ref_lds ? s_ref_len[r] : m.ref_len[r];
       ok = p <= rl;
       const bool single_match = c1 - c0 == 1 && (c_op(op0) == OP_M || c_op(op0) == OP_EQ || c_op(op0) == OP_X);
       if (ok && !(single_match && ls <= (uint32_t)MAX_DESC_READ)) { defer = true; ok = false; }  // the general kernel redoes the tests
@@ -200,13 +210,13 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
           defer = true;
         } else {
           // calculateSkipSlice (bqsr.go:389-414): softStart = POS, softEnd = End
-          const int32_t *sv = m.sites[r];
-          const int64_t ns = m.n_sites[r];
+          const int32_t *sv = ref_lds ? s_sites[r] : m.sites[r];
+          const int64_t ns = ref_lds ? s_nsites[r] : m.n_sites[r];
           if (ns > 0) {
             const int64_t nbuck = ((int64_t)rl >> 6) + 1;
             int64_t bk = (int64_t)p >> 6;
             bk = bk >= nbuck ? nbuck - 1 : bk;
-            int64_t s = m.site_idx[r][bk];
+            int64_t s = (ref_lds ? s_sidx[r] : m.site_idx[r])[bk];
             while (s < ns && sv[2 * s + 1] < p) s++;
             for (; s < ns && sv[2 * s] <= end; s++) {
               const int a0 = sv[2 * s] - p, a1 = sv[2 * s + 1] - p;
@@ -343,7 +353,6 @@ __global__ __launch_bounds__(256) void k_pack_reference(const uint8_t *__restric
 }
 constexpr int64_t REF_PAD = 32;  // bytes of "other" (0x88) after the packed bases of a contig
 constexpr uint64_t REF_OTHER = 0x8888888888888888ull;
-constexpr int REF_LDS = 256;      // contigs whose packed-base pointer and length are kept in LDS by k_bqsr_count
 
 // Reference window of a block: ref_load ISSUES the load of the 32 packed bases around reference index jb (clamped into the
 // contig; its packed bases are followed by REF_PAD bytes of "other") and returns the nibble shift for ref_unpack, REF_NONE if

@@ -264,9 +264,25 @@ class SfmRank:
             collective = os.environ.get("ELP_SFM_COLLECTIVE", "cabi" if (comm.world > 1 and comm.device.type == "cuda") else "torch")
         self.collective = collective if comm.world > 1 else "none"
         if self.collective == "cabi":
-            box = [group_unique_id() if comm.rank == 0 else None]
+            # the group id is made by rank 0 and handed round once; if any rank cannot join (no RCCL to load, ...) ALL ranks fall back
+            # to the torch.distributed collective - the decision itself is a collective, so nobody is left waiting in a group
+            ok = 1
+            try:
+                box = [group_unique_id() if comm.rank == 0 else None]
+            except Exception:
+                box, ok = [None], 0
             comm.dist.broadcast_object_list(box, src=0)
-            self.engines[0].group_init(comm.rank, comm.world, box[0])
+            flag = comm.torch.tensor([ok if box[0] is not None else 0], dtype=comm.torch.int64, device=comm.device)
+            comm.dist.all_reduce(flag, op=comm.dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                try:
+                    self.engines[0].group_init(comm.rank, comm.world, box[0])
+                except Exception:
+                    ok = 0
+                flag = comm.torch.tensor([ok], dtype=comm.torch.int64, device=comm.device)
+                comm.dist.all_reduce(flag, op=comm.dist.ReduceOp.MIN)
+            if int(flag.item()) != 1:
+                self.collective = "torch"
 
     def stage(self, which: int, b: Batch):
         if b.n:
