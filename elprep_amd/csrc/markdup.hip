@@ -85,79 +85,17 @@ __device__ __forceinline__ uint32_t find_or_insert(uint32_t *table, uint64_t mas
   }
 }
 
-// The insert kernels are bound by the latency of dependent random accesses (flag -> key -> slot -> representative's key -> best),
-// so every thread carries TWO records (i and i + half) through the rounds side by side: twice the random accesses in flight per wave.
-// Round by round: keys; first slot; claim an empty slot; the representative's key; then (rare) the rest of the probe sequence.
-template <class KeyOf, class KeyEq, class Hash>
-__device__ __forceinline__ void insert_two(uint32_t *table, uint64_t mask, const bool *cand, const uint32_t *idx, KeyOf key_of, KeyEq key_eq, Hash hash,
-                                           uint32_t *rep_out) {
-  decltype(key_of(0u)) key[2];
-  uint64_t slot[2] = {0, 0};
-  uint32_t cur[2] = {EMPTY, EMPTY};
-  bool done[2];
-#pragma unroll
-  for (int j = 0; j < 2; j++) {
-    done[j] = !cand[j];
-    if (cand[j]) key[j] = key_of(idx[j]);
-  }
-#pragma unroll
-  for (int j = 0; j < 2; j++)
-    if (cand[j]) { slot[j] = hash(key[j]) & mask; cur[j] = ld_agent(&table[slot[j]]); }
-#pragma unroll
-  for (int j = 0; j < 2; j++)
-    if (!done[j] && cur[j] == EMPTY) {
-      cur[j] = atomicCAS(&table[slot[j]], EMPTY, idx[j]);
-      if (cur[j] == EMPTY) { rep_out[j] = idx[j]; done[j] = true; }
-    }
-  decltype(key_of(0u)) other[2];
-#pragma unroll
-  for (int j = 0; j < 2; j++)
-    if (!done[j]) {
-      if (cur[j] == idx[j]) { rep_out[j] = idx[j]; done[j] = true; }
-      else other[j] = key_of(cur[j]);
-    }
-#pragma unroll
-  for (int j = 0; j < 2; j++)
-    if (!done[j]) {
-      if (key_eq(other[j], key[j])) { rep_out[j] = cur[j]; done[j] = true; }
-      else {  // collision: walk on (rare at this load factor)
-        uint64_t sl = (slot[j] + 1) & mask;
-        for (;;) {
-          uint32_t c2 = ld_agent(&table[sl]);
-          if (c2 == EMPTY) {
-            c2 = atomicCAS(&table[sl], EMPTY, idx[j]);
-            if (c2 == EMPTY) { rep_out[j] = idx[j]; break; }
-          }
-          if (c2 == idx[j] || key_eq(key_of(c2), key[j])) { rep_out[j] = c2; break; }
-          sl = (sl + 1) & mask;
-        }
-        done[j] = true;
-      }
-    }
-}
-
 __global__ __launch_bounds__(256) void k_frag_insert(MdCols m, const uint4 *__restrict__ fkey, uint32_t *table, uint64_t mask,
-                                                     uint32_t *__restrict__ frep, unsigned long long *fbest, uint64_t half) {
-  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= half) return;
-  const uint64_t i2[2] = {t, t + half};
-  uint32_t idx[2] = {(uint32_t)i2[0], (uint32_t)i2[1]}, rep[2] = {EMPTY, EMPTY};
-  uint16_t f[2];
-  bool cand[2];
-#pragma unroll
-  for (int j = 0; j < 2; j++) {
-    const bool in = i2[j] < m.n;
-    f[j] = in ? m.flag_in[i2[j]] : (uint16_t)F_UNMAPPED;
-    cand[j] = in && is_candidate(f[j]);
-  }
-  insert_two(table, mask, cand, idx, [&](uint32_t r) { return fkey[r]; }, [](const uint4 &x, const uint4 &y) { return key_eq(x, y); },
-             [](const uint4 &k) { return frag_hash(k); }, rep);
-#pragma unroll
-  for (int j = 0; j < 2; j++) {
-    if (i2[j] >= m.n) continue;
-    frep[i2[j]] = cand[j] ? rep[j] : EMPTY;
-    if (cand[j]) atomicMax(&fbest[rep[j]], is_true_pair(f[j]) ? (1ull << 63) : (unsigned long long)(uint32_t)m.score[i2[j]]);
-  }
+                                                     uint32_t *__restrict__ frep, unsigned long long *fbest) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.n) return;
+  const uint16_t f = m.flag_in[i];
+  if (!is_candidate(f)) { frep[i] = EMPTY; return; }
+  const uint4 mine = fkey[i];
+  const uint32_t rep = find_or_insert(table, mask, frag_hash(mine), (uint32_t)i, [&](uint32_t a, uint32_t) { return key_eq(fkey[a], mine); });
+  frep[i] = rep;
+  const unsigned long long v = is_true_pair(f) ? (1ull << 63) : (unsigned long long)(uint32_t)m.score[i];
+  atomicMax(&fbest[rep], v);
 }
 
 // (QNAME asc, later arrival wins) tournament among contenders
@@ -369,30 +307,20 @@ __device__ __forceinline__ bool pair_key_eq(const PairKey &a, const PairKey &b) 
 }
 
 __global__ __launch_bounds__(256) void k_pair_insert(MdCols m, const uint4 *__restrict__ fkey, const uint32_t *__restrict__ mate, uint32_t *table,
-                                                     uint64_t mask, uint32_t *__restrict__ prep, unsigned long long *pbest, uint64_t half) {
-  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= half) return;
-  const uint64_t i2[2] = {t, t + half};
-  uint32_t idx[2] = {(uint32_t)i2[0], (uint32_t)i2[1]}, rep[2] = {EMPTY, EMPTY}, mt[2];
-  bool cand[2];
-#pragma unroll
-  for (int j = 0; j < 2; j++) {
-    mt[j] = i2[j] < m.n ? mate[i2[j]] : EMPTY;
-    cand[j] = mt[j] != EMPTY && mt[j] < idx[j];  // the later-arriving mate owns the pair (:336-340)
-  }
-  const auto key_of = [&](uint32_t r) { return pair_key(fkey[r], fkey[mate[r]]); };
-  const auto hash = [](const PairKey &k) {
-    uint64_t h = mix64(((uint64_t)k.k1.x << 32) | k.k2.x);
-    h = mix64(h ^ (((uint64_t)k.k1.y << 32) | k.k2.y));
-    return mix64(h ^ (((uint64_t)k.k1.z << 1) | (k.k2.z & 1u)) ^ ((uint64_t)k.k1.w << 40));
-  };
-  insert_two(table, mask, cand, idx, key_of, [](const PairKey &x, const PairKey &y) { return pair_key_eq(x, y); }, hash, rep);
-#pragma unroll
-  for (int j = 0; j < 2; j++) {
-    if (i2[j] >= m.n) continue;
-    prep[i2[j]] = cand[j] ? rep[j] : EMPTY;
-    if (cand[j]) atomicMax(&pbest[rep[j]], (unsigned long long)(uint32_t)(m.score[i2[j]] + m.score[mt[j]]));  // :342
-  }
+                                                     uint64_t mask, uint32_t *__restrict__ prep, unsigned long long *pbest) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.n) return;
+  const uint32_t mt = mate[i];
+  if (mt == EMPTY || mt > (uint32_t)i) { prep[i] = EMPTY; return; }  // the later-arriving mate owns the pair (:336-340)
+  const PairKey mine = pair_key(fkey[i], fkey[mt]);
+  uint64_t h = mix64(((uint64_t)mine.k1.x << 32) | mine.k2.x);
+  h = mix64(h ^ (((uint64_t)mine.k1.y << 32) | mine.k2.y));
+  h = mix64(h ^ (((uint64_t)mine.k1.z << 1) | (mine.k2.z & 1u)) ^ ((uint64_t)mine.k1.w << 40));
+  const uint32_t rep = find_or_insert(table, mask, h, (uint32_t)i,
+                                      [&](uint32_t a, uint32_t) { return pair_key_eq(pair_key(fkey[a], fkey[mate[a]]), mine); });
+  prep[i] = rep;
+  const int32_t sc = m.score[i] + m.score[mt];  // :342
+  atomicMax(&pbest[rep], (unsigned long long)(uint32_t)sc);
 }
 
 __global__ __launch_bounds__(256) void k_pair_tie(MdCols m, const uint32_t *__restrict__ mate, const uint32_t *__restrict__ prep,
@@ -460,8 +388,7 @@ static int markdup_impl(elp_ctx *c) {
   ELP_HIP(c, hipMemsetAsync(table, 0xFF, T * sizeof(uint32_t), st));
   ELP_HIP(c, hipMemsetAsync(best, 0, n * sizeof(unsigned long long), st));
   ELP_HIP(c, hipMemsetAsync(winner, 0xFF, n * sizeof(uint32_t), st));
-  const uint64_t half = (n + 1) / 2;
-  ELP_LAUNCH(c, "md_frag_insert", k_frag_insert, dim3(blocks_for(half, 256)), dim3(256), 0, m, (const uint4 *)fkey, table, T - 1, rep, best, half);
+  ELP_LAUNCH(c, "md_frag_insert", k_frag_insert, dim3(grid), dim3(256), 0, m, (const uint4 *)fkey, table, T - 1, rep, best);
   ELP_LAUNCH(c, "md_frag_tie", k_frag_tie, dim3(grid), dim3(256), 0, m, (const uint32_t *)rep, (const unsigned long long *)best, winner);
   ELP_LAUNCH(c, "md_frag_flag", k_frag_flag, dim3(grid), dim3(256), 0, m, (const uint32_t *)rep, (const unsigned long long *)best,
              (const uint32_t *)winner, c->flag.p);
@@ -531,8 +458,8 @@ static int markdup_impl(elp_ctx *c) {
   ELP_HIP(c, hipMemsetAsync(table, 0xFF, Tp * sizeof(uint32_t), st));
   ELP_HIP(c, hipMemsetAsync(best, 0, n * sizeof(unsigned long long), st));
   ELP_HIP(c, hipMemsetAsync(c->pair_winner.p, 0xFF, n * sizeof(uint32_t), st));
-  ELP_LAUNCH(c, "md_pair_insert", k_pair_insert, dim3(blocks_for(half, 256)), dim3(256), 0, m, (const uint4 *)fkey, (const uint32_t *)c->mate.p, table,
-             Tp - 1, c->pair_slot.p, best, half);
+  ELP_LAUNCH(c, "md_pair_insert", k_pair_insert, dim3(grid), dim3(256), 0, m, (const uint4 *)fkey, (const uint32_t *)c->mate.p, table,
+             Tp - 1, c->pair_slot.p, best);
   ELP_LAUNCH(c, "md_pair_tie", k_pair_tie, dim3(grid), dim3(256), 0, m, (const uint32_t *)c->mate.p, (const uint32_t *)c->pair_slot.p,
              (const unsigned long long *)best, c->pair_winner.p);
   ELP_LAUNCH(c, "md_pair_flag", k_pair_flag, dim3(grid), dim3(256), 0, m, (const uint32_t *)c->mate.p, (const uint32_t *)c->pair_slot.p,
