@@ -859,38 +859,16 @@ __global__ __launch_bounds__(256) void k_bqsr_qual_from_cycle(int n_rows, int nc
 struct ApDesc { uint16_t left, right, len; uint8_t cov; uint8_t fl; };  // fl: BQ_ELIGIBLE recalibrate, BQ_REVERSED, BQ_LAST
 static_assert(sizeof(ApDesc) == 8, "ApDesc is staged as one 8-byte word");
 
-__global__ __launch_bounds__(256) void k_apply_prologue(uint64_t n, const uint16_t *__restrict__ flag, const uint16_t *__restrict__ rgid,
-                                                        const uint16_t *__restrict__ rg_cov, const uint32_t *__restrict__ l_seq,
-                                                        const uint64_t *__restrict__ qual_off, const uint64_t *__restrict__ qbounds,
-                                                        const uint8_t *__restrict__ cov_present, ApDesc *__restrict__ desc, uint32_t *err) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  ApDesc d{0, 0, 0, 0, 0};
-  // all column loads first (one memory latency instead of one per test)
-  const uint16_t rg = rgid[i], f = flag[i];
-  const int len = (int)l_seq[i];
-  const uint64_t q0 = qual_off[i], q1 = qual_off[i + 1], qb = qbounds[i];
-  if (rg == ELP_NIL16) { atomicOr(&err[0], 32u); desc[i] = d; return; }  // readGroupCovariate panics, bqsr.go:38
-  const uint32_t cov = rg_cov[rg];
-  if (!cov_present[cov]) { desc[i] = d; return; }  // :953-955
-  if ((uint64_t)len != q1 - q0) { atomicOr(&err[0], 64u); desc[i] = d; return; }
-  if (len > MAX_DESC_READ) { atomicOr(&err[0], 2u); desc[i] = d; return; }
-  // computeStrandedClippedSeq mask bounds (bqsr.go:316-332) on the full read, precomputed by adapt_score
-  const uint32_t hi1 = (uint32_t)qb;
-  const int left = hi1 ? (int)(qb >> 32) : len, right = hi1 ? (int)hi1 - 1 : len - 1;
-  d.left = (uint16_t)left; d.right = (uint16_t)(right < 0 ? 0xFFFF : right);
-  d.len = (uint16_t)len;
-  d.cov = (uint8_t)cov;
-  d.fl = BQ_ELIGIBLE | ((f & F_REVERSED) ? BQ_REVERSED : 0) | ((f & F_LAST) ? BQ_LAST : 0);
-  desc[i] = d;
-}
-
 struct ApplyArgs {
   uint64_t n, qual_bytes;
   const uint64_t *qual_off, *seq_off;
   uint8_t *qual;
   const uint8_t *seq4;
-  const ApDesc *desc;
+  // per-read facts the stage step turns into the 8-byte descriptor (there is no prologue kernel and no descriptor column any more)
+  const uint16_t *flag, *rgid, *rg_cov;
+  const uint32_t *l_seq;
+  const uint64_t *qbounds;
+  const uint8_t *cov_present;
   const uint32_t *tile_first;
   const uint8_t *lut;  // [n_cov][94][2*max_cycle+1][17]
   int max_cycle;
@@ -921,9 +899,15 @@ struct ApplyBody {
   static constexpr int NT = FL_THREADS, TILES = 4, RMAX = 512;
   static constexpr int ES = MODE == 1 ? 1 : 2;  // bytes per level-1 entry
   const uint64_t *__restrict__ seq_off;
+  const uint64_t *__restrict__ qual_off;
   uint8_t *__restrict__ qual;
   const uint8_t *__restrict__ seq4;
-  const uint64_t *__restrict__ desc;
+  const uint16_t *__restrict__ flag;
+  const uint16_t *__restrict__ rgid;
+  const uint16_t *__restrict__ rg_cov;
+  const uint32_t *__restrict__ l_seq;
+  const uint64_t *__restrict__ qbounds;
+  const uint8_t *__restrict__ cov_present;
   const uint8_t *__restrict__ lut;
   int max_cycle;
   uint64_t *s_desc;
@@ -938,10 +922,35 @@ struct ApplyBody {
   uint64_t out_at;
   int out_nb;
 
+  // the read's descriptor {left, right, len, cov, flags} (ApDesc) straight from the columns: which reads ApplyBQSR touches
+  // (bqsr.go:947-958) and the low-quality-tail bounds of computeStrandedClippedSeq (:316-332) that adapt_score left per read
   __device__ __forceinline__ void stage(uint32_t g0, uint32_t ng) {
-    for (uint32_t k = threadIdx.x; k < ng; k += NT) s_desc[k] = desc[g0 + k];
     seq_base = seq_off[g0];
-    for (uint32_t k = threadIdx.x; k < ng; k += NT) s_seq[k] = (uint32_t)(seq_off[g0 + k] - seq_base);
+    for (uint32_t k = threadIdx.x; k < ng; k += NT) {
+      const uint64_t i = (uint64_t)g0 + k;
+      // all column loads first (one memory latency instead of one per test)
+      const uint16_t rg = rgid[i], f = flag[i];
+      const int len = (int)l_seq[i];
+      const uint64_t q0 = qual_off[i], q1 = qual_off[i + 1], qb = qbounds[i], so = seq_off[i];
+      uint64_t d = 0;
+      if (rg == ELP_NIL16) err |= 32u;                               // readGroupCovariate panics, bqsr.go:38
+      else {
+        const uint32_t cov = rg_cov[rg];
+        if (cov_present[cov]) {                                      // else: read group absent from the tables, read untouched (:953-955)
+          if ((uint64_t)len != q1 - q0) err |= 64u;
+          else if (len > MAX_DESC_READ) err |= 2u;
+          else {
+            const uint32_t hi1 = (uint32_t)qb;
+            const int left = hi1 ? (int)(qb >> 32) : len, right = hi1 ? (int)hi1 - 1 : len - 1;
+            const uint32_t fl = BQ_ELIGIBLE | ((f & F_REVERSED) ? BQ_REVERSED : 0) | ((f & F_LAST) ? BQ_LAST : 0);
+            d = (uint64_t)(uint16_t)left | ((uint64_t)(uint16_t)(right < 0 ? 0xFFFF : right) << 16) | ((uint64_t)(uint16_t)len << 32) | ((uint64_t)(cov & 0xFFu) << 48) |
+                ((uint64_t)fl << 56);
+          }
+        }
+      }
+      s_desc[k] = d;
+      s_seq[k] = (uint32_t)(so - seq_base);
+    }
   }
   // dense LUT in HBM/L2: one byte gather per base
   template <int I>
@@ -1127,7 +1136,8 @@ __global__ __launch_bounds__(FL_THREADS, MODE ? 6 : 4) void k_bqsr_apply_flat(Ap
     __syncthreads();
   }
   AB B;
-  B.seq_off = A.seq_off; B.qual = A.qual; B.seq4 = A.seq4; B.desc = reinterpret_cast<const uint64_t *>(A.desc); B.lut = A.lut;
+  B.seq_off = A.seq_off; B.qual_off = A.qual_off; B.qual = A.qual; B.seq4 = A.seq4; B.lut = A.lut;
+  B.flag = A.flag; B.rgid = A.rgid; B.rg_cov = A.rg_cov; B.l_seq = A.l_seq; B.qbounds = A.qbounds; B.cov_present = A.cov_present;
   B.max_cycle = A.max_cycle; B.s_desc = s_desc; B.s_seq = s_seq;
   B.lmax = A.lmax; B.rows_w = (A.n_qi + 1) * w; B.w_es = (uint32_t)(w * AB::ES);
   B.qlo = (uint32_t)A.qlo; B.qhi1 = (uint32_t)(A.qlo + A.n_qi);
@@ -1483,11 +1493,6 @@ int elp_bqsr_apply(elp_ctx *c, int max_cycle, const uint8_t *lut, const uint8_t 
   ELP_HIP(c, hipMemcpyAsync(dl + lut_bytes, cov_present, (size_t)c->n_cov, hipMemcpyHostToDevice, c->stream));
   const uint64_t n = c->n;
   if (n) {
-    ApDesc *desc;
-    ELP_TRY(scratch(c, 2, n + 4, &desc));
-    ELP_LAUNCH(c, "bqsr_apply_prologue", k_apply_prologue, dim3(blocks_for(n, 256)), dim3(256), 0, n, (const uint16_t *)c->flag.p,
-               (const uint16_t *)c->rgid.p, (const uint16_t *)c->rg_cov.p, (const uint32_t *)c->l_seq.p, (const uint64_t *)c->qual_off.p,
-               (const uint64_t *)c->qbounds.p, (const uint8_t *)(dl + lut_bytes), desc, c->err_flag.p);
     if (c->qual_bytes) {
       typedef ApplyBody<false, 1> AB;
       const uint64_t nsteps = flat_steps<AB>(c->qual_bytes);
@@ -1498,8 +1503,8 @@ int elp_bqsr_apply(elp_ctx *c, int max_cycle, const uint8_t *lut, const uint8_t 
         if ((q < 64 ? (c->qual_present[0] >> q) : (c->qual_present[1] >> (q - 64))) & 1ull) { if (qhi < 0) qlo = q; qhi = q; }
       const int lmax = (int)std::max<uint32_t>(c->max_l_seq, 1);
       const bool chk = (int64_t)c->max_l_seq > (int64_t)max_cycle;
-      ApplyArgs A{n, c->qual_bytes, c->qual_off.p, c->seq_off.p, c->qual.p, c->seq4.p, desc, c->tile_first.p, dl, max_cycle, c->err_flag.p,
-                  nullptr, nullptr, c->n_cov, 0, 0, lmax, 0};
+      ApplyArgs A{n, c->qual_bytes, c->qual_off.p, c->seq_off.p, c->qual.p, c->seq4.p, c->flag.p, c->rgid.p, c->rg_cov.p, c->l_seq.p, c->qbounds.p,
+                  dl + lut_bytes, c->tile_first.p, dl, max_cycle, c->err_flag.p, nullptr, nullptr, c->n_cov, 0, 0, lmax, 0};
       int mode = 0;
       size_t dyn = 0;
       const int n_qi = qhi - qlo + 1, w = 2 * lmax + 1;

@@ -316,11 +316,37 @@ __global__ __launch_bounds__(256) void k_iota(uint32_t *v, uint64_t n) {
   if (i < n) v[i] = (uint32_t)i;
 }
 
-// Resolve runs of <= TIE_SMALL equal keys; flag members of longer runs.
+// Runs of equal primary key.  k_tie_scan (every record, three loads issued together): a record whose neighbours both differ is
+// final; members of runs go to a compact list.  k_tie_small (list members only, all lanes busy with the same kind of work): runs of
+// <= TIE_SMALL records are ranked by all-pairs comparison, members of longer runs are flagged for the radix tie-break.
+__global__ __launch_bounds__(256) void k_tie_scan(uint64_t n, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ perm_in,
+                                                  uint32_t *__restrict__ perm_out, uint32_t *__restrict__ large_flag, uint32_t *__restrict__ list,
+                                                  uint32_t *list_n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool in_run = false;
+  if (i < n) {
+    const uint64_t k = keys[i], kp = i > 0 ? keys[i - 1] : ~k, kn = i + 1 < n ? keys[i + 1] : ~k;
+    const uint32_t me = perm_in[i];
+    in_run = kp == k || kn == k;
+    large_flag[i] = 0;
+    if (!in_run) perm_out[i] = me;
+  }
+  // wave-aggregated append
+  const unsigned long long mask = __ballot(in_run);
+  if (mask) {
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(list_n, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    if (in_run) list[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)i;
+  }
+}
 __global__ __launch_bounds__(256) void k_tie_small(uint64_t n, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ perm_in,
-                                                   uint32_t *__restrict__ perm_out, uint32_t *__restrict__ large_flag, TieCols t) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+                                                   uint32_t *__restrict__ perm_out, uint32_t *__restrict__ large_flag, const uint32_t *__restrict__ list,
+                                                   const uint32_t *__restrict__ list_n, TieCols t) {
+  const uint64_t j0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j0 >= (uint64_t)*list_n) return;
+  const uint64_t i = list[j0];
   const uint64_t k = keys[i];
   const uint32_t me = perm_in[i];
   uint64_t s = i, e = i + 1;  // run [s, e)
@@ -340,8 +366,6 @@ __global__ __launch_bounds__(256) void k_tie_small(uint64_t n, const uint64_t *_
     perm_out[i] = me;
     return;
   }
-  large_flag[i] = 0;
-  if (e - s == 1) { perm_out[i] = me; return; }
   uint32_t rank = 0;
   for (uint64_t j = s; j < e; j++) {
     if (j == i) continue;
@@ -504,8 +528,17 @@ static int sort_impl(elp_ctx *c) {
   ELP_TRY(radix_sort_pairs(c, k0, v0, k1, v1, n, &ks, &vs));
   TieCols t{c->qname_off.p, c->qname.p, c->flag.p, c->mapq.p, c->next_refid.p, c->pnext.p, c->tlen.p};
   uint32_t *large_flag = flags, *large_idx = flags + n;
-  ELP_LAUNCH(c, "tie_small", k_tie_small, dim3(blocks_for(n, 256)), dim3(256), 0, n, (const uint64_t *)ks, (const uint32_t *)vs, c->perm.p,
-             large_flag, t);
+  {
+    // run members -> compact list (the other half of `vbuf` is free: the radix sort left its result in one half)
+    uint32_t *list = (vs == v0) ? v1 : v0, *list_n = c->err_flag.p + 3;  // the scan-total mailbox
+    ELP_HIP(c, hipMemsetAsync(list_n, 0, 4, c->stream));
+    ELP_LAUNCH(c, "tie_scan", k_tie_scan, dim3(blocks_for(n, 256)), dim3(256), 0, n, (const uint64_t *)ks, (const uint32_t *)vs, c->perm.p, large_flag, list,
+               list_n);
+    // sized for the worst case; workgroups beyond the list's end leave at once
+    ELP_LAUNCH(c, "tie_small", k_tie_small, dim3(blocks_for(n, 256)), dim3(256), 0, n, (const uint64_t *)ks, (const uint32_t *)vs, c->perm.p,
+               large_flag, (const uint32_t *)list, (const uint32_t *)list_n, t);
+    ELP_HIP(c, hipMemsetAsync(list_n, 0, 4, c->stream));
+  }
   uint32_t nu = 0;
   ELP_TRY(exclusive_scan_u32(c, large_flag, large_idx, n, &nu));
   if (nu > 0) {
