@@ -202,6 +202,8 @@ __global__ __launch_bounds__(MS_THREADS) void k_mate_scan(MdCols m, uint8_t *__r
   }
   // s_join[u] = joins(base - 2 + u) for u in [0, 259): every neighbour test of the block is made once
   __shared__ uint8_t s_join[264];
+  __shared__ uint32_t s_ntab;
+  if (t == 0) s_ntab = 0;
   if (a_s >= 0 || t >= 256) {
     const int64_t u = a_s - ((int64_t)base - 2);
     if (t < 259) s_join[t < 256 ? t + 2 : (t == 256 ? 0 : (t == 257 ? 1 : 258))] = join;
@@ -232,8 +234,11 @@ __global__ __launch_bounds__(MS_THREADS) void k_mate_scan(MdCols m, uint8_t *__r
     }
   }
   if (t < 256 && i < m.n) code[i] = cd;
+  // one global atomic per workgroup at most (and none in aligner order, where nearly every record is part of a neighbour pair)
   const unsigned long long tb = __ballot(cd == MC_TABLE);
-  if ((t & 63) == 0 && tb) atomicAdd(n_table, (uint32_t)__popcll(tb));
+  if ((t & 63) == 0 && tb) atomicAdd(&s_ntab, (uint32_t)__popcll(tb));
+  __syncthreads();
+  if (t == 0 && s_ntab) atomicAdd(n_table, s_ntab);
 }
 
 // mate[] and rep[] must be EMPTY-initialised.  rep[i] = representative of i's key for records that went through the table and are
