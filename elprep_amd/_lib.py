@@ -12,7 +12,8 @@ import subprocess
 from typing import Optional
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-HIP_SO = os.path.join(_PKG, "libelprep_hip.so")
+# ELP_HIP_SO: another build of the same library (A/B timing of two builds on one box, tools/prof/path_ab.py); never a fallback
+HIP_SO = os.environ.get("ELP_HIP_SO") or os.path.join(_PKG, "libelprep_hip.so")
 HOST_SO = os.path.join(_PKG, "libelprep_host.so")
 
 _hip: Optional[C.CDLL] = None

@@ -183,20 +183,34 @@ __device__ __forceinline__ void flat_run(const uint64_t *__restrict__ qual_off, 
       const uint32_t nslots = (L.off[ng] + 15u * ng) >> 4;  // slot of read k: (off[k] + 15 k) >> 4
       B.slots(nslots);
       const float inv_avg = nslots ? (float)ng / (float)nslots : 0.f, inv_step = 1.0f / (float)(len0 + 15u);
-      // locate slot s and issue its loads
+      // Uniform groups: slot s belongs to read k = (16 s + 15) / step (step = len0 + 15: read k starts at slot (step k) >> 4), and with
+      // r = (16 s + 15) % step the block starts at base r & ~15 of the read.  A lane's slots are NT apart, so (k, r) of its next
+      // slot follow from the current ones by adding the (uniform) quotient and remainder of 16 NT / step - a handful of VALU
+      // instructions per block instead of a division.
+      const uint32_t step = len0 + 15u;  // < 2^24, like every read index: 24-bit multiplies
+      uint32_t uk = 0, ur = 0, udk = 0, udr = 0;
+      if (uniform) {
+        udk = (16u * Body::NT) / step;
+        udr = (16u * Body::NT) - udk * step;
+        const uint32_t q = 16u * threadIdx.x + 15u;  // < 2^24: the float quotient is off by at most one
+        int k = (int)((float)q * inv_step);
+        k = (uint32_t)k * step > q ? k - 1 : k;
+        k = ((uint32_t)k + 1u) * step <= q ? k + 1 : k;
+        uk = (uint32_t)k;
+        ur = q - uk * step;
+      }
+      // locate slot s and issue its loads (the uniform path must be called for s = threadIdx.x, then s + NT, s + 2 NT, ... in turn)
       auto fetch = [&](uint32_t s, typename Body::Pre &pre) __attribute__((always_inline)) -> bool {
         if (uniform) {
-          // read k starts at slot ((len0 + 15) k) >> 4, so slot s belongs to read floor((16 s + 15) / (len0 + 15)); the float
-          // quotient (16 s + 15 < 2^24) is off by at most one
-          const uint32_t step = len0 + 15u;  // < 2^24, like every read index: 24-bit multiplies
-          int k = (int)((float)(16u * s + 15u) * inv_step);
-          k = k >= (int)ng ? (int)ng - 1 : k;
-          k = (__umul24(step, (uint32_t)k) >> 4) > s ? k - 1 : k;
-          k = ((k + 1 < (int)ng) & ((__umul24(step, (uint32_t)(k + 1)) >> 4) <= s)) ? k + 1 : k;
-          const uint32_t k0 = (s - (__umul24(step, (uint32_t)k) >> 4)) << 4;
+          const uint32_t k = uk, k0 = ur & ~15u;
+          // state of the lane's next slot
+          ur += udr;
+          const bool wrap = ur >= step;
+          uk += udk + (wrap ? 1u : 0u);
+          ur = wrap ? ur - step : ur;
           if (k0 >= len0) return false;  // the (at most one) empty slot behind a read
           const uint32_t nb = len0 - k0 < 16u ? len0 - k0 : 16u;
-          return B.prefetch((uint32_t)k, (int)k0, (int)nb, base + __umul24(len0, (uint32_t)k) + k0, s, pre);
+          return B.prefetch(k, (int)k0, (int)nb, base + __umul24(len0, k) + k0, s, pre);
         }
         // read owning slot s: guess g from the mean; the four offsets around g are read at once (one LDS latency) and decide
         // among g-1, g, g+1; otherwise walk
