@@ -187,14 +187,34 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
     bool ok = !has_sr && mq > 0 && mq < 255 && !(f & (F_SECONDARY | F_DUPLICATE | F_QCFAILED)) && !(f & F_UNMAPPED) && r >= 0 && p > 0 && ls != 0 &&
               (uint64_t)ls == q1 - q0 && rg != ELP_NIL16 && r < m.n_ref;
     if (ok) {
-      const uint32_t op0 = c1 > c0 ? m.cigar[c0] : 0u;
+      // CIGARs of the form [H] [S] <match> [S] [H] (one M/=/X operation, clips only at the ends: plain reads and soft-clipped ones):
+      // hardClipSoftClippedBases (utils.go:519-548) leaves the match operation between hard clips, i.e. the clipped copy is bases
+      // [aoff, aoff + len) of the read with ONE reference piece starting at POS, softStart = POS, softEnd = End, and
+      // getReadCoordinateForReferenceCoordinate is ref - POS inside it.  All five operation slots are read at once.
+      const uint64_t nop = c1 - c0;
+      uint32_t opv[5];
+#pragma unroll
+      for (int k = 0; k < 5; k++) opv[k] = (uint64_t)k < nop ? m.cigar[c0 + k] : 0u;
       const int32_t rl = ref_lds ? s_ref_len[r] : m.ref_len[r];
       ok = p <= rl;
-      const bool single_match = c1 - c0 == 1 && (c_op(op0) == OP_M || c_op(op0) == OP_EQ || c_op(op0) == OP_X);
-      if (ok && !(single_match && ls <= (uint32_t)MAX_DESC_READ)) { defer = true; ok = false; }  // the general kernel redoes the tests
-      if (ok) ok = (uint32_t)c_len(op0) == ls;  // SEQ length == CIGAR read length (utils.go:121-128)
+      bool simple = nop >= 1 && nop <= 5;
+      uint32_t aoff = 0, mlen = 0, trail = 0;
+      {
+        uint32_t k = 0;
+        if (simple && c_op(opv[0]) == OP_H) k = 1;
+        // (select chains on purpose: opv[] indexed by a variable would move the array to scratch memory)
+        auto at = [&](uint32_t j) { return j == 0 ? opv[0] : (j == 1 ? opv[1] : (j == 2 ? opv[2] : (j == 3 ? opv[3] : opv[4]))); };
+        if (simple && k < nop && c_op(at(k)) == OP_S) { aoff = (uint32_t)c_len(at(k)); k++; }
+        if (simple && k < nop && (c_op(at(k)) == OP_M || c_op(at(k)) == OP_EQ || c_op(at(k)) == OP_X)) { mlen = (uint32_t)c_len(at(k)); k++; }
+        else simple = false;
+        if (simple && k < nop && c_op(at(k)) == OP_S) { trail = (uint32_t)c_len(at(k)); k++; }
+        if (simple && k < nop && c_op(at(k)) == OP_H) k++;
+        simple = simple && k == nop && mlen != 0;
+      }
+      if (ok && !(simple && ls <= (uint32_t)MAX_DESC_READ)) { defer = true; ok = false; }  // the general kernel redoes the tests
+      if (ok) ok = aoff + mlen + trail == ls;  // SEQ length == CIGAR read length (utils.go:121-128)
       if (ok) {
-        const int len = (int)ls;
+        const int len = (int)mlen;
         const int32_t end = p + len - 1;  // aln.End() (sam/sam-types.go:769-775)
         // hardClipAdaptorSequence (utils.go:149-180, 214-222) would clip?
         const bool rev = f & F_REVERSED;
@@ -204,6 +224,21 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
           if (well) {
             const int boundary = rev ? (int)pnext - 1 : (int)p + (tlen < 0 ? -(int)tlen : (int)tlen);
             clip = boundary >= (int)p && boundary <= (int)end;
+          }
+        }
+        // computeStrandedClippedSeq mask bounds (bqsr.go:316-332) inside the window: adapt_score recorded the first / last quality > 2
+        // of the whole read; where that lies outside the window the window's own end decides (if it does not: general kernel)
+        const uint32_t hi1 = (uint32_t)qb;
+        int left = len, right = len - 1;
+        if (!clip && hi1) {
+          const int f0 = (int)(qb >> 32) - (int)aoff, l0 = (int)hi1 - 1 - (int)aoff;  // relative to the window; f0 <= l0
+          if (f0 < len && l0 >= 0) {
+            if (f0 >= 0) left = f0;
+            else if (m.qual[q0 + aoff] > 2) left = 0;
+            else clip = true;
+            if (l0 < len) right = l0;
+            else if (m.qual[q0 + aoff + (uint32_t)len - 1] > 2) right = len - 1;
+            else clip = true;
           }
         }
         if (clip) {
@@ -222,14 +257,12 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
               const int a0 = sv[2 * s] - p, a1 = sv[2 * s + 1] - p;
               const int fs = (a0 < 0 || a0 >= len) ? 0 : a0;          // !ok || < 0 -> 0
               const int fe = (a1 < 0 || a1 >= len) ? len - 1 : a1;    // !ok || > len-1 -> len-1 (a1 < 0 cannot happen: End >= POS)
-              set_skip_bits(skipbits, q0, fs, fe);
+              set_skip_bits(skipbits, q0 + aoff, fs, fe);
             }
           }
-          // computeStrandedClippedSeq mask bounds (bqsr.go:316-332), precomputed on the full read by adapt_score
-          const uint32_t hi1 = (uint32_t)qb;
-          const int left = hi1 ? (int)(qb >> 32) : len, right = hi1 ? (int)hi1 - 1 : len - 1;
           d.D0 = p - 1;
           d.refid = r;
+          d.a = (uint16_t)aoff;
           d.len = (uint16_t)len;
           d.left = (uint16_t)left; d.right = (uint16_t)(right < 0 ? 0xFFFF : right);
           d.cov = (uint8_t)m.rg_cov[rg];

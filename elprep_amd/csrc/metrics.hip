@@ -61,48 +61,105 @@ __device__ __forceinline__ uint32_t listed_read(const MxCols &m, uint32_t owner)
 // :473-502 — one pass over all records (order does not matter for sums)
 // ReadPairsExamined counts reads and is halved at the end of a filter run (:504-506), i.e. once per split file: the reads of
 // true pairs are counted per (split, library) in pair_reads[n_split][n_lib + 1] and halved by the host, split by split.
-__global__ __launch_bounds__(256) void k_dup_counters(MxCols m, unsigned long long *__restrict__ ctr, unsigned long long *__restrict__ pair_reads) {
+// The same pass lists the LOSING pairs (owner record, pair group) for the optical-duplicate sets: a few per cent of the records,
+// so everything behind this kernel works on a compact list instead of record-indexed arrays.  A workgroup owns a contiguous range
+// of records, collects its losers in LDS and appends them with one global atomic per ~DC_CAP entries (a global atomic per wave
+// on the one list counter would serialise at ~12 ns each).
+constexpr int DC_CAP = 4096, DC_STEP = 2048;
+// one LDS atomic per distinct counter of the wave (nearly all records of a wave add to the same one or two cells: 64 lanes on one
+// LDS address would serialise)
+__device__ __forceinline__ void wave_count(unsigned int *lds, int cell) {
+  unsigned long long todo = __ballot(cell >= 0);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int c0 = __shfl(cell, leader, 64);
+    const unsigned long long peers = __ballot(cell == c0);
+    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&lds[c0], (unsigned int)__popcll(peers));
+    todo &= ~peers;
+  }
+}
+__global__ __launch_bounds__(256) void k_dup_counters(MxCols m, unsigned long long *__restrict__ ctr, unsigned long long *__restrict__ pair_reads,
+                                                      uint64_t chunk, uint64_t *__restrict__ lkeys, uint32_t *__restrict__ lvals, uint32_t *list_n) {
   extern __shared__ unsigned int lds_ctr[];  // [(n_lib+1)*7], then [n_split][n_lib+1]
+  __shared__ uint2 lq[DC_CAP];               // (owner record, pair group) of the losers collected so far
+  __shared__ uint32_t lcount, gbase;
   const int nrow = (m.n_lib + 1) * ELP_NCTR, ncell = nrow + m.n_split * (m.n_lib + 1);
   for (int k = threadIdx.x; k < ncell; k += blockDim.x) lds_ctr[k] = 0;
+  if (threadIdx.x == 0) lcount = 0;
   __syncthreads();
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m.n; i += (uint64_t)gridDim.x * blockDim.x) {
-    if (m.has_sr[i]) continue;  // dropped by RemoveOptionalReads before the metrics pass
-    const uint16_t f = m.flag[i];
-    unsigned int *row = lds_ctr + lib_row(m, (uint32_t)i) * ELP_NCTR;
-    if (f & F_UNMAPPED) { atomicAdd(&row[3], 1u); continue; }
-    if (f & (F_SECONDARY | F_SUPPLEMENTARY)) { atomicAdd(&row[2], 1u); continue; }
-    const bool tp = true_pair(f);
-    if (tp) atomicAdd(&lds_ctr[nrow + (int)m.split[i] * (m.n_lib + 1) + (int)lib_row(m, (uint32_t)i)], 1u);
-    else atomicAdd(&row[0], 1u);
-    if (f & F_DUPLICATE) {
-      if (!tp) atomicAdd(&row[4], 1u);
-      else {
-        const uint32_t mt = m.mate[i];
-        // counted once per pair, when the second of two duplicate-flagged mates is met (:186-192)
-        if (mt != EMPTY && mt < (uint32_t)i && (m.flag[mt] & F_DUPLICATE) && !m.has_sr[mt]) atomicAdd(&row[5], 1u);
+  const uint64_t lo = (uint64_t)blockIdx.x * chunk, hi = lo + chunk < m.n ? lo + chunk : m.n;
+  for (uint64_t base = lo; base < hi; base += DC_STEP) {
+#pragma unroll
+    for (int t = 0; t < DC_STEP / 256; t++) {
+      const uint64_t i = base + (uint64_t)t * 256 + threadIdx.x;
+      bool loser = false;
+      uint32_t rep = EMPTY;
+      int cell1 = -1, cell2 = -1;  // the (at most two) counters the record adds one to
+      if (i < hi && !m.has_sr[i]) {  // sr: dropped by RemoveOptionalReads before the metrics pass
+        const uint16_t f = m.flag[i];
+        const int lib = (int)lib_row(m, (uint32_t)i), row = lib * ELP_NCTR;
+        if (f & F_UNMAPPED) cell1 = row + 3;
+        else if (f & (F_SECONDARY | F_SUPPLEMENTARY)) cell1 = row + 2;
+        else {
+          const bool tp = true_pair(f);
+          cell1 = tp ? nrow + (int)m.split[i] * (m.n_lib + 1) + lib : row;
+          if (f & F_DUPLICATE) {
+            if (!tp) cell2 = row + 4;
+            else {
+              const uint32_t mt = m.mate[i];
+              // counted once per pair, when the second of two duplicate-flagged mates is met (:186-192)
+              if (mt != EMPTY && mt < (uint32_t)i && (m.flag[mt] & F_DUPLICATE) && !m.has_sr[mt]) cell2 = row + 5;
+            }
+          }
+        }
+        // owner of a pair that lost its group; a pair with a tagged read is never completed by the pass over the reads (:186-190)
+        rep = m.prep[i];
+        loser = rep != EMPTY && m.pwinner[rep] != (uint32_t)i && !m.has_sr[m.mate[i]];
+      }
+      wave_count(lds_ctr, cell1);
+      wave_count(lds_ctr, cell2);
+      const unsigned long long mask = __ballot(loser);
+      if (mask) {
+        const int lane = threadIdx.x & 63, leader = __ffsll((long long)mask) - 1;
+        uint32_t at = 0;
+        if (lane == leader) at = atomicAdd(&lcount, (uint32_t)__popcll(mask));
+        at = __shfl(at, leader, 64);
+        if (loser) lq[at + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)i, rep);
       }
     }
+    __syncthreads();
+    const uint32_t have = lcount;
+    if (have > DC_CAP - DC_STEP || base + DC_STEP >= hi) {  // uniform: the next step might not fit, or there is none
+      if (threadIdx.x == 0) gbase = have ? atomicAdd(list_n, have) : 0u;
+      __syncthreads();
+      for (uint32_t k = threadIdx.x; k < have; k += 256) {
+        const uint2 e = lq[k];
+        lkeys[gbase + k] = (uint64_t)e.y;  // sorted by pair group below
+        lvals[gbase + k] = e.x;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) lcount = 0;
+      __syncthreads();
+    }
   }
-  __syncthreads();
   for (int k = threadIdx.x; k < nrow; k += blockDim.x)
     if (lds_ctr[k]) atomicAdd(&ctr[k], (unsigned long long)lds_ctr[k]);
   for (int k = threadIdx.x + nrow; k < ncell; k += blockDim.x)
     if (lds_ctr[k]) atomicAdd(&pair_reads[k - nrow], (unsigned long long)lds_ctr[k]);
 }
 
-// losing pairs per group
-__global__ __launch_bounds__(256) void k_opt_count(MxCols m, uint32_t *gsize) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m.n) return;
-  const uint32_t rep = m.prep[i];
-  if (rep == EMPTY || m.pwinner[rep] == (uint32_t)i) return;
-  if (m.has_sr[i] || m.has_sr[m.mate[i]]) return;  // the pass over the reads never completes this pair (:186-190)
-  atomicAdd(&gsize[rep], 1u);
+// the list sorted by pair group: a group's losers are a run.  Slots of the member table: per group its origin, then its losers.
+__global__ __launch_bounds__(256) void k_opt_heads(uint32_t L, const uint64_t *__restrict__ ks, uint32_t *__restrict__ head) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < L) head[j] = (j == 0 || ks[j] != ks[j - 1]) ? 1u : 0u;
 }
-__global__ __launch_bounds__(256) void k_opt_plus_origin(uint64_t n, uint32_t *gsize) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && gsize[i] > 0) gsize[i] += 1;
+// gidx = exclusive scan of head: a head's group number is gidx[j], a follower's gidx[j] - 1
+__global__ __launch_bounds__(256) void k_opt_starts(uint32_t L, const uint32_t *__restrict__ head, const uint32_t *__restrict__ gidx,
+                                                    uint32_t *__restrict__ gstart, uint32_t G) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= L) return;
+  if (head[j]) gstart[gidx[j]] = j;
+  if (j == L - 1) gstart[G] = L;
 }
 
 struct Tile { long long t, x, y; };
@@ -160,22 +217,26 @@ __device__ inline Member make_member(const MxCols &m, uint32_t read, uint32_t *e
   return Member{tl.t, tl.x, tl.y, ((uint32_t)m.rgid[read] << 1) | ((m.flag[read] & F_REVERSED) ? 1u : 0u)};
 }
 
-// Members of the duplicate sets are laid out group by group (goff); this pass (one thread per record, most exit at once) only
-// decides the slot of each member and notes which read is listed there; the origin's slot also gets {set size, group id}.
-__global__ __launch_bounds__(256) void k_opt_slots(MxCols m, const uint32_t *__restrict__ goff, uint32_t *gfill, uint32_t *__restrict__ mread,
-                                                   uint2 *__restrict__ ginfo, uint32_t *__restrict__ mset) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m.n) return;
-  const uint32_t rep = m.prep[i];
-  if (rep == EMPTY) return;
-  const bool is_origin = m.pwinner[rep] == (uint32_t)i;
-  if (!is_origin && (m.has_sr[i] || m.has_sr[m.mate[i]])) return;
-  const uint32_t g0 = goff[rep], g1 = goff[rep + 1];
-  if (is_origin && g1 == g0) return;  // group without duplicates: count is 0
-  const uint32_t slot = g0 + (is_origin ? 0u : 1u + atomicAdd(&gfill[rep], 1u));
-  mread[slot] = listed_read(m, (uint32_t)i);
-  mset[slot] = g0;  // the set a member belongs to = the slot of its origin
-  if (is_origin) ginfo[slot] = make_uint2(g1 - g0, rep);
+// Members of the duplicate sets are laid out group by group; this pass over the sorted list decides the slot of each member and
+// notes which read is listed there; the origin's slot (filled by the group's first loser) also gets {set size, group id}.
+__global__ __launch_bounds__(256) void k_opt_slots(MxCols m, uint32_t L, const uint64_t *__restrict__ ks, const uint32_t *__restrict__ vs,
+                                                   const uint32_t *__restrict__ head, const uint32_t *__restrict__ gidx,
+                                                   const uint32_t *__restrict__ gstart, uint32_t *__restrict__ mread, uint2 *__restrict__ ginfo,
+                                                   uint32_t *__restrict__ mset) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= L) return;
+  const bool is_head = head[j] != 0;
+  const uint32_t g = gidx[j] - (is_head ? 0u : 1u);
+  const uint32_t j0 = gstart[g], oslot = j0 + g;  // g origins sit in front of the group's own
+  const uint32_t slot = j + g + 1;
+  mread[slot] = listed_read(m, vs[j]);
+  mset[slot] = oslot;  // the set a member belongs to = the slot of its origin
+  if (is_head) {
+    const uint32_t rep = (uint32_t)ks[j];
+    mread[oslot] = listed_read(m, m.pwinner[rep]);
+    mset[oslot] = oslot;
+    ginfo[oslot] = make_uint2(gstart[g + 1] - j0 + 1, rep);
+  }
 }
 // dense pass over the member slots: tile / x / y from the QNAME (every lane busy, unlike a pass over all records)
 __global__ __launch_bounds__(256) void k_opt_fill(MxCols m, uint32_t total, const uint32_t *__restrict__ mread, Member *__restrict__ members, uint32_t *err) {
@@ -388,7 +449,7 @@ static int metrics_impl(elp_ctx *c, int dist, int64_t *counters_host, int64_t *h
   const size_t nhist = hist_host ? (size_t)(c->n_lib + 1) * 3 * (size_t)hist_len : 0, norg = hist_host ? (size_t)(c->n_lib + 1) : 0;
   const int n_split = (int)c->max_split + 1;
   const size_t npr = (size_t)n_split * (size_t)(c->n_lib + 1);
-  if (((size_t)ncell + npr) * sizeof(unsigned int) > 60000)
+  if (((size_t)ncell + npr) * sizeof(unsigned int) > 30000)  // + 32 KB of static LDS in k_dup_counters
     return set_error(c, ELP_ERR_UNSUPPORTED, "elp_dup_metrics: %d split ids x %d libraries in one context", n_split, c->n_lib + 1);
   unsigned long long *ctr;
   ELP_TRY(scratch(c, 0, (size_t)ncell + norg + nhist + npr + 8, &ctr));
@@ -401,16 +462,39 @@ static int metrics_impl(elp_ctx *c, int dist, int64_t *counters_host, int64_t *h
     MxCols m{n, c->refid.p, c->flag.p, c->rgid.p, c->rg_lib.p, c->upos.p, c->qname_off.p, c->qname.p, c->mate.p, c->pair_slot.p, c->pair_winner.p, c->n_lib,
              c->has_sr.p, c->split.p, n_split};
     const unsigned grid = blocks_for(n, 256);
-    ELP_LAUNCH(c, "mx_counters", k_dup_counters, dim3(std::min(grid, 2048u)), dim3(256), ((size_t)ncell + npr) * sizeof(unsigned int), m, ctr, pair_reads);
+    // losing pairs: at most one per two records.  Slot 1: keys (u64) x 2 and values (u32) x 2 of the list and its sort buffers
+    const size_t lcap = n / 2 + 8;
     uint32_t *gs;
-    ELP_TRY(scratch(c, 1, 3 * n + 16, &gs));
-    uint32_t *gsize = gs, *goff = gs + n + 1, *gfill = gs + 2 * n + 2;
-    ELP_HIP(c, hipMemsetAsync(gsize, 0, (n + 1) * sizeof(uint32_t), st));
-    ELP_HIP(c, hipMemsetAsync(gfill, 0, n * sizeof(uint32_t), st));
-    ELP_LAUNCH(c, "mx_opt_count", k_opt_count, dim3(grid), dim3(256), 0, m, gsize);
-    ELP_LAUNCH(c, "mx_opt_plus_origin", k_opt_plus_origin, dim3(grid), dim3(256), 0, n, gsize);
-    uint32_t total = 0;
-    ELP_TRY(exclusive_scan_u32(c, gsize, goff, n + 1, &total));  // goff[n] = total
+    ELP_TRY(scratch(c, 1, 6 * lcap + 16, &gs));
+    uint64_t *pk = reinterpret_cast<uint64_t *>(gs);
+    uint32_t *pv = gs + 4 * lcap;
+    uint32_t *mailbox = c->err_flag.p + 3;  // the scan-total word: length of the list, then members of large sets, then their candidates
+    ELP_HIP(c, hipMemsetAsync(mailbox, 0, 4, st));
+    const unsigned cgrid = (unsigned)std::min<uint64_t>(2048, (n + DC_STEP - 1) / DC_STEP);
+    const uint64_t chunk = (((n + cgrid - 1) / cgrid) + DC_STEP - 1) / DC_STEP * DC_STEP;
+    ELP_LAUNCH(c, "mx_counters", k_dup_counters, dim3(cgrid), dim3(256), ((size_t)ncell + npr) * sizeof(unsigned int), m, ctr, pair_reads, chunk, pk, pv,
+               mailbox);
+    uint32_t L = 0;
+    ELP_HIP(c, hipMemcpyAsync(&L, mailbox, 4, hipMemcpyDeviceToHost, st));
+    ELP_HIP(c, hipStreamSynchronize(st));
+    ELP_HIP(c, hipMemsetAsync(mailbox, 0, 4, st));
+    if ((size_t)L > lcap) return set_error(c, ELP_ERR_HIP, "elp_dup_metrics: more losing pairs than pairs");
+    uint32_t total = 0, G = 0;
+    uint64_t *ks = pk;
+    uint32_t *vs = pv, *head = nullptr, *gidx = nullptr, *gstart = nullptr;
+    if (L) {
+      int ndig = 1;
+      while (ndig < 4 && (n >> (8 * ndig)) != 0) ndig++;  // pair groups are record indices < n < 2^32
+      ELP_TRY(radix_sort_pairs_low(c, pk, pv, pk + lcap, pv + lcap, L, ndig, &ks, &vs));
+      // the halves the sort left free hold the head flags, the group numbers and the group starts
+      head = reinterpret_cast<uint32_t *>(ks == pk ? pk + lcap : pk);
+      gidx = head + lcap;
+      gstart = vs == pv ? pv + lcap : pv;
+      ELP_LAUNCH(c, "mx_opt_heads", k_opt_heads, dim3(blocks_for(L, 256)), dim3(256), 0, L, (const uint64_t *)ks, head);
+      ELP_TRY(exclusive_scan_u32(c, head, gidx, L, &G));
+      ELP_LAUNCH(c, "mx_opt_starts", k_opt_starts, dim3(blocks_for(L, 256)), dim3(256), 0, L, (const uint32_t *)head, (const uint32_t *)gidx, gstart, G);
+      total = L + G;
+    }
     if (total) {
       Member *members;
       uint32_t *wk, *mread;
@@ -423,10 +507,10 @@ static int metrics_impl(elp_ctx *c, int dist, int64_t *counters_host, int64_t *h
       uint32_t *parent = wk, *mset = wk + tp, *linfo = wk + 2 * tp, *lcount = wk + 3 * tp, *lvals = wk + 6 * tp;
       unsigned long long *setcnt = reinterpret_cast<unsigned long long *>(wk + 4 * tp);
       uint64_t *lkeys = reinterpret_cast<uint64_t *>(wk + 8 * tp);
-      uint32_t *mailbox = c->err_flag.p + 3;  // the scan-total word: members of large sets, then the length of their candidate list
       ELP_HIP(c, hipMemsetAsync(ginfo, 0, (size_t)total * sizeof(uint2), st));
       ELP_HIP(c, hipMemsetAsync(linfo, 0, 4 * tp * sizeof(uint32_t), st));  // linfo, lcount, setcnt
-      ELP_LAUNCH(c, "mx_opt_slots", k_opt_slots, dim3(grid), dim3(256), 0, m, (const uint32_t *)goff, gfill, mread, ginfo, mset);
+      ELP_LAUNCH(c, "mx_opt_slots", k_opt_slots, dim3(blocks_for(L, 256)), dim3(256), 0, m, L, (const uint64_t *)ks, (const uint32_t *)vs,
+                 (const uint32_t *)head, (const uint32_t *)gidx, (const uint32_t *)gstart, mread, ginfo, mset);
       ELP_LAUNCH(c, "mx_opt_fill", k_opt_fill, dim3(blocks_for(total, 256)), dim3(256), 0, m, total, (const uint32_t *)mread, members, c->err_flag.p);
       ELP_LAUNCH(c, "mx_opt_eval", k_opt_eval, dim3(blocks_for(total, 128)), dim3(128),
                  (size_t)(c->n_lib + 1) * (1 + (hist ? 3 * (size_t)lds_bins : 0)) * sizeof(unsigned int), m, total, (const uint2 *)ginfo,

@@ -51,7 +51,7 @@ if os.environ.get("ELP_AB_LIB"):
             best[k] = min(best.get(k, 1e9), ms)
     tot = sum(best.values())
     print(os.path.basename(os.environ["ELP_AB_LIB"]), f"crc={crc:08x} kernels_total={tot:.3f}",
-          " ".join(f"{k}={v:.3f}" for k, v in sorted(best.items(), key=lambda kv: -kv[1])[:14]), flush=True)
+          " ".join(f"{k}={v:.3f}" for k, v in sorted(best.items(), key=lambda kv: -kv[1]) if v >= 0.03), flush=True)
 else:
     args = sys.argv[1:]
     extra = []
