@@ -161,6 +161,7 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
   __shared__ uint32_t lcount, gbase;
   // per-contig facts in LDS (contig length, known-site array, its length, its bucket index): the walk over the known sites then
   // depends on ONE global round trip (the bucket entry) instead of three (pointer tables first); the kernel is latency-bound
+  __shared__ uint32_t s_cig[256][5];  // the thread's CIGAR (indel reads): build_pieces / get_read_coord walk it several times
   __shared__ int32_t s_ref_len[REF_LDS];
   __shared__ const int32_t *s_sites[REF_LDS];
   __shared__ int64_t s_nsites[REF_LDS];
@@ -211,11 +212,34 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
         if (simple && k < nop && c_op(at(k)) == OP_H) k++;
         simple = simple && k == nop && mlen != 0;
       }
-      if (ok && !(simple && ls <= (uint32_t)MAX_DESC_READ)) { defer = true; ok = false; }  // the general kernel redoes the tests
-      if (ok) ok = aoff + mlen + trail == ls;  // SEQ length == CIGAR read length (utils.go:121-128)
+      // CIGARs of match / insertion / deletion operations only (two to five of them: reads with an indel or two): nothing is clipped
+      // unless the adaptor test says so, the window is the whole read; reference pieces and read coordinates of known sites come
+      // from the same device functions the general kernel uses, on the CIGAR as staged
+      bool plain = false;
+      uint32_t plain_read = 0, plain_ref = 0;
+      if (!simple && nop >= 2 && nop <= 5) {
+        plain = true;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+          if ((uint64_t)k < nop) {
+            const uint32_t o = c_op(opv[k]), ln = (uint32_t)c_len(opv[k]);
+            if (o == OP_M || o == OP_EQ || o == OP_X) { plain_read += ln; plain_ref += ln; }
+            else if (o == OP_I) plain_read += ln;
+            else if (o == OP_D) plain_ref += ln;
+            else plain = false;
+          }
+        }
+        if (plain) {
+#pragma unroll
+          for (int k = 0; k < 5; k++) s_cig[threadIdx.x][k] = opv[k];
+        }
+      }
+      const uint32_t *my_cig = s_cig[threadIdx.x];
+      if (ok && !((simple || plain) && ls <= (uint32_t)MAX_DESC_READ)) { defer = true; ok = false; }  // the general kernel redoes the tests
+      if (ok) ok = (plain ? plain_read : aoff + mlen + trail) == ls;  // SEQ length == CIGAR read length (utils.go:121-128)
       if (ok) {
-        const int len = (int)mlen;
-        const int32_t end = p + len - 1;  // aln.End() (sam/sam-types.go:769-775)
+        const int len = plain ? (int)ls : (int)mlen;
+        const int32_t end = p + (plain ? (int)plain_ref : len) - 1;  // aln.End() (sam/sam-types.go:769-775)
         // hardClipAdaptorSequence (utils.go:149-180, 214-222) would clip?
         const bool rev = f & F_REVERSED;
         bool clip = false;
@@ -254,9 +278,18 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
             int64_t s = (ref_lds ? s_sidx[r] : m.site_idx[r])[bk];
             while (s < ns && sv[2 * s + 1] < p) s++;
             for (; s < ns && sv[2 * s] <= end; s++) {
-              const int a0 = sv[2 * s] - p, a1 = sv[2 * s + 1] - p;
-              const int fs = (a0 < 0 || a0 >= len) ? 0 : a0;          // !ok || < 0 -> 0
-              const int fe = (a1 < 0 || a1 >= len) ? len - 1 : a1;    // !ok || > len-1 -> len-1 (a1 < 0 cannot happen: End >= POS)
+              int fs, fe;
+              if (plain) {
+                bool okc;
+                fs = get_read_coord(my_cig, (int)nop, (int)p, sv[2 * s], false, &okc);
+                if (!okc || fs < 0) fs = 0;
+                fe = get_read_coord(my_cig, (int)nop, (int)p, sv[2 * s + 1], false, &okc);
+                if (!okc || fe > len - 1) fe = len - 1;
+              } else {
+                const int a0 = sv[2 * s] - p, a1 = sv[2 * s + 1] - p;
+                fs = (a0 < 0 || a0 >= len) ? 0 : a0;          // !ok || < 0 -> 0
+                fe = (a1 < 0 || a1 >= len) ? len - 1 : a1;    // !ok || > len-1 -> len-1 (a1 < 0 cannot happen: End >= POS)
+              }
               set_skip_bits(skipbits, q0 + aoff, fs, fe);
             }
           }
@@ -264,9 +297,16 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
           d.refid = r;
           d.a = (uint16_t)aoff;
           d.len = (uint16_t)len;
+          uint8_t complex_fl = 0;
+          if (plain && !build_pieces(my_cig, (int)nop, p, d)) {  // more than three pieces: the count kernel walks the CIGAR
+            complex_fl = BQ_COMPLEX;
+            d.D0 = (int32_t)c0;
+            d.b1 = (uint16_t)nop;
+            d.D2 = p - 1;
+          }
           d.left = (uint16_t)left; d.right = (uint16_t)(right < 0 ? 0xFFFF : right);
           d.cov = (uint8_t)m.rg_cov[rg];
-          d.fl = BQ_ELIGIBLE | (rev ? BQ_REVERSED : 0) | ((f & F_LAST) ? BQ_LAST : 0);
+          d.fl = BQ_ELIGIBLE | (rev ? BQ_REVERSED : 0) | ((f & F_LAST) ? BQ_LAST : 0) | complex_fl;
         }
       }
     }

@@ -85,6 +85,7 @@ struct elp_ctx {
   uint32_t max_qname_len = 0, max_l_seq = 0;
   uint32_t max_split = 0;  // largest staged split id
   uint32_t max_pos = 0;  // largest staged POS (as uint32): width of the POS field of the coordinate-sort key
+  int key_bits = 64;     // live low bits of the coordinate-sort key column (set with it, ensure_adapted)
 
   // derived state
   bool adapted = false, sorted = false, marked = false;
@@ -292,7 +293,7 @@ int radix_sort_pairs(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *keys_
                      uint64_t **keys_out, uint32_t **vals_out);
 // the same over the low `ndigits` bytes of the keys only, every pass run (no histogram read-back, no host synchronisation)
 int radix_sort_pairs_low(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *keys_tmp, uint32_t *vals_tmp, uint64_t n, int ndigits,
-                         uint64_t **keys_out, uint32_t **vals_out);
+                         uint64_t **keys_out, uint32_t **vals_out, const uint64_t *first_src = nullptr, bool identity_vals = false);
 int exclusive_scan_u32(elp_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n, uint32_t *total_host /* may be null */);
 int ensure_adapted(elp_ctx *c, bool check_quals = true);
 int ensure_qual_present(elp_ctx *c, bool exact = false);  // exact: scan the whole column instead of a sample

@@ -65,7 +65,7 @@ __device__ __forceinline__ uint32_t listed_read(const MxCols &m, uint32_t owner)
 // so everything behind this kernel works on a compact list instead of record-indexed arrays.  A workgroup owns a contiguous range
 // of records, collects its losers in LDS and appends them with one global atomic per ~DC_CAP entries (a global atomic per wave
 // on the one list counter would serialise at ~12 ns each).
-constexpr int DC_CAP = 4096, DC_STEP = 2048;
+constexpr int DC_CAP = 2048, DC_STEP = 1024;
 // one LDS atomic per distinct counter of the wave (nearly all records of a wave add to the same one or two cells: 64 lanes on one
 // LDS address would serialise)
 __device__ __forceinline__ void wave_count(unsigned int *lds, int cell) {
@@ -89,32 +89,54 @@ __global__ __launch_bounds__(256) void k_dup_counters(MxCols m, unsigned long lo
   __syncthreads();
   const uint64_t lo = (uint64_t)blockIdx.x * chunk, hi = lo + chunk < m.n ? lo + chunk : m.n;
   for (uint64_t base = lo; base < hi; base += DC_STEP) {
+    // three rounds over the step's records, each unrolled: the loads of a round are independent of each other and in flight together
+    // (the kernel waits on memory, not on arithmetic)
+    constexpr int R = DC_STEP / 256;
+    uint8_t sr[R];
+    uint16_t fl[R], rg[R], sp[R];
+    uint32_t rep[R], mt[R];
 #pragma unroll
-    for (int t = 0; t < DC_STEP / 256; t++) {
+    for (int t = 0; t < R; t++) {
       const uint64_t i = base + (uint64_t)t * 256 + threadIdx.x;
+      const bool in = i < hi;
+      sr[t] = in ? m.has_sr[i] : (uint8_t)1;
+      fl[t] = in ? m.flag[i] : (uint16_t)0;
+      rg[t] = in ? m.rgid[i] : (uint16_t)ELP_NIL16;
+      sp[t] = in ? m.split[i] : (uint16_t)0;
+      rep[t] = in ? m.prep[i] : EMPTY;
+      mt[t] = in ? m.mate[i] : EMPTY;
+    }
+    uint16_t lb[R], fm[R];
+    uint8_t srm[R];
+    uint32_t pw[R];
+#pragma unroll
+    for (int t = 0; t < R; t++) {
+      lb[t] = rg[t] == ELP_NIL16 ? (uint16_t)ELP_NIL16 : m.rg_lib[rg[t]];
+      pw[t] = rep[t] != EMPTY ? m.pwinner[rep[t]] : EMPTY;
+      srm[t] = mt[t] != EMPTY ? m.has_sr[mt[t]] : (uint8_t)0;
+      fm[t] = mt[t] != EMPTY ? m.flag[mt[t]] : (uint16_t)0;
+    }
+#pragma unroll
+    for (int t = 0; t < R; t++) {
+      const uint32_t i = (uint32_t)(base + (uint64_t)t * 256 + threadIdx.x);
       bool loser = false;
-      uint32_t rep = EMPTY;
       int cell1 = -1, cell2 = -1;  // the (at most two) counters the record adds one to
-      if (i < hi && !m.has_sr[i]) {  // sr: dropped by RemoveOptionalReads before the metrics pass
-        const uint16_t f = m.flag[i];
-        const int lib = (int)lib_row(m, (uint32_t)i), row = lib * ELP_NCTR;
+      if (!sr[t]) {  // sr (and the padding past the range): dropped by RemoveOptionalReads before the metrics pass
+        const uint16_t f = fl[t];
+        const int lib = lb[t] == ELP_NIL16 ? m.n_lib : (int)lb[t], row = lib * ELP_NCTR;  // "Unknown Library" row (:435-447)
         if (f & F_UNMAPPED) cell1 = row + 3;
         else if (f & (F_SECONDARY | F_SUPPLEMENTARY)) cell1 = row + 2;
         else {
           const bool tp = true_pair(f);
-          cell1 = tp ? nrow + (int)m.split[i] * (m.n_lib + 1) + lib : row;
+          cell1 = tp ? nrow + (int)sp[t] * (m.n_lib + 1) + lib : row;
           if (f & F_DUPLICATE) {
             if (!tp) cell2 = row + 4;
-            else {
-              const uint32_t mt = m.mate[i];
-              // counted once per pair, when the second of two duplicate-flagged mates is met (:186-192)
-              if (mt != EMPTY && mt < (uint32_t)i && (m.flag[mt] & F_DUPLICATE) && !m.has_sr[mt]) cell2 = row + 5;
-            }
+            // counted once per pair, when the second of two duplicate-flagged mates is met (:186-192)
+            else if (mt[t] != EMPTY && mt[t] < i && (fm[t] & F_DUPLICATE) && !srm[t]) cell2 = row + 5;
           }
         }
         // owner of a pair that lost its group; a pair with a tagged read is never completed by the pass over the reads (:186-190)
-        rep = m.prep[i];
-        loser = rep != EMPTY && m.pwinner[rep] != (uint32_t)i && !m.has_sr[m.mate[i]];
+        loser = rep[t] != EMPTY && pw[t] != i && !srm[t];
       }
       wave_count(lds_ctr, cell1);
       wave_count(lds_ctr, cell2);
@@ -124,7 +146,7 @@ __global__ __launch_bounds__(256) void k_dup_counters(MxCols m, unsigned long lo
         uint32_t at = 0;
         if (lane == leader) at = atomicAdd(&lcount, (uint32_t)__popcll(mask));
         at = __shfl(at, leader, 64);
-        if (loser) lq[at + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)i, rep);
+        if (loser) lq[at + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = make_uint2(i, rep[t]);
       }
     }
     __syncthreads();
@@ -449,7 +471,7 @@ static int metrics_impl(elp_ctx *c, int dist, int64_t *counters_host, int64_t *h
   const size_t nhist = hist_host ? (size_t)(c->n_lib + 1) * 3 * (size_t)hist_len : 0, norg = hist_host ? (size_t)(c->n_lib + 1) : 0;
   const int n_split = (int)c->max_split + 1;
   const size_t npr = (size_t)n_split * (size_t)(c->n_lib + 1);
-  if (((size_t)ncell + npr) * sizeof(unsigned int) > 30000)  // + 32 KB of static LDS in k_dup_counters
+  if (((size_t)ncell + npr) * sizeof(unsigned int) > 46000)  // + 16 KB of static LDS in k_dup_counters
     return set_error(c, ELP_ERR_UNSUPPORTED, "elp_dup_metrics: %d split ids x %d libraries in one context", n_split, c->n_lib + 1);
   unsigned long long *ctr;
   ELP_TRY(scratch(c, 0, (size_t)ncell + norg + nhist + npr + 8, &ctr));

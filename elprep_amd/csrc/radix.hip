@@ -135,6 +135,7 @@ constexpr int RS_TILE = RS_THREADS * RS_ITEMS;  // 4096 keys per workgroup
 constexpr int RS_WAVES = RS_THREADS / 64;
 
 // one sweep: histograms of all 8 digit positions (decides which passes are live)
+template <int ND>
 __global__ __launch_bounds__(256) void k_radix_hist_all(const uint64_t *__restrict__ keys, uint64_t n, unsigned long long *__restrict__ ghist /* [8][256] */) {
   __shared__ uint32_t h[8][256];
   for (int i = threadIdx.x; i < 8 * 256; i += 256) (&h[0][0])[i] = 0;
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256) void k_radix_hist_all(const uint64_t *__restri
     const unsigned long long act = __ballot(1);
     const int first = __ffsll((long long)act) - 1;
 #pragma unroll
-    for (int d = 0; d < 8; d++) {
+    for (int d = 0; d < ND; d++) {
       // constant digit positions (most of the high bytes) would be a 64-way same-address LDS conflict: aggregate per wave
       uint32_t dg = (uint32_t)(k >> (8 * d)) & 0xFF;
       uint32_t d0 = __shfl(dg, first, 64);
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256) void k_radix_hist_all(const uint64_t *__restri
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 8 * 256; i += 256) {
+  for (int i = threadIdx.x; i < ND * 256; i += 256) {
     uint32_t v = (&h[0][0])[i];
     if (v) atomicAdd(&ghist[i], (unsigned long long)v);
   }
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint64_t *__
     uint64_t i = wbase + (uint64_t)r * 64 + lane;
     bool valid = i < n;
     k[r] = valid ? keys[i] : ~0ull;
-    v[r] = valid ? vals[i] : 0u;
+    v[r] = valid ? (vals ? vals[i] : (uint32_t)i) : 0u;  // no value array: the values are the indices (first pass of a sort)
     uint32_t d = (uint32_t)(k[r] >> shift) & 0xFF;
     // peers = lanes of this wave holding the same digit this round (invalid lanes form their own class)
     unsigned long long peers = __ballot(valid);
@@ -329,24 +330,32 @@ static int radix_next_epoch(elp_ctx *c) {
   return 0;
 }
 
+// first_src (optional): the keys are read from there by the first pass (and `keys` is only written); identity_vals: the values are
+// 0 .. n-1 and `vals` is only written
 int radix_sort_pairs_low(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *keys_tmp, uint32_t *vals_tmp, uint64_t n, int ndigits,
-                         uint64_t **keys_out, uint32_t **vals_out) {
+                         uint64_t **keys_out, uint32_t **vals_out, const uint64_t *first_src, bool identity_vals) {
   *keys_out = keys;
   *vals_out = vals;
-  if (n < 2 || ndigits <= 0) return 0;
+  if ((n < 2 || ndigits <= 0) && !first_src && !identity_vals) return 0;
+  if (ndigits <= 0) ndigits = 1;  // a pass is needed to materialise keys / values
   if (n >= 0xFFFFFFFFull || ndigits > 8) return set_error(c, ELP_ERR_UNSUPPORTED, "radix sort: bad size");
   unsigned long long *ghist;
   ELP_TRY(scratch(c, 6, 8 * 256, &ghist));
   ELP_HIP(c, hipMemsetAsync(ghist, 0, 8 * 256 * sizeof(unsigned long long), c->stream));
   const unsigned hb = (unsigned)std::min<uint64_t>((n + 255) / 256, 2048);
-  ELP_LAUNCH(c, "radix_hist_all", k_radix_hist_all, dim3(hb), dim3(256), 0, (const uint64_t *)keys, n, ghist);
+  // histograms of the digit positions that are sorted, not of all eight
+  if (ndigits <= 2) ELP_LAUNCH(c, "radix_hist_all", k_radix_hist_all<2>, dim3(hb), dim3(256), 0, (const uint64_t *)(first_src ? first_src : keys), n, ghist);
+  else if (ndigits <= 4) ELP_LAUNCH(c, "radix_hist_all", k_radix_hist_all<4>, dim3(hb), dim3(256), 0, (const uint64_t *)(first_src ? first_src : keys), n, ghist);
+  else ELP_LAUNCH(c, "radix_hist_all", k_radix_hist_all<8>, dim3(hb), dim3(256), 0, (const uint64_t *)(first_src ? first_src : keys), n, ghist);
   const uint32_t ntiles = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
   ELP_TRY(radix_pass_setup(c, ntiles));
   uint64_t *ksrc = keys, *kdst = keys_tmp;
   uint32_t *vsrc = vals, *vdst = vals_tmp;
   for (int d = 0; d < ndigits; d++) {
     ELP_TRY(radix_next_epoch(c));
-    ELP_LAUNCH(c, "radix_scatter", k_radix_scatter, dim3(ntiles), dim3(RS_THREADS), 0, (const uint64_t *)ksrc, (const uint32_t *)vsrc, kdst,
+    const uint64_t *kin = (d == 0 && first_src) ? first_src : ksrc;
+    const uint32_t *vin = (d == 0 && identity_vals) ? nullptr : vsrc;
+    ELP_LAUNCH(c, "radix_scatter", k_radix_scatter, dim3(ntiles), dim3(RS_THREADS), 0, kin, vin, kdst,
                vdst, n, 8 * d, (const unsigned long long *)(ghist + d * 256), c->radix_state.p, c->radix_epoch, c->radix_ticket.p + d,
                c->err_flag.p);
     std::swap(ksrc, kdst);
@@ -367,7 +376,7 @@ int radix_sort_pairs(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *keys_
   ELP_TRY(scratch(c, 6, 8 * 256, &ghist));
   ELP_HIP(c, hipMemsetAsync(ghist, 0, 8 * 256 * sizeof(unsigned long long), c->stream));
   unsigned hb = (unsigned)std::min<uint64_t>((n + 255) / 256, 2048);
-  ELP_LAUNCH(c, "radix_hist_all", k_radix_hist_all, dim3(hb), dim3(256), 0, (const uint64_t *)keys, n, ghist);
+  ELP_LAUNCH(c, "radix_hist_all", k_radix_hist_all<8>, dim3(hb), dim3(256), 0, (const uint64_t *)keys, n, ghist);
   unsigned long long hh[8 * 256];
   ELP_HIP(c, hipMemcpyAsync(hh, ghist, sizeof hh, hipMemcpyDeviceToHost, c->stream));
   ELP_HIP(c, hipStreamSynchronize(c->stream));  // (a look-back timeout of any pass is reported by the callers, behind their last pass)

@@ -151,12 +151,13 @@ __global__ __launch_bounds__(FL_THREADS) void k_score_flat(uint64_t n, const uin
 
 // Set of quality values present, from a sample of the tiles (every `stride`-th).  It is a sizing hint for the BQSR gather's
 // LDS tables, not a correctness input: k_bqsr_count reports any counted quality it has no table slot for and the host retries.
-__global__ __launch_bounds__(256) void k_qual_present_sample(const uint8_t *__restrict__ qual, uint64_t qual_bytes, uint64_t stride,
+// `span`: bytes looked at per sampled tile (the exact set after a miss: stride 1, whole tiles)
+__global__ __launch_bounds__(256) void k_qual_present_sample(const uint8_t *__restrict__ qual, uint64_t qual_bytes, uint64_t stride, uint64_t span,
                                                              unsigned long long *qmask) {
   const uint64_t ntiles = (qual_bytes + FL_TILE - 1) / FL_TILE;
   uint32_t m[3] = {0, 0, 0};  // bits 0..95
   for (uint64_t t = (uint64_t)blockIdx.x * stride; t < ntiles; t += (uint64_t)gridDim.x * stride) {
-    const uint64_t tb = t * FL_TILE, te = (tb + FL_TILE < qual_bytes) ? tb + FL_TILE : qual_bytes;
+    const uint64_t tb = t * FL_TILE, te = (tb + span < qual_bytes) ? tb + span : qual_bytes;
     for (uint64_t p = tb + (uint64_t)threadIdx.x * 16; p < te; p += 256 * 16) {
       Chunk ch;
       ch.load(qual + p);
@@ -230,6 +231,11 @@ int ensure_adapted(elp_ctx *c, bool check_quals) {
   c->adapt_bad_qual = false;
   int pos_bits = 1;
   while (pos_bits < 32 && (c->max_pos >> pos_bits) != 0) pos_bits++;
+  {
+    int ref_bits = 1;  // contig codes 0 .. n_ref + 1 (unmapped, then the records that are not sorted at all)
+    while (ref_bits < 32 && (((uint32_t)c->n_ref + 1u) >> ref_bits) != 0) ref_bits++;
+    c->key_bits = ref_bits + pos_bits + 1;
+  }
   if (n) {
     if (!c->qual_bytes) ELP_HIP(c, hipMemsetAsync(c->qbounds.p, 0, n * sizeof(uint64_t), c->stream));  // no QUAL bytes at all: no tile, no kernel
     ELP_LAUNCH(c, "adapt_fixed", k_adapt_fixed, dim3(blocks_for(n, 256)), dim3(256), 0, n, (const int32_t *)c->pos.p, (const int32_t *)c->refid.p,
@@ -263,7 +269,8 @@ int ensure_qual_present(elp_ctx *c, bool exact) {
     const uint64_t ntiles = (c->qual_bytes + FL_TILE - 1) / FL_TILE;
     const uint64_t stride = exact ? 1 : std::min<uint64_t>(16, std::max<uint64_t>(1, ntiles / 2048));
     const unsigned grid = (unsigned)std::min<uint64_t>((ntiles + stride - 1) / stride, 2048);
-    ELP_LAUNCH(c, "qual_present_sample", k_qual_present_sample, dim3(grid), dim3(256), 0, (const uint8_t *)c->qual.p, c->qual_bytes, stride, qm);
+    ELP_LAUNCH(c, "qual_present_sample", k_qual_present_sample, dim3(grid), dim3(256), 0, (const uint8_t *)c->qual.p, c->qual_bytes, stride,
+               (exact || stride == 1) ? FL_TILE : (uint64_t)4096, qm);
     ELP_HIP(c, hipMemcpyAsync(c->qual_present, qm, 16, hipMemcpyDeviceToHost, c->stream));
     ELP_HIP(c, hipStreamSynchronize(c->stream));
   }
@@ -534,11 +541,11 @@ static int sort_impl(elp_ctx *c) {
   ELP_TRY(scratch(c, 2, 2 * n + 8, &flags));
   uint64_t *k0 = kbuf, *k1 = kbuf + n;
   uint32_t *v0 = vbuf, *v1 = vbuf + n;
-  ELP_HIP(c, hipMemcpyAsync(k0, c->key.p, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
-  ELP_LAUNCH(c, "iota", k_iota, dim3(blocks_for(n, 256)), dim3(256), 0, v0, n);
+  // the key column holds key_bits live bits (adapt packs it): that many digit passes, no histogram read-back; the first pass reads
+  // the column itself and numbers the records as it goes (no copy, no index array)
   uint64_t *ks;
   uint32_t *vs;
-  ELP_TRY(radix_sort_pairs(c, k0, v0, k1, v1, n, &ks, &vs));
+  ELP_TRY(radix_sort_pairs_low(c, k0, v0, k1, v1, n, (c->key_bits + 7) / 8, &ks, &vs, c->key.p, true));
   TieCols t{c->qname_off.p, c->qname.p, c->flag.p, c->mapq.p, c->next_refid.p, c->pnext.p, c->tlen.p};
   uint32_t *large_flag = flags, *large_idx = flags + n;
   {
