@@ -104,6 +104,7 @@ struct elp_ctx {
   elp::DVec<unsigned long long> radix_state;  // radix.hip: per (tile, digit) look-back words, tagged with the pass epoch
   elp::DVec<uint32_t> radix_ticket;           // radix.hip: tile ticket counters
   elp::DVec<uint32_t> tie_live;               // sort.hip: bit j = byte j of the comparator string differs among the members of large runs
+  elp::DVec<uint32_t> md_ctr;                 // markdup.hip: device counters read back with one copy (0: true fragments listed)
   static constexpr uint32_t MAX_QNAME = 1000; // staged QNAME length limit; the comparator string (QNAME + 15 bytes) fits TIE_LIVE_WORDS * 32 bits
   static constexpr uint32_t TIE_LIVE_WORDS = 32;
   uint32_t radix_epoch = 0;

@@ -57,10 +57,38 @@ __global__ __launch_bounds__(256) void k_md_flag_in(uint64_t n, const uint16_t *
   if (i < n) flag_in[i] = state[i] == 2 ? (uint16_t)(flag[i] | F_SECONDARY) : flag[i];
 }
 
-__global__ __launch_bounds__(256) void k_md_keys(MdCols m, uint4 *__restrict__ fkey) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m.n) return;
-  fkey[i] = make_uint4((uint32_t)m.refid[i], (uint32_t)m.upos[i], ((uint32_t)lib_of(m, (uint32_t)i) << 1) | ((m.flag_in[i] & F_REVERSED) ? 1u : 0u), (uint32_t)m.split[i]);
+// Also lists the TRUE FRAGMENTS (candidates that are not true pairs: unpaired reads and reads whose mate is unmapped).  They are the
+// only records the fragment map can flag (classifyFragment, :210-251: a true pair is never flagged there, it only turns every true
+// fragment at its key into a duplicate), so only they need grouping; the true pairs look their key up afterwards.  A workgroup
+// handles MK_TILES * 256 records and appends its fragments with one global atomic.
+constexpr int MK_TILES = 16;
+__global__ __launch_bounds__(256) void k_md_keys(MdCols m, uint4 *__restrict__ fkey, uint32_t *__restrict__ flist, uint32_t *nf) {
+  __shared__ uint32_t lq[MK_TILES * 256];
+  __shared__ uint32_t lcount, gbase;
+  if (threadIdx.x == 0) lcount = 0;
+  __syncthreads();
+#pragma unroll 2
+  for (int tile = 0; tile < MK_TILES; tile++) {
+    const uint64_t i = ((uint64_t)blockIdx.x * MK_TILES + (uint64_t)tile) * 256 + threadIdx.x;
+    bool frag = false;
+    if (i < m.n) {
+      const uint16_t f = m.flag_in[i];
+      fkey[i] = make_uint4((uint32_t)m.refid[i], (uint32_t)m.upos[i], ((uint32_t)lib_of(m, (uint32_t)i) << 1) | ((f & F_REVERSED) ? 1u : 0u), (uint32_t)m.split[i]);
+      frag = is_candidate(f) && !is_true_pair(f);
+    }
+    const unsigned long long mask = __ballot(frag);
+    if (mask) {
+      const int lane = threadIdx.x & 63, leader = __ffsll((long long)mask) - 1;
+      uint32_t at = 0;
+      if (lane == leader) at = atomicAdd(&lcount, (uint32_t)__popcll(mask));
+      at = __shfl(at, leader, 64);
+      if (frag) lq[at + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)i;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) gbase = lcount ? atomicAdd(nf, lcount) : 0u;
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < lcount; k += 256) flist[gbase + k] = lq[k];
 }
 __device__ __forceinline__ bool key_eq(const uint4 &a, const uint4 &b) { return a.x == b.x && a.y == b.y && a.z == b.z && a.w == b.w; }
 __device__ __forceinline__ uint64_t frag_hash(const uint4 &k) {
@@ -85,17 +113,56 @@ __device__ __forceinline__ uint32_t find_or_insert(uint32_t *table, uint64_t mas
   }
 }
 
-__global__ __launch_bounds__(256) void k_frag_insert(MdCols m, const uint4 *__restrict__ fkey, uint32_t *table, uint64_t mask,
-                                                     uint32_t *__restrict__ frep, unsigned long long *fbest) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// the true fragments (flist) are grouped by key; group payloads (best score | pair bit, winner) are indexed by the representative
+__global__ __launch_bounds__(256) void k_frag_insert(MdCols m, const uint4 *__restrict__ fkey, const uint32_t *__restrict__ flist, uint32_t nf,
+                                                     uint32_t *table, uint64_t mask, uint32_t *__restrict__ frep, unsigned long long *fbest) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nf) return;
+  const uint32_t i = flist[j];
+  const uint4 mine = fkey[i];
+  const uint32_t rep = find_or_insert(table, mask, frag_hash(mine), i, [&](uint32_t a, uint32_t) { return key_eq(fkey[a], mine); });
+  frep[i] = rep;
+  atomicMax(&fbest[rep], (unsigned long long)(uint32_t)m.score[i]);
+}
+__global__ __launch_bounds__(256) void k_frag_init(const uint32_t *__restrict__ flist, uint32_t nf, unsigned long long *__restrict__ fbest,
+                                                   uint32_t *__restrict__ fwinner) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nf) return;
+  const uint32_t i = flist[j];  // any fragment can become its group's representative
+  fbest[i] = 0;
+  fwinner[i] = EMPTY;
+}
+// every true pair looks its own key up (plain loads: the table is final and small - sized by the fragments, not by the records):
+// a group of fragments at the key of a pair loses as a whole
+// occupancy bits of the fragment table (one word per 32 slots): few hundred KB that stay in every L2, so that the pairs' look-ups
+// (94 % of which end at an empty slot) rarely leave it
+__global__ __launch_bounds__(256) void k_frag_bits(const uint32_t *__restrict__ table, uint64_t nwords, uint32_t *__restrict__ bits) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= nwords) return;
+  const uint4 *t = reinterpret_cast<const uint4 *>(table + 32 * w);
+  uint32_t b = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const uint4 v = t[k];
+    b |= (v.x != EMPTY ? 1u : 0u) << (4 * k) | (v.y != EMPTY ? 2u : 0u) << (4 * k) | (v.z != EMPTY ? 4u : 0u) << (4 * k) | (v.w != EMPTY ? 8u : 0u) << (4 * k);
+  }
+  bits[w] = b;
+}
+__global__ __launch_bounds__(256) void k_frag_probe_pairs(MdCols m, const uint4 *__restrict__ fkey, const uint32_t *__restrict__ table,
+                                                          const uint32_t *__restrict__ bits, uint64_t mask, unsigned long long *fbest) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m.n) return;
   const uint16_t f = m.flag_in[i];
-  if (!is_candidate(f)) { frep[i] = EMPTY; return; }
+  if (!is_candidate(f) || !is_true_pair(f)) return;
   const uint4 mine = fkey[i];
-  const uint32_t rep = find_or_insert(table, mask, frag_hash(mine), (uint32_t)i, [&](uint32_t a, uint32_t) { return key_eq(fkey[a], mine); });
-  frep[i] = rep;
-  const unsigned long long v = is_true_pair(f) ? (1ull << 63) : (unsigned long long)(uint32_t)m.score[i];
-  atomicMax(&fbest[rep], v);
+  for (uint64_t s = frag_hash(mine) & mask;; s = (s + 1) & mask) {
+    if (!((bits[s >> 5] >> (s & 31)) & 1u)) return;
+    const uint32_t cur = table[s];
+    if (key_eq(fkey[cur], mine)) {
+      atomicMax(&fbest[cur], 1ull << 63);
+      return;
+    }
+  }
 }
 
 // (QNAME asc, later arrival wins) tournament among contenders
@@ -117,23 +184,24 @@ __device__ __forceinline__ void tournament(const MdCols &m, uint32_t *winner, ui
   }
 }
 
-__global__ __launch_bounds__(256) void k_frag_tie(MdCols m, const uint32_t *__restrict__ frep, const unsigned long long *__restrict__ fbest,
-                                                  uint32_t *fwinner) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m.n) return;
+__global__ __launch_bounds__(256) void k_frag_tie(MdCols m, const uint32_t *__restrict__ flist, uint32_t nf, const uint32_t *__restrict__ frep,
+                                                  const unsigned long long *__restrict__ fbest, uint32_t *fwinner) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nf) return;
+  const uint32_t i = flist[j];
   const uint32_t rep = frep[i];
-  if (rep == EMPTY || is_true_pair(m.flag_in[i])) return;
   const unsigned long long b = fbest[rep];
   if ((b >> 63) || (unsigned long long)(uint32_t)m.score[i] != b) return;
   tournament(m, &fwinner[rep], (uint32_t)i);
 }
 
-__global__ __launch_bounds__(256) void k_frag_flag(MdCols m, const uint32_t *__restrict__ frep, const unsigned long long *__restrict__ fbest,
-                                                   const uint32_t *__restrict__ fwinner, uint16_t *__restrict__ flag_out) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m.n) return;
+__global__ __launch_bounds__(256) void k_frag_flag(MdCols m, const uint32_t *__restrict__ flist, uint32_t nf, const uint32_t *__restrict__ frep,
+                                                   const unsigned long long *__restrict__ fbest, const uint32_t *__restrict__ fwinner,
+                                                   uint16_t *__restrict__ flag_out) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nf) return;
+  const uint32_t i = flist[j];
   const uint32_t rep = frep[i];
-  if (rep == EMPTY || is_true_pair(m.flag_in[i])) return;
   const unsigned long long b = fbest[rep];
   const bool dup = (b >> 63) || (unsigned long long)(uint32_t)m.score[i] < b || fwinner[rep] != (uint32_t)i;
   if (dup) flag_out[i] = (uint16_t)(m.flag_in[i] | F_DUPLICATE);
@@ -379,7 +447,6 @@ static int markdup_impl(elp_ctx *c) {
   uint32_t *table;
   ELP_TRY(scratch(c, 0, T, &table));
   uint32_t *rep;
-  ELP_TRY(scratch(c, 1, n + 8, &rep));
   unsigned long long *best;
   ELP_TRY(scratch(c, 2, n + 8, &best));
   uint32_t *winner;
@@ -387,16 +454,14 @@ static int markdup_impl(elp_ctx *c) {
 
   uint4 *fkey;
   ELP_TRY(scratch(c, 5, n + 8, &fkey));
-  ELP_LAUNCH(c, "md_keys", k_md_keys, dim3(grid), dim3(256), 0, m, fkey);
-
-  // ---- fragments
-  ELP_HIP(c, hipMemsetAsync(table, 0xFF, T * sizeof(uint32_t), st));
-  ELP_HIP(c, hipMemsetAsync(best, 0, n * sizeof(unsigned long long), st));
-  ELP_HIP(c, hipMemsetAsync(winner, 0xFF, n * sizeof(uint32_t), st));
-  ELP_LAUNCH(c, "md_frag_insert", k_frag_insert, dim3(grid), dim3(256), 0, m, (const uint4 *)fkey, table, T - 1, rep, best);
-  ELP_LAUNCH(c, "md_frag_tie", k_frag_tie, dim3(grid), dim3(256), 0, m, (const uint32_t *)rep, (const unsigned long long *)best, winner);
-  ELP_LAUNCH(c, "md_frag_flag", k_frag_flag, dim3(grid), dim3(256), 0, m, (const uint32_t *)rep, (const unsigned long long *)best,
-             (const uint32_t *)winner, c->flag.p);
+  // keys of all records + the list of true fragments (in `rep`'s scratch slot behind the n entries of frep)
+  ELP_TRY(ensure(c, c->md_ctr, 8));
+  uint32_t *nf_dev = c->md_ctr.p;
+  ELP_TRY(scratch(c, 1, 2 * n + 16, &rep));
+  uint32_t *flist = rep + n + 8;
+  ELP_HIP(c, hipMemsetAsync(nf_dev, 0, 4, st));
+  ELP_LAUNCH(c, "md_keys", k_md_keys, dim3(blocks_for(n, 256 * MK_TILES)), dim3(256), 0, m, fkey, flist, nf_dev);
+  uint32_t nf = 0;  // read together with the mate phase's table estimate below
 
   // ---- mates
   {
@@ -418,6 +483,7 @@ static int markdup_impl(elp_ctx *c) {
     // Bloom-filter hit sends there (at most as many again, in practice a fraction): size it by their number, not by n
     uint32_t n_tab = 0;
     ELP_HIP(c, hipMemcpyAsync(&n_tab, n_table_dev, 4, hipMemcpyDeviceToHost, st));
+    ELP_HIP(c, hipMemcpyAsync(&nf, nf_dev, 4, hipMemcpyDeviceToHost, st));
     ELP_HIP(c, hipStreamSynchronize(st));
     ELP_HIP(c, hipMemsetAsync(n_table_dev, 0, 4, st));
     uint64_t Tm = std::min<uint64_t>(T, table_size_for(std::min<uint64_t>(n, 4ull * n_tab + 1024)));
@@ -456,6 +522,24 @@ static int markdup_impl(elp_ctx *c) {
       ELP_TRY(scratch(c, 2, n + 8, &best));
       ELP_TRY(scratch(c, 3, n + 8, &winner));
     }
+  }
+
+  // ---- fragments: group the true fragments, let the true pairs look their keys up, tournament among the fragments of pair-free groups
+  if (nf) {
+    const uint64_t Tf = std::min<uint64_t>(T, table_size_for(4ull * nf));  // sparse: most look-ups of the pairs end at an empty slot
+    ELP_HIP(c, hipMemsetAsync(table, 0xFF, Tf * sizeof(uint32_t), st));
+    const unsigned fgrid = blocks_for(nf, 256);
+    ELP_LAUNCH(c, "md_frag_init", k_frag_init, dim3(fgrid), dim3(256), 0, (const uint32_t *)flist, nf, best, winner);
+    ELP_LAUNCH(c, "md_frag_insert", k_frag_insert, dim3(fgrid), dim3(256), 0, m, (const uint4 *)fkey, (const uint32_t *)flist, nf, table, Tf - 1, rep, best);
+    uint32_t *fbits;
+    ELP_TRY(scratch(c, 6, Tf / 32 + 16, &fbits));  // the mate phase's scratch is free again
+    ELP_LAUNCH(c, "md_frag_bits", k_frag_bits, dim3(blocks_for(Tf / 32, 256)), dim3(256), 0, (const uint32_t *)table, Tf / 32, fbits);
+    ELP_LAUNCH(c, "md_frag_probe", k_frag_probe_pairs, dim3(grid), dim3(256), 0, m, (const uint4 *)fkey, (const uint32_t *)table, (const uint32_t *)fbits,
+               Tf - 1, best);
+    ELP_LAUNCH(c, "md_frag_tie", k_frag_tie, dim3(fgrid), dim3(256), 0, m, (const uint32_t *)flist, nf, (const uint32_t *)rep,
+               (const unsigned long long *)best, winner);
+    ELP_LAUNCH(c, "md_frag_flag", k_frag_flag, dim3(fgrid), dim3(256), 0, m, (const uint32_t *)flist, nf, (const uint32_t *)rep,
+               (const unsigned long long *)best, (const uint32_t *)winner, c->flag.p);
   }
 
   // ---- pairs (at most n / 2 of them)
