@@ -455,3 +455,44 @@ def test_full_quality_range_tables_and_apply():
     got = e.apply_bqsr(lut, present, 500)
     assert np.array_equal(got, orc.BqsrFinal(oq, oc, ox, 500).apply(b, h, 0))
     e.close()
+
+
+@pytest.mark.parametrize("kind", ["no_true_fragments", "only_fragments", "fragments_at_pair_keys"])
+def test_fragment_phase_extremes(kind):
+    """The fragment phase groups only TRUE fragments and lets the true pairs look their keys up (classifyFragment,
+    filters/mark-duplicates.go:210-251).  The extremes: no true fragment at all (the phase is skipped), single-end data (every
+    candidate is a fragment: the table holds everything), and fragments that sit exactly on keys of pairs (all of them lose)."""
+    from tools import synth
+    cfg = synth.config("tiny", 3)
+    if kind == "no_true_fragments":
+        cfg.p_frag = 0.0; cfg.p_mate_unmapped = 0.0; cfg.p_unmapped_pair = 0.0
+    elif kind == "only_fragments":
+        cfg.p_frag = 1.0
+    else:
+        cfg.p_frag = 0.3; cfg.p_dup = 0.5
+    b = synth.generate(cfg, 0, 6000)
+    h = cfg.header()
+    if kind == "fragments_at_pair_keys":
+        # turn every fifth true pair read's twin into a fragment at the same key: copy the record, clear the pair flags
+        cand = np.flatnonzero(((b.flag & 0x1) != 0) & ((b.flag & 0x8) == 0) & ((b.flag & 0x904) == 0))[::5]
+        twin = b.take(cand)
+        twin.flag[:] = twin.flag & 0x10  # unpaired, strand kept
+        twin.pnext[:] = 0; twin.next_refid[:] = -1; twin.tlen[:] = 0
+        b = Batch.concat([b, twin])
+    oflags = orc.mark_duplicates(b, h)
+    frag = ((oflags & 0x904) == 0) & (((oflags & 0x1) == 0) | ((oflags & 0x8) != 0))
+    if kind == "no_true_fragments":
+        assert frag.sum() == 0
+    elif kind == "only_fragments":
+        assert frag.sum() > 0.9 * ((oflags & 0x904) == 0).sum() and ((oflags[frag] & 0x400) != 0).sum() > 0
+    else:
+        assert ((oflags[b.n - len(cand):] & 0x400) != 0).all()  # a fragment at a pair's key always loses
+    e = Engine(h)
+    e.stage(b)
+    flags = e.mark_duplicates(also_opticals=True)
+    assert np.array_equal(flags, oflags)
+    perm = e.sort_coordinate()
+    assert np.array_equal(perm, orc.sort_coordinate(b, oflags))
+    _, octr, _ = orc.dup_metrics(b, h, perm, 100)
+    assert np.array_equal(e.dup_metrics(100), octr)
+    e.close()
