@@ -213,10 +213,11 @@ def main():
         def step_full():
             eng.mark_duplicates(True, fetch=False)
             eng.sort_coordinate(fetch=False)
-            qt, ct, xt = eng.recalibrate(MAX_CYCLE, reuse=True)
-            # the float64 finalisation + LUT (host) and the duplication-metrics pass (device) do not depend on each other: the
-            # host thread finalises while the GPU counts (the reference runs them one after the other, cmd/filter.go:162-196)
-            fin = host_pool.submit(finalize_lut, qt, ct, xt)
+            eng.recalibrate_device(MAX_CYCLE)
+            # the tables' way to the host, the float64 finalisation + LUT (host thread; the copy runs on the context's copy stream) and
+            # the duplication-metrics pass (device, this thread) do not depend on each other: the host finalises while the GPU counts
+            # (the reference runs them one after the other, cmd/filter.go:162-196)
+            fin = host_pool.submit(lambda: finalize_lut(*eng.tables_fetch(reuse=True)))
             eng.dup_metrics(100)
             lut, present = fin.result()
             eng.apply_bqsr(lut, present, MAX_CYCLE, fetch=False)

@@ -147,6 +147,8 @@ struct elp_ctx {
   elp::DVec<uint32_t> rg_ids_off;
   bool have_rg_ids = false;
   hipStream_t copy_stream = nullptr;
+  hipEvent_t tables_ev = nullptr;  // recorded on `stream` behind the last writer of dev_tables (gather, tables_add, all-reduce): elp_bqsr_tables_fetch
+                                   // copies on copy_stream behind it, so the context's stream is free for the next stage meanwhile
   void *bounce[2] = {nullptr, nullptr};  // pinned double buffer for pageable sources
   hipEvent_t bounce_ev[2] = {nullptr, nullptr};
 
@@ -300,6 +302,7 @@ int ensure_adapted(elp_ctx *c, bool check_quals = true);
 int ensure_qual_present(elp_ctx *c, bool exact = false);  // exact: scan the whole column instead of a sample
 int fetch_err(elp_ctx *c, uint32_t *words /* 4 */);
 void group_release(elp_ctx *c);
+int tables_written(elp_ctx *c);  // bqsr.hip: dev_tables were just written on c->stream
 int stage_reserve(elp_ctx *c, uint64_t n, uint64_t qb, uint64_t co, uint64_t sb, uint64_t lb);  // grows the staged columns (ctx.hip)
 int stage_recode_seq(elp_ctx *c, uint64_t from, uint64_t bytes);                               // BAM nibbles -> code nibbles on seq4[from, from + bytes)
 

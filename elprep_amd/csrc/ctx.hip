@@ -133,6 +133,7 @@ void elp_destroy(elp_ctx *c) {
     if (c->bounce_ev[k]) (void)hipEventDestroy(c->bounce_ev[k]);
   }
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+  if (c->tables_ev) (void)hipEventDestroy(c->tables_ev);
   group_release(c);
   (void)hipStreamDestroy(c->stream);
   delete c;

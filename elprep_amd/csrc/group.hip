@@ -135,7 +135,7 @@ int elp_bqsr_tables_add(elp_ctx *dst, elp_ctx *src) {
   hipLaunchKernelGGL(k_add_i64, dim3(blocks_for(dst->tables_n, 256)), dim3(256), 0, dst->stream, dst->dev_tables.p, (const unsigned long long *)src->dev_tables.p,
                      dst->tables_n);
   ELP_HIP(dst, hipGetLastError());
-  return 0;
+  return tables_written(dst);
 }
 
 int elp_bqsr_tables_allreduce(elp_ctx *c, int64_t *counters, size_t n_counters) {
@@ -148,6 +148,7 @@ int elp_bqsr_tables_allreduce(elp_ctx *c, int64_t *counters, size_t n_counters) 
   unsigned long long *tail = c->dev_tables.p + c->tables_n;
   if (n_counters) ELP_HIP(c, hipMemcpyAsync(tail, counters, n_counters * 8, hipMemcpyHostToDevice, c->stream));
   ELP_TRY(allreduce_device(c, c->dev_tables.p, c->tables_n + n_counters));
+  ELP_TRY(tables_written(c));
   if (n_counters) ELP_HIP(c, hipMemcpyAsync(counters, tail, n_counters * 8, hipMemcpyDeviceToHost, c->stream));
   ELP_HIP(c, hipStreamSynchronize(c->stream));
   return 0;

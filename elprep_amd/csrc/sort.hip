@@ -82,6 +82,7 @@ struct ScoreBody {
   uint32_t *lo;    // LDS [RMAX]: index of the first quality > 2 of the read (0xFFFFFFFF: none yet)
   uint32_t *hi;    // LDS [RMAX]: 1 + index of the last quality > 2 (0: none yet)
   uint8_t *cand;   // LDS [RMAX]: duplicate-marking candidate?
+  const uint4 *mask;  // LDS [17]: byte masks of the first nb bytes of a block, one 16-byte read instead of sixteen instructions
   uint32_t bad;
 
   __device__ __forceinline__ void stage(uint32_t g0, uint32_t ng) {
@@ -107,7 +108,8 @@ struct ScoreBody {
     return true;
   }
   __device__ __forceinline__ void process(Pre &p) {
-    const uint32_t m0 = first_bytes32(p.nb), m1 = first_bytes32(p.nb - 4), m2 = first_bytes32(p.nb - 8), m3 = first_bytes32(p.nb - 12);
+    const uint4 mk = mask[p.nb];
+    const uint32_t m0 = mk.x, m1 = mk.y, m2 = mk.z, m3 = mk.w;
     // low-quality-tail bounds: first / last quality > 2 of the read
     const uint64_t glo = (uint64_t)gt2(p.ch.w0, m0) | ((uint64_t)gt2(p.ch.w1, m1) << 32);
     const uint64_t ghi = (uint64_t)gt2(p.ch.w2, m2) | ((uint64_t)gt2(p.ch.w3, m3) << 32);
@@ -144,7 +146,13 @@ __global__ __launch_bounds__(FL_THREADS) void k_score_flat(uint64_t n, const uin
   __shared__ int32_t acc[ScoreBody::RMAX];
   __shared__ uint32_t lo[ScoreBody::RMAX], hi[ScoreBody::RMAX];
   __shared__ uint8_t cand[ScoreBody::RMAX];
-  ScoreBody B{flag, qual, score, qbounds, acc, lo, hi, cand, 0u};
+  __shared__ uint4 mask[17];
+  if (threadIdx.x <= 16) {
+    const int nb = (int)threadIdx.x;
+    mask[nb] = make_uint4(first_bytes32(nb), first_bytes32(nb - 4), first_bytes32(nb - 8), first_bytes32(nb - 12));
+  }
+  __syncthreads();
+  ScoreBody B{flag, qual, score, qbounds, acc, lo, hi, cand, mask, 0u};
   flat_run(qual_off, n, qual_bytes, tile_first, L, B);
   if (__any(B.bad != 0) && (threadIdx.x & 63) == 0) atomicOr(&err[0], 1u);
 }

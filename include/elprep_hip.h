@@ -205,7 +205,10 @@ int elp_bqsr_set_known_sites(elp_ctx *ctx, int32_t refid, const int32_t *start_e
 #define ELP_NCTX 16
 int elp_bqsr_gather(elp_ctx *ctx, int max_cycle, int64_t *qual_tbl, int64_t *cycle_tbl, int64_t *ctx_tbl);
 
-/* The same, but the tables stay in HBM (ctx-owned) for the device group's all-reduce below; elp_bqsr_tables_fetch copies them out. */
+/* The same, but the tables stay in HBM (ctx-owned) for the device group's all-reduce below; elp_bqsr_tables_fetch copies them out.
+ * The copy runs on a stream of its own behind the last writer of the tables, and it is the ONE call that may run on a second host
+ * thread while the context is busy with another call (elp_dup_metrics): the host fetches and finalises the tables while the GPU
+ * counts optical duplicates - the two steps the reference runs one after the other (cmd/filter.go:162-196). */
 int elp_bqsr_gather_device(elp_ctx *ctx, int max_cycle);
 int elp_bqsr_tables_fetch(elp_ctx *ctx, int64_t *qual_tbl, int64_t *cycle_tbl, int64_t *ctx_tbl);
 
