@@ -268,11 +268,12 @@ class SfmRank:
             # to the torch.distributed collective - the decision itself is a collective, so nobody is left waiting in a group
             ok = 1
             try:
-                box = [group_unique_id() if comm.rank == 0 else None]
+                uid = group_unique_id()  # every rank: also the check that this process can load RCCL at all (rank 0's id is used)
+                box = [uid if comm.rank == 0 else None]
             except Exception:
                 box, ok = [None], 0
             comm.dist.broadcast_object_list(box, src=0)
-            flag = comm.torch.tensor([ok if box[0] is not None else 0], dtype=comm.torch.int64, device=comm.device)
+            flag = comm.torch.tensor([ok if (ok and box[0] is not None) else 0], dtype=comm.torch.int64, device=comm.device)
             comm.dist.all_reduce(flag, op=comm.dist.ReduceOp.MIN)
             if int(flag.item()) == 1:
                 try:
