@@ -394,6 +394,15 @@ __global__ __launch_bounds__(256) void k_tie_small(uint64_t n, const uint64_t *_
     perm_out[i] = me;
     return;
   }
+  if (e - s == 2) {
+    // a run of two (nine runs in ten): its first member places both with ONE comparison, the second has nothing to do
+    if (i != s) return;
+    const uint32_t other = perm_in[s + 1];
+    const bool swap = tie_less(t, other, me);  // `me` came first: it stays in front unless the other one is strictly less
+    perm_out[s] = swap ? other : me;
+    perm_out[s + 1] = swap ? me : other;
+    return;
+  }
   uint32_t rank = 0;
   for (uint64_t j = s; j < e; j++) {
     if (j == i) continue;
