@@ -95,7 +95,10 @@ def timed(step, restore, steps, warmup, prof_eng, barrier):
 
 
 def summarize(prof, steps, n_reads, full_bytes):
-    """per-stage kernel ms per step, the dominant kernel and its roofline figures"""
+    """per-stage kernel ms per step, the dominant kernel and its roofline figures.  `achieved` = the algorithmic bytes of the stage the
+    dominant kernel belongs to (SURVEY.md 8d x the reads of the step) over the time ALL launches of that kernel take in one step (a
+    kernel launched several times per step - the radix scatter - is not priced by the average of its unequal launches); `stage_frac` =
+    the same per stage, over the stage's whole kernel time."""
     stage_ms = {}
     for name, (cnt, ms) in prof.items():
         st = kernel_stage(name)
@@ -103,19 +106,23 @@ def summarize(prof, steps, n_reads, full_bytes):
     dom = max(prof.items(), key=lambda kv: kv[1][1])[0]
     dom_stage = kernel_stage(dom)
     launches_per_step = max(prof[dom][0] / steps, 1)
-    dom_launch_ms = prof[dom][1] / max(prof[dom][0], 1)
-    # achieved = algorithmic bytes of the stage the dominant kernel belongs to (SURVEY.md 8d x the reads one launch processes), per launch
-    achieved = (BYTES_PER_READ.get(dom_stage, 0) * n_reads / launches_per_step) / (dom_launch_ms * 1e-3) / 1e9 if dom_launch_ms > 0 else 0.0
+    dom_ms_per_step = prof[dom][1] / steps
+    achieved = (BYTES_PER_READ.get(dom_stage, 0) * n_reads) / (dom_ms_per_step * 1e-3) / 1e9 if dom_ms_per_step > 0 else 0.0
     kernel_total_ms = sum(stage_ms.values())
     traffic = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         if dom in tj["bytes_per_read"]:
-            traffic = round(tj["bytes_per_read"][dom] * n_reads / launches_per_step)
+            traffic = round(tj["bytes_per_read"][dom] * n_reads)
     except Exception:
         traffic = None
-    roof = {"bound": "hbm", "kernel": dom, "stage": dom_stage, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    stage_frac = {st: round(BYTES_PER_READ[st] * n_reads / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for st, ms in sorted(stage_ms.items())
+                  if st in BYTES_PER_READ and ms > 0}
+    roof = {"bound": "hbm", "kernel": dom, "stage": dom_stage, "launches_per_step": launches_per_step, "kernel_ms_per_step": round(dom_ms_per_step, 4),
+            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+            "traffic_source": "profiles/traffic.json: rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE) of an 8 M-read run of this path, per read, scaled to this run's reads - not measured in this run",
+            "stage_frac": stage_frac,
             "path_frac": round((full_bytes * n_reads / (kernel_total_ms * 1e-3) / 1e9) / HBM_PEAK_GBS, 5) if kernel_total_ms else None}
     kern = {k: round(v[1] / steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:14]}
     return {k: round(v, 3) for k, v in sorted(stage_ms.items())}, kern, roof
@@ -134,6 +141,7 @@ def main():
     ap.add_argument("--total-reads", type=int, default=0, help="strong scaling: reads of the whole job (default: --reads)")
     ap.add_argument("--cpu-reads", type=int, default=8_000_000, help="sample size for the CPU baseline leg (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the comparison of the device path with the CPU leg's outputs (it needs the CPU leg)")
     ap.add_argument("--no-extra", action="store_true", help="N = 1: skip the C2 / full-quality / PCIe-inclusive side measurements")
     ap.add_argument("--extra-reads", type=int, default=16_000_000, help="reads of the full-quality side measurement")
     args = ap.parse_args()
@@ -420,38 +428,48 @@ def main():
             extra["full_quals"] = {"error": repr(e)}
         out["extra"] = extra
 
+    verify_failed = False
     if rank == 0:
-        if not args.no_cpu_baseline and args.cpu_reads > 0:
-            out["cpu_baseline"] = cpu_baseline(cfg, hdr, args.cpu_reads)
+        if world == 1 and not args.no_cpu_baseline and args.cpu_reads > 0:
+            # the CPU leg: timed as the baseline, and its outputs are what the device path is checked against on the same reads
+            # (outside every timed region): the bench line carries its own parity proof at the scale the oracle finishes in seconds
+            if world == 1 and eng is not None:
+                eng.close()
+                eng = None
+            out["cpu_baseline"], ref_out = cpu_baseline(cfg, hdr, args.cpu_reads, refs_sites)
+            if not args.no_verify:
+                out["verify"] = verify_against_oracle(hdr, refs_sites, ref_out, dev_id)
+                verify_failed = not out["verify"]["ok"]
+            del ref_out
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
         rk.close()
     elif eng is not None:
         eng.close()
+    if verify_failed:
+        print("bench.py: device outputs differ from the CPU oracle on the verification sample (see \"verify\" in the line above)", file=sys.stderr)
+        sys.exit(3)
 
 
 def pcie_inclusive(cfg, hdr, n_reads, ms_per_step, n_main):
     """Staging straight from inflated BAM records in page-locked memory (elp_stage_bam: one DMA of the raw bytes, the columns are cut
     on the device) and the way back (elp_emit_sorted_bam: gather in sorted order + D2H), timed: what a host that inflates BGZF blocks
-    into pinned buffers gets.  The BAM bytes are made by the oracle's encoder (test infrastructure standing in for the BAM reader)."""
+    into pinned buffers gets.  The BAM bytes are written by the generator (tools/synth/bam_writer.c, standing in for the BAM reader)."""
     import ctypes
-    import oracle as orc
     from elprep_amd import _lib
     from elprep_amd.engine import Engine
     from tools import synth
     b = synth.generate(cfg, 0, n_reads // 2)
     L = _lib.hip()
-    arr = (ctypes.c_char_p * len(hdr.rg_ids))(*[s.encode() for s in hdr.rg_ids])
-    st = b.as_struct()
-    size = orc.lib().orc_bam_encode(ctypes.byref(st), arr, None, ctypes.c_uint64(0), None, None, ctypes.c_int(0), None)
+    size = synth.bam_records_size(b, hdr.rg_ids)
     ptr = L.elp_pinned_alloc(size)
     buf = np.frombuffer((ctypes.c_uint8 * size).from_address(ptr), dtype=np.uint8)
-    orc.bam_encode(b, hdr.rg_ids, out=buf)
+    _, rec_off = synth.bam_records(b, hdr.rg_ids, out=buf)
     e = Engine(hdr, 0)
     e.set_read_group_ids(hdr.rg_ids)
-    rec_off = orc.bam_offsets(b, hdr.rg_ids)
     e.stage_bam(buf, rec_off=rec_off)  # first call: device allocations (a long-running host reuses its context)
     e.sync()
     e.reset()
@@ -472,7 +490,36 @@ def pcie_inclusive(cfg, hdr, n_reads, ms_per_step, n_main):
     got = e.emit_sorted_bam(out)
     t_out = time.perf_counter() - t0
     n = b.n
+    e.close()
+    # the column route: elp_stage_columns from page-locked column buffers (what the cgo binding of INTEGRATION.md uses when the Go host
+    # keeps its restaging buffers in C memory), batches of 1 M records as the parse nodes would deliver them
+    e = Engine(hdr, 0)
+    cols, keep = {}, []
+    for name in Engine._STAGE_COLS:
+        a = np.ascontiguousarray(getattr(b, name))
+        pp = L.elp_pinned_alloc(max(a.nbytes, 8))
+        ctypes.memmove(pp, a.ctypes.data, a.nbytes)
+        keep.append(pp)
+        cols[name] = (pp, a.dtype.itemsize)
+    def stage_cols():
+        step_n = 1_000_000
+        for lo in range(0, n, step_n):
+            cnt = min(step_n, n - lo)
+            # the per-record columns advance by records, the offset columns too (elp_stage rebases them), the payload columns stay
+            ptrs = {k: (pp + lo * isz if k not in ("qname", "cigar", "seq4", "qual") else pp) for k, (pp, isz) in cols.items()}
+            e.stage_pointers(cnt, ptrs)
+    stage_cols()          # first pass: device allocations
+    e.sync()
+    e.reset()
+    t0 = time.perf_counter()
+    stage_cols()
+    e.sync()
+    t_cols = time.perf_counter() - t0
+    col_bytes = sum(np.ascontiguousarray(getattr(b, name)).nbytes for name in Engine._STAGE_COLS)
+    for pp in keep:
+        L.elp_pinned_free(pp)
     res = {"workload": f"{n} reads as {size} bytes of inflated BAM records in page-locked host memory",
+           "stage_columns_pinned_Mreads_per_s": round(n / t_cols / 1e6, 2), "stage_columns_pinned_GB_per_s": round(col_bytes / t_cols / 1e9, 2),
            "stage_bam_Mreads_per_s": round(n / t_in / 1e6, 2), "stage_bam_GB_per_s": round(size / t_in / 1e9, 2),
            "stage_bam_without_record_offsets_Mreads_per_s": round(n / t_chain / 1e6, 2),
            "emit_sorted_bam_Mreads_per_s": round(n / t_out / 1e6, 2), "emit_sorted_bam_GB_per_s": round(got.size / t_out / 1e9, 2),
@@ -501,11 +548,12 @@ def flatten_sites(raw: np.ndarray) -> np.ndarray:
     return np.stack([starts, ends], axis=1).astype(np.int32)
 
 
-def cpu_baseline(cfg, hdr, n_reads):
+def cpu_baseline(cfg, hdr, n_reads, refs_sites):
     """The CPU oracle (plain-C restatement of the reference's algorithms) on ALL host cores - parallel merge sort with the
     CoordinateLess comparator, sharded duplicate-marking maps, thread-private BQSR tables summed at the end, as the reference's
     pargo-based CPU path is organised - timed on a bounded sample of the same workload.  kind = "port": it is NOT the elPrep binary
-    (no Go toolchain and no elprep on the box: profiles/r2a_reference_toolchain_probe.txt)."""
+    (no Go toolchain and no elprep on the box: profiles/r2a_reference_toolchain_probe.txt).
+    -> (the record, the outputs of the run: what verify_against_oracle() compares the device path with)"""
     import oracle as orc
     from tools import synth
     from concurrent.futures import ThreadPoolExecutor
@@ -516,20 +564,58 @@ def cpu_baseline(cfg, hdr, n_reads):
         parts = list(pool.map(lambda lo: synth.generate(cfg, lo, min(lo + chunk, n_reads // 2)), range(0, n_reads // 2, chunk)))
     b = Batch.concat(parts) if len(parts) > 1 else parts[0]
     del parts
-    refs = [synth.reference(cfg, r) for r in range(hdr.n_ref)]
-    sites = [flatten_sites(synth.known_sites_raw(cfg, r)) for r in range(hdr.n_ref)]
+    refs = [ref for _, ref, _ in refs_sites]
+    sites = [st for _, _, st in refs_sites]
     t0 = time.perf_counter()
-    flags, _ = orc.dup_metrics_mt(b, hdr, None, 100, cores)          # MarkDuplicates while the records stream in
-    perm = orc.sort_coordinate_mt(b, flags, cores)                    # the sort: Finalize of that pipeline
-    flags, ctr = orc.dup_metrics_mt(b, hdr, perm, 100, cores)         # MarkOpticalDuplicates over the sorted reads (marking repeated: part of the port's cost)
+    flags0 = orc.mark_duplicates_mt(b, hdr, cores)                    # MarkDuplicates while the records stream in (phase 1)
+    t_mark = time.perf_counter() - t0
+    perm = orc.sort_coordinate_mt(b, flags0, cores)                   # the sort: Finalize of that pipeline
+    flags, ctr = orc.dup_metrics_mt(b, hdr, perm, 100, cores)         # MarkOpticalDuplicates over the sorted reads; this entry point marks again
     qt, ct, xt = orc.bqsr_gather_mt(b, hdr, orc.BqsrRef(refs, sites), flags, MAX_CYCLE, cores)
     fin = orc.BqsrFinal(qt, ct, xt, MAX_CYCLE)
-    orc.bqsr_apply_mt(fin, b, hdr, 0, (), cores)
-    dt = time.perf_counter() - t0
-    return {"value": round(b.n / dt / 1e6, 4), "unit": "Mreads/s", "cores": cores, "kind": "port",
-            "sample": f"{b.n} reads of the same synthetic workload, full path (mark duplicates + sort + optical metrics + BQSR gather + finalize + apply), "
-                      f"multithreaded C restatement of the reference algorithms (oracle/, OpenMP, {cores} threads = the CPUs the container is granted: "
-                      f"{os.cpu_count()} logical CPUs visible, cgroup quota {cores}), {dt:.1f} s wall = {dt * cores:.0f} core-seconds"}
+    qual = orc.bqsr_apply_mt(fin, b, hdr, 0, (), cores)
+    dt_all = time.perf_counter() - t0
+    dt = dt_all - t_mark  # the marking inside the metrics call repeats the first one (the reference keeps its maps): counted once
+    rec = {"value": round(b.n / dt / 1e6, 4), "unit": "Mreads/s", "cores": cores, "kind": "port",
+           "sample": f"{b.n} reads of the same synthetic workload, full path (mark duplicates + sort + optical metrics + BQSR gather + finalize + apply), "
+                     f"multithreaded C restatement of the reference algorithms (oracle/, OpenMP, {cores} threads = the CPUs the container is granted: "
+                     f"{os.cpu_count()} logical CPUs visible, cgroup quota {cores}), {dt:.1f} s wall = {dt * cores:.0f} core-seconds; the port's metrics "
+                     f"entry point repeats the duplicate marking ({t_mark:.1f} s), that repeat is left out of the {dt:.1f} s"}
+    return rec, {"batch": b, "flags": flags, "perm": perm, "counters": ctr, "tables": (qt, ct, xt), "qual": qual}
+
+
+def verify_against_oracle(hdr, refs_sites, ref, dev_id=0):
+    """The device path on the reads of the CPU leg, every output against the CPU leg's: duplicate flags, the coordinate-sort
+    permutation, the duplication counters, the three BQSR tables, every recalibrated QUAL byte.  Same order of events as step_full.
+    Not timed; a mismatch fails the run (exit code 3)."""
+    from elprep_amd.engine import BqsrTables, Engine
+    b = ref["batch"]
+    e = Engine(hdr, dev_id)
+    try:
+        e.stage(b)
+        for r, refseq, sites in refs_sites:
+            e.set_reference(r, refseq)
+            e.set_known_sites(r, sites)
+        flags = e.mark_duplicates(True)
+        perm = e.sort_coordinate()
+        e.recalibrate_device(MAX_CYCLE)
+        qt, ct, xt = e.tables_fetch()
+        ctr = e.dup_metrics(100)
+        lut, present = BqsrTables(qt, ct, xt, MAX_CYCLE).finalize().build_lut(0)
+        qual = e.apply_bqsr(lut, present, MAX_CYCLE)
+    finally:
+        e.close()
+    oq, oc, ox = ref["tables"]
+    res = {"reads": int(b.n), "bases": int(b.qual.size),
+           "flags": bool(np.array_equal(flags, ref["flags"])), "perm": bool(np.array_equal(perm, ref["perm"])),
+           "counters": bool(np.array_equal(ctr, ref["counters"])),
+           "tables": bool(np.array_equal(qt, oq) and np.array_equal(ct, oc) and np.array_equal(xt, ox)),
+           "qual": bool(np.array_equal(qual, ref["qual"])),
+           "duplicates": int(((flags & 0x400) != 0).sum()), "table_observations": int(qt[..., 0].sum()),
+           "qual_bytes_changed": int((qual != b.qual).sum()),
+           "against": "oracle/ (multithreaded C restatement of the reference; parity unpinned, DESIGN.md section 6), same reads, outside the timed region"}
+    res["ok"] = all(res[k] for k in ("flags", "perm", "counters", "tables", "qual"))
+    return res
 
 
 if __name__ == "__main__":

@@ -40,7 +40,8 @@ __device__ inline uint32_t tag_value_size(uint8_t t, const uint8_t *p, const uin
       const uint32_t cnt = ld_u32(p + 1);
       const uint32_t es = (st == 'c' || st == 'C') ? 1 : ((st == 's' || st == 'S') ? 2 : ((st == 'i' || st == 'I' || st == 'f') ? 4 : 0));
       if (!es) return 0;
-      return 5 + cnt * es;
+      const uint64_t sz = 5ull + (uint64_t)cnt * es;  // 64-bit: a malformed count must not wrap into a small size
+      return sz > (uint64_t)(end - p) ? 0u : (uint32_t)sz;
     }
     default: return 0;
   }
@@ -343,6 +344,19 @@ int elp_set_read_group_ids(elp_ctx *c, const char *const *ids) {
   return 0;
 }
 
+// cgo-friendly form: the ids behind each other, id_off[g] .. id_off[g + 1] = the bytes of read group g (n_rg + 1 offsets)
+int elp_set_read_group_ids_flat(elp_ctx *c, const uint8_t *ids, const uint32_t *id_off) {
+  if (!c || !c->have_header || (c->n_rg && (!ids || !id_off))) return set_error(c, ELP_ERR_ARG, "elp_set_read_group_ids_flat: call elp_set_header first");
+  std::vector<std::string> str((size_t)c->n_rg);
+  std::vector<const char *> ptr((size_t)c->n_rg + 1, nullptr);
+  for (int g = 0; g < c->n_rg; g++) {
+    if (id_off[g + 1] < id_off[g]) return set_error(c, ELP_ERR_ARG, "elp_set_read_group_ids_flat: id_off must not decrease");
+    str[g].assign(reinterpret_cast<const char *>(ids) + id_off[g], id_off[g + 1] - id_off[g]);
+    ptr[g] = str[g].c_str();
+  }
+  return elp_set_read_group_ids(c, ptr.data());
+}
+
 void *elp_pinned_alloc(size_t bytes) {
   void *p = nullptr;
   if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
@@ -362,6 +376,12 @@ int elp_stage_bam(elp_ctx *c, const uint8_t *bytes, uint64_t n_bytes, const uint
   if (c->n_rg && !c->have_rg_ids) return set_error(c, ELP_ERR_ARG, "elp_stage_bam: call elp_set_read_group_ids first");
   if (c->n != c->raw_n) return set_error(c, ELP_ERR_ARG, "elp_stage_bam: the context already holds records staged with elp_stage");
   hipStream_t st = c->stream;
+  // pieces are committed one at a time: whatever was derived from the records staged so far is invalid from here on, also if a later
+  // piece fails
+  c->adapted = c->sorted = c->marked = false;
+  c->have_qual_present = false;
+  c->have_snapshot = false;
+  c->flat_index_n = 0;
   if (!c->copy_stream) ELP_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
   // is the caller's buffer page-locked (elp_pinned_alloc / hipHostRegister)?  then the DMA engine reads it directly
   hipPointerAttribute_t pa;
@@ -376,6 +396,7 @@ int elp_stage_bam(elp_ctx *c, const uint8_t *bytes, uint64_t n_bytes, const uint
     }
   }
   uint64_t at_byte = 0, at_rec = 0;
+  uint64_t max_raw_rec = c->max_raw_rec;
   std::vector<uint64_t> off;
   while (at_byte < n_bytes) {
     // record starts of this piece: given by the caller (a BAM reader knows where every record it hands over begins), else by a walk
@@ -403,6 +424,7 @@ int elp_stage_bam(elp_ctx *c, const uint8_t *bytes, uint64_t n_bytes, const uint
     const uint64_t piece_bytes = p - at_byte;
     const uint32_t n_rec = (uint32_t)off.size();
     off.push_back(piece_bytes);
+    for (uint32_t k = 0; k < n_rec; k++) max_raw_rec = std::max<uint64_t>(max_raw_rec, off[k + 1] - off[k]);
     if (c->n + n_rec > 0xFFFFFFF0ull) return set_error(c, ELP_ERR_UNSUPPORTED, "more than 2^32-16 records per context");
     // raw bytes + record offsets into HBM (kept: elp_emit_sorted_bam reads bases and tags from them)
     ELP_TRY(ensure(c, c->raw, c->raw_bytes + piece_bytes + 64, true, c->raw_bytes));
@@ -464,6 +486,7 @@ int elp_stage_bam(elp_ctx *c, const uint8_t *bytes, uint64_t n_bytes, const uint
     c->max_l_seq = std::max(c->max_l_seq, hs[1]);
     c->max_pos = std::max(c->max_pos, hs[2]);
     c->max_split = std::max<uint32_t>(c->max_split, split_id);
+    c->max_raw_rec = max_raw_rec;
     at_byte = p;
   }
   ELP_HIP(c, hipStreamSynchronize(st));
@@ -482,7 +505,9 @@ int elp_emit_sorted_bam(elp_ctx *c, uint8_t *out, uint64_t cap, uint64_t *n_byte
   const uint64_t n_out = c->n - c->n_sr;
   BamOut m{n_out, c->perm.p, c->raw.p, c->raw_off.p, c->refid.p, c->pos.p, c->next_refid.p, c->pnext.p, c->tlen.p, c->flag.p, c->mapq.p, c->l_seq.p,
            c->qname_off.p, c->cigar_off.p, c->qual_off.p, c->qname.p, c->qual.p, c->cigar.p};
-  constexpr uint32_t CHUNK = 1u << 21;  // records per device pass (u32 scans; ~700 MB of output at 345 B per record)
+  // records per device pass: sizes and offsets of a pass are scanned in 32 bits, so a pass must stay below 4 GiB of output.  An output
+  // record is never longer than the staged one (integer fields only shrink when re-encoded), so the largest staged record bounds it.
+  const uint32_t CHUNK = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(1u << 21, 0xFFFFFFFFull / std::max<uint64_t>(c->max_raw_rec, 64)));
   uint64_t total = 0;
   hipStream_t st = c->stream;
   for (uint64_t k0 = 0; k0 < n_out; k0 += CHUNK) {

@@ -143,6 +143,7 @@ struct elp_ctx {
   elp::DVec<uint8_t> raw;
   elp::DVec<uint64_t> raw_off;  // per staged record: offset of its block_size field in raw (n + 1)
   uint64_t raw_n = 0, raw_bytes = 0;
+  uint64_t max_raw_rec = 0;     // largest staged record in bytes (block_size field included): bounds the chunks of elp_emit_sorted_bam
   elp::DVec<uint8_t> rg_ids;    // header read-group ids, concatenated (RG:Z -> rgid)
   elp::DVec<uint32_t> rg_ids_off;
   bool have_rg_ids = false;

@@ -150,7 +150,8 @@ int elp_sync(elp_ctx *c) {
 void *elp_stream(elp_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
 int elp_set_header(elp_ctx *c, const elp_header *h) {
-  if (!c || !h || h->n_ref < 0 || h->n_rg < 0) return set_error(c, ELP_ERR_ARG, "elp_set_header: bad arguments");
+  if (!c || !h || h->n_ref < 0 || h->n_rg < 0 || (h->n_ref && !h->ref_len) || (h->n_rg && (!h->rg_lib || !h->rg_cov)))
+    return set_error(c, ELP_ERR_ARG, "elp_set_header: bad arguments");
   ELP_HIP(c, hipSetDevice(c->device));
   c->n_ref = h->n_ref; c->n_rg = h->n_rg; c->n_lib = h->n_lib; c->n_cov = h->n_cov;
   c->h_ref_len.assign(h->ref_len, h->ref_len + h->n_ref);
@@ -221,6 +222,7 @@ int elp_reset(elp_ctx *c) {
   c->n_sr = 0;
   c->n_filtered = 0;
   c->raw_n = c->raw_bytes = 0;
+  c->max_raw_rec = 0;
   c->max_split = 0;
   c->max_qname_len = c->max_l_seq = 0;
   c->max_pos = 0;
@@ -246,26 +248,20 @@ int elp_stage(elp_ctx *c, const elp_batch *b) {
   uint64_t q0 = b->qname_off[0], c0 = b->cigar_off[0], s0 = b->seq_off[0], l0 = b->qual_off[0];
   uint64_t qb = b->qname_off[n] - q0, co = b->cigar_off[n] - c0, sb = b->seq_off[n] - s0, lb = b->qual_off[n] - l0;
   ELP_TRY(stage_reserve(c, c->n + n, c->qname_bytes + qb, c->cigar_ops + co, c->seq_bytes + sb, c->qual_bytes + lb));
-  // host-side scan for limits the kernels rely on
-  uint64_t n_sr = 0;
-  uint32_t max_split = c->max_split;
-  uint32_t max_qname_len = c->max_qname_len, max_l_seq = c->max_l_seq, max_pos = c->max_pos;  // committed when the batch is
-  for (uint64_t i = 0; i < n; i++) {
-    uint64_t ql = b->qname_off[i + 1] - b->qname_off[i];
-    if (ql > elp_ctx::MAX_QNAME) return set_error(c, ELP_ERR_UNSUPPORTED, "record %llu: QNAME of %llu bytes (limit %u)", (unsigned long long)i, (unsigned long long)ql, elp_ctx::MAX_QNAME);
-    if (b->has_sr && b->has_sr[i]) n_sr++;
-    if (b->split && b->split[i] > max_split) max_split = b->split[i];
-    if (ql > max_qname_len) max_qname_len = (uint32_t)ql;
-    if (b->l_seq[i] > max_l_seq) max_l_seq = b->l_seq[i];
-    if ((uint32_t)b->pos[i] > max_pos) max_pos = (uint32_t)b->pos[i];
-    if (b->qual_off[i + 1] - b->qual_off[i] > 0x3FFFFFull || b->l_seq[i] > 0x3FFFFFu)  // FL_MAX_READ (flat.hpp)
-      return set_error(c, ELP_ERR_UNSUPPORTED, "record %llu: more than 4194303 bases", (unsigned long long)i);
-    if (b->rgid[i] != ELP_NIL16 && b->rgid[i] >= c->n_rg) return set_error(c, ELP_ERR_ARG, "record %llu: rgid %u not in header", (unsigned long long)i, b->rgid[i]);
-    if (b->refid[i] >= c->n_ref) return set_error(c, ELP_ERR_ARG, "record %llu: refid %d not in header", (unsigned long long)i, b->refid[i]);
-  }
+  // All copies are issued first, behind the staged records (nothing is committed yet); the host-side scan for the limits the kernels
+  // rely on runs while the DMA engine works (from page-locked columns - elp_pinned_alloc - the copies are asynchronous and the
+  // scan is hidden; from pageable memory the runtime stages every copy itself and the call is bound by that).
   hipStream_t st = c->stream;
   uint64_t at = c->n;
 #define H2D(dst, src, cnt, T) ELP_HIP(c, hipMemcpyAsync((dst), (src), (cnt) * sizeof(T), hipMemcpyHostToDevice, st))
+  if (lb) H2D(c->qual.p + c->qual_bytes, b->qual + l0, lb, uint8_t);
+  if (sb) {
+    H2D(c->seq4.p + c->seq_bytes, b->seq4 + s0, sb, uint8_t);
+    hipLaunchKernelGGL(k_recode_seq, dim3(blocks_for((sb + 15) / 16, 256)), dim3(256), 0, st, c->seq4.p + c->seq_bytes, sb);
+    ELP_HIP(c, hipGetLastError());
+  }
+  if (qb) H2D(c->qname.p + c->qname_bytes, b->qname + q0, qb, uint8_t);
+  if (co) H2D(c->cigar.p + c->cigar_ops, b->cigar + c0, co, uint32_t);
   H2D(c->refid.p + at, b->refid, n, int32_t);
   H2D(c->pos.p + at, b->pos, n, int32_t);
   H2D(c->next_refid.p + at, b->next_refid, n, int32_t);
@@ -279,26 +275,38 @@ int elp_stage(elp_ctx *c, const elp_batch *b) {
   H2D(c->l_seq.p + at, b->l_seq, n, uint32_t);
   if (b->has_sr) H2D(c->has_sr.p + at, b->has_sr, n, uint8_t);
   else ELP_HIP(c, hipMemsetAsync(c->has_sr.p + at, 0, n, st));
-  if (qb) H2D(c->qname.p + c->qname_bytes, b->qname + q0, qb, uint8_t);
-  if (co) H2D(c->cigar.p + c->cigar_ops, b->cigar + c0, co, uint32_t);
-  if (sb) {
-    H2D(c->seq4.p + c->seq_bytes, b->seq4 + s0, sb, uint8_t);
-    hipLaunchKernelGGL(k_recode_seq, dim3(blocks_for((sb + 15) / 16, 256)), dim3(256), 0, st, c->seq4.p + c->seq_bytes, sb);
-    ELP_HIP(c, hipGetLastError());
-  }
-  if (lb) H2D(c->qual.p + c->qual_bytes, b->qual + l0, lb, uint8_t);
-  // offsets: copy raw, rebase on device
-  ELP_TRY(ensure(c, c->stage_tmp, n + 1));
+  // offsets: copy raw (four slices of the scratch column, so that no copy waits for a kernel), rebase on device
+  ELP_TRY(ensure(c, c->stage_tmp, 4 * (n + 1)));
   unsigned blk = 256, grd = blocks_for(n + 1, blk);
   struct { const uint64_t *src; uint64_t *dst; uint64_t base; } offs[4] = {
       {b->qname_off, c->qname_off.p + at, c->qname_bytes}, {b->cigar_off, c->cigar_off.p + at, c->cigar_ops},
       {b->seq_off, c->seq_off.p + at, c->seq_bytes}, {b->qual_off, c->qual_off.p + at, c->qual_bytes}};
-  for (auto &o : offs) {
-    H2D(c->stage_tmp.p, o.src, n + 1, uint64_t);
-    hipLaunchKernelGGL(k_rebase_offsets, dim3(grd), dim3(blk), 0, st, (const uint64_t *)c->stage_tmp.p, o.dst, n + 1, o.base, o.src[0]);
+  for (int k = 0; k < 4; k++) H2D(c->stage_tmp.p + (size_t)k * (n + 1), offs[k].src, n + 1, uint64_t);
+  for (int k = 0; k < 4; k++) {
+    hipLaunchKernelGGL(k_rebase_offsets, dim3(grd), dim3(blk), 0, st, (const uint64_t *)(c->stage_tmp.p + (size_t)k * (n + 1)), offs[k].dst, n + 1, offs[k].base,
+                       offs[k].src[0]);
     ELP_HIP(c, hipGetLastError());
   }
 #undef H2D
+  // host-side scan for limits the kernels rely on (an error leaves the context as it was: nothing has been committed)
+  uint64_t n_sr = 0;
+  uint32_t max_split = c->max_split;
+  uint32_t max_qname_len = c->max_qname_len, max_l_seq = c->max_l_seq, max_pos = c->max_pos;  // committed when the batch is
+  int scan_rc = 0;
+  for (uint64_t i = 0; i < n && !scan_rc; i++) {
+    uint64_t ql = b->qname_off[i + 1] - b->qname_off[i];
+    if (ql > elp_ctx::MAX_QNAME) scan_rc = set_error(c, ELP_ERR_UNSUPPORTED, "record %llu: QNAME of %llu bytes (limit %u)", (unsigned long long)i, (unsigned long long)ql, elp_ctx::MAX_QNAME);
+    if (b->has_sr && b->has_sr[i]) n_sr++;
+    if (b->split && b->split[i] > max_split) max_split = b->split[i];
+    if (ql > max_qname_len) max_qname_len = (uint32_t)ql;
+    if (b->l_seq[i] > max_l_seq) max_l_seq = b->l_seq[i];
+    if ((uint32_t)b->pos[i] > max_pos) max_pos = (uint32_t)b->pos[i];
+    if (b->qual_off[i + 1] - b->qual_off[i] > 0x3FFFFFull || b->l_seq[i] > 0x3FFFFFu)  // FL_MAX_READ (flat.hpp)
+      scan_rc = set_error(c, ELP_ERR_UNSUPPORTED, "record %llu: more than 4194303 bases", (unsigned long long)i);
+    if (b->rgid[i] != ELP_NIL16 && b->rgid[i] >= c->n_rg) scan_rc = set_error(c, ELP_ERR_ARG, "record %llu: rgid %u not in header", (unsigned long long)i, b->rgid[i]);
+    if (b->refid[i] >= c->n_ref) scan_rc = set_error(c, ELP_ERR_ARG, "record %llu: refid %d not in header", (unsigned long long)i, b->refid[i]);
+  }
+  if (scan_rc) { (void)hipStreamSynchronize(st); return scan_rc; }
   ELP_HIP(c, hipStreamSynchronize(st));  // host buffers may be reused on return
   c->n += n; c->qname_bytes += qb; c->cigar_ops += co; c->seq_bytes += sb; c->qual_bytes += lb;
   c->n_sr += n_sr;
@@ -309,6 +317,30 @@ int elp_stage(elp_ctx *c, const elp_batch *b) {
   c->have_snapshot = false;
   c->flat_index_n = 0;
   return 0;
+}
+
+// The same with every column as an argument of its own.  cgo may pass a Go pointer to C only if the memory it points to holds no
+// Go pointers (cmd/cgo "Passing pointers"); an elp_batch / elp_header in Go memory whose fields point at Go slices breaks that rule,
+// a call that takes each slice's first element does not.  (With columns in C memory - elp_pinned_alloc - the struct forms are fine.)
+int elp_stage_columns(elp_ctx *c, uint64_t n, const int32_t *refid, const int32_t *pos, const int32_t *next_refid, const int32_t *pnext, const int32_t *tlen,
+                      const uint16_t *flag, const uint8_t *mapq, const uint16_t *rgid, const uint8_t *has_sr, const uint32_t *l_seq,
+                      const uint64_t *qname_off, const uint8_t *qname, const uint64_t *cigar_off, const uint32_t *cigar, const uint64_t *seq_off,
+                      const uint8_t *seq4, const uint64_t *qual_off, const uint8_t *qual, const uint16_t *split) {
+  if (!c) return ELP_ERR_ARG;
+  if (n && (!refid || !pos || !next_refid || !pnext || !tlen || !flag || !mapq || !rgid || !l_seq || !qname_off || !cigar_off || !seq_off || !qual_off))
+    return set_error(c, ELP_ERR_ARG, "elp_stage_columns: a required column is NULL");
+  elp_batch b;
+  b.n = n; b.refid = refid; b.pos = pos; b.next_refid = next_refid; b.pnext = pnext; b.tlen = tlen; b.flag = flag; b.mapq = mapq; b.rgid = rgid;
+  b.has_sr = has_sr; b.l_seq = l_seq; b.qname_off = qname_off; b.qname = qname; b.cigar_off = cigar_off; b.cigar = cigar; b.seq_off = seq_off;
+  b.seq4 = seq4; b.qual_off = qual_off; b.qual = qual; b.split = split;
+  return elp_stage(c, &b);
+}
+
+int elp_set_header_columns(elp_ctx *c, int32_t n_ref, const int32_t *ref_len, int32_t n_rg, const uint16_t *rg_lib, const uint16_t *rg_cov, int32_t n_lib,
+                           int32_t n_cov) {
+  elp_header h;
+  h.n_ref = n_ref; h.ref_len = ref_len; h.n_rg = n_rg; h.rg_lib = rg_lib; h.rg_cov = rg_cov; h.n_lib = n_lib; h.n_cov = n_cov;
+  return elp_set_header(c, &h);
 }
 
 static int d2h(elp_ctx *c, void *dst, const void *src, size_t bytes) {

@@ -46,7 +46,7 @@ __device__ inline bool overlap(const int32_t *iv, int64_t n, int32_t start, int3
 
 __global__ __launch_bounds__(256) void k_filter_records(FilterCols m, elp_predicates p, unsigned long long *n_dropped) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  bool drop = false;
+  bool drop = false, tagged = false;
   if (i < m.n && m.state[i] != 2) {
     const uint16_t f = m.flag[i];
     const int32_t r = m.refid[i], ps = m.pos[i];
@@ -72,12 +72,14 @@ __global__ __launch_bounds__(256) void k_filter_records(FilterCols m, elp_predic
       }
     }
     if (drop) {
-      drop = m.state[i] == 0;  // a tagged copy that is rejected was already counted among the records that leave the output
+      tagged = m.state[i] == 1;  // a tagged copy that is rejected was already counted among the records that leave the output
+      drop = !tagged;
       m.state[i] = 2;
     }
   }
-  const unsigned long long b = __ballot(drop);
+  const unsigned long long b = __ballot(drop), t = __ballot(tagged);
   if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_dropped, (unsigned long long)__popcll(b));
+  if ((threadIdx.x & 63) == 0 && t) atomicAdd(n_dropped + 1, (unsigned long long)__popcll(t));  // rejected tagged copies
 }
 
 // ---- split: routing rule of SplitFilePerChromosome
@@ -136,7 +138,7 @@ int elp_filter_records(elp_ctx *c, const elp_predicates *p, uint64_t *n_dropped_
   ELP_HIP(c, hipSetDevice(c->device));
   if (p->use_regions && (!p->regions || !p->n_regions)) return set_error(c, ELP_ERR_ARG, "elp_filter_records: use_regions without regions");
   const uint64_t n = c->n;
-  unsigned long long dropped = 0;
+  unsigned long long dropped = 0, dropped_tagged = 0;
   if (n) {
     // target regions -> device (per refid pointer table)
     std::vector<int32_t *> h_ptr((size_t)c->n_ref, nullptr);
@@ -167,17 +169,40 @@ int elp_filter_records(elp_ctx *c, const elp_predicates *p, uint64_t *n_dropped_
     }
     unsigned long long *cnt;
     ELP_TRY(scratch(c, 6, 4, &cnt));
-    ELP_HIP(c, hipMemsetAsync(cnt, 0, 8, c->stream));
+    ELP_HIP(c, hipMemsetAsync(cnt, 0, 16, c->stream));
     FilterCols m{n, c->refid.p, c->pos.p, c->flag.p, c->mapq.p, c->cigar_off.p, c->cigar.p, c->has_sr.p, c->n_ref, d_ptr, d_cnt};
     ELP_LAUNCH(c, "filter_records", k_filter_records, dim3(blocks_for(n, 256)), dim3(256), 0, m, *p, cnt);
-    ELP_HIP(c, hipMemcpyAsync(&dropped, cnt, 8, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long both[2] = {0, 0};
+    ELP_HIP(c, hipMemcpyAsync(both, cnt, 16, hipMemcpyDeviceToHost, c->stream));
     ELP_HIP(c, hipStreamSynchronize(c->stream));
+    dropped = both[0];
+    dropped_tagged = both[1];
   }
   c->n_sr += dropped;  // they leave the output like the tagged copies do
-  c->n_filtered += dropped;
+  c->n_filtered += dropped + dropped_tagged;  // state-2 records of either origin: none of them is a duplicate-marking candidate
   c->adapted = c->sorted = c->marked = false;
   if (n_dropped_out) *n_dropped_out = dropped;
   return 0;
+}
+
+// cgo-friendly form (no pointers to pointers): the regions of all contigs behind each other, region_off[r] .. region_off[r + 1] = the
+// [k][2] rows of refid r (n_ref + 1 offsets, in intervals); regions NULL = no target-region test
+int elp_filter_records_flat(elp_ctx *c, int remove_unmapped, int remove_unmapped_strict, int min_mapq, int remove_non_exact, int remove_duplicates,
+                            const int32_t *regions, const int64_t *region_off, uint64_t *n_rejected_out) {
+  if (!c) return ELP_ERR_ARG;
+  if (regions && !region_off) return set_error(c, ELP_ERR_ARG, "elp_filter_records_flat: regions without region_off");
+  std::vector<const int32_t *> ptr((size_t)c->n_ref + 1, nullptr);
+  std::vector<int64_t> cnt((size_t)c->n_ref + 1, 0);
+  if (regions)
+    for (int r = 0; r < c->n_ref; r++) {
+      if (region_off[r + 1] < region_off[r]) return set_error(c, ELP_ERR_ARG, "elp_filter_records_flat: region_off must not decrease");
+      ptr[r] = regions + 2 * region_off[r];
+      cnt[r] = region_off[r + 1] - region_off[r];
+    }
+  elp_predicates p;
+  p.remove_unmapped = remove_unmapped; p.remove_unmapped_strict = remove_unmapped_strict; p.min_mapq = min_mapq; p.remove_non_exact = remove_non_exact;
+  p.remove_duplicates = remove_duplicates; p.use_regions = regions ? 1 : 0; p.regions = ptr.data(); p.n_regions = cnt.data();
+  return elp_filter_records(c, &p, n_rejected_out);
 }
 
 int elp_split_classify(elp_ctx *c, const int32_t *group_of_ref, int32_t n_groups, uint16_t *split_out, uint8_t *spread_out, uint64_t *counts_out) {

@@ -72,6 +72,11 @@ using namespace elp;
 
 extern "C" {
 
+int elp_group_probe(void) {
+  Rccl *R = rccl();
+  return R->err.empty() ? 0 : ELP_ERR_UNSUPPORTED;
+}
+
 int elp_group_unique_id(uint8_t *id_out) {
   if (!id_out) return ELP_ERR_ARG;
   Rccl *R = rccl();

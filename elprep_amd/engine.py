@@ -35,7 +35,9 @@ def _vp(a: Optional[np.ndarray]):
 class Engine:
     """One GPU context holding the staged column store."""
 
-    def __init__(self, header: Header, device: int = 0):
+    def __init__(self, header: Header, device: int = 0, flat_abi: bool = False):
+        """flat_abi: use the entry points that take every array as its own argument (what a cgo binding calls) instead of the
+        struct forms - same library code behind both"""
         self.L = _lib.hip()
         h = C.c_void_p()
         rc = self.L.elp_create(device, C.byref(h))
@@ -43,8 +45,15 @@ class Engine:
             raise ElpError(rc, "elp_create failed: no usable gfx950 device (there is no CPU fallback)")
         self.h = h
         self.header = header
-        hs = header.as_struct()
-        self._check(self.L.elp_set_header(self.h, C.byref(hs)))
+        self.flat_abi = flat_abi
+        if flat_abi:
+            rl = np.ascontiguousarray(header.ref_len, dtype=np.int32)
+            lib_ = np.ascontiguousarray(header.rg_lib, dtype=np.uint16)
+            cov = np.ascontiguousarray(header.rg_cov, dtype=np.uint16)
+            self._check(self.L.elp_set_header_columns(self.h, header.n_ref, _vp(rl), header.n_rg, _vp(lib_), _vp(cov), header.n_lib, header.n_cov))
+        else:
+            hs = header.as_struct()
+            self._check(self.L.elp_set_header(self.h, C.byref(hs)))
 
     def close(self):
         if getattr(self, "h", None) and self.h.value:
@@ -75,8 +84,21 @@ class Engine:
         self._check(self.L.elp_reserve(self.h, n, qname_bytes, cigar_ops, seq_bytes, qual_bytes))
 
     def stage(self, b: Batch):
+        if self.flat_abi:
+            return self.stage_columns(b)
         s = b.as_struct()
         self._check(self.L.elp_stage(self.h, C.byref(s)))
+
+    _STAGE_COLS = ("refid", "pos", "next_refid", "pnext", "tlen", "flag", "mapq", "rgid", "has_sr", "l_seq", "qname_off", "qname", "cigar_off", "cigar",
+                   "seq_off", "seq4", "qual_off", "qual", "split")
+
+    def stage_columns(self, b: Batch):
+        """elp_stage_columns: every column as an argument of its own (the form a cgo binding uses with Go slices)"""
+        self._check(self.L.elp_stage_columns(self.h, b.n, *[_vp(getattr(b, k)) for k in self._STAGE_COLS]))
+
+    def stage_pointers(self, n: int, ptrs: dict):
+        """elp_stage_columns on raw addresses (columns that live in page-locked memory: bench.py's PCIe-inclusive measurement)"""
+        self._check(self.L.elp_stage_columns(self.h, n, *[C.c_void_p(ptrs.get(k, 0)) for k in self._STAGE_COLS]))
 
     def reset(self):
         self._check(self.L.elp_reset(self.h))
@@ -92,6 +114,11 @@ class Engine:
 
     # ---- BAM in / BAM out (include/elprep_hip.h: sam/bam-files.go on the device)
     def set_read_group_ids(self, ids: Sequence[str]):
+        if self.flat_abi:
+            enc = [s.encode() for s in ids]
+            cat = np.frombuffer(b"".join(enc) + b"\0", dtype=np.uint8)
+            off = np.cumsum([0] + [len(e) for e in enc]).astype(np.uint32)
+            return self._check(self.L.elp_set_read_group_ids_flat(self.h, _vp(cat), _vp(off)))
         arr = (C.c_char_p * max(len(ids), 1))(*[s.encode() for s in ids])
         self._check(self.L.elp_set_read_group_ids(self.h, C.cast(arr, C.c_void_p)))
 
@@ -122,6 +149,19 @@ class Engine:
             _fields_ = [(k, C.c_int) for k in ("remove_unmapped", "remove_unmapped_strict", "min_mapq", "remove_non_exact", "remove_duplicates", "use_regions")] + \
                        [("regions", C.c_void_p), ("n_regions", C.c_void_p)]
         p = P(int(remove_unmapped), int(remove_unmapped_strict), int(min_mapq), int(remove_non_exact), int(remove_duplicates), 0, None, None)
+        if self.flat_abi:
+            n = C.c_uint64()
+            reg, off = C.c_void_p(0), C.c_void_p(0)
+            if regions is not None:
+                arrs = [np.asarray(r, dtype=np.int32).reshape(-1, 2) for r in regions]
+                cat = np.ascontiguousarray(np.concatenate(arrs, axis=0)) if arrs else np.zeros((0, 2), np.int32)
+                if cat.size == 0:
+                    cat = np.zeros((1, 2), np.int32)  # a non-NULL pointer switches the region test on
+                offs = np.cumsum([0] + [a.shape[0] for a in arrs]).astype(np.int64)
+                reg, off = C.c_void_p(cat.ctypes.data), C.c_void_p(offs.ctypes.data)
+            self._check(self.L.elp_filter_records_flat(self.h, int(remove_unmapped), int(remove_unmapped_strict), int(min_mapq), int(remove_non_exact),
+                                                       int(remove_duplicates), reg, off, C.byref(n)))
+            return int(n.value)
         keep = []
         if regions is not None:
             arrs = [np.ascontiguousarray(np.asarray(r, dtype=np.int32).reshape(-1, 2)) for r in regions]

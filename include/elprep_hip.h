@@ -101,6 +101,18 @@ int elp_set_header(elp_ctx *ctx, const elp_header *hdr);
 int elp_reserve(elp_ctx *ctx, uint64_t n_records, uint64_t qname_bytes, uint64_t cigar_ops, uint64_t seq_bytes, uint64_t qual_bytes);
 int elp_stage(elp_ctx *ctx, const elp_batch *batch); /* appends; host buffers may be reused when the call returns */
 int elp_reset(elp_ctx *ctx);                         /* drops all staged records and results */
+/* The same two calls with every array as an argument of its own - the forms a cgo binding uses with plain Go slices.  cgo's pointer
+ * rules ("Passing pointers", cmd/cgo) let Go code pass a Go pointer to C only if the memory it points to contains no Go pointers: an
+ * elp_header / elp_batch that lives in Go memory and points at Go slices breaks that rule (run-time panic "cgo argument has Go pointer
+ * to Go pointer"), a call that passes &slice[0] of every slice does not (filters/pedantic.go:28-41 is the reference's own precedent
+ * for a cgo call with scalar / single-pointer arguments).  A host that keeps its column buffers in C memory (elp_pinned_alloc: page-
+ * locked, read in place by the DMA engine - the fast route over PCIe) may use either form.  has_sr and split may be NULL. */
+int elp_set_header_columns(elp_ctx *ctx, int32_t n_ref, const int32_t *ref_len, int32_t n_rg, const uint16_t *rg_lib, const uint16_t *rg_cov,
+                           int32_t n_lib, int32_t n_cov);
+int elp_stage_columns(elp_ctx *ctx, uint64_t n, const int32_t *refid, const int32_t *pos, const int32_t *next_refid, const int32_t *pnext,
+                      const int32_t *tlen, const uint16_t *flag, const uint8_t *mapq, const uint16_t *rgid, const uint8_t *has_sr,
+                      const uint32_t *l_seq, const uint64_t *qname_off, const uint8_t *qname, const uint64_t *cigar_off, const uint32_t *cigar,
+                      const uint64_t *seq_off, const uint8_t *seq4, const uint64_t *qual_off, const uint8_t *qual, const uint16_t *split);
 uint64_t elp_num_records(const elp_ctx *ctx);
 uint64_t elp_num_qual_bytes(const elp_ctx *ctx);     /* size of the staged QUAL column (elp_get_qual) */
 
@@ -117,6 +129,8 @@ uint64_t elp_num_qual_bytes(const elp_ctx *ctx);     /* size of the staged QUAL 
  *   `out` (host memory, `cap` bytes; NULL = just compute *n_bytes_out): FLAG and QUAL as the path left them, bin() recomputed
  *   (:443-468), optional fields re-encoded as formatBamTag does (:481-632).  BGZF deflate stays with the host. */
 int elp_set_read_group_ids(elp_ctx *ctx, const char *const *ids);
+/* cgo form (no array of pointers): the ids behind each other, id_off[g] .. id_off[g + 1] = the bytes of read group g (n_rg + 1 offsets) */
+int elp_set_read_group_ids_flat(elp_ctx *ctx, const uint8_t *ids, const uint32_t *id_off);
 void *elp_pinned_alloc(size_t bytes);
 void elp_pinned_free(void *p);
 int elp_stage_bam(elp_ctx *ctx, const uint8_t *bytes, uint64_t n_bytes, const uint64_t *rec_off /* n_records + 1, may be NULL */,
@@ -140,6 +154,10 @@ typedef struct elp_predicates {
   const int64_t *n_regions;
 } elp_predicates;
 int elp_filter_records(elp_ctx *ctx, const elp_predicates *p, uint64_t *n_rejected_out /* may be NULL */);
+/* cgo form (no pointers to pointers): the target regions of all contigs behind each other, region_off[r] .. region_off[r + 1] = the
+ * {Start, End} rows of refid r (n_ref + 1 offsets, counted in intervals); regions NULL = no target-region test */
+int elp_filter_records_flat(elp_ctx *ctx, int remove_unmapped, int remove_unmapped_strict, int min_mapq, int remove_non_exact, int remove_duplicates,
+                            const int32_t *regions, const int64_t *region_off, uint64_t *n_rejected_out /* may be NULL */);
 
 /* ---- `elprep split` / `merge` without touching payloads on the CPU: sam/split-merge.go ----
  * elp_split_classify: SplitFilePerChromosome's routing rule (:280-293) for every staged record: split_out[i] = 0 for RNAME "*",
@@ -224,6 +242,7 @@ int elp_bqsr_tables_fetch(elp_ctx *ctx, int64_t *qual_tbl, int64_t *cycle_tbl, i
  *                              through the same call and come back summed
  *   elp_allreduce_i64          the same collective for a plain host buffer */
 #define ELP_GROUP_ID_BYTES 128
+int elp_group_probe(void); /* 0 if the communication library (RCCL) can be loaded and has every entry point the group needs; no GPU needed */
 int elp_group_unique_id(uint8_t *id_out /* ELP_GROUP_ID_BYTES */);
 int elp_group_init(elp_ctx *ctx, int rank, int world, const uint8_t *id /* ELP_GROUP_ID_BYTES; may be NULL if world == 1 */);
 int elp_group_rank(const elp_ctx *ctx);

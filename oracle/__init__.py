@@ -369,6 +369,14 @@ def dup_metrics_mt(b: Batch, h: Header, perm: Optional[np.ndarray], pixel_dist: 
     return flags, ctr
 
 
+def mark_duplicates_mt(b: Batch, h: Header, n_threads: int = 0) -> np.ndarray:
+    """MarkDuplicates alone (the phase-1 filter, no metrics pass) on all cores: the flags of mark_duplicates()"""
+    flags = np.empty(b.n, dtype=np.uint16)
+    s, hs = b.as_struct(), h.as_struct()
+    _check(lib().orc_dup_metrics_mt(C.byref(s), C.byref(hs), C.c_void_p(0), C.c_int(0), _p(flags), C.c_void_p(0), C.c_int(n_threads)), "mark_duplicates_mt")
+    return flags
+
+
 def bqsr_gather_mt(b: Batch, h: Header, ref: BqsrRef, flags: Optional[np.ndarray] = None, max_cycle: int = 500, n_threads: int = 0):
     ncyc = 2 * max_cycle + 1
     qt = np.zeros((h.n_cov, NQUAL, 2), dtype=np.int64)

@@ -632,6 +632,13 @@ int orc_dup_metrics_mt(const orc_batch *b, const orc_header *h, const uint32_t *
     for (uint64_t k = lp.start[sh]; k < lp.start[sh + 1]; k++) classify_pair_of(s, lp.idx[k], (uint64_t)pair_of[lp.idx[k]]);
   }
   if (rc_all) return rc_all;
+  if (!counters) { /* MarkDuplicates only (the phase-1 filter): no metrics pass */
+    for (int sh = 0; sh < n_shards; sh++) { fmap_free(&ps[sh].pairs); free(ps[sh].prec); free(ps[sh].cons); }
+    free(ps); free(sh_f); free(sh_q); free(sh_p); free(pair_of);
+    free_shards(&lf); free_shards(&lq); free_shards(&lp);
+    free(g.lib_of); free(g.upos); free(g.score);
+    return 0;
+  }
   /* MarkOpticalDuplicates :469-502: counters over the sorted reads (thread-private, summed: RangeReduce) */
   memset(counters, 0, (size_t)nl * ORC_NCTR * sizeof(int64_t));
 #pragma omp parallel num_threads(n_threads)

@@ -67,9 +67,10 @@ int main(int argc, char **argv) {
 
   elp_ctx *c = nullptr;
   if (elp_create(0, &c) != 0) { fprintf(stderr, "elp_create failed: no gfx950 device\n"); return 4; }
-  CHECK(c, elp_set_header(c, &h));
+  // the flat entry points (every array an argument of its own): what the cgo binding of INTEGRATION.md section 2 calls
+  CHECK(c, elp_set_header_columns(c, h.n_ref, h.ref_len, h.n_rg, h.rg_lib, h.rg_cov, h.n_lib, h.n_cov));
   // record batching: the batches arrive from several threads, as the reference's LimitedPar parse nodes deliver them
-  // (sam/filter-pipeline.go:290-292); elp_stage serialises internally, the staging order is the order of the calls, so the
+  // (sam/filter-pipeline.go:290-292); elp_stage / elp_stage_columns serialise internally, the staging order is the order of the calls, so the
   // threads take turns in batch order here (the reference's Slice node is ordered as well, :108-124)
   {
     const uint64_t per = (n + (uint64_t)n_threads - 1) / (uint64_t)(n_threads ? n_threads : 1);
@@ -82,7 +83,8 @@ int main(int argc, char **argv) {
         s.n = hi - lo;
         s.refid += lo; s.pos += lo; s.next_refid += lo; s.pnext += lo; s.tlen += lo; s.flag += lo; s.mapq += lo; s.rgid += lo; s.has_sr += lo; s.l_seq += lo;
         s.qname_off += lo; s.cigar_off += lo; s.seq_off += lo; s.qual_off += lo;  // offsets are rebased by elp_stage
-        const int rc = elp_stage(c, &s);
+        const int rc = elp_stage_columns(c, s.n, s.refid, s.pos, s.next_refid, s.pnext, s.tlen, s.flag, s.mapq, s.rgid, s.has_sr, s.l_seq, s.qname_off, s.qname,
+                                         s.cigar_off, s.cigar, s.seq_off, s.seq4, s.qual_off, s.qual, nullptr);
         if (rc) rc_all = rc;
       });
       th.join();

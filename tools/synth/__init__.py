@@ -41,8 +41,8 @@ class _Out(C.Structure):
 
 def build(force: bool = False) -> str:
     path = os.path.join(_HERE, "libelprep_synth.so")
-    src = os.path.join(_HERE, "synth.c")
-    if force or not os.path.exists(path) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(path)):
+    srcs = [os.path.join(_HERE, f) for f in ("synth.c", "bam_writer.c")]
+    if force or not os.path.exists(path) or any(os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(path) for src in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return path
 
@@ -52,6 +52,7 @@ def lib() -> C.CDLL:
     if _LIB is None:
         _LIB = C.CDLL(build())
         _LIB.synth_known_sites.restype = C.c_int64
+        _LIB.synth_bam_write.restype = C.c_uint64
     return _LIB
 
 
@@ -139,3 +140,23 @@ def known_sites_raw(cfg: SynthConfig, refid: int) -> np.ndarray:
     e = np.empty(max(n, 1), dtype=np.int32)
     lib().synth_known_sites(C.byref(c), C.c_int(refid), C.c_void_p(s.ctypes.data), C.c_void_p(e.ctypes.data), C.c_int64(n))
     return np.stack([s[:n], e[:n]], axis=1)
+
+
+def bam_records(b: Batch, rg_ids, out: Optional[np.ndarray] = None):
+    """The batch as uncompressed BAM alignment records (what a BAM reader hands over after inflating BGZF blocks) + the byte offsets
+    of the records (n + 1).  out: uint8 array to write into (e.g. over page-locked memory); size query: bam_records_size()."""
+    arr = (C.c_char_p * max(len(rg_ids), 1))(*[s.encode() for s in rg_ids])
+    st = b.as_struct()
+    off = np.empty(b.n + 1, dtype=np.uint64)
+    n = int(lib().synth_bam_write(C.byref(st), arr, C.c_void_p(0), C.c_void_p(off.ctypes.data)))
+    if out is None:
+        out = np.empty(n, dtype=np.uint8)
+    assert out.size >= n
+    lib().synth_bam_write(C.byref(st), arr, C.c_void_p(out.ctypes.data), C.c_void_p(0))
+    return out[:n], off
+
+
+def bam_records_size(b: Batch, rg_ids) -> int:
+    arr = (C.c_char_p * max(len(rg_ids), 1))(*[s.encode() for s in rg_ids])
+    st = b.as_struct()
+    return int(lib().synth_bam_write(C.byref(st), arr, C.c_void_p(0), C.c_void_p(0)))
