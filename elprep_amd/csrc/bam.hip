@@ -382,6 +382,7 @@ int elp_stage_bam(elp_ctx *c, const uint8_t *bytes, uint64_t n_bytes, const uint
   c->have_qual_present = false;
   c->have_snapshot = false;
   c->flat_index_n = 0;
+  c->uniform_n = ~0ull;
   if (!c->copy_stream) ELP_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
   // is the caller's buffer page-locked (elp_pinned_alloc / hipHostRegister)?  then the DMA engine reads it directly
   hipPointerAttribute_t pa;
@@ -494,6 +495,7 @@ int elp_stage_bam(elp_ctx *c, const uint8_t *bytes, uint64_t n_bytes, const uint
   c->have_qual_present = false;
   c->have_snapshot = false;
   c->flat_index_n = 0;
+  c->uniform_n = ~0ull;
   return 0;
 }
 

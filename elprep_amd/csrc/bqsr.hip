@@ -17,12 +17,9 @@
 // independent byte gathers from the L2-resident LUT per lane and chunk).
 #include <utility>
 
-#include "bqsr_dev.hpp"
-#include "flat.hpp"
+#include "bqsr_common.hpp"
 
 namespace elp {
-
-constexpr int MAX_DESC_READ = 65535;  // u16 fields of the record descriptor
 
 struct BqCols {
   uint64_t n;
@@ -69,29 +66,6 @@ __device__ inline bool recalibrate_aln(const BqCols &m, uint64_t i) {
   }
   return refl >= 0 && (int32_t)ls == rl;
 }
-
-// per-record descriptor produced by the prologue (32 bytes, staged into LDS by k_bqsr_count)
-//
-// The clipped working copy of an eligible record is the base window [a, a+len) of the original read, and the mapping of its
-// bases to the reference (computeSnpEvents, bqsr.go:254-285) is piecewise: clipped base c in piece k = [B_k, B_k+1) (B_0 = 0,
-// B_1 = b1, B_2 = b2, B_3 = infinity) lies at 0-based reference index D_k + c, or has no reference base (insertion) if
-// D_k == BQ_NOREF.  A clipped CIGAR of the form M, M I M, M D M, I M ... needs at most three pieces; records that need more
-// are flagged BQ_COMPLEX and walk their CIGAR in the kernel (D0 = CIGAR index, b1 = op count, D2 = POS - 1).
-constexpr int32_t BQ_NOREF = INT32_MIN;
-enum : uint8_t { BQ_ELIGIBLE = 1, BQ_REVERSED = 2, BQ_LAST = 4, BQ_CIG_SCRATCH = 8, BQ_COMPLEX = 16 };
-struct __attribute__((aligned(16))) BqDesc {
-  int32_t D0, D1, D2;
-  int32_t refid;
-  uint16_t b1, b2;
-  uint16_t a;      // first surviving base (original read coordinates)
-  uint16_t len;    // surviving bases; 0 = record contributes nothing
-  uint16_t left;   // low-quality-tail bounds inside the surviving window (left > right: everything masked)
-  uint16_t right;  // 0xFFFF = -1
-  uint8_t cov;     // read-group covariate id
-  uint8_t fl;
-  uint16_t pad;
-};
-static_assert(sizeof(BqDesc) == 32, "BqDesc is staged as two 16-byte words");
 
 // pieces of the clipped CIGAR; false if it needs more than three
 __device__ inline bool build_pieces(const uint32_t *cig, int ncig, int32_t pos, BqDesc &d) {
@@ -151,10 +125,9 @@ __device__ __forceinline__ void set_skip_bits(uint32_t *skipbits, uint64_t bit0,
 // itself, getReadCoordinateForReferenceCoordinate(ref) is ref - POS inside the read and fails outside (utils.go:267-349 with one
 // match operation), and there is one reference piece.  Everything else is appended to `queue` for the general kernel, so that
 // kernel's long divergent code runs with all lanes busy.  All column loads are issued before the first test (one latency, not 15).
-constexpr int REF_LDS = 256;      // contigs whose per-contig facts (pointers, lengths) are kept in LDS by the BQSR kernels
 constexpr int PF_TILES = 16;
 __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__restrict__ desc, uint32_t *skipbits, uint32_t *__restrict__ queue,
-                                                            uint32_t *queue_n, uint32_t *err) {
+                                                            uint32_t *queue_n, uint32_t *err, BqRec *__restrict__ recs) {
   // a workgroup handles PF_TILES * 256 consecutive records and collects the deferred ones in LDS: one global atomic per
   // workgroup (a global atomic per wave on the single queue counter serialises at ~12 ns each: 9 ms for 50 M reads)
   __shared__ uint32_t lq[PF_TILES * 256];
@@ -166,9 +139,14 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
   __shared__ const int32_t *s_sites[REF_LDS];
   __shared__ int64_t s_nsites[REF_LDS];
   __shared__ const uint32_t *s_sidx[REF_LDS];
+  __shared__ const uint8_t *s_refseq[REF_LDS];  // recs != nullptr (records for count3.hip): the packed contigs and their lengths
+  __shared__ int64_t s_refseq_len[REF_LDS];
   const bool ref_lds = m.n_ref <= REF_LDS;
   if (ref_lds)
-    for (int r = threadIdx.x; r < m.n_ref; r += 256) { s_ref_len[r] = m.ref_len[r]; s_sites[r] = m.sites[r]; s_nsites[r] = m.n_sites[r]; s_sidx[r] = m.site_idx[r]; }
+    for (int r = threadIdx.x; r < m.n_ref; r += 256) {
+      s_ref_len[r] = m.ref_len[r]; s_sites[r] = m.sites[r]; s_nsites[r] = m.n_sites[r]; s_sidx[r] = m.site_idx[r];
+      if (recs) { s_refseq[r] = m.ref_seq[r]; s_refseq_len[r] = m.ref_seq_len[r]; }
+    }
   if (threadIdx.x == 0) lcount = 0;
   __syncthreads();
 #pragma unroll 1
@@ -310,7 +288,25 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
         }
       }
     }
-    if (!defer) desc[i] = d;
+    if (!defer) {
+      if (recs) {  // the record count3.hip works from; BqDesc only for the reads the record cannot describe
+        BqRec rc;
+        rc.ref_lo = rc.ref_hi = rc.win = rc.ctxw = 0; rc.t0 = 0; rc.fl = rc.bpk = rc.dpk = 0;
+        if (d.fl & BQ_ELIGIBLE) {
+          Pieces4 P;
+          if (d.fl & BQ_COMPLEX) pieces4(s_cig[threadIdx.x], (int)(c1 - c0), p, P);
+          else if (d.b1 != 0xFFFFu) pieces4(s_cig[threadIdx.x], (int)(c1 - c0), p, P);
+          else { P.v0 = (int64_t)d.D0; P.v1 = P.v2 = P.v3 = 0; P.s1 = P.s2 = P.s3 = 0; P.noref = d.D0 == BQ_NOREF ? 1u : 0u; P.np = 1; }
+          rc = make_rec((int)d.a, (int)d.len, (int)d.left, d.right == 0xFFFFu ? -1 : (int)d.right, d.cov, (d.fl & BQ_REVERSED) != 0, (d.fl & BQ_LAST) != 0, P,
+                        P.np < 0, ref_lds ? s_refseq[r] : m.ref_seq[r], ref_lds ? s_refseq_len[r] : m.ref_seq_len[r], (int64_t)ls);
+        }
+        reinterpret_cast<uint4 *>(recs)[2 * i] = make_uint4(rc.ref_lo, rc.ref_hi, rc.win, rc.ctxw);
+        reinterpret_cast<uint4 *>(recs)[2 * i + 1] = make_uint4((uint32_t)rc.t0, rc.fl, rc.bpk, rc.dpk);
+        if (rc.fl & RC_GENERAL) desc[i] = d;
+      } else {
+        desc[i] = d;
+      }
+    }
   }
   // append deferred records to the workgroup's list: one LDS atomic per wave
   const unsigned long long mask = __ballot(defer);
@@ -334,14 +330,31 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
 // without adaptor read-through); literal transliteration of the reference's clipping code.
 __global__ __launch_bounds__(256) void k_bqsr_prologue(BqCols m, const uint32_t *__restrict__ queue, const uint32_t *__restrict__ queue_n,
                                                        uint32_t *__restrict__ cig_scratch, BqDesc *__restrict__ desc, uint32_t *skipbits,
-                                                       uint32_t *err) {
+                                                       uint32_t *err, BqRec *__restrict__ recs) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (uint64_t)*queue_n) return;
   const uint64_t i = queue[t];
+  int32_t rec_pos = 0;  // POS of the clipped copy (set before the final put)
+  // stores the descriptor, or - recs != nullptr - the record count3.hip works from (and the descriptor only if the record cannot
+  // describe the read)
+  auto put = [&](const BqDesc &dd, const uint32_t *cg, int ncg) {
+    if (!recs) { desc[i] = dd; return; }
+    BqRec rc;
+    rc.ref_lo = rc.ref_hi = rc.win = rc.ctxw = 0; rc.t0 = 0; rc.fl = rc.bpk = rc.dpk = 0;
+    if (dd.fl & BQ_ELIGIBLE) {
+      Pieces4 P;
+      pieces4(cg, ncg, rec_pos, P);
+      rc = make_rec((int)dd.a, (int)dd.len, (int)dd.left, dd.right == 0xFFFFu ? -1 : (int)dd.right, dd.cov, (dd.fl & BQ_REVERSED) != 0, (dd.fl & BQ_LAST) != 0, P,
+                    P.np < 0, m.ref_seq[dd.refid], m.ref_seq_len[dd.refid], (int64_t)m.l_seq[i]);
+    }
+    reinterpret_cast<uint4 *>(recs)[2 * i] = make_uint4(rc.ref_lo, rc.ref_hi, rc.win, rc.ctxw);
+    reinterpret_cast<uint4 *>(recs)[2 * i + 1] = make_uint4((uint32_t)rc.t0, rc.fl, rc.bpk, rc.dpk);
+    if (rc.fl & RC_GENERAL) desc[i] = dd;
+  };
   BqDesc d;
   d.D0 = d.D1 = d.D2 = BQ_NOREF; d.refid = 0; d.b1 = d.b2 = 0xFFFF; d.a = 0; d.len = 0; d.left = 0; d.right = 0; d.cov = 0; d.fl = 0; d.pad = 0;
-  if (!recalibrate_aln(m, i)) { desc[i] = d; return; }
-  if (m.l_seq[i] > (uint32_t)MAX_DESC_READ) { atomicOr(&err[0], 2u); desc[i] = d; return; }
+  if (!recalibrate_aln(m, i)) { { put(d, nullptr, 0); return; } }
+  if (m.l_seq[i] > (uint32_t)MAX_DESC_READ) { atomicOr(&err[0], 2u); { put(d, nullptr, 0); return; } }
   RAln a;
   a.pos = m.pos[i]; a.pnext = m.pnext[i]; a.tlen = m.tlen[i]; a.refid = m.refid[i]; a.next_refid = m.next_refid[i];
   a.flag = m.flag[i];
@@ -351,10 +364,10 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue(BqCols m, const uint32_t 
   uint32_t *sc = cig_scratch + 2 * (m.cigar_off[i] + 4 * i);
   a.buf[0] = sc; a.buf[1] = sc + (a.ncig + 4);
   a.cur = -1;
-  if (!hard_clip_adaptor(a)) { atomicOr(&err[0], 4u); desc[i] = d; return; }
-  if (a.len == 0) { desc[i] = d; return; }
+  if (!hard_clip_adaptor(a)) { atomicOr(&err[0], 4u); { put(d, nullptr, 0); return; } }
+  if (a.len == 0) { { put(d, nullptr, 0); return; } }
   hard_clip_soft_clipped(a);
-  if (a.len == 0) { desc[i] = d; return; }
+  if (a.len == 0) { { put(d, nullptr, 0); return; } }
 
   // calculateSkipSlice, bqsr.go:389-414: bits live at (qual_off[i] + original base index)
   {
@@ -390,6 +403,7 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue(BqCols m, const uint32_t 
   d.left = (uint16_t)v.left; d.right = (uint16_t)(v.right < 0 ? 0xFFFF : v.right);
   d.cov = (uint8_t)m.rg_cov[m.rgid[i]];
   d.fl = BQ_ELIGIBLE | ((a.flag & F_REVERSED) ? BQ_REVERSED : 0) | ((a.flag & F_LAST) ? BQ_LAST : 0);
+  rec_pos = a.pos;
   if (!build_pieces(a.cig, a.ncig, a.pos, d)) {
     d.fl |= BQ_COMPLEX;
     if (a.cur < 0) { d.D0 = (int32_t)m.cigar_off[i]; }
@@ -398,7 +412,7 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue(BqCols m, const uint32_t 
     d.D2 = a.pos - 1;
     if (a.ncig > 0xFFFF) atomicOr(&err[0], 2u);
   }
-  desc[i] = d;
+  put(d, a.cig, a.ncig);
 }
 
 // reference contigs are kept as 4-bit code nibbles like the restaged SEQ column (ctx.hip k_recode_seq), first base in the LOW
@@ -424,66 +438,6 @@ __global__ __launch_bounds__(256) void k_pack_reference(const uint8_t *__restric
   }
   packed[i] = (uint8_t)out;
 }
-constexpr int64_t REF_PAD = 32;  // bytes of "other" (0x88) after the packed bases of a contig
-constexpr uint64_t REF_OTHER = 0x8888888888888888ull;
-
-// Reference window of a block: ref_load ISSUES the load of the 32 packed bases around reference index jb (clamped into the
-// contig; its packed bases are followed by REF_PAD bytes of "other") and returns the nibble shift for ref_unpack, REF_NONE if
-// nothing of [jb, jb+16) lies inside the contig.  ref_unpack: nibble b = reference base jb + b ("other" outside [0, rlen)).
-constexpr int REF_NONE = 99;
-__device__ __forceinline__ int ref_load(const uint8_t *__restrict__ rp, int64_t rlen, int64_t jb, uint64_t &v0, uint64_t &v1) {
-  const bool valid = jb < rlen && jb > -16;
-  int64_t jw = jb < 0 ? 0 : jb;
-  jw = jw > rlen ? rlen : jw;
-  jw &= ~(int64_t)1;
-  __builtin_memcpy(&v0, rp + (jw >> 1), 8);
-  __builtin_memcpy(&v1, rp + (jw >> 1) + 8, 8);
-  return valid ? (int)(jb - jw) : REF_NONE;  // -15 .. 1
-}
-__device__ __forceinline__ uint64_t ref_unpack(uint64_t v0, uint64_t v1, int sn) {
-  if (sn == 0 || sn == 1) {  // the common case (reference index >= 0): two 32-bit funnel shifts
-    const uint32_t w0 = (uint32_t)v0, w1 = (uint32_t)(v0 >> 32), w2 = (uint32_t)v1, sh = 4u * (uint32_t)sn;
-    return (uint64_t)__builtin_amdgcn_alignbit(w1, w0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(w2, w1, sh) << 32);
-  }
-  if (sn == REF_NONE) return REF_OTHER;
-  // window starts at the contig's first base but the block starts before it (sn < 0): positions before the contig are "other"
-  return nib_ext(v0, v1, sn) | (REF_OTHER & ~(NIBF << (4 * -sn)));
-}
-__device__ __forceinline__ uint64_t ref_nibbles(const uint8_t *__restrict__ rp, int64_t rlen, int64_t jb) {
-  uint64_t v0, v1;
-  const int sn = ref_load(rp, rlen, jb, v0, v1);
-  return ref_unpack(v0, v1, sn);
-}
-
-// reference nibbles of a chunk for a record whose clipped CIGAR has more than three pieces: walks the CIGAR.
-// Bits [blo, bhi) of the chunk are clipped bases cbase + b.  Insertions copy the read's own nibble (=> no mismatch).
-__device__ __noinline__ uint64_t ref_nibbles_complex(const uint32_t *__restrict__ cg, int ncig, int64_t j0, int cbase, int blo, int bhi,
-                                                     const uint8_t *__restrict__ rp, int64_t rlen, uint64_t S) {
-  uint64_t R = 0;
-  int ri = 0;
-  int64_t j = j0;
-  for (int i = 0; i < ncig; i++) {
-    const uint32_t op = c_op(cg[i]);
-    const int ln = c_len(cg[i]);
-    if (op == OP_M || op == OP_EQ || op == OP_X || op == OP_I || op == OP_S) {
-      int lo = ri - cbase, hi = ri + ln - cbase;
-      lo = lo > blo ? lo : blo;
-      hi = hi < bhi ? hi : bhi;
-      if (lo < hi) {
-        const uint64_t m = nib_fill(nib_range(lo, hi));
-        if (op == OP_I || op == OP_S) R |= S & m;
-        else R |= ref_nibbles(rp, rlen, j - ri + cbase) & m;
-      }
-      ri += ln;
-      if (op != OP_I && op != OP_S) j += ln;
-      if (ri - cbase >= bhi) break;
-    } else if (op == OP_D || op == OP_N) {
-      j += ln;
-    }
-  }
-  return R;
-}
-
 // idx[b] = first site whose End is >= 64 b (sites are sorted and flattened, so Ends increase with the index)
 __global__ __launch_bounds__(256) void k_site_index(const int32_t *__restrict__ sv, int64_t ns, int64_t nbuck, uint32_t *__restrict__ idx) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -493,11 +447,6 @@ __global__ __launch_bounds__(256) void k_site_index(const int32_t *__restrict__ 
   while (lo < hi) { const int64_t md = lo + (hi - lo) / 2; if (sv[2 * md + 1] < x) lo = md + 1; else hi = md; }
   idx[b] = (uint32_t)lo;
 }
-
-// quality value -> LDS table row offset of this pass; the special values:
-// qualities > 93 count into row n_q ("bad"), qualities 6..93 the host did not give a slot (sampling hint incomplete) into row
-// n_q + 1 ("missing") of their covariate; the flush turns a non-zero cell of those rows into an error bit and the host reacts
-struct QMap { uint8_t slot[96]; };         // 6..93 -> slot of this pass, 255 = other pass, 254 = unknown to the host
 
 struct CountArgs {
   uint64_t n, qual_bytes;
@@ -520,34 +469,6 @@ struct CountArgs {
 // take the zero-adds of bases outside the read.  16-bit cycle counters are safe because a read touches a cycle cell at most once and
 // the table is flushed (atomic adds into the dense int64 tables in HBM) before 2^16 reads have passed (CountBody::tile_end).
 constexpr int CT_CYC = 32, CT_XROWS = 3, CT_PAD = 64;
-
-typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
-typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
-__device__ __forceinline__ uint32_t lds_address(const void *p) {
-  return (uint32_t)reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) void *)p);
-}
-__device__ __forceinline__ void lds_add_u32(uint32_t at, uint32_t v) {
-  __hip_atomic_fetch_add(reinterpret_cast<lds_u32_t *>((uintptr_t)at), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void lds_add_u64(uint32_t at, uint32_t lo, uint32_t hi) {
-  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-  const u32x2 v = {lo, hi};
-  __hip_atomic_fetch_add(reinterpret_cast<lds_u64_t *>((uintptr_t)at), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-// the instruction, not whatever instcombine makes of the shift-and-mask around it
-template <int OFF, int W>
-__device__ __forceinline__ uint32_t bfe_u32(uint32_t x) {
-  uint32_t r;
-  asm("v_bfe_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "n"(OFF), "n"(W));
-  return r;
-}
-template <int SH>
-__device__ __forceinline__ uint32_t lshl_add_u32(uint32_t a, uint32_t b) {  // (a << SH) + b
-  uint32_t r;
-  asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(SH), "v"(b));
-  return r;
-}
 
 // MG ("mismatches global"): the cycle cells hold observations only, 16 bits each, two per word, and the (rare) mismatches of the
 // cycle table go straight to the dense table in HBM with one global atomic each - the private table shrinks from 4 to 2 bytes per
@@ -1359,13 +1280,29 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
     uint32_t *queue;
     ELP_TRY(scratch(c, 5, n + 16, &queue));  // [0] = count, [4..] = records left to the general kernel
     ELP_HIP(c, hipMemsetAsync(queue, 0, 16, st));
-    ELP_LAUNCH(c, "bqsr_prologue_fast", k_bqsr_prologue_fast, dim3(blocks_for(n, 256 * PF_TILES)), dim3(256), 0, m, desc, skipbits, queue + 4, queue, c->err_flag.p);
+    // count3.hip (read sets of one length) works from 32-byte records the prologue kernels write instead of the descriptors; it takes
+    // the count if the staged reads have one length (checked once per staged column), no read can exceed --max-cycle, and the quality
+    // slots fit one table pass - k_bqsr_count otherwise (ELP_COUNT_KERNEL=1 forces it: A/B measurements)
+    BqRec *recs = nullptr;
+    {
+      static const bool force_old = getenv("ELP_COUNT_KERNEL") && atoi(getenv("ELP_COUNT_KERNEL")) == 1;
+      ELP_TRY(ensure_uniform_len(c));
+      const int lmax0 = (int)std::max<uint32_t>(c->max_l_seq, 1);
+      int rsw3 = 0, rlog3 = 0;
+      size_t dyn3 = 0;
+      int nq0 = 0;
+      for (int q = 6; q < ELP_NQUAL; q++) nq0 += (int)((q < 64 ? (c->qual_present[0] >> q) : (c->qual_present[1] >> (q - 64))) & 1ull);
+      if (!force_old && c->uniform_len > 0 && lmax0 <= max_cycle && lmax0 <= 1022 && count3_plan(c->n_cov, std::max(nq0, 1), lmax0, &rsw3, &rlog3, &dyn3) == 0)
+        ELP_TRY(scratch(c, 4, n + 4, &recs));
+    }
+    ELP_LAUNCH(c, "bqsr_prologue_fast", k_bqsr_prologue_fast, dim3(blocks_for(n, 256 * PF_TILES)), dim3(256), 0, m, desc, skipbits, queue + 4, queue, c->err_flag.p,
+               recs);
     uint32_t n_queued = 0;
     ELP_HIP(c, hipMemcpyAsync(&n_queued, queue, 4, hipMemcpyDeviceToHost, st));
     ELP_HIP(c, hipStreamSynchronize(st));
     if (n_queued)
       ELP_LAUNCH(c, "bqsr_prologue", k_bqsr_prologue, dim3(blocks_for(n_queued, 256)), dim3(256), 0, m, (const uint32_t *)(queue + 4), (const uint32_t *)queue,
-                 cs_pool, desc, skipbits, c->err_flag.p);
+                 cs_pool, desc, skipbits, c->err_flag.p, recs);
     const int lmax = (int)std::max<uint32_t>(c->max_l_seq, 1);
     if (lmax > MAX_DESC_READ) return set_error(c, ELP_ERR_UNSUPPORTED, "BQSR: read longer than %d bases", MAX_DESC_READ);
     const bool check_cycle = lmax > max_cycle;
@@ -1403,6 +1340,20 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
         if (cap_mg > qcap) { mg = true; rs_use = rs_mg; qcap = cap_mg; }
       }
       const int grid = (int)std::min<uint64_t>(nsteps, (uint64_t)wg_per_cu * (uint64_t)c->n_cu);
+      if (recs) {
+        int rsw3 = 0, rlog3 = 0;
+        size_t dyn3 = 0;
+        if (count3_plan(c->n_cov, (int)quals.size(), lmax, &rsw3, &rlog3, &dyn3) != 0)
+          return set_error(c, ELP_ERR_UNSUPPORTED, "BQSR: the exact quality set (%d values) does not fit the count tables of one pass", (int)quals.size());
+        QMap qm;
+        memset(qm.slot, 254, sizeof qm.slot);
+        for (size_t s2 = 0; s2 < quals.size(); s2++) qm.slot[quals[s2]] = (uint8_t)s2;
+        Count3Args A3{n, c->uniform_len, c->qual.p, c->seq4.p + elp_ctx::SEQ_FRONT, reinterpret_cast<const uint8_t *>(skipbits), reinterpret_cast<const uint4 *>(recs),
+                      reinterpret_cast<const uint4 *>(desc), c->cigar.p, cs_pool, c->d_ref_seq.p, c->d_ref_seq_len.p, c->n_cov, (int)quals.size(), lmax, max_cycle,
+                      rsw3, rlog3, getenv("ELP_C3_DEBUG") ? atoi(getenv("ELP_C3_DEBUG")) : 0, tb + nq, tb + nq + nc, c->err_flag.p};
+        ELP_TRY(count3_launch(c, A3, qm, dyn3));
+        goto counted;
+      }
       for (size_t q0 = 0; q0 < quals.size(); q0 += (size_t)qcap) {
         const int nqs = (int)std::min<size_t>((size_t)qcap, quals.size() - q0);
         QMap qm;
@@ -1433,6 +1384,7 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
         else ELP_COUNT_LAUNCH(false, false);
 #undef ELP_COUNT_LAUNCH
       }
+    counted:
       uint32_t e[4];
       ELP_TRY(fetch_err(c, e));
       if ((e[0] & ~128u) != 0) return bqsr_error(c, e[0] & ~128u);

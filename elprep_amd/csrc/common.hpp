@@ -70,7 +70,9 @@ struct elp_ctx {
   elp::DVec<uint16_t> rg_lib, rg_cov;
 
   // staged columns
-  uint64_t n = 0, qname_bytes = 0, cigar_ops = 0, seq_bytes = 0, qual_bytes = 0;
+  static constexpr uint64_t SEQ_FRONT = 16;  // the SEQ column starts this many bytes into its allocation: the per-base kernels load the
+                                              // window of a block from one byte in front of it (flat2.hpp bodies), also for the first read
+  uint64_t n = 0, qname_bytes = 0, cigar_ops = 0, seq_bytes = SEQ_FRONT, qual_bytes = 0;
   uint64_t n_sr = 0;  // staged records that carry the sr tag (dropped by RemoveOptionalReads) or were rejected by elp_filter_records:
                       // behind everything else in the permutation
   uint64_t n_filtered = 0;  // of those, rejected by elp_filter_records (state 2 in the has_sr column: no duplicate marking either)
@@ -109,6 +111,8 @@ struct elp_ctx {
   static constexpr uint32_t TIE_LIVE_WORDS = 32;
   uint32_t radix_epoch = 0;
   uint64_t flat_index_n = 0, flat_index_bytes = 0;
+  uint32_t uniform_len = 0;  // > 0: every staged read has this many bases and the offset columns are arithmetic (ensure_uniform_len)
+  uint64_t uniform_n = ~0ull, uniform_bytes = ~0ull;
 
   // mark-duplicates results kept for the metrics pass
   elp::DVec<uint32_t> mate;        // per record: staging index of its mate if the two form a pair (classifyPair), else 0xFFFFFFFF
@@ -300,6 +304,7 @@ int radix_sort_pairs_low(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *k
                          uint64_t **keys_out, uint32_t **vals_out, const uint64_t *first_src = nullptr, bool identity_vals = false);
 int exclusive_scan_u32(elp_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n, uint32_t *total_host /* may be null */);
 int ensure_adapted(elp_ctx *c, bool check_quals = true);
+int ensure_uniform_len(elp_ctx *c);  // sort.hip: c->uniform_len
 int ensure_qual_present(elp_ctx *c, bool exact = false);  // exact: scan the whole column instead of a sample
 int fetch_err(elp_ctx *c, uint32_t *words /* 4 */);
 void group_release(elp_ctx *c);

@@ -218,7 +218,8 @@ int elp_reserve(elp_ctx *c, uint64_t n, uint64_t qb, uint64_t co, uint64_t sb, u
 int elp_reset(elp_ctx *c) {
   if (!c) return ELP_ERR_ARG;
   std::lock_guard<std::mutex> g(c->stage_mu);
-  c->n = c->qname_bytes = c->cigar_ops = c->seq_bytes = c->qual_bytes = 0;
+  c->n = c->qname_bytes = c->cigar_ops = c->qual_bytes = 0;
+  c->seq_bytes = elp_ctx::SEQ_FRONT;
   c->n_sr = 0;
   c->n_filtered = 0;
   c->raw_n = c->raw_bytes = 0;
@@ -230,6 +231,7 @@ int elp_reset(elp_ctx *c) {
   c->have_qual_present = false;
   c->have_snapshot = false;
   c->flat_index_n = 0;
+  c->uniform_n = ~0ull;
   return 0;
 }
 
@@ -316,6 +318,7 @@ int elp_stage(elp_ctx *c, const elp_batch *b) {
   c->have_qual_present = false;
   c->have_snapshot = false;
   c->flat_index_n = 0;
+  c->uniform_n = ~0ull;
   return 0;
 }
 

@@ -221,6 +221,36 @@ int ensure_flat_index(elp_ctx *c) {
   return 0;
 }
 
+// Do all staged reads have one length?  (every QUAL offset i * len, every SEQ offset SEQ_FRONT + i * ((len + 1) / 2)): then the per-base
+// kernels need no offsets at all (count3.hip).  A fact of the staged columns: checked once per staging, like the tile index.
+__global__ __launch_bounds__(256) void k_uniform_check(uint64_t n, const uint64_t *__restrict__ qual_off, const uint64_t *__restrict__ seq_off,
+                                                       const uint32_t *__restrict__ l_seq, uint64_t len, uint64_t sb, uint64_t seq_front, uint32_t *bad) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool b = false;
+  if (i < n) b = qual_off[i] != i * len || seq_off[i] != seq_front + i * sb || (uint64_t)l_seq[i] != len;
+  if (i == n) b = qual_off[n] != n * len || seq_off[n] != seq_front + n * sb;
+  if (__any(b) && (threadIdx.x & 63) == 0) atomicOr(bad, 1u);
+}
+int ensure_uniform_len(elp_ctx *c) {
+  if (c->uniform_n == c->n && c->uniform_bytes == c->qual_bytes && c->n) return 0;
+  c->uniform_len = 0;
+  c->uniform_n = c->n;
+  c->uniform_bytes = c->qual_bytes;
+  if (!c->n || c->qual_bytes % c->n) return 0;
+  const uint64_t len = c->qual_bytes / c->n;
+  if (len == 0 || len > 0x3FFFFFull) return 0;
+  uint32_t *bad = c->err_flag.p + 2;
+  ELP_HIP(c, hipMemsetAsync(bad, 0, 4, c->stream));
+  ELP_LAUNCH(c, "uniform_check", k_uniform_check, dim3(blocks_for(c->n + 1, 256)), dim3(256), 0, c->n, (const uint64_t *)c->qual_off.p,
+             (const uint64_t *)c->seq_off.p, (const uint32_t *)c->l_seq.p, len, (len + 1) / 2, (uint64_t)elp_ctx::SEQ_FRONT, bad);
+  uint32_t hb = 0;
+  ELP_HIP(c, hipMemcpyAsync(&hb, bad, 4, hipMemcpyDeviceToHost, c->stream));
+  ELP_HIP(c, hipStreamSynchronize(c->stream));
+  ELP_HIP(c, hipMemsetAsync(bad, 0, 4, c->stream));
+  if (!hb) c->uniform_len = (uint32_t)len;
+  return 0;
+}
+
 static int adapt_quality_error(elp_ctx *c) {
   return set_error(c, ELP_ERR_DATA, "Invalid QUAL character (phred > 93) in a duplicate-marking candidate (reference: log.Panic, filters/mark-duplicates.go:64-66)");
 }
