@@ -1,0 +1,294 @@
+// apply3.hip — ApplyBQSR for read sets of one length (round 3): the loop shape of count3.hip on the apply side.
+//
+// Reference: BaseRecalibratorTables.ApplyBQSR (filters/bqsr.go:936-1005): every base with quality >= 6 of a record whose read group is
+// in the tables is replaced by the memo value of (read group, quality, cycle, context); cycle and context are taken on the full,
+// unclipped read.  Same bytes as k_bqsr_apply_flat (bqsr.hip), which stays as the general kernel (ragged lengths, reads longer than
+// --max-cycle, LUTs with more than ~250 distinct rows).
+//
+//   - A workgroup trip covers RPI = 1024 / (blocks per read) whole reads; lane t is block t % bpr of read slot t / bpr for the whole
+//     kernel: addresses are a wave-uniform base plus a constant lane offset; no groups, no barriers.
+//   - Per read an 8-byte record (context window, covariate, direction, cycle origin) made by k_apply_records from the columns.
+//   - Two-level LUT in LDS as in k_bqsr_apply_flat (level 1: (covariate, quality, cycle) -> id of one of the few distinct 17-byte LUT
+//     rows; level 2: the rows), with two changes: level 1 starts at quality 0 - qualities 0..5 map to IDENTITY rows (their bytes equal
+//     the quality), so "ApplyBQSR leaves qualities below 6 alone" needs no byte masks behind the look-ups - and every quality from 6
+//     up to the largest one seen in the sample of the column is resident (a quality between 6 and the smallest sampled one was read
+//     from the wrong row by the older kernel's clamp); qualities above the resident range read the 0x80 row and take the fix-up loop.
+#include <algorithm>
+
+#include "bqsr_common.hpp"
+#include "gload.hpp"
+
+namespace elp {
+
+constexpr uint32_t A3_N1 = 0x11111111u, A3_C3 = 0x33333333u;
+constexpr int A3_NT = 512;  // three workgroups per CU around three copies of the LUT (~50 KB each): six waves per SIMD
+enum : uint32_t { AR_ON = 1u << 8, AR_REV = 1u << 9, AR_NEG = 1u << 10 };
+
+// per read: x = context window lo | hi << 16 (bases whose context covariate is valid), y = covariate | AR_* | (cf + lmax) << 16
+__global__ __launch_bounds__(256) void k_apply_records(uint64_t n, uint32_t len, int lmax, const uint16_t *__restrict__ flag, const uint16_t *__restrict__ rgid,
+                                                       const uint16_t *__restrict__ rg_cov, const uint64_t *__restrict__ qbounds,
+                                                       const uint8_t *__restrict__ cov_present, uint2 *__restrict__ recs, uint32_t *err) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint16_t rg = rgid[i], f = flag[i];
+  const uint64_t qb = qbounds[i];
+  uint2 r = make_uint2(0u, 0u);
+  if (rg == ELP_NIL16) {
+    atomicOr(&err[0], 32u);  // readGroupCovariate panics, bqsr.go:38
+  } else {
+    const uint32_t cov = rg_cov[rg];
+    if (cov_present[cov]) {  // else: read group absent from the tables, read untouched (:953-955)
+      const bool rev = f & F_REVERSED;
+      const uint32_t hi1 = (uint32_t)qb;
+      const int left = hi1 ? (int)(qb >> 32) : (int)len, right = hi1 ? (int)hi1 - 1 : (int)len - 1;
+      int cl = left + (rev ? 0 : 1), cr1 = right - (rev ? 1 : 0) + 1;
+      cl = cl < 0 ? 0 : cl;
+      cr1 = cr1 > (int)len ? (int)len : cr1;
+      cr1 = cr1 < cl ? cl : cr1;
+      const int rof = (f & F_LAST) ? -1 : 1;
+      const int cf = rof + (rev ? ((int)len - 1) * rof : 0), ci = rev ? -rof : rof;
+      r.x = (uint32_t)cl | ((uint32_t)cr1 << 16);
+      r.y = (cov & 0xFFu) | AR_ON | (rev ? AR_REV : 0u) | (ci < 0 ? AR_NEG : 0u) | ((uint32_t)(cf + lmax) << 16);
+    }
+  }
+  recs[i] = r;
+}
+
+struct Apply3Args {
+  uint64_t n;
+  uint32_t len;
+  uint8_t *qual;
+  const uint8_t *seq4;  // first SEQ byte of read 0
+  const uint2 *recs;
+  const uint8_t *lut;   // dense [n_cov][94][2*max_cycle+1][17] (fix-up path)
+  const uint16_t *t1;   // [n_cov][n_qi + 1][w] row ids for qualities 6 .. qhi (+ the "not resident" row), w = 2 lmax + 1
+  const uint8_t *t2;    // [n_dict + 1][17]
+  int n_cov, n_qi, lmax, max_cycle, n_dict;
+  uint32_t *err;
+};
+
+struct A3Data { u32x4 q, s; };  // QUAL bytes; SEQ window (three words used): the asm loads of gload.hpp write these registers
+
+__device__ __forceinline__ uint32_t lds_u8(uint32_t at) { return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>((uintptr_t)at); }
+
+template <int BYTE>
+__device__ __forceinline__ uint32_t byte_min(uint32_t w, uint32_t hi) {  // min((w >> 8 BYTE) & 0xFF, hi) in one instruction
+  uint32_t r;
+  if (BYTE == 0) asm("v_min_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(w), "v"(hi));
+  else if (BYTE == 1) asm("v_min_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(w), "v"(hi));
+  else if (BYTE == 2) asm("v_min_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(w), "v"(hi));
+  else asm("v_min_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(w), "v"(hi));
+  return r;
+}
+template <int BYTE>
+__device__ __forceinline__ uint32_t byte_add(uint32_t w, uint32_t b) {  // ((w >> 8 BYTE) & 0xFF) + b in one instruction
+  uint32_t r;
+  if (BYTE == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(w), "v"(b));
+  else if (BYTE == 1) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(w), "v"(b));
+  else if (BYTE == 2) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(w), "v"(b));
+  else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(w), "v"(b));
+  return r;
+}
+
+// nibble word of four bases (bits 4 b .. 4 b + 3, b = 0..3, in the low 16 bits of x) -> one byte per base
+__device__ __forceinline__ uint32_t nib4_to_bytes(uint32_t x) {
+  x = (x | (x << 8)) & 0x00FF00FFu;
+  return (x | (x << 4)) & 0x0F0F0F0Fu;
+}
+
+struct Apply3 {
+  uint32_t k0, nb, qoff, soff;
+  uint32_t t1_at, t2_at;  // LDS byte addresses of the two levels
+  uint32_t w, rows_w;     // level-1 entries per (covariate, quality) row / per covariate
+  uint32_t qhi1;          // qualities above qhi1 - 1 read row qhi1: "not resident"
+  int lmax, max_cycle;
+  const uint8_t *__restrict__ lut;
+  uint32_t err;
+
+  // one base: level 1 (covariate, min(quality, qhi1), cycle) -> row id, level 2 (row, context) -> new quality
+  template <int I>
+  __device__ __forceinline__ uint32_t base(uint32_t qw, uint32_t cxw, uint32_t c1, uint32_t t2r) const {
+    const uint32_t qc = byte_min<(I & 3)>(qw, qhi1);
+    const uint32_t id = lds_u8(__umul24(qc, w) + c1);
+    return lds_u8(lshl_add_u32<5>(id, byte_add<(I & 3)>(cxw, t2r)));
+  }
+
+  // bases whose look-up hit the 0x80 row: quality above the resident range -> dense LUT; quality > 93 -> error
+  __device__ __forceinline__ void fixup(uint32_t &o0, uint32_t &o1, uint32_t &o2, uint32_t &o3, const A3Data &d, uint32_t cov, int cyc0, int ci, uint32_t FV_lo,
+                                        uint32_t FV_hi, uint32_t CX_lo, uint32_t CX_hi) {
+    const int ncyc = 2 * max_cycle + 1;
+    uint64_t lo = (uint64_t)o0 | ((uint64_t)o1 << 32), hi = (uint64_t)o2 | ((uint64_t)o3 << 32);
+    const uint64_t qlo = (uint64_t)d.q.x | ((uint64_t)d.q.y << 32), qhi = (uint64_t)d.q.z | ((uint64_t)d.q.w << 32);
+#pragma unroll 1
+    for (int i = 0; i < (int)nb; i++) {
+      const int bs = 8 * (i & 7);
+      const uint32_t q = (uint32_t)(((i & 8) ? qhi : qlo) >> bs) & 0xFFu;
+      if (q < qhi1) continue;  // resident: done by the straight-line code
+      uint64_t v = q;
+      if (q >= (uint32_t)ELP_NQUAL) {
+        err |= 8u;
+      } else {
+        const uint32_t fv = ((i & 8) ? FV_hi : FV_lo) >> (4 * (i & 7)), cxn = ((i & 8) ? CX_hi : CX_lo) >> (4 * (i & 7));
+        const uint32_t cx = (fv & 1u) ? (cxn & 15u) : 16u;
+        v = (uint64_t)lut[(((size_t)cov * ELP_NQUAL + q) * ncyc + (size_t)(cyc0 + i * ci + max_cycle)) * 17 + cx];
+      }
+      const uint64_t m = ~(0xFFull << bs);
+      lo = (i & 8) ? lo : ((lo & m) | (v << bs));
+      hi = (i & 8) ? ((hi & m) | (v << bs)) : hi;
+    }
+    o0 = (uint32_t)lo; o1 = (uint32_t)(lo >> 32); o2 = (uint32_t)hi; o3 = (uint32_t)(hi >> 32);
+  }
+
+  __device__ __forceinline__ void process(u32x2 rec, const A3Data &d, uint8_t *__restrict__ out) {
+    const uint32_t fl = rec.y;
+    const bool rev = fl & AR_REV;
+    const uint32_t cov = fl & 0xFFu;
+    // SEQ: S = the block's bases, N = their predecessors in sequencing direction
+    const uint32_t ns = rev ? 12u : 4u;
+    const uint32_t S_lo = __builtin_amdgcn_alignbit(d.s.y, d.s.x, 8), S_hi = __builtin_amdgcn_alignbit(d.s.z, d.s.y, 8);
+    const uint32_t N_lo = __builtin_amdgcn_alignbit(d.s.y, d.s.x, ns), N_hi = __builtin_amdgcn_alignbit(d.s.z, d.s.y, ns);
+    const uint32_t o_lo = ((S_lo | N_lo) >> 3) & A3_N1, o_hi = ((S_hi | N_hi) >> 3) & A3_N1;  // base or predecessor not A / C / G / T
+    const uint64_t cw = nib_range_clamped((int)(rec.x & 0xFFFFu) - (int)k0, (int)(rec.x >> 16) - (int)k0);
+    const uint32_t FV_lo = (uint32_t)cw & ~o_lo, FV_hi = (uint32_t)(cw >> 32) & ~o_hi;  // context valid
+    const uint32_t rm = rev ? 0xFFFFFFFFu : 0u;
+    const uint32_t CX_lo = ((N_lo & A3_C3) | ((S_lo & A3_C3) << 2)) ^ rm, CX_hi = ((N_hi & A3_C3) | ((S_hi & A3_C3) << 2)) ^ rm;
+    // context index per base as a byte: 0 .. 15, 16 = no context
+    const uint32_t X_lo = (CX_lo & (FV_lo * 15u)), X_hi = (CX_hi & (FV_hi * 15u));
+    const uint32_t nv_lo = ~FV_lo & A3_N1, nv_hi = ~FV_hi & A3_N1;
+    const uint32_t c0 = nib4_to_bytes(X_lo & 0xFFFFu) | (nib4_to_bytes(nv_lo & 0xFFFFu) << 4), c1w = nib4_to_bytes(X_lo >> 16) | (nib4_to_bytes(nv_lo >> 16) << 4);
+    const uint32_t c2 = nib4_to_bytes(X_hi & 0xFFFFu) | (nib4_to_bytes(nv_hi & 0xFFFFu) << 4), c3 = nib4_to_bytes(X_hi >> 16) | (nib4_to_bytes(nv_hi >> 16) << 4);
+    const int ci = (fl & AR_NEG) ? -1 : 1;
+    const int cyc0l = (int)(fl >> 16) + ci * (int)k0;  // cycle of the block's first base + lmax
+    const uint32_t l1 = t1_at + __umul24(cov, rows_w) + (uint32_t)cyc0l;
+    const uint32_t uci = (uint32_t)ci;
+    const uint32_t t2r = t2_at;
+#define ELP_A3(I, QW, CW) base<I>(QW, CW, l1 + (uint32_t)(I) * uci, t2r)
+    const uint32_t b0 = ELP_A3(0, d.q.x, c0), b1 = ELP_A3(1, d.q.x, c0), b2 = ELP_A3(2, d.q.x, c0), b3 = ELP_A3(3, d.q.x, c0);
+    const uint32_t b4 = ELP_A3(4, d.q.y, c1w), b5 = ELP_A3(5, d.q.y, c1w), b6 = ELP_A3(6, d.q.y, c1w), b7 = ELP_A3(7, d.q.y, c1w);
+    const uint32_t b8 = ELP_A3(8, d.q.z, c2), b9 = ELP_A3(9, d.q.z, c2), b10 = ELP_A3(10, d.q.z, c2), b11 = ELP_A3(11, d.q.z, c2);
+    const uint32_t b12 = ELP_A3(12, d.q.w, c3), b13 = ELP_A3(13, d.q.w, c3), b14 = ELP_A3(14, d.q.w, c3), b15 = ELP_A3(15, d.q.w, c3);
+#undef ELP_A3
+    uint32_t o0 = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24), o1 = b4 | (b5 << 8) | (b6 << 16) | (b7 << 24);
+    uint32_t o2 = b8 | (b9 << 8) | (b10 << 16) | (b11 << 24), o3 = b12 | (b13 << 8) | (b14 << 16) | (b15 << 24);
+    if (((o0 | o1) | (o2 | o3)) & 0x80808080u) fixup(o0, o1, o2, o3, d, cov, cyc0l - lmax, ci, FV_lo, FV_hi, CX_lo, CX_hi);
+    Chunk ch;
+    ch.w0 = o0; ch.w1 = o1; ch.w2 = o2; ch.w3 = o3;
+    ch.store(out, (int)nb);
+  }
+};
+
+__global__ __launch_bounds__(A3_NT) void k_bqsr_apply3(Apply3Args A) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t llut[];
+  // level 1 in LDS: [n_cov][qhi1 + 1][w] bytes, rows for qualities 0 .. 5 (identity), 6 .. qhi (from A.t1), qhi1 ("not resident");
+  // level 2: rows 32 bytes apart: 0 .. n_dict - 1 the distinct LUT rows, n_dict the 0x80 row, n_dict + 1 + q the identity row of q < 6
+  const int w = 2 * A.lmax + 1, qhi1 = 6 + A.n_qi, rows_w = (qhi1 + 1) * w, n1 = A.n_cov * rows_w;
+  const int t1_bytes = (n1 + 15) & ~15;
+  for (int k = threadIdx.x; k < n1; k += A3_NT) {
+    const int x = k % w, q = (k / w) % (qhi1 + 1), cov = k / rows_w;
+    uint32_t id;
+    if (q < 6) id = (uint32_t)(A.n_dict + 1 + q);
+    else id = A.t1[((size_t)cov * (A.n_qi + 1) + (size_t)(q - 6)) * w + x];  // row n_qi of t1 is the "not resident" row (id n_dict)
+    llut[k] = (uint8_t)id;
+  }
+  const int n2 = (A.n_dict + 7) * 17;
+  for (int k = threadIdx.x; k < n2; k += A3_NT) {
+    const int row = k / 17, cx = k - 17 * row;
+    llut[t1_bytes + 32 * row + cx] = row <= A.n_dict ? A.t2[k] : (uint8_t)(row - A.n_dict - 1);
+  }
+  __syncthreads();
+  Apply3 B;
+  const uint32_t len = A.len, bpr = (len + 15u) >> 4, sbytes = (len + 1u) >> 1, RPI = A3_NT / bpr;
+  const uint32_t slot = threadIdx.x / bpr, jb = threadIdx.x - slot * bpr;
+  const bool lane_on = slot < RPI;
+  B.k0 = 16u * jb;
+  B.nb = len - B.k0 < 16u ? len - B.k0 : 16u;
+  B.qoff = slot * len + B.k0;
+  B.soff = slot * sbytes + (B.k0 >> 1);
+  B.t1_at = lds_address(llut); B.t2_at = lds_address(llut) + (uint32_t)t1_bytes;
+  B.w = (uint32_t)w; B.rows_w = (uint32_t)rows_w; B.qhi1 = (uint32_t)qhi1;
+  B.lmax = A.lmax; B.max_cycle = A.max_cycle; B.lut = A.lut; B.err = 0;
+  asm volatile("" : "+v"(B.qhi1));  // the SDWA form takes no inline constant / scalar here
+  const uint64_t n = A.n, stride = (uint64_t)gridDim.x * RPI;
+  const uint64_t n_trips = (n + stride - 1) / stride;
+  const uint8_t *seq_m1 = A.seq4 - 1;
+  auto first_read = [&](uint64_t it) __attribute__((always_inline)) -> uint64_t { return it * stride + (uint64_t)blockIdx.x * RPI; };
+  const uint32_t roff = slot * 8u;
+  auto rec_load = [&](uint64_t it, u32x2 &z) __attribute__((always_inline)) {
+    const uint64_t r0 = first_read(it);
+    if (lane_on && r0 + slot < n) gload_x2(z, reinterpret_cast<const uint8_t *>(A.recs) + r0 * 8u, roff);
+    else z = (u32x2){0u, 0u};
+  };
+  auto data_load = [&](uint64_t it, u32x2 rec, A3Data &d) __attribute__((always_inline)) -> bool {
+    const uint64_t r0 = first_read(it);
+    if (!(lane_on && r0 + slot < n) || !(rec.y & AR_ON)) return false;
+    gload_x4(d.q, A.qual + r0 * len, B.qoff);
+    gload_x4(d.s, seq_m1 + r0 * sbytes, B.soff);
+    return true;
+  };
+  // the ONE wait of a loop trip (gload.hpp); the record moves out of its buffer by copies that stay behind the wait
+  auto landed = [&](A3Data &d, const u32x2 &z, u32x2 &rec) __attribute__((always_inline)) {
+    gwait();
+    asm volatile("" : "+v"(d.q), "+v"(d.s));
+    rec = amov(z);
+  };
+  // records two trips ahead (z), data one trip ahead, two sets X / Y that swap roles
+  A3Data dX, dY;
+  dX.q = (u32x4){0, 0, 0, 0}; dX.s = dX.q;
+  dY = dX;
+  u32x2 rX, rY, rN, z = (u32x2){0u, 0u};  // records of the blocks in X / Y, of the next trip's block, the buffer in flight
+  bool onX, onY = false;
+  rec_load(0, z);
+  landed(dX, z, rX);
+  onX = data_load(0, rX, dX);
+  rec_load(1, z);
+  landed(dX, z, rN);
+#pragma unroll 1
+  for (uint64_t it = 0; it < n_trips; it += 2) {
+    {
+      rY = rN;
+      onY = data_load(it + 1, rY, dY);
+      rec_load(it + 2, z);
+      if (onX) B.process(rX, dX, A.qual + first_read(it) * len + B.qoff);
+      landed(dY, z, rN);
+    }
+    {
+      rX = rN;
+      onX = data_load(it + 2, rX, dX);
+      rec_load(it + 3, z);
+      if (onY) B.process(rY, dY, A.qual + first_read(it + 1) * len + B.qoff);
+      landed(dX, z, rN);
+    }
+  }
+  gwait();
+  uint32_t my_err = B.err;
+  if (__any(my_err != 0)) {
+    for (int d = 32; d >= 1; d >>= 1) my_err |= __shfl_xor(my_err, d, 64);
+    if ((threadIdx.x & 63) == 0) atomicOr(&A.err[0], my_err);
+  }
+}
+
+// -> 0 launched, 1 not applicable (the caller uses k_bqsr_apply_flat)
+int apply3_bytes(int n_cov, int n_qi, int lmax, int n_dict, size_t *dyn_out) {
+  const size_t n1 = (size_t)n_cov * (size_t)(6 + n_qi + 1) * (size_t)(2 * lmax + 1);
+  const size_t dyn = ((n1 + 15) & ~(size_t)15) + (size_t)(n_dict + 7) * 32 + 16;
+  *dyn_out = dyn;
+  return (n_dict + 7 <= 256 && dyn + 512 <= 160 * 1024) ? 0 : 1;
+}
+
+int apply3_launch(elp_ctx *c, int max_cycle, const uint8_t *d_lut, const uint8_t *d_cov_present, const uint16_t *t1, const uint8_t *t2, int n_qi, int lmax, int n_dict,
+                  size_t dyn) {
+  const uint64_t n = c->n;
+  uint2 *recs;
+  ELP_TRY(scratch(c, 5, n + 4, &recs));
+  ELP_LAUNCH(c, "bqsr_apply_records", k_apply_records, dim3(blocks_for(n, 256)), dim3(256), 0, n, c->uniform_len, lmax, (const uint16_t *)c->flag.p,
+             (const uint16_t *)c->rgid.p, (const uint16_t *)c->rg_cov.p, (const uint64_t *)c->qbounds.p, d_cov_present, recs, c->err_flag.p);
+  Apply3Args A{n, c->uniform_len, c->qual.p, c->seq4.p + elp_ctx::SEQ_FRONT, recs, d_lut, t1, t2, c->n_cov, n_qi, lmax, max_cycle, n_dict, c->err_flag.p};
+  const uint32_t bpr = (c->uniform_len + 15u) >> 4, rpi = A3_NT / bpr;
+  const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / (dyn + 512)));
+  const int grid = (int)std::min<uint64_t>((n + rpi - 1) / rpi, (uint64_t)c->n_cu * per_cu);
+  ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bqsr_apply3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+  ELP_LAUNCH(c, "bqsr_apply", k_bqsr_apply3, dim3(grid), dim3(A3_NT), dyn, A);
+  return 0;
+}
+
+}  // namespace elp

@@ -139,13 +139,10 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
   __shared__ const int32_t *s_sites[REF_LDS];
   __shared__ int64_t s_nsites[REF_LDS];
   __shared__ const uint32_t *s_sidx[REF_LDS];
-  __shared__ const uint8_t *s_refseq[REF_LDS];  // recs != nullptr (records for count3.hip): the packed contigs and their lengths
-  __shared__ int64_t s_refseq_len[REF_LDS];
   const bool ref_lds = m.n_ref <= REF_LDS;
   if (ref_lds)
     for (int r = threadIdx.x; r < m.n_ref; r += 256) {
       s_ref_len[r] = m.ref_len[r]; s_sites[r] = m.sites[r]; s_nsites[r] = m.n_sites[r]; s_sidx[r] = m.site_idx[r];
-      if (recs) { s_refseq[r] = m.ref_seq[r]; s_refseq_len[r] = m.ref_seq_len[r]; }
     }
   if (threadIdx.x == 0) lcount = 0;
   __syncthreads();
@@ -162,6 +159,8 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
     const uint64_t qb = m.qbounds[i];
     BqDesc d;
     d.D0 = d.D1 = d.D2 = BQ_NOREF; d.refid = 0; d.b1 = d.b2 = 0xFFFF; d.a = 0; d.len = 0; d.left = 0; d.right = 0; d.cov = 0; d.fl = 0; d.pad = 0;
+    const uint8_t *rec_rp = nullptr;
+    int64_t rec_rlen = 0;
     // recalibrateAln, bqsr.go:225-244 (+ utils.go:121-139), the part that needs no dependent load
     bool ok = !has_sr && mq > 0 && mq < 255 && !(f & (F_SECONDARY | F_DUPLICATE | F_QCFAILED)) && !(f & F_UNMAPPED) && r >= 0 && p > 0 && ls != 0 &&
               (uint64_t)ls == q1 - q0 && rg != ELP_NIL16 && r < m.n_ref;
@@ -171,6 +170,7 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
       // [aoff, aoff + len) of the read with ONE reference piece starting at POS, softStart = POS, softEnd = End, and
       // getReadCoordinateForReferenceCoordinate is ref - POS inside it.  All five operation slots are read at once.
       const uint64_t nop = c1 - c0;
+      if (recs) { rec_rp = m.ref_seq[r]; rec_rlen = m.ref_seq_len[r]; }  // issued with the CIGAR loads: one round trip for both
       uint32_t opv[5];
 #pragma unroll
       for (int k = 0; k < 5; k++) opv[k] = (uint64_t)k < nop ? m.cigar[c0 + k] : 0u;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
           else if (d.b1 != 0xFFFFu) pieces4(s_cig[threadIdx.x], (int)(c1 - c0), p, P);
           else { P.v0 = (int64_t)d.D0; P.v1 = P.v2 = P.v3 = 0; P.s1 = P.s2 = P.s3 = 0; P.noref = d.D0 == BQ_NOREF ? 1u : 0u; P.np = 1; }
           rc = make_rec((int)d.a, (int)d.len, (int)d.left, d.right == 0xFFFFu ? -1 : (int)d.right, d.cov, (d.fl & BQ_REVERSED) != 0, (d.fl & BQ_LAST) != 0, P,
-                        P.np < 0, ref_lds ? s_refseq[r] : m.ref_seq[r], ref_lds ? s_refseq_len[r] : m.ref_seq_len[r], (int64_t)ls);
+                        P.np < 0, rec_rp, rec_rlen, (int64_t)ls);
         }
         reinterpret_cast<uint4 *>(recs)[2 * i] = make_uint4(rc.ref_lo, rc.ref_hi, rc.win, rc.ctxw);
         reinterpret_cast<uint4 *>(recs)[2 * i + 1] = make_uint4((uint32_t)rc.t0, rc.fl, rc.bpk, rc.dpk);
@@ -1350,7 +1350,7 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
         for (size_t s2 = 0; s2 < quals.size(); s2++) qm.slot[quals[s2]] = (uint8_t)s2;
         Count3Args A3{n, c->uniform_len, c->qual.p, c->seq4.p + elp_ctx::SEQ_FRONT, reinterpret_cast<const uint8_t *>(skipbits), reinterpret_cast<const uint4 *>(recs),
                       reinterpret_cast<const uint4 *>(desc), c->cigar.p, cs_pool, c->d_ref_seq.p, c->d_ref_seq_len.p, c->n_cov, (int)quals.size(), lmax, max_cycle,
-                      rsw3, rlog3, getenv("ELP_C3_DEBUG") ? atoi(getenv("ELP_C3_DEBUG")) : 0, tb + nq, tb + nq + nc, c->err_flag.p};
+                      rsw3, rlog3, tb + nq, tb + nq + nc, c->err_flag.p};
         ELP_TRY(count3_launch(c, A3, qm, dyn3));
         goto counted;
       }
@@ -1540,6 +1540,12 @@ int elp_bqsr_apply(elp_ctx *c, int max_cycle, const uint8_t *lut, const uint8_t 
         if ((q < 64 ? (c->qual_present[0] >> q) : (c->qual_present[1] >> (q - 64))) & 1ull) { if (qhi < 0) qlo = q; qhi = q; }
       const int lmax = (int)std::max<uint32_t>(c->max_l_seq, 1);
       const bool chk = (int64_t)c->max_l_seq > (int64_t)max_cycle;
+      // apply3.hip takes read sets of one length (ELP_APPLY_KERNEL=1 forces k_bqsr_apply_flat: A/B measurements); its level-1 table is
+      // resident from quality 6 on, whatever the smallest sampled quality was
+      static const bool force_old = getenv("ELP_APPLY_KERNEL") && atoi(getenv("ELP_APPLY_KERNEL")) == 1;
+      ELP_TRY(ensure_uniform_len(c));
+      const bool want3 = !force_old && !chk && c->uniform_len > 0 && qhi >= 0;
+      if (want3) qlo = 6;
       ApplyArgs A{n, c->qual_bytes, c->qual_off.p, c->seq_off.p, c->qual.p, c->seq4.p, c->flag.p, c->rgid.p, c->rg_cov.p, c->l_seq.p, c->qbounds.p,
                   dl + lut_bytes, c->tile_first.p, dl, max_cycle, c->err_flag.p, nullptr, nullptr, c->n_cov, 0, 0, lmax, 0};
       int mode = 0;
@@ -1568,6 +1574,16 @@ int elp_bqsr_apply(elp_ctx *c, int max_cycle, const uint8_t *lut, const uint8_t 
         ELP_HIP(c, hipMemcpyAsync(&n_dict, counter, 4, hipMemcpyDeviceToHost, c->stream));
         ELP_HIP(c, hipStreamSynchronize(c->stream));
         ELP_HIP(c, hipMemsetAsync(counter, 0, 4, c->stream));
+        size_t dyn3 = 0;
+        if (want3 && apply3_bytes(c->n_cov, n_qi, lmax, (int)n_dict, &dyn3) == 0) {
+          ELP_TRY(apply3_launch(c, max_cycle, dl, dl + lut_bytes, t1, t2, n_qi, lmax, (int)n_dict, dyn3));
+          uint32_t e3[4];
+          ELP_TRY(fetch_err(c, e3));
+          if (e3[0]) return bqsr_error(c, e3[0]);
+          c->adapted = false;
+          c->have_qual_present = false;
+          return 0;
+        }
         if (n_dict < t2_cap) {
           const int m = n_dict + 1 <= 256 ? 1 : 2;
           const size_t bytes = ((n1 * (size_t)m + 15) & ~(size_t)15) + (size_t)(n_dict + 1) * (m == 1 ? 32 : 17) + 16;

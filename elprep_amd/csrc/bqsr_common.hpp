@@ -255,12 +255,14 @@ struct Count3Args {
   const int64_t *ref_seq_len;
   int n_cov, n_q, lmax, max_cycle;
   int rsw, rlog;  // words per row; log2 of the context replication R
-  int dbg;        // measurement only (ELP_C3_DEBUG): bit 0 no mismatch loop, 1 no piece / general reference path, 2 no per-base steps, 3 stop behind the eligible-base mask,
-                  // 4 no reference loads, 5 no known-site loads, 6 no SEQ loads, 7 no QUAL loads
   unsigned long long *cycle_tbl, *ctx_tbl;
   uint32_t *err;
 };
 int count3_plan(int n_cov, int n_q, int lmax, int *rsw_out, int *rlog_out, size_t *dyn_out);
 int count3_launch(elp_ctx *c, const Count3Args &A, const QMap &qm, size_t dyn);
+// ---- ApplyBQSR for read sets of one length (apply3.hip)
+int apply3_bytes(int n_cov, int n_qi, int lmax, int n_dict, size_t *dyn_out);
+int apply3_launch(elp_ctx *c, int max_cycle, const uint8_t *d_lut, const uint8_t *d_cov_present, const uint16_t *t1, const uint8_t *t2, int n_qi, int lmax, int n_dict,
+                  size_t dyn);
 
 }  // namespace elp

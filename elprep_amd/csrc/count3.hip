@@ -13,9 +13,10 @@
 //     dominate; its loads alone (everything up to the eligible-base mask) took 2.8 of its 5.4 ms at 24 M reads = 3.8 TB/s: the
 //     kernel's floor is the memory system, not the ALUs.
 // Hence this shape:
-//   - NO groups, no LDS staging, no barriers in the main loop: blocks are numbered globally (read r, block j: reads have one length,
-//     so offsets are arithmetic), a lane walks blocks g, g + T, g + 2T ...; waves run free of each other and drift apart, so that one
-//     wave's loads overlap another's arithmetic;
+//   - NO groups, no LDS staging, no barriers in the main loop: reads have one length, so offsets are arithmetic.  A workgroup trip
+//     covers RPI = 1024 / (blocks per read) WHOLE reads; lane t is block t % bpr of read slot t / bpr for the whole kernel, so a lane's
+//     offsets inside a trip's span of the columns are constants and every address is a wave-uniform base (scalar arithmetic) plus a
+//     constant 32-bit lane offset; waves run free of each other and drift apart, so that one wave's loads overlap another's arithmetic;
 //   - the per-read facts come as a 32-byte record (BqRec) the prologue kernels write: two 16-byte loads per block (ten lanes share a
 //     record: L1 hits), fetched two blocks ahead; the block's data (QUAL, known-site bits, SEQ window, a 24-byte reference window that
 //     also covers the neighbouring pieces of a read with indels) one block ahead;
@@ -30,6 +31,7 @@
 #include <algorithm>
 
 #include "bqsr_common.hpp"
+#include "gload.hpp"
 
 namespace elp {
 
@@ -47,14 +49,15 @@ __device__ __forceinline__ uint32_t byte_shl2(uint32_t w, uint32_t two) {  // ((
 }
 __device__ __forceinline__ uint32_t lds_read_u32(uint32_t at) { return *reinterpret_cast<const lds_u32_t *>((uintptr_t)at); }
 
-// one block's position: read index, first base, number of bases (0 = no block: the lane is past the end)
-struct BlkPos { uint32_t r, k0, nb; };
-// what a block's loads land in
+// what a block's work needs from its read's record (BqRec)
+struct BlkRec { uint32_t win, ctxw, t0, fl, bpk, dpk; };
+// what a block's loads land in (the asm loads of gload.hpp write these registers directly)
 struct BlkData {
-  uint32_t q0, q1, q2, q3;      // QUAL bytes
-  uint32_t skipw, qlow;         // 32 known-site bits from a byte boundary on; the block's first bit inside them
-  uint32_t s0, s1, s2;          // SEQ window: nibble n = base k0 - 2 + n
-  uint32_t w0, w1, w2, w3, w4, w5;  // reference window: nibble n = reference base E0 - parity + k0 - 16 + n
+  u32x4 q;         // QUAL bytes
+  uint32_t skipw;  // 32 known-site bits from a byte boundary on
+  u32x4 s;         // SEQ window: nibble n = base k0 - 2 + n (three words used)
+  u32x4 w03;       // reference window words 0..3: nibble n = reference base E0 - parity + k0 - 16 + n
+  u32x2 w45;       // words 4, 5
 };
 
 // Reads the record cannot describe: k_bqsr_count's logic on the BqDesc of the read (loads inside the block's work: rare)
@@ -104,9 +107,9 @@ struct Count3 {
   uint8_t *const *__restrict__ ref_seq;
   const int64_t *__restrict__ ref_seq_len;
   unsigned long long *cycle_tbl, *ctx_tbl;
-  uint64_t n_reads;
-  uint32_t len, bpr, sbytes;  // read length, blocks per read, SEQ bytes per read
-  int n_cov, n_q, lmax, max_cycle, rsw, dbg;
+  uint32_t k0, nb;      // the lane's block inside its read: first base, number of bases (constant for the whole kernel)
+  uint32_t qoff, soff;  // byte offsets of the block's QUAL bytes / SEQ window inside a trip's span of the columns
+  int n_cov, n_q, lmax, max_cycle, rsw;
   // LDS
   uint32_t qrow_at, spread_at;
   const uint8_t *slot_q;
@@ -116,42 +119,30 @@ struct Count3 {
   uint32_t rep4, two;
   uint32_t err;
 
-  __device__ __forceinline__ void load_rec(const BlkPos &b, uint4 &ra, uint4 &rb) const {
-    const uint64_t r = b.nb ? (uint64_t)b.r : 0ull;
-    ra = recs[2 * r];
-    rb = recs[2 * r + 1];
-  }
-  __device__ __forceinline__ void load_data(const BlkPos &b, const uint4 &ra, const uint4 &rb, BlkData &d) const {
+  // Issues the loads of the lane's block of one trip (asm loads: nothing waits here).  qual_t / seq_t / skip_t = the trip's first QUAL
+  // byte, first SEQ byte minus one, the byte of the known-site column that holds the trip's first bit (sphase = that bit's position in
+  // it) - all wave-uniform.  Returns whether the block has any base of the clipped copy (else nothing is loaded).
+  __device__ __forceinline__ bool load_data(const u32x4 &ra, const u32x4 &rb, bool on, const uint8_t *__restrict__ qual_t, const uint8_t *__restrict__ seq_t,
+                                            const uint8_t *__restrict__ skip_t, uint32_t sphase, BlkData &d, BlkRec &f, uint32_t &qlow) const {
     const uint32_t a = ra.z & 0xFFFFu, e = ra.z >> 16;
-    if (b.nb == 0 || b.k0 + b.nb <= a || b.k0 >= e) return;  // no base of the clipped copy in the block: nothing is looked at
-    const uint64_t qpos = (uint64_t)b.r * len + b.k0;
-    if (!(dbg & 128)) {
-      uint4 v;
-      __builtin_memcpy(&v, qual + qpos, 16);
-      d.q0 = v.x; d.q1 = v.y; d.q2 = v.z; d.q3 = v.w;
-    }
-    if (!(dbg & 32)) __builtin_memcpy(&d.skipw, skipbits + (qpos >> 3), 4);
-    d.qlow = (uint32_t)qpos & 7u;
-    if (!(dbg & 64)) {
-      uint4 w;
-      __builtin_memcpy(&w, seq_m1 + ((uint64_t)b.r * sbytes + (b.k0 >> 1)), 16);
-      d.s0 = w.x; d.s1 = w.y; d.s2 = w.z;
-    }
-    if (!(dbg & 16)) {
-      const uint8_t *rp = reinterpret_cast<const uint8_t *>((uint64_t)ra.x | ((uint64_t)ra.y << 32)) + ((rb.y & RC_GENERAL) ? 0u : (b.k0 >> 1));
-      uint4 x;
-      uint2 y;
-      __builtin_memcpy(&x, rp, 16);
-      __builtin_memcpy(&y, rp + 16, 8);
-      d.w0 = x.x; d.w1 = x.y; d.w2 = x.z; d.w3 = x.w; d.w4 = y.x; d.w5 = y.y;
-    }
+    f.win = ra.z; f.ctxw = ra.w; f.t0 = rb.x; f.fl = rb.y; f.bpk = rb.z; f.dpk = rb.w;
+    const uint32_t bit = sphase + qoff;
+    qlow = bit & 7u;
+    if (!on || k0 + nb <= a || k0 >= e) return false;
+    gload_x4(d.q, qual_t, qoff);
+    gload_x1(d.skipw, skip_t, bit >> 3);
+    gload_x4(d.s, seq_t, soff);
+    const uint64_t rp = ((uint64_t)ra.x | ((uint64_t)ra.y << 32)) + ((rb.y & RC_GENERAL) ? 0u : (k0 >> 1));
+    gload_x4(d.w03, rp);
+    gload_x2(d.w45, rp + 16);
+    return true;
   }
 
   // 16 nibbles from nibble n0 (0 .. 31) of the 48-nibble reference window.  Two conditional word shifts (by 16 and by 8 nibbles), then
   // one funnel shift.  (The words pass through registers the optimiser cannot look into: a select between MEMBERS of the block's data
   // becomes an indexed load, and the whole object would move to scratch memory.)
   __device__ __forceinline__ static uint64_t win_extract(const BlkData &d, int n0) {
-    uint32_t x0 = d.w0, x1 = d.w1, x2 = d.w2, x3 = d.w3, x4 = d.w4, x5 = d.w5;
+    uint32_t x0 = d.w03.x, x1 = d.w03.y, x2 = d.w03.z, x3 = d.w03.w, x4 = d.w45.x, x5 = d.w45.y;
     asm("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5));
     const bool s16 = n0 & 16, s8 = n0 & 8;
     const uint32_t y0 = s16 ? x2 : x0, y1 = s16 ? x3 : x1, y2 = s16 ? x4 : x2, y3 = s16 ? x5 : x3;
@@ -193,89 +184,86 @@ struct Count3 {
     lds_add_u32(lshl_add_u32<2>(t >> 4, ro), bfe_u32<sh, 1>(Fh));
     lds_add_u32(ro + lshl_add_u32<RLOG + 2>(bfe_u32<sh, 4>(CXh), lrepC), bfe_u32<sh, 1>(FVh));
   }
-  // the block's mismatches (rare): cycle cell += 1 << 16, context-mismatch cell += 1
-  __device__ __forceinline__ void mismatches(uint64_t E, uint64_t FV, uint64_t CX, const BlkData &d, uint32_t tb, int st, uint32_t rowb) {
-    const uint64_t qlo = (uint64_t)d.q0 | ((uint64_t)d.q1 << 32), qhi = (uint64_t)d.q2 | ((uint64_t)d.q3 << 32);
+  // the mismatches of eight bases (rare): cycle cell += 1 << 16, context-mismatch cell += 1.  Eh / FVh / CXh: the half's nibble words,
+  // qa / qb its QUAL words, tb the cell position of the half's first base
+  __device__ __forceinline__ void mismatches(uint32_t Eh, uint32_t FVh, uint32_t CXh, uint32_t qa, uint32_t qb, uint32_t tb, int st, uint32_t rowb) {
     constexpr uint32_t cxm = (uint32_t)(16 << RLOG) * 4u;  // byte offset of the context-mismatch cells in a row
-    while (E) {
-      const int b4 = __builtin_ctzll(E);
-      const int b = b4 >> 2;
-      E &= E - 1;
-      const uint32_t q = (uint32_t)(((b & 8) ? qhi : qlo) >> (8 * (b & 7))) & 0xFFu;
+    while (Eh) {
+      const uint32_t b4 = (uint32_t)__builtin_ctz(Eh);
+      const uint32_t b = b4 >> 2;
+      Eh &= Eh - 1u;
+      const uint32_t q = (((b & 4u) ? qb : qa) >> (8u * (b & 3u))) & 0xFFu;
+      if (q < 6u) continue;  // not counted (its row is thrown away): no look-up, no atomics
       const uint32_t ro = lds_read_u32(qrow_at + 4u * q);
-      const uint32_t t = tb + (uint32_t)(st * b);
+      const uint32_t t = tb + (uint32_t)(st * (int)b);
       lds_add_u32(ro + ((t >> 4) << 2), 0x10000u);
-      if ((FV >> b4) & 1ull) lds_add_u32(ro + rowb + cxm + (((uint32_t)(CX >> b4) & 15u) << 2), 1u);
+      if ((FVh >> b4) & 1u) lds_add_u32(ro + rowb + cxm + (((CXh >> b4) & 15u) << 2), 1u);
     }
   }
 
-  __device__ __forceinline__ void process(const BlkPos &b, const uint4 &ra, const uint4 &rb, const BlkData &d) {
-    const uint32_t k0 = b.k0;
-    const int nb = (int)b.nb;
-    const int a = (int)(ra.z & 0xFFFFu), e = (int)(ra.z >> 16);
-    if (nb == 0 || (int)k0 + nb <= a || (int)k0 >= e) return;
+  __device__ __forceinline__ void process(const BlkRec &f, uint32_t r, const BlkData &d, uint32_t qlow) {
+    const int a = (int)(f.win & 0xFFFFu), e = (int)(f.win >> 16);
     int blo = a - (int)k0, bhi = e - (int)k0;
     blo = blo > 0 ? blo : 0;
-    bhi = bhi < nb ? bhi : nb;
-    const uint32_t fl = rb.y;
+    bhi = bhi < (int)nb ? bhi : (int)nb;
+    const uint32_t fl = f.fl;
     const bool rev = fl & RC_REV;
     // SEQ: S = the block's bases, N = their predecessors in sequencing direction (base - 1 forward, base + 1 reverse)
     const uint32_t ns = rev ? 12u : 4u;
-    const uint32_t S_lo = __builtin_amdgcn_alignbit(d.s1, d.s0, 8), S_hi = __builtin_amdgcn_alignbit(d.s2, d.s1, 8);
-    const uint32_t N_lo = __builtin_amdgcn_alignbit(d.s1, d.s0, ns), N_hi = __builtin_amdgcn_alignbit(d.s2, d.s1, ns);
+    const uint32_t S_lo = __builtin_amdgcn_alignbit(d.s.y, d.s.x, 8), S_hi = __builtin_amdgcn_alignbit(d.s.z, d.s.y, 8);
+    const uint32_t N_lo = __builtin_amdgcn_alignbit(d.s.y, d.s.x, ns), N_hi = __builtin_amdgcn_alignbit(d.s.z, d.s.y, ns);
     const uint32_t oS_lo = (S_lo >> 3) & N1, oS_hi = (S_hi >> 3) & N1;  // not A / C / G / T
     const uint32_t oN_lo = (N_lo >> 3) & N1, oN_hi = (N_hi >> 3) & N1;
     // known-site bits of the block -> nibble flags (LDS table: bit i of a byte -> bit 4 i)
-    const uint32_t sk = d.skipw >> d.qlow;
+    const uint32_t sk = d.skipw >> qlow;
     const uint32_t k_lo = lds_read_u32(spread_at + ((sk & 0xFFu) << 2)), k_hi = lds_read_u32(spread_at + ((sk >> 6) & 0x3FCu));
     const uint64_t inw = nib_range(blo, bhi);
     const uint32_t F_lo = (uint32_t)inw & ~(oS_lo | k_lo), F_hi = (uint32_t)(inw >> 32) & ~(oS_hi | k_hi);
     if ((F_lo | F_hi) == 0u) return;
-    if (dbg & 8) { err |= (F_lo ^ F_hi) == 0x12345u ? 1u << 20 : 0u; return; }
     // SNP events (computeSnpEvents, bqsr.go:254-285): read nibble vs reference nibble
     uint32_t R_lo, R_hi;
     if (!(fl & (RC_MULTI | RC_GENERAL))) {
       const uint32_t sh = (fl & RC_PAR) ? 4u : 0u;  // nibble 16 + parity of the window = words 2, 3, 4
-      R_lo = __builtin_amdgcn_alignbit(d.w3, d.w2, sh);
-      R_hi = __builtin_amdgcn_alignbit(d.w4, d.w3, sh);
-    } else if (dbg & 2) {
-      R_lo = S_lo; R_hi = S_hi;
+      R_lo = __builtin_amdgcn_alignbit(d.w03.w, d.w03.z, sh);
+      R_hi = __builtin_amdgcn_alignbit(d.w45.x, d.w03.w, sh);
     } else {
       const uint64_t S = (uint64_t)S_lo | ((uint64_t)S_hi << 32);
-      const uint64_t R = (fl & RC_GENERAL) ? c3_ref_general(desc, cigar, cig_scratch, ref_seq, ref_seq_len, b.r, S, blo, bhi, (int)k0 - a) : ref_pieces(d, fl, rb.z, rb.w, S, blo, bhi, (int)k0 - a);
+      const uint64_t R = (fl & RC_GENERAL) ? c3_ref_general(desc, cigar, cig_scratch, ref_seq, ref_seq_len, r, S, blo, bhi, (int)k0 - a) : ref_pieces(d, fl, f.bpk, f.dpk, S, blo, bhi, (int)k0 - a);
       R_lo = (uint32_t)R;
       R_hi = (uint32_t)(R >> 32);
     }
     const uint32_t x_lo = S_lo ^ R_lo, x_hi = S_hi ^ R_hi;
     const uint32_t E_lo = (x_lo | (x_lo >> 1) | (x_lo >> 3)) & F_lo & N1, E_hi = (x_hi | (x_hi >> 1) | (x_hi >> 3)) & F_hi & N1;
     // context (bqsr.go:87-146)
-    const uint64_t cw = nib_range_clamped((int)(ra.w & 0xFFFFu) - (int)k0, (int)(ra.w >> 16) - (int)k0);
+    const uint64_t cw = nib_range_clamped((int)(f.ctxw & 0xFFFFu) - (int)k0, (int)(f.ctxw >> 16) - (int)k0);
     const uint32_t FV_lo = F_lo & (uint32_t)cw & ~oN_lo, FV_hi = F_hi & (uint32_t)(cw >> 32) & ~oN_hi;
     const uint32_t rm = rev ? 0xFFFFFFFFu : 0u;
     const uint32_t CX_lo = ((N_lo & C3) | ((S_lo & C3) << 2)) ^ rm, CX_hi = ((N_hi & C3) | ((S_hi & C3) << 2)) ^ rm;
     const int st = (fl & RC_NEG) ? -17 : 17;
     const uint32_t rowb = __umul24(fl & 0xFFu, rpc_bytes);
-    const uint32_t tb = (uint32_t)((int)rb.x + t_origin + st * (int)k0) + 4u * rowb;
+    const uint32_t tb = (uint32_t)((int)f.t0 + t_origin + st * (int)k0) + 4u * rowb;
     const uint32_t lrepC = rowb + rep4;
     const uint32_t ust = (uint32_t)st;
 #define ELP_B3(I, RO, FH, FVH, CXH) base<I>(RO, FH, FVH, CXH, tb + (uint32_t)(I) * ust, lrepC)
-    if (!(dbg & 4)) {
-      const uint32_t r0 = row_of<0>(d.q0), r1 = row_of<1>(d.q0), r2 = row_of<2>(d.q0), r3 = row_of<3>(d.q0);
-      const uint32_t r4 = row_of<4>(d.q1), r5 = row_of<5>(d.q1), r6 = row_of<6>(d.q1), r7 = row_of<7>(d.q1);
+    {
+      const uint32_t r0 = row_of<0>(d.q.x), r1 = row_of<1>(d.q.x), r2 = row_of<2>(d.q.x), r3 = row_of<3>(d.q.x);
+      const uint32_t r4 = row_of<4>(d.q.y), r5 = row_of<5>(d.q.y), r6 = row_of<6>(d.q.y), r7 = row_of<7>(d.q.y);
       ELP_B3(0, r0, F_lo, FV_lo, CX_lo); ELP_B3(1, r1, F_lo, FV_lo, CX_lo); ELP_B3(2, r2, F_lo, FV_lo, CX_lo); ELP_B3(3, r3, F_lo, FV_lo, CX_lo);
       ELP_B3(4, r4, F_lo, FV_lo, CX_lo); ELP_B3(5, r5, F_lo, FV_lo, CX_lo); ELP_B3(6, r6, F_lo, FV_lo, CX_lo); ELP_B3(7, r7, F_lo, FV_lo, CX_lo);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (!(dbg & 4)) {
-      const uint32_t r0 = row_of<8>(d.q2), r1 = row_of<9>(d.q2), r2 = row_of<10>(d.q2), r3 = row_of<11>(d.q2);
-      const uint32_t r4 = row_of<12>(d.q3), r5 = row_of<13>(d.q3), r6 = row_of<14>(d.q3), r7 = row_of<15>(d.q3);
+    {
+      const uint32_t r0 = row_of<8>(d.q.z), r1 = row_of<9>(d.q.z), r2 = row_of<10>(d.q.z), r3 = row_of<11>(d.q.z);
+      const uint32_t r4 = row_of<12>(d.q.w), r5 = row_of<13>(d.q.w), r6 = row_of<14>(d.q.w), r7 = row_of<15>(d.q.w);
       ELP_B3(8, r0, F_hi, FV_hi, CX_hi); ELP_B3(9, r1, F_hi, FV_hi, CX_hi); ELP_B3(10, r2, F_hi, FV_hi, CX_hi); ELP_B3(11, r3, F_hi, FV_hi, CX_hi);
       ELP_B3(12, r4, F_hi, FV_hi, CX_hi); ELP_B3(13, r5, F_hi, FV_hi, CX_hi); ELP_B3(14, r6, F_hi, FV_hi, CX_hi); ELP_B3(15, r7, F_hi, FV_hi, CX_hi);
       __builtin_amdgcn_sched_barrier(0);
     }
 #undef ELP_B3
-    const uint64_t E = (uint64_t)E_lo | ((uint64_t)E_hi << 32);
-    if (E && !(dbg & 1)) mismatches(E, (uint64_t)FV_lo | ((uint64_t)FV_hi << 32), (uint64_t)CX_lo | ((uint64_t)CX_hi << 32), d, tb, st, rowb);
+    {
+      if (E_lo) mismatches(E_lo, FV_lo, CX_lo, d.q.x, d.q.y, tb, st, rowb);
+      if (E_hi) mismatches(E_hi, FV_hi, CX_hi, d.q.z, d.q.w, tb + 8u * ust, st, rowb);
+    }
   }
 
   // adds the private table into the dense int64 tables (cycle: [cov][94][2*max_cycle+1][2], context: [cov][94][16][2]) and clears it
@@ -352,8 +340,7 @@ __global__ __launch_bounds__(C3_NT) void k_bqsr_count3(Count3Args A, QMap qm) {
   Count3<RLOG> B;
   B.qual = A.qual; B.seq_m1 = A.seq4 - 1; B.skipbits = A.skipbits; B.recs = A.recs; B.desc = A.desc; B.cigar = A.cigar; B.cig_scratch = A.cig_scratch;
   B.ref_seq = A.ref_seq; B.ref_seq_len = A.ref_seq_len; B.cycle_tbl = A.cycle_tbl; B.ctx_tbl = A.ctx_tbl;
-  B.n_reads = A.n; B.len = A.len; B.bpr = (A.len + 15u) >> 4; B.sbytes = (A.len + 1u) >> 1;
-  B.n_cov = A.n_cov; B.n_q = A.n_q; B.lmax = A.lmax; B.max_cycle = A.max_cycle; B.rsw = A.rsw; B.dbg = A.dbg;
+  B.n_cov = A.n_cov; B.n_q = A.n_q; B.lmax = A.lmax; B.max_cycle = A.max_cycle; B.rsw = A.rsw;
   B.qrow_at = lds_address(qrow); B.spread_at = lds_address(spread8); B.slot_q = slot_q; B.tbl = tbl;
   B.rpc_bytes = (uint32_t)((A.n_q + C3_XROWS) * A.rsw) * 4u;
   B.t_origin = 16 * ((16 << RLOG) + 16) + 17 * A.lmax;
@@ -362,52 +349,77 @@ __global__ __launch_bounds__(C3_NT) void k_bqsr_count3(Count3Args A, QMap qm) {
   asm volatile("" : "+v"(B.two));  // keep it in a register: the SDWA form takes no inline constant
   B.err = 0;
 
-  // blocks g = it * T + blockIdx.x * NT + threadIdx.x: a workgroup's 1024 lanes cover 1024 consecutive blocks (~100 reads)
-  const uint32_t bpr = B.bpr, len = A.len;
-  const uint64_t nblk = A.n * bpr, T = (uint64_t)gridDim.x * C3_NT;
-  const uint64_t n_it = (nblk + T - 1) / T;
-  const uint32_t dr = (uint32_t)(T / bpr), dj = (uint32_t)(T - (uint64_t)dr * bpr);
-  uint64_t g = (uint64_t)blockIdx.x * C3_NT + threadIdx.x;
-  uint32_t r = (uint32_t)(g / bpr), j = (uint32_t)(g - (uint64_t)r * bpr);
-  auto here = [&]() __attribute__((always_inline)) -> BlkPos {
-    BlkPos p;
-    p.r = r;
-    p.k0 = 16u * j;
-    p.nb = g < nblk ? (len - p.k0 < 16u ? len - p.k0 : 16u) : 0u;
-    return p;
+  // A trip of a workgroup covers RPI whole reads; lane t works on block t % bpr of read slot t / bpr in every trip (the last
+  // 1024 - RPI * bpr lanes idle).  Trip `it` of workgroup w starts at read (it * gridDim + w) * RPI.
+  const uint32_t len = A.len, bpr = (len + 15u) >> 4, sbytes = (len + 1u) >> 1, RPI = C3_NT / bpr;
+  const uint32_t slot = threadIdx.x / bpr, jb = threadIdx.x - slot * bpr;
+  const bool lane_on = slot < RPI;
+  B.k0 = 16u * jb;
+  B.nb = len - B.k0 < 16u ? len - B.k0 : 16u;
+  B.qoff = slot * len + B.k0;
+  B.soff = slot * sbytes + (B.k0 >> 1);
+  const uint64_t n = A.n, stride = (uint64_t)gridDim.x * RPI;
+  const uint64_t n_trips = (n + stride - 1) / stride;  // every workgroup makes the same number of trips (flush barriers stay uniform)
+  const uint8_t *seq_m1 = A.seq4 - 1;
+  // a cycle cell (16 | 16 bits) takes at most one count per read
+  const uint32_t flush_every = 30000u / (RPI + 1u) + 1u;
+  auto first_read = [&](uint64_t it) __attribute__((always_inline)) -> uint64_t { return it * stride + (uint64_t)blockIdx.x * RPI; };
+  const uint32_t roff = slot * 32u;  // the lane's record inside a trip's span of the record array
+  auto rec_load = [&](uint64_t it, u32x4 &za, u32x4 &zb) __attribute__((always_inline)) {
+    const uint64_t r0 = first_read(it);
+    if (lane_on && r0 + slot < n) {
+      const uint8_t *rt = reinterpret_cast<const uint8_t *>(A.recs) + r0 * 32u;
+      gload_x4(za, rt, roff);
+      gload_x4(zb, rt, roff + 16u);
+    }
   };
-  auto advance = [&]() __attribute__((always_inline)) {
-    g += T;
-    j += dj;
-    const bool wrap = j >= bpr;
-    r += dr + (wrap ? 1u : 0u);
-    j = wrap ? j - bpr : j;
+  auto data_load = [&](uint64_t it, const u32x4 &za, const u32x4 &zb, BlkData &d, BlkRec &f, uint32_t &qlow) __attribute__((always_inline)) -> bool {
+    const uint64_t r0 = first_read(it);
+    const bool on = lane_on && r0 + slot < n;
+    const uint64_t bit0 = r0 * len;
+    return B.load_data(za, zb, on, A.qual + bit0, seq_m1 + r0 * sbytes, A.skipbits + (bit0 >> 3), (uint32_t)bit0 & 7u, d, f, qlow);
   };
-  // a cycle cell (16 | 16 bits) takes at most one count per read; a workgroup sees at most NT / bpr + 1 reads per trip
-  const uint32_t flush_every = 30000u / (C3_NT / bpr + 2u) + 1u;
-  BlkPos pc = here(), p1, p2;
-  uint4 ca, cb, a1, b1, a2, b2;
-  BlkData dc, d1;
-  dc.q0 = dc.q1 = dc.q2 = dc.q3 = dc.skipw = dc.qlow = dc.s0 = dc.s1 = dc.s2 = dc.w0 = dc.w1 = dc.w2 = dc.w3 = dc.w4 = dc.w5 = 0;
-  d1 = dc;
-  B.load_rec(pc, ca, cb);
-  advance();
-  p1 = here();
-  B.load_rec(p1, a1, b1);
-  B.load_data(pc, ca, cb, dc);
-  advance();
+  // the ONE wait of a loop trip: everything issued so far has landed.  The data registers are operands of an empty statement behind the
+  // wait (their uses stay behind it); the record moves out of its buffer by copies that stay behind the wait (gload.hpp)
+  auto landed = [&](BlkData &d, const u32x4 &za, const u32x4 &zb, u32x4 &ra, u32x4 &rb) __attribute__((always_inline)) {
+    gwait();
+    asm volatile("" : "+v"(d.q), "+v"(d.skipw), "+v"(d.s), "+v"(d.w03), "+v"(d.w45));
+    ra = amov(za);
+    rb = amov(zb);
+  };
+  // Pipeline: records two trips ahead (buffer Z), data one trip ahead, two sets X / Y that swap roles (no copies).  In a trip: issue the
+  // next trip's data loads and the record loads of the trip behind it, work on the current block, then wait for what was issued.
+  BlkData dX, dY;
+  dX.q = (u32x4){0, 0, 0, 0}; dX.s = dX.q; dX.w03 = dX.q; dX.w45 = (u32x2){0, 0}; dX.skipw = 0;
+  dY = dX;
+  BlkRec fX, fY;
+  u32x4 za = (u32x4){0, 0, 0, 0}, zb = za, na = za, nb4 = za;  // record buffer in flight; record of the next trip's block
+  uint32_t qlX = 0, qlY = 0;
+  bool onX, onY = false;
+  rec_load(0, za, zb);
+  landed(dX, za, zb, na, nb4);
+  onX = data_load(0, na, nb4, dX, fX, qlX);
+  rec_load(1, za, zb);
+  landed(dX, za, zb, na, nb4);
   uint32_t since = 0;
 #pragma unroll 1
-  for (uint64_t it = 0; it < n_it; it++) {
-    p2 = here();
-    B.load_rec(p2, a2, b2);          // records two blocks ahead
-    B.load_data(p1, a1, b1, d1);     // data one block ahead
-    B.process(pc, ca, cb, dc);
-    pc = p1; ca = a1; cb = b1; dc = d1;
-    p1 = p2; a1 = a2; b1 = b2;
-    advance();
-    if (++since == flush_every) { B.flush(); since = 0; }
+  for (uint64_t it = 0; it < n_trips; it += 2) {
+    {  // trip it: work on X; data of trip it + 1 -> Y; record of trip it + 2 -> Z
+      onY = data_load(it + 1, na, nb4, dY, fY, qlY);
+      rec_load(it + 2, za, zb);
+      if (onX) B.process(fX, (uint32_t)(first_read(it) + slot), dX, qlX);
+      landed(dY, za, zb, na, nb4);
+      if (++since == flush_every) { B.flush(); since = 0; }
+    }
+    {  // trip it + 1: work on Y; data of trip it + 2 -> X; record of trip it + 3 -> Z
+      onX = data_load(it + 2, na, nb4, dX, fX, qlX);
+      rec_load(it + 3, za, zb);
+      if (onY) B.process(fY, (uint32_t)(first_read(it + 1) + slot), dY, qlY);
+      landed(dX, za, zb, na, nb4);
+      if (++since == flush_every) { B.flush(); since = 0; }
+    }
   }
+  gwait();
   B.flush();
   uint32_t my_err = B.err;
   if (__any(my_err != 0)) {

@@ -1,6 +1,6 @@
 #!/bin/bash
-# GPU session: parity tests, then the bench path with count3 and with round 2's k_bqsr_count side by side on one box, then runs that
-# leave a part of count3 out (ELP_C3_DEBUG; results wrong by construction, timing only).  Usage: count3_round.sh <tag> [reads] [ablation reads]
+# GPU session: parity tests, then the bench path with count3 / apply3 and with round 2's k_bqsr_count / k_bqsr_apply_flat side by side on
+# one box.  Usage: count3_round.sh <tag> [reads]
 TAG=${1:-c3}; R=${2:-50000000}; RA=${3:-24000000}
 OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
 timeout 700 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -4 $OUT/pytest.log
@@ -15,7 +15,5 @@ try:
 except Exception as e: print("$name failed", e)
 PY
 }
-run count3 $R A=1
-run old $R ELP_COUNT_KERNEL=1
-[ "$RA" != "0" ] && for d in 1 2 4 8; do run dbg$d $RA ELP_C3_DEBUG=$d; done
-[ "$RA" != "0" ] && run full$RA $RA A=1
+run new $R A=1
+run old $R ELP_COUNT_KERNEL=1 ELP_APPLY_KERNEL=1
