@@ -63,7 +63,8 @@ struct Apply3Args {
   const uint8_t *lut;   // dense [n_cov][94][2*max_cycle+1][17] (fix-up path)
   const uint16_t *t1;   // [n_cov][n_qi + 1][w] row ids for qualities 6 .. qhi (+ the "not resident" row), w = 2 lmax + 1
   const uint8_t *t2;    // [n_dict + 1][17]
-  int n_cov, n_qi, lmax, max_cycle, n_dict;
+  const uint32_t *n_dict;  // number of distinct rows, on the device (no read-back in front of the launch)
+  int n_cov, n_qi, lmax, max_cycle;
   uint32_t *err;
 };
 
@@ -183,17 +184,22 @@ __global__ __launch_bounds__(A3_NT) void k_bqsr_apply3(Apply3Args A) {
   // level 2: rows 32 bytes apart: 0 .. n_dict - 1 the distinct LUT rows, n_dict the 0x80 row, n_dict + 1 + q the identity row of q < 6
   const int w = 2 * A.lmax + 1, qhi1 = 6 + A.n_qi, rows_w = (qhi1 + 1) * w, n1 = A.n_cov * rows_w;
   const int t1_bytes = (n1 + 15) & ~15;
+  const int n_dict = (int)*A.n_dict;
+  if (n_dict + 7 > 256) {  // more distinct rows than one-byte ids (and the LDS the launch reserved) hold: the host takes the general kernel
+    if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(&A.err[0], 512u);
+    return;
+  }
   for (int k = threadIdx.x; k < n1; k += A3_NT) {
     const int x = k % w, q = (k / w) % (qhi1 + 1), cov = k / rows_w;
     uint32_t id;
-    if (q < 6) id = (uint32_t)(A.n_dict + 1 + q);
+    if (q < 6) id = (uint32_t)(n_dict + 1 + q);
     else id = A.t1[((size_t)cov * (A.n_qi + 1) + (size_t)(q - 6)) * w + x];  // row n_qi of t1 is the "not resident" row (id n_dict)
     llut[k] = (uint8_t)id;
   }
-  const int n2 = (A.n_dict + 7) * 17;
+  const int n2 = (n_dict + 7) * 17;
   for (int k = threadIdx.x; k < n2; k += A3_NT) {
     const int row = k / 17, cx = k - 17 * row;
-    llut[t1_bytes + 32 * row + cx] = row <= A.n_dict ? A.t2[k] : (uint8_t)(row - A.n_dict - 1);
+    llut[t1_bytes + 32 * row + cx] = row <= n_dict ? A.t2[k] : (uint8_t)(row - n_dict - 1);
   }
   __syncthreads();
   Apply3 B;
@@ -267,22 +273,22 @@ __global__ __launch_bounds__(A3_NT) void k_bqsr_apply3(Apply3Args A) {
   }
 }
 
-// -> 0 launched, 1 not applicable (the caller uses k_bqsr_apply_flat)
-int apply3_bytes(int n_cov, int n_qi, int lmax, int n_dict, size_t *dyn_out) {
+// LDS of a launch: level 1 + room for 256 level-2 rows (their number is not read back in front of the launch); 1 = does not fit
+int apply3_bytes(int n_cov, int n_qi, int lmax, size_t *dyn_out) {
   const size_t n1 = (size_t)n_cov * (size_t)(6 + n_qi + 1) * (size_t)(2 * lmax + 1);
-  const size_t dyn = ((n1 + 15) & ~(size_t)15) + (size_t)(n_dict + 7) * 32 + 16;
+  const size_t dyn = ((n1 + 15) & ~(size_t)15) + (size_t)256 * 32 + 16;
   *dyn_out = dyn;
-  return (n_dict + 7 <= 256 && dyn + 512 <= 160 * 1024) ? 0 : 1;
+  return dyn + 512 <= 160 * 1024 ? 0 : 1;
 }
 
-int apply3_launch(elp_ctx *c, int max_cycle, const uint8_t *d_lut, const uint8_t *d_cov_present, const uint16_t *t1, const uint8_t *t2, int n_qi, int lmax, int n_dict,
-                  size_t dyn) {
+int apply3_launch(elp_ctx *c, int max_cycle, const uint8_t *d_lut, const uint8_t *d_cov_present, const uint16_t *t1, const uint8_t *t2, const uint32_t *n_dict_dev,
+                  int n_qi, int lmax, size_t dyn) {
   const uint64_t n = c->n;
   uint2 *recs;
   ELP_TRY(scratch(c, 5, n + 4, &recs));
   ELP_LAUNCH(c, "bqsr_apply_records", k_apply_records, dim3(blocks_for(n, 256)), dim3(256), 0, n, c->uniform_len, lmax, (const uint16_t *)c->flag.p,
              (const uint16_t *)c->rgid.p, (const uint16_t *)c->rg_cov.p, (const uint64_t *)c->qbounds.p, d_cov_present, recs, c->err_flag.p);
-  Apply3Args A{n, c->uniform_len, c->qual.p, c->seq4.p + elp_ctx::SEQ_FRONT, recs, d_lut, t1, t2, c->n_cov, n_qi, lmax, max_cycle, n_dict, c->err_flag.p};
+  Apply3Args A{n, c->uniform_len, c->qual.p, c->seq4.p + elp_ctx::SEQ_FRONT, recs, d_lut, t1, t2, n_dict_dev, c->n_cov, n_qi, lmax, max_cycle, c->err_flag.p};
   const uint32_t bpr = (c->uniform_len + 15u) >> 4, rpi = A3_NT / bpr;
   const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / (dyn + 512)));
   const int grid = (int)std::min<uint64_t>((n + rpi - 1) / rpi, (uint64_t)c->n_cu * per_cu);

@@ -328,12 +328,8 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
 
 // General prologue: one thread per record of `queue` (the records k_bqsr_prologue_fast left: anything but a plain "<len>M" CIGAR
 // without adaptor read-through); literal transliteration of the reference's clipping code.
-__global__ __launch_bounds__(256) void k_bqsr_prologue(BqCols m, const uint32_t *__restrict__ queue, const uint32_t *__restrict__ queue_n,
-                                                       uint32_t *__restrict__ cig_scratch, BqDesc *__restrict__ desc, uint32_t *skipbits,
-                                                       uint32_t *err, BqRec *__restrict__ recs) {
-  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (uint64_t)*queue_n) return;
-  const uint64_t i = queue[t];
+__device__ inline void prologue_general(const BqCols &m, const uint64_t i, uint32_t *__restrict__ cig_scratch, BqDesc *__restrict__ desc, uint32_t *skipbits,
+                                        uint32_t *err, BqRec *__restrict__ recs) {
   int32_t rec_pos = 0;  // POS of the clipped copy (set before the final put)
   // stores the descriptor, or - recs != nullptr - the record count3.hip works from (and the descriptor only if the record cannot
   // describe the read)
@@ -413,6 +409,15 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue(BqCols m, const uint32_t 
     if (a.ncig > 0xFFFF) atomicOr(&err[0], 2u);
   }
   put(d, a.cig, a.ncig);
+}
+
+// the queue's length stays on the device (no read-back between the two prologue kernels): a fixed grid strides over it
+__global__ __launch_bounds__(256) void k_bqsr_prologue(BqCols m, const uint32_t *__restrict__ queue, const uint32_t *__restrict__ queue_n,
+                                                       uint32_t *__restrict__ cig_scratch, BqDesc *__restrict__ desc, uint32_t *skipbits,
+                                                       uint32_t *err, BqRec *__restrict__ recs) {
+  const uint64_t nq = (uint64_t)*queue_n;
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nq; t += (uint64_t)gridDim.x * blockDim.x)
+    prologue_general(m, queue[t], cig_scratch, desc, skipbits, err, recs);
 }
 
 // reference contigs are kept as 4-bit code nibbles like the restaged SEQ column (ctx.hip k_recode_seq), first base in the LOW
@@ -1285,7 +1290,7 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
     // slots fit one table pass - k_bqsr_count otherwise (ELP_COUNT_KERNEL=1 forces it: A/B measurements)
     BqRec *recs = nullptr;
     {
-      static const bool force_old = getenv("ELP_COUNT_KERNEL") && atoi(getenv("ELP_COUNT_KERNEL")) == 1;
+      const bool force_old = getenv("ELP_COUNT_KERNEL") && atoi(getenv("ELP_COUNT_KERNEL")) == 1;  // read per call: tests switch it
       ELP_TRY(ensure_uniform_len(c));
       const int lmax0 = (int)std::max<uint32_t>(c->max_l_seq, 1);
       int rsw3 = 0, rlog3 = 0;
@@ -1297,12 +1302,8 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
     }
     ELP_LAUNCH(c, "bqsr_prologue_fast", k_bqsr_prologue_fast, dim3(blocks_for(n, 256 * PF_TILES)), dim3(256), 0, m, desc, skipbits, queue + 4, queue, c->err_flag.p,
                recs);
-    uint32_t n_queued = 0;
-    ELP_HIP(c, hipMemcpyAsync(&n_queued, queue, 4, hipMemcpyDeviceToHost, st));
-    ELP_HIP(c, hipStreamSynchronize(st));
-    if (n_queued)
-      ELP_LAUNCH(c, "bqsr_prologue", k_bqsr_prologue, dim3(blocks_for(n_queued, 256)), dim3(256), 0, m, (const uint32_t *)(queue + 4), (const uint32_t *)queue,
-                 cs_pool, desc, skipbits, c->err_flag.p, recs);
+    ELP_LAUNCH(c, "bqsr_prologue", k_bqsr_prologue, dim3(std::min<unsigned>(blocks_for(n, 256), (unsigned)c->n_cu * 16)), dim3(256), 0, m,
+               (const uint32_t *)(queue + 4), (const uint32_t *)queue, cs_pool, desc, skipbits, c->err_flag.p, recs);
     const int lmax = (int)std::max<uint32_t>(c->max_l_seq, 1);
     if (lmax > MAX_DESC_READ) return set_error(c, ELP_ERR_UNSUPPORTED, "BQSR: read longer than %d bases", MAX_DESC_READ);
     const bool check_cycle = lmax > max_cycle;
@@ -1402,12 +1403,7 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
   c->tables_n = nq + nc + nx;
   c->tables_max_cycle = max_cycle;
   ELP_TRY(tables_written(c));
-  if (!qual_tbl) {  // tables stay in HBM
-    uint32_t e[4];
-    ELP_TRY(fetch_err(c, e));
-    if (e[0]) return bqsr_error(c, e[0]);
-    return 0;
-  }
+  if (!qual_tbl) return 0;  // tables stay in HBM (the count loop above fetched the error word behind the last kernel that can raise one)
   // the three tables lie behind each other on the device: one copy into pinned memory, then into the caller's arrays
   const size_t bytes = (nq + nc + nx) * 8;
   if (bytes > c->h_pinned_cap) {
@@ -1542,7 +1538,7 @@ int elp_bqsr_apply(elp_ctx *c, int max_cycle, const uint8_t *lut, const uint8_t 
       const bool chk = (int64_t)c->max_l_seq > (int64_t)max_cycle;
       // apply3.hip takes read sets of one length (ELP_APPLY_KERNEL=1 forces k_bqsr_apply_flat: A/B measurements); its level-1 table is
       // resident from quality 6 on, whatever the smallest sampled quality was
-      static const bool force_old = getenv("ELP_APPLY_KERNEL") && atoi(getenv("ELP_APPLY_KERNEL")) == 1;
+      const bool force_old = getenv("ELP_APPLY_KERNEL") && atoi(getenv("ELP_APPLY_KERNEL")) == 1;  // read per call: tests switch it
       ELP_TRY(ensure_uniform_len(c));
       const bool want3 = !force_old && !chk && c->uniform_len > 0 && qhi >= 0;
       if (want3) qlo = 6;
@@ -1570,20 +1566,25 @@ int elp_bqsr_apply(elp_ctx *c, int max_cycle, const uint8_t *lut, const uint8_t 
         ELP_LAUNCH(c, "bqsr_apply_lut", k_lut_rows_number, dim3(blocks_for(n_slots, 256)), dim3(256), 0, R, (const uint32_t *)slots, n_slots, slot_id, counter, t2, t2_cap);
         ELP_LAUNCH(c, "bqsr_apply_lut", k_lut_rows_index, dim3(blocks_for(std::max<size_t>(n1, 17), 256)), dim3(256), 0, R, (const uint32_t *)row_slot,
                    (const uint32_t *)slot_id, (const uint32_t *)counter, t1, t2, t2_cap);
+        size_t dyn3 = 0;
+        if (want3 && apply3_bytes(c->n_cov, n_qi, lmax, &dyn3) == 0) {
+          // the number of distinct rows stays on the device; if there are more than the one-byte ids hold, the kernel says so and leaves
+          ELP_TRY(apply3_launch(c, max_cycle, dl, dl + lut_bytes, t1, t2, counter, n_qi, lmax, dyn3));
+          uint32_t e3[4];
+          ELP_TRY(fetch_err(c, e3));
+          if ((e3[0] & ~512u) != 0) return bqsr_error(c, e3[0] & ~512u);
+          if (!(e3[0] & 512u)) {
+            ELP_HIP(c, hipMemsetAsync(counter, 0, 4, c->stream));
+            c->adapted = false;
+            c->have_qual_present = false;
+            return 0;
+          }
+          ELP_HIP(c, hipMemsetAsync(c->err_flag.p, 0, 4, c->stream));
+        }
         uint32_t n_dict = 0;
         ELP_HIP(c, hipMemcpyAsync(&n_dict, counter, 4, hipMemcpyDeviceToHost, c->stream));
         ELP_HIP(c, hipStreamSynchronize(c->stream));
         ELP_HIP(c, hipMemsetAsync(counter, 0, 4, c->stream));
-        size_t dyn3 = 0;
-        if (want3 && apply3_bytes(c->n_cov, n_qi, lmax, (int)n_dict, &dyn3) == 0) {
-          ELP_TRY(apply3_launch(c, max_cycle, dl, dl + lut_bytes, t1, t2, n_qi, lmax, (int)n_dict, dyn3));
-          uint32_t e3[4];
-          ELP_TRY(fetch_err(c, e3));
-          if (e3[0]) return bqsr_error(c, e3[0]);
-          c->adapted = false;
-          c->have_qual_present = false;
-          return 0;
-        }
         if (n_dict < t2_cap) {
           const int m = n_dict + 1 <= 256 ? 1 : 2;
           const size_t bytes = ((n1 * (size_t)m + 15) & ~(size_t)15) + (size_t)(n_dict + 1) * (m == 1 ? 32 : 17) + 16;

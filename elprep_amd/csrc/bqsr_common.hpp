@@ -261,8 +261,8 @@ struct Count3Args {
 int count3_plan(int n_cov, int n_q, int lmax, int *rsw_out, int *rlog_out, size_t *dyn_out);
 int count3_launch(elp_ctx *c, const Count3Args &A, const QMap &qm, size_t dyn);
 // ---- ApplyBQSR for read sets of one length (apply3.hip)
-int apply3_bytes(int n_cov, int n_qi, int lmax, int n_dict, size_t *dyn_out);
-int apply3_launch(elp_ctx *c, int max_cycle, const uint8_t *d_lut, const uint8_t *d_cov_present, const uint16_t *t1, const uint8_t *t2, int n_qi, int lmax, int n_dict,
-                  size_t dyn);
+int apply3_bytes(int n_cov, int n_qi, int lmax, size_t *dyn_out);
+int apply3_launch(elp_ctx *c, int max_cycle, const uint8_t *d_lut, const uint8_t *d_cov_present, const uint16_t *t1, const uint8_t *t2, const uint32_t *n_dict_dev,
+                  int n_qi, int lmax, size_t dyn);
 
 }  // namespace elp

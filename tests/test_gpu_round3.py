@@ -148,3 +148,93 @@ def test_stage_error_leaves_the_context_unchanged():
     assert e.n == b.n
     _same(_whole_path(e, b, h, refs, sites), _oracle_path(b, h, refs, sites))
     e.close()
+
+
+# ---- the kernels for read sets of one length (count3.hip, apply3.hip) on adversarial inputs, and against the general kernels
+from tests.test_gpu_ragged import _check_gather_apply, _random_case, _stage  # noqa: E402
+
+
+def _uniform_case(seed, n, length, quals, **kw):
+    """tests/test_gpu_ragged.py's generator (soft / hard clips, up to four indels, adaptor read-through, N bases, reads over the contig
+    end, low-quality tails) with every read `length` bases long; its two odd records (other lengths) are left out"""
+    b, h, refs, sites = _random_case(seed, n, quals, len_mix=((length, length, 1.0),), **kw)
+    return b.take(np.arange(b.n - 2)), h, refs, sites
+
+
+@pytest.mark.parametrize("length,seed", [(150, 1), (151, 2), (16, 3), (17, 4), (33, 5), (100, 6), (250, 7), (1, 8), (48, 9)])
+def test_one_length_read_sets(length, seed):
+    """the dispatch takes count3 / apply3 (uniform length); every output against the oracle"""
+    b, h, refs, sites = _uniform_case(seed, 5000 if length > 8 else 20000, length, quals=[2, 5, 6, 12, 23, 37, 41], ref_len=(6000, 2500, 900))
+    assert len(set(np.diff(b.qual_off).tolist())) == 1
+    _check_gather_apply(b, h, refs, sites)
+
+
+def test_one_length_many_contigs_and_reads_at_contig_starts():
+    """300 contigs of ~700 bases and 150-base reads: most reads start within a few bases of a contig start or hang over its end (the
+    records' general path), every contig pointer comes from the record"""
+    b, h, refs, sites = _uniform_case(12, 4000, 150, quals=[2, 9, 22, 35], ref_len=tuple([700 + 13 * (k % 7) for k in range(300)]))
+    _check_gather_apply(b, h, refs, sites, chunks=2)
+
+
+@pytest.mark.parametrize("drop", ["6", "27", "38"])
+def test_one_length_quality_hint_incomplete(monkeypatch, drop):
+    """a quality missing from the sampled hint - the smallest one >= 6, a middle one, the largest one: the gather retries with the
+    exact set; apply3's level 1 is resident from quality 6 whatever the hint says, qualities above its range take the fix-up loop"""
+    b, h, refs, sites = _uniform_case(13, 4000, 120, quals=[2, 6, 13, 27, 38])
+    monkeypatch.setenv("ELP_DEBUG_QUAL_HINT_DROP", drop)
+    _check_gather_apply(b, h, refs, sites)
+
+
+def test_one_length_empty_quality_hint(monkeypatch):
+    b, h, refs, sites = _uniform_case(14, 3000, 101, quals=[2, 6, 13, 27, 38, 64, 93])
+    monkeypatch.setenv("ELP_DEBUG_NO_QUAL_HINT", "1")
+    _check_gather_apply(b, h, refs, sites)
+
+
+def test_general_kernels_and_one_length_kernels_agree(monkeypatch):
+    """the same staged reads through k_bqsr_count / k_bqsr_apply_flat (forced) and through count3 / apply3: identical tables and bytes"""
+    cfg, b, h, refs, sites = dataset("tiny", 30000, 3, 0.02)
+    out = []
+    for force in ("1", "0"):
+        monkeypatch.setenv("ELP_COUNT_KERNEL", force)
+        monkeypatch.setenv("ELP_APPLY_KERNEL", force)
+        e = Engine(h)
+        e.stage(b)
+        e.mark_duplicates(True)
+        for r in range(h.n_ref):
+            e.set_reference(r, refs[r])
+            e.set_known_sites(r, sites[r])
+        qt, ct, xt = e.recalibrate(500)
+        lut, present = BqsrTables(qt, ct, xt, 500).finalize().build_lut(0)
+        out.append((qt.copy(), ct.copy(), xt.copy(), e.apply_bqsr(lut, present, 500)))
+        e.close()
+    for a, bb in zip(out[0], out[1]):
+        assert np.array_equal(a, bb)
+    assert (out[0][3] != b.qual).any()
+
+
+def test_one_length_runs_are_reproducible():
+    """two contexts, the same 2 M reads: identical QUAL bytes (the loads of the pipelined kernels are hidden from the compiler,
+    elprep_amd/csrc/gload.hpp: a register read before its data has landed shows up as run-to-run differences at this size)"""
+    from tools import synth
+    cfg = synth.config("c3")
+    h = cfg.header()
+    parts = [synth.generate(cfg, lo, lo + 250_000) for lo in range(0, 1_000_000, 250_000)]
+    refs_sites = [(r, synth.reference(cfg, r), orc.flatten(orc.sort_by_start(synth.known_sites_raw(cfg, r)))) for r in range(h.n_ref)]
+    quals, tabs = [], []
+    for _ in range(2):
+        e = Engine(h)
+        for p in parts:
+            e.stage(p)
+        for r, ref, st in refs_sites:
+            e.set_reference(r, ref)
+            e.set_known_sites(r, st)
+        e.mark_duplicates(True)
+        qt, ct, xt = e.recalibrate(500)
+        if not tabs:
+            lut, present = BqsrTables(qt, ct, xt, 500).finalize().build_lut(0)
+        tabs.append((qt.copy(), ct.copy(), xt.copy()))
+        quals.append(e.apply_bqsr(lut, present, 500))
+        e.close()
+    assert all(np.array_equal(a, b_) for a, b_ in zip(tabs[0], tabs[1]))
+    assert np.array_equal(quals[0], quals[1])
