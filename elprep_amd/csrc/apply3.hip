@@ -7,6 +7,11 @@
 //
 //   - A workgroup trip covers RPI = 1024 / (blocks per read) whole reads; lane t is block t % bpr of read slot t / bpr for the whole
 //     kernel: addresses are a wave-uniform base plus a constant lane offset; no groups, no barriers.
+//   - Every block is a full 16 bytes: the last block of a read whose length is not a multiple of 16 is moved back to END at the read's
+//     end and overlaps its neighbour (both lanes compute the same bytes from the same original values: the two blocks sit in one
+//     wave - the layout is chosen so - and the wave's loads of a read come a trip before its stores).  One 16-byte load and ONE
+//     16-byte store per lane and trip, the store issued by every lane (lanes without work write to a dump area), so that the trip's
+//     wait can leave exactly that store in flight (gload.hpp).
 //   - Per read an 8-byte record (context window, covariate, direction, cycle origin) made by k_apply_records from the columns.
 //   - Two-level LUT in LDS as in k_bqsr_apply_flat (level 1: (covariate, quality, cycle) -> id of one of the few distinct 17-byte LUT
 //     rows; level 2: the rows), with two changes: level 1 starts at quality 0 - qualities 0..5 map to IDENTITY rows (their bytes equal
@@ -66,6 +71,8 @@ struct Apply3Args {
   const uint32_t *n_dict;  // number of distinct rows, on the device (no read-back in front of the launch)
   int n_cov, n_qi, lmax, max_cycle;
   uint32_t *err;
+  uint8_t *dump;   // 16 bytes per lane of the launch: where lanes without a block store
+  uint32_t group;  // lanes that share reads: A3_NT (reads packed over the whole workgroup) or 64 (whole reads per wave)
 };
 
 struct A3Data { u32x4 q, s; };  // QUAL bytes; SEQ window (three words used): the asm loads of gload.hpp write these registers
@@ -98,7 +105,7 @@ __device__ __forceinline__ uint32_t nib4_to_bytes(uint32_t x) {
 }
 
 struct Apply3 {
-  uint32_t k0, nb, qoff, soff;
+  uint32_t k0, qoff, soff, ssh;  // first base of the lane's block; byte offsets into the trip's QUAL / SEQ span; SEQ shift
   uint32_t t1_at, t2_at;  // LDS byte addresses of the two levels
   uint32_t w, rows_w;     // level-1 entries per (covariate, quality) row / per covariate
   uint32_t qhi1;          // qualities above qhi1 - 1 read row qhi1: "not resident"
@@ -121,7 +128,7 @@ struct Apply3 {
     uint64_t lo = (uint64_t)o0 | ((uint64_t)o1 << 32), hi = (uint64_t)o2 | ((uint64_t)o3 << 32);
     const uint64_t qlo = (uint64_t)d.q.x | ((uint64_t)d.q.y << 32), qhi = (uint64_t)d.q.z | ((uint64_t)d.q.w << 32);
 #pragma unroll 1
-    for (int i = 0; i < (int)nb; i++) {
+    for (int i = 0; i < 16; i++) {
       const int bs = 8 * (i & 7);
       const uint32_t q = (uint32_t)(((i & 8) ? qhi : qlo) >> bs) & 0xFFu;
       if (q < qhi1) continue;  // resident: done by the straight-line code
@@ -140,13 +147,14 @@ struct Apply3 {
     o0 = (uint32_t)lo; o1 = (uint32_t)(lo >> 32); o2 = (uint32_t)hi; o3 = (uint32_t)(hi >> 32);
   }
 
-  __device__ __forceinline__ void process(u32x2 rec, const A3Data &d, uint8_t *__restrict__ out) {
+  __device__ __forceinline__ u32x4 process(u32x2 rec, const A3Data &d) {
     const uint32_t fl = rec.y;
     const bool rev = fl & AR_REV;
     const uint32_t cov = fl & 0xFFu;
     // SEQ: S = the block's bases, N = their predecessors in sequencing direction
-    const uint32_t ns = rev ? 12u : 4u;
-    const uint32_t S_lo = __builtin_amdgcn_alignbit(d.s.y, d.s.x, 8), S_hi = __builtin_amdgcn_alignbit(d.s.z, d.s.y, 8);
+    // (the window starts at the byte in front of the one that holds base k0: 8 bits to base k0 if k0 is even, 12 if it is odd)
+    const uint32_t ns = rev ? ssh + 4u : ssh - 4u;
+    const uint32_t S_lo = __builtin_amdgcn_alignbit(d.s.y, d.s.x, ssh), S_hi = __builtin_amdgcn_alignbit(d.s.z, d.s.y, ssh);
     const uint32_t N_lo = __builtin_amdgcn_alignbit(d.s.y, d.s.x, ns), N_hi = __builtin_amdgcn_alignbit(d.s.z, d.s.y, ns);
     const uint32_t o_lo = ((S_lo | N_lo) >> 3) & A3_N1, o_hi = ((S_hi | N_hi) >> 3) & A3_N1;  // base or predecessor not A / C / G / T
     const uint64_t cw = nib_range_clamped((int)(rec.x & 0xFFFFu) - (int)k0, (int)(rec.x >> 16) - (int)k0);
@@ -172,9 +180,7 @@ struct Apply3 {
     uint32_t o0 = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24), o1 = b4 | (b5 << 8) | (b6 << 16) | (b7 << 24);
     uint32_t o2 = b8 | (b9 << 8) | (b10 << 16) | (b11 << 24), o3 = b12 | (b13 << 8) | (b14 << 16) | (b15 << 24);
     if (((o0 | o1) | (o2 | o3)) & 0x80808080u) fixup(o0, o1, o2, o3, d, cov, cyc0l - lmax, ci, FV_lo, FV_hi, CX_lo, CX_hi);
-    Chunk ch;
-    ch.w0 = o0; ch.w1 = o1; ch.w2 = o2; ch.w3 = o3;
-    ch.store(out, (int)nb);
+    return (u32x4){o0, o1, o2, o3};
   }
 };
 
@@ -203,13 +209,15 @@ __global__ __launch_bounds__(A3_NT) void k_bqsr_apply3(Apply3Args A) {
   }
   __syncthreads();
   Apply3 B;
-  const uint32_t len = A.len, bpr = (len + 15u) >> 4, sbytes = (len + 1u) >> 1, RPI = A3_NT / bpr;
-  const uint32_t slot = threadIdx.x / bpr, jb = threadIdx.x - slot * bpr;
-  const bool lane_on = slot < RPI;
-  B.k0 = 16u * jb;
-  B.nb = len - B.k0 < 16u ? len - B.k0 : 16u;
+  const uint32_t len = A.len, bpr = (len + 15u) >> 4, sbytes = (len + 1u) >> 1;
+  // lanes in groups of A.group that share whole reads (apply3_launch picks the group so that a read's last two blocks sit in one wave)
+  const uint32_t grp = threadIdx.x / A.group, in_grp = threadIdx.x - grp * A.group, per_grp = A.group / bpr, RPI = per_grp * (A3_NT / A.group);
+  const uint32_t slot_g = in_grp / bpr, jb = in_grp - slot_g * bpr, slot = grp * per_grp + slot_g;
+  const bool lane_on = slot_g < per_grp;
+  B.k0 = (jb == bpr - 1u && (len & 15u)) ? len - 16u : 16u * jb;  // the last block ends at the read's end
   B.qoff = slot * len + B.k0;
   B.soff = slot * sbytes + (B.k0 >> 1);
+  B.ssh = 8u + 4u * (B.k0 & 1u);
   B.t1_at = lds_address(llut); B.t2_at = lds_address(llut) + (uint32_t)t1_bytes;
   B.w = (uint32_t)w; B.rows_w = (uint32_t)rows_w; B.qhi1 = (uint32_t)qhi1;
   B.lmax = A.lmax; B.max_cycle = A.max_cycle; B.lut = A.lut; B.err = 0;
@@ -231,11 +239,25 @@ __global__ __launch_bounds__(A3_NT) void k_bqsr_apply3(Apply3Args A) {
     gload_x4(d.s, seq_m1 + r0 * sbytes, B.soff);
     return true;
   };
-  // the ONE wait of a loop trip (gload.hpp); the record moves out of its buffer by copies that stay behind the wait
-  auto landed = [&](A3Data &d, const u32x2 &z, u32x2 &rec) __attribute__((always_inline)) {
+  // the wait of a loop trip (gload.hpp); the record moves out of its buffer by copies that stay behind the wait.  Inside the loop the
+  // youngest vector-memory instruction of the wave is the trip's store: it may stay in flight
+  auto landed0 = [&](A3Data &d, const u32x2 &z, u32x2 &rec) __attribute__((always_inline)) {
     gwait();
     asm volatile("" : "+v"(d.q), "+v"(d.s));
     rec = amov(z);
+  };
+  auto landed = [&](A3Data &d, const u32x2 &z, u32x2 &rec) __attribute__((always_inline)) {
+    gwait_but<1>();
+    asm volatile("" : "+v"(d.q), "+v"(d.s));
+    rec = amov(z);
+  };
+  const uint64_t my_dump = (uint64_t)(A.dump + ((uint64_t)blockIdx.x * A3_NT + threadIdx.x) * 16u);
+  // one block: the look-ups if the lane has one, then the store EVERY lane issues (exactly one per trip, behind the trip's loads)
+  auto work = [&](uint64_t it, bool on, u32x2 rec, const A3Data &d) __attribute__((always_inline)) {
+    u32x4 o = (u32x4){0u, 0u, 0u, 0u};
+    if (on) o = B.process(rec, d);
+    const uint64_t at = on ? (uint64_t)(A.qual + first_read(it) * len + B.qoff) : my_dump;
+    gstore_x4(at, o);
   };
   // records two trips ahead (z), data one trip ahead, two sets X / Y that swap roles
   A3Data dX, dY;
@@ -244,24 +266,24 @@ __global__ __launch_bounds__(A3_NT) void k_bqsr_apply3(Apply3Args A) {
   u32x2 rX, rY, rN, z = (u32x2){0u, 0u};  // records of the blocks in X / Y, of the next trip's block, the buffer in flight
   bool onX, onY = false;
   rec_load(0, z);
-  landed(dX, z, rX);
+  landed0(dX, z, rX);
   onX = data_load(0, rX, dX);
   rec_load(1, z);
-  landed(dX, z, rN);
+  landed0(dX, z, rN);
 #pragma unroll 1
   for (uint64_t it = 0; it < n_trips; it += 2) {
     {
       rY = rN;
       onY = data_load(it + 1, rY, dY);
       rec_load(it + 2, z);
-      if (onX) B.process(rX, dX, A.qual + first_read(it) * len + B.qoff);
+      work(it, onX, rX, dX);
       landed(dY, z, rN);
     }
     {
       rX = rN;
       onX = data_load(it + 2, rX, dX);
       rec_load(it + 3, z);
-      if (onY) B.process(rY, dY, A.qual + first_read(it + 1) * len + B.qoff);
+      work(it + 1, onY, rY, dY);
       landed(dX, z, rN);
     }
   }
@@ -284,14 +306,23 @@ int apply3_bytes(int n_cov, int n_qi, int lmax, size_t *dyn_out) {
 int apply3_launch(elp_ctx *c, int max_cycle, const uint8_t *d_lut, const uint8_t *d_cov_present, const uint16_t *t1, const uint8_t *t2, const uint32_t *n_dict_dev,
                   int n_qi, int lmax, size_t dyn) {
   const uint64_t n = c->n;
-  uint2 *recs;
-  ELP_TRY(scratch(c, 5, n + 4, &recs));
-  ELP_LAUNCH(c, "bqsr_apply_records", k_apply_records, dim3(blocks_for(n, 256)), dim3(256), 0, n, c->uniform_len, lmax, (const uint16_t *)c->flag.p,
-             (const uint16_t *)c->rgid.p, (const uint16_t *)c->rg_cov.p, (const uint64_t *)c->qbounds.p, d_cov_present, recs, c->err_flag.p);
-  Apply3Args A{n, c->uniform_len, c->qual.p, c->seq4.p + elp_ctx::SEQ_FRONT, recs, d_lut, t1, t2, n_dict_dev, c->n_cov, n_qi, lmax, max_cycle, c->err_flag.p};
-  const uint32_t bpr = (c->uniform_len + 15u) >> 4, rpi = A3_NT / bpr;
+  const uint32_t len = c->uniform_len, bpr = (len + 15u) >> 4;
+  // reads packed over the whole workgroup unless that puts the last two blocks of some read (which overlap when the length is not a
+  // multiple of 16) into different waves: then whole reads per wave
+  uint32_t group = A3_NT;
+  if ((len & 15u) && bpr > 1)
+    for (uint32_t slot = 0; slot < A3_NT / bpr; slot++)
+      if (((slot * bpr + bpr - 1u) & 63u) == 0) group = 64;
+  const uint32_t rpi = (group / bpr) * (A3_NT / group);
   const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / (dyn + 512)));
   const int grid = (int)std::min<uint64_t>((n + rpi - 1) / rpi, (uint64_t)c->n_cu * per_cu);
+  uint2 *recs;
+  const size_t dump_words = (size_t)grid * A3_NT * 2;  // 16 bytes per lane, in uint2 units
+  ELP_TRY(scratch(c, 5, n + 6 + dump_words, &recs));
+  ELP_LAUNCH(c, "bqsr_apply_records", k_apply_records, dim3(blocks_for(n, 256)), dim3(256), 0, n, len, lmax, (const uint16_t *)c->flag.p,
+             (const uint16_t *)c->rgid.p, (const uint16_t *)c->rg_cov.p, (const uint64_t *)c->qbounds.p, d_cov_present, recs, c->err_flag.p);
+  Apply3Args A{n, len, c->qual.p, c->seq4.p + elp_ctx::SEQ_FRONT, recs, d_lut, t1, t2, n_dict_dev, c->n_cov, n_qi, lmax, max_cycle, c->err_flag.p,
+               reinterpret_cast<uint8_t *>(recs + ((n + 4 + 1) & ~(uint64_t)1)), group};
   ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bqsr_apply3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
   ELP_LAUNCH(c, "bqsr_apply", k_bqsr_apply3, dim3(grid), dim3(A3_NT), dyn, A);
   return 0;

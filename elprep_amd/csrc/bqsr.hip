@@ -19,6 +19,10 @@
 
 #include "bqsr_common.hpp"
 
+#ifndef ELP_ABL
+#define ELP_ABL 0
+#endif
+
 namespace elp {
 
 struct BqCols {
@@ -146,17 +150,40 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
     }
   if (threadIdx.x == 0) lcount = 0;
   __syncthreads();
+  // the record's columns are loaded one tile ahead: a record costs a chain of dependent round trips (columns -> CIGAR, bucket entry ->
+  // known sites) and the kernel is bound by that chain, not by bytes; the next tile's columns travel with this tile's second round
+  struct Cols {
+    uint8_t has_sr, mq;
+    uint16_t f, rg;
+    int32_t r, p, pnext, tlen, nrefid;
+    uint32_t ls;
+    uint64_t q0, q1, c0, c1, qb;
+  };
+  auto load_cols = [&](uint64_t i) __attribute__((always_inline)) -> Cols {
+    Cols c;
+    c.has_sr = m.has_sr[i]; c.mq = m.mapq[i]; c.f = m.flag[i]; c.rg = m.rgid[i];
+    c.r = m.refid[i]; c.p = m.pos[i]; c.pnext = m.pnext[i]; c.tlen = m.tlen[i]; c.nrefid = m.next_refid[i];
+    c.ls = m.l_seq[i];
+    c.q0 = m.qual_off[i]; c.q1 = m.qual_off[i + 1]; c.c0 = m.cigar_off[i]; c.c1 = m.cigar_off[i + 1];
+    c.qb = m.qbounds[i];
+    return c;
+  };
+  const uint64_t i_first = (uint64_t)blockIdx.x * PF_TILES * 256 + threadIdx.x;
+  Cols nxt = {};
+  if (i_first < m.n) nxt = load_cols(i_first);
 #pragma unroll 1
   for (int tile = 0; tile < PF_TILES; tile++) {
-  const uint64_t i = ((uint64_t)blockIdx.x * PF_TILES + (uint64_t)tile) * 256 + threadIdx.x;
+  const uint64_t i = i_first + (uint64_t)tile * 256;
   bool defer = false;
+  const Cols cur = nxt;
+  if (tile + 1 < PF_TILES && i + 256 < m.n) nxt = load_cols(i + 256);
   if (i < m.n) {
-    const uint8_t has_sr = m.has_sr[i], mq = m.mapq[i];
-    const uint16_t f = m.flag[i], rg = m.rgid[i];
-    const int32_t r = m.refid[i], p = m.pos[i], pnext = m.pnext[i], tlen = m.tlen[i], nrefid = m.next_refid[i];
-    const uint32_t ls = m.l_seq[i];
-    const uint64_t q0 = m.qual_off[i], q1 = m.qual_off[i + 1], c0 = m.cigar_off[i], c1 = m.cigar_off[i + 1];
-    const uint64_t qb = m.qbounds[i];
+    const uint8_t has_sr = cur.has_sr, mq = cur.mq;
+    const uint16_t f = cur.f, rg = cur.rg;
+    const int32_t r = cur.r, p = cur.p, pnext = cur.pnext, tlen = cur.tlen, nrefid = cur.nrefid;
+    const uint32_t ls = cur.ls;
+    const uint64_t q0 = cur.q0, q1 = cur.q1, c0 = cur.c0, c1 = cur.c1;
+    const uint64_t qb = cur.qb;
     BqDesc d;
     d.D0 = d.D1 = d.D2 = BQ_NOREF; d.refid = 0; d.b1 = d.b2 = 0xFFFF; d.a = 0; d.len = 0; d.left = 0; d.right = 0; d.cov = 0; d.fl = 0; d.pad = 0;
     const uint8_t *rec_rp = nullptr;
@@ -173,8 +200,27 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
       if (recs) { rec_rp = m.ref_seq[r]; rec_rlen = m.ref_seq_len[r]; }  // issued with the CIGAR loads: one round trip for both
       uint32_t opv[5];
 #pragma unroll
+#if ELP_ABL == 6  // ablation build: no CIGAR loads (every read "<l_seq>M")
+      for (int k = 0; k < 5; k++) opv[k] = k == 0 ? (ls << 4) : 0u;
+#else
       for (int k = 0; k < 5; k++) opv[k] = (uint64_t)k < nop ? m.cigar[c0 + k] : 0u;
+#endif
       const int32_t rl = ref_lds ? s_ref_len[r] : m.ref_len[r];
+      // the same round trip: the read group's covariate index and the known-site bucket entry (read whether or not the tests below pass)
+      const uint16_t cov_rg = m.rg_cov[rg];
+      const int32_t *sv = ref_lds ? s_sites[r] : m.sites[r];
+      const int64_t ns = ref_lds ? s_nsites[r] : m.n_sites[r];
+      int64_t s_first = 0;
+#if ELP_ABL == 4  // ablation build (tools/prof/build_abl.sh): no known sites
+      if (ns < 0) {
+#else
+      if (ns > 0) {
+#endif
+        const int64_t nbuck = ((int64_t)rl >> 6) + 1;
+        int64_t bk = (int64_t)(p < rl ? p : rl) >> 6;
+        bk = bk >= nbuck ? nbuck - 1 : bk;
+        s_first = (ref_lds ? s_sidx[r] : m.site_idx[r])[bk];
+      }
       ok = p <= rl;
       bool simple = nop >= 1 && nop <= 5;
       uint32_t aoff = 0, mlen = 0, trail = 0;
@@ -247,24 +293,32 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
           defer = true;
         } else {
           // calculateSkipSlice (bqsr.go:389-414): softStart = POS, softEnd = End
-          const int32_t *sv = ref_lds ? s_sites[r] : m.sites[r];
-          const int64_t ns = ref_lds ? s_nsites[r] : m.n_sites[r];
+#if ELP_ABL == 4
+          if (ns < 0) {
+#else
           if (ns > 0) {
-            const int64_t nbuck = ((int64_t)rl >> 6) + 1;
-            int64_t bk = (int64_t)p >> 6;
-            bk = bk >= nbuck ? nbuck - 1 : bk;
-            int64_t s = (ref_lds ? s_sidx[r] : m.site_idx[r])[bk];
-            while (s < ns && sv[2 * s + 1] < p) s++;
-            for (; s < ns && sv[2 * s] <= end; s++) {
+#endif
+            // the first two candidate sites in one round trip (most reads touch none or one); any further ones from memory
+            const int2 *sv2 = reinterpret_cast<const int2 *>(sv);
+            int64_t s = s_first;
+            const int2 cand0 = s < ns ? sv2[s] : make_int2(0, 0), cand1 = s + 1 < ns ? sv2[s + 1] : make_int2(0, 0);
+            int sk_x = cand0.x, sk_y = cand0.y;  // site s
+            auto fetch = [&]() __attribute__((always_inline)) {
+              if (s == s_first + 1) { sk_x = cand1.x; sk_y = cand1.y; }
+              else if (s < ns) { const int2 t = sv2[s]; sk_x = t.x; sk_y = t.y; }
+            };
+            while (s < ns && sk_y < p) { s++; fetch(); }
+            for (; s < ns && sk_x <= end; s++, fetch()) {
+              struct { int x, y; } sk = {sk_x, sk_y};
               int fs, fe;
               if (plain) {
                 bool okc;
-                fs = get_read_coord(my_cig, (int)nop, (int)p, sv[2 * s], false, &okc);
+                fs = get_read_coord(my_cig, (int)nop, (int)p, sk.x, false, &okc);
                 if (!okc || fs < 0) fs = 0;
-                fe = get_read_coord(my_cig, (int)nop, (int)p, sv[2 * s + 1], false, &okc);
+                fe = get_read_coord(my_cig, (int)nop, (int)p, sk.y, false, &okc);
                 if (!okc || fe > len - 1) fe = len - 1;
               } else {
-                const int a0 = sv[2 * s] - p, a1 = sv[2 * s + 1] - p;
+                const int a0 = sk.x - p, a1 = sk.y - p;
                 fs = (a0 < 0 || a0 >= len) ? 0 : a0;          // !ok || < 0 -> 0
                 fe = (a1 < 0 || a1 >= len) ? len - 1 : a1;    // !ok || > len-1 -> len-1 (a1 < 0 cannot happen: End >= POS)
               }
@@ -283,7 +337,7 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
             d.D2 = p - 1;
           }
           d.left = (uint16_t)left; d.right = (uint16_t)(right < 0 ? 0xFFFF : right);
-          d.cov = (uint8_t)m.rg_cov[rg];
+          d.cov = (uint8_t)cov_rg;
           d.fl = BQ_ELIGIBLE | (rev ? BQ_REVERSED : 0) | ((f & F_LAST) ? BQ_LAST : 0) | complex_fl;
         }
       }
@@ -300,8 +354,13 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
           rc = make_rec((int)d.a, (int)d.len, (int)d.left, d.right == 0xFFFFu ? -1 : (int)d.right, d.cov, (d.fl & BQ_REVERSED) != 0, (d.fl & BQ_LAST) != 0, P,
                         P.np < 0, rec_rp, rec_rlen, (int64_t)ls);
         }
+#if ELP_ABL == 5  // ablation build: no record stores (unless ...)
+        if (rc.win == 0xDEADBEEFu)
+#endif
+        {
         reinterpret_cast<uint4 *>(recs)[2 * i] = make_uint4(rc.ref_lo, rc.ref_hi, rc.win, rc.ctxw);
         reinterpret_cast<uint4 *>(recs)[2 * i + 1] = make_uint4((uint32_t)rc.t0, rc.fl, rc.bpk, rc.dpk);
+        }
         if (rc.fl & RC_GENERAL) desc[i] = d;
       } else {
         desc[i] = d;
@@ -1540,7 +1599,7 @@ int elp_bqsr_apply(elp_ctx *c, int max_cycle, const uint8_t *lut, const uint8_t 
       // resident from quality 6 on, whatever the smallest sampled quality was
       const bool force_old = getenv("ELP_APPLY_KERNEL") && atoi(getenv("ELP_APPLY_KERNEL")) == 1;  // read per call: tests switch it
       ELP_TRY(ensure_uniform_len(c));
-      const bool want3 = !force_old && !chk && c->uniform_len > 0 && qhi >= 0;
+      const bool want3 = !force_old && !chk && c->uniform_len >= 16 && qhi >= 0;  // (apply3 works in whole 16-byte blocks)
       if (want3) qlo = 6;
       ApplyArgs A{n, c->qual_bytes, c->qual_off.p, c->seq_off.p, c->qual.p, c->seq4.p, c->flag.p, c->rgid.p, c->rg_cov.p, c->l_seq.p, c->qbounds.p,
                   dl + lut_bytes, c->tile_first.p, dl, max_cycle, c->err_flag.p, nullptr, nullptr, c->n_cov, 0, 0, lmax, 0};

@@ -28,6 +28,11 @@ __device__ __forceinline__ void gload_x1(uint32_t &v, const void *sbase, uint32_
 __device__ __forceinline__ void gload_x4(u32x4 &v, uint64_t addr) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(addr) : "memory"); }
 __device__ __forceinline__ void gload_x2(u32x2 &v, uint64_t addr) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(addr) : "memory"); }
 
+// a store the compiler does not see either: with every VMEM instruction of a loop trip written by hand the trip's wait can be COUNTED
+// (gwait_but<N>): stores share the vmcnt counter with loads on gfx9 and complete in issue order with them, so a vmcnt(0) behind a
+// block's store would also wait for that store's acknowledgement - a full write round trip exposed in every trip
+__device__ __forceinline__ void gstore_x4(uint64_t addr, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(addr), "v"(v) : "memory"); }
+
 // The wait.  It names NO registers on purpose: an operand tied to a loaded register ("+v") lets the compiler copy that register into
 // the operand's register IN FRONT of the statement - i.e. before the data has arrived (seen in the ISA of the first version: the
 // record registers were copied two instructions ahead of the s_waitcnt, and runs differed from each other at 12 M reads).  The caller
@@ -35,6 +40,10 @@ __device__ __forceinline__ void gload_x2(u32x2 &v, uint64_t addr) { asm volatile
 // whatever copies the compiler wants sit behind the wait, and every use of the loaded values depends on that second statement.
 // tests/test_asm_pipeline.py checks the generated ISA: nothing reads a load's destination between the load and the wait.
 __device__ __forceinline__ void gwait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// waits until at most N vector-memory instructions are outstanding: the N youngest (which the caller knows to be stores issued by hand,
+// unconditionally, behind every load it is waiting for) may still be on their way
+template <int N>
+__device__ __forceinline__ void gwait_but() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
 // A copy the compiler cannot move in front of the wait (volatile statements keep their order): for loaded registers whose values move
 // on to other registers while the buffer they landed in is loaded again (the record buffers of count3 / apply3).
 __device__ __forceinline__ uint32_t amov(uint32_t x) {

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""Invariant of the hand-pipelined kernels (elprep_amd/csrc/gload.hpp): between an asm global load and the next `s_waitcnt vmcnt(0)`
-nothing may read or overwrite the load's destination registers (the compiler does not know they are still in flight).  Compiles the
+"""Invariant of the hand-pipelined kernels (elprep_amd/csrc/gload.hpp): between an asm global load and the hand-placed wait that covers
+it nothing may read or overwrite the load's destination registers (the compiler does not know they are still in flight).  A wait
+`s_waitcnt vmcnt(N)` covers a load when at least N hand-written vector-memory instructions (asm statements, i.e. unconditional ones)
+follow the load in front of the wait: vector-memory instructions complete in issue order, compiler-generated ones in between can
+only push the load further from the youngest N.  Compiles the
 translation unit to ISA and walks every kernel linearly (loads issued under exec masks sit in straight-line code, so program order in
 the listing is what matters; a branch target between load and wait is treated conservatively: the pending set survives labels).
 usage: check_asm_pipeline.py <file.hip> [...]   exit code 1 on a violation"""
@@ -27,7 +30,7 @@ def check(path, hipcc="/opt/rocm/bin/hipcc"):
         subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "-ffp-contract=off", "--cuda-device-only", "-S",
                                path, "-o", tmp.name], stderr=subprocess.DEVNULL)
         lines = open(tmp.name).read().split("\n")
-    bad, kernel, pending, in_asm = [], None, set(), False
+    bad, kernel, pending, in_asm, loads = [], None, set(), False, []
     n_loads = 0
     for ln, raw in enumerate(lines, 1):
         l = raw.strip()
@@ -39,19 +42,30 @@ def check(path, hipcc="/opt/rocm/bin/hipcc"):
             continue
         m = re.match(r"^(_Z\w+):", l)
         if m:
-            kernel, pending = m.group(1), set()
+            kernel, pending, loads = m.group(1), set(), []
             continue
         if not l or l.startswith((";", ".")) or l.endswith(":"):
             continue
-        if "s_waitcnt" in l and "vmcnt(0)" in l:
+        m = re.search(r"s_waitcnt.*vmcnt\((\d+)\)", l)
+        if m:
             if in_asm:  # only the hand-placed wait counts: a compiler-inserted one may sit in a branch that is not taken
-                pending = set()
+                n = int(m.group(1))
+                loads = [ld for ld in loads if ld[1] < n]  # loads with fewer than n hand-written instructions behind them stay pending
+                pending = set().union(*[ld[0] for ld in loads]) if loads else set()
             continue
-        if in_asm and l.startswith("global_load"):
-            dst = l.split()[1].rstrip(",")
-            pending |= regs(dst)
-            n_loads += 1
-            # the address operands are read at issue: fine
+        if in_asm and (l.startswith("global_load") or l.startswith("global_store")):
+            for ld in loads:
+                ld[1] += 1
+            if l.startswith("global_load"):
+                dst = regs(l.split()[1].rstrip(","))
+                loads.append([dst, 0])
+                pending |= dst
+                n_loads += 1
+            # the address (and store data) operands are read at issue - but they must not be in flight themselves
+            srcs = regs(l.split(None, 2)[2]) if l.startswith("global_load") else regs(l)
+            hit = srcs & (pending - (dst if l.startswith("global_load") else set()))
+            if hit:
+                bad.append((kernel, ln, l, sorted(hit)))
             continue
         if pending:
             hit = regs(l) & pending
