@@ -19,10 +19,6 @@
 
 #include "bqsr_common.hpp"
 
-#ifndef ELP_ABL
-#define ELP_ABL 0
-#endif
-
 namespace elp {
 
 struct BqCols {
@@ -188,6 +184,7 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
     d.D0 = d.D1 = d.D2 = BQ_NOREF; d.refid = 0; d.b1 = d.b2 = 0xFFFF; d.a = 0; d.len = 0; d.left = 0; d.right = 0; d.cov = 0; d.fl = 0; d.pad = 0;
     const uint8_t *rec_rp = nullptr;
     int64_t rec_rlen = 0;
+    bool used_col = false, rec_skipped_walk = false;  // known-site bits of the read went into the skip column; no walk: they come with the reference window
     // recalibrateAln, bqsr.go:225-244 (+ utils.go:121-139), the part that needs no dependent load
     bool ok = !has_sr && mq > 0 && mq < 255 && !(f & (F_SECONDARY | F_DUPLICATE | F_QCFAILED)) && !(f & F_UNMAPPED) && r >= 0 && p > 0 && ls != 0 &&
               (uint64_t)ls == q1 - q0 && rg != ELP_NIL16 && r < m.n_ref;
@@ -200,27 +197,23 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
       if (recs) { rec_rp = m.ref_seq[r]; rec_rlen = m.ref_seq_len[r]; }  // issued with the CIGAR loads: one round trip for both
       uint32_t opv[5];
 #pragma unroll
-#if ELP_ABL == 6  // ablation build: no CIGAR loads (every read "<l_seq>M")
-      for (int k = 0; k < 5; k++) opv[k] = k == 0 ? (ls << 4) : 0u;
-#else
       for (int k = 0; k < 5; k++) opv[k] = (uint64_t)k < nop ? m.cigar[c0 + k] : 0u;
-#endif
       const int32_t rl = ref_lds ? s_ref_len[r] : m.ref_len[r];
-      // the same round trip: the read group's covariate index and the known-site bucket entry (read whether or not the tests below pass)
+      // the same round trip: the read group's covariate index and - when descriptors are written - the known-site bucket entry (read
+      // whether or not the tests below pass).  When RECORDS are written (count3.hip) a read that is one run of matches needs no walk over
+      // the site list: its known-site bits come with the reference window (k_ref_mark_sites); the bucket entry is then fetched only by the
+      // reads that do walk (indels; a window the record cannot describe)
       const uint16_t cov_rg = m.rg_cov[rg];
       const int32_t *sv = ref_lds ? s_sites[r] : m.sites[r];
       const int64_t ns = ref_lds ? s_nsites[r] : m.n_sites[r];
-      int64_t s_first = 0;
-#if ELP_ABL == 4  // ablation build (tools/prof/build_abl.sh): no known sites
-      if (ns < 0) {
-#else
-      if (ns > 0) {
-#endif
+      auto bucket_entry = [&]() __attribute__((always_inline)) -> int64_t {
         const int64_t nbuck = ((int64_t)rl >> 6) + 1;
         int64_t bk = (int64_t)(p < rl ? p : rl) >> 6;
         bk = bk >= nbuck ? nbuck - 1 : bk;
-        s_first = (ref_lds ? s_sidx[r] : m.site_idx[r])[bk];
-      }
+        return (int64_t)(ref_lds ? s_sidx[r] : m.site_idx[r])[bk];
+      };
+      int64_t s_first = 0;
+      if (!recs && ns > 0) s_first = bucket_entry();
       ok = p <= rl;
       bool simple = nop >= 1 && nop <= 5;
       uint32_t aoff = 0, mlen = 0, trail = 0;
@@ -293,11 +286,11 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
           defer = true;
         } else {
           // calculateSkipSlice (bqsr.go:389-414): softStart = POS, softEnd = End
-#if ELP_ABL == 4
-          if (ns < 0) {
-#else
-          if (ns > 0) {
-#endif
+          // (records: a plain run of matches whose window the record describes takes its known-site bits from the reference window)
+          const bool rec_simple = recs && !plain && len <= 1022 && (int64_t)p - 1 - (int64_t)aoff >= 16 && (int64_t)p - 1 - (int64_t)aoff + (int64_t)ls <= rec_rlen + 32;
+          rec_skipped_walk = ns > 0 && rec_simple;
+          if (ns > 0 && !rec_simple) {
+            if (recs) s_first = bucket_entry();
             // the first two candidate sites in one round trip (most reads touch none or one); any further ones from memory
             const int2 *sv2 = reinterpret_cast<const int2 *>(sv);
             int64_t s = s_first;
@@ -323,6 +316,7 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
                 fe = (a1 < 0 || a1 >= len) ? len - 1 : a1;    // !ok || > len-1 -> len-1 (a1 < 0 cannot happen: End >= POS)
               }
               set_skip_bits(skipbits, q0 + aoff, fs, fe);
+              used_col = true;
             }
           }
           d.D0 = p - 1;
@@ -353,14 +347,11 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
           else { P.v0 = (int64_t)d.D0; P.v1 = P.v2 = P.v3 = 0; P.s1 = P.s2 = P.s3 = 0; P.noref = d.D0 == BQ_NOREF ? 1u : 0u; P.np = 1; }
           rc = make_rec((int)d.a, (int)d.len, (int)d.left, d.right == 0xFFFFu ? -1 : (int)d.right, d.cov, (d.fl & BQ_REVERSED) != 0, (d.fl & BQ_LAST) != 0, P,
                         P.np < 0, rec_rp, rec_rlen, (int64_t)ls);
+          if (used_col) rc.fl |= RC_SKIPCOL;
+          else if ((rc.fl & RC_GENERAL) && rec_skipped_walk) atomicOr(&err[0], 1024u);  // (cannot happen: rec_simple restates make_rec's tests)
         }
-#if ELP_ABL == 5  // ablation build: no record stores (unless ...)
-        if (rc.win == 0xDEADBEEFu)
-#endif
-        {
         reinterpret_cast<uint4 *>(recs)[2 * i] = make_uint4(rc.ref_lo, rc.ref_hi, rc.win, rc.ctxw);
         reinterpret_cast<uint4 *>(recs)[2 * i + 1] = make_uint4((uint32_t)rc.t0, rc.fl, rc.bpk, rc.dpk);
-        }
         if (rc.fl & RC_GENERAL) desc[i] = d;
       } else {
         desc[i] = d;
@@ -382,7 +373,6 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
   if (threadIdx.x == 0) gbase = lcount ? atomicAdd(queue_n, lcount) : 0u;
   __syncthreads();
   for (uint32_t k = threadIdx.x; k < lcount; k += 256) queue[gbase + k] = lq[k];
-  (void)err;
 }
 
 // General prologue: one thread per record of `queue` (the records k_bqsr_prologue_fast left: anything but a plain "<len>M" CIGAR
@@ -401,6 +391,7 @@ __device__ inline void prologue_general(const BqCols &m, const uint64_t i, uint3
       pieces4(cg, ncg, rec_pos, P);
       rc = make_rec((int)dd.a, (int)dd.len, (int)dd.left, dd.right == 0xFFFFu ? -1 : (int)dd.right, dd.cov, (dd.fl & BQ_REVERSED) != 0, (dd.fl & BQ_LAST) != 0, P,
                     P.np < 0, m.ref_seq[dd.refid], m.ref_seq_len[dd.refid], (int64_t)m.l_seq[i]);
+      rc.fl |= RC_SKIPCOL;  // this kernel's reads have their known-site bits in the skip column
     }
     reinterpret_cast<uint4 *>(recs)[2 * i] = make_uint4(rc.ref_lo, rc.ref_hi, rc.win, rc.ctxw);
     reinterpret_cast<uint4 *>(recs)[2 * i + 1] = make_uint4((uint32_t)rc.t0, rc.fl, rc.bpk, rc.dpk);
@@ -503,6 +494,30 @@ __global__ __launch_bounds__(256) void k_pack_reference(const uint8_t *__restric
   packed[i] = (uint8_t)out;
 }
 // idx[b] = first site whose End is >= 64 b (sites are sorted and flattened, so Ends increase with the index)
+// Known sites inside the packed reference: bit 2 of the nibble of every base that lies in a site interval (the base codes use bits 0, 1
+// and 3; nib_code_differs ignores bit 2).  A read whose clipped copy is ONE run of matches then has its known-site bits in the
+// reference window the count kernel loads anyway (count3.hip): no walk over the site list and no skip-column bits for it.
+__global__ __launch_bounds__(256) void k_ref_clear_site_flags(uint32_t *__restrict__ packed_words, int64_t n_words) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_words) packed_words[i] &= 0xBBBBBBBBu;
+}
+__global__ __launch_bounds__(256) void k_ref_mark_sites(const int32_t *__restrict__ sv, int64_t ns, int64_t cap_bases, uint32_t *__restrict__ packed_words) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= ns) return;
+  int64_t lo = (int64_t)sv[2 * s] - 1, hi = (int64_t)sv[2 * s + 1] - 1;  // 0-based, inclusive
+  lo = lo < 0 ? 0 : lo;
+  hi = hi >= cap_bases ? cap_bases - 1 : hi;  // (bases behind the contig's end are "other" codes inside the allocation: flags there are harmless and exact)
+  for (int64_t j = lo; j <= hi;) {  // word by word (8 bases)
+    const int64_t w = j >> 3;
+    int64_t last = (w << 3) + 7;
+    last = last > hi ? hi : last;
+    const int a = (int)(j & 7), b = (int)(last & 7);
+    const uint32_t m = (0x44444444u >> (4 * (7 - b))) & (0x44444444u << (4 * a));
+    atomicOr(&packed_words[w], m);
+    j = last + 1;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_site_index(const int32_t *__restrict__ sv, int64_t ns, int64_t nbuck, uint32_t *__restrict__ idx) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nbuck) return;
@@ -1280,12 +1295,24 @@ static int bqsr_error(elp_ctx *c, uint32_t e) {
   if (e & 32u) return set_error(c, ELP_ERR_DATA, "BQSR requires input with read groups (reference: log.Panic, filters/bqsr.go:38)");
   if (e & 64u) return set_error(c, ELP_ERR_DATA, "ApplyBQSR: len(QUAL) != len(SEQ) (reference: index out of range panic)");
   if (e & 256u) return set_error(c, ELP_ERR_HIP, "radix sort: tile look-back timed out");
+  if (e & 1024u) return set_error(c, ELP_ERR_HIP, "BQSR prologue: a read without known-site bits took a record form that needs them (internal)");
   return set_error(c, ELP_ERR_DATA, "BQSR: device error word %u", e);
 }
 
 static int sync_bqsr_ptrs(elp_ctx *c) {
   if (!c->bqsr_ptrs_dirty) return 0;
   const size_t nr = (size_t)c->n_ref;
+  // known-site flags of the packed contigs whose reference or site list changed (either order of the two setters)
+  for (size_t r = 0; r < nr; r++) {
+    if (!c->ref_flags_dirty[r] || !c->h_ref_seq[r]) continue;
+    const int64_t len = c->h_ref_seq_len[r], n_words = ((len + 1) / 2 + REF_PAD) / 4;
+    uint32_t *pw = reinterpret_cast<uint32_t *>(c->h_ref_seq[r]);
+    hipLaunchKernelGGL(k_ref_clear_site_flags, dim3(blocks_for((uint64_t)std::max<int64_t>(n_words, 1), 256)), dim3(256), 0, c->stream, pw, n_words);
+    if (c->h_sites[r] && c->h_n_sites[r] > 0)
+      hipLaunchKernelGGL(k_ref_mark_sites, dim3(blocks_for((uint64_t)c->h_n_sites[r], 256)), dim3(256), 0, c->stream, (const int32_t *)c->h_sites[r], c->h_n_sites[r], n_words * 8, pw);
+    ELP_HIP(c, hipGetLastError());
+    c->ref_flags_dirty[r] = 0;
+  }
   ELP_TRY(ensure(c, c->d_ref_seq, nr + 1));
   ELP_TRY(ensure(c, c->d_ref_seq_len, nr + 1));
   ELP_TRY(ensure(c, c->d_sites, nr + 1));
@@ -1507,6 +1534,7 @@ int elp_bqsr_set_reference(elp_ctx *c, int32_t refid, const uint8_t *bases, int6
   ELP_HIP(c, hipStreamSynchronize(c->stream));
   c->h_ref_seq[refid] = d;
   c->h_ref_seq_len[refid] = len;
+  c->ref_flags_dirty[refid] = 1;
   c->bqsr_ptrs_dirty = true;
   return 0;
 }
@@ -1530,6 +1558,7 @@ int elp_bqsr_set_known_sites(elp_ctx *c, int32_t refid, const int32_t *start_end
   c->h_site_idx[refid] = ix;
   c->h_sites[refid] = d;
   c->h_n_sites[refid] = n;
+  c->ref_flags_dirty[refid] = 1;
   c->bqsr_ptrs_dirty = true;
   return 0;
 }

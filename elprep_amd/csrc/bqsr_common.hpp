@@ -152,7 +152,8 @@ struct __attribute__((aligned(16))) BqRec {
   uint32_t fl, bpk, dpk;
 };
 static_assert(sizeof(BqRec) == 32, "BqRec is loaded as two 16-byte words");
-enum : uint32_t { RC_REV = 1u << 8, RC_PAR = 1u << 9, RC_NEG = 1u << 10, RC_MULTI = 1u << 11, RC_GENERAL = 1u << 12 };
+enum : uint32_t { RC_REV = 1u << 8, RC_PAR = 1u << 9, RC_NEG = 1u << 10, RC_MULTI = 1u << 11, RC_GENERAL = 1u << 12,
+                  RC_SKIPCOL = 1u << 13 };  // the read's known-site bits are in the skip column (else: the flags of its reference window)
 
 // pieces of a clipped CIGAR (see BqDesc), up to four; np = -1: more
 struct Pieces4 {

@@ -125,6 +125,7 @@ struct elp_ctx {
   std::vector<int64_t> h_ref_seq_len;
   std::vector<int32_t *> h_sites;    // device pointers per refid, [n][2]
   std::vector<int64_t> h_n_sites;
+  std::vector<uint8_t> ref_flags_dirty;  // per refid: the known-site flags inside the packed reference (bit 2 of a base's nibble) are stale
   std::vector<uint32_t *> h_site_idx;  // device pointers per refid: per 64-bp bucket b the first site whose end is >= 64 b
   elp::DVec<uint8_t *> d_ref_seq;
   elp::DVec<int64_t> d_ref_seq_len;

@@ -23,6 +23,8 @@
 //   - per base: one LDS look-up quality -> row, two 32-bit LDS atomics of a 0 / 1 value (cycle cell, context cell); the rare mismatch
 //     counts are added by a short loop over the set bits of the block's mismatch word;
 //   - the context cells are replicated over the LDS banks (cell * R + lane % R; rows are multiples of 32 words).
+//   - a read that is one run of matches takes its known-site bits from the reference window (bit 2 of a nibble, k_ref_mark_sites in
+//     bqsr.hip): no skip-column load for it; reads with indels or clipped windows carry RC_SKIPCOL and read the column as before.
 // Row of the workgroup-private table (32-bit words), n_q + 3 rows per covariate (extra rows: bad quality, quality without a slot, not
 // counted - as k_bqsr_count):
 //   [0, 16 R)            context observations, cell cx replica r at cx * R + r
@@ -130,7 +132,8 @@ struct Count3 {
     qlow = bit & 7u;
     if (!on || k0 + nb <= a || k0 >= e) return false;
     gload_x4(d.q, qual_t, qoff);
-    gload_x1(d.skipw, skip_t, bit >> 3);
+    d.skipw = 0u;
+    if (rb.y & RC_SKIPCOL) gload_x1(d.skipw, skip_t, bit >> 3);  // else: the flags of the reference window
     gload_x4(d.s, seq_t, soff);
     const uint64_t rp = ((uint64_t)ra.x | ((uint64_t)ra.y << 32)) + ((rb.y & RC_GENERAL) ? 0u : (k0 >> 1));
     gload_x4(d.w03, rp);
@@ -214,19 +217,27 @@ struct Count3 {
     const uint32_t N_lo = __builtin_amdgcn_alignbit(d.s.y, d.s.x, ns), N_hi = __builtin_amdgcn_alignbit(d.s.z, d.s.y, ns);
     const uint32_t oS_lo = (S_lo >> 3) & N1, oS_hi = (S_hi >> 3) & N1;  // not A / C / G / T
     const uint32_t oN_lo = (N_lo >> 3) & N1, oN_hi = (N_hi >> 3) & N1;
-    // known-site bits of the block -> nibble flags (LDS table: bit i of a byte -> bit 4 i)
-    const uint32_t sk = d.skipw >> qlow;
-    const uint32_t k_lo = lds_read_u32(spread_at + ((sk & 0xFFu) << 2)), k_hi = lds_read_u32(spread_at + ((sk >> 6) & 0x3FCu));
+    // reference nibbles of a read that is one run of matches: nibble 16 + parity of the window = words 2, 3, 4.  Bit 2 of a nibble =
+    // the base lies in a known site (k_ref_mark_sites, bqsr.hip)
+    uint32_t R_lo = 0, R_hi = 0, k_lo = 0, k_hi = 0;
+    const bool one_run = !(fl & (RC_MULTI | RC_GENERAL));
+    if (one_run) {
+      const uint32_t sh = (fl & RC_PAR) ? 4u : 0u;
+      R_lo = __builtin_amdgcn_alignbit(d.w03.w, d.w03.z, sh);
+      R_hi = __builtin_amdgcn_alignbit(d.w45.x, d.w03.w, sh);
+      k_lo = (R_lo >> 2) & N1;
+      k_hi = (R_hi >> 2) & N1;
+    }
+    if (fl & RC_SKIPCOL) {  // known-site bits from the skip column -> nibble flags (LDS table: bit i of a byte -> bit 4 i)
+      const uint32_t sk = d.skipw >> qlow;
+      k_lo |= lds_read_u32(spread_at + ((sk & 0xFFu) << 2));
+      k_hi |= lds_read_u32(spread_at + ((sk >> 6) & 0x3FCu));
+    }
     const uint64_t inw = nib_range(blo, bhi);
     const uint32_t F_lo = (uint32_t)inw & ~(oS_lo | k_lo), F_hi = (uint32_t)(inw >> 32) & ~(oS_hi | k_hi);
     if ((F_lo | F_hi) == 0u) return;
     // SNP events (computeSnpEvents, bqsr.go:254-285): read nibble vs reference nibble
-    uint32_t R_lo, R_hi;
-    if (!(fl & (RC_MULTI | RC_GENERAL))) {
-      const uint32_t sh = (fl & RC_PAR) ? 4u : 0u;  // nibble 16 + parity of the window = words 2, 3, 4
-      R_lo = __builtin_amdgcn_alignbit(d.w03.w, d.w03.z, sh);
-      R_hi = __builtin_amdgcn_alignbit(d.w45.x, d.w03.w, sh);
-    } else {
+    if (!one_run) {
       const uint64_t S = (uint64_t)S_lo | ((uint64_t)S_hi << 32);
       const uint64_t R = (fl & RC_GENERAL) ? c3_ref_general(desc, cigar, cig_scratch, ref_seq, ref_seq_len, r, S, blo, bhi, (int)k0 - a) : ref_pieces(d, fl, f.bpk, f.dpk, S, blo, bhi, (int)k0 - a);
       R_lo = (uint32_t)R;

@@ -175,6 +175,7 @@ int elp_set_header(elp_ctx *c, const elp_header *h) {
   c->h_sites.resize(h->n_ref, nullptr);
   c->h_site_idx.resize(h->n_ref, nullptr);
   c->h_n_sites.resize(h->n_ref, 0);
+  c->ref_flags_dirty.assign(h->n_ref, 0);
   c->bqsr_ptrs_dirty = true;
   c->have_header = true;
   return 0;

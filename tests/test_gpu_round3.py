@@ -238,3 +238,35 @@ def test_one_length_runs_are_reproducible():
         e.close()
     assert all(np.array_equal(a, b_) for a, b_ in zip(tabs[0], tabs[1]))
     assert np.array_equal(quals[0], quals[1])
+
+
+def test_known_sites_and_reference_in_either_order_and_replaced():
+    """the known-site flags live inside the packed reference (bit 2 of a base's nibble): whichever of set_reference / set_known_sites
+    comes last, and a site list that replaces another one, must leave exactly the flags of the current list"""
+    b, h, refs, sites = _uniform_case(21, 4000, 150, quals=[2, 6, 13, 27, 38], ref_len=(5000, 3000))
+    flags = orc.mark_duplicates(b, h)
+    oq, oc, ox = orc.bqsr_gather(b, h, orc.BqsrRef(refs, sites), flags, 500)
+    other = [np.ascontiguousarray(s + 7) for s in sites]  # every interval moved by seven bases
+    oq2, oc2, ox2 = orc.bqsr_gather(b, h, orc.BqsrRef(refs, other), flags, 500)
+    assert not np.array_equal(oc, oc2)
+    e = Engine(h)
+    e.stage(b)
+    e.mark_duplicates(True)
+    for r in range(h.n_ref):  # sites first, reference second
+        e.set_known_sites(r, sites[r])
+        e.set_reference(r, refs[r])
+    qt, ct, xt = e.recalibrate(500)
+    assert np.array_equal(ct, oc) and np.array_equal(xt, ox) and np.array_equal(qt, oq)
+    for r in range(h.n_ref):  # another list replaces the first one: no flag of the first list may survive
+        e.set_known_sites(r, other[r])
+    qt, ct, xt = e.recalibrate(500)
+    assert np.array_equal(ct, oc2) and np.array_equal(xt, ox2) and np.array_equal(qt, oq2)
+    for r in range(h.n_ref):  # the reference set again behind the sites, then the first list again
+        e.set_reference(r, refs[r])
+    qt, ct, xt = e.recalibrate(500)
+    assert np.array_equal(ct, oc2)
+    for r in range(h.n_ref):
+        e.set_known_sites(r, sites[r])
+    qt, ct, xt = e.recalibrate(500)
+    assert np.array_equal(ct, oc) and np.array_equal(xt, ox) and np.array_equal(qt, oq)
+    e.close()
