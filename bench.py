@@ -220,12 +220,13 @@ def main():
 
         def step_full():
             eng.mark_duplicates(True, fetch=False)
-            eng.sort_coordinate(fetch=False)
             eng.recalibrate_device(MAX_CYCLE)
-            # the tables' way to the host, the float64 finalisation + LUT (host thread; the copy runs on the context's copy stream) and
-            # the duplication-metrics pass (device, this thread) do not depend on each other: the host finalises while the GPU counts
-            # (the reference runs them one after the other, cmd/filter.go:162-196)
+            # the tables' way to the host, the float64 finalisation + LUT (host thread; the copy runs on the context's copy stream) on one
+            # side, the coordinate sort and the duplication-metrics pass (device, this thread) on the other do not depend on each other:
+            # the host finalises while the GPU sorts and counts (the reference runs them one after the other, cmd/filter.go:162-196;
+            # its sort is the pipeline's Finalize and needs nothing of BQSR either)
             fin = host_pool.submit(lambda: finalize_lut(*eng.tables_fetch(reuse=True)))
+            eng.sort_coordinate(fetch=False)
             eng.dup_metrics(100)
             lut, present = fin.result()
             eng.apply_bqsr(lut, present, MAX_CYCLE, fetch=False)
