@@ -392,8 +392,13 @@ __global__ __launch_bounds__(256) void k_pair_insert(MdCols m, const uint4 *__re
   const uint32_t rep = find_or_insert(table, mask, h, (uint32_t)i,
                                       [&](uint32_t a, uint32_t) { return pair_key_eq(pair_key(fkey[a], fkey[mate[a]]), mine); });
   prep[i] = rep;
-  const int32_t sc = m.score[i] + m.score[mt];  // :342
-  atomicMax(&pbest[rep], (unsigned long long)(uint32_t)sc);
+  // best score of the key (:342), plus one - and only once a SECOND pair arrives at the key: nine pairs in ten are the only one of theirs,
+  // their word stays 0 ("nothing to decide": k_pair_tie) and costs no atomic (the kernel runs at the atomic rate of the
+  // memory system, profiles/r2v_random_access_probe_48M.txt; this halves its atomics).  The later pair brings the first one's score along.
+  if (rep != (uint32_t)i) {
+    const int32_t sc = m.score[i] + m.score[mt], scr = m.score[rep] + m.score[mate[rep]];
+    atomicMax(&pbest[rep], (unsigned long long)(uint32_t)(sc > scr ? sc : scr) + 1ull);
+  }
 }
 
 __global__ __launch_bounds__(256) void k_pair_tie(MdCols m, const uint32_t *__restrict__ mate, const uint32_t *__restrict__ prep,
@@ -402,8 +407,10 @@ __global__ __launch_bounds__(256) void k_pair_tie(MdCols m, const uint32_t *__re
   if (i >= m.n) return;
   const uint32_t rep = prep[i];
   if (rep == EMPTY) return;
+  const unsigned long long best = pbest[rep];
+  if (best == 0) { pwinner[rep] = (uint32_t)i; return; }  // the only pair of its key (rep == i): it wins, no tournament
   const int32_t sc = m.score[i] + m.score[mate[i]];
-  if ((unsigned long long)(uint32_t)sc != pbest[rep]) return;
+  if ((unsigned long long)(uint32_t)sc + 1ull != best) return;
   tournament(m, &pwinner[rep], (uint32_t)i);  // both mates share the QNAME, so the owner's QNAME stands for aln1.QNAME (:383)
 }
 
