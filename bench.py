@@ -244,6 +244,7 @@ def main():
 
     t0 = time.time()
     stage_s = 0.0
+    route_s = 0.0  # sfm: classifying the generated records by split and exchanging the few that belong to another rank
     dev_id = local_rank if world > 1 else 0
     per_rank_reads = None
     if world == 1:
@@ -306,7 +307,9 @@ def main():
         gen = generated(jobs)
         for _ in range(int(rounds.item())):
             b = next(gen, None)
+            tr = time.time()
             got = sfm.route(b if b is not None else sfm.empty_batch(), gof, G, owner, comm)
+            route_s += time.time() - tr
             ts = time.time()
             rk.stage(0, got.local)
             rk.stage(1, got.spread)
@@ -336,7 +339,7 @@ def main():
         counts = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(world)]
         dist.all_gather(counts, torch.tensor([n_total], dtype=torch.int64, device=cdev))
         per_rank_reads = [int(c.item()) for c in counts]
-    gen_s = time.time() - t0 - stage_s
+    gen_s = time.time() - t0 - stage_s - route_s
 
     elapsed, prof = timed(step, restore, args.steps, args.warmup, prof_eng, barrier)
 
@@ -381,6 +384,11 @@ def main():
                         "elp_stage_Mreads_per_s": round(n_total / max(stage_s, 1e-9) / 1e6, 2)},
         }
         if world > 1:
+            # what the first multi-GPU record needs to be read without a second run: the collective's share of a step (the wait for the
+            # slowest rank included: the call is entered behind a stream sync) and the set-up's record exchange
+            ar = rk.allreduce_s[-args.steps:]
+            out["allreduce_ms_per_step"] = round(sum(ar) / max(len(ar), 1) * 1e3, 3)
+            out["staging"]["route_s"] = round(route_s, 2)
             out["ranks_seen"] = dist.get_world_size()
             out["per_rank_reads"] = per_rank_reads
             out["imbalance_max_over_mean"] = round(max(per_rank_reads) / (sum(per_rank_reads) / len(per_rank_reads)), 4)

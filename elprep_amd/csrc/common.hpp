@@ -142,6 +142,8 @@ struct elp_ctx {
   int tables_max_cycle = 0;
   // device group (group.hip)
   void *comm = nullptr;  // ncclComm_t
+  int (*xport)(void *, int64_t *, size_t) = nullptr;  // caller's transport instead of RCCL (elp_group_init_transport)
+  void *xport_user = nullptr;
   int group_rank = 0, group_world = 1;
 
   // records staged from BAM bytes (bam.hip): the inflated records stay in HBM, elp_emit_sorted_bam reads bases and tags from them

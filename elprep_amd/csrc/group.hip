@@ -105,12 +105,37 @@ int elp_group_init(elp_ctx *c, int rank, int world, const uint8_t *id) {
   return 0;
 }
 
+int elp_group_init_transport(elp_ctx *c, int rank, int world, elp_allreduce_fn allreduce, void *user) {
+  if (!c || world < 1 || rank < 0 || rank >= world || (world > 1 && !allreduce)) return set_error(c, ELP_ERR_ARG, "elp_group_init_transport: bad arguments");
+  if (c->comm) return set_error(c, ELP_ERR_ARG, "elp_group_init_transport: the context already belongs to an RCCL group");
+  c->group_rank = rank;
+  c->group_world = world;
+  c->xport = world > 1 ? allreduce : nullptr;
+  c->xport_user = user;
+  return 0;
+}
+
 int elp_group_rank(const elp_ctx *c) { return c ? c->group_rank : -1; }
 int elp_group_size(const elp_ctx *c) { return c ? c->group_world : 0; }
 
 // sum over the group of n int64 values in device memory, in place, on the ctx stream (no host hop)
 static int allreduce_device(elp_ctx *c, unsigned long long *buf, size_t n) {
   if (c->group_world <= 1 || n == 0) return 0;
+  if (c->xport) {  // the caller's transport: through page-locked host memory
+    const size_t bytes = n * 8;
+    if (bytes > c->h_pinned_cap) {
+      if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+      c->h_pinned = nullptr; c->h_pinned_cap = 0;
+      ELP_HIP(c, hipHostMalloc(&c->h_pinned, bytes, hipHostMallocDefault));
+      c->h_pinned_cap = bytes;
+    }
+    ELP_HIP(c, hipMemcpyAsync(c->h_pinned, buf, bytes, hipMemcpyDeviceToHost, c->stream));
+    ELP_HIP(c, hipStreamSynchronize(c->stream));
+    const int rc = c->xport(c->xport_user, static_cast<int64_t *>(c->h_pinned), n);
+    if (rc != 0) return set_error(c, ELP_ERR_HIP, "the group's transport failed (allreduce callback returned %d)", rc);
+    ELP_HIP(c, hipMemcpyAsync(buf, c->h_pinned, bytes, hipMemcpyHostToDevice, c->stream));
+    return 0;
+  }
   if (!c->comm) return set_error(c, ELP_ERR_ARG, "no device group: call elp_group_init first");
   Rccl *R = rccl();
   ELP_NCCL(c, R->AllReduce(buf, buf, n, ncclInt64, ncclSum, static_cast<ncclComm_t>(c->comm), c->stream));

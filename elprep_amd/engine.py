@@ -284,6 +284,17 @@ class Engine:
         buf = (C.c_uint8 * 128).from_buffer_copy(uid) if uid is not None else None
         self._check(self.L.elp_group_init(self.h, rank, world, buf))
 
+    def group_init_transport(self, rank: int, world: int, allreduce):
+        """the group over the caller's transport: allreduce(values: np.ndarray[int64]) sums over the ranks in place (elp_group_init_transport)"""
+        def cb(_user, ptr, n):
+            try:
+                allreduce(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int64)), shape=(n,)))
+                return 0
+            except Exception:  # noqa: BLE001 - reported through the C ABI's return code
+                return 1
+        self._xport_cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)(cb)  # kept alive with the engine
+        self._check(self.L.elp_group_init_transport(self.h, rank, world, C.cast(self._xport_cb, C.c_void_p), C.c_void_p(0)))
+
     def allreduce_i64(self, a: np.ndarray) -> np.ndarray:
         out = np.ascontiguousarray(a, dtype=np.int64).copy()
         self._check(self.L.elp_allreduce_i64(self.h, _vp(out), out.size))

@@ -24,6 +24,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
+import time
+
 import numpy as np
 
 from .batch import Batch, Header, _COLS
@@ -260,6 +262,7 @@ class SfmRank:
         self.header, self.comm = header, comm
         self.engines = [Engine(header, device_ordinal), Engine(header, device_ordinal)]
         self.n = [0, 0]
+        self.allreduce_s = []  # wall time of every all-reduce call (bench.py reports the timed steps' mean)
         if collective is None:
             collective = os.environ.get("ELP_SFM_COLLECTIVE", "cabi" if (comm.world > 1 and comm.device.type == "cuda") else "torch")
         self.collective = collective if comm.world > 1 else "none"
@@ -322,7 +325,9 @@ class SfmRank:
                 flat = np.concatenate([qt.ravel(), ct.ravel(), xt.ravel(), ctr.ravel()])
                 tot = flat if tot is None else tot + flat
                 shapes = (qt.shape, ct.shape, xt.shape, ctr.shape)
+            t0 = time.perf_counter()
             tot = self.comm.allreduce_i64(tot)
+            self.allreduce_s.append(time.perf_counter() - t0)
             out, at = [], 0
             for shp in shapes:
                 n = int(np.prod(shp))
@@ -338,7 +343,10 @@ class SfmRank:
             e.recalibrate_device(max_cycle)  # tables stay in HBM
         e0 = self.engines[0]
         e0.tables_add(self.engines[1])       # this rank's splits, summed on the device
+        e0.sync()                            # (so that the time below is the collective - and the wait for the slowest rank - alone)
+        t0 = time.perf_counter()
         ctr = e0.tables_allreduce(ctr)       # RCCL, in place on the tables in HBM; the counters ride along
+        self.allreduce_s.append(time.perf_counter() - t0)
         qt, ct, xt = e0.tables_fetch(reuse=True)
         return qt, ct, xt, ctr
 

@@ -245,6 +245,12 @@ int elp_bqsr_tables_fetch(elp_ctx *ctx, int64_t *qual_tbl, int64_t *cycle_tbl, i
 int elp_group_probe(void); /* 0 if the communication library (RCCL) can be loaded and has every entry point the group needs; no GPU needed */
 int elp_group_unique_id(uint8_t *id_out /* ELP_GROUP_ID_BYTES */);
 int elp_group_init(elp_ctx *ctx, int rank, int world, const uint8_t *id /* ELP_GROUP_ID_BYTES; may be NULL if world == 1 */);
+/* The same group over a transport of the caller's (a host without RCCL, or a host program that already has its own communicator - MPI,
+ * gloo, the Go side's net/rpc): `allreduce` must sum `n` int64 values over all ranks, in place, and return 0; it is called on the calling
+ * thread of elp_bqsr_tables_allreduce / elp_allreduce_i64 with a page-locked host buffer (the device tables make one round trip over PCIe).
+ * Replaces: nothing in the reference (elprep sfm merges per-split tables through files, cmd/split-filter-merge.go:413-470). */
+typedef int (*elp_allreduce_fn)(void *user, int64_t *values, size_t n);
+int elp_group_init_transport(elp_ctx *ctx, int rank, int world, elp_allreduce_fn allreduce, void *user);
 int elp_group_rank(const elp_ctx *ctx);
 int elp_group_size(const elp_ctx *ctx);
 int elp_bqsr_tables_add(elp_ctx *dst, elp_ctx *src);

@@ -270,3 +270,49 @@ def test_known_sites_and_reference_in_either_order_and_replaced():
     qt, ct, xt = e.recalibrate(500)
     assert np.array_equal(ct, oc) and np.array_equal(xt, ox) and np.array_equal(qt, oq)
     e.close()
+
+
+def test_tables_allreduce_through_a_caller_supplied_transport():
+    """elp_group_init_transport: two contexts (two 'ranks' of one process, each on its own thread) sum their device tables through a
+    host reduction the test supplies; the extra counters ride behind the tables in the same call (the tail packing of
+    elp_bqsr_tables_allreduce) and come back summed on both ranks"""
+    import threading
+    cfg, b, h, refs, sites = dataset("tiny", 24000, 5, 0.02)
+    parts = [b.take(np.arange(0, b.n // 2)), b.take(np.arange(b.n // 2, b.n))]
+    engs, own = [], []
+    for part in parts:
+        e = Engine(h)
+        e.stage(part)
+        for r in range(h.n_ref):
+            e.set_reference(r, refs[r])
+            e.set_known_sites(r, sites[r])
+        e.recalibrate_device(500)
+        own.append([t.copy() for t in e.tables_fetch()])
+        engs.append(e)
+    assert own[0][1].sum() > 0 and own[1][1].sum() > 0
+    shared, barrier = {}, threading.Barrier(2)
+
+    def transport(rank):
+        def allreduce(values):
+            shared[rank] = values.copy()
+            barrier.wait()
+            total = shared[0] + shared[1]
+            barrier.wait()
+            values[:] = total
+        return allreduce
+    for rank, e in enumerate(engs):
+        e.group_init_transport(rank, 2, transport(rank))
+    got = [None, None]
+
+    def run(rank):
+        got[rank] = engs[rank].tables_allreduce(np.array([rank + 1, 10 * (rank + 1), 7], dtype=np.int64))
+    ths = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for rank, e in enumerate(engs):
+        assert got[rank].tolist() == [3, 30, 14]
+        for have, a, bb in zip(e.tables_fetch(), own[0], own[1]):
+            assert np.array_equal(have, a + bb)
+        e.close()
