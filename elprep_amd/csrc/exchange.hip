@@ -1,0 +1,231 @@
+// exchange.hip — records from one context's column store to another's without a trip through the host.
+//
+// Reference: `elprep split` / `sfm` phase 1 (sam/split-merge.go:280-293: SplitFilePerChromosome writes a record to the file of its
+// contig group - and, if its mate lies in another group, to the spread file as well, leaving an sr:i:1 tagged copy in the group file).
+// A Go host is ONE process that drives all GPUs of a node through cgo, one context per GPU (or several per GPU): the split phase is then
+// elp_split_classify on the context that decoded the records and elp_copy_records into the contexts that own the splits - column slices
+// gathered on the source GPU and copied device to device (hipMemcpyPeerAsync over xGMI between GPUs).  One process per GPU (bench.py
+// --gpus N, torch.distributed) exchanges through the harness instead (sfm.route).
+//
+// A record = its eleven fixed columns + its slices of QNAME, CIGAR, SEQ (already code nibbles), QUAL and - if both contexts hold the
+// inflated BAM records (elp_stage_bam) - of those.  The mutable columns (FLAG, QUAL) travel as they are now.
+#include <algorithm>
+
+#include "common.hpp"
+
+namespace elp {
+
+constexpr int XV = 5;  // variable-length columns: QNAME bytes, CIGAR operations, SEQ bytes, QUAL bytes, raw BAM bytes
+struct XSrc {
+  uint64_t n_src;
+  const int32_t *refid, *pos, *next_refid, *pnext, *tlen;
+  const uint16_t *flag, *rgid, *split;
+  const uint8_t *mapq, *has_sr;
+  const uint32_t *l_seq;
+  const uint64_t *off[XV];  // offset columns (n_src + 1); off[4] may be null
+};
+struct XFixed {
+  int32_t *refid, *pos, *next_refid, *pnext, *tlen;
+  uint16_t *flag, *rgid, *split;
+  uint8_t *mapq, *has_sr;
+  uint32_t *l_seq;
+};
+// counters: 0 max QNAME length, 1 max L_SEQ, 2 max POS (as uint32), 3 max split id, 4 records with state != 0, 5 with state 2, 6 bad index
+enum { XC_QNAME, XC_LSEQ, XC_POS, XC_SPLIT, XC_NSR, XC_NFILT, XC_BAD, XC_N };
+
+// lengths of the selected records' slices, the fixed columns, the limits the staging bookkeeping needs
+__global__ __launch_bounds__(256) void k_x_fixed(uint64_t n, const uint32_t *__restrict__ idx, XSrc s, XFixed d, uint32_t *__restrict__ len /* [XV][n] */,
+                                                 int new_split, int tag_sr, uint32_t *ctr) {
+  __shared__ uint32_t acc[XC_N];
+  if (threadIdx.x < XC_N) acc[threadIdx.x] = 0;
+  __syncthreads();
+  const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) {
+    const uint64_t i = idx[k];
+    if (i >= s.n_src) {
+      atomicAdd(&acc[XC_BAD], 1u);
+      for (int v = 0; v < XV; v++) len[(size_t)v * n + k] = 0;
+    } else {
+      uint8_t state = s.has_sr[i];
+      if (tag_sr && state == 0) state = 1;
+      const uint16_t sp = new_split >= 0 ? (uint16_t)new_split : s.split[i];
+      const int32_t p = s.pos[i];
+      const uint32_t ls = s.l_seq[i];
+      d.refid[k] = s.refid[i]; d.pos[k] = p; d.next_refid[k] = s.next_refid[i]; d.pnext[k] = s.pnext[i]; d.tlen[k] = s.tlen[i];
+      d.flag[k] = s.flag[i]; d.rgid[k] = s.rgid[i]; d.split[k] = sp; d.mapq[k] = s.mapq[i]; d.has_sr[k] = state; d.l_seq[k] = ls;
+      uint32_t ql = 0;
+      for (int v = 0; v < XV; v++) {
+        const uint32_t l = s.off[v] ? (uint32_t)(s.off[v][i + 1] - s.off[v][i]) : 0u;
+        len[(size_t)v * n + k] = l;
+        if (v == 0) ql = l;
+      }
+      atomicMax(&acc[XC_QNAME], ql);
+      atomicMax(&acc[XC_LSEQ], ls);
+      atomicMax(&acc[XC_POS], (uint32_t)p);
+      atomicMax(&acc[XC_SPLIT], (uint32_t)sp);
+      if (state) atomicAdd(&acc[XC_NSR], 1u);
+      if (state == 2) atomicAdd(&acc[XC_NFILT], 1u);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < XC_N && acc[threadIdx.x]) {
+    if (threadIdx.x <= XC_SPLIT) atomicMax(&ctr[threadIdx.x], acc[threadIdx.x]);
+    else atomicAdd(&ctr[threadIdx.x], acc[threadIdx.x]);
+  }
+}
+
+// one wave per record and column: the record's slice, 64 elements per step
+template <class T>
+__global__ __launch_bounds__(256) void k_x_var(uint64_t n, const uint32_t *__restrict__ idx, const uint64_t *__restrict__ src_off, const T *__restrict__ src,
+                                               const uint32_t *__restrict__ dst_off, T *__restrict__ dst, uint64_t n_src) {
+  const uint64_t k = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (k >= n) return;
+  const uint64_t i = idx[k];
+  if (i >= n_src) return;
+  const uint64_t a = src_off[i], e = src_off[i + 1];
+  const uint32_t o = dst_off[k];
+  for (uint64_t j = a + (threadIdx.x & 63u); j < e; j += 64) dst[o + (j - a)] = src[j];
+}
+
+__global__ __launch_bounds__(256) void k_x_offsets(uint64_t n_plus_1, const uint32_t *__restrict__ excl, uint32_t total, uint64_t base, uint64_t *__restrict__ out) {
+  const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n_plus_1) out[k] = base + (k + 1 == n_plus_1 ? (uint64_t)total : (uint64_t)excl[k]);
+}
+
+static int peer_copy(elp_ctx *dst, void *to, elp_ctx *src, const void *from, size_t bytes) {
+  if (!bytes) return 0;
+  if (dst->device == src->device) ELP_HIP(src, hipMemcpyAsync(to, from, bytes, hipMemcpyDeviceToDevice, src->stream));
+  else ELP_HIP(src, hipMemcpyPeerAsync(to, dst->device, from, src->device, bytes, src->stream));
+  return 0;
+}
+
+}  // namespace elp
+
+using namespace elp;
+
+extern "C" int elp_copy_records(elp_ctx *dst, elp_ctx *src, const uint32_t *idx, uint64_t n, int new_split, int tag_sr) {
+  if (!dst || !src || dst == src || (!idx && n)) return set_error(dst, ELP_ERR_ARG, "elp_copy_records: bad arguments");
+  if (!dst->have_header || !src->have_header || dst->n_ref != src->n_ref || dst->n_rg != src->n_rg || dst->h_ref_len != src->h_ref_len)
+    return set_error(dst, ELP_ERR_ARG, "elp_copy_records: the two contexts need the same header");
+  if (new_split > 0xFFFF) return set_error(dst, ELP_ERR_ARG, "elp_copy_records: split id %d", new_split);
+  if (n == 0) return 0;
+  std::lock(dst->stage_mu, src->stage_mu);
+  std::lock_guard<std::mutex> g1(dst->stage_mu, std::adopt_lock), g2(src->stage_mu, std::adopt_lock);
+  if (dst->n + n > 0xFFFFFFF0ull) return set_error(dst, ELP_ERR_UNSUPPORTED, "more than 2^32-16 records per context");
+  // the inflated BAM records travel if both sides hold them for every record they have (else the destination could not emit)
+  const bool src_raw = src->raw_n == src->n && src->n > 0, dst_raw = dst->raw_n == dst->n && (dst->n > 0 || src_raw);
+  if ((src->raw_n && !src_raw) || (dst->raw_n && !dst_raw) || (dst->n > 0 && (dst->raw_n > 0) != src_raw))
+    return set_error(dst, ELP_ERR_UNSUPPORTED, "elp_copy_records: either both contexts hold the inflated BAM records of all their reads (elp_stage_bam) or neither does");
+  const bool raw = src_raw;
+
+  // ---- source GPU: lengths + fixed columns, scans, slices
+  ELP_HIP(src, hipSetDevice(src->device));
+  hipStream_t ss = src->stream;
+  uint32_t *w;  // idx | len[XV][n] | excl[XV][n + 1] | counters
+  ELP_TRY(scratch(src, 6, n + (size_t)XV * n + (size_t)XV * (n + 1) + 64, &w));
+  uint32_t *d_idx = w, *len = w + n, *excl = len + (size_t)XV * n, *ctr = excl + (size_t)XV * (n + 1);
+  ELP_HIP(src, hipMemcpyAsync(d_idx, idx, n * 4, hipMemcpyHostToDevice, ss));
+  ELP_HIP(src, hipMemsetAsync(ctr, 0, XC_N * 4, ss));
+  uint8_t *fx;
+  ELP_TRY(scratch(src, 5, n * 40 + 256, &fx));  // 5 x 4 + 3 x 2 + 2 x 1 + 4 = 32 bytes per record, every array 16-byte aligned
+  const size_t n16 = (n + 15) & ~(size_t)15;
+  XFixed F;
+  {
+    uint8_t *p = fx;
+    F.refid = (int32_t *)p; p += n16 * 4; F.pos = (int32_t *)p; p += n16 * 4; F.next_refid = (int32_t *)p; p += n16 * 4; F.pnext = (int32_t *)p; p += n16 * 4;
+    F.tlen = (int32_t *)p; p += n16 * 4; F.l_seq = (uint32_t *)p; p += n16 * 4; F.flag = (uint16_t *)p; p += n16 * 2; F.rgid = (uint16_t *)p; p += n16 * 2;
+    F.split = (uint16_t *)p; p += n16 * 2; F.mapq = p; p += n16; F.has_sr = p;
+  }
+  XSrc S{src->n, src->refid.p, src->pos.p, src->next_refid.p, src->pnext.p, src->tlen.p, src->flag.p, src->rgid.p, src->split.p, src->mapq.p, src->has_sr.p,
+         src->l_seq.p, {src->qname_off.p, src->cigar_off.p, src->seq_off.p, src->qual_off.p, raw ? src->raw_off.p : nullptr}};
+  hipLaunchKernelGGL(k_x_fixed, dim3(blocks_for(n, 256)), dim3(256), 0, ss, n, (const uint32_t *)d_idx, S, F, len, new_split, tag_sr, ctr);
+  ELP_HIP(src, hipGetLastError());
+  uint32_t total[XV] = {0, 0, 0, 0, 0};
+  for (int v = 0; v < XV; v++) {
+    if (v == 4 && !raw) continue;
+    ELP_TRY(exclusive_scan_u32(src, len + (size_t)v * n, excl + (size_t)v * (n + 1), n, &total[v]));  // (a slice total beyond 2^32: see the check below)
+  }
+  uint32_t hc[XC_N];
+  ELP_HIP(src, hipMemcpyAsync(hc, ctr, sizeof hc, hipMemcpyDeviceToHost, ss));
+  ELP_HIP(src, hipStreamSynchronize(ss));
+  if (hc[XC_BAD]) return set_error(dst, ELP_ERR_ARG, "elp_copy_records: %u indices are not records of the source context", hc[XC_BAD]);
+  if (hc[XC_QNAME] > elp_ctx::MAX_QNAME) return set_error(dst, ELP_ERR_UNSUPPORTED, "QNAME of %u bytes (limit %u)", hc[XC_QNAME], elp_ctx::MAX_QNAME);
+  // (the scans are 32-bit: a call moves at most 4 GiB of any one column - ~25 M reads of 150 bases; callers move larger sets in pieces)
+  if ((uint64_t)n * (uint64_t)std::max<uint32_t>(hc[XC_LSEQ], 1) >= 0xFFFFFFFFull || (raw && (uint64_t)n * src->max_raw_rec >= 0xFFFFFFFFull))
+    return set_error(dst, ELP_ERR_UNSUPPORTED, "elp_copy_records: more than 4 GiB of one column in one call: move the records in pieces");
+  uint8_t *pool;
+  const size_t pool_bytes = (size_t)total[0] + (size_t)total[1] * 4 + (size_t)total[2] + (size_t)total[3] + (size_t)total[4] + 5 * 64;
+  ELP_TRY(scratch(src, 4, pool_bytes, &pool));
+  uint8_t *pv[XV];
+  {
+    uint8_t *p = pool;
+    const size_t sz[XV] = {total[0], (size_t)total[1] * 4, total[2], total[3], total[4]};
+    for (int v = 0; v < XV; v++) { pv[v] = p; p += (sz[v] + 63) & ~(size_t)63; }
+  }
+  const unsigned vgrid = blocks_for(n * 64, 256);
+  hipLaunchKernelGGL(k_x_var<uint8_t>, dim3(vgrid), dim3(256), 0, ss, n, (const uint32_t *)d_idx, (const uint64_t *)src->qname_off.p, (const uint8_t *)src->qname.p,
+                     (const uint32_t *)excl, pv[0], src->n);
+  hipLaunchKernelGGL(k_x_var<uint32_t>, dim3(vgrid), dim3(256), 0, ss, n, (const uint32_t *)d_idx, (const uint64_t *)src->cigar_off.p, (const uint32_t *)src->cigar.p,
+                     (const uint32_t *)(excl + (n + 1)), (uint32_t *)pv[1], src->n);
+  hipLaunchKernelGGL(k_x_var<uint8_t>, dim3(vgrid), dim3(256), 0, ss, n, (const uint32_t *)d_idx, (const uint64_t *)src->seq_off.p, (const uint8_t *)src->seq4.p,
+                     (const uint32_t *)(excl + 2 * (n + 1)), pv[2], src->n);
+  hipLaunchKernelGGL(k_x_var<uint8_t>, dim3(vgrid), dim3(256), 0, ss, n, (const uint32_t *)d_idx, (const uint64_t *)src->qual_off.p, (const uint8_t *)src->qual.p,
+                     (const uint32_t *)(excl + 3 * (n + 1)), pv[3], src->n);
+  if (raw)
+    hipLaunchKernelGGL(k_x_var<uint8_t>, dim3(vgrid), dim3(256), 0, ss, n, (const uint32_t *)d_idx, (const uint64_t *)src->raw_off.p, (const uint8_t *)src->raw.p,
+                       (const uint32_t *)(excl + 4 * (n + 1)), pv[4], src->n);
+  ELP_HIP(src, hipGetLastError());
+
+  // ---- destination: room, then the copies (on the source's stream, device to device), then the offset columns
+  ELP_HIP(dst, hipSetDevice(dst->device));
+  ELP_TRY(stage_reserve(dst, dst->n + n, dst->qname_bytes + total[0], dst->cigar_ops + total[1], dst->seq_bytes + total[2], dst->qual_bytes + total[3]));
+  if (raw) {
+    const bool keep = dst->raw_n > 0;
+    ELP_TRY(ensure(dst, dst->raw, dst->raw_bytes + total[4] + 64, keep, dst->raw_bytes));
+    ELP_TRY(ensure(dst, dst->raw_off, dst->n + n + 1, keep, dst->raw_n + 1));
+  }
+  uint32_t *dx;  // the exclusive scans, on the destination GPU
+  ELP_TRY(ensure(dst, dst->stage_tmp, ((size_t)XV * (n + 1) + 1) / 2 + 8));
+  dx = reinterpret_cast<uint32_t *>(dst->stage_tmp.p);
+  ELP_HIP(dst, hipStreamSynchronize(dst->stream));  // (the destination's columns may just have moved to larger allocations on its stream)
+  ELP_HIP(src, hipSetDevice(src->device));
+  const uint64_t at = dst->n;
+#define XCOPY(field, T) ELP_TRY(peer_copy(dst, dst->field.p + at, src, F.field, n * sizeof(T)))
+  XCOPY(refid, int32_t); XCOPY(pos, int32_t); XCOPY(next_refid, int32_t); XCOPY(pnext, int32_t); XCOPY(tlen, int32_t); XCOPY(l_seq, uint32_t);
+  XCOPY(flag, uint16_t); XCOPY(rgid, uint16_t); XCOPY(split, uint16_t); XCOPY(mapq, uint8_t); XCOPY(has_sr, uint8_t);
+#undef XCOPY
+  ELP_TRY(peer_copy(dst, dst->qname.p + dst->qname_bytes, src, pv[0], total[0]));
+  ELP_TRY(peer_copy(dst, dst->cigar.p + dst->cigar_ops, src, pv[1], (size_t)total[1] * 4));
+  ELP_TRY(peer_copy(dst, dst->seq4.p + dst->seq_bytes, src, pv[2], total[2]));
+  ELP_TRY(peer_copy(dst, dst->qual.p + dst->qual_bytes, src, pv[3], total[3]));
+  if (raw) ELP_TRY(peer_copy(dst, dst->raw.p + dst->raw_bytes, src, pv[4], total[4]));
+  ELP_TRY(peer_copy(dst, dx, src, excl, (size_t)XV * (n + 1) * 4));
+  ELP_HIP(src, hipStreamSynchronize(ss));
+  ELP_HIP(dst, hipSetDevice(dst->device));
+  {
+    struct { uint64_t *out; uint64_t base; int v; } oc[XV] = {{dst->qname_off.p + at, dst->qname_bytes, 0}, {dst->cigar_off.p + at, dst->cigar_ops, 1},
+                                                              {dst->seq_off.p + at, dst->seq_bytes, 2}, {dst->qual_off.p + at, dst->qual_bytes, 3},
+                                                              {raw ? dst->raw_off.p + at : nullptr, dst->raw_bytes, 4}};
+    for (auto &o : oc) {
+      if (!o.out) continue;
+      hipLaunchKernelGGL(k_x_offsets, dim3(blocks_for(n + 1, 256)), dim3(256), 0, dst->stream, n + 1, (const uint32_t *)(dx + (size_t)o.v * (n + 1)), total[o.v], o.base, o.out);
+    }
+    ELP_HIP(dst, hipGetLastError());
+  }
+  ELP_HIP(dst, hipStreamSynchronize(dst->stream));
+  // ---- commit (as elp_stage does)
+  dst->n += n; dst->qname_bytes += total[0]; dst->cigar_ops += total[1]; dst->seq_bytes += total[2]; dst->qual_bytes += total[3];
+  if (raw) { dst->raw_n = dst->n; dst->raw_bytes += total[4]; dst->max_raw_rec = std::max(dst->max_raw_rec, src->max_raw_rec); }
+  dst->n_sr += hc[XC_NSR];
+  dst->n_filtered += hc[XC_NFILT];
+  dst->max_split = std::max(dst->max_split, hc[XC_SPLIT]);
+  dst->max_qname_len = std::max(dst->max_qname_len, hc[XC_QNAME]);
+  dst->max_l_seq = std::max(dst->max_l_seq, hc[XC_LSEQ]);
+  dst->max_pos = std::max(dst->max_pos, hc[XC_POS]);
+  dst->adapted = dst->sorted = dst->marked = false;
+  dst->have_qual_present = false;
+  dst->have_snapshot = false;
+  dst->flat_index_n = 0;
+  dst->uniform_n = ~0ull;
+  return 0;
+}

@@ -174,6 +174,11 @@ class Engine:
         del keep
         return int(n.value)
 
+    def copy_records_from(self, src: "Engine", idx: np.ndarray, new_split: Optional[int] = None, tag_sr: bool = False):
+        """appends src's records idx (staging indices) to this context, device to device (elp_copy_records)"""
+        ix = np.ascontiguousarray(idx, dtype=np.uint32)
+        self._check(self.L.elp_copy_records(self.h, src.h, _vp(ix), ix.size, -1 if new_split is None else int(new_split), 1 if tag_sr else 0))
+
     def split_classify(self, group_of_ref: np.ndarray, n_groups: int):
         g = np.ascontiguousarray(group_of_ref, dtype=np.int32)
         split = np.empty(self.n, dtype=np.uint16)

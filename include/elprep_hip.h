@@ -167,6 +167,13 @@ int elp_filter_records_flat(elp_ctx *ctx, int remove_unmapped, int remove_unmapp
  *   output slot of the j-th record of `spread`'s sorted output among `groups`' sorted output (behind every group read of its
  *   (refid, POS) and in front of the first greater one; group reads fill the remaining slots in order). */
 int elp_split_classify(elp_ctx *ctx, const int32_t *group_of_ref, int32_t n_groups, uint16_t *split_out, uint8_t *spread_out, uint64_t *counts_out);
+/* elp_copy_records: the write side of the same routing (:280-293 writes the record into the file of its split, and a copy tagged sr:i:1
+ *   into the group file if the original goes to the spread file): appends the records idx[0 .. n) of `src` (staging indices, any order)
+ *   to `dst` - two contexts of this process on one GPU or on two (device-to-device / peer copies of gathered column slices; nothing
+ *   passes through the host).  new_split >= 0: the split id the copies get (else they keep theirs); tag_sr != 0: live records arrive as
+ *   sr-tagged copies.  FLAG and QUAL travel as they are now; the inflated BAM records travel too if both contexts hold them
+ *   (elp_stage_bam).  At most 4 GiB of any one column per call. */
+int elp_copy_records(elp_ctx *dst, elp_ctx *src, const uint32_t *idx, uint64_t n, int new_split, int tag_sr);
 int elp_merge_spread(elp_ctx *groups, elp_ctx *spread, uint64_t *slot_of_spread_out);
 
 /* ---- coordinate sort: By(CoordinateLess).ParallelStableSort (sam/sam-types.go:425-473, 639-641) ----

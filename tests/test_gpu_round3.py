@@ -316,3 +316,73 @@ def test_tables_allreduce_through_a_caller_supplied_transport():
         for have, a, bb in zip(e.tables_fetch(), own[0], own[1]):
             assert np.array_equal(have, a + bb)
         e.close()
+
+
+def test_copy_records_between_contexts_whole_path():
+    """elp_copy_records (the write side of the split routing, device to device): a context that was staged with a third of the reads and
+    received the others from another context - in a shuffled order, in three calls - is the context the host would have staged with the
+    same records in that order: every output of the path against the oracle on that batch"""
+    cfg, b, h, refs, sites = dataset("tiny", 9000, 11, 0.03)
+    rng = np.random.default_rng(5)
+    k = b.n // 3
+    idx = rng.permutation(np.arange(k, b.n))
+    a, e = Engine(h), Engine(h)
+    a.stage(b)
+    e.stage(b.take(np.arange(k)))
+    for part in np.array_split(idx, 3):
+        e.copy_records_from(a, part)
+    assert e.n == b.n
+    equiv = b.take(np.concatenate([np.arange(k), idx]))
+    _same(_whole_path(e, equiv, h, refs, sites), _oracle_path(equiv, h, refs, sites))
+    # the source is untouched: its own path still gives what the oracle gives for ITS order
+    _same(_whole_path(a, b, h, refs, sites), _oracle_path(b, h, refs, sites))
+    with pytest.raises(Exception):
+        e.copy_records_from(a, np.array([b.n], dtype=np.uint32))  # not a record of the source
+    assert e.n == b.n
+    a.close()
+    e.close()
+
+
+def test_copy_records_tagged_copies_and_split_ids():
+    """tag_sr / new_split: the copies arrive as sr-tagged copies of another split, exactly as if the host had staged them so"""
+    from elprep_amd import sfm
+    cfg, b, h, refs, sites = dataset("tiny", 4000, 12, 0.03)
+    k = b.n // 2
+    pick = np.arange(k, b.n)[(np.arange(k, b.n) % 5 == 0) & ((b.flag[k:] & 0x904) == 0)]
+    a, e, d = Engine(h), Engine(h), Engine(h)
+    a.stage(b)
+    first = b.take(np.arange(k))
+    e.stage(first)
+    e.copy_records_from(a, pick, new_split=3, tag_sr=True)
+    tagged = sfm.with_sr(b.take(pick), np.ones(pick.size, dtype=bool), split=np.full(pick.size, 3, dtype=np.uint16))
+    d.stage(first)
+    d.stage(tagged)
+    assert e.n == d.n and e.n_sorted == d.n_sorted
+    for x, y in zip(_whole_path(e, None, h, refs, sites)[:3], _whole_path(d, None, h, refs, sites)[:3]):
+        assert np.array_equal(x, y)
+    for eng in (a, e, d):
+        eng.close()
+
+
+def test_copy_records_carries_the_inflated_bam_records():
+    """contexts staged from BAM bytes: the records' bytes travel with the columns, the destination emits what the source emits"""
+    cfg, b, h, refs, sites = dataset("tiny", 2500, 13, 0.03)
+    raw = orc.bam_encode(b, h.rg_ids)
+    a, e = Engine(h), Engine(h)
+    for eng in (a, e):
+        eng.set_read_group_ids(h.rg_ids)
+    a.stage_bam(raw)
+    for part in np.array_split(np.arange(b.n), 4):
+        e.copy_records_from(a, part)
+    outs = []
+    for eng in (a, e):
+        eng.mark_duplicates(True)
+        eng.sort_coordinate()
+        outs.append(eng.emit_sorted_bam())
+    assert outs[0].size > 0 and np.array_equal(outs[0], outs[1])
+    f = Engine(h)
+    f.stage(b)  # columns only: mixing is refused
+    with pytest.raises(Exception):
+        f.copy_records_from(a, np.arange(10))
+    for eng in (a, e, f):
+        eng.close()
