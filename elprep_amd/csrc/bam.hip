@@ -225,11 +225,23 @@ __device__ inline uint32_t out_size(const BamOut &m, uint32_t i, uint32_t *err) 
   }
   return size;
 }
-__global__ __launch_bounds__(256) void k_bam_out_sizes(BamOut m, uint64_t k0, uint32_t cnt, uint32_t *__restrict__ sizes, uint32_t *err) {
+// Output record k of a MERGED stream (elp_emit_merged_bam) comes from one of two contexts: src[k] = rank of the record in the first
+// context's sorted output, or MERGE_SECOND | its rank in the second's.  src == nullptr: one context, output record k = perm[k].
+constexpr uint32_t MERGE_SECOND = 0x80000000u;
+__device__ __forceinline__ const BamOut &out_source(const BamOut &m, const BamOut &m2, const uint32_t *__restrict__ src, uint64_t k, uint32_t *i) {
+  if (!src) { *i = m.perm[k]; return m; }
+  const uint32_t s = src[k];
+  const BamOut &mm = (s & MERGE_SECOND) ? m2 : m;
+  *i = mm.perm[s & ~MERGE_SECOND];
+  return mm;
+}
+__global__ __launch_bounds__(256) void k_bam_out_sizes(BamOut m, BamOut m2, const uint32_t *__restrict__ src, uint64_t k0, uint32_t cnt, uint32_t *__restrict__ sizes,
+                                                       uint32_t *err) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= cnt) return;
-  uint32_t e = 0;
-  sizes[j] = out_size(m, m.perm[k0 + j], &e);
+  uint32_t e = 0, i;
+  const BamOut &mm = out_source(m, m2, src, k0 + j, &i);
+  sizes[j] = out_size(mm, i, &e);
   if (e) atomicOr(err, e);
 }
 // Alignment.bin(), sam/bam-files.go:443-468
@@ -242,11 +254,13 @@ __device__ inline uint32_t reg2bin(int32_t beg, int32_t end) {
   return 0;
 }
 // one wavefront per output record; `out` = this chunk's buffer, offs = exclusive scan of the chunk's sizes
-__global__ __launch_bounds__(256) void k_bam_out_emit(BamOut m, uint64_t k0, uint32_t cnt, const uint32_t *__restrict__ offs, uint8_t *__restrict__ out) {
+__global__ __launch_bounds__(256) void k_bam_out_emit(BamOut m_first, BamOut m_second, const uint32_t *__restrict__ src, uint64_t k0, uint32_t cnt,
+                                                      const uint32_t *__restrict__ offs, uint8_t *__restrict__ out) {
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
   for (uint32_t j = wave; j < cnt; j += nwaves) {
-    const uint32_t i = m.perm[k0 + j];
+    uint32_t i;
+    const BamOut &m = out_source(m_first, m_second, src, k0 + j, &i);
     const uint8_t *p = m.raw + m.raw_off[i];
     const uint32_t bs = ld_u32(p);
     const uint8_t *rec = p + 4, *end = rec + bs;
@@ -499,17 +513,12 @@ int elp_stage_bam(elp_ctx *c, const uint8_t *bytes, uint64_t n_bytes, const uint
   return 0;
 }
 
-int elp_emit_sorted_bam(elp_ctx *c, uint8_t *out, uint64_t cap, uint64_t *n_bytes_out) {
-  if (!c || !n_bytes_out) return ELP_ERR_ARG;
-  ELP_HIP(c, hipSetDevice(c->device));
-  if (!c->sorted) return set_error(c, ELP_ERR_ARG, "elp_emit_sorted_bam: call elp_sort_coordinate first");
-  if (c->raw_n != c->n) return set_error(c, ELP_ERR_ARG, "elp_emit_sorted_bam: records were not staged with elp_stage_bam");
-  const uint64_t n_out = c->n - c->n_sr;
-  BamOut m{n_out, c->perm.p, c->raw.p, c->raw_off.p, c->refid.p, c->pos.p, c->next_refid.p, c->pnext.p, c->tlen.p, c->flag.p, c->mapq.p, c->l_seq.p,
-           c->qname_off.p, c->cigar_off.p, c->qual_off.p, c->qname.p, c->qual.p, c->cigar.p};
+// the chunked size / scan / gather loop of both emit calls; src (device, n_out entries) or nullptr
+static int emit_stream(elp_ctx *c, const BamOut &m, const BamOut &m2, const uint32_t *src, uint64_t n_out, uint64_t max_raw_rec, uint8_t *out, uint64_t cap,
+                       uint64_t *n_bytes_out) {
   // records per device pass: sizes and offsets of a pass are scanned in 32 bits, so a pass must stay below 4 GiB of output.  An output
   // record is never longer than the staged one (integer fields only shrink when re-encoded), so the largest staged record bounds it.
-  const uint32_t CHUNK = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(1u << 21, 0xFFFFFFFFull / std::max<uint64_t>(c->max_raw_rec, 64)));
+  const uint32_t CHUNK = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(1u << 21, 0xFFFFFFFFull / std::max<uint64_t>(max_raw_rec, 64)));
   uint64_t total = 0;
   hipStream_t st = c->stream;
   for (uint64_t k0 = 0; k0 < n_out; k0 += CHUNK) {
@@ -518,7 +527,7 @@ int elp_emit_sorted_bam(elp_ctx *c, uint8_t *out, uint64_t cap, uint64_t *n_byte
     ELP_TRY(scratch(c, 4, (size_t)2 * (cnt + 8) + 8, &sizes));
     uint32_t *offs = sizes + cnt + 8, *err = offs + cnt + 8;
     ELP_HIP(c, hipMemsetAsync(err, 0, 4, st));
-    ELP_LAUNCH(c, "emit_bam_sizes", k_bam_out_sizes, dim3(blocks_for(cnt, 256)), dim3(256), 0, m, k0, cnt, sizes, err);
+    ELP_LAUNCH(c, "emit_bam_sizes", k_bam_out_sizes, dim3(blocks_for(cnt, 256)), dim3(256), 0, m, m2, src, k0, cnt, sizes, err);
     uint32_t chunk_bytes = 0;
     ELP_TRY(exclusive_scan_u32(c, sizes, offs, cnt, &chunk_bytes));
     uint32_t he = 0;
@@ -531,13 +540,60 @@ int elp_emit_sorted_bam(elp_ctx *c, uint8_t *out, uint64_t cap, uint64_t *n_byte
     uint8_t *d_out;
     ELP_TRY(scratch(c, 5, (size_t)chunk_bytes + 64, &d_out));
     const unsigned grid = std::min<unsigned>(blocks_for((uint64_t)cnt * 64, 256), (unsigned)c->n_cu * 32);
-    ELP_LAUNCH(c, "emit_bam", k_bam_out_emit, dim3(grid), dim3(256), 0, m, k0, cnt, (const uint32_t *)offs, d_out);
+    ELP_LAUNCH(c, "emit_bam", k_bam_out_emit, dim3(grid), dim3(256), 0, m, m2, src, k0, cnt, (const uint32_t *)offs, d_out);
     ELP_HIP(c, hipMemcpyAsync(out + total, d_out, chunk_bytes, hipMemcpyDeviceToHost, st));
     ELP_HIP(c, hipStreamSynchronize(st));
     total += chunk_bytes;
   }
   *n_bytes_out = total;
   return 0;
+}
+static BamOut bam_out_of(const elp_ctx *c) {
+  return BamOut{c->n - c->n_sr, c->perm.p, c->raw.p, c->raw_off.p, c->refid.p, c->pos.p, c->next_refid.p, c->pnext.p, c->tlen.p, c->flag.p, c->mapq.p, c->l_seq.p,
+                c->qname_off.p, c->cigar_off.p, c->qual_off.p, c->qname.p, c->qual.p, c->cigar.p};
+}
+
+int elp_emit_sorted_bam(elp_ctx *c, uint8_t *out, uint64_t cap, uint64_t *n_bytes_out) {
+  if (!c || !n_bytes_out) return ELP_ERR_ARG;
+  ELP_HIP(c, hipSetDevice(c->device));
+  if (!c->sorted) return set_error(c, ELP_ERR_ARG, "elp_emit_sorted_bam: call elp_sort_coordinate first");
+  if (c->raw_n != c->n) return set_error(c, ELP_ERR_ARG, "elp_emit_sorted_bam: records were not staged with elp_stage_bam");
+  const BamOut m = bam_out_of(c);
+  return emit_stream(c, m, m, nullptr, c->n - c->n_sr, c->max_raw_rec, out, cap, n_bytes_out);
+}
+
+// MergeSortedFilesSplitPerChromosome (sam/split-merge.go:410-576) with payloads: the records of `groups` and of `spread` as ONE stream in
+// the merge's order - every spread read behind all group reads of its (refid, POS) - gathered in HBM from both contexts' columns and
+// inflated records (elp_merge_spread gives the order alone, for a host that merges bytes itself).
+__global__ __launch_bounds__(256) void k_merge_mark(uint64_t ns, const uint64_t *__restrict__ slots, uint32_t *__restrict__ is_spread, uint32_t *__restrict__ src) {
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ns) return;
+  is_spread[slots[j]] = 1u;
+  src[slots[j]] = MERGE_SECOND | (uint32_t)j;
+}
+__global__ __launch_bounds__(256) void k_merge_fill(uint64_t n_out, const uint32_t *__restrict__ is_spread, const uint32_t *__restrict__ before, uint32_t *__restrict__ src) {
+  const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < n_out && !is_spread[s]) src[s] = (uint32_t)s - before[s];  // group reads fill the remaining slots in order
+}
+
+int elp_emit_merged_bam(elp_ctx *groups, elp_ctx *spread, uint8_t *out, uint64_t cap, uint64_t *n_bytes_out) {
+  if (!groups || !spread || groups == spread || !n_bytes_out) return ELP_ERR_ARG;
+  if (groups->raw_n != groups->n || spread->raw_n != spread->n) return set_error(groups, ELP_ERR_ARG, "elp_emit_merged_bam: records were not staged with elp_stage_bam");
+  uint64_t *slots = nullptr;
+  ELP_TRY(merge_spread_slots(groups, spread, &slots));  // checks: both sorted, one device
+  const uint64_t ng = groups->n - groups->n_sr, ns = spread->n - spread->n_sr, n_out = ng + ns;
+  if (n_out >= MERGE_SECOND) return set_error(groups, ELP_ERR_UNSUPPORTED, "elp_emit_merged_bam: more than 2^31 output records");
+  if (n_out == 0) { *n_bytes_out = 0; return 0; }
+  uint32_t *w;
+  ELP_TRY(scratch(groups, 6, 3 * (n_out + 8), &w));
+  uint32_t *src = w, *is_spread = w + (n_out + 8), *before = w + 2 * (n_out + 8);
+  hipStream_t st = groups->stream;
+  ELP_HIP(groups, hipMemsetAsync(is_spread, 0, n_out * 4, st));
+  if (ns) ELP_LAUNCH(groups, "merge_mark", k_merge_mark, dim3(blocks_for(ns, 256)), dim3(256), 0, ns, (const uint64_t *)slots, is_spread, src);
+  ELP_TRY(exclusive_scan_u32(groups, is_spread, before, n_out, nullptr));
+  ELP_LAUNCH(groups, "merge_fill", k_merge_fill, dim3(blocks_for(n_out, 256)), dim3(256), 0, n_out, (const uint32_t *)is_spread, (const uint32_t *)before, src);
+  const BamOut mg = bam_out_of(groups), ms = bam_out_of(spread);
+  return emit_stream(groups, mg, ms, src, n_out, std::max(groups->max_raw_rec, spread->max_raw_rec), out, cap, n_bytes_out);
 }
 
 }  // extern "C"

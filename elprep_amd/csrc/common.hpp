@@ -312,7 +312,8 @@ int ensure_qual_present(elp_ctx *c, bool exact = false);  // exact: scan the who
 int fetch_err(elp_ctx *c, uint32_t *words /* 4 */);
 void group_release(elp_ctx *c);
 int tables_written(elp_ctx *c);  // bqsr.hip: dev_tables were just written on c->stream
-int stage_reserve(elp_ctx *c, uint64_t n, uint64_t qb, uint64_t co, uint64_t sb, uint64_t lb);  // grows the staged columns (ctx.hip)
+int stage_reserve(elp_ctx *c, uint64_t n, uint64_t qb, uint64_t co, uint64_t sb, uint64_t lb);
+int merge_spread_slots(elp_ctx *groups, elp_ctx *spread, uint64_t **slots_out);  // filter.hip: the merge order as ranks, on the device  // grows the staged columns (ctx.hip)
 int stage_recode_seq(elp_ctx *c, uint64_t from, uint64_t bytes);                               // BAM nibbles -> code nibbles on seq4[from, from + bytes)
 
 }  // namespace elp

@@ -127,6 +127,33 @@ __global__ __launch_bounds__(256) void k_perm_keys(uint64_t n_out, const uint32_
   keys[k] = ((uint64_t)(uint32_t)refid[i] << 32) | (uint64_t)(uint32_t)pos[i];  // (refid, POS) as the merge loop compares them (:417-434)
 }
 
+
+// MergeSortedFilesSplitPerChromosome's order as ranks, on the device: slots[j] = output slot of the j-th record of `spread`'s sorted output
+// among `groups`' sorted output (scratch slot 5 of `groups`; valid until that slot is reused).  Queued on groups->stream.
+int merge_spread_slots(elp_ctx *groups, elp_ctx *spread, uint64_t **slots_out) {
+  if (!groups->sorted || !spread->sorted) return set_error(groups, ELP_ERR_ARG, "elp_merge_spread: both contexts must be coordinate-sorted");
+  if (groups->device != spread->device) return set_error(groups, ELP_ERR_ARG, "elp_merge_spread: contexts on different devices");
+  ELP_HIP(groups, hipSetDevice(groups->device));
+  // the mapped part of the groups' output (the unmapped split is appended behind the merge, :560-576)
+  const uint64_t ns = spread->n - spread->n_sr;
+  uint64_t *kg, *ks, *slots;
+  ELP_TRY(scratch(groups, 5, (groups->n + 8) + 2 * (ns + 8), &kg));
+  ks = kg + groups->n + 8;
+  slots = ks + ns + 8;
+  const uint64_t ng_all = groups->n - groups->n_sr;
+  ELP_HIP(groups, hipStreamSynchronize(spread->stream));
+  if (ng_all)
+    ELP_LAUNCH(groups, "merge_keys", k_perm_keys, dim3(blocks_for(ng_all, 256)), dim3(256), 0, ng_all, (const uint32_t *)groups->perm.p,
+               (const int32_t *)groups->refid.p, (const int32_t *)groups->pos.p, kg);
+  if (ns) {
+    ELP_LAUNCH(groups, "merge_keys", k_perm_keys, dim3(blocks_for(ns, 256)), dim3(256), 0, ns, (const uint32_t *)spread->perm.p,
+               (const int32_t *)spread->refid.p, (const int32_t *)spread->pos.p, ks);
+    // unmapped reads (refid -1 -> 0xFFFFFFFF........) sort behind every contig: the search covers them without a special case
+    ELP_LAUNCH(groups, "merge_rank", k_merge_rank, dim3(blocks_for(ns, 256)), dim3(256), 0, ng_all, (const uint64_t *)kg, ns, (const uint64_t *)ks, slots);
+  }
+  *slots_out = slots;
+  return 0;
+}
 }  // namespace elp
 
 using namespace elp;
@@ -235,27 +262,10 @@ int elp_split_classify(elp_ctx *c, const int32_t *group_of_ref, int32_t n_groups
 
 int elp_merge_spread(elp_ctx *groups, elp_ctx *spread, uint64_t *slot_of_spread_out) {
   if (!groups || !spread || groups == spread) return ELP_ERR_ARG;
-  if (!groups->sorted || !spread->sorted) return set_error(groups, ELP_ERR_ARG, "elp_merge_spread: both contexts must be coordinate-sorted");
-  if (groups->device != spread->device) return set_error(groups, ELP_ERR_ARG, "elp_merge_spread: contexts on different devices");
-  ELP_HIP(groups, hipSetDevice(groups->device));
-  // the mapped part of the groups' output (the unmapped split is appended behind the merge, :560-576)
+  uint64_t *slots = nullptr;
+  ELP_TRY(merge_spread_slots(groups, spread, &slots));
   const uint64_t ns = spread->n - spread->n_sr;
-  uint64_t *kg, *ks, *slots;
-  ELP_TRY(scratch(groups, 5, (groups->n + 8) + 2 * (ns + 8), &kg));
-  ks = kg + groups->n + 8;
-  slots = ks + ns + 8;
-  const uint64_t ng_all = groups->n - groups->n_sr;
-  ELP_HIP(groups, hipStreamSynchronize(spread->stream));
-  if (ng_all)
-    ELP_LAUNCH(groups, "merge_keys", k_perm_keys, dim3(blocks_for(ng_all, 256)), dim3(256), 0, ng_all, (const uint32_t *)groups->perm.p,
-               (const int32_t *)groups->refid.p, (const int32_t *)groups->pos.p, kg);
-  if (ns) {
-    ELP_LAUNCH(groups, "merge_keys", k_perm_keys, dim3(blocks_for(ns, 256)), dim3(256), 0, ns, (const uint32_t *)spread->perm.p,
-               (const int32_t *)spread->refid.p, (const int32_t *)spread->pos.p, ks);
-    // unmapped reads (refid -1 -> 0xFFFFFFFF........) sort behind every contig: the search covers them without a special case
-    ELP_LAUNCH(groups, "merge_rank", k_merge_rank, dim3(blocks_for(ns, 256)), dim3(256), 0, ng_all, (const uint64_t *)kg, ns, (const uint64_t *)ks, slots);
-    ELP_HIP(groups, hipMemcpyAsync(slot_of_spread_out, slots, ns * 8, hipMemcpyDeviceToHost, groups->stream));
-  }
+  if (ns) ELP_HIP(groups, hipMemcpyAsync(slot_of_spread_out, slots, ns * 8, hipMemcpyDeviceToHost, groups->stream));
   ELP_HIP(groups, hipStreamSynchronize(groups->stream));
   return 0;
 }

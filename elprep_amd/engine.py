@@ -140,6 +140,14 @@ class Engine:
         self._check(self.L.elp_emit_sorted_bam(self.h, _vp(out), out.size, C.byref(n)))
         return out[:int(n.value)]
 
+    def emit_merged_bam(self, spread: "Engine") -> np.ndarray:
+        """this context's (group splits) and `spread`'s sorted outputs as one BAM record stream in the merge's order (elp_emit_merged_bam)"""
+        n = C.c_uint64()
+        self._check(self.L.elp_emit_merged_bam(self.h, spread.h, C.c_void_p(0), 0, C.byref(n)))
+        out = np.empty(int(n.value), dtype=np.uint8)
+        self._check(self.L.elp_emit_merged_bam(self.h, spread.h, _vp(out), out.size, C.byref(n)))
+        return out[:int(n.value)]
+
     # ---- fused predicates, split / merge bookkeeping (include/elprep_hip.h)
     def filter_records(self, remove_unmapped=False, remove_unmapped_strict=False, min_mapq=0, remove_non_exact=False, remove_duplicates=False,
                        regions=None) -> int:

@@ -136,6 +136,10 @@ void elp_pinned_free(void *p);
 int elp_stage_bam(elp_ctx *ctx, const uint8_t *bytes, uint64_t n_bytes, const uint64_t *rec_off /* n_records + 1, may be NULL */,
                   uint64_t n_records, uint16_t split_id);
 int elp_emit_sorted_bam(elp_ctx *ctx, uint8_t *out, uint64_t cap, uint64_t *n_bytes_out);
+/* The merge of `elprep merge` / `sfm` phase 3 with payloads (MergeSortedFilesSplitPerChromosome, sam/split-merge.go:410-576): the sorted
+ * outputs of a context that holds group splits and of the context that holds the spread split as ONE stream of BAM records in the merge's
+ * order (elp_merge_spread's slots), gathered in HBM.  Both contexts staged with elp_stage_bam, coordinate-sorted, on one device. */
+int elp_emit_merged_bam(elp_ctx *groups, elp_ctx *spread, uint8_t *out, uint64_t cap, uint64_t *n_bytes_out);
 
 /* ---- fused per-record predicates: filters/simple-filters.go ----
  * The filters that stand in front of MarkDuplicates in filters1 (cmd/filter.go:696-803), evaluated in one pass over the staged

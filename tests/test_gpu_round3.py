@@ -386,3 +386,53 @@ def test_copy_records_carries_the_inflated_bam_records():
         f.copy_records_from(a, np.arange(10))
     for eng in (a, e, f):
         eng.close()
+
+
+def _bam_records(buf):
+    """the alignment records of a BAM record stream, one bytes object each (block_size field included)"""
+    out, p = [], 0
+    while p < buf.size:
+        q = p + 4 + int(buf[p:p + 4].view(np.uint32)[0])
+        out.append(buf[p:q].tobytes())
+        p = q
+    return out
+
+
+def test_emit_merged_bam_is_the_merge_of_the_two_sorted_outputs():
+    """elp_emit_merged_bam (MergeSortedFilesSplitPerChromosome with payloads): the group splits (with their sr-tagged copies, which drop
+    out) in one context, the spread split in another, both staged from BAM bytes, marked, sorted: the merged stream is the two contexts'
+    own sorted outputs (elp_emit_sorted_bam, tested byte-exact against the oracle's encoder) interleaved by elp_merge_spread's slots
+    (tested against the transliteration of the reference's insertion loop)"""
+    from elprep_amd import sfm
+    from oracle import simple_filters as sf
+    cfg, b, h, refs, sites = dataset("tiny", 4000, 17, 0.03)
+    n_groups, gof = orc.contig_groups(cfg.ref_len, 80000)
+    osplit, ospread = sf.split_records(b, gof)
+    assert ospread.sum() > 20
+    tagged = sfm.with_sr(b, ospread.astype(bool), osplit)
+    sp = b.take(np.nonzero(ospread)[0])
+    eg, es = Engine(h), Engine(h)
+    for eng, batch in ((eg, tagged), (es, sp)):
+        eng.set_read_group_ids(h.rg_ids)
+        eng.stage_bam(orc.bam_encode(batch, h.rg_ids), split_id=0)
+        eng.mark_duplicates(True)
+        eng.sort_coordinate()
+    # (stage_bam gives every record of a call one split id; the tagged copies are recognised by their sr tag)
+    rg, rs = _bam_records(eg.emit_sorted_bam()), _bam_records(es.emit_sorted_bam())
+    assert len(rg) == eg.n_sorted and len(rs) == es.n_sorted
+    slots = eg.merge_spread(es).astype(np.int64)
+    want = [None] * (len(rg) + len(rs))
+    for j, s in enumerate(slots):
+        want[s] = rs[j]
+    it = iter(rg)
+    want = [w if w is not None else next(it) for w in want]
+    got = eg.emit_merged_bam(es)
+    assert got.tobytes() == b"".join(want)
+    # sizes only, and an empty spread context
+    e0 = Engine(h)
+    e0.set_read_group_ids(h.rg_ids)
+    e0.stage_bam(orc.bam_encode(sp.take(np.arange(0)), h.rg_ids))
+    e0.sort_coordinate()
+    assert eg.emit_merged_bam(e0).tobytes() == b"".join(rg)
+    for eng in (eg, es, e0):
+        eng.close()
