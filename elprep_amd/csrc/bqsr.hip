@@ -126,54 +126,42 @@ __device__ __forceinline__ void set_skip_bits(uint32_t *skipbits, uint64_t bit0,
 // match operation), and there is one reference piece.  Everything else is appended to `queue` for the general kernel, so that
 // kernel's long divergent code runs with all lanes busy.  All column loads are issued before the first test (one latency, not 15).
 constexpr int PF_TILES = 16;
-__global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__restrict__ desc, uint32_t *skipbits, uint32_t *__restrict__ queue,
-                                                            uint32_t *queue_n, uint32_t *err, BqRec *__restrict__ recs) {
-  // a workgroup handles PF_TILES * 256 consecutive records and collects the deferred ones in LDS: one global atomic per
-  // workgroup (a global atomic per wave on the single queue counter serialises at ~12 ns each: 9 ms for 50 M reads)
-  __shared__ uint32_t lq[PF_TILES * 256];
-  __shared__ uint32_t lcount, gbase;
-  // per-contig facts in LDS (contig length, known-site array, its length, its bucket index): the walk over the known sites then
-  // depends on ONE global round trip (the bucket entry) instead of three (pointer tables first); the kernel is latency-bound
-  __shared__ uint32_t s_cig[256][5];  // the thread's CIGAR (indel reads): build_pieces / get_read_coord walk it several times
-  __shared__ int32_t s_ref_len[REF_LDS];
-  __shared__ const int32_t *s_sites[REF_LDS];
-  __shared__ int64_t s_nsites[REF_LDS];
-  __shared__ const uint32_t *s_sidx[REF_LDS];
-  const bool ref_lds = m.n_ref <= REF_LDS;
-  if (ref_lds)
-    for (int r = threadIdx.x; r < m.n_ref; r += 256) {
-      s_ref_len[r] = m.ref_len[r]; s_sites[r] = m.sites[r]; s_nsites[r] = m.n_sites[r]; s_sidx[r] = m.site_idx[r];
-    }
-  if (threadIdx.x == 0) lcount = 0;
-  __syncthreads();
-  // the record's columns are loaded one tile ahead: a record costs a chain of dependent round trips (columns -> CIGAR, bucket entry ->
-  // known sites) and the kernel is bound by that chain, not by bytes; the next tile's columns travel with this tile's second round
-  struct Cols {
-    uint8_t has_sr, mq;
-    uint16_t f, rg;
-    int32_t r, p, pnext, tlen, nrefid;
-    uint32_t ls;
-    uint64_t q0, q1, c0, c1, qb;
-  };
-  auto load_cols = [&](uint64_t i) __attribute__((always_inline)) -> Cols {
-    Cols c;
-    c.has_sr = m.has_sr[i]; c.mq = m.mapq[i]; c.f = m.flag[i]; c.rg = m.rgid[i];
-    c.r = m.refid[i]; c.p = m.pos[i]; c.pnext = m.pnext[i]; c.tlen = m.tlen[i]; c.nrefid = m.next_refid[i];
-    c.ls = m.l_seq[i];
-    c.q0 = m.qual_off[i]; c.q1 = m.qual_off[i + 1]; c.c0 = m.cigar_off[i]; c.c1 = m.cigar_off[i + 1];
-    c.qb = m.qbounds[i];
-    return c;
-  };
-  const uint64_t i_first = (uint64_t)blockIdx.x * PF_TILES * 256 + threadIdx.x;
-  Cols nxt = {};
-  if (i_first < m.n) nxt = load_cols(i_first);
-#pragma unroll 1
-  for (int tile = 0; tile < PF_TILES; tile++) {
-  const uint64_t i = i_first + (uint64_t)tile * 256;
-  bool defer = false;
-  const Cols cur = nxt;
-  if (tile + 1 < PF_TILES && i + 256 < m.n) nxt = load_cols(i + 256);
-  if (i < m.n) {
+// a record's columns (k_bqsr_prologue_fast loads them a tile ahead)
+struct PfCols {
+  uint8_t has_sr, mq;
+  uint16_t f, rg;
+  int32_t r, p, pnext, tlen, nrefid;
+  uint32_t ls;
+  uint64_t q0, q1, c0, c1, qb;
+};
+__device__ __forceinline__ PfCols pf_load_cols(const BqCols &m, uint64_t i) {
+  PfCols c;
+  c.has_sr = m.has_sr[i]; c.mq = m.mapq[i]; c.f = m.flag[i]; c.rg = m.rgid[i];
+  c.r = m.refid[i]; c.p = m.pos[i]; c.pnext = m.pnext[i]; c.tlen = m.tlen[i]; c.nrefid = m.next_refid[i];
+  c.ls = m.l_seq[i];
+  c.q0 = m.qual_off[i]; c.q1 = m.qual_off[i + 1]; c.c0 = m.cigar_off[i]; c.c1 = m.cigar_off[i + 1];
+  c.qb = m.qbounds[i];
+  return c;
+}
+// per-contig facts in LDS (contig length, known-site array, its length, its bucket index): the walk over the known sites then depends on
+// ONE global round trip (the bucket entry) instead of three (pointer tables first)
+struct PfLds {
+  int32_t ref_len[REF_LDS];
+  const int32_t *sites[REF_LDS];
+  int64_t nsites[REF_LDS];
+  const uint32_t *sidx[REF_LDS];
+};
+__device__ __forceinline__ void pf_lds_fill(PfLds &L, const BqCols &m, int nt) {
+  if (m.n_ref <= REF_LDS)
+    for (int r = threadIdx.x; r < m.n_ref; r += nt) { L.ref_len[r] = m.ref_len[r]; L.sites[r] = m.sites[r]; L.nsites[r] = m.n_sites[r]; L.sidx[r] = m.site_idx[r]; }
+}
+
+// The prologue of ONE record.  PLAIN_PASS false: the first, streaming pass - finishes the reads whose CIGAR is [H] [S] <match> [S] [H], sends
+// reads of match / insertion / deletion operations to the second pass (to_plain) and everything else to the general kernel (defer).
+// PLAIN_PASS true: the second pass over the reads the first one listed; my_cig_w = five LDS words of the thread.
+template <bool PLAIN_PASS>
+__device__ __forceinline__ void pf_record(const BqCols &m, const uint64_t i, const PfCols &cur, const PfLds &L, const bool ref_lds, BqDesc *__restrict__ desc,
+                                          uint32_t *skipbits, uint32_t *err, BqRec *__restrict__ recs, uint32_t *my_cig_w, bool &defer, bool &to_plain) {
     const uint8_t has_sr = cur.has_sr, mq = cur.mq;
     const uint16_t f = cur.f, rg = cur.rg;
     const int32_t r = cur.r, p = cur.p, pnext = cur.pnext, tlen = cur.tlen, nrefid = cur.nrefid;
@@ -198,19 +186,19 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
       uint32_t opv[5];
 #pragma unroll
       for (int k = 0; k < 5; k++) opv[k] = (uint64_t)k < nop ? m.cigar[c0 + k] : 0u;
-      const int32_t rl = ref_lds ? s_ref_len[r] : m.ref_len[r];
+      const int32_t rl = ref_lds ? L.ref_len[r] : m.ref_len[r];
       // the same round trip: the read group's covariate index and - when descriptors are written - the known-site bucket entry (read
       // whether or not the tests below pass).  When RECORDS are written (count3.hip) a read that is one run of matches needs no walk over
       // the site list: its known-site bits come with the reference window (k_ref_mark_sites); the bucket entry is then fetched only by the
       // reads that do walk (indels; a window the record cannot describe)
       const uint16_t cov_rg = m.rg_cov[rg];
-      const int32_t *sv = ref_lds ? s_sites[r] : m.sites[r];
-      const int64_t ns = ref_lds ? s_nsites[r] : m.n_sites[r];
+      const int32_t *sv = ref_lds ? L.sites[r] : m.sites[r];
+      const int64_t ns = ref_lds ? L.nsites[r] : m.n_sites[r];
       auto bucket_entry = [&]() __attribute__((always_inline)) -> int64_t {
         const int64_t nbuck = ((int64_t)rl >> 6) + 1;
         int64_t bk = (int64_t)(p < rl ? p : rl) >> 6;
         bk = bk >= nbuck ? nbuck - 1 : bk;
-        return (int64_t)(ref_lds ? s_sidx[r] : m.site_idx[r])[bk];
+        return (int64_t)(ref_lds ? L.sidx[r] : m.site_idx[r])[bk];
       };
       int64_t s_first = 0;
       if (!recs && ns > 0) s_first = bucket_entry();
@@ -246,12 +234,18 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
             else plain = false;
           }
         }
-        if (plain) {
-#pragma unroll
-          for (int k = 0; k < 5; k++) s_cig[threadIdx.x][k] = opv[k];
-        }
       }
-      const uint32_t *my_cig = s_cig[threadIdx.x];
+      if (!PLAIN_PASS) {
+        // first pass: a read with indels goes to the second, dense pass (k_bqsr_prologue_plain) - a wave that holds one would otherwise
+        // run the piece / read-coordinate code for all of its lanes (the kernel is bound by vector issue: 1250 instructions per wave and
+        // tile with both paths in one kernel, profiles/round3 PMC)
+        if (ok && plain && ls <= (uint32_t)MAX_DESC_READ) { to_plain = true; return; }
+        plain = false;
+      } else if (plain) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) my_cig_w[k] = opv[k];
+      }
+      const uint32_t *my_cig = my_cig_w;
       if (ok && !((simple || plain) && ls <= (uint32_t)MAX_DESC_READ)) { defer = true; ok = false; }  // the general kernel redoes the tests
       if (ok) ok = (plain ? plain_read : aoff + mlen + trail) == ls;  // SEQ length == CIGAR read length (utils.go:121-128)
       if (ok) {
@@ -342,8 +336,8 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
         rc.ref_lo = rc.ref_hi = rc.win = rc.ctxw = 0; rc.t0 = 0; rc.fl = rc.bpk = rc.dpk = 0;
         if (d.fl & BQ_ELIGIBLE) {
           Pieces4 P;
-          if (d.fl & BQ_COMPLEX) pieces4(s_cig[threadIdx.x], (int)(c1 - c0), p, P);
-          else if (d.b1 != 0xFFFFu) pieces4(s_cig[threadIdx.x], (int)(c1 - c0), p, P);
+          if (d.fl & BQ_COMPLEX) pieces4(my_cig_w, (int)(c1 - c0), p, P);
+          else if (d.b1 != 0xFFFFu) pieces4(my_cig_w, (int)(c1 - c0), p, P);
           else { P.v0 = (int64_t)d.D0; P.v1 = P.v2 = P.v3 = 0; P.s1 = P.s2 = P.s3 = 0; P.noref = d.D0 == BQ_NOREF ? 1u : 0u; P.np = 1; }
           rc = make_rec((int)d.a, (int)d.len, (int)d.left, d.right == 0xFFFFu ? -1 : (int)d.right, d.cov, (d.fl & BQ_REVERSED) != 0, (d.fl & BQ_LAST) != 0, P,
                         P.np < 0, rec_rp, rec_rlen, (int64_t)ls);
@@ -357,22 +351,90 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
         desc[i] = d;
       }
     }
-  }
-  // append deferred records to the workgroup's list: one LDS atomic per wave
-  const unsigned long long mask = __ballot(defer);
-  if (mask) {
+}
+
+// First pass, one thread per record; all column loads are issued before the first test (one latency, not 15), a tile ahead.
+__global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__restrict__ desc, uint32_t *skipbits, uint32_t *__restrict__ queue,
+                                                            uint32_t *queue_n, uint32_t *err, BqRec *__restrict__ recs, uint32_t *__restrict__ plist) {
+  // a workgroup handles PF_TILES * 256 consecutive records and collects the deferred ones in LDS - the general kernel's from the front of
+  // the list, the second pass's from its end: one global atomic per workgroup and list (a global atomic per wave on a single counter
+  // serialises at ~12 ns each: 9 ms for 50 M reads)
+  __shared__ uint32_t lq[PF_TILES * 256];
+  __shared__ uint32_t lcount, gbase, pcount, pbase;
+  __shared__ PfLds L;
+  const bool ref_lds = m.n_ref <= REF_LDS;
+  pf_lds_fill(L, m, 256);
+  if (threadIdx.x == 0) { lcount = 0; pcount = 0; }
+  __syncthreads();
+  const uint64_t i_first = (uint64_t)blockIdx.x * PF_TILES * 256 + threadIdx.x;
+  PfCols nxt = {};
+  if (i_first < m.n) nxt = pf_load_cols(m, i_first);
+#pragma unroll 1
+  for (int tile = 0; tile < PF_TILES; tile++) {
+    const uint64_t i = i_first + (uint64_t)tile * 256;
+    bool defer = false, to_plain = false;
+    const PfCols cur = nxt;
+    if (tile + 1 < PF_TILES && i + 256 < m.n) nxt = pf_load_cols(m, i + 256);
+    if (i < m.n) pf_record<false>(m, i, cur, L, ref_lds, desc, skipbits, err, recs, nullptr, defer, to_plain);
     const int lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long)mask) - 1;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(&lcount, (uint32_t)__popcll(mask));
-    base = __shfl(base, leader, 64);
-    if (defer) lq[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)i;
-  }
+    const unsigned long long mask = __ballot(defer);
+    if (mask) {  // one LDS atomic per wave
+      const int leader = __ffsll((long long)mask) - 1;
+      uint32_t base = 0;
+      if (lane == leader) base = atomicAdd(&lcount, (uint32_t)__popcll(mask));
+      base = __shfl(base, leader, 64);
+      if (defer) lq[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)i;
+    }
+    const unsigned long long pmask = __ballot(to_plain);
+    if (pmask) {
+      const int leader = __ffsll((long long)pmask) - 1;
+      uint32_t base = 0;
+      if (lane == leader) base = atomicAdd(&pcount, (uint32_t)__popcll(pmask));
+      base = __shfl(base, leader, 64);
+      if (to_plain) lq[PF_TILES * 256 - 1 - (base + (uint32_t)__popcll(pmask & ((1ull << lane) - 1ull)))] = (uint32_t)i;
+    }
   }
   __syncthreads();
-  if (threadIdx.x == 0) gbase = lcount ? atomicAdd(queue_n, lcount) : 0u;
+  if (threadIdx.x == 0) {
+    gbase = lcount ? atomicAdd(queue_n, lcount) : 0u;
+    pbase = pcount ? atomicAdd(queue_n + 1, pcount) : 0u;
+  }
   __syncthreads();
   for (uint32_t k = threadIdx.x; k < lcount; k += 256) queue[gbase + k] = lq[k];
+  for (uint32_t k = threadIdx.x; k < pcount; k += 256) plist[pbase + k] = lq[PF_TILES * 256 - 1 - k];
+}
+
+// Second pass: the reads of match / insertion / deletion operations, one thread per listed read (every lane of a wave does the same
+// kind of work); the list's length stays on the device.  A read this pass cannot finish either (adaptor geometry) joins the general
+// kernel's queue: one global atomic per workgroup and trip.
+__global__ __launch_bounds__(256) void k_bqsr_prologue_plain(BqCols m, BqDesc *__restrict__ desc, uint32_t *skipbits, const uint32_t *__restrict__ plist,
+                                                             uint32_t *__restrict__ queue, uint32_t *queue_n, uint32_t *err, BqRec *__restrict__ recs) {
+  __shared__ uint32_t s_cig[256][5];  // the thread's CIGAR: build_pieces / get_read_coord walk it several times
+  __shared__ uint32_t wg_n, wg_base;
+  __shared__ PfLds L;
+  const bool ref_lds = m.n_ref <= REF_LDS;
+  pf_lds_fill(L, m, 256);
+  __syncthreads();
+  const uint64_t np = (uint64_t)queue_n[1];
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (uint64_t t0 = (uint64_t)blockIdx.x * 256; t0 < np; t0 += stride) {  // (uniform trip count per workgroup: barriers inside)
+    const uint64_t t = t0 + threadIdx.x;
+    bool defer = false, to_plain = false;
+    uint32_t i = 0;
+    if (t < np) {
+      i = plist[t];
+      const PfCols cur = pf_load_cols(m, i);
+      pf_record<true>(m, i, cur, L, ref_lds, desc, skipbits, err, recs, s_cig[threadIdx.x], defer, to_plain);
+    }
+    if (threadIdx.x == 0) wg_n = 0;
+    __syncthreads();
+    uint32_t my = 0;
+    if (defer) my = atomicAdd(&wg_n, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) wg_base = wg_n ? atomicAdd(queue_n, wg_n) : 0u;
+    __syncthreads();
+    if (defer) queue[wg_base + my] = i;
+  }
 }
 
 // General prologue: one thread per record of `queue` (the records k_bqsr_prologue_fast left: anything but a plain "<len>M" CIGAR
@@ -1369,8 +1431,9 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
              c->cigar_off.p, c->seq_off.p, c->qual_off.p, c->cigar.p, c->seq4.p, c->qual.p, c->ref_len.p, c->rg_cov.p, c->n_ref,
              c->d_ref_seq.p, c->d_ref_seq_len.p, c->d_sites.p, c->d_n_sites.p, c->d_site_idx.p, c->qbounds.p};
     uint32_t *queue;
-    ELP_TRY(scratch(c, 5, n + 16, &queue));  // [0] = count, [4..] = records left to the general kernel
+    ELP_TRY(scratch(c, 5, 2 * n + 32, &queue));  // [0] = count, [4..] = records left to the general kernel; [1] = count, [n + 20..] = reads of the second pass
     ELP_HIP(c, hipMemsetAsync(queue, 0, 16, st));
+    uint32_t *plist = queue + n + 20;
     // count3.hip (read sets of one length) works from 32-byte records the prologue kernels write instead of the descriptors; it takes
     // the count if the staged reads have one length (checked once per staged column), no read can exceed --max-cycle, and the quality
     // slots fit one table pass - k_bqsr_count otherwise (ELP_COUNT_KERNEL=1 forces it: A/B measurements)
@@ -1387,7 +1450,10 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
         ELP_TRY(scratch(c, 4, n + 4, &recs));
     }
     ELP_LAUNCH(c, "bqsr_prologue_fast", k_bqsr_prologue_fast, dim3(blocks_for(n, 256 * PF_TILES)), dim3(256), 0, m, desc, skipbits, queue + 4, queue, c->err_flag.p,
-               recs);
+               recs, plist);
+    // (sized for the worst case; workgroups beyond the list's end leave at once)
+    ELP_LAUNCH(c, "bqsr_prologue_plain", k_bqsr_prologue_plain, dim3(std::min<unsigned>(blocks_for(n, 256), (unsigned)c->n_cu * 16)), dim3(256), 0, m, desc, skipbits,
+               (const uint32_t *)plist, queue + 4, queue, c->err_flag.p, recs);
     ELP_LAUNCH(c, "bqsr_prologue", k_bqsr_prologue, dim3(std::min<unsigned>(blocks_for(n, 256), (unsigned)c->n_cu * 16)), dim3(256), 0, m,
                (const uint32_t *)(queue + 4), (const uint32_t *)queue, cs_pool, desc, skipbits, c->err_flag.p, recs);
     const int lmax = (int)std::max<uint32_t>(c->max_l_seq, 1);
