@@ -93,14 +93,15 @@ struct ScoreBody {
       cand[k] = (flag[g0 + k] & (F_UNMAPPED | F_SECONDARY | F_SUPPLEMENTARY)) == 0;
     }
   }
-  static __device__ __forceinline__ uint32_t part(uint32_t x, uint32_t m, uint32_t s, uint32_t &badw) {
-    const uint32_t ge15 = (((x | 0x80808080u) - 0x0F0F0F0Fu) & 0x80808080u) >> 7;  // bit 0 of the byte: low 7 bits >= 15
-    badw |= ((((x | 0x80808080u) - 0x5E5E5E5Eu) | x) & 0x80808080u) & m;          // byte >= 94
-    return __builtin_amdgcn_sad_u8(x & (ge15 * 0xFFu) & m, 0u, s);
+  // Byte tests of a word by ONE add: for bytes below 128 - 113 (every legal quality is) adding 113 / 125 / 34 sets bit 7 of exactly the
+  // bytes >= 15 / > 2 / >= 94 without a carry into the next byte; a byte that does carry is >= 94 in the first place and is reported as
+  // such (`bad`, checked on the same word).  The words are masked to the block's bytes first, so no test needs the mask again.
+  static __device__ __forceinline__ uint32_t part(uint32_t x, uint32_t s) {  // s + the sum of the bytes >= 15
+    const uint32_t ge15 = ((x + 0x71717171u) & 0x80808080u) >> 7;
+    return __builtin_amdgcn_sad_u8(x & (ge15 * 0xFFu), 0u, s);
   }
-  static __device__ __forceinline__ uint32_t gt2(uint32_t x, uint32_t m) {  // bit 7 of every byte > 2 (inside mask m)
-    return ((((x | 0x80808080u) - 0x03030303u) | x) & 0x80808080u) & m;
-  }
+  static __device__ __forceinline__ uint32_t gt2(uint32_t x) { return (x + 0x7D7D7D7Du) & 0x80808080u; }  // bit 7 of every byte > 2
+  static __device__ __forceinline__ uint32_t ge94(uint32_t x) { return x | (x + 0x22222222u); }           // bit 7 of every byte >= 94 (or >= 128)
   struct Pre { Chunk ch; uint32_t rl; int nb; int k0; };
   __device__ __forceinline__ bool prefetch(uint32_t rl, int k0, int nb, uint64_t qpos, uint32_t, Pre &p) {
     p.rl = rl; p.nb = nb; p.k0 = k0;
@@ -109,10 +110,10 @@ struct ScoreBody {
   }
   __device__ __forceinline__ void process(Pre &p) {
     const uint4 mk = mask[p.nb];
-    const uint32_t m0 = mk.x, m1 = mk.y, m2 = mk.z, m3 = mk.w;
+    const uint32_t x0 = p.ch.w0 & mk.x, x1 = p.ch.w1 & mk.y, x2 = p.ch.w2 & mk.z, x3 = p.ch.w3 & mk.w;
     // low-quality-tail bounds: first / last quality > 2 of the read
-    const uint64_t glo = (uint64_t)gt2(p.ch.w0, m0) | ((uint64_t)gt2(p.ch.w1, m1) << 32);
-    const uint64_t ghi = (uint64_t)gt2(p.ch.w2, m2) | ((uint64_t)gt2(p.ch.w3, m3) << 32);
+    const uint64_t glo = (uint64_t)gt2(x0) | ((uint64_t)gt2(x1) << 32);
+    const uint64_t ghi = (uint64_t)gt2(x2) | ((uint64_t)gt2(x3) << 32);
     if (glo | ghi) {
       const int first = glo ? (__builtin_ctzll(glo) >> 3) : 8 + (__builtin_ctzll(ghi) >> 3);
       const int last = ghi ? 8 + ((63 - __builtin_clzll(ghi)) >> 3) : ((63 - __builtin_clzll(glo)) >> 3);
@@ -120,12 +121,9 @@ struct ScoreBody {
       atomicMax(&hi[p.rl], (uint32_t)(p.k0 + last + 1));
     }
     if (!cand[p.rl]) return;
-    uint32_t s = 0, b = 0;
-    s = part(p.ch.w0, m0, s, b);
-    s = part(p.ch.w1, m1, s, b);
-    s = part(p.ch.w2, m2, s, b);
-    s = part(p.ch.w3, m3, s, b);
-    bad |= b;
+    // a quality >= 94 (or a byte whose carry could have spoilt a neighbour's test) in a duplicate-marking candidate: the error bit
+    bad |= (ge94(x0) | ge94(x1) | ge94(x2) | ge94(x3)) & 0x80808080u;
+    const uint32_t s = part(x3, part(x2, part(x1, part(x0, 0u))));
     if (s) atomicAdd(&acc[p.rl], (int32_t)s);
   }
   __device__ __forceinline__ void group_end(uint32_t g0, uint32_t ng) {
