@@ -216,6 +216,7 @@ def main():
             tb = BqsrTables(qt, ct, xt, MAX_CYCLE).finalize()
             lut, present = tb.build_lut(0, out=lut_buf[0])
             lut_buf[0] = (lut, present)
+            eng.lut_upload(lut, present, MAX_CYCLE)  # on the context's copy stream, from this (host) thread, while the GPU sorts
             return lut, present
 
         def step_full():
@@ -228,8 +229,8 @@ def main():
             fin = host_pool.submit(lambda: finalize_lut(*eng.tables_fetch(reuse=True)))
             eng.sort_coordinate(fetch=False)
             eng.dup_metrics(100)
-            lut, present = fin.result()
-            eng.apply_bqsr(lut, present, MAX_CYCLE, fetch=False)
+            fin.result()
+            eng.apply_bqsr(None, None, MAX_CYCLE, fetch=False)
             eng.sync()
 
         def step_c2():

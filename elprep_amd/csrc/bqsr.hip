@@ -1667,17 +1667,47 @@ int elp_bqsr_tables_fetch(elp_ctx *c, int64_t *qual_tbl, int64_t *cycle_tbl, int
   return 0;
 }
 
+// The LUT's way to the device ahead of the apply call: from the thread that built it, on the context's copy stream, while the context's
+// own stream still runs the sort / metrics pass (6.4 MB at --max-cycle 500: ~0.2 ms that elp_bqsr_apply otherwise spends in front of its
+// first kernel).  The LUT lives in a buffer of its own (not in the scratch pool: other stages are running).
+int elp_bqsr_lut_upload(elp_ctx *c, int max_cycle, const uint8_t *lut, const uint8_t *cov_present) {
+  if (!c || !lut || !cov_present || max_cycle < 1) return set_error(c, ELP_ERR_ARG, "elp_bqsr_lut_upload: bad arguments");
+  ELP_HIP(c, hipSetDevice(c->device));
+  const size_t lut_bytes = (size_t)c->n_cov * ELP_NQUAL * (2 * (size_t)max_cycle + 1) * 17, all = lut_bytes + (size_t)c->n_cov;
+  if (c->lut_ev) ELP_HIP(c, hipEventSynchronize(c->lut_ev));  // (a previous upload still in flight reads the pinned buffer)
+  if (all > c->lut_pinned_cap) {
+    if (c->lut_pinned) (void)hipHostFree(c->lut_pinned);
+    c->lut_pinned = nullptr; c->lut_pinned_cap = 0;
+    ELP_HIP(c, hipHostMalloc(&c->lut_pinned, all, hipHostMallocDefault));
+    c->lut_pinned_cap = all;
+  }
+  ELP_TRY(ensure(c, c->lut_dev, all + 64));
+  memcpy(c->lut_pinned, lut, lut_bytes);
+  memcpy(static_cast<uint8_t *>(c->lut_pinned) + lut_bytes, cov_present, (size_t)c->n_cov);
+  if (!c->lut_ev) ELP_HIP(c, hipEventCreateWithFlags(&c->lut_ev, hipEventDisableTiming));
+  ELP_HIP(c, hipMemcpyAsync(c->lut_dev.p, c->lut_pinned, all, hipMemcpyHostToDevice, c->copy_stream));
+  ELP_HIP(c, hipEventRecord(c->lut_ev, c->copy_stream));
+  c->lut_uploaded_cycle = max_cycle;
+  return 0;
+}
+
 int elp_bqsr_apply(elp_ctx *c, int max_cycle, const uint8_t *lut, const uint8_t *cov_present) {
-  if (!c || !lut || !cov_present || max_cycle < 1) return set_error(c, ELP_ERR_ARG, "elp_bqsr_apply: bad arguments");
+  if (!c || max_cycle < 1 || (lut != nullptr) != (cov_present != nullptr)) return set_error(c, ELP_ERR_ARG, "elp_bqsr_apply: bad arguments");
+  if (!lut && c->lut_uploaded_cycle != max_cycle) return set_error(c, ELP_ERR_ARG, "elp_bqsr_apply: no LUT given and none uploaded for this --max-cycle (elp_bqsr_lut_upload)");
   ELP_HIP(c, hipSetDevice(c->device));
   if (c->n_cov > 255) return set_error(c, ELP_ERR_UNSUPPORTED, "more than 255 read-group covariates");
   const size_t ncyc = 2 * (size_t)max_cycle + 1;
   const size_t lut_bytes = (size_t)c->n_cov * ELP_NQUAL * ncyc * 17;
   ELP_TRY(ensure_adapted(c, false));  // low-quality-tail bounds per read (adapt_score)
   uint8_t *dl;
-  ELP_TRY(scratch(c, 0, lut_bytes + (size_t)c->n_cov + 64, &dl));
-  ELP_HIP(c, hipMemcpyAsync(dl, lut, lut_bytes, hipMemcpyHostToDevice, c->stream));
-  ELP_HIP(c, hipMemcpyAsync(dl + lut_bytes, cov_present, (size_t)c->n_cov, hipMemcpyHostToDevice, c->stream));
+  if (lut) {
+    ELP_TRY(scratch(c, 0, lut_bytes + (size_t)c->n_cov + 64, &dl));
+    ELP_HIP(c, hipMemcpyAsync(dl, lut, lut_bytes, hipMemcpyHostToDevice, c->stream));
+    ELP_HIP(c, hipMemcpyAsync(dl + lut_bytes, cov_present, (size_t)c->n_cov, hipMemcpyHostToDevice, c->stream));
+  } else {
+    dl = c->lut_dev.p;  // uploaded ahead of the call: this stream waits for the copy, not the host
+    ELP_HIP(c, hipStreamWaitEvent(c->stream, c->lut_ev, 0));
+  }
   const uint64_t n = c->n;
   if (n) {
     if (c->qual_bytes) {

@@ -155,6 +155,11 @@ struct elp_ctx {
   elp::DVec<uint32_t> rg_ids_off;
   bool have_rg_ids = false;
   hipStream_t copy_stream = nullptr;
+  elp::DVec<uint8_t> lut_dev;      // ApplyBQSR's dense LUT + covariate-present bytes uploaded ahead of elp_bqsr_apply (elp_bqsr_lut_upload)
+  void *lut_pinned = nullptr;
+  size_t lut_pinned_cap = 0;
+  hipEvent_t lut_ev = nullptr;
+  int lut_uploaded_cycle = 0;
   hipEvent_t tables_ev = nullptr;  // recorded on `stream` behind the last writer of dev_tables (gather, tables_add, all-reduce): elp_bqsr_tables_fetch
                                    // copies on copy_stream behind it, so the context's stream is free for the next stage meanwhile
   void *bounce[2] = {nullptr, nullptr};  // pinned double buffer for pageable sources

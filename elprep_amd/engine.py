@@ -313,7 +313,17 @@ class Engine:
         self._check(self.L.elp_allreduce_i64(self.h, _vp(out), out.size))
         return out.reshape(a.shape)
 
-    def apply_bqsr(self, lut: np.ndarray, cov_present: np.ndarray, max_cycle: int = 500, fetch: bool = True) -> Optional[np.ndarray]:
+    def lut_upload(self, lut: np.ndarray, cov_present: np.ndarray, max_cycle: int = 500):
+        """the LUT's way to the device ahead of apply_bqsr(None, None, ...): callable from the thread that built it while other calls run"""
+        lut = np.ascontiguousarray(lut, dtype=np.uint8)
+        cp = np.ascontiguousarray(cov_present, dtype=np.uint8)
+        assert lut.size == self.header.n_cov * NQUAL * (2 * max_cycle + 1) * 17
+        self._check(self.L.elp_bqsr_lut_upload(self.h, max_cycle, _vp(lut), _vp(cp)))
+
+    def apply_bqsr(self, lut: Optional[np.ndarray], cov_present: Optional[np.ndarray], max_cycle: int = 500, fetch: bool = True) -> Optional[np.ndarray]:
+        if lut is None:  # uploaded ahead (lut_upload)
+            self._check(self.L.elp_bqsr_apply(self.h, max_cycle, C.c_void_p(0), C.c_void_p(0)))
+            return self.qual() if fetch else None
         lut = np.ascontiguousarray(lut, dtype=np.uint8)
         cp = np.ascontiguousarray(cov_present, dtype=np.uint8)
         assert lut.size == self.header.n_cov * NQUAL * (2 * max_cycle + 1) * 17

@@ -273,6 +273,10 @@ int elp_allreduce_i64(elp_ctx *ctx, int64_t *buf, size_t n);
  * densely tabulated by the host from the finalized tables (context index 16 = key -1); cov_present[c] = 0 means the read
  * group is absent from the tables (read left untouched, :953-955).  Rewrites the staged qual column in place. */
 int elp_bqsr_apply(elp_ctx *ctx, int max_cycle, const uint8_t *lut, const uint8_t *cov_present);
+/* The LUT's way to the device ahead of the call: from the thread that built it (Go: the goroutine that ran FinalizeBQSRTables), on a copy
+ * stream of the context, while other calls (sort, metrics) run on the context from another thread; elp_bqsr_apply(ctx, max_cycle, NULL,
+ * NULL) then uses it.  The only other call that may share a context with running calls is elp_bqsr_tables_fetch. */
+int elp_bqsr_lut_upload(elp_ctx *ctx, int max_cycle, const uint8_t *lut, const uint8_t *cov_present);
 int elp_get_qual(elp_ctx *ctx, uint8_t *qual_out /* qual_bytes, staging order and offsets */);
 
 /* ---- snapshot of the two columns the path mutates (FLAG by elp_mark_duplicates, QUAL by elp_bqsr_apply) ----

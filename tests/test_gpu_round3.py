@@ -436,3 +436,28 @@ def test_emit_merged_bam_is_the_merge_of_the_two_sorted_outputs():
     assert eg.emit_merged_bam(e0).tobytes() == b"".join(rg)
     for eng in (eg, es, e0):
         eng.close()
+
+
+def test_lut_uploaded_ahead_of_apply():
+    """elp_bqsr_lut_upload + elp_bqsr_apply(NULL, NULL): the same bytes as the call that brings its LUT along; without an upload the
+    call is refused"""
+    cfg, b, h, refs, sites = dataset("tiny", 6000, 19, 0.03)
+    outs = []
+    for ahead in (False, True):
+        e = Engine(h)
+        e.stage(b)
+        e.mark_duplicates(True)
+        for r in range(h.n_ref):
+            e.set_reference(r, refs[r])
+            e.set_known_sites(r, sites[r])
+        qt, ct, xt = e.recalibrate(500)
+        lut, present = BqsrTables(qt, ct, xt, 500).finalize().build_lut(0)
+        if ahead:
+            with pytest.raises(Exception):
+                e.apply_bqsr(None, None, 500)
+            e.lut_upload(lut, present, 500)
+            outs.append(e.apply_bqsr(None, None, 500))
+        else:
+            outs.append(e.apply_bqsr(lut, present, 500))
+        e.close()
+    assert np.array_equal(outs[0], outs[1]) and (outs[0] != b.qual).any()
