@@ -365,8 +365,7 @@ __global__ __launch_bounds__(256) void k_iota(uint32_t *v, uint64_t n) {
 // <= TIE_SMALL records are ranked by all-pairs comparison, members of longer runs are flagged for the radix tie-break.
 constexpr int TS_TILES = 16;
 __global__ __launch_bounds__(256) void k_tie_scan(uint64_t n, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ perm_in,
-                                                  uint32_t *__restrict__ perm_out, uint32_t *__restrict__ large_flag, uint32_t *__restrict__ list,
-                                                  uint32_t *list_n) {
+                                                  uint32_t *__restrict__ perm_out, uint32_t *__restrict__ list, uint32_t *list_n) {
   // a workgroup handles TS_TILES * 256 consecutive records and collects its run members in LDS: ONE global atomic per workgroup
   // (a global atomic per wave on the single list counter serialises at ~12 ns each: 9 ms for 50 M records, measured)
   __shared__ uint32_t lq[TS_TILES * 256];
@@ -381,7 +380,6 @@ __global__ __launch_bounds__(256) void k_tie_scan(uint64_t n, const uint64_t *__
       const uint64_t k = keys[i], kp = i > 0 ? keys[i - 1] : ~k, kn = i + 1 < n ? keys[i + 1] : ~k;
       const uint32_t me = perm_in[i];
       in_run = kp == k || kn == k;
-      large_flag[i] = 0;
       if (!in_run) perm_out[i] = me;
     }
     const unsigned long long mask = __ballot(in_run);
@@ -399,8 +397,8 @@ __global__ __launch_bounds__(256) void k_tie_scan(uint64_t n, const uint64_t *__
   for (uint32_t k = threadIdx.x; k < lcount; k += 256) list[gbase + k] = lq[k];
 }
 __global__ __launch_bounds__(256) void k_tie_small(uint64_t n, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ perm_in,
-                                                   uint32_t *__restrict__ perm_out, uint32_t *__restrict__ large_flag, const uint32_t *__restrict__ list,
-                                                   const uint32_t *__restrict__ list_n, TieCols t) {
+                                                   uint32_t *__restrict__ perm_out, uint32_t *__restrict__ bounds /* [0] starts, [1] ends counted; [4 + k] / [4 + cap + k] the positions */,
+                                                   uint32_t bounds_cap, const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_n, TieCols t) {
   const uint64_t j0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j0 >= (uint64_t)*list_n) return;
   const uint64_t i = list[j0];
@@ -419,8 +417,11 @@ __global__ __launch_bounds__(256) void k_tie_small(uint64_t n, const uint64_t *_
     }
   }
   if (large) {
-    large_flag[i] = 1;
+    // a run of more than TIE_SMALL records goes to the radix tie-break as a RANGE of the sorted array: its first member reports where
+    // it starts, its last one where it ends (two short lists the host pairs up) - no flag per record, no scan over all records
     perm_out[i] = me;
+    if (i == 0 || keys[i - 1] != k) { const uint32_t at = atomicAdd(&bounds[0], 1u); if (at < bounds_cap) bounds[4 + at] = (uint32_t)i; }
+    if (i + 1 == n || keys[i + 1] != k) { const uint32_t at = atomicAdd(&bounds[1], 1u); if (at < bounds_cap) bounds[4 + bounds_cap + at] = (uint32_t)i; }
     return;
   }
   if (e - s == 2) {
@@ -443,15 +444,22 @@ __global__ __launch_bounds__(256) void k_tie_small(uint64_t n, const uint64_t *_
   perm_out[s + rank] = me;
 }
 
-__global__ __launch_bounds__(256) void k_large_fill(uint64_t n, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ perm,
-                                                    const uint32_t *__restrict__ large_flag, const uint32_t *__restrict__ idx,
-                                                    uint32_t *__restrict__ u_pos, uint32_t *__restrict__ u_read, uint32_t *__restrict__ u_head) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || !large_flag[i]) return;
-  const uint32_t j = idx[i];
-  u_pos[j] = (uint32_t)i;
-  u_read[j] = perm[i];
-  u_head[j] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+// members of the large runs, compacted: run r = positions [start[r], start[r] + (first[r + 1] - first[r])) of the sorted array, its members are
+// numbers first[r] .. first[r + 1] - 1; u_seg = 1 + r (the key of the last, stable round: runs stay apart and in order)
+__global__ __launch_bounds__(256) void k_large_fill(uint32_t nu, uint32_t nr, const uint32_t *__restrict__ start, const uint32_t *__restrict__ first,
+                                                    const uint32_t *__restrict__ perm, uint32_t *__restrict__ u_pos, uint32_t *__restrict__ u_read,
+                                                    uint32_t *__restrict__ u_seg) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nu) return;
+  uint32_t lo = 0, hi = nr;  // the run with first[r] <= j < first[r + 1]
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (first[mid] <= j) lo = mid; else hi = mid;
+  }
+  const uint32_t pos = start[lo] + (j - first[lo]);
+  u_pos[j] = pos;
+  u_read[j] = perm[pos];
+  u_seg[j] = lo + 1u;
 }
 
 // comparator byte string of record r: QNAME zero-padded to maxq, then modFlag(2, BE), MAPQ(1), NextREFID^msb(4, BE), PNEXT^msb(4, BE)
@@ -563,11 +571,6 @@ __global__ __launch_bounds__(256) void k_seg_keys(uint32_t nu, const uint32_t *_
   if (j < nu) keys[j] = (uint64_t)u_seg_incl[vals[j]];
 }
 
-// inclusive "segment rank": exclusive scan of head flags + own flag
-__global__ __launch_bounds__(256) void k_add_own(uint32_t nu, const uint32_t *__restrict__ head, uint32_t *__restrict__ excl) {
-  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < nu) excl[j] += head[j];
-}
 
 __global__ __launch_bounds__(256) void k_large_scatter(uint32_t nu, const uint32_t *__restrict__ vals_sorted, const uint32_t *__restrict__ u_pos,
                                                        const uint32_t *__restrict__ u_read, uint32_t *__restrict__ perm_out) {
@@ -593,32 +596,65 @@ static int sort_impl(elp_ctx *c) {
   uint32_t *vs;
   ELP_TRY(radix_sort_pairs_low(c, k0, v0, k1, v1, n, (c->key_bits + 7) / 8, &ks, &vs, c->key.p, true));
   TieCols t{c->qname_off.p, c->qname.p, c->flag.p, c->mapq.p, c->next_refid.p, c->pnext.p, c->tlen.p};
-  uint32_t *large_flag = flags, *large_idx = flags + n;
+  // run members -> compact list (the other half of `vbuf` is free: the radix sort left its result in one half); bounds of the runs
+  // longer than TIE_SMALL -> two short lists in `flags` ([0], [1] their lengths)
+  const uint32_t bounds_cap = (uint32_t)std::min<uint64_t>(n / TIE_SMALL + 16, (2 * n + 8 - 4) / 2);
+  uint32_t *bounds = flags;
   {
-    // run members -> compact list (the other half of `vbuf` is free: the radix sort left its result in one half)
     uint32_t *list = (vs == v0) ? v1 : v0, *list_n = c->err_flag.p + 3;  // the scan-total mailbox
     ELP_HIP(c, hipMemsetAsync(list_n, 0, 4, c->stream));
-    ELP_LAUNCH(c, "tie_scan", k_tie_scan, dim3(blocks_for(n, 256 * TS_TILES)), dim3(256), 0, n, (const uint64_t *)ks, (const uint32_t *)vs, c->perm.p, large_flag, list,
-               list_n);
+    ELP_HIP(c, hipMemsetAsync(bounds, 0, 16, c->stream));
+    ELP_LAUNCH(c, "tie_scan", k_tie_scan, dim3(blocks_for(n, 256 * TS_TILES)), dim3(256), 0, n, (const uint64_t *)ks, (const uint32_t *)vs, c->perm.p, list, list_n);
     // sized for the worst case; workgroups beyond the list's end leave at once
-    ELP_LAUNCH(c, "tie_small", k_tie_small, dim3(blocks_for(n, 256)), dim3(256), 0, n, (const uint64_t *)ks, (const uint32_t *)vs, c->perm.p,
-               large_flag, (const uint32_t *)list, (const uint32_t *)list_n, t);
+    ELP_LAUNCH(c, "tie_small", k_tie_small, dim3(blocks_for(n, 256)), dim3(256), 0, n, (const uint64_t *)ks, (const uint32_t *)vs, c->perm.p, bounds, bounds_cap,
+               (const uint32_t *)list, (const uint32_t *)list_n, t);
     ELP_HIP(c, hipMemsetAsync(list_n, 0, 4, c->stream));
   }
+  // ONE read-back: the two counts and the first run bounds (all of them unless there are more than TIE_HEAD runs: then a second copy)
+  constexpr uint32_t TIE_HEAD = 256;
+  std::vector<uint32_t> hb(4 + 2 * (size_t)TIE_HEAD), starts, ends;
+  {
+    const uint32_t head = std::min<uint32_t>(TIE_HEAD, bounds_cap);
+    ELP_HIP(c, hipMemcpyAsync(hb.data(), bounds, (4 + (size_t)head) * 4, hipMemcpyDeviceToHost, c->stream));
+    ELP_HIP(c, hipMemcpyAsync(hb.data() + 4 + TIE_HEAD, bounds + 4 + bounds_cap, (size_t)head * 4, hipMemcpyDeviceToHost, c->stream));
+    ELP_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  const uint32_t nr = hb[0];
+  if (nr != hb[1] || nr > bounds_cap) return set_error(c, ELP_ERR_HIP, "coordinate sort: %u starts and %u ends of long runs (internal)", hb[0], hb[1]);
   uint32_t nu = 0;
-  ELP_TRY(exclusive_scan_u32(c, large_flag, large_idx, n, &nu));
-  if (nu > 0) {
+  if (nr > 0) {
+    starts.resize(nr); ends.resize(nr);
+    if (nr <= TIE_HEAD) {
+      std::copy(hb.begin() + 4, hb.begin() + 4 + nr, starts.begin());
+      std::copy(hb.begin() + 4 + TIE_HEAD, hb.begin() + 4 + TIE_HEAD + nr, ends.begin());
+    } else {
+      ELP_HIP(c, hipMemcpyAsync(starts.data(), bounds + 4, (size_t)nr * 4, hipMemcpyDeviceToHost, c->stream));
+      ELP_HIP(c, hipMemcpyAsync(ends.data(), bounds + 4 + bounds_cap, (size_t)nr * 4, hipMemcpyDeviceToHost, c->stream));
+      ELP_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    std::sort(starts.begin(), starts.end());
+    std::sort(ends.begin(), ends.end());  // runs are disjoint ranges: the r-th start belongs to the r-th end
+    std::vector<uint32_t> first(nr + 1);
+    uint64_t total = 0;
+    for (uint32_t r = 0; r < nr; r++) {
+      if (ends[r] < starts[r] || (r + 1 < nr && starts[r + 1] <= ends[r])) return set_error(c, ELP_ERR_HIP, "coordinate sort: long runs overlap (internal)");
+      first[r] = (uint32_t)total;
+      total += (uint64_t)ends[r] - starts[r] + 1;
+    }
+    first[nr] = (uint32_t)total;
+    nu = (uint32_t)total;
     // compacted large-run members
     uint32_t *u;
-    ELP_TRY(scratch(c, 3, (size_t)6 * nu + 64, &u));
-    uint32_t *u_pos = u, *u_read = u + nu, *u_head = u + 2 * (size_t)nu, *u_seg = u + 3 * (size_t)nu, *uv0 = u + 4 * (size_t)nu, *uv1 = u + 5 * (size_t)nu;
+    ELP_TRY(scratch(c, 3, (size_t)5 * nu + 2 * (size_t)nr + 64, &u));
+    uint32_t *u_pos = u, *u_read = u + nu, *u_seg = u + 2 * (size_t)nu, *uv0 = u + 3 * (size_t)nu, *uv1 = u + 4 * (size_t)nu, *d_start = u + 5 * (size_t)nu,
+             *d_first = d_start + nr;
     uint64_t *uk;
     ELP_TRY(scratch(c, 4, (size_t)2 * nu + 16, &uk));
     uint64_t *uk0 = uk, *uk1 = uk + nu;
-    ELP_LAUNCH(c, "large_fill", k_large_fill, dim3(blocks_for(n, 256)), dim3(256), 0, n, (const uint64_t *)ks, (const uint32_t *)vs,
-               (const uint32_t *)large_flag, (const uint32_t *)large_idx, u_pos, u_read, u_head);
-    ELP_TRY(exclusive_scan_u32(c, u_head, u_seg, nu, nullptr));
-    ELP_LAUNCH(c, "add_own", k_add_own, dim3(blocks_for(nu, 256)), dim3(256), 0, nu, (const uint32_t *)u_head, u_seg);
+    ELP_HIP(c, hipMemcpyAsync(d_start, starts.data(), (size_t)nr * 4, hipMemcpyHostToDevice, c->stream));
+    ELP_HIP(c, hipMemcpyAsync(d_first, first.data(), ((size_t)nr + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    ELP_LAUNCH(c, "large_fill", k_large_fill, dim3(blocks_for(nu, 256)), dim3(256), 0, nu, nr, (const uint32_t *)d_start, (const uint32_t *)d_first, (const uint32_t *)vs,
+               u_pos, u_read, u_seg);
     ELP_LAUNCH(c, "iota", k_iota, dim3(blocks_for(nu, 256)), dim3(256), 0, uv0, (uint64_t)nu);
     const uint32_t maxq = c->max_qname_len;
     const uint32_t m_bytes = maxq + 15;  // <= MAX_QNAME + 15 <= 32 * TIE_LIVE_WORDS positions (elp_stage enforces the QNAME limit)
