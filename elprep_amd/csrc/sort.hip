@@ -328,6 +328,8 @@ struct TieCols {
   const uint16_t *flag;
   const uint8_t *mapq;
   const int32_t *next_refid, *pnext, *tlen;
+  const uint8_t *rows = nullptr;  // the radix tie-break's comparator strings written out (k_material_rows): rows[m * rw + j] = byte j of member m
+  uint32_t rw = 0;
 };
 
 // comparator tail of CoordinateLess (:439-472) for two records with equal (refid, pos, strand)
@@ -464,7 +466,8 @@ __global__ __launch_bounds__(256) void k_large_fill(uint32_t nu, uint32_t nr, co
 
 // comparator byte string of record r: QNAME zero-padded to maxq, then modFlag(2, BE), MAPQ(1), NextREFID^msb(4, BE), PNEXT^msb(4, BE)
 // (both zero when unpaired; paired-ness is part of modFlag so it is constant within equal prefixes), TLEN^msb(4, BE).
-__device__ inline uint32_t material_byte(const TieCols &t, uint32_t r, uint32_t j, uint32_t maxq) {
+__device__ inline uint32_t material_byte(const TieCols &t, uint32_t r, uint32_t j, uint32_t maxq, uint32_t m = 0) {
+  if (t.rows) return t.rows[(size_t)m * t.rw + j];  // m = the member's number
   if (j < maxq) {
     const uint64_t o = t.qname_off[r];
     const uint32_t l = (uint32_t)(t.qname_off[r + 1] - o);
@@ -487,6 +490,22 @@ __device__ inline uint32_t material_byte(const TieCols &t, uint32_t r, uint32_t 
   return 0u;
 }
 
+// The comparator strings of the large runs' members written out once, `rw` bytes per member (a thread writes eight bytes): the kernels
+// of the LSD rounds then read a member's bytes from one or two cache lines instead of chasing QNAME offsets, names and four columns per
+// byte (k_material_values and the key kernels took 0.5 ms for the 500 K unmapped reads of the bench workload).
+__global__ __launch_bounds__(256) void k_material_rows(uint32_t nu, const uint32_t *__restrict__ u_read, uint32_t maxq, uint32_t nbytes, uint32_t rw,
+                                                       uint8_t *__restrict__ rows, TieCols t /* t.rows == nullptr */) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t per = rw >> 3;
+  const uint64_t m = g / per;
+  if (m >= nu) return;
+  const uint32_t k = (uint32_t)(g - m * per) * 8u, r = u_read[m];
+  uint64_t v = 0;
+  for (uint32_t i = 0; i < 8; i++)
+    if (k + i < nbytes) v |= (uint64_t)material_byte(t, r, k + i, maxq) << (8 * i);
+  reinterpret_cast<uint64_t *>(rows + m * rw)[k >> 3] = v;
+}
+
 // bit j of live[]: byte j of the comparator string is not the same for all members of large runs (compared with member 0's).
 // QNAME bytes are compared eight at a time (zero-padded behind the name's end, as material_byte pads them).
 __global__ __launch_bounds__(256) void k_material_live(uint32_t nu, const uint32_t *__restrict__ u_read, uint32_t maxq, uint32_t nbytes,
@@ -495,7 +514,20 @@ __global__ __launch_bounds__(256) void k_material_live(uint32_t nu, const uint32
   if (threadIdx.x < elp_ctx::TIE_LIVE_WORDS) acc[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
-  if (m < nu) {
+  if (m < nu && t.rows) {
+    // the strings are written out: member m's row against member 0's, eight bytes at a time
+    const uint64_t *a8 = reinterpret_cast<const uint64_t *>(t.rows + (size_t)m * t.rw), *b8 = reinterpret_cast<const uint64_t *>(t.rows);
+    for (uint32_t k = 0; k < nbytes; k += 8) {
+      uint64_t x = a8[k >> 3] ^ b8[k >> 3];
+      if (x) {
+        x |= x >> 4; x |= x >> 2; x |= x >> 1;
+        x &= 0x0101010101010101ull;
+        const uint32_t bits = (uint32_t)((x * 0x0102040810204080ull) >> 56);
+        for (uint32_t i = 0; i < 8 && k + i < nbytes; i++)
+          if ((bits >> i) & 1u) atomicOr(&acc[(k + i) >> 5], 1u << ((k + i) & 31));
+      }
+    }
+  } else if (m < nu) {
     const uint32_t r = u_read[m], r0 = u_read[0];
     const uint64_t oa = t.qname_off[r], ob = t.qname_off[r0];
     const uint32_t la = (uint32_t)(t.qname_off[r + 1] - oa), lb = (uint32_t)(t.qname_off[r0 + 1] - ob);
@@ -529,7 +561,7 @@ __global__ __launch_bounds__(256) void k_material_values(uint32_t nu, const uint
   for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < nu; m += gridDim.x * blockDim.x) {
     const uint32_t r = u_read[m];
     for (uint32_t k = 0; k < lp.n; k++) {
-      const uint32_t v = material_byte(t, r, lp.pos[k], maxq);
+      const uint32_t v = material_byte(t, r, lp.pos[k], maxq, m);
       const uint32_t bit = 1u << (v & 31u);
       uint32_t *w = &acc[k * 8 + (v >> 5)];
       if (!(*w & bit)) atomicOr(w, bit);
@@ -547,9 +579,9 @@ __global__ __launch_bounds__(256) void k_material_keys_packed(uint32_t nu, const
                                                               TieCols t) {
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nu) return;
-  const uint32_t r = u_read[vals[j]];
+  const uint32_t mem = vals[j], r = u_read[mem];
   uint64_t k = 0;
-  for (uint32_t b = 0; b < sel.n; b++) k |= (uint64_t)lut[(uint32_t)sel.slot[b] * 256u + material_byte(t, r, sel.pos[b], maxq)] << sel.shift[b];
+  for (uint32_t b = 0; b < sel.n; b++) k |= (uint64_t)lut[(uint32_t)sel.slot[b] * 256u + material_byte(t, r, sel.pos[b], maxq, mem)] << sel.shift[b];
   keys[j] = k;
 }
 
@@ -559,9 +591,9 @@ __global__ __launch_bounds__(256) void k_material_keys_sel(uint32_t nu, const ui
                                                            TieSel sel, uint32_t maxq, uint64_t *__restrict__ keys, TieCols t) {
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nu) return;
-  const uint32_t r = u_read[vals[j]];
+  const uint32_t mem = vals[j], r = u_read[mem];
   uint64_t k = 0;
-  for (uint32_t b = 0; b < sel.n; b++) k = (k << 8) | material_byte(t, r, sel.pos[b], maxq);
+  for (uint32_t b = 0; b < sel.n; b++) k = (k << 8) | material_byte(t, r, sel.pos[b], maxq, mem);
   keys[j] = k;
 }
 
@@ -644,8 +676,12 @@ static int sort_impl(elp_ctx *c) {
     first[nr] = (uint32_t)total;
     nu = (uint32_t)total;
     // compacted large-run members
+    // (+ the members' comparator strings written out, if that takes at most 512 MB: else every kernel reads the columns)
+    const uint32_t rw = (c->max_qname_len + 15u + 15u) & ~15u;
+    const bool use_rows = (uint64_t)nu * rw <= (512ull << 20);
+    const size_t u_words = ((size_t)5 * nu + 2 * (size_t)nr + 64 + 3) & ~(size_t)3;
     uint32_t *u;
-    ELP_TRY(scratch(c, 3, (size_t)5 * nu + 2 * (size_t)nr + 64, &u));
+    ELP_TRY(scratch(c, 3, u_words + (use_rows ? ((size_t)nu * rw + 64) / 4 : 0), &u));
     uint32_t *u_pos = u, *u_read = u + nu, *u_seg = u + 2 * (size_t)nu, *uv0 = u + 3 * (size_t)nu, *uv1 = u + 4 * (size_t)nu, *d_start = u + 5 * (size_t)nu,
              *d_first = d_start + nr;
     uint64_t *uk;
@@ -663,6 +699,13 @@ static int sort_impl(elp_ctx *c) {
     static_assert(elp_ctx::MAX_QNAME + 15 <= 32 * elp_ctx::TIE_LIVE_WORDS, "live-position bitmap too small");
     ELP_TRY(ensure(c, c->tie_live, elp_ctx::TIE_LIVE_WORDS));
     ELP_HIP(c, hipMemsetAsync(c->tie_live.p, 0, elp_ctx::TIE_LIVE_WORDS * sizeof(uint32_t), c->stream));
+    if (use_rows) {
+      uint8_t *rows = reinterpret_cast<uint8_t *>(u + u_words);
+      ELP_LAUNCH(c, "material_rows", k_material_rows, dim3(blocks_for((uint64_t)nu * (rw >> 3), 256)), dim3(256), 0, nu, (const uint32_t *)u_read, maxq, m_bytes, rw,
+                 rows, t);
+      t.rows = rows;
+      t.rw = rw;
+    }
     ELP_LAUNCH(c, "material_live", k_material_live, dim3(blocks_for(nu, 256)), dim3(256), 0, nu, (const uint32_t *)u_read, maxq, m_bytes,
                c->tie_live.p, t);
     uint32_t live[elp_ctx::TIE_LIVE_WORDS];
