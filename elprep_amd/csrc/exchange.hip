@@ -103,7 +103,21 @@ static int peer_copy(elp_ctx *dst, void *to, elp_ctx *src, const void *from, siz
 
 using namespace elp;
 
+static int copy_piece(elp_ctx *dst, elp_ctx *src, const uint32_t *idx, uint64_t n, int new_split, int tag_sr);
+
+// the call moves its records in pieces whose columns stay below 4 GiB each (the gather's offsets are scanned in 32 bits)
 extern "C" int elp_copy_records(elp_ctx *dst, elp_ctx *src, const uint32_t *idx, uint64_t n, int new_split, int tag_sr) {
+  if (!dst || !src || dst == src || (!idx && n)) return set_error(dst, ELP_ERR_ARG, "elp_copy_records: bad arguments");
+  const uint64_t widest = std::max<uint64_t>({(uint64_t)src->max_l_seq, (uint64_t)elp_ctx::MAX_QNAME, src->max_raw_rec, 1024});
+  const uint64_t piece = std::max<uint64_t>(1, std::min<uint64_t>(1u << 22, 0xF0000000ull / widest));
+  for (uint64_t at = 0; at < n; at += piece) {
+    const int rc = copy_piece(dst, src, idx + at, std::min<uint64_t>(piece, n - at), new_split, tag_sr);
+    if (rc) return rc;  // (pieces already appended stay: the call reports how far it got through dst's record count)
+  }
+  return 0;
+}
+
+static int copy_piece(elp_ctx *dst, elp_ctx *src, const uint32_t *idx, uint64_t n, int new_split, int tag_sr) {
   if (!dst || !src || dst == src || (!idx && n)) return set_error(dst, ELP_ERR_ARG, "elp_copy_records: bad arguments");
   if (!dst->have_header || !src->have_header || dst->n_ref != src->n_ref || dst->n_rg != src->n_rg || dst->h_ref_len != src->h_ref_len)
     return set_error(dst, ELP_ERR_ARG, "elp_copy_records: the two contexts need the same header");

@@ -176,7 +176,7 @@ int elp_split_classify(elp_ctx *ctx, const int32_t *group_of_ref, int32_t n_grou
  *   to `dst` - two contexts of this process on one GPU or on two (device-to-device / peer copies of gathered column slices; nothing
  *   passes through the host).  new_split >= 0: the split id the copies get (else they keep theirs); tag_sr != 0: live records arrive as
  *   sr-tagged copies.  FLAG and QUAL travel as they are now; the inflated BAM records travel too if both contexts hold them
- *   (elp_stage_bam).  At most 4 GiB of any one column per call. */
+ *   (elp_stage_bam).  Large sets move in pieces inside the call; on an error the pieces already appended stay (elp_num_records tells). */
 int elp_copy_records(elp_ctx *dst, elp_ctx *src, const uint32_t *idx, uint64_t n, int new_split, int tag_sr);
 int elp_merge_spread(elp_ctx *groups, elp_ctx *spread, uint64_t *slot_of_spread_out);
 

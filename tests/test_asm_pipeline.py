@@ -16,3 +16,26 @@ def test_no_use_of_in_flight_registers():
         n_loads, bad = chk.check(os.path.join(ROOT, "elprep_amd", "csrc", name))
         assert n_loads > 0, name
         assert not bad, f"{name}: {bad[:5]}"
+
+
+_PROBE = """
+#include <hip/hip_runtime.h>
+#include <cstdint>
+__global__ void k(const uint32_t *p, uint32_t *o) {
+  uint32_t v;
+  asm volatile("global_load_dword %%0, %%1, off" : "=v"(v) : "v"(p + threadIdx.x) : "memory");
+  %s
+  o[threadIdx.x] = v + 1u;
+}
+"""
+
+
+def test_the_checker_sees_a_use_in_front_of_the_wait(tmp_path):
+    """the guard is not vacuous: a load whose result is used without the hand-placed wait is reported, the same kernel with the wait is not"""
+    bad, good = tmp_path / "bad.hip", tmp_path / "good.hip"
+    bad.write_text(_PROBE % "")
+    good.write_text(_PROBE % 'asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); asm volatile("" : "+v"(v));')
+    n_bad, v_bad = chk.check(str(bad))
+    n_good, v_good = chk.check(str(good))
+    assert n_bad == 1 and v_bad, "a use of an in-flight register went unnoticed"
+    assert n_good == 1 and not v_good, v_good
