@@ -161,7 +161,8 @@ __device__ __forceinline__ void pf_lds_fill(PfLds &L, const BqCols &m, int nt) {
 // PLAIN_PASS true: the second pass over the reads the first one listed; my_cig_w = five LDS words of the thread.
 template <bool PLAIN_PASS>
 __device__ __forceinline__ void pf_record(const BqCols &m, const uint64_t i, const PfCols &cur, const PfLds &L, const bool ref_lds, BqDesc *__restrict__ desc,
-                                          uint32_t *skipbits, uint32_t *err, BqRec *__restrict__ recs, uint32_t *my_cig_w, bool &defer, bool &to_plain) {
+                                          uint32_t *skipbits, uint32_t *err, const bool recs /* records, not descriptors */, uint32_t *my_cig_w, bool &defer, bool &to_plain,
+                                          BqRec &rc_out, int &rc_class) {
     const uint8_t has_sr = cur.has_sr, mq = cur.mq;
     const uint16_t f = cur.f, rg = cur.rg;
     const int32_t r = cur.r, p = cur.p, pnext = cur.pnext, tlen = cur.tlen, nrefid = cur.nrefid;
@@ -344,9 +345,10 @@ __device__ __forceinline__ void pf_record(const BqCols &m, const uint64_t i, con
           if (used_col) rc.fl |= RC_SKIPCOL;
           else if ((rc.fl & RC_GENERAL) && rec_skipped_walk) atomicOr(&err[0], 1024u);  // (cannot happen: rec_simple restates make_rec's tests)
         }
-        reinterpret_cast<uint4 *>(recs)[2 * i] = make_uint4(rc.ref_lo, rc.ref_hi, rc.win, rc.ctxw);
-        reinterpret_cast<uint4 *>(recs)[2 * i + 1] = make_uint4((uint32_t)rc.t0, rc.fl, rc.bpk, rc.dpk);
         if (rc.fl & RC_GENERAL) desc[i] = d;
+        rc_class = rec_class(rc);
+        rec_pack_idx(rc, (uint32_t)i);
+        rc_out = rc;
       } else {
         desc[i] = d;
       }
@@ -355,7 +357,7 @@ __device__ __forceinline__ void pf_record(const BqCols &m, const uint64_t i, con
 
 // First pass, one thread per record; all column loads are issued before the first test (one latency, not 15), a tile ahead.
 __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__restrict__ desc, uint32_t *skipbits, uint32_t *__restrict__ queue,
-                                                            uint32_t *queue_n, uint32_t *err, BqRec *__restrict__ recs, uint32_t *__restrict__ plist) {
+                                                            uint32_t *queue_n, uint32_t *err, RecOut ro, uint32_t *__restrict__ plist) {
   // a workgroup handles PF_TILES * 256 consecutive records and collects the deferred ones in LDS - the general kernel's from the front of
   // the list, the second pass's from its end: one global atomic per workgroup and list (a global atomic per wave on a single counter
   // serialises at ~12 ns each: 9 ms for 50 M reads)
@@ -375,7 +377,16 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
     bool defer = false, to_plain = false;
     const PfCols cur = nxt;
     if (tile + 1 < PF_TILES && i + 256 < m.n) nxt = pf_load_cols(m, i + 256);
-    if (i < m.n) pf_record<false>(m, i, cur, L, ref_lds, desc, skipbits, err, recs, nullptr, defer, to_plain);
+    BqRec rc;
+    int rcl = 0;
+    if (i < m.n) pf_record<false>(m, i, cur, L, ref_lds, desc, skipbits, err, ro.recs != nullptr, nullptr, defer, to_plain, rc, rcl);
+    if (ro.recs) {  // the tile's records, compacted: class 1 into this wave's segment, the rare class 2 ones (windows the record cannot describe) behind
+      const uint32_t seg = (blockIdx.x * 4u + (threadIdx.x >> 6)) % (uint32_t)C3_NSEG;
+      const uint32_t at1 = wave_append(rcl == 1, &ro.cnt[seg * C3_CSTRIDE]);
+      if (rcl == 1) rec_store(ro.recs, (uint64_t)seg * ro.cap_s + at1, rc);
+      const uint32_t at2 = wave_append(rcl == 2, &ro.cnt[C3_NSEG * C3_CSTRIDE]);
+      if (rcl == 2) rec_store(ro.recs, (uint64_t)C3_NSEG * ro.cap_s + at2, rc);
+    }
     const int lane = threadIdx.x & 63;
     const unsigned long long mask = __ballot(defer);
     if (mask) {  // one LDS atomic per wave
@@ -408,9 +419,9 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
 // kind of work); the list's length stays on the device.  A read this pass cannot finish either (adaptor geometry) joins the general
 // kernel's queue: one global atomic per workgroup and trip.
 __global__ __launch_bounds__(256) void k_bqsr_prologue_plain(BqCols m, BqDesc *__restrict__ desc, uint32_t *skipbits, const uint32_t *__restrict__ plist,
-                                                             uint32_t *__restrict__ queue, uint32_t *queue_n, uint32_t *err, BqRec *__restrict__ recs) {
+                                                             uint32_t *__restrict__ queue, uint32_t *queue_n, uint32_t *err, RecOut ro) {
   __shared__ uint32_t s_cig[256][5];  // the thread's CIGAR: build_pieces / get_read_coord walk it several times
-  __shared__ uint32_t wg_n, wg_base;
+  __shared__ uint32_t wg_n, wg_base, wr_n, wr_base;
   __shared__ PfLds L;
   const bool ref_lds = m.n_ref <= REF_LDS;
   pf_lds_fill(L, m, 256);
@@ -421,26 +432,35 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_plain(BqCols m, BqDesc *_
     const uint64_t t = t0 + threadIdx.x;
     bool defer = false, to_plain = false;
     uint32_t i = 0;
+    BqRec rc;
+    int rcl = 0;
     if (t < np) {
       i = plist[t];
       const PfCols cur = pf_load_cols(m, i);
-      pf_record<true>(m, i, cur, L, ref_lds, desc, skipbits, err, recs, s_cig[threadIdx.x], defer, to_plain);
+      pf_record<true>(m, i, cur, L, ref_lds, desc, skipbits, err, ro.recs != nullptr, s_cig[threadIdx.x], defer, to_plain, rc, rcl);
     }
-    if (threadIdx.x == 0) wg_n = 0;
+    // deferred reads -> the general kernel's queue, finished records (all class 2 here... or 1 if the CIGAR folded to one run) -> the other
+    // region: one global atomic each per workgroup and trip
+    if (threadIdx.x == 0) { wg_n = 0; wr_n = 0; }
     __syncthreads();
-    uint32_t my = 0;
+    uint32_t my = 0, myr = 0;
     if (defer) my = atomicAdd(&wg_n, 1u);
+    if (rcl) myr = atomicAdd(&wr_n, 1u);
     __syncthreads();
-    if (threadIdx.x == 0) wg_base = wg_n ? atomicAdd(queue_n, wg_n) : 0u;
+    if (threadIdx.x == 0) {
+      wg_base = wg_n ? atomicAdd(queue_n, wg_n) : 0u;
+      wr_base = wr_n ? atomicAdd(&ro.cnt[C3_NSEG * C3_CSTRIDE], wr_n) : 0u;
+    }
     __syncthreads();
     if (defer) queue[wg_base + my] = i;
+    if (rcl) rec_store(ro.recs, (uint64_t)C3_NSEG * ro.cap_s + wr_base + myr, rc);
   }
 }
 
 // General prologue: one thread per record of `queue` (the records k_bqsr_prologue_fast left: anything but a plain "<len>M" CIGAR
 // without adaptor read-through); literal transliteration of the reference's clipping code.
 __device__ inline void prologue_general(const BqCols &m, const uint64_t i, uint32_t *__restrict__ cig_scratch, BqDesc *__restrict__ desc, uint32_t *skipbits,
-                                        uint32_t *err, BqRec *__restrict__ recs) {
+                                        uint32_t *err, const bool recs, BqRec &rc_out, int &rc_class) {
   int32_t rec_pos = 0;  // POS of the clipped copy (set before the final put)
   // stores the descriptor, or - recs != nullptr - the record count3.hip works from (and the descriptor only if the record cannot
   // describe the read)
@@ -455,9 +475,10 @@ __device__ inline void prologue_general(const BqCols &m, const uint64_t i, uint3
                     P.np < 0, m.ref_seq[dd.refid], m.ref_seq_len[dd.refid], (int64_t)m.l_seq[i]);
       rc.fl |= RC_SKIPCOL;  // this kernel's reads have their known-site bits in the skip column
     }
-    reinterpret_cast<uint4 *>(recs)[2 * i] = make_uint4(rc.ref_lo, rc.ref_hi, rc.win, rc.ctxw);
-    reinterpret_cast<uint4 *>(recs)[2 * i + 1] = make_uint4((uint32_t)rc.t0, rc.fl, rc.bpk, rc.dpk);
     if (rc.fl & RC_GENERAL) desc[i] = dd;
+    rc_class = rec_class(rc) ? 2 : 0;  // (this kernel's reads read the skip column)
+    rec_pack_idx(rc, (uint32_t)i);
+    rc_out = rc;
   };
   BqDesc d;
   d.D0 = d.D1 = d.D2 = BQ_NOREF; d.refid = 0; d.b1 = d.b2 = 0xFFFF; d.a = 0; d.len = 0; d.left = 0; d.right = 0; d.cov = 0; d.fl = 0; d.pad = 0;
@@ -526,10 +547,25 @@ __device__ inline void prologue_general(const BqCols &m, const uint64_t i, uint3
 // the queue's length stays on the device (no read-back between the two prologue kernels): a fixed grid strides over it
 __global__ __launch_bounds__(256) void k_bqsr_prologue(BqCols m, const uint32_t *__restrict__ queue, const uint32_t *__restrict__ queue_n,
                                                        uint32_t *__restrict__ cig_scratch, BqDesc *__restrict__ desc, uint32_t *skipbits,
-                                                       uint32_t *err, BqRec *__restrict__ recs) {
+                                                       uint32_t *err, RecOut ro) {
+  __shared__ uint32_t wr_n, wr_base;
   const uint64_t nq = (uint64_t)*queue_n;
-  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nq; t += (uint64_t)gridDim.x * blockDim.x)
-    prologue_general(m, queue[t], cig_scratch, desc, skipbits, err, recs);
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t t0 = (uint64_t)blockIdx.x * blockDim.x; t0 < nq; t0 += stride) {  // (uniform trip count per workgroup: barriers inside)
+    const uint64_t t = t0 + threadIdx.x;
+    BqRec rc;
+    int rcl = 0;
+    if (t < nq) prologue_general(m, queue[t], cig_scratch, desc, skipbits, err, ro.recs != nullptr, rc, rcl);
+    if (!ro.recs) continue;
+    if (threadIdx.x == 0) wr_n = 0;
+    __syncthreads();
+    uint32_t myr = 0;
+    if (rcl) myr = atomicAdd(&wr_n, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) wr_base = wr_n ? atomicAdd(&ro.cnt[C3_NSEG * C3_CSTRIDE], wr_n) : 0u;
+    __syncthreads();
+    if (rcl) rec_store(ro.recs, (uint64_t)C3_NSEG * ro.cap_s + wr_base + myr, rc);
+  }
 }
 
 // reference contigs are kept as 4-bit code nibbles like the restaged SEQ column (ctx.hip k_recode_seq), first base in the LOW
@@ -1431,13 +1467,17 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
              c->cigar_off.p, c->seq_off.p, c->qual_off.p, c->cigar.p, c->seq4.p, c->qual.p, c->ref_len.p, c->rg_cov.p, c->n_ref,
              c->d_ref_seq.p, c->d_ref_seq_len.p, c->d_sites.p, c->d_n_sites.p, c->d_site_idx.p, c->qbounds.p};
     uint32_t *queue;
-    ELP_TRY(scratch(c, 5, 2 * n + 32, &queue));  // [0] = count, [4..] = records left to the general kernel; [1] = count, [n + 20..] = reads of the second pass
-    ELP_HIP(c, hipMemsetAsync(queue, 0, 16, st));
-    uint32_t *plist = queue + n + 20;
+    ELP_TRY(scratch(c, 5, 2 * n + 128 + (size_t)(C3_NSEG + 1) * C3_CSTRIDE, &queue));  // [0] = count, [4..] = records left to the general kernel; [1] = count, [n + 20..] = reads of the second pass;
+    ELP_HIP(c, hipMemsetAsync(queue, 0, 16, st));  // [2 n + 48 ..] = the record counters (RecOut)
+    uint32_t *plist = queue + n + 20, *rec_cnt = queue + ((2 * n + 48 + 63) & ~(uint64_t)63);
+    ELP_HIP(c, hipMemsetAsync(rec_cnt, 0, (size_t)(C3_NSEG + 1) * C3_CSTRIDE * sizeof(uint32_t), st));
     // count3.hip (read sets of one length) works from 32-byte records the prologue kernels write instead of the descriptors; it takes
     // the count if the staged reads have one length (checked once per staged column), no read can exceed --max-cycle, and the quality
     // slots fit one table pass - k_bqsr_count otherwise (ELP_COUNT_KERNEL=1 forces it: A/B measurements)
     BqRec *recs = nullptr;
+    // a wave of the first pass appends its class-1 records (at most PF_TILES * 64) to segment wave % C3_NSEG
+    const unsigned pf_grid = blocks_for(n, 256 * PF_TILES);
+    const uint64_t cap_s = ((uint64_t)pf_grid * 4 + C3_NSEG - 1) / C3_NSEG * (uint64_t)(PF_TILES * 64);
     {
       const bool force_old = getenv("ELP_COUNT_KERNEL") && atoi(getenv("ELP_COUNT_KERNEL")) == 1;  // read per call: tests switch it
       ELP_TRY(ensure_uniform_len(c));
@@ -1447,15 +1487,15 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
       int nq0 = 0;
       for (int q = 6; q < ELP_NQUAL; q++) nq0 += (int)((q < 64 ? (c->qual_present[0] >> q) : (c->qual_present[1] >> (q - 64))) & 1ull);
       if (!force_old && c->uniform_len > 0 && lmax0 <= max_cycle && lmax0 <= 1022 && count3_plan(c->n_cov, std::max(nq0, 1), lmax0, &rsw3, &rlog3, &dyn3) == 0)
-        ELP_TRY(scratch(c, 4, n + 4, &recs));
+        ELP_TRY(scratch(c, 4, (size_t)C3_NSEG * cap_s + n + 64, &recs));
     }
-    ELP_LAUNCH(c, "bqsr_prologue_fast", k_bqsr_prologue_fast, dim3(blocks_for(n, 256 * PF_TILES)), dim3(256), 0, m, desc, skipbits, queue + 4, queue, c->err_flag.p,
-               recs, plist);
+    const RecOut ro{recs, rec_cnt, cap_s};
+    ELP_LAUNCH(c, "bqsr_prologue_fast", k_bqsr_prologue_fast, dim3(pf_grid), dim3(256), 0, m, desc, skipbits, queue + 4, queue, c->err_flag.p, ro, plist);
     // (sized for the worst case; workgroups beyond the list's end leave at once)
     ELP_LAUNCH(c, "bqsr_prologue_plain", k_bqsr_prologue_plain, dim3(std::min<unsigned>(blocks_for(n, 256), (unsigned)c->n_cu * 16)), dim3(256), 0, m, desc, skipbits,
-               (const uint32_t *)plist, queue + 4, queue, c->err_flag.p, recs);
+               (const uint32_t *)plist, queue + 4, queue, c->err_flag.p, ro);
     ELP_LAUNCH(c, "bqsr_prologue", k_bqsr_prologue, dim3(std::min<unsigned>(blocks_for(n, 256), (unsigned)c->n_cu * 16)), dim3(256), 0, m,
-               (const uint32_t *)(queue + 4), (const uint32_t *)queue, cs_pool, desc, skipbits, c->err_flag.p, recs);
+               (const uint32_t *)(queue + 4), (const uint32_t *)queue, cs_pool, desc, skipbits, c->err_flag.p, ro);
     const int lmax = (int)std::max<uint32_t>(c->max_l_seq, 1);
     if (lmax > MAX_DESC_READ) return set_error(c, ELP_ERR_UNSUPPORTED, "BQSR: read longer than %d bases", MAX_DESC_READ);
     const bool check_cycle = lmax > max_cycle;
@@ -1501,10 +1541,12 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
         QMap qm;
         memset(qm.slot, 254, sizeof qm.slot);
         for (size_t s2 = 0; s2 < quals.size(); s2++) qm.slot[quals[s2]] = (uint8_t)s2;
-        Count3Args A3{n, c->uniform_len, c->qual.p, c->seq4.p + elp_ctx::SEQ_FRONT, reinterpret_cast<const uint8_t *>(skipbits), reinterpret_cast<const uint4 *>(recs),
-                      reinterpret_cast<const uint4 *>(desc), c->cigar.p, cs_pool, c->d_ref_seq.p, c->d_ref_seq_len.p, c->n_cov, (int)quals.size(), lmax, max_cycle,
-                      rsw3, rlog3, tb + nq, tb + nq + nc, c->err_flag.p};
-        ELP_TRY(count3_launch(c, A3, qm, dyn3));
+        Count3Args A3{rec_cnt, cap_s, 0, c->uniform_len, c->qual.p, c->seq4.p + elp_ctx::SEQ_FRONT, reinterpret_cast<const uint8_t *>(skipbits),
+                      reinterpret_cast<const uint4 *>(recs), reinterpret_cast<const uint4 *>(desc), c->cigar.p, cs_pool, c->d_ref_seq.p, c->d_ref_seq_len.p, c->n_cov,
+                      (int)quals.size(), lmax, max_cycle, rsw3, rlog3, tb + nq, tb + nq + nc, c->err_flag.p};
+        ELP_TRY(count3_launch(c, A3, qm, dyn3));  // the reads that are one run of matches, segment by segment
+        A3.other = 1;
+        ELP_TRY(count3_launch(c, A3, qm, dyn3));  // the others (indels, clipped windows, descriptors), one region
         goto counted;
       }
       for (size_t q0 = 0; q0 < quals.size(); q0 += (size_t)qcap) {

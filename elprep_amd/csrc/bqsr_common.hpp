@@ -155,6 +155,45 @@ static_assert(sizeof(BqRec) == 32, "BqRec is loaded as two 16-byte words");
 enum : uint32_t { RC_REV = 1u << 8, RC_PAR = 1u << 9, RC_NEG = 1u << 10, RC_MULTI = 1u << 11, RC_GENERAL = 1u << 12,
                   RC_SKIPCOL = 1u << 13 };  // the read's known-site bits are in the skip column (else: the flags of its reference window)
 
+// Where the records go (round 3): only reads that take part in the count get one, COMPACTED - the count kernel then spends no lane on a
+// duplicate / unmapped / filtered read (one read in ten on the bench workload), and the reads whose blocks need the piece logic, the
+// skip column or the descriptor ("other": class 2) sit apart from the reads that are one run of matches (class 1), so that no wave
+// runs the long path for the sake of one lane.  Class 1 records fill C3_NSEG segments of `cap_s` records each (a wave of the first
+// prologue pass appends to segment wave % C3_NSEG with one atomic per tile: a single counter would serialise), class 2 records one region
+// behind them.  The read's staging index travels in spare bits of the record.
+constexpr int C3_NSEG = 64;
+constexpr int C3_CSTRIDE = 64;  // words between two counters: every counter in a 256-byte line of its own (one line = one L2 channel would serialise them all)
+struct RecOut {
+  BqRec *recs;     // nullptr: descriptors are written instead (general count kernel)
+  uint32_t *cnt;   // [s * C3_CSTRIDE], s < C3_NSEG: records in segment s; [C3_NSEG * C3_CSTRIDE]: records in the "other" region
+  uint64_t cap_s;  // capacity of a segment; the other region starts at C3_NSEG * cap_s
+};
+__device__ __forceinline__ void rec_pack_idx(BqRec &r, uint32_t idx) {
+  r.ref_hi = (r.ref_hi & 0xFFFFu) | (idx << 16);
+  r.fl = (r.fl & ~(0x3FFu << 14)) | (((idx >> 16) & 0x3FFu) << 14);
+  r.dpk = (r.dpk & 0x00FFFFFFu) | ((idx >> 26) << 24);
+}
+__device__ __forceinline__ uint32_t rec_idx(uint32_t ref_hi, uint32_t fl, uint32_t dpk) { return (ref_hi >> 16) | (((fl >> 14) & 0x3FFu) << 16) | ((dpk >> 24) << 26); }
+__device__ __forceinline__ void rec_store(BqRec *recs, uint64_t at, const BqRec &rc) {
+  reinterpret_cast<uint4 *>(recs)[2 * at] = make_uint4(rc.ref_lo, rc.ref_hi, rc.win, rc.ctxw);
+  reinterpret_cast<uint4 *>(recs)[2 * at + 1] = make_uint4((uint32_t)rc.t0, rc.fl, rc.bpk, rc.dpk);
+}
+// class of a finished record: 0 = no part in the count, 1 = one run of matches with its known-site bits in the reference window, 2 = other
+__device__ __forceinline__ int rec_class(const BqRec &rc) {
+  if ((rc.win >> 16) == (rc.win & 0xFFFFu)) return 0;
+  return (rc.fl & (RC_MULTI | RC_GENERAL | RC_SKIPCOL)) ? 2 : 1;
+}
+// the lanes of a wave with `flag` set take consecutive places behind *counter (one atomic per wave); returns the lane's place
+__device__ __forceinline__ uint32_t wave_append(bool flag, uint32_t *counter) {
+  const unsigned long long mask = __ballot(flag);
+  if (!mask) return 0;
+  const int lane = threadIdx.x & 63, leader = __ffsll((long long)mask) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+  base = __shfl(base, leader, 64);
+  return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
 // pieces of a clipped CIGAR (see BqDesc), up to four; np = -1: more
 struct Pieces4 {
   int64_t v0, v1, v2, v3;  // reference index minus clipped read index along the piece
@@ -246,7 +285,9 @@ __device__ inline BqRec make_rec(int a, int len, int left, int right, uint32_t c
 
 // ---- the count kernel for read sets of one length (count3.hip)
 struct Count3Args {
-  uint64_t n;
+  const uint32_t *cnt;  // records per segment / in the other region (RecOut)
+  uint64_t cap_s;
+  int other;            // 0: the class-1 segments (the grid is a multiple of C3_NSEG: workgroup w works on segment w % C3_NSEG), 1: the other region
   uint32_t len;  // every staged read has this many bases (SEQ and QUAL)
   const uint8_t *qual, *seq4;  // seq4: first SEQ byte of read 0
   const uint8_t *skipbits;

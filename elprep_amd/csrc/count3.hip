@@ -110,7 +110,6 @@ struct Count3 {
   const int64_t *__restrict__ ref_seq_len;
   unsigned long long *cycle_tbl, *ctx_tbl;
   uint32_t k0, nb;      // the lane's block inside its read: first base, number of bases (constant for the whole kernel)
-  uint32_t qoff, soff;  // byte offsets of the block's QUAL bytes / SEQ window inside a trip's span of the columns
   int n_cov, n_q, lmax, max_cycle, rsw;
   // LDS
   uint32_t qrow_at, spread_at;
@@ -121,21 +120,22 @@ struct Count3 {
   uint32_t rep4, two;
   uint32_t err;
 
-  // Issues the loads of the lane's block of one trip (asm loads: nothing waits here).  qual_t / seq_t / skip_t = the trip's first QUAL
-  // byte, first SEQ byte minus one, the byte of the known-site column that holds the trip's first bit (sphase = that bit's position in
-  // it) - all wave-uniform.  Returns whether the block has any base of the clipped copy (else nothing is loaded).
-  __device__ __forceinline__ bool load_data(const u32x4 &ra, const u32x4 &rb, bool on, const uint8_t *__restrict__ qual_t, const uint8_t *__restrict__ seq_t,
-                                            const uint8_t *__restrict__ skip_t, uint32_t sphase, BlkData &d, BlkRec &f, uint32_t &qlow) const {
+  // Issues the loads of the lane's block of one trip (asm loads: nothing waits here).  The records are compacted (RecOut): the read's
+  // staging index comes out of the record and the block's addresses are per lane.  Returns whether the block has any base of the clipped
+  // copy (else nothing is loaded).
+  __device__ __forceinline__ bool load_data(const u32x4 &ra, const u32x4 &rb, bool on, uint32_t len, uint32_t sbytes, BlkData &d, BlkRec &f, uint32_t &qlow,
+                                            uint32_t &idx) const {
     const uint32_t a = ra.z & 0xFFFFu, e = ra.z >> 16;
     f.win = ra.z; f.ctxw = ra.w; f.t0 = rb.x; f.fl = rb.y; f.bpk = rb.z; f.dpk = rb.w;
-    const uint32_t bit = sphase + qoff;
-    qlow = bit & 7u;
+    idx = rec_idx(ra.y, rb.y, rb.w);
+    const uint64_t bit = (uint64_t)idx * len + k0;
+    qlow = (uint32_t)bit & 7u;
     if (!on || k0 + nb <= a || k0 >= e) return false;
-    gload_x4(d.q, qual_t, qoff);
+    gload_x4(d.q, (uint64_t)qual + bit);
     d.skipw = 0u;
-    if (rb.y & RC_SKIPCOL) gload_x1(d.skipw, skip_t, bit >> 3);  // else: the flags of the reference window
-    gload_x4(d.s, seq_t, soff);
-    const uint64_t rp = ((uint64_t)ra.x | ((uint64_t)ra.y << 32)) + ((rb.y & RC_GENERAL) ? 0u : (k0 >> 1));
+    if (rb.y & RC_SKIPCOL) gload_x1(d.skipw, (uint64_t)skipbits + (bit >> 3));  // else: the flags of the reference window
+    gload_x4(d.s, (uint64_t)seq_m1 + (uint64_t)idx * sbytes + (k0 >> 1));
+    const uint64_t rp = ((uint64_t)ra.x | ((uint64_t)(ra.y & 0xFFFFu) << 32)) + ((rb.y & RC_GENERAL) ? 0u : (k0 >> 1));
     gload_x4(d.w03, rp);
     gload_x2(d.w45, rp + 16);
     return true;
@@ -360,35 +360,35 @@ __global__ __launch_bounds__(C3_NT) void k_bqsr_count3(Count3Args A, QMap qm) {
   asm volatile("" : "+v"(B.two));  // keep it in a register: the SDWA form takes no inline constant
   B.err = 0;
 
-  // A trip of a workgroup covers RPI whole reads; lane t works on block t % bpr of read slot t / bpr in every trip (the last
-  // 1024 - RPI * bpr lanes idle).  Trip `it` of workgroup w starts at read (it * gridDim + w) * RPI.
+  // A trip of a workgroup covers RPI whole records of its segment (class-1 launch: workgroup w works on segment w % C3_NSEG together with
+  // the gridDim / C3_NSEG - 1 other workgroups of that segment; the other launch: all workgroups on the one region); lane t works on block
+  // t % bpr of record slot t / bpr in every trip (the last 1024 - RPI * bpr lanes idle).
   const uint32_t len = A.len, bpr = (len + 15u) >> 4, sbytes = (len + 1u) >> 1, RPI = C3_NT / bpr;
   const uint32_t slot = threadIdx.x / bpr, jb = threadIdx.x - slot * bpr;
   const bool lane_on = slot < RPI;
   B.k0 = 16u * jb;
   B.nb = len - B.k0 < 16u ? len - B.k0 : 16u;
-  B.qoff = slot * len + B.k0;
-  B.soff = slot * sbytes + (B.k0 >> 1);
-  const uint64_t n = A.n, stride = (uint64_t)gridDim.x * RPI;
-  const uint64_t n_trips = (n + stride - 1) / stride;  // every workgroup makes the same number of trips (flush barriers stay uniform)
-  const uint8_t *seq_m1 = A.seq4 - 1;
+  const uint32_t seg = A.other ? (uint32_t)C3_NSEG : blockIdx.x % (uint32_t)C3_NSEG;
+  const uint32_t team = A.other ? gridDim.x : gridDim.x / (uint32_t)C3_NSEG, member = A.other ? blockIdx.x : blockIdx.x / (uint32_t)C3_NSEG;
+  const uint64_t n = A.cnt[seg * (uint32_t)C3_CSTRIDE], stride = (uint64_t)team * RPI;
+  const uint64_t n_trips = (n + stride - 1) / stride;  // every wave of the workgroup makes the same number of trips (flush barriers stay uniform)
+  const uint8_t *seg_recs = reinterpret_cast<const uint8_t *>(A.recs) + (uint64_t)seg * A.cap_s * 32u;
   // a cycle cell (16 | 16 bits) takes at most one count per read
   const uint32_t flush_every = 30000u / (RPI + 1u) + 1u;
-  auto first_read = [&](uint64_t it) __attribute__((always_inline)) -> uint64_t { return it * stride + (uint64_t)blockIdx.x * RPI; };
+  auto first_read = [&](uint64_t it) __attribute__((always_inline)) -> uint64_t { return it * stride + (uint64_t)member * RPI; };
   const uint32_t roff = slot * 32u;  // the lane's record inside a trip's span of the record array
   auto rec_load = [&](uint64_t it, u32x4 &za, u32x4 &zb) __attribute__((always_inline)) {
     const uint64_t r0 = first_read(it);
     if (lane_on && r0 + slot < n) {
-      const uint8_t *rt = reinterpret_cast<const uint8_t *>(A.recs) + r0 * 32u;
+      const uint8_t *rt = seg_recs + r0 * 32u;
       gload_x4(za, rt, roff);
       gload_x4(zb, rt, roff + 16u);
     }
   };
-  auto data_load = [&](uint64_t it, const u32x4 &za, const u32x4 &zb, BlkData &d, BlkRec &f, uint32_t &qlow) __attribute__((always_inline)) -> bool {
+  auto data_load = [&](uint64_t it, const u32x4 &za, const u32x4 &zb, BlkData &d, BlkRec &f, uint32_t &qlow, uint32_t &idx) __attribute__((always_inline)) -> bool {
     const uint64_t r0 = first_read(it);
     const bool on = lane_on && r0 + slot < n;
-    const uint64_t bit0 = r0 * len;
-    return B.load_data(za, zb, on, A.qual + bit0, seq_m1 + r0 * sbytes, A.skipbits + (bit0 >> 3), (uint32_t)bit0 & 7u, d, f, qlow);
+    return B.load_data(za, zb, on, len, sbytes, d, f, qlow, idx);
   };
   // the ONE wait of a loop trip: everything issued so far has landed.  The data registers are operands of an empty statement behind the
   // wait (their uses stay behind it); the record moves out of its buffer by copies that stay behind the wait (gload.hpp)
@@ -405,27 +405,27 @@ __global__ __launch_bounds__(C3_NT) void k_bqsr_count3(Count3Args A, QMap qm) {
   dY = dX;
   BlkRec fX, fY;
   u32x4 za = (u32x4){0, 0, 0, 0}, zb = za, na = za, nb4 = za;  // record buffer in flight; record of the next trip's block
-  uint32_t qlX = 0, qlY = 0;
+  uint32_t qlX = 0, qlY = 0, iX = 0, iY = 0;  // bit phase of the block's skip-column word; staging index of the block's read
   bool onX, onY = false;
   rec_load(0, za, zb);
   landed(dX, za, zb, na, nb4);
-  onX = data_load(0, na, nb4, dX, fX, qlX);
+  onX = data_load(0, na, nb4, dX, fX, qlX, iX);
   rec_load(1, za, zb);
   landed(dX, za, zb, na, nb4);
   uint32_t since = 0;
 #pragma unroll 1
   for (uint64_t it = 0; it < n_trips; it += 2) {
     {  // trip it: work on X; data of trip it + 1 -> Y; record of trip it + 2 -> Z
-      onY = data_load(it + 1, na, nb4, dY, fY, qlY);
+      onY = data_load(it + 1, na, nb4, dY, fY, qlY, iY);
       rec_load(it + 2, za, zb);
-      if (onX) B.process(fX, (uint32_t)(first_read(it) + slot), dX, qlX);
+      if (onX) B.process(fX, iX, dX, qlX);
       landed(dY, za, zb, na, nb4);
       if (++since == flush_every) { B.flush(); since = 0; }
     }
     {  // trip it + 1: work on Y; data of trip it + 2 -> X; record of trip it + 3 -> Z
-      onX = data_load(it + 2, na, nb4, dX, fX, qlX);
+      onX = data_load(it + 2, na, nb4, dX, fX, qlX, iX);
       rec_load(it + 3, za, zb);
-      if (onY) B.process(fY, (uint32_t)(first_read(it + 1) + slot), dY, qlY);
+      if (onY) B.process(fY, iY, dY, qlY);
       landed(dX, za, zb, na, nb4);
       if (++since == flush_every) { B.flush(); since = 0; }
     }
@@ -459,8 +459,8 @@ int count3_plan(int n_cov, int n_q, int lmax, int *rsw_out, int *rlog_out, size_
 }
 
 int count3_launch(elp_ctx *c, const Count3Args &A, const QMap &qm, size_t dyn) {
-  const uint64_t nblk = A.n * ((A.len + 15u) >> 4);
-  const int grid = (int)std::min<uint64_t>((nblk + C3_NT - 1) / C3_NT, (uint64_t)c->n_cu);
+  // one workgroup per CU; the class-1 launch needs a multiple of C3_NSEG workgroups (every segment the same number)
+  const int grid = A.other ? c->n_cu : std::max(C3_NSEG, c->n_cu / C3_NSEG * C3_NSEG);
 #define ELP_C3(RL)                                                                                                                          \
   do {                                                                                                                                      \
     ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bqsr_count3<RL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)); \

@@ -26,6 +26,7 @@ __device__ __forceinline__ void gload_x1(uint32_t &v, const void *sbase, uint32_
 }
 // per-lane 64-bit address
 __device__ __forceinline__ void gload_x4(u32x4 &v, uint64_t addr) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(addr) : "memory"); }
+__device__ __forceinline__ void gload_x1(uint32_t &v, uint64_t addr) { asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(addr) : "memory"); }
 __device__ __forceinline__ void gload_x2(u32x2 &v, uint64_t addr) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(addr) : "memory"); }
 
 // a store the compiler does not see either: with every VMEM instruction of a loop trip written by hand the trip's wait can be COUNTED
