@@ -96,7 +96,9 @@ __device__ __noinline__ uint64_t c3_ref_general(const uint4 *__restrict__ desc, 
 }
 
 
-template <int RLOG>
+// OTHER false: the launch over the class-1 segments (every record a run of matches with its known-site bits in the reference window: the
+// piece logic, the skip-column path and the descriptor path are not compiled in); true: the launch over the other region
+template <int RLOG, bool OTHER>
 struct Count3 {
   // kernel arguments
   const uint8_t *__restrict__ qual;
@@ -133,7 +135,7 @@ struct Count3 {
     if (!on || k0 + nb <= a || k0 >= e) return false;
     gload_x4(d.q, (uint64_t)qual + bit);
     d.skipw = 0u;
-    if (rb.y & RC_SKIPCOL) gload_x1(d.skipw, (uint64_t)skipbits + (bit >> 3));  // else: the flags of the reference window
+    if (OTHER && (rb.y & RC_SKIPCOL)) gload_x1(d.skipw, (uint64_t)skipbits + (bit >> 3));  // else: the flags of the reference window
     gload_x4(d.s, (uint64_t)seq_m1 + (uint64_t)idx * sbytes + (k0 >> 1));
     const uint64_t rp = ((uint64_t)ra.x | ((uint64_t)(ra.y & 0xFFFFu) << 32)) + ((rb.y & RC_GENERAL) ? 0u : (k0 >> 1));
     gload_x4(d.w03, rp);
@@ -220,7 +222,7 @@ struct Count3 {
     // reference nibbles of a read that is one run of matches: nibble 16 + parity of the window = words 2, 3, 4.  Bit 2 of a nibble =
     // the base lies in a known site (k_ref_mark_sites, bqsr.hip)
     uint32_t R_lo = 0, R_hi = 0, k_lo = 0, k_hi = 0;
-    const bool one_run = !(fl & (RC_MULTI | RC_GENERAL));
+    const bool one_run = !OTHER || !(fl & (RC_MULTI | RC_GENERAL));
     if (one_run) {
       const uint32_t sh = (fl & RC_PAR) ? 4u : 0u;
       R_lo = __builtin_amdgcn_alignbit(d.w03.w, d.w03.z, sh);
@@ -228,7 +230,7 @@ struct Count3 {
       k_lo = (R_lo >> 2) & N1;
       k_hi = (R_hi >> 2) & N1;
     }
-    if (fl & RC_SKIPCOL) {  // known-site bits from the skip column -> nibble flags (LDS table: bit i of a byte -> bit 4 i)
+    if (OTHER && (fl & RC_SKIPCOL)) {  // known-site bits from the skip column -> nibble flags (LDS table: bit i of a byte -> bit 4 i)
       const uint32_t sk = d.skipw >> qlow;
       k_lo |= lds_read_u32(spread_at + ((sk & 0xFFu) << 2));
       k_hi |= lds_read_u32(spread_at + ((sk >> 6) & 0x3FCu));
@@ -324,7 +326,7 @@ struct Count3 {
   }
 };
 
-template <int RLOG>
+template <int RLOG, bool OTHER>
 __global__ __launch_bounds__(C3_NT) void k_bqsr_count3(Count3Args A, QMap qm) {
   __shared__ uint32_t qrow[256];
   __shared__ uint32_t spread8[256];
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(C3_NT) void k_bqsr_count3(Count3Args A, QMap qm) {
     spread8[q] = sp;
   }
   __syncthreads();
-  Count3<RLOG> B;
+  Count3<RLOG, OTHER> B;
   B.qual = A.qual; B.seq_m1 = A.seq4 - 1; B.skipbits = A.skipbits; B.recs = A.recs; B.desc = A.desc; B.cigar = A.cigar; B.cig_scratch = A.cig_scratch;
   B.ref_seq = A.ref_seq; B.ref_seq_len = A.ref_seq_len; B.cycle_tbl = A.cycle_tbl; B.ctx_tbl = A.ctx_tbl;
   B.n_cov = A.n_cov; B.n_q = A.n_q; B.lmax = A.lmax; B.max_cycle = A.max_cycle; B.rsw = A.rsw;
@@ -368,8 +370,8 @@ __global__ __launch_bounds__(C3_NT) void k_bqsr_count3(Count3Args A, QMap qm) {
   const bool lane_on = slot < RPI;
   B.k0 = 16u * jb;
   B.nb = len - B.k0 < 16u ? len - B.k0 : 16u;
-  const uint32_t seg = A.other ? (uint32_t)C3_NSEG : blockIdx.x % (uint32_t)C3_NSEG;
-  const uint32_t team = A.other ? gridDim.x : gridDim.x / (uint32_t)C3_NSEG, member = A.other ? blockIdx.x : blockIdx.x / (uint32_t)C3_NSEG;
+  const uint32_t seg = OTHER ? (uint32_t)C3_NSEG : blockIdx.x % (uint32_t)C3_NSEG;
+  const uint32_t team = OTHER ? gridDim.x : gridDim.x / (uint32_t)C3_NSEG, member = OTHER ? blockIdx.x : blockIdx.x / (uint32_t)C3_NSEG;
   const uint64_t n = A.cnt[seg * (uint32_t)C3_CSTRIDE], stride = (uint64_t)team * RPI;
   const uint64_t n_trips = (n + stride - 1) / stride;  // every wave of the workgroup makes the same number of trips (flush barriers stay uniform)
   const uint8_t *seg_recs = reinterpret_cast<const uint8_t *>(A.recs) + (uint64_t)seg * A.cap_s * 32u;
@@ -461,13 +463,15 @@ int count3_plan(int n_cov, int n_q, int lmax, int *rsw_out, int *rlog_out, size_
 int count3_launch(elp_ctx *c, const Count3Args &A, const QMap &qm, size_t dyn) {
   // one workgroup per CU; the class-1 launch needs a multiple of C3_NSEG workgroups (every segment the same number)
   const int grid = A.other ? c->n_cu : std::max(C3_NSEG, c->n_cu / C3_NSEG * C3_NSEG);
-#define ELP_C3(RL)                                                                                                                          \
-  do {                                                                                                                                      \
-    ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bqsr_count3<RL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)); \
-    ELP_LAUNCH(c, "bqsr_count", (k_bqsr_count3<RL>), dim3(grid), dim3(C3_NT), dyn, A, qm);                                                  \
-    return 0;                                                                                                                               \
+#define ELP_C3K(RL, OT)                                                                                                                          \
+  do {                                                                                                                                           \
+    ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bqsr_count3<RL, OT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)); \
+    ELP_LAUNCH(c, "bqsr_count", (k_bqsr_count3<RL, OT>), dim3(grid), dim3(C3_NT), dyn, A, qm);                                                  \
+    return 0;                                                                                                                                    \
   } while (0)
+#define ELP_C3(RL) do { if (A.other) ELP_C3K(RL, true); else ELP_C3K(RL, false); } while (0)
   switch (A.rlog) { case 5: ELP_C3(5); case 4: ELP_C3(4); case 3: ELP_C3(3); case 2: ELP_C3(2); default: ELP_C3(1); }
+#undef ELP_C3K
 #undef ELP_C3
 }
 
