@@ -1709,6 +1709,46 @@ int elp_bqsr_tables_fetch(elp_ctx *c, int64_t *qual_tbl, int64_t *cycle_tbl, int
   return 0;
 }
 
+
+// Distinct rows of the resident part of the dense LUT (three small kernels): wk = slots | slot ids | row -> slot | t1 | t2 | counter.
+struct LutDict { uint32_t *slots, *slot_id, *row_slot, *counter; uint16_t *t1; uint8_t *t2; uint32_t n_slots; size_t n_rows, n1; };
+constexpr uint32_t LUT_T2_CAP = 3855;  // 16-bit byte offsets
+static size_t lut_dict_words(int n_cov, int n_qi, int lmax, uint32_t *n_slots_out) {
+  const size_t w = 2 * (size_t)lmax + 1, n_rows = (size_t)n_cov * (size_t)std::max(n_qi, 0) * w, n1 = (size_t)n_cov * (size_t)(n_qi + 1) * w;
+  uint32_t n_slots = 1024;
+  while (n_slots < 2 * n_rows) n_slots <<= 1;
+  *n_slots_out = n_slots;
+  return (size_t)2 * n_slots + n_rows + n1 + (size_t)(LUT_T2_CAP + 1) * 5 + 64 + 16;
+}
+static LutDict lut_dict_layout(uint32_t *wk, int n_cov, int n_qi, int lmax, uint32_t n_slots) {
+  const size_t w = 2 * (size_t)lmax + 1, n_rows = (size_t)n_cov * (size_t)std::max(n_qi, 0) * w, n1 = (size_t)n_cov * (size_t)(n_qi + 1) * w;
+  LutDict D;
+  D.n_slots = n_slots; D.n_rows = n_rows; D.n1 = n1;
+  D.counter = wk;  // (own word: the err_flag mailbox other stages use is not touched from the upload thread)
+  D.slots = wk + 16; D.slot_id = D.slots + n_slots; D.row_slot = D.slots + 2 * (size_t)n_slots;
+  D.t1 = reinterpret_cast<uint16_t *>(D.row_slot + n_rows);
+  D.t2 = reinterpret_cast<uint8_t *>(D.t1 + ((n1 + 1) & ~(size_t)1));
+  return D;
+}
+// (plain launches, no profiling brackets: also called from the upload thread while the context's own stream is busy)
+static int lut_dict_build(elp_ctx *c, hipStream_t st, const LutDict &D, const uint8_t *dl, int qlo, int n_qi, int lmax, int max_cycle) {
+  ELP_HIP(c, hipMemsetAsync(D.slots, 0xFF, (size_t)D.n_slots * 4, st));
+  ELP_HIP(c, hipMemsetAsync(D.counter, 0, 4, st));
+  LutRows R{dl, c->n_cov, qlo, n_qi, lmax, max_cycle};
+  hipLaunchKernelGGL(k_lut_rows_insert, dim3(blocks_for(D.n_rows, 256)), dim3(256), 0, st, R, (int)D.n_rows, D.slots, D.n_slots - 1, D.row_slot);
+  hipLaunchKernelGGL(k_lut_rows_number, dim3(blocks_for(D.n_slots, 256)), dim3(256), 0, st, R, (const uint32_t *)D.slots, D.n_slots, D.slot_id, D.counter, D.t2, LUT_T2_CAP);
+  hipLaunchKernelGGL(k_lut_rows_index, dim3(blocks_for(std::max<size_t>(D.n1, 17), 256)), dim3(256), 0, st, R, (const uint32_t *)D.row_slot, (const uint32_t *)D.slot_id,
+                     (const uint32_t *)D.counter, D.t1, D.t2, LUT_T2_CAP);
+  ELP_HIP(c, hipGetLastError());
+  return 0;
+}
+// the resident quality range of ApplyBQSR's LDS tables, from the quality hint (-1: no quality >= 6 seen)
+static void lut_quality_range(const elp_ctx *c, int *qlo, int *qhi) {
+  *qlo = 0; *qhi = -1;
+  for (int q = 6; q < ELP_NQUAL; q++)
+    if ((q < 64 ? (c->qual_present[0] >> q) : (c->qual_present[1] >> (q - 64))) & 1ull) { if (*qhi < 0) *qlo = q; *qhi = q; }
+}
+
 // The LUT's way to the device ahead of the apply call: from the thread that built it, on the context's copy stream, while the context's
 // own stream still runs the sort / metrics pass (6.4 MB at --max-cycle 500: ~0.2 ms that elp_bqsr_apply otherwise spends in front of its
 // first kernel).  The LUT lives in a buffer of its own (not in the scratch pool: other stages are running).
@@ -1727,13 +1767,45 @@ int elp_bqsr_lut_upload(elp_ctx *c, int max_cycle, const uint8_t *lut, const uin
   memcpy(c->lut_pinned, lut, lut_bytes);
   memcpy(static_cast<uint8_t *>(c->lut_pinned) + lut_bytes, cov_present, (size_t)c->n_cov);
   if (!c->lut_ev) ELP_HIP(c, hipEventCreateWithFlags(&c->lut_ev, hipEventDisableTiming));
+  if (c->apply_ev) ELP_HIP(c, hipStreamWaitEvent(c->copy_stream, c->apply_ev, 0));  // an apply that still reads the previous LUT
   ELP_HIP(c, hipMemcpyAsync(c->lut_dev.p, c->lut_pinned, all, hipMemcpyHostToDevice, c->copy_stream));
+  // the row dictionary apply3 works from, behind the copy on the same stream - if what it depends on is known now (the quality hint of the
+  // gather that produced these tables, a read set of one length): 0.25 ms that elp_bqsr_apply otherwise spends in front of its kernel
+  c->dict_ready = false;
+  const bool force_old = getenv("ELP_APPLY_KERNEL") && atoi(getenv("ELP_APPLY_KERNEL")) == 1;
+  if (!force_old && c->have_qual_present && c->uniform_n == c->n && c->uniform_len >= 16 && c->n > 0 && (int64_t)c->max_l_seq <= (int64_t)max_cycle) {
+    int qlo, qhi;
+    lut_quality_range(c, &qlo, &qhi);
+    const int lmax = (int)std::max<uint32_t>(c->max_l_seq, 1);
+    size_t dyn3 = 0;
+    if (qhi >= 0 && apply3_bytes(c->n_cov, qhi - 6 + 1, lmax, &dyn3) == 0) {
+      const int n_qi = qhi - 6 + 1;  // (apply3: resident from quality 6 on)
+      uint32_t n_slots = 0;
+      const size_t words = lut_dict_words(c->n_cov, n_qi, lmax, &n_slots);
+      if ((size_t)c->n_cov * (size_t)n_qi * (size_t)(2 * lmax + 1) < (1u << 22)) {
+        ELP_TRY(ensure(c, c->lut_wk, words));
+        const LutDict D = lut_dict_layout(c->lut_wk.p, c->n_cov, n_qi, lmax, n_slots);
+        ELP_TRY(lut_dict_build(c, c->copy_stream, D, c->lut_dev.p, 6, n_qi, lmax, max_cycle));
+        c->dict_qlo = 6; c->dict_nqi = n_qi; c->dict_lmax = lmax; c->dict_cycle = max_cycle; c->dict_ncov = c->n_cov;
+        c->dict_ready = true;
+      }
+    }
+  }
   ELP_HIP(c, hipEventRecord(c->lut_ev, c->copy_stream));
   c->lut_uploaded_cycle = max_cycle;
   return 0;
 }
 
+static int bqsr_apply_impl(elp_ctx *c, int max_cycle, const uint8_t *lut, const uint8_t *cov_present);
 int elp_bqsr_apply(elp_ctx *c, int max_cycle, const uint8_t *lut, const uint8_t *cov_present) {
+  const int rc = bqsr_apply_impl(c, max_cycle, lut, cov_present);
+  if (c && !lut && rc == 0) {  // the kernels just queued read the uploaded LUT: the next upload waits for them
+    if (!c->apply_ev && hipEventCreateWithFlags(&c->apply_ev, hipEventDisableTiming) != hipSuccess) return set_error(c, ELP_ERR_HIP, "hipEventCreate failed");
+    ELP_HIP(c, hipEventRecord(c->apply_ev, c->stream));
+  }
+  return rc;
+}
+static int bqsr_apply_impl(elp_ctx *c, int max_cycle, const uint8_t *lut, const uint8_t *cov_present) {
   if (!c || max_cycle < 1 || (lut != nullptr) != (cov_present != nullptr)) return set_error(c, ELP_ERR_ARG, "elp_bqsr_apply: bad arguments");
   if (!lut && c->lut_uploaded_cycle != max_cycle) return set_error(c, ELP_ERR_ARG, "elp_bqsr_apply: no LUT given and none uploaded for this --max-cycle (elp_bqsr_lut_upload)");
   ELP_HIP(c, hipSetDevice(c->device));
@@ -1758,8 +1830,7 @@ int elp_bqsr_apply(elp_ctx *c, int max_cycle, const uint8_t *lut, const uint8_t 
       ELP_TRY(ensure_flat_index(c));
       ELP_TRY(ensure_qual_present(c));  // the resident quality range comes from a sample of the column (a hint: qualities outside it take the fix-up path)
       int qlo = 0, qhi = -1;
-      for (int q = 6; q < ELP_NQUAL; q++)
-        if ((q < 64 ? (c->qual_present[0] >> q) : (c->qual_present[1] >> (q - 64))) & 1ull) { if (qhi < 0) qlo = q; qhi = q; }
+      lut_quality_range(c, &qlo, &qhi);
       const int lmax = (int)std::max<uint32_t>(c->max_l_seq, 1);
       const bool chk = (int64_t)c->max_l_seq > (int64_t)max_cycle;
       // apply3.hip takes read sets of one length (ELP_APPLY_KERNEL=1 forces k_bqsr_apply_flat: A/B measurements); its level-1 table is
@@ -1776,22 +1847,19 @@ int elp_bqsr_apply(elp_ctx *c, int max_cycle, const uint8_t *lut, const uint8_t 
       const size_t static_lds = sizeof(FlatLds<AB::RMAX>) + (size_t)AB::RMAX * 12 + 512;
       const size_t n_rows = (size_t)c->n_cov * (size_t)std::max(n_qi, 0) * (size_t)w, n1 = (size_t)c->n_cov * (size_t)(n_qi + 1) * (size_t)w;
       if (!chk && qhi >= 0 && lmax <= max_cycle && n1 + static_lds <= 160 * 1024 && n_rows < (1u << 22)) {
-        // distinct rows of the resident part of the LUT (three small kernels, one read-back of their number)
-        uint32_t n_slots = 1024;
-        while (n_slots < 2 * n_rows) n_slots <<= 1;
-        const uint32_t t2_cap = 3855;  // 16-bit byte offsets
-        uint32_t *wk;
-        ELP_TRY(scratch(c, 4, (size_t)2 * n_slots + n_rows + n1 + (size_t)(t2_cap + 1) * 5 + 64, &wk));
-        uint32_t *slots = wk, *slot_id = wk + n_slots, *row_slot = wk + 2 * (size_t)n_slots, *counter = c->err_flag.p + 3;
-        uint16_t *t1 = reinterpret_cast<uint16_t *>(row_slot + n_rows);
-        uint8_t *t2 = reinterpret_cast<uint8_t *>(t1 + ((n1 + 1) & ~(size_t)1));
-        ELP_HIP(c, hipMemsetAsync(slots, 0xFF, (size_t)n_slots * 4, c->stream));
-        ELP_HIP(c, hipMemsetAsync(counter, 0, 4, c->stream));
-        LutRows R{dl, c->n_cov, qlo, n_qi, lmax, max_cycle};
-        ELP_LAUNCH(c, "bqsr_apply_lut", k_lut_rows_insert, dim3(blocks_for(n_rows, 256)), dim3(256), 0, R, (int)n_rows, slots, n_slots - 1, row_slot);
-        ELP_LAUNCH(c, "bqsr_apply_lut", k_lut_rows_number, dim3(blocks_for(n_slots, 256)), dim3(256), 0, R, (const uint32_t *)slots, n_slots, slot_id, counter, t2, t2_cap);
-        ELP_LAUNCH(c, "bqsr_apply_lut", k_lut_rows_index, dim3(blocks_for(std::max<size_t>(n1, 17), 256)), dim3(256), 0, R, (const uint32_t *)row_slot,
-                   (const uint32_t *)slot_id, (const uint32_t *)counter, t1, t2, t2_cap);
+        // distinct rows of the resident part of the LUT: built behind the LUT's upload if that was possible (elp_bqsr_lut_upload), else here
+        const bool prebuilt = !lut && c->dict_ready && c->dict_qlo == qlo && c->dict_nqi == n_qi && c->dict_lmax == lmax && c->dict_cycle == max_cycle &&
+                              c->dict_ncov == c->n_cov;
+        uint32_t n_slots = 0;
+        const size_t dict_words = lut_dict_words(c->n_cov, n_qi, lmax, &n_slots);
+        uint32_t *wk = c->lut_wk.p;
+        if (!prebuilt) ELP_TRY(scratch(c, 4, dict_words, &wk));
+        const LutDict D = lut_dict_layout(wk, c->n_cov, n_qi, lmax, n_slots);
+        if (!prebuilt) ELP_TRY(lut_dict_build(c, c->stream, D, dl, qlo, n_qi, lmax, max_cycle));
+        uint32_t *counter = D.counter;
+        uint16_t *t1 = D.t1;
+        uint8_t *t2 = D.t2;
+        const uint32_t t2_cap = LUT_T2_CAP;
         size_t dyn3 = 0;
         if (want3 && apply3_bytes(c->n_cov, n_qi, lmax, &dyn3) == 0) {
           // the number of distinct rows stays on the device; if there are more than the one-byte ids hold, the kernel says so and leaves
@@ -1800,7 +1868,6 @@ int elp_bqsr_apply(elp_ctx *c, int max_cycle, const uint8_t *lut, const uint8_t 
           ELP_TRY(fetch_err(c, e3));
           if ((e3[0] & ~512u) != 0) return bqsr_error(c, e3[0] & ~512u);
           if (!(e3[0] & 512u)) {
-            ELP_HIP(c, hipMemsetAsync(counter, 0, 4, c->stream));
             c->adapted = false;
             c->have_qual_present = false;
             return 0;
@@ -1810,7 +1877,6 @@ int elp_bqsr_apply(elp_ctx *c, int max_cycle, const uint8_t *lut, const uint8_t 
         uint32_t n_dict = 0;
         ELP_HIP(c, hipMemcpyAsync(&n_dict, counter, 4, hipMemcpyDeviceToHost, c->stream));
         ELP_HIP(c, hipStreamSynchronize(c->stream));
-        ELP_HIP(c, hipMemsetAsync(counter, 0, 4, c->stream));
         if (n_dict < t2_cap) {
           const int m = n_dict + 1 <= 256 ? 1 : 2;
           const size_t bytes = ((n1 * (size_t)m + 15) & ~(size_t)15) + (size_t)(n_dict + 1) * (m == 1 ? 32 : 17) + 16;

@@ -159,7 +159,13 @@ struct elp_ctx {
   void *lut_pinned = nullptr;
   size_t lut_pinned_cap = 0;
   hipEvent_t lut_ev = nullptr;
+  hipEvent_t apply_ev = nullptr;   // behind the last elp_bqsr_apply that read lut_dev / lut_wk: the next upload's copy waits for it
   int lut_uploaded_cycle = 0;
+  // the row dictionary of the uploaded LUT (bqsr.hip: lut_dictionary), built on the copy stream behind the upload when the facts it needs
+  // are known at that time; elp_bqsr_apply uses it if they still hold
+  elp::DVec<uint32_t> lut_wk;
+  bool dict_ready = false;
+  int dict_qlo = 0, dict_nqi = 0, dict_lmax = 0, dict_cycle = 0, dict_ncov = 0;
   hipEvent_t tables_ev = nullptr;  // recorded on `stream` behind the last writer of dev_tables (gather, tables_add, all-reduce): elp_bqsr_tables_fetch
                                    // copies on copy_stream behind it, so the context's stream is free for the next stage meanwhile
   void *bounce[2] = {nullptr, nullptr};  // pinned double buffer for pageable sources

@@ -126,6 +126,7 @@ void elp_destroy(elp_ctx *c) {
   for (auto &p : c->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   if (c->lut_pinned) (void)hipHostFree(c->lut_pinned);
   if (c->lut_ev) (void)hipEventDestroy(c->lut_ev);
+  if (c->apply_ev) (void)hipEventDestroy(c->apply_ev);
   for (auto p : c->h_ref_seq) if (p) (void)hipFree(p);
   for (auto p : c->h_sites) if (p) (void)hipFree(p);
   for (auto p : c->h_site_idx) if (p) (void)hipFree(p);
