@@ -1,9 +1,12 @@
 """Known-answer tests that pin the CPU oracle.
 
-(a) the reference's own interval tests (intervals/intervals_test.go:53-213) restated verbatim;
+(a) the reference's own interval tests (intervals/intervals_test.go:53-213): their vectors, kept as data in tests/golden/;
 (b) hand-derived vectors of SURVEY.md §8(c), re-derived here from the cited reference lines.
 The oracle is otherwise PARITY UNPINNED (the reference has no tests for sort/markdup/BQSR).
 """
+import json
+import os
+
 import numpy as np
 import pytest
 
@@ -15,18 +18,13 @@ def iv(x):
     return np.asarray(x, dtype=np.int32).reshape(-1, 2)
 
 
-# ---------- (a) intervals/intervals_test.go ----------
-@pytest.mark.parametrize("inp,exp", [
-    ([], []),                                                               # :54
-    ([[2, 3], [3, 4]], [[2, 4]]),                                           # :57
-    ([[2, 3], [4, 5]], [[2, 3], [4, 5]]),                                   # :60
-    ([[2, 4], [3, 5], [4, 6]], [[2, 6]]),                                   # :63
-    ([[2, 4], [3, 5], [4, 6], [7, 9]], [[2, 6], [7, 9]]),                   # :66
-    ([[2, 3], [3, 4], [5, 6], [6, 7]], [[2, 4], [5, 7]]),                   # :69
-    ([[2, 3], [2, 5], [2, 4], [2, 3], [2, 6], [2, 7]], [[2, 7]]),           # :72
-])
-def test_flatten_reference_vectors(inp, exp):
-    assert orc.flatten(iv(inp)).tolist() == iv(exp).tolist()
+# ---------- (a) intervals/intervals_test.go: the vectors live in tests/golden/intervals_test_go.json ----------
+_GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "intervals_test_go.json")))
+
+
+@pytest.mark.parametrize("case", _GOLD["flatten"])
+def test_flatten_reference_vectors(case):  # :53-73
+    assert orc.flatten(iv(case["in"])).tolist() == iv(case["out"]).tolist()
 
 
 def test_flatten_large_random():  # :75-84 with makeLargeIntervalsSlice :38-50
@@ -38,26 +36,14 @@ def test_flatten_large_random():  # :75-84 with makeLargeIntervalsSlice :38-50
     assert (out[1:, 0] > out[:-1, 1]).all()
 
 
-@pytest.mark.parametrize("ivs,s,e,exp", [
-    ([], 2, 3, False), ([[1, 3], [7, 8]], 4, 6, False),
-    ([[2, 4], [6, 8]], 1, 3, True), ([[2, 4], [6, 8]], 2, 3, True), ([[2, 4], [6, 8]], 2, 5, True),
-    ([[2, 4], [6, 8]], 2, 6, True), ([[2, 4], [6, 8]], 3, 7, True), ([[2, 4], [6, 8]], 5, 7, True),
-    ([[2, 4], [6, 8]], 6, 8, True), ([[2, 4], [6, 8]], 6, 9, True), ([[2, 4], [6, 8]], 5, 9, True),
-    ([[2, 4], [6, 8]], 1, 10, True),
-])
-def test_overlap_reference_vectors(ivs, s, e, exp):  # :137-174
-    assert orc.overlap(iv(ivs), s, e) == exp
+@pytest.mark.parametrize("case", _GOLD["overlap"])
+def test_overlap_reference_vectors(case):  # :137-174
+    assert orc.overlap(iv(case["intervals"]), case["start"], case["end"]) == case["out"]
 
 
-@pytest.mark.parametrize("ivs,s,e,exp", [
-    ([], 2, 3, []), ([[1, 3], [7, 8]], 4, 6, []),
-    ([[2, 4], [6, 8]], 1, 3, [[2, 4]]), ([[2, 4], [6, 8]], 2, 3, [[2, 4]]), ([[2, 4], [6, 8]], 2, 5, [[2, 4]]),
-    ([[2, 4], [6, 8]], 2, 6, [[2, 4], [6, 8]]), ([[2, 4], [6, 8]], 3, 7, [[2, 4], [6, 8]]),
-    ([[2, 4], [6, 8]], 5, 7, [[6, 8]]), ([[2, 4], [6, 8]], 6, 8, [[6, 8]]), ([[2, 4], [6, 8]], 6, 9, [[6, 8]]),
-    ([[2, 4], [6, 8]], 5, 9, [[6, 8]]), ([[2, 4], [6, 8]], 1, 10, [[2, 4], [6, 8]]),
-])
-def test_intersect_reference_vectors(ivs, s, e, exp):  # :176-213
-    assert orc.intersect(iv(ivs), s, e).tolist() == iv(exp).tolist()
+@pytest.mark.parametrize("case", _GOLD["intersect"])
+def test_intersect_reference_vectors(case):  # :176-213
+    assert orc.intersect(iv(case["intervals"]), case["start"], case["end"]).tolist() == iv(case["out"]).tolist()
 
 
 # ---------- (b) hand-derived KATs ----------
