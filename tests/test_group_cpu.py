@@ -18,3 +18,16 @@ def test_group_id_size_matches_rccl():
     assert int(re.search(r"#define ELP_GROUP_ID_BYTES (\d+)", hdr).group(1)) == 128
     rccl = open("/opt/rocm/include/rccl/rccl.h").read()
     assert int(re.search(r"#define NCCL_UNIQUE_ID_BYTES (\d+)", rccl).group(1)) == 128
+
+
+def test_entry_points_reject_null_contexts_without_a_gpu():
+    """argument checks come in front of any device call: a NULL context is an error code, not a crash (no compute without a GPU)"""
+    L = _lib.hip()
+    null = ctypes.c_void_p(0)
+    n = ctypes.c_uint64(0)
+    assert L.elp_copy_records(null, null, null, 0, -1, 0) != 0
+    assert L.elp_emit_merged_bam(null, null, null, 0, ctypes.byref(n)) != 0
+    assert L.elp_bqsr_lut_upload(null, 500, null, null) != 0
+    assert L.elp_bqsr_apply(null, 500, null, null) != 0
+    assert L.elp_group_init_transport(null, 0, 2, null, null) != 0
+    assert L.elp_group_rank(null) == -1 and L.elp_group_size(null) == 0
