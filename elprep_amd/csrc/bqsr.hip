@@ -1473,29 +1473,34 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
     ELP_HIP(c, hipMemsetAsync(rec_cnt, 0, (size_t)(C3_NSEG + 1) * C3_CSTRIDE * sizeof(uint32_t), st));
     // count3.hip (read sets of one length) works from 32-byte records the prologue kernels write instead of the descriptors; it takes
     // the count if the staged reads have one length (checked once per staged column), no read can exceed --max-cycle, and the quality
-    // slots fit one table pass - k_bqsr_count otherwise (ELP_COUNT_KERNEL=1 forces it: A/B measurements)
+    // slots fit one table pass - k_bqsr_count otherwise (elp_set_tuning "count_kernel" = 1 forces it: A/B measurements)
     BqRec *recs = nullptr;
     // a wave of the first pass appends its class-1 records (at most PF_TILES * 64) to segment wave % C3_NSEG
     const unsigned pf_grid = blocks_for(n, 256 * PF_TILES);
     const uint64_t cap_s = ((uint64_t)pf_grid * 4 + C3_NSEG - 1) / C3_NSEG * (uint64_t)(PF_TILES * 64);
     {
-      const bool force_old = getenv("ELP_COUNT_KERNEL") && atoi(getenv("ELP_COUNT_KERNEL")) == 1;  // read per call: tests switch it
+      const bool force_old = c->tune.count_kernel == 1;  // elp_set_tuning
       ELP_TRY(ensure_uniform_len(c));
       const int lmax0 = (int)std::max<uint32_t>(c->max_l_seq, 1);
       int rsw3 = 0, rlog3 = 0;
       size_t dyn3 = 0;
       int nq0 = 0;
       for (int q = 6; q < ELP_NQUAL; q++) nq0 += (int)((q < 64 ? (c->qual_present[0] >> q) : (c->qual_present[1] >> (q - 64))) & 1ull);
-      if (!force_old && c->uniform_len > 0 && lmax0 <= max_cycle && lmax0 <= 1022 && count3_plan(c->n_cov, std::max(nq0, 1), lmax0, &rsw3, &rlog3, &dyn3) == 0)
+      if (!force_old && c->uniform_len > 0 && lmax0 <= max_cycle && lmax0 <= 1022 && count3_plan(c->n_cov, std::max(nq0, 1), lmax0, &rsw3, &rlog3, &dyn3, c->tune.count3_rlog) == 0)
         ELP_TRY(scratch(c, 4, (size_t)C3_NSEG * cap_s + n + 64, &recs));
     }
-    const RecOut ro{recs, rec_cnt, cap_s};
-    ELP_LAUNCH(c, "bqsr_prologue_fast", k_bqsr_prologue_fast, dim3(pf_grid), dim3(256), 0, m, desc, skipbits, queue + 4, queue, c->err_flag.p, ro, plist);
-    // (sized for the worst case; workgroups beyond the list's end leave at once)
-    ELP_LAUNCH(c, "bqsr_prologue_plain", k_bqsr_prologue_plain, dim3(std::min<unsigned>(blocks_for(n, 256), (unsigned)c->n_cu * 16)), dim3(256), 0, m, desc, skipbits,
-               (const uint32_t *)plist, queue + 4, queue, c->err_flag.p, ro);
-    ELP_LAUNCH(c, "bqsr_prologue", k_bqsr_prologue, dim3(std::min<unsigned>(blocks_for(n, 256), (unsigned)c->n_cu * 16)), dim3(256), 0, m,
-               (const uint32_t *)(queue + 4), (const uint32_t *)queue, cs_pool, desc, skipbits, c->err_flag.p, ro);
+    // the three prologue passes; with `r` they leave 32-byte records for count3.hip, without it the descriptors of k_bqsr_count
+    auto run_prologues = [&](BqRec *r) -> int {
+      const RecOut ro{r, rec_cnt, cap_s};
+      ELP_LAUNCH(c, "bqsr_prologue_fast", k_bqsr_prologue_fast, dim3(pf_grid), dim3(256), 0, m, desc, skipbits, queue + 4, queue, c->err_flag.p, ro, plist);
+      // (sized for the worst case; workgroups beyond the list's end leave at once)
+      ELP_LAUNCH(c, "bqsr_prologue_plain", k_bqsr_prologue_plain, dim3(std::min<unsigned>(blocks_for(n, 256), (unsigned)c->n_cu * 16)), dim3(256), 0, m, desc, skipbits,
+                 (const uint32_t *)plist, queue + 4, queue, c->err_flag.p, ro);
+      ELP_LAUNCH(c, "bqsr_prologue", k_bqsr_prologue, dim3(std::min<unsigned>(blocks_for(n, 256), (unsigned)c->n_cu * 16)), dim3(256), 0, m,
+                 (const uint32_t *)(queue + 4), (const uint32_t *)queue, cs_pool, desc, skipbits, c->err_flag.p, ro);
+      return 0;
+    };
+    ELP_TRY(run_prologues(recs));
     const int lmax = (int)std::max<uint32_t>(c->max_l_seq, 1);
     if (lmax > MAX_DESC_READ) return set_error(c, ELP_ERR_UNSUPPORTED, "BQSR: read longer than %d bases", MAX_DESC_READ);
     const bool check_cycle = lmax > max_cycle;
@@ -1536,8 +1541,21 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
       if (recs) {
         int rsw3 = 0, rlog3 = 0;
         size_t dyn3 = 0;
-        if (count3_plan(c->n_cov, (int)quals.size(), lmax, &rsw3, &rlog3, &dyn3) != 0)
-          return set_error(c, ELP_ERR_UNSUPPORTED, "BQSR: the exact quality set (%d values) does not fit the count tables of one pass", (int)quals.size());
+        if (count3_plan(c->n_cov, (int)quals.size(), lmax, &rsw3, &rlog3, &dyn3, c->tune.count3_rlog) != 0) {
+          // the sampled hint fitted one table pass, the exact set (taken after the count met a quality without a slot) does not: the
+          // reference just runs (filters/bqsr.go:467-551), so does this - the prologues once more, leaving descriptors, and the general
+          // count kernel, which takes its quality slots in several passes
+          recs = nullptr;
+          ELP_HIP(c, hipMemsetAsync(skipbits, 0, skip_words * 4, st));
+          ELP_HIP(c, hipMemsetAsync(queue, 0, 16, st));
+          ELP_HIP(c, hipMemsetAsync(rec_cnt, 0, (size_t)(C3_NSEG + 1) * C3_CSTRIDE * sizeof(uint32_t), st));
+          ELP_TRY(run_prologues(nullptr));
+        }
+      }
+      if (recs) {
+        int rsw3 = 0, rlog3 = 0;
+        size_t dyn3 = 0;
+        (void)count3_plan(c->n_cov, (int)quals.size(), lmax, &rsw3, &rlog3, &dyn3, c->tune.count3_rlog);
         QMap qm;
         memset(qm.slot, 254, sizeof qm.slot);
         for (size_t s2 = 0; s2 < quals.size(); s2++) qm.slot[quals[s2]] = (uint8_t)s2;
@@ -1772,7 +1790,7 @@ int elp_bqsr_lut_upload(elp_ctx *c, int max_cycle, const uint8_t *lut, const uin
   // the row dictionary apply3 works from, behind the copy on the same stream - if what it depends on is known now (the quality hint of the
   // gather that produced these tables, a read set of one length): 0.25 ms that elp_bqsr_apply otherwise spends in front of its kernel
   c->dict_ready = false;
-  const bool force_old = getenv("ELP_APPLY_KERNEL") && atoi(getenv("ELP_APPLY_KERNEL")) == 1;
+  const bool force_old = c->tune.apply_kernel == 1;
   if (!force_old && c->have_qual_present && c->uniform_n == c->n && c->uniform_len >= 16 && c->n > 0 && (int64_t)c->max_l_seq <= (int64_t)max_cycle) {
     int qlo, qhi;
     lut_quality_range(c, &qlo, &qhi);
@@ -1833,9 +1851,9 @@ static int bqsr_apply_impl(elp_ctx *c, int max_cycle, const uint8_t *lut, const 
       lut_quality_range(c, &qlo, &qhi);
       const int lmax = (int)std::max<uint32_t>(c->max_l_seq, 1);
       const bool chk = (int64_t)c->max_l_seq > (int64_t)max_cycle;
-      // apply3.hip takes read sets of one length (ELP_APPLY_KERNEL=1 forces k_bqsr_apply_flat: A/B measurements); its level-1 table is
+      // apply3.hip takes read sets of one length (elp_set_tuning "apply_kernel" = 1 forces k_bqsr_apply_flat: A/B measurements); its level-1 table is
       // resident from quality 6 on, whatever the smallest sampled quality was
-      const bool force_old = getenv("ELP_APPLY_KERNEL") && atoi(getenv("ELP_APPLY_KERNEL")) == 1;  // read per call: tests switch it
+      const bool force_old = c->tune.apply_kernel == 1;  // elp_set_tuning
       ELP_TRY(ensure_uniform_len(c));
       const bool want3 = !force_old && !chk && c->uniform_len >= 16 && qhi >= 0;  // (apply3 works in whole 16-byte blocks)
       if (want3) qlo = 6;

@@ -300,7 +300,7 @@ struct Count3Args {
   unsigned long long *cycle_tbl, *ctx_tbl;
   uint32_t *err;
 };
-int count3_plan(int n_cov, int n_q, int lmax, int *rsw_out, int *rlog_out, size_t *dyn_out);
+int count3_plan(int n_cov, int n_q, int lmax, int *rsw_out, int *rlog_out, size_t *dyn_out, int force_rlog = -1);
 int count3_launch(elp_ctx *c, const Count3Args &A, const QMap &qm, size_t dyn);
 // ---- ApplyBQSR for read sets of one length (apply3.hip)
 int apply3_bytes(int n_cov, int n_qi, int lmax, size_t *dyn_out);

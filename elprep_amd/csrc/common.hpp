@@ -116,9 +116,8 @@ struct elp_ctx {
 
   // mark-duplicates results kept for the metrics pass
   elp::DVec<uint32_t> mate;        // per record: staging index of its mate if the two form a pair (classifyPair), else 0xFFFFFFFF
-  elp::DVec<uint32_t> pair_slot;   // per record that owns a pair (the later-arriving mate): slot in the pair table
-  elp::DVec<uint32_t> pair_winner; // per pair-table slot: owner record of the best pair
-  uint64_t pair_table_size = 0;
+  elp::DVec<uint32_t> pair_win;    // per record: for the owner (the later-arriving mate) of a pair that LOST its key's tournament, the owner of
+                                   // the winning pair; 0xFFFFFFFF for every other record
 
   // BQSR inputs
   std::vector<uint8_t *> h_ref_seq;  // device pointers per refid
@@ -176,6 +175,17 @@ struct elp_ctx {
   elp::DVec<uint8_t> snap_qual;
   uint64_t snap_n = 0, snap_qual_bytes = 0;
   bool have_snapshot = false;
+
+  // elp_set_tuning: kernel choices a caller (tests, A/B measurements) can pin; 0 = the library decides
+  struct Tuning {
+    int count_kernel = 0;      // 1: the general count kernel even where the one-length kernel applies
+    int apply_kernel = 0;      // 1: the general apply kernel
+    int count3_rlog = -1;      // >= 0: log2 of the context-cell replication of the one-length count kernel
+    int qual_hint = 0;         // 1: no sampled quality hint (tables sized for every quality); 2: hint without the value qual_hint_drop
+    int qual_hint_drop = -1;
+    int pair_table_slots = 1024;  // LDS table slots of the pair buckets (mark duplicates); tests shrink it to reach the overflow path
+    int mate_path = 0;         // 1: every mate candidate goes through the table path (no neighbour shortcut)
+  } tune;
 
   // generic scratch pool (grown on demand, reused between calls)
   elp::DVec<uint8_t> scratch[8];
@@ -315,7 +325,8 @@ int radix_sort_pairs(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *keys_
                      uint64_t **keys_out, uint32_t **vals_out);
 // the same over the low `ndigits` bytes of the keys only, every pass run (no histogram read-back, no host synchronisation)
 int radix_sort_pairs_low(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *keys_tmp, uint32_t *vals_tmp, uint64_t n, int ndigits,
-                         uint64_t **keys_out, uint32_t **vals_out, const uint64_t *first_src = nullptr, bool identity_vals = false);
+                         uint64_t **keys_out, uint32_t **vals_out, const uint64_t *first_src = nullptr, bool identity_vals = false,
+                         const uint32_t *n_dev = nullptr /* the length is *n_dev on the device and `n` its upper bound */);
 int exclusive_scan_u32(elp_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n, uint32_t *total_host /* may be null */);
 int ensure_adapted(elp_ctx *c, bool check_quals = true);
 int ensure_uniform_len(elp_ctx *c);  // sort.hip: c->uniform_len

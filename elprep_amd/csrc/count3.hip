@@ -443,13 +443,12 @@ __global__ __launch_bounds__(C3_NT) void k_bqsr_count3(Count3Args A, QMap qm) {
 
 // Launch plan: one workgroup of 1024 threads per CU around one table; the context cells are replicated as often as the CU's LDS allows.
 // Returns 1 if the tables of this pass do not fit (the caller uses k_bqsr_count).
-int count3_plan(int n_cov, int n_q, int lmax, int *rsw_out, int *rlog_out, size_t *dyn_out) {
+int count3_plan(int n_cov, int n_q, int lmax, int *rsw_out, int *rlog_out, size_t *dyn_out, int force_rlog) {
   const size_t lds_cu = 160 * 1024, static_lds = 1024 + 1024 + 96 + 256;
   const int ncw = ((17 * 2 * lmax) >> 4) + 2;
   const size_t rows = (size_t)n_cov * (size_t)(n_q + C3_XROWS);
-  const char *force = getenv("ELP_COUNT3_RLOG");  // measurements only
   for (int rlog = 5; rlog >= 1; rlog--) {
-    if (force && atoi(force) != rlog) continue;
+    if (force_rlog >= 0 && force_rlog != rlog) continue;  // elp_set_tuning "count3_rlog": measurements only
     const int rsw = ((16 << rlog) + 16 + ncw + 31) & ~31;
     const size_t dyn = (rows * (size_t)rsw + C3_PAD) * 4;
     if (dyn + static_lds <= lds_cu && rows * (size_t)rsw * 4 < (1u << 22)) {

@@ -403,6 +403,23 @@ int elp_rollback(elp_ctx *c) {
   return 0;
 }
 
+int elp_set_tuning(elp_ctx *c, const char *key, int64_t value) {
+  if (!c || !key) return ELP_ERR_ARG;
+  const std::string k(key);
+  const int v = (int)value;
+  if (k == "count_kernel") c->tune.count_kernel = v;
+  else if (k == "apply_kernel") c->tune.apply_kernel = v;
+  else if (k == "count3_rlog") c->tune.count3_rlog = v;
+  else if (k == "qual_hint") { c->tune.qual_hint = v; c->have_qual_present = false; }
+  else if (k == "qual_hint_drop") { c->tune.qual_hint_drop = v; c->have_qual_present = false; }
+  else if (k == "pair_table_slots") {
+    if (v < 2 || v > 1024 || (v & (v - 1))) return set_error(c, ELP_ERR_ARG, "elp_set_tuning: pair_table_slots must be a power of two in [2, 1024]");
+    c->tune.pair_table_slots = v;
+  } else if (k == "mate_path") c->tune.mate_path = v;
+  else return set_error(c, ELP_ERR_ARG, "elp_set_tuning: unknown key '%s'", key);
+  return 0;
+}
+
 int elp_profile_enable(elp_ctx *c, int on) {
   if (!c) return ELP_ERR_ARG;
   if (!on) ELP_TRY(prof_flush(c));

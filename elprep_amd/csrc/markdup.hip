@@ -378,51 +378,205 @@ __device__ __forceinline__ bool pair_key_eq(const PairKey &a, const PairKey &b) 
          a.k1.w == b.k1.w;  // mates share their split id
 }
 
-__global__ __launch_bounds__(256) void k_pair_insert(MdCols m, const uint4 *__restrict__ fkey, const uint32_t *__restrict__ mate, uint32_t *table,
-                                                     uint64_t mask, uint32_t *__restrict__ prep, unsigned long long *pbest) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m.n) return;
-  const uint32_t mt = mate[i];
-  if (mt == EMPTY || mt > (uint32_t)i) { prep[i] = EMPTY; return; }  // the later-arriving mate owns the pair (:336-340)
-  const PairKey mine = pair_key(fkey[i], fkey[mt]);
-  uint64_t h = mix64(((uint64_t)mine.k1.x << 32) | mine.k2.x);
-  h = mix64(h ^ (((uint64_t)mine.k1.y << 32) | mine.k2.y));
-  h = mix64(h ^ (((uint64_t)mine.k1.z << 1) | (mine.k2.z & 1u)) ^ ((uint64_t)mine.k1.w << 40));
-  const uint32_t rep = find_or_insert(table, mask, h, (uint32_t)i,
-                                      [&](uint32_t a, uint32_t) { return pair_key_eq(pair_key(fkey[a], fkey[mate[a]]), mine); });
-  prep[i] = rep;
-  // best score of the key (:342), plus one - and only once a SECOND pair arrives at the key: nine pairs in ten are the only one of theirs,
-  // their word stays 0 ("nothing to decide": k_pair_tie) and costs no atomic (the kernel runs at the atomic rate of the
-  // memory system, profiles/r2v_random_access_probe_48M.txt; this halves its atomics).  The later pair brings the first one's score along.
-  if (rep != (uint32_t)i) {
-    const int32_t sc = m.score[i] + m.score[mt], scr = m.score[rep] + m.score[mate[rep]];
-    atomicMax(&pbest[rep], (unsigned long long)(uint32_t)(sc > scr ? sc : scr) + 1ull);
+__device__ __forceinline__ uint64_t pair_hash(const PairKey &k) {
+  uint64_t h = mix64(((uint64_t)k.k1.x << 32) | k.k2.x);
+  h = mix64(h ^ (((uint64_t)k.k1.y << 32) | k.k2.y));
+  return mix64(h ^ (((uint64_t)k.k1.z << 1) | (k.k2.z & 1u)) ^ ((uint64_t)k.k1.w << 40));
+}
+
+// The pairs are grouped by key WITHOUT a table in HBM (rounds 1-3 ran one compare-and-swap per pair on a 256 MB table: the rate of
+// random device-scope atomics, not bandwidth, bounded it).  Round 4:
+//   k_pair_list    every pair's owner (its later-arriving record, :336-340) writes ONE 12-byte entry - {score sum | 32 hash bits of the
+//                  pair key, owner} - to a compact list (one global atomic per workgroup);
+//   radix passes   the list is partitioned by `bbits` hash bits into buckets of <= ~384 pairs (the sort's own scatter kernel; the
+//                  list's length stays on the device: over-launched tiles leave at once);
+//   k_pair_bounds  first / last entry of every bucket;
+//   k_pair_bucket  one workgroup per bucket: find-or-insert into a table in LDS (64-bit compare-and-swap on {hash bits | first
+//                  owner}; a hash match is confirmed on the two ends' packed keys, so there are no false merges), best score by LDS
+//                  atomic max, the (QNAME asc, later arrival) tournament among the score-tied pairs by LDS compare-and-swap, and the
+//                  flags of both reads of every losing pair - insert, tie and flag of :329-396 in one kernel.
+// pair_win[owner] = the owner of the winning pair of its key, for the owners of LOSING pairs only (EMPTY everywhere else): all the
+// metrics pass needs (metrics.hip).
+constexpr int PL_TILES = 8;
+__global__ __launch_bounds__(256) void k_pair_list(MdCols m, const uint4 *__restrict__ fkey, const uint32_t *__restrict__ mate,
+                                                   uint64_t *__restrict__ pk, uint32_t *__restrict__ pv, uint32_t *np) {
+  __shared__ uint64_t lk[PL_TILES * 256];
+  __shared__ uint32_t lv[PL_TILES * 256];
+  __shared__ uint32_t lcount, gbase;
+  if (threadIdx.x == 0) lcount = 0;
+  __syncthreads();
+#pragma unroll 2
+  for (int tile = 0; tile < PL_TILES; tile++) {
+    const uint64_t i = ((uint64_t)blockIdx.x * PL_TILES + (uint64_t)tile) * 256 + threadIdx.x;
+    const uint32_t mt = i < m.n ? mate[i] : EMPTY;
+    const bool own = mt != EMPTY && mt < (uint32_t)i;  // the later-arriving mate owns the pair (:336-340)
+    uint64_t key = 0;
+    if (own) {
+      const PairKey mine = pair_key(fkey[i], fkey[mt]);
+      key = ((uint64_t)(uint32_t)(m.score[i] + m.score[mt]) << 32) | (uint32_t)pair_hash(mine);
+    }
+    const unsigned long long mask = __ballot(own);
+    if (mask) {
+      const int lane = threadIdx.x & 63, leader = __ffsll((long long)mask) - 1;
+      uint32_t at = 0;
+      if (lane == leader) at = atomicAdd(&lcount, (uint32_t)__popcll(mask));
+      at = __shfl(at, leader, 64);
+      if (own) {
+        at += (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        lk[at] = key;
+        lv[at] = (uint32_t)i;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) gbase = lcount ? atomicAdd(np, lcount) : 0u;
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < lcount; k += 256) {
+    pk[gbase + k] = lk[k];
+    pv[gbase + k] = lv[k];
   }
 }
 
-__global__ __launch_bounds__(256) void k_pair_tie(MdCols m, const uint32_t *__restrict__ mate, const uint32_t *__restrict__ prep,
-                                                  const unsigned long long *__restrict__ pbest, uint32_t *pwinner) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m.n) return;
-  const uint32_t rep = prep[i];
-  if (rep == EMPTY) return;
-  const unsigned long long best = pbest[rep];
-  if (best == 0) { pwinner[rep] = (uint32_t)i; return; }  // the only pair of its key (rep == i): it wins, no tournament
-  const int32_t sc = m.score[i] + m.score[mate[i]];
-  if ((unsigned long long)(uint32_t)sc + 1ull != best) return;
-  tournament(m, &pwinner[rep], (uint32_t)i);  // both mates share the QNAME, so the owner's QNAME stands for aln1.QNAME (:383)
+// bucket of an entry: the top `bbits` of the `sbits` low hash bits the list was sorted by
+__device__ __forceinline__ uint32_t pair_bucket(uint64_t key, int sbits, int bbits) {
+  return bbits ? ((uint32_t)key & ((1u << sbits) - 1u)) >> (sbits - bbits) : 0u;
+}
+__global__ __launch_bounds__(256) void k_pair_bounds(const uint64_t *__restrict__ ks, const uint32_t *__restrict__ np, int sbits, int bbits,
+                                                     uint32_t *__restrict__ bstart, uint32_t *__restrict__ bend) {
+  const uint32_t n = *np;
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t b = pair_bucket(ks[j], sbits, bbits);
+  if (j == 0 || pair_bucket(ks[j - 1], sbits, bbits) != b) bstart[b] = j;
+  if (j + 1 == n || pair_bucket(ks[j + 1], sbits, bbits) != b) bend[b] = j + 1;
 }
 
-__global__ __launch_bounds__(256) void k_pair_flag(MdCols m, const uint32_t *__restrict__ mate, const uint32_t *__restrict__ prep,
-                                                   const uint32_t *__restrict__ pwinner, uint16_t *__restrict__ flag_out) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m.n) return;
-  const uint32_t rep = prep[i];
-  if (rep == EMPTY) return;
-  if (pwinner[rep] != (uint32_t)i) {
-    const uint32_t mt = mate[i];
-    flag_out[i] = (uint16_t)(flag_out[i] | F_DUPLICATE);
-    flag_out[mt] = (uint16_t)(flag_out[mt] | F_DUPLICATE);
+__device__ __forceinline__ PairKey pair_key_of(const uint4 *__restrict__ fkey, const uint32_t *__restrict__ mate, uint32_t owner) {
+  return pair_key(fkey[owner], fkey[mate[owner]]);
+}
+// (QNAME asc, later arrival wins) among the best-scoring pairs of a key, on a word in LDS
+__device__ __forceinline__ void tournament_lds(const MdCols &m, uint32_t *winner, uint32_t me) {
+  uint32_t w = *(volatile uint32_t *)winner;
+  for (;;) {
+    if (w != EMPTY) {
+      const int cq = qname_cmp(m.qname, m.qname_off, me, w);
+      if (!(cq < 0 || (cq == 0 && me > w))) return;  // :383-389: on equal QNAME the later completion replaces the holder
+    }
+    const uint32_t old = atomicCAS(winner, w, me);
+    if (old == w) return;
+    w = old;
+  }
+}
+__device__ __forceinline__ void pair_lost(const MdCols &m, const uint32_t *__restrict__ mate, uint32_t o, uint32_t w, uint32_t *__restrict__ pair_win,
+                                          uint16_t *__restrict__ flag_out) {
+  const uint32_t mt = mate[o];
+  pair_win[o] = w;
+  flag_out[o] = (uint16_t)(flag_out[o] | F_DUPLICATE);
+  flag_out[mt] = (uint16_t)(flag_out[mt] | F_DUPLICATE);
+}
+
+constexpr int PB_CAP = 1024;       // table slots in LDS (a bucket holds ~384 pairs at most on average)
+constexpr int PB_ECAP = 1024;      // entries whose table slot is remembered in LDS between the phases (the others look theirs up again)
+constexpr unsigned long long PB_EMPTY = ~0ull;
+
+// table slot of entry {h32, o}: find-or-insert.  Returns -1 if the table is full.
+__device__ __forceinline__ int pb_slot(const MdCols &m, const uint4 *__restrict__ fkey, const uint32_t *__restrict__ mate,
+                                       unsigned long long *s_key, uint32_t tmask, uint32_t h32, uint32_t o, bool insert) {
+  uint32_t idx = (h32 * 0x9E3779B1u) >> 16 & tmask;
+  const unsigned long long mine = ((unsigned long long)h32 << 32) | o;
+  for (uint32_t probes = 0; probes <= tmask; probes++, idx = (idx + 1) & tmask) {
+    unsigned long long cur = insert ? atomicCAS(&s_key[idx], PB_EMPTY, mine) : s_key[idx];
+    if (cur == PB_EMPTY) { if (insert) return (int)idx; else continue; }
+    if (cur == mine) return (int)idx;
+    if ((uint32_t)(cur >> 32) == h32 && pair_key_eq(pair_key_of(fkey, mate, (uint32_t)cur), pair_key_of(fkey, mate, o))) return (int)idx;
+  }
+  return -1;
+}
+
+__global__ __launch_bounds__(256) void k_pair_bucket(MdCols m, const uint4 *__restrict__ fkey, const uint32_t *__restrict__ mate,
+                                                     const uint64_t *__restrict__ ks, uint32_t *__restrict__ vs,
+                                                     const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ bend, int cap_slots,
+                                                     uint32_t *__restrict__ pair_win, uint16_t *__restrict__ flag_out) {
+  __shared__ unsigned long long s_key[PB_CAP];
+  __shared__ uint32_t s_best[PB_CAP], s_win[PB_CAP];
+  __shared__ uint16_t s_slot[PB_ECAP];
+  __shared__ uint32_t s_full, s_min, s_h;
+  const uint32_t start = bstart[blockIdx.x], cnt = bend[blockIdx.x] - start;
+  if (cnt == 0) return;
+  const uint32_t t = threadIdx.x;
+  if (cnt == 1) return;  // the only pair of its bucket wins
+  uint32_t T = 2;
+  while (T < 2 * cnt && T < (uint32_t)cap_slots) T <<= 1;
+  const uint32_t tmask = T - 1;
+  for (uint32_t k = t; k < T; k += 256) { s_key[k] = PB_EMPTY; s_best[k] = 0; s_win[k] = EMPTY; }
+  if (t == 0) s_full = 0;
+  __syncthreads();
+  ks += start;
+  vs += start;
+  // insert + best score (:342-378)
+  for (uint32_t e = t; e < cnt; e += 256) {
+    const uint64_t key = ks[e];
+    const uint32_t o = vs[e];
+    const int slot = pb_slot(m, fkey, mate, s_key, tmask, (uint32_t)key, o, true);
+    if (slot < 0) { s_full = 1; break; }
+    atomicMax(&s_best[slot], (uint32_t)(key >> 32));
+    if (e < PB_ECAP) s_slot[e] = (uint16_t)slot;
+  }
+  __syncthreads();
+  if (!s_full) {
+    // tournament among the pairs with the best score (:379-391)
+    for (uint32_t e = t; e < cnt; e += 256) {
+      const uint64_t key = ks[e];
+      const uint32_t o = vs[e];
+      const int slot = e < PB_ECAP ? (int)s_slot[e] : pb_slot(m, fkey, mate, s_key, tmask, (uint32_t)key, o, false);
+      if ((uint32_t)(key >> 32) == s_best[slot]) tournament_lds(m, &s_win[slot], o);
+    }
+    __syncthreads();
+    for (uint32_t e = t; e < cnt; e += 256) {
+      const uint32_t o = vs[e];
+      const int slot = e < PB_ECAP ? (int)s_slot[e] : pb_slot(m, fkey, mate, s_key, tmask, (uint32_t)ks[e], o, false);
+      const uint32_t w = s_win[slot];
+      if (w != o) pair_lost(m, mate, o, w, pair_win, flag_out);
+    }
+    return;
+  }
+  // More distinct keys than the table holds: not a natural case (the hash spreads the keys evenly over the buckets; only keys crafted
+  // to share their hash bits get here).  Exact and slow: the groups are peeled off one by one - the unresolved pair with the smallest
+  // owner names the next key, every unresolved pair compares its key with that one; a resolved entry's owner is overwritten with EMPTY.
+  for (;;) {
+    __syncthreads();
+    if (t == 0) { s_min = EMPTY; s_best[0] = 0; s_win[0] = EMPTY; }
+    __syncthreads();
+    for (uint32_t e = t; e < cnt; e += 256) {
+      const uint32_t o = vs[e];
+      if (o != EMPTY) atomicMin(&s_min, o);
+    }
+    __syncthreads();
+    const uint32_t rep = s_min;
+    if (rep == EMPTY) return;
+    for (uint32_t e = t; e < cnt; e += 256)
+      if (vs[e] == rep) s_h = (uint32_t)ks[e];
+    __syncthreads();
+    const uint32_t rh = s_h;
+    const PairKey rk = pair_key_of(fkey, mate, rep);
+    for (uint32_t e = t; e < cnt; e += 256) {
+      const uint32_t o = vs[e];
+      if (o != EMPTY && (uint32_t)ks[e] == rh && pair_key_eq(rk, pair_key_of(fkey, mate, o))) atomicMax(&s_best[0], (uint32_t)(ks[e] >> 32));
+    }
+    __syncthreads();
+    for (uint32_t e = t; e < cnt; e += 256) {
+      const uint32_t o = vs[e];
+      if (o != EMPTY && (uint32_t)ks[e] == rh && (uint32_t)(ks[e] >> 32) == s_best[0] && pair_key_eq(rk, pair_key_of(fkey, mate, o)))
+        tournament_lds(m, &s_win[0], o);
+    }
+    __syncthreads();
+    for (uint32_t e = t; e < cnt; e += 256) {
+      const uint32_t o = vs[e];
+      if (o != EMPTY && (uint32_t)ks[e] == rh && pair_key_eq(rk, pair_key_of(fkey, mate, o))) {
+        if (s_win[0] != o) pair_lost(m, mate, o, s_win[0], pair_win, flag_out);
+        vs[e] = EMPTY;
+      }
+    }
   }
 }
 
@@ -436,8 +590,7 @@ static int markdup_impl(elp_ctx *c) {
   const uint64_t n = c->n;
   ELP_TRY(ensure_adapted(c));
   ELP_TRY(ensure(c, c->mate, n + 1));
-  ELP_TRY(ensure(c, c->pair_slot, n + 1));
-  ELP_TRY(ensure(c, c->pair_winner, n + 1));
+  ELP_TRY(ensure(c, c->pair_win, n + 1));
   if (n == 0) { c->marked = true; return 0; }
   const unsigned grid = blocks_for(n, 256);
   hipStream_t st = c->stream;
@@ -454,9 +607,9 @@ static int markdup_impl(elp_ctx *c) {
   ELP_TRY(scratch(c, 0, T, &table));
   uint32_t *rep;
   unsigned long long *best;
-  ELP_TRY(scratch(c, 2, n + 8, &best));
+  ELP_TRY(scratch(c, 2, n + 16, &best));  // (sized for the pair phase's list as well: no reallocation in mid-call)
   uint32_t *winner;
-  ELP_TRY(scratch(c, 3, n + 8, &winner));
+  ELP_TRY(scratch(c, 3, n + 16, &winner));
 
   uint4 *fkey;
   ELP_TRY(scratch(c, 5, n + 8, &fkey));
@@ -478,7 +631,7 @@ static int markdup_impl(elp_ctx *c) {
     ELP_TRY(scratch(c, 6, bw + n + 16 + (n + 16) / 4, &bloom));
     hash32 = bloom + bw;
     code = reinterpret_cast<uint8_t *>(hash32 + n + 8);
-    uint32_t *rep_of = c->pair_slot.p;  // free until k_pair_insert fills it
+    uint32_t *rep_of = c->pair_win.p;  // free until the pair phase fills it
     uint32_t *n_table_dev = c->err_flag.p + 3;  // the scan-total mailbox
     ELP_HIP(c, hipMemsetAsync(bloom, 0, bw * sizeof(uint32_t), st));
     ELP_HIP(c, hipMemsetAsync(n_table_dev, 0, 4, st));
@@ -548,17 +701,31 @@ static int markdup_impl(elp_ctx *c) {
                (const unsigned long long *)best, (const uint32_t *)winner, c->flag.p);
   }
 
-  // ---- pairs (at most n / 2 of them)
-  const uint64_t Tp = table_size_for(n / 2 + 8);
-  ELP_HIP(c, hipMemsetAsync(table, 0xFF, Tp * sizeof(uint32_t), st));
-  ELP_HIP(c, hipMemsetAsync(best, 0, n * sizeof(unsigned long long), st));
-  ELP_HIP(c, hipMemsetAsync(c->pair_winner.p, 0xFF, n * sizeof(uint32_t), st));
-  ELP_LAUNCH(c, "md_pair_insert", k_pair_insert, dim3(grid), dim3(256), 0, m, (const uint4 *)fkey, (const uint32_t *)c->mate.p, table,
-             Tp - 1, c->pair_slot.p, best);
-  ELP_LAUNCH(c, "md_pair_tie", k_pair_tie, dim3(grid), dim3(256), 0, m, (const uint32_t *)c->mate.p, (const uint32_t *)c->pair_slot.p,
-             (const unsigned long long *)best, c->pair_winner.p);
-  ELP_LAUNCH(c, "md_pair_flag", k_pair_flag, dim3(grid), dim3(256), 0, m, (const uint32_t *)c->mate.p, (const uint32_t *)c->pair_slot.p,
-             (const uint32_t *)c->pair_winner.p, c->flag.p);
+  // ---- pairs (at most n / 2 of them): list, partition by hash bits, one LDS table per bucket
+  {
+    const uint64_t npmax = n / 2 + 1;
+    int bbits = 0;
+    while (bbits < 24 && (npmax >> bbits) > 384) bbits++;
+    const int ndig = (bbits + 7) / 8, sbits = 8 * ndig;
+    uint64_t *pk;
+    uint32_t *pv, *bounds, *np_dev = c->md_ctr.p + 1;
+    ELP_TRY(scratch(c, 2, 2 * npmax + 8, &pk));   // `best` and `winner` of the fragment phase are free again
+    ELP_TRY(scratch(c, 3, 2 * npmax + 8, &pv));
+    const size_t nb = (size_t)1 << bbits;
+    ELP_TRY(scratch(c, 1, 2 * nb + 8, &bounds));  // so are `frep` and the fragment list
+    ELP_HIP(c, hipMemsetAsync(np_dev, 0, 4, st));
+    ELP_HIP(c, hipMemsetAsync(bounds, 0, 2 * nb * sizeof(uint32_t), st));
+    ELP_HIP(c, hipMemsetAsync(c->pair_win.p, 0xFF, n * sizeof(uint32_t), st));
+    ELP_LAUNCH(c, "md_pair_list", k_pair_list, dim3(blocks_for(n, 256 * PL_TILES)), dim3(256), 0, m, (const uint4 *)fkey, (const uint32_t *)c->mate.p, pk, pv,
+               np_dev);
+    uint64_t *ks = pk;
+    uint32_t *vs = pv;
+    if (ndig) ELP_TRY(radix_sort_pairs_low(c, pk, pv, pk + npmax, pv + npmax, npmax, ndig, &ks, &vs, nullptr, false, np_dev));
+    ELP_LAUNCH(c, "md_pair_bounds", k_pair_bounds, dim3(blocks_for(npmax, 256)), dim3(256), 0, (const uint64_t *)ks, (const uint32_t *)np_dev, sbits, bbits,
+               bounds, bounds + nb);
+    ELP_LAUNCH(c, "md_pair_bucket", k_pair_bucket, dim3((unsigned)nb), dim3(256), 0, m, (const uint4 *)fkey, (const uint32_t *)c->mate.p,
+               (const uint64_t *)ks, vs, (const uint32_t *)bounds, (const uint32_t *)(bounds + nb), c->tune.pair_table_slots, c->pair_win.p, c->flag.p);
+  }
   c->marked = true;
   return 0;
 }

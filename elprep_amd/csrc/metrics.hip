@@ -28,7 +28,7 @@ struct MxCols {
   const int32_t *upos;
   const uint64_t *qname_off;
   const uint8_t *qname;
-  const uint32_t *mate, *prep, *pwinner;
+  const uint32_t *mate, *pair_win;  // markdup.hip: pair_win[owner of a losing pair] = owner of the winning pair of the key
   int32_t n_lib;
   const uint8_t *has_sr;
   const uint16_t *split;
@@ -81,7 +81,7 @@ __device__ __forceinline__ void wave_count(unsigned int *lds, int cell) {
 __global__ __launch_bounds__(256) void k_dup_counters(MxCols m, unsigned long long *__restrict__ ctr, unsigned long long *__restrict__ pair_reads,
                                                       uint64_t chunk, uint64_t *__restrict__ lkeys, uint32_t *__restrict__ lvals, uint32_t *list_n) {
   extern __shared__ unsigned int lds_ctr[];  // [(n_lib+1)*7], then [n_split][n_lib+1]
-  __shared__ uint2 lq[DC_CAP];               // (owner record, pair group) of the losers collected so far
+  __shared__ uint2 lq[DC_CAP];               // (owner record, owner of its key's winning pair = the pair group) of the losers collected so far
   __shared__ uint32_t lcount, gbase;
   const int nrow = (m.n_lib + 1) * ELP_NCTR, ncell = nrow + m.n_split * (m.n_lib + 1);
   for (int k = threadIdx.x; k < ncell; k += blockDim.x) lds_ctr[k] = 0;
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void k_dup_counters(MxCols m, unsigned long lo
     constexpr int R = DC_STEP / 256;
     uint8_t sr[R];
     uint16_t fl[R], rg[R], sp[R];
-    uint32_t rep[R], mt[R];
+    uint32_t pw[R], mt[R];
 #pragma unroll
     for (int t = 0; t < R; t++) {
       const uint64_t i = base + (uint64_t)t * 256 + threadIdx.x;
@@ -103,16 +103,14 @@ __global__ __launch_bounds__(256) void k_dup_counters(MxCols m, unsigned long lo
       fl[t] = in ? m.flag[i] : (uint16_t)0;
       rg[t] = in ? m.rgid[i] : (uint16_t)ELP_NIL16;
       sp[t] = in ? m.split[i] : (uint16_t)0;
-      rep[t] = in ? m.prep[i] : EMPTY;
+      pw[t] = in ? m.pair_win[i] : EMPTY;
       mt[t] = in ? m.mate[i] : EMPTY;
     }
     uint16_t lb[R], fm[R];
     uint8_t srm[R];
-    uint32_t pw[R];
 #pragma unroll
     for (int t = 0; t < R; t++) {
       lb[t] = rg[t] == ELP_NIL16 ? (uint16_t)ELP_NIL16 : m.rg_lib[rg[t]];
-      pw[t] = rep[t] != EMPTY ? m.pwinner[rep[t]] : EMPTY;
       srm[t] = mt[t] != EMPTY ? m.has_sr[mt[t]] : (uint8_t)0;
       fm[t] = mt[t] != EMPTY ? m.flag[mt[t]] : (uint16_t)0;
     }
@@ -136,7 +134,7 @@ __global__ __launch_bounds__(256) void k_dup_counters(MxCols m, unsigned long lo
           }
         }
         // owner of a pair that lost its group; a pair with a tagged read is never completed by the pass over the reads (:186-190)
-        loser = rep[t] != EMPTY && pw[t] != i && !srm[t];
+        loser = pw[t] != EMPTY && !srm[t];
       }
       wave_count(lds_ctr, cell1);
       wave_count(lds_ctr, cell2);
@@ -146,7 +144,7 @@ __global__ __launch_bounds__(256) void k_dup_counters(MxCols m, unsigned long lo
         uint32_t at = 0;
         if (lane == leader) at = atomicAdd(&lcount, (uint32_t)__popcll(mask));
         at = __shfl(at, leader, 64);
-        if (loser) lq[at + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = make_uint2(i, rep[t]);
+        if (loser) lq[at + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = make_uint2(i, pw[t]);
       }
     }
     __syncthreads();
@@ -254,10 +252,10 @@ __global__ __launch_bounds__(256) void k_opt_slots(MxCols m, uint32_t L, const u
   mread[slot] = listed_read(m, vs[j]);
   mset[slot] = oslot;  // the set a member belongs to = the slot of its origin
   if (is_head) {
-    const uint32_t rep = (uint32_t)ks[j];
-    mread[oslot] = listed_read(m, m.pwinner[rep]);
+    const uint32_t origin = (uint32_t)ks[j];  // the list is keyed by the owner of the winning pair
+    mread[oslot] = listed_read(m, origin);
     mset[oslot] = oslot;
-    ginfo[oslot] = make_uint2(gstart[g + 1] - j0 + 1, rep);
+    ginfo[oslot] = make_uint2(gstart[g + 1] - j0 + 1, origin);
   }
 }
 // dense pass over the member slots: tile / x / y from the QNAME (every lane busy, unlike a pass over all records)
@@ -341,7 +339,7 @@ __global__ __launch_bounds__(128) void k_opt_eval(MxCols m, uint32_t total, cons
   }
   }
   if (!large && (optical || (hist && cnt >= 2))) {
-    const uint32_t owner = m.pwinner[gi.y];
+    const uint32_t owner = gi.y;
     uint32_t a1, a2;
     order_ends(m, owner, m.mate[owner], a1, a2);
     const uint32_t lib = lib_row(m, a1);  // origin.aln1.LIBID() :381
@@ -426,7 +424,7 @@ __global__ __launch_bounds__(256) void k_large_final(MxCols m, uint32_t total, c
   if (b >= total || !(linfo[b] & 1u) || ginfo[b].x == 0) return;
   const unsigned long long sc = setcnt[b];
   const uint32_t optical = (uint32_t)sc - (uint32_t)(sc >> 32);
-  const uint32_t owner = m.pwinner[ginfo[b].y];
+  const uint32_t owner = ginfo[b].y;
   uint32_t a1, a2;
   order_ends(m, owner, m.mate[owner], a1, a2);
   const uint32_t lib = lib_row(m, a1);
@@ -452,10 +450,10 @@ __global__ __launch_bounds__(256) void k_origin_count(MxCols m, unsigned long lo
   for (int k = threadIdx.x; k <= m.n_lib; k += blockDim.x) lds_org[k] = 0;
   __syncthreads();
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m.n; i += (uint64_t)gridDim.x * blockDim.x) {
-    const uint32_t rep = m.prep[i];
-    if (rep == EMPTY || m.pwinner[rep] != (uint32_t)i) continue;
+    const uint32_t mt = m.mate[i];
+    if (mt == EMPTY || mt > (uint32_t)i || m.pair_win[i] != EMPTY) continue;  // not the owner of a pair, or of a pair that lost
     uint32_t a1, a2;
-    order_ends(m, (uint32_t)i, m.mate[i], a1, a2);
+    order_ends(m, (uint32_t)i, mt, a1, a2);
     atomicAdd(&lds_org[lib_row(m, a1)], 1u);
   }
   __syncthreads();
@@ -481,7 +479,7 @@ static int metrics_impl(elp_ctx *c, int dist, int64_t *counters_host, int64_t *h
   int lds_bins = hist_host ? std::min(hist_len, 32) : 0;
   if ((size_t)(c->n_lib + 1) * (1 + 3 * (size_t)lds_bins) * sizeof(unsigned int) > 32768) lds_bins = 0;
   if (n) {
-    MxCols m{n, c->refid.p, c->flag.p, c->rgid.p, c->rg_lib.p, c->upos.p, c->qname_off.p, c->qname.p, c->mate.p, c->pair_slot.p, c->pair_winner.p, c->n_lib,
+    MxCols m{n, c->refid.p, c->flag.p, c->rgid.p, c->rg_lib.p, c->upos.p, c->qname_off.p, c->qname.p, c->mate.p, c->pair_win.p, c->n_lib,
              c->has_sr.p, c->split.p, n_split};
     const unsigned grid = blocks_for(n, 256);
     // losing pairs: at most one per two records.  Slot 1: keys (u64) x 2 and values (u32) x 2 of the list and its sort buffers

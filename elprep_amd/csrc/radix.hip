@@ -136,8 +136,10 @@ constexpr int RS_WAVES = RS_THREADS / 64;
 
 // one sweep: histograms of all 8 digit positions (decides which passes are live)
 template <int ND>
-__global__ __launch_bounds__(256) void k_radix_hist_all(const uint64_t *__restrict__ keys, uint64_t n, unsigned long long *__restrict__ ghist /* [8][256] */) {
+__global__ __launch_bounds__(256) void k_radix_hist_all(const uint64_t *__restrict__ keys, uint64_t n, unsigned long long *__restrict__ ghist /* [8][256] */,
+                                                        const uint32_t *__restrict__ n_dev) {
   __shared__ uint32_t h[8][256];
+  if (n_dev) n = *n_dev;  // the length is a device-side count (no read-back): `n` was its upper bound
   for (int i = threadIdx.x; i < 8 * 256; i += 256) (&h[0][0])[i] = 0;
   __syncthreads();
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint64_t *__
                                                               uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint64_t n,
                                                               int shift, const unsigned long long *__restrict__ ghist /* [256] of this digit */,
                                                               unsigned long long *state, uint32_t epoch, uint32_t *ticket,
-                                                              uint32_t *err) {
+                                                              uint32_t *err, const uint32_t *__restrict__ n_dev) {
   __shared__ uint32_t cnt[RS_WAVES][256];
   __shared__ uint32_t gbase[256];   // global position of the tile's first key with digit d, minus its position inside the sorted tile
   __shared__ uint32_t scan_lds[8];
@@ -188,6 +190,10 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint64_t *__
   __syncthreads();
   const uint32_t tile = my_tile;
   const uint64_t tbase = (uint64_t)tile * RS_TILE;
+  if (n_dev) {  // device-side length: the launch covers its upper bound, tiles behind the end leave at once (nobody looks back at them)
+    n = *n_dev;
+    if (tbase >= n) return;
+  }
   const uint64_t wbase = tbase + (uint64_t)w * (64 * RS_ITEMS);
   const uint32_t tile_n = (uint32_t)((n - tbase) < (uint64_t)RS_TILE ? (n - tbase) : (uint64_t)RS_TILE);
   uint64_t k[RS_ITEMS];
@@ -333,10 +339,10 @@ static int radix_next_epoch(elp_ctx *c) {
 // first_src (optional): the keys are read from there by the first pass (and `keys` is only written); identity_vals: the values are
 // 0 .. n-1 and `vals` is only written
 int radix_sort_pairs_low(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *keys_tmp, uint32_t *vals_tmp, uint64_t n, int ndigits,
-                         uint64_t **keys_out, uint32_t **vals_out, const uint64_t *first_src, bool identity_vals) {
+                         uint64_t **keys_out, uint32_t **vals_out, const uint64_t *first_src, bool identity_vals, const uint32_t *n_dev) {
   *keys_out = keys;
   *vals_out = vals;
-  if ((n < 2 || ndigits <= 0) && !first_src && !identity_vals) return 0;
+  if ((ndigits <= 0 || (n < 2 && !n_dev)) && !first_src && !identity_vals) return 0;
   if (ndigits <= 0) ndigits = 1;  // a pass is needed to materialise keys / values
   if (n >= 0xFFFFFFFFull || ndigits > 8) return set_error(c, ELP_ERR_UNSUPPORTED, "radix sort: bad size");
   unsigned long long *ghist;
@@ -344,9 +350,9 @@ int radix_sort_pairs_low(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *k
   ELP_HIP(c, hipMemsetAsync(ghist, 0, 8 * 256 * sizeof(unsigned long long), c->stream));
   const unsigned hb = (unsigned)std::min<uint64_t>((n + 255) / 256, 2048);
   // histograms of the digit positions that are sorted, not of all eight
-  if (ndigits <= 2) ELP_LAUNCH(c, "radix_hist_all", k_radix_hist_all<2>, dim3(hb), dim3(256), 0, (const uint64_t *)(first_src ? first_src : keys), n, ghist);
-  else if (ndigits <= 4) ELP_LAUNCH(c, "radix_hist_all", k_radix_hist_all<4>, dim3(hb), dim3(256), 0, (const uint64_t *)(first_src ? first_src : keys), n, ghist);
-  else ELP_LAUNCH(c, "radix_hist_all", k_radix_hist_all<8>, dim3(hb), dim3(256), 0, (const uint64_t *)(first_src ? first_src : keys), n, ghist);
+  if (ndigits <= 2) ELP_LAUNCH(c, "radix_hist_all", k_radix_hist_all<2>, dim3(hb), dim3(256), 0, (const uint64_t *)(first_src ? first_src : keys), n, ghist, n_dev);
+  else if (ndigits <= 4) ELP_LAUNCH(c, "radix_hist_all", k_radix_hist_all<4>, dim3(hb), dim3(256), 0, (const uint64_t *)(first_src ? first_src : keys), n, ghist, n_dev);
+  else ELP_LAUNCH(c, "radix_hist_all", k_radix_hist_all<8>, dim3(hb), dim3(256), 0, (const uint64_t *)(first_src ? first_src : keys), n, ghist, n_dev);
   const uint32_t ntiles = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
   ELP_TRY(radix_pass_setup(c, ntiles));
   uint64_t *ksrc = keys, *kdst = keys_tmp;
@@ -357,7 +363,7 @@ int radix_sort_pairs_low(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *k
     const uint32_t *vin = (d == 0 && identity_vals) ? nullptr : vsrc;
     ELP_LAUNCH(c, "radix_scatter", k_radix_scatter, dim3(ntiles), dim3(RS_THREADS), 0, kin, vin, kdst,
                vdst, n, 8 * d, (const unsigned long long *)(ghist + d * 256), c->radix_state.p, c->radix_epoch, c->radix_ticket.p + d,
-               c->err_flag.p);
+               c->err_flag.p, n_dev);
     std::swap(ksrc, kdst);
     std::swap(vsrc, vdst);
   }
@@ -376,7 +382,7 @@ int radix_sort_pairs(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *keys_
   ELP_TRY(scratch(c, 6, 8 * 256, &ghist));
   ELP_HIP(c, hipMemsetAsync(ghist, 0, 8 * 256 * sizeof(unsigned long long), c->stream));
   unsigned hb = (unsigned)std::min<uint64_t>((n + 255) / 256, 2048);
-  ELP_LAUNCH(c, "radix_hist_all", k_radix_hist_all<8>, dim3(hb), dim3(256), 0, (const uint64_t *)keys, n, ghist);
+  ELP_LAUNCH(c, "radix_hist_all", k_radix_hist_all<8>, dim3(hb), dim3(256), 0, (const uint64_t *)keys, n, ghist, (const uint32_t *)nullptr);
   unsigned long long hh[8 * 256];
   ELP_HIP(c, hipMemcpyAsync(hh, ghist, sizeof hh, hipMemcpyDeviceToHost, c->stream));
   ELP_HIP(c, hipStreamSynchronize(c->stream));  // (a look-back timeout of any pass is reported by the callers, behind their last pass)
@@ -392,7 +398,7 @@ int radix_sort_pairs(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *keys_
     ELP_TRY(radix_next_epoch(c));
     ELP_LAUNCH(c, "radix_scatter", k_radix_scatter, dim3(ntiles), dim3(RS_THREADS), 0, (const uint64_t *)ksrc, (const uint32_t *)vsrc, kdst,
                vdst, n, 8 * d, (const unsigned long long *)(ghist + d * 256), c->radix_state.p, c->radix_epoch, c->radix_ticket.p + d,
-               c->err_flag.p);
+               c->err_flag.p, (const uint32_t *)nullptr);
     std::swap(ksrc, kdst);
     std::swap(vsrc, vdst);
   }

@@ -298,8 +298,8 @@ int ensure_adapted(elp_ctx *c, bool check_quals) {
 int ensure_qual_present(elp_ctx *c, bool exact) {
   if (c->have_qual_present) return 0;
   c->qual_present[0] = c->qual_present[1] = 0;
-  // test hook: with ELP_DEBUG_NO_QUAL_HINT set the hint stays empty, which forces the gather's report-and-retry path
-  if (c->qual_bytes && (exact || !getenv("ELP_DEBUG_NO_QUAL_HINT"))) {
+  // elp_set_tuning "qual_hint" = 1: the hint stays empty, which forces the gather's report-and-retry path (tests)
+  if (c->qual_bytes && (exact || c->tune.qual_hint != 1)) {
     unsigned long long *qm;
     ELP_TRY(scratch(c, 6, 4, &qm));
     ELP_HIP(c, hipMemsetAsync(qm, 0, 16, c->stream));
@@ -311,10 +311,10 @@ int ensure_qual_present(elp_ctx *c, bool exact) {
     ELP_HIP(c, hipMemcpyAsync(c->qual_present, qm, 16, hipMemcpyDeviceToHost, c->stream));
     ELP_HIP(c, hipStreamSynchronize(c->stream));
   }
-  // test hook: ELP_DEBUG_QUAL_HINT_DROP=<q> removes one quality from the hint (exercises the kernels' no-slot paths)
-  if (const char *d = exact ? nullptr : getenv("ELP_DEBUG_QUAL_HINT_DROP")) {
-    const int q = atoi(d);
-    if (q >= 0 && q < 64) c->qual_present[0] &= ~(1ull << q);
+  // elp_set_tuning "qual_hint_drop" = q removes one quality from the hint (tests: the kernels' no-slot paths)
+  if (!exact && c->tune.qual_hint_drop >= 0) {
+    const int q = c->tune.qual_hint_drop;
+    if (q < 64) c->qual_present[0] &= ~(1ull << q);
     else if (q < 128) c->qual_present[1] &= ~(1ull << (q - 64));
   }
   c->have_qual_present = true;

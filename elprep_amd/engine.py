@@ -35,9 +35,10 @@ def _vp(a: Optional[np.ndarray]):
 class Engine:
     """One GPU context holding the staged column store."""
 
-    def __init__(self, header: Header, device: int = 0, flat_abi: bool = False):
+    def __init__(self, header: Header, device: int = 0, flat_abi: bool = False, tuning: Optional[Dict[str, int]] = None):
         """flat_abi: use the entry points that take every array as its own argument (what a cgo binding calls) instead of the
-        struct forms - same library code behind both"""
+        struct forms - same library code behind both.  tuning: elp_set_tuning pairs; the harness also takes them from the environment
+        variable ELP_TUNE="key=value,key=value" (A/B sessions and tests; the library itself reads no environment)"""
         self.L = _lib.hip()
         h = C.c_void_p()
         rc = self.L.elp_create(device, C.byref(h))
@@ -54,6 +55,16 @@ class Engine:
         else:
             hs = header.as_struct()
             self._check(self.L.elp_set_header(self.h, C.byref(hs)))
+        import os
+        for kv in filter(None, os.environ.get("ELP_TUNE", "").split(",")):
+            k, v = kv.split("=")
+            self.set_tuning(k.strip(), int(v))
+        for k, v in (tuning or {}).items():
+            self.set_tuning(k, v)
+
+    def set_tuning(self, key: str, value: int):
+        """elp_set_tuning: pin a kernel choice of this context (include/elprep_hip.h lists the keys)"""
+        self._check(self.L.elp_set_tuning(self.h, key.encode(), int(value)))
 
     def close(self):
         if getattr(self, "h", None) and self.h.value:

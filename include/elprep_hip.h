@@ -286,6 +286,22 @@ int elp_get_qual(elp_ctx *ctx, uint8_t *qual_out /* qual_bytes, staging order an
 int elp_snapshot(elp_ctx *ctx);
 int elp_rollback(elp_ctx *ctx);
 
+/* ---- kernel choices ----
+ * The library picks its kernels from the staged data (read sets of one length, number of distinct qualities, order of the
+ * mates).  Tests and A/B measurements pin a choice per context with elp_set_tuning instead of process-wide environment
+ * variables; value 0 (or -1 where 0 is a value) gives the choice back to the library.  The reference has no counterpart: its
+ * one code path per operator is what every choice here must reproduce bit for bit.
+ *   "count_kernel"     1: general BQSR count kernel even for read sets of one length
+ *   "apply_kernel"     1: general ApplyBQSR kernel
+ *   "count3_rlog"      >= 0: log2 of the context-cell replication of the one-length count kernel (measurements)
+ *   "qual_hint"        1: no sampled quality hint (the gather sizes its tables on the report-and-retry path)
+ *   "qual_hint_drop"   q >= 0: quality q is removed from the sampled hint (the kernels' no-slot paths)
+ *   "pair_table_slots" LDS table slots per pair bucket of elp_mark_duplicates (power of two, 2..1024; default 1024): a small
+ *                      value sends every bucket through the overflow path
+ *   "mate_path"        1: every mate candidate is matched through the partitioned table, no neighbour shortcut
+ * Returns ELP_ERR_ARG for an unknown key or a value out of range. */
+int elp_set_tuning(elp_ctx *ctx, const char *key, int64_t value);
+
 /* ---- measurement ----
  * With profiling on, every kernel launch is bracketed by hipEvents on the ctx stream; elp_profile_get returns, per
  * kernel name, the launch count and the summed duration in milliseconds. */

@@ -214,14 +214,14 @@ def test_many_contigs():
 def test_quality_hint_retry(monkeypatch):
     """With an empty sampling hint the count kernel must report the qualities it met and the host must retry: same tables."""
     b, h, refs, sites = _random_case(5, 3000, quals=[2, 6, 13, 27, 38, 64, 93])
-    monkeypatch.setenv("ELP_DEBUG_NO_QUAL_HINT", "1")
+    monkeypatch.setenv("ELP_TUNE", "qual_hint=1")
     _check_gather_apply(b, h, refs, sites)
 
 
 def test_quality_hint_incomplete(monkeypatch):
     """One quality missing from the hint: the gather retries, the LDS-LUT apply kernel takes its dense-LUT fix-up path."""
     b, h, refs, sites = _random_case(6, 3000, quals=[2, 6, 13, 27, 38])
-    monkeypatch.setenv("ELP_DEBUG_QUAL_HINT_DROP", "27")
+    monkeypatch.setenv("ELP_TUNE", "qual_hint_drop=27")
     _check_gather_apply(b, h, refs, sites)
 
 

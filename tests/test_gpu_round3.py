@@ -181,13 +181,13 @@ def test_one_length_quality_hint_incomplete(monkeypatch, drop):
     """a quality missing from the sampled hint - the smallest one >= 6, a middle one, the largest one: the gather retries with the
     exact set; apply3's level 1 is resident from quality 6 whatever the hint says, qualities above its range take the fix-up loop"""
     b, h, refs, sites = _uniform_case(13, 4000, 120, quals=[2, 6, 13, 27, 38])
-    monkeypatch.setenv("ELP_DEBUG_QUAL_HINT_DROP", drop)
+    monkeypatch.setenv("ELP_TUNE", "qual_hint_drop=" + drop)
     _check_gather_apply(b, h, refs, sites)
 
 
 def test_one_length_empty_quality_hint(monkeypatch):
     b, h, refs, sites = _uniform_case(14, 3000, 101, quals=[2, 6, 13, 27, 38, 64, 93])
-    monkeypatch.setenv("ELP_DEBUG_NO_QUAL_HINT", "1")
+    monkeypatch.setenv("ELP_TUNE", "qual_hint=1")
     _check_gather_apply(b, h, refs, sites)
 
 
@@ -196,9 +196,7 @@ def test_general_kernels_and_one_length_kernels_agree(monkeypatch):
     cfg, b, h, refs, sites = dataset("tiny", 30000, 3, 0.02)
     out = []
     for force in ("1", "0"):
-        monkeypatch.setenv("ELP_COUNT_KERNEL", force)
-        monkeypatch.setenv("ELP_APPLY_KERNEL", force)
-        e = Engine(h)
+        e = Engine(h, tuning={"count_kernel": int(force), "apply_kernel": int(force)})
         e.stage(b)
         e.mark_duplicates(True)
         for r in range(h.n_ref):

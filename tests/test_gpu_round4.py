@@ -1,0 +1,98 @@
+"""GPU parity tests (-m gpu) added in round 4: the pair phase of mark duplicates as a hash partition + one LDS table per bucket
+(elprep_amd/csrc/markdup.hip: k_pair_list, k_pair_bounds, k_pair_bucket) on its three paths - table, entries beyond the remembered
+slots, table overflow (groups peeled off one by one) - against the oracle's restatement of filters/mark-duplicates.go:329-396."""
+import numpy as np
+import pytest
+
+import oracle as orc
+from elprep_amd.batch import Header
+from elprep_amd.engine import Engine
+from tests.common import dataset
+from tests.test_gpu_round2 import _pileup
+
+pytestmark = pytest.mark.gpu
+
+
+def _flags_and_metrics(b, h, tuning=None):
+    e = Engine(h, tuning=tuning)
+    e.stage(b)
+    flags = e.mark_duplicates(True)
+    ctr, hist = e.dup_metrics(100, hist_len=16)
+    e.close()
+    return flags, ctr, hist
+
+
+@pytest.mark.parametrize("slots", [2, 16, 1024])
+def test_pair_buckets_table_sizes_and_overflow_path(slots):
+    """the same reads with LDS tables of 1024 slots (the default), 16 slots (most buckets overflow) and 2 slots (every bucket with more
+    than two keys takes the peeling path): flags, counters and set-size histograms are the oracle's every time"""
+    cfg, b, h, refs, sites = dataset("tiny", 30000, 5, 0.03)
+    oflags, octr, ohist = orc.dup_metrics(b, h, None, 100, hist_len=16)
+    flags, ctr, hist = _flags_and_metrics(b, h, {"pair_table_slots": slots})
+    assert np.array_equal(flags, oflags)
+    assert np.array_equal(ctr, octr) and np.array_equal(hist, ohist)
+    assert int(((flags & 0x400) != 0).sum()) > 1000
+
+
+@pytest.mark.parametrize("slots", [2, 1024])
+def test_pair_tournament_on_score_ties(slots):
+    """5 500 pairs on ONE pair key, all with the same score sum: the QNAME decides (filters/mark-duplicates.go:383-389); the bucket is
+    larger than the remembered slots, so the later phases look their table slot up again"""
+    rng = np.random.default_rng(11)
+    b = _pileup(3000, 2500, rng)
+    b.qual[:] = 30  # no best pair by score
+    h = Header(ref_len=np.array([5000], np.int32), rg_lib=np.array([0, 0], np.uint16), rg_cov=np.array([0, 1], np.uint16))
+    oflags, octr, ohist = orc.dup_metrics(b, h, None, 100, hist_len=16)
+    flags, ctr, hist = _flags_and_metrics(b, h, {"pair_table_slots": slots})
+    assert np.array_equal(flags, oflags)
+    assert int(((flags & 0x400) == 0).sum()) == 2
+    assert np.array_equal(ctr, octr) and np.array_equal(hist, ohist)
+
+
+def test_pairs_of_several_libraries_and_splits_share_positions():
+    """pairs at the same two ends but in different libraries / split files are different keys (the key carries LIBID of the first end and
+    the split id): the pileup's read groups are given two libraries, half of the records a second split id"""
+    rng = np.random.default_rng(12)
+    b = _pileup(600, 500, rng)
+    b.split = np.zeros(b.n, np.uint16)
+    b.split[(np.arange(b.n) // 2) % 2 == 1] = 1  # both mates of a pair share the split
+    h = Header(ref_len=np.array([5000], np.int32), rg_lib=np.array([0, 1], np.uint16), rg_cov=np.array([0, 1], np.uint16))
+    e = Engine(h)
+    e.stage(b)
+    flags = e.mark_duplicates(True)
+    e.close()
+    # the oracle runs split file by split file
+    want = np.zeros(b.n, np.uint16)
+    for sp in (0, 1):
+        idx = np.nonzero(b.split == sp)[0]
+        sub = b.take(idx)
+        sub.split[:] = 0
+        want[idx] = orc.mark_duplicates(sub, h)
+    assert np.array_equal(flags, want)
+    assert int(((flags & 0x400) == 0).sum()) == 2 * 4  # one surviving pair per (library, split)
+
+
+def test_set_tuning_rejects_unknown_keys_and_bad_values():
+    from elprep_amd.engine import ElpError
+    h = Header(ref_len=np.array([5000], np.int32), rg_lib=np.array([0], np.uint16), rg_cov=np.array([0], np.uint16))
+    e = Engine(h)
+    with pytest.raises(ElpError, match="unknown key"):
+        e.set_tuning("no_such_key", 1)
+    with pytest.raises(ElpError, match="power of two"):
+        e.set_tuning("pair_table_slots", 3)
+    e.set_tuning("pair_table_slots", 64)
+    e.close()
+
+
+@pytest.mark.parametrize("n_q", [23, 24])
+def test_one_length_quality_hint_incomplete_at_the_lds_boundary(monkeypatch, n_q):
+    """150-base reads, 4 covariates: the one-length count kernel holds 104 LDS rows = 4 x (23 qualities + 3).  A hint that misses one of
+    23 qualities is retried on the same kernel with the last row count that fits; a hint that misses one of 24 fitted, the exact set does
+    not: the gather runs the prologues again and the general count kernel (round 3 returned ELP_ERR_UNSUPPORTED there; the reference
+    just runs, filters/bqsr.go:467-551)"""
+    from tests.test_gpu_round3 import _check_gather_apply, _uniform_case
+    quals = [2] + list(range(6, 6 + n_q))
+    b, h, refs, sites = _uniform_case(21, 6000, 150, quals=quals, n_cov=4)
+    assert h.n_cov == 4 and len(set(b.qual[b.qual >= 6].tolist())) == n_q
+    monkeypatch.setenv("ELP_TUNE", "qual_hint_drop=17")
+    _check_gather_apply(b, h, refs, sites)
