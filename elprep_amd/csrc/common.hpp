@@ -192,6 +192,7 @@ struct elp_ctx {
 
   // profiling
   bool profiling = false;
+  const char *prof_prefix = nullptr;  // prepended to the names of the launches made while it is set (ProfScope)
   std::vector<std::string> prof_names;
   std::map<std::string, int> prof_index;
   std::vector<uint64_t> prof_launches;
@@ -205,6 +206,12 @@ int set_error(elp_ctx *c, int code, const char *fmt, ...);
 int prof_begin(elp_ctx *c, const char *name);  // returns pending index or -1
 void prof_end(elp_ctx *c, int pending);
 int prof_flush(elp_ctx *c);
+struct ProfScope {  // launches inside the scope are booked as <prefix><name>
+  elp_ctx *c;
+  const char *saved;
+  ProfScope(elp_ctx *ctx, const char *prefix) : c(ctx), saved(ctx->prof_prefix) { ctx->prof_prefix = prefix; }
+  ~ProfScope() { c->prof_prefix = saved; }
+};
 
 #define ELP_HIP(ctx, call)                                                                             \
   do {                                                                                                 \

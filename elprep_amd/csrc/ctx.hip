@@ -14,7 +14,9 @@ int set_error(elp_ctx *c, int code, const char *fmt, ...) {
   return code;
 }
 
-int prof_begin(elp_ctx *c, const char *name) {
+int prof_begin(elp_ctx *c, const char *name0) {
+  // the shared radix / scan launches are booked under the stage that called them ("md_radix_scatter", "mx_radix_scatter")
+  const std::string name = c->prof_prefix ? std::string(c->prof_prefix) + name0 : std::string(name0);
   auto it = c->prof_index.find(name);
   int id;
   if (it == c->prof_index.end()) {

@@ -147,23 +147,6 @@ __global__ __launch_bounds__(256) void k_frag_bits(const uint32_t *__restrict__ 
   }
   bits[w] = b;
 }
-__global__ __launch_bounds__(256) void k_frag_probe_pairs(MdCols m, const uint4 *__restrict__ fkey, const uint32_t *__restrict__ table,
-                                                          const uint32_t *__restrict__ bits, uint64_t mask, unsigned long long *fbest) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m.n) return;
-  const uint16_t f = m.flag_in[i];
-  if (!is_candidate(f) || !is_true_pair(f)) return;
-  const uint4 mine = fkey[i];
-  for (uint64_t s = frag_hash(mine) & mask;; s = (s + 1) & mask) {
-    if (!((bits[s >> 5] >> (s & 31)) & 1u)) return;
-    const uint32_t cur = table[s];
-    if (key_eq(fkey[cur], mine)) {
-      atomicMax(&fbest[cur], 1ull << 63);
-      return;
-    }
-  }
-}
-
 // (QNAME asc, later arrival wins) tournament among contenders
 __device__ __forceinline__ void tournament(const MdCols &m, uint32_t *winner, uint32_t me) {
   uint32_t w = ld_agent(winner);
@@ -229,7 +212,7 @@ __device__ __forceinline__ bool is_mate_candidate(uint16_t f) { return is_candid
 //      sorts them by (representative, staging index) and pairs them up 0-1, 2-3, ... within every group (k_big_collect, k_big_pair).
 // k_mate_scan: code[i] = 0 not a mate candidate, 1 table path, 2 leader / 3 follower of a neighbour pair; hash32 of the leader = the
 // high half of its key hash (the bits the table index does not use).
-enum : uint8_t { MC_NONE = 0, MC_TABLE = 1, MC_LEAD = 2, MC_FOLLOW = 3 };
+enum : uint8_t { MC_NONE = 0, MC_TABLE = 1, MC_LEAD = 2, MC_FOLLOW = 3, MC_KIND = 3, MC_TABBED = 4 /* k_mate_pairs: went through the mate table */ };
 constexpr uint32_t MATE_BIG = 0xFFFFFFFEu;
 
 // The kernel is bound by memory latency (a wave waits for ~40 dependent loads otherwise), so every load of a record and its
@@ -254,7 +237,10 @@ __global__ __launch_bounds__(MS_THREADS) void k_mate_scan(MdCols m, uint8_t *__r
   const uint16_t lia = ra == ELP_NIL16 ? (uint16_t)ELP_NIL16 : m.rg_lib[ra], lib_b = rb == ELP_NIL16 ? (uint16_t)ELP_NIL16 : m.rg_lib[rb];
   const uint8_t *pa = m.qname + oa, *pb = m.qname + ob;
   const uint64_t a0 = load8(pa), a1 = load8(pa + 8), a2 = load8(pa + 16), a3 = load8(pa + 24);
-  const uint64_t b0 = load8(pb), b1 = load8(pb + 8), b2 = load8(pb + 16), b3 = load8(pb + 24);
+  // the neighbour's name is what the next lane loaded as its own: only the last lane of a wave (and the border threads) load it
+  // themselves - the names are the bulk of this kernel's traffic, and every one used to be fetched twice
+  uint64_t b0 = __shfl_down(a0, 1, 64), b1 = __shfl_down(a1, 1, 64), b2 = __shfl_down(a2, 1, 64), b3 = __shfl_down(a3, 1, 64);
+  if ((t & 63u) == 63u || t >= 256u) { b0 = load8(pb); b1 = load8(pb + 8); b2 = load8(pb + 16); b3 = load8(pb + 24); }
   // first 32 bytes of a's name, zero behind its end (the hash takes them as they are)
   const uint64_t w0 = la > 0 ? low_bytes(a0, la) : 0ull, w1 = la > 8 ? low_bytes(a1, la - 8) : 0ull, w2 = la > 16 ? low_bytes(a2, la - 16) : 0ull,
                  w3 = la > 24 ? low_bytes(a3, la - 24) : 0ull;
@@ -308,30 +294,94 @@ __global__ __launch_bounds__(MS_THREADS) void k_mate_scan(MdCols m, uint8_t *__r
   if (t == 0 && s_ntab) atomicAdd(n_table, s_ntab);
 }
 
-// mate[] and rep[] must be EMPTY-initialised.  rep[i] = representative of i's key for records that went through the table and are
-// not the representative themselves; rep[representative] = MATE_BIG iff its key has more than two records.
-__global__ __launch_bounds__(256) void k_mate_insert(MdCols m, const uint8_t *__restrict__ code, const uint32_t *__restrict__ hash32,
-                                                     const uint32_t *__restrict__ bloom, uint32_t bloom_mask, uint32_t *table, uint64_t mask,
-                                                     uint32_t *mate, uint32_t *rep_of, uint32_t *err) {
-  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= m.n) return;
-  const uint8_t cd = code[i];
-  if (cd == MC_NONE) return;
-  if (cd != MC_TABLE) {
-    const uint32_t hi = hash32[cd == MC_LEAD ? i : i - 1];
-    if (!((bloom[(hi >> 5) & bloom_mask] >> (hi & 31u)) & 1u)) {  // nobody else announced this key: the two neighbours are the pair
-      mate[i] = cd == MC_LEAD ? (uint32_t)i + 1 : (uint32_t)i - 1;
-      return;
+// k_mate_pairs - ONE pass over the records behind k_mate_scan does what three passes did (md_mate_insert, md_frag_probe,
+// md_pair_list):
+//  * every true pair looks its own fragment key up in the (final, small) table of the true fragments - plain loads behind the
+//    L2-resident occupancy bits - and sets the pair bit of the group it finds (classifyFragment :210-251: a fragment group that
+//    holds a read of a true pair loses as a whole);
+//  * mates: a neighbour pair nobody else announced is a pair at once; the other mate candidates go through the table (paths 2 and 3
+//    above) and are marked in the code column (MC_TABBED);
+//  * the follower of a neighbour pair is the pair's owner (the later arrival, :336-340) and has both keys and both scores at hand: it
+//    writes the pair's entry {score sum | hash bits, owner} for the pair phase.  Pairs that form in the table are entered by
+//    k_pair_list_table afterwards.
+// mate[] and rep_of[] must be EMPTY-initialised.  rep_of[i] = representative of i's key for records that went through the table and
+// are not the representative themselves; rep_of[representative] = MATE_BIG iff its key has more than two records.
+__device__ __forceinline__ uint64_t pair_entry(const MdCols &m, const uint4 &later, const uint4 &earlier, uint32_t i, uint32_t mt);
+constexpr int MP_TILES = 16, MP_OWN = 129;  // owners per tile: a follower sits behind its leader, so at most every other record + 1
+__global__ __launch_bounds__(256) void k_mate_pairs(MdCols m, const uint4 *__restrict__ fkey, uint8_t *__restrict__ code,
+                                                    const uint32_t *__restrict__ hash32, const uint32_t *__restrict__ bloom, uint32_t bloom_mask,
+                                                    uint32_t *table, uint64_t mask, uint32_t *mate, uint32_t *rep_of, uint32_t *err,
+                                                    const uint32_t *__restrict__ ftable, const uint32_t *__restrict__ fbits, uint64_t fmask /* 0: no fragments */,
+                                                    unsigned long long *fbest, uint64_t *__restrict__ pk, uint32_t *__restrict__ pv, uint32_t *np) {
+  __shared__ uint64_t lk[MP_TILES * MP_OWN];
+  __shared__ uint32_t lv[MP_TILES * MP_OWN];
+  __shared__ uint32_t lcount, gbase;
+  if (threadIdx.x == 0) lcount = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll 2
+  for (int tile = 0; tile < MP_TILES; tile++) {
+    const uint64_t i = ((uint64_t)blockIdx.x * MP_TILES + (uint64_t)tile) * 256 + threadIdx.x;
+    const uint8_t cd = i < m.n ? (uint8_t)(code[i] & MC_KIND) : (uint8_t)MC_NONE;
+    bool own = false;
+    uint64_t key = 0;
+    if (cd != MC_NONE) {  // a candidate that is a true pair
+      const uint4 mine = fkey[i];
+      uint32_t hi = 0;
+      if (cd != MC_TABLE) hi = hash32[cd == MC_LEAD ? i : i - 1];
+      if (fmask) {
+        for (uint64_t s = frag_hash(mine) & fmask;; s = (s + 1) & fmask) {
+          if (!((fbits[s >> 5] >> (s & 31)) & 1u)) break;
+          const uint32_t cur = ftable[s];
+          if (key_eq(fkey[cur], mine)) {
+            atomicMax(&fbest[cur], 1ull << 63);
+            break;
+          }
+        }
+      }
+      const bool tab = cd == MC_TABLE || ((bloom[(hi >> 5) & bloom_mask] >> (hi & 31u)) & 1u);
+      if (!tab) {  // nobody else announced this key: the two neighbours are the pair
+        mate[i] = cd == MC_LEAD ? (uint32_t)i + 1 : (uint32_t)i - 1;
+        if (cd == MC_FOLLOW) {
+          own = true;
+          key = pair_entry(m, mine, fkey[i - 1], (uint32_t)i, (uint32_t)i - 1);
+        }
+      } else {
+        code[i] = (uint8_t)(cd | MC_TABBED);
+        const uint32_t rep = find_or_insert(table, mask, qname_hash(m, (uint32_t)i), (uint32_t)i, [&](uint32_t a, uint32_t b) { return mate_key_eq(m, a, b); }, mask);
+        if (rep == EMPTY) atomicOr(&err[1], 2u);  // the estimated table is full: the host repeats the pass with the full-size one
+        else if (rep != (uint32_t)i) {            // (the first of its key at the slot waits for the second)
+          rep_of[i] = rep;
+          const uint32_t old = atomicCAS(&mate[rep], EMPTY, (uint32_t)i);
+          if (old == EMPTY) mate[i] = rep;
+          else {
+            rep_of[rep] = MATE_BIG;  // more than two records share {split, library, QNAME}
+            atomicOr(&err[1], 1u);
+          }
+        }
+      }
+    }
+    const unsigned long long om = __ballot(own);
+    if (om) {
+      const int leader = __ffsll((long long)om) - 1;
+      uint32_t at = 0;
+      if (lane == leader) at = atomicAdd(&lcount, (uint32_t)__popcll(om));
+      at = __shfl(at, leader, 64);
+      if (own) {
+        at += (uint32_t)__popcll(om & lt_mask);
+        lk[at] = key;
+        lv[at] = (uint32_t)i;
+      }
     }
   }
-  const uint32_t rep = find_or_insert(table, mask, qname_hash(m, (uint32_t)i), (uint32_t)i, [&](uint32_t a, uint32_t b) { return mate_key_eq(m, a, b); }, mask);
-  if (rep == EMPTY) { atomicOr(&err[1], 2u); return; }  // the estimated table is full: the host repeats the pass with the full-size one
-  if (rep == (uint32_t)i) return;  // first of its key at the slot
-  rep_of[i] = rep;
-  const uint32_t old = atomicCAS(&mate[rep], EMPTY, (uint32_t)i);
-  if (old == EMPTY) { mate[i] = rep; return; }
-  rep_of[rep] = MATE_BIG;  // more than two records share {split, library, QNAME}
-  atomicOr(&err[1], 1u);
+  __syncthreads();
+  if (threadIdx.x == 0) gbase = lcount ? atomicAdd(np, lcount) : 0u;
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < lcount; k += 256) {
+    pk[gbase + k] = lk[k];
+    pv[gbase + k] = lv[k];
+  }
 }
 
 // members of big groups -> list of (representative << 32 | record); their mate entries are reset
@@ -397,9 +447,15 @@ __device__ __forceinline__ uint64_t pair_hash(const PairKey &k) {
 //                  flags of both reads of every losing pair - insert, tie and flag of :329-396 in one kernel.
 // pair_win[owner] = the owner of the winning pair of its key, for the owners of LOSING pairs only (EMPTY everywhere else): all the
 // metrics pass needs (metrics.hip).
+__device__ __forceinline__ uint64_t pair_entry(const MdCols &m, const uint4 &later, const uint4 &earlier, uint32_t i, uint32_t mt) {
+  return ((uint64_t)(uint32_t)(m.score[i] + m.score[mt]) << 32) | (uint32_t)pair_hash(pair_key(later, earlier));
+}
+// the pairs that formed in the mate table (or in the big groups' arrival-order pairing): their owners carry MC_TABBED in the code
+// column (one byte per record to scan; in aligner order next to none of them is marked)
 constexpr int PL_TILES = 8;
-__global__ __launch_bounds__(256) void k_pair_list(MdCols m, const uint4 *__restrict__ fkey, const uint32_t *__restrict__ mate,
-                                                   uint64_t *__restrict__ pk, uint32_t *__restrict__ pv, uint32_t *np) {
+__global__ __launch_bounds__(256) void k_pair_list_table(MdCols m, const uint4 *__restrict__ fkey, const uint32_t *__restrict__ mate,
+                                                         const uint8_t *__restrict__ code, uint64_t *__restrict__ pk, uint32_t *__restrict__ pv,
+                                                         uint32_t *np) {
   __shared__ uint64_t lk[PL_TILES * 256];
   __shared__ uint32_t lv[PL_TILES * 256];
   __shared__ uint32_t lcount, gbase;
@@ -407,14 +463,12 @@ __global__ __launch_bounds__(256) void k_pair_list(MdCols m, const uint4 *__rest
   __syncthreads();
 #pragma unroll 2
   for (int tile = 0; tile < PL_TILES; tile++) {
-    const uint64_t i = ((uint64_t)blockIdx.x * PL_TILES + (uint64_t)tile) * 256 + threadIdx.x;
-    const uint32_t mt = i < m.n ? mate[i] : EMPTY;
-    const bool own = mt != EMPTY && mt < (uint32_t)i;  // the later-arriving mate owns the pair (:336-340)
+    const uint64_t i64 = ((uint64_t)blockIdx.x * PL_TILES + (uint64_t)tile) * 256 + threadIdx.x;
+    const uint32_t i = (uint32_t)i64;
+    const uint32_t mt = (i64 < m.n && (code[i64] & MC_TABBED)) ? mate[i] : EMPTY;
+    const bool own = mt != EMPTY && mt < i;  // the later-arriving mate owns the pair (:336-340)
     uint64_t key = 0;
-    if (own) {
-      const PairKey mine = pair_key(fkey[i], fkey[mt]);
-      key = ((uint64_t)(uint32_t)(m.score[i] + m.score[mt]) << 32) | (uint32_t)pair_hash(mine);
-    }
+    if (own) key = pair_entry(m, fkey[i], fkey[mt], i, mt);
     const unsigned long long mask = __ballot(own);
     if (mask) {
       const int lane = threadIdx.x & 63, leader = __ffsll((long long)mask) - 1;
@@ -424,7 +478,7 @@ __global__ __launch_bounds__(256) void k_pair_list(MdCols m, const uint4 *__rest
       if (own) {
         at += (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
         lk[at] = key;
-        lv[at] = (uint32_t)i;
+        lv[at] = i;
       }
     }
   }
@@ -622,105 +676,110 @@ static int markdup_impl(elp_ctx *c) {
   ELP_LAUNCH(c, "md_keys", k_md_keys, dim3(blocks_for(n, 256 * MK_TILES)), dim3(256), 0, m, fkey, flist, nf_dev);
   uint32_t nf = 0;  // read together with the mate phase's table estimate below
 
-  // ---- mates
-  {
-    uint64_t bw = 1024;  // Bloom filter words: ~2 bits per record, at most 4 MiB (what one XCD's L2 holds)
-    while (bw < n / 16 && bw < (1u << 20)) bw <<= 1;
-    uint32_t *bloom, *hash32;
-    uint8_t *code;
-    ELP_TRY(scratch(c, 6, bw + n + 16 + (n + 16) / 4, &bloom));
-    hash32 = bloom + bw;
-    code = reinterpret_cast<uint8_t *>(hash32 + n + 8);
-    uint32_t *rep_of = c->pair_win.p;  // free until the pair phase fills it
-    uint32_t *n_table_dev = c->err_flag.p + 3;  // the scan-total mailbox
-    ELP_HIP(c, hipMemsetAsync(bloom, 0, bw * sizeof(uint32_t), st));
-    ELP_HIP(c, hipMemsetAsync(n_table_dev, 0, 4, st));
-    ELP_HIP(c, hipMemsetAsync(c->mate.p, 0xFF, n * sizeof(uint32_t), st));
-    ELP_HIP(c, hipMemsetAsync(rep_of, 0xFF, n * sizeof(uint32_t), st));
-    ELP_LAUNCH(c, "md_mate_scan", k_mate_scan, dim3(grid), dim3(MS_THREADS), 0, m, code, hash32, bloom, (uint32_t)(bw - 1), n_table_dev);
-    // the table only has to hold the records that are not exactly-two-neighbours (few in aligner order) plus the neighbour pairs a
-    // Bloom-filter hit sends there (at most as many again, in practice a fraction): size it by their number, not by n
-    uint32_t n_tab = 0;
-    ELP_HIP(c, hipMemcpyAsync(&n_tab, n_table_dev, 4, hipMemcpyDeviceToHost, st));
-    ELP_HIP(c, hipMemcpyAsync(&nf, nf_dev, 4, hipMemcpyDeviceToHost, st));
-    ELP_HIP(c, hipStreamSynchronize(st));
-    ELP_HIP(c, hipMemsetAsync(n_table_dev, 0, 4, st));
-    uint64_t Tm = std::min<uint64_t>(T, table_size_for(std::min<uint64_t>(n, 4ull * n_tab + 1024)));
-    uint32_t e[4];
-    for (;;) {
-      ELP_HIP(c, hipMemsetAsync(table, 0xFF, Tm * sizeof(uint32_t), st));
-      ELP_LAUNCH(c, "md_mate_insert", k_mate_insert, dim3(grid), dim3(256), 0, m, (const uint8_t *)code, (const uint32_t *)hash32,
-                 (const uint32_t *)bloom, (uint32_t)(bw - 1), table, Tm - 1, c->mate.p, rep_of, c->err_flag.p);
-      ELP_TRY(fetch_err(c, e));
-      if (!(e[1] & 2u)) break;
-      if (Tm == T) return set_error(c, ELP_ERR_HIP, "mark duplicates: mate table overflow");
-      // more Bloom-filter hits than estimated: once more with the full-size table
-      Tm = T;
-      ELP_HIP(c, hipMemsetAsync(c->err_flag.p + 1, 0, 4, st));
-      ELP_HIP(c, hipMemsetAsync(c->mate.p, 0xFF, n * sizeof(uint32_t), st));
-      ELP_HIP(c, hipMemsetAsync(rep_of, 0xFF, n * sizeof(uint32_t), st));
-    }
-    if (e[1]) {
-      // keys with more than two records: pair their members up in arrival order
-      ELP_HIP(c, hipMemsetAsync(c->err_flag.p + 1, 0, 4, st));
-      uint64_t *bk;
-      uint32_t *bv, *cnt_dev = c->err_flag.p + 3;  // the scan-total mailbox doubles as the list counter
-      ELP_TRY(scratch(c, 2, 2 * n + 8, &bk));  // `best` is free between the fragment and the pair phase
-      ELP_TRY(scratch(c, 3, 2 * n + 8, &bv));  // so is `winner`
-      ELP_HIP(c, hipMemsetAsync(cnt_dev, 0, 4, st));
-      ELP_LAUNCH(c, "md_big_collect", k_big_collect, dim3(grid), dim3(256), 0, n, (const uint32_t *)rep_of, c->mate.p, bk, bv, cnt_dev);
-      uint32_t cnt = 0;
-      ELP_HIP(c, hipMemcpyAsync(&cnt, cnt_dev, 4, hipMemcpyDeviceToHost, st));
-      ELP_HIP(c, hipStreamSynchronize(st));
-      ELP_HIP(c, hipMemsetAsync(cnt_dev, 0, 4, st));
-      uint64_t *ks;
-      uint32_t *vs;
-      ELP_TRY(radix_sort_pairs(c, bk, bv, bk + n, bv + n, cnt, &ks, &vs));
-      ELP_LAUNCH(c, "md_big_pair", k_big_pair, dim3(blocks_for(cnt, 256)), dim3(256), 0, cnt, (const uint64_t *)ks, c->mate.p);
-      // the scratch the pair phase uses was re-pointed above: take the (possibly grown) arrays again
-      ELP_TRY(scratch(c, 2, n + 8, &best));
-      ELP_TRY(scratch(c, 3, n + 8, &winner));
-    }
+  // the pair phase's list, partitioned by hash bits: at most n / 2 pairs
+  const uint64_t npmax = n / 2 + 1;
+  int bbits = 0;
+  while (bbits < 24 && (npmax >> bbits) > 384) bbits++;
+  const int ndig = (bbits + 7) / 8, sbits = 8 * ndig;
+  const size_t nb = (size_t)1 << bbits;
+  uint32_t *np_dev = c->md_ctr.p + 1;
+
+  // ---- mates (+ the pairs' fragment look-ups and the entries of the neighbour pairs, k_mate_pairs)
+  uint64_t bw = 1024;  // Bloom filter words: ~2 bits per record, at most 4 MiB (what one XCD's L2 holds)
+  while (bw < n / 16 && bw < (1u << 20)) bw <<= 1;
+  uint32_t *bloom, *hash32;
+  uint8_t *code;
+  ELP_TRY(scratch(c, 6, bw + n + 16 + (n + 16) / 4, &bloom));
+  hash32 = bloom + bw;
+  code = reinterpret_cast<uint8_t *>(hash32 + n + 8);
+  uint32_t *rep_of = c->pair_win.p;  // free until the pair phase fills it
+  uint32_t *n_table_dev = c->err_flag.p + 3;  // the scan-total mailbox
+  ELP_HIP(c, hipMemsetAsync(bloom, 0, bw * sizeof(uint32_t), st));
+  ELP_HIP(c, hipMemsetAsync(n_table_dev, 0, 4, st));
+  ELP_HIP(c, hipMemsetAsync(c->mate.p, 0xFF, n * sizeof(uint32_t), st));
+  ELP_HIP(c, hipMemsetAsync(rep_of, 0xFF, n * sizeof(uint32_t), st));
+  ELP_LAUNCH(c, "md_mate_scan", k_mate_scan, dim3(grid), dim3(MS_THREADS), 0, m, code, hash32, bloom, (uint32_t)(bw - 1), n_table_dev);
+  // the table only has to hold the records that are not exactly-two-neighbours (few in aligner order) plus the neighbour pairs a
+  // Bloom-filter hit sends there (at most as many again, in practice a fraction): size it by their number, not by n
+  uint32_t n_tab = 0;
+  ELP_HIP(c, hipMemcpyAsync(&n_tab, n_table_dev, 4, hipMemcpyDeviceToHost, st));
+  ELP_HIP(c, hipMemcpyAsync(&nf, nf_dev, 4, hipMemcpyDeviceToHost, st));
+  ELP_HIP(c, hipStreamSynchronize(st));
+  ELP_HIP(c, hipMemsetAsync(n_table_dev, 0, 4, st));
+
+  // pair list (two buffers each for the radix passes) | fragment table and its occupancy bits
+  const uint64_t Tf = nf ? std::min<uint64_t>(T, table_size_for(4ull * nf)) : 0;  // sparse: most look-ups of the pairs end at an empty slot
+  uint64_t *pk;
+  ELP_TRY(scratch(c, 7, 2 * npmax + (2 * npmax + Tf + Tf / 32 + 64) / 2 + 8, &pk));
+  uint32_t *pv = reinterpret_cast<uint32_t *>(pk + 2 * npmax), *ftable = pv + 2 * npmax, *fbits = ftable + Tf;
+
+  // fragments: group the true fragments (their table is final before the pairs look their keys up)
+  const unsigned fgrid = blocks_for(nf, 256);
+  if (nf) {
+    ELP_HIP(c, hipMemsetAsync(ftable, 0xFF, Tf * sizeof(uint32_t), st));
+    ELP_LAUNCH(c, "md_frag_init", k_frag_init, dim3(fgrid), dim3(256), 0, (const uint32_t *)flist, nf, best, winner);
+    ELP_LAUNCH(c, "md_frag_insert", k_frag_insert, dim3(fgrid), dim3(256), 0, m, (const uint4 *)fkey, (const uint32_t *)flist, nf, ftable, Tf - 1, rep, best);
+    ELP_LAUNCH(c, "md_frag_bits", k_frag_bits, dim3(blocks_for(Tf / 32, 256)), dim3(256), 0, (const uint32_t *)ftable, Tf / 32, fbits);
   }
 
-  // ---- fragments: group the true fragments, let the true pairs look their keys up, tournament among the fragments of pair-free groups
+  uint64_t Tm = std::min<uint64_t>(T, table_size_for(std::min<uint64_t>(n, 4ull * n_tab + 1024)));
+  uint32_t e[4];
+  for (;;) {
+    ELP_HIP(c, hipMemsetAsync(table, 0xFF, Tm * sizeof(uint32_t), st));
+    ELP_HIP(c, hipMemsetAsync(np_dev, 0, 4, st));
+    ELP_LAUNCH(c, "md_mate_pairs", k_mate_pairs, dim3(blocks_for(n, 256 * MP_TILES)), dim3(256), 0, m, (const uint4 *)fkey, code,
+               (const uint32_t *)hash32, (const uint32_t *)bloom, (uint32_t)(bw - 1), table, Tm - 1, c->mate.p, rep_of, c->err_flag.p,
+               (const uint32_t *)ftable, (const uint32_t *)fbits, nf ? Tf - 1 : (uint64_t)0, best, pk, pv, np_dev);
+    ELP_TRY(fetch_err(c, e));
+    if (!(e[1] & 2u)) break;
+    if (Tm == T) return set_error(c, ELP_ERR_HIP, "mark duplicates: mate table overflow");
+    // more Bloom-filter hits than estimated: once more with the full-size table (the look-ups and entries are simply made again)
+    Tm = T;
+    ELP_HIP(c, hipMemsetAsync(c->err_flag.p + 1, 0, 4, st));
+    ELP_HIP(c, hipMemsetAsync(c->mate.p, 0xFF, n * sizeof(uint32_t), st));
+    ELP_HIP(c, hipMemsetAsync(rep_of, 0xFF, n * sizeof(uint32_t), st));
+  }
+  // tournament among the fragments of pair-free groups
   if (nf) {
-    const uint64_t Tf = std::min<uint64_t>(T, table_size_for(4ull * nf));  // sparse: most look-ups of the pairs end at an empty slot
-    ELP_HIP(c, hipMemsetAsync(table, 0xFF, Tf * sizeof(uint32_t), st));
-    const unsigned fgrid = blocks_for(nf, 256);
-    ELP_LAUNCH(c, "md_frag_init", k_frag_init, dim3(fgrid), dim3(256), 0, (const uint32_t *)flist, nf, best, winner);
-    ELP_LAUNCH(c, "md_frag_insert", k_frag_insert, dim3(fgrid), dim3(256), 0, m, (const uint4 *)fkey, (const uint32_t *)flist, nf, table, Tf - 1, rep, best);
-    uint32_t *fbits;
-    ELP_TRY(scratch(c, 6, Tf / 32 + 16, &fbits));  // the mate phase's scratch is free again
-    ELP_LAUNCH(c, "md_frag_bits", k_frag_bits, dim3(blocks_for(Tf / 32, 256)), dim3(256), 0, (const uint32_t *)table, Tf / 32, fbits);
-    ELP_LAUNCH(c, "md_frag_probe", k_frag_probe_pairs, dim3(grid), dim3(256), 0, m, (const uint4 *)fkey, (const uint32_t *)table, (const uint32_t *)fbits,
-               Tf - 1, best);
     ELP_LAUNCH(c, "md_frag_tie", k_frag_tie, dim3(fgrid), dim3(256), 0, m, (const uint32_t *)flist, nf, (const uint32_t *)rep,
                (const unsigned long long *)best, winner);
     ELP_LAUNCH(c, "md_frag_flag", k_frag_flag, dim3(fgrid), dim3(256), 0, m, (const uint32_t *)flist, nf, (const uint32_t *)rep,
                (const unsigned long long *)best, (const uint32_t *)winner, c->flag.p);
   }
+  if (e[1]) {
+    // keys with more than two records: pair their members up in arrival order
+    ELP_HIP(c, hipMemsetAsync(c->err_flag.p + 1, 0, 4, st));
+    uint64_t *bk;
+    uint32_t *bv, *cnt_dev = c->err_flag.p + 3;  // the scan-total mailbox doubles as the list counter
+    ELP_TRY(scratch(c, 2, 2 * n + 8, &bk));  // `best` and `winner` of the fragment phase are free
+    ELP_TRY(scratch(c, 3, 2 * n + 8, &bv));
+    ELP_HIP(c, hipMemsetAsync(cnt_dev, 0, 4, st));
+    ELP_LAUNCH(c, "md_big_collect", k_big_collect, dim3(grid), dim3(256), 0, n, (const uint32_t *)rep_of, c->mate.p, bk, bv, cnt_dev);
+    uint32_t cnt = 0;
+    ELP_HIP(c, hipMemcpyAsync(&cnt, cnt_dev, 4, hipMemcpyDeviceToHost, st));
+    ELP_HIP(c, hipStreamSynchronize(st));
+    ELP_HIP(c, hipMemsetAsync(cnt_dev, 0, 4, st));
+    uint64_t *ks;
+    uint32_t *vs;
+    ProfScope ps(c, "md_big_");
+    ELP_TRY(radix_sort_pairs(c, bk, bv, bk + n, bv + n, cnt, &ks, &vs));
+    ELP_LAUNCH(c, "md_big_pair", k_big_pair, dim3(blocks_for(cnt, 256)), dim3(256), 0, cnt, (const uint64_t *)ks, c->mate.p);
+  }
 
-  // ---- pairs (at most n / 2 of them): list, partition by hash bits, one LDS table per bucket
+  // ---- pairs: the entries of the pairs that formed in the table, partition by hash bits, one LDS table per bucket
   {
-    const uint64_t npmax = n / 2 + 1;
-    int bbits = 0;
-    while (bbits < 24 && (npmax >> bbits) > 384) bbits++;
-    const int ndig = (bbits + 7) / 8, sbits = 8 * ndig;
-    uint64_t *pk;
-    uint32_t *pv, *bounds, *np_dev = c->md_ctr.p + 1;
-    ELP_TRY(scratch(c, 2, 2 * npmax + 8, &pk));   // `best` and `winner` of the fragment phase are free again
-    ELP_TRY(scratch(c, 3, 2 * npmax + 8, &pv));
-    const size_t nb = (size_t)1 << bbits;
-    ELP_TRY(scratch(c, 1, 2 * nb + 8, &bounds));  // so are `frep` and the fragment list
-    ELP_HIP(c, hipMemsetAsync(np_dev, 0, 4, st));
+    uint32_t *bounds;
+    ELP_TRY(scratch(c, 1, 2 * nb + 8, &bounds));  // `frep` and the fragment list are free again
     ELP_HIP(c, hipMemsetAsync(bounds, 0, 2 * nb * sizeof(uint32_t), st));
     ELP_HIP(c, hipMemsetAsync(c->pair_win.p, 0xFF, n * sizeof(uint32_t), st));
-    ELP_LAUNCH(c, "md_pair_list", k_pair_list, dim3(blocks_for(n, 256 * PL_TILES)), dim3(256), 0, m, (const uint4 *)fkey, (const uint32_t *)c->mate.p, pk, pv,
-               np_dev);
+    ELP_LAUNCH(c, "md_pair_list", k_pair_list_table, dim3(blocks_for(n, 256 * PL_TILES)), dim3(256), 0, m, (const uint4 *)fkey, (const uint32_t *)c->mate.p,
+               (const uint8_t *)code, pk, pv, np_dev);
     uint64_t *ks = pk;
     uint32_t *vs = pv;
-    if (ndig) ELP_TRY(radix_sort_pairs_low(c, pk, pv, pk + npmax, pv + npmax, npmax, ndig, &ks, &vs, nullptr, false, np_dev));
+    if (ndig) {
+      ProfScope ps(c, "md_pair_");
+      ELP_TRY(radix_sort_pairs_low(c, pk, pv, pk + npmax, pv + npmax, npmax, ndig, &ks, &vs, nullptr, false, np_dev));
+    }
     ELP_LAUNCH(c, "md_pair_bounds", k_pair_bounds, dim3(blocks_for(npmax, 256)), dim3(256), 0, (const uint64_t *)ks, (const uint32_t *)np_dev, sbits, bbits,
                bounds, bounds + nb);
     ELP_LAUNCH(c, "md_pair_bucket", k_pair_bucket, dim3((unsigned)nb), dim3(256), 0, m, (const uint4 *)fkey, (const uint32_t *)c->mate.p,

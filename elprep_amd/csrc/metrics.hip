@@ -505,13 +505,19 @@ static int metrics_impl(elp_ctx *c, int dist, int64_t *counters_host, int64_t *h
     if (L) {
       int ndig = 1;
       while (ndig < 4 && (n >> (8 * ndig)) != 0) ndig++;  // pair groups are record indices < n < 2^32
-      ELP_TRY(radix_sort_pairs_low(c, pk, pv, pk + lcap, pv + lcap, L, ndig, &ks, &vs));
+      {
+        ProfScope ps(c, "mx_");
+        ELP_TRY(radix_sort_pairs_low(c, pk, pv, pk + lcap, pv + lcap, L, ndig, &ks, &vs));
+      }
       // the halves the sort left free hold the head flags, the group numbers and the group starts
       head = reinterpret_cast<uint32_t *>(ks == pk ? pk + lcap : pk);
       gidx = head + lcap;
       gstart = vs == pv ? pv + lcap : pv;
       ELP_LAUNCH(c, "mx_opt_heads", k_opt_heads, dim3(blocks_for(L, 256)), dim3(256), 0, L, (const uint64_t *)ks, head);
-      ELP_TRY(exclusive_scan_u32(c, head, gidx, L, &G));
+      {
+        ProfScope ps(c, "mx_");
+        ELP_TRY(exclusive_scan_u32(c, head, gidx, L, &G));
+      }
       ELP_LAUNCH(c, "mx_opt_starts", k_opt_starts, dim3(blocks_for(L, 256)), dim3(256), 0, L, (const uint32_t *)head, (const uint32_t *)gidx, gstart, G);
       total = L + G;
     }
@@ -549,6 +555,7 @@ static int metrics_impl(elp_ctx *c, int dist, int64_t *counters_host, int64_t *h
         if (cl) {
           uint64_t *ks;
           uint32_t *vs;
+          ProfScope ps(c, "mx_large_");
           ELP_TRY(radix_sort_pairs(c, lkeys, lvals, lkeys + tp, lvals + tp, cl, &ks, &vs));
           ELP_LAUNCH(c, "mx_large_iota", k_iota32, dim3(blocks_for(cl, 256)), dim3(256), 0, parent, cl);
           ELP_LAUNCH(c, "mx_large_union", k_large_union, dim3(blocks_for(cl, 256)), dim3(256), 0, cl, (const uint64_t *)ks, (const uint32_t *)vs,
