@@ -26,6 +26,7 @@
 namespace elp {
 
 constexpr uint32_t A3_N1 = 0x11111111u, A3_C3 = 0x33333333u;
+constexpr int A3_ROW = 32;  // bytes between two level-2 rows in LDS (17 used)
 constexpr int A3_NT = 512;  // three workgroups per CU around three copies of the LUT (~50 KB each): six waves per SIMD
 enum : uint32_t { AR_ON = 1u << 8, AR_REV = 1u << 9, AR_NEG = 1u << 10 };
 
@@ -118,7 +119,8 @@ struct Apply3 {
   __device__ __forceinline__ uint32_t base(uint32_t qw, uint32_t cxw, uint32_t c1, uint32_t t2r) const {
     const uint32_t qc = byte_min<(I & 3)>(qw, qhi1);
     const uint32_t id = lds_u8(__umul24(qc, w) + c1);
-    return lds_u8(lshl_add_u32<5>(id, byte_add<(I & 3)>(cxw, t2r)));
+    if (A3_ROW == 32) return lds_u8(lshl_add_u32<5>(id, byte_add<(I & 3)>(cxw, t2r)));
+    return lds_u8(__umul24(id, (uint32_t)A3_ROW) + byte_add<(I & 3)>(cxw, t2r));
   }
 
   // bases whose look-up hit the 0x80 row: quality above the resident range -> dense LUT; quality > 93 -> error
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(A3_NT) void k_bqsr_apply3(Apply3Args A) {
   const int n2 = (n_dict + 7) * 17;
   for (int k = threadIdx.x; k < n2; k += A3_NT) {
     const int row = k / 17, cx = k - 17 * row;
-    llut[t1_bytes + 32 * row + cx] = row <= n_dict ? A.t2[k] : (uint8_t)(row - n_dict - 1);
+    llut[t1_bytes + A3_ROW * row + cx] = row <= n_dict ? A.t2[k] : (uint8_t)(row - n_dict - 1);
   }
   __syncthreads();
   Apply3 B;
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(A3_NT) void k_bqsr_apply3(Apply3Args A) {
 // LDS of a launch: level 1 + room for 256 level-2 rows (their number is not read back in front of the launch); 1 = does not fit
 int apply3_bytes(int n_cov, int n_qi, int lmax, size_t *dyn_out) {
   const size_t n1 = (size_t)n_cov * (size_t)(6 + n_qi + 1) * (size_t)(2 * lmax + 1);
-  const size_t dyn = ((n1 + 15) & ~(size_t)15) + (size_t)256 * 32 + 16;
+  const size_t dyn = ((n1 + 15) & ~(size_t)15) + (size_t)256 * A3_ROW + 16;
   *dyn_out = dyn;
   return dyn + 512 <= 160 * 1024 ? 0 : 1;
 }

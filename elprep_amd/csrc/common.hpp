@@ -183,7 +183,7 @@ struct elp_ctx {
     int count3_rlog = -1;      // >= 0: log2 of the context-cell replication of the one-length count kernel
     int qual_hint = 0;         // 1: no sampled quality hint (tables sized for every quality); 2: hint without the value qual_hint_drop
     int qual_hint_drop = -1;
-    int pair_table_slots = 1024;  // LDS table slots of the pair buckets (mark duplicates); tests shrink it to reach the overflow path
+    int pair_table_slots = 1 << 20;  // cap on the LDS table slots of a pair bucket (mark duplicates); tests shrink it to reach the overflow path
     int mate_path = 0;         // 1: every mate candidate goes through the table path (no neighbour shortcut)
   } tune;
 

@@ -415,7 +415,8 @@ int elp_set_tuning(elp_ctx *c, const char *key, int64_t value) {
   else if (k == "qual_hint") { c->tune.qual_hint = v; c->have_qual_present = false; }
   else if (k == "qual_hint_drop") { c->tune.qual_hint_drop = v; c->have_qual_present = false; }
   else if (k == "pair_table_slots") {
-    if (v < 2 || v > 1024 || (v & (v - 1))) return set_error(c, ELP_ERR_ARG, "elp_set_tuning: pair_table_slots must be a power of two in [2, 1024]");
+    if (v == 0) { c->tune.pair_table_slots = 1 << 20; return 0; }
+    if (v < 2 || v > (1 << 20) || (v & (v - 1))) return set_error(c, ELP_ERR_ARG, "elp_set_tuning: pair_table_slots must be a power of two >= 2");
     c->tune.pair_table_slots = v;
   } else if (k == "mate_path") c->tune.mate_path = v;
   else return set_error(c, ELP_ERR_ARG, "elp_set_tuning: unknown key '%s'", key);

@@ -189,6 +189,27 @@ __global__ __launch_bounds__(256) void k_frag_flag(MdCols m, const uint32_t *__r
   if (dup) flag_out[i] = (uint16_t)(m.flag_in[i] | F_DUPLICATE);
 }
 
+// ---------------- pair keys (used by the mate pass as well: it writes the entries of the neighbour pairs)
+struct PairKey { uint4 k1, k2; };  // fragment keys of the two ends, ordered (:347-353)
+// `second` arrived later than `first`
+__device__ __forceinline__ PairKey pair_key(const uint4 &second, const uint4 &first) {
+  const int32_t r1 = (int32_t)second.x, r2 = (int32_t)first.x, p1 = (int32_t)second.y, p2 = (int32_t)first.y;
+  const bool v1 = second.z & 1u, v2 = first.z & 1u;
+  const bool swap = r1 > r2 || (r1 == r2 && (p1 > p2 || (p1 == p2 && v1 && !v2)));
+  return swap ? PairKey{first, second} : PairKey{second, first};
+}
+// same two ends (positions, orientations) in the same library (the library of the first end stands for the pair, :355)
+__device__ __forceinline__ bool pair_key_eq(const PairKey &a, const PairKey &b) {
+  return a.k1.x == b.k1.x && a.k2.x == b.k2.x && a.k1.y == b.k1.y && a.k2.y == b.k2.y && a.k1.z == b.k1.z && ((a.k2.z ^ b.k2.z) & 1u) == 0 &&
+         a.k1.w == b.k1.w;  // mates share their split id
+}
+
+__device__ __forceinline__ uint64_t pair_hash(const PairKey &k) {
+  uint64_t h = mix64(((uint64_t)k.k1.x << 32) | k.k2.x);
+  h = mix64(h ^ (((uint64_t)k.k1.y << 32) | k.k2.y));
+  return mix64(h ^ (((uint64_t)k.k1.z << 1) | (k.k2.z & 1u)) ^ ((uint64_t)k.k1.w << 40));
+}
+
 // ---------------- mates
 __device__ __forceinline__ uint64_t qname_hash(const MdCols &m, uint32_t i) {
   const uint64_t o = m.qname_off[i];
@@ -294,6 +315,22 @@ __global__ __launch_bounds__(MS_THREADS) void k_mate_scan(MdCols m, uint8_t *__r
   if (t == 0 && s_ntab) atomicAdd(n_table, s_ntab);
 }
 
+// one bit per 64-byte line of the Bloom filter: set if any announcement landed in the line
+__global__ __launch_bounds__(256) void k_bloom_coarse(const uint32_t *__restrict__ bloom, uint32_t n_lines, uint32_t *__restrict__ coarse) {
+  const uint32_t line = blockIdx.x * 256 + threadIdx.x;  // n_lines is a multiple of 64
+  bool nz = false;
+  if (line < n_lines) {
+    const uint4 *l = reinterpret_cast<const uint4 *>(bloom + (size_t)line * 16);
+    const uint4 a = l[0], b = l[1], c2 = l[2], d = l[3];
+    nz = (a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w | c2.x | c2.y | c2.z | c2.w | d.x | d.y | d.z | d.w) != 0;
+  }
+  const unsigned long long bits = __ballot(nz);
+  if ((threadIdx.x & 63) == 0 && line < n_lines) {
+    coarse[line >> 5] = (uint32_t)bits;
+    coarse[(line >> 5) + 1] = (uint32_t)(bits >> 32);
+  }
+}
+
 // k_mate_pairs - ONE pass over the records behind k_mate_scan does what three passes did (md_mate_insert, md_frag_probe,
 // md_pair_list):
 //  * every true pair looks its own fragment key up in the (final, small) table of the true fragments - plain loads behind the
@@ -306,49 +343,97 @@ __global__ __launch_bounds__(MS_THREADS) void k_mate_scan(MdCols m, uint8_t *__r
 //    k_pair_list_table afterwards.
 // mate[] and rep_of[] must be EMPTY-initialised.  rep_of[i] = representative of i's key for records that went through the table and
 // are not the representative themselves; rep_of[representative] = MATE_BIG iff its key has more than two records.
-__device__ __forceinline__ uint64_t pair_entry(const MdCols &m, const uint4 &later, const uint4 &earlier, uint32_t i, uint32_t mt);
-constexpr int MP_TILES = 16, MP_OWN = 129;  // owners per tile: a follower sits behind its leader, so at most every other record + 1
+// `fixed`: the entry of the pair owned by record i goes to slot i >> 1 of the list (two neighbouring followers cannot both own a
+// pair, so the slot is the owner's alone); a slot nobody owns gets a hole {score 0xFFFFFFFF | scattered hash bits, EMPTY} that the
+// bucket kernel skips - no list counter, no staging, a record per thread.  Holes are ~5 % of the slots in aligner order.  Without
+// `fixed` (the host saw that most candidates take the table path) the followers are marked like table pairs and entered afterwards.
+// A thread handles MP_R records (one per 256-record tile of its workgroup) and issues the loads of all of them level by level - codes,
+// keys and name hashes; then occupancy bits, Bloom words, the neighbour's key and the scores; then the fragment table's entry; then
+// that fragment's key: a wave otherwise waits four dependent round trips per record, one after the other, for the sake of the one
+// lane in sixteen whose look-up reaches the table (the one-record-per-thread form ran at the latency of that chain, not at bandwidth).
+constexpr int MP_R = 1;
 __global__ __launch_bounds__(256) void k_mate_pairs(MdCols m, const uint4 *__restrict__ fkey, uint8_t *__restrict__ code,
                                                     const uint32_t *__restrict__ hash32, const uint32_t *__restrict__ bloom, uint32_t bloom_mask,
+                                                    const uint32_t *__restrict__ coarse /* null: nobody announced a key */,
                                                     uint32_t *table, uint64_t mask, uint32_t *mate, uint32_t *rep_of, uint32_t *err,
                                                     const uint32_t *__restrict__ ftable, const uint32_t *__restrict__ fbits, uint64_t fmask /* 0: no fragments */,
-                                                    unsigned long long *fbest, uint64_t *__restrict__ pk, uint32_t *__restrict__ pv, uint32_t *np) {
-  __shared__ uint64_t lk[MP_TILES * MP_OWN];
-  __shared__ uint32_t lv[MP_TILES * MP_OWN];
-  __shared__ uint32_t lcount, gbase;
-  if (threadIdx.x == 0) lcount = 0;
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
-#pragma unroll 2
-  for (int tile = 0; tile < MP_TILES; tile++) {
-    const uint64_t i = ((uint64_t)blockIdx.x * MP_TILES + (uint64_t)tile) * 256 + threadIdx.x;
-    const uint8_t cd = i < m.n ? (uint8_t)(code[i] & MC_KIND) : (uint8_t)MC_NONE;
-    bool own = false;
-    uint64_t key = 0;
-    if (cd != MC_NONE) {  // a candidate that is a true pair
-      const uint4 mine = fkey[i];
-      uint32_t hi = 0;
-      if (cd != MC_TABLE) hi = hash32[cd == MC_LEAD ? i : i - 1];
-      if (fmask) {
-        for (uint64_t s = frag_hash(mine) & fmask;; s = (s + 1) & fmask) {
+                                                    unsigned long long *fbest, int fixed, uint64_t *__restrict__ pk, uint32_t *__restrict__ pv) {
+  const uint64_t base = (uint64_t)blockIdx.x * (256 * MP_R) + threadIdx.x;
+  uint8_t cd[MP_R];
+  uint4 mine[MP_R], prev[MP_R], kc[MP_R];
+  uint32_t hi[MP_R], bl[MP_R], fw[MP_R], cur[MP_R];
+  int32_t sc[MP_R];
+  uint64_t fs[MP_R];
+  bool hit[MP_R];
+  // level 0
+#pragma unroll
+  for (int r = 0; r < MP_R; r++) {
+    const uint64_t i = base + (uint64_t)r * 256;
+    const bool in = i < m.n;
+    cd[r] = in ? (uint8_t)(code[i] & MC_KIND) : (uint8_t)MC_NONE;
+    mine[r] = in ? fkey[i] : make_uint4(0, 0, 0, 0);
+    const uint32_t h0 = in ? hash32[i] : 0u, h1 = (in && i > 0) ? hash32[i - 1] : 0u;  // (only a leader's entry is defined; the unused one is dropped)
+    hi[r] = cd[r] == MC_LEAD ? h0 : h1;
+  }
+  // level 1
+#pragma unroll
+  for (int r = 0; r < MP_R; r++) {
+    const uint64_t i = base + (uint64_t)r * 256;
+    const bool cand = cd[r] != MC_NONE;
+    fs[r] = frag_hash(mine[r]) & fmask;
+    fw[r] = (cand && fmask) ? fbits[fs[r] >> 5] : 0u;
+    // the filter's word, behind a coarse level (one bit per 64-byte line of the filter, 8 KB that stay in the L1): in aligner order
+    // next to nobody announces a key, and 48 M look-ups of a 4 MB filter in the L2 cost as much as streaming this kernel's columns
+    bl[r] = ~0u;
+    if (cand && cd[r] != MC_TABLE) {
+      const uint32_t wi = (hi[r] >> 5) & bloom_mask, line = wi >> 4;
+      bl[r] = (coarse && ((coarse[line >> 5] >> (line & 31u)) & 1u)) ? bloom[wi] : 0u;
+    }
+    const bool fol = cd[r] == MC_FOLLOW;
+    prev[r] = fol ? fkey[i - 1] : make_uint4(0, 0, 0, 0);
+    sc[r] = fol ? m.score[i] + m.score[i - 1] : 0;
+  }
+  // level 2, 3: the first probe of the fragment table
+#pragma unroll
+  for (int r = 0; r < MP_R; r++) {
+    hit[r] = (fw[r] >> (fs[r] & 31)) & 1u;
+    cur[r] = hit[r] ? ftable[fs[r]] : 0u;
+  }
+#pragma unroll
+  for (int r = 0; r < MP_R; r++) kc[r] = hit[r] ? fkey[cur[r]] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < MP_R; r++) {
+    const uint64_t i = base + (uint64_t)r * 256;
+    if (hit[r]) {
+      if (key_eq(kc[r], mine[r])) atomicMax(&fbest[cur[r]], 1ull << 63);
+      else {
+        // an occupied slot of another key: on along the probe sequence (rare: the table is sparse)
+        for (uint64_t s = (fs[r] + 1) & fmask;; s = (s + 1) & fmask) {
           if (!((fbits[s >> 5] >> (s & 31)) & 1u)) break;
-          const uint32_t cur = ftable[s];
-          if (key_eq(fkey[cur], mine)) {
-            atomicMax(&fbest[cur], 1ull << 63);
+          const uint32_t c2 = ftable[s];
+          if (key_eq(fkey[c2], mine[r])) {
+            atomicMax(&fbest[c2], 1ull << 63);
             break;
           }
         }
       }
-      const bool tab = cd == MC_TABLE || ((bloom[(hi >> 5) & bloom_mask] >> (hi & 31u)) & 1u);
+    }
+    bool own = false;
+    uint64_t key = 0;
+    if (cd[r] != MC_NONE) {  // a candidate that is a true pair
+      const bool tab = cd[r] == MC_TABLE || ((bl[r] >> (hi[r] & 31u)) & 1u);
       if (!tab) {  // nobody else announced this key: the two neighbours are the pair
-        mate[i] = cd == MC_LEAD ? (uint32_t)i + 1 : (uint32_t)i - 1;
-        if (cd == MC_FOLLOW) {
-          own = true;
-          key = pair_entry(m, mine, fkey[i - 1], (uint32_t)i, (uint32_t)i - 1);
+        mate[i] = cd[r] == MC_LEAD ? (uint32_t)i + 1 : (uint32_t)i - 1;
+        if (cd[r] == MC_FOLLOW) {
+          if (fixed) {
+            own = true;
+            key = ((uint64_t)(uint32_t)sc[r] << 32) | (uint32_t)pair_hash(pair_key(mine[r], prev[r]));
+          } else {
+            code[i] = (uint8_t)(cd[r] | MC_TABBED);
+          }
         }
       } else {
-        code[i] = (uint8_t)(cd | MC_TABBED);
+        code[i] = (uint8_t)(cd[r] | MC_TABBED);
         const uint32_t rep = find_or_insert(table, mask, qname_hash(m, (uint32_t)i), (uint32_t)i, [&](uint32_t a, uint32_t b) { return mate_key_eq(m, a, b); }, mask);
         if (rep == EMPTY) atomicOr(&err[1], 2u);  // the estimated table is full: the host repeats the pass with the full-size one
         else if (rep != (uint32_t)i) {            // (the first of its key at the slot waits for the second)
@@ -362,25 +447,16 @@ __global__ __launch_bounds__(256) void k_mate_pairs(MdCols m, const uint4 *__res
         }
       }
     }
-    const unsigned long long om = __ballot(own);
-    if (om) {
-      const int leader = __ffsll((long long)om) - 1;
-      uint32_t at = 0;
-      if (lane == leader) at = atomicAdd(&lcount, (uint32_t)__popcll(om));
-      at = __shfl(at, leader, 64);
+    if (fixed) {
+      const int next_owns = __shfl_down((int)own, 1, 64);
       if (own) {
-        at += (uint32_t)__popcll(om & lt_mask);
-        lk[at] = key;
-        lv[at] = (uint32_t)i;
+        pk[i >> 1] = key;
+        pv[i >> 1] = (uint32_t)i;
+      } else if (!(threadIdx.x & 1u) && !next_owns && i < m.n) {
+        pk[i >> 1] = 0xFFFFFFFF00000000ull | (uint32_t)mix64(i);
+        pv[i >> 1] = EMPTY;
       }
     }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) gbase = lcount ? atomicAdd(np, lcount) : 0u;
-  __syncthreads();
-  for (uint32_t k = threadIdx.x; k < lcount; k += 256) {
-    pk[gbase + k] = lk[k];
-    pv[gbase + k] = lv[k];
   }
 }
 
@@ -414,26 +490,6 @@ __global__ __launch_bounds__(256) void k_big_pair(uint32_t cnt, const uint64_t *
 }
 
 // ---------------- pairs
-struct PairKey { uint4 k1, k2; };  // fragment keys of the two ends, ordered (:347-353)
-// `second` arrived later than `first`
-__device__ __forceinline__ PairKey pair_key(const uint4 &second, const uint4 &first) {
-  const int32_t r1 = (int32_t)second.x, r2 = (int32_t)first.x, p1 = (int32_t)second.y, p2 = (int32_t)first.y;
-  const bool v1 = second.z & 1u, v2 = first.z & 1u;
-  const bool swap = r1 > r2 || (r1 == r2 && (p1 > p2 || (p1 == p2 && v1 && !v2)));
-  return swap ? PairKey{first, second} : PairKey{second, first};
-}
-// same two ends (positions, orientations) in the same library (the library of the first end stands for the pair, :355)
-__device__ __forceinline__ bool pair_key_eq(const PairKey &a, const PairKey &b) {
-  return a.k1.x == b.k1.x && a.k2.x == b.k2.x && a.k1.y == b.k1.y && a.k2.y == b.k2.y && a.k1.z == b.k1.z && ((a.k2.z ^ b.k2.z) & 1u) == 0 &&
-         a.k1.w == b.k1.w;  // mates share their split id
-}
-
-__device__ __forceinline__ uint64_t pair_hash(const PairKey &k) {
-  uint64_t h = mix64(((uint64_t)k.k1.x << 32) | k.k2.x);
-  h = mix64(h ^ (((uint64_t)k.k1.y << 32) | k.k2.y));
-  return mix64(h ^ (((uint64_t)k.k1.z << 1) | (k.k2.z & 1u)) ^ ((uint64_t)k.k1.w << 40));
-}
-
 // The pairs are grouped by key WITHOUT a table in HBM (rounds 1-3 ran one compare-and-swap per pair on a 256 MB table: the rate of
 // random device-scope atomics, not bandwidth, bounded it).  Round 4:
 //   k_pair_list    every pair's owner (its later-arriving record, :336-340) writes ONE 12-byte entry - {score sum | 32 hash bits of the
@@ -529,7 +585,9 @@ __device__ __forceinline__ void pair_lost(const MdCols &m, const uint32_t *__res
   flag_out[mt] = (uint16_t)(flag_out[mt] | F_DUPLICATE);
 }
 
-constexpr int PB_CAP = 1024;       // table slots in LDS (a bucket holds ~384 pairs at most on average)
+constexpr int PB_THREADS = 256;
+constexpr int PB_TARGET = 384;     // the list is partitioned until a bucket holds at most this many entries on average
+constexpr int PB_CAP = 1024;       // table slots in LDS
 constexpr int PB_ECAP = 1024;      // entries whose table slot is remembered in LDS between the phases (the others look theirs up again)
 constexpr unsigned long long PB_EMPTY = ~0ull;
 
@@ -547,7 +605,7 @@ __device__ __forceinline__ int pb_slot(const MdCols &m, const uint4 *__restrict_
   return -1;
 }
 
-__global__ __launch_bounds__(256) void k_pair_bucket(MdCols m, const uint4 *__restrict__ fkey, const uint32_t *__restrict__ mate,
+__global__ __launch_bounds__(PB_THREADS) void k_pair_bucket(MdCols m, const uint4 *__restrict__ fkey, const uint32_t *__restrict__ mate,
                                                      const uint64_t *__restrict__ ks, uint32_t *__restrict__ vs,
                                                      const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ bend, int cap_slots,
                                                      uint32_t *__restrict__ pair_win, uint16_t *__restrict__ flag_out) {
@@ -562,15 +620,16 @@ __global__ __launch_bounds__(256) void k_pair_bucket(MdCols m, const uint4 *__re
   uint32_t T = 2;
   while (T < 2 * cnt && T < (uint32_t)cap_slots) T <<= 1;
   const uint32_t tmask = T - 1;
-  for (uint32_t k = t; k < T; k += 256) { s_key[k] = PB_EMPTY; s_best[k] = 0; s_win[k] = EMPTY; }
+  for (uint32_t k = t; k < T; k += PB_THREADS) { s_key[k] = PB_EMPTY; s_best[k] = 0; s_win[k] = EMPTY; }
   if (t == 0) s_full = 0;
   __syncthreads();
   ks += start;
   vs += start;
   // insert + best score (:342-378)
-  for (uint32_t e = t; e < cnt; e += 256) {
+  for (uint32_t e = t; e < cnt; e += PB_THREADS) {
     const uint64_t key = ks[e];
     const uint32_t o = vs[e];
+    if (o == EMPTY) continue;  // a hole of the list (k_mate_pairs)
     const int slot = pb_slot(m, fkey, mate, s_key, tmask, (uint32_t)key, o, true);
     if (slot < 0) { s_full = 1; break; }
     atomicMax(&s_best[slot], (uint32_t)(key >> 32));
@@ -579,15 +638,17 @@ __global__ __launch_bounds__(256) void k_pair_bucket(MdCols m, const uint4 *__re
   __syncthreads();
   if (!s_full) {
     // tournament among the pairs with the best score (:379-391)
-    for (uint32_t e = t; e < cnt; e += 256) {
+    for (uint32_t e = t; e < cnt; e += PB_THREADS) {
       const uint64_t key = ks[e];
       const uint32_t o = vs[e];
+      if (o == EMPTY) continue;
       const int slot = e < PB_ECAP ? (int)s_slot[e] : pb_slot(m, fkey, mate, s_key, tmask, (uint32_t)key, o, false);
       if ((uint32_t)(key >> 32) == s_best[slot]) tournament_lds(m, &s_win[slot], o);
     }
     __syncthreads();
-    for (uint32_t e = t; e < cnt; e += 256) {
+    for (uint32_t e = t; e < cnt; e += PB_THREADS) {
       const uint32_t o = vs[e];
+      if (o == EMPTY) continue;
       const int slot = e < PB_ECAP ? (int)s_slot[e] : pb_slot(m, fkey, mate, s_key, tmask, (uint32_t)ks[e], o, false);
       const uint32_t w = s_win[slot];
       if (w != o) pair_lost(m, mate, o, w, pair_win, flag_out);
@@ -601,30 +662,30 @@ __global__ __launch_bounds__(256) void k_pair_bucket(MdCols m, const uint4 *__re
     __syncthreads();
     if (t == 0) { s_min = EMPTY; s_best[0] = 0; s_win[0] = EMPTY; }
     __syncthreads();
-    for (uint32_t e = t; e < cnt; e += 256) {
+    for (uint32_t e = t; e < cnt; e += PB_THREADS) {
       const uint32_t o = vs[e];
       if (o != EMPTY) atomicMin(&s_min, o);
     }
     __syncthreads();
     const uint32_t rep = s_min;
     if (rep == EMPTY) return;
-    for (uint32_t e = t; e < cnt; e += 256)
+    for (uint32_t e = t; e < cnt; e += PB_THREADS)
       if (vs[e] == rep) s_h = (uint32_t)ks[e];
     __syncthreads();
     const uint32_t rh = s_h;
     const PairKey rk = pair_key_of(fkey, mate, rep);
-    for (uint32_t e = t; e < cnt; e += 256) {
+    for (uint32_t e = t; e < cnt; e += PB_THREADS) {
       const uint32_t o = vs[e];
       if (o != EMPTY && (uint32_t)ks[e] == rh && pair_key_eq(rk, pair_key_of(fkey, mate, o))) atomicMax(&s_best[0], (uint32_t)(ks[e] >> 32));
     }
     __syncthreads();
-    for (uint32_t e = t; e < cnt; e += 256) {
+    for (uint32_t e = t; e < cnt; e += PB_THREADS) {
       const uint32_t o = vs[e];
       if (o != EMPTY && (uint32_t)ks[e] == rh && (uint32_t)(ks[e] >> 32) == s_best[0] && pair_key_eq(rk, pair_key_of(fkey, mate, o)))
         tournament_lds(m, &s_win[0], o);
     }
     __syncthreads();
-    for (uint32_t e = t; e < cnt; e += 256) {
+    for (uint32_t e = t; e < cnt; e += PB_THREADS) {
       const uint32_t o = vs[e];
       if (o != EMPTY && (uint32_t)ks[e] == rh && pair_key_eq(rk, pair_key_of(fkey, mate, o))) {
         if (s_win[0] != o) pair_lost(m, mate, o, s_win[0], pair_win, flag_out);
@@ -677,9 +738,8 @@ static int markdup_impl(elp_ctx *c) {
   uint32_t nf = 0;  // read together with the mate phase's table estimate below
 
   // the pair phase's list, partitioned by hash bits: at most n / 2 pairs
-  const uint64_t npmax = n / 2 + 1;
   int bbits = 0;
-  while (bbits < 24 && (npmax >> bbits) > 384) bbits++;
+  while (bbits < 24 && ((n / 2 + 1) >> bbits) > (uint64_t)PB_TARGET) bbits++;
   const int ndig = (bbits + 7) / 8, sbits = 8 * ndig;
   const size_t nb = (size_t)1 << bbits;
   uint32_t *np_dev = c->md_ctr.p + 1;
@@ -689,8 +749,9 @@ static int markdup_impl(elp_ctx *c) {
   while (bw < n / 16 && bw < (1u << 20)) bw <<= 1;
   uint32_t *bloom, *hash32;
   uint8_t *code;
-  ELP_TRY(scratch(c, 6, bw + n + 16 + (n + 16) / 4, &bloom));
-  hash32 = bloom + bw;
+  ELP_TRY(scratch(c, 6, bw + bw / 512 + 16 + n + 16 + (n + 16) / 4, &bloom));
+  uint32_t *coarse = bloom + bw;  // one bit per 16 words of the filter
+  hash32 = coarse + bw / 512 + 16;
   code = reinterpret_cast<uint8_t *>(hash32 + n + 8);
   uint32_t *rep_of = c->pair_win.p;  // free until the pair phase fills it
   uint32_t *n_table_dev = c->err_flag.p + 3;  // the scan-total mailbox
@@ -706,7 +767,11 @@ static int markdup_impl(elp_ctx *c) {
   ELP_HIP(c, hipMemcpyAsync(&nf, nf_dev, 4, hipMemcpyDeviceToHost, st));
   ELP_HIP(c, hipStreamSynchronize(st));
   ELP_HIP(c, hipMemsetAsync(n_table_dev, 0, 4, st));
+  if (n_tab) ELP_LAUNCH(c, "md_bloom_coarse", k_bloom_coarse, dim3(blocks_for(bw / 16, 256)), dim3(256), 0, (const uint32_t *)bloom, (uint32_t)(bw / 16), coarse);
 
+  // aligner order (few candidates need the table): the neighbour pairs' entries go to fixed slots, the table's pairs behind them
+  const bool fixed = (uint64_t)n_tab < n / 8;
+  const uint64_t nfixed = fixed ? (n + 1) / 2 : 0, npmax = nfixed + n / 2 + 1;
   // pair list (two buffers each for the radix passes) | fragment table and its occupancy bits
   const uint64_t Tf = nf ? std::min<uint64_t>(T, table_size_for(4ull * nf)) : 0;  // sparse: most look-ups of the pairs end at an empty slot
   uint64_t *pk;
@@ -726,10 +791,10 @@ static int markdup_impl(elp_ctx *c) {
   uint32_t e[4];
   for (;;) {
     ELP_HIP(c, hipMemsetAsync(table, 0xFF, Tm * sizeof(uint32_t), st));
-    ELP_HIP(c, hipMemsetAsync(np_dev, 0, 4, st));
-    ELP_LAUNCH(c, "md_mate_pairs", k_mate_pairs, dim3(blocks_for(n, 256 * MP_TILES)), dim3(256), 0, m, (const uint4 *)fkey, code,
-               (const uint32_t *)hash32, (const uint32_t *)bloom, (uint32_t)(bw - 1), table, Tm - 1, c->mate.p, rep_of, c->err_flag.p,
-               (const uint32_t *)ftable, (const uint32_t *)fbits, nf ? Tf - 1 : (uint64_t)0, best, pk, pv, np_dev);
+    ELP_HIP(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(np_dev), (int)(uint32_t)nfixed, 1, st));
+    ELP_LAUNCH(c, "md_mate_pairs", k_mate_pairs, dim3(blocks_for(n, 256 * MP_R)), dim3(256), 0, m, (const uint4 *)fkey, code,
+               (const uint32_t *)hash32, (const uint32_t *)bloom, (uint32_t)(bw - 1), (const uint32_t *)(n_tab ? coarse : nullptr), table, Tm - 1, c->mate.p, rep_of, c->err_flag.p,
+               (const uint32_t *)ftable, (const uint32_t *)fbits, nf ? Tf - 1 : (uint64_t)0, best, fixed ? 1 : 0, pk, pv);
     ELP_TRY(fetch_err(c, e));
     if (!(e[1] & 2u)) break;
     if (Tm == T) return set_error(c, ELP_ERR_HIP, "mark duplicates: mate table overflow");
@@ -782,8 +847,8 @@ static int markdup_impl(elp_ctx *c) {
     }
     ELP_LAUNCH(c, "md_pair_bounds", k_pair_bounds, dim3(blocks_for(npmax, 256)), dim3(256), 0, (const uint64_t *)ks, (const uint32_t *)np_dev, sbits, bbits,
                bounds, bounds + nb);
-    ELP_LAUNCH(c, "md_pair_bucket", k_pair_bucket, dim3((unsigned)nb), dim3(256), 0, m, (const uint4 *)fkey, (const uint32_t *)c->mate.p,
-               (const uint64_t *)ks, vs, (const uint32_t *)bounds, (const uint32_t *)(bounds + nb), c->tune.pair_table_slots, c->pair_win.p, c->flag.p);
+    ELP_LAUNCH(c, "md_pair_bucket", k_pair_bucket, dim3((unsigned)nb), dim3(PB_THREADS), 0, m, (const uint4 *)fkey, (const uint32_t *)c->mate.p,
+               (const uint64_t *)ks, vs, (const uint32_t *)bounds, (const uint32_t *)(bounds + nb), std::min(c->tune.pair_table_slots, PB_CAP), c->pair_win.p, c->flag.p);
   }
   c->marked = true;
   return 0;

@@ -111,8 +111,11 @@ __global__ __launch_bounds__(256) void k_dup_counters(MxCols m, unsigned long lo
 #pragma unroll
     for (int t = 0; t < R; t++) {
       lb[t] = rg[t] == ELP_NIL16 ? (uint16_t)ELP_NIL16 : m.rg_lib[rg[t]];
-      srm[t] = mt[t] != EMPTY ? m.has_sr[mt[t]] : (uint8_t)0;
-      fm[t] = mt[t] != EMPTY ? m.flag[mt[t]] : (uint16_t)0;
+      // the mate's state and flags only matter for a record that is flagged itself (the second of two flagged mates counts the pair;
+      // a losing pair's owner is flagged): one record in eleven instead of two random loads for every paired record
+      const bool need = mt[t] != EMPTY && ((fl[t] & F_DUPLICATE) || pw[t] != EMPTY);
+      srm[t] = need ? m.has_sr[mt[t]] : (uint8_t)0;
+      fm[t] = need ? m.flag[mt[t]] : (uint16_t)0;
     }
 #pragma unroll
     for (int t = 0; t < R; t++) {

@@ -296,8 +296,8 @@ int elp_rollback(elp_ctx *ctx);
  *   "count3_rlog"      >= 0: log2 of the context-cell replication of the one-length count kernel (measurements)
  *   "qual_hint"        1: no sampled quality hint (the gather sizes its tables on the report-and-retry path)
  *   "qual_hint_drop"   q >= 0: quality q is removed from the sampled hint (the kernels' no-slot paths)
- *   "pair_table_slots" LDS table slots per pair bucket of elp_mark_duplicates (power of two, 2..1024; default 1024): a small
- *                      value sends every bucket through the overflow path
+ *   "pair_table_slots" cap on the LDS table slots per pair bucket of elp_mark_duplicates (a power of two >= 2; 0 = no cap): a
+ *                      small value sends every bucket through the overflow path
  *   "mate_path"        1: every mate candidate is matched through the partitioned table, no neighbour shortcut
  * Returns ELP_ERR_ARG for an unknown key or a value out of range. */
 int elp_set_tuning(elp_ctx *ctx, const char *key, int64_t value);
