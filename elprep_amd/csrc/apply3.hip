@@ -26,7 +26,7 @@
 namespace elp {
 
 constexpr uint32_t A3_N1 = 0x11111111u, A3_C3 = 0x33333333u;
-constexpr int A3_ROW = 32;  // bytes between two level-2 rows in LDS (17 used)
+constexpr int A3_ROW = 20;  // bytes between two level-2 rows in LDS (17 used)
 constexpr int A3_NT = 512;  // three workgroups per CU around three copies of the LUT (~50 KB each): six waves per SIMD
 enum : uint32_t { AR_ON = 1u << 8, AR_REV = 1u << 9, AR_NEG = 1u << 10 };
 

@@ -184,6 +184,7 @@ struct elp_ctx {
     int qual_hint = 0;         // 1: no sampled quality hint (tables sized for every quality); 2: hint without the value qual_hint_drop
     int qual_hint_drop = -1;
     int pair_table_slots = 1 << 20;  // cap on the LDS table slots of a pair bucket (mark duplicates); tests shrink it to reach the overflow path
+    int score_kernel = 0;      // 1: the general (flat) score kernel even for read sets of one length
     int mate_path = 0;         // 1: every mate candidate goes through the table path (no neighbour shortcut)
   } tune;
 

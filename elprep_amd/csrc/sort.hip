@@ -100,7 +100,7 @@ struct ScoreBody {
     const uint32_t ge15 = ((x + 0x71717171u) & 0x80808080u) >> 7;
     return __builtin_amdgcn_sad_u8(x & (ge15 * 0xFFu), 0u, s);
   }
-  static __device__ __forceinline__ uint32_t gt2(uint32_t x) { return (x + 0x7D7D7D7Du) & 0x80808080u; }  // bit 7 of every byte > 2
+  static __device__ __forceinline__ uint32_t gt2(uint32_t x) { return (((x | 0x80808080u) - 0x03030303u) | x) & 0x80808080u; }  // bit 7 of every byte > 2, whatever the bytes (a missing-QUAL filler of 0xFF in a non-candidate must not spill into its neighbour's test)
   static __device__ __forceinline__ uint32_t ge94(uint32_t x) { return x | (x + 0x22222222u); }           // bit 7 of every byte >= 94 (or >= 128)
   struct Pre { Chunk ch; uint32_t rl; int nb; int k0; };
   __device__ __forceinline__ bool prefetch(uint32_t rl, int k0, int nb, uint64_t qpos, uint32_t, Pre &p) {
@@ -153,6 +153,110 @@ __global__ __launch_bounds__(FL_THREADS) void k_score_flat(uint64_t n, const uin
   ScoreBody B{flag, qual, score, qbounds, acc, lo, hi, cand, mask, 0u};
   flat_run(qual_off, n, qual_bytes, tile_first, L, B);
   if (__any(B.bad != 0) && (threadIdx.x & 63) == 0) atomicOr(&err[0], 1u);
+}
+
+// computePhredScore + the low-quality-tail bounds for read sets of ONE length (what a sequencer writes; ensure_uniform_len): a READ per
+// lane.  A wave copies the QUAL bytes of 64 consecutive reads - one contiguous, 64-byte-aligned span - into its own LDS tile with
+// coalesced 16-byte loads and every lane then walks the words of its read: the sums, the error test and the positions of the first /
+// last quality > 2 stay in the lane's registers.  k_score_flat spreads a read over ~10 lanes and combines them through three LDS
+// atomics per 16-byte block on the read's cells (PMC, round 3: 79 % of its LDS cycles were bank conflicts of exactly those).
+constexpr int SU_WAVES = 8, SU_MAX_LEN = 250;  // a read touches at most 64 words (the bitmap of words with a quality > 2)
+__device__ __forceinline__ uint32_t su_gt2(uint32_t x) { return (((x | 0x80808080u) - 0x03030303u) | x) & 0x80808080u; }  // bit 7 of every byte > 2, any byte value
+template <int R>
+__global__ __launch_bounds__(64 * SU_WAVES) void k_score_uniform(uint64_t n, uint32_t L, const uint8_t *__restrict__ qual, const uint16_t *__restrict__ flag,
+                                                                 int32_t *__restrict__ score, uint64_t *__restrict__ qbounds, uint32_t *err) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t su_lds[];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t tile_bytes = 64u * L, tile_words = tile_bytes / 4u + 4u;
+  uint32_t *tile = su_lds + (size_t)wave * tile_words;
+  const uint32_t s = lane * L, w0 = s >> 2, skip = s & 3u;  // the read's first word and the bytes of it in front of the read
+  const uint32_t nw = (skip + L + 3u) >> 2, tail = (skip + L) & 3u;
+  const uint32_t m_first = 0xFFFFFFFFu << (8u * skip), m_last = tail ? 0xFFFFFFFFu >> (32u - 8u * tail) : 0xFFFFFFFFu;
+  uint32_t bad = 0;
+  const uint64_t ngroups = (n + 63) / 64;
+  for (uint64_t g = (uint64_t)blockIdx.x * SU_WAVES + wave; g < ngroups; g += (uint64_t)gridDim.x * SU_WAVES) {
+    const uint64_t r0 = g * 64;
+    const uint8_t *base = qual + r0 * L;
+    const uint64_t have = (n - r0 < 64 ? n - r0 : 64) * (uint64_t)L;  // the last group may be short
+    uint4 v[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+      const uint32_t off = (uint32_t)k * 1024u + lane * 16u;
+      v[k] = make_uint4(0u, 0u, 0u, 0u);
+      if (off < have) v[k] = *reinterpret_cast<const uint4 *>(base + off);  // (the column is padded: the last chunk may read past `have`)
+    }
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+      const uint32_t off = (uint32_t)k * 1024u + lane * 16u;
+      if (off < tile_bytes) *reinterpret_cast<uint4 *>(tile + off / 4u) = v[k];
+    }
+    // (the tile is the wave's own, and a wave's LDS operations execute in order: no barrier)
+    const uint64_t r = r0 + lane;
+    if (r < n) {
+      const bool cand = (flag[r] & (F_UNMAPPED | F_SECONDARY | F_SUPPLEMENTARY)) == 0;
+      const uint32_t *rw = tile + w0;
+      uint32_t x = rw[0] & m_first;
+      if (nw == 1) x &= m_last;
+      uint32_t sum = ScoreBody::part(x, 0u), bd = ScoreBody::ge94(x);
+      unsigned long long live = su_gt2(x) ? 1ull : 0ull;
+#pragma unroll 8
+      for (uint32_t k = 1; k + 1 < nw; k++) {
+        x = rw[k];
+        sum = ScoreBody::part(x, sum);
+        bd |= ScoreBody::ge94(x);
+        live |= (unsigned long long)(su_gt2(x) != 0u) << k;
+      }
+      if (nw > 1) {
+        x = rw[nw - 1] & m_last;
+        sum = ScoreBody::part(x, sum);
+        bd |= ScoreBody::ge94(x);
+        live |= (unsigned long long)(su_gt2(x) != 0u) << (nw - 1);
+      }
+      uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+      if (live) {
+        const uint32_t kf = (uint32_t)__builtin_ctzll(live), kl = 63u - (uint32_t)__builtin_clzll(live);
+        uint32_t xf = rw[kf], xl = rw[kl];
+        if (kf == 0) xf &= m_first;
+        if (kf == nw - 1) xf &= m_last;
+        if (kl == 0) xl &= m_first;
+        if (kl == nw - 1) xl &= m_last;
+        lo = kf * 4u + ((uint32_t)__builtin_ctz(su_gt2(xf)) >> 3) - skip;
+        hi = kl * 4u + ((31u - (uint32_t)__builtin_clz(su_gt2(xl))) >> 3) - skip + 1u;
+      }
+      score[r] = cand ? (int32_t)sum : 0;
+      qbounds[r] = (uint64_t)hi | ((uint64_t)lo << 32);
+      if (cand) bad |= bd & 0x80808080u;
+    }
+  }
+  if (__any(bad != 0) && lane == 0) atomicOr(&err[0], 1u);
+}
+// LDS bank conflicts of the per-lane walk: lanes are L bytes apart; if that is a whole number of words with a large power of two in it,
+// many lanes sit on one bank - those lengths stay with k_score_flat
+static bool score_uniform_ok(uint32_t L) {
+  if (L < 16 || L > (uint32_t)SU_MAX_LEN) return false;
+  if (L % 4u) return true;
+  return ((L / 4u) % 4u) != 0;  // at most two lanes more per bank than the 64-lanes-on-32-banks minimum
+}
+template <int R>
+static int score_uniform_launch(elp_ctx *c) {
+  const uint32_t L = c->uniform_len;
+  const size_t dyn = (size_t)SU_WAVES * ((size_t)64 * L + 16);
+  const unsigned per_cu = (unsigned)std::max<size_t>(1, (160 * 1024) / (dyn + 256));
+  const uint64_t ngroups = (c->n + 63) / 64;
+  const unsigned grid = (unsigned)std::min<uint64_t>((ngroups + SU_WAVES - 1) / SU_WAVES, (uint64_t)c->n_cu * per_cu);
+  ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_score_uniform<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+  ELP_LAUNCH(c, "adapt_score", k_score_uniform<R>, dim3(grid), dim3(64 * SU_WAVES), dyn, c->n, L, (const uint8_t *)c->qual.p, (const uint16_t *)c->flag.p,
+             c->score.p, c->qbounds.p, c->err_flag.p);
+  return 0;
+}
+static int score_uniform(elp_ctx *c) {
+  switch ((c->uniform_len + 15u) / 16u) {  // 16-byte load rounds of a wave's tile
+#define ELP_SU(R) case R: return score_uniform_launch<R>(c);
+    ELP_SU(1) ELP_SU(2) ELP_SU(3) ELP_SU(4) ELP_SU(5) ELP_SU(6) ELP_SU(7) ELP_SU(8) ELP_SU(9) ELP_SU(10) ELP_SU(11) ELP_SU(12) ELP_SU(13) ELP_SU(14)
+    ELP_SU(15) ELP_SU(16)
+#undef ELP_SU
+  }
+  return set_error(c, ELP_ERR_ARG, "score_uniform: read length %u", c->uniform_len);
 }
 
 // Set of quality values present, from a sample of the tiles (every `stride`-th).  It is a sizing hint for the BQSR gather's
@@ -278,7 +382,9 @@ int ensure_adapted(elp_ctx *c, bool check_quals) {
                (const uint16_t *)c->flag.p, (const uint64_t *)c->cigar_off.p, (const uint32_t *)c->cigar.p, c->upos.p, c->score.p, c->key.p,
                (uint32_t)c->n_ref, pos_bits, (const uint8_t *)c->has_sr.p);
     ELP_TRY(ensure_uniform_len(c));
-    if (c->qual_bytes) {
+    if (c->qual_bytes && c->uniform_len && score_uniform_ok(c->uniform_len) && c->tune.score_kernel != 1) {
+      ELP_TRY(score_uniform(c));
+    } else if (c->qual_bytes) {
       const unsigned grid = (unsigned)std::min<uint64_t>(flat_steps<ScoreBody>(c->qual_bytes), (uint64_t)c->n_cu * 4);
       ELP_LAUNCH(c, "adapt_score", k_score_flat, dim3(grid), dim3(FL_THREADS), 0, n, (const uint64_t *)c->qual_off.p, (const uint8_t *)c->qual.p,
                  c->qual_bytes, (const uint32_t *)c->tile_first.p, (const uint16_t *)c->flag.p, c->score.p, c->qbounds.p, c->err_flag.p);

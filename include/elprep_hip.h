@@ -293,6 +293,7 @@ int elp_rollback(elp_ctx *ctx);
  * one code path per operator is what every choice here must reproduce bit for bit.
  *   "count_kernel"     1: general BQSR count kernel even for read sets of one length
  *   "apply_kernel"     1: general ApplyBQSR kernel
+ *   "score_kernel"     1: general Phred-score / low-quality-tail kernel even for read sets of one length
  *   "count3_rlog"      >= 0: log2 of the context-cell replication of the one-length count kernel (measurements)
  *   "qual_hint"        1: no sampled quality hint (the gather sizes its tables on the report-and-retry path)
  *   "qual_hint_drop"   q >= 0: quality q is removed from the sampled hint (the kernels' no-slot paths)

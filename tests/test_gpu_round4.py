@@ -96,3 +96,43 @@ def test_one_length_quality_hint_incomplete_at_the_lds_boundary(monkeypatch, n_q
     assert h.n_cov == 4 and len(set(b.qual[b.qual >= 6].tolist())) == n_q
     monkeypatch.setenv("ELP_TUNE", "qual_hint_drop=17")
     _check_gather_apply(b, h, refs, sites)
+
+
+@pytest.mark.parametrize("length,seed", [(150, 31), (100, 32), (37, 33), (250, 34), (19, 35)])
+def test_read_per_lane_score_kernel_against_the_flat_one_and_the_oracle(length, seed):
+    """k_score_uniform (a read per lane over an LDS tile, one-length read sets) and k_score_flat (tuning score_kernel = 1) on the same
+    reads - low-quality tails at both ends, reads without any quality > 2, non-candidates: the Phred sums are the oracle's, and the
+    low-quality-tail bounds (visible through the BQSR tables and the recalibrated qualities) agree between the kernels and with the oracle"""
+    from tests.test_gpu_round3 import _uniform_case
+    from elprep_amd.engine import BqsrTables
+    b, h, refs, sites = _uniform_case(seed, 5000, length, quals=[0, 1, 2, 3, 14, 15, 16, 30, 41, 93])
+    rng = np.random.default_rng(seed)
+    qual = b.qual.reshape(b.n, length).copy()
+    k = rng.integers(0, length + 1, b.n)
+    for r in range(0, b.n, 3):  # a tail of qualities <= 2 at the end, at the start, or the whole read
+        if r % 9 == 0:
+            qual[r, :] = rng.integers(0, 3, length)
+        elif r % 2:
+            qual[r, int(k[r]):] = 2
+        else:
+            qual[r, :int(k[r])] = 1
+    b.qual = np.ascontiguousarray(qual.reshape(-1))
+    oflags, oupos, oscore = orc.mark_duplicates(b, h, with_adapted=True)
+    oq, oc, ox = orc.bqsr_gather(b, h, orc.BqsrRef(refs, sites), oflags, 500)
+    out = []
+    for kern in (0, 1):
+        e = Engine(h, tuning={"score_kernel": kern})
+        e.stage(b)
+        up, sc = e.adapted()
+        assert np.array_equal(up, oupos) and np.array_equal(sc, oscore)
+        assert np.array_equal(e.mark_duplicates(), oflags)
+        for r in range(h.n_ref):
+            e.set_reference(r, refs[r])
+            e.set_known_sites(r, sites[r])
+        qt, ct, xt = e.recalibrate(500)
+        assert np.array_equal(qt, oq) and np.array_equal(ct, oc) and np.array_equal(xt, ox)
+        lut, present = BqsrTables(qt, ct, xt, 500).finalize().build_lut(0)
+        out.append(e.apply_bqsr(lut, present, 500))
+        e.close()
+    assert np.array_equal(out[0], out[1])
+    assert np.array_equal(out[0], orc.BqsrFinal(oq, oc, ox, 500).apply(b, h, 0))
