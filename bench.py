@@ -144,6 +144,10 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="skip the comparison of the device path with the CPU leg's outputs (it needs the CPU leg)")
     ap.add_argument("--no-extra", action="store_true", help="N = 1: skip the C2 / full-quality / PCIe-inclusive side measurements")
     ap.add_argument("--extra-reads", type=int, default=16_000_000, help="reads of the full-quality side measurement")
+    ap.add_argument("--mode", choices=["auto", "filter", "sfm"], default="auto",
+                    help="auto: `elprep filter` (one context) when started as a plain process, the `elprep sfm` step (contig-group splits + spread split, "
+                         "all-reduce) whenever started under torch.distributed.run - also with ONE rank, so that a scaling curve's N = 1 point runs the "
+                         "same code as its N > 1 points")
     args = ap.parse_args()
 
     import torch
@@ -155,7 +159,12 @@ def main():
     # ELP_BENCH_BACKEND=gloo lets the N > 1 path be exercised on a box with fewer GPUs than ranks (ranks then share devices and
     # the collectives run over gloo on the host); the driver's runs use the default: nccl = RCCL over xGMI, one GPU per rank
     backend = os.environ.get("ELP_BENCH_BACKEND", "nccl")
-    if world > 1:
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    sfm_mode = world > 1 or args.mode == "sfm" or (args.mode == "auto" and under_launcher)
+    if sfm_mode and not under_launcher:
+        os.environ.update({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+        os.environ.setdefault("MASTER_PORT", "29533")
+    if sfm_mode:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
@@ -168,8 +177,8 @@ def main():
     else:
         torch.cuda.set_device(0)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
-    cdev = dev if (world == 1 or backend == "nccl") else torch.device("cpu")  # where collective buffers live
+    dev = torch.device("cuda", local_rank if sfm_mode else 0)
+    cdev = dev if (not sfm_mode or backend == "nccl") else torch.device("cpu")  # where collective buffers live
 
     from elprep_amd.engine import BqsrTables, Engine
     from tools import synth
@@ -204,7 +213,7 @@ def main():
                 yield b
 
     def barrier():
-        if world > 1:
+        if sfm_mode:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -246,9 +255,9 @@ def main():
     t0 = time.time()
     stage_s = 0.0
     route_s = 0.0  # sfm: classifying the generated records by split and exchanging the few that belong to another rank
-    dev_id = local_rank if world > 1 else 0
+    dev_id = local_rank if sfm_mode else 0
     per_rank_reads = None
-    if world == 1:
+    if not sfm_mode:
         # ---- `elprep filter`: one context holds everything (untimed staging; PCIe-inclusive rate reported separately)
         eng = Engine(hdr, dev_id)
         n_total = 0
@@ -329,12 +338,16 @@ def main():
             rk.rollback()
             rk.sync()
 
-        def step():
-            qt, ct, xt, ctr = rk.gather(MAX_CYCLE, 100)
+        def finalize_lut(qt, ct, xt):
             tb = BqsrTables(qt, ct, xt, MAX_CYCLE).finalize()
             lut, present = tb.build_lut(0, out=lut_buf[0])
             lut_buf[0] = (lut, present)
-            rk.apply(lut, present, MAX_CYCLE)
+            return lut, present
+
+        def step():
+            # same shape as the filter step: the host finalises the all-reduced tables (and uploads the LUT to both contexts) while the
+            # GPU sorts the rank's splits
+            rk.step(MAX_CYCLE, 100, host_pool, finalize_lut)
             rk.sync()
         mode = "sfm"
         counts = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(world)]
@@ -344,7 +357,7 @@ def main():
 
     elapsed, prof = timed(step, restore, args.steps, args.warmup, prof_eng, barrier)
 
-    if world > 1:
+    if sfm_mode:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -369,14 +382,14 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True,
-            "scaling": args.scaling if world > 1 else "weak",
+            "scaling": args.scaling if sfm_mode else "weak",
             "vs_baseline": None,
             "dtype": "u8/int32/int64 (integer path; float64 finalize on host)",
             "data": "synthetic",
             "config": {"workload": f"{'C3' if args.stages == 'full' else 'C2'}-style ({mode}): {n_total} reads on rank 0, {args.reads} requested per GPU, 150bp PE, genome {args.genome} "
                                    f"(24 contigs hg38/12), {args.quals} qualities, {what}",
                        "reads_per_gpu": n_total, "max_cycle": MAX_CYCLE,
-                       "parallelism": ("filter: one context" if world == 1 else f"sfm: contig groups over {world} GPUs, spread split on one rank, one all-reduce per step "
+                       "parallelism": ("filter: one context" if not sfm_mode else f"sfm: contig groups over {world} GPUs, spread split on one rank, one all-reduce per step "
                                                                               f"({rk.collective} collective)")},
             "roofline": roof,
             "stage_ms_per_step": stage_ms,
@@ -384,7 +397,7 @@ def main():
             "staging": {"gen_s": round(gen_s, 2), "h2d_stage_s": round(stage_s, 2),
                         "elp_stage_Mreads_per_s": round(n_total / max(stage_s, 1e-9) / 1e6, 2)},
         }
-        if world > 1:
+        if sfm_mode:
             # what the first multi-GPU record needs to be read without a second run: the collective's share of a step (the wait for the
             # slowest rank included: the call is entered behind a stream sync) and the set-up's record exchange
             ar = rk.allreduce_s[-args.steps:]
@@ -395,7 +408,7 @@ def main():
             out["imbalance_max_over_mean"] = round(max(per_rank_reads) / (sum(per_rank_reads) / len(per_rank_reads)), 4)
 
     # ---- N = 1 side measurements: config C2 on the same reads, the ~40-quality read set, the PCIe-inclusive staging rate
-    if world == 1 and rank == 0 and not args.no_extra:
+    if not sfm_mode and rank == 0 and not args.no_extra:
         extra = {}
         try:
             if args.stages == "full":
@@ -412,13 +425,19 @@ def main():
             extra["pcie_inclusive"] = pcie_inclusive(cfg, hdr, min(args.extra_reads, 8_000_000), out["ms_per_step"], n_total)
         except Exception as e:
             extra["pcie_inclusive"] = {"error": repr(e)}
-        try:
-            if args.quals == "binned" and args.extra_reads > 0:
+        def side_run(key, workload, mutate, shuffle=False):
+            """the full path on `--extra-reads` reads of a variant of the main workload (data shapes the main line is not tuned on)"""
+            try:
                 cq = synth.config(args.genome)
-                cq.qual_mode = 1
-                e2 = Engine(hdr, dev_id)
+                cq.qual_mode = cfg.qual_mode
+                mutate(cq)
+                hq = cq.header()
+                e2 = Engine(hq, dev_id)
                 n2 = 0
+                rng = np.random.default_rng(7)
                 for b in generated([(cq, lo, min(lo + chunk, args.extra_reads // 2)) for lo in range(0, args.extra_reads // 2, chunk)]):
+                    if shuffle:
+                        b = b.take(rng.permutation(b.n))
                     e2.stage(b)
                     n2 += b.n
                     del b
@@ -430,20 +449,27 @@ def main():
                 sf2, _, rs2 = make_filter_steps(e2, [None])
                 el, pr = timed(sf2, rs2, 3, 1, e2, barrier)
                 st, km, rf = summarize(pr, 3, n2, BYTES_FULL_PATH)
-                extra["full_quals"] = {"workload": f"{n2} reads, same generator with ~40 distinct quality values (3..41 and 2), full path",
-                                       "value": round(n2 / (el / 3) / 1e6, 3), "unit": "Mreads/s", "ms_per_step": round(el / 3 * 1e3, 3),
-                                       "stage_ms_per_step": st, "kernel_ms_per_step": km, "roofline": rf}
+                extra[key] = {"workload": f"{n2} reads, {workload}, full path",
+                              "value": round(n2 / (el / 3) / 1e6, 3), "unit": "Mreads/s", "ms_per_step": round(el / 3 * 1e3, 3),
+                              "stage_ms_per_step": st, "kernel_ms_per_step": km, "roofline": rf}
                 e2.close()
-        except Exception as e:
-            extra["full_quals"] = {"error": repr(e)}
+            except Exception as e:
+                extra[key] = {"error": repr(e)}
+
+        if args.extra_reads > 0:
+            if args.quals == "binned":
+                side_run("full_quals", "same generator with ~40 distinct quality values (3..41 and 2)", lambda c: setattr(c, "qual_mode", 1))
+            side_run("shuffled_input", "the main workload's reads staged in random order within every 2 M-record batch (mates are not neighbours: "
+                     "the mate table path of mark duplicates)", lambda c: None, shuffle=True)
+            side_run("rg16", "the main workload with 16 read groups (16 BQSR covariates instead of 4)", lambda c: setattr(c, "n_lanes", 16))
         out["extra"] = extra
 
     verify_failed = False
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline and args.cpu_reads > 0:
+        if not sfm_mode and not args.no_cpu_baseline and args.cpu_reads > 0:
             # the CPU leg: timed as the baseline, and its outputs are what the device path is checked against on the same reads
             # (outside every timed region): the bench line carries its own parity proof at the scale the oracle finishes in seconds
-            if world == 1 and eng is not None:
+            if not sfm_mode and eng is not None:
                 eng.close()
                 eng = None
             out["cpu_baseline"], ref_out = cpu_baseline(cfg, hdr, args.cpu_reads, refs_sites)
@@ -453,7 +479,7 @@ def main():
             del ref_out
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1:
+    if sfm_mode:
         dist.barrier()
         dist.destroy_process_group()
         rk.close()

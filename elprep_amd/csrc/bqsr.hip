@@ -1785,6 +1785,7 @@ int elp_bqsr_lut_upload(elp_ctx *c, int max_cycle, const uint8_t *lut, const uin
   memcpy(c->lut_pinned, lut, lut_bytes);
   memcpy(static_cast<uint8_t *>(c->lut_pinned) + lut_bytes, cov_present, (size_t)c->n_cov);
   if (!c->lut_ev) ELP_HIP(c, hipEventCreateWithFlags(&c->lut_ev, hipEventDisableTiming));
+  if (!c->copy_stream) ELP_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));  // (not the NULL stream all contexts share)
   if (c->apply_ev) ELP_HIP(c, hipStreamWaitEvent(c->copy_stream, c->apply_ev, 0));  // an apply that still reads the previous LUT
   ELP_HIP(c, hipMemcpyAsync(c->lut_dev.p, c->lut_pinned, all, hipMemcpyHostToDevice, c->copy_stream));
   // the row dictionary apply3 works from, behind the copy on the same stream - if what it depends on is known now (the quality hint of the

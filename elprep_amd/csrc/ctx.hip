@@ -218,7 +218,8 @@ int elp_reserve(elp_ctx *c, uint64_t n, uint64_t qb, uint64_t co, uint64_t sb, u
   if (!c) return ELP_ERR_ARG;
   std::lock_guard<std::mutex> g(c->stage_mu);
   ELP_HIP(c, hipSetDevice(c->device));
-  return stage_reserve(c, n, qb, co, sb, lb);
+  // (the SEQ column starts SEQ_FRONT bytes into its allocation: a caller that sizes it exactly must not trigger a regrow on the first stage)
+  return stage_reserve(c, n, qb, co, sb + elp_ctx::SEQ_FRONT, lb);
 }
 
 int elp_reset(elp_ctx *c) {

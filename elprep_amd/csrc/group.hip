@@ -64,6 +64,8 @@ void group_release(elp_ctx *c) {
     if (R->CommDestroy) (void)R->CommDestroy(static_cast<ncclComm_t>(c->comm));
     c->comm = nullptr;
   }
+  c->xport = nullptr;  // a transport of an earlier elp_group_init_transport does not outlive the group either
+  c->xport_user = nullptr;
 }
 
 }  // namespace elp

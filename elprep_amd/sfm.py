@@ -350,6 +350,43 @@ class SfmRank:
         qt, ct, xt = e0.tables_fetch(reuse=True)
         return qt, ct, xt, ctr
 
+    def step(self, max_cycle: int, pixel_dist: int, host_pool, finalize):
+        """One pass of the path over this rank's splits with the host's float64 finalisation hidden behind the sorts, as the one-context
+        filter step has it: mark duplicates, duplication metrics (order-independent sums: they do not need the sort) and the BQSR count of
+        every split, THE all-reduce (tables + counters), then the tables' way to the host, FinalizeBQSRTables and the LUT's upload to both
+        contexts on a host thread while the GPU sorts the splits, then ApplyBQSR.  `finalize(qt, ct, xt) -> (lut, present)`.
+        Returns the all-reduced duplication counters."""
+        if self.collective == "torch":
+            qt, ct, xt, ctr = self.gather(max_cycle, pixel_dist)
+            lut, present = finalize(qt, ct, xt)
+            self.apply(lut, present, max_cycle)
+            return ctr
+        ctr = None
+        for e in self.engines:
+            e.mark_duplicates(True, fetch=False)
+            c7 = e.dup_metrics(pixel_dist)
+            ctr = c7 if ctr is None else ctr + c7
+            e.recalibrate_device(max_cycle)  # tables stay in HBM
+        e0 = self.engines[0]
+        e0.tables_add(self.engines[1])
+        e0.sync()                            # (so that the time below is the collective - and the wait for the slowest rank - alone)
+        t0 = time.perf_counter()
+        ctr = e0.tables_allreduce(ctr)
+        self.allreduce_s.append(time.perf_counter() - t0)
+
+        def host_side():
+            lut, present = finalize(*e0.tables_fetch(reuse=True))
+            for e in self.engines:
+                e.lut_upload(lut, present, max_cycle)
+            return lut, present
+        fin = host_pool.submit(host_side)
+        for e in self.engines:
+            e.sort_coordinate(fetch=False)
+        fin.result()
+        for e in self.engines:
+            e.apply_bqsr(None, None, max_cycle, fetch=False)
+        return ctr
+
     def apply(self, lut: np.ndarray, present: np.ndarray, max_cycle: int):
         for e in self.engines:
             e.apply_bqsr(lut, present, max_cycle, fetch=False)

@@ -275,7 +275,9 @@ int elp_allreduce_i64(elp_ctx *ctx, int64_t *buf, size_t n);
 int elp_bqsr_apply(elp_ctx *ctx, int max_cycle, const uint8_t *lut, const uint8_t *cov_present);
 /* The LUT's way to the device ahead of the call: from the thread that built it (Go: the goroutine that ran FinalizeBQSRTables), on a copy
  * stream of the context, while other calls (sort, metrics) run on the context from another thread; elp_bqsr_apply(ctx, max_cycle, NULL,
- * NULL) then uses it.  The only other call that may share a context with running calls is elp_bqsr_tables_fetch. */
+ * NULL) then uses it.  The only other call that may share a context with running calls is elp_bqsr_tables_fetch.  Ordering the
+ * caller must keep: no staging call (elp_stage*, elp_reset, elp_rollback) and no elp_bqsr_gather* runs on the context at the same time -
+ * the upload reads the staged read length and the gather's quality hint without a lock; sort, metrics, emit and tables_fetch may. */
 int elp_bqsr_lut_upload(elp_ctx *ctx, int max_cycle, const uint8_t *lut, const uint8_t *cov_present);
 int elp_get_qual(elp_ctx *ctx, uint8_t *qual_out /* qual_bytes, staging order and offsets */);
 

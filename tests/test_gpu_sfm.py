@@ -103,3 +103,53 @@ def test_sfm_ranks_on_one_gpu(world):
             if p.n:
                 assert np.array_equal(ranks[r].engines[w].qual(), fin.apply(p, h, 0)), (r, w)
         ranks[r].close()
+
+
+def test_sfm_one_rank_step_with_the_host_behind_the_sorts():
+    """SfmRank.step on ONE rank through the C ABI's device group (a group of one): the same flags, permutation, tables, counters and
+    qualities as the oracle run split by split - the order of events differs from gather() + apply() (metrics in front of the sort, the
+    finalisation on a host thread while the GPU sorts), the results must not"""
+    from concurrent.futures import ThreadPoolExecutor
+    cfg, gof, G, owner, b = sfm_worker.make_rank_input(0, 1, pairs_per_rank=6000)
+    h = cfg.header()
+    refs = [synth.reference(cfg, r) for r in range(h.n_ref)]
+    sites = [orc.flatten(orc.sort_by_start(synth.known_sites_raw(cfg, r))) for r in range(h.n_ref)]
+    g, sp = sfm.split_records(b, gof)
+    parts = [sfm.with_sr(b, sp, g), b.take(np.nonzero(sp)[0])]
+    rk = sfm.SfmRank(h, 0, sfm.Comm(), collective="cabi")
+    assert rk.collective == "none"  # a group of one: the device path without a communicator
+    for w in (0, 1):
+        rk.stage(w, parts[w])
+    for k in range(h.n_ref):
+        rk.set_reference(k, refs[k])
+        rk.set_known_sites(k, sites[k])
+    box = {}
+
+    def finalize(qt, ct, xt):
+        box["tables"] = (qt.copy(), ct.copy(), xt.copy())
+        return BqsrTables(qt, ct, xt, 500).finalize().build_lut(0)
+    with ThreadPoolExecutor(1) as pool:
+        ctr = rk.step(500, 100, pool, finalize)
+    rk.sync()
+    oq = oc = ox = octr = None
+    for w, p in enumerate(parts):
+        fl_all = np.zeros(p.n, np.uint16)
+        for sid in np.unique(p.split):
+            sel = np.nonzero(p.split == sid)[0]
+            sub = p.take(sel)
+            perm = orc.sort_coordinate(sub, orc.mark_duplicates(sub, h))
+            fl, c7, _ = orc.dup_metrics(sub, h, perm, 100)
+            q, c, x = orc.bqsr_gather(sub, h, orc.BqsrRef(refs, sites), fl, 500)
+            fl_all[sel] = fl
+            oq = q if oq is None else oq + q
+            oc = c if oc is None else oc + c
+            ox = x if ox is None else ox + x
+            octr = c7 if octr is None else octr + c7
+        assert np.array_equal(rk.engines[w].flags(), fl_all), w
+    qt, ct, xt = box["tables"]
+    assert np.array_equal(qt, oq) and np.array_equal(ct, oc) and np.array_equal(xt, ox)
+    assert np.array_equal(ctr, octr)
+    fin = orc.BqsrFinal(oq, oc, ox, 500)
+    for w, p in enumerate(parts):
+        assert np.array_equal(rk.engines[w].qual(), fin.apply(p, h, 0)), w
+    rk.close()
