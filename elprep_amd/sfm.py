@@ -263,6 +263,7 @@ class SfmRank:
         self.engines = [Engine(header, device_ordinal), Engine(header, device_ordinal)]
         self.n = [0, 0]
         self.allreduce_s = []  # wall time of every all-reduce call (bench.py reports the timed steps' mean)
+        self._side = None      # host thread for the spread split's context (step)
         if collective is None:
             collective = os.environ.get("ELP_SFM_COLLECTIVE", "cabi" if (comm.world > 1 and comm.device.type == "cuda") else "torch")
         self.collective = collective if comm.world > 1 else "none"
@@ -361,30 +362,45 @@ class SfmRank:
             lut, present = finalize(qt, ct, xt)
             self.apply(lut, present, max_cycle)
             return ctr
-        ctr = None
-        for e in self.engines:
+        # the spread split's context is small (a few per cent of the reads): its chain of launches and read-backs runs from a second host
+        # thread on its own stream, under the kernels of the group splits' context, instead of in front of them
+        e0, e1 = self.engines
+        if self._side is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._side = ThreadPoolExecutor(1)
+
+        def count(e):
             e.mark_duplicates(True, fetch=False)
             c7 = e.dup_metrics(pixel_dist)
-            ctr = c7 if ctr is None else ctr + c7
             e.recalibrate_device(max_cycle)  # tables stay in HBM
-        e0 = self.engines[0]
-        e0.tables_add(self.engines[1])
-        e0.sync()                            # (so that the time below is the collective - and the wait for the slowest rank - alone)
+            e.sync()
+            return c7
+        side = self._side.submit(count, e1) if self.n[1] else None
+        ctr = count(e0)
+        if side is not None:
+            ctr = ctr + side.result()
+            e0.tables_add(e1)
+            e0.sync()                        # (so that the time below is the collective - and the wait for the slowest rank - alone)
         t0 = time.perf_counter()
         ctr = e0.tables_allreduce(ctr)
         self.allreduce_s.append(time.perf_counter() - t0)
 
         def host_side():
             lut, present = finalize(*e0.tables_fetch(reuse=True))
-            for e in self.engines:
-                e.lut_upload(lut, present, max_cycle)
+            e0.lut_upload(lut, present, max_cycle)
+            if self.n[1]:
+                e1.lut_upload(lut, present, max_cycle)
             return lut, present
         fin = host_pool.submit(host_side)
-        for e in self.engines:
-            e.sort_coordinate(fetch=False)
+        side = self._side.submit(lambda: e1.sort_coordinate(fetch=False)) if self.n[1] else None
+        e0.sort_coordinate(fetch=False)
+        if side is not None:
+            side.result()
         fin.result()
-        for e in self.engines:
-            e.apply_bqsr(None, None, max_cycle, fetch=False)
+        side = self._side.submit(lambda: e1.apply_bqsr(None, None, max_cycle, fetch=False)) if self.n[1] else None
+        e0.apply_bqsr(None, None, max_cycle, fetch=False)
+        if side is not None:
+            side.result()
         return ctr
 
     def apply(self, lut: np.ndarray, present: np.ndarray, max_cycle: int):
@@ -392,5 +408,8 @@ class SfmRank:
             e.apply_bqsr(lut, present, max_cycle, fetch=False)
 
     def close(self):
+        if self._side is not None:
+            self._side.shutdown()
+            self._side = None
         for e in self.engines:
             e.close()
