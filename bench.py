@@ -307,7 +307,11 @@ def main():
         for g in mine:
             c = synth.config(args.genome)
             c.qual_mode = cfg.qual_mode
+            # a seed of its own per group (distinct read names and layouts), ONE genome: the reference sequence and the known sites keep the
+            # main configuration's seed (rounds 2 and 3 let them follow the group's seed: the reads were reads of another genome, three
+            # bases in four a mismatch, and the sfm path was timed on that)
             c.seed = cfg.seed + 7919 * g
+            c.ref_seed = cfg.seed
             c.home_lo, c.home_hi = ranges[g - 1]
             jobs += [(c, lo, min(lo + chunk, pairs_of_group[g])) for lo in range(0, pairs_of_group[g], chunk)]
         rounds = torch.tensor([len(jobs)], dtype=torch.int64, device=cdev)

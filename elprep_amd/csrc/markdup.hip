@@ -312,7 +312,9 @@ __global__ __launch_bounds__(MS_THREADS) void k_mate_scan(MdCols m, uint8_t *__r
   const unsigned long long tb = __ballot(cd == MC_TABLE);
   if ((t & 63) == 0 && tb) atomicAdd(&s_ntab, (uint32_t)__popcll(tb));
   __syncthreads();
-  if (t == 0 && s_ntab) atomicAdd(n_table, s_ntab);
+  // (64 counters, a cache line each: with a few per cent of the records on the table path - the sr-tagged copies of an sfm context, whose
+  // mates sit in another split - every workgroup adds here, and ~200 K adds to ONE word serialise at ~12 ns each: 2 ms, measured)
+  if (t == 0 && s_ntab) atomicAdd(&n_table[(blockIdx.x & 63u) * 16u], s_ntab);
 }
 
 // one bit per 64-byte line of the Bloom filter: set if any announcement landed in the line
@@ -729,11 +731,11 @@ static int markdup_impl(elp_ctx *c) {
   uint4 *fkey;
   ELP_TRY(scratch(c, 5, n + 8, &fkey));
   // keys of all records + the list of true fragments (in `rep`'s scratch slot behind the n entries of frep)
-  ELP_TRY(ensure(c, c->md_ctr, 8));
+  ELP_TRY(ensure(c, c->md_ctr, 16 + 64 * 16));
   uint32_t *nf_dev = c->md_ctr.p;
   ELP_TRY(scratch(c, 1, 2 * n + 16, &rep));
   uint32_t *flist = rep + n + 8;
-  ELP_HIP(c, hipMemsetAsync(nf_dev, 0, 4, st));
+  ELP_HIP(c, hipMemsetAsync(c->md_ctr.p, 0, (16 + 64 * 16) * sizeof(uint32_t), st));  // every counter of this call in one fill
   ELP_LAUNCH(c, "md_keys", k_md_keys, dim3(blocks_for(n, 256 * MK_TILES)), dim3(256), 0, m, fkey, flist, nf_dev);
   uint32_t nf = 0;  // read together with the mate phase's table estimate below
 
@@ -754,19 +756,18 @@ static int markdup_impl(elp_ctx *c) {
   hash32 = coarse + bw / 512 + 16;
   code = reinterpret_cast<uint8_t *>(hash32 + n + 8);
   uint32_t *rep_of = c->pair_win.p;  // free until the pair phase fills it
-  uint32_t *n_table_dev = c->err_flag.p + 3;  // the scan-total mailbox
+  uint32_t *n_table_dev = c->md_ctr.p + 16;  // 64 counters, 16 words apart
   ELP_HIP(c, hipMemsetAsync(bloom, 0, bw * sizeof(uint32_t), st));
-  ELP_HIP(c, hipMemsetAsync(n_table_dev, 0, 4, st));
   ELP_HIP(c, hipMemsetAsync(c->mate.p, 0xFF, n * sizeof(uint32_t), st));
   ELP_HIP(c, hipMemsetAsync(rep_of, 0xFF, n * sizeof(uint32_t), st));
   ELP_LAUNCH(c, "md_mate_scan", k_mate_scan, dim3(grid), dim3(MS_THREADS), 0, m, code, hash32, bloom, (uint32_t)(bw - 1), n_table_dev);
   // the table only has to hold the records that are not exactly-two-neighbours (few in aligner order) plus the neighbour pairs a
   // Bloom-filter hit sends there (at most as many again, in practice a fraction): size it by their number, not by n
-  uint32_t n_tab = 0;
-  ELP_HIP(c, hipMemcpyAsync(&n_tab, n_table_dev, 4, hipMemcpyDeviceToHost, st));
+  uint32_t n_tab = 0, n_tab64[64 * 16];
+  ELP_HIP(c, hipMemcpyAsync(n_tab64, n_table_dev, sizeof n_tab64, hipMemcpyDeviceToHost, st));
   ELP_HIP(c, hipMemcpyAsync(&nf, nf_dev, 4, hipMemcpyDeviceToHost, st));
   ELP_HIP(c, hipStreamSynchronize(st));
-  ELP_HIP(c, hipMemsetAsync(n_table_dev, 0, 4, st));
+  for (int k = 0; k < 64; k++) n_tab += n_tab64[k * 16];
   if (n_tab) ELP_LAUNCH(c, "md_bloom_coarse", k_bloom_coarse, dim3(blocks_for(bw / 16, 256)), dim3(256), 0, (const uint32_t *)bloom, (uint32_t)(bw / 16), coarse);
 
   // aligner order (few candidates need the table): the neighbour pairs' entries go to fixed slots, the table's pairs behind them

@@ -28,8 +28,10 @@ def make_rank_input(rank, world, pairs_per_rank=1500):
             continue
         c = synth.config("tiny")
         c.seed = cfg.seed + 1000 * g
+        c.ref_seed = cfg.seed  # one genome: the reference and the known sites do not follow the group's seed
         c.home_lo, c.home_hi = ranges[g - 1]
-        parts.append(synth.generate(c, 0, max(1, int(pairs_per_rank * glen[g - 1] / max(sum(glen[k - 1] for k in range(1, G + 1) if owner[k] == rank), 1)))))
+        npairs = max(1, int(pairs_per_rank * glen[g - 1] / max(sum(glen[k - 1] for k in range(1, G + 1) if owner[k] == rank), 1)))
+        parts.append(synth.generate(c, 0, npairs))
     b = Batch.concat(parts) if parts else sfm.empty_batch()
     return cfg, gof, G, owner, b
 

@@ -27,7 +27,7 @@ class _Cfg(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("n_ref", C.c_int32), ("ref_len", C.c_void_p), ("read_len", C.c_int32),
                 ("p_dup", C.c_double), ("p_optical", C.c_double), ("p_unmapped_pair", C.c_double), ("p_mate_unmapped", C.c_double),
                 ("p_supp", C.c_double), ("p_sec", C.c_double), ("p_spread", C.c_double), ("p_frag", C.c_double), ("n_lanes", C.c_int32),
-                ("qual_mode", C.c_int32), ("home_lo", C.c_int32), ("home_hi", C.c_int32)]
+                ("qual_mode", C.c_int32), ("home_lo", C.c_int32), ("home_hi", C.c_int32), ("ref_seed", C.c_uint64)]
 
 
 class _Sizes(C.Structure):
@@ -74,6 +74,7 @@ class SynthConfig:
     qual_mode: int = 0  # 0 = binned qualities (7 values), 1 = full range (~40 values)
     home_lo: int = 0   # fragments start on contigs [home_lo, home_hi) (0, 0 = all): the reads of one contig group
     home_hi: int = 0
+    ref_seed: int = 0  # seed of the reference and the known sites (0 = seed): shards with seeds of their own are reads of one genome
 
     def __post_init__(self):
         self._ref_len = np.asarray(self.ref_len, dtype=np.int32)
@@ -83,7 +84,7 @@ class SynthConfig:
     def cstruct(self) -> _Cfg:
         return _Cfg(self.seed, len(self.ref_len), self._ref_len.ctypes.data, self.read_len, self.p_dup, self.p_optical,
                     self.p_unmapped_pair, self.p_mate_unmapped, self.p_supp, self.p_sec, self.p_spread, self.p_frag, self.n_lanes,
-                    self.qual_mode, self.home_lo, self.home_hi)
+                    self.qual_mode, self.home_lo, self.home_hi, self.ref_seed)
 
     def header(self) -> Header:
         half = (self.n_lanes + 1) // 2

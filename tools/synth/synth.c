@@ -33,7 +33,10 @@ typedef struct synth_cfg {
                               unbinned HiSeq run reports them) */
   int32_t home_lo, home_hi; /* the fragment's contig is drawn from [home_lo, home_hi) (both 0 = all contigs); the mate of a spread pair
                               is drawn from the whole genome.  Used to generate the reads of one contig group directly (sfm-style shards). */
+  uint64_t ref_seed;       /* seed of the reference sequence and the known sites (0 = `seed`): shards generated with seeds of their own
+                              must still be reads of ONE genome */
 } synth_cfg;
+static inline uint64_t rseed(const struct synth_cfg *c) { return c->ref_seed ? c->ref_seed : c->seed; }
 
 typedef struct synth_sizes { uint64_t n_records, qname_bytes, cigar_ops, seq_bytes, qual_bytes; } synth_sizes;
 
@@ -58,13 +61,13 @@ static inline double u01(uint64_t h) { return (double)(h >> 11) * (1.0 / 9007199
 /* ---- reference genome: uniform ACGT with ~0.1 % N runs ---- */
 static inline uint8_t ref_base(const synth_cfg *c, int refid, int64_t pos0) {
   uint64_t blk = (uint64_t)pos0 / 4096;
-  uint64_t hb = hsh(c->seed, ((uint64_t)refid << 40) ^ blk, 101);
+  uint64_t hb = hsh(rseed(c), ((uint64_t)refid << 40) ^ blk, 101);
   if ((hb & 0xFF) < 10) { /* ~4 % of 4 KiB blocks carry one N run of 20..120 bases => ~0.07 % N */
     uint32_t off = (uint32_t)((hb >> 8) % 3900), len = 20 + (uint32_t)((hb >> 24) % 101);
     uint32_t in = (uint32_t)((uint64_t)pos0 % 4096);
     if (in >= off && in < off + len) return 'N';
   }
-  uint64_t h = hsh(c->seed, ((uint64_t)refid << 40) ^ ((uint64_t)pos0 >> 5), 102);
+  uint64_t h = hsh(rseed(c), ((uint64_t)refid << 40) ^ ((uint64_t)pos0 >> 5), 102);
   return "ACGT"[(h >> (2 * ((uint64_t)pos0 & 31))) & 3];
 }
 void synth_reference(const synth_cfg *c, int refid, uint8_t *out) {
@@ -75,10 +78,10 @@ void synth_reference(const synth_cfg *c, int refid, uint8_t *out) {
 
 /* ---- known sites: one 1-bp site per 1000 bp + one 3..20 bp interval per 50 kbp (1-based inclusive) ---- */
 static inline int32_t site1_pos(const synth_cfg *c, int refid, int64_t k) { /* 1-based position of the site in block k */
-  return (int32_t)(k * 1000 + 1 + (int64_t)(hsh(c->seed, ((uint64_t)refid << 40) ^ (uint64_t)k, 201) % 1000));
+  return (int32_t)(k * 1000 + 1 + (int64_t)(hsh(rseed(c), ((uint64_t)refid << 40) ^ (uint64_t)k, 201) % 1000));
 }
 static inline void site2_iv(const synth_cfg *c, int refid, int64_t k, int32_t *s, int32_t *e) {
-  uint64_t h = hsh(c->seed, ((uint64_t)refid << 40) ^ (uint64_t)k, 202);
+  uint64_t h = hsh(rseed(c), ((uint64_t)refid << 40) ^ (uint64_t)k, 202);
   *s = (int32_t)(k * 50000 + 1 + (int64_t)(h % 49000));
   *e = *s + 2 + (int32_t)((h >> 32) % 18);
 }
