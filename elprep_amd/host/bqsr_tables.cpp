@@ -29,13 +29,63 @@ namespace {
 
 constexpr int NQ = 94, NX = 16;
 
+// math.Log as Go computes it on amd64 (math/log.go, a port of FreeBSD's e_log.c; glibc's log is another algorithm and differs in
+// the last bit for one argument in ~300): reduction x = 2^k (1 + f), sqrt(2)/2 < 1 + f < sqrt(2); log(1 + f) = f - s (f - R) with
+// s = f / (2 + f) and R a degree-14 polynomial in s; same constants, same operation order, no contraction (-ffp-contract=off)
+double go_log(double x) {
+  constexpr double Ln2Hi = 6.93147180369123816490e-01, Ln2Lo = 1.90821492927058770002e-10, L1 = 6.666666666666735130e-01,
+                   L2 = 3.999999999940941908e-01, L3 = 2.857142874366239149e-01, L4 = 2.222219843214978396e-01, L5 = 1.818357216161805012e-01,
+                   L6 = 1.531383769920937332e-01, L7 = 1.479819860511658591e-01,
+                   Sqrt2 = 1.41421356237309504880168872420969807856967187537694807317667974;
+  if (x != x || x == HUGE_VAL) return x;
+  if (x < 0) return std::nan("");
+  if (x == 0) return -HUGE_VAL;
+  int ki;
+  double f1 = std::frexp(x, &ki);
+  if (f1 < Sqrt2 / 2) { f1 *= 2; ki--; }
+  const double f = f1 - 1, k = double(ki);
+  const double s = f / (2 + f), s2 = s * s, s4 = s2 * s2;
+  const double t1 = s2 * (L1 + s4 * (L3 + s4 * (L5 + s4 * L7)));
+  const double t2 = s4 * (L2 + s4 * (L4 + s4 * L6));
+  const double R = t1 + t2, hfsq = 0.5 * f * f;
+  return k * Ln2Hi - ((hfsq - (s * (hfsq + R) + k * Ln2Lo)) - f);
+}
 inline double go_log2(double x) {
   int e;
   double frac = std::frexp(x, &e);
   if (frac == 0.5) return double(e - 1);
-  return std::log(frac) * 1.44269504088896340735992468100189213742664595415298593413 + double(e);
+  return go_log(frac) * 1.44269504088896340735992468100189213742664595415298593413 + double(e);
 }
 inline double go_log10(double x) { return go_log2(x) * 0.30102999566398119521373889472449302676818988146210854131; }
+
+// math.Lgamma for the arguments the reference passes (counts + 1: integers >= 1, bqsr.go:598-606), math/lgamma.go: 0 at 1 and 2; for
+// 3 .. 7 the logarithm of (x - 1)! built as the product (y + 2) .. (y + 6) with y = 0; from 8 on Stirling's series in 1 / x
+double go_lgamma_count(double x) {
+  constexpr double W0 = 4.18938533204672725052e-01, W1 = 8.33333333333329678849e-02, W2 = -2.77777777728775536470e-03,
+                   W3 = 7.93650558643019558500e-04, W4 = -5.95187557450339963135e-04, W5 = 8.36339918996282139126e-04,
+                   W6 = -1.63092934096575273989e-03, Two58 = 288230376151711744.0;
+  if (x == 1 || x == 2) return 0;
+  if (x < 8) {
+    const int i = int(x);
+    const double y = x - double(i);  // 0 for a count; the polynomial part p / q of the source is then exactly 0
+    double lg = 0.5 * y;
+    double z = 1.0;
+    switch (i) {
+      case 7: z *= (y + 6); [[fallthrough]];
+      case 6: z *= (y + 5); [[fallthrough]];
+      case 5: z *= (y + 4); [[fallthrough]];
+      case 4: z *= (y + 3); [[fallthrough]];
+      case 3: z *= (y + 2); lg += go_log(z);
+    }
+    return lg;
+  }
+  if (x < Two58) {
+    const double t = go_log(x), z = 1 / x, y = z * z;
+    const double w = W0 + z * (W1 + y * (W2 + y * (W3 + y * (W4 + y * (W5 + y * W6)))));
+    return (x - 0.5) * (t - 1) + w;
+  }
+  return x * (go_log(x) - 1);
+}
 
 double go_pow(double x, double y) {  // finite x > 0
   if (y == 0 || x == 1) return 1;
@@ -48,7 +98,7 @@ double go_pow(double x, double y) {  // finite x > 0
   int ae = 0;
   if (yf != 0) {
     if (yf > 0.5) { yf--; yi++; }
-    a1 = std::exp(yf * std::log(x));
+    a1 = std::exp(yf * go_log(x));  // (math.Exp is an assembly kernel on amd64 whose last bit depends on the CPU: libm stands in)
   }
   int xe;
   double x1 = std::frexp(x, &xe);
@@ -73,8 +123,7 @@ const double kPrior[21] = {-0.045757490560675115, -0.9143464543671788, -3.520113
                            -1.7976931348623157e308};
 
 inline double log10_gamma(long long n) {
-  int sg;
-  return lgamma_r(double(n), &sg) * 0.43429448190325182765112891891660508229439700580366656611445378316586464920887077;
+  return go_lgamma_count(double(n)) * 0.43429448190325182765112891891660508229439700580366656611445378316586464920887077;
 }
 
 // log10(1 - 10^(-Q/10)) for Q = 1..60: the only transcendental work of the likelihood that depends on the bin alone

@@ -28,7 +28,7 @@ CTR_NAMES = ["UnpairedReadsExamined", "ReadPairsExamined", "SecondaryOrSupplemen
 
 def build(force: bool = False) -> str:
     path = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("orc_sort.c", "orc_markdup.c", "orc_bqsr.c", "orc_bam.c", "orc.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("orc_sort.c", "orc_markdup.c", "orc_bqsr.c", "orc_bam.c", "orc_gomath.c", "orc.h")]
     if force or not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in srcs if os.path.exists(s)):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return path
@@ -50,6 +50,10 @@ def lib() -> C.CDLL:
         L.orc_go_log10.argtypes = [C.c_double]
         L.orc_go_pow10.restype = C.c_double
         L.orc_go_pow10.argtypes = [C.c_double]
+        L.orc_go_log.restype = C.c_double
+        L.orc_go_log.argtypes = [C.c_double]
+        L.orc_go_lgamma.restype = C.c_double
+        L.orc_go_lgamma.argtypes = [C.c_double]
         L.orc_bayesian_estimate.restype = C.c_uint8
         L.orc_bayesian_estimate.argtypes = [C.c_int64, C.c_int64, C.c_double]
         L.orc_estimate_library_size.restype = C.c_int64
@@ -316,6 +320,19 @@ def go_log10(x: float) -> float:
 
 def go_pow10(y: float) -> float:
     return float(lib().orc_go_pow10(y))
+
+
+def go_log(x: float) -> float:
+    """math.Log as Go computes it on amd64 (orc_gomath.c)"""
+    return float(lib().orc_go_log(x))
+
+
+def go_lgamma(x: float) -> float:
+    return float(lib().orc_go_lgamma(x))
+
+
+def gomath_selfcheck() -> int:
+    return int(lib().orc_gomath_selfcheck())
 
 
 def bayesian_estimate(obs: int, mism: int, prior: float) -> int:

@@ -145,6 +145,9 @@ void orc_free(void *p);
 /* float helpers exposed for KATs */
 double orc_go_log10(double x);
 double orc_go_pow10(double y);  /* math.Pow(10, y) */
+double orc_go_log(double x);     /* math.Log as Go computes it on amd64 (math/log.go), orc_gomath.c */
+double orc_go_lgamma(double x);  /* math.Lgamma for x > 0 (math/lgamma.go) */
+int orc_gomath_selfcheck(void);  /* 0 if the constants of orc_go_log have the bit patterns the Go source prints */
 uint8_t orc_bayesian_estimate(int64_t observations, int64_t mismatches, double prior);
 
 /* BAM alignment records (sam/bam-files.go:443-468, 481-737): the records order[0 .. n_order) of b (NULL: all, in input order) behind

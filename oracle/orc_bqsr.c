@@ -8,9 +8,9 @@
  * Count tables are dense arrays instead of Go maps; an entry "exists" iff Observations > 0 (a map entry is
  * created by its first update, bqsr.go:195-203).
  *
- * Float path: Go's math.Log10 / math.Pow are restated structurally on top of libm log/exp/frexp/ldexp
- * (Go's own ports of the FreeBSD msun kernels are not reproduced); math.Lgamma -> lgamma_r (same Sun
- * algorithm).  These only feed an argmax over 61 bins and a %.4f print.
+ * Float path: Go's math.Log10 / math.Pow are restated structurally (math/log10.go, math/pow.go) on top of Go's own
+ * math.Log and math.Lgamma as orc_gomath.c restates them (round 4; rounds 1-3 leaned on glibc's log / lgamma_r);
+ * math.Exp stays libm's (see orc_gomath.c).  These only feed an argmax over 61 bins and a %.4f print.
  */
 #include "orc.h"
 #include <math.h>
@@ -718,7 +718,7 @@ static double go_log2(double x) { /* math/log10.go: log2 */
   int exp;
   double frac = frexp(x, &exp);
   if (frac == 0.5) return (double)(exp - 1);
-  return log(frac) * GO_1_OVER_LN2 + (double)exp;
+  return orc_go_log(frac) * GO_1_OVER_LN2 + (double)exp;
 }
 double orc_go_log10(double x) { return go_log2(x) * GO_LN2_OVER_LN10; } /* math.Log10; filters/unpedantic.go:28 */
 
@@ -734,7 +734,7 @@ static double go_pow(double x, double y) {
   int ae = 0;
   if (yf != 0) {
     if (yf > 0.5) { yf--; yi++; }
-    a1 = exp(yf * log(x));
+    a1 = exp(yf * orc_go_log(x));  /* (math.Exp: libm, see orc_gomath.c) */
   }
   int xe;
   double x1 = frexp(x, &xe);
@@ -768,7 +768,7 @@ static double log10_qual_empirical_prior(double emp, double rep) { /* :593-596 *
   if (d > 20) d = 20;
   return prior_cache[d];
 }
-static double log10_gamma(int64_t n) { int sg; return lgamma_r((double)n, &sg) * GO_LOG10E; } /* :598-601 */
+static double log10_gamma(int64_t n) { return orc_go_lgamma((double)n) * GO_LOG10E; } /* :598-601 */
 static double log10_binomial_coefficient(int64_t n, int64_t k) { return log10_gamma(n + 1) - log10_gamma(k + 1) - log10_gamma(n - k + 1); }
 static double log10_binomial_probability(int64_t n, int64_t k, double log10p) { /* :607-613 */
   if (log10p == 0.0) return -DBL_MAX;
