@@ -333,6 +333,55 @@ __global__ __launch_bounds__(256) void k_bam_out_emit(BamOut m_first, BamOut m_s
 
 int stage_reserve(elp_ctx *c, uint64_t n, uint64_t qb, uint64_t co, uint64_t sb, uint64_t lb);  // ctx.hip
 
+// the columns of n_rec records whose inflated bytes lie in c->raw and whose offsets (n_rec + 1, into c->raw) lie at c->raw_off[c->n ..]:
+// fixed fields, the four scans, payload copies, SEQ recoding, the commit.  piece_bytes bounds the variable-length columns of the piece;
+// raw_end = the first byte of c->raw behind the last record.  Shared by elp_stage_bam and elp_stage_bgzf (bgzf.hip).
+int stage_bam_columns(elp_ctx *c, uint32_t n_rec, uint64_t piece_bytes, uint64_t raw_end, uint64_t max_raw_rec, uint16_t split_id) {
+  hipStream_t st = c->stream;
+  // columns
+  ELP_TRY(stage_reserve(c, c->n + n_rec, c->qname_bytes + piece_bytes, c->cigar_ops + piece_bytes / 4, c->seq_bytes + piece_bytes, c->qual_bytes + piece_bytes));
+  uint32_t *wk;
+  ELP_TRY(scratch(c, 4, (size_t)8 * (n_rec + 8) + 16, &wk));
+  const size_t np = (size_t)n_rec + 8;
+  uint32_t *len_q = wk, *len_c = wk + np, *len_s = wk + 2 * np, *len_l = wk + 3 * np, *sc_q = wk + 4 * np, *sc_c = wk + 5 * np, *sc_s = wk + 6 * np,
+           *sc_l = wk + 7 * np, *stats = wk + 8 * np;
+  ELP_HIP(c, hipMemsetAsync(stats, 0, 32, st));
+  BamIn in{c->raw.p, c->raw_off.p + c->n, n_rec, c->n, c->refid.p, c->pos.p, c->next_refid.p, c->pnext.p, c->tlen.p, c->flag.p, c->rgid.p, c->split.p,
+           c->mapq.p, c->has_sr.p, c->l_seq.p, len_q, len_c, len_s, len_l, c->rg_ids.p, c->rg_ids_off.p, c->n_rg, c->n_ref, split_id, stats};
+  ELP_LAUNCH(c, "stage_bam_fixed", k_bam_fixed, dim3(blocks_for(n_rec, 256)), dim3(256), 0, in);
+  uint32_t tq = 0, tc = 0, ts = 0, tl = 0;
+  ELP_TRY(exclusive_scan_u32(c, len_q, sc_q, n_rec, &tq));
+  ELP_TRY(exclusive_scan_u32(c, len_c, sc_c, n_rec, &tc));
+  ELP_TRY(exclusive_scan_u32(c, len_s, sc_s, n_rec, &ts));
+  ELP_TRY(exclusive_scan_u32(c, len_l, sc_l, n_rec, &tl));
+  uint32_t hs[8];
+  ELP_HIP(c, hipMemcpyAsync(hs, stats, 32, hipMemcpyDeviceToHost, st));
+  ELP_HIP(c, hipStreamSynchronize(st));
+  if (hs[4]) {
+    if (hs[4] & 8u) return set_error(c, ELP_ERR_ARG, "elp_stage_bam: an RG:Z tag names a read group that is not in the header");
+    if (hs[4] & 4u) return set_error(c, ELP_ERR_UNSUPPORTED, "elp_stage_bam: CIGAR in a CG:B tag (more than 65535 operations)");
+    return set_error(c, ELP_ERR_DATA, "elp_stage_bam: malformed alignment record (bits %u)", hs[4]);
+  }
+  if (hs[0] > elp_ctx::MAX_QNAME) return set_error(c, ELP_ERR_UNSUPPORTED, "QNAME of %u bytes (limit %u)", hs[0], elp_ctx::MAX_QNAME);
+  if (hs[1] > 0x3FFFFFu) return set_error(c, ELP_ERR_UNSUPPORTED, "record with more than 4194303 bases");
+  BamPay pay{c->raw.p, c->raw_off.p + c->n, n_rec, c->n, sc_q, sc_c, sc_s, sc_l, len_q, len_c, len_s, len_l, c->qname_bytes, c->cigar_ops, c->seq_bytes,
+             c->qual_bytes, c->qname_off.p, c->cigar_off.p, c->seq_off.p, c->qual_off.p, c->qname.p, c->seq4.p, c->qual.p, c->cigar.p};
+  if (n_rec) {
+    const unsigned grid = std::min<unsigned>(blocks_for((uint64_t)n_rec * 64, 256), (unsigned)c->n_cu * 32);
+    ELP_LAUNCH(c, "stage_bam_payload", k_bam_payload, dim3(grid), dim3(256), 0, pay);
+    if (ts) ELP_TRY(stage_recode_seq(c, c->seq_bytes, ts));
+  }
+  c->n += n_rec; c->raw_n += n_rec; c->raw_bytes = raw_end;
+  c->qname_bytes += tq; c->cigar_ops += tc; c->seq_bytes += ts; c->qual_bytes += tl;
+  c->n_sr += hs[3];
+  c->max_qname_len = std::max(c->max_qname_len, hs[0]);
+  c->max_l_seq = std::max(c->max_l_seq, hs[1]);
+  c->max_pos = std::max(c->max_pos, hs[2]);
+  c->max_split = std::max<uint32_t>(c->max_split, split_id);
+  c->max_raw_rec = std::max(c->max_raw_rec, max_raw_rec);
+  return 0;
+}
+
 }  // namespace elp
 
 using namespace elp;
@@ -461,47 +510,7 @@ int elp_stage_bam(elp_ctx *c, const uint8_t *bytes, uint64_t n_bytes, const uint
     }
     for (auto &o : off) o += c->raw_bytes;  // offsets into c->raw
     ELP_HIP(c, hipMemcpyAsync(c->raw_off.p + c->n, off.data(), (size_t)(n_rec + 1) * 8, hipMemcpyHostToDevice, st));
-    // columns
-    ELP_TRY(stage_reserve(c, c->n + n_rec, c->qname_bytes + piece_bytes, c->cigar_ops + piece_bytes / 4, c->seq_bytes + piece_bytes, c->qual_bytes + piece_bytes));
-    uint32_t *wk;
-    ELP_TRY(scratch(c, 4, (size_t)8 * (n_rec + 8) + 16, &wk));
-    const size_t np = (size_t)n_rec + 8;
-    uint32_t *len_q = wk, *len_c = wk + np, *len_s = wk + 2 * np, *len_l = wk + 3 * np, *sc_q = wk + 4 * np, *sc_c = wk + 5 * np, *sc_s = wk + 6 * np,
-             *sc_l = wk + 7 * np, *stats = wk + 8 * np;
-    ELP_HIP(c, hipMemsetAsync(stats, 0, 32, st));
-    BamIn in{c->raw.p, c->raw_off.p + c->n, n_rec, c->n, c->refid.p, c->pos.p, c->next_refid.p, c->pnext.p, c->tlen.p, c->flag.p, c->rgid.p, c->split.p,
-             c->mapq.p, c->has_sr.p, c->l_seq.p, len_q, len_c, len_s, len_l, c->rg_ids.p, c->rg_ids_off.p, c->n_rg, c->n_ref, split_id, stats};
-    ELP_LAUNCH(c, "stage_bam_fixed", k_bam_fixed, dim3(blocks_for(n_rec, 256)), dim3(256), 0, in);
-    uint32_t tq = 0, tc = 0, ts = 0, tl = 0;
-    ELP_TRY(exclusive_scan_u32(c, len_q, sc_q, n_rec, &tq));
-    ELP_TRY(exclusive_scan_u32(c, len_c, sc_c, n_rec, &tc));
-    ELP_TRY(exclusive_scan_u32(c, len_s, sc_s, n_rec, &ts));
-    ELP_TRY(exclusive_scan_u32(c, len_l, sc_l, n_rec, &tl));
-    uint32_t hs[8];
-    ELP_HIP(c, hipMemcpyAsync(hs, stats, 32, hipMemcpyDeviceToHost, st));
-    ELP_HIP(c, hipStreamSynchronize(st));
-    if (hs[4]) {
-      if (hs[4] & 8u) return set_error(c, ELP_ERR_ARG, "elp_stage_bam: an RG:Z tag names a read group that is not in the header");
-      if (hs[4] & 4u) return set_error(c, ELP_ERR_UNSUPPORTED, "elp_stage_bam: CIGAR in a CG:B tag (more than 65535 operations)");
-      return set_error(c, ELP_ERR_DATA, "elp_stage_bam: malformed alignment record (bits %u)", hs[4]);
-    }
-    if (hs[0] > elp_ctx::MAX_QNAME) return set_error(c, ELP_ERR_UNSUPPORTED, "QNAME of %u bytes (limit %u)", hs[0], elp_ctx::MAX_QNAME);
-    if (hs[1] > 0x3FFFFFu) return set_error(c, ELP_ERR_UNSUPPORTED, "record with more than 4194303 bases");
-    BamPay pay{c->raw.p, c->raw_off.p + c->n, n_rec, c->n, sc_q, sc_c, sc_s, sc_l, len_q, len_c, len_s, len_l, c->qname_bytes, c->cigar_ops, c->seq_bytes,
-               c->qual_bytes, c->qname_off.p, c->cigar_off.p, c->seq_off.p, c->qual_off.p, c->qname.p, c->seq4.p, c->qual.p, c->cigar.p};
-    if (n_rec) {
-      const unsigned grid = std::min<unsigned>(blocks_for((uint64_t)n_rec * 64, 256), (unsigned)c->n_cu * 32);
-      ELP_LAUNCH(c, "stage_bam_payload", k_bam_payload, dim3(grid), dim3(256), 0, pay);
-      if (ts) ELP_TRY(stage_recode_seq(c, c->seq_bytes, ts));
-    }
-    c->n += n_rec; c->raw_n += n_rec; c->raw_bytes += piece_bytes;
-    c->qname_bytes += tq; c->cigar_ops += tc; c->seq_bytes += ts; c->qual_bytes += tl;
-    c->n_sr += hs[3];
-    c->max_qname_len = std::max(c->max_qname_len, hs[0]);
-    c->max_l_seq = std::max(c->max_l_seq, hs[1]);
-    c->max_pos = std::max(c->max_pos, hs[2]);
-    c->max_split = std::max<uint32_t>(c->max_split, split_id);
-    c->max_raw_rec = max_raw_rec;
+    ELP_TRY(stage_bam_columns(c, n_rec, piece_bytes, c->raw_bytes + piece_bytes, max_raw_rec, split_id));
     at_byte = p;
   }
   ELP_HIP(c, hipStreamSynchronize(st));
@@ -514,8 +523,9 @@ int elp_stage_bam(elp_ctx *c, const uint8_t *bytes, uint64_t n_bytes, const uint
 }
 
 // the chunked size / scan / gather loop of both emit calls; src (device, n_out entries) or nullptr
+// bgzf: the stream leaves as BGZF blocks (stored DEFLATE, bgzf.hip), framed on the device pass by pass
 static int emit_stream(elp_ctx *c, const BamOut &m, const BamOut &m2, const uint32_t *src, uint64_t n_out, uint64_t max_raw_rec, uint8_t *out, uint64_t cap,
-                       uint64_t *n_bytes_out) {
+                       uint64_t *n_bytes_out, bool bgzf = false) {
   // records per device pass: sizes and offsets of a pass are scanned in 32 bits, so a pass must stay below 4 GiB of output.  An output
   // record is never longer than the staged one (integer fields only shrink when re-encoded), so the largest staged record bounds it.
   const uint32_t CHUNK = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(1u << 21, 0xFFFFFFFFull / std::max<uint64_t>(max_raw_rec, 64)));
@@ -535,15 +545,23 @@ static int emit_stream(elp_ctx *c, const BamOut &m, const BamOut &m2, const uint
     ELP_HIP(c, hipStreamSynchronize(st));
     if (he & 16u) return set_error(c, ELP_ERR_UNSUPPORTED, "elp_emit_sorted_bam: H-typed optional field");
     if (he) return set_error(c, ELP_ERR_DATA, "elp_emit_sorted_bam: malformed optional fields");
-    if (!out) { total += chunk_bytes; continue; }  // size query
-    if (total + chunk_bytes > cap) return set_error(c, ELP_ERR_ARG, "elp_emit_sorted_bam: output buffer too small (%llu bytes needed so far)", (unsigned long long)(total + chunk_bytes));
+    const uint64_t out_bytes = bgzf ? bgzf_framed_size(chunk_bytes) : (uint64_t)chunk_bytes;
+    if (!out) { total += out_bytes; continue; }  // size query
+    if (total + out_bytes > cap) return set_error(c, ELP_ERR_ARG, "elp_emit_sorted_bam: output buffer too small (%llu bytes needed so far)", (unsigned long long)(total + out_bytes));
     uint8_t *d_out;
     ELP_TRY(scratch(c, 5, (size_t)chunk_bytes + 64, &d_out));
     const unsigned grid = std::min<unsigned>(blocks_for((uint64_t)cnt * 64, 256), (unsigned)c->n_cu * 32);
     ELP_LAUNCH(c, "emit_bam", k_bam_out_emit, dim3(grid), dim3(256), 0, m, m2, src, k0, cnt, (const uint32_t *)offs, d_out);
-    ELP_HIP(c, hipMemcpyAsync(out + total, d_out, chunk_bytes, hipMemcpyDeviceToHost, st));
+    const uint8_t *d_send = d_out;
+    if (bgzf) {
+      uint8_t *d_framed;
+      ELP_TRY(scratch(c, 7, (size_t)out_bytes + 64, &d_framed));
+      ELP_TRY(bgzf_frame(c, d_out, chunk_bytes, d_framed));
+      d_send = d_framed;
+    }
+    ELP_HIP(c, hipMemcpyAsync(out + total, d_send, out_bytes, hipMemcpyDeviceToHost, st));
     ELP_HIP(c, hipStreamSynchronize(st));
-    total += chunk_bytes;
+    total += out_bytes;
   }
   *n_bytes_out = total;
   return 0;
@@ -560,6 +578,18 @@ int elp_emit_sorted_bam(elp_ctx *c, uint8_t *out, uint64_t cap, uint64_t *n_byte
   if (c->raw_n != c->n) return set_error(c, ELP_ERR_ARG, "elp_emit_sorted_bam: records were not staged with elp_stage_bam");
   const BamOut m = bam_out_of(c);
   return emit_stream(c, m, m, nullptr, c->n - c->n_sr, c->max_raw_rec, out, cap, n_bytes_out);
+}
+
+// The same records as BGZF blocks (utils/bgzf/bgzf-files.go:324-383 at compression level 0: stored DEFLATE blocks of at most 65280 bytes,
+// CRC-32 and ISIZE per block, framed on the device): what follows a BAM file's header blocks; the host appends the 28-byte end-of-file
+// block (:53-62).  Inflating the blocks gives elp_emit_sorted_bam's bytes.
+int elp_emit_sorted_bgzf(elp_ctx *c, uint8_t *out, uint64_t cap, uint64_t *n_bytes_out) {
+  if (!c || !n_bytes_out) return ELP_ERR_ARG;
+  ELP_HIP(c, hipSetDevice(c->device));
+  if (!c->sorted) return set_error(c, ELP_ERR_ARG, "elp_emit_sorted_bgzf: call elp_sort_coordinate first");
+  if (c->raw_n != c->n) return set_error(c, ELP_ERR_ARG, "elp_emit_sorted_bgzf: records were not staged with elp_stage_bam");
+  const BamOut m = bam_out_of(c);
+  return emit_stream(c, m, m, nullptr, c->n - c->n_sr, c->max_raw_rec, out, cap, n_bytes_out, true);
 }
 
 // MergeSortedFilesSplitPerChromosome (sam/split-merge.go:410-576) with payloads: the records of `groups` and of `spread` as ONE stream in

@@ -1,0 +1,549 @@
+// bgzf.hip — BGZF on the device: the blocks of a BAM file written from HBM, and inflated in HBM.
+//
+// Reference: utils/bgzf/bgzf-files.go.  Writer (:324-383): every block is a gzip member with the 6-byte "BC" extra field that holds
+// the block's size, a raw DEFLATE stream, the CRC-32 of the uncompressed bytes and their number; the file ends with the 28-byte empty
+// block (:53-62).  `elprep filter --compression-level 0`-style output is what is produced here: DEFLATE *stored* blocks (BTYPE 00,
+// RFC 1951 3.2.4) - valid BGZF that every reader inflates, byte-identical after inflation to what the reference writes (parity of a
+// BAM file is defined on the inflated stream); a block carries at most 65280 bytes so that its size fits the BC field.
+// The CRC-32 (IEEE, reflected 0xEDB88320) of a block is computed by the workgroup that frames it: every thread its 255 bytes by table,
+// the 256 parts combined by multiplication with x^(8 * bytes behind the part) modulo the polynomial (the algebra of zlib's
+// crc32_combine).
+#include "common.hpp"
+
+namespace elp {
+
+constexpr uint32_t BGZF_PAYLOAD = 65280, BGZF_OVERHEAD = 31, BGZF_POLY = 0xEDB88320u;
+
+// a(x) * b(x) mod p(x), reflected bit order (bit 31 = x^0)
+__host__ __device__ inline uint32_t crc_mulmod(uint32_t a, uint32_t b) {
+  uint32_t m = 1u << 31, p = 0;
+  for (;;) {
+    if (a & m) {
+      p ^= b;
+      if ((a & (m - 1)) == 0) break;
+    }
+    m >>= 1;
+    b = (b & 1u) ? (b >> 1) ^ BGZF_POLY : b >> 1;
+  }
+  return p;
+}
+struct CrcPow { uint32_t x2n[32]; };  // x^(2^k) mod p
+static CrcPow crc_pow_table() {
+  CrcPow t;
+  uint32_t p = 1u << 30;  // x^1
+  t.x2n[0] = p;
+  for (int k = 1; k < 32; k++) t.x2n[k] = p = crc_mulmod(p, p);
+  return t;
+}
+// x^(8 n) mod p
+__device__ inline uint32_t crc_x8n(const CrcPow &t, uint32_t n) {
+  uint32_t p = 1u << 31;
+  for (int k = 3; n; n >>= 1, k++)
+    if (n & 1u) p = crc_mulmod(t.x2n[k & 31], p);
+  return p;
+}
+
+// one workgroup per block: out[blk * (PAYLOAD + OVERHEAD) ...] = header | stored-block header | payload | CRC-32 | ISIZE
+__global__ __launch_bounds__(256) void k_bgzf_frame(const uint8_t *__restrict__ raw, uint64_t n_bytes, uint8_t *__restrict__ out, CrcPow pw) {
+  __shared__ uint32_t tbl[256];
+  __shared__ uint32_t s_crc;
+  __shared__ __attribute__((aligned(16))) uint8_t buf[BGZF_PAYLOAD];
+  const uint32_t t = threadIdx.x;
+  {
+    uint32_t c = t;
+    for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ BGZF_POLY : c >> 1;
+    tbl[t] = c;
+  }
+  if (t == 0) s_crc = 0;
+  const uint64_t at = (uint64_t)blockIdx.x * BGZF_PAYLOAD;
+  const uint32_t len = (uint32_t)((n_bytes - at) < (uint64_t)BGZF_PAYLOAD ? (n_bytes - at) : (uint64_t)BGZF_PAYLOAD);
+  uint8_t *o = out + (uint64_t)blockIdx.x * (BGZF_PAYLOAD + BGZF_OVERHEAD);
+  // payload: through LDS (the CRC reads it from there), 16 bytes per thread and step; `raw` is 16-byte aligned and PAYLOAD a multiple of 16
+  for (uint32_t k = t * 16u; k < len; k += 256u * 16u) {
+    uint4 v;
+    if (k + 16u <= len) v = *reinterpret_cast<const uint4 *>(raw + at + k);
+    else {
+      uint8_t tmp[16];
+      for (uint32_t j = 0; j < 16; j++) tmp[j] = k + j < len ? raw[at + k + j] : (uint8_t)0;
+      __builtin_memcpy(&v, tmp, 16);
+    }
+    *reinterpret_cast<uint4 *>(buf + k) = v;
+    if (k + 16u <= len) __builtin_memcpy(o + 23 + k, &v, 16);
+    else
+      for (uint32_t j = 0; k + j < len; j++) o[23 + k + j] = buf[k + j];
+  }
+  __syncthreads();
+  // CRC-32 of the thread's part [lo, hi), then its place in the block's polynomial
+  const uint32_t lo = t * 255u < len ? t * 255u : len, hi = lo + 255u < len ? lo + 255u : len;
+  if (hi > lo) {
+    uint32_t c = 0xFFFFFFFFu;
+    for (uint32_t k = lo; k < hi; k++) c = tbl[(c ^ buf[k]) & 0xFFu] ^ (c >> 8);
+    c ^= 0xFFFFFFFFu;
+    atomicXor(&s_crc, crc_mulmod(crc_x8n(pw, len - hi), c));
+  }
+  __syncthreads();
+  if (t == 0) {
+    const uint32_t total = len + BGZF_OVERHEAD, crc = s_crc;
+    const uint8_t head[23] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, (uint8_t)((total - 1) & 0xFF), (uint8_t)((total - 1) >> 8),
+                              0x01, (uint8_t)(len & 0xFF), (uint8_t)(len >> 8), (uint8_t)(~len & 0xFF), (uint8_t)((~len >> 8) & 0xFF)};
+    for (int k = 0; k < 23; k++) o[k] = head[k];
+    uint8_t *tail = o + 23 + len;
+    for (int k = 0; k < 4; k++) { tail[k] = (uint8_t)(crc >> (8 * k)); tail[4 + k] = (uint8_t)(len >> (8 * k)); }
+  }
+}
+
+uint64_t bgzf_framed_size(uint64_t n_bytes) { return n_bytes + (uint64_t)BGZF_OVERHEAD * ((n_bytes + BGZF_PAYLOAD - 1) / BGZF_PAYLOAD); }
+
+// frames n_bytes of `raw` (device, 16-byte aligned) into `out` (device, bgzf_framed_size(n_bytes) bytes): full blocks are PAYLOAD +
+// OVERHEAD bytes apart, the last one is short
+int bgzf_frame(elp_ctx *c, const uint8_t *raw, uint64_t n_bytes, uint8_t *out) {
+  if (!n_bytes) return 0;
+  static const CrcPow pw = crc_pow_table();
+  const uint64_t nblk = (n_bytes + BGZF_PAYLOAD - 1) / BGZF_PAYLOAD;
+  ELP_LAUNCH(c, "emit_bgzf_frame", k_bgzf_frame, dim3((unsigned)nblk), dim3(256), 0, raw, n_bytes, out, pw);
+  return 0;
+}
+
+
+// ------------------------------------------------------------------ inflate (RFC 1951), one THREAD per BGZF block
+// Reference: the reader inflates every block with compress/flate on a worker goroutine (utils/bgzf/bgzf-files.go:164-221) and checks
+// its CRC-32.  A BAM file of a 30x genome is a few hundred thousand independent blocks of <= 64 KB: one thread per block - a plain
+// sequential decoder, canonical Huffman codes decoded length by length from per-thread count / symbol arrays - keeps every lane of the
+// chip busy on a block of its own.
+struct BgzfBlk { uint64_t in_off; uint32_t in_len, out_len; uint64_t out_off; uint32_t crc; uint32_t pad; };  // CDATA in the piece; ISIZE; place in c->raw
+
+struct Inflater {
+  const uint8_t *in;
+  uint32_t in_len, in_at, bitbuf;
+  int bitcnt;
+  uint8_t *out;
+  uint32_t out_len, out_at;
+  int err;
+  __device__ __forceinline__ uint32_t bits(int need) {
+    uint32_t v = bitbuf;
+    while (bitcnt < need) {
+      if (in_at == in_len) { err = 1; return 0; }
+      v |= (uint32_t)in[in_at++] << bitcnt;
+      bitcnt += 8;
+    }
+    bitbuf = need < 32 ? v >> need : 0u;
+    bitcnt -= need;
+    return need < 32 ? v & ((1u << need) - 1u) : v;
+  }
+};
+struct Huff { int16_t count[16]; int16_t *symbol; };
+__device__ inline int huff_decode(Inflater &s, const Huff &h) {
+  int code = 0, first = 0, index = 0;
+  for (int len = 1; len <= 15; len++) {
+    code |= (int)s.bits(1);
+    if (s.err) return -1;
+    const int count = h.count[len];
+    if (code - count < first) return h.symbol[index + (code - first)];
+    index += count;
+    first += count;
+    first <<= 1;
+    code <<= 1;
+  }
+  return -1;
+}
+// canonical code from the code lengths of n symbols; > 0: incomplete, < 0: over-subscribed
+__device__ inline int huff_construct(Huff &h, const int16_t *length, int n) {
+  int16_t offs[16];
+  for (int len = 0; len <= 15; len++) h.count[len] = 0;
+  for (int sym = 0; sym < n; sym++) h.count[length[sym]]++;
+  if (h.count[0] == n) return 0;
+  int left = 1;
+  for (int len = 1; len <= 15; len++) {
+    left <<= 1;
+    left -= h.count[len];
+    if (left < 0) return left;
+  }
+  offs[1] = 0;
+  for (int len = 1; len < 15; len++) offs[len + 1] = offs[len] + h.count[len];
+  for (int sym = 0; sym < n; sym++)
+    if (length[sym] != 0) h.symbol[offs[length[sym]]++] = (int16_t)sym;
+  return left;
+}
+__constant__ int16_t INF_LENS[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__constant__ int16_t INF_LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__constant__ int16_t INF_DISTS[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__constant__ int16_t INF_DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__constant__ uint8_t INF_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+__device__ inline int inflate_codes(Inflater &s, const Huff &lencode, const Huff &distcode) {
+  for (;;) {
+    int symbol = huff_decode(s, lencode);
+    if (symbol < 0) return 2;
+    if (symbol < 256) {
+      if (s.out_at == s.out_len) return 3;
+      s.out[s.out_at++] = (uint8_t)symbol;
+    } else if (symbol == 256) {
+      return 0;
+    } else {
+      symbol -= 257;
+      if (symbol >= 29) return 4;
+      const int len = INF_LENS[symbol] + (int)s.bits(INF_LEXT[symbol]);
+      symbol = huff_decode(s, distcode);
+      if (symbol < 0 || symbol >= 30) return 5;
+      const uint32_t dist = (uint32_t)INF_DISTS[symbol] + s.bits(INF_DEXT[symbol]);
+      if (s.err) return 1;
+      if (dist > s.out_at) return 6;
+      if (s.out_at + (uint32_t)len > s.out_len) return 3;
+      for (int k = 0; k < len; k++, s.out_at++) s.out[s.out_at] = s.out[s.out_at - dist];
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__ cdata, const BgzfBlk *__restrict__ blk, uint32_t n_blk, uint8_t *__restrict__ raw,
+                                                     uint32_t *err) {
+  const uint32_t b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= n_blk) return;
+  const BgzfBlk B = blk[b];
+  Inflater s{cdata + B.in_off, B.in_len, 0, 0, 0, raw + B.out_off, B.out_len, 0, 0};
+  int16_t lengths[320], lensym[288], distsym[30];
+  Huff lencode, distcode;
+  lencode.symbol = lensym;
+  distcode.symbol = distsym;
+  int rc = 0, last;
+  do {
+    last = (int)s.bits(1);
+    const int type = (int)s.bits(2);
+    if (s.err) { rc = 1; break; }
+    if (type == 0) {  // stored
+      s.bitbuf = 0;
+      s.bitcnt = 0;
+      if (s.in_at + 4 > s.in_len) { rc = 1; break; }
+      const uint32_t len = s.in[s.in_at] | ((uint32_t)s.in[s.in_at + 1] << 8), nlen = s.in[s.in_at + 2] | ((uint32_t)s.in[s.in_at + 3] << 8);
+      s.in_at += 4;
+      if (len != (~nlen & 0xFFFFu)) { rc = 7; break; }
+      if (s.in_at + len > s.in_len) { rc = 1; break; }
+      if (s.out_at + len > s.out_len) { rc = 3; break; }
+      for (uint32_t k = 0; k < len; k++) s.out[s.out_at++] = s.in[s.in_at++];
+    } else if (type == 1) {  // fixed codes
+      int sym = 0;
+      for (; sym < 144; sym++) lengths[sym] = 8;
+      for (; sym < 256; sym++) lengths[sym] = 9;
+      for (; sym < 280; sym++) lengths[sym] = 7;
+      for (; sym < 288; sym++) lengths[sym] = 8;
+      huff_construct(lencode, lengths, 288);
+      for (sym = 0; sym < 30; sym++) lengths[sym] = 5;
+      huff_construct(distcode, lengths, 30);
+      rc = inflate_codes(s, lencode, distcode);
+    } else if (type == 2) {  // dynamic codes
+      const int nlen = (int)s.bits(5) + 257, ndist = (int)s.bits(5) + 1, ncode = (int)s.bits(4) + 4;
+      if (s.err) { rc = 1; break; }
+      if (nlen > 286 || ndist > 30) { rc = 8; break; }
+      int index = 0;
+      for (; index < ncode; index++) lengths[INF_ORDER[index]] = (int16_t)s.bits(3);
+      for (; index < 19; index++) lengths[INF_ORDER[index]] = 0;
+      if (huff_construct(lencode, lengths, 19) != 0) { rc = 9; break; }
+      index = 0;
+      while (index < nlen + ndist) {
+        int symbol = huff_decode(s, lencode);
+        if (symbol < 0) { rc = 2; break; }
+        if (symbol < 16) lengths[index++] = (int16_t)symbol;
+        else {
+          int len = 0, rep;
+          if (symbol == 16) {
+            if (index == 0) { rc = 10; break; }
+            len = lengths[index - 1];
+            rep = 3 + (int)s.bits(2);
+          } else if (symbol == 17) rep = 3 + (int)s.bits(3);
+          else rep = 11 + (int)s.bits(7);
+          if (index + rep > nlen + ndist) { rc = 11; break; }
+          while (rep--) lengths[index++] = (int16_t)len;
+        }
+      }
+      if (rc) break;
+      if (lengths[256] == 0) { rc = 12; break; }
+      // (the distance lengths are moved to the front of a second array: huff_construct indexes its input by symbol)
+      int16_t dl[30];
+      for (int k = 0; k < ndist; k++) dl[k] = lengths[nlen + k];
+      int e = huff_construct(lencode, lengths, nlen);
+      if (e && (e < 0 || nlen != lencode.count[0] + lencode.count[1])) { rc = 13; break; }
+      e = huff_construct(distcode, dl, ndist);
+      if (e && (e < 0 || ndist != distcode.count[0] + distcode.count[1])) { rc = 14; break; }
+      rc = inflate_codes(s, lencode, distcode);
+    } else rc = 15;
+  } while (!rc && !last);
+  if (!rc && s.out_at != s.out_len) rc = 16;  // ISIZE promised another number of bytes
+  if (rc) atomicOr(&err[0], 1u);
+}
+
+// CRC-32 of every inflated block against the value in its trailer (one workgroup per block, as in k_bgzf_frame)
+__global__ __launch_bounds__(256) void k_bgzf_crc_check(const uint8_t *__restrict__ raw, const BgzfBlk *__restrict__ blk, CrcPow pw, uint32_t *err) {
+  __shared__ uint32_t tbl[256];
+  __shared__ uint32_t s_crc;
+  const uint32_t t = threadIdx.x;
+  {
+    uint32_t c = t;
+    for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ BGZF_POLY : c >> 1;
+    tbl[t] = c;
+  }
+  if (t == 0) s_crc = 0;
+  __syncthreads();
+  const BgzfBlk B = blk[blockIdx.x];
+  const uint8_t *d = raw + B.out_off;
+  const uint32_t len = B.out_len, per = (len + 255u) / 256u;
+  const uint32_t lo = t * per < len ? t * per : len, hi = lo + per < len ? lo + per : len;
+  if (hi > lo) {
+    uint32_t c = 0xFFFFFFFFu;
+    for (uint32_t k = lo; k < hi; k++) c = tbl[(c ^ d[k]) & 0xFFu] ^ (c >> 8);
+    c ^= 0xFFFFFFFFu;
+    atomicXor(&s_crc, crc_mulmod(crc_x8n(pw, len - hi), c));
+  }
+  __syncthreads();
+  if (t == 0 && s_crc != B.crc) atomicOr(&err[0], 2u);
+}
+
+// ------------------------------------------------------------------ where the alignment records start in the inflated stream
+// A reader walks the block_size chain record by record (sam/bam-files.go: one record after the other from the stream); that is one
+// dependent load per record - 50 M of them.  Here every inflated block GUESSES its first record start (the first offset at which a
+// well-formed record header stands and whose block_size chain stays well-formed for a few records), walks its own records from there
+// and reports where its chain leaves the block; the guesses are then PROVEN: the chain that starts at the known first record of the
+// stream enters every block exactly at that block's guess iff every block's exit equals the next block's guess - checked for all
+// blocks at once.  Where a guess was wrong (a byte pattern that happened to look like a record), one thread repairs the entries in
+// order.  The result is exact; the guessing only decides how much runs in parallel.
+struct RecScan {
+  const uint8_t *raw;
+  uint64_t begin, end;  // the stream's bytes in c->raw: the first record of the piece starts at `begin`
+  int32_t n_ref;
+};
+constexpr uint64_t REC_NONE = ~0ull;
+__device__ __forceinline__ uint32_t ld32(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+// could a record start at p?  (fields of the fixed part, sam/bam-files.go:parseBamAlignment; everything that is checkable inside the data)
+__device__ inline bool rec_plausible(const RecScan &r, uint64_t p) {
+  if (p + 36 > r.end) return false;
+  const uint8_t *q = r.raw + p;
+  const uint32_t bs = ld32(q);
+  if (bs < 32 || bs > (1u << 28)) return false;
+  const int32_t refid = (int32_t)ld32(q + 4), pos = (int32_t)ld32(q + 8), next_refid = (int32_t)ld32(q + 24), next_pos = (int32_t)ld32(q + 28);
+  if (refid < -1 || refid >= r.n_ref || next_refid < -1 || next_refid >= r.n_ref || pos < -1 || next_pos < -1) return false;
+  const uint32_t l_name = q[12], n_cig = q[16] | ((uint32_t)q[17] << 8), l_seq = ld32(q + 20);
+  if (l_name < 1 || l_seq > (1u << 28)) return false;
+  const uint64_t need = 32ull + l_name + 4ull * n_cig + (l_seq + 1) / 2 + l_seq;
+  if (need > bs) return false;
+  const uint64_t nul = p + 36 + l_name - 1;
+  if (nul < r.end && r.raw[nul] != 0) return false;
+  return true;
+}
+// per inflated block: first / one-past-last byte in c->raw
+__global__ __launch_bounds__(256) void k_rec_guess(RecScan r, const BgzfBlk *__restrict__ blk, uint64_t *__restrict__ guess, int weak) {
+  __shared__ unsigned long long s_best;
+  const BgzfBlk B = blk[blockIdx.x];
+  // (the first block of a piece also owns the bytes in front of it: the record that was pending when the previous piece ended starts there)
+  const uint64_t lo = (blockIdx.x == 0 || B.out_off < r.begin) ? r.begin : B.out_off, hi = B.out_off + B.out_len;
+  if (threadIdx.x == 0) s_best = (weak && lo < hi) ? lo + (blockIdx.x % 3u) : REC_NONE;  // weak: a guess without a look at the bytes
+  __syncthreads();
+  for (uint64_t base = lo; !weak && base < hi; base += 256) {
+    const uint64_t p = base + threadIdx.x;
+    if (p < hi && rec_plausible(r, p)) {
+      // the chain must stay plausible for up to three more records (as far as the data at hand goes)
+      uint64_t q = p + 4ull + ld32(r.raw + p);
+      bool ok = true;
+      for (int k = 0; ok && k < 3 && q + 36 <= r.end; k++) {
+        ok = rec_plausible(r, q);
+        q += 4ull + ld32(r.raw + q);
+      }
+      if (ok) atomicMin(&s_best, (unsigned long long)p);
+    }
+    __syncthreads();
+    if (s_best != REC_NONE) break;  // (uniform: read behind the barrier)
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) guess[blockIdx.x] = s_best;
+}
+// the record at p is not complete in the data at hand: it stays pending (the next piece brings the rest)
+__device__ __forceinline__ bool rec_incomplete(const RecScan &r, uint64_t p) { return p + 4 > r.end || p + 4ull + ld32(r.raw + p) > r.end; }
+// thread per block: the complete records that START in the block, from its entry; exit = where the chain leaves the block, or the first
+// record that is not complete in the data.  fill: also writes the starts (second pass)
+__device__ inline void rec_walk(const RecScan &r, uint64_t entry, uint64_t hi, uint64_t *exit_out, uint32_t *cnt_out, uint64_t *starts, uint32_t *max_rec) {
+  uint64_t p = entry;
+  uint32_t cnt = 0, mx = 0;
+  while (p < hi) {
+    if (rec_incomplete(r, p)) break;
+    const uint64_t nx = p + 4ull + ld32(r.raw + p);
+    if (starts) starts[cnt] = p;
+    cnt++;
+    const uint32_t sz = (uint32_t)(nx - p);
+    mx = sz > mx ? sz : mx;
+    p = nx;
+  }
+  *exit_out = p;
+  *cnt_out = cnt;
+  if (max_rec && mx) atomicMax(max_rec, mx);
+}
+__global__ __launch_bounds__(64) void k_rec_walk(RecScan r, const BgzfBlk *__restrict__ blk, uint32_t n_blk, const uint64_t *__restrict__ entry, uint64_t *__restrict__ exit_,
+                                                 uint32_t *__restrict__ cnt) {
+  const uint32_t b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= n_blk) return;
+  const uint64_t hi = blk[b].out_off + blk[b].out_len;
+  if (entry[b] == REC_NONE) { exit_[b] = REC_NONE; cnt[b] = 0; return; }
+  rec_walk(r, entry[b], hi, &exit_[b], &cnt[b], nullptr, nullptr);
+}
+// the proof: block b's guess is the true entry iff the nearest block in front of it that has an entry leaves its records exactly there
+// (blocks in between hold no record start: the chain jumps over them); the first entry must be the stream's known first record
+__global__ __launch_bounds__(256) void k_rec_check(RecScan r, const BgzfBlk *__restrict__ blk, uint32_t n_blk, const uint64_t *__restrict__ entry,
+                                                   const uint64_t *__restrict__ exit_, uint32_t *bad) {
+  const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= n_blk) return;
+  const uint64_t lo = blk[b].out_off, hi = lo + blk[b].out_len;
+  int64_t a = (int64_t)b - 1;
+  while (a >= 0 && entry[a] == REC_NONE) a--;
+  const uint64_t came = a >= 0 ? exit_[a] : r.begin;  // where the true chain stands when it reaches this block (if everything in front is right)
+  bool ok;
+  if (entry[b] == REC_NONE) ok = came >= hi || rec_incomplete(r, came);  // no complete record starts here: the chain jumps over the block, or stands at the pending record
+  else ok = came == entry[b];
+  if (hi <= r.begin) ok = true;  // a block of the header prefix
+  (void)lo;
+  if (!ok) atomicAdd(bad, 1u);
+}
+// one thread, in order: entries that the proof rejected are replaced by where the chain really arrives
+__global__ void k_rec_repair(RecScan r, const BgzfBlk *__restrict__ blk, uint32_t n_blk, uint64_t *entry, uint64_t *exit_, uint32_t *cnt) {
+  uint64_t came = r.begin;
+  for (uint32_t b = 0; b < n_blk; b++) {
+    const uint64_t lo = blk[b].out_off, hi = lo + blk[b].out_len;
+    if (hi <= r.begin) continue;
+    const uint64_t want = (came < hi && !rec_incomplete(r, came)) ? came : REC_NONE;
+    (void)lo;
+    if (entry[b] != want && !(want == REC_NONE && entry[b] == came)) {  // (an entry at the pending record itself is as good as none)
+      entry[b] = want;
+      if (want == REC_NONE) { exit_[b] = REC_NONE; cnt[b] = 0; }
+      else rec_walk(r, want, hi, &exit_[b], &cnt[b], nullptr, nullptr);
+    }
+    if (entry[b] != REC_NONE) came = exit_[b];
+  }
+}
+__global__ __launch_bounds__(64) void k_rec_fill(RecScan r, const BgzfBlk *__restrict__ blk, uint32_t n_blk, const uint64_t *__restrict__ entry,
+                                                 const uint32_t *__restrict__ base, uint64_t *__restrict__ rec_off, uint32_t *max_rec) {
+  const uint32_t b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= n_blk || entry[b] == REC_NONE) return;
+  uint64_t ex;
+  uint32_t cn;
+  rec_walk(r, entry[b], blk[b].out_off + blk[b].out_len, &ex, &cn, rec_off + base[b], max_rec);
+}
+__global__ void k_rec_tail(const uint64_t *__restrict__ entry, const uint64_t *__restrict__ exit_, uint32_t n_blk, uint64_t begin, uint64_t *__restrict__ out /* [0] = end of the last complete record */) {
+  uint64_t e = begin;
+  for (int64_t b = (int64_t)n_blk - 1; b >= 0; b--)
+    if (entry[b] != REC_NONE) { e = exit_[b]; break; }
+  out[0] = e;
+}
+
+
+}  // namespace elp
+
+using namespace elp;
+
+// elp_stage_bgzf: see include/elprep_hip.h
+extern "C" int elp_stage_bgzf(elp_ctx *c, const uint8_t *bgzf, uint64_t n_bytes, uint64_t first_record, uint16_t split_id) {
+  if (!c || (!bgzf && n_bytes)) return ELP_ERR_ARG;
+  std::lock_guard<std::mutex> g(c->stage_mu);
+  ELP_HIP(c, hipSetDevice(c->device));
+  if (!c->have_header) return set_error(c, ELP_ERR_ARG, "elp_stage_bgzf: call elp_set_header first");
+  if (c->n_rg && !c->have_rg_ids) return set_error(c, ELP_ERR_ARG, "elp_stage_bgzf: call elp_set_read_group_ids first");
+  if (c->n != c->raw_n) return set_error(c, ELP_ERR_ARG, "elp_stage_bgzf: the context already holds records staged with elp_stage");
+  // ---- the blocks (host: a few fields per 64 KB; utils/bgzf/bgzf-files.go:95-123)
+  std::vector<BgzfBlk> blocks;
+  uint64_t p = 0, inflated = 0;
+  bool saw_eof = false;
+  while (p < n_bytes) {
+    if (p + 18 > n_bytes) return set_error(c, ELP_ERR_DATA, "elp_stage_bgzf: truncated block header at byte %llu", (unsigned long long)p);
+    const uint8_t *h = bgzf + p;
+    if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return set_error(c, ELP_ERR_DATA, "elp_stage_bgzf: not a BGZF block at byte %llu", (unsigned long long)p);
+    const uint32_t xlen = h[10] | ((uint32_t)h[11] << 8);
+    if (p + 12 + xlen > n_bytes) return set_error(c, ELP_ERR_DATA, "elp_stage_bgzf: truncated extra field at byte %llu", (unsigned long long)p);
+    uint32_t bsize = 0;
+    for (uint32_t i = 0; i + 4 <= xlen;) {
+      const uint32_t slen = h[12 + i + 2] | ((uint32_t)h[12 + i + 3] << 8);
+      if (h[12 + i] == 66 && h[12 + i + 1] == 67 && slen == 2 && i + 6 <= xlen) { bsize = (h[12 + i + 4] | ((uint32_t)h[12 + i + 5] << 8)) + 1u; break; }
+      i += 4 + slen;
+    }
+    if (!bsize) return set_error(c, ELP_ERR_DATA, "missing BC extra subfield in BGZF header (block at byte %llu)", (unsigned long long)p);
+    if (bsize < 12 + xlen + 8 || p + bsize > n_bytes) return set_error(c, ELP_ERR_DATA, "elp_stage_bgzf: bad block size at byte %llu", (unsigned long long)p);
+    uint32_t crc, isize;
+    memcpy(&crc, bgzf + p + bsize - 8, 4);
+    memcpy(&isize, bgzf + p + bsize - 4, 4);
+    if (isize > 65536) return set_error(c, ELP_ERR_DATA, "elp_stage_bgzf: block at byte %llu claims %u inflated bytes", (unsigned long long)p, isize);
+    saw_eof = isize == 0;
+    if (isize) blocks.push_back(BgzfBlk{p + 12 + xlen, bsize - 12 - xlen - 8, isize, inflated, crc, 0});
+    inflated += isize;
+    p += bsize;
+  }
+  (void)saw_eof;  // (the end-of-file block is the host's to insist on: a caller may hand over a file in several calls)
+  if (first_record > inflated) return set_error(c, ELP_ERR_ARG, "elp_stage_bgzf: first_record lies behind the inflated data");
+  c->adapted = c->sorted = c->marked = false;
+  c->have_qual_present = false;
+  c->have_snapshot = false;
+  c->flat_index_n = 0;
+  c->uniform_n = ~0ull;
+  if (blocks.empty()) return 0;
+  hipStream_t st = c->stream;
+  static const CrcPow pw = crc_pow_table();
+  // the inflated stream goes to c->raw behind what is there; the records of the header prefix are never referenced
+  const uint64_t raw0 = c->raw_bytes;
+  ELP_TRY(ensure(c, c->raw, raw0 + inflated + 64, true, raw0));
+  // pieces of blocks: <= 192 MiB inflated each (u32 scans and bounded scratch in stage_bam_columns)
+  const uint64_t PIECE = (uint64_t)c->tune.bgzf_piece;
+  uint64_t begin = raw0 + first_record;  // where the next record starts in c->raw
+  size_t b0 = 0;
+  while (b0 < blocks.size()) {
+    size_t b1 = b0;
+    uint64_t in_lo = blocks[b0].in_off, in_hi = in_lo, out_bytes = 0;
+    while (b1 < blocks.size() && (b1 == b0 || out_bytes + blocks[b1].out_len <= PIECE)) {
+      in_hi = blocks[b1].in_off + blocks[b1].in_len;
+      out_bytes += blocks[b1].out_len;
+      b1++;
+    }
+    const uint32_t nb = (uint32_t)(b1 - b0);
+    // compressed bytes + block table of the piece to the device
+    uint8_t *d_in;
+    ELP_TRY(scratch(c, 5, (size_t)(in_hi - in_lo) + 64, &d_in));
+    ELP_HIP(c, hipMemcpyAsync(d_in, bgzf + in_lo, (size_t)(in_hi - in_lo), hipMemcpyHostToDevice, st));
+    std::vector<BgzfBlk> tb(blocks.begin() + b0, blocks.begin() + b1);
+    for (auto &t : tb) { t.in_off -= in_lo; t.out_off += raw0; }
+    // block table | entry | exit (u64 each) | result words | cnt | base (u32 each)
+    static_assert(sizeof(BgzfBlk) == 32, "BgzfBlk is four 64-bit words");
+    uint64_t *wk;
+    ELP_TRY(scratch(c, 6, (size_t)nb * 6 + 8 + (size_t)(nb + 8) + 16, &wk));
+    BgzfBlk *d_blk = reinterpret_cast<BgzfBlk *>(wk);
+    uint64_t *entry = wk + (size_t)nb * 4, *exit_ = entry + nb, *res = exit_ + nb;
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(res + 8), *base = cnt + nb + 8;
+    ELP_HIP(c, hipMemcpyAsync(d_blk, tb.data(), (size_t)nb * sizeof(BgzfBlk), hipMemcpyHostToDevice, st));
+    ELP_HIP(c, hipMemsetAsync(res, 0, 64, st));
+    uint32_t *err = reinterpret_cast<uint32_t *>(res), *bad = err + 1, *max_rec = err + 2;
+    ELP_LAUNCH(c, "stage_bgzf_inflate", k_bgzf_inflate, dim3(blocks_for(nb, 64)), dim3(64), 0, (const uint8_t *)d_in, (const BgzfBlk *)d_blk, nb, c->raw.p, err);
+    ELP_LAUNCH(c, "stage_bgzf_crc", k_bgzf_crc_check, dim3(nb), dim3(256), 0, (const uint8_t *)c->raw.p, (const BgzfBlk *)d_blk, pw, err);
+    const uint64_t end = tb.back().out_off + tb.back().out_len;
+    const RecScan rs{c->raw.p, begin, end, c->n_ref};
+    ELP_LAUNCH(c, "stage_bgzf_guess", k_rec_guess, dim3(nb), dim3(256), 0, rs, (const BgzfBlk *)d_blk, entry, c->tune.bgzf_weak_guess);
+    ELP_LAUNCH(c, "stage_bgzf_walk", k_rec_walk, dim3(blocks_for(nb, 64)), dim3(64), 0, rs, (const BgzfBlk *)d_blk, nb, (const uint64_t *)entry, exit_, cnt);
+    ELP_LAUNCH(c, "stage_bgzf_check", k_rec_check, dim3(blocks_for(nb, 256)), dim3(256), 0, rs, (const BgzfBlk *)d_blk, nb, (const uint64_t *)entry, (const uint64_t *)exit_, bad);
+    uint32_t hr[4];
+    ELP_HIP(c, hipMemcpyAsync(hr, res, sizeof hr, hipMemcpyDeviceToHost, st));
+    ELP_HIP(c, hipStreamSynchronize(st));
+    if (hr[0] & 1u) return set_error(c, ELP_ERR_DATA, "elp_stage_bgzf: a block does not inflate (corrupt DEFLATE data or wrong ISIZE)");
+    if (hr[0] & 2u) return set_error(c, ELP_ERR_DATA, "invalid CRC-32 value for a data block in a BGZF file");
+    if (hr[1]) ELP_LAUNCH(c, "stage_bgzf_repair", k_rec_repair, dim3(1), dim3(1), 0, rs, (const BgzfBlk *)d_blk, nb, entry, exit_, cnt);
+    uint32_t n_rec = 0;
+    ELP_TRY(exclusive_scan_u32(c, cnt, base, nb, &n_rec));
+    if (c->n + n_rec > 0xFFFFFFF0ull) return set_error(c, ELP_ERR_UNSUPPORTED, "more than 2^32-16 records per context");
+    ELP_TRY(ensure(c, c->raw_off, c->n + n_rec + 2, true, c->n + 1));
+    ELP_LAUNCH(c, "stage_bgzf_fill", k_rec_fill, dim3(blocks_for(nb, 64)), dim3(64), 0, rs, (const BgzfBlk *)d_blk, nb, (const uint64_t *)entry, (const uint32_t *)base,
+               c->raw_off.p + c->n, max_rec);
+    ELP_LAUNCH(c, "stage_bgzf_tail", k_rec_tail, dim3(1), dim3(1), 0, (const uint64_t *)entry, (const uint64_t *)exit_, nb, begin, c->raw_off.p + c->n + n_rec);
+    uint64_t rec_end = 0;
+    ELP_HIP(c, hipMemcpyAsync(&rec_end, c->raw_off.p + c->n + n_rec, 8, hipMemcpyDeviceToHost, st));
+    ELP_HIP(c, hipMemcpyAsync(hr, res, sizeof hr, hipMemcpyDeviceToHost, st));
+    ELP_HIP(c, hipStreamSynchronize(st));
+    if (rec_end < begin || rec_end > end) return set_error(c, ELP_ERR_DATA, "elp_stage_bgzf: the alignment records do not chain (block_size fields)");
+    if (n_rec) ELP_TRY(stage_bam_columns(c, n_rec, rec_end - begin, rec_end, hr[2], split_id));
+    begin = rec_end;
+    b0 = b1;
+  }
+  if (begin != raw0 + inflated) return set_error(c, ELP_ERR_DATA, "elp_stage_bgzf: the data ends inside an alignment record (%llu bytes left over)", (unsigned long long)(raw0 + inflated - begin));
+  c->raw_bytes = raw0 + inflated;
+  return 0;
+}
+
+namespace elp {
+}  // namespace elp

@@ -184,6 +184,8 @@ struct elp_ctx {
     int qual_hint = 0;         // 1: no sampled quality hint (tables sized for every quality); 2: hint without the value qual_hint_drop
     int qual_hint_drop = -1;
     int pair_table_slots = 1 << 20;  // cap on the LDS table slots of a pair bucket (mark duplicates); tests shrink it to reach the overflow path
+    long long bgzf_piece = 192ll << 20;  // elp_stage_bgzf: inflated bytes per device pass (tests: small pieces, records pending across them)
+    int bgzf_weak_guess = 0;   // 1: a block guesses its first record start without looking at the bytes (tests: every guess wrong, all repaired)
     int score_kernel = 0;      // 1: the general (flat) score kernel even for read sets of one length
     int mate_path = 0;         // 1: every mate candidate goes through the table path (no neighbour shortcut)
   } tune;
@@ -344,6 +346,9 @@ void group_release(elp_ctx *c);
 int tables_written(elp_ctx *c);  // bqsr.hip: dev_tables were just written on c->stream
 int stage_reserve(elp_ctx *c, uint64_t n, uint64_t qb, uint64_t co, uint64_t sb, uint64_t lb);
 int merge_spread_slots(elp_ctx *groups, elp_ctx *spread, uint64_t **slots_out);  // filter.hip: the merge order as ranks, on the device  // grows the staged columns (ctx.hip)
-int stage_recode_seq(elp_ctx *c, uint64_t from, uint64_t bytes);                               // BAM nibbles -> code nibbles on seq4[from, from + bytes)
+int stage_recode_seq(elp_ctx *c, uint64_t from, uint64_t bytes);
+int stage_bam_columns(elp_ctx *c, uint32_t n_rec, uint64_t piece_bytes, uint64_t raw_end, uint64_t max_raw_rec, uint16_t split_id);  // bam.hip
+uint64_t bgzf_framed_size(uint64_t n_bytes);                                   // bgzf.hip
+int bgzf_frame(elp_ctx *c, const uint8_t *raw, uint64_t n_bytes, uint8_t *out);  // device to device                               // BAM nibbles -> code nibbles on seq4[from, from + bytes)
 
 }  // namespace elp

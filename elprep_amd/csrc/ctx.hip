@@ -412,6 +412,8 @@ int elp_set_tuning(elp_ctx *c, const char *key, int64_t value) {
   const int v = (int)value;
   if (k == "count_kernel") c->tune.count_kernel = v;
   else if (k == "apply_kernel") c->tune.apply_kernel = v;
+  else if (k == "bgzf_piece") { if (value < 1) return set_error(c, ELP_ERR_ARG, "elp_set_tuning: bgzf_piece must be positive"); c->tune.bgzf_piece = value; }
+  else if (k == "bgzf_weak_guess") c->tune.bgzf_weak_guess = v;
   else if (k == "score_kernel") { c->tune.score_kernel = v; c->adapted = false; }
   else if (k == "count3_rlog") c->tune.count3_rlog = v;
   else if (k == "qual_hint") { c->tune.qual_hint = v; c->have_qual_present = false; }

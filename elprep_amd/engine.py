@@ -151,6 +151,19 @@ class Engine:
         self._check(self.L.elp_emit_sorted_bam(self.h, _vp(out), out.size, C.byref(n)))
         return out[:int(n.value)]
 
+    def emit_sorted_bgzf(self) -> np.ndarray:
+        """the sorted records as BGZF blocks (stored DEFLATE, CRC-32 on the device): elp_emit_sorted_bgzf"""
+        n = C.c_uint64()
+        self._check(self.L.elp_emit_sorted_bgzf(self.h, C.c_void_p(0), 0, C.byref(n)))
+        out = np.empty(int(n.value), dtype=np.uint8)
+        self._check(self.L.elp_emit_sorted_bgzf(self.h, _vp(out), out.size, C.byref(n)))
+        return out[:int(n.value)]
+
+    def stage_bgzf(self, bgzf: np.ndarray, first_record: int = 0, split_id: int = 0):
+        """whole BGZF blocks of a BAM file: inflated, checked and cut into records on the device (elp_stage_bgzf)"""
+        bgzf = np.ascontiguousarray(bgzf, dtype=np.uint8)
+        self._check(self.L.elp_stage_bgzf(self.h, _vp(bgzf), bgzf.size, first_record, split_id))
+
     def emit_merged_bam(self, spread: "Engine") -> np.ndarray:
         """this context's (group splits) and `spread`'s sorted outputs as one BAM record stream in the merge's order (elp_emit_merged_bam)"""
         n = C.c_uint64()

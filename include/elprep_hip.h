@@ -136,6 +136,20 @@ void elp_pinned_free(void *p);
 int elp_stage_bam(elp_ctx *ctx, const uint8_t *bytes, uint64_t n_bytes, const uint64_t *rec_off /* n_records + 1, may be NULL */,
                   uint64_t n_records, uint16_t split_id);
 int elp_emit_sorted_bam(elp_ctx *ctx, uint8_t *out, uint64_t cap, uint64_t *n_bytes_out);
+/* BGZF on the device (utils/bgzf/bgzf-files.go).
+ * elp_stage_bgzf = the reader (:95-221) + elp_stage_bam: `bgzf` holds whole BGZF blocks of a BAM file (the file, or a part of it that
+ * starts at a block and ends with a complete alignment record; an end-of-file block is skipped).  The compressed bytes are copied to the
+ * device, every block is inflated by a thread of its own (RFC 1951: stored, fixed and dynamic Huffman blocks), its CRC-32 is checked
+ * ("invalid CRC-32 value for a data block in a BGZF file"), the starts of the alignment records are found on the device (every block
+ * guesses its first record start, walks its records, and the guesses are proven by checking that every block's chain ends where the
+ * next one's begins; wrong guesses are repaired in order), and the records are staged as elp_stage_bam stages them.  first_record = the
+ * offset of the first alignment record in the inflated stream (behind magic, header text and reference dictionary, which the host
+ * parses from the first block(s) itself); 0 for a part that starts with a record.
+ * elp_emit_sorted_bgzf = elp_emit_sorted_bam + the writer (:324-383) at compression level 0: the sorted records as BGZF blocks with
+ * stored DEFLATE data (<= 65280 bytes each), CRC-32 and ISIZE computed on the device.  Inflating the blocks gives elp_emit_sorted_bam's
+ * bytes; a BAM file = the host's header block(s) + these blocks + the 28-byte end-of-file block (:53-62). */
+int elp_stage_bgzf(elp_ctx *ctx, const uint8_t *bgzf, uint64_t n_bytes, uint64_t first_record, uint16_t split_id);
+int elp_emit_sorted_bgzf(elp_ctx *ctx, uint8_t *out, uint64_t cap, uint64_t *n_bytes_out);
 /* The merge of `elprep merge` / `sfm` phase 3 with payloads (MergeSortedFilesSplitPerChromosome, sam/split-merge.go:410-576): the sorted
  * outputs of a context that holds group splits and of the context that holds the spread split as ONE stream of BAM records in the merge's
  * order (elp_merge_spread's slots), gathered in HBM.  Both contexts staged with elp_stage_bam, coordinate-sorted, on one device. */
@@ -295,6 +309,8 @@ int elp_rollback(elp_ctx *ctx);
  * one code path per operator is what every choice here must reproduce bit for bit.
  *   "count_kernel"     1: general BQSR count kernel even for read sets of one length
  *   "apply_kernel"     1: general ApplyBQSR kernel
+ *   "bgzf_piece"       inflated bytes per device pass of elp_stage_bgzf (default 192 MiB)
+ *   "bgzf_weak_guess"  1: elp_stage_bgzf's blocks guess their first record start blindly (every guess is then repaired: same result)
  *   "score_kernel"     1: general Phred-score / low-quality-tail kernel even for read sets of one length
  *   "count3_rlog"      >= 0: log2 of the context-cell replication of the one-length count kernel (measurements)
  *   "qual_hint"        1: no sampled quality hint (the gather sizes its tables on the report-and-retry path)

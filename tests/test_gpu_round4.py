@@ -136,3 +136,109 @@ def test_read_per_lane_score_kernel_against_the_flat_one_and_the_oracle(length, 
         e.close()
     assert np.array_equal(out[0], out[1])
     assert np.array_equal(out[0], orc.BqsrFinal(oq, oc, ox, 500).apply(b, h, 0))
+
+
+# ---- BGZF on the device (elprep_amd/csrc/bgzf.hip; utils/bgzf/bgzf-files.go)
+def _bam_case(n_pairs=3000, seed=2):
+    from tools import synth
+    cfg, b, h, refs, sites = dataset("tiny", n_pairs, seed, 0.02)
+    raw, rec_off = synth.bam_records(b, h.rg_ids)
+    return b, h, raw, rec_off
+
+
+def _members(bz: bytes):
+    """the gzip members of a BGZF stream: (total size from the BC field, inflated bytes) - zlib checks every CRC-32 and ISIZE"""
+    import struct
+    import zlib
+    out, p = [], 0
+    while p < len(bz):
+        assert bz[p:p + 4] == b"\x1f\x8b\x08\x04" and bz[p + 12:p + 16] == b"BC\x02\x00"
+        bsize = struct.unpack_from("<H", bz, p + 16)[0] + 1
+        out.append((bsize, zlib.decompress(bz[p:p + bsize], wbits=31)))
+        p += bsize
+    return out
+
+
+def test_emit_sorted_bgzf_inflates_to_the_record_stream():
+    b, h, raw, rec_off = _bam_case()
+    e = Engine(h)
+    e.set_read_group_ids(h.rg_ids)
+    e.stage_bam(raw, rec_off=rec_off)
+    e.mark_duplicates(True)
+    e.sort_coordinate()
+    want = e.emit_sorted_bam().tobytes()
+    bz = e.emit_sorted_bgzf().tobytes()
+    e.close()
+    mem = _members(bz)
+    assert b"".join(m for _, m in mem) == want
+    assert all(size <= 65536 and 0 < len(m) <= 65280 for size, m in mem)
+    assert [len(m) for _, m in mem[:-1]] == [65280] * (len(mem) - 1) and len(mem) >= 3
+
+
+def _bgzf(stream: bytes, level: int, strategy: int = 0, cut: int = 65280) -> bytes:
+    import struct
+    import zlib
+    out = []
+    for k in range(0, len(stream), cut):
+        part = stream[k:k + cut]
+        co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+        data = co.compress(part) + co.flush()
+        out.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(data) + 25) + data +
+                   struct.pack("<II", zlib.crc32(part), len(part)))
+    out.append(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))  # the end-of-file block
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("level,strategy,cut,tuning", [
+    (6, 0, 65280, None),                                         # dynamic Huffman blocks, records span the BGZF blocks
+    (1, 0, 30011, None),
+    (0, 0, 65280, None),                                         # stored
+    (6, 4, 65280, None),                                         # Z_FIXED: fixed Huffman codes
+    (6, 0, 65280, {"bgzf_piece": 200_000}),                     # many device passes: a record pending at the end of each
+    (6, 0, 4099, {"bgzf_weak_guess": 1, "bgzf_piece": 1 << 20}),  # every guess wrong: the repair pass finds the same starts
+])
+def test_stage_bgzf_gives_the_records_of_stage_bam(level, strategy, cut, tuning):
+    import numpy as _np
+    b, h, raw, rec_off = _bam_case()
+    header = bytes(_np.random.default_rng(1).integers(0, 256, 1234, dtype=_np.uint8))  # stands for magic + header text + dictionary
+    bz = _np.frombuffer(_bgzf(header + raw.tobytes(), level, strategy, cut), dtype=_np.uint8)
+    outs = []
+    for how in ("bam", "bgzf"):
+        e = Engine(h, tuning=tuning)
+        e.set_read_group_ids(h.rg_ids)
+        if how == "bam":
+            e.stage_bam(raw, rec_off=rec_off)
+        else:
+            e.stage_bgzf(bz, first_record=len(header))
+        assert e.n == b.n
+        flags = e.mark_duplicates(True)
+        perm = e.sort_coordinate()
+        outs.append((flags, perm, e.emit_sorted_bam().tobytes()))
+        e.close()
+    assert _np.array_equal(outs[0][0], outs[1][0]) and _np.array_equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
+    assert _np.array_equal(outs[0][0], orc.mark_duplicates(b, h))
+
+
+def test_stage_bgzf_reports_corrupt_blocks():
+    import numpy as _np
+    from elprep_amd.engine import ElpError
+    b, h, raw, rec_off = _bam_case(600)
+    good = bytearray(_bgzf(raw.tobytes(), 6))
+    for what, at, msg in (("crc", None, "invalid CRC-32"), ("data", 40, "does not inflate|invalid CRC-32")):
+        bad = bytearray(good)
+        if what == "crc":
+            import struct
+            bsize = struct.unpack_from("<H", bad, 16)[0] + 1
+            bad[bsize - 8] ^= 0x55
+        else:
+            bad[at] ^= 0xFF
+        e = Engine(h)
+        e.set_read_group_ids(h.rg_ids)
+        with pytest.raises(ElpError, match=msg):
+            e.stage_bgzf(_np.frombuffer(bytes(bad), dtype=_np.uint8))
+        e.close()
+    e = Engine(h)
+    e.set_read_group_ids(h.rg_ids)
+    with pytest.raises(ElpError, match="ends inside an alignment record"):
+        e.stage_bgzf(_np.frombuffer(_bgzf(raw.tobytes()[:-7], 6), dtype=_np.uint8))
+    e.close()
