@@ -566,6 +566,47 @@ def pcie_inclusive(cfg, hdr, n_reads, ms_per_step, n_main):
            # one pass of the path with both transfers, at the main run's step time per read
            "end_to_end_Mreads_per_s": round(n / (t_in + t_out + ms_per_step * 1e-3 * n / max(n_main, 1)) / 1e6, 2)}
     e.close()
+    # the BGZF route (round 4): the COMPRESSED blocks cross PCIe, the device inflates them, finds the records and stages them
+    # (elp_stage_bgzf); on the way out the device frames the sorted records as BGZF blocks (elp_emit_sorted_bgzf: stored DEFLATE + CRC-32).
+    # The compressed input is made here with zlib level 1 on a thread pool (it stands for the file on disk)
+    try:
+        import struct
+        import zlib
+        from concurrent.futures import ThreadPoolExecutor
+        nb_reads = min(n, 4_000_000)
+        nbytes = int(rec_off[nb_reads])
+        cut = 65280
+
+        def member(k):
+            part = bytes(buf[k:min(k + cut, nbytes)])
+            co = zlib.compressobj(1, zlib.DEFLATED, -15)
+            data = co.compress(part) + co.flush()
+            return b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(data) + 25) + data + struct.pack("<II", zlib.crc32(part), len(part))
+        with ThreadPoolExecutor(max(1, min(16, effective_cores()))) as pool:
+            bz = np.frombuffer(b"".join(pool.map(member, range(0, nbytes, cut))), dtype=np.uint8)
+        e = Engine(hdr, 0)
+        e.set_read_group_ids(hdr.rg_ids)
+        e.stage_bgzf(bz)  # first call: device allocations
+        e.sync()
+        e.reset()
+        t0 = time.perf_counter()
+        e.stage_bgzf(bz)
+        e.sync()
+        t_bz_in = time.perf_counter() - t0
+        e.mark_duplicates(True, fetch=False)
+        e.sort_coordinate(fetch=False)
+        e.emit_sorted_bgzf()
+        t0 = time.perf_counter()
+        got_bz = e.emit_sorted_bgzf()
+        t_bz_out = time.perf_counter() - t0
+        e.close()
+        res.update({"bgzf_workload": f"{nb_reads} reads: {bz.size} bytes of BGZF blocks (zlib level 1, {bz.size / nbytes:.2f} of the inflated size) from pageable memory in, "
+                                     f"{got_bz.size} bytes of BGZF blocks (stored DEFLATE) out",
+                    "stage_bgzf_Mreads_per_s": round(nb_reads / t_bz_in / 1e6, 2), "stage_bgzf_inflated_GB_per_s": round(nbytes / t_bz_in / 1e9, 2),
+                    "emit_sorted_bgzf_Mreads_per_s": round(nb_reads / t_bz_out / 1e6, 2),
+                    "end_to_end_bgzf_Mreads_per_s": round(nb_reads / (t_bz_in + t_bz_out + ms_per_step * 1e-3 * nb_reads / max(n_main, 1)) / 1e6, 2)})
+    except Exception as ex:  # a side measurement must not cost the main line
+        res["bgzf_error"] = repr(ex)
     del buf, out
     L.elp_pinned_free(ptr)
     L.elp_pinned_free(out_ptr)

@@ -143,6 +143,8 @@ struct elp_ctx {
   void *comm = nullptr;  // ncclComm_t
   int (*xport)(void *, int64_t *, size_t) = nullptr;  // caller's transport instead of RCCL (elp_group_init_transport)
   void *xport_user = nullptr;
+  int (*p2p)(void *, int, const void *, size_t, int, void *, size_t) = nullptr;  // caller's send-receive (elp_group_set_p2p)
+  void *p2p_user = nullptr;
   int group_rank = 0, group_world = 1;
 
   // records staged from BAM bytes (bam.hip): the inflated records stay in HBM, elp_emit_sorted_bam reads bases and tags from them
@@ -343,6 +345,7 @@ int ensure_uniform_len(elp_ctx *c);  // sort.hip: c->uniform_len
 int ensure_qual_present(elp_ctx *c, bool exact = false);  // exact: scan the whole column instead of a sample
 int fetch_err(elp_ctx *c, uint32_t *words /* 4 */);
 void group_release(elp_ctx *c);
+int group_sendrecv(elp_ctx *c, int send_peer, const void *send_dev, size_t send_bytes, int recv_peer, void *recv_dev, size_t recv_bytes);  // group.hip
 int tables_written(elp_ctx *c);  // bqsr.hip: dev_tables were just written on c->stream
 int stage_reserve(elp_ctx *c, uint64_t n, uint64_t qb, uint64_t co, uint64_t sb, uint64_t lb);
 int merge_spread_slots(elp_ctx *groups, elp_ctx *spread, uint64_t **slots_out);  // filter.hip: the merge order as ranks, on the device  // grows the staged columns (ctx.hip)

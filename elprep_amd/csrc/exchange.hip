@@ -103,6 +103,148 @@ static int peer_copy(elp_ctx *dst, void *to, elp_ctx *src, const void *from, siz
 
 using namespace elp;
 
+// ---- a piece of records, gathered on the source GPU: the fixed columns (eleven arrays, each n16 elements apart), the five
+// variable-length pools (64-byte aligned sections) and the exclusive scans of the slice lengths (XV x (n + 1)); all in src's scratch
+struct Gathered {
+  uint64_t n = 0;
+  uint32_t total[XV] = {0, 0, 0, 0, 0};
+  uint32_t hc[XC_N] = {0};
+  bool raw = false;
+  uint8_t *fx = nullptr;   // fixed block, gathered_fixed_bytes(n)
+  uint8_t *pool = nullptr; // gathered_pool_bytes(total)
+  uint32_t *excl = nullptr;
+};
+static size_t n16_of(uint64_t n) { return (size_t)((n + 15) & ~(uint64_t)15); }
+static size_t gathered_fixed_bytes(uint64_t n) { return n16_of(n) * 32; }  // 5 x 4 + 4 + 3 x 2 + 2 x 1 bytes per record
+static size_t pool_section(size_t bytes) { return (bytes + 63) & ~(size_t)63; }
+static size_t gathered_pool_bytes(const uint32_t *total) {
+  return pool_section(total[0]) + pool_section((size_t)total[1] * 4) + pool_section(total[2]) + pool_section(total[3]) + pool_section(total[4]);
+}
+static XFixed fixed_view(uint8_t *fx, uint64_t n) {
+  const size_t n16 = n16_of(n);
+  XFixed F;
+  uint8_t *p = fx;
+  F.refid = (int32_t *)p; p += n16 * 4; F.pos = (int32_t *)p; p += n16 * 4; F.next_refid = (int32_t *)p; p += n16 * 4; F.pnext = (int32_t *)p; p += n16 * 4;
+  F.tlen = (int32_t *)p; p += n16 * 4; F.l_seq = (uint32_t *)p; p += n16 * 4; F.flag = (uint16_t *)p; p += n16 * 2; F.rgid = (uint16_t *)p; p += n16 * 2;
+  F.split = (uint16_t *)p; p += n16 * 2; F.mapq = p; p += n16; F.has_sr = p;
+  return F;
+}
+static void pool_view(uint8_t *pool, const uint32_t *total, uint8_t **pv) {
+  const size_t sz[XV] = {total[0], (size_t)total[1] * 4, total[2], total[3], total[4]};
+  uint8_t *p = pool;
+  for (int v = 0; v < XV; v++) { pv[v] = p; p += pool_section(sz[v]); }
+}
+
+// source GPU: lengths + fixed columns, scans, slices.  err_ctx = the context an error is reported on
+static int gather_piece(elp_ctx *err_ctx, elp_ctx *src, const uint32_t *idx, uint64_t n, int new_split, int tag_sr, bool raw, Gathered *G) {
+  ELP_HIP(src, hipSetDevice(src->device));
+  hipStream_t ss = src->stream;
+  uint32_t *w;  // idx | len[XV][n] | excl[XV][n + 1] | counters
+  ELP_TRY(scratch(src, 6, n + (size_t)XV * n + (size_t)XV * (n + 1) + 64, &w));
+  uint32_t *d_idx = w, *len = w + n, *excl = len + (size_t)XV * n, *ctr = excl + (size_t)XV * (n + 1);
+  ELP_HIP(src, hipMemcpyAsync(d_idx, idx, n * 4, hipMemcpyHostToDevice, ss));
+  ELP_HIP(src, hipMemsetAsync(ctr, 0, XC_N * 4, ss));
+  uint8_t *fx;
+  ELP_TRY(scratch(src, 5, gathered_fixed_bytes(n) + 256, &fx));
+  const XFixed F = fixed_view(fx, n);
+  XSrc S{src->n, src->refid.p, src->pos.p, src->next_refid.p, src->pnext.p, src->tlen.p, src->flag.p, src->rgid.p, src->split.p, src->mapq.p, src->has_sr.p,
+         src->l_seq.p, {src->qname_off.p, src->cigar_off.p, src->seq_off.p, src->qual_off.p, raw ? src->raw_off.p : nullptr}};
+  hipLaunchKernelGGL(k_x_fixed, dim3(blocks_for(n, 256)), dim3(256), 0, ss, n, (const uint32_t *)d_idx, S, F, len, new_split, tag_sr, ctr);
+  ELP_HIP(src, hipGetLastError());
+  for (int v = 0; v < XV; v++) {
+    G->total[v] = 0;
+    if (v == 4 && !raw) continue;
+    ELP_TRY(exclusive_scan_u32(src, len + (size_t)v * n, excl + (size_t)v * (n + 1), n, &G->total[v]));  // (a slice total beyond 2^32: see the check below)
+  }
+  ELP_HIP(src, hipMemcpyAsync(G->hc, ctr, sizeof G->hc, hipMemcpyDeviceToHost, ss));
+  ELP_HIP(src, hipStreamSynchronize(ss));
+  if (G->hc[XC_BAD]) return set_error(err_ctx, ELP_ERR_ARG, "elp_copy_records: %u indices are not records of the source context", G->hc[XC_BAD]);
+  if (G->hc[XC_QNAME] > elp_ctx::MAX_QNAME) return set_error(err_ctx, ELP_ERR_UNSUPPORTED, "QNAME of %u bytes (limit %u)", G->hc[XC_QNAME], elp_ctx::MAX_QNAME);
+  // (the scans are 32-bit: a call moves at most 4 GiB of any one column - ~25 M reads of 150 bases; callers move larger sets in pieces)
+  if ((uint64_t)n * (uint64_t)std::max<uint32_t>(G->hc[XC_LSEQ], 1) >= 0xFFFFFFFFull || (raw && (uint64_t)n * src->max_raw_rec >= 0xFFFFFFFFull))
+    return set_error(err_ctx, ELP_ERR_UNSUPPORTED, "elp_copy_records: more than 4 GiB of one column in one call: move the records in pieces");
+  uint8_t *pool;
+  ELP_TRY(scratch(src, 4, gathered_pool_bytes(G->total) + 64, &pool));
+  uint8_t *pv[XV];
+  pool_view(pool, G->total, pv);
+  const unsigned vgrid = blocks_for(n * 64, 256);
+  hipLaunchKernelGGL(k_x_var<uint8_t>, dim3(vgrid), dim3(256), 0, ss, n, (const uint32_t *)d_idx, (const uint64_t *)src->qname_off.p, (const uint8_t *)src->qname.p,
+                     (const uint32_t *)excl, pv[0], src->n);
+  hipLaunchKernelGGL(k_x_var<uint32_t>, dim3(vgrid), dim3(256), 0, ss, n, (const uint32_t *)d_idx, (const uint64_t *)src->cigar_off.p, (const uint32_t *)src->cigar.p,
+                     (const uint32_t *)(excl + (n + 1)), (uint32_t *)pv[1], src->n);
+  hipLaunchKernelGGL(k_x_var<uint8_t>, dim3(vgrid), dim3(256), 0, ss, n, (const uint32_t *)d_idx, (const uint64_t *)src->seq_off.p, (const uint8_t *)src->seq4.p,
+                     (const uint32_t *)(excl + 2 * (n + 1)), pv[2], src->n);
+  hipLaunchKernelGGL(k_x_var<uint8_t>, dim3(vgrid), dim3(256), 0, ss, n, (const uint32_t *)d_idx, (const uint64_t *)src->qual_off.p, (const uint8_t *)src->qual.p,
+                     (const uint32_t *)(excl + 3 * (n + 1)), pv[3], src->n);
+  if (raw)
+    hipLaunchKernelGGL(k_x_var<uint8_t>, dim3(vgrid), dim3(256), 0, ss, n, (const uint32_t *)d_idx, (const uint64_t *)src->raw_off.p, (const uint8_t *)src->raw.p,
+                       (const uint32_t *)(excl + 4 * (n + 1)), pv[4], src->n);
+  ELP_HIP(src, hipGetLastError());
+  G->n = n; G->raw = raw; G->fx = fx; G->pool = pool; G->excl = excl;
+  return 0;
+}
+
+// destination: room, then the copies - from `from`'s device and on its stream (the gathering context, or dst itself for a piece that
+// arrived through the group) -, then the offset columns and the commit (as elp_stage does)
+static int append_piece(elp_ctx *dst, elp_ctx *from, const Gathered &G, uint64_t src_max_raw_rec) {
+  const uint64_t n = G.n;
+  const bool raw = G.raw;
+  const uint32_t *total = G.total, *hc = G.hc;
+  ELP_HIP(dst, hipSetDevice(dst->device));
+  ELP_TRY(stage_reserve(dst, dst->n + n, dst->qname_bytes + total[0], dst->cigar_ops + total[1], dst->seq_bytes + total[2], dst->qual_bytes + total[3]));
+  if (raw) {
+    const bool keep = dst->raw_n > 0;
+    ELP_TRY(ensure(dst, dst->raw, dst->raw_bytes + total[4] + 64, keep, dst->raw_bytes));
+    ELP_TRY(ensure(dst, dst->raw_off, dst->n + n + 1, keep, dst->raw_n + 1));
+  }
+  uint32_t *dx;  // the exclusive scans, on the destination GPU
+  ELP_TRY(ensure(dst, dst->stage_tmp, ((size_t)XV * (n + 1) + 1) / 2 + 8));
+  dx = reinterpret_cast<uint32_t *>(dst->stage_tmp.p);
+  ELP_HIP(dst, hipStreamSynchronize(dst->stream));  // (the destination's columns may just have moved to larger allocations on its stream)
+  ELP_HIP(from, hipSetDevice(from->device));
+  const uint64_t at = dst->n;
+  const XFixed F = fixed_view(G.fx, n);
+  uint8_t *pv[XV];
+  pool_view(G.pool, total, pv);
+#define XCOPY(field, T) ELP_TRY(peer_copy(dst, dst->field.p + at, from, F.field, n * sizeof(T)))
+  XCOPY(refid, int32_t); XCOPY(pos, int32_t); XCOPY(next_refid, int32_t); XCOPY(pnext, int32_t); XCOPY(tlen, int32_t); XCOPY(l_seq, uint32_t);
+  XCOPY(flag, uint16_t); XCOPY(rgid, uint16_t); XCOPY(split, uint16_t); XCOPY(mapq, uint8_t); XCOPY(has_sr, uint8_t);
+#undef XCOPY
+  ELP_TRY(peer_copy(dst, dst->qname.p + dst->qname_bytes, from, pv[0], total[0]));
+  ELP_TRY(peer_copy(dst, dst->cigar.p + dst->cigar_ops, from, pv[1], (size_t)total[1] * 4));
+  ELP_TRY(peer_copy(dst, dst->seq4.p + dst->seq_bytes, from, pv[2], total[2]));
+  ELP_TRY(peer_copy(dst, dst->qual.p + dst->qual_bytes, from, pv[3], total[3]));
+  if (raw) ELP_TRY(peer_copy(dst, dst->raw.p + dst->raw_bytes, from, pv[4], total[4]));
+  ELP_TRY(peer_copy(dst, dx, from, G.excl, (size_t)XV * (n + 1) * 4));
+  ELP_HIP(from, hipStreamSynchronize(from->stream));
+  ELP_HIP(dst, hipSetDevice(dst->device));
+  {
+    struct { uint64_t *out; uint64_t base; int v; } oc[XV] = {{dst->qname_off.p + at, dst->qname_bytes, 0}, {dst->cigar_off.p + at, dst->cigar_ops, 1},
+                                                              {dst->seq_off.p + at, dst->seq_bytes, 2}, {dst->qual_off.p + at, dst->qual_bytes, 3},
+                                                              {raw ? dst->raw_off.p + at : nullptr, dst->raw_bytes, 4}};
+    for (auto &o : oc) {
+      if (!o.out) continue;
+      hipLaunchKernelGGL(k_x_offsets, dim3(blocks_for(n + 1, 256)), dim3(256), 0, dst->stream, n + 1, (const uint32_t *)(dx + (size_t)o.v * (n + 1)), total[o.v], o.base, o.out);
+    }
+    ELP_HIP(dst, hipGetLastError());
+  }
+  ELP_HIP(dst, hipStreamSynchronize(dst->stream));
+  dst->n += n; dst->qname_bytes += total[0]; dst->cigar_ops += total[1]; dst->seq_bytes += total[2]; dst->qual_bytes += total[3];
+  if (raw) { dst->raw_n = dst->n; dst->raw_bytes += total[4]; dst->max_raw_rec = std::max(dst->max_raw_rec, src_max_raw_rec); }
+  dst->n_sr += hc[XC_NSR];
+  dst->n_filtered += hc[XC_NFILT];
+  dst->max_split = std::max(dst->max_split, hc[XC_SPLIT]);
+  dst->max_qname_len = std::max(dst->max_qname_len, hc[XC_QNAME]);
+  dst->max_l_seq = std::max(dst->max_l_seq, hc[XC_LSEQ]);
+  dst->max_pos = std::max(dst->max_pos, hc[XC_POS]);
+  dst->adapted = dst->sorted = dst->marked = false;
+  dst->have_qual_present = false;
+  dst->have_snapshot = false;
+  dst->flat_index_n = 0;
+  dst->uniform_n = ~0ull;
+  return 0;
+}
+
 static int copy_piece(elp_ctx *dst, elp_ctx *src, const uint32_t *idx, uint64_t n, int new_split, int tag_sr);
 
 // the call moves its records in pieces whose columns stay below 4 GiB each (the gather's offsets are scanned in 32 bits)
@@ -130,116 +272,84 @@ static int copy_piece(elp_ctx *dst, elp_ctx *src, const uint32_t *idx, uint64_t 
   const bool src_raw = src->raw_n == src->n && src->n > 0, dst_raw = dst->raw_n == dst->n && (dst->n > 0 || src_raw);
   if ((src->raw_n && !src_raw) || (dst->raw_n && !dst_raw) || (dst->n > 0 && (dst->raw_n > 0) != src_raw))
     return set_error(dst, ELP_ERR_UNSUPPORTED, "elp_copy_records: either both contexts hold the inflated BAM records of all their reads (elp_stage_bam) or neither does");
-  const bool raw = src_raw;
+  Gathered G;
+  ELP_TRY(gather_piece(dst, src, idx, n, new_split, tag_sr, src_raw, &G));
+  return append_piece(dst, src, G, src->max_raw_rec);
+}
 
-  // ---- source GPU: lengths + fixed columns, scans, slices
-  ELP_HIP(src, hipSetDevice(src->device));
-  hipStream_t ss = src->stream;
-  uint32_t *w;  // idx | len[XV][n] | excl[XV][n + 1] | counters
-  ELP_TRY(scratch(src, 6, n + (size_t)XV * n + (size_t)XV * (n + 1) + 64, &w));
-  uint32_t *d_idx = w, *len = w + n, *excl = len + (size_t)XV * n, *ctr = excl + (size_t)XV * (n + 1);
-  ELP_HIP(src, hipMemcpyAsync(d_idx, idx, n * 4, hipMemcpyHostToDevice, ss));
-  ELP_HIP(src, hipMemsetAsync(ctr, 0, XC_N * 4, ss));
-  uint8_t *fx;
-  ELP_TRY(scratch(src, 5, n * 40 + 256, &fx));  // 5 x 4 + 3 x 2 + 2 x 1 + 4 = 32 bytes per record, every array 16-byte aligned
-  const size_t n16 = (n + 15) & ~(size_t)15;
-  XFixed F;
-  {
-    uint8_t *p = fx;
-    F.refid = (int32_t *)p; p += n16 * 4; F.pos = (int32_t *)p; p += n16 * 4; F.next_refid = (int32_t *)p; p += n16 * 4; F.pnext = (int32_t *)p; p += n16 * 4;
-    F.tlen = (int32_t *)p; p += n16 * 4; F.l_seq = (uint32_t *)p; p += n16 * 4; F.flag = (uint16_t *)p; p += n16 * 2; F.rgid = (uint16_t *)p; p += n16 * 2;
-    F.split = (uint16_t *)p; p += n16 * 2; F.mapq = p; p += n16; F.has_sr = p;
+// ------------------------------------------------------------------ between PROCESSES: one step of the split phase's all-to-all
+// elp_exchange_records: the records `idx` of `src` go to rank send_peer of the device group, the records rank recv_peer selected for this
+// rank in ITS matching call are appended to `dst` (either side may be absent: peer -1).  The piece is gathered on the source GPU as for
+// elp_copy_records; a 128-byte header (counts, totals, limits) is exchanged first, then the three payload blocks - fixed columns, pools,
+// scans - device to device: ncclSend / ncclRecv inside one ncclGroupStart / ncclGroupEnd per message (RCCL over xGMI), or the group's own
+// send-receive callback through page-locked memory (elp_group_set_p2p: a host with its own communicator, and the tests on one GPU).
+extern "C" int elp_exchange_records(elp_ctx *src, int send_peer, const uint32_t *idx, uint64_t n, int new_split, int tag_sr, elp_ctx *dst, int recv_peer) {
+  // the context that belongs to the device group: the one of the two that has a communicator / a transport
+  elp_ctx *g = (src && (src->comm || src->p2p)) ? src : ((dst && (dst->comm || dst->p2p)) ? dst : (src ? src : dst));
+  if (!g || (send_peer >= 0 && (!src || (!idx && n))) || (recv_peer >= 0 && !dst)) return set_error(g, ELP_ERR_ARG, "elp_exchange_records: bad arguments");
+  if (send_peer < 0) n = 0;
+  if (new_split > 0xFFFF) return set_error(g, ELP_ERR_ARG, "elp_exchange_records: split id %d", new_split);
+  constexpr int HDR = 16;
+  constexpr uint64_t MAGIC = 0x454c505845434847ull;
+  // ---- what goes out
+  Gathered G;
+  uint64_t h_out[HDR] = {0}, h_in[HDR] = {0};
+  if (send_peer >= 0) {
+    std::lock_guard<std::mutex> lk(src->stage_mu);
+    const bool raw = src->raw_n == src->n && src->n > 0;
+    if (src->raw_n && !raw) return set_error(g, ELP_ERR_UNSUPPORTED, "elp_exchange_records: some but not all records of the source hold their inflated BAM bytes");
+    if (n) ELP_TRY(gather_piece(g, src, idx, n, new_split, tag_sr, raw, &G));
+    h_out[0] = n;
+    for (int v = 0; v < XV; v++) h_out[1 + v] = G.total[v];
+    for (int k = 0; k < XC_N; k++) h_out[6 + k] = G.hc[k];
+    h_out[13] = n ? (G.raw ? 1 : 0) : 2;  // 2: no records, either kind of destination is fine
+    h_out[14] = src->max_raw_rec;
+    h_out[15] = MAGIC;
   }
-  XSrc S{src->n, src->refid.p, src->pos.p, src->next_refid.p, src->pnext.p, src->tlen.p, src->flag.p, src->rgid.p, src->split.p, src->mapq.p, src->has_sr.p,
-         src->l_seq.p, {src->qname_off.p, src->cigar_off.p, src->seq_off.p, src->qual_off.p, raw ? src->raw_off.p : nullptr}};
-  hipLaunchKernelGGL(k_x_fixed, dim3(blocks_for(n, 256)), dim3(256), 0, ss, n, (const uint32_t *)d_idx, S, F, len, new_split, tag_sr, ctr);
-  ELP_HIP(src, hipGetLastError());
-  uint32_t total[XV] = {0, 0, 0, 0, 0};
-  for (int v = 0; v < XV; v++) {
-    if (v == 4 && !raw) continue;
-    ELP_TRY(exclusive_scan_u32(src, len + (size_t)v * n, excl + (size_t)v * (n + 1), n, &total[v]));  // (a slice total beyond 2^32: see the check below)
-  }
-  uint32_t hc[XC_N];
-  ELP_HIP(src, hipMemcpyAsync(hc, ctr, sizeof hc, hipMemcpyDeviceToHost, ss));
-  ELP_HIP(src, hipStreamSynchronize(ss));
-  if (hc[XC_BAD]) return set_error(dst, ELP_ERR_ARG, "elp_copy_records: %u indices are not records of the source context", hc[XC_BAD]);
-  if (hc[XC_QNAME] > elp_ctx::MAX_QNAME) return set_error(dst, ELP_ERR_UNSUPPORTED, "QNAME of %u bytes (limit %u)", hc[XC_QNAME], elp_ctx::MAX_QNAME);
-  // (the scans are 32-bit: a call moves at most 4 GiB of any one column - ~25 M reads of 150 bases; callers move larger sets in pieces)
-  if ((uint64_t)n * (uint64_t)std::max<uint32_t>(hc[XC_LSEQ], 1) >= 0xFFFFFFFFull || (raw && (uint64_t)n * src->max_raw_rec >= 0xFFFFFFFFull))
-    return set_error(dst, ELP_ERR_UNSUPPORTED, "elp_copy_records: more than 4 GiB of one column in one call: move the records in pieces");
-  uint8_t *pool;
-  const size_t pool_bytes = (size_t)total[0] + (size_t)total[1] * 4 + (size_t)total[2] + (size_t)total[3] + (size_t)total[4] + 5 * 64;
-  ELP_TRY(scratch(src, 4, pool_bytes, &pool));
-  uint8_t *pv[XV];
-  {
-    uint8_t *p = pool;
-    const size_t sz[XV] = {total[0], (size_t)total[1] * 4, total[2], total[3], total[4]};
-    for (int v = 0; v < XV; v++) { pv[v] = p; p += (sz[v] + 63) & ~(size_t)63; }
-  }
-  const unsigned vgrid = blocks_for(n * 64, 256);
-  hipLaunchKernelGGL(k_x_var<uint8_t>, dim3(vgrid), dim3(256), 0, ss, n, (const uint32_t *)d_idx, (const uint64_t *)src->qname_off.p, (const uint8_t *)src->qname.p,
-                     (const uint32_t *)excl, pv[0], src->n);
-  hipLaunchKernelGGL(k_x_var<uint32_t>, dim3(vgrid), dim3(256), 0, ss, n, (const uint32_t *)d_idx, (const uint64_t *)src->cigar_off.p, (const uint32_t *)src->cigar.p,
-                     (const uint32_t *)(excl + (n + 1)), (uint32_t *)pv[1], src->n);
-  hipLaunchKernelGGL(k_x_var<uint8_t>, dim3(vgrid), dim3(256), 0, ss, n, (const uint32_t *)d_idx, (const uint64_t *)src->seq_off.p, (const uint8_t *)src->seq4.p,
-                     (const uint32_t *)(excl + 2 * (n + 1)), pv[2], src->n);
-  hipLaunchKernelGGL(k_x_var<uint8_t>, dim3(vgrid), dim3(256), 0, ss, n, (const uint32_t *)d_idx, (const uint64_t *)src->qual_off.p, (const uint8_t *)src->qual.p,
-                     (const uint32_t *)(excl + 3 * (n + 1)), pv[3], src->n);
-  if (raw)
-    hipLaunchKernelGGL(k_x_var<uint8_t>, dim3(vgrid), dim3(256), 0, ss, n, (const uint32_t *)d_idx, (const uint64_t *)src->raw_off.p, (const uint8_t *)src->raw.p,
-                       (const uint32_t *)(excl + 4 * (n + 1)), pv[4], src->n);
-  ELP_HIP(src, hipGetLastError());
-
-  // ---- destination: room, then the copies (on the source's stream, device to device), then the offset columns
-  ELP_HIP(dst, hipSetDevice(dst->device));
-  ELP_TRY(stage_reserve(dst, dst->n + n, dst->qname_bytes + total[0], dst->cigar_ops + total[1], dst->seq_bytes + total[2], dst->qual_bytes + total[3]));
-  if (raw) {
-    const bool keep = dst->raw_n > 0;
-    ELP_TRY(ensure(dst, dst->raw, dst->raw_bytes + total[4] + 64, keep, dst->raw_bytes));
-    ELP_TRY(ensure(dst, dst->raw_off, dst->n + n + 1, keep, dst->raw_n + 1));
-  }
-  uint32_t *dx;  // the exclusive scans, on the destination GPU
-  ELP_TRY(ensure(dst, dst->stage_tmp, ((size_t)XV * (n + 1) + 1) / 2 + 8));
-  dx = reinterpret_cast<uint32_t *>(dst->stage_tmp.p);
-  ELP_HIP(dst, hipStreamSynchronize(dst->stream));  // (the destination's columns may just have moved to larger allocations on its stream)
-  ELP_HIP(src, hipSetDevice(src->device));
-  const uint64_t at = dst->n;
-#define XCOPY(field, T) ELP_TRY(peer_copy(dst, dst->field.p + at, src, F.field, n * sizeof(T)))
-  XCOPY(refid, int32_t); XCOPY(pos, int32_t); XCOPY(next_refid, int32_t); XCOPY(pnext, int32_t); XCOPY(tlen, int32_t); XCOPY(l_seq, uint32_t);
-  XCOPY(flag, uint16_t); XCOPY(rgid, uint16_t); XCOPY(split, uint16_t); XCOPY(mapq, uint8_t); XCOPY(has_sr, uint8_t);
-#undef XCOPY
-  ELP_TRY(peer_copy(dst, dst->qname.p + dst->qname_bytes, src, pv[0], total[0]));
-  ELP_TRY(peer_copy(dst, dst->cigar.p + dst->cigar_ops, src, pv[1], (size_t)total[1] * 4));
-  ELP_TRY(peer_copy(dst, dst->seq4.p + dst->seq_bytes, src, pv[2], total[2]));
-  ELP_TRY(peer_copy(dst, dst->qual.p + dst->qual_bytes, src, pv[3], total[3]));
-  if (raw) ELP_TRY(peer_copy(dst, dst->raw.p + dst->raw_bytes, src, pv[4], total[4]));
-  ELP_TRY(peer_copy(dst, dx, src, excl, (size_t)XV * (n + 1) * 4));
-  ELP_HIP(src, hipStreamSynchronize(ss));
-  ELP_HIP(dst, hipSetDevice(dst->device));
-  {
-    struct { uint64_t *out; uint64_t base; int v; } oc[XV] = {{dst->qname_off.p + at, dst->qname_bytes, 0}, {dst->cigar_off.p + at, dst->cigar_ops, 1},
-                                                              {dst->seq_off.p + at, dst->seq_bytes, 2}, {dst->qual_off.p + at, dst->qual_bytes, 3},
-                                                              {raw ? dst->raw_off.p + at : nullptr, dst->raw_bytes, 4}};
-    for (auto &o : oc) {
-      if (!o.out) continue;
-      hipLaunchKernelGGL(k_x_offsets, dim3(blocks_for(n + 1, 256)), dim3(256), 0, dst->stream, n + 1, (const uint32_t *)(dx + (size_t)o.v * (n + 1)), total[o.v], o.base, o.out);
+  // ---- headers
+  elp_ctx *sc = send_peer >= 0 ? src : dst, *rc = recv_peer >= 0 ? dst : src;
+  uint64_t *d_hdr;  // out | in, on the group context's device
+  ELP_HIP(g, hipSetDevice(g->device));
+  ELP_TRY(scratch(g, 7, 2 * HDR + 8, &d_hdr));
+  ELP_HIP(g, hipMemcpyAsync(d_hdr, h_out, sizeof h_out, hipMemcpyHostToDevice, g->stream));
+  ELP_HIP(g, hipStreamSynchronize(sc->stream));  // (the gather ran on the source's stream)
+  ELP_TRY(group_sendrecv(g, send_peer, d_hdr, sizeof h_out, recv_peer, d_hdr + HDR, sizeof h_in));
+  ELP_HIP(g, hipMemcpyAsync(h_in, d_hdr + HDR, sizeof h_in, hipMemcpyDeviceToHost, g->stream));
+  ELP_HIP(g, hipStreamSynchronize(g->stream));
+  (void)rc;
+  Gathered R;
+  if (recv_peer >= 0) {
+    if (h_in[15] != MAGIC) return set_error(g, ELP_ERR_DATA, "elp_exchange_records: rank %d did not send a record header (calls out of step?)", recv_peer);
+    R.n = h_in[0];
+    for (int v = 0; v < XV; v++) R.total[v] = (uint32_t)h_in[1 + v];
+    for (int k = 0; k < XC_N; k++) R.hc[k] = (uint32_t)h_in[6 + k];
+    R.raw = h_in[13] == 1;
+    if (R.n) {
+      std::lock_guard<std::mutex> lk(dst->stage_mu);
+      if (dst->n + R.n > 0xFFFFFFF0ull) return set_error(g, ELP_ERR_UNSUPPORTED, "more than 2^32-16 records per context");
+      const bool dst_raw = dst->raw_n == dst->n && dst->n > 0;
+      if ((dst->raw_n && !dst_raw) || (dst->n > 0 && dst_raw != R.raw))
+        return set_error(g, ELP_ERR_UNSUPPORTED, "elp_exchange_records: the records that arrive and the destination's differ in whether they hold inflated BAM bytes");
     }
-    ELP_HIP(dst, hipGetLastError());
   }
-  ELP_HIP(dst, hipStreamSynchronize(dst->stream));
-  // ---- commit (as elp_stage does)
-  dst->n += n; dst->qname_bytes += total[0]; dst->cigar_ops += total[1]; dst->seq_bytes += total[2]; dst->qual_bytes += total[3];
-  if (raw) { dst->raw_n = dst->n; dst->raw_bytes += total[4]; dst->max_raw_rec = std::max(dst->max_raw_rec, src->max_raw_rec); }
-  dst->n_sr += hc[XC_NSR];
-  dst->n_filtered += hc[XC_NFILT];
-  dst->max_split = std::max(dst->max_split, hc[XC_SPLIT]);
-  dst->max_qname_len = std::max(dst->max_qname_len, hc[XC_QNAME]);
-  dst->max_l_seq = std::max(dst->max_l_seq, hc[XC_LSEQ]);
-  dst->max_pos = std::max(dst->max_pos, hc[XC_POS]);
-  dst->adapted = dst->sorted = dst->marked = false;
-  dst->have_qual_present = false;
-  dst->have_snapshot = false;
-  dst->flat_index_n = 0;
-  dst->uniform_n = ~0ull;
+  // ---- payload: three blocks each way (a rank without records sends / receives none: both sides know from the header)
+  if (R.n) {
+    ELP_HIP(dst, hipSetDevice(dst->device));
+    ELP_TRY(scratch(dst, 1, gathered_fixed_bytes(R.n) + 256, &R.fx));
+    ELP_TRY(scratch(dst, 2, gathered_pool_bytes(R.total) + 64, &R.pool));
+    ELP_TRY(scratch(dst, 3, (size_t)XV * (R.n + 1) + 16, &R.excl));
+    ELP_HIP(dst, hipStreamSynchronize(dst->stream));
+  }
+  const int sp = n ? send_peer : -1, rp = R.n ? recv_peer : -1;
+  if (sp >= 0 || rp >= 0) {
+    ELP_TRY(group_sendrecv(g, sp, G.fx, n ? gathered_fixed_bytes(n) : 0, rp, R.fx, R.n ? gathered_fixed_bytes(R.n) : 0));
+    ELP_TRY(group_sendrecv(g, sp, G.pool, n ? gathered_pool_bytes(G.total) : 0, rp, R.pool, R.n ? gathered_pool_bytes(R.total) : 0));
+    ELP_TRY(group_sendrecv(g, sp, G.excl, n ? (size_t)XV * (n + 1) * 4 : 0, rp, R.excl, R.n ? (size_t)XV * (R.n + 1) * 4 : 0));
+    ELP_HIP(g, hipStreamSynchronize(g->stream));
+  }
+  if (R.n) {
+    std::lock_guard<std::mutex> lk(dst->stage_mu);
+    ELP_TRY(append_piece(dst, dst, R, h_in[14]));
+  }
   return 0;
 }

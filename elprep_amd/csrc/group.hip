@@ -24,6 +24,10 @@ struct Rccl {
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
   std::string err;
 };
@@ -42,7 +46,12 @@ static Rccl *rccl() {
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
     r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.lib, "ncclAllReduce"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
-    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.GetErrorString) r.err = "RCCL library lacks a required symbol";
+    r.Send = reinterpret_cast<decltype(r.Send)>(dlsym(r.lib, "ncclSend"));
+    r.Recv = reinterpret_cast<decltype(r.Recv)>(dlsym(r.lib, "ncclRecv"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(r.lib, "ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(r.lib, "ncclGroupEnd"));
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.GetErrorString || !r.Send || !r.Recv || !r.GroupStart || !r.GroupEnd)
+      r.err = "RCCL library lacks a required symbol";
   });
   return &r;
 }
@@ -66,6 +75,40 @@ void group_release(elp_ctx *c) {
   }
   c->xport = nullptr;  // a transport of an earlier elp_group_init_transport does not outlive the group either
   c->xport_user = nullptr;
+  c->p2p = nullptr;
+  c->p2p_user = nullptr;
+}
+
+// one message each way between this rank and two peers of the device group (either may be absent: peer -1 or no bytes); device buffers
+int group_sendrecv(elp_ctx *c, int send_peer, const void *send_dev, size_t send_bytes, int recv_peer, void *recv_dev, size_t recv_bytes) {
+  if (send_peer < 0) send_bytes = 0;
+  if (recv_peer < 0) recv_bytes = 0;
+  if (!send_bytes && !recv_bytes) return 0;
+  ELP_HIP(c, hipSetDevice(c->device));
+  if (c->p2p) {  // the caller's transport, through page-locked host memory
+    const size_t need = send_bytes + recv_bytes + 64;
+    if (need > c->h_pinned_cap) {
+      if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+      c->h_pinned = nullptr; c->h_pinned_cap = 0;
+      ELP_HIP(c, hipHostMalloc(&c->h_pinned, need, hipHostMallocDefault));
+      c->h_pinned_cap = need;
+    }
+    uint8_t *hs = static_cast<uint8_t *>(c->h_pinned), *hr = hs + ((send_bytes + 63) & ~(size_t)63);
+    if (send_bytes) ELP_HIP(c, hipMemcpyAsync(hs, send_dev, send_bytes, hipMemcpyDeviceToHost, c->stream));
+    ELP_HIP(c, hipStreamSynchronize(c->stream));
+    const int rc = c->p2p(c->p2p_user, send_bytes ? send_peer : -1, hs, send_bytes, recv_bytes ? recv_peer : -1, hr, recv_bytes);
+    if (rc != 0) return set_error(c, ELP_ERR_HIP, "the group's transport failed (send-receive callback returned %d)", rc);
+    if (recv_bytes) ELP_HIP(c, hipMemcpyAsync(recv_dev, hr, recv_bytes, hipMemcpyHostToDevice, c->stream));
+    ELP_HIP(c, hipStreamSynchronize(c->stream));  // (the pinned buffer is reused by the next message)
+    return 0;
+  }
+  if (!c->comm) return set_error(c, ELP_ERR_ARG, "no device group with point-to-point transport: call elp_group_init (RCCL) or elp_group_set_p2p first");
+  Rccl *R = rccl();
+  ELP_NCCL(c, R->GroupStart());  // (send and receive of one step progress together: no rank waits for its own send before it posts its receive)
+  if (send_bytes) ELP_NCCL(c, R->Send(send_dev, send_bytes, ncclUint8, send_peer, static_cast<ncclComm_t>(c->comm), c->stream));
+  if (recv_bytes) ELP_NCCL(c, R->Recv(recv_dev, recv_bytes, ncclUint8, recv_peer, static_cast<ncclComm_t>(c->comm), c->stream));
+  ELP_NCCL(c, R->GroupEnd());
+  return 0;
 }
 
 }  // namespace elp
@@ -114,6 +157,14 @@ int elp_group_init_transport(elp_ctx *c, int rank, int world, elp_allreduce_fn a
   c->group_world = world;
   c->xport = world > 1 ? allreduce : nullptr;
   c->xport_user = user;
+  return 0;
+}
+
+int elp_group_set_p2p(elp_ctx *c, elp_sendrecv_fn fn, void *user) {
+  if (!c) return ELP_ERR_ARG;
+  if (c->comm) return set_error(c, ELP_ERR_ARG, "elp_group_set_p2p: the context belongs to an RCCL group (its send / receive are RCCL's)");
+  c->p2p = fn;
+  c->p2p_user = user;
   return 0;
 }
 

@@ -211,6 +211,31 @@ class Engine:
         ix = np.ascontiguousarray(idx, dtype=np.uint32)
         self._check(self.L.elp_copy_records(self.h, src.h, _vp(ix), ix.size, -1 if new_split is None else int(new_split), 1 if tag_sr else 0))
 
+    def group_set_p2p(self, sendrecv):
+        """point-to-point messages of a transport group: sendrecv(send_peer, send: bytes or None, recv_peer, recv_bytes) -> bytes or None
+        (elp_group_set_p2p)"""
+        def cb(_user, sp, sbuf, sbytes, rp, rbuf, rbytes):
+            try:
+                out = C.string_at(sbuf, sbytes) if sp >= 0 and sbytes else None
+                got = sendrecv(sp, out, rp, rbytes)
+                if rp >= 0 and rbytes:
+                    if got is None or len(got) != rbytes:
+                        return 2
+                    C.memmove(rbuf, got, rbytes)
+                return 0
+            except Exception:  # noqa: BLE001 - reported through the C ABI's return code
+                return 1
+        self._p2p_cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t)(cb)
+        self._check(self.L.elp_group_set_p2p(self.h, C.cast(self._p2p_cb, C.c_void_p), C.c_void_p(0)))
+
+    def exchange_records(self, send_peer: int, idx: Optional[np.ndarray], dst: Optional["Engine"], recv_peer: int, new_split: Optional[int] = None,
+                         tag_sr: bool = False):
+        """one step of the split phase's all-to-all (elp_exchange_records): this context's records idx go to rank send_peer of the device
+        group, what rank recv_peer sends in its matching call is appended to dst"""
+        ix = np.ascontiguousarray(idx if idx is not None else np.zeros(0), dtype=np.uint32)
+        self._check(self.L.elp_exchange_records(self.h, send_peer, _vp(ix), ix.size, -1 if new_split is None else int(new_split), 1 if tag_sr else 0,
+                                                dst.h if dst is not None else C.c_void_p(0), recv_peer))
+
     def split_classify(self, group_of_ref: np.ndarray, n_groups: int):
         g = np.ascontiguousarray(group_of_ref, dtype=np.int32)
         split = np.empty(self.n, dtype=np.uint16)

@@ -276,6 +276,19 @@ int elp_group_init(elp_ctx *ctx, int rank, int world, const uint8_t *id /* ELP_G
  * Replaces: nothing in the reference (elprep sfm merges per-split tables through files, cmd/split-filter-merge.go:413-470). */
 typedef int (*elp_allreduce_fn)(void *user, int64_t *values, size_t n);
 int elp_group_init_transport(elp_ctx *ctx, int rank, int world, elp_allreduce_fn allreduce, void *user);
+/* Point-to-point messages of such a group: `sendrecv` must deliver send_bytes from send_buf to rank send_peer and fill recv_buf with the
+ * recv_bytes that rank recv_peer sends to this rank in its matching call (a peer of -1: nothing that way), then return 0; page-locked
+ * host buffers.  An RCCL group (elp_group_init) needs no callback: ncclSend / ncclRecv over xGMI, device to device. */
+typedef int (*elp_sendrecv_fn)(void *user, int send_peer, const void *send_buf, size_t send_bytes, int recv_peer, void *recv_buf, size_t recv_bytes);
+int elp_group_set_p2p(elp_ctx *ctx, elp_sendrecv_fn sendrecv, void *user);
+/* The split phase of `elprep sfm` between PROCESSES (sam/split-merge.go:280-293 writes a record to the file of the split it belongs
+ * to; with one process per GPU the "file" is a context of another rank): one step of the all-to-all.  The records `idx` (staging
+ * indices, n of them) of `src` are gathered on its GPU as elp_copy_records gathers them - new_split / tag_sr as there - and sent to rank
+ * send_peer of the device group; the records that rank recv_peer selected for this rank in ITS matching call are appended to `dst`.  Either
+ * direction may be absent (peer -1; then src resp. dst may be NULL).  Every rank calls it world - 1 times, step s with send_peer =
+ * (rank + s) % world and recv_peer = (rank - s + world) % world; src or dst must belong to the group.  No host copy of a record: a
+ * 128-byte header and three device buffers per direction (fixed columns, variable-length pools, scans). */
+int elp_exchange_records(elp_ctx *src, int send_peer, const uint32_t *idx, uint64_t n, int new_split, int tag_sr, elp_ctx *dst, int recv_peer);
 int elp_group_rank(const elp_ctx *ctx);
 int elp_group_size(const elp_ctx *ctx);
 int elp_bqsr_tables_add(elp_ctx *dst, elp_ctx *src);

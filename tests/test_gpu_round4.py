@@ -242,3 +242,63 @@ def test_stage_bgzf_reports_corrupt_blocks():
     with pytest.raises(ElpError, match="ends inside an alignment record"):
         e.stage_bgzf(_np.frombuffer(_bgzf(raw.tobytes()[:-7], 6), dtype=_np.uint8))
     e.close()
+
+
+# ---- the split phase between processes through the C ABI (elp_exchange_records), over a caller's point-to-point transport
+def test_exchange_records_between_two_ranks_through_a_transport():
+    """two ranks as two host threads on the one GPU, each with a reader context (its half of the reads) and a destination context; the
+    group's messages go through a Python queue (elp_group_set_p2p).  Rank 0 sends its records at odd indices (as sr-tagged copies of split
+    5), rank 1 sends its records on contig 0; both receive what the other sent: the destination contexts behave exactly like contexts the
+    host staged with the same records - every output of mark duplicates / sort against them.  Then a step in which only one side sends."""
+    import queue
+    import threading
+    from elprep_amd import sfm
+    cfg, b, h, refs, sites = dataset("tiny", 6000, 21, 0.03)
+    half = b.n // 2
+    parts = [b.take(np.arange(half)), b.take(np.arange(half, b.n))]
+    pick = [np.arange(1, parts[0].n, 2), np.nonzero(parts[1].refid == 0)[0]]
+    chan = {(0, 1): queue.Queue(), (1, 0): queue.Queue()}
+    readers = [Engine(h), Engine(h)]
+    dests = [Engine(h), Engine(h)]
+    errors = []
+
+    def rank(r):
+        try:
+            other = 1 - r
+
+            def sendrecv(sp, data, rp, nbytes):
+                if sp >= 0 and data is not None:
+                    chan[(r, sp)].put(data)
+                return chan[(rp, r)].get(timeout=60) if rp >= 0 and nbytes else None
+            readers[r].stage(parts[r])
+            readers[r].group_init_transport(r, 2, lambda v: None)
+            readers[r].group_set_p2p(sendrecv)
+            if r == 0:
+                readers[0].exchange_records(other, pick[0], dests[0], other, new_split=5, tag_sr=True)
+                readers[0].exchange_records(-1, None, dests[0], other)          # second step: rank 0 only receives
+            else:
+                readers[1].exchange_records(other, pick[1], dests[1], other)
+                readers[1].exchange_records(other, pick[1][:7], None, -1)       # ... rank 1 only sends
+        except Exception as ex:  # noqa: BLE001
+            errors.append((r, repr(ex)))
+    th = [threading.Thread(target=rank, args=(r,)) for r in (0, 1)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(120)
+    assert not errors, errors
+    # rank 0 got rank 1's contig-0 records (twice the first seven), rank 1 got rank 0's odd records as tagged copies of split 5
+    from elprep_amd.batch import Batch
+    want0 = Batch.concat([parts[1].take(pick[1]), parts[1].take(pick[1][:7])])
+    want1 = sfm.with_sr(parts[0].take(pick[0]), np.ones(pick[0].size, dtype=bool), split=np.full(pick[0].size, 5, dtype=np.uint16))
+    for got, want in ((dests[0], want0), (dests[1], want1)):
+        ref = Engine(h)
+        ref.stage(want)
+        assert got.n == want.n and got.n_sorted == ref.n_sorted
+        assert np.array_equal(got.mark_duplicates(True), ref.mark_duplicates(True))
+        assert np.array_equal(got.sort_coordinate(), ref.sort_coordinate())
+        assert np.array_equal(got.dup_metrics(100), ref.dup_metrics(100))
+        ref.close()
+    assert np.array_equal(dests[1].mark_duplicates(True), orc.mark_duplicates(want1, h))
+    for e in readers + dests:
+        e.close()
