@@ -398,35 +398,42 @@ def _bam_records(buf):
 
 def test_emit_merged_bam_is_the_merge_of_the_two_sorted_outputs():
     """elp_emit_merged_bam (MergeSortedFilesSplitPerChromosome with payloads): the group splits (with their sr-tagged copies, which drop
-    out) in one context, the spread split in another, both staged from BAM bytes, marked, sorted: the merged stream is the two contexts'
-    own sorted outputs (elp_emit_sorted_bam, tested byte-exact against the oracle's encoder) interleaved by elp_merge_spread's slots
-    (tested against the transliteration of the reference's insertion loop)"""
+    out) in one context, the spread split in another, both staged from BAM bytes, marked, sorted.  The expectation is built WITHOUT the
+    device (round 3 built it from the device's own sorted outputs): the oracle's flags and coordinate order of either batch, the oracle's
+    BAM encoder (formatBamAlignment) for the records, and the transliteration of the reference's insertion loop
+    (sam/split-merge.go:519-549, tests/test_sfm_cpu.py) for where every spread read goes."""
     from elprep_amd import sfm
     from oracle import simple_filters as sf
+    from tests.test_sfm_cpu import _merge_reference
     cfg, b, h, refs, sites = dataset("tiny", 4000, 17, 0.03)
     n_groups, gof = orc.contig_groups(cfg.ref_len, 80000)
     osplit, ospread = sf.split_records(b, gof)
     assert ospread.sum() > 20
     tagged = sfm.with_sr(b, ospread.astype(bool), osplit)
+    tagged.split[:] = 0  # (stage_bam gives every record of a call one split id; the tagged copies are recognised by their sr tag)
     sp = b.take(np.nonzero(ospread)[0])
     eg, es = Engine(h), Engine(h)
+    recs, keys = [], []
     for eng, batch in ((eg, tagged), (es, sp)):
         eng.set_read_group_ids(h.rg_ids)
         eng.stage_bam(orc.bam_encode(batch, h.rg_ids), split_id=0)
         eng.mark_duplicates(True)
         eng.sort_coordinate()
-    # (stage_bam gives every record of a call one split id; the tagged copies are recognised by their sr tag)
-    rg, rs = _bam_records(eg.emit_sorted_bam()), _bam_records(es.emit_sorted_bam())
-    assert len(rg) == eg.n_sorted and len(rs) == es.n_sorted
-    slots = eg.merge_spread(es).astype(np.int64)
-    want = [None] * (len(rg) + len(rs))
-    for j, s in enumerate(slots):
-        want[s] = rs[j]
-    it = iter(rg)
-    want = [w if w is not None else next(it) for w in want]
+        oflags = orc.mark_duplicates(batch, h)
+        order = orc.sort_coordinate(batch, oflags)[:orc.num_sorted(batch)]
+        recs.append(_bam_records(orc.bam_encode(batch, h.rg_ids, order=order, flags=oflags, normalize_tags=True)))
+        keys.append([(int(batch.refid[i]), int(batch.pos[i])) for i in order])
+        assert len(recs[-1]) == eng.n_sorted
+    rg, rs = recs
+    # the merge runs over the mapped group reads; the unmapped split (refid -1, at the end of the group context's output) follows it
+    n_mapped = sum(1 for k in keys[0] if k[0] >= 0)
+    codes = _merge_reference(keys[0][:n_mapped], keys[1])
+    want = [rg[c] if c >= 0 else rs[-c - 1] for c in codes] + rg[n_mapped:]
     got = eg.emit_merged_bam(es)
     assert got.tobytes() == b"".join(want)
-    # sizes only, and an empty spread context
+    # the device's own pieces agree with the same expectation
+    assert eg.emit_sorted_bam().tobytes() == b"".join(rg) and es.emit_sorted_bam().tobytes() == b"".join(rs)
+    # an empty spread context
     e0 = Engine(h)
     e0.set_read_group_ids(h.rg_ids)
     e0.stage_bam(orc.bam_encode(sp.take(np.arange(0)), h.rg_ids))
