@@ -575,6 +575,7 @@ int elp_emit_sorted_bam(elp_ctx *c, uint8_t *out, uint64_t cap, uint64_t *n_byte
   if (!c || !n_bytes_out) return ELP_ERR_ARG;
   ELP_HIP(c, hipSetDevice(c->device));
   if (!c->sorted) return set_error(c, ELP_ERR_ARG, "elp_emit_sorted_bam: call elp_sort_coordinate first");
+  ELP_TRY(radix_check(c));
   if (c->raw_n != c->n) return set_error(c, ELP_ERR_ARG, "elp_emit_sorted_bam: records were not staged with elp_stage_bam");
   const BamOut m = bam_out_of(c);
   return emit_stream(c, m, m, nullptr, c->n - c->n_sr, c->max_raw_rec, out, cap, n_bytes_out);
@@ -587,6 +588,7 @@ int elp_emit_sorted_bgzf(elp_ctx *c, uint8_t *out, uint64_t cap, uint64_t *n_byt
   if (!c || !n_bytes_out) return ELP_ERR_ARG;
   ELP_HIP(c, hipSetDevice(c->device));
   if (!c->sorted) return set_error(c, ELP_ERR_ARG, "elp_emit_sorted_bgzf: call elp_sort_coordinate first");
+  ELP_TRY(radix_check(c));
   if (c->raw_n != c->n) return set_error(c, ELP_ERR_ARG, "elp_emit_sorted_bgzf: records were not staged with elp_stage_bam");
   const BamOut m = bam_out_of(c);
   return emit_stream(c, m, m, nullptr, c->n - c->n_sr, c->max_raw_rec, out, cap, n_bytes_out, true);

@@ -91,7 +91,10 @@ struct elp_ctx {
 
   // derived state
   bool adapted = false, sorted = false, marked = false;
+  bool radix_check_pending = false;  // radix passes were queued whose look-back timeout bit nobody has read yet (fetch_err)
   bool adapt_bad_qual = false;  // adapt_score met a quality > 93 in a duplicate-marking candidate
+  bool adapt_pending = false;   // ... or may have: its error word (adapt_err) has not been read yet
+  elp::DVec<uint32_t> adapt_err;
   bool have_qual_present = false;
   unsigned long long qual_present[2] = {0, 0};  // bit q set if quality value q was seen in a sample of the QUAL column (sizing hint for the BQSR tables)
   elp::DVec<int32_t> upos, score;
@@ -341,9 +344,12 @@ int radix_sort_pairs_low(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *k
                          const uint32_t *n_dev = nullptr /* the length is *n_dev on the device and `n` its upper bound */);
 int exclusive_scan_u32(elp_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n, uint32_t *total_host /* may be null */);
 int ensure_adapted(elp_ctx *c, bool check_quals = true);
+void adapt_note(elp_ctx *c, uint32_t word);  // sort.hip: the score kernel's error word was read (by whoever synchronised anyway)
+int adapt_quality_error(elp_ctx *c);
 int ensure_uniform_len(elp_ctx *c);  // sort.hip: c->uniform_len
 int ensure_qual_present(elp_ctx *c, bool exact = false);  // exact: scan the whole column instead of a sample
 int fetch_err(elp_ctx *c, uint32_t *words /* 4 */);
+int radix_check(elp_ctx *c);  // reads the error words if radix passes were queued since they were last read
 void group_release(elp_ctx *c);
 int group_sendrecv(elp_ctx *c, int send_peer, const void *send_dev, size_t send_bytes, int recv_peer, void *recv_dev, size_t recv_bytes);  // group.hip
 int tables_written(elp_ctx *c);  // bqsr.hip: dev_tables were just written on c->stream

@@ -90,10 +90,27 @@ int stage_recode_seq(elp_ctx *c, uint64_t from, uint64_t bytes) {
   return 0;
 }
 
+// the device-side error words, behind everything queued on the context's stream.  Bit 256 of word 0 (a tile look-back of a radix pass
+// timed out: radix.hip; the result of that sort is wrong) is everybody's to report: the sorts do not synchronise for it themselves, the
+// next read of the words - the following stage's, elp_sync's, a getter's - does.
 int fetch_err(elp_ctx *c, uint32_t *words) {
   ELP_HIP(c, hipMemcpyAsync(words, c->err_flag.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   ELP_HIP(c, hipStreamSynchronize(c->stream));
+  c->radix_check_pending = false;
+  if (words[0] & 256u) {
+    const uint32_t w0 = words[0] & ~256u;
+    ELP_HIP(c, hipMemcpyAsync(c->err_flag.p, &w0, 4, hipMemcpyHostToDevice, c->stream));
+    ELP_HIP(c, hipStreamSynchronize(c->stream));
+    c->sorted = false;
+    c->marked = false;
+    return set_error(c, ELP_ERR_HIP, "radix sort: tile look-back timed out");
+  }
   return 0;
+}
+int radix_check(elp_ctx *c) {
+  if (!c->radix_check_pending) return 0;
+  uint32_t e[4];
+  return fetch_err(c, e);
 }
 
 }  // namespace elp
@@ -148,6 +165,7 @@ const char *elp_last_error(const elp_ctx *c) { return c ? c->err.c_str() : "null
 
 int elp_sync(elp_ctx *c) {
   if (!c) return ELP_ERR_ARG;
+  if (c->radix_check_pending) return radix_check(c);  // (synchronises)
   ELP_HIP(c, hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -364,10 +382,12 @@ static int d2h(elp_ctx *c, void *dst, const void *src, size_t bytes) {
 int elp_get_permutation(elp_ctx *c, uint32_t *out) {
   if (!c || (!out && c->n)) return ELP_ERR_ARG;
   if (!c->sorted) return set_error(c, ELP_ERR_ARG, "elp_get_permutation: call elp_sort_coordinate first");
+  ELP_TRY(radix_check(c));
   return d2h(c, out, c->perm.p, c->n * sizeof(uint32_t));
 }
 int elp_get_flags(elp_ctx *c, uint16_t *out) {
   if (!c || (!out && c->n)) return ELP_ERR_ARG;
+  ELP_TRY(radix_check(c));  // (mark duplicates partitions its pairs with radix passes)
   return d2h(c, out, c->flag.p, c->n * sizeof(uint16_t));
 }
 int elp_get_adapted(elp_ctx *c, int32_t *upos, int32_t *score) {

@@ -705,10 +705,10 @@ static uint64_t table_size_for(uint64_t n) {
 
 static int markdup_impl(elp_ctx *c) {
   const uint64_t n = c->n;
-  ELP_TRY(ensure_adapted(c));
+  ELP_TRY(ensure_adapted(c, false));  // (its quality-error word is read with this call's first read-back, below)
   ELP_TRY(ensure(c, c->mate, n + 1));
   ELP_TRY(ensure(c, c->pair_win, n + 1));
-  if (n == 0) { c->marked = true; return 0; }
+  if (n == 0) { ELP_TRY(ensure_adapted(c, true)); c->marked = true; return 0; }
   const unsigned grid = blocks_for(n, 256);
   hipStream_t st = c->stream;
   // flag_in snapshot: tournaments must see the flags as staged (isTruePair/IsReversed never change, but keep it explicit)
@@ -766,7 +766,12 @@ static int markdup_impl(elp_ctx *c) {
   uint32_t n_tab = 0, n_tab64[64 * 16];
   ELP_HIP(c, hipMemcpyAsync(n_tab64, n_table_dev, sizeof n_tab64, hipMemcpyDeviceToHost, st));
   ELP_HIP(c, hipMemcpyAsync(&nf, nf_dev, 4, hipMemcpyDeviceToHost, st));
+  uint32_t adapt_word = 0;
+  const bool adapt_read = c->adapt_pending;
+  if (adapt_read) ELP_HIP(c, hipMemcpyAsync(&adapt_word, c->adapt_err.p, 4, hipMemcpyDeviceToHost, st));
   ELP_HIP(c, hipStreamSynchronize(st));
+  if (adapt_read) adapt_note(c, adapt_word);
+  if (c->adapt_bad_qual) return adapt_quality_error(c);  // computePhredScore panics on such a record (filters/mark-duplicates.go:64-66)
   for (int k = 0; k < 64; k++) n_tab += n_tab64[k * 16];
   if (n_tab) ELP_LAUNCH(c, "md_bloom_coarse", k_bloom_coarse, dim3(blocks_for(bw / 16, 256)), dim3(256), 0, (const uint32_t *)bloom, (uint32_t)(bw / 16), coarse);
 
@@ -851,6 +856,7 @@ static int markdup_impl(elp_ctx *c) {
     ELP_LAUNCH(c, "md_pair_bucket", k_pair_bucket, dim3((unsigned)nb), dim3(PB_THREADS), 0, m, (const uint4 *)fkey, (const uint32_t *)c->mate.p,
                (const uint64_t *)ks, vs, (const uint32_t *)bounds, (const uint32_t *)(bounds + nb), std::min(c->tune.pair_table_slots, PB_CAP), c->pair_win.p, c->flag.p);
   }
+  c->radix_check_pending = true;
   c->marked = true;
   return 0;
 }

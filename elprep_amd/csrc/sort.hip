@@ -246,7 +246,7 @@ static int score_uniform_launch(elp_ctx *c) {
   const unsigned grid = (unsigned)std::min<uint64_t>((ngroups + SU_WAVES - 1) / SU_WAVES, (uint64_t)c->n_cu * per_cu);
   ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_score_uniform<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
   ELP_LAUNCH(c, "adapt_score", k_score_uniform<R>, dim3(grid), dim3(64 * SU_WAVES), dyn, c->n, L, (const uint8_t *)c->qual.p, (const uint16_t *)c->flag.p,
-             c->score.p, c->qbounds.p, c->err_flag.p);
+             c->score.p, c->qbounds.p, c->adapt_err.p);
   return 0;
 }
 static int score_uniform(elp_ctx *c) {
@@ -353,14 +353,31 @@ int ensure_uniform_len(elp_ctx *c) {
   return 0;
 }
 
-static int adapt_quality_error(elp_ctx *c) {
+int adapt_quality_error(elp_ctx *c) {
   return set_error(c, ELP_ERR_DATA, "Invalid QUAL character (phred > 93) in a duplicate-marking candidate (reference: log.Panic, filters/mark-duplicates.go:64-66)");
 }
 
 // check_quals: report a quality > 93 in a duplicate-marking candidate (computePhredScore panics); the BQSR entry points, which
 // only need the per-read low-quality-tail bounds, pass false and leave that error to a later elp_mark_duplicates
+// the quality-error word of the score kernel, read when somebody needs it (check_quals) - or by elp_mark_duplicates together with its
+// own first read-back (adapt_note): the adapt stage has no synchronisation of its own
+static int adapt_resolve(elp_ctx *c) {
+  if (!c->adapt_pending) return 0;
+  uint32_t w = 0;
+  ELP_HIP(c, hipMemcpyAsync(&w, c->adapt_err.p, 4, hipMemcpyDeviceToHost, c->stream));
+  ELP_HIP(c, hipStreamSynchronize(c->stream));
+  adapt_note(c, w);
+  return 0;
+}
+void adapt_note(elp_ctx *c, uint32_t word) {
+  c->adapt_pending = false;
+  if (word & 1u) c->adapt_bad_qual = true;
+}
 int ensure_adapted(elp_ctx *c, bool check_quals) {
-  if (c->adapted) return (check_quals && c->adapt_bad_qual) ? adapt_quality_error(c) : 0;
+  if (c->adapted) {
+    if (check_quals) ELP_TRY(adapt_resolve(c));
+    return (check_quals && c->adapt_bad_qual) ? adapt_quality_error(c) : 0;
+  }
   ELP_HIP(c, hipSetDevice(c->device));
   uint64_t n = c->n;
   ELP_TRY(ensure_flat_index(c));
@@ -368,7 +385,10 @@ int ensure_adapted(elp_ctx *c, bool check_quals) {
   ELP_TRY(ensure(c, c->score, n + 1));
   ELP_TRY(ensure(c, c->key, n + 1));
   ELP_TRY(ensure(c, c->qbounds, n + 1));
+  ELP_TRY(ensure(c, c->adapt_err, 4));
+  ELP_HIP(c, hipMemsetAsync(c->adapt_err.p, 0, 16, c->stream));
   c->adapt_bad_qual = false;
+  c->adapt_pending = false;
   int pos_bits = 1;
   while (pos_bits < 32 && (c->max_pos >> pos_bits) != 0) pos_bits++;
   {
@@ -387,16 +407,12 @@ int ensure_adapted(elp_ctx *c, bool check_quals) {
     } else if (c->qual_bytes) {
       const unsigned grid = (unsigned)std::min<uint64_t>(flat_steps<ScoreBody>(c->qual_bytes), (uint64_t)c->n_cu * 4);
       ELP_LAUNCH(c, "adapt_score", k_score_flat, dim3(grid), dim3(FL_THREADS), 0, n, (const uint64_t *)c->qual_off.p, (const uint8_t *)c->qual.p,
-                 c->qual_bytes, (const uint32_t *)c->tile_first.p, (const uint16_t *)c->flag.p, c->score.p, c->qbounds.p, c->err_flag.p);
+                 c->qual_bytes, (const uint32_t *)c->tile_first.p, (const uint16_t *)c->flag.p, c->score.p, c->qbounds.p, c->adapt_err.p);
     }
-    uint32_t e[4];
-    ELP_TRY(fetch_err(c, e));
-    if (e[0] & 1u) {
-      ELP_HIP(c, hipMemsetAsync(c->err_flag.p, 0, 4, c->stream));
-      c->adapt_bad_qual = true;
-    }
+    c->adapt_pending = c->qual_bytes != 0;
   }
   c->adapted = true;
+  if (check_quals) ELP_TRY(adapt_resolve(c));
   return (check_quals && c->adapt_bad_qual) ? adapt_quality_error(c) : 0;
 }
 
@@ -882,8 +898,10 @@ static int sort_impl(elp_ctx *c) {
       if (vo != vcur) { vtmp = vcur; vcur = vo; }
       hi = lo;
     }
-    ELP_LAUNCH(c, "seg_keys", k_seg_keys, dim3(blocks_for(nu, 256)), dim3(256), 0, nu, (const uint32_t *)vcur, (const uint32_t *)u_seg, uk0);
-    {
+    // the last, stable round on the run id keeps the runs apart and in order - with ONE long run (the unmapped block of a file without
+    // pile-ups) there is nothing to keep apart
+    if (nr > 1) ELP_LAUNCH(c, "seg_keys", k_seg_keys, dim3(blocks_for(nu, 256)), dim3(256), 0, nu, (const uint32_t *)vcur, (const uint32_t *)u_seg, uk0);
+    if (nr > 1) {
       uint64_t *ko;
       uint32_t *vo;
       ELP_TRY(radix_sort_pairs(c, uk0, vcur, uk1, vtmp, nu, &ko, &vo));
@@ -892,13 +910,9 @@ static int sort_impl(elp_ctx *c) {
     ELP_LAUNCH(c, "large_scatter", k_large_scatter, dim3(blocks_for(nu, 256)), dim3(256), 0, nu, (const uint32_t *)vcur, (const uint32_t *)u_pos,
                (const uint32_t *)u_read, c->perm.p);
   }
-  // a look-back that timed out (radix.hip) leaves a wrong permutation: report it here, behind the last pass, and clear the bit
-  uint32_t e[4];
-  ELP_TRY(fetch_err(c, e));
-  if (e[0] & 256u) {
-    ELP_HIP(c, hipMemsetAsync(c->err_flag.p, 0, 4, c->stream));
-    return set_error(c, ELP_ERR_HIP, "radix sort: tile look-back timed out");
-  }
+  // (a look-back that timed out leaves a wrong permutation: the bit is read by whoever reads the error words next - the following
+  // stage, elp_sync, elp_get_permutation, the emit calls: fetch_err - instead of a synchronisation of its own here)
+  c->radix_check_pending = true;
   c->sorted = true;
   return 0;
 }
