@@ -381,9 +381,25 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
     int rcl = 0;
     if (i < m.n) pf_record<false>(m, i, cur, L, ref_lds, desc, skipbits, err, ro.recs != nullptr, nullptr, defer, to_plain, rc, rcl);
     if (ro.recs) {  // the tile's records, compacted: class 1 into this wave's segment, the rare class 2 ones (windows the record cannot describe) behind
-      const uint32_t seg = (blockIdx.x * 4u + (threadIdx.x >> 6)) % (uint32_t)C3_NSEG;
-      const uint32_t at1 = wave_append(rcl == 1, &ro.cnt[seg * C3_CSTRIDE]);
-      if (rcl == 1) rec_store(ro.recs, (uint64_t)seg * ro.cap_s + at1, rc);
+      const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+      if (!ro.ncs) {
+        const uint32_t seg = wave % (uint32_t)C3_NSEG;
+        const uint32_t at1 = wave_append(rcl == 1, &ro.cnt[seg * C3_CSTRIDE]);
+        if (rcl == 1) rec_store(ro.recs, (uint64_t)seg * ro.cap_s + at1, rc);
+      } else {
+        // segments by covariate: one append per covariate that occurs among the wave's class-1 records of this tile
+        const uint32_t cov = rc.fl & 0xFFu, grp = (wave % ((uint32_t)C3_NSEG / ro.ncs)) * ro.ncs;
+        unsigned long long todo = __ballot(rcl == 1);
+        while (todo) {
+          const int leader = __ffsll((long long)todo) - 1;
+          const uint32_t c0 = __shfl(cov, leader, 64);
+          const bool mine = rcl == 1 && cov == c0;
+          const uint32_t seg = grp + c0;
+          const uint32_t at1 = wave_append(mine, &ro.cnt[seg * C3_CSTRIDE]);
+          if (mine) rec_store(ro.recs, (uint64_t)seg * ro.cap_s + at1, rc);
+          todo &= ~__ballot(mine);
+        }
+      }
       const uint32_t at2 = wave_append(rcl == 2, &ro.cnt[C3_NSEG * C3_CSTRIDE]);
       if (rcl == 2) rec_store(ro.recs, (uint64_t)C3_NSEG * ro.cap_s + at2, rc);
     }
@@ -1435,6 +1451,51 @@ int tables_written(elp_ctx *c) {
   return 0;
 }
 
+// The "other" region of the count kernel's records (reads with indels, clipped windows, descriptors; appended by three kernels in
+// arrival order) sorted by covariate for the covariate-split count: counts per covariate, offsets, a scatter into a second region.
+constexpr int CO_TILE = 1024, CO_MAXCOV = 16;
+__global__ __launch_bounds__(256) void k_c3_other_hist(const uint4 *__restrict__ recs, const uint32_t *__restrict__ n_dev, uint32_t *__restrict__ cnt /* [CO_MAXCOV] */) {
+  __shared__ uint32_t h[CO_MAXCOV];
+  const uint32_t n = *n_dev;
+  if ((uint64_t)blockIdx.x * CO_TILE >= n) return;
+  if (threadIdx.x < CO_MAXCOV) h[threadIdx.x] = 0;
+  __syncthreads();
+  for (uint32_t k = blockIdx.x * CO_TILE + threadIdx.x; k < n && k < (blockIdx.x + 1u) * CO_TILE; k += 256) atomicAdd(&h[recs[2 * (size_t)k + 1].y & (CO_MAXCOV - 1)], 1u);
+  __syncthreads();
+  if (threadIdx.x < CO_MAXCOV && h[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], h[threadIdx.x]);
+}
+__global__ void k_c3_other_offsets(const uint32_t *__restrict__ cnt, uint32_t *__restrict__ off /* [CO_MAXCOV + 1] */, uint32_t *__restrict__ cursor) {
+  uint32_t at = 0;
+  for (int c = 0; c < CO_MAXCOV; c++) { off[c] = at; cursor[c] = at; at += cnt[c]; }
+  off[CO_MAXCOV] = at;
+}
+__global__ __launch_bounds__(256) void k_c3_other_scatter(const uint4 *__restrict__ recs, const uint32_t *__restrict__ n_dev, uint32_t *cursor, uint4 *__restrict__ out) {
+  __shared__ uint32_t h[CO_MAXCOV], base[CO_MAXCOV];
+  const uint32_t n = *n_dev;
+  if ((uint64_t)blockIdx.x * CO_TILE >= n) return;
+  if (threadIdx.x < CO_MAXCOV) h[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t my[CO_TILE / 256], cv[CO_TILE / 256];
+#pragma unroll
+  for (int j = 0; j < CO_TILE / 256; j++) {
+    const uint32_t k = blockIdx.x * CO_TILE + j * 256 + threadIdx.x;
+    cv[j] = k < n ? (recs[2 * (size_t)k + 1].y & (CO_MAXCOV - 1)) : 0xFFFFFFFFu;
+    my[j] = k < n ? atomicAdd(&h[cv[j]], 1u) : 0u;
+  }
+  __syncthreads();
+  if (threadIdx.x < CO_MAXCOV) base[threadIdx.x] = h[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], h[threadIdx.x]) : 0u;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < CO_TILE / 256; j++) {
+    const uint32_t k = blockIdx.x * CO_TILE + j * 256 + threadIdx.x;
+    if (k < n) {
+      const size_t to = (size_t)base[cv[j]] + my[j];
+      out[2 * to] = recs[2 * (size_t)k];
+      out[2 * to + 1] = recs[2 * (size_t)k + 1];
+    }
+  }
+}
+
 static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cycle_tbl, int64_t *ctx_tbl) {
   for (int r = 0; r < c->n_ref; r++)
     if (!c->h_ref_seq[r]) return set_error(c, ELP_ERR_ARG, "elp_bqsr_gather: no reference sequence set for refid %d", r);
@@ -1467,31 +1528,47 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
              c->cigar_off.p, c->seq_off.p, c->qual_off.p, c->cigar.p, c->seq4.p, c->qual.p, c->ref_len.p, c->rg_cov.p, c->n_ref,
              c->d_ref_seq.p, c->d_ref_seq_len.p, c->d_sites.p, c->d_n_sites.p, c->d_site_idx.p, c->qbounds.p};
     uint32_t *queue;
-    ELP_TRY(scratch(c, 5, 2 * n + 128 + (size_t)(C3_NSEG + 1) * C3_CSTRIDE, &queue));  // [0] = count, [4..] = records left to the general kernel; [1] = count, [n + 20..] = reads of the second pass;
+    ELP_TRY(scratch(c, 5, 2 * n + 128 + (size_t)(C3_NSEG + 1) * C3_CSTRIDE + 4 * CO_MAXCOV + 16, &queue));  // [0] = count, [4..] = records left to the general kernel; [1] = count, [n + 20..] = reads of the second pass;
     ELP_HIP(c, hipMemsetAsync(queue, 0, 16, st));  // [2 n + 48 ..] = the record counters (RecOut)
     uint32_t *plist = queue + n + 20, *rec_cnt = queue + ((2 * n + 48 + 63) & ~(uint64_t)63);
     ELP_HIP(c, hipMemsetAsync(rec_cnt, 0, (size_t)(C3_NSEG + 1) * C3_CSTRIDE * sizeof(uint32_t), st));
     // count3.hip (read sets of one length) works from 32-byte records the prologue kernels write instead of the descriptors; it takes
     // the count if the staged reads have one length (checked once per staged column), no read can exceed --max-cycle, and the quality
     // slots fit one table pass - k_bqsr_count otherwise (elp_set_tuning "count_kernel" = 1 forces it: A/B measurements)
-    BqRec *recs = nullptr;
     // a wave of the first pass appends its class-1 records (at most PF_TILES * 64) to segment wave % C3_NSEG
     const unsigned pf_grid = blocks_for(n, 256 * PF_TILES);
-    const uint64_t cap_s = ((uint64_t)pf_grid * 4 + C3_NSEG - 1) / C3_NSEG * (uint64_t)(PF_TILES * 64);
-    {
-      const bool force_old = c->tune.count_kernel == 1;  // elp_set_tuning
-      ELP_TRY(ensure_uniform_len(c));
-      const int lmax0 = (int)std::max<uint32_t>(c->max_l_seq, 1);
+    const uint64_t cap_s1 = ((uint64_t)pf_grid * 4 + C3_NSEG - 1) / C3_NSEG * (uint64_t)(PF_TILES * 64);
+    // How the one-length count kernel (count3.hip) takes this read set: 0 not at all (k_bqsr_count), 1 one private table with the rows of
+    // every covariate, or - if those do not fit, or only with little replication of the context cells - 2: split by covariate (records
+    // in per-covariate segments, a workgroup counts ONE covariate: the table needs n_q + 3 rows whatever the number of read groups)
+    ELP_TRY(ensure_uniform_len(c));
+    const int lmax0 = (int)std::max<uint32_t>(c->max_l_seq, 1);
+    uint32_t ncs = 1;
+    while ((int)ncs < c->n_cov) ncs <<= 1;
+    auto c3_mode = [&](int nq) -> int {
+      if (c->tune.count_kernel == 1 || c->uniform_len == 0 || lmax0 > max_cycle || lmax0 > 1022) return 0;
       int rsw3 = 0, rlog3 = 0;
       size_t dyn3 = 0;
-      int nq0 = 0;
-      for (int q = 6; q < ELP_NQUAL; q++) nq0 += (int)((q < 64 ? (c->qual_present[0] >> q) : (c->qual_present[1] >> (q - 64))) & 1ull);
-      if (!force_old && c->uniform_len > 0 && lmax0 <= max_cycle && lmax0 <= 1022 && count3_plan(c->n_cov, std::max(nq0, 1), lmax0, &rsw3, &rlog3, &dyn3, c->tune.count3_rlog) == 0)
-        ELP_TRY(scratch(c, 4, (size_t)C3_NSEG * cap_s + n + 64, &recs));
-    }
+      const bool all_fits = count3_plan(c->n_cov, nq, lmax0, &rsw3, &rlog3, &dyn3, c->tune.count3_rlog) == 0;
+      if (all_fits && (rlog3 >= 3 || c->n_cov == 1) && c->tune.count_kernel != 3) return 1;
+      if (c->n_cov > 1 && (int)ncs <= CO_MAXCOV && c->tune.count_kernel != 2 && count3_plan(1, nq, lmax0, &rsw3, &rlog3, &dyn3, c->tune.count3_rlog) == 0) return 2;
+      return all_fits ? 1 : 0;
+    };
+    int nq0 = 0;
+    for (int q = 6; q < ELP_NQUAL; q++) nq0 += (int)((q < 64 ? (c->qual_present[0] >> q) : (c->qual_present[1] >> (q - 64))) & 1ull);
+    int mode = c3_mode(std::max(nq0, 1));
+    BqRec *recs = nullptr;
+    uint64_t cap_s = cap_s1;
+    auto rec_buffers = [&]() -> int {  // class-1 segments | the other region | (mode 2) the other region sorted by covariate
+      cap_s = mode == 2 ? cap_s1 * ncs : cap_s1;
+      recs = nullptr;
+      if (mode) ELP_TRY(scratch(c, 4, (size_t)C3_NSEG * cap_s + (mode == 2 ? 2 : 1) * (size_t)n + 64, &recs));
+      return 0;
+    };
+    ELP_TRY(rec_buffers());
     // the three prologue passes; with `r` they leave 32-byte records for count3.hip, without it the descriptors of k_bqsr_count
     auto run_prologues = [&](BqRec *r) -> int {
-      const RecOut ro{r, rec_cnt, cap_s};
+      const RecOut ro{r, rec_cnt, cap_s, (r && mode == 2) ? ncs : 0u};
       ELP_LAUNCH(c, "bqsr_prologue_fast", k_bqsr_prologue_fast, dim3(pf_grid), dim3(256), 0, m, desc, skipbits, queue + 4, queue, c->err_flag.p, ro, plist);
       // (sized for the worst case; workgroups beyond the list's end leave at once)
       ELP_LAUNCH(c, "bqsr_prologue_plain", k_bqsr_prologue_plain, dim3(std::min<unsigned>(blocks_for(n, 256), (unsigned)c->n_cu * 16)), dim3(256), 0, m, desc, skipbits,
@@ -1539,32 +1616,47 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
       }
       const int grid = (int)std::min<uint64_t>(nsteps, (uint64_t)wg_per_cu * (uint64_t)c->n_cu);
       if (recs) {
-        int rsw3 = 0, rlog3 = 0;
-        size_t dyn3 = 0;
-        if (count3_plan(c->n_cov, (int)quals.size(), lmax, &rsw3, &rlog3, &dyn3, c->tune.count3_rlog) != 0) {
-          // the sampled hint fitted one table pass, the exact set (taken after the count met a quality without a slot) does not: the
-          // reference just runs (filters/bqsr.go:467-551), so does this - the prologues once more, leaving descriptors, and the general
-          // count kernel, which takes its quality slots in several passes
-          recs = nullptr;
+        // the sampled hint chose a form of the one-length kernel; the exact set (taken after the count met a quality without a slot) may
+        // need another one - the covariate split, or the general kernel with its several passes: the reference just runs
+        // (filters/bqsr.go:467-551), so does this - the prologues once more, leaving what the new form reads
+        const int mode2 = c3_mode((int)quals.size());
+        if (mode2 != mode) {
+          mode = mode2;
+          ELP_TRY(rec_buffers());
           ELP_HIP(c, hipMemsetAsync(skipbits, 0, skip_words * 4, st));
           ELP_HIP(c, hipMemsetAsync(queue, 0, 16, st));
           ELP_HIP(c, hipMemsetAsync(rec_cnt, 0, (size_t)(C3_NSEG + 1) * C3_CSTRIDE * sizeof(uint32_t), st));
-          ELP_TRY(run_prologues(nullptr));
+          ELP_TRY(run_prologues(recs));
         }
       }
       if (recs) {
         int rsw3 = 0, rlog3 = 0;
         size_t dyn3 = 0;
-        (void)count3_plan(c->n_cov, (int)quals.size(), lmax, &rsw3, &rlog3, &dyn3, c->tune.count3_rlog);
+        (void)count3_plan(mode == 2 ? 1 : c->n_cov, (int)quals.size(), lmax, &rsw3, &rlog3, &dyn3, c->tune.count3_rlog);
         QMap qm;
         memset(qm.slot, 254, sizeof qm.slot);
         for (size_t s2 = 0; s2 < quals.size(); s2++) qm.slot[quals[s2]] = (uint8_t)s2;
-        Count3Args A3{rec_cnt, cap_s, 0, c->uniform_len, c->qual.p, c->seq4.p + elp_ctx::SEQ_FRONT, reinterpret_cast<const uint8_t *>(skipbits),
-                      reinterpret_cast<const uint4 *>(recs), reinterpret_cast<const uint4 *>(desc), c->cigar.p, cs_pool, c->d_ref_seq.p, c->d_ref_seq_len.p, c->n_cov,
-                      (int)quals.size(), lmax, max_cycle, rsw3, rlog3, tb + nq, tb + nq + nc, c->err_flag.p};
+        const uint4 *other = reinterpret_cast<const uint4 *>(recs) + 2 * (size_t)C3_NSEG * cap_s;  // the other region (32-byte records)
+        uint32_t *ooff = nullptr;
+        if (mode == 2) {
+          // the other region sorted by covariate (behind it), offsets per covariate
+          uint32_t *cw = rec_cnt + (size_t)(C3_NSEG + 1) * C3_CSTRIDE;  // [CO_MAXCOV] counts | [CO_MAXCOV + 1] offsets | [CO_MAXCOV] cursors
+          ooff = cw + CO_MAXCOV;
+          ELP_HIP(c, hipMemsetAsync(cw, 0, (3 * CO_MAXCOV + 1) * sizeof(uint32_t), st));
+          const uint32_t *n_other = rec_cnt + (size_t)C3_NSEG * C3_CSTRIDE;
+          uint4 *sorted = const_cast<uint4 *>(other) + 2 * (size_t)n;
+          const unsigned og = blocks_for(n, CO_TILE);  // (launched for the worst case; blocks behind the region's end leave at once)
+          ELP_LAUNCH(c, "bqsr_other_hist", k_c3_other_hist, dim3(og), dim3(256), 0, other, n_other, cw);
+          ELP_LAUNCH(c, "bqsr_other_offsets", k_c3_other_offsets, dim3(1), dim3(1), 0, (const uint32_t *)cw, ooff, ooff + CO_MAXCOV + 1);
+          ELP_LAUNCH(c, "bqsr_other_scatter", k_c3_other_scatter, dim3(og), dim3(256), 0, other, n_other, ooff + CO_MAXCOV + 1, sorted);
+          other = sorted;
+        }
+        Count3Args A3{rec_cnt, cap_s, 0, mode == 2 ? (int)ncs : 0, ooff, other, c->uniform_len, c->qual.p, c->seq4.p + elp_ctx::SEQ_FRONT,
+                      reinterpret_cast<const uint8_t *>(skipbits), reinterpret_cast<const uint4 *>(recs), reinterpret_cast<const uint4 *>(desc), c->cigar.p, cs_pool,
+                      c->d_ref_seq.p, c->d_ref_seq_len.p, c->n_cov, (int)quals.size(), lmax, max_cycle, rsw3, rlog3, tb + nq, tb + nq + nc, c->err_flag.p};
         ELP_TRY(count3_launch(c, A3, qm, dyn3));  // the reads that are one run of matches, segment by segment
         A3.other = 1;
-        ELP_TRY(count3_launch(c, A3, qm, dyn3));  // the others (indels, clipped windows, descriptors), one region
+        ELP_TRY(count3_launch(c, A3, qm, dyn3));  // the others (indels, clipped windows, descriptors), one region (or one per covariate)
         goto counted;
       }
       for (size_t q0 = 0; q0 < quals.size(); q0 += (size_t)qcap) {

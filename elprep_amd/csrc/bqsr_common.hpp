@@ -167,6 +167,9 @@ struct RecOut {
   BqRec *recs;     // nullptr: descriptors are written instead (general count kernel)
   uint32_t *cnt;   // [s * C3_CSTRIDE], s < C3_NSEG: records in segment s; [C3_NSEG * C3_CSTRIDE]: records in the "other" region
   uint64_t cap_s;  // capacity of a segment; the other region starts at C3_NSEG * cap_s
+  uint32_t ncs;    // 0: a segment holds records of every covariate.  > 0 (a power of two <= C3_NSEG): segment s holds records of covariate
+                   // s % ncs only (a wave appends to segment (wave % (C3_NSEG / ncs)) * ncs + covariate): a workgroup of the count kernel
+                   // then meets ONE covariate and its private table needs that covariate's rows only
 };
 __device__ __forceinline__ void rec_pack_idx(BqRec &r, uint32_t idx) {
   r.ref_hi = (r.ref_hi & 0xFFFFu) | (idx << 16);
@@ -288,6 +291,9 @@ struct Count3Args {
   const uint32_t *cnt;  // records per segment / in the other region (RecOut)
   uint64_t cap_s;
   int other;            // 0: the class-1 segments (the grid is a multiple of C3_NSEG: workgroup w works on segment w % C3_NSEG), 1: the other region
+  int ncs;              // RecOut.ncs: > 0 = workgroup w counts covariate (w % C3_NSEG) % ncs only; the other region is then sorted by covariate:
+  const uint32_t *ooff; // [17] record offsets of the covariates inside the (sorted) other region
+  const uint4 *orecs;   // the other region's records (sorted by covariate if ncs > 0)
   uint32_t len;  // every staged read has this many bases (SEQ and QUAL)
   const uint8_t *qual, *seq4;  // seq4: first SEQ byte of read 0
   const uint8_t *skipbits;

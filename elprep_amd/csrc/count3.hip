@@ -118,6 +118,7 @@ struct Count3 {
   const uint8_t *slot_q;
   uint32_t *tbl;
   uint32_t rpc_bytes;
+  int cov_fixed;  // >= 0: this workgroup counts ONE covariate (covariate-split records): the table holds that covariate's rows only
   int t_origin;
   uint32_t rep4, two;
   uint32_t err;
@@ -253,7 +254,7 @@ struct Count3 {
     const uint32_t rm = rev ? 0xFFFFFFFFu : 0u;
     const uint32_t CX_lo = ((N_lo & C3) | ((S_lo & C3) << 2)) ^ rm, CX_hi = ((N_hi & C3) | ((S_hi & C3) << 2)) ^ rm;
     const int st = (fl & RC_NEG) ? -17 : 17;
-    const uint32_t rowb = __umul24(fl & 0xFFu, rpc_bytes);
+    const uint32_t rowb = cov_fixed >= 0 ? 0u : __umul24(fl & 0xFFu, rpc_bytes);
     const uint32_t tb = (uint32_t)((int)f.t0 + t_origin + st * (int)k0) + 4u * rowb;
     const uint32_t lrepC = rowb + rep4;
     const uint32_t ust = (uint32_t)st;
@@ -282,7 +283,7 @@ struct Count3 {
   // adds the private table into the dense int64 tables (cycle: [cov][94][2*max_cycle+1][2], context: [cov][94][16][2]) and clears it
   __device__ __forceinline__ void flush() {
     __syncthreads();
-    const int rpc = n_q + C3_XROWS, rows = n_cov * rpc;
+    const int rpc = n_q + C3_XROWS, rows = (cov_fixed >= 0 ? 1 : n_cov) * rpc;
     const int ncyc_l = 2 * lmax + 1, ncyc_g = 2 * max_cycle + 1;
     constexpr int R = 1 << RLOG, cyc_w = 16 * R + 16;
     for (int k = threadIdx.x; k < rows * ncyc_l; k += C3_NT) {
@@ -291,7 +292,7 @@ struct Count3 {
       const uint32_t v = *cell;
       if (v) {
         *cell = 0;
-        const int cov = row / rpc, slot = row - cov * rpc;
+        const int cov = cov_fixed >= 0 ? cov_fixed : row / rpc, slot = row % rpc;
         const int cyc = x - lmax;
         if (slot >= n_q) {
           err |= slot == n_q ? 8u : (slot == n_q + 1 ? 128u : 0u);
@@ -312,7 +313,7 @@ struct Count3 {
       const uint32_t m = *mc;
       *mc = 0;
       if (o | m) {
-        const int cov = row / rpc, slot = row - cov * rpc;
+        const int cov = cov_fixed >= 0 ? cov_fixed : row / rpc, slot = row % rpc;
         if (slot < n_q) {
           const int q = slot_q[slot];
           // cx = prev | cur << 2 is exactly (key >> 4) & 15 of keyFromContext (bqsr.go:64-76)
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(C3_NT) void k_bqsr_count3(Count3Args A, QMap qm) {
   __shared__ uint32_t spread8[256];
   __shared__ uint8_t slot_q[96];
   extern __shared__ __attribute__((aligned(16))) uint32_t tbl[];
-  const int n_all = A.n_cov * (A.n_q + C3_XROWS) * A.rsw + C3_PAD;
+  const int n_all = (A.ncs ? 1 : A.n_cov) * (A.n_q + C3_XROWS) * A.rsw + C3_PAD;
   const uint32_t tbl_at = lds_address(tbl);
   for (int k = threadIdx.x; k < n_all; k += C3_NT) tbl[k] = 0;
   for (int q = threadIdx.x; q < 256; q += C3_NT) {
@@ -370,11 +371,18 @@ __global__ __launch_bounds__(C3_NT) void k_bqsr_count3(Count3Args A, QMap qm) {
   const bool lane_on = slot < RPI;
   B.k0 = 16u * jb;
   B.nb = len - B.k0 < 16u ? len - B.k0 : 16u;
+  // class-1 launch: workgroup w works on segment w % C3_NSEG (with A.ncs: the segment holds covariate seg % ncs only); the other launch:
+  // all workgroups on the one region - or, with A.ncs, workgroup w on covariate w % ncs's part of the region sorted by covariate
   const uint32_t seg = OTHER ? (uint32_t)C3_NSEG : blockIdx.x % (uint32_t)C3_NSEG;
-  const uint32_t team = OTHER ? gridDim.x : gridDim.x / (uint32_t)C3_NSEG, member = OTHER ? blockIdx.x : blockIdx.x / (uint32_t)C3_NSEG;
-  const uint64_t n = A.cnt[seg * (uint32_t)C3_CSTRIDE], stride = (uint64_t)team * RPI;
+  const uint32_t split = OTHER ? (A.ncs ? (uint32_t)A.ncs : 1u) : (uint32_t)C3_NSEG;
+  const uint32_t team = gridDim.x / split, member = blockIdx.x / split;
+  const uint32_t ocov = OTHER && A.ncs ? blockIdx.x % (uint32_t)A.ncs : 0u;
+  B.cov_fixed = A.ncs ? (int)(OTHER ? ocov : seg % (uint32_t)A.ncs) : -1;
+  const uint64_t n = OTHER ? (A.ncs ? (uint64_t)(A.ooff[ocov + 1] - A.ooff[ocov]) : (uint64_t)A.cnt[seg * (uint32_t)C3_CSTRIDE]) : (uint64_t)A.cnt[seg * (uint32_t)C3_CSTRIDE];
+  const uint64_t stride = (uint64_t)team * RPI;
   const uint64_t n_trips = (n + stride - 1) / stride;  // every wave of the workgroup makes the same number of trips (flush barriers stay uniform)
-  const uint8_t *seg_recs = reinterpret_cast<const uint8_t *>(A.recs) + (uint64_t)seg * A.cap_s * 32u;
+  const uint8_t *seg_recs = OTHER ? reinterpret_cast<const uint8_t *>(A.orecs) + (A.ncs ? (uint64_t)A.ooff[ocov] * 32u : 0u)
+                                  : reinterpret_cast<const uint8_t *>(A.recs) + (uint64_t)seg * A.cap_s * 32u;
   // a cycle cell (16 | 16 bits) takes at most one count per read
   const uint32_t flush_every = 30000u / (RPI + 1u) + 1u;
   auto first_read = [&](uint64_t it) __attribute__((always_inline)) -> uint64_t { return it * stride + (uint64_t)member * RPI; };
@@ -461,7 +469,7 @@ int count3_plan(int n_cov, int n_q, int lmax, int *rsw_out, int *rlog_out, size_
 
 int count3_launch(elp_ctx *c, const Count3Args &A, const QMap &qm, size_t dyn) {
   // one workgroup per CU; the class-1 launch needs a multiple of C3_NSEG workgroups (every segment the same number)
-  const int grid = A.other ? c->n_cu : std::max(C3_NSEG, c->n_cu / C3_NSEG * C3_NSEG);
+  const int grid = A.other ? (A.ncs ? std::max(A.ncs, c->n_cu / A.ncs * A.ncs) : c->n_cu) : std::max(C3_NSEG, c->n_cu / C3_NSEG * C3_NSEG);
 #define ELP_C3K(RL, OT)                                                                                                                          \
   do {                                                                                                                                           \
     ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bqsr_count3<RL, OT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)); \

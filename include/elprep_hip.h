@@ -320,7 +320,8 @@ int elp_rollback(elp_ctx *ctx);
  * mates).  Tests and A/B measurements pin a choice per context with elp_set_tuning instead of process-wide environment
  * variables; value 0 (or -1 where 0 is a value) gives the choice back to the library.  The reference has no counterpart: its
  * one code path per operator is what every choice here must reproduce bit for bit.
- *   "count_kernel"     1: general BQSR count kernel even for read sets of one length
+ *   "count_kernel"     1: general BQSR count kernel even for read sets of one length; 2: the one-length kernel with one table for all
+ *                      covariates (never the covariate split); 3: the one-length kernel split by covariate wherever it applies
  *   "apply_kernel"     1: general ApplyBQSR kernel
  *   "bgzf_piece"       inflated bytes per device pass of elp_stage_bgzf (default 192 MiB)
  *   "bgzf_weak_guess"  1: elp_stage_bgzf's blocks guess their first record start blindly (every guess is then repaired: same result)

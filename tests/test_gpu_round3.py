@@ -195,8 +195,8 @@ def test_general_kernels_and_one_length_kernels_agree(monkeypatch):
     """the same staged reads through k_bqsr_count / k_bqsr_apply_flat (forced) and through count3 / apply3: identical tables and bytes"""
     cfg, b, h, refs, sites = dataset("tiny", 30000, 3, 0.02)
     out = []
-    for force in ("1", "0"):
-        e = Engine(h, tuning={"count_kernel": int(force), "apply_kernel": int(force)})
+    for force in ("1", "0", "2", "3"):  # general kernels; the library's choice; one-length count with one table / split by covariate
+        e = Engine(h, tuning={"count_kernel": int(force), "apply_kernel": 1 if force == "1" else 0})
         e.stage(b)
         e.mark_duplicates(True)
         for r in range(h.n_ref):
@@ -206,8 +206,9 @@ def test_general_kernels_and_one_length_kernels_agree(monkeypatch):
         lut, present = BqsrTables(qt, ct, xt, 500).finalize().build_lut(0)
         out.append((qt.copy(), ct.copy(), xt.copy(), e.apply_bqsr(lut, present, 500)))
         e.close()
-    for a, bb in zip(out[0], out[1]):
-        assert np.array_equal(a, bb)
+    for other in out[1:]:
+        for a, bb in zip(out[0], other):
+            assert np.array_equal(a, bb)
     assert (out[0][3] != b.qual).any()
 
 

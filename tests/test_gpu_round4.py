@@ -302,3 +302,28 @@ def test_exchange_records_between_two_ranks_through_a_transport():
     assert np.array_equal(dests[1].mark_duplicates(True), orc.mark_duplicates(want1, h))
     for e in readers + dests:
         e.close()
+
+
+@pytest.mark.parametrize("n_cov,n_q,length", [(4, 40, 150), (16, 7, 150), (3, 30, 101), (8, 12, 250)])
+def test_count_split_by_covariate(n_cov, n_q, length):
+    """read sets whose private count tables do not fit one workgroup's LDS with the rows of every covariate (40 qualities x 4 read groups,
+    7 x 16, ...): the one-length count kernel runs split by covariate - records in per-covariate segments, the other region sorted by
+    covariate, a workgroup's table holds ONE covariate's rows - and gives the oracle's tables; so does every forced form"""
+    from tests.test_gpu_round3 import _uniform_case
+    from elprep_amd.engine import BqsrTables
+    quals = [2] + list(range(6, 6 + n_q))
+    b, h, refs, sites = _uniform_case(40 + n_cov, 6000, length, quals=quals, n_cov=n_cov)
+    assert h.n_cov == n_cov
+    oflags = orc.mark_duplicates(b, h)
+    oq, oc, ox = orc.bqsr_gather(b, h, orc.BqsrRef(refs, sites), oflags, 500)
+    for force in (0, 3, 1):
+        e = Engine(h, tuning={"count_kernel": force})
+        e.stage(b)
+        e.mark_duplicates(True)
+        for r in range(h.n_ref):
+            e.set_reference(r, refs[r])
+            e.set_known_sites(r, sites[r])
+        qt, ct, xt = e.recalibrate(500)
+        assert np.array_equal(ct, oc), ("cycle table", force)
+        assert np.array_equal(xt, ox) and np.array_equal(qt, oq), force
+        e.close()
