@@ -105,169 +105,307 @@ int bgzf_frame(elp_ctx *c, const uint8_t *raw, uint64_t n_bytes, uint8_t *out) {
 }
 
 
-// ------------------------------------------------------------------ inflate (RFC 1951), one THREAD per BGZF block
+// ------------------------------------------------------------------ inflate (RFC 1951), one WAVE per BGZF block
 // Reference: the reader inflates every block with compress/flate on a worker goroutine (utils/bgzf/bgzf-files.go:164-221) and checks
-// its CRC-32.  A BAM file of a 30x genome is a few hundred thousand independent blocks of <= 64 KB: one thread per block - a plain
-// sequential decoder, canonical Huffman codes decoded length by length from per-thread count / symbol arrays - keeps every lane of the
-// chip busy on a block of its own.
+// its CRC-32.  A BAM file of a 30x genome is a few hundred thousand independent blocks of <= 64 KB.  A wavefront takes a block: a 32 KB
+// ring of its output (DEFLATE's look-back; complete 16 KB parts go to HBM as the decoder advances), a 2 KB ring of the compressed bytes and
+// the decoding tables live in its LDS (~39 KB: four waves per CU); every lane runs the same
+// decoder on the same bits (no divergence), so the window is written by lane 0 for literals and by ALL lanes for a match (out[at + k] =
+// out[at - dist + k mod dist]), the ring is refilled and the window is flushed to HBM 16 bytes per lane.  Symbols are decoded by ONE
+// look-up of 9 (literal / length) resp. 8 (distance) bits; longer codes take the canonical bit-by-bit walk (count / symbol arrays), which
+// is also what builds the look-up tables - every lane decodes sixteen of the 1024 bit patterns.
+// (Round 4's first form gave a block to a THREAD, tables in private memory, bytes straight from / to HBM: a dependent round trip per
+// byte, 1.1 GB/s inflated.)
 struct BgzfBlk { uint64_t in_off; uint32_t in_len, out_len; uint64_t out_off; uint32_t crc; uint32_t pad; };  // CDATA in the piece; ISIZE; place in c->raw
 
+constexpr int INF_RING = 2048, INF_LBITS = 9, INF_DBITS = 8, INF_WIN = 32768, INF_FLUSH = 16384;
+struct InfLds {
+  uint8_t window[INF_WIN];  // a ring: DEFLATE looks back 32768 bytes at most; older output is in HBM already (Inflater::drain)
+  uint8_t ring[INF_RING];
+  uint32_t ltab[1 << INF_LBITS], dtab[1 << INF_DBITS];  // symbol << 8 | code length; 0: longer than the table's bits
+  uint16_t lcount[16], dcount[16], lsym[288], dsym[32];
+  uint8_t lengths[320];
+};
+__constant__ uint16_t INF_LENS[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__constant__ uint8_t INF_LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__constant__ uint16_t INF_DISTS[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__constant__ uint8_t INF_DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__constant__ uint8_t INF_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
 struct Inflater {
-  const uint8_t *in;
-  uint32_t in_len, in_at, bitbuf;
-  int bitcnt;
-  uint8_t *out;
+  InfLds *L;
+  const uint8_t *in;       // the block's compressed bytes (HBM)
+  uint32_t in_len, in_at;  // consumed so far
+  uint32_t loaded;         // bytes of the input that have been copied into the ring so far (a multiple of INF_RING / 2, or in_len)
+  unsigned long long bitbuf;
+  int bitcnt, err;
   uint32_t out_len, out_at;
-  int err;
-  __device__ __forceinline__ uint32_t bits(int need) {
-    uint32_t v = bitbuf;
-    while (bitcnt < need) {
-      if (in_at == in_len) { err = 1; return 0; }
-      v |= (uint32_t)in[in_at++] << bitcnt;
-      bitcnt += 8;
+  uint8_t *out;      // the block's place in HBM
+  uint32_t flushed;  // output bytes [0, flushed) are in HBM
+  // whole 16 KB parts of the window that are complete go out (16 bytes per lane and step; `out` is unaligned: the block's place in the
+  // stream).  Called often enough that a byte is in HBM before its slot of the ring is written again.
+  __device__ __forceinline__ void drain(bool all) {
+    while (out_at - flushed >= (uint32_t)INF_FLUSH + 512u || (all && flushed < out_at)) {
+      const uint32_t n = (all && out_at - flushed < (uint32_t)INF_FLUSH + 512u) ? out_at - flushed : (uint32_t)INF_FLUSH;
+      __syncthreads();
+      for (uint32_t k = (threadIdx.x & 63u) * 16u; k < n; k += 1024u) {
+        const uint32_t at = flushed + k;
+        if (k + 16u <= n) {
+          const uint4 v = *reinterpret_cast<const uint4 *>(&L->window[at & (INF_WIN - 1)]);  // (flushed is a multiple of 16: aligned, never wraps inside)
+          __builtin_memcpy(out + at, &v, 16);
+        } else {
+          for (uint32_t j = at; j < flushed + n; j++) out[j] = L->window[j & (INF_WIN - 1)];
+        }
+      }
+      flushed += n;
+      __syncthreads();
     }
-    bitbuf = need < 32 ? v >> need : 0u;
-    bitcnt -= need;
-    return need < 32 ? v & ((1u << need) - 1u) : v;
+  }
+  // the ring holds input [loaded - INF_RING, loaded): top it up whenever the reader enters its last half (all lanes, 32 bytes each)
+  __device__ __forceinline__ void feed() {
+    while (loaded < in_len && in_at + INF_RING / 2 > loaded) {
+      const uint32_t p = loaded + (threadIdx.x & 63u) * 16u;  // 64 lanes x 16 bytes = half the ring
+      __syncthreads();
+      if (p < in_len) {  // (the compressed bytes are followed by 8 bytes of trailer and the scratch buffer's padding: a 16-byte read is safe)
+        uint4 v;
+        __builtin_memcpy(&v, in + p, 16);
+        *reinterpret_cast<uint4 *>(&L->ring[p & (INF_RING - 1)]) = v;
+      }
+      __syncthreads();
+      loaded = loaded + INF_RING / 2 < in_len ? loaded + INF_RING / 2 : in_len;
+    }
+  }
+  // at least 48 bits in the buffer (or everything that is left): the next eight bytes of the ring are read at once (independent LDS
+  // reads: one round trip), as many of them as fit are taken
+  __device__ __forceinline__ void refill() {
+    if (bitcnt >= 48) return;
+    feed();
+    uint32_t nb = (uint32_t)(64 - bitcnt) >> 3;
+    nb = nb < in_len - in_at ? nb : in_len - in_at;
+    unsigned long long w = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) w |= (unsigned long long)L->ring[(in_at + (uint32_t)k) & (INF_RING - 1)] << (8 * k);
+    if (nb < 8) w &= (1ull << (8 * nb)) - 1ull;
+    bitbuf |= bitcnt < 64 ? w << bitcnt : 0ull;
+    in_at += nb;
+    bitcnt += 8 * (int)nb;
+  }
+  __device__ __forceinline__ uint32_t bits(int n) {  // n <= 16, taken from what refill() provided
+    if (bitcnt < n) { err = 1; return 0; }
+    const uint32_t v = (uint32_t)bitbuf & ((1u << n) - 1u);
+    bitbuf >>= n;
+    bitcnt -= n;
+    return v;
   }
 };
-struct Huff { int16_t count[16]; int16_t *symbol; };
-__device__ inline int huff_decode(Inflater &s, const Huff &h) {
+// canonical decoding of the next code in `word` (LSB first), at most 15 bits: symbol, *len = its length; -1: no such code
+__device__ inline int canon_decode(const uint16_t *count, const uint16_t *symbol, uint32_t word, int *len_out) {
   int code = 0, first = 0, index = 0;
   for (int len = 1; len <= 15; len++) {
-    code |= (int)s.bits(1);
-    if (s.err) return -1;
-    const int count = h.count[len];
-    if (code - count < first) return h.symbol[index + (code - first)];
-    index += count;
-    first += count;
+    code |= (int)(word & 1u);
+    word >>= 1;
+    const int cnt = count[len];
+    if (code - cnt < first) { *len_out = len; return symbol[index + (code - first)]; }
+    index += cnt;
+    first += cnt;
     first <<= 1;
     code <<= 1;
   }
   return -1;
 }
-// canonical code from the code lengths of n symbols; > 0: incomplete, < 0: over-subscribed
-__device__ inline int huff_construct(Huff &h, const int16_t *length, int n) {
-  int16_t offs[16];
-  for (int len = 0; len <= 15; len++) h.count[len] = 0;
-  for (int sym = 0; sym < n; sym++) h.count[length[sym]]++;
-  if (h.count[0] == n) return 0;
-  int left = 1;
-  for (int len = 1; len <= 15; len++) {
-    left <<= 1;
-    left -= h.count[len];
-    if (left < 0) return left;
+// count / symbol arrays of a canonical code from the code lengths of n symbols (lane 0; the arrays are tiny); > 0: incomplete, < 0:
+// over-subscribed.  Then the look-up table of `tbits` bits, every lane its share of the bit patterns.
+__device__ inline int huff_build(uint16_t *count, uint16_t *symbol, const uint8_t *length, int n, uint32_t *tab, int tbits) {
+  __shared__ int s_left[1];
+  // (one wave per workgroup: __shared__ here is the wave's own)
+  if ((threadIdx.x & 63u) == 0) {
+    uint16_t offs[16];
+    for (int len = 0; len <= 15; len++) count[len] = 0;
+    for (int sym = 0; sym < n; sym++) count[length[sym]]++;
+    int left = 1;
+    if (count[0] == n) left = 0;
+    else {
+      for (int len = 1; len <= 15 && left >= 0; len++) { left <<= 1; left -= count[len]; }
+      if (left >= 0) {
+        offs[1] = 0;
+        for (int len = 1; len < 15; len++) offs[len + 1] = offs[len] + count[len];
+        for (int sym = 0; sym < n; sym++)
+          if (length[sym] != 0) symbol[offs[length[sym]]++] = (uint16_t)sym;
+      }
+    }
+    s_left[0] = left;
   }
-  offs[1] = 0;
-  for (int len = 1; len < 15; len++) offs[len + 1] = offs[len] + h.count[len];
-  for (int sym = 0; sym < n; sym++)
-    if (length[sym] != 0) h.symbol[offs[length[sym]]++] = (int16_t)sym;
+  __syncthreads();  // (one wave per workgroup: orders its lanes' LDS writes before the reads that follow)
+  const int left = s_left[0];
+  if (left >= 0)
+    for (uint32_t idx = threadIdx.x & 63u; idx < (1u << tbits); idx += 64u) {
+      int len = 0;
+      const int sym = canon_decode(count, symbol, idx, &len);
+      tab[idx] = (sym >= 0 && len <= tbits) ? ((uint32_t)sym << 8) | (uint32_t)len : 0u;
+    }
+  __syncthreads();  // (one wave per workgroup: orders its lanes' LDS writes before the reads that follow)
   return left;
 }
-__constant__ int16_t INF_LENS[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__constant__ int16_t INF_LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__constant__ int16_t INF_DISTS[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-__constant__ int16_t INF_DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
-__constant__ uint8_t INF_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-
-__device__ inline int inflate_codes(Inflater &s, const Huff &lencode, const Huff &distcode) {
+__device__ __forceinline__ int inf_symbol(Inflater &s, const uint32_t *tab, int tbits, const uint16_t *count, const uint16_t *symbol) {
+  const uint32_t e = tab[(uint32_t)s.bitbuf & ((1u << tbits) - 1u)];
+  if (e) {
+    const int len = (int)(e & 0xFFu);
+    if (s.bitcnt < len) { s.err = 1; return -1; }
+    s.bitbuf >>= len;
+    s.bitcnt -= len;
+    return (int)(e >> 8);
+  }
+  int len = 0;
+  const int sym = canon_decode(count, symbol, (uint32_t)s.bitbuf, &len);
+  if (sym < 0 || s.bitcnt < len) { s.err = 1; return -1; }
+  s.bitbuf >>= len;
+  s.bitcnt -= len;
+  return sym;
+}
+__device__ inline int inflate_codes(Inflater &s) {
+  InfLds *L = s.L;
+  const uint32_t lane = threadIdx.x & 63u;
   for (;;) {
-    int symbol = huff_decode(s, lencode);
+    s.refill();
+    s.drain(false);
+    int symbol = inf_symbol(s, L->ltab, INF_LBITS, L->lcount, L->lsym);
     if (symbol < 0) return 2;
     if (symbol < 256) {
       if (s.out_at == s.out_len) return 3;
-      s.out[s.out_at++] = (uint8_t)symbol;
+      if (lane == 0) L->window[s.out_at & (INF_WIN - 1)] = (uint8_t)symbol;
+      s.out_at++;
     } else if (symbol == 256) {
       return 0;
     } else {
       symbol -= 257;
       if (symbol >= 29) return 4;
-      const int len = INF_LENS[symbol] + (int)s.bits(INF_LEXT[symbol]);
-      symbol = huff_decode(s, distcode);
+      const uint32_t len = (uint32_t)INF_LENS[symbol] + s.bits(INF_LEXT[symbol]);
+      symbol = inf_symbol(s, L->dtab, INF_DBITS, L->dcount, L->dsym);
       if (symbol < 0 || symbol >= 30) return 5;
       const uint32_t dist = (uint32_t)INF_DISTS[symbol] + s.bits(INF_DEXT[symbol]);
       if (s.err) return 1;
       if (dist > s.out_at) return 6;
-      if (s.out_at + (uint32_t)len > s.out_len) return 3;
-      for (int k = 0; k < len; k++, s.out_at++) s.out[s.out_at] = s.out[s.out_at - dist];
+      if (s.out_at + len > s.out_len) return 3;
+      // the match, all lanes: byte k comes from the dist bytes in front of the match, periodically (they are all written already)
+      const uint32_t from = s.out_at - dist;
+      for (uint32_t k = lane; k < len; k += 64u) L->window[(s.out_at + k) & (INF_WIN - 1)] = L->window[(from + (dist >= len ? k : k % dist)) & (INF_WIN - 1)];
+      s.out_at += len;
     }
   }
 }
 
 __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__ cdata, const BgzfBlk *__restrict__ blk, uint32_t n_blk, uint8_t *__restrict__ raw,
                                                      uint32_t *err) {
-  const uint32_t b = blockIdx.x * 64 + threadIdx.x;
-  if (b >= n_blk) return;
-  const BgzfBlk B = blk[b];
-  Inflater s{cdata + B.in_off, B.in_len, 0, 0, 0, raw + B.out_off, B.out_len, 0, 0};
-  int16_t lengths[320], lensym[288], distsym[30];
-  Huff lencode, distcode;
-  lencode.symbol = lensym;
-  distcode.symbol = distsym;
+  __shared__ __attribute__((aligned(16))) InfLds L;
+  const uint32_t lane = threadIdx.x;
+  const BgzfBlk B = blk[blockIdx.x];
+  Inflater s{&L, cdata + B.in_off, B.in_len, 0, 0, 0ull, 0, 0, B.out_len, 0, raw + B.out_off, 0};
   int rc = 0, last;
   do {
+    s.refill();
     last = (int)s.bits(1);
     const int type = (int)s.bits(2);
     if (s.err) { rc = 1; break; }
-    if (type == 0) {  // stored
-      s.bitbuf = 0;
-      s.bitcnt = 0;
-      if (s.in_at + 4 > s.in_len) { rc = 1; break; }
-      const uint32_t len = s.in[s.in_at] | ((uint32_t)s.in[s.in_at + 1] << 8), nlen = s.in[s.in_at + 2] | ((uint32_t)s.in[s.in_at + 3] << 8);
-      s.in_at += 4;
+    if (type == 0) {  // stored: back to a byte boundary, LEN, NLEN, the bytes
+      const int drop = s.bitcnt & 7;
+      s.bitbuf >>= drop;
+      s.bitcnt -= drop;
+      s.refill();
+      const uint32_t len = s.bits(16), nlen = s.bits(16);
+      if (s.err) { rc = 1; break; }
       if (len != (~nlen & 0xFFFFu)) { rc = 7; break; }
-      if (s.in_at + len > s.in_len) { rc = 1; break; }
       if (s.out_at + len > s.out_len) { rc = 3; break; }
-      for (uint32_t k = 0; k < len; k++) s.out[s.out_at++] = s.in[s.in_at++];
+      uint32_t done = 0;
+      while (done < len) {  // what the bit buffer still holds first, then ring pieces
+        if (s.bitcnt) {
+          if (lane == 0) L.window[s.out_at & (INF_WIN - 1)] = (uint8_t)s.bitbuf;
+          s.bitbuf >>= 8;
+          s.bitcnt -= 8;
+          s.out_at++;
+          done++;
+          continue;
+        }
+        s.feed();
+        const uint32_t avail = s.loaded - s.in_at;
+        uint32_t piece = (len - done) < avail ? (len - done) : avail;
+        piece = piece < 1024u ? piece : 1024u;  // (the window is drained between pieces)
+        if (!piece) { rc = 1; break; }
+        __syncthreads();
+        for (uint32_t k = lane; k < piece; k += 64u) L.window[(s.out_at + k) & (INF_WIN - 1)] = L.ring[(s.in_at + k) & (INF_RING - 1)];
+        s.in_at += piece;
+        s.out_at += piece;
+        done += piece;
+        s.drain(false);
+        continue;
+      }
+      if (rc) break;
     } else if (type == 1) {  // fixed codes
-      int sym = 0;
-      for (; sym < 144; sym++) lengths[sym] = 8;
-      for (; sym < 256; sym++) lengths[sym] = 9;
-      for (; sym < 280; sym++) lengths[sym] = 7;
-      for (; sym < 288; sym++) lengths[sym] = 8;
-      huff_construct(lencode, lengths, 288);
-      for (sym = 0; sym < 30; sym++) lengths[sym] = 5;
-      huff_construct(distcode, lengths, 30);
-      rc = inflate_codes(s, lencode, distcode);
+      for (uint32_t sym = lane; sym < 288; sym += 64) L.lengths[sym] = sym < 144 ? 8 : (sym < 256 ? 9 : (sym < 280 ? 7 : 8));
+      __syncthreads();  // (one wave per workgroup: orders its lanes' LDS writes before the reads that follow)
+      huff_build(L.lcount, L.lsym, L.lengths, 288, L.ltab, INF_LBITS);
+      if (lane < 30) L.lengths[lane] = 5;
+      __syncthreads();  // (one wave per workgroup: orders its lanes' LDS writes before the reads that follow)
+      huff_build(L.dcount, L.dsym, L.lengths, 30, L.dtab, INF_DBITS);
+      rc = inflate_codes(s);
     } else if (type == 2) {  // dynamic codes
       const int nlen = (int)s.bits(5) + 257, ndist = (int)s.bits(5) + 1, ncode = (int)s.bits(4) + 4;
       if (s.err) { rc = 1; break; }
       if (nlen > 286 || ndist > 30) { rc = 8; break; }
+      if (lane < 19) L.lengths[lane] = 0;
+      __syncthreads();  // (one wave per workgroup: orders its lanes' LDS writes before the reads that follow)
+      for (int index = 0; index < ncode; index++) {
+        s.refill();
+        const uint32_t v = s.bits(3);
+        if (lane == 0) L.lengths[INF_ORDER[index]] = (uint8_t)v;
+      }
+      __syncthreads();  // (one wave per workgroup: orders its lanes' LDS writes before the reads that follow)
+      if (huff_build(L.lcount, L.lsym, L.lengths, 19, L.ltab, INF_LBITS) != 0) { rc = 9; break; }
+      // the code lengths of the two codes (decoded with the code-length code, which sits in ltab for the moment) -> lengths[0 .. nlen + ndist)
       int index = 0;
-      for (; index < ncode; index++) lengths[INF_ORDER[index]] = (int16_t)s.bits(3);
-      for (; index < 19; index++) lengths[INF_ORDER[index]] = 0;
-      if (huff_construct(lencode, lengths, 19) != 0) { rc = 9; break; }
-      index = 0;
+      uint32_t prev = 0;
       while (index < nlen + ndist) {
-        int symbol = huff_decode(s, lencode);
+        s.refill();
+        const int symbol = inf_symbol(s, L.ltab, INF_LBITS, L.lcount, L.lsym);
         if (symbol < 0) { rc = 2; break; }
-        if (symbol < 16) lengths[index++] = (int16_t)symbol;
-        else {
-          int len = 0, rep;
+        if (symbol < 16) {
+          if (lane == 0) L.lengths[index] = (uint8_t)symbol;
+          prev = (uint32_t)symbol;
+          index++;
+        } else {
+          uint32_t len = 0;
+          int rep;
           if (symbol == 16) {
             if (index == 0) { rc = 10; break; }
-            len = lengths[index - 1];
+            len = prev;
             rep = 3 + (int)s.bits(2);
           } else if (symbol == 17) rep = 3 + (int)s.bits(3);
           else rep = 11 + (int)s.bits(7);
           if (index + rep > nlen + ndist) { rc = 11; break; }
-          while (rep--) lengths[index++] = (int16_t)len;
+          if ((int)lane < rep) L.lengths[index + lane] = (uint8_t)len;
+          if ((int)lane + 64 < rep) L.lengths[index + lane + 64] = (uint8_t)len;
+          if ((int)lane + 128 < rep) L.lengths[index + lane + 128] = (uint8_t)len;
+          index += rep;
+          prev = len;
         }
       }
       if (rc) break;
-      if (lengths[256] == 0) { rc = 12; break; }
-      // (the distance lengths are moved to the front of a second array: huff_construct indexes its input by symbol)
-      int16_t dl[30];
-      for (int k = 0; k < ndist; k++) dl[k] = lengths[nlen + k];
-      int e = huff_construct(lencode, lengths, nlen);
-      if (e && (e < 0 || nlen != lencode.count[0] + lencode.count[1])) { rc = 13; break; }
-      e = huff_construct(distcode, dl, ndist);
-      if (e && (e < 0 || ndist != distcode.count[0] + distcode.count[1])) { rc = 14; break; }
-      rc = inflate_codes(s, lencode, distcode);
+      __syncthreads();  // (one wave per workgroup: orders its lanes' LDS writes before the reads that follow)
+      if (L.lengths[256] == 0) { rc = 12; break; }
+      // the distance code first (its lengths sit behind the literal / length code's; huff_build indexes its input by symbol)
+      int e = huff_build(L.dcount, L.dsym, L.lengths + nlen, ndist, L.dtab, INF_DBITS);
+      if (e && (e < 0 || ndist != (int)L.dcount[0] + (int)L.dcount[1])) { rc = 14; break; }
+      e = huff_build(L.lcount, L.lsym, L.lengths, nlen, L.ltab, INF_LBITS);
+      if (e && (e < 0 || nlen != (int)L.lcount[0] + (int)L.lcount[1])) { rc = 13; break; }
+      rc = inflate_codes(s);
     } else rc = 15;
   } while (!rc && !last);
   if (!rc && s.out_at != s.out_len) rc = 16;  // ISIZE promised another number of bytes
-  if (rc) atomicOr(&err[0], 1u);
+  if (rc) {
+    if (lane == 0) atomicOr(&err[0], 1u);
+    return;
+  }
+  s.drain(true);  // what is left of the window
+  (void)n_blk;
 }
 
 // CRC-32 of every inflated block against the value in its trailer (one workgroup per block, as in k_bgzf_frame)
@@ -511,7 +649,7 @@ extern "C" int elp_stage_bgzf(elp_ctx *c, const uint8_t *bgzf, uint64_t n_bytes,
     ELP_HIP(c, hipMemcpyAsync(d_blk, tb.data(), (size_t)nb * sizeof(BgzfBlk), hipMemcpyHostToDevice, st));
     ELP_HIP(c, hipMemsetAsync(res, 0, 64, st));
     uint32_t *err = reinterpret_cast<uint32_t *>(res), *bad = err + 1, *max_rec = err + 2;
-    ELP_LAUNCH(c, "stage_bgzf_inflate", k_bgzf_inflate, dim3(blocks_for(nb, 64)), dim3(64), 0, (const uint8_t *)d_in, (const BgzfBlk *)d_blk, nb, c->raw.p, err);
+    ELP_LAUNCH(c, "stage_bgzf_inflate", k_bgzf_inflate, dim3(nb), dim3(64), 0, (const uint8_t *)d_in, (const BgzfBlk *)d_blk, nb, c->raw.p, err);
     ELP_LAUNCH(c, "stage_bgzf_crc", k_bgzf_crc_check, dim3(nb), dim3(256), 0, (const uint8_t *)c->raw.p, (const BgzfBlk *)d_blk, pw, err);
     const uint64_t end = tb.back().out_off + tb.back().out_len;
     const RecScan rs{c->raw.p, begin, end, c->n_ref};
