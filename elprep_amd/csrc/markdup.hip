@@ -21,6 +21,7 @@
 namespace elp {
 
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+constexpr unsigned long long PB_EMPTY = ~0ull;  // an empty slot of the LDS tables (k_pair_bucket, k_mate_bucket)
 
 struct MdCols {
   uint64_t n;
@@ -303,8 +304,8 @@ __global__ __launch_bounds__(MS_THREADS) void k_mate_scan(MdCols m, uint8_t *__r
       for (uint32_t k = 32; k < la; k += 8) h = (h ^ low_bytes(load8(pa + k), la - k)) * K + (h >> 29);
       h = mix64(h ^ ((uint64_t)lia << 48) ^ ((uint64_t)sa << 24));
       const uint32_t hi = (uint32_t)(h >> 32);
-      if (cd == MC_LEAD) hash32[i] = hi;
-      else atomicOr(&bloom[(hi >> 5) & bloom_mask], 1u << (hi & 31u));
+      hash32[i] = hi;  // (a follower's key is its leader's: hash32[i - 1])
+      if (cd != MC_LEAD) atomicOr(&bloom[(hi >> 5) & bloom_mask], 1u << (hi & 31u));
     }
   }
   if (t < 256 && i < m.n) code[i] = cd;
@@ -359,7 +360,9 @@ __global__ __launch_bounds__(256) void k_mate_pairs(MdCols m, const uint4 *__res
                                                     const uint32_t *__restrict__ coarse /* null: nobody announced a key */,
                                                     uint32_t *table, uint64_t mask, uint32_t *mate, uint32_t *rep_of, uint32_t *err,
                                                     const uint32_t *__restrict__ ftable, const uint32_t *__restrict__ fbits, uint64_t fmask /* 0: no fragments */,
-                                                    unsigned long long *fbest, int fixed, uint64_t *__restrict__ pk, uint32_t *__restrict__ pv) {
+                                                    unsigned long long *fbest, int fixed /* 2: every candidate is matched by the partitioned pass
+                                                    (k_mate_bucket) - only the fragment look-ups and the marks are made here */,
+                                                    uint64_t *__restrict__ pk, uint32_t *__restrict__ pv) {
   const uint64_t base = (uint64_t)blockIdx.x * (256 * MP_R) + threadIdx.x;
   uint8_t cd[MP_R];
   uint4 mine[MP_R], prev[MP_R], kc[MP_R];
@@ -422,12 +425,14 @@ __global__ __launch_bounds__(256) void k_mate_pairs(MdCols m, const uint4 *__res
     }
     bool own = false;
     uint64_t key = 0;
-    if (cd[r] != MC_NONE) {  // a candidate that is a true pair
+    if (cd[r] != MC_NONE && fixed == 2) {
+      code[i] = (uint8_t)(cd[r] | MC_TABBED);
+    } else if (cd[r] != MC_NONE) {  // a candidate that is a true pair
       const bool tab = cd[r] == MC_TABLE || ((bl[r] >> (hi[r] & 31u)) & 1u);
       if (!tab) {  // nobody else announced this key: the two neighbours are the pair
         mate[i] = cd[r] == MC_LEAD ? (uint32_t)i + 1 : (uint32_t)i - 1;
         if (cd[r] == MC_FOLLOW) {
-          if (fixed) {
+          if (fixed == 1) {
             own = true;
             key = ((uint64_t)(uint32_t)sc[r] << 32) | (uint32_t)pair_hash(pair_key(mine[r], prev[r]));
           } else {
@@ -449,7 +454,7 @@ __global__ __launch_bounds__(256) void k_mate_pairs(MdCols m, const uint4 *__res
         }
       }
     }
-    if (fixed) {
+    if (fixed == 1) {
       const int next_owns = __shfl_down((int)own, 1, 64);
       if (own) {
         pk[i >> 1] = key;
@@ -458,6 +463,81 @@ __global__ __launch_bounds__(256) void k_mate_pairs(MdCols m, const uint4 *__res
         pk[i >> 1] = 0xFFFFFFFF00000000ull | (uint32_t)mix64(i);
         pv[i >> 1] = EMPTY;
       }
+    }
+  }
+}
+
+// ---- mates that are NOT neighbours (coordinate-ordered or shuffled input: every candidate would go through the table in HBM, one
+// random compare-and-swap each).  The same remedy as for the pairs: the candidates' {32 hash bits of the mate key, record} entries are
+// partitioned by hash bits (the sort's scatter passes), one workgroup per bucket matches its entries in an LDS table.  The table pairs
+// records up exactly as the global one does (first at the slot = representative, the second claims it, a third marks the group BIG for
+// the arrival-order pairing) - DeleteOrStore toggling, :336-340.
+constexpr int ML_TILES = 8;
+__global__ __launch_bounds__(256) void k_mate_list(uint64_t n, const uint8_t *__restrict__ code, const uint32_t *__restrict__ hash32, uint64_t *__restrict__ mk,
+                                                   uint32_t *__restrict__ mv, uint32_t *ne) {
+  __shared__ uint64_t lk[ML_TILES * 256];
+  __shared__ uint32_t lv[ML_TILES * 256];
+  __shared__ uint32_t lcount, gbase;
+  if (threadIdx.x == 0) lcount = 0;
+  __syncthreads();
+#pragma unroll 2
+  for (int tile = 0; tile < ML_TILES; tile++) {
+    const uint64_t i = ((uint64_t)blockIdx.x * ML_TILES + (uint64_t)tile) * 256 + threadIdx.x;
+    const uint8_t cd = i < n ? (uint8_t)(code[i] & MC_KIND) : (uint8_t)MC_NONE;
+    const bool cand = cd != MC_NONE;
+    const uint32_t h = cand ? hash32[cd == MC_FOLLOW ? i - 1 : i] : 0u;
+    const unsigned long long mask = __ballot(cand);
+    if (mask) {
+      const int lane = threadIdx.x & 63, leader = __ffsll((long long)mask) - 1;
+      uint32_t at = 0;
+      if (lane == leader) at = atomicAdd(&lcount, (uint32_t)__popcll(mask));
+      at = __shfl(at, leader, 64);
+      if (cand) {
+        at += (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        lk[at] = (uint64_t)h;
+        lv[at] = (uint32_t)i;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) gbase = lcount ? atomicAdd(ne, lcount) : 0u;
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < lcount; k += 256) {
+    mk[gbase + k] = lk[k];
+    mv[gbase + k] = lv[k];
+  }
+}
+constexpr int MB_TARGET = 640, MB_CAP = 2048;
+__global__ __launch_bounds__(256) void k_mate_bucket(MdCols m, const uint64_t *__restrict__ ks, const uint32_t *__restrict__ vs, const uint32_t *__restrict__ bstart,
+                                                     const uint32_t *__restrict__ bend, uint32_t *mate, uint32_t *rep_of, uint32_t *err) {
+  __shared__ unsigned long long s_key[MB_CAP];  // hash bits << 32 | representative (the first record of its key to arrive at the slot)
+  __shared__ uint32_t s_mate[MB_CAP];           // the second one
+  const uint32_t start = bstart[blockIdx.x], cnt = bend[blockIdx.x] - start;
+  if (cnt == 0) return;
+  const uint32_t t = threadIdx.x;
+  uint32_t T = 2;
+  while (T < 2 * cnt && T < (uint32_t)MB_CAP) T <<= 1;
+  const uint32_t tmask = T - 1;
+  for (uint32_t k = t; k < T; k += 256) { s_key[k] = PB_EMPTY; s_mate[k] = EMPTY; }
+  __syncthreads();
+  for (uint32_t e = t; e < cnt; e += 256) {
+    const uint32_t h32 = (uint32_t)ks[start + e], i = vs[start + e];
+    const unsigned long long mine = ((unsigned long long)h32 << 32) | i;
+    uint32_t idx = ((h32 * 0x9E3779B1u) >> 16) & tmask;
+    uint32_t rep = EMPTY, slot = 0;
+    for (uint32_t probes = 0; probes <= tmask; probes++, idx = (idx + 1) & tmask) {
+      const unsigned long long cur = atomicCAS(&s_key[idx], PB_EMPTY, mine);
+      if (cur == PB_EMPTY) { rep = i; slot = idx; break; }
+      if ((uint32_t)(cur >> 32) == h32 && mate_key_eq(m, (uint32_t)cur, i)) { rep = (uint32_t)cur; slot = idx; break; }
+    }
+    if (rep == EMPTY) { atomicOr(&err[1], 4u); continue; }  // the table is full (keys crafted to share hash bits): the host takes the table in HBM
+    if (rep == i) continue;  // first of its key at the slot: waits for the second
+    rep_of[i] = rep;
+    const uint32_t old = atomicCAS(&s_mate[slot], EMPTY, i);
+    if (old == EMPTY) { mate[i] = rep; mate[rep] = i; }
+    else {
+      rep_of[rep] = MATE_BIG;  // more than two records share {split, library, QNAME}
+      atomicOr(&err[1], 1u);
     }
   }
 }
@@ -591,7 +671,6 @@ constexpr int PB_THREADS = 256;
 constexpr int PB_TARGET = 384;     // the list is partitioned until a bucket holds at most this many entries on average
 constexpr int PB_CAP = 1024;       // table slots in LDS
 constexpr int PB_ECAP = 1024;      // entries whose table slot is remembered in LDS between the phases (the others look theirs up again)
-constexpr unsigned long long PB_EMPTY = ~0ull;
 
 // table slot of entry {h32, o}: find-or-insert.  Returns -1 if the table is full.
 __device__ __forceinline__ int pb_slot(const MdCols &m, const uint4 *__restrict__ fkey, const uint32_t *__restrict__ mate,
@@ -775,10 +854,12 @@ static int markdup_impl(elp_ctx *c) {
   for (int k = 0; k < 64; k++) n_tab += n_tab64[k * 16];
   if (n_tab) ELP_LAUNCH(c, "md_bloom_coarse", k_bloom_coarse, dim3(blocks_for(bw / 16, 256)), dim3(256), 0, (const uint32_t *)bloom, (uint32_t)(bw / 16), coarse);
 
-  // aligner order (few candidates need the table): the neighbour pairs' entries go to fixed slots, the table's pairs behind them
-  const bool fixed = (uint64_t)n_tab < n / 8;
-  const uint64_t nfixed = fixed ? (n + 1) / 2 : 0, npmax = nfixed + n / 2 + 1;
-  // pair list (two buffers each for the radix passes) | fragment table and its occupancy bits
+  // aligner order (few candidates need a table): the neighbour pairs' entries go to fixed slots, the table's pairs behind them.  Else
+  // (coordinate-ordered, shuffled input) every candidate is matched by the partitioned pass (k_mate_list, k_mate_bucket)
+  const bool fixed = (uint64_t)n_tab < n / 8 && c->tune.mate_path == 0;
+  int mate_mode = fixed ? 1 : (c->tune.mate_path == 2 ? 0 : 2);  // 1 neighbours + table in HBM for the rest, 2 partitioned, 0 table in HBM for all
+  const uint64_t nfixed = fixed ? (n + 1) / 2 : 0, npmax = std::max<uint64_t>(nfixed + n / 2 + 1, fixed ? 0 : n + 1);
+  // pair list (two buffers each for the radix passes; the partitioned mate pass uses them first) | fragment table and its occupancy bits
   const uint64_t Tf = nf ? std::min<uint64_t>(T, table_size_for(4ull * nf)) : 0;  // sparse: most look-ups of the pairs end at an empty slot
   uint64_t *pk;
   ELP_TRY(scratch(c, 7, 2 * npmax + (2 * npmax + Tf + Tf / 32 + 64) / 2 + 8, &pk));
@@ -793,19 +874,48 @@ static int markdup_impl(elp_ctx *c) {
     ELP_LAUNCH(c, "md_frag_bits", k_frag_bits, dim3(blocks_for(Tf / 32, 256)), dim3(256), 0, (const uint32_t *)ftable, Tf / 32, fbits);
   }
 
-  uint64_t Tm = std::min<uint64_t>(T, table_size_for(std::min<uint64_t>(n, 4ull * n_tab + 1024)));
+  uint64_t Tm = mate_mode == 0 ? T : std::min<uint64_t>(T, table_size_for(std::min<uint64_t>(n, 4ull * n_tab + 1024)));
   uint32_t e[4];
   for (;;) {
-    ELP_HIP(c, hipMemsetAsync(table, 0xFF, Tm * sizeof(uint32_t), st));
+    if (mate_mode != 2) ELP_HIP(c, hipMemsetAsync(table, 0xFF, Tm * sizeof(uint32_t), st));
     ELP_HIP(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(np_dev), (int)(uint32_t)nfixed, 1, st));
     ELP_LAUNCH(c, "md_mate_pairs", k_mate_pairs, dim3(blocks_for(n, 256 * MP_R)), dim3(256), 0, m, (const uint4 *)fkey, code,
                (const uint32_t *)hash32, (const uint32_t *)bloom, (uint32_t)(bw - 1), (const uint32_t *)(n_tab ? coarse : nullptr), table, Tm - 1, c->mate.p, rep_of, c->err_flag.p,
-               (const uint32_t *)ftable, (const uint32_t *)fbits, nf ? Tf - 1 : (uint64_t)0, best, fixed ? 1 : 0, pk, pv);
+               (const uint32_t *)ftable, (const uint32_t *)fbits, nf ? Tf - 1 : (uint64_t)0, best, mate_mode == 1 ? 1 : (mate_mode == 2 ? 2 : 0), pk, pv);
+    if (mate_mode == 2) {
+      int mbits = 0;
+      while (mbits < 24 && ((n + 1) >> mbits) > (uint64_t)MB_TARGET) mbits++;
+      const int mdig = (mbits + 7) / 8, msbits = 8 * mdig;
+      const size_t mnb = (size_t)1 << mbits;
+      uint32_t *ne_dev = c->md_ctr.p + 2, *mbounds;
+      ELP_TRY(scratch(c, 0, 2 * mnb + 8, &mbounds));  // (the table in HBM is not used in this mode)
+      ELP_HIP(c, hipMemsetAsync(ne_dev, 0, 4, st));
+      ELP_HIP(c, hipMemsetAsync(mbounds, 0, 2 * mnb * sizeof(uint32_t), st));
+      ELP_LAUNCH(c, "md_mate_list", k_mate_list, dim3(blocks_for(n, 256 * ML_TILES)), dim3(256), 0, n, (const uint8_t *)code, (const uint32_t *)hash32, pk, pv, ne_dev);
+      uint64_t *mks = pk;
+      uint32_t *mvs = pv;
+      if (mdig) {
+        ProfScope ps(c, "md_mate_");
+        ELP_TRY(radix_sort_pairs_low(c, pk, pv, pk + npmax, pv + npmax, n + 1, mdig, &mks, &mvs, nullptr, false, ne_dev));
+      }
+      ELP_LAUNCH(c, "md_mate_bounds", k_pair_bounds, dim3(blocks_for(n + 1, 256)), dim3(256), 0, (const uint64_t *)mks, (const uint32_t *)ne_dev, msbits, mbits, mbounds,
+                 mbounds + mnb);
+      ELP_LAUNCH(c, "md_mate_bucket", k_mate_bucket, dim3((unsigned)mnb), dim3(256), 0, m, (const uint64_t *)mks, (const uint32_t *)mvs, (const uint32_t *)mbounds,
+                 (const uint32_t *)(mbounds + mnb), c->mate.p, rep_of, c->err_flag.p);
+      // (`table` may have been re-pointed by the scratch call above: take it again for a fall-back pass)
+      ELP_TRY(scratch(c, 0, T, &table));
+    }
     ELP_TRY(fetch_err(c, e));
-    if (!(e[1] & 2u)) break;
-    if (Tm == T) return set_error(c, ELP_ERR_HIP, "mark duplicates: mate table overflow");
-    // more Bloom-filter hits than estimated: once more with the full-size table (the look-ups and entries are simply made again)
-    Tm = T;
+    if (mate_mode == 2 && (e[1] & 4u)) {
+      // a bucket's keys did not fit its LDS table (keys crafted to share hash bits): the table in HBM takes all candidates
+      mate_mode = 0;
+      Tm = T;
+    } else if (!(e[1] & 2u)) {
+      break;
+    } else {
+      if (Tm == T) return set_error(c, ELP_ERR_HIP, "mark duplicates: mate table overflow");
+      Tm = T;  // more Bloom-filter hits than estimated: once more with the full-size table (the look-ups and entries are simply made again)
+    }
     ELP_HIP(c, hipMemsetAsync(c->err_flag.p + 1, 0, 4, st));
     ELP_HIP(c, hipMemsetAsync(c->mate.p, 0xFF, n * sizeof(uint32_t), st));
     ELP_HIP(c, hipMemsetAsync(rep_of, 0xFF, n * sizeof(uint32_t), st));

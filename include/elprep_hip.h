@@ -331,7 +331,8 @@ int elp_rollback(elp_ctx *ctx);
  *   "qual_hint_drop"   q >= 0: quality q is removed from the sampled hint (the kernels' no-slot paths)
  *   "pair_table_slots" cap on the LDS table slots per pair bucket of elp_mark_duplicates (a power of two >= 2; 0 = no cap): a
  *                      small value sends every bucket through the overflow path
- *   "mate_path"        1: every mate candidate is matched through the partitioned table, no neighbour shortcut
+ *   "mate_path"        1: every mate candidate is matched by the partitioned pass (hash partition + LDS tables), no neighbour
+ *                      shortcut - what coordinate-ordered or shuffled input takes by itself; 2: ... by the table in HBM
  * Returns ELP_ERR_ARG for an unknown key or a value out of range. */
 int elp_set_tuning(elp_ctx *ctx, const char *key, int64_t value);
 

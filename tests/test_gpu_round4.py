@@ -327,3 +327,37 @@ def test_count_split_by_covariate(n_cov, n_q, length):
         assert np.array_equal(ct, oc), ("cycle table", force)
         assert np.array_equal(xt, ox) and np.array_equal(qt, oq), force
         e.close()
+
+
+@pytest.mark.parametrize("mate_path", [0, 1, 2])
+def test_mates_by_every_path(mate_path):
+    """the neighbour shortcut (0, aligner order), the partitioned pass (1: hash partition + LDS tables, what shuffled input takes) and the
+    table in HBM (2) pair the same records: aligner order, shuffled order, and the DeleteOrStore toggling cases with three and four records
+    per QNAME (the arrival-order pairing of big groups) - flags, counters and set-size histograms against the oracle"""
+    from tests import kat_cases
+    from elprep_amd.batch import Batch
+    tune = {"mate_path": mate_path}
+    cfg, b, h, refs, sites = dataset("tiny", 20000, 8, 0.03)
+    rng = np.random.default_rng(4)
+    for batch in (b, b.take(rng.permutation(b.n))):
+        oflags, octr, ohist = orc.dup_metrics(batch, h, None, 100, hist_len=16)
+        flags, ctr, hist = _flags_and_metrics(batch, h, tune)
+        assert np.array_equal(flags, oflags)
+        assert np.array_equal(ctr, octr) and np.array_equal(hist, ohist)
+    h2 = kat_cases.header2()
+    for k, (tb, want) in enumerate(kat_cases.toggling_cases()):
+        e = Engine(h2, tuning=tune)
+        e.stage(tb)
+        flags = e.mark_duplicates(True)
+        assert np.nonzero(flags & 0x400)[0].tolist() == want, k
+        e.close()
+    # a third primary record for 300 QNAMEs, anywhere in a shuffled batch
+    cand = np.nonzero(((b.flag & 0x904) == 0) & ((b.flag & 0x9) == 0x1))[0]
+    ext = b.take(rng.choice(cand, 300, replace=False))
+    ext.pos[:] = np.maximum(1, ext.pos + rng.integers(-40, 40, ext.n)).astype(np.int32)
+    pb = Batch.concat([b, ext])
+    pb = pb.take(rng.permutation(pb.n))
+    e = Engine(h, tuning=tune)
+    e.stage(pb)
+    assert np.array_equal(e.mark_duplicates(True), orc.mark_duplicates(pb, h))
+    e.close()
