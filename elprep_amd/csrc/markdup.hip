@@ -857,7 +857,11 @@ static int markdup_impl(elp_ctx *c) {
   // aligner order (few candidates need a table): the neighbour pairs' entries go to fixed slots, the table's pairs behind them.  Else
   // (coordinate-ordered, shuffled input) every candidate is matched by the partitioned pass (k_mate_list, k_mate_bucket)
   const bool fixed = (uint64_t)n_tab < n / 8 && c->tune.mate_path == 0;
-  int mate_mode = fixed ? 1 : (c->tune.mate_path == 2 ? 0 : 2);  // 1 neighbours + table in HBM for the rest, 2 partitioned, 0 table in HBM for all
+  // 1 neighbours + table in HBM for the rest, 2 partitioned, 0 table in HBM for all.  Measured (16 M reads staged in random order,
+  // tools/prof/shuffled_md.py): partitioned 1.59 (buckets) + 0.32 (two scatter passes) + 0.15 (list, bounds) ms, table in HBM 1.84 ms - both
+  // are bound by the ~10 random loads of the key comparison every pair needs once (two names, their offsets, read group -> library, split),
+  // not by the insert; the table in HBM therefore stays the default for input whose mates are not neighbours
+  int mate_mode = fixed ? 1 : (c->tune.mate_path == 1 ? 2 : 0);
   const uint64_t nfixed = fixed ? (n + 1) / 2 : 0, npmax = std::max<uint64_t>(nfixed + n / 2 + 1, fixed ? 0 : n + 1);
   // pair list (two buffers each for the radix passes; the partitioned mate pass uses them first) | fragment table and its occupancy bits
   const uint64_t Tf = nf ? std::min<uint64_t>(T, table_size_for(4ull * nf)) : 0;  // sparse: most look-ups of the pairs end at an empty slot
