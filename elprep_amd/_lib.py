@@ -25,7 +25,7 @@ HIP_SYMBOLS = [
     "elp_dup_metrics", "elp_dup_metrics_hist", "elp_bqsr_set_reference", "elp_bqsr_set_known_sites", "elp_bqsr_gather", "elp_bqsr_apply", "elp_get_qual",
     "elp_bqsr_gather_device", "elp_bqsr_tables_fetch", "elp_group_unique_id", "elp_group_init", "elp_group_rank", "elp_group_size",
     "elp_bqsr_tables_add", "elp_bqsr_tables_allreduce", "elp_allreduce_i64",
-    "elp_filter_records", "elp_split_classify", "elp_merge_spread",
+    "elp_filter_records", "elp_clean_sam", "elp_split_classify", "elp_merge_spread",
     "elp_set_read_group_ids", "elp_pinned_alloc", "elp_pinned_free", "elp_stage_bam", "elp_emit_sorted_bam", "elp_stage_bgzf", "elp_emit_sorted_bgzf",
     "elp_set_header_columns", "elp_stage_columns", "elp_set_read_group_ids_flat", "elp_filter_records_flat", "elp_group_probe", "elp_group_init_transport", "elp_copy_records", "elp_exchange_records", "elp_group_set_p2p", "elp_emit_merged_bam", "elp_bqsr_lut_upload",
     "elp_snapshot", "elp_rollback", "elp_set_tuning", "elp_profile_enable", "elp_profile_reset", "elp_profile_count", "elp_profile_get",
@@ -92,6 +92,7 @@ def hip() -> C.CDLL:
         L.elp_emit_sorted_bgzf.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.elp_stage_bgzf.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint16]
         L.elp_filter_records.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.elp_clean_sam.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.elp_split_classify.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.elp_merge_spread.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.elp_bqsr_gather_device.argtypes = [C.c_void_p, C.c_int]

@@ -211,7 +211,9 @@ __device__ inline uint32_t out_size(const BamOut &m, uint32_t i, uint32_t *err) 
   const uint8_t *rec = p + 4, *end = rec + bs;
   const uint32_t l_name = rec[8], n_cig = ld_u16(rec + 12), l_seq = ld_u32(rec + 16);
   const uint64_t fixed = 32ull + l_name + 4ull * n_cig + ((l_seq + 1) >> 1) + l_seq;
-  uint32_t size = 4 + (uint32_t)fixed;
+  // (the record goes out with the CIGAR column's operations - elp_clean_sam may have rewritten them -, the tags come from the staged bytes)
+  const uint64_t n_cig_out = m.cigar_off[i + 1] - m.cigar_off[i];
+  uint32_t size = 4 + (uint32_t)(fixed + 4ull * n_cig_out - 4ull * n_cig);
   const uint8_t *t = rec + fixed;
   while (t + 3 <= end) {
     const uint8_t ty = t[2];

@@ -154,6 +154,158 @@ int merge_spread_slots(elp_ctx *groups, elp_ctx *spread, uint64_t **slots_out) {
   *slots_out = slots;
   return 0;
 }
+// ---------------- CleanSam (filters/simple-filters.go:292-306): MAPQ 0 for unmapped reads; an alignment that ends behind its reference
+// sequence is soft-clipped there by softClipEndOfRead (filters/utils.go:102-119) - restated with its arithmetic as it stands: the
+// running position accumulates (`pos += endPos`, :116) and the clip's length is ReadLengthFromCigar + clipFrom (:112); a drop-in must
+// write what the reference writes.  The rewritten CIGAR has at most one operation more than the old one, so the CIGAR column is rebuilt
+// (new lengths, a scan, a copy pass) - only if a record is affected at all.
+struct CleanCols {
+  uint64_t n;
+  const int32_t *refid, *pos, *ref_len;
+  const uint16_t *flag;
+  uint8_t *mapq;
+  const uint8_t *state;
+  const uint64_t *cigar_off;
+  const uint32_t *cigar;
+  int32_t n_ref;
+};
+// the new CIGAR of record i (out may be null: count only); returns the number of operations, -1: the reference panics, -2: a length the
+// 28-bit BAM field cannot hold; *changed = the record is rewritten
+__device__ inline int clean_cigar(const CleanCols &m, uint64_t i, uint32_t *out, bool *changed) {
+  const uint64_t c0 = m.cigar_off[i], c1 = m.cigar_off[i + 1];
+  const int nop = (int)(c1 - c0);
+  *changed = false;
+  const uint16_t f = m.flag[i];
+  const int32_t r = m.refid[i];
+  bool clip = false;
+  int32_t clip_from = 0, read_len = 0;
+  if (!(f & F_UNMAPPED) && r >= 0 && r < m.n_ref) {
+    int32_t ref_span = 0;
+    for (int k = 0; k < nop; k++) {
+      const uint32_t op = m.cigar[c0 + k], o = op & 15u;
+      const int32_t l = (int32_t)(op >> 4);
+      if (op_consumes_ref(o)) ref_span += l;
+      if (op_consumes_read(o)) read_len += l;
+    }
+    const int32_t length = m.ref_len[r], end = m.pos[i] + ref_span - 1;  // Alignment.End, sam/sam-types.go:769-775
+    if (end > length) { clip = true; clip_from = length - m.pos[i] + 1; }
+  }
+  if (!clip) {
+    if (out) for (int k = 0; k < nop; k++) out[k] = m.cigar[c0 + k];
+    return nop;
+  }
+  *changed = true;
+  int32_t pos = 0;
+  clip_from--;
+  int n_new = 0;
+  for (int k = 0; k < nop; k++) {
+    const uint32_t op = m.cigar[c0 + k], o = op & 15u;
+    const int32_t end_pos = pos + (op_consumes_read(o) ? (int32_t)(op >> 4) : 0);
+    if (end_pos < clip_from) {
+      if (out) out[n_new] = op;
+      n_new++;
+    } else {
+      int32_t clipped = read_len + clip_from;
+      const int32_t rel = clip_from - pos;
+      if (op_consumes_read(o)) {
+        if (op_consumes_ref(o)) {
+          if (rel > 0) {
+            if (rel >= (1 << 28)) return -2;
+            if (out) out[n_new] = ((uint32_t)rel << 4) | o;
+            n_new++;
+          }
+        } else {
+          clipped += rel;
+        }
+      } else if (rel != 0) {
+        return -1;  // "Unexpected non-0 relative clipping position in CleanSam." (filters/utils.go:93)
+      }
+      if (clipped < 0 || clipped >= (1 << 28)) return -2;
+      if (out) out[n_new] = ((uint32_t)clipped << 4) | OP_S;
+      n_new++;
+      break;
+    }
+    pos += end_pos;
+  }
+  return n_new;
+}
+__global__ __launch_bounds__(256) void k_clean_count(CleanCols m, uint32_t *__restrict__ newcnt, uint32_t *res /* [0] rewritten records, [1] error bits */) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.n) return;
+  uint32_t cnt = (uint32_t)(m.cigar_off[i + 1] - m.cigar_off[i]);
+  if (m.state[i] != 2) {  // (records an earlier filter removed never reach CleanSam)
+    if (m.flag[i] & F_UNMAPPED) m.mapq[i] = 0;
+    bool changed;
+    const int nn = clean_cigar(m, i, nullptr, &changed);
+    if (nn < 0) atomicOr(&res[1], nn == -1 ? 1u : 2u);
+    else cnt = (uint32_t)nn;
+    if (changed) atomicAdd(&res[0], 1u);
+  }
+  newcnt[i] = cnt;
+}
+__global__ __launch_bounds__(256) void k_clean_write(CleanCols m, const uint32_t *__restrict__ newoff, uint32_t total, uint32_t *__restrict__ cigar_new,
+                                                     uint64_t *__restrict__ off_new) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > m.n) return;
+  if (i == m.n) { off_new[i] = total; return; }
+  off_new[i] = newoff[i];
+  bool changed;
+  if (m.state[i] != 2) (void)clean_cigar(m, i, cigar_new + newoff[i], &changed);
+  else {
+    const uint64_t c0 = m.cigar_off[i], c1 = m.cigar_off[i + 1];
+    for (uint64_t k = c0; k < c1; k++) cigar_new[newoff[i] + (k - c0)] = m.cigar[k];
+  }
+}
+__global__ __launch_bounds__(256) void k_copy_u64(uint64_t n, const uint64_t *__restrict__ src, uint64_t *__restrict__ dst) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+}  // namespace elp
+
+extern "C" int elp_clean_sam(elp_ctx *c, uint64_t *n_clipped_out) {
+  using namespace elp;
+  if (!c) return ELP_ERR_ARG;
+  std::lock_guard<std::mutex> g(c->stage_mu);
+  ELP_HIP(c, hipSetDevice(c->device));
+  if (!c->have_header) return set_error(c, ELP_ERR_ARG, "elp_clean_sam: call elp_set_header first");
+  if (n_clipped_out) *n_clipped_out = 0;
+  const uint64_t n = c->n;
+  if (!n) return 0;
+  if (c->cigar_ops + n >= 0xFFFFFFFFull) return set_error(c, ELP_ERR_UNSUPPORTED, "elp_clean_sam: more than 2^32 CIGAR operations in one context");
+  hipStream_t st = c->stream;
+  uint32_t *wk;
+  ELP_TRY(scratch(c, 4, 2 * (n + 8) + 16, &wk));
+  uint32_t *newcnt = wk, *newoff = wk + n + 8, *res = newoff + n + 8;
+  ELP_HIP(c, hipMemsetAsync(res, 0, 8, st));
+  CleanCols m{n, c->refid.p, c->pos.p, c->ref_len.p, c->flag.p, c->mapq.p, c->has_sr.p, c->cigar_off.p, c->cigar.p, c->n_ref};
+  ELP_LAUNCH(c, "clean_count", k_clean_count, dim3(blocks_for(n, 256)), dim3(256), 0, m, newcnt, res);
+  uint32_t hr[2] = {0, 0};
+  ELP_HIP(c, hipMemcpyAsync(hr, res, 8, hipMemcpyDeviceToHost, st));
+  ELP_HIP(c, hipStreamSynchronize(st));
+  // MAPQ changed, CIGARs may: whatever was derived from them is stale
+  c->adapted = c->sorted = c->marked = false;
+  if (hr[1] & 1u) return set_error(c, ELP_ERR_DATA, "Unexpected non-0 relative clipping position in CleanSam. (reference: log.Panic, filters/utils.go:93)");
+  if (hr[1] & 2u) return set_error(c, ELP_ERR_UNSUPPORTED, "elp_clean_sam: a clipped CIGAR needs an operation length outside the 28 bits of a BAM CIGAR field");
+  if (n_clipped_out) *n_clipped_out = hr[0];
+  if (!hr[0]) return 0;
+  uint32_t total = 0;
+  ELP_TRY(exclusive_scan_u32(c, newcnt, newoff, n, &total));
+  uint32_t *cig_new;
+  uint64_t *off_new;
+  ELP_TRY(scratch(c, 5, (size_t)total + 64, &cig_new));
+  ELP_TRY(scratch(c, 6, n + 8, &off_new));
+  ELP_LAUNCH(c, "clean_write", k_clean_write, dim3(blocks_for(n + 1, 256)), dim3(256), 0, m, (const uint32_t *)newoff, total, cig_new, off_new);
+  // the rebuilt column replaces the staged one (the offsets first: the kernel above read the old ones)
+  ELP_TRY(ensure(c, c->cigar, (size_t)total + 64));
+  ELP_HIP(c, hipMemcpyAsync(c->cigar.p, cig_new, (size_t)total * 4, hipMemcpyDeviceToDevice, st));
+  ELP_LAUNCH(c, "clean_offsets", k_copy_u64, dim3(blocks_for(n + 1, 256)), dim3(256), 0, n + 1, (const uint64_t *)off_new, c->cigar_off.p);
+  ELP_HIP(c, hipStreamSynchronize(st));
+  c->cigar_ops = total;
+  return 0;
+}
+
+namespace elp {
 }  // namespace elp
 
 using namespace elp;

@@ -236,6 +236,12 @@ class Engine:
         self._check(self.L.elp_exchange_records(self.h, send_peer, _vp(ix), ix.size, -1 if new_split is None else int(new_split), 1 if tag_sr else 0,
                                                 dst.h if dst is not None else C.c_void_p(0), recv_peer))
 
+    def clean_sam(self) -> int:
+        """filters.CleanSam on the staged records (elp_clean_sam); returns the number of records whose CIGAR was rewritten"""
+        n = C.c_uint64()
+        self._check(self.L.elp_clean_sam(self.h, C.byref(n)))
+        return int(n.value)
+
     def split_classify(self, group_of_ref: np.ndarray, n_groups: int):
         g = np.ascontiguousarray(group_of_ref, dtype=np.int32)
         split = np.empty(self.n, dtype=np.uint16)

@@ -315,6 +315,15 @@ int elp_get_qual(elp_ctx *ctx, uint8_t *qual_out /* qual_bytes, staging order an
 int elp_snapshot(elp_ctx *ctx);
 int elp_rollback(elp_ctx *ctx);
 
+/* ---- CleanSam (filters/simple-filters.go:292-306, `elprep filter --clean-sam`: a filter of the phase-1 pipeline, cmd/filter.go:747) ----
+ * On the staged records, in front of elp_mark_duplicates: MAPQ of unmapped reads becomes 0; an alignment whose End() lies behind the
+ * LN of its reference sequence is soft-clipped there by softClipEndOfRead (filters/utils.go:102-119) - with that function's arithmetic as
+ * it stands in the reference (the running position accumulates, the clip's length is ReadLengthFromCigar + clipFrom): a drop-in writes
+ * what the reference writes.  The CIGAR column is rebuilt if any record is rewritten (a rewritten CIGAR can be one operation longer).
+ * n_clipped_out (may be NULL): records rewritten.  ELP_ERR_DATA where the reference panics ("Unexpected non-0 relative clipping
+ * position in CleanSam."), ELP_ERR_UNSUPPORTED for a clip length that does not fit the 28 bits of a BAM CIGAR field. */
+int elp_clean_sam(elp_ctx *ctx, uint64_t *n_clipped_out);
+
 /* ---- kernel choices ----
  * The library picks its kernels from the staged data (read sets of one length, number of distinct qualities, order of the
  * mates).  Tests and A/B measurements pin a choice per context with elp_set_tuning instead of process-wide environment

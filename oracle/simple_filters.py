@@ -87,3 +87,64 @@ def merge_slots(group_keys, spread_keys):
         slot += 1
         j += 1
     return np.asarray(out, dtype=np.uint64)
+
+
+_READ = {0, 1, 4, 7, 8}  # M I S = X consume read bases (sam/sam-types.go CigarOperatorConsumesReadBases)
+_REF = {0, 2, 3, 7, 8}   # M D N = X consume reference bases
+
+
+def _soft_clip_end_of_read(clip_from, ops):
+    """softClipEndOfRead (filters/utils.go:102-119) + elementStradlessClippedRead (:82-100), statement by statement - including
+    `pos += endPos` and `clippedBases := ReadLengthFromCigar(cigars) + clipFrom` as the reference has them.  ops: list of (length, op code)"""
+    pos = 0
+    clip_from -= 1
+    new = []
+    read_len = sum(l for l, o in ops if o in _READ)
+    for l, o in ops:
+        end_pos = pos + (l if o in _READ else 0)
+        if end_pos < clip_from:
+            new.append((l, o))
+        else:
+            clipped = read_len + clip_from
+            rel = clip_from - pos
+            if o in _READ:
+                if o in _REF:
+                    if rel > 0:
+                        new.append((rel, o))
+                else:
+                    clipped += rel
+            elif rel != 0:
+                raise ValueError("Unexpected non-0 relative clipping position in CleanSam.")
+            new.append((clipped, 4))
+            break
+        pos += end_pos
+    return new
+
+
+def clean_sam(b, ref_len):
+    """filters.CleanSam (filters/simple-filters.go:292-306) on a batch: returns (new batch, number of rewritten records).  MAPQ 0 for
+    unmapped reads; an alignment with End() > LN of its reference is soft-clipped by softClipEndOfRead."""
+    from elprep_amd.batch import Batch
+    mapq = b.mapq.copy()
+    mapq[(b.flag & 0x4) != 0] = 0
+    cig_parts, counts, changed = [], np.zeros(b.n, dtype=np.int64), 0
+    for i in range(b.n):
+        ops = b.cigar[int(b.cigar_off[i]):int(b.cigar_off[i + 1])]
+        new = ops
+        if not (b.flag[i] & 0x4) and 0 <= b.refid[i] < len(ref_len):
+            span = int(sum(int(c) >> 4 for c in ops if (int(c) & 15) in _REF))
+            end = int(b.pos[i]) + span - 1
+            length = int(ref_len[b.refid[i]])
+            if end > length:
+                lst = _soft_clip_end_of_read(length - int(b.pos[i]) + 1, [(int(c) >> 4, int(c) & 15) for c in ops])
+                new = np.asarray([(l << 4) | o for l, o in lst], dtype=np.uint32)
+                changed += 1
+        cig_parts.append(np.asarray(new, dtype=np.uint32))
+        counts[i] = len(new)
+    off = np.zeros(b.n + 1, dtype=np.uint64)
+    np.cumsum(counts, out=off[1:])
+    cols = {name: getattr(b, name) for name in b.__dataclass_fields__}
+    cols["mapq"] = mapq
+    cols["cigar"] = np.concatenate(cig_parts) if cig_parts else np.zeros(0, np.uint32)
+    cols["cigar_off"] = off
+    return Batch(**cols), changed

@@ -361,3 +361,45 @@ def test_mates_by_every_path(mate_path):
     e.stage(pb)
     assert np.array_equal(e.mark_duplicates(True), orc.mark_duplicates(pb, h))
     e.close()
+
+
+def test_clean_sam_against_the_oracle():
+    """elp_clean_sam: the contigs' LN is cut so that a few hundred alignments end behind their reference sequence; MAPQ and CIGAR of every
+    record (read back through the BAM encoder) and everything downstream of the rewritten CIGARs (unclipped positions -> duplicate flags)
+    equal the oracle's restatement of CleanSam / softClipEndOfRead - with that function's arithmetic as the reference has it"""
+    from oracle import simple_filters as sf
+    from elprep_amd.batch import Header
+    cfg, b, h, refs, sites = dataset("tiny", 8000, 9, 0.03)
+    cut = np.array([41000, 30000, 22000], np.int32)
+    keep = np.nonzero((b.refid < 0) | (b.pos <= cut[np.clip(b.refid, 0, None)] - 140))[0]   # (no alignment starts near / behind the new end:
+    over = np.nonzero((b.refid >= 0) & (b.pos > cut[np.clip(b.refid, 0, None)] - 140) & (b.pos <= cut[np.clip(b.refid, 0, None)] - 20))[0]  # ... but some hang over it)
+    sel = np.sort(np.concatenate([keep, over]))
+    bb = b.take(sel)
+    h2 = Header(ref_len=cut, rg_lib=h.rg_lib, rg_cov=h.rg_cov, ref_names=h.ref_names, rg_ids=h.rg_ids, lib_names=h.lib_names, cov_names=h.cov_names)
+    want, n_changed = sf.clean_sam(bb, cut)
+    assert n_changed > 100
+    e = Engine(h2)
+    e.set_read_group_ids(h2.rg_ids)
+    e.stage_bam(orc.bam_encode(bb, h2.rg_ids))
+    assert e.clean_sam() == n_changed
+    assert e.clean_sam() == 0  # (the clipped alignments now end at the reference's end)
+    e.close()
+    e = Engine(h2)
+    e.set_read_group_ids(h2.rg_ids)
+    e.stage_bam(orc.bam_encode(bb, h2.rg_ids))
+    e.clean_sam()
+    flags = e.mark_duplicates(True)
+    oflags = orc.mark_duplicates(want, h2)
+    assert np.array_equal(flags, oflags)
+    perm = e.sort_coordinate()
+    operm = orc.sort_coordinate(want, oflags)
+    assert np.array_equal(perm, operm)
+    got = e.emit_sorted_bam().tobytes()
+    assert got == orc.bam_encode(want, h2.rg_ids, order=operm[:orc.num_sorted(want)], flags=oflags, normalize_tags=True).tobytes()
+    e.close()
+    # columns staged without BAM bytes take the same path
+    e = Engine(h2)
+    e.stage(bb)
+    assert e.clean_sam() == n_changed
+    assert np.array_equal(e.mark_duplicates(True), oflags)
+    e.close()
