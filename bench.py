@@ -220,15 +220,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    host_ms, wait_ms = [], []  # per step: the host's FinalizeBQSRTables + LUT (ms), and the part of it the device's sort + metrics did not hide
+
     def make_filter_steps(eng, lut_buf):
         """the step functions of one `elprep filter` context.  Order of events as in the reference (cmd/filter.go:142-211): MarkDuplicates
         is a filter of the phase-1 pipeline, the sort is that pipeline's Finalize (sam/filter-pipeline.go:116), then the metrics pass,
         Recalibrate, finalize, ApplyBQSR."""
         def finalize_lut(qt, ct, xt):
+            t0 = time.perf_counter()
             tb = BqsrTables(qt, ct, xt, MAX_CYCLE).finalize()
             lut, present = tb.build_lut(0, out=lut_buf[0])
             lut_buf[0] = (lut, present)
             eng.lut_upload(lut, present, MAX_CYCLE)  # on the context's copy stream, from this (host) thread, while the GPU sorts
+            host_ms.append((time.perf_counter() - t0) * 1e3)
             return lut, present
 
         def step_full():
@@ -241,7 +245,9 @@ def main():
             fin = host_pool.submit(lambda: finalize_lut(*eng.tables_fetch(reuse=True)))
             eng.sort_coordinate(fetch=False)
             eng.dup_metrics(100)
+            t_dev = time.perf_counter()
             fin.result()
+            wait_ms.append((time.perf_counter() - t_dev) * 1e3)  # what the device's sort + metrics did not hide of the host's finalisation
             eng.apply_bqsr(None, None, MAX_CYCLE, fetch=False)
             eng.sync()
 
@@ -405,6 +411,8 @@ def main():
             "roofline": roof,
             "stage_ms_per_step": stage_ms,
             "kernel_ms_per_step": kern_ms,
+            "host_finalize_ms_per_step": round(sum(host_ms[-args.steps:]) / max(len(host_ms[-args.steps:]), 1), 3) if host_ms else None,
+            "host_finalize_exposed_ms_per_step": round(sum(wait_ms[-args.steps:]) / max(len(wait_ms[-args.steps:]), 1), 3) if wait_ms else None,
             "staging": {"gen_s": round(gen_s, 2), "h2d_stage_s": round(stage_s, 2),
                         "elp_stage_Mreads_per_s": round(n_total / max(stage_s, 1e-9) / 1e6, 2)},
         }
@@ -462,6 +470,7 @@ def main():
                 st, km, rf = summarize(pr, 3, n2, BYTES_FULL_PATH)
                 extra[key] = {"workload": f"{n2} reads, {workload}, full path",
                               "value": round(n2 / (el / 3) / 1e6, 3), "unit": "Mreads/s", "ms_per_step": round(el / 3 * 1e3, 3),
+                              "host_finalize_ms_per_step": round(sum(host_ms[-3:]) / 3, 3), "host_finalize_exposed_ms_per_step": round(sum(wait_ms[-3:]) / 3, 3),
                               "stage_ms_per_step": st, "kernel_ms_per_step": km, "roofline": rf}
                 e2.close()
             except Exception as e:
