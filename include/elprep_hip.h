@@ -139,7 +139,7 @@ int elp_emit_sorted_bam(elp_ctx *ctx, uint8_t *out, uint64_t cap, uint64_t *n_by
 /* BGZF on the device (utils/bgzf/bgzf-files.go).
  * elp_stage_bgzf = the reader (:95-221) + elp_stage_bam: `bgzf` holds whole BGZF blocks of a BAM file (the file, or a part of it that
  * starts at a block and ends with a complete alignment record; an end-of-file block is skipped).  The compressed bytes are copied to the
- * device, every block is inflated by a thread of its own (RFC 1951: stored, fixed and dynamic Huffman blocks), its CRC-32 is checked
+ * device, every block is inflated by a wavefront of its own (RFC 1951: stored, fixed and dynamic Huffman blocks), its CRC-32 is checked
  * ("invalid CRC-32 value for a data block in a BGZF file"), the starts of the alignment records are found on the device (every block
  * guesses its first record start, walks its records, and the guesses are proven by checking that every block's chain ends where the
  * next one's begins; wrong guesses are repaired in order), and the records are staged as elp_stage_bam stages them.  first_record = the
