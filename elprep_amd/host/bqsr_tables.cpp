@@ -136,40 +136,101 @@ struct Log10MinP {
 };
 const Log10MinP kLog10MinP;
 
-// calculateBayesianEstimateOfEmpiricalQuality, bqsr.go:623-642.  The binomial coefficient term (three Lgamma calls) does not
-// depend on the bin and log10(1-p) only on the bin: both are hoisted, every floating-point operation and its order is the
-// reference's (log10QualEmpiricalLikelihood :598-613), so the argmax is unchanged.
-uint8_t bayes(long long obs, long long mism, double prior) {
+// calculateBayesianEstimateOfEmpiricalQuality, bqsr.go:623-642, in three pieces that share work between the entries of a table row
+// and between the two priors every entry is evaluated with (its reported quality in FinalizeBQSRTables, the row's conditional
+// estimate in ApplyBQSR's hierarchy).  The binomial coefficient term (three Lgamma calls) does not depend on the bin, log10(1-p)
+// only on the bin, the prior only on (bin, prior): every floating-point operation and its order is the reference's
+// (log10QualEmpiricalLikelihood :598-613), so the argmax is unchanged.
+constexpr int NBIN = 61, NBIN_PAD = 64;
+struct BinConst {
+  alignas(64) double log10p[NBIN_PAD], log10minp[NBIN_PAD];
+  BinConst() {
+    for (int i = 0; i < NBIN_PAD; i++) { log10p[i] = 0.0; log10minp[i] = 0.0; }
+    for (int i = 0; i < NBIN; i++) { log10p[i] = double(i) / -10.0; log10minp[i] = kLog10MinP.v[i]; }
+  }
+};
+const BinConst kBin;
+
+struct Curve { alignas(64) double v[NBIN_PAD]; };
+
+inline void clamp_counts(long long &obs, long long &mism) {
   const long long kMax = 2147483647LL - 1;
   if (obs > kMax) {
     mism = (long long)std::round(double(mism) * (double(kMax) / double(obs)));
     obs = kMax;
   }
-  const double c = obs == 0 ? 0.0 : log10_gamma(obs + 1) - log10_gamma(mism + 1) - log10_gamma(obs - mism + 1);
+}
+// the likelihood of every bin for one table entry (obs > 0 after the clamp)
+__attribute__((target_clones("avx2", "default"))) void like_curve(long long obs, long long mism, Curve &out) {
+  const double c = log10_gamma(obs + 1) - log10_gamma(mism + 1) - log10_gamma(obs - mism + 1);
   const double dm = double(mism), dn = double(obs - mism);
-  double best = -DBL_MAX;
-  uint8_t arg = 0;
-  for (int i = 0; i <= 60; i++) {
-    const double fi = double(i);
-    int d = int(fi - prior);
+  for (int i = 0; i < NBIN_PAD; i++) out.v[i] = c + kBin.log10p[i] * dm + kBin.log10minp[i] * dn;
+  out.v[0] = -DBL_MAX;  // log10p == 0
+}
+// the prior of every bin: the same for all entries of a (covariate, quality) row
+inline void prior_curve(double prior, Curve &out) {
+  for (int i = 0; i < NBIN; i++) {
+    int d = int(double(i) - prior);
     if (d < 0) d = -d;
     if (d > 20) d = 20;
-    double like;
-    if (obs == 0) {
-      like = 0.0;
-    } else {
-      const double log10p = fi / -10.0;
-      if (log10p == 0.0) like = -DBL_MAX;
-      else like = c + log10p * dm + kLog10MinP.v[i] * dn;
-    }
-    const double post = kPrior[d] + like;
-    if (best < post) { best = post; arg = uint8_t(i); }
+    out.v[i] = kPrior[d];
   }
-  return arg;
+  for (int i = NBIN; i < NBIN_PAD; i++) out.v[i] = 0.0;
 }
-inline uint8_t empirical(long long obs, long long mism, double prior) {  // bqsr.go:644-649
-  const uint8_t q = bayes(obs + 2, mism + 1, prior);
-  return q < 93 ? q : 93;
+// the first bin with the largest posterior (:630-641: `if best < post`), capped as calculateEmpiricalQuality caps it (:644-649)
+// = per lane of four (bins 4 g + lane) the first largest posterior and its group, then the lanes' best with ties to the smaller bin;
+// two priors at a time (independent dependency chains over the same likelihoods)
+typedef double v4d __attribute__((vector_size(32)));
+typedef long long v4i __attribute__((vector_size(32)));
+inline uint8_t argmax_lanes(const v4d &m4, const v4i &g4, double last) {
+  double m = -DBL_MAX;
+  int arg = 0;  // no bin ever passes `best < post`: bin 0
+  for (int k = 0; k < 4; k++) {
+    const int bin = int(g4[k]) * 4 + k;
+    const bool take = m4[k] > m || (m4[k] == m && m4[k] > -DBL_MAX && bin < arg);
+    m = take ? m4[k] : m;
+    arg = take ? bin : arg;
+  }
+  if (last > m) arg = NBIN - 1;  // bin 60, alone in its group
+  return uint8_t(arg < 93 ? arg : 93);
+}
+__attribute__((target_clones("avx2", "default"))) void argmax_posterior2(const Curve &prior_a, const Curve &prior_b, const Curve &like,
+                                                                         uint8_t &a, uint8_t &b) {
+  const v4d *pa = reinterpret_cast<const v4d *>(prior_a.v), *pb = reinterpret_cast<const v4d *>(prior_b.v);
+  const v4d *lv = reinterpret_cast<const v4d *>(like.v);
+  v4d ma = {-DBL_MAX, -DBL_MAX, -DBL_MAX, -DBL_MAX}, mb = ma;
+  v4i ga = {0, 0, 0, 0}, gb = ga;
+  for (int g = 0; g < NBIN_PAD / 4 - 1; g++) {
+    const v4d l = lv[g], qa = pa[g] + l, qb = pb[g] + l;
+    const v4i ua = qa > ma, ub = qb > mb;
+    const v4i gg = {g, g, g, g};
+    ma = ua ? qa : ma; ga = ua ? gg : ga;
+    mb = ub ? qb : mb; gb = ub ? gg : gb;
+  }
+  a = argmax_lanes(ma, ga, prior_a.v[NBIN - 1] + like.v[NBIN - 1]);
+  b = argmax_lanes(mb, gb, prior_b.v[NBIN - 1] + like.v[NBIN - 1]);
+}
+inline uint8_t argmax_posterior(const Curve &prior, const Curve &like) {
+  uint8_t a, b;
+  argmax_posterior2(prior, prior, like, a, b);
+  return a;
+}
+// one entry, one prior (the q table, the combined entries: a handful per call)
+uint8_t empirical(long long obs, long long mism, double prior) {  // bqsr.go:644-649: obs + 2, mism + 1
+  obs += 2; mism += 1;
+  clamp_counts(obs, mism);
+  Curve like, pr;
+  like_curve(obs, mism, like);
+  prior_curve(prior, pr);
+  return argmax_posterior(pr, like);
+}
+// one entry, the two priors of its row
+inline void empirical2(long long obs, long long mism, const Curve &prior_a, const Curve &prior_b, uint8_t &a, uint8_t &b) {
+  obs += 2; mism += 1;
+  clamp_counts(obs, mism);
+  Curve like;
+  like_curve(obs, mism, like);
+  argmax_posterior2(prior_a, prior_b, like, a, b);
 }
 
 // rows are independent (the results do not depend on the split): a small pool of workers that lives as long as the library,
@@ -238,6 +299,8 @@ struct elp_bqsr_tables {
   int n_cov, max_cycle, ncyc;
   std::vector<long long> q, c, x;           // {obs, mism} pairs
   std::vector<uint8_t> qe, ce, xe;          // EmpiricalQuality, 255 = absent
+  std::vector<uint8_t> ce_cond, xe_cond;    // the same entries under the prior of ApplyBQSR's hierarchy (cond[row]), for the LUT
+  std::vector<double> cond;                 // per (cov, quality): deltaQReported + deltaQ + epsilon (:959-975)
   std::vector<double> rep;                  // combined reportedQuality per cov
   std::vector<uint8_t> cemp, present;
   std::vector<long long> cobs, cmism;
@@ -275,15 +338,11 @@ int elp_bqsr_tables_merge(elp_bqsr_tables *t, const int64_t *qt, const int64_t *
 int elp_bqsr_tables_finalize(elp_bqsr_tables *t) {
   if (!t) return -1;
   const size_t nq = size_t(t->n_cov) * NQ;
-  t->qe.assign(nq, 255); t->ce.assign(nq * t->ncyc, 255); t->xe.assign(nq * NX, 255);
+  const int ncyc = t->ncyc;
+  t->qe.assign(nq, 255); t->ce.assign(nq * ncyc, 255); t->xe.assign(nq * NX, 255);
+  t->ce_cond.assign(nq * ncyc, 255); t->xe_cond.assign(nq * NX, 255); t->cond.assign(nq, 0.0);
   for (size_t i = 0; i < nq; i++)
     if (t->q[2 * i] > 0) t->qe[i] = empirical(t->q[2 * i], t->q[2 * i + 1], double(i % NQ));
-  parallel_rows(nq, [&](size_t row) {  // one (covariate, quality) row of cycle entries per task
-    for (size_t i = row * t->ncyc; i < (row + 1) * t->ncyc; i++)
-      if (t->c[2 * i] > 0) t->ce[i] = empirical(t->c[2 * i], t->c[2 * i + 1], double(row % NQ));
-  });
-  for (size_t i = 0; i < nq * NX; i++)
-    if (t->x[2 * i] > 0) t->xe[i] = empirical(t->x[2 * i], t->x[2 * i + 1], double((i / NX) % NQ));
   t->rep.assign(t->n_cov, 0.0); t->cemp.assign(t->n_cov, 0); t->present.assign(t->n_cov, 0);
   t->cobs.assign(t->n_cov, 0); t->cmism.assign(t->n_cov, 0);
   for (int cv = 0; cv < t->n_cov; cv++) {
@@ -298,8 +357,41 @@ int elp_bqsr_tables_finalize(elp_bqsr_tables *t) {
         t->present[cv] = 1; t->rep[cv] = double(ql); t->cobs[cv] = obs; t->cmism[cv] = mism;
       }
     }
-    if (t->present[cv]) t->cemp[cv] = empirical(t->cobs[cv], t->cmism[cv], t->rep[cv]);
+    if (!t->present[cv]) continue;
+    t->cemp[cv] = empirical(t->cobs[cv], t->cmism[cv], t->rep[cv]);
+    // the prior under which ApplyBQSR's hierarchy reads the cycle and context entries of a row (:959-975; globalQualityScorePrior = -1)
+    const double epsilon = t->rep[cv], d_global = double(t->cemp[cv]) - epsilon;
+    for (int ql = 0; ql < NQ; ql++) {
+      const size_t qi = t->qi(cv, ql);
+      double d_reported = 0;
+      if (t->q[2 * qi] > 0) d_reported = double(empirical(t->q[2 * qi], t->q[2 * qi + 1], d_global + epsilon)) - d_global - epsilon;
+      t->cond[qi] = d_reported + d_global + epsilon;
+    }
   }
+  // the cycle and context entries: a task = one eighth of a (covariate, quality) row's cycles (+ the row's contexts with the first)
+  constexpr int kParts = 8;
+  const int part_len = (ncyc + kParts - 1) / kParts;
+  parallel_rows(nq * kParts, [&](size_t task) {
+    const size_t row = task / kParts;
+    const int part = int(task % kParts);
+    const int lo = part * part_len, hi = std::min(ncyc, lo + part_len);
+    bool any = false;
+    for (int cy = lo; cy < hi && !any; cy++) any = t->c[2 * (row * ncyc + cy)] > 0;
+    if (part == 0) for (int cx = 0; cx < NX && !any; cx++) any = t->x[2 * (row * NX + cx)] > 0;
+    if (!any) return;
+    Curve pr_fin, pr_cond;
+    prior_curve(double(row % NQ), pr_fin);
+    prior_curve(t->cond[row], pr_cond);
+    for (int cy = lo; cy < hi; cy++) {
+      const size_t i = row * ncyc + cy;
+      if (t->c[2 * i] > 0) empirical2(t->c[2 * i], t->c[2 * i + 1], pr_fin, pr_cond, t->ce[i], t->ce_cond[i]);
+    }
+    if (part == 0)
+      for (int cx = 0; cx < NX; cx++) {
+        const size_t i = row * NX + cx;
+        if (t->x[2 * i] > 0) empirical2(t->x[2 * i], t->x[2 * i + 1], pr_fin, pr_cond, t->xe[i], t->xe_cond[i]);
+      }
+  });
   t->finalized = true;
   return 0;
 }
@@ -400,31 +492,25 @@ int elp_bqsr_tables_build_lut(const elp_bqsr_tables *t, int quantize_levels, con
   elp_bqsr_tables_quantize(t, quantize_levels, counts, quantized);
   if (n_sqq > 0) static_quantized(sqq, n_sqq, stat);
   const int ncyc = t->ncyc;
-  std::vector<double> eps(t->n_cov, 0.0), dglob(t->n_cov, 0.0);
   for (int cv = 0; cv < t->n_cov; cv++) {
     cov_present[cv] = t->present[cv];
-    if (!t->present[cv]) { std::memset(lut + size_t(cv) * NQ * ncyc * 17, 0, size_t(NQ) * ncyc * 17); continue; }
-    eps[cv] = t->rep[cv];  // globalQualityScorePrior = -1 (:959-964)
-    dglob[cv] = double(empirical(t->cobs[cv], t->cmism[cv], eps[cv])) - eps[cv];
+    if (!t->present[cv]) std::memset(lut + size_t(cv) * NQ * ncyc * 17, 0, size_t(NQ) * ncyc * 17);
   }
   {
     parallel_rows(size_t(t->n_cov) * NQ, [&](size_t row) {  // one (covariate, quality) row of the LUT per task
       const int cv = int(row / NQ), ql = int(row % NQ);
       if (!t->present[cv]) return;
       uint8_t *lc = lut + size_t(cv) * NQ * ncyc * 17;
-      const double epsilon = eps[cv], d_global = dglob[cv];
       std::vector<double> dcyc(ncyc), dctx(17);
       const size_t qi = t->qi(cv, ql);
-      double d_reported = 0;
-      if (t->q[2 * qi] > 0) d_reported = double(empirical(t->q[2 * qi], t->q[2 * qi + 1], d_global + epsilon)) - d_global - epsilon;
-      const double cond = d_reported + d_global + epsilon;
+      const double cond = t->cond[qi];  // deltaQReported + deltaQ + epsilon, and the entries' estimates under it: elp_bqsr_tables_finalize
       for (int cy = 0; cy < ncyc; cy++) {
         const size_t ci = qi * ncyc + cy;
-        dcyc[cy] = t->c[2 * ci] > 0 ? double(empirical(t->c[2 * ci], t->c[2 * ci + 1], cond)) - cond : 0.0;
+        dcyc[cy] = t->c[2 * ci] > 0 ? double(t->ce_cond[ci]) - cond : 0.0;
       }
       for (int cx = 0; cx < 16; cx++) {
         const size_t xi = qi * NX + cx;
-        dctx[cx] = t->x[2 * xi] > 0 ? double(empirical(t->x[2 * xi], t->x[2 * xi + 1], cond)) - cond : 0.0;
+        dctx[cx] = t->x[2 * xi] > 0 ? double(t->xe_cond[xi]) - cond : 0.0;
       }
       uint8_t *lq = lc + size_t(ql) * ncyc * 17;
       auto entry = [&](bool has_c, int cy, int cx) {
