@@ -443,6 +443,7 @@ int elp_set_tuning(elp_ctx *c, const char *key, int64_t value) {
     if (v < 2 || v > (1 << 20) || (v & (v - 1))) return set_error(c, ELP_ERR_ARG, "elp_set_tuning: pair_table_slots must be a power of two >= 2");
     c->tune.pair_table_slots = v;
   } else if (k == "mate_path") c->tune.mate_path = v;
+  else if (k == "tie_rounds") c->tune.tie_rounds = v;
   else return set_error(c, ELP_ERR_ARG, "elp_set_tuning: unknown key '%s'", key);
   return 0;
 }

@@ -324,9 +324,7 @@ static int radix_pass_setup(elp_ctx *c, uint32_t ntiles) {
     ELP_HIP(c, hipMemsetAsync(c->radix_state.p, 0, c->radix_state.cap * sizeof(unsigned long long), c->stream));
     c->radix_epoch = 0;
   }
-  ELP_TRY(ensure(c, c->radix_ticket, 8));  // one ticket counter per digit position
-  ELP_HIP(c, hipMemsetAsync(c->radix_ticket.p, 0, 8 * sizeof(uint32_t), c->stream));
-  return 0;
+  return 0;  // (the ticket counters, one per digit position, live behind the caller's histograms: one fill clears both)
 }
 static int radix_next_epoch(elp_ctx *c) {
   if (++c->radix_epoch >= (1u << 30)) {  // the tag wrapped: forget every word
@@ -346,8 +344,9 @@ int radix_sort_pairs_low(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *k
   if (ndigits <= 0) ndigits = 1;  // a pass is needed to materialise keys / values
   if (n >= 0xFFFFFFFFull || ndigits > 8) return set_error(c, ELP_ERR_UNSUPPORTED, "radix sort: bad size");
   unsigned long long *ghist;
-  ELP_TRY(scratch(c, 6, 8 * 256, &ghist));
-  ELP_HIP(c, hipMemsetAsync(ghist, 0, 8 * 256 * sizeof(unsigned long long), c->stream));
+  ELP_TRY(scratch(c, 6, 8 * 256 + 4, &ghist));
+  ELP_HIP(c, hipMemsetAsync(ghist, 0, (8 * 256 + 4) * sizeof(unsigned long long), c->stream));
+  uint32_t *ticket = reinterpret_cast<uint32_t *>(ghist + 8 * 256);
   const unsigned hb = (unsigned)std::min<uint64_t>((n + 255) / 256, 2048);
   // histograms of the digit positions that are sorted, not of all eight
   if (ndigits <= 2) ELP_LAUNCH(c, "radix_hist_all", k_radix_hist_all<2>, dim3(hb), dim3(256), 0, (const uint64_t *)(first_src ? first_src : keys), n, ghist, n_dev);
@@ -362,7 +361,7 @@ int radix_sort_pairs_low(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *k
     const uint64_t *kin = (d == 0 && first_src) ? first_src : ksrc;
     const uint32_t *vin = (d == 0 && identity_vals) ? nullptr : vsrc;
     ELP_LAUNCH(c, "radix_scatter", k_radix_scatter, dim3(ntiles), dim3(RS_THREADS), 0, kin, vin, kdst,
-               vdst, n, 8 * d, (const unsigned long long *)(ghist + d * 256), c->radix_state.p, c->radix_epoch, c->radix_ticket.p + d,
+               vdst, n, 8 * d, (const unsigned long long *)(ghist + d * 256), c->radix_state.p, c->radix_epoch, ticket + d,
                c->err_flag.p, n_dev);
     std::swap(ksrc, kdst);
     std::swap(vsrc, vdst);
@@ -379,8 +378,9 @@ int radix_sort_pairs(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *keys_
   if (n < 2) return 0;
   if (n >= 0xFFFFFFFFull) return set_error(c, ELP_ERR_UNSUPPORTED, "radix sort: more than 2^32-1 elements");
   unsigned long long *ghist;
-  ELP_TRY(scratch(c, 6, 8 * 256, &ghist));
-  ELP_HIP(c, hipMemsetAsync(ghist, 0, 8 * 256 * sizeof(unsigned long long), c->stream));
+  ELP_TRY(scratch(c, 6, 8 * 256 + 4, &ghist));
+  ELP_HIP(c, hipMemsetAsync(ghist, 0, (8 * 256 + 4) * sizeof(unsigned long long), c->stream));
+  uint32_t *ticket = reinterpret_cast<uint32_t *>(ghist + 8 * 256);
   unsigned hb = (unsigned)std::min<uint64_t>((n + 255) / 256, 2048);
   ELP_LAUNCH(c, "radix_hist_all", k_radix_hist_all<8>, dim3(hb), dim3(256), 0, (const uint64_t *)keys, n, ghist, (const uint32_t *)nullptr);
   unsigned long long hh[8 * 256];
@@ -397,7 +397,7 @@ int radix_sort_pairs(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *keys_
     if (!live) continue;
     ELP_TRY(radix_next_epoch(c));
     ELP_LAUNCH(c, "radix_scatter", k_radix_scatter, dim3(ntiles), dim3(RS_THREADS), 0, (const uint64_t *)ksrc, (const uint32_t *)vsrc, kdst,
-               vdst, n, 8 * d, (const unsigned long long *)(ghist + d * 256), c->radix_state.p, c->radix_epoch, c->radix_ticket.p + d,
+               vdst, n, 8 * d, (const unsigned long long *)(ghist + d * 256), c->radix_state.p, c->radix_epoch, ticket + d,
                c->err_flag.p, (const uint32_t *)nullptr);
     std::swap(ksrc, kdst);
     std::swap(vsrc, vdst);

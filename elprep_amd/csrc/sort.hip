@@ -489,7 +489,9 @@ __global__ __launch_bounds__(256) void k_iota(uint32_t *v, uint64_t n) {
 // <= TIE_SMALL records are ranked by all-pairs comparison, members of longer runs are flagged for the radix tie-break.
 constexpr int TS_TILES = 16;
 __global__ __launch_bounds__(256) void k_tie_scan(uint64_t n, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ perm_in,
-                                                  uint32_t *__restrict__ perm_out, uint32_t *__restrict__ list, uint32_t *list_n) {
+                                                  uint32_t *__restrict__ perm_out, uint32_t *__restrict__ list, uint32_t *list_n,
+                                                  uint32_t *__restrict__ bounds) {
+  if (blockIdx.x == 0 && threadIdx.x < 4) bounds[threadIdx.x] = 0;  // the counters of k_tie_small's lists (it runs behind this kernel)
   // a workgroup handles TS_TILES * 256 consecutive records and collects its run members in LDS: ONE global atomic per workgroup
   // (a global atomic per wave on the single list counter serialises at ~12 ns each: 9 ms for 50 M records, measured)
   __shared__ uint32_t lq[TS_TILES * 256];
@@ -698,11 +700,11 @@ __global__ __launch_bounds__(256) void k_material_values(uint32_t nu, const uint
 struct TiePacked { uint16_t pos[64]; uint8_t shift[64]; uint8_t slot[64]; uint32_t n; };
 __global__ __launch_bounds__(256) void k_material_keys_packed(uint32_t nu, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ u_read,
                                                               TiePacked sel, const uint8_t *__restrict__ lut, uint32_t maxq, uint64_t *__restrict__ keys,
-                                                              TieCols t) {
+                                                              TieCols t, const uint32_t *__restrict__ u_seg, uint32_t seg_shift) {
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nu) return;
   const uint32_t mem = vals[j], r = u_read[mem];
-  uint64_t k = 0;
+  uint64_t k = u_seg ? (uint64_t)u_seg[mem] << seg_shift : 0ull;  // the run id in front: runs stay apart and in order
   for (uint32_t b = 0; b < sel.n; b++) k |= (uint64_t)lut[(uint32_t)sel.slot[b] * 256u + material_byte(t, r, sel.pos[b], maxq, mem)] << sel.shift[b];
   keys[j] = k;
 }
@@ -725,6 +727,63 @@ __global__ __launch_bounds__(256) void k_seg_keys(uint32_t nu, const uint32_t *_
   if (j < nu) keys[j] = (uint64_t)u_seg_incl[vals[j]];
 }
 
+
+// The comparator strings of two members, all positions (the order the LSD rounds over every live position give).
+__device__ inline int material_cmp(const TieCols &t, uint32_t ma, uint32_t ra, uint32_t mb, uint32_t rb, uint32_t nbytes, uint32_t maxq) {
+  if (t.rows) {
+    const uint64_t *a8 = reinterpret_cast<const uint64_t *>(t.rows + (size_t)ma * t.rw), *b8 = reinterpret_cast<const uint64_t *>(t.rows + (size_t)mb * t.rw);
+    for (uint32_t k = 0; k < nbytes; k += 8) {  // bytes behind nbytes are zero in every row
+      const uint64_t x = a8[k >> 3], y = b8[k >> 3];
+      if (x != y) return __builtin_bswap64(x) < __builtin_bswap64(y) ? -1 : 1;
+    }
+    return 0;
+  }
+  for (uint32_t j = 0; j < nbytes; j++) {
+    const uint32_t x = material_byte(t, ra, j, maxq), y = material_byte(t, rb, j, maxq);
+    if (x != y) return x < y ? -1 : 1;
+  }
+  return 0;
+}
+// Members of the large runs sorted on ONE key: the run id and the ranks of the most significant live positions that fit 64 bits
+// (read names differ early: nearly every key is unique or shared by the two mates of a pair).  What the key leaves open is settled
+// here: a member whose neighbours have other keys is final; the members of a group of equal keys rank themselves by comparing the
+// whole strings (equal strings: the earlier member first, as the stable rounds leave them).  A group of more than LT_CAP members
+// raises `over`: the host then runs the LSD rounds over all positions instead.
+constexpr uint32_t LT_CAP = 1024;
+__global__ __launch_bounds__(256) void k_large_ties(uint32_t nu, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                    uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ u_read, uint32_t nbytes, uint32_t maxq,
+                                                    uint32_t *over, TieCols t) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nu) return;
+  const uint64_t k = keys[j];
+  const uint32_t me = vals[j];
+  const bool eq_prev = j > 0 && keys[j - 1] == k, eq_next = j + 1 < nu && keys[j + 1] == k;
+  if (!eq_prev && !eq_next) { vals_out[j] = me; return; }
+  uint32_t s = j, e = j + 1;  // group [s, e)
+  bool large = false;
+  while (s > 0 && keys[s - 1] == k) {
+    s--;
+    if (j - s >= LT_CAP) { large = true; break; }
+  }
+  while (!large && e < nu && keys[e] == k) {
+    e++;
+    if (e - s > LT_CAP) large = true;
+  }
+  if (large) {
+    vals_out[j] = me;
+    if (!eq_prev) atomicOr(over, 1u);
+    return;
+  }
+  const uint32_t rme = u_read[me];
+  uint32_t rank = 0;
+  for (uint32_t i = s; i < e; i++) {
+    if (i == j) continue;
+    const uint32_t other = vals[i];
+    const int c = material_cmp(t, other, u_read[other], me, rme, nbytes, maxq);
+    if (c < 0 || (c == 0 && other < me)) rank++;
+  }
+  vals_out[s + rank] = me;
+}
 
 __global__ __launch_bounds__(256) void k_large_scatter(uint32_t nu, const uint32_t *__restrict__ vals_sorted, const uint32_t *__restrict__ u_pos,
                                                        const uint32_t *__restrict__ u_read, uint32_t *__restrict__ perm_out) {
@@ -757,8 +816,8 @@ static int sort_impl(elp_ctx *c) {
   {
     uint32_t *list = (vs == v0) ? v1 : v0, *list_n = c->err_flag.p + 3;  // the scan-total mailbox
     ELP_HIP(c, hipMemsetAsync(list_n, 0, 4, c->stream));
-    ELP_HIP(c, hipMemsetAsync(bounds, 0, 16, c->stream));
-    ELP_LAUNCH(c, "tie_scan", k_tie_scan, dim3(blocks_for(n, 256 * TS_TILES)), dim3(256), 0, n, (const uint64_t *)ks, (const uint32_t *)vs, c->perm.p, list, list_n);
+    ELP_LAUNCH(c, "tie_scan", k_tie_scan, dim3(blocks_for(n, 256 * TS_TILES)), dim3(256), 0, n, (const uint64_t *)ks, (const uint32_t *)vs, c->perm.p, list, list_n,
+               bounds);
     // sized for the worst case; workgroups beyond the list's end leave at once
     ELP_LAUNCH(c, "tie_small", k_tie_small, dim3(blocks_for(n, 256)), dim3(256), 0, n, (const uint64_t *)ks, (const uint32_t *)vs, c->perm.p, bounds, bounds_cap,
                (const uint32_t *)list, (const uint32_t *)list_n, t);
@@ -863,6 +922,54 @@ static int sort_impl(elp_ctx *c) {
         bits[k] = b;
       }
       ELP_HIP(c, hipMemcpyAsync(d_lut, lut.data(), lut.size(), hipMemcpyHostToDevice, c->stream));
+      // ONE round if everything fits a key, or - round 4 - on the most significant positions that do, with the rest settled by
+      // comparison inside the groups of equal keys (k_large_ties); the run id rides in front of the key (no last round on it)
+      int segbits = 0;
+      while (nr > 1 && (1u << segbits) <= nr) segbits++;  // u_seg = 1 .. nr
+      if (c->tune.tie_rounds != 1 && segbits + bits[0] <= 64) {
+        TiePacked sel;
+        memset(&sel, 0, sizeof sel);
+        int total = 0, hi = 0;
+        while (hi < (int)pl.n && hi < 64 && segbits + total + bits[hi] <= 64) total += bits[hi++];
+        int sh = total;
+        for (int k = 0; k < hi; k++) {
+          sh -= bits[k];
+          sel.pos[sel.n] = pl.pos[k]; sel.shift[sel.n] = (uint8_t)sh; sel.slot[sel.n] = (uint8_t)k;
+          sel.n++;
+        }
+        ELP_LAUNCH(c, "material_keys", k_material_keys_packed, dim3(blocks_for(nu, 256)), dim3(256), 0, nu, (const uint32_t *)vcur, (const uint32_t *)u_read,
+                   sel, (const uint8_t *)d_lut, maxq, uk0, t, (const uint32_t *)(nr > 1 ? u_seg : nullptr), (uint32_t)total);
+        uint64_t *ko;
+        uint32_t *vo;
+        ELP_TRY(radix_sort_pairs_low(c, uk0, vcur, uk1, vtmp, nu, (segbits + total + 7) / 8, &ko, &vo));
+        if (vo != vcur) { vtmp = vcur; vcur = vo; }
+        bool settled = hi == (int)pl.n;  // every live position is in the key: equal keys are equal strings, the stable passes kept their order
+        if (!settled) {
+          uint32_t *over = c->err_flag.p + 3;  // the scan-total mailbox (zero here)
+          ELP_LAUNCH(c, "large_ties", k_large_ties, dim3(blocks_for(nu, 256)), dim3(256), 0, nu, (const uint64_t *)ko, (const uint32_t *)vcur, vtmp,
+                     (const uint32_t *)u_read, m_bytes, maxq, over, t);
+          std::swap(vcur, vtmp);
+          ELP_LAUNCH(c, "large_scatter", k_large_scatter, dim3(blocks_for(nu, 256)), dim3(256), 0, nu, (const uint32_t *)vcur, (const uint32_t *)u_pos,
+                     (const uint32_t *)u_read, c->perm.p);
+          uint32_t h_over = 0;
+          ELP_HIP(c, hipMemcpyAsync(&h_over, over, 4, hipMemcpyDeviceToHost, c->stream));
+          ELP_HIP(c, hipStreamSynchronize(c->stream));
+          settled = h_over == 0;
+          if (!settled) {  // a group of > LT_CAP equal keys: the rounds over all positions, from the members' first order
+            ELP_HIP(c, hipMemsetAsync(over, 0, 4, c->stream));
+            ELP_LAUNCH(c, "iota", k_iota, dim3(blocks_for(nu, 256)), dim3(256), 0, uv0, (uint64_t)nu);
+            vcur = uv0; vtmp = uv1;
+          }
+        } else {
+          ELP_LAUNCH(c, "large_scatter", k_large_scatter, dim3(blocks_for(nu, 256)), dim3(256), 0, nu, (const uint32_t *)vcur, (const uint32_t *)u_pos,
+                     (const uint32_t *)u_read, c->perm.p);
+        }
+        if (settled) {
+          c->radix_check_pending = true;
+          c->sorted = true;
+          return 0;
+        }
+      }
       // rounds from the least significant position upwards, each filling at most 64 bits / 64 positions
       for (int hi = (int)pl.n; hi > 0;) {
         TiePacked sel;
@@ -876,7 +983,7 @@ static int sort_impl(elp_ctx *c) {
           sel.n++;
         }
         ELP_LAUNCH(c, "material_keys", k_material_keys_packed, dim3(blocks_for(nu, 256)), dim3(256), 0, nu, (const uint32_t *)vcur, (const uint32_t *)u_read,
-                   sel, (const uint8_t *)d_lut, maxq, uk0, t);
+                   sel, (const uint8_t *)d_lut, maxq, uk0, t, (const uint32_t *)nullptr, 0u);
         uint64_t *ko;
         uint32_t *vo;
         ELP_TRY(radix_sort_pairs_low(c, uk0, vcur, uk1, vtmp, nu, (total + 7) / 8, &ko, &vo));

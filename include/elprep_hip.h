@@ -342,6 +342,9 @@ int elp_clean_sam(elp_ctx *ctx, uint64_t *n_clipped_out);
  *                      small value sends every bucket through the overflow path
  *   "mate_path"        1: every mate candidate is matched by the partitioned pass (hash partition + LDS tables), no neighbour
  *                      shortcut - what coordinate-ordered or shuffled input takes by itself; 2: ... by the table in HBM
+ *   "tie_rounds"       1: the coordinate sort orders its long runs of equal coordinates (the unmapped block, pile-ups) by radix rounds
+ *                      over every live name position - the path a group of > 1024 names that agree in their leading positions takes
+ *                      by itself - instead of one round on the leading positions + comparison of what it leaves equal
  * Returns ELP_ERR_ARG for an unknown key or a value out of range. */
 int elp_set_tuning(elp_ctx *ctx, const char *key, int64_t value);
 

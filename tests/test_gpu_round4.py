@@ -403,3 +403,41 @@ def test_clean_sam_against_the_oracle():
     assert e.clean_sam() == n_changed
     assert np.array_equal(e.mark_duplicates(True), oflags)
     e.close()
+
+
+@pytest.mark.parametrize("tie_rounds", [0, 1])
+@pytest.mark.parametrize("big_group", [False, True])
+def test_sort_long_runs_one_key_then_compare(big_group, tie_rounds):
+    """Long runs of equal coordinates (pile-ups, the unmapped block) whose names do not fit one 64-bit key of position ranks: the sort
+    takes ONE radix round on the run id and the leading live positions and settles the groups of equal keys by comparing the whole
+    comparator strings (k_large_ties) - mates with one name, names that differ only far behind the key, three runs that must stay apart.
+    With a group of more than 1024 names that agree in everything the key holds, it falls back to the rounds over all positions
+    (what "tie_rounds" = 1 forces).  Same permutation as the oracle's stable sort (sam/sam-types.go:425-473, :639-641) every time."""
+    from elprep_amd.batch import batch_from_records
+    rng = np.random.default_rng(11 + (1 if big_group else 0))
+    recs = []
+    def rec(name, refid, pos, k):
+        paired = bool(rng.integers(0, 2))
+        return dict(qname=name, flag=(0x1 | (0x40 if k % 2 else 0x80)) if paired else 0, refid=refid, pos=pos, cigar="10M", mapq=int(rng.integers(0, 3)),
+                    next_refid=int(rng.integers(-1, 2)), pnext=int(rng.integers(0, 4)), tlen=int(rng.integers(-2, 3)), seq="A" * 10, qual=[30] * 10, rgid=0)
+    heads = ["%020d" % rng.integers(0, 10**18) for _ in range(40)]
+    for k in range(3000):  # run 1: 40 heads of 20 digits (the key ends inside or right behind them), tails that differ behind the key, exact ties
+        tail = "%020d" % rng.integers(0, 10**18) if rng.integers(0, 4) else "7" * 20
+        recs.append(rec("N" + heads[int(rng.integers(0, 40))] + tail, 0, 100, k))
+    for k in range(400):   # run 2: names of two alternatives per position (one bit each), of several lengths
+        recs.append(rec("N" + "".join("ab"[int(x)] for x in rng.integers(0, 2, int(rng.integers(30, 42)))), 0, 200, k))
+    if big_group:          # run 3: 1500 names that agree in the 33 leading positions and differ behind them
+        for k in range(1500):
+            recs.append(rec("N" + "5" * 32 + "%07d" % rng.integers(0, 3000), 1, 50, k))
+    for k in range(600):   # the unmapped block: pairs of mates with one name
+        recs.append(dict(qname="N%030d" % rng.integers(0, 250), flag=0x4 | 0x1 | (0x40 if k % 2 else 0x80) | 0x8, refid=-1, pos=0, cigar="*", seq="A" * 10,
+                         qual=[30] * 10, rgid=0))
+    for k in range(100):
+        recs.append(rec("s%d" % k, 1, int(rng.integers(1, 30)), k))
+    order = rng.permutation(len(recs))
+    b = batch_from_records([recs[i] for i in order])
+    h = Header(ref_len=np.array([1000, 1000], np.int32), rg_lib=np.array([0], np.uint16), rg_cov=np.array([0], np.uint16))
+    e = Engine(h, tuning={"tie_rounds": tie_rounds})
+    e.stage(b)
+    assert np.array_equal(e.sort_coordinate(), orc.sort_coordinate(b))
+    e.close()
