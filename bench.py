@@ -229,6 +229,8 @@ def main():
         def finalize_lut(qt, ct, xt):
             t0 = time.perf_counter()
             tb = BqsrTables(qt, ct, xt, MAX_CYCLE).finalize()
+            if lut_buf[0] is None:  # the LUT is built in page-locked memory (its upload then runs at the PCIe rate), once per context
+                lut_buf[0] = (eng.pinned_zeros((eng.header.n_cov, 94, 2 * MAX_CYCLE + 1, 17), np.uint8), np.zeros(eng.header.n_cov, np.uint8))
             lut, present = tb.build_lut(0, out=lut_buf[0])
             lut_buf[0] = (lut, present)
             eng.lut_upload(lut, present, MAX_CYCLE)  # on the context's copy stream, from this (host) thread, while the GPU sorts

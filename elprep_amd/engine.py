@@ -70,6 +70,23 @@ class Engine:
         if getattr(self, "h", None) and self.h.value:
             self.L.elp_destroy(self.h)
             self.h = C.c_void_p()
+        for ptr in getattr(self, "_pinned", []):
+            self.L.elp_pinned_free(ptr)
+        self._pinned = []
+
+    def pinned_zeros(self, shape, dtype) -> np.ndarray:
+        """a zeroed array in page-locked host memory (elp_pinned_alloc; freed by close()): the buffers the tables and the LUT travel through,
+        so that their copies run at the PCIe rate instead of through the runtime's staging of pageable memory"""
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        ptr = self.L.elp_pinned_alloc(max(nbytes, 8))
+        if not ptr:
+            raise MemoryError("elp_pinned_alloc(%d)" % nbytes)
+        if not hasattr(self, "_pinned"):
+            self._pinned = []
+        self._pinned.append(ptr)
+        a = np.frombuffer((C.c_uint8 * max(nbytes, 8)).from_address(ptr), dtype=np.uint8)[:nbytes].view(dtype).reshape(shape)
+        a[...] = 0
+        return a
 
     def __del__(self):
         try:
@@ -306,8 +323,8 @@ class Engine:
         nc = self.header.n_cov
         bufs = getattr(self, "_tables", None) if reuse else None
         if bufs is None or bufs[0] != (nc, max_cycle):
-            bufs = ((nc, max_cycle), np.zeros((nc, NQUAL, 2), dtype=np.int64), np.zeros((nc, NQUAL, ncyc, 2), dtype=np.int64),
-                    np.zeros((nc, NQUAL, NCTX, 2), dtype=np.int64))
+            mk = self.pinned_zeros if reuse else (lambda shape, dtype: np.zeros(shape, dtype=dtype))  # buffers that stay: page-locked
+            bufs = ((nc, max_cycle), mk((nc, NQUAL, 2), np.int64), mk((nc, NQUAL, ncyc, 2), np.int64), mk((nc, NQUAL, NCTX, 2), np.int64))
             if reuse:
                 self._tables = bufs
         _, qt, ct, xt = bufs
@@ -340,8 +357,8 @@ class Engine:
         nc = self.header.n_cov
         bufs = getattr(self, "_tables", None) if reuse else None
         if bufs is None or bufs[0] != (nc, max_cycle):
-            bufs = ((nc, max_cycle), np.zeros((nc, NQUAL, 2), dtype=np.int64), np.zeros((nc, NQUAL, ncyc, 2), dtype=np.int64),
-                    np.zeros((nc, NQUAL, NCTX, 2), dtype=np.int64))
+            mk = self.pinned_zeros if reuse else (lambda shape, dtype: np.zeros(shape, dtype=dtype))  # buffers that stay: page-locked
+            bufs = ((nc, max_cycle), mk((nc, NQUAL, 2), np.int64), mk((nc, NQUAL, ncyc, 2), np.int64), mk((nc, NQUAL, NCTX, 2), np.int64))
             if reuse:
                 self._tables = bufs
         _, qt, ct, xt = bufs

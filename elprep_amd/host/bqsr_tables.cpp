@@ -295,9 +295,27 @@ inline double err_rate(long long nobs, long long nerr) { return nobs == 0 ? 0.0 
 
 }  // namespace
 
+// a dense array whose untouched pages stay untouched: calloc hands out zero pages that cost nothing until they are written.  Most
+// (covariate, quality) rows of the cycle and context tables are empty (the qualities a sequencer never reports, the cycles beyond the
+// read length): with 16 read groups the tables are 24 MB of which 1 MB is used
+struct LazyZero {
+  long long *p = nullptr;
+  size_t n = 0;
+  LazyZero() = default;
+  LazyZero(const LazyZero &) = delete;
+  LazyZero &operator=(const LazyZero &) = delete;
+  ~LazyZero() { std::free(p); }
+  bool alloc(size_t count) { std::free(p); n = count; p = static_cast<long long *>(std::calloc(count ? count : 1, sizeof(long long))); return p != nullptr; }
+  long long &operator[](size_t i) { return p[i]; }
+  const long long &operator[](size_t i) const { return p[i]; }
+  size_t size() const { return n; }
+};
+
 struct elp_bqsr_tables {
   int n_cov, max_cycle, ncyc;
-  std::vector<long long> q, c, x;           // {obs, mism} pairs
+  std::vector<long long> q;                 // {obs, mism} pairs
+  LazyZero c, x;
+  std::vector<uint8_t> live;                // per (cov, quality) row: some cycle or context entry is not zero
   std::vector<uint8_t> qe, ce, xe;          // EmpiricalQuality, 255 = absent
   std::vector<uint8_t> ce_cond, xe_cond;    // the same entries under the prior of ApplyBQSR's hierarchy (cond[row]), for the LUT
   std::vector<double> cond;                 // per (cov, quality): deltaQReported + deltaQ + epsilon (:959-975)
@@ -311,17 +329,33 @@ struct elp_bqsr_tables {
 
 extern "C" {
 
+// adds the rows of ct / xt that hold anything into the tables (rows are independent: one task each)
+static void add_rows(elp_bqsr_tables *t, const int64_t *ct, const int64_t *xt) {
+  const size_t nq = size_t(t->n_cov) * NQ, cw = size_t(t->ncyc) * 2, xw = size_t(NX) * 2;
+  parallel_rows(nq, [&](size_t row) {
+    const long long *cs = ct ? reinterpret_cast<const long long *>(ct) + row * cw : nullptr;
+    const long long *xs = xt ? reinterpret_cast<const long long *>(xt) + row * xw : nullptr;
+    bool any = false;
+    for (size_t k = 0; cs && k < cw && !any; k++) any = cs[k] != 0;
+    for (size_t k = 0; xs && k < xw && !any; k++) any = xs[k] != 0;
+    if (!any) return;
+    if (cs) { long long *d = &t->c[row * cw]; for (size_t k = 0; k < cw; k++) d[k] += cs[k]; }
+    if (xs) { long long *d = &t->x[row * xw]; for (size_t k = 0; k < xw; k++) d[k] += xs[k]; }
+    t->live[row] = 1;
+  });
+}
+
 elp_bqsr_tables *elp_bqsr_tables_new(int n_cov, int max_cycle, const int64_t *qt, const int64_t *ct, const int64_t *xt) {
   if (n_cov < 0 || max_cycle < 1) return nullptr;
   auto *t = new elp_bqsr_tables();
   t->n_cov = n_cov; t->max_cycle = max_cycle; t->ncyc = 2 * max_cycle + 1;
   const size_t nq = size_t(n_cov) * NQ;
   static_assert(sizeof(long long) == sizeof(int64_t), "tables are kept as long long");
-  const auto fill = [](std::vector<long long> &v, const int64_t *src, size_t n) {
-    if (src) v.assign(reinterpret_cast<const long long *>(src), reinterpret_cast<const long long *>(src) + n);
-    else v.assign(n, 0);
-  };
-  fill(t->q, qt, nq * 2); fill(t->c, ct, nq * t->ncyc * 2); fill(t->x, xt, nq * NX * 2);
+  if (qt) t->q.assign(reinterpret_cast<const long long *>(qt), reinterpret_cast<const long long *>(qt) + nq * 2);
+  else t->q.assign(nq * 2, 0);
+  t->live.assign(nq, 0);
+  if (!t->c.alloc(nq * t->ncyc * 2) || !t->x.alloc(nq * NX * 2)) { delete t; return nullptr; }
+  add_rows(t, ct, xt);
   return t;
 }
 void elp_bqsr_tables_free(elp_bqsr_tables *t) { delete t; }
@@ -329,8 +363,7 @@ void elp_bqsr_tables_free(elp_bqsr_tables *t) { delete t; }
 int elp_bqsr_tables_merge(elp_bqsr_tables *t, const int64_t *qt, const int64_t *ct, const int64_t *xt) {
   if (!t || !qt || !ct || !xt) return -1;
   for (size_t i = 0; i < t->q.size(); i++) t->q[i] += qt[i];
-  for (size_t i = 0; i < t->c.size(); i++) t->c[i] += ct[i];
-  for (size_t i = 0; i < t->x.size(); i++) t->x[i] += xt[i];
+  add_rows(t, ct, xt);
   t->finalized = false;
   return 0;
 }
@@ -375,6 +408,7 @@ int elp_bqsr_tables_finalize(elp_bqsr_tables *t) {
     const size_t row = task / kParts;
     const int part = int(task % kParts);
     const int lo = part * part_len, hi = std::min(ncyc, lo + part_len);
+    if (!t->live[row]) return;
     bool any = false;
     for (int cy = lo; cy < hi && !any; cy++) any = t->c[2 * (row * ncyc + cy)] > 0;
     if (part == 0) for (int cx = 0; cx < NX && !any; cx++) any = t->x[2 * (row * NX + cx)] > 0;
@@ -504,17 +538,18 @@ int elp_bqsr_tables_build_lut(const elp_bqsr_tables *t, int quantize_levels, con
       std::vector<double> dcyc(ncyc), dctx(17);
       const size_t qi = t->qi(cv, ql);
       const double cond = t->cond[qi];  // deltaQReported + deltaQ + epsilon, and the entries' estimates under it: elp_bqsr_tables_finalize
-      for (int cy = 0; cy < ncyc; cy++) {
+      const bool live = t->live[qi] != 0;  // else: no cycle or context entry in this row
+      for (int cy = 0; live && cy < ncyc; cy++) {
         const size_t ci = qi * ncyc + cy;
         dcyc[cy] = t->c[2 * ci] > 0 ? double(t->ce_cond[ci]) - cond : 0.0;
       }
       for (int cx = 0; cx < 16; cx++) {
         const size_t xi = qi * NX + cx;
-        dctx[cx] = t->x[2 * xi] > 0 ? double(t->xe_cond[xi]) - cond : 0.0;
+        dctx[cx] = live && t->x[2 * xi] > 0 ? double(t->xe_cond[xi]) - cond : 0.0;
       }
       uint8_t *lq = lc + size_t(ql) * ncyc * 17;
       auto entry = [&](bool has_c, int cy, int cx) {
-        const bool has_x = cx < 16 && t->x[2 * (qi * NX + cx)] > 0;
+        const bool has_x = live && cx < 16 && t->x[2 * (qi * NX + cx)] > 0;
         double d_cov = 0;
         if (has_c) d_cov = dcyc[cy];
         if (has_x) d_cov += dctx[cx];
@@ -536,7 +571,7 @@ int elp_bqsr_tables_build_lut(const elp_bqsr_tables *t, int quantize_levels, con
         std::memcpy(lq + have, lq, n);
         have += n;
       }
-      for (int cy = 0; cy < ncyc; cy++) {
+      for (int cy = 0; live && cy < ncyc; cy++) {
         if (t->c[2 * (qi * ncyc + cy)] > 0) {
           uint8_t *le = lq + size_t(cy) * 17;
           for (int cx = 0; cx < 17; cx++) le[cx] = entry(true, cy, cx);
