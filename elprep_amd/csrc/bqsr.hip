@@ -1867,19 +1867,31 @@ int elp_bqsr_lut_upload(elp_ctx *c, int max_cycle, const uint8_t *lut, const uin
   ELP_HIP(c, hipSetDevice(c->device));
   const size_t lut_bytes = (size_t)c->n_cov * ELP_NQUAL * (2 * (size_t)max_cycle + 1) * 17, all = lut_bytes + (size_t)c->n_cov;
   if (c->lut_ev) ELP_HIP(c, hipEventSynchronize(c->lut_ev));  // (a previous upload still in flight reads the pinned buffer)
-  if (all > c->lut_pinned_cap) {
+  // a LUT that already sits in page-locked memory (elp_pinned_alloc) is copied from where it is - with many read groups the LUT is tens of
+  // megabytes and the staging copy below was the longest part of the host's table path; the caller then leaves it alone until the
+  // elp_bqsr_apply that uses it has been called and the context synchronised
+  hipPointerAttribute_t pa;
+  const bool caller_pinned = hipPointerGetAttributes(&pa, lut) == hipSuccess && pa.type == hipMemoryTypeHost;
+  if (!caller_pinned) (void)hipGetLastError();  // (ordinary memory: the query fails, by design)
+  const size_t staged = caller_pinned ? (size_t)c->n_cov : all;
+  if (staged > c->lut_pinned_cap) {
     if (c->lut_pinned) (void)hipHostFree(c->lut_pinned);
     c->lut_pinned = nullptr; c->lut_pinned_cap = 0;
-    ELP_HIP(c, hipHostMalloc(&c->lut_pinned, all, hipHostMallocDefault));
-    c->lut_pinned_cap = all;
+    ELP_HIP(c, hipHostMalloc(&c->lut_pinned, staged, hipHostMallocDefault));
+    c->lut_pinned_cap = staged;
   }
   ELP_TRY(ensure(c, c->lut_dev, all + 64));
-  memcpy(c->lut_pinned, lut, lut_bytes);
-  memcpy(static_cast<uint8_t *>(c->lut_pinned) + lut_bytes, cov_present, (size_t)c->n_cov);
+  if (!caller_pinned) memcpy(c->lut_pinned, lut, lut_bytes);
+  memcpy(static_cast<uint8_t *>(c->lut_pinned) + (caller_pinned ? 0 : lut_bytes), cov_present, (size_t)c->n_cov);
   if (!c->lut_ev) ELP_HIP(c, hipEventCreateWithFlags(&c->lut_ev, hipEventDisableTiming));
   if (!c->copy_stream) ELP_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));  // (not the NULL stream all contexts share)
   if (c->apply_ev) ELP_HIP(c, hipStreamWaitEvent(c->copy_stream, c->apply_ev, 0));  // an apply that still reads the previous LUT
-  ELP_HIP(c, hipMemcpyAsync(c->lut_dev.p, c->lut_pinned, all, hipMemcpyHostToDevice, c->copy_stream));
+  if (caller_pinned) {
+    ELP_HIP(c, hipMemcpyAsync(c->lut_dev.p, lut, lut_bytes, hipMemcpyHostToDevice, c->copy_stream));
+    ELP_HIP(c, hipMemcpyAsync(c->lut_dev.p + lut_bytes, c->lut_pinned, (size_t)c->n_cov, hipMemcpyHostToDevice, c->copy_stream));
+  } else {
+    ELP_HIP(c, hipMemcpyAsync(c->lut_dev.p, c->lut_pinned, all, hipMemcpyHostToDevice, c->copy_stream));
+  }
   // the row dictionary apply3 works from, behind the copy on the same stream - if what it depends on is known now (the quality hint of the
   // gather that produced these tables, a read set of one length): 0.25 ms that elp_bqsr_apply otherwise spends in front of its kernel
   c->dict_ready = false;

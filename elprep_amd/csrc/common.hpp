@@ -193,6 +193,7 @@ struct elp_ctx {
     int bgzf_weak_guess = 0;   // 1: a block guesses its first record start without looking at the bytes (tests: every guess wrong, all repaired)
     int score_kernel = 0;      // 1: the general (flat) score kernel even for read sets of one length
     int mate_path = 0;         // 1: every mate candidate goes through the table path (no neighbour shortcut)
+    int radix_tile = 0;        // 1: radix passes in tiles of 4096 keys whatever the length; 2: of 8192 (default: 8192 from 8 M keys on)
     int tie_rounds = 0;        // 1: the sort's long runs by LSD rounds over every live position (no key-then-compare shortcut)
   } tune;
 

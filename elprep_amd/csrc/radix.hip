@@ -132,7 +132,6 @@ int exclusive_scan_u32(elp_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n
 constexpr int RS_THREADS = 256;
 constexpr int RS_ITEMS = 16;
 constexpr int RS_TILE = RS_THREADS * RS_ITEMS;  // 4096 keys per workgroup
-constexpr int RS_WAVES = RS_THREADS / 64;
 
 // one sweep: histograms of all 8 digit positions (decides which passes are live)
 template <int ND>
@@ -174,28 +173,33 @@ __global__ __launch_bounds__(256) void k_radix_hist_all(const uint64_t *__restri
 // [31:0] the count.  Words of earlier passes carry an older epoch and read as "not there yet", so the array is never cleared.
 constexpr unsigned long long RS_AGG = 1ull << 32, RS_INCL = 2ull << 32;
 
-__global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+template <int THREADS>
+__global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 1) void k_radix_scatter_t(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
                                                               uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint64_t n,
                                                               int shift, const unsigned long long *__restrict__ ghist /* [256] of this digit */,
                                                               unsigned long long *state, uint32_t epoch, uint32_t *ticket,
                                                               uint32_t *err, const uint32_t *__restrict__ n_dev) {
-  __shared__ uint32_t cnt[RS_WAVES][256];
+  constexpr int WAVES = THREADS / 64, TILE = THREADS * RS_ITEMS;  // 4096 keys (256 threads) or 8192 (512: runs of twice the length per digit)
+  __shared__ uint32_t cnt[WAVES][256];
   __shared__ uint32_t gbase[256];   // global position of the tile's first key with digit d, minus its position inside the sorted tile
-  __shared__ uint32_t scan_lds[8];
-  __shared__ uint64_t sbuf[RS_TILE];  // the tile in digit order: keys first, then (as uint32) the values
+  __shared__ uint32_t scan_lds[16];
+  // the tile in digit order: keys first, then (as uint32) the values - 32 KB static, or 64 KB of dynamic LDS
+  extern __shared__ __attribute__((aligned(16))) uint64_t sbuf_dyn[];
+  __shared__ uint64_t sbuf_static[THREADS == 256 ? RS_TILE : 1];
+  uint64_t *const sbuf = THREADS == 256 ? sbuf_static : sbuf_dyn;
   __shared__ uint32_t my_tile;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (threadIdx.x == 0) my_tile = atomicAdd(ticket, 1u);  // tiles are numbered in the order they start (the host zeroes the counter)
-  for (int i = threadIdx.x; i < RS_WAVES * 256; i += RS_THREADS) (&cnt[0][0])[i] = 0;
+  for (int i = threadIdx.x; i < WAVES * 256; i += THREADS) (&cnt[0][0])[i] = 0;
   __syncthreads();
   const uint32_t tile = my_tile;
-  const uint64_t tbase = (uint64_t)tile * RS_TILE;
+  const uint64_t tbase = (uint64_t)tile * TILE;
   if (n_dev) {  // device-side length: the launch covers its upper bound, tiles behind the end leave at once (nobody looks back at them)
     n = *n_dev;
     if (tbase >= n) return;
   }
   const uint64_t wbase = tbase + (uint64_t)w * (64 * RS_ITEMS);
-  const uint32_t tile_n = (uint32_t)((n - tbase) < (uint64_t)RS_TILE ? (n - tbase) : (uint64_t)RS_TILE);
+  const uint32_t tile_n = (uint32_t)((n - tbase) < (uint64_t)TILE ? (n - tbase) : (uint64_t)TILE);
   uint64_t k[RS_ITEMS];
   uint32_t v[RS_ITEMS];
   uint32_t pos[RS_ITEMS];
@@ -229,21 +233,27 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint64_t *__
   // thread t owns digit t: position of the digit inside the sorted tile (exclusive scan over digits), then per-wave starts
   uint32_t tot = 0, tstart;
   const unsigned long long tag = (unsigned long long)epoch << 34;
-  unsigned long long *mine = state + (size_t)tile * 256 + threadIdx.x;
+  const bool owner = THREADS == 256 || threadIdx.x < 256;  // the first 256 threads own a digit each
+  const uint32_t dg = THREADS == 256 ? threadIdx.x : (threadIdx.x & 255u);
+  unsigned long long *mine = state + (size_t)tile * 256 + dg;
   {
+    if (owner) {
 #pragma unroll
-    for (int i = 0; i < RS_WAVES; i++) tot += cnt[i][threadIdx.x];
-    // the tile's own count goes out as early as possible, the look-back comes as late as possible (behind the LDS reorder of the
-    // keys): the tiles in front get that time to publish
-    __hip_atomic_store(mine, tag | (tile == 0 ? RS_INCL : RS_AGG) | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int i = 0; i < WAVES; i++) tot += cnt[i][dg];
+      // the tile's own count goes out as early as possible, the look-back comes as late as possible (behind the LDS reorder of the
+      // keys): the tiles in front get that time to publish
+      __hip_atomic_store(mine, tag | (tile == 0 ? RS_INCL : RS_AGG) | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     uint32_t all;
-    tstart = block_excl_scan_256(tot, &all, scan_lds);
-    uint32_t run = tstart;
+    tstart = block_excl_scan_256(tot, &all, scan_lds);  // (waves 4 .. 7 of a 512-thread tile add zeros behind the 256 digits)
+    if (owner) {
+      uint32_t run = tstart;
 #pragma unroll
-    for (int i = 0; i < RS_WAVES; i++) {
-      uint32_t t = cnt[i][threadIdx.x];
-      cnt[i][threadIdx.x] = run;
-      run += t;
+      for (int i = 0; i < WAVES; i++) {
+        uint32_t t = cnt[i][dg];
+        cnt[i][dg] = run;
+        run += t;
+      }
     }
   }
   __syncthreads();
@@ -260,9 +270,9 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint64_t *__
   {
     // first output position of digit t: keys with a smaller digit (global histogram) + keys with digit t in the tiles in front
     uint32_t dall;
-    const uint32_t dbase = block_excl_scan_256((uint32_t)ghist[threadIdx.x], &dall, scan_lds);
+    const uint32_t dbase = block_excl_scan_256(owner ? (uint32_t)ghist[dg] : 0u, &dall, scan_lds);
     uint32_t prefix = 0;
-    if (tile != 0) {
+    if (tile != 0 && owner) {
       // walk back over the tiles in front, eight words per round trip (device-scope loads cross the XCDs: ~1 us each)
       constexpr int LB = 8;
       uint32_t back = 1, spins = 0;  // next tile to look at: tile - back
@@ -288,13 +298,13 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint64_t *__
       }
       __hip_atomic_store(mine, tag | RS_INCL | (prefix + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    gbase[threadIdx.x] = dbase + prefix - tstart;
+    if (owner) gbase[dg] = dbase + prefix - tstart;
   }
   __syncthreads();
   uint32_t dst[RS_ITEMS];
 #pragma unroll
   for (int r = 0; r < RS_ITEMS; r++) {
-    const uint32_t j = (uint32_t)r * RS_THREADS + threadIdx.x;
+    const uint32_t j = (uint32_t)r * THREADS + threadIdx.x;
     if (j < tile_n) {
       const uint64_t key = sbuf[j];
       dst[r] = gbase[(uint32_t)(key >> shift) & 0xFF] + j;
@@ -312,7 +322,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint64_t *__
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < RS_ITEMS; r++) {
-    const uint32_t j = (uint32_t)r * RS_THREADS + threadIdx.x;
+    const uint32_t j = (uint32_t)r * THREADS + threadIdx.x;
     if (j < tile_n) vals_out[dst[r]] = sval[j];
   }
 }
@@ -330,6 +340,37 @@ static int radix_next_epoch(elp_ctx *c) {
   if (++c->radix_epoch >= (1u << 30)) {  // the tag wrapped: forget every word
     ELP_HIP(c, hipMemsetAsync(c->radix_state.p, 0, c->radix_state.cap * sizeof(unsigned long long), c->stream));
     c->radix_epoch = 1;
+  }
+  return 0;
+}
+
+// one pass.  Tiles of 8192 keys (512 threads) for the long arrays - a digit's keys leave a tile as runs of twice the length -, of 4096 for
+// the short ones (more tiles than CUs matter more there); elp_set_tuning "radix_tile": 1 = 4096 always, 2 = 8192 always
+static int radix_tile_shift(const elp_ctx *c, uint64_t n) {  // tile = 4096 keys << shift
+  if (c->tune.radix_tile >= 1 && c->tune.radix_tile <= 3) return c->tune.radix_tile - 1;
+  return n >= (8ull << 20) ? 1 : 0;
+}
+static bool radix_big_tiles(const elp_ctx *c, uint64_t n) { return radix_tile_shift(c, n) == 1; }
+static uint32_t radix_tiles(const elp_ctx *c, uint64_t n) {
+  const uint64_t tile = (uint64_t)RS_TILE << radix_tile_shift(c, n);
+  return (uint32_t)((n + tile - 1) / tile);
+}
+static int radix_scatter_launch(elp_ctx *c, uint64_t n, const uint64_t *kin, const uint32_t *vin, uint64_t *kdst, uint32_t *vdst, int shift,
+                                const unsigned long long *ghist, uint32_t *ticket, const uint32_t *n_dev) {
+  const uint32_t ntiles = radix_tiles(c, n);
+  if (radix_tile_shift(c, n) == 2) {  // (measurements: one workgroup of 16 waves per CU)
+    const size_t dyn = (size_t)4 * RS_TILE * sizeof(uint64_t);
+    ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_radix_scatter_t<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    ELP_LAUNCH(c, "radix_scatter", k_radix_scatter_t<1024>, dim3(ntiles), dim3(1024), dyn, kin, vin, kdst, vdst, n, shift, ghist, c->radix_state.p, c->radix_epoch,
+               ticket, c->err_flag.p, n_dev);
+  } else if (radix_big_tiles(c, n)) {
+    const size_t dyn = (size_t)2 * RS_TILE * sizeof(uint64_t);
+    ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_radix_scatter_t<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    ELP_LAUNCH(c, "radix_scatter", k_radix_scatter_t<512>, dim3(ntiles), dim3(512), dyn, kin, vin, kdst, vdst, n, shift, ghist, c->radix_state.p, c->radix_epoch,
+               ticket, c->err_flag.p, n_dev);
+  } else {
+    ELP_LAUNCH(c, "radix_scatter", k_radix_scatter_t<256>, dim3(ntiles), dim3(256), 0, kin, vin, kdst, vdst, n, shift, ghist, c->radix_state.p, c->radix_epoch, ticket,
+               c->err_flag.p, n_dev);
   }
   return 0;
 }
@@ -352,17 +393,14 @@ int radix_sort_pairs_low(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *k
   if (ndigits <= 2) ELP_LAUNCH(c, "radix_hist_all", k_radix_hist_all<2>, dim3(hb), dim3(256), 0, (const uint64_t *)(first_src ? first_src : keys), n, ghist, n_dev);
   else if (ndigits <= 4) ELP_LAUNCH(c, "radix_hist_all", k_radix_hist_all<4>, dim3(hb), dim3(256), 0, (const uint64_t *)(first_src ? first_src : keys), n, ghist, n_dev);
   else ELP_LAUNCH(c, "radix_hist_all", k_radix_hist_all<8>, dim3(hb), dim3(256), 0, (const uint64_t *)(first_src ? first_src : keys), n, ghist, n_dev);
-  const uint32_t ntiles = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
-  ELP_TRY(radix_pass_setup(c, ntiles));
+  ELP_TRY(radix_pass_setup(c, radix_tiles(c, n)));
   uint64_t *ksrc = keys, *kdst = keys_tmp;
   uint32_t *vsrc = vals, *vdst = vals_tmp;
   for (int d = 0; d < ndigits; d++) {
     ELP_TRY(radix_next_epoch(c));
     const uint64_t *kin = (d == 0 && first_src) ? first_src : ksrc;
     const uint32_t *vin = (d == 0 && identity_vals) ? nullptr : vsrc;
-    ELP_LAUNCH(c, "radix_scatter", k_radix_scatter, dim3(ntiles), dim3(RS_THREADS), 0, kin, vin, kdst,
-               vdst, n, 8 * d, (const unsigned long long *)(ghist + d * 256), c->radix_state.p, c->radix_epoch, ticket + d,
-               c->err_flag.p, n_dev);
+    ELP_TRY(radix_scatter_launch(c, n, kin, vin, kdst, vdst, 8 * d, (const unsigned long long *)(ghist + d * 256), ticket + d, n_dev));
     std::swap(ksrc, kdst);
     std::swap(vsrc, vdst);
   }
@@ -386,8 +424,7 @@ int radix_sort_pairs(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *keys_
   unsigned long long hh[8 * 256];
   ELP_HIP(c, hipMemcpyAsync(hh, ghist, sizeof hh, hipMemcpyDeviceToHost, c->stream));
   ELP_HIP(c, hipStreamSynchronize(c->stream));  // (a look-back timeout of any pass is reported by the callers, behind their last pass)
-  const uint32_t ntiles = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
-  ELP_TRY(radix_pass_setup(c, ntiles));
+  ELP_TRY(radix_pass_setup(c, radix_tiles(c, n)));
   uint64_t *ksrc = keys, *kdst = keys_tmp;
   uint32_t *vsrc = vals, *vdst = vals_tmp;
   for (int d = 0; d < 8; d++) {
@@ -396,9 +433,7 @@ int radix_sort_pairs(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *keys_
       if (hh[d * 256 + b] == n) { live = false; break; }
     if (!live) continue;
     ELP_TRY(radix_next_epoch(c));
-    ELP_LAUNCH(c, "radix_scatter", k_radix_scatter, dim3(ntiles), dim3(RS_THREADS), 0, (const uint64_t *)ksrc, (const uint32_t *)vsrc, kdst,
-               vdst, n, 8 * d, (const unsigned long long *)(ghist + d * 256), c->radix_state.p, c->radix_epoch, ticket + d,
-               c->err_flag.p, (const uint32_t *)nullptr);
+    ELP_TRY(radix_scatter_launch(c, n, ksrc, vsrc, kdst, vdst, 8 * d, (const unsigned long long *)(ghist + d * 256), ticket + d, nullptr));
     std::swap(ksrc, kdst);
     std::swap(vsrc, vdst);
   }

@@ -304,7 +304,9 @@ int elp_bqsr_apply(elp_ctx *ctx, int max_cycle, const uint8_t *lut, const uint8_
  * stream of the context, while other calls (sort, metrics) run on the context from another thread; elp_bqsr_apply(ctx, max_cycle, NULL,
  * NULL) then uses it.  The only other call that may share a context with running calls is elp_bqsr_tables_fetch.  Ordering the
  * caller must keep: no staging call (elp_stage*, elp_reset, elp_rollback) and no elp_bqsr_gather* runs on the context at the same time -
- * the upload reads the staged read length and the gather's quality hint without a lock; sort, metrics, emit and tables_fetch may. */
+ * the upload reads the staged read length and the gather's quality hint without a lock; sort, metrics, emit and tables_fetch may.
+ * A `lut` in page-locked memory (elp_pinned_alloc) is copied from where it lies (no staging copy: with 16 read groups the LUT is 25 MB):
+ * the caller then leaves it unchanged until the elp_bqsr_apply that uses it has been called and the context synchronised. */
 int elp_bqsr_lut_upload(elp_ctx *ctx, int max_cycle, const uint8_t *lut, const uint8_t *cov_present);
 int elp_get_qual(elp_ctx *ctx, uint8_t *qual_out /* qual_bytes, staging order and offsets */);
 
@@ -342,6 +344,7 @@ int elp_clean_sam(elp_ctx *ctx, uint64_t *n_clipped_out);
  *                      small value sends every bucket through the overflow path
  *   "mate_path"        1: every mate candidate is matched by the partitioned pass (hash partition + LDS tables), no neighbour
  *                      shortcut - what coordinate-ordered or shuffled input takes by itself; 2: ... by the table in HBM
+ *   "radix_tile"       1: every radix pass in tiles of 4096 keys; 2: of 8192 keys; 3: of 16384 (default: 8192 for arrays of 8 M keys and more)
  *   "tie_rounds"       1: the coordinate sort orders its long runs of equal coordinates (the unmapped block, pile-ups) by radix rounds
  *                      over every live name position - the path a group of > 1024 names that agree in their leading positions takes
  *                      by itself - instead of one round on the leading positions + comparison of what it leaves equal

@@ -441,3 +441,21 @@ def test_sort_long_runs_one_key_then_compare(big_group, tie_rounds):
     e.stage(b)
     assert np.array_equal(e.sort_coordinate(), orc.sort_coordinate(b))
     e.close()
+
+
+@pytest.mark.parametrize("radix_tile", [1, 2, 3])
+def test_radix_passes_in_tiles_of_4096_and_8192_keys(radix_tile):
+    """every radix pass of the path (coordinate sort, tie-break rounds, the pair list's partition with its device-side length, the
+    metrics' group sort) in tiles of 4096 keys (256 threads) and of 8192 (512 threads, what arrays of 8 M keys and more take by
+    themselves): permutation, flags and counters are the oracle's"""
+    cfg, b, h, refs, sites = dataset("tiny", 40000, 9, 0.03)
+    oflags, octr, ohist = orc.dup_metrics(b, h, None, 100, hist_len=16)
+    e = Engine(h, tuning={"radix_tile": radix_tile})
+    e.stage(b)
+    flags = e.mark_duplicates(True)
+    perm = e.sort_coordinate()
+    ctr, hist = e.dup_metrics(100, hist_len=16)
+    e.close()
+    assert np.array_equal(flags, oflags)
+    assert np.array_equal(ctr, octr) and np.array_equal(hist, ohist)
+    assert np.array_equal(perm, orc.sort_coordinate(b, oflags))
