@@ -194,6 +194,7 @@ struct elp_ctx {
     int score_kernel = 0;      // 1: the general (flat) score kernel even for read sets of one length
     int mate_path = 0;         // 1: every mate candidate goes through the table path (no neighbour shortcut)
     int radix_tile = 0;        // 1: radix passes in tiles of 4096 keys whatever the length; 2: of 8192 (default: 8192 from 8 M keys on)
+    int sort_pairs = 0;        // 1: the coordinate sort moves (key, index) pairs even where key << b | index fits one word
     int tie_rounds = 0;        // 1: the sort's long runs by LSD rounds over every live position (no key-then-compare shortcut)
   } tune;
 
@@ -341,6 +342,7 @@ __host__ __device__ inline uint16_t mod_flag(uint16_t flag) {
 int radix_sort_pairs(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *keys_tmp, uint32_t *vals_tmp, uint64_t n,
                      uint64_t **keys_out, uint32_t **vals_out);
 // the same over the low `ndigits` bytes of the keys only, every pass run (no histogram read-back, no host synchronisation)
+int radix_sort_fused(elp_ctx *c, const uint64_t *keycol, uint64_t n, int key_bits, int idx_bits, uint64_t *buf0, uint64_t *buf1, uint64_t **out);
 int radix_sort_pairs_low(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *keys_tmp, uint32_t *vals_tmp, uint64_t n, int ndigits,
                          uint64_t **keys_out, uint32_t **vals_out, const uint64_t *first_src = nullptr, bool identity_vals = false,
                          const uint32_t *n_dev = nullptr /* the length is *n_dev on the device and `n` its upper bound */);

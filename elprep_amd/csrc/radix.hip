@@ -173,12 +173,14 @@ __global__ __launch_bounds__(256) void k_radix_hist_all(const uint64_t *__restri
 // [31:0] the count.  Words of earlier passes carry an older epoch and read as "not there yet", so the array is never cleared.
 constexpr unsigned long long RS_AGG = 1ull << 32, RS_INCL = 2ull << 32;
 
-template <int THREADS>
+// PAIRS = false: no values - the sort's elements are single words, e.g. key << b | index (`fuse` = b > 0: this pass reads bare keys and
+// appends the element's index: the first pass of such a sort); 16 instead of 24 bytes per element and pass.
+template <int THREADS, bool PAIRS>
 __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 1) void k_radix_scatter_t(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
                                                               uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint64_t n,
                                                               int shift, const unsigned long long *__restrict__ ghist /* [256] of this digit */,
                                                               unsigned long long *state, uint32_t epoch, uint32_t *ticket,
-                                                              uint32_t *err, const uint32_t *__restrict__ n_dev) {
+                                                              uint32_t *err, const uint32_t *__restrict__ n_dev, int fuse) {
   constexpr int WAVES = THREADS / 64, TILE = THREADS * RS_ITEMS;  // 4096 keys (256 threads) or 8192 (512: runs of twice the length per digit)
   __shared__ uint32_t cnt[WAVES][256];
   __shared__ uint32_t gbase[256];   // global position of the tile's first key with digit d, minus its position inside the sorted tile
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 1) void k_radix_scatt
   const uint64_t wbase = tbase + (uint64_t)w * (64 * RS_ITEMS);
   const uint32_t tile_n = (uint32_t)((n - tbase) < (uint64_t)TILE ? (n - tbase) : (uint64_t)TILE);
   uint64_t k[RS_ITEMS];
-  uint32_t v[RS_ITEMS];
+  uint32_t v[PAIRS ? RS_ITEMS : 1];
   uint32_t pos[RS_ITEMS];
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
@@ -209,7 +211,8 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 1) void k_radix_scatt
     uint64_t i = wbase + (uint64_t)r * 64 + lane;
     bool valid = i < n;
     k[r] = valid ? keys[i] : ~0ull;
-    v[r] = valid ? (vals ? vals[i] : (uint32_t)i) : 0u;  // no value array: the values are the indices (first pass of a sort)
+    if (!PAIRS && fuse && valid) k[r] = (k[r] << fuse) | i;
+    if (PAIRS) v[r] = valid ? (vals ? vals[i] : (uint32_t)i) : 0u;  // no value array: the values are the indices (first pass of a sort)
     uint32_t d = (uint32_t)(k[r] >> shift) & 0xFF;
     // peers = lanes of this wave holding the same digit this round (invalid lanes form their own class)
     unsigned long long peers = __ballot(valid);
@@ -311,13 +314,14 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 1) void k_radix_scatt
       keys_out[dst[r]] = key;
     }
   }
+  if (!PAIRS) return;
   __syncthreads();
   // values through the same buffer
   uint32_t *sval = reinterpret_cast<uint32_t *>(sbuf);
 #pragma unroll
   for (int r = 0; r < RS_ITEMS; r++) {
     uint64_t i = wbase + (uint64_t)r * 64 + lane;
-    if (i < n) sval[pos[r]] = v[r];
+    if (i < n) sval[pos[r]] = v[PAIRS ? r : 0];
   }
   __syncthreads();
 #pragma unroll
@@ -344,34 +348,68 @@ static int radix_next_epoch(elp_ctx *c) {
   return 0;
 }
 
-// one pass.  Tiles of 8192 keys (512 threads) for the long arrays - a digit's keys leave a tile as runs of twice the length -, of 4096 for
-// the short ones (more tiles than CUs matter more there); elp_set_tuning "radix_tile": 1 = 4096 always, 2 = 8192 always
+// one pass.  Tiles of 16384 keys (1024 threads, 128 KB of LDS: one workgroup per CU) for arrays of 16 M elements and more, of 8192 from 4 M
+// on - a digit's keys leave a tile as runs of four times / twice the length: 50 M pairs, four passes: 2.14 ms (4096), 2.01 (8192), 1.81
+// (16384) -, of 4096 for the short ones (more tiles than CUs matter more there); elp_set_tuning "radix_tile": 1 / 2 / 3 = 4096 / 8192 /
+// 16384 always
 static int radix_tile_shift(const elp_ctx *c, uint64_t n) {  // tile = 4096 keys << shift
   if (c->tune.radix_tile >= 1 && c->tune.radix_tile <= 3) return c->tune.radix_tile - 1;
-  return n >= (8ull << 20) ? 1 : 0;
+  return n >= (16ull << 20) ? 2 : n >= (4ull << 20) ? 1 : 0;
 }
 static bool radix_big_tiles(const elp_ctx *c, uint64_t n) { return radix_tile_shift(c, n) == 1; }
 static uint32_t radix_tiles(const elp_ctx *c, uint64_t n) {
   const uint64_t tile = (uint64_t)RS_TILE << radix_tile_shift(c, n);
   return (uint32_t)((n + tile - 1) / tile);
 }
+template <bool PAIRS>
+static int radix_scatter_launch_t(elp_ctx *c, uint64_t n, const uint64_t *kin, const uint32_t *vin, uint64_t *kdst, uint32_t *vdst, int shift,
+                                  const unsigned long long *ghist, uint32_t *ticket, const uint32_t *n_dev, int fuse) {
+  const uint32_t ntiles = radix_tiles(c, n);
+  const int ts = radix_tile_shift(c, n);
+  if (ts == 2) {  // one workgroup of 16 waves per CU
+    const size_t dyn = (size_t)4 * RS_TILE * sizeof(uint64_t);
+    ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_radix_scatter_t<1024, PAIRS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    ELP_LAUNCH(c, "radix_scatter", (k_radix_scatter_t<1024, PAIRS>), dim3(ntiles), dim3(1024), dyn, kin, vin, kdst, vdst, n, shift, ghist, c->radix_state.p,
+               c->radix_epoch, ticket, c->err_flag.p, n_dev, fuse);
+  } else if (ts == 1) {
+    const size_t dyn = (size_t)2 * RS_TILE * sizeof(uint64_t);
+    ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_radix_scatter_t<512, PAIRS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    ELP_LAUNCH(c, "radix_scatter", (k_radix_scatter_t<512, PAIRS>), dim3(ntiles), dim3(512), dyn, kin, vin, kdst, vdst, n, shift, ghist, c->radix_state.p,
+               c->radix_epoch, ticket, c->err_flag.p, n_dev, fuse);
+  } else {
+    ELP_LAUNCH(c, "radix_scatter", (k_radix_scatter_t<256, PAIRS>), dim3(ntiles), dim3(256), 0, kin, vin, kdst, vdst, n, shift, ghist, c->radix_state.p,
+               c->radix_epoch, ticket, c->err_flag.p, n_dev, fuse);
+  }
+  return 0;
+}
 static int radix_scatter_launch(elp_ctx *c, uint64_t n, const uint64_t *kin, const uint32_t *vin, uint64_t *kdst, uint32_t *vdst, int shift,
                                 const unsigned long long *ghist, uint32_t *ticket, const uint32_t *n_dev) {
-  const uint32_t ntiles = radix_tiles(c, n);
-  if (radix_tile_shift(c, n) == 2) {  // (measurements: one workgroup of 16 waves per CU)
-    const size_t dyn = (size_t)4 * RS_TILE * sizeof(uint64_t);
-    ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_radix_scatter_t<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-    ELP_LAUNCH(c, "radix_scatter", k_radix_scatter_t<1024>, dim3(ntiles), dim3(1024), dyn, kin, vin, kdst, vdst, n, shift, ghist, c->radix_state.p, c->radix_epoch,
-               ticket, c->err_flag.p, n_dev);
-  } else if (radix_big_tiles(c, n)) {
-    const size_t dyn = (size_t)2 * RS_TILE * sizeof(uint64_t);
-    ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_radix_scatter_t<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-    ELP_LAUNCH(c, "radix_scatter", k_radix_scatter_t<512>, dim3(ntiles), dim3(512), dyn, kin, vin, kdst, vdst, n, shift, ghist, c->radix_state.p, c->radix_epoch,
-               ticket, c->err_flag.p, n_dev);
-  } else {
-    ELP_LAUNCH(c, "radix_scatter", k_radix_scatter_t<256>, dim3(ntiles), dim3(256), 0, kin, vin, kdst, vdst, n, shift, ghist, c->radix_state.p, c->radix_epoch, ticket,
-               c->err_flag.p, n_dev);
+  return radix_scatter_launch_t<true>(c, n, kin, vin, kdst, vdst, shift, ghist, ticket, n_dev, 0);
+}
+
+// The coordinate sort's own form: elements key << idx_bits | index in ONE word (the sort's key has ~31 live bits, an index 26), sorted on the
+// key's digits by stable passes - 16 bytes of traffic per element and pass instead of 24, and a tile's runs per digit are twice as
+// long in bytes.  `keycol` holds the bare keys (key_bits live bits); the result (n words) ends in *out (buf0 or buf1).
+int radix_sort_fused(elp_ctx *c, const uint64_t *keycol, uint64_t n, int key_bits, int idx_bits, uint64_t *buf0, uint64_t *buf1, uint64_t **out) {
+  if (n >= 0xFFFFFFFFull || key_bits + idx_bits > 64 || key_bits < 1 || idx_bits < 1) return set_error(c, ELP_ERR_UNSUPPORTED, "radix sort: bad size");
+  const int ndigits = (key_bits + 7) / 8;
+  unsigned long long *ghist;
+  ELP_TRY(scratch(c, 6, 8 * 256 + 4, &ghist));
+  ELP_HIP(c, hipMemsetAsync(ghist, 0, (8 * 256 + 4) * sizeof(unsigned long long), c->stream));
+  uint32_t *ticket = reinterpret_cast<uint32_t *>(ghist + 8 * 256);
+  const unsigned hb = (unsigned)std::min<uint64_t>((n + 255) / 256, 2048);
+  if (ndigits <= 2) ELP_LAUNCH(c, "radix_hist_all", k_radix_hist_all<2>, dim3(hb), dim3(256), 0, keycol, n, ghist, (const uint32_t *)nullptr);
+  else if (ndigits <= 4) ELP_LAUNCH(c, "radix_hist_all", k_radix_hist_all<4>, dim3(hb), dim3(256), 0, keycol, n, ghist, (const uint32_t *)nullptr);
+  else ELP_LAUNCH(c, "radix_hist_all", k_radix_hist_all<8>, dim3(hb), dim3(256), 0, keycol, n, ghist, (const uint32_t *)nullptr);
+  ELP_TRY(radix_pass_setup(c, radix_tiles(c, n)));
+  uint64_t *src = buf1, *dst = buf0;  // (the first pass reads the key column)
+  for (int d = 0; d < ndigits; d++) {
+    ELP_TRY(radix_next_epoch(c));
+    ELP_TRY(radix_scatter_launch_t<false>(c, n, d == 0 ? keycol : src, nullptr, dst, nullptr, idx_bits + 8 * d, (const unsigned long long *)(ghist + d * 256),
+                                          ticket + d, nullptr, d == 0 ? idx_bits : 0));
+    std::swap(src, dst);
   }
+  *out = src;
   return 0;
 }
 

@@ -484,12 +484,20 @@ __global__ __launch_bounds__(256) void k_iota(uint32_t *v, uint64_t n) {
   if (i < n) v[i] = (uint32_t)i;
 }
 
+// the sorted array: (key, index) pairs in two arrays, or - idx_bits > 0 - words key << idx_bits | index (radix_sort_fused)
+struct SortedView {
+  const uint64_t *__restrict__ keys;
+  const uint32_t *__restrict__ vals;
+  uint32_t idx_bits;
+  __device__ __forceinline__ uint64_t key(uint64_t i) const { return idx_bits ? keys[i] >> idx_bits : keys[i]; }
+  __device__ __forceinline__ uint32_t val(uint64_t i) const { return idx_bits ? (uint32_t)(keys[i] & ((1ull << idx_bits) - 1ull)) : vals[i]; }
+};
+
 // Runs of equal primary key.  k_tie_scan (every record, three loads issued together): a record whose neighbours both differ is
 // final; members of runs go to a compact list.  k_tie_small (list members only, all lanes busy with the same kind of work): runs of
 // <= TIE_SMALL records are ranked by all-pairs comparison, members of longer runs are flagged for the radix tie-break.
 constexpr int TS_TILES = 16;
-__global__ __launch_bounds__(256) void k_tie_scan(uint64_t n, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ perm_in,
-                                                  uint32_t *__restrict__ perm_out, uint32_t *__restrict__ list, uint32_t *list_n,
+__global__ __launch_bounds__(256) void k_tie_scan(uint64_t n, SortedView sv, uint32_t *__restrict__ perm_out, uint32_t *__restrict__ list, uint32_t *list_n,
                                                   uint32_t *__restrict__ bounds) {
   if (blockIdx.x == 0 && threadIdx.x < 4) bounds[threadIdx.x] = 0;  // the counters of k_tie_small's lists (it runs behind this kernel)
   // a workgroup handles TS_TILES * 256 consecutive records and collects its run members in LDS: ONE global atomic per workgroup
@@ -503,8 +511,9 @@ __global__ __launch_bounds__(256) void k_tie_scan(uint64_t n, const uint64_t *__
     const uint64_t i = ((uint64_t)blockIdx.x * TS_TILES + (uint64_t)tile) * 256 + threadIdx.x;
     bool in_run = false;
     if (i < n) {
-      const uint64_t k = keys[i], kp = i > 0 ? keys[i - 1] : ~k, kn = i + 1 < n ? keys[i + 1] : ~k;
-      const uint32_t me = perm_in[i];
+      const uint64_t w = sv.keys[i], wp = i > 0 ? sv.keys[i - 1] : 0ull, wn = i + 1 < n ? sv.keys[i + 1] : 0ull;
+      const uint64_t k = w >> sv.idx_bits, kp = i > 0 ? wp >> sv.idx_bits : ~k, kn = i + 1 < n ? wn >> sv.idx_bits : ~k;
+      const uint32_t me = sv.idx_bits ? (uint32_t)(w & ((1ull << sv.idx_bits) - 1ull)) : sv.vals[i];
       in_run = kp == k || kn == k;
       if (!in_run) perm_out[i] = me;
     }
@@ -522,22 +531,21 @@ __global__ __launch_bounds__(256) void k_tie_scan(uint64_t n, const uint64_t *__
   __syncthreads();
   for (uint32_t k = threadIdx.x; k < lcount; k += 256) list[gbase + k] = lq[k];
 }
-__global__ __launch_bounds__(256) void k_tie_small(uint64_t n, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ perm_in,
-                                                   uint32_t *__restrict__ perm_out, uint32_t *__restrict__ bounds /* [0] starts, [1] ends counted; [4 + k] / [4 + cap + k] the positions */,
+__global__ __launch_bounds__(256) void k_tie_small(uint64_t n, SortedView sv, uint32_t *__restrict__ perm_out, uint32_t *__restrict__ bounds /* [0] starts, [1] ends counted; [4 + k] / [4 + cap + k] the positions */,
                                                    uint32_t bounds_cap, const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_n, TieCols t) {
   const uint64_t j0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j0 >= (uint64_t)*list_n) return;
   const uint64_t i = list[j0];
-  const uint64_t k = keys[i];
-  const uint32_t me = perm_in[i];
+  const uint64_t k = sv.key(i);
+  const uint32_t me = sv.val(i);
   uint64_t s = i, e = i + 1;  // run [s, e)
   bool large = false;
-  while (s > 0 && keys[s - 1] == k) {
+  while (s > 0 && sv.key(s - 1) == k) {
     s--;
     if (i - s >= (uint64_t)TIE_SMALL) { large = true; break; }
   }
   if (!large) {
-    while (e < n && keys[e] == k) {
+    while (e < n && sv.key(e) == k) {
       e++;
       if (e - s > (uint64_t)TIE_SMALL) { large = true; break; }
     }
@@ -546,14 +554,14 @@ __global__ __launch_bounds__(256) void k_tie_small(uint64_t n, const uint64_t *_
     // a run of more than TIE_SMALL records goes to the radix tie-break as a RANGE of the sorted array: its first member reports where
     // it starts, its last one where it ends (two short lists the host pairs up) - no flag per record, no scan over all records
     perm_out[i] = me;
-    if (i == 0 || keys[i - 1] != k) { const uint32_t at = atomicAdd(&bounds[0], 1u); if (at < bounds_cap) bounds[4 + at] = (uint32_t)i; }
-    if (i + 1 == n || keys[i + 1] != k) { const uint32_t at = atomicAdd(&bounds[1], 1u); if (at < bounds_cap) bounds[4 + bounds_cap + at] = (uint32_t)i; }
+    if (i == 0 || sv.key(i - 1) != k) { const uint32_t at = atomicAdd(&bounds[0], 1u); if (at < bounds_cap) bounds[4 + at] = (uint32_t)i; }
+    if (i + 1 == n || sv.key(i + 1) != k) { const uint32_t at = atomicAdd(&bounds[1], 1u); if (at < bounds_cap) bounds[4 + bounds_cap + at] = (uint32_t)i; }
     return;
   }
   if (e - s == 2) {
     // a run of two (nine runs in ten): its first member places both with ONE comparison, the second has nothing to do
     if (i != s) return;
-    const uint32_t other = perm_in[s + 1];
+    const uint32_t other = sv.val(s + 1);
     const bool swap = tie_less(t, other, me);  // `me` came first: it stays in front unless the other one is strictly less
     perm_out[s] = swap ? other : me;
     perm_out[s + 1] = swap ? me : other;
@@ -562,7 +570,7 @@ __global__ __launch_bounds__(256) void k_tie_small(uint64_t n, const uint64_t *_
   uint32_t rank = 0;
   for (uint64_t j = s; j < e; j++) {
     if (j == i) continue;
-    const uint32_t other = perm_in[j];
+    const uint32_t other = sv.val(j);
     // other precedes me iff other < me, or neither is less and other came first (radix sort is stable: j < i <=> earlier staging index)
     if (tie_less(t, other, me)) rank++;
     else if (j < i && !tie_less(t, me, other)) rank++;
@@ -573,7 +581,7 @@ __global__ __launch_bounds__(256) void k_tie_small(uint64_t n, const uint64_t *_
 // members of the large runs, compacted: run r = positions [start[r], start[r] + (first[r + 1] - first[r])) of the sorted array, its members are
 // numbers first[r] .. first[r + 1] - 1; u_seg = 1 + r (the key of the last, stable round: runs stay apart and in order)
 __global__ __launch_bounds__(256) void k_large_fill(uint32_t nu, uint32_t nr, const uint32_t *__restrict__ start, const uint32_t *__restrict__ first,
-                                                    const uint32_t *__restrict__ perm, uint32_t *__restrict__ u_pos, uint32_t *__restrict__ u_read,
+                                                    SortedView sv, uint32_t *__restrict__ u_pos, uint32_t *__restrict__ u_read,
                                                     uint32_t *__restrict__ u_seg) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nu) return;
@@ -584,7 +592,7 @@ __global__ __launch_bounds__(256) void k_large_fill(uint32_t nu, uint32_t nr, co
   }
   const uint32_t pos = start[lo] + (j - first[lo]);
   u_pos[j] = pos;
-  u_read[j] = perm[pos];
+  u_read[j] = sv.val(pos);
   u_seg[j] = lo + 1u;
 }
 
@@ -806,21 +814,25 @@ static int sort_impl(elp_ctx *c) {
   // the key column holds key_bits live bits (adapt packs it): that many digit passes, no histogram read-back; the first pass reads
   // the column itself and numbers the records as it goes (no copy, no index array)
   uint64_t *ks;
-  uint32_t *vs;
-  ELP_TRY(radix_sort_pairs_low(c, k0, v0, k1, v1, n, (c->key_bits + 7) / 8, &ks, &vs, c->key.p, true));
+  uint32_t *vs = nullptr;
+  // where key << b | index fits one word (a genome's coordinate key has ~31-34 live bits), the passes move words, not pairs
+  int idx_bits = 1;
+  while (idx_bits < 32 && (n >> idx_bits) != 0) idx_bits++;
+  const bool words = c->tune.sort_pairs != 1 && c->key_bits >= 1 && c->key_bits + idx_bits <= 64;
+  if (words) ELP_TRY(radix_sort_fused(c, c->key.p, n, c->key_bits, idx_bits, k0, k1, &ks));
+  else ELP_TRY(radix_sort_pairs_low(c, k0, v0, k1, v1, n, (c->key_bits + 7) / 8, &ks, &vs, c->key.p, true));
+  const SortedView sv{ks, vs, words ? (uint32_t)idx_bits : 0u};
   TieCols t{c->qname_off.p, c->qname.p, c->flag.p, c->mapq.p, c->next_refid.p, c->pnext.p, c->tlen.p};
   // run members -> compact list (the other half of `vbuf` is free: the radix sort left its result in one half); bounds of the runs
   // longer than TIE_SMALL -> two short lists in `flags` ([0], [1] their lengths)
   const uint32_t bounds_cap = (uint32_t)std::min<uint64_t>(n / TIE_SMALL + 16, (2 * n + 8 - 4) / 2);
   uint32_t *bounds = flags;
   {
-    uint32_t *list = (vs == v0) ? v1 : v0, *list_n = c->err_flag.p + 3;  // the scan-total mailbox
+    uint32_t *list = (vs == v0) ? v1 : v0, *list_n = c->err_flag.p + 3;  // the scan-total mailbox (sorted words: `vbuf` is free altogether)
     ELP_HIP(c, hipMemsetAsync(list_n, 0, 4, c->stream));
-    ELP_LAUNCH(c, "tie_scan", k_tie_scan, dim3(blocks_for(n, 256 * TS_TILES)), dim3(256), 0, n, (const uint64_t *)ks, (const uint32_t *)vs, c->perm.p, list, list_n,
-               bounds);
+    ELP_LAUNCH(c, "tie_scan", k_tie_scan, dim3(blocks_for(n, 256 * TS_TILES)), dim3(256), 0, n, sv, c->perm.p, list, list_n, bounds);
     // sized for the worst case; workgroups beyond the list's end leave at once
-    ELP_LAUNCH(c, "tie_small", k_tie_small, dim3(blocks_for(n, 256)), dim3(256), 0, n, (const uint64_t *)ks, (const uint32_t *)vs, c->perm.p, bounds, bounds_cap,
-               (const uint32_t *)list, (const uint32_t *)list_n, t);
+    ELP_LAUNCH(c, "tie_small", k_tie_small, dim3(blocks_for(n, 256)), dim3(256), 0, n, sv, c->perm.p, bounds, bounds_cap, (const uint32_t *)list, (const uint32_t *)list_n, t);
     ELP_HIP(c, hipMemsetAsync(list_n, 0, 4, c->stream));
   }
   // ONE read-back: the two counts and the first run bounds (all of them unless there are more than TIE_HEAD runs: then a second copy)
@@ -870,8 +882,7 @@ static int sort_impl(elp_ctx *c) {
     uint64_t *uk0 = uk, *uk1 = uk + nu;
     ELP_HIP(c, hipMemcpyAsync(d_start, starts.data(), (size_t)nr * 4, hipMemcpyHostToDevice, c->stream));
     ELP_HIP(c, hipMemcpyAsync(d_first, first.data(), ((size_t)nr + 1) * 4, hipMemcpyHostToDevice, c->stream));
-    ELP_LAUNCH(c, "large_fill", k_large_fill, dim3(blocks_for(nu, 256)), dim3(256), 0, nu, nr, (const uint32_t *)d_start, (const uint32_t *)d_first, (const uint32_t *)vs,
-               u_pos, u_read, u_seg);
+    ELP_LAUNCH(c, "large_fill", k_large_fill, dim3(blocks_for(nu, 256)), dim3(256), 0, nu, nr, (const uint32_t *)d_start, (const uint32_t *)d_first, sv, u_pos, u_read, u_seg);
     ELP_LAUNCH(c, "iota", k_iota, dim3(blocks_for(nu, 256)), dim3(256), 0, uv0, (uint64_t)nu);
     const uint32_t maxq = c->max_qname_len;
     const uint32_t m_bytes = maxq + 15;  // <= MAX_QNAME + 15 <= 32 * TIE_LIVE_WORDS positions (elp_stage enforces the QNAME limit)

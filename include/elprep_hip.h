@@ -344,7 +344,8 @@ int elp_clean_sam(elp_ctx *ctx, uint64_t *n_clipped_out);
  *                      small value sends every bucket through the overflow path
  *   "mate_path"        1: every mate candidate is matched by the partitioned pass (hash partition + LDS tables), no neighbour
  *                      shortcut - what coordinate-ordered or shuffled input takes by itself; 2: ... by the table in HBM
- *   "radix_tile"       1: every radix pass in tiles of 4096 keys; 2: of 8192 keys; 3: of 16384 (default: 8192 for arrays of 8 M keys and more)
+ *   "radix_tile"       1: every radix pass in tiles of 4096 keys; 2: of 8192 keys; 3: of 16384 (default: by the array's length)
+ *   "sort_pairs"       1: the coordinate sort moves (key, index) pairs through its passes even where key << b | index fits one word
  *   "tie_rounds"       1: the coordinate sort orders its long runs of equal coordinates (the unmapped block, pile-ups) by radix rounds
  *                      over every live name position - the path a group of > 1024 names that agree in their leading positions takes
  *                      by itself - instead of one round on the leading positions + comparison of what it leaves equal

@@ -437,20 +437,21 @@ def test_sort_long_runs_one_key_then_compare(big_group, tie_rounds):
     order = rng.permutation(len(recs))
     b = batch_from_records([recs[i] for i in order])
     h = Header(ref_len=np.array([1000, 1000], np.int32), rg_lib=np.array([0], np.uint16), rg_cov=np.array([0], np.uint16))
-    e = Engine(h, tuning={"tie_rounds": tie_rounds})
+    e = Engine(h, tuning={"tie_rounds": tie_rounds, "sort_pairs": tie_rounds})
     e.stage(b)
     assert np.array_equal(e.sort_coordinate(), orc.sort_coordinate(b))
     e.close()
 
 
-@pytest.mark.parametrize("radix_tile", [1, 2, 3])
-def test_radix_passes_in_tiles_of_4096_and_8192_keys(radix_tile):
+@pytest.mark.parametrize("radix_tile,sort_pairs", [(1, 0), (2, 0), (3, 0), (1, 1), (3, 1)])
+def test_radix_passes_in_tiles_of_4096_and_8192_keys(radix_tile, sort_pairs):
     """every radix pass of the path (coordinate sort, tie-break rounds, the pair list's partition with its device-side length, the
     metrics' group sort) in tiles of 4096 keys (256 threads) and of 8192 (512 threads, what arrays of 8 M keys and more take by
-    themselves): permutation, flags and counters are the oracle's"""
+    themselves; 16384: 1024 threads), the coordinate sort on words key << b | index and on (key, index) pairs: permutation, flags and
+    counters are the oracle's"""
     cfg, b, h, refs, sites = dataset("tiny", 40000, 9, 0.03)
     oflags, octr, ohist = orc.dup_metrics(b, h, None, 100, hist_len=16)
-    e = Engine(h, tuning={"radix_tile": radix_tile})
+    e = Engine(h, tuning={"radix_tile": radix_tile, "sort_pairs": sort_pairs})
     e.stage(b)
     flags = e.mark_duplicates(True)
     perm = e.sort_coordinate()
