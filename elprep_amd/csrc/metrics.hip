@@ -312,8 +312,10 @@ __global__ __launch_bounds__(128) void k_opt_eval(MxCols m, uint32_t total, cons
   const int n_h = hist ? (m.n_lib + 1) * 3 * lds_bins : 0;
   for (int k = threadIdx.x; k <= m.n_lib + n_h; k += blockDim.x) lds_opt[k] = 0;
   __syncthreads();
-  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint2 gi = b < total ? ginfo[b] : make_uint2(0u, 0u);
+  // (a few thousand workgroups stride over the slots: every workgroup ends with atomics on the same few global counters, and 31 K of
+  // them - one per 128 slots - queued up there for 0.37 ms: 12 ns each)
+  for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < total; b += gridDim.x * blockDim.x) {
+  const uint2 gi = ginfo[b];
   const uint32_t cnt = gi.x;
   uint32_t optical = 0;
   bool large = false;
@@ -370,6 +372,7 @@ __global__ __launch_bounds__(128) void k_opt_eval(MxCols m, uint32_t total, cons
         else atomicAdd(&hist[((size_t)lib * 3 + k) * hist_len + bin], 1ull);
       }
     }
+  }
   }
   __syncthreads();
   for (int k = threadIdx.x; k <= m.n_lib; k += blockDim.x)
@@ -554,7 +557,7 @@ static int metrics_impl(elp_ctx *c, int dist, int64_t *counters_host, int64_t *h
       ELP_LAUNCH(c, "mx_opt_slots", k_opt_slots, dim3(blocks_for(L, 256)), dim3(256), 0, m, L, (const uint64_t *)ks, (const uint32_t *)vs,
                  (const uint32_t *)head, (const uint32_t *)gidx, (const uint32_t *)gstart, mread, ginfo, mset);
       ELP_LAUNCH(c, "mx_opt_fill", k_opt_fill, dim3(blocks_for(total, 256)), dim3(256), 0, m, total, (const uint32_t *)mread, members, c->err_flag.p);
-      ELP_LAUNCH(c, "mx_opt_eval", k_opt_eval, dim3(blocks_for(total, 128)), dim3(128),
+      ELP_LAUNCH(c, "mx_opt_eval", k_opt_eval, dim3(std::min(blocks_for(total, 128), 2048u)), dim3(128),
                  (size_t)(c->n_lib + 1) * (1 + (hist ? 3 * (size_t)lds_bins : 0)) * sizeof(unsigned int), m, total, (const uint2 *)ginfo,
                  (const Member *)members, parent, (long long)dist, ctr, c->err_flag.p, hist, hist_len, lds_bins, linfo, lcount, mailbox);
       uint32_t n_large = 0;

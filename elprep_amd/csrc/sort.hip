@@ -496,7 +496,7 @@ struct SortedView {
 // Runs of equal primary key.  k_tie_scan (every record, three loads issued together): a record whose neighbours both differ is
 // final; members of runs go to a compact list.  k_tie_small (list members only, all lanes busy with the same kind of work): runs of
 // <= TIE_SMALL records are ranked by all-pairs comparison, members of longer runs are flagged for the radix tie-break.
-constexpr int TS_TILES = 16;
+constexpr int TS_TILES = 32;  // (16: 12 K workgroups queue at the one list counter for 0.15 ms of the kernel's 0.30)
 __global__ __launch_bounds__(256) void k_tie_scan(uint64_t n, SortedView sv, uint32_t *__restrict__ perm_out, uint32_t *__restrict__ list, uint32_t *list_n,
                                                   uint32_t *__restrict__ bounds) {
   if (blockIdx.x == 0 && threadIdx.x < 4) bounds[threadIdx.x] = 0;  // the counters of k_tie_small's lists (it runs behind this kernel)
