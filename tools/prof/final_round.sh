@@ -11,6 +11,7 @@ python tools/prof/db_to_csv.py $DB $OUT/kernel_stats.csv "rocprofv3 --kernel-tra
 python tools/prof/db_to_csv.py $DB $OUT/kernel_stats_all_steps.csv "rocprofv3 top_kernels summary of the same trace: all 10 steps incl. warm-up"
 python tools/prof/timeline.py $DB $OUT/timeline.csv; head -2 $OUT/timeline.csv
 find $OUT/prof -size +20M -delete
+timeout 400 python bench.py --mode sfm --no-cpu-baseline --no-extra > $OUT/bench_sfm1.json 2> $OUT/sfm1.err; echo "sfm1 rc=$?"; cat $OUT/bench_sfm1.json | cut -c1-400
 ELP_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 2 --reads 8000000 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_sfm_gloo2.json 2> $OUT/sfm.err; echo "sfm rc=$?"; cat $OUT/bench_sfm_gloo2.json; tail -2 $OUT/sfm.err
 ELP_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29514 bench.py --gpus 2 --scaling strong --total-reads 12000000 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_sfm_strong2.json 2> $OUT/sfm2.err; echo "strong rc=$?"; cat $OUT/bench_sfm_strong2.json; tail -2 $OUT/sfm2.err
 bash tools/prof/pmc_round.sh $TAG/pmc 8000000 > $OUT/pmc.log 2>&1; tail -3 $OUT/pmc.log
