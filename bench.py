@@ -132,6 +132,11 @@ def summarize(prof, steps, n_reads, full_bytes):
 
 
 def main():
+    # the ONE line on stdout is the result: whatever libraries print there (RCCL greets with five lines of versions when its first
+    # communicator comes up) goes to stderr - file descriptor 1 points at stderr until the line is written to the saved descriptor
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
@@ -499,8 +504,8 @@ def main():
                 out["verify"] = verify_against_oracle(hdr, refs_sites, ref_out, dev_id)
                 verify_failed = not out["verify"]["ok"]
             del ref_out
-        print(json.dumps(out))
         sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if sfm_mode:
         dist.barrier()
         dist.destroy_process_group()
