@@ -956,9 +956,14 @@ static int markdup_impl(elp_ctx *c) {
     uint32_t *bounds;
     ELP_TRY(scratch(c, 1, 2 * nb + 8, &bounds));  // `frep` and the fragment list are free again
     ELP_HIP(c, hipMemsetAsync(bounds, 0, 2 * nb * sizeof(uint32_t), st));
-    ELP_HIP(c, hipMemsetAsync(c->pair_win.p, 0xFF, n * sizeof(uint32_t), st));
-    ELP_LAUNCH(c, "md_pair_list", k_pair_list_table, dim3(blocks_for(n, 256 * PL_TILES)), dim3(256), 0, m, (const uint4 *)fkey, (const uint32_t *)c->mate.p,
-               (const uint8_t *)code, pk, pv, np_dev);
+    // aligner order without stragglers: no record announced its key, so nothing went through the mate table - `rep_of` (pair_win's
+    // buffer) is still all EMPTY from its fill in front of the scan and no owner carries MC_TABBED: no second fill, no scan of the codes
+    const bool no_table = fixed && n_tab == 0 && !e[1];
+    if (!no_table) {
+      ELP_HIP(c, hipMemsetAsync(c->pair_win.p, 0xFF, n * sizeof(uint32_t), st));
+      ELP_LAUNCH(c, "md_pair_list", k_pair_list_table, dim3(blocks_for(n, 256 * PL_TILES)), dim3(256), 0, m, (const uint4 *)fkey, (const uint32_t *)c->mate.p,
+                 (const uint8_t *)code, pk, pv, np_dev);
+    }
     uint64_t *ks = pk;
     uint32_t *vs = pv;
     if (ndig) {
