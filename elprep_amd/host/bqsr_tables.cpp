@@ -287,8 +287,19 @@ class RowPool {
   uint64_t gen_ = 0;
   bool stop_ = false;
 };
+// `small`: the whole job is well under a millisecond on one core (one or two read groups with a handful of qualities: what a binned
+// sequencer run gives) - run it on the caller's thread: no wake-ups, and no waiting for a worker the scheduler took off its core (on a
+// box with busy neighbours a 0.5 ms job spread over 16 threads was seen to take 6 ms)
 template <class F>
-void parallel_rows(size_t n, F f) { RowPool::get().run(n, std::function<void(size_t)>(f)); }
+void parallel_rows(size_t n, F f, bool small = false) {
+  if (small) { for (size_t i = 0; i < n; i++) f(i); return; }
+  RowPool::get().run(n, std::function<void(size_t)>(f));
+}
+inline bool small_job(const std::vector<uint8_t> &live, int n_cov) {
+  size_t rows = 0;
+  for (uint8_t l : live) rows += l;
+  return n_cov <= 2 && rows <= 12;
+}
 
 struct Interval { int next; double rate; long long nobs, leaf, nerr; };
 inline double err_rate(long long nobs, long long nerr) { return nobs == 0 ? 0.0 : double(nerr + 1) / double(nobs + 1); }
@@ -342,7 +353,7 @@ static void add_rows(elp_bqsr_tables *t, const int64_t *ct, const int64_t *xt) {
     if (cs) { long long *d = &t->c[row * cw]; for (size_t k = 0; k < cw; k++) d[k] += cs[k]; }
     if (xs) { long long *d = &t->x[row * xw]; for (size_t k = 0; k < xw; k++) d[k] += xs[k]; }
     t->live[row] = 1;
-  });
+  }, t->n_cov <= 2);
 }
 
 elp_bqsr_tables *elp_bqsr_tables_new(int n_cov, int max_cycle, const int64_t *qt, const int64_t *ct, const int64_t *xt) {
@@ -425,7 +436,7 @@ int elp_bqsr_tables_finalize(elp_bqsr_tables *t) {
         const size_t i = row * NX + cx;
         if (t->x[2 * i] > 0) empirical2(t->x[2 * i], t->x[2 * i + 1], pr_fin, pr_cond, t->xe[i], t->xe_cond[i]);
       }
-  });
+  }, small_job(t->live, t->n_cov));
   t->finalized = true;
   return 0;
 }
@@ -577,7 +588,7 @@ int elp_bqsr_tables_build_lut(const elp_bqsr_tables *t, int quantize_levels, con
           for (int cx = 0; cx < 17; cx++) le[cx] = entry(true, cy, cx);
         }
       }
-    });
+    }, small_job(t->live, t->n_cov));
   }
   return 0;
 }
