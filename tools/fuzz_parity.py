@@ -26,7 +26,11 @@ for seed in range(first, first + count):
     h = cfg.header()
     refs = [synth.reference(cfg, r) for r in range(h.n_ref)]
     sites = [orc.flatten(orc.sort_by_start(synth.known_sites_raw(cfg, r))) for r in range(h.n_ref)]
-    e = Engine(h, 0)
+    # kernel choices at random too (elp_set_tuning): every choice must give the oracle's bytes
+    tuning = {"radix_tile": int(rng.integers(0, 4)), "sort_pairs": int(rng.integers(0, 2)), "tie_rounds": int(rng.integers(0, 2)),
+              "mate_path": int(rng.choice([0, 0, 1, 2])), "pair_table_slots": int(rng.choice([0, 0, 16, 1024])),
+              "count_kernel": int(rng.choice([0, 0, 1, 2, 3])), "apply_kernel": int(rng.choice([0, 0, 1])), "score_kernel": int(rng.choice([0, 0, 1]))}
+    e = Engine(h, 0, tuning=tuning)
     cuts = np.linspace(0, b.n, int(rng.integers(1, 5)) + 1).astype(int)
     for lo, hi in zip(cuts[:-1], cuts[1:]):
         e.stage(b.take(np.arange(lo, hi)))
@@ -47,7 +51,7 @@ for seed in range(first, first + count):
     ok = (np.array_equal(flags, oflags), np.array_equal(perm, operm), np.array_equal(ctr, octr),
           np.array_equal(qt, oq) and np.array_equal(ct, oc) and np.array_equal(xt, ox), np.array_equal(qual, oqual))
     e.close()
-    print(f"seed {seed}: {b.n} records, p_frag {cfg.p_frag}, p_dup {cfg.p_dup}, quals {cfg.qual_mode}: "
+    print(f"seed {seed}: {b.n} records, p_frag {cfg.p_frag}, p_dup {cfg.p_dup}, quals {cfg.qual_mode}, {tuning}: "
           f"flags {ok[0]} perm {ok[1]} metrics {ok[2]} tables {ok[3]} qual {ok[4]}", flush=True)
     if not all(ok):
         bad += 1
