@@ -880,6 +880,7 @@ static int markdup_impl(elp_ctx *c) {
 
   uint64_t Tm = mate_mode == 0 ? T : std::min<uint64_t>(T, table_size_for(std::min<uint64_t>(n, 4ull * n_tab + 1024)));
   uint32_t e[4];
+  bool frag_done = false;
   for (;;) {
     if (mate_mode != 2) ELP_HIP(c, hipMemsetAsync(table, 0xFF, Tm * sizeof(uint32_t), st));
     ELP_HIP(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(np_dev), (int)(uint32_t)nfixed, 1, st));
@@ -909,6 +910,15 @@ static int markdup_impl(elp_ctx *c) {
       // (`table` may have been re-pointed by the scratch call above: take it again for a fall-back pass)
       ELP_TRY(scratch(c, 0, T, &table));
     }
+    // tournament among the fragments of pair-free groups (the marks k_mate_pairs left in `best` are complete whatever the error words
+    // will say): queued in front of the read-back, so that the device works on it while the host waits
+    if (nf && !frag_done) {
+      ELP_LAUNCH(c, "md_frag_tie", k_frag_tie, dim3(fgrid), dim3(256), 0, m, (const uint32_t *)flist, nf, (const uint32_t *)rep,
+                 (const unsigned long long *)best, winner);
+      ELP_LAUNCH(c, "md_frag_flag", k_frag_flag, dim3(fgrid), dim3(256), 0, m, (const uint32_t *)flist, nf, (const uint32_t *)rep,
+                 (const unsigned long long *)best, (const uint32_t *)winner, c->flag.p);
+      frag_done = true;
+    }
     ELP_TRY(fetch_err(c, e));
     if (mate_mode == 2 && (e[1] & 4u)) {
       // a bucket's keys did not fit its LDS table (keys crafted to share hash bits): the table in HBM takes all candidates
@@ -923,13 +933,6 @@ static int markdup_impl(elp_ctx *c) {
     ELP_HIP(c, hipMemsetAsync(c->err_flag.p + 1, 0, 4, st));
     ELP_HIP(c, hipMemsetAsync(c->mate.p, 0xFF, n * sizeof(uint32_t), st));
     ELP_HIP(c, hipMemsetAsync(rep_of, 0xFF, n * sizeof(uint32_t), st));
-  }
-  // tournament among the fragments of pair-free groups
-  if (nf) {
-    ELP_LAUNCH(c, "md_frag_tie", k_frag_tie, dim3(fgrid), dim3(256), 0, m, (const uint32_t *)flist, nf, (const uint32_t *)rep,
-               (const unsigned long long *)best, winner);
-    ELP_LAUNCH(c, "md_frag_flag", k_frag_flag, dim3(fgrid), dim3(256), 0, m, (const uint32_t *)flist, nf, (const uint32_t *)rep,
-               (const unsigned long long *)best, (const uint32_t *)winner, c->flag.p);
   }
   if (e[1]) {
     // keys with more than two records: pair their members up in arrival order
