@@ -76,3 +76,40 @@ def test_host_finalize_agrees_with_the_oracle_on_a_million_entries():
     for a, b in zip(fo.empirical(), ft.empirical()):
         assert np.array_equal(a, b)
     assert int((ct[..., 0] > 0).sum()) > 1_000_000
+
+
+def test_host_lut_agrees_with_the_oracle_on_random_tables():
+    """The host evaluates every table entry under two priors in one pass (its reported quality for FinalizeBQSRTables, the row's
+    conditional estimate for the LUT) and keeps the cycle / context tables as lazily zeroed arrays with an index of the rows that hold
+    anything.  Random tables - dense rows, rows that hold a single entry, rows whose quality entry is empty although cycle entries are
+    not (no gather produces those; the index must come from the rows themselves) - and 30 000 random LUT keys against the oracle's
+    direct estimateHierarchicalBayesianQuality (bqsr.go:901-919)."""
+    rng = np.random.default_rng(17)
+    n_cov, mc = 3, 300
+    ncyc = 2 * mc + 1
+    obs = np.floor(np.exp(rng.uniform(0, 21, (n_cov, 94, ncyc)))).astype(np.int64)
+    obs[:, rng.random(94) < 0.5] = 0                       # half of the qualities do not occur at all
+    obs[rng.random(obs.shape) < 0.3] = 0
+    lonely = rng.integers(0, 94, 6)
+    obs[:, lonely] = 0
+    obs[:, lonely, rng.integers(0, ncyc, 6)] = 12345       # rows with one entry
+    mism = rng.binomial(np.minimum(obs, 2**31 - 1), np.exp(rng.uniform(-9, -0.5, obs.shape))).astype(np.int64)
+    ct = np.stack([obs, mism], axis=-1)
+    qt = ct.sum(axis=2)
+    xobs = np.floor(np.exp(rng.uniform(0, 21, (n_cov, 94, 16)))).astype(np.int64) * (qt[..., 0:1] > 0)
+    xt = np.stack([xobs, rng.binomial(np.minimum(xobs, 2**31 - 1), 0.01).astype(np.int64)], axis=-1)
+    orphan = int(lonely[0])
+    qt[:, orphan] = 0                                       # quality entry empty, cycle entry not
+    fo = orc.BqsrFinal(qt, ct, xt, mc)
+    ft = BqsrTables(qt, ct, xt, mc).finalize()
+    for a, b in zip(fo.empirical(), ft.empirical()):
+        assert np.array_equal(a, b)
+    lut, present = ft.build_lut(0)
+    _, quantized = fo.quantize(0)
+    assert present.tolist() == [1] * n_cov
+    for _ in range(30000):
+        cov, q, cyc, cx = int(rng.integers(0, n_cov)), int(rng.integers(0, 94)), int(rng.integers(-mc, mc + 1)), int(rng.integers(-1, 16))
+        if cyc == 0:
+            continue
+        key = -1 if cx < 0 else (2 | ((cx & 3) << 4) | ((cx >> 2) << 6))
+        assert lut[cov, q, cyc + mc, 16 if cx < 0 else cx] == fo.recal_qual(cov, q, cyc, key, quantized, None), (cov, q, cyc, cx)
