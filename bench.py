@@ -152,6 +152,8 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="skip the comparison of the device path with the CPU leg's outputs (it needs the CPU leg)")
     ap.add_argument("--no-extra", action="store_true", help="N = 1: skip the C2 / full-quality / PCIe-inclusive side measurements")
     ap.add_argument("--extra-reads", type=int, default=16_000_000, help="reads of the full-quality side measurement")
+    ap.add_argument("--c4-reads", type=int, default=int(os.environ.get("ELP_BENCH_C4_READS", 75_000_000)),
+                    help="N = 1 side measurement `c4_share`: reads on the hg38-sized genome (0 = skip)")
     ap.add_argument("--mode", choices=["auto", "filter", "sfm"], default="auto",
                     help="auto: `elprep filter` (one context) when started as a plain process, the `elprep sfm` step (contig-group splits + spread split, "
                          "all-reduce) whenever started under torch.distributed.run - also with ONE rank, so that a scaling curve's N = 1 point runs the "
@@ -451,25 +453,31 @@ def main():
             extra["pcie_inclusive"] = pcie_inclusive(cfg, hdr, min(args.extra_reads, 8_000_000), out["ms_per_step"], n_total)
         except Exception as e:
             extra["pcie_inclusive"] = {"error": repr(e)}
-        def side_run(key, workload, mutate, shuffle=False):
+        def side_run(key, workload, mutate, shuffle=False, genome=None, reads=None):
             """the full path on `--extra-reads` reads of a variant of the main workload (data shapes the main line is not tuned on)"""
             try:
-                cq = synth.config(args.genome)
+                cq = synth.config(genome or args.genome)
                 cq.qual_mode = cfg.qual_mode
                 mutate(cq)
                 hq = cq.header()
+                n_want = reads or args.extra_reads
+                rs = refs_sites
+                if genome and genome != args.genome:  # another genome: its own reference and known sites (made on the generator's thread pool)
+                    with ThreadPoolExecutor(workers) as pool:
+                        rs = list(pool.map(lambda r: (r, synth.reference(cq, r), flatten_sites(synth.known_sites_raw(cq, r))), range(hq.n_ref)))
                 e2 = Engine(hq, dev_id)
                 n2 = 0
                 rng = np.random.default_rng(7)
-                for b in generated([(cq, lo, min(lo + chunk, args.extra_reads // 2)) for lo in range(0, args.extra_reads // 2, chunk)]):
+                for b in generated([(cq, lo, min(lo + chunk, n_want // 2)) for lo in range(0, n_want // 2, chunk)]):
                     if shuffle:
                         b = b.take(rng.permutation(b.n))
                     e2.stage(b)
                     n2 += b.n
                     del b
-                for r, ref, sites in refs_sites:
+                for r, ref, sites in rs:
                     e2.set_reference(r, ref)
                     e2.set_known_sites(r, sites)
+                del rs
                 e2.sync()
                 e2.snapshot()
                 sf2, _, rs2 = make_filter_steps(e2, [None])
@@ -489,6 +497,12 @@ def main():
             side_run("shuffled_input", "the main workload's reads staged in random order within every 2 M-record batch (mates are not neighbours: "
                      "the mate table path of mark duplicates)", lambda c: None, shuffle=True)
             side_run("rg16", "the main workload with 16 read groups (16 BQSR covariates instead of 4)", lambda c: setattr(c, "n_lanes", 16))
+            side_run("rg32", "the main workload with 32 read groups (32 BQSR covariates)", lambda c: setattr(c, "n_lanes", 32))
+        if args.c4_reads > 0:
+            # one GPU's share of BASELINE config C4 (30x WGS over 8 GPUs) on the REAL genome shape: hg38's contig lengths (POS needs 28 bits: the
+            # coordinate sort runs five radix passes instead of four), 3.1 Gbp of packed reference and known-site flags in HBM
+            side_run("c4_share", "genome c4 = hg38 contig lengths (3.1 Gbp; 248 Mbp contigs: 34 live key bits = five radix passes), one GPU's share of a 600 M-read "
+                     "30x WGS run over 8 GPUs", lambda c: None, genome="c4", reads=args.c4_reads)
         out["extra"] = extra
 
     verify_failed = False

@@ -31,6 +31,18 @@ constexpr int A3_NT = 512;  // three workgroups per CU around three copies of th
 enum : uint32_t { AR_ON = 1u << 8, AR_REV = 1u << 9, AR_NEG = 1u << 10 };
 
 // per read: x = context window lo | hi << 16 (bases whose context covariate is valid), y = covariate | AR_* | (cf + lmax) << 16
+__device__ __forceinline__ uint2 apply_record(uint32_t len, int lmax, uint16_t f, uint64_t qb, uint32_t cov) {
+  const bool rev = f & F_REVERSED;
+  const uint32_t hi1 = (uint32_t)qb;
+  const int left = hi1 ? (int)(qb >> 32) : (int)len, right = hi1 ? (int)hi1 - 1 : (int)len - 1;
+  int cl = left + (rev ? 0 : 1), cr1 = right - (rev ? 1 : 0) + 1;
+  cl = cl < 0 ? 0 : cl;
+  cr1 = cr1 > (int)len ? (int)len : cr1;
+  cr1 = cr1 < cl ? cl : cr1;
+  const int rof = (f & F_LAST) ? -1 : 1;
+  const int cf = rof + (rev ? ((int)len - 1) * rof : 0), ci = rev ? -rof : rof;
+  return make_uint2((uint32_t)cl | ((uint32_t)cr1 << 16), (cov & 0xFFu) | AR_ON | (rev ? AR_REV : 0u) | (ci < 0 ? AR_NEG : 0u) | ((uint32_t)(cf + lmax) << 16));
+}
 __global__ __launch_bounds__(256) void k_apply_records(uint64_t n, uint32_t len, int lmax, const uint16_t *__restrict__ flag, const uint16_t *__restrict__ rgid,
                                                        const uint16_t *__restrict__ rg_cov, const uint64_t *__restrict__ qbounds,
                                                        const uint8_t *__restrict__ cov_present, uint2 *__restrict__ recs, uint32_t *err) {
@@ -43,21 +55,68 @@ __global__ __launch_bounds__(256) void k_apply_records(uint64_t n, uint32_t len,
     atomicOr(&err[0], 32u);  // readGroupCovariate panics, bqsr.go:38
   } else {
     const uint32_t cov = rg_cov[rg];
-    if (cov_present[cov]) {  // else: read group absent from the tables, read untouched (:953-955)
-      const bool rev = f & F_REVERSED;
-      const uint32_t hi1 = (uint32_t)qb;
-      const int left = hi1 ? (int)(qb >> 32) : (int)len, right = hi1 ? (int)hi1 - 1 : (int)len - 1;
-      int cl = left + (rev ? 0 : 1), cr1 = right - (rev ? 1 : 0) + 1;
-      cl = cl < 0 ? 0 : cl;
-      cr1 = cr1 > (int)len ? (int)len : cr1;
-      cr1 = cr1 < cl ? cl : cr1;
-      const int rof = (f & F_LAST) ? -1 : 1;
-      const int cf = rof + (rev ? ((int)len - 1) * rof : 0), ci = rev ? -rof : rof;
-      r.x = (uint32_t)cl | ((uint32_t)cr1 << 16);
-      r.y = (cov & 0xFFu) | AR_ON | (rev ? AR_REV : 0u) | (ci < 0 ? AR_NEG : 0u) | ((uint32_t)(cf + lmax) << 16);
-    }
+    if (cov_present[cov]) r = apply_record(len, lmax, f, qb, cov);  // else: read group absent from the tables, read untouched (:953-955)
   }
   recs[i] = r;
+}
+
+// Round 5 - the records SPLIT BY COVARIATE (many read groups: the level-1 tables of all covariates do not fit one workgroup's LDS, or the
+// LUT has more distinct rows than one-byte ids hold): only the reads ApplyBQSR touches get a record, the records of one covariate lie
+// together (counts per covariate, offsets, a scatter: the shape of k_c3_other_* in bqsr.hip), the read's staging index next to the
+// record; a workgroup of k_bqsr_apply3<true> then holds ONE covariate's level 1 and that covariate's own row dictionary at a time.
+constexpr int A3_MAXCOV = 256, A3_RTILE = 1024;
+__device__ __forceinline__ int apply_read_cov(uint16_t rg, const uint16_t *__restrict__ rg_cov, const uint8_t *__restrict__ cov_present, uint32_t *err) {
+  if (rg == ELP_NIL16) { atomicOr(&err[0], 32u); return -1; }
+  const uint32_t cov = rg_cov[rg] & 0xFFu;
+  return cov_present[cov] ? (int)cov : -1;
+}
+__global__ __launch_bounds__(256) void k_apply_cov_hist(uint64_t n, const uint16_t *__restrict__ rgid, const uint16_t *__restrict__ rg_cov,
+                                                        const uint8_t *__restrict__ cov_present, uint32_t *__restrict__ cnt /* [A3_MAXCOV] */, uint32_t *err) {
+  __shared__ uint32_t h[A3_MAXCOV];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  for (int j = 0; j < A3_RTILE / 256; j++) {
+    const uint64_t i = (uint64_t)blockIdx.x * A3_RTILE + j * 256 + threadIdx.x;
+    if (i < n) {
+      const int cov = apply_read_cov(rgid[i], rg_cov, cov_present, err);
+      if (cov >= 0) atomicAdd(&h[cov], 1u);
+    }
+  }
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], h[threadIdx.x]);
+}
+__global__ void k_apply_cov_offsets(const uint32_t *__restrict__ cnt, uint32_t *__restrict__ off /* [A3_MAXCOV + 1] */, uint32_t *__restrict__ cursor) {
+  uint32_t at = 0;
+  for (int c = 0; c < A3_MAXCOV; c++) { off[c] = at; cursor[c] = at; at += cnt[c]; }
+  off[A3_MAXCOV] = at;
+}
+__global__ __launch_bounds__(256) void k_apply_records_split(uint64_t n, uint32_t len, int lmax, const uint16_t *__restrict__ flag, const uint16_t *__restrict__ rgid,
+                                                             const uint16_t *__restrict__ rg_cov, const uint64_t *__restrict__ qbounds,
+                                                             const uint8_t *__restrict__ cov_present, uint32_t *cursor, uint2 *__restrict__ recs,
+                                                             uint32_t *__restrict__ ridx, uint32_t *err) {
+  __shared__ uint32_t h[A3_MAXCOV], base[A3_MAXCOV];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  int cv[A3_RTILE / 256];
+  uint32_t my[A3_RTILE / 256];
+#pragma unroll
+  for (int j = 0; j < A3_RTILE / 256; j++) {
+    const uint64_t i = (uint64_t)blockIdx.x * A3_RTILE + j * 256 + threadIdx.x;
+    cv[j] = i < n ? apply_read_cov(rgid[i], rg_cov, cov_present, err) : -1;
+    my[j] = cv[j] >= 0 ? atomicAdd(&h[cv[j]], 1u) : 0u;
+  }
+  __syncthreads();
+  base[threadIdx.x] = h[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], h[threadIdx.x]) : 0u;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < A3_RTILE / 256; j++) {
+    const uint64_t i = (uint64_t)blockIdx.x * A3_RTILE + j * 256 + threadIdx.x;
+    if (cv[j] >= 0) {
+      const size_t to = (size_t)base[cv[j]] + my[j];
+      recs[to] = apply_record(len, lmax, flag[i], qbounds[i], (uint32_t)cv[j]);
+      ridx[to] = (uint32_t)i;
+    }
+  }
 }
 
 struct Apply3Args {
@@ -74,6 +133,11 @@ struct Apply3Args {
   uint32_t *err;
   uint8_t *dump;   // 16 bytes per lane of the launch: where lanes without a block store
   uint32_t group;  // lanes that share reads: A3_NT (reads packed over the whole workgroup) or 64 (whole reads per wave)
+  // SPLIT (k_bqsr_apply3<true>): recs / ridx hold the records sorted by covariate; t1's ids and t2 [n_cov][256][17] / n_dict [n_cov] are
+  // per covariate
+  const uint32_t *ridx;     // staging index of record k
+  const uint32_t *cov_cnt;  // [A3_MAXCOV] records per covariate
+  const uint32_t *cov_off;  // [A3_MAXCOV + 1] first record of a covariate
 };
 
 struct A3Data { u32x4 q, s; };  // QUAL bytes; SEQ window (three words used): the asm loads of gload.hpp write these registers
@@ -105,6 +169,7 @@ __device__ __forceinline__ uint32_t nib4_to_bytes(uint32_t x) {
   return (x | (x << 4)) & 0x0F0F0F0Fu;
 }
 
+template <bool SPLIT>
 struct Apply3 {
   uint32_t k0, qoff, soff, ssh;  // first base of the lane's block; byte offsets into the trip's QUAL / SEQ span; SEQ shift
   uint32_t t1_at, t2_at;  // LDS byte addresses of the two levels
@@ -170,7 +235,7 @@ struct Apply3 {
     const uint32_t c2 = nib4_to_bytes(X_hi & 0xFFFFu) | (nib4_to_bytes(nv_hi & 0xFFFFu) << 4), c3 = nib4_to_bytes(X_hi >> 16) | (nib4_to_bytes(nv_hi >> 16) << 4);
     const int ci = (fl & AR_NEG) ? -1 : 1;
     const int cyc0l = (int)(fl >> 16) + ci * (int)k0;  // cycle of the block's first base + lmax
-    const uint32_t l1 = t1_at + __umul24(cov, rows_w) + (uint32_t)cyc0l;
+    const uint32_t l1 = t1_at + (SPLIT ? 0u : __umul24(cov, rows_w)) + (uint32_t)cyc0l;  // (SPLIT: the one covariate's level 1 is resident)
     const uint32_t uci = (uint32_t)ci;
     const uint32_t t2r = t2_at;
 #define ELP_A3(I, QW, CW) base<I>(QW, CW, l1 + (uint32_t)(I) * uci, t2r)
@@ -186,31 +251,45 @@ struct Apply3 {
   }
 };
 
-__global__ __launch_bounds__(A3_NT) void k_bqsr_apply3(Apply3Args A) {
+template <bool SPLIT>
+__global__ __launch_bounds__(A3_NT, 6) void k_bqsr_apply3(Apply3Args A) {  // six waves per SIMD = three workgroups per CU: <= 80 vector registers
   extern __shared__ __attribute__((aligned(16))) uint8_t llut[];
-  // level 1 in LDS: [n_cov][qhi1 + 1][w] bytes, rows for qualities 0 .. 5 (identity), 6 .. qhi (from A.t1), qhi1 ("not resident");
-  // level 2: rows 32 bytes apart: 0 .. n_dict - 1 the distinct LUT rows, n_dict the 0x80 row, n_dict + 1 + q the identity row of q < 6
-  const int w = 2 * A.lmax + 1, qhi1 = 6 + A.n_qi, rows_w = (qhi1 + 1) * w, n1 = A.n_cov * rows_w;
+  // level 1 in LDS: [n_cov][qhi1 + 1][w] bytes (SPLIT: ONE covariate's [qhi1 + 1][w]), rows for qualities 0 .. 5 (identity), 6 .. qhi (from
+  // A.t1), qhi1 ("not resident"); level 2: rows A3_ROW bytes apart: 0 .. n_dict - 1 the distinct LUT rows, n_dict the 0x80 row,
+  // n_dict + 1 + q the identity row of q < 6
+  const int w = 2 * A.lmax + 1, qhi1 = 6 + A.n_qi, rows_w = (qhi1 + 1) * w, n1 = (SPLIT ? 1 : A.n_cov) * rows_w;
   const int t1_bytes = (n1 + 15) & ~15;
-  const int n_dict = (int)*A.n_dict;
-  if (n_dict + 7 > 256) {  // more distinct rows than one-byte ids (and the LDS the launch reserved) hold: the host takes the general kernel
-    if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(&A.err[0], 512u);
-    return;
+  // more distinct rows than one-byte ids (and the LDS the launch reserved) hold - SPLIT: in any covariate's dictionary -: nothing is
+  // touched, the host takes another form
+  {
+    int over = 0;
+    if (SPLIT) { for (int k = threadIdx.x; k < A.n_cov; k += A3_NT) over |= (int)A.n_dict[k] + 7 > 256; }
+    else over = (int)*A.n_dict + 7 > 256;
+    if (__syncthreads_or(over)) {
+      if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(&A.err[0], 512u);
+      return;
+    }
   }
-  for (int k = threadIdx.x; k < n1; k += A3_NT) {
-    const int x = k % w, q = (k / w) % (qhi1 + 1), cov = k / rows_w;
-    uint32_t id;
-    if (q < 6) id = (uint32_t)(n_dict + 1 + q);
-    else id = A.t1[((size_t)cov * (A.n_qi + 1) + (size_t)(q - 6)) * w + x];  // row n_qi of t1 is the "not resident" row (id n_dict)
-    llut[k] = (uint8_t)id;
+  // fills the tables: level 1 of covariates [cov_lo, cov_lo + ncv) and the dictionary with `n_dict` rows at t2
+  auto fill = [&](int cov_lo, int ncv, int n_dict, const uint8_t *t2) {
+    for (int k = threadIdx.x; k < ncv * rows_w; k += A3_NT) {
+      const int x = k % w, q = (k / w) % (qhi1 + 1), cov = cov_lo + k / rows_w;
+      uint32_t id;
+      if (q < 6) id = (uint32_t)(n_dict + 1 + q);
+      else id = A.t1[((size_t)cov * (A.n_qi + 1) + (size_t)(q - 6)) * w + x];  // row n_qi of t1 is the "not resident" row (id n_dict)
+      llut[k] = (uint8_t)id;
+    }
+    const int n2 = (n_dict + 7) * 17;
+    for (int k = threadIdx.x; k < n2; k += A3_NT) {
+      const int row = k / 17, cx = k - 17 * row;
+      llut[t1_bytes + A3_ROW * row + cx] = row <= n_dict ? t2[k] : (uint8_t)(row - n_dict - 1);
+    }
+  };
+  if (!SPLIT) {
+    fill(0, A.n_cov, (int)*A.n_dict, A.t2);
+    __syncthreads();
   }
-  const int n2 = (n_dict + 7) * 17;
-  for (int k = threadIdx.x; k < n2; k += A3_NT) {
-    const int row = k / 17, cx = k - 17 * row;
-    llut[t1_bytes + A3_ROW * row + cx] = row <= n_dict ? A.t2[k] : (uint8_t)(row - n_dict - 1);
-  }
-  __syncthreads();
-  Apply3 B;
+  Apply3<SPLIT> B;
   const uint32_t len = A.len, bpr = (len + 15u) >> 4, sbytes = (len + 1u) >> 1;
   // lanes in groups of A.group that share whole reads (apply3_launch picks the group so that a read's last two blocks sit in one wave)
   const uint32_t grp = threadIdx.x / A.group, in_grp = threadIdx.x - grp * A.group, per_grp = A.group / bpr, RPI = per_grp * (A3_NT / A.group);
@@ -224,41 +303,57 @@ __global__ __launch_bounds__(A3_NT) void k_bqsr_apply3(Apply3Args A) {
   B.w = (uint32_t)w; B.rows_w = (uint32_t)rows_w; B.qhi1 = (uint32_t)qhi1;
   B.lmax = A.lmax; B.max_cycle = A.max_cycle; B.lut = A.lut; B.err = 0;
   asm volatile("" : "+v"(B.qhi1));  // the SDWA form takes no inline constant / scalar here
-  const uint64_t n = A.n, stride = (uint64_t)gridDim.x * RPI;
-  const uint64_t n_trips = (n + stride - 1) / stride;
   const uint8_t *seq_m1 = A.seq4 - 1;
-  auto first_read = [&](uint64_t it) __attribute__((always_inline)) -> uint64_t { return it * stride + (uint64_t)blockIdx.x * RPI; };
-  const uint32_t roff = slot * 8u;
-  auto rec_load = [&](uint64_t it, u32x2 &z) __attribute__((always_inline)) {
+  // The records of a launch: every staged read in staging order (a trip of a workgroup covers RPI consecutive reads, the workgroups
+  // stride over the trips), or - SPLIT - the records sorted by covariate: the launch's trips, covariate after covariate, are shared
+  // evenly among the workgroups; a workgroup takes a contiguous range of them and loads the tables of every covariate its range crosses.
+  uint64_t n = SPLIT ? 0 : A.n;       // records of the part this workgroup works on (SPLIT: of the current covariate) ...
+  uint64_t r_base = 0;                // ... and the first of them
+  const uint64_t stride = SPLIT ? (uint64_t)RPI : (uint64_t)gridDim.x * RPI, r_mine = SPLIT ? 0 : (uint64_t)blockIdx.x * RPI;
+  auto first_read = [&](uint64_t it) __attribute__((always_inline)) -> uint64_t { return it * stride + r_mine; };
+  const uint32_t roff = slot * 8u, ioff = slot * 4u;
+  auto rec_load = [&](uint64_t it, u32x2 &z, uint32_t &zi) __attribute__((always_inline)) {
     const uint64_t r0 = first_read(it);
-    if (lane_on && r0 + slot < n) gload_x2(z, reinterpret_cast<const uint8_t *>(A.recs) + r0 * 8u, roff);
-    else z = (u32x2){0u, 0u};
+    if (lane_on && r0 + slot < n) {
+      gload_x2(z, reinterpret_cast<const uint8_t *>(A.recs) + (r_base + r0) * 8u, roff);
+      if (SPLIT) gload_x1(zi, reinterpret_cast<const uint8_t *>(A.ridx) + (r_base + r0) * 4u, ioff);
+    } else z = (u32x2){0u, 0u};
   };
-  auto data_load = [&](uint64_t it, u32x2 rec, A3Data &d) __attribute__((always_inline)) -> bool {
+  // idx: the read's staging index (SPLIT: out of the record's index word; else the trip's first read + the lane's slot, folded into the
+  // wave-uniform base)
+  auto data_load = [&](uint64_t it, u32x2 rec, uint32_t idx, A3Data &d) __attribute__((always_inline)) -> bool {
     const uint64_t r0 = first_read(it);
     if (!(lane_on && r0 + slot < n) || !(rec.y & AR_ON)) return false;
-    gload_x4(d.q, A.qual + r0 * len, B.qoff);
-    gload_x4(d.s, seq_m1 + r0 * sbytes, B.soff);
+    if (SPLIT) {
+      gload_x4(d.q, (uint64_t)A.qual + (uint64_t)idx * len + B.k0);
+      gload_x4(d.s, (uint64_t)seq_m1 + (uint64_t)idx * sbytes + (B.k0 >> 1));
+    } else {
+      gload_x4(d.q, A.qual + r0 * len, B.qoff);
+      gload_x4(d.s, seq_m1 + r0 * sbytes, B.soff);
+    }
     return true;
   };
   // the wait of a loop trip (gload.hpp); the record moves out of its buffer by copies that stay behind the wait.  Inside the loop the
   // youngest vector-memory instruction of the wave is the trip's store: it may stay in flight
-  auto landed0 = [&](A3Data &d, const u32x2 &z, u32x2 &rec) __attribute__((always_inline)) {
+  auto landed0 = [&](A3Data &d, const u32x2 &z, const uint32_t &zi, u32x2 &rec, uint32_t &ri) __attribute__((always_inline)) {
     gwait();
     asm volatile("" : "+v"(d.q), "+v"(d.s));
     rec = amov(z);
+    if (SPLIT) ri = amov(zi);
   };
-  auto landed = [&](A3Data &d, const u32x2 &z, u32x2 &rec) __attribute__((always_inline)) {
+  auto landed = [&](A3Data &d, const u32x2 &z, const uint32_t &zi, u32x2 &rec, uint32_t &ri) __attribute__((always_inline)) {
     gwait_but<1>();
     asm volatile("" : "+v"(d.q), "+v"(d.s));
     rec = amov(z);
+    if (SPLIT) ri = amov(zi);
   };
   const uint64_t my_dump = (uint64_t)(A.dump + ((uint64_t)blockIdx.x * A3_NT + threadIdx.x) * 16u);
   // one block: the look-ups if the lane has one, then the store EVERY lane issues (exactly one per trip, behind the trip's loads)
-  auto work = [&](uint64_t it, bool on, u32x2 rec, const A3Data &d) __attribute__((always_inline)) {
+  auto work = [&](uint64_t it, bool on, u32x2 rec, uint32_t idx, const A3Data &d) __attribute__((always_inline)) {
     u32x4 o = (u32x4){0u, 0u, 0u, 0u};
     if (on) o = B.process(rec, d);
-    const uint64_t at = on ? (uint64_t)(A.qual + first_read(it) * len + B.qoff) : my_dump;
+    const uint64_t mine = SPLIT ? (uint64_t)A.qual + (uint64_t)idx * len + B.k0 : (uint64_t)(A.qual + first_read(it) * len + B.qoff);
+    const uint64_t at = on ? mine : my_dump;
     gstore_x4(at, o);
   };
   // records two trips ahead (z), data one trip ahead, two sets X / Y that swap roles
@@ -266,30 +361,81 @@ __global__ __launch_bounds__(A3_NT) void k_bqsr_apply3(Apply3Args A) {
   dX.q = (u32x4){0, 0, 0, 0}; dX.s = dX.q;
   dY = dX;
   u32x2 rX, rY, rN, z = (u32x2){0u, 0u};  // records of the blocks in X / Y, of the next trip's block, the buffer in flight
+  uint32_t iX = 0, iY = 0, iN = 0, zi = 0;  // SPLIT: their reads' staging indices
   bool onX, onY = false;
-  rec_load(0, z);
-  landed0(dX, z, rX);
-  onX = data_load(0, rX, dX);
-  rec_load(1, z);
-  landed0(dX, z, rN);
+  // one pass of the pipeline over trips [0, n_trips) of the current part
+  auto run = [&](uint64_t n_trips) __attribute__((always_inline)) {
+    rec_load(0, z, zi);
+    landed0(dX, z, zi, rX, iX);
+    onX = data_load(0, rX, iX, dX);
+    rec_load(1, z, zi);
+    landed0(dX, z, zi, rN, iN);
 #pragma unroll 1
-  for (uint64_t it = 0; it < n_trips; it += 2) {
-    {
-      rY = rN;
-      onY = data_load(it + 1, rY, dY);
-      rec_load(it + 2, z);
-      work(it, onX, rX, dX);
-      landed(dY, z, rN);
+    for (uint64_t it = 0; it < n_trips; it += 2) {
+      {
+        rY = rN; iY = iN;
+        onY = data_load(it + 1, rY, iY, dY);
+        rec_load(it + 2, z, zi);
+        work(it, onX, rX, iX, dX);
+        landed(dY, z, zi, rN, iN);
+      }
+      {
+        rX = rN; iX = iN;
+        onX = data_load(it + 2, rX, iX, dX);
+        rec_load(it + 3, z, zi);
+        work(it + 1, onY, rY, iY, dY);
+        landed(dX, z, zi, rN, iN);
+      }
     }
+    gwait();
+  };
+  if (!SPLIT) {
+    run((n + stride - 1) / stride);
+  } else {
+    // trips per covariate, their exclusive prefix sums (s_pre[k] for k >= n_cov = the total)
+    __shared__ uint32_t s_cnt[A3_MAXCOV], s_pre[A3_MAXCOV + 1], s_wsum[4];
     {
-      rX = rN;
-      onX = data_load(it + 2, rX, dX);
-      rec_load(it + 3, z);
-      work(it + 1, onY, rY, dY);
-      landed(dX, z, rN);
+      const uint32_t my_cnt = (int)threadIdx.x < A.n_cov ? A.cov_cnt[threadIdx.x] : 0u;
+      const uint32_t my_trips = (my_cnt + RPI - 1u) / RPI;
+      uint32_t incl = my_trips;
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t v = __shfl_up(incl, d, 64);
+        if ((int)(threadIdx.x & 63u) >= d) incl += v;
+      }
+      if (threadIdx.x < (uint32_t)A3_MAXCOV && (threadIdx.x & 63u) == 63u) s_wsum[threadIdx.x >> 6] = incl;
+      __syncthreads();
+      if (threadIdx.x < (uint32_t)A3_MAXCOV) {
+        uint32_t off = 0;
+        for (uint32_t wv = 0; wv < (threadIdx.x >> 6); wv++) off += s_wsum[wv];
+        s_cnt[threadIdx.x] = my_cnt;
+        s_pre[threadIdx.x] = off + incl - my_trips;
+        if (threadIdx.x == (uint32_t)A3_MAXCOV - 1u) s_pre[A3_MAXCOV] = off + incl;
+      }
+      __syncthreads();
+    }
+    const uint64_t trips_all = to_sgpr(s_pre[A3_MAXCOV]);
+    const uint32_t my_lo = to_sgpr((uint32_t)(trips_all * blockIdx.x / gridDim.x)), my_hi = to_sgpr((uint32_t)(trips_all * (blockIdx.x + 1ull) / gridDim.x));
+    uint32_t cov = 0;
+    for (uint32_t a = 0, b = (uint32_t)A.n_cov; b - a > 1u;) {
+      const uint32_t md = (a + b) >> 1;
+      if (s_pre[md] <= my_lo) { a = md; cov = md; } else b = md;
+    }
+#pragma unroll 1
+    for (; cov < (uint32_t)A.n_cov; cov++) {
+      const uint32_t p0 = to_sgpr(s_pre[cov]);
+      if (p0 >= my_hi) break;
+      const uint32_t tr = to_sgpr(s_pre[cov + 1]) - p0, cnt_c = to_sgpr(s_cnt[cov]);
+      const uint32_t t0 = my_lo > p0 ? my_lo - p0 : 0u, t1 = my_hi - p0 < tr ? my_hi - p0 : tr;
+      if (t0 >= t1) continue;
+      __syncthreads();  // (every wave is through with the previous covariate's tables)
+      fill((int)cov, 1, (int)A.n_dict[cov], A.t2 + (size_t)cov * 256 * 17);
+      __syncthreads();
+      const uint64_t r_first = (uint64_t)t0 * RPI, r_end = (uint64_t)t1 * RPI < (uint64_t)cnt_c ? (uint64_t)t1 * RPI : (uint64_t)cnt_c;
+      n = to_sgpr(r_end - r_first);
+      r_base = to_sgpr((uint64_t)A.cov_off[cov] + r_first);
+      run(t1 - t0);
     }
   }
-  gwait();
   uint32_t my_err = B.err;
   if (__any(my_err != 0)) {
     for (int d = 32; d >= 1; d >>= 1) my_err |= __shfl_xor(my_err, d, 64);
@@ -306,7 +452,7 @@ int apply3_bytes(int n_cov, int n_qi, int lmax, size_t *dyn_out) {
 }
 
 int apply3_launch(elp_ctx *c, int max_cycle, const uint8_t *d_lut, const uint8_t *d_cov_present, const uint16_t *t1, const uint8_t *t2, const uint32_t *n_dict_dev,
-                  int n_qi, int lmax, size_t dyn) {
+                  int n_qi, int lmax, size_t dyn, bool split) {
   const uint64_t n = c->n;
   const uint32_t len = c->uniform_len, bpr = (len + 15u) >> 4;
   // reads packed over the whole workgroup unless that puts the last two blocks of some read (which overlap when the length is not a
@@ -316,17 +462,36 @@ int apply3_launch(elp_ctx *c, int max_cycle, const uint8_t *d_lut, const uint8_t
     for (uint32_t slot = 0; slot < A3_NT / bpr; slot++)
       if (((slot * bpr + bpr - 1u) & 63u) == 0) group = 64;
   const uint32_t rpi = (group / bpr) * (A3_NT / group);
-  const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / (dyn + 512)));
+  const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / (dyn + 512 + (split ? 2304 : 0))));
   const int grid = (int)std::min<uint64_t>((n + rpi - 1) / rpi, (uint64_t)c->n_cu * per_cu);
   uint2 *recs;
   const size_t dump_words = (size_t)grid * A3_NT * 2;  // 16 bytes per lane, in uint2 units
-  ELP_TRY(scratch(c, 5, n + 6 + dump_words, &recs));
-  ELP_LAUNCH(c, "bqsr_apply_records", k_apply_records, dim3(blocks_for(n, 256)), dim3(256), 0, n, len, lmax, (const uint16_t *)c->flag.p,
-             (const uint16_t *)c->rgid.p, (const uint16_t *)c->rg_cov.p, (const uint64_t *)c->qbounds.p, d_cov_present, recs, c->err_flag.p);
+  // records | dump | (split) staging indices | counts per covariate, offsets, cursors
+  const size_t rec_words = (n + 4 + 1) & ~(uint64_t)1;
+  ELP_TRY(scratch(c, 5, rec_words + dump_words + (split ? (n + 1) / 2 + 2 * A3_MAXCOV + 8 : 0) + 8, &recs));
+  uint8_t *dump = reinterpret_cast<uint8_t *>(recs + rec_words);
+  uint32_t *ridx = reinterpret_cast<uint32_t *>(recs + rec_words + dump_words), *cw = ridx + ((n + 1) & ~(uint64_t)1);  // cw: [256] counts | [257] offsets | [256] cursors
+  if (split) {
+    ELP_HIP(c, hipMemsetAsync(cw, 0, (3 * A3_MAXCOV + 1) * sizeof(uint32_t), c->stream));
+    const unsigned rg = blocks_for(n, A3_RTILE);
+    ELP_LAUNCH(c, "bqsr_apply_cov_hist", k_apply_cov_hist, dim3(rg), dim3(256), 0, n, (const uint16_t *)c->rgid.p, (const uint16_t *)c->rg_cov.p, d_cov_present, cw,
+               c->err_flag.p);
+    ELP_LAUNCH(c, "bqsr_apply_cov_offsets", k_apply_cov_offsets, dim3(1), dim3(1), 0, (const uint32_t *)cw, cw + A3_MAXCOV, cw + 2 * A3_MAXCOV + 1);
+    ELP_LAUNCH(c, "bqsr_apply_records", k_apply_records_split, dim3(rg), dim3(256), 0, n, len, lmax, (const uint16_t *)c->flag.p, (const uint16_t *)c->rgid.p,
+               (const uint16_t *)c->rg_cov.p, (const uint64_t *)c->qbounds.p, d_cov_present, cw + 2 * A3_MAXCOV + 1, recs, ridx, c->err_flag.p);
+  } else {
+    ELP_LAUNCH(c, "bqsr_apply_records", k_apply_records, dim3(blocks_for(n, 256)), dim3(256), 0, n, len, lmax, (const uint16_t *)c->flag.p,
+               (const uint16_t *)c->rgid.p, (const uint16_t *)c->rg_cov.p, (const uint64_t *)c->qbounds.p, d_cov_present, recs, c->err_flag.p);
+  }
   Apply3Args A{n, len, c->qual.p, c->seq4.p + elp_ctx::SEQ_FRONT, recs, d_lut, t1, t2, n_dict_dev, c->n_cov, n_qi, lmax, max_cycle, c->err_flag.p,
-               reinterpret_cast<uint8_t *>(recs + ((n + 4 + 1) & ~(uint64_t)1)), group};
-  ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bqsr_apply3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-  ELP_LAUNCH(c, "bqsr_apply", k_bqsr_apply3, dim3(grid), dim3(A3_NT), dyn, A);
+               dump, group, ridx, cw, cw + A3_MAXCOV};
+  if (split) {
+    ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bqsr_apply3<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    ELP_LAUNCH(c, "bqsr_apply", k_bqsr_apply3<true>, dim3(grid), dim3(A3_NT), dyn, A);
+  } else {
+    ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bqsr_apply3<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    ELP_LAUNCH(c, "bqsr_apply", k_bqsr_apply3<false>, dim3(grid), dim3(A3_NT), dyn, A);
+  }
   return 0;
 }
 

@@ -529,8 +529,10 @@ int elp_stage_bam(elp_ctx *c, const uint8_t *bytes, uint64_t n_bytes, const uint
 static int emit_stream(elp_ctx *c, const BamOut &m, const BamOut &m2, const uint32_t *src, uint64_t n_out, uint64_t max_raw_rec, uint8_t *out, uint64_t cap,
                        uint64_t *n_bytes_out, bool bgzf = false) {
   // records per device pass: sizes and offsets of a pass are scanned in 32 bits, so a pass must stay below 4 GiB of output.  An output
-  // record is never longer than the staged one (integer fields only shrink when re-encoded), so the largest staged record bounds it.
-  const uint32_t CHUNK = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(1u << 21, 0xFFFFFFFFull / std::max<uint64_t>(max_raw_rec, 64)));
+  // record is never longer than the staged one (integer fields only shrink when re-encoded) - except that elp_clean_sam may have added
+  // ONE CIGAR operation (4 bytes) - so the largest staged record + 4 bounds it; BGZF framing adds 26 bytes per 65280 (< 0.1 %: the bound
+  // leaves 1/64 of headroom).
+  const uint32_t CHUNK = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(1u << 21, 0xFC000000ull / (std::max<uint64_t>(max_raw_rec, 64) + 4)));
   uint64_t total = 0;
   hipStream_t st = c->stream;
   for (uint64_t k0 = 0; k0 < n_out; k0 += CHUNK) {

@@ -125,7 +125,7 @@ __device__ __forceinline__ void set_skip_bits(uint32_t *skipbits, uint64_t bit0,
 // itself, getReadCoordinateForReferenceCoordinate(ref) is ref - POS inside the read and fails outside (utils.go:267-349 with one
 // match operation), and there is one reference piece.  Everything else is appended to `queue` for the general kernel, so that
 // kernel's long divergent code runs with all lanes busy.  All column loads are issued before the first test (one latency, not 15).
-constexpr int PF_TILES = 16;
+// (PF_TILES: bqsr_common.hpp)
 // a record's columns (k_bqsr_prologue_fast loads them a tile ahead)
 struct PfCols {
   uint8_t has_sr, mq;
@@ -381,14 +381,14 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
     int rcl = 0;
     if (i < m.n) pf_record<false>(m, i, cur, L, ref_lds, desc, skipbits, err, ro.recs != nullptr, nullptr, defer, to_plain, rc, rcl);
     if (ro.recs) {  // the tile's records, compacted: class 1 into this wave's segment, the rare class 2 ones (windows the record cannot describe) behind
-      const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+      const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);  // == pf_wave_of_record(i), bqsr_common.hpp
       if (!ro.ncs) {
-        const uint32_t seg = wave % (uint32_t)C3_NSEG;
+        const uint32_t seg = wave % ro.nseg;
         const uint32_t at1 = wave_append(rcl == 1, &ro.cnt[seg * C3_CSTRIDE]);
-        if (rcl == 1) rec_store(ro.recs, (uint64_t)seg * ro.cap_s + at1, rc);
+        if (rcl == 1) rec_store(ro.recs, (uint64_t)ro.seg_base[seg] + at1, rc);
       } else {
         // segments by covariate: one append per covariate that occurs among the wave's class-1 records of this tile
-        const uint32_t cov = rc.fl & 0xFFu, grp = (wave % ((uint32_t)C3_NSEG / ro.ncs)) * ro.ncs;
+        const uint32_t cov = rc.fl & 0xFFu, grp = (wave % (ro.nseg / ro.ncs)) * ro.ncs;
         unsigned long long todo = __ballot(rcl == 1);
         while (todo) {
           const int leader = __ffsll((long long)todo) - 1;
@@ -396,12 +396,12 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
           const bool mine = rcl == 1 && cov == c0;
           const uint32_t seg = grp + c0;
           const uint32_t at1 = wave_append(mine, &ro.cnt[seg * C3_CSTRIDE]);
-          if (mine) rec_store(ro.recs, (uint64_t)seg * ro.cap_s + at1, rc);
+          if (mine) rec_store(ro.recs, (uint64_t)ro.seg_base[seg] + at1, rc);
           todo &= ~__ballot(mine);
         }
       }
-      const uint32_t at2 = wave_append(rcl == 2, &ro.cnt[C3_NSEG * C3_CSTRIDE]);
-      if (rcl == 2) rec_store(ro.recs, (uint64_t)C3_NSEG * ro.cap_s + at2, rc);
+      const uint32_t at2 = wave_append(rcl == 2, &ro.cnt[ro.nseg * C3_CSTRIDE]);
+      if (rcl == 2) rec_store(ro.recs, ro.other_at + at2, rc);
     }
     const int lane = threadIdx.x & 63;
     const unsigned long long mask = __ballot(defer);
@@ -465,11 +465,11 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_plain(BqCols m, BqDesc *_
     __syncthreads();
     if (threadIdx.x == 0) {
       wg_base = wg_n ? atomicAdd(queue_n, wg_n) : 0u;
-      wr_base = wr_n ? atomicAdd(&ro.cnt[C3_NSEG * C3_CSTRIDE], wr_n) : 0u;
+      wr_base = wr_n ? atomicAdd(&ro.cnt[ro.nseg * C3_CSTRIDE], wr_n) : 0u;
     }
     __syncthreads();
     if (defer) queue[wg_base + my] = i;
-    if (rcl) rec_store(ro.recs, (uint64_t)C3_NSEG * ro.cap_s + wr_base + myr, rc);
+    if (rcl) rec_store(ro.recs, ro.other_at + wr_base + myr, rc);
   }
 }
 
@@ -578,9 +578,9 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue(BqCols m, const uint32_t 
     uint32_t myr = 0;
     if (rcl) myr = atomicAdd(&wr_n, 1u);
     __syncthreads();
-    if (threadIdx.x == 0) wr_base = wr_n ? atomicAdd(&ro.cnt[C3_NSEG * C3_CSTRIDE], wr_n) : 0u;
+    if (threadIdx.x == 0) wr_base = wr_n ? atomicAdd(&ro.cnt[ro.nseg * C3_CSTRIDE], wr_n) : 0u;
     __syncthreads();
-    if (rcl) rec_store(ro.recs, (uint64_t)C3_NSEG * ro.cap_s + wr_base + myr, rc);
+    if (rcl) rec_store(ro.recs, ro.other_at + wr_base + myr, rc);
   }
 }
 
@@ -654,6 +654,10 @@ struct CountArgs {
   unsigned long long *cycle_tbl, *ctx_tbl;  // dense int64 tables of the C ABI (device copies)
   uint32_t *err;
   const uint32_t *tile_first;
+  // this pass counts the reads of covariates [cov0, cov0 + n_cov) only (n_cov above = the covariates of the PASS): with many read groups
+  // the rows of all covariates do not fit one workgroup's LDS, the host then runs one pass per covariate subset - the reference's maps
+  // just grow (filters/bqsr.go:467-551)
+  int cov0;
 };
 
 // private table of one workgroup: per covariate n_q + CT_XROWS rows of rs words - [0, CT_CYC) sixteen context cells of 32 | 32
@@ -684,6 +688,7 @@ struct CountBody {
   const int64_t *__restrict__ ref_seq_len;
   unsigned long long *cycle_tbl, *ctx_tbl;
   int n_cov, n_q, lmax, rs, max_cycle;
+  uint32_t cov0;           // first covariate of this pass (n_cov = covariates of the pass)
   // LDS
   const uint64_t *s_refp;  // [REF_LDS] packed-contig pointers and lengths (REFLDS: n_ref <= REF_LDS; else they are read from HBM)
   const int64_t *s_refl;
@@ -773,6 +778,7 @@ struct CountBody {
     const uint4 dy = s_desc[2 * rl + 1];
     const uint32_t fl = (dy.w >> 8) & 0xFFu;
     if (!(fl & BQ_ELIGIBLE)) return false;
+    if ((dy.w & 0xFFu) - cov0 >= (uint32_t)n_cov) return false;  // a covariate of another pass
     const int a = (int)(dy.y & 0xFFFFu), len = (int)(dy.y >> 16);
     const int cbase = k0 - a;   // clipped base index of block bit 0
     if ((cbase < 0 ? -cbase : 0) >= (len - cbase < nb ? len - cbase : nb)) return false;  // no clipped base in the block
@@ -864,7 +870,7 @@ struct CountBody {
     const int rof = (fl & BQ_LAST) ? -1 : 1;
     const int cf = rof + (rev ? (len - 1) * rof : 0), ci = rev ? -rof : rof;
     const int cyc0 = cf + cbase * ci;
-    const uint32_t rowb = cov * rpc_bytes;                               // the covariate's rows
+    const uint32_t rowb = (cov - cov0) * rpc_bytes;                      // the covariate's rows
     // cycle cell (in words from the row start): (P + b * st) >> 4;  MG: two cells per word, word (P + b * st) >> 5 (CT_CYC doubled in P)
     const int P = (CT_CYC << (MG ? 5 : 4)) + 17 * (cyc0 + lmax), st = 17 * ci;
 
@@ -913,7 +919,7 @@ struct CountBody {
         const uint32_t v = *cell;
         if (v) {
           *cell = 0;
-          const int cov = row / rpc, slot = row % rpc;
+          const int cov = (int)cov0 + row / rpc, slot = row % rpc;
           if (slot >= n_q) {
             err |= slot == n_q ? 8u : (slot == n_q + 1 ? 128u : 0u);
           } else {
@@ -935,7 +941,7 @@ struct CountBody {
       const uint32_t v = *cell;
       if (v) {
         *cell = 0;
-        const int cov = row / rpc, slot = row % rpc;
+        const int cov = (int)cov0 + row / rpc, slot = row % rpc;
         const int cyc = x - lmax;
         if (slot >= n_q) {
           err |= slot == n_q ? 8u : (slot == n_q + 1 ? 128u : 0u);
@@ -953,7 +959,7 @@ struct CountBody {
       const unsigned long long v = *cell;
       if (v) {
         *cell = 0;
-        const int cov = row / rpc, slot = row % rpc;
+        const int cov = (int)cov0 + row / rpc, slot = row % rpc;
         if (slot < n_q) {
           const int q = slot_q[slot];
           // cx = prev | cur << 2 is exactly (key >> 4) & 15 of keyFromContext (bqsr.go:64-76)
@@ -1008,7 +1014,7 @@ __global__ __launch_bounds__(NTV, 4) void k_bqsr_count(CountArgs A, QMap qm) {
   B.seq_off = A.seq_off; B.qual = A.qual; B.seq4 = A.seq4; B.desc = reinterpret_cast<const uint4 *>(A.desc);
   B.cigar = A.cigar; B.cig_scratch = A.cig_scratch; B.skipbits = A.skipbits; B.ref_seq = A.ref_seq; B.ref_seq_len = A.ref_seq_len;
   B.cycle_tbl = A.cycle_tbl; B.ctx_tbl = A.ctx_tbl;
-  B.n_cov = A.n_cov; B.n_q = A.n_q; B.lmax = A.lmax; B.rs = A.rs; B.max_cycle = A.max_cycle;
+  B.n_cov = A.n_cov; B.n_q = A.n_q; B.lmax = A.lmax; B.rs = A.rs; B.max_cycle = A.max_cycle; B.cov0 = (uint32_t)A.cov0;
   B.s_desc = s_desc; B.s_seq = s_seq; B.qrow = qrow; B.slot_q = slot_q; B.tbl = tbl;
   B.s_refp = s_refp; B.s_refl = s_refl; B.s_rp = s_rp; B.s_rl = s_rl;
   B.real_end = tbl_at + (uint32_t)(A.n_q * A.rs) * 4u;
@@ -1341,12 +1347,16 @@ __global__ __launch_bounds__(FL_THREADS, MODE ? 6 : 4) void k_bqsr_apply_flat(Ap
 }
 
 // ---- distinct rows of the dense LUT over (read group, quality in [qlo, qlo + n_qi), cycle in [-lmax, lmax]) ----
-struct LutRows { const uint8_t *lut; int n_cov, qlo, n_qi, lmax, max_cycle; };
+// per_cov (round 5, apply3's covariate split): one dictionary PER covariate - rows of different covariates never share an id, the ids
+// count from 0 in every covariate (counter[cov]), covariate c's rows lie at t2 + c * LUT_PC_ROWS * 17
+constexpr uint32_t LUT_PC_ROWS = 256;
+struct LutRows { const uint8_t *lut; int n_cov, qlo, n_qi, lmax, max_cycle, per_cov; };
 __device__ __forceinline__ const uint8_t *lut_row(const LutRows &R, int r) {  // r = (cov * n_qi + qi) * w + x
   const int w = 2 * R.lmax + 1, ncyc = 2 * R.max_cycle + 1;
   const int x = r % w, qi = (r / w) % R.n_qi, cov = r / (w * R.n_qi);
   return R.lut + (((size_t)cov * ELP_NQUAL + (size_t)(R.qlo + qi)) * ncyc + (size_t)(x - R.lmax + R.max_cycle)) * 17;
 }
+__device__ __forceinline__ int lut_row_cov(const LutRows &R, int r) { return r / ((2 * R.lmax + 1) * R.n_qi); }
 __device__ __forceinline__ bool row_eq(const uint8_t *a, const uint8_t *b) {
   bool eq = true;
 #pragma unroll
@@ -1358,7 +1368,8 @@ __global__ __launch_bounds__(256) void k_lut_rows_insert(LutRows R, int n_rows, 
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_rows) return;
   const uint8_t *mine = lut_row(R, r);
-  uint64_t h = 0x9e3779b97f4a7c15ull;
+  const int my_cov = R.per_cov ? lut_row_cov(R, r) : 0;
+  uint64_t h = 0x9e3779b97f4a7c15ull + (uint64_t)my_cov;
 #pragma unroll
   for (int k = 0; k < 17; k++) h = (h ^ mine[k]) * 0x100000001b3ull;
   uint32_t s = (uint32_t)mix64(h) & mask;
@@ -1368,7 +1379,7 @@ __global__ __launch_bounds__(256) void k_lut_rows_insert(LutRows R, int n_rows, 
       cur = atomicCAS(&slots[s], 0xFFFFFFFFu, (uint32_t)r);
       if (cur == 0xFFFFFFFFu) break;
     }
-    if (row_eq(lut_row(R, (int)cur), mine)) break;
+    if ((!R.per_cov || lut_row_cov(R, (int)cur) == my_cov) && row_eq(lut_row(R, (int)cur), mine)) break;
     s = (s + 1) & mask;
   }
   row_slot[r] = s;
@@ -1380,11 +1391,13 @@ __global__ __launch_bounds__(256) void k_lut_rows_number(LutRows R, const uint32
   if (s >= n_slots) return;
   const uint32_t rep = slots[s];
   if (rep == 0xFFFFFFFFu) return;
-  const uint32_t id = atomicAdd(counter, 1u);
+  const int cov = R.per_cov ? lut_row_cov(R, (int)rep) : 0;
+  const uint32_t id = atomicAdd(counter + cov, 1u);
   slot_id[s] = id;
   if (id < t2_cap) {
     const uint8_t *src = lut_row(R, (int)rep);
-    for (int k = 0; k < 17; k++) t2[(size_t)id * 17 + k] = src[k];
+    uint8_t *dst = t2 + ((size_t)cov * LUT_PC_ROWS + id) * 17;  // (cov = 0 without per_cov)
+    for (int k = 0; k < 17; k++) dst[k] = src[k];
   }
 }
 // level 1 [cov][n_qi + 1][w]: ids; the extra row per read group and (below) the extra level-2 row stand for "not resident"
@@ -1393,10 +1406,14 @@ __global__ __launch_bounds__(256) void k_lut_rows_index(LutRows R, const uint32_
                                                         uint32_t t2_cap) {
   const int w = 2 * R.lmax + 1, n1 = R.n_cov * (R.n_qi + 1) * w;
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t n_dict = *counter;
-  if (k < 17 && n_dict < t2_cap) t2[(size_t)n_dict * 17 + k] = 0x80;
+  if (k < 17 * (R.per_cov ? R.n_cov : 1)) {  // the 0x80 row behind (every covariate's) distinct rows
+    const int cv = k / 17;
+    const uint32_t nd = counter[cv];
+    if (nd < t2_cap) t2[((size_t)cv * LUT_PC_ROWS + nd) * 17 + (k - 17 * cv)] = 0x80;
+  }
   if (k >= n1) return;
   const int x = k % w, qi = (k / w) % (R.n_qi + 1), cov = k / (w * (R.n_qi + 1));
+  const uint32_t n_dict = counter[R.per_cov ? cov : 0];
   t1[k] = qi == R.n_qi ? (uint16_t)n_dict : (uint16_t)slot_id[row_slot[(cov * R.n_qi + qi) * w + x]];
 }
 
@@ -1453,16 +1470,16 @@ int tables_written(elp_ctx *c) {
 
 // The "other" region of the count kernel's records (reads with indels, clipped windows, descriptors; appended by three kernels in
 // arrival order) sorted by covariate for the covariate-split count: counts per covariate, offsets, a scatter into a second region.
-constexpr int CO_TILE = 1024, CO_MAXCOV = 16;
+constexpr int CO_TILE = 1024, CO_MAXCOV = 256;  // (a covariate id is a byte: any number of read groups the context accepts)
 __global__ __launch_bounds__(256) void k_c3_other_hist(const uint4 *__restrict__ recs, const uint32_t *__restrict__ n_dev, uint32_t *__restrict__ cnt /* [CO_MAXCOV] */) {
   __shared__ uint32_t h[CO_MAXCOV];
   const uint32_t n = *n_dev;
   if ((uint64_t)blockIdx.x * CO_TILE >= n) return;
-  if (threadIdx.x < CO_MAXCOV) h[threadIdx.x] = 0;
+  h[threadIdx.x] = 0;
   __syncthreads();
   for (uint32_t k = blockIdx.x * CO_TILE + threadIdx.x; k < n && k < (blockIdx.x + 1u) * CO_TILE; k += 256) atomicAdd(&h[recs[2 * (size_t)k + 1].y & (CO_MAXCOV - 1)], 1u);
   __syncthreads();
-  if (threadIdx.x < CO_MAXCOV && h[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], h[threadIdx.x]);
+  if (h[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], h[threadIdx.x]);
 }
 __global__ void k_c3_other_offsets(const uint32_t *__restrict__ cnt, uint32_t *__restrict__ off /* [CO_MAXCOV + 1] */, uint32_t *__restrict__ cursor) {
   uint32_t at = 0;
@@ -1473,17 +1490,17 @@ __global__ __launch_bounds__(256) void k_c3_other_scatter(const uint4 *__restric
   __shared__ uint32_t h[CO_MAXCOV], base[CO_MAXCOV];
   const uint32_t n = *n_dev;
   if ((uint64_t)blockIdx.x * CO_TILE >= n) return;
-  if (threadIdx.x < CO_MAXCOV) h[threadIdx.x] = 0;
+  h[threadIdx.x] = 0;
   __syncthreads();
   uint32_t my[CO_TILE / 256], cv[CO_TILE / 256];
 #pragma unroll
   for (int j = 0; j < CO_TILE / 256; j++) {
     const uint32_t k = blockIdx.x * CO_TILE + j * 256 + threadIdx.x;
-    cv[j] = k < n ? (recs[2 * (size_t)k + 1].y & (CO_MAXCOV - 1)) : 0xFFFFFFFFu;
+    cv[j] = k < n ? (recs[2 * (size_t)k + 1].y & (CO_MAXCOV - 1)) : 0u;
     my[j] = k < n ? atomicAdd(&h[cv[j]], 1u) : 0u;
   }
   __syncthreads();
-  if (threadIdx.x < CO_MAXCOV) base[threadIdx.x] = h[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], h[threadIdx.x]) : 0u;
+  base[threadIdx.x] = h[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], h[threadIdx.x]) : 0u;
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < CO_TILE / 256; j++) {
@@ -1494,6 +1511,33 @@ __global__ __launch_bounds__(256) void k_c3_other_scatter(const uint4 *__restric
       out[2 * to + 1] = recs[2 * (size_t)k + 1];
     }
   }
+}
+
+// Covariate-split class-1 segments (RecOut, round 5): how many records segment (wave % groups) * ncs + covariate can receive at most - the
+// reads of that covariate among the records the first prologue pass's waves of that group handle (pf_wave_of_record) - and the
+// segments' first slots as the prefix sums of those counts (or, fixed != 0: a fixed stride apart).  Workgroup b covers the records of the
+// prologue's workgroup b.
+__global__ __launch_bounds__(256) void k_c3_seg_hist(uint64_t n, const uint16_t *__restrict__ rgid, const uint16_t *__restrict__ rg_cov, uint32_t groups, uint32_t ncs,
+                                                     uint32_t *__restrict__ seg_cap /* [groups * ncs] */) {
+  __shared__ uint32_t h[C3_MAXSEG];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint64_t i0 = (uint64_t)blockIdx.x * PF_TILES * 256 + threadIdx.x;
+  for (int tile = 0; tile < PF_TILES; tile++) {
+    const uint64_t i = i0 + (uint64_t)tile * 256;
+    if (i >= n) break;
+    const uint16_t rg = rgid[i];
+    if (rg == ELP_NIL16) continue;
+    const uint32_t cov = rg_cov[rg] & 0xFFu;
+    if (cov < ncs) atomicAdd(&h[(pf_wave_of_record(i) % groups) * ncs + cov], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < groups * ncs && h[threadIdx.x]) atomicAdd(&seg_cap[threadIdx.x], h[threadIdx.x]);
+}
+__global__ void k_c3_seg_offsets(const uint32_t *__restrict__ seg_cap, uint32_t nseg, uint32_t fixed, uint32_t *__restrict__ seg_base /* [nseg + 1] */) {
+  uint32_t at = 0;
+  for (uint32_t s2 = 0; s2 < nseg; s2++) { seg_base[s2] = at; at += fixed ? fixed : seg_cap[s2]; }
+  seg_base[nseg] = at;
 }
 
 static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cycle_tbl, int64_t *ctx_tbl) {
@@ -1527,48 +1571,61 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
     BqCols m{n, c->refid.p, c->pos.p, c->next_refid.p, c->pnext.p, c->tlen.p, c->flag.p, c->rgid.p, c->mapq.p, c->has_sr.p, c->l_seq.p,
              c->cigar_off.p, c->seq_off.p, c->qual_off.p, c->cigar.p, c->seq4.p, c->qual.p, c->ref_len.p, c->rg_cov.p, c->n_ref,
              c->d_ref_seq.p, c->d_ref_seq_len.p, c->d_sites.p, c->d_n_sites.p, c->d_site_idx.p, c->qbounds.p};
-    uint32_t *queue;
-    ELP_TRY(scratch(c, 5, 2 * n + 128 + (size_t)(C3_NSEG + 1) * C3_CSTRIDE + 4 * CO_MAXCOV + 16, &queue));  // [0] = count, [4..] = records left to the general kernel; [1] = count, [n + 20..] = reads of the second pass;
-    ELP_HIP(c, hipMemsetAsync(queue, 0, 16, st));  // [2 n + 48 ..] = the record counters (RecOut)
-    uint32_t *plist = queue + n + 20, *rec_cnt = queue + ((2 * n + 48 + 63) & ~(uint64_t)63);
-    ELP_HIP(c, hipMemsetAsync(rec_cnt, 0, (size_t)(C3_NSEG + 1) * C3_CSTRIDE * sizeof(uint32_t), st));
     // count3.hip (read sets of one length) works from 32-byte records the prologue kernels write instead of the descriptors; it takes
     // the count if the staged reads have one length (checked once per staged column), no read can exceed --max-cycle, and the quality
     // slots fit one table pass - k_bqsr_count otherwise (elp_set_tuning "count_kernel" = 1 forces it: A/B measurements)
-    // a wave of the first pass appends its class-1 records (at most PF_TILES * 64) to segment wave % C3_NSEG
-    const unsigned pf_grid = blocks_for(n, 256 * PF_TILES);
-    const uint64_t cap_s1 = ((uint64_t)pf_grid * 4 + C3_NSEG - 1) / C3_NSEG * (uint64_t)(PF_TILES * 64);
-    // How the one-length count kernel (count3.hip) takes this read set: 0 not at all (k_bqsr_count), 1 one private table with the rows of
+    // How the one-length count kernel takes this read set: 0 not at all (k_bqsr_count), 1 one private table with the rows of
     // every covariate, or - if those do not fit, or only with little replication of the context cells - 2: split by covariate (records
-    // in per-covariate segments, a workgroup counts ONE covariate: the table needs n_q + 3 rows whatever the number of read groups)
+    // in per-covariate segments, a workgroup counts ONE covariate at a time: the table needs n_q + 3 rows whatever the number of read groups)
     ELP_TRY(ensure_uniform_len(c));
     const int lmax0 = (int)std::max<uint32_t>(c->max_l_seq, 1);
     uint32_t ncs = 1;
     while ((int)ncs < c->n_cov) ncs <<= 1;
+    const uint32_t nseg2 = std::max<uint32_t>((uint32_t)C3_NSEG, ncs);  // segments of the covariate split (ncs <= 256: n_cov <= 255 above)
+    uint32_t *queue;
+    ELP_TRY(scratch(c, 5, 2 * n + 128 + (size_t)(C3_MAXSEG + 1) * C3_CSTRIDE + 4 * CO_MAXCOV + 2 * C3_MAXSEG + 32, &queue));  // [0] = count, [4..] = records left to the general kernel; [1] = count, [n + 20..] = reads of the second pass;
+    ELP_HIP(c, hipMemsetAsync(queue, 0, 16, st));  // [2 n + 48 ..] = the record counters (RecOut), the other region's sort words, the segments' sizes and first slots
+    uint32_t *plist = queue + n + 20, *rec_cnt = queue + ((2 * n + 48 + 63) & ~(uint64_t)63);
+    uint32_t *cw = rec_cnt + (size_t)(C3_MAXSEG + 1) * C3_CSTRIDE;  // [CO_MAXCOV] counts | [CO_MAXCOV + 1] offsets | [CO_MAXCOV] cursors
+    uint32_t *seg_cap = cw + 3 * CO_MAXCOV + 1, *seg_base = seg_cap + C3_MAXSEG;  // [C3_MAXSEG] | [C3_MAXSEG + 1]
+    // a wave of the first pass appends its class-1 records (at most PF_TILES * 64) to segment wave % C3_NSEG
+    const unsigned pf_grid = blocks_for(n, 256 * PF_TILES);
+    const uint64_t cap_s1 = ((uint64_t)pf_grid * 4 + C3_NSEG - 1) / C3_NSEG * (uint64_t)(PF_TILES * 64);
     auto c3_mode = [&](int nq) -> int {
       if (c->tune.count_kernel == 1 || c->uniform_len == 0 || lmax0 > max_cycle || lmax0 > 1022) return 0;
       int rsw3 = 0, rlog3 = 0;
       size_t dyn3 = 0;
       const bool all_fits = count3_plan(c->n_cov, nq, lmax0, &rsw3, &rlog3, &dyn3, c->tune.count3_rlog) == 0;
       if (all_fits && (rlog3 >= 3 || c->n_cov == 1) && c->tune.count_kernel != 3) return 1;
-      if (c->n_cov > 1 && (int)ncs <= CO_MAXCOV && c->tune.count_kernel != 2 && count3_plan(1, nq, lmax0, &rsw3, &rlog3, &dyn3, c->tune.count3_rlog) == 0) return 2;
+      if (c->n_cov > 1 && c->tune.count_kernel != 2 && count3_plan(1, nq, lmax0, &rsw3, &rlog3, &dyn3, c->tune.count3_rlog) == 0) return 2;
       return all_fits ? 1 : 0;
     };
     int nq0 = 0;
     for (int q = 6; q < ELP_NQUAL; q++) nq0 += (int)((q < 64 ? (c->qual_present[0] >> q) : (c->qual_present[1] >> (q - 64))) & 1ull);
     int mode = c3_mode(std::max(nq0, 1));
     BqRec *recs = nullptr;
-    uint64_t cap_s = cap_s1;
-    auto rec_buffers = [&]() -> int {  // class-1 segments | the other region | (mode 2) the other region sorted by covariate
-      cap_s = mode == 2 ? cap_s1 * ncs : cap_s1;
+    uint64_t other_at = 0;  // first slot of the other region = the class-1 area's capacity
+    uint32_t nseg = C3_NSEG;
+    // class-1 segments | the other region | (mode 2) the other region sorted by covariate; the counters and the segments' first slots
+    auto rec_buffers = [&]() -> int {
+      nseg = mode == 2 ? nseg2 : (uint32_t)C3_NSEG;
+      other_at = mode == 2 ? n : (uint64_t)C3_NSEG * cap_s1;
       recs = nullptr;
-      if (mode) ELP_TRY(scratch(c, 4, (size_t)C3_NSEG * cap_s + (mode == 2 ? 2 : 1) * (size_t)n + 64, &recs));
+      if (!mode) return 0;
+      ELP_TRY(scratch(c, 4, (size_t)other_at + (mode == 2 ? 2 : 1) * (size_t)n + 64, &recs));
+      ELP_HIP(c, hipMemsetAsync(rec_cnt, 0, (size_t)(C3_MAXSEG + 1) * C3_CSTRIDE * sizeof(uint32_t), st));
+      if (mode == 2) {
+        ELP_HIP(c, hipMemsetAsync(seg_cap, 0, (size_t)C3_MAXSEG * sizeof(uint32_t), st));
+        ELP_LAUNCH(c, "bqsr_seg_hist", k_c3_seg_hist, dim3(pf_grid), dim3(256), 0, n, (const uint16_t *)c->rgid.p, (const uint16_t *)c->rg_cov.p, nseg / ncs, ncs, seg_cap);
+      }
+      ELP_LAUNCH(c, "bqsr_seg_offsets", k_c3_seg_offsets, dim3(1), dim3(1), 0, (const uint32_t *)seg_cap, nseg, mode == 2 ? 0u : (uint32_t)cap_s1, seg_base);
       return 0;
     };
+    if ((uint64_t)C3_NSEG * cap_s1 + 2 * n >= 0xFFFFFFF0ull) return set_error(c, ELP_ERR_UNSUPPORTED, "BQSR: more than ~1.4 G records per context");
     ELP_TRY(rec_buffers());
     // the three prologue passes; with `r` they leave 32-byte records for count3.hip, without it the descriptors of k_bqsr_count
     auto run_prologues = [&](BqRec *r) -> int {
-      const RecOut ro{r, rec_cnt, cap_s, (r && mode == 2) ? ncs : 0u};
+      const RecOut ro{r, rec_cnt, seg_base, other_at, nseg, (r && mode == 2) ? ncs : 0u};
       ELP_LAUNCH(c, "bqsr_prologue_fast", k_bqsr_prologue_fast, dim3(pf_grid), dim3(256), 0, m, desc, skipbits, queue + 4, queue, c->err_flag.p, ro, plist);
       // (sized for the worst case; workgroups beyond the list's end leave at once)
       ELP_LAUNCH(c, "bqsr_prologue_plain", k_bqsr_prologue_plain, dim3(std::min<unsigned>(blocks_for(n, 256), (unsigned)c->n_cu * 16)), dim3(256), 0, m, desc, skipbits,
@@ -1595,24 +1652,43 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
       for (int q = 6; q < ELP_NQUAL; q++)
         if ((q < 64 ? (c->qual_present[0] >> q) : (c->qual_present[1] >> (q - 64))) & 1ull) quals.push_back(q);
       if (quals.empty()) quals.push_back(6);
-      // as many workgroups per CU (512 threads each) as still hold all slots in one pass; else one per CU and several passes
-      // if not even two workgroups fit: ONE workgroup of 1024 threads per CU around one table (as many waves per SIMD as two of 512)
-      int wg_per_cu = 1, qcap = 0;
+      // as many workgroups per CU (512 threads each) as still hold the rows of every covariate and quality slot in one pass; else ONE
+      // workgroup of 1024 threads per CU around one table (as many waves per SIMD as two of 512) and, if that does not hold them either,
+      // several passes: over quality subsets and - many read groups - over covariate subsets [cov0, cov0 + ncp) (a pass skips the reads of
+      // the other covariates).  The reference's tables are maps that just grow (filters/bqsr.go:467-551): any number of read groups runs.
+      int wg_per_cu = 1, qcap = 0, ncp = c->n_cov;
       bool big = false;
-      for (int w = 3; w >= 1; w--) {
-        const size_t budget = lds_cu / (size_t)w, st_lds = w == 1 ? static_lds1 : static_lds;
-        if (budget <= st_lds + 256) continue;
-        const int cap = (int)((budget - st_lds - 256) / per_slot) - CT_XROWS;  // minus the extra rows per covariate
-        if (cap >= (int)quals.size() || w == 1) { wg_per_cu = w; qcap = cap; big = w == 1; break; }
+      for (int w = 3; w >= 2; w--) {
+        const size_t budget = lds_cu / (size_t)w;
+        if (budget <= static_lds + 256) continue;
+        const int cap = (int)((budget - static_lds - 256) / per_slot) - CT_XROWS;  // minus the extra rows per covariate
+        if (cap >= (int)quals.size()) { wg_per_cu = w; qcap = cap; break; }
       }
-      if (qcap < 1) return set_error(c, ELP_ERR_UNSUPPORTED, "BQSR private tables do not fit in LDS (n_cov=%d, max read length=%d)", c->n_cov, lmax);
-      // one workgroup per CU and still several passes: observation-only cycle cells (half the bytes; mismatches by global atomics)
       bool mg = false;
       int rs_use = rs;
-      if (big && qcap < (int)quals.size()) {
-        const int rs_mg = (CT_CYC + (((17 * 2 * lmax) >> 4) >> 1) + 1 + 1) & ~1;
-        const int cap_mg = (int)((lds_cu - static_lds1 - 256) / ((size_t)c->n_cov * (size_t)rs_mg * 4)) - CT_XROWS;
-        if (cap_mg > qcap) { mg = true; rs_use = rs_mg; qcap = cap_mg; }
+      if (!qcap) {
+        big = true;
+        // rows of `rsx` words that fit -> the (covariates, quality slots) per pass with the fewest passes; 0 = not even one covariate's four rows fit
+        auto plan = [&](int rsx, int *ncp_out, int *qcap_out) -> long {
+          const long rows_fit = (long)((lds_cu - static_lds1 - 256) / ((size_t)rsx * 4));
+          long best = 0;
+          for (int k = c->n_cov; k >= 1; k--) {
+            const long qc = std::min<long>((long)quals.size(), rows_fit / k - CT_XROWS);
+            if (qc < 1) continue;
+            const long passes = (long)((c->n_cov + k - 1) / k) * (long)(((long)quals.size() + qc - 1) / qc);
+            if (!best || passes < best) { best = passes; *ncp_out = k; *qcap_out = (int)qc; }
+          }
+          return best;
+        };
+        const long passes = plan(rs, &ncp, &qcap);
+        // still several passes: observation-only cycle cells (half the bytes; mismatches by global atomics)
+        if (passes != 1) {
+          const int rs_mg = (CT_CYC + (((17 * 2 * lmax) >> 4) >> 1) + 1 + 1) & ~1;
+          int ncp_mg = 0, qcap_mg = 0;
+          const long passes_mg = plan(rs_mg, &ncp_mg, &qcap_mg);
+          if (passes_mg && (!passes || passes_mg < passes)) { mg = true; rs_use = rs_mg; ncp = ncp_mg; qcap = qcap_mg; }
+        }
+        if (qcap < 1) return set_error(c, ELP_ERR_UNSUPPORTED, "BQSR: one covariate's private table rows do not fit in LDS (max read length=%d)", lmax);
       }
       const int grid = (int)std::min<uint64_t>(nsteps, (uint64_t)wg_per_cu * (uint64_t)c->n_cu);
       if (recs) {
@@ -1625,7 +1701,6 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
           ELP_TRY(rec_buffers());
           ELP_HIP(c, hipMemsetAsync(skipbits, 0, skip_words * 4, st));
           ELP_HIP(c, hipMemsetAsync(queue, 0, 16, st));
-          ELP_HIP(c, hipMemsetAsync(rec_cnt, 0, (size_t)(C3_NSEG + 1) * C3_CSTRIDE * sizeof(uint32_t), st));
           ELP_TRY(run_prologues(recs));
         }
       }
@@ -1636,14 +1711,12 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
         QMap qm;
         memset(qm.slot, 254, sizeof qm.slot);
         for (size_t s2 = 0; s2 < quals.size(); s2++) qm.slot[quals[s2]] = (uint8_t)s2;
-        const uint4 *other = reinterpret_cast<const uint4 *>(recs) + 2 * (size_t)C3_NSEG * cap_s;  // the other region (32-byte records)
-        uint32_t *ooff = nullptr;
+        const uint4 *other = reinterpret_cast<const uint4 *>(recs) + 2 * (size_t)other_at;  // the other region (32-byte records)
+        const uint32_t *n_other = rec_cnt + (size_t)nseg * C3_CSTRIDE;
+        ELP_HIP(c, hipMemsetAsync(cw, 0, (3 * CO_MAXCOV + 1) * sizeof(uint32_t), st));
+        uint32_t *ooff = cw + CO_MAXCOV;
         if (mode == 2) {
-          // the other region sorted by covariate (behind it), offsets per covariate
-          uint32_t *cw = rec_cnt + (size_t)(C3_NSEG + 1) * C3_CSTRIDE;  // [CO_MAXCOV] counts | [CO_MAXCOV + 1] offsets | [CO_MAXCOV] cursors
-          ooff = cw + CO_MAXCOV;
-          ELP_HIP(c, hipMemsetAsync(cw, 0, (3 * CO_MAXCOV + 1) * sizeof(uint32_t), st));
-          const uint32_t *n_other = rec_cnt + (size_t)C3_NSEG * C3_CSTRIDE;
+          // the other region sorted by covariate (behind it), counts and offsets per covariate
           uint4 *sorted = const_cast<uint4 *>(other) + 2 * (size_t)n;
           const unsigned og = blocks_for(n, CO_TILE);  // (launched for the worst case; blocks behind the region's end leave at once)
           ELP_LAUNCH(c, "bqsr_other_hist", k_c3_other_hist, dim3(og), dim3(256), 0, other, n_other, cw);
@@ -1651,24 +1724,31 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
           ELP_LAUNCH(c, "bqsr_other_scatter", k_c3_other_scatter, dim3(og), dim3(256), 0, other, n_other, ooff + CO_MAXCOV + 1, sorted);
           other = sorted;
         }
-        Count3Args A3{rec_cnt, cap_s, 0, mode == 2 ? (int)ncs : 0, ooff, other, c->uniform_len, c->qual.p, c->seq4.p + elp_ctx::SEQ_FRONT,
-                      reinterpret_cast<const uint8_t *>(skipbits), reinterpret_cast<const uint4 *>(recs), reinterpret_cast<const uint4 *>(desc), c->cigar.p, cs_pool,
+        // launch 1: the reads that are one run of matches, in the class-1 segments; launch 2: the others (indels, clipped windows,
+        // descriptors) - one segment (its first slot: the zero in front of the offsets... ooff[0], cleared above), or one per covariate
+        Count3Args A3{rec_cnt, (uint32_t)C3_CSTRIDE, seg_base, reinterpret_cast<const uint4 *>(recs), nseg, 0, mode == 2 ? (int)ncs : 0, c->uniform_len, c->qual.p,
+                      c->seq4.p + elp_ctx::SEQ_FRONT, reinterpret_cast<const uint8_t *>(skipbits), reinterpret_cast<const uint4 *>(desc), c->cigar.p, cs_pool,
                       c->d_ref_seq.p, c->d_ref_seq_len.p, c->n_cov, (int)quals.size(), lmax, max_cycle, rsw3, rlog3, tb + nq, tb + nq + nc, c->err_flag.p};
-        ELP_TRY(count3_launch(c, A3, qm, dyn3));  // the reads that are one run of matches, segment by segment
+        ELP_TRY(count3_launch(c, A3, qm, dyn3));
         A3.other = 1;
-        ELP_TRY(count3_launch(c, A3, qm, dyn3));  // the others (indels, clipped windows, descriptors), one region (or one per covariate)
+        A3.srecs = other;
+        A3.seg_base = ooff;
+        if (mode == 2) { A3.seg_cnt = cw; A3.cnt_stride = 1; A3.nseg = ncs; }
+        else { A3.seg_cnt = n_other; A3.cnt_stride = 1; A3.nseg = 1; }
+        ELP_TRY(count3_launch(c, A3, qm, dyn3));
         goto counted;
       }
+      for (int cov0 = 0; cov0 < c->n_cov; cov0 += ncp)
       for (size_t q0 = 0; q0 < quals.size(); q0 += (size_t)qcap) {
-        const int nqs = (int)std::min<size_t>((size_t)qcap, quals.size() - q0);
+        const int nqs = (int)std::min<size_t>((size_t)qcap, quals.size() - q0), ncov_pass = std::min(ncp, c->n_cov - cov0);
         QMap qm;
         memset(qm.slot, 254, sizeof qm.slot);
         for (int q : quals) qm.slot[q] = 255;
         for (int s = 0; s < nqs; s++) qm.slot[quals[q0 + s]] = (uint8_t)s;
-        const size_t dyn = ((size_t)c->n_cov * (nqs + CT_XROWS) * rs_use + CT_PAD) * 4;
+        const size_t dyn = ((size_t)ncov_pass * (nqs + CT_XROWS) * rs_use + CT_PAD) * 4;
         CountArgs A{n, c->qual_bytes, c->qual_off.p, c->seq_off.p, c->qual.p, c->seq4.p, desc, c->cigar.p, cs_pool,
-                    reinterpret_cast<const uint8_t *>(skipbits), c->d_ref_seq.p, c->d_ref_seq_len.p, c->n_ref, c->n_cov, nqs, lmax, rs_use, max_cycle,
-                    tb + nq, tb + nq + nc, c->err_flag.p, c->tile_first.p};
+                    reinterpret_cast<const uint8_t *>(skipbits), c->d_ref_seq.p, c->d_ref_seq_len.p, c->n_ref, ncov_pass, nqs, lmax, rs_use, max_cycle,
+                    tb + nq, tb + nq + nc, c->err_flag.p, c->tile_first.p, cov0};
         const bool ref_lds = c->n_ref <= REF_LDS;
 #define ELP_COUNT_LAUNCH(CC, RL)                                                                                                              \
   do {                                                                                                                                        \
@@ -1820,7 +1900,7 @@ int elp_bqsr_tables_fetch(elp_ctx *c, int64_t *qual_tbl, int64_t *cycle_tbl, int
 }
 
 
-// Distinct rows of the resident part of the dense LUT (three small kernels): wk = slots | slot ids | row -> slot | t1 | t2 | counter.
+// Distinct rows of the resident part of the dense LUT (three small kernels): wk = counters | slots | slot ids | row -> slot | t1 | t2.
 struct LutDict { uint32_t *slots, *slot_id, *row_slot, *counter; uint16_t *t1; uint8_t *t2; uint32_t n_slots; size_t n_rows, n1; };
 constexpr uint32_t LUT_T2_CAP = 3855;  // 16-bit byte offsets
 static size_t lut_dict_words(int n_cov, int n_qi, int lmax, uint32_t *n_slots_out) {
@@ -1828,28 +1908,38 @@ static size_t lut_dict_words(int n_cov, int n_qi, int lmax, uint32_t *n_slots_ou
   uint32_t n_slots = 1024;
   while (n_slots < 2 * n_rows) n_slots <<= 1;
   *n_slots_out = n_slots;
-  return (size_t)2 * n_slots + n_rows + n1 + (size_t)(LUT_T2_CAP + 1) * 5 + 64 + 16;
+  const size_t t2_bytes = std::max<size_t>((size_t)(LUT_T2_CAP + 1) * 17, (size_t)n_cov * LUT_PC_ROWS * 17);  // one dictionary, or one per covariate
+  return 256 + (size_t)2 * n_slots + n_rows + n1 + t2_bytes / 4 + 64 + 16;
 }
 static LutDict lut_dict_layout(uint32_t *wk, int n_cov, int n_qi, int lmax, uint32_t n_slots) {
   const size_t w = 2 * (size_t)lmax + 1, n_rows = (size_t)n_cov * (size_t)std::max(n_qi, 0) * w, n1 = (size_t)n_cov * (size_t)(n_qi + 1) * w;
   LutDict D;
   D.n_slots = n_slots; D.n_rows = n_rows; D.n1 = n1;
-  D.counter = wk;  // (own word: the err_flag mailbox other stages use is not touched from the upload thread)
-  D.slots = wk + 16; D.slot_id = D.slots + n_slots; D.row_slot = D.slots + 2 * (size_t)n_slots;
+  D.counter = wk;  // [256] (own words: the err_flag mailbox other stages use is not touched from the upload thread)
+  D.slots = wk + 256; D.slot_id = D.slots + n_slots; D.row_slot = D.slots + 2 * (size_t)n_slots;
   D.t1 = reinterpret_cast<uint16_t *>(D.row_slot + n_rows);
   D.t2 = reinterpret_cast<uint8_t *>(D.t1 + ((n1 + 1) & ~(size_t)1));
   return D;
 }
 // (plain launches, no profiling brackets: also called from the upload thread while the context's own stream is busy)
-static int lut_dict_build(elp_ctx *c, hipStream_t st, const LutDict &D, const uint8_t *dl, int qlo, int n_qi, int lmax, int max_cycle) {
+static int lut_dict_build(elp_ctx *c, hipStream_t st, const LutDict &D, const uint8_t *dl, int qlo, int n_qi, int lmax, int max_cycle, bool per_cov) {
   ELP_HIP(c, hipMemsetAsync(D.slots, 0xFF, (size_t)D.n_slots * 4, st));
-  ELP_HIP(c, hipMemsetAsync(D.counter, 0, 4, st));
-  LutRows R{dl, c->n_cov, qlo, n_qi, lmax, max_cycle};
+  ELP_HIP(c, hipMemsetAsync(D.counter, 0, 256 * 4, st));
+  LutRows R{dl, c->n_cov, qlo, n_qi, lmax, max_cycle, per_cov ? 1 : 0};
+  const uint32_t cap = per_cov ? LUT_PC_ROWS : LUT_T2_CAP;
   hipLaunchKernelGGL(k_lut_rows_insert, dim3(blocks_for(D.n_rows, 256)), dim3(256), 0, st, R, (int)D.n_rows, D.slots, D.n_slots - 1, D.row_slot);
-  hipLaunchKernelGGL(k_lut_rows_number, dim3(blocks_for(D.n_slots, 256)), dim3(256), 0, st, R, (const uint32_t *)D.slots, D.n_slots, D.slot_id, D.counter, D.t2, LUT_T2_CAP);
-  hipLaunchKernelGGL(k_lut_rows_index, dim3(blocks_for(std::max<size_t>(D.n1, 17), 256)), dim3(256), 0, st, R, (const uint32_t *)D.row_slot, (const uint32_t *)D.slot_id,
-                     (const uint32_t *)D.counter, D.t1, D.t2, LUT_T2_CAP);
+  hipLaunchKernelGGL(k_lut_rows_number, dim3(blocks_for(D.n_slots, 256)), dim3(256), 0, st, R, (const uint32_t *)D.slots, D.n_slots, D.slot_id, D.counter, D.t2, cap);
+  hipLaunchKernelGGL(k_lut_rows_index, dim3(blocks_for(std::max<size_t>(D.n1, 17 * 256), 256)), dim3(256), 0, st, R, (const uint32_t *)D.row_slot, (const uint32_t *)D.slot_id,
+                     (const uint32_t *)D.counter, D.t1, D.t2, cap);
   ELP_HIP(c, hipGetLastError());
+  return 0;
+}
+// How apply3.hip (read sets of one length) takes a LUT: 0 not at all, 1 the level-1 tables of every covariate in one workgroup's LDS,
+// 2 split by covariate (their level 1 does not fit - many read groups -, or elp_set_tuning "apply_kernel" = 3): a workgroup holds one
+// covariate's tables at a time
+static int apply3_mode(const elp_ctx *c, int n_qi, int lmax, size_t *dyn_out) {
+  if (c->tune.apply_kernel != 3 && apply3_bytes(c->n_cov, n_qi, lmax, dyn_out) == 0) return 1;
+  if (apply3_bytes(1, n_qi, lmax, dyn_out) == 0) return 2;
   return 0;
 }
 // the resident quality range of ApplyBQSR's LDS tables, from the quality hint (-1: no quality >= 6 seen)
@@ -1901,15 +1991,16 @@ int elp_bqsr_lut_upload(elp_ctx *c, int max_cycle, const uint8_t *lut, const uin
     lut_quality_range(c, &qlo, &qhi);
     const int lmax = (int)std::max<uint32_t>(c->max_l_seq, 1);
     size_t dyn3 = 0;
-    if (qhi >= 0 && apply3_bytes(c->n_cov, qhi - 6 + 1, lmax, &dyn3) == 0) {
+    const int a3 = qhi >= 0 ? apply3_mode(c, qhi - 6 + 1, lmax, &dyn3) : 0;
+    if (a3) {
       const int n_qi = qhi - 6 + 1;  // (apply3: resident from quality 6 on)
       uint32_t n_slots = 0;
       const size_t words = lut_dict_words(c->n_cov, n_qi, lmax, &n_slots);
       if ((size_t)c->n_cov * (size_t)n_qi * (size_t)(2 * lmax + 1) < (1u << 22)) {
         ELP_TRY(ensure(c, c->lut_wk, words));
         const LutDict D = lut_dict_layout(c->lut_wk.p, c->n_cov, n_qi, lmax, n_slots);
-        ELP_TRY(lut_dict_build(c, c->copy_stream, D, c->lut_dev.p, 6, n_qi, lmax, max_cycle));
-        c->dict_qlo = 6; c->dict_nqi = n_qi; c->dict_lmax = lmax; c->dict_cycle = max_cycle; c->dict_ncov = c->n_cov;
+        ELP_TRY(lut_dict_build(c, c->copy_stream, D, c->lut_dev.p, 6, n_qi, lmax, max_cycle, a3 == 2));
+        c->dict_qlo = 6; c->dict_nqi = n_qi; c->dict_lmax = lmax; c->dict_cycle = max_cycle; c->dict_ncov = c->n_cov; c->dict_per_cov = a3 == 2;
         c->dict_ready = true;
       }
     }
@@ -1969,34 +2060,49 @@ static int bqsr_apply_impl(elp_ctx *c, int max_cycle, const uint8_t *lut, const 
       const int n_qi = qhi - qlo + 1, w = 2 * lmax + 1;
       const size_t static_lds = sizeof(FlatLds<AB::RMAX>) + (size_t)AB::RMAX * 12 + 512;
       const size_t n_rows = (size_t)c->n_cov * (size_t)std::max(n_qi, 0) * (size_t)w, n1 = (size_t)c->n_cov * (size_t)(n_qi + 1) * (size_t)w;
-      if (!chk && qhi >= 0 && lmax <= max_cycle && n1 + static_lds <= 160 * 1024 && n_rows < (1u << 22)) {
-        // distinct rows of the resident part of the LUT: built behind the LUT's upload if that was possible (elp_bqsr_lut_upload), else here
-        const bool prebuilt = !lut && c->dict_ready && c->dict_qlo == qlo && c->dict_nqi == n_qi && c->dict_lmax == lmax && c->dict_cycle == max_cycle &&
-                              c->dict_ncov == c->n_cov;
-        uint32_t n_slots = 0;
-        const size_t dict_words = lut_dict_words(c->n_cov, n_qi, lmax, &n_slots);
-        uint32_t *wk = c->lut_wk.p;
-        if (!prebuilt) ELP_TRY(scratch(c, 4, dict_words, &wk));
+      // apply3.hip first: the distinct rows of the resident part of the LUT (one dictionary, or - covariate split - one per covariate), built
+      // behind the LUT's upload if that was possible (elp_bqsr_lut_upload), else here; the number(s) of distinct rows stay on the device: if
+      // there are more than the one-byte ids hold the kernel says so and leaves without touching a byte - the next form takes over
+      size_t dyn3 = 0;
+      int a3 = (want3 && lmax <= max_cycle && n_rows < (1u << 22)) ? apply3_mode(c, n_qi, lmax, &dyn3) : 0;
+      int dict_form = 0;  // the dictionary in `wk`: 0 none, 1 one for all covariates, 2 one per covariate
+      uint32_t n_slots = 0;
+      const size_t dict_words = lut_dict_words(c->n_cov, std::max(n_qi, 0), lmax, &n_slots);
+      const bool prebuilt = !lut && c->dict_ready && c->dict_qlo == qlo && c->dict_nqi == n_qi && c->dict_lmax == lmax && c->dict_cycle == max_cycle &&
+                            c->dict_ncov == c->n_cov;
+      uint32_t *wk = c->lut_wk.p;
+      if (prebuilt) dict_form = c->dict_per_cov ? 2 : 1;
+      else if (a3 || (!chk && qhi >= 0 && lmax <= max_cycle && n1 + static_lds <= 160 * 1024 && n_rows < (1u << 22))) ELP_TRY(scratch(c, 4, dict_words, &wk));
+      while (a3) {
         const LutDict D = lut_dict_layout(wk, c->n_cov, n_qi, lmax, n_slots);
-        if (!prebuilt) ELP_TRY(lut_dict_build(c, c->stream, D, dl, qlo, n_qi, lmax, max_cycle));
+        if (dict_form != a3) {
+          c->dict_ready = false;  // (a prebuilt dictionary of the other form is overwritten)
+          ELP_TRY(lut_dict_build(c, c->stream, D, dl, qlo, n_qi, lmax, max_cycle, a3 == 2));
+          dict_form = a3;
+        }
+        ELP_TRY(apply3_launch(c, max_cycle, dl, dl + lut_bytes, D.t1, D.t2, D.counter, n_qi, lmax, dyn3, a3 == 2));
+        uint32_t e3[4];
+        ELP_TRY(fetch_err(c, e3));
+        if ((e3[0] & ~512u) != 0) return bqsr_error(c, e3[0] & ~512u);
+        if (!(e3[0] & 512u)) {
+          c->adapted = false;
+          c->have_qual_present = false;
+          return 0;
+        }
+        ELP_HIP(c, hipMemsetAsync(c->err_flag.p, 0, 4, c->stream));
+        // too many distinct rows for one dictionary: one per covariate (a covariate's rows are the n_cov-th part); else the general kernel
+        a3 = (a3 == 1 && c->n_cov > 1 && apply3_bytes(1, n_qi, lmax, &dyn3) == 0) ? 2 : 0;
+      }
+      if (!chk && qhi >= 0 && lmax <= max_cycle && n1 + static_lds <= 160 * 1024 && n_rows < (1u << 22)) {
+        const LutDict D = lut_dict_layout(wk, c->n_cov, n_qi, lmax, n_slots);
+        if (dict_form != 1) {
+          c->dict_ready = false;
+          ELP_TRY(lut_dict_build(c, c->stream, D, dl, qlo, n_qi, lmax, max_cycle, false));
+        }
         uint32_t *counter = D.counter;
         uint16_t *t1 = D.t1;
         uint8_t *t2 = D.t2;
         const uint32_t t2_cap = LUT_T2_CAP;
-        size_t dyn3 = 0;
-        if (want3 && apply3_bytes(c->n_cov, n_qi, lmax, &dyn3) == 0) {
-          // the number of distinct rows stays on the device; if there are more than the one-byte ids hold, the kernel says so and leaves
-          ELP_TRY(apply3_launch(c, max_cycle, dl, dl + lut_bytes, t1, t2, counter, n_qi, lmax, dyn3));
-          uint32_t e3[4];
-          ELP_TRY(fetch_err(c, e3));
-          if ((e3[0] & ~512u) != 0) return bqsr_error(c, e3[0] & ~512u);
-          if (!(e3[0] & 512u)) {
-            c->adapted = false;
-            c->have_qual_present = false;
-            return 0;
-          }
-          ELP_HIP(c, hipMemsetAsync(c->err_flag.p, 0, 4, c->stream));
-        }
         uint32_t n_dict = 0;
         ELP_HIP(c, hipMemcpyAsync(&n_dict, counter, 4, hipMemcpyDeviceToHost, c->stream));
         ELP_HIP(c, hipStreamSynchronize(c->stream));

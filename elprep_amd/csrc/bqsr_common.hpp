@@ -158,19 +158,31 @@ enum : uint32_t { RC_REV = 1u << 8, RC_PAR = 1u << 9, RC_NEG = 1u << 10, RC_MULT
 // Where the records go (round 3): only reads that take part in the count get one, COMPACTED - the count kernel then spends no lane on a
 // duplicate / unmapped / filtered read (one read in ten on the bench workload), and the reads whose blocks need the piece logic, the
 // skip column or the descriptor ("other": class 2) sit apart from the reads that are one run of matches (class 1), so that no wave
-// runs the long path for the sake of one lane.  Class 1 records fill C3_NSEG segments of `cap_s` records each (a wave of the first
-// prologue pass appends to segment wave % C3_NSEG with one atomic per tile: a single counter would serialise), class 2 records one region
-// behind them.  The read's staging index travels in spare bits of the record.
-constexpr int C3_NSEG = 64;
+// runs the long path for the sake of one lane.  Class 1 records fill `nseg` segments (a wave of the first prologue pass appends to
+// segment wave % nseg with one atomic per tile: a single counter would serialise), class 2 records one region behind them.  The read's
+// staging index travels in spare bits of the record.
+// Round 5: the segments' first slots come from a device array (`seg_base`) instead of a fixed stride.  Without the covariate split they
+// are a fixed stride apart as before; with it (ncs > 0) they are the prefix sums of an exact count of the reads each segment can receive
+// (k_c3_seg_hist: the prologue's wave -> segment mapping applied to the RGID column), so the class-1 area is n records whatever the
+// number of read groups - the fixed stride had to hold the worst case per segment, ncs * n records in all: 100 GB for 64 read groups and
+// 50 M reads.  nseg = max(64, ncs): up to 256 segments, i.e. any number of read-group covariates a u8 holds.
+constexpr int C3_NSEG = 64;       // segments without the covariate split; the least with it
+constexpr int C3_MAXSEG = 256;
 constexpr int C3_CSTRIDE = 64;  // words between two counters: every counter in a 256-byte line of its own (one line = one L2 channel would serialise them all)
 struct RecOut {
   BqRec *recs;     // nullptr: descriptors are written instead (general count kernel)
-  uint32_t *cnt;   // [s * C3_CSTRIDE], s < C3_NSEG: records in segment s; [C3_NSEG * C3_CSTRIDE]: records in the "other" region
-  uint64_t cap_s;  // capacity of a segment; the other region starts at C3_NSEG * cap_s
-  uint32_t ncs;    // 0: a segment holds records of every covariate.  > 0 (a power of two <= C3_NSEG): segment s holds records of covariate
-                   // s % ncs only (a wave appends to segment (wave % (C3_NSEG / ncs)) * ncs + covariate): a workgroup of the count kernel
-                   // then meets ONE covariate and its private table needs that covariate's rows only
+  uint32_t *cnt;   // [s * C3_CSTRIDE], s < nseg: records in segment s; [nseg * C3_CSTRIDE]: records in the "other" region
+  const uint32_t *seg_base;  // [nseg] first record slot of segment s
+  uint64_t other_at;  // first record slot of the other region
+  uint32_t nseg;   // 64, 128 or 256
+  uint32_t ncs;    // 0: a segment holds records of every covariate.  > 0 (a power of two <= nseg): segment s holds records of covariate
+                   // s % ncs only (a wave appends to segment (wave % (nseg / ncs)) * ncs + covariate): a workgroup of the count kernel
+                   // then meets ONE covariate at a time and its private table needs that covariate's rows only
 };
+// the wave of k_bqsr_prologue_fast that handles staged record i (its workgroups take PF_TILES * 256 consecutive records, thread t of a
+// workgroup the records t, t + 256, ...): what k_c3_seg_hist applies to the RGID column to size the covariate-split segments exactly
+constexpr int PF_TILES = 16;
+__host__ __device__ inline uint32_t pf_wave_of_record(uint64_t i) { return (uint32_t)(i / (uint64_t)(PF_TILES * 256)) * 4u + (uint32_t)((i & 255u) >> 6); }
 __device__ __forceinline__ void rec_pack_idx(BqRec &r, uint32_t idx) {
   r.ref_hi = (r.ref_hi & 0xFFFFu) | (idx << 16);
   r.fl = (r.fl & ~(0x3FFu << 14)) | (((idx >> 16) & 0x3FFu) << 14);
@@ -288,16 +300,21 @@ __device__ inline BqRec make_rec(int a, int len, int left, int right, uint32_t c
 
 // ---- the count kernel for read sets of one length (count3.hip)
 struct Count3Args {
-  const uint32_t *cnt;  // records per segment / in the other region (RecOut)
-  uint64_t cap_s;
-  int other;            // 0: the class-1 segments (the grid is a multiple of C3_NSEG: workgroup w works on segment w % C3_NSEG), 1: the other region
-  int ncs;              // RecOut.ncs: > 0 = workgroup w counts covariate (w % C3_NSEG) % ncs only; the other region is then sorted by covariate:
-  const uint32_t *ooff; // [17] record offsets of the covariates inside the (sorted) other region
-  const uint4 *orecs;   // the other region's records (sorted by covariate if ncs > 0)
+  // The records of a launch lie in `nseg` segments of one array: the class-1 segments (RecOut), or the other region - one segment, or,
+  // with the covariate split, one per covariate (the region sorted by covariate).  The workgroups share the launch's trips evenly,
+  // whatever the segments' sizes (a workgroup takes a contiguous range of the concatenated segments' trips and meets one segment after
+  // the other): read groups of very different sizes, or fewer covariates than segments, leave nobody idle.
+  const uint32_t *seg_cnt;   // records in segment s: seg_cnt[s * cnt_stride]
+  uint32_t cnt_stride;
+  const uint32_t *seg_base;  // first record of segment s in srecs
+  const uint4 *srecs;        // the record array of this launch (32-byte records)
+  uint32_t nseg;
+  int other;            // 0: the class-1 segments, 1: the other region
+  int ncs;              // RecOut.ncs: > 0 = segment s holds covariate s % ncs only
   uint32_t len;  // every staged read has this many bases (SEQ and QUAL)
   const uint8_t *qual, *seq4;  // seq4: first SEQ byte of read 0
   const uint8_t *skipbits;
-  const uint4 *recs, *desc;
+  const uint4 *desc;
   const uint32_t *cigar, *cig_scratch;
   uint8_t *const *ref_seq;
   const int64_t *ref_seq_len;
@@ -311,6 +328,6 @@ int count3_launch(elp_ctx *c, const Count3Args &A, const QMap &qm, size_t dyn);
 // ---- ApplyBQSR for read sets of one length (apply3.hip)
 int apply3_bytes(int n_cov, int n_qi, int lmax, size_t *dyn_out);
 int apply3_launch(elp_ctx *c, int max_cycle, const uint8_t *d_lut, const uint8_t *d_cov_present, const uint16_t *t1, const uint8_t *t2, const uint32_t *n_dict_dev,
-                  int n_qi, int lmax, size_t dyn);
+                  int n_qi, int lmax, size_t dyn, bool split /* records sorted by covariate, per-covariate row dictionaries */);
 
 }  // namespace elp

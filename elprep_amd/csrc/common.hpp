@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/elprep_hip.h"
+#include "../../include/elprep_hip_debug.h"
 
 namespace elp {
 
@@ -169,6 +170,7 @@ struct elp_ctx {
   // are known at that time; elp_bqsr_apply uses it if they still hold
   elp::DVec<uint32_t> lut_wk;
   bool dict_ready = false;
+  bool dict_per_cov = false;  // the prebuilt dictionary is one per covariate (apply3's covariate split)
   int dict_qlo = 0, dict_nqi = 0, dict_lmax = 0, dict_cycle = 0, dict_ncov = 0;
   hipEvent_t tables_ev = nullptr;  // recorded on `stream` behind the last writer of dev_tables (gather, tables_add, all-reduce): elp_bqsr_tables_fetch
                                    // copies on copy_stream behind it, so the context's stream is free for the next stage meanwhile
@@ -183,8 +185,8 @@ struct elp_ctx {
 
   // elp_set_tuning: kernel choices a caller (tests, A/B measurements) can pin; 0 = the library decides
   struct Tuning {
-    int count_kernel = 0;      // 1: the general count kernel even where the one-length kernel applies
-    int apply_kernel = 0;      // 1: the general apply kernel
+    int count_kernel = 0;      // 1: the general count kernel even where the one-length kernel applies; 2: never split by covariate; 3: always
+    int apply_kernel = 0;      // 1: the general apply kernel; 3: the one-length kernel split by covariate even where one table holds them all
     int count3_rlog = -1;      // >= 0: log2 of the context-cell replication of the one-length count kernel
     int qual_hint = 0;         // 1: no sampled quality hint (tables sized for every quality); 2: hint without the value qual_hint_drop
     int qual_hint_drop = -1;
@@ -196,6 +198,7 @@ struct elp_ctx {
     int radix_tile = 0;        // 1: radix passes in tiles of 4096 keys whatever the length; 2: of 8192 (default: 8192 from 8 M keys on)
     int sort_pairs = 0;        // 1: the coordinate sort moves (key, index) pairs even where key << b | index fits one word
     int tie_rounds = 0;        // 1: the sort's long runs by LSD rounds over every live position (no key-then-compare shortcut)
+    int exchange_piece = 0;    // > 0: records per piece of elp_exchange_records (tests: several pieces on small inputs)
   } tune;
 
   // generic scratch pool (grown on demand, reused between calls)

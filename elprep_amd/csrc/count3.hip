@@ -104,7 +104,6 @@ struct Count3 {
   const uint8_t *__restrict__ qual;
   const uint8_t *__restrict__ seq_m1;  // SEQ column minus one byte (the window of a block starts one byte in front of it)
   const uint8_t *__restrict__ skipbits;
-  const uint4 *__restrict__ recs;
   const uint4 *__restrict__ desc;
   const uint32_t *__restrict__ cigar;
   const uint32_t *__restrict__ cig_scratch;
@@ -352,7 +351,7 @@ __global__ __launch_bounds__(C3_NT) void k_bqsr_count3(Count3Args A, QMap qm) {
   }
   __syncthreads();
   Count3<RLOG, OTHER> B;
-  B.qual = A.qual; B.seq_m1 = A.seq4 - 1; B.skipbits = A.skipbits; B.recs = A.recs; B.desc = A.desc; B.cigar = A.cigar; B.cig_scratch = A.cig_scratch;
+  B.qual = A.qual; B.seq_m1 = A.seq4 - 1; B.skipbits = A.skipbits; B.desc = A.desc; B.cigar = A.cigar; B.cig_scratch = A.cig_scratch;
   B.ref_seq = A.ref_seq; B.ref_seq_len = A.ref_seq_len; B.cycle_tbl = A.cycle_tbl; B.ctx_tbl = A.ctx_tbl;
   B.n_cov = A.n_cov; B.n_q = A.n_q; B.lmax = A.lmax; B.max_cycle = A.max_cycle; B.rsw = A.rsw;
   B.qrow_at = lds_address(qrow); B.spread_at = lds_address(spread8); B.slot_q = slot_q; B.tbl = tbl;
@@ -362,30 +361,45 @@ __global__ __launch_bounds__(C3_NT) void k_bqsr_count3(Count3Args A, QMap qm) {
   B.two = 2u;
   asm volatile("" : "+v"(B.two));  // keep it in a register: the SDWA form takes no inline constant
   B.err = 0;
+  B.cov_fixed = A.ncs ? 0 : -1;
 
-  // A trip of a workgroup covers RPI whole records of its segment (class-1 launch: workgroup w works on segment w % C3_NSEG together with
-  // the gridDim / C3_NSEG - 1 other workgroups of that segment; the other launch: all workgroups on the one region); lane t works on block
-  // t % bpr of record slot t / bpr in every trip (the last 1024 - RPI * bpr lanes idle).
+  // A trip of a workgroup covers RPI whole records of ONE segment; lane t works on block t % bpr of record slot t / bpr in every trip (the
+  // last 1024 - RPI * bpr lanes idle).  Round 5: the launch's trips - segment after segment - are shared evenly among the workgroups: a
+  // workgroup takes a contiguous range of them and meets the segments that range crosses one after the other (with the covariate split a
+  // segment is one covariate: the private table is flushed and reused) - whatever the segments' sizes and however many there are.
   const uint32_t len = A.len, bpr = (len + 15u) >> 4, sbytes = (len + 1u) >> 1, RPI = C3_NT / bpr;
   const uint32_t slot = threadIdx.x / bpr, jb = threadIdx.x - slot * bpr;
   const bool lane_on = slot < RPI;
   B.k0 = 16u * jb;
   B.nb = len - B.k0 < 16u ? len - B.k0 : 16u;
-  // class-1 launch: workgroup w works on segment w % C3_NSEG (with A.ncs: the segment holds covariate seg % ncs only); the other launch:
-  // all workgroups on the one region - or, with A.ncs, workgroup w on covariate w % ncs's part of the region sorted by covariate
-  const uint32_t seg = OTHER ? (uint32_t)C3_NSEG : blockIdx.x % (uint32_t)C3_NSEG;
-  const uint32_t split = OTHER ? (A.ncs ? (uint32_t)A.ncs : 1u) : (uint32_t)C3_NSEG;
-  const uint32_t team = gridDim.x / split, member = blockIdx.x / split;
-  const uint32_t ocov = OTHER && A.ncs ? blockIdx.x % (uint32_t)A.ncs : 0u;
-  B.cov_fixed = A.ncs ? (int)(OTHER ? ocov : seg % (uint32_t)A.ncs) : -1;
-  const uint64_t n = OTHER ? (A.ncs ? (uint64_t)(A.ooff[ocov + 1] - A.ooff[ocov]) : (uint64_t)A.cnt[seg * (uint32_t)C3_CSTRIDE]) : (uint64_t)A.cnt[seg * (uint32_t)C3_CSTRIDE];
-  const uint64_t stride = (uint64_t)team * RPI;
-  const uint64_t n_trips = (n + stride - 1) / stride;  // every wave of the workgroup makes the same number of trips (flush barriers stay uniform)
-  const uint8_t *seg_recs = OTHER ? reinterpret_cast<const uint8_t *>(A.orecs) + (A.ncs ? (uint64_t)A.ooff[ocov] * 32u : 0u)
-                                  : reinterpret_cast<const uint8_t *>(A.recs) + (uint64_t)seg * A.cap_s * 32u;
+  // trips per segment, their exclusive prefix sums (s_pre[k] for k >= nseg = the total)
+  __shared__ uint32_t s_cnt[C3_MAXSEG], s_pre[C3_MAXSEG + 1], s_wsum[4];
+  {
+    const uint32_t my_cnt = threadIdx.x < A.nseg ? A.seg_cnt[(size_t)threadIdx.x * A.cnt_stride] : 0u;
+    const uint32_t my_trips = (my_cnt + RPI - 1u) / RPI;
+    uint32_t incl = my_trips;
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t v = __shfl_up(incl, d, 64);
+      if ((int)(threadIdx.x & 63u) >= d) incl += v;
+    }
+    if (threadIdx.x < (uint32_t)C3_MAXSEG && (threadIdx.x & 63u) == 63u) s_wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    if (threadIdx.x < (uint32_t)C3_MAXSEG) {
+      uint32_t off = 0;
+      for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) off += s_wsum[w];
+      s_cnt[threadIdx.x] = my_cnt;
+      s_pre[threadIdx.x] = off + incl - my_trips;
+      if (threadIdx.x == (uint32_t)C3_MAXSEG - 1u) s_pre[C3_MAXSEG] = off + incl;
+    }
+    __syncthreads();
+  }
+  const uint64_t trips_all = to_sgpr(s_pre[C3_MAXSEG]);
+  const uint32_t my_lo = to_sgpr((uint32_t)(trips_all * blockIdx.x / gridDim.x)), my_hi = to_sgpr((uint32_t)(trips_all * (blockIdx.x + 1ull) / gridDim.x));
   // a cycle cell (16 | 16 bits) takes at most one count per read
   const uint32_t flush_every = 30000u / (RPI + 1u) + 1u;
-  auto first_read = [&](uint64_t it) __attribute__((always_inline)) -> uint64_t { return it * stride + (uint64_t)member * RPI; };
+  uint64_t n = 0;                     // records of the current segment's part this workgroup works on ...
+  const uint8_t *seg_recs = nullptr;  // ... and the first of them
+  auto first_read = [&](uint64_t it) __attribute__((always_inline)) -> uint64_t { return it * RPI; };
   const uint32_t roff = slot * 32u;  // the lane's record inside a trip's span of the record array
   auto rec_load = [&](uint64_t it, u32x4 &za, u32x4 &zb) __attribute__((always_inline)) {
     const uint64_t r0 = first_read(it);
@@ -417,27 +431,51 @@ __global__ __launch_bounds__(C3_NT) void k_bqsr_count3(Count3Args A, QMap qm) {
   u32x4 za = (u32x4){0, 0, 0, 0}, zb = za, na = za, nb4 = za;  // record buffer in flight; record of the next trip's block
   uint32_t qlX = 0, qlY = 0, iX = 0, iY = 0;  // bit phase of the block's skip-column word; staging index of the block's read
   bool onX, onY = false;
-  rec_load(0, za, zb);
-  landed(dX, za, zb, na, nb4);
-  onX = data_load(0, na, nb4, dX, fX, qlX, iX);
-  rec_load(1, za, zb);
-  landed(dX, za, zb, na, nb4);
   uint32_t since = 0;
+  // the first segment of the range: the last one whose first trip is not behind my_lo
+  uint32_t seg = 0;
+  for (uint32_t a = 0, b = A.nseg; b - a > 1u;) {
+    const uint32_t md = (a + b) >> 1;
+    if (s_pre[md] <= my_lo) { a = md; seg = md; } else b = md;
+  }
 #pragma unroll 1
-  for (uint64_t it = 0; it < n_trips; it += 2) {
-    {  // trip it: work on X; data of trip it + 1 -> Y; record of trip it + 2 -> Z
-      onY = data_load(it + 1, na, nb4, dY, fY, qlY, iY);
-      rec_load(it + 2, za, zb);
-      if (onX) B.process(fX, iX, dX, qlX);
-      landed(dY, za, zb, na, nb4);
-      if (++since == flush_every) { B.flush(); since = 0; }
+  for (; seg < A.nseg; seg++) {
+    const uint32_t p0 = to_sgpr(s_pre[seg]);
+    if (p0 >= my_hi) break;
+    const uint32_t tr = to_sgpr(s_pre[seg + 1]) - p0, cnt_s = to_sgpr(s_cnt[seg]);
+    const uint32_t t0 = my_lo > p0 ? my_lo - p0 : 0u, t1 = my_hi - p0 < tr ? my_hi - p0 : tr;
+    if (t0 >= t1) continue;
+    const uint64_t r_first = (uint64_t)t0 * RPI, r_end = (uint64_t)t1 * RPI < (uint64_t)cnt_s ? (uint64_t)t1 * RPI : (uint64_t)cnt_s;
+    n = to_sgpr(r_end - r_first);
+    seg_recs = reinterpret_cast<const uint8_t *>(to_sgpr(reinterpret_cast<uint64_t>(A.srecs) + ((uint64_t)A.seg_base[seg] + r_first) * 32u));
+    const uint64_t n_trips = t1 - t0;  // every wave of the workgroup makes the same number of trips (flush barriers stay uniform)
+    B.cov_fixed = A.ncs ? (int)(seg & ((uint32_t)A.ncs - 1u)) : -1;
+    rec_load(0, za, zb);
+    landed(dX, za, zb, na, nb4);
+    onX = data_load(0, na, nb4, dX, fX, qlX, iX);
+    rec_load(1, za, zb);
+    landed(dX, za, zb, na, nb4);
+#pragma unroll 1
+    for (uint64_t it = 0; it < n_trips; it += 2) {
+      {  // trip it: work on X; data of trip it + 1 -> Y; record of trip it + 2 -> Z
+        onY = data_load(it + 1, na, nb4, dY, fY, qlY, iY);
+        rec_load(it + 2, za, zb);
+        if (onX) B.process(fX, iX, dX, qlX);
+        landed(dY, za, zb, na, nb4);
+        if (++since == flush_every) { B.flush(); since = 0; }
+      }
+      {  // trip it + 1: work on Y; data of trip it + 2 -> X; record of trip it + 3 -> Z
+        onX = data_load(it + 2, na, nb4, dX, fX, qlX, iX);
+        rec_load(it + 3, za, zb);
+        if (onY) B.process(fY, iY, dY, qlY);
+        landed(dX, za, zb, na, nb4);
+        if (++since == flush_every) { B.flush(); since = 0; }
+      }
     }
-    {  // trip it + 1: work on Y; data of trip it + 2 -> X; record of trip it + 3 -> Z
-      onX = data_load(it + 2, na, nb4, dX, fX, qlX, iX);
-      rec_load(it + 3, za, zb);
-      if (onY) B.process(fY, iY, dY, qlY);
-      landed(dX, za, zb, na, nb4);
-      if (++since == flush_every) { B.flush(); since = 0; }
+    if (A.ncs) {  // the next segment is another covariate: its counts go into a cleared table
+      gwait();
+      B.flush();
+      since = 0;
     }
   }
   gwait();
@@ -452,7 +490,7 @@ __global__ __launch_bounds__(C3_NT) void k_bqsr_count3(Count3Args A, QMap qm) {
 // Launch plan: one workgroup of 1024 threads per CU around one table; the context cells are replicated as often as the CU's LDS allows.
 // Returns 1 if the tables of this pass do not fit (the caller uses k_bqsr_count).
 int count3_plan(int n_cov, int n_q, int lmax, int *rsw_out, int *rlog_out, size_t *dyn_out, int force_rlog) {
-  const size_t lds_cu = 160 * 1024, static_lds = 1024 + 1024 + 96 + 256;
+  const size_t lds_cu = 160 * 1024, static_lds = 1024 + 1024 + 96 + 256 + (2 * C3_MAXSEG + 8) * 4;
   const int ncw = ((17 * 2 * lmax) >> 4) + 2;
   const size_t rows = (size_t)n_cov * (size_t)(n_q + C3_XROWS);
   for (int rlog = 5; rlog >= 1; rlog--) {
@@ -468,8 +506,8 @@ int count3_plan(int n_cov, int n_q, int lmax, int *rsw_out, int *rlog_out, size_
 }
 
 int count3_launch(elp_ctx *c, const Count3Args &A, const QMap &qm, size_t dyn) {
-  // one workgroup per CU; the class-1 launch needs a multiple of C3_NSEG workgroups (every segment the same number)
-  const int grid = A.other ? (A.ncs ? std::max(A.ncs, c->n_cu / A.ncs * A.ncs) : c->n_cu) : std::max(C3_NSEG, c->n_cu / C3_NSEG * C3_NSEG);
+  // one workgroup per CU; they share the launch's trips evenly
+  const int grid = c->n_cu;
 #define ELP_C3K(RL, OT)                                                                                                                          \
   do {                                                                                                                                           \
     ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bqsr_count3<RL, OT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)); \

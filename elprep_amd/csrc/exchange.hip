@@ -279,77 +279,128 @@ static int copy_piece(elp_ctx *dst, elp_ctx *src, const uint32_t *idx, uint64_t 
 
 // ------------------------------------------------------------------ between PROCESSES: one step of the split phase's all-to-all
 // elp_exchange_records: the records `idx` of `src` go to rank send_peer of the device group, the records rank recv_peer selected for this
-// rank in ITS matching call are appended to `dst` (either side may be absent: peer -1).  The piece is gathered on the source GPU as for
-// elp_copy_records; a 128-byte header (counts, totals, limits) is exchanged first, then the three payload blocks - fixed columns, pools,
-// scans - device to device: ncclSend / ncclRecv inside one ncclGroupStart / ncclGroupEnd per message (RCCL over xGMI), or the group's own
-// send-receive callback through page-locked memory (elp_group_set_p2p: a host with its own communicator, and the tests on one GPU).
+// rank in ITS matching call are appended to `dst` (either side may be absent: peer -1).  The records move in pieces whose columns stay
+// below 4 GiB each (as elp_copy_records: the gather's offsets are scanned in 32 bits); a piece is gathered on the source GPU as for
+// elp_copy_records.  Per piece and direction: a 160-byte header (counts, totals, limits, the sender's status, the number of pieces), an
+// 8-byte verdict back from the receiver (its destination-side checks), then - only if both are clean - the three payload blocks: fixed
+// columns, pools, scans, device to device: ncclSend / ncclRecv inside one ncclGroupStart / ncclGroupEnd per message (RCCL over xGMI), or
+// the group's own send-receive callback through page-locked memory (elp_group_set_p2p: a host with its own communicator, and the tests
+// on one GPU).  No rank returns while its peer still waits in a matching message: a failure on either side of a direction
+// travels in the header or the verdict, both sides then skip that direction's payload and its remaining pieces, and report the error.
 extern "C" int elp_exchange_records(elp_ctx *src, int send_peer, const uint32_t *idx, uint64_t n, int new_split, int tag_sr, elp_ctx *dst, int recv_peer) {
   // the context that belongs to the device group: the one of the two that has a communicator / a transport
   elp_ctx *g = (src && (src->comm || src->p2p)) ? src : ((dst && (dst->comm || dst->p2p)) ? dst : (src ? src : dst));
   if (!g || (send_peer >= 0 && (!src || (!idx && n))) || (recv_peer >= 0 && !dst)) return set_error(g, ELP_ERR_ARG, "elp_exchange_records: bad arguments");
   if (send_peer < 0) n = 0;
   if (new_split > 0xFFFF) return set_error(g, ELP_ERR_ARG, "elp_exchange_records: split id %d", new_split);
-  constexpr int HDR = 16;
+  constexpr int HDR = 20;  // 0 records, 1-5 slice totals, 6-12 limits / counts (XC_*), 13 raw kind, 14 largest raw record, 15 magic, 16 status, 17 pieces, 18 piece
   constexpr uint64_t MAGIC = 0x454c505845434847ull;
-  // ---- what goes out
-  Gathered G;
-  uint64_t h_out[HDR] = {0}, h_in[HDR] = {0};
+  uint64_t piece = 1;
+  uint64_t out_pieces = 0;
   if (send_peer >= 0) {
-    std::lock_guard<std::mutex> lk(src->stage_mu);
-    const bool raw = src->raw_n == src->n && src->n > 0;
-    if (src->raw_n && !raw) return set_error(g, ELP_ERR_UNSUPPORTED, "elp_exchange_records: some but not all records of the source hold their inflated BAM bytes");
-    if (n) ELP_TRY(gather_piece(g, src, idx, n, new_split, tag_sr, raw, &G));
-    h_out[0] = n;
-    for (int v = 0; v < XV; v++) h_out[1 + v] = G.total[v];
-    for (int k = 0; k < XC_N; k++) h_out[6 + k] = G.hc[k];
-    h_out[13] = n ? (G.raw ? 1 : 0) : 2;  // 2: no records, either kind of destination is fine
-    h_out[14] = src->max_raw_rec;
-    h_out[15] = MAGIC;
+    const uint64_t widest = std::max<uint64_t>({(uint64_t)src->max_l_seq, (uint64_t)elp_ctx::MAX_QNAME, src->max_raw_rec, 1024});
+    piece = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)(src->tune.exchange_piece > 0 ? src->tune.exchange_piece : (1 << 22)), 0xF0000000ull / widest));
+    out_pieces = std::max<uint64_t>(1, (n + piece - 1) / piece);  // (a rank without records still sends one header: the receiver learns there is nothing)
   }
-  // ---- headers
-  elp_ctx *sc = send_peer >= 0 ? src : dst, *rc = recv_peer >= 0 ? dst : src;
-  uint64_t *d_hdr;  // out | in, on the group context's device
+  uint64_t *d_hdr;  // out | in | verdict out | verdict in, on the group context's device
   ELP_HIP(g, hipSetDevice(g->device));
-  ELP_TRY(scratch(g, 7, 2 * HDR + 8, &d_hdr));
-  ELP_HIP(g, hipMemcpyAsync(d_hdr, h_out, sizeof h_out, hipMemcpyHostToDevice, g->stream));
-  ELP_HIP(g, hipStreamSynchronize(sc->stream));  // (the gather ran on the source's stream)
-  ELP_TRY(group_sendrecv(g, send_peer, d_hdr, sizeof h_out, recv_peer, d_hdr + HDR, sizeof h_in));
-  ELP_HIP(g, hipMemcpyAsync(h_in, d_hdr + HDR, sizeof h_in, hipMemcpyDeviceToHost, g->stream));
-  ELP_HIP(g, hipStreamSynchronize(g->stream));
-  (void)rc;
-  Gathered R;
-  if (recv_peer >= 0) {
-    if (h_in[15] != MAGIC) return set_error(g, ELP_ERR_DATA, "elp_exchange_records: rank %d did not send a record header (calls out of step?)", recv_peer);
-    R.n = h_in[0];
-    for (int v = 0; v < XV; v++) R.total[v] = (uint32_t)h_in[1 + v];
-    for (int k = 0; k < XC_N; k++) R.hc[k] = (uint32_t)h_in[6 + k];
-    R.raw = h_in[13] == 1;
+  ELP_TRY(scratch(g, 7, 2 * HDR + 16, &d_hdr));
+  uint64_t *d_ack = d_hdr + 2 * HDR;
+  int first_err = 0;         // the call's result: the first failure of either direction (the error text is that one's)
+  std::string first_text;
+  auto note = [&](int st) { if (st && !first_err) { first_err = st; first_text = g->err; } };
+  bool out_on = send_peer >= 0, in_on = recv_peer >= 0;
+  uint64_t in_pieces = 1;    // known from the first header
+  int in_refuse = 0;         // a piece arrived but could not be appended: the next header is answered with this verdict
+  for (uint64_t j = 0; (out_on && j < out_pieces) || (in_on && j < in_pieces); j++) {
+    const bool out_now = out_on && j < out_pieces, in_now = in_on && j < in_pieces;
+    // ---- what goes out: piece j, gathered on the source GPU
+    Gathered G;
+    uint64_t h_out[HDR] = {0}, h_in[HDR] = {0};
+    uint64_t n_j = 0;
+    if (out_now) {
+      std::lock_guard<std::mutex> lk(src->stage_mu);
+      const bool raw = src->raw_n == src->n && src->n > 0;
+      int st = 0;
+      n_j = n > j * piece ? std::min<uint64_t>(piece, n - j * piece) : 0;
+      if (src->raw_n && !raw) st = set_error(g, ELP_ERR_UNSUPPORTED, "elp_exchange_records: some but not all records of the source hold their inflated BAM bytes");
+      else if (n_j) st = gather_piece(g, src, idx + j * piece, n_j, new_split, tag_sr, raw, &G);
+      if (st) { n_j = 0; note(st); }
+      h_out[0] = n_j;
+      for (int v = 0; v < XV; v++) h_out[1 + v] = G.total[v];
+      for (int k = 0; k < XC_N; k++) h_out[6 + k] = G.hc[k];
+      h_out[13] = n_j ? (G.raw ? 1 : 0) : 2;  // 2: no records, either kind of destination is fine
+      h_out[14] = src->max_raw_rec;
+      h_out[15] = MAGIC;
+      h_out[16] = (uint64_t)(uint32_t)(-st);
+      h_out[17] = out_pieces;
+      h_out[18] = j;
+    }
+    // ---- headers
+    elp_ctx *sc = send_peer >= 0 ? src : dst;
+    ELP_HIP(g, hipSetDevice(g->device));
+    ELP_HIP(g, hipMemcpyAsync(d_hdr, h_out, sizeof h_out, hipMemcpyHostToDevice, g->stream));
+    ELP_HIP(g, hipStreamSynchronize(sc->stream));  // (the gather ran on the source's stream)
+    ELP_HIP(g, hipStreamSynchronize(g->stream));
+    ELP_TRY(group_sendrecv(g, out_now ? send_peer : -1, d_hdr, sizeof h_out, in_now ? recv_peer : -1, d_hdr + HDR, sizeof h_in));
+    ELP_HIP(g, hipMemcpyAsync(h_in, d_hdr + HDR, sizeof h_in, hipMemcpyDeviceToHost, g->stream));
+    ELP_HIP(g, hipStreamSynchronize(g->stream));
+    // ---- the receiver's checks and buffers, then its verdict back to the sender
+    Gathered R;
+    uint64_t verdict_out = 0, verdict_in = 0;
+    if (in_now) {
+      int st = 0;
+      if (in_refuse) st = in_refuse;
+      else if (h_in[15] != MAGIC || h_in[18] != j) st = set_error(g, ELP_ERR_DATA, "elp_exchange_records: rank %d did not send the header of piece %llu (calls out of step?)", recv_peer, (unsigned long long)j);
+      else if (h_in[16]) st = set_error(g, -(int)(uint32_t)h_in[16], "elp_exchange_records: rank %d failed on its side of the exchange (status %d)", recv_peer, -(int)(uint32_t)h_in[16]);
+      else {
+        if (j == 0) in_pieces = std::max<uint64_t>(1, h_in[17]);
+        R.n = h_in[0];
+        for (int v = 0; v < XV; v++) R.total[v] = (uint32_t)h_in[1 + v];
+        for (int k = 0; k < XC_N; k++) R.hc[k] = (uint32_t)h_in[6 + k];
+        R.raw = h_in[13] == 1;
+        if (R.n) {
+          std::lock_guard<std::mutex> lk(dst->stage_mu);
+          const bool dst_raw = dst->raw_n == dst->n && dst->n > 0;
+          if (dst->n + R.n > 0xFFFFFFF0ull) st = set_error(g, ELP_ERR_UNSUPPORTED, "more than 2^32-16 records per context");
+          else if ((dst->raw_n && !dst_raw) || (dst->n > 0 && dst_raw != R.raw))
+            st = set_error(g, ELP_ERR_UNSUPPORTED, "elp_exchange_records: the records that arrive and the destination's differ in whether they hold inflated BAM bytes");
+          else if (hipSetDevice(dst->device) != hipSuccess) st = set_error(g, ELP_ERR_HIP, "hipSetDevice failed");
+          else if ((st = scratch(dst, 1, gathered_fixed_bytes(R.n) + 256, &R.fx)) == 0 && (st = scratch(dst, 2, gathered_pool_bytes(R.total) + 64, &R.pool)) == 0 &&
+                   (st = scratch(dst, 3, (size_t)XV * (R.n + 1) + 16, &R.excl)) == 0)
+            (void)hipStreamSynchronize(dst->stream);
+        }
+      }
+      if (st) { R.n = 0; in_on = false; note(st); verdict_out = (uint64_t)(uint32_t)(-st); }
+    }
+    // the verdict travels against the records: to the rank I receive from, from the rank I send to
+    ELP_HIP(g, hipSetDevice(g->device));
+    ELP_HIP(g, hipMemcpyAsync(d_ack, &verdict_out, 8, hipMemcpyHostToDevice, g->stream));
+    ELP_HIP(g, hipStreamSynchronize(g->stream));
+    ELP_TRY(group_sendrecv(g, in_now ? recv_peer : -1, d_ack, 8, out_now ? send_peer : -1, d_ack + 1, 8));
+    if (out_now) {
+      ELP_HIP(g, hipMemcpyAsync(&verdict_in, d_ack + 1, 8, hipMemcpyDeviceToHost, g->stream));
+      ELP_HIP(g, hipStreamSynchronize(g->stream));
+      if (verdict_in) {
+        note(set_error(g, -(int)(uint32_t)verdict_in, "elp_exchange_records: rank %d refused the records (status %d)", send_peer, -(int)(uint32_t)verdict_in));
+      }
+      if (verdict_in || h_out[16]) { out_on = false; n_j = 0; }
+    }
+    // ---- payload: three blocks each way (a direction without records, or one that failed, sends / receives none: both ends know)
+    const int sp = (out_now && n_j) ? send_peer : -1, rp = (in_now && R.n) ? recv_peer : -1;
+    if (sp >= 0 || rp >= 0) {
+      ELP_TRY(group_sendrecv(g, sp, G.fx, n_j ? gathered_fixed_bytes(n_j) : 0, rp, R.fx, R.n ? gathered_fixed_bytes(R.n) : 0));
+      ELP_TRY(group_sendrecv(g, sp, G.pool, n_j ? gathered_pool_bytes(G.total) : 0, rp, R.pool, R.n ? gathered_pool_bytes(R.total) : 0));
+      ELP_TRY(group_sendrecv(g, sp, G.excl, n_j ? (size_t)XV * (n_j + 1) * 4 : 0, rp, R.excl, R.n ? (size_t)XV * (R.n + 1) * 4 : 0));
+      ELP_HIP(g, hipStreamSynchronize(g->stream));
+    }
     if (R.n) {
       std::lock_guard<std::mutex> lk(dst->stage_mu);
-      if (dst->n + R.n > 0xFFFFFFF0ull) return set_error(g, ELP_ERR_UNSUPPORTED, "more than 2^32-16 records per context");
-      const bool dst_raw = dst->raw_n == dst->n && dst->n > 0;
-      if ((dst->raw_n && !dst_raw) || (dst->n > 0 && dst_raw != R.raw))
-        return set_error(g, ELP_ERR_UNSUPPORTED, "elp_exchange_records: the records that arrive and the destination's differ in whether they hold inflated BAM bytes");
+      const int st = append_piece(dst, dst, R, h_in[14]);
+      // (the records of this piece have arrived; a failure to append them ends this direction with the next header's verdict)
+      if (st) { note(st); in_refuse = st; }
     }
   }
-  // ---- payload: three blocks each way (a rank without records sends / receives none: both sides know from the header)
-  if (R.n) {
-    ELP_HIP(dst, hipSetDevice(dst->device));
-    ELP_TRY(scratch(dst, 1, gathered_fixed_bytes(R.n) + 256, &R.fx));
-    ELP_TRY(scratch(dst, 2, gathered_pool_bytes(R.total) + 64, &R.pool));
-    ELP_TRY(scratch(dst, 3, (size_t)XV * (R.n + 1) + 16, &R.excl));
-    ELP_HIP(dst, hipStreamSynchronize(dst->stream));
-  }
-  const int sp = n ? send_peer : -1, rp = R.n ? recv_peer : -1;
-  if (sp >= 0 || rp >= 0) {
-    ELP_TRY(group_sendrecv(g, sp, G.fx, n ? gathered_fixed_bytes(n) : 0, rp, R.fx, R.n ? gathered_fixed_bytes(R.n) : 0));
-    ELP_TRY(group_sendrecv(g, sp, G.pool, n ? gathered_pool_bytes(G.total) : 0, rp, R.pool, R.n ? gathered_pool_bytes(R.total) : 0));
-    ELP_TRY(group_sendrecv(g, sp, G.excl, n ? (size_t)XV * (n + 1) * 4 : 0, rp, R.excl, R.n ? (size_t)XV * (R.n + 1) * 4 : 0));
-    ELP_HIP(g, hipStreamSynchronize(g->stream));
-  }
-  if (R.n) {
-    std::lock_guard<std::mutex> lk(dst->stage_mu);
-    ELP_TRY(append_piece(dst, dst, R, h_in[14]));
-  }
-  return 0;
+  if (first_err) g->err = first_text;
+  return first_err;
 }

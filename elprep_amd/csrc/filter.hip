@@ -134,6 +134,9 @@ int merge_spread_slots(elp_ctx *groups, elp_ctx *spread, uint64_t **slots_out) {
   if (!groups->sorted || !spread->sorted) return set_error(groups, ELP_ERR_ARG, "elp_merge_spread: both contexts must be coordinate-sorted");
   if (groups->device != spread->device) return set_error(groups, ELP_ERR_ARG, "elp_merge_spread: contexts on different devices");
   ELP_HIP(groups, hipSetDevice(groups->device));
+  // (a sort defers the read of its radix passes' look-back timeout bit: nothing is merged from a permutation that was flagged wrong)
+  ELP_TRY(radix_check(groups));
+  if (radix_check(spread) != 0) return set_error(groups, ELP_ERR_HIP, "elp_merge_spread: the spread context's sort failed: %s", spread->err.c_str());
   // the mapped part of the groups' output (the unmapped split is appended behind the merge, :560-576)
   const uint64_t ns = spread->n - spread->n_sr;
   uint64_t *kg, *ks, *slots;
@@ -179,7 +182,7 @@ __device__ inline int clean_cigar(const CleanCols &m, uint64_t i, uint32_t *out,
   const int32_t r = m.refid[i];
   bool clip = false;
   int32_t clip_from = 0, read_len = 0;
-  if (!(f & F_UNMAPPED) && r >= 0 && r < m.n_ref) {
+  if (!(f & F_UNMAPPED)) {
     int32_t ref_span = 0;
     for (int k = 0; k < nop; k++) {
       const uint32_t op = m.cigar[c0 + k], o = op & 15u;
@@ -187,7 +190,9 @@ __device__ inline int clean_cigar(const CleanCols &m, uint64_t i, uint32_t *out,
       if (op_consumes_ref(o)) ref_span += l;
       if (op_consumes_read(o)) read_len += l;
     }
-    const int32_t length = m.ref_len[r], end = m.pos[i] + ref_span - 1;  // Alignment.End, sam/sam-types.go:769-775
+    // referenceSequenceTable[aln.RNAME] (simple-filters.go:300): a Go map - RNAME '*' or a name the header does not have gives length 0, so
+    // a read with the mapped flag and no reference (End() > 0) is soft-clipped from its first base on
+    const int32_t length = (r >= 0 && r < m.n_ref) ? m.ref_len[r] : 0, end = m.pos[i] + ref_span - 1;  // Alignment.End, sam/sam-types.go:769-775
     if (end > length) { clip = true; clip_from = length - m.pos[i] + 1; }
   }
   if (!clip) {
@@ -234,7 +239,6 @@ __global__ __launch_bounds__(256) void k_clean_count(CleanCols m, uint32_t *__re
   if (i >= m.n) return;
   uint32_t cnt = (uint32_t)(m.cigar_off[i + 1] - m.cigar_off[i]);
   if (m.state[i] != 2) {  // (records an earlier filter removed never reach CleanSam)
-    if (m.flag[i] & F_UNMAPPED) m.mapq[i] = 0;
     bool changed;
     const int nn = clean_cigar(m, i, nullptr, &changed);
     if (nn < 0) atomicOr(&res[1], nn == -1 ? 1u : 2u);
@@ -255,6 +259,12 @@ __global__ __launch_bounds__(256) void k_clean_write(CleanCols m, const uint32_t
     const uint64_t c0 = m.cigar_off[i], c1 = m.cigar_off[i + 1];
     for (uint64_t k = c0; k < c1; k++) cigar_new[newoff[i] + (k - c0)] = m.cigar[k];
   }
+}
+// aln.MAPQ = 0 for unmapped reads - queued once the count pass has shown that no record makes the call fail (a failed call leaves the
+// columns as they were: ADVICE r4)
+__global__ __launch_bounds__(256) void k_clean_mapq(uint64_t n, const uint16_t *__restrict__ flag, const uint8_t *__restrict__ state, uint8_t *__restrict__ mapq) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && state[i] != 2 && (flag[i] & F_UNMAPPED)) mapq[i] = 0;
 }
 __global__ __launch_bounds__(256) void k_copy_u64(uint64_t n, const uint64_t *__restrict__ src, uint64_t *__restrict__ dst) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -287,8 +297,9 @@ extern "C" int elp_clean_sam(elp_ctx *c, uint64_t *n_clipped_out) {
   c->adapted = c->sorted = c->marked = false;
   if (hr[1] & 1u) return set_error(c, ELP_ERR_DATA, "Unexpected non-0 relative clipping position in CleanSam. (reference: log.Panic, filters/utils.go:93)");
   if (hr[1] & 2u) return set_error(c, ELP_ERR_UNSUPPORTED, "elp_clean_sam: a clipped CIGAR needs an operation length outside the 28 bits of a BAM CIGAR field");
+  ELP_LAUNCH(c, "clean_mapq", k_clean_mapq, dim3(blocks_for(n, 256)), dim3(256), 0, n, (const uint16_t *)c->flag.p, (const uint8_t *)c->has_sr.p, c->mapq.p);
   if (n_clipped_out) *n_clipped_out = hr[0];
-  if (!hr[0]) return 0;
+  if (!hr[0]) { ELP_HIP(c, hipStreamSynchronize(st)); return 0; }
   uint32_t total = 0;
   ELP_TRY(exclusive_scan_u32(c, newcnt, newoff, n, &total));
   uint32_t *cig_new;

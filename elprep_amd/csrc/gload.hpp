@@ -14,6 +14,9 @@ namespace elp {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
+// a wave-uniform value the compiler holds in vector registers (it came out of LDS, say) moved to scalar registers: the "s" operands below
+__device__ __forceinline__ uint32_t to_sgpr(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ uint64_t to_sgpr(uint64_t x) { return (uint64_t)to_sgpr((uint32_t)x) | ((uint64_t)to_sgpr((uint32_t)(x >> 32)) << 32); }
 // base (wave-uniform, in scalar registers) + off (32-bit, per lane)
 __device__ __forceinline__ void gload_x4(u32x4 &v, const void *sbase, uint32_t off) {
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(off), "s"(sbase) : "memory");

@@ -75,8 +75,9 @@ class Engine:
         self._pinned = []
 
     def pinned_zeros(self, shape, dtype) -> np.ndarray:
-        """a zeroed array in page-locked host memory (elp_pinned_alloc; freed by close()): the buffers the tables and the LUT travel through,
-        so that their copies run at the PCIe rate instead of through the runtime's staging of pageable memory"""
+        """a zeroed array in page-locked host memory (elp_pinned_alloc; freed by close(), which __del__ also calls: the array dies with the
+        engine - copy what must outlive it): the buffers the tables and the LUT travel through, so that their copies run at the PCIe rate
+        instead of through the runtime's staging of pageable memory"""
         nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
         ptr = self.L.elp_pinned_alloc(max(nbytes, 8))
         if not ptr:
@@ -87,6 +88,13 @@ class Engine:
         a = np.frombuffer((C.c_uint8 * max(nbytes, 8)).from_address(ptr), dtype=np.uint8)[:nbytes].view(dtype).reshape(shape)
         a[...] = 0
         return a
+
+    def pinned_release(self, a: np.ndarray):
+        """frees an array pinned_zeros handed out (nobody may touch it afterwards)"""
+        ptr = a.ctypes.data
+        if ptr in getattr(self, "_pinned", []):
+            self._pinned.remove(ptr)
+            self.L.elp_pinned_free(ptr)
 
     def __del__(self):
         try:
@@ -316,17 +324,27 @@ class Engine:
         iv = np.ascontiguousarray(np.asarray(intervals, dtype=np.int32).reshape(-1, 2))
         self._check(self.L.elp_bqsr_set_known_sites(self.h, refid, _vp(iv), iv.shape[0]))
 
-    def recalibrate(self, max_cycle: int = 500, reuse: bool = False):
-        """BaseRecalibrator tables.  reuse=True hands out the engine's own arrays (overwritten by the next call): a caller that
-        merges or finalizes right away saves the page faults of 6 MB of fresh memory per call."""
+    def _table_buffers(self, max_cycle: int, reuse: bool):
+        """the three count tables' host arrays.  reuse=True: the engine's own page-locked arrays (elp_pinned_alloc), overwritten by the next
+        call and FREED by close() - also when the engine is collected: a caller that keeps the tables past the engine copies them
+        (np.array(qt)); buffers of another shape that these replace are freed here."""
         ncyc = 2 * max_cycle + 1
         nc = self.header.n_cov
         bufs = getattr(self, "_tables", None) if reuse else None
         if bufs is None or bufs[0] != (nc, max_cycle):
+            if bufs is not None:
+                for a in bufs[1:]:
+                    self.pinned_release(a)
             mk = self.pinned_zeros if reuse else (lambda shape, dtype: np.zeros(shape, dtype=dtype))  # buffers that stay: page-locked
             bufs = ((nc, max_cycle), mk((nc, NQUAL, 2), np.int64), mk((nc, NQUAL, ncyc, 2), np.int64), mk((nc, NQUAL, NCTX, 2), np.int64))
             if reuse:
                 self._tables = bufs
+        return bufs
+
+    def recalibrate(self, max_cycle: int = 500, reuse: bool = False):
+        """BaseRecalibrator tables.  reuse=True hands out the engine's own arrays (overwritten by the next call): a caller that
+        merges or finalizes right away saves the page faults of 6 MB of fresh memory per call."""
+        bufs = self._table_buffers(max_cycle, reuse)
         _, qt, ct, xt = bufs
         self._check(self.L.elp_bqsr_gather(self.h, max_cycle, _vp(qt), _vp(ct), _vp(xt)))
         return qt, ct, xt
@@ -352,15 +370,7 @@ class Engine:
         return c.reshape(np.shape(counters))
 
     def tables_fetch(self, reuse: bool = False):
-        max_cycle = self._max_cycle
-        ncyc = 2 * max_cycle + 1
-        nc = self.header.n_cov
-        bufs = getattr(self, "_tables", None) if reuse else None
-        if bufs is None or bufs[0] != (nc, max_cycle):
-            mk = self.pinned_zeros if reuse else (lambda shape, dtype: np.zeros(shape, dtype=dtype))  # buffers that stay: page-locked
-            bufs = ((nc, max_cycle), mk((nc, NQUAL, 2), np.int64), mk((nc, NQUAL, ncyc, 2), np.int64), mk((nc, NQUAL, NCTX, 2), np.int64))
-            if reuse:
-                self._tables = bufs
+        bufs = self._table_buffers(self._max_cycle, reuse)
         _, qt, ct, xt = bufs
         self._check(self.L.elp_bqsr_tables_fetch(self.h, _vp(qt), _vp(ct), _vp(xt)))
         return qt, ct, xt

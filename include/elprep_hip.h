@@ -286,8 +286,11 @@ int elp_group_set_p2p(elp_ctx *ctx, elp_sendrecv_fn sendrecv, void *user);
  * indices, n of them) of `src` are gathered on its GPU as elp_copy_records gathers them - new_split / tag_sr as there - and sent to rank
  * send_peer of the device group; the records that rank recv_peer selected for this rank in ITS matching call are appended to `dst`.  Either
  * direction may be absent (peer -1; then src resp. dst may be NULL).  Every rank calls it world - 1 times, step s with send_peer =
- * (rank + s) % world and recv_peer = (rank - s + world) % world; src or dst must belong to the group.  No host copy of a record: a
- * 128-byte header and three device buffers per direction (fixed columns, variable-length pools, scans). */
+ * (rank + s) % world and recv_peer = (rank - s + world) % world; src or dst must belong to the group.  No host copy of a record: the
+ * records move in pieces of at most 4 M records (columns below 4 GiB each); per piece and direction a 160-byte header (with the sender's
+ * status), an 8-byte verdict back from the receiver, then three device buffers (fixed columns, variable-length pools, scans).  A failure
+ * on either side of a direction reaches the other side in the header or the verdict: both calls return an error, neither waits in a
+ * message its peer will not post. */
 int elp_exchange_records(elp_ctx *src, int send_peer, const uint32_t *idx, uint64_t n, int new_split, int tag_sr, elp_ctx *dst, int recv_peer);
 int elp_group_rank(const elp_ctx *ctx);
 int elp_group_size(const elp_ctx *ctx);
@@ -310,13 +313,6 @@ int elp_bqsr_apply(elp_ctx *ctx, int max_cycle, const uint8_t *lut, const uint8_
 int elp_bqsr_lut_upload(elp_ctx *ctx, int max_cycle, const uint8_t *lut, const uint8_t *cov_present);
 int elp_get_qual(elp_ctx *ctx, uint8_t *qual_out /* qual_bytes, staging order and offsets */);
 
-/* ---- snapshot of the two columns the path mutates (FLAG by elp_mark_duplicates, QUAL by elp_bqsr_apply) ----
- * elp_snapshot copies them aside in HBM; elp_rollback restores them and invalidates derived state (sort keys, scores,
- * duplicate tables).  Lets a host re-run the path on identical input (bench.py's timed steps; `--bqsr-tables-only`
- * style what-if runs) without re-staging over PCIe. */
-int elp_snapshot(elp_ctx *ctx);
-int elp_rollback(elp_ctx *ctx);
-
 /* ---- CleanSam (filters/simple-filters.go:292-306, `elprep filter --clean-sam`: a filter of the phase-1 pipeline, cmd/filter.go:747) ----
  * On the staged records, in front of elp_mark_duplicates: MAPQ of unmapped reads becomes 0; an alignment whose End() lies behind the
  * LN of its reference sequence is soft-clipped there by softClipEndOfRead (filters/utils.go:102-119) - with that function's arithmetic as
@@ -326,39 +322,8 @@ int elp_rollback(elp_ctx *ctx);
  * position in CleanSam."), ELP_ERR_UNSUPPORTED for a clip length that does not fit the 28 bits of a BAM CIGAR field. */
 int elp_clean_sam(elp_ctx *ctx, uint64_t *n_clipped_out);
 
-/* ---- kernel choices ----
- * The library picks its kernels from the staged data (read sets of one length, number of distinct qualities, order of the
- * mates).  Tests and A/B measurements pin a choice per context with elp_set_tuning instead of process-wide environment
- * variables; value 0 (or -1 where 0 is a value) gives the choice back to the library.  The reference has no counterpart: its
- * one code path per operator is what every choice here must reproduce bit for bit.
- *   "count_kernel"     1: general BQSR count kernel even for read sets of one length; 2: the one-length kernel with one table for all
- *                      covariates (never the covariate split); 3: the one-length kernel split by covariate wherever it applies
- *   "apply_kernel"     1: general ApplyBQSR kernel
- *   "bgzf_piece"       inflated bytes per device pass of elp_stage_bgzf (default 192 MiB)
- *   "bgzf_weak_guess"  1: elp_stage_bgzf's blocks guess their first record start blindly (every guess is then repaired: same result)
- *   "score_kernel"     1: general Phred-score / low-quality-tail kernel even for read sets of one length
- *   "count3_rlog"      >= 0: log2 of the context-cell replication of the one-length count kernel (measurements)
- *   "qual_hint"        1: no sampled quality hint (the gather sizes its tables on the report-and-retry path)
- *   "qual_hint_drop"   q >= 0: quality q is removed from the sampled hint (the kernels' no-slot paths)
- *   "pair_table_slots" cap on the LDS table slots per pair bucket of elp_mark_duplicates (a power of two >= 2; 0 = no cap): a
- *                      small value sends every bucket through the overflow path
- *   "mate_path"        1: every mate candidate is matched by the partitioned pass (hash partition + LDS tables), no neighbour
- *                      shortcut - what coordinate-ordered or shuffled input takes by itself; 2: ... by the table in HBM
- *   "radix_tile"       1: every radix pass in tiles of 4096 keys; 2: of 8192 keys; 3: of 16384 (default: by the array's length)
- *   "sort_pairs"       1: the coordinate sort moves (key, index) pairs through its passes even where key << b | index fits one word
- *   "tie_rounds"       1: the coordinate sort orders its long runs of equal coordinates (the unmapped block, pile-ups) by radix rounds
- *                      over every live name position - the path a group of > 1024 names that agree in their leading positions takes
- *                      by itself - instead of one round on the leading positions + comparison of what it leaves equal
- * Returns ELP_ERR_ARG for an unknown key or a value out of range. */
-int elp_set_tuning(elp_ctx *ctx, const char *key, int64_t value);
-
-/* ---- measurement ----
- * With profiling on, every kernel launch is bracketed by hipEvents on the ctx stream; elp_profile_get returns, per
- * kernel name, the launch count and the summed duration in milliseconds. */
-int elp_profile_enable(elp_ctx *ctx, int on);
-int elp_profile_reset(elp_ctx *ctx);
-int elp_profile_count(elp_ctx *ctx);
-int elp_profile_get(elp_ctx *ctx, int index, const char **name, uint64_t *launches, double *total_ms);
+/* Measurement and test harness entry points of the same library (snapshot / rollback of the mutable columns, pinned kernel choices, per-kernel
+ * timing) are declared in elprep_hip_debug.h: they are not part of the reference's interface and a drop-in host does not need them. */
 
 #ifdef __cplusplus
 }

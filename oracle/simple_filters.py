@@ -131,10 +131,11 @@ def clean_sam(b, ref_len):
     for i in range(b.n):
         ops = b.cigar[int(b.cigar_off[i]):int(b.cigar_off[i + 1])]
         new = ops
-        if not (b.flag[i] & 0x4) and 0 <= b.refid[i] < len(ref_len):
+        if not (b.flag[i] & 0x4):
             span = int(sum(int(c) >> 4 for c in ops if (int(c) & 15) in _REF))
             end = int(b.pos[i]) + span - 1
-            length = int(ref_len[b.refid[i]])
+            # referenceSequenceTable[aln.RNAME] (simple-filters.go:300) is a Go map: RNAME '*' or a name the header lacks gives 0
+            length = int(ref_len[b.refid[i]]) if 0 <= b.refid[i] < len(ref_len) else 0
             if end > length:
                 lst = _soft_clip_end_of_read(length - int(b.pos[i]) + 1, [(int(c) >> 4, int(c) & 15) for c in ops])
                 new = np.asarray([(l << 4) | o for l, o in lst], dtype=np.uint32)

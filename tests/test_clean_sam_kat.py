@@ -31,14 +31,21 @@ CASES = [
     (("100M", 951, 0x4, 37), ("100M", 0)),
     # reverse strand, hard clip in front (clipFrom = 40 -> 39): H consumes neither: ends at 0 < 39, pos stays 0; 60M ends at 60: 39M, S of 60 + 39
     (("5H60M", 961, 0x10, 13), ("5H39M99S", 13)),
+    # mapped flag but RNAME '*' (refid -1): the reference's map lookup gives length 0 (simple-filters.go:300); End = 0 + 10 - 1 = 9 > 0:
+    # clipFrom = 1 -> 0; the one operation ends at 10 >= 0 with relative position 0: no M piece, S of 10 + 0 (the port skipped these)
+    (("10M", 0, 0, 60, -1), ("10S", 60)),
+    # the same at POS 5: clipFrom = -4 -> -5, relative position -5: no M piece, S of 10 - 5 (what the reference writes)
+    (("10M", 5, 0, 60, -1), ("5S", 60)),
 ]
 
 
 def _batch(cases):
     recs = []
-    for k, ((cig, pos, flag, mapq), _) in enumerate(cases):
+    for k, (rec, _) in enumerate(cases):
+        cig, pos, flag, mapq = rec[:4]
+        refid = rec[4] if len(rec) > 4 else 0
         rl = sum(int(n) for n, o in re.findall(r"(\d+)([MIDNSHP=X])", cig) if o in "MIS=X")
-        recs.append(dict(qname="r%d" % k, flag=flag, refid=0, pos=pos, mapq=mapq, cigar=cig, seq="A" * rl, qual=[30] * rl, rgid=0))
+        recs.append(dict(qname="r%d" % k, flag=flag, refid=refid, pos=pos, mapq=mapq, cigar=cig, seq="A" * rl, qual=[30] * rl, rgid=0))
     return batch_from_records(recs)
 
 
@@ -51,7 +58,7 @@ def test_oracle_clean_sam_known_answers():
     out, changed = sf.clean_sam(_batch(ok), np.array([LN], np.int32))
     assert _cigars(out) == [want[0] for _, want in ok]
     assert out.mapq.tolist() == [want[1] for _, want in ok]
-    assert changed == 6
+    assert changed == 8
     bad = [c for c in CASES if c[1] is None]
     with pytest.raises(ValueError, match="Unexpected non-0 relative clipping position"):
         sf.clean_sam(_batch(bad), np.array([LN], np.int32))
@@ -68,7 +75,7 @@ def test_elp_clean_sam_known_answers():
     e = Engine(h)
     e.set_read_group_ids(rg)
     e.stage_bam(orc.bam_encode(b, rg))
-    assert e.clean_sam() == 6
+    assert e.clean_sam() == 8
     e.sort_coordinate()
     want, _ = sf.clean_sam(b, h.ref_len)
     assert _cigars(want) == [w[0] for _, w in ok]   # (the oracle's output is the hand-derived one: test above)

@@ -1,0 +1,251 @@
+"""GPU parity tests (-m gpu) of round 5, every output bit-exact against the CPU oracle through the C ABI:
+any number of read groups in BQSR gather and apply (the reference's tables are maps that just grow, filters/bqsr.go:467-551, :936-1005) -
+the general count kernel in passes over covariate subsets, the one-length count kernel on exactly-sized per-covariate segments with its
+trips shared evenly among the workgroups, ApplyBQSR split by covariate with one row dictionary per covariate."""
+import numpy as np
+import pytest
+
+import oracle as orc
+from elprep_amd.engine import BqsrTables, Engine
+from tests.test_gpu_ragged import _random_case
+from tests.test_gpu_round3 import _uniform_case
+
+pytestmark = pytest.mark.gpu
+
+QUALS7 = [2, 5, 6, 12, 23, 37, 41]
+
+
+def _gather_apply(b, h, refs, sites, tuning=None, max_cycle=500, oracle=None, chunks=2):
+    """stage, mark, gather, finalize, apply on the device; -> (tables, qual); compared with `oracle` = (flags, tables, qual) if given"""
+    e = Engine(h, tuning=tuning or {})
+    cuts = np.linspace(0, b.n, chunks + 1).astype(int)
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        if hi > lo:
+            e.stage(b.take(np.arange(lo, hi)))
+    flags = e.mark_duplicates()
+    for r in range(h.n_ref):
+        e.set_reference(r, refs[r])
+        e.set_known_sites(r, sites[r])
+    qt, ct, xt = e.recalibrate(max_cycle)
+    lut, present = BqsrTables(qt, ct, xt, max_cycle).finalize().build_lut(0)
+    qual = e.apply_bqsr(lut, present, max_cycle)
+    e.close()
+    if oracle is not None:
+        oflags, (oq, oc, ox), oqual = oracle
+        assert np.array_equal(flags, oflags), tuning
+        assert np.array_equal(ct, oc), ("cycle table", tuning)
+        assert np.array_equal(xt, ox) and np.array_equal(qt, oq), ("context / quality table", tuning)
+        assert np.array_equal(qual, oqual), ("recalibrated qualities", tuning)
+    return (qt, ct, xt), qual
+
+
+def _oracle(b, h, refs, sites, max_cycle=500):
+    oflags = orc.mark_duplicates(b, h)
+    oq, oc, ox = orc.bqsr_gather(b, h, orc.BqsrRef(refs, sites), oflags, max_cycle)
+    assert oq[..., 0].sum() > 0
+    oqual = orc.BqsrFinal(oq, oc, ox, max_cycle).apply(b, h, 0)
+    return oflags, (oq, oc, ox), oqual
+
+
+@pytest.mark.parametrize("n_cov", [17, 32, 64])
+def test_many_read_groups_ragged_reads(n_cov):
+    """ragged read lengths (adapter-trimmed data) with more read groups than one workgroup's LDS holds table rows for: round 4 returned
+    ELP_ERR_UNSUPPORTED here; the general count kernel now runs one pass per covariate subset, the general apply
+    kernel gathers from the dense LUT"""
+    b, h, refs, sites = _random_case(100 + n_cov, 6000, quals=QUALS7, n_cov=n_cov)
+    assert h.n_cov == n_cov
+    _gather_apply(b, h, refs, sites, oracle=_oracle(b, h, refs, sites))
+
+
+@pytest.mark.parametrize("n_cov,length", [(17, 150), (32, 151), (64, 100), (130, 76)])
+def test_many_read_groups_one_length(n_cov, length):
+    """read sets of one length with 17 .. 130 read groups: the one-length count kernel split by covariate (64, 128 or 256 exactly-sized
+    segments), ApplyBQSR split by covariate with per-covariate row dictionaries; and the general kernels (forced) on the same reads"""
+    b, h, refs, sites = _uniform_case(200 + n_cov, 7000, length, quals=QUALS7, n_cov=n_cov)
+    assert h.n_cov == n_cov
+    want = _oracle(b, h, refs, sites)
+    _gather_apply(b, h, refs, sites, oracle=want)
+    if n_cov <= 32:
+        _gather_apply(b, h, refs, sites, tuning={"count_kernel": 1, "apply_kernel": 1}, oracle=want, chunks=1)
+
+
+@pytest.mark.parametrize("n_cov,length,n_q", [(2, 150, 7), (4, 151, 7), (3, 33, 4), (4, 250, 12), (1, 150, 7), (5, 16, 3)])
+def test_split_forms_forced_on_few_read_groups(n_cov, length, n_q):
+    """the covariate split of both one-length kernels on read sets that would fit one table (what decides is only the LDS): same bytes"""
+    quals = [2] + list(range(6, 6 + n_q))
+    b, h, refs, sites = _uniform_case(300 + length, 6000, length, quals=quals, n_cov=n_cov)
+    want = _oracle(b, h, refs, sites)
+    for tune in ({"count_kernel": 3, "apply_kernel": 3}, {}, {"apply_kernel": 3, "count_kernel": 2}):
+        _gather_apply(b, h, refs, sites, tuning=tune, oracle=want, chunks=3)
+
+
+def test_read_groups_of_very_different_sizes():
+    """nine reads in ten belong to one read group, three read groups are empty: the split kernels' workgroups share the trips evenly
+    whatever the segments' sizes (round 4: a covariate's share of the workgroups was fixed); empty covariates have no tables"""
+    b, h, refs, sites = _uniform_case(77, 9000, 150, quals=QUALS7, n_cov=12)
+    rng = np.random.default_rng(5)
+    rg = b.rgid.copy()
+    rg[rng.random(b.n) < 0.9] = 3
+    rg[np.isin(rg, [5, 6, 7])] = 8
+    b.rgid[:] = rg
+    want = _oracle(b, h, refs, sites)
+    for tune in ({"count_kernel": 3, "apply_kernel": 3}, {}):
+        _gather_apply(b, h, refs, sites, tuning=tune, oracle=want)
+
+
+def _random_tables(h, quals, max_cycle, length, seed, spread):
+    """count tables that did not come from a gather: random observations / mismatches for the given qualities and the cycles of
+    `length`-base reads, so that the LUT has many distinct rows"""
+    rng = np.random.default_rng(seed)
+    nc = 2 * max_cycle + 1
+    qt = np.zeros((h.n_cov, 94, 2), np.int64)
+    ct = np.zeros((h.n_cov, 94, nc, 2), np.int64)
+    xt = np.zeros((h.n_cov, 94, 16, 2), np.int64)
+    for c in range(h.n_cov):
+        for q in quals:
+            obs = rng.integers(20000, 400000, 2 * length + 1)
+            mis = (obs * spread * 10.0 ** (-4.0 * rng.random(2 * length + 1))).astype(np.int64)  # error rates over four decades
+            ct[c, q, max_cycle - length:max_cycle + length + 1, 0] = obs
+            ct[c, q, max_cycle - length:max_cycle + length + 1, 1] = mis
+            ct[c, q, max_cycle, :] = 0  # cycle 0 does not exist
+            qt[c, q] = ct[c, q].sum(axis=0)
+            o = rng.integers(100, 5000, 16)
+            xt[c, q, :, 0] = o
+            xt[c, q, :, 1] = (o * rng.random(16) * spread).astype(np.int64)
+    return qt, ct, xt
+
+
+@pytest.mark.parametrize("n_q,expect", [(3, "per covariate"), (14, "general")])
+def test_apply_with_more_distinct_lut_rows_than_one_dictionary_holds(n_q, expect):
+    """a LUT whose rows are (nearly) all distinct: the one dictionary of ApplyBQSR's one-length kernel overflows its one-byte ids, the
+    kernel leaves without touching a byte and the host takes one dictionary per covariate - or, if a covariate's rows do not fit
+    either, the general kernel; the bytes are the oracle's ApplyBQSR on the same tables each time"""
+    quals = [2] + [6 + 3 * k for k in range(n_q)]
+    b, h, refs, sites = _uniform_case(55, 5000, 120, quals=quals, n_cov=4)
+    qt, ct, xt = _random_tables(h, quals[1:], 500, 120, 9, 0.5)
+    want = orc.BqsrFinal(qt, ct, xt, 500).apply(b, h, 0)
+    lut, present = BqsrTables(qt, ct, xt, 500).finalize().build_lut(0)
+    rows = lut.reshape(h.n_cov, 94, 1001, 17)[:, quals[1:], 500 - 120:500 + 121]
+    n_all = len({r.tobytes() for r in rows.reshape(-1, 17)})
+    n_per = max(len({r.tobytes() for r in rows[c].reshape(-1, 17)}) for c in range(h.n_cov))
+    assert n_all > 249
+    assert (n_per <= 249) == (expect == "per covariate"), (n_all, n_per)
+    for tune in ({}, {"apply_kernel": 3}, {"apply_kernel": 1}):
+        e = Engine(h, tuning=tune)
+        e.stage(b)
+        got = e.apply_bqsr(lut, present, 500)
+        e.close()
+        assert np.array_equal(got, want), tune
+
+
+def test_genome_with_hg38_sized_contigs():
+    """the key and window arithmetic at the REAL genome's sizes: a 249 Mbp and a 57 Mbp contig among 24 (POS needs 28
+    bits: 34 live bits in the coordinate-sort key = five radix passes; positions above 2^27; reference windows 120 MB into a packed
+    contig), reads at the very start of the contigs and hanging over their ends - every output against the oracle"""
+    from tools import synth
+    ref_len = [248_956_422] + [3000 + 100 * k for k in range(22)] + [57_227_415]
+    cfg = synth.SynthConfig(ref_len=ref_len, seed=synth.BASE_SEED + 77)
+    h = cfg.header()
+    b = synth.generate(cfg, 0, 30000)
+    rng = np.random.default_rng(3)
+    big = np.nonzero(((b.refid == 0) | (b.refid == 23)) & ((b.flag & 0x4) == 0))[0]
+    assert big.size > 40000 and int(b.pos.max()) > (1 << 27)
+    ends = rng.choice(big, 600, replace=False)
+    rl = np.asarray(ref_len, np.int64)[b.refid[ends]]
+    b.pos[ends[:400]] = (rl[:400] - rng.integers(0, 170, 400)).astype(np.int32)   # the last bases of the contig, or over its end
+    b.pos[ends[400:]] = rng.integers(1, 20, 200).astype(np.int32)                  # its first bases
+    refs = [synth.reference(cfg, r) for r in range(h.n_ref)]
+    sites = [orc.flatten(orc.sort_by_start(synth.known_sites_raw(cfg, r))) for r in range(h.n_ref)]
+    oflags = orc.mark_duplicates(b, h)
+    operm = orc.sort_coordinate(b, oflags)
+    _, octr, _ = orc.dup_metrics(b, h, operm, 100)
+    oq, oc, ox = orc.bqsr_gather(b, h, orc.BqsrRef(refs, sites), oflags, 500)
+    oqual = orc.BqsrFinal(oq, oc, ox, 500).apply(b, h, 0)
+    for tune in ({}, {"count_kernel": 1, "apply_kernel": 1}):
+        e = Engine(h, tuning=tune)
+        e.stage(b)
+        flags = e.mark_duplicates(True)
+        perm = e.sort_coordinate()
+        ctr = e.dup_metrics(100)
+        for r in range(h.n_ref):
+            e.set_reference(r, refs[r])
+            e.set_known_sites(r, sites[r])
+        qt, ct, xt = e.recalibrate(500)
+        lut, present = BqsrTables(qt, ct, xt, 500).finalize().build_lut(0)
+        qual = e.apply_bqsr(lut, present, 500)
+        e.close()
+        assert np.array_equal(flags, oflags) and np.array_equal(perm, operm) and np.array_equal(ctr, octr), tune
+        assert np.array_equal(ct, oc) and np.array_equal(xt, ox) and np.array_equal(qt, oq), tune
+        assert np.array_equal(qual, oqual), tune
+
+
+def _two_ranks(h, parts, body):
+    """two ranks as two host threads on the one GPU; the group's messages go through Python queues (elp_group_set_p2p)"""
+    import queue
+    import threading
+    chan = {(0, 1): queue.Queue(), (1, 0): queue.Queue()}
+    readers = [Engine(h), Engine(h)]
+    dests = [Engine(h), Engine(h)]
+    errors = [None, None]
+
+    def rank(r):
+        def sendrecv(sp, data, rp, nbytes):
+            if sp >= 0 and data is not None:
+                chan[(r, sp)].put(data)
+            return chan[(rp, r)].get(timeout=60) if rp >= 0 and nbytes else None
+        try:
+            readers[r].stage(parts[r])
+            readers[r].group_init_transport(r, 2, lambda v: None)
+            readers[r].group_set_p2p(sendrecv)
+            body(r, readers[r], dests[r])
+        except Exception as ex:  # noqa: BLE001
+            errors[r] = ex
+    th = [threading.Thread(target=rank, args=(r,)) for r in (0, 1)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(180)
+    assert not any(t.is_alive() for t in th), "a rank still waits for its peer"
+    return readers, dests, errors
+
+
+def test_exchange_in_several_pieces_and_a_failure_that_reaches_both_ranks():
+    """elp_exchange_records moves its records in pieces (here 700 records each: rank 0 sends five pieces and receives two); and when one
+    rank's side of a step fails - an index that is no record of its source - BOTH calls return an error and neither rank hangs in a
+    message the other will never post (exchange.hip)"""
+    from elprep_amd.batch import Batch
+    from elprep_amd.engine import ElpError
+    from tests.common import dataset
+    cfg, b, h, refs, sites = dataset("tiny", 8000, 23, 0.03)
+    half = b.n // 2
+    parts = [b.take(np.arange(half)), b.take(np.arange(half, b.n))]
+    pick = [np.arange(0, 3300), np.arange(100, 1300)]
+
+    def good(r, reader, dest):
+        reader.set_tuning("exchange_piece", 700)
+        reader.exchange_records(1 - r, pick[r], dest, 1 - r)
+    readers, dests, errors = _two_ranks(h, parts, good)
+    assert errors == [None, None], errors
+    for r in (0, 1):
+        want = parts[1 - r].take(pick[1 - r])
+        ref = Engine(h)
+        ref.stage(want)
+        assert dests[r].n == want.n
+        assert np.array_equal(dests[r].mark_duplicates(True), ref.mark_duplicates(True))
+        assert np.array_equal(dests[r].sort_coordinate(), ref.sort_coordinate())
+        ref.close()
+    for e in readers + dests:
+        e.close()
+
+    def bad(r, reader, dest):
+        reader.set_tuning("exchange_piece", 700)
+        idx = pick[r].copy()
+        if r == 0:
+            idx[1500] = parts[0].n + 5  # in the third piece: two pieces arrive, then the failure
+        reader.exchange_records(1 - r, idx, dest, 1 - r)
+    readers, dests, errors = _two_ranks(h, parts, bad)
+    assert isinstance(errors[0], ElpError) and "not records of the source" in str(errors[0]), errors
+    assert isinstance(errors[1], ElpError) and "failed on its side" in str(errors[1]), errors
+    assert dests[1].n == 1400 and dests[0].n == pick[1].size  # what arrived before the failure stays; rank 1's records all reached rank 0
+    for e in readers + dests:
+        e.close()
