@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared(header):
-    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", " ", open(os.path.join(ROOT, "include", header)).read(), flags=re.S)  # declarations, not the prose around them
     return sorted(set(re.findall(r"\b(elp_[a-z0-9_]+)\s*\(", txt)))
 
 
