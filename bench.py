@@ -340,14 +340,13 @@ def main():
         for _ in range(int(rounds.item())):
             b = next(gen, None)
             tr = time.time()
-            got = sfm.route(b if b is not None else sfm.empty_batch(), gof, G, owner, comm)
+            # the split phase through the C ABI: staged into the rank's reader context, classified on the device (elp_split_classify), every
+            # record delivered device to device to the context of its split's owner (elp_copy_records / elp_exchange_records: RCCL send /
+            # receive over xGMI when every rank has its own GPU)
+            rk.route(b if b is not None else sfm.empty_batch(), gof, G, owner)
             route_s += time.time() - tr
-            ts = time.time()
-            rk.stage(0, got.local)
-            rk.stage(1, got.spread)
-            stage_s += time.time() - ts
-            n_total += int((got.local.has_sr == 0).sum()) + got.spread.n  # the tagged copies are not reads of their own
-            del b, got
+            del b
+        n_total = rk.n_reads  # the tagged copies are not reads of their own
         for r, ref, sites in refs_sites:
             rk.set_reference(r, ref)
             rk.set_known_sites(r, sites)

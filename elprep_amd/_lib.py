@@ -27,7 +27,7 @@ HIP_SYMBOLS = [
     "elp_bqsr_tables_add", "elp_bqsr_tables_allreduce", "elp_allreduce_i64",
     "elp_filter_records", "elp_clean_sam", "elp_split_classify", "elp_merge_spread",
     "elp_set_read_group_ids", "elp_pinned_alloc", "elp_pinned_free", "elp_stage_bam", "elp_emit_sorted_bam", "elp_stage_bgzf", "elp_emit_sorted_bgzf",
-    "elp_set_header_columns", "elp_stage_columns", "elp_set_read_group_ids_flat", "elp_filter_records_flat", "elp_group_probe", "elp_group_init_transport", "elp_copy_records", "elp_exchange_records", "elp_group_set_p2p", "elp_emit_merged_bam", "elp_bqsr_lut_upload",
+    "elp_set_header_columns", "elp_stage_columns", "elp_set_read_group_ids_flat", "elp_filter_records_flat", "elp_group_probe", "elp_group_init_transport", "elp_copy_records", "elp_exchange_records", "elp_group_set_p2p", "elp_group_share", "elp_emit_merged_bam", "elp_bqsr_lut_upload",
     "elp_snapshot", "elp_rollback", "elp_set_tuning", "elp_profile_enable", "elp_profile_reset", "elp_profile_count", "elp_profile_get",
 ]
 HOST_SYMBOLS = [
@@ -115,6 +115,7 @@ def hip() -> C.CDLL:
         L.elp_group_init_transport.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.elp_group_set_p2p.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.elp_exchange_records.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.elp_group_share.argtypes = [C.c_void_p, C.c_void_p]
         L.elp_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         L.elp_profile_enable.argtypes = [C.c_void_p, C.c_int]
         L.elp_profile_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]

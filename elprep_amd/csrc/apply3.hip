@@ -75,12 +75,13 @@ __global__ __launch_bounds__(256) void k_apply_cov_hist(uint64_t n, const uint16
   __shared__ uint32_t h[A3_MAXCOV];
   h[threadIdx.x] = 0;
   __syncthreads();
+  const int lane = threadIdx.x & 63;
   for (int j = 0; j < A3_RTILE / 256; j++) {
     const uint64_t i = (uint64_t)blockIdx.x * A3_RTILE + j * 256 + threadIdx.x;
-    if (i < n) {
-      const int cov = apply_read_cov(rgid[i], rg_cov, cov_present, err);
-      if (cov >= 0) atomicAdd(&h[cov], 1u);
-    }
+    const int cov = i < n ? apply_read_cov(rgid[i], rg_cov, cov_present, err) : -1;
+    // one LDS atomic per covariate that occurs in the wave (lanes adding one each to a handful of counters serialise)
+    const unsigned long long same = wave_same_mask((uint32_t)cov, cov >= 0);
+    if (same && lane == __ffsll((long long)same) - 1) atomicAdd(&h[cov], (uint32_t)__popcll(same));
   }
   __syncthreads();
   if (h[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], h[threadIdx.x]);
@@ -97,13 +98,19 @@ __global__ __launch_bounds__(256) void k_apply_records_split(uint64_t n, uint32_
   __shared__ uint32_t h[A3_MAXCOV], base[A3_MAXCOV];
   h[threadIdx.x] = 0;
   __syncthreads();
+  const int lane = threadIdx.x & 63;
   int cv[A3_RTILE / 256];
   uint32_t my[A3_RTILE / 256];
 #pragma unroll
   for (int j = 0; j < A3_RTILE / 256; j++) {
     const uint64_t i = (uint64_t)blockIdx.x * A3_RTILE + j * 256 + threadIdx.x;
     cv[j] = i < n ? apply_read_cov(rgid[i], rg_cov, cov_present, err) : -1;
-    my[j] = cv[j] >= 0 ? atomicAdd(&h[cv[j]], 1u) : 0u;
+    // the record's place among the workgroup's records of its covariate: one LDS atomic per covariate that occurs in the wave
+    const unsigned long long same = wave_same_mask((uint32_t)cv[j], cv[j] >= 0);
+    const int leader = same ? __ffsll((long long)same) - 1 : lane;
+    uint32_t at = 0;
+    if (same && lane == leader) at = atomicAdd(&h[cv[j]], (uint32_t)__popcll(same));
+    my[j] = __shfl(at, leader, 64) + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
   }
   __syncthreads();
   base[threadIdx.x] = h[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], h[threadIdx.x]) : 0u;

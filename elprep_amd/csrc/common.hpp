@@ -145,6 +145,7 @@ struct elp_ctx {
   int tables_max_cycle = 0;
   // device group (group.hip)
   void *comm = nullptr;  // ncclComm_t
+  bool comm_borrowed = false;  // elp_group_share: another context of this process owns (and destroys) it
   int (*xport)(void *, int64_t *, size_t) = nullptr;  // caller's transport instead of RCCL (elp_group_init_transport)
   void *xport_user = nullptr;
   int (*p2p)(void *, int, const void *, size_t, int, void *, size_t) = nullptr;  // caller's send-receive (elp_group_set_p2p)

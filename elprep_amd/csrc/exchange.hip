@@ -41,13 +41,15 @@ __global__ __launch_bounds__(256) void k_x_fixed(uint64_t n, const uint32_t *__r
   __syncthreads();
   const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k < n) {
-    const uint64_t i = idx[k];
+    const uint32_t iw = idx[k];
+    const bool tag_me = tag_sr == 1 || (tag_sr == 2 && (iw >> 31));  // tag_sr 2: bit 31 of an index = this copy is tagged
+    const uint64_t i = tag_sr == 2 ? (iw & 0x7FFFFFFFu) : iw;
     if (i >= s.n_src) {
       atomicAdd(&acc[XC_BAD], 1u);
       for (int v = 0; v < XV; v++) len[(size_t)v * n + k] = 0;
     } else {
       uint8_t state = s.has_sr[i];
-      if (tag_sr && state == 0) state = 1;
+      if (tag_me && state == 0) state = 1;
       const uint16_t sp = new_split >= 0 ? (uint16_t)new_split : s.split[i];
       const int32_t p = s.pos[i];
       const uint32_t ls = s.l_seq[i];
@@ -77,10 +79,10 @@ __global__ __launch_bounds__(256) void k_x_fixed(uint64_t n, const uint32_t *__r
 // one wave per record and column: the record's slice, 64 elements per step
 template <class T>
 __global__ __launch_bounds__(256) void k_x_var(uint64_t n, const uint32_t *__restrict__ idx, const uint64_t *__restrict__ src_off, const T *__restrict__ src,
-                                               const uint32_t *__restrict__ dst_off, T *__restrict__ dst, uint64_t n_src) {
+                                               const uint32_t *__restrict__ dst_off, T *__restrict__ dst, uint64_t n_src, uint32_t idx_mask) {
   const uint64_t k = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (k >= n) return;
-  const uint64_t i = idx[k];
+  const uint64_t i = idx[k] & idx_mask;
   if (i >= n_src) return;
   const uint64_t a = src_off[i], e = src_off[i + 1];
   const uint32_t o = dst_off[k];
@@ -137,6 +139,7 @@ static void pool_view(uint8_t *pool, const uint32_t *total, uint8_t **pv) {
 
 // source GPU: lengths + fixed columns, scans, slices.  err_ctx = the context an error is reported on
 static int gather_piece(elp_ctx *err_ctx, elp_ctx *src, const uint32_t *idx, uint64_t n, int new_split, int tag_sr, bool raw, Gathered *G) {
+  if (tag_sr == 2 && src->n > 0x7FFFFFFFull) return set_error(err_ctx, ELP_ERR_UNSUPPORTED, "per-record sr tags (tag_sr = 2) need a source context of at most 2^31 records");
   ELP_HIP(src, hipSetDevice(src->device));
   hipStream_t ss = src->stream;
   uint32_t *w;  // idx | len[XV][n] | excl[XV][n + 1] | counters
@@ -168,17 +171,18 @@ static int gather_piece(elp_ctx *err_ctx, elp_ctx *src, const uint32_t *idx, uin
   uint8_t *pv[XV];
   pool_view(pool, G->total, pv);
   const unsigned vgrid = blocks_for(n * 64, 256);
+  const uint32_t idx_mask = tag_sr == 2 ? 0x7FFFFFFFu : 0xFFFFFFFFu;
   hipLaunchKernelGGL(k_x_var<uint8_t>, dim3(vgrid), dim3(256), 0, ss, n, (const uint32_t *)d_idx, (const uint64_t *)src->qname_off.p, (const uint8_t *)src->qname.p,
-                     (const uint32_t *)excl, pv[0], src->n);
+                     (const uint32_t *)excl, pv[0], src->n, idx_mask);
   hipLaunchKernelGGL(k_x_var<uint32_t>, dim3(vgrid), dim3(256), 0, ss, n, (const uint32_t *)d_idx, (const uint64_t *)src->cigar_off.p, (const uint32_t *)src->cigar.p,
-                     (const uint32_t *)(excl + (n + 1)), (uint32_t *)pv[1], src->n);
+                     (const uint32_t *)(excl + (n + 1)), (uint32_t *)pv[1], src->n, idx_mask);
   hipLaunchKernelGGL(k_x_var<uint8_t>, dim3(vgrid), dim3(256), 0, ss, n, (const uint32_t *)d_idx, (const uint64_t *)src->seq_off.p, (const uint8_t *)src->seq4.p,
-                     (const uint32_t *)(excl + 2 * (n + 1)), pv[2], src->n);
+                     (const uint32_t *)(excl + 2 * (n + 1)), pv[2], src->n, idx_mask);
   hipLaunchKernelGGL(k_x_var<uint8_t>, dim3(vgrid), dim3(256), 0, ss, n, (const uint32_t *)d_idx, (const uint64_t *)src->qual_off.p, (const uint8_t *)src->qual.p,
-                     (const uint32_t *)(excl + 3 * (n + 1)), pv[3], src->n);
+                     (const uint32_t *)(excl + 3 * (n + 1)), pv[3], src->n, idx_mask);
   if (raw)
     hipLaunchKernelGGL(k_x_var<uint8_t>, dim3(vgrid), dim3(256), 0, ss, n, (const uint32_t *)d_idx, (const uint64_t *)src->raw_off.p, (const uint8_t *)src->raw.p,
-                       (const uint32_t *)(excl + 4 * (n + 1)), pv[4], src->n);
+                       (const uint32_t *)(excl + 4 * (n + 1)), pv[4], src->n, idx_mask);
   ELP_HIP(src, hipGetLastError());
   G->n = n; G->raw = raw; G->fx = fx; G->pool = pool; G->excl = excl;
   return 0;

@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256) void k_filter_records(FilterCols m, elp_predic
 __global__ __launch_bounds__(256) void k_split_classify(uint64_t n, const int32_t *__restrict__ refid, const int32_t *__restrict__ next_refid,
                                                         const int32_t *__restrict__ group_of_ref, int32_t n_ref, int32_t n_groups,
                                                         uint16_t *__restrict__ split_out, uint8_t *__restrict__ spread_out,
-                                                        unsigned long long *__restrict__ counts /* [n_groups + 2]: unmapped, groups, spread */) {
+                                                        unsigned long long *__restrict__ counts /* [n_groups + 2]: unmapped, groups, spread */,
+                                                        uint16_t *__restrict__ split_col /* the context's split-id column */) {
   extern __shared__ unsigned int lds_cnt[];
   for (int k = threadIdx.x; k < n_groups + 2; k += blockDim.x) lds_cnt[k] = 0;
   __syncthreads();
@@ -97,6 +98,7 @@ __global__ __launch_bounds__(256) void k_split_classify(uint64_t n, const int32_
     // :286: RNEXT != "=" (BAM: next_refid != refid, sam/bam-files.go:344-346), RNAME != "*", and the mate's group differs
     const bool spread = nr != r && r >= 0 && gn != g;
     split_out[i] = (uint16_t)g;
+    split_col[i] = (uint16_t)g;  // the record's split file: travels with it (elp_copy_records / elp_exchange_records keep it)
     spread_out[i] = spread ? 1 : 0;
     atomicAdd(&lds_cnt[g], 1u);
     if (spread) atomicAdd(&lds_cnt[n_groups + 1], 1u);
@@ -411,7 +413,10 @@ int elp_split_classify(elp_ctx *c, const int32_t *group_of_ref, int32_t n_groups
   if (n) {
     const unsigned grid = std::min(blocks_for(n, 256), 2048u);
     ELP_LAUNCH(c, "split_classify", k_split_classify, dim3(grid), dim3(256), nc * sizeof(unsigned int), n, (const int32_t *)c->refid.p,
-               (const int32_t *)c->next_refid.p, (const int32_t *)d_gof, c->n_ref, n_groups, d_split, d_spread, d_cnt);
+               (const int32_t *)c->next_refid.p, (const int32_t *)d_gof, c->n_ref, n_groups, d_split, d_spread, d_cnt, c->split.p);
+    // the split ids are part of every duplicate-marking key; records with equal keys share their contig, hence their split: no result changes
+    c->max_split = std::max<uint32_t>(c->max_split, (uint32_t)n_groups);
+    c->marked = false;
     if (split_out) ELP_HIP(c, hipMemcpyAsync(split_out, d_split, n * 2, hipMemcpyDeviceToHost, c->stream));
     if (spread_out) ELP_HIP(c, hipMemcpyAsync(spread_out, d_spread, n, hipMemcpyDeviceToHost, c->stream));
   }

@@ -70,8 +70,9 @@ __global__ __launch_bounds__(256) void k_add_i64(unsigned long long *__restrict_
 void group_release(elp_ctx *c) {
   if (c->comm) {
     Rccl *R = rccl();
-    if (R->CommDestroy) (void)R->CommDestroy(static_cast<ncclComm_t>(c->comm));
+    if (R->CommDestroy && !c->comm_borrowed) (void)R->CommDestroy(static_cast<ncclComm_t>(c->comm));
     c->comm = nullptr;
+    c->comm_borrowed = false;
   }
   c->xport = nullptr;  // a transport of an earlier elp_group_init_transport does not outlive the group either
   c->xport_user = nullptr;
@@ -165,6 +166,19 @@ int elp_group_set_p2p(elp_ctx *c, elp_sendrecv_fn fn, void *user) {
   if (c->comm) return set_error(c, ELP_ERR_ARG, "elp_group_set_p2p: the context belongs to an RCCL group (its send / receive are RCCL's)");
   c->p2p = fn;
   c->p2p_user = user;
+  return 0;
+}
+
+int elp_group_share(elp_ctx *c, elp_ctx *member) {
+  if (!c || !member || c == member) return ELP_ERR_ARG;
+  if (c->device != member->device) return set_error(c, ELP_ERR_ARG, "elp_group_share: the two contexts live on different devices");
+  group_release(c);
+  c->group_rank = member->group_rank;
+  c->group_world = member->group_world;
+  c->comm = member->comm;
+  c->comm_borrowed = member->comm != nullptr;
+  c->xport = member->xport; c->xport_user = member->xport_user;
+  c->p2p = member->p2p; c->p2p_user = member->p2p_user;
   return 0;
 }
 

@@ -231,10 +231,17 @@ class Engine:
         del keep
         return int(n.value)
 
-    def copy_records_from(self, src: "Engine", idx: np.ndarray, new_split: Optional[int] = None, tag_sr: bool = False):
-        """appends src's records idx (staging indices) to this context, device to device (elp_copy_records)"""
+    def copy_records_from(self, src: "Engine", idx: np.ndarray, new_split: Optional[int] = None, tag_sr=False):
+        """appends src's records idx (staging indices) to this context, device to device (elp_copy_records).  tag_sr: False / True (all
+        copies tagged sr) / 2 (the copies whose index has bit 31 set)"""
         ix = np.ascontiguousarray(idx, dtype=np.uint32)
-        self._check(self.L.elp_copy_records(self.h, src.h, _vp(ix), ix.size, -1 if new_split is None else int(new_split), 1 if tag_sr else 0))
+        self._check(self.L.elp_copy_records(self.h, src.h, _vp(ix), ix.size, -1 if new_split is None else int(new_split), int(tag_sr)))
+
+    def group_share(self, member: "Engine"):
+        """this context uses the device group of `member` (same process and device): elp_group_share"""
+        self._check(self.L.elp_group_share(self.h, member.h))
+        if getattr(member, "_p2p_cb", None) is not None:
+            self._p2p_cb = member._p2p_cb  # (keeps the callback object alive as long as either context)
 
     def group_set_p2p(self, sendrecv):
         """point-to-point messages of a transport group: sendrecv(send_peer, send: bytes or None, recv_peer, recv_bytes) -> bytes or None
@@ -254,11 +261,11 @@ class Engine:
         self._check(self.L.elp_group_set_p2p(self.h, C.cast(self._p2p_cb, C.c_void_p), C.c_void_p(0)))
 
     def exchange_records(self, send_peer: int, idx: Optional[np.ndarray], dst: Optional["Engine"], recv_peer: int, new_split: Optional[int] = None,
-                         tag_sr: bool = False):
+                         tag_sr=False):
         """one step of the split phase's all-to-all (elp_exchange_records): this context's records idx go to rank send_peer of the device
         group, what rank recv_peer sends in its matching call is appended to dst"""
         ix = np.ascontiguousarray(idx if idx is not None else np.zeros(0), dtype=np.uint32)
-        self._check(self.L.elp_exchange_records(self.h, send_peer, _vp(ix), ix.size, -1 if new_split is None else int(new_split), 1 if tag_sr else 0,
+        self._check(self.L.elp_exchange_records(self.h, send_peer, _vp(ix), ix.size, -1 if new_split is None else int(new_split), int(tag_sr),
                                                 dst.h if dst is not None else C.c_void_p(0), recv_peer))
 
     def clean_sam(self) -> int:

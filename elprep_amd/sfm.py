@@ -176,6 +176,26 @@ class Comm:
         return [out[src] if src == self.rank else recv[src].cpu().numpy() for src in range(world)]
 
 
+    def sendrecv(self, send_peer: int, data, recv_peer: int, recv_bytes: int):
+        """one message each way (either may be absent): the send-receive callback of the C ABI's device group (elp_group_set_p2p) over
+        torch.distributed - what ranks that share a GPU, and the gloo tests, route their records through"""
+        torch, dist = self.torch, self.dist
+        ops, recv = [], None
+        if send_peer >= 0 and data is not None:
+            ops.append(dist.P2POp(dist.isend, torch.frombuffer(bytearray(data), dtype=torch.uint8).to(self.device), send_peer))
+        if recv_peer >= 0 and recv_bytes:
+            recv = torch.empty(recv_bytes, dtype=torch.uint8, device=self.device)
+            ops.append(dist.P2POp(dist.irecv, recv, recv_peer))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if recv is None:
+            return None
+        if self.device.type == "cuda":
+            torch.cuda.synchronize()
+        return recv.cpu().numpy().tobytes()
+
+
 @dataclass
 class RankSplits:
     local: Batch    # records of the group splits (and the unmapped split) this rank owns, spread copies tagged has_sr
@@ -202,6 +222,48 @@ def route(b: Batch, group_of_ref: np.ndarray, n_groups: int, owner: np.ndarray, 
     lp = [unpack_batch(x) for x in got_local if x.size]
     sp = [unpack_batch(x) for x in got_spread if x.size]
     return RankSplits(Batch.concat(lp) if lp else empty_batch(), Batch.concat(sp) if sp else empty_batch())
+
+
+def route_device(reader, b: Batch, group_of_ref: np.ndarray, n_groups: int, owner: np.ndarray, rank: int, world: int, dst_local, dst_spread) -> Tuple[int, int]:
+    """The split phase through the C ABI (SplitFilePerChromosome, sam/split-merge.go:230-311): `b` is staged into the rank's READER
+    context, classified on the device (elp_split_classify: split id and spread flag per record; the ids are written to the split-id
+    column and travel with the records), and every record goes to the context of the rank that owns its split - device to device:
+    elp_copy_records inside the rank, elp_exchange_records between ranks (a ring of world - 1 steps; RCCL send / receive over xGMI when
+    every rank has its own GPU, the group's send-receive callback otherwise).  A group file's records arrive in input order, the copies
+    of reads that also go to the spread file tagged sr among them (bit 31 of the index, tag_sr = 2); the spread file's records arrive in
+    the spread owner's second context with split id 0.  The host sees three small arrays per batch (split ids, spread flags, counts) and
+    builds index lists from them - no record passes through it.  `reader` belongs to the device group (elp_group_init /
+    elp_group_share / elp_group_set_p2p).  Every rank calls this the same number of times (empty batches where it has nothing).
+    -> (live records that arrived in dst_local, records that arrived in dst_spread)"""
+    reader.reset()
+    if b.n:
+        reader.stage(b)
+    if b.n:
+        split, spread, _ = reader.split_classify(group_of_ref, n_groups)
+        spread = spread.astype(bool)
+    else:
+        split, spread = np.zeros(0, np.uint16), np.zeros(0, bool)
+    dest = owner[split] if b.n else np.zeros(0, np.int32)
+    spread_owner = int(owner[n_groups + 1])
+    n0, n1 = dst_local.n, dst_spread.n
+    for s in range(world):
+        sp, rp = (rank + s) % world, (rank - s + world) % world
+        idx = np.nonzero(dest == sp)[0].astype(np.uint32)
+        idx |= (spread[idx].astype(np.uint32) << np.uint32(31))
+        sidx = np.nonzero(spread)[0].astype(np.uint32) if sp == spread_owner else np.zeros(0, np.uint32)
+        if s == 0:
+            if idx.size:
+                dst_local.copy_records_from(reader, idx, tag_sr=2)
+            if sidx.size:
+                dst_spread.copy_records_from(reader, sidx, new_split=0)
+        else:
+            reader.exchange_records(sp, idx, dst_local, rp, tag_sr=2)
+            # the spread file: only its owner receives, everybody sends to it in the step that reaches it
+            send_to = sp if sp == spread_owner else -1
+            recv_from = rp if rank == spread_owner else -1
+            if send_to >= 0 or recv_from >= 0:
+                reader.exchange_records(send_to, sidx, dst_spread if recv_from >= 0 else None, recv_from, new_split=0)
+    return dst_local.n - n0, dst_spread.n - n1
 
 
 # ------------------------------------------------------------------------------------------------ output order
@@ -264,6 +326,8 @@ class SfmRank:
         self.n = [0, 0]
         self.allreduce_s = []  # wall time of every all-reduce call (bench.py reports the timed steps' mean)
         self._side = None      # host thread for the spread split's context (step)
+        self.reader = None     # the split phase's reader context (route)
+        self._device_ordinal = device_ordinal
         if collective is None:
             collective = os.environ.get("ELP_SFM_COLLECTIVE", "cabi" if (comm.world > 1 and comm.device.type == "cuda") else "torch")
         self.collective = collective if comm.world > 1 else "none"
@@ -293,6 +357,28 @@ class SfmRank:
         if b.n:
             self.engines[which].stage(b)
             self.n[which] += b.n
+
+    def route(self, b: Batch, group_of_ref: np.ndarray, n_groups: int, owner: np.ndarray):
+        """the split phase for one batch of input records through the C ABI (route_device): staged into the rank's reader context,
+        classified on the device, delivered device to device to the contexts of the ranks that own the splits.  Every rank calls it the
+        same number of times."""
+        from .engine import Engine
+        if self.reader is None:
+            self.reader = Engine(self.header, self._device_ordinal)
+            if self.comm.world > 1:
+                if self.collective == "cabi":
+                    self.reader.group_share(self.engines[0])  # RCCL send / receive on the communicator the tables are reduced on
+                else:
+                    self.reader.group_init_transport(self.comm.rank, self.comm.world, lambda v: None)
+                    self.reader.group_set_p2p(self.comm.sendrecv)
+        nl, ns = route_device(self.reader, b, group_of_ref, n_groups, owner, self.comm.rank, self.comm.world, self.engines[0], self.engines[1])
+        self.n[0] += nl
+        self.n[1] += ns
+
+    @property
+    def n_reads(self) -> int:
+        """reads of this rank's splits (the sr-tagged copies in the group splits are not reads of their own)"""
+        return self.engines[0].n_sorted + self.engines[1].n
 
     def set_reference(self, refid: int, bases: np.ndarray):
         for e in self.engines:
@@ -411,5 +497,8 @@ class SfmRank:
         if self._side is not None:
             self._side.shutdown()
             self._side = None
+        if self.reader is not None:
+            self.reader.close()
+            self.reader = None
         for e in self.engines:
             e.close()

@@ -180,7 +180,9 @@ int elp_filter_records_flat(elp_ctx *ctx, int remove_unmapped, int remove_unmapp
 /* ---- `elprep split` / `merge` without touching payloads on the CPU: sam/split-merge.go ----
  * elp_split_classify: SplitFilePerChromosome's routing rule (:280-293) for every staged record: split_out[i] = 0 for RNAME "*",
  *   else group_of_ref[refid] (1..n_groups, computeContigGroups :178-213 on the host); spread_out[i] = 1 if the read also goes to the
- *   spread file (mate in another group); counts_out[n_groups + 2] = records per split (unmapped, groups, spread).
+ *   spread file (mate in another group); counts_out[n_groups + 2] = records per split (unmapped, groups, spread).  The split ids are
+ *   also written to the context's split-id column (elp_batch.split), so that elp_copy_records / elp_exchange_records with new_split = -1
+ *   deliver every record with the id of its split file.
  * elp_merge_spread: MergeSortedFilesSplitPerChromosome (:410-576) as ranks: both contexts coordinate-sorted; slot_of_spread_out[j] =
  *   output slot of the j-th record of `spread`'s sorted output among `groups`' sorted output (behind every group read of its
  *   (refid, POS) and in front of the first greater one; group reads fill the remaining slots in order). */
@@ -188,8 +190,9 @@ int elp_split_classify(elp_ctx *ctx, const int32_t *group_of_ref, int32_t n_grou
 /* elp_copy_records: the write side of the same routing (:280-293 writes the record into the file of its split, and a copy tagged sr:i:1
  *   into the group file if the original goes to the spread file): appends the records idx[0 .. n) of `src` (staging indices, any order)
  *   to `dst` - two contexts of this process on one GPU or on two (device-to-device / peer copies of gathered column slices; nothing
- *   passes through the host).  new_split >= 0: the split id the copies get (else they keep theirs); tag_sr != 0: live records arrive as
- *   sr-tagged copies.  FLAG and QUAL travel as they are now; the inflated BAM records travel too if both contexts hold them
+ *   passes through the host).  new_split >= 0: the split id the copies get (else they keep theirs); tag_sr = 1: live records arrive as
+ *   sr-tagged copies; tag_sr = 2: only the records whose index has bit 31 set do (the index is its low 31 bits: one call delivers a
+ *   split file's records in input order, tagged copies among the others, as :280-293 writes them).  FLAG and QUAL travel as they are now; the inflated BAM records travel too if both contexts hold them
  *   (elp_stage_bam).  Large sets move in pieces inside the call; on an error the pieces already appended stay (elp_num_records tells). */
 int elp_copy_records(elp_ctx *dst, elp_ctx *src, const uint32_t *idx, uint64_t n, int new_split, int tag_sr);
 int elp_merge_spread(elp_ctx *groups, elp_ctx *spread, uint64_t *slot_of_spread_out);
@@ -292,6 +295,10 @@ int elp_group_set_p2p(elp_ctx *ctx, elp_sendrecv_fn sendrecv, void *user);
  * on either side of a direction reaches the other side in the header or the verdict: both calls return an error, neither waits in a
  * message its peer will not post. */
 int elp_exchange_records(elp_ctx *src, int send_peer, const uint32_t *idx, uint64_t n, int new_split, int tag_sr, elp_ctx *dst, int recv_peer);
+/* elp_group_share: `ctx` joins the device group `member` belongs to by BORROWING its communicator / transport (same process, same
+ * device; `member` must outlive the use, calls of the two contexts on the group must not overlap): the reader context of the split phase
+ * exchanges records through the group the rank's processing context reduces its tables in - one communicator per rank. */
+int elp_group_share(elp_ctx *ctx, elp_ctx *member);
 int elp_group_rank(const elp_ctx *ctx);
 int elp_group_size(const elp_ctx *ctx);
 int elp_bqsr_tables_add(elp_ctx *dst, elp_ctx *src);
