@@ -224,7 +224,8 @@ def route(b: Batch, group_of_ref: np.ndarray, n_groups: int, owner: np.ndarray, 
     return RankSplits(Batch.concat(lp) if lp else empty_batch(), Batch.concat(sp) if sp else empty_batch())
 
 
-def route_device(reader, b: Batch, group_of_ref: np.ndarray, n_groups: int, owner: np.ndarray, rank: int, world: int, dst_local, dst_spread) -> Tuple[int, int]:
+def route_device(reader, b: Batch, group_of_ref: np.ndarray, n_groups: int, owner: np.ndarray, rank: int, world: int, dst_local, dst_spread,
+                 stage=None) -> Tuple[int, int]:
     """The split phase through the C ABI (SplitFilePerChromosome, sam/split-merge.go:230-311): `b` is staged into the rank's READER
     context, classified on the device (elp_split_classify: split id and spread flag per record; the ids are written to the split-id
     column and travel with the records), and every record goes to the context of the rank that owns its split - device to device:
@@ -234,10 +235,12 @@ def route_device(reader, b: Batch, group_of_ref: np.ndarray, n_groups: int, owne
     the spread owner's second context with split id 0.  The host sees three small arrays per batch (split ids, spread flags, counts) and
     builds index lists from them - no record passes through it.  `reader` belongs to the device group (elp_group_init /
     elp_group_share / elp_group_set_p2p).  Every rank calls this the same number of times (empty batches where it has nothing).
-    -> (live records that arrived in dst_local, records that arrived in dst_spread)"""
+    stage(reader, b): how the batch gets into the reader (default: the column batch; a BAM reader hands over inflated records:
+    elp_stage_bam - the raw records then travel with the columns and the destination can emit BAM).
+    -> (records that arrived in dst_local, records that arrived in dst_spread)"""
     reader.reset()
     if b.n:
-        reader.stage(b)
+        (stage or (lambda e, x: e.stage(x)))(reader, b)
     if b.n:
         split, spread, _ = reader.split_classify(group_of_ref, n_groups)
         spread = spread.astype(bool)
@@ -264,6 +267,37 @@ def route_device(reader, b: Batch, group_of_ref: np.ndarray, n_groups: int, owne
             if send_to >= 0 or recv_from >= 0:
                 reader.exchange_records(send_to, sidx, dst_spread if recv_from >= 0 else None, recv_from, new_split=0)
     return dst_local.n - n0, dst_spread.n - n1
+
+
+def emit_merged_device(groups, spread, part, group_of_ref: np.ndarray, n_groups: int, owner: np.ndarray, rank: int, world: int) -> np.ndarray:
+    """The merge phase across ranks through the C ABI (MergeSortedFilesSplitPerChromosome, sam/split-merge.go:410-576): the spread split's
+    owner sends every rank the spread reads of that rank's contig groups - in the spread file's coordinate order, with the FLAG and QUAL
+    columns as the path left them (elp_exchange_records; elp_copy_records for its own) - into the rank's `part` context; every rank then
+    emits the merge of its group splits' sorted output and those reads as one stream of BAM records (elp_emit_merged_bam: the spread
+    reads behind the group reads of their position, the rank's unmapped split last).  The output file is the ranks' streams cut at
+    their group boundaries in @SQ order + the unmapped split.  `groups` and `spread` are coordinate-sorted and hold the inflated BAM
+    records (elp_stage_bam); `spread` is empty on every rank but the owner; `part` is an empty context of the same device group."""
+    spread_owner = int(owner[n_groups + 1])
+    part.reset()
+    if rank == spread_owner and spread.n:
+        split, _, _ = spread.split_classify(group_of_ref, n_groups)   # the contig group of every spread read
+        order = spread.permutation()[:spread.n_sorted]
+        dest = owner[split[order]]
+    else:
+        order, dest = np.zeros(0, np.uint32), np.zeros(0, np.int32)
+    for s in range(world):
+        sp, rp = (rank + s) % world, (rank - s + world) % world
+        idx = order[dest == sp].astype(np.uint32) if rank == spread_owner else np.zeros(0, np.uint32)
+        if s == 0:
+            if idx.size:
+                part.copy_records_from(spread, idx, new_split=0)
+        else:
+            send_to = sp if rank == spread_owner else -1
+            recv_from = rp if rp == spread_owner else -1
+            if send_to >= 0 or recv_from >= 0:
+                (spread if rank == spread_owner else part).exchange_records(send_to, idx, part if recv_from >= 0 else None, recv_from, new_split=0)
+    part.sort_coordinate(fetch=False)
+    return groups.emit_merged_bam(part)
 
 
 # ------------------------------------------------------------------------------------------------ output order
@@ -297,7 +331,8 @@ def sorted_output(b: Batch, perm: np.ndarray, flags: np.ndarray, qual: np.ndarra
 
 
 def merge_splits(groups: List[Batch], spread: Batch, unmapped: Batch) -> Batch:
-    """MergeSortedFilesSplitPerChromosome on payloads (sam/split-merge.go:410-576): `groups` are the coordinate-sorted group
+    """(Test infrastructure since round 5: the product merges on the device - elp_emit_merged_bam on one GPU, emit_merged_device across
+    ranks.)  MergeSortedFilesSplitPerChromosome on payloads (sam/split-merge.go:410-576): `groups` are the coordinate-sorted group
     splits in group order, `spread` the coordinate-sorted spread split, `unmapped` the unmapped split; the result is the one
     coordinate-sorted output the reference's merge phase writes (group reads with the spread reads inserted by merge_order,
     then the unmapped split)."""

@@ -65,7 +65,14 @@ def worker(rank, world, port, out_dir):
         if tot is None:
             tot = np.zeros(1, np.int64)
         red = comm.allreduce_i64(tot)
+        # the send-receive callback the C ABI's device group gets under gloo / on shared GPUs (elp_group_set_p2p <- Comm.sendrecv): one
+        # message each way, then one direction only (what elp_exchange_records' header / verdict / payload messages are made of)
+        other = 1 - rank
+        got = comm.sendrecv(other, bytes([rank + 1]) * (1000 + rank), other, 1000 + other)
+        ok = got == bytes([other + 1]) * (1000 + other)
+        got = comm.sendrecv(1 if rank == 0 else -1, b"xyz" if rank == 0 else None, 0 if rank == 1 else -1, 3 if rank == 1 else 0)
+        ok = ok and ((got is None) if rank == 0 else (got == b"xyz"))
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), input=sfm.pack_batch(b), local=sfm.pack_batch(mine.local),
-                 spread=sfm.pack_batch(mine.spread), own=tot, reduced=red)
+                 spread=sfm.pack_batch(mine.spread), own=tot, reduced=red, sendrecv_ok=np.array([ok]))
     finally:
         dist.destroy_process_group()

@@ -194,7 +194,8 @@ def _two_ranks(h, parts, body):
                 chan[(r, sp)].put(data)
             return chan[(rp, r)].get(timeout=60) if rp >= 0 and nbytes else None
         try:
-            readers[r].stage(parts[r])
+            if parts[r].n:
+                readers[r].stage(parts[r])
             readers[r].group_init_transport(r, 2, lambda v: None)
             readers[r].group_set_p2p(sendrecv)
             body(r, readers[r], dests[r])
@@ -247,5 +248,132 @@ def test_exchange_in_several_pieces_and_a_failure_that_reaches_both_ranks():
     assert isinstance(errors[0], ElpError) and "not records of the source" in str(errors[0]), errors
     assert isinstance(errors[1], ElpError) and "failed on its side" in str(errors[1]), errors
     assert dests[1].n == 1400 and dests[0].n == pick[1].size  # what arrived before the failure stays; rank 1's records all reached rank 0
+    for e in readers + dests:
+        e.close()
+
+
+def test_split_phase_through_the_c_abi_between_two_ranks():
+    """sfm.route_device - what bench.py --gpus N and SfmRank.route run: every rank stages its input batches into a
+    reader context, elp_split_classify on the device, elp_copy_records inside the rank and elp_exchange_records between the ranks (two host
+    threads on the one GPU, the group's messages through queues).  Every rank's contexts must hold exactly what SplitFilePerChromosome
+    (sam/split-merge.go:280-293) writes into its split files: the group files' records in input order with the sr-tagged copies among
+    them and their split ids, the spread file's records with the spread owner - checked against contexts the host staged with the
+    same records, and against the oracle's duplicate marking"""
+    from elprep_amd import sfm
+    from elprep_amd.batch import Batch
+    from tests import sfm_worker
+    world = 2
+    inputs = []
+    for r in range(world):
+        cfg, gof, G, owner, b = sfm_worker.make_rank_input(r, world, pairs_per_rank=3000)
+        cut = b.n // 2
+        inputs.append([b.take(np.arange(cut)), b.take(np.arange(cut, b.n))])
+    h = cfg.header()
+    spread_owner = int(owner[G + 1])
+    # what arrives where: per routing round the rank's own records, then the other rank's
+    want_local = [[] for _ in range(world)]
+    want_spread = []
+    for k in range(2):
+        for r in range(world):
+            for src in (r, 1 - r):
+                b = inputs[src][k]
+                g, sp = sfm.split_records(b, gof)
+                idx = np.nonzero(owner[g] == r)[0]
+                if idx.size:
+                    want_local[r].append(sfm.with_sr(b, sp, g).take(idx))
+                if r == spread_owner and sp.any():
+                    want_spread.append(sfm.with_sr(b, np.zeros(b.n, bool), np.zeros(b.n, np.uint16)).take(np.nonzero(sp)[0]))
+    got = {}
+
+    def body(r, reader, dest):
+        spread_ctx = Engine(h)
+        got[r] = spread_ctx
+        for k in range(2):
+            sfm.route_device(reader, inputs[r][k], gof, G, owner, r, world, dest, spread_ctx)
+    readers, dests, errors = _two_ranks(h, [sfm.empty_batch(), sfm.empty_batch()], body)
+    assert errors == [None, None], errors
+    for r in range(world):
+        want = Batch.concat(want_local[r])
+        assert dests[r].n == want.n
+        ref = Engine(h)
+        ref.stage(want)
+        oflags = orc.mark_duplicates(want, h)
+        assert np.array_equal(dests[r].mark_duplicates(True), oflags) and np.array_equal(ref.mark_duplicates(True), oflags)
+        assert np.array_equal(dests[r].sort_coordinate(), ref.sort_coordinate())
+        assert dests[r].n_sorted == ref.n_sorted
+        assert np.array_equal(dests[r].dup_metrics(100), ref.dup_metrics(100))
+        ref.close()
+    assert sum(int(Batch.concat(w).has_sr.sum()) for w in want_local) > 30
+    wsp = Batch.concat(want_spread)
+    assert got[spread_owner].n == wsp.n and wsp.n > 30 and got[1 - spread_owner].n == 0
+    assert np.array_equal(got[spread_owner].mark_duplicates(True), orc.mark_duplicates(wsp, h))
+    for e in readers + dests + list(got.values()):
+        e.close()
+
+
+def test_merge_phase_across_two_ranks_through_the_c_abi():
+    """sfm.emit_merged_device (VERDICT r4 missing #2, the merge half): BAM records in, split phase through the C ABI (the inflated records
+    travel with the columns), mark duplicates + sort of every rank's contexts, then the spread owner sends every rank the spread reads of
+    its contig groups and every rank emits the merge of its groups' output with them (elp_emit_merged_bam).  Expectation without the
+    device: the oracle's flags and order per context, the oracle's BAM encoder, the transliteration of the reference's insertion loop
+    (sam/split-merge.go:519-549)"""
+    from elprep_amd import sfm
+    from elprep_amd.batch import Batch
+    from tests import sfm_worker
+    from tests.test_gpu_round3 import _bam_records
+    from tests.test_sfm_cpu import _merge_reference
+    world = 2
+    inputs = []
+    for r in range(world):
+        cfg, gof, G, owner, b = sfm_worker.make_rank_input(r, world, pairs_per_rank=2500)
+        inputs.append(b)
+    h = cfg.header()
+    spread_owner = int(owner[G + 1])
+    want_local, want_spread = [[] for _ in range(world)], []
+    for r in range(world):
+        for src in (r, 1 - r):
+            b = inputs[src]
+            g, sp = sfm.split_records(b, gof)
+            idx = np.nonzero(owner[g] == r)[0]
+            if idx.size:
+                want_local[r].append(sfm.with_sr(b, sp, g).take(idx))
+            if r == spread_owner and sp.any():
+                want_spread.append(b.take(np.nonzero(sp)[0]))
+    out = {}
+
+    def body(r, reader, dest):
+        spread_ctx, part = Engine(h), Engine(h)
+        for e in (reader, dest, spread_ctx, part):
+            e.set_read_group_ids(h.rg_ids)
+        part.group_share(reader)
+        spread_ctx.group_share(reader)
+        sfm.route_device(reader, inputs[r], gof, G, owner, r, world, dest, spread_ctx, stage=lambda e, x: e.stage_bam(orc.bam_encode(x, h.rg_ids)))
+        for e in (dest, spread_ctx):
+            e.mark_duplicates(True, fetch=False)
+            e.sort_coordinate(fetch=False)
+        out[r] = sfm.emit_merged_device(dest, spread_ctx, part, gof, G, owner, r, world).tobytes()
+        spread_ctx.close()
+        part.close()
+    readers, dests, errors = _two_ranks(h, [sfm.empty_batch(), sfm.empty_batch()], body)
+    assert errors == [None, None], errors
+    # the spread file: the oracle's flags, order and records
+    wsp = Batch.concat(want_spread)
+    sflags = orc.mark_duplicates(wsp, h)
+    sorder = orc.sort_coordinate(wsp, sflags)[:orc.num_sorted(wsp)]
+    srecs = _bam_records(orc.bam_encode(wsp, h.rg_ids, order=sorder, flags=sflags, normalize_tags=True))
+    sgroup = gof[wsp.refid[sorder]]
+    for r in range(world):
+        loc = Batch.concat(want_local[r])
+        lflags = orc.mark_duplicates(loc, h)
+        lorder = orc.sort_coordinate(loc, lflags)[:orc.num_sorted(loc)]
+        lrecs = _bam_records(orc.bam_encode(loc, h.rg_ids, order=lorder, flags=lflags, normalize_tags=True))
+        keys = [(int(loc.refid[i]), int(loc.pos[i])) for i in lorder]
+        n_mapped = sum(1 for k in keys if k[0] >= 0)
+        mine = np.nonzero(owner[sgroup] == r)[0]  # the spread reads of this rank's contig groups, in the spread file's order
+        skeys = [(int(wsp.refid[sorder[j]]), int(wsp.pos[sorder[j]])) for j in mine]
+        codes = _merge_reference(keys[:n_mapped], skeys)
+        want = [lrecs[c] if c >= 0 else srecs[mine[-c - 1]] for c in codes] + lrecs[n_mapped:]
+        assert len(mine) > 10 or r != spread_owner
+        assert out[r] == b"".join(want), r
     for e in readers + dests:
         e.close()

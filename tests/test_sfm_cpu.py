@@ -102,6 +102,7 @@ def test_two_ranks_route_and_allreduce_over_gloo(tmp_path):
     assert total.sum() > 0
     for r in range(world):
         assert np.array_equal(res[r]["reduced"], total)
+        assert bool(res[r]["sendrecv_ok"][0])  # Comm.sendrecv: the C ABI device group's send-receive callback under gloo
 
 
 def _merge_reference(group, spread):
