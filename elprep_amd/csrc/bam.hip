@@ -549,7 +549,9 @@ static int emit_stream(elp_ctx *c, const BamOut &m, const BamOut &m2, const uint
     ELP_HIP(c, hipStreamSynchronize(st));
     if (he & 16u) return set_error(c, ELP_ERR_UNSUPPORTED, "elp_emit_sorted_bam: H-typed optional field");
     if (he) return set_error(c, ELP_ERR_DATA, "elp_emit_sorted_bam: malformed optional fields");
-    const uint64_t out_bytes = bgzf ? bgzf_framed_size(chunk_bytes) : (uint64_t)chunk_bytes;
+    // (BGZF: the size of the stored form - what the pass needs room for; the compressed members are never larger, their actual size is
+    // known behind the device pass.  A size query returns this upper bound)
+    uint64_t out_bytes = bgzf ? bgzf_framed_size(chunk_bytes) : (uint64_t)chunk_bytes;
     if (!out) { total += out_bytes; continue; }  // size query
     if (total + out_bytes > cap) return set_error(c, ELP_ERR_ARG, "elp_emit_sorted_bam: output buffer too small (%llu bytes needed so far)", (unsigned long long)(total + out_bytes));
     uint8_t *d_out;
@@ -560,7 +562,8 @@ static int emit_stream(elp_ctx *c, const BamOut &m, const BamOut &m2, const uint
     if (bgzf) {
       uint8_t *d_framed;
       ELP_TRY(scratch(c, 7, (size_t)out_bytes + 64, &d_framed));
-      ELP_TRY(bgzf_frame(c, d_out, chunk_bytes, d_framed));
+      if (c->tune.bgzf_stored) ELP_TRY(bgzf_frame(c, d_out, chunk_bytes, d_framed));  // stored DEFLATE blocks (tests, measurements)
+      else ELP_TRY(bgzf_deflate(c, d_out, chunk_bytes, d_framed, &out_bytes));
       d_send = d_framed;
     }
     ELP_HIP(c, hipMemcpyAsync(out + total, d_send, out_bytes, hipMemcpyDeviceToHost, st));

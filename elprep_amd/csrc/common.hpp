@@ -200,6 +200,7 @@ struct elp_ctx {
     int sort_pairs = 0;        // 1: the coordinate sort moves (key, index) pairs even where key << b | index fits one word
     int tie_rounds = 0;        // 1: the sort's long runs by LSD rounds over every live position (no key-then-compare shortcut)
     int exchange_piece = 0;    // > 0: records per piece of elp_exchange_records (tests: several pieces on small inputs)
+    int bgzf_stored = 0;       // 1: elp_emit_sorted_bgzf writes stored DEFLATE blocks (round 4's form) instead of compressing
   } tune;
 
   // generic scratch pool (grown on demand, reused between calls)
@@ -366,6 +367,7 @@ int merge_spread_slots(elp_ctx *groups, elp_ctx *spread, uint64_t **slots_out); 
 int stage_recode_seq(elp_ctx *c, uint64_t from, uint64_t bytes);
 int stage_bam_columns(elp_ctx *c, uint32_t n_rec, uint64_t piece_bytes, uint64_t raw_end, uint64_t max_raw_rec, uint16_t split_id);  // bam.hip
 uint64_t bgzf_framed_size(uint64_t n_bytes);                                   // bgzf.hip
-int bgzf_frame(elp_ctx *c, const uint8_t *raw, uint64_t n_bytes, uint8_t *out);  // device to device                               // BAM nibbles -> code nibbles on seq4[from, from + bytes)
+int bgzf_frame(elp_ctx *c, const uint8_t *raw, uint64_t n_bytes, uint8_t *out);  // device to device, stored blocks
+int bgzf_deflate(elp_ctx *c, const uint8_t *raw, uint64_t n_bytes, uint8_t *out, uint64_t *out_bytes);  // device to device, compressed members; *out_bytes <= bgzf_framed_size                               // BAM nibbles -> code nibbles on seq4[from, from + bytes)
 
 }  // namespace elp

@@ -447,6 +447,7 @@ int elp_set_tuning(elp_ctx *c, const char *key, int64_t value) {
   else if (k == "radix_tile") c->tune.radix_tile = v;
   else if (k == "sort_pairs") c->tune.sort_pairs = v;
   else if (k == "exchange_piece") c->tune.exchange_piece = v;
+  else if (k == "bgzf_stored") c->tune.bgzf_stored = v;
   else return set_error(c, ELP_ERR_ARG, "elp_set_tuning: unknown key '%s'", key);
   return 0;
 }

@@ -177,7 +177,8 @@ class Engine:
         return out[:int(n.value)]
 
     def emit_sorted_bgzf(self) -> np.ndarray:
-        """the sorted records as BGZF blocks (stored DEFLATE, CRC-32 on the device): elp_emit_sorted_bgzf"""
+        """the sorted records as BGZF blocks (compressed on the device, CRC-32 on the device): elp_emit_sorted_bgzf; the size query gives an
+        upper bound (the stored form), the call the actual size"""
         n = C.c_uint64()
         self._check(self.L.elp_emit_sorted_bgzf(self.h, C.c_void_p(0), 0, C.byref(n)))
         out = np.empty(int(n.value), dtype=np.uint8)

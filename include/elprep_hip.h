@@ -145,9 +145,12 @@ int elp_emit_sorted_bam(elp_ctx *ctx, uint8_t *out, uint64_t cap, uint64_t *n_by
  * next one's begins; wrong guesses are repaired in order), and the records are staged as elp_stage_bam stages them.  first_record = the
  * offset of the first alignment record in the inflated stream (behind magic, header text and reference dictionary, which the host
  * parses from the first block(s) itself); 0 for a part that starts with a record.
- * elp_emit_sorted_bgzf = elp_emit_sorted_bam + the writer (:324-383) at compression level 0: the sorted records as BGZF blocks with
- * stored DEFLATE data (<= 65280 bytes each), CRC-32 and ISIZE computed on the device.  Inflating the blocks gives elp_emit_sorted_bam's
- * bytes; a BAM file = the host's header block(s) + these blocks + the 28-byte end-of-file block (:53-62). */
+ * elp_emit_sorted_bgzf = elp_emit_sorted_bam + the writer (:324-383): the sorted records as BGZF blocks of <= 65280 payload bytes, each
+ * COMPRESSED on the device (round 5: DEFLATE with fixed Huffman codes over a parallel LZ77 parse, csrc/deflate_core.hpp; a block that
+ * would not shrink is stored), CRC-32 and ISIZE computed on the device.  Inflating the blocks gives elp_emit_sorted_bam's bytes (parity
+ * of a BAM file is defined on the inflated stream: the reference's own bytes are whatever Go's compress/flate emits); a BAM file = the
+ * host's header block(s) + these blocks + the 28-byte end-of-file block (:53-62).  A size query (out = NULL) returns an UPPER BOUND - the
+ * size of the stored form, which is also the room `out` must offer; *n_bytes_out of the real call is the actual size. */
 int elp_stage_bgzf(elp_ctx *ctx, const uint8_t *bgzf, uint64_t n_bytes, uint64_t first_record, uint16_t split_id);
 int elp_emit_sorted_bgzf(elp_ctx *ctx, uint8_t *out, uint64_t cap, uint64_t *n_bytes_out);
 /* The merge of `elprep merge` / `sfm` phase 3 with payloads (MergeSortedFilesSplitPerChromosome, sam/split-merge.go:410-576): the sorted

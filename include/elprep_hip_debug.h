@@ -26,6 +26,7 @@ int elp_rollback(elp_ctx *ctx);
  *                      covariates (never the covariate split); 3: the one-length kernel split by covariate wherever it applies
  *   "apply_kernel"     1: general ApplyBQSR kernel; 3: the one-length kernel split by covariate even where one table holds every covariate
  *   "exchange_piece"   > 0: records per piece of elp_exchange_records (default 4 M, less for long records: a piece's columns stay below 4 GiB)
+ *   "bgzf_stored"      1: elp_emit_sorted_bgzf frames stored DEFLATE blocks (BTYPE 00) instead of compressing
  *   "bgzf_piece"       inflated bytes per device pass of elp_stage_bgzf (default 192 MiB)
  *   "bgzf_weak_guess"  1: elp_stage_bgzf's blocks guess their first record start blindly (every guess is then repaired: same result)
  *   "score_kernel"     1: general Phred-score / low-quality-tail kernel even for read sets of one length

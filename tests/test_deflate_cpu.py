@@ -1,0 +1,99 @@
+"""CPU tests of the device's DEFLATE compressor through its host emulation (tests/deflate_host.cpp runs the functions of
+elprep_amd/csrc/deflate_core.hpp that the kernel k_bgzf_deflate runs): zlib inflates every block to exactly its payload - BAM records of
+the synthetic workload, runs, random bytes (stored fallback), short and empty tails - in both part orders."""
+import ctypes as C
+import os
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "tests", "libdeflate_host.so")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    src = os.path.join(ROOT, "tests", "deflate_host.cpp")
+    hdr = os.path.join(ROOT, "elprep_amd", "csrc", "deflate_core.hpp")
+    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", SO, src])
+    L = C.CDLL(SO)
+    L.dfl_emulate_block.restype = C.c_uint32
+    L.dfl_emulate_block.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_uint32)]
+    return L
+
+
+def _deflate(L, data: bytes, order: int):
+    a = np.frombuffer(data, dtype=np.uint8) if data else np.zeros(1, np.uint8)
+    out = np.zeros(len(data) + 64, np.uint8)
+    stored, ntok = C.c_int(), C.c_uint32()
+    n = L.dfl_emulate_block(a.ctypes.data, len(data), out.ctypes.data, order, C.byref(stored), C.byref(ntok))
+    return out[:n].tobytes(), bool(stored.value), int(ntok.value)
+
+
+def _inflate(cdata: bytes) -> bytes:
+    d = zlib.decompressobj(-15)
+    out = d.decompress(cdata) + d.flush()
+    assert d.eof and not d.unused_data
+    return out
+
+
+def _cases():
+    from tools import synth
+    rng = np.random.default_rng(1)
+    cfg = synth.config("c3")
+    b = synth.generate(cfg, 0, 1500)
+    bam, _ = synth.bam_records(b, cfg.header().rg_ids)
+    bam = bam.tobytes()
+    yield "bam block", bam[:65280]
+    yield "bam block 2", bam[65280:2 * 65280]
+    yield "short tail", bam[:30011]
+    yield "one part and a bit", bam[:300]
+    yield "three bytes", b"abc"
+    yield "empty", b""
+    yield "zeros", bytes(65280)
+    yield "one run per part", bytes([k % 251 for k in range(256) for _ in range(255)])
+    yield "random", rng.integers(0, 256, 65280, dtype=np.uint8).tobytes()
+    yield "text", (b"SIM0:1:FC1:1:1656:18011:10371 " * 3000)[:65280]
+    yield "high literals", bytes(rng.integers(144, 256, 5000, dtype=np.uint8)) + bytes(200) + bytes(rng.integers(250, 256, 4000, dtype=np.uint8))
+    yield "far matches", (rng.integers(0, 256, 20000, dtype=np.uint8).tobytes() * 4)[:65280]
+
+
+@pytest.mark.parametrize("order", [0, 1])
+def test_every_block_inflates_to_its_payload(lib, order):
+    ratios = {}
+    for name, data in _cases():
+        cdata, stored, ntok = _deflate(lib, data, order)
+        assert _inflate(cdata) == data, name
+        assert len(cdata) <= len(data) + 5, name
+        ratios[name] = (round(len(cdata) / max(len(data), 1), 3), stored, ntok)
+    assert ratios["random"][1] and not ratios["bam block"][1]
+    assert ratios["zeros"][0] < 0.05
+    # the synthetic BAM records: zlib's own fixed-Huffman level-1 encoder reaches 0.55 on them; the strip-parallel match finder reaches the same
+    assert ratios["bam block"][0] < 0.58, ratios
+
+
+def test_symbol_tables_against_the_rfc(lib):
+    """match lengths and distances through the encoder and zlib's decoder: random bytes, then a copy of `length` bytes from `dist` back
+    that starts a strip of the match finder (its source is in the table by then) and lies inside one part of the parse"""
+    rng = np.random.default_rng(3)
+    base = rng.integers(0, 256, 70000, dtype=np.uint8).tobytes()
+    seen = set()
+    for dist in [1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 13, 16, 17, 24, 25, 32, 33, 48, 49, 64, 65, 96, 97, 128, 129, 192, 193, 256, 257, 384, 385, 512, 513, 768, 769, 1024,
+                 1025, 1536, 1537, 2048, 2049, 3072, 3073, 4096, 4097, 6144, 6145, 8192, 8193, 12288, 12289, 16384, 16385, 24576, 24577, 32767, 32768]:
+        for length in (4, 5, 10, 11, 12, 13, 18, 19, 34, 35, 66, 67, 115, 130, 131, 226, 227, 250, 254):
+            k = max((dist + 255) // 256, 1)       # the copy starts strip k, i.e. at offset k of part k
+            if k + length > 255:
+                continue
+            pre = 256 * k
+            data = bytearray(base[:pre])
+            for j in range(length):
+                data.append(data[pre - dist + j])
+            data += base[60000:60050]
+            for order in (0, 1):
+                cdata, stored, _ = _deflate(lib, bytes(data), order)
+                assert _inflate(cdata) == bytes(data), (dist, length, order)
+            seen.add((dist, length))
+    assert len(seen) > 500
