@@ -76,9 +76,22 @@ __global__ __launch_bounds__(256) void k_apply_cov_hist(uint64_t n, const uint16
   h[threadIdx.x] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63;
+  // (the tile's four read-group ids first, then the covariates they lead to: one round trip per level, not four)
+  uint16_t rg[A3_RTILE / 256];
+#pragma unroll
   for (int j = 0; j < A3_RTILE / 256; j++) {
     const uint64_t i = (uint64_t)blockIdx.x * A3_RTILE + j * 256 + threadIdx.x;
-    const int cov = i < n ? apply_read_cov(rgid[i], rg_cov, cov_present, err) : -1;
+    rg[j] = i < n ? rgid[i] : (uint16_t)ELP_NIL16;
+  }
+  int cv[A3_RTILE / 256];
+#pragma unroll
+  for (int j = 0; j < A3_RTILE / 256; j++) {
+    const uint64_t i = (uint64_t)blockIdx.x * A3_RTILE + j * 256 + threadIdx.x;
+    cv[j] = i < n ? apply_read_cov(rg[j], rg_cov, cov_present, err) : -1;
+  }
+#pragma unroll
+  for (int j = 0; j < A3_RTILE / 256; j++) {
+    const int cov = cv[j];
     // one LDS atomic per covariate that occurs in the wave (lanes adding one each to a handful of counters serialise)
     const unsigned long long same = wave_same_mask((uint32_t)cov, cov >= 0);
     if (same && lane == __ffsll((long long)same) - 1) atomicAdd(&h[cov], (uint32_t)__popcll(same));
@@ -101,10 +114,22 @@ __global__ __launch_bounds__(256) void k_apply_records_split(uint64_t n, uint32_
   const int lane = threadIdx.x & 63;
   int cv[A3_RTILE / 256];
   uint32_t my[A3_RTILE / 256];
+  uint16_t rg[A3_RTILE / 256], fl[A3_RTILE / 256];
+  uint64_t qb[A3_RTILE / 256];
+#pragma unroll
+  for (int j = 0; j < A3_RTILE / 256; j++) {  // every column load of the tile up front
+    const uint64_t i = (uint64_t)blockIdx.x * A3_RTILE + j * 256 + threadIdx.x;
+    rg[j] = i < n ? rgid[i] : (uint16_t)ELP_NIL16;
+    fl[j] = i < n ? flag[i] : (uint16_t)0;
+    qb[j] = i < n ? qbounds[i] : 0ull;
+  }
 #pragma unroll
   for (int j = 0; j < A3_RTILE / 256; j++) {
     const uint64_t i = (uint64_t)blockIdx.x * A3_RTILE + j * 256 + threadIdx.x;
-    cv[j] = i < n ? apply_read_cov(rgid[i], rg_cov, cov_present, err) : -1;
+    cv[j] = i < n ? apply_read_cov(rg[j], rg_cov, cov_present, err) : -1;
+  }
+#pragma unroll
+  for (int j = 0; j < A3_RTILE / 256; j++) {
     // the record's place among the workgroup's records of its covariate: one LDS atomic per covariate that occurs in the wave
     const unsigned long long same = wave_same_mask((uint32_t)cv[j], cv[j] >= 0);
     const int leader = same ? __ffsll((long long)same) - 1 : lane;
@@ -120,7 +145,7 @@ __global__ __launch_bounds__(256) void k_apply_records_split(uint64_t n, uint32_
     const uint64_t i = (uint64_t)blockIdx.x * A3_RTILE + j * 256 + threadIdx.x;
     if (cv[j] >= 0) {
       const size_t to = (size_t)base[cv[j]] + my[j];
-      recs[to] = apply_record(len, lmax, flag[i], qbounds[i], (uint32_t)cv[j]);
+      recs[to] = apply_record(len, lmax, fl[j], qb[j], (uint32_t)cv[j]);
       ridx[to] = (uint32_t)i;
     }
   }

@@ -374,7 +374,14 @@ def test_merge_phase_across_two_ranks_through_the_c_abi():
         codes = _merge_reference(keys[:n_mapped], skeys)
         want = [lrecs[c] if c >= 0 else srecs[mine[-c - 1]] for c in codes] + lrecs[n_mapped:]
         assert len(mine) > 10 or r != spread_owner
-        assert out[r] == b"".join(want), r
+        if out[r] != b"".join(want):  # say what differs: a missing part, an order, or a record
+            got = _bam_records(np.frombuffer(out[r], dtype=np.uint8))
+            first = next((k for k, (a, c) in enumerate(zip(got, want)) if a != c), min(len(got), len(want)))
+            def who(rec):
+                rid, pos = np.frombuffer(rec[4:12], dtype=np.int32)
+                return (int(rid), int(pos) + 1, rec[36:36 + rec[12] - 1].decode(), "spread" if rec in set(srecs) else ("group" if rec in set(lrecs) else "neither"))
+            raise AssertionError((r, "records", len(got), len(want), "same multiset", sorted(got) == sorted(want), "first difference at", first,
+                                  [who(x) for x in got[first:first + 3]], [who(x) for x in want[first:first + 3]], "spread reads of the rank", len(mine)))
     for e in readers + dests:
         e.close()
 

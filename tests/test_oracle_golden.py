@@ -76,3 +76,24 @@ def test_oracle_against_the_real_elprep(name):
     lines = ["".join(chr(int(x) + 33) for x in qual[int(b.qual_off[i]):int(b.qual_off[i + 1])]) or "*" for i in range(b.n)]
     assert lines[:8] == fix["qual_head"]
     assert hashlib.sha256("\n".join(lines).encode()).hexdigest() == fix["qual_sha256"], "recalibrated qualities differ from elprep's output"
+
+
+def test_fixture_recipe_dry_run(tmp_path, monkeypatch):
+    """tools/ref/make_fixtures.sh with the oracle standing in for the elprep binary: write_inputs.py -> the stand-in
+    (out.sam, metrics.txt, recal.txt in elprep's formats) -> collect.py -> the comparison above, all in a temporary directory.  It proves
+    the PLUMBING - that the SAM writer, the identification of the output's records and the parsing of the two text files work on the
+    day somebody with a Go toolchain runs the real recipe; it pins nothing (the oracle is compared with itself) and leaves no fixture."""
+    import subprocess
+    root = os.path.dirname(HERE)
+    work, fixdir = tmp_path / "w", tmp_path / "ref"
+    fixdir.mkdir()
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "ref", "write_inputs.py"), str(work), "1500", "0"])
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "ref", "oracle_as_elprep.py"), str(work)])
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "ref", "collect.py"), str(work), str(fixdir / "filter_tiny_seed0.json")])
+    fix = json.load(open(fixdir / "filter_tiny_seed0.json"))
+    assert fix["records"] > 2900 and len(fix["order"]) <= fix["records"] and sum(1 for x in fix["flags"] if x & 0x400) > 50
+    assert "LIBRARY" in fix["metrics_txt"] and "#:GATKTable" in fix["recal_txt"]
+    monkeypatch.setattr(sys.modules[__name__], "_REF_DIR", str(fixdir))
+    test_oracle_against_the_real_elprep.__wrapped__("filter_tiny_seed0.json") if hasattr(test_oracle_against_the_real_elprep, "__wrapped__") else \
+        test_oracle_against_the_real_elprep("filter_tiny_seed0.json")
+    assert not os.path.isdir(os.path.join(HERE, "golden", "ref")) or "filter_tiny_seed0.json" not in os.listdir(os.path.join(HERE, "golden", "ref"))

@@ -8,6 +8,8 @@
 # or a proxy).  Neither exists in the build container nor on the GPU box of this project (profiles/r2a_reference_toolchain_probe.txt):
 # the script has never run here and says so in DESIGN.md section 6.  Nothing of the reference's SOURCE enters the repository; the binary goes
 # to oracle/_ref/ (git-ignored).
+# The recipe's plumbing is exercised without Go by tests/test_oracle_golden.py::test_fixture_recipe_dry_run (tools/ref/oracle_as_elprep.py stands
+# in for the binary, in a temporary directory; it pins nothing).
 # usage: tools/ref/make_fixtures.sh [reference-dir (default /root/reference)] [pairs (default 20000)]
 set -euo pipefail
 ROOT="$(cd "$(dirname "$0")/../.." && pwd)"
