@@ -233,16 +233,25 @@ def main():
         """the step functions of one `elprep filter` context.  Order of events as in the reference (cmd/filter.go:142-211): MarkDuplicates
         is a filter of the phase-1 pipeline, the sort is that pipeline's Finalize (sam/filter-pipeline.go:116), then the metrics pass,
         Recalibrate, finalize, ApplyBQSR."""
-        def finalize_lut(qt, ct, xt):
+        def finalize_lut():
+            """the tables' way to the host, FinalizeBQSRTables, the LUT and its way back - in the ROWS form (round 5): only the rows of the
+            qualities the gather gave table slots cross PCIe and are scanned / filled by the host (with 16 read groups 1.8 MB of tables
+            down and 1.9 MB of LUT up instead of 24 + 26 MB); the dense forms if the tables hold other rows (summed tables)"""
             t0 = time.perf_counter()
-            tb = BqsrTables(qt, ct, xt, MAX_CYCLE).finalize()
-            if lut_buf[0] is None:  # the LUT is built in page-locked memory (its upload then runs at the PCIe rate), once per context
-                lut_buf[0] = (eng.pinned_zeros((eng.header.n_cov, 94, 2 * MAX_CYCLE + 1, 17), np.uint8), np.zeros(eng.header.n_cov, np.uint8))
-            lut, present = tb.build_lut(0, out=lut_buf[0])
-            lut_buf[0] = (lut, present)
-            eng.lut_upload(lut, present, MAX_CYCLE)  # on the context's copy stream, from this (host) thread, while the GPU sorts
+            quals = eng.quals_counted()
+            got = eng.tables_fetch_rows(quals, reuse=True)
+            if got is not None:
+                tb = BqsrTables.from_rows(eng.header.n_cov, quals, *got, MAX_CYCLE).finalize()
+                if lut_buf[0] is None or lut_buf[0][0] != tuple(quals):  # built in page-locked memory (its upload runs at the PCIe rate), once per context
+                    lut_buf[0] = (tuple(quals), (eng.pinned_zeros((eng.header.n_cov, len(quals), 2 * MAX_CYCLE + 1, 17), np.uint8),
+                                                 np.zeros((eng.header.n_cov, 94), np.uint8), np.zeros(eng.header.n_cov, np.uint8)))
+                rows, defaults, present = tb.build_lut_rows(quals, 0, out=lut_buf[0][1])
+                eng.lut_upload_rows(quals, rows, defaults, present, MAX_CYCLE)  # on the context's copy stream, from this (host) thread, while the GPU sorts
+            else:
+                tb = BqsrTables(*eng.tables_fetch(reuse=True), MAX_CYCLE).finalize()
+                lut, present = tb.build_lut(0)
+                eng.lut_upload(lut, present, MAX_CYCLE)
             host_ms.append((time.perf_counter() - t0) * 1e3)
-            return lut, present
 
         def step_full():
             eng.mark_duplicates(True, fetch=False)
@@ -251,7 +260,7 @@ def main():
             # side, the coordinate sort and the duplication-metrics pass (device, this thread) on the other do not depend on each other:
             # the host finalises while the GPU sorts and counts (the reference runs them one after the other, cmd/filter.go:162-196;
             # its sort is the pipeline's Finalize and needs nothing of BQSR either)
-            fin = host_pool.submit(lambda: finalize_lut(*eng.tables_fetch(reuse=True)))
+            fin = host_pool.submit(finalize_lut)
             eng.sort_coordinate(fetch=False)
             eng.dup_metrics(100)
             t_dev = time.perf_counter()
@@ -718,8 +727,12 @@ def verify_against_oracle(hdr, refs_sites, ref, dev_id=0):
         e.recalibrate_device(MAX_CYCLE)
         qt, ct, xt = e.tables_fetch()
         ctr = e.dup_metrics(100)
-        lut, present = BqsrTables(qt, ct, xt, MAX_CYCLE).finalize().build_lut(0)
-        qual = e.apply_bqsr(lut, present, MAX_CYCLE)
+        # the LUT as the timed step makes it: the rows form (tables' rows of the counted qualities down, LUT rows + defaults up, the dense LUT
+        # expanded on the device)
+        quals = e.quals_counted()
+        tb = BqsrTables.from_rows(hdr.n_cov, quals, *e.tables_fetch_rows(quals), MAX_CYCLE).finalize()
+        e.lut_upload_rows(quals, *tb.build_lut_rows(quals, 0), MAX_CYCLE)
+        qual = e.apply_bqsr(None, None, MAX_CYCLE)
     finally:
         e.close()
     oq, oc, ox = ref["tables"]

@@ -23,7 +23,7 @@ HIP_SYMBOLS = [
     "elp_create", "elp_destroy", "elp_last_error", "elp_sync", "elp_stream", "elp_set_header", "elp_reserve", "elp_stage", "elp_reset",
     "elp_num_records", "elp_num_qual_bytes", "elp_num_sorted", "elp_sort_coordinate", "elp_get_permutation", "elp_mark_duplicates", "elp_get_flags", "elp_get_adapted",
     "elp_dup_metrics", "elp_dup_metrics_hist", "elp_bqsr_set_reference", "elp_bqsr_set_known_sites", "elp_bqsr_gather", "elp_bqsr_apply", "elp_get_qual",
-    "elp_bqsr_gather_device", "elp_bqsr_tables_fetch", "elp_group_unique_id", "elp_group_init", "elp_group_rank", "elp_group_size",
+    "elp_bqsr_gather_device", "elp_bqsr_tables_fetch", "elp_bqsr_quals_counted", "elp_bqsr_tables_fetch_rows", "elp_bqsr_lut_upload_rows", "elp_group_unique_id", "elp_group_init", "elp_group_rank", "elp_group_size",
     "elp_bqsr_tables_add", "elp_bqsr_tables_allreduce", "elp_allreduce_i64",
     "elp_filter_records", "elp_clean_sam", "elp_split_classify", "elp_merge_spread",
     "elp_set_read_group_ids", "elp_pinned_alloc", "elp_pinned_free", "elp_stage_bam", "elp_emit_sorted_bam", "elp_stage_bgzf", "elp_emit_sorted_bgzf",
@@ -31,8 +31,8 @@ HIP_SYMBOLS = [
     "elp_snapshot", "elp_rollback", "elp_set_tuning", "elp_profile_enable", "elp_profile_reset", "elp_profile_count", "elp_profile_get",
 ]
 HOST_SYMBOLS = [
-    "elp_bqsr_tables_new", "elp_bqsr_tables_free", "elp_bqsr_tables_merge", "elp_bqsr_tables_finalize", "elp_bqsr_tables_empirical",
-    "elp_bqsr_tables_combined", "elp_bqsr_tables_quantize", "elp_bqsr_tables_build_lut", "elp_bqsr_tables_report", "elp_host_free",
+    "elp_bqsr_tables_new", "elp_bqsr_tables_new_rows", "elp_bqsr_tables_free", "elp_bqsr_tables_merge", "elp_bqsr_tables_finalize", "elp_bqsr_tables_empirical",
+    "elp_bqsr_tables_combined", "elp_bqsr_tables_quantize", "elp_bqsr_tables_build_lut", "elp_bqsr_tables_build_lut_rows", "elp_bqsr_tables_report", "elp_host_free",
     "elp_dup_derived", "elp_dup_metrics_report", "elp_dup_metrics_report_hist",
 ]
 
@@ -110,6 +110,9 @@ def hip() -> C.CDLL:
         L.elp_filter_records_flat.argtypes = [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_void_p]
         L.elp_group_probe.argtypes = []
         L.elp_bqsr_lut_upload.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.elp_bqsr_lut_upload_rows.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.elp_bqsr_quals_counted.argtypes = [C.c_void_p, C.c_void_p]
+        L.elp_bqsr_tables_fetch_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.elp_emit_merged_bam.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.elp_copy_records.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int]
         L.elp_group_init_transport.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
@@ -131,6 +134,9 @@ def host() -> C.CDLL:
         L = C.CDLL(HOST_SO)
         L.elp_bqsr_tables_new.restype = C.c_void_p
         L.elp_bqsr_tables_new.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.elp_bqsr_tables_new_rows.restype = C.c_void_p
+        L.elp_bqsr_tables_new_rows.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.elp_bqsr_tables_build_lut_rows.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.elp_bqsr_tables_free.argtypes = [C.c_void_p]
         L.elp_bqsr_tables_free.restype = None
         L.elp_bqsr_tables_merge.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

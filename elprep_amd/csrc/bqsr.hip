@@ -1539,6 +1539,39 @@ __global__ void k_c3_seg_offsets(const uint32_t *__restrict__ seg_cap, uint32_t 
   seg_base[nseg] = at;
 }
 
+// ---- the tables' and the LUT's rows form (round 5): with many read groups the dense tables / LUT are tens of megabytes of which only the
+// rows of the qualities that occur hold anything; only those rows cross PCIe.
+// packs the rows of `quals` (slot k = quality quals[k]) of the three dense tables behind each other: q [n_cov][nq][2] | c [n_cov][nq][ncyc][2]
+// | x [n_cov][nq][16][2]; flags a row with observations whose quality is not among them (the caller then fetches the dense tables)
+__global__ __launch_bounds__(256) void k_tables_pack_rows(const unsigned long long *__restrict__ tb, int n_cov, int ncyc, const uint8_t *__restrict__ quals, int nq,
+                                                          unsigned long long *__restrict__ out, uint32_t *uncovered) {
+  const size_t row_w = 2 + (size_t)ncyc * 2 + ELP_NCTX * 2;  // words of one (covariate, quality) row over the three tables
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x, n_rows = (size_t)n_cov * (size_t)nq;
+  if (k < (size_t)n_cov * ELP_NQUAL) {  // (the first n_cov * 94 threads also check the qualities that were not asked for)
+    const int q = (int)(k % ELP_NQUAL);
+    bool asked = false;
+    for (int j = 0; j < nq; j++) asked |= quals[j] == q;
+    if (!asked && tb[2 * k] != 0) atomicOr(uncovered, 1u);
+  }
+  if (k >= n_rows * row_w) return;
+  const size_t r = k / row_w, w = k - r * row_w;
+  const size_t cv = r / (size_t)nq, q = quals[r % (size_t)nq], src_row = cv * ELP_NQUAL + q;
+  const size_t nq_all = (size_t)n_cov * ELP_NQUAL * 2, nc_all = nq_all * (size_t)ncyc;
+  const size_t oq = 0, oc = n_rows * 2, ox = oc + n_rows * (size_t)ncyc * 2;
+  if (w < 2) out[oq + r * 2 + w] = tb[src_row * 2 + w];
+  else if (w < 2 + (size_t)ncyc * 2) out[oc + r * (size_t)ncyc * 2 + (w - 2)] = tb[nq_all + src_row * (size_t)ncyc * 2 + (w - 2)];
+  else out[ox + r * ELP_NCTX * 2 + (w - 2 - (size_t)ncyc * 2)] = tb[nq_all + nc_all + src_row * ELP_NCTX * 2 + (w - 2 - (size_t)ncyc * 2)];
+}
+// the dense LUT [n_cov][94][ncyc][17] from its rows form: rows [n_cov][nq][ncyc][17] for the qualities with a slot, the default byte else
+__global__ __launch_bounds__(256) void k_lut_expand_rows(const uint8_t *__restrict__ rows, const uint8_t *__restrict__ defaults, const uint8_t *__restrict__ slot_of /* [94], 255 = none */,
+                                                        int n_cov, int nq, int ncyc, uint8_t *__restrict__ lut) {
+  const size_t row_b = (size_t)ncyc * 17, k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= (size_t)n_cov * ELP_NQUAL * row_b) return;
+  const size_t r = k / row_b, w = k - r * row_b, cv = r / ELP_NQUAL, q = r % ELP_NQUAL;
+  const uint8_t sl = slot_of[q];
+  lut[k] = sl == 255 ? defaults[r] : rows[((cv * (size_t)nq + sl) * row_b) + w];
+}
+
 static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cycle_tbl, int64_t *ctx_tbl) {
   for (int r = 0; r < c->n_ref; r++)
     if (!c->h_ref_seq[r]) return set_error(c, ELP_ERR_ARG, "elp_bqsr_gather: no reference sequence set for refid %d", r);
@@ -1785,6 +1818,8 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
   }
   c->tables_n = nq + nc + nx;
   c->tables_max_cycle = max_cycle;
+  c->tables_quals[0] = c->qual_present[0] & ~0x3Full;  // (qualities below 6 are never counted)
+  c->tables_quals[1] = c->qual_present[1];
   ELP_TRY(tables_written(c));
   if (!qual_tbl) return 0;  // tables stay in HBM (the count loop above fetched the error word behind the last kernel that can raise one)
   // the three tables lie behind each other on the device: one copy into pinned memory, then into the caller's arrays
@@ -1803,6 +1838,62 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
   memcpy(qual_tbl, hp, nq * 8);
   memcpy(cycle_tbl, hp + nq, nc * 8);
   memcpy(ctx_tbl, hp + nq + nc, nx * 8);
+  return 0;
+}
+
+// the qualities that had table slots in the gather that made the device tables: bit q of bits[q / 64]
+int elp_bqsr_quals_counted(elp_ctx *c, uint64_t *bits) {
+  if (!c || !bits) return ELP_ERR_ARG;
+  if (!c->tables_n) return set_error(c, ELP_ERR_ARG, "elp_bqsr_quals_counted: no device tables (elp_bqsr_gather_device)");
+  bits[0] = c->tables_quals[0];
+  bits[1] = c->tables_quals[1];
+  return 0;
+}
+
+// elp_bqsr_tables_fetch for the rows of the qualities `quals` only: q_rows [n_cov][n_quals][2], c_rows [n_cov][n_quals][2*max_cycle+1][2],
+// x_rows [n_cov][n_quals][16][2] - packed on the device, one copy.  Returns 1 (and copies nothing) if a quality that was not asked for has
+// observations (tables that were summed with another context's or rank's: the caller fetches the dense tables then).
+int elp_bqsr_tables_fetch_rows(elp_ctx *c, const uint8_t *quals, int n_quals, int64_t *q_rows, int64_t *c_rows, int64_t *x_rows) {
+  if (!c || n_quals < 0 || n_quals > ELP_NQUAL || (n_quals && (!quals || !q_rows || !c_rows || !x_rows))) return ELP_ERR_ARG;
+  if (!c->tables_n) return set_error(c, ELP_ERR_ARG, "elp_bqsr_tables_fetch_rows: no device tables (elp_bqsr_gather_device)");
+  for (int k = 0; k < n_quals; k++)
+    if (quals[k] >= ELP_NQUAL) return set_error(c, ELP_ERR_ARG, "elp_bqsr_tables_fetch_rows: quality %d", (int)quals[k]);
+  ELP_HIP(c, hipSetDevice(c->device));
+  const int ncyc = 2 * c->tables_max_cycle + 1;
+  const size_t n_rows = (size_t)c->n_cov * (size_t)n_quals, row_w = 2 + (size_t)ncyc * 2 + ELP_NCTX * 2, words = n_rows * row_w;
+  const size_t bytes = words * 8 + 256;
+  if (bytes > c->h_pinned_cap) {
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    c->h_pinned = nullptr; c->h_pinned_cap = 0;
+    ELP_HIP(c, hipHostMalloc(&c->h_pinned, bytes, hipHostMallocDefault));
+    c->h_pinned_cap = bytes;
+  }
+  ELP_TRY(ensure(c, c->tables_pack, words + 64));
+  if (!c->copy_stream) ELP_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  if (c->tables_ev) ELP_HIP(c, hipStreamWaitEvent(c->copy_stream, c->tables_ev, 0));
+  else ELP_HIP(c, hipStreamSynchronize(c->stream));
+  // the quality list and the "uncovered" word ride in the pack buffer's tail
+  uint8_t *d_quals = reinterpret_cast<uint8_t *>(c->tables_pack.p + words);
+  uint32_t *d_unc = reinterpret_cast<uint32_t *>(c->tables_pack.p + words + 16);
+  uint8_t *hq = static_cast<uint8_t *>(c->h_pinned) + words * 8;
+  memset(hq, 0, 256);
+  if (n_quals) memcpy(hq, quals, (size_t)n_quals);
+  ELP_HIP(c, hipMemcpyAsync(d_quals, hq, 128 + 8, hipMemcpyHostToDevice, c->copy_stream));  // (also clears the word)
+  const size_t work = std::max(words, (size_t)c->n_cov * ELP_NQUAL);
+  hipLaunchKernelGGL(k_tables_pack_rows, dim3(blocks_for(work, 256)), dim3(256), 0, c->copy_stream, (const unsigned long long *)c->dev_tables.p, c->n_cov, ncyc,
+                     (const uint8_t *)d_quals, n_quals, c->tables_pack.p, d_unc);
+  ELP_HIP(c, hipGetLastError());
+  ELP_HIP(c, hipMemcpyAsync(c->h_pinned, c->tables_pack.p, words * 8, hipMemcpyDeviceToHost, c->copy_stream));
+  uint32_t unc = 0;
+  ELP_HIP(c, hipMemcpyAsync(&unc, d_unc, 4, hipMemcpyDeviceToHost, c->copy_stream));
+  ELP_HIP(c, hipStreamSynchronize(c->copy_stream));
+  if (unc) return 1;
+  const int64_t *hp = static_cast<const int64_t *>(c->h_pinned);
+  if (n_rows) {
+    memcpy(q_rows, hp, n_rows * 2 * 8);
+    memcpy(c_rows, hp + n_rows * 2, n_rows * (size_t)ncyc * 2 * 8);
+    memcpy(x_rows, hp + n_rows * 2 + n_rows * (size_t)ncyc * 2, n_rows * ELP_NCTX * 2 * 8);
+  }
   return 0;
 }
 
@@ -1951,6 +2042,7 @@ static void lut_quality_range(const elp_ctx *c, int *qlo, int *qhi) {
 // The LUT's way to the device ahead of the apply call: from the thread that built it, on the context's copy stream, while the context's
 // own stream still runs the sort / metrics pass (6.4 MB at --max-cycle 500: ~0.2 ms that elp_bqsr_apply otherwise spends in front of its
 // first kernel).  The LUT lives in a buffer of its own (not in the scratch pool: other stages are running).
+static int lut_uploaded(elp_ctx *c, int max_cycle);
 int elp_bqsr_lut_upload(elp_ctx *c, int max_cycle, const uint8_t *lut, const uint8_t *cov_present) {
   if (!c || !lut || !cov_present || max_cycle < 1) return set_error(c, ELP_ERR_ARG, "elp_bqsr_lut_upload: bad arguments");
   ELP_HIP(c, hipSetDevice(c->device));
@@ -1981,8 +2073,13 @@ int elp_bqsr_lut_upload(elp_ctx *c, int max_cycle, const uint8_t *lut, const uin
   } else {
     ELP_HIP(c, hipMemcpyAsync(c->lut_dev.p, c->lut_pinned, all, hipMemcpyHostToDevice, c->copy_stream));
   }
-  // the row dictionary apply3 works from, behind the copy on the same stream - if what it depends on is known now (the quality hint of the
-  // gather that produced these tables, a read set of one length): 0.25 ms that elp_bqsr_apply otherwise spends in front of its kernel
+  return lut_uploaded(c, max_cycle);
+}
+
+// behind the LUT's arrival in lut_dev on the copy stream: the row dictionary apply3 works from - if what it depends on is known now (the
+// quality hint of the gather that produced these tables, a read set of one length): 0.25 ms that elp_bqsr_apply otherwise spends in front of
+// its kernel - and the event the apply waits for
+static int lut_uploaded(elp_ctx *c, int max_cycle) {
   c->dict_ready = false;
   const bool force_old = c->tune.apply_kernel == 1;
   if (!force_old && c->have_qual_present && c->uniform_n == c->n && c->uniform_len >= 16 && c->n > 0 && (int64_t)c->max_l_seq <= (int64_t)max_cycle) {
@@ -2007,6 +2104,53 @@ int elp_bqsr_lut_upload(elp_ctx *c, int max_cycle, const uint8_t *lut, const uin
   ELP_HIP(c, hipEventRecord(c->lut_ev, c->copy_stream));
   c->lut_uploaded_cycle = max_cycle;
   return 0;
+}
+
+// elp_bqsr_lut_upload for the LUT in rows form (the host library's elp_bqsr_tables_build_lut_rows): n_cov x n_quals rows + one default byte
+// per other row instead of n_cov x 94 rows - with 16 read groups 1.9 MB instead of 25.6 MB over PCIe (and 13 x less for the host to fill);
+// a kernel on the copy stream expands it into the dense LUT every apply kernel reads.
+int elp_bqsr_lut_upload_rows(elp_ctx *c, int max_cycle, const uint8_t *quals, int n_quals, const uint8_t *rows, const uint8_t *defaults, const uint8_t *cov_present) {
+  if (!c || max_cycle < 1 || n_quals < 0 || n_quals > ELP_NQUAL || (n_quals && (!quals || !rows)) || !defaults || !cov_present)
+    return set_error(c, ELP_ERR_ARG, "elp_bqsr_lut_upload_rows: bad arguments");
+  uint8_t slot_of[ELP_NQUAL];
+  memset(slot_of, 255, sizeof slot_of);
+  for (int k = 0; k < n_quals; k++) {
+    if (quals[k] >= ELP_NQUAL || slot_of[quals[k]] != 255) return set_error(c, ELP_ERR_ARG, "elp_bqsr_lut_upload_rows: quality list");
+    slot_of[quals[k]] = (uint8_t)k;
+  }
+  ELP_HIP(c, hipSetDevice(c->device));
+  const size_t ncyc = 2 * (size_t)max_cycle + 1, row_b = ncyc * 17;
+  const size_t rows_bytes = (size_t)c->n_cov * (size_t)n_quals * row_b, def_bytes = (size_t)c->n_cov * ELP_NQUAL;
+  const size_t lut_bytes = (size_t)c->n_cov * ELP_NQUAL * row_b, small = def_bytes + ELP_NQUAL + (size_t)c->n_cov;  // defaults | slot_of | cov_present
+  if (c->lut_ev) ELP_HIP(c, hipEventSynchronize(c->lut_ev));  // (a previous upload still in flight reads the pinned buffer)
+  hipPointerAttribute_t pa;
+  const bool caller_pinned = rows_bytes && hipPointerGetAttributes(&pa, rows) == hipSuccess && pa.type == hipMemoryTypeHost;
+  if (!caller_pinned) (void)hipGetLastError();
+  const size_t staged = small + (caller_pinned ? 0 : rows_bytes);
+  if (staged > c->lut_pinned_cap) {
+    if (c->lut_pinned) (void)hipHostFree(c->lut_pinned);
+    c->lut_pinned = nullptr; c->lut_pinned_cap = 0;
+    ELP_HIP(c, hipHostMalloc(&c->lut_pinned, staged, hipHostMallocDefault));
+    c->lut_pinned_cap = staged;
+  }
+  uint8_t *hp = static_cast<uint8_t *>(c->lut_pinned);
+  memcpy(hp, defaults, def_bytes);
+  memcpy(hp + def_bytes, slot_of, ELP_NQUAL);
+  memcpy(hp + def_bytes + ELP_NQUAL, cov_present, (size_t)c->n_cov);
+  if (!caller_pinned && rows_bytes) memcpy(hp + small, rows, rows_bytes);
+  ELP_TRY(ensure(c, c->lut_dev, lut_bytes + (size_t)c->n_cov + 64));
+  ELP_TRY(ensure(c, c->lut_rows_dev, rows_bytes + small + 64));
+  if (!c->lut_ev) ELP_HIP(c, hipEventCreateWithFlags(&c->lut_ev, hipEventDisableTiming));
+  if (!c->copy_stream) ELP_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  if (c->apply_ev) ELP_HIP(c, hipStreamWaitEvent(c->copy_stream, c->apply_ev, 0));  // an apply that still reads the previous LUT
+  uint8_t *d_small = c->lut_rows_dev.p, *d_rows = c->lut_rows_dev.p + ((small + 63) & ~(size_t)63);
+  ELP_HIP(c, hipMemcpyAsync(d_small, hp, small, hipMemcpyHostToDevice, c->copy_stream));
+  if (rows_bytes) ELP_HIP(c, hipMemcpyAsync(d_rows, caller_pinned ? rows : hp + small, rows_bytes, hipMemcpyHostToDevice, c->copy_stream));
+  hipLaunchKernelGGL(k_lut_expand_rows, dim3(blocks_for(lut_bytes, 256)), dim3(256), 0, c->copy_stream, (const uint8_t *)d_rows, (const uint8_t *)d_small,
+                     (const uint8_t *)(d_small + def_bytes), c->n_cov, n_quals, (int)ncyc, c->lut_dev.p);
+  ELP_HIP(c, hipGetLastError());
+  ELP_HIP(c, hipMemcpyAsync(c->lut_dev.p + lut_bytes, d_small + def_bytes + ELP_NQUAL, (size_t)c->n_cov, hipMemcpyDeviceToDevice, c->copy_stream));
+  return lut_uploaded(c, max_cycle);
 }
 
 static int bqsr_apply_impl(elp_ctx *c, int max_cycle, const uint8_t *lut, const uint8_t *cov_present);

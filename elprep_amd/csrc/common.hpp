@@ -143,6 +143,9 @@ struct elp_ctx {
   elp::DVec<unsigned long long> dev_tables;
   size_t tables_n = 0;
   int tables_max_cycle = 0;
+  unsigned long long tables_quals[2] = {0, 0};  // the qualities that had table slots in the gather that made dev_tables (no other row holds anything)
+  elp::DVec<unsigned long long> tables_pack;    // elp_bqsr_tables_fetch_rows: the rows of the asked qualities, packed on the device
+  elp::DVec<uint8_t> lut_rows_dev;              // elp_bqsr_lut_upload_rows: the LUT in rows form before its expansion into lut_dev
   // device group (group.hip)
   void *comm = nullptr;  // ncclComm_t
   bool comm_borrowed = false;  // elp_group_share: another context of this process owns (and destroys) it

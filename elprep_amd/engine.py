@@ -403,6 +403,43 @@ class Engine:
         self._check(self.L.elp_allreduce_i64(self.h, _vp(out), out.size))
         return out.reshape(a.shape)
 
+    def quals_counted(self) -> list:
+        """the qualities that had table slots in the gather that made the device tables (elp_bqsr_quals_counted), ascending"""
+        bits = np.zeros(2, np.uint64)
+        self._check(self.L.elp_bqsr_quals_counted(self.h, _vp(bits)))
+        return [q for q in range(NQUAL) if (int(bits[q >> 6]) >> (q & 63)) & 1]
+
+    def tables_fetch_rows(self, quals, reuse: bool = False):
+        """the device tables' rows of `quals` only (elp_bqsr_tables_fetch_rows): (q_rows, c_rows, x_rows), or None if another quality has
+        observations (tables that were summed with another context's: fetch the dense ones).  reuse: the engine's own page-locked arrays"""
+        max_cycle = self._max_cycle
+        qs = np.ascontiguousarray(list(quals), dtype=np.uint8)
+        nc, nq, ncyc = self.header.n_cov, int(qs.size), 2 * max_cycle + 1
+        bufs = getattr(self, "_row_tables", None) if reuse else None
+        if bufs is None or bufs[0] != (nc, nq, max_cycle):
+            if bufs is not None:
+                for a in bufs[1:]:
+                    self.pinned_release(a)
+            mk = self.pinned_zeros if reuse else (lambda shape, dtype: np.zeros(shape, dtype=dtype))
+            bufs = ((nc, nq, max_cycle), mk((nc, nq, 2), np.int64), mk((nc, nq, ncyc, 2), np.int64), mk((nc, nq, NCTX, 2), np.int64))
+            if reuse:
+                self._row_tables = bufs
+        _, qr, cr, xr = bufs
+        rc = self.L.elp_bqsr_tables_fetch_rows(self.h, _vp(qs), nq, _vp(qr), _vp(cr), _vp(xr))
+        if rc == 1:
+            return None
+        self._check(rc)
+        return qr, cr, xr
+
+    def lut_upload_rows(self, quals, rows: np.ndarray, defaults: np.ndarray, cov_present: np.ndarray, max_cycle: int = 500):
+        """lut_upload for the LUT in rows form (BqsrTables.build_lut_rows): expanded into the dense LUT on the device"""
+        qs = np.ascontiguousarray(list(quals), dtype=np.uint8)
+        rows = np.ascontiguousarray(rows, dtype=np.uint8)
+        d = np.ascontiguousarray(defaults, dtype=np.uint8)
+        cp = np.ascontiguousarray(cov_present, dtype=np.uint8)
+        assert rows.size == self.header.n_cov * qs.size * (2 * max_cycle + 1) * 17 and d.size == self.header.n_cov * NQUAL
+        self._check(self.L.elp_bqsr_lut_upload_rows(self.h, max_cycle, _vp(qs), int(qs.size), _vp(rows), _vp(d), _vp(cp)))
+
     def lut_upload(self, lut: np.ndarray, cov_present: np.ndarray, max_cycle: int = 500):
         """the LUT's way to the device ahead of apply_bqsr(None, None, ...): callable from the thread that built it while other calls run"""
         lut = np.ascontiguousarray(lut, dtype=np.uint8)
@@ -465,6 +502,37 @@ class BqsrTables:
         self.t = C.c_void_p(self.H.elp_bqsr_tables_new(self.n_cov, max_cycle, _vp(q), _vp(c), _vp(x)))
         if not self.t.value:
             raise RuntimeError("elp_bqsr_tables_new failed")
+
+    @classmethod
+    def from_rows(cls, n_cov: int, quals: Sequence[int], q_rows: np.ndarray, c_rows: np.ndarray, x_rows: np.ndarray, max_cycle: int = 500) -> "BqsrTables":
+        """the tables from the rows of the qualities that can hold anything (Engine.tables_fetch_rows): q_rows [n_cov][len(quals)][2],
+        c_rows [n_cov][len(quals)][2*max_cycle+1][2], x_rows [n_cov][len(quals)][16][2]; every other row is empty"""
+        self = cls.__new__(cls)
+        self.H = _lib.host()
+        self.n_cov, self.max_cycle = int(n_cov), max_cycle
+        qs = np.ascontiguousarray(list(quals), dtype=np.uint8)
+        q, c, x = (np.ascontiguousarray(t, dtype=np.int64) for t in (q_rows, c_rows, x_rows))
+        self.t = C.c_void_p(self.H.elp_bqsr_tables_new_rows(self.n_cov, max_cycle, _vp(qs), qs.size, _vp(q), _vp(c), _vp(x)))
+        if not self.t.value:
+            raise RuntimeError("elp_bqsr_tables_new_rows failed")
+        return self
+
+    def build_lut_rows(self, quals: Sequence[int], quantize_levels: int = 0, sqq: Sequence[int] = (), out=None):
+        """the LUT in rows form: (rows [n_cov][len(quals)][2*max_cycle+1][17], defaults [n_cov][94], present [n_cov]) - what
+        Engine.lut_upload_rows expands on the device into build_lut's dense LUT.  out: the triple of an earlier call to fill again."""
+        ncyc = 2 * self.max_cycle + 1
+        qs = np.ascontiguousarray(list(quals), dtype=np.uint8)
+        if out is not None and out[0].shape == (self.n_cov, qs.size, ncyc, 17):
+            rows, defaults, present = out
+        else:
+            rows = np.zeros((self.n_cov, qs.size, ncyc, 17), np.uint8)
+            defaults = np.zeros((self.n_cov, NQUAL), np.uint8)
+            present = np.zeros(self.n_cov, np.uint8)
+        s = np.asarray(list(sqq), dtype=np.uint8)
+        rc = self.H.elp_bqsr_tables_build_lut_rows(self.t, quantize_levels, _vp(s), s.size, _vp(qs), qs.size, _vp(rows), _vp(defaults), _vp(present))
+        if rc != 0:
+            raise RuntimeError("elp_bqsr_tables_build_lut_rows: %d (a quality outside `quals` has table entries)" % rc)
+        return rows, defaults, present
 
     def __del__(self):
         try:

@@ -369,6 +369,37 @@ elp_bqsr_tables *elp_bqsr_tables_new(int n_cov, int max_cycle, const int64_t *qt
   add_rows(t, ct, xt);
   return t;
 }
+// The same object from the rows of the qualities that CAN hold anything (round 5): with many read groups the dense tables are tens of
+// megabytes of zeros around a few hundred rows - n_cov x 94 rows of 16 KB, of which n_cov x (qualities in the read set) are used - and
+// carrying them over PCIe and scanning them was most of the host's time per step.  quals: ascending quality values; q_rows
+// [n_cov][n_quals][2], c_rows [n_cov][n_quals][2*max_cycle+1][2], x_rows [n_cov][n_quals][16][2]; every other row is empty.
+elp_bqsr_tables *elp_bqsr_tables_new_rows(int n_cov, int max_cycle, const uint8_t *quals, int n_quals, const int64_t *q_rows, const int64_t *c_rows,
+                                          const int64_t *x_rows) {
+  if (n_cov < 0 || max_cycle < 1 || n_quals < 0 || n_quals > NQ || (n_quals && (!quals || !q_rows || !c_rows || !x_rows))) return nullptr;
+  for (int k = 0; k < n_quals; k++)
+    if (quals[k] >= NQ || (k && quals[k] <= quals[k - 1])) return nullptr;
+  auto *t = new elp_bqsr_tables();
+  t->n_cov = n_cov; t->max_cycle = max_cycle; t->ncyc = 2 * max_cycle + 1;
+  const size_t nq = size_t(n_cov) * NQ, cw = size_t(t->ncyc) * 2, xw = size_t(NX) * 2;
+  t->q.assign(nq * 2, 0);
+  t->live.assign(nq, 0);
+  if (!t->c.alloc(nq * t->ncyc * 2) || !t->x.alloc(nq * NX * 2)) { delete t; return nullptr; }
+  parallel_rows(size_t(n_cov) * size_t(n_quals), [&](size_t k) {
+    const size_t cv = k / size_t(n_quals), row = cv * NQ + quals[k % size_t(n_quals)];
+    const long long *qs = reinterpret_cast<const long long *>(q_rows) + k * 2;
+    const long long *cs = reinterpret_cast<const long long *>(c_rows) + k * cw;
+    const long long *xs = reinterpret_cast<const long long *>(x_rows) + k * xw;
+    t->q[2 * row] = qs[0]; t->q[2 * row + 1] = qs[1];
+    bool any = false;
+    for (size_t j = 0; j < cw && !any; j++) any = cs[j] != 0;
+    for (size_t j = 0; j < xw && !any; j++) any = xs[j] != 0;
+    if (!any) return;
+    std::memcpy(&t->c[row * cw], cs, cw * sizeof(long long));
+    std::memcpy(&t->x[row * xw], xs, xw * sizeof(long long));
+    t->live[row] = 1;
+  }, n_cov <= 2);
+  return t;
+}
 void elp_bqsr_tables_free(elp_bqsr_tables *t) { delete t; }
 
 int elp_bqsr_tables_merge(elp_bqsr_tables *t, const int64_t *qt, const int64_t *ct, const int64_t *xt) {
@@ -530,6 +561,55 @@ static void static_quantized(const uint8_t *quals_in, int n, uint8_t *out) {  //
 // (:901-919) factorises: deltaGlobal depends on rg; deltaReported and the conditional prior on (rg, qual); the cycle term on
 // (rg, qual, cycle); the context term on (rg, qual, context).  Tabulating the three factors and combining them with the very
 // same float64 operations in the same order (conditionalPrior + (cycleTerm + contextTerm)) reproduces every memo value.
+// one (covariate, quality) row of the LUT, [ncyc][17] bytes at lq; returns the byte every cycle WITHOUT a table entry holds at context
+// index 16 (a row that is not live is that byte everywhere)
+static uint8_t lut_row(const elp_bqsr_tables *t, int cv, int ql, const uint8_t *quantized, const uint8_t *stat, int n_sqq, uint8_t *lq) {
+  const int ncyc = t->ncyc;
+  std::vector<double> dcyc(ncyc), dctx(17);
+  const size_t qi = t->qi(cv, ql);
+  const double cond = t->cond[qi];  // deltaQReported + deltaQ + epsilon, and the entries' estimates under it: elp_bqsr_tables_finalize
+  const bool live = t->live[qi] != 0;  // else: no cycle or context entry in this row
+  for (int cy = 0; live && cy < ncyc; cy++) {
+    const size_t ci = qi * ncyc + cy;
+    dcyc[cy] = t->c[2 * ci] > 0 ? double(t->ce_cond[ci]) - cond : 0.0;
+  }
+  for (int cx = 0; cx < 16; cx++) {
+    const size_t xi = qi * NX + cx;
+    dctx[cx] = live && t->x[2 * xi] > 0 ? double(t->xe_cond[xi]) - cond : 0.0;
+  }
+  auto entry = [&](bool has_c, int cy, int cx) {
+    const bool has_x = live && cx < 16 && t->x[2 * (qi * NX + cx)] > 0;
+    double d_cov = 0;
+    if (has_c) d_cov = dcyc[cy];
+    if (has_x) d_cov += dctx[cx];
+    const double est = cond + d_cov;
+    int r = int(std::round(est));
+    if (r > 93) r = 93;
+    if (r < 1) r = 1;
+    uint8_t o = quantized[r];
+    if (n_sqq > 0) o = stat[o];
+    return o;
+  };
+  uint8_t no_cycle[17];  // the 17 values of a cycle without table entry (the same for every such cycle)
+  for (int cx = 0; cx < 17; cx++) no_cycle[cx] = entry(false, 0, cx);
+  if (!lq) return no_cycle[16];
+  // the whole (cov, quality) row = that pattern repeated (filled by doubling), then the cycles that do have an entry
+  const size_t row_bytes = size_t(ncyc) * 17;
+  std::memcpy(lq, no_cycle, 17);
+  for (size_t have = 17; have < row_bytes;) {
+    const size_t n = std::min(have, row_bytes - have);
+    std::memcpy(lq + have, lq, n);
+    have += n;
+  }
+  for (int cy = 0; live && cy < ncyc; cy++) {
+    if (t->c[2 * (qi * ncyc + cy)] > 0) {
+      uint8_t *le = lq + size_t(cy) * 17;
+      for (int cx = 0; cx < 17; cx++) le[cx] = entry(true, cy, cx);
+    }
+  }
+  return no_cycle[16];
+}
+
 int elp_bqsr_tables_build_lut(const elp_bqsr_tables *t, int quantize_levels, const uint8_t *sqq, int n_sqq, uint8_t *lut, uint8_t *cov_present) {
   if (!t || !t->finalized || !lut || !cov_present) return -1;
   int64_t counts[94];
@@ -541,55 +621,45 @@ int elp_bqsr_tables_build_lut(const elp_bqsr_tables *t, int quantize_levels, con
     cov_present[cv] = t->present[cv];
     if (!t->present[cv]) std::memset(lut + size_t(cv) * NQ * ncyc * 17, 0, size_t(NQ) * ncyc * 17);
   }
-  {
-    parallel_rows(size_t(t->n_cov) * NQ, [&](size_t row) {  // one (covariate, quality) row of the LUT per task
-      const int cv = int(row / NQ), ql = int(row % NQ);
-      if (!t->present[cv]) return;
-      uint8_t *lc = lut + size_t(cv) * NQ * ncyc * 17;
-      std::vector<double> dcyc(ncyc), dctx(17);
-      const size_t qi = t->qi(cv, ql);
-      const double cond = t->cond[qi];  // deltaQReported + deltaQ + epsilon, and the entries' estimates under it: elp_bqsr_tables_finalize
-      const bool live = t->live[qi] != 0;  // else: no cycle or context entry in this row
-      for (int cy = 0; live && cy < ncyc; cy++) {
-        const size_t ci = qi * ncyc + cy;
-        dcyc[cy] = t->c[2 * ci] > 0 ? double(t->ce_cond[ci]) - cond : 0.0;
-      }
-      for (int cx = 0; cx < 16; cx++) {
-        const size_t xi = qi * NX + cx;
-        dctx[cx] = live && t->x[2 * xi] > 0 ? double(t->xe_cond[xi]) - cond : 0.0;
-      }
-      uint8_t *lq = lc + size_t(ql) * ncyc * 17;
-      auto entry = [&](bool has_c, int cy, int cx) {
-        const bool has_x = live && cx < 16 && t->x[2 * (qi * NX + cx)] > 0;
-        double d_cov = 0;
-        if (has_c) d_cov = dcyc[cy];
-        if (has_x) d_cov += dctx[cx];
-        const double est = cond + d_cov;
-        int r = int(std::round(est));
-        if (r > 93) r = 93;
-        if (r < 1) r = 1;
-        uint8_t o = quantized[r];
-        if (n_sqq > 0) o = stat[o];
-        return o;
-      };
-      uint8_t no_cycle[17];  // the 17 values of a cycle without table entry (the same for every such cycle)
-      for (int cx = 0; cx < 17; cx++) no_cycle[cx] = entry(false, 0, cx);
-      // the whole (cov, quality) row = that pattern repeated (filled by doubling), then the cycles that do have an entry
-      const size_t row_bytes = size_t(ncyc) * 17;
-      std::memcpy(lq, no_cycle, 17);
-      for (size_t have = 17; have < row_bytes;) {
-        const size_t n = std::min(have, row_bytes - have);
-        std::memcpy(lq + have, lq, n);
-        have += n;
-      }
-      for (int cy = 0; live && cy < ncyc; cy++) {
-        if (t->c[2 * (qi * ncyc + cy)] > 0) {
-          uint8_t *le = lq + size_t(cy) * 17;
-          for (int cx = 0; cx < 17; cx++) le[cx] = entry(true, cy, cx);
-        }
-      }
-    }, small_job(t->live, t->n_cov));
+  parallel_rows(size_t(t->n_cov) * NQ, [&](size_t row) {  // one (covariate, quality) row of the LUT per task
+    const int cv = int(row / NQ), ql = int(row % NQ);
+    if (!t->present[cv]) return;
+    (void)lut_row(t, cv, ql, quantized, stat, n_sqq, lut + (size_t(cv) * NQ + size_t(ql)) * ncyc * 17);
+  }, small_job(t->live, t->n_cov));
+  return 0;
+}
+
+// The LUT in the rows form (round 5): rows [n_cov][n_quals][2*max_cycle+1][17] for the qualities `quals` (ascending), and for every other
+// (covariate, quality) the ONE byte its whole row consists of (a row without cycle and context entries: the estimate is the row's prior
+// whatever the cycle and the context), defaults [n_cov][94].  Expanding the two gives elp_bqsr_tables_build_lut's dense LUT byte for
+// byte (elp_bqsr_lut_upload_rows does that on the device); returns -2 if a quality outside `quals` has table entries.
+int elp_bqsr_tables_build_lut_rows(const elp_bqsr_tables *t, int quantize_levels, const uint8_t *sqq, int n_sqq, const uint8_t *quals, int n_quals, uint8_t *rows,
+                                   uint8_t *defaults, uint8_t *cov_present) {
+  if (!t || !t->finalized || !defaults || !cov_present || n_quals < 0 || n_quals > NQ || (n_quals && (!quals || !rows))) return -1;
+  int slot[NQ];
+  for (int q = 0; q < NQ; q++) slot[q] = -1;
+  for (int k = 0; k < n_quals; k++) {
+    if (quals[k] >= NQ || (k && quals[k] <= quals[k - 1])) return -1;
+    slot[quals[k]] = k;
   }
+  for (size_t row = 0; row < size_t(t->n_cov) * NQ; row++)
+    if (t->live[row] && slot[row % NQ] < 0) return -2;
+  int64_t counts[94];
+  uint8_t quantized[94], stat[254];
+  elp_bqsr_tables_quantize(t, quantize_levels, counts, quantized);
+  if (n_sqq > 0) static_quantized(sqq, n_sqq, stat);
+  const int ncyc = t->ncyc;
+  for (int cv = 0; cv < t->n_cov; cv++) cov_present[cv] = t->present[cv];
+  parallel_rows(size_t(t->n_cov) * NQ, [&](size_t row) {
+    const int cv = int(row / NQ), ql = int(row % NQ), k = slot[ql];
+    uint8_t *lq = k >= 0 ? rows + (size_t(cv) * size_t(n_quals) + size_t(k)) * ncyc * 17 : nullptr;
+    if (!t->present[cv]) {
+      defaults[row] = 0;
+      if (lq) std::memset(lq, 0, size_t(ncyc) * 17);
+      return;
+    }
+    defaults[row] = lut_row(t, cv, ql, quantized, stat, n_sqq, lq);
+  }, small_job(t->live, t->n_cov));
   return 0;
 }
 

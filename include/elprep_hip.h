@@ -260,6 +260,14 @@ int elp_bqsr_gather(elp_ctx *ctx, int max_cycle, int64_t *qual_tbl, int64_t *cyc
  * counts optical duplicates - the two steps the reference runs one after the other (cmd/filter.go:162-196). */
 int elp_bqsr_gather_device(elp_ctx *ctx, int max_cycle);
 int elp_bqsr_tables_fetch(elp_ctx *ctx, int64_t *qual_tbl, int64_t *cycle_tbl, int64_t *ctx_tbl);
+/* The rows form of the device tables (round 5): with many read groups the dense tables are tens of megabytes around a few hundred rows
+ * that hold anything (a Go map of the reference has those entries only, filters/bqsr.go:445-459).  elp_bqsr_quals_counted: bit q of
+ * bits[q / 64] = quality q had table slots in the gather that made the tables (no other quality's rows hold anything).
+ * elp_bqsr_tables_fetch_rows: the rows of `quals` only - q_rows [n_cov][n_quals][2], c_rows [n_cov][n_quals][2*max_cycle+1][2], x_rows
+ * [n_cov][n_quals][16][2]; returns 1 and copies nothing if a quality that was not asked for has observations (tables summed with
+ * another context's or rank's: fetch the dense tables then).  Same threading rule as elp_bqsr_tables_fetch. */
+int elp_bqsr_quals_counted(elp_ctx *ctx, uint64_t *bits /* [2] */);
+int elp_bqsr_tables_fetch_rows(elp_ctx *ctx, const uint8_t *quals, int n_quals, int64_t *q_rows, int64_t *c_rows, int64_t *x_rows);
 
 /* ---- device group and its one collective: the table / metrics combination of `elprep sfm`'s merge phase ----
  * LoadAndCombineBQSRTables (filters/print-bqsr.go:310-329) and LoadAndCombineDuplicateMetrics
@@ -321,6 +329,11 @@ int elp_bqsr_apply(elp_ctx *ctx, int max_cycle, const uint8_t *lut, const uint8_
  * A `lut` in page-locked memory (elp_pinned_alloc) is copied from where it lies (no staging copy: with 16 read groups the LUT is 25 MB):
  * the caller then leaves it unchanged until the elp_bqsr_apply that uses it has been called and the context synchronised. */
 int elp_bqsr_lut_upload(elp_ctx *ctx, int max_cycle, const uint8_t *lut, const uint8_t *cov_present);
+/* The same for the LUT in rows form: rows [n_cov][n_quals][2*max_cycle+1][17] for the qualities `quals`, defaults [n_cov][94] = the one byte
+ * every other (read group, quality) row consists of (a row without cycle and context entries is its prior whatever the cycle and the
+ * context); the dense LUT is made from them on the device.  With 16 read groups 1.9 MB instead of 25.6 MB cross PCIe. */
+int elp_bqsr_lut_upload_rows(elp_ctx *ctx, int max_cycle, const uint8_t *quals, int n_quals, const uint8_t *rows, const uint8_t *defaults,
+                             const uint8_t *cov_present);
 int elp_get_qual(elp_ctx *ctx, uint8_t *qual_out /* qual_bytes, staging order and offsets */);
 
 /* ---- CleanSam (filters/simple-filters.go:292-306, `elprep filter --clean-sam`: a filter of the phase-1 pipeline, cmd/filter.go:747) ----

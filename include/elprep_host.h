@@ -21,6 +21,10 @@ typedef struct elp_bqsr_tables elp_bqsr_tables;
 
 /* BaseRecalibratorTables (filters/bqsr.go:445-459) as dense arrays; shapes as in elp_bqsr_gather. Copies the inputs. */
 elp_bqsr_tables *elp_bqsr_tables_new(int n_cov, int max_cycle, const int64_t *qual_tbl, const int64_t *cycle_tbl, const int64_t *ctx_tbl);
+/* The same from the rows of the qualities that can hold anything (elp_bqsr_tables_fetch_rows): quals ascending; q_rows [n_cov][n_quals][2],
+ * c_rows [n_cov][n_quals][2*max_cycle+1][2], x_rows [n_cov][n_quals][16][2]; every other row is empty. */
+elp_bqsr_tables *elp_bqsr_tables_new_rows(int n_cov, int max_cycle, const uint8_t *quals, int n_quals, const int64_t *q_rows, const int64_t *c_rows,
+                                          const int64_t *x_rows);
 void elp_bqsr_tables_free(elp_bqsr_tables *t);
 /* bqsrTable.merge (filters/bqsr.go:210-223) / LoadAndCombineBQSRTables (filters/print-bqsr.go:310-329): t += other */
 int elp_bqsr_tables_merge(elp_bqsr_tables *t, const int64_t *qual_tbl, const int64_t *cycle_tbl, const int64_t *ctx_tbl);
@@ -35,6 +39,10 @@ int elp_bqsr_tables_quantize(const elp_bqsr_tables *t, int levels, int64_t *coun
 /* Dense tabulation of ApplyBQSR's memo map (filters/bqsr.go:936-1003): lut [n_cov][94][2*max_cycle+1][17],
  * cov_present [n_cov].  sqq = --sqq list (may be NULL, n_sqq 0). */
 int elp_bqsr_tables_build_lut(const elp_bqsr_tables *t, int quantize_levels, const uint8_t *sqq, int n_sqq, uint8_t *lut, uint8_t *cov_present);
+/* The same LUT in rows form: rows [n_cov][n_quals][2*max_cycle+1][17] for the qualities `quals`, defaults [n_cov][94] = the one byte every
+ * other (covariate, quality) row consists of; -2 if a quality outside `quals` has table entries.  (elp_bqsr_lut_upload_rows expands it.) */
+int elp_bqsr_tables_build_lut_rows(const elp_bqsr_tables *t, int quantize_levels, const uint8_t *sqq, int n_sqq, const uint8_t *quals, int n_quals, uint8_t *rows,
+                                   uint8_t *defaults, uint8_t *cov_present);
 /* PrintBQSRTables (filters/print-bqsr.go:269-298) into a malloc'd string (free with elp_host_free) */
 char *elp_bqsr_tables_report(const elp_bqsr_tables *t, const char *const *cov_names, const char *tablename_prefix);
 void elp_host_free(void *p);

@@ -329,7 +329,11 @@ def test_merge_phase_across_two_ranks_through_the_c_abi():
         inputs.append(b)
     h = cfg.header()
     spread_owner = int(owner[G + 1])
+    # what arrives where (as in the split-phase test), and for every arriving record the input batch and index it came from: the oracle's
+    # BAM encoder derives a record's optional fields from its index in the batch it encodes, so the expected records are encoded from
+    # the INPUT batches
     want_local, want_spread = [[] for _ in range(world)], []
+    from_local, from_spread = [[] for _ in range(world)], []
     for r in range(world):
         for src in (r, 1 - r):
             b = inputs[src]
@@ -337,8 +341,24 @@ def test_merge_phase_across_two_ranks_through_the_c_abi():
             idx = np.nonzero(owner[g] == r)[0]
             if idx.size:
                 want_local[r].append(sfm.with_sr(b, sp, g).take(idx))
+                from_local[r] += [(src, int(i)) for i in idx]
             if r == spread_owner and sp.any():
                 want_spread.append(b.take(np.nonzero(sp)[0]))
+                from_spread += [(src, int(i)) for i in np.nonzero(sp)[0]]
+
+    def encoded(origin, flags):
+        """the records of a context (arrival order; origin[j] = (input batch, index), flags[j] = the oracle's FLAG) as elprep writes them"""
+        recs = [None] * len(origin)
+        for src in range(world):
+            js = [j for j, (s_, _) in enumerate(origin) if s_ == src]
+            if not js:
+                continue
+            fl = inputs[src].flag.copy()
+            idx = np.asarray([origin[j][1] for j in js], dtype=np.uint32)
+            fl[idx] = flags[js]
+            for j, rec in zip(js, _bam_records(orc.bam_encode(inputs[src], h.rg_ids, order=idx, flags=fl, normalize_tags=True))):
+                recs[j] = rec
+        return recs
     out = {}
 
     def body(r, reader, dest):
@@ -360,13 +380,15 @@ def test_merge_phase_across_two_ranks_through_the_c_abi():
     wsp = Batch.concat(want_spread)
     sflags = orc.mark_duplicates(wsp, h)
     sorder = orc.sort_coordinate(wsp, sflags)[:orc.num_sorted(wsp)]
-    srecs = _bam_records(orc.bam_encode(wsp, h.rg_ids, order=sorder, flags=sflags, normalize_tags=True))
+    s_all = encoded(from_spread, sflags)
+    srecs = [s_all[j] for j in sorder]
     sgroup = gof[wsp.refid[sorder]]
     for r in range(world):
         loc = Batch.concat(want_local[r])
         lflags = orc.mark_duplicates(loc, h)
         lorder = orc.sort_coordinate(loc, lflags)[:orc.num_sorted(loc)]
-        lrecs = _bam_records(orc.bam_encode(loc, h.rg_ids, order=lorder, flags=lflags, normalize_tags=True))
+        l_all = encoded(from_local[r], lflags)
+        lrecs = [l_all[j] for j in lorder]
         keys = [(int(loc.refid[i]), int(loc.pos[i])) for i in lorder]
         n_mapped = sum(1 for k in keys if k[0] >= 0)
         mine = np.nonzero(owner[sgroup] == r)[0]  # the spread reads of this rank's contig groups, in the spread file's order
@@ -424,3 +446,30 @@ def test_emit_sorted_bgzf_compresses_on_the_device(n_pairs):
     assert e2.emit_sorted_bam().tobytes() == e3.emit_sorted_bam().tobytes()
     e2.close()
     e3.close()
+
+
+@pytest.mark.parametrize("n_cov,length", [(3, 150), (20, 100)])
+def test_tables_and_lut_in_rows_form_on_the_device(n_cov, length):
+    """the rows form of the host's table path (round 5): elp_bqsr_tables_fetch_rows gives the dense tables' rows of the counted qualities,
+    the LUT uploaded as rows + defaults (elp_bqsr_lut_upload_rows, expanded on the device) recalibrates to the same bytes as the dense LUT
+    - the oracle's; tables that hold another quality's rows (summed with another context's) are reported, not truncated"""
+    b, h, refs, sites = _uniform_case(400 + n_cov, 6000, length, quals=QUALS7, n_cov=n_cov)
+    want = _oracle(b, h, refs, sites)
+    e = Engine(h)
+    e.stage(b)
+    e.mark_duplicates()
+    for r in range(h.n_ref):
+        e.set_reference(r, refs[r])
+        e.set_known_sites(r, sites[r])
+    e.recalibrate_device(500)
+    qt, ct, xt = e.tables_fetch()
+    quals = e.quals_counted()
+    assert quals == [q for q in QUALS7 if q >= 6]
+    qr, cr, xr = e.tables_fetch_rows(quals)
+    assert np.array_equal(qr, qt[:, quals]) and np.array_equal(cr, ct[:, quals]) and np.array_equal(xr, xt[:, quals])
+    assert not np.delete(qt, quals, axis=1).any() and np.array_equal(ct, want[1][1])
+    assert e.tables_fetch_rows(quals[1:]) is None            # a counted quality that was not asked for: reported
+    tb = BqsrTables.from_rows(h.n_cov, quals, qr, cr, xr, 500).finalize()
+    e.lut_upload_rows(quals, *tb.build_lut_rows(quals, 0), 500)
+    assert np.array_equal(e.apply_bqsr(None, None, 500), want[2])
+    e.close()

@@ -189,3 +189,28 @@ def test_host_pool_is_reentrant_and_arrays_can_be_reused(tables):
     pair = twice.build_lut(0)
     again = ref.build_lut(0, out=pair)
     assert again[0] is pair[0] and np.array_equal(again[0], lut0) and np.array_equal(again[1], present0)
+
+
+def test_tables_and_lut_in_rows_form_equal_the_dense_forms():
+    """round 5: the host's table path on the rows of the qualities that occur (what crosses PCIe with many read groups) - the object built
+    from rows finalizes to the same empirical qualities, and the LUT in rows form (rows + one default byte per other row) expands to
+    the dense LUT byte for byte"""
+    cfg, b, h, refs, sites = dataset("tiny", 6000, 3, 0.02)
+    flags = orc.mark_duplicates(b, h)
+    qt, ct, xt = orc.bqsr_gather(b, h, orc.BqsrRef(refs, sites), flags, 500)
+    quals = [q for q in range(94) if qt[:, q, 0].any()] + [50]       # (a quality without entries may be among them)
+    quals = sorted(set(quals))
+    assert 3 <= len(quals) < 20
+    dense = BqsrTables(qt, ct, xt, 500).finalize()
+    rows = BqsrTables.from_rows(h.n_cov, quals, qt[:, quals], ct[:, quals], xt[:, quals], 500).finalize()
+    for a, c in zip(dense.empirical(), rows.empirical()):
+        assert np.array_equal(a, c)
+    for levels, sqq in ((0, ()), (4, ()), (0, (10, 20, 30))):
+        lut, present = dense.build_lut(levels, sqq)
+        r, d, p = rows.build_lut_rows(quals, levels, sqq)
+        assert np.array_equal(p, present)
+        full = np.broadcast_to(d[:, :, None, None], lut.shape).copy()
+        full[:, quals] = r
+        assert np.array_equal(full, lut), (levels, sqq)
+    with pytest.raises(RuntimeError):
+        rows.build_lut_rows(quals[:-2])
