@@ -1841,62 +1841,6 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
   return 0;
 }
 
-// the qualities that had table slots in the gather that made the device tables: bit q of bits[q / 64]
-int elp_bqsr_quals_counted(elp_ctx *c, uint64_t *bits) {
-  if (!c || !bits) return ELP_ERR_ARG;
-  if (!c->tables_n) return set_error(c, ELP_ERR_ARG, "elp_bqsr_quals_counted: no device tables (elp_bqsr_gather_device)");
-  bits[0] = c->tables_quals[0];
-  bits[1] = c->tables_quals[1];
-  return 0;
-}
-
-// elp_bqsr_tables_fetch for the rows of the qualities `quals` only: q_rows [n_cov][n_quals][2], c_rows [n_cov][n_quals][2*max_cycle+1][2],
-// x_rows [n_cov][n_quals][16][2] - packed on the device, one copy.  Returns 1 (and copies nothing) if a quality that was not asked for has
-// observations (tables that were summed with another context's or rank's: the caller fetches the dense tables then).
-int elp_bqsr_tables_fetch_rows(elp_ctx *c, const uint8_t *quals, int n_quals, int64_t *q_rows, int64_t *c_rows, int64_t *x_rows) {
-  if (!c || n_quals < 0 || n_quals > ELP_NQUAL || (n_quals && (!quals || !q_rows || !c_rows || !x_rows))) return ELP_ERR_ARG;
-  if (!c->tables_n) return set_error(c, ELP_ERR_ARG, "elp_bqsr_tables_fetch_rows: no device tables (elp_bqsr_gather_device)");
-  for (int k = 0; k < n_quals; k++)
-    if (quals[k] >= ELP_NQUAL) return set_error(c, ELP_ERR_ARG, "elp_bqsr_tables_fetch_rows: quality %d", (int)quals[k]);
-  ELP_HIP(c, hipSetDevice(c->device));
-  const int ncyc = 2 * c->tables_max_cycle + 1;
-  const size_t n_rows = (size_t)c->n_cov * (size_t)n_quals, row_w = 2 + (size_t)ncyc * 2 + ELP_NCTX * 2, words = n_rows * row_w;
-  const size_t bytes = words * 8 + 256;
-  if (bytes > c->h_pinned_cap) {
-    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
-    c->h_pinned = nullptr; c->h_pinned_cap = 0;
-    ELP_HIP(c, hipHostMalloc(&c->h_pinned, bytes, hipHostMallocDefault));
-    c->h_pinned_cap = bytes;
-  }
-  ELP_TRY(ensure(c, c->tables_pack, words + 64));
-  if (!c->copy_stream) ELP_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-  if (c->tables_ev) ELP_HIP(c, hipStreamWaitEvent(c->copy_stream, c->tables_ev, 0));
-  else ELP_HIP(c, hipStreamSynchronize(c->stream));
-  // the quality list and the "uncovered" word ride in the pack buffer's tail
-  uint8_t *d_quals = reinterpret_cast<uint8_t *>(c->tables_pack.p + words);
-  uint32_t *d_unc = reinterpret_cast<uint32_t *>(c->tables_pack.p + words + 16);
-  uint8_t *hq = static_cast<uint8_t *>(c->h_pinned) + words * 8;
-  memset(hq, 0, 256);
-  if (n_quals) memcpy(hq, quals, (size_t)n_quals);
-  ELP_HIP(c, hipMemcpyAsync(d_quals, hq, 128 + 8, hipMemcpyHostToDevice, c->copy_stream));  // (also clears the word)
-  const size_t work = std::max(words, (size_t)c->n_cov * ELP_NQUAL);
-  hipLaunchKernelGGL(k_tables_pack_rows, dim3(blocks_for(work, 256)), dim3(256), 0, c->copy_stream, (const unsigned long long *)c->dev_tables.p, c->n_cov, ncyc,
-                     (const uint8_t *)d_quals, n_quals, c->tables_pack.p, d_unc);
-  ELP_HIP(c, hipGetLastError());
-  ELP_HIP(c, hipMemcpyAsync(c->h_pinned, c->tables_pack.p, words * 8, hipMemcpyDeviceToHost, c->copy_stream));
-  uint32_t unc = 0;
-  ELP_HIP(c, hipMemcpyAsync(&unc, d_unc, 4, hipMemcpyDeviceToHost, c->copy_stream));
-  ELP_HIP(c, hipStreamSynchronize(c->copy_stream));
-  if (unc) return 1;
-  const int64_t *hp = static_cast<const int64_t *>(c->h_pinned);
-  if (n_rows) {
-    memcpy(q_rows, hp, n_rows * 2 * 8);
-    memcpy(c_rows, hp + n_rows * 2, n_rows * (size_t)ncyc * 2 * 8);
-    memcpy(x_rows, hp + n_rows * 2 + n_rows * (size_t)ncyc * 2, n_rows * ELP_NCTX * 2 * 8);
-  }
-  return 0;
-}
-
 }  // namespace elp
 
 using namespace elp;
@@ -1988,6 +1932,63 @@ int elp_bqsr_tables_fetch(elp_ctx *c, int64_t *qual_tbl, int64_t *cycle_tbl, int
   memcpy(ctx_tbl, hp + nq + nc, nx * 8);
   return 0;
 }
+
+// the qualities that had table slots in the gather that made the device tables: bit q of bits[q / 64]
+int elp_bqsr_quals_counted(elp_ctx *c, uint64_t *bits) {
+  if (!c || !bits) return ELP_ERR_ARG;
+  if (!c->tables_n) return set_error(c, ELP_ERR_ARG, "elp_bqsr_quals_counted: no device tables (elp_bqsr_gather_device)");
+  bits[0] = c->tables_quals[0];
+  bits[1] = c->tables_quals[1];
+  return 0;
+}
+
+// elp_bqsr_tables_fetch for the rows of the qualities `quals` only: q_rows [n_cov][n_quals][2], c_rows [n_cov][n_quals][2*max_cycle+1][2],
+// x_rows [n_cov][n_quals][16][2] - packed on the device, one copy.  Returns 1 (and copies nothing) if a quality that was not asked for has
+// observations (tables that were summed with another context's or rank's: the caller fetches the dense tables then).
+int elp_bqsr_tables_fetch_rows(elp_ctx *c, const uint8_t *quals, int n_quals, int64_t *q_rows, int64_t *c_rows, int64_t *x_rows) {
+  if (!c || n_quals < 0 || n_quals > ELP_NQUAL || (n_quals && (!quals || !q_rows || !c_rows || !x_rows))) return ELP_ERR_ARG;
+  if (!c->tables_n) return set_error(c, ELP_ERR_ARG, "elp_bqsr_tables_fetch_rows: no device tables (elp_bqsr_gather_device)");
+  for (int k = 0; k < n_quals; k++)
+    if (quals[k] >= ELP_NQUAL) return set_error(c, ELP_ERR_ARG, "elp_bqsr_tables_fetch_rows: quality %d", (int)quals[k]);
+  ELP_HIP(c, hipSetDevice(c->device));
+  const int ncyc = 2 * c->tables_max_cycle + 1;
+  const size_t n_rows = (size_t)c->n_cov * (size_t)n_quals, row_w = 2 + (size_t)ncyc * 2 + ELP_NCTX * 2, words = n_rows * row_w;
+  const size_t bytes = words * 8 + 256;
+  if (bytes > c->h_pinned_cap) {
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    c->h_pinned = nullptr; c->h_pinned_cap = 0;
+    ELP_HIP(c, hipHostMalloc(&c->h_pinned, bytes, hipHostMallocDefault));
+    c->h_pinned_cap = bytes;
+  }
+  ELP_TRY(ensure(c, c->tables_pack, words + 64));
+  if (!c->copy_stream) ELP_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  if (c->tables_ev) ELP_HIP(c, hipStreamWaitEvent(c->copy_stream, c->tables_ev, 0));
+  else ELP_HIP(c, hipStreamSynchronize(c->stream));
+  // the quality list and the "uncovered" word ride in the pack buffer's tail
+  uint8_t *d_quals = reinterpret_cast<uint8_t *>(c->tables_pack.p + words);
+  uint32_t *d_unc = reinterpret_cast<uint32_t *>(c->tables_pack.p + words + 16);
+  uint8_t *hq = static_cast<uint8_t *>(c->h_pinned) + words * 8;
+  memset(hq, 0, 256);
+  if (n_quals) memcpy(hq, quals, (size_t)n_quals);
+  ELP_HIP(c, hipMemcpyAsync(d_quals, hq, 128 + 8, hipMemcpyHostToDevice, c->copy_stream));  // (also clears the word)
+  const size_t work = std::max(words, (size_t)c->n_cov * ELP_NQUAL);
+  hipLaunchKernelGGL(k_tables_pack_rows, dim3(blocks_for(work, 256)), dim3(256), 0, c->copy_stream, (const unsigned long long *)c->dev_tables.p, c->n_cov, ncyc,
+                     (const uint8_t *)d_quals, n_quals, c->tables_pack.p, d_unc);
+  ELP_HIP(c, hipGetLastError());
+  ELP_HIP(c, hipMemcpyAsync(c->h_pinned, c->tables_pack.p, words * 8, hipMemcpyDeviceToHost, c->copy_stream));
+  uint32_t unc = 0;
+  ELP_HIP(c, hipMemcpyAsync(&unc, d_unc, 4, hipMemcpyDeviceToHost, c->copy_stream));
+  ELP_HIP(c, hipStreamSynchronize(c->copy_stream));
+  if (unc) return 1;
+  const int64_t *hp = static_cast<const int64_t *>(c->h_pinned);
+  if (n_rows) {
+    memcpy(q_rows, hp, n_rows * 2 * 8);
+    memcpy(c_rows, hp + n_rows * 2, n_rows * (size_t)ncyc * 2 * 8);
+    memcpy(x_rows, hp + n_rows * 2 + n_rows * (size_t)ncyc * 2, n_rows * ELP_NCTX * 2 * 8);
+  }
+  return 0;
+}
+
 
 
 // Distinct rows of the resident part of the dense LUT (three small kernels): wk = counters | slots | slot ids | row -> slot | t1 | t2.
