@@ -271,10 +271,24 @@ struct InfLds {
   uint16_t lcount[16], dcount[16], lsym[288], dsym[32];
   uint8_t lengths[320];
 };
-__constant__ uint16_t INF_LENS[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__constant__ uint8_t INF_LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__constant__ uint16_t INF_DISTS[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-__constant__ uint8_t INF_DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+// base values and extra-bit counts of the length codes 257.. and the distance codes (RFC 1951 3.2.5), by arithmetic (round 5: as tables in
+// constant memory they cost every match four dependent memory round trips); checked against the RFC's tables at compile time
+__host__ __device__ constexpr uint32_t inf_len_ext(uint32_t ls) { return ls < 8u || ls == 28u ? 0u : (ls - 4u) >> 2; }
+__host__ __device__ constexpr uint32_t inf_len_base(uint32_t ls) { return ls < 8u ? 3u + ls : (ls == 28u ? 258u : 3u + ((4u + (ls & 3u)) << inf_len_ext(ls))); }
+__host__ __device__ constexpr uint32_t inf_dist_ext(uint32_t ds) { return ds < 4u ? 0u : (ds - 2u) >> 1; }
+__host__ __device__ constexpr uint32_t inf_dist_base(uint32_t ds) { return ds < 4u ? 1u + ds : 1u + ((2u + (ds & 1u)) << inf_dist_ext(ds)); }
+namespace inf_check {
+constexpr uint16_t LENS[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+constexpr uint8_t LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+constexpr uint16_t DISTS[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+constexpr uint8_t DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+constexpr bool ok() {
+  for (uint32_t k = 0; k < 29; k++) if (inf_len_base(k) != LENS[k] || inf_len_ext(k) != LEXT[k]) return false;
+  for (uint32_t k = 0; k < 30; k++) if (inf_dist_base(k) != DISTS[k] || inf_dist_ext(k) != DEXT[k]) return false;
+  return true;
+}
+static_assert(ok(), "length / distance code arithmetic differs from RFC 1951 3.2.5");
+}  // namespace inf_check
 __constant__ uint8_t INF_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 struct Inflater {
@@ -424,10 +438,10 @@ __device__ inline int inflate_codes(Inflater &s) {
     } else {
       symbol -= 257;
       if (symbol >= 29) return 4;
-      const uint32_t len = (uint32_t)INF_LENS[symbol] + s.bits(INF_LEXT[symbol]);
+      const uint32_t len = inf_len_base((uint32_t)symbol) + s.bits((int)inf_len_ext((uint32_t)symbol));
       symbol = inf_symbol(s, L->dtab, INF_DBITS, L->dcount, L->dsym);
       if (symbol < 0 || symbol >= 30) return 5;
-      const uint32_t dist = (uint32_t)INF_DISTS[symbol] + s.bits(INF_DEXT[symbol]);
+      const uint32_t dist = inf_dist_base((uint32_t)symbol) + s.bits((int)inf_dist_ext((uint32_t)symbol));
       if (s.err) return 1;
       if (dist > s.out_at) return 6;
       if (s.out_at + len > s.out_len) return 3;

@@ -21,6 +21,7 @@ for seed in range(first, first + count):
     cfg.p_dup = float(rng.choice([0.05, 0.1, 0.5]))
     cfg.p_mate_unmapped = float(rng.choice([0.0, 0.01, 0.1]))
     cfg.qual_mode = int(rng.integers(0, 2))
+    cfg.n_lanes = int(rng.choice([4, 4, 4, 1, 9, 20, 40]))  # read groups = BQSR covariates (round 5: any number of them)
     pairs = int(rng.choice([50, 700, 5000, 30000]))
     b = synth.generate(cfg, 0, pairs)
     h = cfg.header()
@@ -29,7 +30,7 @@ for seed in range(first, first + count):
     # kernel choices at random too (elp_set_tuning): every choice must give the oracle's bytes
     tuning = {"radix_tile": int(rng.integers(0, 4)), "sort_pairs": int(rng.integers(0, 2)), "tie_rounds": int(rng.integers(0, 2)),
               "mate_path": int(rng.choice([0, 0, 1, 2])), "pair_table_slots": int(rng.choice([0, 0, 16, 1024])),
-              "count_kernel": int(rng.choice([0, 0, 1, 2, 3])), "apply_kernel": int(rng.choice([0, 0, 1])), "score_kernel": int(rng.choice([0, 0, 1]))}
+              "count_kernel": int(rng.choice([0, 0, 1, 2, 3])), "apply_kernel": int(rng.choice([0, 0, 1, 3])), "score_kernel": int(rng.choice([0, 0, 1]))}
     e = Engine(h, 0, tuning=tuning)
     cuts = np.linspace(0, b.n, int(rng.integers(1, 5)) + 1).astype(int)
     for lo, hi in zip(cuts[:-1], cuts[1:]):

@@ -15,7 +15,7 @@ one = len(sys.argv) > 3 and sys.argv[3] == "one"
 bad = 0
 for seed in range(first, first + count):
     quals = [2, 5, 6, 12, 23, 37, 41] if seed % 3 else list(range(2, 45))
-    n_cov = 2 + seed % 3
+    n_cov = (2 + seed % 3) if seed % 4 else [17, 33, 70, 24][(seed // 4) % 4]  # (round 5: every fourth seed many read groups)
     if one:
         length = int(np.random.default_rng(seed).integers(17, 261))
         b, h, refs, sites = _random_case(seed, 3000 + 500 * (seed % 7), quals=quals, n_cov=n_cov, len_mix=((length, length, 1.0),))
