@@ -352,7 +352,13 @@ def main():
             # the split phase through the C ABI: staged into the rank's reader context, classified on the device (elp_split_classify), every
             # record delivered device to device to the context of its split's owner (elp_copy_records / elp_exchange_records: RCCL send /
             # receive over xGMI when every rank has its own GPU)
-            rk.route(b if b is not None else sfm.empty_batch(), gof, G, owner)
+            if os.environ.get("ELP_SFM_ROUTE") == "host":  # escape hatch: round 4's routing through host numpy + torch.distributed
+                got = sfm.route(b if b is not None else sfm.empty_batch(), gof, G, owner, comm)
+                rk.stage(0, got.local)
+                rk.stage(1, got.spread)
+                del got
+            else:
+                rk.route(b if b is not None else sfm.empty_batch(), gof, G, owner)
             route_s += time.time() - tr
             del b
         n_total = rk.n_reads  # the tagged copies are not reads of their own
@@ -431,7 +437,7 @@ def main():
             "host_finalize_ms_per_step": round(sum(host_ms[-args.steps:]) / max(len(host_ms[-args.steps:]), 1), 3) if host_ms else None,
             "host_finalize_exposed_ms_per_step": round(sum(wait_ms[-args.steps:]) / max(len(wait_ms[-args.steps:]), 1), 3) if wait_ms else None,
             "staging": {"gen_s": round(gen_s, 2), "h2d_stage_s": round(stage_s, 2),
-                        "elp_stage_Mreads_per_s": round(n_total / max(stage_s, 1e-9) / 1e6, 2)},
+                        "elp_stage_Mreads_per_s": round(n_total / stage_s / 1e6, 2) if stage_s > 0 else None},
         }
         if sfm_mode:
             # what the first multi-GPU record needs to be read without a second run: the collective's share of a step (the wait for the
