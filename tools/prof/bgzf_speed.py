@@ -49,7 +49,12 @@ print({k: round(v[1], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][
 e.mark_duplicates(True, fetch=False)
 e.sort_coordinate(fetch=False)
 e.emit_sorted_bgzf()
+e.profile_enable(True)
+e.profile_reset()
 t0 = time.perf_counter()
 out = e.emit_sorted_bgzf()
 t = time.perf_counter() - t0
-print(f"emit_sorted_bgzf {t * 1e3:.1f} ms = {b.n / t / 1e6:.1f} Mreads/s ({out.size} bytes)")
+prof = e.profile()
+e.profile_enable(False)
+print(f"emit_sorted_bgzf {t * 1e3:.1f} ms = {b.n / t / 1e6:.1f} Mreads/s ({out.size} bytes = {out.size / len(raw):.3f} of the inflated size)")
+print({k: round(v[1], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:8]})
