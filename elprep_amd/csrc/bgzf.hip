@@ -263,9 +263,13 @@ int bgzf_deflate(elp_ctx *c, const uint8_t *raw, uint64_t n_bytes, uint8_t *out,
 // byte, 1.1 GB/s inflated.)
 struct BgzfBlk { uint64_t in_off; uint32_t in_len, out_len; uint64_t out_off; uint32_t crc; uint32_t pad; };  // CDATA in the piece; ISIZE; place in c->raw
 
-constexpr int INF_RING = 2048, INF_LBITS = 9, INF_DBITS = 8, INF_WIN = 32768, INF_FLUSH = 16384;
+// Round 5: the LDS window is the RECENT 8 KB of the block's output, not DEFLATE's whole 32 KB look-back: a match that reaches further
+// back reads its source from the block's own output in HBM (drained long before: Inflater::drain keeps at most ~2.8 KB pending) - 14 KB of
+// LDS per wave instead of 39, eleven waves per CU instead of four.  The kernel is a serial chain of dependent LDS round trips per
+// symbol (one wave per SIMD ran it at full latency); more waves per SIMD interleave the chains of more blocks.
+constexpr int INF_RING = 2048, INF_LBITS = 9, INF_DBITS = 8, INF_WIN = 4096, INF_FLUSH = 1024, INF_NEAR = INF_WIN - 258;
 struct InfLds {
-  uint8_t window[INF_WIN];  // a ring: DEFLATE looks back 32768 bytes at most; older output is in HBM already (Inflater::drain)
+  uint8_t window[INF_WIN];  // a ring of the most recent output; older output is in HBM already (Inflater::drain)
   uint8_t ring[INF_RING];
   uint32_t ltab[1 << INF_LBITS], dtab[1 << INF_DBITS];  // symbol << 8 | code length; 0: longer than the table's bits
   uint16_t lcount[16], dcount[16], lsym[288], dsym[32];
@@ -447,7 +451,18 @@ __device__ inline int inflate_codes(Inflater &s) {
       if (s.out_at + len > s.out_len) return 3;
       // the match, all lanes: byte k comes from the dist bytes in front of the match, periodically (they are all written already)
       const uint32_t from = s.out_at - dist;
-      for (uint32_t k = lane; k < len; k += 64u) L->window[(s.out_at + k) & (INF_WIN - 1)] = L->window[(from + (dist >= len ? k : k % dist)) & (INF_WIN - 1)];
+      if (dist <= (uint32_t)INF_NEAR) {
+        for (uint32_t k = lane; k < len; k += 64u) L->window[(s.out_at + k) & (INF_WIN - 1)] = L->window[(from + (dist >= len ? k : k % dist)) & (INF_WIN - 1)];
+      } else {
+        // the source has left the window (dist > len: no overlap with the match itself) and was drained to HBM by this wave's own stores,
+        // completed before the drain's barrier; read around the L1 (a line may have been fetched before the drain that completed it)
+        const uint8_t *src = s.out + from;
+        for (uint32_t k = lane; k < len; k += 64u) {
+          const uintptr_t a = reinterpret_cast<uintptr_t>(src + k);
+          const uint32_t w = __hip_atomic_load(reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          L->window[(s.out_at + k) & (INF_WIN - 1)] = (uint8_t)(w >> (8u * (uint32_t)(a & 3u)));
+        }
+      }
       s.out_at += len;
     }
   }
