@@ -227,6 +227,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    host_parts = []  # per step: [tables to the host, FinalizeBQSRTables, LUT rows, LUT upload] in ms (ELP_BENCH_HOST_PARTS=1 prints them per side run)
     host_ms, wait_ms = [], []  # per step: the host's FinalizeBQSRTables + LUT (ms), and the part of it the device's sort + metrics did not hide
 
     def make_filter_steps(eng, lut_buf):
@@ -240,13 +241,17 @@ def main():
             t0 = time.perf_counter()
             quals = eng.quals_counted()
             got = eng.tables_fetch_rows(quals, reuse=True)
+            t1 = time.perf_counter()
             if got is not None:
                 tb = BqsrTables.from_rows(eng.header.n_cov, quals, *got, MAX_CYCLE).finalize()
+                t2 = time.perf_counter()
                 if lut_buf[0] is None or lut_buf[0][0] != tuple(quals):  # built in page-locked memory (its upload runs at the PCIe rate), once per context
                     lut_buf[0] = (tuple(quals), (eng.pinned_zeros((eng.header.n_cov, len(quals), 2 * MAX_CYCLE + 1, 17), np.uint8),
                                                  np.zeros((eng.header.n_cov, 94), np.uint8), np.zeros(eng.header.n_cov, np.uint8)))
                 rows, defaults, present = tb.build_lut_rows(quals, 0, out=lut_buf[0][1])
+                t3 = time.perf_counter()
                 eng.lut_upload_rows(quals, rows, defaults, present, MAX_CYCLE)  # on the context's copy stream, from this (host) thread, while the GPU sorts
+                host_parts.append([round((b - a) * 1e3, 3) for a, b in ((t0, t1), (t1, t2), (t2, t3), (t3, time.perf_counter()))])
             else:
                 tb = BqsrTables(*eng.tables_fetch(reuse=True), MAX_CYCLE).finalize()
                 lut, present = tb.build_lut(0)
@@ -439,6 +444,9 @@ def main():
             "staging": {"gen_s": round(gen_s, 2), "h2d_stage_s": round(stage_s, 2),
                         "elp_stage_Mreads_per_s": round(n_total / stage_s / 1e6, 2) if stage_s > 0 else None},
         }
+        if os.environ.get("ELP_BENCH_HOST_PARTS") and host_parts:
+            out["host_parts_ms"] = {"per_step_total": [round(v, 3) for v in host_ms[-args.steps:]], "per_step_exposed": [round(v, 3) for v in wait_ms[-args.steps:]],
+                                    "fetch_finalize_lut_upload": host_parts[-args.steps:]}
         if sfm_mode:
             # what the first multi-GPU record needs to be read without a second run: the collective's share of a step (the wait for the
             # slowest rank included: the call is entered behind a stream sync) and the set-up's record exchange
@@ -495,12 +503,18 @@ def main():
                 e2.sync()
                 e2.snapshot()
                 sf2, _, rs2 = make_filter_steps(e2, [None])
-                el, pr = timed(sf2, rs2, 3, 1, e2, barrier)
-                st, km, rf = summarize(pr, 3, n2, BYTES_FULL_PATH)
+                side_steps, side_warmup = int(os.environ.get("ELP_BENCH_SIDE_STEPS", "6")), int(os.environ.get("ELP_BENCH_SIDE_WARMUP", "2"))
+                el, pr = timed(sf2, rs2, side_steps, side_warmup, e2, barrier)
+                st, km, rf = summarize(pr, side_steps, n2, BYTES_FULL_PATH)
                 extra[key] = {"workload": f"{n2} reads, {workload}, full path",
-                              "value": round(n2 / (el / 3) / 1e6, 3), "unit": "Mreads/s", "ms_per_step": round(el / 3 * 1e3, 3),
-                              "host_finalize_ms_per_step": round(sum(host_ms[-3:]) / 3, 3), "host_finalize_exposed_ms_per_step": round(sum(wait_ms[-3:]) / 3, 3),
+                              "value": round(n2 / (el / side_steps) / 1e6, 3), "unit": "Mreads/s", "ms_per_step": round(el / side_steps * 1e3, 3),
+                              "steps": side_steps, "warmup": side_warmup,
+                              "host_finalize_ms_per_step": round(sum(host_ms[-side_steps:]) / side_steps, 3),
+                              "host_finalize_exposed_ms_per_step": round(sum(wait_ms[-side_steps:]) / side_steps, 3),
                               "stage_ms_per_step": st, "kernel_ms_per_step": km, "roofline": rf}
+                if os.environ.get("ELP_BENCH_HOST_PARTS"):
+                    extra[key]["host_parts_ms"] = {"per_step_total": [round(v, 3) for v in host_ms[-side_steps:]], "per_step_exposed": [round(v, 3) for v in wait_ms[-side_steps:]],
+                                                   "fetch_finalize_lut_upload": host_parts[-side_steps:]}
                 e2.close()
             except Exception as e:
                 extra[key] = {"error": repr(e)}

@@ -66,37 +66,38 @@ __global__ __launch_bounds__(256) void k_apply_records(uint64_t n, uint32_t len,
 // record; a workgroup of k_bqsr_apply3<true> then holds ONE covariate's level 1 and that covariate's own row dictionary at a time.
 constexpr int A3_MAXCOV = 256, A3_RTILE = 1024;
 __device__ __forceinline__ int apply_read_cov(uint16_t rg, const uint16_t *__restrict__ rg_cov, const uint8_t *__restrict__ cov_present, uint32_t *err) {
-  if (rg == ELP_NIL16) { atomicOr(&err[0], 32u); return -1; }
+  if (rg == ELP_NIL16) { if (err) atomicOr(&err[0], 32u); return -1; }
   const uint32_t cov = rg_cov[rg] & 0xFFu;
   return cov_present[cov] ? (int)cov : -1;
 }
-__global__ __launch_bounds__(256) void k_apply_cov_hist(uint64_t n, const uint16_t *__restrict__ rgid, const uint16_t *__restrict__ rg_cov,
-                                                        const uint8_t *__restrict__ cov_present, uint32_t *__restrict__ cnt /* [A3_MAXCOV] */, uint32_t *err) {
+// Both passes run the SAME few workgroups over the same chunks of tiles (workgroup b: tiles [b * per, (b + 1) * per)): the counters all
+// workgroups add to share one cache line, and a line takes about one atomic per clock - with a workgroup per tile (15 700 of them at
+// 16 M reads, 16 to 32 counters each) those flushes were the two kernels' time (0.19 + 0.21 ms; 0.03 of it the loads).
+constexpr int A3_RBLOCKS = 1024;
+__global__ __launch_bounds__(256) void k_apply_cov_hist(uint64_t n, uint32_t per, const uint16_t *__restrict__ rgid, const uint16_t *__restrict__ rg_cov,
+                                                        const uint8_t *__restrict__ cov_present, uint32_t *__restrict__ cnt /* [A3_MAXCOV] */,
+                                                        uint32_t *__restrict__ blk /* [gridDim.x][A3_MAXCOV] */, uint32_t *err) {
   __shared__ uint32_t h[A3_MAXCOV];
   h[threadIdx.x] = 0;
   __syncthreads();
-  const int lane = threadIdx.x & 63;
-  // (the tile's four read-group ids first, then the covariates they lead to: one round trip per level, not four)
-  uint16_t rg[A3_RTILE / 256];
+  for (uint32_t t = 0; t < per; t++) {
+    const uint64_t i0 = ((uint64_t)blockIdx.x * per + t) * A3_RTILE + threadIdx.x;
+    if (i0 - threadIdx.x >= n) break;
+    // (the tile's four read-group ids first, then the covariates they lead to: one round trip per level, not four)
+    uint16_t rg[A3_RTILE / 256];
 #pragma unroll
-  for (int j = 0; j < A3_RTILE / 256; j++) {
-    const uint64_t i = (uint64_t)blockIdx.x * A3_RTILE + j * 256 + threadIdx.x;
-    rg[j] = i < n ? rgid[i] : (uint16_t)ELP_NIL16;
-  }
-  int cv[A3_RTILE / 256];
+    for (int j = 0; j < A3_RTILE / 256; j++) rg[j] = i0 + j * 256 < n ? rgid[i0 + j * 256] : (uint16_t)ELP_NIL16;
+    int cv[A3_RTILE / 256];
 #pragma unroll
-  for (int j = 0; j < A3_RTILE / 256; j++) {
-    const uint64_t i = (uint64_t)blockIdx.x * A3_RTILE + j * 256 + threadIdx.x;
-    cv[j] = i < n ? apply_read_cov(rg[j], rg_cov, cov_present, err) : -1;
-  }
+    for (int j = 0; j < A3_RTILE / 256; j++) cv[j] = i0 + j * 256 < n ? apply_read_cov(rg[j], rg_cov, cov_present, err) : -1;
+    // (every lane adds its one: lanes that share a counter serialise in the LDS - 30 cycles for eight lanes per counter -, cheaper than
+    // forming the wave's groups by covariate first)
 #pragma unroll
-  for (int j = 0; j < A3_RTILE / 256; j++) {
-    const int cov = cv[j];
-    // one LDS atomic per covariate that occurs in the wave (lanes adding one each to a handful of counters serialise)
-    const unsigned long long same = wave_same_mask((uint32_t)cov, cov >= 0);
-    if (same && lane == __ffsll((long long)same) - 1) atomicAdd(&h[cov], (uint32_t)__popcll(same));
+    for (int j = 0; j < A3_RTILE / 256; j++)
+      if (cv[j] >= 0) atomicAdd(&h[cv[j]], 1u);
   }
   __syncthreads();
+  blk[(size_t)blockIdx.x * A3_MAXCOV + threadIdx.x] = h[threadIdx.x];
   if (h[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], h[threadIdx.x]);
 }
 __global__ void k_apply_cov_offsets(const uint32_t *__restrict__ cnt, uint32_t *__restrict__ off /* [A3_MAXCOV + 1] */, uint32_t *__restrict__ cursor) {
@@ -104,49 +105,40 @@ __global__ void k_apply_cov_offsets(const uint32_t *__restrict__ cnt, uint32_t *
   for (int c = 0; c < A3_MAXCOV; c++) { off[c] = at; cursor[c] = at; at += cnt[c]; }
   off[A3_MAXCOV] = at;
 }
-__global__ __launch_bounds__(256) void k_apply_records_split(uint64_t n, uint32_t len, int lmax, const uint16_t *__restrict__ flag, const uint16_t *__restrict__ rgid,
-                                                             const uint16_t *__restrict__ rg_cov, const uint64_t *__restrict__ qbounds,
-                                                             const uint8_t *__restrict__ cov_present, uint32_t *cursor, uint2 *__restrict__ recs,
-                                                             uint32_t *__restrict__ ridx, uint32_t *err) {
-  __shared__ uint32_t h[A3_MAXCOV], base[A3_MAXCOV];
-  h[threadIdx.x] = 0;
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
-  int cv[A3_RTILE / 256];
-  uint32_t my[A3_RTILE / 256];
-  uint16_t rg[A3_RTILE / 256], fl[A3_RTILE / 256];
-  uint64_t qb[A3_RTILE / 256];
-#pragma unroll
-  for (int j = 0; j < A3_RTILE / 256; j++) {  // every column load of the tile up front
-    const uint64_t i = (uint64_t)blockIdx.x * A3_RTILE + j * 256 + threadIdx.x;
-    rg[j] = i < n ? rgid[i] : (uint16_t)ELP_NIL16;
-    fl[j] = i < n ? flag[i] : (uint16_t)0;
-    qb[j] = i < n ? qbounds[i] : 0ull;
-  }
-#pragma unroll
-  for (int j = 0; j < A3_RTILE / 256; j++) {
-    const uint64_t i = (uint64_t)blockIdx.x * A3_RTILE + j * 256 + threadIdx.x;
-    cv[j] = i < n ? apply_read_cov(rg[j], rg_cov, cov_present, err) : -1;
-  }
-#pragma unroll
-  for (int j = 0; j < A3_RTILE / 256; j++) {
-    // the record's place among the workgroup's records of its covariate: one LDS atomic per covariate that occurs in the wave
-    const unsigned long long same = wave_same_mask((uint32_t)cv[j], cv[j] >= 0);
-    const int leader = same ? __ffsll((long long)same) - 1 : lane;
-    uint32_t at = 0;
-    if (same && lane == leader) at = atomicAdd(&h[cv[j]], (uint32_t)__popcll(same));
-    my[j] = __shfl(at, leader, 64) + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+__global__ __launch_bounds__(256) void k_apply_records_split(uint64_t n, uint32_t per, uint32_t len, int lmax, const uint16_t *__restrict__ flag,
+                                                             const uint16_t *__restrict__ rgid, const uint16_t *__restrict__ rg_cov, const uint64_t *__restrict__ qbounds,
+                                                             const uint8_t *__restrict__ cov_present, const uint32_t *__restrict__ blk, uint32_t *cursor,
+                                                             uint2 *__restrict__ recs, uint32_t *__restrict__ ridx, uint32_t *err) {
+  // the workgroup's places in every covariate's range (its counts of the first pass), then a running counter per covariate in the LDS
+  __shared__ uint32_t run[A3_MAXCOV], base[A3_MAXCOV];
+  {
+    const uint32_t mine = blk[(size_t)blockIdx.x * A3_MAXCOV + threadIdx.x];
+    base[threadIdx.x] = mine ? atomicAdd(&cursor[threadIdx.x], mine) : 0u;
+    run[threadIdx.x] = 0;
   }
   __syncthreads();
-  base[threadIdx.x] = h[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], h[threadIdx.x]) : 0u;
-  __syncthreads();
+  for (uint32_t t = 0; t < per; t++) {
+    const uint64_t i0 = ((uint64_t)blockIdx.x * per + t) * A3_RTILE + threadIdx.x;
+    if (i0 - threadIdx.x >= n) break;
+    int cv[A3_RTILE / 256];
+    uint16_t rg[A3_RTILE / 256], fl[A3_RTILE / 256];
+    uint64_t qb[A3_RTILE / 256];
 #pragma unroll
-  for (int j = 0; j < A3_RTILE / 256; j++) {
-    const uint64_t i = (uint64_t)blockIdx.x * A3_RTILE + j * 256 + threadIdx.x;
-    if (cv[j] >= 0) {
-      const size_t to = (size_t)base[cv[j]] + my[j];
-      recs[to] = apply_record(len, lmax, fl[j], qb[j], (uint32_t)cv[j]);
-      ridx[to] = (uint32_t)i;
+    for (int j = 0; j < A3_RTILE / 256; j++) {  // every column load of the tile up front
+      const uint64_t i = i0 + j * 256;
+      rg[j] = i < n ? rgid[i] : (uint16_t)ELP_NIL16;
+      fl[j] = i < n ? flag[i] : (uint16_t)0;
+      qb[j] = i < n ? qbounds[i] : 0ull;
+    }
+#pragma unroll
+    for (int j = 0; j < A3_RTILE / 256; j++) cv[j] = i0 + j * 256 < n ? apply_read_cov(rg[j], rg_cov, cov_present, nullptr) : -1;  // (errors: noted by the first pass)
+#pragma unroll
+    for (int j = 0; j < A3_RTILE / 256; j++) {
+      if (cv[j] >= 0) {
+        const size_t to = (size_t)base[cv[j]] + atomicAdd(&run[cv[j]], 1u);
+        recs[to] = apply_record(len, lmax, fl[j], qb[j], (uint32_t)cv[j]);
+        ridx[to] = (uint32_t)(i0 + j * 256);
+      }
     }
   }
 }
@@ -500,17 +492,21 @@ int apply3_launch(elp_ctx *c, int max_cycle, const uint8_t *d_lut, const uint8_t
   const size_t dump_words = (size_t)grid * A3_NT * 2;  // 16 bytes per lane, in uint2 units
   // records | dump | (split) staging indices | counts per covariate, offsets, cursors
   const size_t rec_words = (n + 4 + 1) & ~(uint64_t)1;
-  ELP_TRY(scratch(c, 5, rec_words + dump_words + (split ? (n + 1) / 2 + 2 * A3_MAXCOV + 8 : 0) + 8, &recs));
+  ELP_TRY(scratch(c, 5, rec_words + dump_words + (split ? (n + 1) / 2 + 2 * A3_MAXCOV + 8 + (size_t)A3_RBLOCKS * A3_MAXCOV / 2 : 0) + 8, &recs));
   uint8_t *dump = reinterpret_cast<uint8_t *>(recs + rec_words);
   uint32_t *ridx = reinterpret_cast<uint32_t *>(recs + rec_words + dump_words), *cw = ridx + ((n + 1) & ~(uint64_t)1);  // cw: [256] counts | [257] offsets | [256] cursors
   if (split) {
     ELP_HIP(c, hipMemsetAsync(cw, 0, (3 * A3_MAXCOV + 1) * sizeof(uint32_t), c->stream));
-    const unsigned rg = blocks_for(n, A3_RTILE);
-    ELP_LAUNCH(c, "bqsr_apply_cov_hist", k_apply_cov_hist, dim3(rg), dim3(256), 0, n, (const uint16_t *)c->rgid.p, (const uint16_t *)c->rg_cov.p, d_cov_present, cw,
+    // cw: ... | [A3_RBLOCKS][256] the workgroups' counts (written whole by the first pass)
+    const uint64_t tiles = blocks_for(n, A3_RTILE);
+    const unsigned rg = (unsigned)std::min<uint64_t>(tiles, A3_RBLOCKS);
+    const uint32_t per = (uint32_t)((tiles + rg - 1) / rg);
+    uint32_t *blk = cw + 3 * A3_MAXCOV + 8;
+    ELP_LAUNCH(c, "bqsr_apply_cov_hist", k_apply_cov_hist, dim3(rg), dim3(256), 0, n, per, (const uint16_t *)c->rgid.p, (const uint16_t *)c->rg_cov.p, d_cov_present, cw, blk,
                c->err_flag.p);
     ELP_LAUNCH(c, "bqsr_apply_cov_offsets", k_apply_cov_offsets, dim3(1), dim3(1), 0, (const uint32_t *)cw, cw + A3_MAXCOV, cw + 2 * A3_MAXCOV + 1);
-    ELP_LAUNCH(c, "bqsr_apply_records", k_apply_records_split, dim3(rg), dim3(256), 0, n, len, lmax, (const uint16_t *)c->flag.p, (const uint16_t *)c->rgid.p,
-               (const uint16_t *)c->rg_cov.p, (const uint64_t *)c->qbounds.p, d_cov_present, cw + 2 * A3_MAXCOV + 1, recs, ridx, c->err_flag.p);
+    ELP_LAUNCH(c, "bqsr_apply_records", k_apply_records_split, dim3(rg), dim3(256), 0, n, per, len, lmax, (const uint16_t *)c->flag.p, (const uint16_t *)c->rgid.p,
+               (const uint16_t *)c->rg_cov.p, (const uint64_t *)c->qbounds.p, d_cov_present, (const uint32_t *)blk, cw + 2 * A3_MAXCOV + 1, recs, ridx, c->err_flag.p);
   } else {
     ELP_LAUNCH(c, "bqsr_apply_records", k_apply_records, dim3(blocks_for(n, 256)), dim3(256), 0, n, len, lmax, (const uint16_t *)c->flag.p,
                (const uint16_t *)c->rgid.p, (const uint16_t *)c->rg_cov.p, (const uint64_t *)c->qbounds.p, d_cov_present, recs, c->err_flag.p);

@@ -363,10 +363,12 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
   // serialises at ~12 ns each: 9 ms for 50 M reads)
   __shared__ uint32_t lq[PF_TILES * 256];
   __shared__ uint32_t lcount, gbase, pcount, pbase;
+  __shared__ uint32_t seg_n[C3_MAXSEG], seg_at[C3_MAXSEG];  // covariate-split segments: the tile's class-1 records per covariate, their first place
   __shared__ PfLds L;
   const bool ref_lds = m.n_ref <= REF_LDS;
   pf_lds_fill(L, m, 256);
   if (threadIdx.x == 0) { lcount = 0; pcount = 0; }
+  seg_n[threadIdx.x] = 0;
   __syncthreads();
   const uint64_t i_first = (uint64_t)blockIdx.x * PF_TILES * 256 + threadIdx.x;
   PfCols nxt = {};
@@ -381,22 +383,28 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
     int rcl = 0;
     if (i < m.n) pf_record<false>(m, i, cur, L, ref_lds, desc, skipbits, err, ro.recs != nullptr, nullptr, defer, to_plain, rc, rcl);
     if (ro.recs) {  // the tile's records, compacted: class 1 into this wave's segment, the rare class 2 ones (windows the record cannot describe) behind
-      const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);  // == pf_wave_of_record(i), bqsr_common.hpp
       if (!ro.ncs) {
-        const uint32_t seg = wave % ro.nseg;
+        const uint32_t seg = (blockIdx.x * 4u + (threadIdx.x >> 6)) % ro.nseg;  // the wave's segment
         const uint32_t at1 = wave_append(rcl == 1, &ro.cnt[seg * C3_CSTRIDE]);
         if (rcl == 1) rec_store(ro.recs, (uint64_t)ro.seg_base[seg] + at1, rc);
       } else {
-        // segments by covariate: the wave's class-1 records of this tile in groups of one covariate each; the first lane of every group
-        // reserves the group's places in its segment - ONE atomic instruction for all groups (round 4 looped: a round trip per covariate
-        // that occurs in the tile, sixteen in a row with sixteen read groups: the kernel took twice its time)
-        const uint32_t cov = rc.fl & 0xFFu, seg = (wave % (ro.nseg / ro.ncs)) * ro.ncs + cov;
-        const unsigned long long same = wave_same_mask(cov, rcl == 1);
-        const int lane = threadIdx.x & 63, leader = same ? __ffsll((long long)same) - 1 : lane;
-        uint32_t at1 = 0;
-        if (same && lane == leader) at1 = atomicAdd(&ro.cnt[seg * C3_CSTRIDE], (uint32_t)__popcll(same));
-        at1 = __shfl(at1, leader, 64) + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-        if (rcl == 1) rec_store(ro.recs, (uint64_t)ro.seg_base[seg] + at1, rc);
+        // segments by covariate: the workgroup's class-1 records of this tile take their rank among those of their covariate from a
+        // returning LDS atomic, then ONE global atomic per covariate that occurs reserves the places in segment (workgroup % groups, covariate)
+        // (measured with the reservation taken out: the global atomics WERE the cost of many read groups - one per wave and covariate,
+        // 4 M / 7 M of them at 16 / 32 read groups and 16 M reads, 0.74 / 0.98 ms against 0.41 / 0.43 without)
+        const uint32_t cov = rc.fl & 0xFFu, seg = (blockIdx.x % (ro.nseg / ro.ncs)) * ro.ncs + cov;
+        uint32_t rank = 0;
+        if (rcl == 1) rank = atomicAdd(&seg_n[cov], 1u);
+        __syncthreads();
+        if (threadIdx.x < ro.ncs) {
+          const uint32_t t = seg_n[threadIdx.x];
+          if (t) {
+            seg_at[threadIdx.x] = atomicAdd(&ro.cnt[((blockIdx.x % (ro.nseg / ro.ncs)) * ro.ncs + threadIdx.x) * C3_CSTRIDE], t);
+            seg_n[threadIdx.x] = 0;
+          }
+        }
+        __syncthreads();
+        if (rcl == 1) rec_store(ro.recs, (uint64_t)ro.seg_base[seg] + seg_at[cov] + rank, rc);
       }
       const uint32_t at2 = wave_append(rcl == 2, &ro.cnt[ro.nseg * C3_CSTRIDE]);
       if (rcl == 2) rec_store(ro.recs, ro.other_at + at2, rc);
@@ -1512,7 +1520,7 @@ __global__ __launch_bounds__(256) void k_c3_other_scatter(const uint4 *__restric
 }
 
 // Covariate-split class-1 segments (RecOut, round 5): how many records segment (wave % groups) * ncs + covariate can receive at most - the
-// reads of that covariate among the records the first prologue pass's waves of that group handle (pf_wave_of_record) - and the
+// reads of that covariate among the records the first prologue pass's workgroups of that group handle - and the
 // segments' first slots as the prefix sums of those counts (or, fixed != 0: a fixed stride apart).  Workgroup b covers the records of the
 // prologue's workgroup b.
 __global__ __launch_bounds__(256) void k_c3_seg_hist(uint64_t n, const uint16_t *__restrict__ rgid, const uint16_t *__restrict__ rg_cov, uint32_t groups, uint32_t ncs,
@@ -1526,9 +1534,8 @@ __global__ __launch_bounds__(256) void k_c3_seg_hist(uint64_t n, const uint16_t 
     if (i0 - threadIdx.x + (uint64_t)tile * 256 >= n) break;  // (uniform: the whole tile lies behind the last record)
     const uint16_t rg = i < n ? rgid[i] : (uint16_t)ELP_NIL16;
     const uint32_t cov = rg == ELP_NIL16 ? 0xFFFFu : (uint32_t)(rg_cov[rg] & 0xFFu);
-    // (a wave's records share their prologue wave: its lanes differ in the covariate only; one LDS atomic per covariate that occurs)
-    const unsigned long long same = wave_same_mask(cov, cov < ncs);
-    if (same && (int)(threadIdx.x & 63) == __ffsll((long long)same) - 1) atomicAdd(&h[(pf_wave_of_record(i) % groups) * ncs + cov], (uint32_t)__popcll(same));
+    // (every lane adds its one in the LDS: cheaper than forming the wave's groups by covariate first, apply3.hip k_apply_cov_hist)
+    if (cov < ncs) atomicAdd(&h[(blockIdx.x % groups) * ncs + cov], 1u);  // (workgroup b covers the records of the prologue's workgroup b)
   }
   __syncthreads();
   if (threadIdx.x < groups * ncs && h[threadIdx.x]) atomicAdd(&seg_cap[threadIdx.x], h[threadIdx.x]);

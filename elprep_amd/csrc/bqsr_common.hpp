@@ -176,13 +176,12 @@ struct RecOut {
   uint64_t other_at;  // first record slot of the other region
   uint32_t nseg;   // 64, 128 or 256
   uint32_t ncs;    // 0: a segment holds records of every covariate.  > 0 (a power of two <= nseg): segment s holds records of covariate
-                   // s % ncs only (a wave appends to segment (wave % (nseg / ncs)) * ncs + covariate): a workgroup of the count kernel
+                   // s % ncs only (workgroup b of the prologue appends to segment (b % (nseg / ncs)) * ncs + covariate): a workgroup of the count kernel
                    // then meets ONE covariate at a time and its private table needs that covariate's rows only
 };
-// the wave of k_bqsr_prologue_fast that handles staged record i (its workgroups take PF_TILES * 256 consecutive records, thread t of a
-// workgroup the records t, t + 256, ...): what k_c3_seg_hist applies to the RGID column to size the covariate-split segments exactly
+// k_bqsr_prologue_fast's workgroups take PF_TILES * 256 consecutive staged records, thread t of a workgroup the records t, t + 256, ...;
+// k_c3_seg_hist walks the RGID column in the same workgroups to size the covariate-split segments exactly
 constexpr int PF_TILES = 16;
-__host__ __device__ inline uint32_t pf_wave_of_record(uint64_t i) { return (uint32_t)(i / (uint64_t)(PF_TILES * 256)) * 4u + (uint32_t)((i & 255u) >> 6); }
 __device__ __forceinline__ void rec_pack_idx(BqRec &r, uint32_t idx) {
   r.ref_hi = (r.ref_hi & 0xFFFFu) | (idx << 16);
   r.fl = (r.fl & ~(0x3FFu << 14)) | (((idx >> 16) & 0x3FFu) << 14);
@@ -215,8 +214,8 @@ __device__ __forceinline__ uint32_t wave_append(bool flag, uint32_t *counter) {
 __device__ __forceinline__ unsigned long long wave_same_mask(uint32_t key, bool valid) {
   unsigned long long todo = __ballot(valid), mine = 0;
   while (todo) {
-    const int leader = __ffsll((long long)todo) - 1;
-    const uint32_t k0 = __shfl(key, leader, 64);
+    const int leader = __ffsll((long long)todo) - 1;  // (wave-uniform: a scalar, so the key comes by v_readlane - no trip through the LDS crossbar per group)
+    const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
     const unsigned long long m = __ballot(valid && key == k0);
     if (valid && key == k0) mine = m;
     todo &= ~m;
