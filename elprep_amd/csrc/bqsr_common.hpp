@@ -208,21 +208,6 @@ __device__ __forceinline__ uint32_t wave_append(bool flag, uint32_t *counter) {
   return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
-// the lanes of the wave that are `valid` and hold the same `key` as this lane (0 for a lane that is not valid): one ballot per distinct
-// key of the wave, no memory access - the groups a wave then serves with ONE atomic instruction (the first lane of every group adds the
-// group's size) instead of one round trip per group
-__device__ __forceinline__ unsigned long long wave_same_mask(uint32_t key, bool valid) {
-  unsigned long long todo = __ballot(valid), mine = 0;
-  while (todo) {
-    const int leader = __ffsll((long long)todo) - 1;  // (wave-uniform: a scalar, so the key comes by v_readlane - no trip through the LDS crossbar per group)
-    const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
-    const unsigned long long m = __ballot(valid && key == k0);
-    if (valid && key == k0) mine = m;
-    todo &= ~m;
-  }
-  return mine;
-}
-
 // pieces of a clipped CIGAR (see BqDesc), up to four; np = -1: more
 struct Pieces4 {
   int64_t v0, v1, v2, v3;  // reference index minus clipped read index along the piece

@@ -72,7 +72,7 @@ __device__ __forceinline__ void wave_count(unsigned int *lds, int cell) {
   unsigned long long todo = __ballot(cell >= 0);
   while (todo) {
     const int leader = __ffsll((long long)todo) - 1;
-    const int c0 = __shfl(cell, leader, 64);
+    const int c0 = __builtin_amdgcn_readlane(cell, leader);  // (the leader is wave-uniform: no trip through the LDS crossbar)
     const unsigned long long peers = __ballot(cell == c0);
     if ((int)(threadIdx.x & 63) == leader) atomicAdd(&lds[c0], (unsigned int)__popcll(peers));
     todo &= ~peers;
