@@ -109,6 +109,13 @@ struct elp_ctx {
   size_t h_pinned_cap = 0;
   elp::DVec<unsigned long long> radix_state;  // radix.hip: per (tile, digit) look-back words, tagged with the pass epoch
   elp::DVec<uint32_t> radix_ticket;           // radix.hip: tile ticket counters
+  // radix.hip's own workspaces.  Until round 5 the digit histograms lived in scratch slot 6 and the scan's partial sums in slot 7 - the
+  // slots in which mark duplicates keeps its candidate codes and its pair list ACROSS its radix passes, and the record exchange its
+  // headers across the gather's scans: a context whose slot was larger than the asking call needed (a small read set behind a large one)
+  // had those overwritten; a smaller slot was reallocated under the live pointers.
+  elp::DVec<unsigned long long> radix_hist;   // digit histograms of a sort + its ticket word
+  elp::DVec<uint32_t> scan_pool;              // partial sums of exclusive_scan_u32's levels
+  elp::DVec<unsigned long long> xchg_hdr;     // exchange.hip: piece headers and verdicts
   elp::DVec<uint32_t> tie_live;               // sort.hip: bit j = byte j of the comparator string differs among the members of large runs
   elp::DVec<uint32_t> md_ctr;                 // markdup.hip: device counters read back with one copy (0: true fragments listed)
   static constexpr uint32_t MAX_QNAME = 1000; // staged QNAME length limit; the comparator string (QNAME + 15 bytes) fits TIE_LIVE_WORDS * 32 bits
@@ -246,6 +253,9 @@ struct ProfScope {  // launches inside the scope are booked as <prefix><name>
     if (rc__ != 0) return rc__;  \
   } while (0)
 
+int debug_poison();  // ctx.hip: the byte of ELP_DEBUG_POISON, or -1
+bool debug_trace();  // ctx.hip: ELP_DEBUG_TRACE=1 - every launch is named on stderr and waited for (which kernel faulted)
+
 // grow-only allocation; keep = copy old contents (device to device)
 template <class T>
 int ensure(elp_ctx *c, DVec<T> &v, size_t n, bool keep = false, size_t keep_elems = 0) {
@@ -253,6 +263,12 @@ int ensure(elp_ctx *c, DVec<T> &v, size_t n, bool keep = false, size_t keep_elem
   size_t ncap = keep ? (n + n / 2 + 16) : n;
   T *np = nullptr;
   ELP_HIP(c, hipMalloc((void **)&np, ncap * sizeof(T)));
+  // ELP_DEBUG_POISON=<byte> (tests): every new device buffer starts filled with that byte - a kernel that reads memory nothing wrote
+  // shows up as a parity failure instead of depending on what the allocator hands out
+  if (const int pz = debug_poison(); pz >= 0) {  // (on the context's stream and waited for: a fill on the null stream could land behind later kernels)
+    ELP_HIP(c, hipMemsetAsync(np, pz, ncap * sizeof(T), c->stream));
+    ELP_HIP(c, hipStreamSynchronize(c->stream));
+  }
   if (keep && v.p && keep_elems) {
     hipError_t e = hipMemcpyAsync(np, v.p, keep_elems * sizeof(T), hipMemcpyDeviceToDevice, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -282,9 +298,11 @@ int scratch(elp_ctx *c, int slot, size_t n, T **out) {
 #define ELP_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                              \
   do {                                                                                      \
     int pp__ = (ctx)->profiling ? elp::prof_begin((ctx), (name)) : -1;                      \
+    if (elp::debug_trace()) fprintf(stderr, "[elp] %s\n", (name));                          \
     hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__);             \
     if (pp__ >= 0) elp::prof_end((ctx), pp__);                                              \
     ELP_HIP((ctx), hipGetLastError());                                                      \
+    if (elp::debug_trace()) ELP_HIP((ctx), hipStreamSynchronize((ctx)->stream));            \
   } while (0)
 
 inline unsigned blocks_for(uint64_t n, unsigned per_block) { return (unsigned)((n + per_block - 1) / per_block); }

@@ -4,6 +4,19 @@
 
 namespace elp {
 
+bool debug_trace() {
+  static const bool v = [] { const char *e = getenv("ELP_DEBUG_TRACE"); return e && *e && *e != '0'; }();
+  return v;
+}
+int debug_poison() {
+  static const int v = [] {
+    const char *e = getenv("ELP_DEBUG_POISON");
+    return (e && *e) ? (int)(strtol(e, nullptr, 0) & 0xFF) : -1;
+  }();
+  return v;
+}
+
+
 int set_error(elp_ctx *c, int code, const char *fmt, ...) {
   char buf[1024];
   va_list ap;

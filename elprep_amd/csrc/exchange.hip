@@ -308,7 +308,8 @@ extern "C" int elp_exchange_records(elp_ctx *src, int send_peer, const uint32_t 
   }
   uint64_t *d_hdr;  // out | in | verdict out | verdict in, on the group context's device
   ELP_HIP(g, hipSetDevice(g->device));
-  ELP_TRY(scratch(g, 7, 2 * HDR + 16, &d_hdr));
+  ELP_TRY(ensure(g, g->xchg_hdr, 2 * HDR + 16));
+  d_hdr = reinterpret_cast<uint64_t *>(g->xchg_hdr.p);
   uint64_t *d_ack = d_hdr + 2 * HDR;
   int first_err = 0;         // the call's result: the first failure of either direction (the error text is that one's)
   std::string first_text;

@@ -93,7 +93,8 @@ static int scan_levels(elp_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n
   size_t need = 0;
   for (size_t k = 1; k < cnt.size(); k++) need += cnt[k] + 4;
   uint32_t *pool;
-  ELP_TRY(scratch(c, 7, need + 16, &pool));
+  ELP_TRY(ensure(c, c->scan_pool, need + 16));  // (its own buffer, as radix_hist)
+  pool = c->scan_pool.p;
   std::vector<uint32_t *> sums(cnt.size(), nullptr);
   size_t off = 0;
   for (size_t k = 1; k < cnt.size(); k++) { sums[k] = pool + off; off += cnt[k] + 4; }
@@ -394,7 +395,8 @@ int radix_sort_fused(elp_ctx *c, const uint64_t *keycol, uint64_t n, int key_bit
   if (n >= 0xFFFFFFFFull || key_bits + idx_bits > 64 || key_bits < 1 || idx_bits < 1) return set_error(c, ELP_ERR_UNSUPPORTED, "radix sort: bad size");
   const int ndigits = (key_bits + 7) / 8;
   unsigned long long *ghist;
-  ELP_TRY(scratch(c, 6, 8 * 256 + 4, &ghist));
+  ELP_TRY(ensure(c, c->radix_hist, 8 * 256 + 4));  // (its own buffer: callers keep live data in the scratch slots across a sort)
+  ghist = c->radix_hist.p;
   ELP_HIP(c, hipMemsetAsync(ghist, 0, (8 * 256 + 4) * sizeof(unsigned long long), c->stream));
   uint32_t *ticket = reinterpret_cast<uint32_t *>(ghist + 8 * 256);
   const unsigned hb = (unsigned)std::min<uint64_t>((n + 255) / 256, 2048);
@@ -423,7 +425,8 @@ int radix_sort_pairs_low(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *k
   if (ndigits <= 0) ndigits = 1;  // a pass is needed to materialise keys / values
   if (n >= 0xFFFFFFFFull || ndigits > 8) return set_error(c, ELP_ERR_UNSUPPORTED, "radix sort: bad size");
   unsigned long long *ghist;
-  ELP_TRY(scratch(c, 6, 8 * 256 + 4, &ghist));
+  ELP_TRY(ensure(c, c->radix_hist, 8 * 256 + 4));  // (its own buffer: callers keep live data in the scratch slots across a sort)
+  ghist = c->radix_hist.p;
   ELP_HIP(c, hipMemsetAsync(ghist, 0, (8 * 256 + 4) * sizeof(unsigned long long), c->stream));
   uint32_t *ticket = reinterpret_cast<uint32_t *>(ghist + 8 * 256);
   const unsigned hb = (unsigned)std::min<uint64_t>((n + 255) / 256, 2048);
@@ -454,7 +457,8 @@ int radix_sort_pairs(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *keys_
   if (n < 2) return 0;
   if (n >= 0xFFFFFFFFull) return set_error(c, ELP_ERR_UNSUPPORTED, "radix sort: more than 2^32-1 elements");
   unsigned long long *ghist;
-  ELP_TRY(scratch(c, 6, 8 * 256 + 4, &ghist));
+  ELP_TRY(ensure(c, c->radix_hist, 8 * 256 + 4));  // (its own buffer: callers keep live data in the scratch slots across a sort)
+  ghist = c->radix_hist.p;
   ELP_HIP(c, hipMemsetAsync(ghist, 0, (8 * 256 + 4) * sizeof(unsigned long long), c->stream));
   uint32_t *ticket = reinterpret_cast<uint32_t *>(ghist + 8 * 256);
   unsigned hb = (unsigned)std::min<uint64_t>((n + 255) / 256, 2048);

@@ -2,7 +2,12 @@
  *
  * The reference has no counterpart for any of them: a Go host binds elprep_hip.h only.  bench.py, the parity tests and the A/B tools use
  * these to re-run the path on resident input (elp_snapshot / elp_rollback), to pin a kernel choice per context (elp_set_tuning) and to
- * read per-kernel times (elp_profile_*).  Same shared object, separate header. */
+ * read per-kernel times (elp_profile_*).  Same shared object, separate header.
+ *
+ * Two process-wide switches for fault hunts, read from the environment when the library first allocates / launches:
+ *   ELP_DEBUG_POISON=<byte>  every new device buffer of a context is filled with that byte before its first use: a kernel that reads
+ *                            memory nothing wrote shows as a parity failure instead of depending on what the allocator hands out
+ *   ELP_DEBUG_TRACE=1        every kernel launch is named on stderr and waited for (which kernel faulted; ~100 x slower) */
 #ifndef ELPREP_HIP_DEBUG_H
 #define ELPREP_HIP_DEBUG_H
 #include "elprep_hip.h"

@@ -2,6 +2,8 @@
 any number of read groups in BQSR gather and apply (the reference's tables are maps that just grow, filters/bqsr.go:467-551, :936-1005) -
 the general count kernel in passes over covariate subsets, the one-length count kernel on exactly-sized per-covariate segments with its
 trips shared evenly among the workgroups, ApplyBQSR split by covariate with one row dictionary per covariate."""
+import dataclasses
+
 import numpy as np
 import pytest
 
@@ -473,3 +475,33 @@ def test_tables_and_lut_in_rows_form_on_the_device(n_cov, length):
     e.lut_upload_rows(quals, *tb.build_lut_rows(quals, 0), 500)
     assert np.array_equal(e.apply_bqsr(None, None, 500), want[2])
     e.close()
+
+
+@pytest.mark.gpu
+def test_small_read_set_behind_a_large_one_in_one_context():
+    """A context's scratch buffers only grow.  Mark duplicates keeps its candidate codes and its pair list in two of them across the
+    radix passes of the big-group pairing, the partitioned mate pass and the pair partition; until round 5 the radix sort's digit
+    histograms and the scan's partial sums lived in the SAME two slots: a five-record read set staged behind a large one (slots larger
+    than the small call asks for: no reallocation, the histograms land on the live codes) came out with the wrong pairs."""
+    from tests import kat_cases
+    from tests.kat_cases import _rec, batch_from_records
+    h = kat_cases.header2()
+    rng = np.random.default_rng(11)
+    big = []
+    for k in range(6000):  # pairs all over the two contigs, a few of them duplicates of each other
+        p, q = int(rng.integers(1, 400)), int(rng.integers(500, 900))
+        big += [_rec("b%d" % k, 99, k & 1, p, k & 1, q, q - p + 10), _rec("b%d" % k, 147, k & 1, q, k & 1, p, -(q - p + 10))]
+    bb = batch_from_records(big)
+    for path in (0, 1, 2):
+        e = Engine(h, tuning={"mate_path": path})
+        for k, (b, want) in enumerate(kat_cases.toggling_cases()):
+            e.reset()
+            e.stage(bb)
+            assert np.array_equal(e.mark_duplicates(True), orc.mark_duplicates(bb, h)), (path, k)
+            e.reset()
+            e.stage(b)
+            flags = e.mark_duplicates(True)
+            assert np.nonzero(flags & 0x400)[0].tolist() == want, (path, k)
+            # (the sort is the pipeline's Finalize behind the filter: CoordinateLess's modFlag tie-break sees the duplicate bits)
+            assert np.array_equal(e.sort_coordinate(), orc.sort_coordinate(dataclasses.replace(b, flag=flags.astype(b.flag.dtype)))), (path, k)
+        e.close()
