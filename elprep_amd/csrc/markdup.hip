@@ -334,6 +334,48 @@ __global__ __launch_bounds__(256) void k_bloom_coarse(const uint32_t *__restrict
   }
 }
 
+// path (2) / (3) of the mate matching for record i: the first record of a key at its table slot becomes the representative, the second
+// claims it with one CAS on mate[representative], a third marks the group BIG
+__device__ __forceinline__ void mate_table_insert(const MdCols &m, uint32_t i, uint32_t *table, uint64_t mask, uint32_t *mate, uint32_t *rep_of, uint32_t *err) {
+  const uint32_t rep = find_or_insert(table, mask, qname_hash(m, i), i, [&](uint32_t a, uint32_t b) { return mate_key_eq(m, a, b); }, mask);
+  if (rep == EMPTY) atomicOr(&err[1], 2u);  // the estimated table is full: the host repeats the pass with the full-size one
+  else if (rep != i) {                      // (the first of its key at the slot waits for the second)
+    rep_of[i] = rep;
+    const uint32_t old = atomicCAS(&mate[rep], EMPTY, i);
+    if (old == EMPTY) mate[i] = rep;
+    else {
+      rep_of[rep] = MATE_BIG;  // more than two records share {split, library, QNAME}
+      atomicOr(&err[1], 1u);
+    }
+  }
+}
+// the table inserts k_mate_pairs listed (64 lists of `cap` entries, their lengths 16 words apart), every lane busy: thread g takes entry
+// g of the lists laid end to end (a prefix sum of the 64 lengths per workgroup)
+__global__ __launch_bounds__(256) void k_mate_table(MdCols m, const uint32_t *__restrict__ tab_list, const uint32_t *__restrict__ tab_cnt, uint32_t cap, uint32_t *table,
+                                                    uint64_t mask, uint32_t *mate, uint32_t *rep_of, uint32_t *err) {
+  __shared__ uint32_t first[65];
+  if (threadIdx.x < 64) {
+    const uint32_t c = tab_cnt[threadIdx.x * 16u];
+    uint32_t incl = c;  // inclusive prefix over the wave's 64 lanes
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t up = __shfl_up(incl, d, 64);
+      if ((int)threadIdx.x >= d) incl += up;
+    }
+    first[threadIdx.x + 1] = incl;
+    if (threadIdx.x == 0) first[0] = 0;
+  }
+  __syncthreads();
+  // (the grid is sized by the host's estimate of the lists' lengths; whatever they hold is walked)
+  for (uint32_t g = blockIdx.x * 256u + threadIdx.x; g < first[64]; g += gridDim.x * 256u) {
+    uint32_t lo = 0, hi = 64;  // the list with first[l] <= g < first[l + 1]
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (first[mid] <= g) lo = mid; else hi = mid;
+    }
+    mate_table_insert(m, tab_list[(size_t)lo * cap + (g - first[lo])], table, mask, mate, rep_of, err);
+  }
+}
+
 // k_mate_pairs - ONE pass over the records behind k_mate_scan does what three passes did (md_mate_insert, md_frag_probe,
 // md_pair_list):
 //  * every true pair looks its own fragment key up in the (final, small) table of the true fragments - plain loads behind the
@@ -362,7 +404,8 @@ __global__ __launch_bounds__(256) void k_mate_pairs(MdCols m, const uint4 *__res
                                                     const uint32_t *__restrict__ ftable, const uint32_t *__restrict__ fbits, uint64_t fmask /* 0: no fragments */,
                                                     unsigned long long *fbest, int fixed /* 2: every candidate is matched by the partitioned pass
                                                     (k_mate_bucket) - only the fragment look-ups and the marks are made here */,
-                                                    uint64_t *__restrict__ pk, uint32_t *__restrict__ pv) {
+                                                    uint64_t *__restrict__ pk, uint32_t *__restrict__ pv,
+                                                    uint32_t *__restrict__ tab_list /* null: table inserts are made here */, uint32_t *tab_cnt, uint32_t tab_cap) {
   const uint64_t base = (uint64_t)blockIdx.x * (256 * MP_R) + threadIdx.x;
   uint8_t cd[MP_R];
   uint4 mine[MP_R], prev[MP_R], kc[MP_R];
@@ -423,7 +466,7 @@ __global__ __launch_bounds__(256) void k_mate_pairs(MdCols m, const uint4 *__res
         }
       }
     }
-    bool own = false;
+    bool own = false, want_tab = false;
     uint64_t key = 0;
     if (cd[r] != MC_NONE && fixed == 2) {
       code[i] = (uint8_t)(cd[r] | MC_TABBED);
@@ -441,17 +484,23 @@ __global__ __launch_bounds__(256) void k_mate_pairs(MdCols m, const uint4 *__res
         }
       } else {
         code[i] = (uint8_t)(cd[r] | MC_TABBED);
-        const uint32_t rep = find_or_insert(table, mask, qname_hash(m, (uint32_t)i), (uint32_t)i, [&](uint32_t a, uint32_t b) { return mate_key_eq(m, a, b); }, mask);
-        if (rep == EMPTY) atomicOr(&err[1], 2u);  // the estimated table is full: the host repeats the pass with the full-size one
-        else if (rep != (uint32_t)i) {            // (the first of its key at the slot waits for the second)
-          rep_of[i] = rep;
-          const uint32_t old = atomicCAS(&mate[rep], EMPTY, (uint32_t)i);
-          if (old == EMPTY) mate[i] = rep;
-          else {
-            rep_of[rep] = MATE_BIG;  // more than two records share {split, library, QNAME}
-            atomicOr(&err[1], 1u);
-          }
-        }
+        if (tab_list) want_tab = true;  // (deferred: k_mate_table)
+        else mate_table_insert(m, (uint32_t)i, table, mask, mate, rep_of, err);
+      }
+    }
+    // Round 5: in aligner order the few records that need the table (the sr-tagged copies of an sfm context: 2 % of the records, one or two
+    // lanes of EVERY wave) are listed for a dense pass of their own (k_mate_table) instead of walking the table here: a wave waited for
+    // its one lane's name hash and compare-and-swap in HBM - 63 lanes idle - and the kernel took 1.7 instead of 0.8 ms.  64 lists, a wave
+    // appends to list (workgroup % 64) with one atomic on that list's counter (a cache line of its own).
+    if (tab_list) {
+      const unsigned long long tm = __ballot(want_tab);
+      if (tm) {
+        const int lane = threadIdx.x & 63, leader = __ffsll((long long)tm) - 1;
+        const uint32_t li = blockIdx.x & 63u;
+        uint32_t at = 0;
+        if (lane == leader) at = atomicAdd(&tab_cnt[li * 16u], (uint32_t)__popcll(tm));
+        at = __shfl(at, leader, 64) + (uint32_t)__popcll(tm & ((1ull << lane) - 1ull));
+        if (want_tab) tab_list[(size_t)li * tab_cap + at] = (uint32_t)i;
       }
     }
     if (fixed == 1) {
@@ -626,6 +675,70 @@ __global__ __launch_bounds__(256) void k_pair_list_table(MdCols m, const uint4 *
   for (uint32_t k = threadIdx.x; k < lcount; k += 256) {
     pk[gbase + k] = lk[k];
     pv[gbase + k] = lv[k];
+  }
+}
+
+// the same over the lists of k_mate_pairs' deferred table inserts (aligner order with a few records on the table path: every owner that
+// carries MC_TABBED is in the lists, so the code column of ALL records need not be scanned: 0.31 -> 0.03 ms per 49 M records)
+__global__ __launch_bounds__(256) void k_pair_list_lists(MdCols m, const uint4 *__restrict__ fkey, const uint32_t *__restrict__ mate, const uint32_t *__restrict__ tab_list,
+                                                         const uint32_t *__restrict__ tab_cnt, uint32_t cap, uint64_t *__restrict__ pk, uint32_t *__restrict__ pv, uint32_t *np) {
+  __shared__ uint32_t first[65];
+  if (threadIdx.x < 64) {
+    uint32_t incl = tab_cnt[threadIdx.x * 16u];
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t up = __shfl_up(incl, d, 64);
+      if ((int)threadIdx.x >= d) incl += up;
+    }
+    first[threadIdx.x + 1] = incl;
+    if (threadIdx.x == 0) first[0] = 0;
+  }
+  __syncthreads();
+  __shared__ uint64_t lk[PL_TILES * 256];
+  __shared__ uint32_t lv[PL_TILES * 256];
+  __shared__ uint32_t lcount, gbase;
+  const uint32_t total = first[64], chunk = PL_TILES * 256u;
+  // a workgroup collects the entries of PL_TILES * 256 list members in LDS and appends them with ONE global atomic (a returning atomic
+  // per wave on the one counter serialises at ~12 ns each: 0.66 ms for 1.3 M members, measured)
+  for (uint32_t c0 = blockIdx.x * chunk; c0 < total; c0 += gridDim.x * chunk) {  // (uniform per workgroup)
+    if (threadIdx.x == 0) lcount = 0;
+    __syncthreads();
+#pragma unroll 2
+    for (int tile = 0; tile < PL_TILES; tile++) {
+      const uint32_t g = c0 + (uint32_t)tile * 256u + threadIdx.x;
+      uint32_t i = 0, mt = EMPTY;
+      if (g < total) {
+        uint32_t lo = 0, hi = 64;
+        while (hi - lo > 1) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (first[mid] <= g) lo = mid; else hi = mid;
+        }
+        i = tab_list[(size_t)lo * cap + (g - first[lo])];
+        mt = mate[i];
+      }
+      const bool own = mt != EMPTY && mt < i;  // the later-arriving mate owns the pair (:336-340)
+      uint64_t key = 0;
+      if (own) key = pair_entry(m, fkey[i], fkey[mt], i, mt);
+      const unsigned long long mask = __ballot(own);
+      if (mask) {
+        const int lane = threadIdx.x & 63, leader = __ffsll((long long)mask) - 1;
+        uint32_t at = 0;
+        if (lane == leader) at = atomicAdd(&lcount, (uint32_t)__popcll(mask));
+        at = __shfl(at, leader, 64);
+        if (own) {
+          at += (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+          lk[at] = key;
+          lv[at] = i;
+        }
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) gbase = lcount ? atomicAdd(np, lcount) : 0u;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < lcount; k += 256) {
+      pk[gbase + k] = lk[k];
+      pv[gbase + k] = lv[k];
+    }
+    __syncthreads();
   }
 }
 
@@ -830,10 +943,12 @@ static int markdup_impl(elp_ctx *c) {
   while (bw < n / 16 && bw < (1u << 20)) bw <<= 1;
   uint32_t *bloom, *hash32;
   uint8_t *code;
-  ELP_TRY(scratch(c, 6, bw + bw / 512 + 16 + n + 16 + (n + 16) / 4, &bloom));
+  const uint32_t tab_cap = (uint32_t)((blocks_for(n, 256 * MP_R) + 63) / 64) * 256u * MP_R;  // a list's share of the workgroups x their records
+  ELP_TRY(scratch(c, 6, bw + bw / 512 + 16 + n + 16 + (n + 16) / 4 + 64 * (size_t)tab_cap + 16, &bloom));
   uint32_t *coarse = bloom + bw;  // one bit per 16 words of the filter
   hash32 = coarse + bw / 512 + 16;
   code = reinterpret_cast<uint8_t *>(hash32 + n + 8);
+  uint32_t *tab_list = hash32 + n + 16 + (n + 16) / 4;  // k_mate_pairs' deferred table inserts (aligner order): 64 lists
   uint32_t *rep_of = c->pair_win.p;  // free until the pair phase fills it
   uint32_t *n_table_dev = c->md_ctr.p + 16;  // 64 counters, 16 words apart
   ELP_HIP(c, hipMemsetAsync(bloom, 0, bw * sizeof(uint32_t), st));
@@ -880,13 +995,22 @@ static int markdup_impl(elp_ctx *c) {
 
   uint64_t Tm = mate_mode == 0 ? T : std::min<uint64_t>(T, table_size_for(std::min<uint64_t>(n, 4ull * n_tab + 1024)));
   uint32_t e[4];
-  bool frag_done = false;
+  bool frag_done = false, listed = false;  // listed: the last pass of k_mate_pairs listed its table inserts (tab_list)
   for (;;) {
     if (mate_mode != 2) ELP_HIP(c, hipMemsetAsync(table, 0xFF, Tm * sizeof(uint32_t), st));
     ELP_HIP(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(np_dev), (int)(uint32_t)nfixed, 1, st));
+    // aligner order with a few records on the table path: their inserts are listed and made by a dense pass (the counters of k_mate_scan,
+    // read back above, serve as the lists' lengths)
+    const bool defer_tab = mate_mode == 1 && n_tab != 0;
+    listed = defer_tab;
+    if (defer_tab) ELP_HIP(c, hipMemsetAsync(n_table_dev, 0, 64 * 16 * sizeof(uint32_t), st));
     ELP_LAUNCH(c, "md_mate_pairs", k_mate_pairs, dim3(blocks_for(n, 256 * MP_R)), dim3(256), 0, m, (const uint4 *)fkey, code,
                (const uint32_t *)hash32, (const uint32_t *)bloom, (uint32_t)(bw - 1), (const uint32_t *)(n_tab ? coarse : nullptr), table, Tm - 1, c->mate.p, rep_of, c->err_flag.p,
-               (const uint32_t *)ftable, (const uint32_t *)fbits, nf ? Tf - 1 : (uint64_t)0, best, mate_mode == 1 ? 1 : (mate_mode == 2 ? 2 : 0), pk, pv);
+               (const uint32_t *)ftable, (const uint32_t *)fbits, nf ? Tf - 1 : (uint64_t)0, best, mate_mode == 1 ? 1 : (mate_mode == 2 ? 2 : 0), pk, pv,
+               defer_tab ? tab_list : (uint32_t *)nullptr, n_table_dev, tab_cap);
+    if (defer_tab)  // (the lists hold the records k_mate_scan counted plus the neighbour pairs a filter hit sent along: in practice a fraction as many again)
+      ELP_LAUNCH(c, "md_mate_table", k_mate_table, dim3(blocks_for(std::min<uint64_t>(n, 2ull * n_tab + 4096), 256)), dim3(256), 0, m, (const uint32_t *)tab_list,
+                 (const uint32_t *)n_table_dev, tab_cap, table, Tm - 1, c->mate.p, rep_of, c->err_flag.p);
     if (mate_mode == 2) {
       int mbits = 0;
       while (mbits < 24 && ((n + 1) >> mbits) > (uint64_t)MB_TARGET) mbits++;
@@ -964,8 +1088,12 @@ static int markdup_impl(elp_ctx *c) {
     const bool no_table = fixed && n_tab == 0 && !e[1];
     if (!no_table) {
       ELP_HIP(c, hipMemsetAsync(c->pair_win.p, 0xFF, n * sizeof(uint32_t), st));
-      ELP_LAUNCH(c, "md_pair_list", k_pair_list_table, dim3(blocks_for(n, 256 * PL_TILES)), dim3(256), 0, m, (const uint4 *)fkey, (const uint32_t *)c->mate.p,
-                 (const uint8_t *)code, pk, pv, np_dev);
+      if (listed)
+        ELP_LAUNCH(c, "md_pair_list", k_pair_list_lists, dim3(blocks_for(std::min<uint64_t>(n, 2ull * n_tab + 4096), 256 * PL_TILES)), dim3(256), 0, m, (const uint4 *)fkey,
+                   (const uint32_t *)c->mate.p, (const uint32_t *)tab_list, (const uint32_t *)n_table_dev, tab_cap, pk, pv, np_dev);
+      else
+        ELP_LAUNCH(c, "md_pair_list", k_pair_list_table, dim3(blocks_for(n, 256 * PL_TILES)), dim3(256), 0, m, (const uint4 *)fkey, (const uint32_t *)c->mate.p,
+                   (const uint8_t *)code, pk, pv, np_dev);
     }
     uint64_t *ks = pk;
     uint32_t *vs = pv;
