@@ -28,7 +28,7 @@ HIP_SYMBOLS = [
     "elp_filter_records", "elp_clean_sam", "elp_split_classify", "elp_merge_spread",
     "elp_set_read_group_ids", "elp_pinned_alloc", "elp_pinned_free", "elp_stage_bam", "elp_emit_sorted_bam", "elp_stage_bgzf", "elp_emit_sorted_bgzf",
     "elp_set_header_columns", "elp_stage_columns", "elp_set_read_group_ids_flat", "elp_filter_records_flat", "elp_group_probe", "elp_group_init_transport", "elp_copy_records", "elp_exchange_records", "elp_group_set_p2p", "elp_group_share", "elp_emit_merged_bam", "elp_bqsr_lut_upload",
-    "elp_snapshot", "elp_rollback", "elp_set_tuning", "elp_profile_enable", "elp_profile_reset", "elp_profile_count", "elp_profile_get",
+    "elp_snapshot", "elp_rollback", "elp_set_tuning", "elp_profile_enable", "elp_profile_reset", "elp_profile_count", "elp_profile_get", "elp_debug_check_guards",
 ]
 HOST_SYMBOLS = [
     "elp_bqsr_tables_new", "elp_bqsr_tables_new_rows", "elp_bqsr_tables_free", "elp_bqsr_tables_merge", "elp_bqsr_tables_finalize", "elp_bqsr_tables_empirical",

@@ -32,6 +32,14 @@ enum : uint32_t { OP_M = 0, OP_I = 1, OP_D = 2, OP_N = 3, OP_S = 4, OP_H = 5, OP
 __host__ __device__ inline bool op_consumes_read(uint32_t op) { return op == OP_M || op == OP_I || op == OP_S || op == OP_EQ || op == OP_X; }
 __host__ __device__ inline bool op_consumes_ref(uint32_t op) { return op == OP_M || op == OP_D || op == OP_N || op == OP_EQ || op == OP_X; }
 
+// ELP_DEBUG_GUARD=1 (tests): every device buffer of a context gets 4 KB behind its end filled with a pattern; the pattern is checked when
+// the buffer is released or regrown (and by elp_debug_check_guards): a kernel that writes past the end of its buffer aborts the process
+// with the buffer's size on stderr instead of corrupting a neighbour.  ctx.hip.
+size_t debug_guard_bytes();
+void debug_guard_arm(void *p, size_t payload_bytes);
+void debug_guard_release(void *p);
+int debug_guard_check_all();
+
 template <class T>
 struct DVec {
   T *p = nullptr;
@@ -41,7 +49,7 @@ struct DVec {
   DVec &operator=(const DVec &) = delete;
   ~DVec() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) { debug_guard_release(p); (void)hipFree(p); }
     p = nullptr;
     cap = 0;
   }
@@ -262,7 +270,8 @@ int ensure(elp_ctx *c, DVec<T> &v, size_t n, bool keep = false, size_t keep_elem
   if (n <= v.cap) return 0;
   size_t ncap = keep ? (n + n / 2 + 16) : n;
   T *np = nullptr;
-  ELP_HIP(c, hipMalloc((void **)&np, ncap * sizeof(T)));
+  ELP_HIP(c, hipMalloc((void **)&np, ncap * sizeof(T) + debug_guard_bytes()));
+  if (debug_guard_bytes()) debug_guard_arm(np, ncap * sizeof(T));
   // ELP_DEBUG_POISON=<byte> (tests): every new device buffer starts filled with that byte - a kernel that reads memory nothing wrote
   // shows up as a parity failure instead of depending on what the allocator hands out
   if (const int pz = debug_poison(); pz >= 0) {  // (on the context's stream and waited for: a fill on the null stream could land behind later kernels)
@@ -279,6 +288,7 @@ int ensure(elp_ctx *c, DVec<T> &v, size_t n, bool keep = false, size_t keep_elem
   }
   if (v.p) {
     (void)hipStreamSynchronize(c->stream);
+    debug_guard_release(v.p);
     (void)hipFree(v.p);
   }
   v.p = np;

@@ -4,6 +4,53 @@
 
 namespace elp {
 
+// ---- ELP_DEBUG_GUARD: a pattern behind every buffer, checked at release
+namespace {
+constexpr size_t GUARD = 4096;
+constexpr uint8_t GUARD_BYTE = 0xC3;
+std::mutex guard_mu;
+std::map<void *, size_t> guard_of;  // buffer -> payload bytes
+int guard_check_one(void *p, size_t payload) {
+  uint8_t host[GUARD];
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host, static_cast<uint8_t *>(p) + payload, GUARD, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  for (size_t k = 0; k < GUARD; k++)
+    if (host[k] != GUARD_BYTE) {
+      fprintf(stderr, "[elp] ELP_DEBUG_GUARD: byte %zu behind the end of a %zu-byte device buffer was overwritten (0x%02x)\n", k, payload, host[k]);
+      return 1;
+    }
+  return 0;
+}
+}  // namespace
+size_t debug_guard_bytes() {
+  static const size_t v = [] { const char *e = getenv("ELP_DEBUG_GUARD"); return (e && *e && *e != '0') ? GUARD : (size_t)0; }();
+  return v;
+}
+void debug_guard_arm(void *p, size_t payload) {
+  (void)hipMemset(static_cast<uint8_t *>(p) + payload, GUARD_BYTE, GUARD);
+  (void)hipDeviceSynchronize();
+  std::lock_guard<std::mutex> lk(guard_mu);
+  guard_of[p] = payload;
+}
+void debug_guard_release(void *p) {
+  if (!debug_guard_bytes()) return;
+  size_t payload = 0;
+  {
+    std::lock_guard<std::mutex> lk(guard_mu);
+    auto it = guard_of.find(p);
+    if (it == guard_of.end()) return;
+    payload = it->second;
+    guard_of.erase(it);
+  }
+  if (guard_check_one(p, payload)) abort();
+}
+int debug_guard_check_all() {
+  if (!debug_guard_bytes()) return 0;
+  std::lock_guard<std::mutex> lk(guard_mu);
+  int bad = 0;
+  for (auto &kv : guard_of) bad += guard_check_one(kv.first, kv.second);
+  return bad;
+}
+
 bool debug_trace() {
   static const bool v = [] { const char *e = getenv("ELP_DEBUG_TRACE"); return e && *e && *e != '0'; }();
   return v;
@@ -131,6 +178,9 @@ int radix_check(elp_ctx *c) {
 using namespace elp;
 
 extern "C" {
+
+int elp_debug_check_guards(void) { return elp::debug_guard_check_all(); }
+
 
 int elp_create(int device_ordinal, elp_ctx **out) {
   if (!out) return ELP_ERR_ARG;

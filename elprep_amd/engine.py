@@ -68,8 +68,11 @@ class Engine:
 
     def close(self):
         if getattr(self, "h", None) and self.h.value:
+            bad = self.L.elp_debug_check_guards()  # (ELP_DEBUG_GUARD=1: a kernel wrote past the end of a device buffer; 0 otherwise)
             self.L.elp_destroy(self.h)
             self.h = C.c_void_p()
+            if bad:
+                raise RuntimeError(f"ELP_DEBUG_GUARD: {bad} device buffer(s) were written past their end (sizes on stderr)")
         for ptr in getattr(self, "_pinned", []):
             self.L.elp_pinned_free(ptr)
         self._pinned = []

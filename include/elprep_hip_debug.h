@@ -7,7 +7,9 @@
  * Two process-wide switches for fault hunts, read from the environment when the library first allocates / launches:
  *   ELP_DEBUG_POISON=<byte>  every new device buffer of a context is filled with that byte before its first use: a kernel that reads
  *                            memory nothing wrote shows as a parity failure instead of depending on what the allocator hands out
- *   ELP_DEBUG_TRACE=1        every kernel launch is named on stderr and waited for (which kernel faulted; ~100 x slower) */
+ *   ELP_DEBUG_TRACE=1        every kernel launch is named on stderr and waited for (which kernel faulted; ~100 x slower)
+ *   ELP_DEBUG_GUARD=1        4 KB of pattern behind every device buffer of a context, checked when the buffer is released or regrown and by
+ *                            elp_debug_check_guards: a kernel that writes past the end of its buffer aborts the process (buffer size on stderr) */
 #ifndef ELPREP_HIP_DEBUG_H
 #define ELPREP_HIP_DEBUG_H
 #include "elprep_hip.h"
@@ -19,6 +21,9 @@ extern "C" {
  * elp_snapshot copies them aside in HBM; elp_rollback restores them and invalidates derived state (sort keys, scores,
  * duplicate tables).  Lets a host re-run the path on identical input (bench.py's timed steps; `--bqsr-tables-only`
  * style what-if runs) without re-staging over PCIe. */
+/* number of live device buffers whose guard pattern was overwritten (0 without ELP_DEBUG_GUARD) */
+int elp_debug_check_guards(void);
+
 int elp_snapshot(elp_ctx *ctx);
 int elp_rollback(elp_ctx *ctx);
 

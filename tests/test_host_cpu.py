@@ -26,7 +26,7 @@ def test_hip_library_exports_every_declared_symbol():
     names = sorted(set(_declared("elprep_hip.h")) | set(_declared("elprep_hip_debug.h")))  # the boundary + the harness header of the same library
     assert set(names) == set(_lib.HIP_SYMBOLS)
     assert set(_declared("elprep_hip_debug.h")) == {"elp_snapshot", "elp_rollback", "elp_set_tuning", "elp_profile_enable", "elp_profile_reset",
-                                                    "elp_profile_count", "elp_profile_get"}
+                                                    "elp_profile_count", "elp_profile_get", "elp_debug_check_guards"}
     for n in names:
         assert hasattr(L, n), n
 
