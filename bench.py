@@ -127,7 +127,7 @@ def summarize(prof, steps, n_reads, full_bytes):
             "traffic_source": "profiles/traffic.json: rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE) of an 8 M-read run of this path, per read, scaled to this run's reads - not measured in this run",
             "stage_frac": stage_frac,
             "path_frac": round((full_bytes * n_reads / (kernel_total_ms * 1e-3) / 1e9) / HBM_PEAK_GBS, 5) if kernel_total_ms else None}
-    kern = {k: round(v[1] / steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:14]}
+    kern = {k: round(v[1] / steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:28]}
     return {k: round(v, 3) for k, v in sorted(stage_ms.items())}, kern, roof
 
 
@@ -385,10 +385,22 @@ def main():
             lut_buf[0] = (lut, present)
             return lut, present
 
+        rows_buf = [None]
+
+        def finalize_lut_rows(quals, q_rows, c_rows, x_rows):
+            # the rows form of the filter step's table path (only the rows of the counted qualities cross PCIe; the LUT rows are built in
+            # page-locked memory once per set of qualities)
+            tb = BqsrTables.from_rows(hdr.n_cov, quals, q_rows, c_rows, x_rows, MAX_CYCLE).finalize()
+            if rows_buf[0] is None or rows_buf[0][0] != tuple(quals):
+                e0 = rk.engines[0]
+                rows_buf[0] = (tuple(quals), (e0.pinned_zeros((hdr.n_cov, len(quals), 2 * MAX_CYCLE + 1, 17), np.uint8),
+                                              np.zeros((hdr.n_cov, 94), np.uint8), np.zeros(hdr.n_cov, np.uint8)))
+            return tb.build_lut_rows(quals, 0, out=rows_buf[0][1])
+
         def step():
             # same shape as the filter step: the host finalises the all-reduced tables (and uploads the LUT to both contexts) while the
             # GPU sorts the rank's splits
-            rk.step(MAX_CYCLE, 100, host_pool, finalize_lut)
+            rk.step(MAX_CYCLE, 100, host_pool, finalize_lut, None if os.environ.get("ELP_SFM_DENSE_TABLES") else finalize_lut_rows)
             rk.sync()
         mode = "sfm"
         counts = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(world)]

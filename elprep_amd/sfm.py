@@ -472,11 +472,14 @@ class SfmRank:
         qt, ct, xt = e0.tables_fetch(reuse=True)
         return qt, ct, xt, ctr
 
-    def step(self, max_cycle: int, pixel_dist: int, host_pool, finalize):
+    def step(self, max_cycle: int, pixel_dist: int, host_pool, finalize, finalize_rows=None):
         """One pass of the path over this rank's splits with the host's float64 finalisation hidden behind the sorts, as the one-context
         filter step has it: mark duplicates, duplication metrics (order-independent sums: they do not need the sort) and the BQSR count of
         every split, THE all-reduce (tables + counters), then the tables' way to the host, FinalizeBQSRTables and the LUT's upload to both
-        contexts on a host thread while the GPU sorts the splits, then ApplyBQSR.  `finalize(qt, ct, xt) -> (lut, present)`.
+        contexts on a host thread while the GPU sorts the splits, then ApplyBQSR.  `finalize(qt, ct, xt) -> (lut, present)`;
+        `finalize_rows(quals, q_rows, c_rows, x_rows) -> (rows, defaults, present)` (optional): the tables and the LUT in ROWS form - only the
+        rows of the qualities this rank's contexts counted cross PCIe (Engine.tables_fetch_rows / lut_upload_rows); if another rank
+        counted a quality this one did not, the all-reduced tables hold a row outside that set and the dense forms are taken.
         Returns the all-reduced duplication counters."""
         if self.collective == "torch":
             qt, ct, xt, ctr = self.gather(max_cycle, pixel_dist)
@@ -507,6 +510,15 @@ class SfmRank:
         self.allreduce_s.append(time.perf_counter() - t0)
 
         def host_side():
+            if finalize_rows is not None:
+                quals = sorted(set(e0.quals_counted()) | (set(e1.quals_counted()) if self.n[1] else set()))
+                got = e0.tables_fetch_rows(quals, reuse=True)
+                if got is not None:
+                    rows, defaults, present = finalize_rows(quals, *got)
+                    e0.lut_upload_rows(quals, rows, defaults, present, max_cycle)
+                    if self.n[1]:
+                        e1.lut_upload_rows(quals, rows, defaults, present, max_cycle)
+                    return rows, present
             lut, present = finalize(*e0.tables_fetch(reuse=True))
             e0.lut_upload(lut, present, max_cycle)
             if self.n[1]:

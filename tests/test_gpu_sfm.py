@@ -105,10 +105,11 @@ def test_sfm_ranks_on_one_gpu(world):
         ranks[r].close()
 
 
-def test_sfm_one_rank_step_with_the_host_behind_the_sorts():
+@pytest.mark.parametrize("form", ["dense", "rows"])
+def test_sfm_one_rank_step_with_the_host_behind_the_sorts(form):
     """SfmRank.step on ONE rank through the C ABI's device group (a group of one): the same flags, permutation, tables, counters and
     qualities as the oracle run split by split - the order of events differs from gather() + apply() (metrics in front of the sort, the
-    finalisation on a host thread while the GPU sorts), the results must not"""
+    finalisation on a host thread while the GPU sorts), the results must not.  "rows": the tables and the LUT travel in rows form (round 5)"""
     from concurrent.futures import ThreadPoolExecutor
     cfg, gof, G, owner, b = sfm_worker.make_rank_input(0, 1, pairs_per_rank=6000)
     h = cfg.header()
@@ -128,9 +129,19 @@ def test_sfm_one_rank_step_with_the_host_behind_the_sorts():
     def finalize(qt, ct, xt):
         box["tables"] = (qt.copy(), ct.copy(), xt.copy())
         return BqsrTables(qt, ct, xt, 500).finalize().build_lut(0)
+    def finalize_rows(quals, q_rows, c_rows, x_rows):
+        tb = BqsrTables.from_rows(h.n_cov, quals, q_rows, c_rows, x_rows, 500).finalize()
+        box["rows"] = (list(quals), q_rows.copy(), c_rows.copy(), x_rows.copy())
+        return tb.build_lut_rows(quals, 0)
     with ThreadPoolExecutor(1) as pool:
-        ctr = rk.step(500, 100, pool, finalize)
+        ctr = rk.step(500, 100, pool, finalize, finalize_rows if form == "rows" else None)
     rk.sync()
+    if form == "rows":  # the rows that came back, put where they belong in the dense tables
+        assert "tables" not in box, "the rows form was not taken"
+        quals, qr, cr, xr = box["rows"]
+        qt = np.zeros((h.n_cov, 94, 2), np.int64); ct = np.zeros((h.n_cov, 94, 1001, 2), np.int64); xt = np.zeros((h.n_cov, 94, 16, 2), np.int64)
+        qt[:, quals], ct[:, quals], xt[:, quals] = qr.reshape(h.n_cov, len(quals), 2), cr.reshape(h.n_cov, len(quals), 1001, 2), xr.reshape(h.n_cov, len(quals), 16, 2)
+        box["tables"] = (qt, ct, xt)
     oq = oc = ox = octr = None
     for w, p in enumerate(parts):
         fl_all = np.zeros(p.n, np.uint16)
