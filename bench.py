@@ -174,6 +174,14 @@ def main():
     if sfm_mode and not under_launcher:
         os.environ.update({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
         os.environ.setdefault("MASTER_PORT", "29533")
+    if world > 1:
+        # one process per GPU on one node: the host's cores are shared.  The table path's worker pool takes its share (all ranks finalise
+        # at the same moment, right behind the all-reduce), and a rank only polls its stream while it waits (ELP_SYNC_SPIN) if every
+        # rank's two waiting threads can keep a core of their own next to that
+        share = max(1, effective_cores() // world)
+        os.environ.setdefault("ELP_HOST_THREADS", str(share))
+        if share < 4:
+            os.environ.setdefault("ELP_SYNC_SPIN", "0")
     if sfm_mode:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

@@ -358,7 +358,7 @@ int stage_bam_columns(elp_ctx *c, uint32_t n_rec, uint64_t piece_bytes, uint64_t
   ELP_TRY(exclusive_scan_u32(c, len_l, sc_l, n_rec, &tl));
   uint32_t hs[8];
   ELP_HIP(c, hipMemcpyAsync(hs, stats, 32, hipMemcpyDeviceToHost, st));
-  ELP_HIP(c, hipStreamSynchronize(st));
+  ELP_HIP(c, elp::stream_wait(st));
   if (hs[4]) {
     if (hs[4] & 8u) return set_error(c, ELP_ERR_ARG, "elp_stage_bam: an RG:Z tag names a read group that is not in the header");
     if (hs[4] & 4u) return set_error(c, ELP_ERR_UNSUPPORTED, "elp_stage_bam: CIGAR in a CG:B tag (more than 65535 operations)");
@@ -404,7 +404,7 @@ int elp_set_read_group_ids(elp_ctx *c, const char *const *ids) {
   ELP_TRY(ensure(c, c->rg_ids_off, off.size() + 4));
   if (!cat.empty()) ELP_HIP(c, hipMemcpyAsync(c->rg_ids.p, cat.data(), cat.size(), hipMemcpyHostToDevice, c->stream));
   ELP_HIP(c, hipMemcpyAsync(c->rg_ids_off.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, c->stream));
-  ELP_HIP(c, hipStreamSynchronize(c->stream));
+  ELP_HIP(c, elp::stream_wait(c->stream));
   c->have_rg_ids = true;
   return 0;
 }
@@ -508,14 +508,14 @@ int elp_stage_bam(elp_ctx *c, const uint8_t *bytes, uint64_t n_bytes, const uint
         ELP_HIP(c, hipMemcpyAsync(d_raw + o, c->bounce[k], len, hipMemcpyHostToDevice, c->copy_stream));
         ELP_HIP(c, hipEventRecord(c->bounce_ev[k], c->copy_stream));
       }
-      ELP_HIP(c, hipStreamSynchronize(c->copy_stream));
+      ELP_HIP(c, elp::stream_wait(c->copy_stream));
     }
     for (auto &o : off) o += c->raw_bytes;  // offsets into c->raw
     ELP_HIP(c, hipMemcpyAsync(c->raw_off.p + c->n, off.data(), (size_t)(n_rec + 1) * 8, hipMemcpyHostToDevice, st));
     ELP_TRY(stage_bam_columns(c, n_rec, piece_bytes, c->raw_bytes + piece_bytes, max_raw_rec, split_id));
     at_byte = p;
   }
-  ELP_HIP(c, hipStreamSynchronize(st));
+  ELP_HIP(c, elp::stream_wait(st));
   c->adapted = c->sorted = c->marked = false;
   c->have_qual_present = false;
   c->have_snapshot = false;
@@ -546,7 +546,7 @@ static int emit_stream(elp_ctx *c, const BamOut &m, const BamOut &m2, const uint
     ELP_TRY(exclusive_scan_u32(c, sizes, offs, cnt, &chunk_bytes));
     uint32_t he = 0;
     ELP_HIP(c, hipMemcpyAsync(&he, err, 4, hipMemcpyDeviceToHost, st));
-    ELP_HIP(c, hipStreamSynchronize(st));
+    ELP_HIP(c, elp::stream_wait(st));
     if (he & 16u) return set_error(c, ELP_ERR_UNSUPPORTED, "elp_emit_sorted_bam: H-typed optional field");
     if (he) return set_error(c, ELP_ERR_DATA, "elp_emit_sorted_bam: malformed optional fields");
     // (BGZF: the size of the stored form - what the pass needs room for; the compressed members are never larger, their actual size is
@@ -567,7 +567,7 @@ static int emit_stream(elp_ctx *c, const BamOut &m, const BamOut &m2, const uint
       d_send = d_framed;
     }
     ELP_HIP(c, hipMemcpyAsync(out + total, d_send, out_bytes, hipMemcpyDeviceToHost, st));
-    ELP_HIP(c, hipStreamSynchronize(st));
+    ELP_HIP(c, elp::stream_wait(st));
     total += out_bytes;
   }
   *n_bytes_out = total;

@@ -832,7 +832,7 @@ extern "C" int elp_stage_bgzf(elp_ctx *c, const uint8_t *bgzf, uint64_t n_bytes,
     ELP_LAUNCH(c, "stage_bgzf_check", k_rec_check, dim3(blocks_for(nb, 256)), dim3(256), 0, rs, (const BgzfBlk *)d_blk, nb, (const uint64_t *)entry, (const uint64_t *)exit_, bad);
     uint32_t hr[4];
     ELP_HIP(c, hipMemcpyAsync(hr, res, sizeof hr, hipMemcpyDeviceToHost, st));
-    ELP_HIP(c, hipStreamSynchronize(st));
+    ELP_HIP(c, elp::stream_wait(st));
     if (hr[0] & 1u) return set_error(c, ELP_ERR_DATA, "elp_stage_bgzf: a block does not inflate (corrupt DEFLATE data or wrong ISIZE)");
     if (hr[0] & 2u) return set_error(c, ELP_ERR_DATA, "invalid CRC-32 value for a data block in a BGZF file");
     if (hr[1]) ELP_LAUNCH(c, "stage_bgzf_repair", k_rec_repair, dim3(1), dim3(1), 0, rs, (const BgzfBlk *)d_blk, nb, entry, exit_, cnt);
@@ -846,7 +846,7 @@ extern "C" int elp_stage_bgzf(elp_ctx *c, const uint8_t *bgzf, uint64_t n_bytes,
     uint64_t rec_end = 0;
     ELP_HIP(c, hipMemcpyAsync(&rec_end, c->raw_off.p + c->n + n_rec, 8, hipMemcpyDeviceToHost, st));
     ELP_HIP(c, hipMemcpyAsync(hr, res, sizeof hr, hipMemcpyDeviceToHost, st));
-    ELP_HIP(c, hipStreamSynchronize(st));
+    ELP_HIP(c, elp::stream_wait(st));
     if (rec_end < begin || rec_end > end) return set_error(c, ELP_ERR_DATA, "elp_stage_bgzf: the alignment records do not chain (block_size fields)");
     if (n_rec) ELP_TRY(stage_bam_columns(c, n_rec, rec_end - begin, rec_end, hr[2], split_id));
     begin = rec_end;

@@ -1461,7 +1461,7 @@ static int sync_bqsr_ptrs(elp_ctx *c) {
     ELP_HIP(c, hipMemcpyAsync(c->d_sites.p, c->h_sites.data(), nr * sizeof(int32_t *), hipMemcpyHostToDevice, c->stream));
     ELP_HIP(c, hipMemcpyAsync(c->d_n_sites.p, c->h_n_sites.data(), nr * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
     ELP_HIP(c, hipMemcpyAsync(c->d_site_idx.p, c->h_site_idx.data(), nr * sizeof(uint32_t *), hipMemcpyHostToDevice, c->stream));
-    ELP_HIP(c, hipStreamSynchronize(c->stream));
+    ELP_HIP(c, elp::stream_wait(c->stream));
   }
   c->bqsr_ptrs_dirty = false;
   return 0;
@@ -1857,7 +1857,7 @@ extern "C" {
 int elp_bqsr_set_reference(elp_ctx *c, int32_t refid, const uint8_t *bases, int64_t len) {
   if (!c || !c->have_header || refid < 0 || refid >= c->n_ref || len < 0 || (len && !bases)) return set_error(c, ELP_ERR_ARG, "elp_bqsr_set_reference: bad arguments");
   ELP_HIP(c, hipSetDevice(c->device));
-  if (c->h_ref_seq[refid]) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->h_ref_seq[refid]); c->h_ref_seq[refid] = nullptr; }
+  if (c->h_ref_seq[refid]) { (void)elp::stream_wait(c->stream); (void)hipFree(c->h_ref_seq[refid]); c->h_ref_seq[refid] = nullptr; }
   // the contig is kept as 4-bit base codes (k_pack_reference); the ASCII bytes only pass through scratch
   const int64_t packed = (len + 1) / 2;
   uint8_t *d = nullptr;
@@ -1870,7 +1870,7 @@ int elp_bqsr_set_reference(elp_ctx *c, int32_t refid, const uint8_t *bases, int6
     hipLaunchKernelGGL(k_pack_reference, dim3(blocks_for((uint64_t)packed, 256)), dim3(256), 0, c->stream, (const uint8_t *)tmp, len, d, packed);
     ELP_HIP(c, hipGetLastError());
   }
-  ELP_HIP(c, hipStreamSynchronize(c->stream));
+  ELP_HIP(c, elp::stream_wait(c->stream));
   c->h_ref_seq[refid] = d;
   c->h_ref_seq_len[refid] = len;
   c->ref_flags_dirty[refid] = 1;
@@ -1883,7 +1883,7 @@ int elp_bqsr_set_known_sites(elp_ctx *c, int32_t refid, const int32_t *start_end
   for (int64_t k = 1; k < n; k++)
     if (!(start_end[2 * k] > start_end[2 * k - 1])) return set_error(c, ELP_ERR_ARG, "known sites of refid %d are not sorted and flattened at index %lld", refid, (long long)k);
   ELP_HIP(c, hipSetDevice(c->device));
-  if (c->h_sites[refid]) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->h_sites[refid]); c->h_sites[refid] = nullptr; }
+  if (c->h_sites[refid]) { (void)elp::stream_wait(c->stream); (void)hipFree(c->h_sites[refid]); c->h_sites[refid] = nullptr; }
   if (c->h_site_idx[refid]) { (void)hipFree(c->h_site_idx[refid]); c->h_site_idx[refid] = nullptr; }
   int32_t *d = nullptr;
   ELP_HIP(c, hipMalloc((void **)&d, (size_t)(2 * n + 4) * sizeof(int32_t)));
@@ -1893,7 +1893,7 @@ int elp_bqsr_set_known_sites(elp_ctx *c, int32_t refid, const int32_t *start_end
   ELP_HIP(c, hipMalloc((void **)&ix, (size_t)(nbuck + 4) * sizeof(uint32_t)));
   hipLaunchKernelGGL(k_site_index, dim3(blocks_for((uint64_t)nbuck, 256)), dim3(256), 0, c->stream, (const int32_t *)d, n, nbuck, ix);
   ELP_HIP(c, hipGetLastError());
-  ELP_HIP(c, hipStreamSynchronize(c->stream));
+  ELP_HIP(c, elp::stream_wait(c->stream));
   c->h_site_idx[refid] = ix;
   c->h_sites[refid] = d;
   c->h_n_sites[refid] = n;
@@ -1930,9 +1930,9 @@ int elp_bqsr_tables_fetch(elp_ctx *c, int64_t *qual_tbl, int64_t *cycle_tbl, int
   // next stage on the context's stream (the copy is 6 MB over PCIe: ~0.2 ms during which the GPU would otherwise sit idle)
   if (!c->copy_stream) ELP_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
   if (c->tables_ev) ELP_HIP(c, hipStreamWaitEvent(c->copy_stream, c->tables_ev, 0));
-  else ELP_HIP(c, hipStreamSynchronize(c->stream));
+  else ELP_HIP(c, elp::stream_wait(c->stream));
   ELP_HIP(c, hipMemcpyAsync(c->h_pinned, c->dev_tables.p, bytes, hipMemcpyDeviceToHost, c->copy_stream));
-  ELP_HIP(c, hipStreamSynchronize(c->copy_stream));
+  ELP_HIP(c, elp::stream_wait(c->copy_stream));
   const int64_t *hp = static_cast<const int64_t *>(c->h_pinned);
   memcpy(qual_tbl, hp, nq * 8);
   memcpy(cycle_tbl, hp + nq, nc * 8);
@@ -1970,7 +1970,7 @@ int elp_bqsr_tables_fetch_rows(elp_ctx *c, const uint8_t *quals, int n_quals, in
   ELP_TRY(ensure(c, c->tables_pack, words + 64));
   if (!c->copy_stream) ELP_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
   if (c->tables_ev) ELP_HIP(c, hipStreamWaitEvent(c->copy_stream, c->tables_ev, 0));
-  else ELP_HIP(c, hipStreamSynchronize(c->stream));
+  else ELP_HIP(c, elp::stream_wait(c->stream));
   // the quality list and the "uncovered" word ride in the pack buffer's tail
   uint8_t *d_quals = reinterpret_cast<uint8_t *>(c->tables_pack.p + words);
   uint32_t *d_unc = reinterpret_cast<uint32_t *>(c->tables_pack.p + words + 16);
@@ -1985,7 +1985,7 @@ int elp_bqsr_tables_fetch_rows(elp_ctx *c, const uint8_t *quals, int n_quals, in
   ELP_HIP(c, hipMemcpyAsync(c->h_pinned, c->tables_pack.p, words * 8, hipMemcpyDeviceToHost, c->copy_stream));
   uint32_t unc = 0;
   ELP_HIP(c, hipMemcpyAsync(&unc, d_unc, 4, hipMemcpyDeviceToHost, c->copy_stream));
-  ELP_HIP(c, hipStreamSynchronize(c->copy_stream));
+  ELP_HIP(c, elp::stream_wait(c->copy_stream));
   if (unc) return 1;
   const int64_t *hp = static_cast<const int64_t *>(c->h_pinned);
   if (n_rows) {
@@ -2256,7 +2256,7 @@ static int bqsr_apply_impl(elp_ctx *c, int max_cycle, const uint8_t *lut, const 
         const uint32_t t2_cap = LUT_T2_CAP;
         uint32_t n_dict = 0;
         ELP_HIP(c, hipMemcpyAsync(&n_dict, counter, 4, hipMemcpyDeviceToHost, c->stream));
-        ELP_HIP(c, hipStreamSynchronize(c->stream));
+        ELP_HIP(c, elp::stream_wait(c->stream));
         if (n_dict < t2_cap) {
           const int m = n_dict + 1 <= 256 ? 1 : 2;
           const size_t bytes = ((n1 * (size_t)m + 15) & ~(size_t)15) + (size_t)(n_dict + 1) * (m == 1 ? 32 : 17) + 16;

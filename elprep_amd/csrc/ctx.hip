@@ -51,6 +51,10 @@ int debug_guard_check_all() {
   return bad;
 }
 
+bool sync_spin() {
+  static const bool v = [] { const char *e = getenv("ELP_SYNC_SPIN"); return !(e && *e == '0'); }();
+  return v;
+}
 bool debug_trace() {
   static const bool v = [] { const char *e = getenv("ELP_DEBUG_TRACE"); return e && *e && *e != '0'; }();
   return v;
@@ -99,7 +103,7 @@ int prof_begin(elp_ctx *c, const char *name0) {
 void prof_end(elp_ctx *c, int pending) { (void)hipEventRecord(c->prof_pending[pending].b, c->stream); }
 int prof_flush(elp_ctx *c) {
   if (c->prof_pending.empty()) return 0;
-  ELP_HIP(c, hipStreamSynchronize(c->stream));
+  ELP_HIP(c, elp::stream_wait(c->stream));
   for (auto &p : c->prof_pending) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
@@ -155,12 +159,12 @@ int stage_recode_seq(elp_ctx *c, uint64_t from, uint64_t bytes) {
 // next read of the words - the following stage's, elp_sync's, a getter's - does.
 int fetch_err(elp_ctx *c, uint32_t *words) {
   ELP_HIP(c, hipMemcpyAsync(words, c->err_flag.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-  ELP_HIP(c, hipStreamSynchronize(c->stream));
+  ELP_HIP(c, elp::stream_wait(c->stream));
   c->radix_check_pending = false;
   if (words[0] & 256u) {
     const uint32_t w0 = words[0] & ~256u;
     ELP_HIP(c, hipMemcpyAsync(c->err_flag.p, &w0, 4, hipMemcpyHostToDevice, c->stream));
-    ELP_HIP(c, hipStreamSynchronize(c->stream));
+    ELP_HIP(c, elp::stream_wait(c->stream));
     c->sorted = false;
     c->marked = false;
     return set_error(c, ELP_ERR_HIP, "radix sort: tile look-back timed out");
@@ -204,7 +208,7 @@ int elp_create(int device_ordinal, elp_ctx **out) {
 void elp_destroy(elp_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->stream);
+  (void)elp::stream_wait(c->stream);
   for (auto &p : c->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   if (c->lut_pinned) (void)hipHostFree(c->lut_pinned);
   if (c->lut_ev) (void)hipEventDestroy(c->lut_ev);
@@ -229,7 +233,7 @@ const char *elp_last_error(const elp_ctx *c) { return c ? c->err.c_str() : "null
 int elp_sync(elp_ctx *c) {
   if (!c) return ELP_ERR_ARG;
   if (c->radix_check_pending) return radix_check(c);  // (synchronises)
-  ELP_HIP(c, hipStreamSynchronize(c->stream));
+  ELP_HIP(c, elp::stream_wait(c->stream));
   return 0;
 }
 
@@ -255,7 +259,7 @@ int elp_set_header(elp_ctx *c, const elp_header *h) {
     ELP_HIP(c, hipMemcpyAsync(c->rg_lib.p, h->rg_lib, h->n_rg * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
     ELP_HIP(c, hipMemcpyAsync(c->rg_cov.p, h->rg_cov, h->n_rg * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
   }
-  ELP_HIP(c, hipStreamSynchronize(c->stream));
+  ELP_HIP(c, elp::stream_wait(c->stream));
   c->h_ref_seq.resize(h->n_ref, nullptr);
   c->h_ref_seq_len.resize(h->n_ref, 0);
   c->h_sites.resize(h->n_ref, nullptr);
@@ -396,8 +400,8 @@ int elp_stage(elp_ctx *c, const elp_batch *b) {
     if (b->rgid[i] != ELP_NIL16 && b->rgid[i] >= c->n_rg) scan_rc = set_error(c, ELP_ERR_ARG, "record %llu: rgid %u not in header", (unsigned long long)i, b->rgid[i]);
     if (b->refid[i] >= c->n_ref) scan_rc = set_error(c, ELP_ERR_ARG, "record %llu: refid %d not in header", (unsigned long long)i, b->refid[i]);
   }
-  if (scan_rc) { (void)hipStreamSynchronize(st); return scan_rc; }
-  ELP_HIP(c, hipStreamSynchronize(st));  // host buffers may be reused on return
+  if (scan_rc) { (void)elp::stream_wait(st); return scan_rc; }
+  ELP_HIP(c, elp::stream_wait(st));  // host buffers may be reused on return
   c->n += n; c->qname_bytes += qb; c->cigar_ops += co; c->seq_bytes += sb; c->qual_bytes += lb;
   c->n_sr += n_sr;
   c->max_split = max_split;
@@ -438,7 +442,7 @@ static int d2h(elp_ctx *c, void *dst, const void *src, size_t bytes) {
   if (!bytes) return 0;
   ELP_HIP(c, hipSetDevice(c->device));
   ELP_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
-  ELP_HIP(c, hipStreamSynchronize(c->stream));
+  ELP_HIP(c, elp::stream_wait(c->stream));
   return 0;
 }
 

@@ -160,7 +160,7 @@ static int gather_piece(elp_ctx *err_ctx, elp_ctx *src, const uint32_t *idx, uin
     ELP_TRY(exclusive_scan_u32(src, len + (size_t)v * n, excl + (size_t)v * (n + 1), n, &G->total[v]));  // (a slice total beyond 2^32: see the check below)
   }
   ELP_HIP(src, hipMemcpyAsync(G->hc, ctr, sizeof G->hc, hipMemcpyDeviceToHost, ss));
-  ELP_HIP(src, hipStreamSynchronize(ss));
+  ELP_HIP(src, elp::stream_wait(ss));
   if (G->hc[XC_BAD]) return set_error(err_ctx, ELP_ERR_ARG, "elp_copy_records: %u indices are not records of the source context", G->hc[XC_BAD]);
   if (G->hc[XC_QNAME] > elp_ctx::MAX_QNAME) return set_error(err_ctx, ELP_ERR_UNSUPPORTED, "QNAME of %u bytes (limit %u)", G->hc[XC_QNAME], elp_ctx::MAX_QNAME);
   // (the scans are 32-bit: a call moves at most 4 GiB of any one column - ~25 M reads of 150 bases; callers move larger sets in pieces)
@@ -204,7 +204,7 @@ static int append_piece(elp_ctx *dst, elp_ctx *from, const Gathered &G, uint64_t
   uint32_t *dx;  // the exclusive scans, on the destination GPU
   ELP_TRY(ensure(dst, dst->stage_tmp, ((size_t)XV * (n + 1) + 1) / 2 + 8));
   dx = reinterpret_cast<uint32_t *>(dst->stage_tmp.p);
-  ELP_HIP(dst, hipStreamSynchronize(dst->stream));  // (the destination's columns may just have moved to larger allocations on its stream)
+  ELP_HIP(dst, elp::stream_wait(dst->stream));  // (the destination's columns may just have moved to larger allocations on its stream)
   ELP_HIP(from, hipSetDevice(from->device));
   const uint64_t at = dst->n;
   const XFixed F = fixed_view(G.fx, n);
@@ -220,7 +220,7 @@ static int append_piece(elp_ctx *dst, elp_ctx *from, const Gathered &G, uint64_t
   ELP_TRY(peer_copy(dst, dst->qual.p + dst->qual_bytes, from, pv[3], total[3]));
   if (raw) ELP_TRY(peer_copy(dst, dst->raw.p + dst->raw_bytes, from, pv[4], total[4]));
   ELP_TRY(peer_copy(dst, dx, from, G.excl, (size_t)XV * (n + 1) * 4));
-  ELP_HIP(from, hipStreamSynchronize(from->stream));
+  ELP_HIP(from, elp::stream_wait(from->stream));
   ELP_HIP(dst, hipSetDevice(dst->device));
   {
     struct { uint64_t *out; uint64_t base; int v; } oc[XV] = {{dst->qname_off.p + at, dst->qname_bytes, 0}, {dst->cigar_off.p + at, dst->cigar_ops, 1},
@@ -232,7 +232,7 @@ static int append_piece(elp_ctx *dst, elp_ctx *from, const Gathered &G, uint64_t
     }
     ELP_HIP(dst, hipGetLastError());
   }
-  ELP_HIP(dst, hipStreamSynchronize(dst->stream));
+  ELP_HIP(dst, elp::stream_wait(dst->stream));
   dst->n += n; dst->qname_bytes += total[0]; dst->cigar_ops += total[1]; dst->seq_bytes += total[2]; dst->qual_bytes += total[3];
   if (raw) { dst->raw_n = dst->n; dst->raw_bytes += total[4]; dst->max_raw_rec = std::max(dst->max_raw_rec, src_max_raw_rec); }
   dst->n_sr += hc[XC_NSR];
@@ -345,11 +345,11 @@ extern "C" int elp_exchange_records(elp_ctx *src, int send_peer, const uint32_t 
     elp_ctx *sc = send_peer >= 0 ? src : dst;
     ELP_HIP(g, hipSetDevice(g->device));
     ELP_HIP(g, hipMemcpyAsync(d_hdr, h_out, sizeof h_out, hipMemcpyHostToDevice, g->stream));
-    ELP_HIP(g, hipStreamSynchronize(sc->stream));  // (the gather ran on the source's stream)
-    ELP_HIP(g, hipStreamSynchronize(g->stream));
+    ELP_HIP(g, elp::stream_wait(sc->stream));  // (the gather ran on the source's stream)
+    ELP_HIP(g, elp::stream_wait(g->stream));
     ELP_TRY(group_sendrecv(g, out_now ? send_peer : -1, d_hdr, sizeof h_out, in_now ? recv_peer : -1, d_hdr + HDR, sizeof h_in));
     ELP_HIP(g, hipMemcpyAsync(h_in, d_hdr + HDR, sizeof h_in, hipMemcpyDeviceToHost, g->stream));
-    ELP_HIP(g, hipStreamSynchronize(g->stream));
+    ELP_HIP(g, elp::stream_wait(g->stream));
     // ---- the receiver's checks and buffers, then its verdict back to the sender
     Gathered R;
     uint64_t verdict_out = 0, verdict_in = 0;
@@ -373,7 +373,7 @@ extern "C" int elp_exchange_records(elp_ctx *src, int send_peer, const uint32_t 
           else if (hipSetDevice(dst->device) != hipSuccess) st = set_error(g, ELP_ERR_HIP, "hipSetDevice failed");
           else if ((st = scratch(dst, 1, gathered_fixed_bytes(R.n) + 256, &R.fx)) == 0 && (st = scratch(dst, 2, gathered_pool_bytes(R.total) + 64, &R.pool)) == 0 &&
                    (st = scratch(dst, 3, (size_t)XV * (R.n + 1) + 16, &R.excl)) == 0)
-            (void)hipStreamSynchronize(dst->stream);
+            (void)elp::stream_wait(dst->stream);
         }
       }
       if (st) { R.n = 0; in_on = false; note(st); verdict_out = (uint64_t)(uint32_t)(-st); }
@@ -381,11 +381,11 @@ extern "C" int elp_exchange_records(elp_ctx *src, int send_peer, const uint32_t 
     // the verdict travels against the records: to the rank I receive from, from the rank I send to
     ELP_HIP(g, hipSetDevice(g->device));
     ELP_HIP(g, hipMemcpyAsync(d_ack, &verdict_out, 8, hipMemcpyHostToDevice, g->stream));
-    ELP_HIP(g, hipStreamSynchronize(g->stream));
+    ELP_HIP(g, elp::stream_wait(g->stream));
     ELP_TRY(group_sendrecv(g, in_now ? recv_peer : -1, d_ack, 8, out_now ? send_peer : -1, d_ack + 1, 8));
     if (out_now) {
       ELP_HIP(g, hipMemcpyAsync(&verdict_in, d_ack + 1, 8, hipMemcpyDeviceToHost, g->stream));
-      ELP_HIP(g, hipStreamSynchronize(g->stream));
+      ELP_HIP(g, elp::stream_wait(g->stream));
       if (verdict_in) {
         note(set_error(g, -(int)(uint32_t)verdict_in, "elp_exchange_records: rank %d refused the records (status %d)", send_peer, -(int)(uint32_t)verdict_in));
       }
@@ -397,7 +397,7 @@ extern "C" int elp_exchange_records(elp_ctx *src, int send_peer, const uint32_t 
       ELP_TRY(group_sendrecv(g, sp, G.fx, n_j ? gathered_fixed_bytes(n_j) : 0, rp, R.fx, R.n ? gathered_fixed_bytes(R.n) : 0));
       ELP_TRY(group_sendrecv(g, sp, G.pool, n_j ? gathered_pool_bytes(G.total) : 0, rp, R.pool, R.n ? gathered_pool_bytes(R.total) : 0));
       ELP_TRY(group_sendrecv(g, sp, G.excl, n_j ? (size_t)XV * (n_j + 1) * 4 : 0, rp, R.excl, R.n ? (size_t)XV * (R.n + 1) * 4 : 0));
-      ELP_HIP(g, hipStreamSynchronize(g->stream));
+      ELP_HIP(g, elp::stream_wait(g->stream));
     }
     if (R.n) {
       std::lock_guard<std::mutex> lk(dst->stage_mu);

@@ -146,7 +146,7 @@ int merge_spread_slots(elp_ctx *groups, elp_ctx *spread, uint64_t **slots_out) {
   ks = kg + groups->n + 8;
   slots = ks + ns + 8;
   const uint64_t ng_all = groups->n - groups->n_sr;
-  ELP_HIP(groups, hipStreamSynchronize(spread->stream));
+  ELP_HIP(groups, elp::stream_wait(spread->stream));
   if (ng_all)
     ELP_LAUNCH(groups, "merge_keys", k_perm_keys, dim3(blocks_for(ng_all, 256)), dim3(256), 0, ng_all, (const uint32_t *)groups->perm.p,
                (const int32_t *)groups->refid.p, (const int32_t *)groups->pos.p, kg);
@@ -294,14 +294,14 @@ extern "C" int elp_clean_sam(elp_ctx *c, uint64_t *n_clipped_out) {
   ELP_LAUNCH(c, "clean_count", k_clean_count, dim3(blocks_for(n, 256)), dim3(256), 0, m, newcnt, res);
   uint32_t hr[2] = {0, 0};
   ELP_HIP(c, hipMemcpyAsync(hr, res, 8, hipMemcpyDeviceToHost, st));
-  ELP_HIP(c, hipStreamSynchronize(st));
+  ELP_HIP(c, elp::stream_wait(st));
   // MAPQ changed, CIGARs may: whatever was derived from them is stale
   c->adapted = c->sorted = c->marked = false;
   if (hr[1] & 1u) return set_error(c, ELP_ERR_DATA, "Unexpected non-0 relative clipping position in CleanSam. (reference: log.Panic, filters/utils.go:93)");
   if (hr[1] & 2u) return set_error(c, ELP_ERR_UNSUPPORTED, "elp_clean_sam: a clipped CIGAR needs an operation length outside the 28 bits of a BAM CIGAR field");
   ELP_LAUNCH(c, "clean_mapq", k_clean_mapq, dim3(blocks_for(n, 256)), dim3(256), 0, n, (const uint16_t *)c->flag.p, (const uint8_t *)c->has_sr.p, c->mapq.p);
   if (n_clipped_out) *n_clipped_out = hr[0];
-  if (!hr[0]) { ELP_HIP(c, hipStreamSynchronize(st)); return 0; }
+  if (!hr[0]) { ELP_HIP(c, elp::stream_wait(st)); return 0; }
   uint32_t total = 0;
   ELP_TRY(exclusive_scan_u32(c, newcnt, newoff, n, &total));
   uint32_t *cig_new;
@@ -313,7 +313,7 @@ extern "C" int elp_clean_sam(elp_ctx *c, uint64_t *n_clipped_out) {
   ELP_TRY(ensure(c, c->cigar, (size_t)total + 64));
   ELP_HIP(c, hipMemcpyAsync(c->cigar.p, cig_new, (size_t)total * 4, hipMemcpyDeviceToDevice, st));
   ELP_LAUNCH(c, "clean_offsets", k_copy_u64, dim3(blocks_for(n + 1, 256)), dim3(256), 0, n + 1, (const uint64_t *)off_new, c->cigar_off.p);
-  ELP_HIP(c, hipStreamSynchronize(st));
+  ELP_HIP(c, elp::stream_wait(st));
   c->cigar_ops = total;
   return 0;
 }
@@ -366,7 +366,7 @@ int elp_filter_records(elp_ctx *c, const elp_predicates *p, uint64_t *n_dropped_
     ELP_LAUNCH(c, "filter_records", k_filter_records, dim3(blocks_for(n, 256)), dim3(256), 0, m, *p, cnt);
     unsigned long long both[2] = {0, 0};
     ELP_HIP(c, hipMemcpyAsync(both, cnt, 16, hipMemcpyDeviceToHost, c->stream));
-    ELP_HIP(c, hipStreamSynchronize(c->stream));
+    ELP_HIP(c, elp::stream_wait(c->stream));
     dropped = both[0];
     dropped_tagged = both[1];
   }
@@ -422,7 +422,7 @@ int elp_split_classify(elp_ctx *c, const int32_t *group_of_ref, int32_t n_groups
   }
   std::vector<unsigned long long> h(nc);
   ELP_HIP(c, hipMemcpyAsync(h.data(), d_cnt, nc * 8, hipMemcpyDeviceToHost, c->stream));
-  ELP_HIP(c, hipStreamSynchronize(c->stream));
+  ELP_HIP(c, elp::stream_wait(c->stream));
   if (counts_out)
     for (size_t k = 0; k < nc; k++) counts_out[k] = h[k];
   return 0;
@@ -434,7 +434,7 @@ int elp_merge_spread(elp_ctx *groups, elp_ctx *spread, uint64_t *slot_of_spread_
   ELP_TRY(merge_spread_slots(groups, spread, &slots));
   const uint64_t ns = spread->n - spread->n_sr;
   if (ns) ELP_HIP(groups, hipMemcpyAsync(slot_of_spread_out, slots, ns * 8, hipMemcpyDeviceToHost, groups->stream));
-  ELP_HIP(groups, hipStreamSynchronize(groups->stream));
+  ELP_HIP(groups, elp::stream_wait(groups->stream));
   return 0;
 }
 

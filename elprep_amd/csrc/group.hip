@@ -96,11 +96,11 @@ int group_sendrecv(elp_ctx *c, int send_peer, const void *send_dev, size_t send_
     }
     uint8_t *hs = static_cast<uint8_t *>(c->h_pinned), *hr = hs + ((send_bytes + 63) & ~(size_t)63);
     if (send_bytes) ELP_HIP(c, hipMemcpyAsync(hs, send_dev, send_bytes, hipMemcpyDeviceToHost, c->stream));
-    ELP_HIP(c, hipStreamSynchronize(c->stream));
+    ELP_HIP(c, elp::stream_wait(c->stream));
     const int rc = c->p2p(c->p2p_user, send_bytes ? send_peer : -1, hs, send_bytes, recv_bytes ? recv_peer : -1, hr, recv_bytes);
     if (rc != 0) return set_error(c, ELP_ERR_HIP, "the group's transport failed (send-receive callback returned %d)", rc);
     if (recv_bytes) ELP_HIP(c, hipMemcpyAsync(recv_dev, hr, recv_bytes, hipMemcpyHostToDevice, c->stream));
-    ELP_HIP(c, hipStreamSynchronize(c->stream));  // (the pinned buffer is reused by the next message)
+    ELP_HIP(c, elp::stream_wait(c->stream));  // (the pinned buffer is reused by the next message)
     return 0;
   }
   if (!c->comm) return set_error(c, ELP_ERR_ARG, "no device group with point-to-point transport: call elp_group_init (RCCL) or elp_group_set_p2p first");
@@ -197,7 +197,7 @@ static int allreduce_device(elp_ctx *c, unsigned long long *buf, size_t n) {
       c->h_pinned_cap = bytes;
     }
     ELP_HIP(c, hipMemcpyAsync(c->h_pinned, buf, bytes, hipMemcpyDeviceToHost, c->stream));
-    ELP_HIP(c, hipStreamSynchronize(c->stream));
+    ELP_HIP(c, elp::stream_wait(c->stream));
     const int rc = c->xport(c->xport_user, static_cast<int64_t *>(c->h_pinned), n);
     if (rc != 0) return set_error(c, ELP_ERR_HIP, "the group's transport failed (allreduce callback returned %d)", rc);
     ELP_HIP(c, hipMemcpyAsync(buf, c->h_pinned, bytes, hipMemcpyHostToDevice, c->stream));
@@ -218,7 +218,7 @@ int elp_allreduce_i64(elp_ctx *c, int64_t *buf, size_t n) {
   ELP_HIP(c, hipMemcpyAsync(d, buf, n * 8, hipMemcpyHostToDevice, c->stream));
   ELP_TRY(allreduce_device(c, d, n));
   ELP_HIP(c, hipMemcpyAsync(buf, d, n * 8, hipMemcpyDeviceToHost, c->stream));
-  ELP_HIP(c, hipStreamSynchronize(c->stream));
+  ELP_HIP(c, elp::stream_wait(c->stream));
   return 0;
 }
 
@@ -228,7 +228,7 @@ int elp_bqsr_tables_add(elp_ctx *dst, elp_ctx *src) {
       dst->device != src->device)
     return set_error(dst, ELP_ERR_ARG, "elp_bqsr_tables_add: both contexts need device tables of the same shape on the same device (elp_bqsr_gather_device)");
   ELP_HIP(dst, hipSetDevice(dst->device));
-  ELP_HIP(dst, hipStreamSynchronize(src->stream));  // src's gather kernels are done before dst's stream reads its tables
+  ELP_HIP(dst, elp::stream_wait(src->stream));  // src's gather kernels are done before dst's stream reads its tables
   hipLaunchKernelGGL(k_add_i64, dim3(blocks_for(dst->tables_n, 256)), dim3(256), 0, dst->stream, dst->dev_tables.p, (const unsigned long long *)src->dev_tables.p,
                      dst->tables_n);
   ELP_HIP(dst, hipGetLastError());
@@ -247,7 +247,7 @@ int elp_bqsr_tables_allreduce(elp_ctx *c, int64_t *counters, size_t n_counters) 
   ELP_TRY(allreduce_device(c, c->dev_tables.p, c->tables_n + n_counters));
   ELP_TRY(tables_written(c));
   if (n_counters) ELP_HIP(c, hipMemcpyAsync(counters, tail, n_counters * 8, hipMemcpyDeviceToHost, c->stream));
-  ELP_HIP(c, hipStreamSynchronize(c->stream));
+  ELP_HIP(c, elp::stream_wait(c->stream));
   return 0;
 }
 

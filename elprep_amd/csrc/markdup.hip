@@ -963,7 +963,7 @@ static int markdup_impl(elp_ctx *c) {
   uint32_t adapt_word = 0;
   const bool adapt_read = c->adapt_pending;
   if (adapt_read) ELP_HIP(c, hipMemcpyAsync(&adapt_word, c->adapt_err.p, 4, hipMemcpyDeviceToHost, st));
-  ELP_HIP(c, hipStreamSynchronize(st));
+  ELP_HIP(c, elp::stream_wait(st));
   if (adapt_read) adapt_note(c, adapt_word);
   if (c->adapt_bad_qual) return adapt_quality_error(c);  // computePhredScore panics on such a record (filters/mark-duplicates.go:64-66)
   for (int k = 0; k < 64; k++) n_tab += n_tab64[k * 16];
@@ -1069,7 +1069,7 @@ static int markdup_impl(elp_ctx *c) {
     ELP_LAUNCH(c, "md_big_collect", k_big_collect, dim3(grid), dim3(256), 0, n, (const uint32_t *)rep_of, c->mate.p, bk, bv, cnt_dev);
     uint32_t cnt = 0;
     ELP_HIP(c, hipMemcpyAsync(&cnt, cnt_dev, 4, hipMemcpyDeviceToHost, st));
-    ELP_HIP(c, hipStreamSynchronize(st));
+    ELP_HIP(c, elp::stream_wait(st));
     ELP_HIP(c, hipMemsetAsync(cnt_dev, 0, 4, st));
     uint64_t *ks;
     uint32_t *vs;

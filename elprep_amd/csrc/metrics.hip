@@ -515,7 +515,7 @@ static int metrics_impl(elp_ctx *c, int dist, int64_t *counters_host, int64_t *h
                mailbox);
     uint32_t L = 0;
     ELP_HIP(c, hipMemcpyAsync(&L, mailbox, 4, hipMemcpyDeviceToHost, st));
-    ELP_HIP(c, hipStreamSynchronize(st));
+    ELP_HIP(c, elp::stream_wait(st));
     ELP_HIP(c, hipMemsetAsync(mailbox, 0, 4, st));
     if ((size_t)L > lcap) return set_error(c, ELP_ERR_HIP, "elp_dup_metrics: more losing pairs than pairs");
     uint32_t total = 0, G = 0;
@@ -562,14 +562,14 @@ static int metrics_impl(elp_ctx *c, int dist, int64_t *counters_host, int64_t *h
                  (const Member *)members, parent, (long long)dist, ctr, c->err_flag.p, hist, hist_len, lds_bins, linfo, lcount, mailbox);
       uint32_t n_large = 0;
       ELP_HIP(c, hipMemcpyAsync(&n_large, mailbox, 4, hipMemcpyDeviceToHost, st));
-      ELP_HIP(c, hipStreamSynchronize(st));
+      ELP_HIP(c, elp::stream_wait(st));
       ELP_HIP(c, hipMemsetAsync(mailbox, 0, 4, st));
       if (n_large) {
         ELP_LAUNCH(c, "mx_large_list", k_large_list, dim3(blocks_for(total, 256)), dim3(256), 0, total, (const uint32_t *)mset, (const uint32_t *)linfo,
                    (const Member *)members, lkeys, lvals, mailbox);
         uint32_t cl = 0;
         ELP_HIP(c, hipMemcpyAsync(&cl, mailbox, 4, hipMemcpyDeviceToHost, st));
-        ELP_HIP(c, hipStreamSynchronize(st));
+        ELP_HIP(c, elp::stream_wait(st));
         ELP_HIP(c, hipMemsetAsync(mailbox, 0, 4, st));
         if (cl) {
           uint64_t *ks;

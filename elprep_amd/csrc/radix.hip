@@ -123,7 +123,7 @@ int exclusive_scan_u32(elp_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n
   ELP_TRY(scan_levels(c, in, out, n, tot_dev));
   if (total_host) {
     ELP_HIP(c, hipMemcpyAsync(total_host, tot_dev, 4, hipMemcpyDeviceToHost, c->stream));
-    ELP_HIP(c, hipStreamSynchronize(c->stream));
+    ELP_HIP(c, elp::stream_wait(c->stream));
     ELP_HIP(c, hipMemsetAsync(tot_dev, 0, 4, c->stream));
   }
   return 0;
@@ -465,7 +465,7 @@ int radix_sort_pairs(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *keys_
   ELP_LAUNCH(c, "radix_hist_all", k_radix_hist_all<8>, dim3(hb), dim3(256), 0, (const uint64_t *)keys, n, ghist, (const uint32_t *)nullptr);
   unsigned long long hh[8 * 256];
   ELP_HIP(c, hipMemcpyAsync(hh, ghist, sizeof hh, hipMemcpyDeviceToHost, c->stream));
-  ELP_HIP(c, hipStreamSynchronize(c->stream));  // (a look-back timeout of any pass is reported by the callers, behind their last pass)
+  ELP_HIP(c, elp::stream_wait(c->stream));  // (a look-back timeout of any pass is reported by the callers, behind their last pass)
   ELP_TRY(radix_pass_setup(c, radix_tiles(c, n)));
   uint64_t *ksrc = keys, *kdst = keys_tmp;
   uint32_t *vsrc = vals, *vdst = vals_tmp;

@@ -347,7 +347,7 @@ int ensure_uniform_len(elp_ctx *c) {
              (const uint64_t *)c->seq_off.p, (const uint32_t *)c->l_seq.p, len, (len + 1) / 2, (uint64_t)elp_ctx::SEQ_FRONT, bad);
   uint32_t hb = 0;
   ELP_HIP(c, hipMemcpyAsync(&hb, bad, 4, hipMemcpyDeviceToHost, c->stream));
-  ELP_HIP(c, hipStreamSynchronize(c->stream));
+  ELP_HIP(c, elp::stream_wait(c->stream));
   ELP_HIP(c, hipMemsetAsync(bad, 0, 4, c->stream));
   if (!hb) c->uniform_len = (uint32_t)len;
   return 0;
@@ -365,7 +365,7 @@ static int adapt_resolve(elp_ctx *c) {
   if (!c->adapt_pending) return 0;
   uint32_t w = 0;
   ELP_HIP(c, hipMemcpyAsync(&w, c->adapt_err.p, 4, hipMemcpyDeviceToHost, c->stream));
-  ELP_HIP(c, hipStreamSynchronize(c->stream));
+  ELP_HIP(c, elp::stream_wait(c->stream));
   adapt_note(c, w);
   return 0;
 }
@@ -431,7 +431,7 @@ int ensure_qual_present(elp_ctx *c, bool exact) {
     ELP_LAUNCH(c, "qual_present_sample", k_qual_present_sample, dim3(grid), dim3(256), 0, (const uint8_t *)c->qual.p, c->qual_bytes, stride,
                (exact || stride == 1) ? FL_TILE : (uint64_t)4096, qm);
     ELP_HIP(c, hipMemcpyAsync(c->qual_present, qm, 16, hipMemcpyDeviceToHost, c->stream));
-    ELP_HIP(c, hipStreamSynchronize(c->stream));
+    ELP_HIP(c, elp::stream_wait(c->stream));
   }
   // elp_set_tuning "qual_hint_drop" = q removes one quality from the hint (tests: the kernels' no-slot paths)
   if (!exact && c->tune.qual_hint_drop >= 0) {
@@ -842,7 +842,7 @@ static int sort_impl(elp_ctx *c) {
     const uint32_t head = std::min<uint32_t>(TIE_HEAD, bounds_cap);
     ELP_HIP(c, hipMemcpyAsync(hb.data(), bounds, (4 + (size_t)head) * 4, hipMemcpyDeviceToHost, c->stream));
     ELP_HIP(c, hipMemcpyAsync(hb.data() + 4 + TIE_HEAD, bounds + 4 + bounds_cap, (size_t)head * 4, hipMemcpyDeviceToHost, c->stream));
-    ELP_HIP(c, hipStreamSynchronize(c->stream));
+    ELP_HIP(c, elp::stream_wait(c->stream));
   }
   const uint32_t nr = hb[0];
   if (nr != hb[1] || nr > bounds_cap) return set_error(c, ELP_ERR_HIP, "coordinate sort: %u starts and %u ends of long runs (internal)", hb[0], hb[1]);
@@ -855,7 +855,7 @@ static int sort_impl(elp_ctx *c) {
     } else {
       ELP_HIP(c, hipMemcpyAsync(starts.data(), bounds + 4, (size_t)nr * 4, hipMemcpyDeviceToHost, c->stream));
       ELP_HIP(c, hipMemcpyAsync(ends.data(), bounds + 4 + bounds_cap, (size_t)nr * 4, hipMemcpyDeviceToHost, c->stream));
-      ELP_HIP(c, hipStreamSynchronize(c->stream));
+      ELP_HIP(c, elp::stream_wait(c->stream));
     }
     std::sort(starts.begin(), starts.end());
     std::sort(ends.begin(), ends.end());  // runs are disjoint ranges: the r-th start belongs to the r-th end
@@ -902,7 +902,7 @@ static int sort_impl(elp_ctx *c) {
                c->tie_live.p, t);
     uint32_t live[elp_ctx::TIE_LIVE_WORDS];
     ELP_HIP(c, hipMemcpyAsync(live, c->tie_live.p, sizeof live, hipMemcpyDeviceToHost, c->stream));
-    ELP_HIP(c, hipStreamSynchronize(c->stream));
+    ELP_HIP(c, elp::stream_wait(c->stream));
     std::vector<uint16_t> lp;
     for (uint32_t j = 0; j < m_bytes; j++)
       if ((live[j >> 5] >> (j & 31)) & 1u) lp.push_back((uint16_t)j);
@@ -921,7 +921,7 @@ static int sort_impl(elp_ctx *c) {
       ELP_LAUNCH(c, "material_values", k_material_values, dim3(std::min(blocks_for(nu, 256), 1024u)), dim3(256), 0, nu, (const uint32_t *)u_read, pl, maxq, d_vals, t);
       std::vector<uint32_t> hv((size_t)pl.n * 8);
       ELP_HIP(c, hipMemcpyAsync(hv.data(), d_vals, hv.size() * 4, hipMemcpyDeviceToHost, c->stream));
-      ELP_HIP(c, hipStreamSynchronize(c->stream));
+      ELP_HIP(c, elp::stream_wait(c->stream));
       std::vector<uint8_t> lut((size_t)pl.n * 256, 0);
       std::vector<int> bits(pl.n);
       for (uint32_t k = 0; k < pl.n; k++) {
@@ -964,7 +964,7 @@ static int sort_impl(elp_ctx *c) {
                      (const uint32_t *)u_read, c->perm.p);
           uint32_t h_over = 0;
           ELP_HIP(c, hipMemcpyAsync(&h_over, over, 4, hipMemcpyDeviceToHost, c->stream));
-          ELP_HIP(c, hipStreamSynchronize(c->stream));
+          ELP_HIP(c, elp::stream_wait(c->stream));
           settled = h_over == 0;
           if (!settled) {  // a group of > LT_CAP equal keys: the rounds over all positions, from the members' first order
             ELP_HIP(c, hipMemsetAsync(over, 0, 4, c->stream));

@@ -254,7 +254,11 @@ class RowPool {
 
  private:
   RowPool() {
-    const unsigned hw = std::thread::hardware_concurrency();
+    // ELP_HOST_THREADS=<n>: threads per process for the table path (a host that runs one process per GPU on one node divides the
+    // cores among them: eight processes that each wake fifteen workers at the same moment - right behind the all-reduce - on sixteen
+    // cores make each other wait); default: the hardware's threads, at most 16
+    unsigned hw = std::thread::hardware_concurrency();
+    if (const char *e = std::getenv("ELP_HOST_THREADS")) { const long v = std::strtol(e, nullptr, 10); if (v >= 1) hw = (unsigned)std::min<long>(v, 64); }
     const unsigned nt = hw > 1 ? std::min(hw, 16u) - 1 : 0;  // the caller works too
     for (unsigned k = 0; k < nt; k++) workers_.emplace_back([this] { loop(); });
   }

@@ -22,6 +22,10 @@
  *    puts them behind every other record (elp_num_sorted() records are output), and the duplication metrics and BQSR ignore them.
  *  - Limits (ELP_ERR_UNSUPPORTED): 2^32-16 records per context, 4194303 bases per read, QNAMEs of at most 1000 bytes.
  *  - There is NO CPU fallback: if no gfx950 device is usable, elp_create fails.
+ *  - Environment (read once per process): ELP_SYNC_SPIN=0 makes the library wait for its stream with hipStreamSynchronize instead of
+ *    polling it (the default: the path waits ~15 times per pass for a few words that size the next launches, and an interrupt wake-up
+ *    costs 100-200 us on a busy host; a host that runs many contexts per core may prefer to give the core up).  The host library
+ *    (elprep_host.h) takes ELP_HOST_THREADS=<n>: worker threads of its table path per process (default: the hardware's, at most 16).
  */
 #ifndef ELPREP_HIP_H
 #define ELPREP_HIP_H
