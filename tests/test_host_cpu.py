@@ -214,3 +214,25 @@ def test_tables_and_lut_in_rows_form_equal_the_dense_forms():
         assert np.array_equal(full, lut), (levels, sqq)
     with pytest.raises(RuntimeError):
         rows.build_lut_rows(quals[:-2])
+
+
+def test_host_threads_setting_changes_nothing_but_the_pool():
+    """ELP_HOST_THREADS (a host that runs one process per GPU divides its cores among them): FinalizeBQSRTables and the LUT are the same
+    bytes with one worker as with the default pool - run in fresh processes, the pool is sized when the library is first used"""
+    import subprocess
+    import sys
+    code = ("import sys, hashlib, numpy as np; sys.path.insert(0, %r); from elprep_amd.engine import BqsrTables; rng = np.random.default_rng(5);"
+            "n_cov, mc = 6, 40; ncyc = 2 * mc + 1;"
+            "ct = np.zeros((n_cov, 94, ncyc, 2), np.int64); ct[:, 20:40, :, 0] = rng.integers(0, 50000, (n_cov, 20, ncyc)); ct[..., 1] = rng.binomial(ct[..., 0], 0.01);"
+            "xt = np.zeros((n_cov, 94, 16, 2), np.int64); xt[:, 20:40, :, 0] = rng.integers(0, 900000, (n_cov, 20, 16)); xt[..., 1] = rng.binomial(xt[..., 0], 0.01);"
+            "qt = np.zeros((n_cov, 94, 2), np.int64); qt[..., 0] = ct[..., 0].sum(2); qt[..., 1] = ct[..., 1].sum(2);"
+            "tb = BqsrTables(qt, ct, xt, mc).finalize(); lut, present = tb.build_lut(0); q, c, x = tb.empirical();"
+            "print(hashlib.sha256(lut.tobytes() + present.tobytes() + q.tobytes() + c.tobytes() + x.tobytes()).hexdigest())") % ROOT
+    outs = []
+    for threads in (None, "1", "3"):
+        env = dict(os.environ)
+        env.pop("ELP_HOST_THREADS", None)
+        if threads:
+            env["ELP_HOST_THREADS"] = threads
+        outs.append(subprocess.check_output([sys.executable, "-c", code], env=env, text=True).strip())
+    assert len(outs[0]) == 64 and outs[0] == outs[1] == outs[2]
