@@ -301,6 +301,9 @@ int ensure(elp_ctx *c, DVec<T> &v, size_t n, bool keep = false, size_t keep_elem
   if (v.p) {
     (void)elp::stream_wait(c->stream);
     debug_guard_release(v.p);
+    // (ELP_DEBUG_POISON: the buffer that is given up is overwritten first - a pointer into it that somebody still holds reads 0xDD
+    // instead of the old contents a freed block usually keeps)
+    if (debug_poison() >= 0) { (void)hipMemsetAsync(v.p, 0xDD, v.cap * sizeof(T), c->stream); (void)elp::stream_wait(c->stream); }
     (void)hipFree(v.p);
   }
   v.p = np;

@@ -6,7 +6,8 @@
  *
  * Two process-wide switches for fault hunts, read from the environment when the library first allocates / launches:
  *   ELP_DEBUG_POISON=<byte>  every new device buffer of a context is filled with that byte before its first use: a kernel that reads
- *                            memory nothing wrote shows as a parity failure instead of depending on what the allocator hands out
+ *                            memory nothing wrote shows as a parity failure instead of depending on what the allocator hands out;
+ *                            a buffer that is regrown is overwritten with 0xDD before it is freed (a stale pointer into it reads that)
  *   ELP_DEBUG_TRACE=1        every kernel launch is named on stderr and waited for (which kernel faulted; ~100 x slower)
  *   ELP_DEBUG_GUARD=1        4 KB of pattern behind every device buffer of a context, checked when the buffer is released or regrown and by
  *                            elp_debug_check_guards: a kernel that writes past the end of its buffer aborts the process (buffer size on stderr) */
