@@ -2,7 +2,10 @@
 quality hint, adapted values, tables, LUT, sort) - every other parity test and fuzz tool makes a fresh context per read set.  A session
 keeps one Engine and runs the whole path on read sets of very different sizes and shapes (ragged / one length, few / many qualities,
 1-30 000 records), elp_reset between them, kernel choices redrawn per read set; every output against the oracle.
-usage: python tools/fuzz_reuse.py [first_seed] [n_sessions] [read sets per session]   (exit code 1 on a mismatch)"""
+usage: python tools/fuzz_reuse.py [first_seed] [n_sessions] [read sets per session] [sfm]   (exit code 1 on a mismatch)
+"sfm": every read set is the group-split context of an `sfm` rank - the reads of two contig groups of the synthetic genome in aligner
+order, split ids in the split column, the spread reads' copies tagged sr among them (mark duplicates in aligner order WITH records on
+the table path: the listed inserts of round 5) - 100 to 60 000 records, the oracle run split by split."""
 import os
 import sys
 
@@ -17,6 +20,79 @@ first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 sessions = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 bad = 0
+if len(sys.argv) > 4 and sys.argv[4] == "sfm":
+    from elprep_amd import sfm
+    from elprep_amd.batch import Batch
+    from tools import synth
+    for s in range(first, first + sessions):
+        srng = np.random.default_rng(s)
+        base = synth.config("tiny", s)
+        base.n_lanes = int(srng.choice([1, 4, 9]))
+        h = base.header()
+        gof, G = sfm.contig_groups(base.ref_len, 80000)
+        ranges = sfm.group_ranges(gof, G)
+        refs = [synth.reference(base, r) for r in range(h.n_ref)]
+        sites = [orc.flatten(orc.sort_by_start(synth.known_sites_raw(base, r))) for r in range(h.n_ref)]
+        e = Engine(h, 0)
+        for r in range(h.n_ref):
+            e.set_reference(r, refs[r])
+            e.set_known_sites(r, sites[r])
+        for k in range(rounds):
+            seed = 1000 * s + k
+            rng = np.random.default_rng(seed)
+            parts = []
+            for g in range(1, G + 1):
+                c = synth.config("tiny", s)
+                c.n_lanes = base.n_lanes
+                c.seed = base.seed + 7919 * g + 13 * k + 1
+                c.ref_seed = base.seed
+                c.home_lo, c.home_hi = ranges[g - 1]
+                c.p_frag = float(rng.choice([0.0, 0.02, 0.3]))
+                c.p_dup = float(rng.choice([0.05, 0.1, 0.5]))
+                c.p_mate_unmapped = float(rng.choice([0.0, 0.01, 0.1]))
+                c.qual_mode = base.qual_mode
+                parts.append(synth.generate(c, 0, int(rng.choice([25, 400, 3000, 15000]))))
+            b = Batch.concat(parts)
+            g_of, sp = sfm.split_records(b, gof)
+            p = sfm.with_sr(b, sp, g_of)
+            tuning = {"radix_tile": int(rng.integers(0, 4)), "mate_path": int(rng.choice([0, 0, 0, 1, 2])), "pair_table_slots": int(rng.choice([0, 0, 16, 1024])),
+                      "count_kernel": int(rng.choice([0, 0, 1, 3])), "apply_kernel": int(rng.choice([0, 0, 1, 3]))}
+            for key, v in tuning.items():
+                e.set_tuning(key, v)
+            e.reset()
+            cuts = np.linspace(0, p.n, int(rng.integers(1, 4)) + 1).astype(int)
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                if hi > lo:
+                    e.stage(p.take(np.arange(lo, hi)))
+            flags = e.mark_duplicates(True)
+            e.sort_coordinate(fetch=False)
+            ctr = e.dup_metrics(100)
+            qt, ct, xt = e.recalibrate(500)
+            lut, present = BqsrTables(qt, ct, xt, 500).finalize().build_lut(0)
+            qual = e.apply_bqsr(lut, present, 500)
+            oflags = np.zeros(p.n, np.uint16)
+            oq = oc = ox = octr = None
+            for sid in np.unique(p.split):  # the reference runs one `filter` process per split file
+                sel = np.nonzero(p.split == sid)[0]
+                sub = p.take(sel)
+                perm = orc.sort_coordinate(sub, orc.mark_duplicates(sub, h))
+                fl, c7, _ = orc.dup_metrics(sub, h, perm, 100)
+                q, c2, x = orc.bqsr_gather(sub, h, orc.BqsrRef(refs, sites), fl, 500)
+                oflags[sel] = fl
+                oq = q if oq is None else oq + q
+                oc = c2 if oc is None else oc + c2
+                ox = x if ox is None else ox + x
+                octr = c7 if octr is None else octr + c7
+            oqual = orc.BqsrFinal(oq, oc, ox, 500).apply(p, h, 0)
+            ok = (np.array_equal(flags, oflags), np.array_equal(ctr, octr), np.array_equal(qt, oq) and np.array_equal(ct, oc) and np.array_equal(xt, ox),
+                  np.array_equal(qual, oqual))
+            print(f"session {s} ({base.n_lanes} read groups) sfm read set {k}: {p.n} records, {int(p.has_sr.sum())} tagged copies, {tuning}: "
+                  f"flags {ok[0]} metrics {ok[1]} tables {ok[2]} qual {ok[3]}", flush=True)
+            if not all(ok):
+                bad += 1
+        e.close()
+    print("mismatching read sets:", bad)
+    sys.exit(1 if bad else 0)
 for s in range(first, first + sessions):
     srng = np.random.default_rng(s)
     n_cov = int(srng.choice([2, 3, 4, 17, 33]))
