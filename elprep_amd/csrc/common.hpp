@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <sched.h>
+
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -103,7 +105,10 @@ struct elp_ctx {
   bool radix_check_pending = false;  // radix passes were queued whose look-back timeout bit nobody has read yet (fetch_err)
   bool adapt_bad_qual = false;  // adapt_score met a quality > 93 in a duplicate-marking candidate
   bool adapt_pending = false;   // ... or may have: its error word (adapt_err) has not been read yet
-  elp::DVec<uint32_t> adapt_err;
+  elp::DVec<uint32_t> adapt_err;  // [0] the score kernel's error word, [2 .. 5] the quality values k_score_uniform's sampled groups saw
+  bool adapt_sampled = false;      // the score kernel of this adapt stage sampled the quality values ...
+  bool adapt_qmask_valid = false;  // ... and they have been read (adapt_note)
+  unsigned long long adapt_qmask[2] = {0, 0};
   bool have_qual_present = false;
   unsigned long long qual_present[2] = {0, 0};  // bit q set if quality value q was seen in a sample of the QUAL column (sizing hint for the BQSR tables)
   elp::DVec<int32_t> upos, score;
@@ -196,6 +201,10 @@ struct elp_ctx {
   void *bounce[2] = {nullptr, nullptr};  // pinned double buffer for pageable sources
   hipEvent_t bounce_ev[2] = {nullptr, nullptr};
 
+  // a page of page-locked host memory + an event: a few words come back while the stream runs on (mailbox(), ctx.hip)
+  uint32_t *mail = nullptr;
+  hipEvent_t mail_ev = nullptr;
+
   // snapshot of the mutable columns
   elp::DVec<uint16_t> snap_flag;
   elp::DVec<uint8_t> snap_qual;
@@ -219,6 +228,8 @@ struct elp_ctx {
     int tie_rounds = 0;        // 1: the sort's long runs by LSD rounds over every live position (no key-then-compare shortcut)
     int exchange_piece = 0;    // > 0: records per piece of elp_exchange_records (tests: several pieces on small inputs)
     int bgzf_stored = 0;       // 1: elp_emit_sorted_bgzf writes stored DEFLATE blocks (round 4's form) instead of compressing
+    int md_fused = 0;          // 1: mark duplicates by the separate passes of rounds 2-5 (adapt_fixed, md_keys, md_mate_scan, md_mate_pairs) instead of
+                               // the fused front pass of round 6 (k_md_front); tests run both
   } tune;
 
   // generic scratch pool (grown on demand, reused between calls)
@@ -266,10 +277,31 @@ struct ProfScope {  // launches inside the scope are booked as <prefix><name>
 // times, 0.9 against 2.3 ms per step without a kernel running).  ELP_SYNC_SPIN=1 (default) polls the stream instead: the waiting
 // thread keeps its core.  0: hipStreamSynchronize.
 bool sync_spin();  // ctx.hip
+// (the pause instruction is x86's; after ~200 us of polling the waiting thread offers its core to whoever is runnable between
+// two queries - several ranks per node, the sfm side threads - instead of holding it for a whole kernel)
+inline void spin_relax(unsigned &spins) {
+  if (++spins < 4096u) {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield");
+#endif
+  } else {
+    sched_yield();
+  }
+}
 inline hipError_t stream_wait(hipStream_t st) {
   if (!sync_spin()) return hipStreamSynchronize(st);
   hipError_t e;
-  while ((e = hipStreamQuery(st)) == hipErrorNotReady) __builtin_ia32_pause();
+  unsigned spins = 0;
+  while ((e = hipStreamQuery(st)) == hipErrorNotReady) spin_relax(spins);
+  return e;
+}
+inline hipError_t event_wait(hipEvent_t ev) {
+  if (!sync_spin()) return hipEventSynchronize(ev);
+  hipError_t e;
+  unsigned spins = 0;
+  while ((e = hipEventQuery(ev)) == hipErrorNotReady) spin_relax(spins);
   return e;
 }
 
@@ -399,7 +431,14 @@ int radix_sort_pairs_low(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *k
                          const uint32_t *n_dev = nullptr /* the length is *n_dev on the device and `n` its upper bound */);
 int exclusive_scan_u32(elp_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n, uint32_t *total_host /* may be null */);
 int ensure_adapted(elp_ctx *c, bool check_quals = true);
-void adapt_note(elp_ctx *c, uint32_t word);  // sort.hip: the score kernel's error word was read (by whoever synchronised anyway)
+// the two halves of ensure_adapted for a caller that computes the fixed-field part (unclipped positions, sort keys) itself - mark
+// duplicates' front pass, markdup.hip: adapt_begin = buffers, key width (*pos_bits), the error word's fill; adapt_scores = the score kernel
+// (every record's score and low-quality-tail bounds).  The caller sets c->adapted once its own pass is queued.
+int adapt_begin(elp_ctx *c, int *pos_bits);
+int adapt_scores(elp_ctx *c);
+int mailbox(elp_ctx *c);  // ctx.hip: c->mail (1024 words, page-locked) and c->mail_ev exist
+constexpr int ADAPT_WORDS = 6;
+void adapt_note(elp_ctx *c, const uint32_t *words /* ADAPT_WORDS of adapt_err */);  // sort.hip: the score kernel's words were read (by whoever synchronised anyway)
 int adapt_quality_error(elp_ctx *c);
 int ensure_uniform_len(elp_ctx *c);  // sort.hip: c->uniform_len
 int ensure_qual_present(elp_ctx *c, bool exact = false);  // exact: scan the whole column instead of a sample

@@ -171,6 +171,11 @@ int fetch_err(elp_ctx *c, uint32_t *words) {
   }
   return 0;
 }
+int mailbox(elp_ctx *c) {
+  if (!c->mail) ELP_HIP(c, hipHostMalloc((void **)&c->mail, 1024 * sizeof(uint32_t), hipHostMallocDefault));
+  if (!c->mail_ev) ELP_HIP(c, hipEventCreateWithFlags(&c->mail_ev, hipEventDisableTiming));
+  return 0;
+}
 int radix_check(elp_ctx *c) {
   if (!c->radix_check_pending) return 0;
   uint32_t e[4];
@@ -217,6 +222,8 @@ void elp_destroy(elp_ctx *c) {
   for (auto p : c->h_sites) if (p) (void)hipFree(p);
   for (auto p : c->h_site_idx) if (p) (void)hipFree(p);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+  if (c->mail) (void)hipHostFree(c->mail);
+  if (c->mail_ev) (void)hipEventDestroy(c->mail_ev);
   for (int k = 0; k < 2; k++) {
     if (c->bounce[k]) (void)hipHostFree(c->bounce[k]);
     if (c->bounce_ev[k]) (void)hipEventDestroy(c->bounce_ev[k]);
@@ -515,6 +522,7 @@ int elp_set_tuning(elp_ctx *c, const char *key, int64_t value) {
   else if (k == "sort_pairs") c->tune.sort_pairs = v;
   else if (k == "exchange_piece") c->tune.exchange_piece = v;
   else if (k == "bgzf_stored") c->tune.bgzf_stored = v;
+  else if (k == "md_fused") c->tune.md_fused = v;
   else return set_error(c, ELP_ERR_ARG, "elp_set_tuning: unknown key '%s'", key);
   return 0;
 }

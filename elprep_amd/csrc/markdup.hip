@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void k_frag_flag(MdCols m, const uint32_t *__r
   const uint32_t rep = frep[i];
   const unsigned long long b = fbest[rep];
   const bool dup = (b >> 63) || (unsigned long long)(uint32_t)m.score[i] < b || fwinner[rep] != (uint32_t)i;
-  if (dup) flag_out[i] = (uint16_t)(m.flag_in[i] | F_DUPLICATE);
+  if (dup) flag_out[i] = (uint16_t)(flag_out[i] | F_DUPLICATE);  // (a fragment's flag_in is its staged flag)
 }
 
 // ---------------- pair keys (used by the mate pass as well: it writes the entries of the neighbour pairs)
@@ -889,6 +889,246 @@ __global__ __launch_bounds__(PB_THREADS) void k_pair_bucket(MdCols m, const uint
   }
 }
 
+// ---------------- the front pass (round 6; VERDICT r5 next #1a / #1b)
+// Rounds 2-5 streamed the fixed fields four times before the pair phase: k_adapt_fixed (unclipped positions, sort keys), k_md_keys (packed
+// fragment keys, list of true fragments), k_mate_scan (neighbour test on the names) and k_mate_pairs (fragment look-ups, neighbour pairs,
+// pair entries) - 180 bytes per read where the data is ~100.  k_md_front makes ONE pass of them:
+//   k_frag_list   the true fragments (~0.5 % of paired-end reads) are listed from the FLAG column alone, their keys (unclipped position
+//                 from the CIGAR) and group payloads written; the host reads the list's length while the score kernel runs;
+//   (k_frag_insert, k_frag_bits: the fragments' table is FINAL before any pair looks its key up)
+//   k_md_front    a record per thread (+ three border threads per 256 records, as k_mate_scan): every load of the record is issued up front;
+//                 unclipped position, sort key (when the adapt stage has not run yet), packed key, the neighbour test, code / name hash /
+//                 Bloom announcement of the records that are not exactly-two-neighbours, the fragment look-up of every true pair, and -
+//                 optimistically - the neighbour pairs' mates and entries at their fixed slots, as if nobody announced a key.  In
+//                 aligner order nobody does (the count comes back with the call's one read-back) and the mate phase is over; otherwise the
+//                 mates are cleared and k_mate_pairs redoes them with the filter, the table and the lists, as before.
+// the value the NEXT lane of the wave holds (lane 63: unspecified): one DPP move - a ds_bpermute takes six times the issue time
+// (profiles/r3m_isa_rate_probe.txt).  Every lane of the wave must be active.
+__device__ __forceinline__ uint32_t next_lane(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130 /* wave_shl:1 */, 0xf, 0xf, false); }
+__device__ __forceinline__ uint64_t next_lane64(uint64_t x) { return (uint64_t)next_lane((uint32_t)x) | ((uint64_t)next_lane((uint32_t)(x >> 32)) << 32); }
+
+struct FrontCols {
+  uint64_t n;
+  const int32_t *refid, *pos;
+  const uint16_t *flag;   // as staged
+  const uint8_t *state;   // the has_sr column: 0 live, 1 sr-tagged copy, 2 rejected by the fused predicates (never a candidate: k_md_flag_in)
+  const uint16_t *rgid, *rg_lib, *split;
+  const uint64_t *cigar_off;
+  const uint32_t *cigar;
+  const uint64_t *qname_off;
+  const uint8_t *qname;
+  uint32_t n_ref;
+  int pos_bits;
+};
+// computeUnclippedPosition (:79-110) as k_adapt_fixed has it; o0 .. o3 = the record's first four CIGAR operations (loaded with everything
+// else), further ones come from memory
+__device__ __forceinline__ int32_t unclipped_pos(uint16_t f, int32_t p, uint64_t c0, uint64_t c1, const uint32_t *__restrict__ cigar, uint32_t o0, uint32_t o1,
+                                                 uint32_t o2, uint32_t o3) {
+  if ((f & (F_UNMAPPED | F_SECONDARY | F_SUPPLEMENTARY)) != 0) return 0;  // mark-duplicates.go:427,436
+  int32_t up = p;
+  const uint64_t nop = c1 - c0;
+  auto at = [&](uint64_t k) __attribute__((always_inline)) -> uint32_t { return k == 0 ? o0 : (k == 1 ? o1 : (k == 2 ? o2 : (k == 3 ? o3 : cigar[c0 + k]))); };
+  if (nop) {
+    if (f & F_REVERSED) {  // :90-100
+      int32_t clipped = 1;
+      up--;
+      for (uint64_t k = nop; k-- > 0;) {
+        const uint32_t c = at(k), op = c & 0xF;
+        const int32_t isclip = (op == OP_S || op == OP_H) ? 1 : 0;
+        const int32_t isref = op_consumes_ref(op) ? 1 : 0;
+        clipped *= isclip;
+        up += (isref | clipped) * (int32_t)(c >> 4);
+      }
+    } else {  // :101-108
+      for (uint64_t k = 0; k < nop; k++) {
+        const uint32_t c = at(k), op = c & 0xF;
+        if (!(op == OP_S || op == OP_H)) break;
+        up -= (int32_t)(c >> 4);
+      }
+    }
+  }
+  return up;
+}
+__device__ __forceinline__ uint16_t flag_in_of(uint16_t f, uint8_t state) { return state == 2 ? (uint16_t)(f | F_SECONDARY) : f; }
+
+// (a thread takes eight consecutive records per round: one 16-byte load of their flags, one 8-byte load of their states.  A few persistent
+// workgroups, each appending with ONE global atomic per flush of its LDS list: with a workgroup per 4096 records, 12 K of them queued at
+// the one counter for ~12 ns each - 0.15 of the kernel's 0.18 ms)
+constexpr int FLI_CAP = 4096, FLI_CHUNK = 2048;
+__global__ __launch_bounds__(256) void k_frag_list(FrontCols m, uint4 *__restrict__ fkey, uint32_t *__restrict__ flist, uint32_t *nf,
+                                                   unsigned long long *__restrict__ fbest, uint32_t *__restrict__ fwinner) {
+  __shared__ uint32_t lq[FLI_CAP];
+  __shared__ uint32_t lcount, gbase;
+  if (threadIdx.x == 0) lcount = 0;
+  __syncthreads();
+  const uint64_t nchunks = (m.n + FLI_CHUNK - 1) / FLI_CHUNK;
+  for (uint64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {  // (uniform per workgroup: barriers inside)
+    const uint64_t i0 = (ch * 256 + threadIdx.x) * 8;
+    uint4 fv = make_uint4(0, 0, 0, 0);
+    uint2 sv = make_uint2(0, 0);
+    if (i0 < m.n) {  // (a load may run past record n - 1 inside its aligned 16 / 8 bytes; the tests below do not)
+      fv = *reinterpret_cast<const uint4 *>(m.flag + i0);
+      sv = *reinterpret_cast<const uint2 *>(m.state + i0);
+    }
+    const uint32_t fw[4] = {fv.x, fv.y, fv.z, fv.w};
+    const uint64_t st8 = (uint64_t)sv.x | ((uint64_t)sv.y << 32);
+    uint32_t fm = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const uint16_t f = flag_in_of((uint16_t)(fw[k >> 1] >> (16 * (k & 1))), (uint8_t)(st8 >> (8 * k)));
+      if (i0 + (uint64_t)k < m.n && is_candidate(f) && !is_true_pair(f)) fm |= 1u << k;
+    }
+    if (fm) {
+      uint32_t at = atomicAdd(&lcount, (uint32_t)__popc(fm));
+      for (; fm; fm &= fm - 1u) lq[at++] = (uint32_t)i0 + (uint32_t)(__ffs((int)fm) - 1);
+    }
+    __syncthreads();
+    const uint32_t cnt = lcount;
+    if (cnt + FLI_CHUNK <= (uint32_t)FLI_CAP && ch + gridDim.x < nchunks) continue;  // room for another chunk, and there is one
+    // flush: the listed fragments' keys (unclipped position from the CIGAR) and group payloads, all lanes busy
+    if (threadIdx.x == 0) gbase = cnt ? atomicAdd(nf, cnt) : 0u;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < cnt; k += 256) {
+      const uint32_t i = lq[k];
+      const uint16_t f = m.flag[i], rg = m.rgid[i];  // (a fragment's state is 0 or 1: the flag is the staged one)
+      const uint64_t c0 = m.cigar_off[i], c1 = m.cigar_off[i + 1];
+      const uint64_t nop = c1 - c0;
+      const uint32_t o0 = nop > 0 ? m.cigar[c0] : 0u, o1 = nop > 1 ? m.cigar[c0 + 1] : 0u, o2 = nop > 2 ? m.cigar[c0 + 2] : 0u, o3 = nop > 3 ? m.cigar[c0 + 3] : 0u;
+      const uint16_t lib = rg == ELP_NIL16 ? (uint16_t)ELP_NIL16 : m.rg_lib[rg];
+      const int32_t up = unclipped_pos(f, m.pos[i], c0, c1, m.cigar, o0, o1, o2, o3);
+      fkey[i] = make_uint4((uint32_t)m.refid[i], (uint32_t)up, ((uint32_t)lib << 1) | ((f & F_REVERSED) ? 1u : 0u), (uint32_t)m.split[i]);
+      fbest[i] = 0;  // any fragment can become its group's representative
+      fwinner[i] = EMPTY;
+      flist[gbase + k] = i;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) lcount = 0;
+    __syncthreads();
+  }
+}
+
+// Lanes and records: a workgroup of five waves covers MF_RECS = 312 records.  Wave w, lane l holds record base - 2 + 63 w + l: lane 63 holds
+// the record lane 0 of the next wave holds as well, so that every neighbour test (lanes 0 .. 62 against the next lane) finds its right-hand
+// record one DPP move away, whatever the wave - no border threads, no second fetch of a record's cache lines.  u = 63 w + l in [0, 315)
+// numbers the workgroup's records; the tests' results and what a follower needs of its leader (key, score) go through LDS; records
+// u = 2 .. 313 are the workgroup's own.
+constexpr int MF_THREADS = 320, MF_RECS = 312;
+template <bool ADAPT>
+__global__ __launch_bounds__(MF_THREADS) void k_md_front(FrontCols m, const int32_t *__restrict__ score, int32_t *__restrict__ upos_out, uint64_t *__restrict__ key_out,
+                                                         uint4 *fkey, uint8_t *__restrict__ code, uint32_t *__restrict__ hash32, uint32_t *bloom, uint32_t bloom_mask,
+                                                         uint32_t *n_table, const uint32_t *__restrict__ ftable, const uint32_t *__restrict__ fbits,
+                                                         uint64_t fmask /* 0: no fragments */, unsigned long long *fbest, uint32_t *__restrict__ mate,
+                                                         uint32_t *__restrict__ pair_win, uint64_t *__restrict__ pk, uint32_t *__restrict__ pv, uint32_t *np,
+                                                         uint32_t nfixed, int optimistic) {
+  const uint64_t base = (uint64_t)blockIdx.x * MF_RECS;
+  const uint32_t t = threadIdx.x, lane = t & 63u, u = 63u * (t >> 6) + lane;
+  const int64_t a_s = (int64_t)base - 2 + (int64_t)u;
+  const bool own_rec = a_s >= 0 && (uint64_t)a_s < m.n;             // the record exists
+  const bool valid = a_s >= 0 && (uint64_t)a_s + 1 < m.n;           // ... and so does its right neighbour
+  const uint64_t a = own_rec ? (uint64_t)a_s : 0;
+  // round 1: the fixed columns and the offsets
+  const uint16_t fa_st = m.flag[a], ra = m.rgid[a], sa = m.split[a];
+  const uint8_t sta = m.state[a];
+  const int32_t r = m.refid[a], p = m.pos[a], sc = score[a];
+  const uint64_t oa = m.qname_off[a], oa1 = m.qname_off[a + 1];
+  const uint64_t c0 = m.cigar_off[a], c1 = m.cigar_off[a + 1];
+  const uint32_t la = (uint32_t)(oa1 - oa);
+  const uint64_t nop = c1 - c0;
+  // round 2: library id, the first 32 bytes of the name, the first four CIGAR operations
+  const uint16_t lia = ra == ELP_NIL16 ? (uint16_t)ELP_NIL16 : m.rg_lib[ra];
+  const uint8_t *pa = m.qname + oa;
+  const uint64_t a0 = load8(pa), a1 = load8(pa + 8), a2 = load8(pa + 16), a3 = load8(pa + 24);
+  const uint32_t o0 = nop > 0 ? m.cigar[c0] : 0u, o1 = nop > 1 ? m.cigar[c0 + 1] : 0u, o2 = nop > 2 ? m.cigar[c0 + 2] : 0u, o3 = nop > 3 ? m.cigar[c0 + 3] : 0u;
+  const uint16_t fa = flag_in_of(fa_st, sta);
+  const int32_t up = unclipped_pos(fa_st, p, c0, c1, m.cigar, o0, o1, o2, o3);
+  const uint4 mine = make_uint4((uint32_t)r, (uint32_t)up, ((uint32_t)lia << 1) | ((fa & F_REVERSED) ? 1u : 0u), (uint32_t)sa);
+  // first 32 bytes of the name, zero behind its end (the hash takes them as they are)
+  const uint64_t w0 = la > 0 ? low_bytes(a0, la) : 0ull, w1 = la > 8 ? low_bytes(a1, la - 8) : 0ull, w2 = la > 16 ? low_bytes(a2, la - 16) : 0ull,
+                 w3 = la > 24 ? low_bytes(a3, la - 24) : 0ull;
+  // the right neighbour's side of the test: candidate? library, split, name length, name words (masked like ours: equal lengths are tested first)
+  const uint32_t mcand = own_rec && is_mate_candidate(fa) ? 1u : 0u;
+  const uint32_t nA = next_lane(mcand | ((uint32_t)lia << 1)), nL = next_lane(la);
+  const uint32_t nS = next_lane((uint32_t)sa);
+  const uint64_t b0 = next_lane64(w0), b1 = next_lane64(w1), b2 = next_lane64(w2), b3 = next_lane64(w3);
+  const uint64_t n_oa = next_lane64(oa);
+  bool join = valid && lane < 63u && mcand && (nA & 1u) && (uint16_t)(nA >> 1) == lia && (uint16_t)nS == sa && nL == la;
+  if (join) {
+    join = ((w0 ^ b0) | (w1 ^ b1) | (w2 ^ b2) | (w3 ^ b3)) == 0;
+    const uint8_t *pb = m.qname + n_oa;
+    for (uint32_t k = 32; join && k < la; k += 8) join = low_bytes(load8(pa + k), la - k) == low_bytes(load8(pb + k), la - k);
+  }
+  __shared__ uint8_t s_join[320];
+  __shared__ uint4 s_fk[316];
+  __shared__ int32_t s_sc[316];
+  if (lane < 63u) {
+    s_join[u] = join;
+    s_fk[u] = mine;
+    s_sc[u] = sc;
+  }
+  __syncthreads();
+  const bool mine_rec = own_rec && lane < 63u && u >= 2u && u < 2u + (uint32_t)MF_RECS;  // this thread's record is one of the workgroup's own
+  const uint64_t i = a;
+  uint8_t cd = MC_NONE;
+  if (mine_rec) {
+    if (ADAPT) {
+      // CoordinateLess primary key (k_adapt_fixed, sort.hip): REFID with unmapped behind the last contig and the records that are not sorted
+      // at all behind those, POS, strand
+      const uint64_t ru = sta ? (uint64_t)m.n_ref + 1 : (r < 0 ? (uint64_t)m.n_ref : (uint64_t)(uint32_t)r);
+      key_out[i] = (ru << (m.pos_bits + 1)) | ((uint64_t)(uint32_t)p << 1) | ((fa_st & F_REVERSED) ? 1ull : 0ull);
+      upos_out[i] = up;
+    }
+    if (!(is_candidate(fa) && !is_true_pair(fa))) fkey[i] = mine;  // (k_frag_list wrote the true fragments' keys: k_frag_insert read them)
+    pair_win[i] = EMPTY;
+  }
+  const uint8_t *j = s_join + u;  // j[0] = joins(i)
+  if (mine_rec && mcand) {
+    const bool nx = j[0], pv_ = j[-1];
+    cd = MC_TABLE;
+    if (nx && !pv_ && !j[1]) cd = MC_LEAD;
+    else if (pv_ && !nx && !j[-2]) cd = MC_FOLLOW;
+    if (cd != MC_FOLLOW) {
+      uint64_t h = 0x9e3779b97f4a7c15ull ^ la;  // qname_hash(m, i) from the words at hand
+      const uint64_t K = 0xff51afd7ed558ccdull;
+      if (la > 0) h = (h ^ w0) * K + (h >> 29);
+      if (la > 8) h = (h ^ w1) * K + (h >> 29);
+      if (la > 16) h = (h ^ w2) * K + (h >> 29);
+      if (la > 24) h = (h ^ w3) * K + (h >> 29);
+      for (uint32_t k = 32; k < la; k += 8) h = (h ^ low_bytes(load8(pa + k), la - k)) * K + (h >> 29);
+      h = mix64(h ^ ((uint64_t)lia << 48) ^ ((uint64_t)sa << 24));
+      const uint32_t hi = (uint32_t)(h >> 32);
+      hash32[i] = hi;
+      if (cd != MC_LEAD) atomicOr(&bloom[(hi >> 5) & bloom_mask], 1u << (hi & 31u));
+    }
+  }
+  if (mine_rec) code[i] = cd;
+  const unsigned long long tb = __ballot(cd == MC_TABLE);
+  if (lane == 0 && tb) atomicAdd(&n_table[((blockIdx.x * 5u + (t >> 6)) & 63u) * 16u], (uint32_t)__popcll(tb));  // (64 counters a cache line apart, none in aligner order)
+  // every true pair looks its fragment key up (classifyFragment :210-251: a fragment group that holds a read of a true pair loses as a whole)
+  if (cd != MC_NONE && fmask) {
+    uint64_t s = frag_hash(mine) & fmask;
+    for (;; s = (s + 1) & fmask) {
+      if (!((fbits[s >> 5] >> (s & 31)) & 1u)) break;
+      const uint32_t c2 = ftable[s];
+      if (key_eq(fkey[c2], mine)) {
+        atomicMax(&fbest[c2], 1ull << 63);
+        break;
+      }
+    }
+  }
+  // the neighbour pairs, as if nobody announced a key (the caller knows whether anybody did when the count of MC_TABLE records is back)
+  if (mine_rec) mate[i] = !optimistic ? EMPTY : (cd == MC_LEAD ? (uint32_t)i + 1 : (cd == MC_FOLLOW ? (uint32_t)i - 1 : EMPTY));
+  if (optimistic && mine_rec) {
+    if (cd == MC_FOLLOW) {  // the later arrival owns the pair (:336-340): its entry goes to slot i >> 1 (two neighbouring followers cannot both own one)
+      pk[i >> 1] = ((uint64_t)(uint32_t)(sc + s_sc[u - 1]) << 32) | (uint32_t)pair_hash(pair_key(mine, s_fk[u - 1]));
+      pv[i >> 1] = (uint32_t)i;
+    } else if (!(i & 1ull) && !(j[0] && !j[1] && !j[-1])) {  // an even record that owns no pair and whose odd neighbour is no follower either: a hole
+      pk[i >> 1] = 0xFFFFFFFF00000000ull | (uint32_t)mix64(i);
+      pv[i >> 1] = EMPTY;
+    }
+    if (i == 0) *np = nfixed;
+  }
+}
+
 static uint64_t table_size_for(uint64_t n) {
   uint64_t t = 1024;
   while (t < 2 * n + 16) t <<= 1;
@@ -897,19 +1137,28 @@ static uint64_t table_size_for(uint64_t n) {
 
 static int markdup_impl(elp_ctx *c) {
   const uint64_t n = c->n;
-  ELP_TRY(ensure_adapted(c, false));  // (its quality-error word is read with this call's first read-back, below)
   ELP_TRY(ensure(c, c->mate, n + 1));
   ELP_TRY(ensure(c, c->pair_win, n + 1));
   if (n == 0) { ELP_TRY(ensure_adapted(c, true)); c->marked = true; return 0; }
+  const bool fused = c->tune.md_fused != 1;
+  // the front pass also does the adapt stage's fixed-field part when that has not run yet (what a host that marks duplicates first - the
+  // reference's order, cmd/filter.go:142-211 - gets)
+  const bool fuse_adapt = fused && !c->adapted;
+  int pos_bits = 1;
+  if (fuse_adapt) ELP_TRY(adapt_begin(c, &pos_bits));
+  else ELP_TRY(ensure_adapted(c, false));  // (its quality-error word is read with this call's first read-back, below)
   const unsigned grid = blocks_for(n, 256);
   hipStream_t st = c->stream;
-  // flag_in snapshot: tournaments must see the flags as staged (isTruePair/IsReversed never change, but keep it explicit)
-  uint16_t *flag_in;
-  ELP_TRY(scratch(c, 4, n + 8, &flag_in));
-  if (c->n_filtered)
-    ELP_LAUNCH(c, "md_flag_in", k_md_flag_in, dim3(grid), dim3(256), 0, n, (const uint16_t *)c->flag.p, (const uint8_t *)c->has_sr.p, flag_in);
-  else
-    ELP_HIP(c, hipMemcpyAsync(flag_in, c->flag.p, n * sizeof(uint16_t), hipMemcpyDeviceToDevice, st));
+  // flag_in: tournaments see the flags as staged, with the records the fused predicates rejected made non-candidates.  The front pass
+  // derives it from the state column as it goes; the separate passes read a patched copy
+  uint16_t *flag_in = c->flag.p;
+  if (!fused) {
+    ELP_TRY(scratch(c, 4, n + 8, &flag_in));
+    if (c->n_filtered)
+      ELP_LAUNCH(c, "md_flag_in", k_md_flag_in, dim3(grid), dim3(256), 0, n, (const uint16_t *)c->flag.p, (const uint8_t *)c->has_sr.p, flag_in);
+    else
+      ELP_HIP(c, hipMemcpyAsync(flag_in, c->flag.p, n * sizeof(uint16_t), hipMemcpyDeviceToDevice, st));
+  }
   MdCols m{n, c->refid.p, flag_in, c->rgid.p, c->rg_lib.p, c->split.p, c->upos.p, c->score.p, c->qname_off.p, c->qname.p};
   const uint64_t T = table_size_for(n);
   uint32_t *table;
@@ -928,8 +1177,19 @@ static int markdup_impl(elp_ctx *c) {
   ELP_TRY(scratch(c, 1, 2 * n + 16, &rep));
   uint32_t *flist = rep + n + 8;
   ELP_HIP(c, hipMemsetAsync(c->md_ctr.p, 0, (16 + 64 * 16) * sizeof(uint32_t), st));  // every counter of this call in one fill
-  ELP_LAUNCH(c, "md_keys", k_md_keys, dim3(blocks_for(n, 256 * MK_TILES)), dim3(256), 0, m, fkey, flist, nf_dev);
-  uint32_t nf = 0;  // read together with the mate phase's table estimate below
+  uint32_t nf = 0;
+  FrontCols fc{n, c->refid.p, c->pos.p, c->flag.p, c->has_sr.p, c->rgid.p, c->rg_lib.p, c->split.p, c->cigar_off.p, c->cigar.p, c->qname_off.p, c->qname.p,
+               (uint32_t)c->n_ref, pos_bits};
+  if (fused) {
+    // the list's length comes back through the mailbox while the stream runs on (the score kernel, when the adapt stage is this call's)
+    ELP_TRY(mailbox(c));
+    ELP_LAUNCH(c, "md_frag_list", k_frag_list, dim3(std::min<unsigned>(blocks_for(n, FLI_CHUNK), (unsigned)c->n_cu * 8)), dim3(256), 0, fc, fkey, flist, nf_dev, best, winner);
+    ELP_HIP(c, hipMemcpyAsync(c->mail, nf_dev, 4, hipMemcpyDeviceToHost, st));
+    ELP_HIP(c, hipEventRecord(c->mail_ev, st));
+    if (fuse_adapt) ELP_TRY(adapt_scores(c));
+  } else {
+    ELP_LAUNCH(c, "md_keys", k_md_keys, dim3(blocks_for(n, 256 * MK_TILES)), dim3(256), 0, m, fkey, flist, nf_dev);  // (nf: read with the mate phase's table estimate below)
+  }
 
   // the pair phase's list, partitioned by hash bits: at most n / 2 pairs
   int bbits = 0;
@@ -938,7 +1198,7 @@ static int markdup_impl(elp_ctx *c) {
   const size_t nb = (size_t)1 << bbits;
   uint32_t *np_dev = c->md_ctr.p + 1;
 
-  // ---- mates (+ the pairs' fragment look-ups and the entries of the neighbour pairs, k_mate_pairs)
+  // ---- mates (+ the pairs' fragment look-ups and the entries of the neighbour pairs)
   uint64_t bw = 1024;  // Bloom filter words: ~2 bits per record, at most 4 MiB (what one XCD's L2 holds)
   while (bw < n / 16 && bw < (1u << 20)) bw <<= 1;
   uint32_t *bloom, *hash32;
@@ -952,51 +1212,98 @@ static int markdup_impl(elp_ctx *c) {
   uint32_t *rep_of = c->pair_win.p;  // free until the pair phase fills it
   uint32_t *n_table_dev = c->md_ctr.p + 16;  // 64 counters, 16 words apart
   ELP_HIP(c, hipMemsetAsync(bloom, 0, bw * sizeof(uint32_t), st));
-  ELP_HIP(c, hipMemsetAsync(c->mate.p, 0xFF, n * sizeof(uint32_t), st));
-  ELP_HIP(c, hipMemsetAsync(rep_of, 0xFF, n * sizeof(uint32_t), st));
-  ELP_LAUNCH(c, "md_mate_scan", k_mate_scan, dim3(grid), dim3(MS_THREADS), 0, m, code, hash32, bloom, (uint32_t)(bw - 1), n_table_dev);
+  uint32_t n_tab = 0, n_tab64[64 * 16];
+  uint32_t adapt_word[ADAPT_WORDS] = {0, 0, 0, 0, 0, 0};
+  uint64_t npmax = 0, nfixed = 0, Tf = 0;
+  uint64_t *pk = nullptr;
+  uint32_t *pv = nullptr, *ftable = nullptr, *fbits = nullptr;
+  unsigned fgrid = 0;
+  bool fixed = false, frag_done = false, fast = false;
+  if (fused) {
+    // the fragments' table first: it is final before any pair looks its key up
+    ELP_HIP(c, elp::event_wait(c->mail_ev));
+    nf = c->mail[0];
+    fgrid = blocks_for(nf, 256);
+    Tf = nf ? std::min<uint64_t>(T, table_size_for(4ull * nf)) : 0;  // sparse: most look-ups of the pairs end at an empty slot
+    npmax = n + 2;  // (whatever the mates' order turns out to be)
+    ELP_TRY(scratch(c, 7, 2 * npmax + (2 * npmax + Tf + Tf / 32 + 64) / 2 + 8, &pk));
+    pv = reinterpret_cast<uint32_t *>(pk + 2 * npmax); ftable = pv + 2 * npmax; fbits = ftable + Tf;
+    if (nf) {
+      ELP_HIP(c, hipMemsetAsync(ftable, 0xFF, Tf * sizeof(uint32_t), st));
+      ELP_LAUNCH(c, "md_frag_insert", k_frag_insert, dim3(fgrid), dim3(256), 0, m, (const uint4 *)fkey, (const uint32_t *)flist, nf, ftable, Tf - 1, rep, best);
+      ELP_LAUNCH(c, "md_frag_bits", k_frag_bits, dim3(blocks_for(Tf / 32, 256)), dim3(256), 0, (const uint32_t *)ftable, Tf / 32, fbits);
+    }
+    const int optimistic = c->tune.mate_path == 0;
+    const uint32_t nfx = (uint32_t)((n + 1) / 2);
+    if (fuse_adapt)
+      ELP_LAUNCH(c, "md_front", k_md_front<true>, dim3(blocks_for(n, MF_RECS)), dim3(MF_THREADS), 0, fc, (const int32_t *)c->score.p, c->upos.p, c->key.p, fkey, code, hash32, bloom,
+                 (uint32_t)(bw - 1), n_table_dev, (const uint32_t *)ftable, (const uint32_t *)fbits, nf ? Tf - 1 : (uint64_t)0, best, c->mate.p, c->pair_win.p, pk, pv,
+                 np_dev, nfx, optimistic);
+    else
+      ELP_LAUNCH(c, "md_front", k_md_front<false>, dim3(blocks_for(n, MF_RECS)), dim3(MF_THREADS), 0, fc, (const int32_t *)c->score.p, c->upos.p, c->key.p, fkey, code, hash32, bloom,
+                 (uint32_t)(bw - 1), n_table_dev, (const uint32_t *)ftable, (const uint32_t *)fbits, nf ? Tf - 1 : (uint64_t)0, best, c->mate.p, c->pair_win.p, pk, pv,
+                 np_dev, nfx, optimistic);
+    if (fuse_adapt) c->adapted = true;
+    // tournament among the fragments of pair-free groups (the pair bits are complete): queued in front of the read-back
+    if (nf) {
+      ELP_LAUNCH(c, "md_frag_tie", k_frag_tie, dim3(fgrid), dim3(256), 0, m, (const uint32_t *)flist, nf, (const uint32_t *)rep,
+                 (const unsigned long long *)best, winner);
+      ELP_LAUNCH(c, "md_frag_flag", k_frag_flag, dim3(fgrid), dim3(256), 0, m, (const uint32_t *)flist, nf, (const uint32_t *)rep,
+                 (const unsigned long long *)best, (const uint32_t *)winner, c->flag.p);
+    }
+    frag_done = true;
+  } else {
+    ELP_HIP(c, hipMemsetAsync(c->mate.p, 0xFF, n * sizeof(uint32_t), st));
+    ELP_HIP(c, hipMemsetAsync(rep_of, 0xFF, n * sizeof(uint32_t), st));
+    ELP_LAUNCH(c, "md_mate_scan", k_mate_scan, dim3(grid), dim3(MS_THREADS), 0, m, code, hash32, bloom, (uint32_t)(bw - 1), n_table_dev);
+    ELP_HIP(c, hipMemcpyAsync(&nf, nf_dev, 4, hipMemcpyDeviceToHost, st));
+  }
   // the table only has to hold the records that are not exactly-two-neighbours (few in aligner order) plus the neighbour pairs a
   // Bloom-filter hit sends there (at most as many again, in practice a fraction): size it by their number, not by n
-  uint32_t n_tab = 0, n_tab64[64 * 16];
   ELP_HIP(c, hipMemcpyAsync(n_tab64, n_table_dev, sizeof n_tab64, hipMemcpyDeviceToHost, st));
-  ELP_HIP(c, hipMemcpyAsync(&nf, nf_dev, 4, hipMemcpyDeviceToHost, st));
-  uint32_t adapt_word = 0;
   const bool adapt_read = c->adapt_pending;
-  if (adapt_read) ELP_HIP(c, hipMemcpyAsync(&adapt_word, c->adapt_err.p, 4, hipMemcpyDeviceToHost, st));
+  if (adapt_read) ELP_HIP(c, hipMemcpyAsync(adapt_word, c->adapt_err.p, sizeof adapt_word, hipMemcpyDeviceToHost, st));
   ELP_HIP(c, elp::stream_wait(st));
   if (adapt_read) adapt_note(c, adapt_word);
   if (c->adapt_bad_qual) return adapt_quality_error(c);  // computePhredScore panics on such a record (filters/mark-duplicates.go:64-66)
   for (int k = 0; k < 64; k++) n_tab += n_tab64[k * 16];
-  if (n_tab) ELP_LAUNCH(c, "md_bloom_coarse", k_bloom_coarse, dim3(blocks_for(bw / 16, 256)), dim3(256), 0, (const uint32_t *)bloom, (uint32_t)(bw / 16), coarse);
 
   // aligner order (few candidates need a table): the neighbour pairs' entries go to fixed slots, the table's pairs behind them.  Else
   // (coordinate-ordered, shuffled input) every candidate is matched by the partitioned pass (k_mate_list, k_mate_bucket)
-  const bool fixed = (uint64_t)n_tab < n / 8 && c->tune.mate_path == 0;
+  fixed = (uint64_t)n_tab < n / 8 && c->tune.mate_path == 0;
   // 1 neighbours + table in HBM for the rest, 2 partitioned, 0 table in HBM for all.  Measured (16 M reads staged in random order,
   // tools/prof/shuffled_md.py): partitioned 1.59 (buckets) + 0.32 (two scatter passes) + 0.15 (list, bounds) ms, table in HBM 1.84 ms - both
   // are bound by the ~10 random loads of the key comparison every pair needs once (two names, their offsets, read group -> library, split),
   // not by the insert; the table in HBM therefore stays the default for input whose mates are not neighbours
   int mate_mode = fixed ? 1 : (c->tune.mate_path == 1 ? 2 : 0);
-  const uint64_t nfixed = fixed ? (n + 1) / 2 : 0, npmax = std::max<uint64_t>(nfixed + n / 2 + 1, fixed ? 0 : n + 1);
-  // pair list (two buffers each for the radix passes; the partitioned mate pass uses them first) | fragment table and its occupancy bits
-  const uint64_t Tf = nf ? std::min<uint64_t>(T, table_size_for(4ull * nf)) : 0;  // sparse: most look-ups of the pairs end at an empty slot
-  uint64_t *pk;
-  ELP_TRY(scratch(c, 7, 2 * npmax + (2 * npmax + Tf + Tf / 32 + 64) / 2 + 8, &pk));
-  uint32_t *pv = reinterpret_cast<uint32_t *>(pk + 2 * npmax), *ftable = pv + 2 * npmax, *fbits = ftable + Tf;
-
-  // fragments: group the true fragments (their table is final before the pairs look their keys up)
-  const unsigned fgrid = blocks_for(nf, 256);
-  if (nf) {
-    ELP_HIP(c, hipMemsetAsync(ftable, 0xFF, Tf * sizeof(uint32_t), st));
-    ELP_LAUNCH(c, "md_frag_init", k_frag_init, dim3(fgrid), dim3(256), 0, (const uint32_t *)flist, nf, best, winner);
-    ELP_LAUNCH(c, "md_frag_insert", k_frag_insert, dim3(fgrid), dim3(256), 0, m, (const uint4 *)fkey, (const uint32_t *)flist, nf, ftable, Tf - 1, rep, best);
-    ELP_LAUNCH(c, "md_frag_bits", k_frag_bits, dim3(blocks_for(Tf / 32, 256)), dim3(256), 0, (const uint32_t *)ftable, Tf / 32, fbits);
+  nfixed = fixed ? (n + 1) / 2 : 0;
+  if (!fused) {
+    npmax = std::max<uint64_t>(nfixed + n / 2 + 1, fixed ? 0 : n + 1);
+    // pair list (two buffers each for the radix passes; the partitioned mate pass uses them first) | fragment table and its occupancy bits
+    Tf = nf ? std::min<uint64_t>(T, table_size_for(4ull * nf)) : 0;  // sparse: most look-ups of the pairs end at an empty slot
+    ELP_TRY(scratch(c, 7, 2 * npmax + (2 * npmax + Tf + Tf / 32 + 64) / 2 + 8, &pk));
+    pv = reinterpret_cast<uint32_t *>(pk + 2 * npmax); ftable = pv + 2 * npmax; fbits = ftable + Tf;
+    // fragments: group the true fragments (their table is final before the pairs look their keys up)
+    fgrid = blocks_for(nf, 256);
+    if (nf) {
+      ELP_HIP(c, hipMemsetAsync(ftable, 0xFF, Tf * sizeof(uint32_t), st));
+      ELP_LAUNCH(c, "md_frag_init", k_frag_init, dim3(fgrid), dim3(256), 0, (const uint32_t *)flist, nf, best, winner);
+      ELP_LAUNCH(c, "md_frag_insert", k_frag_insert, dim3(fgrid), dim3(256), 0, m, (const uint4 *)fkey, (const uint32_t *)flist, nf, ftable, Tf - 1, rep, best);
+      ELP_LAUNCH(c, "md_frag_bits", k_frag_bits, dim3(blocks_for(Tf / 32, 256)), dim3(256), 0, (const uint32_t *)ftable, Tf / 32, fbits);
+    }
+  } else {
+    // nobody announced a key: the front pass's neighbour pairs stand (mates, entries at their fixed slots, pair_win all EMPTY)
+    fast = fixed && n_tab == 0;
+    if (!fast) ELP_HIP(c, hipMemsetAsync(c->mate.p, 0xFF, n * sizeof(uint32_t), st));  // (rep_of = pair_win is all EMPTY from the front pass)
   }
+  if (n_tab && !fast) ELP_LAUNCH(c, "md_bloom_coarse", k_bloom_coarse, dim3(blocks_for(bw / 16, 256)), dim3(256), 0, (const uint32_t *)bloom, (uint32_t)(bw / 16), coarse);
+  // (the front pass made the pairs' fragment look-ups: k_mate_pairs skips them)
+  const uint64_t fmask_pairs = (nf && !fused) ? Tf - 1 : (uint64_t)0;
 
   uint64_t Tm = mate_mode == 0 ? T : std::min<uint64_t>(T, table_size_for(std::min<uint64_t>(n, 4ull * n_tab + 1024)));
-  uint32_t e[4];
-  bool frag_done = false, listed = false;  // listed: the last pass of k_mate_pairs listed its table inserts (tab_list)
-  for (;;) {
+  uint32_t e[4] = {0, 0, 0, 0};
+  bool listed = false;  // listed: the last pass of k_mate_pairs listed its table inserts (tab_list)
+  while (!fast) {
     if (mate_mode != 2) ELP_HIP(c, hipMemsetAsync(table, 0xFF, Tm * sizeof(uint32_t), st));
     ELP_HIP(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(np_dev), (int)(uint32_t)nfixed, 1, st));
     // aligner order with a few records on the table path: their inserts are listed and made by a dense pass (the counters of k_mate_scan,
@@ -1006,7 +1313,7 @@ static int markdup_impl(elp_ctx *c) {
     if (defer_tab) ELP_HIP(c, hipMemsetAsync(n_table_dev, 0, 64 * 16 * sizeof(uint32_t), st));
     ELP_LAUNCH(c, "md_mate_pairs", k_mate_pairs, dim3(blocks_for(n, 256 * MP_R)), dim3(256), 0, m, (const uint4 *)fkey, code,
                (const uint32_t *)hash32, (const uint32_t *)bloom, (uint32_t)(bw - 1), (const uint32_t *)(n_tab ? coarse : nullptr), table, Tm - 1, c->mate.p, rep_of, c->err_flag.p,
-               (const uint32_t *)ftable, (const uint32_t *)fbits, nf ? Tf - 1 : (uint64_t)0, best, mate_mode == 1 ? 1 : (mate_mode == 2 ? 2 : 0), pk, pv,
+               (const uint32_t *)ftable, (const uint32_t *)fbits, fmask_pairs, best, mate_mode == 1 ? 1 : (mate_mode == 2 ? 2 : 0), pk, pv,
                defer_tab ? tab_list : (uint32_t *)nullptr, n_table_dev, tab_cap);
     if (defer_tab)  // (the lists hold the records k_mate_scan counted plus the neighbour pairs a filter hit sent along: in practice a fraction as many again)
       ELP_LAUNCH(c, "md_mate_table", k_mate_table, dim3(blocks_for(std::min<uint64_t>(n, 2ull * n_tab + 4096), 256)), dim3(256), 0, m, (const uint32_t *)tab_list,

@@ -164,7 +164,9 @@ constexpr int SU_WAVES = 8, SU_MAX_LEN = 250;  // a read touches at most 64 word
 __device__ __forceinline__ uint32_t su_gt2(uint32_t x) { return (((x | 0x80808080u) - 0x03030303u) | x) & 0x80808080u; }  // bit 7 of every byte > 2, any byte value
 template <int R>
 __global__ __launch_bounds__(64 * SU_WAVES) void k_score_uniform(uint64_t n, uint32_t L, const uint8_t *__restrict__ qual, const uint16_t *__restrict__ flag,
-                                                                 int32_t *__restrict__ score, uint64_t *__restrict__ qbounds, uint32_t *err) {
+                                                                 int32_t *__restrict__ score, uint64_t *__restrict__ qbounds, uint32_t *err,
+                                                                 uint32_t qstride /* every qstride-th group of 64 reads notes the quality values it holds */,
+                                                                 unsigned long long *qmask) {
   extern __shared__ __attribute__((aligned(16))) uint32_t su_lds[];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t tile_bytes = 64u * L, tile_words = tile_bytes / 4u + 4u;
@@ -173,6 +175,7 @@ __global__ __launch_bounds__(64 * SU_WAVES) void k_score_uniform(uint64_t n, uin
   const uint32_t nw = (skip + L + 3u) >> 2, tail = (skip + L) & 3u;
   const uint32_t m_first = 0xFFFFFFFFu << (8u * skip), m_last = tail ? 0xFFFFFFFFu >> (32u - 8u * tail) : 0xFFFFFFFFu;
   uint32_t bad = 0;
+  uint32_t qm[3] = {0, 0, 0};  // bits 0 .. 95: quality values seen by the sampled groups (the BQSR gather's sizing hint, ensure_qual_present)
   const uint64_t ngroups = (n + 63) / 64;
   for (uint64_t g = (uint64_t)blockIdx.x * SU_WAVES + wave; g < ngroups; g += (uint64_t)gridDim.x * SU_WAVES) {
     const uint64_t r0 = g * 64;
@@ -226,9 +229,33 @@ __global__ __launch_bounds__(64 * SU_WAVES) void k_score_uniform(uint64_t n, uin
       score[r] = cand ? (int32_t)sum : 0;
       qbounds[r] = (uint64_t)hi | ((uint64_t)lo << 32);
       if (cand) bad |= bd & 0x80808080u;
+      if (g % qstride == 0) {  // (wave-uniform)
+        for (uint32_t k = 0; k < nw; k++) {
+          const uint32_t vm = (k == 0 ? m_first : 0xFFFFFFFFu) & (k + 1 == nw ? m_last : 0xFFFFFFFFu), xw = rw[k];
+#pragma unroll
+          for (int b = 0; b < 4; b++) {
+            const uint32_t q = (xw >> (8 * b)) & 0xFFu, bit = ((vm >> (8 * b)) & 1u) << (q & 31u), ws = q >> 5;
+            qm[0] |= ws == 0 ? bit : 0u;
+            qm[1] |= ws == 1 ? bit : 0u;
+            qm[2] |= ws == 2 ? bit : 0u;
+          }
+        }
+      }
     }
   }
   if (__any(bad != 0) && lane == 0) atomicOr(&err[0], 1u);
+  if (__any((qm[0] | qm[1] | qm[2]) != 0)) {
+    for (int d = 32; d >= 1; d >>= 1) {
+      qm[0] |= __shfl_xor(qm[0], d, 64);
+      qm[1] |= __shfl_xor(qm[1], d, 64);
+      qm[2] |= __shfl_xor(qm[2], d, 64);
+    }
+    if (lane == 0) {
+      const unsigned long long lo = (unsigned long long)qm[0] | ((unsigned long long)qm[1] << 32);
+      if (lo) atomicOr(&qmask[0], lo);
+      if (qm[2]) atomicOr(&qmask[1], (unsigned long long)qm[2]);
+    }
+  }
 }
 // LDS bank conflicts of the per-lane walk: lanes are L bytes apart; if that is a whole number of words with a large power of two in it,
 // many lanes sit on one bank - those lengths stay with k_score_flat
@@ -245,8 +272,12 @@ static int score_uniform_launch(elp_ctx *c) {
   const uint64_t ngroups = (c->n + 63) / 64;
   const unsigned grid = (unsigned)std::min<uint64_t>((ngroups + SU_WAVES - 1) / SU_WAVES, (uint64_t)c->n_cu * per_cu);
   ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_score_uniform<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+  // the sample of the quality values: everything up to ~500 K reads (the hint is then exact, as k_qual_present_sample's is), one group in
+  // up to 128 of longer columns
+  const uint32_t qstride = (uint32_t)std::min<uint64_t>(128, std::max<uint64_t>(1, ngroups / 8192));
   ELP_LAUNCH(c, "adapt_score", k_score_uniform<R>, dim3(grid), dim3(64 * SU_WAVES), dyn, c->n, L, (const uint8_t *)c->qual.p, (const uint16_t *)c->flag.p,
-             c->score.p, c->qbounds.p, c->adapt_err.p);
+             c->score.p, c->qbounds.p, c->adapt_err.p, qstride, reinterpret_cast<unsigned long long *>(c->adapt_err.p + 2));
+  c->adapt_sampled = true;
   return 0;
 }
 static int score_uniform(elp_ctx *c) {
@@ -363,53 +394,77 @@ int adapt_quality_error(elp_ctx *c) {
 // own first read-back (adapt_note): the adapt stage has no synchronisation of its own
 static int adapt_resolve(elp_ctx *c) {
   if (!c->adapt_pending) return 0;
-  uint32_t w = 0;
-  ELP_HIP(c, hipMemcpyAsync(&w, c->adapt_err.p, 4, hipMemcpyDeviceToHost, c->stream));
+  uint32_t w[ADAPT_WORDS];
+  ELP_HIP(c, hipMemcpyAsync(w, c->adapt_err.p, sizeof w, hipMemcpyDeviceToHost, c->stream));
   ELP_HIP(c, elp::stream_wait(c->stream));
   adapt_note(c, w);
   return 0;
 }
-void adapt_note(elp_ctx *c, uint32_t word) {
+// words: [0] the score kernel's error word, [2 .. 5] the quality values its sampled groups saw (k_score_uniform only)
+void adapt_note(elp_ctx *c, const uint32_t *words) {
   c->adapt_pending = false;
-  if (word & 1u) c->adapt_bad_qual = true;
+  if (words[0] & 1u) c->adapt_bad_qual = true;
+  if (c->adapt_sampled) {
+    c->adapt_qmask[0] = (unsigned long long)words[2] | ((unsigned long long)words[3] << 32);
+    c->adapt_qmask[1] = (unsigned long long)words[4] | ((unsigned long long)words[5] << 32);
+    c->adapt_qmask_valid = true;
+  }
+}
+int adapt_begin(elp_ctx *c, int *pos_bits_out) {
+  ELP_HIP(c, hipSetDevice(c->device));
+  const uint64_t n = c->n;
+  ELP_TRY(ensure_flat_index(c));
+  ELP_TRY(ensure(c, c->upos, n + 1));
+  ELP_TRY(ensure(c, c->score, n + 1));
+  ELP_TRY(ensure(c, c->key, n + 1));
+  ELP_TRY(ensure(c, c->qbounds, n + 1));
+  ELP_TRY(ensure(c, c->adapt_err, ADAPT_WORDS + 2));
+  ELP_HIP(c, hipMemsetAsync(c->adapt_err.p, 0, ADAPT_WORDS * sizeof(uint32_t), c->stream));
+  c->adapt_bad_qual = false;
+  c->adapt_pending = false;
+  c->adapt_sampled = c->adapt_qmask_valid = false;
+  int pos_bits = 1;
+  while (pos_bits < 32 && (c->max_pos >> pos_bits) != 0) pos_bits++;
+  int ref_bits = 1;  // contig codes 0 .. n_ref + 1 (unmapped, then the records that are not sorted at all)
+  while (ref_bits < 32 && (((uint32_t)c->n_ref + 1u) >> ref_bits) != 0) ref_bits++;
+  c->key_bits = ref_bits + pos_bits + 1;
+  *pos_bits_out = pos_bits;
+  return 0;
+}
+// every record's score and low-quality-tail bounds (records without QUAL bytes: zero)
+int adapt_scores(elp_ctx *c) {
+  const uint64_t n = c->n;
+  if (!n) return 0;
+  if (!c->qual_bytes) {  // no QUAL bytes at all: no tile, no kernel
+    ELP_HIP(c, hipMemsetAsync(c->qbounds.p, 0, n * sizeof(uint64_t), c->stream));
+    ELP_HIP(c, hipMemsetAsync(c->score.p, 0, n * sizeof(int32_t), c->stream));
+    return 0;
+  }
+  ELP_TRY(ensure_uniform_len(c));
+  if (c->uniform_len && score_uniform_ok(c->uniform_len) && c->tune.score_kernel != 1) {
+    ELP_TRY(score_uniform(c));  // (writes the score of every record)
+  } else {
+    ELP_HIP(c, hipMemsetAsync(c->score.p, 0, n * sizeof(int32_t), c->stream));  // (a read without bases belongs to no tile's group)
+    const unsigned grid = (unsigned)std::min<uint64_t>(flat_steps<ScoreBody>(c->qual_bytes), (uint64_t)c->n_cu * 4);
+    ELP_LAUNCH(c, "adapt_score", k_score_flat, dim3(grid), dim3(FL_THREADS), 0, n, (const uint64_t *)c->qual_off.p, (const uint8_t *)c->qual.p,
+               c->qual_bytes, (const uint32_t *)c->tile_first.p, (const uint16_t *)c->flag.p, c->score.p, c->qbounds.p, c->adapt_err.p);
+  }
+  c->adapt_pending = true;
+  return 0;
 }
 int ensure_adapted(elp_ctx *c, bool check_quals) {
   if (c->adapted) {
     if (check_quals) ELP_TRY(adapt_resolve(c));
     return (check_quals && c->adapt_bad_qual) ? adapt_quality_error(c) : 0;
   }
-  ELP_HIP(c, hipSetDevice(c->device));
-  uint64_t n = c->n;
-  ELP_TRY(ensure_flat_index(c));
-  ELP_TRY(ensure(c, c->upos, n + 1));
-  ELP_TRY(ensure(c, c->score, n + 1));
-  ELP_TRY(ensure(c, c->key, n + 1));
-  ELP_TRY(ensure(c, c->qbounds, n + 1));
-  ELP_TRY(ensure(c, c->adapt_err, 4));
-  ELP_HIP(c, hipMemsetAsync(c->adapt_err.p, 0, 16, c->stream));
-  c->adapt_bad_qual = false;
-  c->adapt_pending = false;
   int pos_bits = 1;
-  while (pos_bits < 32 && (c->max_pos >> pos_bits) != 0) pos_bits++;
-  {
-    int ref_bits = 1;  // contig codes 0 .. n_ref + 1 (unmapped, then the records that are not sorted at all)
-    while (ref_bits < 32 && (((uint32_t)c->n_ref + 1u) >> ref_bits) != 0) ref_bits++;
-    c->key_bits = ref_bits + pos_bits + 1;
-  }
+  ELP_TRY(adapt_begin(c, &pos_bits));
+  const uint64_t n = c->n;
   if (n) {
-    if (!c->qual_bytes) ELP_HIP(c, hipMemsetAsync(c->qbounds.p, 0, n * sizeof(uint64_t), c->stream));  // no QUAL bytes at all: no tile, no kernel
     ELP_LAUNCH(c, "adapt_fixed", k_adapt_fixed, dim3(blocks_for(n, 256)), dim3(256), 0, n, (const int32_t *)c->pos.p, (const int32_t *)c->refid.p,
                (const uint16_t *)c->flag.p, (const uint64_t *)c->cigar_off.p, (const uint32_t *)c->cigar.p, c->upos.p, c->score.p, c->key.p,
                (uint32_t)c->n_ref, pos_bits, (const uint8_t *)c->has_sr.p);
-    ELP_TRY(ensure_uniform_len(c));
-    if (c->qual_bytes && c->uniform_len && score_uniform_ok(c->uniform_len) && c->tune.score_kernel != 1) {
-      ELP_TRY(score_uniform(c));
-    } else if (c->qual_bytes) {
-      const unsigned grid = (unsigned)std::min<uint64_t>(flat_steps<ScoreBody>(c->qual_bytes), (uint64_t)c->n_cu * 4);
-      ELP_LAUNCH(c, "adapt_score", k_score_flat, dim3(grid), dim3(FL_THREADS), 0, n, (const uint64_t *)c->qual_off.p, (const uint8_t *)c->qual.p,
-                 c->qual_bytes, (const uint32_t *)c->tile_first.p, (const uint16_t *)c->flag.p, c->score.p, c->qbounds.p, c->adapt_err.p);
-    }
-    c->adapt_pending = c->qual_bytes != 0;
+    ELP_TRY(adapt_scores(c));
   }
   c->adapted = true;
   if (check_quals) ELP_TRY(adapt_resolve(c));
@@ -421,7 +476,12 @@ int ensure_qual_present(elp_ctx *c, bool exact) {
   if (c->have_qual_present) return 0;
   c->qual_present[0] = c->qual_present[1] = 0;
   // elp_set_tuning "qual_hint" = 1: the hint stays empty, which forces the gather's report-and-retry path (tests)
-  if (c->qual_bytes && (exact || c->tune.qual_hint != 1)) {
+  if (!exact && c->tune.qual_hint != 1 && c->adapted && c->adapt_sampled) {
+    // the score kernel sampled the column as it went (k_score_uniform): no pass, and no wait of its own if the error word is in already
+    ELP_TRY(adapt_resolve(c));
+    c->qual_present[0] = c->adapt_qmask[0];
+    c->qual_present[1] = c->adapt_qmask[1];
+  } else if (c->qual_bytes && (exact || c->tune.qual_hint != 1)) {
     unsigned long long *qm;
     ELP_TRY(scratch(c, 6, 4, &qm));
     ELP_HIP(c, hipMemsetAsync(qm, 0, 16, c->stream));

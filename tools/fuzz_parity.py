@@ -30,7 +30,8 @@ for seed in range(first, first + count):
     # kernel choices at random too (elp_set_tuning): every choice must give the oracle's bytes
     tuning = {"radix_tile": int(rng.integers(0, 4)), "sort_pairs": int(rng.integers(0, 2)), "tie_rounds": int(rng.integers(0, 2)),
               "mate_path": int(rng.choice([0, 0, 1, 2])), "pair_table_slots": int(rng.choice([0, 0, 16, 1024])),
-              "count_kernel": int(rng.choice([0, 0, 1, 2, 3])), "apply_kernel": int(rng.choice([0, 0, 1, 3])), "score_kernel": int(rng.choice([0, 0, 1]))}
+              "count_kernel": int(rng.choice([0, 0, 1, 2, 3])), "apply_kernel": int(rng.choice([0, 0, 1, 3])), "score_kernel": int(rng.choice([0, 0, 1])),
+              "md_fused": int(rng.choice([0, 0, 1]))}
     e = Engine(h, 0, tuning=tuning)
     cuts = np.linspace(0, b.n, int(rng.integers(1, 5)) + 1).astype(int)
     for lo, hi in zip(cuts[:-1], cuts[1:]):

@@ -56,7 +56,7 @@ if len(sys.argv) > 4 and sys.argv[4] == "sfm":
             g_of, sp = sfm.split_records(b, gof)
             p = sfm.with_sr(b, sp, g_of)
             tuning = {"radix_tile": int(rng.integers(0, 4)), "mate_path": int(rng.choice([0, 0, 0, 1, 2])), "pair_table_slots": int(rng.choice([0, 0, 16, 1024])),
-                      "count_kernel": int(rng.choice([0, 0, 1, 3])), "apply_kernel": int(rng.choice([0, 0, 1, 3]))}
+                      "count_kernel": int(rng.choice([0, 0, 1, 3])), "apply_kernel": int(rng.choice([0, 0, 1, 3])), "md_fused": int(rng.choice([0, 0, 1]))}
             for key, v in tuning.items():
                 e.set_tuning(key, v)
             e.reset()
@@ -111,7 +111,8 @@ for s in range(first, first + sessions):
             b, h, refs, sites = _random_case(seed, n, quals=quals, n_cov=n_cov)
         tuning = {"radix_tile": int(rng.integers(0, 4)), "sort_pairs": int(rng.integers(0, 2)), "tie_rounds": int(rng.integers(0, 2)),
                   "mate_path": int(rng.choice([0, 0, 1, 2])), "pair_table_slots": int(rng.choice([0, 0, 16, 1024])),
-                  "count_kernel": int(rng.choice([0, 0, 1, 2, 3])), "apply_kernel": int(rng.choice([0, 0, 1, 3])), "score_kernel": int(rng.choice([0, 0, 1]))}
+                  "count_kernel": int(rng.choice([0, 0, 1, 2, 3])), "apply_kernel": int(rng.choice([0, 0, 1, 3])), "score_kernel": int(rng.choice([0, 0, 1])),
+                  "md_fused": int(rng.choice([0, 0, 1]))}
         if e is None:
             e = Engine(h, 0)
         for key, v in tuning.items():

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn a rocprofv3 rocpd database (trace_results.db) into the per-kernel summary CSV committed under profiles/.
 usage: db_to_csv.py <trace_results.db> <out.csv> [header comment] [skip_steps]
-skip_steps > 0: leave out the dispatches of the first `skip_steps` steps of a bench.py run (a step starts at k_adapt_fixed) - the
+skip_steps > 0: leave out the dispatches of the first `skip_steps` steps of a bench.py run (a step starts at k_frag_list; k_adapt_fixed before round 6) - the
 warm-up steps, whose first launches run cold (the first k_bqsr_count of a process takes 3x its steady time) and are not part of
 what bench.py times.  With skip_steps = 0 the numbers are rocprofv3's own `top_kernels` summary."""
 import sqlite3
@@ -17,7 +17,7 @@ if skip == 0:
             c.execute("select name, total_calls, total_duration, average, percentage from top_kernels")]
 else:
     ks = list(c.execute("select name, start, end from kernels order by start"))
-    starts = [s for n, s, e in ks if "k_adapt_fixed" in n]
+    starts = [s for n, s, e in ks if "k_frag_list" in n] or [s for n, s, e in ks if "k_adapt_fixed" in n]
     if len(starts) <= skip:
         sys.exit(f"only {len(starts)} steps in the trace")
     t0 = starts[skip]

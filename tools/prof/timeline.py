@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Timeline of the LAST step of a bench.py run from a rocprofv3 rocpd database (kernel trace): every dispatch in order with its
-duration and the idle gap in front of it, folded into runs of the same kernel.  A step starts at k_adapt_fixed.
+duration and the idle gap in front of it, folded into runs of the same kernel.  A step starts at k_frag_list (k_adapt_fixed before round 6).
 usage: timeline.py <trace_results.db> [out.txt]"""
 import sqlite3
 import sys
@@ -8,9 +8,10 @@ import sys
 c = sqlite3.connect(sys.argv[1])
 rows = list(c.execute("select name, start, end from kernels order by start"))
 rows = [(n.split("(")[0].replace("void ", "").replace("elp::", ""), s, e) for n, s, e in rows]
-starts = [i for i, r in enumerate(rows) if r[0].startswith("k_adapt_fixed")]
+# (round 6: mark duplicates' front pass does the adapt stage's fixed-field part; a step then starts at k_frag_list)
+starts = [i for i, r in enumerate(rows) if r[0].startswith("k_frag_list")] or [i for i, r in enumerate(rows) if r[0].startswith("k_adapt_fixed")]
 if not starts:
-    sys.exit("no k_adapt_fixed dispatch in the trace")
+    sys.exit("no k_frag_list / k_adapt_fixed dispatch in the trace")
 step = rows[starts[-1]:]
 out = open(sys.argv[2], "w") if len(sys.argv) > 2 else sys.stdout
 t0 = step[0][1]
