@@ -20,6 +20,7 @@
 //     from the wrong row by the older kernel's clamp); qualities above the resident range read the 0x80 row and take the fix-up loop.
 #include <algorithm>
 
+#include "apply_rec.hpp"
 #include "bqsr_common.hpp"
 #include "gload.hpp"
 
@@ -28,21 +29,6 @@ namespace elp {
 constexpr uint32_t A3_N1 = 0x11111111u, A3_C3 = 0x33333333u;
 constexpr int A3_ROW = 20;  // bytes between two level-2 rows in LDS (17 used)
 constexpr int A3_NT = 512;  // three workgroups per CU around three copies of the LUT (~50 KB each): six waves per SIMD
-enum : uint32_t { AR_ON = 1u << 8, AR_REV = 1u << 9, AR_NEG = 1u << 10 };
-
-// per read: x = context window lo | hi << 16 (bases whose context covariate is valid), y = covariate | AR_* | (cf + lmax) << 16
-__device__ __forceinline__ uint2 apply_record(uint32_t len, int lmax, uint16_t f, uint64_t qb, uint32_t cov) {
-  const bool rev = f & F_REVERSED;
-  const uint32_t hi1 = (uint32_t)qb;
-  const int left = hi1 ? (int)(qb >> 32) : (int)len, right = hi1 ? (int)hi1 - 1 : (int)len - 1;
-  int cl = left + (rev ? 0 : 1), cr1 = right - (rev ? 1 : 0) + 1;
-  cl = cl < 0 ? 0 : cl;
-  cr1 = cr1 > (int)len ? (int)len : cr1;
-  cr1 = cr1 < cl ? cl : cr1;
-  const int rof = (f & F_LAST) ? -1 : 1;
-  const int cf = rof + (rev ? ((int)len - 1) * rof : 0), ci = rev ? -rof : rof;
-  return make_uint2((uint32_t)cl | ((uint32_t)cr1 << 16), (cov & 0xFFu) | AR_ON | (rev ? AR_REV : 0u) | (ci < 0 ? AR_NEG : 0u) | ((uint32_t)(cf + lmax) << 16));
-}
 __global__ __launch_bounds__(256) void k_apply_records(uint64_t n, uint32_t len, int lmax, const uint16_t *__restrict__ flag, const uint16_t *__restrict__ rgid,
                                                        const uint16_t *__restrict__ rg_cov, const uint64_t *__restrict__ qbounds,
                                                        const uint8_t *__restrict__ cov_present, uint2 *__restrict__ recs, uint32_t *err) {
@@ -162,6 +148,7 @@ struct Apply3Args {
   const uint32_t *ridx;     // staging index of record k
   const uint32_t *cov_cnt;  // [A3_MAXCOV] records per covariate
   const uint32_t *cov_off;  // [A3_MAXCOV + 1] first record of a covariate
+  const uint8_t *cov_present;  // not null: the records are the adapt stage's (apply_rec.hpp) - whether a read's group is in the tables is tested here
 };
 
 struct A3Data { u32x4 q, s; };  // QUAL bytes; SEQ window (three words used): the asm loads of gload.hpp write these registers
@@ -309,10 +296,14 @@ __global__ __launch_bounds__(A3_NT, 6) void k_bqsr_apply3(Apply3Args A) {  // si
       llut[t1_bytes + A3_ROW * row + cx] = row <= n_dict ? t2[k] : (uint8_t)(row - n_dict - 1);
     }
   };
+  __shared__ uint8_t s_present[A3_MAXCOV];
   if (!SPLIT) {
     fill(0, A.n_cov, (int)*A.n_dict, A.t2);
+    if (A.cov_present)
+      for (int k = threadIdx.x; k < A3_MAXCOV; k += A3_NT) s_present[k] = k < A.n_cov ? A.cov_present[k] : (uint8_t)0;
     __syncthreads();
   }
+  const bool adapt_recs = !SPLIT && A.cov_present != nullptr;
   Apply3<SPLIT> B;
   const uint32_t len = A.len, bpr = (len + 15u) >> 4, sbytes = (len + 1u) >> 1;
   // lanes in groups of A.group that share whole reads (apply3_launch picks the group so that a read's last two blocks sit in one wave)
@@ -347,7 +338,11 @@ __global__ __launch_bounds__(A3_NT, 6) void k_bqsr_apply3(Apply3Args A) {  // si
   // wave-uniform base)
   auto data_load = [&](uint64_t it, u32x2 rec, uint32_t idx, A3Data &d) __attribute__((always_inline)) -> bool {
     const uint64_t r0 = first_read(it);
-    if (!(lane_on && r0 + slot < n) || !(rec.y & AR_ON)) return false;
+    if (!(lane_on && r0 + slot < n) || !(rec.y & AR_ON)) {
+      if (adapt_recs && rec.x == AR_NO_RG) B.err |= 32u;  // readGroupCovariate panics, bqsr.go:38
+      return false;
+    }
+    if (adapt_recs && !s_present[rec.y & 0xFFu]) return false;  // read group absent from the tables, read untouched (:953-955)
     if (SPLIT) {
       gload_x4(d.q, (uint64_t)A.qual + (uint64_t)idx * len + B.k0);
       gload_x4(d.s, (uint64_t)seq_m1 + (uint64_t)idx * sbytes + (B.k0 >> 1));
@@ -507,12 +502,14 @@ int apply3_launch(elp_ctx *c, int max_cycle, const uint8_t *d_lut, const uint8_t
     ELP_LAUNCH(c, "bqsr_apply_cov_offsets", k_apply_cov_offsets, dim3(1), dim3(1), 0, (const uint32_t *)cw, cw + A3_MAXCOV, cw + 2 * A3_MAXCOV + 1);
     ELP_LAUNCH(c, "bqsr_apply_records", k_apply_records_split, dim3(rg), dim3(256), 0, n, per, len, lmax, (const uint16_t *)c->flag.p, (const uint16_t *)c->rgid.p,
                (const uint16_t *)c->rg_cov.p, (const uint64_t *)c->qbounds.p, d_cov_present, (const uint32_t *)blk, cw + 2 * A3_MAXCOV + 1, recs, ridx, c->err_flag.p);
-  } else {
+  }
+  // the adapt stage's score kernel left the records (same length, same lmax: both are the one length of the staged reads)
+  const bool adapt_recs = !split && c->adapted && c->apply_recs_valid && c->apply_recs_lmax == lmax && c->apply_recs.cap >= n;
+  if (!split && !adapt_recs)
     ELP_LAUNCH(c, "bqsr_apply_records", k_apply_records, dim3(blocks_for(n, 256)), dim3(256), 0, n, len, lmax, (const uint16_t *)c->flag.p,
                (const uint16_t *)c->rgid.p, (const uint16_t *)c->rg_cov.p, (const uint64_t *)c->qbounds.p, d_cov_present, recs, c->err_flag.p);
-  }
-  Apply3Args A{n, len, c->qual.p, c->seq4.p + elp_ctx::SEQ_FRONT, recs, d_lut, t1, t2, n_dict_dev, c->n_cov, n_qi, lmax, max_cycle, c->err_flag.p,
-               dump, group, ridx, cw, cw + A3_MAXCOV};
+  Apply3Args A{n, len, c->qual.p, c->seq4.p + elp_ctx::SEQ_FRONT, adapt_recs ? (const uint2 *)c->apply_recs.p : (const uint2 *)recs, d_lut, t1, t2, n_dict_dev, c->n_cov, n_qi,
+               lmax, max_cycle, c->err_flag.p, dump, group, ridx, cw, cw + A3_MAXCOV, adapt_recs ? d_cov_present : (const uint8_t *)nullptr};
   if (split) {
     ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bqsr_apply3<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     ELP_LAUNCH(c, "bqsr_apply", k_bqsr_apply3<true>, dim3(grid), dim3(A3_NT), dyn, A);

@@ -162,7 +162,8 @@ __device__ __forceinline__ void pf_lds_fill(PfLds &L, const BqCols &m, int nt) {
 template <bool PLAIN_PASS>
 __device__ __forceinline__ void pf_record(const BqCols &m, const uint64_t i, const PfCols &cur, const PfLds &L, const bool ref_lds, BqDesc *__restrict__ desc,
                                           uint32_t *skipbits, uint32_t *err, const bool recs /* records, not descriptors */, uint32_t *my_cig_w, bool &defer, bool &to_plain,
-                                          BqRec &rc_out, int &rc_class) {
+                                          BqRec &rc_out, int &rc_class, uint4 *__restrict__ plain_rec /* first pass: where a read of the second pass leaves its columns */,
+                                          const uint32_t *pre_ops /* second pass: the read's five CIGAR operation slots, handed over */) {
     const uint8_t has_sr = cur.has_sr, mq = cur.mq;
     const uint16_t f = cur.f, rg = cur.rg;
     const int32_t r = cur.r, p = cur.p, pnext = cur.pnext, tlen = cur.tlen, nrefid = cur.nrefid;
@@ -186,7 +187,7 @@ __device__ __forceinline__ void pf_record(const BqCols &m, const uint64_t i, con
       if (recs) { rec_rp = m.ref_seq[r]; rec_rlen = m.ref_seq_len[r]; }  // issued with the CIGAR loads: one round trip for both
       uint32_t opv[5];
 #pragma unroll
-      for (int k = 0; k < 5; k++) opv[k] = (uint64_t)k < nop ? m.cigar[c0 + k] : 0u;
+      for (int k = 0; k < 5; k++) opv[k] = PLAIN_PASS ? pre_ops[k] : ((uint64_t)k < nop ? m.cigar[c0 + k] : 0u);
       const int32_t rl = ref_lds ? L.ref_len[r] : m.ref_len[r];
       // the same round trip: the read group's covariate index and - when descriptors are written - the known-site bucket entry (read
       // whether or not the tests below pass).  When RECORDS are written (count3.hip) a read that is one run of matches needs no walk over
@@ -240,7 +241,17 @@ __device__ __forceinline__ void pf_record(const BqCols &m, const uint64_t i, con
         // first pass: a read with indels goes to the second, dense pass (k_bqsr_prologue_plain) - a wave that holds one would otherwise
         // run the piece / read-coordinate code for all of its lanes (the kernel is bound by vector issue: 1250 instructions per wave and
         // tile with both paths in one kernel, profiles/round3 PMC)
-        if (ok && plain && ls <= (uint32_t)MAX_DESC_READ) { to_plain = true; return; }
+        if (ok && plain && ls <= (uint32_t)MAX_DESC_READ) {
+          // the columns this thread holds go along in ONE 64-byte line at the read's own place (round 6): the second pass gathered them
+          // again from fifteen columns - 850 bytes of sectors per listed read, 0.52 ms for the 7.5 % of the reads that have an indel
+          uint4 *pr = plain_rec + 4 * i;
+          pr[0] = make_uint4(opv[0], opv[1], opv[2], opv[3]);
+          pr[1] = make_uint4(opv[4], (uint32_t)f | ((uint32_t)rg << 16), (uint32_t)r, (uint32_t)p);
+          pr[2] = make_uint4(ls | ((uint32_t)nop << 16) | (nrefid < 0 ? 1u << 19 : 0u), (uint32_t)c0, (uint32_t)q0, (uint32_t)(q0 >> 32));
+          pr[3] = make_uint4((uint32_t)qb, (uint32_t)(qb >> 32), (uint32_t)pnext, (uint32_t)tlen);
+          to_plain = true;
+          return;
+        }
         plain = false;
       } else if (plain) {
 #pragma unroll
@@ -357,7 +368,7 @@ __device__ __forceinline__ void pf_record(const BqCols &m, const uint64_t i, con
 
 // First pass, one thread per record; all column loads are issued before the first test (one latency, not 15), a tile ahead.
 __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__restrict__ desc, uint32_t *skipbits, uint32_t *__restrict__ queue,
-                                                            uint32_t *queue_n, uint32_t *err, RecOut ro, uint32_t *__restrict__ plist) {
+                                                            uint32_t *queue_n, uint32_t *err, RecOut ro, uint32_t *__restrict__ plist, uint4 *__restrict__ plain_rec) {
   // a workgroup handles PF_TILES * 256 consecutive records and collects the deferred ones in LDS - the general kernel's from the front of
   // the list, the second pass's from its end: one global atomic per workgroup and list (a global atomic per wave on a single counter
   // serialises at ~12 ns each: 9 ms for 50 M reads)
@@ -381,7 +392,7 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
     if (tile + 1 < PF_TILES && i + 256 < m.n) nxt = pf_load_cols(m, i + 256);
     BqRec rc;
     int rcl = 0;
-    if (i < m.n) pf_record<false>(m, i, cur, L, ref_lds, desc, skipbits, err, ro.recs != nullptr, nullptr, defer, to_plain, rc, rcl);
+    if (i < m.n) pf_record<false>(m, i, cur, L, ref_lds, desc, skipbits, err, ro.recs != nullptr, nullptr, defer, to_plain, rc, rcl, plain_rec, nullptr);
     if (ro.recs) {  // the tile's records, compacted: class 1 into this wave's segment, the rare class 2 ones (windows the record cannot describe) behind
       if (!ro.ncs) {
         const uint32_t seg = (blockIdx.x * 4u + (threadIdx.x >> 6)) % ro.nseg;  // the wave's segment
@@ -441,7 +452,7 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_fast(BqCols m, BqDesc *__
 // kind of work); the list's length stays on the device.  A read this pass cannot finish either (adaptor geometry) joins the general
 // kernel's queue: one global atomic per workgroup and trip.
 __global__ __launch_bounds__(256) void k_bqsr_prologue_plain(BqCols m, BqDesc *__restrict__ desc, uint32_t *skipbits, const uint32_t *__restrict__ plist,
-                                                             uint32_t *__restrict__ queue, uint32_t *queue_n, uint32_t *err, RecOut ro) {
+                                                             uint32_t *__restrict__ queue, uint32_t *queue_n, uint32_t *err, RecOut ro, const uint4 *__restrict__ plain_rec) {
   __shared__ uint32_t s_cig[256][5];  // the thread's CIGAR: build_pieces / get_read_coord walk it several times
   __shared__ uint32_t wg_n, wg_base, wr_n, wr_base;
   __shared__ PfLds L;
@@ -458,8 +469,21 @@ __global__ __launch_bounds__(256) void k_bqsr_prologue_plain(BqCols m, BqDesc *_
     int rcl = 0;
     if (t < np) {
       i = plist[t];
-      const PfCols cur = pf_load_cols(m, i);
-      pf_record<true>(m, i, cur, L, ref_lds, desc, skipbits, err, ro.recs != nullptr, s_cig[threadIdx.x], defer, to_plain, rc, rcl);
+      // the read's columns as the first pass left them (pf_record<false>): one 64-byte line
+      const uint4 *pr = plain_rec + 4 * (size_t)i;
+      const uint4 w0 = pr[0], w1 = pr[1], w2 = pr[2], w3 = pr[3];
+      const uint32_t ops[5] = {w0.x, w0.y, w0.z, w0.w, w1.x};
+      PfCols cur;
+      cur.has_sr = 0; cur.mq = 1;  // (the first pass made recalibrateAln's tests)
+      cur.f = (uint16_t)w1.y; cur.rg = (uint16_t)(w1.y >> 16);
+      cur.r = (int32_t)w1.z; cur.p = (int32_t)w1.w;
+      cur.ls = w2.x & 0xFFFFu;
+      cur.nrefid = (w2.x >> 19) & 1u ? -1 : 0;  // (only its sign is looked at)
+      cur.c0 = (uint64_t)w2.y; cur.c1 = cur.c0 + ((w2.x >> 16) & 7u);
+      cur.q0 = (uint64_t)w2.z | ((uint64_t)w2.w << 32); cur.q1 = cur.q0 + cur.ls;
+      cur.qb = (uint64_t)w3.x | ((uint64_t)w3.y << 32);
+      cur.pnext = (int32_t)w3.z; cur.tlen = (int32_t)w3.w;
+      pf_record<true>(m, i, cur, L, ref_lds, desc, skipbits, err, ro.recs != nullptr, s_cig[threadIdx.x], defer, to_plain, rc, rcl, nullptr, ops);
     }
     // deferred reads -> the general kernel's queue, finished records (all class 2 here... or 1 if the CIGAR folded to one run) -> the other
     // region: one global atomic each per workgroup and trip
@@ -1603,6 +1627,8 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
     ELP_TRY(scratch(c, 1, 2 * (c->cigar_ops + 4 * n) + 64, &cs_pool));
     BqDesc *desc;
     ELP_TRY(scratch(c, 2, n + 4, &desc));
+    uint4 *plain_rec;  // a 64-byte line per staged read, written for the reads with indels only (pf_record<false> -> k_bqsr_prologue_plain)
+    ELP_TRY(scratch(c, 0, 4 * n + 8, &plain_rec));
     uint32_t *skipbits;
     const size_t skip_words = (size_t)((c->qual_bytes + 31) / 32 + 8);
     ELP_TRY(scratch(c, 3, skip_words, &skipbits));
@@ -1665,10 +1691,10 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
     // the three prologue passes; with `r` they leave 32-byte records for count3.hip, without it the descriptors of k_bqsr_count
     auto run_prologues = [&](BqRec *r) -> int {
       const RecOut ro{r, rec_cnt, seg_base, other_at, nseg, (r && mode == 2) ? ncs : 0u};
-      ELP_LAUNCH(c, "bqsr_prologue_fast", k_bqsr_prologue_fast, dim3(pf_grid), dim3(256), 0, m, desc, skipbits, queue + 4, queue, c->err_flag.p, ro, plist);
+      ELP_LAUNCH(c, "bqsr_prologue_fast", k_bqsr_prologue_fast, dim3(pf_grid), dim3(256), 0, m, desc, skipbits, queue + 4, queue, c->err_flag.p, ro, plist, plain_rec);
       // (sized for the worst case; workgroups beyond the list's end leave at once)
       ELP_LAUNCH(c, "bqsr_prologue_plain", k_bqsr_prologue_plain, dim3(std::min<unsigned>(blocks_for(n, 256), (unsigned)c->n_cu * 16)), dim3(256), 0, m, desc, skipbits,
-                 (const uint32_t *)plist, queue + 4, queue, c->err_flag.p, ro);
+                 (const uint32_t *)plist, queue + 4, queue, c->err_flag.p, ro, (const uint4 *)plain_rec);
       ELP_LAUNCH(c, "bqsr_prologue", k_bqsr_prologue, dim3(std::min<unsigned>(blocks_for(n, 256), (unsigned)c->n_cu * 16)), dim3(256), 0, m,
                  (const uint32_t *)(queue + 4), (const uint32_t *)queue, cs_pool, desc, skipbits, c->err_flag.p, ro);
       return 0;

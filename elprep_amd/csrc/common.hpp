@@ -109,6 +109,9 @@ struct elp_ctx {
   bool adapt_sampled = false;      // the score kernel of this adapt stage sampled the quality values ...
   bool adapt_qmask_valid = false;  // ... and they have been read (adapt_note)
   unsigned long long adapt_qmask[2] = {0, 0};
+  elp::DVec<uint2> apply_recs;     // ApplyBQSR's per-read records (apply_rec.hpp), written by k_score_uniform ...
+  bool apply_recs_valid = false;   // ... of this adapt stage, for reads of apply_recs_lmax bases
+  int apply_recs_lmax = 0;
   bool have_qual_present = false;
   unsigned long long qual_present[2] = {0, 0};  // bit q set if quality value q was seen in a sample of the QUAL column (sizing hint for the BQSR tables)
   elp::DVec<int32_t> upos, score;

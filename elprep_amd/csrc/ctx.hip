@@ -251,6 +251,7 @@ int elp_set_header(elp_ctx *c, const elp_header *h) {
     return set_error(c, ELP_ERR_ARG, "elp_set_header: bad arguments");
   ELP_HIP(c, hipSetDevice(c->device));
   c->n_ref = h->n_ref; c->n_rg = h->n_rg; c->n_lib = h->n_lib; c->n_cov = h->n_cov;
+  c->apply_recs_valid = false;  // (they hold the read groups' covariates)
   c->h_ref_len.assign(h->ref_len, h->ref_len + h->n_ref);
   c->h_rg_lib.assign(h->rg_lib, h->rg_lib + h->n_rg);
   c->h_rg_cov.assign(h->rg_cov, h->rg_cov + h->n_rg);

@@ -11,6 +11,7 @@
 //            8 bytes per round, then one stable round on the run id.
 #include <cstdlib>
 
+#include "apply_rec.hpp"
 #include "common.hpp"
 #include "flat.hpp"
 
@@ -166,7 +167,8 @@ template <int R>
 __global__ __launch_bounds__(64 * SU_WAVES) void k_score_uniform(uint64_t n, uint32_t L, const uint8_t *__restrict__ qual, const uint16_t *__restrict__ flag,
                                                                  int32_t *__restrict__ score, uint64_t *__restrict__ qbounds, uint32_t *err,
                                                                  uint32_t qstride /* every qstride-th group of 64 reads notes the quality values it holds */,
-                                                                 unsigned long long *qmask) {
+                                                                 unsigned long long *qmask, const uint16_t *__restrict__ rgid, const uint16_t *__restrict__ rg_cov,
+                                                                 uint2 *__restrict__ arecs /* not null: ApplyBQSR's per-read records (apply_rec.hpp) */) {
   extern __shared__ __attribute__((aligned(16))) uint32_t su_lds[];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t tile_bytes = 64u * L, tile_words = tile_bytes / 4u + 4u;
@@ -196,7 +198,9 @@ __global__ __launch_bounds__(64 * SU_WAVES) void k_score_uniform(uint64_t n, uin
     // (the tile is the wave's own, and a wave's LDS operations execute in order: no barrier)
     const uint64_t r = r0 + lane;
     if (r < n) {
-      const bool cand = (flag[r] & (F_UNMAPPED | F_SECONDARY | F_SUPPLEMENTARY)) == 0;
+      const uint16_t f = flag[r];
+      const bool cand = (f & (F_UNMAPPED | F_SECONDARY | F_SUPPLEMENTARY)) == 0;
+      const uint16_t rg = arecs ? rgid[r] : (uint16_t)ELP_NIL16;
       const uint32_t *rw = tile + w0;
       uint32_t x = rw[0] & m_first;
       if (nw == 1) x &= m_last;
@@ -229,7 +233,8 @@ __global__ __launch_bounds__(64 * SU_WAVES) void k_score_uniform(uint64_t n, uin
       score[r] = cand ? (int32_t)sum : 0;
       qbounds[r] = (uint64_t)hi | ((uint64_t)lo << 32);
       if (cand) bad |= bd & 0x80808080u;
-      if (g % qstride == 0) {  // (wave-uniform)
+      if (arecs) arecs[r] = rg == ELP_NIL16 ? make_uint2(AR_NO_RG, 0u) : apply_record(L, (int)L, f, (uint64_t)hi | ((uint64_t)lo << 32), rg_cov[rg]);
+      if ((uint32_t)g % qstride == 0) {  // (wave-uniform)
         for (uint32_t k = 0; k < nw; k++) {
           const uint32_t vm = (k == 0 ? m_first : 0xFFFFFFFFu) & (k + 1 == nw ? m_last : 0xFFFFFFFFu), xw = rw[k];
 #pragma unroll
@@ -272,12 +277,21 @@ static int score_uniform_launch(elp_ctx *c) {
   const uint64_t ngroups = (c->n + 63) / 64;
   const unsigned grid = (unsigned)std::min<uint64_t>((ngroups + SU_WAVES - 1) / SU_WAVES, (uint64_t)c->n_cu * per_cu);
   ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_score_uniform<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+  // ApplyBQSR's records on the way (apply3.hip takes whole 16-byte blocks of reads of one length)
+  uint2 *arecs = nullptr;
+  if (L >= 16 && L <= 0x7FFF && c->n_rg > 0) {
+    ELP_TRY(ensure(c, c->apply_recs, c->n + 4));
+    arecs = c->apply_recs.p;
+  }
   // the sample of the quality values: everything up to ~500 K reads (the hint is then exact, as k_qual_present_sample's is), one group in
   // up to 128 of longer columns
   const uint32_t qstride = (uint32_t)std::min<uint64_t>(128, std::max<uint64_t>(1, ngroups / 8192));
   ELP_LAUNCH(c, "adapt_score", k_score_uniform<R>, dim3(grid), dim3(64 * SU_WAVES), dyn, c->n, L, (const uint8_t *)c->qual.p, (const uint16_t *)c->flag.p,
-             c->score.p, c->qbounds.p, c->adapt_err.p, qstride, reinterpret_cast<unsigned long long *>(c->adapt_err.p + 2));
+             c->score.p, c->qbounds.p, c->adapt_err.p, qstride, reinterpret_cast<unsigned long long *>(c->adapt_err.p + 2), (const uint16_t *)c->rgid.p,
+             (const uint16_t *)c->rg_cov.p, arecs);
   c->adapt_sampled = true;
+  c->apply_recs_valid = arecs != nullptr;
+  c->apply_recs_lmax = (int)L;
   return 0;
 }
 static int score_uniform(elp_ctx *c) {
@@ -423,6 +437,7 @@ int adapt_begin(elp_ctx *c, int *pos_bits_out) {
   c->adapt_bad_qual = false;
   c->adapt_pending = false;
   c->adapt_sampled = c->adapt_qmask_valid = false;
+  c->apply_recs_valid = false;
   int pos_bits = 1;
   while (pos_bits < 32 && (c->max_pos >> pos_bits) != 0) pos_bits++;
   int ref_bits = 1;  // contig codes 0 .. n_ref + 1 (unmapped, then the records that are not sorted at all)
