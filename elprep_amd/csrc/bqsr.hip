@@ -120,6 +120,22 @@ __device__ __forceinline__ void set_skip_bits(uint32_t *skipbits, uint64_t bit0,
   }
 }
 
+// clears the bits of bases [0, nbits) of the record whose first QUAL byte is at bit0.  Round 6: when RECORDS are written (count3.hip) only the
+// reads that put known-site bits into the column ever read it (RC_SKIPCOL), and only their own bits - such a read clears its range before
+// it sets bits, and the fill of the whole column (a bit per staged base: 0.14 ms per 50 M reads) is made for the descriptor form only.
+// Neighbouring reads share words, never bits: atomics on the words, in program order per thread.
+__device__ __forceinline__ void clear_skip_bits(uint32_t *skipbits, uint64_t bit0, uint32_t nbits) {
+  for (uint32_t k = 0; k < nbits;) {
+    const uint64_t b = bit0 + (uint64_t)k;
+    const uint32_t in_word = (uint32_t)(b & 31);
+    uint32_t cnt = 32 - in_word;
+    if (cnt > nbits - k) cnt = nbits - k;
+    const uint32_t mask = (cnt == 32 ? 0xFFFFFFFFu : ((1u << cnt) - 1u)) << in_word;
+    atomicAnd(&skipbits[b >> 5], ~mask);
+    k += cnt;
+  }
+}
+
 // Fast prologue, one thread per record.  Decides eligibility (recalibrateAln) for every record and finishes the records whose
 // CIGAR is a single M/=/X operation and that need no adaptor clipping (≈ 5 of 6 reads): for those the clipped copy is the read
 // itself, getReadCoordinateForReferenceCoordinate(ref) is ref - POS inside the read and fails outside (utils.go:267-349 with one
@@ -321,6 +337,7 @@ __device__ __forceinline__ void pf_record(const BqCols &m, const uint64_t i, con
                 fs = (a0 < 0 || a0 >= len) ? 0 : a0;          // !ok || < 0 -> 0
                 fe = (a1 < 0 || a1 >= len) ? len - 1 : a1;    // !ok || > len-1 -> len-1 (a1 < 0 cannot happen: End >= POS)
               }
+              if (recs && !used_col) clear_skip_bits(skipbits, q0, ls);
               set_skip_bits(skipbits, q0 + aoff, fs, fe);
               used_col = true;
             }
@@ -562,6 +579,7 @@ __device__ inline void prologue_general(const BqCols &m, const uint64_t i, uint3
       while (last < ns && sv[2 * last] <= se) last++;
     }
     const uint64_t bit0 = m.qual_off[i] + (uint64_t)a.off;
+    if (recs) clear_skip_bits(skipbits, m.qual_off[i], m.l_seq[i]);  // (this kernel's reads all read the column, RC_SKIPCOL)
     for (int64_t s = first; s < last; s++) {
       bool ok;
       int fs = get_read_coord(a.cig, a.ncig, ss, sv[2 * s], false, &ok);
@@ -1632,7 +1650,6 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
     uint32_t *skipbits;
     const size_t skip_words = (size_t)((c->qual_bytes + 31) / 32 + 8);
     ELP_TRY(scratch(c, 3, skip_words, &skipbits));
-    ELP_HIP(c, hipMemsetAsync(skipbits, 0, skip_words * 4, st));
     BqCols m{n, c->refid.p, c->pos.p, c->next_refid.p, c->pnext.p, c->tlen.p, c->flag.p, c->rgid.p, c->mapq.p, c->has_sr.p, c->l_seq.p,
              c->cigar_off.p, c->seq_off.p, c->qual_off.p, c->cigar.p, c->seq4.p, c->qual.p, c->ref_len.p, c->rg_cov.p, c->n_ref,
              c->d_ref_seq.p, c->d_ref_seq_len.p, c->d_sites.p, c->d_n_sites.p, c->d_site_idx.p, c->qbounds.p};
@@ -1688,6 +1705,7 @@ static int gather_impl(elp_ctx *c, int max_cycle, int64_t *qual_tbl, int64_t *cy
     };
     if ((uint64_t)C3_NSEG * cap_s1 + 2 * n >= 0xFFFFFFF0ull) return set_error(c, ELP_ERR_UNSUPPORTED, "BQSR: more than ~1.4 G records per context");
     ELP_TRY(rec_buffers());
+    if (!recs) ELP_HIP(c, hipMemsetAsync(skipbits, 0, skip_words * 4, st));  // (with records the reads that use the column clear their own bits: clear_skip_bits)
     // the three prologue passes; with `r` they leave 32-byte records for count3.hip, without it the descriptors of k_bqsr_count
     auto run_prologues = [&](BqRec *r) -> int {
       const RecOut ro{r, rec_cnt, seg_base, other_at, nseg, (r && mode == 2) ? ncs : 0u};
