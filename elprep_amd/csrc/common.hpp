@@ -429,9 +429,17 @@ int radix_sort_pairs(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *keys_
                      uint64_t **keys_out, uint32_t **vals_out);
 // the same over the low `ndigits` bytes of the keys only, every pass run (no histogram read-back, no host synchronisation)
 int radix_sort_fused(elp_ctx *c, const uint64_t *keycol, uint64_t n, int key_bits, int idx_bits, uint64_t *buf0, uint64_t *buf1, uint64_t **out);
+// bounds of the buckets the sorted low key bits define, reported by the LAST pass of radix_sort_pairs_low: bucket of a key = (key & mask) >> shift;
+// start[b] = first element of bucket b, nend[b] = ~(one behind its last) - both arrays filled with 0xFF by the caller (an empty bucket keeps
+// start 0xFFFFFFFF, end ~nend = 0)
+struct RadixBounds {
+  uint32_t *start = nullptr, *nend = nullptr;
+  uint32_t mask = 0;
+  int shift = 0;
+};
 int radix_sort_pairs_low(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *keys_tmp, uint32_t *vals_tmp, uint64_t n, int ndigits,
                          uint64_t **keys_out, uint32_t **vals_out, const uint64_t *first_src = nullptr, bool identity_vals = false,
-                         const uint32_t *n_dev = nullptr /* the length is *n_dev on the device and `n` its upper bound */);
+                         const uint32_t *n_dev = nullptr /* the length is *n_dev on the device and `n` its upper bound */, RadixBounds bnd = RadixBounds{});
 int exclusive_scan_u32(elp_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n, uint32_t *total_host /* may be null */);
 int ensure_adapted(elp_ctx *c, bool check_quals = true);
 // the two halves of ensure_adapted for a caller that computes the fixed-field part (unclipped positions, sort keys) itself - mark

@@ -802,13 +802,14 @@ __device__ __forceinline__ int pb_slot(const MdCols &m, const uint4 *__restrict_
 __global__ __launch_bounds__(PB_THREADS) void k_pair_bucket(MdCols m, const uint4 *__restrict__ fkey, const uint32_t *__restrict__ mate,
                                                      const uint64_t *__restrict__ ks, uint32_t *__restrict__ vs,
                                                      const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ bend, int cap_slots,
-                                                     uint32_t *__restrict__ pair_win, uint16_t *__restrict__ flag_out) {
+                                                     uint32_t *__restrict__ pair_win, uint16_t *__restrict__ flag_out, int inv_end /* bend holds ~end (RadixBounds) */) {
   __shared__ unsigned long long s_key[PB_CAP];
   __shared__ uint32_t s_best[PB_CAP], s_win[PB_CAP];
   __shared__ uint16_t s_slot[PB_ECAP];
   __shared__ uint32_t s_full, s_min, s_h;
-  const uint32_t start = bstart[blockIdx.x], cnt = bend[blockIdx.x] - start;
-  if (cnt == 0) return;
+  const uint32_t start = bstart[blockIdx.x], end = inv_end ? ~bend[blockIdx.x] : bend[blockIdx.x];
+  if (end <= start) return;
+  const uint32_t cnt = end - start;
   const uint32_t t = threadIdx.x;
   if (cnt == 1) return;  // the only pair of its bucket wins
   uint32_t T = 2;
@@ -1389,7 +1390,10 @@ static int markdup_impl(elp_ctx *c) {
   {
     uint32_t *bounds;
     ELP_TRY(scratch(c, 1, 2 * nb + 8, &bounds));  // `frep` and the fragment list are free again
-    ELP_HIP(c, hipMemsetAsync(bounds, 0, 2 * nb * sizeof(uint32_t), st));
+    // with radix passes in front, the last of them reports the buckets' bounds (RadixBounds: both arrays start as 0xFF..); a list that is
+    // one bucket (tiny inputs) takes its bounds from k_pair_bounds
+    const bool folded = ndig > 0;
+    ELP_HIP(c, hipMemsetAsync(bounds, folded ? 0xFF : 0, 2 * nb * sizeof(uint32_t), st));
     // aligner order without stragglers: no record announced its key, so nothing went through the mate table - `rep_of` (pair_win's
     // buffer) is still all EMPTY from its fill in front of the scan and no owner carries MC_TABBED: no second fill, no scan of the codes
     const bool no_table = fixed && n_tab == 0 && !e[1];
@@ -1406,12 +1410,15 @@ static int markdup_impl(elp_ctx *c) {
     uint32_t *vs = pv;
     if (ndig) {
       ProfScope ps(c, "md_pair_");
-      ELP_TRY(radix_sort_pairs_low(c, pk, pv, pk + npmax, pv + npmax, npmax, ndig, &ks, &vs, nullptr, false, np_dev));
+      ELP_TRY(radix_sort_pairs_low(c, pk, pv, pk + npmax, pv + npmax, npmax, ndig, &ks, &vs, nullptr, false, np_dev,
+                                   RadixBounds{bounds, bounds + nb, (uint32_t)((1ull << sbits) - 1ull), sbits - bbits}));
     }
-    ELP_LAUNCH(c, "md_pair_bounds", k_pair_bounds, dim3(blocks_for(npmax, 256)), dim3(256), 0, (const uint64_t *)ks, (const uint32_t *)np_dev, sbits, bbits,
-               bounds, bounds + nb);
+    if (!folded)
+      ELP_LAUNCH(c, "md_pair_bounds", k_pair_bounds, dim3(blocks_for(npmax, 256)), dim3(256), 0, (const uint64_t *)ks, (const uint32_t *)np_dev, sbits, bbits,
+                 bounds, bounds + nb);
     ELP_LAUNCH(c, "md_pair_bucket", k_pair_bucket, dim3((unsigned)nb), dim3(PB_THREADS), 0, m, (const uint4 *)fkey, (const uint32_t *)c->mate.p,
-               (const uint64_t *)ks, vs, (const uint32_t *)bounds, (const uint32_t *)(bounds + nb), std::min(c->tune.pair_table_slots, PB_CAP), c->pair_win.p, c->flag.p);
+               (const uint64_t *)ks, vs, (const uint32_t *)bounds, (const uint32_t *)(bounds + nb), std::min(c->tune.pair_table_slots, PB_CAP), c->pair_win.p, c->flag.p,
+               folded ? 1 : 0);
   }
   c->radix_check_pending = true;
   c->marked = true;

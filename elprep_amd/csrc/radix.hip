@@ -181,7 +181,7 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 1) void k_radix_scatt
                                                               uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint64_t n,
                                                               int shift, const unsigned long long *__restrict__ ghist /* [256] of this digit */,
                                                               unsigned long long *state, uint32_t epoch, uint32_t *ticket,
-                                                              uint32_t *err, const uint32_t *__restrict__ n_dev, int fuse) {
+                                                              uint32_t *err, const uint32_t *__restrict__ n_dev, int fuse, RadixBounds bnd) {
   constexpr int WAVES = THREADS / 64, TILE = THREADS * RS_ITEMS;  // 4096 keys (256 threads) or 8192 (512: runs of twice the length per digit)
   __shared__ uint32_t cnt[WAVES][256];
   __shared__ uint32_t gbase[256];   // global position of the tile's first key with digit d, minus its position inside the sorted tile
@@ -313,6 +313,17 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 1) void k_radix_scatt
       const uint64_t key = sbuf[j];
       dst[r] = gbase[(uint32_t)(key >> shift) & 0xFF] + j;
       keys_out[dst[r]] = key;
+      if (PAIRS && bnd.start) {
+        // the LAST pass of a sort whose caller wants the bounds of the buckets its (sorted) low key bits define: inside the tile the
+        // elements of a bucket are neighbours (the tile is in digit order, and the passes before sorted what is left of the bucket's
+        // bits); the first / last one of such a run reports its output position - a few hundred atomics per tile instead of a pass
+        // over the sorted array (k_pair_bounds)
+        const uint32_t b = ((uint32_t)key & bnd.mask) >> bnd.shift;
+        const bool first = j == 0 || (((uint32_t)sbuf[j - 1] & bnd.mask) >> bnd.shift) != b;
+        const bool last = j + 1 == tile_n || (((uint32_t)sbuf[j + 1] & bnd.mask) >> bnd.shift) != b;
+        if (first) atomicMin(&bnd.start[b], dst[r]);
+        if (last) atomicMin(&bnd.nend[b], ~(dst[r] + 1u));
+      }
     }
   }
   if (!PAIRS) return;
@@ -364,28 +375,28 @@ static uint32_t radix_tiles(const elp_ctx *c, uint64_t n) {
 }
 template <bool PAIRS>
 static int radix_scatter_launch_t(elp_ctx *c, uint64_t n, const uint64_t *kin, const uint32_t *vin, uint64_t *kdst, uint32_t *vdst, int shift,
-                                  const unsigned long long *ghist, uint32_t *ticket, const uint32_t *n_dev, int fuse) {
+                                  const unsigned long long *ghist, uint32_t *ticket, const uint32_t *n_dev, int fuse, RadixBounds bnd = RadixBounds{}) {
   const uint32_t ntiles = radix_tiles(c, n);
   const int ts = radix_tile_shift(c, n);
   if (ts == 2) {  // one workgroup of 16 waves per CU
     const size_t dyn = (size_t)4 * RS_TILE * sizeof(uint64_t);
     ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_radix_scatter_t<1024, PAIRS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     ELP_LAUNCH(c, "radix_scatter", (k_radix_scatter_t<1024, PAIRS>), dim3(ntiles), dim3(1024), dyn, kin, vin, kdst, vdst, n, shift, ghist, c->radix_state.p,
-               c->radix_epoch, ticket, c->err_flag.p, n_dev, fuse);
+               c->radix_epoch, ticket, c->err_flag.p, n_dev, fuse, bnd);
   } else if (ts == 1) {
     const size_t dyn = (size_t)2 * RS_TILE * sizeof(uint64_t);
     ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_radix_scatter_t<512, PAIRS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     ELP_LAUNCH(c, "radix_scatter", (k_radix_scatter_t<512, PAIRS>), dim3(ntiles), dim3(512), dyn, kin, vin, kdst, vdst, n, shift, ghist, c->radix_state.p,
-               c->radix_epoch, ticket, c->err_flag.p, n_dev, fuse);
+               c->radix_epoch, ticket, c->err_flag.p, n_dev, fuse, bnd);
   } else {
     ELP_LAUNCH(c, "radix_scatter", (k_radix_scatter_t<256, PAIRS>), dim3(ntiles), dim3(256), 0, kin, vin, kdst, vdst, n, shift, ghist, c->radix_state.p,
-               c->radix_epoch, ticket, c->err_flag.p, n_dev, fuse);
+               c->radix_epoch, ticket, c->err_flag.p, n_dev, fuse, bnd);
   }
   return 0;
 }
 static int radix_scatter_launch(elp_ctx *c, uint64_t n, const uint64_t *kin, const uint32_t *vin, uint64_t *kdst, uint32_t *vdst, int shift,
-                                const unsigned long long *ghist, uint32_t *ticket, const uint32_t *n_dev) {
-  return radix_scatter_launch_t<true>(c, n, kin, vin, kdst, vdst, shift, ghist, ticket, n_dev, 0);
+                                const unsigned long long *ghist, uint32_t *ticket, const uint32_t *n_dev, RadixBounds bnd = RadixBounds{}) {
+  return radix_scatter_launch_t<true>(c, n, kin, vin, kdst, vdst, shift, ghist, ticket, n_dev, 0, bnd);
 }
 
 // The coordinate sort's own form: elements key << idx_bits | index in ONE word (the sort's key has ~31 live bits, an index 26), sorted on the
@@ -418,7 +429,7 @@ int radix_sort_fused(elp_ctx *c, const uint64_t *keycol, uint64_t n, int key_bit
 // first_src (optional): the keys are read from there by the first pass (and `keys` is only written); identity_vals: the values are
 // 0 .. n-1 and `vals` is only written
 int radix_sort_pairs_low(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *keys_tmp, uint32_t *vals_tmp, uint64_t n, int ndigits,
-                         uint64_t **keys_out, uint32_t **vals_out, const uint64_t *first_src, bool identity_vals, const uint32_t *n_dev) {
+                         uint64_t **keys_out, uint32_t **vals_out, const uint64_t *first_src, bool identity_vals, const uint32_t *n_dev, RadixBounds bnd) {
   *keys_out = keys;
   *vals_out = vals;
   if ((ndigits <= 0 || (n < 2 && !n_dev)) && !first_src && !identity_vals) return 0;
@@ -441,7 +452,8 @@ int radix_sort_pairs_low(elp_ctx *c, uint64_t *keys, uint32_t *vals, uint64_t *k
     ELP_TRY(radix_next_epoch(c));
     const uint64_t *kin = (d == 0 && first_src) ? first_src : ksrc;
     const uint32_t *vin = (d == 0 && identity_vals) ? nullptr : vsrc;
-    ELP_TRY(radix_scatter_launch(c, n, kin, vin, kdst, vdst, 8 * d, (const unsigned long long *)(ghist + d * 256), ticket + d, n_dev));
+    ELP_TRY(radix_scatter_launch(c, n, kin, vin, kdst, vdst, 8 * d, (const unsigned long long *)(ghist + d * 256), ticket + d, n_dev,
+                                 d == ndigits - 1 ? bnd : RadixBounds{}));
     std::swap(ksrc, kdst);
     std::swap(vsrc, vdst);
   }

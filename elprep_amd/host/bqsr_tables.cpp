@@ -5,9 +5,10 @@
 //   initializeCombinedBQSRTable (:655-674), quantisation (:746-899), estimateHierarchicalBayesianQuality (:901-919),
 //   the quality mapping of ApplyBQSR (:959-999), PrintBQSRTables (filters/print-bqsr.go:49-298).
 //
-// Go's math.Log10 and math.Pow are restated structurally (log2(x)*Ln2/Ln10; frexp/ldexp exponentiation) on top of libm;
-// math.Lgamma is lgamma_r (same Sun algorithm).  Where the reference iterates a Go map (initializeCombinedBQSRTable) the
-// (rg, qual) entries are visited in ascending qual.
+// Go's math.Log, math.Lgamma and math.Exp are restated from the pure-Go sources (math/log.go, lgamma.go, exp.go: ports of FreeBSD's msun),
+// math.Log10 and math.Pow structurally on top of them (log2(x) * Ln2 / Ln10; frexp / ldexp exponentiation): libm only supplies frexp,
+// ldexp, modf and sqrt, which are exact.  (math.Exp on amd64 builds of Go is an assembly kernel, not the pure-Go function: see go_exp.)
+// Where the reference iterates a Go map (initializeCombinedBQSRTable) the (rg, qual) entries are visited in ascending qual.
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -87,6 +88,29 @@ double go_lgamma_count(double x) {
   return x * (go_log(x) - 1);
 }
 
+// math.Exp as the pure-Go function computes it (math/exp.go: exp / expmulti, FreeBSD's e_exp.c): k = round(x / ln 2), r = x - k ln 2 in two
+// pieces, a degree-5 polynomial in r^2, scaled by 2^k; no contraction.  An amd64 build of Go dispatches to math/exp_amd64.s instead
+// (another reduction, FMA where the CPU has it) and can differ in the last bit: the reference itself is only bit-defined in this reading.
+double go_exp(double x) {
+  constexpr double Ln2Hi = 6.93147180369123816490e-01, Ln2Lo = 1.90821492927058770002e-10, Log2e = 1.44269504088896338700e+00,
+                   Overflow = 7.09782712893383973096e+02, Underflow = -7.45133219101941108420e+02, NearZero = 1.0 / (1 << 28),
+                   P1 = 1.66666666666666657415e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                   P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+  if (x != x || x == HUGE_VAL) return x;
+  if (x == -HUGE_VAL) return 0;
+  if (x > Overflow) return HUGE_VAL;
+  if (x < Underflow) return 0;
+  if (-NearZero < x && x < NearZero) return 1 + x;
+  int k = 0;
+  if (x < 0) k = int(Log2e * x - 0.5);
+  else if (x > 0) k = int(Log2e * x + 0.5);
+  const double hi = x - double(k) * Ln2Hi, lo = double(k) * Ln2Lo;
+  const double r = hi - lo, t = r * r;
+  const double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+  const double y = 1 - ((lo - (r * c) / (2 - c)) - hi);
+  return std::ldexp(y, k);
+}
+
 double go_pow(double x, double y) {  // finite x > 0
   if (y == 0 || x == 1) return 1;
   if (y == 1) return x;
@@ -98,7 +122,7 @@ double go_pow(double x, double y) {  // finite x > 0
   int ae = 0;
   if (yf != 0) {
     if (yf > 0.5) { yf--; yi++; }
-    a1 = std::exp(yf * go_log(x));  // (math.Exp is an assembly kernel on amd64 whose last bit depends on the CPU: libm stands in)
+    a1 = go_exp(yf * go_log(x));
   }
   int xe;
   double x1 = std::frexp(x, &xe);
@@ -806,7 +830,7 @@ char *elp_bqsr_tables_report(const elp_bqsr_tables *t, const char *const *names,
 void elp_host_free(void *p) { std::free(p); }
 
 // ---------------------------------------------------------------- duplication metrics (filters/mark-optical-duplicates.go:527-699)
-static double f_lib(double x, double c, double n) { return c / x - 1 + std::exp(-n / x); }
+static double f_lib(double x, double c, double n) { return c / x - 1 + go_exp(-n / x); }
 static long long estimate_library_size(long long n_pairs, long long n_unique) {
   const double n = double(n_pairs), c = double(n_unique);
   if (n_pairs > 0 && n_pairs - n_unique > 0) {
@@ -884,7 +908,7 @@ char *elp_dup_metrics_report_hist(const int64_t *ctr, const int64_t *hist, int h
     o.f("## HISTOGRAM\tjava.lang.Double\n");
     o.f("BIN\tCoverageMult\tall_sets\toptical_sets\tnon_optical_sets\n");
     for (int x = 1; x <= 100; x++) {  // histogramRoi / estimateRoi :576-588
-      const double roi = double(ls) * (1.0 - std::exp(-double(int64_t(x) * n_pairs) / double(ls))) / double(n_unique);
+      const double roi = double(ls) * (1.0 - go_exp(-double(int64_t(x) * n_pairs) / double(ls))) / double(n_unique);
       o.f("%d.0\t%s\t%lld\t%lld\t%lld\n", x, format_float(roi).c_str(), at(h0, x), at(h2, x), at(h1, x));
     }
     for (int b = 101; b < hist_len; b++)  // set sizes beyond 100 that occur (the reference sorts its map keys, :659-697)

@@ -52,6 +52,8 @@ def lib() -> C.CDLL:
         L.orc_go_pow10.argtypes = [C.c_double]
         L.orc_go_log.restype = C.c_double
         L.orc_go_log.argtypes = [C.c_double]
+        L.orc_go_exp.restype = C.c_double
+        L.orc_go_exp.argtypes = [C.c_double]
         L.orc_go_lgamma.restype = C.c_double
         L.orc_go_lgamma.argtypes = [C.c_double]
         L.orc_bayesian_estimate.restype = C.c_uint8
@@ -325,6 +327,11 @@ def go_pow10(y: float) -> float:
 def go_log(x: float) -> float:
     """math.Log as Go computes it on amd64 (orc_gomath.c)"""
     return float(lib().orc_go_log(x))
+
+
+def go_exp(x: float) -> float:
+    """Go's math.Exp, the pure-Go function (oracle/orc_gomath.c)"""
+    return float(lib().orc_go_exp(x))
 
 
 def go_lgamma(x: float) -> float:

@@ -146,6 +146,7 @@ void orc_free(void *p);
 double orc_go_log10(double x);
 double orc_go_pow10(double y);  /* math.Pow(10, y) */
 double orc_go_log(double x);     /* math.Log as Go computes it on amd64 (math/log.go), orc_gomath.c */
+double orc_go_exp(double x);     /* math.Exp, the pure-Go function (math/exp.go); amd64 builds of Go run an assembly kernel instead: orc_gomath.c */
 double orc_go_lgamma(double x);  /* math.Lgamma for x > 0 (math/lgamma.go) */
 int orc_gomath_selfcheck(void);  /* 0 if the constants of orc_go_log have the bit patterns the Go source prints */
 uint8_t orc_bayesian_estimate(int64_t observations, int64_t mismatches, double prior);

@@ -734,7 +734,7 @@ static double go_pow(double x, double y) {
   int ae = 0;
   if (yf != 0) {
     if (yf > 0.5) { yf--; yi++; }
-    a1 = exp(yf * orc_go_log(x));  /* (math.Exp: libm, see orc_gomath.c) */
+    a1 = orc_go_exp(yf * orc_go_log(x));  /* (math.Exp: the pure-Go function, see orc_gomath.c for the amd64 caveat) */
   }
   int xe;
   double x1 = frexp(x, &xe);

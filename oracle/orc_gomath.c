@@ -6,9 +6,13 @@
  * in the last bit of a log-likelihood - and that bit decides an argmax over 61 bins.  The algorithms below follow the Go sources
  * statement by statement: same constants (checked against the bit patterns the sources print next to them, orc_gomath_selfcheck),
  * same operation order, no fused multiply-add (-ffp-contract=off; Go does not fuse on amd64).
- * math.Exp is NOT restated: on amd64 Go runs an assembly kernel (math/exp_amd64.s) whose result depends on the CPU's FMA support, so the
- * reference itself is not defined to the last bit there; libm's exp stands in (it feeds math.Pow's fractional part and the
- * library-size estimate's printed text, never a tie that the tests could see).  Only tests may call this file. */
+ * math.Exp (round 6, VERDICT r5 next #3c): restated from the PURE-GO function (math/exp.go: exp / expmulti, a port of FreeBSD's e_exp.c) - what
+ * Go runs on every architecture without an assembly kernel and the reading of the reference that is defined to the last bit.  CAVEAT: on
+ * amd64 Go dispatches math.Exp to an assembly kernel (math/exp_amd64.s: another argument reduction and a Remez polynomial evaluated with
+ * FMA where the CPU has it), so an elPrep binary built for amd64 can differ from this function in the last bit of exp - it feeds math.Pow's
+ * fractional part (qualities that are not integers: none on the paths the tests reach - phred / -10 of an integer quality has a fractional
+ * part, but every consumer rounds the result) and the library-size estimate's printed text.  arm64 / ppc64 / s390x builds fuse the
+ * multiply-adds of the pure-Go function; this restatement is the unfused reading (-ffp-contract=off).  Only tests may call this file. */
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
@@ -40,6 +44,35 @@ double orc_go_log(double x) {
   const double t2 = s4 * (L2 + s4 * (L4 + s4 * L6));
   const double R = t1 + t2, hfsq = 0.5 * f * f;
   return k * Ln2Hi - ((hfsq - (s * (hfsq + R) + k * Ln2Lo)) - f);
+}
+
+/* math/exp.go: func exp(x float64) float64 (the pure-Go function) */
+static double go_expmulti(double hi, double lo, int k) {
+  static const double P1 = 1.66666666666666657415e-01, /* 0x3FC55555; 0x55555555 */
+      P2 = -2.77777777770155933842e-03,                /* 0xBF66C16C; 0x16BEBD93 */
+      P3 = 6.61375632143793436117e-05,                 /* 0x3F11566A; 0xAF25DE2C */
+      P4 = -1.65339022054652515390e-06,                /* 0xBEBBBD41; 0xC5D26BF1 */
+      P5 = 4.13813679705723846039e-08;                 /* 0x3E663769; 0x72BEA4D0 */
+  const double r = hi - lo;
+  const double t = r * r;
+  const double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+  const double y = 1 - ((lo - (r * c) / (2 - c)) - hi);
+  return ldexp(y, k);
+}
+double orc_go_exp(double x) {
+  static const double Log2e = 1.44269504088896338700e+00, Overflow = 7.09782712893383973096e+02, Underflow = -7.45133219101941108420e+02,
+                      NearZero = 1.0 / (1 << 28);
+  if (x != x || x == INFINITY) return x;
+  if (x == -INFINITY) return 0;
+  if (x > Overflow) return INFINITY;
+  if (x < Underflow) return 0;
+  if (-NearZero < x && x < NearZero) return 1 + x;
+  int k = 0;
+  if (x < 0) k = (int)(Log2e * x - 0.5);
+  else if (x > 0) k = (int)(Log2e * x + 0.5);
+  const double hi = x - (double)k * Ln2Hi;
+  const double lo = (double)k * Ln2Lo;
+  return go_expmulti(hi, lo, k);
 }
 
 static const double lgamA[12] = {7.72156649015328655494e-02, 3.22467033424113591611e-01, 6.73523010531292681824e-02, 2.05808084325167332806e-02,

@@ -768,7 +768,7 @@ int orc_dup_metrics_mt(const orc_batch *b, const orc_header *h, const uint32_t *
 
 /* :537-569 */
 #include <math.h>
-static double f_lib(double x, double c, double n) { return c / x - 1 + exp(-n / x); }
+static double f_lib(double x, double c, double n) { return c / x - 1 + orc_go_exp(-n / x); } /* (math.Exp: the pure-Go function, orc_gomath.c) */
 int64_t orc_estimate_library_size(int64_t n_pairs, int64_t n_unique_pairs) {
   double n = (double)n_pairs, c = (double)n_unique_pairs;
   int64_t dups = n_pairs - n_unique_pairs;

@@ -36,6 +36,36 @@ def test_go_log_is_within_one_ulp_of_the_correctly_rounded_value():
     assert differs > 0  # Go's log is not glibc's: that is the reason the restatement exists
 
 
+def test_go_exp_is_the_pure_go_function():
+    """math/exp.go (FreeBSD's e_exp.c): < 1 ulp from the correctly rounded value, the documented special cases, the same bits in the
+    oracle's C and the host library's C++ copy (through math.Pow(10, .), the one caller the two share an entry point for) - and NOT glibc's
+    exp everywhere, which is why it is restated (round 6; the amd64 assembly caveat is in oracle/orc_gomath.c)."""
+    mp = pytest.importorskip("mpmath")
+    mp.mp.dps = 40
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([rng.uniform(-700, 700, 3000), rng.uniform(-1, 1, 3000), rng.uniform(-1e-3, 1e-3, 500), [0.0, 1.0, -1.0, 0.5, 709.0, -745.0]])
+    differs = 0
+    for x in xs:
+        x = float(x)
+        got, want = orc.go_exp(x), float(mp.exp(mp.mpf(x)))
+        assert _ulps(got, want) <= 1, (x, got, want)
+        differs += got != math.exp(x)
+    assert orc.go_exp(0.0) == 1.0 and orc.go_exp(1e-10) == 1.0 + 1e-10                      # |x| < 2^-28: 1 + x
+    assert orc.go_exp(710.0) == math.inf and orc.go_exp(-746.0) == 0.0                        # beyond Overflow / Underflow
+    assert orc.go_exp(math.inf) == math.inf and orc.go_exp(-math.inf) == 0.0 and math.isnan(orc.go_exp(math.nan))
+    assert orc.go_exp(1.0) == 2.718281828459045
+    assert differs > 0
+    # the host library's own copy of the function (elprep_amd/host/bqsr_tables.cpp: go_exp) through its one caller with an entry point of
+    # its own, the library-size estimate (filters/mark-optical-duplicates.go:537-569: a bisection on exp(-n / x)), bit for bit
+    from elprep_amd.engine import dup_derived
+    for _ in range(300):
+        pairs = int(rng.integers(2, 5_000_000))
+        dups = int(rng.integers(1, pairs))
+        opt = int(rng.integers(0, dups + 1))
+        row = np.array([0, pairs, 0, 0, 0, dups, opt], np.int64)
+        assert dup_derived(row)[1] == orc.estimate_library_size(pairs - opt, pairs - dups), (pairs, dups, opt)
+
+
 def test_go_lgamma_on_counts_and_in_every_branch():
     mp = pytest.importorskip("mpmath")
     mp.mp.dps = 40

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""What the real `elprep filter` wrote, as a fixture the oracle is compared with (tools/ref/make_fixtures.sh).
-usage: collect.py <workdir with in.sam out.sam metrics.txt recal.txt case.json> <fixture.json>
-Records are identified by (QNAME, first/last/secondary/supplementary bits, RNAME, POS): the input's staging index of every output line."""
+"""What the real elprep wrote for a case of tools/ref/cases.py, as a fixture the oracle is compared with (tools/ref/make_fixtures.sh).
+usage: collect.py <workdir with in.sam out.sam case.json [metrics.txt recal.txt]> <fixture.json>
+Output records are identified by the XI:i:<staging index> field the inputs carry (elprep passes unknown optional fields through); inputs
+without it (round 5's) by (QNAME, first/last/secondary/supplementary bits, RNAME, POS, CIGAR), a CleanSam case by line number."""
 import hashlib
 import json
 import os
@@ -20,27 +21,49 @@ def records(path):
 
 def main():
     w, out = sys.argv[1], sys.argv[2]
+    fix = json.load(open(os.path.join(w, "case.json")))
+    in_order = fix.get("kind") == "cleansam"
+    inp = list(records(os.path.join(w, "in.sam")))
+    n = len(inp)
     index = {}
-    for i, f in enumerate(records(os.path.join(w, "in.sam"))):
-        k = key(f)
-        if k in index:
-            sys.exit(f"collect: input records {index[k]} and {i} share the identifying fields {k}")
-        index[k] = i
-    n = len(index)
-    order, flags, quals = [], [0] * n, [""] * n
-    for f in records(os.path.join(w, "out.sam")):
-        i = index[key(f)]
+    if not in_order:
+        for i, f in enumerate(inp):
+            k = key(f)
+            if k in index:
+                # (the hand-derived cases hold records that agree in all identifying fields - the same read staged twice: told apart by
+                # their remaining fields, else by their order among equals, which a stable sort keeps)
+                index[k] = index[k] if isinstance(index[k], list) else [index[k]]
+                index[k].append(i)
+            else:
+                index[k] = i
+    order, flags, quals, mapq, cigar = [], [0] * n, [""] * n, [0] * n, [""] * n
+    taken = {}
+    for ln, f in enumerate(records(os.path.join(w, "out.sam"))):
+        xi = [t for t in f[11:] if t.startswith("XI:i:")]
+        if xi:  # the staging index travels with the record (tools/ref/cases.py: sam_line)
+            i = int(xi[0][5:])
+        elif in_order:
+            i = ln
+        else:
+            i = index[key(f)]
+            if isinstance(i, list):
+                t = taken.get(key(f), 0)
+                taken[key(f)] = t + 1
+                i = i[t]
         order.append(i)
         flags[i] = int(f[1])
+        mapq[i] = int(f[4])
+        cigar[i] = f[5]
         quals[i] = f[10]
-    fix = json.load(open(os.path.join(w, "case.json")))
+    rd = lambda p: open(os.path.join(w, p)).read() if os.path.exists(os.path.join(w, p)) else None
     fix.update({
         "order": order,                      # output line -> staging index (records dropped by the pipeline are absent)
         "flags": flags,                      # by staging index (0 for dropped records)
+        "mapq": mapq, "cigar": cigar,        # by staging index, as the output carries them
         "qual_sha256": hashlib.sha256("\n".join(quals).encode()).hexdigest(),
         "qual_head": quals[:8],
-        "metrics_txt": open(os.path.join(w, "metrics.txt")).read(),
-        "recal_txt": open(os.path.join(w, "recal.txt")).read(),
+        "metrics_txt": rd("metrics.txt"),
+        "recal_txt": rd("recal.txt"),
     })
     json.dump(fix, open(out, "w"))
     print(f"collect: {len(order)} of {n} records in the output, {sum(1 for x in flags if x & 0x400)} duplicates -> {out}")
