@@ -588,9 +588,11 @@ int elp_emit_sorted_bam(elp_ctx *c, uint8_t *out, uint64_t cap, uint64_t *n_byte
   return emit_stream(c, m, m, nullptr, c->n - c->n_sr, c->max_raw_rec, out, cap, n_bytes_out);
 }
 
-// The same records as BGZF blocks (utils/bgzf/bgzf-files.go:324-383 at compression level 0: stored DEFLATE blocks of at most 65280 bytes,
-// CRC-32 and ISIZE per block, framed on the device): what follows a BAM file's header blocks; the host appends the 28-byte end-of-file
-// block (:53-62).  Inflating the blocks gives elp_emit_sorted_bam's bytes.
+// The same records as BGZF blocks (utils/bgzf/bgzf-files.go:324-383): members of at most 65280 input bytes, COMPRESSED on the device since
+// round 5 (bgzf.hip: strip-parallel LZ77 + fixed-Huffman DEFLATE; the reference writes compress/flate's default level with dynamic codes -
+// its files are ~7 % smaller, the bytes inside are the same; `elp_set_tuning "bgzf_stored"` = 1 keeps round 4's stored blocks), CRC-32 and
+// ISIZE per member, framed on the device: what follows a BAM file's header blocks; the host appends the 28-byte end-of-file block (:53-62).
+// Inflating the members gives elp_emit_sorted_bam's bytes.
 int elp_emit_sorted_bgzf(elp_ctx *c, uint8_t *out, uint64_t cap, uint64_t *n_bytes_out) {
   if (!c || !n_bytes_out) return ELP_ERR_ARG;
   ELP_HIP(c, hipSetDevice(c->device));

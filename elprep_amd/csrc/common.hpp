@@ -177,6 +177,8 @@ struct elp_ctx {
   int (*p2p)(void *, int, const void *, size_t, int, void *, size_t) = nullptr;  // caller's send-receive (elp_group_set_p2p)
   void *p2p_user = nullptr;
   int group_rank = 0, group_world = 1;
+  elp_ctx *group_owner = nullptr;            // elp_group_share: the context whose group this one uses ...
+  std::vector<elp_ctx *> group_borrowers;    // ... and, at the owner, the contexts that use its group (group_release takes it from them)
 
   // records staged from BAM bytes (bam.hip): the inflated records stay in HBM, elp_emit_sorted_bam reads bases and tags from them
   elp::DVec<uint8_t> raw;

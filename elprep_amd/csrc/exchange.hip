@@ -291,6 +291,10 @@ static int copy_piece(elp_ctx *dst, elp_ctx *src, const uint32_t *idx, uint64_t 
 // the group's own send-receive callback through page-locked memory (elp_group_set_p2p: a host with its own communicator, and the tests
 // on one GPU).  No rank returns while its peer still waits in a matching message: a failure on either side of a direction
 // travels in the header or the verdict, both sides then skip that direction's payload and its remaining pieces, and report the error.
+// That covers failures of the DATA (a bad index, limits, records the destination cannot take).  A failure of the machinery in mid-protocol -
+// a HIP call, the transport itself - returns at once: the message the peer waits for would have to travel through what just failed, so
+// such an error is FATAL FOR THE GROUP: the caller tears the group down (elp_group_init again, or the process), as a host
+// would after a failed ncclSend; RCCL's own watchdog / the transport's time-out is what releases the peer.
 extern "C" int elp_exchange_records(elp_ctx *src, int send_peer, const uint32_t *idx, uint64_t n, int new_split, int tag_sr, elp_ctx *dst, int recv_peer) {
   // the context that belongs to the device group: the one of the two that has a communicator / a transport
   elp_ctx *g = (src && (src->comm || src->p2p)) ? src : ((dst && (dst->comm || dst->p2p)) ? dst : (src ? src : dst));

@@ -14,6 +14,8 @@
 
 #include <rccl/rccl.h>
 
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace elp {
@@ -67,7 +69,25 @@ __global__ __launch_bounds__(256) void k_add_i64(unsigned long long *__restrict_
   if (i < n) dst[i] += src[i];
 }
 
+// (a context that borrowed the group of another - elp_group_share - must not keep a communicator its owner destroyed: the
+// owner knows its borrowers and takes the group from them when it lets go of it; a borrower signs off at its owner's)
+static std::mutex g_share_mu;
 void group_release(elp_ctx *c) {
+  {
+    std::lock_guard<std::mutex> g(g_share_mu);
+    if (c->group_owner) {
+      auto &v = c->group_owner->group_borrowers;
+      v.erase(std::remove(v.begin(), v.end(), c), v.end());
+      c->group_owner = nullptr;
+    }
+    for (elp_ctx *b : c->group_borrowers) {  // this context's group goes away: so does every borrower's view of it
+      b->comm = nullptr; b->comm_borrowed = false;
+      b->xport = nullptr; b->xport_user = nullptr; b->p2p = nullptr; b->p2p_user = nullptr;
+      b->group_rank = 0; b->group_world = 1;
+      b->group_owner = nullptr;
+    }
+    c->group_borrowers.clear();
+  }
   if (c->comm) {
     Rccl *R = rccl();
     if (R->CommDestroy && !c->comm_borrowed) (void)R->CommDestroy(static_cast<ncclComm_t>(c->comm));
@@ -179,6 +199,12 @@ int elp_group_share(elp_ctx *c, elp_ctx *member) {
   c->comm_borrowed = member->comm != nullptr;
   c->xport = member->xport; c->xport_user = member->xport_user;
   c->p2p = member->p2p; c->p2p_user = member->p2p_user;
+  {
+    std::lock_guard<std::mutex> g(g_share_mu);
+    elp_ctx *owner = member->group_owner ? member->group_owner : member;  // (a borrower's group is its owner's)
+    c->group_owner = owner;
+    owner->group_borrowers.push_back(c);
+  }
   return 0;
 }
 

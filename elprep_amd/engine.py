@@ -71,11 +71,13 @@ class Engine:
             bad = self.L.elp_debug_check_guards()  # (ELP_DEBUG_GUARD=1: a kernel wrote past the end of a device buffer; 0 otherwise)
             self.L.elp_destroy(self.h)
             self.h = C.c_void_p()
-            if bad:
-                raise RuntimeError(f"ELP_DEBUG_GUARD: {bad} device buffer(s) were written past their end (sizes on stderr)")
-        for ptr in getattr(self, "_pinned", []):
+        else:
+            bad = 0
+        for ptr in getattr(self, "_pinned", []):  # (before the guard's report: an exception must not leave page-locked memory behind)
             self.L.elp_pinned_free(ptr)
         self._pinned = []
+        if bad:
+            raise RuntimeError(f"ELP_DEBUG_GUARD: {bad} device buffer(s) were written past their end (sizes on stderr)")
 
     def pinned_zeros(self, shape, dtype) -> np.ndarray:
         """a zeroed array in page-locked host memory (elp_pinned_alloc; freed by close(), which __del__ also calls: the array dies with the
@@ -244,6 +246,7 @@ class Engine:
     def group_share(self, member: "Engine"):
         """this context uses the device group of `member` (same process and device): elp_group_share"""
         self._check(self.L.elp_group_share(self.h, member.h))
+        self._group_owner = member  # (ADVICE r5: the borrowed communicator lives in `member`: it must not be collected while this context can use it)
         if getattr(member, "_p2p_cb", None) is not None:
             self._p2p_cb = member._p2p_cb  # (keeps the callback object alive as long as either context)
 
@@ -418,16 +421,21 @@ class Engine:
         max_cycle = self._max_cycle
         qs = np.ascontiguousarray(list(quals), dtype=np.uint8)
         nc, nq, ncyc = self.header.n_cov, int(qs.size), 2 * max_cycle + 1
-        bufs = getattr(self, "_row_tables", None) if reuse else None
-        if bufs is None or bufs[0] != (nc, nq, max_cycle):
-            if bufs is not None:
-                for a in bufs[1:]:
-                    self.pinned_release(a)
-            mk = self.pinned_zeros if reuse else (lambda shape, dtype: np.zeros(shape, dtype=dtype))
-            bufs = ((nc, nq, max_cycle), mk((nc, nq, 2), np.int64), mk((nc, nq, ncyc, 2), np.int64), mk((nc, nq, NCTX, 2), np.int64))
-            if reuse:
+        if reuse:
+            #  the engine's own page-locked arrays hold room for EVERY quality's rows and are handed out as views of their leading
+            # part: the number of qualities changes from step to step, and arrays that were freed and re-made whenever it did left views a
+            # caller still held pointing at released memory; they are only re-made when the header's covariates or --max-cycle change
+            bufs = getattr(self, "_row_tables", None)
+            if bufs is None or bufs[0] != (nc, max_cycle):
+                if bufs is not None:
+                    for a in bufs[1:]:
+                        self.pinned_release(a)
+                bufs = ((nc, max_cycle), self.pinned_zeros((nc * NQUAL * 2,), np.int64), self.pinned_zeros((nc * NQUAL * ncyc * 2,), np.int64),
+                        self.pinned_zeros((nc * NQUAL * NCTX * 2,), np.int64))
                 self._row_tables = bufs
-        _, qr, cr, xr = bufs
+            qr, cr, xr = bufs[1][:nc * nq * 2].reshape(nc, nq, 2), bufs[2][:nc * nq * ncyc * 2].reshape(nc, nq, ncyc, 2), bufs[3][:nc * nq * NCTX * 2].reshape(nc, nq, NCTX, 2)
+        else:
+            qr, cr, xr = np.zeros((nc, nq, 2), np.int64), np.zeros((nc, nq, ncyc, 2), np.int64), np.zeros((nc, nq, NCTX, 2), np.int64)
         rc = self.L.elp_bqsr_tables_fetch_rows(self.h, _vp(qs), nq, _vp(qr), _vp(cr), _vp(xr))
         if rc == 1:
             return None

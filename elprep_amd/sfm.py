@@ -393,20 +393,22 @@ class SfmRank:
             self.engines[which].stage(b)
             self.n[which] += b.n
 
-    def route(self, b: Batch, group_of_ref: np.ndarray, n_groups: int, owner: np.ndarray):
+    def route(self, b: Batch, group_of_ref: np.ndarray, n_groups: int, owner: np.ndarray, stage=None):
         """the split phase for one batch of input records through the C ABI (route_device): staged into the rank's reader context,
         classified on the device, delivered device to device to the contexts of the ranks that own the splits.  Every rank calls it the
-        same number of times."""
+        same number of times.  stage(reader, batch): how the batch enters the reader (route_device; a BAM reader: elp_stage_bam)."""
         from .engine import Engine
         if self.reader is None:
             self.reader = Engine(self.header, self._device_ordinal)
+            if self.header.rg_ids:
+                self.reader.set_read_group_ids(self.header.rg_ids)
             if self.comm.world > 1:
                 if self.collective == "cabi":
                     self.reader.group_share(self.engines[0])  # RCCL send / receive on the communicator the tables are reduced on
                 else:
                     self.reader.group_init_transport(self.comm.rank, self.comm.world, lambda v: None)
                     self.reader.group_set_p2p(self.comm.sendrecv)
-        nl, ns = route_device(self.reader, b, group_of_ref, n_groups, owner, self.comm.rank, self.comm.world, self.engines[0], self.engines[1])
+        nl, ns = route_device(self.reader, b, group_of_ref, n_groups, owner, self.comm.rank, self.comm.world, self.engines[0], self.engines[1], stage)
         self.n[0] += nl
         self.n[1] += ns
 
@@ -540,6 +542,24 @@ class SfmRank:
         for e in self.engines:
             e.apply_bqsr(lut, present, max_cycle, fetch=False)
 
+    def emit_merged(self, group_of_ref: np.ndarray, n_groups: int, owner: np.ndarray) -> np.ndarray:
+        """the merge phase of this rank (emit_merged_device): the BAM records of its contig groups' output with the spread reads of those
+        groups inserted - every context of the rank that sends or receives joins the device group first (the communicator the tables were
+        reduced on, or the send-receive callback).  The records must have been staged from BAM bytes (route(..., stage=...))."""
+        from .engine import Engine
+        if getattr(self, "_part", None) is None:
+            self._part = Engine(self.header, self._device_ordinal)
+            if self.header.rg_ids:
+                self._part.set_read_group_ids(self.header.rg_ids)
+            if self.comm.world > 1:
+                for e in (self._part, self.engines[1]):
+                    if self.collective == "cabi":
+                        e.group_share(self.engines[0])
+                    else:
+                        e.group_init_transport(self.comm.rank, self.comm.world, lambda v: None)
+                        e.group_set_p2p(self.comm.sendrecv)
+        return emit_merged_device(self.engines[0], self.engines[1], self._part, group_of_ref, n_groups, owner, self.comm.rank, self.comm.world)
+
     def close(self):
         if self._side is not None:
             self._side.shutdown()
@@ -547,5 +567,8 @@ class SfmRank:
         if self.reader is not None:
             self.reader.close()
             self.reader = None
+        if getattr(self, "_part", None) is not None:
+            self._part.close()
+            self._part = None
         for e in self.engines:
             e.close()

@@ -1,0 +1,160 @@
+"""Round 6 (-m gpu): the whole `elprep sfm` path between two RANKS that are two PROCESSES - split phase
+(sfm.route_device: elp_split_classify, elp_copy_records, elp_exchange_records), mark duplicates / metrics / BQSR count per split, THE
+all-reduce of tables + counters, finalisation, ApplyBQSR, merge phase (sfm.emit_merged_device) - every output compared with the oracle run
+split by split.  With a GPU per rank the records travel by ncclSend / ncclRecv and the tables by ncclAllReduce (RCCL over xGMI, through
+the C ABI's device group); on a box with ONE GPU the same code runs with both ranks on it and the transport swapped (the group's
+send-receive callback and torch.distributed over gloo).  And `bench.py --gpus 2` as the driver launches it."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle as orc
+from elprep_amd import sfm
+from elprep_amd.batch import Batch
+from tests import sfm_worker
+from tests.test_sfm_cpu import _merge_reference
+from tools import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _backend(world):
+    import torch
+    return "nccl" if torch.cuda.device_count() >= world else "gloo"
+
+
+def _bam_fields(buf):
+    """(refid, 1-based pos, flag, qname, qual bytes) of every record of a BAM record stream"""
+    out, p = [], 0
+    while p < buf.size:
+        size = int(buf[p:p + 4].view(np.uint32)[0])
+        rec = buf[p + 4:p + 4 + size]
+        refid, pos = (int(x) for x in rec[0:8].view(np.int32))
+        l_name, n_cig, flag, l_seq = int(rec[8]), int(rec[12:14].view(np.uint16)[0]), int(rec[14:16].view(np.uint16)[0]), int(rec[16:20].view(np.uint32)[0])
+        name = rec[32:32 + l_name - 1].tobytes()
+        q0 = 32 + l_name + 4 * n_cig + (l_seq + 1) // 2
+        out.append((refid, pos + 1, flag, name, rec[q0:q0 + l_seq].tobytes()))
+        p += 4 + size
+    return out
+
+
+def test_sfm_two_ranks_as_two_processes_whole_path(tmp_path):
+    world = 2
+    backend = _backend(world)
+    port = str(_free_port())
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "sfm_gpu_worker.py"), str(r), str(world), port, str(tmp_path), backend],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    res = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    assert bytes(res[0]["collective"]).decode() == ("cabi" if backend == "nccl" else "torch"), outs
+    inputs = [sfm.unpack_batch(res[r]["input"]) for r in range(world)]
+    cfg, gof, G, owner, _ = sfm_worker.make_rank_input(0, world, pairs_per_rank=2500)
+    h = cfg.header()
+    refs = [synth.reference(cfg, r) for r in range(h.n_ref)]
+    sites = [orc.flatten(orc.sort_by_start(synth.known_sites_raw(cfg, r))) for r in range(h.n_ref)]
+    so = int(owner[G + 1])  # the spread split's owner
+    # what arrives where, in arrival order: per routing round a rank's own records, then the other rank's
+    halves = [[b.take(np.arange(b.n // 2)), b.take(np.arange(b.n // 2, b.n))] for b in inputs]
+    want_local, want_spread = [[] for _ in range(world)], []
+    for k in range(2):
+        for r in range(world):
+            for src in (r, 1 - r):
+                bb = halves[src][k]
+                g, sp = sfm.split_records(bb, gof)
+                idx = np.nonzero(owner[g] == r)[0]
+                if idx.size:
+                    want_local[r].append(sfm.with_sr(bb, sp, g).take(idx))
+                if r == so and sp.any():
+                    want_spread.append(sfm.with_sr(bb, np.zeros(bb.n, bool), np.zeros(bb.n, np.uint16)).take(np.nonzero(sp)[0]))
+    parts = {(r, 0): Batch.concat(want_local[r]) for r in range(world)}
+    for r in range(world):
+        parts[(r, 1)] = Batch.concat(want_spread) if r == so else sfm.empty_batch()
+    assert parts[(so, 1)].n > 50 and sum(int(p.has_sr.sum()) for p in parts.values()) > 50
+    # ---- the oracle: split file by split file (one `filter` run each, cmd/sfm.go), tables and counters summed
+    oq = oc = ox = octr = None
+    oflags, operms = {}, {}
+    for key, p in parts.items():
+        if p.n == 0:
+            continue
+        oflags[key] = np.zeros(p.n, np.uint16)
+        order = []
+        for sid in np.unique(p.split):
+            sel = np.nonzero(p.split == sid)[0]
+            sub = p.take(sel)
+            perm = orc.sort_coordinate(sub, orc.mark_duplicates(sub, h))
+            fl, c7, _ = orc.dup_metrics(sub, h, perm, 100)
+            q, c, x = orc.bqsr_gather(sub, h, orc.BqsrRef(refs, sites), fl, 500)
+            oflags[key][sel] = fl
+            order.append((int(sid), sel[perm[:orc.num_sorted(sub)]]))
+            oq, oc, ox, octr = (q, c, x, c7) if oq is None else (oq + q, oc + c, ox + x, octr + c7)
+        operms[key] = np.concatenate([o for sid, o in sorted(order, key=lambda t: (t[0] == 0, t[0]))])
+    fin = orc.BqsrFinal(oq, oc, ox, 500)
+    oqual = {key: fin.apply(p, h, 0) for key, p in parts.items() if p.n}
+    for r in range(world):
+        assert np.array_equal(res[r]["qt"], oq) and np.array_equal(res[r]["ct"], oc) and np.array_equal(res[r]["xt"], ox), ("tables", r)
+        assert np.array_equal(res[r]["ctr"], octr), ("counters", r)
+        for w in (0, 1):
+            p = parts[(r, w)]
+            assert int(res[r][f"n{w}"][0]) == p.n, ("records that arrived", r, w)
+            if p.n:
+                assert np.array_equal(res[r][f"flags{w}"], oflags[(r, w)]), ("flags", r, w)
+                assert np.array_equal(res[r][f"perm{w}"], operms[(r, w)]), ("order", r, w)
+                assert np.array_equal(res[r][f"qual{w}"], oqual[(r, w)]), ("qualities", r, w)
+    # ---- the merge phase: every rank's stream = its groups' output with the spread reads of those groups inserted (sam/split-merge.go:519-549)
+    wsp = parts[(so, 1)]
+    sorder = operms[(so, 1)]
+    sgroup = gof[wsp.refid[sorder]]
+
+    def fields(p, i, flags, qual):
+        return (int(p.refid[i]), int(p.pos[i]), int(flags[i]), p.qname_of(int(i)), qual[int(p.qual_off[i]):int(p.qual_off[i + 1])].tobytes())
+    n_spread_inserted = 0
+    for r in range(world):
+        loc, lorder = parts[(r, 0)], operms[(r, 0)]
+        keys = [(int(loc.refid[i]), int(loc.pos[i])) for i in lorder]
+        n_mapped = sum(1 for k in keys if k[0] >= 0)
+        mine = np.nonzero(owner[sgroup] == r)[0]  # the spread reads of this rank's contig groups, in the spread file's order
+        skeys = [(int(wsp.refid[sorder[j]]), int(wsp.pos[sorder[j]])) for j in mine]
+        codes = _merge_reference(keys[:n_mapped], skeys)
+        want = [fields(loc, lorder[c], oflags[(r, 0)], oqual[(r, 0)]) if c >= 0 else fields(wsp, sorder[mine[-c - 1]], oflags[(so, 1)], oqual[(so, 1)]) for c in codes]
+        want += [fields(loc, i, oflags[(r, 0)], oqual[(r, 0)]) for i in lorder[n_mapped:]]
+        got = _bam_fields(res[r]["merged"])
+        assert len(got) == len(want), (r, len(got), len(want))
+        first = next((k for k, (a, c) in enumerate(zip(got, want)) if a != c), None)
+        assert first is None, (r, "first difference at", first, got[first][:4], want[first][:4])
+        n_spread_inserted += len(mine)
+    assert n_spread_inserted == len(sorder) > 50
+
+
+@pytest.mark.fresh_only
+def test_bench_with_two_ranks_as_the_driver_launches_it(tmp_path):
+    """python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2: the N > 1 line (one rank per GPU over RCCL where there are two
+    GPUs; ELP_BENCH_BACKEND=gloo with both ranks on the one GPU otherwise)"""
+    world = 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if _backend(world) == "gloo":
+        env["ELP_BENCH_BACKEND"] = "gloo"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--reads", "600000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    line = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(line) == 1, p.stdout.decode()[-2000:]
+    d = json.loads(line[0])
+    assert d["n_gpus"] == world and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["config"]["workload"] and "roofline" in d
