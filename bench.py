@@ -103,11 +103,17 @@ def summarize(prof, steps, n_reads, full_bytes):
     for name, (cnt, ms) in prof.items():
         st = kernel_stage(name)
         stage_ms[st] = stage_ms.get(st, 0.0) + ms / steps
+    # round 6: mark duplicates' front pass (md_front) also does the adapt stage's fixed-field part (unclipped positions, sort keys: the
+    # 35 bytes per read SURVEY 8(d) budgets under "adapt" next to the 150 QUAL bytes of the score): its time is booked under markdup, so
+    # the bytes go there too - the stages' sum, and the path's, do not change
+    bpr = dict(BYTES_PER_READ)
+    if any(k.endswith("md_front") for k in prof):
+        bpr["adapt"], bpr["markdup"] = BYTES_PER_READ["adapt"] - 35, BYTES_PER_READ["markdup"] + 35
     dom = max(prof.items(), key=lambda kv: kv[1][1])[0]
     dom_stage = kernel_stage(dom)
     launches_per_step = max(prof[dom][0] / steps, 1)
     dom_ms_per_step = prof[dom][1] / steps
-    achieved = (BYTES_PER_READ.get(dom_stage, 0) * n_reads) / (dom_ms_per_step * 1e-3) / 1e9 if dom_ms_per_step > 0 else 0.0
+    achieved = (bpr.get(dom_stage, 0) * n_reads) / (dom_ms_per_step * 1e-3) / 1e9 if dom_ms_per_step > 0 else 0.0
     kernel_total_ms = sum(stage_ms.values())
     traffic = None
     try:
@@ -116,8 +122,11 @@ def summarize(prof, steps, n_reads, full_bytes):
             traffic = round(tj["bytes_per_read"][dom] * n_reads)
     except Exception:
         traffic = None
-    stage_frac = {st: round(BYTES_PER_READ[st] * n_reads / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for st, ms in sorted(stage_ms.items())
-                  if st in BYTES_PER_READ and ms > 0}
+    stage_frac = {st: round(bpr[st] * n_reads / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for st, ms in sorted(stage_ms.items())
+                  if st in bpr and ms > 0}
+    if "adapt" in stage_ms and "markdup" in stage_ms:  # the two stages the front pass joins, as one figure whatever the booking
+        both = stage_ms["adapt"] + stage_ms["markdup"]
+        stage_frac["adapt+markdup"] = round((BYTES_PER_READ["adapt"] + BYTES_PER_READ["markdup"]) * n_reads / (both * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     roof = {"bound": "hbm", "kernel": dom, "stage": dom_stage, "launches_per_step": launches_per_step, "kernel_ms_per_step": round(dom_ms_per_step, 4),
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
@@ -125,7 +134,7 @@ def summarize(prof, steps, n_reads, full_bytes):
             # flatters, next to it on purpose
             "frac_of_whole_stage": stage_frac.get(dom_stage), "traffic": traffic,
             "traffic_source": "profiles/traffic.json: rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE) of an 8 M-read run of this path, per read, scaled to this run's reads - not measured in this run",
-            "stage_frac": stage_frac,
+            "stage_frac": stage_frac, "stage_bytes_per_read": bpr,
             "path_frac": round((full_bytes * n_reads / (kernel_total_ms * 1e-3) / 1e9) / HBM_PEAK_GBS, 5) if kernel_total_ms else None}
     kern = {k: round(v[1] / steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:28]}
     return {k: round(v, 3) for k, v in sorted(stage_ms.items())}, kern, roof
@@ -212,6 +221,8 @@ def main():
     workers = max(1, min(12, effective_cores() // max(world, 1)))
     chunk = 1_000_000
     host_pool = ThreadPoolExecutor(1)
+    metrics_pool = ThreadPoolExecutor(1)
+    serial_metrics = os.environ.get("ELP_BENCH_SERIAL_METRICS") == "1"  # (A/B: the metrics pass behind the sort, as until round 5)
 
     def generated(jobs):
         """yield the batches of `jobs` = [(config, pair_lo, pair_hi), ...] in order; the generator is deterministic per pair index,
@@ -274,8 +285,15 @@ def main():
             # the host finalises while the GPU sorts and counts (the reference runs them one after the other, cmd/filter.go:162-196;
             # its sort is the pipeline's Finalize and needs nothing of BQSR either)
             fin = host_pool.submit(finalize_lut)
-            eng.sort_coordinate(fetch=False)
-            eng.dup_metrics(100)
+            if serial_metrics:
+                eng.sort_coordinate(fetch=False)
+                eng.dup_metrics(100)
+            else:
+                # round 6: the duplication-metrics pass runs on the context's side lane (a stream and scratch of its own, elp_dup_metrics):
+                # a second host thread drives its ~25 small launches and five read-backs while this one drives the sort
+                mx = metrics_pool.submit(eng.dup_metrics, 100)
+                eng.sort_coordinate(fetch=False)
+                mx.result()
             t_dev = time.perf_counter()
             fin.result()
             wait_ms.append((time.perf_counter() - t_dev) * 1e3)  # what the device's sort + metrics did not hide of the host's finalisation

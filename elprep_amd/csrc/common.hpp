@@ -210,6 +210,13 @@ struct elp_ctx {
   uint32_t *mail = nullptr;
   hipEvent_t mail_ev = nullptr;
 
+  // the side lane (round 6): a shadow context with a stream, scratch pool, error words and radix workspaces of its OWN whose columns are
+  // views of this context's.  The duplication-metrics pass runs there (metrics.hip): it reads what mark duplicates left and writes nothing
+  // another stage reads, so a host may call elp_dup_metrics from a second thread while this context sorts - the pass's two dozen small
+  // launches and five read-backs then hide under the sort's kernels instead of standing behind them.
+  elp_ctx *side = nullptr;
+  hipEvent_t side_ev = nullptr;
+
   // snapshot of the mutable columns
   elp::DVec<uint16_t> snap_flag;
   elp::DVec<uint8_t> snap_qual;
@@ -450,6 +457,8 @@ int ensure_adapted(elp_ctx *c, bool check_quals = true);
 int adapt_begin(elp_ctx *c, int *pos_bits);
 int adapt_scores(elp_ctx *c);
 int mailbox(elp_ctx *c);  // ctx.hip: c->mail (1024 words, page-locked) and c->mail_ev exist
+int side_lane(elp_ctx *c, elp_ctx **out);  // ctx.hip: c->side exists; its stream waits for what is queued on c->stream now
+void prof_merge_side(elp_ctx *c);          // ctx.hip: the side lane's launch times join the context's
 constexpr int ADAPT_WORDS = 6;
 void adapt_note(elp_ctx *c, const uint32_t *words /* ADAPT_WORDS of adapt_err */);  // sort.hip: the score kernel's words were read (by whoever synchronised anyway)
 int adapt_quality_error(elp_ctx *c);

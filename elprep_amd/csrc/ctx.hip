@@ -176,6 +176,51 @@ int mailbox(elp_ctx *c) {
   if (!c->mail_ev) ELP_HIP(c, hipEventCreateWithFlags(&c->mail_ev, hipEventDisableTiming));
   return 0;
 }
+int side_lane(elp_ctx *c, elp_ctx **out) {
+  if (!c->side) {
+    elp_ctx *s = new elp_ctx();
+    s->device = c->device;
+    s->n_cu = c->n_cu;
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess || ensure(s, s->err_flag, 4) != 0 ||
+        hipMemsetAsync(s->err_flag.p, 0, 16, s->stream) != hipSuccess) {
+      if (s->stream) (void)hipStreamDestroy(s->stream);
+      delete s;
+      return set_error(c, ELP_ERR_HIP, "the side lane's stream could not be made");
+    }
+    c->side = s;
+  }
+  if (!c->side_ev) ELP_HIP(c, hipEventCreateWithFlags(&c->side_ev, hipEventDisableTiming));
+  // what is queued on the context's stream up to here (mark duplicates) comes first
+  ELP_HIP(c, hipEventRecord(c->side_ev, c->stream));
+  ELP_HIP(c, hipStreamWaitEvent(c->side->stream, c->side_ev, 0));
+  c->side->profiling = c->profiling;
+  c->side->tune = c->tune;
+  *out = c->side;
+  return 0;
+}
+void prof_merge_side(elp_ctx *c) {
+  elp_ctx *s = c->side;
+  if (!s) return;
+  (void)prof_flush(s);
+  for (size_t k = 0; k < s->prof_names.size(); k++) {
+    if (!s->prof_launches[k]) continue;
+    auto it = c->prof_index.find(s->prof_names[k]);
+    int id;
+    if (it == c->prof_index.end()) {
+      id = (int)c->prof_names.size();
+      c->prof_names.push_back(s->prof_names[k]);
+      c->prof_index[s->prof_names[k]] = id;
+      c->prof_launches.push_back(0);
+      c->prof_ms.push_back(0.0);
+    } else {
+      id = it->second;
+    }
+    c->prof_launches[id] += s->prof_launches[k];
+    c->prof_ms[id] += s->prof_ms[k];
+    s->prof_launches[k] = 0;
+    s->prof_ms[k] = 0.0;
+  }
+}
 int radix_check(elp_ctx *c) {
   if (!c->radix_check_pending) return 0;
   uint32_t e[4];
@@ -222,6 +267,14 @@ void elp_destroy(elp_ctx *c) {
   for (auto p : c->h_sites) if (p) (void)hipFree(p);
   for (auto p : c->h_site_idx) if (p) (void)hipFree(p);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+  if (c->side) {  // (its columns are views that were taken back when the pass that used them returned: it owns its scratch only)
+    (void)elp::stream_wait(c->side->stream);
+    for (auto &p : c->side->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    (void)hipStreamDestroy(c->side->stream);
+    delete c->side;
+    c->side = nullptr;
+  }
+  if (c->side_ev) (void)hipEventDestroy(c->side_ev);
   if (c->mail) (void)hipHostFree(c->mail);
   if (c->mail_ev) (void)hipEventDestroy(c->mail_ev);
   for (int k = 0; k < 2; k++) {
@@ -530,13 +583,15 @@ int elp_set_tuning(elp_ctx *c, const char *key, int64_t value) {
 
 int elp_profile_enable(elp_ctx *c, int on) {
   if (!c) return ELP_ERR_ARG;
-  if (!on) ELP_TRY(prof_flush(c));
+  if (!on) { ELP_TRY(prof_flush(c)); prof_merge_side(c); }
   c->profiling = on != 0;
+  if (c->side) c->side->profiling = c->profiling;
   return 0;
 }
 int elp_profile_reset(elp_ctx *c) {
   if (!c) return ELP_ERR_ARG;
   ELP_TRY(prof_flush(c));
+  prof_merge_side(c);
   for (auto &v : c->prof_launches) v = 0;
   for (auto &v : c->prof_ms) v = 0.0;
   return 0;
@@ -544,6 +599,7 @@ int elp_profile_reset(elp_ctx *c) {
 int elp_profile_count(elp_ctx *c) {
   if (!c) return ELP_ERR_ARG;
   if (prof_flush(c) != 0) return ELP_ERR_HIP;
+  prof_merge_side(c);
   return (int)c->prof_names.size();
 }
 int elp_profile_get(elp_ctx *c, int index, const char **name, uint64_t *launches, double *total_ms) {

@@ -624,14 +624,39 @@ static int metrics_impl(elp_ctx *c, int dist, int64_t *counters_host, int64_t *h
 
 }  // namespace elp
 
+namespace elp {
+// The pass on the context's side lane (common.hpp): the shadow context sees the columns the pass reads as VIEWS for the duration of the
+// call (they are taken back whatever happens: the shadow owns nothing but its scratch), runs on its own stream behind what the context's
+// stream holds now, and returns when its own stream is done - the context's stream never waits for it.
+static int metrics_on_side(elp_ctx *c, int dist, int64_t *counters_host, int64_t *hist_host, int hist_len) {
+  if (!c->marked) return set_error(c, ELP_ERR_ARG, "elp_dup_metrics: call elp_mark_duplicates first");
+  // (the time-out word of mark duplicates' radix passes is the context's: whoever reads its error words next - the sort's last read-back,
+  // elp_sync, elp_get_flags - reports it; reading it here would wait for the context's whole stream)
+  elp_ctx *s = nullptr;
+  ELP_TRY(side_lane(c, &s));
+  s->n = c->n; s->n_lib = c->n_lib; s->n_rg = c->n_rg; s->n_ref = c->n_ref; s->max_split = c->max_split; s->marked = c->marked;
+  s->n_sr = c->n_sr; s->n_filtered = c->n_filtered;
+  s->flag.p = c->flag.p; s->rgid.p = c->rgid.p; s->rg_lib.p = c->rg_lib.p; s->refid.p = c->refid.p; s->qname_off.p = c->qname_off.p; s->qname.p = c->qname.p;
+  s->pair_win.p = c->pair_win.p; s->mate.p = c->mate.p; s->has_sr.p = c->has_sr.p; s->upos.p = c->upos.p; s->split.p = c->split.p;
+  const int rc = metrics_impl(s, dist, counters_host, hist_host, hist_len);
+  s->flag.p = nullptr; s->rgid.p = nullptr; s->rg_lib.p = nullptr; s->refid.p = nullptr; s->qname_off.p = nullptr; s->qname.p = nullptr;
+  s->pair_win.p = nullptr; s->mate.p = nullptr; s->has_sr.p = nullptr; s->upos.p = nullptr; s->split.p = nullptr;
+  if (rc != 0) {
+    (void)elp::stream_wait(s->stream);
+    c->err = s->err;
+  }
+  return rc;
+}
+}  // namespace elp
+
 extern "C" int elp_dup_metrics(elp_ctx *c, int optical_pixel_distance, int64_t *counters) {
   if (!c || !counters) return ELP_ERR_ARG;
   ELP_HIP(c, hipSetDevice(c->device));
-  return elp::metrics_impl(c, optical_pixel_distance, counters, nullptr, 0);
+  return elp::metrics_on_side(c, optical_pixel_distance, counters, nullptr, 0);
 }
 
 extern "C" int elp_dup_metrics_hist(elp_ctx *c, int optical_pixel_distance, int64_t *counters, int64_t *hist, int hist_len) {
   if (!c || !counters || !hist || hist_len < 2) return elp::set_error(c, ELP_ERR_ARG, "elp_dup_metrics_hist: bad arguments (hist_len >= 2)");
   ELP_HIP(c, hipSetDevice(c->device));
-  return elp::metrics_impl(c, optical_pixel_distance, counters, hist, hist_len);
+  return elp::metrics_on_side(c, optical_pixel_distance, counters, hist, hist_len);
 }

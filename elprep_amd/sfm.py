@@ -495,14 +495,24 @@ class SfmRank:
             from concurrent.futures import ThreadPoolExecutor
             self._side = ThreadPoolExecutor(1)
 
-        def count(e):
+        def count(e, pool=None):
             e.mark_duplicates(True, fetch=False)
-            c7 = e.dup_metrics(pixel_dist)
-            e.recalibrate_device(max_cycle)  # tables stay in HBM
+            if pool is not None:
+                # the metrics pass on the context's side lane (round 6: a stream and scratch of its own), driven from a thread of its own
+                # under the gather's kernels
+                mx = pool.submit(e.dup_metrics, pixel_dist)
+                e.recalibrate_device(max_cycle)  # tables stay in HBM
+                c7 = mx.result()
+            else:
+                c7 = e.dup_metrics(pixel_dist)
+                e.recalibrate_device(max_cycle)
             e.sync()
             return c7
+        if getattr(self, "_mx_pool", None) is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._mx_pool = ThreadPoolExecutor(1)
         side = self._side.submit(count, e1) if self.n[1] else None
-        ctr = count(e0)
+        ctr = count(e0, self._mx_pool)
         if side is not None:
             ctr = ctr + side.result()
             e0.tables_add(e1)
@@ -564,6 +574,9 @@ class SfmRank:
         if self._side is not None:
             self._side.shutdown()
             self._side = None
+        if getattr(self, "_mx_pool", None) is not None:
+            self._mx_pool.shutdown()
+            self._mx_pool = None
         if self.reader is not None:
             self.reader.close()
             self.reader = None
