@@ -94,7 +94,7 @@ def timed(step, restore, steps, warmup, prof_eng, barrier):
     return elapsed, prof
 
 
-def summarize(prof, steps, n_reads, full_bytes):
+def summarize(prof, steps, n_reads, full_bytes, wall_ms=None, concurrent=False):
     """per-stage kernel ms per step, the dominant kernel and its roofline figures.  `achieved` = the algorithmic bytes of the stage the
     dominant kernel belongs to (SURVEY.md 8d x the reads of the step) over the time ALL launches of that kernel take in one step (a
     kernel launched several times per step - the radix scatter - is not priced by the average of its unequal launches); `stage_frac` =
@@ -136,6 +136,15 @@ def summarize(prof, steps, n_reads, full_bytes):
             "traffic_source": "profiles/traffic.json: rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE) of an 8 M-read run of this path, per read, scaled to this run's reads - not measured in this run",
             "stage_frac": stage_frac, "stage_bytes_per_read": bpr,
             "path_frac": round((full_bytes * n_reads / (kernel_total_ms * 1e-3) / 1e9) / HBM_PEAK_GBS, 5) if kernel_total_ms else None}
+    if wall_ms:
+        roof["path_frac_wall"] = round((full_bytes * n_reads / (wall_ms * 1e-3) / 1e9) / HBM_PEAK_GBS, 5)
+    if concurrent:
+        # the stages run at once on three streams (sort, metrics, BQSR chain): every kernel's event time includes what it waited for a
+        # CU, LDS or bandwidth another stream's kernel held - the sums exceed the step and the per-stage fractions are those of CONTENDED
+        # kernels; the path's figure is the wall one, the uncontended stage table is under `serial_order`
+        roof["path_frac"] = roof.get("path_frac_wall")
+        roof["concurrent_streams"] = ("sort, duplication metrics and the BQSR chain run at once behind mark duplicates: kernel times are contended, "
+                                      "their sum exceeds the step; `path_frac` is over the step's wall time; uncontended kernels: `serial_order`")
     kern = {k: round(v[1] / steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:28]}
     return {k: round(v, 3) for k, v in sorted(stage_ms.items())}, kern, roof
 
@@ -222,7 +231,10 @@ def main():
     chunk = 1_000_000
     host_pool = ThreadPoolExecutor(1)
     metrics_pool = ThreadPoolExecutor(1)
-    serial_metrics = os.environ.get("ELP_BENCH_SERIAL_METRICS") == "1"  # (A/B: the metrics pass behind the sort, as until round 5)
+    sort_pool = ThreadPoolExecutor(1)
+    # how a step's stages are driven: "three" (default) = sort, metrics and the BQSR chain at once behind mark duplicates; "metrics" = the
+    # metrics pass under the sort, both behind the gather (round 6's first form); "serial" = one after the other, as until round 5 (A/B)
+    order = os.environ.get("ELP_BENCH_ORDER", "three")
 
     def generated(jobs):
         """yield the batches of `jobs` = [(config, pair_lo, pair_hi), ...] in order; the generator is deterministic per pair index,
@@ -277,20 +289,35 @@ def main():
                 eng.lut_upload(lut, present, MAX_CYCLE)
             host_ms.append((time.perf_counter() - t0) * 1e3)
 
-        def step_full():
+        def step_full(order=order):
             eng.mark_duplicates(True, fetch=False)
+            if order == "three":
+                # round 6: behind mark duplicates three chains need nothing of each other - the coordinate sort (the pipeline's Finalize,
+                # sam/filter-pipeline.go:116), the duplication-metrics pass, and Recalibrate -> FinalizeBQSRTables -> ApplyBQSR - and the
+                # library runs the first two on side lanes of the context (streams, scratch and error words of their own:
+                # elp_sort_coordinate, elp_dup_metrics), so a host thread each drives them while this one drives the BQSR chain.  The
+                # reference runs them one after the other (cmd/filter.go:162-196); what the step does is the same.
+                st = sort_pool.submit(eng.sort_coordinate, False)
+                mx = metrics_pool.submit(eng.dup_metrics, 100)
+                eng.recalibrate_device(MAX_CYCLE)
+                finalize_lut()
+                wait_ms.append(0.0)
+                eng.apply_bqsr(None, None, MAX_CYCLE, fetch=False)
+                st.result()
+                mx.result()
+                eng.sync()
+                return
             eng.recalibrate_device(MAX_CYCLE)
             # the tables' way to the host, the float64 finalisation + LUT (host thread; the copy runs on the context's copy stream) on one
             # side, the coordinate sort and the duplication-metrics pass (device, this thread) on the other do not depend on each other:
             # the host finalises while the GPU sorts and counts (the reference runs them one after the other, cmd/filter.go:162-196;
             # its sort is the pipeline's Finalize and needs nothing of BQSR either)
             fin = host_pool.submit(finalize_lut)
-            if serial_metrics:
+            if order == "serial":
                 eng.sort_coordinate(fetch=False)
                 eng.dup_metrics(100)
             else:
-                # round 6: the duplication-metrics pass runs on the context's side lane (a stream and scratch of its own, elp_dup_metrics):
-                # a second host thread drives its ~25 small launches and five read-backs while this one drives the sort
+                # the duplication-metrics pass on its side lane, driven by a second host thread while this one drives the sort
                 mx = metrics_pool.submit(eng.dup_metrics, 100)
                 eng.sort_coordinate(fetch=False)
                 mx.result()
@@ -449,7 +476,16 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = n_global / (elapsed / args.steps) / 1e6
         full_bytes = BYTES_FULL_PATH if args.stages == "full" else BYTES_C2
-        stage_ms, kern_ms, roof = summarize(prof, args.steps, n_total, full_bytes)
+        conc = (not sfm_mode and args.stages == "full" and order != "serial") or sfm_mode
+        stage_ms, kern_ms, roof = summarize(prof, args.steps, n_total, full_bytes, ms_per_step, conc)
+        serial_order = None
+        if conc and not sfm_mode:
+            # the same step with its stages one after the other (as until round 5), OUTSIDE the timed region: what every kernel takes when it
+            # has the GPU to itself - the stage table and the dominant kernel's roofline without the other streams' kernels in its way
+            el_s, prof_s = timed(lambda: step_full("serial"), restore, 3, 1, eng, barrier)
+            st_s, km_s, rf_s = summarize(prof_s, 3, n_total, full_bytes, el_s / 3 * 1e3, False)
+            serial_order = {"ms_per_step": round(el_s / 3 * 1e3, 3), "stage_ms_per_step": st_s, "roofline": rf_s,
+                            "note": "3 steps after 1 warm-up, stages one after the other on one stream each call; not part of `value`"}
         what = ("mark duplicates + coordinate sort + optical metrics + BQSR gather + finalize + apply (BASELINE config C3)" if args.stages == "full"
                 else "mark duplicates + coordinate sort (BASELINE config C2)")
         out = {
@@ -475,6 +511,7 @@ def main():
                        "parallelism": ("filter: one context" if not sfm_mode else f"sfm: contig groups over {world} GPUs, spread split on one rank, one all-reduce per step "
                                                                               f"({rk.collective} collective)")},
             "roofline": roof,
+            "serial_order": serial_order,
             "stage_ms_per_step": stage_ms,
             "kernel_ms_per_step": kern_ms,
             "host_finalize_ms_per_step": round(sum(host_ms[-args.steps:]) / max(len(host_ms[-args.steps:]), 1), 3) if host_ms else None,

@@ -214,8 +214,12 @@ struct elp_ctx {
   // views of this context's.  The duplication-metrics pass runs there (metrics.hip): it reads what mark duplicates left and writes nothing
   // another stage reads, so a host may call elp_dup_metrics from a second thread while this context sorts - the pass's two dozen small
   // launches and five read-backs then hide under the sort's kernels instead of standing behind them.
-  elp_ctx *side = nullptr;
-  hipEvent_t side_ev = nullptr;
+  // Two of them: lane 0 = the metrics pass, lane 1 = the coordinate sort (sort.hip: it reads the key column and the comparator's columns
+  // and writes the permutation - nothing the BQSR stages touch; a host may call elp_sort_coordinate from a thread of its own right behind
+  // elp_mark_duplicates while the context gathers, finalises and applies: the reference runs these one after the other, cmd/filter.go:162-196).
+  elp_ctx *side[2] = {nullptr, nullptr};
+  hipEvent_t side_ev[2] = {nullptr, nullptr};   // in: the lane's stream waits for the context's
+  hipEvent_t side_done[2] = {nullptr, nullptr}; // out: the context's stream waits for what the lane left queued
 
   // snapshot of the mutable columns
   elp::DVec<uint16_t> snap_flag;
@@ -457,7 +461,8 @@ int ensure_adapted(elp_ctx *c, bool check_quals = true);
 int adapt_begin(elp_ctx *c, int *pos_bits);
 int adapt_scores(elp_ctx *c);
 int mailbox(elp_ctx *c);  // ctx.hip: c->mail (1024 words, page-locked) and c->mail_ev exist
-int side_lane(elp_ctx *c, elp_ctx **out);  // ctx.hip: c->side exists; its stream waits for what is queued on c->stream now
+int side_lane(elp_ctx *c, int lane, elp_ctx **out);  // ctx.hip: c->side[lane] exists; its stream waits for what is queued on c->stream now
+int side_join(elp_ctx *c, int lane);                 // ctx.hip: c->stream waits for what is queued on the lane's stream now
 void prof_merge_side(elp_ctx *c);          // ctx.hip: the side lane's launch times join the context's
 constexpr int ADAPT_WORDS = 6;
 void adapt_note(elp_ctx *c, const uint32_t *words /* ADAPT_WORDS of adapt_err */);  // sort.hip: the score kernel's words were read (by whoever synchronised anyway)

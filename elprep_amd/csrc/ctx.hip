@@ -176,8 +176,8 @@ int mailbox(elp_ctx *c) {
   if (!c->mail_ev) ELP_HIP(c, hipEventCreateWithFlags(&c->mail_ev, hipEventDisableTiming));
   return 0;
 }
-int side_lane(elp_ctx *c, elp_ctx **out) {
-  if (!c->side) {
+int side_lane(elp_ctx *c, int lane, elp_ctx **out) {
+  if (!c->side[lane]) {
     elp_ctx *s = new elp_ctx();
     s->device = c->device;
     s->n_cu = c->n_cu;
@@ -187,38 +187,46 @@ int side_lane(elp_ctx *c, elp_ctx **out) {
       delete s;
       return set_error(c, ELP_ERR_HIP, "the side lane's stream could not be made");
     }
-    c->side = s;
+    c->side[lane] = s;
   }
-  if (!c->side_ev) ELP_HIP(c, hipEventCreateWithFlags(&c->side_ev, hipEventDisableTiming));
+  if (!c->side_ev[lane]) ELP_HIP(c, hipEventCreateWithFlags(&c->side_ev[lane], hipEventDisableTiming));
+  if (!c->side_done[lane]) ELP_HIP(c, hipEventCreateWithFlags(&c->side_done[lane], hipEventDisableTiming));
   // what is queued on the context's stream up to here (mark duplicates) comes first
-  ELP_HIP(c, hipEventRecord(c->side_ev, c->stream));
-  ELP_HIP(c, hipStreamWaitEvent(c->side->stream, c->side_ev, 0));
-  c->side->profiling = c->profiling;
-  c->side->tune = c->tune;
-  *out = c->side;
+  ELP_HIP(c, hipEventRecord(c->side_ev[lane], c->stream));
+  ELP_HIP(c, hipStreamWaitEvent(c->side[lane]->stream, c->side_ev[lane], 0));
+  c->side[lane]->profiling = c->profiling;
+  c->side[lane]->tune = c->tune;
+  *out = c->side[lane];
+  return 0;
+}
+int side_join(elp_ctx *c, int lane) {
+  ELP_HIP(c, hipEventRecord(c->side_done[lane], c->side[lane]->stream));
+  ELP_HIP(c, hipStreamWaitEvent(c->stream, c->side_done[lane], 0));
   return 0;
 }
 void prof_merge_side(elp_ctx *c) {
-  elp_ctx *s = c->side;
-  if (!s) return;
-  (void)prof_flush(s);
-  for (size_t k = 0; k < s->prof_names.size(); k++) {
-    if (!s->prof_launches[k]) continue;
-    auto it = c->prof_index.find(s->prof_names[k]);
-    int id;
-    if (it == c->prof_index.end()) {
-      id = (int)c->prof_names.size();
-      c->prof_names.push_back(s->prof_names[k]);
-      c->prof_index[s->prof_names[k]] = id;
-      c->prof_launches.push_back(0);
-      c->prof_ms.push_back(0.0);
-    } else {
-      id = it->second;
+  for (int lane = 0; lane < 2; lane++) {
+    elp_ctx *s = c->side[lane];
+    if (!s) continue;
+    (void)prof_flush(s);
+    for (size_t k = 0; k < s->prof_names.size(); k++) {
+      if (!s->prof_launches[k]) continue;
+      auto it = c->prof_index.find(s->prof_names[k]);
+      int id;
+      if (it == c->prof_index.end()) {
+        id = (int)c->prof_names.size();
+        c->prof_names.push_back(s->prof_names[k]);
+        c->prof_index[s->prof_names[k]] = id;
+        c->prof_launches.push_back(0);
+        c->prof_ms.push_back(0.0);
+      } else {
+        id = it->second;
+      }
+      c->prof_launches[id] += s->prof_launches[k];
+      c->prof_ms[id] += s->prof_ms[k];
+      s->prof_launches[k] = 0;
+      s->prof_ms[k] = 0.0;
     }
-    c->prof_launches[id] += s->prof_launches[k];
-    c->prof_ms[id] += s->prof_ms[k];
-    s->prof_launches[k] = 0;
-    s->prof_ms[k] = 0.0;
   }
 }
 int radix_check(elp_ctx *c) {
@@ -267,14 +275,17 @@ void elp_destroy(elp_ctx *c) {
   for (auto p : c->h_sites) if (p) (void)hipFree(p);
   for (auto p : c->h_site_idx) if (p) (void)hipFree(p);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
-  if (c->side) {  // (its columns are views that were taken back when the pass that used them returned: it owns its scratch only)
-    (void)elp::stream_wait(c->side->stream);
-    for (auto &p : c->side->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-    (void)hipStreamDestroy(c->side->stream);
-    delete c->side;
-    c->side = nullptr;
+  for (int lane = 0; lane < 2; lane++) {
+    if (c->side[lane]) {  // (its columns are views that were taken back when the pass that used them returned: it owns its scratch only)
+      (void)elp::stream_wait(c->side[lane]->stream);
+      for (auto &p : c->side[lane]->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+      (void)hipStreamDestroy(c->side[lane]->stream);
+      delete c->side[lane];
+      c->side[lane] = nullptr;
+    }
+    if (c->side_ev[lane]) (void)hipEventDestroy(c->side_ev[lane]);
+    if (c->side_done[lane]) (void)hipEventDestroy(c->side_done[lane]);
   }
-  if (c->side_ev) (void)hipEventDestroy(c->side_ev);
   if (c->mail) (void)hipHostFree(c->mail);
   if (c->mail_ev) (void)hipEventDestroy(c->mail_ev);
   for (int k = 0; k < 2; k++) {
@@ -585,7 +596,8 @@ int elp_profile_enable(elp_ctx *c, int on) {
   if (!c) return ELP_ERR_ARG;
   if (!on) { ELP_TRY(prof_flush(c)); prof_merge_side(c); }
   c->profiling = on != 0;
-  if (c->side) c->side->profiling = c->profiling;
+  for (int lane = 0; lane < 2; lane++)
+    if (c->side[lane]) c->side[lane]->profiling = c->profiling;
   return 0;
 }
 int elp_profile_reset(elp_ctx *c) {

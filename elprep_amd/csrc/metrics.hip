@@ -633,7 +633,7 @@ static int metrics_on_side(elp_ctx *c, int dist, int64_t *counters_host, int64_t
   // (the time-out word of mark duplicates' radix passes is the context's: whoever reads its error words next - the sort's last read-back,
   // elp_sync, elp_get_flags - reports it; reading it here would wait for the context's whole stream)
   elp_ctx *s = nullptr;
-  ELP_TRY(side_lane(c, &s));
+  ELP_TRY(side_lane(c, 0, &s));
   s->n = c->n; s->n_lib = c->n_lib; s->n_rg = c->n_rg; s->n_ref = c->n_ref; s->max_split = c->max_split; s->marked = c->marked;
   s->n_sr = c->n_sr; s->n_filtered = c->n_filtered;
   s->flag.p = c->flag.p; s->rgid.p = c->rgid.p; s->rg_lib.p = c->rg_lib.p; s->refid.p = c->refid.p; s->qname_off.p = c->qname_off.p; s->qname.p = c->qname.p;

@@ -1131,9 +1131,39 @@ static int sort_impl(elp_ctx *c) {
 
 }  // namespace elp
 
+namespace elp {
+// The sort on the context's side lane 1 (common.hpp): the shadow context sees the key column, the comparator's columns and the
+// permutation's buffer as views for the duration of the call, runs on its own stream behind what the context's stream holds now, and
+// before it returns the context's stream is made to wait for whatever the lane still has queued - later stages find the permutation.
+static int sort_on_side(elp_ctx *c) {
+  ELP_TRY(ensure_adapted(c, false));  // (on the context: the shadow takes the key column as it is)
+  ELP_TRY(ensure(c, c->perm, c->n + 1));
+  elp_ctx *s = nullptr;
+  ELP_TRY(side_lane(c, 1, &s));
+  s->n = c->n; s->n_sr = c->n_sr; s->n_filtered = c->n_filtered; s->key_bits = c->key_bits; s->max_qname_len = c->max_qname_len; s->max_pos = c->max_pos;
+  s->n_ref = c->n_ref; s->adapted = true; s->adapt_pending = false; s->sorted = false;
+  s->key.p = c->key.p; s->flag.p = c->flag.p; s->mapq.p = c->mapq.p; s->next_refid.p = c->next_refid.p; s->pnext.p = c->pnext.p; s->tlen.p = c->tlen.p;
+  s->qname_off.p = c->qname_off.p; s->qname.p = c->qname.p; s->has_sr.p = c->has_sr.p;
+  s->perm.p = c->perm.p; s->perm.cap = c->perm.cap;
+  int rc = sort_impl(s);
+  s->key.p = nullptr; s->flag.p = nullptr; s->mapq.p = nullptr; s->next_refid.p = nullptr; s->pnext.p = nullptr; s->tlen.p = nullptr;
+  s->qname_off.p = nullptr; s->qname.p = nullptr; s->has_sr.p = nullptr;
+  s->perm.p = nullptr; s->perm.cap = 0;
+  if (rc == 0) rc = radix_check(s);  // (the lane's own error words: nothing of the sort stays unread)
+  if (rc != 0) {
+    (void)elp::stream_wait(s->stream);
+    c->err = s->err;
+    return rc;
+  }
+  ELP_TRY(side_join(c, 1));
+  c->sorted = s->sorted;
+  return 0;
+}
+}  // namespace elp
+
 extern "C" int elp_sort_coordinate(elp_ctx *c) {
   if (!c) return ELP_ERR_ARG;
   ELP_HIP(c, hipSetDevice(c->device));
   c->sorted = false;
-  return elp::sort_impl(c);
+  return elp::sort_on_side(c);
 }

@@ -495,11 +495,14 @@ class SfmRank:
             from concurrent.futures import ThreadPoolExecutor
             self._side = ThreadPoolExecutor(1)
 
-        def count(e, pool=None):
+        def count(e, pool=None, sort_pool=None):
             e.mark_duplicates(True, fetch=False)
+            st = None
             if pool is not None:
-                # the metrics pass on the context's side lane (round 6: a stream and scratch of its own), driven from a thread of its own
+                # round 6: behind mark duplicates the coordinate sort, the metrics pass and the BQSR count need nothing of each other; the
+                # library runs the first two on side lanes of the context (streams and scratch of their own), a host thread each drives them
                 # under the gather's kernels
+                st = sort_pool.submit(e.sort_coordinate, False)
                 mx = pool.submit(e.dup_metrics, pixel_dist)
                 e.recalibrate_device(max_cycle)  # tables stay in HBM
                 c7 = mx.result()
@@ -507,14 +510,14 @@ class SfmRank:
                 c7 = e.dup_metrics(pixel_dist)
                 e.recalibrate_device(max_cycle)
             e.sync()
-            return c7
+            return c7, st
         if getattr(self, "_mx_pool", None) is None:
             from concurrent.futures import ThreadPoolExecutor
-            self._mx_pool = ThreadPoolExecutor(1)
+            self._mx_pool, self._sort_pool = ThreadPoolExecutor(1), ThreadPoolExecutor(1)
         side = self._side.submit(count, e1) if self.n[1] else None
-        ctr = count(e0, self._mx_pool)
+        ctr, sort0 = count(e0, self._mx_pool, self._sort_pool)
         if side is not None:
-            ctr = ctr + side.result()
+            ctr = ctr + side.result()[0]
             e0.tables_add(e1)
             e0.sync()                        # (so that the time below is the collective - and the wait for the slowest rank - alone)
         t0 = time.perf_counter()
@@ -538,7 +541,6 @@ class SfmRank:
             return lut, present
         fin = host_pool.submit(host_side)
         side = self._side.submit(lambda: e1.sort_coordinate(fetch=False)) if self.n[1] else None
-        e0.sort_coordinate(fetch=False)
         if side is not None:
             side.result()
         fin.result()
@@ -546,6 +548,7 @@ class SfmRank:
         e0.apply_bqsr(None, None, max_cycle, fetch=False)
         if side is not None:
             side.result()
+        sort0.result()  # (the group splits' sort, running on its side lane since mark duplicates)
         return ctr
 
     def apply(self, lut: np.ndarray, present: np.ndarray, max_cycle: int):
@@ -576,7 +579,8 @@ class SfmRank:
             self._side = None
         if getattr(self, "_mx_pool", None) is not None:
             self._mx_pool.shutdown()
-            self._mx_pool = None
+            self._sort_pool.shutdown()
+            self._mx_pool = self._sort_pool = None
         if self.reader is not None:
             self.reader.close()
             self.reader = None
