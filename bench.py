@@ -232,9 +232,12 @@ def main():
     host_pool = ThreadPoolExecutor(1)
     metrics_pool = ThreadPoolExecutor(1)
     sort_pool = ThreadPoolExecutor(1)
-    # how a step's stages are driven: "three" (default) = sort, metrics and the BQSR chain at once behind mark duplicates; "metrics" = the
-    # metrics pass under the sort, both behind the gather (round 6's first form); "serial" = one after the other, as until round 5 (A/B)
-    order = os.environ.get("ELP_BENCH_ORDER", "three")
+    # how a step's stages are driven (the library runs the sort and the metrics pass on side lanes of the context; the host decides what
+    # it calls at once): "metrics" (default) = the metrics pass under the sort, both behind the gather - the BQSR kernels, which the
+    # roofline figures are about, have the GPU to themselves; "three" = sort, metrics and the BQSR chain all at once behind mark
+    # duplicates - the fastest step (reported as extra.order_three), but every kernel's time then includes what it waited for another
+    # stream's kernel; "serial" = one after the other, as until round 5
+    order = os.environ.get("ELP_BENCH_ORDER", "metrics")
 
     def generated(jobs):
         """yield the batches of `jobs` = [(config, pair_lo, pair_hi), ...] in order; the generator is deterministic per pair index,
@@ -476,10 +479,14 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = n_global / (elapsed / args.steps) / 1e6
         full_bytes = BYTES_FULL_PATH if args.stages == "full" else BYTES_C2
-        conc = (not sfm_mode and args.stages == "full" and order != "serial") or sfm_mode
+        conc = (not sfm_mode and args.stages == "full" and order == "three") or sfm_mode
         stage_ms, kern_ms, roof = summarize(prof, args.steps, n_total, full_bytes, ms_per_step, conc)
+        if not sfm_mode and args.stages == "full" and order == "metrics":
+            roof["concurrent_streams"] = ("the duplication-metrics pass runs under the coordinate sort (side lanes of the context, two host threads): the two "
+                                          "stages' kernel times are contended and their sum exceeds what they add to the step; mark duplicates, the BQSR "
+                                          "gather and ApplyBQSR run alone; uncontended sort / metrics: `serial_order`")
         serial_order = None
-        if conc and not sfm_mode:
+        if not sfm_mode and args.stages == "full" and order != "serial":
             # the same step with its stages one after the other (as until round 5), OUTSIDE the timed region: what every kernel takes when it
             # has the GPU to itself - the stage table and the dominant kernel's roofline without the other streams' kernels in its way
             el_s, prof_s = timed(lambda: step_full("serial"), restore, 3, 1, eng, barrier)
@@ -535,6 +542,14 @@ def main():
     # ---- N = 1 side measurements: config C2 on the same reads, the ~40-quality read set, the PCIe-inclusive staging rate
     if not sfm_mode and rank == 0 and not args.no_extra:
         extra = {}
+        try:
+            if args.stages == "full" and order != "three":
+                el3, _ = timed(lambda: step_full("three"), restore, 4, 1, eng, barrier)
+                extra["order_three"] = {"workload": "the main line's step with the coordinate sort, the metrics pass and the BQSR chain (gather, finalize, apply) driven "
+                                                    "at once behind mark duplicates (three host threads, three streams of the one context)",
+                                        "value": round(n_total / (el3 / 4) / 1e6, 3), "unit": "Mreads/s", "ms_per_step": round(el3 / 4 * 1e3, 3)}
+        except Exception as e:
+            extra["order_three"] = {"error": repr(e)}
         try:
             if args.stages == "full":
                 el, pr = timed(step_c2, restore, 3, 1, eng, barrier)
