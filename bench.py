@@ -94,7 +94,7 @@ def timed(step, restore, steps, warmup, prof_eng, barrier):
     return elapsed, prof
 
 
-def summarize(prof, steps, n_reads, full_bytes, wall_ms=None, concurrent=False):
+def summarize(prof, steps, n_reads, full_bytes, wall_ms=None, concurrent=False, dom=None):
     """per-stage kernel ms per step, the dominant kernel and its roofline figures.  `achieved` = the algorithmic bytes of the stage the
     dominant kernel belongs to (SURVEY.md 8d x the reads of the step) over the time ALL launches of that kernel take in one step (a
     kernel launched several times per step - the radix scatter - is not priced by the average of its unequal launches); `stage_frac` =
@@ -109,7 +109,10 @@ def summarize(prof, steps, n_reads, full_bytes, wall_ms=None, concurrent=False):
     bpr = dict(BYTES_PER_READ)
     if any(k.endswith("md_front") for k in prof):
         bpr["adapt"], bpr["markdup"] = BYTES_PER_READ["adapt"] - 35, BYTES_PER_READ["markdup"] + 35
-    dom = max(prof.items(), key=lambda kv: kv[1][1])[0]
+    # the dominant kernel: the one with the most time per step - taken from the serial-order steps (`dom`) when this profile's stages ran
+    # at once: a kernel that WAITS for another stream's kernel (the sort's passes under the count kernel) is not the one that dominates
+    if dom is None or dom not in prof:
+        dom = max(prof.items(), key=lambda kv: kv[1][1])[0]
     dom_stage = kernel_stage(dom)
     launches_per_step = max(prof[dom][0] / steps, 1)
     dom_ms_per_step = prof[dom][1] / steps
@@ -233,11 +236,11 @@ def main():
     metrics_pool = ThreadPoolExecutor(1)
     sort_pool = ThreadPoolExecutor(1)
     # how a step's stages are driven (the library runs the sort and the metrics pass on side lanes of the context; the host decides what
-    # it calls at once): "metrics" (default) = the metrics pass under the sort, both behind the gather - the BQSR kernels, which the
-    # roofline figures are about, have the GPU to themselves; "three" = sort, metrics and the BQSR chain all at once behind mark
-    # duplicates - the fastest step (reported as extra.order_three), but every kernel's time then includes what it waited for another
-    # stream's kernel; "serial" = one after the other, as until round 5
-    order = os.environ.get("ELP_BENCH_ORDER", "metrics")
+    # it calls at once): "three" (default) = sort, metrics and the BQSR chain all at once behind mark duplicates - the fastest step; every
+    # kernel's time then includes what it waited for another stream's kernel, so the line also carries the same step's kernels measured
+    # one after the other (`serial_order`, outside the timed region); "metrics" = the metrics pass under the sort, both behind the gather
+    # (the BQSR kernels have the GPU to themselves); "serial" = one after the other, as until round 5
+    order = os.environ.get("ELP_BENCH_ORDER", "three")
 
     def generated(jobs):
         """yield the batches of `jobs` = [(config, pair_lo, pair_hi), ...] in order; the generator is deterministic per pair index,
@@ -480,19 +483,26 @@ def main():
         value = n_global / (elapsed / args.steps) / 1e6
         full_bytes = BYTES_FULL_PATH if args.stages == "full" else BYTES_C2
         conc = (not sfm_mode and args.stages == "full" and order == "three") or sfm_mode
-        stage_ms, kern_ms, roof = summarize(prof, args.steps, n_total, full_bytes, ms_per_step, conc)
-        if not sfm_mode and args.stages == "full" and order == "metrics":
-            roof["concurrent_streams"] = ("the duplication-metrics pass runs under the coordinate sort (side lanes of the context, two host threads): the two "
-                                          "stages' kernel times are contended and their sum exceeds what they add to the step; mark duplicates, the BQSR "
-                                          "gather and ApplyBQSR run alone; uncontended sort / metrics: `serial_order`")
         serial_order = None
+        dom_serial = None
         if not sfm_mode and args.stages == "full" and order != "serial":
             # the same step with its stages one after the other (as until round 5), OUTSIDE the timed region: what every kernel takes when it
             # has the GPU to itself - the stage table and the dominant kernel's roofline without the other streams' kernels in its way
             el_s, prof_s = timed(lambda: step_full("serial"), restore, 3, 1, eng, barrier)
             st_s, km_s, rf_s = summarize(prof_s, 3, n_total, full_bytes, el_s / 3 * 1e3, False)
+            dom_serial = rf_s["kernel"]
             serial_order = {"ms_per_step": round(el_s / 3 * 1e3, 3), "stage_ms_per_step": st_s, "roofline": rf_s,
-                            "note": "3 steps after 1 warm-up, stages one after the other on one stream each call; not part of `value`"}
+                            "note": "3 steps after 1 warm-up, stages one after the other; not part of `value`"}
+        stage_ms, kern_ms, roof = summarize(prof, args.steps, n_total, full_bytes, ms_per_step, conc, dom_serial)
+        if serial_order is not None and conc:
+            roof["frac_uncontended"] = serial_order["roofline"]["frac"]
+            roof["note"] = ("`achieved` / `frac`: the dominant kernel's time in the TIMED steps, where the coordinate sort and the metrics pass run at the same "
+                            "time on streams of their own and take CUs, LDS and bandwidth from it; `frac_uncontended`: the same kernel, same reads, in the "
+                            "serial-order steps behind the timed region (serial_order.roofline)")
+        if not sfm_mode and args.stages == "full" and order == "metrics":
+            roof["concurrent_streams"] = ("the duplication-metrics pass runs under the coordinate sort (side lanes of the context, two host threads): the two "
+                                          "stages' kernel times are contended and their sum exceeds what they add to the step; mark duplicates, the BQSR "
+                                          "gather and ApplyBQSR run alone; uncontended sort / metrics: `serial_order`")
         what = ("mark duplicates + coordinate sort + optical metrics + BQSR gather + finalize + apply (BASELINE config C3)" if args.stages == "full"
                 else "mark duplicates + coordinate sort (BASELINE config C2)")
         out = {
@@ -543,13 +553,17 @@ def main():
     if not sfm_mode and rank == 0 and not args.no_extra:
         extra = {}
         try:
-            if args.stages == "full" and order != "three":
-                el3, _ = timed(lambda: step_full("three"), restore, 4, 1, eng, barrier)
-                extra["order_three"] = {"workload": "the main line's step with the coordinate sort, the metrics pass and the BQSR chain (gather, finalize, apply) driven "
-                                                    "at once behind mark duplicates (three host threads, three streams of the one context)",
-                                        "value": round(n_total / (el3 / 4) / 1e6, 3), "unit": "Mreads/s", "ms_per_step": round(el3 / 4 * 1e3, 3)}
+            if args.stages == "full":
+                for o, wl in (("three", "the coordinate sort, the metrics pass and the BQSR chain (gather, finalize, apply) driven at once behind mark duplicates"),
+                              ("metrics", "the metrics pass under the coordinate sort, both behind the gather: the BQSR kernels have the GPU to themselves"),
+                              ("serial", "the stages one after the other, as until round 5")):
+                    if o == order:
+                        continue
+                    elo, _ = timed(lambda: step_full(o), restore, 4, 1, eng, barrier)
+                    extra["order_" + o] = {"workload": "the main line's step, " + wl, "value": round(n_total / (elo / 4) / 1e6, 3), "unit": "Mreads/s",
+                                           "ms_per_step": round(elo / 4 * 1e3, 3)}
         except Exception as e:
-            extra["order_three"] = {"error": repr(e)}
+            extra["order_ab"] = {"error": repr(e)}
         try:
             if args.stages == "full":
                 el, pr = timed(step_c2, restore, 3, 1, eng, barrier)

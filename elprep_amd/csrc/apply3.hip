@@ -481,7 +481,8 @@ int apply3_launch(elp_ctx *c, int max_cycle, const uint8_t *d_lut, const uint8_t
     for (uint32_t slot = 0; slot < A3_NT / bpr; slot++)
       if (((slot * bpr + bpr - 1u) & 63u) == 0) group = 64;
   const uint32_t rpi = (group / bpr) * (A3_NT / group);
-  const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / (dyn + 512 + (split ? 2304 : 0))));
+  unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / (dyn + 512 + (split ? 2304 : 0))));
+  if (c->tune.apply_wgs >= 1 && c->tune.apply_wgs <= 3) per_cu = std::min(per_cu, (unsigned)c->tune.apply_wgs);
   const int grid = (int)std::min<uint64_t>((n + rpi - 1) / rpi, (uint64_t)c->n_cu * per_cu);
   uint2 *recs;
   const size_t dump_words = (size_t)grid * A3_NT * 2;  // 16 bytes per lane, in uint2 units

@@ -244,6 +244,8 @@ struct elp_ctx {
     int tie_rounds = 0;        // 1: the sort's long runs by LSD rounds over every live position (no key-then-compare shortcut)
     int exchange_piece = 0;    // > 0: records per piece of elp_exchange_records (tests: several pieces on small inputs)
     int bgzf_stored = 0;       // 1: elp_emit_sorted_bgzf writes stored DEFLATE blocks (round 4's form) instead of compressing
+    int apply_wgs = 0;         // 1 .. 3: workgroups per CU of the one-length ApplyBQSR kernel (default: as many as its LDS allows, at most 3) - A/B runs
+                               // of a step whose sort runs at the same time and needs LDS of its own
     int md_fused = 0;          // 1: mark duplicates by the separate passes of rounds 2-5 (adapt_fixed, md_keys, md_mate_scan, md_mate_pairs) instead of
                                // the fused front pass of round 6 (k_md_front); tests run both
   } tune;

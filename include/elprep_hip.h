@@ -209,7 +209,15 @@ int elp_merge_spread(elp_ctx *groups, elp_ctx *spread, uint64_t *slot_of_spread_
  * under all nine keys of CoordinateLess keep staging order.  Payload permutation is the caller's (host) work.
  * The comparator's modFlag(FLAG) tie-break reads the FLAG column as it is at the time of the call.  In `elprep filter` the sort is
  * the Finalize step of the phase-1 pipeline (sam/filter-pipeline.go:116): it runs BEHIND the filters, so with --mark-duplicates it
- * sees the duplicate bits.  A drop-in host therefore calls elp_mark_duplicates first, then elp_sort_coordinate. */
+ * sees the duplicate bits.  A drop-in host therefore calls elp_mark_duplicates first, then elp_sort_coordinate.
+ * Concurrency (round 6): the sort runs on a SIDE LANE of the context - a stream, scratch pool and error words of its own; it reads the
+ * key column and the comparator's columns and writes the permutation, nothing the BQSR calls touch.  Once elp_mark_duplicates has
+ * returned, a host may therefore call elp_sort_coordinate from a thread of its own (a goroutine locked to its OS thread) WHILE another
+ * thread calls elp_dup_metrics (side lane of its own, below) and a third drives elp_bqsr_gather(_device) -> finalize -> elp_bqsr_apply
+ * on the same context: the three chains need nothing of each other (the reference runs them one after the other,
+ * cmd/filter.go:162-196).  The call returns when the permutation is complete; calls that read it afterwards (elp_get_permutation,
+ * elp_emit_*) are ordered behind it.  Calls that CHANGE staged records (staging, reset, rollback, filters, exchange) must not overlap
+ * with any other call on the context. */
 int elp_sort_coordinate(elp_ctx *ctx);
 int elp_get_permutation(elp_ctx *ctx, uint32_t *perm_out /* n */);
 /* number of records that survive RemoveOptionalReads = staged records without the sr tag: the first elp_num_sorted() entries of
@@ -230,7 +238,8 @@ int elp_get_adapted(elp_ctx *ctx, int32_t *upos_out, int32_t *score_out);
  * counters: [(n_lib + 1)][7] int64 in the order UnpairedReadsExamined, ReadPairsExamined, SecondaryOrSupplementaryReads,
  * UnmappedReads, UnpairedReadDuplicates, ReadPairDuplicates, ReadPairOpticalDuplicates; row n_lib = "Unknown Library".
  * Requires elp_mark_duplicates.  Derived float metrics (PERCENT_DUPLICATION, ESTIMATED_LIBRARY_SIZE, :527-569) and the
- * Picard text (:608-699) stay on the host. */
+ * Picard text (:608-699) stay on the host.  Runs on a side lane of the context (see elp_sort_coordinate): it reads what mark duplicates
+ * left and writes nothing another call reads, so it may be called from a second host thread while the context sorts or gathers. */
 #define ELP_NCTR 7
 int elp_dup_metrics(elp_ctx *ctx, int optical_pixel_distance, int64_t *counters);
 /* The same plus the three set-size histograms the reference keeps per library (duplicatesCountHistogram,

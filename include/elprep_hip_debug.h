@@ -46,6 +46,9 @@ int elp_rollback(elp_ctx *ctx);
  *   "qual_hint_drop"   q >= 0: quality q is removed from the sampled hint (the kernels' no-slot paths)
  *   "pair_table_slots" cap on the LDS table slots per pair bucket of elp_mark_duplicates (a power of two >= 2; 0 = no cap): a
  *                      small value sends every bucket through the overflow path
+ *   "apply_wgs"        1 .. 3: workgroups per CU of the one-length ApplyBQSR kernel (default: what its LDS allows, at most 3)
+ *   "md_fused"         1: mark duplicates by the separate passes of rounds 2-5 (adapt_fixed, md_keys, md_mate_scan, md_mate_pairs) instead of
+ *                      the fused front pass of round 6 (md_front) - same flags; A/B timing and the tests run both
  *   "mate_path"        1: every mate candidate is matched by the partitioned pass (hash partition + LDS tables), no neighbour
  *                      shortcut - what coordinate-ordered or shuffled input takes by itself; 2: ... by the table in HBM
  *   "radix_tile"       1: every radix pass in tiles of 4096 keys; 2: of 8192 keys; 3: of 16384 (default: by the array's length)
