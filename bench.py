@@ -241,6 +241,7 @@ def main():
     # one after the other (`serial_order`, outside the timed region); "metrics" = the metrics pass under the sort, both behind the gather
     # (the BQSR kernels have the GPU to themselves); "serial" = one after the other, as until round 5
     order = os.environ.get("ELP_BENCH_ORDER", "three")
+    sort_ahead = os.environ.get("ELP_BENCH_SORT_AHEAD", "1") != "0"
 
     def generated(jobs):
         """yield the batches of `jobs` = [(config, pair_lo, pair_hi), ...] in order; the generator is deterministic per pair index,
@@ -296,6 +297,7 @@ def main():
             host_ms.append((time.perf_counter() - t0) * 1e3)
 
         def step_full(order=order):
+            eng.sort_ahead(order == "three" and sort_ahead)  # (the sort's key passes queued from inside mark duplicates, elp_sort_ahead)
             eng.mark_duplicates(True, fetch=False)
             if order == "three":
                 # round 6: behind mark duplicates three chains need nothing of each other - the coordinate sort (the pipeline's Finalize,

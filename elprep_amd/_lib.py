@@ -21,7 +21,7 @@ _host: Optional[C.CDLL] = None
 
 HIP_SYMBOLS = [
     "elp_create", "elp_destroy", "elp_last_error", "elp_sync", "elp_stream", "elp_set_header", "elp_reserve", "elp_stage", "elp_reset",
-    "elp_num_records", "elp_num_qual_bytes", "elp_num_sorted", "elp_sort_coordinate", "elp_get_permutation", "elp_mark_duplicates", "elp_get_flags", "elp_get_adapted",
+    "elp_num_records", "elp_num_qual_bytes", "elp_num_sorted", "elp_sort_coordinate", "elp_sort_ahead", "elp_get_permutation", "elp_mark_duplicates", "elp_get_flags", "elp_get_adapted",
     "elp_dup_metrics", "elp_dup_metrics_hist", "elp_bqsr_set_reference", "elp_bqsr_set_known_sites", "elp_bqsr_gather", "elp_bqsr_apply", "elp_get_qual",
     "elp_bqsr_gather_device", "elp_bqsr_tables_fetch", "elp_bqsr_quals_counted", "elp_bqsr_tables_fetch_rows", "elp_bqsr_lut_upload_rows", "elp_group_unique_id", "elp_group_init", "elp_group_rank", "elp_group_size",
     "elp_bqsr_tables_add", "elp_bqsr_tables_allreduce", "elp_allreduce_i64",
@@ -73,6 +73,7 @@ def hip() -> C.CDLL:
         L.elp_reserve.argtypes = [C.c_void_p] + [C.c_uint64] * 5
         L.elp_get_permutation.argtypes = [C.c_void_p, C.c_void_p]
         L.elp_mark_duplicates.argtypes = [C.c_void_p, C.c_int]
+        L.elp_sort_ahead.argtypes = [C.c_void_p, C.c_int]
         L.elp_get_flags.argtypes = [C.c_void_p, C.c_void_p]
         L.elp_get_adapted.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.elp_dup_metrics.argtypes = [C.c_void_p, C.c_int, C.c_void_p]

@@ -220,6 +220,14 @@ struct elp_ctx {
   elp_ctx *side[2] = {nullptr, nullptr};
   hipEvent_t side_ev[2] = {nullptr, nullptr};   // in: the lane's stream waits for the context's
   hipEvent_t side_done[2] = {nullptr, nullptr}; // out: the context's stream waits for what the lane left queued
+  // elp_sort_ahead (round 6): the coordinate sort's KEY passes need the key column only, not the duplicate bits - with the option on,
+  // elp_mark_duplicates queues them on the sort lane the moment its front pass has written the keys (no host wait involved), and they run
+  // under the pair phase; elp_sort_coordinate then finds the sorted words and only breaks the ties (which see the final FLAGs)
+  bool sort_ahead = false;
+  uint64_t adapt_epoch = 0;          // counts the writes of the key column (adapt_begin)
+  uint64_t presort_epoch = ~0ull, presort_n = 0;
+  uint64_t *presort_ks = nullptr;    // the sorted words, in the sort lane's scratch slot 0 (valid while presort_epoch == adapt_epoch)
+  int presort_idx_bits = 0;
 
   // snapshot of the mutable columns
   elp::DVec<uint16_t> snap_flag;
@@ -465,6 +473,7 @@ int adapt_scores(elp_ctx *c);
 int mailbox(elp_ctx *c);  // ctx.hip: c->mail (1024 words, page-locked) and c->mail_ev exist
 int side_lane(elp_ctx *c, int lane, elp_ctx **out);  // ctx.hip: c->side[lane] exists; its stream waits for what is queued on c->stream now
 int side_join(elp_ctx *c, int lane);                 // ctx.hip: c->stream waits for what is queued on the lane's stream now
+int sort_presort(elp_ctx *c);                        // sort.hip: the sort's key passes queued on lane 1 behind what c->stream holds now (elp_sort_ahead)
 void prof_merge_side(elp_ctx *c);          // ctx.hip: the side lane's launch times join the context's
 constexpr int ADAPT_WORDS = 6;
 void adapt_note(elp_ctx *c, const uint32_t *words /* ADAPT_WORDS of adapt_err */);  // sort.hip: the score kernel's words were read (by whoever synchronised anyway)

@@ -1245,6 +1245,8 @@ static int markdup_impl(elp_ctx *c) {
                  (uint32_t)(bw - 1), n_table_dev, (const uint32_t *)ftable, (const uint32_t *)fbits, nf ? Tf - 1 : (uint64_t)0, best, c->mate.p, c->pair_win.p, pk, pv,
                  np_dev, nfx, optimistic);
     if (fuse_adapt) c->adapted = true;
+    // elp_sort_ahead: the keys exist - the coordinate sort's key passes go to the sort lane now and run under the pair phase
+    ELP_TRY(sort_presort(c));
     // tournament among the fragments of pair-free groups (the pair bits are complete): queued in front of the read-back
     if (nf) {
       ELP_LAUNCH(c, "md_frag_tie", k_frag_tie, dim3(fgrid), dim3(256), 0, m, (const uint32_t *)flist, nf, (const uint32_t *)rep,

@@ -457,6 +457,7 @@ int adapt_begin(elp_ctx *c, int *pos_bits_out) {
   c->adapt_pending = false;
   c->adapt_sampled = c->adapt_qmask_valid = false;
   c->apply_recs_valid = false;
+  c->adapt_epoch++;  // (the key column is about to be rewritten: sorted words made from it are stale)
   int pos_bits = 1;
   while (pos_bits < 32 && (c->max_pos >> pos_bits) != 0) pos_bits++;
   int ref_bits = 1;  // contig codes 0 .. n_ref + 1 (unmapped, then the records that are not sorted at all)
@@ -893,7 +894,7 @@ __global__ __launch_bounds__(256) void k_large_scatter(uint32_t nu, const uint32
   if (j < nu) perm_out[u_pos[j]] = u_read[vals_sorted[j]];
 }
 
-static int sort_impl(elp_ctx *c) {
+static int sort_impl(elp_ctx *c, uint64_t *presorted = nullptr /* the key passes' result, made ahead (sort_presort) */) {
   const uint64_t n = c->n;
   ELP_TRY(ensure_adapted(c, false));
   ELP_TRY(ensure(c, c->perm, n + 1));
@@ -913,7 +914,8 @@ static int sort_impl(elp_ctx *c) {
   int idx_bits = 1;
   while (idx_bits < 32 && (n >> idx_bits) != 0) idx_bits++;
   const bool words = c->tune.sort_pairs != 1 && c->key_bits >= 1 && c->key_bits + idx_bits <= 64;
-  if (words) ELP_TRY(radix_sort_fused(c, c->key.p, n, c->key_bits, idx_bits, k0, k1, &ks));
+  if (words && presorted) ks = presorted;
+  else if (words) ELP_TRY(radix_sort_fused(c, c->key.p, n, c->key_bits, idx_bits, k0, k1, &ks));
   else ELP_TRY(radix_sort_pairs_low(c, k0, v0, k1, v1, n, (c->key_bits + 7) / 8, &ks, &vs, c->key.p, true));
   const SortedView sv{ks, vs, words ? (uint32_t)idx_bits : 0u};
   TieCols t{c->qname_off.p, c->qname.p, c->flag.p, c->mapq.p, c->next_refid.p, c->pnext.p, c->tlen.p};
@@ -1145,7 +1147,12 @@ static int sort_on_side(elp_ctx *c) {
   s->key.p = c->key.p; s->flag.p = c->flag.p; s->mapq.p = c->mapq.p; s->next_refid.p = c->next_refid.p; s->pnext.p = c->pnext.p; s->tlen.p = c->tlen.p;
   s->qname_off.p = c->qname_off.p; s->qname.p = c->qname.p; s->has_sr.p = c->has_sr.p;
   s->perm.p = c->perm.p; s->perm.cap = c->perm.cap;
-  int rc = sort_impl(s);
+  // the key passes may have been queued ahead (elp_sort_ahead, from inside elp_mark_duplicates): same keys, same length, same lane
+  int ib = 1;
+  while (ib < 32 && (c->n >> ib) != 0) ib++;
+  uint64_t *pre = (c->presort_ks && c->presort_epoch == c->adapt_epoch && c->presort_n == c->n && c->presort_idx_bits == ib && c->tune.sort_pairs != 1) ? c->presort_ks : nullptr;
+  c->presort_epoch = ~0ull;  // (used once: the tie-break leaves its marks in the buffer's other half)
+  int rc = sort_impl(s, pre);
   s->key.p = nullptr; s->flag.p = nullptr; s->mapq.p = nullptr; s->next_refid.p = nullptr; s->pnext.p = nullptr; s->tlen.p = nullptr;
   s->qname_off.p = nullptr; s->qname.p = nullptr; s->has_sr.p = nullptr;
   s->perm.p = nullptr; s->perm.cap = 0;
@@ -1160,6 +1167,33 @@ static int sort_on_side(elp_ctx *c) {
   return 0;
 }
 }  // namespace elp
+
+namespace elp {
+int sort_presort(elp_ctx *c) {
+  const uint64_t n = c->n;
+  c->presort_epoch = ~0ull;
+  if (!c->sort_ahead || n < 2 || !c->adapted || c->tune.sort_pairs == 1) return 0;
+  int idx_bits = 1;
+  while (idx_bits < 32 && (n >> idx_bits) != 0) idx_bits++;
+  if (c->key_bits < 1 || c->key_bits + idx_bits > 64) return 0;  // (pairs, not words: the sort makes its passes itself)
+  elp_ctx *s = nullptr;
+  ELP_TRY(side_lane(c, 1, &s));
+  s->n = n; s->key_bits = c->key_bits;
+  uint64_t *kbuf, *ks = nullptr;
+  int rc = scratch(s, 0, 2 * n + 8, &kbuf);
+  if (rc == 0) rc = radix_sort_fused(s, c->key.p, n, c->key_bits, idx_bits, kbuf, kbuf + n, &ks);
+  if (rc != 0) { c->err = s->err; return rc; }
+  c->presort_ks = ks; c->presort_n = n; c->presort_idx_bits = idx_bits; c->presort_epoch = c->adapt_epoch;
+  return 0;
+}
+}  // namespace elp
+
+extern "C" int elp_sort_ahead(elp_ctx *c, int on) {
+  if (!c) return ELP_ERR_ARG;
+  c->sort_ahead = on != 0;
+  if (!on) c->presort_epoch = ~0ull;
+  return 0;
+}
 
 extern "C" int elp_sort_coordinate(elp_ctx *c) {
   if (!c) return ELP_ERR_ARG;

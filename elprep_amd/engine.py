@@ -295,6 +295,11 @@ class Engine:
         return slots
 
     # ---- operators
+    def sort_ahead(self, on: bool = True):
+        """elp_sort_ahead: a coordinate sort will follow mark duplicates - its key passes are queued on the sort lane from inside
+        elp_mark_duplicates, as soon as the keys exist"""
+        self._check(self.L.elp_sort_ahead(self.h, 1 if on else 0))
+
     def sort_coordinate(self, fetch: bool = True) -> Optional[np.ndarray]:
         self._check(self.L.elp_sort_coordinate(self.h))
         return self.permutation() if fetch else None

@@ -219,6 +219,12 @@ int elp_merge_spread(elp_ctx *groups, elp_ctx *spread, uint64_t *slot_of_spread_
  * elp_emit_*) are ordered behind it.  Calls that CHANGE staged records (staging, reset, rollback, filters, exchange) must not overlap
  * with any other call on the context. */
 int elp_sort_coordinate(elp_ctx *ctx);
+/* on != 0: the host announces that elp_sort_coordinate will follow elp_mark_duplicates on this context (what `elprep filter
+ * --mark-duplicates --sorting-order coordinate` does, sam/filter-pipeline.go:116).  The sort's key passes read the coordinate keys only -
+ * not the duplicate bits, which only the comparator's tail (modFlag, sam/sam-types.go:447-452) looks at - so elp_mark_duplicates queues
+ * them on the sort lane as soon as it has made the keys, and they run while it finishes; elp_sort_coordinate then breaks the ties on the
+ * final FLAGs.  Same permutation either way; without a sort behind it the option costs the passes' time. */
+int elp_sort_ahead(elp_ctx *ctx, int on);
 int elp_get_permutation(elp_ctx *ctx, uint32_t *perm_out /* n */);
 /* number of records that survive RemoveOptionalReads = staged records without the sr tag: the first elp_num_sorted() entries of
  * the permutation are the output of the run, the tagged copies follow behind them */

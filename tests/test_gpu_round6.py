@@ -158,3 +158,57 @@ def test_bench_with_two_ranks_as_the_driver_launches_it(tmp_path):
     d = json.loads(line[0])
     assert d["n_gpus"] == world and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["config"]["workload"] and "roofline" in d
+
+
+@pytest.mark.parametrize("ahead", [False, True])
+@pytest.mark.parametrize("name,pairs,seed,pfrag,n_lanes", [("tiny", 6000, 3, 0.02, 4), ("tiny", 30000, 7, 0.0, 4), ("tiny", 2500, 11, 0.3, 20), ("tiny", 40, 13, 0.0, 1)])
+def test_sort_metrics_and_the_bqsr_chain_at_once(name, pairs, seed, pfrag, n_lanes, ahead):
+    """Behind elp_mark_duplicates the coordinate sort (side lane 1), the metrics pass (side lane 0) and gather -> finalize -> apply need
+    nothing of each other: three host threads drive them at once on ONE context (what bench.py's default step and SfmRank.step do,
+    include/elprep_hip.h at elp_sort_coordinate) - several rounds on the same context (snapshot / rollback), every output against the
+    oracle each time.  ahead: elp_sort_ahead - the sort's key passes are queued from inside elp_mark_duplicates (rounds alternate with a
+    plain sequential round, so a stale set of sorted words would show)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from elprep_amd.engine import BqsrTables, Engine
+    cfg = synth.config(name, seed)
+    cfg.p_frag = pfrag
+    cfg.n_lanes = n_lanes
+    b = synth.generate(cfg, 0, pairs)
+    h = cfg.header()
+    refs = [synth.reference(cfg, r) for r in range(h.n_ref)]
+    sites = [orc.flatten(orc.sort_by_start(synth.known_sites_raw(cfg, r))) for r in range(h.n_ref)]
+    oflags = orc.mark_duplicates(b, h)
+    operm = orc.sort_coordinate(b, oflags)
+    _, octr, _ = orc.dup_metrics(b, h, operm, 100)
+    oq, oc, ox = orc.bqsr_gather(b, h, orc.BqsrRef(refs, sites), oflags, 500)
+    oqual = orc.BqsrFinal(oq, oc, ox, 500).apply(b, h, 0)
+    e = Engine(h, 0)
+    cuts = np.linspace(0, b.n, 4).astype(int)
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        e.stage(b.take(np.arange(lo, hi)))
+    for r in range(h.n_ref):
+        e.set_reference(r, refs[r])
+        e.set_known_sites(r, sites[r])
+    e.snapshot()
+    e.sort_ahead(ahead)
+    with ThreadPoolExecutor(1) as sort_pool, ThreadPoolExecutor(1) as mx_pool:
+        for rnd in range(4):
+            e.rollback()
+            if ahead and rnd == 2:  # a sort WITHOUT mark duplicates in front (keys by the adapt stage, no passes made ahead), then on
+                e.sort_ahead(False)
+                assert np.array_equal(e.sort_coordinate(), orc.sort_coordinate(b))
+                e.sort_ahead(True)
+                e.rollback()
+            e.mark_duplicates(True, fetch=False)
+            st = sort_pool.submit(e.sort_coordinate)
+            mx = mx_pool.submit(e.dup_metrics, 100)
+            qt, ct, xt = e.recalibrate(500)
+            lut, present = BqsrTables(qt, ct, xt, 500).finalize().build_lut(0)
+            qual = e.apply_bqsr(lut, present, 500)
+            perm, ctr = st.result(), mx.result()
+            assert np.array_equal(e.flags(), oflags), ("flags", rnd)
+            assert np.array_equal(perm, operm), ("order", rnd)
+            assert np.array_equal(ctr, octr), ("counters", rnd)
+            assert np.array_equal(qt, oq) and np.array_equal(ct, oc) and np.array_equal(xt, ox), ("tables", rnd)
+            assert np.array_equal(qual, oqual), ("qualities", rnd)
+    e.close()

@@ -39,12 +39,25 @@ for seed in range(first, first + count):
     for r in range(h.n_ref):
         e.set_reference(r, refs[r])
         e.set_known_sites(r, sites[r])
-    flags = e.mark_duplicates(True)
-    perm = e.sort_coordinate()
-    ctr = e.dup_metrics(100)
-    qt, ct, xt = e.recalibrate(500)
-    lut, present = BqsrTables(qt, ct, xt, 500).finalize().build_lut(0)
-    qual = e.apply_bqsr(lut, present, 500)
+    at_once = bool(rng.integers(0, 2))  # round 6: the sort, the metrics pass and the BQSR chain driven at once from three host threads
+    e.sort_ahead(bool(rng.integers(0, 2)))  # elp_sort_ahead: the sort's key passes queued from inside mark duplicates
+    if at_once:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(2) as pool:
+            e.mark_duplicates(True, fetch=False)
+            st, mx = pool.submit(e.sort_coordinate), pool.submit(e.dup_metrics, 100)
+            qt, ct, xt = e.recalibrate(500)
+            lut, present = BqsrTables(qt, ct, xt, 500).finalize().build_lut(0)
+            qual = e.apply_bqsr(lut, present, 500)
+            perm, ctr = st.result(), mx.result()
+        flags = e.flags()
+    else:
+        flags = e.mark_duplicates(True)
+        perm = e.sort_coordinate()
+        ctr = e.dup_metrics(100)
+        qt, ct, xt = e.recalibrate(500)
+        lut, present = BqsrTables(qt, ct, xt, 500).finalize().build_lut(0)
+        qual = e.apply_bqsr(lut, present, 500)
     oflags = orc.mark_duplicates(b, h)
     operm = orc.sort_coordinate(b, oflags)
     _, octr, _ = orc.dup_metrics(b, h, operm, 100)
@@ -53,7 +66,7 @@ for seed in range(first, first + count):
     ok = (np.array_equal(flags, oflags), np.array_equal(perm, operm), np.array_equal(ctr, octr),
           np.array_equal(qt, oq) and np.array_equal(ct, oc) and np.array_equal(xt, ox), np.array_equal(qual, oqual))
     e.close()
-    print(f"seed {seed}: {b.n} records, p_frag {cfg.p_frag}, p_dup {cfg.p_dup}, quals {cfg.qual_mode}, {tuning}: "
+    print(f"seed {seed}: {b.n} records, p_frag {cfg.p_frag}, p_dup {cfg.p_dup}, quals {cfg.qual_mode}, {tuning}, at once {at_once}: "
           f"flags {ok[0]} perm {ok[1]} metrics {ok[2]} tables {ok[3]} qual {ok[4]}", flush=True)
     if not all(ok):
         bad += 1

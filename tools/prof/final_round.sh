@@ -7,7 +7,7 @@ OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
 timeout 1200 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json; tail -2 $OUT/bench.err
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extra > $OUT/bench_prof.json 2> $OUT/prof.err; echo "prof rc=$?")
 DB=$(find $OUT/prof -name "*results.db" | head -1)
-python tools/prof/db_to_csv.py $DB $OUT/kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-extra (50M reads); the 8 timed steps (the 2 warm-up steps left out: their first launches run cold)" 2
+python tools/prof/db_to_csv.py $DB $OUT/kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-extra (50M reads); the 8 timed steps (the 2 warm-up steps in front and the serial-order steps behind them left out)" 2 8
 python tools/prof/db_to_csv.py $DB $OUT/kernel_stats_all_steps.csv "rocprofv3 top_kernels summary of the same trace: all 10 steps incl. warm-up"
 python tools/prof/timeline.py $DB $OUT/timeline.csv; head -2 $OUT/timeline.csv
 find $OUT/prof -size +20M -delete
