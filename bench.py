@@ -241,7 +241,10 @@ def main():
     # one after the other (`serial_order`, outside the timed region); "metrics" = the metrics pass under the sort, both behind the gather
     # (the BQSR kernels have the GPU to themselves); "serial" = one after the other, as until round 5
     order = os.environ.get("ELP_BENCH_ORDER", "three")
-    sort_ahead = os.environ.get("ELP_BENCH_SORT_AHEAD", "1") != "0"
+    # elp_sort_ahead (the sort's key passes queued from inside mark duplicates): measured on the bench's step, it does not pay - the passes'
+    # 1024-thread workgroups find no CU while the pair phase's and the prologues' small workgroups keep every CU partly occupied, and with
+    # smaller tiles they slow the pair phase by what they gain (profiles/round6_sort_ahead_ab.txt); off unless asked for
+    sort_ahead = os.environ.get("ELP_BENCH_SORT_AHEAD", "0") != "0"
 
     def generated(jobs):
         """yield the batches of `jobs` = [(config, pair_lo, pair_hi), ...] in order; the generator is deterministic per pair index,

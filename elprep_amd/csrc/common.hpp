@@ -254,6 +254,11 @@ struct elp_ctx {
     int bgzf_stored = 0;       // 1: elp_emit_sorted_bgzf writes stored DEFLATE blocks (round 4's form) instead of compressing
     int apply_wgs = 0;         // 1 .. 3: workgroups per CU of the one-length ApplyBQSR kernel (default: as many as its LDS allows, at most 3) - A/B runs
                                // of a step whose sort runs at the same time and needs LDS of its own
+    int presort_tile = 0;      // elp_sort_ahead: radix tile of the key passes made ahead (1 / 2 / 3 = 4096 / 8192 / 16384 keys; default 2: a tile of
+                               // 16384 keys is a 1024-thread workgroup around 128 KB of LDS, which finds no CU while kernels of small workgroups
+                               // keep every CU partly occupied)
+    int side_priority = 0;     // 1: the side lanes' streams are made with the highest priority the device offers (default: the default priority;
+                               // measured with the bench's step: no difference)
     int md_fused = 0;          // 1: mark duplicates by the separate passes of rounds 2-5 (adapt_fixed, md_keys, md_mate_scan, md_mate_pairs) instead of
                                // the fused front pass of round 6 (k_md_front); tests run both
   } tune;

@@ -181,7 +181,12 @@ int side_lane(elp_ctx *c, int lane, elp_ctx **out) {
     elp_ctx *s = new elp_ctx();
     s->device = c->device;
     s->n_cu = c->n_cu;
-    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess || ensure(s, s->err_flag, 4) != 0 ||
+    // (elp_set_tuning "side_priority" = 1, before the lane's first use: the highest stream priority - measured: no difference)
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    const hipError_t se = c->tune.side_priority != 1 ? hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)
+                                                     : hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, prio_hi);
+    if (se != hipSuccess || ensure(s, s->err_flag, 4) != 0 ||
         hipMemsetAsync(s->err_flag.p, 0, 16, s->stream) != hipSuccess) {
       if (s->stream) (void)hipStreamDestroy(s->stream);
       delete s;
@@ -589,6 +594,8 @@ int elp_set_tuning(elp_ctx *c, const char *key, int64_t value) {
   else if (k == "bgzf_stored") c->tune.bgzf_stored = v;
   else if (k == "md_fused") c->tune.md_fused = v;
   else if (k == "apply_wgs") c->tune.apply_wgs = v;
+  else if (k == "presort_tile") c->tune.presort_tile = v;
+  else if (k == "side_priority") c->tune.side_priority = v;
   else return set_error(c, ELP_ERR_ARG, "elp_set_tuning: unknown key '%s'", key);
   return 0;
 }

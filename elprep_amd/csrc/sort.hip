@@ -1179,9 +1179,12 @@ int sort_presort(elp_ctx *c) {
   elp_ctx *s = nullptr;
   ELP_TRY(side_lane(c, 1, &s));
   s->n = n; s->key_bits = c->key_bits;
+  const int tile_saved = s->tune.radix_tile;
+  if (!s->tune.radix_tile) s->tune.radix_tile = c->tune.presort_tile >= 1 && c->tune.presort_tile <= 3 ? c->tune.presort_tile : 2;
   uint64_t *kbuf, *ks = nullptr;
   int rc = scratch(s, 0, 2 * n + 8, &kbuf);
   if (rc == 0) rc = radix_sort_fused(s, c->key.p, n, c->key_bits, idx_bits, kbuf, kbuf + n, &ks);
+  s->tune.radix_tile = tile_saved;
   if (rc != 0) { c->err = s->err; return rc; }
   c->presort_ks = ks; c->presort_n = n; c->presort_idx_bits = idx_bits; c->presort_epoch = c->adapt_epoch;
   return 0;

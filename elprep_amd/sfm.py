@@ -496,7 +496,6 @@ class SfmRank:
             self._side = ThreadPoolExecutor(1)
 
         def count(e, pool=None, sort_pool=None):
-            e.sort_ahead(pool is not None)  # (the group splits' context: its sort's key passes start inside mark duplicates)
             e.mark_duplicates(True, fetch=False)
             st = None
             if pool is not None:

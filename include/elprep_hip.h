@@ -223,7 +223,9 @@ int elp_sort_coordinate(elp_ctx *ctx);
  * --mark-duplicates --sorting-order coordinate` does, sam/filter-pipeline.go:116).  The sort's key passes read the coordinate keys only -
  * not the duplicate bits, which only the comparator's tail (modFlag, sam/sam-types.go:447-452) looks at - so elp_mark_duplicates queues
  * them on the sort lane as soon as it has made the keys, and they run while it finishes; elp_sort_coordinate then breaks the ties on the
- * final FLAGs.  Same permutation either way; without a sort behind it the option costs the passes' time. */
+ * final FLAGs.  Same permutation either way; without a sort behind it the option costs the passes' time.  (Measured with bench.py's step,
+ * where the gather follows mark duplicates at once: no gain - the GPU is busy either way, profiles/round6_sort_ahead_ab.txt; it is for a
+ * host that has work of its own between the two calls.) */
 int elp_sort_ahead(elp_ctx *ctx, int on);
 int elp_get_permutation(elp_ctx *ctx, uint32_t *perm_out /* n */);
 /* number of records that survive RemoveOptionalReads = staged records without the sr tag: the first elp_num_sorted() entries of

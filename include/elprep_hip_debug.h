@@ -46,6 +46,8 @@ int elp_rollback(elp_ctx *ctx);
  *   "qual_hint_drop"   q >= 0: quality q is removed from the sampled hint (the kernels' no-slot paths)
  *   "pair_table_slots" cap on the LDS table slots per pair bucket of elp_mark_duplicates (a power of two >= 2; 0 = no cap): a
  *                      small value sends every bucket through the overflow path
+ *   "presort_tile"     1 / 2 / 3: radix tile (4096 / 8192 / 16384 keys) of the key passes elp_sort_ahead queues from inside mark duplicates (default 2)
+ *   "side_priority"    1: the side lanes' streams (sort, metrics) get the highest stream priority instead of the default - set before their first use
  *   "apply_wgs"        1 .. 3: workgroups per CU of the one-length ApplyBQSR kernel (default: what its LDS allows, at most 3)
  *   "md_fused"         1: mark duplicates by the separate passes of rounds 2-5 (adapt_fixed, md_keys, md_mate_scan, md_mate_pairs) instead of
  *                      the fused front pass of round 6 (md_front) - same flags; A/B timing and the tests run both
