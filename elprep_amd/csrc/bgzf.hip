@@ -10,6 +10,7 @@
 // crc32_combine).
 #include "common.hpp"
 #include "deflate_core.hpp"
+#include <atomic>
 
 namespace elp {
 
@@ -582,6 +583,342 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
   (void)n_blk;
 }
 
+
+// ------------------------------------------------------------------ inflate in two phases (round 6)
+// What bounds the one-wave-per-block decoder above, measured on the bench's BAM records (zlib level 1 and 6): 61 % / 39 % of the symbols
+// are matches of 5 / 7 bytes, literal runs are 0.6 / 1.6 symbols long, 31 % / 40 % of the matches reach further back than the 4 KB of the
+// block's output the wave keeps in LDS (a global round trip each), and the rate follows the waves per CU (4 / 8 / 11 waves: 4.0 / 6.1 / 7.1
+// GB/s), i.e. the LDS per wave - window, ring, tables.  The serial part of DEFLATE is the bit stream, not the copies:
+//   phase A  k_bgzf_tokens   a wave per block walks the Huffman stream and does NOTHING else: a literal goes straight to its place in the
+//            block's output (HBM), a match becomes an 8-byte token {output position | length << 16, distance}, 64 of them at a time
+//            written coalesced.  No window, no drain: 4 KB of LDS per wave (ring, u16 tables), eight waves per SIMD.
+//   phase B  k_bgzf_resolve  a workgroup per block: every output byte gets a PARENT in LDS (u16 [65536]) - itself for a literal, position
+//            - distance for a byte of a match (also inside an overlapping match) -; pointer jumping (parent = parent[parent], until nothing
+//            changes: the depth of the copy-of-a-copy chains, logarithmically) leaves every byte pointing at the literal it descends from;
+//            one gather from the block's own output, which holds the literals already, fills the matches in.
+// Stored blocks copy their bytes in phase A.  The tokens of a block: at most (bytes / 3) of 8 bytes each, 174 KB per block of scratch.
+constexpr int TOK_RING = 1024, TOK_BUF = 64;
+constexpr uint32_t TOK_STRIDE = 21824;  // tokens per block: >= 65536 / 3 + 1, a multiple of 64
+struct TokLds {
+  uint8_t ring[TOK_RING];
+  uint16_t ltab[1 << INF_LBITS], dtab[1 << INF_DBITS];  // symbol << 4 | code length; 0: longer than the table's bits
+  uint16_t lcount[16], dcount[16], lsym[288], dsym[32];
+  uint8_t lengths[320];
+  uint32_t tok[TOK_BUF][2];
+  int left;
+};
+// (canon_decode as above)
+__device__ inline int tok_huff_build(TokLds *L, uint16_t *count, uint16_t *symbol, const uint8_t *length, int n, uint16_t *tab, int tbits) {
+  if ((threadIdx.x & 63u) == 0) {
+    uint16_t offs[16];
+    for (int len = 0; len <= 15; len++) count[len] = 0;
+    for (int sym = 0; sym < n; sym++) count[length[sym]]++;
+    int left = 1;
+    if (count[0] == n) left = 0;
+    else {
+      for (int len = 1; len <= 15 && left >= 0; len++) { left <<= 1; left -= count[len]; }
+      if (left >= 0) {
+        offs[1] = 0;
+        for (int len = 1; len < 15; len++) offs[len + 1] = offs[len] + count[len];
+        for (int sym = 0; sym < n; sym++)
+          if (length[sym] != 0) symbol[offs[length[sym]]++] = (uint16_t)sym;
+      }
+    }
+    L->left = left;
+  }
+  __syncthreads();  // (one wave per workgroup: orders its lanes' LDS writes before the reads that follow)
+  const int left = L->left;
+  if (left >= 0)
+    for (uint32_t idx = threadIdx.x & 63u; idx < (1u << tbits); idx += 64u) {
+      int len = 0;
+      const int sym = canon_decode(count, symbol, idx, &len);
+      tab[idx] = (sym >= 0 && len <= tbits) ? (uint16_t)(((uint32_t)sym << 4) | (uint32_t)len) : (uint16_t)0;
+    }
+  __syncthreads();
+  return left;
+}
+struct TokInflater {
+  TokLds *L;
+  const uint8_t *in;
+  uint32_t in_len, in_at, loaded;
+  unsigned long long bitbuf;
+  int bitcnt, err;
+  uint32_t out_len, out_at;
+  uint8_t *out;
+  uint2 *tokens;   // the block's token array (HBM)
+  uint32_t ntok;
+  // the ring holds input [loaded - TOK_RING, loaded): topped up whenever the reader enters its last half (32 lanes x 16 bytes = half the ring)
+  __device__ __forceinline__ void feed() {
+    while (loaded < in_len && in_at + TOK_RING / 2 > loaded) {
+      const uint32_t lane = threadIdx.x & 63u, p = loaded + lane * 16u;
+      __syncthreads();
+      if (lane < (uint32_t)TOK_RING / 32u && p < in_len) {  // (the compressed bytes are followed by the trailer and the buffer's padding: a 16-byte read is safe)
+        uint4 v;
+        __builtin_memcpy(&v, in + p, 16);
+        *reinterpret_cast<uint4 *>(&L->ring[p & (TOK_RING - 1)]) = v;
+      }
+      __syncthreads();
+      loaded = loaded + TOK_RING / 2 < in_len ? loaded + TOK_RING / 2 : in_len;
+    }
+  }
+  // at least 48 bits in the buffer (or everything that is left): two aligned 8-byte reads of the ring, shifted together
+  __device__ __forceinline__ void refill() {
+    if (bitcnt >= 48) return;
+    feed();
+    uint32_t nb = (uint32_t)(64 - bitcnt) >> 3;
+    nb = nb < in_len - in_at ? nb : in_len - in_at;
+    const unsigned long long *r64 = reinterpret_cast<const unsigned long long *>(L->ring);
+    const uint32_t a = (in_at & (TOK_RING - 1)) >> 3, sh = (in_at & 7u) * 8u;
+    const unsigned long long w0 = r64[a], w1 = r64[(a + 1) & (TOK_RING / 8 - 1)];
+    unsigned long long w = sh ? (w0 >> sh) | (w1 << (64u - sh)) : w0;
+    if (nb < 8) w &= (1ull << (8 * nb)) - 1ull;
+    bitbuf |= bitcnt < 64 ? w << bitcnt : 0ull;
+    in_at += nb;
+    bitcnt += 8 * (int)nb;
+  }
+  __device__ __forceinline__ uint32_t bits(int n) {  // n <= 16, taken from what refill() provided
+    if (bitcnt < n) { err = 1; return 0; }
+    const uint32_t v = (uint32_t)bitbuf & ((1u << n) - 1u);
+    bitbuf >>= n;
+    bitcnt -= n;
+    return v;
+  }
+  __device__ __forceinline__ int symbol(const uint16_t *tab, int tbits, const uint16_t *count, const uint16_t *sym_of) {
+    const uint32_t e = tab[(uint32_t)bitbuf & ((1u << tbits) - 1u)];
+    if (e) {
+      const int len = (int)(e & 0xFu);
+      if (bitcnt < len) { err = 1; return -1; }
+      bitbuf >>= len;
+      bitcnt -= len;
+      return (int)(e >> 4);
+    }
+    int len = 0;
+    const int sym = canon_decode(count, sym_of, (uint32_t)bitbuf, &len);
+    if (sym < 0 || bitcnt < len) { err = 1; return -1; }
+    bitbuf >>= len;
+    bitcnt -= len;
+    return sym;
+  }
+  __device__ __forceinline__ void flush_tokens(uint32_t n_in_buf) {  // the buffered tokens go out, a lane each
+    const uint32_t lane = threadIdx.x & 63u;
+    __syncthreads();
+    if (lane < n_in_buf) tokens[ntok - n_in_buf + lane] = make_uint2(L->tok[lane][0], L->tok[lane][1]);
+    __syncthreads();
+  }
+  __device__ __forceinline__ void put_token(uint32_t len, uint32_t dist) {
+    const uint32_t k = ntok & (TOK_BUF - 1);
+    if ((threadIdx.x & 63u) == 0) { L->tok[k][0] = out_at | (len << 16); L->tok[k][1] = dist; }
+    ntok++;
+    if (k == TOK_BUF - 1) flush_tokens(TOK_BUF);
+  }
+};
+__device__ inline int tok_codes(TokInflater &s) {
+  TokLds *L = s.L;
+  const uint32_t lane = threadIdx.x & 63u;
+  for (;;) {
+    s.refill();
+    int symbol = s.symbol(L->ltab, INF_LBITS, L->lcount, L->lsym);
+    if (symbol < 0) return 2;
+    if (symbol < 256) {
+      if (s.out_at == s.out_len) return 3;
+      if (lane == 0) s.out[s.out_at] = (uint8_t)symbol;
+      s.out_at++;
+    } else if (symbol == 256) {
+      return 0;
+    } else {
+      symbol -= 257;
+      if (symbol >= 29) return 4;
+      const uint32_t len = inf_len_base((uint32_t)symbol) + s.bits((int)inf_len_ext((uint32_t)symbol));
+      symbol = s.symbol(L->dtab, INF_DBITS, L->dcount, L->dsym);
+      if (symbol < 0 || symbol >= 30) return 5;
+      const uint32_t dist = inf_dist_base((uint32_t)symbol) + s.bits((int)inf_dist_ext((uint32_t)symbol));
+      if (s.err) return 1;
+      if (dist > s.out_at) return 6;
+      if (s.out_at + len > s.out_len) return 3;
+      if (s.ntok >= TOK_STRIDE) return 17;  // (cannot happen: a match is three bytes or more)
+      s.put_token(len, dist);
+      s.out_at += len;
+    }
+  }
+}
+__global__ __launch_bounds__(64) void k_bgzf_tokens(const uint8_t *__restrict__ cdata, const BgzfBlk *__restrict__ blk, uint32_t n_blk, uint8_t *__restrict__ raw,
+                                                    uint2 *__restrict__ tokens, uint32_t *__restrict__ ntok_out, uint32_t *err) {
+  __shared__ __attribute__((aligned(16))) TokLds L;
+  const uint32_t lane = threadIdx.x;
+  const BgzfBlk B = blk[blockIdx.x];
+  TokInflater s{&L, cdata + B.in_off, B.in_len, 0, 0, 0ull, 0, 0, B.out_len, 0, raw + B.out_off, tokens + (size_t)blockIdx.x * TOK_STRIDE, 0};
+  int rc = 0, last;
+  do {
+    s.refill();
+    last = (int)s.bits(1);
+    const int type = (int)s.bits(2);
+    if (s.err) { rc = 1; break; }
+    if (type == 0) {  // stored: back to a byte boundary, LEN, NLEN, the bytes - straight to the output
+      const int drop = s.bitcnt & 7;
+      s.bitbuf >>= drop;
+      s.bitcnt -= drop;
+      s.refill();
+      const uint32_t len = s.bits(16), nlen = s.bits(16);
+      if (s.err) { rc = 1; break; }
+      if (len != (~nlen & 0xFFFFu)) { rc = 7; break; }
+      if (s.out_at + len > s.out_len) { rc = 3; break; }
+      // the bytes the bit buffer still holds are the next bytes of the input: step the reader back onto them, then copy from HBM
+      const uint32_t pos = s.in_at - (uint32_t)(s.bitcnt >> 3);
+      if (pos + len > s.in_len) { rc = 1; break; }
+      for (uint32_t k = lane; k < len; k += 64u) s.out[s.out_at + k] = s.in[pos + k];
+      s.out_at += len;
+      s.in_at = pos + len;
+      s.bitbuf = 0;
+      s.bitcnt = 0;
+      // (the ring: everything up to a multiple of its half that the reader has passed counts as loaded; the next feed brings what follows)
+      s.loaded = s.in_at & ~(uint32_t)(TOK_RING / 2 - 1);
+      if (s.loaded > s.in_len) s.loaded = s.in_len;
+      {  // the half the reader stands in must be in the ring before it reads: load it whole
+        const uint32_t p = s.loaded + lane * 16u;
+        __syncthreads();
+        if (lane < (uint32_t)TOK_RING / 32u && p < s.in_len) {
+          uint4 v;
+          __builtin_memcpy(&v, s.in + p, 16);
+          *reinterpret_cast<uint4 *>(&L.ring[p & (TOK_RING - 1)]) = v;
+        }
+        __syncthreads();
+        s.loaded = s.loaded + TOK_RING / 2 < s.in_len ? s.loaded + TOK_RING / 2 : s.in_len;
+      }
+    } else if (type == 1) {  // fixed codes
+      for (uint32_t sym = lane; sym < 288; sym += 64) L.lengths[sym] = sym < 144 ? 8 : (sym < 256 ? 9 : (sym < 280 ? 7 : 8));
+      __syncthreads();
+      tok_huff_build(&L, L.lcount, L.lsym, L.lengths, 288, L.ltab, INF_LBITS);
+      if (lane < 30) L.lengths[lane] = 5;
+      __syncthreads();
+      tok_huff_build(&L, L.dcount, L.dsym, L.lengths, 30, L.dtab, INF_DBITS);
+      rc = tok_codes(s);
+    } else if (type == 2) {  // dynamic codes
+      const int nlen = (int)s.bits(5) + 257, ndist = (int)s.bits(5) + 1, ncode = (int)s.bits(4) + 4;
+      if (s.err) { rc = 1; break; }
+      if (nlen > 286 || ndist > 30) { rc = 8; break; }
+      if (lane < 19) L.lengths[lane] = 0;
+      __syncthreads();
+      for (int index = 0; index < ncode; index++) {
+        s.refill();
+        const uint32_t v = s.bits(3);
+        if (lane == 0) L.lengths[INF_ORDER[index]] = (uint8_t)v;
+      }
+      __syncthreads();
+      if (tok_huff_build(&L, L.lcount, L.lsym, L.lengths, 19, L.ltab, INF_LBITS) != 0) { rc = 9; break; }
+      int index = 0;
+      uint32_t prev = 0;
+      while (index < nlen + ndist) {
+        s.refill();
+        const int symbol = s.symbol(L.ltab, INF_LBITS, L.lcount, L.lsym);
+        if (symbol < 0) { rc = 2; break; }
+        if (symbol < 16) {
+          if (lane == 0) L.lengths[index] = (uint8_t)symbol;
+          prev = (uint32_t)symbol;
+          index++;
+        } else {
+          uint32_t len = 0;
+          int rep;
+          if (symbol == 16) {
+            if (index == 0) { rc = 10; break; }
+            len = prev;
+            rep = 3 + (int)s.bits(2);
+          } else if (symbol == 17) rep = 3 + (int)s.bits(3);
+          else rep = 11 + (int)s.bits(7);
+          if (index + rep > nlen + ndist) { rc = 11; break; }
+          if ((int)lane < rep) L.lengths[index + lane] = (uint8_t)len;
+          if ((int)lane + 64 < rep) L.lengths[index + lane + 64] = (uint8_t)len;
+          if ((int)lane + 128 < rep) L.lengths[index + lane + 128] = (uint8_t)len;
+          index += rep;
+          prev = len;
+        }
+      }
+      if (rc) break;
+      __syncthreads();
+      if (L.lengths[256] == 0) { rc = 12; break; }
+      int e = tok_huff_build(&L, L.dcount, L.dsym, L.lengths + nlen, ndist, L.dtab, INF_DBITS);
+      if (e && (e < 0 || ndist != (int)L.dcount[0] + (int)L.dcount[1])) { rc = 14; break; }
+      e = tok_huff_build(&L, L.lcount, L.lsym, L.lengths, nlen, L.ltab, INF_LBITS);
+      if (e && (e < 0 || nlen != (int)L.lcount[0] + (int)L.lcount[1])) { rc = 13; break; }
+      rc = tok_codes(s);
+    } else rc = 15;
+  } while (!rc && !last);
+  if (!rc && s.out_at != s.out_len) rc = 16;  // ISIZE promised another number of bytes
+  if (rc) {
+    if (lane == 0) { atomicOr(&err[0], 1u); ntok_out[blockIdx.x] = 0; }
+    return;
+  }
+  s.flush_tokens(s.ntok & (TOK_BUF - 1));
+  if (lane == 0) ntok_out[blockIdx.x] = s.ntok;
+  (void)n_blk;
+}
+
+// phase B: see above.  One workgroup of 1024 threads per block around the parents of its (at most 65536) output bytes; then the block's
+// CRC-32 while its bytes are in the L2: 64 bytes per thread, four bytes per step (tables of the CRC of a byte 0..3 positions further on -
+// four independent look-ups instead of four dependent ones), the partial CRCs shifted to their place by x^(8 * bytes behind) mod p.
+constexpr int RES_THREADS = 1024;
+__global__ __launch_bounds__(RES_THREADS) void k_bgzf_resolve(const BgzfBlk *__restrict__ blk, uint8_t *__restrict__ raw, const uint2 *__restrict__ tokens,
+                                                            const uint32_t *__restrict__ ntok_in, CrcPow pw, uint32_t *err) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t parent[];  // [65536]; the CRC tables afterwards
+  __shared__ uint32_t s_crc;
+  const uint32_t nt = ntok_in[blockIdx.x];
+  const BgzfBlk B = blk[blockIdx.x];
+  uint8_t *out = raw + B.out_off;
+  const uint32_t n = B.out_len, t = threadIdx.x;
+  if (nt) {  // (0: nothing but literals and stored bytes - or the block did not inflate: reported by phase A)
+    for (uint32_t j = t; j < n; j += RES_THREADS) parent[j] = (uint16_t)j;
+    __syncthreads();
+    const uint2 *tk = tokens + (size_t)blockIdx.x * TOK_STRIDE;
+    for (uint32_t k = t; k < nt; k += RES_THREADS) {
+      const uint2 tok = tk[k];
+      const uint32_t p = tok.x & 0xFFFFu, len = tok.x >> 16, src = p - tok.y;
+      for (uint32_t i = 0; i < len; i++) parent[p + i] = (uint16_t)(src + i);
+    }
+    __syncthreads();
+    // pointer jumping: a byte of a match points at a byte in front of it; when nothing moves any more, at a literal
+    for (int round = 0; round < 17; round++) {
+      int moved = 0;
+      for (uint32_t j = t; j < n; j += RES_THREADS) {
+        const uint16_t q = parent[j], r = parent[q];
+        if (r != q) { parent[j] = r; moved = 1; }
+      }
+      if (!__syncthreads_or(moved)) break;
+    }
+    for (uint32_t j = t; j < n; j += RES_THREADS) {
+      const uint16_t q = parent[j];
+      if (q != (uint16_t)j) out[j] = out[q];
+    }
+    __syncthreads();  // (and the workgroup's stores are visible to its own loads below)
+  }
+  uint32_t *T = reinterpret_cast<uint32_t *>(parent);  // [4][256]
+  if (t < 256) {
+    uint32_t c = t;
+    for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ BGZF_POLY : c >> 1;
+    T[t] = c;
+  }
+  if (t == 0) s_crc = 0;
+  __syncthreads();
+  if (t < 256) {
+    uint32_t c = T[t];
+    for (int k = 1; k < 4; k++) { c = (c >> 8) ^ T[c & 0xFFu]; T[k * 256 + t] = c; }
+  }
+  __syncthreads();
+  const uint32_t lo = t * 64u < n ? t * 64u : n, hi = lo + 64u < n ? lo + 64u : n;
+  if (hi > lo) {
+    uint32_t c = 0xFFFFFFFFu, k = lo;
+    for (; k + 4u <= hi; k += 4u) {
+      uint32_t w;
+      __builtin_memcpy(&w, out + k, 4);
+      c ^= w;
+      c = T[768 + (c & 0xFFu)] ^ T[512 + ((c >> 8) & 0xFFu)] ^ T[256 + ((c >> 16) & 0xFFu)] ^ T[c >> 24];
+    }
+    for (; k < hi; k++) c = T[(c ^ out[k]) & 0xFFu] ^ (c >> 8);
+    c ^= 0xFFFFFFFFu;
+    atomicXor(&s_crc, crc_mulmod(crc_x8n(pw, n - hi), c));
+  }
+  __syncthreads();
+  if (t == 0 && s_crc != B.crc) atomicOr(&err[0], 2u);
+}
+
 // CRC-32 of every inflated block against the value in its trailer (one workgroup per block, as in k_bgzf_frame)
 __global__ __launch_bounds__(256) void k_bgzf_crc_check(const uint8_t *__restrict__ raw, const BgzfBlk *__restrict__ blk, CrcPow pw, uint32_t *err) {
   __shared__ uint32_t tbl[256];
@@ -823,8 +1160,22 @@ extern "C" int elp_stage_bgzf(elp_ctx *c, const uint8_t *bgzf, uint64_t n_bytes,
     ELP_HIP(c, hipMemcpyAsync(d_blk, tb.data(), (size_t)nb * sizeof(BgzfBlk), hipMemcpyHostToDevice, st));
     ELP_HIP(c, hipMemsetAsync(res, 0, 64, st));
     uint32_t *err = reinterpret_cast<uint32_t *>(res), *bad = err + 1, *max_rec = err + 2;
-    ELP_LAUNCH(c, "stage_bgzf_inflate", k_bgzf_inflate, dim3(nb), dim3(64), 0, (const uint8_t *)d_in, (const BgzfBlk *)d_blk, nb, c->raw.p, err);
-    ELP_LAUNCH(c, "stage_bgzf_crc", k_bgzf_crc_check, dim3(nb), dim3(256), 0, (const uint8_t *)c->raw.p, (const BgzfBlk *)d_blk, pw, err);
+    if (c->tune.bgzf_inflate == 1) {  // round 5's form: one kernel that decodes and copies, and the CRC pass
+      ELP_LAUNCH(c, "stage_bgzf_inflate", k_bgzf_inflate, dim3(nb), dim3(64), 0, (const uint8_t *)d_in, (const BgzfBlk *)d_blk, nb, c->raw.p, err);
+      ELP_LAUNCH(c, "stage_bgzf_crc", k_bgzf_crc_check, dim3(nb), dim3(256), 0, (const uint8_t *)c->raw.p, (const BgzfBlk *)d_blk, pw, err);
+    } else {  // the bit stream first (literals placed, matches as tokens), then the matches and the CRC, a workgroup per block
+      uint2 *tok;
+      ELP_TRY(scratch(c, 7, (size_t)nb * TOK_STRIDE + (size_t)(nb + 2) / 2 + 8, &tok));
+      uint32_t *ntok = reinterpret_cast<uint32_t *>(tok + (size_t)nb * TOK_STRIDE);
+      static std::atomic<bool> lds_set{false};
+      if (!lds_set.load()) {
+        ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bgzf_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(65536 * sizeof(uint16_t))));
+        lds_set.store(true);
+      }
+      ELP_LAUNCH(c, "stage_bgzf_tokens", k_bgzf_tokens, dim3(nb), dim3(64), 0, (const uint8_t *)d_in, (const BgzfBlk *)d_blk, nb, c->raw.p, tok, ntok, err);
+      ELP_LAUNCH(c, "stage_bgzf_resolve", k_bgzf_resolve, dim3(nb), dim3(RES_THREADS), 65536 * sizeof(uint16_t), (const BgzfBlk *)d_blk, c->raw.p, (const uint2 *)tok,
+                 (const uint32_t *)ntok, pw, err);
+    }
     const uint64_t end = tb.back().out_off + tb.back().out_len;
     const RecScan rs{c->raw.p, begin, end, c->n_ref};
     ELP_LAUNCH(c, "stage_bgzf_guess", k_rec_guess, dim3(nb), dim3(256), 0, rs, (const BgzfBlk *)d_blk, entry, c->tune.bgzf_weak_guess);
