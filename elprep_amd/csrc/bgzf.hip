@@ -597,18 +597,38 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
 //            changes: the depth of the copy-of-a-copy chains, logarithmically) leaves every byte pointing at the literal it descends from;
 //            one gather from the block's own output, which holds the literals already, fills the matches in.
 // Stored blocks copy their bytes in phase A.  The tokens of a block: at most (bytes / 3) of 8 bytes each, 174 KB per block of scratch.
-constexpr int TOK_RING = 1024, TOK_BUF = 64;
-constexpr uint32_t TOK_STRIDE = 21824;  // tokens per block: >= 65536 / 3 + 1, a multiple of 64
+// Phase A is bound by instruction issue, not by latency (a wave that decodes symbol after symbol spends ~150 instructions on each, and the
+// lanes beside lane 0 repeat them), so the lanes decode AT ONCE: lane k decodes the symbol that would start k bits behind the wave's place
+// in the stream - all 64 candidates, one table look-up (two for a match) each -; the wave then walks the true chain (start at 0, step by
+// the bits the symbol there consumed: a handful of scalar steps per 64 bits), which also gives every true symbol its place in the output;
+// the lanes on the chain store their literal or their token.  ~5 symbols per round of ~120 instructions instead of one per ~150.
+// A symbol whose code is longer than the tables' bits is decoded on the walk (canonical decoding, rare).
+constexpr int TK_RING = 1024, TK_HALF = TK_RING / 2, TK_LB = 10, TK_DB = 8;
+constexpr uint32_t TOK_STRIDE = 21888;  // tokens per block: >= 65536 / 3 + 1, a multiple of 64
+// table entry: code length (4 bits; 0: the code is longer than the table's bits) | kind << 4 | extra bits << 6 | base value << 10
+enum : uint32_t { TK_LIT = 0, TK_MATCH = 1, TK_EOB = 2, TK_BAD = 3 };
+// what a lane found at its offset: bits consumed | output bytes << 7 | flag << 16
+enum : uint32_t { TF_SLOW = 1, TF_EOB = 2, TF_BAD = 3 };
 struct TokLds {
-  uint8_t ring[TOK_RING];
-  uint16_t ltab[1 << INF_LBITS], dtab[1 << INF_DBITS];  // symbol << 4 | code length; 0: longer than the table's bits
+  uint32_t ring[TK_RING / 4 + 4];  // the last four words mirror the first four: a window is three consecutive words from anywhere in the ring
+  uint32_t ltab[1 << TK_LB], dtab[1 << TK_DB];
   uint16_t lcount[16], dcount[16], lsym[288], dsym[32];
   uint8_t lengths[320];
-  uint32_t tok[TOK_BUF][2];
   int left;
 };
-// (canon_decode as above)
-__device__ inline int tok_huff_build(TokLds *L, uint16_t *count, uint16_t *symbol, const uint8_t *length, int n, uint16_t *tab, int tbits) {
+__device__ __forceinline__ uint32_t tk_lit_entry(uint32_t sym, uint32_t len) {
+  if (sym < 256u) return len | (TK_LIT << 4) | (sym << 10);
+  if (sym == 256u) return len | (TK_EOB << 4);
+  if (sym >= 286u) return len | (TK_BAD << 4);
+  return len | (TK_MATCH << 4) | (inf_len_ext(sym - 257u) << 6) | (inf_len_base(sym - 257u) << 10);
+}
+__device__ __forceinline__ uint32_t tk_dist_entry(uint32_t sym, uint32_t len) {
+  if (sym >= 30u) return len | (TK_BAD << 4);
+  return len | (TK_MATCH << 4) | (inf_dist_ext(sym) << 6) | (inf_dist_base(sym) << 10);
+}
+// count / symbol arrays of the canonical code (lane 0), then the table, every lane its share of the bit patterns.  `kind`: 0 the code of
+// the code lengths (entries: symbol << 10 | length), 1 literals / lengths, 2 distances.  > 0: incomplete, < 0: over-subscribed.
+__device__ inline int tok_huff_build(TokLds *L, uint16_t *count, uint16_t *symbol, const uint8_t *length, int n, uint32_t *tab, int tbits, int kind) {
   if ((threadIdx.x & 63u) == 0) {
     uint16_t offs[16];
     for (int len = 0; len <= 15; len++) count[len] = 0;
@@ -632,7 +652,9 @@ __device__ inline int tok_huff_build(TokLds *L, uint16_t *count, uint16_t *symbo
     for (uint32_t idx = threadIdx.x & 63u; idx < (1u << tbits); idx += 64u) {
       int len = 0;
       const int sym = canon_decode(count, symbol, idx, &len);
-      tab[idx] = (sym >= 0 && len <= tbits) ? (uint16_t)(((uint32_t)sym << 4) | (uint32_t)len) : (uint16_t)0;
+      uint32_t e = 0;
+      if (sym >= 0 && len <= tbits) e = kind == 0 ? ((uint32_t)sym << 10) | (uint32_t)len : (kind == 1 ? tk_lit_entry((uint32_t)sym, (uint32_t)len) : tk_dist_entry((uint32_t)sym, (uint32_t)len));
+      tab[idx] = e;
     }
   __syncthreads();
   return left;
@@ -640,177 +662,186 @@ __device__ inline int tok_huff_build(TokLds *L, uint16_t *count, uint16_t *symbo
 struct TokInflater {
   TokLds *L;
   const uint8_t *in;
-  uint32_t in_len, in_at, loaded;
-  unsigned long long bitbuf;
-  int bitcnt, err;
+  uint32_t in_len, in_bits, loaded;
+  uint32_t bp;  // the reader's place in the block's input, in bits
   uint32_t out_len, out_at;
   uint8_t *out;
-  uint2 *tokens;   // the block's token array (HBM)
+  uint2 *tokens;  // the block's token array (HBM)
   uint32_t ntok;
-  // the ring holds input [loaded - TOK_RING, loaded): topped up whenever the reader enters its last half (32 lanes x 16 bytes = half the ring)
+  // the ring holds input [loaded - TK_RING, loaded): topped up whenever the reader enters its last half (16 bytes per lane)
   __device__ __forceinline__ void feed() {
-    while (loaded < in_len && in_at + TOK_RING / 2 > loaded) {
-      const uint32_t lane = threadIdx.x & 63u, p = loaded + lane * 16u;
+    while (loaded < in_len && (bp >> 3) + TK_HALF > loaded) {
+      const uint32_t lane16 = (threadIdx.x & 63u) * 16u, p = loaded + lane16;
       __syncthreads();
-      if (lane < (uint32_t)TOK_RING / 32u && p < in_len) {  // (the compressed bytes are followed by the trailer and the buffer's padding: a 16-byte read is safe)
+      if (lane16 < (uint32_t)TK_HALF && p < in_len) {  // (the compressed bytes are followed by the trailer and the buffer's padding: a 16-byte read is safe)
         uint4 v;
         __builtin_memcpy(&v, in + p, 16);
-        *reinterpret_cast<uint4 *>(&L->ring[p & (TOK_RING - 1)]) = v;
+        const uint32_t at = (p & (TK_RING - 1)) >> 2;
+        *reinterpret_cast<uint4 *>(&L->ring[at]) = v;
+        if (at == 0) *reinterpret_cast<uint4 *>(&L->ring[TK_RING / 4]) = v;
       }
       __syncthreads();
-      loaded = loaded + TOK_RING / 2 < in_len ? loaded + TOK_RING / 2 : in_len;
+      loaded = loaded + TK_HALF < in_len ? loaded + TK_HALF : in_len;
     }
   }
-  // at least 48 bits in the buffer (or everything that is left): two aligned 8-byte reads of the ring, shifted together
-  __device__ __forceinline__ void refill() {
-    if (bitcnt >= 48) return;
+  // the 64 bits of the input from bit b on (what lies behind the input's end is garbage: the callers check their place against in_bits)
+  __device__ __forceinline__ unsigned long long window(uint32_t b) const {
+    const uint32_t *r = &L->ring[(b >> 5) & (TK_RING / 4 - 1)];
+    const uint32_t w0 = r[0], w1 = r[1], w2 = r[2];
+    // (v_alignbit: the low 32 bits of {hi, lo} >> (b & 31))
+    return ((unsigned long long)__builtin_amdgcn_alignbit(w2, w1, b) << 32) | __builtin_amdgcn_alignbit(w1, w0, b);
+  }
+  __device__ __forceinline__ uint32_t bits(int n) {  // n <= 16; the header's fields
     feed();
-    uint32_t nb = (uint32_t)(64 - bitcnt) >> 3;
-    nb = nb < in_len - in_at ? nb : in_len - in_at;
-    const unsigned long long *r64 = reinterpret_cast<const unsigned long long *>(L->ring);
-    const uint32_t a = (in_at & (TOK_RING - 1)) >> 3, sh = (in_at & 7u) * 8u;
-    const unsigned long long w0 = r64[a], w1 = r64[(a + 1) & (TOK_RING / 8 - 1)];
-    unsigned long long w = sh ? (w0 >> sh) | (w1 << (64u - sh)) : w0;
-    if (nb < 8) w &= (1ull << (8 * nb)) - 1ull;
-    bitbuf |= bitcnt < 64 ? w << bitcnt : 0ull;
-    in_at += nb;
-    bitcnt += 8 * (int)nb;
+    const uint32_t v = (uint32_t)window(bp) & ((1u << n) - 1u);
+    bp += (uint32_t)n;
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
   }
-  __device__ __forceinline__ uint32_t bits(int n) {  // n <= 16, taken from what refill() provided
-    if (bitcnt < n) { err = 1; return 0; }
-    const uint32_t v = (uint32_t)bitbuf & ((1u << n) - 1u);
-    bitbuf >>= n;
-    bitcnt -= n;
-    return v;
-  }
-  __device__ __forceinline__ int symbol(const uint16_t *tab, int tbits, const uint16_t *count, const uint16_t *sym_of) {
-    const uint32_t e = tab[(uint32_t)bitbuf & ((1u << tbits) - 1u)];
-    if (e) {
-      const int len = (int)(e & 0xFu);
-      if (bitcnt < len) { err = 1; return -1; }
-      bitbuf >>= len;
-      bitcnt -= len;
-      return (int)(e >> 4);
-    }
-    int len = 0;
-    const int sym = canon_decode(count, sym_of, (uint32_t)bitbuf, &len);
-    if (sym < 0 || bitcnt < len) { err = 1; return -1; }
-    bitbuf >>= len;
-    bitcnt -= len;
-    return sym;
-  }
-  __device__ __forceinline__ void flush_tokens(uint32_t n_in_buf) {  // the buffered tokens go out, a lane each
-    const uint32_t lane = threadIdx.x & 63u;
-    __syncthreads();
-    if (lane < n_in_buf) tokens[ntok - n_in_buf + lane] = make_uint2(L->tok[lane][0], L->tok[lane][1]);
-    __syncthreads();
-  }
-  __device__ __forceinline__ void put_token(uint32_t len, uint32_t dist) {
-    const uint32_t k = ntok & (TOK_BUF - 1);
-    if ((threadIdx.x & 63u) == 0) { L->tok[k][0] = out_at | (len << 16); L->tok[k][1] = dist; }
-    ntok++;
-    if (k == TOK_BUF - 1) flush_tokens(TOK_BUF);
+  // a symbol of the code of the code lengths (table entries symbol << 10 | length, 7 bits: never a miss)
+  __device__ __forceinline__ int cl_symbol() {
+    feed();
+    const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)L->ltab[(uint32_t)window(bp) & 127u]);
+    if (!e) return -1;
+    bp += e & 15u;
+    return (int)(e >> 10);
   }
 };
+// one symbol at bit b by canonical decoding, for the walk: its entry in the table's form with the true code length (0: no such code)
+__device__ __forceinline__ uint32_t tk_slow_entry(const TokInflater &s, uint32_t b, bool dist) {
+  int len = 0;
+  const int sym = canon_decode(dist ? s.L->dcount : s.L->lcount, dist ? s.L->dsym : s.L->lsym, (uint32_t)s.window(b), &len);
+  if (sym < 0) return 0;
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)(dist ? tk_dist_entry((uint32_t)sym, (uint32_t)len) : tk_lit_entry((uint32_t)sym, (uint32_t)len)));
+}
 __device__ inline int tok_codes(TokInflater &s) {
   TokLds *L = s.L;
   const uint32_t lane = threadIdx.x & 63u;
   for (;;) {
-    s.refill();
-    int symbol = s.symbol(L->ltab, INF_LBITS, L->lcount, L->lsym);
-    if (symbol < 0) return 2;
-    if (symbol < 256) {
-      if (s.out_at == s.out_len) return 3;
-      if (lane == 0) s.out[s.out_at] = (uint8_t)symbol;
-      s.out_at++;
-    } else if (symbol == 256) {
-      return 0;
-    } else {
-      symbol -= 257;
-      if (symbol >= 29) return 4;
-      const uint32_t len = inf_len_base((uint32_t)symbol) + s.bits((int)inf_len_ext((uint32_t)symbol));
-      symbol = s.symbol(L->dtab, INF_DBITS, L->dcount, L->dsym);
-      if (symbol < 0 || symbol >= 30) return 5;
-      const uint32_t dist = inf_dist_base((uint32_t)symbol) + s.bits((int)inf_dist_ext((uint32_t)symbol));
-      if (s.err) return 1;
-      if (dist > s.out_at) return 6;
-      if (s.out_at + len > s.out_len) return 3;
-      if (s.ntok >= TOK_STRIDE) return 17;  // (cannot happen: a match is three bytes or more)
-      s.put_token(len, dist);
-      s.out_at += len;
+    s.feed();
+    // every lane: the symbol that starts `lane` bits on.  Without branches: the distance part is computed for every lane (for a literal's
+    // entry the extra-bit count is 0 and the look-up lands somewhere in the table: discarded)
+    const unsigned long long w = s.window(s.bp + lane);
+    const uint32_t e = L->ltab[(uint32_t)w & ((1u << TK_LB) - 1u)];
+    const uint32_t cl = e & 15u, xb = (e >> 6) & 15u, t = cl + xb;
+    uint32_t kind = (e >> 4) & 3u, val = e >> 10;
+    const uint32_t e2 = L->dtab[(uint32_t)(w >> t) & ((1u << TK_DB) - 1u)];
+    const uint32_t dl = e2 & 15u, db = (e2 >> 6) & 15u;
+    uint32_t dist = (e2 >> 10) + ((uint32_t)(w >> (t + dl)) & ((1u << db) - 1u));
+    const bool is_m = kind == TK_MATCH;
+    uint32_t olen = is_m ? val + ((uint32_t)(w >> cl) & ((1u << xb) - 1u)) : 1u;
+    const bool special = e == 0 || kind >= TK_EOB || (is_m && (e2 == 0 || ((e2 >> 4) & 3u) == TK_BAD));
+    const int info = special ? -1 : (int)((is_m ? t + dl + db : cl) | (olen << 7));  // bits consumed | output bytes << 7
+    // the walk along the true chain (wave-uniform values throughout); a lane on the chain learns its place in the output
+    uint32_t off = 0, outpos = s.out_at;
+    int vpos = -1, rc = 0;
+    bool eob = false;
+    for (;;) {
+      int inf = 0;
+      while (off < 64u) {
+        inf = __builtin_amdgcn_readlane(info, (int)off);
+        if (inf < 0) break;
+        if (lane == off) vpos = (int)outpos;
+        outpos += (uint32_t)inf >> 7;
+        off += (uint32_t)inf & 127u;
+      }
+      if (off >= 64u) break;
+      // end of block, a code longer than a table's bits, an invalid symbol: this one symbol step by step
+      asm volatile("" ::: "memory");  // (keeps the loads below in here)
+      const uint32_t b = s.bp + off;
+      uint32_t e1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)L->ltab[(uint32_t)s.window(b) & ((1u << TK_LB) - 1u)]);
+      if (!e1) e1 = tk_slow_entry(s, b, false);
+      if (!e1) { rc = 2; break; }
+      uint32_t a = e1 & 15u, ol = 1, d = 0;
+      const uint32_t k1 = (e1 >> 4) & 3u;
+      if (k1 == TK_BAD) { rc = 4; break; }
+      if (k1 == TK_EOB) {
+        off += a;
+        eob = true;
+        break;
+      }
+      if (k1 == TK_MATCH) {
+        const uint32_t x1 = (e1 >> 6) & 15u;
+        ol = (e1 >> 10) + ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(s.window(b + a))) & ((1u << x1) - 1u));
+        a += x1;
+        uint32_t f2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)L->dtab[(uint32_t)s.window(b + a) & ((1u << TK_DB) - 1u)]);
+        if (!f2) f2 = tk_slow_entry(s, b + a, true);
+        if (!f2 || ((f2 >> 4) & 3u) == TK_BAD) { rc = 5; break; }
+        const uint32_t l2 = f2 & 15u, b2 = (f2 >> 6) & 15u;
+        d = (f2 >> 10) + ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(s.window(b + a + l2))) & ((1u << b2) - 1u));
+        a += l2 + b2;
+      }
+      if (lane == off) { kind = k1; val = e1 >> 10; olen = ol; dist = d; vpos = (int)outpos; }  // (the lane at this offset stores it with the others)
+      outpos += ol;
+      off += a;
     }
+    if (rc) return rc;
+    if (outpos > s.out_len) return 3;
+    if (s.bp + off > s.in_bits) return 1;
+    // the lanes on the chain: literal to its place, match to the token list
+    const bool on = vpos >= 0;
+    const bool mat = on && kind == TK_MATCH;
+    if (on && kind == TK_LIT) s.out[(uint32_t)vpos] = (uint8_t)val;
+    const unsigned long long mb = __ballot(mat);
+    if (mat) {
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0u));
+      s.tokens[s.ntok + rank] = make_uint2((uint32_t)vpos | (olen << 16), dist);
+    }
+    if (__ballot(mat && dist > (uint32_t)vpos)) return 6;
+    s.ntok += (uint32_t)__popcll(mb);
+    s.out_at = outpos;
+    s.bp += off;
+    if (eob) return 0;
   }
 }
-__global__ __launch_bounds__(64) void k_bgzf_tokens(const uint8_t *__restrict__ cdata, const BgzfBlk *__restrict__ blk, uint32_t n_blk, uint8_t *__restrict__ raw,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_bgzf_tokens(const uint8_t *__restrict__ cdata, const BgzfBlk *__restrict__ blk, uint32_t n_blk, uint8_t *__restrict__ raw,
                                                     uint2 *__restrict__ tokens, uint32_t *__restrict__ ntok_out, uint32_t *err) {
   __shared__ __attribute__((aligned(16))) TokLds L;
   const uint32_t lane = threadIdx.x;
   const BgzfBlk B = blk[blockIdx.x];
-  TokInflater s{&L, cdata + B.in_off, B.in_len, 0, 0, 0ull, 0, 0, B.out_len, 0, raw + B.out_off, tokens + (size_t)blockIdx.x * TOK_STRIDE, 0};
+  TokInflater s{&L, cdata + B.in_off, B.in_len, B.in_len * 8u, 0, 0, B.out_len, 0, raw + B.out_off, tokens + (size_t)blockIdx.x * TOK_STRIDE, 0};
   int rc = 0, last;
   do {
-    s.refill();
     last = (int)s.bits(1);
     const int type = (int)s.bits(2);
-    if (s.err) { rc = 1; break; }
-    if (type == 0) {  // stored: back to a byte boundary, LEN, NLEN, the bytes - straight to the output
-      const int drop = s.bitcnt & 7;
-      s.bitbuf >>= drop;
-      s.bitcnt -= drop;
-      s.refill();
+    if (s.bp > s.in_bits) { rc = 1; break; }
+    if (type == 0) {  // stored: on to a byte boundary, LEN, NLEN, the bytes - from HBM straight to the output
+      s.bp = (s.bp + 7u) & ~7u;
       const uint32_t len = s.bits(16), nlen = s.bits(16);
-      if (s.err) { rc = 1; break; }
+      if (s.bp > s.in_bits) { rc = 1; break; }
       if (len != (~nlen & 0xFFFFu)) { rc = 7; break; }
       if (s.out_at + len > s.out_len) { rc = 3; break; }
-      // the bytes the bit buffer still holds are the next bytes of the input: step the reader back onto them, then copy from HBM
-      const uint32_t pos = s.in_at - (uint32_t)(s.bitcnt >> 3);
+      const uint32_t pos = s.bp >> 3;
       if (pos + len > s.in_len) { rc = 1; break; }
       for (uint32_t k = lane; k < len; k += 64u) s.out[s.out_at + k] = s.in[pos + k];
       s.out_at += len;
-      s.in_at = pos + len;
-      s.bitbuf = 0;
-      s.bitcnt = 0;
-      // (the ring: everything up to a multiple of its half that the reader has passed counts as loaded; the next feed brings what follows)
-      s.loaded = s.in_at & ~(uint32_t)(TOK_RING / 2 - 1);
-      if (s.loaded > s.in_len) s.loaded = s.in_len;
-      {  // the half the reader stands in must be in the ring before it reads: load it whole
-        const uint32_t p = s.loaded + lane * 16u;
-        __syncthreads();
-        if (lane < (uint32_t)TOK_RING / 32u && p < s.in_len) {
-          uint4 v;
-          __builtin_memcpy(&v, s.in + p, 16);
-          *reinterpret_cast<uint4 *>(&L.ring[p & (TOK_RING - 1)]) = v;
-        }
-        __syncthreads();
-        s.loaded = s.loaded + TOK_RING / 2 < s.in_len ? s.loaded + TOK_RING / 2 : s.in_len;
-      }
+      s.bp += len * 8u;
+      // the ring starts over at the half the reader stands in (feed() brings it and the next one)
+      if ((s.bp >> 3) + TK_HALF > s.loaded + TK_HALF) s.loaded = (s.bp >> 3) & ~(uint32_t)(TK_HALF - 1);
     } else if (type == 1) {  // fixed codes
       for (uint32_t sym = lane; sym < 288; sym += 64) L.lengths[sym] = sym < 144 ? 8 : (sym < 256 ? 9 : (sym < 280 ? 7 : 8));
       __syncthreads();
-      tok_huff_build(&L, L.lcount, L.lsym, L.lengths, 288, L.ltab, INF_LBITS);
+      tok_huff_build(&L, L.lcount, L.lsym, L.lengths, 288, L.ltab, TK_LB, 1);
       if (lane < 30) L.lengths[lane] = 5;
       __syncthreads();
-      tok_huff_build(&L, L.dcount, L.dsym, L.lengths, 30, L.dtab, INF_DBITS);
+      tok_huff_build(&L, L.dcount, L.dsym, L.lengths, 30, L.dtab, TK_DB, 2);
       rc = tok_codes(s);
     } else if (type == 2) {  // dynamic codes
       const int nlen = (int)s.bits(5) + 257, ndist = (int)s.bits(5) + 1, ncode = (int)s.bits(4) + 4;
-      if (s.err) { rc = 1; break; }
+      if (s.bp > s.in_bits) { rc = 1; break; }
       if (nlen > 286 || ndist > 30) { rc = 8; break; }
       if (lane < 19) L.lengths[lane] = 0;
       __syncthreads();
       for (int index = 0; index < ncode; index++) {
-        s.refill();
         const uint32_t v = s.bits(3);
         if (lane == 0) L.lengths[INF_ORDER[index]] = (uint8_t)v;
       }
       __syncthreads();
-      if (tok_huff_build(&L, L.lcount, L.lsym, L.lengths, 19, L.ltab, INF_LBITS) != 0) { rc = 9; break; }
+      if (tok_huff_build(&L, L.lcount, L.lsym, L.lengths, 19, L.ltab, 7, 0) != 0) { rc = 9; break; }
       int index = 0;
       uint32_t prev = 0;
       while (index < nlen + ndist) {
-        s.refill();
-        const int symbol = s.symbol(L.ltab, INF_LBITS, L.lcount, L.lsym);
-        if (symbol < 0) { rc = 2; break; }
+        const int symbol = s.cl_symbol();
+        if (symbol < 0 || s.bp > s.in_bits) { rc = 2; break; }
         if (symbol < 16) {
           if (lane == 0) L.lengths[index] = (uint8_t)symbol;
           prev = (uint32_t)symbol;
@@ -833,22 +864,21 @@ __global__ __launch_bounds__(64) void k_bgzf_tokens(const uint8_t *__restrict__ 
         }
       }
       if (rc) break;
+      if (s.bp > s.in_bits) { rc = 1; break; }
       __syncthreads();
       if (L.lengths[256] == 0) { rc = 12; break; }
-      int e = tok_huff_build(&L, L.dcount, L.dsym, L.lengths + nlen, ndist, L.dtab, INF_DBITS);
+      int e = tok_huff_build(&L, L.dcount, L.dsym, L.lengths + nlen, ndist, L.dtab, TK_DB, 2);
       if (e && (e < 0 || ndist != (int)L.dcount[0] + (int)L.dcount[1])) { rc = 14; break; }
-      e = tok_huff_build(&L, L.lcount, L.lsym, L.lengths, nlen, L.ltab, INF_LBITS);
+      e = tok_huff_build(&L, L.lcount, L.lsym, L.lengths, nlen, L.ltab, TK_LB, 1);
       if (e && (e < 0 || nlen != (int)L.lcount[0] + (int)L.lcount[1])) { rc = 13; break; }
       rc = tok_codes(s);
     } else rc = 15;
   } while (!rc && !last);
   if (!rc && s.out_at != s.out_len) rc = 16;  // ISIZE promised another number of bytes
-  if (rc) {
-    if (lane == 0) { atomicOr(&err[0], 1u); ntok_out[blockIdx.x] = 0; }
-    return;
+  if (lane == 0) {
+    if (rc) atomicOr(&err[0], 1u);
+    ntok_out[blockIdx.x] = rc ? 0u : s.ntok;
   }
-  s.flush_tokens(s.ntok & (TOK_BUF - 1));
-  if (lane == 0) ntok_out[blockIdx.x] = s.ntok;
   (void)n_blk;
 }
 
@@ -857,7 +887,7 @@ __global__ __launch_bounds__(64) void k_bgzf_tokens(const uint8_t *__restrict__ 
 // four independent look-ups instead of four dependent ones), the partial CRCs shifted to their place by x^(8 * bytes behind) mod p.
 constexpr int RES_THREADS = 1024;
 __global__ __launch_bounds__(RES_THREADS) void k_bgzf_resolve(const BgzfBlk *__restrict__ blk, uint8_t *__restrict__ raw, const uint2 *__restrict__ tokens,
-                                                            const uint32_t *__restrict__ ntok_in, CrcPow pw, uint32_t *err) {
+                                                            const uint32_t *__restrict__ ntok_in, CrcPow pw, uint32_t n_common, const uint32_t *__restrict__ pow_common, uint32_t *err) {
   extern __shared__ __attribute__((aligned(16))) uint16_t parent[];  // [65536]; the CRC tables afterwards
   __shared__ uint32_t s_crc;
   const uint32_t nt = ntok_in[blockIdx.x];
@@ -870,18 +900,29 @@ __global__ __launch_bounds__(RES_THREADS) void k_bgzf_resolve(const BgzfBlk *__r
     const uint2 *tk = tokens + (size_t)blockIdx.x * TOK_STRIDE;
     for (uint32_t k = t; k < nt; k += RES_THREADS) {
       const uint2 tok = tk[k];
-      const uint32_t p = tok.x & 0xFFFFu, len = tok.x >> 16, src = p - tok.y;
-      for (uint32_t i = 0; i < len; i++) parent[p + i] = (uint16_t)(src + i);
+      // (a match that overlaps itself repeats the `dist` bytes in front of it: every byte points into that first period, not at the byte
+      // `dist` in front of it - a run of one byte is then one step deep instead of as deep as it is long)
+      const uint32_t p = tok.x & 0xFFFFu, len = tok.x >> 16, dist = tok.y, src = p - dist;
+      for (uint32_t i = 0, o = 0; i < len; i++) {
+        parent[p + i] = (uint16_t)(src + o);
+        o = o + 1u == dist ? 0u : o + 1u;
+      }
     }
     __syncthreads();
-    // pointer jumping: a byte of a match points at a byte in front of it; when nothing moves any more, at a literal
+    // pointer jumping: a byte of a match points at a byte in front of it; a byte is done when it points at a literal (a byte that points
+    // at itself).  Each thread keeps the bytes it still has to move as a bit mask (byte t + 1024 k: bit k): after the first rounds few are
+    // left, and a round costs what is left (round 6: all bytes in every round took 3/4 of this kernel's time).
+    unsigned long long todo = 0;
+    for (uint32_t k = 0, j = t; j < n; k++, j += RES_THREADS)
+      if (parent[j] != (uint16_t)j) todo |= 1ull << k;
     for (int round = 0; round < 17; round++) {
-      int moved = 0;
-      for (uint32_t j = t; j < n; j += RES_THREADS) {
+      for (unsigned long long m = todo; m; m &= m - 1ull) {
+        const uint32_t k = (uint32_t)__builtin_ctzll(m), j = t + k * RES_THREADS;
         const uint16_t q = parent[j], r = parent[q];
-        if (r != q) { parent[j] = r; moved = 1; }
+        if (r != q) parent[j] = r;
+        else todo &= ~(1ull << k);
       }
-      if (!__syncthreads_or(moved)) break;
+      if (!__syncthreads_or(todo != 0ull)) break;
     }
     for (uint32_t j = t; j < n; j += RES_THREADS) {
       const uint16_t q = parent[j];
@@ -913,10 +954,15 @@ __global__ __launch_bounds__(RES_THREADS) void k_bgzf_resolve(const BgzfBlk *__r
     }
     for (; k < hi; k++) c = T[(c ^ out[k]) & 0xFFu] ^ (c >> 8);
     c ^= 0xFFFFFFFFu;
-    atomicXor(&s_crc, crc_mulmod(crc_x8n(pw, n - hi), c));
+    atomicXor(&s_crc, crc_mulmod(n == n_common ? pow_common[t] : crc_x8n(pw, n - hi), c));
   }
   __syncthreads();
   if (t == 0 && s_crc != B.crc) atomicOr(&err[0], 2u);
+}
+// x^(8 * bytes behind thread t's 64 bytes) mod p for a block of n bytes: the same for every block of that length (nearly all of a file)
+__global__ __launch_bounds__(RES_THREADS) void k_crc_pow_common(uint32_t n, CrcPow pw, uint32_t *__restrict__ out) {
+  const uint32_t t = threadIdx.x, lo = t * 64u < n ? t * 64u : n, hi = lo + 64u < n ? lo + 64u : n;
+  out[t] = crc_x8n(pw, n - hi);
 }
 
 // CRC-32 of every inflated block against the value in its trailer (one workgroup per block, as in k_bgzf_frame)
@@ -1030,10 +1076,11 @@ __global__ __launch_bounds__(64) void k_rec_walk(RecScan r, const BgzfBlk *__res
   if (entry[b] == REC_NONE) { exit_[b] = REC_NONE; cnt[b] = 0; return; }
   rec_walk(r, entry[b], hi, &exit_[b], &cnt[b], nullptr, nullptr);
 }
+constexpr uint32_t REC_BAD_CAP = 1024;  // rejected guesses that are listed (more: the repair goes through all blocks)
 // the proof: block b's guess is the true entry iff the nearest block in front of it that has an entry leaves its records exactly there
 // (blocks in between hold no record start: the chain jumps over them); the first entry must be the stream's known first record
 __global__ __launch_bounds__(256) void k_rec_check(RecScan r, const BgzfBlk *__restrict__ blk, uint32_t n_blk, const uint64_t *__restrict__ entry,
-                                                   const uint64_t *__restrict__ exit_, uint32_t *bad) {
+                                                   const uint64_t *__restrict__ exit_, uint32_t *bad, uint32_t *__restrict__ bad_list) {
   const uint32_t b = blockIdx.x * 256 + threadIdx.x;
   if (b >= n_blk) return;
   const uint64_t lo = blk[b].out_off, hi = lo + blk[b].out_len;
@@ -1045,22 +1092,55 @@ __global__ __launch_bounds__(256) void k_rec_check(RecScan r, const BgzfBlk *__r
   else ok = came == entry[b];
   if (hi <= r.begin) ok = true;  // a block of the header prefix
   (void)lo;
-  if (!ok) atomicAdd(bad, 1u);
+  if (!ok) {
+    const uint32_t k = atomicAdd(bad, 1u);
+    if (k < REC_BAD_CAP) bad_list[k] = b;
+  }
 }
-// one thread, in order: entries that the proof rejected are replaced by where the chain really arrives
-__global__ void k_rec_repair(RecScan r, const BgzfBlk *__restrict__ blk, uint32_t n_blk, uint64_t *entry, uint64_t *exit_, uint32_t *cnt) {
-  uint64_t came = r.begin;
-  for (uint32_t b = 0; b < n_blk; b++) {
-    const uint64_t lo = blk[b].out_off, hi = lo + blk[b].out_len;
-    if (hi <= r.begin) continue;
-    const uint64_t want = (came < hi && !rec_incomplete(r, came)) ? came : REC_NONE;
-    (void)lo;
-    if (entry[b] != want && !(want == REC_NONE && entry[b] == came)) {  // (an entry at the pending record itself is as good as none)
-      entry[b] = want;
-      if (want == REC_NONE) { exit_[b] = REC_NONE; cnt[b] = 0; }
-      else rec_walk(r, want, hi, &exit_[b], &cnt[b], nullptr, nullptr);
+// one thread, in order: entries that the proof rejected are replaced by where the chain really arrives.  Only the rejected blocks are
+// visited (round 6: the loop over all blocks - a dependent load each - took 15 ms for 19 k blocks because of one wrong guess), each followed
+// by the blocks behind it for as long as the repaired chain arrives somewhere else than they assumed.
+__device__ inline uint64_t rec_repair_block(const RecScan &r, const BgzfBlk *blk, uint32_t b, uint64_t came, uint64_t *entry, uint64_t *exit_, uint32_t *cnt) {
+  const uint64_t hi = blk[b].out_off + blk[b].out_len;
+  if (hi <= r.begin) return came;
+  const uint64_t want = (came < hi && !rec_incomplete(r, came)) ? came : REC_NONE;
+  if (entry[b] != want && !(want == REC_NONE && entry[b] == came)) {  // (an entry at the pending record itself is as good as none)
+    entry[b] = want;
+    if (want == REC_NONE) { exit_[b] = REC_NONE; cnt[b] = 0; }
+    else rec_walk(r, want, hi, &exit_[b], &cnt[b], nullptr, nullptr);
+  }
+  return entry[b] != REC_NONE ? exit_[b] : came;
+}
+__global__ void k_rec_repair(RecScan r, const BgzfBlk *__restrict__ blk, uint32_t n_blk, uint64_t *entry, uint64_t *exit_, uint32_t *cnt, const uint32_t *bad,
+                             uint32_t *bad_list) {
+  const uint32_t n_bad = bad[0];
+  if (n_bad > REC_BAD_CAP) {
+    uint64_t came = r.begin;
+    for (uint32_t b = 0; b < n_blk; b++) came = rec_repair_block(r, blk, b, came, entry, exit_, cnt);
+    return;
+  }
+  for (uint32_t i = 1; i < n_bad; i++) {  // (the list is in the order of the atomics: sort it, it is short)
+    const uint32_t v = bad_list[i];
+    uint32_t j = i;
+    for (; j > 0 && bad_list[j - 1] > v; j--) bad_list[j] = bad_list[j - 1];
+    bad_list[j] = v;
+  }
+  uint32_t done = 0;  // blocks below are consistent with the repaired chain
+  for (uint32_t i = 0; i < n_bad; i++) {
+    uint32_t b = bad_list[i];
+    if (b < done) continue;
+    int64_t a = (int64_t)b - 1;
+    while (a >= 0 && entry[a] == REC_NONE) a--;
+    uint64_t came = a >= 0 ? exit_[a] : r.begin;
+    for (;;) {
+      came = rec_repair_block(r, blk, b, came, entry, exit_, cnt);
+      if (++b >= n_blk) break;
+      // does the next block stand as it is?  (k_rec_check's condition, with the chain as it is now)
+      const uint64_t hi = blk[b].out_off + blk[b].out_len;
+      const bool ok = hi <= r.begin || (entry[b] == REC_NONE ? (came >= hi || rec_incomplete(r, came)) : came == entry[b]);
+      if (ok) break;
     }
-    if (entry[b] != REC_NONE) came = exit_[b];
+    done = b;
   }
 }
 __global__ __launch_bounds__(64) void k_rec_fill(RecScan r, const BgzfBlk *__restrict__ blk, uint32_t n_blk, const uint64_t *__restrict__ entry,
@@ -1131,62 +1211,108 @@ extern "C" int elp_stage_bgzf(elp_ctx *c, const uint8_t *bgzf, uint64_t n_bytes,
   // the inflated stream goes to c->raw behind what is there; the records of the header prefix are never referenced
   const uint64_t raw0 = c->raw_bytes;
   ELP_TRY(ensure(c, c->raw, raw0 + inflated + 64, true, raw0));
-  // pieces of blocks: <= 192 MiB inflated each (u32 scans and bounded scratch in stage_bam_columns)
-  const uint64_t PIECE = (uint64_t)c->tune.bgzf_piece;
+  // Two sizes of pieces.  INFLATE pieces (<= 1 GiB inflated: ~16 k blocks) - the decoder wants every block of the file in flight at once (a
+  // wave per block, 22 of them per CU: 5.6 k blocks fill the chip once; round 6: 192 MiB pieces left it half empty and cost 1.7x) and pays
+  // 171 KB of token scratch per block for it.  Inside one, SCAN pieces (<= 192 MiB: u32 scans and bounded scratch in stage_bam_columns)
+  // find the records and stage the columns as before.
+  const uint64_t PIECE = (uint64_t)c->tune.bgzf_piece, IPIECE = (uint64_t)c->tune.bgzf_inflate_piece;
   uint64_t begin = raw0 + first_record;  // where the next record starts in c->raw
-  size_t b0 = 0;
+  size_t b0 = 0, a1 = 0;
+  BgzfBlk *d_blk_all = nullptr;
+  uint64_t *entry_all = nullptr, *exit_all = nullptr, *res = nullptr;
+  uint32_t *cnt_all = nullptr, *base_all = nullptr, *bad_list = nullptr;
+  std::vector<BgzfBlk> tb_all;
+  size_t a0 = 0;
+  bool inflate_checked = true;
   while (b0 < blocks.size()) {
+    if (b0 == a1) {  // the next inflate piece: compressed bytes + block table to the device, every block inflated
+      a0 = a1;
+      uint64_t in_lo = blocks[a0].in_off, in_hi = in_lo, out_bytes = 0;
+      while (a1 < blocks.size() && (a1 == a0 || out_bytes + blocks[a1].out_len <= IPIECE)) {
+        in_hi = blocks[a1].in_off + blocks[a1].in_len;
+        out_bytes += blocks[a1].out_len;
+        a1++;
+      }
+      const uint32_t na = (uint32_t)(a1 - a0);
+      uint8_t *d_in;
+      ELP_TRY(scratch(c, 5, (size_t)(in_hi - in_lo) + 64, &d_in));
+      ELP_HIP(c, hipMemcpyAsync(d_in, bgzf + in_lo, (size_t)(in_hi - in_lo), hipMemcpyHostToDevice, st));
+      tb_all.assign(blocks.begin() + a0, blocks.begin() + a1);
+      for (auto &t : tb_all) { t.in_off -= in_lo; t.out_off += raw0; }
+      // block table | entry | exit (u64 each) | result words | cnt | base (u32 each) | list of rejected guesses
+      static_assert(sizeof(BgzfBlk) == 32, "BgzfBlk is four 64-bit words");
+      uint64_t *wk;
+      ELP_TRY(scratch(c, 6, (size_t)na * 6 + 8 + (size_t)(na + 8) + 16 + REC_BAD_CAP / 2, &wk));
+      d_blk_all = reinterpret_cast<BgzfBlk *>(wk);
+      entry_all = wk + (size_t)na * 4;
+      exit_all = entry_all + na;
+      res = exit_all + na;
+      cnt_all = reinterpret_cast<uint32_t *>(res + 8);
+      base_all = cnt_all + na + 8;
+      bad_list = base_all + na + 8;
+      ELP_HIP(c, hipMemcpyAsync(d_blk_all, tb_all.data(), (size_t)na * sizeof(BgzfBlk), hipMemcpyHostToDevice, st));
+      ELP_HIP(c, hipMemsetAsync(res, 0, 64, st));
+      uint32_t *ierr = reinterpret_cast<uint32_t *>(res + 4);  // (its own word: the scan pieces clear theirs)
+      if (c->tune.bgzf_inflate == 1) {  // round 5's form: one kernel that decodes and copies, and the CRC pass
+        ELP_LAUNCH(c, "stage_bgzf_inflate", k_bgzf_inflate, dim3(na), dim3(64), 0, (const uint8_t *)d_in, (const BgzfBlk *)d_blk_all, na, c->raw.p, ierr);
+        ELP_LAUNCH(c, "stage_bgzf_crc", k_bgzf_crc_check, dim3(na), dim3(256), 0, (const uint8_t *)c->raw.p, (const BgzfBlk *)d_blk_all, pw, ierr);
+      } else {  // the bit stream first (literals placed, matches as tokens), then the matches and the CRC, a workgroup per block
+        uint2 *tok;
+        ELP_TRY(scratch(c, 7, (size_t)na * TOK_STRIDE + (size_t)(na + 2) / 2 + RES_THREADS / 2 + 8, &tok));
+        uint32_t *ntok = reinterpret_cast<uint32_t *>(tok + (size_t)na * TOK_STRIDE), *pow_common = ntok + ((na + 1u) & ~1u);
+        uint32_t n_common = tb_all[0].out_len;  // the inflated length most blocks have (majority vote; any value is correct, the common one is fast)
+        {
+          uint32_t votes = 0;
+          for (const auto &t : tb_all) {
+            if (votes == 0) { n_common = t.out_len; votes = 1; }
+            else if (t.out_len == n_common) votes++;
+            else votes--;
+          }
+        }
+        ELP_LAUNCH(c, "stage_bgzf_crc_pow", k_crc_pow_common, dim3(1), dim3(RES_THREADS), 0, n_common, pw, pow_common);
+        static std::atomic<bool> lds_set{false};
+        if (!lds_set.load()) {
+          ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bgzf_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(65536 * sizeof(uint16_t))));
+          lds_set.store(true);
+        }
+        ELP_LAUNCH(c, "stage_bgzf_tokens", k_bgzf_tokens, dim3(na), dim3(64), 0, (const uint8_t *)d_in, (const BgzfBlk *)d_blk_all, na, c->raw.p, tok, ntok, ierr);
+        ELP_LAUNCH(c, "stage_bgzf_resolve", k_bgzf_resolve, dim3(na), dim3(RES_THREADS), 65536 * sizeof(uint16_t), (const BgzfBlk *)d_blk_all, c->raw.p, (const uint2 *)tok,
+                   (const uint32_t *)ntok, pw, n_common, (const uint32_t *)pow_common, ierr);
+      }
+      inflate_checked = false;
+    }
+    // the next scan piece, inside the inflate piece
     size_t b1 = b0;
-    uint64_t in_lo = blocks[b0].in_off, in_hi = in_lo, out_bytes = 0;
-    while (b1 < blocks.size() && (b1 == b0 || out_bytes + blocks[b1].out_len <= PIECE)) {
-      in_hi = blocks[b1].in_off + blocks[b1].in_len;
-      out_bytes += blocks[b1].out_len;
-      b1++;
+    {
+      uint64_t out_bytes = 0;
+      while (b1 < a1 && (b1 == b0 || out_bytes + blocks[b1].out_len <= PIECE)) {
+        out_bytes += blocks[b1].out_len;
+        b1++;
+      }
     }
     const uint32_t nb = (uint32_t)(b1 - b0);
-    // compressed bytes + block table of the piece to the device
-    uint8_t *d_in;
-    ELP_TRY(scratch(c, 5, (size_t)(in_hi - in_lo) + 64, &d_in));
-    ELP_HIP(c, hipMemcpyAsync(d_in, bgzf + in_lo, (size_t)(in_hi - in_lo), hipMemcpyHostToDevice, st));
-    std::vector<BgzfBlk> tb(blocks.begin() + b0, blocks.begin() + b1);
-    for (auto &t : tb) { t.in_off -= in_lo; t.out_off += raw0; }
-    // block table | entry | exit (u64 each) | result words | cnt | base (u32 each)
-    static_assert(sizeof(BgzfBlk) == 32, "BgzfBlk is four 64-bit words");
-    uint64_t *wk;
-    ELP_TRY(scratch(c, 6, (size_t)nb * 6 + 8 + (size_t)(nb + 8) + 16, &wk));
-    BgzfBlk *d_blk = reinterpret_cast<BgzfBlk *>(wk);
-    uint64_t *entry = wk + (size_t)nb * 4, *exit_ = entry + nb, *res = exit_ + nb;
-    uint32_t *cnt = reinterpret_cast<uint32_t *>(res + 8), *base = cnt + nb + 8;
-    ELP_HIP(c, hipMemcpyAsync(d_blk, tb.data(), (size_t)nb * sizeof(BgzfBlk), hipMemcpyHostToDevice, st));
-    ELP_HIP(c, hipMemsetAsync(res, 0, 64, st));
+    const size_t rel = b0 - a0;
+    const BgzfBlk *d_blk = d_blk_all + rel;
+    uint64_t *entry = entry_all + rel, *exit_ = exit_all + rel;
+    uint32_t *cnt = cnt_all + rel, *base = base_all + rel;
+    ELP_HIP(c, hipMemsetAsync(res, 0, 16, st));
     uint32_t *err = reinterpret_cast<uint32_t *>(res), *bad = err + 1, *max_rec = err + 2;
-    if (c->tune.bgzf_inflate == 1) {  // round 5's form: one kernel that decodes and copies, and the CRC pass
-      ELP_LAUNCH(c, "stage_bgzf_inflate", k_bgzf_inflate, dim3(nb), dim3(64), 0, (const uint8_t *)d_in, (const BgzfBlk *)d_blk, nb, c->raw.p, err);
-      ELP_LAUNCH(c, "stage_bgzf_crc", k_bgzf_crc_check, dim3(nb), dim3(256), 0, (const uint8_t *)c->raw.p, (const BgzfBlk *)d_blk, pw, err);
-    } else {  // the bit stream first (literals placed, matches as tokens), then the matches and the CRC, a workgroup per block
-      uint2 *tok;
-      ELP_TRY(scratch(c, 7, (size_t)nb * TOK_STRIDE + (size_t)(nb + 2) / 2 + 8, &tok));
-      uint32_t *ntok = reinterpret_cast<uint32_t *>(tok + (size_t)nb * TOK_STRIDE);
-      static std::atomic<bool> lds_set{false};
-      if (!lds_set.load()) {
-        ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bgzf_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(65536 * sizeof(uint16_t))));
-        lds_set.store(true);
-      }
-      ELP_LAUNCH(c, "stage_bgzf_tokens", k_bgzf_tokens, dim3(nb), dim3(64), 0, (const uint8_t *)d_in, (const BgzfBlk *)d_blk, nb, c->raw.p, tok, ntok, err);
-      ELP_LAUNCH(c, "stage_bgzf_resolve", k_bgzf_resolve, dim3(nb), dim3(RES_THREADS), 65536 * sizeof(uint16_t), (const BgzfBlk *)d_blk, c->raw.p, (const uint2 *)tok,
-                 (const uint32_t *)ntok, pw, err);
-    }
-    const uint64_t end = tb.back().out_off + tb.back().out_len;
+    (void)err;
+    const BgzfBlk &last = tb_all[b1 - 1 - a0];
+    const uint64_t end = last.out_off + last.out_len;
     const RecScan rs{c->raw.p, begin, end, c->n_ref};
     ELP_LAUNCH(c, "stage_bgzf_guess", k_rec_guess, dim3(nb), dim3(256), 0, rs, (const BgzfBlk *)d_blk, entry, c->tune.bgzf_weak_guess);
     ELP_LAUNCH(c, "stage_bgzf_walk", k_rec_walk, dim3(blocks_for(nb, 64)), dim3(64), 0, rs, (const BgzfBlk *)d_blk, nb, (const uint64_t *)entry, exit_, cnt);
-    ELP_LAUNCH(c, "stage_bgzf_check", k_rec_check, dim3(blocks_for(nb, 256)), dim3(256), 0, rs, (const BgzfBlk *)d_blk, nb, (const uint64_t *)entry, (const uint64_t *)exit_, bad);
-    uint32_t hr[4];
+    ELP_LAUNCH(c, "stage_bgzf_check", k_rec_check, dim3(blocks_for(nb, 256)), dim3(256), 0, rs, (const BgzfBlk *)d_blk, nb, (const uint64_t *)entry, (const uint64_t *)exit_, bad, bad_list);
+    uint32_t hr[10];
     ELP_HIP(c, hipMemcpyAsync(hr, res, sizeof hr, hipMemcpyDeviceToHost, st));
     ELP_HIP(c, elp::stream_wait(st));
-    if (hr[0] & 1u) return set_error(c, ELP_ERR_DATA, "elp_stage_bgzf: a block does not inflate (corrupt DEFLATE data or wrong ISIZE)");
-    if (hr[0] & 2u) return set_error(c, ELP_ERR_DATA, "invalid CRC-32 value for a data block in a BGZF file");
-    if (hr[1]) ELP_LAUNCH(c, "stage_bgzf_repair", k_rec_repair, dim3(1), dim3(1), 0, rs, (const BgzfBlk *)d_blk, nb, entry, exit_, cnt);
+    if (!inflate_checked) {
+      if (hr[8] & 1u) return set_error(c, ELP_ERR_DATA, "elp_stage_bgzf: a block does not inflate (corrupt DEFLATE data or wrong ISIZE)");
+      if (hr[8] & 2u) return set_error(c, ELP_ERR_DATA, "invalid CRC-32 value for a data block in a BGZF file");
+      inflate_checked = true;
+    }
+    if (hr[1]) ELP_LAUNCH(c, "stage_bgzf_repair", k_rec_repair, dim3(1), dim3(1), 0, rs, d_blk, nb, entry, exit_, cnt, (const uint32_t *)bad, bad_list);
     uint32_t n_rec = 0;
     ELP_TRY(exclusive_scan_u32(c, cnt, base, nb, &n_rec));
     if (c->n + n_rec > 0xFFFFFFF0ull) return set_error(c, ELP_ERR_UNSUPPORTED, "more than 2^32-16 records per context");

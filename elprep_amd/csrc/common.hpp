@@ -251,6 +251,7 @@ struct elp_ctx {
     int sort_pairs = 0;        // 1: the coordinate sort moves (key, index) pairs even where key << b | index fits one word
     int tie_rounds = 0;        // 1: the sort's long runs by LSD rounds over every live position (no key-then-compare shortcut)
     int exchange_piece = 0;    // > 0: records per piece of elp_exchange_records (tests: several pieces on small inputs)
+    long long bgzf_inflate_piece = 1ll << 30;  // elp_stage_bgzf: inflated bytes whose blocks are decoded by one launch (token scratch: 2.7x that)
     int bgzf_inflate = 0;      // 1: elp_stage_bgzf inflates with round 5's one-kernel decoder (window in LDS) instead of tokens + resolve
     int bgzf_stored = 0;       // 1: elp_emit_sorted_bgzf writes stored DEFLATE blocks (round 4's form) instead of compressing
     int apply_wgs = 0;         // 1 .. 3: workgroups per CU of the one-length ApplyBQSR kernel (default: as many as its LDS allows, at most 3) - A/B runs

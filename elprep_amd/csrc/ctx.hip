@@ -593,6 +593,7 @@ int elp_set_tuning(elp_ctx *c, const char *key, int64_t value) {
   else if (k == "exchange_piece") c->tune.exchange_piece = v;
   else if (k == "bgzf_stored") c->tune.bgzf_stored = v;
   else if (k == "bgzf_inflate") c->tune.bgzf_inflate = v;
+  else if (k == "bgzf_inflate_piece") { if (value < 1) return set_error(c, ELP_ERR_ARG, "elp_set_tuning: bgzf_inflate_piece must be positive"); c->tune.bgzf_inflate_piece = value; }
   else if (k == "md_fused") c->tune.md_fused = v;
   else if (k == "apply_wgs") c->tune.apply_wgs = v;
   else if (k == "presort_tile") c->tune.presort_tile = v;

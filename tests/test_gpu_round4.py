@@ -175,13 +175,13 @@ def test_emit_sorted_bgzf_inflates_to_the_record_stream():
     assert [len(m) for _, m in mem[:-1]] == [65280] * (len(mem) - 1) and len(mem) >= 3
 
 
-def _bgzf(stream: bytes, level: int, strategy: int = 0, cut: int = 65280) -> bytes:
+def _bgzf(stream: bytes, level: int, strategy: int = 0, cut: int = 65280, mem_level: int = 8) -> bytes:
     import struct
     import zlib
     out = []
     for k in range(0, len(stream), cut):
         part = stream[k:k + cut]
-        co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+        co = zlib.compressobj(level, zlib.DEFLATED, -15, mem_level, strategy)
         data = co.compress(part) + co.flush()
         out.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(data) + 25) + data +
                    struct.pack("<II", zlib.crc32(part), len(part)))
@@ -196,12 +196,21 @@ def _bgzf(stream: bytes, level: int, strategy: int = 0, cut: int = 65280) -> byt
     (6, 4, 65280, None),                                         # Z_FIXED: fixed Huffman codes
     (6, 0, 65280, {"bgzf_piece": 200_000}),                     # many device passes: a record pending at the end of each
     (6, 0, 4099, {"bgzf_weak_guess": 1, "bgzf_piece": 1 << 20}),  # every guess wrong: the repair pass finds the same starts
+    # round 6 (the decoder in two phases: tokens, then matches + CRC):
+    (6, 0, 65280, {"bgzf_inflate_piece": 150_000, "bgzf_piece": 70_000}),  # several inflate pieces, scan pieces inside each
+    (9, 0, 65280, {"mem_level": 1}),                             # many small DEFLATE blocks per member: a header every few hundred symbols
+    (6, 2, 65280, None),                                         # Z_HUFFMAN_ONLY: literals only, codes longer than the tables' bits
+    (6, 3, 65280, None),                                         # Z_RLE: matches at distance 1 (a match that overlaps itself)
+    (6, 1, 2111, {"mem_level": 3}),                              # Z_FILTERED, small members
+    (1, 0, 30011, {"bgzf_inflate": 1}),                          # round 5's one-kernel decoder stays available
 ])
 def test_stage_bgzf_gives_the_records_of_stage_bam(level, strategy, cut, tuning):
     import numpy as _np
     b, h, raw, rec_off = _bam_case()
     header = bytes(_np.random.default_rng(1).integers(0, 256, 1234, dtype=_np.uint8))  # stands for magic + header text + dictionary
-    bz = _np.frombuffer(_bgzf(header + raw.tobytes(), level, strategy, cut), dtype=_np.uint8)
+    tuning = dict(tuning or {})
+    mem_level = tuning.pop("mem_level", 8)
+    bz = _np.frombuffer(_bgzf(header + raw.tobytes(), level, strategy, cut, mem_level), dtype=_np.uint8)
     outs = []
     for how in ("bam", "bgzf"):
         e = Engine(h, tuning=tuning)

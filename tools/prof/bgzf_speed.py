@@ -32,14 +32,20 @@ with ThreadPoolExecutor(16) as pool:
     bz = np.frombuffer(b"".join(pool.map(member, range(0, len(raw), cut))), dtype=np.uint8)
 e = Engine(h, 0)
 e.set_read_group_ids(h.rg_ids)
-e.stage_bgzf(bz)
+try:
+    e.stage_bgzf(bz)
+except Exception as ex:
+    print("stage_bgzf:", str(ex)[:80])
 e.sync()
 for _ in range(2):
     e.reset()
     e.profile_enable(True)
     e.profile_reset()
     t0 = time.perf_counter()
-    e.stage_bgzf(bz)
+    try:
+        e.stage_bgzf(bz)
+    except Exception as ex:
+        print("stage_bgzf:", str(ex)[:80])
     e.sync()
     t = time.perf_counter() - t0
     prof = e.profile()
