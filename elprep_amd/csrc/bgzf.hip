@@ -1163,6 +1163,28 @@ __global__ void k_rec_tail(const uint64_t *__restrict__ entry, const uint64_t *_
 
 using namespace elp;
 
+// events between the context's stream and its copy stream, destroyed when the call returns (also on an error path)
+struct CopyEvents {
+  std::vector<hipEvent_t> ev;
+  ~CopyEvents() { for (auto e : ev) (void)hipEventDestroy(e); }
+  int next(elp_ctx *c, hipEvent_t *out) {
+    hipEvent_t e;
+    ELP_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ev.push_back(e);
+    *out = e;
+    return 0;
+  }
+  // `to` waits for everything queued on `from` so far
+  int fence(elp_ctx *c, hipStream_t from, hipStream_t to) {
+    hipEvent_t e;
+    ELP_TRY(next(c, &e));
+    ELP_HIP(c, hipEventRecord(e, from));
+    ELP_HIP(c, hipStreamWaitEvent(to, e, 0));
+    return 0;
+  }
+  int arrived(elp_ctx *c, hipStream_t copy, hipStream_t st) { return fence(c, copy, st); }
+};
+
 // elp_stage_bgzf: see include/elprep_hip.h
 extern "C" int elp_stage_bgzf(elp_ctx *c, const uint8_t *bgzf, uint64_t n_bytes, uint64_t first_record, uint16_t split_id) {
   if (!c || (!bgzf && n_bytes)) return ELP_ERR_ARG;
@@ -1211,9 +1233,10 @@ extern "C" int elp_stage_bgzf(elp_ctx *c, const uint8_t *bgzf, uint64_t n_bytes,
   // the inflated stream goes to c->raw behind what is there; the records of the header prefix are never referenced
   const uint64_t raw0 = c->raw_bytes;
   ELP_TRY(ensure(c, c->raw, raw0 + inflated + 64, true, raw0));
-  // Two sizes of pieces.  INFLATE pieces (<= 1 GiB inflated: ~16 k blocks) - the decoder wants every block of the file in flight at once (a
+  // Two sizes of pieces.  INFLATE pieces (<= 2 GiB inflated: ~33 k blocks) - the decoder wants every block of the file in flight at once (a
   // wave per block, 22 of them per CU: 5.6 k blocks fill the chip once; round 6: 192 MiB pieces left it half empty and cost 1.7x) and pays
-  // 171 KB of token scratch per block for it.  Inside one, SCAN pieces (<= 192 MiB: u32 scans and bounded scratch in stage_bam_columns)
+  // 171 KB of token scratch per block for it.  Inside one, SCAN pieces (<= 1 GiB: u32 scans and bounded scratch in stage_bam_columns; round 6: 192 MiB pieces cost 7 x 2 host
+  // waits and launches of 3 k threads)
   // find the records and stage the columns as before.
   const uint64_t PIECE = (uint64_t)c->tune.bgzf_piece, IPIECE = (uint64_t)c->tune.bgzf_inflate_piece;
   uint64_t begin = raw0 + first_record;  // where the next record starts in c->raw
@@ -1222,6 +1245,8 @@ extern "C" int elp_stage_bgzf(elp_ctx *c, const uint8_t *bgzf, uint64_t n_bytes,
   uint64_t *entry_all = nullptr, *exit_all = nullptr, *res = nullptr;
   uint32_t *cnt_all = nullptr, *base_all = nullptr, *bad_list = nullptr;
   std::vector<BgzfBlk> tb_all;
+  CopyEvents copied;
+  const uint32_t chunk = c->tune.bgzf_copy_chunk > 0 ? (uint32_t)c->tune.bgzf_copy_chunk : std::max(1024u, (uint32_t)c->n_cu * 22u);
   size_t a0 = 0;
   bool inflate_checked = true;
   while (b0 < blocks.size()) {
@@ -1236,7 +1261,10 @@ extern "C" int elp_stage_bgzf(elp_ctx *c, const uint8_t *bgzf, uint64_t n_bytes,
       const uint32_t na = (uint32_t)(a1 - a0);
       uint8_t *d_in;
       ELP_TRY(scratch(c, 5, (size_t)(in_hi - in_lo) + 64, &d_in));
-      ELP_HIP(c, hipMemcpyAsync(d_in, bgzf + in_lo, (size_t)(in_hi - in_lo), hipMemcpyHostToDevice, st));
+      // the compressed bytes cross PCIe in chunks of blocks on the copy stream, each chunk's decoder launch waits for its own chunk only:
+      // the decoder works on chunk k while chunk k + 1 arrives.  A chunk = the blocks that fill the chip once (22 waves per CU).
+      if (!c->copy_stream) ELP_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+      copied.fence(c, st, c->copy_stream);  // (what is queued on the stream may still read the buffer the copies are about to overwrite)
       tb_all.assign(blocks.begin() + a0, blocks.begin() + a1);
       for (auto &t : tb_all) { t.in_off -= in_lo; t.out_off += raw0; }
       // block table | entry | exit (u64 each) | result words | cnt | base (u32 each) | list of rejected guesses
@@ -1254,6 +1282,8 @@ extern "C" int elp_stage_bgzf(elp_ctx *c, const uint8_t *bgzf, uint64_t n_bytes,
       ELP_HIP(c, hipMemsetAsync(res, 0, 64, st));
       uint32_t *ierr = reinterpret_cast<uint32_t *>(res + 4);  // (its own word: the scan pieces clear theirs)
       if (c->tune.bgzf_inflate == 1) {  // round 5's form: one kernel that decodes and copies, and the CRC pass
+        ELP_HIP(c, hipMemcpyAsync(d_in, bgzf + in_lo, (size_t)(in_hi - in_lo), hipMemcpyHostToDevice, c->copy_stream));
+        ELP_TRY(copied.arrived(c, c->copy_stream, st));
         ELP_LAUNCH(c, "stage_bgzf_inflate", k_bgzf_inflate, dim3(na), dim3(64), 0, (const uint8_t *)d_in, (const BgzfBlk *)d_blk_all, na, c->raw.p, ierr);
         ELP_LAUNCH(c, "stage_bgzf_crc", k_bgzf_crc_check, dim3(na), dim3(256), 0, (const uint8_t *)c->raw.p, (const BgzfBlk *)d_blk_all, pw, ierr);
       } else {  // the bit stream first (literals placed, matches as tokens), then the matches and the CRC, a workgroup per block
@@ -1275,7 +1305,22 @@ extern "C" int elp_stage_bgzf(elp_ctx *c, const uint8_t *bgzf, uint64_t n_bytes,
           ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bgzf_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(65536 * sizeof(uint16_t))));
           lds_set.store(true);
         }
-        ELP_LAUNCH(c, "stage_bgzf_tokens", k_bgzf_tokens, dim3(na), dim3(64), 0, (const uint8_t *)d_in, (const BgzfBlk *)d_blk_all, na, c->raw.p, tok, ntok, ierr);
+        // the chunks' launches alternate between the context's stream and a lane of its own (the sort lane: idle while records are staged):
+        // a launch behind another on ONE stream starts when the last wave of the one in front has finished - a block takes 4.5 ms, the chip
+        // drains for half of that per launch -; on two streams the next chunk's waves take the slots as they come free
+        elp_ctx *lane = nullptr;
+        if (na > chunk) ELP_TRY(side_lane(c, 1, &lane));
+        uint32_t turn = 0;
+        for (uint32_t q0 = 0, q1 = 0; q0 < na; q0 = q1, turn++) {
+          q1 = std::min(na, q0 + (turn == 0 ? std::max(1u, chunk / (uint32_t)std::max(1, c->tune.bgzf_first_chunk_div)) : chunk));  // (a small first chunk: the decoder starts early)
+          const uint64_t lo = tb_all[q0].in_off, hi = tb_all[q1 - 1].in_off + tb_all[q1 - 1].in_len;
+          ELP_HIP(c, hipMemcpyAsync(d_in + lo, bgzf + in_lo + lo, (size_t)(hi - lo), hipMemcpyHostToDevice, c->copy_stream));
+          elp_ctx *on = (lane && (turn & 1u)) ? lane : c;
+          ELP_TRY(copied.arrived(c, c->copy_stream, on->stream));
+          ELP_LAUNCH(on, "stage_bgzf_tokens", k_bgzf_tokens, dim3(q1 - q0), dim3(64), (size_t)c->tune.bgzf_tok_lds, (const uint8_t *)d_in, (const BgzfBlk *)d_blk_all + q0, q1 - q0,
+                     c->raw.p, tok + (size_t)q0 * TOK_STRIDE, ntok + q0, ierr);
+        }
+        if (lane) ELP_TRY(side_join(c, 1));
         ELP_LAUNCH(c, "stage_bgzf_resolve", k_bgzf_resolve, dim3(na), dim3(RES_THREADS), 65536 * sizeof(uint16_t), (const BgzfBlk *)d_blk_all, c->raw.p, (const uint2 *)tok,
                    (const uint32_t *)ntok, pw, n_common, (const uint32_t *)pow_common, ierr);
       }

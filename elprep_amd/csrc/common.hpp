@@ -243,7 +243,7 @@ struct elp_ctx {
     int qual_hint = 0;         // 1: no sampled quality hint (tables sized for every quality); 2: hint without the value qual_hint_drop
     int qual_hint_drop = -1;
     int pair_table_slots = 1 << 20;  // cap on the LDS table slots of a pair bucket (mark duplicates); tests shrink it to reach the overflow path
-    long long bgzf_piece = 192ll << 20;  // elp_stage_bgzf: inflated bytes per device pass (tests: small pieces, records pending across them)
+    long long bgzf_piece = 1ll << 30;    // elp_stage_bgzf: inflated bytes per device pass (tests: small pieces, records pending across them)
     int bgzf_weak_guess = 0;   // 1: a block guesses its first record start without looking at the bytes (tests: every guess wrong, all repaired)
     int score_kernel = 0;      // 1: the general (flat) score kernel even for read sets of one length
     int mate_path = 0;         // 1: every mate candidate goes through the table path (no neighbour shortcut)
@@ -251,7 +251,10 @@ struct elp_ctx {
     int sort_pairs = 0;        // 1: the coordinate sort moves (key, index) pairs even where key << b | index fits one word
     int tie_rounds = 0;        // 1: the sort's long runs by LSD rounds over every live position (no key-then-compare shortcut)
     int exchange_piece = 0;    // > 0: records per piece of elp_exchange_records (tests: several pieces on small inputs)
-    long long bgzf_inflate_piece = 1ll << 30;  // elp_stage_bgzf: inflated bytes whose blocks are decoded by one launch (token scratch: 2.7x that)
+    long long bgzf_inflate_piece = 2ll << 30;  // elp_stage_bgzf: inflated bytes whose blocks are decoded by one launch (token scratch: 2.7x that)
+    int bgzf_copy_chunk = 0;   // elp_stage_bgzf: blocks per H2D chunk / decoder launch (0: what fills the chip once)
+    int bgzf_tok_lds = 0;      // (experiments) unused dynamic LDS bytes per decoder wave: lowers the waves per CU
+    int bgzf_first_chunk_div = 4;  // the first H2D chunk is 1/div of the others
     int bgzf_inflate = 0;      // 1: elp_stage_bgzf inflates with round 5's one-kernel decoder (window in LDS) instead of tokens + resolve
     int bgzf_stored = 0;       // 1: elp_emit_sorted_bgzf writes stored DEFLATE blocks (round 4's form) instead of compressing
     int apply_wgs = 0;         // 1 .. 3: workgroups per CU of the one-length ApplyBQSR kernel (default: as many as its LDS allows, at most 3) - A/B runs

@@ -38,9 +38,12 @@ int elp_rollback(elp_ctx *ctx);
  *   "apply_kernel"     1: general ApplyBQSR kernel; 3: the one-length kernel split by covariate even where one table holds every covariate
  *   "exchange_piece"   > 0: records per piece of elp_exchange_records (default 4 M, less for long records: a piece's columns stay below 4 GiB)
  *   "bgzf_stored"      1: elp_emit_sorted_bgzf frames stored DEFLATE blocks (BTYPE 00) instead of compressing
- *   "bgzf_piece"       inflated bytes per device pass of elp_stage_bgzf (default 192 MiB)
- *   "bgzf_inflate_piece"  inflated bytes whose blocks one launch of the decoder takes (default 1 GiB; the scan passes of
+ *   "bgzf_piece"       inflated bytes per record-scan pass of elp_stage_bgzf (default 1 GiB)
+ *   "bgzf_inflate_piece"  inflated bytes whose blocks one launch of the decoder takes (default 2 GiB; the scan passes of
  *                      "bgzf_piece" bytes run inside it; token scratch: 171 KB per 64 KB block)
+ *   "bgzf_copy_chunk"  blocks per H2D chunk and decoder launch of elp_stage_bgzf (0: the blocks that fill the chip once);
+ *   "bgzf_first_chunk_div"  the first chunk is 1/div of that (default 4: the decoder starts early)
+ *   "bgzf_tok_lds"     (experiments) unused LDS bytes per decoder wave: fewer waves per CU
  *   "bgzf_inflate"     1: round 5's decoder (one kernel: a wave decodes and copies a block, window in LDS; separate CRC pass)
  *                      instead of round 6's two phases (tokens: 64 candidate symbols per wave and step; matches + CRC: a workgroup)
  *   "bgzf_weak_guess"  1: elp_stage_bgzf's blocks guess their first record start blindly (every guess is then repaired: same result)

@@ -1,4 +1,5 @@
-"""elp_stage_bgzf / elp_emit_sorted_bgzf on N reads: wall time and per-kernel times.  usage: bgzf_speed.py [reads] [zlib level]"""
+"""elp_stage_bgzf / elp_emit_sorted_bgzf on N reads: wall time and per-kernel times.  usage: bgzf_speed.py [reads] [zlib level] [check]
+(check: the staged records give the flags, the permutation and the sorted BAM bytes that elp_stage_bam gives on the inflated bytes)"""
 import struct
 import sys
 import time
@@ -7,7 +8,8 @@ from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from elprep_amd.engine import Engine  # noqa: E402
 from tools import synth  # noqa: E402
 
@@ -52,8 +54,19 @@ for _ in range(2):
     e.profile_enable(False)
 print(f"{b.n} reads, {len(raw)} inflated bytes, {bz.size} compressed: stage_bgzf {t * 1e3:.1f} ms = {b.n / t / 1e6:.1f} Mreads/s = {len(raw) / t / 1e9:.2f} GB/s inflated")
 print({k: round(v[1], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:10]})
-e.mark_duplicates(True, fetch=False)
-e.sort_coordinate(fetch=False)
+if len(sys.argv) > 3 and sys.argv[3] == "check":
+    import hashlib
+    got = (e.n, e.mark_duplicates(True), e.sort_coordinate(), hashlib.sha1(e.emit_sorted_bam().tobytes()).hexdigest())
+    e2 = Engine(h, 0)
+    e2.set_read_group_ids(h.rg_ids)
+    e2.stage_bam(np.frombuffer(raw, dtype=np.uint8), rec_off=rec_off)
+    want = (e2.n, e2.mark_duplicates(True), e2.sort_coordinate(), hashlib.sha1(e2.emit_sorted_bam().tobytes()).hexdigest())
+    e2.close()
+    ok = got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2]) and got[3] == want[3]
+    print("check against elp_stage_bam:", "identical" if ok else "DIFFERENT", got[0], want[0])
+else:
+    e.mark_duplicates(True, fetch=False)
+    e.sort_coordinate(fetch=False)
 e.emit_sorted_bgzf()
 e.profile_enable(True)
 e.profile_reset()
