@@ -109,18 +109,19 @@ int bgzf_frame(elp_ctx *c, const uint8_t *raw, uint64_t n_bytes, uint8_t *out) {
 
 
 // ------------------------------------------------------------------ the compressing writer (round 5, VERDICT r4 missing #1)
-// Reference: utils/bgzf/bgzf-files.go:324-383 compresses every block with compress/flate.  Here: a workgroup per block, fixed-Huffman
-// DEFLATE over a parallel LZ77 parse (deflate_core.hpp has the algorithm and every function that decides a bit; this kernel is its
+// Reference: utils/bgzf/bgzf-files.go:324-383 compresses every block with compress/flate.  Here: a workgroup per block, DEFLATE with the
+// block's own Huffman codes (round 6; fixed codes where those are not longer, and under the tuning key "bgzf_fixed": round 5's form)
+// over a parallel LZ77 parse (deflate_core.hpp has the algorithm and every function that decides a bit; this kernel is its
 // phases with barriers between them).  A block's member (18-byte header | DEFLATE data | CRC-32 | ISIZE) lands in a slot of fixed stride;
 // the members' sizes differ, so a second kernel moves them together behind a scan of the sizes.  A block that would not shrink is stored.
 constexpr uint32_t BGZF_SLOT = 65344;  // bytes between two slots (>= PAYLOAD + OVERHEAD, a multiple of 64)
 constexpr uint32_t DFL_LD = dfl::PAYLOAD + 256;  // words of match notes / tokens per workgroup
 __global__ __launch_bounds__(256) void k_bgzf_deflate(const uint8_t *__restrict__ raw, uint64_t n_bytes, uint32_t nblk, uint8_t *__restrict__ slots,
-                                                      uint32_t *__restrict__ sizes, uint32_t *__restrict__ ld_all, CrcPow pw) {
+                                                      uint32_t *__restrict__ sizes, uint32_t *__restrict__ ld_all, CrcPow pw, int fixed_only) {
   using namespace dfl;
   __shared__ uint32_t tbl[256];
   __shared__ uint32_t s_crc, s_wsum[4];
-  __shared__ uint16_t table[(size_t)WAYS << HBITS];
+  __shared__ __attribute__((aligned(16))) uint16_t table[(size_t)WAYS << HBITS];
   __shared__ __attribute__((aligned(16))) uint8_t buf[PAYLOAD + IN_PAD];  // the block's payload; behind the parse: its DEFLATE data
   const uint32_t t = threadIdx.x;
   {
@@ -164,8 +165,15 @@ __global__ __launch_bounds__(256) void k_bgzf_deflate(const uint8_t *__restrict_
       __syncthreads();
     }
     // ---- 2. the parse of the thread's part: tokens in place of the notes, their bits
+    DynCodes &D = *reinterpret_cast<DynCodes *>(table);  // (the hash table's LDS is free from here on: deflate_core.hpp, dynamic codes)
+    static_assert(sizeof(DynCodes) <= sizeof(table), "the codes' tables live where the hash table was");
+    for (uint32_t k = t; k < 320u; k += 256u) { D.freq[k] = 0u; D.len[k] = 0; }
+    if (t < 2u) { D.m[t] = 0u; D.over[t] = 0u; }
+    if (t < 34u) D.cnt[t / 17u][t % 17u] = 0u;
+    __syncthreads();
     uint32_t my_bits = 0;
-    const uint32_t my_tok = parse_part(buf, ld, lo, hi, &my_bits);
+    uint32_t *freq = D.freq;
+    const uint32_t my_tok = parse_part(buf, ld, lo, hi, &my_bits, [freq](uint32_t sy) { atomicAdd(&freq[sy], 1u); });
     // ---- 3. bit offsets: exclusive scan over the 256 parts
     uint32_t incl = my_bits;
     for (int d = 1; d < 64; d <<= 1) {
@@ -176,12 +184,94 @@ __global__ __launch_bounds__(256) void k_bgzf_deflate(const uint8_t *__restrict_
     __syncthreads();  // (also: every thread is through with the payload in `buf`, the CRC is complete)
     uint32_t off = 0;
     for (uint32_t w = 0; w < (t >> 6); w++) off += s_wsum[w];
-    const uint32_t my_off = off + incl - my_bits;
-    const uint32_t total_bits = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-    const uint32_t cbytes = deflate_bytes(total_bits);
+    uint32_t my_off = off + incl - my_bits;
+    uint32_t total_bits = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    uint32_t cbytes = deflate_bytes(total_bits);
+    // ---- 3b. dynamic codes (deflate_core.hpp: count | rank | build | codes | header | bits); the hash table's LDS is free by now
+    bool dynamic = false;
+    if (!fixed_only) {
+      if (t == 0) atomicAdd(&D.freq[256], 1u);
+      __syncthreads();
+      for (uint32_t sy = t; sy < (uint32_t)NLL; sy += 256u) {
+        const int r = symbol_rank(D.freq, NLL, (int)sy);
+        if (r >= 0) { D.order[r] = (uint16_t)sy; atomicAdd(&D.m[0], 1u); }
+      }
+      if (t < (uint32_t)NDIST) {
+        const int r = symbol_rank(D.freq + DOFF, NDIST, (int)t);
+        if (r >= 0) { D.order[DOFF + r] = (uint16_t)t; atomicAdd(&D.m[1], 1u); }
+      }
+      __syncthreads();
+      const int m0 = (int)D.m[0], m1 = (int)D.m[1];
+      if (t == 0 && m0 >= 2) huffman_merge(D.freq, D.order, m0, D.w, D.up);
+      if (t == 64 && m1 >= 2) huffman_merge(D.freq + DOFF, D.order + DOFF, m1, D.w + 2 * DOFF, D.up + 2 * DOFF);
+      __syncthreads();
+      for (int leaf = (int)t; leaf < m0 && m0 >= 2; leaf += 256) {
+        uint32_t d = leaf_depth(D.up, leaf, m0);
+        if (d > 15u) { d = 15u; atomicAdd(&D.over[0], 1u); }
+        atomicAdd(&D.cnt[0][d], 1u);
+      }
+      if ((int)t < m1 && m1 >= 2) {
+        uint32_t d = leaf_depth(D.up + 2 * DOFF, (int)t, m1);
+        if (d > 15u) { d = 15u; atomicAdd(&D.over[1], 1u); }
+        atomicAdd(&D.cnt[1][d], 1u);
+      }
+      __syncthreads();
+      if (t == 0) {
+        if (m0 >= 2) limit_counts(D.cnt[0], 15, (int)D.over[0], D.base[0]);
+        else trivial_lengths(D.order, m0, NLL, D.len, D.cnt[0], D.base[0]);
+      } else if (t == 64) {
+        if (m1 >= 2) limit_counts(D.cnt[1], 15, (int)D.over[1], D.base[1]);
+        else trivial_lengths(D.order + DOFF, m1, NDIST, D.len + DOFF, D.cnt[1], D.base[1]);
+      }
+      __syncthreads();
+      for (int leaf = (int)t; leaf < m0 && m0 >= 2; leaf += 256) D.len[D.order[leaf]] = (uint8_t)length_of_rank(D.cnt[0], 15, leaf);
+      if ((int)t < m1 && m1 >= 2) D.len[DOFF + D.order[DOFF + t]] = (uint8_t)length_of_rank(D.cnt[1], 15, (int)t);
+      __syncthreads();
+      for (uint32_t sy = t; sy < (uint32_t)NLL; sy += 256u) D.code[sy] = canonical_code(D.len, (int)sy, D.base[0]);
+      if (t < (uint32_t)NDIST) D.code[DOFF + t] = canonical_code(D.len + DOFF, (int)t, D.base[1]);
+      if (t == 128) build_header(D);  // (reads the lengths only; the other threads count their bits meanwhile)
+      uint32_t dyn_bits = 0;
+      for (uint32_t j = 0; j < my_tok; j++) dyn_bits += token_bits_dyn(ld[lo + j], D);
+      uint32_t dincl = dyn_bits;
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t v = __shfl_up(dincl, d, 64);
+        if ((int)(t & 63u) >= d) dincl += v;
+      }
+      __syncthreads();  // (s_wsum's readers above are through)
+      if ((t & 63u) == 63u) s_wsum[t >> 6] = dincl;
+      __syncthreads();
+      uint32_t doff = 0;
+      for (uint32_t w = 0; w < (t >> 6); w++) doff += s_wsum[w];
+      const uint32_t dtotal = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+      const uint32_t dyn_bytes = deflate_bytes_dyn(D, dtotal);
+      if (dyn_bytes < cbytes) {
+        dynamic = true;
+        cbytes = dyn_bytes;
+        total_bits = dtotal;
+        my_off = doff + dincl - dyn_bits;
+      }
+    }
     const bool stored = cbytes >= len + 5u;
     const uint32_t dbytes = stored ? len + 5u : cbytes;  // the member's DEFLATE data
-    if (!stored) {
+    if (!stored && dynamic) {
+      for (uint32_t k = t; k < (cbytes + 3u) / 4u + 1u; k += 256u) words[k] = 0u;
+      __syncthreads();
+      auto orw = [words](uint32_t w, uint32_t v) { atomicOr(&words[w], v); };
+      if (t == 0) {
+        BitWriter<decltype(orw)> hw(orw, 0u);
+        emit_dyn_header(hw, D);
+        hw.finish();
+      }
+      if (t == 255) {  // the end-of-block code behind the last part's tokens
+        BitWriter<decltype(orw)> ew(orw, D.header_bits + total_bits);
+        ew.put(D.code[256], D.len[256]);
+        ew.finish();
+      }
+      BitWriter<decltype(orw)> bw(orw, D.header_bits + my_off);
+      for (uint32_t j = 0; j < my_tok; j++) emit_token_dyn(bw, ld[lo + j], D);
+      bw.finish();
+      __syncthreads();
+    } else if (!stored) {
       // ---- 4. the codes at their bit offsets, OR-ed into the zeroed words (neighbouring parts share words)
       for (uint32_t k = t; k < (cbytes + 3u) / 4u + 1u; k += 256u) words[k] = 0u;
       __syncthreads();
@@ -242,7 +332,7 @@ int bgzf_deflate(elp_ctx *c, const uint8_t *raw, uint64_t n_bytes, uint8_t *out,
   uint32_t *ld_all = wk, *sizes = wk + (size_t)grid * DFL_LD, *offs = sizes + nblk + 8;
   uint8_t *slots;
   ELP_TRY(scratch(c, 1, nblk * BGZF_SLOT + 64, &slots));
-  ELP_LAUNCH(c, "emit_bgzf_deflate", k_bgzf_deflate, dim3(grid), dim3(256), 0, raw, n_bytes, (uint32_t)nblk, slots, sizes, ld_all, pw);
+  ELP_LAUNCH(c, "emit_bgzf_deflate", k_bgzf_deflate, dim3(grid), dim3(256), 0, raw, n_bytes, (uint32_t)nblk, slots, sizes, ld_all, pw, c->tune.bgzf_fixed);
   uint32_t total = 0;
   ELP_TRY(exclusive_scan_u32(c, sizes, offs, nblk, &total));  // (a pass is below 4 GiB: emit_stream's chunks)
   ELP_LAUNCH(c, "emit_bgzf_compact", k_bgzf_compact, dim3((unsigned)nblk), dim3(256), 0, (const uint8_t *)slots, (const uint32_t *)sizes, (const uint32_t *)offs, out);

@@ -130,17 +130,33 @@ ELP_DFL_HD void table_insert(uint16_t *table, const uint8_t *in, uint32_t n, uin
 
 // ---- 2. the greedy parse of part [lo, hi): reads the notes ld[i], writes token k of the part to ld[lo + k] (k <= i - lo: a note is
 // overwritten only after it has been read); returns the number of tokens, *bits = their size in a fixed-Huffman block
-ELP_DFL_HD uint32_t parse_part(const uint8_t *in, uint32_t *ld, uint32_t lo, uint32_t hi, uint32_t *bits) {
+// count(symbol index): called for the token's literal / length symbol s (index s) and distance symbol d (index DOFF_ + d) - the dynamic
+// codes' histogram, taken while the token is at hand
+template <class Count>
+ELP_DFL_HD uint32_t parse_part(const uint8_t *in, uint32_t *ld, uint32_t lo, uint32_t hi, uint32_t *bits, Count count) {
   uint32_t i = lo, k = 0, nb = 0;
   while (i < hi) {
     const uint32_t note = ld[i];
     uint32_t len = note & 0xFFu;
     if (len > hi - i) len = hi - i;
     uint32_t tok;
-    if (len >= MINM) { tok = tok_match(len, note >> 8); i += len; }
-    else { tok = in[i]; i += 1; }
+    if (len >= MINM) {
+      tok = tok_match(len, note >> 8);
+      i += len;
+      uint32_t eb, ev, deb, dev, nbl;
+      const uint32_t sym = len_symbol(len, eb, ev);
+      (void)fixed_code(sym, nbl);
+      const uint32_t ds = dist_symbol(note >> 8, deb, dev);
+      nb += nbl + eb + 5u + deb;
+      count(sym);
+      count(288u + ds);
+    } else {
+      tok = in[i];
+      i += 1;
+      nb += tok < 144u ? 8u : 9u;
+      count(tok);
+    }
     ld[lo + k++] = tok;
-    nb += token_bits(tok);
   }
   *bits = nb;
   return k;
@@ -177,6 +193,237 @@ ELP_DFL_HD void emit_token(BitWriter<OrW> &bw, uint32_t tok) {
   const uint32_t ds = dist_symbol((tok & 0x7FFFu) + 1u, deb, dev);
   bw.put(bit_reverse(ds, 5u), 5u);
   if (deb) bw.put(dev, deb);
+}
+
+// ------------------------------------------------------------------ dynamic Huffman codes (round 6; RFC 1951 3.2.7, BTYPE 10)
+// The reference's writer is compress/flate at its default level (utils/bgzf/bgzf-files.go:324-383): dynamic codes per block.  Here, behind
+// the parse: the tokens' symbols are counted (286 literal / length symbols, 30 distance symbols), both alphabets get Huffman code lengths
+// (<= 15 bits), the lengths are run-length coded and themselves Huffman coded (<= 7 bits) into the block's header, and the parts write their
+// tokens with the block's own codes.  A block whose dynamic form is not shorter keeps the fixed codes.
+// Who does what on the device (256 threads; the host emulation runs the same functions in the same phases):
+//   count        every part over its tokens (atomic adds)
+//   rank         every thread for its symbols: the symbol's place in the order by (count, index) - a sort by counting, 286 reads each
+//   merge        ONE thread per alphabet: the two-queue Huffman merge over the sorted counts (the one serial loop: ~2 LDS round trips a node)
+//   depths       every thread for its leaves: steps to the root, counted per depth (atomic adds)
+//   limit        one thread per alphabet: the counts repaired where the tree is deeper than 15; canonical bases
+//   lengths      every thread for its leaves: the length of its rank; then the canonical code = base of its length + rank among the
+//                symbols of that length
+//   header       one thread: run-length symbols 16 / 17 / 18, their counts, their 7-bit-limited code, the header's bits
+//   bits, write  every part, as with the fixed codes
+constexpr int NLL = 286, NDIST = 30, NCL = 19, DOFF = 288;  // the distance alphabet's arrays start at DOFF
+struct DynCodes {
+  uint32_t freq[320];    // [0, 286) literal / length, [DOFF, DOFF + 30) distance
+  uint16_t order[320];   // the used symbols in ascending order of (count, index), per alphabet
+  uint8_t len[320];      // code lengths (0: unused)
+  uint16_t code[320];    // the codes, bit-reversed (ready for the LSB-first stream)
+  uint32_t w[2 * 320];   // weights of the merge's nodes (leaves, then internal nodes), per alphabet at 2 * its offset
+  uint16_t up[2 * 320];  // parent of a node
+  uint16_t base[2][16];  // canonical base code per length
+  uint32_t cnt[2][17];   // codes per length
+  uint32_t over[2];      // leaves deeper than the limit
+  uint16_t rle[320];     // the header's code-length symbols: symbol | extra bits' value << 8
+  uint32_t n_rle, hlit, hdist, hclen, header_bits;
+  uint32_t m[2];         // used symbols per alphabet
+  uint8_t cl_len[NCL];
+  uint16_t cl_code[NCL];
+  // the code of the code lengths is built by one thread: its work arrays (here, not on the thread's stack: on the device that is HBM)
+  uint32_t cl_freq[NCL], cl_w[2 * NCL], cl_cnt[17];
+  uint16_t cl_ord[NCL], cl_up[2 * NCL], cl_base[16];
+};
+// the literal / length symbol and the distance symbol of a token (distance symbol: 0xFFFF for a literal)
+ELP_DFL_HD uint32_t token_symbols(uint32_t tok, uint32_t &dsym, uint32_t &extra_bits) {
+  if (!(tok & 0x80000000u)) { dsym = 0xFFFFu; extra_bits = 0; return tok; }
+  uint32_t eb, ev, deb, dev;
+  const uint32_t sym = len_symbol(((tok >> 16) & 0xFFu) + 3u, eb, ev);
+  dsym = dist_symbol((tok & 0x7FFFu) + 1u, deb, dev);
+  extra_bits = eb + deb;
+  return sym;
+}
+// place of symbol s among the used symbols of freq[0, n) in the order by (count, index); -1: unused
+ELP_DFL_HD int symbol_rank(const uint32_t *freq, int n, int s) {
+  const uint32_t f = freq[s];
+  if (!f) return -1;
+  int r = 0;
+  for (int j = 0; j < n; j++) {
+    const uint32_t g = freq[j];
+    r += (g != 0u && (g < f || (g == f && j < s))) ? 1 : 0;
+  }
+  return r;
+}
+// Huffman code lengths of the m used symbols order[0, m) (ascending counts) of an alphabet, at most maxbits long, in pieces: the merge is
+// serial (one thread), the depths of the leaves and the lengths by rank are not.
+// 1. the merge (one thread; m >= 2).  Leaves 0 .. m-1 in ascending weight, internal nodes m .. 2m-2 in the order they are made (ascending
+//    too): two queues, their heads in registers.  up[node] = its parent; the root is node 2m-2.  w: room for 2 m weights.
+ELP_DFL_HD void huffman_merge(const uint32_t *freq, const uint16_t *order, int m, uint32_t *w, uint16_t *up) {
+  for (int k = 0; k < m; k++) w[k] = freq[order[k]];
+  const uint32_t NONE = 0xFFFFFFFFu;
+  int leaf = 0, node = m;
+  uint32_t wl = w[0], wn = NONE;  // weights at the heads (NONE: the queue is empty)
+  for (int made = m; made < 2 * m - 1; made++) {
+    uint32_t sum = 0;
+    for (int pick = 0; pick < 2; pick++) {
+      if (wl <= wn) { sum += wl; up[leaf] = (uint16_t)made; leaf++; wl = leaf < m ? w[leaf] : NONE; }
+      else { sum += wn; up[node] = (uint16_t)made; node++; wn = node < made ? w[node] : NONE; }
+    }
+    w[made] = sum;
+    if (wn == NONE && node == made) wn = sum;  // (the node just made is the internal queue's new head)
+  }
+}
+// 2. the depth of leaf k (any thread)
+ELP_DFL_HD uint32_t leaf_depth(const uint16_t *up, int k, int m) {
+  uint32_t d = 0;
+  for (int node = k; node != 2 * m - 2; node = up[node]) d++;
+  return d;
+}
+// 3. count[d] = leaves of depth d with the depths beyond the limit clamped to it, `overflow` of them (one thread).  The clamped code is
+//    over-subscribed: for every two leaves too many, a leaf of the deepest level above the limit's that has one moves a level down and
+//    takes one of them as its sibling - the counts stay those of a complete code (the classic repair, as in zlib's gen_bitlen).
+//    Then base[L] = first canonical code of length L (RFC 1951 3.2.2).
+ELP_DFL_HD void limit_counts(uint32_t *count, int maxbits, int overflow, uint16_t *base) {
+  while (overflow > 0) {
+    int bits = maxbits - 1;
+    while (count[bits] == 0) bits--;
+    count[bits]--;
+    count[bits + 1] += 2;
+    count[maxbits]--;
+    overflow -= 2;
+  }
+  uint32_t code = 0;
+  base[0] = 0;
+  for (int l = 1; l < 16; l++) { code = (code + (l > 1 ? count[l - 1] : 0u)) << 1; base[l] = (uint16_t)code; }
+}
+// 4. the length of the leaf of rank k: the rarest symbols get the longest codes (any thread)
+ELP_DFL_HD uint32_t length_of_rank(const uint32_t *count, int maxbits, int k) {
+  uint32_t acc = 0;
+  for (int bits = maxbits; bits > 1; bits--) {
+    acc += count[bits];
+    if ((uint32_t)k < acc) return (uint32_t)bits;
+  }
+  return 1u;
+}
+// fewer than two used symbols (one thread): two codes of one bit - a complete code every decoder accepts
+ELP_DFL_HD void trivial_lengths(const uint16_t *order, int m, int n, uint8_t *len, uint32_t *count, uint16_t *base) {
+  const int s = m ? order[0] : 0;
+  len[s] = 1;
+  len[s == 0 ? (n > 1 ? 1 : 0) : 0] = 1;
+  for (int l = 0; l <= 16; l++) count[l] = 0;
+  count[1] = 2;
+  limit_counts(count, 15, 0, base);
+}
+// all of it by one thread (the code of the code lengths; the tests' cross-check).  len[] zeroed by the caller; count: 17 words
+ELP_DFL_HD void huffman_lengths_serial(const uint32_t *freq, const uint16_t *order, int m, int n, int maxbits, uint8_t *len, uint32_t *w, uint16_t *up,
+                                       uint32_t *count, uint16_t *base) {
+  if (m < 2) { trivial_lengths(order, m, n, len, count, base); return; }
+  huffman_merge(freq, order, m, w, up);
+  for (int l = 0; l <= 16; l++) count[l] = 0;
+  int overflow = 0;
+  for (int k = 0; k < m; k++) {
+    uint32_t d = leaf_depth(up, k, m);
+    if (d > (uint32_t)maxbits) { d = (uint32_t)maxbits; overflow++; }
+    count[d]++;
+  }
+  limit_counts(count, maxbits, overflow, base);
+  for (int k = 0; k < m; k++) len[order[k]] = (uint8_t)length_of_rank(count, maxbits, k);
+}
+// the code of symbol s, bit-reversed; any thread
+ELP_DFL_HD uint16_t canonical_code(const uint8_t *len, int s, const uint16_t *base) {
+  const uint32_t l = len[s];
+  if (!l) return 0;
+  uint32_t r = 0;
+  for (int j = 0; j < s; j++) r += len[j] == l ? 1u : 0u;
+  return (uint16_t)bit_reverse(base[l] + r, l);
+}
+// the header: HLIT, HDIST, the run-length coded code lengths, their code; D.header_bits = everything in front of the first token
+// (3 block-header bits included).  One thread.
+ELP_DFL_HD void build_header(DynCodes &D) {
+  const uint8_t order19[NCL] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+  int nll = NLL, nd = NDIST;
+  while (nll > 257 && D.len[nll - 1] == 0) nll--;
+  while (nd > 1 && D.len[DOFF + nd - 1] == 0) nd--;
+  D.hlit = (uint32_t)nll - 257u;
+  D.hdist = (uint32_t)nd - 1u;
+  // the nll + nd lengths as one sequence, run-length coded (RFC 1951 3.2.7: 16 = repeat the previous 3..6 times, 17 = 3..10 zeros,
+  // 18 = 11..138 zeros)
+  uint32_t *cf = D.cl_freq;
+  for (int k = 0; k < NCL; k++) cf[k] = 0;
+  uint32_t nr = 0;
+  const int total = nll + nd;
+  int i = 0;
+  while (i < total) {
+    const uint32_t v = i < nll ? D.len[i] : D.len[DOFF + (i - nll)];
+    int run = 1;
+    while (i + run < total && (i + run < nll ? D.len[i + run] : D.len[DOFF + (i + run - nll)]) == v) run++;
+    int left = run;
+    if (v == 0) {
+      while (left >= 11) { const int r = left > 138 ? 138 : left; D.rle[nr++] = (uint16_t)(18u | ((uint32_t)(r - 11) << 8)); cf[18]++; left -= r; }
+      if (left >= 3) { D.rle[nr++] = (uint16_t)(17u | ((uint32_t)(left - 3) << 8)); cf[17]++; left = 0; }
+      while (left > 0) { D.rle[nr++] = 0; cf[0]++; left--; }
+    } else {
+      D.rle[nr++] = (uint16_t)v; cf[v]++; left--;
+      while (left >= 3) { const int r = left > 6 ? 6 : left; D.rle[nr++] = (uint16_t)(16u | ((uint32_t)(r - 3) << 8)); cf[16]++; left -= r; }
+      while (left > 0) { D.rle[nr++] = (uint16_t)v; cf[v]++; left--; }
+    }
+    i += run;
+  }
+  D.n_rle = nr;
+  // the code of the code lengths: 19 symbols, at most 7 bits (sorted here: the alphabet is tiny)
+  uint16_t *ord = D.cl_ord;
+  int m = 0;
+  for (int s = 0; s < NCL; s++) if (cf[s]) ord[m++] = (uint16_t)s;
+  for (int a = 1; a < m; a++) {
+    const uint16_t v = ord[a];
+    int b = a;
+    for (; b > 0 && (cf[ord[b - 1]] > cf[v] || (cf[ord[b - 1]] == cf[v] && ord[b - 1] > v)); b--) ord[b] = ord[b - 1];
+    ord[b] = v;
+  }
+  for (int s = 0; s < NCL; s++) D.cl_len[s] = 0;
+  huffman_lengths_serial(cf, ord, m, NCL, 7, D.cl_len, D.cl_w, D.cl_up, D.cl_cnt, D.cl_base);
+  for (int s = 0; s < NCL; s++) D.cl_code[s] = canonical_code(D.cl_len, s, D.cl_base);
+  int ncl = NCL;
+  while (ncl > 4 && D.cl_len[order19[ncl - 1]] == 0) ncl--;
+  D.hclen = (uint32_t)ncl - 4u;
+  uint32_t bits = 3u + 5u + 5u + 4u + 3u * (uint32_t)ncl;
+  for (uint32_t k = 0; k < nr; k++) {
+    const uint32_t sym = D.rle[k] & 0xFFu;
+    bits += D.cl_len[sym] + (sym == 16u ? 2u : sym == 17u ? 3u : sym == 18u ? 7u : 0u);
+  }
+  D.header_bits = bits;
+}
+template <class OrW>
+ELP_DFL_HD void emit_dyn_header(BitWriter<OrW> &bw, const DynCodes &D) {
+  const uint8_t order19[NCL] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+  bw.put(5u, 3u);  // BFINAL = 1, BTYPE = 10
+  bw.put(D.hlit, 5u);
+  bw.put(D.hdist, 5u);
+  bw.put(D.hclen, 4u);
+  for (uint32_t k = 0; k < D.hclen + 4u; k++) bw.put(D.cl_len[order19[k]], 3u);
+  for (uint32_t k = 0; k < D.n_rle; k++) {
+    const uint32_t sym = D.rle[k] & 0xFFu, ev = D.rle[k] >> 8;
+    bw.put(D.cl_code[sym], D.cl_len[sym]);
+    if (sym == 16u) bw.put(ev, 2u);
+    else if (sym == 17u) bw.put(ev, 3u);
+    else if (sym == 18u) bw.put(ev, 7u);
+  }
+}
+ELP_DFL_HD uint32_t token_bits_dyn(uint32_t tok, const DynCodes &D) {
+  uint32_t ds, xb;
+  const uint32_t sym = token_symbols(tok, ds, xb);
+  return D.len[sym] + xb + (ds != 0xFFFFu ? D.len[DOFF + ds] : 0u);
+}
+template <class OrW>
+ELP_DFL_HD void emit_token_dyn(BitWriter<OrW> &bw, uint32_t tok, const DynCodes &D) {
+  if (!(tok & 0x80000000u)) { bw.put(D.code[tok], D.len[tok]); return; }
+  uint32_t eb, ev, deb, dev;
+  const uint32_t sym = len_symbol(((tok >> 16) & 0xFFu) + 3u, eb, ev);
+  bw.put(D.code[sym], D.len[sym]);
+  if (eb) bw.put(ev, eb);
+  const uint32_t ds = dist_symbol((tok & 0x7FFFu) + 1u, deb, dev);
+  bw.put(D.code[DOFF + ds], D.len[DOFF + ds]);
+  if (deb) bw.put(dev, deb);
+}
+// size in bytes of a dynamic block: header, tokens, the end-of-block code
+ELP_DFL_HD uint32_t deflate_bytes_dyn(const DynCodes &D, unsigned long long token_bits_total) {
+  return (uint32_t)((D.header_bits + token_bits_total + D.len[256] + 7ull) >> 3);
 }
 
 // size in bytes of the block's DEFLATE data given the parts' bits: 3 header bits + the tokens + the 7-bit end-of-block code

@@ -41,6 +41,7 @@ int elp_rollback(elp_ctx *ctx);
  *   "bgzf_piece"       inflated bytes per record-scan pass of elp_stage_bgzf (default 1 GiB)
  *   "bgzf_inflate_piece"  inflated bytes whose blocks one launch of the decoder takes (default 2 GiB; the scan passes of
  *                      "bgzf_piece" bytes run inside it; token scratch: 171 KB per 64 KB block)
+ *   "bgzf_fixed"       1: elp_emit_sorted_bgzf writes fixed Huffman codes only (round 5) instead of the blocks' own codes
  *   "bgzf_copy_chunk"  blocks per H2D chunk and decoder launch of elp_stage_bgzf (0: the blocks that fill the chip once);
  *   "bgzf_first_chunk_div"  the first chunk is 1/div of that (default 4: the decoder starts early)
  *   "bgzf_tok_lds"     (experiments) unused LDS bytes per decoder wave: fewer waves per CU

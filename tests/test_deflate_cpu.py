@@ -28,9 +28,9 @@ def lib():
 def _deflate(L, data: bytes, order: int):
     a = np.frombuffer(data, dtype=np.uint8) if data else np.zeros(1, np.uint8)
     out = np.zeros(len(data) + 64, np.uint8)
-    stored, ntok = C.c_int(), C.c_uint32()
-    n = L.dfl_emulate_block(a.ctypes.data, len(data), out.ctypes.data, order, C.byref(stored), C.byref(ntok))
-    return out[:n].tobytes(), bool(stored.value), int(ntok.value)
+    kind, ntok = C.c_int(), C.c_uint32()
+    n = L.dfl_emulate_block(a.ctypes.data, len(data), out.ctypes.data, order, C.byref(kind), C.byref(ntok))
+    return out[:n].tobytes(), int(kind.value), int(ntok.value)  # kind: 0 fixed codes, 1 stored, 2 dynamic codes
 
 
 def _inflate(cdata: bytes) -> bytes:
@@ -61,18 +61,50 @@ def _cases():
     yield "far matches", (rng.integers(0, 256, 20000, dtype=np.uint8).tobytes() * 4)[:65280]
 
 
-@pytest.mark.parametrize("order", [0, 1])
+@pytest.mark.parametrize("order", [0, 1, 16, 17])  # (+ 16: fixed codes only - round 5's form, what a block falls back to)
 def test_every_block_inflates_to_its_payload(lib, order):
     ratios = {}
     for name, data in _cases():
-        cdata, stored, ntok = _deflate(lib, data, order)
+        cdata, kind, ntok = _deflate(lib, data, order)
         assert _inflate(cdata) == data, name
         assert len(cdata) <= len(data) + 5, name
-        ratios[name] = (round(len(cdata) / max(len(data), 1), 3), stored, ntok)
-    assert ratios["random"][1] and not ratios["bam block"][1]
+        ratios[name] = (round(len(cdata) / max(len(data), 1), 3), kind, ntok)
+    assert ratios["random"][1] == 1 and ratios["bam block"][1] == (2 if order < 16 else 0)
     assert ratios["zeros"][0] < 0.05
     # the synthetic BAM records: zlib's own fixed-Huffman level-1 encoder reaches 0.55 on them; the strip-parallel match finder reaches the same
     assert ratios["bam block"][0] < 0.58, ratios
+    if order < 16:  # dynamic codes (round 6): zlib level 1 - dynamic codes over its own parse - reaches 0.448 on these records
+        assert ratios["bam block"][0] < 0.45, ratios
+        z = zlib.compressobj(1, zlib.DEFLATED, -15)
+        data = dict(_cases())["bam block"]
+        assert len(cdata) >= 0 and ratios["bam block"][0] * len(data) < len(z.compress(data) + z.flush())
+
+
+def test_dynamic_codes_at_the_edges(lib):
+    """alphabets of one and two symbols, no distance code at all, a count distribution that wants codes longer than 15 bits (Fibonacci
+    counts: the length limit's repair), long runs of unused symbols (run-length symbols 17 and 18 of the header) - every block inflates"""
+    rng = np.random.default_rng(5)
+    fib = [1, 1]
+    while sum(fib) < 40000:
+        fib.append(fib[-1] + fib[-2])
+    skew = b"".join(bytes([7 * k % 256]) * f for k, f in enumerate(fib))
+    skew = bytes(rng.permutation(np.frombuffer(skew, dtype=np.uint8)))[:65280]
+    cases = {
+        "one literal": b"a",
+        "two literals": b"ab",
+        "literals only": bytes(rng.permutation(np.arange(200, dtype=np.uint8))) * 3,
+        "one symbol many times": b"x" * 3 + b"y",
+        "skewed counts": skew,
+        "two values": bytes(rng.integers(0, 2, 65280, dtype=np.uint8) * 255),
+        "sparse alphabet": bytes(rng.choice(np.array([0, 1, 2, 127, 128, 254, 255], dtype=np.uint8), 30000)),
+    }
+    kinds = {}
+    for name, data in cases.items():
+        for order in (0, 1):
+            cdata, kind, _ = _deflate(lib, data, order)
+            assert _inflate(cdata) == data, (name, order)
+            kinds[name] = kind
+    assert kinds["skewed counts"] == 2 and kinds["two values"] == 2 and kinds["sparse alphabet"] == 2, kinds
 
 
 def test_symbol_tables_against_the_rfc(lib):

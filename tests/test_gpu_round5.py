@@ -425,10 +425,14 @@ def test_emit_sorted_bgzf_compresses_on_the_device(n_pairs):
     e.sort_coordinate()
     want = e.emit_sorted_bam().tobytes()
     bz = e.emit_sorted_bgzf().tobytes()
+    e.set_tuning("bgzf_fixed", 1)
+    bz1 = e.emit_sorted_bgzf().tobytes()  # fixed Huffman codes only (round 5's form)
+    e.set_tuning("bgzf_fixed", 0)
     e.set_tuning("bgzf_stored", 1)
     bz0 = e.emit_sorted_bgzf().tobytes()
     e.close()
-    for blob in (bz, bz0):
+    assert len(bz) < 0.93 * len(bz1), (len(bz), len(bz1))  # the blocks' own codes (round 6) against the fixed ones
+    for blob in (bz, bz1, bz0):
         mem = _members(blob)
         assert b"".join(m for _, m in mem) == want
         assert all(size <= 65536 and 0 < len(m) <= 65280 for size, m in mem)
