@@ -212,3 +212,115 @@ def test_sort_metrics_and_the_bqsr_chain_at_once(name, pairs, seed, pfrag, n_lan
             assert np.array_equal(qt, oq) and np.array_equal(ct, oc) and np.array_equal(xt, ox), ("tables", rnd)
             assert np.array_equal(qual, oqual), ("qualities", rnd)
     e.close()
+
+
+# ---- the BGZF decoder in two phases (bgzf.hip, round 6): whatever zlib can write, byte for byte
+def _records_with_payload_tags(raw, rec_off, seed):
+    """every record of the stream gets an XB:B:C tag of bytes that DEFLATE treats differently: noise (long codes, stored blocks), runs
+    (matches that overlap themselves), text, copies of data far back (distances up to 32 KB), nothing.  Returns the new stream + offsets."""
+    import struct
+    rng = np.random.default_rng(seed)
+    src = raw.tobytes()
+    far = rng.integers(0, 256, 40000, dtype=np.uint8).tobytes()
+    out, offs = [], [0]
+    total = 0
+    for k in range(len(rec_off) - 1):
+        rec = src[int(rec_off[k]):int(rec_off[k + 1])]
+        kind = int(rng.integers(0, 8))
+        n = int(rng.integers(1, 700))
+        if kind == 0:
+            pay = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        elif kind == 1:
+            pay = bytes([int(rng.integers(0, 256))]) * n
+        elif kind == 2:
+            pay = (b"ACGTTGCA" * 90)[:n]
+        elif kind == 3:
+            at = int(rng.integers(0, len(far) - n))
+            pay = far[at:at + n]
+        elif kind == 4:
+            pay = bytes(rng.choice(np.array([33, 35, 70, 70, 70, 58], dtype=np.uint8), n))
+        elif kind == 5:
+            pay = (bytes(rng.integers(0, 256, 3, dtype=np.uint8)) * 300)[:n]
+        else:
+            pay = b""
+        tag = b"XBBC" + struct.pack("<I", len(pay)) + pay if kind != 7 else b""
+        size = struct.unpack_from("<I", rec, 0)[0] + len(tag)
+        new = struct.pack("<I", size) + rec[4:] + tag
+        out.append(new)
+        total += len(new)
+        offs.append(total)
+    return np.frombuffer(b"".join(out), dtype=np.uint8), np.asarray(offs, dtype=np.uint64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_stage_bgzf_inflates_whatever_zlib_wrote(seed):
+    """random compression parameters per member (level 0-9, every strategy, memLevel 1-9, window 512 B-32 KB, member sizes 1 B-65280 B)
+    over records with payload tags of every kind: the staged records give the sorted BAM bytes of elp_stage_bam on the inflated stream"""
+    import struct
+    import zlib
+    from elprep_amd.engine import Engine
+    from tests.test_gpu_round4 import _bam_case
+    b, h, raw0, rec_off0 = _bam_case(2500, seed=30 + seed)
+    raw, rec_off = _records_with_payload_tags(raw0, rec_off0, seed)
+    stream = raw.tobytes()
+    rng = np.random.default_rng(100 + seed)
+    members, k = [], 0
+    while k < len(stream):
+        cut = int(rng.choice([1, 17, 300, 4099, 30011, 65280, 65280, 65280]))
+        part = stream[k:k + cut]
+        k += len(part)
+        co = zlib.compressobj(int(rng.integers(0, 10)), zlib.DEFLATED, -int(rng.integers(9, 16)), int(rng.integers(1, 10)), int(rng.integers(0, 5)))
+        data = co.compress(part) + co.flush()
+        members.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(data) + 25) + data +
+                       struct.pack("<II", zlib.crc32(part), len(part)))
+        if rng.random() < 0.05:
+            members.append(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))  # an empty member in mid-stream
+    bz = np.frombuffer(b"".join(members), dtype=np.uint8)
+    outs = []
+    for how in ("bam", "bgzf", "bgzf small pieces"):
+        e = Engine(h, tuning={"bgzf_inflate_piece": 300_000, "bgzf_piece": 90_000, "bgzf_copy_chunk": 3} if how.endswith("pieces") else None)
+        e.set_read_group_ids(h.rg_ids)
+        if how == "bam":
+            e.stage_bam(raw, rec_off=rec_off)
+        else:
+            e.stage_bgzf(bz)
+        assert e.n == b.n
+        e.mark_duplicates(True)
+        e.sort_coordinate()
+        outs.append(e.emit_sorted_bam().tobytes())
+        e.close()
+    assert outs[0] == outs[1] and outs[0] == outs[2]
+
+
+@pytest.mark.gpu
+def test_stage_bgzf_survives_damaged_blocks():
+    """bytes of the compressed data overwritten at random places: every call comes back with an error (a block that does not inflate, a
+    CRC that does not match, records that do not chain) - or, where the damage fell on bits nothing reads, with the records; it never
+    hangs and the context stays usable"""
+    import zlib
+    from elprep_amd.engine import ElpError, Engine
+    from tests.test_gpu_round4 import _bam_case, _bgzf
+    b, h, raw, rec_off = _bam_case(1500, seed=9)
+    good = _bgzf(raw.tobytes(), 6)
+    rng = np.random.default_rng(11)
+    e = Engine(h)
+    e.set_read_group_ids(h.rg_ids)
+    errors = 0
+    for trial in range(40):
+        bad = bytearray(good)
+        for _ in range(int(rng.integers(1, 4))):
+            at = int(rng.integers(18, len(bad) - 28))
+            bad[at] = int(rng.integers(0, 256))
+        e.reset()
+        try:
+            e.stage_bgzf(np.frombuffer(bytes(bad), dtype=np.uint8))
+        except ElpError:
+            errors += 1
+            continue
+        assert e.n == b.n  # (the damage changed nothing that matters - e.g. the byte was rewritten with its own value)
+    assert errors >= 30, errors
+    e.reset()
+    e.stage_bgzf(np.frombuffer(good, dtype=np.uint8))
+    assert e.n == b.n
+    e.close()
