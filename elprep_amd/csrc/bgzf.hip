@@ -119,16 +119,13 @@ constexpr uint32_t DFL_LD = dfl::PAYLOAD + 256;  // words of match notes / token
 __global__ __launch_bounds__(256) void k_bgzf_deflate(const uint8_t *__restrict__ raw, uint64_t n_bytes, uint32_t nblk, uint8_t *__restrict__ slots,
                                                       uint32_t *__restrict__ sizes, uint32_t *__restrict__ ld_all, CrcPow pw, int fixed_only) {
   using namespace dfl;
-  __shared__ uint32_t tbl[256];
   __shared__ uint32_t s_crc, s_wsum[4];
   __shared__ __attribute__((aligned(16))) uint16_t table[(size_t)WAYS << HBITS];
   __shared__ __attribute__((aligned(16))) uint8_t buf[PAYLOAD + IN_PAD];  // the block's payload; behind the parse: its DEFLATE data
+  // (81.7 KB: two workgroups per CU.  The CRC's byte table lives in the hash table's place: the CRC is taken before the table is cleared)
+  static_assert(sizeof(table) + sizeof(buf) + 64 <= 81920, "two workgroups per CU");
+  uint32_t *tbl = reinterpret_cast<uint32_t *>(table);
   const uint32_t t = threadIdx.x;
-  {
-    uint32_t c = t;
-    for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ BGZF_POLY : c >> 1;
-    tbl[t] = c;
-  }
   uint32_t *ld = ld_all + (size_t)blockIdx.x * DFL_LD;
   uint32_t *words = reinterpret_cast<uint32_t *>(buf);
   for (uint32_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
@@ -145,7 +142,11 @@ __global__ __launch_bounds__(256) void k_bgzf_deflate(const uint8_t *__restrict_
       }
       *reinterpret_cast<uint4 *>(buf + k) = v;
     }
-    for (uint32_t k = t; k < ((uint32_t)WAYS << HBITS); k += 256u) table[k] = NOPOS;
+    {
+      uint32_t c = t;
+      for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ BGZF_POLY : c >> 1;
+      tbl[t] = c;
+    }
     if (t == 0) s_crc = 0;
     __syncthreads();
     // ---- CRC-32 of the thread's part [lo, hi), then its place in the block's polynomial (as k_bgzf_frame)
@@ -156,6 +157,9 @@ __global__ __launch_bounds__(256) void k_bgzf_deflate(const uint8_t *__restrict_
       c ^= 0xFFFFFFFFu;
       atomicXor(&s_crc, crc_mulmod(crc_x8n(pw, len - hi), c));
     }
+    __syncthreads();
+    for (uint32_t k = t; k < ((uint32_t)WAYS << HBITS); k += 256u) table[k] = NOPOS;
+    __syncthreads();
     // ---- 1. match finding, a strip of 256 positions at a time: look-ups against everything in front of the strip, then its inserts
     for (uint32_t base = 0; base < len; base += 256u) {
       const uint32_t i = base + t;
@@ -326,7 +330,7 @@ int bgzf_deflate(elp_ctx *c, const uint8_t *raw, uint64_t n_bytes, uint8_t *out,
   static const CrcPow pw = crc_pow_table();
   const uint64_t nblk = (n_bytes + BGZF_PAYLOAD - 1) / BGZF_PAYLOAD;
   if (nblk >= 0x7FFFFFFFull) return set_error(c, ELP_ERR_UNSUPPORTED, "bgzf_deflate: too many blocks in one pass");
-  const unsigned grid = (unsigned)std::min<uint64_t>(nblk, (uint64_t)c->n_cu);  // one workgroup per CU (100 KB of LDS each), looping over the blocks
+  const unsigned grid = (unsigned)std::min<uint64_t>(nblk, 2ull * (uint64_t)c->n_cu);  // two workgroups per CU (82 KB of LDS each), looping over the blocks
   uint32_t *wk;
   ELP_TRY(scratch(c, 0, (size_t)grid * DFL_LD + 2 * (nblk + 8) + 16, &wk));
   uint32_t *ld_all = wk, *sizes = wk + (size_t)grid * DFL_LD, *offs = sizes + nblk + 8;
