@@ -219,8 +219,11 @@ __device__ __forceinline__ uint64_t qname_hash(const MdCols &m, uint32_t i) {
   for (uint32_t k = 0; k < l; k += 8) h = (h ^ low_bytes(load8(m.qname + o + k), l - k)) * 0xff51afd7ed558ccdull + (h >> 29);
   return mix64(h ^ ((uint64_t)lib_of(m, i) << 48) ^ ((uint64_t)m.split[i] << 24));
 }
-__device__ __forceinline__ bool mate_key_eq(const MdCols &m, uint32_t a, uint32_t b) {
-  return lib_of(m, a) == lib_of(m, b) && m.split[a] == m.split[b] && qname_eq(m.qname, m.qname_off, a, b);
+// {split, library, QNAME} of records a and b.  Library and split come from the records' packed fragment keys (round 6: ONE 16-byte load
+// per record instead of READ GROUP -> library and split: two dependent loads and a third)
+__device__ __forceinline__ bool mate_key_eq(const MdCols &m, const uint4 *__restrict__ fkey, uint32_t a, const uint4 &kb, uint32_t b) {
+  const uint4 ka = fkey[a];
+  return (ka.z >> 1) == (kb.z >> 1) && ka.w == kb.w && qname_eq(m.qname, m.qname_off, a, b);
 }
 __device__ __forceinline__ bool is_mate_candidate(uint16_t f) { return is_candidate(f) && is_true_pair(f); }
 
@@ -242,7 +245,7 @@ constexpr uint32_t MATE_BIG = 0xFFFFFFFEu;
 // names - and the tests follow without further loads (names longer than 32 bytes finish in a loop).  Threads 256..258 of the
 // 320-thread workgroup make the three neighbour tests across the block's borders the same way.
 constexpr int MS_THREADS = 320;
-__global__ __launch_bounds__(MS_THREADS) void k_mate_scan(MdCols m, uint8_t *__restrict__ code, uint32_t *__restrict__ hash32, uint32_t *bloom,
+__global__ __launch_bounds__(MS_THREADS) void k_mate_scan(MdCols m, uint8_t *__restrict__ code, uint32_t *__restrict__ hash32, uint32_t *__restrict__ hash_lo, uint32_t *bloom,
                                                           uint32_t bloom_mask, uint32_t *n_table /* records that announce their key (sizes the table) */) {
   const uint64_t base = (uint64_t)blockIdx.x * 256;
   const uint32_t t = threadIdx.x;
@@ -305,6 +308,7 @@ __global__ __launch_bounds__(MS_THREADS) void k_mate_scan(MdCols m, uint8_t *__r
       h = mix64(h ^ ((uint64_t)lia << 48) ^ ((uint64_t)sa << 24));
       const uint32_t hi = (uint32_t)(h >> 32);
       hash32[i] = hi;  // (a follower's key is its leader's: hash32[i - 1])
+      if (cd == MC_TABLE) hash_lo[i] = (uint32_t)h;  // (the table's index bits: a neighbour pair that goes there after all computes them again)
       if (cd != MC_LEAD) atomicOr(&bloom[(hi >> 5) & bloom_mask], 1u << (hi & 31u));
     }
   }
@@ -336,8 +340,12 @@ __global__ __launch_bounds__(256) void k_bloom_coarse(const uint32_t *__restrict
 
 // path (2) / (3) of the mate matching for record i: the first record of a key at its table slot becomes the representative, the second
 // claims it with one CAS on mate[representative], a third marks the group BIG
-__device__ __forceinline__ void mate_table_insert(const MdCols &m, uint32_t i, uint32_t *table, uint64_t mask, uint32_t *mate, uint32_t *rep_of, uint32_t *err) {
-  const uint32_t rep = find_or_insert(table, mask, qname_hash(m, i), i, [&](uint32_t a, uint32_t b) { return mate_key_eq(m, a, b); }, mask);
+// h = the record's key hash as k_md_front / k_mate_scan stored it (round 6: it was computed again here - the record's name, its offsets,
+// read group and split, five random sectors per record of input whose mates are not neighbours)
+__device__ __forceinline__ void mate_table_insert(const MdCols &m, const uint4 *__restrict__ fkey, uint32_t i, uint64_t h, uint32_t *table, uint64_t mask, uint32_t *mate,
+                                                  uint32_t *rep_of, uint32_t *err) {
+  const uint4 mine = fkey[i];
+  const uint32_t rep = find_or_insert(table, mask, h, i, [&](uint32_t a, uint32_t b) { return mate_key_eq(m, fkey, a, mine, b); }, mask);
   if (rep == EMPTY) atomicOr(&err[1], 2u);  // the estimated table is full: the host repeats the pass with the full-size one
   else if (rep != i) {                      // (the first of its key at the slot waits for the second)
     rep_of[i] = rep;
@@ -351,8 +359,9 @@ __device__ __forceinline__ void mate_table_insert(const MdCols &m, uint32_t i, u
 }
 // the table inserts k_mate_pairs listed (64 lists of `cap` entries, their lengths 16 words apart), every lane busy: thread g takes entry
 // g of the lists laid end to end (a prefix sum of the 64 lengths per workgroup)
-__global__ __launch_bounds__(256) void k_mate_table(MdCols m, const uint32_t *__restrict__ tab_list, const uint32_t *__restrict__ tab_cnt, uint32_t cap, uint32_t *table,
-                                                    uint64_t mask, uint32_t *mate, uint32_t *rep_of, uint32_t *err) {
+__global__ __launch_bounds__(256) void k_mate_table(MdCols m, const uint4 *__restrict__ fkey, const uint8_t *__restrict__ code, const uint32_t *__restrict__ hash32,
+                                                    const uint32_t *__restrict__ hash_lo, const uint32_t *__restrict__ tab_list, const uint32_t *__restrict__ tab_cnt,
+                                                    uint32_t cap, uint32_t *table, uint64_t mask, uint32_t *mate, uint32_t *rep_of, uint32_t *err) {
   __shared__ uint32_t first[65];
   if (threadIdx.x < 64) {
     const uint32_t c = tab_cnt[threadIdx.x * 16u];
@@ -372,7 +381,9 @@ __global__ __launch_bounds__(256) void k_mate_table(MdCols m, const uint32_t *__
       const uint32_t mid = (lo + hi) >> 1;
       if (first[mid] <= g) lo = mid; else hi = mid;
     }
-    mate_table_insert(m, tab_list[(size_t)lo * cap + (g - first[lo])], table, mask, mate, rep_of, err);
+    const uint32_t i = tab_list[(size_t)lo * cap + (g - first[lo])];
+    const uint64_t h = (code[i] & MC_KIND) == MC_TABLE ? ((uint64_t)hash32[i] << 32) | hash_lo[i] : qname_hash(m, i);  // (stored for the records that were table-bound from the start)
+    mate_table_insert(m, fkey, i, h, table, mask, mate, rep_of, err);
   }
 }
 
@@ -398,8 +409,8 @@ __global__ __launch_bounds__(256) void k_mate_table(MdCols m, const uint32_t *__
 // lane in sixteen whose look-up reaches the table (the one-record-per-thread form ran at the latency of that chain, not at bandwidth).
 constexpr int MP_R = 1;
 __global__ __launch_bounds__(256) void k_mate_pairs(MdCols m, const uint4 *__restrict__ fkey, uint8_t *__restrict__ code,
-                                                    const uint32_t *__restrict__ hash32, const uint32_t *__restrict__ bloom, uint32_t bloom_mask,
-                                                    const uint32_t *__restrict__ coarse /* null: nobody announced a key */,
+                                                    const uint32_t *__restrict__ hash32, const uint32_t *__restrict__ hash_lo, const uint32_t *__restrict__ bloom,
+                                                    uint32_t bloom_mask, const uint32_t *__restrict__ coarse /* null: nobody announced a key */,
                                                     uint32_t *table, uint64_t mask, uint32_t *mate, uint32_t *rep_of, uint32_t *err,
                                                     const uint32_t *__restrict__ ftable, const uint32_t *__restrict__ fbits, uint64_t fmask /* 0: no fragments */,
                                                     unsigned long long *fbest, int fixed /* 2: every candidate is matched by the partitioned pass
@@ -409,7 +420,7 @@ __global__ __launch_bounds__(256) void k_mate_pairs(MdCols m, const uint4 *__res
   const uint64_t base = (uint64_t)blockIdx.x * (256 * MP_R) + threadIdx.x;
   uint8_t cd[MP_R];
   uint4 mine[MP_R], prev[MP_R], kc[MP_R];
-  uint32_t hi[MP_R], bl[MP_R], fw[MP_R], cur[MP_R];
+  uint32_t hi[MP_R], hl[MP_R], bl[MP_R], fw[MP_R], cur[MP_R];
   int32_t sc[MP_R];
   uint64_t fs[MP_R];
   bool hit[MP_R];
@@ -422,6 +433,7 @@ __global__ __launch_bounds__(256) void k_mate_pairs(MdCols m, const uint4 *__res
     mine[r] = in ? fkey[i] : make_uint4(0, 0, 0, 0);
     const uint32_t h0 = in ? hash32[i] : 0u, h1 = (in && i > 0) ? hash32[i - 1] : 0u;  // (only a leader's entry is defined; the unused one is dropped)
     hi[r] = cd[r] == MC_LEAD ? h0 : h1;
+    hl[r] = (in && cd[r] == MC_TABLE) ? hash_lo[i] : 0u;
   }
   // level 1
 #pragma unroll
@@ -485,7 +497,7 @@ __global__ __launch_bounds__(256) void k_mate_pairs(MdCols m, const uint4 *__res
       } else {
         code[i] = (uint8_t)(cd[r] | MC_TABBED);
         if (tab_list) want_tab = true;  // (deferred: k_mate_table)
-        else mate_table_insert(m, (uint32_t)i, table, mask, mate, rep_of, err);
+        else mate_table_insert(m, fkey, (uint32_t)i, cd[r] == MC_TABLE ? ((uint64_t)hash32[i] << 32) | hl[r] : qname_hash(m, (uint32_t)i), table, mask, mate, rep_of, err);
       }
     }
     // Round 5: in aligner order the few records that need the table (the sr-tagged copies of an sfm context: 2 % of the records, one or two
@@ -557,8 +569,8 @@ __global__ __launch_bounds__(256) void k_mate_list(uint64_t n, const uint8_t *__
   }
 }
 constexpr int MB_TARGET = 640, MB_CAP = 2048;
-__global__ __launch_bounds__(256) void k_mate_bucket(MdCols m, const uint64_t *__restrict__ ks, const uint32_t *__restrict__ vs, const uint32_t *__restrict__ bstart,
-                                                     const uint32_t *__restrict__ bend, uint32_t *mate, uint32_t *rep_of, uint32_t *err) {
+__global__ __launch_bounds__(256) void k_mate_bucket(MdCols m, const uint4 *__restrict__ fkey, const uint64_t *__restrict__ ks, const uint32_t *__restrict__ vs,
+                                                     const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ bend, uint32_t *mate, uint32_t *rep_of, uint32_t *err) {
   __shared__ unsigned long long s_key[MB_CAP];  // hash bits << 32 | representative (the first record of its key to arrive at the slot)
   __shared__ uint32_t s_mate[MB_CAP];           // the second one
   const uint32_t start = bstart[blockIdx.x], cnt = bend[blockIdx.x] - start;
@@ -577,7 +589,7 @@ __global__ __launch_bounds__(256) void k_mate_bucket(MdCols m, const uint64_t *_
     for (uint32_t probes = 0; probes <= tmask; probes++, idx = (idx + 1) & tmask) {
       const unsigned long long cur = atomicCAS(&s_key[idx], PB_EMPTY, mine);
       if (cur == PB_EMPTY) { rep = i; slot = idx; break; }
-      if ((uint32_t)(cur >> 32) == h32 && mate_key_eq(m, (uint32_t)cur, i)) { rep = (uint32_t)cur; slot = idx; break; }
+      if ((uint32_t)(cur >> 32) == h32 && mate_key_eq(m, fkey, (uint32_t)cur, fkey[i], i)) { rep = (uint32_t)cur; slot = idx; break; }
     }
     if (rep == EMPTY) { atomicOr(&err[1], 4u); continue; }  // the table is full (keys crafted to share hash bits): the host takes the table in HBM
     if (rep == i) continue;  // first of its key at the slot: waits for the second
@@ -1016,8 +1028,8 @@ __global__ __launch_bounds__(256) void k_frag_list(FrontCols m, uint4 *__restric
 constexpr int MF_THREADS = 320, MF_RECS = 312;
 template <bool ADAPT>
 __global__ __launch_bounds__(MF_THREADS) void k_md_front(FrontCols m, const int32_t *__restrict__ score, int32_t *__restrict__ upos_out, uint64_t *__restrict__ key_out,
-                                                         uint4 *fkey, uint8_t *__restrict__ code, uint32_t *__restrict__ hash32, uint32_t *bloom, uint32_t bloom_mask,
-                                                         uint32_t *n_table, const uint32_t *__restrict__ ftable, const uint32_t *__restrict__ fbits,
+                                                         uint4 *fkey, uint8_t *__restrict__ code, uint32_t *__restrict__ hash32, uint32_t *__restrict__ hash_lo, uint32_t *bloom,
+                                                         uint32_t bloom_mask, uint32_t *n_table, const uint32_t *__restrict__ ftable, const uint32_t *__restrict__ fbits,
                                                          uint64_t fmask /* 0: no fragments */, unsigned long long *fbest, uint32_t *__restrict__ mate,
                                                          uint32_t *__restrict__ pair_win, uint64_t *__restrict__ pk, uint32_t *__restrict__ pv, uint32_t *np,
                                                          uint32_t nfixed, int optimistic) {
@@ -1098,6 +1110,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_md_front(FrontCols m, const int3
       h = mix64(h ^ ((uint64_t)lia << 48) ^ ((uint64_t)sa << 24));
       const uint32_t hi = (uint32_t)(h >> 32);
       hash32[i] = hi;
+      if (cd == MC_TABLE) hash_lo[i] = (uint32_t)h;  // (as k_mate_scan)
       if (cd != MC_LEAD) atomicOr(&bloom[(hi >> 5) & bloom_mask], 1u << (hi & 31u));
     }
   }
@@ -1205,11 +1218,12 @@ static int markdup_impl(elp_ctx *c) {
   uint32_t *bloom, *hash32;
   uint8_t *code;
   const uint32_t tab_cap = (uint32_t)((blocks_for(n, 256 * MP_R) + 63) / 64) * 256u * MP_R;  // a list's share of the workgroups x their records
-  ELP_TRY(scratch(c, 6, bw + bw / 512 + 16 + n + 16 + (n + 16) / 4 + 64 * (size_t)tab_cap + 16, &bloom));
+  ELP_TRY(scratch(c, 6, bw + bw / 512 + 16 + n + 16 + (n + 16) / 4 + 64 * (size_t)tab_cap + 16 + n + 16, &bloom));
   uint32_t *coarse = bloom + bw;  // one bit per 16 words of the filter
   hash32 = coarse + bw / 512 + 16;
   code = reinterpret_cast<uint8_t *>(hash32 + n + 8);
   uint32_t *tab_list = hash32 + n + 16 + (n + 16) / 4;  // k_mate_pairs' deferred table inserts (aligner order): 64 lists
+  uint32_t *hash_lo = tab_list + 64 * (size_t)tab_cap + 8;  // the low half of the key hashes (hash32: the high half)
   uint32_t *rep_of = c->pair_win.p;  // free until the pair phase fills it
   uint32_t *n_table_dev = c->md_ctr.p + 16;  // 64 counters, 16 words apart
   ELP_HIP(c, hipMemsetAsync(bloom, 0, bw * sizeof(uint32_t), st));
@@ -1237,11 +1251,11 @@ static int markdup_impl(elp_ctx *c) {
     const int optimistic = c->tune.mate_path == 0;
     const uint32_t nfx = (uint32_t)((n + 1) / 2);
     if (fuse_adapt)
-      ELP_LAUNCH(c, "md_front", k_md_front<true>, dim3(blocks_for(n, MF_RECS)), dim3(MF_THREADS), 0, fc, (const int32_t *)c->score.p, c->upos.p, c->key.p, fkey, code, hash32, bloom,
+      ELP_LAUNCH(c, "md_front", k_md_front<true>, dim3(blocks_for(n, MF_RECS)), dim3(MF_THREADS), 0, fc, (const int32_t *)c->score.p, c->upos.p, c->key.p, fkey, code, hash32, hash_lo, bloom,
                  (uint32_t)(bw - 1), n_table_dev, (const uint32_t *)ftable, (const uint32_t *)fbits, nf ? Tf - 1 : (uint64_t)0, best, c->mate.p, c->pair_win.p, pk, pv,
                  np_dev, nfx, optimistic);
     else
-      ELP_LAUNCH(c, "md_front", k_md_front<false>, dim3(blocks_for(n, MF_RECS)), dim3(MF_THREADS), 0, fc, (const int32_t *)c->score.p, c->upos.p, c->key.p, fkey, code, hash32, bloom,
+      ELP_LAUNCH(c, "md_front", k_md_front<false>, dim3(blocks_for(n, MF_RECS)), dim3(MF_THREADS), 0, fc, (const int32_t *)c->score.p, c->upos.p, c->key.p, fkey, code, hash32, hash_lo, bloom,
                  (uint32_t)(bw - 1), n_table_dev, (const uint32_t *)ftable, (const uint32_t *)fbits, nf ? Tf - 1 : (uint64_t)0, best, c->mate.p, c->pair_win.p, pk, pv,
                  np_dev, nfx, optimistic);
     if (fuse_adapt) c->adapted = true;
@@ -1258,7 +1272,7 @@ static int markdup_impl(elp_ctx *c) {
   } else {
     ELP_HIP(c, hipMemsetAsync(c->mate.p, 0xFF, n * sizeof(uint32_t), st));
     ELP_HIP(c, hipMemsetAsync(rep_of, 0xFF, n * sizeof(uint32_t), st));
-    ELP_LAUNCH(c, "md_mate_scan", k_mate_scan, dim3(grid), dim3(MS_THREADS), 0, m, code, hash32, bloom, (uint32_t)(bw - 1), n_table_dev);
+    ELP_LAUNCH(c, "md_mate_scan", k_mate_scan, dim3(grid), dim3(MS_THREADS), 0, m, code, hash32, hash_lo, bloom, (uint32_t)(bw - 1), n_table_dev);
     ELP_HIP(c, hipMemcpyAsync(&nf, nf_dev, 4, hipMemcpyDeviceToHost, st));
   }
   // the table only has to hold the records that are not exactly-two-neighbours (few in aligner order) plus the neighbour pairs a
@@ -1315,12 +1329,14 @@ static int markdup_impl(elp_ctx *c) {
     listed = defer_tab;
     if (defer_tab) ELP_HIP(c, hipMemsetAsync(n_table_dev, 0, 64 * 16 * sizeof(uint32_t), st));
     ELP_LAUNCH(c, "md_mate_pairs", k_mate_pairs, dim3(blocks_for(n, 256 * MP_R)), dim3(256), 0, m, (const uint4 *)fkey, code,
-               (const uint32_t *)hash32, (const uint32_t *)bloom, (uint32_t)(bw - 1), (const uint32_t *)(n_tab ? coarse : nullptr), table, Tm - 1, c->mate.p, rep_of, c->err_flag.p,
+               (const uint32_t *)hash32, (const uint32_t *)hash_lo, (const uint32_t *)bloom, (uint32_t)(bw - 1), (const uint32_t *)(n_tab ? coarse : nullptr), table, Tm - 1, c->mate.p,
+               rep_of, c->err_flag.p,
                (const uint32_t *)ftable, (const uint32_t *)fbits, fmask_pairs, best, mate_mode == 1 ? 1 : (mate_mode == 2 ? 2 : 0), pk, pv,
                defer_tab ? tab_list : (uint32_t *)nullptr, n_table_dev, tab_cap);
     if (defer_tab)  // (the lists hold the records k_mate_scan counted plus the neighbour pairs a filter hit sent along: in practice a fraction as many again)
-      ELP_LAUNCH(c, "md_mate_table", k_mate_table, dim3(blocks_for(std::min<uint64_t>(n, 2ull * n_tab + 4096), 256)), dim3(256), 0, m, (const uint32_t *)tab_list,
-                 (const uint32_t *)n_table_dev, tab_cap, table, Tm - 1, c->mate.p, rep_of, c->err_flag.p);
+      ELP_LAUNCH(c, "md_mate_table", k_mate_table, dim3(blocks_for(std::min<uint64_t>(n, 2ull * n_tab + 4096), 256)), dim3(256), 0, m, (const uint4 *)fkey, (const uint8_t *)code,
+                 (const uint32_t *)hash32, (const uint32_t *)hash_lo, (const uint32_t *)tab_list, (const uint32_t *)n_table_dev, tab_cap, table, Tm - 1, c->mate.p, rep_of,
+                 c->err_flag.p);
     if (mate_mode == 2) {
       int mbits = 0;
       while (mbits < 24 && ((n + 1) >> mbits) > (uint64_t)MB_TARGET) mbits++;
@@ -1339,7 +1355,7 @@ static int markdup_impl(elp_ctx *c) {
       }
       ELP_LAUNCH(c, "md_mate_bounds", k_pair_bounds, dim3(blocks_for(n + 1, 256)), dim3(256), 0, (const uint64_t *)mks, (const uint32_t *)ne_dev, msbits, mbits, mbounds,
                  mbounds + mnb);
-      ELP_LAUNCH(c, "md_mate_bucket", k_mate_bucket, dim3((unsigned)mnb), dim3(256), 0, m, (const uint64_t *)mks, (const uint32_t *)mvs, (const uint32_t *)mbounds,
+      ELP_LAUNCH(c, "md_mate_bucket", k_mate_bucket, dim3((unsigned)mnb), dim3(256), 0, m, (const uint4 *)fkey, (const uint64_t *)mks, (const uint32_t *)mvs, (const uint32_t *)mbounds,
                  (const uint32_t *)(mbounds + mnb), c->mate.p, rep_of, c->err_flag.p);
       // (`table` may have been re-pointed by the scratch call above: take it again for a fall-back pass)
       ELP_TRY(scratch(c, 0, T, &table));
