@@ -697,7 +697,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
 // the bits the symbol there consumed: a handful of scalar steps per 64 bits), which also gives every true symbol its place in the output;
 // the lanes on the chain store their literal or their token.  ~5 symbols per round of ~120 instructions instead of one per ~150.
 // A symbol whose code is longer than the tables' bits is decoded on the walk (canonical decoding, rare).
-constexpr int TK_RING = 1024, TK_HALF = TK_RING / 2, TK_LB = 10, TK_DB = 8;
+constexpr int TK_RING = 1024, TK_HALF = TK_RING / 2, TK_LB = 9, TK_DB = 8;
 constexpr uint32_t TOK_STRIDE = 21888;  // tokens per block: >= 65536 / 3 + 1, a multiple of 64
 // table entry: code length (4 bits; 0: the code is longer than the table's bits) | kind << 4 | extra bits << 6 | base value << 10
 enum : uint32_t { TK_LIT = 0, TK_MATCH = 1, TK_EOB = 2, TK_BAD = 3 };
@@ -830,13 +830,30 @@ __device__ inline int tok_codes(TokInflater &s) {
     int vpos = -1, rc = 0;
     bool eob = false;
     for (;;) {
-      int inf = 0;
-      while (off < 64u) {
-        inf = __builtin_amdgcn_readlane(info, (int)off);
-        if (inf < 0) break;
-        if (lane == off) vpos = (int)outpos;
-        outpos += (uint32_t)inf >> 7;
-        off += (uint32_t)inf & 127u;
+      // the chain's fast steps, by hand (the compiler's loop: 9 scalar + 4 vector + 3 branch instructions a step, two of the branches
+      // taken; this one: 8 + 2 + 2, one taken - the kernel is bound by issued instructions, profiles/round6_bgzf_pmc.csv):
+      //   while (off < 64) { inf = readlane(info, off); if (inf < 0) break; vpos[lane off] = outpos; outpos += inf >> 7; off += inf & 127; }
+      if (off < 64u) {
+        int inf, tmp, m0_was;
+        asm volatile(
+            "s_mov_b32 %[m0w], m0\n\t"
+            "1:\n\t"
+            "v_readlane_b32 %[inf], %[info], %[off]\n\t"
+            "s_cmp_lt_i32 %[inf], 0\n\t"
+            "s_cbranch_scc1 2f\n\t"
+            "s_mov_b32 m0, %[off]\n\t"
+            "v_writelane_b32 %[vpos], %[outpos], m0\n\t"
+            "s_lshr_b32 %[tmp], %[inf], 7\n\t"
+            "s_add_u32 %[outpos], %[outpos], %[tmp]\n\t"
+            "s_and_b32 %[tmp], %[inf], 0x7f\n\t"
+            "s_add_u32 %[off], %[off], %[tmp]\n\t"
+            "s_cmp_lt_u32 %[off], 64\n\t"
+            "s_cbranch_scc1 1b\n\t"
+            "2:\n\t"
+            "s_mov_b32 m0, %[m0w]\n\t"
+            : [inf] "=&s"(inf), [tmp] "=&s"(tmp), [m0w] "=&s"(m0_was), [off] "+s"(off), [outpos] "+s"(outpos), [vpos] "+v"(vpos)
+            : [info] "v"(info)
+            : "scc");
       }
       if (off >= 64u) break;
       // end of block, a code longer than a table's bits, an invalid symbol: this one symbol step by step
