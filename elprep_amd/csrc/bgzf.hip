@@ -1026,15 +1026,17 @@ __global__ __launch_bounds__(RES_THREADS) void k_bgzf_resolve(const BgzfBlk *__r
     unsigned long long todo = 0;
     for (uint32_t k = 0, j = t; j < n; k++, j += RES_THREADS)
       if (parent[j] != (uint16_t)j) todo |= 1ull << k;
-    for (int round = 0; round < 17; round++) {
+    // (no barrier between the rounds: a pointer only ever moves towards the literal - a match copies from in front of it -, so a wave
+    // that reads another wave's half-finished pointers reads ancestors all the same and finishes its own bytes at its own pace)
+    while (todo) {
       for (unsigned long long m = todo; m; m &= m - 1ull) {
         const uint32_t k = (uint32_t)__builtin_ctzll(m), j = t + k * RES_THREADS;
         const uint16_t q = parent[j], r = parent[q];
         if (r != q) parent[j] = r;
         else todo &= ~(1ull << k);
       }
-      if (!__syncthreads_or(todo != 0ull)) break;
     }
+    __syncthreads();
     for (uint32_t j = t; j < n; j += RES_THREADS) {
       const uint16_t q = parent[j];
       if (q != (uint16_t)j) out[j] = out[q];
