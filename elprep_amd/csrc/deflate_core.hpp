@@ -35,9 +35,12 @@
 namespace elp {
 namespace dfl {
 
-constexpr int NT = 256;               // parts (threads) per block
+#ifndef ELP_DFL_NT
+#define ELP_DFL_NT 256
+#endif
+constexpr int NT = ELP_DFL_NT;        // parts (threads) per block
 constexpr uint32_t PAYLOAD = 65280;   // BGZF payload bytes per block (bgzf-files.go:33)
-constexpr uint32_t PART = 255;        // PAYLOAD / NT
+constexpr uint32_t PART = (PAYLOAD + NT - 1) / NT;  // 255 bytes per part with 256 parts
 #ifndef ELP_DFL_HBITS
 #define ELP_DFL_HBITS 12
 #endif
