@@ -53,7 +53,17 @@ constexpr uint32_t MINM = 4, MAXM = 258, WINDOW = 32768;
 constexpr uint16_t NOPOS = 0xFFFF;
 constexpr uint32_t IN_PAD = 16;       // readable bytes behind the payload in the input buffer (4-byte loads at its end)
 
-ELP_DFL_HD uint32_t load4(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+ELP_DFL_HD uint32_t load4(const uint8_t *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // (the payload lives in LDS, 16-byte aligned and padded: the two aligned words around the four bytes in ONE ds_read2_b32 and a funnel
+  // shift, instead of four byte reads and three shift-ors - the match finder is this function, 2/3 of the kernel's time)
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  const uint32_t *w = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
+  return __builtin_amdgcn_alignbit(w[1], w[0], (uint32_t)(a & 3u) * 8u);
+#else
+  return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+#endif
+}
 ELP_DFL_HD uint32_t hash4(uint32_t w) { return (w * 2654435761u) >> (32 - HBITS); }
 ELP_DFL_HD uint32_t ilog2(uint32_t x) { return 31u - (uint32_t)__builtin_clz(x); }  // x > 0
 
@@ -105,11 +115,22 @@ ELP_DFL_HD uint32_t token_bits(uint32_t tok) {
 }
 
 // ---- 1. match finding.  table: [1 << HBITS][WAYS] positions (NOPOS = empty), way 0 the most recent
+// equal bytes at c.. and i.., at most maxl
 ELP_DFL_HD uint32_t match_len(const uint8_t *in, uint32_t c, uint32_t i, uint32_t maxl) {
   uint32_t l = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  // four bytes a step to the end (the bytes behind the payload are padding: reading them is safe, counting them is not)
+  for (;;) {
+    const uint32_t x = load4(in + c + l) ^ load4(in + i + l);
+    const uint32_t eq = x ? (uint32_t)__builtin_ctz(x) >> 3 : 4u, left = maxl - l;
+    if (eq < 4u || left <= 4u) return l + (eq < left ? eq : left);
+    l += 4u;
+  }
+#else
   while (l + 4u <= maxl && load4(in + c + l) == load4(in + i + l)) l += 4u;
   while (l < maxl && in[c + l] == in[i + l]) l++;
   return l;
+#endif
 }
 // the note of position i: length (0 = no match of MINM bytes or more; at most 255) | distance << 8
 ELP_DFL_HD uint32_t find_match(const uint8_t *in, uint32_t n, uint32_t i, const uint16_t *table) {
@@ -117,8 +138,15 @@ ELP_DFL_HD uint32_t find_match(const uint8_t *in, uint32_t n, uint32_t i, const 
   uint32_t best = 0, bd = 0;
   if (maxl >= MINM) {
     const uint32_t h = hash4(load4(in + i));
+#if defined(__HIP_DEVICE_COMPILE__) && ELP_DFL_WAYS == 2
+    const uint32_t both = *reinterpret_cast<const uint32_t *>(table + h * 2u);  // (the two ways in one read)
+#endif
     for (int k = 0; k < WAYS; k++) {
+#if defined(__HIP_DEVICE_COMPILE__) && ELP_DFL_WAYS == 2
+      const uint32_t c = k ? both >> 16 : both & 0xFFFFu;
+#else
       const uint32_t c = table[h * WAYS + k];
+#endif
       if (c < i && i - c <= WINDOW) {
         const uint32_t l = match_len(in, c, i, maxl);
         if (l > best) { best = l; bd = i - c; }
@@ -134,8 +162,13 @@ ELP_DFL_HD uint32_t find_match(const uint8_t *in, uint32_t n, uint32_t i, const 
 ELP_DFL_HD void table_insert(uint16_t *table, const uint8_t *in, uint32_t n, uint32_t i) {
   if (i + MINM > n) return;
   const uint32_t h = hash4(load4(in + i));
+#if defined(__HIP_DEVICE_COMPILE__) && ELP_DFL_WAYS == 2
+  uint32_t *e = reinterpret_cast<uint32_t *>(table + h * 2u);
+  *e = (*e << 16) | i;  // (way 0 moves to way 1; unordered against the other threads of the strip, like the two stores it replaces)
+#else
   table[h * WAYS + 1] = table[h * WAYS];
   table[h * WAYS] = (uint16_t)i;
+#endif
 }
 
 // ---- 2. the greedy parse of part [lo, hi): reads the notes ld[i], writes token k of the part to ld[lo + k] (k <= i - lo: a note is
