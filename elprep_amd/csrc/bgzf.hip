@@ -163,9 +163,10 @@ __global__ __launch_bounds__(256) void k_bgzf_deflate(const uint8_t *__restrict_
     // ---- 1. match finding, a strip of 256 positions at a time: look-ups against everything in front of the strip, then its inserts
     for (uint32_t base = 0; base < len; base += 256u) {
       const uint32_t i = base + t;
-      if (i < len) ld[i] = find_match(buf, len, i, table);
+      const uint32_t w = i < len ? load4(buf + i) : 0u;
+      if (i < len) ld[i] = find_match(buf, len, i, table, w);
       __syncthreads();
-      if (i < len) table_insert(table, buf, len, i);
+      if (i < len) table_insert(table, len, i, w);
       __syncthreads();
     }
     // ---- 2. the parse of the thread's part: tokens in place of the notes, their bits

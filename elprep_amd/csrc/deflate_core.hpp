@@ -133,20 +133,41 @@ ELP_DFL_HD uint32_t match_len(const uint8_t *in, uint32_t c, uint32_t i, uint32_
 #endif
 }
 // the note of position i: length (0 = no match of MINM bytes or more; at most 255) | distance << 8
+#if defined(__HIPCC__) && ELP_DFL_WAYS == 2
+// the device's form of the function below, same result: the first words of the three candidates (two ways of the bucket, the byte in front)
+// are read TOGETHER - one LDS round trip instead of three, one after the other - and only candidates whose first four bytes match go on
+ELP_DFL_HD uint32_t match_rest(const uint8_t *in, uint32_t c, uint32_t i, uint32_t maxl, uint32_t x /* first words xor-ed */) {
+  const uint32_t eq = x ? (uint32_t)__builtin_ctz(x) >> 3 : 4u;
+  if (eq < 4u || maxl <= 4u) return eq < maxl ? eq : maxl;
+  return 4u + match_len(in, c + 4u, i + 4u, maxl - 4u);
+}
+ELP_DFL_HD uint32_t find_match(const uint8_t *in, uint32_t n, uint32_t i, const uint16_t *table, uint32_t w /* load4(in + i) */) {
+  const uint32_t maxl = n - i < 255u ? n - i : 255u;
+  if (maxl < MINM) return 0u;
+  const uint32_t both = *reinterpret_cast<const uint32_t *>(table + hash4(w) * 2u);
+  const uint32_t c0 = both & 0xFFFFu, c1 = both >> 16;
+  const bool ok0 = c0 < i && i - c0 <= WINDOW, ok1 = c1 < i && i - c1 <= WINDOW, okr = i > 0;
+  const uint32_t x0 = ok0 ? load4(in + c0) ^ w : 1u, x1 = ok1 ? load4(in + c1) ^ w : 1u, xr = okr ? load4(in + i - 1u) ^ w : 1u;
+  uint32_t best = 0, bd = 0;
+  if (ok0) { const uint32_t l = match_rest(in, c0, i, maxl, x0); if (l > best) { best = l; bd = i - c0; } }
+  if (ok1) { const uint32_t l = match_rest(in, c1, i, maxl, x1); if (l > best) { best = l; bd = i - c1; } }
+  if (okr) { const uint32_t l = match_rest(in, i - 1u, i, maxl, xr); if (l > best) { best = l; bd = 1u; } }
+  return best >= MINM ? (best | (bd << 8)) : 0u;
+}
+// (the position's first four bytes are read once for the look-up and the insert)
+ELP_DFL_HD void table_insert(uint16_t *table, uint32_t n, uint32_t i, uint32_t w /* load4(in + i) */) {
+  if (i + MINM > n) return;
+  uint32_t *e = reinterpret_cast<uint32_t *>(table + hash4(w) * 2u);
+  *e = (*e << 16) | i;  // (way 0 moves to way 1; unordered against the other threads of the strip, like the two stores of the host's form)
+}
+#else
 ELP_DFL_HD uint32_t find_match(const uint8_t *in, uint32_t n, uint32_t i, const uint16_t *table) {
   const uint32_t maxl = n - i < 255u ? n - i : 255u;
   uint32_t best = 0, bd = 0;
   if (maxl >= MINM) {
     const uint32_t h = hash4(load4(in + i));
-#if defined(__HIP_DEVICE_COMPILE__) && ELP_DFL_WAYS == 2
-    const uint32_t both = *reinterpret_cast<const uint32_t *>(table + h * 2u);  // (the two ways in one read)
-#endif
     for (int k = 0; k < WAYS; k++) {
-#if defined(__HIP_DEVICE_COMPILE__) && ELP_DFL_WAYS == 2
-      const uint32_t c = k ? both >> 16 : both & 0xFFFFu;
-#else
       const uint32_t c = table[h * WAYS + k];
-#endif
       if (c < i && i - c <= WINDOW) {
         const uint32_t l = match_len(in, c, i, maxl);
         if (l > best) { best = l; bd = i - c; }
@@ -159,16 +180,12 @@ ELP_DFL_HD uint32_t find_match(const uint8_t *in, uint32_t n, uint32_t i, const 
   }
   return best >= MINM ? (best | (bd << 8)) : 0u;
 }
+#endif
 ELP_DFL_HD void table_insert(uint16_t *table, const uint8_t *in, uint32_t n, uint32_t i) {
   if (i + MINM > n) return;
   const uint32_t h = hash4(load4(in + i));
-#if defined(__HIP_DEVICE_COMPILE__) && ELP_DFL_WAYS == 2
-  uint32_t *e = reinterpret_cast<uint32_t *>(table + h * 2u);
-  *e = (*e << 16) | i;  // (way 0 moves to way 1; unordered against the other threads of the strip, like the two stores it replaces)
-#else
   table[h * WAYS + 1] = table[h * WAYS];
   table[h * WAYS] = (uint16_t)i;
-#endif
 }
 
 // ---- 2. the greedy parse of part [lo, hi): reads the notes ld[i], writes token k of the part to ld[lo + k] (k <= i - lo: a note is
