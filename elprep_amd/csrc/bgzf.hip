@@ -708,6 +708,7 @@ struct TokLds {
   uint32_t ring[TK_RING / 4 + 4];  // the last four words mirror the first four: a window is three consecutive words from anywhere in the ring
   uint32_t ltab[1 << TK_LB], dtab[1 << TK_DB];
   uint16_t lcount[16], dcount[16], lsym[288], dsym[32];
+  uint16_t lfirst[16], loffs[16], dfirst[16], doffs[16];  // per code length: the first canonical code, the place of its symbol in lsym / dsym
   uint8_t lengths[320];
   int left;
 };
@@ -735,6 +736,13 @@ __device__ inline int tok_huff_build(TokLds *L, uint16_t *count, uint16_t *symbo
       if (left >= 0) {
         offs[1] = 0;
         for (int len = 1; len < 15; len++) offs[len + 1] = offs[len] + count[len];
+        if (kind) {  // the walk's decoder of long codes (tk_slow_entry): first code and first symbol per length
+          uint16_t *first = kind == 1 ? L->lfirst : L->dfirst, *ofs = kind == 1 ? L->loffs : L->doffs;
+          uint32_t f = 0;
+          first[0] = 0;
+          ofs[0] = 0;
+          for (int len = 1; len <= 15; len++) { first[len] = (uint16_t)f; ofs[len] = offs[len]; f = (f + count[len]) << 1; }
+        }
         for (int sym = 0; sym < n; sym++)
           if (length[sym] != 0) symbol[offs[length[sym]]++] = (uint16_t)sym;
       }
@@ -802,11 +810,20 @@ struct TokInflater {
   }
 };
 // one symbol at bit b by canonical decoding, for the walk: its entry in the table's form with the true code length (0: no such code)
+// (every code length at once: lane L tests whether the first L bits are a code of length L - canonical codes of one length are consecutive
+// numbers, first[L] .. first[L] + count[L] - 1, MSB first -; the bit-by-bit walk of canon_decode took fifteen dependent LDS reads)
 __device__ __forceinline__ uint32_t tk_slow_entry(const TokInflater &s, uint32_t b, bool dist) {
-  int len = 0;
-  const int sym = canon_decode(dist ? s.L->dcount : s.L->lcount, dist ? s.L->dsym : s.L->lsym, (uint32_t)s.window(b), &len);
-  if (sym < 0) return 0;
-  return (uint32_t)__builtin_amdgcn_readfirstlane((int)(dist ? tk_dist_entry((uint32_t)sym, (uint32_t)len) : tk_lit_entry((uint32_t)sym, (uint32_t)len)));
+  const uint32_t lane = threadIdx.x & 63u, ll = lane & 15u;
+  const uint16_t *count = dist ? s.L->dcount : s.L->lcount, *first = dist ? s.L->dfirst : s.L->lfirst, *ofs = dist ? s.L->doffs : s.L->loffs;
+  const uint32_t rev = __brev((uint32_t)s.window(b)) >> 17;  // the next fifteen bits, the first one on top
+  const uint32_t c = rev >> (15u - ll), f = first[ll], cnt = count[ll];
+  const bool hit = lane >= 1u && lane <= 15u && c - f < cnt;
+  const unsigned long long m = __ballot(hit);
+  if (!m) return 0;
+  const int len = __builtin_ctzll(m);
+  const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)(ofs[ll] + c - f), len);
+  const uint32_t sym = (uint32_t)__builtin_amdgcn_readfirstlane((int)(dist ? s.L->dsym : s.L->lsym)[idx]);
+  return dist ? tk_dist_entry(sym, (uint32_t)len) : tk_lit_entry(sym, (uint32_t)len);
 }
 __device__ inline int tok_codes(TokInflater &s) {
   TokLds *L = s.L;
