@@ -1365,7 +1365,7 @@ extern "C" int elp_stage_bgzf(elp_ctx *c, const uint8_t *bgzf, uint64_t n_bytes,
   const uint64_t raw0 = c->raw_bytes;
   ELP_TRY(ensure(c, c->raw, raw0 + inflated + 64, true, raw0));
   // Two sizes of pieces.  INFLATE pieces (<= 2 GiB inflated: ~33 k blocks) - the decoder wants every block of the file in flight at once (a
-  // wave per block, 22 of them per CU: 5.6 k blocks fill the chip once; round 6: 192 MiB pieces left it half empty and cost 1.7x) and pays
+  // wave per block, 24 of them per CU: 6.1 k blocks fill the chip once; round 6: 192 MiB pieces left it half empty and cost 1.7x) and pays
   // 171 KB of token scratch per block for it.  Inside one, SCAN pieces (<= 1 GiB: u32 scans and bounded scratch in stage_bam_columns; round 6: 192 MiB pieces cost 7 x 2 host
   // waits and launches of 3 k threads)
   // find the records and stage the columns as before.
@@ -1377,7 +1377,7 @@ extern "C" int elp_stage_bgzf(elp_ctx *c, const uint8_t *bgzf, uint64_t n_bytes,
   uint32_t *cnt_all = nullptr, *base_all = nullptr, *bad_list = nullptr;
   std::vector<BgzfBlk> tb_all;
   CopyEvents copied;
-  const uint32_t chunk = c->tune.bgzf_copy_chunk > 0 ? (uint32_t)c->tune.bgzf_copy_chunk : std::max(1024u, (uint32_t)c->n_cu * 22u);
+  const uint32_t chunk = c->tune.bgzf_copy_chunk > 0 ? (uint32_t)c->tune.bgzf_copy_chunk : std::max(1024u, (uint32_t)c->n_cu * 24u);
   size_t a0 = 0;
   bool inflate_checked = true;
   while (b0 < blocks.size()) {
@@ -1393,7 +1393,7 @@ extern "C" int elp_stage_bgzf(elp_ctx *c, const uint8_t *bgzf, uint64_t n_bytes,
       uint8_t *d_in;
       ELP_TRY(scratch(c, 5, (size_t)(in_hi - in_lo) + 64, &d_in));
       // the compressed bytes cross PCIe in chunks of blocks on the copy stream, each chunk's decoder launch waits for its own chunk only:
-      // the decoder works on chunk k while chunk k + 1 arrives.  A chunk = the blocks that fill the chip once (22 waves per CU).
+      // the decoder works on chunk k while chunk k + 1 arrives.  A chunk = the blocks that fill the chip once (24 waves per CU).
       if (!c->copy_stream) ELP_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
       copied.fence(c, st, c->copy_stream);  // (what is queued on the stream may still read the buffer the copies are about to overwrite)
       tb_all.assign(blocks.begin() + a0, blocks.begin() + a1);

@@ -1,5 +1,6 @@
-// deflate_core.hpp — the compressing half of the BGZF writer (round 5): one BGZF block = one DEFLATE block with FIXED Huffman codes
-// (RFC 1951 3.2.6, BTYPE 01) over an LZ77 parse made by 256 parts in parallel.
+// deflate_core.hpp — the compressing half of the BGZF writer: one BGZF block = one DEFLATE block over an LZ77 parse made by 256 parts in
+// parallel, with the block's OWN Huffman codes (RFC 1951 3.2.7, BTYPE 10: round 6, the second half of this file) or - where those are not
+// shorter - the FIXED ones (3.2.6, BTYPE 01: round 5).
 //
 // Reference: utils/bgzf/bgzf-files.go:324-383 (Writer.Write / writeBlock: flate.NewWriter at level -1, 65280 payload bytes per block,
 // CRC-32 + ISIZE trailer).  The reference's bytes are whatever Go's compress/flate emits; any valid DEFLATE stream that inflates to the

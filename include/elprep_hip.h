@@ -143,15 +143,17 @@ int elp_emit_sorted_bam(elp_ctx *ctx, uint8_t *out, uint64_t cap, uint64_t *n_by
 /* BGZF on the device (utils/bgzf/bgzf-files.go).
  * elp_stage_bgzf = the reader (:95-221) + elp_stage_bam: `bgzf` holds whole BGZF blocks of a BAM file (the file, or a part of it that
  * starts at a block and ends with a complete alignment record; an end-of-file block is skipped).  The compressed bytes are copied to the
- * device, every block is inflated by a wavefront of its own (RFC 1951: stored, fixed and dynamic Huffman blocks), its CRC-32 is checked
+ * device (in chunks, while the decoder works on the chunks in front), every block is inflated (RFC 1951: stored, fixed and dynamic Huffman
+ * blocks; round 6, csrc/bgzf.hip: a wavefront turns the block's bit stream into literals in place and match tokens - 64 candidate symbols
+ * per step -, a workgroup resolves the matches by pointer jumping in LDS), its CRC-32 is checked
  * ("invalid CRC-32 value for a data block in a BGZF file"), the starts of the alignment records are found on the device (every block
  * guesses its first record start, walks its records, and the guesses are proven by checking that every block's chain ends where the
  * next one's begins; wrong guesses are repaired in order), and the records are staged as elp_stage_bam stages them.  first_record = the
  * offset of the first alignment record in the inflated stream (behind magic, header text and reference dictionary, which the host
  * parses from the first block(s) itself); 0 for a part that starts with a record.
  * elp_emit_sorted_bgzf = elp_emit_sorted_bam + the writer (:324-383): the sorted records as BGZF blocks of <= 65280 payload bytes, each
- * COMPRESSED on the device (round 5: DEFLATE with fixed Huffman codes over a parallel LZ77 parse, csrc/deflate_core.hpp; a block that
- * would not shrink is stored), CRC-32 and ISIZE computed on the device.  Inflating the blocks gives elp_emit_sorted_bam's bytes (parity
+ * COMPRESSED on the device (DEFLATE over a parallel LZ77 parse with the block's own Huffman codes - round 6; fixed codes where those are
+ * not longer -, csrc/deflate_core.hpp; a block that would not shrink is stored), CRC-32 and ISIZE computed on the device.  Inflating the blocks gives elp_emit_sorted_bam's bytes (parity
  * of a BAM file is defined on the inflated stream: the reference's own bytes are whatever Go's compress/flate emits); a BAM file = the
  * host's header block(s) + these blocks + the 28-byte end-of-file block (:53-62).  A size query (out = NULL) returns an UPPER BOUND - the
  * size of the stored form, which is also the room `out` must offer; *n_bytes_out of the real call is the actual size. */
