@@ -1017,14 +1017,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
 constexpr int RES_THREADS = 1024;
 __global__ __launch_bounds__(RES_THREADS) void k_bgzf_resolve(const BgzfBlk *__restrict__ blk, uint8_t *__restrict__ raw, const uint2 *__restrict__ tokens,
                                                             const uint32_t *__restrict__ ntok_in, CrcPow pw, uint32_t n_common, const uint32_t *__restrict__ pow_common, uint32_t *err) {
-  extern __shared__ __attribute__((aligned(16))) uint16_t parent[];  // [65536]; the CRC tables afterwards
-  __shared__ uint32_t s_crc;
+  extern __shared__ __attribute__((aligned(16))) uint16_t parent[];  // [65536]
+  __shared__ uint32_t s_crc, T[4 * 256];  // the CRC's tables: of a byte 0 .. 3 positions further on
   const uint32_t nt = ntok_in[blockIdx.x];
   const BgzfBlk B = blk[blockIdx.x];
   uint8_t *out = raw + B.out_off;
   const uint32_t n = B.out_len, t = threadIdx.x;
   if (nt) {  // (0: nothing but literals and stored bytes - or the block did not inflate: reported by phase A)
-    for (uint32_t j = t; j < n; j += RES_THREADS) parent[j] = (uint16_t)j;
+    // every byte its own parent (eight entries per store; entries behind n are never read)
+    for (uint32_t j = t * 8u; j < n; j += RES_THREADS * 8u) {
+      const uint32_t a = j | ((j + 1u) << 16), two = 0x00020002u;
+      *reinterpret_cast<uint4 *>(&parent[j]) = make_uint4(a, a + two, a + 2u * two, a + 3u * two);
+    }
     __syncthreads();
     const uint2 *tk = tokens + (size_t)blockIdx.x * TOK_STRIDE;
     for (uint32_t k = t; k < nt; k += RES_THREADS) {
@@ -1055,13 +1059,11 @@ __global__ __launch_bounds__(RES_THREADS) void k_bgzf_resolve(const BgzfBlk *__r
       }
     }
     __syncthreads();
-    for (uint32_t j = t; j < n; j += RES_THREADS) {
-      const uint16_t q = parent[j];
-      if (q != (uint16_t)j) out[j] = out[q];
-    }
-    __syncthreads();  // (and the workgroup's stores are visible to its own loads below)
   }
-  uint32_t *T = reinterpret_cast<uint32_t *>(parent);  // [4][256]
+  // ONE pass fills the matches in and takes the CRC: a thread owns 64 consecutive bytes; per four of them the word as phase A left it
+  // (literals in place), their four parents from LDS, the bytes of the matches from the literals they point at (a literal is never
+  // written here: no order to keep), the word back if it changed, the word into the CRC.  (Rounds before: a gather over all bytes, then
+  // the CRC's own pass over them.)
   if (t < 256) {
     uint32_t c = t;
     for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ BGZF_POLY : c >> 1;
@@ -1080,10 +1082,22 @@ __global__ __launch_bounds__(RES_THREADS) void k_bgzf_resolve(const BgzfBlk *__r
     for (; k + 4u <= hi; k += 4u) {
       uint32_t w;
       __builtin_memcpy(&w, out + k, 4);
+      if (nt) {
+        const uint2 p4 = *reinterpret_cast<const uint2 *>(&parent[k]);  // (k is a multiple of 4: aligned)
+        const uint32_t q0 = p4.x & 0xFFFFu, q1 = p4.x >> 16, q2 = p4.y & 0xFFFFu, q3 = p4.y >> 16;
+        const uint32_t b0 = q0 != k ? out[q0] : w & 0xFFu, b1 = q1 != k + 1u ? out[q1] : (w >> 8) & 0xFFu, b2 = q2 != k + 2u ? out[q2] : (w >> 16) & 0xFFu,
+                       b3 = q3 != k + 3u ? out[q3] : w >> 24;
+        const uint32_t v = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+        if (v != w) { __builtin_memcpy(out + k, &v, 4); w = v; }
+      }
       c ^= w;
       c = T[768 + (c & 0xFFu)] ^ T[512 + ((c >> 8) & 0xFFu)] ^ T[256 + ((c >> 16) & 0xFFu)] ^ T[c >> 24];
     }
-    for (; k < hi; k++) c = T[(c ^ out[k]) & 0xFFu] ^ (c >> 8);
+    for (; k < hi; k++) {
+      uint32_t byte = out[k];
+      if (nt) { const uint32_t q = parent[k]; if (q != k) { byte = out[q]; out[k] = (uint8_t)byte; } }
+      c = T[(c ^ byte) & 0xFFu] ^ (c >> 8);
+    }
     c ^= 0xFFFFFFFFu;
     atomicXor(&s_crc, crc_mulmod(n == n_common ? pow_common[t] : crc_x8n(pw, n - hi), c));
   }
