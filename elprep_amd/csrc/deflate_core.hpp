@@ -50,7 +50,10 @@ constexpr uint32_t PART = (PAYLOAD + NT - 1) / NT;  // 255 bytes per part with 2
 #endif
 constexpr int HBITS = ELP_DFL_HBITS, WAYS = ELP_DFL_WAYS;   // hash table: 4096 buckets of two u16 positions (16 KB of LDS: two workgroups per CU; round 5's
                                                              // 8192 buckets compress the bench's records to 0.4198 instead of 0.4220 and leave room for one)
-constexpr uint32_t MINM = 4, MAXM = 258, WINDOW = 32768;
+#ifndef ELP_DFL_MAXL
+#define ELP_DFL_MAXL 255
+#endif
+constexpr uint32_t MINM = 4, MAXM = 258, WINDOW = 32768, MAXL = ELP_DFL_MAXL;  // MAXL: the longest match the finder reports
 constexpr uint16_t NOPOS = 0xFFFF;
 constexpr uint32_t IN_PAD = 16;       // readable bytes behind the payload in the input buffer (4-byte loads at its end)
 
@@ -143,7 +146,7 @@ ELP_DFL_HD uint32_t match_rest(const uint8_t *in, uint32_t c, uint32_t i, uint32
   return 4u + match_len(in, c + 4u, i + 4u, maxl - 4u);
 }
 ELP_DFL_HD uint32_t find_match(const uint8_t *in, uint32_t n, uint32_t i, const uint16_t *table, uint32_t w /* load4(in + i) */) {
-  const uint32_t maxl = n - i < 255u ? n - i : 255u;
+  const uint32_t maxl = n - i < MAXL ? n - i : MAXL;
   if (maxl < MINM) return 0u;
   const uint32_t both = *reinterpret_cast<const uint32_t *>(table + hash4(w) * 2u);
   const uint32_t c0 = both & 0xFFFFu, c1 = both >> 16;
@@ -163,7 +166,7 @@ ELP_DFL_HD void table_insert(uint16_t *table, uint32_t n, uint32_t i, uint32_t w
 }
 #else
 ELP_DFL_HD uint32_t find_match(const uint8_t *in, uint32_t n, uint32_t i, const uint16_t *table) {
-  const uint32_t maxl = n - i < 255u ? n - i : 255u;
+  const uint32_t maxl = n - i < MAXL ? n - i : MAXL;
   uint32_t best = 0, bd = 0;
   if (maxl >= MINM) {
     const uint32_t h = hash4(load4(in + i));
