@@ -240,7 +240,11 @@ def main():
     # kernel's time then includes what it waited for another stream's kernel, so the line also carries the same step's kernels measured
     # one after the other (`serial_order`, outside the timed region); "metrics" = the metrics pass under the sort, both behind the gather
     # (the BQSR kernels have the GPU to themselves); "serial" = one after the other, as until round 5
-    order = os.environ.get("ELP_BENCH_ORDER", "three")
+    # "auto" (default): three steps of "three" and of "metrics" each in front of the warm-up, the faster order is the one that is timed - which
+    # of the two wins is a property of the box's HOST (how well three threads' launches interleave), not of the kernels: one build measured
+    # 20.57 / 20.88 ms on one box of the pool and 21.98 / 21.55 on another (profiles/round6_*, round6d_*)
+    order = os.environ.get("ELP_BENCH_ORDER", "auto")
+    order_probe = None
     # elp_sort_ahead (the sort's key passes queued from inside mark duplicates): measured on the bench's step, it does not pay - the passes'
     # 1024-thread workgroups find no CU while the pair phase's and the prologues' small workgroups keep every CU partly occupied, and with
     # smaller tiles they slow the pair phase by what they gain (profiles/round6_sort_ahead_ab.txt); off unless asked for
@@ -370,7 +374,15 @@ def main():
         eng.snapshot()  # FLAG and QUAL are the only columns the path mutates; every step starts from the same staged input
         prof_eng = eng
         step_full, step_c2, restore = make_filter_steps(eng, [None])
-        step = step_full if args.stages == "full" else step_c2
+        if order == "auto":
+            order = "three"
+            if args.stages == "full":
+                order_probe = {}
+                for o in ("three", "metrics"):
+                    elo, _ = timed(lambda: step_full(o), restore, 3, 1, eng, barrier)
+                    order_probe[o] = round(elo / 3 * 1e3, 3)
+                order = min(order_probe, key=order_probe.get)
+        step = (lambda: step_full(order)) if args.stages == "full" else step_c2
         mode = "filter"
     else:
         # ---- `elprep sfm`: contig groups -> ranks; every rank produces the reads of the groups it owns, the few records that
@@ -526,6 +538,8 @@ def main():
             "config": {"workload": f"{'C3' if args.stages == 'full' else 'C2'}-style ({mode}): {n_total} reads on rank 0, {args.reads} requested per GPU, 150bp PE, genome {args.genome} "
                                    f"(24 contigs hg38/12), {args.quals} qualities, {what}",
                        "reads_per_gpu": n_total, "max_cycle": MAX_CYCLE,
+                       "step_order": (order if not sfm_mode and args.stages == "full" else None),
+                       "step_order_probe_ms": order_probe,
                        "resident_rerun": "every timed step starts from the same staged columns (elp_rollback restores FLAG and QUAL); two facts of the "
                                          "staged columns are computed once per staging, not per step: the one-length check of the offset columns "
                                          "(k_uniform_check) and the tile index of the QUAL column (k_flat_index) - together ~0.15 ms that a one-shot "
