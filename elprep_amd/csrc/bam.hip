@@ -293,30 +293,46 @@ __global__ __launch_bounds__(256) void k_bam_out_emit(BamOut m_first, BamOut m_s
       st_u32(o + 24, (uint32_t)m.next_refid[i]);
       st_u32(o + 28, (uint32_t)(m.pnext[i] - 1));
       st_u32(o + 32, (uint32_t)m.tlen[i]);
-      // tags, re-encoded as formatBamTag does
+    }
+    {
+      // tags, re-encoded as formatBamTag does.  The WAVE walks them (round 6: lane 0 did, byte by byte - a dependent load per byte of
+      // every string while 63 lanes waited): every lane reads the same tag header, a string's end is found by all lanes at once, a value
+      // that stays as it is is copied by all lanes; only an integer's new form is written by lane 0.
       uint8_t *w = o + 4 + fixed;
       const uint8_t *t = rec + (32ull + l_name + 4ull * ld_u16(rec + 12) + ((ld_u32(rec + 16) + 1) >> 1) + ld_u32(rec + 16));
       while (t + 3 <= end) {
         const uint8_t ty = t[2];
         const uint8_t *v = t + 3;
-        const uint32_t sz = tag_value_size(ty, v, end);
+        uint32_t sz;
+        if (ty == 'Z' || ty == 'H') {  // (tag_value_size's loop, 64 bytes a step)
+          sz = 0;
+          for (uint32_t at = 0;; at += 64) {
+            const uint8_t *q = v + at + lane;
+            const bool in = q < end;
+            const unsigned long long zero = __ballot(in && *q == 0);
+            if (zero) { sz = at + (uint32_t)__builtin_ctzll(zero) + 1u; break; }
+            if (__ballot(!in)) break;  // no NUL in front of the record's end: malformed, as tag_value_size says
+          }
+        } else {
+          sz = tag_value_size(ty, v, end);
+        }
         if (!sz) break;
-        w[0] = t[0]; w[1] = t[1];
         if (tag_is_int(ty)) {
           const long long val = tag_int_value(ty, v);
           uint8_t ot;
           const uint32_t os = int_out(val, &ot);
-          w[2] = ot;
-          for (uint32_t b = 0; b < os; b++) w[3 + b] = (uint8_t)((unsigned long long)val >> (8 * b));
+          if (lane == 0) {
+            w[0] = t[0]; w[1] = t[1]; w[2] = ot;
+            for (uint32_t b = 0; b < os; b++) w[3 + b] = (uint8_t)((unsigned long long)val >> (8 * b));
+          }
           w += 3 + os;
         } else {
-          w[2] = ty;
-          for (uint32_t b = 0; b < sz; b++) w[3 + b] = v[b];
+          for (uint32_t b = lane; b < 3 + sz; b += 64) w[b] = t[b];
           w += 3 + sz;
         }
         t = v + sz;
       }
-      st_u32(o, (uint32_t)(w - o - 4));  // block_size
+      if (lane == 0) st_u32(o, (uint32_t)(w - o - 4));  // block_size
     }
     // read name (+ NUL), CIGAR, the original bases, the qualities as they are now
     uint8_t *w = o + 36;
