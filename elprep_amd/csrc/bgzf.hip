@@ -685,19 +685,23 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
 // block's output the wave keeps in LDS (a global round trip each), and the rate follows the waves per CU (4 / 8 / 11 waves: 4.0 / 6.1 / 7.1
 // GB/s), i.e. the LDS per wave - window, ring, tables.  The serial part of DEFLATE is the bit stream, not the copies:
 //   phase A  k_bgzf_tokens   a wave per block walks the Huffman stream and does NOTHING else: a literal goes straight to its place in the
-//            block's output (HBM), a match becomes an 8-byte token {output position | length << 16, distance}, 64 of them at a time
-//            written coalesced.  No window, no drain: 4 KB of LDS per wave (ring, u16 tables), eight waves per SIMD.
-//   phase B  k_bgzf_resolve  a workgroup per block: every output byte gets a PARENT in LDS (u16 [65536]) - itself for a literal, position
-//            - distance for a byte of a match (also inside an overlapping match) -; pointer jumping (parent = parent[parent], until nothing
-//            changes: the depth of the copy-of-a-copy chains, logarithmically) leaves every byte pointing at the literal it descends from;
-//            one gather from the block's own output, which holds the literals already, fills the matches in.
-// Stored blocks copy their bytes in phase A.  The tokens of a block: at most (bytes / 3) of 8 bytes each, 174 KB per block of scratch.
-// Phase A is bound by instruction issue, not by latency (a wave that decodes symbol after symbol spends ~150 instructions on each, and the
+//            block's output (HBM), a match becomes an 8-byte token {output position | length << 16, distance} appended to the block's token
+//            list (the lanes that hold matches write theirs together).  No window, no drain: 5 KB of LDS per wave (1 KB input ring, u32
+//            tables of 9 / 8 bits), 80 VGPRs: 24 waves per CU.
+//   phase B  k_bgzf_resolve  a workgroup per block: every output byte gets a PARENT in LDS (u16 [65536]) - itself for a literal; for
+//            byte i of a match: position - distance + (i mod distance), i.e. always a byte in front of the match -; pointer jumping
+//            (parent = parent[parent], every thread over its unfinished bytes, no barrier between the rounds) leaves every byte pointing at
+//            the literal it descends from; ONE pass then fills the matches in from the block's own output, which holds the literals
+//            already, and takes the CRC-32.
+// Stored blocks copy their bytes in phase A.  The tokens of a block: at most (bytes / 3) of 8 bytes each, 171 KB per block of scratch.
+// Phase A is bound by issued instructions, not by latency (a wave that decodes symbol after symbol spends ~150 instructions on each, and the
 // lanes beside lane 0 repeat them), so the lanes decode AT ONCE: lane k decodes the symbol that would start k bits behind the wave's place
-// in the stream - all 64 candidates, one table look-up (two for a match) each -; the wave then walks the true chain (start at 0, step by
-// the bits the symbol there consumed: a handful of scalar steps per 64 bits), which also gives every true symbol its place in the output;
-// the lanes on the chain store their literal or their token.  ~5 symbols per round of ~120 instructions instead of one per ~150.
-// A symbol whose code is longer than the tables' bits is decoded on the walk (canonical decoding, rare).
+// in the stream - all 64 candidates, one table look-up (two for a match) each, branch-free -; the wave then walks the true chain (start at
+// 0, step by the bits the symbol there consumed: ~6 scalar steps per 64 bits, a hand-written loop), which also gives every true symbol its
+// place in the output; the lanes on the chain store their literal or their token.  ~5 symbols per round of ~230 issued instructions
+// (110 scalar, 76 vector, 34 branches, 7 LDS: profiles/round6_bgzf_pmc.csv and the run behind it) instead of one per ~150.
+// A symbol whose code is longer than the tables' bits, the end of a block and an invalid symbol are decoded on the walk: for a long code
+// lane L tests whether the first L bits are a code of length L, all lengths at once (tk_slow_entry).
 constexpr int TK_RING = 1024, TK_HALF = TK_RING / 2, TK_LB = 9, TK_DB = 8;
 constexpr uint32_t TOK_STRIDE = 21888;  // tokens per block: >= 65536 / 3 + 1, a multiple of 64
 // table entry: code length (4 bits; 0: the code is longer than the table's bits) | kind << 4 | extra bits << 6 | base value << 10
