@@ -846,38 +846,46 @@ __device__ inline int tok_codes(TokInflater &s) {
     const bool is_m = kind == TK_MATCH;
     uint32_t olen = is_m ? val + ((uint32_t)(w >> cl) & ((1u << xb) - 1u)) : 1u;
     const bool special = e == 0 || kind >= TK_EOB || (is_m && (e2 == 0 || ((e2 >> 4) & 3u) == TK_BAD));
-    const int info = special ? -1 : (int)((is_m ? t + dl + db : cl) | (olen << 7));  // bits consumed | output bytes << 7
+    // bits consumed | output bytes << 7; a symbol for the walk's slow path: 64 bits "consumed" (the walk's loop ends there) | a mark
+    constexpr uint32_t TK_SPECIAL = 64u | (1u << 30);
+    const int info = special ? (int)TK_SPECIAL : (int)((is_m ? t + dl + db : cl) | (olen << 7));
     // the walk along the true chain (wave-uniform values throughout); a lane on the chain learns its place in the output
     uint32_t off = 0, outpos = s.out_at;
     int vpos = -1, rc = 0;
     bool eob = false;
     for (;;) {
       // the chain's fast steps, by hand (the compiler's loop: 9 scalar + 4 vector + 3 branch instructions a step, two of the branches
-      // taken; this one: 8 + 2 + 2, one taken - the kernel is bound by issued instructions, profiles/round6_bgzf_pmc.csv):
-      //   while (off < 64) { inf = readlane(info, off); if (inf < 0) break; vpos[lane off] = outpos; outpos += inf >> 7; off += inf & 127; }
+      // taken; this one: 5 + 2 + 1 - the kernel is bound by issued scalar instructions, profiles/round6_bgzf_pmc_final.csv).  The place in
+      // the input and the place in the output advance in ONE register (acc = off | outpos << 7: a lane's `info` has the same layout and
+      // off stays below 128); a special lane's info carries 64 as its bits: the loop's one test (off < 64) ends on it too, its mark says why
+      //   while (off < 64) { inf = readlane(info, off); vpos[lane off] = outpos; acc += inf; }
+      bool special_hit = false;
       if (off < 64u) {
         int inf, tmp, m0_was;
+        uint32_t acc = off | (outpos << 7);
         asm volatile(
             "s_mov_b32 %[m0w], m0\n\t"
             "1:\n\t"
             "v_readlane_b32 %[inf], %[info], %[off]\n\t"
-            "s_cmp_lt_i32 %[inf], 0\n\t"
-            "s_cbranch_scc1 2f\n\t"
+            "s_lshr_b32 %[tmp], %[acc], 7\n\t"
             "s_mov_b32 m0, %[off]\n\t"
-            "v_writelane_b32 %[vpos], %[outpos], m0\n\t"
-            "s_lshr_b32 %[tmp], %[inf], 7\n\t"
-            "s_add_u32 %[outpos], %[outpos], %[tmp]\n\t"
-            "s_and_b32 %[tmp], %[inf], 0x7f\n\t"
-            "s_add_u32 %[off], %[off], %[tmp]\n\t"
-            "s_cmp_lt_u32 %[off], 64\n\t"
+            "v_writelane_b32 %[vpos], %[tmp], m0\n\t"
+            "s_add_u32 %[acc], %[acc], %[inf]\n\t"
+            "s_and_b32 %[off], %[acc], 0x7f\n\t"
+            "s_bitcmp0_b32 %[acc], 6\n\t"
             "s_cbranch_scc1 1b\n\t"
-            "2:\n\t"
             "s_mov_b32 m0, %[m0w]\n\t"
-            : [inf] "=&s"(inf), [tmp] "=&s"(tmp), [m0w] "=&s"(m0_was), [off] "+s"(off), [outpos] "+s"(outpos), [vpos] "+v"(vpos)
+            : [inf] "=&s"(inf), [tmp] "=&s"(tmp), [m0w] "=&s"(m0_was), [off] "+s"(off), [acc] "+s"(acc), [vpos] "+v"(vpos)
             : [info] "v"(info)
             : "scc");
+        if ((uint32_t)inf & (1u << 30)) {  // the loop ended on a special lane: take its step back (that lane's vpos is set below, or unset)
+          acc -= (uint32_t)inf;
+          special_hit = true;
+        }
+        off = acc & 127u;
+        outpos = acc >> 7;
       }
-      if (off >= 64u) break;
+      if (!special_hit) break;  // (off >= 64)
       // end of block, a code longer than a table's bits, an invalid symbol: this one symbol step by step
       asm volatile("" ::: "memory");  // (keeps the loads below in here)
       const uint32_t b = s.bp + off;
@@ -888,6 +896,7 @@ __device__ inline int tok_codes(TokInflater &s) {
       const uint32_t k1 = (e1 >> 4) & 3u;
       if (k1 == TK_BAD) { rc = 4; break; }
       if (k1 == TK_EOB) {
+        if (lane == off) vpos = -1;  // (the fast loop marked the lane: it holds no symbol that is stored)
         off += a;
         eob = true;
         break;
