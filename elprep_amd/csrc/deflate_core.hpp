@@ -339,18 +339,22 @@ ELP_DFL_HD uint32_t leaf_depth(const uint16_t *up, int k, int m) {
   for (int node = k; node != 2 * m - 2; node = up[node]) d++;
   return d;
 }
-// 3. count[d] = leaves of depth d with the depths beyond the limit clamped to it, `overflow` of them (one thread).  The clamped code is
-//    over-subscribed: for every two leaves too many, a leaf of the deepest level above the limit's that has one moves a level down and
-//    takes one of them as its sibling - the counts stay those of a complete code (the classic repair, as in zlib's gen_bitlen).
+// 3. count[d] = leaves of depth d with the depths beyond the limit clamped to it (one thread).  The clamped code is over-subscribed by
+//    `excess` units of 2^-maxbits (less than one unit per clamped leaf); one step of the classic repair (as in zlib's gen_bitlen) takes
+//    exactly one unit away and keeps the number of leaves: a leaf of the deepest level above the limit's that has one moves a level down
+//    and takes a leaf of the limit's level as its sibling.  (`overflow` = the number of clamped leaves: 0 means nothing to do.)
 //    Then base[L] = first canonical code of length L (RFC 1951 3.2.2).
 ELP_DFL_HD void limit_counts(uint32_t *count, int maxbits, int overflow, uint16_t *base) {
-  while (overflow > 0) {
-    int bits = maxbits - 1;
-    while (count[bits] == 0) bits--;
-    count[bits]--;
-    count[bits + 1] += 2;
-    count[maxbits]--;
-    overflow -= 2;
+  if (overflow > 0) {
+    unsigned long long kraft = 0;
+    for (int l = 1; l <= maxbits; l++) kraft += (unsigned long long)count[l] << (maxbits - l);
+    for (unsigned long long excess = kraft - (1ull << maxbits); excess > 0; excess--) {
+      int bits = maxbits - 1;
+      while (count[bits] == 0) bits--;
+      count[bits]--;
+      count[bits + 1] += 2;
+      count[maxbits]--;
+    }
   }
   uint32_t code = 0;
   base[0] = 0;

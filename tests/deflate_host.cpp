@@ -132,3 +132,17 @@ extern "C" uint32_t dfl_emulate_block(const uint8_t *in_bytes, uint32_t n, uint8
   memcpy(out, words.data(), cbytes);
   return cbytes;
 }
+
+// code lengths of an alphabet of n <= 320 symbols with the counts freq[], at most maxbits long, by the functions the kernel uses (rank by
+// counting, merge, depths, limit, lengths by rank): for the tests' comparison with a textbook Huffman construction
+extern "C" void dfl_code_lengths(const uint32_t *freq, int n, int maxbits, uint8_t *len_out) {
+  uint16_t order[320], up[2 * 320], base[16];
+  uint32_t w[2 * 320], count[17];
+  int m = 0;
+  for (int s = 0; s < n; s++) {
+    len_out[s] = 0;
+    const int r = symbol_rank(freq, n, s);
+    if (r >= 0) { order[r] = (uint16_t)s; m++; }
+  }
+  huffman_lengths_serial(freq, order, m, n, maxbits, len_out, w, up, count, base);
+}

@@ -129,3 +129,60 @@ def test_symbol_tables_against_the_rfc(lib):
                 assert _inflate(cdata) == bytes(data), (dist, length, order)
             seen.add((dist, length))
     assert len(seen) > 500
+
+
+def test_code_lengths_are_huffman_lengths(lib):
+    """the builder's code lengths against a textbook Huffman construction (heap): the same total cost whenever the tree fits the limit,
+    a complete code (Kraft sum exactly 1) always - also where the limit bites (Fibonacci counts, limit 7 as for the code of the code
+    lengths: the first form of the repair left such a code over-subscribed by 3 / 32768 - found by this test) -, and near the unlimited
+    optimum there"""
+    import heapq
+    lib.dfl_code_lengths.restype = None
+    lib.dfl_code_lengths.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    rng = np.random.default_rng(9)
+
+    def textbook(freq):
+        heap = [(int(f), k, (k,)) for k, f in enumerate(freq) if f]
+        depth = {k: 0 for _, k, _ in heap}
+        heapq.heapify(heap)
+        tie = len(freq)
+        while len(heap) > 1:
+            fa, _, sa = heapq.heappop(heap)
+            fb, _, sb = heapq.heappop(heap)
+            for k in sa + sb:
+                depth[k] += 1
+            heapq.heappush(heap, (fa + fb, tie, sa + sb))
+            tie += 1
+        return depth
+
+    cases = []
+    for n, maxbits in ((286, 15), (30, 15), (19, 7)):
+        for _ in range(30):
+            f = rng.integers(0, 2000, n).astype(np.uint32)
+            f[rng.random(n) < rng.random() * 0.8] = 0
+            if (f != 0).sum() < 2:
+                f[:2] = 5
+            cases.append((f, maxbits))
+        fib = [1, 1]
+        while len(fib) < min(n, 24):
+            fib.append(fib[-1] + fib[-2])
+        f = np.zeros(n, np.uint32)
+        f[:len(fib)] = fib
+        cases.append((rng.permutation(f).astype(np.uint32), maxbits))
+    limited = 0
+    for f, maxbits in cases:
+        out = np.zeros(f.size, np.uint8)
+        fa = np.ascontiguousarray(f)
+        lib.dfl_code_lengths(fa.ctypes.data, int(f.size), maxbits, out.ctypes.data)
+        used = f != 0
+        assert (out[used] >= 1).all() and (out[~used] == 0).all() and out.max() <= maxbits
+        assert sum(2.0 ** -int(l) for l in out[used]) == 1.0  # a complete code
+        d = textbook(f)
+        best = sum(int(f[k]) * v for k, v in d.items())
+        cost = int((f.astype(np.int64) * out).sum())
+        if max(d.values()) <= maxbits:
+            assert cost == best, (cost, best)
+        else:
+            limited += 1
+            assert best <= cost <= best * 1.3, (cost, best, maxbits)  # (Fibonacci counts on 19 symbols under a 7-bit limit: +12 %)
+    assert limited >= 3
