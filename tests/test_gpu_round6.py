@@ -324,3 +324,51 @@ def test_stage_bgzf_survives_damaged_blocks():
     e.stage_bgzf(np.frombuffer(good, dtype=np.uint8))
     assert e.n == b.n
     e.close()
+
+
+@pytest.mark.gpu
+def test_emit_sorted_bgzf_with_counts_that_want_codes_longer_than_15_bits():
+    """records whose payload tags hold byte values with Fibonacci counts (the Huffman tree of such a block is deeper than 15: the length
+    limit's repair, deflate_core.hpp limit_counts) and tags of two byte values only: zlib inflates every member to the record stream"""
+    import struct
+    import zlib
+    from elprep_amd.engine import Engine
+    from tests.test_gpu_round4 import _bam_case
+    b, h, raw0, rec_off0 = _bam_case(1200, seed=77)
+    rng = np.random.default_rng(5)
+    fib = [1, 1]
+    while sum(fib) < 52000:
+        fib.append(fib[-1] + fib[-2])
+    pool = np.frombuffer(b"".join(bytes([(37 * k + 11) % 256]) * f for k, f in enumerate(fib)), dtype=np.uint8)
+    src = raw0.tobytes()
+    out, offs, total = [], [0], 0
+    for k in range(len(rec_off0) - 1):
+        rec = src[int(rec_off0[k]):int(rec_off0[k + 1])]
+        n = int(rng.integers(200, 900))
+        pay = bytes(rng.choice(pool, n)) if k % 3 else bytes(rng.choice(np.array([0, 255], dtype=np.uint8), n))
+        tag = b"XBBC" + struct.pack("<I", len(pay)) + pay
+        new = struct.pack("<I", struct.unpack_from("<I", rec, 0)[0] + len(tag)) + rec[4:] + tag
+        out.append(new)
+        total += len(new)
+        offs.append(total)
+    raw = np.frombuffer(b"".join(out), dtype=np.uint8)
+    e = Engine(h)
+    e.set_read_group_ids(h.rg_ids)
+    e.stage_bam(raw, rec_off=np.asarray(offs, dtype=np.uint64))
+    e.mark_duplicates(True)
+    e.sort_coordinate()
+    want = e.emit_sorted_bam().tobytes()
+    bz = e.emit_sorted_bgzf().tobytes()
+    e.close()
+    p, got, dynamic = 0, [], 0
+    while p < len(bz):
+        bsize = struct.unpack_from("<H", bz, p + 16)[0] + 1
+        data = bz[p + 18:p + bsize - 8]
+        dynamic += ((data[0] >> 1) & 3) == 2
+        d = zlib.decompressobj(-15)
+        part = d.decompress(data) + d.flush()
+        crc, isize = struct.unpack_from("<II", bz, p + bsize - 8)
+        assert d.eof and zlib.crc32(part) == crc and len(part) == isize
+        got.append(part)
+        p += bsize
+    assert b"".join(got) == want and dynamic >= 3
