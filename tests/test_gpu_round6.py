@@ -372,3 +372,15 @@ def test_emit_sorted_bgzf_with_counts_that_want_codes_longer_than_15_bits():
         got.append(part)
         p += bsize
     assert b"".join(got) == want and dynamic >= 3
+    # and the other way round: the same stream as zlib compresses it (its own 15-bit-limited codes, Z_HUFFMAN_ONLY: literals only, the
+    # longest codes there are) through the device's decoder
+    from tests.test_gpu_round4 import _bgzf
+    for level, strategy in ((9, 0), (6, 2)):
+        e = Engine(h)
+        e.set_read_group_ids(h.rg_ids)
+        e.stage_bgzf(np.frombuffer(_bgzf(raw.tobytes(), level, strategy), dtype=np.uint8))
+        assert e.n == b.n
+        e.mark_duplicates(True)
+        e.sort_coordinate()
+        assert e.emit_sorted_bam().tobytes() == want
+        e.close()
