@@ -146,3 +146,20 @@ extern "C" void dfl_code_lengths(const uint32_t *freq, int n, int maxbits, uint8
   }
   huffman_lengths_serial(freq, order, m, n, maxbits, len_out, w, up, count, base);
 }
+
+// the dynamic block header for given code lengths (286 literal / length + 30 distance, each a complete code or the two-codes-of-one-bit
+// form), written LSB first into out (cap bytes); returns the header's bits (the 3 block-header bits included)
+extern "C" uint32_t dfl_header_bits(const uint8_t *len_ll, const uint8_t *len_d, uint8_t *out, uint32_t cap) {
+  static DynCodes D;
+  for (int s = 0; s < 320; s++) D.len[s] = 0;
+  for (int s = 0; s < NLL; s++) D.len[s] = len_ll[s];
+  for (int s = 0; s < NDIST; s++) D.len[DOFF + s] = len_d[s];
+  build_header(D);
+  std::vector<uint32_t> words(cap / 4 + 2, 0u);
+  auto orw = [&](uint32_t w, uint32_t v) { words[w] |= v; };
+  BitWriter<decltype(orw)> bw(orw, 0);
+  emit_dyn_header(bw, D);
+  bw.finish();
+  memcpy(out, words.data(), cap);
+  return D.header_bits;
+}

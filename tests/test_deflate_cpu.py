@@ -186,3 +186,93 @@ def test_code_lengths_are_huffman_lengths(lib):
             limited += 1
             assert best <= cost <= best * 1.3, (cost, best, maxbits)  # (Fibonacci counts on 19 symbols under a 7-bit limit: +12 %)
     assert limited >= 3
+
+
+def test_block_header_reads_back(lib):
+    """the run-length coded header (build_header / emit_dyn_header) parsed back by a reader written from RFC 1951 3.2.7: random length
+    vectors with long runs of unused symbols (symbols 17 / 18, runs longer than 138), repeats (symbol 16, runs longer than 6), trailing
+    zeros (HLIT / HDIST trimmed), a single distance code"""
+    lib.dfl_header_bits.restype = C.c_uint32
+    lib.dfl_header_bits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    rng = np.random.default_rng(21)
+
+    def complete_lengths(n_used, n, maxbits):
+        """a random complete prefix code on n_used of n symbols (split the Kraft budget at random)"""
+        lens = [1, 1]
+        while len(lens) < n_used:
+            k = int(rng.integers(0, len(lens)))
+            if lens[k] >= maxbits:
+                if all(l >= maxbits for l in lens):
+                    break
+                continue
+            lens[k] += 1
+            lens.insert(k, lens[k])
+        out = np.zeros(n, np.uint8)
+        pos = np.sort(rng.choice(n, len(lens), replace=False)) if rng.random() < 0.5 else np.arange(len(lens)) + int(rng.integers(0, n - len(lens) + 1))
+        out[pos] = rng.permutation(np.asarray(lens, np.uint8)) if rng.random() < 0.5 else np.sort(np.asarray(lens, np.uint8))
+        return out
+
+    def read_header(buf):
+        bits = int.from_bytes(buf, "little")
+        at = [0]
+
+        def take(k):
+            v = (bits >> at[0]) & ((1 << k) - 1)
+            at[0] += k
+            return v
+        assert take(1) == 1 and take(2) == 2
+        hlit, hdist, hclen = take(5) + 257, take(5) + 1, take(4) + 4
+        order = [16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15]
+        cl = [0] * 19
+        for k in range(hclen):
+            cl[order[k]] = take(3)
+        # canonical decoding table of the code-length code
+        code, table = 0, {}
+        for length in range(1, 8):
+            for sym in range(19):
+                if cl[sym] == length:
+                    table[(length, code)] = sym
+                    code += 1
+            code <<= 1
+        used = [l for l in cl if l]
+        assert sum(2.0 ** -l for l in used) == 1.0 or len(used) == 1 or used == [1, 1]
+
+        def symbol():
+            c = 0
+            for length in range(1, 8):
+                c = (c << 1) | take(1)
+                if (length, c) in table:
+                    return table[(length, c)]
+            raise AssertionError("no code")
+        lens = []
+        while len(lens) < hlit + hdist:
+            s = symbol()
+            if s < 16:
+                lens.append(s)
+            elif s == 16:
+                assert lens
+                lens += [lens[-1]] * (3 + take(2))
+            elif s == 17:
+                lens += [0] * (3 + take(3))
+            else:
+                lens += [0] * (11 + take(7))
+        assert len(lens) == hlit + hdist
+        return lens[:hlit], lens[hlit:], at[0]
+
+    for trial in range(120):
+        ll = complete_lengths(int(rng.integers(2, 287)), 286, 15)
+        if ll[256] == 0:  # the end-of-block symbol is always used
+            j = int(np.nonzero(ll)[0][0])
+            ll[256], ll[j] = ll[j], 0
+        nd = int(rng.integers(0, 31))
+        if nd < 2:
+            d = np.zeros(30, np.uint8)
+            d[:2] = 1
+        else:
+            d = complete_lengths(nd, 30, 15)
+        out = np.zeros(1024, np.uint8)
+        nbits = lib.dfl_header_bits(np.ascontiguousarray(ll).ctypes.data, np.ascontiguousarray(d).ctypes.data, out.ctypes.data, 1024)
+        got_ll, got_d, read = read_header(out.tobytes())
+        assert read == nbits
+        assert got_ll == [int(x) for x in ll[:len(got_ll)]] and not ll[len(got_ll):].any()
+        assert got_d == [int(x) for x in d[:len(got_d)]] and not d[len(got_d):].any()
