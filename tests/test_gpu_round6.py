@@ -291,6 +291,9 @@ def test_stage_bgzf_inflates_whatever_zlib_wrote(seed):
         e.mark_duplicates(True)
         e.sort_coordinate()
         outs.append(e.emit_sorted_bam().tobytes())
+        if how == "bam":  # and the writer on the same records (runs, noise - stored blocks -, far copies): zlib reads what it wrote
+            from tests.test_gpu_round4 import _members
+            assert b"".join(m for _, m in _members(e.emit_sorted_bgzf().tobytes())) == outs[0]
         e.close()
     assert outs[0] == outs[1] and outs[0] == outs[2]
 
