@@ -1416,6 +1416,20 @@ extern "C" int elp_stage_bgzf(elp_ctx *c, const uint8_t *bgzf, uint64_t n_bytes,
         out_bytes += blocks[a1].out_len;
         a1++;
       }
+      // the decoder's token scratch is 171 KB per block in flight: where the device's free memory does not hold it for the whole piece
+      // the launch takes half the blocks, and half of that ... (a part of 2 GiB wants 5.7 GB)
+      uint2 *tok = nullptr;
+      if (c->tune.bgzf_inflate != 1) {
+        for (;;) {
+          const size_t nt = a1 - a0;
+          const bool pretend = c->tune.bgzf_tok_fail_above > 0 && nt > (size_t)c->tune.bgzf_tok_fail_above;  // (tests: this path without a full device)
+          if (!pretend && scratch(c, 7, nt * TOK_STRIDE + (nt + 2) / 2 + RES_THREADS / 2 + 8, &tok) == 0) break;
+          if (nt <= 1) return pretend ? set_error(c, ELP_ERR_HIP, "elp_stage_bgzf: no device memory for the decoder's token scratch") : ELP_ERR_HIP;
+          (void)hipGetLastError();
+          a1 = a0 + nt / 2;
+        }
+        in_hi = blocks[a1 - 1].in_off + blocks[a1 - 1].in_len;
+      }
       const uint32_t na = (uint32_t)(a1 - a0);
       uint8_t *d_in;
       ELP_TRY(scratch(c, 5, (size_t)(in_hi - in_lo) + 64, &d_in));
@@ -1445,8 +1459,6 @@ extern "C" int elp_stage_bgzf(elp_ctx *c, const uint8_t *bgzf, uint64_t n_bytes,
         ELP_LAUNCH(c, "stage_bgzf_inflate", k_bgzf_inflate, dim3(na), dim3(64), 0, (const uint8_t *)d_in, (const BgzfBlk *)d_blk_all, na, c->raw.p, ierr);
         ELP_LAUNCH(c, "stage_bgzf_crc", k_bgzf_crc_check, dim3(na), dim3(256), 0, (const uint8_t *)c->raw.p, (const BgzfBlk *)d_blk_all, pw, ierr);
       } else {  // the bit stream first (literals placed, matches as tokens), then the matches and the CRC, a workgroup per block
-        uint2 *tok;
-        ELP_TRY(scratch(c, 7, (size_t)na * TOK_STRIDE + (size_t)(na + 2) / 2 + RES_THREADS / 2 + 8, &tok));
         uint32_t *ntok = reinterpret_cast<uint32_t *>(tok + (size_t)na * TOK_STRIDE), *pow_common = ntok + ((na + 1u) & ~1u);
         uint32_t n_common = tb_all[0].out_len;  // the inflated length most blocks have (majority vote; any value is correct, the common one is fast)
         {

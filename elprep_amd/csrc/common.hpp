@@ -256,6 +256,7 @@ struct elp_ctx {
     int bgzf_tok_lds = 0;      // (experiments) unused dynamic LDS bytes per decoder wave: lowers the waves per CU
     int bgzf_first_chunk_div = 4;  // the first H2D chunk is 1/div of the others
     int bgzf_fixed = 0;        // 1: elp_emit_sorted_bgzf writes fixed Huffman codes only (round 5's form) instead of dynamic codes
+    int bgzf_tok_fail_above = 0;  // (tests) the token scratch "does not fit" for more than this many blocks: the halving path
     int bgzf_inflate = 0;      // 1: elp_stage_bgzf inflates with round 5's one-kernel decoder (window in LDS) instead of tokens + resolve
     int bgzf_stored = 0;       // 1: elp_emit_sorted_bgzf writes stored DEFLATE blocks (round 4's form) instead of compressing
     int apply_wgs = 0;         // 1 .. 3: workgroups per CU of the one-length ApplyBQSR kernel (default: as many as its LDS allows, at most 3) - A/B runs

@@ -593,6 +593,7 @@ int elp_set_tuning(elp_ctx *c, const char *key, int64_t value) {
   else if (k == "exchange_piece") c->tune.exchange_piece = v;
   else if (k == "bgzf_stored") c->tune.bgzf_stored = v;
   else if (k == "bgzf_inflate") c->tune.bgzf_inflate = v;
+  else if (k == "bgzf_tok_fail_above") c->tune.bgzf_tok_fail_above = v;
   else if (k == "bgzf_fixed") c->tune.bgzf_fixed = v;
   else if (k == "bgzf_first_chunk_div") c->tune.bgzf_first_chunk_div = v;
   else if (k == "bgzf_tok_lds") c->tune.bgzf_tok_lds = v;

@@ -44,6 +44,7 @@ int elp_rollback(elp_ctx *ctx);
  *   "bgzf_fixed"       1: elp_emit_sorted_bgzf writes fixed Huffman codes only (round 5) instead of the blocks' own codes
  *   "bgzf_copy_chunk"  blocks per H2D chunk and decoder launch of elp_stage_bgzf (0: the blocks that fill the chip once);
  *   "bgzf_first_chunk_div"  the first chunk is 1/div of that (default 4: the decoder starts early)
+ *   "bgzf_tok_fail_above"  (tests) the decoder's token scratch "does not fit" for more than this many blocks: the launch halves
  *   "bgzf_tok_lds"     (experiments) unused LDS bytes per decoder wave: fewer waves per CU
  *   "bgzf_inflate"     1: round 5's decoder (one kernel: a wave decodes and copies a block, window in LDS; separate CRC pass)
  *                      instead of round 6's two phases (tokens: 64 candidate symbols per wave and step; matches + CRC: a workgroup)

@@ -48,7 +48,7 @@ _OUT = []           # pooled engines handed out during the current test
 _STATE = {"reuse": False, "primed": 0, "reused": 0}
 _TUNE_DEFAULTS = {"count_kernel": 0, "apply_kernel": 0, "bgzf_piece": 1 << 30, "bgzf_weak_guess": 0, "score_kernel": 0, "count3_rlog": -1, "qual_hint": 0,
                   "qual_hint_drop": -1, "pair_table_slots": 0, "mate_path": 0, "tie_rounds": 0, "radix_tile": 0, "sort_pairs": 0, "exchange_piece": 0,
-                  "bgzf_stored": 0, "md_fused": 0, "apply_wgs": 0, "presort_tile": 0, "side_priority": 0, "bgzf_inflate": 0, "bgzf_fixed": 0, "bgzf_copy_chunk": 0, "bgzf_first_chunk_div": 4, "bgzf_tok_lds": 0, "bgzf_inflate_piece": 2 << 30}
+                  "bgzf_stored": 0, "md_fused": 0, "apply_wgs": 0, "presort_tile": 0, "side_priority": 0, "bgzf_inflate": 0, "bgzf_fixed": 0, "bgzf_copy_chunk": 0, "bgzf_first_chunk_div": 4, "bgzf_tok_lds": 0, "bgzf_tok_fail_above": 0, "bgzf_inflate_piece": 2 << 30}
 
 
 def _header_key(header, device, flat_abi):

@@ -203,6 +203,7 @@ def _bgzf(stream: bytes, level: int, strategy: int = 0, cut: int = 65280, mem_le
     (6, 3, 65280, None),                                         # Z_RLE: matches at distance 1 (a match that overlaps itself)
     (6, 1, 2111, {"mem_level": 3}),                              # Z_FILTERED, small members
     (1, 0, 30011, {"bgzf_inflate": 1}),                          # round 5's one-kernel decoder stays available
+    (6, 0, 4099, {"bgzf_tok_fail_above": 37}),                   # the token scratch "does not fit": the decoder's launches halve
 ])
 def test_stage_bgzf_gives_the_records_of_stage_bam(level, strategy, cut, tuning):
     import numpy as _np
