@@ -1470,11 +1470,7 @@ extern "C" int elp_stage_bgzf(elp_ctx *c, const uint8_t *bgzf, uint64_t n_bytes,
           }
         }
         ELP_LAUNCH(c, "stage_bgzf_crc_pow", k_crc_pow_common, dim3(1), dim3(RES_THREADS), 0, n_common, pw, pow_common);
-        static std::atomic<bool> lds_set{false};
-        if (!lds_set.load()) {
-          ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bgzf_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(65536 * sizeof(uint16_t))));
-          lds_set.store(true);
-        }
+        ELP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bgzf_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(65536 * sizeof(uint16_t))));
         // the chunks' launches alternate between the context's stream and a lane of its own (the sort lane: idle while records are staged):
         // a launch behind another on ONE stream starts when the last wave of the one in front has finished - a block takes 4.5 ms, the chip
         // drains for half of that per launch -; on two streams the next chunk's waves take the slots as they come free
