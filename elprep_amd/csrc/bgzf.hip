@@ -116,7 +116,7 @@ int bgzf_frame(elp_ctx *c, const uint8_t *raw, uint64_t n_bytes, uint8_t *out) {
 // the members' sizes differ, so a second kernel moves them together behind a scan of the sizes.  A block that would not shrink is stored.
 constexpr uint32_t BGZF_SLOT = 65344;  // bytes between two slots (>= PAYLOAD + OVERHEAD, a multiple of 64)
 constexpr uint32_t DFL_LD = dfl::PAYLOAD + 256;  // words of match notes / tokens per workgroup
-__global__ __launch_bounds__(256) void k_bgzf_deflate(const uint8_t *__restrict__ raw, uint64_t n_bytes, uint32_t nblk, uint8_t *__restrict__ slots,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_bgzf_deflate(const uint8_t *__restrict__ raw, uint64_t n_bytes, uint32_t nblk, uint8_t *__restrict__ slots,
                                                       uint32_t *__restrict__ sizes, uint32_t *__restrict__ ld_all, CrcPow pw, int fixed_only) {
   using namespace dfl;
   __shared__ uint32_t s_crc, s_wsum[4];
